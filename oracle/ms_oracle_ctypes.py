@@ -1,0 +1,130 @@
+"""ctypes binding of the CPU oracle (oracle/libms_oracle.so).
+
+TEST INFRASTRUCTURE ONLY: import from tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
+The product package (muchsalsa_amd) never imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libms_oracle.so")
+
+ROW_DTYPE = np.dtype([("anchor_id", "<u4"), ("read_id", "<u4"), ("read_len", "<i4"), ("i_lo", "<i4"),
+                      ("i_hi", "<i4"), ("n_lo", "<i4"), ("n_hi", "<i4"), ("score", "<u4"), ("line", "<u4"),
+                      ("flags", "<u4")])
+EDGE_DTYPE = np.dtype([("v1", "<u4"), ("v2", "<u4"), ("em_off", "<u8"), ("order_off", "<u8"), ("em_cnt", "<u4"),
+                       ("order_cnt", "<u2"), ("shadow", "u1"), ("pad", "u1")])
+EM_DTYPE = np.dtype([("ov_lo", "<i4"), ("ov_hi", "<i4"), ("score", "<f8"), ("anchor_id", "<u4"), ("line", "<u4"),
+                     ("flags", "<u4"), ("edge_idx", "<u4")])
+ORDER_DTYPE = np.dtype([("edge_idx", "<u4"), ("flags", "<u4"), ("left_offset", "<f8"), ("right_offset", "<f8"),
+                        ("score", "<u8"), ("ids_off", "<u8"), ("ids_cnt", "<u4"), ("start", "<u4"), ("end", "<u4"),
+                        ("base", "<u4"), ("pad", "<u4", (2,))])
+assert ROW_DTYPE.itemsize == 40 and EDGE_DTYPE.itemsize == 32 and EM_DTYPE.itemsize == 32
+assert ORDER_DTYPE.itemsize == 64
+
+
+class Params(C.Structure):
+    _fields_ = [("min_matches", C.c_uint32), ("th_length", C.c_uint32), ("th_matches", C.c_uint32),
+                ("th_overlap", C.c_uint32), ("wiggle_room", C.c_uint64), ("ratio_pct", C.c_double),
+                ("alt_frac", C.c_double)]
+
+
+class _Rows(C.Structure):
+    _fields_ = [("rows", C.c_void_p), ("n_rows", C.c_size_t), ("n_lines", C.c_size_t), ("n_reads", C.c_uint32),
+                ("n_anchors", C.c_uint32), ("read_names", C.c_void_p), ("anchor_names", C.c_void_p),
+                ("read_names_len", C.c_size_t), ("anchor_names_len", C.c_size_t)]
+
+
+class _Tables(C.Structure):
+    _fields_ = [("edges", C.c_void_p), ("n_edges", C.c_size_t), ("ems", C.c_void_p), ("n_ems", C.c_size_t),
+                ("orders", C.c_void_p), ("n_orders", C.c_size_t), ("ids", C.c_void_p), ("n_ids", C.c_size_t),
+                ("read_len", C.c_void_p), ("read_first_line", C.c_void_p), ("n_reads", C.c_uint32),
+                ("rows_alive", C.c_uint64), ("n_anchors", C.c_uint64), ("p_eval", C.c_uint64),
+                ("compat_checks", C.c_uint64), ("shadow_edges", C.c_uint64)]
+
+
+_lib = None
+
+
+def build():
+    """Compile oracle/libms_oracle.so with gcc (no-op when up to date)."""
+    subprocess.run(["make", "-s", "-C", _HERE], check=True)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            build()
+        _lib = C.CDLL(_SO)
+        _lib.ms_oracle_default_params.argtypes = [C.POINTER(Params)]
+        _lib.ms_oracle_parse_paf.argtypes = [C.c_char_p, C.POINTER(Params), C.POINTER(_Rows)]
+        _lib.ms_oracle_parse_paf.restype = C.c_int
+        _lib.ms_oracle_free_rows.argtypes = [C.POINTER(_Rows)]
+        _lib.ms_oracle_overlap.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(Params), C.POINTER(_Tables)]
+        _lib.ms_oracle_overlap.restype = C.c_int
+        _lib.ms_oracle_free_tables.argtypes = [C.POINTER(_Tables)]
+        _lib.ms_oracle_strerror.argtypes = [C.c_int]
+        _lib.ms_oracle_strerror.restype = C.c_char_p
+    return _lib
+
+
+def default_params():
+    p = Params()
+    lib().ms_oracle_default_params(C.byref(p))
+    return p
+
+
+class OracleError(RuntimeError):
+    def __init__(self, code):
+        super().__init__(lib().ms_oracle_strerror(code).decode())
+        self.code = code
+
+
+def _copy(ptr, n, dtype):
+    if n == 0:
+        return np.zeros(0, dtype=dtype)
+    buf = (C.c_char * (n * np.dtype(dtype).itemsize)).from_address(ptr)
+    return np.frombuffer(buf, dtype=dtype, count=n).copy()
+
+
+def parse_paf(path, params=None):
+    """A1.  Returns dict(rows, n_lines, read_names, anchor_names)."""
+    p = params or default_params()
+    r = _Rows()
+    rc = lib().ms_oracle_parse_paf(os.fsencode(path), C.byref(p), C.byref(r))
+    if rc != 0:
+        raise OracleError(rc)
+    try:
+        rows = _copy(r.rows, r.n_rows, ROW_DTYPE)
+        rn = C.string_at(r.read_names, r.read_names_len).decode().split("\0")[:-1] if r.read_names_len else []
+        an = C.string_at(r.anchor_names, r.anchor_names_len).decode().split("\0")[:-1] if r.anchor_names_len else []
+        return {"rows": rows, "n_lines": r.n_lines, "read_names": rn, "anchor_names": an}
+    finally:
+        lib().ms_oracle_free_rows(C.byref(r))
+
+
+def overlap(rows, params=None):
+    """A1 tail + A2..A7.  Returns dict of canonical tables and counters."""
+    p = params or default_params()
+    rows = np.ascontiguousarray(rows, dtype=ROW_DTYPE)
+    t = _Tables()
+    rc = lib().ms_oracle_overlap(rows.ctypes.data, len(rows), C.byref(p), C.byref(t))
+    if rc != 0:
+        raise OracleError(rc)
+    try:
+        return {
+            "edges": _copy(t.edges, t.n_edges, EDGE_DTYPE),
+            "ems": _copy(t.ems, t.n_ems, EM_DTYPE),
+            "orders": _copy(t.orders, t.n_orders, ORDER_DTYPE),
+            "ids": _copy(t.ids, t.n_ids, np.dtype("<u4")),
+            "read_len": _copy(t.read_len, t.n_reads, np.dtype("<i4")),
+            "read_first_line": _copy(t.read_first_line, t.n_reads, np.dtype("<u4")),
+            "rows_alive": t.rows_alive, "n_anchors": t.n_anchors, "p_eval": t.p_eval,
+            "compat_checks": t.compat_checks, "shadow_edges": t.shadow_edges,
+        }
+    finally:
+        lib().ms_oracle_free_tables(C.byref(t))
