@@ -1,0 +1,211 @@
+/*
+ * msgpu.h -- C-ABI of the MI355X-native overlap core for MuCHSALSA (libmsgpu.so).
+ *
+ * Drop-in boundary for the reference's overlap path.  Plain C, opaque context, caller-owned input buffers,
+ * int status codes (0 = ok) + msgpu_last_error(); no exception crosses it.  Each entry point names the
+ * reference interface it replaces (paths relative to the reference tree).
+ *
+ *   reference call site (src/main.cpp)                   replaced by
+ *   ---------------------------------------------------  --------------------------------------------
+ *   ThreadPool(threadCount)                      :143    msgpu_create          (HIP stream dispatcher)
+ *   BlastFileAccessor + BlastFileReader::read()  :153-156 msgpu_parse_paf + msgpu_load_rows
+ *   MatchMap::calculateEdges()                   :157    msgpu_calculate_edges
+ *   for edge: Job(chainingAndOverlaps)           :170-178 msgpu_chaining_and_overlaps
+ *   graph.getEdges()/Edge::getEdgeOrders()/...           msgpu_get_counts + msgpu_copy_tables
+ *
+ * Semantics are the single-thread reference's, bit for bit: int32 coordinates, IEEE fp64 scores/offsets
+ * evaluated in the reference's expression order (kernels are built with -ffp-contract=off).
+ */
+#ifndef MSGPU_H
+#define MSGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MSGPU_VERSION 1
+
+/* ---- status codes ------------------------------------------------------------------------------------------- */
+#define MSGPU_OK 0
+#define MSGPU_E_IO (-1)       /* "Can't open blast file."   BlastFileAccessor.cpp:43-45                        */
+#define MSGPU_E_FORMAT (-2)   /* "Invalid BLAST file."      BlastFileReader.cpp:97-99                          */
+#define MSGPU_E_NUMBER (-3)   /* a field std::stoi would reject (BlastFileReader.cpp:101-116)                  */
+#define MSGPU_E_NOMEM (-4)
+#define MSGPU_E_ARG (-5)      /* "Unexpected nullptr." & friends (MatchMap.cpp:55-57)                          */
+#define MSGPU_E_HIP (-6)      /* a HIP runtime call failed; text in msgpu_last_error                           */
+#define MSGPU_E_STATE (-7)    /* entry points called out of order                                              */
+#define MSGPU_E_IDS (-8)      /* read ids are not in first-line (Registry) order, Registry.cpp:36-45           */
+#define MSGPU_E_NODEVICE (-9) /* no HIP device: the product has NO CPU fallback                                */
+
+/* ---- records (byte-identical to oracle/ms_oracle.h) ----------------------------------------------------------- */
+
+/* One ACCEPTED PAF line = what BlastFileReader::parseLine hands to Graph::addVertex and
+ * MatchMap::addVertexMatch (BlastFileReader.cpp:101-126).  40 bytes. */
+typedef struct msgpu_row {
+  uint32_t anchor_id; /* illumina/unitig id, Registry first-seen order (registered second, :111)             */
+  uint32_t read_id;   /* nanopore id, Registry first-seen order (registered first, :110)                     */
+  int32_t  read_len;  /* col 6                                                                                */
+  int32_t  i_lo, i_hi; /* VertexMatch::illuminaRange = (col2, col3-1)                                          */
+  int32_t  n_lo, n_hi; /* VertexMatch::nanoporeRange = (col7, col8-1)                                          */
+  uint32_t score;     /* VertexMatch::score = col 9                                                           */
+  uint32_t line;      /* VertexMatch::lineNumber                                                              */
+  uint32_t flags;     /* bit0 VertexMatch::direction, bit1 VertexMatch::isPrimary                             */
+} msgpu_row;
+#define MSGPU_ROW_DIR 1u
+#define MSGPU_ROW_PRIMARY 2u
+
+/* graph::Edge (Edge.h:212-218) as a table row.  32 bytes.  Table order: ascending (v1, v2). */
+typedef struct msgpu_edge {
+  uint32_t v1, v2;    /* Edge::getVertices(): v1 = read with the lower first line (MatchMap.cpp:204-213)      */
+  uint64_t em_off;    /* this edge's EdgeMatches are ems[em_off .. em_off+em_cnt)                             */
+  uint64_t order_off; /* this edge's EdgeOrders are orders[order_off .. order_off+order_cnt)                  */
+  uint32_t em_cnt;
+  uint16_t order_cnt;
+  uint8_t  shadow;    /* Edge::isShadow (src/main.cpp:389-395)                                                */
+  uint8_t  pad;
+} msgpu_edge;
+
+/* matching::EdgeMatch (MatchMap.h:68-74).  32 bytes.  Within an edge: ascending
+ * (nanoporeRange on v1, anchor_id) = the vStart order of mpp.cpp:164-172. */
+typedef struct msgpu_edgematch {
+  int32_t  ov_lo, ov_hi; /* EdgeMatch::overlap                                                                */
+  double   score;        /* EdgeMatch::score (MatchMap.cpp:200-202)                                           */
+  uint32_t anchor_id;
+  uint32_t line;         /* EdgeMatch::lineNumber = outerMatch->lineNumber (MatchMap.cpp:218)                 */
+  uint32_t flags;        /* bit0 direction, bit1 isPrimary                                                    */
+  uint32_t edge_idx;
+} msgpu_edgematch;
+
+/* graph::EdgeOrder (Edge.h:49-60).  64 bytes.  Within an edge: emission order of src/main.cpp:397-411
+ * (minus-direction paths first, then plus). */
+typedef struct msgpu_order {
+  uint32_t edge_idx;
+  uint32_t flags;        /* MSGPU_ORD_* */
+  double   left_offset;
+  double   right_offset;
+  uint64_t score;        /* path score truncated like path_t's std::size_t (mpp.cpp:34,221,244)               */
+  uint64_t ids_off;      /* EdgeOrder::ids = ids[ids_off .. ids_off+ids_cnt)                                  */
+  uint32_t ids_cnt;
+  uint32_t start, end, base; /* startVertex / endVertex / baseVertex as read ids                              */
+  uint32_t pad[2];
+} msgpu_order;
+#define MSGPU_ORD_START_V1 1u  /* startVertex == v1 (else startVertex == v2, endVertex == v1)                 */
+#define MSGPU_ORD_CONTAINED 2u /* EdgeOrder::isContained                                                      */
+#define MSGPU_ORD_DIR 4u       /* EdgeOrder::direction                                                        */
+#define MSGPU_ORD_PRIMARY 8u   /* EdgeOrder::isPrimary                                                        */
+
+/* compile-time constants of the reference, exposed as parameters ("Config / flags") */
+typedef struct msgpu_params {
+  uint32_t min_matches; /* 400  MINIMUM_MATCHES  BlastFileReader.cpp:48 */
+  uint32_t th_length;   /* 500  TH_LENGTH        BlastFileReader.cpp:49 */
+  uint32_t th_matches;  /* 500  TH_MATCHES       BlastFileReader.cpp:50 */
+  uint32_t th_overlap;  /* 100  TH_OVERLAP       MatchMap.cpp:41        */
+  uint64_t wiggle_room; /* 300  Application::getWiggleRoom, Application.h:132 */
+  double   ratio_pct;   /* 15   mpp.cpp:136 */
+  double   alt_frac;    /* 0.75 mpp.cpp:223 */
+} msgpu_params;
+
+typedef struct msgpu_counts {
+  uint64_t n_rows_in;    /* rows handed to msgpu_load_rows                                                    */
+  uint64_t n_rows_alive; /* after the (read, anchor) lowest-line rule of MatchMap::addVertexMatch             */
+  uint32_t n_reads;      /* Graph::getOrder()                                                                 */
+  uint32_t n_anchors;    /* anchor id space                                                                   */
+  uint64_t n_edges;      /* Graph::getSize() (this shard)                                                     */
+  uint64_t n_ems;        /* EdgeMatches (this shard)                                                          */
+  uint64_t n_orders;     /* EdgeOrders (this shard)                                                           */
+  uint64_t n_ids;        /* sum of |EdgeOrder::ids| (this shard)                                              */
+  uint64_t n_pairs_scanned; /* scaffold rows visited while looking for pairs (both directions of each pair)   */
+} msgpu_counts;
+
+/* Device time of the last run of each stage, milliseconds, measured with HIP events on the context's stream. */
+typedef struct msgpu_timings {
+  float index_ms;      /* msgpu_load_rows: MatchMap-equivalent index build (device part)                      */
+  float candidates_ms; /* msgpu_calculate_edges: pair scan + group by edge                                    */
+  float chain_ms;      /* msgpu_chaining_and_overlaps: EdgeMatch + chaining DP + overlap kernel (dominant)    */
+  float compact_ms;    /* msgpu_chaining_and_overlaps: order/id compaction                                    */
+  float chain_kernel_ms; /* the chaining kernel alone (HIP events directly around its launch)                 */
+  uint32_t chain_kernel_launches;
+  uint32_t pad;
+} msgpu_timings;
+
+typedef struct msgpu_ctx msgpu_ctx;
+typedef struct msgpu_paf msgpu_paf;
+
+/* ---- life cycle ------------------------------------------------------------------------------------------------ */
+
+void msgpu_default_params(msgpu_params *p);
+const char *msgpu_strerror(int code);
+
+/* Replaces ThreadPool(threadCount) + Graph + MatchMap construction (src/main.cpp:143-148).
+ * `device` is a HIP device ordinal.  Fails with MSGPU_E_NODEVICE when there is none: there is no CPU path. */
+int  msgpu_create(int device, const msgpu_params *params, msgpu_ctx **out);
+void msgpu_destroy(msgpu_ctx *ctx);
+const char *msgpu_last_error(const msgpu_ctx *ctx);
+
+/* Run all work of this context on an existing HIP stream (hipStream_t), e.g. the caller's current stream.
+ * NULL restores the context's own stream. */
+int msgpu_set_stream(msgpu_ctx *ctx, void *hip_stream);
+
+/* Multi-GPU: this context owns the edges whose v1 satisfies v1 % n_shards == shard (default 0 of 1).
+ * Every shard loads the full row table; edges/orders of different shards are disjoint and their union is the
+ * 1-GPU result.  Must be called before msgpu_calculate_edges. */
+int msgpu_set_shard(msgpu_ctx *ctx, uint32_t shard, uint32_t n_shards);
+
+/* ---- A1: PAF loader (host) ------------------------------------------------------------------------------------- */
+
+/* Replaces BlastFileAccessor::_buildIndex (BlastFileAccessor.cpp:77-91) + BlastFileReader::read/parseLine
+ * (BlastFileReader.cpp:72-130): indexes all lines, parses all but the LAST one (:76), keeps a line iff
+ * col9 >= min_matches and col3-col2 >= min_matches, assigns Registry ids in first-seen order. */
+int  msgpu_parse_paf(const char *path, const msgpu_params *params, msgpu_paf **out);
+void msgpu_paf_free(msgpu_paf *paf);
+const msgpu_row *msgpu_paf_rows(const msgpu_paf *paf, size_t *n_rows);
+size_t      msgpu_paf_line_count(const msgpu_paf *paf);
+uint32_t    msgpu_paf_read_count(const msgpu_paf *paf);
+uint32_t    msgpu_paf_anchor_count(const msgpu_paf *paf);
+const char *msgpu_paf_read_name(const msgpu_paf *paf, uint32_t read_id);     /* Registry reverse lookup */
+const char *msgpu_paf_anchor_name(const msgpu_paf *paf, uint32_t anchor_id);
+
+/* ---- A1 tail: fill the device-resident MatchMap/Graph-vertex equivalent ---------------------------------------- */
+
+/* Replaces the effect of BlastFileReader::read() on Graph (addVertex: first line wins, Graph.cpp:148) and
+ * MatchMap (addVertexMatch: lowest line per (read, anchor) wins, MatchMap.cpp:52-81).
+ * `rows` may be in any order and may contain (read, anchor) duplicates.  Read ids must follow first-line
+ * order (what msgpu_parse_paf produces), else MSGPU_E_IDS.  Host buffer; copied to HBM. */
+int msgpu_load_rows(msgpu_ctx *ctx, const msgpu_row *rows, size_t n_rows);
+/* Same, rows already resident in HBM (device pointer, n_rows * 40 bytes).  The buffer is only read. */
+int msgpu_load_rows_device(msgpu_ctx *ctx, const void *d_rows, size_t n_rows);
+
+/* ---- A2/A3: MatchMap::calculateEdges (MatchMap.cpp:161-224) ----------------------------------------------------- */
+
+/* All pairs of reads sharing an anchor, overlap test (> th_overlap), grouping by edge.  After it returns
+ * msgpu_get_counts().n_edges / .n_ems are valid (Graph::getSize()). */
+int msgpu_calculate_edges(msgpu_ctx *ctx);
+
+/* ---- A4..A7: the chainingAndOverlaps fan-out (src/main.cpp:170-178, 328-414) ------------------------------------ */
+
+/* EdgeMatch scores, getMaxPairwisePaths (mpp.cpp:145-305) for both directions, the primary/multi filters,
+ * Edge::setShadow, getOverlap (ol.cpp:53-101), Edge::appendOrder -- for every edge of this shard. */
+int msgpu_chaining_and_overlaps(msgpu_ctx *ctx);
+
+/* ---- results ----------------------------------------------------------------------------------------------------- */
+
+int msgpu_get_counts(msgpu_ctx *ctx, msgpu_counts *out);
+int msgpu_get_timings(msgpu_ctx *ctx, msgpu_timings *out);
+
+/* Copy result tables to HOST buffers sized from msgpu_get_counts (any pointer may be NULL to skip). */
+int msgpu_copy_tables(msgpu_ctx *ctx, msgpu_edge *edges, msgpu_edgematch *ems, msgpu_order *orders, uint32_t *ids);
+/* Same into DEVICE buffers (device-to-device on the context's stream; used in front of the RCCL all-gather). */
+int msgpu_copy_tables_device(msgpu_ctx *ctx, void *d_edges, void *d_ems, void *d_orders, void *d_ids);
+/* Per-read Vertex facts: Vertex::getNanoporeLength() and metaDatum(0) (first line), n_reads entries each (host). */
+int msgpu_copy_reads(msgpu_ctx *ctx, int32_t *read_len, uint32_t *read_first_line);
+
+/* Block the host until everything queued on the context's stream has finished. */
+int msgpu_synchronize(msgpu_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MSGPU_H */

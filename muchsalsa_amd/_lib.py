@@ -1,0 +1,95 @@
+"""ctypes binding of include/msgpu.h (muchsalsa_amd/libmsgpu.so).
+
+There is no fallback: if the HIP library is missing or no GPU is present the calls raise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmsgpu.so")
+
+ROW_DTYPE = np.dtype([("anchor_id", "<u4"), ("read_id", "<u4"), ("read_len", "<i4"), ("i_lo", "<i4"),
+                      ("i_hi", "<i4"), ("n_lo", "<i4"), ("n_hi", "<i4"), ("score", "<u4"), ("line", "<u4"),
+                      ("flags", "<u4")])
+EDGE_DTYPE = np.dtype([("v1", "<u4"), ("v2", "<u4"), ("em_off", "<u8"), ("order_off", "<u8"), ("em_cnt", "<u4"),
+                       ("order_cnt", "<u2"), ("shadow", "u1"), ("pad", "u1")])
+EM_DTYPE = np.dtype([("ov_lo", "<i4"), ("ov_hi", "<i4"), ("score", "<f8"), ("anchor_id", "<u4"), ("line", "<u4"),
+                     ("flags", "<u4"), ("edge_idx", "<u4")])
+ORDER_DTYPE = np.dtype([("edge_idx", "<u4"), ("flags", "<u4"), ("left_offset", "<f8"), ("right_offset", "<f8"),
+                        ("score", "<u8"), ("ids_off", "<u8"), ("ids_cnt", "<u4"), ("start", "<u4"), ("end", "<u4"),
+                        ("base", "<u4"), ("pad", "<u4", (2,))])
+assert (ROW_DTYPE.itemsize, EDGE_DTYPE.itemsize, EM_DTYPE.itemsize, ORDER_DTYPE.itemsize) == (40, 32, 32, 64)
+
+OK = 0
+E_IO, E_FORMAT, E_NUMBER, E_NOMEM, E_ARG, E_HIP, E_STATE, E_IDS, E_NODEVICE = -1, -2, -3, -4, -5, -6, -7, -8, -9
+
+ORD_START_V1, ORD_CONTAINED, ORD_DIR, ORD_PRIMARY = 1, 2, 4, 8
+
+
+class Params(C.Structure):
+    _fields_ = [("min_matches", C.c_uint32), ("th_length", C.c_uint32), ("th_matches", C.c_uint32),
+                ("th_overlap", C.c_uint32), ("wiggle_room", C.c_uint64), ("ratio_pct", C.c_double),
+                ("alt_frac", C.c_double)]
+
+
+class Counts(C.Structure):
+    _fields_ = [("n_rows_in", C.c_uint64), ("n_rows_alive", C.c_uint64), ("n_reads", C.c_uint32),
+                ("n_anchors", C.c_uint32), ("n_edges", C.c_uint64), ("n_ems", C.c_uint64), ("n_orders", C.c_uint64),
+                ("n_ids", C.c_uint64), ("n_pairs_scanned", C.c_uint64)]
+
+
+class Timings(C.Structure):
+    _fields_ = [("index_ms", C.c_float), ("candidates_ms", C.c_float), ("chain_ms", C.c_float),
+                ("compact_ms", C.c_float), ("chain_kernel_ms", C.c_float), ("chain_kernel_launches", C.c_uint32),
+                ("pad", C.c_uint32)]
+
+
+# every symbol include/msgpu.h declares: (name, restype, argtypes)
+SYMBOLS = [
+    ("msgpu_default_params", None, [C.POINTER(Params)]),
+    ("msgpu_strerror", C.c_char_p, [C.c_int]),
+    ("msgpu_create", C.c_int, [C.c_int, C.POINTER(Params), C.POINTER(C.c_void_p)]),
+    ("msgpu_destroy", None, [C.c_void_p]),
+    ("msgpu_last_error", C.c_char_p, [C.c_void_p]),
+    ("msgpu_set_stream", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("msgpu_set_shard", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32]),
+    ("msgpu_parse_paf", C.c_int, [C.c_char_p, C.POINTER(Params), C.POINTER(C.c_void_p)]),
+    ("msgpu_paf_free", None, [C.c_void_p]),
+    ("msgpu_paf_rows", C.c_void_p, [C.c_void_p, C.POINTER(C.c_size_t)]),
+    ("msgpu_paf_line_count", C.c_size_t, [C.c_void_p]),
+    ("msgpu_paf_read_count", C.c_uint32, [C.c_void_p]),
+    ("msgpu_paf_anchor_count", C.c_uint32, [C.c_void_p]),
+    ("msgpu_paf_read_name", C.c_char_p, [C.c_void_p, C.c_uint32]),
+    ("msgpu_paf_anchor_name", C.c_char_p, [C.c_void_p, C.c_uint32]),
+    ("msgpu_load_rows", C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    ("msgpu_load_rows_device", C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    ("msgpu_calculate_edges", C.c_int, [C.c_void_p]),
+    ("msgpu_chaining_and_overlaps", C.c_int, [C.c_void_p]),
+    ("msgpu_get_counts", C.c_int, [C.c_void_p, C.POINTER(Counts)]),
+    ("msgpu_get_timings", C.c_int, [C.c_void_p, C.POINTER(Timings)]),
+    ("msgpu_copy_tables", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("msgpu_copy_tables_device", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("msgpu_copy_reads", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("msgpu_synchronize", C.c_int, [C.c_void_p]),
+]
+
+_lib = None
+
+
+def lib():
+    """Load libmsgpu.so; raises (never falls back) when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "muchsalsa_amd/libmsgpu.so is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or `make -C muchsalsa_amd/csrc`). There is no CPU fallback.")
+        handle = C.CDLL(LIB_PATH)
+        for name, restype, argtypes in SYMBOLS:
+            fn = getattr(handle, name)  # AttributeError if the library lacks a declared symbol
+            fn.restype = restype
+            fn.argtypes = argtypes
+        _lib = handle
+    return _lib

@@ -1,0 +1,573 @@
+// msgpu_api.hip -- C-ABI host layer of libmsgpu: context, HBM arena, stage orchestration on one HIP stream.
+//
+// This is the replacement of the reference's ThreadPool/WaitGroup fan-out (libms/src/threading/*): every reference
+// phase "one Job per line/anchor/edge + WaitGroup::wait()" becomes a handful of kernel launches on the context's
+// stream; the phase barrier is stream order.  The host blocks only where a table size is needed to allocate.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "msgpu.h"
+#include "msgpu_internal.h"
+
+using namespace msgpu;
+
+namespace {
+
+struct DevBuf {
+  void  *p   = nullptr;
+  size_t cap = 0;
+  hipError_t ensure(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    if (p) {
+      hipError_t e = hipFree(p);
+      p   = nullptr;
+      cap = 0;
+      if (e != hipSuccess) return e;
+    }
+    size_t want = bytes + bytes / 8 + 256; // slack so slowly growing inputs do not reallocate each run
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) {
+      p = nullptr;
+      return e;
+    }
+    cap = want;
+    return hipSuccess;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p   = nullptr;
+    cap = 0;
+  }
+  template <class T> T *as() const { return static_cast<T *>(p); }
+};
+
+enum State { ST_CREATED = 0, ST_LOADED = 1, ST_EDGES = 2, ST_CHAINED = 3 };
+
+} // namespace
+
+struct msgpu_ctx {
+  int          device     = 0;
+  hipStream_t  stream     = nullptr;
+  hipStream_t  own_stream = nullptr;
+  msgpu_params p;
+  char         err[512]   = {0};
+  State        state      = ST_CREATED;
+  uint32_t     shard = 0, nshards = 1;
+
+  // loaded rows
+  uint64_t n_rows = 0, n_alive = 0;
+  uint32_t V = 0, A = 0;
+  const msgpu_row *d_rows = nullptr; // either rows_in.p or the caller's device buffer
+
+  // results
+  uint64_t n_edges = 0, n_ems = 0, n_orders = 0, n_ids = 0, n_visit = 0, total_bound = 0;
+  uint32_t n_list[3] = {0, 0, 0};
+
+  // arena
+  DevBuf rows_in, cnt_read, first_key, read_off, cursor, bkt_key, bkt_idx, bkt_dead, by_read, read_cnt, alive_rank,
+      anchor_cnt, anchor_off, bkt2_idx, bkt2_line, by_anchor, read_len, read_first, scalars, scan_tmp;
+  DevBuf bound, cand_off, cand_j, cand_t, scr_v2, scr_start, n_cand, n_edge, n_visit_arr, lists, em_base, edge_base,
+      visit_base, edges, edge_cand;
+  DevBuf big_key, big_t, big_r2s, big_pfx;
+  DevBuf ems, order_scr, ids_scr, edge_norders, edge_nids, order_base, ids_base, orders, ids, big_list, big_elems,
+      big_paths;
+
+  // timing
+  hipEvent_t ev[10] = {nullptr};
+  bool       have_index_t = false, have_cand_t = false, have_chain_t = false;
+};
+
+namespace {
+
+// scalar slots in ctx->scalars (uint64 each)
+enum { SC_MAXIDS = 0 /*2 x u32*/, SC_ERR = 1, SC_TOTAL_A = 2, SC_TOTAL_B = 3, SC_TOTAL_C = 4, SC_NLISTS = 5 /*3 x u32, spans 5..6*/,
+       SC_NBIG = 7, SC_NALIVE = 8, SC_COUNT = 16 };
+
+int fail(msgpu_ctx *c, int code, const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(c->err, sizeof(c->err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define HIPCHK(c, expr)                                                                                                \
+  do {                                                                                                                 \
+    hipError_t _e = (expr);                                                                                            \
+    if (_e != hipSuccess)                                                                                              \
+      return fail((c), _e == hipErrorOutOfMemory ? MSGPU_E_NOMEM : MSGPU_E_HIP, "%s failed: %s (%s:%d)", #expr,        \
+                  hipGetErrorString(_e), __FILE__, __LINE__);                                                          \
+  } while (0)
+
+#define ENSURE(c, buf, bytes) HIPCHK(c, (c)->buf.ensure(bytes))
+
+template <class T> T *scalar(msgpu_ctx *c, int slot) { return reinterpret_cast<T *>(c->scalars.as<uint64_t>() + slot); }
+
+void release_all(msgpu_ctx *c) {
+  DevBuf *all[] = {&c->rows_in, &c->cnt_read, &c->first_key, &c->read_off, &c->cursor, &c->bkt_key, &c->bkt_idx,
+                   &c->bkt_dead, &c->by_read, &c->read_cnt, &c->alive_rank, &c->anchor_cnt, &c->anchor_off,
+                   &c->bkt2_idx, &c->bkt2_line, &c->by_anchor, &c->read_len, &c->read_first, &c->scalars, &c->scan_tmp,
+                   &c->bound, &c->cand_off, &c->cand_j, &c->cand_t, &c->scr_v2, &c->scr_start, &c->n_cand, &c->n_edge,
+                   &c->n_visit_arr, &c->lists, &c->em_base, &c->edge_base, &c->visit_base, &c->edges, &c->edge_cand,
+                   &c->big_key, &c->big_t, &c->big_r2s, &c->big_pfx, &c->ems, &c->order_scr, &c->ids_scr,
+                   &c->edge_norders, &c->edge_nids, &c->order_base, &c->ids_base, &c->orders, &c->ids, &c->big_list,
+                   &c->big_elems, &c->big_paths};
+  for (DevBuf *b : all) b->release();
+}
+
+int build_index(msgpu_ctx *c) {
+  hipStream_t st = c->stream;
+  const uint64_t n = c->n_rows;
+  ENSURE(c, scalars, SC_COUNT * sizeof(uint64_t));
+  HIPCHK(c, hipMemsetAsync(c->scalars.p, 0, SC_COUNT * sizeof(uint64_t), st));
+  HIPCHK(c, hipEventRecord(c->ev[0], st));
+
+  // id spaces
+  launch_max_ids(st, c->d_rows, n, scalar<uint32_t>(c, SC_MAXIDS));
+  uint32_t maxids[2] = {0, 0};
+  HIPCHK(c, hipMemcpyAsync(maxids, scalar<uint32_t>(c, SC_MAXIDS), sizeof(maxids), hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipStreamSynchronize(st));
+  c->V = maxids[0];
+  c->A = maxids[1];
+  const uint32_t V = c->V, A = c->A;
+
+  const size_t nz = n ? n : 1;
+  ENSURE(c, cnt_read, (size_t(V) + 1) * 4);
+  ENSURE(c, first_key, (size_t(V) + 1) * 8);
+  ENSURE(c, read_off, (size_t(V) + 2) * 4);
+  ENSURE(c, cursor, (size_t(V > A ? V : A) + 1) * 4);
+  ENSURE(c, bkt_key, nz * 16);
+  ENSURE(c, bkt_idx, nz * 4);
+  ENSURE(c, bkt_dead, nz);
+  ENSURE(c, by_read, nz * sizeof(IRow));
+  ENSURE(c, read_cnt, (size_t(V) + 1) * 4);
+  ENSURE(c, alive_rank, nz * 4);
+  ENSURE(c, anchor_cnt, (size_t(A) + 1) * 4);
+  ENSURE(c, anchor_off, (size_t(A) + 2) * 4);
+  ENSURE(c, bkt2_idx, nz * 4);
+  ENSURE(c, bkt2_line, nz * 4);
+  ENSURE(c, by_anchor, nz * sizeof(IRow));
+  ENSURE(c, read_len, (size_t(V) + 1) * 4);
+  ENSURE(c, read_first, (size_t(V) + 1) * 4);
+  {
+    uint64_t m = n;
+    if (V > m) m = V;
+    if (A > m) m = A;
+    ENSURE(c, scan_tmp, (size_t(scan_blocks(m)) + 1) * 8);
+  }
+
+  HIPCHK(c, hipMemsetAsync(c->cnt_read.p, 0, (size_t(V) + 1) * 4, st));
+  HIPCHK(c, hipMemsetAsync(c->first_key.p, 0xff, (size_t(V) + 1) * 8, st));
+  HIPCHK(c, hipMemsetAsync(c->cursor.p, 0, (size_t(V > A ? V : A) + 1) * 4, st));
+  HIPCHK(c, hipMemsetAsync(c->read_cnt.p, 0, (size_t(V) + 1) * 4, st));
+  HIPCHK(c, hipMemsetAsync(c->anchor_cnt.p, 0, (size_t(A) + 1) * 4, st));
+
+  launch_hist_read(st, c->d_rows, n, c->cnt_read.as<uint32_t>(), c->first_key.as<uint64_t>());
+  launch_read_facts(st, c->d_rows, c->first_key.as<uint64_t>(), V, c->read_len.as<int32_t>(),
+                    c->read_first.as<uint32_t>(), scalar<uint32_t>(c, SC_ERR));
+  exclusive_scan<uint32_t>(st, c->cnt_read.as<uint32_t>(), V, c->read_off.as<uint32_t>(), c->scan_tmp.as<uint32_t>(),
+                           scalar<uint32_t>(c, SC_TOTAL_A));
+  launch_scatter_read(st, c->d_rows, n, c->read_off.as<uint32_t>(), c->cursor.as<uint32_t>(), c->bkt_key.p,
+                      c->bkt_idx.as<uint32_t>());
+  launch_dedupe(st, c->read_off.as<uint32_t>(), n, c->bkt_key.p, c->bkt_idx.as<uint32_t>(), c->d_rows,
+                c->bkt_dead.as<uint8_t>());
+  launch_rank_read(st, c->read_off.as<uint32_t>(), n, c->bkt_key.p, c->bkt_idx.as<uint32_t>(), c->bkt_dead.as<uint8_t>(),
+                   c->d_rows, c->by_read.as<IRow>(), c->read_cnt.as<uint32_t>(), c->alive_rank.as<uint32_t>(),
+                   c->anchor_cnt.as<uint32_t>());
+  exclusive_scan<uint32_t>(st, c->anchor_cnt.as<uint32_t>(), A, c->anchor_off.as<uint32_t>(), c->scan_tmp.as<uint32_t>(),
+                           scalar<uint32_t>(c, SC_NALIVE));
+  HIPCHK(c, hipMemsetAsync(c->cursor.p, 0, (size_t(V > A ? V : A) + 1) * 4, st));
+  launch_scatter_anchor(st, c->d_rows, n, c->alive_rank.as<uint32_t>(), c->anchor_off.as<uint32_t>(),
+                        c->cursor.as<uint32_t>(), c->bkt2_idx.as<uint32_t>(), c->bkt2_line.as<uint32_t>());
+  launch_rank_anchor(st, c->anchor_off.as<uint32_t>(), n, scalar<uint32_t>(c, SC_NALIVE), c->bkt2_idx.as<uint32_t>(),
+                     c->bkt2_line.as<uint32_t>(), c->d_rows, c->alive_rank.as<uint32_t>(), c->by_anchor.as<IRow>());
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipEventRecord(c->ev[1], st));
+
+  uint32_t err = 0, n_alive = 0;
+  HIPCHK(c, hipMemcpyAsync(&err, scalar<uint32_t>(c, SC_ERR), 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipMemcpyAsync(&n_alive, scalar<uint32_t>(c, SC_NALIVE), 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipStreamSynchronize(st));
+  c->have_index_t = true;
+  c->n_alive      = n_alive;
+  if (err & 1u)
+    return fail(c, MSGPU_E_IDS,
+                "read ids are not dense Registry ids in first-line order (Registry.cpp:36-45): use msgpu_parse_paf ids");
+  c->state = ST_LOADED;
+  return MSGPU_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+void msgpu_default_params(msgpu_params *p) {
+  if (!p) return;
+  p->min_matches = 400;
+  p->th_length   = 500;
+  p->th_matches  = 500;
+  p->th_overlap  = 100;
+  p->wiggle_room = 300;
+  p->ratio_pct   = 15;
+  p->alt_frac    = 0.75;
+}
+
+const char *msgpu_strerror(int code) {
+  switch (code) {
+  case MSGPU_OK: return "ok";
+  case MSGPU_E_IO: return "can't open blast file";
+  case MSGPU_E_FORMAT: return "invalid BLAST file";
+  case MSGPU_E_NUMBER: return "invalid integer field in BLAST file";
+  case MSGPU_E_NOMEM: return "out of memory";
+  case MSGPU_E_ARG: return "invalid argument (unexpected nullptr)";
+  case MSGPU_E_HIP: return "HIP runtime error";
+  case MSGPU_E_STATE: return "entry points called out of order";
+  case MSGPU_E_IDS: return "read ids are not in Registry (first-line) order";
+  case MSGPU_E_NODEVICE: return "no HIP device (libmsgpu has no CPU fallback)";
+  default: return "unknown error";
+  }
+}
+
+int msgpu_create(int device, const msgpu_params *params, msgpu_ctx **out) {
+  if (!out) return MSGPU_E_ARG;
+  *out = nullptr;
+  int        ndev = 0;
+  hipError_t e    = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0) return MSGPU_E_NODEVICE;
+  if (device < 0 || device >= ndev) return MSGPU_E_ARG;
+  msgpu_ctx *c = new (std::nothrow) msgpu_ctx();
+  if (!c) return MSGPU_E_NOMEM;
+  c->device = device;
+  if (params)
+    c->p = *params;
+  else
+    msgpu_default_params(&c->p);
+  if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) {
+    delete c;
+    return MSGPU_E_HIP;
+  }
+  c->stream = c->own_stream;
+  for (auto &ev : c->ev)
+    if (hipEventCreate(&ev) != hipSuccess) {
+      msgpu_destroy(c);
+      return MSGPU_E_HIP;
+    }
+  *out = c;
+  return MSGPU_OK;
+}
+
+void msgpu_destroy(msgpu_ctx *c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  release_all(c);
+  for (auto &ev : c->ev)
+    if (ev) (void)hipEventDestroy(ev);
+  if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+  delete c;
+}
+
+const char *msgpu_last_error(const msgpu_ctx *c) { return c ? c->err : "null context"; }
+
+int msgpu_set_stream(msgpu_ctx *c, void *hip_stream) {
+  if (!c) return MSGPU_E_ARG;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->own_stream;
+  return MSGPU_OK;
+}
+
+int msgpu_set_shard(msgpu_ctx *c, uint32_t shard, uint32_t n_shards) {
+  if (!c) return MSGPU_E_ARG;
+  if (n_shards == 0 || shard >= n_shards) return fail(c, MSGPU_E_ARG, "shard %u of %u is out of range", shard, n_shards);
+  c->shard   = shard;
+  c->nshards = n_shards;
+  if (c->state > ST_LOADED) c->state = ST_LOADED;
+  return MSGPU_OK;
+}
+
+int msgpu_load_rows(msgpu_ctx *c, const msgpu_row *rows, size_t n_rows) {
+  if (!c) return MSGPU_E_ARG;
+  if (n_rows && !rows) return fail(c, MSGPU_E_ARG, "Unexpected nullptr.");
+  if (n_rows >= 0xfffffff0ull) return fail(c, MSGPU_E_ARG, "row table too large (%zu rows)", n_rows);
+  HIPCHK(c, hipSetDevice(c->device));
+  c->state = ST_CREATED;
+  ENSURE(c, rows_in, (n_rows ? n_rows : 1) * sizeof(msgpu_row));
+  if (n_rows)
+    HIPCHK(c, hipMemcpyAsync(c->rows_in.p, rows, n_rows * sizeof(msgpu_row), hipMemcpyHostToDevice, c->stream));
+  c->d_rows = c->rows_in.as<msgpu_row>();
+  c->n_rows = n_rows;
+  return build_index(c);
+}
+
+int msgpu_load_rows_device(msgpu_ctx *c, const void *d_rows, size_t n_rows) {
+  if (!c) return MSGPU_E_ARG;
+  if (n_rows && !d_rows) return fail(c, MSGPU_E_ARG, "Unexpected nullptr.");
+  if (n_rows >= 0xfffffff0ull) return fail(c, MSGPU_E_ARG, "row table too large (%zu rows)", n_rows);
+  HIPCHK(c, hipSetDevice(c->device));
+  c->state  = ST_CREATED;
+  c->d_rows = static_cast<const msgpu_row *>(d_rows);
+  c->n_rows = n_rows;
+  return build_index(c);
+}
+
+int msgpu_calculate_edges(msgpu_ctx *c) {
+  if (!c) return MSGPU_E_ARG;
+  if (c->state < ST_LOADED) return fail(c, MSGPU_E_STATE, "msgpu_calculate_edges before msgpu_load_rows");
+  HIPCHK(c, hipSetDevice(c->device));
+  hipStream_t    st = c->stream;
+  const uint32_t V  = c->V;
+  c->state          = ST_LOADED;
+  HIPCHK(c, hipEventRecord(c->ev[2], st));
+
+  ENSURE(c, bound, (size_t(V) + 1) * 4);
+  ENSURE(c, cand_off, (size_t(V) + 2) * 8);
+  ENSURE(c, lists, (size_t(V) + 1) * 4 * 3);
+  ENSURE(c, n_cand, (size_t(V) + 1) * 4);
+  ENSURE(c, n_edge, (size_t(V) + 1) * 4);
+  ENSURE(c, n_visit_arr, (size_t(V) + 1) * 4);
+  ENSURE(c, em_base, (size_t(V) + 2) * 8);
+  ENSURE(c, edge_base, (size_t(V) + 2) * 8);
+  ENSURE(c, visit_base, (size_t(V) + 2) * 8);
+  uint32_t *l0 = c->lists.as<uint32_t>(), *l1 = l0 + V + 1, *l2 = l1 + V + 1;
+
+  HIPCHK(c, hipMemsetAsync(scalar<uint32_t>(c, SC_NLISTS), 0, 16, st));
+  HIPCHK(c, hipMemsetAsync(c->n_cand.p, 0, (size_t(V) + 1) * 4, st));
+  HIPCHK(c, hipMemsetAsync(c->n_edge.p, 0, (size_t(V) + 1) * 4, st));
+  HIPCHK(c, hipMemsetAsync(c->n_visit_arr.p, 0, (size_t(V) + 1) * 4, st));
+  launch_bound(st, c->read_off.as<uint32_t>(), c->read_cnt.as<uint32_t>(), c->by_read.as<IRow>(),
+               c->anchor_off.as<uint32_t>(), V, c->shard, c->nshards, c->bound.as<uint32_t>());
+  exclusive_scan<uint64_t>(st, c->bound.as<uint32_t>(), V, c->cand_off.as<uint64_t>(), c->scan_tmp.as<uint64_t>(),
+                           scalar<uint64_t>(c, SC_TOTAL_A));
+  launch_classify_reads(st, c->read_cnt.as<uint32_t>(), c->bound.as<uint32_t>(), V, c->shard, c->nshards, l0, l1, l2,
+                        scalar<uint32_t>(c, SC_NLISTS));
+  HIPCHK(c, hipGetLastError());
+  uint64_t total_bound = 0;
+  HIPCHK(c, hipMemcpyAsync(&total_bound, scalar<uint64_t>(c, SC_TOTAL_A), 8, hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipMemcpyAsync(c->n_list, scalar<uint32_t>(c, SC_NLISTS), 12, hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipStreamSynchronize(st)); // sizes of the candidate scratch
+  c->total_bound = total_bound;
+
+  const size_t tb = total_bound ? total_bound : 1;
+  ENSURE(c, cand_j, tb * 4);
+  ENSURE(c, cand_t, tb * 4);
+  ENSURE(c, scr_v2, tb * 4);
+  ENSURE(c, scr_start, tb * 4);
+
+  CandArgs a;
+  a.read_off       = c->read_off.as<uint32_t>();
+  a.read_cnt       = c->read_cnt.as<uint32_t>();
+  a.anchor_off     = c->anchor_off.as<uint32_t>();
+  a.by_read        = c->by_read.as<IRow>();
+  a.by_anchor      = c->by_anchor.as<IRow>();
+  a.cand_off       = c->cand_off.as<uint64_t>();
+  a.cand_j         = c->cand_j.as<uint32_t>();
+  a.cand_t         = c->cand_t.as<uint32_t>();
+  a.edge_scr_v2    = c->scr_v2.as<uint32_t>();
+  a.edge_scr_start = c->scr_start.as<uint32_t>();
+  a.n_cand         = c->n_cand.as<uint32_t>();
+  a.n_edge         = c->n_edge.as<uint32_t>();
+  a.n_visit        = c->n_visit_arr.as<uint32_t>();
+  a.th_overlap     = c->p.th_overlap;
+  launch_candidates(st, a, 0, l0, c->n_list[0]);
+  launch_candidates(st, a, 1, l1, c->n_list[1]);
+  if (c->n_list[2]) {
+    ENSURE(c, big_key, tb * 8);
+    ENSURE(c, big_t, tb * 4);
+    ENSURE(c, big_r2s, tb * 4);
+    ENSURE(c, big_pfx, (c->n_rows ? c->n_rows : 1) * 4);
+    launch_candidates_big(st, a, l2, c->n_list[2], c->big_key.as<uint64_t>(), c->big_t.as<uint32_t>(),
+                          c->big_r2s.as<uint32_t>(), c->big_pfx.as<uint32_t>());
+  }
+  exclusive_scan<uint64_t>(st, c->n_cand.as<uint32_t>(), V, c->em_base.as<uint64_t>(), c->scan_tmp.as<uint64_t>(),
+                           scalar<uint64_t>(c, SC_TOTAL_A));
+  exclusive_scan<uint64_t>(st, c->n_edge.as<uint32_t>(), V, c->edge_base.as<uint64_t>(), c->scan_tmp.as<uint64_t>(),
+                           scalar<uint64_t>(c, SC_TOTAL_B));
+  exclusive_scan<uint64_t>(st, c->n_visit_arr.as<uint32_t>(), V, c->visit_base.as<uint64_t>(),
+                           c->scan_tmp.as<uint64_t>(), scalar<uint64_t>(c, SC_TOTAL_C));
+  HIPCHK(c, hipGetLastError());
+  uint64_t tot[3] = {0, 0, 0};
+  HIPCHK(c, hipMemcpyAsync(tot, scalar<uint64_t>(c, SC_TOTAL_A), 24, hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipStreamSynchronize(st)); // sizes of the edge / EdgeMatch tables
+  c->n_ems   = tot[0];
+  c->n_edges = tot[1];
+  c->n_visit = tot[2];
+  if (c->n_edges >= 0xfffffff0ull) return fail(c, MSGPU_E_ARG, "edge table too large (%llu)", (unsigned long long)c->n_edges);
+
+  ENSURE(c, edges, (c->n_edges ? c->n_edges : 1) * sizeof(msgpu_edge));
+  ENSURE(c, edge_cand, (c->n_edges ? c->n_edges : 1) * 8);
+  launch_emit_edges(st, c->n_edge.as<uint32_t>(), c->n_cand.as<uint32_t>(), c->edge_base.as<uint64_t>(),
+                    c->em_base.as<uint64_t>(), c->cand_off.as<uint64_t>(), c->scr_v2.as<uint32_t>(),
+                    c->scr_start.as<uint32_t>(), V, c->edges.as<msgpu_edge>(), c->edge_cand.as<uint64_t>());
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipEventRecord(c->ev[3], st));
+  c->have_cand_t = true;
+  c->n_orders    = 0;
+  c->n_ids       = 0;
+  c->state       = ST_EDGES;
+  return MSGPU_OK;
+}
+
+int msgpu_chaining_and_overlaps(msgpu_ctx *c) {
+  if (!c) return MSGPU_E_ARG;
+  if (c->state < ST_EDGES) return fail(c, MSGPU_E_STATE, "msgpu_chaining_and_overlaps before msgpu_calculate_edges");
+  HIPCHK(c, hipSetDevice(c->device));
+  hipStream_t    st = c->stream;
+  const uint64_t E = c->n_edges, M = c->n_ems;
+  HIPCHK(c, hipEventRecord(c->ev[4], st));
+
+  ENSURE(c, ems, (M ? M : 1) * sizeof(msgpu_edgematch));
+  ENSURE(c, order_scr, (M ? M : 1) * sizeof(msgpu_order));
+  ENSURE(c, ids_scr, (M ? M : 1) * 4);
+  ENSURE(c, edge_norders, (E + 1) * 4);
+  ENSURE(c, edge_nids, (E + 1) * 4);
+  ENSURE(c, order_base, (E + 2) * 8);
+  ENSURE(c, ids_base, (E + 2) * 8);
+  ENSURE(c, big_list, (E + 1) * 4);
+  ENSURE(c, scan_tmp, (size_t(scan_blocks(E > c->V ? E : c->V)) + 1) * 8);
+  HIPCHK(c, hipMemsetAsync(c->edge_norders.p, 0, (E + 1) * 4, st));
+  HIPCHK(c, hipMemsetAsync(c->edge_nids.p, 0, (E + 1) * 4, st));
+  HIPCHK(c, hipMemsetAsync(scalar<uint32_t>(c, SC_NBIG), 0, 8, st));
+
+  ChainArgs a;
+  a.edges        = c->edges.as<msgpu_edge>();
+  a.edge_cand    = c->edge_cand.as<uint64_t>();
+  a.n_edges      = E;
+  a.cand_j       = c->cand_j.as<uint32_t>();
+  a.cand_t       = c->cand_t.as<uint32_t>();
+  a.read_off     = c->read_off.as<uint32_t>();
+  a.read_cnt     = c->read_cnt.as<uint32_t>();
+  a.read_len     = c->read_len.as<int32_t>();
+  a.by_read      = c->by_read.as<IRow>();
+  a.by_anchor    = c->by_anchor.as<IRow>();
+  a.ems          = c->ems.as<msgpu_edgematch>();
+  a.order_scr    = c->order_scr.as<msgpu_order>();
+  a.ids_scr      = c->ids_scr.as<uint32_t>();
+  a.edge_norders = c->edge_norders.as<uint32_t>();
+  a.edge_nids    = c->edge_nids.as<uint32_t>();
+  a.err          = scalar<uint32_t>(c, SC_ERR);
+  a.wiggle       = static_cast<double>(c->p.wiggle_room);
+  a.ratio_pct    = c->p.ratio_pct;
+  a.alt_frac     = c->p.alt_frac;
+
+  launch_list_big_edges(st, a.edges, E, c->big_list.as<uint32_t>(), scalar<uint32_t>(c, SC_NBIG));
+  HIPCHK(c, hipEventRecord(c->ev[5], st));
+  launch_chain(st, a);
+  HIPCHK(c, hipEventRecord(c->ev[6], st));
+  HIPCHK(c, hipGetLastError());
+
+  uint64_t tot[2] = {0, 0};
+  uint32_t n_big  = 0;
+  for (int round = 0; round < 2; ++round) {
+    exclusive_scan<uint64_t>(st, c->edge_norders.as<uint32_t>(), E, c->order_base.as<uint64_t>(),
+                             c->scan_tmp.as<uint64_t>(), scalar<uint64_t>(c, SC_TOTAL_A));
+    exclusive_scan<uint64_t>(st, c->edge_nids.as<uint32_t>(), E, c->ids_base.as<uint64_t>(),
+                             c->scan_tmp.as<uint64_t>(), scalar<uint64_t>(c, SC_TOTAL_B));
+    HIPCHK(c, hipEventRecord(c->ev[7], st));
+    HIPCHK(c, hipMemcpyAsync(tot, scalar<uint64_t>(c, SC_TOTAL_A), 16, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(&n_big, scalar<uint32_t>(c, SC_NBIG), 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st)); // sizes of the order / id tables (+ the number of oversized edges)
+    if (round == 1 || n_big == 0) break;
+    // rare: edges with more than 64 EdgeMatches take the global-scratch kernel, then the scans are redone
+    ENSURE(c, big_elems, (M ? M : 1) * big_elem_bytes());
+    ENSURE(c, big_paths, (M ? M : 1) * 2 * big_path_bytes());
+    launch_chain_big(st, a, c->big_list.as<uint32_t>(), n_big, c->big_elems.p, c->big_paths.p);
+    HIPCHK(c, hipGetLastError());
+  }
+  c->n_orders = tot[0];
+  c->n_ids    = tot[1];
+  ENSURE(c, orders, (c->n_orders ? c->n_orders : 1) * sizeof(msgpu_order));
+  ENSURE(c, ids, (c->n_ids ? c->n_ids : 1) * 4);
+
+  CompactArgs k;
+  k.edges        = c->edges.as<msgpu_edge>();
+  k.n_edges      = E;
+  k.edge_norders = c->edge_norders.as<uint32_t>();
+  k.order_base   = c->order_base.as<uint64_t>();
+  k.ids_base     = c->ids_base.as<uint64_t>();
+  k.order_scr    = c->order_scr.as<msgpu_order>();
+  k.ids_scr      = c->ids_scr.as<uint32_t>();
+  k.orders       = c->orders.as<msgpu_order>();
+  k.ids          = c->ids.as<uint32_t>();
+  launch_compact(st, k);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipEventRecord(c->ev[8], st));
+  c->have_chain_t = true;
+  c->state        = ST_CHAINED;
+  return MSGPU_OK;
+}
+
+int msgpu_get_counts(msgpu_ctx *c, msgpu_counts *out) {
+  if (!c || !out) return MSGPU_E_ARG;
+  memset(out, 0, sizeof(*out));
+  out->n_rows_in       = c->n_rows;
+  out->n_rows_alive    = c->n_alive;
+  out->n_reads         = c->V;
+  out->n_anchors       = c->A;
+  out->n_edges         = c->state >= ST_EDGES ? c->n_edges : 0;
+  out->n_ems           = c->state >= ST_EDGES ? c->n_ems : 0;
+  out->n_orders        = c->state >= ST_CHAINED ? c->n_orders : 0;
+  out->n_ids           = c->state >= ST_CHAINED ? c->n_ids : 0;
+  out->n_pairs_scanned = c->state >= ST_EDGES ? c->n_visit : 0;
+  return MSGPU_OK;
+}
+
+int msgpu_get_timings(msgpu_ctx *c, msgpu_timings *out) {
+  if (!c || !out) return MSGPU_E_ARG;
+  memset(out, 0, sizeof(*out));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (c->have_index_t) HIPCHK(c, hipEventElapsedTime(&out->index_ms, c->ev[0], c->ev[1]));
+  if (c->have_cand_t) HIPCHK(c, hipEventElapsedTime(&out->candidates_ms, c->ev[2], c->ev[3]));
+  if (c->have_chain_t) {
+    HIPCHK(c, hipEventElapsedTime(&out->chain_ms, c->ev[4], c->ev[7]));
+    HIPCHK(c, hipEventElapsedTime(&out->compact_ms, c->ev[7], c->ev[8]));
+    HIPCHK(c, hipEventElapsedTime(&out->chain_kernel_ms, c->ev[5], c->ev[6]));
+    out->chain_kernel_launches = c->n_edges ? 1 : 0;
+  }
+  return MSGPU_OK;
+}
+
+static int copy_tables(msgpu_ctx *c, void *edges, void *ems, void *orders, void *ids, hipMemcpyKind kind) {
+  if (!c) return MSGPU_E_ARG;
+  if (c->state < ST_EDGES) return fail(c, MSGPU_E_STATE, "no tables yet");
+  if ((ems || orders || ids) && c->state < ST_CHAINED)
+    return fail(c, MSGPU_E_STATE, "EdgeMatch/order tables exist only after msgpu_chaining_and_overlaps");
+  HIPCHK(c, hipSetDevice(c->device));
+  hipStream_t st = c->stream;
+  if (edges && c->n_edges) HIPCHK(c, hipMemcpyAsync(edges, c->edges.p, c->n_edges * sizeof(msgpu_edge), kind, st));
+  if (ems && c->n_ems) HIPCHK(c, hipMemcpyAsync(ems, c->ems.p, c->n_ems * sizeof(msgpu_edgematch), kind, st));
+  if (orders && c->n_orders) HIPCHK(c, hipMemcpyAsync(orders, c->orders.p, c->n_orders * sizeof(msgpu_order), kind, st));
+  if (ids && c->n_ids) HIPCHK(c, hipMemcpyAsync(ids, c->ids.p, c->n_ids * 4, kind, st));
+  if (kind == hipMemcpyDeviceToHost) HIPCHK(c, hipStreamSynchronize(st));
+  return MSGPU_OK;
+}
+
+int msgpu_copy_tables(msgpu_ctx *c, msgpu_edge *edges, msgpu_edgematch *ems, msgpu_order *orders, uint32_t *ids) {
+  return copy_tables(c, edges, ems, orders, ids, hipMemcpyDeviceToHost);
+}
+int msgpu_copy_tables_device(msgpu_ctx *c, void *d_edges, void *d_ems, void *d_orders, void *d_ids) {
+  return copy_tables(c, d_edges, d_ems, d_orders, d_ids, hipMemcpyDeviceToDevice);
+}
+
+int msgpu_copy_reads(msgpu_ctx *c, int32_t *read_len, uint32_t *read_first_line) {
+  if (!c) return MSGPU_E_ARG;
+  if (c->state < ST_LOADED) return fail(c, MSGPU_E_STATE, "no rows loaded");
+  HIPCHK(c, hipSetDevice(c->device));
+  if (read_len && c->V)
+    HIPCHK(c, hipMemcpyAsync(read_len, c->read_len.p, size_t(c->V) * 4, hipMemcpyDeviceToHost, c->stream));
+  if (read_first_line && c->V)
+    HIPCHK(c, hipMemcpyAsync(read_first_line, c->read_first.p, size_t(c->V) * 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return MSGPU_OK;
+}
+
+int msgpu_synchronize(msgpu_ctx *c) {
+  if (!c) return MSGPU_E_ARG;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return MSGPU_OK;
+}
+
+} // extern "C"

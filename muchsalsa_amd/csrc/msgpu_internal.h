@@ -1,0 +1,102 @@
+// msgpu_internal.h -- types shared by the kernels (msgpu_kernels.hip) and the C-ABI host layer (msgpu_api.hip).
+#ifndef MSGPU_INTERNAL_H
+#define MSGPU_INTERNAL_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "msgpu.h"
+
+namespace msgpu {
+
+// 32-byte row of the two device tables (two 16-byte vector loads per row).
+//   by_read  : rows of one read sorted by (n_lo, n_hi, anchor) -- `other` = anchor id, pf = flags | own rank
+//   by_anchor: rows of one anchor (scaffold) sorted by line    -- `other` = read id,   pf = flags | rank in its read
+struct IRow {
+  int32_t  n_lo, n_hi, i_lo, i_hi;
+  uint32_t score, line, other, pf;
+};
+static_assert(sizeof(IRow) == 32, "IRow must be 32 bytes");
+constexpr uint32_t PF_POS_MASK = 0x3fffffffu;
+constexpr uint32_t PF_DIR      = 1u << 30;
+constexpr uint32_t PF_PRIM     = 1u << 31;
+
+struct CandArgs {
+  const uint32_t *read_off, *read_cnt, *anchor_off;
+  const IRow     *by_read, *by_anchor;
+  const uint64_t *cand_off;     // per read: first slot of its candidate / edge scratch (exclusive scan of bound)
+  uint32_t       *cand_j;       // sorted candidates: rank of the anchor in v1's row list
+  uint32_t       *cand_t;       // sorted candidates: row of v2 in by_anchor
+  uint32_t       *edge_scr_v2;  // per-read edge scratch: v2
+  uint32_t       *edge_scr_start; // per-read edge scratch: first candidate of the edge
+  uint32_t       *n_cand, *n_edge, *n_visit; // per read
+  uint32_t        th_overlap;
+};
+
+struct ChainArgs {
+  msgpu_edge      *edges;
+  const uint64_t  *edge_cand;
+  uint64_t         n_edges;
+  const uint32_t  *cand_j, *cand_t;
+  const uint32_t  *read_off, *read_cnt;
+  const int32_t   *read_len;
+  const IRow      *by_read, *by_anchor;
+  msgpu_edgematch *ems;
+  msgpu_order     *order_scr; // slot em_off + i for the i-th order of an edge
+  uint32_t        *ids_scr;   // slots em_off .. em_off + em_cnt of an edge
+  uint32_t        *edge_norders, *edge_nids;
+  uint32_t        *err;
+  double           wiggle, ratio_pct, alt_frac;
+};
+
+struct CompactArgs {
+  msgpu_edge        *edges;
+  uint64_t           n_edges;
+  const uint32_t    *edge_norders;
+  const uint64_t    *order_base, *ids_base;
+  const msgpu_order *order_scr;
+  const uint32_t    *ids_scr;
+  msgpu_order       *orders;
+  uint32_t          *ids;
+};
+
+template <class T> void exclusive_scan(hipStream_t st, const uint32_t *in, uint64_t n, T *out, T *block_sums, T *d_total);
+uint32_t scan_blocks(uint64_t n);
+
+void launch_max_ids(hipStream_t st, const msgpu_row *rows, uint64_t n, uint32_t *max_ids);
+void launch_hist_read(hipStream_t st, const msgpu_row *rows, uint64_t n, uint32_t *cnt_read, uint64_t *first_key);
+void launch_read_facts(hipStream_t st, const msgpu_row *rows, const uint64_t *first_key, uint32_t V, int32_t *read_len,
+                       uint32_t *read_first, uint32_t *err);
+void launch_scatter_read(hipStream_t st, const msgpu_row *rows, uint64_t n, const uint32_t *read_off, uint32_t *cursor,
+                         void *bkt_key, uint32_t *bkt_idx);
+void launch_dedupe(hipStream_t st, const uint32_t *read_off, uint64_t n, const void *bkt_key, const uint32_t *bkt_idx,
+                   const msgpu_row *rows, uint8_t *bkt_dead);
+void launch_rank_read(hipStream_t st, const uint32_t *read_off, uint64_t n, const void *bkt_key, const uint32_t *bkt_idx,
+                      const uint8_t *bkt_dead, const msgpu_row *rows, IRow *by_read, uint32_t *read_cnt,
+                      uint32_t *alive_rank, uint32_t *anchor_cnt);
+void launch_scatter_anchor(hipStream_t st, const msgpu_row *rows, uint64_t n, const uint32_t *alive_rank,
+                           const uint32_t *anchor_off, uint32_t *cursor, uint32_t *bkt_idx, uint32_t *bkt_line);
+void launch_rank_anchor(hipStream_t st, const uint32_t *anchor_off, uint64_t n_rows, const uint32_t *d_n_alive,
+                        const uint32_t *bkt_idx, const uint32_t *bkt_line, const msgpu_row *rows,
+                        const uint32_t *alive_rank, IRow *by_anchor);
+void launch_bound(hipStream_t st, const uint32_t *read_off, const uint32_t *read_cnt, const IRow *by_read,
+                  const uint32_t *anchor_off, uint32_t V, uint32_t shard, uint32_t nshards, uint32_t *bound);
+void launch_classify_reads(hipStream_t st, const uint32_t *read_cnt, const uint32_t *bound, uint32_t V, uint32_t shard,
+                           uint32_t nshards, uint32_t *l0, uint32_t *l1, uint32_t *l2, uint32_t *n_lists);
+void launch_candidates(hipStream_t st, const CandArgs &a, int cls, const uint32_t *list, uint32_t n_list);
+void launch_candidates_big(hipStream_t st, const CandArgs &a, const uint32_t *list, uint32_t n_list, uint64_t *big_key,
+                           uint32_t *big_t, uint32_t *big_r2s, uint32_t *big_pfx);
+void launch_emit_edges(hipStream_t st, const uint32_t *n_edge, const uint32_t *n_cand, const uint64_t *edge_base,
+                       const uint64_t *em_base, const uint64_t *cand_off, const uint32_t *scr_v2,
+                       const uint32_t *scr_start, uint32_t V, msgpu_edge *edges, uint64_t *edge_cand);
+void launch_chain(hipStream_t st, const ChainArgs &a);
+void launch_list_big_edges(hipStream_t st, const msgpu_edge *edges, uint64_t n_edges, uint32_t *big_list, uint32_t *n_big);
+size_t big_elem_bytes();
+size_t big_path_bytes();
+void launch_chain_big(hipStream_t st, const ChainArgs &a, const uint32_t *big_list, uint32_t n_big, void *elems,
+                      void *paths);
+void launch_compact(hipStream_t st, const CompactArgs &a);
+
+} // namespace msgpu
+
+#endif

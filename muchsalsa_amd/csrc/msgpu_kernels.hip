@@ -1,0 +1,1535 @@
+// msgpu_kernels.hip -- hand-written HIP kernels (gfx950 / CDNA4, wave64) of the MuCHSALSA overlap core.
+//
+// Pipeline (SURVEY.md section 8, rows A1-tail .. A7):
+//
+//   index build   rows (40 B, HBM) -> two 32-B row tables:  by_read  [read ][nanoporeRange, anchor]   (m_vertexMatches)
+//                                                           by_anchor[anchor][line]                    (m_scaffolds)
+//   candidates    one workgroup per owner read v1: scan the scaffolds of v1's anchors, keep rows of reads v2 > v1
+//                 whose anchor interval overlaps by > TH_OVERLAP, sort (v2, j) in LDS, cut into edges
+//                 (= MatchMap::processScaffold, MatchMap.cpp:175-224, turned inside out so that every edge is born
+//                 grouped and in vStart order -- no global sort of EdgeMatches)
+//   chain         one wavefront per edge, one lane per EdgeMatch: EdgeMatch score, corrected ranges, the O(n^2)
+//                 chaining DP with readlane broadcast + per-lane path bitmasks, alternatives, demotion, filters,
+//                 shadow, overhangs -> EdgeOrders   (mpp.cpp:38-305, ol.cpp:31-101, src/main.cpp:328-414)
+//   compact       per-edge order slots -> dense canonical order / id tables
+//
+// Everything is integer or IEEE fp64 VALU work (no MFMA: there is no contraction on this path).  The file is built
+// with -ffp-contract=off: the reference's fp64 expressions are evaluated in its operation order, bit for bit.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "msgpu.h"
+#include "msgpu_internal.h"
+
+namespace msgpu {
+
+// ---------------------------------------------------------------------------------------------------------------------
+// helpers
+// ---------------------------------------------------------------------------------------------------------------------
+
+__device__ __forceinline__ IRow load_irow(const IRow *p) {
+  const uint4 *q = reinterpret_cast<const uint4 *>(p);
+  uint4        a = q[0], b = q[1];
+  IRow         r;
+  r.n_lo  = static_cast<int>(a.x);
+  r.n_hi  = static_cast<int>(a.y);
+  r.i_lo  = static_cast<int>(a.z);
+  r.i_hi  = static_cast<int>(a.w);
+  r.score = b.x;
+  r.line  = b.y;
+  r.other = b.z;
+  r.pf    = b.w;
+  return r;
+}
+__device__ __forceinline__ void store_irow(IRow *p, const IRow &r) {
+  uint4 *q = reinterpret_cast<uint4 *>(p);
+  q[0]     = make_uint4(static_cast<uint32_t>(r.n_lo), static_cast<uint32_t>(r.n_hi), static_cast<uint32_t>(r.i_lo),
+                        static_cast<uint32_t>(r.i_hi));
+  q[1]     = make_uint4(r.score, r.line, r.other, r.pf);
+}
+
+// readlane of wider types (lane index must be wave-uniform)
+__device__ __forceinline__ int rl_i32(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+__device__ __forceinline__ uint32_t rl_u32(uint32_t v, int lane) {
+  return static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(v), lane));
+}
+__device__ __forceinline__ uint64_t rl_u64(uint64_t v, int lane) {
+  uint32_t lo = rl_u32(static_cast<uint32_t>(v), lane), hi = rl_u32(static_cast<uint32_t>(v >> 32), lane);
+  return (static_cast<uint64_t>(hi) << 32) | lo;
+}
+__device__ __forceinline__ double rl_f64(double v, int lane) {
+  return __longlong_as_double(static_cast<long long>(rl_u64(static_cast<uint64_t>(__double_as_longlong(v)), lane)));
+}
+
+// std::max / std::min on doubles with the library's tie and NaN behaviour (NOT fmax/fmin)
+__device__ __forceinline__ double std_max(double a, double b) { return (a < b) ? b : a; }
+__device__ __forceinline__ double std_min(double a, double b) { return (b < a) ? b : a; }
+
+// block-wide exclusive scan of one value per thread, 256 threads; returns exclusive prefix, total through *total
+__device__ __forceinline__ uint32_t block_excl_scan_256(uint32_t v, uint32_t *s_wave /*[4]*/, uint32_t *total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t  inc  = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    uint32_t t = __shfl_up(inc, d);
+    if (lane >= d) inc += t;
+  }
+  if (lane == 63) s_wave[wave] = inc;
+  __syncthreads();
+  uint32_t w0 = s_wave[0], w1 = s_wave[1], w2 = s_wave[2], w3 = s_wave[3];
+  uint32_t base = (wave > 0 ? w0 : 0) + (wave > 1 ? w1 : 0) + (wave > 2 ? w2 : 0);
+  *total        = w0 + w1 + w2 + w3;
+  __syncthreads();
+  return base + inc - v;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// generic exclusive scan (u32 in, T out), three launches; total written to *d_total
+// ---------------------------------------------------------------------------------------------------------------------
+
+constexpr int SCAN_ITEMS = 8; // per thread -> 2048 per block
+
+template <class T> __global__ __launch_bounds__(256) void k_scan_reduce(const uint32_t *in, uint64_t n, T *block_sums) {
+  __shared__ T s[4];
+  uint64_t     base = static_cast<uint64_t>(blockIdx.x) * 256 * SCAN_ITEMS;
+  T            sum  = 0;
+  for (int i = 0; i < SCAN_ITEMS; ++i) {
+    uint64_t idx = base + static_cast<uint64_t>(i) * 256 + threadIdx.x;
+    if (idx < n) sum += in[idx];
+  }
+  for (int d = 32; d > 0; d >>= 1) sum += __shfl_down(sum, d);
+  if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = sum;
+  __syncthreads();
+  if (threadIdx.x == 0) block_sums[blockIdx.x] = s[0] + s[1] + s[2] + s[3];
+}
+
+template <class T> __global__ __launch_bounds__(256) void k_scan_blocksums(T *block_sums, uint32_t nb, T *d_total) {
+  // single workgroup; sequential chunks of 256 with a running carry
+  __shared__ T s_w[4];
+  __shared__ T s_carry;
+  if (threadIdx.x == 0) s_carry = 0;
+  __syncthreads();
+  for (uint32_t c = 0; c < nb; c += 256) {
+    uint32_t  i    = c + threadIdx.x;
+    T         v    = i < nb ? block_sums[i] : 0;
+    T         inc  = v;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int d = 1; d < 64; d <<= 1) {
+      T t = __shfl_up(inc, d);
+      if (lane >= d) inc += t;
+    }
+    if (lane == 63) s_w[wave] = inc;
+    __syncthreads();
+    T base = s_carry;
+    for (int w = 0; w < wave; ++w) base += s_w[w];
+    if (i < nb) block_sums[i] = base + inc - v;
+    __syncthreads();
+    if (threadIdx.x == 255) s_carry = base + inc;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *d_total = s_carry;
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void k_scan_apply(const uint32_t *in, uint64_t n, const T *block_sums, T *out) {
+  // out has n+1 entries; out[n] = total is written by the last block
+  __shared__ T s_w[4];
+  __shared__ T s_carry;
+  uint64_t     base = static_cast<uint64_t>(blockIdx.x) * 256 * SCAN_ITEMS;
+  if (threadIdx.x == 0) s_carry = block_sums[blockIdx.x];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int it = 0; it < SCAN_ITEMS; ++it) {
+    uint64_t idx = base + static_cast<uint64_t>(it) * 256 + threadIdx.x;
+    T        v   = idx < n ? in[idx] : 0;
+    T        inc = v;
+    for (int d = 1; d < 64; d <<= 1) {
+      T t = __shfl_up(inc, d);
+      if (lane >= d) inc += t;
+    }
+    if (lane == 63) s_w[wave] = inc;
+    __syncthreads();
+    T b = s_carry;
+    for (int w = 0; w < wave; ++w) b += s_w[w];
+    if (idx < n) out[idx] = b + inc - v;
+    if (idx == n - 1) out[n] = b + inc;
+    __syncthreads();
+    if (threadIdx.x == 255) s_carry = b + inc;
+    __syncthreads();
+  }
+}
+
+template <class T> void exclusive_scan(hipStream_t st, const uint32_t *in, uint64_t n, T *out, T *block_sums, T *d_total) {
+  if (n == 0) {
+    (void)hipMemsetAsync(out, 0, sizeof(T), st);
+    (void)hipMemsetAsync(d_total, 0, sizeof(T), st);
+    return;
+  }
+  uint32_t nb = static_cast<uint32_t>((n + 256 * SCAN_ITEMS - 1) / (256 * SCAN_ITEMS));
+  hipLaunchKernelGGL(k_scan_reduce<T>, dim3(nb), dim3(256), 0, st, in, n, block_sums);
+  hipLaunchKernelGGL(k_scan_blocksums<T>, dim3(1), dim3(256), 0, st, block_sums, nb, d_total);
+  hipLaunchKernelGGL(k_scan_apply<T>, dim3(nb), dim3(256), 0, st, in, n, block_sums, out);
+}
+template void exclusive_scan<uint32_t>(hipStream_t, const uint32_t *, uint64_t, uint32_t *, uint32_t *, uint32_t *);
+template void exclusive_scan<uint64_t>(hipStream_t, const uint32_t *, uint64_t, uint64_t *, uint64_t *, uint64_t *);
+
+uint32_t scan_blocks(uint64_t n) { return static_cast<uint32_t>((n + 256 * SCAN_ITEMS - 1) / (256 * SCAN_ITEMS)); }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// index build: the device-resident equivalent of Graph vertices + MatchMap::m_vertexMatches + m_scaffolds
+// (Graph.cpp:148 first line wins; MatchMap.cpp:52-81 lowest line per (read, anchor) wins)
+// ---------------------------------------------------------------------------------------------------------------------
+
+__global__ __launch_bounds__(256) void k_max_ids(const msgpu_row *rows, uint64_t n, uint32_t *max_ids /*[2]*/) {
+  uint64_t i  = static_cast<uint64_t>(blockIdx.x) * 256 + threadIdx.x;
+  uint32_t mr = 0, ma = 0;
+  if (i < n) {
+    mr = rows[i].read_id + 1;
+    ma = rows[i].anchor_id + 1;
+  }
+  for (int d = 32; d > 0; d >>= 1) {
+    mr = max(mr, __shfl_down(mr, d));
+    ma = max(ma, __shfl_down(ma, d));
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicMax(&max_ids[0], mr);
+    atomicMax(&max_ids[1], ma);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_hist_read(const msgpu_row *rows, uint64_t n, uint32_t *cnt_read,
+                                                   unsigned long long *first_key) {
+  uint64_t i = static_cast<uint64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (i >= n) return;
+  uint32_t r = rows[i].read_id;
+  atomicAdd(&cnt_read[r], 1u);
+  atomicMin(&first_key[r], (static_cast<unsigned long long>(rows[i].line) << 32) | static_cast<uint32_t>(i));
+}
+
+// per read: Vertex(nanoporeLength, metaDatum(0) = first line) + Registry-order check
+__global__ __launch_bounds__(256) void k_read_facts(const msgpu_row *rows, const unsigned long long *first_key, uint32_t V,
+                                                    int32_t *read_len, uint32_t *read_first, uint32_t *err) {
+  uint32_t r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= V) return;
+  unsigned long long k = first_key[r];
+  if (k == ~0ull) { // an id without any row: ids are not Registry-dense
+    atomicOr(err, 1u);
+    read_len[r]   = 0;
+    read_first[r] = 0xffffffffu;
+    return;
+  }
+  read_len[r]   = rows[static_cast<uint32_t>(k)].read_len;
+  read_first[r] = static_cast<uint32_t>(k >> 32);
+  if (r + 1 < V) {
+    unsigned long long k2 = first_key[r + 1];
+    if (k2 != ~0ull && (k2 >> 32) <= (k >> 32)) atomicOr(err, 1u); // ids must follow first-line order
+  }
+}
+
+// bucket rows by read: key record {anchor, line, n_lo, n_hi} + source index
+__global__ __launch_bounds__(256) void k_scatter_read(const msgpu_row *rows, uint64_t n, const uint32_t *read_off,
+                                                      uint32_t *cursor, uint4 *bkt_key, uint32_t *bkt_idx) {
+  uint64_t i = static_cast<uint64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (i >= n) return;
+  msgpu_row r   = rows[i];
+  uint32_t  pos = read_off[r.read_id] + atomicAdd(&cursor[r.read_id], 1u);
+  bkt_key[pos]  = make_uint4(r.anchor_id, r.line, static_cast<uint32_t>(r.n_lo), static_cast<uint32_t>(r.n_hi));
+  bkt_idx[pos]  = static_cast<uint32_t>(i);
+}
+
+// MatchMap::addVertexMatch: a row dies if its read holds another row of the same anchor with a lower line
+__global__ __launch_bounds__(256) void k_dedupe(const uint32_t *read_off, uint64_t n, const uint4 *bkt_key,
+                                                const uint32_t *bkt_idx, const msgpu_row *rows, uint8_t *bkt_dead) {
+  uint64_t p = static_cast<uint64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (p >= n) return;
+  uint32_t idx = bkt_idx[p];
+  uint32_t r   = rows[idx].read_id;
+  uint4    me  = bkt_key[p];
+  uint32_t b = read_off[r], e = read_off[r + 1];
+  bool     dead = false;
+  for (uint32_t q = b; q < e; ++q) {
+    uint4 o = bkt_key[q];
+    if (o.x == me.x && (o.y < me.y || (o.y == me.y && bkt_idx[q] < idx))) dead = true;
+  }
+  bkt_dead[p] = dead ? 1 : 0;
+}
+
+// rank of every alive row inside its read by (nanoporeRange, anchor id) = the order of mpp.cpp:164-172 / :259-267
+__global__ __launch_bounds__(256) void k_rank_read(const uint32_t *read_off, uint64_t n, const uint4 *bkt_key,
+                                                   const uint32_t *bkt_idx, const uint8_t *bkt_dead,
+                                                   const msgpu_row *rows, IRow *by_read, uint32_t *read_cnt,
+                                                   uint32_t *alive_rank, uint32_t *anchor_cnt) {
+  uint64_t p = static_cast<uint64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (p >= n) return;
+  uint32_t idx = bkt_idx[p];
+  if (bkt_dead[p]) {
+    alive_rank[idx] = 0xffffffffu;
+    return;
+  }
+  msgpu_row row = rows[idx];
+  uint32_t  r   = row.read_id;
+  uint32_t  b = read_off[r], e = read_off[r + 1];
+  uint32_t  rank = 0;
+  for (uint32_t q = b; q < e; ++q) {
+    if (bkt_dead[q]) continue;
+    uint4 o  = bkt_key[q];
+    int   lo = static_cast<int>(o.z), hi = static_cast<int>(o.w);
+    bool  less = lo < row.n_lo || (lo == row.n_lo && (hi < row.n_hi || (hi == row.n_hi && o.x < row.anchor_id)));
+    rank += less ? 1u : 0u;
+  }
+  IRow out;
+  out.n_lo  = row.n_lo;
+  out.n_hi  = row.n_hi;
+  out.i_lo  = row.i_lo;
+  out.i_hi  = row.i_hi;
+  out.score = row.score;
+  out.line  = row.line;
+  out.other = row.anchor_id;
+  out.pf    = ((row.flags & MSGPU_ROW_DIR) ? PF_DIR : 0u) | ((row.flags & MSGPU_ROW_PRIMARY) ? PF_PRIM : 0u) | rank;
+  store_irow(&by_read[b + rank], out);
+  alive_rank[idx] = rank;
+  atomicAdd(&read_cnt[r], 1u);
+  atomicAdd(&anchor_cnt[row.anchor_id], 1u);
+}
+
+__global__ __launch_bounds__(256) void k_scatter_anchor(const msgpu_row *rows, uint64_t n, const uint32_t *alive_rank,
+                                                        const uint32_t *anchor_off, uint32_t *cursor, uint32_t *bkt_idx,
+                                                        uint32_t *bkt_line) {
+  uint64_t i = static_cast<uint64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (i >= n) return;
+  if (alive_rank[i] == 0xffffffffu) return;
+  uint32_t a    = rows[i].anchor_id;
+  uint32_t pos  = anchor_off[a] + atomicAdd(&cursor[a], 1u);
+  bkt_idx[pos]  = static_cast<uint32_t>(i);
+  bkt_line[pos] = rows[i].line;
+}
+
+// scaffold of each anchor sorted by line number (MatchMap.cpp:178-183)
+__global__ __launch_bounds__(256) void k_rank_anchor(const uint32_t *anchor_off, const uint32_t *d_n_alive, const uint32_t *bkt_idx,
+                                                     const uint32_t *bkt_line, const msgpu_row *rows,
+                                                     const uint32_t *alive_rank, IRow *by_anchor) {
+  uint64_t p = static_cast<uint64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (p >= *d_n_alive) return;
+  uint32_t  idx = bkt_idx[p];
+  msgpu_row row = rows[idx];
+  uint32_t  b = anchor_off[row.anchor_id], e = anchor_off[row.anchor_id + 1];
+  uint32_t  rank = 0;
+  for (uint32_t q = b; q < e; ++q) {
+    uint32_t l = bkt_line[q];
+    rank += (l < row.line || (l == row.line && bkt_idx[q] < idx)) ? 1u : 0u;
+  }
+  IRow out;
+  out.n_lo  = row.n_lo;
+  out.n_hi  = row.n_hi;
+  out.i_lo  = row.i_lo;
+  out.i_hi  = row.i_hi;
+  out.score = row.score;
+  out.line  = row.line;
+  out.other = row.read_id;
+  out.pf    = ((row.flags & MSGPU_ROW_DIR) ? PF_DIR : 0u) | ((row.flags & MSGPU_ROW_PRIMARY) ? PF_PRIM : 0u) |
+           (alive_rank[idx] & PF_POS_MASK);
+  store_irow(&by_anchor[b + rank], out);
+}
+
+// upper bound of the scaffold rows a read has to visit = sum over its anchors of the scaffold size
+__global__ __launch_bounds__(256) void k_bound(const uint32_t *read_off, const uint32_t *read_cnt, const IRow *by_read,
+                                               const uint32_t *anchor_off, uint32_t V, uint32_t shard, uint32_t nshards,
+                                               uint32_t *bound) {
+  uint32_t r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= V) return;
+  uint32_t s = 0;
+  if (r % nshards == shard) {
+    uint32_t b = read_off[r], n = read_cnt[r];
+    for (uint32_t j = 0; j < n; ++j) {
+      uint32_t a = by_read[b + j].other;
+      s += anchor_off[a + 1] - anchor_off[a];
+    }
+  }
+  bound[r] = s;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// candidates: MatchMap::calculateEdges / processScaffold (MatchMap.cpp:161-224) from the owner read's point of view
+// ---------------------------------------------------------------------------------------------------------------------
+//
+// The reference walks each anchor's scaffold and tests all pairs (inner < outer by line).  A pair of reads (x, y) that
+// passes becomes an EdgeMatch of the edge whose first vertex is the read with the lower first line = the lower
+// Registry id.  Here the workgroup of read v1 visits the scaffolds of v1's own anchors and keeps exactly the pairs
+// (v1, v2) with v2 > v1 -- every pair is produced once, by its edge's first vertex, so all EdgeMatches of an edge are
+// born in one workgroup and can be grouped in LDS.  The list is sorted by (v2, j) where j is the rank of the anchor
+// in v1's (nanoporeRange, anchor) order, i.e. each edge comes out in the vStart order of mpp.cpp:164-172.
+
+template <int R1MAX, int CMAX>
+__global__ __launch_bounds__(256) void k_candidates(CandArgs a, const uint32_t *read_list, uint32_t n_list) {
+  __shared__ int      s_ilo[R1MAX], s_ihi[R1MAX];
+  __shared__ uint32_t s_aoff[R1MAX], s_pfx[R1MAX + 1];
+  __shared__ uint64_t s_key[CMAX];
+  __shared__ uint32_t s_t[CMAX], s_r2s[CMAX];
+  __shared__ uint32_t s_wave[4], s_nc;
+
+  if (blockIdx.x >= n_list) return;
+  const uint32_t r  = read_list[blockIdx.x];
+  const uint32_t rb = a.read_off[r], n1 = a.read_cnt[r];
+  const uint64_t co = a.cand_off[r];
+  const int      tid = threadIdx.x;
+  if (tid == 0) s_nc = 0;
+
+  // (a) v1's rows (already in vStart order) and the scaffold extents of their anchors
+  constexpr int JPT = R1MAX / 256; // rows per thread, consecutive
+  uint32_t      cnt[JPT], tsum = 0;
+#pragma unroll
+  for (int q = 0; q < JPT; ++q) {
+    uint32_t j = tid * JPT + q;
+    cnt[q]     = 0;
+    if (j < n1) {
+      IRow row  = load_irow(&a.by_read[rb + j]);
+      s_ilo[j]  = row.i_lo;
+      s_ihi[j]  = row.i_hi;
+      uint32_t ao = a.anchor_off[row.other];
+      s_aoff[j] = ao;
+      cnt[q]    = a.anchor_off[row.other + 1] - ao;
+    }
+    tsum += cnt[q];
+  }
+  uint32_t T;
+  uint32_t ex = block_excl_scan_256(tsum, s_wave, &T);
+#pragma unroll
+  for (int q = 0; q < JPT; ++q) {
+    uint32_t j = tid * JPT + q;
+    if (j < n1) s_pfx[j] = ex;
+    ex += cnt[q];
+  }
+  if (tid == 0) s_pfx[n1] = T;
+  __syncthreads();
+
+  // (b) visit every scaffold row of every anchor of v1
+  for (uint32_t x0 = 0; x0 < T; x0 += 256) {
+    uint32_t x    = x0 + tid;
+    bool     pass = false;
+    uint32_t j = 0, vm = 0, r2 = 0;
+    if (x < T) {
+      uint32_t lo = 0, hi = n1; // largest j with s_pfx[j] <= x
+      while (hi - lo > 1) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (s_pfx[mid] <= x)
+          lo = mid;
+        else
+          hi = mid;
+      }
+      j        = lo;
+      vm       = s_aoff[j] + (x - s_pfx[j]);
+      IRow o   = load_irow(&a.by_anchor[vm]);
+      r2       = o.other;
+      int ovlo = max(o.i_lo, s_ilo[j]), ovhi = min(o.i_hi, s_ihi[j]);
+      // owner rule (v2 > v1 <=> v1 has the lower first line, MatchMap.cpp:204-213) + overlap test (:192)
+      pass = r2 > r && ovlo <= ovhi && (ovhi - ovlo) > static_cast<int>(a.th_overlap);
+    }
+    unsigned long long m = __ballot(pass);
+    if (m) {
+      uint32_t base = 0;
+      int      lane = tid & 63;
+      if (lane == 0) base = atomicAdd(&s_nc, static_cast<uint32_t>(__popcll(m)));
+      base = __shfl(base, 0);
+      if (pass) {
+        uint32_t c = base + static_cast<uint32_t>(__popcll(m & ((1ull << lane) - 1)));
+        s_key[c]   = (static_cast<uint64_t>(r2) << 32) | j;
+        s_t[c]     = vm;
+      }
+    }
+  }
+  __syncthreads();
+  const uint32_t nc = s_nc;
+
+  // (c) rank sort by (v2, j); keys are unique.  Sorted (j, t) go to the candidate scratch, v2 stays in LDS.
+  for (uint32_t c = tid; c < nc; c += 256) {
+    uint64_t k    = s_key[c];
+    uint32_t rank = 0;
+    for (uint32_t q = 0; q < nc; ++q) rank += (s_key[q] < k) ? 1u : 0u;
+    s_r2s[rank]          = static_cast<uint32_t>(k >> 32);
+    a.cand_j[co + rank]  = static_cast<uint32_t>(k);
+    a.cand_t[co + rank]  = s_t[c];
+  }
+  __syncthreads();
+
+  // (d) cut into edges: a new edge starts where v2 changes
+  constexpr int CPT = CMAX / 256;
+  uint32_t      fl[CPT], fsum = 0;
+#pragma unroll
+  for (int q = 0; q < CPT; ++q) {
+    uint32_t i = tid * CPT + q;
+    fl[q]      = (i < nc && (i == 0 || s_r2s[i] != s_r2s[i - 1])) ? 1u : 0u;
+    fsum += fl[q];
+  }
+  uint32_t ne;
+  uint32_t eex = block_excl_scan_256(fsum, s_wave, &ne);
+#pragma unroll
+  for (int q = 0; q < CPT; ++q) {
+    uint32_t i = tid * CPT + q;
+    if (fl[q]) {
+      a.edge_scr_v2[co + eex]    = s_r2s[i];
+      a.edge_scr_start[co + eex] = i;
+      ++eex;
+    }
+  }
+  if (tid == 0) {
+    a.n_cand[r]  = nc;
+    a.n_edge[r]  = ne;
+    a.n_visit[r] = T;
+  }
+}
+
+template __global__ void k_candidates<256, 1024>(CandArgs, const uint32_t *, uint32_t);
+template __global__ void k_candidates<1024, 8192>(CandArgs, const uint32_t *, uint32_t);
+
+// classify reads of this shard by the LDS footprint their candidate scan needs
+__global__ __launch_bounds__(256) void k_classify_reads(const uint32_t *read_cnt, const uint32_t *bound, uint32_t V,
+                                                        uint32_t shard, uint32_t nshards, uint32_t *list0,
+                                                        uint32_t *list1, uint32_t *list2, uint32_t *n_lists /*[3]*/) {
+  uint32_t r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= V || r % nshards != shard) return;
+  uint32_t n1 = read_cnt[r], bd = bound[r];
+  if (n1 == 0 || bd == 0) return;
+  if (n1 <= 256 && bd <= 1024)
+    list0[atomicAdd(&n_lists[0], 1u)] = r;
+  else if (n1 <= 1024 && bd <= 8192)
+    list1[atomicAdd(&n_lists[1], 1u)] = r;
+  else
+    list2[atomicAdd(&n_lists[2], 1u)] = r;
+}
+
+// big reads: same algorithm with every staging array in global memory (slow path, any size)
+__global__ __launch_bounds__(256) void k_candidates_big(CandArgs a, const uint32_t *read_list, uint32_t n_list,
+                                                        uint64_t *big_key, uint32_t *big_t, uint32_t *big_r2s,
+                                                        uint32_t *big_pfx) {
+  __shared__ uint32_t s_wave[4], s_nc, s_carry;
+  if (blockIdx.x >= n_list) return;
+  const uint32_t r  = read_list[blockIdx.x];
+  const uint32_t rb = a.read_off[r], n1 = a.read_cnt[r];
+  const uint64_t co = a.cand_off[r];
+  const uint64_t bo = co; // staging arrays share the candidate-scratch index space
+  const int      tid = threadIdx.x;
+  uint32_t      *pfx = big_pfx + rb; // n1 entries; the total stays in LDS
+  if (tid == 0) {
+    s_nc    = 0;
+    s_carry = 0;
+  }
+  __syncthreads();
+  // (a) exclusive prefix of scaffold sizes over v1's rows, chunks of 256
+  for (uint32_t j0 = 0; j0 < n1; j0 += 256) {
+    uint32_t j = j0 + tid, c = 0;
+    if (j < n1) {
+      uint32_t an = a.by_read[rb + j].other;
+      c           = a.anchor_off[an + 1] - a.anchor_off[an];
+    }
+    uint32_t tot;
+    uint32_t ex = block_excl_scan_256(c, s_wave, &tot);
+    if (j < n1) pfx[j] = s_carry + ex;
+    __syncthreads();
+    if (tid == 0) s_carry += tot;
+    __syncthreads();
+  }
+  const uint32_t T = s_carry;
+  __threadfence_block();
+  __syncthreads();
+  // (b)
+  for (uint32_t x0 = 0; x0 < T; x0 += 256) {
+    uint32_t x    = x0 + tid;
+    bool     pass = false;
+    uint32_t j = 0, vm = 0, r2 = 0;
+    if (x < T) {
+      uint32_t lo = 0, hi = n1;
+      while (hi - lo > 1) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (pfx[mid] <= x)
+          lo = mid;
+        else
+          hi = mid;
+      }
+      j        = lo;
+      IRow me  = load_irow(&a.by_read[rb + j]);
+      vm       = a.anchor_off[me.other] + (x - pfx[j]);
+      IRow o   = load_irow(&a.by_anchor[vm]);
+      r2       = o.other;
+      int ovlo = max(o.i_lo, me.i_lo), ovhi = min(o.i_hi, me.i_hi);
+      pass     = r2 > r && ovlo <= ovhi && (ovhi - ovlo) > static_cast<int>(a.th_overlap);
+    }
+    unsigned long long m = __ballot(pass);
+    if (m) {
+      uint32_t base = 0;
+      int      lane = tid & 63;
+      if (lane == 0) base = atomicAdd(&s_nc, static_cast<uint32_t>(__popcll(m)));
+      base = __shfl(base, 0);
+      if (pass) {
+        uint32_t c       = base + static_cast<uint32_t>(__popcll(m & ((1ull << lane) - 1)));
+        big_key[bo + c]  = (static_cast<uint64_t>(r2) << 32) | j;
+        big_t[bo + c]    = vm;
+      }
+    }
+  }
+  __threadfence_block();
+  __syncthreads();
+  const uint32_t nc = s_nc;
+  // (c)
+  for (uint32_t c = tid; c < nc; c += 256) {
+    uint64_t k    = big_key[bo + c];
+    uint32_t rank = 0;
+    for (uint32_t q = 0; q < nc; ++q) rank += (big_key[bo + q] < k) ? 1u : 0u;
+    big_r2s[bo + rank]  = static_cast<uint32_t>(k >> 32);
+    a.cand_j[co + rank] = static_cast<uint32_t>(k);
+    a.cand_t[co + rank] = big_t[bo + c];
+  }
+  __threadfence_block();
+  __syncthreads();
+  // (d)
+  if (tid == 0) s_carry = 0;
+  __syncthreads();
+  for (uint32_t i0 = 0; i0 < nc; i0 += 256) {
+    uint32_t i  = i0 + tid;
+    uint32_t fl = (i < nc && (i == 0 || big_r2s[bo + i] != big_r2s[bo + i - 1])) ? 1u : 0u;
+    uint32_t tot;
+    uint32_t ex = block_excl_scan_256(fl, s_wave, &tot);
+    if (fl) {
+      a.edge_scr_v2[co + s_carry + ex]    = big_r2s[bo + i];
+      a.edge_scr_start[co + s_carry + ex] = i;
+    }
+    __syncthreads();
+    if (tid == 0) s_carry += tot;
+    __syncthreads();
+  }
+  if (tid == 0) {
+    a.n_cand[r]  = nc;
+    a.n_edge[r]  = s_carry;
+    a.n_visit[r] = T;
+  }
+}
+
+// dense edge table (ascending (v1, v2)) from the per-read edge scratch
+__global__ __launch_bounds__(256) void k_emit_edges(const uint32_t *n_edge, const uint32_t *n_cand,
+                                                    const uint64_t *edge_base, const uint64_t *em_base,
+                                                    const uint64_t *cand_off, const uint32_t *edge_scr_v2,
+                                                    const uint32_t *edge_scr_start, uint32_t V, msgpu_edge *edges,
+                                                    uint64_t *edge_cand) {
+  // one wave per read
+  uint32_t r    = blockIdx.x * 4 + (threadIdx.x >> 6);
+  int      lane = threadIdx.x & 63;
+  if (r >= V) return;
+  uint32_t ne = n_edge[r];
+  if (ne == 0) return;
+  uint32_t nc = n_cand[r];
+  uint64_t eb = edge_base[r], mb = em_base[r], co = cand_off[r];
+  for (uint32_t e = lane; e < ne; e += 64) {
+    uint32_t   st  = edge_scr_start[co + e];
+    uint32_t   en  = (e + 1 < ne) ? edge_scr_start[co + e + 1] : nc;
+    msgpu_edge ed;
+    ed.v1        = r;
+    ed.v2        = edge_scr_v2[co + e];
+    ed.em_off    = mb + st;
+    ed.order_off = 0;
+    ed.em_cnt    = en - st;
+    ed.order_cnt = 0;
+    ed.shadow    = 0;
+    ed.pad       = 0;
+    edges[eb + e]     = ed;
+    edge_cand[eb + e] = co + st;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// chain: EdgeMatch + getMaxPairwisePaths + chainingAndOverlaps filters + getOverlap, one wavefront per edge
+// ---------------------------------------------------------------------------------------------------------------------
+
+struct PathRec {
+  uint64_t mask;    // lanes (= EdgeMatches of the edge, vStart order) on the path
+  uint64_t score;   // truncated like path_t's std::size_t
+  uint32_t primary;
+  uint32_t pad;
+};
+
+// One direction of getMaxPairwisePaths (mpp.cpp:145-305) for an edge with <= 64 EdgeMatches.
+// `act` = lanes whose EdgeMatch has this direction.  Results appended to paths[*n_paths..].
+__device__ __forceinline__ int chain_direction(unsigned long long act, bool direction, int lane, double em_score,
+                                               bool em_prim, int rlo1, int rhi1, double clo1, double chi1, int rlo2,
+                                               int rhi2, double clo2, double chi2, uint32_t j1, uint32_t q2, uint32_t n1,
+                                               uint32_t n2, double wiggle, double ratio_pct, double alt_frac,
+                                               PathRec *paths) {
+  if (act == 0) return 0; // :150-152
+  const bool mine = (act >> lane) & 1ull;
+  double     pop  = em_score;           // population[l].score, :181-183
+  uint64_t   pm   = 1ull << lane;       // path of population[l] incl. l itself (self index appended at :203)
+
+  // DP, :185-199.  Outer loop over k in vStart order; every lane l > k evaluates (k, l) at once.
+  for (unsigned long long rem = act; rem;) {
+    const int k = __builtin_ctzll(rem);
+    rem &= rem - 1;
+    if ((rem) == 0) break; // k is the last element: no l > k
+    const int    k_rlo1 = rl_i32(rlo1, k), k_rhi1 = rl_i32(rhi1, k), k_rlo2 = rl_i32(rlo2, k), k_rhi2 = rl_i32(rhi2, k);
+    const double k_clo1 = rl_f64(clo1, k), k_chi1 = rl_f64(chi1, k), k_clo2 = rl_f64(clo2, k), k_chi2 = rl_f64(chi2, k);
+    const double k_pop = rl_f64(pop, k);
+    const uint64_t k_pm = rl_u64(pm, k);
+    if (mine && lane > k) {
+      // checkCompatibility(k, l), mpp.cpp:38-142.  "1" = k (illuminaId1), "2" = this lane.
+      int    o1, o2;
+      double d1, d2;
+      bool   abort_ = false;
+      { // nanoCheck on vertices.first, :40-118
+        o1 = 0;
+        d1 = 0;
+        if (k_clo1 <= chi1 && clo1 <= k_chi1) {
+          if (k_clo1 < clo1 && k_chi1 < chi1) {
+            o1 = 2;
+            d1 = k_chi1 - clo1 + 1;
+          }
+          if (k_clo1 > clo1 && k_chi1 > chi1) {
+            o1 = -2;
+            d1 = chi1 - k_clo1 + 1;
+          }
+        } else if (k_clo1 < clo1) {
+          o1 = 1;
+          d1 = clo1 - k_chi1 + 1;
+        } else {
+          o1 = -1;
+          d1 = k_clo1 - chi1 + 1;
+        }
+        int uco = 0;
+        if (k_rlo1 <= rhi1 && rlo1 <= k_rhi1) {
+          if (k_rlo1 < rlo1 && k_rhi1 < rhi1) uco = 2;
+          if (k_rlo1 > rlo1 && k_rhi1 > rhi1) uco = -2;
+          if ((o1 < 0 && uco >= 0) || (o1 > 0 && uco <= 0)) abort_ = true;
+        }
+      }
+      { // nanoCheck on vertices.second
+        o2 = 0;
+        d2 = 0;
+        if (k_clo2 <= chi2 && clo2 <= k_chi2) {
+          if (k_clo2 < clo2 && k_chi2 < chi2) {
+            o2 = 2;
+            d2 = k_chi2 - clo2 + 1;
+          }
+          if (k_clo2 > clo2 && k_chi2 > chi2) {
+            o2 = -2;
+            d2 = chi2 - k_clo2 + 1;
+          }
+        } else if (k_clo2 < clo2) {
+          o2 = 1;
+          d2 = clo2 - k_chi2 + 1;
+        } else {
+          o2 = -1;
+          d2 = k_clo2 - chi2 + 1;
+        }
+        int uco = 0;
+        if (k_rlo2 <= rhi2 && rlo2 <= k_rhi2) {
+          if (k_rlo2 < rlo2 && k_rhi2 < rhi2) uco = 2;
+          if (k_rlo2 > rlo2 && k_rhi2 > rhi2) uco = -2;
+          if ((o2 < 0 && uco >= 0) || (o2 > 0 && uco <= 0)) abort_ = true;
+        }
+      }
+      bool matching = false;
+      if (!abort_) {
+        if (!direction) o2 = -o2; // :131 (EdgeMatch(k).direction == this pass's direction)
+        if (o1 == o2 && o1 != 0) {
+          const double mx = std_max(d1, d2);
+          const double df = mx - std_min(d1, d2);
+          matching        = (df <= wiggle) || (df * 100 / mx <= ratio_pct);
+        } else if ((o1 < 0 && o2 < 0) || (o1 > 0 && o2 > 0)) {
+          matching = d1 + d2 <= wiggle;
+        }
+      }
+      const double cand = k_pop + em_score; // :189
+      if (matching && cand > pop) {         // :190-197
+        pop = cand;
+        pm  = k_pm | (1ull << lane);
+      }
+    }
+  }
+
+  // argmax, :201-210: strict > starting from 0.0, first maximum wins, iterator starts at begin()
+  double best = mine ? pop : -1.0;
+  int    bi   = mine ? lane : 64;
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) {
+    double ob = __shfl_xor(best, d);
+    int    oi = __shfl_xor(bi, d);
+    if (ob > best || (ob == best && oi < bi)) {
+      best = ob;
+      bi   = oi;
+    }
+  }
+  double maxv;
+  int    maxi;
+  if (best > 0.0) {
+    maxv = best;
+    maxi = bi;
+  } else {
+    maxv = 0.0;
+    maxi = __builtin_ctzll(act);
+  }
+  const unsigned long long prim_lanes = __ballot(mine && em_prim);
+  int                      np         = 0;
+  {
+    const uint64_t m  = rl_u64(pm, maxi);
+    bool           hp = (m & prim_lanes) != 0; // :217-219
+    hp |= __popcll(m) > 2;                     // :220
+    if (lane == 0) {
+      paths[0].mask    = m;
+      paths[0].score   = static_cast<uint64_t>(maxv);
+      paths[0].primary = hp;
+    }
+    np = 1;
+    // alternatives, :223-249: population order, score > 0.75*max, id-disjoint from every accepted path
+    const double       thr  = maxv * alt_frac;
+    uint64_t           used = m;
+    unsigned long long cand = __ballot(mine && pop > thr);
+    while (true) {
+      cand &= __ballot((pm & used) == 0); // a path that touches a used anchor can never become disjoint again
+      if (!cand) break;
+      const int      p  = __builtin_ctzll(cand);
+      const uint64_t mp = rl_u64(pm, p);
+      const double   sp = rl_f64(pop, p);
+      if (lane == 0) {
+        paths[np].mask    = mp;
+        paths[np].score   = static_cast<uint64_t>(sp);
+        paths[np].primary = (mp & prim_lanes) != 0;
+      }
+      ++np;
+      used |= mp;
+      cand &= ~(1ull << p);
+    }
+    // single primary result, :251-302
+    if (np == 1 && hp) {
+      const int  first = __builtin_ctzll(m), last = 63 - __builtin_clzll(m);
+      // position of each path anchor in v1's list is j1, in v2's (reversed when !direction) list is qe
+      const uint32_t qe      = direction ? q2 : (n2 - 1 - q2);
+      const uint32_t jf = rl_u32(j1, first), jl = rl_u32(j1, last), qf = rl_u32(qe, first), ql = rl_u32(qe, last);
+      bool demote;
+      if ((jf != 0 && qf != 0) || (jl != n1 - 1 && ql != n2 - 1)) {
+        demote = true; // :272-274
+      } else {
+        long long i = 0, jj = 0;
+        bool      is_shadow = false;
+        for (uint64_t rem = m; rem && !is_shadow;) { // :280-296
+          const int t = __builtin_ctzll(rem);
+          rem &= rem - 1;
+          const long long rs = static_cast<long long>(rl_u32(j1, t)); // always >= i: the path follows v1's order
+          bool inter = rs > i;
+          i          = rs + 1;
+          long long re = static_cast<long long>(rl_u32(qe, t));
+          if (re < jj) re = static_cast<long long>(n2); // std::find_if found nothing from position jj on
+          inter &= re > jj;
+          jj        = re + 1;
+          is_shadow = inter;
+        }
+        demote = is_shadow;
+      }
+      if (demote && lane == 0) paths[0].primary = 0;
+    }
+  }
+  return np;
+}
+
+__global__ __launch_bounds__(256) void k_chain(ChainArgs a) {
+  __shared__ PathRec s_paths[4][2][64];
+  const int      wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const uint64_t e = static_cast<uint64_t>(blockIdx.x) * 4 + wave;
+  if (e >= a.n_edges) return;
+  const msgpu_edge ed = a.edges[e];
+  const uint32_t   n  = ed.em_cnt;
+  if (n > 64) { // handled by k_chain_big
+    return;
+  }
+  const uint64_t cp  = a.edge_cand[e];
+  const bool     act = lane < static_cast<int>(n);
+  const uint32_t v1 = ed.v1, v2 = ed.v2;
+  const uint32_t n1 = a.read_cnt[v1], n2 = a.read_cnt[v2];
+  const int      len1 = a.read_len[v1], len2 = a.read_len[v2];
+
+  // per-lane element: VertexMatch on v1 (row j of v1), VertexMatch on v2 (scaffold row t), EdgeMatch
+  uint32_t j1 = 0, q2 = 0, anchor = 0;
+  int      rlo1 = 0, rhi1 = 0, rlo2 = 0, rhi2 = 0;
+  double   clo1 = 0, chi1 = 0, clo2 = 0, chi2 = 0, ovr1 = 0, ovr2 = 0, em_score = 0;
+  bool     em_dir = false, em_prim = false;
+  if (act) {
+    j1            = a.cand_j[cp + lane];
+    const uint32_t t = a.cand_t[cp + lane];
+    const IRow m1 = load_irow(&a.by_read[a.read_off[v1] + j1]);
+    const IRow m2 = load_irow(&a.by_anchor[t]);
+    anchor        = m1.other;
+    q2            = m2.pf & PF_POS_MASK;
+    // EdgeMatch, MatchMap.cpp:188-202,218.  outer = the row with the higher line number.
+    const int  ov_lo = max(m1.i_lo, m2.i_lo), ov_hi = min(m1.i_hi, m2.i_hi);
+    const bool d1 = (m1.pf & PF_DIR) != 0, d2 = (m2.pf & PF_DIR) != 0;
+    em_dir           = d1 == d2;
+    em_prim          = (m1.pf & PF_PRIM) && (m2.pf & PF_PRIM);
+    const bool   o1  = m1.line > m2.line;
+    const IRow  &om = o1 ? m1 : m2, &im = o1 ? m2 : m1;
+    const double ol  = static_cast<double>(om.i_hi - om.i_lo + 1);
+    const double il  = static_cast<double>(im.i_hi - im.i_lo + 1);
+    const double cl  = static_cast<double>(ov_hi - ov_lo + 1);
+    const double os  = static_cast<double>(om.score) * cl / ol;
+    const double is_ = static_cast<double>(im.score) * cl / il;
+    em_score         = os + is_;
+    msgpu_edgematch em;
+    em.ov_lo     = ov_lo;
+    em.ov_hi     = ov_hi;
+    em.score     = em_score;
+    em.anchor_id = anchor;
+    em.line      = om.line;
+    em.flags     = (em_dir ? 1u : 0u) | (em_prim ? 2u : 0u);
+    em.edge_idx  = static_cast<uint32_t>(e);
+    {
+      uint4 *q = reinterpret_cast<uint4 *>(&a.ems[ed.em_off + lane]);
+      q[0]     = make_uint4(static_cast<uint32_t>(em.ov_lo), static_cast<uint32_t>(em.ov_hi),
+                            static_cast<uint32_t>(__double_as_longlong(em.score)),
+                            static_cast<uint32_t>(__double_as_longlong(em.score) >> 32));
+      q[1]     = make_uint4(em.anchor_id, em.line, em.flags, em.edge_idx);
+    }
+    // corrected nanopore ranges (mpp.cpp:48-65) and overhangs (ol.cpp:37-47) on both vertices
+    {
+      const double rr  = static_cast<double>(m1.i_hi - m1.i_lo + 1) / static_cast<double>(m1.n_hi - m1.n_lo + 1);
+      double       ncl = static_cast<double>(ov_lo - m1.i_lo) / rr;
+      double       ncr = static_cast<double>(m1.i_hi - ov_hi) / rr;
+      if (!d1) {
+        double tmp = ncl;
+        ncl        = ncr;
+        ncr        = tmp;
+      }
+      rlo1 = m1.n_lo;
+      rhi1 = m1.n_hi;
+      clo1 = static_cast<double>(m1.n_lo) + ncl; // == overhangLeft
+      chi1 = static_cast<double>(m1.n_hi) - ncr;
+      ovr1 = static_cast<double>(len1 - m1.n_hi) + ncr;
+    }
+    {
+      const double rr  = static_cast<double>(m2.i_hi - m2.i_lo + 1) / static_cast<double>(m2.n_hi - m2.n_lo + 1);
+      double       ncl = static_cast<double>(ov_lo - m2.i_lo) / rr;
+      double       ncr = static_cast<double>(m2.i_hi - ov_hi) / rr;
+      if (!d2) {
+        double tmp = ncl;
+        ncl        = ncr;
+        ncr        = tmp;
+      }
+      rlo2 = m2.n_lo;
+      rhi2 = m2.n_hi;
+      clo2 = static_cast<double>(m2.n_lo) + ncl;
+      chi2 = static_cast<double>(m2.n_hi) - ncr;
+      ovr2 = static_cast<double>(len2 - m2.n_hi) + ncr;
+    }
+  }
+
+  // src/main.cpp:341-353: split by EdgeMatch direction, chain minus then plus
+  const unsigned long long m_plus = __ballot(act && em_dir), m_minus = __ballot(act && !em_dir);
+  PathRec *pm = s_paths[wave][0], *pp = s_paths[wave][1];
+  const int n_m = chain_direction(m_minus, false, lane, em_score, em_prim, rlo1, rhi1, clo1, chi1, rlo2, rhi2, clo2,
+                                  chi2, j1, q2, n1, n2, a.wiggle, a.ratio_pct, a.alt_frac, pm);
+  const int n_p = chain_direction(m_plus, true, lane, em_score, em_prim, rlo1, rhi1, clo1, chi1, rlo2, rhi2, clo2, chi2,
+                                  j1, q2, n1, n2, a.wiggle, a.ratio_pct, a.alt_frac, pp);
+  __builtin_amdgcn_wave_barrier();
+  __threadfence_block();
+
+  // filters of src/main.cpp:355-387 on the union of both lists.  lane p < n_m: minus path p;
+  // lane 32.. not needed: at most 64 paths per direction, handle minus on pass 0 and plus on pass 1.
+  bool     k_m = false, k_p = false; // keep flags of path `lane` in each list
+  uint32_t prim_m = 0, prim_p = 0, len_m = 0, len_p = 0;
+  if (lane < n_m) {
+    prim_m = pm[lane].primary;
+    len_m  = static_cast<uint32_t>(__popcll(pm[lane].mask));
+    k_m    = true;
+  }
+  if (lane < n_p) {
+    prim_p = pp[lane].primary;
+    len_p  = static_cast<uint32_t>(__popcll(pp[lane].mask));
+    k_p    = true;
+  }
+  const bool has_primary = __ballot((k_m && prim_m) || (k_p && prim_p)) != 0;
+  if (has_primary) {
+    k_m = k_m && prim_m;
+    k_p = k_p && prim_p;
+  }
+  const bool has_multi = __ballot((k_m && len_m > 1) || (k_p && len_p > 1)) != 0;
+  if (has_multi) {
+    k_m = k_m && len_m > 1;
+    k_p = k_p && len_p > 1;
+  }
+  const unsigned long long keep_m = __ballot(k_m), keep_p = __ballot(k_p);
+  const int                combined = __popcll(keep_m) + __popcll(keep_p);
+  bool                     shadow;
+  if (combined > 1) {
+    shadow = true; // :389-391
+  } else {
+    // the single remaining path: minus list first (:393)
+    uint32_t pr = keep_m ? rl_u32(prim_m, __builtin_ctzll(keep_m)) : rl_u32(prim_p, __builtin_ctzll(keep_p));
+    shadow      = !pr;
+  }
+
+  // getOverlap (ol.cpp:53-101) per kept path, minus first; orders into this edge's slots, ids into its id slots
+  uint32_t n_orders = 0, n_ids = 0;
+  for (int pass = 0; pass < 2; ++pass) {
+    unsigned long long keep = pass == 0 ? keep_m : keep_p;
+    const PathRec     *pv   = pass == 0 ? pm : pp;
+    const bool         dir  = pass == 1;
+    while (keep) {
+      const int pi = __builtin_ctzll(keep);
+      keep &= keep - 1;
+      const uint64_t mask = pv[pi].mask;
+      const int      f = __builtin_ctzll(mask), l = 63 - __builtin_clzll(mask);
+      const double   L1 = rl_f64(clo1, f), R1 = rl_f64(ovr1, l);
+      double         L2 = rl_f64(clo2, f), R2 = rl_f64(ovr2, l);
+      if (!dir) { // :73-76
+        L2 = rl_f64(ovr2, f);
+        R2 = rl_f64(clo2, l);
+      }
+      bool     have = false;
+      uint32_t fl   = 0;
+      double   lo = 0, ro = 0;
+      if (L1 <= L2 && R1 <= R2) {
+        have = true;
+        fl   = MSGPU_ORD_START_V1 | MSGPU_ORD_CONTAINED;
+        lo   = L2 - L1;
+        ro   = R2 - R1;
+      } else if (L1 >= L2 && R1 >= R2) {
+        have = true;
+        fl   = MSGPU_ORD_CONTAINED;
+        lo   = L1 - L2;
+        ro   = R1 - R2;
+      } else if (L1 > L2 && R1 < R2) {
+        have = true;
+        fl   = MSGPU_ORD_START_V1;
+        lo   = L1 - L2;
+        ro   = R2 - R1;
+      } else if (L1 < L2 && R1 > R2) {
+        have = true;
+        fl   = 0;
+        lo   = L2 - L1;
+        ro   = R1 - R2;
+      }
+      if (!have) continue;
+      const uint32_t cnt = static_cast<uint32_t>(__popcll(mask));
+      // ids in path order = ascending lane
+      if ((mask >> lane) & 1ull) {
+        const uint32_t pos = static_cast<uint32_t>(__popcll(mask & ((1ull << lane) - 1)));
+        a.ids_scr[ed.em_off + n_ids + pos] = anchor;
+      }
+      if (lane == 0) {
+        msgpu_order o;
+        o.edge_idx     = static_cast<uint32_t>(e);
+        o.flags        = fl | (dir ? MSGPU_ORD_DIR : 0u) | (pv[pi].primary ? MSGPU_ORD_PRIMARY : 0u);
+        o.left_offset  = lo;
+        o.right_offset = ro;
+        o.score        = pv[pi].score;
+        o.ids_off      = n_ids; // relative to the edge's id slots; made absolute by k_compact
+        o.ids_cnt      = cnt;
+        o.start        = (fl & MSGPU_ORD_START_V1) ? v1 : v2;
+        o.end          = (fl & MSGPU_ORD_START_V1) ? v2 : v1;
+        o.base         = v1;
+        o.pad[0]       = 0;
+        o.pad[1]       = 0;
+        a.order_scr[ed.em_off + n_orders] = o;
+      }
+      ++n_orders;
+      n_ids += cnt;
+    }
+  }
+  if (lane == 0) {
+    a.edge_norders[e] = n_orders;
+    a.edge_nids[e]    = n_ids;
+    a.edges[e].shadow = shadow ? 1 : 0;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// chain, big edges (> 64 EdgeMatches): same algorithm, one wavefront per edge, element state in global scratch.
+// The O(n^2) compatibility sweep is lane-parallel; the (short) sequential tails run on lane 0.  Slow path, any size.
+// ---------------------------------------------------------------------------------------------------------------------
+
+struct BigElem { // 96 bytes per EdgeMatch
+  int      rlo1, rhi1, rlo2, rhi2;
+  double   clo1, chi1, clo2, chi2, ovr1, ovr2, score;
+  uint32_t anchor, j1, q2, flags; // flags bit0 dir, bit1 prim
+  double   pop;
+  uint32_t pred, used;
+};
+
+struct BigPath {
+  uint32_t end, first, len, primary;
+  uint64_t score;
+};
+
+__device__ __forceinline__ bool big_compat(const BigElem &K, const BigElem &L, bool direction, double wiggle,
+                                           double ratio_pct) {
+  int    o1 = 0, o2 = 0;
+  double d1 = 0, d2 = 0;
+  bool   abort_ = false;
+  {
+    if (K.clo1 <= L.chi1 && L.clo1 <= K.chi1) {
+      if (K.clo1 < L.clo1 && K.chi1 < L.chi1) {
+        o1 = 2;
+        d1 = K.chi1 - L.clo1 + 1;
+      }
+      if (K.clo1 > L.clo1 && K.chi1 > L.chi1) {
+        o1 = -2;
+        d1 = L.chi1 - K.clo1 + 1;
+      }
+    } else if (K.clo1 < L.clo1) {
+      o1 = 1;
+      d1 = L.clo1 - K.chi1 + 1;
+    } else {
+      o1 = -1;
+      d1 = K.clo1 - L.chi1 + 1;
+    }
+    int uco = 0;
+    if (K.rlo1 <= L.rhi1 && L.rlo1 <= K.rhi1) {
+      if (K.rlo1 < L.rlo1 && K.rhi1 < L.rhi1) uco = 2;
+      if (K.rlo1 > L.rlo1 && K.rhi1 > L.rhi1) uco = -2;
+      if ((o1 < 0 && uco >= 0) || (o1 > 0 && uco <= 0)) abort_ = true;
+    }
+  }
+  {
+    if (K.clo2 <= L.chi2 && L.clo2 <= K.chi2) {
+      if (K.clo2 < L.clo2 && K.chi2 < L.chi2) {
+        o2 = 2;
+        d2 = K.chi2 - L.clo2 + 1;
+      }
+      if (K.clo2 > L.clo2 && K.chi2 > L.chi2) {
+        o2 = -2;
+        d2 = L.chi2 - K.clo2 + 1;
+      }
+    } else if (K.clo2 < L.clo2) {
+      o2 = 1;
+      d2 = L.clo2 - K.chi2 + 1;
+    } else {
+      o2 = -1;
+      d2 = K.clo2 - L.chi2 + 1;
+    }
+    int uco = 0;
+    if (K.rlo2 <= L.rhi2 && L.rlo2 <= K.rhi2) {
+      if (K.rlo2 < L.rlo2 && K.rhi2 < L.rhi2) uco = 2;
+      if (K.rlo2 > L.rlo2 && K.rhi2 > L.rhi2) uco = -2;
+      if ((o2 < 0 && uco >= 0) || (o2 > 0 && uco <= 0)) abort_ = true;
+    }
+  }
+  if (abort_) return false;
+  if (!direction) o2 = -o2;
+  if (o1 == o2 && o1 != 0) {
+    const double mx = std_max(d1, d2);
+    const double df = mx - std_min(d1, d2);
+    return (df <= wiggle) || (df * 100 / mx <= ratio_pct);
+  }
+  if ((o1 < 0 && o2 < 0) || (o1 > 0 && o2 > 0)) return d1 + d2 <= wiggle;
+  return false;
+}
+
+__global__ __launch_bounds__(64) void k_chain_big(ChainArgs a, const uint32_t *big_list, uint32_t n_big, BigElem *elems,
+                                                  BigPath *paths /* 2 slots per EdgeMatch: minus then plus */) {
+  if (blockIdx.x >= n_big) return;
+  const int        lane = threadIdx.x;
+  const uint64_t   e    = big_list[blockIdx.x];
+  const msgpu_edge ed   = a.edges[e];
+  const uint32_t   n    = ed.em_cnt;
+  const uint64_t   cp   = a.edge_cand[e];
+  const uint32_t   v1 = ed.v1, v2 = ed.v2;
+  const uint32_t   n1 = a.read_cnt[v1], n2 = a.read_cnt[v2];
+  const int        len1 = a.read_len[v1], len2 = a.read_len[v2];
+  BigElem         *E  = elems + ed.em_off;
+  BigPath         *Pm = paths + 2 * ed.em_off, *Pp = Pm + n;
+
+  // elements + EdgeMatch table
+  for (uint32_t i = lane; i < n; i += 64) {
+    const uint32_t j1 = a.cand_j[cp + i], t = a.cand_t[cp + i];
+    const IRow     m1 = load_irow(&a.by_read[a.read_off[v1] + j1]);
+    const IRow     m2 = load_irow(&a.by_anchor[t]);
+    const int      ov_lo = max(m1.i_lo, m2.i_lo), ov_hi = min(m1.i_hi, m2.i_hi);
+    const bool     d1 = (m1.pf & PF_DIR) != 0, d2 = (m2.pf & PF_DIR) != 0;
+    const bool     em_dir = d1 == d2, em_prim = (m1.pf & PF_PRIM) && (m2.pf & PF_PRIM);
+    const bool     o1 = m1.line > m2.line;
+    const IRow    &om = o1 ? m1 : m2, &im = o1 ? m2 : m1;
+    const double   ol = static_cast<double>(om.i_hi - om.i_lo + 1);
+    const double   il = static_cast<double>(im.i_hi - im.i_lo + 1);
+    const double   cl = static_cast<double>(ov_hi - ov_lo + 1);
+    const double   os = static_cast<double>(om.score) * cl / ol;
+    const double   is_ = static_cast<double>(im.score) * cl / il;
+    BigElem        x;
+    x.score  = os + is_;
+    x.anchor = m1.other;
+    x.j1     = j1;
+    x.q2     = m2.pf & PF_POS_MASK;
+    x.flags  = (em_dir ? 1u : 0u) | (em_prim ? 2u : 0u);
+    msgpu_edgematch em;
+    em.ov_lo     = ov_lo;
+    em.ov_hi     = ov_hi;
+    em.score     = x.score;
+    em.anchor_id = x.anchor;
+    em.line      = om.line;
+    em.flags     = x.flags;
+    em.edge_idx  = static_cast<uint32_t>(e);
+    a.ems[ed.em_off + i] = em;
+    {
+      const double rr  = static_cast<double>(m1.i_hi - m1.i_lo + 1) / static_cast<double>(m1.n_hi - m1.n_lo + 1);
+      double       ncl = static_cast<double>(ov_lo - m1.i_lo) / rr;
+      double       ncr = static_cast<double>(m1.i_hi - ov_hi) / rr;
+      if (!d1) {
+        double tmp = ncl;
+        ncl        = ncr;
+        ncr        = tmp;
+      }
+      x.rlo1 = m1.n_lo;
+      x.rhi1 = m1.n_hi;
+      x.clo1 = static_cast<double>(m1.n_lo) + ncl;
+      x.chi1 = static_cast<double>(m1.n_hi) - ncr;
+      x.ovr1 = static_cast<double>(len1 - m1.n_hi) + ncr;
+    }
+    {
+      const double rr  = static_cast<double>(m2.i_hi - m2.i_lo + 1) / static_cast<double>(m2.n_hi - m2.n_lo + 1);
+      double       ncl = static_cast<double>(ov_lo - m2.i_lo) / rr;
+      double       ncr = static_cast<double>(m2.i_hi - ov_hi) / rr;
+      if (!d2) {
+        double tmp = ncl;
+        ncl        = ncr;
+        ncr        = tmp;
+      }
+      x.rlo2 = m2.n_lo;
+      x.rhi2 = m2.n_hi;
+      x.clo2 = static_cast<double>(m2.n_lo) + ncl;
+      x.chi2 = static_cast<double>(m2.n_hi) - ncr;
+      x.ovr2 = static_cast<double>(len2 - m2.n_hi) + ncr;
+    }
+    x.pop  = x.score;
+    x.pred = 0xffffffffu;
+    x.used = 0;
+    E[i]   = x;
+  }
+  __threadfence_block();
+  __syncthreads();
+
+  uint32_t np_dir[2] = {0, 0};
+  for (int pass = 0; pass < 2; ++pass) {
+    const bool     direction = pass == 1;
+    const uint32_t want      = direction ? 1u : 0u;
+    BigPath       *P         = direction ? Pp : Pm;
+    // DP
+    for (uint32_t k = 0; k + 1 < n; ++k) {
+      const BigElem K = E[k];
+      if ((K.flags & 1u) != want) continue;
+      for (uint32_t l = k + 1 + lane; l < n; l += 64) {
+        BigElem L = E[l];
+        if ((L.flags & 1u) != want) continue;
+        const bool   ok   = big_compat(K, L, direction, a.wiggle, a.ratio_pct);
+        const double cand = K.pop + L.score;
+        if (ok && cand > L.pop) {
+          E[l].pop  = cand;
+          E[l].pred = k;
+        }
+      }
+      __threadfence_block();
+      __syncthreads();
+    }
+    // sequential tail on lane 0
+    uint32_t np = 0;
+    if (lane == 0) {
+      double   maxv = 0.0;
+      uint32_t maxi = 0xffffffffu, firsti = 0xffffffffu;
+      for (uint32_t i = 0; i < n; ++i) {
+        if ((E[i].flags & 1u) != want) continue;
+        if (firsti == 0xffffffffu) firsti = i;
+        if (E[i].pop > maxv) {
+          maxv = E[i].pop;
+          maxi = i;
+        }
+      }
+      if (firsti != 0xffffffffu) {
+        if (maxi == 0xffffffffu) maxi = firsti;
+        // best path
+        {
+          uint32_t len = 0, first = maxi;
+          bool     prim = false;
+          for (uint32_t c = maxi; c != 0xffffffffu; c = E[c].pred) {
+            E[c].used = 1;
+            prim |= (E[c].flags & 2u) != 0;
+            first = c;
+            ++len;
+          }
+          P[0].end     = maxi;
+          P[0].first   = first;
+          P[0].len     = len;
+          P[0].primary = (prim || len > 2) ? 1u : 0u;
+          P[0].score   = static_cast<uint64_t>(maxv);
+          np           = 1;
+        }
+        const double thr = maxv * a.alt_frac;
+        for (uint32_t p = 0; p < n; ++p) {
+          if ((E[p].flags & 1u) != want || !(E[p].pop > thr)) continue;
+          bool     disjoint = true;
+          uint32_t len = 0, first = p;
+          bool     prim = false;
+          for (uint32_t c = p; c != 0xffffffffu; c = E[c].pred) {
+            if (E[c].used) {
+              disjoint = false;
+              break;
+            }
+            prim |= (E[c].flags & 2u) != 0;
+            first = c;
+            ++len;
+          }
+          if (!disjoint) continue;
+          for (uint32_t c = p; c != 0xffffffffu; c = E[c].pred) E[c].used = 1;
+          P[np].end     = p;
+          P[np].first   = first;
+          P[np].len     = len;
+          P[np].primary = prim ? 1u : 0u;
+          P[np].score   = static_cast<uint64_t>(E[p].pop);
+          ++np;
+        }
+        if (np == 1 && P[0].primary) {
+          const uint32_t f = P[0].first, l = P[0].end;
+          auto           qe = [&](uint32_t i) { return direction ? E[i].q2 : (n2 - 1 - E[i].q2); };
+          bool           demote;
+          if ((E[f].j1 != 0 && qe(f) != 0) || (E[l].j1 != n1 - 1 && qe(l) != n2 - 1)) {
+            demote = true;
+          } else {
+            // ascending walk: reverse the pred chain into the id scratch of this edge (free at this point)
+            uint32_t *tmp = a.ids_scr + ed.em_off;
+            uint32_t  len = P[0].len, w = len;
+            for (uint32_t c = l; c != 0xffffffffu; c = E[c].pred) tmp[--w] = c;
+            long long i = 0, jj = 0;
+            bool      is_shadow = false;
+            for (uint32_t t = 0; t < len && !is_shadow; ++t) {
+              const uint32_t  c  = tmp[t];
+              const long long rs = static_cast<long long>(E[c].j1);
+              bool            inter = rs > i;
+              i                     = rs + 1;
+              long long re          = static_cast<long long>(qe(c));
+              if (re < jj) re = static_cast<long long>(n2);
+              inter &= re > jj;
+              jj        = re + 1;
+              is_shadow = inter;
+            }
+            demote = is_shadow;
+          }
+          if (demote) P[0].primary = 0;
+        }
+      }
+    }
+    np_dir[pass] = np; // valid on lane 0
+    __threadfence_block();
+    __syncthreads();
+  }
+
+  if (lane == 0) {
+    const uint32_t n_m = np_dir[0], n_p = np_dir[1];
+    bool           has_primary = false;
+    for (uint32_t i = 0; i < n_p; ++i) has_primary |= Pp[i].primary != 0;
+    for (uint32_t i = 0; i < n_m; ++i) has_primary |= Pm[i].primary != 0;
+    // keep flag in bit 31 of .primary's companion: reuse .first's top bit is unsafe; recompute on the fly instead
+    auto keep1 = [&](const BigPath &p) { return !has_primary || p.primary; };
+    bool has_multi = false;
+    for (uint32_t i = 0; i < n_p; ++i) has_multi |= keep1(Pp[i]) && Pp[i].len > 1;
+    for (uint32_t i = 0; i < n_m; ++i) has_multi |= keep1(Pm[i]) && Pm[i].len > 1;
+    auto     keep = [&](const BigPath &p) { return keep1(p) && (!has_multi || p.len > 1); };
+    uint32_t combined = 0;
+    for (uint32_t i = 0; i < n_m; ++i) combined += keep(Pm[i]) ? 1u : 0u;
+    for (uint32_t i = 0; i < n_p; ++i) combined += keep(Pp[i]) ? 1u : 0u;
+    bool shadow;
+    if (combined > 1) {
+      shadow = true;
+    } else {
+      const BigPath *first = nullptr;
+      for (uint32_t i = 0; i < n_m && !first; ++i)
+        if (keep(Pm[i])) first = &Pm[i];
+      for (uint32_t i = 0; i < n_p && !first; ++i)
+        if (keep(Pp[i])) first = &Pp[i];
+      shadow = first ? !first->primary : false;
+    }
+    uint32_t n_orders = 0, n_ids = 0;
+    for (int pass = 0; pass < 2; ++pass) {
+      const BigPath *pv  = pass == 0 ? Pm : Pp;
+      const uint32_t npv = pass == 0 ? n_m : n_p;
+      const bool     dir = pass == 1;
+      for (uint32_t pi = 0; pi < npv; ++pi) {
+        if (!keep(pv[pi])) continue;
+        const uint32_t f = pv[pi].first, l = pv[pi].end;
+        const double   L1 = E[f].clo1, R1 = E[l].ovr1;
+        double         L2 = E[f].clo2, R2 = E[l].ovr2;
+        if (!dir) {
+          L2 = E[f].ovr2;
+          R2 = E[l].clo2;
+        }
+        bool     have = false;
+        uint32_t fl   = 0;
+        double   lo = 0, ro = 0;
+        if (L1 <= L2 && R1 <= R2) {
+          have = true;
+          fl   = MSGPU_ORD_START_V1 | MSGPU_ORD_CONTAINED;
+          lo   = L2 - L1;
+          ro   = R2 - R1;
+        } else if (L1 >= L2 && R1 >= R2) {
+          have = true;
+          fl   = MSGPU_ORD_CONTAINED;
+          lo   = L1 - L2;
+          ro   = R1 - R2;
+        } else if (L1 > L2 && R1 < R2) {
+          have = true;
+          fl   = MSGPU_ORD_START_V1;
+          lo   = L1 - L2;
+          ro   = R2 - R1;
+        } else if (L1 < L2 && R1 > R2) {
+          have = true;
+          fl   = 0;
+          lo   = L2 - L1;
+          ro   = R1 - R2;
+        }
+        if (!have) continue;
+        const uint32_t cnt = pv[pi].len;
+        uint32_t       w   = cnt;
+        for (uint32_t c = l; c != 0xffffffffu; c = E[c].pred) a.ids_scr[ed.em_off + n_ids + --w] = E[c].anchor;
+        msgpu_order o;
+        o.edge_idx     = static_cast<uint32_t>(e);
+        o.flags        = fl | (dir ? MSGPU_ORD_DIR : 0u) | (pv[pi].primary ? MSGPU_ORD_PRIMARY : 0u);
+        o.left_offset  = lo;
+        o.right_offset = ro;
+        o.score        = pv[pi].score;
+        o.ids_off      = n_ids;
+        o.ids_cnt      = cnt;
+        o.start        = (fl & MSGPU_ORD_START_V1) ? v1 : v2;
+        o.end          = (fl & MSGPU_ORD_START_V1) ? v2 : v1;
+        o.base         = v1;
+        o.pad[0]       = 0;
+        o.pad[1]       = 0;
+        a.order_scr[ed.em_off + n_orders] = o;
+        ++n_orders;
+        n_ids += cnt;
+      }
+    }
+    a.edge_norders[e] = n_orders;
+    a.edge_nids[e]    = n_ids;
+    a.edges[e].shadow = shadow ? 1 : 0;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_list_big_edges(const msgpu_edge *edges, uint64_t n_edges, uint32_t *big_list,
+                                                        uint32_t *n_big) {
+  uint64_t e = static_cast<uint64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (e >= n_edges) return;
+  if (edges[e].em_cnt > 64) big_list[atomicAdd(n_big, 1u)] = static_cast<uint32_t>(e);
+}
+
+// dense, canonical order + id tables
+__global__ __launch_bounds__(256) void k_compact(CompactArgs a) {
+  uint64_t e = static_cast<uint64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (e >= a.n_edges) return;
+  msgpu_edge ed  = a.edges[e];
+  uint32_t   no  = a.edge_norders[e];
+  uint64_t   oo  = a.order_base[e];
+  uint64_t   io  = a.ids_base[e];
+  for (uint32_t i = 0; i < no; ++i) {
+    msgpu_order o = a.order_scr[ed.em_off + i];
+    const uint64_t src = ed.em_off + o.ids_off;
+    o.ids_off          = io;
+    a.orders[oo + i]   = o;
+    for (uint32_t q = 0; q < o.ids_cnt; ++q) a.ids[io + q] = a.ids_scr[src + q];
+    io += o.ids_cnt;
+  }
+  a.edges[e].order_off = oo;
+  a.edges[e].order_cnt = static_cast<uint16_t>(no);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// host-callable launchers
+// ---------------------------------------------------------------------------------------------------------------------
+
+static inline dim3 grid1(uint64_t n, uint32_t per_block) { return dim3(static_cast<uint32_t>((n + per_block - 1) / per_block)); }
+
+void launch_max_ids(hipStream_t st, const msgpu_row *rows, uint64_t n, uint32_t *max_ids) {
+  if (n) hipLaunchKernelGGL(k_max_ids, grid1(n, 256), dim3(256), 0, st, rows, n, max_ids);
+}
+void launch_hist_read(hipStream_t st, const msgpu_row *rows, uint64_t n, uint32_t *cnt_read, uint64_t *first_key) {
+  if (n)
+    hipLaunchKernelGGL(k_hist_read, grid1(n, 256), dim3(256), 0, st, rows, n, cnt_read,
+                       reinterpret_cast<unsigned long long *>(first_key));
+}
+void launch_read_facts(hipStream_t st, const msgpu_row *rows, const uint64_t *first_key, uint32_t V, int32_t *read_len,
+                       uint32_t *read_first, uint32_t *err) {
+  if (V)
+    hipLaunchKernelGGL(k_read_facts, grid1(V, 256), dim3(256), 0, st, rows,
+                       reinterpret_cast<const unsigned long long *>(first_key), V, read_len, read_first, err);
+}
+void launch_scatter_read(hipStream_t st, const msgpu_row *rows, uint64_t n, const uint32_t *read_off, uint32_t *cursor,
+                         void *bkt_key, uint32_t *bkt_idx) {
+  if (n)
+    hipLaunchKernelGGL(k_scatter_read, grid1(n, 256), dim3(256), 0, st, rows, n, read_off, cursor,
+                       static_cast<uint4 *>(bkt_key), bkt_idx);
+}
+void launch_dedupe(hipStream_t st, const uint32_t *read_off, uint64_t n, const void *bkt_key, const uint32_t *bkt_idx,
+                   const msgpu_row *rows, uint8_t *bkt_dead) {
+  if (n)
+    hipLaunchKernelGGL(k_dedupe, grid1(n, 256), dim3(256), 0, st, read_off, n, static_cast<const uint4 *>(bkt_key),
+                       bkt_idx, rows, bkt_dead);
+}
+void launch_rank_read(hipStream_t st, const uint32_t *read_off, uint64_t n, const void *bkt_key, const uint32_t *bkt_idx,
+                      const uint8_t *bkt_dead, const msgpu_row *rows, IRow *by_read, uint32_t *read_cnt,
+                      uint32_t *alive_rank, uint32_t *anchor_cnt) {
+  if (n)
+    hipLaunchKernelGGL(k_rank_read, grid1(n, 256), dim3(256), 0, st, read_off, n, static_cast<const uint4 *>(bkt_key),
+                       bkt_idx, bkt_dead, rows, by_read, read_cnt, alive_rank, anchor_cnt);
+}
+void launch_scatter_anchor(hipStream_t st, const msgpu_row *rows, uint64_t n, const uint32_t *alive_rank,
+                           const uint32_t *anchor_off, uint32_t *cursor, uint32_t *bkt_idx, uint32_t *bkt_line) {
+  if (n)
+    hipLaunchKernelGGL(k_scatter_anchor, grid1(n, 256), dim3(256), 0, st, rows, n, alive_rank, anchor_off, cursor,
+                       bkt_idx, bkt_line);
+}
+void launch_rank_anchor(hipStream_t st, const uint32_t *anchor_off, uint64_t n_rows, const uint32_t *d_n_alive,
+                        const uint32_t *bkt_idx, const uint32_t *bkt_line, const msgpu_row *rows,
+                        const uint32_t *alive_rank, IRow *by_anchor) {
+  if (n_rows)
+    hipLaunchKernelGGL(k_rank_anchor, grid1(n_rows, 256), dim3(256), 0, st, anchor_off, d_n_alive, bkt_idx, bkt_line,
+                       rows, alive_rank, by_anchor);
+}
+void launch_bound(hipStream_t st, const uint32_t *read_off, const uint32_t *read_cnt, const IRow *by_read,
+                  const uint32_t *anchor_off, uint32_t V, uint32_t shard, uint32_t nshards, uint32_t *bound) {
+  if (V)
+    hipLaunchKernelGGL(k_bound, grid1(V, 256), dim3(256), 0, st, read_off, read_cnt, by_read, anchor_off, V, shard,
+                       nshards, bound);
+}
+void launch_classify_reads(hipStream_t st, const uint32_t *read_cnt, const uint32_t *bound, uint32_t V, uint32_t shard,
+                           uint32_t nshards, uint32_t *l0, uint32_t *l1, uint32_t *l2, uint32_t *n_lists) {
+  if (V)
+    hipLaunchKernelGGL(k_classify_reads, grid1(V, 256), dim3(256), 0, st, read_cnt, bound, V, shard, nshards, l0, l1, l2,
+                       n_lists);
+}
+void launch_candidates(hipStream_t st, const CandArgs &a, int cls, const uint32_t *list, uint32_t n_list) {
+  if (!n_list) return;
+  if (cls == 0)
+    hipLaunchKernelGGL((k_candidates<256, 1024>), dim3(n_list), dim3(256), 0, st, a, list, n_list);
+  else
+    hipLaunchKernelGGL((k_candidates<1024, 8192>), dim3(n_list), dim3(256), 0, st, a, list, n_list);
+}
+void launch_candidates_big(hipStream_t st, const CandArgs &a, const uint32_t *list, uint32_t n_list, uint64_t *big_key,
+                           uint32_t *big_t, uint32_t *big_r2s, uint32_t *big_pfx) {
+  if (!n_list) return;
+  hipLaunchKernelGGL(k_candidates_big, dim3(n_list), dim3(256), 0, st, a, list, n_list, big_key, big_t, big_r2s,
+                     big_pfx);
+}
+void launch_emit_edges(hipStream_t st, const uint32_t *n_edge, const uint32_t *n_cand, const uint64_t *edge_base,
+                       const uint64_t *em_base, const uint64_t *cand_off, const uint32_t *scr_v2,
+                       const uint32_t *scr_start, uint32_t V, msgpu_edge *edges, uint64_t *edge_cand) {
+  if (V)
+    hipLaunchKernelGGL(k_emit_edges, grid1(V, 4), dim3(256), 0, st, n_edge, n_cand, edge_base, em_base, cand_off, scr_v2,
+                       scr_start, V, edges, edge_cand);
+}
+void launch_chain(hipStream_t st, const ChainArgs &a) {
+  if (a.n_edges) hipLaunchKernelGGL(k_chain, grid1(a.n_edges, 4), dim3(256), 0, st, a);
+}
+void launch_list_big_edges(hipStream_t st, const msgpu_edge *edges, uint64_t n_edges, uint32_t *big_list, uint32_t *n_big) {
+  if (n_edges) hipLaunchKernelGGL(k_list_big_edges, grid1(n_edges, 256), dim3(256), 0, st, edges, n_edges, big_list, n_big);
+}
+size_t big_elem_bytes() { return sizeof(BigElem); }
+size_t big_path_bytes() { return sizeof(BigPath); }
+void launch_chain_big(hipStream_t st, const ChainArgs &a, const uint32_t *big_list, uint32_t n_big, void *elems,
+                      void *paths) {
+  if (n_big)
+    hipLaunchKernelGGL(k_chain_big, dim3(n_big), dim3(64), 0, st, a, big_list, n_big, static_cast<BigElem *>(elems),
+                       static_cast<BigPath *>(paths));
+}
+void launch_compact(hipStream_t st, const CompactArgs &a) {
+  if (a.n_edges) hipLaunchKernelGGL(k_compact, grid1(a.n_edges, 256), dim3(256), 0, st, a);
+}
+
+} // namespace msgpu

@@ -1,0 +1,157 @@
+"""Python view of the C-ABI (include/msgpu.h): the call sequence of src/main.cpp:153-178 of the reference.
+
+    paf = parse_paf(path)                      # BlastFileAccessor + BlastFileReader::read  (host)
+    ctx = OverlapContext(device=0)             # ThreadPool + Graph + MatchMap construction
+    ctx.load_rows(paf.rows)                    # Graph::addVertex + MatchMap::addVertexMatch, in HBM
+    ctx.calculate_edges()                      # MatchMap::calculateEdges
+    ctx.chaining_and_overlaps()                # the chainingAndOverlaps fan-out
+    t = ctx.tables()                           # graph.getEdges() / getEdgeMatches / getEdgeOrders / isShadow
+
+All compute happens in libmsgpu.so on the GPU; this module only moves buffers.  No CPU fallback exists.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _lib
+from ._lib import EDGE_DTYPE, EM_DTYPE, ORDER_DTYPE, ROW_DTYPE, Counts, Params, Timings
+
+
+class MsgpuError(RuntimeError):
+    def __init__(self, code, detail=""):
+        msg = _lib.lib().msgpu_strerror(code).decode()
+        super().__init__("%s (%d)%s" % (msg, code, (": " + detail) if detail else ""))
+        self.code = code
+
+
+def default_params():
+    p = Params()
+    _lib.lib().msgpu_default_params(C.byref(p))
+    return p
+
+
+class Paf:
+    """Result of msgpu_parse_paf: accepted rows + the two registries."""
+
+    def __init__(self, rows, n_lines, read_names, anchor_names):
+        self.rows = rows
+        self.n_lines = n_lines
+        self.read_names = read_names
+        self.anchor_names = anchor_names
+
+
+def parse_paf(path, params=None):
+    L = _lib.lib()
+    h = C.c_void_p()
+    rc = L.msgpu_parse_paf(os.fsencode(path), C.byref(params) if params is not None else None, C.byref(h))
+    if rc != 0:
+        raise MsgpuError(rc, str(path))
+    try:
+        n = C.c_size_t()
+        ptr = L.msgpu_paf_rows(h, C.byref(n))
+        if n.value:
+            buf = (C.c_char * (n.value * ROW_DTYPE.itemsize)).from_address(ptr)
+            rows = np.frombuffer(buf, dtype=ROW_DTYPE, count=n.value).copy()
+        else:
+            rows = np.zeros(0, dtype=ROW_DTYPE)
+        rn = [L.msgpu_paf_read_name(h, i).decode() for i in range(L.msgpu_paf_read_count(h))]
+        an = [L.msgpu_paf_anchor_name(h, i).decode() for i in range(L.msgpu_paf_anchor_count(h))]
+        return Paf(rows, L.msgpu_paf_line_count(h), rn, an)
+    finally:
+        L.msgpu_paf_free(h)
+
+
+class OverlapContext:
+    def __init__(self, device=0, params=None):
+        self._L = _lib.lib()
+        self._h = C.c_void_p()
+        self.params = params if params is not None else default_params()
+        rc = self._L.msgpu_create(int(device), C.byref(self.params), C.byref(self._h))
+        if rc != 0:
+            self._h = C.c_void_p()
+            raise MsgpuError(rc)
+        self._keep = None
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._L.msgpu_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _check(self, rc):
+        if rc != 0:
+            raise MsgpuError(rc, self._L.msgpu_last_error(self._h).decode())
+
+    def set_stream(self, hip_stream_ptr):
+        self._check(self._L.msgpu_set_stream(self._h, C.c_void_p(hip_stream_ptr)))
+
+    def set_shard(self, shard, n_shards):
+        self._check(self._L.msgpu_set_shard(self._h, shard, n_shards))
+
+    def load_rows(self, rows):
+        rows = np.ascontiguousarray(rows, dtype=ROW_DTYPE)
+        self._check(self._L.msgpu_load_rows(self._h, rows.ctypes.data, len(rows)))
+
+    def load_rows_device(self, dev_ptr, n_rows, keep_alive=None):
+        self._keep = keep_alive  # the caller's device buffer must outlive the context's use of it
+        self._check(self._L.msgpu_load_rows_device(self._h, C.c_void_p(dev_ptr), n_rows))
+
+    def calculate_edges(self):
+        self._check(self._L.msgpu_calculate_edges(self._h))
+
+    def chaining_and_overlaps(self):
+        self._check(self._L.msgpu_chaining_and_overlaps(self._h))
+
+    def synchronize(self):
+        self._check(self._L.msgpu_synchronize(self._h))
+
+    def counts(self):
+        c = Counts()
+        self._check(self._L.msgpu_get_counts(self._h, C.byref(c)))
+        return c
+
+    def timings(self):
+        t = Timings()
+        self._check(self._L.msgpu_get_timings(self._h, C.byref(t)))
+        return t
+
+    def tables(self):
+        """Host copies of the result tables (canonical order, see include/msgpu.h)."""
+        c = self.counts()
+        edges = np.zeros(c.n_edges, dtype=EDGE_DTYPE)
+        ems = np.zeros(c.n_ems, dtype=EM_DTYPE)
+        orders = np.zeros(c.n_orders, dtype=ORDER_DTYPE)
+        ids = np.zeros(c.n_ids, dtype="<u4")
+        self._check(self._L.msgpu_copy_tables(self._h, edges.ctypes.data, ems.ctypes.data, orders.ctypes.data,
+                                              ids.ctypes.data))
+        return {"edges": edges, "ems": ems, "orders": orders, "ids": ids}
+
+    def copy_tables_device(self, d_edges=None, d_ems=None, d_orders=None, d_ids=None):
+        self._check(self._L.msgpu_copy_tables_device(self._h, C.c_void_p(d_edges), C.c_void_p(d_ems),
+                                                     C.c_void_p(d_orders), C.c_void_p(d_ids)))
+
+    def reads(self):
+        c = self.counts()
+        rl = np.zeros(c.n_reads, dtype="<i4")
+        fl = np.zeros(c.n_reads, dtype="<u4")
+        self._check(self._L.msgpu_copy_reads(self._h, rl.ctypes.data, fl.ctypes.data))
+        return rl, fl
+
+
+def build_overlaps(rows, device=0, params=None, shard=0, n_shards=1):
+    """rows -> result tables in one call."""
+    with OverlapContext(device, params) as ctx:
+        if n_shards != 1:
+            ctx.set_shard(shard, n_shards)
+        ctx.load_rows(rows)
+        ctx.calculate_edges()
+        ctx.chaining_and_overlaps()
+        return ctx.tables()

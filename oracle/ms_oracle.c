@@ -666,6 +666,17 @@ typedef struct {
   uint32_t     edge_tmp;
 } em_tmp;
 
+typedef struct {
+  ms_edgematch em;
+  int32_t      n_lo, n_hi;
+} em_sort;
+static int cmp_em_sort(const void *a, const void *b) {
+  const em_sort *x = (const em_sort *)a, *y = (const em_sort *)b;
+  if (x->n_lo != y->n_lo) return x->n_lo < y->n_lo ? -1 : 1;
+  if (x->n_hi != y->n_hi) return x->n_hi < y->n_hi ? -1 : 1;
+  return x->em.anchor_id < y->em.anchor_id ? -1 : x->em.anchor_id > y->em.anchor_id;
+}
+
 static const ekey *g_sort_edges;
 static int cmp_edge_idx(const void *a, const void *b) {
   const ekey *x = &g_sort_edges[*(const uint32_t *)a], *y = &g_sort_edges[*(const uint32_t *)b];
@@ -857,6 +868,29 @@ int ms_oracle_overlap(const ms_row *rows_in, size_t n_rows, const ms_params *p, 
   free(eperm);
   free(einv);
   free(ekeys);
+
+  /* canonical EdgeMatch order inside an edge = the vStart order of mpp.cpp:164-172:
+   * (nanoporeRange of the anchor on v1, anchor id) */
+  {
+    em_sort *tmp = NULL;
+    size_t   cap = 0;
+    for (size_t i = 0; i < n_edges; ++i) {
+      ms_edge *E = &edges[i];
+      if (E->em_cnt > cap) {
+        cap = (size_t)E->em_cnt * 2;
+        tmp = (em_sort *)xrealloc(tmp, cap * sizeof(em_sort));
+      }
+      for (uint32_t q = 0; q < E->em_cnt; ++q) {
+        const ms_row *m = get_vertex_match(&S, E->v1, emt[E->em_off + q].anchor_id);
+        tmp[q].em   = emt[E->em_off + q];
+        tmp[q].n_lo = m->n_lo;
+        tmp[q].n_hi = m->n_hi;
+      }
+      qsort(tmp, E->em_cnt, sizeof(em_sort), cmp_em_sort);
+      for (uint32_t q = 0; q < E->em_cnt; ++q) emt[E->em_off + q] = tmp[q].em;
+    }
+    free(tmp);
+  }
 
   /* chainingAndOverlaps, src/main.cpp:328-414 */
   ms_order *orders = NULL;

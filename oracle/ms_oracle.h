@@ -103,7 +103,7 @@ typedef struct ms_rows {
 
 typedef struct ms_tables {
   ms_edge      *edges;   size_t n_edges;   /* sorted by (v1, v2)                          */
-  ms_edgematch *ems;     size_t n_ems;     /* grouped by edge, then by anchor_id          */
+  ms_edgematch *ems;     size_t n_ems;     /* grouped by edge, then vStart order (mpp.cpp:164-172) */
   ms_order     *orders;  size_t n_orders;  /* grouped by edge, reference emission order   */
   uint32_t     *ids;     size_t n_ids;
   /* per-read facts (Vertex): indexed by read id, n_reads = max id + 1 */
