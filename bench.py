@@ -1,0 +1,170 @@
+#!/usr/bin/env python3
+"""bench.py -- overlap hot path of MuCHSALSA on MI355X: overlap-pairs/s on the BASELINE.json workload.
+
+A step = one pass of the hot path over the synthetic batch, starting with the accepted-row table resident in HBM:
+  msgpu_load_rows_device   (device index build = MatchMap/Graph-vertex fill)
+  msgpu_calculate_edges    (MatchMap::calculateEdges)
+  msgpu_chaining_and_overlaps (the chainingAndOverlaps fan-out)
+  N > 1: one RCCL all-gather of the per-rank edge + order + id tables (each rank owns the edges with v1 % N == rank)
+
+Contract: python bench.py --gpus N --steps K --warmup W ; rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+WORKLOADS = {
+    # BASELINE.json configs[2]: the configuration the metric is quoted on
+    "cfg3": dict(n_reads=100_000, read_len=10_000, n_anchors=500_000, seed=43,
+                 name="100k synthetic Nanopore x10 kb, 500k unitig anchors, 10x coverage (BASELINE.json configs[2])"),
+    # BASELINE.json configs[1]
+    "cfg2": dict(n_reads=10_000, read_len=5_000, n_anchors=50_000, seed=42,
+                 name="10k synthetic Nanopore x5 kb, 50k unitig anchors, 10x coverage (BASELINE.json configs[1])"),
+    "tiny": dict(n_reads=2_000, read_len=5_000, n_anchors=10_000, seed=7, name="2k x5 kb, 10k anchors (smoke)"),
+}
+
+
+def cpu_baseline(workload, budget_reads):
+    """Oracle (C restatement, 1 thread) timed on a bounded sample of the same workload shape."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import ms_oracle_ctypes as oracle
+    from muchsalsa_amd import synth
+    oracle.build()
+    w = WORKLOADS[workload]
+    scale = min(1.0, budget_reads / w["n_reads"])
+    n_reads = max(1, int(w["n_reads"] * scale))
+    n_anchors = max(1, int(w["n_anchors"] * scale))
+    rows = synth.synth_rows(n_reads, w["read_len"], n_anchors, w["seed"])
+    t0 = time.perf_counter()
+    t = oracle.overlap(rows)
+    dt = time.perf_counter() - t0
+    return {
+        "value": len(t["edges"]) / dt, "unit": "overlap-pairs/s", "cores": 1, "kind": "port",
+        "sample": "%d reads x %d bp, %d anchors (same generator/seed/density as the GPU workload, %.0f%% scale): "
+                  "%d edges, %d EdgeMatches, %d compat checks in %.2f s" % (
+                      n_reads, w["read_len"], n_anchors, 100 * scale, len(t["edges"]), len(t["ems"]),
+                      t["compat_checks"], dt),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
+    ap.add_argument("--cpu-sample-reads", type=int, default=25_000,
+                    help="reads in the CPU-baseline sample (0 disables the baseline leg)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from muchsalsa_amd import overlap, synth
+    from muchsalsa_amd._lib import EDGE_DTYPE, ORDER_DTYPE
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    w = WORKLOADS[args.workload]
+    rows = synth.synth_rows(w["n_reads"], w["read_len"], w["n_anchors"], w["seed"])
+    d_rows = torch.from_numpy(rows.view(np.uint8).copy()).to(dev)  # the accepted-row table, resident in HBM
+    torch.cuda.synchronize()
+
+    ctx = overlap.OverlapContext(device=local_rank)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    if world > 1:
+        ctx.set_shard(rank, world)
+
+    def step():
+        ctx.load_rows_device(d_rows.data_ptr(), len(rows), keep_alive=d_rows)
+        ctx.calculate_edges()
+        ctx.chaining_and_overlaps()
+        c = ctx.counts()
+        if world > 1:
+            # merge the edge list: one all-gather of the per-rank edge / order / id tables over xGMI
+            mine = torch.tensor([c.n_edges, c.n_orders, c.n_ids], dtype=torch.int64, device=dev)
+            allc = torch.empty((world, 3), dtype=torch.int64, device=dev)
+            dist.all_gather_into_tensor(allc, mine)
+            mx = allc.max(dim=0).values.tolist()
+            nb = (mx[0] * EDGE_DTYPE.itemsize, mx[1] * ORDER_DTYPE.itemsize, mx[2] * 4)
+            off = (0, nb[0], nb[0] + nb[1])
+            slab = torch.empty(sum(nb), dtype=torch.uint8, device=dev)
+            ctx.copy_tables_device(d_edges=slab.data_ptr() + off[0], d_orders=slab.data_ptr() + off[1],
+                                   d_ids=slab.data_ptr() + off[2])
+            merged = torch.empty(world * sum(nb), dtype=torch.uint8, device=dev)
+            dist.all_gather_into_tensor(merged, slab)
+            return c, allc
+        return c, None
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    chain_ms = []
+    for _ in range(args.steps):
+        c, allc = step()
+        chain_ms.append(ctx.timings().chain_kernel_ms)  # HIP events on the launch stream (syncs that stream only)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    tm = ctx.timings()
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+        n_edges_total = int(allc[:, 0].sum().item())
+    else:
+        n_edges_total = int(c.n_edges)
+
+    if rank == 0:
+        ms_per_step = 1e3 * dt / args.steps
+        # algorithmic bytes of the dominant kernel (k_chain), SURVEY.md section 8(d):
+        #   96 B per EdgeMatch (32 B EdgeMatch written + two 32 B VertexMatch rows read) + 64 B per order + 4 B per id
+        alg_bytes = 96 * c.n_ems + 64 * c.n_orders + 4 * c.n_ids
+        k_ms = float(np.mean(chain_ms))
+        achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        out = {
+            "metric": "overlap-pairs/s", "value": n_edges_total / (dt / args.steps), "unit": "overlap-pairs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "int32+f64",
+            "data": "synthetic",
+            "config": {"workload": w["name"], "rows": int(len(rows)), "reads": int(c.n_reads),
+                       "anchors": int(c.n_anchors), "edges": n_edges_total, "edgematches_rank0": int(c.n_ems),
+                       "orders_rank0": int(c.n_orders), "parallelism": "edges sharded by v1 %% %d" % world,
+                       "consensus_mbases_per_s": None,
+                       "note": "consensus (assemblePath) stage not built yet; value is the overlap half of the metric"},
+            "stage_ms": {"index": tm.index_ms, "candidates": tm.candidates_ms, "chain_total": tm.chain_ms,
+                         "chain_kernel": k_ms, "compact": tm.compact_ms},
+            "roofline": {"bound": "hbm", "kernel": "k_chain", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": int(alg_bytes), "kernel_ms": k_ms},
+        }
+        if world == 1 and args.cpu_sample_reads > 0:
+            out["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_sample_reads)
+        print(json.dumps(out))
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
