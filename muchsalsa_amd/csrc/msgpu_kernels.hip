@@ -181,19 +181,26 @@ uint32_t scan_blocks(uint64_t n) { return static_cast<uint32_t>((n + 256 * SCAN_
 // ---------------------------------------------------------------------------------------------------------------------
 
 __global__ __launch_bounds__(256) void k_max_ids(const msgpu_row *rows, uint64_t n, uint32_t *max_ids /*[2]*/) {
-  uint64_t i  = static_cast<uint64_t>(blockIdx.x) * 256 + threadIdx.x;
-  uint32_t mr = 0, ma = 0;
-  if (i < n) {
-    mr = rows[i].read_id + 1;
-    ma = rows[i].anchor_id + 1;
+  // grid-stride, one atomic pair per workgroup (a single word takes only ~88 atomics/us on MI355X)
+  __shared__ uint32_t s_r[4], s_a[4];
+  uint32_t            mr = 0, ma = 0;
+  for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * 256 + threadIdx.x; i < n;
+       i += static_cast<uint64_t>(gridDim.x) * 256) {
+    mr = max(mr, rows[i].read_id + 1);
+    ma = max(ma, rows[i].anchor_id + 1);
   }
   for (int d = 32; d > 0; d >>= 1) {
     mr = max(mr, __shfl_down(mr, d));
     ma = max(ma, __shfl_down(ma, d));
   }
   if ((threadIdx.x & 63) == 0) {
-    atomicMax(&max_ids[0], mr);
-    atomicMax(&max_ids[1], ma);
+    s_r[threadIdx.x >> 6] = mr;
+    s_a[threadIdx.x >> 6] = ma;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicMax(&max_ids[0], max(max(s_r[0], s_r[1]), max(s_r[2], s_r[3])));
+    atomicMax(&max_ids[1], max(max(s_a[0], s_a[1]), max(s_a[2], s_a[3])));
   }
 }
 
@@ -485,16 +492,24 @@ template __global__ void k_candidates<1024, 8192>(CandArgs, const uint32_t *, ui
 __global__ __launch_bounds__(256) void k_classify_reads(const uint32_t *read_cnt, const uint32_t *bound, uint32_t V,
                                                         uint32_t shard, uint32_t nshards, uint32_t *list0,
                                                         uint32_t *list1, uint32_t *list2, uint32_t *n_lists /*[3]*/) {
-  uint32_t r = blockIdx.x * 256 + threadIdx.x;
-  if (r >= V || r % nshards != shard) return;
-  uint32_t n1 = read_cnt[r], bd = bound[r];
-  if (n1 == 0 || bd == 0) return;
-  if (n1 <= 256 && bd <= 1024)
-    list0[atomicAdd(&n_lists[0], 1u)] = r;
-  else if (n1 <= 1024 && bd <= 8192)
-    list1[atomicAdd(&n_lists[1], 1u)] = r;
-  else
-    list2[atomicAdd(&n_lists[2], 1u)] = r;
+  uint32_t r   = blockIdx.x * 256 + threadIdx.x;
+  int      cls = -1;
+  if (r < V && r % nshards == shard) {
+    uint32_t n1 = read_cnt[r], bd = bound[r];
+    if (n1 != 0 && bd != 0) cls = (n1 <= 256 && bd <= 1024) ? 0 : (n1 <= 1024 && bd <= 8192) ? 1 : 2;
+  }
+  // one atomic per wave and class
+  const int lane = threadIdx.x & 63;
+  uint32_t *lists[3] = {list0, list1, list2};
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    unsigned long long m = __ballot(cls == k);
+    if (!m) continue;
+    uint32_t base = 0;
+    if (lane == __builtin_ctzll(m)) base = atomicAdd(&n_lists[k], static_cast<uint32_t>(__popcll(m)));
+    base = __shfl(base, __builtin_ctzll(m));
+    if (cls == k) lists[k][base + static_cast<uint32_t>(__popcll(m & ((1ull << lane) - 1)))] = r;
+  }
 }
 
 // big reads: same algorithm with every staging array in global memory (slow path, any size)
@@ -645,103 +660,50 @@ struct PathRec {
   uint32_t pad;
 };
 
-// One direction of getMaxPairwisePaths (mpp.cpp:145-305) for an edge with <= 64 EdgeMatches.
-// `act` = lanes whose EdgeMatch has this direction.  Results appended to paths[*n_paths..].
-__device__ __forceinline__ int chain_direction(unsigned long long act, bool direction, int lane, double em_score,
-                                               bool em_prim, int rlo1, int rhi1, double clo1, double chi1, int rlo2,
-                                               int rhi2, double clo2, double chi2, uint32_t j1, uint32_t q2, uint32_t n1,
-                                               uint32_t n2, double wiggle, double ratio_pct, double alt_frac,
-                                               PathRec *paths) {
+// Element of an edge as the compatibility test needs it: corrected + raw nanopore ranges on both vertices. 48 bytes,
+// read from LDS with three 16-byte loads.
+struct __attribute__((aligned(16))) ChainElem {
+  double clo1, chi1;
+  double clo2, chi2;
+  int    rlo1, rhi1, rlo2, rhi2;
+};
+
+// nanoCheck (mpp.cpp:40-118) for one vertex: "1" = K (illuminaId1), "2" = L.  Returns abort; orientation/diff by ref.
+__device__ __forceinline__ bool nano_check(double k_clo, double k_chi, double l_clo, double l_chi, int k_rlo, int k_rhi,
+                                           int l_rlo, int l_rhi, int &o, double &d) {
+  o = 0;
+  d = 0;
+  if (k_clo <= l_chi && l_clo <= k_chi) {
+    if (k_clo < l_clo && k_chi < l_chi) {
+      o = 2;
+      d = k_chi - l_clo + 1;
+    }
+    if (k_clo > l_clo && k_chi > l_chi) {
+      o = -2;
+      d = l_chi - k_clo + 1;
+    }
+  } else if (k_clo < l_clo) {
+    o = 1;
+    d = l_clo - k_chi + 1;
+  } else {
+    o = -1;
+    d = k_clo - l_chi + 1;
+  }
+  if (k_rlo <= l_rhi && l_rlo <= k_rhi) {
+    int uco = 0;
+    if (k_rlo < l_rlo && k_rhi < l_rhi) uco = 2;
+    if (k_rlo > l_rlo && k_rhi > l_rhi) uco = -2;
+    if ((o < 0 && uco >= 0) || (o > 0 && uco <= 0)) return true;
+  }
+  return false;
+}
+
+// Post-DP part of getMaxPairwisePaths (mpp.cpp:201-302) for the lanes `act` of one direction.
+__device__ __forceinline__ int paths_of_direction(unsigned long long act, bool direction, int lane, double pop,
+                                                  uint64_t pm, bool em_prim, uint32_t j1, uint32_t q2, uint32_t n1,
+                                                  uint32_t n2, double alt_frac, PathRec *paths) {
   if (act == 0) return 0; // :150-152
   const bool mine = (act >> lane) & 1ull;
-  double     pop  = em_score;           // population[l].score, :181-183
-  uint64_t   pm   = 1ull << lane;       // path of population[l] incl. l itself (self index appended at :203)
-
-  // DP, :185-199.  Outer loop over k in vStart order; every lane l > k evaluates (k, l) at once.
-  for (unsigned long long rem = act; rem;) {
-    const int k = __builtin_ctzll(rem);
-    rem &= rem - 1;
-    if ((rem) == 0) break; // k is the last element: no l > k
-    const int    k_rlo1 = rl_i32(rlo1, k), k_rhi1 = rl_i32(rhi1, k), k_rlo2 = rl_i32(rlo2, k), k_rhi2 = rl_i32(rhi2, k);
-    const double k_clo1 = rl_f64(clo1, k), k_chi1 = rl_f64(chi1, k), k_clo2 = rl_f64(clo2, k), k_chi2 = rl_f64(chi2, k);
-    const double k_pop = rl_f64(pop, k);
-    const uint64_t k_pm = rl_u64(pm, k);
-    if (mine && lane > k) {
-      // checkCompatibility(k, l), mpp.cpp:38-142.  "1" = k (illuminaId1), "2" = this lane.
-      int    o1, o2;
-      double d1, d2;
-      bool   abort_ = false;
-      { // nanoCheck on vertices.first, :40-118
-        o1 = 0;
-        d1 = 0;
-        if (k_clo1 <= chi1 && clo1 <= k_chi1) {
-          if (k_clo1 < clo1 && k_chi1 < chi1) {
-            o1 = 2;
-            d1 = k_chi1 - clo1 + 1;
-          }
-          if (k_clo1 > clo1 && k_chi1 > chi1) {
-            o1 = -2;
-            d1 = chi1 - k_clo1 + 1;
-          }
-        } else if (k_clo1 < clo1) {
-          o1 = 1;
-          d1 = clo1 - k_chi1 + 1;
-        } else {
-          o1 = -1;
-          d1 = k_clo1 - chi1 + 1;
-        }
-        int uco = 0;
-        if (k_rlo1 <= rhi1 && rlo1 <= k_rhi1) {
-          if (k_rlo1 < rlo1 && k_rhi1 < rhi1) uco = 2;
-          if (k_rlo1 > rlo1 && k_rhi1 > rhi1) uco = -2;
-          if ((o1 < 0 && uco >= 0) || (o1 > 0 && uco <= 0)) abort_ = true;
-        }
-      }
-      { // nanoCheck on vertices.second
-        o2 = 0;
-        d2 = 0;
-        if (k_clo2 <= chi2 && clo2 <= k_chi2) {
-          if (k_clo2 < clo2 && k_chi2 < chi2) {
-            o2 = 2;
-            d2 = k_chi2 - clo2 + 1;
-          }
-          if (k_clo2 > clo2 && k_chi2 > chi2) {
-            o2 = -2;
-            d2 = chi2 - k_clo2 + 1;
-          }
-        } else if (k_clo2 < clo2) {
-          o2 = 1;
-          d2 = clo2 - k_chi2 + 1;
-        } else {
-          o2 = -1;
-          d2 = k_clo2 - chi2 + 1;
-        }
-        int uco = 0;
-        if (k_rlo2 <= rhi2 && rlo2 <= k_rhi2) {
-          if (k_rlo2 < rlo2 && k_rhi2 < rhi2) uco = 2;
-          if (k_rlo2 > rlo2 && k_rhi2 > rhi2) uco = -2;
-          if ((o2 < 0 && uco >= 0) || (o2 > 0 && uco <= 0)) abort_ = true;
-        }
-      }
-      bool matching = false;
-      if (!abort_) {
-        if (!direction) o2 = -o2; // :131 (EdgeMatch(k).direction == this pass's direction)
-        if (o1 == o2 && o1 != 0) {
-          const double mx = std_max(d1, d2);
-          const double df = mx - std_min(d1, d2);
-          matching        = (df <= wiggle) || (df * 100 / mx <= ratio_pct);
-        } else if ((o1 < 0 && o2 < 0) || (o1 > 0 && o2 > 0)) {
-          matching = d1 + d2 <= wiggle;
-        }
-      }
-      const double cand = k_pop + em_score; // :189
-      if (matching && cand > pop) {         // :190-197
-        pop = cand;
-        pm  = k_pm | (1ull << lane);
-      }
-    }
-  }
-
   // argmax, :201-210: strict > starting from 0.0, first maximum wins, iterator starts at begin()
   double best = mine ? pop : -1.0;
   int    bi   = mine ? lane : 64;
@@ -763,92 +725,93 @@ __device__ __forceinline__ int chain_direction(unsigned long long act, bool dire
     maxv = 0.0;
     maxi = __builtin_ctzll(act);
   }
+  maxi = __builtin_amdgcn_readfirstlane(maxi);
   const unsigned long long prim_lanes = __ballot(mine && em_prim);
   int                      np         = 0;
-  {
-    const uint64_t m  = rl_u64(pm, maxi);
-    bool           hp = (m & prim_lanes) != 0; // :217-219
-    hp |= __popcll(m) > 2;                     // :220
+  const uint64_t           m          = rl_u64(pm, maxi);
+  bool                     hp         = (m & prim_lanes) != 0; // :217-219
+  hp |= __popcll(m) > 2;                                       // :220
+  if (lane == 0) {
+    paths[0].mask    = m;
+    paths[0].score   = static_cast<uint64_t>(maxv);
+    paths[0].primary = hp;
+  }
+  np = 1;
+  // alternatives, :223-249: population order, score > 0.75*max, id-disjoint from every accepted path
+  const double       thr  = maxv * alt_frac;
+  uint64_t           used = m;
+  unsigned long long cand = __ballot(mine && pop > thr);
+  while (true) {
+    cand &= __ballot((pm & used) == 0); // a path that touches a used anchor can never become disjoint again
+    if (!cand) break;
+    const int      p  = __builtin_ctzll(cand);
+    const uint64_t mp = rl_u64(pm, p);
+    const double   sp = rl_f64(pop, p);
     if (lane == 0) {
-      paths[0].mask    = m;
-      paths[0].score   = static_cast<uint64_t>(maxv);
-      paths[0].primary = hp;
+      paths[np].mask    = mp;
+      paths[np].score   = static_cast<uint64_t>(sp);
+      paths[np].primary = (mp & prim_lanes) != 0;
     }
-    np = 1;
-    // alternatives, :223-249: population order, score > 0.75*max, id-disjoint from every accepted path
-    const double       thr  = maxv * alt_frac;
-    uint64_t           used = m;
-    unsigned long long cand = __ballot(mine && pop > thr);
-    while (true) {
-      cand &= __ballot((pm & used) == 0); // a path that touches a used anchor can never become disjoint again
-      if (!cand) break;
-      const int      p  = __builtin_ctzll(cand);
-      const uint64_t mp = rl_u64(pm, p);
-      const double   sp = rl_f64(pop, p);
-      if (lane == 0) {
-        paths[np].mask    = mp;
-        paths[np].score   = static_cast<uint64_t>(sp);
-        paths[np].primary = (mp & prim_lanes) != 0;
+    ++np;
+    used |= mp;
+    cand &= ~(1ull << p);
+  }
+  // single primary result, :251-302
+  if (np == 1 && hp) {
+    const int first = __builtin_ctzll(m), last = 63 - __builtin_clzll(m);
+    // position of each path anchor in v1's list is j1, in v2's (reversed when !direction) list is qe
+    const uint32_t qe = direction ? q2 : (n2 - 1 - q2);
+    const uint32_t jf = rl_u32(j1, first), jl = rl_u32(j1, last), qf = rl_u32(qe, first), ql = rl_u32(qe, last);
+    bool           demote;
+    if ((jf != 0 && qf != 0) || (jl != n1 - 1 && ql != n2 - 1)) {
+      demote = true; // :272-274
+    } else {
+      long long i = 0, jj = 0;
+      bool      is_shadow = false;
+      for (uint64_t rem = m; rem && !is_shadow;) { // :280-296
+        const int t = __builtin_ctzll(rem);
+        rem &= rem - 1;
+        const long long rs    = static_cast<long long>(rl_u32(j1, t)); // always >= i: the path follows v1's order
+        bool            inter = rs > i;
+        i                     = rs + 1;
+        long long re          = static_cast<long long>(rl_u32(qe, t));
+        if (re < jj) re = static_cast<long long>(n2); // std::find_if found nothing from position jj on
+        inter &= re > jj;
+        jj        = re + 1;
+        is_shadow = inter;
       }
-      ++np;
-      used |= mp;
-      cand &= ~(1ull << p);
+      demote = is_shadow;
     }
-    // single primary result, :251-302
-    if (np == 1 && hp) {
-      const int  first = __builtin_ctzll(m), last = 63 - __builtin_clzll(m);
-      // position of each path anchor in v1's list is j1, in v2's (reversed when !direction) list is qe
-      const uint32_t qe      = direction ? q2 : (n2 - 1 - q2);
-      const uint32_t jf = rl_u32(j1, first), jl = rl_u32(j1, last), qf = rl_u32(qe, first), ql = rl_u32(qe, last);
-      bool demote;
-      if ((jf != 0 && qf != 0) || (jl != n1 - 1 && ql != n2 - 1)) {
-        demote = true; // :272-274
-      } else {
-        long long i = 0, jj = 0;
-        bool      is_shadow = false;
-        for (uint64_t rem = m; rem && !is_shadow;) { // :280-296
-          const int t = __builtin_ctzll(rem);
-          rem &= rem - 1;
-          const long long rs = static_cast<long long>(rl_u32(j1, t)); // always >= i: the path follows v1's order
-          bool inter = rs > i;
-          i          = rs + 1;
-          long long re = static_cast<long long>(rl_u32(qe, t));
-          if (re < jj) re = static_cast<long long>(n2); // std::find_if found nothing from position jj on
-          inter &= re > jj;
-          jj        = re + 1;
-          is_shadow = inter;
-        }
-        demote = is_shadow;
-      }
-      if (demote && lane == 0) paths[0].primary = 0;
-    }
+    if (demote && lane == 0) paths[0].primary = 0;
   }
   return np;
 }
 
 __global__ __launch_bounds__(256) void k_chain(ChainArgs a) {
-  __shared__ PathRec s_paths[4][2][64];
+  __shared__ ChainElem s_el[4][64];
+  __shared__ uint64_t  s_cm[4][64];
+  __shared__ PathRec   s_paths[4][2][64];
   const int      wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const uint64_t e = static_cast<uint64_t>(blockIdx.x) * 4 + wave;
+  const uint64_t e = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(blockIdx.x * 4 + wave));
   if (e >= a.n_edges) return;
   const msgpu_edge ed = a.edges[e];
   const uint32_t   n  = ed.em_cnt;
-  if (n > 64) { // handled by k_chain_big
-    return;
-  }
+  if (n > 64) return; // handled by k_chain_big
   const uint64_t cp  = a.edge_cand[e];
   const bool     act = lane < static_cast<int>(n);
   const uint32_t v1 = ed.v1, v2 = ed.v2;
   const uint32_t n1 = a.read_cnt[v1], n2 = a.read_cnt[v2];
   const int      len1 = a.read_len[v1], len2 = a.read_len[v2];
+  ChainElem     *el = s_el[wave];
+  uint64_t      *cm = s_cm[wave];
 
-  // per-lane element: VertexMatch on v1 (row j of v1), VertexMatch on v2 (scaffold row t), EdgeMatch
+  // ---- per-lane element: VertexMatch on v1 (row j of v1), VertexMatch on v2 (scaffold row t), EdgeMatch ----------
   uint32_t j1 = 0, q2 = 0, anchor = 0;
-  int      rlo1 = 0, rhi1 = 0, rlo2 = 0, rhi2 = 0;
-  double   clo1 = 0, chi1 = 0, clo2 = 0, chi2 = 0, ovr1 = 0, ovr2 = 0, em_score = 0;
+  double   clo1 = 0, clo2 = 0, ovr1 = 0, ovr2 = 0, em_score = 0;
   bool     em_dir = false, em_prim = false;
+  cm[lane]        = 0;
   if (act) {
-    j1            = a.cand_j[cp + lane];
+    j1               = a.cand_j[cp + lane];
     const uint32_t t = a.cand_t[cp + lane];
     const IRow m1 = load_irow(&a.by_read[a.read_off[v1] + j1]);
     const IRow m2 = load_irow(&a.by_anchor[t]);
@@ -867,22 +830,15 @@ __global__ __launch_bounds__(256) void k_chain(ChainArgs a) {
     const double os  = static_cast<double>(om.score) * cl / ol;
     const double is_ = static_cast<double>(im.score) * cl / il;
     em_score         = os + is_;
-    msgpu_edgematch em;
-    em.ov_lo     = ov_lo;
-    em.ov_hi     = ov_hi;
-    em.score     = em_score;
-    em.anchor_id = anchor;
-    em.line      = om.line;
-    em.flags     = (em_dir ? 1u : 0u) | (em_prim ? 2u : 0u);
-    em.edge_idx  = static_cast<uint32_t>(e);
     {
       uint4 *q = reinterpret_cast<uint4 *>(&a.ems[ed.em_off + lane]);
-      q[0]     = make_uint4(static_cast<uint32_t>(em.ov_lo), static_cast<uint32_t>(em.ov_hi),
-                            static_cast<uint32_t>(__double_as_longlong(em.score)),
-                            static_cast<uint32_t>(__double_as_longlong(em.score) >> 32));
-      q[1]     = make_uint4(em.anchor_id, em.line, em.flags, em.edge_idx);
+      q[0]     = make_uint4(static_cast<uint32_t>(ov_lo), static_cast<uint32_t>(ov_hi),
+                            static_cast<uint32_t>(__double_as_longlong(em_score)),
+                            static_cast<uint32_t>(__double_as_longlong(em_score) >> 32));
+      q[1]     = make_uint4(anchor, om.line, (em_dir ? 1u : 0u) | (em_prim ? 2u : 0u), static_cast<uint32_t>(e));
     }
     // corrected nanopore ranges (mpp.cpp:48-65) and overhangs (ol.cpp:37-47) on both vertices
+    ChainElem x;
     {
       const double rr  = static_cast<double>(m1.i_hi - m1.i_lo + 1) / static_cast<double>(m1.n_hi - m1.n_lo + 1);
       double       ncl = static_cast<double>(ov_lo - m1.i_lo) / rr;
@@ -892,11 +848,11 @@ __global__ __launch_bounds__(256) void k_chain(ChainArgs a) {
         ncl        = ncr;
         ncr        = tmp;
       }
-      rlo1 = m1.n_lo;
-      rhi1 = m1.n_hi;
-      clo1 = static_cast<double>(m1.n_lo) + ncl; // == overhangLeft
-      chi1 = static_cast<double>(m1.n_hi) - ncr;
-      ovr1 = static_cast<double>(len1 - m1.n_hi) + ncr;
+      x.rlo1 = m1.n_lo;
+      x.rhi1 = m1.n_hi;
+      x.clo1 = static_cast<double>(m1.n_lo) + ncl; // == overhangLeft
+      x.chi1 = static_cast<double>(m1.n_hi) - ncr;
+      ovr1   = static_cast<double>(len1 - m1.n_hi) + ncr;
     }
     {
       const double rr  = static_cast<double>(m2.i_hi - m2.i_lo + 1) / static_cast<double>(m2.n_hi - m2.n_lo + 1);
@@ -907,36 +863,100 @@ __global__ __launch_bounds__(256) void k_chain(ChainArgs a) {
         ncl        = ncr;
         ncr        = tmp;
       }
-      rlo2 = m2.n_lo;
-      rhi2 = m2.n_hi;
-      clo2 = static_cast<double>(m2.n_lo) + ncl;
-      chi2 = static_cast<double>(m2.n_hi) - ncr;
-      ovr2 = static_cast<double>(len2 - m2.n_hi) + ncr;
+      x.rlo2 = m2.n_lo;
+      x.rhi2 = m2.n_hi;
+      x.clo2 = static_cast<double>(m2.n_lo) + ncl;
+      x.chi2 = static_cast<double>(m2.n_hi) - ncr;
+      ovr2   = static_cast<double>(len2 - m2.n_hi) + ncr;
+    }
+    clo1     = x.clo1;
+    clo2     = x.clo2;
+    el[lane] = x;
+  }
+  const unsigned long long m_plus = __ballot(act && em_dir), m_minus = __ballot(act && !em_dir);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+
+  // ---- checkCompatibility (mpp.cpp:38-142) for every pair k < l of one direction, all 64 lanes busy ---------------
+  // pair p = l(l-1)/2 + k, row-major over l; a lane handles p = it*64 + lane
+  const int P = static_cast<int>(n * (n - 1) / 2);
+  for (int p0 = 0; p0 < P; p0 += 64) {
+    const int p  = p0 + lane;
+    bool      ok = false;
+    int       k = 0, l = 1;
+    if (p < P) {
+      l = static_cast<int>((1.0f + __fsqrt_rn(1.0f + 8.0f * static_cast<float>(p))) * 0.5f);
+      if (l * (l - 1) / 2 > p) --l;
+      if ((l + 1) * l / 2 <= p) ++l;
+      k                  = p - l * (l - 1) / 2;
+      const bool kd      = (m_plus >> k) & 1ull, ld = (m_plus >> l) & 1ull;
+      if (kd == ld) {
+        const ChainElem K = el[k], L = el[l];
+        int             o1, o2;
+        double          d1, d2;
+        bool            abort_ = nano_check(K.clo1, K.chi1, L.clo1, L.chi1, K.rlo1, K.rhi1, L.rlo1, L.rhi1, o1, d1);
+        abort_ |= nano_check(K.clo2, K.chi2, L.clo2, L.chi2, K.rlo2, K.rhi2, L.rlo2, L.rhi2, o2, d2);
+        if (!kd) o2 = -o2; // :131 EdgeMatch(k).direction
+        bool need_div = false;
+        double df = 0, mx = 1;
+        if (!abort_) {
+          if (o1 == o2 && o1 != 0) {
+            mx       = std_max(d1, d2);
+            df       = mx - std_min(d1, d2);
+            ok       = df <= a.wiggle;
+            need_div = !ok;
+          } else if ((o1 < 0 && o2 < 0) || (o1 > 0 && o2 > 0)) {
+            ok = d1 + d2 <= a.wiggle;
+          }
+        }
+        // the fp64 division of :136 only where the first test failed (rare for true overlaps)
+        if (need_div) ok = (df * 100 / mx <= a.ratio_pct);
+      }
+    }
+    const unsigned long long bits = __ballot(ok);
+    // the pairs of row l are consecutive lanes; the first lane of each run stores the run's bits
+    if (p < P && (k == 0 || lane == 0)) {
+      const int          len = min(l - k, 64 - lane);
+      unsigned long long seg = bits >> lane;
+      if (len < 64) seg &= (1ull << len) - 1;
+      cm[l] |= seg << k;
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  const uint64_t mycm = cm[lane]; // bit k: checkCompatibility(k, lane) for k < lane of the same direction
+
+  // ---- chaining DP (mpp.cpp:181-199), both directions at once: they never share a compatible pair -----------------
+  double   pop = em_score;      // population[l].score
+  uint64_t pm  = 1ull << lane;  // path of population[l] incl. l itself (self index appended at :203)
+  for (int k = 0; k + 1 < static_cast<int>(n); ++k) {
+    const double   k_pop = rl_f64(pop, k);
+    const uint64_t k_pm  = rl_u64(pm, k);
+    const double   cand  = k_pop + em_score; // :189
+    if (((mycm >> k) & 1ull) && cand > pop) { // :190-197
+      pop = cand;
+      pm  = k_pm | (1ull << lane);
     }
   }
 
-  // src/main.cpp:341-353: split by EdgeMatch direction, chain minus then plus
-  const unsigned long long m_plus = __ballot(act && em_dir), m_minus = __ballot(act && !em_dir);
-  PathRec *pm = s_paths[wave][0], *pp = s_paths[wave][1];
-  const int n_m = chain_direction(m_minus, false, lane, em_score, em_prim, rlo1, rhi1, clo1, chi1, rlo2, rhi2, clo2,
-                                  chi2, j1, q2, n1, n2, a.wiggle, a.ratio_pct, a.alt_frac, pm);
-  const int n_p = chain_direction(m_plus, true, lane, em_score, em_prim, rlo1, rhi1, clo1, chi1, rlo2, rhi2, clo2, chi2,
-                                  j1, q2, n1, n2, a.wiggle, a.ratio_pct, a.alt_frac, pp);
+  // src/main.cpp:341-353: split by EdgeMatch direction, minus then plus
+  PathRec  *pmn = s_paths[wave][0], *ppl = s_paths[wave][1];
+  const int n_m = paths_of_direction(m_minus, false, lane, pop, pm, em_prim, j1, q2, n1, n2, a.alt_frac, pmn);
+  const int n_p = paths_of_direction(m_plus, true, lane, pop, pm, em_prim, j1, q2, n1, n2, a.alt_frac, ppl);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
-  __threadfence_block();
 
-  // filters of src/main.cpp:355-387 on the union of both lists.  lane p < n_m: minus path p;
-  // lane 32.. not needed: at most 64 paths per direction, handle minus on pass 0 and plus on pass 1.
-  bool     k_m = false, k_p = false; // keep flags of path `lane` in each list
+  // filters of src/main.cpp:355-387 on the union of both lists: lane p holds path p of each list
+  bool     k_m = false, k_p = false;
   uint32_t prim_m = 0, prim_p = 0, len_m = 0, len_p = 0;
   if (lane < n_m) {
-    prim_m = pm[lane].primary;
-    len_m  = static_cast<uint32_t>(__popcll(pm[lane].mask));
+    prim_m = pmn[lane].primary;
+    len_m  = static_cast<uint32_t>(__popcll(pmn[lane].mask));
     k_m    = true;
   }
   if (lane < n_p) {
-    prim_p = pp[lane].primary;
-    len_p  = static_cast<uint32_t>(__popcll(pp[lane].mask));
+    prim_p = ppl[lane].primary;
+    len_p  = static_cast<uint32_t>(__popcll(ppl[lane].mask));
     k_p    = true;
   }
   const bool has_primary = __ballot((k_m && prim_m) || (k_p && prim_p)) != 0;
@@ -964,7 +984,7 @@ __global__ __launch_bounds__(256) void k_chain(ChainArgs a) {
   uint32_t n_orders = 0, n_ids = 0;
   for (int pass = 0; pass < 2; ++pass) {
     unsigned long long keep = pass == 0 ? keep_m : keep_p;
-    const PathRec     *pv   = pass == 0 ? pm : pp;
+    const PathRec     *pv   = pass == 0 ? pmn : ppl;
     const bool         dir  = pass == 1;
     while (keep) {
       const int pi = __builtin_ctzll(keep);
@@ -1437,7 +1457,10 @@ __global__ __launch_bounds__(256) void k_compact(CompactArgs a) {
 static inline dim3 grid1(uint64_t n, uint32_t per_block) { return dim3(static_cast<uint32_t>((n + per_block - 1) / per_block)); }
 
 void launch_max_ids(hipStream_t st, const msgpu_row *rows, uint64_t n, uint32_t *max_ids) {
-  if (n) hipLaunchKernelGGL(k_max_ids, grid1(n, 256), dim3(256), 0, st, rows, n, max_ids);
+  if (n) {
+    uint64_t nb = (n + 255) / 256;
+    hipLaunchKernelGGL(k_max_ids, dim3(static_cast<uint32_t>(nb < 2048 ? nb : 2048)), dim3(256), 0, st, rows, n, max_ids);
+  }
 }
 void launch_hist_read(hipStream_t st, const msgpu_row *rows, uint64_t n, uint32_t *cnt_read, uint64_t *first_key) {
   if (n)
