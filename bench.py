@@ -68,7 +68,7 @@ def main():
 
     import torch
     import torch.distributed as dist
-    from muchsalsa_amd import overlap, synth
+    from muchsalsa_amd import distributed as D, overlap, synth
     from muchsalsa_amd._lib import EDGE_DTYPE, ORDER_DTYPE
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -97,18 +97,18 @@ def main():
         ctx.chaining_and_overlaps()
         c = ctx.counts()
         if world > 1:
-            # merge the edge list: one all-gather of the per-rank edge / order / id tables over xGMI
-            mine = torch.tensor([c.n_edges, c.n_orders, c.n_ids], dtype=torch.int64, device=dev)
-            allc = torch.empty((world, 3), dtype=torch.int64, device=dev)
-            dist.all_gather_into_tensor(allc, mine)
-            mx = allc.max(dim=0).values.tolist()
-            nb = (mx[0] * EDGE_DTYPE.itemsize, mx[1] * ORDER_DTYPE.itemsize, mx[2] * 4)
-            off = (0, nb[0], nb[0] + nb[1])
-            slab = torch.empty(sum(nb), dtype=torch.uint8, device=dev)
-            ctx.copy_tables_device(d_edges=slab.data_ptr() + off[0], d_orders=slab.data_ptr() + off[1],
-                                   d_ids=slab.data_ptr() + off[2])
-            merged = torch.empty(world * sum(nb), dtype=torch.uint8, device=dev)
-            dist.all_gather_into_tensor(merged, slab)
+            # merge the edge list: ONE all-gather of the per-rank (edges | orders | ids) slab over xGMI, then the
+            # HIP compaction/re-base kernel (msgpu_merge_gathered)
+            def fill(slab, offs):
+                ctx.copy_tables_device(d_edges=slab.data_ptr() + offs[0], d_orders=slab.data_ptr() + offs[1],
+                                       d_ids=slab.data_ptr() + offs[2])
+            gathered, allc, offs, slab_bytes = D.gather_slabs((c.n_edges, c.n_orders, c.n_ids), fill, dev)
+            tot = allc.sum(axis=0)
+            m_e = torch.empty(max(int(tot[0]), 1) * EDGE_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+            m_o = torch.empty(max(int(tot[1]), 1) * ORDER_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+            m_i = torch.empty(max(int(tot[2]), 1) * 4, dtype=torch.uint8, device=dev)
+            ctx.merge_gathered(gathered.data_ptr(), allc, slab_bytes, offs, m_e.data_ptr(), m_o.data_ptr(),
+                               m_i.data_ptr())
             return c, allc
         return c, None
 
@@ -131,7 +131,7 @@ def main():
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-        n_edges_total = int(allc[:, 0].sum().item())
+        n_edges_total = int(allc[:, 0].sum())
     else:
         n_edges_total = int(c.n_edges)
 

@@ -202,6 +202,16 @@ int msgpu_copy_tables_device(msgpu_ctx *ctx, void *d_edges, void *d_ems, void *d
 /* Per-read Vertex facts: Vertex::getNanoporeLength() and metaDatum(0) (first line), n_reads entries each (host). */
 int msgpu_copy_reads(msgpu_ctx *ctx, int32_t *read_len, uint32_t *read_first_line);
 
+/* Multi-GPU merge of the edge list (north_star: "a single RCCL all-gather over xGMI to merge the edge list").
+ * Input: the result of ONE all-gather of equally sized slabs, slab r (from rank r) at d_gathered + r*slab_bytes,
+ * holding that rank's edge / order / id tables at off_edges / off_orders / off_ids (padding after each is ignored).
+ * counts = world x {n_edges, n_orders, n_ids} (host).  Output (device): dense rank-major tables with order_off,
+ * edge_idx and ids_off re-based to the merged tables; em_off stays rank-local (EdgeMatch tables are not gathered).
+ * The reference has no counterpart (single process); consumed like graph.getEdges() + Edge::getEdgeOrders(). */
+int msgpu_merge_gathered(msgpu_ctx *ctx, const void *d_gathered, uint32_t world, const uint64_t *counts,
+                         uint64_t slab_bytes, uint64_t off_edges, uint64_t off_orders, uint64_t off_ids, void *d_edges,
+                         void *d_orders, void *d_ids);
+
 /* Block the host until everything queued on the context's stream has finished. */
 int msgpu_synchronize(msgpu_ctx *ctx);
 

@@ -72,6 +72,8 @@ SYMBOLS = [
     ("msgpu_copy_tables", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("msgpu_copy_tables_device", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("msgpu_copy_reads", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("msgpu_merge_gathered", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_uint64,
+                                       C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("msgpu_synchronize", C.c_int, [C.c_void_p]),
 ]
 

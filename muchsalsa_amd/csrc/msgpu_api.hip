@@ -564,6 +564,34 @@ int msgpu_copy_reads(msgpu_ctx *c, int32_t *read_len, uint32_t *read_first_line)
   return MSGPU_OK;
 }
 
+int msgpu_merge_gathered(msgpu_ctx *c, const void *d_gathered, uint32_t world, const uint64_t *counts,
+                         uint64_t slab_bytes, uint64_t off_edges, uint64_t off_orders, uint64_t off_ids, void *d_edges,
+                         void *d_orders, void *d_ids) {
+  if (!c) return MSGPU_E_ARG;
+  if (!d_gathered || !counts || world == 0 || world > MAX_WORLD) return fail(c, MSGPU_E_ARG, "bad merge arguments");
+  HIPCHK(c, hipSetDevice(c->device));
+  MergeArgs a;
+  a.gathered   = static_cast<const uint8_t *>(d_gathered);
+  a.slab_bytes = slab_bytes;
+  a.off_edges  = off_edges;
+  a.off_orders = off_orders;
+  a.off_ids    = off_ids;
+  a.world      = world;
+  a.base[0]    = MergeBase{0, 0, 0};
+  for (uint32_t r = 0; r < world; ++r) {
+    a.base[r + 1].edges  = a.base[r].edges + counts[3 * r + 0];
+    a.base[r + 1].orders = a.base[r].orders + counts[3 * r + 1];
+    a.base[r + 1].ids    = a.base[r].ids + counts[3 * r + 2];
+  }
+  if (a.base[world].edges >= 0xfffffff0ull) return fail(c, MSGPU_E_ARG, "merged edge table too large");
+  a.edges  = static_cast<msgpu_edge *>(d_edges);
+  a.orders = static_cast<msgpu_order *>(d_orders);
+  a.ids    = static_cast<uint32_t *>(d_ids);
+  launch_merge_gathered(c->stream, a);
+  HIPCHK(c, hipGetLastError());
+  return MSGPU_OK;
+}
+
 int msgpu_synchronize(msgpu_ctx *c) {
   if (!c) return MSGPU_E_ARG;
   HIPCHK(c, hipStreamSynchronize(c->stream));

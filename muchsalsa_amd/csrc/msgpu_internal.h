@@ -60,6 +60,20 @@ struct CompactArgs {
   uint32_t          *ids;
 };
 
+constexpr uint32_t MAX_WORLD = 64;
+struct MergeBase {
+  uint64_t edges, orders, ids;
+};
+struct MergeArgs {
+  const uint8_t *gathered;
+  uint64_t       slab_bytes, off_edges, off_orders, off_ids;
+  uint32_t       world;
+  MergeBase      base[MAX_WORLD + 1]; // exclusive prefix over ranks; base[world] = totals
+  msgpu_edge    *edges;
+  msgpu_order   *orders;
+  uint32_t      *ids;
+};
+
 template <class T> void exclusive_scan(hipStream_t st, const uint32_t *in, uint64_t n, T *out, T *block_sums, T *d_total);
 uint32_t scan_blocks(uint64_t n);
 
@@ -95,6 +109,7 @@ size_t big_elem_bytes();
 size_t big_path_bytes();
 void launch_chain_big(hipStream_t st, const ChainArgs &a, const uint32_t *big_list, uint32_t n_big, void *elems,
                       void *paths);
+void launch_merge_gathered(hipStream_t st, const MergeArgs &a);
 void launch_compact(hipStream_t st, const CompactArgs &a);
 
 } // namespace msgpu

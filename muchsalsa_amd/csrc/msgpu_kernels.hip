@@ -669,33 +669,30 @@ struct __attribute__((aligned(16))) ChainElem {
 };
 
 // nanoCheck (mpp.cpp:40-118) for one vertex: "1" = K (illuminaId1), "2" = L.  Returns abort; orientation/diff by ref.
+// Branch-free restatement: the four (orientation, diff) cases of :67-91 are mutually exclusive, and
+//   diff = (c1.second - c2.first) + 1   (o = +2)      (c2.first - c1.second) + 1 = -(c1.second - c2.first) + 1  (o = +1)
+//   diff = (c2.second - c1.first) + 1   (o = -2)      (c1.first - c2.second) + 1 = -(c2.second - c1.first) + 1  (o = -1)
+// (negation is exact in IEEE arithmetic, so the two subtractions below reproduce all four differences bit for bit).
 __device__ __forceinline__ bool nano_check(double k_clo, double k_chi, double l_clo, double l_chi, int k_rlo, int k_rhi,
                                            int l_rlo, int l_rhi, int &o, double &d) {
-  o = 0;
-  d = 0;
-  if (k_clo <= l_chi && l_clo <= k_chi) {
-    if (k_clo < l_clo && k_chi < l_chi) {
-      o = 2;
-      d = k_chi - l_clo + 1;
-    }
-    if (k_clo > l_clo && k_chi > l_chi) {
-      o = -2;
-      d = l_chi - k_clo + 1;
-    }
-  } else if (k_clo < l_clo) {
-    o = 1;
-    d = l_clo - k_chi + 1;
-  } else {
-    o = -1;
-    d = k_clo - l_chi + 1;
-  }
-  if (k_rlo <= l_rhi && l_rlo <= k_rhi) {
-    int uco = 0;
-    if (k_rlo < l_rlo && k_rhi < l_rhi) uco = 2;
-    if (k_rlo > l_rlo && k_rhi > l_rhi) uco = -2;
-    if ((o < 0 && uco >= 0) || (o > 0 && uco <= 0)) return true;
-  }
-  return false;
+  const bool ovl   = (k_clo <= l_chi) & (l_clo <= k_chi);
+  const bool lt_lo = k_clo < l_clo;
+  const bool fwd2  = ovl & lt_lo & (k_chi < l_chi);
+  const bool bwd2  = ovl & (k_clo > l_clo) & (k_chi > l_chi);
+  const bool fwd1  = (!ovl) & lt_lo;
+  const bool bwd1  = (!ovl) & (!lt_lo);
+  const bool fwd   = fwd2 | fwd1;
+  const double x   = k_chi - l_clo;
+  const double y   = l_chi - k_clo;
+  double       t   = fwd ? x : y;
+  t                = (fwd1 | bwd1) ? -t : t;
+  d                = (fwd | bwd2 | bwd1) ? t + 1 : 0.0;
+  o                = fwd2 ? 2 : bwd2 ? -2 : fwd1 ? 1 : bwd1 ? -1 : 0;
+  const bool rovl  = (k_rlo <= l_rhi) & (l_rlo <= k_rhi);
+  const bool u2    = (k_rlo < l_rlo) & (k_rhi < l_rhi);
+  const bool um2   = (k_rlo > l_rlo) & (k_rhi > l_rhi);
+  // abort when the raw ranges overlap and their order contradicts the corrected orientation (:93-109)
+  return rovl & (((o < 0) & !um2) | ((o > 0) & !u2));
 }
 
 // Post-DP part of getMaxPairwisePaths (mpp.cpp:201-302) for the lanes `act` of one direction.
@@ -896,21 +893,15 @@ __global__ __launch_bounds__(256) void k_chain(ChainArgs a) {
         double          d1, d2;
         bool            abort_ = nano_check(K.clo1, K.chi1, L.clo1, L.chi1, K.rlo1, K.rhi1, L.rlo1, L.rhi1, o1, d1);
         abort_ |= nano_check(K.clo2, K.chi2, L.clo2, L.chi2, K.rlo2, K.rhi2, L.rlo2, L.rhi2, o2, d2);
-        if (!kd) o2 = -o2; // :131 EdgeMatch(k).direction
-        bool need_div = false;
-        double df = 0, mx = 1;
-        if (!abort_) {
-          if (o1 == o2 && o1 != 0) {
-            mx       = std_max(d1, d2);
-            df       = mx - std_min(d1, d2);
-            ok       = df <= a.wiggle;
-            need_div = !ok;
-          } else if ((o1 < 0 && o2 < 0) || (o1 > 0 && o2 > 0)) {
-            ok = d1 + d2 <= a.wiggle;
-          }
-        }
+        o2 = kd ? o2 : -o2; // :131 EdgeMatch(k).direction
+        const bool   same  = (o1 == o2) & (o1 != 0);                       // :133
+        const bool   codir = ((o1 < 0) & (o2 < 0)) | ((o1 > 0) & (o2 > 0)); // :137
+        const double mx    = std_max(d1, d2);
+        const double df    = mx - std_min(d1, d2);
+        const bool   near_ = df <= a.wiggle;
+        ok                 = (!abort_) & (same ? near_ : (codir & (d1 + d2 <= a.wiggle)));
         // the fp64 division of :136 only where the first test failed (rare for true overlaps)
-        if (need_div) ok = (df * 100 / mx <= a.ratio_pct);
+        if ((!abort_) & same & !near_) ok = (df * 100 / mx <= a.ratio_pct);
       }
     }
     const unsigned long long bits = __ballot(ok);
@@ -1451,6 +1442,43 @@ __global__ __launch_bounds__(256) void k_compact(CompactArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// multi-GPU merge: after the all-gather every rank holds `world` padded slabs (edges | orders | ids); compact them into
+// dense rank-major tables and re-base the cross references (edge -> orders, order -> edge, order -> ids).
+// EdgeMatch offsets (em_off) stay rank-local: EdgeMatch tables are not gathered.
+// ---------------------------------------------------------------------------------------------------------------------
+
+__global__ __launch_bounds__(256) void k_merge_gathered(MergeArgs a) {
+  const uint64_t i = static_cast<uint64_t>(blockIdx.x) * 256 + threadIdx.x;
+  const uint64_t nE = a.base[a.world].edges, nO = a.base[a.world].orders, nI = a.base[a.world].ids;
+  if (i < nE) {
+    uint32_t r = 0;
+    while (i >= a.base[r + 1].edges) ++r;
+    const uint64_t    k  = i - a.base[r].edges;
+    const msgpu_edge *src = reinterpret_cast<const msgpu_edge *>(a.gathered + r * a.slab_bytes + a.off_edges);
+    msgpu_edge        e  = src[k];
+    e.order_off += a.base[r].orders;
+    a.edges[i] = e;
+  }
+  if (i < nO) {
+    uint32_t r = 0;
+    while (i >= a.base[r + 1].orders) ++r;
+    const uint64_t     k   = i - a.base[r].orders;
+    const msgpu_order *src = reinterpret_cast<const msgpu_order *>(a.gathered + r * a.slab_bytes + a.off_orders);
+    msgpu_order        o   = src[k];
+    o.edge_idx += static_cast<uint32_t>(a.base[r].edges);
+    o.ids_off += a.base[r].ids;
+    a.orders[i] = o;
+  }
+  if (i < nI) {
+    uint32_t r = 0;
+    while (i >= a.base[r + 1].ids) ++r;
+    const uint64_t  k   = i - a.base[r].ids;
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(a.gathered + r * a.slab_bytes + a.off_ids);
+    a.ids[i]            = src[k];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // host-callable launchers
 // ---------------------------------------------------------------------------------------------------------------------
 
@@ -1550,6 +1578,12 @@ void launch_chain_big(hipStream_t st, const ChainArgs &a, const uint32_t *big_li
   if (n_big)
     hipLaunchKernelGGL(k_chain_big, dim3(n_big), dim3(64), 0, st, a, big_list, n_big, static_cast<BigElem *>(elems),
                        static_cast<BigPath *>(paths));
+}
+void launch_merge_gathered(hipStream_t st, const MergeArgs &a) {
+  uint64_t n = a.base[a.world].edges;
+  if (a.base[a.world].orders > n) n = a.base[a.world].orders;
+  if (a.base[a.world].ids > n) n = a.base[a.world].ids;
+  if (n) hipLaunchKernelGGL(k_merge_gathered, grid1(n, 256), dim3(256), 0, st, a);
 }
 void launch_compact(hipStream_t st, const CompactArgs &a) {
   if (a.n_edges) hipLaunchKernelGGL(k_compact, grid1(a.n_edges, 256), dim3(256), 0, st, a);

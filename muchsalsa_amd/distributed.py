@@ -1,0 +1,143 @@
+"""Multi-GPU exchange of the overlap tables: one process per GPU, torch.distributed (RCCL over xGMI; gloo on CPU).
+
+Sharding: every rank loads the full row table and owns the edges whose first vertex v1
+satisfies v1 % world == rank (msgpu_set_shard).  There is no collective on the data path before the results exist;
+the only exchange is ONE all-gather of the per-rank (edges | orders | ids) slab ("merge the edge list").
+
+`gather_slabs` is the protocol (device-agnostic: CUDA tensors + nccl on GPUs, CPU tensors + gloo in tests).
+On GPUs the gathered slabs are compacted and re-based by the HIP kernel behind msgpu_merge_gathered;
+`merge_tables_host` is the host-side statement of the same merge used to check it.
+"""
+import numpy as np
+
+from ._lib import EDGE_DTYPE, ORDER_DTYPE
+
+ALIGN = 256  # sub-table alignment inside a slab (bytes)
+
+
+def shard_of(v1, world):
+    """Owner rank of an edge: its first vertex modulo the world size."""
+    return v1 % world
+
+
+def _round_up(n, a=ALIGN):
+    return (n + a - 1) // a * a
+
+
+def slab_layout(max_counts):
+    """Byte offsets of (edges, orders, ids) inside a slab sized for the largest rank, and the slab size."""
+    ne, no, ni = (int(x) for x in max_counts)
+    off_e = 0
+    off_o = _round_up(off_e + ne * EDGE_DTYPE.itemsize)
+    off_i = _round_up(off_o + no * ORDER_DTYPE.itemsize)
+    size = _round_up(off_i + ni * 4)
+    return (off_e, off_o, off_i), max(size, ALIGN)
+
+
+def gather_slabs(counts, fill_slab, device, group=None):
+    """The exchange step.
+
+    counts     -- (n_edges, n_orders, n_ids) of this rank
+    fill_slab  -- callable(slab_uint8_tensor, offs) that writes this rank's three tables into the slab
+    returns (gathered uint8 tensor [world * slab_bytes], all_counts int64 ndarray [world, 3], offs, slab_bytes)
+    """
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    mine = torch.tensor([int(c) for c in counts], dtype=torch.int64, device=device)
+    allc = torch.empty(world * 3, dtype=torch.int64, device=device)  # flat: gloo rejects a 2-D output
+    dist.all_gather_into_tensor(allc, mine, group=group)
+    all_counts = allc.cpu().numpy().reshape(world, 3)
+    offs, slab_bytes = slab_layout(all_counts.max(axis=0))
+    slab = torch.zeros(slab_bytes, dtype=torch.uint8, device=device)
+    fill_slab(slab, offs)
+    gathered = torch.empty(world * slab_bytes, dtype=torch.uint8, device=device)
+    dist.all_gather_into_tensor(gathered, slab, group=group)  # the one collective of the path
+    return gathered, all_counts, offs, slab_bytes
+
+
+def split_gathered_host(gathered, all_counts, offs, slab_bytes):
+    """Host view of a gathered buffer: list of per-rank {edges, orders, ids} numpy tables."""
+    buf = np.asarray(gathered, dtype=np.uint8)
+    out = []
+    for r, (ne, no, ni) in enumerate(np.asarray(all_counts, dtype=np.int64)):
+        base = r * slab_bytes
+        out.append({
+            "edges": buf[base + offs[0]: base + offs[0] + ne * EDGE_DTYPE.itemsize].view(EDGE_DTYPE).copy(),
+            "orders": buf[base + offs[1]: base + offs[1] + no * ORDER_DTYPE.itemsize].view(ORDER_DTYPE).copy(),
+            "ids": buf[base + offs[2]: base + offs[2] + ni * 4].view("<u4").copy(),
+        })
+    return out
+
+
+def merge_tables_host(per_rank):
+    """Rank-major merge with re-based cross references (what msgpu_merge_gathered produces on the GPU)."""
+    eb = ob = ib = 0
+    edges, orders, ids = [], [], []
+    for t in per_rank:
+        e, o = t["edges"].copy(), t["orders"].copy()
+        e["order_off"] += ob
+        o["edge_idx"] += eb
+        o["ids_off"] += ib
+        edges.append(e)
+        orders.append(o)
+        ids.append(t["ids"])
+        eb += len(e)
+        ob += len(o)
+        ib += len(t["ids"])
+    cat = lambda xs, dt: np.concatenate(xs) if xs else np.zeros(0, dtype=dt)  # noqa: E731
+    return {"edges": cat(edges, EDGE_DTYPE), "orders": cat(orders, ORDER_DTYPE), "ids": cat(ids, "<u4")}
+
+
+def canonicalize(merged):
+    """Sort a merged (rank-major) edge list into the canonical single-GPU order: edges by (v1, v2), orders and ids
+    following their edges.  em_off is rank-local and left untouched (callers comparing with a single-GPU table
+    should ignore it).  Used by tests to prove that any GPU count gives the same edge list."""
+    e, o, ids = merged["edges"], merged["orders"], merged["ids"]
+    perm = np.lexsort((e["v2"], e["v1"]))
+    e2 = e[perm].copy()
+    o_parts, id_parts = [], []
+    ob = ib = 0
+    for k, src in enumerate(perm):
+        n = int(e[src]["order_cnt"])
+        oo = o[int(e[src]["order_off"]): int(e[src]["order_off"]) + n].copy()
+        e2[k]["order_off"] = ob
+        for q in range(n):
+            c = int(oo[q]["ids_cnt"])
+            id_parts.append(ids[int(oo[q]["ids_off"]): int(oo[q]["ids_off"]) + c])
+            oo[q]["ids_off"] = ib
+            oo[q]["edge_idx"] = k
+            ib += c
+        o_parts.append(oo)
+        ob += n
+    return {"edges": e2,
+            "orders": np.concatenate(o_parts) if o_parts else np.zeros(0, dtype=ORDER_DTYPE),
+            "ids": np.concatenate(id_parts) if id_parts else np.zeros(0, dtype="<u4")}
+
+
+def shard_view_host(tables, shard, world):
+    """The tables a shard produces, cut out of single-GPU tables (edges with v1 % world == shard, dense, re-based).
+    Test helper: states what msgpu_set_shard(shard, world) must return."""
+    e, em, o, ids = tables["edges"], tables["ems"], tables["orders"], tables["ids"]
+    keep = np.nonzero(e["v1"] % world == shard)[0]
+    e2 = e[keep].copy()
+    em_parts, o_parts, id_parts = [], [], []
+    mb = ob = ib = 0
+    for k, src in enumerate(keep):
+        ne, no = int(e[src]["em_cnt"]), int(e[src]["order_cnt"])
+        m = em[int(e[src]["em_off"]): int(e[src]["em_off"]) + ne].copy()
+        m["edge_idx"] = k
+        em_parts.append(m)
+        oo = o[int(e[src]["order_off"]): int(e[src]["order_off"]) + no].copy()
+        for q in range(no):
+            c = int(oo[q]["ids_cnt"])
+            id_parts.append(ids[int(oo[q]["ids_off"]): int(oo[q]["ids_off"]) + c])
+            oo[q]["ids_off"] = ib
+            oo[q]["edge_idx"] = k
+            ib += c
+        o_parts.append(oo)
+        e2[k]["em_off"], e2[k]["order_off"] = mb, ob
+        mb += ne
+        ob += no
+    cat = lambda xs, dt: np.concatenate(xs) if xs else np.zeros(0, dtype=dt)  # noqa: E731
+    return {"edges": e2, "ems": cat(em_parts, em.dtype), "orders": cat(o_parts, ORDER_DTYPE), "ids": cat(id_parts, "<u4")}

@@ -138,6 +138,13 @@ class OverlapContext:
         self._check(self._L.msgpu_copy_tables_device(self._h, C.c_void_p(d_edges), C.c_void_p(d_ems),
                                                      C.c_void_p(d_orders), C.c_void_p(d_ids)))
 
+    def merge_gathered(self, d_gathered, counts, slab_bytes, offs, d_edges, d_orders, d_ids):
+        """counts: world x 3 (n_edges, n_orders, n_ids); offs: byte offsets (edges, orders, ids) inside a slab."""
+        cnt = np.ascontiguousarray(counts, dtype="<u8")
+        self._check(self._L.msgpu_merge_gathered(self._h, C.c_void_p(d_gathered), cnt.shape[0], cnt.ctypes.data,
+                                                 slab_bytes, offs[0], offs[1], offs[2], C.c_void_p(d_edges),
+                                                 C.c_void_p(d_orders), C.c_void_p(d_ids)))
+
     def reads(self):
         c = self.counts()
         rl = np.zeros(c.n_reads, dtype="<i4")

@@ -1,0 +1,81 @@
+"""N > 1 exchange path on CPU: world_size 2, gloo.  Each rank holds the tables its shard would produce (cut out of
+the oracle's single-process tables), runs the real gather protocol of muchsalsa_amd.distributed and merges; the
+canonicalised merge must equal the single-process edge list on every rank."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from helpers import assert_tables_equal
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, rows_bytes, out_dir):
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path[:0] = [os.path.dirname(here), os.path.join(os.path.dirname(here), "oracle"), here]
+    import ms_oracle_ctypes as oracle
+    from muchsalsa_amd import distributed as D
+    from muchsalsa_amd._lib import ROW_DTYPE
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rows = np.frombuffer(rows_bytes, dtype=ROW_DTYPE)
+        full = oracle.overlap(rows)
+        mine = D.shard_view_host(full, rank, world)
+
+        def fill(slab, offs):
+            for name, off in zip(("edges", "orders", "ids"), offs):
+                b = torch.from_numpy(mine[name].view(np.uint8).copy())
+                slab[off: off + b.numel()] = b
+
+        counts = (len(mine["edges"]), len(mine["orders"]), len(mine["ids"]))
+        gathered, all_counts, offs, slab_bytes = D.gather_slabs(counts, fill, torch.device("cpu"))
+        per_rank = D.split_gathered_host(gathered.numpy(), all_counts, offs, slab_bytes)
+        merged = D.canonicalize(D.merge_tables_host(per_rank))
+        assert int(all_counts[:, 0].sum()) == len(full["edges"])
+        # em_off is rank-local by contract; everything else must equal the single-process tables
+        want = {k: full[k].copy() for k in ("edges", "orders", "ids")}
+        got = {k: merged[k] for k in ("edges", "orders", "ids")}
+        want["edges"]["em_off"] = 0
+        got["edges"]["em_off"] = 0
+        got["ems"] = want["ems"] = np.zeros(0, dtype=full["ems"].dtype)
+        assert_tables_equal(got, want, "rank %d" % rank)
+        open(os.path.join(out_dir, "ok%d" % rank), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_gather_and_merge_equals_single_process(tmp_path, world):
+    from muchsalsa_amd import synth
+    rows = synth.synth_rows(400, 4000, 1500, 5)
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, rows.tobytes(), str(tmp_path)), nprocs=world, join=True)
+    assert all(os.path.exists(tmp_path / ("ok%d" % r)) for r in range(world))
+
+
+def test_shard_views_partition_the_edge_list(oracle):
+    from muchsalsa_amd import distributed as D, synth
+    rows = synth.synth_rows(300, 3000, 900, 1)
+    full = oracle.overlap(rows)
+    for world in (1, 2, 4, 8):
+        shards = [D.shard_view_host(full, r, world) for r in range(world)]
+        assert sum(len(s["edges"]) for s in shards) == len(full["edges"])
+        assert sum(len(s["ems"]) for s in shards) == len(full["ems"])
+        merged = D.canonicalize(D.merge_tables_host(shards))
+        assert np.array_equal(merged["edges"]["v1"], full["edges"]["v1"])
+        assert np.array_equal(merged["edges"]["v2"], full["edges"]["v2"])
+        assert merged["orders"].tobytes() == full["orders"].tobytes() and merged["ids"].tobytes() == full["ids"].tobytes()

@@ -30,3 +30,147 @@ def test_empty_and_tiny(oracle):
         _, sub["read_id"] = np.unique(sub["read_id"], return_inverse=True)
         _, sub["anchor_id"] = np.unique(sub["anchor_id"], return_inverse=True)
         assert_tables_equal(_gpu_tables(sub), oracle.overlap(sub), "n=%d" % n)
+
+
+def test_hand_derived_cases(oracle):
+    """The known-answer vectors of test_golden_hand.py through the HIP path."""
+    import test_golden_hand as H
+    for name, rows in H.CASES.items():
+        got = _gpu_tables(rows)
+        assert_tables_equal(got, oracle.overlap(rows), name)
+    H.check_single_anchor(_gpu_tables(H.CASES["single_plus"]), True)
+    H.check_single_anchor(_gpu_tables(H.CASES["single_minus"]), False)
+
+
+def test_duplicates_and_row_order_do_not_matter(oracle):
+    """addVertexMatch keeps the lowest line of a (read, anchor) pair (MatchMap.cpp:64-80); row order is free."""
+    from muchsalsa_amd import synth
+    rows = synth.synth_rows(300, 4000, 1000, 9)
+    rng = np.random.default_rng(5)
+    dup = rows[rng.choice(len(rows), 200, replace=False)].copy()
+    dup["line"] = rows["line"].max() + 1 + np.arange(len(dup))
+    dup["n_lo"] += 7
+    allrows = np.concatenate([rows, dup])
+    rng.shuffle(allrows)
+    want = oracle.overlap(rows)
+    assert_tables_equal(_gpu_tables(allrows), want, "dups")
+
+
+def test_golden_fixtures():
+    """Committed golden tables (tests/golden/, made by tools/make_golden.py from the oracle)."""
+    import glob
+    import os
+    files = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+    assert files
+    for f in files:
+        z = np.load(f)
+        got = _gpu_tables(z["rows"])
+        assert_tables_equal(got, {k: z[k] for k in ("edges", "ems", "orders", "ids")}, os.path.basename(f))
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_shards_union_equals_single_gpu(oracle, world):
+    """Any GPU count gives the same edge list: run every shard (on this one GPU), check each against the cut of the
+    oracle's tables it must equal, merge on the device like the N-GPU path does, and compare with the 1-GPU result."""
+    import torch
+    from muchsalsa_amd import distributed as D, overlap, synth
+    from muchsalsa_amd._lib import EDGE_DTYPE, ORDER_DTYPE
+    rows = synth.synth_rows(1000, 5000, 4000, 13)
+    full = oracle.overlap(rows)
+    shards = []
+    for r in range(world):
+        t = _gpu_tables(rows, shard=r, n_shards=world)
+        assert_tables_equal(t, D.shard_view_host(full, r, world), "shard %d/%d" % (r, world))
+        shards.append(t)
+    counts = np.array([[len(t["edges"]), len(t["orders"]), len(t["ids"])] for t in shards], dtype=np.int64)
+    offs, slab_bytes = D.slab_layout(counts.max(axis=0))
+    gathered = np.zeros(world * slab_bytes, dtype=np.uint8)
+    for r, t in enumerate(shards):
+        for name, off in zip(("edges", "orders", "ids"), offs):
+            b = t[name].view(np.uint8)
+            gathered[r * slab_bytes + off: r * slab_bytes + off + len(b)] = b
+    dev = torch.device("cuda", 0)
+    d_g = torch.from_numpy(gathered).to(dev)
+    tot = counts.sum(axis=0)
+    d_e = torch.empty(max(int(tot[0]), 1) * EDGE_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+    d_o = torch.empty(max(int(tot[1]), 1) * ORDER_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+    d_i = torch.empty(max(int(tot[2]), 1) * 4, dtype=torch.uint8, device=dev)
+    with overlap.OverlapContext(0) as ctx:
+        ctx.merge_gathered(d_g.data_ptr(), counts, slab_bytes, offs, d_e.data_ptr(), d_o.data_ptr(), d_i.data_ptr())
+        ctx.synchronize()
+    merged = {"edges": d_e.cpu().numpy()[: int(tot[0]) * 32].view(EDGE_DTYPE),
+              "orders": d_o.cpu().numpy()[: int(tot[1]) * 64].view(ORDER_DTYPE),
+              "ids": d_i.cpu().numpy()[: int(tot[2]) * 4].view("<u4")}
+    host = D.merge_tables_host(shards)
+    for k in merged:
+        assert merged[k].tobytes() == host[k].tobytes(), k
+    canon = D.canonicalize(merged)
+    want = {k: full[k].copy() for k in ("edges", "orders", "ids")}
+    want["edges"]["em_off"] = 0
+    canon["edges"]["em_off"] = 0
+    canon["ems"] = want["ems"] = np.zeros(0, dtype=full["ems"].dtype)
+    assert_tables_equal(canon, want, "merged world=%d" % world)
+
+
+def test_api_state_and_id_checks():
+    from muchsalsa_amd import _lib, overlap, synth
+    rows = synth.synth_rows(100, 3000, 300, 2)
+    with overlap.OverlapContext(0) as ctx:
+        with pytest.raises(overlap.MsgpuError) as e:
+            ctx.calculate_edges()
+        assert e.value.code == _lib.E_STATE
+        bad = rows.copy()
+        bad["read_id"] = bad["read_id"].max() - bad["read_id"]  # reversed ids: not first-line order
+        with pytest.raises(overlap.MsgpuError) as e:
+            ctx.load_rows(bad)
+        assert e.value.code == _lib.E_IDS
+        ctx.load_rows(rows)
+        with pytest.raises(overlap.MsgpuError) as e:
+            ctx.chaining_and_overlaps()
+        assert e.value.code == _lib.E_STATE
+        ctx.calculate_edges()
+        ctx.chaining_and_overlaps()
+        c = ctx.counts()
+        assert c.n_rows_in == len(rows) and c.n_edges > 0 and c.n_orders > 0
+        # the context is reusable: a second run gives the same tables
+        a = ctx.tables()
+        ctx.load_rows(rows)
+        ctx.calculate_edges()
+        ctx.chaining_and_overlaps()
+        b = ctx.tables()
+        for k in a:
+            assert a[k].tobytes() == b[k].tobytes()
+
+
+def test_property_checks_at_full_size():
+    """cfg2-size run checked through size-independent properties (no oracle): table cross references are dense and
+    consistent, every order's ids are a subset of its edge's EdgeMatch anchors in vStart order, shards partition."""
+    from muchsalsa_amd import synth
+    rows = synth.synth_rows(**synth.CONFIGS["cfg2"])
+    t = _gpu_tables(rows)
+    e, em, o, ids = t["edges"], t["ems"], t["orders"], t["ids"]
+    assert np.all(e["v1"] < e["v2"])
+    key = e["v1"].astype(np.uint64) << np.uint64(32) | e["v2"].astype(np.uint64)
+    assert np.all(key[1:] > key[:-1])  # sorted, unique edges
+    assert np.array_equal(e["em_off"], np.concatenate([[0], np.cumsum(e["em_cnt"])[:-1]]))
+    assert np.array_equal(e["order_off"], np.concatenate([[0], np.cumsum(e["order_cnt"])[:-1]]))
+    assert e["em_cnt"].sum() == len(em) and e["order_cnt"].sum() == len(o) and o["ids_cnt"].sum() == len(ids)
+    assert np.array_equal(em["edge_idx"], np.repeat(np.arange(len(e)), e["em_cnt"]))
+    assert np.array_equal(o["edge_idx"], np.repeat(np.arange(len(e)), e["order_cnt"]))
+    assert np.all(o["base"] == e["v1"][o["edge_idx"]])
+    assert np.all(np.where(o["flags"] & 1, o["start"], o["end"]) == e["v1"][o["edge_idx"]])
+    assert np.all(em["ov_hi"] - em["ov_lo"] > 100) and np.all(em["score"] > 0)
+    assert np.all(o["left_offset"] >= 0) and np.all(o["right_offset"] >= 0)
+    assert np.all(e["order_cnt"] >= 1)
+    # an edge with more than one order is a shadow (main.cpp:389-391)
+    assert np.all(e["shadow"][e["order_cnt"] > 1] == 1)
+    # ids of an order: anchors of the edge with the order's direction, ascending vStart position
+    rng = np.random.default_rng(0)
+    for q in rng.choice(len(o), 2000, replace=False):
+        ed = e[o[q]["edge_idx"]]
+        anchors = em["anchor_id"][int(ed["em_off"]): int(ed["em_off"]) + int(ed["em_cnt"])]
+        flags = em["flags"][int(ed["em_off"]): int(ed["em_off"]) + int(ed["em_cnt"])]
+        mine = ids[int(o[q]["ids_off"]): int(o[q]["ids_off"]) + int(o[q]["ids_cnt"])]
+        pos = [int(np.nonzero(anchors == a)[0][0]) for a in mine]
+        assert pos == sorted(pos) and len(set(pos)) == len(pos)
+        assert np.all((flags[pos] & 1) == ((int(o[q]["flags"]) >> 2) & 1))

@@ -1,0 +1,95 @@
+"""A1: msgpu_parse_paf (host code of libmsgpu, runs without a GPU) against the oracle's parser and hand-made cases."""
+import numpy as np
+import pytest
+
+from muchsalsa_amd import overlap, synth
+
+
+def _line(q="u1", qlen=1000, qs=0, qe=600, strand="+", t="r1", tlen=5000, ts=100, te=700, nm=550, extra="600\t60"):
+    return "\t".join(str(x) for x in (q, qlen, qs, qe, strand, t, tlen, ts, te, nm)) + ("\t" + extra if extra else "")
+
+
+SENTINEL = "u0\t1\t0\t1\t+\tr0\t1\t0\t1\t0\t1\t0"
+
+
+def _write(tmp_path, lines, trailing_newline=True, name="x.paf"):
+    p = tmp_path / name
+    p.write_text("\n".join(lines) + ("\n" if trailing_newline else ""))
+    return str(p)
+
+
+def test_matches_oracle_on_synthetic_text(oracle, tmp_path):
+    tab = synth.paf_table(150, 4000, 400, 21)
+    path = _write(tmp_path, synth.paf_lines(tab))
+    got = overlap.parse_paf(path)
+    want = oracle.parse_paf(path)
+    assert got.rows.tobytes() == want["rows"].tobytes()
+    assert got.n_lines == want["n_lines"]
+    assert got.read_names == want["read_names"] and got.anchor_names == want["anchor_names"]
+
+
+def test_last_line_is_never_parsed(tmp_path):
+    # BlastFileReader.cpp:76: lineIdx < getLineCount() - 1
+    good = _line()
+    for nl in (True, False):
+        p = overlap.parse_paf(_write(tmp_path, [good, good.replace("r1", "r2")], trailing_newline=nl))
+        assert p.n_lines == 2 and len(p.rows) == 1 and p.read_names == ["r1"]
+    assert len(overlap.parse_paf(_write(tmp_path, [good])).rows) == 0
+    assert len(overlap.parse_paf(_write(tmp_path, [], trailing_newline=False)).rows) == 0
+
+
+def test_filter_and_primary_thresholds(tmp_path):
+    # keep iff nmatch >= 400 and span >= 400 (:106-107); primary iff span >= 500 and nmatch >= 500 (:121-122)
+    cases = [  # (qs, qe, nmatch) -> (kept, primary)
+        ((0, 400, 400), (True, False)), ((0, 399, 400), (False, False)), ((0, 400, 399), (False, False)),
+        ((0, 500, 500), (True, True)), ((0, 499, 500), (True, False)), ((0, 500, 499), (True, False)),
+        ((10, 510, 1000), (True, True)),
+    ]
+    lines = [_line(q="u%d" % i, qs=c[0][0], qe=c[0][1], nm=c[0][2], t="r%d" % i) for i, c in enumerate(cases)]
+    p = overlap.parse_paf(_write(tmp_path, lines + [SENTINEL]))
+    kept = {int(r["line"]): bool(r["flags"] & 2) for r in p.rows}
+    for i, c in enumerate(cases):
+        assert (i in kept) == c[1][0], (i, c)
+        if c[1][0]:
+            assert kept[i] == c[1][1], (i, c)
+
+
+def test_fields_ranges_direction_and_registry_order(tmp_path):
+    lines = [
+        _line(q="uB", qs=5, qe=905, strand="-", t="rZ", tlen=7777, ts=40, te=950, nm=800),
+        _line(q="uA", qs=0, qe=300, t="rSKIP", nm=900),              # rejected: span < 400 -> registers nothing
+        _line(q="uA", qs=0, qe=450, strand="+", t="rY", tlen=6000, ts=0, te=460, nm=420),
+        _line(q="uB", qs=0, qe=450, strand="x", t="rZ", tlen=1, ts=3, te=9, nm=444),
+        SENTINEL,
+    ]
+    p = overlap.parse_paf(_write(tmp_path, lines))
+    assert p.read_names == ["rZ", "rY"] and p.anchor_names == ["uB", "uA"]  # first-seen, rejected rows skipped
+    r0, r1, r2 = p.rows
+    assert (r0["anchor_id"], r0["read_id"], r0["read_len"], r0["i_lo"], r0["i_hi"], r0["n_lo"], r0["n_hi"], r0["score"],
+            r0["line"], r0["flags"]) == (0, 0, 7777, 5, 904, 40, 949, 800, 0, 2)  # '-' -> dir 0, primary
+    assert (r1["anchor_id"], r1["read_id"], r1["line"], r1["flags"]) == (1, 1, 2, 1)
+    assert (r2["anchor_id"], r2["read_id"], r2["line"], r2["flags"], r2["read_len"]) == (0, 0, 3, 0, 1)  # "x" != "+"
+
+
+def test_errors(tmp_path):
+    from muchsalsa_amd import _lib
+    with pytest.raises(overlap.MsgpuError) as e:
+        overlap.parse_paf(str(tmp_path / "missing.paf"))
+    assert e.value.code == _lib.E_IO
+    with pytest.raises(overlap.MsgpuError) as e:  # "Invalid BLAST file."
+        overlap.parse_paf(_write(tmp_path, ["a\tb\tc", SENTINEL]))
+    assert e.value.code == _lib.E_FORMAT
+    with pytest.raises(overlap.MsgpuError) as e:  # empty line -> no tokens
+        overlap.parse_paf(_write(tmp_path, ["", SENTINEL]))
+    assert e.value.code == _lib.E_FORMAT
+    with pytest.raises(overlap.MsgpuError) as e:  # std::stoi would throw
+        overlap.parse_paf(_write(tmp_path, [_line(qs="abc"), SENTINEL]))
+    assert e.value.code == _lib.E_NUMBER
+    # a malformed LAST line is harmless: it is never parsed
+    assert len(overlap.parse_paf(_write(tmp_path, [_line(), "garbage"])).rows) == 1
+
+
+def test_crlf_and_leading_space_numbers(tmp_path):
+    # std::stoi skips leading whitespace and stops at the first non-digit ('\r' stays in the last column)
+    p = overlap.parse_paf(_write(tmp_path, [_line(qs=" 7", nm="550\r", extra=""), SENTINEL]))
+    assert len(p.rows) == 1 and int(p.rows[0]["i_lo"]) == 7 and int(p.rows[0]["score"]) == 550
