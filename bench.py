@@ -64,6 +64,8 @@ def main():
     ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
     ap.add_argument("--cpu-sample-reads", type=int, default=25_000,
                     help="reads in the CPU-baseline sample (0 disables the baseline leg)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="run the N>1 exchange path (all-gather + merge) even at world size 1 (used by the GPU tests)")
     args = ap.parse_args()
 
     import torch
@@ -78,8 +80,11 @@ def main():
         raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+    multi = world > 1 or args.force_dist
+    if multi:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
 
     w = WORKLOADS[args.workload]
     rows = synth.synth_rows(w["n_reads"], w["read_len"], w["n_anchors"], w["seed"])
@@ -96,7 +101,7 @@ def main():
         ctx.calculate_edges()
         ctx.chaining_and_overlaps()
         c = ctx.counts()
-        if world > 1:
+        if multi:
             # merge the edge list: ONE all-gather of the per-rank (edges | orders | ids) slab over xGMI, then the
             # HIP compaction/re-base kernel (msgpu_merge_gathered)
             def fill(slab, offs):
@@ -114,7 +119,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -123,11 +128,11 @@ def main():
         c, allc = step()
         chain_ms.append(ctx.timings().chain_kernel_ms)  # HIP events on the launch stream (syncs that stream only)
     torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         dist.barrier()
     dt = time.perf_counter() - t0
     tm = ctx.timings()
-    if world > 1:
+    if multi:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -162,7 +167,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_sample_reads)
         print(json.dumps(out))
     ctx.close()
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 

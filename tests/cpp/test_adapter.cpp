@@ -1,0 +1,133 @@
+// Compiles include/msgpu_adapter.hpp against MOCKS of the reference's Graph / MatchMap / Registry interface (same
+// member names and argument shapes as include/ms/graph/Graph.h, include/ms/matching/MatchMap.h, include/ms/Registry.h)
+// and drives the reference call sequence of src/main.cpp:153-178 through it.
+//   test_adapter <paf>          -> prints one line of counts (needs a GPU)
+//   test_adapter --errors       -> checks the exception behaviour that needs no GPU
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "msgpu_adapter.hpp"
+
+namespace mock {
+struct Vertex {
+  Vertex(unsigned id, std::size_t len, std::size_t line) : id(id), len(len), line(line) {}
+  unsigned    id;
+  std::size_t len, line;
+};
+struct EdgeOrder {
+  Vertex const *startVertex, *endVertex;
+  double        leftOffset, rightOffset;
+  bool          isContained;
+  Vertex const *baseVertex;
+  std::size_t   score;
+  std::vector<unsigned int> ids;
+  bool          direction, isPrimary;
+};
+struct Edge {
+  std::vector<EdgeOrder> orders;
+  bool                   shadow = false;
+  void appendOrder(EdgeOrder &&o) { orders.push_back(std::move(o)); }
+  void setShadow(bool s) { shadow = s; }
+};
+struct Graph {
+  std::unordered_map<unsigned, std::shared_ptr<Vertex>> vertices;
+  std::map<std::pair<unsigned, unsigned>, std::unique_ptr<Edge>> edges;
+  void addVertex(std::shared_ptr<Vertex> &&v) { vertices.emplace(v->id, std::move(v)); } // first wins (Graph.cpp:148)
+  Vertex *getVertex(unsigned id) const { return vertices.at(id).get(); }
+  void addEdge(std::pair<Vertex *, Vertex *> const &p) {
+    auto &e = edges[{p.first->id, p.second->id}];
+    if (!e) e = std::make_unique<Edge>();
+  }
+  Edge *getEdge(std::pair<Vertex *, Vertex *> const &p) const { return edges.at({p.first->id, p.second->id}).get(); }
+};
+struct VertexMatch {
+  std::pair<int, int> nanoporeRange, illuminaRange;
+  double              rRatio;
+  bool                direction;
+  std::size_t         score;
+  bool                isPrimary;
+  std::size_t         lineNumber;
+};
+struct EdgeMatch {
+  std::pair<int, int> overlap;
+  bool                direction;
+  double              score;
+  bool                isPrimary;
+  std::size_t         lineNumber;
+};
+struct MatchMap {
+  std::size_t nVertexMatches = 0, nEdgeMatches = 0;
+  std::map<std::pair<unsigned, unsigned>, std::size_t> vm;
+  void addVertexMatch(unsigned n, unsigned i, std::shared_ptr<VertexMatch> const &m) {
+    auto it = vm.find({n, i});
+    if (it == vm.end() || it->second > m->lineNumber) { // lowest line wins (MatchMap.cpp:64-80)
+      if (it == vm.end()) ++nVertexMatches;
+      vm[{n, i}] = m->lineNumber;
+    }
+  }
+  void addEdgeMatch(Edge const *, unsigned, std::shared_ptr<EdgeMatch> const &) { ++nEdgeMatches; }
+};
+struct Registry {
+  std::unordered_map<std::string, unsigned> ids;
+  unsigned next = 0;
+  unsigned const &operator[](std::string const &s) {
+    auto it = ids.find(s);
+    if (it == ids.end()) it = ids.emplace(s, next++).first;
+    return it->second;
+  }
+};
+} // namespace mock
+
+int main(int argc, char **argv) {
+  if (argc < 2) return 2;
+  if (std::strcmp(argv[1], "--errors") == 0) {
+    // no GPU needed: construction either works (GPU box) or throws the loud "no HIP device" error
+    try {
+      msgpu::OverlapCore core(0);
+      try {
+        core.read("/nonexistent/file.paf");
+        std::puts("FAIL: missing file accepted");
+        return 1;
+      } catch (std::runtime_error const &e) {
+        if (std::string(e.what()) != "Can't open blast file.") {
+          std::printf("FAIL: %s\n", e.what());
+          return 1;
+        }
+      }
+      std::puts("ok gpu");
+    } catch (std::runtime_error const &e) {
+      if (std::string(e.what()).find("no HIP device") == std::string::npos) {
+        std::printf("FAIL: %s\n", e.what());
+        return 1;
+      }
+      std::puts("ok nogpu");
+    }
+    return 0;
+  }
+  msgpu::OverlapCore core(0, 300);
+  core.read(argv[1]);
+  core.calculateEdges();
+  core.chainingAndOverlaps();
+  auto const t = core.tables();
+  mock::Graph    graph;
+  mock::MatchMap matchMap;
+  mock::Registry rn, ri;
+  msgpu::fillReferenceObjects<mock::Vertex, mock::VertexMatch, mock::EdgeMatch, mock::EdgeOrder>(core, t, graph, matchMap,
+                                                                                                rn, ri);
+  std::size_t orders = 0, shadows = 0, ids = 0;
+  for (auto const &kv : graph.edges) {
+    orders += kv.second->orders.size();
+    shadows += kv.second->shadow;
+    for (auto const &o : kv.second->orders) ids += o.ids.size();
+  }
+  std::printf("{\"vertices\": %zu, \"edges\": %zu, \"vertexmatches\": %zu, \"edgematches\": %zu, \"orders\": %zu, "
+              "\"shadows\": %zu, \"ids\": %zu}\n",
+              graph.vertices.size(), graph.edges.size(), matchMap.nVertexMatches, matchMap.nEdgeMatches, orders, shadows,
+              ids);
+  return 0;
+}

@@ -1,0 +1,42 @@
+"""include/msgpu_adapter.hpp: compiles against mocks of the reference interface; error behaviour; GPU end-to-end."""
+import json
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def adapter_bin(tmp_path_factory):
+    import __graft_entry__ as g
+    g.build()
+    out = str(tmp_path_factory.mktemp("cpp") / "test_adapter")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", "-I", os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tests", "cpp", "test_adapter.cpp"), "-o", out,
+                    "-L", os.path.join(ROOT, "muchsalsa_amd"), "-lmsgpu",
+                    "-Wl,-rpath," + os.path.join(ROOT, "muchsalsa_amd"), "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    return out
+
+
+def test_adapter_compiles_and_reports_errors_like_the_reference(adapter_bin):
+    r = subprocess.run([adapter_bin, "--errors"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.strip() in ("ok gpu", "ok nogpu")
+
+
+@pytest.mark.gpu
+def test_adapter_end_to_end_fills_reference_shaped_objects(adapter_bin, oracle, tmp_path):
+    from muchsalsa_amd import synth
+    tab = synth.paf_table(300, 4000, 1000, 31)
+    path = tmp_path / "in.paf"
+    path.write_text("\n".join(synth.paf_lines(tab)) + "\n")
+    r = subprocess.run([adapter_bin, str(path)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    got = json.loads(r.stdout.strip().splitlines()[-1])
+    rows = oracle.parse_paf(str(path))["rows"]
+    t = oracle.overlap(rows)
+    assert got == {"vertices": int(rows["read_id"].max()) + 1, "edges": len(t["edges"]),
+                   "vertexmatches": t["rows_alive"], "edgematches": len(t["ems"]), "orders": len(t["orders"]),
+                   "shadows": t["shadow_edges"], "ids": len(t["ids"])}

@@ -174,3 +174,20 @@ def test_property_checks_at_full_size():
         pos = [int(np.nonzero(anchors == a)[0][0]) for a in mine]
         assert pos == sorted(pos) and len(set(pos)) == len(pos)
         assert np.all((flags[pos] & 1) == ((int(o[q]["flags"]) >> 2) & 1))
+
+
+def test_bench_distributed_path_smoke():
+    """bench.py's N>1 step (copy_tables_device -> all-gather over RCCL -> msgpu_merge_gathered) at world size 1."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "tiny", "--steps", "2",
+                          "--warmup", "1", "--cpu-sample-reads", "0", "--force-dist"], env=env, capture_output=True,
+                         text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["value"] > 0 and line["config"]["edges"] > 0
+    assert 0 < line["roofline"]["frac"] < 1
