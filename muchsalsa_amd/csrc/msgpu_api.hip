@@ -69,7 +69,8 @@ struct msgpu_ctx {
 
   // arena
   DevBuf rows_in, cnt_read, first_key, read_off, cursor, bkt_key, bkt_idx, bkt_dead, by_read, read_cnt, alive_rank,
-      anchor_cnt, anchor_off, bkt2_idx, bkt2_line, by_anchor, read_len, read_first, scalars, scan_tmp;
+      anchor_cnt, anchor_off, anchor_first, anchor_off_gen, bkt2_idx, bkt2_line, by_anchor, read_len, read_first, scalars,
+      scan_tmp;
   DevBuf bound, cand_off, cand_j, cand_t, scr_v2, scr_start, n_cand, n_edge, n_visit_arr, lists, em_base, edge_base,
       visit_base, edges, edge_cand;
   DevBuf big_key, big_t, big_r2s, big_pfx;
@@ -78,14 +79,14 @@ struct msgpu_ctx {
 
   // timing
   hipEvent_t ev[10] = {nullptr};
-  bool       have_index_t = false, have_cand_t = false, have_chain_t = false;
+  bool       have_index_t = false, have_cand_t = false, have_chain_t = false, index_fast = false;
 };
 
 namespace {
 
 // scalar slots in ctx->scalars (uint64 each)
 enum { SC_MAXIDS = 0 /*2 x u32*/, SC_ERR = 1, SC_TOTAL_A = 2, SC_TOTAL_B = 3, SC_TOTAL_C = 4, SC_NLISTS = 5 /*3 x u32, spans 5..6*/,
-       SC_NBIG = 7, SC_NALIVE = 8, SC_COUNT = 16 };
+       SC_NBIG = 7, SC_NALIVE = 8, SC_IXFLAGS = 9, SC_COUNT = 16 };
 
 int fail(msgpu_ctx *c, int code, const char *fmt, ...) {
   va_list ap;
@@ -110,6 +111,7 @@ template <class T> T *scalar(msgpu_ctx *c, int slot) { return reinterpret_cast<T
 void release_all(msgpu_ctx *c) {
   DevBuf *all[] = {&c->rows_in, &c->cnt_read, &c->first_key, &c->read_off, &c->cursor, &c->bkt_key, &c->bkt_idx,
                    &c->bkt_dead, &c->by_read, &c->read_cnt, &c->alive_rank, &c->anchor_cnt, &c->anchor_off,
+                   &c->anchor_first, &c->anchor_off_gen,
                    &c->bkt2_idx, &c->bkt2_line, &c->by_anchor, &c->read_len, &c->read_first, &c->scalars, &c->scan_tmp,
                    &c->bound, &c->cand_off, &c->cand_j, &c->cand_t, &c->scr_v2, &c->scr_start, &c->n_cand, &c->n_edge,
                    &c->n_visit_arr, &c->lists, &c->em_base, &c->edge_base, &c->visit_base, &c->edges, &c->edge_cand,
@@ -119,12 +121,11 @@ void release_all(msgpu_ctx *c) {
   for (DevBuf *b : all) b->release();
 }
 
-int build_index(msgpu_ctx *c) {
+int build_index_once(msgpu_ctx *c, bool force_generic, uint32_t *ix_flags_out) {
   hipStream_t st = c->stream;
   const uint64_t n = c->n_rows;
   ENSURE(c, scalars, SC_COUNT * sizeof(uint64_t));
   HIPCHK(c, hipMemsetAsync(c->scalars.p, 0, SC_COUNT * sizeof(uint64_t), st));
-  HIPCHK(c, hipEventRecord(c->ev[0], st));
 
   // id spaces
   launch_max_ids(st, c->d_rows, n, scalar<uint32_t>(c, SC_MAXIDS));
@@ -136,17 +137,19 @@ int build_index(msgpu_ctx *c) {
   const uint32_t V = c->V, A = c->A;
 
   const size_t nz = n ? n : 1;
+  const size_t mva = size_t(V > A ? V : A) + 2;
   ENSURE(c, cnt_read, (size_t(V) + 1) * 4);
   ENSURE(c, first_key, (size_t(V) + 1) * 8);
   ENSURE(c, read_off, (size_t(V) + 2) * 4);
-  ENSURE(c, cursor, (size_t(V > A ? V : A) + 1) * 4);
+  ENSURE(c, cursor, mva * 4);
   ENSURE(c, bkt_key, nz * 16);
-  ENSURE(c, bkt_idx, nz * 4);
   ENSURE(c, bkt_dead, nz);
   ENSURE(c, by_read, nz * sizeof(IRow));
   ENSURE(c, read_cnt, (size_t(V) + 1) * 4);
   ENSURE(c, alive_rank, nz * 4);
   ENSURE(c, anchor_cnt, (size_t(A) + 1) * 4);
+  ENSURE(c, anchor_first, (size_t(A) + 2) * 4);
+  ENSURE(c, anchor_off_gen, (size_t(A) + 2) * 4);
   ENSURE(c, anchor_off, (size_t(A) + 2) * 4);
   ENSURE(c, bkt2_idx, nz * 4);
   ENSURE(c, bkt2_line, nz * 4);
@@ -162,42 +165,66 @@ int build_index(msgpu_ctx *c) {
 
   HIPCHK(c, hipMemsetAsync(c->cnt_read.p, 0, (size_t(V) + 1) * 4, st));
   HIPCHK(c, hipMemsetAsync(c->first_key.p, 0xff, (size_t(V) + 1) * 8, st));
-  HIPCHK(c, hipMemsetAsync(c->cursor.p, 0, (size_t(V > A ? V : A) + 1) * 4, st));
+  HIPCHK(c, hipMemsetAsync(c->cursor.p, 0, mva * 4, st));
   HIPCHK(c, hipMemsetAsync(c->read_cnt.p, 0, (size_t(V) + 1) * 4, st));
   HIPCHK(c, hipMemsetAsync(c->anchor_cnt.p, 0, (size_t(A) + 1) * 4, st));
+  HIPCHK(c, hipMemsetAsync(c->anchor_first.p, 0xff, (size_t(A) + 2) * 4, st));
+  uint32_t *d_flags = scalar<uint32_t>(c, SC_IXFLAGS);
+  if (force_generic) {
+    const uint32_t f = IXF_FORCE;
+    HIPCHK(c, hipMemcpyAsync(d_flags, &f, 4, hipMemcpyHostToDevice, st));
+  }
 
-  launch_hist_read(st, c->d_rows, n, c->cnt_read.as<uint32_t>(), c->first_key.as<uint64_t>());
+  launch_index_pass1(st, c->d_rows, n, c->cnt_read.as<uint32_t>(), c->first_key.as<uint64_t>(),
+                     c->anchor_first.as<uint32_t>(), A, d_flags);
   launch_read_facts(st, c->d_rows, c->first_key.as<uint64_t>(), V, c->read_len.as<int32_t>(),
                     c->read_first.as<uint32_t>(), scalar<uint32_t>(c, SC_ERR));
   exclusive_scan<uint32_t>(st, c->cnt_read.as<uint32_t>(), V, c->read_off.as<uint32_t>(), c->scan_tmp.as<uint32_t>(),
                            scalar<uint32_t>(c, SC_TOTAL_A));
-  launch_scatter_read(st, c->d_rows, n, c->read_off.as<uint32_t>(), c->cursor.as<uint32_t>(), c->bkt_key.p,
-                      c->bkt_idx.as<uint32_t>());
-  launch_dedupe(st, c->read_off.as<uint32_t>(), n, c->bkt_key.p, c->bkt_idx.as<uint32_t>(), c->d_rows,
-                c->bkt_dead.as<uint8_t>());
-  launch_rank_read(st, c->read_off.as<uint32_t>(), n, c->bkt_key.p, c->bkt_idx.as<uint32_t>(), c->bkt_dead.as<uint8_t>(),
-                   c->d_rows, c->by_read.as<IRow>(), c->read_cnt.as<uint32_t>(), c->alive_rank.as<uint32_t>(),
-                   c->anchor_cnt.as<uint32_t>());
-  exclusive_scan<uint32_t>(st, c->anchor_cnt.as<uint32_t>(), A, c->anchor_off.as<uint32_t>(), c->scan_tmp.as<uint32_t>(),
-                           scalar<uint32_t>(c, SC_NALIVE));
-  HIPCHK(c, hipMemsetAsync(c->cursor.p, 0, (size_t(V > A ? V : A) + 1) * 4, st));
+  launch_scatter_read(st, c->d_rows, n, c->read_off.as<uint32_t>(), c->cursor.as<uint32_t>(), c->bkt_key.p);
+  launch_sort_read(st, c->read_off.as<uint32_t>(), c->cnt_read.as<uint32_t>(), V, c->bkt_key.p, c->d_rows,
+                   c->by_read.as<IRow>(), c->read_cnt.as<uint32_t>(), c->alive_rank.as<uint32_t>(),
+                   c->anchor_cnt.as<uint32_t>(), c->by_anchor.as<IRow>(), c->bkt_dead.as<uint8_t>(), d_flags);
+  // generic by_anchor path (no-ops in fast mode)
+  exclusive_scan<uint32_t>(st, c->anchor_cnt.as<uint32_t>(), A, c->anchor_off_gen.as<uint32_t>(),
+                           c->scan_tmp.as<uint32_t>(), scalar<uint32_t>(c, SC_NALIVE));
+  launch_select_anchor_off(st, d_flags, c->anchor_first.as<uint32_t>(), c->anchor_off_gen.as<uint32_t>(), A,
+                           c->anchor_off.as<uint32_t>(), scalar<uint32_t>(c, SC_NALIVE), static_cast<uint32_t>(n));
+  HIPCHK(c, hipMemsetAsync(c->cursor.p, 0, mva * 4, st));
   launch_scatter_anchor(st, c->d_rows, n, c->alive_rank.as<uint32_t>(), c->anchor_off.as<uint32_t>(),
-                        c->cursor.as<uint32_t>(), c->bkt2_idx.as<uint32_t>(), c->bkt2_line.as<uint32_t>());
+                        c->cursor.as<uint32_t>(), c->bkt2_idx.as<uint32_t>(), c->bkt2_line.as<uint32_t>(), d_flags);
   launch_rank_anchor(st, c->anchor_off.as<uint32_t>(), n, scalar<uint32_t>(c, SC_NALIVE), c->bkt2_idx.as<uint32_t>(),
-                     c->bkt2_line.as<uint32_t>(), c->d_rows, c->alive_rank.as<uint32_t>(), c->by_anchor.as<IRow>());
+                     c->bkt2_line.as<uint32_t>(), c->d_rows, c->alive_rank.as<uint32_t>(), c->by_anchor.as<IRow>(),
+                     d_flags);
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipEventRecord(c->ev[1], st));
 
-  uint32_t err = 0, n_alive = 0;
+  uint32_t err = 0, n_alive = 0, ixf = 0;
   HIPCHK(c, hipMemcpyAsync(&err, scalar<uint32_t>(c, SC_ERR), 4, hipMemcpyDeviceToHost, st));
   HIPCHK(c, hipMemcpyAsync(&n_alive, scalar<uint32_t>(c, SC_NALIVE), 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipMemcpyAsync(&ixf, d_flags, 4, hipMemcpyDeviceToHost, st));
   HIPCHK(c, hipStreamSynchronize(st));
-  c->have_index_t = true;
-  c->n_alive      = n_alive;
+  c->n_alive    = n_alive;
+  *ix_flags_out = ixf;
   if (err & 1u)
     return fail(c, MSGPU_E_IDS,
                 "read ids are not dense Registry ids in first-line order (Registry.cpp:36-45): use msgpu_parse_paf ids");
-  c->state = ST_LOADED;
+  return MSGPU_OK;
+}
+
+int build_index(msgpu_ctx *c) {
+  HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+  uint32_t ixf = 0;
+  int      rc  = build_index_once(c, false, &ixf);
+  if (rc != MSGPU_OK) return rc;
+  // the fast by_anchor path assumed no duplicate (read, anchor) pair; if one turned up, rebuild generically
+  if ((ixf & IXF_DUPS) && (ixf & ~IXF_DUPS) == 0) {
+    rc = build_index_once(c, true, &ixf);
+    if (rc != MSGPU_OK) return rc;
+  }
+  c->index_fast   = (ixf & ~IXF_DUPS) == 0;
+  c->have_index_t = true;
+  c->state        = ST_LOADED;
   return MSGPU_OK;
 }
 

@@ -78,21 +78,28 @@ template <class T> void exclusive_scan(hipStream_t st, const uint32_t *in, uint6
 uint32_t scan_blocks(uint64_t n);
 
 void launch_max_ids(hipStream_t st, const msgpu_row *rows, uint64_t n, uint32_t *max_ids);
-void launch_hist_read(hipStream_t st, const msgpu_row *rows, uint64_t n, uint32_t *cnt_read, uint64_t *first_key);
+// index flags (device word): why the fast by_anchor path cannot be used
+constexpr uint32_t IXF_UNSORTED = 1u; // rows are not strictly ascending in (anchor id, line)
+constexpr uint32_t IXF_SPARSE   = 2u; // an anchor id has no row
+constexpr uint32_t IXF_DUPS     = 4u; // a (read, anchor) pair occurs more than once
+constexpr uint32_t IXF_FORCE    = 8u; // host asked for the generic path
+void launch_index_pass1(hipStream_t st, const msgpu_row *rows, uint64_t n, uint32_t *cnt_read, uint64_t *first_key,
+                        uint32_t *anchor_first, uint32_t A, uint32_t *flags);
 void launch_read_facts(hipStream_t st, const msgpu_row *rows, const uint64_t *first_key, uint32_t V, int32_t *read_len,
                        uint32_t *read_first, uint32_t *err);
 void launch_scatter_read(hipStream_t st, const msgpu_row *rows, uint64_t n, const uint32_t *read_off, uint32_t *cursor,
-                         void *bkt_key, uint32_t *bkt_idx);
-void launch_dedupe(hipStream_t st, const uint32_t *read_off, uint64_t n, const void *bkt_key, const uint32_t *bkt_idx,
-                   const msgpu_row *rows, uint8_t *bkt_dead);
-void launch_rank_read(hipStream_t st, const uint32_t *read_off, uint64_t n, const void *bkt_key, const uint32_t *bkt_idx,
-                      const uint8_t *bkt_dead, const msgpu_row *rows, IRow *by_read, uint32_t *read_cnt,
-                      uint32_t *alive_rank, uint32_t *anchor_cnt);
+                         void *bkt_key);
+void launch_sort_read(hipStream_t st, const uint32_t *read_off, const uint32_t *cnt_read, uint32_t V, const void *bkt_key,
+                      const msgpu_row *rows, IRow *by_read, uint32_t *read_cnt, uint32_t *alive_rank,
+                      uint32_t *anchor_cnt, IRow *by_anchor, uint8_t *bkt_dead, uint32_t *flags);
+void launch_select_anchor_off(hipStream_t st, const uint32_t *flags, const uint32_t *fast_off, const uint32_t *gen_off,
+                              uint32_t A, uint32_t *anchor_off, uint32_t *d_n_alive, uint32_t n_rows);
 void launch_scatter_anchor(hipStream_t st, const msgpu_row *rows, uint64_t n, const uint32_t *alive_rank,
-                           const uint32_t *anchor_off, uint32_t *cursor, uint32_t *bkt_idx, uint32_t *bkt_line);
+                           const uint32_t *anchor_off, uint32_t *cursor, uint32_t *bkt_idx, uint32_t *bkt_line,
+                           const uint32_t *flags);
 void launch_rank_anchor(hipStream_t st, const uint32_t *anchor_off, uint64_t n_rows, const uint32_t *d_n_alive,
                         const uint32_t *bkt_idx, const uint32_t *bkt_line, const msgpu_row *rows,
-                        const uint32_t *alive_rank, IRow *by_anchor);
+                        const uint32_t *alive_rank, IRow *by_anchor, const uint32_t *flags);
 void launch_bound(hipStream_t st, const uint32_t *read_off, const uint32_t *read_cnt, const IRow *by_read,
                   const uint32_t *anchor_off, uint32_t V, uint32_t shard, uint32_t nshards, uint32_t *bound);
 void launch_classify_reads(hipStream_t st, const uint32_t *read_cnt, const uint32_t *bound, uint32_t V, uint32_t shard,

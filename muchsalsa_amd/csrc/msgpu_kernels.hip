@@ -204,13 +204,33 @@ __global__ __launch_bounds__(256) void k_max_ids(const msgpu_row *rows, uint64_t
   }
 }
 
-__global__ __launch_bounds__(256) void k_hist_read(const msgpu_row *rows, uint64_t n, uint32_t *cnt_read,
-                                                   unsigned long long *first_key) {
+// pass 1 over the rows: per-read row counts, first line per read, and -- speculatively -- the scaffold offsets that
+// hold when the table is already grouped by anchor with ascending lines (what a PAF from minimap2 looks like).
+__global__ __launch_bounds__(256) void k_index_pass1(const msgpu_row *rows, uint64_t n, uint32_t *cnt_read,
+                                                     unsigned long long *first_key, uint32_t *anchor_first,
+                                                     uint32_t *flags) {
   uint64_t i = static_cast<uint64_t>(blockIdx.x) * 256 + threadIdx.x;
   if (i >= n) return;
-  uint32_t r = rows[i].read_id;
-  atomicAdd(&cnt_read[r], 1u);
-  atomicMin(&first_key[r], (static_cast<unsigned long long>(rows[i].line) << 32) | static_cast<uint32_t>(i));
+  const uint32_t rd = rows[i].read_id, an = rows[i].anchor_id, ln = rows[i].line;
+  atomicAdd(&cnt_read[rd], 1u);
+  atomicMin(&first_key[rd], (static_cast<unsigned long long>(ln) << 32) | static_cast<uint32_t>(i));
+  if (i == 0) {
+    anchor_first[an] = 0;
+  } else {
+    const uint32_t pa = rows[i - 1].anchor_id, pl = rows[i - 1].line;
+    if (pa > an || (pa == an && pl >= ln)) atomicOr(flags, IXF_UNSORTED);
+    if (pa != an) anchor_first[an] = static_cast<uint32_t>(i);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_check_anchor_first(uint32_t *anchor_first, uint32_t A, uint32_t n, uint32_t *flags) {
+  uint32_t a = blockIdx.x * 256 + threadIdx.x;
+  if (a > A) return;
+  if (a == A) {
+    anchor_first[A] = n;
+    return;
+  }
+  if (anchor_first[a] == 0xffffffffu) atomicOr(flags, IXF_SPARSE);
 }
 
 // per read: Vertex(nanoporeLength, metaDatum(0) = first line) + Registry-order check
@@ -233,57 +253,22 @@ __global__ __launch_bounds__(256) void k_read_facts(const msgpu_row *rows, const
   }
 }
 
-// bucket rows by read: key record {anchor, line, n_lo, n_hi} + source index
+// bucket rows by read: key record {n_lo, n_hi, anchor, source index}
 __global__ __launch_bounds__(256) void k_scatter_read(const msgpu_row *rows, uint64_t n, const uint32_t *read_off,
-                                                      uint32_t *cursor, uint4 *bkt_key, uint32_t *bkt_idx) {
+                                                      uint32_t *cursor, uint4 *bkt_key) {
   uint64_t i = static_cast<uint64_t>(blockIdx.x) * 256 + threadIdx.x;
   if (i >= n) return;
-  msgpu_row r   = rows[i];
-  uint32_t  pos = read_off[r.read_id] + atomicAdd(&cursor[r.read_id], 1u);
-  bkt_key[pos]  = make_uint4(r.anchor_id, r.line, static_cast<uint32_t>(r.n_lo), static_cast<uint32_t>(r.n_hi));
-  bkt_idx[pos]  = static_cast<uint32_t>(i);
+  const uint32_t rd  = rows[i].read_id;
+  const uint32_t pos = read_off[rd] + atomicAdd(&cursor[rd], 1u);
+  bkt_key[pos] = make_uint4(static_cast<uint32_t>(rows[i].n_lo), static_cast<uint32_t>(rows[i].n_hi), rows[i].anchor_id,
+                            static_cast<uint32_t>(i));
 }
 
-// MatchMap::addVertexMatch: a row dies if its read holds another row of the same anchor with a lower line
-__global__ __launch_bounds__(256) void k_dedupe(const uint32_t *read_off, uint64_t n, const uint4 *bkt_key,
-                                                const uint32_t *bkt_idx, const msgpu_row *rows, uint8_t *bkt_dead) {
-  uint64_t p = static_cast<uint64_t>(blockIdx.x) * 256 + threadIdx.x;
-  if (p >= n) return;
-  uint32_t idx = bkt_idx[p];
-  uint32_t r   = rows[idx].read_id;
-  uint4    me  = bkt_key[p];
-  uint32_t b = read_off[r], e = read_off[r + 1];
-  bool     dead = false;
-  for (uint32_t q = b; q < e; ++q) {
-    uint4 o = bkt_key[q];
-    if (o.x == me.x && (o.y < me.y || (o.y == me.y && bkt_idx[q] < idx))) dead = true;
-  }
-  bkt_dead[p] = dead ? 1 : 0;
+__device__ __forceinline__ bool key_less(int alo, int ahi, uint32_t aan, int blo, int bhi, uint32_t ban) {
+  return alo < blo || (alo == blo && (ahi < bhi || (ahi == bhi && aan < ban)));
 }
 
-// rank of every alive row inside its read by (nanoporeRange, anchor id) = the order of mpp.cpp:164-172 / :259-267
-__global__ __launch_bounds__(256) void k_rank_read(const uint32_t *read_off, uint64_t n, const uint4 *bkt_key,
-                                                   const uint32_t *bkt_idx, const uint8_t *bkt_dead,
-                                                   const msgpu_row *rows, IRow *by_read, uint32_t *read_cnt,
-                                                   uint32_t *alive_rank, uint32_t *anchor_cnt) {
-  uint64_t p = static_cast<uint64_t>(blockIdx.x) * 256 + threadIdx.x;
-  if (p >= n) return;
-  uint32_t idx = bkt_idx[p];
-  if (bkt_dead[p]) {
-    alive_rank[idx] = 0xffffffffu;
-    return;
-  }
-  msgpu_row row = rows[idx];
-  uint32_t  r   = row.read_id;
-  uint32_t  b = read_off[r], e = read_off[r + 1];
-  uint32_t  rank = 0;
-  for (uint32_t q = b; q < e; ++q) {
-    if (bkt_dead[q]) continue;
-    uint4 o  = bkt_key[q];
-    int   lo = static_cast<int>(o.z), hi = static_cast<int>(o.w);
-    bool  less = lo < row.n_lo || (lo == row.n_lo && (hi < row.n_hi || (hi == row.n_hi && o.x < row.anchor_id)));
-    rank += less ? 1u : 0u;
-  }
+__device__ __forceinline__ IRow make_irow(const msgpu_row &row, uint32_t other, uint32_t rank) {
   IRow out;
   out.n_lo  = row.n_lo;
   out.n_hi  = row.n_hi;
@@ -291,17 +276,131 @@ __global__ __launch_bounds__(256) void k_rank_read(const uint32_t *read_off, uin
   out.i_hi  = row.i_hi;
   out.score = row.score;
   out.line  = row.line;
-  out.other = row.anchor_id;
-  out.pf    = ((row.flags & MSGPU_ROW_DIR) ? PF_DIR : 0u) | ((row.flags & MSGPU_ROW_PRIMARY) ? PF_PRIM : 0u) | rank;
-  store_irow(&by_read[b + rank], out);
-  alive_rank[idx] = rank;
-  atomicAdd(&read_cnt[r], 1u);
-  atomicAdd(&anchor_cnt[row.anchor_id], 1u);
+  out.other = other;
+  out.pf    = ((row.flags & MSGPU_ROW_DIR) ? PF_DIR : 0u) | ((row.flags & MSGPU_ROW_PRIMARY) ? PF_PRIM : 0u) |
+           (rank & PF_POS_MASK);
+  return out;
+}
+
+// One wavefront per read: MatchMap::addVertexMatch's lowest-line rule (MatchMap.cpp:64-80) + the rank of every alive
+// row by (nanoporeRange, anchor id) = the order of mpp.cpp:164-172 / :259-267.  Reads with <= 64 rows sort in
+// registers (readlane broadcast); longer ones loop over the bucket in global memory.
+// Fast mode (flags == 0): the input order IS the scaffold order, so the by_anchor row is written right here.
+__global__ __launch_bounds__(256) void k_sort_read(const uint32_t *read_off, const uint32_t *cnt_read, uint32_t V,
+                                                   const uint4 *bkt_key, const msgpu_row *rows, IRow *by_read,
+                                                   uint32_t *read_cnt, uint32_t *alive_rank, uint32_t *anchor_cnt,
+                                                   IRow *by_anchor, uint8_t *bkt_dead, uint32_t *flags) {
+  const int      lane = threadIdx.x & 63;
+  const uint32_t r    = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+  if (r >= V) return;
+  const uint32_t b = read_off[r], n = cnt_read[r];
+  if (n == 0) return;
+  const bool fast = (*flags & ~IXF_DUPS) == 0; // decided by pass 1; a duplicate found later is reported to the host
+  if (n <= 64) {
+    const bool have = lane < static_cast<int>(n);
+    uint4      k    = have ? bkt_key[b + lane] : make_uint4(0x7fffffffu, 0x7fffffffu, 0xffffffffu, 0xffffffffu);
+    msgpu_row  row{};
+    if (have) row = rows[k.w];
+    const int      mlo = static_cast<int>(k.x), mhi = static_cast<int>(k.y);
+    const uint32_t man = k.z;
+    uint32_t       less = 0;
+    bool           dup  = false;
+    for (int t = 0; t < static_cast<int>(n); ++t) {
+      const int      olo = rl_i32(mlo, t), ohi = rl_i32(mhi, t);
+      const uint32_t oan = rl_u32(man, t);
+      less += key_less(olo, ohi, oan, mlo, mhi, man) ? 1u : 0u;
+      dup |= (t != lane) & (oan == man);
+    }
+    bool alive = have;
+    if (__ballot(dup && have)) { // rare: a (read, anchor) pair occurs more than once -- lowest line wins
+      bool dead = false;
+      for (int t = 0; t < static_cast<int>(n); ++t) {
+        const uint32_t oan = rl_u32(man, t), oln = rl_u32(row.line, t), oix = rl_u32(k.w, t);
+        dead |= (t != lane) & (oan == man) & (oln < row.line || (oln == row.line && oix < k.w));
+      }
+      alive = have && !dead;
+      less  = 0;
+      for (unsigned long long rem = __ballot(alive); rem; rem &= rem - 1) {
+        const int t = __builtin_ctzll(rem);
+        less += key_less(rl_i32(mlo, t), rl_i32(mhi, t), rl_u32(man, t), mlo, mhi, man) ? 1u : 0u;
+      }
+      if (lane == 0) atomicOr(flags, IXF_DUPS);
+    }
+    if (alive) {
+      store_irow(&by_read[b + less], make_irow(row, row.anchor_id, less));
+      alive_rank[k.w] = less;
+      if (fast)
+        store_irow(&by_anchor[k.w], make_irow(row, r, less));
+      else
+        atomicAdd(&anchor_cnt[row.anchor_id], 1u);
+    } else if (have) {
+      alive_rank[k.w] = 0xffffffffu;
+    }
+    const unsigned long long alive_mask = __ballot(alive); // all lanes vote (not inside the lane-0 branch)
+    if (lane == 0) read_cnt[r] = static_cast<uint32_t>(__popcll(alive_mask));
+    return;
+  }
+  // long read: bucket stays in global memory
+  uint32_t n_alive = 0;
+  for (uint32_t e0 = 0; e0 < n; e0 += 64) {
+    const uint32_t e = e0 + lane;
+    bool           dead = false;
+    if (e < n) {
+      const uint4 k = bkt_key[b + e];
+      for (uint32_t q = 0; q < n; ++q) {
+        const uint4 o = bkt_key[b + q];
+        if (q != e && o.z == k.z) {
+          const uint32_t oln = rows[o.w].line, mln = rows[k.w].line;
+          dead |= oln < mln || (oln == mln && o.w < k.w);
+        }
+      }
+      bkt_dead[b + e] = dead ? 1 : 0;
+      if (dead) alive_rank[k.w] = 0xffffffffu;
+    }
+    if (__ballot(e < n && dead) && lane == 0) atomicOr(flags, IXF_DUPS);
+  }
+  __threadfence(); // the dead flags are read back by other lanes of this wave
+  for (uint32_t e0 = 0; e0 < n; e0 += 64) {
+    const uint32_t e     = e0 + lane;
+    const bool     alive = e < n && !bkt_dead[b + e];
+    if (alive) {
+      const uint4 k    = bkt_key[b + e];
+      uint32_t    less = 0;
+      for (uint32_t q = 0; q < n; ++q) {
+        const uint4 o = bkt_key[b + q];
+        if (!bkt_dead[b + q])
+          less += key_less(static_cast<int>(o.x), static_cast<int>(o.y), o.z, static_cast<int>(k.x),
+                           static_cast<int>(k.y), k.z)
+                      ? 1u
+                      : 0u;
+      }
+      const msgpu_row row = rows[k.w];
+      store_irow(&by_read[b + less], make_irow(row, row.anchor_id, less));
+      alive_rank[k.w] = less;
+      if (fast)
+        store_irow(&by_anchor[k.w], make_irow(row, r, less));
+      else
+        atomicAdd(&anchor_cnt[row.anchor_id], 1u);
+    }
+    n_alive += static_cast<uint32_t>(__popcll(__ballot(alive)));
+  }
+  if (lane == 0) read_cnt[r] = n_alive;
+}
+
+// scaffold offsets: the speculative ones of pass 1 (fast) or the scan of the alive counts (generic)
+__global__ __launch_bounds__(256) void k_select_anchor_off(const uint32_t *flags, const uint32_t *fast_off,
+                                                           const uint32_t *gen_off, uint32_t A, uint32_t *anchor_off,
+                                                           uint32_t *d_n_alive, uint32_t n_rows) {
+  uint32_t   a    = blockIdx.x * 256 + threadIdx.x;
+  const bool fast = (*flags & ~IXF_DUPS) == 0;
+  if (a <= A) anchor_off[a] = fast ? fast_off[a] : gen_off[a];
+  if (a == 0 && fast) *d_n_alive = n_rows;
 }
 
 __global__ __launch_bounds__(256) void k_scatter_anchor(const msgpu_row *rows, uint64_t n, const uint32_t *alive_rank,
                                                         const uint32_t *anchor_off, uint32_t *cursor, uint32_t *bkt_idx,
-                                                        uint32_t *bkt_line) {
+                                                        uint32_t *bkt_line, const uint32_t *flags) {
+  if ((*flags & ~IXF_DUPS) == 0) return; // fast mode: by_anchor already written
   uint64_t i = static_cast<uint64_t>(blockIdx.x) * 256 + threadIdx.x;
   if (i >= n) return;
   if (alive_rank[i] == 0xffffffffu) return;
@@ -314,7 +413,8 @@ __global__ __launch_bounds__(256) void k_scatter_anchor(const msgpu_row *rows, u
 // scaffold of each anchor sorted by line number (MatchMap.cpp:178-183)
 __global__ __launch_bounds__(256) void k_rank_anchor(const uint32_t *anchor_off, const uint32_t *d_n_alive, const uint32_t *bkt_idx,
                                                      const uint32_t *bkt_line, const msgpu_row *rows,
-                                                     const uint32_t *alive_rank, IRow *by_anchor) {
+                                                     const uint32_t *alive_rank, IRow *by_anchor, const uint32_t *flags) {
+  if ((*flags & ~IXF_DUPS) == 0) return;
   uint64_t p = static_cast<uint64_t>(blockIdx.x) * 256 + threadIdx.x;
   if (p >= *d_n_alive) return;
   uint32_t  idx = bkt_idx[p];
@@ -325,17 +425,7 @@ __global__ __launch_bounds__(256) void k_rank_anchor(const uint32_t *anchor_off,
     uint32_t l = bkt_line[q];
     rank += (l < row.line || (l == row.line && bkt_idx[q] < idx)) ? 1u : 0u;
   }
-  IRow out;
-  out.n_lo  = row.n_lo;
-  out.n_hi  = row.n_hi;
-  out.i_lo  = row.i_lo;
-  out.i_hi  = row.i_hi;
-  out.score = row.score;
-  out.line  = row.line;
-  out.other = row.read_id;
-  out.pf    = ((row.flags & MSGPU_ROW_DIR) ? PF_DIR : 0u) | ((row.flags & MSGPU_ROW_PRIMARY) ? PF_PRIM : 0u) |
-           (alive_rank[idx] & PF_POS_MASK);
-  store_irow(&by_anchor[b + rank], out);
+  store_irow(&by_anchor[b + rank], make_irow(row, row.read_id, alive_rank[idx]));
 }
 
 // upper bound of the scaffold rows a read has to visit = sum over its anchors of the scaffold size
@@ -1490,10 +1580,13 @@ void launch_max_ids(hipStream_t st, const msgpu_row *rows, uint64_t n, uint32_t 
     hipLaunchKernelGGL(k_max_ids, dim3(static_cast<uint32_t>(nb < 2048 ? nb : 2048)), dim3(256), 0, st, rows, n, max_ids);
   }
 }
-void launch_hist_read(hipStream_t st, const msgpu_row *rows, uint64_t n, uint32_t *cnt_read, uint64_t *first_key) {
+void launch_index_pass1(hipStream_t st, const msgpu_row *rows, uint64_t n, uint32_t *cnt_read, uint64_t *first_key,
+                        uint32_t *anchor_first, uint32_t A, uint32_t *flags) {
   if (n)
-    hipLaunchKernelGGL(k_hist_read, grid1(n, 256), dim3(256), 0, st, rows, n, cnt_read,
-                       reinterpret_cast<unsigned long long *>(first_key));
+    hipLaunchKernelGGL(k_index_pass1, grid1(n, 256), dim3(256), 0, st, rows, n, cnt_read,
+                       reinterpret_cast<unsigned long long *>(first_key), anchor_first, flags);
+  hipLaunchKernelGGL(k_check_anchor_first, grid1(static_cast<uint64_t>(A) + 1, 256), dim3(256), 0, st, anchor_first, A,
+                     static_cast<uint32_t>(n), flags);
 }
 void launch_read_facts(hipStream_t st, const msgpu_row *rows, const uint64_t *first_key, uint32_t V, int32_t *read_len,
                        uint32_t *read_first, uint32_t *err) {
@@ -1502,36 +1595,37 @@ void launch_read_facts(hipStream_t st, const msgpu_row *rows, const uint64_t *fi
                        reinterpret_cast<const unsigned long long *>(first_key), V, read_len, read_first, err);
 }
 void launch_scatter_read(hipStream_t st, const msgpu_row *rows, uint64_t n, const uint32_t *read_off, uint32_t *cursor,
-                         void *bkt_key, uint32_t *bkt_idx) {
+                         void *bkt_key) {
   if (n)
     hipLaunchKernelGGL(k_scatter_read, grid1(n, 256), dim3(256), 0, st, rows, n, read_off, cursor,
-                       static_cast<uint4 *>(bkt_key), bkt_idx);
+                       static_cast<uint4 *>(bkt_key));
 }
-void launch_dedupe(hipStream_t st, const uint32_t *read_off, uint64_t n, const void *bkt_key, const uint32_t *bkt_idx,
-                   const msgpu_row *rows, uint8_t *bkt_dead) {
-  if (n)
-    hipLaunchKernelGGL(k_dedupe, grid1(n, 256), dim3(256), 0, st, read_off, n, static_cast<const uint4 *>(bkt_key),
-                       bkt_idx, rows, bkt_dead);
+void launch_sort_read(hipStream_t st, const uint32_t *read_off, const uint32_t *cnt_read, uint32_t V, const void *bkt_key,
+                      const msgpu_row *rows, IRow *by_read, uint32_t *read_cnt, uint32_t *alive_rank,
+                      uint32_t *anchor_cnt, IRow *by_anchor, uint8_t *bkt_dead, uint32_t *flags) {
+  if (V)
+    hipLaunchKernelGGL(k_sort_read, grid1(V, 4), dim3(256), 0, st, read_off, cnt_read, V,
+                       static_cast<const uint4 *>(bkt_key), rows, by_read, read_cnt, alive_rank, anchor_cnt, by_anchor,
+                       bkt_dead, flags);
 }
-void launch_rank_read(hipStream_t st, const uint32_t *read_off, uint64_t n, const void *bkt_key, const uint32_t *bkt_idx,
-                      const uint8_t *bkt_dead, const msgpu_row *rows, IRow *by_read, uint32_t *read_cnt,
-                      uint32_t *alive_rank, uint32_t *anchor_cnt) {
-  if (n)
-    hipLaunchKernelGGL(k_rank_read, grid1(n, 256), dim3(256), 0, st, read_off, n, static_cast<const uint4 *>(bkt_key),
-                       bkt_idx, bkt_dead, rows, by_read, read_cnt, alive_rank, anchor_cnt);
+void launch_select_anchor_off(hipStream_t st, const uint32_t *flags, const uint32_t *fast_off, const uint32_t *gen_off,
+                              uint32_t A, uint32_t *anchor_off, uint32_t *d_n_alive, uint32_t n_rows) {
+  hipLaunchKernelGGL(k_select_anchor_off, grid1(static_cast<uint64_t>(A) + 1, 256), dim3(256), 0, st, flags, fast_off,
+                     gen_off, A, anchor_off, d_n_alive, n_rows);
 }
 void launch_scatter_anchor(hipStream_t st, const msgpu_row *rows, uint64_t n, const uint32_t *alive_rank,
-                           const uint32_t *anchor_off, uint32_t *cursor, uint32_t *bkt_idx, uint32_t *bkt_line) {
+                           const uint32_t *anchor_off, uint32_t *cursor, uint32_t *bkt_idx, uint32_t *bkt_line,
+                           const uint32_t *flags) {
   if (n)
     hipLaunchKernelGGL(k_scatter_anchor, grid1(n, 256), dim3(256), 0, st, rows, n, alive_rank, anchor_off, cursor,
-                       bkt_idx, bkt_line);
+                       bkt_idx, bkt_line, flags);
 }
 void launch_rank_anchor(hipStream_t st, const uint32_t *anchor_off, uint64_t n_rows, const uint32_t *d_n_alive,
                         const uint32_t *bkt_idx, const uint32_t *bkt_line, const msgpu_row *rows,
-                        const uint32_t *alive_rank, IRow *by_anchor) {
+                        const uint32_t *alive_rank, IRow *by_anchor, const uint32_t *flags) {
   if (n_rows)
     hipLaunchKernelGGL(k_rank_anchor, grid1(n_rows, 256), dim3(256), 0, st, anchor_off, d_n_alive, bkt_idx, bkt_line,
-                       rows, alive_rank, by_anchor);
+                       rows, alive_rank, by_anchor, flags);
 }
 void launch_bound(hipStream_t st, const uint32_t *read_off, const uint32_t *read_cnt, const IRow *by_read,
                   const uint32_t *anchor_off, uint32_t V, uint32_t shard, uint32_t nshards, uint32_t *bound) {

@@ -21,6 +21,19 @@ def test_synthetic_matches_oracle(oracle, shape):
     assert_tables_equal(got, want, "synth%r" % (shape,))
 
 
+@pytest.mark.parametrize("shape,coverage,what", [
+    ((120, 20000, 2400, 5), 10, "reads with ~190 rows (global-memory sort path), candidate class 1, edges > 64"),
+    ((400, 4000, 120, 6), 200, "200x coverage: candidate lists beyond LDS (k_candidates_big), many edges > 64"),
+])
+def test_dense_inputs_take_the_big_paths(oracle, shape, coverage, what):
+    from muchsalsa_amd import synth
+    rows, _, _ = synth.accepted_rows(synth.paf_table(*shape, coverage=coverage))
+    want = oracle.overlap(rows)
+    assert want["edges"]["em_cnt"].max() > 64, what
+    got = _gpu_tables(rows)
+    assert_tables_equal(got, want, what)
+
+
 def test_empty_and_tiny(oracle):
     from muchsalsa_amd import synth
     rows = synth.synth_rows(300, 3000, 900, 1)
