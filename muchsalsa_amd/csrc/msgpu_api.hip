@@ -73,7 +73,7 @@ struct msgpu_ctx {
       scan_tmp;
   DevBuf bound, cand_off, cand_j, cand_t, scr_v2, scr_start, n_cand, n_edge, n_visit_arr, lists, em_base, edge_base,
       visit_base, edges, edge_cand;
-  DevBuf big_key, big_t, big_r2s, big_pfx;
+  DevBuf big_key, big_t, big_r2s, big_pfx, pair_tab;
   DevBuf ems, order_scr, ids_scr, edge_norders, edge_nids, order_base, ids_base, orders, ids, big_list, big_elems,
       big_paths;
 
@@ -115,7 +115,7 @@ void release_all(msgpu_ctx *c) {
                    &c->bkt2_idx, &c->bkt2_line, &c->by_anchor, &c->read_len, &c->read_first, &c->scalars, &c->scan_tmp,
                    &c->bound, &c->cand_off, &c->cand_j, &c->cand_t, &c->scr_v2, &c->scr_start, &c->n_cand, &c->n_edge,
                    &c->n_visit_arr, &c->lists, &c->em_base, &c->edge_base, &c->visit_base, &c->edges, &c->edge_cand,
-                   &c->big_key, &c->big_t, &c->big_r2s, &c->big_pfx, &c->ems, &c->order_scr, &c->ids_scr,
+                   &c->big_key, &c->big_t, &c->big_r2s, &c->big_pfx, &c->pair_tab, &c->ems, &c->order_scr, &c->ids_scr,
                    &c->edge_norders, &c->edge_nids, &c->order_base, &c->ids_base, &c->orders, &c->ids, &c->big_list,
                    &c->big_elems, &c->big_paths};
   for (DevBuf *b : all) b->release();
@@ -476,6 +476,11 @@ int msgpu_chaining_and_overlaps(msgpu_ctx *c) {
   a.edge_norders = c->edge_norders.as<uint32_t>();
   a.edge_nids    = c->edge_nids.as<uint32_t>();
   a.err          = scalar<uint32_t>(c, SC_ERR);
+  if (!c->pair_tab.p) {
+    ENSURE(c, pair_tab, 2016 * sizeof(uint16_t));
+    launch_fill_pair_tab(st, c->pair_tab.as<uint16_t>());
+  }
+  a.pair_tab     = c->pair_tab.as<uint16_t>();
   a.wiggle       = static_cast<double>(c->p.wiggle_room);
   a.ratio_pct    = c->p.ratio_pct;
   a.alt_frac     = c->p.alt_frac;

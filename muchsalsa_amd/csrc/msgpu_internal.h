@@ -46,6 +46,7 @@ struct ChainArgs {
   uint32_t        *ids_scr;   // slots em_off .. em_off + em_cnt of an edge
   uint32_t        *edge_norders, *edge_nids;
   uint32_t        *err;
+  const uint16_t  *pair_tab; // (l << 8 | k) for the 2016 pairs k < l < 64
   double           wiggle, ratio_pct, alt_frac;
 };
 
@@ -110,6 +111,7 @@ void launch_candidates_big(hipStream_t st, const CandArgs &a, const uint32_t *li
 void launch_emit_edges(hipStream_t st, const uint32_t *n_edge, const uint32_t *n_cand, const uint64_t *edge_base,
                        const uint64_t *em_base, const uint64_t *cand_off, const uint32_t *scr_v2,
                        const uint32_t *scr_start, uint32_t V, msgpu_edge *edges, uint64_t *edge_cand);
+void launch_fill_pair_tab(hipStream_t st, uint16_t *tab);
 void launch_chain(hipStream_t st, const ChainArgs &a);
 void launch_list_big_edges(hipStream_t st, const msgpu_edge *edges, uint64_t n_edges, uint32_t *big_list, uint32_t *n_big);
 size_t big_elem_bytes();

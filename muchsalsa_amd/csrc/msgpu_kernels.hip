@@ -853,21 +853,27 @@ __device__ __forceinline__ int paths_of_direction(unsigned long long act, bool d
     if ((jf != 0 && qf != 0) || (jl != n1 - 1 && ql != n2 - 1)) {
       demote = true; // :272-274
     } else {
-      long long i = 0, jj = 0;
-      bool      is_shadow = false;
-      for (uint64_t rem = m; rem && !is_shadow;) { // :280-296
-        const int t = __builtin_ctzll(rem);
-        rem &= rem - 1;
-        const long long rs    = static_cast<long long>(rl_u32(j1, t)); // always >= i: the path follows v1's order
-        bool            inter = rs > i;
-        i                     = rs + 1;
-        long long re          = static_cast<long long>(rl_u32(qe, t));
-        if (re < jj) re = static_cast<long long>(n2); // std::find_if found nothing from position jj on
-        inter &= re > jj;
-        jj        = re + 1;
-        is_shadow = inter;
-      }
-      demote = is_shadow;
+      // :280-296, all path anchors at once.  The scan walks the path in order; for anchor t it looks for t's position
+      // in v1's list from i (always found: the path follows v1's order) and in v2's list from jj, and calls t
+      // "interleaved" when BOTH searches skipped at least one foreign anchor; it stops at the first such t, so the
+      // outcome is "any t interleaved" with i/jj evolving as if it never stopped:
+      //   i_t  = j1(prev)+1                          -> inter1(t) = j1(t) > j1(prev)+1      (first: j1(t) > 0)
+      //   jj_t = qe(prev)+1 while v2's order agrees  -> inter2(t) = qe(t) > qe(prev)+1      (first: qe(t) > 0)
+      //   at the first t whose qe(t) < jj_t std::find_if runs off the end: re = n2, inter2 = n2 > jj_t, and from then
+      //   on jj = n2+1 so no later anchor can be interleaved.
+      const bool     on   = (m >> lane) & 1ull;
+      const uint64_t below = m & ((1ull << lane) - 1);
+      const int      prev  = below ? 63 - __builtin_clzll(below) : lane; // previous path anchor (self for the first)
+      const uint32_t pj = __shfl(j1, prev), pq = __shfl(qe, prev);
+      const bool     firstt = below == 0;
+      const uint32_t i_t    = firstt ? 0u : pj + 1u;
+      const uint32_t jj_t   = firstt ? 0u : pq + 1u;
+      const bool     viol   = on && qe < jj_t; // v2's order disagrees here
+      const unsigned long long vmask = __ballot(viol);
+      const int      fv   = vmask ? __builtin_ctzll(vmask) : 64;
+      const bool     i1   = j1 > i_t;
+      const bool     i2   = lane < fv ? (qe > jj_t) : (lane == fv ? (n2 > jj_t) : false);
+      demote              = __ballot(on && i1 && i2) != 0;
     }
     if (demote && lane == 0) paths[0].primary = 0;
   }
@@ -972,10 +978,9 @@ __global__ __launch_bounds__(256) void k_chain(ChainArgs a) {
     bool      ok = false;
     int       k = 0, l = 1;
     if (p < P) {
-      l = static_cast<int>((1.0f + __fsqrt_rn(1.0f + 8.0f * static_cast<float>(p))) * 0.5f);
-      if (l * (l - 1) / 2 > p) --l;
-      if ((l + 1) * l / 2 <= p) ++l;
-      k                  = p - l * (l - 1) / 2;
+      const uint32_t kl = a.pair_tab[p]; // (k, l) of pair p: precomputed, the same for every edge
+      k                 = static_cast<int>(kl & 0xffu);
+      l                 = static_cast<int>(kl >> 8);
       const bool kd      = (m_plus >> k) & 1ull, ld = (m_plus >> l) & 1ull;
       if (kd == ld) {
         const ChainElem K = el[k], L = el[l];
@@ -1511,6 +1516,16 @@ __global__ __launch_bounds__(256) void k_list_big_edges(const msgpu_edge *edges,
   if (edges[e].em_cnt > 64) big_list[atomicAdd(n_big, 1u)] = static_cast<uint32_t>(e);
 }
 
+// (k, l) of the flattened pair index p = l(l-1)/2 + k, k < l < 64
+__global__ __launch_bounds__(256) void k_fill_pair_tab(uint16_t *tab) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= 2016) return;
+  int l = static_cast<int>((1.0f + __fsqrt_rn(1.0f + 8.0f * static_cast<float>(p))) * 0.5f);
+  if (l * (l - 1) / 2 > p) --l;
+  if ((l + 1) * l / 2 <= p) ++l;
+  tab[p] = static_cast<uint16_t>((l << 8) | (p - l * (l - 1) / 2));
+}
+
 // dense, canonical order + id tables
 __global__ __launch_bounds__(256) void k_compact(CompactArgs a) {
   uint64_t e = static_cast<uint64_t>(blockIdx.x) * 256 + threadIdx.x;
@@ -1658,6 +1673,9 @@ void launch_emit_edges(hipStream_t st, const uint32_t *n_edge, const uint32_t *n
   if (V)
     hipLaunchKernelGGL(k_emit_edges, grid1(V, 4), dim3(256), 0, st, n_edge, n_cand, edge_base, em_base, cand_off, scr_v2,
                        scr_start, V, edges, edge_cand);
+}
+void launch_fill_pair_tab(hipStream_t st, uint16_t *tab) {
+  hipLaunchKernelGGL(k_fill_pair_tab, dim3(8), dim3(256), 0, st, tab);
 }
 void launch_chain(hipStream_t st, const ChainArgs &a) {
   if (a.n_edges) hipLaunchKernelGGL(k_chain, grid1(a.n_edges, 4), dim3(256), 0, st, a);
