@@ -458,10 +458,17 @@ __global__ __launch_bounds__(256) void k_bound(const uint32_t *read_off, const u
 
 template <int R1MAX, int CMAX>
 __global__ __launch_bounds__(256) void k_candidates(CandArgs a, const uint32_t *read_list, uint32_t n_list) {
+  constexpr int      HSZ   = CMAX; // hash slots >= candidates: insertion always terminates
+  constexpr int      HBITS = CMAX == 1024 ? 10 : CMAX == 2048 ? 11 : CMAX == 4096 ? 12 : 13;
+  static_assert((1 << HBITS) == HSZ, "CMAX must be 1024, 2048, 4096 or 8192");
+  constexpr uint32_t EMPTY = 0xffffffffu;
   __shared__ int      s_ilo[R1MAX], s_ihi[R1MAX];
   __shared__ uint32_t s_aoff[R1MAX], s_pfx[R1MAX + 1];
-  __shared__ uint64_t s_key[CMAX];
-  __shared__ uint32_t s_t[CMAX], s_r2s[CMAX];
+  __shared__ uint32_t s_v2[CMAX];               // v2 of candidate c
+  __shared__ uint32_t s_t[CMAX];                // by_anchor row of candidate c, later of staging position pos
+  __shared__ uint16_t s_j[CMAX], s_g[CMAX];     // j of candidate c / of staging position pos; group of pos
+  __shared__ uint32_t h_key[HSZ], h_cnt[HSZ];   // open-addressing table v2 -> group; members per group
+  __shared__ uint16_t g_list[CMAX], g_rank[HSZ], g_slot[CMAX], g_off[CMAX + 1];
   __shared__ uint32_t s_wave[4], s_nc;
 
   if (blockIdx.x >= n_list) return;
@@ -470,6 +477,10 @@ __global__ __launch_bounds__(256) void k_candidates(CandArgs a, const uint32_t *
   const uint64_t co = a.cand_off[r];
   const int      tid = threadIdx.x;
   if (tid == 0) s_nc = 0;
+  for (int h = tid; h < HSZ; h += 256) {
+    h_key[h] = EMPTY;
+    h_cnt[h] = 0;
+  }
 
   // (a) v1's rows (already in vStart order) and the scaffold extents of their anchors
   constexpr int JPT = R1MAX / 256; // rows per thread, consecutive
@@ -529,7 +540,8 @@ __global__ __launch_bounds__(256) void k_candidates(CandArgs a, const uint32_t *
       base = __shfl(base, 0);
       if (pass) {
         uint32_t c = base + static_cast<uint32_t>(__popcll(m & ((1ull << lane) - 1)));
-        s_key[c]   = (static_cast<uint64_t>(r2) << 32) | j;
+        s_v2[c]    = r2;
+        s_j[c]     = static_cast<uint16_t>(j);
         s_t[c]     = vm;
       }
     }
@@ -537,46 +549,110 @@ __global__ __launch_bounds__(256) void k_candidates(CandArgs a, const uint32_t *
   __syncthreads();
   const uint32_t nc = s_nc;
 
-  // (c) rank sort by (v2, j); keys are unique.  Sorted (j, t) go to the candidate scratch, v2 stays in LDS.
-  for (uint32_t c = tid; c < nc; c += 256) {
-    uint64_t k    = s_key[c];
-    uint32_t rank = 0;
-    for (uint32_t q = 0; q < nc; ++q) rank += (s_key[q] < k) ? 1u : 0u;
-    s_r2s[rank]          = static_cast<uint32_t>(k >> 32);
-    a.cand_j[co + rank]  = static_cast<uint32_t>(k);
-    a.cand_t[co + rank]  = s_t[c];
+  // (c1) group by v2: open-addressing insert; li = arrival number inside the group (any order)
+  constexpr int CPT = CMAX / 256;
+  uint16_t      c_slot[CPT], c_li[CPT], c_j[CPT];
+  uint32_t      c_t[CPT];
+#pragma unroll
+  for (int q = 0; q < CPT; ++q) {
+    const uint32_t c = tid + 256 * q;
+    c_slot[q] = c_li[q] = c_j[q] = 0;
+    c_t[q]                       = 0;
+    if (c < nc) {
+      const uint32_t v2 = s_v2[c];
+      uint32_t       h  = (v2 * 2654435761u) >> (32 - HBITS);
+      while (true) {
+        const uint32_t old = atomicCAS(&h_key[h], EMPTY, v2);
+        if (old == EMPTY || old == v2) break;
+        h = (h + 1) & (HSZ - 1);
+      }
+      c_slot[q] = static_cast<uint16_t>(h);
+      c_li[q]   = static_cast<uint16_t>(atomicAdd(&h_cnt[h], 1u));
+      c_j[q]    = s_j[c];
+      c_t[q]    = s_t[c];
+    }
   }
   __syncthreads();
 
-  // (d) cut into edges: a new edge starts where v2 changes
-  constexpr int CPT = CMAX / 256;
-  uint32_t      fl[CPT], fsum = 0;
+  // (c2) the groups (= edges), ranked by v2
+  uint32_t occ[CPT], osum = 0;
 #pragma unroll
   for (int q = 0; q < CPT; ++q) {
-    uint32_t i = tid * CPT + q;
-    fl[q]      = (i < nc && (i == 0 || s_r2s[i] != s_r2s[i - 1])) ? 1u : 0u;
-    fsum += fl[q];
+    const int h = tid * CPT + q;
+    occ[q]      = h_key[h] != EMPTY ? 1u : 0u;
+    osum += occ[q];
   }
-  uint32_t ne;
-  uint32_t eex = block_excl_scan_256(fsum, s_wave, &ne);
+  uint32_t ng;
+  uint32_t gex = block_excl_scan_256(osum, s_wave, &ng);
+#pragma unroll
+  for (int q = 0; q < CPT; ++q)
+    if (occ[q]) g_list[gex++] = static_cast<uint16_t>(tid * CPT + q);
+  __syncthreads();
+  for (uint32_t g = tid; g < ng; g += 256) {
+    const uint32_t slot = g_list[g], key = h_key[slot];
+    uint32_t       rank = 0;
+    for (uint32_t q = 0; q < ng; ++q) rank += (h_key[g_list[q]] < key) ? 1u : 0u;
+    g_rank[slot] = static_cast<uint16_t>(rank);
+    g_slot[rank] = static_cast<uint16_t>(slot);
+  }
+  __syncthreads();
+
+  // (c3) first staging position of every group, in v2 order
+  uint32_t gc[CPT], gsum = 0;
 #pragma unroll
   for (int q = 0; q < CPT; ++q) {
-    uint32_t i = tid * CPT + q;
-    if (fl[q]) {
-      a.edge_scr_v2[co + eex]    = s_r2s[i];
-      a.edge_scr_start[co + eex] = i;
-      ++eex;
+    const uint32_t rk = tid * CPT + q;
+    gc[q]             = rk < ng ? h_cnt[g_slot[rk]] : 0u;
+    gsum += gc[q];
+  }
+  uint32_t tot;
+  uint32_t oex = block_excl_scan_256(gsum, s_wave, &tot);
+#pragma unroll
+  for (int q = 0; q < CPT; ++q) {
+    const uint32_t rk = tid * CPT + q;
+    if (rk < ng) g_off[rk] = static_cast<uint16_t>(oex);
+    oex += gc[q];
+  }
+  if (tid == 0) g_off[ng] = static_cast<uint16_t>(nc);
+  __syncthreads();
+
+  // (c4) move every candidate to its group's staging segment (own values were read into registers before the sync)
+#pragma unroll
+  for (int q = 0; q < CPT; ++q) {
+    const uint32_t c = tid + 256 * q;
+    if (c < nc) {
+      const uint32_t rk  = g_rank[c_slot[q]];
+      const uint32_t pos = g_off[rk] + c_li[q];
+      s_j[pos]           = c_j[q];
+      s_t[pos]           = c_t[q];
+      s_g[pos]           = static_cast<uint16_t>(rk);
     }
+  }
+  __syncthreads();
+
+  // (c5) inside a group order by j = the vStart order of mpp.cpp:164-172 (j is unique inside a group)
+  for (uint32_t pos = tid; pos < nc; pos += 256) {
+    const uint32_t rk = s_g[pos], gs = g_off[rk], ge = g_off[rk + 1];
+    const uint16_t mj = s_j[pos];
+    uint32_t       rr = 0;
+    for (uint32_t q = gs; q < ge; ++q) rr += (s_j[q] < mj) ? 1u : 0u;
+    a.cand_j[co + gs + rr] = mj;
+    a.cand_t[co + gs + rr] = s_t[pos];
+  }
+  // (d) one edge per group
+  for (uint32_t g = tid; g < ng; g += 256) {
+    a.edge_scr_v2[co + g]    = h_key[g_slot[g]];
+    a.edge_scr_start[co + g] = g_off[g];
   }
   if (tid == 0) {
     a.n_cand[r]  = nc;
-    a.n_edge[r]  = ne;
+    a.n_edge[r]  = ng;
     a.n_visit[r] = T;
   }
 }
 
 template __global__ void k_candidates<256, 1024>(CandArgs, const uint32_t *, uint32_t);
-template __global__ void k_candidates<1024, 8192>(CandArgs, const uint32_t *, uint32_t);
+template __global__ void k_candidates<1024, 4096>(CandArgs, const uint32_t *, uint32_t);
 
 // classify reads of this shard by the LDS footprint their candidate scan needs
 __global__ __launch_bounds__(256) void k_classify_reads(const uint32_t *read_cnt, const uint32_t *bound, uint32_t V,
@@ -586,7 +662,7 @@ __global__ __launch_bounds__(256) void k_classify_reads(const uint32_t *read_cnt
   int      cls = -1;
   if (r < V && r % nshards == shard) {
     uint32_t n1 = read_cnt[r], bd = bound[r];
-    if (n1 != 0 && bd != 0) cls = (n1 <= 256 && bd <= 1024) ? 0 : (n1 <= 1024 && bd <= 8192) ? 1 : 2;
+    if (n1 != 0 && bd != 0) cls = (n1 <= 256 && bd <= 1024) ? 0 : (n1 <= 1024 && bd <= 4096) ? 1 : 2;
   }
   // one atomic per wave and class
   const int lane = threadIdx.x & 63;
@@ -1526,24 +1602,43 @@ __global__ __launch_bounds__(256) void k_fill_pair_tab(uint16_t *tab) {
   tab[p] = static_cast<uint16_t>((l << 8) | (p - l * (l - 1) / 2));
 }
 
-// dense, canonical order + id tables
+// dense, canonical order + id tables.  One wavefront per 64 edges: every lane fetches its edge's bookkeeping, then
+// the wave walks the 64 edges together and copies each order (16 dwords) and its ids (<= 64 per order in one step)
+// with all lanes -- no serial per-thread copy loops.
 __global__ __launch_bounds__(256) void k_compact(CompactArgs a) {
-  uint64_t e = static_cast<uint64_t>(blockIdx.x) * 256 + threadIdx.x;
-  if (e >= a.n_edges) return;
-  msgpu_edge ed  = a.edges[e];
-  uint32_t   no  = a.edge_norders[e];
-  uint64_t   oo  = a.order_base[e];
-  uint64_t   io  = a.ids_base[e];
-  for (uint32_t i = 0; i < no; ++i) {
-    msgpu_order o = a.order_scr[ed.em_off + i];
-    const uint64_t src = ed.em_off + o.ids_off;
-    o.ids_off          = io;
-    a.orders[oo + i]   = o;
-    for (uint32_t q = 0; q < o.ids_cnt; ++q) a.ids[io + q] = a.ids_scr[src + q];
-    io += o.ids_cnt;
+  const int      lane = threadIdx.x & 63;
+  const uint64_t e0   = (static_cast<uint64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6)) * 64;
+  if (e0 >= a.n_edges) return;
+  const uint64_t e    = e0 + lane;
+  const bool     have = e < a.n_edges;
+  uint32_t       no = 0;
+  uint64_t       oo = 0, io = 0, em_off = 0;
+  if (have) {
+    no     = a.edge_norders[e];
+    oo     = a.order_base[e];
+    io     = a.ids_base[e];
+    em_off = a.edges[e].em_off;
+    a.edges[e].order_off = oo;
+    a.edges[e].order_cnt = static_cast<uint16_t>(no);
   }
-  a.edges[e].order_off = oo;
-  a.edges[e].order_cnt = static_cast<uint16_t>(no);
+  for (unsigned long long rem = __ballot(no != 0); rem; rem &= rem - 1) {
+    const int      t    = __builtin_ctzll(rem);
+    const uint32_t t_no = rl_u32(no, t);
+    const uint64_t t_oo = rl_u64(oo, t), t_em = rl_u64(em_off, t);
+    uint64_t       t_io = rl_u64(io, t);
+    for (uint32_t i = 0; i < t_no; ++i) {
+      const uint32_t *src = reinterpret_cast<const uint32_t *>(&a.order_scr[t_em + i]);
+      uint32_t       *dst = reinterpret_cast<uint32_t *>(&a.orders[t_oo + i]);
+      // msgpu_order as 16 dwords: [8,9] = ids_off (edge-relative in the scratch), [10] = ids_cnt
+      uint32_t w = lane < 16 ? src[lane] : 0;
+      const uint32_t rel = rl_u32(w, 8), cnt = rl_u32(w, 10);
+      if (lane == 8) w = static_cast<uint32_t>(t_io);
+      if (lane == 9) w = static_cast<uint32_t>(t_io >> 32);
+      if (lane < 16) dst[lane] = w;
+      for (uint32_t q = lane; q < cnt; q += 64) a.ids[t_io + q] = a.ids_scr[t_em + rel + q];
+      t_io += cnt;
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1659,7 +1754,7 @@ void launch_candidates(hipStream_t st, const CandArgs &a, int cls, const uint32_
   if (cls == 0)
     hipLaunchKernelGGL((k_candidates<256, 1024>), dim3(n_list), dim3(256), 0, st, a, list, n_list);
   else
-    hipLaunchKernelGGL((k_candidates<1024, 8192>), dim3(n_list), dim3(256), 0, st, a, list, n_list);
+    hipLaunchKernelGGL((k_candidates<1024, 4096>), dim3(n_list), dim3(256), 0, st, a, list, n_list);
 }
 void launch_candidates_big(hipStream_t st, const CandArgs &a, const uint32_t *list, uint32_t n_list, uint64_t *big_key,
                            uint32_t *big_t, uint32_t *big_r2s, uint32_t *big_pfx) {
@@ -1698,7 +1793,7 @@ void launch_merge_gathered(hipStream_t st, const MergeArgs &a) {
   if (n) hipLaunchKernelGGL(k_merge_gathered, grid1(n, 256), dim3(256), 0, st, a);
 }
 void launch_compact(hipStream_t st, const CompactArgs &a) {
-  if (a.n_edges) hipLaunchKernelGGL(k_compact, grid1(a.n_edges, 256), dim3(256), 0, st, a);
+  if (a.n_edges) hipLaunchKernelGGL(k_compact, grid1(a.n_edges, 256), dim3(256), 0, st, a);  // 4 waves x 64 edges
 }
 
 } // namespace msgpu
