@@ -142,7 +142,8 @@ int build_index_once(msgpu_ctx *c, bool force_generic, uint32_t *ix_flags_out) {
   ENSURE(c, first_key, (size_t(V) + 1) * 8);
   ENSURE(c, read_off, (size_t(V) + 2) * 4);
   ENSURE(c, cursor, mva * 4);
-  ENSURE(c, bkt_key, nz * 16);
+  ENSURE(c, bkt_key, nz * sizeof(IRow));
+  ENSURE(c, bkt_idx, nz * 4);
   ENSURE(c, bkt_dead, nz);
   ENSURE(c, by_read, nz * sizeof(IRow));
   ENSURE(c, read_cnt, (size_t(V) + 1) * 4);
@@ -181,10 +182,12 @@ int build_index_once(msgpu_ctx *c, bool force_generic, uint32_t *ix_flags_out) {
                     c->read_first.as<uint32_t>(), scalar<uint32_t>(c, SC_ERR));
   exclusive_scan<uint32_t>(st, c->cnt_read.as<uint32_t>(), V, c->read_off.as<uint32_t>(), c->scan_tmp.as<uint32_t>(),
                            scalar<uint32_t>(c, SC_TOTAL_A));
-  launch_scatter_read(st, c->d_rows, n, c->read_off.as<uint32_t>(), c->cursor.as<uint32_t>(), c->bkt_key.p);
-  launch_sort_read(st, c->read_off.as<uint32_t>(), c->cnt_read.as<uint32_t>(), V, c->bkt_key.p, c->d_rows,
-                   c->by_read.as<IRow>(), c->read_cnt.as<uint32_t>(), c->alive_rank.as<uint32_t>(),
-                   c->anchor_cnt.as<uint32_t>(), c->by_anchor.as<IRow>(), c->bkt_dead.as<uint8_t>(), d_flags);
+  launch_scatter_read(st, c->d_rows, n, c->read_off.as<uint32_t>(), c->cursor.as<uint32_t>(), c->bkt_key.as<IRow>(),
+                      c->bkt_idx.as<uint32_t>());
+  launch_sort_read(st, c->read_off.as<uint32_t>(), c->cnt_read.as<uint32_t>(), V, c->bkt_key.as<IRow>(),
+                   c->bkt_idx.as<uint32_t>(), c->by_read.as<IRow>(), c->read_cnt.as<uint32_t>(),
+                   c->alive_rank.as<uint32_t>(), c->anchor_cnt.as<uint32_t>(), c->bkt_dead.as<uint8_t>(), d_flags);
+  launch_fill_by_anchor(st, c->d_rows, n, c->alive_rank.as<uint32_t>(), c->by_anchor.as<IRow>(), d_flags);
   // generic by_anchor path (no-ops in fast mode)
   exclusive_scan<uint32_t>(st, c->anchor_cnt.as<uint32_t>(), A, c->anchor_off_gen.as<uint32_t>(),
                            c->scan_tmp.as<uint32_t>(), scalar<uint32_t>(c, SC_NALIVE));

@@ -48,6 +48,20 @@ __device__ __forceinline__ void store_irow(IRow *p, const IRow &r) {
   q[1]     = make_uint4(r.score, r.line, r.other, r.pf);
 }
 
+__device__ __forceinline__ IRow make_irow(const msgpu_row &row, uint32_t other, uint32_t rank) {
+  IRow out;
+  out.n_lo  = row.n_lo;
+  out.n_hi  = row.n_hi;
+  out.i_lo  = row.i_lo;
+  out.i_hi  = row.i_hi;
+  out.score = row.score;
+  out.line  = row.line;
+  out.other = other;
+  out.pf    = ((row.flags & MSGPU_ROW_DIR) ? PF_DIR : 0u) | ((row.flags & MSGPU_ROW_PRIMARY) ? PF_PRIM : 0u) |
+           (rank & PF_POS_MASK);
+  return out;
+}
+
 // readlane of wider types (lane index must be wave-uniform)
 __device__ __forceinline__ int rl_i32(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
 __device__ __forceinline__ uint32_t rl_u32(uint32_t v, int lane) {
@@ -253,43 +267,31 @@ __global__ __launch_bounds__(256) void k_read_facts(const msgpu_row *rows, const
   }
 }
 
-// bucket rows by read: key record {n_lo, n_hi, anchor, source index}
+// bucket rows by read: the whole row goes into the bucket (a fire-and-forget 32 B + 4 B scatter), so the sort
+// kernel reads its bucket with contiguous loads instead of gathering 40 B rows.  IRow.other = anchor, IRow.pf = flags.
 __global__ __launch_bounds__(256) void k_scatter_read(const msgpu_row *rows, uint64_t n, const uint32_t *read_off,
-                                                      uint32_t *cursor, uint4 *bkt_key) {
+                                                      uint32_t *cursor, IRow *bkt_row, uint32_t *bkt_idx) {
   uint64_t i = static_cast<uint64_t>(blockIdx.x) * 256 + threadIdx.x;
   if (i >= n) return;
-  const uint32_t rd  = rows[i].read_id;
-  const uint32_t pos = read_off[rd] + atomicAdd(&cursor[rd], 1u);
-  bkt_key[pos] = make_uint4(static_cast<uint32_t>(rows[i].n_lo), static_cast<uint32_t>(rows[i].n_hi), rows[i].anchor_id,
-                            static_cast<uint32_t>(i));
+  const msgpu_row row = rows[i];
+  const uint32_t  pos = read_off[row.read_id] + atomicAdd(&cursor[row.read_id], 1u);
+  store_irow(&bkt_row[pos], make_irow(row, row.anchor_id, 0));
+  bkt_idx[pos] = static_cast<uint32_t>(i);
 }
 
 __device__ __forceinline__ bool key_less(int alo, int ahi, uint32_t aan, int blo, int bhi, uint32_t ban) {
   return alo < blo || (alo == blo && (ahi < bhi || (ahi == bhi && aan < ban)));
 }
 
-__device__ __forceinline__ IRow make_irow(const msgpu_row &row, uint32_t other, uint32_t rank) {
-  IRow out;
-  out.n_lo  = row.n_lo;
-  out.n_hi  = row.n_hi;
-  out.i_lo  = row.i_lo;
-  out.i_hi  = row.i_hi;
-  out.score = row.score;
-  out.line  = row.line;
-  out.other = other;
-  out.pf    = ((row.flags & MSGPU_ROW_DIR) ? PF_DIR : 0u) | ((row.flags & MSGPU_ROW_PRIMARY) ? PF_PRIM : 0u) |
-           (rank & PF_POS_MASK);
-  return out;
-}
-
 // One wavefront per read: MatchMap::addVertexMatch's lowest-line rule (MatchMap.cpp:64-80) + the rank of every alive
 // row by (nanoporeRange, anchor id) = the order of mpp.cpp:164-172 / :259-267.  Reads with <= 64 rows sort in
 // registers (readlane broadcast); longer ones loop over the bucket in global memory.
-// Fast mode (flags == 0): the input order IS the scaffold order, so the by_anchor row is written right here.
+// Output: by_read rows (rank order), read_cnt, alive_rank[source row] (rank, or 0xffffffff for a dead row) and, in
+// generic mode, the per-anchor alive counts.
 __global__ __launch_bounds__(256) void k_sort_read(const uint32_t *read_off, const uint32_t *cnt_read, uint32_t V,
-                                                   const uint4 *bkt_key, const msgpu_row *rows, IRow *by_read,
+                                                   const IRow *bkt_row, const uint32_t *bkt_idx, IRow *by_read,
                                                    uint32_t *read_cnt, uint32_t *alive_rank, uint32_t *anchor_cnt,
-                                                   IRow *by_anchor, uint8_t *bkt_dead, uint32_t *flags) {
+                                                   uint8_t *bkt_dead, uint32_t *flags) {
   const int      lane = threadIdx.x & 63;
   const uint32_t r    = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
   if (r >= V) return;
@@ -298,11 +300,14 @@ __global__ __launch_bounds__(256) void k_sort_read(const uint32_t *read_off, con
   const bool fast = (*flags & ~IXF_DUPS) == 0; // decided by pass 1; a duplicate found later is reported to the host
   if (n <= 64) {
     const bool have = lane < static_cast<int>(n);
-    uint4      k    = have ? bkt_key[b + lane] : make_uint4(0x7fffffffu, 0x7fffffffu, 0xffffffffu, 0xffffffffu);
-    msgpu_row  row{};
-    if (have) row = rows[k.w];
-    const int      mlo = static_cast<int>(k.x), mhi = static_cast<int>(k.y);
-    const uint32_t man = k.z;
+    IRow       row{};
+    uint32_t   idx = 0xffffffffu;
+    if (have) {
+      row = load_irow(&bkt_row[b + lane]);
+      idx = bkt_idx[b + lane];
+    }
+    const int      mlo = have ? row.n_lo : 0x7fffffff, mhi = have ? row.n_hi : 0x7fffffff;
+    const uint32_t man = have ? row.other : 0xffffffffu;
     uint32_t       less = 0;
     bool           dup  = false;
     for (int t = 0; t < static_cast<int>(n); ++t) {
@@ -315,8 +320,8 @@ __global__ __launch_bounds__(256) void k_sort_read(const uint32_t *read_off, con
     if (__ballot(dup && have)) { // rare: a (read, anchor) pair occurs more than once -- lowest line wins
       bool dead = false;
       for (int t = 0; t < static_cast<int>(n); ++t) {
-        const uint32_t oan = rl_u32(man, t), oln = rl_u32(row.line, t), oix = rl_u32(k.w, t);
-        dead |= (t != lane) & (oan == man) & (oln < row.line || (oln == row.line && oix < k.w));
+        const uint32_t oan = rl_u32(man, t), oln = rl_u32(row.line, t), oix = rl_u32(idx, t);
+        dead |= (t != lane) & (oan == man) & (oln < row.line || (oln == row.line && oix < idx));
       }
       alive = have && !dead;
       less  = 0;
@@ -327,14 +332,12 @@ __global__ __launch_bounds__(256) void k_sort_read(const uint32_t *read_off, con
       if (lane == 0) atomicOr(flags, IXF_DUPS);
     }
     if (alive) {
-      store_irow(&by_read[b + less], make_irow(row, row.anchor_id, less));
-      alive_rank[k.w] = less;
-      if (fast)
-        store_irow(&by_anchor[k.w], make_irow(row, r, less));
-      else
-        atomicAdd(&anchor_cnt[row.anchor_id], 1u);
+      row.pf = (row.pf & ~PF_POS_MASK) | less;
+      store_irow(&by_read[b + less], row);
+      alive_rank[idx] = less;
+      if (!fast) atomicAdd(&anchor_cnt[row.other], 1u);
     } else if (have) {
-      alive_rank[k.w] = 0xffffffffu;
+      alive_rank[idx] = 0xffffffffu;
     }
     const unsigned long long alive_mask = __ballot(alive); // all lanes vote (not inside the lane-0 branch)
     if (lane == 0) read_cnt[r] = static_cast<uint32_t>(__popcll(alive_mask));
@@ -346,16 +349,14 @@ __global__ __launch_bounds__(256) void k_sort_read(const uint32_t *read_off, con
     const uint32_t e = e0 + lane;
     bool           dead = false;
     if (e < n) {
-      const uint4 k = bkt_key[b + e];
+      const IRow     k   = load_irow(&bkt_row[b + e]);
+      const uint32_t kix = bkt_idx[b + e];
       for (uint32_t q = 0; q < n; ++q) {
-        const uint4 o = bkt_key[b + q];
-        if (q != e && o.z == k.z) {
-          const uint32_t oln = rows[o.w].line, mln = rows[k.w].line;
-          dead |= oln < mln || (oln == mln && o.w < k.w);
-        }
+        const IRow o = load_irow(&bkt_row[b + q]);
+        if (q != e && o.other == k.other) dead |= o.line < k.line || (o.line == k.line && bkt_idx[b + q] < kix);
       }
       bkt_dead[b + e] = dead ? 1 : 0;
-      if (dead) alive_rank[k.w] = 0xffffffffu;
+      if (dead) alive_rank[kix] = 0xffffffffu;
     }
     if (__ballot(e < n && dead) && lane == 0) atomicOr(flags, IXF_DUPS);
   }
@@ -364,27 +365,31 @@ __global__ __launch_bounds__(256) void k_sort_read(const uint32_t *read_off, con
     const uint32_t e     = e0 + lane;
     const bool     alive = e < n && !bkt_dead[b + e];
     if (alive) {
-      const uint4 k    = bkt_key[b + e];
-      uint32_t    less = 0;
+      IRow     k    = load_irow(&bkt_row[b + e]);
+      uint32_t less = 0;
       for (uint32_t q = 0; q < n; ++q) {
-        const uint4 o = bkt_key[b + q];
-        if (!bkt_dead[b + q])
-          less += key_less(static_cast<int>(o.x), static_cast<int>(o.y), o.z, static_cast<int>(k.x),
-                           static_cast<int>(k.y), k.z)
-                      ? 1u
-                      : 0u;
+        const IRow o = load_irow(&bkt_row[b + q]);
+        if (!bkt_dead[b + q]) less += key_less(o.n_lo, o.n_hi, o.other, k.n_lo, k.n_hi, k.other) ? 1u : 0u;
       }
-      const msgpu_row row = rows[k.w];
-      store_irow(&by_read[b + less], make_irow(row, row.anchor_id, less));
-      alive_rank[k.w] = less;
-      if (fast)
-        store_irow(&by_anchor[k.w], make_irow(row, r, less));
-      else
-        atomicAdd(&anchor_cnt[row.anchor_id], 1u);
+      k.pf = (k.pf & ~PF_POS_MASK) | less;
+      store_irow(&by_read[b + less], k);
+      alive_rank[bkt_idx[b + e]] = less;
+      if (!fast) atomicAdd(&anchor_cnt[k.other], 1u);
     }
     n_alive += static_cast<uint32_t>(__popcll(__ballot(alive)));
   }
   if (lane == 0) read_cnt[r] = n_alive;
+}
+
+// fast mode: the input order is the scaffold order, so by_anchor is a streaming rewrite of the rows
+// (other = read id, pf = flags | rank of the row inside its read)
+__global__ __launch_bounds__(256) void k_fill_by_anchor(const msgpu_row *rows, uint64_t n, const uint32_t *alive_rank,
+                                                        IRow *by_anchor, const uint32_t *flags) {
+  if ((*flags & ~IXF_DUPS) != 0) return; // generic mode: k_scatter_anchor + k_rank_anchor build it
+  uint64_t i = static_cast<uint64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (i >= n) return;
+  const msgpu_row row = rows[i];
+  store_irow(&by_anchor[i], make_irow(row, row.read_id, alive_rank[i]));
 }
 
 // scaffold offsets: the speculative ones of pass 1 (fast) or the scan of the alive counts (generic)
@@ -1705,18 +1710,20 @@ void launch_read_facts(hipStream_t st, const msgpu_row *rows, const uint64_t *fi
                        reinterpret_cast<const unsigned long long *>(first_key), V, read_len, read_first, err);
 }
 void launch_scatter_read(hipStream_t st, const msgpu_row *rows, uint64_t n, const uint32_t *read_off, uint32_t *cursor,
-                         void *bkt_key) {
+                         IRow *bkt_row, uint32_t *bkt_idx) {
   if (n)
-    hipLaunchKernelGGL(k_scatter_read, grid1(n, 256), dim3(256), 0, st, rows, n, read_off, cursor,
-                       static_cast<uint4 *>(bkt_key));
+    hipLaunchKernelGGL(k_scatter_read, grid1(n, 256), dim3(256), 0, st, rows, n, read_off, cursor, bkt_row, bkt_idx);
 }
-void launch_sort_read(hipStream_t st, const uint32_t *read_off, const uint32_t *cnt_read, uint32_t V, const void *bkt_key,
-                      const msgpu_row *rows, IRow *by_read, uint32_t *read_cnt, uint32_t *alive_rank,
-                      uint32_t *anchor_cnt, IRow *by_anchor, uint8_t *bkt_dead, uint32_t *flags) {
+void launch_sort_read(hipStream_t st, const uint32_t *read_off, const uint32_t *cnt_read, uint32_t V, const IRow *bkt_row,
+                      const uint32_t *bkt_idx, IRow *by_read, uint32_t *read_cnt, uint32_t *alive_rank,
+                      uint32_t *anchor_cnt, uint8_t *bkt_dead, uint32_t *flags) {
   if (V)
-    hipLaunchKernelGGL(k_sort_read, grid1(V, 4), dim3(256), 0, st, read_off, cnt_read, V,
-                       static_cast<const uint4 *>(bkt_key), rows, by_read, read_cnt, alive_rank, anchor_cnt, by_anchor,
-                       bkt_dead, flags);
+    hipLaunchKernelGGL(k_sort_read, grid1(V, 4), dim3(256), 0, st, read_off, cnt_read, V, bkt_row, bkt_idx, by_read,
+                       read_cnt, alive_rank, anchor_cnt, bkt_dead, flags);
+}
+void launch_fill_by_anchor(hipStream_t st, const msgpu_row *rows, uint64_t n, const uint32_t *alive_rank, IRow *by_anchor,
+                           const uint32_t *flags) {
+  if (n) hipLaunchKernelGGL(k_fill_by_anchor, grid1(n, 256), dim3(256), 0, st, rows, n, alive_rank, by_anchor, flags);
 }
 void launch_select_anchor_off(hipStream_t st, const uint32_t *flags, const uint32_t *fast_off, const uint32_t *gen_off,
                               uint32_t A, uint32_t *anchor_off, uint32_t *d_n_alive, uint32_t n_rows) {
