@@ -215,6 +215,64 @@ int msgpu_merge_gathered(msgpu_ctx *ctx, const void *d_gathered, uint32_t world,
 /* Block the host until everything queued on the context's stream has finished. */
 int msgpu_synchronize(msgpu_ctx *ctx);
 
+/* ==== sequence store + slice / reverse-complement / stitch kernel: device half of the "consensus" stage (A9) ========
+ *
+ * assemblePath (libms/src/kernel/ap.cpp:615-1362) decides where every piece of sequence goes; the bytes come from
+ *   SequenceAccessor::buildIndex / get{Nanopore,Illumina}Sequence(id)     SequenceAccessor.cpp:54-69,114-231
+ *   strSlice, getReverseComplement, get{Illumina,Nanopore}Sequence(l,r,d)  SequenceUtils.cpp:27-85
+ *   updateConsensusBase (prepend / append the uncovered part)              ap.cpp:205-229
+ * Here: the files are parsed once on the host (msgpu_seq_parse), every record lives whitespace-free in HBM
+ * (msgpu_seq_upload), and a whole batch of pieces is produced by ONE kernel launch (msgpu_gather_run). */
+
+typedef struct msgpu_seqfile msgpu_seqfile;     /* a parsed FASTA/FASTQ file on the host              */
+typedef struct msgpu_seqctx msgpu_seqctx;       /* the two sequence stores (nanopore, illumina) in HBM */
+typedef struct msgpu_gather_plan msgpu_gather_plan;
+
+/* Replaces SequenceAccessor::_buildNanoporeIdx/_buildIlluminaIdx + getSequenceFromFile.  is_fastq: 1, 0, or -1 to
+ * decide from the extension like isFastQ (SequenceAccessor.cpp:71-80: FASTQ unless ".fa"/".fasta"). */
+int         msgpu_seq_parse(const char *path, int is_fastq, msgpu_seqfile **out);
+void        msgpu_seq_free(msgpu_seqfile *f);
+uint32_t    msgpu_seq_count(const msgpu_seqfile *f);
+const char *msgpu_seq_name(const msgpu_seqfile *f, uint32_t record);   /* cleaned id (cut at the first whitespace) */
+uint64_t    msgpu_seq_length(const msgpu_seqfile *f, uint32_t record);
+const char *msgpu_seq_bases(const msgpu_seqfile *f, uint32_t record);  /* not NUL-terminated                       */
+
+/* strSlice (SequenceUtils.cpp:27-38) as (returned offset, *len): Python-like indices, INCLUSIVE clipped end. */
+uint64_t msgpu_str_slice(uint64_t size, int32_t start, int32_t end, uint64_t *len);
+
+int         msgpu_seq_create(int device, msgpu_seqctx **out);   /* MSGPU_E_NODEVICE without a GPU */
+void        msgpu_seq_destroy(msgpu_seqctx *ctx);
+const char *msgpu_seq_last_error(const msgpu_seqctx *ctx);
+/* kind 0 = nanopore reads, 1 = illumina unitigs.  ids[record] = Registry id of that record (0xffffffff = skip);
+ * NULL = record order.  n_ids = size of the id space. */
+int msgpu_seq_upload(msgpu_seqctx *ctx, int kind, const msgpu_seqfile *f, const uint32_t *ids, uint32_t n_ids);
+
+/* One piece of output: `len` bases starting at `src_off` of a store, as they are or reverse-complemented, written
+ * at dst_off.  24 bytes. */
+typedef struct msgpu_copy {
+  uint64_t src_off; /* first source base, offset inside the store                     */
+  uint64_t dst_off; /* first output byte                                               */
+  uint32_t len;
+  uint32_t flags;   /* MSGPU_COPY_*                                                    */
+} msgpu_copy;
+#define MSGPU_COPY_ILLUMINA 1u /* source store: illumina (else nanopore)                */
+#define MSGPU_COPY_REVCOMP 2u  /* reverse complement (direction == false)               */
+
+/* get{Nanopore,Illumina}Sequence(seq_id, left, right, direction) (SequenceUtils.cpp:63-85) as a piece: fills src_off,
+ * len and flags of *out (dst_off is the caller's layout decision). */
+int msgpu_seq_resolve(msgpu_seqctx *ctx, int kind, uint32_t seq_id, int32_t left, int32_t right, int direction,
+                      msgpu_copy *out);
+
+/* Upload a batch of pieces (+ its work partition) once; run it any number of times. */
+int      msgpu_gather_plan_create(msgpu_seqctx *ctx, const msgpu_copy *pieces, size_t n, msgpu_gather_plan **out);
+void     msgpu_gather_plan_free(msgpu_gather_plan *plan);
+uint64_t msgpu_gather_plan_out_bytes(const msgpu_gather_plan *plan); /* max(dst_off + len)  */
+uint64_t msgpu_gather_plan_bases(const msgpu_gather_plan *plan);     /* sum(len)            */
+/* d_out: device buffer of out_capacity >= out_bytes.  hip_stream NULL = the context's stream. Asynchronous. */
+int msgpu_gather_run(msgpu_seqctx *ctx, const msgpu_gather_plan *plan, void *d_out, uint64_t out_capacity,
+                     void *hip_stream);
+int msgpu_seq_synchronize(msgpu_seqctx *ctx);
+
 #ifdef __cplusplus
 }
 #endif

@@ -2,4 +2,4 @@
 
 The compute lives in libmsgpu.so (hand-written HIP for gfx950); nothing here computes on the CPU.
 """
-__all__ = ["overlap", "synth"]
+__all__ = ["overlap", "sequences", "distributed", "synth"]

@@ -20,7 +20,10 @@ EM_DTYPE = np.dtype([("ov_lo", "<i4"), ("ov_hi", "<i4"), ("score", "<f8"), ("anc
 ORDER_DTYPE = np.dtype([("edge_idx", "<u4"), ("flags", "<u4"), ("left_offset", "<f8"), ("right_offset", "<f8"),
                         ("score", "<u8"), ("ids_off", "<u8"), ("ids_cnt", "<u4"), ("start", "<u4"), ("end", "<u4"),
                         ("base", "<u4"), ("pad", "<u4", (2,))])
+COPY_DTYPE = np.dtype([("src_off", "<u8"), ("dst_off", "<u8"), ("len", "<u4"), ("flags", "<u4")])
 assert (ROW_DTYPE.itemsize, EDGE_DTYPE.itemsize, EM_DTYPE.itemsize, ORDER_DTYPE.itemsize) == (40, 32, 32, 64)
+assert COPY_DTYPE.itemsize == 24
+COPY_ILLUMINA, COPY_REVCOMP = 1, 2
 
 OK = 0
 E_IO, E_FORMAT, E_NUMBER, E_NOMEM, E_ARG, E_HIP, E_STATE, E_IDS, E_NODEVICE = -1, -2, -3, -4, -5, -6, -7, -8, -9
@@ -75,6 +78,24 @@ SYMBOLS = [
     ("msgpu_merge_gathered", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_uint64,
                                        C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("msgpu_synchronize", C.c_int, [C.c_void_p]),
+    ("msgpu_seq_parse", C.c_int, [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]),
+    ("msgpu_seq_free", None, [C.c_void_p]),
+    ("msgpu_seq_count", C.c_uint32, [C.c_void_p]),
+    ("msgpu_seq_name", C.c_char_p, [C.c_void_p, C.c_uint32]),
+    ("msgpu_seq_length", C.c_uint64, [C.c_void_p, C.c_uint32]),
+    ("msgpu_seq_bases", C.c_void_p, [C.c_void_p, C.c_uint32]),
+    ("msgpu_str_slice", C.c_uint64, [C.c_uint64, C.c_int32, C.c_int32, C.POINTER(C.c_uint64)]),
+    ("msgpu_seq_create", C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    ("msgpu_seq_destroy", None, [C.c_void_p]),
+    ("msgpu_seq_last_error", C.c_char_p, [C.c_void_p]),
+    ("msgpu_seq_upload", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_uint32]),
+    ("msgpu_seq_resolve", C.c_int, [C.c_void_p, C.c_int, C.c_uint32, C.c_int32, C.c_int32, C.c_int, C.c_void_p]),
+    ("msgpu_gather_plan_create", C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
+    ("msgpu_gather_plan_free", None, [C.c_void_p]),
+    ("msgpu_gather_plan_out_bytes", C.c_uint64, [C.c_void_p]),
+    ("msgpu_gather_plan_bases", C.c_uint64, [C.c_void_p]),
+    ("msgpu_gather_run", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
+    ("msgpu_seq_synchronize", C.c_int, [C.c_void_p]),
 ]
 
 _lib = None

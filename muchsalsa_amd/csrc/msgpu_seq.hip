@@ -1,0 +1,287 @@
+// msgpu_seq.hip -- sequence store in HBM + batched slice / reverse-complement / stitch kernel.
+//
+// Device half of the reference's "consensus" stage: assemblePath (libms/src/kernel/ap.cpp)
+// decides WHERE every piece of sequence goes (layout, host); the bytes themselves are produced by
+//   SequenceAccessor::get{Nanopore,Illumina}Sequence      (SequenceAccessor.cpp:54-69,129-139: whole-record fetch)
+//   strSlice / getReverseComplement / get*Sequence(l,r,d) (SequenceUtils.cpp:27-85)
+//   updateConsensusBase                                   (ap.cpp:205-229: prepend / append the uncovered part)
+// which here become one kernel over a list of copy pieces {source range, orientation, destination}.  Sequences stay
+// resident in HBM one byte per base (exact: N, lower case and IUPAC codes survive; only A,C,G,T are complemented).
+// HBM-bound byte work: 16 B per lane, aligned 16-B stores, unaligned source handled with v_alignbyte.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "msgpu.h"
+#include "msgpu_internal.h"
+
+namespace msgpu {
+
+constexpr uint32_t GCHUNK = 4096; // output bytes per workgroup: 256 lanes x 16 B
+
+struct __attribute__((packed, aligned(4))) U4A4 { // 16 bytes that are only dword-aligned
+  uint32_t x, y, z, w;
+};
+
+// 0x80 in every byte of w that equals c
+__device__ __forceinline__ uint32_t byte_eq(uint32_t w, uint32_t c) {
+  const uint32_t z = w ^ (c * 0x01010101u);
+  const uint32_t t = (z & 0x7f7f7f7fu) + 0x7f7f7f7fu;
+  return ~(t | z | 0x7f7f7f7fu);
+}
+// getReverseComplement's switch (SequenceUtils.cpp:46-57) on four bytes at once: A<->T, C<->G, all else unchanged
+__device__ __forceinline__ uint32_t complement4(uint32_t w) {
+  const uint32_t at = byte_eq(w, 'A') | byte_eq(w, 'T');
+  const uint32_t cg = byte_eq(w, 'C') | byte_eq(w, 'G');
+  return w ^ (((at >> 7) * 0x15u) | ((cg >> 7) * 0x04u));
+}
+
+// 16 bytes starting at an arbitrary byte address (the store is padded, so reading a few bytes around is safe)
+__device__ __forceinline__ void load16_unaligned(const uint8_t *p, uint32_t out[4]) {
+  const uintptr_t a  = reinterpret_cast<uintptr_t>(p);
+  const uint32_t  sh = static_cast<uint32_t>(a & 3);
+  const uint8_t  *b  = reinterpret_cast<const uint8_t *>(a & ~static_cast<uintptr_t>(3));
+  const U4A4      v  = *reinterpret_cast<const U4A4 *>(b);
+  const uint32_t  w4 = *reinterpret_cast<const uint32_t *>(b + 16);
+  out[0]             = __builtin_amdgcn_alignbyte(v.y, v.x, sh);
+  out[1]             = __builtin_amdgcn_alignbyte(v.z, v.y, sh);
+  out[2]             = __builtin_amdgcn_alignbyte(v.w, v.z, sh);
+  out[3]             = __builtin_amdgcn_alignbyte(w4, v.w, sh);
+}
+
+__global__ __launch_bounds__(256) void k_gather(const msgpu_copy *pieces, const uint64_t *chunk_first, uint32_t n,
+                                                const uint8_t *base0, const uint8_t *base1, uint8_t *out) {
+  // which piece does this 4 KiB output chunk belong to?  (uniform binary search)
+  const uint64_t chunk = blockIdx.x;
+  uint32_t       lo = 0, hi = n;
+  while (hi - lo > 1) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (chunk_first[mid] <= chunk)
+      lo = mid;
+    else
+      hi = mid;
+  }
+  const msgpu_copy pc  = pieces[lo];
+  const uint64_t   d0  = pc.dst_off, d1 = pc.dst_off + pc.len;
+  const uint64_t   A   = (d0 & ~15ull) + (chunk - chunk_first[lo]) * GCHUNK + threadIdx.x * 16ull; // 16-B aligned
+  const uint64_t   qlo = A > d0 ? A : d0, qhi = (A + 16 < d1) ? A + 16 : d1;
+  if (qlo >= qhi) return;
+  const uint8_t *src = (pc.flags & MSGPU_COPY_ILLUMINA) ? base1 : base0;
+  uint32_t       w[4];
+  if (!(pc.flags & MSGPU_COPY_REVCOMP)) {
+    // out[q] = src[src_off + (q - d0)]
+    load16_unaligned(src + pc.src_off + (A - d0), w); // A < d0 only for the head lane: reads into the padding
+  } else {
+    // out[q] = complement(src[src_off + len - 1 - (q - d0)]): 16 source bytes ending at that address, reversed
+    uint32_t r[4];
+    load16_unaligned(src + pc.src_off + pc.len - 1 - (A - d0) - 15, r);
+    w[0] = complement4(__builtin_bswap32(r[3]));
+    w[1] = complement4(__builtin_bswap32(r[2]));
+    w[2] = complement4(__builtin_bswap32(r[1]));
+    w[3] = complement4(__builtin_bswap32(r[0]));
+  }
+  if (qlo == A && qhi == A + 16) {
+    *reinterpret_cast<uint4 *>(out + A) = make_uint4(w[0], w[1], w[2], w[3]);
+  } else { // head / tail of a piece
+    for (uint64_t q = qlo; q < qhi; ++q) {
+      const uint32_t k = static_cast<uint32_t>(q - A);
+      out[q]           = static_cast<uint8_t>(w[k >> 2] >> (8 * (k & 3)));
+    }
+  }
+}
+
+} // namespace msgpu
+
+using namespace msgpu;
+
+// ---- host side -----------------------------------------------------------------------------------------------------
+
+namespace {
+constexpr size_t SEQ_PAD = 64; // bytes of zero padding in front of and behind the bases of a store
+
+struct SeqStore {
+  void                 *d_buf = nullptr; // SEQ_PAD + bases + SEQ_PAD
+  uint64_t              n_bases = 0;
+  std::vector<uint64_t> off;   // by id: offset of the sequence inside the bases (~0 = no such id)
+  std::vector<uint64_t> len;
+};
+} // namespace
+
+struct msgpu_seqctx {
+  int         device = 0;
+  hipStream_t stream = nullptr;
+  SeqStore    st[2];
+  char        err[256] = {0};
+};
+
+struct msgpu_gather_plan {
+  void    *d_pieces = nullptr, *d_chunk_first = nullptr;
+  uint32_t n = 0;
+  uint64_t n_chunks = 0, out_bytes = 0, bases = 0;
+};
+
+namespace {
+int sfail(msgpu_seqctx *c, int code, const char *what, hipError_t e) {
+  snprintf(c->err, sizeof(c->err), "%s: %s", what, hipGetErrorString(e));
+  return code;
+}
+#define SHIP(c, expr)                                                                                                  \
+  do {                                                                                                                 \
+    hipError_t _e = (expr);                                                                                            \
+    if (_e != hipSuccess) return sfail((c), _e == hipErrorOutOfMemory ? MSGPU_E_NOMEM : MSGPU_E_HIP, #expr, _e);        \
+  } while (0)
+} // namespace
+
+extern "C" {
+
+int msgpu_seq_create(int device, msgpu_seqctx **out) {
+  if (!out) return MSGPU_E_ARG;
+  *out     = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return MSGPU_E_NODEVICE;
+  if (device < 0 || device >= ndev) return MSGPU_E_ARG;
+  auto *c = new (std::nothrow) msgpu_seqctx();
+  if (!c) return MSGPU_E_NOMEM;
+  c->device = device;
+  if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+    delete c;
+    return MSGPU_E_HIP;
+  }
+  *out = c;
+  return MSGPU_OK;
+}
+
+void msgpu_seq_destroy(msgpu_seqctx *c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  for (auto &s : c->st)
+    if (s.d_buf) (void)hipFree(s.d_buf);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+const char *msgpu_seq_last_error(const msgpu_seqctx *c) { return c ? c->err : "null context"; }
+
+int msgpu_seq_upload(msgpu_seqctx *c, int kind, const msgpu_seqfile *f, const uint32_t *ids, uint32_t n_ids) {
+  if (!c || !f || kind < 0 || kind > 1) return MSGPU_E_ARG;
+  SHIP(c, hipSetDevice(c->device));
+  SeqStore      &s = c->st[kind];
+  const uint32_t n = msgpu_seq_count(f);
+  uint32_t       space = ids ? n_ids : n;
+  for (uint32_t i = 0; ids && i < n; ++i)
+    if (ids[i] != 0xffffffffu && ids[i] >= space) return MSGPU_E_ARG;
+  s.off.assign(space, ~0ull);
+  s.len.assign(space, 0);
+  const char *first = n ? msgpu_seq_bases(f, 0) : nullptr;
+  uint64_t    total = 0;
+  for (uint32_t i = 0; i < n; ++i) {
+    const uint32_t id = ids ? ids[i] : i;
+    const uint64_t l  = msgpu_seq_length(f, i);
+    if (id != 0xffffffffu && s.off[id] == ~0ull) { // emplace: the first record of an id wins
+      s.off[id] = static_cast<uint64_t>(msgpu_seq_bases(f, i) - first);
+      s.len[id] = l;
+    }
+    total += l;
+  }
+  if (s.d_buf) {
+    SHIP(c, hipFree(s.d_buf));
+    s.d_buf = nullptr;
+  }
+  s.n_bases = total;
+  SHIP(c, hipMalloc(&s.d_buf, total + 2 * SEQ_PAD));
+  SHIP(c, hipMemsetAsync(s.d_buf, 0, total + 2 * SEQ_PAD, c->stream));
+  if (total)
+    SHIP(c, hipMemcpyAsync(static_cast<uint8_t *>(s.d_buf) + SEQ_PAD, first, total, hipMemcpyHostToDevice, c->stream));
+  SHIP(c, hipStreamSynchronize(c->stream));
+  return MSGPU_OK;
+}
+
+int msgpu_seq_resolve(msgpu_seqctx *c, int kind, uint32_t seq_id, int32_t left, int32_t right, int direction,
+                      msgpu_copy *out) {
+  if (!c || !out || kind < 0 || kind > 1) return MSGPU_E_ARG;
+  const SeqStore &s = c->st[kind];
+  if (seq_id >= s.off.size() || s.off[seq_id] == ~0ull) return MSGPU_E_ARG; // m_idx.at(id) would throw
+  uint64_t       len   = 0;
+  const uint64_t start = msgpu_str_slice(s.len[seq_id], left, right + 1, &len); // SequenceUtils.cpp:66,78
+  if (len > 0xffffffffull) return MSGPU_E_ARG;
+  out->src_off = s.off[seq_id] + start;
+  out->len     = static_cast<uint32_t>(len);
+  out->flags   = (kind ? MSGPU_COPY_ILLUMINA : 0u) | (direction ? 0u : MSGPU_COPY_REVCOMP);
+  return MSGPU_OK;
+}
+
+int msgpu_gather_plan_create(msgpu_seqctx *c, const msgpu_copy *pieces, size_t n, msgpu_gather_plan **out) {
+  if (!c || !out || (n && !pieces) || n >= 0xfffffff0ull) return MSGPU_E_ARG;
+  *out = nullptr;
+  SHIP(c, hipSetDevice(c->device));
+  std::vector<uint64_t> first(n + 1);
+  uint64_t              chunks = 0, out_bytes = 0, bases = 0;
+  for (size_t i = 0; i < n; ++i) {
+    first[i] = chunks;
+    const msgpu_copy &p = pieces[i];
+    const SeqStore   &s = c->st[(p.flags & MSGPU_COPY_ILLUMINA) ? 1 : 0];
+    if (p.src_off + p.len > s.n_bases) return MSGPU_E_ARG; // never read outside the store
+    if (p.len) chunks += ((p.dst_off + p.len) - (p.dst_off & ~15ull) + GCHUNK - 1) / GCHUNK;
+    if (p.dst_off + p.len > out_bytes) out_bytes = p.dst_off + p.len;
+    bases += p.len;
+  }
+  first[n] = chunks;
+  if (chunks >= 0x7fffffffull) return MSGPU_E_ARG;
+  auto *pl = new (std::nothrow) msgpu_gather_plan();
+  if (!pl) return MSGPU_E_NOMEM;
+  pl->n         = static_cast<uint32_t>(n);
+  pl->n_chunks  = chunks;
+  pl->out_bytes = out_bytes;
+  pl->bases     = bases;
+  hipError_t e  = hipMalloc(&pl->d_pieces, (n ? n : 1) * sizeof(msgpu_copy));
+  if (e == hipSuccess) e = hipMalloc(&pl->d_chunk_first, (n + 1) * sizeof(uint64_t));
+  if (e == hipSuccess && n)
+    e = hipMemcpyAsync(pl->d_pieces, pieces, n * sizeof(msgpu_copy), hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess)
+    e = hipMemcpyAsync(pl->d_chunk_first, first.data(), (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  if (e != hipSuccess) {
+    if (pl->d_pieces) (void)hipFree(pl->d_pieces);
+    if (pl->d_chunk_first) (void)hipFree(pl->d_chunk_first);
+    delete pl;
+    return sfail(c, e == hipErrorOutOfMemory ? MSGPU_E_NOMEM : MSGPU_E_HIP, "gather plan", e);
+  }
+  *out = pl;
+  return MSGPU_OK;
+}
+
+void msgpu_gather_plan_free(msgpu_gather_plan *pl) {
+  if (!pl) return;
+  if (pl->d_pieces) (void)hipFree(pl->d_pieces);
+  if (pl->d_chunk_first) (void)hipFree(pl->d_chunk_first);
+  delete pl;
+}
+
+uint64_t msgpu_gather_plan_out_bytes(const msgpu_gather_plan *pl) { return pl ? pl->out_bytes : 0; }
+uint64_t msgpu_gather_plan_bases(const msgpu_gather_plan *pl) { return pl ? pl->bases : 0; }
+
+int msgpu_gather_run(msgpu_seqctx *c, const msgpu_gather_plan *pl, void *d_out, uint64_t out_capacity, void *hip_stream) {
+  if (!c || !pl || (!d_out && pl->out_bytes)) return MSGPU_E_ARG;
+  if (out_capacity < pl->out_bytes) return MSGPU_E_ARG;
+  SHIP(c, hipSetDevice(c->device));
+  if (!pl->n_chunks) return MSGPU_OK;
+  hipStream_t st = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->stream;
+  const uint8_t *b0 = c->st[0].d_buf ? static_cast<const uint8_t *>(c->st[0].d_buf) + SEQ_PAD : nullptr;
+  const uint8_t *b1 = c->st[1].d_buf ? static_cast<const uint8_t *>(c->st[1].d_buf) + SEQ_PAD : nullptr;
+  hipLaunchKernelGGL(k_gather, dim3(static_cast<uint32_t>(pl->n_chunks)), dim3(256), 0, st,
+                     static_cast<const msgpu_copy *>(pl->d_pieces), static_cast<const uint64_t *>(pl->d_chunk_first),
+                     pl->n, b0, b1, static_cast<uint8_t *>(d_out));
+  SHIP(c, hipGetLastError());
+  return MSGPU_OK;
+}
+
+int msgpu_seq_synchronize(msgpu_seqctx *c) {
+  if (!c) return MSGPU_E_ARG;
+  SHIP(c, hipStreamSynchronize(c->stream));
+  return MSGPU_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,163 @@
+// seq_loader.cpp -- host-side FASTA/FASTQ loader of libmsgpu (sequence store of the consensus stage).
+//
+// Replaces SequenceAccessor::buildIndex (_buildNanoporeIdx / _buildIlluminaIdx, libms/src/SequenceAccessor.cpp:143-231)
+// and the per-call getSequenceFromFile (:54-69).  The reference keeps only file offsets and re-reads + re-strips the
+// whole record from disk under a mutex for every slice; here the file is read once (mmap) and every record is kept
+// whitespace-free, one byte per base, ready to be uploaded to HBM.  Behaviour kept:
+//   * FASTQ iff the extension is neither "fa" nor "fasta" (isFastQ, :71-80); description '>' / '@', split '>' / '+';
+//   * record id = description line without its first character, cut at the first whitespace (cleanSequenceId, :82-87);
+//   * a record's bytes are all lines up to the next description (FASTA) or '+' (FASTQ) line; in FASTQ everything up
+//     to the next line starting with '@' is skipped (:181-184) -- including the quirk that a quality line starting
+//     with '@' is taken for a description line;
+//   * std::isspace characters are removed, the record is cut at an embedded NUL (std::string(buffer.data()), :65-67);
+//   * of two records with the same id the first one wins (unordered_map::emplace, :171).
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <cctype>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <string_view>
+#include <unordered_map>
+#include <vector>
+
+#include "msgpu.h"
+
+struct msgpu_seqfile {
+  std::vector<std::string> names; // cleaned ids, first-occurrence order
+  std::vector<uint64_t>    off;   // names.size() + 1 offsets into bases
+  std::string              bases;
+};
+
+namespace {
+
+struct LineReader { // readline (libms/src/IO.cpp:54-97) over a memory image
+  const char *buf;
+  size_t      len, pos = 0;
+  const char *line = "";
+  size_t      line_len = 0;
+  long next() {
+    if (pos >= len) return -1;
+    const void *nl = memchr(buf + pos, '\n', len - pos);
+    size_t      e  = nl ? static_cast<size_t>(static_cast<const char *>(nl) - buf) + 1 : len;
+    line           = buf + pos;
+    line_len       = e - pos;
+    pos            = e;
+    return static_cast<long>(line_len);
+  }
+};
+
+bool is_fastq_name(const char *path) {
+  std::string_view p(path);
+  size_t           dot = p.find_last_of('.');
+  std::string      ext(p.substr(dot == std::string_view::npos ? 0 : dot + 1));
+  for (auto &c : ext) c = static_cast<char>(std::tolower(static_cast<unsigned char>(c)));
+  return ext != "fa" && ext != "fasta";
+}
+
+} // namespace
+
+extern "C" {
+
+int msgpu_seq_parse(const char *path, int is_fastq, msgpu_seqfile **out) {
+  if (!path || !out) return MSGPU_E_ARG;
+  *out   = nullptr;
+  int fd = open(path, O_RDONLY | O_CLOEXEC);
+  if (fd < 0) return MSGPU_E_IO; // "Can't open sequence file(s)." SequenceAccessor.cpp:105-107
+  struct stat st;
+  if (fstat(fd, &st) != 0) {
+    close(fd);
+    return MSGPU_E_IO;
+  }
+  size_t      len  = static_cast<size_t>(st.st_size);
+  const char *data = nullptr;
+  if (len) {
+    void *m = mmap(nullptr, len, PROT_READ, MAP_PRIVATE, fd, 0);
+    if (m == MAP_FAILED) {
+      close(fd);
+      return MSGPU_E_IO;
+    }
+    madvise(m, len, MADV_SEQUENTIAL);
+    data = static_cast<const char *>(m);
+  }
+  close(fd);
+  if (is_fastq < 0) is_fastq = is_fastq_name(path) ? 1 : 0;
+  const char desc = is_fastq ? '@' : '>', split = is_fastq ? '+' : '>';
+
+  std::unique_ptr<msgpu_seqfile> f;
+  try {
+    f = std::make_unique<msgpu_seqfile>();
+    f->bases.reserve(len);
+    std::unordered_map<std::string, uint32_t> ids;
+    LineReader rl{data, len};
+    long       ret = rl.next();
+    while (ret != -1 && rl.line[0] != desc) ret = rl.next(); // :149-158
+    while (ret != -1 && rl.line[0] == desc) {                 // :160 (a last line starting with the description character would loop forever in the reference; EOF ends it here)
+      size_t idl = 0;
+      while (1 + idl < rl.line_len && !std::isspace(static_cast<unsigned char>(rl.line[1 + idl]))) ++idl;
+      std::string id(rl.line + 1, idl);
+      const bool  is_new   = ids.emplace(id, static_cast<uint32_t>(f->names.size())).second;
+      const char *body     = data + rl.pos;
+      size_t      body_len = 0;
+      while (true) { // :167-179
+        ret = rl.next();
+        if (ret == -1 || rl.line[0] == split) break;
+        body_len += static_cast<size_t>(ret);
+      }
+      if (is_new) {
+        f->names.push_back(std::move(id));
+        f->off.push_back(f->bases.size());
+        for (size_t k = 0; k < body_len; ++k) {
+          const char ch = body[k];
+          if (ch == '\0') break;
+          if (!std::isspace(static_cast<unsigned char>(ch))) f->bases.push_back(ch);
+        }
+      }
+      while (ret != -1 && rl.line[0] != desc) ret = rl.next(); // :181-184
+    }
+    f->off.push_back(f->bases.size());
+  } catch (std::bad_alloc const &) {
+    if (data) munmap(const_cast<char *>(data), len);
+    return MSGPU_E_NOMEM;
+  }
+  if (data) munmap(const_cast<char *>(data), len);
+  *out = f.release();
+  return MSGPU_OK;
+}
+
+void msgpu_seq_free(msgpu_seqfile *f) { delete f; }
+uint32_t msgpu_seq_count(const msgpu_seqfile *f) { return f ? static_cast<uint32_t>(f->names.size()) : 0; }
+const char *msgpu_seq_name(const msgpu_seqfile *f, uint32_t i) {
+  return f && i < f->names.size() ? f->names[i].c_str() : nullptr;
+}
+uint64_t msgpu_seq_length(const msgpu_seqfile *f, uint32_t i) {
+  return f && i < f->names.size() ? f->off[i + 1] - f->off[i] : 0;
+}
+const char *msgpu_seq_bases(const msgpu_seqfile *f, uint32_t i) {
+  return f && i < f->names.size() ? f->bases.data() + f->off[i] : nullptr;
+}
+
+// strSlice (libms/src/SequenceUtils.cpp:27-38) as (offset, length): Python-like indices, INCLUSIVE clipped end.
+uint64_t msgpu_str_slice(uint64_t size, int32_t start, int32_t end, uint64_t *len) {
+  const long long sz = static_cast<long long>(size);
+  const long long i  = start >= 0 ? start : sz + start;
+  const long long j  = end >= 0 ? end : sz + end;
+  const uint64_t  s  = static_cast<uint64_t>(i > 0 ? i : 0);
+  uint64_t        e  = static_cast<uint64_t>(j > 0 ? j : 0);
+  if (e > size) e = size;
+  const uint64_t ic = static_cast<uint64_t>(i); // static_cast<std::size_t>(i): a negative i wraps
+  if (e < ic) e = ic;
+  if (s > size) { // substr would throw std::out_of_range
+    if (len) *len = 0;
+    return size;
+  }
+  uint64_t cnt = e - s + 1;
+  if (cnt > size - s) cnt = size - s;
+  if (len) *len = cnt;
+  return s;
+}
+
+} // extern "C"

@@ -1,0 +1,122 @@
+"""Python view of the sequence half of the C-ABI (include/msgpu.h): sequence store in HBM + batched gather.
+
+    f = SeqFile(path)                       # SequenceAccessor::buildIndex + whole-record fetch (host)
+    store = SeqStore(device=0)
+    store.upload(NANOPORE, f, ids)          # records -> HBM, keyed by Registry id
+    piece = store.resolve(NANOPORE, read_id, left, right, direction)   # get*Sequence(l, r, d) as a copy piece
+    plan = store.plan(pieces)               # batch of pieces with destinations (the layout)
+    store.run(plan, d_out_ptr, capacity)    # one kernel launch
+
+Nothing here computes on the CPU except the (l, r) -> (offset, length) arithmetic of strSlice.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _lib
+from ._lib import COPY_DTYPE, COPY_ILLUMINA, COPY_REVCOMP  # noqa: F401
+from .overlap import MsgpuError
+
+NANOPORE, ILLUMINA = 0, 1
+
+
+class SeqFile:
+    def __init__(self, path, is_fastq=-1):
+        self._L = _lib.lib()
+        self._h = C.c_void_p()
+        rc = self._L.msgpu_seq_parse(os.fsencode(path), is_fastq, C.byref(self._h))
+        if rc != 0:
+            self._h = C.c_void_p()
+            raise MsgpuError(rc, str(path))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._L.msgpu_seq_free(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def __len__(self):
+        return self._L.msgpu_seq_count(self._h)
+
+    @property
+    def names(self):
+        return [self._L.msgpu_seq_name(self._h, i).decode() for i in range(len(self))]
+
+    def sequence(self, i):
+        n = self._L.msgpu_seq_length(self._h, i)
+        return C.string_at(self._L.msgpu_seq_bases(self._h, i), n) if n else b""
+
+    def length(self, i):
+        return int(self._L.msgpu_seq_length(self._h, i))
+
+
+def str_slice(size, start, end):
+    n = C.c_uint64()
+    s = _lib.lib().msgpu_str_slice(size, start, end, C.byref(n))
+    return int(s), int(n.value)
+
+
+class SeqStore:
+    def __init__(self, device=0):
+        self._L = _lib.lib()
+        self._h = C.c_void_p()
+        rc = self._L.msgpu_seq_create(int(device), C.byref(self._h))
+        if rc != 0:
+            self._h = C.c_void_p()
+            raise MsgpuError(rc)
+        self._plans = []
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            for p in self._plans:
+                self._L.msgpu_gather_plan_free(p)
+            self._plans = []
+            self._L.msgpu_seq_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _check(self, rc):
+        if rc != 0:
+            raise MsgpuError(rc, self._L.msgpu_seq_last_error(self._h).decode())
+
+    def upload(self, kind, seqfile, ids=None, n_ids=0):
+        if ids is not None:
+            ids = np.ascontiguousarray(ids, dtype="<u4")
+            self._check(self._L.msgpu_seq_upload(self._h, kind, seqfile._h, ids.ctypes.data, int(n_ids)))
+        else:
+            self._check(self._L.msgpu_seq_upload(self._h, kind, seqfile._h, None, 0))
+
+    def resolve(self, kind, seq_id, left, right, direction, dst_off=0):
+        out = np.zeros(1, dtype=COPY_DTYPE)
+        self._check(self._L.msgpu_seq_resolve(self._h, kind, int(seq_id), int(left), int(right), 1 if direction else 0,
+                                              out.ctypes.data))
+        out["dst_off"] = dst_off
+        return out[0]
+
+    def plan(self, pieces):
+        pieces = np.ascontiguousarray(pieces, dtype=COPY_DTYPE)
+        h = C.c_void_p()
+        self._check(self._L.msgpu_gather_plan_create(self._h, pieces.ctypes.data, len(pieces), C.byref(h)))
+        self._plans.append(h)
+        return h
+
+    def plan_out_bytes(self, plan):
+        return int(self._L.msgpu_gather_plan_out_bytes(plan))
+
+    def plan_bases(self, plan):
+        return int(self._L.msgpu_gather_plan_bases(plan))
+
+    def run(self, plan, d_out_ptr, capacity, stream=None):
+        self._check(self._L.msgpu_gather_run(self._h, plan, C.c_void_p(d_out_ptr), int(capacity), C.c_void_p(stream)))
+
+    def synchronize(self):
+        self._check(self._L.msgpu_seq_synchronize(self._h))

@@ -1068,3 +1068,187 @@ void ms_oracle_free_tables(ms_tables *t) {
   free(t->read_first_line);
   memset(t, 0, sizeof(*t));
 }
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * sequence side (A9, data-parallel half)
+ * ---------------------------------------------------------------------------------------------------------------- */
+
+#include <ctype.h>
+
+typedef struct {
+  const char *buf;
+  size_t      len, pos;
+  const char *line;     /* last line read (like pLine: unchanged by a failed read) */
+  size_t      line_len; /* including the '\n' */
+} rl_state;
+
+/* readline (IO.cpp:54-97) over a memory image: returns the line length incl. '\n', or -1 at EOF */
+static long rl_next(rl_state *st) {
+  if (st->pos >= st->len) return -1;
+  const char *nl = (const char *)memchr(st->buf + st->pos, '\n', st->len - st->pos);
+  size_t      e  = nl ? (size_t)(nl - st->buf) + 1 : st->len;
+  st->line       = st->buf + st->pos;
+  st->line_len   = e - st->pos;
+  st->pos        = e;
+  return (long)st->line_len;
+}
+
+static int seq_is_fastq(const char *path) { /* isFastQ, SequenceAccessor.cpp:71-80 */
+  const char *dot = strrchr(path, '.');
+  const char *ext = dot ? dot + 1 : path; /* find_last_of('.') == npos -> substr(0) = whole name */
+  char        low[64];
+  size_t      i = 0;
+  for (; ext[i] && i + 1 < sizeof(low); ++i) low[i] = (char)tolower((unsigned char)ext[i]);
+  low[i] = '\0';
+  return strcmp(low, "fa") != 0 && strcmp(low, "fasta") != 0;
+}
+
+int ms_oracle_seq_load(const char *path, int is_fastq, ms_seqs *out) {
+  memset(out, 0, sizeof(*out));
+  FILE *f = fopen(path, "rb");
+  if (!f) return MS_E_IO; /* "Can't open sequence file(s)." SequenceAccessor.cpp:105-107 */
+  fseek(f, 0, SEEK_END);
+  long sz = ftell(f);
+  fseek(f, 0, SEEK_SET);
+  char *buf = (char *)xrealloc(NULL, (size_t)sz + 1);
+  if (sz > 0 && fread(buf, 1, (size_t)sz, f) != (size_t)sz) {
+    fclose(f);
+    free(buf);
+    return MS_E_IO;
+  }
+  fclose(f);
+  if (is_fastq < 0) is_fastq = seq_is_fastq(path);
+  const char desc  = is_fastq ? '@' : '>'; /* SequenceAccessor.cpp:40-42,144-145 */
+  const char split = is_fastq ? '+' : '>';
+
+  registry reg;
+  reg_init(&reg);
+  size_t    cap = 64, n = 0;
+  uint64_t *rec_off  = (uint64_t *)xrealloc(NULL, cap * sizeof(uint64_t)); /* file offset of the record body */
+  uint64_t *rec_len  = (uint64_t *)xrealloc(NULL, cap * sizeof(uint64_t)); /* raw length incl. newlines      */
+  uint8_t  *rec_seen = (uint8_t *)calloc(cap, 1);
+
+  rl_state st  = {buf, (size_t)sz, 0, "", 0};
+  long     ret = rl_next(&st);
+  size_t   offset_start = st.pos;
+  while (ret != -1) { /* :149-158 skip to the first description line */
+    if (st.line[0] == desc) break;
+    ret          = rl_next(&st);
+    offset_start = st.pos;
+  }
+  /* :160 `while (*pLine == desc)`; at EOF pLine keeps the last line, which the reference would test again -- a
+   * last line starting with the description character loops forever there; here EOF ends the loop. */
+  while (ret != -1 && st.line[0] == desc) {
+    const char *idp = st.line + 1; /* :161-163 id = line + 1, cut at the first whitespace (cleanSequenceId) */
+    size_t      idl = 0;
+    while (1 + idl < st.line_len && !isspace((unsigned char)idp[idl])) ++idl;
+    const uint32_t id = reg_get(&reg, idp, idl); /* (*m_pRegistry)[sequenceId] */
+    size_t         length = 0;
+    while (1) { /* :167-179 */
+      ret = rl_next(&st);
+      const size_t offset_end = st.pos;
+      if (ret == -1 || st.line[0] == split) {
+        if (id >= cap) {
+          size_t nc = cap;
+          while (nc <= id) nc *= 2;
+          rec_off  = (uint64_t *)xrealloc(rec_off, nc * sizeof(uint64_t));
+          rec_len  = (uint64_t *)xrealloc(rec_len, nc * sizeof(uint64_t));
+          rec_seen = (uint8_t *)xrealloc(rec_seen, nc);
+          memset(rec_seen + cap, 0, nc - cap);
+          cap = nc;
+        }
+        if (!rec_seen[id]) { /* unordered_map::emplace keeps the first record of a name */
+          rec_seen[id] = 1;
+          rec_off[id]  = offset_start;
+          rec_len[id]  = length;
+          if (id + 1 > n) n = id + 1;
+        }
+        offset_start = offset_end;
+        break;
+      }
+      length += (size_t)ret;
+    }
+    /* :181-184 (nanopore file only; a no-op for FASTA where split == desc): skip to the next description line */
+    while (ret != -1 && st.line[0] != desc) {
+      ret          = rl_next(&st);
+      offset_start = st.pos;
+    }
+  }
+
+  /* getSequenceFromFile for every record (:54-69): rec_len bytes, cut at the first NUL, isspace removed */
+  out->n   = (uint32_t)n;
+  out->off = (uint64_t *)xrealloc(NULL, (n + 1) * sizeof(uint64_t));
+  size_t total = 0;
+  for (size_t i = 0; i < n; ++i) total += rec_len[i];
+  out->bases = (char *)xrealloc(NULL, total + 1);
+  size_t w = 0;
+  for (size_t i = 0; i < n; ++i) {
+    out->off[i] = w;
+    for (size_t k = 0; k < rec_len[i]; ++k) {
+      char ch = buf[rec_off[i] + k];
+      if (ch == '\0') break;
+      if (!isspace((unsigned char)ch)) out->bases[w++] = ch;
+    }
+  }
+  out->off[n]    = w;
+  out->names     = reg.blob;
+  out->names_len = reg.blob_len;
+  reg.blob       = NULL;
+  reg_free(&reg);
+  free(rec_off);
+  free(rec_len);
+  free(rec_seen);
+  free(buf);
+  return MS_OK;
+}
+
+void ms_oracle_seq_free(ms_seqs *s) {
+  free(s->names);
+  free(s->bases);
+  free(s->off);
+  memset(s, 0, sizeof(*s));
+}
+
+size_t ms_oracle_str_slice(size_t size, int start, int end, size_t *len) { /* SequenceUtils.cpp:27-38 */
+  int    sz = (int)size;
+  int    i  = start >= 0 ? start : sz + start;
+  int    j  = end >= 0 ? end : sz + end;
+  size_t s  = (size_t)(i > 0 ? i : 0);
+  size_t jj = (size_t)(j > 0 ? j : 0);
+  size_t e  = size < jj ? size : jj;  /* min(original.size(), max(0, j)) */
+  size_t ic = (size_t)i;              /* static_cast<std::size_t>(i): a negative i wraps to a huge value */
+  if (e < ic) e = ic;                 /* max(..., size_t(i)) */
+  /* substr(s, e - s + 1): throws std::out_of_range when s > size; clipped at size otherwise */
+  if (s > size) {
+    *len = 0;
+    return size;
+  }
+  size_t cnt = e - s + 1;
+  if (cnt > size - s) cnt = size - s;
+  *len = cnt;
+  return s;
+}
+
+void ms_oracle_revcomp(const char *in, size_t n, char *out) { /* SequenceUtils.cpp:41-61 */
+  for (size_t i = 0; i < n; ++i) {
+    char c = in[n - 1 - i];
+    switch (c) {
+    case 'A': c = 'T'; break;
+    case 'T': c = 'A'; break;
+    case 'G': c = 'C'; break;
+    case 'C': c = 'G'; break;
+    default: break;
+    }
+    out[i] = c;
+  }
+}
+
+size_t ms_oracle_get_sequence(const char *seq, size_t size, int left, int right, int direction, char *out) {
+  size_t len;
+  size_t s = ms_oracle_str_slice(size, left, right + 1, &len); /* SequenceUtils.cpp:66,78 */
+  if (direction)
+    memcpy(out, seq + s, len);
+  else
+    ms_oracle_revcomp(seq + s, len, out);
+  return len;
+}

@@ -128,6 +128,31 @@ void ms_oracle_free_tables(ms_tables *t);
 
 const char *ms_oracle_strerror(int code);
 
+/* ---- sequence side of the "consensus" stage (data-parallel half) ------------------------
+ * PINNED by the reference's own fixtures: libms/tests/SA_test.cpp:11-136 (whole-record fetch of test_data/fasta.fa
+ * and test_data/fastq.fq), copied as data into tests/golden/. */
+
+typedef struct ms_seqs {
+  uint32_t  n;        /* records, in file order (duplicate names keep the first: unordered_map::emplace)          */
+  char     *names;    /* NUL-separated cleaned ids (cut at the first whitespace, SequenceAccessor.cpp:82-87)      */
+  size_t    names_len;
+  char     *bases;    /* concatenated sequences, whitespace stripped (SequenceAccessor.cpp:54-69)                 */
+  uint64_t *off;      /* n + 1 offsets into bases                                                                 */
+} ms_seqs;
+
+/* SequenceAccessor::_buildNanoporeIdx / _buildIlluminaIdx + getSequenceFromFile (SequenceAccessor.cpp:54-69,143-231).
+ * is_fastq < 0: decide from the file extension like isFastQ (SequenceAccessor.cpp:71-80). */
+int  ms_oracle_seq_load(const char *path, int is_fastq, ms_seqs *out);
+void ms_oracle_seq_free(ms_seqs *s);
+
+/* strSlice (SequenceUtils.cpp:27-38): Python-like indices, INCLUSIVE end, clipped.  Returns start, writes length. */
+size_t ms_oracle_str_slice(size_t size, int start, int end, size_t *len);
+/* getReverseComplement (SequenceUtils.cpp:41-61): A<->T, C<->G, everything else unchanged. */
+void ms_oracle_revcomp(const char *in, size_t n, char *out);
+/* getIlluminaSequence / getNanoporeSequence (SequenceUtils.cpp:63-85) = strSlice(seq, l, r + 1), reverse complement
+ * when !direction.  out must hold ms_oracle_get_sequence_len bytes; returns the length. */
+size_t ms_oracle_get_sequence(const char *seq, size_t size, int left, int right, int direction, char *out);
+
 #ifdef __cplusplus
 }
 #endif

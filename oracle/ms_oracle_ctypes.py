@@ -46,6 +46,11 @@ class _Tables(C.Structure):
                 ("compat_checks", C.c_uint64), ("shadow_edges", C.c_uint64)]
 
 
+class _Seqs(C.Structure):
+    _fields_ = [("n", C.c_uint32), ("names", C.c_void_p), ("names_len", C.c_size_t), ("bases", C.c_void_p),
+                ("off", C.c_void_p)]
+
+
 _lib = None
 
 
@@ -69,6 +74,13 @@ def lib():
         _lib.ms_oracle_free_tables.argtypes = [C.POINTER(_Tables)]
         _lib.ms_oracle_strerror.argtypes = [C.c_int]
         _lib.ms_oracle_strerror.restype = C.c_char_p
+        _lib.ms_oracle_seq_load.argtypes = [C.c_char_p, C.c_int, C.POINTER(_Seqs)]
+        _lib.ms_oracle_seq_load.restype = C.c_int
+        _lib.ms_oracle_seq_free.argtypes = [C.POINTER(_Seqs)]
+        _lib.ms_oracle_str_slice.argtypes = [C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_size_t)]
+        _lib.ms_oracle_str_slice.restype = C.c_size_t
+        _lib.ms_oracle_get_sequence.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_char_p]
+        _lib.ms_oracle_get_sequence.restype = C.c_size_t
     return _lib
 
 
@@ -128,3 +140,33 @@ def overlap(rows, params=None):
         }
     finally:
         lib().ms_oracle_free_tables(C.byref(t))
+
+
+def seq_load(path, is_fastq=-1):
+    """SequenceAccessor index + whole-record fetch.  Returns (names, [bytes per record])."""
+    sq = _Seqs()
+    rc = lib().ms_oracle_seq_load(os.fsencode(path), is_fastq, C.byref(sq))
+    if rc != 0:
+        raise OracleError(rc)
+    try:
+        names = C.string_at(sq.names, sq.names_len).decode().split("\0")[:-1] if sq.names_len else []
+        off = _copy(sq.off, sq.n + 1, np.dtype("<u8"))
+        total = int(off[-1]) if sq.n else 0
+        bases = C.string_at(sq.bases, total) if total else b""
+        return names, [bases[int(off[i]):int(off[i + 1])] for i in range(sq.n)]
+    finally:
+        lib().ms_oracle_seq_free(C.byref(sq))
+
+
+def str_slice(size, start, end):
+    """strSlice(original, start, end) -> (offset, length) into the original string."""
+    n = C.c_size_t()
+    s = lib().ms_oracle_str_slice(size, start, end, C.byref(n))
+    return int(s), int(n.value)
+
+
+def get_sequence(seq, left, right, direction):
+    """getNanoporeSequence/getIlluminaSequence(seq, left, right, direction) on a bytes object."""
+    out = C.create_string_buffer(len(seq) + 2)
+    n = lib().ms_oracle_get_sequence(seq, len(seq), left, right, 1 if direction else 0, out)
+    return out.raw[:n]

@@ -1,0 +1,181 @@
+"""GPU parity of the sequence store + gather kernel (device half of the consensus stage) through the C-ABI:
+against the reference's own SA_test fixtures, against the oracle's strSlice/reverse-complement, and against a
+host statement of updateConsensusBase (ap.cpp:205-229)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_test_data")
+
+
+def _run(store, pieces, total=None):
+    import torch
+    plan = store.plan(pieces)
+    n = store.plan_out_bytes(plan) if total is None else total
+    out = torch.full((max(n, 1) + 64,), 0x2e, dtype=torch.uint8, device="cuda:0")  # '.' canary
+    store.run(plan, out.data_ptr(), n)
+    store.synchronize()
+    host = out.cpu().numpy()
+    assert (host[n:] == 0x2e).all(), "wrote past the end of the output"
+    return host[:n].tobytes()
+
+
+def _write_fasta(path, seqs, prefix, width=60):
+    with open(path, "w") as f:
+        for i, s in enumerate(seqs):
+            f.write(">%s%d extra words\n" % (prefix, i))
+            for k in range(0, len(s), width):
+                f.write(s[k:k + width] + "\n")
+
+
+def test_whole_records_match_the_reference_SA_test_fixtures():
+    from muchsalsa_amd import sequences as S
+    sa = json.load(open(os.path.join(GOLD, "sa_test_expected.json")))
+    with S.SeqStore(0) as store:
+        fa, fq = S.SeqFile(os.path.join(GOLD, "fasta.fa")), S.SeqFile(os.path.join(GOLD, "fastq.fq"))
+        store.upload(S.ILLUMINA, fa)
+        store.upload(S.NANOPORE, fq)
+        for kind, want in ((S.ILLUMINA, sa["FastQTest"]["illumina"]), (S.NANOPORE, sa["FastQTest"]["nanopore"])):
+            off = 0
+            pieces = []
+            for i, w in enumerate(want):
+                # getXSequence(id, 0, size, true) = strSlice(seq, 0, size + 1) = the whole record
+                pieces.append(store.resolve(kind, i, 0, len(w), True, dst_off=off))
+                off += len(w)
+            assert _run(store, np.array(pieces)).decode() == "".join(want)
+
+
+def test_random_slices_match_oracle(oracle, tmp_path):
+    from muchsalsa_amd import sequences as S
+    rng = np.random.default_rng(3)
+    alphabet = np.frombuffer(b"ACGTACGTACGTNacgtRY", dtype=np.uint8)
+    seqs = ["".join(map(chr, rng.choice(alphabet, int(n)))) for n in rng.integers(1, 3000, 40)]
+    unis = ["".join(map(chr, rng.choice(alphabet, int(n)))) for n in rng.integers(1, 1500, 25)]
+    _write_fasta(tmp_path / "reads.fa", seqs, "r")
+    _write_fasta(tmp_path / "unitigs.fa", unis, "u")
+    with S.SeqStore(0) as store:
+        fr, fu = S.SeqFile(str(tmp_path / "reads.fa")), S.SeqFile(str(tmp_path / "unitigs.fa"))
+        assert [fr.sequence(i).decode() for i in range(len(fr))] == seqs
+        # Registry ids need not follow file order
+        rid = rng.permutation(len(seqs)).astype(np.uint32)
+        store.upload(S.NANOPORE, fr, rid, len(seqs))
+        store.upload(S.ILLUMINA, fu)
+        by_id = {int(rid[i]): seqs[i] for i in range(len(seqs))}
+        pieces, want, off = [], [], 0
+        for _ in range(4000):
+            kind = int(rng.integers(0, 2))
+            pool = by_id if kind == S.NANOPORE else dict(enumerate(unis))
+            sid = int(rng.integers(0, len(pool)))
+            s = pool[sid].encode()
+            left = int(rng.integers(-20, len(s) + 20))
+            right = int(rng.integers(-20, len(s) + 40))
+            direction = bool(rng.integers(0, 2))
+            w = oracle.get_sequence(s, left, right, direction)
+            p = store.resolve(kind, sid, left, right, direction, dst_off=off)
+            assert int(p["len"]) == len(w), (len(s), left, right)
+            pieces.append(p)
+            want.append(w)
+            off += len(w)
+        got = _run(store, np.array(pieces))
+        assert got == b"".join(want)
+
+
+def update_consensus_base(old, old_b, new, new_b):
+    """updateConsensusBase, ap.cpp:205-229, on byte strings (strSlice = inclusive end)."""
+    if old is None:
+        return new, new_b[0], new_b[1]
+
+    def str_slice(s, i, j):
+        size = len(s)
+        i2 = i if i >= 0 else size + i
+        j2 = j if j >= 0 else size + j
+        st = max(0, i2)
+        en = max(min(size, max(0, j2)), i2)
+        return s[st:st + (en - st + 1)]
+    if new_b[0] < old_b[0]:
+        upd = str_slice(new, 0, old_b[0] - new_b[0]) + old
+    elif new_b[1] > old_b[1]:
+        upd = old + str_slice(new, -(new_b[1] - old_b[1]), len(new))
+    else:
+        upd = old
+    return upd, min(old_b[0], new_b[0]), max(old_b[1], new_b[1])
+
+
+def test_stitching_like_updateConsensusBase(oracle, tmp_path):
+    """A tiling of reads over a genome, stitched by the reference's prepend/append rule: the host turns every rule
+    application into one copy piece (a sub-range of an oriented read), the GPU materialises the contig."""
+    from muchsalsa_amd import sequences as S
+    rng = np.random.default_rng(11)
+    G = 60000
+    genome = bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), G))
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    reads = []
+    pos = 0
+    while pos < G - 3000:
+        L = int(rng.integers(2000, 6000))
+        fwd = bool(rng.integers(0, 2))
+        seg = genome[pos:pos + L]
+        reads.append((pos, min(pos + L, G), fwd, seg if fwd else seg.translate(comp)[::-1]))
+        pos += int(rng.integers(500, L - 400))
+    order = rng.permutation(len(reads))  # stitch in a random order: exercises both prepend and append
+    _write_fasta(tmp_path / "r.fa", [r[3].decode() for r in reads], "r")
+    with S.SeqStore(0) as store:
+        store.upload(S.NANOPORE, S.SeqFile(str(tmp_path / "r.fa")))
+        # host layout: reference rule on (borders only) -> pieces; oracle strings -> expected contig
+        want, wb = None, (0, 0)
+        segs = []  # (read, lo, hi) genome interval contributed by each accepted read, in contig order
+        for k in order:
+            a, b, fwd, seq = reads[k]
+            oriented = oracle.get_sequence(seq, 0, len(seq), fwd)  # whole read, in genome orientation
+            assert oriented == genome[a:b]
+            if want is None:
+                segs = [(k, a, b)]
+            elif a < wb[0]:
+                segs.insert(0, (k, a, min(b, a + (wb[0] - a) + 1)))  # strSlice(new, 0, borderRight): inclusive
+            elif b - 1 > wb[1]:
+                take = (b - 1) - wb[1]
+                segs.append((k, b - take, b))
+            want, lo, hi = update_consensus_base(want, wb, oriented, (a, b - 1))
+            wb = (lo, hi)
+        pieces, off = [], 0
+        for k, lo, hi in segs:
+            a, b, fwd, seq = reads[k]
+            # genome interval [lo, hi) of read k = oriented[lo-a : hi-a]; in read coordinates:
+            if fwd:
+                left, right = lo - a, hi - a - 2          # getNanoporeSequence(l, r) yields chars l .. r+1
+            else:
+                left, right = (b - hi), (b - lo) - 2
+            p = store.resolve(S.NANOPORE, k, left, right, fwd, dst_off=off)
+            assert int(p["len"]) == hi - lo
+            pieces.append(p)
+            off += hi - lo
+        got = _run(store, np.array(pieces))
+        assert got == want
+
+
+def test_unaligned_tiny_and_empty_pieces(oracle, tmp_path):
+    from muchsalsa_amd import sequences as S
+    rng = np.random.default_rng(5)
+    s = bytes(rng.choice(np.frombuffer(b"ACGTN", dtype=np.uint8), 5000))
+    _write_fasta(tmp_path / "one.fa", [s.decode()], "x")
+    with S.SeqStore(0) as store:
+        store.upload(S.NANOPORE, S.SeqFile(str(tmp_path / "one.fa")))
+        pieces, want, off = [], [], 0
+        for length in list(range(0, 40)) + [63, 64, 65, 4095, 4096, 4097]:
+            for start in (0, 1, 2, 3, 5, 17):
+                for direction in (True, False):
+                    left, right = start, start + length - 2
+                    w = oracle.get_sequence(s, left, right, direction) if length else b""
+                    p = store.resolve(S.NANOPORE, 0, left, right, direction, dst_off=off)
+                    if length == 0:
+                        p["len"] = 0
+                    assert int(p["len"]) == len(w)
+                    pieces.append(p)
+                    want.append(w)
+                    off += len(w)
+        assert _run(store, np.array(pieces)) == b"".join(want)
+        assert _run(store, np.zeros(0, dtype=S.COPY_DTYPE), total=0) == b""

@@ -1,0 +1,63 @@
+"""msgpu_seq_parse / msgpu_str_slice (host code of libmsgpu; no GPU needed) against the reference's SA_test fixtures
+and against the oracle."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from muchsalsa_amd import sequences
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_test_data")
+
+
+@pytest.fixture(scope="module")
+def sa():
+    return json.load(open(os.path.join(GOLD, "sa_test_expected.json")))
+
+
+def test_fasta_matches_SA_test(sa):
+    f = sequences.SeqFile(os.path.join(GOLD, "fasta.fa"))
+    assert f.names == sa["FastaTest"]["names"]
+    assert [f.sequence(i).decode() for i in range(len(f))] == sa["FastaTest"]["sequences"]
+
+
+def test_fastq_matches_SA_test(sa):
+    f = sequences.SeqFile(os.path.join(GOLD, "fastq.fq"))
+    assert [f.sequence(i).decode() for i in range(len(f))] == sa["FastQTest"]["nanopore"]
+    assert f.names == ["A00456:495:HHVKWDSXY:1:1101:25952:1031", "A00456:495:HHVKWDSXY:1:1101:3016:1047"]
+
+
+def _write(tmp_path, name, text):
+    p = tmp_path / name
+    p.write_bytes(text)
+    return str(p)
+
+
+@pytest.mark.parametrize("name,text", [
+    ("a.fa", b">r1 desc\nACGT\nNN\n>r2\n\nTT TT\r\n>r1\nGGGG\n>r3"),           # dup id (first wins), blank/CRLF/space, empty
+    ("b.fasta", b"junk before\n>x\tdesc\nAC\nGT"),                                # no trailing newline, tab in header
+    ("c.fq", b"@q1 a\nACGT\nAC\n+\nFFFF\nFF\n@q2\nTTTT\n+q2\nIIII\n"),          # multi-line FASTQ record
+    ("d.txt", b"@only\nACGT\n+\n!!!!\n"),                                         # unknown extension -> FASTQ
+    ("e.fa", b""), ("f.fa", b"no records here\n"),
+])
+def test_loader_matches_oracle_on_edge_cases(oracle, tmp_path, name, text):
+    path = _write(tmp_path, name, text)
+    want_names, want_seqs = oracle.seq_load(path)
+    f = sequences.SeqFile(path)
+    assert f.names == want_names
+    assert [f.sequence(i) for i in range(len(f))] == want_seqs
+
+
+def test_first_cases_by_hand(tmp_path):
+    f = sequences.SeqFile(_write(tmp_path, "a.fa", b">r1 desc\nACGT\nNN\n>r2\n\nTT TT\r\n>r1\nGGGG\n>r3"))
+    assert f.names == ["r1", "r2", "r3"]
+    assert [f.sequence(i) for i in range(3)] == [b"ACGTNN", b"TTTT", b""]
+
+
+def test_str_slice_matches_oracle(oracle):
+    rng = np.random.default_rng(1)
+    for _ in range(3000):
+        size = int(rng.integers(0, 40))
+        i, j = (int(x) for x in rng.integers(-60, 60, 2))
+        assert sequences.str_slice(size, i, j) == oracle.str_slice(size, i, j), (size, i, j)
