@@ -109,6 +109,13 @@ def lib():
             raise ImportError(
                 "muchsalsa_amd/libmsgpu.so is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(or `make -C muchsalsa_amd/csrc`). There is no CPU fallback.")
+        # PyTorch-ROCm wheels bundle their own HIP/HSA runtime.  Two HIP runtimes in one process do not share the
+        # device: whichever is initialised second sees "no GPU".  Importing torch first (when it is installed) makes
+        # libmsgpu's libamdhip64.so.7 dependency resolve to the copy torch already loaded, so load order stops mattering.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         handle = C.CDLL(LIB_PATH)
         for name, restype, argtypes in SYMBOLS:
             fn = getattr(handle, name)  # AttributeError if the library lacks a declared symbol
