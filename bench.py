@@ -56,6 +56,99 @@ def cpu_baseline(workload, budget_reads):
     }
 
 
+def consensus_leg(torch, dev, world, rank, w, steps, warmup):
+    """Device half of the consensus stage (A9) on the same synthetic reads: slice / reverse-complement / stitch.
+
+    Sequences: a random genome; read i = genome[start_i : start_i + L], reverse-complemented for '-' reads (built on the
+    device with the gather kernel itself and installed as the nanopore store).  Layout (host, numpy, NOT timed -- the
+    reference's layout logic, assemblePath's anchor DAG, is not built yet): reads in genome order stitched by the
+    updateConsensusBase append rule (ap.cpp:205-229: a read contributes the part that extends the contig) -> target
+    contigs; every read, oriented to the genome strand, is a query.  Timed: the gather kernel producing target+queries.
+    Checked at full size: the stitched target equals the genome intervals it covers, byte for byte.
+    """
+    from muchsalsa_amd import sequences as S, synth
+    from muchsalsa_amd._lib import COPY_DTYPE, COPY_ILLUMINA, COPY_REVCOMP
+    n_reads, L = w["n_reads"], w["read_len"]
+    G, r_start, r_fwd = synth.read_layout(n_reads, L, w["seed"])
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(w["seed"])
+    genome = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)[
+        torch.randint(0, 4, (G,), device=dev, generator=gen)]
+    store = S.SeqStore(device=dev.index)
+    tstream = torch.cuda.Stream(device=dev)  # a real (non-null) stream: kernels and timing events share it
+    torch.cuda.synchronize()
+    stream = tstream.cuda_stream
+    store.upload_device(S.ILLUMINA, genome.data_ptr(), G, [0], [G])  # the genome as "unitig 0"
+
+    # reads on the device: one piece per read out of the genome
+    mk = np.zeros(n_reads, dtype=COPY_DTYPE)
+    mk["src_off"], mk["dst_off"], mk["len"] = r_start, np.arange(n_reads, dtype=np.uint64) * L, L
+    mk["flags"] = COPY_ILLUMINA | np.where(r_fwd, 0, COPY_REVCOMP).astype(np.uint32)
+    d_reads = torch.empty(n_reads * L, dtype=torch.uint8, device=dev)
+    store.run(store.plan(mk), d_reads.data_ptr(), d_reads.numel(), stream=stream)
+    torch.cuda.synchronize()
+    store.upload_device(S.NANOPORE, d_reads.data_ptr(), d_reads.numel(), np.arange(n_reads, dtype=np.uint64) * L,
+                        np.full(n_reads, L, dtype=np.uint64))
+    del d_reads
+
+    # layout: append rule over reads in genome order
+    order = np.argsort(r_start, kind="stable")
+    st, en = r_start[order], r_start[order] + L
+    cur = np.maximum.accumulate(np.concatenate([[0], en[:-1]]))  # contig end before each read
+    lo = np.maximum(st, cur)                                      # a gap (st > cur) starts a new contig
+    ext = en > cur
+    rid, lo, hi, fwd = order[ext], lo[ext], en[ext], r_fwd[order][ext]
+    t_len = (hi - lo).astype(np.uint64)
+    t_off = np.concatenate([[0], np.cumsum(t_len)[:-1]]).astype(np.uint64)
+    T = int(t_len.sum())
+    tgt = np.zeros(len(rid), dtype=COPY_DTYPE)
+    # genome interval [lo, hi) of read r: read coordinates lo-start.. (forward) / start+L-hi.. (reverse strand)
+    left = np.where(fwd, lo - r_start[rid], r_start[rid] + L - hi)
+    tgt["src_off"], tgt["dst_off"], tgt["len"] = rid.astype(np.uint64) * L + left.astype(np.uint64), t_off, t_len
+    tgt["flags"] = np.where(fwd, 0, COPY_REVCOMP).astype(np.uint32)
+    qry = np.zeros(n_reads, dtype=COPY_DTYPE)
+    qry["src_off"] = np.arange(n_reads, dtype=np.uint64) * L
+    qry["dst_off"] = np.uint64(T) + np.arange(n_reads, dtype=np.uint64) * L
+    qry["len"], qry["flags"] = L, np.where(r_fwd, 0, COPY_REVCOMP).astype(np.uint32)
+    pieces = np.concatenate([tgt, qry])
+    mine = pieces[rank::world] if world > 1 else pieces
+    plan = store.plan(mine)
+    out_bytes = T + n_reads * L
+    out = torch.empty(out_bytes, dtype=torch.uint8, device=dev)
+
+    for _ in range(warmup):
+        store.run(plan, out.data_ptr(), out_bytes, stream=stream)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ev0.record(tstream)
+    for _ in range(steps):
+        store.run(plan, out.data_ptr(), out_bytes, stream=stream)
+    ev1.record(tstream)
+    torch.cuda.synchronize()
+    wall_ms = 1e3 * (time.perf_counter() - t0) / steps
+    ms = ev0.elapsed_time(ev1) / steps
+    assert ms > 0.5 * wall_ms - 0.05, "event timing (%.4f ms) disagrees with the wall clock (%.4f ms)" % (ms, wall_ms)
+
+    # full-size check: the stitched target equals the genome it covers; queries equal the genome under each read
+    exp = np.zeros(len(rid), dtype=COPY_DTYPE)
+    exp["src_off"], exp["dst_off"], exp["len"], exp["flags"] = lo.astype(np.uint64), t_off, t_len, COPY_ILLUMINA
+    want = torch.empty(max(T, 1), dtype=torch.uint8, device=dev)
+    store.run(store.plan(exp), want.data_ptr(), T, stream=stream)
+    torch.cuda.synchronize()
+    ok = True
+    if world == 1:
+        ok = bool(torch.equal(out[:T], want[:T]))
+        probe = np.random.default_rng(0).choice(n_reads, 64, replace=False)
+        for i in probe:
+            a = int(r_start[i])
+            ok &= bool(torch.equal(out[T + int(i) * L: T + (int(i) + 1) * L], genome[a:a + L]))
+    bases_mine = int(mine["len"].sum())
+    store.close()
+    return {"ms": ms, "target_bases": T, "query_bases": n_reads * L, "pieces": int(len(pieces)),
+            "bases_this_rank": bases_mine, "verified": ok}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -64,6 +157,7 @@ def main():
     ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
     ap.add_argument("--cpu-sample-reads", type=int, default=25_000,
                     help="reads in the CPU-baseline sample (0 disables the baseline leg)")
+    ap.add_argument("--no-consensus", action="store_true", help="skip the consensus (sequence gather) leg")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the N>1 exchange path (all-gather + merge) even at world size 1 (used by the GPU tests)")
     args = ap.parse_args()
@@ -140,6 +234,15 @@ def main():
     else:
         n_edges_total = int(c.n_edges)
 
+    cons = None
+    if not args.no_consensus:
+        ctx.close()  # give the arena back before the ~3 GB of sequence buffers
+        cons = consensus_leg(torch, dev, world, rank, w, args.steps, args.warmup)
+        if multi:
+            tt = torch.tensor([cons["ms"]], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            cons["ms"] = float(tt.item())
+
     if rank == 0:
         ms_per_step = 1e3 * dt / args.steps
         # algorithmic bytes of the dominant kernel (k_chain), SURVEY.md section 8(d):
@@ -155,14 +258,27 @@ def main():
             "config": {"workload": w["name"], "rows": int(len(rows)), "reads": int(c.n_reads),
                        "anchors": int(c.n_anchors), "edges": n_edges_total, "edgematches_rank0": int(c.n_ems),
                        "orders_rank0": int(c.n_orders), "parallelism": "edges sharded by v1 %% %d" % world,
-                       "consensus_mbases_per_s": None,
-                       "note": "consensus (assemblePath) stage not built yet; value is the overlap half of the metric"},
+                       "note": "value = overlap half of the metric; the consensus half is reported under 'consensus' "
+                               "(device gather stage only: assemblePath's layout logic is host-side and not built yet)"},
             "stage_ms": {"index": tm.index_ms, "candidates": tm.candidates_ms, "chain_total": tm.chain_ms,
                          "chain_kernel": k_ms, "compact": tm.compact_ms},
             "roofline": {"bound": "hbm", "kernel": "k_chain", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "algorithmic_bytes_per_launch": int(alg_bytes), "kernel_ms": k_ms},
         }
+        if cons is not None:
+            gb = 2.0 * (cons["target_bases"] + cons["query_bases"]) / 1e9  # 1 B read + 1 B written per base
+            g_gbs = gb / (cons["ms"] * 1e-3)
+            out["consensus"] = {
+                "stage": "slice / reverse-complement / stitch kernel k_gather (layout precomputed on the host, not timed)",
+                "consensus_mbases_per_s": cons["target_bases"] / (cons["ms"] * 1e-3) / 1e6,
+                "query_mbases_per_s": cons["query_bases"] / (cons["ms"] * 1e-3) / 1e6,
+                "target_bases": cons["target_bases"], "query_bases": cons["query_bases"], "pieces": cons["pieces"],
+                "ms": cons["ms"], "verified_against_genome": cons["verified"],
+                "roofline": {"bound": "hbm", "kernel": "k_gather", "achieved": g_gbs, "peak": HBM_PEAK_GBS,
+                             "unit": "GB/s", "frac": g_gbs / HBM_PEAK_GBS, "traffic": None,
+                             "algorithmic_bytes_per_launch": int(gb * 1e9)},
+            }
         if world == 1 and args.cpu_sample_reads > 0:
             out["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_sample_reads)
         print(json.dumps(out))

@@ -247,6 +247,11 @@ const char *msgpu_seq_last_error(const msgpu_seqctx *ctx);
  * NULL = record order.  n_ids = size of the id space. */
 int msgpu_seq_upload(msgpu_seqctx *ctx, int kind, const msgpu_seqfile *f, const uint32_t *ids, uint32_t n_ids);
 
+/* Same from a device buffer that already holds the whitespace-free bases (copied device-to-device into the store):
+ * off[id] / len[id] = position of sequence `id` inside it (off = ~0 for an id without sequence). */
+int msgpu_seq_upload_device(msgpu_seqctx *ctx, int kind, const void *d_bases, uint64_t n_bases, const uint64_t *off,
+                            const uint64_t *len, uint32_t n_ids);
+
 /* One piece of output: `len` bases starting at `src_off` of a store, as they are or reverse-complemented, written
  * at dst_off.  24 bytes. */
 typedef struct msgpu_copy {

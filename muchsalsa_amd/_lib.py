@@ -89,6 +89,8 @@ SYMBOLS = [
     ("msgpu_seq_destroy", None, [C.c_void_p]),
     ("msgpu_seq_last_error", C.c_char_p, [C.c_void_p]),
     ("msgpu_seq_upload", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_uint32]),
+    ("msgpu_seq_upload_device", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,
+                                          C.c_uint32]),
     ("msgpu_seq_resolve", C.c_int, [C.c_void_p, C.c_int, C.c_uint32, C.c_int32, C.c_int32, C.c_int, C.c_void_p]),
     ("msgpu_gather_plan_create", C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     ("msgpu_gather_plan_free", None, [C.c_void_p]),

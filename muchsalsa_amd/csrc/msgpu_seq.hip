@@ -19,7 +19,7 @@
 
 namespace msgpu {
 
-constexpr uint32_t GCHUNK = 4096; // output bytes per workgroup: 256 lanes x 16 B
+constexpr uint32_t GCHUNK = 1024; // output bytes per wavefront: 64 lanes x 16 B (a workgroup takes 4 consecutive chunks)
 
 struct __attribute__((packed, aligned(4))) U4A4 { // 16 bytes that are only dword-aligned
   uint32_t x, y, z, w;
@@ -51,43 +51,59 @@ __device__ __forceinline__ void load16_unaligned(const uint8_t *p, uint32_t out[
   out[3]             = __builtin_amdgcn_alignbyte(w4, v.w, sh);
 }
 
-__global__ __launch_bounds__(256) void k_gather(const msgpu_copy *pieces, const uint64_t *chunk_first, uint32_t n,
+constexpr int GUNROLL = 2; // chunks per wavefront: both chunks' loads are in flight before the first is consumed
+
+__global__ __launch_bounds__(256) void k_gather(const msgpu_copy *pieces, const uint2 *chunk_map, uint64_t n_chunks,
                                                 const uint8_t *base0, const uint8_t *base1, uint8_t *out) {
-  // which piece does this 4 KiB output chunk belong to?  (uniform binary search)
-  const uint64_t chunk = blockIdx.x;
-  uint32_t       lo = 0, hi = n;
-  while (hi - lo > 1) {
-    const uint32_t mid = (lo + hi) >> 1;
-    if (chunk_first[mid] <= chunk)
-      lo = mid;
-    else
-      hi = mid;
+  // 1 KiB output chunks; chunk_map[chunk] = (piece, index of the chunk inside the piece), precomputed by the host when
+  // the plan was made (a binary search here would cost ~18 dependent loads per KiB)
+  const uint64_t c0   = (static_cast<uint64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6)) * GUNROLL;
+  const int      lane = threadIdx.x & 63;
+  uint64_t       A[GUNROLL], qlo[GUNROLL], qhi[GUNROLL];
+  uint32_t       r[GUNROLL][4];
+  bool           rev[GUNROLL];
+#pragma unroll
+  for (int u = 0; u < GUNROLL; ++u) {
+    const uint64_t chunk = c0 + u;
+    qlo[u] = qhi[u] = A[u] = 0;
+    rev[u]                 = false;
+    if (chunk >= n_chunks) continue;
+    const uint2      cm = chunk_map[chunk];
+    const msgpu_copy pc = pieces[cm.x];
+    const uint64_t   d0 = pc.dst_off, d1 = pc.dst_off + pc.len;
+    A[u]   = (d0 & ~15ull) + static_cast<uint64_t>(cm.y) * GCHUNK + lane * 16ull; // 16-B aligned output address
+    qlo[u] = A[u] > d0 ? A[u] : d0;
+    qhi[u] = (A[u] + 16 < d1) ? A[u] + 16 : d1;
+    if (qlo[u] >= qhi[u]) continue;
+    const uint8_t *src = (pc.flags & MSGPU_COPY_ILLUMINA) ? base1 : base0;
+    rev[u]             = (pc.flags & MSGPU_COPY_REVCOMP) != 0;
+    // forward: out[q] = src[src_off + (q - d0)]   (A < d0 only for the head lane: reads into the padding)
+    // reverse: out[q] = complement(src[src_off + len - 1 - (q - d0)]): the 16 source bytes ending at that address
+    const uint8_t *p = rev[u] ? src + pc.src_off + pc.len - 1 - (A[u] - d0) - 15 : src + pc.src_off + (A[u] - d0);
+    load16_unaligned(p, r[u]);
   }
-  const msgpu_copy pc  = pieces[lo];
-  const uint64_t   d0  = pc.dst_off, d1 = pc.dst_off + pc.len;
-  const uint64_t   A   = (d0 & ~15ull) + (chunk - chunk_first[lo]) * GCHUNK + threadIdx.x * 16ull; // 16-B aligned
-  const uint64_t   qlo = A > d0 ? A : d0, qhi = (A + 16 < d1) ? A + 16 : d1;
-  if (qlo >= qhi) return;
-  const uint8_t *src = (pc.flags & MSGPU_COPY_ILLUMINA) ? base1 : base0;
-  uint32_t       w[4];
-  if (!(pc.flags & MSGPU_COPY_REVCOMP)) {
-    // out[q] = src[src_off + (q - d0)]
-    load16_unaligned(src + pc.src_off + (A - d0), w); // A < d0 only for the head lane: reads into the padding
-  } else {
-    // out[q] = complement(src[src_off + len - 1 - (q - d0)]): 16 source bytes ending at that address, reversed
-    uint32_t r[4];
-    load16_unaligned(src + pc.src_off + pc.len - 1 - (A - d0) - 15, r);
-    w[0] = complement4(__builtin_bswap32(r[3]));
-    w[1] = complement4(__builtin_bswap32(r[2]));
-    w[2] = complement4(__builtin_bswap32(r[1]));
-    w[3] = complement4(__builtin_bswap32(r[0]));
-  }
-  if (qlo == A && qhi == A + 16) {
-    *reinterpret_cast<uint4 *>(out + A) = make_uint4(w[0], w[1], w[2], w[3]);
-  } else { // head / tail of a piece
-    for (uint64_t q = qlo; q < qhi; ++q) {
-      const uint32_t k = static_cast<uint32_t>(q - A);
-      out[q]           = static_cast<uint8_t>(w[k >> 2] >> (8 * (k & 3)));
+#pragma unroll
+  for (int u = 0; u < GUNROLL; ++u) {
+    if (qlo[u] >= qhi[u]) continue;
+    uint32_t w[4];
+    if (!rev[u]) {
+      w[0] = r[u][0];
+      w[1] = r[u][1];
+      w[2] = r[u][2];
+      w[3] = r[u][3];
+    } else {
+      w[0] = complement4(__builtin_bswap32(r[u][3]));
+      w[1] = complement4(__builtin_bswap32(r[u][2]));
+      w[2] = complement4(__builtin_bswap32(r[u][1]));
+      w[3] = complement4(__builtin_bswap32(r[u][0]));
+    }
+    if (qlo[u] == A[u] && qhi[u] == A[u] + 16) {
+      *reinterpret_cast<uint4 *>(out + A[u]) = make_uint4(w[0], w[1], w[2], w[3]);
+    } else { // head / tail of a piece
+      for (uint64_t q = qlo[u]; q < qhi[u]; ++q) {
+        const uint32_t k = static_cast<uint32_t>(q - A[u]);
+        out[q]           = static_cast<uint8_t>(w[k >> 2] >> (8 * (k & 3)));
+      }
     }
   }
 }
@@ -117,7 +133,7 @@ struct msgpu_seqctx {
 };
 
 struct msgpu_gather_plan {
-  void    *d_pieces = nullptr, *d_chunk_first = nullptr;
+  void    *d_pieces = nullptr, *d_chunk_map = nullptr; // chunk_map: uint2 {piece, chunk inside the piece} per 1 KiB chunk
   uint32_t n = 0;
   uint64_t n_chunks = 0, out_bytes = 0, bases = 0;
 };
@@ -199,6 +215,29 @@ int msgpu_seq_upload(msgpu_seqctx *c, int kind, const msgpu_seqfile *f, const ui
   return MSGPU_OK;
 }
 
+int msgpu_seq_upload_device(msgpu_seqctx *c, int kind, const void *d_bases, uint64_t n_bases, const uint64_t *off,
+                            const uint64_t *len, uint32_t n_ids) {
+  if (!c || kind < 0 || kind > 1 || (n_bases && !d_bases) || (n_ids && (!off || !len))) return MSGPU_E_ARG;
+  SHIP(c, hipSetDevice(c->device));
+  SeqStore &s = c->st[kind];
+  for (uint32_t i = 0; i < n_ids; ++i)
+    if (off[i] != ~0ull && off[i] + len[i] > n_bases) return MSGPU_E_ARG;
+  s.off.assign(off, off + n_ids);
+  s.len.assign(len, len + n_ids);
+  if (s.d_buf) {
+    SHIP(c, hipFree(s.d_buf));
+    s.d_buf = nullptr;
+  }
+  s.n_bases = n_bases;
+  SHIP(c, hipMalloc(&s.d_buf, n_bases + 2 * SEQ_PAD));
+  SHIP(c, hipMemsetAsync(s.d_buf, 0, SEQ_PAD, c->stream));
+  SHIP(c, hipMemsetAsync(static_cast<uint8_t *>(s.d_buf) + SEQ_PAD + n_bases, 0, SEQ_PAD, c->stream));
+  if (n_bases)
+    SHIP(c, hipMemcpyAsync(static_cast<uint8_t *>(s.d_buf) + SEQ_PAD, d_bases, n_bases, hipMemcpyDeviceToDevice, c->stream));
+  SHIP(c, hipStreamSynchronize(c->stream));
+  return MSGPU_OK;
+}
+
 int msgpu_seq_resolve(msgpu_seqctx *c, int kind, uint32_t seq_id, int32_t left, int32_t right, int direction,
                       msgpu_copy *out) {
   if (!c || !out || kind < 0 || kind > 1) return MSGPU_E_ARG;
@@ -217,19 +256,26 @@ int msgpu_gather_plan_create(msgpu_seqctx *c, const msgpu_copy *pieces, size_t n
   if (!c || !out || (n && !pieces) || n >= 0xfffffff0ull) return MSGPU_E_ARG;
   *out = nullptr;
   SHIP(c, hipSetDevice(c->device));
-  std::vector<uint64_t> first(n + 1);
+  std::vector<uint32_t> cmap; // 2 words per chunk
   uint64_t              chunks = 0, out_bytes = 0, bases = 0;
   for (size_t i = 0; i < n; ++i) {
-    first[i] = chunks;
     const msgpu_copy &p = pieces[i];
     const SeqStore   &s = c->st[(p.flags & MSGPU_COPY_ILLUMINA) ? 1 : 0];
     if (p.src_off + p.len > s.n_bases) return MSGPU_E_ARG; // never read outside the store
-    if (p.len) chunks += ((p.dst_off + p.len) - (p.dst_off & ~15ull) + GCHUNK - 1) / GCHUNK;
+    if (p.len) {
+      const uint64_t k = ((p.dst_off + p.len) - (p.dst_off & ~15ull) + GCHUNK - 1) / GCHUNK;
+      if (chunks + k >= 0x1fffffffcull) return MSGPU_E_ARG; // grid.x = chunks / 4 must fit 31 bits
+      try {
+        for (uint64_t q = 0; q < k; ++q) {
+          cmap.push_back(static_cast<uint32_t>(i));
+          cmap.push_back(static_cast<uint32_t>(q));
+        }
+      } catch (std::bad_alloc const &) { return MSGPU_E_NOMEM; }
+      chunks += k;
+    }
     if (p.dst_off + p.len > out_bytes) out_bytes = p.dst_off + p.len;
     bases += p.len;
   }
-  first[n] = chunks;
-  if (chunks >= 0x7fffffffull) return MSGPU_E_ARG;
   auto *pl = new (std::nothrow) msgpu_gather_plan();
   if (!pl) return MSGPU_E_NOMEM;
   pl->n         = static_cast<uint32_t>(n);
@@ -237,15 +283,15 @@ int msgpu_gather_plan_create(msgpu_seqctx *c, const msgpu_copy *pieces, size_t n
   pl->out_bytes = out_bytes;
   pl->bases     = bases;
   hipError_t e  = hipMalloc(&pl->d_pieces, (n ? n : 1) * sizeof(msgpu_copy));
-  if (e == hipSuccess) e = hipMalloc(&pl->d_chunk_first, (n + 1) * sizeof(uint64_t));
+  if (e == hipSuccess) e = hipMalloc(&pl->d_chunk_map, (chunks ? chunks : 1) * 8);
   if (e == hipSuccess && n)
     e = hipMemcpyAsync(pl->d_pieces, pieces, n * sizeof(msgpu_copy), hipMemcpyHostToDevice, c->stream);
-  if (e == hipSuccess)
-    e = hipMemcpyAsync(pl->d_chunk_first, first.data(), (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess && chunks)
+    e = hipMemcpyAsync(pl->d_chunk_map, cmap.data(), chunks * 8, hipMemcpyHostToDevice, c->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
   if (e != hipSuccess) {
     if (pl->d_pieces) (void)hipFree(pl->d_pieces);
-    if (pl->d_chunk_first) (void)hipFree(pl->d_chunk_first);
+    if (pl->d_chunk_map) (void)hipFree(pl->d_chunk_map);
     delete pl;
     return sfail(c, e == hipErrorOutOfMemory ? MSGPU_E_NOMEM : MSGPU_E_HIP, "gather plan", e);
   }
@@ -256,7 +302,7 @@ int msgpu_gather_plan_create(msgpu_seqctx *c, const msgpu_copy *pieces, size_t n
 void msgpu_gather_plan_free(msgpu_gather_plan *pl) {
   if (!pl) return;
   if (pl->d_pieces) (void)hipFree(pl->d_pieces);
-  if (pl->d_chunk_first) (void)hipFree(pl->d_chunk_first);
+  if (pl->d_chunk_map) (void)hipFree(pl->d_chunk_map);
   delete pl;
 }
 
@@ -271,9 +317,9 @@ int msgpu_gather_run(msgpu_seqctx *c, const msgpu_gather_plan *pl, void *d_out, 
   hipStream_t st = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->stream;
   const uint8_t *b0 = c->st[0].d_buf ? static_cast<const uint8_t *>(c->st[0].d_buf) + SEQ_PAD : nullptr;
   const uint8_t *b1 = c->st[1].d_buf ? static_cast<const uint8_t *>(c->st[1].d_buf) + SEQ_PAD : nullptr;
-  hipLaunchKernelGGL(k_gather, dim3(static_cast<uint32_t>(pl->n_chunks)), dim3(256), 0, st,
-                     static_cast<const msgpu_copy *>(pl->d_pieces), static_cast<const uint64_t *>(pl->d_chunk_first),
-                     pl->n, b0, b1, static_cast<uint8_t *>(d_out));
+  hipLaunchKernelGGL(k_gather, dim3(static_cast<uint32_t>((pl->n_chunks + 4 * GUNROLL - 1) / (4 * GUNROLL))), dim3(256), 0, st,
+                     static_cast<const msgpu_copy *>(pl->d_pieces), static_cast<const uint2 *>(pl->d_chunk_map),
+                     pl->n_chunks, b0, b1, static_cast<uint8_t *>(d_out));
   SHIP(c, hipGetLastError());
   return MSGPU_OK;
 }

@@ -95,6 +95,12 @@ class SeqStore:
         else:
             self._check(self._L.msgpu_seq_upload(self._h, kind, seqfile._h, None, 0))
 
+    def upload_device(self, kind, d_bases_ptr, n_bases, off, length):
+        off = np.ascontiguousarray(off, dtype="<u8")
+        length = np.ascontiguousarray(length, dtype="<u8")
+        self._check(self._L.msgpu_seq_upload_device(self._h, kind, C.c_void_p(d_bases_ptr), int(n_bases),
+                                                    off.ctypes.data, length.ctypes.data, len(off)))
+
     def resolve(self, kind, seq_id, left, right, direction, dst_off=0):
         out = np.zeros(1, dtype=COPY_DTYPE)
         self._check(self._L.msgpu_seq_resolve(self._h, kind, int(seq_id), int(left), int(right), 1 if direction else 0,

@@ -46,6 +46,22 @@ def _uniform(seed, stream, n, lo, hi):
     return lo + (hi - lo) * u
 
 
+def read_layout(n_reads, read_len, seed, coverage=10):
+    """(genome length, read starts, read strands) -- the same draws paf_table() makes."""
+    G = max(int(n_reads) * int(read_len) // int(coverage), read_len + 1500)
+    r_start = _randint(seed, 3, n_reads, 0, G - read_len)
+    r_fwd = (splitmix64(seed, 4, n_reads) & np.uint64(1)).astype(bool)
+    return G, r_start, r_fwd
+
+
+def genome_bases(G, seed):
+    """Uniform ACGT genome of length G as a uint8 array (32 bases per splitmix64 draw)."""
+    u = splitmix64(seed, 8, (G + 31) // 32)
+    shifts = (np.arange(32, dtype=np.uint64) * np.uint64(2))[None, :]
+    codes = ((u[:, None] >> shifts) & np.uint64(3)).astype(np.uint8).reshape(-1)[:G]
+    return np.frombuffer(b"ACGT", dtype=np.uint8)[codes]
+
+
 def paf_table(n_reads, read_len, n_anchors, seed, coverage=10, min_intersection=420):
     """PAF-level columns of the synthetic alignment set (before the reference's filter)."""
     G = max(int(n_reads) * int(read_len) // int(coverage), read_len + 1500)

@@ -17,6 +17,7 @@ def _run(store, pieces, total=None):
     plan = store.plan(pieces)
     n = store.plan_out_bytes(plan) if total is None else total
     out = torch.full((max(n, 1) + 64,), 0x2e, dtype=torch.uint8, device="cuda:0")  # '.' canary
+    torch.cuda.synchronize()  # the store runs on its own non-blocking stream: finish the fill first
     store.run(plan, out.data_ptr(), n)
     store.synchronize()
     host = out.cpu().numpy()
