@@ -258,6 +258,7 @@ def main():
             "config": {"workload": w["name"], "rows": int(len(rows)), "reads": int(c.n_reads),
                        "anchors": int(c.n_anchors), "edges": n_edges_total, "edgematches_rank0": int(c.n_ems),
                        "orders_rank0": int(c.n_orders), "parallelism": "edges sharded by v1 %% %d" % world,
+                       "edges_proven_clean_rank0": int(c.n_edges_fastpath),
                        "note": "value = overlap half of the metric; the consensus half is reported under 'consensus' "
                                "(device gather stage only: assemblePath's layout logic is host-side and not built yet)"},
             "stage_ms": {"index": tm.index_ms, "candidates": tm.candidates_ms, "chain_total": tm.chain_ms,

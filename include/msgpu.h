@@ -118,6 +118,7 @@ typedef struct msgpu_counts {
   uint64_t n_orders;     /* EdgeOrders (this shard)                                                           */
   uint64_t n_ids;        /* sum of |EdgeOrder::ids| (this shard)                                              */
   uint64_t n_pairs_scanned; /* scaffold rows visited while looking for pairs (both directions of each pair)   */
+  uint64_t n_edges_fastpath; /* edges whose pairs were all proven compatible without the O(n^2) sweep (this shard) */
 } msgpu_counts;
 
 /* Device time of the last run of each stage, milliseconds, measured with HIP events on the context's stream. */

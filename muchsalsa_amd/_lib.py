@@ -40,7 +40,7 @@ class Params(C.Structure):
 class Counts(C.Structure):
     _fields_ = [("n_rows_in", C.c_uint64), ("n_rows_alive", C.c_uint64), ("n_reads", C.c_uint32),
                 ("n_anchors", C.c_uint32), ("n_edges", C.c_uint64), ("n_ems", C.c_uint64), ("n_orders", C.c_uint64),
-                ("n_ids", C.c_uint64), ("n_pairs_scanned", C.c_uint64)]
+                ("n_ids", C.c_uint64), ("n_pairs_scanned", C.c_uint64), ("n_edges_fastpath", C.c_uint64)]
 
 
 class Timings(C.Structure):

@@ -7,6 +7,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -73,7 +74,9 @@ struct msgpu_ctx {
       scan_tmp;
   DevBuf bound, cand_off, cand_j, cand_t, scr_v2, scr_start, n_cand, n_edge, n_visit_arr, lists, em_base, edge_base,
       visit_base, edges, edge_cand;
-  DevBuf big_key, big_t, big_r2s, big_pfx, pair_tab;
+  DevBuf big_key, big_t, big_r2s, big_pfx, pair_tab, edge_fast;
+  bool   fast_path = true;
+  uint64_t n_edges_fast = 0;
   DevBuf ems, order_scr, ids_scr, edge_norders, edge_nids, order_base, ids_base, orders, ids, big_list, big_elems,
       big_paths;
 
@@ -115,7 +118,7 @@ void release_all(msgpu_ctx *c) {
                    &c->bkt2_idx, &c->bkt2_line, &c->by_anchor, &c->read_len, &c->read_first, &c->scalars, &c->scan_tmp,
                    &c->bound, &c->cand_off, &c->cand_j, &c->cand_t, &c->scr_v2, &c->scr_start, &c->n_cand, &c->n_edge,
                    &c->n_visit_arr, &c->lists, &c->em_base, &c->edge_base, &c->visit_base, &c->edges, &c->edge_cand,
-                   &c->big_key, &c->big_t, &c->big_r2s, &c->big_pfx, &c->pair_tab, &c->ems, &c->order_scr, &c->ids_scr,
+                   &c->big_key, &c->big_t, &c->big_r2s, &c->big_pfx, &c->pair_tab, &c->edge_fast, &c->ems, &c->order_scr, &c->ids_scr,
                    &c->edge_norders, &c->edge_nids, &c->order_base, &c->ids_base, &c->orders, &c->ids, &c->big_list,
                    &c->big_elems, &c->big_paths};
   for (DevBuf *b : all) b->release();
@@ -281,6 +284,10 @@ int msgpu_create(int device, const msgpu_params *params, msgpu_ctx **out) {
     return MSGPU_E_HIP;
   }
   c->stream = c->own_stream;
+  {
+    const char *nf = getenv("MSGPU_NO_FASTPATH"); // test hook: force the full pair sweep on every edge
+    c->fast_path   = !(nf && nf[0] == '1');
+  }
   for (auto &ev : c->ev)
     if (hipEventCreate(&ev) != hipSuccess) {
       msgpu_destroy(c);
@@ -457,6 +464,7 @@ int msgpu_chaining_and_overlaps(msgpu_ctx *c) {
   ENSURE(c, order_base, (E + 2) * 8);
   ENSURE(c, ids_base, (E + 2) * 8);
   ENSURE(c, big_list, (E + 1) * 4);
+  ENSURE(c, visit_base, (E + 2) * 8); // re-used as the scan output of the per-edge shortcut flags
   ENSURE(c, scan_tmp, (size_t(scan_blocks(E > c->V ? E : c->V)) + 1) * 8);
   HIPCHK(c, hipMemsetAsync(c->edge_norders.p, 0, (E + 1) * 4, st));
   HIPCHK(c, hipMemsetAsync(c->edge_nids.p, 0, (E + 1) * 4, st));
@@ -484,6 +492,10 @@ int msgpu_chaining_and_overlaps(msgpu_ctx *c) {
     launch_fill_pair_tab(st, c->pair_tab.as<uint16_t>());
   }
   a.pair_tab     = c->pair_tab.as<uint16_t>();
+  ENSURE(c, edge_fast, (E + 1) * 4);
+  HIPCHK(c, hipMemsetAsync(c->edge_fast.p, 0, (E + 1) * 4, st));
+  a.edge_fast    = c->edge_fast.as<uint32_t>();
+  a.fast_path    = c->fast_path ? 1 : 0;
   a.wiggle       = static_cast<double>(c->p.wiggle_room);
   a.ratio_pct    = c->p.ratio_pct;
   a.alt_frac     = c->p.alt_frac;
@@ -501,7 +513,10 @@ int msgpu_chaining_and_overlaps(msgpu_ctx *c) {
                              c->scan_tmp.as<uint64_t>(), scalar<uint64_t>(c, SC_TOTAL_A));
     exclusive_scan<uint64_t>(st, c->edge_nids.as<uint32_t>(), E, c->ids_base.as<uint64_t>(),
                              c->scan_tmp.as<uint64_t>(), scalar<uint64_t>(c, SC_TOTAL_B));
+    exclusive_scan<uint64_t>(st, c->edge_fast.as<uint32_t>(), E, c->visit_base.as<uint64_t>(),
+                             c->scan_tmp.as<uint64_t>(), scalar<uint64_t>(c, SC_TOTAL_C));
     HIPCHK(c, hipEventRecord(c->ev[7], st));
+    HIPCHK(c, hipMemcpyAsync(&c->n_edges_fast, scalar<uint64_t>(c, SC_TOTAL_C), 8, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipMemcpyAsync(tot, scalar<uint64_t>(c, SC_TOTAL_A), 16, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipMemcpyAsync(&n_big, scalar<uint32_t>(c, SC_NBIG), 4, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st)); // sizes of the order / id tables (+ the number of oversized edges)
@@ -547,6 +562,7 @@ int msgpu_get_counts(msgpu_ctx *c, msgpu_counts *out) {
   out->n_orders        = c->state >= ST_CHAINED ? c->n_orders : 0;
   out->n_ids           = c->state >= ST_CHAINED ? c->n_ids : 0;
   out->n_pairs_scanned = c->state >= ST_EDGES ? c->n_visit : 0;
+  out->n_edges_fastpath = c->state >= ST_CHAINED ? c->n_edges_fast : 0;
   return MSGPU_OK;
 }
 

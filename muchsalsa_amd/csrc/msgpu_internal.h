@@ -47,6 +47,8 @@ struct ChainArgs {
   uint32_t        *edge_norders, *edge_nids;
   uint32_t        *err;
   const uint16_t  *pair_tab; // (l << 8 | k) for the 2016 pairs k < l < 64
+  uint32_t        *edge_fast; // per edge: 1 if the all-pairs-compatible shortcut was taken (may be null)
+  int              fast_path; // 0 disables the shortcut (every edge takes the full pair sweep)
   double           wiggle, ratio_pct, alt_frac;
 };
 

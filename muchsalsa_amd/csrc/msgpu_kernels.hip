@@ -983,6 +983,7 @@ __global__ __launch_bounds__(256) void k_chain(ChainArgs a) {
   uint32_t j1 = 0, q2 = 0, anchor = 0;
   double   clo1 = 0, clo2 = 0, ovr1 = 0, ovr2 = 0, em_score = 0;
   bool     em_dir = false, em_prim = false;
+  ChainElem x{};
   cm[lane]        = 0;
   if (act) {
     j1               = a.cand_j[cp + lane];
@@ -1012,7 +1013,6 @@ __global__ __launch_bounds__(256) void k_chain(ChainArgs a) {
       q[1]     = make_uint4(anchor, om.line, (em_dir ? 1u : 0u) | (em_prim ? 2u : 0u), static_cast<uint32_t>(e));
     }
     // corrected nanopore ranges (mpp.cpp:48-65) and overhangs (ol.cpp:37-47) on both vertices
-    ChainElem x;
     {
       const double rr  = static_cast<double>(m1.i_hi - m1.i_lo + 1) / static_cast<double>(m1.n_hi - m1.n_lo + 1);
       double       ncl = static_cast<double>(ov_lo - m1.i_lo) / rr;
@@ -1051,9 +1051,54 @@ __global__ __launch_bounds__(256) void k_chain(ChainArgs a) {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
 
+  // ---- all-pairs-compatible shortcut -----------------------------------------------------------------------------
+  // A true overlap is a strictly monotone chain of anchors on both reads.  If, for a one-direction edge,
+  //   (1) corrected AND raw nanopore ranges are strictly increasing in lo and hi along v1's order, and strictly
+  //       increasing (plus) / decreasing (minus) on v2  -> every pair has orientation +1/+2 on v1 and, after the flip
+  //       of mpp.cpp:131, +1/+2 on v2, and nanoCheck never aborts (uco = +-2 whenever raw ranges overlap);
+  //   (2) with the signed gaps g1 = c1lo(l) - c1hi(k), g2 = c2lo(l) - c2hi(k) (plus) or c2lo(k) - c2hi(l) (minus):
+  //       diff = |g| + 1 in every case, so "same orientation" pairs need |g1 - g2| <= wiggle and mixed pairs
+  //       (overlap on one read, gap on the other) need d1 + d2 = |g1 - g2| + 2 <= wiggle (:133-138); and
+  //       g1 - g2 = a(l) - b(k) with a = c1lo -+ c2lo/c2hi, b = c1hi -+ c2hi/c2lo, so max a - min b and
+  //       max b - min a bound every pair;
+  // then checkCompatibility is true for ALL pairs, and with positive scores the DP of :185-199 takes k = l-1 at every
+  // l: population[l] = population[l-1] + score(l), path = all anchors up to l.  The bound is checked in integers with
+  // a margin of 3 (> every rounding error of the reference's fp64 expressions), so a "clean" verdict is exact; any
+  // edge that is not provably clean takes the full pair sweep below.
+  bool clean = false;
+  if ((m_plus == 0 || m_minus == 0) && n >= 2 && a.fast_path) {
+    const bool      plus = m_minus == 0;
+    const ChainElem Pv   = el[lane > 0 ? lane - 1 : 0];
+    bool            good = true;
+    if (act && lane > 0) {
+      good = (Pv.clo1 < x.clo1) & (Pv.chi1 < x.chi1) & (Pv.rlo1 < x.rlo1) & (Pv.rhi1 < x.rhi1);
+      good &= plus ? ((Pv.clo2 < x.clo2) & (Pv.chi2 < x.chi2) & (Pv.rlo2 < x.rlo2) & (Pv.rhi2 < x.rhi2))
+                   : ((Pv.clo2 > x.clo2) & (Pv.chi2 > x.chi2) & (Pv.rlo2 > x.rlo2) & (Pv.rhi2 > x.rhi2));
+    }
+    const double av = plus ? x.clo1 - x.clo2 : x.clo1 + x.chi2;
+    const double bv = plus ? x.chi1 - x.chi2 : x.chi1 + x.clo2;
+    good &= (av > -1.0e9) & (av < 1.0e9) & (bv > -1.0e9) & (bv < 1.0e9) & (em_score > 1.0e-6);
+    if (__ballot(act && !good) == 0) { // the cheap monotonicity test first: most non-clean edges stop here
+      int a_hi = act ? static_cast<int>(ceil(av)) : -2147483647 - 1;
+      int a_lo = act ? static_cast<int>(floor(av)) : 2147483647;
+      int b_hi = act ? static_cast<int>(ceil(bv)) : -2147483647 - 1;
+      int b_lo = act ? static_cast<int>(floor(bv)) : 2147483647;
+#pragma unroll
+      for (int d = 32; d > 0; d >>= 1) {
+        a_hi = max(a_hi, __shfl_xor(a_hi, d));
+        a_lo = min(a_lo, __shfl_xor(a_lo, d));
+        b_hi = max(b_hi, __shfl_xor(b_hi, d));
+        b_lo = min(b_lo, __shfl_xor(b_lo, d));
+      }
+      const long long W = static_cast<long long>(a.wiggle) - 3;
+      clean = static_cast<long long>(a_hi) - b_lo <= W && static_cast<long long>(b_hi) - a_lo <= W;
+    }
+  }
+  if (a.edge_fast && lane == 0) a.edge_fast[e] = clean ? 1u : 0u;
+
   // ---- checkCompatibility (mpp.cpp:38-142) for every pair k < l of one direction, all 64 lanes busy ---------------
   // pair p = l(l-1)/2 + k, row-major over l; a lane handles p = it*64 + lane
-  const int P = static_cast<int>(n * (n - 1) / 2);
+  const int P = clean ? 0 : static_cast<int>(n * (n - 1) / 2);
   for (int p0 = 0; p0 < P; p0 += 64) {
     const int p  = p0 + lane;
     bool      ok = false;
@@ -1096,13 +1141,23 @@ __global__ __launch_bounds__(256) void k_chain(ChainArgs a) {
   // ---- chaining DP (mpp.cpp:181-199), both directions at once: they never share a compatible pair -----------------
   double   pop = em_score;      // population[l].score
   uint64_t pm  = 1ull << lane;  // path of population[l] incl. l itself (self index appended at :203)
-  for (int k = 0; k + 1 < static_cast<int>(n); ++k) {
-    const double   k_pop = rl_f64(pop, k);
-    const uint64_t k_pm  = rl_u64(pm, k);
-    const double   cand  = k_pop + em_score; // :189
-    if (((mycm >> k) & 1ull) && cand > pop) { // :190-197
-      pop = cand;
-      pm  = k_pm | (1ull << lane);
+  if (clean) {
+    // every pair compatible, scores positive: population[l] = population[l-1] + score(l), summed in the reference's
+    // left-to-right order; path(l) = {0..l}
+    for (int l = 1; l < static_cast<int>(n); ++l) {
+      const double prev = rl_f64(pop, l - 1);
+      if (lane == l) pop = prev + em_score;
+    }
+    pm = lane < 63 ? ((2ull << lane) - 1) : ~0ull;
+  } else {
+    for (int k = 0; k + 1 < static_cast<int>(n); ++k) {
+      const double   k_pop = rl_f64(pop, k);
+      const uint64_t k_pm  = rl_u64(pm, k);
+      const double   cand  = k_pop + em_score; // :189
+      if (((mycm >> k) & 1ull) && cand > pop) { // :190-197
+        pop = cand;
+        pm  = k_pm | (1ull << lane);
+      }
     }
   }
 

@@ -34,6 +34,30 @@ def test_dense_inputs_take_the_big_paths(oracle, shape, coverage, what):
     assert_tables_equal(got, want, what)
 
 
+def test_shortcut_and_full_sweep_agree(oracle, monkeypatch):
+    """k_chain's all-pairs-compatible shortcut must change nothing: same tables with it disabled, and equal to the
+    oracle's; and it must actually be taken on clean synthetic overlaps."""
+    from muchsalsa_amd import overlap, synth
+    rows = synth.synth_rows(2000, 5000, 10000, 7)
+    want = oracle.overlap(rows)
+    with overlap.OverlapContext(0) as ctx:
+        ctx.load_rows(rows)
+        ctx.calculate_edges()
+        ctx.chaining_and_overlaps()
+        fast = ctx.tables()
+        c = ctx.counts()
+    assert 0 < c.n_edges_fastpath <= c.n_edges
+    monkeypatch.setenv("MSGPU_NO_FASTPATH", "1")
+    with overlap.OverlapContext(0) as ctx:
+        ctx.load_rows(rows)
+        ctx.calculate_edges()
+        ctx.chaining_and_overlaps()
+        slow = ctx.tables()
+        assert ctx.counts().n_edges_fastpath == 0
+    assert_tables_equal(fast, want, "shortcut")
+    assert_tables_equal(slow, want, "full sweep")
+
+
 def test_empty_and_tiny(oracle):
     from muchsalsa_amd import synth
     rows = synth.synth_rows(300, 3000, 900, 1)
