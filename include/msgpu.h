@@ -241,7 +241,9 @@ const char *msgpu_seq_bases(const msgpu_seqfile *f, uint32_t record);  /* not NU
 /* strSlice (SequenceUtils.cpp:27-38) as (returned offset, *len): Python-like indices, INCLUSIVE clipped end. */
 uint64_t msgpu_str_slice(uint64_t size, int32_t start, int32_t end, uint64_t *len);
 
-int         msgpu_seq_create(int device, msgpu_seqctx **out);   /* MSGPU_E_NODEVICE without a GPU */
+/* device = HIP ordinal (MSGPU_E_NODEVICE without a GPU), or -1 for a layout-only context: the slice arithmetic and the
+ * segment composers below work on it, but nothing can be uploaded to or gathered on a device. */
+int         msgpu_seq_create(int device, msgpu_seqctx **out);
 void        msgpu_seq_destroy(msgpu_seqctx *ctx);
 const char *msgpu_seq_last_error(const msgpu_seqctx *ctx);
 /* kind 0 = nanopore reads, 1 = illumina unitigs.  ids[record] = Registry id of that record (0xffffffff = skip);
@@ -268,6 +270,24 @@ typedef struct msgpu_copy {
  * len and flags of *out (dst_off is the caller's layout decision). */
 int msgpu_seq_resolve(msgpu_seqctx *ctx, int kind, uint32_t seq_id, int32_t left, int32_t right, int direction,
                       msgpu_copy *out);
+
+/* The segment builders of assemblePath as piece composers (libms/src/kernel/ap.cpp:191-203, 352-579).  m / ml / mr =
+ * the read's VertexMatch rows on the anchor(s) (read_id, anchor_id, ranges, direction bit); ov* = the anchor's
+ * overlap from Id2OverlapMap; direction = the read's orientation in the layout (Vertex::getVertexDirection() == e_POS).
+ * `out` receives the pieces in output order with dst_off relative to the start of the segment (up to 1 / 2 / 2 / 3
+ * pieces); add the segment's position in the output to every dst_off before planning the gather. */
+int msgpu_seg_anchor(msgpu_seqctx *ctx, const msgpu_row *m, int32_t ov_lo, int32_t ov_hi, int direction,
+                     msgpu_copy *out, uint32_t *n_out, uint64_t *len);                       /* getAnchorSequence        */
+int msgpu_seg_left_of_anchor(msgpu_seqctx *ctx, const msgpu_row *m, uint64_t nanopore_length, int32_t ov_lo,
+                             int32_t ov_hi, int direction, msgpu_copy *out, uint32_t *n_out,
+                             uint64_t *len);                                                  /* getSequenceLeftOfAnchor  */
+int msgpu_seg_right_of_anchor(msgpu_seqctx *ctx, const msgpu_row *m, uint64_t nanopore_length, int32_t ov_lo,
+                              int32_t ov_hi, int direction, msgpu_copy *out, uint32_t *n_out,
+                              uint64_t *len);                                                 /* getSequenceRightOfAnchor */
+/* getSequenceBetweenAnchors: *has_sequence = 0 mirrors std::nullopt; *distance = std::get<0> of its result. */
+int msgpu_seg_between_anchors(msgpu_seqctx *ctx, const msgpu_row *ml, const msgpu_row *mr, int32_t ovl_lo,
+                              int32_t ovl_hi, int32_t ovr_lo, int32_t ovr_hi, int direction, msgpu_copy *out,
+                              uint32_t *n_out, int32_t *distance, int *has_sequence);
 
 /* Upload a batch of pieces (+ its work partition) once; run it any number of times. */
 int      msgpu_gather_plan_create(msgpu_seqctx *ctx, const msgpu_copy *pieces, size_t n, msgpu_gather_plan **out);

@@ -92,6 +92,15 @@ SYMBOLS = [
     ("msgpu_seq_upload_device", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,
                                           C.c_uint32]),
     ("msgpu_seq_resolve", C.c_int, [C.c_void_p, C.c_int, C.c_uint32, C.c_int32, C.c_int32, C.c_int, C.c_void_p]),
+    ("msgpu_seg_anchor", C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int, C.c_void_p,
+                                   C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]),
+    ("msgpu_seg_left_of_anchor", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32, C.c_int32, C.c_int,
+                                           C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]),
+    ("msgpu_seg_right_of_anchor", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32, C.c_int32, C.c_int,
+                                            C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]),
+    ("msgpu_seg_between_anchors", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                            C.c_int32, C.c_int, C.c_void_p, C.POINTER(C.c_uint32),
+                                            C.POINTER(C.c_int32), C.POINTER(C.c_int)]),
     ("msgpu_gather_plan_create", C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     ("msgpu_gather_plan_free", None, [C.c_void_p]),
     ("msgpu_gather_plan_out_bytes", C.c_uint64, [C.c_void_p]),

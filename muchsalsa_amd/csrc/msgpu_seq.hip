@@ -154,7 +154,14 @@ extern "C" {
 
 int msgpu_seq_create(int device, msgpu_seqctx **out) {
   if (!out) return MSGPU_E_ARG;
-  *out     = nullptr;
+  *out = nullptr;
+  if (device == -1) { // layout-only context: slice arithmetic and segment composers work, nothing can be gathered
+    auto *c = new (std::nothrow) msgpu_seqctx();
+    if (!c) return MSGPU_E_NOMEM;
+    c->device = -1;
+    *out      = c;
+    return MSGPU_OK;
+  }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return MSGPU_E_NODEVICE;
   if (device < 0 || device >= ndev) return MSGPU_E_ARG;
@@ -171,6 +178,10 @@ int msgpu_seq_create(int device, msgpu_seqctx **out) {
 
 void msgpu_seq_destroy(msgpu_seqctx *c) {
   if (!c) return;
+  if (c->device < 0) {
+    delete c;
+    return;
+  }
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   for (auto &s : c->st)
@@ -183,7 +194,7 @@ const char *msgpu_seq_last_error(const msgpu_seqctx *c) { return c ? c->err : "n
 
 int msgpu_seq_upload(msgpu_seqctx *c, int kind, const msgpu_seqfile *f, const uint32_t *ids, uint32_t n_ids) {
   if (!c || !f || kind < 0 || kind > 1) return MSGPU_E_ARG;
-  SHIP(c, hipSetDevice(c->device));
+  if (c->device >= 0) SHIP(c, hipSetDevice(c->device));
   SeqStore      &s = c->st[kind];
   const uint32_t n = msgpu_seq_count(f);
   uint32_t       space = ids ? n_ids : n;
@@ -202,11 +213,12 @@ int msgpu_seq_upload(msgpu_seqctx *c, int kind, const msgpu_seqfile *f, const ui
     }
     total += l;
   }
+  s.n_bases = total;
+  if (c->device < 0) return MSGPU_OK; // layout-only context: offsets and lengths are all it needs
   if (s.d_buf) {
     SHIP(c, hipFree(s.d_buf));
     s.d_buf = nullptr;
   }
-  s.n_bases = total;
   SHIP(c, hipMalloc(&s.d_buf, total + 2 * SEQ_PAD));
   SHIP(c, hipMemsetAsync(s.d_buf, 0, total + 2 * SEQ_PAD, c->stream));
   if (total)
@@ -218,6 +230,7 @@ int msgpu_seq_upload(msgpu_seqctx *c, int kind, const msgpu_seqfile *f, const ui
 int msgpu_seq_upload_device(msgpu_seqctx *c, int kind, const void *d_bases, uint64_t n_bases, const uint64_t *off,
                             const uint64_t *len, uint32_t n_ids) {
   if (!c || kind < 0 || kind > 1 || (n_bases && !d_bases) || (n_ids && (!off || !len))) return MSGPU_E_ARG;
+  if (c->device < 0) return MSGPU_E_NODEVICE;
   SHIP(c, hipSetDevice(c->device));
   SeqStore &s = c->st[kind];
   for (uint32_t i = 0; i < n_ids; ++i)
@@ -255,6 +268,7 @@ int msgpu_seq_resolve(msgpu_seqctx *c, int kind, uint32_t seq_id, int32_t left, 
 int msgpu_gather_plan_create(msgpu_seqctx *c, const msgpu_copy *pieces, size_t n, msgpu_gather_plan **out) {
   if (!c || !out || (n && !pieces) || n >= 0xfffffff0ull) return MSGPU_E_ARG;
   *out = nullptr;
+  if (c->device < 0) return MSGPU_E_NODEVICE;
   SHIP(c, hipSetDevice(c->device));
   std::vector<uint32_t> cmap; // 2 words per chunk
   uint64_t              chunks = 0, out_bytes = 0, bases = 0;
@@ -312,6 +326,7 @@ uint64_t msgpu_gather_plan_bases(const msgpu_gather_plan *pl) { return pl ? pl->
 int msgpu_gather_run(msgpu_seqctx *c, const msgpu_gather_plan *pl, void *d_out, uint64_t out_capacity, void *hip_stream) {
   if (!c || !pl || (!d_out && pl->out_bytes)) return MSGPU_E_ARG;
   if (out_capacity < pl->out_bytes) return MSGPU_E_ARG;
+  if (c->device < 0) return MSGPU_E_NODEVICE;
   SHIP(c, hipSetDevice(c->device));
   if (!pl->n_chunks) return MSGPU_OK;
   hipStream_t st = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->stream;
@@ -326,6 +341,7 @@ int msgpu_gather_run(msgpu_seqctx *c, const msgpu_gather_plan *pl, void *d_out, 
 
 int msgpu_seq_synchronize(msgpu_seqctx *c) {
   if (!c) return MSGPU_E_ARG;
+  if (c->device < 0) return MSGPU_OK;
   SHIP(c, hipStreamSynchronize(c->stream));
   return MSGPU_OK;
 }

@@ -108,6 +108,37 @@ class SeqStore:
         out["dst_off"] = dst_off
         return out[0]
 
+    # ---- segment builders of assemblePath (ap.cpp:352-579) as piece composers ----------------------------------
+    def _row(self, m):
+        from ._lib import ROW_DTYPE
+        return np.ascontiguousarray(np.asarray(m, dtype=ROW_DTYPE).reshape(1))
+
+    def seg_anchor(self, m, ov, direction):
+        r, out, n, ln = self._row(m), np.zeros(1, dtype=COPY_DTYPE), C.c_uint32(), C.c_uint64()
+        self._check(self._L.msgpu_seg_anchor(self._h, r.ctypes.data, ov[0], ov[1], 1 if direction else 0,
+                                             out.ctypes.data, C.byref(n), C.byref(ln)))
+        return out[:n.value], int(ln.value)
+
+    def seg_left_of_anchor(self, m, nanopore_length, ov, direction):
+        r, out, n, ln = self._row(m), np.zeros(2, dtype=COPY_DTYPE), C.c_uint32(), C.c_uint64()
+        self._check(self._L.msgpu_seg_left_of_anchor(self._h, r.ctypes.data, int(nanopore_length), ov[0], ov[1],
+                                                     1 if direction else 0, out.ctypes.data, C.byref(n), C.byref(ln)))
+        return out[:n.value], int(ln.value)
+
+    def seg_right_of_anchor(self, m, nanopore_length, ov, direction):
+        r, out, n, ln = self._row(m), np.zeros(2, dtype=COPY_DTYPE), C.c_uint32(), C.c_uint64()
+        self._check(self._L.msgpu_seg_right_of_anchor(self._h, r.ctypes.data, int(nanopore_length), ov[0], ov[1],
+                                                      1 if direction else 0, out.ctypes.data, C.byref(n), C.byref(ln)))
+        return out[:n.value], int(ln.value)
+
+    def seg_between_anchors(self, ml, mr, ov_l, ov_r, direction):
+        a, b = self._row(ml), self._row(mr)
+        out, n, dist, has = np.zeros(3, dtype=COPY_DTYPE), C.c_uint32(), C.c_int32(), C.c_int()
+        self._check(self._L.msgpu_seg_between_anchors(self._h, a.ctypes.data, b.ctypes.data, ov_l[0], ov_l[1], ov_r[0],
+                                                      ov_r[1], 1 if direction else 0, out.ctypes.data, C.byref(n),
+                                                      C.byref(dist), C.byref(has)))
+        return out[:n.value], int(dist.value), bool(has.value)
+
     def plan(self, pieces):
         pieces = np.ascontiguousarray(pieces, dtype=COPY_DTYPE)
         h = C.c_void_p()

@@ -1252,3 +1252,183 @@ size_t ms_oracle_get_sequence(const char *seq, size_t size, int left, int right,
     ms_oracle_revcomp(seq + s, len, out);
   return len;
 }
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * segment builders of assemblePath (ap.cpp:191-203, 352-579)
+ * ---------------------------------------------------------------------------------------------------------------- */
+
+#include <math.h>
+
+static size_t append_seq(char *out, size_t w, const char *seq, size_t size, int left, int right, int direction) {
+  return w + ms_oracle_get_sequence(seq, size, left, right, direction, out + w);
+}
+static void revcomp_inplace(char *s, size_t n) {
+  char *tmp = (char *)xrealloc(NULL, n ? n : 1);
+  ms_oracle_revcomp(s, n, tmp);
+  memcpy(s, tmp, n);
+  free(tmp);
+}
+
+size_t ms_oracle_anchor_sequence(const ms_row *m, const char *illu, size_t illu_len, int ov_lo, int ov_hi,
+                                 int direction, char *out) {
+  /* combinedDirection = match.direction * direction (Toggle: XNOR), ap.cpp:428 */
+  int combined = ((m->flags & MS_ROW_DIR) != 0) == (direction != 0);
+  return append_seq(out, 0, illu, illu_len, ov_lo, ov_hi, combined);
+}
+
+size_t ms_oracle_left_of_anchor(const ms_row *m, const char *nano, size_t nano_len, const char *illu, size_t illu_len,
+                                size_t nanopore_length, int ov_lo, int ov_hi, int direction, char *out) {
+  int    mdir = (m->flags & MS_ROW_DIR) != 0;
+  size_t w    = 0;
+  if (!direction) { /* :358-373 */
+    if (!mdir)
+      w = append_seq(out, w, illu, illu_len, m->i_lo, ov_lo, 0);
+    else
+      w = append_seq(out, w, illu, illu_len, ov_hi, m->i_hi, 1);
+    w = append_seq(out, w, nano, nano_len, m->n_hi, (int)nanopore_length - 1, 1);
+    revcomp_inplace(out, w);
+    return w;
+  }
+  w = append_seq(out, w, nano, nano_len, 0, m->n_lo, 1); /* :375 */
+  if (!mdir)
+    w = append_seq(out, w, illu, illu_len, ov_hi, m->i_hi, 0);
+  else
+    w = append_seq(out, w, illu, illu_len, m->i_lo, ov_lo, 1);
+  return w;
+}
+
+size_t ms_oracle_right_of_anchor(const ms_row *m, const char *nano, size_t nano_len, const char *illu, size_t illu_len,
+                                 size_t nanopore_length, int ov_lo, int ov_hi, int direction, char *out) {
+  int    mdir = (m->flags & MS_ROW_DIR) != 0;
+  size_t w    = 0;
+  if (!direction) { /* :394-406 */
+    w = append_seq(out, w, nano, nano_len, 0, m->n_lo, 1);
+    if (!mdir)
+      w = append_seq(out, w, illu, illu_len, ov_hi, m->i_hi, 0);
+    else
+      w = append_seq(out, w, illu, illu_len, m->i_lo, ov_lo, 1);
+    revcomp_inplace(out, w);
+    return w;
+  }
+  if (!mdir) /* :408-417 */
+    w = append_seq(out, w, illu, illu_len, m->i_lo, ov_lo, 0);
+  else
+    w = append_seq(out, w, illu, illu_len, ov_hi, m->i_hi, 1);
+  w = append_seq(out, w, nano, nano_len, m->n_hi, (int)nanopore_length - 1, 1);
+  return w;
+}
+
+/* getCorrectedNanoporeRange, ap.cpp:191-203 */
+static void corrected_nanopore_range(const ms_row *m, int ov_lo, int ov_hi, double *first, double *second) {
+  double l = (ov_lo - m->i_lo) / rratio(m);
+  double r = (m->i_hi - ov_hi) / rratio(m);
+  if (!(m->flags & MS_ROW_DIR)) {
+    double t = l;
+    l = r;
+    r = t;
+  }
+  *first  = m->n_lo + l;
+  *second = m->n_hi - r;
+}
+
+int ms_oracle_between_anchors(const ms_row *ml, const ms_row *mr, const char *nano, size_t nano_len,
+                              const char *illu_l, size_t illu_l_len, const char *illu_r, size_t illu_r_len, int ovl_lo,
+                              int ovl_hi, int ovr_lo, int ovr_hi, int direction, int *distance, char *out,
+                              size_t *out_len) {
+  const int    ldir = (ml->flags & MS_ROW_DIR) != 0, rdir = (mr->flags & MS_ROW_DIR) != 0;
+  const double rl = rratio(ml), rr = rratio(mr);
+  int          corr_l = 0, corr_r = 0;
+  size_t       w = 0;
+  *out_len = 0;
+  if (!direction) { /* :458-518 */
+    double err = mr->n_hi - ml->n_lo;
+    if (err > 0) {
+      double clf, cls, crf, crs;
+      corrected_nanopore_range(ml, ovl_lo, ovl_hi, &clf, &cls);
+      corrected_nanopore_range(mr, ovr_lo, ovr_hi, &crf, &crs);
+      if (clf < crs) {
+        *distance = (int)floor(clf - crs);
+        return 0;
+      }
+      double avail_l, avail_r;
+      if (!ldir) {
+        avail_l = (ml->i_hi - ovl_hi) / rl;
+        corr_l  = ml->i_hi - ovl_hi;
+      } else {
+        avail_l = (ovl_lo - ml->i_lo) / rl;
+        corr_l  = ovl_lo - ml->i_lo;
+      }
+      if (avail_l > err) {
+        corr_l = (int)floor(err * rl);
+        err    = 0;
+      } else {
+        err -= avail_l;
+      }
+      if (!rdir) {
+        avail_r = (ovr_lo - mr->i_lo) / rr;
+        corr_r  = ovr_lo - mr->i_lo;
+      } else {
+        avail_r = (mr->i_hi - ovr_hi) / rr;
+        corr_r  = mr->i_hi - ovr_hi;
+      }
+      if (avail_r > err) corr_r = (int)floor(err * rr);
+    }
+    if (!rdir)
+      w = append_seq(out, w, illu_r, illu_r_len, mr->i_lo + corr_r, ovr_lo, 0);
+    else
+      w = append_seq(out, w, illu_r, illu_r_len, ovr_hi, mr->i_hi - corr_r, 1);
+    w = append_seq(out, w, nano, nano_len, mr->n_hi, ml->n_lo, 1);
+    if (!ldir)
+      w = append_seq(out, w, illu_l, illu_l_len, ovl_hi, ml->i_hi - corr_l, 0);
+    else
+      w = append_seq(out, w, illu_l, illu_l_len, ml->i_lo + corr_l, ovl_lo, 1);
+    *distance = (int)w;
+    revcomp_inplace(out, w);
+    *out_len = w;
+    return 1;
+  }
+  double err = ml->n_hi - mr->n_lo; /* :520-578 */
+  if (err > 0) {
+    double clf, cls, crf, crs;
+    corrected_nanopore_range(ml, ovl_lo, ovl_hi, &clf, &cls);
+    corrected_nanopore_range(mr, ovr_lo, ovr_hi, &crf, &crs);
+    if (cls > crf) {
+      *distance = (int)floor(crf - cls);
+      return 0;
+    }
+    double avail_l, avail_r;
+    if (!ldir) {
+      avail_l = (ovl_lo - ml->i_lo) / rl;
+      corr_l  = ovl_lo - ml->i_lo;
+    } else {
+      avail_l = (ml->i_hi - ovl_hi) / rl;
+      corr_l  = ml->i_hi - ovl_hi;
+    }
+    if (avail_l > err) {
+      corr_l = (int)floor(err * rl);
+      err    = 0;
+    } else {
+      err -= avail_l;
+    }
+    if (!rdir) {
+      avail_r = (mr->i_hi - ovr_hi) / rr;
+      corr_r  = mr->i_hi - ovr_hi;
+    } else {
+      avail_r = (ovr_lo - mr->i_lo) / rr;
+      corr_r  = ovr_lo - mr->i_lo;
+    }
+    if (avail_r > err) corr_r = (int)floor(err * rr);
+  }
+  if (!ldir)
+    w = append_seq(out, w, illu_l, illu_l_len, ml->i_lo + corr_l, ovl_lo, 0);
+  else
+    w = append_seq(out, w, illu_l, illu_l_len, ovl_hi, ml->i_hi - corr_l, 1);
+  w = append_seq(out, w, nano, nano_len, ml->n_hi, mr->n_lo, 1);
+  if (!rdir)
+    w = append_seq(out, w, illu_r, illu_r_len, ovr_hi, mr->i_hi - corr_r, 0);
+  else
+    w = append_seq(out, w, illu_r, illu_r_len, mr->i_lo + corr_r, ovr_lo, 1);
+  *distance = (int)w;
+  *out_len  = w;
+  return 1;
+}

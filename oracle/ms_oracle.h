@@ -153,6 +153,23 @@ void ms_oracle_revcomp(const char *in, size_t n, char *out);
  * when !direction.  out must hold ms_oracle_get_sequence_len bytes; returns the length. */
 size_t ms_oracle_get_sequence(const char *seq, size_t size, int left, int right, int direction, char *out);
 
+/* ---- segment builders of assemblePath (ap.cpp:191-203, 352-579): which pieces of which sequence, in which
+ * orientation, make up an anchor / the flank left or right of an anchor / the stretch between two anchors.
+ * `m*` = the VertexMatch of the read on the anchor(s); nano / illu* = the whole sequences; ov* = the anchor's (cluster)
+ * overlap from Id2OverlapMap.  `out` must hold nano_len + illu lengths + 8 bytes.  Returns the length written. */
+size_t ms_oracle_anchor_sequence(const ms_row *m, const char *illu, size_t illu_len, int ov_lo, int ov_hi,
+                                 int direction, char *out);                                    /* ap.cpp:424-433 */
+size_t ms_oracle_left_of_anchor(const ms_row *m, const char *nano, size_t nano_len, const char *illu, size_t illu_len,
+                                size_t nanopore_length, int ov_lo, int ov_hi, int direction, char *out); /* :352-386 */
+size_t ms_oracle_right_of_anchor(const ms_row *m, const char *nano, size_t nano_len, const char *illu, size_t illu_len,
+                                 size_t nanopore_length, int ov_lo, int ov_hi, int direction, char *out); /* :388-422 */
+/* getSequenceBetweenAnchors (ap.cpp:435-579): returns 1 and the sequence, or 0 (std::nullopt) when the corrected
+ * ranges overlap; *distance = std::get<0> of the result. */
+int ms_oracle_between_anchors(const ms_row *ml, const ms_row *mr, const char *nano, size_t nano_len,
+                              const char *illu_l, size_t illu_l_len, const char *illu_r, size_t illu_r_len, int ovl_lo,
+                              int ovl_hi, int ovr_lo, int ovr_hi, int direction, int *distance, char *out,
+                              size_t *out_len);
+
 #ifdef __cplusplus
 }
 #endif

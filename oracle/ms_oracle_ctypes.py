@@ -81,6 +81,18 @@ def lib():
         _lib.ms_oracle_str_slice.restype = C.c_size_t
         _lib.ms_oracle_get_sequence.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_char_p]
         _lib.ms_oracle_get_sequence.restype = C.c_size_t
+        _lib.ms_oracle_anchor_sequence.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_int, C.c_int, C.c_int,
+                                                   C.c_char_p]
+        _lib.ms_oracle_anchor_sequence.restype = C.c_size_t
+        for fn in (_lib.ms_oracle_left_of_anchor, _lib.ms_oracle_right_of_anchor):
+            fn.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_size_t, C.c_int, C.c_int,
+                           C.c_int, C.c_char_p]
+            fn.restype = C.c_size_t
+        _lib.ms_oracle_between_anchors.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, C.c_size_t, C.c_char_p,
+                                                   C.c_size_t, C.c_char_p, C.c_size_t, C.c_int, C.c_int, C.c_int,
+                                                   C.c_int, C.c_int, C.POINTER(C.c_int), C.c_char_p,
+                                                   C.POINTER(C.c_size_t)]
+        _lib.ms_oracle_between_anchors.restype = C.c_int
     return _lib
 
 
@@ -170,3 +182,43 @@ def get_sequence(seq, left, right, direction):
     out = C.create_string_buffer(len(seq) + 2)
     n = lib().ms_oracle_get_sequence(seq, len(seq), left, right, 1 if direction else 0, out)
     return out.raw[:n]
+
+
+def _rowp(m):
+    r = np.ascontiguousarray(np.asarray(m, dtype=ROW_DTYPE).reshape(1))
+    return r, r.ctypes.data
+
+
+def anchor_sequence(m, illu, ov, direction):
+    r, p = _rowp(m)
+    out = C.create_string_buffer(len(illu) + 8)
+    n = lib().ms_oracle_anchor_sequence(p, illu, len(illu), ov[0], ov[1], 1 if direction else 0, out)
+    return out.raw[:n]
+
+
+def left_of_anchor(m, nano, illu, nanopore_length, ov, direction):
+    r, p = _rowp(m)
+    out = C.create_string_buffer(len(nano) + len(illu) + 16)
+    n = lib().ms_oracle_left_of_anchor(p, nano, len(nano), illu, len(illu), nanopore_length, ov[0], ov[1],
+                                       1 if direction else 0, out)
+    return out.raw[:n]
+
+
+def right_of_anchor(m, nano, illu, nanopore_length, ov, direction):
+    r, p = _rowp(m)
+    out = C.create_string_buffer(len(nano) + len(illu) + 16)
+    n = lib().ms_oracle_right_of_anchor(p, nano, len(nano), illu, len(illu), nanopore_length, ov[0], ov[1],
+                                        1 if direction else 0, out)
+    return out.raw[:n]
+
+
+def between_anchors(ml, mr, nano, illu_l, illu_r, ov_l, ov_r, direction):
+    """-> (distance, sequence or None)"""
+    a, pa = _rowp(ml)
+    b, pb = _rowp(mr)
+    out = C.create_string_buffer(len(nano) + len(illu_l) + len(illu_r) + 24)
+    dist, n = C.c_int(), C.c_size_t()
+    has = lib().ms_oracle_between_anchors(pa, pb, nano, len(nano), illu_l, len(illu_l), illu_r, len(illu_r), ov_l[0],
+                                          ov_l[1], ov_r[0], ov_r[1], 1 if direction else 0, C.byref(dist), out,
+                                          C.byref(n))
+    return dist.value, (out.raw[:n.value] if has else None)

@@ -338,3 +338,148 @@ def overlap(rows, th_overlap=100, wiggle=300):
                       flags=(1 if m.direction else 0) | (2 if m.is_primary else 0), line=m.line) for i, m in ems],
             orders=e.orders))
     return edges, counters
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# sequence helpers and the segment builders of assemblePath, second restatement (strings, like the reference)
+# ----------------------------------------------------------------------------------------------------------------------
+
+def str_slice(s, i, j):  # SequenceUtils.cpp:27-38
+    size = len(s)
+    i2 = i if i >= 0 else size + i
+    j2 = j if j >= 0 else size + j
+    start = max(0, i2)
+    end = max(min(size, max(0, j2)), i2 % (1 << 64))
+    if start > size:
+        raise IndexError("std::out_of_range")
+    return s[start:start + (end - start + 1)]
+
+
+_COMP = bytes.maketrans(b"ACGT", b"TGCA")
+
+
+def reverse_complement(s):  # SequenceUtils.cpp:41-61
+    return s.translate(_COMP)[::-1]
+
+
+def get_sequence(seq, left, right, direction):  # getIlluminaSequence / getNanoporeSequence, SequenceUtils.cpp:63-85
+    s = str_slice(seq, left, right + 1)
+    return s if direction else reverse_complement(s)
+
+
+def _vm(m):
+    i_span = int(m["i_hi"]) - int(m["i_lo"]) + 1
+    n_span = int(m["n_hi"]) - int(m["n_lo"]) + 1
+    return dict(illu=(int(m["i_lo"]), int(m["i_hi"])), nano=(int(m["n_lo"]), int(m["n_hi"])),
+                r_ratio=_div(float(i_span), float(n_span)), direction=bool(int(m["flags"]) & 1))
+
+
+def get_anchor_sequence(m, illu, ov, direction):  # ap.cpp:424-433
+    v = _vm(m)
+    return get_sequence(illu, ov[0], ov[1], v["direction"] == bool(direction))
+
+
+def get_sequence_left_of_anchor(m, nano, illu, nanopore_length, ov, direction):  # ap.cpp:352-386
+    v = _vm(m)
+    if not direction:
+        if not v["direction"]:
+            s = get_sequence(illu, v["illu"][0], ov[0], False)
+        else:
+            s = get_sequence(illu, ov[1], v["illu"][1], True)
+        s += get_sequence(nano, v["nano"][1], int(nanopore_length) - 1, True)
+        return reverse_complement(s)
+    s = get_sequence(nano, 0, v["nano"][0], True)
+    if not v["direction"]:
+        s += get_sequence(illu, ov[1], v["illu"][1], False)
+    else:
+        s += get_sequence(illu, v["illu"][0], ov[0], True)
+    return s
+
+
+def get_sequence_right_of_anchor(m, nano, illu, nanopore_length, ov, direction):  # ap.cpp:388-422
+    v = _vm(m)
+    if not direction:
+        s = get_sequence(nano, 0, v["nano"][0], True)
+        if not v["direction"]:
+            s += get_sequence(illu, ov[1], v["illu"][1], False)
+        else:
+            s += get_sequence(illu, v["illu"][0], ov[0], True)
+        return reverse_complement(s)
+    if not v["direction"]:
+        s = get_sequence(illu, v["illu"][0], ov[0], False)
+    else:
+        s = get_sequence(illu, ov[1], v["illu"][1], True)
+    return s + get_sequence(nano, v["nano"][1], int(nanopore_length) - 1, True)
+
+
+def _corrected_range(v, ov):  # getCorrectedNanoporeRange, ap.cpp:191-203
+    left = _div(float(ov[0] - v["illu"][0]), v["r_ratio"])
+    right = _div(float(v["illu"][1] - ov[1]), v["r_ratio"])
+    if not v["direction"]:
+        left, right = right, left
+    return v["nano"][0] + left, v["nano"][1] - right
+
+
+def get_sequence_between_anchors(ml, mr, nano, illu_l, illu_r, ov_l, ov_r, direction):  # ap.cpp:435-579
+    import math
+    L, R = _vm(ml), _vm(mr)
+    corr_l = corr_r = 0
+    if not direction:
+        err = float(R["nano"][1] - L["nano"][0])
+        if err > 0:
+            cl, cr = _corrected_range(L, ov_l), _corrected_range(R, ov_r)
+            if cl[0] < cr[1]:
+                return int(math.floor(cl[0] - cr[1])), None
+            if not L["direction"]:
+                avail, corr_l = _div(float(L["illu"][1] - ov_l[1]), L["r_ratio"]), L["illu"][1] - ov_l[1]
+            else:
+                avail, corr_l = _div(float(ov_l[0] - L["illu"][0]), L["r_ratio"]), ov_l[0] - L["illu"][0]
+            if avail > err:
+                corr_l, err = int(math.floor(err * L["r_ratio"])), 0.0
+            else:
+                err -= avail
+            if not R["direction"]:
+                avail, corr_r = _div(float(ov_r[0] - R["illu"][0]), R["r_ratio"]), ov_r[0] - R["illu"][0]
+            else:
+                avail, corr_r = _div(float(R["illu"][1] - ov_r[1]), R["r_ratio"]), R["illu"][1] - ov_r[1]
+            if avail > err:
+                corr_r = int(math.floor(err * R["r_ratio"]))
+        if not R["direction"]:
+            s = get_sequence(illu_r, R["illu"][0] + corr_r, ov_r[0], False)
+        else:
+            s = get_sequence(illu_r, ov_r[1], R["illu"][1] - corr_r, True)
+        s += get_sequence(nano, R["nano"][1], L["nano"][0], True)
+        if not L["direction"]:
+            s += get_sequence(illu_l, ov_l[1], L["illu"][1] - corr_l, False)
+        else:
+            s += get_sequence(illu_l, L["illu"][0] + corr_l, ov_l[0], True)
+        return len(s), reverse_complement(s)
+    err = float(L["nano"][1] - R["nano"][0])
+    if err > 0:
+        cl, cr = _corrected_range(L, ov_l), _corrected_range(R, ov_r)
+        if cl[1] > cr[0]:
+            return int(math.floor(cr[0] - cl[1])), None
+        if not L["direction"]:
+            avail, corr_l = _div(float(ov_l[0] - L["illu"][0]), L["r_ratio"]), ov_l[0] - L["illu"][0]
+        else:
+            avail, corr_l = _div(float(L["illu"][1] - ov_l[1]), L["r_ratio"]), L["illu"][1] - ov_l[1]
+        if avail > err:
+            corr_l, err = int(math.floor(err * L["r_ratio"])), 0.0
+        else:
+            err -= avail
+        if not R["direction"]:
+            avail, corr_r = _div(float(R["illu"][1] - ov_r[1]), R["r_ratio"]), R["illu"][1] - ov_r[1]
+        else:
+            avail, corr_r = _div(float(ov_r[0] - R["illu"][0]), R["r_ratio"]), ov_r[0] - R["illu"][0]
+        if avail > err:
+            corr_r = int(math.floor(err * R["r_ratio"]))
+    if not L["direction"]:
+        s = get_sequence(illu_l, L["illu"][0] + corr_l, ov_l[0], False)
+    else:
+        s = get_sequence(illu_l, ov_l[1], L["illu"][1] - corr_l, True)
+    s += get_sequence(nano, L["nano"][1], R["nano"][0], True)
+    if not R["direction"]:
+        s += get_sequence(illu_r, ov_r[1], R["illu"][1] - corr_r, False)
+    else:
+        s += get_sequence(illu_r, R["illu"][0] + corr_r, ov_r[0], True)
+    return len(s), s

@@ -180,3 +180,43 @@ def test_unaligned_tiny_and_empty_pieces(oracle, tmp_path):
                     off += len(w)
         assert _run(store, np.array(pieces)) == b"".join(want)
         assert _run(store, np.zeros(0, dtype=S.COPY_DTYPE), total=0) == b""
+
+
+def test_segment_builders_through_the_gather_kernel(oracle, tmp_path):
+    """getAnchorSequence / getSequence{Left,Right}OfAnchor / getSequenceBetweenAnchors (ap.cpp:352-579): libmsgpu's
+    piece composers + one gather launch for a whole batch of segments == the oracle's strings."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import segcases as SC
+    from muchsalsa_amd import sequences as S
+    rng, reads, unis = SC.make_world(21, n_reads=30, n_unitigs=40)
+    _write_fasta(tmp_path / "r.fa", [r.decode() for r in reads], "r")
+    _write_fasta(tmp_path / "u.fa", [u.decode() for u in unis], "u")
+    with S.SeqStore(0) as store:
+        store.upload(S.NANOPORE, S.SeqFile(str(tmp_path / "r.fa")))
+        store.upload(S.ILLUMINA, S.SeqFile(str(tmp_path / "u.fa")))
+        pieces, want, off = [], [], 0
+
+        def emit(ps, s):
+            nonlocal off
+            ps = ps.copy()
+            ps["dst_off"] += off
+            pieces.append(ps)
+            want.append(s)
+            off += len(s)
+        for _ in range(1500):
+            m, ov = SC.random_match(rng, reads, unis)
+            nano, illu = reads[int(m["read_id"])], unis[int(m["anchor_id"])]
+            d = bool(rng.integers(0, 2))
+            emit(store.seg_anchor(m, ov, d)[0], oracle.anchor_sequence(m, illu, ov, d))
+            emit(store.seg_left_of_anchor(m, len(nano), ov, d)[0], oracle.left_of_anchor(m, nano, illu, len(nano), ov, d))
+            emit(store.seg_right_of_anchor(m, len(nano), ov, d)[0],
+                 oracle.right_of_anchor(m, nano, illu, len(nano), ov, d))
+            m2, ov2 = SC.random_match(rng, reads, unis, read_id=int(m["read_id"]))
+            ps, dist, has = store.seg_between_anchors(m, m2, ov, ov2, d)
+            odist, oseq = oracle.between_anchors(m, m2, nano, illu, unis[int(m2["anchor_id"])], ov, ov2, d)
+            assert dist == odist and has == (oseq is not None)
+            if has:
+                emit(ps, oseq)
+        got = _run(store, np.concatenate(pieces))
+        assert got == b"".join(want)
