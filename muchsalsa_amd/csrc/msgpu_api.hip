@@ -74,7 +74,10 @@ struct msgpu_ctx {
       scan_tmp;
   DevBuf bound, cand_off, cand_j, cand_t, scr_v2, scr_start, n_cand, n_edge, n_visit_arr, lists, em_base, edge_base,
       visit_base, edges, edge_cand;
-  DevBuf big_key, big_t, big_r2s, big_pfx, pair_tab, edge_fast;
+  DevBuf big_key, big_t, big_r2s, big_pfx, pair_tab, edge_fast, big_off;
+  hipStream_t side_stream = nullptr;
+  hipEvent_t  ev_side[2]  = {nullptr, nullptr};
+  uint64_t    n_big_edges = 0, n_big_ems = 0;
   bool   fast_path = true;
   uint64_t n_edges_fast = 0;
   DevBuf ems, order_scr, ids_scr, edge_norders, edge_nids, order_base, ids_base, orders, ids, big_list, big_elems,
@@ -89,7 +92,8 @@ namespace {
 
 // scalar slots in ctx->scalars (uint64 each)
 enum { SC_MAXIDS = 0 /*2 x u32*/, SC_ERR = 1, SC_TOTAL_A = 2, SC_TOTAL_B = 3, SC_TOTAL_C = 4, SC_NLISTS = 5 /*3 x u32, spans 5..6*/,
-       SC_NBIG = 7, SC_NALIVE = 8, SC_IXFLAGS = 9, SC_COUNT = 16 };
+       SC_NBIG = 7, SC_NALIVE = 8, SC_IXFLAGS = 9, SC_BIGSTATS = 10 /*2 x u64*/, SC_BIGCUR = 12 /*2 x u64*/,
+       SC_COUNT = 16 };
 
 int fail(msgpu_ctx *c, int code, const char *fmt, ...) {
   va_list ap;
@@ -118,7 +122,7 @@ void release_all(msgpu_ctx *c) {
                    &c->bkt2_idx, &c->bkt2_line, &c->by_anchor, &c->read_len, &c->read_first, &c->scalars, &c->scan_tmp,
                    &c->bound, &c->cand_off, &c->cand_j, &c->cand_t, &c->scr_v2, &c->scr_start, &c->n_cand, &c->n_edge,
                    &c->n_visit_arr, &c->lists, &c->em_base, &c->edge_base, &c->visit_base, &c->edges, &c->edge_cand,
-                   &c->big_key, &c->big_t, &c->big_r2s, &c->big_pfx, &c->pair_tab, &c->edge_fast, &c->ems, &c->order_scr, &c->ids_scr,
+                   &c->big_key, &c->big_t, &c->big_r2s, &c->big_pfx, &c->pair_tab, &c->edge_fast, &c->big_off, &c->ems, &c->order_scr, &c->ids_scr,
                    &c->edge_norders, &c->edge_nids, &c->order_base, &c->ids_base, &c->orders, &c->ids, &c->big_list,
                    &c->big_elems, &c->big_paths};
   for (DevBuf *b : all) b->release();
@@ -293,6 +297,12 @@ int msgpu_create(int device, const msgpu_params *params, msgpu_ctx **out) {
       msgpu_destroy(c);
       return MSGPU_E_HIP;
     }
+  if (hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_side[0], hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_side[1], hipEventDisableTiming) != hipSuccess) {
+    msgpu_destroy(c);
+    return MSGPU_E_HIP;
+  }
   *out = c;
   return MSGPU_OK;
 }
@@ -304,6 +314,12 @@ void msgpu_destroy(msgpu_ctx *c) {
   release_all(c);
   for (auto &ev : c->ev)
     if (ev) (void)hipEventDestroy(ev);
+  for (auto &ev : c->ev_side)
+    if (ev) (void)hipEventDestroy(ev);
+  if (c->side_stream) {
+    (void)hipStreamSynchronize(c->side_stream);
+    (void)hipStreamDestroy(c->side_stream);
+  }
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
 }
@@ -409,6 +425,8 @@ int msgpu_calculate_edges(msgpu_ctx *c) {
   a.n_edge         = c->n_edge.as<uint32_t>();
   a.n_visit        = c->n_visit_arr.as<uint32_t>();
   a.th_overlap     = c->p.th_overlap;
+  a.big_stats      = scalar<unsigned long long>(c, SC_BIGSTATS);
+  HIPCHK(c, hipMemsetAsync(a.big_stats, 0, 16, st));
   launch_candidates(st, a, 0, l0, c->n_list[0]);
   launch_candidates(st, a, 1, l1, c->n_list[1]);
   if (c->n_list[2]) {
@@ -426,9 +444,12 @@ int msgpu_calculate_edges(msgpu_ctx *c) {
   exclusive_scan<uint64_t>(st, c->n_visit_arr.as<uint32_t>(), V, c->visit_base.as<uint64_t>(),
                            c->scan_tmp.as<uint64_t>(), scalar<uint64_t>(c, SC_TOTAL_C));
   HIPCHK(c, hipGetLastError());
-  uint64_t tot[3] = {0, 0, 0};
+  uint64_t tot[3] = {0, 0, 0}, big[2] = {0, 0};
   HIPCHK(c, hipMemcpyAsync(tot, scalar<uint64_t>(c, SC_TOTAL_A), 24, hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipMemcpyAsync(big, scalar<uint64_t>(c, SC_BIGSTATS), 16, hipMemcpyDeviceToHost, st));
   HIPCHK(c, hipStreamSynchronize(st)); // sizes of the edge / EdgeMatch tables
+  c->n_big_edges = big[0];
+  c->n_big_ems   = big[1];
   c->n_ems   = tot[0];
   c->n_edges = tot[1];
   c->n_visit = tot[2];
@@ -468,7 +489,6 @@ int msgpu_chaining_and_overlaps(msgpu_ctx *c) {
   ENSURE(c, scan_tmp, (size_t(scan_blocks(E > c->V ? E : c->V)) + 1) * 8);
   HIPCHK(c, hipMemsetAsync(c->edge_norders.p, 0, (E + 1) * 4, st));
   HIPCHK(c, hipMemsetAsync(c->edge_nids.p, 0, (E + 1) * 4, st));
-  HIPCHK(c, hipMemsetAsync(scalar<uint32_t>(c, SC_NBIG), 0, 8, st));
 
   ChainArgs a;
   a.edges        = c->edges.as<msgpu_edge>();
@@ -500,33 +520,39 @@ int msgpu_chaining_and_overlaps(msgpu_ctx *c) {
   a.ratio_pct    = c->p.ratio_pct;
   a.alt_frac     = c->p.alt_frac;
 
-  launch_list_big_edges(st, a.edges, E, c->big_list.as<uint32_t>(), scalar<uint32_t>(c, SC_NBIG));
+  // Edges with more than 64 EdgeMatches (counted by the candidate kernels, so the host already knows how many there
+  // are and how much scratch they need) run in k_chain_big on the side stream, concurrently with k_chain.
+  const uint32_t n_big = static_cast<uint32_t>(c->n_big_edges);
+  if (n_big) {
+    ENSURE(c, big_off, (size_t(n_big) + 1) * 8);
+    ENSURE(c, big_elems, (c->n_big_ems ? c->n_big_ems : 1) * big_elem_bytes());
+    ENSURE(c, big_paths, (c->n_big_ems ? c->n_big_ems : 1) * 2 * big_path_bytes());
+    HIPCHK(c, hipMemsetAsync(scalar<uint64_t>(c, SC_BIGCUR), 0, 16, st));
+    launch_list_big_edges(st, a.edges, E, c->big_list.as<uint32_t>(), c->big_off.as<uint64_t>(),
+                          scalar<uint64_t>(c, SC_BIGCUR));
+    HIPCHK(c, hipEventRecord(c->ev_side[0], st));
+    HIPCHK(c, hipStreamWaitEvent(c->side_stream, c->ev_side[0], 0));
+    launch_chain_big(c->side_stream, a, c->big_list.as<uint32_t>(), c->big_off.as<uint64_t>(), n_big,
+                     c->big_elems.p, c->big_paths.p);
+    HIPCHK(c, hipEventRecord(c->ev_side[1], c->side_stream));
+  }
   HIPCHK(c, hipEventRecord(c->ev[5], st));
   launch_chain(st, a);
   HIPCHK(c, hipEventRecord(c->ev[6], st));
   HIPCHK(c, hipGetLastError());
+  if (n_big) HIPCHK(c, hipStreamWaitEvent(st, c->ev_side[1], 0));
 
   uint64_t tot[2] = {0, 0};
-  uint32_t n_big  = 0;
-  for (int round = 0; round < 2; ++round) {
-    exclusive_scan<uint64_t>(st, c->edge_norders.as<uint32_t>(), E, c->order_base.as<uint64_t>(),
-                             c->scan_tmp.as<uint64_t>(), scalar<uint64_t>(c, SC_TOTAL_A));
-    exclusive_scan<uint64_t>(st, c->edge_nids.as<uint32_t>(), E, c->ids_base.as<uint64_t>(),
-                             c->scan_tmp.as<uint64_t>(), scalar<uint64_t>(c, SC_TOTAL_B));
-    exclusive_scan<uint64_t>(st, c->edge_fast.as<uint32_t>(), E, c->visit_base.as<uint64_t>(),
-                             c->scan_tmp.as<uint64_t>(), scalar<uint64_t>(c, SC_TOTAL_C));
-    HIPCHK(c, hipEventRecord(c->ev[7], st));
-    HIPCHK(c, hipMemcpyAsync(&c->n_edges_fast, scalar<uint64_t>(c, SC_TOTAL_C), 8, hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipMemcpyAsync(tot, scalar<uint64_t>(c, SC_TOTAL_A), 16, hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipMemcpyAsync(&n_big, scalar<uint32_t>(c, SC_NBIG), 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipStreamSynchronize(st)); // sizes of the order / id tables (+ the number of oversized edges)
-    if (round == 1 || n_big == 0) break;
-    // rare: edges with more than 64 EdgeMatches take the global-scratch kernel, then the scans are redone
-    ENSURE(c, big_elems, (M ? M : 1) * big_elem_bytes());
-    ENSURE(c, big_paths, (M ? M : 1) * 2 * big_path_bytes());
-    launch_chain_big(st, a, c->big_list.as<uint32_t>(), n_big, c->big_elems.p, c->big_paths.p);
-    HIPCHK(c, hipGetLastError());
-  }
+  exclusive_scan<uint64_t>(st, c->edge_norders.as<uint32_t>(), E, c->order_base.as<uint64_t>(),
+                           c->scan_tmp.as<uint64_t>(), scalar<uint64_t>(c, SC_TOTAL_A));
+  exclusive_scan<uint64_t>(st, c->edge_nids.as<uint32_t>(), E, c->ids_base.as<uint64_t>(), c->scan_tmp.as<uint64_t>(),
+                           scalar<uint64_t>(c, SC_TOTAL_B));
+  exclusive_scan<uint64_t>(st, c->edge_fast.as<uint32_t>(), E, c->visit_base.as<uint64_t>(),
+                           c->scan_tmp.as<uint64_t>(), scalar<uint64_t>(c, SC_TOTAL_C));
+  HIPCHK(c, hipEventRecord(c->ev[7], st));
+  HIPCHK(c, hipMemcpyAsync(&c->n_edges_fast, scalar<uint64_t>(c, SC_TOTAL_C), 8, hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipMemcpyAsync(tot, scalar<uint64_t>(c, SC_TOTAL_A), 16, hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipStreamSynchronize(st)); // sizes of the order / id tables
   c->n_orders = tot[0];
   c->n_ids    = tot[1];
   ENSURE(c, orders, (c->n_orders ? c->n_orders : 1) * sizeof(msgpu_order));

@@ -30,6 +30,7 @@ struct CandArgs {
   uint32_t       *edge_scr_v2;  // per-read edge scratch: v2
   uint32_t       *edge_scr_start; // per-read edge scratch: first candidate of the edge
   uint32_t       *n_cand, *n_edge, *n_visit; // per read
+  unsigned long long *big_stats; // [0] edges with > 64 EdgeMatches, [1] their EdgeMatches (this launch set)
   uint32_t        th_overlap;
 };
 
@@ -117,11 +118,12 @@ void launch_emit_edges(hipStream_t st, const uint32_t *n_edge, const uint32_t *n
                        const uint32_t *scr_start, uint32_t V, msgpu_edge *edges, uint64_t *edge_cand);
 void launch_fill_pair_tab(hipStream_t st, uint16_t *tab);
 void launch_chain(hipStream_t st, const ChainArgs &a);
-void launch_list_big_edges(hipStream_t st, const msgpu_edge *edges, uint64_t n_edges, uint32_t *big_list, uint32_t *n_big);
+void launch_list_big_edges(hipStream_t st, const msgpu_edge *edges, uint64_t n_edges, uint32_t *big_list,
+                           uint64_t *big_off, uint64_t *cursor);
 size_t big_elem_bytes();
 size_t big_path_bytes();
-void launch_chain_big(hipStream_t st, const ChainArgs &a, const uint32_t *big_list, uint32_t n_big, void *elems,
-                      void *paths);
+void launch_chain_big(hipStream_t st, const ChainArgs &a, const uint32_t *big_list, const uint64_t *big_off,
+                      uint32_t n_big, void *elems, void *paths);
 void launch_merge_gathered(hipStream_t st, const MergeArgs &a);
 void launch_compact(hipStream_t st, const CompactArgs &a);
 

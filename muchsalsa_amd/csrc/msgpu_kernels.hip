@@ -659,10 +659,15 @@ __global__ __launch_bounds__(256) void k_candidates(CandArgs a, const uint32_t *
     a.cand_j[co + gs + rr] = mj;
     a.cand_t[co + gs + rr] = s_t[pos];
   }
-  // (d) one edge per group
+  // (d) one edge per group (edges with more than 64 EdgeMatches are counted: they take k_chain_big)
   for (uint32_t g = tid; g < ng; g += 256) {
     a.edge_scr_v2[co + g]    = h_key[g_slot[g]];
     a.edge_scr_start[co + g] = g_off[g];
+    const uint32_t cnt = static_cast<uint32_t>(g_off[g + 1]) - g_off[g];
+    if (cnt > 64) {
+      atomicAdd(&a.big_stats[0], 1ull);
+      atomicAdd(&a.big_stats[1], static_cast<unsigned long long>(cnt));
+    }
   }
   if (tid == 0) {
     a.n_cand[r]  = nc;
@@ -796,6 +801,19 @@ __global__ __launch_bounds__(256) void k_candidates_big(CandArgs a, const uint32
     __syncthreads();
     if (tid == 0) s_carry += tot;
     __syncthreads();
+  }
+  __threadfence_block();
+  __syncthreads();
+  {
+    const uint32_t ne = s_carry;
+    for (uint32_t g = tid; g < ne; g += 256) {
+      const uint32_t st  = a.edge_scr_start[co + g];
+      const uint32_t en  = g + 1 < ne ? a.edge_scr_start[co + g + 1] : nc;
+      if (en - st > 64) {
+        atomicAdd(&a.big_stats[0], 1ull);
+        atomicAdd(&a.big_stats[1], static_cast<unsigned long long>(en - st));
+      }
+    }
   }
   if (tid == 0) {
     a.n_cand[r]  = nc;
@@ -1374,7 +1392,8 @@ __device__ __forceinline__ bool big_compat(const BigElem &K, const BigElem &L, b
   return false;
 }
 
-__global__ __launch_bounds__(64) void k_chain_big(ChainArgs a, const uint32_t *big_list, uint32_t n_big, BigElem *elems,
+__global__ __launch_bounds__(64) void k_chain_big(ChainArgs a, const uint32_t *big_list, const uint64_t *big_off,
+                                                  uint32_t n_big, BigElem *elems,
                                                   BigPath *paths /* 2 slots per EdgeMatch: minus then plus */) {
   if (blockIdx.x >= n_big) return;
   const int        lane = threadIdx.x;
@@ -1385,8 +1404,8 @@ __global__ __launch_bounds__(64) void k_chain_big(ChainArgs a, const uint32_t *b
   const uint32_t   v1 = ed.v1, v2 = ed.v2;
   const uint32_t   n1 = a.read_cnt[v1], n2 = a.read_cnt[v2];
   const int        len1 = a.read_len[v1], len2 = a.read_len[v2];
-  BigElem         *E  = elems + ed.em_off;
-  BigPath         *Pm = paths + 2 * ed.em_off, *Pp = Pm + n;
+  BigElem         *E  = elems + big_off[blockIdx.x];
+  BigPath         *Pm = paths + 2 * big_off[blockIdx.x], *Pp = Pm + n;
 
   // elements + EdgeMatch table
   for (uint32_t i = lane; i < n; i += 64) {
@@ -1661,10 +1680,15 @@ __global__ __launch_bounds__(64) void k_chain_big(ChainArgs a, const uint32_t *b
 }
 
 __global__ __launch_bounds__(256) void k_list_big_edges(const msgpu_edge *edges, uint64_t n_edges, uint32_t *big_list,
-                                                        uint32_t *n_big) {
+                                                        uint64_t *big_off, unsigned long long *cursor /*[2]*/) {
   uint64_t e = static_cast<uint64_t>(blockIdx.x) * 256 + threadIdx.x;
   if (e >= n_edges) return;
-  if (edges[e].em_cnt > 64) big_list[atomicAdd(n_big, 1u)] = static_cast<uint32_t>(e);
+  const uint32_t n = edges[e].em_cnt;
+  if (n > 64) {
+    const unsigned long long i = atomicAdd(&cursor[0], 1ull);
+    big_list[i] = static_cast<uint32_t>(e);
+    big_off[i]  = atomicAdd(&cursor[1], static_cast<unsigned long long>(n)); // first scratch element of this edge
+  }
 }
 
 // (k, l) of the flattened pair index p = l(l-1)/2 + k, k < l < 64
@@ -1852,16 +1876,19 @@ void launch_fill_pair_tab(hipStream_t st, uint16_t *tab) {
 void launch_chain(hipStream_t st, const ChainArgs &a) {
   if (a.n_edges) hipLaunchKernelGGL(k_chain, grid1(a.n_edges, 4), dim3(256), 0, st, a);
 }
-void launch_list_big_edges(hipStream_t st, const msgpu_edge *edges, uint64_t n_edges, uint32_t *big_list, uint32_t *n_big) {
-  if (n_edges) hipLaunchKernelGGL(k_list_big_edges, grid1(n_edges, 256), dim3(256), 0, st, edges, n_edges, big_list, n_big);
+void launch_list_big_edges(hipStream_t st, const msgpu_edge *edges, uint64_t n_edges, uint32_t *big_list,
+                           uint64_t *big_off, uint64_t *cursor) {
+  if (n_edges)
+    hipLaunchKernelGGL(k_list_big_edges, grid1(n_edges, 256), dim3(256), 0, st, edges, n_edges, big_list, big_off,
+                       reinterpret_cast<unsigned long long *>(cursor));
 }
 size_t big_elem_bytes() { return sizeof(BigElem); }
 size_t big_path_bytes() { return sizeof(BigPath); }
-void launch_chain_big(hipStream_t st, const ChainArgs &a, const uint32_t *big_list, uint32_t n_big, void *elems,
-                      void *paths) {
+void launch_chain_big(hipStream_t st, const ChainArgs &a, const uint32_t *big_list, const uint64_t *big_off,
+                      uint32_t n_big, void *elems, void *paths) {
   if (n_big)
-    hipLaunchKernelGGL(k_chain_big, dim3(n_big), dim3(64), 0, st, a, big_list, n_big, static_cast<BigElem *>(elems),
-                       static_cast<BigPath *>(paths));
+    hipLaunchKernelGGL(k_chain_big, dim3(n_big), dim3(64), 0, st, a, big_list, big_off, n_big,
+                       static_cast<BigElem *>(elems), static_cast<BigPath *>(paths));
 }
 void launch_merge_gathered(hipStream_t st, const MergeArgs &a) {
   uint64_t n = a.base[a.world].edges;
