@@ -289,6 +289,17 @@ int msgpu_seg_between_anchors(msgpu_seqctx *ctx, const msgpu_row *ml, const msgp
                               int32_t ovl_hi, int32_t ovr_lo, int32_t ovr_hi, int direction, msgpu_copy *out,
                               uint32_t *n_out, int32_t *distance, int *has_sequence);
 
+/* updateConsensusBase (ap.cpp:205-229) on piece lists: the growing contig of visitOrdered as (pieces, borderLeft,
+ * borderRight).  An update takes the new sequence as a segment (pieces with segment-relative dst_off, e.g. what the
+ * msgpu_seg_* composers return) plus its borders and prepends / appends the part the contig does not cover yet. */
+typedef struct msgpu_consensus msgpu_consensus;
+msgpu_consensus *msgpu_consensus_new(void);
+void             msgpu_consensus_free(msgpu_consensus *c);
+int msgpu_consensus_update(msgpu_consensus *c, const msgpu_copy *seg, uint32_t n, int32_t new_lo, int32_t new_hi);
+int msgpu_consensus_borders(const msgpu_consensus *c, int32_t *lo, int32_t *hi, uint64_t *length);
+/* The contig as pieces laid out from dst_off = base; returns the piece count (call with out = NULL to size). */
+size_t msgpu_consensus_pieces(const msgpu_consensus *c, uint64_t base, msgpu_copy *out, size_t cap);
+
 /* Upload a batch of pieces (+ its work partition) once; run it any number of times. */
 int      msgpu_gather_plan_create(msgpu_seqctx *ctx, const msgpu_copy *pieces, size_t n, msgpu_gather_plan **out);
 void     msgpu_gather_plan_free(msgpu_gather_plan *plan);

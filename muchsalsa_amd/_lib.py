@@ -101,6 +101,12 @@ SYMBOLS = [
     ("msgpu_seg_between_anchors", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                             C.c_int32, C.c_int, C.c_void_p, C.POINTER(C.c_uint32),
                                             C.POINTER(C.c_int32), C.POINTER(C.c_int)]),
+    ("msgpu_consensus_new", C.c_void_p, []),
+    ("msgpu_consensus_free", None, [C.c_void_p]),
+    ("msgpu_consensus_update", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int32, C.c_int32]),
+    ("msgpu_consensus_borders", C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                          C.POINTER(C.c_uint64)]),
+    ("msgpu_consensus_pieces", C.c_size_t, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_size_t]),
     ("msgpu_gather_plan_create", C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     ("msgpu_gather_plan_free", None, [C.c_void_p]),
     ("msgpu_gather_plan_out_bytes", C.c_uint64, [C.c_void_p]),

@@ -16,6 +16,7 @@
 #include <climits>
 #include <cstring>
 #include <memory>
+#include <new>
 #include <string>
 #include <string_view>
 #include <unordered_map>
@@ -101,8 +102,10 @@ int msgpu_parse_paf(const char *path, const msgpu_params *params, msgpu_paf **ou
   }
   close(fd);
 
-  auto *paf = new msgpu_paf();
-  int   rc  = MSGPU_OK;
+  msgpu_paf *paf = nullptr;
+  int        rc  = MSGPU_OK;
+  try { // no exception may cross the C-ABI
+  paf = new msgpu_paf();
   // count lines first: the parser must know which line is the last one
   size_t n_lines = 0;
   for (const char *q = data, *end = data + len; q < end;) {
@@ -166,6 +169,9 @@ int msgpu_parse_paf(const char *path, const msgpu_params *params, msgpu_paf **ou
     r.line     = static_cast<uint32_t>(li);
     r.flags    = (dir ? MSGPU_ROW_DIR : 0u) | (prim ? MSGPU_ROW_PRIMARY : 0u);
     paf->rows.push_back(r);
+  }
+  } catch (std::bad_alloc const &) {
+    rc = MSGPU_E_NOMEM;
   }
   if (data) munmap(const_cast<char *>(data), len);
   if (rc != MSGPU_OK) {

@@ -58,6 +58,40 @@ def str_slice(size, start, end):
     return int(s), int(n.value)
 
 
+class ConsensusBase:
+    """updateConsensusBase (ap.cpp:205-229) on piece lists: (pieces, borderLeft, borderRight) of a growing contig."""
+
+    def __init__(self):
+        self._L = _lib.lib()
+        self._h = C.c_void_p(self._L.msgpu_consensus_new())
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._L.msgpu_consensus_free(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def update(self, segment, new_lo, new_hi):
+        seg = np.ascontiguousarray(segment, dtype=COPY_DTYPE)
+        rc = self._L.msgpu_consensus_update(self._h, seg.ctypes.data, len(seg), int(new_lo), int(new_hi))
+        if rc != 0:
+            raise MsgpuError(rc)
+
+    @property
+    def borders(self):
+        lo, hi, n = C.c_int32(), C.c_int32(), C.c_uint64()
+        self._L.msgpu_consensus_borders(self._h, C.byref(lo), C.byref(hi), C.byref(n))
+        return lo.value, hi.value, int(n.value)
+
+    def pieces(self, base=0):
+        n = self._L.msgpu_consensus_pieces(self._h, base, None, 0)
+        out = np.zeros(n, dtype=COPY_DTYPE)
+        if n:
+            self._L.msgpu_consensus_pieces(self._h, base, out.ctypes.data, n)
+        return out
+
+
 class SeqStore:
     def __init__(self, device=0):
         self._L = _lib.lib()

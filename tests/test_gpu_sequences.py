@@ -107,8 +107,8 @@ def update_consensus_base(old, old_b, new, new_b):
 
 
 def test_stitching_like_updateConsensusBase(oracle, tmp_path):
-    """A tiling of reads over a genome, stitched by the reference's prepend/append rule: the host turns every rule
-    application into one copy piece (a sub-range of an oriented read), the GPU materialises the contig."""
+    """A tiling of reads over a genome, stitched in a random order by the reference's prepend/append rule:
+    libmsgpu's ConsensusBase (updateConsensusBase on pieces) + one gather launch == the string version."""
     from muchsalsa_amd import sequences as S
     rng = np.random.default_rng(11)
     G = 60000
@@ -122,40 +122,24 @@ def test_stitching_like_updateConsensusBase(oracle, tmp_path):
         seg = genome[pos:pos + L]
         reads.append((pos, min(pos + L, G), fwd, seg if fwd else seg.translate(comp)[::-1]))
         pos += int(rng.integers(500, L - 400))
-    order = rng.permutation(len(reads))  # stitch in a random order: exercises both prepend and append
+    order = rng.permutation(len(reads))  # random order: exercises both prepend and append
     _write_fasta(tmp_path / "r.fa", [r[3].decode() for r in reads], "r")
     with S.SeqStore(0) as store:
         store.upload(S.NANOPORE, S.SeqFile(str(tmp_path / "r.fa")))
-        # host layout: reference rule on (borders only) -> pieces; oracle strings -> expected contig
+        cb = S.ConsensusBase()
         want, wb = None, (0, 0)
-        segs = []  # (read, lo, hi) genome interval contributed by each accepted read, in contig order
         for k in order:
             a, b, fwd, seq = reads[k]
-            oriented = oracle.get_sequence(seq, 0, len(seq), fwd)  # whole read, in genome orientation
+            oriented = oracle.get_sequence(seq, 0, len(seq), fwd)  # the whole read in genome orientation
             assert oriented == genome[a:b]
-            if want is None:
-                segs = [(k, a, b)]
-            elif a < wb[0]:
-                segs.insert(0, (k, a, min(b, a + (wb[0] - a) + 1)))  # strSlice(new, 0, borderRight): inclusive
-            elif b - 1 > wb[1]:
-                take = (b - 1) - wb[1]
-                segs.append((k, b - take, b))
+            piece = store.resolve(S.NANOPORE, int(k), 0, len(seq), fwd)
+            cb.update(np.array([piece]), a, b - 1)
             want, lo, hi = update_consensus_base(want, wb, oriented, (a, b - 1))
             wb = (lo, hi)
-        pieces, off = [], 0
-        for k, lo, hi in segs:
-            a, b, fwd, seq = reads[k]
-            # genome interval [lo, hi) of read k = oriented[lo-a : hi-a]; in read coordinates:
-            if fwd:
-                left, right = lo - a, hi - a - 2          # getNanoporeSequence(l, r) yields chars l .. r+1
-            else:
-                left, right = (b - hi), (b - lo) - 2
-            p = store.resolve(S.NANOPORE, k, left, right, fwd, dst_off=off)
-            assert int(p["len"]) == hi - lo
-            pieces.append(p)
-            off += hi - lo
-        got = _run(store, np.array(pieces))
+        assert cb.borders == (wb[0], wb[1], len(want))
+        got = _run(store, cb.pieces())
         assert got == want
+        cb.close()
 
 
 def test_unaligned_tiny_and_empty_pieces(oracle, tmp_path):

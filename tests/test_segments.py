@@ -77,3 +77,49 @@ def test_between_anchors_hits_every_branch(oracle):
             seen.add((direction, err > 0, seq is None))
     assert {(True, True, True), (True, True, False), (True, False, False)} <= seen
     assert any(k[0] is False and k[1] for k in seen)
+
+
+def py_update_consensus_base(old, old_b, new, new_b):
+    """updateConsensusBase, ap.cpp:205-229, on byte strings."""
+    if old is None:
+        return new, new_b[0], new_b[1]
+    if new_b[0] < old_b[0]:
+        upd = P.str_slice(new, 0, old_b[0] - new_b[0]) + old
+    elif new_b[1] > old_b[1]:
+        upd = old + P.str_slice(new, -(new_b[1] - old_b[1]), len(new))
+    else:
+        upd = old
+    return upd, min(old_b[0], new_b[0]), max(old_b[1], new_b[1])
+
+
+@pytest.mark.parametrize("seed", [4, 5, 6])
+def test_update_consensus_base_on_pieces(oracle, tmp_path, seed):
+    """Random walks of updateConsensusBase: libmsgpu's piece version against the string version, including new
+    sequences that are shorter/longer than the uncovered stretch (the strSlice clipping cases)."""
+    rng, reads, unis = SC.make_world(seed)
+    st, stores = _store(tmp_path, reads, unis)
+    for _ in range(40):
+        cb = S.ConsensusBase()
+        want, wb = None, (0, 0)
+        for _ in range(int(rng.integers(1, 25))):
+            m, ov = SC.random_match(rng, reads, unis)
+            nano, illu = reads[int(m["read_id"])], unis[int(m["anchor_id"])]
+            d = bool(rng.integers(0, 2))
+            kind = int(rng.integers(0, 3))
+            if kind == 0:
+                seg, s = st.seg_anchor(m, ov, d)[0], oracle.anchor_sequence(m, illu, ov, d)
+            elif kind == 1:
+                seg, s = st.seg_left_of_anchor(m, len(nano), ov, d)[0], oracle.left_of_anchor(m, nano, illu, len(nano), ov, d)
+            else:
+                seg, s = st.seg_right_of_anchor(m, len(nano), ov, d)[0], oracle.right_of_anchor(m, nano, illu, len(nano), ov, d)
+            # borders: sometimes consistent with the length, sometimes not (then strSlice clips)
+            lo = int(rng.integers(-3000, 3000))
+            hi = lo + len(s) - 1 + int(rng.choice([0, 0, 0, -7, 11, 400]))
+            cb.update(seg, lo, hi)
+            want, a, b = py_update_consensus_base(want, wb, s, (lo, hi))
+            wb = (a, b)
+            blo, bhi, length = cb.borders
+            assert (blo, bhi) == wb and length == len(want)
+            assert SC.apply_pieces(cb.pieces(), stores, P.reverse_complement) == want
+        cb.close()
+    st.close()
