@@ -13,37 +13,74 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <algorithm>
+#include <chrono>
 #include <climits>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <new>
 #include <string>
 #include <string_view>
-#include <unordered_map>
+#include <system_error>
+#include <thread>
 #include <vector>
 
 #include "msgpu.h"
 
 namespace {
 
+inline uint64_t name_hash(const char *s, size_t n) { // FNV-1a, computed by the parallel tokenisers
+  uint64_t h = 1469598103934665603ull;
+  for (size_t i = 0; i < n; ++i) {
+    h ^= static_cast<unsigned char>(s[i]);
+    h *= 1099511628211ull;
+  }
+  return h;
+}
+
 // Registry (libms/src/Registry.cpp:36-45): name -> dense id in first-seen order, plus the reverse table.
-// Names live in individually heap-allocated strings, so the string_view keys stay valid as the table grows.
+// Open addressing over precomputed hashes; names are copied into individually allocated strings (stable addresses).
 class NameRegistry {
 public:
-  uint32_t operator[](std::string_view name) {
-    auto it = m_ids.find(name);
-    if (it != m_ids.end()) return it->second;
-    const auto id = static_cast<uint32_t>(m_names.size());
-    m_names.push_back(std::make_unique<std::string>(name));
-    m_ids.emplace(std::string_view(*m_names.back()), id);
-    return id;
+  NameRegistry() : m_slots(1024) {}
+  uint32_t get(const char *s, size_t n, uint64_t h) {
+    if ((m_names.size() + 1) * 2 > m_slots.size()) grow();
+    size_t i = h & (m_slots.size() - 1);
+    while (m_slots[i].id_plus_1) {
+      const Slot &sl = m_slots[i];
+      if (sl.hash == h) {
+        const std::string &nm = *m_names[sl.id_plus_1 - 1];
+        if (nm.size() == n && memcmp(nm.data(), s, n) == 0) return sl.id_plus_1 - 1;
+      }
+      i = (i + 1) & (m_slots.size() - 1);
+    }
+    m_names.push_back(std::make_unique<std::string>(s, n));
+    m_slots[i] = Slot{h, static_cast<uint32_t>(m_names.size())};
+    return static_cast<uint32_t>(m_names.size() - 1);
   }
+  uint32_t operator[](std::string_view name) { return get(name.data(), name.size(), name_hash(name.data(), name.size())); }
   uint32_t    size() const { return static_cast<uint32_t>(m_names.size()); }
   const char *name(uint32_t id) const { return id < m_names.size() ? m_names[id]->c_str() : nullptr; }
 
 private:
-  std::vector<std::unique_ptr<std::string>>      m_names;
-  std::unordered_map<std::string_view, uint32_t> m_ids;
+  struct Slot {
+    uint64_t hash      = 0;
+    uint32_t id_plus_1 = 0;
+  };
+  void grow() {
+    std::vector<Slot> ns(m_slots.size() * 2);
+    for (const Slot &sl : m_slots)
+      if (sl.id_plus_1) {
+        size_t i = sl.hash & (ns.size() - 1);
+        while (ns[i].id_plus_1) i = (i + 1) & (ns.size() - 1);
+        ns[i] = sl;
+      }
+    m_slots.swap(ns);
+  }
+  std::vector<std::unique_ptr<std::string>> m_names;
+  std::vector<Slot>                         m_slots;
 };
 
 // std::stoi: optional whitespace, optional sign, at least one digit, value must fit int.
@@ -71,6 +108,106 @@ struct msgpu_paf {
   NameRegistry           reads, anchors;
 };
 
+namespace {
+
+// one accepted line before Registry ids exist: names are views into the mmap'ed file
+struct RawRow {
+  const char *qname, *tname;
+  uint64_t    qhash, thash;    // name hashes (computed in parallel, consumed by the sequential Registry pass)
+  uint32_t    qlen, tlen_name; // name lengths
+  int32_t     read_len, i_lo, i_hi, n_lo, n_hi;
+  uint32_t    score, line, flags;
+};
+
+struct Chunk {
+  const char         *begin = nullptr, *end = nullptr;
+  size_t              n_lines = 0, first_line = 0;
+  std::vector<RawRow> rows;
+  int                 err = MSGPU_OK;
+  size_t              err_line = 0;
+};
+
+// parse the lines of one chunk (BlastFileReader::parseLine, BlastFileReader.cpp:86-130), except the file's last line
+void parse_chunk(Chunk &ch, size_t last_line, const msgpu_params &p) {
+  const char *q = ch.begin;
+  size_t      li = ch.first_line;
+  ch.rows.reserve(ch.n_lines);
+  for (; q < ch.end; ++li) {
+    const void *nlp = memchr(q, '\n', static_cast<size_t>(ch.end - q));
+    const char *le  = nlp ? static_cast<const char *>(nlp) : ch.end;
+    const char *ls  = q;
+    q               = nlp ? le + 1 : ch.end;
+    if (li == last_line) break; // BlastFileReader.cpp:76: the last line is never parsed
+    // columns 0..9; std::getline drops an empty token after the final delimiter
+    const char *tb[10], *te[10];
+    int         nt = 0;
+    const char *s  = ls;
+    for (const char *c = ls;; ++c) {
+      if (c == le || *c == '\t') {
+        if (c == le && s == le) break;
+        if (nt < 10) {
+          tb[nt] = s;
+          te[nt] = c;
+        }
+        ++nt;
+        s = c + 1;
+        if (c == le) break;
+      }
+    }
+    // the reference checks for >= 9 tokens and then reads tokens[9]; we ask for the 10 it needs
+    if (nt < 10) {
+      ch.err      = MSGPU_E_FORMAT;
+      ch.err_line = li;
+      return;
+    }
+    int irs, ire, nom, nle;
+    if (!parse_int(tb[2], te[2], irs) || !parse_int(tb[3], te[3], ire) || !parse_int(tb[9], te[9], nom) ||
+        !parse_int(tb[6], te[6], nle) || nom < 0) {
+      ch.err      = MSGPU_E_NUMBER;
+      ch.err_line = li;
+      return;
+    }
+    const int span = (ire - 1) - irs + 1;
+    if (!(static_cast<uint32_t>(nom) >= p.min_matches && span >= static_cast<int>(p.min_matches))) continue;
+    int nrs, nre;
+    if (!parse_int(tb[7], te[7], nrs) || !parse_int(tb[8], te[8], nre)) {
+      ch.err      = MSGPU_E_NUMBER;
+      ch.err_line = li;
+      return;
+    }
+    const bool dir  = (te[4] - tb[4] == 1) && *tb[4] == '+';
+    const bool prim = span >= static_cast<int>(p.th_length) && static_cast<uint32_t>(nom) >= p.th_matches;
+    RawRow     r;
+    r.qname     = tb[0];
+    r.qlen      = static_cast<uint32_t>(te[0] - tb[0]);
+    r.tname     = tb[5];
+    r.tlen_name = static_cast<uint32_t>(te[5] - tb[5]);
+    r.qhash     = name_hash(r.qname, r.qlen);
+    r.thash     = name_hash(r.tname, r.tlen_name);
+    r.read_len  = nle;
+    r.i_lo      = irs;
+    r.i_hi      = ire - 1;
+    r.n_lo      = nrs;
+    r.n_hi      = nre - 1;
+    r.score     = static_cast<uint32_t>(nom);
+    r.line      = static_cast<uint32_t>(li);
+    r.flags     = (dir ? MSGPU_ROW_DIR : 0u) | (prim ? MSGPU_ROW_PRIMARY : 0u);
+    ch.rows.push_back(r);
+  }
+}
+
+size_t count_lines(const char *b, const char *e) {
+  size_t n = 0;
+  for (const char *q = b; q < e;) {
+    ++n;
+    const void *nl = memchr(q, '\n', static_cast<size_t>(e - q));
+    q              = nl ? static_cast<const char *>(nl) + 1 : e;
+  }
+  return n;
+}
+
+} // namespace
+
 extern "C" {
 
 int msgpu_parse_paf(const char *path, const msgpu_params *params, msgpu_paf **out) {
@@ -97,7 +234,6 @@ int msgpu_parse_paf(const char *path, const msgpu_params *params, msgpu_paf **ou
       close(fd);
       return MSGPU_E_IO;
     }
-    madvise(m, len, MADV_SEQUENTIAL);
     data = static_cast<const char *>(m);
   }
   close(fd);
@@ -105,73 +241,89 @@ int msgpu_parse_paf(const char *path, const msgpu_params *params, msgpu_paf **ou
   msgpu_paf *paf = nullptr;
   int        rc  = MSGPU_OK;
   try { // no exception may cross the C-ABI
-  paf = new msgpu_paf();
-  // count lines first: the parser must know which line is the last one
-  size_t n_lines = 0;
-  for (const char *q = data, *end = data + len; q < end;) {
-    ++n_lines;
-    const void *nl = memchr(q, '\n', static_cast<size_t>(end - q));
-    q              = nl ? static_cast<const char *>(nl) + 1 : end;
-  }
-  paf->n_lines = n_lines;
-  paf->rows.reserve(n_lines);
-
-  const char *q = data, *end = data + len;
-  for (size_t li = 0; li + 1 < n_lines; ++li) {
-    const void *nlp = memchr(q, '\n', static_cast<size_t>(end - q));
-    const char *le  = nlp ? static_cast<const char *>(nlp) : end;
-    // columns 0..9; std::getline drops an empty token after the final delimiter
-    const char *tb[10], *te[10];
-    int         nt = 0;
-    const char *s  = q;
-    for (const char *c = q;; ++c) {
-      if (c == le || *c == '\t') {
-        if (c == le && s == le) break;
-        if (nt < 10) {
-          tb[nt] = s;
-          te[nt] = c;
-        }
-        ++nt;
-        s = c + 1;
-        if (c == le) break;
+    paf = new msgpu_paf();
+    // The reference parses one line per pool job; here the file is cut into one chunk per host thread at line
+    // boundaries.  Lines are independent except for the Registry (first-seen ids), which is applied afterwards in
+    // line order -- the ids are those of the single-thread reference.
+    unsigned nthr = std::thread::hardware_concurrency();
+    if (nthr == 0) nthr = 1;
+    if (nthr > 32) nthr = 32;
+    if (const char *e = getenv("MSGPU_PARSE_THREADS")) nthr = static_cast<unsigned>(std::max(1, atoi(e)));
+    while (nthr > 1 && len / nthr < (1u << 20)) --nthr; // at least 1 MiB per thread
+    std::vector<Chunk> chunks(nthr);
+    const char        *end = data + len, *cur = data;
+    for (unsigned t = 0; t < nthr; ++t) {
+      chunks[t].begin = cur;
+      const char *cut = (t + 1 == nthr) ? end : data + (len / nthr) * (t + 1);
+      if (cut < cur) cut = cur;
+      if (cut < end) {
+        const void *nl = memchr(cut, '\n', static_cast<size_t>(end - cut));
+        cut            = nl ? static_cast<const char *>(nl) + 1 : end;
       }
+      chunks[t].end = cut;
+      cur           = cut;
     }
-    q = nlp ? le + 1 : end;
-    // the reference checks for >= 9 tokens and then reads tokens[9]; we ask for the 10 it needs
-    if (nt < 10) {
-      rc = MSGPU_E_FORMAT;
-      break;
+    auto run = [&](auto &&fn) {
+      std::vector<std::thread> th;
+      for (unsigned t = 1; t < nthr; ++t) th.emplace_back(fn, t);
+      fn(0u);
+      for (auto &x : th) x.join();
+    };
+    const bool dbg = getenv("MSGPU_PARSE_DEBUG") != nullptr;
+    auto       t0  = std::chrono::steady_clock::now();
+    auto       lap = [&](const char *what) {
+      if (!dbg) return;
+      auto t1 = std::chrono::steady_clock::now();
+      fprintf(stderr, "msgpu_parse_paf: %-10s %.1f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+      t0 = t1;
+    };
+    run([&](unsigned t) { chunks[t].n_lines = count_lines(chunks[t].begin, chunks[t].end); });
+    lap("count");
+    size_t n_lines = 0;
+    for (auto &c : chunks) {
+      c.first_line = n_lines;
+      n_lines += c.n_lines;
     }
-    int irs, ire, nom, nle;
-    if (!parse_int(tb[2], te[2], irs) || !parse_int(tb[3], te[3], ire) || !parse_int(tb[9], te[9], nom) ||
-        !parse_int(tb[6], te[6], nle) || nom < 0) {
-      rc = MSGPU_E_NUMBER;
-      break;
+    paf->n_lines          = n_lines;
+    const size_t last     = n_lines ? n_lines - 1 : 0;
+    std::vector<int> oom(nthr, 0);
+    run([&](unsigned t) {
+      try {
+        if (n_lines) parse_chunk(chunks[t], last, p);
+      } catch (std::bad_alloc const &) { oom[t] = 1; }
+    });
+    lap("tokenise");
+    for (unsigned t = 0; t < nthr; ++t)
+      if (oom[t]) throw std::bad_alloc();
+    // the reference stops at the first bad line in line order
+    for (auto &c : chunks)
+      if (c.err != MSGPU_OK) {
+        rc = c.err;
+        break;
+      }
+    if (rc == MSGPU_OK) {
+      size_t total = 0;
+      for (auto &c : chunks) total += c.rows.size();
+      paf->rows.reserve(total);
+      for (auto &c : chunks)
+        for (const RawRow &r : c.rows) { // Registry in line order: nanopore id first (:110), then illumina (:111)
+          msgpu_row o;
+          o.read_id   = paf->reads.get(r.tname, r.tlen_name, r.thash);
+          o.anchor_id = paf->anchors.get(r.qname, r.qlen, r.qhash);
+          o.read_len  = r.read_len;
+          o.i_lo      = r.i_lo;
+          o.i_hi      = r.i_hi;
+          o.n_lo      = r.n_lo;
+          o.n_hi      = r.n_hi;
+          o.score     = r.score;
+          o.line      = r.line;
+          o.flags     = r.flags;
+          paf->rows.push_back(o);
+        }
+      lap("registry");
     }
-    const int span = (ire - 1) - irs + 1;
-    if (!(static_cast<uint32_t>(nom) >= p.min_matches && span >= static_cast<int>(p.min_matches))) continue;
-    msgpu_row r;
-    r.read_id   = paf->reads[std::string_view(tb[5], static_cast<size_t>(te[5] - tb[5]))];
-    r.anchor_id = paf->anchors[std::string_view(tb[0], static_cast<size_t>(te[0] - tb[0]))];
-    int nrs, nre;
-    if (!parse_int(tb[7], te[7], nrs) || !parse_int(tb[8], te[8], nre)) {
-      rc = MSGPU_E_NUMBER;
-      break;
-    }
-    const bool dir  = (te[4] - tb[4] == 1) && *tb[4] == '+';
-    const bool prim = span >= static_cast<int>(p.th_length) && static_cast<uint32_t>(nom) >= p.th_matches;
-    r.read_len = nle;
-    r.i_lo     = irs;
-    r.i_hi     = ire - 1;
-    r.n_lo     = nrs;
-    r.n_hi     = nre - 1;
-    r.score    = static_cast<uint32_t>(nom);
-    r.line     = static_cast<uint32_t>(li);
-    r.flags    = (dir ? MSGPU_ROW_DIR : 0u) | (prim ? MSGPU_ROW_PRIMARY : 0u);
-    paf->rows.push_back(r);
-  }
-  } catch (std::bad_alloc const &) {
-    rc = MSGPU_E_NOMEM;
+  } catch (std::bad_alloc const &) { rc = MSGPU_E_NOMEM; } catch (std::system_error const &) {
+    rc = MSGPU_E_NOMEM; // could not start a thread
   }
   if (data) munmap(const_cast<char *>(data), len);
   if (rc != MSGPU_OK) {
