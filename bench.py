@@ -22,6 +22,11 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
+# HBM bytes per launch from the PMC counters (FETCH_SIZE x 2 per the gfx950 note of MI355X_MICROARCH.md + WRITE_SIZE),
+# collected with rocprofv3 in separate --pmc passes of this same command: profiles/r1_03_final/pmc_summary.csv.
+# They cannot be read from inside this process, so they are quoted for the one configuration they were measured on.
+PMC_TRAFFIC_BYTES = {("cfg3", 1): {"k_chain": 3.26e9, "k_gather": 2.23e9}}
+
 WORKLOADS = {
     # BASELINE.json configs[2]: the configuration the metric is quoted on
     "cfg3": dict(n_reads=100_000, read_len=10_000, n_anchors=500_000, seed=43,
@@ -264,8 +269,10 @@ def main():
             "stage_ms": {"index": tm.index_ms, "candidates": tm.candidates_ms, "chain_total": tm.chain_ms,
                          "chain_kernel": k_ms, "compact": tm.compact_ms},
             "roofline": {"bound": "hbm", "kernel": "k_chain", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "algorithmic_bytes_per_launch": int(alg_bytes), "kernel_ms": k_ms},
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": PMC_TRAFFIC_BYTES.get((args.workload, world), {}).get("k_chain"),
+                         "algorithmic_bytes_per_launch": int(alg_bytes), "kernel_ms": k_ms,
+                         "note": "VALU-bound (fp64/int issue), see profiles/r1_03_final/README.md"},
         }
         if cons is not None:
             gb = 2.0 * (cons["target_bases"] + cons["query_bases"]) / 1e9  # 1 B read + 1 B written per base
@@ -277,7 +284,8 @@ def main():
                 "target_bases": cons["target_bases"], "query_bases": cons["query_bases"], "pieces": cons["pieces"],
                 "ms": cons["ms"], "verified_against_genome": cons["verified"],
                 "roofline": {"bound": "hbm", "kernel": "k_gather", "achieved": g_gbs, "peak": HBM_PEAK_GBS,
-                             "unit": "GB/s", "frac": g_gbs / HBM_PEAK_GBS, "traffic": None,
+                             "unit": "GB/s", "frac": g_gbs / HBM_PEAK_GBS,
+                             "traffic": PMC_TRAFFIC_BYTES.get((args.workload, world), {}).get("k_gather"),
                              "algorithmic_bytes_per_launch": int(gb * 1e9)},
             }
         if world == 1 and args.cpu_sample_reads > 0:
