@@ -310,6 +310,17 @@ int msgpu_gather_run(msgpu_seqctx *ctx, const msgpu_gather_plan *plan, void *d_o
                      void *hip_stream);
 int msgpu_seq_synchronize(msgpu_seqctx *ctx);
 
+/* ---- banded edit distance (no reference counterpart) ---------------------------------
+ * The meter for north_star's "consensus sequences within a stated edit-distance tolerance": Levenshtein distance
+ * (unit costs, global) of n pairs a[a_off .. a_off+a_len) vs b[b_off .. b_off+b_len) taken from two DEVICE buffers,
+ * inside the band |j - i| <= band (band <= 127).  out[p] (host) = the distance when it is <= band, else band + 1. */
+typedef struct msgpu_align_pair {
+  uint64_t a_off, b_off;
+  uint32_t a_len, b_len;
+} msgpu_align_pair;
+int msgpu_edit_distance(msgpu_seqctx *ctx, const void *d_a, const void *d_b, const msgpu_align_pair *pairs, size_t n,
+                        uint32_t band, uint32_t *out);
+
 #ifdef __cplusplus
 }
 #endif

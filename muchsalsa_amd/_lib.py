@@ -24,6 +24,8 @@ COPY_DTYPE = np.dtype([("src_off", "<u8"), ("dst_off", "<u8"), ("len", "<u4"), (
 assert (ROW_DTYPE.itemsize, EDGE_DTYPE.itemsize, EM_DTYPE.itemsize, ORDER_DTYPE.itemsize) == (40, 32, 32, 64)
 assert COPY_DTYPE.itemsize == 24
 COPY_ILLUMINA, COPY_REVCOMP = 1, 2
+ALIGN_PAIR_DTYPE = np.dtype([("a_off", "<u8"), ("b_off", "<u8"), ("a_len", "<u4"), ("b_len", "<u4")])
+assert ALIGN_PAIR_DTYPE.itemsize == 24
 
 OK = 0
 E_IO, E_FORMAT, E_NUMBER, E_NOMEM, E_ARG, E_HIP, E_STATE, E_IDS, E_NODEVICE = -1, -2, -3, -4, -5, -6, -7, -8, -9
@@ -113,6 +115,8 @@ SYMBOLS = [
     ("msgpu_gather_plan_bases", C.c_uint64, [C.c_void_p]),
     ("msgpu_gather_run", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
     ("msgpu_seq_synchronize", C.c_int, [C.c_void_p]),
+    ("msgpu_edit_distance", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32,
+                                      C.c_void_p]),
 ]
 
 _lib = None

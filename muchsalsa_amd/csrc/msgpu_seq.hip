@@ -347,3 +347,141 @@ int msgpu_seq_synchronize(msgpu_seqctx *c) {
 }
 
 } // extern "C"
+
+// =====================================================================================================================
+// banded edit distance
+// =====================================================================================================================
+//
+// The reference contains no sequence-level alignment; north_star asks for consensus sequences "within a
+// stated edit-distance tolerance" of the reference's, so the tolerance needs a meter: this kernel measures the
+// Levenshtein distance of pairs of sequences (e.g. our contig vs. another build's contig, or a query vs. its window of
+// the target given by align.paf).  Unit costs, global alignment, band |j - i| <= W: exact whenever the true distance is
+// <= W, otherwise reported as W + 1.
+//
+// One wavefront per pair.  The DP runs along anti-diagonals t = i + j: cell (i, j) on diagonal k = j - i needs
+//   up   (i-1, j)   = diagonal k+1, anti-diagonal t-1
+//   left (i, j-1)   = diagonal k-1, anti-diagonal t-1
+//   diag (i-1, j-1) = diagonal k,   anti-diagonal t-2
+// so one value per diagonal is all the state there is, and only diagonals with k = t (mod 2) are active in step t.
+// Each lane owns four consecutive diagonals (two active per step), exchanges its edge values with the neighbour lanes
+// by wavefront shuffle once per step, and reads the bases from LDS where both sequences were staged.
+
+namespace msgpu {
+
+constexpr int      ED_DPL   = 4;                 // diagonals per lane
+constexpr int      ED_NDIAG = 64 * ED_DPL;       // 256 diagonals: k in [-128, 127]
+constexpr uint32_t ED_MAXW  = 127;
+constexpr uint32_t ED_LDS   = 24 * 1024;         // bytes of LDS per sequence; longer sequences stay in global memory
+constexpr uint32_t ED_INF   = 0x3fffffffu;
+
+template <bool IN_LDS>
+__device__ __forceinline__ uint32_t edit_distance_wave(const uint8_t *a, uint32_t n, const uint8_t *b, uint32_t m,
+                                                       uint32_t W, const uint8_t *la, const uint8_t *lb) {
+  const int lane = threadIdx.x & 63;
+  const int k0   = lane * ED_DPL - ED_NDIAG / 2; // first diagonal of this lane
+  uint32_t  val[ED_DPL];
+#pragma unroll
+  for (int c = 0; c < ED_DPL; ++c) {
+    const int k = k0 + c;
+    val[c]      = (static_cast<uint32_t>(k < 0 ? -k : k) <= W) ? static_cast<uint32_t>(k < 0 ? -k : k) : ED_INF;
+  }
+  const int total = static_cast<int>(n + m);
+  for (int t = 2; t <= total; ++t) {
+    // values of the neighbouring lanes' edge diagonals (computed in step t-1, or boundary / INF)
+    const uint32_t from_left  = __shfl_up(val[ED_DPL - 1], 1);  // diagonal k0 - 1
+    const uint32_t from_right = __shfl_down(val[0], 1);         // diagonal k0 + ED_DPL
+    const uint32_t nb_lo      = lane == 0 ? ED_INF : from_left;
+    const uint32_t nb_hi      = lane == 63 ? ED_INF : from_right;
+    const int      par        = (t - k0) & 1; // active diagonals: c = par, par + 2
+#pragma unroll
+    for (int cc = 0; cc < ED_DPL; cc += 2) {
+      // written so that c is a compile-time pair {cc, cc+1} selected by `par` without dynamic register indexing
+      const int      k_even = k0 + cc, k_odd = k0 + cc + 1;
+      const int      k      = par ? k_odd : k_even;
+      const uint32_t ak     = static_cast<uint32_t>(k < 0 ? -k : k);
+      const int      i = (t - k) >> 1, j = (t + k) >> 1;
+      const bool     ok = ak <= W && i >= 1 && j >= 1 && i <= static_cast<int>(n) && j <= static_cast<int>(m);
+      // neighbours k-1 / k+1
+      uint32_t left, up, self;
+      if (!par) { // c = cc: left = (cc == 0 ? nb_lo : val[cc-1]), up = val[cc+1]
+        left = cc == 0 ? nb_lo : val[cc - 1];
+        up   = val[cc + 1];
+        self = val[cc];
+      } else { // c = cc+1: left = val[cc], up = (cc+2 == ED_DPL ? nb_hi : val[cc+2])
+        left = val[cc];
+        up   = cc + 2 == ED_DPL ? nb_hi : val[cc + 2];
+        self = val[cc + 1];
+      }
+      uint32_t nv = self;
+      if (ok) {
+        const uint8_t ca = IN_LDS ? la[i - 1] : a[i - 1];
+        const uint8_t cb = IN_LDS ? lb[j - 1] : b[j - 1];
+        nv               = min(min(up, left) + 1u, self + (ca != cb ? 1u : 0u));
+      }
+      if (!par)
+        val[cc] = nv;
+      else
+        val[cc + 1] = nv;
+    }
+  }
+  // D[n][m] lives on diagonal k* = m - n
+  const int ks = static_cast<int>(m) - static_cast<int>(n);
+  if (static_cast<uint32_t>(ks < 0 ? -ks : ks) > W) return W + 1;
+  const int idx = ks + ED_NDIAG / 2, src_lane = idx / ED_DPL, c = idx % ED_DPL;
+  uint32_t  v   = c == 0 ? val[0] : c == 1 ? val[1] : c == 2 ? val[2] : val[3];
+  v             = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(v), src_lane));
+  return v > W ? W + 1 : v;
+}
+
+__global__ __launch_bounds__(128) void k_edit_distance(const uint8_t *base_a, const uint8_t *base_b,
+                                                       const msgpu_align_pair *pairs, uint32_t n_pairs, uint32_t W,
+                                                       uint32_t *out) {
+  __shared__ uint8_t s_a[2][ED_LDS], s_b[2][ED_LDS];
+  const int      wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const uint32_t p    = blockIdx.x * 2 + wave;
+  if (p >= n_pairs) return;
+  const msgpu_align_pair pr = pairs[p];
+  const uint8_t *a = base_a + pr.a_off, *b = base_b + pr.b_off;
+  uint32_t       d;
+  if (pr.a_len <= ED_LDS && pr.b_len <= ED_LDS) {
+    for (uint32_t i = lane; i < pr.a_len; i += 64) s_a[wave][i] = a[i];
+    for (uint32_t i = lane; i < pr.b_len; i += 64) s_b[wave][i] = b[i];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    d = edit_distance_wave<true>(a, pr.a_len, b, pr.b_len, W, s_a[wave], s_b[wave]);
+  } else {
+    d = edit_distance_wave<false>(a, pr.a_len, b, pr.b_len, W, nullptr, nullptr);
+  }
+  if (lane == 0) out[p] = d;
+}
+
+} // namespace msgpu
+
+extern "C" {
+
+int msgpu_edit_distance(msgpu_seqctx *c, const void *d_a, const void *d_b, const msgpu_align_pair *pairs, size_t n,
+                        uint32_t band, uint32_t *out) {
+  if (!c || (n && (!pairs || !out || !d_a || !d_b)) || band > ED_MAXW || n >= 0x7fffffffull) return MSGPU_E_ARG;
+  if (c->device < 0) return MSGPU_E_NODEVICE;
+  if (!n) return MSGPU_OK;
+  SHIP(c, hipSetDevice(c->device));
+  void *d_pairs = nullptr, *d_out = nullptr;
+  SHIP(c, hipMalloc(&d_pairs, n * sizeof(msgpu_align_pair)));
+  hipError_t e = hipMalloc(&d_out, n * sizeof(uint32_t));
+  if (e == hipSuccess) e = hipMemcpyAsync(d_pairs, pairs, n * sizeof(msgpu_align_pair), hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(k_edit_distance, dim3(static_cast<uint32_t>((n + 1) / 2)), dim3(128), 0, c->stream,
+                       static_cast<const uint8_t *>(d_a), static_cast<const uint8_t *>(d_b),
+                       static_cast<const msgpu_align_pair *>(d_pairs), static_cast<uint32_t>(n), band,
+                       static_cast<uint32_t *>(d_out));
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, n * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  (void)hipFree(d_pairs);
+  if (d_out) (void)hipFree(d_out);
+  if (e != hipSuccess) return sfail(c, MSGPU_E_HIP, "msgpu_edit_distance", e);
+  return MSGPU_OK;
+}
+
+} // extern "C"

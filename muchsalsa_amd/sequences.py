@@ -191,3 +191,12 @@ class SeqStore:
 
     def synchronize(self):
         self._check(self._L.msgpu_seq_synchronize(self._h))
+
+    def edit_distance(self, d_a_ptr, d_b_ptr, pairs, band):
+        """Banded Levenshtein distance of pairs of ranges of two device buffers; band + 1 = 'more than band'."""
+        from ._lib import ALIGN_PAIR_DTYPE
+        pairs = np.ascontiguousarray(pairs, dtype=ALIGN_PAIR_DTYPE)
+        out = np.zeros(len(pairs), dtype="<u4")
+        self._check(self._L.msgpu_edit_distance(self._h, C.c_void_p(d_a_ptr), C.c_void_p(d_b_ptr), pairs.ctypes.data,
+                                                len(pairs), int(band), out.ctypes.data))
+        return out

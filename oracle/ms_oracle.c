@@ -1432,3 +1432,26 @@ int ms_oracle_between_anchors(const ms_row *ml, const ms_row *mr, const char *na
   *out_len  = w;
   return 1;
 }
+
+uint32_t ms_oracle_edit_distance(const char *a, size_t n, const char *b, size_t m, uint32_t band) {
+  uint32_t *prev = (uint32_t *)xrealloc(NULL, (m + 1) * sizeof(uint32_t));
+  uint32_t *cur  = (uint32_t *)xrealloc(NULL, (m + 1) * sizeof(uint32_t));
+  for (size_t j = 0; j <= m; ++j) prev[j] = (uint32_t)j;
+  for (size_t i = 1; i <= n; ++i) {
+    cur[0] = (uint32_t)i;
+    for (size_t j = 1; j <= m; ++j) {
+      uint32_t d = prev[j - 1] + (a[i - 1] != b[j - 1] ? 1u : 0u);
+      uint32_t u = prev[j] + 1u, l = cur[j - 1] + 1u;
+      if (u < d) d = u;
+      if (l < d) d = l;
+      cur[j] = d;
+    }
+    uint32_t *t = prev;
+    prev = cur;
+    cur  = t;
+  }
+  uint32_t r = prev[m];
+  free(prev);
+  free(cur);
+  return r > band ? band + 1 : r;
+}

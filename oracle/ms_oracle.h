@@ -170,6 +170,10 @@ int ms_oracle_between_anchors(const ms_row *ml, const ms_row *mr, const char *na
                               int ovl_hi, int ovr_lo, int ovr_hi, int direction, int *distance, char *out,
                               size_t *out_len);
 
+/* Levenshtein distance (unit costs, global alignment), full O(n*m) DP -- the checker of the banded GPU kernel
+ * (the reference has no counterpart).  Returns min(distance, band + 1). */
+uint32_t ms_oracle_edit_distance(const char *a, size_t n, const char *b, size_t m, uint32_t band);
+
 #ifdef __cplusplus
 }
 #endif

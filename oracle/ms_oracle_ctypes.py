@@ -93,6 +93,8 @@ def lib():
                                                    C.c_int, C.c_int, C.POINTER(C.c_int), C.c_char_p,
                                                    C.POINTER(C.c_size_t)]
         _lib.ms_oracle_between_anchors.restype = C.c_int
+        _lib.ms_oracle_edit_distance.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_uint32]
+        _lib.ms_oracle_edit_distance.restype = C.c_uint32
     return _lib
 
 
@@ -222,3 +224,8 @@ def between_anchors(ml, mr, nano, illu_l, illu_r, ov_l, ov_r, direction):
                                           ov_l[1], ov_r[0], ov_r[1], 1 if direction else 0, C.byref(dist), out,
                                           C.byref(n))
     return dist.value, (out.raw[:n.value] if has else None)
+
+
+def edit_distance(a, b, band):
+    """min(Levenshtein(a, b), band + 1)"""
+    return int(lib().ms_oracle_edit_distance(a, len(a), b, len(b), band))
