@@ -167,6 +167,12 @@ def main():
                     help="run the N>1 exchange path (all-gather + merge) even at world size 1 (used by the GPU tests)")
     args = ap.parse_args()
 
+    # stdout must carry exactly one JSON line: libraries (RCCL prints a version banner on stdout) write to fd 1 while
+    # we run, so fd 1 is pointed at stderr for the duration and the JSON line goes to the saved descriptor.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
     from muchsalsa_amd import distributed as D, overlap, synth
@@ -191,9 +197,13 @@ def main():
     torch.cuda.synchronize()
 
     ctx = overlap.OverlapContext(device=local_rank)
-    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    # One real (non-null) stream carries everything: libmsgpu's kernels, torch's allocations and the RCCL collective
+    # are ordered by it, so the all-gather cannot overtake the table copies nor the merge kernel the all-gather.
+    work = torch.cuda.Stream(device=dev)
+    ctx.set_stream(work.cuda_stream)
     if world > 1:
         ctx.set_shard(rank, world)
+    merged_keep = {}
 
     def step():
         ctx.load_rows_device(d_rows.data_ptr(), len(rows), keep_alive=d_rows)
@@ -213,24 +223,41 @@ def main():
             m_i = torch.empty(max(int(tot[2]), 1) * 4, dtype=torch.uint8, device=dev)
             ctx.merge_gathered(gathered.data_ptr(), allc, slab_bytes, offs, m_e.data_ptr(), m_o.data_ptr(),
                                m_i.data_ptr())
+            merged_keep.update(e=m_e, o=m_o, i=m_i, tot=tot)
             return c, allc
         return c, None
 
-    for _ in range(args.warmup):
-        step()
-    if multi:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    chain_ms = []
-    for _ in range(args.steps):
-        c, allc = step()
-        chain_ms.append(ctx.timings().chain_kernel_ms)  # HIP events on the launch stream (syncs that stream only)
-    torch.cuda.synchronize()
-    if multi:
-        dist.barrier()
-    dt = time.perf_counter() - t0
+    with torch.cuda.stream(work):
+        for _ in range(args.warmup):
+            step()
+        if multi:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        chain_ms = []
+        for _ in range(args.steps):
+            c, allc = step()
+            chain_ms.append(ctx.timings().chain_kernel_ms)  # HIP events on the launch stream (syncs that stream only)
+        torch.cuda.synchronize()
+        if multi:
+            dist.barrier()
+        dt = time.perf_counter() - t0
     tm = ctx.timings()
+    merge_ok = None
+    if multi and rank == 0:  # not timed: the merged edge list must be a consistent table (and, alone, equal our own)
+        tot = merged_keep["tot"]
+        me = merged_keep["e"].cpu().numpy()[: int(tot[0]) * EDGE_DTYPE.itemsize].view(EDGE_DTYPE)
+        mo = merged_keep["o"].cpu().numpy()[: int(tot[1]) * ORDER_DTYPE.itemsize].view(ORDER_DTYPE)
+        mi = merged_keep["i"].cpu().numpy()[: int(tot[2]) * 4].view("<u4")
+        merge_ok = bool(
+            np.array_equal(me["order_off"], np.concatenate([[0], np.cumsum(me["order_cnt"])[:-1]]).astype(np.uint64))
+            and np.array_equal(mo["edge_idx"], np.repeat(np.arange(len(me), dtype=np.uint32), me["order_cnt"]))
+            and np.array_equal(mo["ids_off"], np.concatenate([[0], np.cumsum(mo["ids_cnt"])[:-1]]).astype(np.uint64))
+            and int(mo["ids_cnt"].sum()) == len(mi) and bool(np.all(mo["base"] == me["v1"][mo["edge_idx"]])))
+        if world == 1:
+            own = ctx.tables()
+            merge_ok = merge_ok and me.tobytes() == own["edges"].tobytes() and mo.tobytes() == own["orders"].tobytes() \
+                and mi.tobytes() == own["ids"].tobytes()
     if multi:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -263,7 +290,7 @@ def main():
             "config": {"workload": w["name"], "rows": int(len(rows)), "reads": int(c.n_reads),
                        "anchors": int(c.n_anchors), "edges": n_edges_total, "edgematches_rank0": int(c.n_ems),
                        "orders_rank0": int(c.n_orders), "parallelism": "edges sharded by v1 %% %d" % world,
-                       "edges_proven_clean_rank0": int(c.n_edges_fastpath),
+                       "edges_proven_clean_rank0": int(c.n_edges_fastpath), "merged_edge_list_consistent": merge_ok,
                        "note": "value = overlap half of the metric; the consensus half is reported under 'consensus' "
                                "(device gather stage only: assemblePath's layout logic is host-side and not built yet)"},
             "stage_ms": {"index": tm.index_ms, "candidates": tm.candidates_ms, "chain_total": tm.chain_ms,
@@ -290,7 +317,7 @@ def main():
             }
         if world == 1 and args.cpu_sample_reads > 0:
             out["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_sample_reads)
-        print(json.dumps(out))
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     ctx.close()
     if multi:
         dist.destroy_process_group()

@@ -228,3 +228,5 @@ def test_bench_distributed_path_smoke():
     line = json.loads(out.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 1 and line["value"] > 0 and line["config"]["edges"] > 0
     assert 0 < line["roofline"]["frac"] < 1
+    assert line["config"]["merged_edge_list_consistent"] is True   # all-gather + merge reproduced our own tables
+    assert line["consensus"]["verified_against_genome"] is True
