@@ -39,6 +39,8 @@ extern "C" {
 #define MSGPU_E_STATE (-7)    /* entry points called out of order                                              */
 #define MSGPU_E_IDS (-8)      /* read ids are not in first-line (Registry) order, Registry.cpp:36-45           */
 #define MSGPU_E_NODEVICE (-9) /* no HIP device: the product has NO CPU fallback                                */
+#define MSGPU_E_LAYOUT (-10)  /* assemblePath input the reference itself cannot assemble (it would terminate, hang
+                                 or read past a container): text in msgpu_assembly_last_error                     */
 
 /* ---- records (byte-identical to oracle/ms_oracle.h) ----------------------------------------------------------- */
 
@@ -299,6 +301,7 @@ int msgpu_consensus_update(msgpu_consensus *c, const msgpu_copy *seg, uint32_t n
 int msgpu_consensus_borders(const msgpu_consensus *c, int32_t *lo, int32_t *hi, uint64_t *length);
 /* The contig as pieces laid out from dst_off = base; returns the piece count (call with out = NULL to size). */
 size_t msgpu_consensus_pieces(const msgpu_consensus *c, uint64_t base, msgpu_copy *out, size_t cap);
+msgpu_consensus *msgpu_consensus_clone(const msgpu_consensus *c);
 
 /* Upload a batch of pieces (+ its work partition) once; run it any number of times. */
 int      msgpu_gather_plan_create(msgpu_seqctx *ctx, const msgpu_copy *pieces, size_t n, msgpu_gather_plan **out);
@@ -309,6 +312,109 @@ uint64_t msgpu_gather_plan_bases(const msgpu_gather_plan *plan);     /* sum(len)
 int msgpu_gather_run(msgpu_seqctx *ctx, const msgpu_gather_plan *plan, void *d_out, uint64_t out_capacity,
                      void *hip_stream);
 int msgpu_seq_synchronize(msgpu_seqctx *ctx);
+
+/* ---- assemblePath (libms/src/kernel/ap.cpp:615-1362; caller assemblePathsSub, src/main.cpp:663-677) ---------------
+ * One msgpu_assembly collects any number of paths.  msgpu_assembly_add_path runs the reference's layout decisions on
+ * the host for one path (candidate EdgeOrders, anchor cliques, the anchor DAG, placement, flanks, contained reads) and
+ * records every output sequence as copy pieces; it reads no base.  msgpu_assembly_finish then produces all bases of
+ * all paths with ONE gather launch and wraps them into FASTA text on the device (60 columns, ap.cpp:52,61-76):
+ * the texts are what OutputWriter::writeTarget / writeQuery / writePaf (OutputWriter.cpp:49-62) receive, in path order.
+ *
+ * Hash-order note: where ap.cpp iterates std::unordered_map / unordered_set (graph vertices, edges, successors, tap
+ * entries) the reference's order is unspecified; this library uses ascending ids / creation order. */
+typedef struct msgpu_path_read {
+  uint32_t read_id;          /* Vertex::getId()                                         */
+  uint32_t direction;        /* 1: Direction::e_POS, 0: e_NEG (Vertex::getVertexDirection) */
+  uint64_t nanopore_length;  /* Vertex::getNanoporeLength()                             */
+} msgpu_path_read;
+typedef struct msgpu_path_order { /* an EdgeOrder (include/ms/graph/Edge.h:49-60) of a directed path edge */
+  uint64_t score;
+  uint32_t base_read; /* baseVertex id                                                 */
+  uint32_t ids_off;   /* its ids = ids[ids_off .. ids_off + ids_cnt)                   */
+  uint32_t ids_cnt;
+  uint32_t pad;
+} msgpu_path_order;
+typedef struct msgpu_path_em { /* EdgeMatch::overlap of a path edge on one anchor, MatchMap.h:68-74 */
+  uint32_t anchor_id;
+  int32_t  ov_lo, ov_hi;
+} msgpu_path_em;
+typedef struct msgpu_path_contain { /* a ContainElement (MatchMap.h:80-87) attached to a read of the path */
+  uint32_t host_read;   /* the path read that contains it                              */
+  uint32_t nano;        /* the contained read                                          */
+  uint32_t direction;   /* ContainElement::direction                                   */
+  uint32_t anchors_off; /* keys of ContainElement::matches = contain_anchors[off .. off + cnt); the VertexMatch of */
+  uint32_t anchors_cnt; /* (nano, anchor) is looked up in `rows`                       */
+} msgpu_path_contain;
+typedef struct msgpu_path_input {
+  const msgpu_path_read  *reads;     /* the path, n_reads >= 2                                              */
+  uint32_t                n_reads;
+  int32_t                 asm_idx;   /* asmIdx: names ">muchsalsa_<asmIdx>", ">Middle.<asmIdx>.<n>" ...     */
+  const uint32_t         *order_off; /* n_reads entries: path edge i = reads[i] -> reads[i+1] owns orders   */
+  const msgpu_path_order *orders;    /*   [order_off[i], order_off[i+1]) (diGraph.getEdge(..)->getEdgeOrders()) */
+  const uint32_t         *ids;       /* id pool of the orders                                               */
+  const uint32_t         *em_off;    /* n_reads entries: EdgeMatches of path edge i                         */
+  const msgpu_path_em    *ems;
+  const msgpu_row        *rows;      /* MatchMap::getVertexMatch source: every (read, anchor) row of the path's */
+  size_t                  n_rows;    /*   reads and of the contained reads (any order, lowest line per pair)  */
+  const msgpu_path_contain *contains;
+  uint32_t                n_contains;
+  uint32_t                pad;
+  const uint32_t         *contain_anchors;
+} msgpu_path_input;
+
+typedef struct msgpu_assembly msgpu_assembly;
+typedef struct msgpu_path_info {
+  uint64_t target_len;     /* bases of the contig                                        */
+  uint64_t target_raw_off; /* where its bases start in the raw (unwrapped) buffer        */
+  uint32_t query_begin, query_end; /* its query records                                  */
+  uint32_t n_anchors, n_anchor_edges;
+  int32_t  border_lo, border_hi;   /* globalPos1, globalPos2 (ap.cpp:880-881)            */
+  int32_t  asm_idx;
+  uint32_t pad;
+} msgpu_path_info;
+#define MSGPU_QUERY_MIDDLE 0u
+#define MSGPU_QUERY_LEFT 1u
+#define MSGPU_QUERY_RIGHT 2u
+#define MSGPU_QUERY_CONTAIN_ILLUMINA 3u
+#define MSGPU_QUERY_CONTAIN_NANO 4u
+typedef struct msgpu_query_info {
+  uint64_t len;
+  uint64_t raw_off;
+  int64_t  lb, rb; /* PAF columns 8 and 9 as the reference prints them                   */
+  uint32_t kind;   /* MSGPU_QUERY_*                                                      */
+  uint32_t path;
+} msgpu_query_info;
+
+int         msgpu_assembly_create(msgpu_seqctx *ctx, msgpu_assembly **out);
+void        msgpu_assembly_free(msgpu_assembly *a);
+const char *msgpu_assembly_last_error(const msgpu_assembly *a);
+/* MSGPU_E_LAYOUT leaves the assembly unchanged (the path is skipped). */
+int      msgpu_assembly_add_path(msgpu_assembly *a, const msgpu_path_input *in);
+uint32_t msgpu_assembly_path_count(const msgpu_assembly *a);
+uint32_t msgpu_assembly_query_count(const msgpu_assembly *a);
+int      msgpu_assembly_path_info(const msgpu_assembly *a, uint32_t path, msgpu_path_info *out);
+int      msgpu_assembly_query_info(const msgpu_assembly *a, uint32_t query, msgpu_query_info *out);
+/* every copy piece of every record, dst_off = position in the raw buffer; returns the count (out = NULL to size) */
+size_t   msgpu_assembly_pieces(const msgpu_assembly *a, msgpu_copy *out, size_t cap);
+uint64_t msgpu_assembly_raw_bytes(const msgpu_assembly *a);
+/* gather + FASTA wrapping on the device, texts copied to host memory owned by the assembly.  hip_stream NULL = the
+ * context's stream.  Synchronous.  MSGPU_E_NODEVICE on a layout-only context. */
+int msgpu_assembly_finish(msgpu_assembly *a, void *hip_stream);
+/* which: 0 = temp_1.target.fa, 1 = temp_1.query.fa (both after finish), 2 = temp_1.align.paf (after add_path) */
+const char *msgpu_assembly_text(const msgpu_assembly *a, int which, uint64_t *len);
+
+/* FASTA wrapping on the device: record r = header bytes, then `len` bases from d_raw + raw_off in lines of 60
+ * (limitLength, ap.cpp:61-76), then '\n'; written at d_text + text_off.  Asynchronous on hip_stream / the ctx stream. */
+typedef struct msgpu_fasta_record {
+  uint64_t raw_off, text_off;
+  uint32_t len;
+  uint32_t header_off, header_len; /* header = headers[header_off .. +header_len), e.g. ">muchsalsa_1\n" */
+  uint32_t pad;
+} msgpu_fasta_record;
+uint64_t msgpu_fasta_text_bytes(uint32_t header_len, uint64_t len);
+int msgpu_fasta_format(msgpu_seqctx *ctx, const void *d_raw, const msgpu_fasta_record *records, size_t n,
+                       const char *headers, size_t headers_bytes, void *d_text, uint64_t text_capacity,
+                       void *hip_stream);
 
 /* ---- banded edit distance (no reference counterpart) ---------------------------------
  * The meter for north_star's "consensus sequences within a stated edit-distance tolerance": Levenshtein distance

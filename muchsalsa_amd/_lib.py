@@ -24,11 +24,27 @@ COPY_DTYPE = np.dtype([("src_off", "<u8"), ("dst_off", "<u8"), ("len", "<u4"), (
 assert (ROW_DTYPE.itemsize, EDGE_DTYPE.itemsize, EM_DTYPE.itemsize, ORDER_DTYPE.itemsize) == (40, 32, 32, 64)
 assert COPY_DTYPE.itemsize == 24
 COPY_ILLUMINA, COPY_REVCOMP = 1, 2
+PATH_READ_DTYPE = np.dtype([("read_id", "<u4"), ("direction", "<u4"), ("nanopore_length", "<u8")])
+PATH_ORDER_DTYPE = np.dtype([("score", "<u8"), ("base_read", "<u4"), ("ids_off", "<u4"), ("ids_cnt", "<u4"),
+                             ("pad", "<u4")])
+PATH_EM_DTYPE = np.dtype([("anchor_id", "<u4"), ("ov_lo", "<i4"), ("ov_hi", "<i4")])
+PATH_CONTAIN_DTYPE = np.dtype([("host_read", "<u4"), ("nano", "<u4"), ("direction", "<u4"), ("anchors_off", "<u4"),
+                               ("anchors_cnt", "<u4")])
+PATH_INFO_DTYPE = np.dtype([("target_len", "<u8"), ("target_raw_off", "<u8"), ("query_begin", "<u4"),
+                            ("query_end", "<u4"), ("n_anchors", "<u4"), ("n_anchor_edges", "<u4"),
+                            ("border_lo", "<i4"), ("border_hi", "<i4"), ("asm_idx", "<i4"), ("pad", "<u4")])
+QUERY_INFO_DTYPE = np.dtype([("len", "<u8"), ("raw_off", "<u8"), ("lb", "<i8"), ("rb", "<i8"), ("kind", "<u4"),
+                             ("path", "<u4")])
+FASTA_RECORD_DTYPE = np.dtype([("raw_off", "<u8"), ("text_off", "<u8"), ("len", "<u4"), ("header_off", "<u4"),
+                               ("header_len", "<u4"), ("pad", "<u4")])
+assert (PATH_READ_DTYPE.itemsize, PATH_ORDER_DTYPE.itemsize, PATH_EM_DTYPE.itemsize, PATH_CONTAIN_DTYPE.itemsize,
+        PATH_INFO_DTYPE.itemsize, QUERY_INFO_DTYPE.itemsize, FASTA_RECORD_DTYPE.itemsize) == (16, 24, 12, 20, 48, 40, 32)
 ALIGN_PAIR_DTYPE = np.dtype([("a_off", "<u8"), ("b_off", "<u8"), ("a_len", "<u4"), ("b_len", "<u4")])
 assert ALIGN_PAIR_DTYPE.itemsize == 24
 
 OK = 0
 E_IO, E_FORMAT, E_NUMBER, E_NOMEM, E_ARG, E_HIP, E_STATE, E_IDS, E_NODEVICE = -1, -2, -3, -4, -5, -6, -7, -8, -9
+E_LAYOUT = -10
 
 ORD_START_V1, ORD_CONTAINED, ORD_DIR, ORD_PRIMARY = 1, 2, 4, 8
 
@@ -37,6 +53,13 @@ class Params(C.Structure):
     _fields_ = [("min_matches", C.c_uint32), ("th_length", C.c_uint32), ("th_matches", C.c_uint32),
                 ("th_overlap", C.c_uint32), ("wiggle_room", C.c_uint64), ("ratio_pct", C.c_double),
                 ("alt_frac", C.c_double)]
+
+
+class PathInput(C.Structure):
+    _fields_ = [("reads", C.c_void_p), ("n_reads", C.c_uint32), ("asm_idx", C.c_int32), ("order_off", C.c_void_p),
+                ("orders", C.c_void_p), ("ids", C.c_void_p), ("em_off", C.c_void_p), ("ems", C.c_void_p),
+                ("rows", C.c_void_p), ("n_rows", C.c_size_t), ("contains", C.c_void_p), ("n_contains", C.c_uint32),
+                ("pad", C.c_uint32), ("contain_anchors", C.c_void_p)]
 
 
 class Counts(C.Structure):
@@ -109,6 +132,22 @@ SYMBOLS = [
     ("msgpu_consensus_borders", C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                           C.POINTER(C.c_uint64)]),
     ("msgpu_consensus_pieces", C.c_size_t, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_size_t]),
+    ("msgpu_consensus_clone", C.c_void_p, [C.c_void_p]),
+    ("msgpu_assembly_create", C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    ("msgpu_assembly_free", None, [C.c_void_p]),
+    ("msgpu_assembly_last_error", C.c_char_p, [C.c_void_p]),
+    ("msgpu_assembly_add_path", C.c_int, [C.c_void_p, C.POINTER(PathInput)]),
+    ("msgpu_assembly_path_count", C.c_uint32, [C.c_void_p]),
+    ("msgpu_assembly_query_count", C.c_uint32, [C.c_void_p]),
+    ("msgpu_assembly_path_info", C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p]),
+    ("msgpu_assembly_query_info", C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p]),
+    ("msgpu_assembly_pieces", C.c_size_t, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    ("msgpu_assembly_raw_bytes", C.c_uint64, [C.c_void_p]),
+    ("msgpu_assembly_finish", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("msgpu_assembly_text", C.c_void_p, [C.c_void_p, C.c_int, C.POINTER(C.c_uint64)]),
+    ("msgpu_fasta_text_bytes", C.c_uint64, [C.c_uint32, C.c_uint64]),
+    ("msgpu_fasta_format", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_char_p, C.c_size_t,
+                                     C.c_void_p, C.c_uint64, C.c_void_p]),
     ("msgpu_gather_plan_create", C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     ("msgpu_gather_plan_free", None, [C.c_void_p]),
     ("msgpu_gather_plan_out_bytes", C.c_uint64, [C.c_void_p]),

@@ -1,0 +1,25 @@
+// asm_internal.h -- the assembly object shared by assemble_path.cpp (host layout) and msgpu_seq.hip (device finish).
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "msgpu.h"
+
+struct msgpu_assembly {
+  msgpu_seqctx                 *ctx = nullptr;
+  std::vector<msgpu_copy>       pieces; // dst_off = position in the raw buffer (records start 16-B aligned)
+  uint64_t                      raw_bytes = 0;
+  std::vector<msgpu_path_info>  paths;
+  std::vector<msgpu_query_info> queries;
+  std::string                   paf;                 // temp_1.align.paf
+  std::string                   target_fa, query_fa; // filled by msgpu_assembly_finish
+  bool                          finished = false;
+  char                          err[256] = {0};
+};
+
+namespace msgpu {
+// header lines of the FASTA records, reference spelling (ap.cpp:1035-1040, 1059-1066, 1118-1125, 1175-1182, 1309-1318)
+std::string target_header(int32_t asm_idx);
+std::string query_header(uint32_t kind, int32_t asm_idx, uint32_t query_idx);
+} // namespace msgpu

@@ -1,0 +1,814 @@
+// assemble_path.cpp -- the layout half of muchsalsa::assemblePath (libms/src/kernel/ap.cpp:615-1362) on copy pieces.
+//
+// The reference turns one linearised path of reads into a target contig, query segments and a PAF by building
+// std::strings as it goes (whole-record reads from disk, slices, reverse complements, O(L^2) re-copies of the growing
+// contig).  Here the same decisions are taken on the host over integers only -- which EdgeOrder per path edge
+// (:621-706), anchor cliques and their common overlaps (:91-189, :708-719), the per-read anchor order (:721-777), the
+// anchor DAG (:779-853), anchor distances (:581-611), placement (:231-349, :865-1010), flanks (:1012-1032) and the
+// contained reads (:1227-1361) -- and every sequence the reference would have built is recorded as a short list of
+// copy pieces.  No base is read here; msgpu_assembly_finish (msgpu_seq.hip) produces all of them in one gather launch.
+//
+// Iteration orders the reference leaves to std::unordered_* are fixed as: vertices ascending id, anchor-DAG edges in
+// creation order, successors / predecessors ascending id, tap entries ascending id, std::sort ties stable.
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <new>
+#include <set>
+#include <stdexcept>
+#include <tuple>
+#include <unordered_map>
+#include <vector>
+
+#include "asm_internal.h"
+#include "msgpu.h"
+
+namespace msgpu {
+std::string target_header(int32_t asm_idx) { return ">muchsalsa_" + std::to_string(asm_idx) + "\n"; }
+std::string query_header(uint32_t kind, int32_t asm_idx, uint32_t query_idx) {
+  static const char *const names[] = {">Middle.", ">Left.", ">Right.", ">Contain_Illumina_Match.", ">Contain_Nano_Middle."};
+  return std::string(names[kind]) + std::to_string(asm_idx) + "." + std::to_string(query_idx) + "\n";
+}
+} // namespace msgpu
+
+namespace {
+
+constexpr uint64_t TH_SEQUENCE_LENGTH = 200; // ap.cpp:53
+constexpr int      NANO = 0, ILLU = 1;
+
+struct LayoutError : std::runtime_error {
+  using std::runtime_error::runtime_error;
+};
+struct ApiError {
+  int code;
+};
+
+struct Seg { // a sequence the reference would hold in a std::string
+  std::vector<msgpu_copy> p;
+  uint64_t                len = 0;
+};
+
+using Key = std::pair<uint32_t, uint32_t>; // (illumina id, clique index): the key of Id2OverlapMap
+using Ov  = std::pair<int, int>;
+struct Match { // tuple<tuple<id, clique>, modifier>, ap.cpp:721-723
+  Key      key;
+  uint32_t mod;
+  bool     operator==(const Match &o) const { return key == o.key && mod == o.mod; }
+};
+struct Info { // one entry of vertexInfo
+  Ov    nr;
+  Match m;
+};
+
+// (sequence, borderLeft, borderRight) of updateConsensusBase
+struct Base {
+  msgpu_consensus *c   = msgpu_consensus_new();
+  bool             has = false;
+  Base() {
+    if (!c) throw std::bad_alloc();
+  }
+  Base(const Base &o) : c(msgpu_consensus_clone(o.c)), has(o.has) {
+    if (!c) throw std::bad_alloc();
+  }
+  Base &operator=(const Base &) = delete;
+  ~Base() { msgpu_consensus_free(c); }
+  void update(const Seg &s, int lo, int hi) {
+    const int rc = msgpu_consensus_update(c, s.p.data(), static_cast<uint32_t>(s.p.size()), lo, hi);
+    if (rc != MSGPU_OK) throw ApiError{rc};
+    has = true;
+  }
+  void reset(const Seg &s, int lo, int hi) { // "sequence = anchorSequences.at(v); pos1 = 0; pos2 = ..."
+    msgpu_consensus_free(c);
+    c = msgpu_consensus_new();
+    if (!c) throw std::bad_alloc();
+    has = false;
+    update(s, lo, hi);
+  }
+  int lo() const {
+    int32_t l = 0;
+    msgpu_consensus_borders(c, &l, nullptr, nullptr);
+    return has ? l : 0;
+  }
+  int hi() const {
+    int32_t h = 0;
+    msgpu_consensus_borders(c, nullptr, &h, nullptr);
+    return has ? h : 0;
+  }
+  Seg seg() const {
+    Seg s;
+    s.p.resize(msgpu_consensus_pieces(c, 0, nullptr, 0));
+    msgpu_consensus_pieces(c, 0, s.p.data(), s.p.size());
+    for (const auto &q : s.p) s.len += q.len;
+    return s;
+  }
+};
+
+struct Adg { // the anchor DiGraph of one path; vertices are registry ids 0..n-1
+  std::vector<std::map<uint32_t, uint32_t>> succ, pred; // neighbour -> edge index, ascending
+  std::vector<std::pair<uint32_t, uint32_t>> edges;     // creation order
+  uint32_t add_vertex() {
+    succ.emplace_back();
+    pred.emplace_back();
+    return static_cast<uint32_t>(succ.size() - 1);
+  }
+  uint32_t add_edge(uint32_t u, uint32_t v) { // GraphBase::_addEdgeInternal keeps an existing edge, Graph.cpp:291-311
+    auto it = succ[u].find(v);
+    if (it != succ[u].end()) return it->second;
+    const uint32_t e = static_cast<uint32_t>(edges.size());
+    edges.emplace_back(u, v);
+    succ[u][v] = e;
+    pred[v][u] = e;
+    return e;
+  }
+  std::vector<uint32_t> sort_topologically() const { // DiGraph::sortTopologically, Graph.cpp:359-395
+    const uint32_t        n = static_cast<uint32_t>(succ.size());
+    std::vector<uint32_t> indeg(n), ready, result;
+    for (uint32_t v = 0; v < n; ++v) {
+      indeg[v] = static_cast<uint32_t>(pred[v].size());
+      if (!indeg[v]) ready.push_back(v);
+    }
+    while (!ready.empty()) {
+      const uint32_t v = ready.back();
+      ready.pop_back();
+      for (const auto &t : succ[v])
+        if (--indeg[t.first] == 0) ready.push_back(t.first);
+      result.push_back(v);
+    }
+    return result;
+  }
+};
+
+// ramseyR2 / getAnchorCliques, ap.cpp:91-138, on the small interval-intersection graph of one anchor
+std::vector<uint32_t> ramsey(const std::map<uint32_t, std::set<uint32_t>> &adj, const std::vector<uint32_t> &vs) {
+  if (vs.empty()) return {};
+  const uint32_t        first = vs[0];
+  std::vector<uint32_t> nb, non;
+  const auto           &a = adj.at(first);
+  for (size_t i = 1; i < vs.size(); ++i) (a.count(vs[i]) ? nb : non).push_back(vs[i]);
+  std::vector<uint32_t> cn  = ramsey(adj, nb);
+  std::vector<uint32_t> cnn = ramsey(adj, non);
+  cn.push_back(first);
+  return cn.size() >= cnn.size() ? cn : cnn;
+}
+
+struct PathLayout {
+  msgpu_seqctx           *ctx;
+  const msgpu_path_input &in;
+  std::unordered_map<uint64_t, const msgpu_row *> vm;
+  std::unordered_map<uint32_t, uint32_t>          dir_of; // read id -> direction
+  std::vector<std::map<uint32_t, Ov>>             em;     // per path edge: anchor -> overlap
+
+  PathLayout(msgpu_seqctx *c, const msgpu_path_input &i) : ctx(c), in(i) {}
+
+  const msgpu_row *row(uint32_t read, uint32_t anchor) const {
+    auto it = vm.find((static_cast<uint64_t>(read) << 32) | anchor);
+    if (it == vm.end())
+      throw LayoutError("no VertexMatch for read " + std::to_string(read) + " on anchor " + std::to_string(anchor));
+    return it->second;
+  }
+  static bool mdir(const msgpu_row *m) { return (m->flags & MSGPU_ROW_DIR) != 0; }
+  static void check(int rc) {
+    if (rc != MSGPU_OK) throw ApiError{rc};
+  }
+  static void close(Seg &s, uint32_t n, uint64_t len) {
+    s.p.resize(n);
+    s.len = len;
+  }
+
+  Seg anchor_seq(uint32_t read, uint32_t anchor, Ov ov, bool pos) const {
+    Seg      s;
+    uint32_t n = 0;
+    s.p.resize(1);
+    check(msgpu_seg_anchor(ctx, row(read, anchor), ov.first, ov.second, pos, s.p.data(), &n, &s.len));
+    close(s, n, s.len);
+    return s;
+  }
+  Seg flank(bool left, const msgpu_path_read &r, uint32_t anchor, Ov ov) const {
+    Seg      s;
+    uint32_t n = 0;
+    s.p.resize(2);
+    check((left ? msgpu_seg_left_of_anchor : msgpu_seg_right_of_anchor)(
+        ctx, row(r.read_id, anchor), r.nanopore_length, ov.first, ov.second, r.direction != 0, s.p.data(), &n, &s.len));
+    close(s, n, s.len);
+    return s;
+  }
+  // one get{Illumina,Nanopore}Sequence(id, l, r, d) as a segment
+  Seg slice(int kind, uint32_t id, int l, int r, bool d) const {
+    Seg s;
+    s.p.resize(1);
+    check(msgpu_seq_resolve(ctx, kind, id, l, r, d, s.p.data()));
+    s.p[0].dst_off = 0;
+    s.len          = s.p[0].len;
+    return s;
+  }
+};
+
+struct Candidate { // ap.cpp:621-629 (edges[i] is always path edge i)
+  std::set<uint32_t>                 open, visited;
+  uint64_t                           score = 0, kinks = 0;
+  std::vector<uint32_t>              orders; // index into in.orders
+  std::vector<std::vector<uint32_t>> modifiers;
+};
+
+void find_best(const std::vector<Candidate> &cs, bool &any, uint64_t &min_kinks, uint64_t &max_score) { // :633-642
+  any = false;
+  for (const auto &c : cs)
+    if (!any || c.kinks < min_kinks || (c.kinks == min_kinks && c.score > max_score)) {
+      any       = true;
+      min_kinks = c.kinks;
+      max_score = c.score;
+    }
+}
+
+struct Record { // one output sequence of the path
+  uint32_t kind; // MSGPU_QUERY_* or ~0u for the target
+  Seg      seg;
+  int64_t  lb = 0, rb = 0;
+};
+
+// visitOrdered, ap.cpp:231-349
+Base visit_ordered(std::map<uint32_t, bool> &visited, std::map<uint32_t, Ov> &tap, const Adg &adg,
+                   const std::vector<Key> &reg2id, const std::vector<uint32_t> &pos_of,
+                   const std::vector<uint32_t> &order, const std::vector<int> &distances,
+                   const std::vector<std::vector<Seg>> &sequences, const std::vector<Seg> &anchor_seq,
+                   const std::map<Key, Ov> &id2ov, uint32_t start) {
+  Base base;
+  auto cmp = [](const std::pair<size_t, int> &l, const std::pair<size_t, int> &r) { // :244-250
+    return std::make_pair(l.first, -l.second) < std::make_pair(r.first, -r.second);
+  };
+  std::set<std::pair<size_t, int>, decltype(cmp)> queue_edges(cmp);
+  std::set<size_t>                                queue_vertices;
+  queue_vertices.insert(pos_of[start]);
+  while (!queue_vertices.empty()) {
+    const size_t   idx = *queue_vertices.begin();
+    const uint32_t v   = order[idx];
+    queue_vertices.erase(queue_vertices.begin());
+    if (!visited[v]) {
+      visited[v] = true;
+      for (const auto &t : adg.succ[v]) {
+        queue_edges.emplace(pos_of[t.first], static_cast<int>(idx));
+        queue_vertices.insert(pos_of[t.first]);
+      }
+      while (!queue_edges.empty() && queue_edges.begin()->first == idx) {
+        const uint32_t left = order[static_cast<size_t>(queue_edges.begin()->second)], right = order[queue_edges.begin()->first];
+        const bool     has_l = tap.count(left) != 0, has_r = tap.count(right) != 0;
+        const Ov       ov_l = id2ov.at(reg2id[left]), ov_r = id2ov.at(reg2id[right]);
+        const uint32_t e      = adg.succ[left].at(right);
+        const int      offset = distances[e];
+        const int      len_l = ov_l.second - ov_l.first + 1, len_r = ov_r.second - ov_r.first + 1;
+        if (has_l && !has_r) { // :295-307
+          const int pos = tap.at(left).second;
+          tap[right]    = Ov(pos + offset + 1, pos + offset + len_r);
+          if (offset > 0) base.update(sequences[e].front(), pos + 1, pos + offset);
+          base.update(anchor_seq[right], tap[right].first, tap[right].second);
+        } else if (!has_l && has_r) { // :308-320
+          const int pos = tap.at(right).first;
+          tap[left]     = Ov(pos - offset - len_l, pos - offset - 1);
+          if (offset > 0) base.update(sequences[e].front(), pos - offset, pos);
+          base.update(anchor_seq[left], tap[left].first, tap[left].second);
+        } else if (!has_l && !has_r) { // :321-337
+          tap[left]  = Ov(0, len_l - 1);
+          tap[right] = Ov(len_l + offset, len_l + offset + len_r - 1);
+          if (offset > 0) base.update(sequences[e].front(), len_l, len_l + offset - 1);
+          base.update(anchor_seq[left], tap[left].first, tap[left].second);
+          base.update(anchor_seq[right], tap[right].first, tap[right].second);
+        }
+        queue_edges.erase(queue_edges.begin());
+      }
+    } else {
+      while (!queue_edges.empty() && queue_edges.begin()->first == idx) queue_edges.erase(queue_edges.begin());
+    }
+  }
+  return base;
+}
+
+struct PathResult {
+  Seg                 target;
+  std::vector<Record> queries;
+  msgpu_path_info     info{};
+  int                 left_most = 0;
+};
+
+PathResult layout_path(msgpu_seqctx *ctx, const msgpu_path_input &in) {
+  PathLayout L(ctx, in);
+  const uint32_t n_reads = in.n_reads, n_edges = n_reads - 1;
+  for (size_t i = 0; i < in.n_rows; ++i) { // MatchMap::addVertexMatch keeps the lowest line, MatchMap.cpp:64-80
+    const uint64_t k = (static_cast<uint64_t>(in.rows[i].read_id) << 32) | in.rows[i].anchor_id;
+    auto           it = L.vm.find(k);
+    if (it == L.vm.end() || in.rows[i].line < it->second->line) L.vm[k] = &in.rows[i];
+  }
+  for (uint32_t i = 0; i < n_reads; ++i) L.dir_of[in.reads[i].read_id] = in.reads[i].direction;
+  L.em.resize(n_edges);
+  for (uint32_t i = 0; i < n_edges; ++i)
+    for (uint32_t k = in.em_off[i]; k < in.em_off[i + 1]; ++k)
+      L.em[i].emplace(in.ems[k].anchor_id, Ov(in.ems[k].ov_lo, in.ems[k].ov_hi));
+  auto order_ids = [&](uint32_t oi) { // ids of an order, reversed when its base vertex is e_NEG (:658-661, :731-735)
+    const msgpu_path_order &o = in.orders[oi];
+    std::vector<uint32_t>   ids(in.ids + o.ids_off, in.ids + o.ids_off + o.ids_cnt);
+    auto                    d = L.dir_of.find(o.base_read);
+    if (d == L.dir_of.end()) throw LayoutError("EdgeOrder based at a read that is not on the path");
+    if (!d->second) std::reverse(ids.begin(), ids.end());
+    return ids;
+  };
+  auto em_of = [&](uint32_t edge, uint32_t anchor) {
+    auto it = L.em[edge].find(anchor);
+    if (it == L.em[edge].end())
+      throw LayoutError("no EdgeMatch for anchor " + std::to_string(anchor) + " on path edge " + std::to_string(edge));
+    return it->second;
+  };
+
+  // ---- which EdgeOrder per path edge, ap.cpp:631-706 -----------------------------------------------------------------
+  std::vector<Candidate> candidates(1);
+  for (uint32_t i = 0; i < n_edges; ++i) {
+    std::vector<Candidate> next;
+    for (uint32_t oi = in.order_off[i]; oi < in.order_off[i + 1]; ++oi) {
+      const std::vector<uint32_t> ids = order_ids(oi);
+      std::vector<Candidate>      sub;
+      for (const Candidate &c : candidates) {
+        Candidate n;
+        std::vector<uint32_t> mods;
+        for (uint32_t id : ids)
+          if (!c.open.count(id) && c.visited.count(id)) mods.push_back(id);
+        n.open.insert(ids.begin(), ids.end());
+        n.visited = c.visited;
+        n.visited.insert(ids.begin(), ids.end());
+        n.score = c.score + in.orders[oi].score;
+        n.kinks = c.kinks + mods.size();
+        n.orders = c.orders;
+        n.orders.push_back(oi);
+        n.modifiers = c.modifiers;
+        n.modifiers.push_back(std::move(mods));
+        sub.push_back(std::move(n));
+      }
+      bool     any;
+      uint64_t mk = 0, ms = 0;
+      find_best(sub, any, mk, ms);
+      for (auto &c : sub)
+        if (any && c.kinks == mk && c.score == ms) next.push_back(std::move(c));
+    }
+    candidates = std::move(next);
+  }
+  if (candidates.empty()) throw LayoutError("a path edge has no EdgeOrder");
+  bool     any;
+  uint64_t mk = 0, ms = 0;
+  find_best(candidates, any, mk, ms);
+  const Candidate &best =
+      *std::find_if(candidates.begin(), candidates.end(), [&](const Candidate &c) { return c.kinks == mk && c.score == ms; });
+
+  // ---- anchor clusters -> cliques -> common overlaps, :708-719 + getClusterAnchors :140-189 ----------------------------
+  std::map<uint32_t, std::vector<uint32_t>> clusters;
+  for (uint32_t idx = 0; idx < n_edges; ++idx) {
+    const msgpu_path_order &o = in.orders[best.orders[idx]];
+    for (uint32_t k = 0; k < o.ids_cnt; ++k) clusters[in.ids[o.ids_off + k]].push_back(idx);
+  }
+  std::map<Key, Ov>                              id2ov;
+  std::vector<std::unordered_map<uint32_t, uint32_t>> cluster_modifier(n_edges);
+  for (const auto &cl : clusters) {
+    const uint32_t                         anchor = cl.first;
+    std::map<uint32_t, std::set<uint32_t>> adj;
+    for (uint32_t e1 : cl.second) {
+      adj[e1];
+      for (uint32_t e2 : cl.second) {
+        if (e1 == e2) break;
+        const Ov o1 = em_of(e1, anchor), o2 = em_of(e2, anchor);
+        if (std::max(o1.first, o2.first) <= std::min(o1.second, o2.second)) {
+          adj[e2].insert(e1);
+          adj[e1].insert(e2);
+        }
+      }
+    }
+    std::set<uint32_t> left;
+    for (const auto &a : adj) left.insert(a.first);
+    std::vector<std::vector<uint32_t>> cliques;
+    std::vector<uint32_t> current = ramsey(adj, std::vector<uint32_t>(left.begin(), left.end()));
+    cliques.push_back(current);
+    while (!left.empty()) {
+      for (uint32_t v : current) left.erase(v);
+      current = ramsey(adj, std::vector<uint32_t>(left.begin(), left.end()));
+      if (!current.empty()) cliques.push_back(current);
+    }
+    for (uint32_t idx = 0; idx < cliques.size(); ++idx) {
+      bool have = false;
+      Ov   common;
+      for (uint32_t v : cliques[idx]) {
+        cluster_modifier[v][anchor] = idx;
+        const Ov ov                 = em_of(v, anchor);
+        common = have ? Ov(std::max(common.first, ov.first), std::min(common.second, ov.second)) : ov;
+        have   = true;
+      }
+      if (!have) throw LayoutError("empty anchor clique"); // commonOverlap.value() would throw
+      id2ov[Key(anchor, idx)] = common;
+    }
+  }
+
+  // ---- anchors per read in read order, :721-752 --------------------------------------------------------------------------
+  std::vector<std::vector<Info>>          vertex_info(n_edges + 1);
+  std::unordered_map<uint32_t, uint32_t> match_modifiers;
+  for (uint32_t idx = 0; idx < n_edges; ++idx) {
+    for (uint32_t m : best.modifiers[idx]) ++match_modifiers[m];
+    const uint32_t ra = in.reads[idx].read_id, rb = in.reads[idx + 1].read_id;
+    for (uint32_t id : order_ids(best.orders[idx])) {
+      auto        mm = match_modifiers.find(id);
+      const Match m{Key(id, cluster_modifier[idx][id]), mm == match_modifiers.end() ? 0u : mm->second};
+      const msgpu_row *a = L.row(ra, id), *b = L.row(rb, id);
+      vertex_info[idx].push_back(Info{Ov(a->n_lo, a->n_hi), m});
+      vertex_info[idx + 1].push_back(Info{Ov(b->n_lo, b->n_hi), m});
+    }
+  }
+
+  // ---- anchor DAG, anchor sequences, flanks, :754-853 ----------------------------------------------------------------------
+  std::map<std::tuple<uint32_t, uint32_t, uint32_t>, uint32_t> registry; // tupleTuple2Id -> Registry id
+  Adg                                                          adg;
+  std::vector<Key>                                             reg2id;
+  std::vector<Seg>                                             anchor_seq;
+  std::vector<std::vector<uint32_t>>                           nanopores; // per DAG edge: path positions of its reads
+  std::map<uint32_t, std::vector<Seg>>                         pre, post;
+  for (uint32_t idx = 0; idx <= n_edges; ++idx) {
+    const msgpu_path_read &r   = in.reads[idx];
+    const bool             pos = r.direction != 0;
+    auto                  &info = vertex_info[idx];
+    std::stable_sort(info.begin(), info.end(), [&](const Info &l, const Info &rr) { // :760-770
+      if (l.nr == rr.nr) {
+        const Ov lo = id2ov.at(l.m.key), ro = id2ov.at(rr.m.key);
+        if (!PathLayout::mdir(L.row(r.read_id, l.m.key.first))) return ro < lo;
+        return lo < ro;
+      }
+      return l.nr < rr.nr;
+    });
+    if (!pos) std::reverse(info.begin(), info.end());
+    if (info.empty()) continue;
+    auto ensure = [&](const Match &m) { // :787-793, :800-806
+      const auto key = std::make_tuple(m.key.first, m.key.second, m.mod);
+      auto       it  = registry.find(key);
+      if (it != registry.end()) return it->second;
+      const uint32_t v = adg.add_vertex();
+      registry.emplace(key, v);
+      anchor_seq.push_back(L.anchor_seq(r.read_id, m.key.first, id2ov.at(m.key), pos));
+      reg2id.push_back(m.key);
+      return v;
+    };
+    Ov    last_nr    = info.front().nr;
+    Match last_match = info.front().m;
+    for (const Info &it : info) {
+      const uint32_t v = ensure(it.m);
+      if (it.m == last_match) continue;
+      const uint32_t vl   = ensure(last_match);
+      bool           flip = false;
+      if ((last_nr.second > it.nr.second && last_nr.first < it.nr.first) ||
+          (last_nr.second < it.nr.second && last_nr.first > it.nr.first)) { // :809-822, getCorrectedNanoporeRange :191-203
+        auto corrected = [&](const Match &m, double &first, double &second) {
+          const msgpu_row *row = L.row(r.read_id, m.key.first);
+          const Ov         ov  = id2ov.at(m.key);
+          const double ratio = static_cast<double>(row->i_hi - row->i_lo + 1) / static_cast<double>(row->n_hi - row->n_lo + 1);
+          double       cl = (ov.first - row->i_lo) / ratio, cr = (row->i_hi - ov.second) / ratio;
+          if (!PathLayout::mdir(row)) std::swap(cl, cr);
+          first  = row->n_lo + cl;
+          second = row->n_hi - cr;
+        };
+        double lf, ls, rf, rs;
+        corrected(last_match, lf, ls);
+        corrected(it.m, rf, rs);
+        flip = (pos && (lf > rf || (lf == rf && ls > rs))) || (!pos && (lf < rf || (lf == rf && ls < rs)));
+      }
+      const uint32_t e = flip ? adg.add_edge(v, vl) : adg.add_edge(vl, v);
+      if (e >= nanopores.size()) nanopores.resize(e + 1);
+      nanopores[e].push_back(idx);
+      last_match = it.m;
+      last_nr    = it.nr;
+    }
+    const Match &first = info.front().m, &second = info.back().m;
+    pre[registry.at(std::make_tuple(first.key.first, first.key.second, first.mod))].push_back(
+        L.flank(true, r, first.key.first, id2ov.at(first.key)));
+    post[registry.at(std::make_tuple(second.key.first, second.key.second, second.mod))].push_back(
+        L.flank(false, r, second.key.first, id2ov.at(second.key)));
+  }
+  const uint32_t n_anchors = static_cast<uint32_t>(adg.succ.size());
+
+  // ---- sequences between neighbouring anchors, :855-863 + alignAnchorRegion :581-611 ---------------------------------------
+  std::vector<int>              distances(adg.edges.size());
+  std::vector<std::vector<Seg>> sequences(adg.edges.size());
+  for (uint32_t e = 0; e < adg.edges.size(); ++e) {
+    const Key  kl = reg2id[adg.edges[e].first], kr = reg2id[adg.edges[e].second];
+    const Ov   ovl = id2ov.at(kl), ovr = id2ov.at(kr);
+    bool       have = false;
+    for (uint32_t pi : nanopores[e]) {
+      const msgpu_path_read &r = in.reads[pi];
+      Seg                    s;
+      uint32_t               n = 0;
+      int32_t                dist = 0;
+      int                    has  = 0;
+      s.p.resize(3);
+      PathLayout::check(msgpu_seg_between_anchors(ctx, L.row(r.read_id, kl.first), L.row(r.read_id, kr.first), ovl.first,
+                                                  ovl.second, ovr.first, ovr.second, r.direction != 0, s.p.data(), &n,
+                                                  &dist, &has));
+      if (has) {
+        PathLayout::close(s, n, static_cast<uint64_t>(dist));
+        sequences[e].push_back(std::move(s));
+      }
+      if (!have) {
+        distances[e] = dist;
+        have         = true;
+      }
+    }
+  }
+
+  // ---- placement, :865-1010 -----------------------------------------------------------------------------------------------------
+  const std::vector<uint32_t> order = adg.sort_topologically();
+  if (order.empty() || order.size() != n_anchors) throw LayoutError("the anchor graph of the path has a cycle");
+  std::vector<uint32_t> pos_of(n_anchors);
+  for (uint32_t i = 0; i < n_anchors; ++i) pos_of[order[i]] = i;
+  std::map<uint32_t, bool> visited;
+  std::map<uint32_t, Ov>   tap;
+  Base glob = visit_ordered(visited, tap, adg, reg2id, pos_of, order, distances, sequences, anchor_seq, id2ov, order[0]);
+  if (n_anchors == 1) { // :886-895
+    const Ov ov = id2ov.at(reg2id[0]);
+    tap[0]      = Ov(0, ov.second - ov.first);
+    glob.reset(anchor_seq[0], 0, ov.second - ov.first);
+  }
+  struct Extra {
+    Base                   base;
+    std::map<uint32_t, Ov> tap;
+    bool                   added;
+  };
+  std::vector<Extra> additional;
+  for (size_t i = 1; i < order.size(); ++i) { // :897-925
+    const uint32_t v = order[i];
+    if (visited.count(v)) continue;
+    std::map<uint32_t, Ov> ltap;
+    Base loc = visit_ordered(visited, ltap, adg, reg2id, pos_of, order, distances, sequences, anchor_seq, id2ov, v);
+    if (ltap.empty()) {
+      const Ov ov = id2ov.at(reg2id[v]);
+      ltap[v]     = Ov(0, ov.second - ov.first);
+      loc.reset(anchor_seq[v], 0, ov.second - ov.first);
+    }
+    additional.push_back(Extra{loc, std::move(ltap), false});
+  }
+  for (bool loop = true; loop;) { // :927-1010
+    loop          = false;
+    bool progress = false;
+    for (Extra &x : additional) {
+      if (x.added) continue;
+      Base loc(x.base);
+      int  group_offset = 0;
+      bool found        = false;
+      for (const auto &m : x.tap) {
+        found = false;
+        for (const auto &t : adg.succ[m.first]) {
+          auto tp = tap.find(t.first);
+          if (tp == tap.end()) continue;
+          const uint32_t e = t.second;
+          group_offset     = tp->second.first - distances[e] - m.second.second - 1;
+          if (!sequences[e].empty()) loc.update(sequences[e].front(), m.second.second + 1, m.second.second + distances[e]);
+          found = true;
+          break;
+        }
+        if (found) break;
+        for (const auto &t : adg.pred[m.first]) {
+          auto tp = tap.find(t.first);
+          if (tp == tap.end()) continue;
+          const uint32_t e = t.second;
+          group_offset     = tp->second.second + distances[e] + 1 - m.second.first + 1;
+          if (!sequences[e].empty()) loc.update(sequences[e].front(), m.second.first - distances[e], m.second.first - 1);
+          found = true;
+          break;
+        }
+        if (found) break;
+      }
+      if (!found) {
+        loop = true;
+        continue;
+      }
+      x.added  = true;
+      progress = true;
+      for (const auto &m : x.tap) tap[m.first] = Ov(m.second.first + group_offset, m.second.second + group_offset);
+      if (!loc.has) throw LayoutError("anchor group without a sequence"); // localSequence.value()
+      glob.update(loc.seg(), loc.lo() + group_offset, loc.hi() + group_offset);
+    }
+    if (loop && !progress) throw LayoutError("a group of anchors never connects to the contig");
+  }
+  if (!glob.has) throw LayoutError("path without a sequence"); // globalSequence.value()
+
+  auto longest = [](const std::vector<Seg> &v) { // std::max_element: the first of the longest
+    return &*std::max_element(v.begin(), v.end(), [](const Seg &a, const Seg &b) { return a.len < b.len; });
+  };
+  auto tap_at = [&](uint32_t v) {
+    auto it = tap.find(v);
+    if (it == tap.end()) throw LayoutError("anchor without a position"); // tap.at
+    return it->second;
+  };
+  for (uint32_t v = 0; v < n_anchors; ++v) { // :1012-1032
+    auto p = pre.find(v);
+    if (p != pre.end()) {
+      const Seg *s   = longest(p->second);
+      const int  len = static_cast<int>(s->len);
+      glob.update(*s, tap_at(v).first - len, tap_at(v).first - 1);
+    }
+    p = post.find(v);
+    if (p != post.end()) {
+      const Seg *s   = longest(p->second);
+      const int  len = static_cast<int>(s->len);
+      glob.update(*s, tap_at(v).second + 1, tap_at(v).second + len);
+    }
+  }
+
+  // ---- output records, :1034-1361 ----------------------------------------------------------------------------------------------
+  PathResult res;
+  res.target    = glob.seg();
+  res.left_most = -glob.lo();
+  const int lm  = res.left_most;
+  for (uint32_t e = 0; e < adg.edges.size(); ++e) // :1052-1109
+    for (const Seg &s : sequences[e]) {
+      if (!s.len) continue;
+      res.queries.push_back(Record{MSGPU_QUERY_MIDDLE, s, tap_at(adg.edges[e].first).second + 1 + lm,
+                                   tap_at(adg.edges[e].second).first - 1 + lm});
+    }
+  for (uint32_t v = 0; v < n_anchors; ++v) { // :1111-1225
+    auto p = pre.find(v);
+    if (p != pre.end())
+      for (const Seg &s : p->second) {
+        if (s.len < TH_SEQUENCE_LENGTH) continue;
+        const int64_t rb = tap_at(v).first - 1 + lm;
+        res.queries.push_back(Record{MSGPU_QUERY_LEFT, s, rb - static_cast<int>(s.len) + 1, rb});
+      }
+    p = post.find(v);
+    if (p != post.end())
+      for (const Seg &s : p->second) {
+        if (s.len < TH_SEQUENCE_LENGTH) continue;
+        const int64_t lb = tap_at(v).second + 1 + lm;
+        res.queries.push_back(Record{MSGPU_QUERY_RIGHT, s, lb, lb + static_cast<int>(s.len) - 1});
+      }
+  }
+  for (uint32_t idx = 0; idx <= n_edges; ++idx) { // contained reads, :1227-1361
+    const msgpu_path_read            &r = in.reads[idx];
+    const bool                        pos = r.direction != 0;
+    std::unordered_map<uint32_t, Match> id2anchor;
+    for (const Info &i : vertex_info[idx]) id2anchor[i.m.key.first] = i.m;
+    for (uint32_t ci = 0; ci < in.n_contains; ++ci) {
+      const msgpu_path_contain &ce = in.contains[ci];
+      if (ce.host_read != r.read_id) continue;
+      std::vector<std::pair<Ov, uint32_t>> cinfo;
+      for (uint32_t k = 0; k < ce.anchors_cnt; ++k) {
+        const uint32_t a = in.contain_anchors[ce.anchors_off + k];
+        if (!id2anchor.count(a)) continue;
+        const msgpu_row *cm = L.row(ce.nano, a);
+        cinfo.emplace_back(Ov(cm->n_lo, cm->n_hi), a);
+      }
+      if (cinfo.empty()) continue;
+      std::sort(cinfo.begin(), cinfo.end());
+      const bool direction = (ce.direction != 0) == pos; // Toggle * bool = XNOR
+      if (!direction) std::reverse(cinfo.begin(), cinfo.end());
+      std::vector<std::pair<int, int>> ranges;
+      for (const auto &ci2 : cinfo) {
+        const uint32_t   a       = ci2.second;
+        const Match     &tap_id  = id2anchor.at(a);
+        const bool       tap_dir = PathLayout::mdir(L.row(r.read_id, a)) == pos;
+        const Ov         ov      = id2ov.at(tap_id.key);
+        const int        illumina_ref = tap_dir ? ov.second : ov.first;
+        const int        total_ref =
+            tap_at(registry.at(std::make_tuple(tap_id.key.first, tap_id.key.second, tap_id.mod))).second + lm;
+        const msgpu_row *cm       = L.row(ce.nano, a);
+        const bool       cont_dir = PathLayout::mdir(cm) == direction;
+        if (!cont_dir) {
+          const int off = cm->i_lo - illumina_ref;
+          ranges.emplace_back(total_ref - off - (cm->i_hi - cm->i_lo), total_ref - off);
+        } else {
+          const int off = cm->i_hi - illumina_ref;
+          ranges.emplace_back(total_ref + off - (cm->i_hi - cm->i_lo), total_ref + off);
+        }
+      }
+      std::vector<Record> to_write;
+      for (size_t k = 0; k < cinfo.size(); ++k) {
+        const uint32_t   a  = cinfo[k].second;
+        const msgpu_row *cm = L.row(ce.nano, a);
+        to_write.push_back(Record{MSGPU_QUERY_CONTAIN_ILLUMINA,
+                                  L.slice(ILLU, a, cm->i_lo, cm->i_hi, PathLayout::mdir(cm) == direction), ranges[k].first,
+                                  ranges[k].second});
+        if (k == 0) continue;
+        const Ov pre_n = cinfo[k - 1].first;
+        to_write.push_back(Record{MSGPU_QUERY_CONTAIN_NANO, L.slice(NANO, ce.nano, pre_n.second + 1, cm->n_lo - 1, direction),
+                                  ranges[k - 1].second + 1, ranges[k].first - 1});
+      }
+      for (Record &w : to_write) {
+        if (w.seg.len < TH_SEQUENCE_LENGTH) continue;
+        res.queries.push_back(std::move(w));
+      }
+    }
+  }
+  res.info.target_len     = res.target.len;
+  res.info.n_anchors      = n_anchors;
+  res.info.n_anchor_edges = static_cast<uint32_t>(adg.edges.size());
+  res.info.border_lo      = glob.lo();
+  res.info.border_hi      = glob.hi();
+  res.info.asm_idx        = in.asm_idx;
+  return res;
+}
+
+uint64_t place(msgpu_assembly *a, const Seg &s) { // append a record's pieces to the raw layout, 16-B aligned
+  const uint64_t off = (a->raw_bytes + 15) & ~15ull;
+  for (msgpu_copy p : s.p) {
+    if (!p.len) continue;
+    p.dst_off += off;
+    a->pieces.push_back(p);
+  }
+  a->raw_bytes = off + s.len;
+  return off;
+}
+
+} // namespace
+
+extern "C" {
+
+int msgpu_assembly_create(msgpu_seqctx *ctx, msgpu_assembly **out) {
+  if (!ctx || !out) return MSGPU_E_ARG;
+  *out = new (std::nothrow) msgpu_assembly();
+  if (!*out) return MSGPU_E_NOMEM;
+  (*out)->ctx = ctx;
+  return MSGPU_OK;
+}
+
+void        msgpu_assembly_free(msgpu_assembly *a) { delete a; }
+const char *msgpu_assembly_last_error(const msgpu_assembly *a) { return a ? a->err : "null assembly"; }
+
+int msgpu_assembly_add_path(msgpu_assembly *a, const msgpu_path_input *in) {
+  if (!a || !in || !in->reads || !in->order_off || !in->em_off || (in->n_rows && !in->rows)) return MSGPU_E_ARG;
+  if (a->finished) return MSGPU_E_STATE;
+  a->err[0] = 0;
+  if (in->n_reads < 2) {
+    snprintf(a->err, sizeof(a->err), "a path needs at least two reads");
+    return MSGPU_E_LAYOUT;
+  }
+  const uint32_t ne = in->n_reads - 1;
+  if ((in->order_off[ne] && (!in->orders || !in->ids)) || (in->em_off[ne] && !in->ems) ||
+      (in->n_contains && (!in->contains || !in->contain_anchors)))
+    return MSGPU_E_ARG;
+  try {
+    PathResult r = layout_path(a->ctx, *in);
+    // commit: raw layout, records, PAF text
+    r.info.target_raw_off = place(a, r.target);
+    r.info.query_begin    = static_cast<uint32_t>(a->queries.size());
+    const std::string tname = "muchsalsa_" + std::to_string(in->asm_idx);
+    uint32_t          qi    = 0;
+    for (const Record &q : r.queries) {
+      msgpu_query_info info{};
+      info.len     = q.seg.len;
+      info.raw_off = place(a, q.seg);
+      info.lb      = q.lb;
+      info.rb      = q.rb;
+      info.kind    = q.kind;
+      info.path    = static_cast<uint32_t>(a->paths.size());
+      a->queries.push_back(info);
+      std::string name = msgpu::query_header(q.kind, in->asm_idx, qi++);
+      name             = name.substr(1, name.size() - 2); // without '>' and '\n'
+      char line[512];
+      const long long len = static_cast<long long>(q.seg.len), span = static_cast<long long>(q.rb - q.lb + 1);
+      snprintf(line, sizeof(line), "%s\t%lld\t0\t%lld\t+\t%s\t%llu\t%lld\t%lld\t%lld\t%lld\t255\n", name.c_str(), len, len,
+               tname.c_str(), static_cast<unsigned long long>(r.target.len), static_cast<long long>(q.lb),
+               static_cast<long long>(q.rb), span, span);
+      a->paf += line;
+    }
+    r.info.query_end = static_cast<uint32_t>(a->queries.size());
+    a->paths.push_back(r.info);
+  } catch (LayoutError const &e) {
+    snprintf(a->err, sizeof(a->err), "%s", e.what());
+    return MSGPU_E_LAYOUT;
+  } catch (ApiError const &e) {
+    snprintf(a->err, sizeof(a->err), "%s (%s)", msgpu_strerror(e.code), msgpu_seq_last_error(a->ctx));
+    return e.code;
+  } catch (std::out_of_range const &e) {
+    snprintf(a->err, sizeof(a->err), "missing map entry (%s)", e.what());
+    return MSGPU_E_LAYOUT;
+  } catch (std::bad_alloc const &) { return MSGPU_E_NOMEM; }
+  return MSGPU_OK;
+}
+
+uint32_t msgpu_assembly_path_count(const msgpu_assembly *a) { return a ? static_cast<uint32_t>(a->paths.size()) : 0; }
+uint32_t msgpu_assembly_query_count(const msgpu_assembly *a) { return a ? static_cast<uint32_t>(a->queries.size()) : 0; }
+int      msgpu_assembly_path_info(const msgpu_assembly *a, uint32_t path, msgpu_path_info *out) {
+  if (!a || !out || path >= a->paths.size()) return MSGPU_E_ARG;
+  *out = a->paths[path];
+  return MSGPU_OK;
+}
+int msgpu_assembly_query_info(const msgpu_assembly *a, uint32_t query, msgpu_query_info *out) {
+  if (!a || !out || query >= a->queries.size()) return MSGPU_E_ARG;
+  *out = a->queries[query];
+  return MSGPU_OK;
+}
+size_t msgpu_assembly_pieces(const msgpu_assembly *a, msgpu_copy *out, size_t cap) {
+  if (!a) return 0;
+  if (out) std::copy_n(a->pieces.begin(), std::min(cap, a->pieces.size()), out);
+  return a->pieces.size();
+}
+uint64_t msgpu_assembly_raw_bytes(const msgpu_assembly *a) { return a ? a->raw_bytes : 0; }
+
+const char *msgpu_assembly_text(const msgpu_assembly *a, int which, uint64_t *len) {
+  if (!a || which < 0 || which > 2 || (which < 2 && !a->finished)) {
+    if (len) *len = 0;
+    return nullptr;
+  }
+  const std::string &s = which == 0 ? a->target_fa : which == 1 ? a->query_fa : a->paf;
+  if (len) *len = s.size();
+  return s.data();
+}
+
+} // extern "C"

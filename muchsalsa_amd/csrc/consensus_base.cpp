@@ -45,6 +45,8 @@ extern "C" {
 msgpu_consensus *msgpu_consensus_new(void) { return new (std::nothrow) msgpu_consensus(); }
 void             msgpu_consensus_free(msgpu_consensus *c) { delete c; }
 
+msgpu_consensus *msgpu_consensus_clone(const msgpu_consensus *c) { return c ? new (std::nothrow) msgpu_consensus(*c) : nullptr; }
+
 // updateConsensusBase(oldSequence, oldBorders, newSequence, newBorders)
 int msgpu_consensus_update(msgpu_consensus *c, const msgpu_copy *seg, uint32_t n, int32_t new_lo, int32_t new_hi) {
   if (!c || (n && !seg)) return MSGPU_E_ARG;

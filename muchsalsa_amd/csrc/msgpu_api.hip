@@ -265,6 +265,7 @@ const char *msgpu_strerror(int code) {
   case MSGPU_E_STATE: return "entry points called out of order";
   case MSGPU_E_IDS: return "read ids are not in Registry (first-line) order";
   case MSGPU_E_NODEVICE: return "no HIP device (libmsgpu has no CPU fallback)";
+  case MSGPU_E_LAYOUT: return "path cannot be assembled (the reference would terminate or hang on it)";
   default: return "unknown error";
   }
 }

@@ -14,6 +14,7 @@
 #include <new>
 #include <vector>
 
+#include "asm_internal.h"
 #include "msgpu.h"
 #include "msgpu_internal.h"
 
@@ -104,6 +105,57 @@ __global__ __launch_bounds__(256) void k_gather(const msgpu_copy *pieces, const 
         const uint32_t k = static_cast<uint32_t>(q - A[u]);
         out[q]           = static_cast<uint8_t>(w[k >> 2] >> (8 * (k & 3)));
       }
+    }
+  }
+}
+
+// FASTA wrapping (limitLength, ap.cpp:61-76): text record = header, the bases in lines of 60 separated by '\n', '\n'.
+// One wavefront per 1 KiB of text, 16 output bytes per lane, one aligned 16-B store; chunk_map as in k_gather.
+constexpr uint32_t FLINE = 60;
+
+__global__ __launch_bounds__(256) void k_fasta_format(const msgpu_fasta_record *recs, const uint2 *chunk_map,
+                                                      uint64_t n_chunks, const uint8_t *raw, const uint8_t *headers,
+                                                      uint8_t *text) {
+  const uint64_t chunk = static_cast<uint64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  if (chunk >= n_chunks) return;
+  const int                lane = threadIdx.x & 63;
+  const uint2              cm   = chunk_map[chunk];
+  const msgpu_fasta_record rc   = recs[cm.x];
+  const uint64_t body = rc.len + (rc.len ? (rc.len - 1) / FLINE : 0); // bases + inner newlines
+  const uint64_t t0 = rc.text_off, t1 = t0 + rc.header_len + body + 1;
+  const uint64_t A  = (t0 & ~15ull) + static_cast<uint64_t>(cm.y) * GCHUNK + lane * 16ull;
+  const uint64_t qlo = A > t0 ? A : t0, qhi = (A + 16 < t1) ? A + 16 : t1;
+  if (qlo >= qhi) return;
+  uint32_t w[4] = {0, 0, 0, 0};
+  uint64_t j    = qlo - t0; // position inside the record's text
+  // position inside the body -> (line, column); advanced incrementally (at most one line break per 16 bytes)
+  uint64_t b = j > rc.header_len ? j - rc.header_len : 0;
+  uint64_t line = b / (FLINE + 1);
+  uint32_t col  = static_cast<uint32_t>(b - line * (FLINE + 1));
+  const uint8_t *src = raw + rc.raw_off;
+  for (uint64_t q = qlo; q < qhi; ++q, ++j) {
+    uint8_t c;
+    if (j < rc.header_len) {
+      c = headers[rc.header_off + j];
+    } else {
+      if (j - rc.header_len == body || col == FLINE) {
+        c = '\n';
+        col = 0;
+        ++line;
+      } else {
+        c = src[line * FLINE + col];
+        ++col;
+      }
+    }
+    const uint32_t k = static_cast<uint32_t>(q - A);
+    w[k >> 2] |= static_cast<uint32_t>(c) << (8 * (k & 3));
+  }
+  if (qlo == A && qhi == A + 16) {
+    *reinterpret_cast<uint4 *>(text + A) = make_uint4(w[0], w[1], w[2], w[3]);
+  } else {
+    for (uint64_t q = qlo; q < qhi; ++q) {
+      const uint32_t k = static_cast<uint32_t>(q - A);
+      text[q]          = static_cast<uint8_t>(w[k >> 2] >> (8 * (k & 3)));
     }
   }
 }
@@ -336,6 +388,118 @@ int msgpu_gather_run(msgpu_seqctx *c, const msgpu_gather_plan *pl, void *d_out, 
                      static_cast<const msgpu_copy *>(pl->d_pieces), static_cast<const uint2 *>(pl->d_chunk_map),
                      pl->n_chunks, b0, b1, static_cast<uint8_t *>(d_out));
   SHIP(c, hipGetLastError());
+  return MSGPU_OK;
+}
+
+uint64_t msgpu_fasta_text_bytes(uint32_t header_len, uint64_t len) {
+  return header_len + len + (len ? (len - 1) / FLINE : 0) + 1;
+}
+
+int msgpu_fasta_format(msgpu_seqctx *c, const void *d_raw, const msgpu_fasta_record *records, size_t n,
+                       const char *headers, size_t headers_bytes, void *d_text, uint64_t text_capacity,
+                       void *hip_stream) {
+  if (!c || (n && (!records || !d_text)) || (headers_bytes && !headers) || n >= 0xfffffff0ull) return MSGPU_E_ARG;
+  if (c->device < 0) return MSGPU_E_NODEVICE;
+  SHIP(c, hipSetDevice(c->device));
+  if (!n) return MSGPU_OK;
+  std::vector<uint32_t> cmap;
+  uint64_t              chunks = 0;
+  try {
+    for (size_t i = 0; i < n; ++i) {
+      const msgpu_fasta_record &r = records[i];
+      if (static_cast<uint64_t>(r.header_off) + r.header_len > headers_bytes) return MSGPU_E_ARG;
+      if (r.len && !d_raw) return MSGPU_E_ARG;
+      const uint64_t t1 = r.text_off + msgpu_fasta_text_bytes(r.header_len, r.len);
+      if (t1 > text_capacity) return MSGPU_E_ARG; // never write outside the text buffer
+      const uint64_t k = (t1 - (r.text_off & ~15ull) + GCHUNK - 1) / GCHUNK;
+      if (chunks + k >= 0x1fffffffcull) return MSGPU_E_ARG;
+      for (uint64_t q = 0; q < k; ++q) {
+        cmap.push_back(static_cast<uint32_t>(i));
+        cmap.push_back(static_cast<uint32_t>(q));
+      }
+      chunks += k;
+    }
+  } catch (std::bad_alloc const &) { return MSGPU_E_NOMEM; }
+  hipStream_t st = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->stream;
+  void       *d_recs = nullptr, *d_map = nullptr, *d_hdr = nullptr;
+  hipError_t  e = hipMalloc(&d_recs, n * sizeof(msgpu_fasta_record));
+  if (e == hipSuccess) e = hipMalloc(&d_map, chunks * 8);
+  if (e == hipSuccess) e = hipMalloc(&d_hdr, headers_bytes ? headers_bytes : 1);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_recs, records, n * sizeof(msgpu_fasta_record), hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_map, cmap.data(), chunks * 8, hipMemcpyHostToDevice, st);
+  if (e == hipSuccess && headers_bytes) e = hipMemcpyAsync(d_hdr, headers, headers_bytes, hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(k_fasta_format, dim3(static_cast<uint32_t>((chunks + 3) / 4)), dim3(256), 0, st,
+                       static_cast<const msgpu_fasta_record *>(d_recs), static_cast<const uint2 *>(d_map), chunks,
+                       static_cast<const uint8_t *>(d_raw), static_cast<const uint8_t *>(d_hdr),
+                       static_cast<uint8_t *>(d_text));
+    e = hipGetLastError();
+  }
+  // the staging buffers are pageable-host copies + device scratch: wait before they go out of scope
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  if (d_recs) (void)hipFree(d_recs);
+  if (d_map) (void)hipFree(d_map);
+  if (d_hdr) (void)hipFree(d_hdr);
+  if (e != hipSuccess) return sfail(c, e == hipErrorOutOfMemory ? MSGPU_E_NOMEM : MSGPU_E_HIP, "fasta format", e);
+  return MSGPU_OK;
+}
+
+// gather every piece of every path once, wrap targets and queries into FASTA text on the device, copy the texts back
+int msgpu_assembly_finish(msgpu_assembly *a, void *hip_stream) {
+  if (!a) return MSGPU_E_ARG;
+  if (a->finished) return MSGPU_OK;
+  msgpu_seqctx *c = a->ctx;
+  if (c->device < 0) return MSGPU_E_NODEVICE;
+  SHIP(c, hipSetDevice(c->device));
+  hipStream_t st = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->stream;
+  std::vector<msgpu_fasta_record> trec, qrec;
+  std::string                     hdr;
+  uint64_t                        t_bytes = 0, q_bytes = 0;
+  try {
+    for (const msgpu_path_info &p : a->paths) {
+      if (p.target_len > 0xffffffffull) return MSGPU_E_ARG;
+      const std::string h = msgpu::target_header(p.asm_idx);
+      trec.push_back(msgpu_fasta_record{p.target_raw_off, t_bytes, static_cast<uint32_t>(p.target_len),
+                                        static_cast<uint32_t>(hdr.size()), static_cast<uint32_t>(h.size()), 0});
+      hdr += h;
+      t_bytes += msgpu_fasta_text_bytes(static_cast<uint32_t>(h.size()), p.target_len);
+      for (uint32_t q = p.query_begin; q < p.query_end; ++q) {
+        const msgpu_query_info &qi = a->queries[q];
+        const std::string       qh = msgpu::query_header(qi.kind, p.asm_idx, q - p.query_begin);
+        qrec.push_back(msgpu_fasta_record{qi.raw_off, q_bytes, static_cast<uint32_t>(qi.len),
+                                          static_cast<uint32_t>(hdr.size()), static_cast<uint32_t>(qh.size()), 0});
+        hdr += qh;
+        q_bytes += msgpu_fasta_text_bytes(static_cast<uint32_t>(qh.size()), qi.len);
+      }
+    }
+    a->target_fa.resize(t_bytes);
+    a->query_fa.resize(q_bytes);
+  } catch (std::bad_alloc const &) { return MSGPU_E_NOMEM; }
+  msgpu_gather_plan *plan = nullptr;
+  int rc = msgpu_gather_plan_create(c, a->pieces.data(), a->pieces.size(), &plan);
+  if (rc != MSGPU_OK) return rc;
+  void      *d_raw = nullptr, *d_t = nullptr, *d_q = nullptr;
+  hipError_t e     = hipMalloc(&d_raw, a->raw_bytes + 64);
+  if (e == hipSuccess) e = hipMalloc(&d_t, t_bytes + 16);
+  if (e == hipSuccess) e = hipMalloc(&d_q, q_bytes + 16);
+  if (e == hipSuccess) {
+    rc = msgpu_gather_run(c, plan, d_raw, a->raw_bytes + 64, st);
+    if (rc == MSGPU_OK)
+      rc = msgpu_fasta_format(c, d_raw, trec.data(), trec.size(), hdr.data(), hdr.size(), d_t, t_bytes, st);
+    if (rc == MSGPU_OK)
+      rc = msgpu_fasta_format(c, d_raw, qrec.data(), qrec.size(), hdr.data(), hdr.size(), d_q, q_bytes, st);
+    if (rc == MSGPU_OK && t_bytes) e = hipMemcpyAsync(&a->target_fa[0], d_t, t_bytes, hipMemcpyDeviceToHost, st);
+    if (rc == MSGPU_OK && e == hipSuccess && q_bytes)
+      e = hipMemcpyAsync(&a->query_fa[0], d_q, q_bytes, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+  }
+  if (d_raw) (void)hipFree(d_raw);
+  if (d_t) (void)hipFree(d_t);
+  if (d_q) (void)hipFree(d_q);
+  msgpu_gather_plan_free(plan);
+  if (e != hipSuccess) return sfail(c, e == hipErrorOutOfMemory ? MSGPU_E_NOMEM : MSGPU_E_HIP, "assembly finish", e);
+  if (rc != MSGPU_OK) return rc;
+  a->finished = true;
   return MSGPU_OK;
 }
 

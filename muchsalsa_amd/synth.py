@@ -54,6 +54,14 @@ def read_layout(n_reads, read_len, seed, coverage=10):
     return G, r_start, r_fwd
 
 
+def anchor_layout(n_reads, read_len, n_anchors, seed, coverage=10):
+    """(anchor starts, anchor lengths) on the genome -- the same draws paf_table() makes."""
+    G = max(int(n_reads) * int(read_len) // int(coverage), read_len + 1500)
+    a_len = _randint(seed, 1, n_anchors, 500, 1500)
+    a_start = _randint(seed, 2, n_anchors, 0, G - a_len)
+    return a_start, a_len
+
+
 def genome_bases(G, seed):
     """Uniform ACGT genome of length G as a uint8 array (32 bases per splitmix64 draw)."""
     u = splitmix64(seed, 8, (G + 31) // 32)
@@ -62,7 +70,7 @@ def genome_bases(G, seed):
     return np.frombuffer(b"ACGT", dtype=np.uint8)[codes]
 
 
-def paf_table(n_reads, read_len, n_anchors, seed, coverage=10, min_intersection=420):
+def paf_table(n_reads, read_len, n_anchors, seed, coverage=10, min_intersection=420, jitter=15):
     """PAF-level columns of the synthetic alignment set (before the reference's filter)."""
     G = max(int(n_reads) * int(read_len) // int(coverage), read_len + 1500)
     a_len = _randint(seed, 1, n_anchors, 500, 1500)
@@ -93,8 +101,8 @@ def paf_table(n_reads, read_len, n_anchors, seed, coverage=10, min_intersection=
     fwd = r_fwd[rid]
     t_lo = np.where(fwd, g_lo - r_start[rid], r_start[rid] + read_len - g_hi)
     t_hi = np.where(fwd, g_hi - r_start[rid], r_start[rid] + read_len - g_lo)
-    t_lo = np.maximum(0, t_lo + _randint(seed, 5, n, -15, 15))
-    t_hi = np.minimum(read_len, t_hi + _randint(seed, 6, n, -15, 15))
+    t_lo = np.maximum(0, t_lo + _randint(seed, 5, n, -jitter, jitter))
+    t_hi = np.minimum(read_len, t_hi + _randint(seed, 6, n, -jitter, jitter))
     nmatch = np.floor((q_hi - q_lo) * _uniform(seed, 7, n, 0.86, 0.97)).astype(np.int64)
     return {"qname_id": aid, "qlen": a_len[aid], "qstart": q_lo, "qend": q_hi, "strand": fwd, "tname_id": rid,
             "tlen": np.full(n, read_len, dtype=np.int64), "tstart": t_lo, "tend": t_hi, "nmatch": nmatch,

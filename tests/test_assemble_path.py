@@ -1,0 +1,226 @@
+"""assemblePath (ap.cpp:615-1362): the product's host layout (copy pieces, layout-only context, no GPU) against the
+Python restatement in oracle/ms_assemble_py.py, on chains of the synthetic workload and on fuzzed variants of them that
+reach every branch of the function (several EdgeOrders per path edge, kinks, split anchor cliques, flipped anchor
+pairs, equal nanopore ranges, detached anchor groups, reads without a sequence between anchors, contained reads)."""
+import copy
+
+import numpy as np
+import pytest
+
+from asmcases import World, revcomp
+from segcases import apply_pieces
+
+from muchsalsa_amd import _lib
+from muchsalsa_amd.assembly import Assembly
+from muchsalsa_amd.overlap import MsgpuError
+from muchsalsa_amd.sequences import ILLUMINA, NANOPORE, SeqFile, SeqStore
+
+
+@pytest.fixture(scope="module")
+def world(oracle, tmp_path_factory):
+    w = World(300, 5000, 1500, 7, jitter=15)
+    w.attach(oracle.overlap(w.rows))
+    d = tmp_path_factory.mktemp("asm")
+    for name, seqs in (("n.fa", w.nano), ("i.fa", w.illu)):
+        with open(d / name, "wb") as f:
+            for i in range(len(seqs)):
+                f.write(b">s%d\n" % i + seqs[i] + b"\n")
+    w.files = (SeqFile(str(d / "n.fa")), SeqFile(str(d / "i.fa")))
+    w.store = SeqStore(device=-1)  # layout-only: offsets and lengths, nothing can be gathered
+    w.store.upload(NANOPORE, w.files[0])
+    w.store.upload(ILLUMINA, w.files[1])
+    w.flat = (b"".join(w.nano[i] for i in range(len(w.nano))), b"".join(w.illu[i] for i in range(len(w.illu))))
+    return w
+
+
+def fuzz_case(w, rng, trial):
+    """One (path, steps, rows, vm, contains) input; modes documented inline."""
+    order = np.argsort(w.read_start)
+    s = int(order[rng.integers(0, len(order) - 20)])
+    path, steps = w.chain(s, max_len=int(rng.integers(2, 12)), flip_all=bool(rng.integers(0, 2)),
+                          dense=bool(rng.integers(0, 2)))
+    if len(path) < 2:
+        return None
+    path, steps = copy.deepcopy(path), copy.deepcopy(steps)
+    rows, vm, contains = w.rows, w.vm, {}
+    mode = int(rng.integers(0, 8))
+
+    def shrink(st):  # make overlaps of the same anchor on different path edges disjoint -> several cliques
+        for a in list(st["em"]):
+            if rng.integers(0, 3) == 0:
+                lo, hi = st["em"][a]
+                st["em"][a] = (lo, lo + (hi - lo) // 4) if rng.integers(0, 2) else (hi - (hi - lo) // 4, hi)
+
+    if mode == 1:  # arbitrary read directions
+        for p in path:
+            p["dir"] = bool(rng.integers(0, 2))
+    elif mode == 2:  # several EdgeOrders per path edge
+        for st in steps:
+            o = st["orders"][0]
+            for _ in range(int(rng.integers(1, 3))):
+                ids = list(o["ids"])
+                if len(ids) > 2 and rng.integers(0, 2):
+                    ids = ids[:len(ids) // 2 + 1]
+                if rng.integers(0, 2):
+                    ids = ids[::-1]
+                st["orders"].append({"ids": ids, "score": int(o["score"]) + int(rng.integers(-5, 6)), "base": o["base"]})
+    elif mode == 3:  # anchors that leave and come back -> kinks / modifiers
+        for st in steps:
+            for o in st["orders"]:
+                if len(o["ids"]) > 2 and rng.integers(0, 2):
+                    o["ids"] = [o["ids"][0], o["ids"][-1]]
+    elif mode == 4:
+        for st in steps:
+            shrink(st)
+    elif mode == 5:  # contained reads
+        for p in path:
+            c = w.contained_in(p["id"])
+            if c:
+                contains[p["id"]] = c
+    elif mode >= 6:  # nested (6) / equal (7) nanopore ranges on a read
+        rows = w.rows.copy()
+        on_path = {p["id"] for p in path}
+        idx = [i for i in range(len(rows)) if int(rows[i]["read_id"]) in on_path]
+        for i in idx:
+            if rng.integers(0, 3) == 0:
+                j = idx[rng.integers(0, len(idx))]
+                if rows[j]["read_id"] == rows[i]["read_id"]:
+                    if mode == 6:
+                        rows[i]["n_lo"] = rows[j]["n_lo"] + 5
+                        rows[i]["n_hi"] = max(rows[j]["n_hi"] - 5, rows[i]["n_lo"] + 10)
+                    else:
+                        rows[i]["n_lo"], rows[i]["n_hi"] = rows[j]["n_lo"], rows[j]["n_hi"]
+        vm = {(int(r["read_id"]), int(r["anchor_id"])): r for r in rows}
+        if rng.integers(0, 2):
+            for st in steps:
+                shrink(st)
+    return path, steps, rows, vm, contains
+
+
+def compare(w, asm, r, path_idx=0):
+    raw = apply_pieces(asm.pieces, w.flat, revcomp)
+    p, qs = asm.paths[path_idx], asm.queries
+    qs = qs[int(p["query_begin"]):int(p["query_end"])]
+    assert raw[int(p["target_raw_off"]): int(p["target_raw_off"]) + int(p["target_len"])] == r["target"]
+    assert (int(p["n_anchors"]), int(p["n_anchor_edges"])) == (r["n_anchors"], r["n_anchor_edges"])
+    assert (int(p["border_lo"]), int(p["border_hi"])) == r["borders"]
+    assert len(qs) == len(r["queries"])
+    for q, (name, seq, lb, rb) in zip(qs, r["queries"]):
+        assert raw[int(q["raw_off"]): int(q["raw_off"]) + int(q["len"])] == seq, name
+        assert (int(q["lb"]), int(q["rb"])) == (lb, rb), name
+        assert name.startswith(("Middle", "Left", "Right", "Contain_Illumina_Match", "Contain_Nano_Middle")[int(q["kind"])].encode())
+
+
+def test_chains_match_oracle_and_paf_text(world):
+    from oracle.ms_assemble_py import assemble_path
+    w = world
+    order = np.argsort(w.read_start)
+    asm, want = Assembly(w.store), []
+    for k, s in enumerate(order[:60:4]):
+        for flip in (False, True):
+            path, steps = w.chain(int(s), max_len=8, flip_all=flip)
+            if len(path) < 2:
+                continue
+            want.append(assemble_path(path, steps, w.vm, {}, w.nano, w.illu, k))
+            asm.add_path(path, steps, w.rows, None, k)
+    assert len(want) >= 20
+    for i, r in enumerate(want):
+        compare(w, asm, r, i)
+    assert asm.text(2) == b"".join(r["paf"] for r in want)  # temp_1.align.paf, path order
+    with pytest.raises(MsgpuError) as e:  # no device behind this context: the bases cannot be produced
+        asm.finish()
+    assert e.value.code == _lib.E_NODEVICE
+
+
+def test_fuzzed_paths_match_oracle_every_branch(world):
+    from oracle.ms_assemble_py import AssemblyError, assemble_path
+    w = world
+    rng = np.random.default_rng(5)
+    cover, n_ok, n_err = {}, 0, 0
+    for trial in range(500):
+        case = fuzz_case(w, rng, trial)
+        if case is None:
+            continue
+        path, steps, rows, vm, contains = case
+        ocont = {k: [dict(nano=c["nano"], dir=c["dir"], matches=c["matches"]) for c in v] for k, v in contains.items()}
+        pcont = {k: [dict(nano=c["nano"], dir=c["dir"], anchors=list(c["matches"])) for c in v]
+                 for k, v in contains.items()}
+        try:
+            r = assemble_path(path, steps, vm, ocont, w.nano, w.illu, trial)
+        except (AssemblyError, KeyError, IndexError):
+            r = None  # the reference terminates / hangs / reads past a container on this input
+        asm = Assembly(w.store)
+        if r is None:
+            with pytest.raises(MsgpuError) as e:
+                asm.add_path(path, steps, rows, pcont, trial)
+            assert e.value.code in (_lib.E_LAYOUT, _lib.E_ARG), "trial %d" % trial
+            assert len(asm.paths) == 0 and asm.raw_bytes == 0  # a rejected path leaves nothing behind
+            n_err += 1
+            continue
+        asm.add_path(path, steps, rows, pcont, trial)
+        compare(w, asm, r)
+        assert asm.text(2) == r["paf"]
+        for k, v in r["cover"].items():
+            cover[k] = cover.get(k, 0) + (v > 0)
+        n_ok += 1
+    assert n_ok > 250 and n_err > 20
+    for k in ("multi_order", "kinks", "multi_clique", "flips", "nr_ties", "extra_groups", "dup_edges", "no_seq",
+              "contain_records"):
+        assert cover.get(k, 0) > 0, "branch %s never exercised: %r" % (k, cover)
+
+
+def test_contig_of_exact_reads_is_the_genome_up_to_joint_duplicates(oracle, world):
+    """Size-independent property: with error-free reads and exact PAF coordinates the contig is the genome span of the
+    path except for the bases the reference's inclusive slices duplicate at every joint (SequenceUtils.cpp:27-38)."""
+    from oracle.ms_assemble_py import assemble_path
+    w = World(300, 5000, 1500, 7, jitter=0)
+    w.attach(oracle.overlap(w.rows))
+    order = np.argsort(w.read_start)
+    for flip in (False, True):
+        path, steps = w.chain(int(order[3]), max_len=10, flip_all=flip)
+        r = assemble_path(path, steps, w.vm, {}, w.nano, w.illu, 1)
+        lo = min(w.read_start[p["id"]] for p in path)
+        hi = max(w.read_start[p["id"]] for p in path) + w.read_len
+        t = revcomp(r["target"]) if flip else r["target"]
+        d = oracle.edit_distance(t, w.genome[lo:hi], 400)
+        assert d <= 6 * r["n_anchors"], (d, r["n_anchors"])  # ~4 duplicated bases per placed anchor
+        assert abs(len(t) - (hi - lo)) == d  # pure insertions
+
+
+def test_two_reads_one_anchor_by_hand(world):
+    """Smallest path: both reads carry one common anchor -> one anchor vertex, no DAG edge; the contig is
+    Left(longest) + anchor + Right(longest) (ap.cpp:886-895, 1012-1032)."""
+    from oracle.ms_assemble_py import assemble_path
+    from oracle.ms_oracle_py import (get_anchor_sequence, get_sequence_left_of_anchor, get_sequence_right_of_anchor,
+                                     str_slice)
+    w = world
+    order = np.argsort(w.read_start)
+    path, steps = w.chain(int(order[5]), max_len=2)
+    a = steps[0]["orders"][0]["ids"][0]
+    steps = [{"orders": [dict(steps[0]["orders"][0], ids=[a])], "em": steps[0]["em"]}]
+    r = assemble_path(path, steps, w.vm, {}, w.nano, w.illu, 3)
+    ov = steps[0]["em"][a]
+    anchor = get_anchor_sequence(w.vm[(path[0]["id"], a)], w.illu[a], ov, path[0]["dir"])
+    lefts = [get_sequence_left_of_anchor(w.vm[(p["id"], a)], w.nano[p["id"]], w.illu[a], p["len"], ov, p["dir"])
+             for p in path]
+    rights = [get_sequence_right_of_anchor(w.vm[(p["id"], a)], w.nano[p["id"]], w.illu[a], p["len"], ov, p["dir"])
+              for p in path]
+    left, right = max(lefts, key=len), max(rights, key=len)
+    # updateConsensusBase: strSlice(new, 0, old_lo - new_lo) is inclusive, so one base more than the gap is taken
+    want = str_slice(left, 0, len(left)) + anchor + str_slice(right, -len(right), len(right))
+    assert r["target"] == want
+    assert r["n_anchors"] == 1 and r["n_anchor_edges"] == 0
+    asm = Assembly(w.store)
+    asm.add_path(path, steps, w.rows, None, 3)
+    compare(w, asm, r)
+
+
+def test_limit_length_and_headers():
+    from oracle.ms_assemble_py import limit_length
+    assert limit_length(b"") == b""
+    assert limit_length(b"A" * 60) == b"A" * 60
+    assert limit_length(b"A" * 61) == b"A" * 60 + b"\n" + b"A"
+    assert limit_length(b"A" * 120) == b"A" * 60 + b"\n" + b"A" * 60
+    L = _lib.lib()
+    for n in (0, 1, 59, 60, 61, 120, 121, 6001):
+        assert L.msgpu_fasta_text_bytes(5, n) == 5 + len(limit_length(b"A" * n)) + 1
