@@ -154,6 +154,92 @@ def consensus_leg(torch, dev, world, rank, w, steps, warmup):
             "bases_this_rank": bases_mine, "verified": ok}
 
 
+def assemble_leg(torch, dev, w, rows, read_names, anchor_names, tables, window_mb, verify_paths):
+    """assemblePath (A9) end to end on a bounded sample: every read starting in the first `window_mb` Mb of the synthetic
+    genome is chained into paths (muchsalsa_amd.synth.chain_paths, the stand-in for linearizeGraph) over the overlap
+    tables the timed steps just produced; then, timed: host layout of every path (msgpu_assembly_add_path) and ONE
+    gather + FASTA-wrapping pass on the device with the texts copied back (msgpu_assembly_finish).  The first
+    `verify_paths` paths are checked byte for byte against the Python restatement of ap.cpp (oracle/, checker only)."""
+    from muchsalsa_amd import sequences as S, synth
+    from muchsalsa_amd._lib import COPY_DTYPE, COPY_ILLUMINA, COPY_REVCOMP
+    from muchsalsa_amd.assembly import Assembly
+    n_reads, L, seed = w["n_reads"], w["read_len"], w["seed"]
+    G, r_start, r_fwd = synth.read_layout(n_reads, L, seed)
+    a_start, a_len = synth.anchor_layout(n_reads, L, w["n_anchors"], seed)
+    read_orig = np.array([int(n[1:]) for n in read_names])      # Registry id -> generator index
+    anchor_orig = np.array([int(n[1:]) for n in anchor_names])
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(seed)
+    genome = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)[
+        torch.randint(0, 4, (G,), device=dev, generator=gen)]
+    store = S.SeqStore(device=dev.index)
+    store.upload_device(S.ILLUMINA, genome.data_ptr(), G, [0], [G])
+    # the two stores, keyed by Registry id, cut out of the genome on the device
+    rs, rf = r_start[read_orig], r_fwd[read_orig]
+    mk = np.zeros(len(read_orig), dtype=COPY_DTYPE)
+    mk["src_off"], mk["dst_off"], mk["len"] = rs, np.arange(len(rs), dtype=np.uint64) * L, L
+    mk["flags"] = COPY_ILLUMINA | np.where(rf, 0, COPY_REVCOMP).astype(np.uint32)
+    d_reads = torch.empty(len(rs) * L, dtype=torch.uint8, device=dev)
+    store.run(store.plan(mk), d_reads.data_ptr(), d_reads.numel())
+    al = a_len[anchor_orig].astype(np.uint64)
+    aoff = np.concatenate([[0], np.cumsum(al)[:-1]]).astype(np.uint64)
+    mk = np.zeros(len(anchor_orig), dtype=COPY_DTYPE)
+    mk["src_off"], mk["dst_off"], mk["len"], mk["flags"] = a_start[anchor_orig], aoff, al, COPY_ILLUMINA
+    d_anch = torch.empty(int(al.sum()), dtype=torch.uint8, device=dev)
+    store.run(store.plan(mk), d_anch.data_ptr(), d_anch.numel())
+    store.synchronize()
+    store.upload_device(S.NANOPORE, d_reads.data_ptr(), d_reads.numel(), np.arange(len(rs), dtype=np.uint64) * L,
+                        np.full(len(rs), L, dtype=np.uint64))
+    store.upload_device(S.ILLUMINA, d_anch.data_ptr(), d_anch.numel(), aoff, al)
+    del d_reads, d_anch
+
+    t0 = time.perf_counter()
+    paths = synth.chain_paths(tables, rs, rf, L, int(window_mb * 1e6), max_reads=12)
+    t_paths = time.perf_counter() - t0
+    asm = Assembly(store)
+    t0 = time.perf_counter()
+    asm.set_rows(rows)
+    t_index = time.perf_counter() - t0
+    prepared = [Assembly.prepare(p, st, None, None, i) for i, (p, st) in enumerate(paths)]
+    threads = max(1, min(16, os.cpu_count() or 1))
+    t0 = time.perf_counter()
+    status = asm.add_prepared_batch(prepared, threads)
+    t_layout = time.perf_counter() - t0
+    assert not status.any(), "a synthetic chain was rejected: %r" % status
+    t0 = time.perf_counter()
+    asm.finish()
+    t_device = time.perf_counter() - t0
+    info, qinfo = asm.paths, asm.queries
+    T, Q = int(info["target_len"].sum()), int(qinfo["len"].sum())
+
+    ok = None
+    if verify_paths:
+        sys.path.insert(0, ROOT)
+        from oracle.ms_assemble_py import assemble_path, limit_length  # the checker
+        comp = bytes.maketrans(b"ACGT", b"TGCA")
+        g = genome.cpu().numpy()
+        tfa, qfa, paf = asm.text(0), asm.text(1), asm.text(2)
+        want_t = want_q = want_p = b""
+        for i, (p, st) in enumerate(paths[:verify_paths]):
+            nano, illu, vm = {}, {}, {}
+            for rd in p:
+                b = g[int(rs[rd["id"]]): int(rs[rd["id"]]) + L].tobytes()
+                nano[rd["id"]] = b if rf[rd["id"]] else b.translate(comp)[::-1]
+                for r in rows[rows["read_id"] == rd["id"]]:
+                    vm[(int(r["read_id"]), int(r["anchor_id"]))] = r
+                    j = anchor_orig[int(r["anchor_id"])]
+                    illu[int(r["anchor_id"])] = g[int(a_start[j]): int(a_start[j]) + int(a_len[j])].tobytes()
+            r = assemble_path(p, st, vm, {}, nano, illu, i)
+            want_t, want_q, want_p = want_t + r["target_fa"], want_q + r["query_fa"], want_p + r["paf"]
+        ok = tfa.startswith(want_t) and qfa.startswith(want_q) and paf.startswith(want_p) and len(want_t) > 0
+    store.close()
+    return {"paths": len(paths), "reads_on_paths": int(sum(len(p) for p, _ in paths)), "target_bases": T,
+            "query_bases": Q, "queries": int(len(qinfo)), "pieces": int(len(asm.pieces)),
+            "layout_ms": 1e3 * t_layout, "layout_threads": threads, "device_ms": 1e3 * t_device, "row_index_ms": 1e3 * t_index,
+            "path_builder_ms_untimed": 1e3 * t_paths, "verified_paths": verify_paths, "verified": ok,
+            "text_bytes": len(asm.text(0)) + len(asm.text(1)) + len(asm.text(2)), "window_mb": window_mb}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -163,6 +249,8 @@ def main():
     ap.add_argument("--cpu-sample-reads", type=int, default=25_000,
                     help="reads in the CPU-baseline sample (0 disables the baseline leg)")
     ap.add_argument("--no-consensus", action="store_true", help="skip the consensus (sequence gather) leg")
+    ap.add_argument("--assemble-window-mb", type=float, default=10.0,
+                    help="assemblePath leg: chain the reads starting in the first this-many Mb of the genome (0 = skip)")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the N>1 exchange path (all-gather + merge) even at world size 1 (used by the GPU tests)")
     args = ap.parse_args()
@@ -192,7 +280,8 @@ def main():
         dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
 
     w = WORKLOADS[args.workload]
-    rows = synth.synth_rows(w["n_reads"], w["read_len"], w["n_anchors"], w["seed"])
+    rows, read_names, anchor_names = synth.accepted_rows(
+        synth.paf_table(w["n_reads"], w["read_len"], w["n_anchors"], w["seed"]))
     d_rows = torch.from_numpy(rows.view(np.uint8).copy()).to(dev)  # the accepted-row table, resident in HBM
     torch.cuda.synchronize()
 
@@ -266,6 +355,12 @@ def main():
     else:
         n_edges_total = int(c.n_edges)
 
+    asm_leg = None
+    if world == 1 and rank == 0 and args.assemble_window_mb > 0 and not args.no_consensus:
+        tables = ctx.tables()
+        ctx.close()
+        asm_leg = assemble_leg(torch, dev, w, rows, read_names, anchor_names, tables, args.assemble_window_mb, 3)
+        del tables
     cons = None
     if not args.no_consensus:
         ctx.close()  # give the arena back before the ~3 GB of sequence buffers
@@ -315,6 +410,12 @@ def main():
                              "traffic": PMC_TRAFFIC_BYTES.get((args.workload, world), {}).get("k_gather"),
                              "algorithmic_bytes_per_launch": int(gb * 1e9)},
             }
+        if asm_leg is not None:
+            tot_ms = asm_leg["layout_ms"] + asm_leg["device_ms"]
+            asm_leg["consensus_mbases_per_s"] = asm_leg["target_bases"] / (tot_ms * 1e-3) / 1e6
+            asm_leg["stage"] = ("assemblePath on a bounded sample: host layout of every path + one gather + FASTA "
+                                "wrapping + copy-back of target.fa/query.fa (layout_ms + device_ms)")
+            out["assemble_path"] = asm_leg
         if world == 1 and args.cpu_sample_reads > 0:
             out["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_sample_reads)
         os.write(real_stdout, (json.dumps(out) + "\n").encode())

@@ -354,8 +354,8 @@ typedef struct msgpu_path_input {
   const uint32_t         *ids;       /* id pool of the orders                                               */
   const uint32_t         *em_off;    /* n_reads entries: EdgeMatches of path edge i                         */
   const msgpu_path_em    *ems;
-  const msgpu_row        *rows;      /* MatchMap::getVertexMatch source: every (read, anchor) row of the path's */
-  size_t                  n_rows;    /*   reads and of the contained reads (any order, lowest line per pair)  */
+  const msgpu_row        *rows;      /* MatchMap::getVertexMatch source: the (read, anchor) rows of the path's reads */
+  size_t                  n_rows;    /*   and of the contained reads (any order); optional after msgpu_assembly_set_rows */
   const msgpu_path_contain *contains;
   uint32_t                n_contains;
   uint32_t                pad;
@@ -388,8 +388,15 @@ typedef struct msgpu_query_info {
 int         msgpu_assembly_create(msgpu_seqctx *ctx, msgpu_assembly **out);
 void        msgpu_assembly_free(msgpu_assembly *a);
 const char *msgpu_assembly_last_error(const msgpu_assembly *a);
+/* Install the VertexMatch table once (MatchMap::getVertexMatch for every later path; copied, n_rows < 2^32).  A path's
+ * own msgpu_path_input.rows, when given, are looked up first. */
+int msgpu_assembly_set_rows(msgpu_assembly *a, const msgpu_row *rows, size_t n_rows);
 /* MSGPU_E_LAYOUT leaves the assembly unchanged (the path is skipped). */
 int      msgpu_assembly_add_path(msgpu_assembly *a, const msgpu_path_input *in);
+/* The assemblePaths fan-out (src/main.cpp:620-677): n paths laid out by n_threads host threads, appended in input
+ * order.  status (optional, n entries) receives each path's result; MSGPU_E_LAYOUT paths are skipped.  Returns the
+ * first status that is neither MSGPU_OK nor MSGPU_E_LAYOUT, else MSGPU_OK. */
+int msgpu_assembly_add_paths(msgpu_assembly *a, const msgpu_path_input *in, size_t n, uint32_t n_threads, int *status);
 uint32_t msgpu_assembly_path_count(const msgpu_assembly *a);
 uint32_t msgpu_assembly_query_count(const msgpu_assembly *a);
 int      msgpu_assembly_path_info(const msgpu_assembly *a, uint32_t path, msgpu_path_info *out);

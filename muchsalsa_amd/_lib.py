@@ -136,7 +136,9 @@ SYMBOLS = [
     ("msgpu_assembly_create", C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     ("msgpu_assembly_free", None, [C.c_void_p]),
     ("msgpu_assembly_last_error", C.c_char_p, [C.c_void_p]),
+    ("msgpu_assembly_set_rows", C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     ("msgpu_assembly_add_path", C.c_int, [C.c_void_p, C.POINTER(PathInput)]),
+    ("msgpu_assembly_add_paths", C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p]),
     ("msgpu_assembly_path_count", C.c_uint32, [C.c_void_p]),
     ("msgpu_assembly_query_count", C.c_uint32, [C.c_void_p]),
     ("msgpu_assembly_path_info", C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p]),

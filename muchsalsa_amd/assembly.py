@@ -43,7 +43,28 @@ class Assembly:
         if rc != 0:
             raise MsgpuError(rc, (self._L.msgpu_assembly_last_error(self._h) or b"").decode())
 
+    def set_rows(self, rows):
+        """install the VertexMatch table once; later paths may pass rows=None"""
+        rows = np.ascontiguousarray(rows, dtype=ROW_DTYPE)
+        self._check(self._L.msgpu_assembly_set_rows(self._h, rows.ctypes.data if len(rows) else None, len(rows)))
+
     def add_path(self, path, steps, rows, contains=None, asm_idx=1):
+        self.add_prepared(self.prepare(path, steps, rows, contains, asm_idx))
+
+    def add_prepared(self, prepared):
+        """msgpu_assembly_add_path on an input marshalled by prepare() (so callers can time the layout alone)"""
+        self._check(self._L.msgpu_assembly_add_path(self._h, C.byref(prepared[0])))
+
+    def add_prepared_batch(self, prepared, n_threads=1):
+        """msgpu_assembly_add_paths: layouts on n_threads host threads, appended in order -> per-path status codes"""
+        arr = (PathInput * len(prepared))(*[p[0] for p in prepared])
+        status = np.zeros(len(prepared), dtype=np.int32)
+        self._check(self._L.msgpu_assembly_add_paths(self._h, arr, len(prepared), int(n_threads), status.ctypes.data))
+        return status
+
+    @staticmethod
+    def prepare(path, steps, rows, contains=None, asm_idx=1):
+        """dict/list description of one path -> (msgpu_path_input, the arrays it points into)"""
         n = len(path)
         reads = np.zeros(n, dtype=PATH_READ_DTYPE)
         for i, p in enumerate(path):
@@ -60,7 +81,7 @@ class Assembly:
         orders = np.array(orders, dtype=PATH_ORDER_DTYPE) if orders else np.zeros(0, dtype=PATH_ORDER_DTYPE)
         ems = np.array(ems, dtype=PATH_EM_DTYPE) if ems else np.zeros(0, dtype=PATH_EM_DTYPE)
         ids = np.asarray(ids, dtype="<u4")
-        rows = np.ascontiguousarray(rows, dtype=ROW_DTYPE)
+        rows = np.ascontiguousarray(rows if rows is not None else np.zeros(0, dtype=ROW_DTYPE), dtype=ROW_DTYPE)
         cont, canch = [], []
         for host, lst in (contains or {}).items():
             for ce in lst:
@@ -74,7 +95,7 @@ class Assembly:
 
         inp = PathInput(reads.ctypes.data, n, int(asm_idx), order_off.ctypes.data, ptr(orders), ptr(ids),
                         em_off.ctypes.data, ptr(ems), ptr(rows), len(rows), ptr(cont), len(cont), 0, ptr(canch))
-        self._check(self._L.msgpu_assembly_add_path(self._h, C.byref(inp)))
+        return inp, (reads, order_off, em_off, orders, ids, ems, rows, cont, canch)
 
     @property
     def paths(self):

@@ -11,12 +11,16 @@
 // Iteration orders the reference leaves to std::unordered_* are fixed as: vertices ascending id, anchor-DAG edges in
 // creation order, successors / predecessors ascending id, tap entries ascending id, std::sort ties stable.
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstring>
 #include <map>
 #include <new>
 #include <set>
 #include <stdexcept>
+#include <string>
+#include <system_error>
+#include <thread>
 #include <tuple>
 #include <unordered_map>
 #include <vector>
@@ -155,6 +159,7 @@ std::vector<uint32_t> ramsey(const std::map<uint32_t, std::set<uint32_t>> &adj, 
 struct PathLayout {
   msgpu_seqctx           *ctx;
   const msgpu_path_input &in;
+  const msgpu_assembly   *shared = nullptr; // rows installed once with msgpu_assembly_set_rows
   std::unordered_map<uint64_t, const msgpu_row *> vm;
   std::unordered_map<uint32_t, uint32_t>          dir_of; // read id -> direction
   std::vector<std::map<uint32_t, Ov>>             em;     // per path edge: anchor -> overlap
@@ -162,10 +167,14 @@ struct PathLayout {
   PathLayout(msgpu_seqctx *c, const msgpu_path_input &i) : ctx(c), in(i) {}
 
   const msgpu_row *row(uint32_t read, uint32_t anchor) const {
-    auto it = vm.find((static_cast<uint64_t>(read) << 32) | anchor);
-    if (it == vm.end())
-      throw LayoutError("no VertexMatch for read " + std::to_string(read) + " on anchor " + std::to_string(anchor));
-    return it->second;
+    const uint64_t key = (static_cast<uint64_t>(read) << 32) | anchor;
+    auto           it  = vm.find(key);
+    if (it != vm.end()) return it->second;
+    if (shared) {
+      auto lo = std::lower_bound(shared->row_keys.begin(), shared->row_keys.end(), key);
+      if (lo != shared->row_keys.end() && *lo == key) return &shared->rows[static_cast<size_t>(lo - shared->row_keys.begin())];
+    }
+    throw LayoutError("no VertexMatch for read " + std::to_string(read) + " on anchor " + std::to_string(anchor));
   }
   static bool mdir(const msgpu_row *m) { return (m->flags & MSGPU_ROW_DIR) != 0; }
   static void check(int rc) {
@@ -290,8 +299,10 @@ struct PathResult {
   int                 left_most = 0;
 };
 
-PathResult layout_path(msgpu_seqctx *ctx, const msgpu_path_input &in) {
-  PathLayout L(ctx, in);
+PathResult layout_path(const msgpu_assembly *a, const msgpu_path_input &in) {
+  msgpu_seqctx *ctx = a->ctx;
+  PathLayout    L(ctx, in);
+  L.shared = a;
   const uint32_t n_reads = in.n_reads, n_edges = n_reads - 1;
   for (size_t i = 0; i < in.n_rows; ++i) { // MatchMap::addVertexMatch keeps the lowest line, MatchMap.cpp:64-80
     const uint64_t k = (static_cast<uint64_t>(in.rows[i].read_id) << 32) | in.rows[i].anchor_id;
@@ -730,24 +741,64 @@ int msgpu_assembly_create(msgpu_seqctx *ctx, msgpu_assembly **out) {
 void        msgpu_assembly_free(msgpu_assembly *a) { delete a; }
 const char *msgpu_assembly_last_error(const msgpu_assembly *a) { return a ? a->err : "null assembly"; }
 
-int msgpu_assembly_add_path(msgpu_assembly *a, const msgpu_path_input *in) {
-  if (!a || !in || !in->reads || !in->order_off || !in->em_off || (in->n_rows && !in->rows)) return MSGPU_E_ARG;
-  if (a->finished) return MSGPU_E_STATE;
-  a->err[0] = 0;
-  if (in->n_reads < 2) {
-    snprintf(a->err, sizeof(a->err), "a path needs at least two reads");
-    return MSGPU_E_LAYOUT;
-  }
+int msgpu_assembly_set_rows(msgpu_assembly *a, const msgpu_row *rows, size_t n_rows) {
+  if (!a || (n_rows && !rows)) return MSGPU_E_ARG;
+  try {
+    std::vector<uint32_t> order(n_rows);
+    for (size_t i = 0; i < n_rows; ++i) order[i] = static_cast<uint32_t>(i);
+    auto key = [&](uint32_t i) { return (static_cast<uint64_t>(rows[i].read_id) << 32) | rows[i].anchor_id; };
+    std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { // lowest line first: MatchMap.cpp:64-80
+      const uint64_t kx = key(x), ky = key(y);
+      return kx != ky ? kx < ky : rows[x].line < rows[y].line;
+    });
+    a->rows.resize(n_rows);
+    a->row_keys.resize(n_rows);
+    for (size_t i = 0; i < n_rows; ++i) {
+      a->rows[i]     = rows[order[i]];
+      a->row_keys[i] = key(order[i]);
+    }
+  } catch (std::bad_alloc const &) { return MSGPU_E_NOMEM; }
+  return MSGPU_OK;
+}
+
+namespace {
+
+int check_input(const msgpu_path_input *in) {
+  if (!in || !in->reads || !in->order_off || !in->em_off || (in->n_rows && !in->rows)) return MSGPU_E_ARG;
+  if (in->n_reads < 2) return MSGPU_E_LAYOUT;
   const uint32_t ne = in->n_reads - 1;
   if ((in->order_off[ne] && (!in->orders || !in->ids)) || (in->em_off[ne] && !in->ems) ||
       (in->n_contains && (!in->contains || !in->contain_anchors)))
     return MSGPU_E_ARG;
+  return MSGPU_OK;
+}
+
+// layout of one path; never throws.  msg receives the reason when the result is not MSGPU_OK.
+int try_layout(const msgpu_assembly *a, const msgpu_path_input *in, PathResult &r, std::string &msg) {
+  int rc = check_input(in);
+  if (rc == MSGPU_E_LAYOUT) msg = "a path needs at least two reads";
+  if (rc != MSGPU_OK) return rc;
   try {
-    PathResult r = layout_path(a->ctx, *in);
-    // commit: raw layout, records, PAF text
+    r = layout_path(a, *in);
+  } catch (LayoutError const &e) {
+    msg = e.what();
+    return MSGPU_E_LAYOUT;
+  } catch (ApiError const &e) {
+    msg = std::string(msgpu_strerror(e.code)) + " (" + msgpu_seq_last_error(a->ctx) + ")";
+    return e.code;
+  } catch (std::out_of_range const &e) {
+    msg = std::string("missing map entry (") + e.what() + ")";
+    return MSGPU_E_LAYOUT;
+  } catch (std::bad_alloc const &) { return MSGPU_E_NOMEM; }
+  return MSGPU_OK;
+}
+
+// append a laid-out path to the assembly: raw layout, records, PAF text (OutputWriter order = path order)
+int commit(msgpu_assembly *a, PathResult &r, int32_t asm_idx) {
+  try {
     r.info.target_raw_off = place(a, r.target);
     r.info.query_begin    = static_cast<uint32_t>(a->queries.size());
-    const std::string tname = "muchsalsa_" + std::to_string(in->asm_idx);
+    const std::string tname = "muchsalsa_" + std::to_string(asm_idx);
     uint32_t          qi    = 0;
     for (const Record &q : r.queries) {
       msgpu_query_info info{};
@@ -758,7 +809,7 @@ int msgpu_assembly_add_path(msgpu_assembly *a, const msgpu_path_input *in) {
       info.kind    = q.kind;
       info.path    = static_cast<uint32_t>(a->paths.size());
       a->queries.push_back(info);
-      std::string name = msgpu::query_header(q.kind, in->asm_idx, qi++);
+      std::string name = msgpu::query_header(q.kind, asm_idx, qi++);
       name             = name.substr(1, name.size() - 2); // without '>' and '\n'
       char line[512];
       const long long len = static_cast<long long>(q.seg.len), span = static_cast<long long>(q.rb - q.lb + 1);
@@ -769,17 +820,58 @@ int msgpu_assembly_add_path(msgpu_assembly *a, const msgpu_path_input *in) {
     }
     r.info.query_end = static_cast<uint32_t>(a->queries.size());
     a->paths.push_back(r.info);
-  } catch (LayoutError const &e) {
-    snprintf(a->err, sizeof(a->err), "%s", e.what());
-    return MSGPU_E_LAYOUT;
-  } catch (ApiError const &e) {
-    snprintf(a->err, sizeof(a->err), "%s (%s)", msgpu_strerror(e.code), msgpu_seq_last_error(a->ctx));
-    return e.code;
-  } catch (std::out_of_range const &e) {
-    snprintf(a->err, sizeof(a->err), "missing map entry (%s)", e.what());
-    return MSGPU_E_LAYOUT;
   } catch (std::bad_alloc const &) { return MSGPU_E_NOMEM; }
   return MSGPU_OK;
+}
+
+} // namespace
+
+int msgpu_assembly_add_path(msgpu_assembly *a, const msgpu_path_input *in) {
+  if (!a) return MSGPU_E_ARG;
+  if (a->finished) return MSGPU_E_STATE;
+  a->err[0] = 0;
+  PathResult  r;
+  std::string msg;
+  int         rc = try_layout(a, in, r, msg);
+  if (rc == MSGPU_OK) rc = commit(a, r, in->asm_idx);
+  if (rc != MSGPU_OK) snprintf(a->err, sizeof(a->err), "%s", msg.c_str());
+  return rc;
+}
+
+// The assemblePaths fan-out (src/main.cpp:620-677: one job per path on the ThreadPool): the layouts of n paths are
+// computed by n_threads host threads, then appended in input order.  status[i] (optional) = result for path i;
+// paths with MSGPU_E_LAYOUT are skipped.  Returns the first status that is neither MSGPU_OK nor MSGPU_E_LAYOUT.
+int msgpu_assembly_add_paths(msgpu_assembly *a, const msgpu_path_input *in, size_t n, uint32_t n_threads, int *status) {
+  if (!a || (n && !in)) return MSGPU_E_ARG;
+  if (a->finished) return MSGPU_E_STATE;
+  a->err[0] = 0;
+  if (!n_threads) n_threads = 1;
+  if (n_threads > n) n_threads = static_cast<uint32_t>(n ? n : 1);
+  std::vector<PathResult>  res;
+  std::vector<std::string> msg;
+  std::vector<int>         rc(n, MSGPU_OK);
+  try {
+    res.resize(n);
+    msg.resize(n);
+    std::atomic<size_t> next{0};
+    auto                work = [&]() {
+      for (size_t i = next.fetch_add(1); i < n; i = next.fetch_add(1)) rc[i] = try_layout(a, &in[i], res[i], msg[i]);
+    };
+    std::vector<std::thread> pool;
+    for (uint32_t t = 1; t < n_threads; ++t) pool.emplace_back(work);
+    work();
+    for (auto &t : pool) t.join();
+  } catch (std::bad_alloc const &) { return MSGPU_E_NOMEM; } catch (std::system_error const &) {
+    return MSGPU_E_NOMEM;
+  }
+  int first_bad = MSGPU_OK;
+  for (size_t i = 0; i < n; ++i) {
+    if (rc[i] == MSGPU_OK) rc[i] = commit(a, res[i], in[i].asm_idx);
+    if (status) status[i] = rc[i];
+    if (rc[i] != MSGPU_OK && a->err[0] == 0) snprintf(a->err, sizeof(a->err), "path %zu: %s", i, msg[i].c_str());
+    if (rc[i] != MSGPU_OK && rc[i] != MSGPU_E_LAYOUT && first_bad == MSGPU_OK) first_bad = rc[i];
+  }
+  return first_bad;
 }
 
 uint32_t msgpu_assembly_path_count(const msgpu_assembly *a) { return a ? static_cast<uint32_t>(a->paths.size()) : 0; }

@@ -156,6 +156,68 @@ def synth_rows(n_reads, read_len, n_anchors, seed, coverage=10):
     return rows
 
 
+ORD_DIR = 4  # msgpu_order.flags: EdgeOrder::direction
+
+
+def directed_step(tables, edge_idx, a, b, dir_a):
+    """EdgeOrders + EdgeMatches of the directed edge a -> b as getDirectedGraph fills it (dg.cpp:70-102): an order of
+    the undirected edge goes onto (start, end), swapped when exactly one of {!order.direction and base == b, !dir_a}."""
+    e = tables["edges"][edge_idx]
+    orders = []
+    for o in tables["orders"][int(e["order_off"]): int(e["order_off"]) + int(e["order_cnt"])]:
+        flip = (not (int(o["flags"]) & ORD_DIR) and int(o["base"]) == b) != (not dir_a)
+        start, end = (int(o["end"]), int(o["start"])) if flip else (int(o["start"]), int(o["end"]))
+        if (start, end) != (a, b):
+            continue
+        ids = tables["ids"][int(o["ids_off"]): int(o["ids_off"]) + int(o["ids_cnt"])]
+        orders.append({"ids": [int(x) for x in ids], "score": int(o["score"]), "base": int(o["base"])})
+    ems = tables["ems"][int(e["em_off"]): int(e["em_off"]) + int(e["em_cnt"])]
+    return {"orders": orders, "em": {int(m["anchor_id"]): (int(m["ov_lo"]), int(m["ov_hi"])) for m in ems}}
+
+
+def chain_paths(tables, read_start, read_fwd, read_len, window_end, max_reads=12, max_paths=1 << 30):
+    """Disjoint greedy left-to-right chains of reads starting before `window_end` on the synthetic genome.
+
+    Stands in for the phases between the overlap path and assemblePath (graph clean-up, getDirectedGraph,
+    linearizeGraph): consecutive reads share an overlap-graph edge with at least one
+    EdgeOrder pointing along the chain; read direction = its strand.  read_start / read_fwd are indexed by read id.
+    -> [(path, steps)] in the form muchsalsa_amd.assembly.Assembly.add_path takes."""
+    edges = tables["edges"]
+    inside = (read_start[edges["v1"]] < window_end) & (read_start[edges["v2"]] < window_end)
+    adj = {}
+    for i in np.nonzero(inside)[0]:
+        a, b = int(edges["v1"][i]), int(edges["v2"][i])
+        adj.setdefault(a, []).append((b, int(i)))
+        adj.setdefault(b, []).append((a, int(i)))
+    reads = [int(r) for r in np.argsort(read_start, kind="stable") if read_start[r] < window_end]
+    used, out, frontier = set(), [], -1
+    for s in reads:
+        if s in used or read_start[s] <= frontier or len(out) >= max_paths:
+            continue
+        path, steps, cur = [s], [], s
+        used.add(s)
+        while len(path) < max_reads:
+            best = None
+            for nb, ei in adj.get(cur, []):
+                if nb in used or read_start[nb] <= read_start[cur]:
+                    continue
+                if best is not None and read_start[nb] <= read_start[best[0]]:
+                    continue
+                st = directed_step(tables, ei, cur, nb, bool(read_fwd[cur]))
+                if st["orders"]:
+                    best = (nb, st)
+            if best is None:
+                break
+            path.append(best[0])
+            steps.append(best[1])
+            used.add(best[0])
+            cur = best[0]
+        if len(path) >= 2:
+            out.append(([{"id": r, "dir": bool(read_fwd[r]), "len": int(read_len)} for r in path], steps))
+            frontier = int(read_start[path[-1]])
+    return out
+
+
 # the configurations BASELINE.json names
 CONFIGS = {
     "cfg2": dict(n_reads=10_000, read_len=5_000, n_anchors=50_000, seed=42),

@@ -116,13 +116,14 @@ def test_chains_match_oracle_and_paf_text(world):
     w = world
     order = np.argsort(w.read_start)
     asm, want = Assembly(w.store), []
+    asm.set_rows(w.rows[::-1])  # any order: the table is indexed by (read, anchor, line)
     for k, s in enumerate(order[:60:4]):
         for flip in (False, True):
             path, steps = w.chain(int(s), max_len=8, flip_all=flip)
             if len(path) < 2:
                 continue
             want.append(assemble_path(path, steps, w.vm, {}, w.nano, w.illu, k))
-            asm.add_path(path, steps, w.rows, None, k)
+            asm.add_path(path, steps, None if flip else w.rows, None, k)  # flip: rows come from set_rows
     assert len(want) >= 20
     for i, r in enumerate(want):
         compare(w, asm, r, i)
@@ -167,6 +168,37 @@ def test_fuzzed_paths_match_oracle_every_branch(world):
     for k in ("multi_order", "kinks", "multi_clique", "flips", "nr_ties", "extra_groups", "dup_edges", "no_seq",
               "contain_records"):
         assert cover.get(k, 0) > 0, "branch %s never exercised: %r" % (k, cover)
+
+
+def test_batch_on_threads_equals_one_by_one(world):
+    """msgpu_assembly_add_paths (the assemblePaths fan-out): same records in the same order for any thread count; a
+    path the reference cannot assemble is reported and skipped."""
+    w = world
+    order = np.argsort(w.read_start)
+    cases = []
+    for k, s in enumerate(order[:120:5]):
+        path, steps = w.chain(int(s), max_len=9, dense=bool(k & 1))
+        if len(path) >= 2:
+            cases.append((path, steps))
+    bad = (cases[0][0], [dict(st, orders=[]) for st in cases[0][1]])  # no EdgeOrder on its edges
+    cases.insert(3, bad)
+    one = Assembly(w.store)
+    one.set_rows(w.rows)
+    for i, (p, st) in enumerate(cases):
+        if i == 3:
+            with pytest.raises(MsgpuError):
+                one.add_path(p, st, None, None, i)
+        else:
+            one.add_path(p, st, None, None, i)
+    for threads in (1, 4, 64):
+        many = Assembly(w.store)
+        many.set_rows(w.rows)
+        status = many.add_prepared_batch([Assembly.prepare(p, st, None, None, i) for i, (p, st) in enumerate(cases)],
+                                         threads)
+        assert list(np.nonzero(status)[0]) == [3] and status[3] == _lib.E_LAYOUT
+        assert many.text(2) == one.text(2)
+        assert many.pieces.tobytes() == one.pieces.tobytes()
+        assert many.paths.tobytes() == one.paths.tobytes() and many.queries.tobytes() == one.queries.tobytes()
 
 
 def test_contig_of_exact_reads_is_the_genome_up_to_joint_duplicates(oracle, world):
