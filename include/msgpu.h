@@ -216,6 +216,16 @@ int msgpu_merge_gathered(msgpu_ctx *ctx, const void *d_gathered, uint32_t world,
                          void *d_orders, void *d_ids);
 
 /* Block the host until everything queued on the context's stream has finished. */
+/* findContractionEdges (src/main.cpp:183-190, 416-463) with sanityCheck (libms/src/kernel/sc.cpp:29-90) -- the step
+ * that follows the chaining fan-out -- on an edge/order table resident in HBM.  contraction_order (host, n_edges
+ * entries): for every edge the index in the order table of its first contained & primary EdgeOrder that is sane against
+ * every non-shadow neighbour of the order's start vertex (what the reference inserts into `contractionEdges`), or -1.
+ * d_edges = d_orders = NULL: the context's own tables (single GPU, after msgpu_chaining_and_overlaps); otherwise any
+ * (v1, v2)-sorted edge table + its order table, e.g. the merged list of msgpu_merge_gathered; n_reads = max id + 1.
+ * Uses msgpu_params.wiggle_room.  Synchronous. */
+int msgpu_find_contraction_edges(msgpu_ctx *ctx, const void *d_edges, uint64_t n_edges, const void *d_orders,
+                                 uint64_t n_orders, uint32_t n_reads, int64_t *contraction_order);
+
 int msgpu_synchronize(msgpu_ctx *ctx);
 
 /* ==== sequence store + slice / reverse-complement / stitch kernel: device half of the "consensus" stage (A9) ========

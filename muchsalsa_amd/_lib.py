@@ -102,6 +102,8 @@ SYMBOLS = [
     ("msgpu_copy_reads", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     ("msgpu_merge_gathered", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_uint64,
                                        C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("msgpu_find_contraction_edges", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint32,
+                                               C.c_void_p]),
     ("msgpu_synchronize", C.c_int, [C.c_void_p]),
     ("msgpu_seq_parse", C.c_int, [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]),
     ("msgpu_seq_free", None, [C.c_void_p]),

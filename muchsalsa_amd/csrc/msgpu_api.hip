@@ -82,6 +82,7 @@ struct msgpu_ctx {
   uint64_t n_edges_fast = 0;
   DevBuf ems, order_scr, ids_scr, edge_norders, edge_nids, order_base, ids_base, orders, ids, big_list, big_elems,
       big_paths;
+  DevBuf g_deg, g_off, g_adj, g_cand, g_sane, g_out; // findContractionEdges
 
   // timing
   hipEvent_t ev[10] = {nullptr};
@@ -116,7 +117,7 @@ int fail(msgpu_ctx *c, int code, const char *fmt, ...) {
 template <class T> T *scalar(msgpu_ctx *c, int slot) { return reinterpret_cast<T *>(c->scalars.as<uint64_t>() + slot); }
 
 void release_all(msgpu_ctx *c) {
-  DevBuf *all[] = {&c->rows_in, &c->cnt_read, &c->first_key, &c->read_off, &c->cursor, &c->bkt_key, &c->bkt_idx,
+  DevBuf *all[] = {&c->g_deg, &c->g_off, &c->g_adj, &c->g_cand, &c->g_sane, &c->g_out, &c->rows_in, &c->cnt_read, &c->first_key, &c->read_off, &c->cursor, &c->bkt_key, &c->bkt_idx,
                    &c->bkt_dead, &c->by_read, &c->read_cnt, &c->alive_rank, &c->anchor_cnt, &c->anchor_off,
                    &c->anchor_first, &c->anchor_off_gen,
                    &c->bkt2_idx, &c->bkt2_line, &c->by_anchor, &c->read_len, &c->read_first, &c->scalars, &c->scan_tmp,
@@ -638,6 +639,55 @@ int msgpu_copy_reads(msgpu_ctx *c, int32_t *read_len, uint32_t *read_first_line)
     HIPCHK(c, hipMemcpyAsync(read_len, c->read_len.p, size_t(c->V) * 4, hipMemcpyDeviceToHost, c->stream));
   if (read_first_line && c->V)
     HIPCHK(c, hipMemcpyAsync(read_first_line, c->read_first.p, size_t(c->V) * 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return MSGPU_OK;
+}
+
+// findContractionEdges (src/main.cpp:183-190, 416-463) + sanityCheck (sc.cpp:29-90) over a resident edge/order table
+int msgpu_find_contraction_edges(msgpu_ctx *c, const void *d_edges, uint64_t n_edges, const void *d_orders,
+                                 uint64_t n_orders, uint32_t n_reads, int64_t *contraction_order) {
+  if (!c) return MSGPU_E_ARG;
+  if ((d_edges == nullptr) != (d_orders == nullptr)) return fail(c, MSGPU_E_ARG, "pass both tables or neither");
+  if (!d_edges) {
+    if (c->state < ST_CHAINED) return fail(c, MSGPU_E_STATE, "msgpu_find_contraction_edges before msgpu_chaining_and_overlaps");
+    if (c->nshards > 1)
+      return fail(c, MSGPU_E_STATE, "a shard holds only its own edges: pass the merged tables (msgpu_merge_gathered)");
+    d_edges  = c->edges.p;
+    d_orders = c->orders.p;
+    n_edges  = c->n_edges;
+    n_orders = c->n_orders;
+    n_reads  = c->V;
+  }
+  if (n_edges && !contraction_order) return MSGPU_E_ARG;
+  if (n_edges >= 0x7ffffff0ull || n_orders >= 0xfffffff0ull) return fail(c, MSGPU_E_ARG, "tables too large");
+  if (!n_edges) return MSGPU_OK;
+  HIPCHK(c, hipSetDevice(c->device));
+  const auto *edges  = static_cast<const msgpu_edge *>(d_edges);
+  const auto *orders = static_cast<const msgpu_order *>(d_orders);
+  const size_t V = n_reads;
+  ENSURE(c, g_deg, (2 * V + 2) * 4);                 // degree | cursor
+  ENSURE(c, g_off, (V + 2) * 8);
+  ENSURE(c, g_adj, 2 * n_edges * 4);
+  ENSURE(c, g_cand, (n_orders + 2) * 4);            // [0] = count, then the list
+  ENSURE(c, g_sane, n_orders + 1);
+  ENSURE(c, g_out, n_edges * 8);
+  ENSURE(c, scan_tmp, (size_t(scan_blocks(V + 1)) + 1) * 8);
+  ENSURE(c, scalars, SC_COUNT * 8);
+  uint32_t *deg = c->g_deg.as<uint32_t>(), *cursor = deg + V + 1;
+  uint64_t *off = c->g_off.as<uint64_t>();
+  uint32_t *cand = c->g_cand.as<uint32_t>();
+  HIPCHK(c, hipMemsetAsync(deg, 0, (2 * V + 2) * 4, c->stream));
+  HIPCHK(c, hipMemsetAsync(cand, 0, 4, c->stream));
+  HIPCHK(c, hipMemsetAsync(c->g_sane.p, 0, n_orders + 1, c->stream));
+  launch_degree(c->stream, edges, n_edges, deg);
+  exclusive_scan<uint64_t>(c->stream, deg, V + 1, off, c->scan_tmp.as<uint64_t>(), scalar<uint64_t>(c, SC_TOTAL_A));
+  launch_fill_adj(c->stream, edges, n_edges, off, cursor, c->g_adj.as<uint32_t>());
+  launch_mark_contained(c->stream, orders, n_orders, cand + 1, cand);
+  launch_check_contraction(c->stream, edges, n_edges, orders, off, c->g_adj.as<uint32_t>(), cand + 1, cand, n_orders,
+                           static_cast<double>(c->p.wiggle_room), c->g_sane.as<uint8_t>());
+  launch_pick_contraction(c->stream, edges, n_edges, c->g_sane.as<uint8_t>(), c->g_out.as<int64_t>());
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpyAsync(contraction_order, c->g_out.p, n_edges * 8, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return MSGPU_OK;
 }

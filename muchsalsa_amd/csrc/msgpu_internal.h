@@ -125,6 +125,17 @@ size_t big_path_bytes();
 void launch_chain_big(hipStream_t st, const ChainArgs &a, const uint32_t *big_list, const uint64_t *big_off,
                       uint32_t n_big, void *elems, void *paths);
 void launch_merge_gathered(hipStream_t st, const MergeArgs &a);
+// msgpu_graph.hip: findContractionEdges + sanityCheck
+void launch_degree(hipStream_t st, const msgpu_edge *edges, uint64_t n_edges, uint32_t *deg);
+void launch_fill_adj(hipStream_t st, const msgpu_edge *edges, uint64_t n_edges, const uint64_t *adj_off,
+                     uint32_t *cursor, uint32_t *adj);
+void launch_mark_contained(hipStream_t st, const msgpu_order *orders, uint64_t n_orders, uint32_t *cand,
+                           uint32_t *n_cand);
+void launch_check_contraction(hipStream_t st, const msgpu_edge *edges, uint64_t n_edges, const msgpu_order *orders,
+                              const uint64_t *adj_off, const uint32_t *adj, const uint32_t *cand,
+                              const uint32_t *n_cand, uint64_t n_orders, double wiggle, uint8_t *sane);
+void launch_pick_contraction(hipStream_t st, const msgpu_edge *edges, uint64_t n_edges, const uint8_t *sane,
+                             int64_t *out);
 void launch_compact(hipStream_t st, const CompactArgs &a);
 
 } // namespace msgpu

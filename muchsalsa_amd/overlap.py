@@ -145,6 +145,17 @@ class OverlapContext:
                                                  slab_bytes, offs[0], offs[1], offs[2], C.c_void_p(d_edges),
                                                  C.c_void_p(d_orders), C.c_void_p(d_ids)))
 
+    def find_contraction_edges(self, d_edges=None, n_edges=0, d_orders=None, n_orders=0, n_reads=0):
+        """findContractionEdges + sanityCheck (src/main.cpp:416-463, sc.cpp:29-90) on the context's own tables, or on
+        device tables given by pointer -> int64 per edge: index of its contraction order, -1 = none."""
+        if d_edges is None:
+            n_edges = self.counts().n_edges
+        out = np.full(int(n_edges), -1, dtype="<i8")
+        self._check(self._L.msgpu_find_contraction_edges(self._h, C.c_void_p(d_edges), int(n_edges),
+                                                         C.c_void_p(d_orders), int(n_orders), int(n_reads),
+                                                         out.ctypes.data if len(out) else None))
+        return out
+
     def reads(self):
         c = self.counts()
         rl = np.zeros(c.n_reads, dtype="<i4")

@@ -170,6 +170,12 @@ int ms_oracle_between_anchors(const ms_row *ml, const ms_row *mr, const char *na
                               int ovl_hi, int ovr_lo, int ovr_hi, int direction, int *distance, char *out,
                               size_t *out_len);
 
+/* ---- graph clean-up, first step: findContractionEdges (src/main.cpp:416-463) with
+ * sanityCheck (libms/src/kernel/sc.cpp:29-90) over the result tables.  out[e] (n_edges entries) = index in the order
+ * table of the first contained & primary EdgeOrder of edge e that is sane against every non-shadow neighbour of its
+ * start vertex, or -1.  Defined in ms_oracle_graph.c. */
+int ms_oracle_find_contraction_edges(const ms_tables *t, uint64_t wiggle, int64_t *out);
+
 /* Levenshtein distance (unit costs, global alignment), full O(n*m) DP -- the checker of the banded GPU kernel
  * (the reference has no counterpart).  Returns min(distance, band + 1). */
 uint32_t ms_oracle_edit_distance(const char *a, size_t n, const char *b, size_t m, uint32_t band);

@@ -93,6 +93,8 @@ def lib():
                                                    C.c_int, C.c_int, C.POINTER(C.c_int), C.c_char_p,
                                                    C.POINTER(C.c_size_t)]
         _lib.ms_oracle_between_anchors.restype = C.c_int
+        _lib.ms_oracle_find_contraction_edges.argtypes = [C.POINTER(_Tables), C.c_uint64, C.c_void_p]
+        _lib.ms_oracle_find_contraction_edges.restype = C.c_int
         _lib.ms_oracle_edit_distance.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_uint32]
         _lib.ms_oracle_edit_distance.restype = C.c_uint32
     return _lib
@@ -154,6 +156,23 @@ def overlap(rows, params=None):
         }
     finally:
         lib().ms_oracle_free_tables(C.byref(t))
+
+
+def find_contraction_edges(tables, n_reads=None, wiggle=300):
+    """findContractionEdges + sanityCheck over result tables (dict with edges, orders) -> int64[n_edges], -1 = none."""
+    edges = np.ascontiguousarray(tables["edges"], dtype=EDGE_DTYPE)
+    orders = np.ascontiguousarray(tables["orders"], dtype=ORDER_DTYPE)
+    if n_reads is None:
+        n_reads = int(max(edges["v1"].max(), edges["v2"].max())) + 1 if len(edges) else 0
+    t = _Tables()
+    t.edges, t.n_edges = edges.ctypes.data, len(edges)
+    t.orders, t.n_orders = orders.ctypes.data, len(orders)
+    t.n_reads = n_reads
+    out = np.full(len(edges), -1, dtype="<i8")
+    rc = lib().ms_oracle_find_contraction_edges(C.byref(t), int(wiggle), out.ctypes.data)
+    if rc != 0:
+        raise OracleError(rc)
+    return out
 
 
 def seq_load(path, is_fastq=-1):

@@ -1,0 +1,39 @@
+"""Row tables with reads of mixed length, so that short reads lie inside long ones: contained + primary EdgeOrders, the
+input of the graph clean-up after the overlap path (findContractionEdges / sanityCheck, src/main.cpp:416-463)."""
+import numpy as np
+
+from muchsalsa_amd.synth import ROW_DTYPE
+
+
+def varlen_rows(n_reads, n_anchors, genome, seed, len_lo=1500, len_hi=9000, jitter=10):
+    rng = np.random.default_rng(seed)
+    r_len = rng.integers(len_lo, len_hi + 1, n_reads)
+    r_start = rng.integers(0, genome - r_len)
+    r_fwd = rng.integers(0, 2, n_reads).astype(bool)
+    a_len = rng.integers(500, 1501, n_anchors)
+    a_start = rng.integers(0, genome - a_len)
+    recs = []
+    for a in range(n_anchors):  # rows grouped by anchor, then read: what a PAF sorted by query looks like
+        lo = np.maximum(a_start[a], r_start)
+        hi = np.minimum(a_start[a] + a_len[a], r_start + r_len)
+        for r in np.nonzero(hi - lo >= 420)[0]:
+            q_lo, q_hi = lo[r] - a_start[a], hi[r] - a_start[a]
+            if r_fwd[r]:
+                t_lo, t_hi = lo[r] - r_start[r], hi[r] - r_start[r]
+            else:
+                t_lo, t_hi = r_start[r] + r_len[r] - hi[r], r_start[r] + r_len[r] - lo[r]
+            t_lo = max(0, int(t_lo) + int(rng.integers(-jitter, jitter + 1)))
+            t_hi = min(int(r_len[r]), int(t_hi) + int(rng.integers(-jitter, jitter + 1)))
+            nm = int((q_hi - q_lo) * rng.uniform(0.86, 0.97))
+            if nm < 400 or q_hi - q_lo < 400:
+                continue
+            prim = (q_hi - q_lo) >= 500 and nm >= 500
+            recs.append((a, r, int(r_len[r]), int(q_lo), int(q_hi) - 1, t_lo, t_hi - 1, nm, len(recs),
+                         int(r_fwd[r]) | (int(prim) << 1)))
+    rows = np.array(recs, dtype=ROW_DTYPE)
+    for f in ("read_id", "anchor_id"):  # Registry ids: first-seen order (Registry.cpp:36-45)
+        uniq, first, inv = np.unique(rows[f], return_index=True, return_inverse=True)
+        rank = np.empty(len(uniq), dtype=np.int64)
+        rank[np.argsort(first, kind="stable")] = np.arange(len(uniq))
+        rows[f] = rank[inv]
+    return rows

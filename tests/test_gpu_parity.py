@@ -230,3 +230,49 @@ def test_bench_distributed_path_smoke():
     assert 0 < line["roofline"]["frac"] < 1
     assert line["config"]["merged_edge_list_consistent"] is True   # all-gather + merge reproduced our own tables
     assert line["consensus"]["verified_against_genome"] is True
+
+
+def test_find_contraction_edges_matches_oracle(oracle):
+    """findContractionEdges + sanityCheck (main.cpp:416-463, sc.cpp:29-90) on resident tables: reads of mixed length
+    give contained orders; the order tables are also run with every contained order promoted to primary (more
+    candidates, all four containment cases of sanityCheck) -- through the device-pointer form of the entry point."""
+    import torch
+    from graphcases import varlen_rows
+    from muchsalsa_amd.overlap import OverlapContext
+    n_hit = n_cand = 0
+    for seed in (1, 2, 3):
+        rows = varlen_rows(400, 2500, 250_000, seed)
+        ctx = OverlapContext(device=0)
+        ctx.load_rows(rows)
+        ctx.calculate_edges()
+        ctx.chaining_and_overlaps()
+        t = ctx.tables()
+        n_reads = ctx.counts().n_reads
+        want = oracle.find_contraction_edges(t, n_reads)
+        got = ctx.find_contraction_edges()
+        assert np.array_equal(got, want)
+        # promoted variant on caller-owned device tables
+        t2 = {"edges": t["edges"].copy(), "orders": t["orders"].copy()}
+        t2["orders"]["flags"] |= np.where(t2["orders"]["flags"] & 2, 8, 0).astype(np.uint32)
+        if seed == 3:  # and with some edges un-shadowed / shadowed
+            t2["edges"]["shadow"] ^= (np.arange(len(t2["edges"])) % 3 == 0).astype(np.uint8)
+        want2 = oracle.find_contraction_edges(t2, n_reads)
+        d_e = torch.from_numpy(t2["edges"].view(np.uint8).copy()).cuda()
+        d_o = torch.from_numpy(t2["orders"].view(np.uint8).copy()).cuda()
+        torch.cuda.synchronize()
+        got2 = ctx.find_contraction_edges(d_e.data_ptr(), len(t2["edges"]), d_o.data_ptr(), len(t2["orders"]), n_reads)
+        assert np.array_equal(got2, want2)
+        n_hit += int((want2 >= 0).sum())
+        n_cand += int(((t2["orders"]["flags"] & 10) == 10).sum())
+        ctx.close()
+    assert n_cand > 1000 and 50 < n_hit < n_cand  # both outcomes are well represented
+
+
+def test_find_contraction_edges_state_and_empty():
+    from muchsalsa_amd.overlap import MsgpuError, OverlapContext
+    from muchsalsa_amd import _lib
+    ctx = OverlapContext(device=0)
+    with pytest.raises(MsgpuError) as e:
+        ctx.find_contraction_edges()
+    assert e.value.code == _lib.E_STATE
+    ctx.close()
