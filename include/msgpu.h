@@ -334,7 +334,7 @@ int msgpu_seq_synchronize(msgpu_seqctx *ctx);
  * entries) the reference's order is unspecified; this library uses ascending ids / creation order. */
 typedef struct msgpu_path_read {
   uint32_t read_id;          /* Vertex::getId()                                         */
-  uint32_t direction;        /* 1: Direction::e_POS, 0: e_NEG (Vertex::getVertexDirection) */
+  uint32_t direction;        /* Vertex::getVertexDirection(): 1 = e_POS, 0 = e_NEG, 2 = e_NONE */
   uint64_t nanopore_length;  /* Vertex::getNanoporeLength()                             */
 } msgpu_path_read;
 typedef struct msgpu_path_order { /* an EdgeOrder (include/ms/graph/Edge.h:49-60) of a directed path edge */
@@ -432,6 +432,39 @@ uint64_t msgpu_fasta_text_bytes(uint32_t header_len, uint64_t len);
 int msgpu_fasta_format(msgpu_seqctx *ctx, const void *d_raw, const msgpu_fasta_record *records, size_t n,
                        const char *headers, size_t headers_bytes, void *d_text, uint64_t text_capacity,
                        void *hip_stream);
+
+/* ---- between the overlap path and assemblePath (host) -----------------------------
+ * graph clean-up (src/main.cpp:194-288, 465-618: contraction targets and roots, ContainElements, deletions,
+ * computeBitweight, getMaxSpanTree mst.cpp:34-111, decycle), getConnectedComponents (cc.cpp:33-70) and, per component,
+ * getDirectedGraph (dg.cpp:35-121) + linearizeGraph (lg.cpp:41-629) as the assemblePaths job does (main.cpp:620-661).
+ * Input: the tables of msgpu_copy_tables / msgpu_copy_reads (copied) and the result of msgpu_find_contraction_edges.
+ * Output: one msgpu_path_input per linearised path, ready for msgpu_assembly_add_paths.  Iteration orders the
+ * reference leaves to hash containers follow DESIGN.md section 9.  MSGPU_E_LAYOUT = the reference would terminate. */
+typedef struct msgpu_graph msgpu_graph;
+typedef struct msgpu_graph_stats {
+  uint64_t n_vertices_in, n_edges_in;
+  uint64_t n_contraction_edges, n_deleted_vertices, n_contain_elements, n_decycled_edges;
+  uint64_t n_vertices, n_edges; /* after the clean-up */
+  uint64_t n_components, n_paths, n_path_reads;
+} msgpu_graph_stats;
+int  msgpu_graph_create(const msgpu_edge *edges, uint64_t n_edges, const msgpu_edgematch *ems, uint64_t n_ems,
+                        const msgpu_order *orders, uint64_t n_orders, const uint32_t *ids, uint64_t n_ids,
+                        const int32_t *read_len, const uint32_t *read_first_line, uint32_t n_reads, msgpu_graph **out);
+void msgpu_graph_free(msgpu_graph *g);
+const char *msgpu_graph_last_error(const msgpu_graph *g);
+/* rows (optional): the VertexMatch table, for contract()'s "getVertexMatch(start, id) != nullptr" (main.cpp:514-519);
+ * NULL = every id of an order has one (true for tables produced by this library). */
+int msgpu_graph_clean_up(msgpu_graph *g, const int64_t *contraction_order, const msgpu_row *rows, size_t n_rows);
+int msgpu_graph_linearize(msgpu_graph *g);
+int msgpu_graph_get_stats(const msgpu_graph *g, msgpu_graph_stats *out);
+uint32_t msgpu_graph_path_count(const msgpu_graph *g);
+/* path i (asm_idx = i) as assemblePath input; pointers are owned by the graph and valid until msgpu_graph_free;
+ * rows / n_rows are left empty (use msgpu_assembly_set_rows). */
+int msgpu_graph_path_input(const msgpu_graph *g, uint32_t i, msgpu_path_input *out);
+/* inspection (all optional): per vertex alive flag and direction (1 e_POS / 0 e_NEG / 2 e_NONE); per edge (table
+ * order) alive flag, consensus direction (same coding) and weight */
+int msgpu_graph_state(const msgpu_graph *g, uint8_t *vertex_alive, uint8_t *vertex_direction, uint8_t *edge_alive,
+                      uint8_t *edge_consensus, uint64_t *edge_weight);
 
 /* ---- banded edit distance (no reference counterpart) ---------------------------------
  * The meter for north_star's "consensus sequences within a stated edit-distance tolerance": Levenshtein distance

@@ -62,6 +62,12 @@ class PathInput(C.Structure):
                 ("pad", C.c_uint32), ("contain_anchors", C.c_void_p)]
 
 
+class GraphStats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("n_vertices_in", "n_edges_in", "n_contraction_edges", "n_deleted_vertices",
+                                          "n_contain_elements", "n_decycled_edges", "n_vertices", "n_edges",
+                                          "n_components", "n_paths", "n_path_reads")]
+
+
 class Counts(C.Structure):
     _fields_ = [("n_rows_in", C.c_uint64), ("n_rows_alive", C.c_uint64), ("n_reads", C.c_uint32),
                 ("n_anchors", C.c_uint32), ("n_edges", C.c_uint64), ("n_ems", C.c_uint64), ("n_orders", C.c_uint64),
@@ -152,6 +158,16 @@ SYMBOLS = [
     ("msgpu_fasta_text_bytes", C.c_uint64, [C.c_uint32, C.c_uint64]),
     ("msgpu_fasta_format", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_char_p, C.c_size_t,
                                      C.c_void_p, C.c_uint64, C.c_void_p]),
+    ("msgpu_graph_create", C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p,
+                                     C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]),
+    ("msgpu_graph_free", None, [C.c_void_p]),
+    ("msgpu_graph_last_error", C.c_char_p, [C.c_void_p]),
+    ("msgpu_graph_clean_up", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    ("msgpu_graph_linearize", C.c_int, [C.c_void_p]),
+    ("msgpu_graph_get_stats", C.c_int, [C.c_void_p, C.POINTER(GraphStats)]),
+    ("msgpu_graph_path_count", C.c_uint32, [C.c_void_p]),
+    ("msgpu_graph_path_input", C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(PathInput)]),
+    ("msgpu_graph_state", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("msgpu_gather_plan_create", C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     ("msgpu_gather_plan_free", None, [C.c_void_p]),
     ("msgpu_gather_plan_out_bytes", C.c_uint64, [C.c_void_p]),

@@ -68,7 +68,7 @@ class Assembly:
         n = len(path)
         reads = np.zeros(n, dtype=PATH_READ_DTYPE)
         for i, p in enumerate(path):
-            reads[i] = (p["id"], 1 if p["dir"] else 0, p["len"])
+            reads[i] = (p["id"], 2 if p["dir"] is None else (1 if p["dir"] else 0), p["len"])  # e_NONE / e_POS / e_NEG
         order_off, em_off = np.zeros(max(n, 1), dtype="<u4"), np.zeros(max(n, 1), dtype="<u4")
         orders, ids, ems = [], [], []
         for i, st in enumerate(steps):

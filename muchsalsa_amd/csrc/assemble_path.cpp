@@ -198,7 +198,7 @@ struct PathLayout {
     uint32_t n = 0;
     s.p.resize(2);
     check((left ? msgpu_seg_left_of_anchor : msgpu_seg_right_of_anchor)(
-        ctx, row(r.read_id, anchor), r.nanopore_length, ov.first, ov.second, r.direction != 0, s.p.data(), &n, &s.len));
+        ctx, row(r.read_id, anchor), r.nanopore_length, ov.first, ov.second, r.direction == 1, s.p.data(), &n, &s.len));
     close(s, n, s.len);
     return s;
   }
@@ -319,7 +319,7 @@ PathResult layout_path(const msgpu_assembly *a, const msgpu_path_input &in) {
     std::vector<uint32_t>   ids(in.ids + o.ids_off, in.ids + o.ids_off + o.ids_cnt);
     auto                    d = L.dir_of.find(o.base_read);
     if (d == L.dir_of.end()) throw LayoutError("EdgeOrder based at a read that is not on the path");
-    if (!d->second) std::reverse(ids.begin(), ids.end());
+    if (d->second == 0) std::reverse(ids.begin(), ids.end()); // getVertexDirection() == e_NEG
     return ids;
   };
   auto em_of = [&](uint32_t edge, uint32_t anchor) {
@@ -437,7 +437,7 @@ PathResult layout_path(const msgpu_assembly *a, const msgpu_path_input &in) {
   std::map<uint32_t, std::vector<Seg>>                         pre, post;
   for (uint32_t idx = 0; idx <= n_edges; ++idx) {
     const msgpu_path_read &r   = in.reads[idx];
-    const bool             pos = r.direction != 0;
+    const bool             pos = r.direction == 1, neg = r.direction == 0; // e_POS / e_NEG; 2 = e_NONE is neither
     auto                  &info = vertex_info[idx];
     std::stable_sort(info.begin(), info.end(), [&](const Info &l, const Info &rr) { // :760-770
       if (l.nr == rr.nr) {
@@ -447,7 +447,7 @@ PathResult layout_path(const msgpu_assembly *a, const msgpu_path_input &in) {
       }
       return l.nr < rr.nr;
     });
-    if (!pos) std::reverse(info.begin(), info.end());
+    if (neg) std::reverse(info.begin(), info.end());
     if (info.empty()) continue;
     auto ensure = [&](const Match &m) { // :787-793, :800-806
       const auto key = std::make_tuple(m.key.first, m.key.second, m.mod);
@@ -480,7 +480,7 @@ PathResult layout_path(const msgpu_assembly *a, const msgpu_path_input &in) {
         double lf, ls, rf, rs;
         corrected(last_match, lf, ls);
         corrected(it.m, rf, rs);
-        flip = (pos && (lf > rf || (lf == rf && ls > rs))) || (!pos && (lf < rf || (lf == rf && ls < rs)));
+        flip = (pos && (lf > rf || (lf == rf && ls > rs))) || (neg && (lf < rf || (lf == rf && ls < rs)));
       }
       const uint32_t e = flip ? adg.add_edge(v, vl) : adg.add_edge(vl, v);
       if (e >= nanopores.size()) nanopores.resize(e + 1);
@@ -511,7 +511,7 @@ PathResult layout_path(const msgpu_assembly *a, const msgpu_path_input &in) {
       int                    has  = 0;
       s.p.resize(3);
       PathLayout::check(msgpu_seg_between_anchors(ctx, L.row(r.read_id, kl.first), L.row(r.read_id, kr.first), ovl.first,
-                                                  ovl.second, ovr.first, ovr.second, r.direction != 0, s.p.data(), &n,
+                                                  ovl.second, ovr.first, ovr.second, r.direction == 1, s.p.data(), &n,
                                                   &dist, &has));
       if (has) {
         PathLayout::close(s, n, static_cast<uint64_t>(dist));
@@ -652,7 +652,7 @@ PathResult layout_path(const msgpu_assembly *a, const msgpu_path_input &in) {
   }
   for (uint32_t idx = 0; idx <= n_edges; ++idx) { // contained reads, :1227-1361
     const msgpu_path_read            &r = in.reads[idx];
-    const bool                        pos = r.direction != 0;
+    const bool                        pos = r.direction == 1;
     std::unordered_map<uint32_t, Match> id2anchor;
     for (const Info &i : vertex_info[idx]) id2anchor[i.m.key.first] = i.m;
     for (uint32_t ci = 0; ci < in.n_contains; ++ci) {

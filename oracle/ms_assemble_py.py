@@ -12,7 +12,8 @@ product uses the same one (DESIGN.md "canonical orders"):
   * std::sort on elements the comparator calls equivalent: stable.
 
 Inputs (plain Python):
-  path       [{"id": read id, "dir": True for Direction::e_POS, "len": Vertex::getNanoporeLength()}, ...]
+  path       [{"id": read id, "dir": True for Direction::e_POS / False for e_NEG / None for e_NONE (a vertex
+             getDirectedGraph never reached through an edge with a consensus direction), "len": getNanoporeLength()}, ...]
   steps      one per consecutive pair of the path: {"orders": [{"ids": [...], "score": int, "base": read id}, ...],
              "em": {anchor id: (ov_lo, ov_hi)}}    -- EdgeOrders of diGraph.getEdge(path[i], path[i+1]) + its EdgeMatches
   vm         {(read id, anchor id): row}           -- MatchMap::getVertexMatch (row = record with i_lo,i_hi,n_lo,n_hi,flags)
@@ -194,7 +195,7 @@ def assemble_path(path, steps, vm, contains, nano, illu, asm_idx):
         raise AssemblyError("path with fewer than two reads")
     cover = dict(multi_order=0, kinks=0, multi_clique=0, flips=0, nr_ties=0, extra_groups=0, dup_edges=0, no_seq=0,
                  contain_records=0)  # which branches this input exercised (for the tests' coverage assertions)
-    dir_of = {p["id"]: bool(p["dir"]) for p in path}
+    is_neg = {p["id"]: p["dir"] is not None and not p["dir"] for p in path}  # getVertexDirection() == e_NEG
 
     # ---- candidate selection over the EdgeOrders of the path edges, ap.cpp:621-706 --------------------------------
     def find_best(cands):  # :633-642
@@ -211,7 +212,7 @@ def assemble_path(path, steps, vm, contains, nano, illu, asm_idx):
             sub = []
             for c in candidates:
                 ids = [int(x) for x in order["ids"]]
-                if not dir_of[order["base"]]:
+                if is_neg[order["base"]]:
                     ids.reverse()
                 mods = [x for x in ids if x not in c["open"] and x in c["visited"]]
                 sub.append(dict(open=set(ids), visited=c["visited"] | set(ids), score=c["score"] + int(order["score"]),
@@ -247,7 +248,7 @@ def assemble_path(path, steps, vm, contains, nano, illu, asm_idx):
         for m in best["modifiers"][idx]:
             match_modifiers[m] = match_modifiers.get(m, 0) + 1
         ids = [int(x) for x in best["orders"][idx]["ids"]]
-        if not dir_of[best["orders"][idx]["base"]]:
+        if is_neg[best["orders"][idx]["base"]]:
             ids.reverse()
         va, vb = path[idx], path[idx + 1]
         for a in ids:
@@ -266,7 +267,7 @@ def assemble_path(path, steps, vm, contains, nano, illu, asm_idx):
     adg = _Adg()
     reg2id, anchor_seq, nanopores, pre, post = {}, {}, {}, {}, {}
     for idx, v in enumerate(vertices):
-        rid, pos = v["id"], bool(v["dir"])
+        rid, pos, neg = v["id"], v["dir"] is True or v["dir"] == 1, is_neg[v["id"]]
 
         def cmp(lhs, rhs):  # :760-770
             if lhs[0] == rhs[0]:
@@ -278,7 +279,7 @@ def assemble_path(path, steps, vm, contains, nano, illu, asm_idx):
             return -1 if lhs[0] < rhs[0] else 1
 
         info = sorted(vertex_info[idx], key=functools.cmp_to_key(cmp))
-        if not pos:
+        if neg:
             info.reverse()
         vertex_info[idx] = info
         if not info:
@@ -305,7 +306,7 @@ def assemble_path(path, steps, vm, contains, nano, illu, asm_idx):
                 cl = _corrected_range(_vm(vm[(rid, last_match[0][0])]), id2overlap[last_match[0]])
                 cr = _corrected_range(_vm(vm[(rid, match[0][0])]), id2overlap[match[0]])
                 flip = (pos and (cl[0] > cr[0] or (cl[0] == cr[0] and cl[1] > cr[1]))) or \
-                       (not pos and (cl[0] < cr[0] or (cl[0] == cr[0] and cl[1] < cr[1])))
+                       (neg and (cl[0] < cr[0] or (cl[0] == cr[0] and cl[1] < cr[1])))
             cover["flips"] += flip
             cover["dup_edges"] += ((r, rl) if flip else (rl, r)) in adg.edge_of
             e = adg.add_edge(r, rl) if flip else adg.add_edge(rl, r)
@@ -325,7 +326,8 @@ def assemble_path(path, steps, vm, contains, nano, illu, asm_idx):
         dist, seqs = None, []
         for v in nanopores[e]:
             d, s = get_sequence_between_anchors(vm[(v["id"], a_l)], vm[(v["id"], a_r)], nano[v["id"]], illu[a_l],
-                                                illu[a_r], id2overlap[reg2id[u]], id2overlap[reg2id[w]], bool(v["dir"]))
+                                                illu[a_r], id2overlap[reg2id[u]], id2overlap[reg2id[w]],
+                                                v["dir"] is True or v["dir"] == 1)
             if s is not None:
                 seqs.append(s)
             else:
@@ -446,7 +448,7 @@ def assemble_path(path, steps, vm, contains, nano, illu, asm_idx):
         id2anchor = {}
         for info in vertex_info[idx]:
             id2anchor[info[1][0][0]] = info[1]
-        pos = bool(v["dir"])
+        pos = v["dir"] is True or v["dir"] == 1
         for ce in contains.get(v["id"], []):
             cinfo = sorted(((int(r["n_lo"]), int(r["n_hi"])), int(a)) for a, r in ce["matches"].items()
                            if int(a) in id2anchor)

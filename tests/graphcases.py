@@ -5,13 +5,26 @@ import numpy as np
 from muchsalsa_amd.synth import ROW_DTYPE
 
 
-def varlen_rows(n_reads, n_anchors, genome, seed, len_lo=1500, len_hi=9000, jitter=10):
+def varlen_rows(n_reads, n_anchors, genome, seed, len_lo=1500, len_hi=9000, jitter=10, tiled=False, layout=None):
+    """tiled: anchors are consecutive, non-overlapping stretches of the genome separated by gaps of 0..300 bases (what
+    unitigs of one genome look like) instead of independent random intervals; n_anchors is then ignored.
+    layout (optional dict) receives r_start, r_len, r_fwd, a_start, a_len indexed by Registry id."""
     rng = np.random.default_rng(seed)
     r_len = rng.integers(len_lo, len_hi + 1, n_reads)
     r_start = rng.integers(0, genome - r_len)
     r_fwd = rng.integers(0, 2, n_reads).astype(bool)
-    a_len = rng.integers(500, 1501, n_anchors)
-    a_start = rng.integers(0, genome - a_len)
+    if tiled:
+        starts, lens, pos = [], [], int(rng.integers(0, 200))
+        while pos + 1500 < genome:
+            ln = int(rng.integers(500, 1501))
+            starts.append(pos)
+            lens.append(ln)
+            pos += ln + int(rng.integers(0, 301))
+        a_start, a_len = np.array(starts), np.array(lens)
+        n_anchors = len(starts)
+    else:
+        a_len = rng.integers(500, 1501, n_anchors)
+        a_start = rng.integers(0, genome - a_len)
     recs = []
     for a in range(n_anchors):  # rows grouped by anchor, then read: what a PAF sorted by query looks like
         lo = np.maximum(a_start[a], r_start)
@@ -31,9 +44,16 @@ def varlen_rows(n_reads, n_anchors, genome, seed, len_lo=1500, len_hi=9000, jitt
             recs.append((a, r, int(r_len[r]), int(q_lo), int(q_hi) - 1, t_lo, t_hi - 1, nm, len(recs),
                          int(r_fwd[r]) | (int(prim) << 1)))
     rows = np.array(recs, dtype=ROW_DTYPE)
+    orig = {}
     for f in ("read_id", "anchor_id"):  # Registry ids: first-seen order (Registry.cpp:36-45)
         uniq, first, inv = np.unique(rows[f], return_index=True, return_inverse=True)
         rank = np.empty(len(uniq), dtype=np.int64)
-        rank[np.argsort(first, kind="stable")] = np.arange(len(uniq))
+        by_first = np.argsort(first, kind="stable")
+        rank[by_first] = np.arange(len(uniq))
         rows[f] = rank[inv]
+        orig[f] = uniq[by_first]  # Registry id -> generator index
+    if layout is not None:
+        r, a = orig["read_id"], orig["anchor_id"]
+        layout.update(r_start=r_start[r], r_len=r_len[r], r_fwd=r_fwd[r], a_start=a_start[a], a_len=a_len[a],
+                      genome=genome)
     return rows

@@ -51,9 +51,9 @@ def fuzz_case(w, rng, trial):
                 lo, hi = st["em"][a]
                 st["em"][a] = (lo, lo + (hi - lo) // 4) if rng.integers(0, 2) else (hi - (hi - lo) // 4, hi)
 
-    if mode == 1:  # arbitrary read directions
+    if mode == 1:  # arbitrary read directions, e_NONE included
         for p in path:
-            p["dir"] = bool(rng.integers(0, 2))
+            p["dir"] = (True, False, None)[int(rng.integers(0, 3))]
     elif mode == 2:  # several EdgeOrders per path edge
         for st in steps:
             o = st["orders"][0]

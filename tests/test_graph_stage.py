@@ -1,0 +1,128 @@
+"""Host graph stage (clean-up, span tree, decycle, components, getDirectedGraph, linearizeGraph; src/main.cpp:194-310,
+mst.cpp, cc.cpp, dg.cpp, lg.cpp) of libmsgpu against the object-model restatement in oracle/ms_graph_py.py.  No GPU:
+the contraction edges come from the C oracle here (tests/test_gpu_pipeline.py takes them from the HIP kernel)."""
+import numpy as np
+import pytest
+
+from graphcases import varlen_rows
+
+from muchsalsa_amd import _lib
+from muchsalsa_amd.graph import GraphStage
+from muchsalsa_amd.overlap import MsgpuError
+
+
+def oracle_stage(oracle, rows, t, co):
+    from oracle import ms_graph_py as G
+    vm = {(int(r["read_id"]), int(r["anchor_id"])) for r in rows}
+    g, el, oo = G.build_graph(t, t["read_len"], t["read_first_line"])
+    contain = G.clean_up(g, el, oo, co, lambda r, a: (r, a) in vm)
+    state = dict(vertex_alive=np.array([v in g.vertices for v in range(len(t["read_len"]))]),
+                 edge_alive=np.array([id(e) in g.edges for e in el]),
+                 edge_consensus=np.array([{G.POS: 1, G.NEG: 0, G.NONE: 2}[e.consensus] for e in el], dtype=np.uint8),
+                 edge_weight=np.array([e.weight for e in el], dtype=np.uint64))
+    edges, ems = t["edges"], t["ems"]
+    eidx = {(int(e["v1"]), int(e["v2"])): i for i, e in enumerate(edges)}
+
+    def em_of(a, b):
+        e = edges[eidx[(a, b)]]
+        return {int(m["anchor_id"]): (int(m["ov_lo"]), int(m["ov_hi"]))
+                for m in ems[int(e["em_off"]): int(e["em_off"]) + int(e["em_cnt"])]}
+    paths = G.assemble_all(g, em_of)
+    dirs = np.array([{G.POS: 1, G.NEG: 0, G.NONE: 2}[g.vertices[v].direction] if v in g.vertices else 255
+                     for v in range(len(t["read_len"]))])
+    return state, contain, paths, dirs
+
+
+def variants(oracle):
+    """(name, rows, tables, contraction_order): random and tiled anchors, natural and forced contractions, mixed shadows"""
+    for seed, tiled in ((1, False), (2, True), (3, True), (4, False)):
+        rows = varlen_rows(400, 2500, 250_000, seed, tiled=tiled)
+        t = oracle.overlap(rows)
+        n = len(t["read_len"])
+        yield "seed%d%s" % (seed, "t" if tiled else "r"), rows, t, oracle.find_contraction_edges(t, n)
+        t2 = dict(t, edges=t["edges"].copy(), orders=t["orders"].copy())
+        t2["orders"]["flags"] |= np.where(t2["orders"]["flags"] & 2, 8, 0).astype(np.uint32)  # contained -> primary
+        if seed & 1:
+            t2["edges"]["shadow"] ^= (np.arange(len(t2["edges"])) % 3 == 0).astype(np.uint8)
+        yield "seed%d-forced" % seed, rows, t2, oracle.find_contraction_edges(t2, n)
+        # inconsistent strands: flip EdgeOrder::direction on a tenth of the orders -> odd cycles for decycle(), shadow
+        # edges whose orders disagree (consensus e_NONE), vertices getDirectedGraph never orients
+        t3 = dict(t, edges=t["edges"].copy(), orders=t["orders"].copy())
+        rng = np.random.default_rng(seed)
+        t3["orders"]["flags"] ^= np.where(rng.integers(0, 10, len(t3["orders"])) == 0, 4, 0).astype(np.uint32)
+        t3["edges"]["shadow"] ^= (rng.integers(0, 4, len(t3["edges"])) == 0).astype(np.uint8)
+        yield "seed%d-strands" % seed, rows, t3, oracle.find_contraction_edges(t3, n)
+
+
+def test_graph_stage_matches_oracle(oracle):
+    seen = dict(contain=0, decycled=0, deleted=0, paths=0, long_path=0, multi_comp=0)
+    for name, rows, t, co in variants(oracle):
+        from oracle.ms_graph_py import GraphError
+        try:
+            state, contain, paths, dirs = oracle_stage(oracle, rows, t, co)
+        except GraphError:
+            state = None
+        g = GraphStage(t, t["read_len"], t["read_first_line"])
+        if state is None:
+            with pytest.raises(MsgpuError):
+                g.clean_up(co, rows)
+                g.linearize()
+            continue
+        g.clean_up(co, rows)
+        got = g.state()
+        for k in ("vertex_alive", "edge_alive"):
+            assert np.array_equal(got[k], state[k]), (name, k)
+        alive = state["edge_alive"]
+        assert np.array_equal(got["edge_consensus"][alive], state["edge_consensus"][alive]), name
+        assert np.array_equal(got["edge_weight"][alive], state["edge_weight"][alive]), name
+        g.linearize()
+        st = g.stats
+        assert st.n_paths == len(paths), name
+        got_contain = {}
+        for i, (want_path, want_steps) in enumerate(paths):
+            p, steps, cont = g.path(i)
+            assert p == want_path, (name, i)
+            assert steps == want_steps, (name, i)
+            got_contain.update(cont)
+        on_paths = {r["id"] for p, _ in paths for r in p}
+        want_contain = {v: [dict(nano=c["nano"], dir=c["direction"], anchors=c["anchors"]) for c in lst]
+                        for v, lst in contain.items() if v in on_paths}
+        assert got_contain == want_contain, name
+        vd = g.state()["vertex_direction"]
+        assert np.array_equal(vd[state["vertex_alive"]], dirs[state["vertex_alive"]]), name
+        assert st.n_contain_elements == sum(len(v) for v in contain.values())
+        seen["contain"] += st.n_contain_elements
+        seen["decycled"] += st.n_decycled_edges
+        seen["deleted"] += st.n_deleted_vertices
+        seen["paths"] += st.n_paths
+        seen["long_path"] += any(len(p) >= 10 for p, _ in paths)
+        # every vertex of a component is reached through edges with a consensus direction, so none stays e_NONE
+        assert not (dirs[state["vertex_alive"]] == 2).any()
+        seen["multi_comp"] += st.n_components > 1
+    for k, v in seen.items():
+        assert v > 0, "never exercised: %s (%r)" % (k, seen)
+
+
+def test_graph_stage_argument_and_state_errors(oracle):
+    rows = varlen_rows(60, 300, 40_000, 5, tiled=True)
+    t = oracle.overlap(rows)
+    g = GraphStage(t, t["read_len"], t["read_first_line"])
+    with pytest.raises(MsgpuError) as e:
+        g.linearize()  # before clean_up
+    assert e.value.code == _lib.E_STATE
+    bad = np.full(len(t["edges"]), -1, dtype=np.int64)
+    if len(t["orders"]):
+        bad[0] = len(t["orders"]) + 5  # not an order of that edge
+        with pytest.raises(MsgpuError) as e:
+            g.clean_up(bad)
+        assert e.value.code == _lib.E_ARG
+    g.clean_up(np.full(len(t["edges"]), -1, dtype=np.int64))
+    with pytest.raises(MsgpuError) as e:
+        g.clean_up(np.full(len(t["edges"]), -1, dtype=np.int64))
+    assert e.value.code == _lib.E_STATE
+    g.linearize()
+    assert g.path_count == g.stats.n_paths
+    t_bad = dict(t, edges=t["edges"].copy())
+    t_bad["edges"]["v2"][0] = 10 ** 6  # vertex out of range
+    with pytest.raises(MsgpuError):
+        GraphStage(t_bad, t["read_len"], t["read_first_line"])
