@@ -1,0 +1,96 @@
+"""The `muchsalsa` executable's main() (src/main.cpp:130-322) over the C-ABI: PAF + unitigs + long reads ->
+temp_1.target.fa / temp_1.query.fa / temp_1.align.paf.
+
+    stage (reference, src/main.cpp)                     here
+    :153-157 BlastFileReader::read + calculateEdges      parse_paf (host) + OverlapContext (HIP)
+    :161-163 SequenceAccessor::buildIndex                SeqFile (host parse) + SeqStore.upload (HBM)
+    :170-178 chainingAndOverlaps fan-out                 OverlapContext.chaining_and_overlaps (HIP)
+    :183-190 findContractionEdges                        OverlapContext.find_contraction_edges (HIP)
+    :194-288 contraction, deletions, bitweight, MST, decycle   GraphStage.clean_up (host)
+    :300-310 components -> getDirectedGraph -> linearizeGraph   GraphStage.linearize (host)
+    :663-677 assemblePath per path                       Assembly.add_prepared_batch (host layout, threads)
+             OutputWriter                                Assembly.finish (one gather + FASTA wrapping, HIP) + 3 writes
+"""
+import os
+import time
+
+import numpy as np
+
+from . import overlap
+from .assembly import Assembly
+from .graph import GraphStage
+from .sequences import ILLUMINA, NANOPORE, SeqFile, SeqStore
+
+
+def _registry_ids(seqfile, names):
+    """Registry::operator[] for every record of a sequence file (SequenceAccessor.cpp:171,215): names the PAF
+    registered keep their id, unknown names get the next free ids in file order."""
+    reg = {n: i for i, n in enumerate(names)}
+    ids = np.zeros(len(seqfile), dtype="<u4")
+    for i, n in enumerate(seqfile.names):
+        ids[i] = reg.setdefault(n, len(reg))
+    return ids, len(reg)
+
+
+def run(contigs_paf, unitigs_path, nanopore_path, out_dir, threads=None, wiggle_room=300, device=0, timings=None):
+    """-> dict of counts; writes the three output files into out_dir (created by the caller, Application.cpp:65-82)."""
+    t = {}
+    t0 = time.perf_counter()
+    params = overlap.default_params()
+    params.wiggle_room = int(wiggle_room)
+    paf = overlap.parse_paf(contigs_paf, params)
+    t["parse_paf"] = time.perf_counter() - t0
+
+    t0 = time.perf_counter()
+    ctx = overlap.OverlapContext(device=device, params=params)
+    ctx.load_rows(paf.rows)
+    ctx.calculate_edges()
+    ctx.chaining_and_overlaps()
+    contraction = ctx.find_contraction_edges()
+    tables = ctx.tables()
+    read_len, read_first = ctx.reads()
+    counts = ctx.counts()
+    ctx.close()
+    t["overlap_gpu"] = time.perf_counter() - t0
+
+    t0 = time.perf_counter()
+    fn, fi = SeqFile(nanopore_path), SeqFile(unitigs_path)
+    store = SeqStore(device=device)
+    ids, n = _registry_ids(fn, paf.read_names)
+    store.upload(NANOPORE, fn, ids, n)
+    ids, n = _registry_ids(fi, paf.anchor_names)
+    store.upload(ILLUMINA, fi, ids, n)
+    t["sequences"] = time.perf_counter() - t0
+
+    t0 = time.perf_counter()
+    g = GraphStage(tables, read_len, read_first)
+    g.clean_up(contraction, paf.rows)
+    g.linearize()
+    t["graph_host"] = time.perf_counter() - t0
+
+    t0 = time.perf_counter()
+    asm = Assembly(store)
+    asm.set_rows(paf.rows)
+    n_threads = int(threads) if threads else max(1, min(16, os.cpu_count() or 1))
+    status = asm.add_prepared_batch([(g.path_input(i), g) for i in range(g.path_count)], n_threads) \
+        if g.path_count else np.zeros(0, dtype=np.int32)
+    asm.finish()
+    t["assemble"] = time.perf_counter() - t0
+
+    t0 = time.perf_counter()
+    for which, name in ((0, "temp_1.target.fa"), (1, "temp_1.query.fa"), (2, "temp_1.align.paf")):
+        with open(os.path.join(out_dir, name), "wb") as f:
+            f.write(asm.text(which))
+    t["write"] = time.perf_counter() - t0
+    st = g.stats
+    info = asm.paths
+    out = {"rows": len(paf.rows), "reads": int(counts.n_reads), "anchors": int(counts.n_anchors),
+           "edges": int(counts.n_edges), "orders": int(counts.n_orders),
+           "contraction_edges": int((contraction >= 0).sum()), "vertices_after_cleanup": int(st.n_vertices),
+           "edges_after_cleanup": int(st.n_edges), "components": int(st.n_components), "paths": int(st.n_paths),
+           "paths_skipped": int((status != 0).sum()), "contigs": int(len(info)),
+           "target_bases": int(info["target_len"].sum()) if len(info) else 0, "queries": int(len(asm.queries))}
+    if timings is not None:
+        timings.update(t)
+    store.close()
+    return out
