@@ -1455,3 +1455,34 @@ uint32_t ms_oracle_edit_distance(const char *a, size_t n, const char *b, size_t 
   free(cur);
   return r > band ? band + 1 : r;
 }
+
+/* Same distance restricted to the band |i - j| <= band (cells outside count as "more than band"): exact whenever the
+ * true distance is <= band, O(n * band) -- for the long contig-vs-genome checks of the tests. */
+uint32_t ms_oracle_edit_distance_banded(const char *a, size_t n, const char *b, size_t m, uint32_t band) {
+  const uint32_t INF = 0x3fffffffu;
+  size_t diff = n > m ? n - m : m - n;
+  if (diff > band) return band + 1;
+  uint32_t *prev = (uint32_t *)xrealloc(NULL, (m + 2) * sizeof(uint32_t));
+  uint32_t *cur  = (uint32_t *)xrealloc(NULL, (m + 2) * sizeof(uint32_t));
+  for (size_t j = 0; j <= m; ++j) prev[j] = j <= band ? (uint32_t)j : INF;
+  for (size_t i = 1; i <= n; ++i) {
+    size_t lo = i > band ? i - band : 1, hi = i + band < m ? i + band : m;
+    cur[lo - 1] = (lo == 1 && i <= band) ? (uint32_t)i : INF;
+    for (size_t j = lo; j <= hi; ++j) {
+      uint32_t d = prev[j - 1] + (a[i - 1] != b[j - 1] ? 1u : 0u);
+      uint32_t u = (j <= i - 1 + band) ? prev[j] + 1u : INF; /* prev row holds columns up to (i - 1) + band */
+      uint32_t l = cur[j - 1] + 1u;
+      if (u < d) d = u;
+      if (l < d) d = l;
+      cur[j] = d > INF ? INF : d;
+    }
+    if (hi < m) cur[hi + 1] = INF;
+    uint32_t *t = prev;
+    prev = cur;
+    cur  = t;
+  }
+  uint32_t r = prev[m];
+  free(prev);
+  free(cur);
+  return r > band ? band + 1 : r;
+}

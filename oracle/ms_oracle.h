@@ -179,6 +179,8 @@ int ms_oracle_find_contraction_edges(const ms_tables *t, uint64_t wiggle, int64_
 /* Levenshtein distance (unit costs, global alignment), full O(n*m) DP -- the checker of the banded GPU kernel
  * (the reference has no counterpart).  Returns min(distance, band + 1). */
 uint32_t ms_oracle_edit_distance(const char *a, size_t n, const char *b, size_t m, uint32_t band);
+/* the same restricted to |i - j| <= band: exact when the distance is <= band, O(n * band) */
+uint32_t ms_oracle_edit_distance_banded(const char *a, size_t n, const char *b, size_t m, uint32_t band);
 
 #ifdef __cplusplus
 }

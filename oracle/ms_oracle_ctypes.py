@@ -97,6 +97,8 @@ def lib():
         _lib.ms_oracle_find_contraction_edges.restype = C.c_int
         _lib.ms_oracle_edit_distance.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_uint32]
         _lib.ms_oracle_edit_distance.restype = C.c_uint32
+        _lib.ms_oracle_edit_distance_banded.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_uint32]
+        _lib.ms_oracle_edit_distance_banded.restype = C.c_uint32
     return _lib
 
 
@@ -248,3 +250,8 @@ def between_anchors(ml, mr, nano, illu_l, illu_r, ov_l, ov_r, direction):
 def edit_distance(a, b, band):
     """min(Levenshtein(a, b), band + 1)"""
     return int(lib().ms_oracle_edit_distance(a, len(a), b, len(b), band))
+
+
+def edit_distance_banded(a, b, band):
+    """Levenshtein distance inside the band |i - j| <= band; band + 1 = 'more than band'.  O(len * band)."""
+    return int(lib().ms_oracle_edit_distance_banded(a, len(a), b, len(b), band))

@@ -214,7 +214,7 @@ def test_contig_of_exact_reads_is_the_genome_up_to_joint_duplicates(oracle, worl
         lo = min(w.read_start[p["id"]] for p in path)
         hi = max(w.read_start[p["id"]] for p in path) + w.read_len
         t = revcomp(r["target"]) if flip else r["target"]
-        d = oracle.edit_distance(t, w.genome[lo:hi], 400)
+        d = oracle.edit_distance_banded(t, w.genome[lo:hi], 400)
         assert d <= 6 * r["n_anchors"], (d, r["n_anchors"])  # ~4 duplicated bases per placed anchor
         assert abs(len(t) - (hi - lo)) == d  # pure insertions
 
