@@ -251,6 +251,9 @@ def main():
     ap.add_argument("--no-consensus", action="store_true", help="skip the consensus (sequence gather) leg")
     ap.add_argument("--assemble-window-mb", type=float, default=10.0,
                     help="assemblePath leg: chain the reads starting in the first this-many Mb of the genome (0 = skip)")
+    ap.add_argument("--graph-stage", action="store_true",
+                    help="also time findContractionEdges (GPU) and the host graph stage on the job's tables (slow on "
+                         "this workload: one 100k-vertex component, see DESIGN.md section 10)")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the N>1 exchange path (all-gather + merge) even at world size 1 (used by the GPU tests)")
     args = ap.parse_args()
@@ -355,9 +358,37 @@ def main():
     else:
         n_edges_total = int(c.n_edges)
 
-    asm_leg = None
+    asm_leg = graph_leg = None
     if world == 1 and rank == 0 and args.assemble_window_mb > 0 and not args.no_consensus:
+        # what follows the chaining fan-out in main(): findContractionEdges on the GPU (tables still resident), then the
+        # host graph stage (src/main.cpp:183-310).  Reported beside the metric, never inside `value`.
+        torch.cuda.synchronize()
+        ctx.find_contraction_edges()  # warm-up: arena allocation
+        t0 = time.perf_counter()
+        contraction = ctx.find_contraction_edges()
+        t_contr = time.perf_counter() - t0
         tables = ctx.tables()
+        graph_leg = {"find_contraction_edges_ms_incl_copy_back": 1e3 * t_contr,
+                     "contraction_edges": int((contraction >= 0).sum()),
+                     "shadow_edges": int(tables["edges"]["shadow"].sum())}
+        if args.graph_stage:
+            from muchsalsa_amd.graph import GraphStage
+            read_len, read_first = ctx.reads()
+            t0 = time.perf_counter()
+            gs = GraphStage(tables, read_len, read_first)
+            t_build = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            gs.clean_up(contraction, None)
+            t_clean = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            gs.linearize()
+            t_lin = time.perf_counter() - t0
+            st = gs.stats
+            graph_leg.update({"graph_build_ms": 1e3 * t_build, "clean_up_ms": 1e3 * t_clean, "linearize_ms": 1e3 * t_lin,
+                              "vertices_after": int(st.n_vertices), "edges_after": int(st.n_edges),
+                              "decycled_edges": int(st.n_decycled_edges), "components": int(st.n_components),
+                              "paths": int(st.n_paths), "path_reads": int(st.n_path_reads)})
+            gs.close()
         ctx.close()
         asm_leg = assemble_leg(torch, dev, w, rows, read_names, anchor_names, tables, args.assemble_window_mb, 3)
         del tables
@@ -410,6 +441,8 @@ def main():
                              "traffic": PMC_TRAFFIC_BYTES.get((args.workload, world), {}).get("k_gather"),
                              "algorithmic_bytes_per_launch": int(gb * 1e9)},
             }
+        if graph_leg is not None:
+            out["graph_stage"] = graph_leg
         if asm_leg is not None:
             tot_ms = asm_leg["layout_ms"] + asm_leg["device_ms"]
             asm_leg["consensus_mbases_per_s"] = asm_leg["target_bases"] / (tot_ms * 1e-3) / 1e6

@@ -57,3 +57,40 @@ def varlen_rows(n_reads, n_anchors, genome, seed, len_lo=1500, len_hi=9000, jitt
         layout.update(r_start=r_start[r], r_len=r_len[r], r_fwd=r_fwd[r], a_start=a_start[a], a_len=a_len[a],
                       genome=genome)
     return rows
+
+
+_COMP = bytes.maketrans(b"ACGT", b"TGCA")
+
+
+def make_dataset(d, seed, jitter, fastq, n_reads=400, genome_len=250_000):
+    """Write contigs.paf, unitigs.fa and nanopore.fa/.fq for a tiled-anchor data set into directory d (a pathlib.Path)
+    -> (rows, layout, genome, nano {id: bytes}, illu {id: bytes}, name of the read file)"""
+    lay = {}
+    rows = varlen_rows(n_reads, 0, genome_len, seed, tiled=True, layout=lay, jitter=jitter)
+    genome = np.random.default_rng(99 + seed).choice(np.frombuffer(b"ACGT", dtype=np.uint8), genome_len).tobytes()
+    nano, illu = {}, {}
+    for i in range(len(lay["r_start"])):
+        s = genome[int(lay["r_start"][i]): int(lay["r_start"][i]) + int(lay["r_len"][i])]
+        nano[i] = s if lay["r_fwd"][i] else s.translate(_COMP)[::-1]
+    for j in range(len(lay["a_start"])):
+        illu[j] = genome[int(lay["a_start"][j]): int(lay["a_start"][j]) + int(lay["a_len"][j])]
+    with open(d / "contigs.paf", "w") as f:  # one line per row, in line order, + the line the reference never parses
+        for r in rows:
+            a, rd = int(r["anchor_id"]), int(r["read_id"])
+            f.write("u%d\t%d\t%d\t%d\t%s\tr%d\t%d\t%d\t%d\t%d\t%d\t60\n" % (
+                a, len(illu[a]), r["i_lo"], int(r["i_hi"]) + 1, "+" if int(r["flags"]) & 1 else "-", rd, r["read_len"],
+                r["n_lo"], int(r["n_hi"]) + 1, r["score"], int(r["i_hi"]) + 1 - int(r["i_lo"])))
+        f.write("u0\t1\t0\t1\t+\tr0\t1\t0\t1\t0\t1\t0\n")
+    with open(d / "unitigs.fa", "wb") as f:
+        for j in sorted(illu, reverse=True):  # file order is unrelated to Registry order
+            f.write(b">u%d some description\n" % j)
+            for k in range(0, len(illu[j]), 70):
+                f.write(illu[j][k:k + 70] + b"\n")
+    name = "nanopore.fq" if fastq else "nanopore.fa"
+    with open(d / name, "wb") as f:
+        for i in sorted(nano):
+            if fastq:
+                f.write(b"@r%d\n" % i + nano[i] + b"\n+\n" + b"I" * len(nano[i]) + b"\n")
+            else:
+                f.write(b">r%d\n" % i + nano[i] + b"\n")
+    return rows, lay, genome, nano, illu, name
