@@ -19,7 +19,9 @@
 // as in DESIGN.md section 9: vertices ascending id, edges in creation order ((v1, v2) table order for the undirected
 // graph), neighbours ascending id, std::sort ties stable, pointer-ordered containers ordered by vertex id.
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <map>
@@ -446,65 +448,19 @@ ClusterWeights find_cluster_weights_heuristic(const DiGraph &dg) { // lg.cpp:72-
   return result;
 }
 
-std::vector<uint32_t> find_conservation_path_alt(const DiGraph &dg, const ClusterWeights &cw) { // lg.cpp:267-344
-  const std::vector<uint32_t> order = dg.sort_topologically();
-  std::vector<uint32_t>       final_path;
-  std::unordered_map<uint32_t, std::pair<uint64_t, std::vector<uint32_t>>> open;
-  for (uint32_t v : order) {
-    if (dg.outdeg.at(v) == 0) {
-      auto it = open.find(v);
-      if (it == open.end()) {
-        if (final_path.empty()) final_path = {v};
-      } else {
-        if (it->second.second.size() > final_path.size()) final_path = std::move(it->second.second);
-        it->second.second.clear();
-      }
-      continue;
-    }
-    std::vector<std::pair<uint32_t, uint32_t>> max_outs;
-    uint64_t                                   max_out = 0;
-    for (auto &t : dg.successors(v)) {
-      uint32_t a = t.second->a, b = t.second->b;
-      if (b != t.first) std::swap(a, b);
-      const uint64_t w = cw.at(t.second.get());
-      if (w > max_out) {
-        max_out  = w;
-        max_outs = {{a, b}};
-      } else if (w == max_out) {
-        max_outs.emplace_back(a, b);
-      }
-    }
-    for (auto &edge : max_outs) {
-      const uint32_t nxt = edge.second;
-      auto           pn  = open.find(nxt);
-      if (pn != open.end()) {
-        // open[v] is default-constructed exactly when the reference's expression touches it (:320-321)
-        bool take;
-        if (pn->second.first < max_out) take = true;
-        else if (pn->second.first == max_out) take = pn->second.second.size() < open[v].second.size() + 1;
-        else take = false;
-        if (take) {
-          std::vector<uint32_t> tmp = open[v].second;
-          tmp.push_back(nxt);
-          open[nxt] = {max_out, std::move(tmp)};
-        }
-      } else {
-        auto pv = open.find(v);
-        if (pv != open.end()) {
-          std::vector<uint32_t> tmp = pv->second.second;
-          tmp.push_back(nxt);
-          open[nxt] = {max_out, std::move(tmp)};
-        } else {
-          open[nxt] = {max_out, {edge.first, edge.second}};
-        }
-      }
-    }
-    open[v].second.clear();
+struct Tick { // MSGPU_GRAPH_DEBUG=1: phase timings on stderr
+  std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+  bool on = std::getenv("MSGPU_GRAPH_DEBUG") != nullptr;
+  void operator()(const char *what) {
+    if (!on) return;
+    auto n = std::chrono::steady_clock::now();
+    fprintf(stderr, "[graph] %-28s %8.3f s\n", what, std::chrono::duration<double>(n - t).count());
+    t = n;
   }
-  return final_path;
-}
+};
 
 std::vector<std::vector<uint32_t>> extract_paths(DiGraph &dg) { // lg.cpp:347-414
+  Tick tick;
   DiGraph cyc = dg;                                              // shallow: edges are shared
   {
     std::vector<DEdgeP> sh;
@@ -512,29 +468,154 @@ std::vector<std::vector<uint32_t>> extract_paths(DiGraph &dg) { // lg.cpp:347-41
       if (e.second->shadow) sh.push_back(e.second);
     for (auto &e : sh) cyc.delete_edge(e);
   }
+  tick("copy + drop shadow edges");
   sort_reduction_by_weight(cyc);
+  tick("sortReductionByWeight");
   const ClusterWeights cw =
       cyc.vertices.size() < 150000 ? find_cluster_weights(cyc) : find_cluster_weights_heuristic(cyc);
+  tick("findClusterWeights");
   std::vector<std::vector<uint32_t>> paths;
   std::unordered_set<uint32_t>       visited;
-  while (!cyc.edges.empty()) {
-    const std::vector<uint32_t> longest = find_conservation_path_alt(cyc, cw);
-    if (longest.empty()) throw GraphError("extractPaths: empty path");
+  // The reference re-sorts the whole remaining graph topologically and re-runs findConservationPathAlt for every path
+  // it peels off (lg.cpp:371-407), O(paths x (V + E)) on hash maps.  Same loop here on a dense mirror of `cyc` that
+  // only holds vertices which still have an edge: vertices without edges keep their relative place in the stack-based
+  // topological order, can only ever offer a one-vertex path, and a path of >= 2 vertices exists while edges exist,
+  // so dropping them changes neither the path found nor the tie-breaks among the others.
+  struct Arc {
+    uint32_t     to;
+    const DEdge *e;
+  };
+  std::vector<uint32_t>                ids; // local -> global, ascending
+  std::unordered_map<uint32_t, uint32_t> loc;
+  for (uint32_t v : cyc.vertices)
+    if (!cyc.successors(v).empty() || !cyc.predecessors(v).empty()) {
+      loc.emplace(v, static_cast<uint32_t>(ids.size()));
+      ids.push_back(v);
+    }
+  const uint32_t                n = static_cast<uint32_t>(ids.size());
+  std::vector<std::vector<Arc>> succ(n), pred(n); // ascending neighbour (local ids keep the global order)
+  size_t                        n_arcs = 0;
+  for (uint32_t l = 0; l < n; ++l) {
+    for (auto &t : cyc.successors(ids[l])) succ[l].push_back(Arc{loc.at(t.first), t.second.get()});
+    for (auto &t : cyc.predecessors(ids[l])) pred[l].push_back(Arc{loc.at(t.first), t.second.get()});
+    n_arcs += succ[l].size();
+  }
+  std::vector<uint32_t> active(n);
+  for (uint32_t l = 0; l < n; ++l) active[l] = l;
+  std::vector<int64_t>  deg(n);
+  std::vector<uint32_t> order, ready, stamp(n, 0);
+  std::vector<std::pair<uint64_t, std::vector<uint32_t>>> open(n);
+  uint32_t round = 0;
+  while (n_arcs > 0) {
+    // DiGraph::sortTopologically (Graph.cpp:359-395) over the active vertices
+    order.clear();
+    ready.clear();
+    for (uint32_t v : active) {
+      deg[v] = static_cast<int64_t>(pred[v].size());
+      if (!deg[v]) ready.push_back(v);
+    }
+    while (!ready.empty()) {
+      const uint32_t v = ready.back();
+      ready.pop_back();
+      for (const Arc &t : succ[v])
+        if (--deg[t.to] == 0) ready.push_back(t.to);
+      order.push_back(v);
+    }
+    // findConservationPathAlt (lg.cpp:267-344); open[] entries are valid when stamp[] == round
+    ++round;
+    std::vector<uint32_t> final_path;
+    auto has_open = [&](uint32_t v) { return stamp[v] == round; };
+    auto touch    = [&](uint32_t v) -> std::pair<uint64_t, std::vector<uint32_t>> & { // operator[] of the reference
+      if (stamp[v] != round) {
+        stamp[v]      = round;
+        open[v].first = 0;
+        open[v].second.clear();
+      }
+      return open[v];
+    };
+    std::vector<std::pair<uint32_t, uint32_t>> max_outs;
+    for (uint32_t v : order) {
+      if (succ[v].empty()) {
+        if (!has_open(v)) {
+          if (final_path.empty()) final_path = {v};
+        } else {
+          if (open[v].second.size() > final_path.size()) final_path = std::move(open[v].second);
+          open[v].second.clear();
+        }
+        continue;
+      }
+      max_outs.clear();
+      uint64_t max_out = 0;
+      for (const Arc &t : succ[v]) {
+        const uint64_t w = cw.at(t.e);
+        if (w > max_out) {
+          max_out = w;
+          max_outs.clear();
+          max_outs.emplace_back(v, t.to);
+        } else if (w == max_out) {
+          max_outs.emplace_back(v, t.to);
+        }
+      }
+      for (auto &edge : max_outs) {
+        const uint32_t nxt = edge.second;
+        if (has_open(nxt)) {
+          bool take;
+          if (open[nxt].first < max_out) take = true;
+          else if (open[nxt].first == max_out) take = open[nxt].second.size() < touch(v).second.size() + 1;
+          else take = false;
+          if (take) {
+            std::vector<uint32_t> tmp = touch(v).second;
+            tmp.push_back(nxt);
+            open[nxt] = {max_out, std::move(tmp)};
+          }
+        } else if (has_open(v)) {
+          std::vector<uint32_t> tmp = open[v].second;
+          tmp.push_back(nxt);
+          touch(nxt) = {max_out, std::move(tmp)};
+        } else {
+          touch(nxt) = {max_out, {edge.first, edge.second}};
+        }
+      }
+      touch(v).second.clear();
+    }
+    if (final_path.empty()) throw GraphError("extractPaths: empty path");
+    std::vector<uint32_t> longest;
+    for (uint32_t l : final_path) longest.push_back(ids[l]);
     if (longest.size() < 10) {
       bool in_visit = false, out_visit = false;
       for (auto &p : dg.predecessors(longest.front())) in_visit = in_visit || visited.count(p.first);
-      for (auto &s : dg.successors(longest.back())) out_visit = out_visit || visited.count(s.first);
+      for (auto &q : dg.successors(longest.back())) out_visit = out_visit || visited.count(q.first);
       if ((!in_visit && !out_visit) || ((in_visit || out_visit) && longest.size() > 5)) paths.push_back(longest);
     } else {
       paths.push_back(longest);
     }
-    for (uint32_t v : longest) {
-      visited.insert(v);
-      cyc.delete_vertex(v);
+    for (uint32_t l : final_path) { // diGraphCycle.deleteVertex
+      visited.insert(ids[l]);
+      for (const Arc &t : succ[l]) {
+        auto &pv = pred[t.to];
+        pv.erase(std::find_if(pv.begin(), pv.end(), [&](const Arc &a) { return a.to == l; }));
+      }
+      for (const Arc &t : pred[l]) {
+        auto &sv = succ[t.to];
+        sv.erase(std::find_if(sv.begin(), sv.end(), [&](const Arc &a) { return a.to == l; }));
+        --n_arcs;
+      }
+      n_arcs -= succ[l].size();
+      succ[l].clear();
+      pred[l].clear();
     }
+    active.erase(std::remove_if(active.begin(), active.end(),
+                                [&](uint32_t v) { return succ[v].empty() && pred[v].empty(); }),
+                 active.end());
   }
-  for (uint32_t v : cyc.vertices) paths.push_back({v});
-  return paths;
+  {
+    std::vector<uint32_t> left;
+    for (uint32_t v : cyc.vertices)
+      if (!visited.count(v)) left.push_back(v);
+    tick("conservation paths loop");
+    for (uint32_t v : left) paths.push_back({v});
+    return paths;
+  }
 }
 
 std::vector<std::vector<uint32_t>> linearize_graph(DiGraph &dg) { // lg.cpp:522-629
