@@ -52,7 +52,10 @@ __device__ __forceinline__ void load16_unaligned(const uint8_t *p, uint32_t out[
   out[3]             = __builtin_amdgcn_alignbyte(w4, v.w, sh);
 }
 
-constexpr int GUNROLL = 2; // chunks per wavefront: both chunks' loads are in flight before the first is consumed
+#ifndef MSGPU_GUNROLL
+#define MSGPU_GUNROLL 2
+#endif
+constexpr int GUNROLL = MSGPU_GUNROLL; // chunks per wavefront: all chunks' loads are in flight before the first is consumed
 
 __global__ __launch_bounds__(256) void k_gather(const msgpu_copy *pieces, const uint2 *chunk_map, uint64_t n_chunks,
                                                 const uint8_t *base0, const uint8_t *base1, uint8_t *out) {
