@@ -11,13 +11,18 @@
 //                               phases after src/main.cpp:178 run unchanged.  It is a template over the reference
 //                               types, so this header has no dependency on the reference tree (or on GSL).
 //
+//   3. msgpu::assemble(...)     the whole of main() (src/main.cpp:130-322) over the C-ABI: PAF + unitigs + long reads ->
+//                               the three output files, for builds that drop the reference's own phases altogether.
+//
 // INTEGRATION.md shows the patch of src/main.cpp that uses it.
 #ifndef MSGPU_ADAPTER_HPP
 #define MSGPU_ADAPTER_HPP
 
 #include <cstddef>
 #include <cstdint>
+#include <cstdio>
 #include <memory>
+#include <unordered_map>
 #include <stdexcept>
 #include <string>
 #include <utility>
@@ -95,6 +100,14 @@ public:
   }
 
   // Registry reverse look-ups (valid after read())
+  // findContractionEdges fan-out (src/main.cpp:183-190): per edge the index of its contraction order, or -1
+  std::vector<std::int64_t> findContractionEdges() {
+    std::vector<std::int64_t> out(counts().n_edges, -1);
+    check(msgpu_find_contraction_edges(m_ctx, nullptr, 0, nullptr, 0, 0, out.data()), m_ctx);
+    return out;
+  }
+  std::uint32_t readCount() const { return msgpu_paf_read_count(m_paf); }
+  std::uint32_t anchorCount() const { return msgpu_paf_anchor_count(m_paf); }
   char const *readName(std::uint32_t id) const { return msgpu_paf_read_name(m_paf, id); }
   char const *anchorName(std::uint32_t id) const { return msgpu_paf_anchor_name(m_paf, id); }
   msgpu_row const *rows(std::size_t *n) const { return msgpu_paf_rows(m_paf, n); }
@@ -171,6 +184,115 @@ void fillReferenceObjects(OverlapCore const &core, OverlapTables const &t, Graph
                                    (o.flags & MSGPU_ORD_DIR) != 0, (o.flags & MSGPU_ORD_PRIMARY) != 0});
     }
   }
+}
+
+// ---- 3. the whole executable ------------------------------------------------------------------------------------------
+
+struct AssemblyCounts {
+  std::uint64_t rows = 0, reads = 0, edges = 0, orders = 0, contractionEdges = 0, paths = 0, pathsSkipped = 0,
+                contigs = 0, targetBases = 0, queries = 0;
+};
+
+namespace detail {
+inline void require(int rc, char const *what, char const *detail = nullptr) {
+  if (rc == MSGPU_OK) return;
+  std::string msg = std::string(what) + ": " + msgpu_strerror(rc);
+  if (detail && *detail) msg += std::string(" (") + detail + ")";
+  throw std::runtime_error(msg);
+}
+// SequenceAccessor::_build*Idx (SequenceAccessor.cpp:143-231): Registry::operator[] per record -- names the PAF
+// registered keep their id, unknown names take the next free ids in file order
+inline std::vector<std::uint32_t> registryIds(msgpu_seqfile const *f, std::uint32_t known, char const *(*name)(void const *, std::uint32_t),
+                                              void const *ctx, std::uint32_t *space) {
+  std::unordered_map<std::string, std::uint32_t> reg;
+  for (std::uint32_t i = 0; i < known; ++i) reg.emplace(name(ctx, i), i);
+  std::vector<std::uint32_t> ids(msgpu_seq_count(f));
+  for (std::uint32_t i = 0; i < ids.size(); ++i)
+    ids[i] = reg.emplace(msgpu_seq_name(f, i), static_cast<std::uint32_t>(reg.size())).first->second;
+  *space = static_cast<std::uint32_t>(reg.size());
+  return ids;
+}
+} // namespace detail
+
+// main() of the reference (src/main.cpp:130-322): contigs PAF, unitig FASTA, long-read FASTA/FASTQ -> outDir/temp_1.*
+inline AssemblyCounts assemble(std::string const &contigsPaf, std::string const &unitigsPath,
+                               std::string const &nanoporePath, std::string const &outDir, unsigned threads = 1,
+                               std::size_t wiggleRoom = 300, int device = 0) {
+  AssemblyCounts n;
+  OverlapCore    core(device, wiggleRoom);
+  core.read(contigsPaf);                       // :153-156
+  core.calculateEdges();                       // :157
+  core.chainingAndOverlaps();                  // :170-178
+  auto const contraction = core.findContractionEdges(); // :183-190
+  auto const t           = core.tables();
+  std::size_t      nRows = 0;
+  msgpu_row const *rows  = core.rows(&nRows);
+  n.rows = nRows, n.reads = t.readLength.size(), n.edges = t.edges.size(), n.orders = t.orders.size();
+  for (auto c : contraction) n.contractionEdges += c >= 0;
+
+  struct Graph { // :194-310
+    msgpu_graph *g = nullptr;
+    ~Graph() { msgpu_graph_free(g); }
+  } graph;
+  detail::require(msgpu_graph_create(t.edges.data(), t.edges.size(), t.ems.data(), t.ems.size(), t.orders.data(),
+                                     t.orders.size(), t.ids.data(), t.ids.size(), t.readLength.data(),
+                                     t.readFirstLine.data(), static_cast<std::uint32_t>(t.readLength.size()), &graph.g),
+                  "msgpu_graph_create");
+  detail::require(msgpu_graph_clean_up(graph.g, contraction.data(), rows, nRows), "msgpu_graph_clean_up",
+                  msgpu_graph_last_error(graph.g));
+  detail::require(msgpu_graph_linearize(graph.g), "msgpu_graph_linearize", msgpu_graph_last_error(graph.g));
+
+  struct Seq { // :161-163
+    msgpu_seqctx  *ctx = nullptr;
+    msgpu_seqfile *fn = nullptr, *fi = nullptr;
+    msgpu_assembly *as = nullptr;
+    ~Seq() {
+      msgpu_assembly_free(as);
+      msgpu_seq_free(fn);
+      msgpu_seq_free(fi);
+      msgpu_seq_destroy(ctx);
+    }
+  } s;
+  detail::require(msgpu_seq_create(device, &s.ctx), "msgpu_seq_create");
+  detail::require(msgpu_seq_parse(nanoporePath.c_str(), -1, &s.fn), "nanopore file");
+  detail::require(msgpu_seq_parse(unitigsPath.c_str(), 0, &s.fi), "unitig file");
+  std::uint32_t space = 0;
+  auto          ids   = detail::registryIds(
+      s.fn, core.readCount(), [](void const *c, std::uint32_t i) { return static_cast<OverlapCore const *>(c)->readName(i); },
+      &core, &space);
+  detail::require(msgpu_seq_upload(s.ctx, 0, s.fn, ids.data(), space), "upload reads", msgpu_seq_last_error(s.ctx));
+  ids = detail::registryIds(
+      s.fi, core.anchorCount(), [](void const *c, std::uint32_t i) { return static_cast<OverlapCore const *>(c)->anchorName(i); },
+      &core, &space);
+  detail::require(msgpu_seq_upload(s.ctx, 1, s.fi, ids.data(), space), "upload unitigs", msgpu_seq_last_error(s.ctx));
+
+  detail::require(msgpu_assembly_create(s.ctx, &s.as), "msgpu_assembly_create"); // :300-310, 620-677
+  detail::require(msgpu_assembly_set_rows(s.as, rows, nRows), "msgpu_assembly_set_rows");
+  std::vector<msgpu_path_input> in(msgpu_graph_path_count(graph.g));
+  for (std::uint32_t i = 0; i < in.size(); ++i) detail::require(msgpu_graph_path_input(graph.g, i, &in[i]), "path input");
+  std::vector<int> status(in.size(), 0);
+  detail::require(msgpu_assembly_add_paths(s.as, in.data(), in.size(), threads ? threads : 1, status.data()),
+                  "msgpu_assembly_add_paths", msgpu_assembly_last_error(s.as));
+  detail::require(msgpu_assembly_finish(s.as, nullptr), "msgpu_assembly_finish", msgpu_seq_last_error(s.ctx));
+  n.paths = in.size();
+  for (int st : status) n.pathsSkipped += st != MSGPU_OK;
+  n.contigs = msgpu_assembly_path_count(s.as);
+  n.queries = msgpu_assembly_query_count(s.as);
+  for (std::uint32_t i = 0; i < n.contigs; ++i) {
+    msgpu_path_info pi;
+    msgpu_assembly_path_info(s.as, i, &pi);
+    n.targetBases += pi.target_len;
+  }
+  char const *const names[3] = {"/temp_1.target.fa", "/temp_1.query.fa", "/temp_1.align.paf"}; // :294-296
+  for (int w = 0; w < 3; ++w) {
+    std::uint64_t len  = 0;
+    char const   *text = msgpu_assembly_text(s.as, w, &len);
+    std::FILE    *f    = std::fopen((outDir + names[w]).c_str(), "wb");
+    if (!f) throw std::runtime_error("cannot write " + outDir + names[w]);
+    if (len) std::fwrite(text, 1, len, f);
+    std::fclose(f);
+  }
+  return n;
 }
 
 } // namespace msgpu

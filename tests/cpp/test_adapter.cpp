@@ -109,6 +109,20 @@ int main(int argc, char **argv) {
     }
     return 0;
   }
+  if (argc >= 6 && std::string(argv[1]) == "--assemble") { // <paf> <unitigs> <nanopore> <outdir>: the whole main()
+    try {
+      auto const n = msgpu::assemble(argv[2], argv[3], argv[4], argv[5], 4, 300, 0);
+      std::printf("{\"rows\": %llu, \"edges\": %llu, \"contraction_edges\": %llu, \"paths\": %llu, \"paths_skipped\": %llu, "
+                  "\"contigs\": %llu, \"target_bases\": %llu, \"queries\": %llu}\n",
+                  (unsigned long long)n.rows, (unsigned long long)n.edges, (unsigned long long)n.contractionEdges,
+                  (unsigned long long)n.paths, (unsigned long long)n.pathsSkipped, (unsigned long long)n.contigs,
+                  (unsigned long long)n.targetBases, (unsigned long long)n.queries);
+      return 0;
+    } catch (std::exception const &e) {
+      std::printf("FAIL: %s\n", e.what());
+      return 1;
+    }
+  }
   msgpu::OverlapCore core(0, 300);
   core.read(argv[1]);
   core.calculateEdges();

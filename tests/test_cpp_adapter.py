@@ -40,3 +40,25 @@ def test_adapter_end_to_end_fills_reference_shaped_objects(adapter_bin, oracle, 
     assert got == {"vertices": int(rows["read_id"].max()) + 1, "edges": len(t["edges"]),
                    "vertexmatches": t["rows_alive"], "edgematches": len(t["ems"]), "orders": len(t["orders"]),
                    "shadows": t["shadow_edges"], "ids": len(t["ids"])}
+
+
+@pytest.mark.gpu
+def test_cpp_whole_flow_writes_the_same_files_as_the_python_driver(adapter_bin, tmp_path):
+    """msgpu::assemble (the C++ statement of main(), include/msgpu_adapter.hpp) and muchsalsa_amd.pipeline.run drive the
+    same C-ABI: identical temp_1.* files from the same inputs, with no Python between the calls."""
+    from graphcases import make_dataset
+    from muchsalsa_amd import pipeline
+    make_dataset(tmp_path, 7, 8, True)
+    (tmp_path / "cpp").mkdir()
+    (tmp_path / "py").mkdir()
+    r = subprocess.run([adapter_bin, "--assemble", str(tmp_path / "contigs.paf"), str(tmp_path / "unitigs.fa"),
+                        str(tmp_path / "nanopore.fq"), str(tmp_path / "cpp")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    got = json.loads(r.stdout.strip().splitlines()[-1])
+    want = pipeline.run(str(tmp_path / "contigs.paf"), str(tmp_path / "unitigs.fa"), str(tmp_path / "nanopore.fq"),
+                        str(tmp_path / "py"), threads=2)
+    for k in ("rows", "edges", "contraction_edges", "paths", "paths_skipped", "contigs", "target_bases", "queries"):
+        assert got[k] == want[k], k
+    assert got["contigs"] >= 1 and got["target_bases"] > 200_000
+    for name in ("temp_1.target.fa", "temp_1.query.fa", "temp_1.align.paf"):
+        assert (tmp_path / "cpp" / name).read_bytes() == (tmp_path / "py" / name).read_bytes(), name
