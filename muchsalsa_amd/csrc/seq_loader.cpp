@@ -50,6 +50,31 @@ struct LineReader { // readline (libms/src/IO.cpp:54-97) over a memory image
   }
 };
 
+// 1: std::isspace in the "C" locale (removed), 2: NUL (cuts the record), 0: kept
+struct BlankTable {
+  unsigned char t[256] = {0};
+  constexpr BlankTable() {
+    t[static_cast<unsigned char>(' ')] = t[static_cast<unsigned char>('\t')] = t[static_cast<unsigned char>('\n')] = 1;
+    t[static_cast<unsigned char>('\v')] = t[static_cast<unsigned char>('\f')] = t[static_cast<unsigned char>('\r')] = 1;
+    t[0] = 2;
+  }
+  constexpr unsigned char operator[](unsigned char c) const { return t[c]; }
+};
+constexpr BlankTable BLANK{};
+
+// any byte < 0x21 among n bytes (8 at a time): every std::isspace character and NUL is below 0x21
+inline bool has_byte_below_0x21(const char *p, size_t n) {
+  size_t k = 0;
+  for (; k + 8 <= n; k += 8) {
+    uint64_t x;
+    std::memcpy(&x, p + k, 8);
+    if ((x - 0x2121212121212121ull) & ~x & 0x8080808080808080ull) return true;
+  }
+  for (; k < n; ++k)
+    if (static_cast<unsigned char>(p[k]) < 0x21) return true;
+  return false;
+}
+
 bool is_fastq_name(const char *path) {
   std::string_view p(path);
   size_t           dot = p.find_last_of('.');
@@ -100,20 +125,31 @@ int msgpu_seq_parse(const char *path, int is_fastq, msgpu_seqfile **out) {
       while (1 + idl < rl.line_len && !std::isspace(static_cast<unsigned char>(rl.line[1 + idl]))) ++idl;
       std::string id(rl.line + 1, idl);
       const bool  is_new   = ids.emplace(id, static_cast<uint32_t>(f->names.size())).second;
-      const char *body     = data + rl.pos;
-      size_t      body_len = 0;
-      while (true) { // :167-179
-        ret = rl.next();
-        if (ret == -1 || rl.line[0] == split) break;
-        body_len += static_cast<size_t>(ret);
-      }
       if (is_new) {
         f->names.push_back(std::move(id));
         f->off.push_back(f->bases.size());
-        for (size_t k = 0; k < body_len; ++k) {
-          const char ch = body[k];
-          if (ch == '\0') break;
-          if (!std::isspace(static_cast<unsigned char>(ch))) f->bases.push_back(ch);
+      }
+      bool cut = false; // an embedded NUL ends the record (std::string(buffer.data()), :65-67)
+      while (true) {    // :167-179
+        ret = rl.next();
+        if (ret == -1 || rl.line[0] == split) break;
+        if (!is_new || cut) continue;
+        // strip std::isspace characters: the usual line is bases + '\n' (or "\r\n"), so trim the tail and copy the
+        // rest with one memcpy when no other blank or NUL is inside; fall back to the byte loop otherwise
+        const char *p = rl.line;
+        size_t      n = rl.line_len;
+        while (n && BLANK[static_cast<unsigned char>(p[n - 1])] == 1) --n;
+        if (!has_byte_below_0x21(p, n)) { // no blank, no NUL, no control byte inside
+          f->bases.append(p, n);
+        } else {
+          for (size_t q = 0; q < n; ++q) {
+            const unsigned char ch = static_cast<unsigned char>(p[q]);
+            if (ch == 0) {
+              cut = true;
+              break;
+            }
+            if (BLANK[ch] != 1) f->bases.push_back(static_cast<char>(ch));
+          }
         }
       }
       while (ret != -1 && rl.line[0] != desc) ret = rl.next(); // :181-184
