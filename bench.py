@@ -418,7 +418,8 @@ def main():
                        "orders_rank0": int(c.n_orders), "parallelism": "edges sharded by v1 %% %d" % world,
                        "edges_proven_clean_rank0": int(c.n_edges_fastpath), "merged_edge_list_consistent": merge_ok,
                        "note": "value = overlap half of the metric; the consensus half is reported under 'consensus' "
-                               "(device gather stage only: assemblePath's layout logic is host-side and not built yet)"},
+                               "(the gather kernel alone at full size) and 'assemble_path' (assemblePath end to end: "
+                               "host layout + gather + FASTA wrapping, on a bounded sample of paths)"},
             "stage_ms": {"index": tm.index_ms, "candidates": tm.candidates_ms, "chain_total": tm.chain_ms,
                          "chain_kernel": k_ms, "compact": tm.compact_ms},
             "roofline": {"bound": "hbm", "kernel": "k_chain", "achieved": achieved, "peak": HBM_PEAK_GBS,
