@@ -417,6 +417,11 @@ uint64_t msgpu_assembly_raw_bytes(const msgpu_assembly *a);
 /* gather + FASTA wrapping on the device, texts copied to host memory owned by the assembly.  hip_stream NULL = the
  * context's stream.  Synchronous.  MSGPU_E_NODEVICE on a layout-only context. */
 int msgpu_assembly_finish(msgpu_assembly *a, void *hip_stream);
+/* After finish: banded Levenshtein distance (msgpu_edit_distance semantics, band <= 127) of every query record against
+ * the stretch of its contig that its PAF line names, clipped to the contig; distance[i] for query i (host, query_count
+ * entries): the distance when <= band, else band + 1.  dp_cells (optional): DP cells inside the band that were evaluated.
+ * No reference counterpart: it is the meter of how well the query records agree with the contig. */
+int msgpu_assembly_validate(msgpu_assembly *a, uint32_t band, uint32_t *distance, uint64_t *dp_cells);
 /* which: 0 = temp_1.target.fa, 1 = temp_1.query.fa (both after finish), 2 = temp_1.align.paf (after add_path) */
 const char *msgpu_assembly_text(const msgpu_assembly *a, int which, uint64_t *len);
 

@@ -154,6 +154,7 @@ SYMBOLS = [
     ("msgpu_assembly_pieces", C.c_size_t, [C.c_void_p, C.c_void_p, C.c_size_t]),
     ("msgpu_assembly_raw_bytes", C.c_uint64, [C.c_void_p]),
     ("msgpu_assembly_finish", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("msgpu_assembly_validate", C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(C.c_uint64)]),
     ("msgpu_assembly_text", C.c_void_p, [C.c_void_p, C.c_int, C.POINTER(C.c_uint64)]),
     ("msgpu_fasta_text_bytes", C.c_uint64, [C.c_uint32, C.c_uint64]),
     ("msgpu_fasta_format", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_char_p, C.c_size_t,

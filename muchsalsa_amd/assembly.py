@@ -126,6 +126,14 @@ class Assembly:
     def finish(self, stream=None):
         self._check(self._L.msgpu_assembly_finish(self._h, C.c_void_p(stream)))
 
+    def validate(self, band=64):
+        """banded edit distance of every query against its PAF window on the contig -> (uint32 per query, DP cells)"""
+        out = np.zeros(self._L.msgpu_assembly_query_count(self._h), dtype="<u4")
+        cells = C.c_uint64()
+        self._check(self._L.msgpu_assembly_validate(self._h, int(band), out.ctypes.data if len(out) else None,
+                                                    C.byref(cells)))
+        return out, int(cells.value)
+
     def text(self, which):
         n = C.c_uint64()
         p = self._L.msgpu_assembly_text(self._h, int(which), C.byref(n))

@@ -17,6 +17,8 @@ struct msgpu_assembly {
   std::string                   paf;                 // temp_1.align.paf
   std::string                   target_fa, query_fa; // filled by msgpu_assembly_finish
   bool                          finished = false;
+  void                         *d_raw    = nullptr; // the gathered bases, kept after finish for msgpu_assembly_validate
+  void (*release)(msgpu_assembly *) = nullptr;      // frees d_raw (set by msgpu_seq.hip, which owns the HIP calls)
   char                          err[256] = {0};
 };
 

@@ -738,7 +738,10 @@ int msgpu_assembly_create(msgpu_seqctx *ctx, msgpu_assembly **out) {
   return MSGPU_OK;
 }
 
-void        msgpu_assembly_free(msgpu_assembly *a) { delete a; }
+void msgpu_assembly_free(msgpu_assembly *a) {
+  if (a && a->release) a->release(a);
+  delete a;
+}
 const char *msgpu_assembly_last_error(const msgpu_assembly *a) { return a ? a->err : "null assembly"; }
 
 int msgpu_assembly_set_rows(msgpu_assembly *a, const msgpu_row *rows, size_t n_rows) {

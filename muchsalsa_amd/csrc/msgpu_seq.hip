@@ -496,14 +496,52 @@ int msgpu_assembly_finish(msgpu_assembly *a, void *hip_stream) {
       e = hipMemcpyAsync(&a->query_fa[0], d_q, q_bytes, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
   }
-  if (d_raw) (void)hipFree(d_raw);
   if (d_t) (void)hipFree(d_t);
   if (d_q) (void)hipFree(d_q);
   msgpu_gather_plan_free(plan);
-  if (e != hipSuccess) return sfail(c, e == hipErrorOutOfMemory ? MSGPU_E_NOMEM : MSGPU_E_HIP, "assembly finish", e);
-  if (rc != MSGPU_OK) return rc;
+  if (e != hipSuccess || rc != MSGPU_OK) {
+    if (d_raw) (void)hipFree(d_raw);
+    if (e != hipSuccess) return sfail(c, e == hipErrorOutOfMemory ? MSGPU_E_NOMEM : MSGPU_E_HIP, "assembly finish", e);
+    return rc;
+  }
+  a->d_raw   = d_raw; // kept for msgpu_assembly_validate
+  a->release = [](msgpu_assembly *x) {
+    if (x->d_raw) {
+      if (x->ctx && x->ctx->device >= 0) (void)hipSetDevice(x->ctx->device);
+      (void)hipFree(x->d_raw);
+      x->d_raw = nullptr;
+    }
+  };
   a->finished = true;
   return MSGPU_OK;
+}
+
+// Banded edit distance of every query record against the stretch of its contig that its PAF line names (columns 8-9):
+// the self-check of an assembly, and the first real workload of the anti-diagonal DP kernel.
+int msgpu_assembly_validate(msgpu_assembly *a, uint32_t band, uint32_t *distance, uint64_t *dp_cells) {
+  if (!a || (!a->queries.empty() && !distance)) return MSGPU_E_ARG;
+  if (!a->finished || !a->d_raw) return MSGPU_E_STATE;
+  std::vector<msgpu_align_pair> pairs(a->queries.size());
+  uint64_t                      cells = 0;
+  for (size_t i = 0; i < pairs.size(); ++i) {
+    const msgpu_query_info &q = a->queries[i];
+    const msgpu_path_info  &p = a->paths[q.path];
+    // window [lb, rb] on the contig, clipped to it (records placed outside the contig get an empty window)
+    int64_t lo = q.lb < 0 ? 0 : q.lb, hi = q.rb >= static_cast<int64_t>(p.target_len) ? static_cast<int64_t>(p.target_len) - 1 : q.rb;
+    if (hi < lo) {
+      lo = 0;
+      hi = -1;
+    }
+    if (q.len > 0xffffffffull) return MSGPU_E_ARG;
+    pairs[i].a_off = q.raw_off;
+    pairs[i].a_len = static_cast<uint32_t>(q.len);
+    pairs[i].b_off = p.target_raw_off + static_cast<uint64_t>(lo);
+    pairs[i].b_len = static_cast<uint32_t>(hi - lo + 1);
+    const uint64_t shorter = pairs[i].a_len < pairs[i].b_len ? pairs[i].a_len : pairs[i].b_len;
+    cells += shorter * (2ull * band + 1);
+  }
+  if (dp_cells) *dp_cells = cells;
+  return msgpu_edit_distance(a->ctx, a->d_raw, a->d_raw, pairs.data(), pairs.size(), band, distance);
 }
 
 int msgpu_seq_synchronize(msgpu_seqctx *c) {

@@ -27,7 +27,7 @@ def gpu_world(oracle, tmp_path_factory):
     return w
 
 
-def test_texts_match_oracle(gpu_world):
+def test_texts_match_oracle(gpu_world, oracle):
     from oracle.ms_assemble_py import AssemblyError, assemble_path
     from muchsalsa_amd.assembly import Assembly
     from muchsalsa_amd.overlap import MsgpuError
@@ -69,6 +69,20 @@ def test_texts_match_oracle(gpu_world):
     assert tgt == b"".join(r["target_fa"] for r in want)
     assert qry == b"".join(r["query_fa"] for r in want)
     assert sum(len(r["target"]) for r in want) == int(asm.paths["target_len"].sum())
+    # self-check on the device: every query against the stretch of the contig its PAF line names (banded DP kernel)
+    band = 100
+    dist, cells = asm.validate(band)
+    k, n_in_band = 0, 0
+    for r in want:
+        tlen = len(r["target"])
+        for name, seq, lb, rb in r["queries"]:
+            lo, hi = max(lb, 0), min(rb, tlen - 1)
+            window = r["target"][lo:hi + 1] if hi >= lo else b""
+            assert int(dist[k]) == oracle.edit_distance_banded(seq, window, band), (name, lb, rb)
+            n_in_band += int(dist[k]) <= band
+            k += 1
+    assert k == len(dist) and cells > 0
+    assert n_in_band > 0.5 * k  # the query records do lie where their PAF lines say
 
 
 def test_fasta_format_line_boundaries():
