@@ -211,6 +211,12 @@ def assemble_leg(torch, dev, w, rows, read_names, anchor_names, tables, window_m
     t_device = time.perf_counter() - t0
     info, qinfo = asm.paths, asm.queries
     T, Q = int(info["target_len"].sum()), int(qinfo["len"].sum())
+    # A10: the banded anti-diagonal DP kernel as the assembly's self-check (every query against its PAF window)
+    band = 64
+    asm.validate(band)  # warm-up
+    t0 = time.perf_counter()
+    dist, cells = asm.validate(band)
+    t_val = time.perf_counter() - t0
 
     ok = None
     if verify_paths:
@@ -237,7 +243,11 @@ def assemble_leg(torch, dev, w, rows, read_names, anchor_names, tables, window_m
             "query_bases": Q, "queries": int(len(qinfo)), "pieces": int(len(asm.pieces)),
             "layout_ms": 1e3 * t_layout, "layout_threads": threads, "device_ms": 1e3 * t_device, "row_index_ms": 1e3 * t_index,
             "path_builder_ms_untimed": 1e3 * t_paths, "verified_paths": verify_paths, "verified": ok,
-            "text_bytes": len(asm.text(0)) + len(asm.text(1)) + len(asm.text(2)), "window_mb": window_mb}
+            "text_bytes": len(asm.text(0)) + len(asm.text(1)) + len(asm.text(2)), "window_mb": window_mb,
+            "validate": {"kernel": "k_edit_distance", "band": band, "pairs": int(len(dist)), "ms_incl_copies": 1e3 * t_val,
+                         "dp_cells": cells, "dp_gcells_per_s": cells / t_val / 1e9,
+                         "queries_within_band": int((dist <= band).sum()),
+                         "median_distance": float(np.median(dist)) if len(dist) else None}}
 
 
 def main():
