@@ -792,7 +792,12 @@ int try_layout(const msgpu_assembly *a, const msgpu_path_input *in, PathResult &
   } catch (std::out_of_range const &e) {
     msg = std::string("missing map entry (") + e.what() + ")";
     return MSGPU_E_LAYOUT;
-  } catch (std::bad_alloc const &) { return MSGPU_E_NOMEM; }
+  } catch (std::bad_alloc const &) {
+    return MSGPU_E_NOMEM;
+  } catch (std::exception const &e) { // nothing may leave a worker thread or cross the C-ABI
+    msg = e.what();
+    return MSGPU_E_LAYOUT;
+  }
   return MSGPU_OK;
 }
 

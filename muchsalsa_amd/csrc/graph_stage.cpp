@@ -885,10 +885,12 @@ int msgpu_graph_clean_up(msgpu_graph *g, const int64_t *contraction_order, const
     g->stats.n_vertices = nv_alive;
     g->stats.n_edges    = ne_alive;
     g->cleaned          = true;
-  } catch (GraphError const &e) {
+  } catch (std::bad_alloc const &) {
+    return MSGPU_E_NOMEM;
+  } catch (std::exception const &e) { // GraphError and anything a container throws
     snprintf(g->err, sizeof(g->err), "%s", e.what());
     return MSGPU_E_LAYOUT;
-  } catch (std::bad_alloc const &) { return MSGPU_E_NOMEM; }
+  }
   return MSGPU_OK;
 }
 
@@ -972,13 +974,12 @@ int msgpu_graph_linearize(msgpu_graph *g) {
     }
     g->stats.n_paths = g->paths.size();
     g->linearized    = true;
-  } catch (GraphError const &e) {
+  } catch (std::bad_alloc const &) {
+    return MSGPU_E_NOMEM;
+  } catch (std::exception const &e) {
     snprintf(g->err, sizeof(g->err), "%s", e.what());
     return MSGPU_E_LAYOUT;
-  } catch (std::out_of_range const &e) {
-    snprintf(g->err, sizeof(g->err), "missing map entry (%s)", e.what());
-    return MSGPU_E_LAYOUT;
-  } catch (std::bad_alloc const &) { return MSGPU_E_NOMEM; }
+  }
   return MSGPU_OK;
 }
 
