@@ -24,6 +24,13 @@ BASE_WEIGHT_MULTIPLICATOR = 1.1  # src/main.cpp:96
 MAX_WEIGHT_MULTIPLICATOR = 0.8  # src/main.cpp:97
 
 
+COVER = {}  # branch counters for the tests' coverage assertions
+
+
+def _hit(name, n=1):
+    COVER[name] = COVER.get(name, 0) + n
+
+
 class GraphError(Exception):
     """The reference would terminate / hang / hit undefined behaviour here."""
 
@@ -299,7 +306,9 @@ def clean_up(g, edge_list, order_owner, contraction_order, vm_has):
                     i = weights.index(lo)
                     pe = g.get_edge(path[i], path[i + 1])
                     dele[id(pe)] = pe
+                    _hit("decycle_weak_tree_edge")
                 dele[id(e)] = e
+                _hit("decycle")
     for e in dele.values():  # :285-287
         g.delete_edge(e)
     return contain
@@ -412,6 +421,8 @@ def get_directed_graph(graph, component, start):
                 s, t = (o.end, o.start) if flip else (o.start, o.end)
                 ne = dg.get_edge(s, t)
                 if ne is None:
+                    if dg.has_edge(t, s):
+                        _hit("two_way_edge")
                     dg.add_edge(s, t)
                     ne = dg.get_edge(s, t)
                     ne.shadow = edge.shadow
@@ -460,6 +471,7 @@ def sort_reduction_by_weight(dg):  # lg.cpp:418-520
         if min_edge is None:
             raise GraphError("sortReductionByWeight: null edge dereferenced")
         min_edge.shadow = True
+        _hit("cycle_cut")
         dg.delete_edge(min_edge)
         nonnull[min_vertex] -= 1
         if nonnull[min_vertex] == 0:
@@ -597,6 +609,8 @@ def extract_paths(dg):  # lg.cpp:347-414
             out_visit = any(s in visited for s, _ in dg.successors(longest[-1]))
             if (not in_visit and not out_visit) or ((in_visit or out_visit) and len(longest) > 5):
                 paths.append(longest)
+            else:
+                _hit("short_path_dropped")
         else:
             paths.append(longest)
         for v in longest:
@@ -644,6 +658,7 @@ def linearize_graph(dg):  # lg.cpp:522-629
         i1, i2 = paths[c1].index(a), paths[c2].index(b)
         if color_len[c1] - i1 - 1 + i2 != dist:
             continue
+        _hit("join")
         paths[c1] = paths[c1][:i1 + 1] + paths[c2][i2:]
         paths[c2] = []
         color_corr[c2] = color_corr[c1]

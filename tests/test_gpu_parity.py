@@ -276,3 +276,29 @@ def test_find_contraction_edges_state_and_empty():
         ctx.find_contraction_edges()
     assert e.value.code == _lib.E_STATE
     ctx.close()
+
+
+def test_find_contraction_edges_on_random_graphs(oracle):
+    """sanityCheck's four containment cases and both outcomes on tables no overlap run would produce (random pairs,
+    random strand / containment / start side, 1-3 orders per edge), through the device-pointer form."""
+    import torch
+    from test_graph_stage import random_tables
+    from muchsalsa_amd.overlap import OverlapContext
+    rng = np.random.default_rng(77)
+    ctx = OverlapContext(device=0)
+    hits = cands = 0
+    for trial in range(60):
+        n_reads = int(rng.integers(5, 200))
+        n_edges = int(rng.integers(n_reads // 2, min(n_reads * 4, n_reads * (n_reads - 1) // 2) + 1))
+        t = random_tables(rng, n_reads, n_edges)
+        t["orders"]["flags"] |= np.where(rng.integers(0, 2, len(t["orders"])) == 0, 2, 0).astype(np.uint32)  # more contained
+        want = oracle.find_contraction_edges(t, n_reads)
+        d_e = torch.from_numpy(t["edges"].view(np.uint8).copy()).cuda()
+        d_o = torch.from_numpy(t["orders"].view(np.uint8).copy()).cuda()
+        torch.cuda.synchronize()
+        got = ctx.find_contraction_edges(d_e.data_ptr(), len(t["edges"]), d_o.data_ptr(), len(t["orders"]), n_reads)
+        assert np.array_equal(got, want), trial
+        hits += int((want >= 0).sum())
+        cands += int(((t["orders"]["flags"] & 10) == 10).sum())
+    ctx.close()
+    assert cands > 2000 and 20 < hits < cands

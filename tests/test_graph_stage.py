@@ -126,3 +126,79 @@ def test_graph_stage_argument_and_state_errors(oracle):
     t_bad["edges"]["v2"][0] = 10 ** 6  # vertex out of range
     with pytest.raises(MsgpuError):
         GraphStage(t_bad, t["read_len"], t["read_first_line"])
+
+
+def random_tables(rng, n_reads, n_edges, max_orders=3):
+    """Arbitrary (not overlap-derived) edge/order tables: random pairs, 1..max_orders orders per edge with random start
+    side, strand, containment, scores; a few anchors per order.  Everything the graph stage reads, nothing it checks."""
+    from muchsalsa_amd._lib import EDGE_DTYPE, EM_DTYPE, ORDER_DTYPE
+    pairs = set()
+    while len(pairs) < n_edges:
+        a, b = int(rng.integers(0, n_reads)), int(rng.integers(0, n_reads))
+        if a != b:
+            pairs.add((min(a, b), max(a, b)))
+    pairs = sorted(pairs)
+    edges = np.zeros(len(pairs), dtype=EDGE_DTYPE)
+    orders, ids, ems = [], [], []
+    for i, (a, b) in enumerate(pairs):
+        k = int(rng.integers(1, max_orders + 1))
+        edges[i] = (a, b, len(ems), len(orders), 2, k, int(rng.integers(0, 4) == 0), 0)
+        anchors = [int(x) for x in rng.choice(500, 2, replace=False)]
+        for anc in anchors:
+            ems.append((10, 400, 1.0, anc, 0, 3, i))
+        for _ in range(k):
+            start_v1 = bool(rng.integers(0, 2))
+            fl = (1 if start_v1 else 0) | (2 if rng.integers(0, 5) == 0 else 0) | (4 if rng.integers(0, 3) else 0) | \
+                 (8 if rng.integers(0, 2) else 0)
+            orders.append((i, fl, float(rng.integers(0, 400)), float(rng.integers(0, 400)), int(rng.integers(500, 5000)),
+                           len(ids), 2, a if start_v1 else b, b if start_v1 else a, a, (0, 0)))
+            ids.extend(anchors)
+    return dict(edges=edges, ems=np.array(ems, dtype=EM_DTYPE), orders=np.array(orders, dtype=ORDER_DTYPE),
+                ids=np.array(ids, dtype="<u4"), read_len=rng.integers(1000, 9000, n_reads).astype("<i4"),
+                read_first_line=rng.permutation(n_reads).astype("<u4"))
+
+
+def test_graph_stage_on_random_graphs(oracle):
+    """Differential fuzz on graphs the overlap path would never produce: dense cycles, two-way directed edges, strand
+    conflicts, many contractions.  Product and object-model oracle must agree on every state, path and rejection."""
+    from oracle import ms_graph_py as G
+    rng = np.random.default_rng(2024)
+    G.COVER.clear()
+    n_ok = n_rejected = n_paths = 0
+    for trial in range(400):
+        n_reads = int(rng.integers(5, 90))
+        n_edges = int(rng.integers(n_reads // 2, min(n_reads * 3, n_reads * (n_reads - 1) // 2) + 1))
+        t = random_tables(rng, n_reads, n_edges)
+        co = oracle.find_contraction_edges(t, n_reads)
+        rows = np.zeros(0, dtype=_lib.ROW_DTYPE)
+        try:
+            g, el, oo = G.build_graph(t, t["read_len"], t["read_first_line"])
+            contain = G.clean_up(g, el, oo, co, lambda r, a: True)
+            state_alive = np.array([id(e) in g.edges for e in el])
+            cons = np.array([{G.POS: 1, G.NEG: 0, G.NONE: 2}[e.consensus] for e in el], dtype=np.uint8)
+            paths = G.assemble_all(g, lambda a, b: {})
+        except (G.GraphError, KeyError, IndexError):
+            paths = None
+        gs = GraphStage(t, t["read_len"], t["read_first_line"])
+        if paths is None:
+            with pytest.raises(MsgpuError):
+                gs.clean_up(co, None)
+                gs.linearize()
+            n_rejected += 1
+            continue
+        gs.clean_up(co, None)
+        st = gs.state()
+        assert np.array_equal(st["edge_alive"], state_alive), trial
+        assert np.array_equal(st["edge_consensus"][state_alive], cons[state_alive]), trial
+        gs.linearize()
+        assert gs.path_count == len(paths), trial
+        for i, (want_path, want_steps) in enumerate(paths):
+            p, steps, cont = gs.path(i)
+            assert p == want_path, (trial, i)
+            assert [s["orders"] for s in steps] == [s["orders"] for s in want_steps], (trial, i)
+        n_ok += 1
+        n_paths += len(paths)
+    print('random graphs: ok %d, rejected %d, paths %d, branches %r' % (n_ok, n_rejected, n_paths, G.COVER))
+    for k in ("cycle_cut", "decycle", "decycle_weak_tree_edge", "short_path_dropped", "two_way_edge"):
+        assert G.COVER.get(k, 0) > 0, "branch never reached: " + k
+    assert n_ok > 200 and n_paths > 300, (n_ok, n_rejected, n_paths)
