@@ -23,8 +23,10 @@
 #include <cstdio>
 #include <memory>
 #include <unordered_map>
+#include <exception>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -220,7 +222,44 @@ inline AssemblyCounts assemble(std::string const &contigsPaf, std::string const 
                                std::size_t wiggleRoom = 300, int device = 0) {
   AssemblyCounts n;
   OverlapCore    core(device, wiggleRoom);
-  core.read(contigsPaf);                       // :153-156
+  core.read(contigsPaf); // :153-156
+
+  struct Seq { // :161-163 -- needs only the Registry, so it loads on a second host thread while the GPU and the graph
+               // stage work (every libmsgpu entry point selects its device itself)
+    msgpu_seqctx   *ctx = nullptr;
+    msgpu_seqfile  *fn = nullptr, *fi = nullptr;
+    msgpu_assembly *as = nullptr;
+    ~Seq() {
+      msgpu_assembly_free(as);
+      msgpu_seq_free(fn);
+      msgpu_seq_free(fi);
+      msgpu_seq_destroy(ctx);
+    }
+  } s;
+  std::exception_ptr loadError;
+  std::thread        loader([&]() {
+    try {
+      detail::require(msgpu_seq_create(device, &s.ctx), "msgpu_seq_create");
+      detail::require(msgpu_seq_parse(nanoporePath.c_str(), -1, &s.fn), "nanopore file");
+      detail::require(msgpu_seq_parse(unitigsPath.c_str(), 0, &s.fi), "unitig file");
+      std::uint32_t space = 0;
+      auto          ids   = detail::registryIds(
+          s.fn, core.readCount(),
+          [](void const *c, std::uint32_t i) { return static_cast<OverlapCore const *>(c)->readName(i); }, &core, &space);
+      detail::require(msgpu_seq_upload(s.ctx, 0, s.fn, ids.data(), space), "upload reads", msgpu_seq_last_error(s.ctx));
+      ids = detail::registryIds(
+          s.fi, core.anchorCount(),
+          [](void const *c, std::uint32_t i) { return static_cast<OverlapCore const *>(c)->anchorName(i); }, &core, &space);
+      detail::require(msgpu_seq_upload(s.ctx, 1, s.fi, ids.data(), space), "upload unitigs", msgpu_seq_last_error(s.ctx));
+    } catch (...) { loadError = std::current_exception(); }
+  });
+  struct Joiner {
+    std::thread &t;
+    ~Joiner() {
+      if (t.joinable()) t.join();
+    }
+  } joiner{loader};
+
   core.calculateEdges();                       // :157
   core.chainingAndOverlaps();                  // :170-178
   auto const contraction = core.findContractionEdges(); // :183-190
@@ -242,29 +281,8 @@ inline AssemblyCounts assemble(std::string const &contigsPaf, std::string const 
                   msgpu_graph_last_error(graph.g));
   detail::require(msgpu_graph_linearize(graph.g), "msgpu_graph_linearize", msgpu_graph_last_error(graph.g));
 
-  struct Seq { // :161-163
-    msgpu_seqctx  *ctx = nullptr;
-    msgpu_seqfile *fn = nullptr, *fi = nullptr;
-    msgpu_assembly *as = nullptr;
-    ~Seq() {
-      msgpu_assembly_free(as);
-      msgpu_seq_free(fn);
-      msgpu_seq_free(fi);
-      msgpu_seq_destroy(ctx);
-    }
-  } s;
-  detail::require(msgpu_seq_create(device, &s.ctx), "msgpu_seq_create");
-  detail::require(msgpu_seq_parse(nanoporePath.c_str(), -1, &s.fn), "nanopore file");
-  detail::require(msgpu_seq_parse(unitigsPath.c_str(), 0, &s.fi), "unitig file");
-  std::uint32_t space = 0;
-  auto          ids   = detail::registryIds(
-      s.fn, core.readCount(), [](void const *c, std::uint32_t i) { return static_cast<OverlapCore const *>(c)->readName(i); },
-      &core, &space);
-  detail::require(msgpu_seq_upload(s.ctx, 0, s.fn, ids.data(), space), "upload reads", msgpu_seq_last_error(s.ctx));
-  ids = detail::registryIds(
-      s.fi, core.anchorCount(), [](void const *c, std::uint32_t i) { return static_cast<OverlapCore const *>(c)->anchorName(i); },
-      &core, &space);
-  detail::require(msgpu_seq_upload(s.ctx, 1, s.fi, ids.data(), space), "upload unitigs", msgpu_seq_last_error(s.ctx));
+  loader.join();
+  if (loadError) std::rethrow_exception(loadError);
 
   detail::require(msgpu_assembly_create(s.ctx, &s.as), "msgpu_assembly_create"); // :300-310, 620-677
   detail::require(msgpu_assembly_set_rows(s.as, rows, nRows), "msgpu_assembly_set_rows");

@@ -12,6 +12,7 @@ temp_1.target.fa / temp_1.query.fa / temp_1.align.paf.
              OutputWriter                                Assembly.finish (one gather + FASTA wrapping, HIP) + 3 writes
 """
 import os
+import threading
 import time
 
 import numpy as np
@@ -41,6 +42,27 @@ def run(contigs_paf, unitigs_path, nanopore_path, out_dir, threads=None, wiggle_
     paf = overlap.parse_paf(contigs_paf, params)
     t["parse_paf"] = time.perf_counter() - t0
 
+    # SequenceAccessor::buildIndex needs only the Registry: parse + upload the sequence files on a second host thread
+    # while the GPU builds the overlap graph and the host runs the graph stage (ctypes calls release the GIL)
+    seq = {}
+
+    def load_sequences():
+        t1 = time.perf_counter()
+        try:
+            fn, fi = SeqFile(nanopore_path), SeqFile(unitigs_path)
+            store = SeqStore(device=device)
+            ids, n = _registry_ids(fn, paf.read_names)
+            store.upload(NANOPORE, fn, ids, n)
+            ids, n = _registry_ids(fi, paf.anchor_names)
+            store.upload(ILLUMINA, fi, ids, n)
+            seq["store"], seq["files"] = store, (fn, fi)
+        except BaseException as e:  # re-raised on the main thread
+            seq["error"] = e
+        t["sequences"] = time.perf_counter() - t1
+
+    loader = threading.Thread(target=load_sequences, name="msgpu-sequences")
+    loader.start()
+
     t0 = time.perf_counter()
     ctx = overlap.OverlapContext(device=device, params=params)
     ctx.load_rows(paf.rows)
@@ -54,19 +76,17 @@ def run(contigs_paf, unitigs_path, nanopore_path, out_dir, threads=None, wiggle_
     t["overlap_gpu"] = time.perf_counter() - t0
 
     t0 = time.perf_counter()
-    fn, fi = SeqFile(nanopore_path), SeqFile(unitigs_path)
-    store = SeqStore(device=device)
-    ids, n = _registry_ids(fn, paf.read_names)
-    store.upload(NANOPORE, fn, ids, n)
-    ids, n = _registry_ids(fi, paf.anchor_names)
-    store.upload(ILLUMINA, fi, ids, n)
-    t["sequences"] = time.perf_counter() - t0
-
-    t0 = time.perf_counter()
     g = GraphStage(tables, read_len, read_first)
     g.clean_up(contraction, paf.rows)
     g.linearize()
     t["graph_host"] = time.perf_counter() - t0
+
+    t0 = time.perf_counter()
+    loader.join()
+    t["sequences_wait"] = time.perf_counter() - t0
+    if "error" in seq:
+        raise seq["error"]
+    store = seq["store"]
 
     t0 = time.perf_counter()
     asm = Assembly(store)

@@ -15,7 +15,7 @@ def adapter_bin(tmp_path_factory):
     out = str(tmp_path_factory.mktemp("cpp") / "test_adapter")
     subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", "-I", os.path.join(ROOT, "include"),
                     os.path.join(ROOT, "tests", "cpp", "test_adapter.cpp"), "-o", out,
-                    "-L", os.path.join(ROOT, "muchsalsa_amd"), "-lmsgpu",
+                    "-pthread", "-L", os.path.join(ROOT, "muchsalsa_amd"), "-lmsgpu",
                     "-Wl,-rpath," + os.path.join(ROOT, "muchsalsa_amd"), "-Wl,-rpath,/opt/rocm/lib"], check=True)
     return out
 
