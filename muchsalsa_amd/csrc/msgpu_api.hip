@@ -36,6 +36,14 @@ struct DevBuf {
       return e;
     }
     cap = want;
+    // MSGPU_POISON=1 (debugging): fresh device memory is filled with 0xA5 so that a kernel which relies on zeroed scratch
+    // fails every time instead of only when the allocator hands back recycled pages
+    static const bool poison = std::getenv("MSGPU_POISON") != nullptr;
+    if (poison) {
+      e = hipMemset(p, 0xA5, want); // null stream, may return before it ran: wait, the context's stream does not
+      if (e == hipSuccess) e = hipDeviceSynchronize();
+      if (e != hipSuccess) return e;
+    }
     return hipSuccess;
   }
   void release() {

@@ -10,6 +10,7 @@
 // HBM-bound byte work: 16 B per lane, aligned 16-B stores, unaligned source handled with v_alignbyte.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -485,6 +486,12 @@ int msgpu_assembly_finish(msgpu_assembly *a, void *hip_stream) {
   hipError_t e     = hipMalloc(&d_raw, a->raw_bytes + 64);
   if (e == hipSuccess) e = hipMalloc(&d_t, t_bytes + 16);
   if (e == hipSuccess) e = hipMalloc(&d_q, q_bytes + 16);
+  if (e == hipSuccess && std::getenv("MSGPU_POISON")) { // see DevBuf::ensure in msgpu_api.hip
+    e = hipMemset(d_raw, 0xA5, a->raw_bytes + 64);
+    if (e == hipSuccess) e = hipMemset(d_t, 0xA5, t_bytes + 16);
+    if (e == hipSuccess) e = hipMemset(d_q, 0xA5, q_bytes + 16);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+  }
   if (e == hipSuccess) {
     rc = msgpu_gather_run(c, plan, d_raw, a->raw_bytes + 64, st);
     if (rc == MSGPU_OK)
