@@ -224,8 +224,8 @@ inline AssemblyCounts assemble(std::string const &contigsPaf, std::string const 
   OverlapCore    core(device, wiggleRoom);
   core.read(contigsPaf); // :153-156
 
-  struct Seq { // :161-163 -- needs only the Registry, so it loads on a second host thread while the GPU and the graph
-               // stage work (every libmsgpu entry point selects its device itself)
+  struct Seq { // :161-163 -- needs only the Registry: the files are parsed (pure host work) on a second thread while the
+               // GPU and the graph stage work; every HIP call stays on the calling thread (upload after the join)
     msgpu_seqctx   *ctx = nullptr;
     msgpu_seqfile  *fn = nullptr, *fi = nullptr;
     msgpu_assembly *as = nullptr;
@@ -236,21 +236,20 @@ inline AssemblyCounts assemble(std::string const &contigsPaf, std::string const 
       msgpu_seq_destroy(ctx);
     }
   } s;
-  std::exception_ptr loadError;
-  std::thread        loader([&]() {
+  std::exception_ptr         loadError;
+  std::vector<std::uint32_t> readIds, anchorIds;
+  std::uint32_t              readSpace = 0, anchorSpace = 0;
+  std::thread                loader([&]() {
     try {
-      detail::require(msgpu_seq_create(device, &s.ctx), "msgpu_seq_create");
       detail::require(msgpu_seq_parse(nanoporePath.c_str(), -1, &s.fn), "nanopore file");
       detail::require(msgpu_seq_parse(unitigsPath.c_str(), 0, &s.fi), "unitig file");
-      std::uint32_t space = 0;
-      auto          ids   = detail::registryIds(
+      readIds = detail::registryIds(
           s.fn, core.readCount(),
-          [](void const *c, std::uint32_t i) { return static_cast<OverlapCore const *>(c)->readName(i); }, &core, &space);
-      detail::require(msgpu_seq_upload(s.ctx, 0, s.fn, ids.data(), space), "upload reads", msgpu_seq_last_error(s.ctx));
-      ids = detail::registryIds(
+          [](void const *c, std::uint32_t i) { return static_cast<OverlapCore const *>(c)->readName(i); }, &core, &readSpace);
+      anchorIds = detail::registryIds(
           s.fi, core.anchorCount(),
-          [](void const *c, std::uint32_t i) { return static_cast<OverlapCore const *>(c)->anchorName(i); }, &core, &space);
-      detail::require(msgpu_seq_upload(s.ctx, 1, s.fi, ids.data(), space), "upload unitigs", msgpu_seq_last_error(s.ctx));
+          [](void const *c, std::uint32_t i) { return static_cast<OverlapCore const *>(c)->anchorName(i); }, &core,
+          &anchorSpace);
     } catch (...) { loadError = std::current_exception(); }
   });
   struct Joiner {
@@ -283,6 +282,10 @@ inline AssemblyCounts assemble(std::string const &contigsPaf, std::string const 
 
   loader.join();
   if (loadError) std::rethrow_exception(loadError);
+  detail::require(msgpu_seq_create(device, &s.ctx), "msgpu_seq_create");
+  detail::require(msgpu_seq_upload(s.ctx, 0, s.fn, readIds.data(), readSpace), "upload reads", msgpu_seq_last_error(s.ctx));
+  detail::require(msgpu_seq_upload(s.ctx, 1, s.fi, anchorIds.data(), anchorSpace), "upload unitigs",
+                  msgpu_seq_last_error(s.ctx));
 
   detail::require(msgpu_assembly_create(s.ctx, &s.as), "msgpu_assembly_create"); // :300-310, 620-677
   detail::require(msgpu_assembly_set_rows(s.as, rows, nRows), "msgpu_assembly_set_rows");

@@ -42,23 +42,20 @@ def run(contigs_paf, unitigs_path, nanopore_path, out_dir, threads=None, wiggle_
     paf = overlap.parse_paf(contigs_paf, params)
     t["parse_paf"] = time.perf_counter() - t0
 
-    # SequenceAccessor::buildIndex needs only the Registry: parse + upload the sequence files on a second host thread
-    # while the GPU builds the overlap graph and the host runs the graph stage (ctypes calls release the GIL)
+    # SequenceAccessor::buildIndex needs only the Registry: the sequence files are parsed (pure host work) on a second
+    # thread while the GPU builds the overlap graph and the host runs the graph stage (ctypes calls release the GIL).
+    # Every HIP call stays on this thread: the upload happens after the join.
     seq = {}
 
     def load_sequences():
         t1 = time.perf_counter()
         try:
             fn, fi = SeqFile(nanopore_path), SeqFile(unitigs_path)
-            store = SeqStore(device=device)
-            ids, n = _registry_ids(fn, paf.read_names)
-            store.upload(NANOPORE, fn, ids, n)
-            ids, n = _registry_ids(fi, paf.anchor_names)
-            store.upload(ILLUMINA, fi, ids, n)
-            seq["store"], seq["files"] = store, (fn, fi)
+            seq["files"] = (fn, fi)
+            seq["ids"] = (_registry_ids(fn, paf.read_names), _registry_ids(fi, paf.anchor_names))
         except BaseException as e:  # re-raised on the main thread
             seq["error"] = e
-        t["sequences"] = time.perf_counter() - t1
+        t["sequences_parse"] = time.perf_counter() - t1
 
     loader = threading.Thread(target=load_sequences, name="msgpu-sequences")
     loader.start()
@@ -86,7 +83,11 @@ def run(contigs_paf, unitigs_path, nanopore_path, out_dir, threads=None, wiggle_
     t["sequences_wait"] = time.perf_counter() - t0
     if "error" in seq:
         raise seq["error"]
-    store = seq["store"]
+    t0 = time.perf_counter()
+    store = SeqStore(device=device)
+    for kind, f, (ids, n) in zip((NANOPORE, ILLUMINA), seq["files"], seq["ids"]):
+        store.upload(kind, f, ids, n)
+    t["sequences_upload"] = time.perf_counter() - t0
 
     t0 = time.perf_counter()
     asm = Assembly(store)
