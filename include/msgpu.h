@@ -395,6 +395,7 @@ typedef struct msgpu_query_info {
   uint32_t path;
 } msgpu_query_info;
 
+/* The assembly uses `ctx` until msgpu_assembly_finish / _validate have returned; freeing it never touches `ctx`. */
 int         msgpu_assembly_create(msgpu_seqctx *ctx, msgpu_assembly **out);
 void        msgpu_assembly_free(msgpu_assembly *a);
 const char *msgpu_assembly_last_error(const msgpu_assembly *a);

@@ -31,6 +31,7 @@ class Assembly:
         if rc != 0:
             self._h = C.c_void_p()
             raise MsgpuError(rc)
+        store._assemblies.append(self)  # closed with (before) the store
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:

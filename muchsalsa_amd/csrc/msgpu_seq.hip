@@ -512,9 +512,8 @@ int msgpu_assembly_finish(msgpu_assembly *a, void *hip_stream) {
     return rc;
   }
   a->d_raw   = d_raw; // kept for msgpu_assembly_validate
-  a->release = [](msgpu_assembly *x) {
+  a->release = [](msgpu_assembly *x) { // must not touch x->ctx: the sequence context may already be gone
     if (x->d_raw) {
-      if (x->ctx && x->ctx->device >= 0) (void)hipSetDevice(x->ctx->device);
       (void)hipFree(x->d_raw);
       x->d_raw = nullptr;
     }

@@ -101,9 +101,13 @@ class SeqStore:
             self._h = C.c_void_p()
             raise MsgpuError(rc)
         self._plans = []
+        self._assemblies = []  # muchsalsa_amd.assembly.Assembly objects laid out over this store
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
+            for a in self._assemblies:
+                a.close()
+            self._assemblies = []
             for p in self._plans:
                 self._L.msgpu_gather_plan_free(p)
             self._plans = []
