@@ -238,8 +238,7 @@ def assemble_leg(torch, dev, w, rows, read_names, anchor_names, tables, window_m
             r = assemble_path(p, st, vm, {}, nano, illu, i)
             want_t, want_q, want_p = want_t + r["target_fa"], want_q + r["query_fa"], want_p + r["paf"]
         ok = tfa.startswith(want_t) and qfa.startswith(want_q) and paf.startswith(want_p) and len(want_t) > 0
-    store.close()
-    return {"paths": len(paths), "reads_on_paths": int(sum(len(p) for p, _ in paths)), "target_bases": T,
+    res = {"paths": len(paths), "reads_on_paths": int(sum(len(p) for p, _ in paths)), "target_bases": T,
             "query_bases": Q, "queries": int(len(qinfo)), "pieces": int(len(asm.pieces)),
             "layout_ms": 1e3 * t_layout, "layout_threads": threads, "device_ms": 1e3 * t_device, "row_index_ms": 1e3 * t_index,
             "path_builder_ms_untimed": 1e3 * t_paths, "verified_paths": verify_paths, "verified": ok,
@@ -248,6 +247,8 @@ def assemble_leg(torch, dev, w, rows, read_names, anchor_names, tables, window_m
                          "dp_cells": cells, "dp_gcells_per_s": cells / t_val / 1e9,
                          "queries_within_band": int((dist <= band).sum()),
                          "median_distance": float(np.median(dist)) if len(dist) else None}}
+    store.close()  # closes the assembly laid out over it as well
+    return res
 
 
 def main():
