@@ -621,9 +621,11 @@ std::vector<std::vector<uint32_t>> extract_paths(DiGraph &dg) { // lg.cpp:347-41
 std::vector<std::vector<uint32_t>> linearize_graph(DiGraph &dg) { // lg.cpp:522-629
   std::vector<std::vector<uint32_t>>   paths = extract_paths(dg);
   std::vector<size_t>                  color_corr(paths.size()), color_len(paths.size());
-  std::unordered_map<uint32_t, size_t> v2idx;
+  std::unordered_map<uint32_t, size_t> v2idx, v2pos; // v2pos: what std::find returns on the still unjoined paths (:553-556)
   for (size_t i = 0; i < paths.size(); ++i) {
-    for (uint32_t v : paths[i]) v2idx.emplace(v, i);
+    for (size_t k = 0; k < paths[i].size(); ++k) {
+      if (v2idx.emplace(paths[i][k], i).second) v2pos.emplace(paths[i][k], k);
+    }
     color_corr[i] = i;
     color_len[i]  = paths[i].size();
   }
@@ -636,7 +638,7 @@ std::vector<std::vector<uint32_t>> linearize_graph(DiGraph &dg) { // lg.cpp:522-
     if (!e->shadow) continue;
     auto i1 = v2idx.find(e->a), i2 = v2idx.find(e->b);
     if (i1 == v2idx.end() || i2 == v2idx.end()) continue;
-    const size_t s1 = index_in(paths[i1->second], e->a), s2 = index_in(paths[i2->second], e->b);
+    const size_t s1 = v2pos.at(e->a), s2 = v2pos.at(e->b);
     const size_t l1_end = color_len[i1->second] - s1 - 1, l2_end = color_len[i2->second] - s2 - 1;
     if (i1->second != i2->second && l1_end < s1 && s2 < l2_end) joins.emplace_back(l1_end + s2, e);
   }
@@ -922,8 +924,12 @@ int msgpu_graph_linearize(msgpu_graph *g) {
       uint32_t                 start = *cset.begin();
       for (uint32_t v : cset) // std::max_element: the first of the longest, vertices ascending
         if (g->V[v].length > g->V[start].length) start = v;
+      Tick    tk;
       DiGraph dg = get_directed_graph(*g, cset, start);
-      for (const std::vector<uint32_t> &p : linearize_graph(dg)) {
+      tk("getDirectedGraph");
+      const std::vector<std::vector<uint32_t>> lin = linearize_graph(dg);
+      tk("linearizeGraph");
+      for (const std::vector<uint32_t> &p : lin) {
         msgpu_graph::PathStore ps;
         ps.order_off.push_back(0);
         ps.em_off.push_back(0);
