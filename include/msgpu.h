@@ -461,6 +461,9 @@ const char *msgpu_graph_last_error(const msgpu_graph *g);
 /* rows (optional): the VertexMatch table, for contract()'s "getVertexMatch(start, id) != nullptr" (main.cpp:514-519);
  * NULL = every id of an order has one (true for tables produced by this library). */
 int msgpu_graph_clean_up(msgpu_graph *g, const int64_t *contraction_order, const msgpu_row *rows, size_t n_rows);
+/* host threads for msgpu_graph_linearize (components are independent, cf. one assemblePaths job per component,
+ * src/main.cpp:300-310); default 1; the result does not depend on it */
+int msgpu_graph_set_threads(msgpu_graph *g, uint32_t n_threads);
 int msgpu_graph_linearize(msgpu_graph *g);
 int msgpu_graph_get_stats(const msgpu_graph *g, msgpu_graph_stats *out);
 uint32_t msgpu_graph_path_count(const msgpu_graph *g);

@@ -278,6 +278,7 @@ inline AssemblyCounts assemble(std::string const &contigsPaf, std::string const 
                   "msgpu_graph_create");
   detail::require(msgpu_graph_clean_up(graph.g, contraction.data(), rows, nRows), "msgpu_graph_clean_up",
                   msgpu_graph_last_error(graph.g));
+  msgpu_graph_set_threads(graph.g, threads ? threads : 1);
   detail::require(msgpu_graph_linearize(graph.g), "msgpu_graph_linearize", msgpu_graph_last_error(graph.g));
 
   loader.join();

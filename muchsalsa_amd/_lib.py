@@ -164,6 +164,7 @@ SYMBOLS = [
     ("msgpu_graph_free", None, [C.c_void_p]),
     ("msgpu_graph_last_error", C.c_char_p, [C.c_void_p]),
     ("msgpu_graph_clean_up", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    ("msgpu_graph_set_threads", C.c_int, [C.c_void_p, C.c_uint32]),
     ("msgpu_graph_linearize", C.c_int, [C.c_void_p]),
     ("msgpu_graph_get_stats", C.c_int, [C.c_void_p, C.POINTER(GraphStats)]),
     ("msgpu_graph_path_count", C.c_uint32, [C.c_void_p]),

@@ -19,6 +19,7 @@
 // as in DESIGN.md section 9: vertices ascending id, edges in creation order ((v1, v2) table order for the undirected
 // graph), neighbours ascending id, std::sort ties stable, pointer-ordered containers ordered by vertex id.
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -31,6 +32,7 @@
 #include <set>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <unordered_set>
 #include <vector>
@@ -45,6 +47,17 @@ constexpr double MAX_WEIGHT_MULTIPLICATOR  = 0.8; // src/main.cpp:97
 
 struct GraphError : std::runtime_error {
   using std::runtime_error::runtime_error;
+};
+
+struct Tick { // MSGPU_GRAPH_DEBUG=1: phase timings on stderr
+  std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+  bool on = std::getenv("MSGPU_GRAPH_DEBUG") != nullptr;
+  void operator()(const char *what) {
+    if (!on) return;
+    auto n = std::chrono::steady_clock::now();
+    fprintf(stderr, "[graph] %-28s %8.3f s\n", what, std::chrono::duration<double>(n - t).count());
+    t = n;
+  }
 };
 
 struct Vertex {
@@ -186,6 +199,7 @@ struct msgpu_graph {
   };
   std::map<uint32_t, std::vector<Contain>> contain;
   bool cleaned = false, linearized = false;
+  uint32_t n_threads = 1;
   msgpu_graph_stats stats{};
   // paths + storage the msgpu_path_input views point into
   struct PathStore {
@@ -222,18 +236,19 @@ struct msgpu_graph {
 namespace {
 
 // mst.cpp:35-73, including unify()'s use of the weights of the vertices rather than of their roots
-struct UnionFind {
-  std::unordered_map<uint32_t, uint32_t> parent;
-  std::unordered_map<uint32_t, uint64_t> weight;
+struct UnionFind { // vertex ids are dense: vectors instead of the reference's two hash maps; weight 0 = "not seen yet"
+  std::vector<uint32_t> parent;
+  std::vector<uint64_t> weight;
+  std::vector<uint32_t> path;
+  explicit UnionFind(uint32_t n) : parent(n), weight(n, 0) {}
   uint32_t find(uint32_t v) {
-    auto it = parent.find(v);
-    if (it == parent.end()) {
+    if (!weight[v]) {
       parent[v] = v;
       weight[v] = 1;
       return v;
     }
-    std::vector<uint32_t> path{v};
-    uint32_t              root = it->second;
+    path.assign(1, v);
+    uint32_t root = parent[v];
     while (root != path.back()) {
       path.push_back(root);
       root = parent[root];
@@ -251,40 +266,41 @@ struct UnionFind {
 
 using TreeAdj = std::vector<std::map<uint32_t, uint32_t>>;
 
-// GraphUtil::getShortestPath on the span tree (unit weights, FIFO ties), Graph.h:927-978
-std::vector<uint32_t> shortest_path(const TreeAdj &tree, uint32_t src, uint32_t dst) {
-  using Item = std::tuple<uint64_t, uint64_t, uint32_t>;
-  std::priority_queue<Item, std::vector<Item>, std::greater<Item>> heap;
-  std::unordered_map<uint32_t, uint64_t>                           dist, seen;
-  std::unordered_map<uint32_t, uint32_t>                           from; // paths[] of the reference as back pointers
-  uint64_t                                                         c = 1;
-  seen[src] = 0;
-  heap.emplace(0, 0, src);
-  while (!heap.empty()) {
-    const Item next = heap.top();
-    heap.pop();
-    const uint32_t v = std::get<2>(next);
-    if (dist.count(v)) continue;
-    dist[v] = std::get<0>(next);
-    if (v == dst) break;
-    for (auto &n : tree[v]) {
-      const uint64_t nd = dist[v] + 1;
-      if (!dist.count(n.first) && (!seen.count(n.first) || nd < seen[n.first])) {
-        seen[n.first] = nd;
-        heap.emplace(nd, c++, n.first);
-        from[n.first] = v;
+// GraphUtil::getShortestPath (Graph.h:927-978: Dijkstra with unit weights, ties by insertion order) on the span tree.
+// In a forest the path between two vertices is unique, and (distance, insertion counter) order is breadth-first order,
+// so this is a BFS with dense, stamp-reset scratch instead of three hash maps per call.
+struct TreeSearch {
+  std::vector<uint32_t> from, stamp, queue;
+  uint32_t              round = 0;
+  explicit TreeSearch(uint32_t n) : from(n), stamp(n, 0) {}
+  std::vector<uint32_t> path(const TreeAdj &tree, uint32_t src, uint32_t dst) {
+    ++round;
+    queue.assign(1, src);
+    stamp[src] = round;
+    bool found = src == dst;
+    for (size_t h = 0; h < queue.size() && !found; ++h) {
+      const uint32_t v = queue[h];
+      for (auto &n : tree[v]) {
+        if (stamp[n.first] == round) continue;
+        stamp[n.first] = round;
+        from[n.first]  = v;
+        if (n.first == dst) {
+          found = true;
+          break;
+        }
+        queue.push_back(n.first);
       }
     }
+    std::vector<uint32_t> p;
+    if (!found) return p;
+    for (uint32_t v = dst;; v = from[v]) {
+      p.push_back(v);
+      if (v == src) break;
+    }
+    std::reverse(p.begin(), p.end());
+    return p;
   }
-  std::vector<uint32_t> path;
-  if (src != dst && !from.count(dst)) return path;
-  for (uint32_t v = dst;; v = from[v]) {
-    path.push_back(v);
-    if (v == src) break;
-  }
-  std::reverse(path.begin(), path.end());
-  return path;
-}
+};
 
 // ---- linearizeGraph, lg.cpp ------------------------------------------------------------------------------------------
 
@@ -447,17 +463,6 @@ ClusterWeights find_cluster_weights_heuristic(const DiGraph &dg) { // lg.cpp:72-
   }
   return result;
 }
-
-struct Tick { // MSGPU_GRAPH_DEBUG=1: phase timings on stderr
-  std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
-  bool on = std::getenv("MSGPU_GRAPH_DEBUG") != nullptr;
-  void operator()(const char *what) {
-    if (!on) return;
-    auto n = std::chrono::steady_clock::now();
-    fprintf(stderr, "[graph] %-28s %8.3f s\n", what, std::chrono::duration<double>(n - t).count());
-    t = n;
-  }
-};
 
 std::vector<std::vector<uint32_t>> extract_paths(DiGraph &dg) { // lg.cpp:347-414
   Tick tick;
@@ -774,8 +779,10 @@ int msgpu_graph_clean_up(msgpu_graph *g, const int64_t *contraction_order, const
   if (g->cleaned) return MSGPU_E_STATE;
   g->err[0] = 0;
   try {
-    std::unordered_set<uint64_t> has_vm; // MatchMap::getVertexMatch(read, anchor) != nullptr
-    for (size_t i = 0; i < n_rows; ++i) has_vm.insert((static_cast<uint64_t>(rows[i].read_id) << 32) | rows[i].anchor_id);
+    Tick tick;
+    std::vector<uint64_t> has_vm(n_rows); // MatchMap::getVertexMatch(read, anchor) != nullptr: sorted (read, anchor) keys
+    for (size_t i = 0; i < n_rows; ++i) has_vm[i] = (static_cast<uint64_t>(rows[i].read_id) << 32) | rows[i].anchor_id;
+    std::sort(has_vm.begin(), has_vm.end());
     std::vector<uint32_t> contraction; // order indices, in edge order
     for (size_t e = 0; e < g->E.size(); ++e) {
       const int64_t k = contraction_order[e];
@@ -807,11 +814,13 @@ int msgpu_graph_clean_up(msgpu_graph *g, const int64_t *contraction_order, const
       c.direction = g->odir(k) ? 1u : 0u;
       for (uint32_t i = 0; i < o.ids_cnt; ++i) {
         const uint32_t a = g->t_ids[o.ids_off + i];
-        if (!rows || has_vm.count((static_cast<uint64_t>(o.start) << 32) | a)) c.anchors.push_back(a);
+        if (!rows || std::binary_search(has_vm.begin(), has_vm.end(), (static_cast<uint64_t>(o.start) << 32) | a))
+          c.anchors.push_back(a);
       }
       g->contain[o.end].push_back(std::move(c));
       ++g->stats.n_contain_elements;
     }
+    tick("contraction bookkeeping");
     for (uint32_t v : deletable) g->delete_vertex(v); // :242-244
     g->stats.n_deleted_vertices = deletable.size();
     for (uint32_t e = 0; e < g->E.size(); ++e) { // findDeletableEdges, :534-549 (+ deletion :258-260)
@@ -839,12 +848,13 @@ int msgpu_graph_clean_up(msgpu_graph *g, const int64_t *contraction_order, const
         u.consensus = d0 ? D_POS : D_NEG;
       }
     }
+    tick("deletions + bitweight");
     // getMaxSpanTree, mst.cpp:75-111
     std::vector<uint32_t> cand;
     for (uint32_t e : edges)
       if (g->E[e].consensus != D_NONE) cand.push_back(e);
     std::stable_sort(cand.begin(), cand.end(), [&](uint32_t x, uint32_t y) { return g->E[x].weight > g->E[y].weight; });
-    UnionFind uf;
+    UnionFind uf(nv);
     TreeAdj   tree(nv);
     for (uint32_t e : cand) {
       const UEdge &u = g->E[e];
@@ -854,11 +864,13 @@ int msgpu_graph_clean_up(msgpu_graph *g, const int64_t *contraction_order, const
         uf.unify(u.a, u.b);
       }
     }
+    tick("span tree");
     std::set<uint32_t> dele;
+    TreeSearch         search(nv);
     for (uint32_t e : edges) { // decycle, :575-618
       const UEdge &u = g->E[e];
       if (u.consensus == D_NONE || tree[u.a].count(u.b)) continue;
-      const std::vector<uint32_t> path = shortest_path(tree, u.a, u.b);
+      const std::vector<uint32_t> path = search.path(tree, u.a, u.b);
       require(!path.empty(), "decycle: the span tree does not connect the ends of an edge");
       bool                direction = u.consensus == D_POS;
       std::vector<double> weights;
@@ -879,6 +891,7 @@ int msgpu_graph_clean_up(msgpu_graph *g, const int64_t *contraction_order, const
         dele.insert(e);
       }
     }
+    tick("decycle");
     for (uint32_t e : dele) g->delete_edge(e); // :285-287
     g->stats.n_decycled_edges = dele.size();
     uint64_t nv_alive = 0, ne_alive = 0;
@@ -897,13 +910,93 @@ int msgpu_graph_clean_up(msgpu_graph *g, const int64_t *contraction_order, const
 }
 
 // getConnectedComponents (cc.cpp:33-70) + per component getDirectedGraph + linearizeGraph (src/main.cpp:300-310, 620-661)
+} // extern "C"
+
+namespace {
+
+// one connected component: getDirectedGraph + linearizeGraph + the assemblePath inputs of its paths (main.cpp:620-661)
+std::vector<msgpu_graph::PathStore> component_paths(msgpu_graph *g, const std::vector<uint32_t> &comp) {
+  const std::set<uint32_t> cset(comp.begin(), comp.end());
+  uint32_t                 start = *cset.begin();
+  for (uint32_t v : cset) // std::max_element: the first of the longest, vertices ascending
+    if (g->V[v].length > g->V[start].length) start = v;
+  Tick    tk;
+  DiGraph dg = get_directed_graph(*g, cset, start);
+  tk("getDirectedGraph");
+  const std::vector<std::vector<uint32_t>> lin = linearize_graph(dg);
+  tk("linearizeGraph");
+  std::vector<msgpu_graph::PathStore> out;
+  for (const std::vector<uint32_t> &p : lin) {
+    msgpu_graph::PathStore ps;
+    ps.order_off.push_back(0);
+    ps.em_off.push_back(0);
+    for (uint32_t v : p) {
+      msgpu_path_read r{};
+      r.read_id         = v;
+      r.direction       = g->V[v].direction == D_POS ? 1u : g->V[v].direction == D_NEG ? 0u : 2u;
+      r.nanopore_length = static_cast<uint64_t>(g->V[v].length);
+      ps.reads.push_back(r);
+    }
+    for (size_t i = 0; i + 1 < p.size(); ++i) {
+      const DEdgeP de = dg.get_edge(p[i], p[i + 1]);
+      require(de != nullptr, "path edge missing in the directed graph");
+      for (uint32_t oi : de->orders) {
+        const msgpu_order &o = g->t_orders[oi];
+        msgpu_path_order   po{};
+        po.score     = o.score;
+        po.base_read = o.base;
+        po.ids_off   = static_cast<uint32_t>(o.ids_off);
+        po.ids_cnt   = o.ids_cnt;
+        ps.orders.push_back(po);
+      }
+      const msgpu_edge &te = g->t_edges[de->src];
+      for (uint32_t k = 0; k < te.em_cnt; ++k) {
+        const msgpu_edgematch &m = g->t_ems[te.em_off + k];
+        ps.ems.push_back(msgpu_path_em{m.anchor_id, m.ov_lo, m.ov_hi});
+      }
+      ps.order_off.push_back(static_cast<uint32_t>(ps.orders.size()));
+      ps.em_off.push_back(static_cast<uint32_t>(ps.ems.size()));
+    }
+    for (uint32_t v : p) {
+      auto c = g->contain.find(v);
+      if (c == g->contain.end()) continue;
+      for (const msgpu_graph::Contain &ce : c->second) {
+        msgpu_path_contain pc{};
+        pc.host_read   = v;
+        pc.nano        = ce.nano;
+        pc.direction   = ce.direction;
+        pc.anchors_off = static_cast<uint32_t>(ps.contain_anchors.size());
+        pc.anchors_cnt = static_cast<uint32_t>(ce.anchors.size());
+        ps.contain_anchors.insert(ps.contain_anchors.end(), ce.anchors.begin(), ce.anchors.end());
+        ps.contains.push_back(pc);
+      }
+    }
+    out.push_back(std::move(ps));
+  }
+  return out;
+}
+
+} // namespace
+
+extern "C" {
+
+// host threads for the per-component work of msgpu_graph_linearize (default 1; the reference runs one assemblePaths job
+// per component on its ThreadPool, src/main.cpp:300-310)
+int msgpu_graph_set_threads(msgpu_graph *g, uint32_t n_threads) {
+  if (!g) return MSGPU_E_ARG;
+  g->n_threads = n_threads ? n_threads : 1;
+  return MSGPU_OK;
+}
+
 int msgpu_graph_linearize(msgpu_graph *g) {
   if (!g) return MSGPU_E_ARG;
   if (!g->cleaned || g->linearized) return MSGPU_E_STATE;
   g->err[0] = 0;
   try {
-    const uint32_t    nv = static_cast<uint32_t>(g->V.size());
-    std::vector<bool> visited(nv, false);
+    // getConnectedComponents, cc.cpp:33-70
+    const uint32_t                     nv = static_cast<uint32_t>(g->V.size());
+    std::vector<bool>                  visited(nv, false);
+    std::vector<std::vector<uint32_t>> comps;
     for (uint32_t s = 0; s < nv; ++s) {
       if (!g->V[s].alive || visited[s]) continue;
       std::vector<uint32_t> comp{s};
@@ -919,65 +1012,45 @@ int msgpu_graph_linearize(msgpu_graph *g) {
             visited[n.first] = true;
           }
       }
-      ++g->stats.n_components;
-      const std::set<uint32_t> cset(comp.begin(), comp.end());
-      uint32_t                 start = *cset.begin();
-      for (uint32_t v : cset) // std::max_element: the first of the longest, vertices ascending
-        if (g->V[v].length > g->V[start].length) start = v;
-      Tick    tk;
-      DiGraph dg = get_directed_graph(*g, cset, start);
-      tk("getDirectedGraph");
-      const std::vector<std::vector<uint32_t>> lin = linearize_graph(dg);
-      tk("linearizeGraph");
-      for (const std::vector<uint32_t> &p : lin) {
-        msgpu_graph::PathStore ps;
-        ps.order_off.push_back(0);
-        ps.em_off.push_back(0);
-        for (uint32_t v : p) {
-          msgpu_path_read r{};
-          r.read_id         = v;
-          r.direction       = g->V[v].direction == D_POS ? 1u : g->V[v].direction == D_NEG ? 0u : 2u;
-          r.nanopore_length = static_cast<uint64_t>(g->V[v].length);
-          ps.reads.push_back(r);
+      comps.push_back(std::move(comp));
+    }
+    g->stats.n_components = comps.size();
+    // Components are independent (a component only orients and reads its own vertices): largest first on the worker
+    // threads, results appended in component order -- the order a single-threaded reference run assembles them in.
+    std::vector<std::vector<msgpu_graph::PathStore>> per(comps.size());
+    std::vector<std::string>                         errs(comps.size());
+    std::vector<int>                                 rcs(comps.size(), MSGPU_OK);
+    std::vector<size_t>                              by_size(comps.size());
+    for (size_t i = 0; i < by_size.size(); ++i) by_size[i] = i;
+    std::stable_sort(by_size.begin(), by_size.end(), [&](size_t x, size_t y) { return comps[x].size() > comps[y].size(); });
+    std::atomic<size_t> next{0};
+    auto                work = [&]() {
+      for (size_t k = next.fetch_add(1); k < by_size.size(); k = next.fetch_add(1)) {
+        const size_t i = by_size[k];
+        try {
+          per[i] = component_paths(g, comps[i]);
+        } catch (std::bad_alloc const &) { rcs[i] = MSGPU_E_NOMEM; } catch (std::exception const &e) {
+          rcs[i]  = MSGPU_E_LAYOUT;
+          errs[i] = e.what();
         }
-        for (size_t i = 0; i + 1 < p.size(); ++i) {
-          const DEdgeP de = dg.get_edge(p[i], p[i + 1]);
-          require(de != nullptr, "path edge missing in the directed graph");
-          for (uint32_t oi : de->orders) {
-            const msgpu_order &o = g->t_orders[oi];
-            msgpu_path_order   po{};
-            po.score     = o.score;
-            po.base_read = o.base;
-            po.ids_off   = static_cast<uint32_t>(o.ids_off);
-            po.ids_cnt   = o.ids_cnt;
-            ps.orders.push_back(po);
-          }
-          const msgpu_edge &te = g->t_edges[de->src];
-          for (uint32_t k = 0; k < te.em_cnt; ++k) {
-            const msgpu_edgematch &m = g->t_ems[te.em_off + k];
-            ps.ems.push_back(msgpu_path_em{m.anchor_id, m.ov_lo, m.ov_hi});
-          }
-          ps.order_off.push_back(static_cast<uint32_t>(ps.orders.size()));
-          ps.em_off.push_back(static_cast<uint32_t>(ps.ems.size()));
-        }
-        for (uint32_t v : p) {
-          auto c = g->contain.find(v);
-          if (c == g->contain.end()) continue;
-          for (const msgpu_graph::Contain &ce : c->second) {
-            msgpu_path_contain pc{};
-            pc.host_read   = v;
-            pc.nano        = ce.nano;
-            pc.direction   = ce.direction;
-            pc.anchors_off = static_cast<uint32_t>(ps.contain_anchors.size());
-            pc.anchors_cnt = static_cast<uint32_t>(ce.anchors.size());
-            ps.contain_anchors.insert(ps.contain_anchors.end(), ce.anchors.begin(), ce.anchors.end());
-            ps.contains.push_back(pc);
-          }
-        }
-        g->stats.n_path_reads += p.size();
+      }
+    };
+    uint32_t nt = g->n_threads;
+    if (nt > comps.size()) nt = static_cast<uint32_t>(comps.size() ? comps.size() : 1);
+    std::vector<std::thread> pool;
+    for (uint32_t t = 1; t < nt; ++t) pool.emplace_back(work);
+    work();
+    for (auto &t : pool) t.join();
+    for (size_t i = 0; i < comps.size(); ++i)
+      if (rcs[i] != MSGPU_OK) {
+        snprintf(g->err, sizeof(g->err), "%s", errs[i].c_str());
+        return rcs[i];
+      }
+    for (auto &v : per)
+      for (auto &ps : v) {
+        g->stats.n_path_reads += ps.reads.size();
         g->paths.push_back(std::move(ps));
       }
-    }
     g->stats.n_paths = g->paths.size();
     g->linearized    = true;
   } catch (std::bad_alloc const &) {

@@ -54,7 +54,8 @@ class GraphStage:
                                                  rows.ctypes.data if rows is not None and len(rows) else None,
                                                  0 if rows is None else len(rows)))
 
-    def linearize(self):
+    def linearize(self, threads=1):
+        self._check(self._L.msgpu_graph_set_threads(self._h, int(threads)))
         self._check(self._L.msgpu_graph_linearize(self._h))
 
     @property

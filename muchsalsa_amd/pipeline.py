@@ -36,6 +36,7 @@ def _registry_ids(seqfile, names):
 def run(contigs_paf, unitigs_path, nanopore_path, out_dir, threads=None, wiggle_room=300, device=0, timings=None):
     """-> dict of counts; writes the three output files into out_dir (created by the caller, Application.cpp:65-82)."""
     t = {}
+    n_threads = int(threads) if threads else max(1, min(16, os.cpu_count() or 1))
     t0 = time.perf_counter()
     params = overlap.default_params()
     params.wiggle_room = int(wiggle_room)
@@ -75,7 +76,7 @@ def run(contigs_paf, unitigs_path, nanopore_path, out_dir, threads=None, wiggle_
     t0 = time.perf_counter()
     g = GraphStage(tables, read_len, read_first)
     g.clean_up(contraction, paf.rows)
-    g.linearize()
+    g.linearize(n_threads)
     t["graph_host"] = time.perf_counter() - t0
 
     t0 = time.perf_counter()
@@ -92,7 +93,6 @@ def run(contigs_paf, unitigs_path, nanopore_path, out_dir, threads=None, wiggle_
     t0 = time.perf_counter()
     asm = Assembly(store)
     asm.set_rows(paf.rows)
-    n_threads = int(threads) if threads else max(1, min(16, os.cpu_count() or 1))
     status = asm.add_prepared_batch([(g.path_input(i), g) for i in range(g.path_count)], n_threads) \
         if g.path_count else np.zeros(0, dtype=np.int32)
     asm.finish()

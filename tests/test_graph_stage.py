@@ -75,7 +75,7 @@ def test_graph_stage_matches_oracle(oracle):
         alive = state["edge_alive"]
         assert np.array_equal(got["edge_consensus"][alive], state["edge_consensus"][alive]), name
         assert np.array_equal(got["edge_weight"][alive], state["edge_weight"][alive]), name
-        g.linearize()
+        g.linearize(threads=1 + len(name) % 5)  # the thread count must not matter
         st = g.stats
         assert st.n_paths == len(paths), name
         got_contain = {}
