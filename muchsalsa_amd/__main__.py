@@ -3,7 +3,11 @@
 import json
 import sys
 
-from .pipeline import run
+from . import _lib
+
+_lib.PRELOAD_TORCH = False  # this process never imports torch: load libmsgpu against the system HIP runtime directly
+
+from .pipeline import run  # noqa: E402
 
 
 def main(argv):

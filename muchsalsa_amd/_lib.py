@@ -181,6 +181,7 @@ SYMBOLS = [
 ]
 
 _lib = None
+PRELOAD_TORCH = True  # the command-line driver turns this off: it never imports torch, so there is nothing to reconcile
 
 
 def lib():
@@ -194,10 +195,12 @@ def lib():
         # PyTorch-ROCm wheels bundle their own HIP/HSA runtime.  Two HIP runtimes in one process do not share the
         # device: whichever is initialised second sees "no GPU".  Importing torch first (when it is installed) makes
         # libmsgpu's libamdhip64.so.7 dependency resolve to the copy torch already loaded, so load order stops mattering.
-        try:
-            import torch  # noqa: F401
-        except ImportError:
-            pass
+        import sys
+        if PRELOAD_TORCH or "torch" in sys.modules:
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
         handle = C.CDLL(LIB_PATH)
         for name, restype, argtypes in SYMBOLS:
             fn = getattr(handle, name)  # AttributeError if the library lacks a declared symbol
