@@ -747,13 +747,24 @@ const char *msgpu_assembly_last_error(const msgpu_assembly *a) { return a ? a->e
 int msgpu_assembly_set_rows(msgpu_assembly *a, const msgpu_row *rows, size_t n_rows) {
   if (!a || (n_rows && !rows)) return MSGPU_E_ARG;
   try {
+    // bucket by read id (dense Registry ids: a counting sort), then order each read's few rows by (anchor, line)
+    uint32_t max_read = 0;
+    for (size_t i = 0; i < n_rows; ++i) max_read = std::max(max_read, rows[i].read_id);
+    std::vector<uint64_t> start(static_cast<size_t>(max_read) + 2, 0);
+    for (size_t i = 0; i < n_rows; ++i) ++start[rows[i].read_id + 1];
+    for (size_t r = 0; r + 1 < start.size(); ++r) start[r + 1] += start[r];
     std::vector<uint32_t> order(n_rows);
-    for (size_t i = 0; i < n_rows; ++i) order[i] = static_cast<uint32_t>(i);
+    {
+      std::vector<uint64_t> cur(start.begin(), start.end() - 1);
+      for (size_t i = 0; i < n_rows; ++i) order[cur[rows[i].read_id]++] = static_cast<uint32_t>(i);
+    }
     auto key = [&](uint32_t i) { return (static_cast<uint64_t>(rows[i].read_id) << 32) | rows[i].anchor_id; };
-    std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { // lowest line first: MatchMap.cpp:64-80
-      const uint64_t kx = key(x), ky = key(y);
-      return kx != ky ? kx < ky : rows[x].line < rows[y].line;
-    });
+    for (size_t r = 0; r + 1 < start.size(); ++r)
+      std::sort(order.begin() + static_cast<long>(start[r]), order.begin() + static_cast<long>(start[r + 1]),
+                [&](uint32_t x, uint32_t y) { // lowest line first: MatchMap.cpp:64-80
+                  return rows[x].anchor_id != rows[y].anchor_id ? rows[x].anchor_id < rows[y].anchor_id
+                                                                : rows[x].line < rows[y].line;
+                });
     a->rows.resize(n_rows);
     a->row_keys.resize(n_rows);
     for (size_t i = 0; i < n_rows; ++i) {
