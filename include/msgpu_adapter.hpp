@@ -287,6 +287,7 @@ inline AssemblyCounts assemble(std::string const &contigsPaf, std::string const 
   detail::require(msgpu_seq_upload(s.ctx, 0, s.fn, readIds.data(), readSpace), "upload reads", msgpu_seq_last_error(s.ctx));
   detail::require(msgpu_seq_upload(s.ctx, 1, s.fi, anchorIds.data(), anchorSpace), "upload unitigs",
                   msgpu_seq_last_error(s.ctx));
+  detail::require(msgpu_seq_pack(s.ctx), "msgpu_seq_pack", msgpu_seq_last_error(s.ctx)); // 2 bits per base in HBM
 
   detail::require(msgpu_assembly_create(s.ctx, &s.as), "msgpu_assembly_create"); // :300-310, 620-677
   detail::require(msgpu_assembly_set_rows(s.as, rows, nRows), "msgpu_assembly_set_rows");

@@ -124,6 +124,7 @@ SYMBOLS = [
     ("msgpu_seq_upload", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_uint32]),
     ("msgpu_seq_upload_device", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,
                                           C.c_uint32]),
+    ("msgpu_seq_pack", C.c_int, [C.c_void_p]),
     ("msgpu_seq_resolve", C.c_int, [C.c_void_p, C.c_int, C.c_uint32, C.c_int32, C.c_int32, C.c_int, C.c_void_p]),
     ("msgpu_seg_anchor", C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int, C.c_void_p,
                                    C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]),

@@ -10,6 +10,7 @@
 // HBM-bound byte work: 16 B per lane, aligned 16-B stores, unaligned source handled with v_alignbyte.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -113,6 +114,124 @@ __global__ __launch_bounds__(256) void k_gather(const msgpu_copy *pieces, const 
   }
 }
 
+// ---- 2-bit store ---------------------------------------------------------------------------------
+// After msgpu_seq_pack a store holds 2 bits per base (A C G T = 0 1 2 3, base i in word i >> 4 at bits 2 (i & 15)) plus
+// a sorted list of the positions whose byte is none of ACGT (N, lower case, IUPAC codes; they carry code 0 in the
+// packed words and are written back verbatim by k_patch_exceptions).  The gather then reads a quarter of the bytes:
+// 1.25 B of HBM traffic per base instead of 2.  Complement is code ^ 3; reversing a lane's 16 bases is a bit reverse.
+
+// the 16 codes starting at base index b (may be negative by < 16 at the head of a piece: the words are padded)
+__device__ __forceinline__ uint32_t codes16(const uint32_t *words, int64_t b) {
+  const int64_t  w  = b >> 4; // floor
+  const uint32_t sh = static_cast<uint32_t>(b & 15) * 2;
+  return __builtin_amdgcn_alignbit(words[w + 1], words[w], sh);
+}
+// 4 codes (low 8 bits of c) -> 4 ASCII bytes
+__device__ __forceinline__ uint32_t decode4(uint32_t c) {
+  const uint32_t sel = (c | (c << 6) | (c << 12) | (c << 18)) & 0x03030303u;
+  return __builtin_amdgcn_perm(0u, 0x54474341u /* 'A','C','G','T' */, sel);
+}
+
+__global__ __launch_bounds__(256) void k_gather_packed(const msgpu_copy *pieces, const uint2 *chunk_map, uint64_t n_chunks,
+                                                       const uint32_t *words0, const uint32_t *words1, uint8_t *out) {
+  const uint64_t c0   = (static_cast<uint64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6)) * GUNROLL;
+  const int      lane = threadIdx.x & 63;
+  uint64_t       A[GUNROLL], qlo[GUNROLL], qhi[GUNROLL];
+  uint32_t       code[GUNROLL];
+  bool           rev[GUNROLL];
+#pragma unroll
+  for (int u = 0; u < GUNROLL; ++u) {
+    const uint64_t chunk = c0 + u;
+    qlo[u] = qhi[u] = A[u] = 0;
+    rev[u]  = false;
+    code[u] = 0;
+    if (chunk >= n_chunks) continue;
+    const uint2      cm = chunk_map[chunk];
+    const msgpu_copy pc = pieces[cm.x];
+    const uint64_t   d0 = pc.dst_off, d1 = pc.dst_off + pc.len;
+    A[u]   = (d0 & ~15ull) + static_cast<uint64_t>(cm.y) * GCHUNK + lane * 16ull;
+    qlo[u] = A[u] > d0 ? A[u] : d0;
+    qhi[u] = (A[u] + 16 < d1) ? A[u] + 16 : d1;
+    if (qlo[u] >= qhi[u]) continue;
+    const uint32_t *w = (pc.flags & MSGPU_COPY_ILLUMINA) ? words1 : words0;
+    rev[u]            = (pc.flags & MSGPU_COPY_REVCOMP) != 0;
+    const int64_t rel = static_cast<int64_t>(A[u]) - static_cast<int64_t>(d0); // >= -15
+    const int64_t b   = rev[u] ? static_cast<int64_t>(pc.src_off) + pc.len - 1 - rel - 15 : static_cast<int64_t>(pc.src_off) + rel;
+    code[u]           = codes16(w, b);
+  }
+#pragma unroll
+  for (int u = 0; u < GUNROLL; ++u) {
+    if (qlo[u] >= qhi[u]) continue;
+    uint32_t c = code[u];
+    if (rev[u]) { // reverse the 16 two-bit fields and complement them
+      c = __builtin_bitreverse32(c);
+      c = ((c >> 1) & 0x55555555u) | ((c & 0x55555555u) << 1);
+      c = ~c;
+    }
+    const uint32_t w0 = decode4(c & 0xffu), w1 = decode4((c >> 8) & 0xffu), w2 = decode4((c >> 16) & 0xffu),
+                   w3 = decode4(c >> 24);
+    if (qlo[u] == A[u] && qhi[u] == A[u] + 16) {
+      *reinterpret_cast<uint4 *>(out + A[u]) = make_uint4(w0, w1, w2, w3);
+    } else {
+      const uint32_t w[4] = {w0, w1, w2, w3};
+      for (uint64_t q = qlo[u]; q < qhi[u]; ++q) {
+        const uint32_t k = static_cast<uint32_t>(q - A[u]);
+        out[q]           = static_cast<uint8_t>(w[k >> 2] >> (8 * (k & 3)));
+      }
+    }
+  }
+}
+
+// 16 bases -> one word; counts (pass 0) or records (pass 1) the bytes that are none of ACGT
+__global__ __launch_bounds__(256) void k_pack_bases(const uint8_t *bases, uint64_t n_bases, uint32_t *words,
+                                                    unsigned long long *n_exc, uint64_t *exc_pos, uint8_t *exc_byte,
+                                                    int record) {
+  const uint64_t w = static_cast<uint64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (w * 16 >= n_bases) return;
+  uint32_t word = 0;
+  for (int k = 0; k < 16; ++k) {
+    const uint64_t i = w * 16 + k;
+    if (i >= n_bases) break;
+    const uint8_t b = bases[i];
+    uint32_t      c = 0;
+    if (b == 'C') c = 1;
+    else if (b == 'G') c = 2;
+    else if (b == 'T') c = 3;
+    else if (b != 'A') {
+      const unsigned long long slot = atomicAdd(n_exc, 1ull);
+      if (record) {
+        exc_pos[slot]  = i;
+        exc_byte[slot] = b;
+      }
+    }
+    word |= c << (2 * k);
+  }
+  if (!record) words[w] = word;
+}
+
+// bytes that are not ACGT: written verbatim at their (possibly mirrored) place, SequenceUtils.cpp:46-57 leaves them alone
+__global__ __launch_bounds__(256) void k_patch_exceptions(const msgpu_copy *pieces, uint32_t n_pieces, const uint64_t *pos0,
+                                                          const uint8_t *byte0, uint64_t n0, const uint64_t *pos1,
+                                                          const uint8_t *byte1, uint64_t n1, uint8_t *out) {
+  const uint32_t p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= n_pieces) return;
+  const msgpu_copy pc  = pieces[p];
+  const bool       il  = (pc.flags & MSGPU_COPY_ILLUMINA) != 0;
+  const uint64_t  *pos = il ? pos1 : pos0;
+  const uint8_t   *byt = il ? byte1 : byte0;
+  const uint64_t   n   = il ? n1 : n0;
+  uint64_t         lo = 0, hi = n; // first exception at or after src_off
+  while (lo < hi) {
+    const uint64_t mid = lo + (hi - lo) / 2;
+    if (pos[mid] < pc.src_off) lo = mid + 1;
+    else hi = mid;
+  }
+  for (; lo < n && pos[lo] < pc.src_off + pc.len; ++lo) {
+    const uint64_t r = pos[lo] - pc.src_off;
+    out[pc.dst_off + ((pc.flags & MSGPU_COPY_REVCOMP) ? pc.len - 1 - r : r)] = byt[lo];
+  }
+}
+
 // FASTA wrapping (limitLength, ap.cpp:61-76): text record = header, the bases in lines of 60 separated by '\n', '\n'.
 // One wavefront per 1 KiB of text, 16 output bytes per lane, one aligned 16-B store; chunk_map as in k_gather.
 constexpr uint32_t FLINE = 60;
@@ -171,11 +290,24 @@ using namespace msgpu;
 // ---- host side -----------------------------------------------------------------------------------------------------
 
 namespace {
-constexpr size_t SEQ_PAD = 64; // bytes of zero padding in front of and behind the bases of a store
+constexpr size_t SEQ_PAD  = 64; // bytes of zero padding in front of and behind the bases of a store
+constexpr size_t PACK_PAD = 16; // words of zero padding in front of and behind the packed words
 
 struct SeqStore {
-  void                 *d_buf = nullptr; // SEQ_PAD + bases + SEQ_PAD
+  void                 *d_buf = nullptr; // SEQ_PAD + bases + SEQ_PAD (freed by msgpu_seq_pack)
   uint64_t              n_bases = 0;
+  // 2-bit form (msgpu_seq_pack): 16 words of zero padding, (n_bases + 15) / 16 words, 16 words of padding
+  void    *d_words = nullptr, *d_exc_pos = nullptr, *d_exc_byte = nullptr;
+  uint64_t n_exc = 0;
+  bool     packed = false;
+  void     drop_packed() {
+    if (d_words) (void)hipFree(d_words);
+    if (d_exc_pos) (void)hipFree(d_exc_pos);
+    if (d_exc_byte) (void)hipFree(d_exc_byte);
+    d_words = d_exc_pos = d_exc_byte = nullptr;
+    n_exc                            = 0;
+    packed                           = false;
+  }
   std::vector<uint64_t> off;   // by id: offset of the sequence inside the bases (~0 = no such id)
   std::vector<uint64_t> len;
 };
@@ -240,8 +372,10 @@ void msgpu_seq_destroy(msgpu_seqctx *c) {
   }
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
-  for (auto &s : c->st)
+  for (auto &s : c->st) {
     if (s.d_buf) (void)hipFree(s.d_buf);
+    s.drop_packed();
+  }
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -271,6 +405,7 @@ int msgpu_seq_upload(msgpu_seqctx *c, int kind, const msgpu_seqfile *f, const ui
   }
   s.n_bases = total;
   if (c->device < 0) return MSGPU_OK; // layout-only context: offsets and lengths are all it needs
+  s.drop_packed();
   if (s.d_buf) {
     SHIP(c, hipFree(s.d_buf));
     s.d_buf = nullptr;
@@ -293,6 +428,7 @@ int msgpu_seq_upload_device(msgpu_seqctx *c, int kind, const void *d_bases, uint
     if (off[i] != ~0ull && off[i] + len[i] > n_bases) return MSGPU_E_ARG;
   s.off.assign(off, off + n_ids);
   s.len.assign(len, len + n_ids);
+  s.drop_packed();
   if (s.d_buf) {
     SHIP(c, hipFree(s.d_buf));
     s.d_buf = nullptr;
@@ -386,12 +522,97 @@ int msgpu_gather_run(msgpu_seqctx *c, const msgpu_gather_plan *pl, void *d_out, 
   SHIP(c, hipSetDevice(c->device));
   if (!pl->n_chunks) return MSGPU_OK;
   hipStream_t st = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->stream;
+  if ((c->st[0].packed && c->st[1].d_buf) || (c->st[1].packed && c->st[0].d_buf)) {
+    snprintf(c->err, sizeof(c->err), "one store is packed and the other is not: call msgpu_seq_pack after the last upload");
+    return MSGPU_E_STATE;
+  }
+  if (c->st[0].packed || c->st[1].packed) { // msgpu_seq_pack converts both stores
+    const uint32_t *w0 = c->st[0].d_words ? static_cast<const uint32_t *>(c->st[0].d_words) + PACK_PAD : nullptr;
+    const uint32_t *w1 = c->st[1].d_words ? static_cast<const uint32_t *>(c->st[1].d_words) + PACK_PAD : nullptr;
+    hipLaunchKernelGGL(k_gather_packed, dim3(static_cast<uint32_t>((pl->n_chunks + 4 * GUNROLL - 1) / (4 * GUNROLL))),
+                       dim3(256), 0, st, static_cast<const msgpu_copy *>(pl->d_pieces),
+                       static_cast<const uint2 *>(pl->d_chunk_map), pl->n_chunks, w0, w1, static_cast<uint8_t *>(d_out));
+    if (c->st[0].n_exc || c->st[1].n_exc)
+      hipLaunchKernelGGL(k_patch_exceptions, dim3((pl->n + 255) / 256), dim3(256), 0, st,
+                         static_cast<const msgpu_copy *>(pl->d_pieces), pl->n,
+                         static_cast<const uint64_t *>(c->st[0].d_exc_pos), static_cast<const uint8_t *>(c->st[0].d_exc_byte),
+                         c->st[0].n_exc, static_cast<const uint64_t *>(c->st[1].d_exc_pos),
+                         static_cast<const uint8_t *>(c->st[1].d_exc_byte), c->st[1].n_exc, static_cast<uint8_t *>(d_out));
+    SHIP(c, hipGetLastError());
+    return MSGPU_OK;
+  }
   const uint8_t *b0 = c->st[0].d_buf ? static_cast<const uint8_t *>(c->st[0].d_buf) + SEQ_PAD : nullptr;
   const uint8_t *b1 = c->st[1].d_buf ? static_cast<const uint8_t *>(c->st[1].d_buf) + SEQ_PAD : nullptr;
   hipLaunchKernelGGL(k_gather, dim3(static_cast<uint32_t>((pl->n_chunks + 4 * GUNROLL - 1) / (4 * GUNROLL))), dim3(256), 0, st,
                      static_cast<const msgpu_copy *>(pl->d_pieces), static_cast<const uint2 *>(pl->d_chunk_map),
                      pl->n_chunks, b0, b1, static_cast<uint8_t *>(d_out));
   SHIP(c, hipGetLastError());
+  return MSGPU_OK;
+}
+
+// Convert both resident stores to the 2-bit form (+ exception lists) and free the byte-per-base buffers.
+int msgpu_seq_pack(msgpu_seqctx *c) {
+  if (!c) return MSGPU_E_ARG;
+  if (c->device < 0) return MSGPU_E_NODEVICE;
+  SHIP(c, hipSetDevice(c->device));
+  for (SeqStore &s : c->st) {
+    if (s.packed || !s.d_buf) continue;
+    const uint64_t n_words = (s.n_bases + 15) / 16;
+    const uint8_t *bases   = static_cast<const uint8_t *>(s.d_buf) + SEQ_PAD;
+    void          *d_cnt   = nullptr;
+    SHIP(c, hipMalloc(&s.d_words, (n_words + 2 * PACK_PAD) * 4));
+    hipError_t e = hipMalloc(&d_cnt, 8);
+    if (e == hipSuccess) e = hipMemsetAsync(s.d_words, 0, (n_words + 2 * PACK_PAD) * 4, c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(d_cnt, 0, 8, c->stream);
+    unsigned long long n_exc = 0;
+    if (e == hipSuccess && n_words) {
+      hipLaunchKernelGGL(k_pack_bases, dim3(static_cast<uint32_t>((n_words + 255) / 256)), dim3(256), 0, c->stream, bases,
+                         s.n_bases, static_cast<uint32_t *>(s.d_words) + PACK_PAD, static_cast<unsigned long long *>(d_cnt),
+                         static_cast<uint64_t *>(nullptr), static_cast<uint8_t *>(nullptr), 0);
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(&n_exc, d_cnt, 8, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess && n_exc) { // second pass records them; sorted by position on the host (they are few)
+      e = hipMalloc(&s.d_exc_pos, n_exc * 8);
+      if (e == hipSuccess) e = hipMalloc(&s.d_exc_byte, n_exc);
+      if (e == hipSuccess) e = hipMemsetAsync(d_cnt, 0, 8, c->stream);
+      if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_pack_bases, dim3(static_cast<uint32_t>((n_words + 255) / 256)), dim3(256), 0, c->stream, bases,
+                           s.n_bases, static_cast<uint32_t *>(nullptr), static_cast<unsigned long long *>(d_cnt),
+                           static_cast<uint64_t *>(s.d_exc_pos), static_cast<uint8_t *>(s.d_exc_byte), 1);
+        e = hipGetLastError();
+      }
+      std::vector<uint64_t> pos(n_exc);
+      std::vector<uint8_t>  byt(n_exc);
+      if (e == hipSuccess) e = hipMemcpyAsync(pos.data(), s.d_exc_pos, n_exc * 8, hipMemcpyDeviceToHost, c->stream);
+      if (e == hipSuccess) e = hipMemcpyAsync(byt.data(), s.d_exc_byte, n_exc, hipMemcpyDeviceToHost, c->stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+      if (e == hipSuccess) {
+        std::vector<uint64_t> idx(n_exc);
+        for (uint64_t i = 0; i < n_exc; ++i) idx[i] = i;
+        std::sort(idx.begin(), idx.end(), [&](uint64_t x, uint64_t y) { return pos[x] < pos[y]; });
+        std::vector<uint64_t> spos(n_exc);
+        std::vector<uint8_t>  sbyt(n_exc);
+        for (uint64_t i = 0; i < n_exc; ++i) {
+          spos[i] = pos[idx[i]];
+          sbyt[i] = byt[idx[i]];
+        }
+        e = hipMemcpyAsync(s.d_exc_pos, spos.data(), n_exc * 8, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(s.d_exc_byte, sbyt.data(), n_exc, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+      }
+    }
+    if (d_cnt) (void)hipFree(d_cnt);
+    if (e != hipSuccess) {
+      s.drop_packed();
+      return sfail(c, e == hipErrorOutOfMemory ? MSGPU_E_NOMEM : MSGPU_E_HIP, "msgpu_seq_pack", e);
+    }
+    s.n_exc  = n_exc;
+    s.packed = true;
+    (void)hipFree(s.d_buf); // the byte-per-base copy is no longer needed
+    s.d_buf = nullptr;
+  }
   return MSGPU_OK;
 }
 

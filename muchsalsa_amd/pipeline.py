@@ -88,6 +88,7 @@ def run(contigs_paf, unitigs_path, nanopore_path, out_dir, threads=None, wiggle_
     store = SeqStore(device=device)
     for kind, f, (ids, n) in zip((NANOPORE, ILLUMINA), seq["files"], seq["ids"]):
         store.upload(kind, f, ids, n)
+    store.pack()  # 2 bits per base + exception list: a quarter of the footprint, less gather traffic, same bytes out
     t["sequences_upload"] = time.perf_counter() - t0
 
     t0 = time.perf_counter()

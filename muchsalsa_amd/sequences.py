@@ -139,6 +139,10 @@ class SeqStore:
         self._check(self._L.msgpu_seq_upload_device(self._h, kind, C.c_void_p(d_bases_ptr), int(n_bases),
                                                     off.ctypes.data, length.ctypes.data, len(off)))
 
+    def pack(self):
+        """2 bits per base + exception list for both stores (results of later gathers are unchanged)"""
+        self._check(self._L.msgpu_seq_pack(self._h))
+
     def resolve(self, kind, seq_id, left, right, direction, dst_off=0):
         out = np.zeros(1, dtype=COPY_DTYPE)
         self._check(self._L.msgpu_seq_resolve(self._h, kind, int(seq_id), int(left), int(right), 1 if direction else 0,

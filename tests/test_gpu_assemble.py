@@ -9,8 +9,8 @@ from test_assemble_path import fuzz_case
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def gpu_world(oracle, tmp_path_factory):
+@pytest.fixture(scope="module", params=["bytes", "two_bit"])
+def gpu_world(request, oracle, tmp_path_factory):
     from muchsalsa_amd.overlap import build_overlaps
     from muchsalsa_amd.sequences import ILLUMINA, NANOPORE, SeqFile, SeqStore
     w = World(300, 5000, 1500, 7, jitter=15)
@@ -24,6 +24,8 @@ def gpu_world(oracle, tmp_path_factory):
     w.store = SeqStore(device=0)
     w.store.upload(NANOPORE, w.files[0])
     w.store.upload(ILLUMINA, w.files[1])
+    if request.param == "two_bit":
+        w.store.pack()
     return w
 
 

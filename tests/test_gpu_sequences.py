@@ -12,6 +12,20 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_test_data")
 
 
+@pytest.fixture(autouse=True, params=["bytes", "two_bit"])
+def store_form(request, monkeypatch):
+    """every test of this module runs on the byte-per-base store and on the 2-bit store (msgpu_seq_pack)"""
+    if request.param == "two_bit":
+        from muchsalsa_amd import sequences as S
+        plain_plan = S.SeqStore.plan
+
+        def plan(self, pieces):
+            self.pack()  # idempotent; both stores are uploaded by the time a test plans its first gather
+            return plain_plan(self, pieces)
+        monkeypatch.setattr(S.SeqStore, "plan", plan)
+    return request.param
+
+
 def _run(store, pieces, total=None):
     import torch
     plan = store.plan(pieces)
