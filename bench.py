@@ -25,7 +25,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # HBM bytes per launch from the PMC counters (FETCH_SIZE x 2 per the gfx950 note of MI355X_MICROARCH.md + WRITE_SIZE),
 # collected with rocprofv3 in separate --pmc passes of this same command: profiles/r1_03_final/pmc_summary.csv.
 # They cannot be read from inside this process, so they are quoted for the one configuration they were measured on.
-PMC_TRAFFIC_BYTES = {("cfg3", 1): {"k_chain": 3.26e9, "k_gather_packed": None}}
+PMC_TRAFFIC_BYTES = {("cfg3", 1): {"k_chain": 3.26e9, "k_gather_packed": 1.48e9}}  # profiles/r1_05_gather
 
 WORKLOADS = {
     # BASELINE.json configs[2]: the configuration the metric is quoted on
@@ -424,7 +424,9 @@ def main():
                          "note": "VALU-bound (fp64/int issue), see profiles/r1_03_final/README.md"},
         }
         if cons is not None:
-            gb = 2.0 * (cons["target_bases"] + cons["query_bases"]) / 1e9  # 1 B read + 1 B written per base
+            # algorithmic bytes on the 2-bit store: 0.25 B read + 1 B written per base (SURVEY 8(d) counted 1 B + 1 B for a
+            # byte-per-base source; that figure is kept as "bytes_if_byte_store" for comparison)
+            gb = 1.25 * (cons["target_bases"] + cons["query_bases"]) / 1e9
             g_gbs = gb / (cons["ms"] * 1e-3)
             out["consensus"] = {
                 "stage": "slice / reverse-complement / stitch kernel k_gather_packed on the 2-bit sequence store "
@@ -436,7 +438,10 @@ def main():
                 "roofline": {"bound": "hbm", "kernel": "k_gather_packed", "achieved": g_gbs, "peak": HBM_PEAK_GBS,
                              "unit": "GB/s", "frac": g_gbs / HBM_PEAK_GBS,
                              "traffic": PMC_TRAFFIC_BYTES.get((args.workload, world), {}).get("k_gather_packed"),
-                             "algorithmic_bytes_per_launch": int(gb * 1e9)},
+                             "algorithmic_bytes_per_launch": int(gb * 1e9),
+                             "bytes_if_byte_store": int(2 * (cons["target_bases"] + cons["query_bases"])),
+                             "note": "2 bits in + 1 byte out per base; the same launch on a byte-per-base source would "
+                                     "move 2 B per base"},
             }
         if graph_leg is not None:
             out["graph_stage"] = graph_leg
