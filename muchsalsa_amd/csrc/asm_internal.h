@@ -15,8 +15,11 @@ struct msgpu_assembly {
   std::vector<msgpu_path_info>  paths;
   std::vector<msgpu_query_info> queries;
   std::string                   paf;                 // temp_1.align.paf
-  std::string                   target_fa, query_fa; // filled by msgpu_assembly_finish
+  // filled by msgpu_assembly_finish: both texts live in one pinned host buffer (target text, then query text)
+  char    *text = nullptr;
+  uint64_t target_fa_len = 0, query_fa_off = 0, query_fa_len = 0;
   bool                          finished = false;
+  int                           raw_device = 0;
   void                         *d_raw    = nullptr; // the gathered bases, kept after finish for msgpu_assembly_validate
   void (*release)(msgpu_assembly *) = nullptr;      // frees d_raw (set by msgpu_seq.hip, which owns the HIP calls)
   char                          err[256] = {0};

@@ -917,9 +917,12 @@ const char *msgpu_assembly_text(const msgpu_assembly *a, int which, uint64_t *le
     if (len) *len = 0;
     return nullptr;
   }
-  const std::string &s = which == 0 ? a->target_fa : which == 1 ? a->query_fa : a->paf;
-  if (len) *len = s.size();
-  return s.data();
+  if (which == 2) {
+    if (len) *len = a->paf.size();
+    return a->paf.data();
+  }
+  if (len) *len = which == 0 ? a->target_fa_len : a->query_fa_len;
+  return a->text + (which == 0 ? 0 : a->query_fa_off);
 }
 
 } // extern "C"

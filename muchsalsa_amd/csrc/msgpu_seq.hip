@@ -11,9 +11,12 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
+#include <unordered_map>
 #include <vector>
 
 #include "asm_internal.h"
@@ -337,6 +340,22 @@ struct msgpu_seqctx {
   hipStream_t stream = nullptr;
   SeqStore    st[2];
   char        err[256] = {0};
+  // device scratch that only grows (msgpu_assembly_finish / msgpu_fasta_format would otherwise pay several
+  // hipMalloc + hipFree round trips, each a device-wide synchronisation, per call)
+  struct Scratch {
+    void  *p   = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes) {
+      if (bytes <= cap) return hipSuccess;
+      if (p) (void)hipFree(p);
+      p   = nullptr;
+      cap = 0;
+      const size_t want = bytes + bytes / 4 + 4096;
+      hipError_t   e    = hipMalloc(&p, want);
+      if (e == hipSuccess) cap = want;
+      return e;
+    }
+  } scr_text, scr_recs, scr_map, scr_hdr;
 };
 
 struct msgpu_gather_plan {
@@ -396,6 +415,8 @@ void msgpu_seq_destroy(msgpu_seqctx *c) {
     if (s.d_buf) (void)hipFree(s.d_buf);
     s.drop_packed();
   }
+  for (msgpu_seqctx::Scratch *x : {&c->scr_text, &c->scr_recs, &c->scr_map, &c->scr_hdr})
+    if (x->p) (void)hipFree(x->p);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -677,10 +698,10 @@ int msgpu_fasta_format(msgpu_seqctx *c, const void *d_raw, const msgpu_fasta_rec
     }
   } catch (std::bad_alloc const &) { return MSGPU_E_NOMEM; }
   hipStream_t st = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->stream;
-  void       *d_recs = nullptr, *d_map = nullptr, *d_hdr = nullptr;
-  hipError_t  e = hipMalloc(&d_recs, n * sizeof(msgpu_fasta_record));
-  if (e == hipSuccess) e = hipMalloc(&d_map, chunks * 8);
-  if (e == hipSuccess) e = hipMalloc(&d_hdr, headers_bytes ? headers_bytes : 1);
+  hipError_t  e  = c->scr_recs.ensure(n * sizeof(msgpu_fasta_record));
+  if (e == hipSuccess) e = c->scr_map.ensure(chunks * 8);
+  if (e == hipSuccess) e = c->scr_hdr.ensure(headers_bytes ? headers_bytes : 1);
+  void *d_recs = c->scr_recs.p, *d_map = c->scr_map.p, *d_hdr = c->scr_hdr.p;
   if (e == hipSuccess) e = hipMemcpyAsync(d_recs, records, n * sizeof(msgpu_fasta_record), hipMemcpyHostToDevice, st);
   if (e == hipSuccess) e = hipMemcpyAsync(d_map, cmap.data(), chunks * 8, hipMemcpyHostToDevice, st);
   if (e == hipSuccess && headers_bytes) e = hipMemcpyAsync(d_hdr, headers, headers_bytes, hipMemcpyHostToDevice, st);
@@ -691,14 +712,69 @@ int msgpu_fasta_format(msgpu_seqctx *c, const void *d_raw, const msgpu_fasta_rec
                        static_cast<uint8_t *>(d_text));
     e = hipGetLastError();
   }
-  // the staging buffers are pageable-host copies + device scratch: wait before they go out of scope
+  // the staging copies come from pageable host memory (`cmap` is local): wait before they go out of scope
   if (e == hipSuccess) e = hipStreamSynchronize(st);
-  if (d_recs) (void)hipFree(d_recs);
-  if (d_map) (void)hipFree(d_map);
-  if (d_hdr) (void)hipFree(d_hdr);
   if (e != hipSuccess) return sfail(c, e == hipErrorOutOfMemory ? MSGPU_E_NOMEM : MSGPU_E_HIP, "fasta format", e);
   return MSGPU_OK;
 }
+
+} // extern "C"
+
+namespace {
+// Process-wide pools for the two buffers an assembly keeps after msgpu_assembly_finish (the gathered bases on the device,
+// the texts in pinned host memory).  Pinning 20 MB costs > 1 ms and a hipMalloc / hipFree pair synchronises the device,
+// so a freed assembly parks its buffers here (at most two of each kind) for the next one; nothing here refers to a
+// context, so an assembly may outlive the sequence context it was laid out over.
+struct ParkedBuffers {
+  struct Buf {
+    void  *p;
+    size_t cap;
+    int    device; // -1: pinned host memory
+  };
+  std::mutex       m;
+  std::vector<Buf> free_list;
+  void *take(size_t bytes, int device) {
+    std::lock_guard<std::mutex> g(m);
+    for (size_t i = 0; i < free_list.size(); ++i)
+      if (free_list[i].device == device && free_list[i].cap >= bytes && free_list[i].cap <= 2 * bytes + (1u << 20)) {
+        void *p = free_list[i].p;
+        caps[p] = free_list[i].cap;
+        free_list.erase(free_list.begin() + static_cast<long>(i));
+        return p;
+      }
+    return nullptr;
+  }
+  void give(void *p, size_t cap, int device) {
+    std::unique_lock<std::mutex> g(m);
+    caps.erase(p);
+    size_t same = 0;
+    for (const Buf &b : free_list) same += b.device == device;
+    if (same >= 2) { // keep the pool small: release instead
+      g.unlock();
+      if (device < 0) (void)hipHostFree(p);
+      else (void)hipFree(p);
+      return;
+    }
+    free_list.push_back(Buf{p, cap, device});
+  }
+  std::unordered_map<void *, size_t> caps; // capacity of buffers currently lent out
+  size_t cap_of(void *p) {
+    std::lock_guard<std::mutex> g(m);
+    auto it = caps.find(p);
+    return it == caps.end() ? 0 : it->second;
+  }
+  void lend(void *p, size_t cap) {
+    std::lock_guard<std::mutex> g(m);
+    caps[p] = cap;
+  }
+};
+ParkedBuffers &parked() {
+  static ParkedBuffers *pool = new ParkedBuffers(); // never destroyed: no HIP calls during static destruction
+  return *pool;
+}
+} // namespace
+
+extern "C" {
 
 // gather every piece of every path once, wrap targets and queries into FASTA text on the device, copy the texts back
 int msgpu_assembly_finish(msgpu_assembly *a, void *hip_stream) {
@@ -708,67 +784,89 @@ int msgpu_assembly_finish(msgpu_assembly *a, void *hip_stream) {
   if (c->device < 0) return MSGPU_E_NODEVICE;
   SHIP(c, hipSetDevice(c->device));
   hipStream_t st = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->stream;
-  std::vector<msgpu_fasta_record> trec, qrec;
+  // one text buffer: all target records, then (16-byte aligned) all query records; one wrapping launch, one copy back
+  std::vector<msgpu_fasta_record> recs;
   std::string                     hdr;
-  uint64_t                        t_bytes = 0, q_bytes = 0;
+  uint64_t                        t_bytes = 0, q_bytes = 0, q_off = 0;
   try {
     for (const msgpu_path_info &p : a->paths) {
       if (p.target_len > 0xffffffffull) return MSGPU_E_ARG;
       const std::string h = msgpu::target_header(p.asm_idx);
-      trec.push_back(msgpu_fasta_record{p.target_raw_off, t_bytes, static_cast<uint32_t>(p.target_len),
+      recs.push_back(msgpu_fasta_record{p.target_raw_off, t_bytes, static_cast<uint32_t>(p.target_len),
                                         static_cast<uint32_t>(hdr.size()), static_cast<uint32_t>(h.size()), 0});
       hdr += h;
       t_bytes += msgpu_fasta_text_bytes(static_cast<uint32_t>(h.size()), p.target_len);
+    }
+    q_off = (t_bytes + 15) & ~15ull;
+    for (const msgpu_path_info &p : a->paths)
       for (uint32_t q = p.query_begin; q < p.query_end; ++q) {
         const msgpu_query_info &qi = a->queries[q];
         const std::string       qh = msgpu::query_header(qi.kind, p.asm_idx, q - p.query_begin);
-        qrec.push_back(msgpu_fasta_record{qi.raw_off, q_bytes, static_cast<uint32_t>(qi.len),
+        recs.push_back(msgpu_fasta_record{qi.raw_off, q_off + q_bytes, static_cast<uint32_t>(qi.len),
                                           static_cast<uint32_t>(hdr.size()), static_cast<uint32_t>(qh.size()), 0});
         hdr += qh;
         q_bytes += msgpu_fasta_text_bytes(static_cast<uint32_t>(qh.size()), qi.len);
       }
-    }
-    a->target_fa.resize(t_bytes);
-    a->query_fa.resize(q_bytes);
   } catch (std::bad_alloc const &) { return MSGPU_E_NOMEM; }
-  msgpu_gather_plan *plan = nullptr;
-  int rc = msgpu_gather_plan_create(c, a->pieces.data(), a->pieces.size(), &plan);
+  const uint64_t     text_bytes = q_off + q_bytes;
+  const bool         dbg        = std::getenv("MSGPU_SEQ_DEBUG") != nullptr;
+  auto               t_prev     = std::chrono::steady_clock::now();
+  auto               tick       = [&](const char *what) {
+    if (!dbg) return;
+    auto n = std::chrono::steady_clock::now();
+    fprintf(stderr, "[finish] %-22s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(n - t_prev).count());
+    t_prev = n;
+  };
+  msgpu_gather_plan *plan       = nullptr;
+  int                rc         = msgpu_gather_plan_create(c, a->pieces.data(), a->pieces.size(), &plan);
   if (rc != MSGPU_OK) return rc;
-  void      *d_raw = nullptr, *d_t = nullptr, *d_q = nullptr;
-  hipError_t e     = hipMalloc(&d_raw, a->raw_bytes + 64);
-  if (e == hipSuccess) e = hipMalloc(&d_t, t_bytes + 16);
-  if (e == hipSuccess) e = hipMalloc(&d_q, q_bytes + 16);
+  tick("plan");
+  hipError_t e      = hipSuccess;
+  void      *d_raw  = parked().take(a->raw_bytes + 64, c->device);
+  char      *h_text = static_cast<char *>(parked().take(text_bytes + 16, -1));
+  if (!d_raw) {
+    e = hipMalloc(&d_raw, a->raw_bytes + 64);
+    if (e == hipSuccess) parked().lend(d_raw, a->raw_bytes + 64);
+  }
+  if (e == hipSuccess) e = c->scr_text.ensure(text_bytes + 16);
+  if (e == hipSuccess && !h_text) {
+    e = hipHostMalloc(reinterpret_cast<void **>(&h_text), text_bytes + 16, hipHostMallocDefault);
+    if (e == hipSuccess) parked().lend(h_text, text_bytes + 16);
+  }
   if (e == hipSuccess && std::getenv("MSGPU_POISON")) { // see DevBuf::ensure in msgpu_api.hip
     e = hipMemset(d_raw, 0xA5, a->raw_bytes + 64);
-    if (e == hipSuccess) e = hipMemset(d_t, 0xA5, t_bytes + 16);
-    if (e == hipSuccess) e = hipMemset(d_q, 0xA5, q_bytes + 16);
+    if (e == hipSuccess) e = hipMemset(c->scr_text.p, 0xA5, text_bytes + 16);
     if (e == hipSuccess) e = hipDeviceSynchronize();
   }
+  tick("allocations");
   if (e == hipSuccess) {
     rc = msgpu_gather_run(c, plan, d_raw, a->raw_bytes + 64, st);
     if (rc == MSGPU_OK)
-      rc = msgpu_fasta_format(c, d_raw, trec.data(), trec.size(), hdr.data(), hdr.size(), d_t, t_bytes, st);
-    if (rc == MSGPU_OK)
-      rc = msgpu_fasta_format(c, d_raw, qrec.data(), qrec.size(), hdr.data(), hdr.size(), d_q, q_bytes, st);
-    if (rc == MSGPU_OK && t_bytes) e = hipMemcpyAsync(&a->target_fa[0], d_t, t_bytes, hipMemcpyDeviceToHost, st);
-    if (rc == MSGPU_OK && e == hipSuccess && q_bytes)
-      e = hipMemcpyAsync(&a->query_fa[0], d_q, q_bytes, hipMemcpyDeviceToHost, st);
+      rc = msgpu_fasta_format(c, d_raw, recs.data(), recs.size(), hdr.data(), hdr.size(), c->scr_text.p, text_bytes, st);
+    tick("gather + format");
+    if (rc == MSGPU_OK && text_bytes) e = hipMemcpyAsync(h_text, c->scr_text.p, text_bytes, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
+    tick("copy back");
   }
-  if (d_t) (void)hipFree(d_t);
-  if (d_q) (void)hipFree(d_q);
   msgpu_gather_plan_free(plan);
+  tick("plan free");
   if (e != hipSuccess || rc != MSGPU_OK) {
-    if (d_raw) (void)hipFree(d_raw);
+    if (d_raw) parked().give(d_raw, parked().cap_of(d_raw), c->device);
+    if (h_text) parked().give(h_text, parked().cap_of(h_text), -1);
     if (e != hipSuccess) return sfail(c, e == hipErrorOutOfMemory ? MSGPU_E_NOMEM : MSGPU_E_HIP, "assembly finish", e);
     return rc;
   }
-  a->d_raw   = d_raw; // kept for msgpu_assembly_validate
-  a->release = [](msgpu_assembly *x) { // must not touch x->ctx: the sequence context may already be gone
-    if (x->d_raw) {
-      (void)hipFree(x->d_raw);
-      x->d_raw = nullptr;
-    }
+  a->text          = h_text;
+  a->target_fa_len = t_bytes;
+  a->query_fa_off  = q_off;
+  a->query_fa_len  = q_bytes;
+  a->d_raw         = d_raw; // kept for msgpu_assembly_validate
+  a->raw_device    = c->device;
+  a->release       = [](msgpu_assembly *x) { // must not touch x->ctx: the sequence context may already be gone
+    if (x->d_raw) parked().give(x->d_raw, parked().cap_of(x->d_raw), x->raw_device);
+    if (x->text) parked().give(x->text, parked().cap_of(x->text), -1);
+    x->d_raw = nullptr;
+    x->text  = nullptr;
   };
   a->finished = true;
   return MSGPU_OK;
