@@ -877,26 +877,35 @@ struct __attribute__((aligned(16))) ChainElem {
 //   diff = (c1.second - c2.first) + 1   (o = +2)      (c2.first - c1.second) + 1 = -(c1.second - c2.first) + 1  (o = +1)
 //   diff = (c2.second - c1.first) + 1   (o = -2)      (c1.first - c2.second) + 1 = -(c2.second - c1.first) + 1  (o = -1)
 // (negation is exact in IEEE arithmetic, so the two subtractions below reproduce all four differences bit for bit).
+// nanoCheck of checkCompatibility (mpp.cpp:67-109) for one vertex.  The orientation stays a pair of predicates
+// (pos = +1 / +2, neg = -1 / -2; two = |orientation| == 2) -- lane masks in scalar registers -- instead of an integer
+// that later has to be compared again; returns the abort verdict of :93-109.
+struct NanoFlags {
+  bool pos, neg, two;
+};
 __device__ __forceinline__ bool nano_check(double k_clo, double k_chi, double l_clo, double l_chi, int k_rlo, int k_rhi,
-                                           int l_rlo, int l_rhi, int &o, double &d) {
+                                           int l_rlo, int l_rhi, NanoFlags &f, double &d) {
   const bool ovl   = (k_clo <= l_chi) & (l_clo <= k_chi);
   const bool lt_lo = k_clo < l_clo;
   const bool fwd2  = ovl & lt_lo & (k_chi < l_chi);
   const bool bwd2  = ovl & (k_clo > l_clo) & (k_chi > l_chi);
   const bool fwd1  = (!ovl) & lt_lo;
   const bool bwd1  = (!ovl) & (!lt_lo);
-  const bool fwd   = fwd2 | fwd1;
-  const double x   = k_chi - l_clo;
-  const double y   = l_chi - k_clo;
-  double       t   = fwd ? x : y;
-  t                = (fwd1 | bwd1) ? -t : t;
-  d                = (fwd | bwd2 | bwd1) ? t + 1 : 0.0;
-  o                = fwd2 ? 2 : bwd2 ? -2 : fwd1 ? 1 : bwd1 ? -1 : 0;
-  const bool rovl  = (k_rlo <= l_rhi) & (l_rlo <= k_rhi);
-  const bool u2    = (k_rlo < l_rlo) & (k_rhi < l_rhi);
-  const bool um2   = (k_rlo > l_rlo) & (k_rhi > l_rhi);
+  f.pos            = fwd2 | fwd1;
+  f.neg            = bwd2 | bwd1;
+  f.two            = ovl;
+  // diff (:70-91): fwd -> k_chi - l_clo, bwd -> l_chi - k_clo, negated when the ranges do not overlap, + 1; 0 when
+  // the ranges overlap without a strict order.  lt_lo selects the right difference in every case that has an order.
+  const double x = k_chi - l_clo;
+  const double y = l_chi - k_clo;
+  double       t = lt_lo ? x : y;
+  t              = ovl ? t : -t;
+  d              = (f.pos | f.neg) ? t + 1 : 0.0;
+  const bool rovl = (k_rlo <= l_rhi) & (l_rlo <= k_rhi);
+  const bool u2   = (k_rlo < l_rlo) & (k_rhi < l_rhi);
+  const bool um2  = (k_rlo > l_rlo) & (k_rhi > l_rhi);
   // abort when the raw ranges overlap and their order contradicts the corrected orientation (:93-109)
-  return rovl & (((o < 0) & !um2) | ((o > 0) & !u2));
+  return rovl & ((f.neg & !um2) | (f.pos & !u2));
 }
 
 // Post-DP part of getMaxPairwisePaths (mpp.cpp:201-302) for the lanes `act` of one direction.
@@ -1143,15 +1152,15 @@ __global__ __launch_bounds__(256) void k_chain(ChainArgs a) {
       const bool kd      = (m_plus >> k) & 1ull, ld = (m_plus >> l) & 1ull;
       if (kd == ld) {
         const ChainElem K = el[k], L = el[l];
-        int             o1, o2;
+        NanoFlags       f1, f2;
         double          d1, d2;
-        bool            abort_ = nano_check(K.clo1, K.chi1, L.clo1, L.chi1, K.rlo1, K.rhi1, L.rlo1, L.rhi1, o1, d1);
-        abort_ |= nano_check(K.clo2, K.chi2, L.clo2, L.chi2, K.rlo2, K.rhi2, L.rlo2, L.rhi2, o2, d2);
-        o2 = kd ? o2 : -o2; // :131 EdgeMatch(k).direction
-        const bool   same  = (o1 == o2) & (o1 != 0);                       // :133
-        const bool   codir = ((o1 < 0) & (o2 < 0)) | ((o1 > 0) & (o2 > 0)); // :137
-        const double mx    = std_max(d1, d2);
-        const double df    = mx - std_min(d1, d2);
+        bool            abort_ = nano_check(K.clo1, K.chi1, L.clo1, L.chi1, K.rlo1, K.rhi1, L.rlo1, L.rhi1, f1, d1);
+        abort_ |= nano_check(K.clo2, K.chi2, L.clo2, L.chi2, K.rlo2, K.rhi2, L.rlo2, L.rhi2, f2, d2);
+        const bool   p2    = kd ? f2.pos : f2.neg, n2 = kd ? f2.neg : f2.pos; // :131 orientation2 *= EdgeMatch(k).direction
+        const bool   codir = (f1.pos & p2) | (f1.neg & n2);                  // :137 same sign
+        const bool   same  = codir & (f1.two == f2.two);                     // :133 equal and non-zero
+        const double mx    = fmax(d1, d2); // finite operands: the same values std::max / std::min return
+        const double df    = mx - fmin(d1, d2);
         const bool   near_ = df <= a.wiggle;
         ok                 = (!abort_) & (same ? near_ : (codir & (d1 + d2 <= a.wiggle)));
         // the fp64 division of :136 only where the first test failed (rare for true overlaps)
