@@ -1054,36 +1054,38 @@ __global__ __launch_bounds__(256) void k_chain(ChainArgs a) {
                             static_cast<uint32_t>(__double_as_longlong(em_score) >> 32));
       q[1]     = make_uint4(anchor, om.line, (em_dir ? 1u : 0u) | (em_prim ? 2u : 0u), static_cast<uint32_t>(e));
     }
-    // corrected nanopore ranges (mpp.cpp:48-65) and overhangs (ol.cpp:37-47) on both vertices
+    // corrected nanopore ranges (mpp.cpp:48-65) and overhangs (ol.cpp:37-47) on both vertices.  ov = [max lo, min hi]:
+    // on each side at most ONE of the two rows has a non-zero correction numerator (the other one is 0 / rRatio = +0),
+    // so one division per side serves both rows: (|difference of the anchor coordinates|) / (rRatio of the row that
+    // reaches further out).  Six fp64 divisions per EdgeMatch instead of eight, bit for bit the same quotients.
     {
-      const double rr  = static_cast<double>(m1.i_hi - m1.i_lo + 1) / static_cast<double>(m1.n_hi - m1.n_lo + 1);
-      double       ncl = static_cast<double>(ov_lo - m1.i_lo) / rr;
-      double       ncr = static_cast<double>(m1.i_hi - ov_hi) / rr;
+      const double rr1 = static_cast<double>(m1.i_hi - m1.i_lo + 1) / static_cast<double>(m1.n_hi - m1.n_lo + 1);
+      const double rr2 = static_cast<double>(m2.i_hi - m2.i_lo + 1) / static_cast<double>(m2.n_hi - m2.n_lo + 1);
+      const bool   l1  = m1.i_lo < m2.i_lo, l2 = m2.i_lo < m1.i_lo; // whose start lies left of the overlap
+      const bool   h1  = m1.i_hi > m2.i_hi, h2 = m2.i_hi > m1.i_hi; // whose end lies right of the overlap
+      const double qL  = static_cast<double>(l1 ? m2.i_lo - m1.i_lo : m1.i_lo - m2.i_lo) / (l1 ? rr1 : rr2);
+      const double qR  = static_cast<double>(h1 ? m1.i_hi - m2.i_hi : m2.i_hi - m1.i_hi) / (h1 ? rr1 : rr2);
+      double ncl1 = l1 ? qL : 0.0, ncr1 = h1 ? qR : 0.0, ncl2 = l2 ? qL : 0.0, ncr2 = h2 ? qR : 0.0;
       if (!d1) {
-        double tmp = ncl;
-        ncl        = ncr;
-        ncr        = tmp;
+        const double tmp = ncl1;
+        ncl1             = ncr1;
+        ncr1             = tmp;
+      }
+      if (!d2) {
+        const double tmp = ncl2;
+        ncl2             = ncr2;
+        ncr2             = tmp;
       }
       x.rlo1 = m1.n_lo;
       x.rhi1 = m1.n_hi;
-      x.clo1 = static_cast<double>(m1.n_lo) + ncl; // == overhangLeft
-      x.chi1 = static_cast<double>(m1.n_hi) - ncr;
-      ovr1   = static_cast<double>(len1 - m1.n_hi) + ncr;
-    }
-    {
-      const double rr  = static_cast<double>(m2.i_hi - m2.i_lo + 1) / static_cast<double>(m2.n_hi - m2.n_lo + 1);
-      double       ncl = static_cast<double>(ov_lo - m2.i_lo) / rr;
-      double       ncr = static_cast<double>(m2.i_hi - ov_hi) / rr;
-      if (!d2) {
-        double tmp = ncl;
-        ncl        = ncr;
-        ncr        = tmp;
-      }
+      x.clo1 = static_cast<double>(m1.n_lo) + ncl1; // == overhangLeft
+      x.chi1 = static_cast<double>(m1.n_hi) - ncr1;
+      ovr1   = static_cast<double>(len1 - m1.n_hi) + ncr1;
       x.rlo2 = m2.n_lo;
       x.rhi2 = m2.n_hi;
-      x.clo2 = static_cast<double>(m2.n_lo) + ncl;
-      x.chi2 = static_cast<double>(m2.n_hi) - ncr;
-      ovr2   = static_cast<double>(len2 - m2.n_hi) + ncr;
+      x.clo2 = static_cast<double>(m2.n_lo) + ncl2;
+      x.chi2 = static_cast<double>(m2.n_hi) - ncr2;
+      ovr2   = static_cast<double>(len2 - m2.n_hi) + ncr2;
     }
     clo1     = x.clo1;
     clo2     = x.clo2;
