@@ -877,35 +877,36 @@ struct __attribute__((aligned(16))) ChainElem {
 //   diff = (c1.second - c2.first) + 1   (o = +2)      (c2.first - c1.second) + 1 = -(c1.second - c2.first) + 1  (o = +1)
 //   diff = (c2.second - c1.first) + 1   (o = -2)      (c1.first - c2.second) + 1 = -(c2.second - c1.first) + 1  (o = -1)
 // (negation is exact in IEEE arithmetic, so the two subtractions below reproduce all four differences bit for bit).
-// nanoCheck of checkCompatibility (mpp.cpp:67-109) for one vertex.  The orientation stays a pair of predicates
-// (pos = +1 / +2, neg = -1 / -2; two = |orientation| == 2) -- lane masks in scalar registers -- instead of an integer
-// that later has to be compared again; returns the abort verdict of :93-109.
-struct NanoFlags {
-  bool pos, neg, two;
+// nanoCheck of checkCompatibility (mpp.cpp:67-109) for one vertex, for all pairs of a sweep step at once: every
+// predicate is a wavefront mask in scalar registers (a v_cmp writes it directly, the logic is s_and / s_or) and only the
+// selects of the difference use it as a lane condition again (inverse ballot = free).  pos = orientation +1 / +2,
+// neg = -1 / -2, ovl = |orientation| is 2 (or the ranges overlap without an order: pos = neg = 0).
+struct NanoMasks {
+  unsigned long long pos, neg, ovl, abort_;
 };
-__device__ __forceinline__ bool nano_check(double k_clo, double k_chi, double l_clo, double l_chi, int k_rlo, int k_rhi,
-                                           int l_rlo, int l_rhi, NanoFlags &f, double &d) {
-  const bool ovl   = (k_clo <= l_chi) & (l_clo <= k_chi);
-  const bool lt_lo = k_clo < l_clo;
-  const bool fwd2  = ovl & lt_lo & (k_chi < l_chi);
-  const bool bwd2  = ovl & (k_clo > l_clo) & (k_chi > l_chi);
-  const bool fwd1  = (!ovl) & lt_lo;
-  const bool bwd1  = (!ovl) & (!lt_lo);
-  f.pos            = fwd2 | fwd1;
-  f.neg            = bwd2 | bwd1;
-  f.two            = ovl;
+__device__ __forceinline__ NanoMasks nano_check(double k_clo, double k_chi, double l_clo, double l_chi, int k_rlo,
+                                                int k_rhi, int l_rlo, int l_rhi, double &d) {
+  typedef unsigned long long M;
+  const bool lt_lo_b = k_clo < l_clo;
+  const M    lt_lo = __ballot(lt_lo_b), lt_hi = __ballot(k_chi < l_chi);
+  const M    gt_lo = __ballot(k_clo > l_clo), gt_hi = __ballot(k_chi > l_chi);
+  NanoMasks  f;
+  f.ovl = __ballot(k_clo <= l_chi) & __ballot(l_clo <= k_chi);
+  f.pos = (f.ovl & lt_lo & lt_hi) | (~f.ovl & lt_lo);  // fwd2 | fwd1
+  f.neg = (f.ovl & gt_lo & gt_hi) | (~f.ovl & ~lt_lo); // bwd2 | bwd1
   // diff (:70-91): fwd -> k_chi - l_clo, bwd -> l_chi - k_clo, negated when the ranges do not overlap, + 1; 0 when
   // the ranges overlap without a strict order.  lt_lo selects the right difference in every case that has an order.
   const double x = k_chi - l_clo;
   const double y = l_chi - k_clo;
-  double       t = lt_lo ? x : y;
-  t              = ovl ? t : -t;
-  d              = (f.pos | f.neg) ? t + 1 : 0.0;
-  const bool rovl = (k_rlo <= l_rhi) & (l_rlo <= k_rhi);
-  const bool u2   = (k_rlo < l_rlo) & (k_rhi < l_rhi);
-  const bool um2  = (k_rlo > l_rlo) & (k_rhi > l_rhi);
+  double       t = lt_lo_b ? x : y;
+  t              = __builtin_amdgcn_inverse_ballot_w64(f.ovl) ? t : -t;
+  d              = __builtin_amdgcn_inverse_ballot_w64(f.pos | f.neg) ? t + 1 : 0.0;
+  const M rovl = __ballot(k_rlo <= l_rhi) & __ballot(l_rlo <= k_rhi);
+  const M u2   = __ballot(k_rlo < l_rlo) & __ballot(k_rhi < l_rhi);
+  const M um2  = __ballot(k_rlo > l_rlo) & __ballot(k_rhi > l_rhi);
   // abort when the raw ranges overlap and their order contradicts the corrected orientation (:93-109)
-  return rovl & ((f.neg & !um2) | (f.pos & !u2));
+  f.abort_ = rovl & ((f.neg & ~um2) | (f.pos & ~u2));
+  return f;
 }
 
 // Post-DP part of getMaxPairwisePaths (mpp.cpp:201-302) for the lanes `act` of one direction.
@@ -1144,32 +1145,42 @@ __global__ __launch_bounds__(256) void k_chain(ChainArgs a) {
   // pair p = l(l-1)/2 + k, row-major over l; a lane handles p = it*64 + lane
   const int P = clean ? 0 : static_cast<int>(n * (n - 1) / 2);
   for (int p0 = 0; p0 < P; p0 += 64) {
-    const int p  = p0 + lane;
-    bool      ok = false;
-    int       k = 0, l = 1;
+    const int          p = p0 + lane;
+    int                k = 0, l = 1;
+    unsigned long long bits = 0; // checkCompatibility(k, l) of the 64 pairs of this step
+    bool               kd = false, ld = true;
     if (p < P) {
       const uint32_t kl = a.pair_tab[p]; // (k, l) of pair p: precomputed, the same for every edge
       k                 = static_cast<int>(kl & 0xffu);
       l                 = static_cast<int>(kl >> 8);
-      const bool kd      = (m_plus >> k) & 1ull, ld = (m_plus >> l) & 1ull;
-      if (kd == ld) {
-        const ChainElem K = el[k], L = el[l];
-        NanoFlags       f1, f2;
-        double          d1, d2;
-        bool            abort_ = nano_check(K.clo1, K.chi1, L.clo1, L.chi1, K.rlo1, K.rhi1, L.rlo1, L.rhi1, f1, d1);
-        abort_ |= nano_check(K.clo2, K.chi2, L.clo2, L.chi2, K.rlo2, K.rhi2, L.rlo2, L.rhi2, f2, d2);
-        const bool   p2    = kd ? f2.pos : f2.neg, n2 = kd ? f2.neg : f2.pos; // :131 orientation2 *= EdgeMatch(k).direction
-        const bool   codir = (f1.pos & p2) | (f1.neg & n2);                  // :137 same sign
-        const bool   same  = codir & (f1.two == f2.two);                     // :133 equal and non-zero
-        const double mx    = fmax(d1, d2); // finite operands: the same values std::max / std::min return
-        const double df    = mx - fmin(d1, d2);
-        const bool   near_ = df <= a.wiggle;
-        ok                 = (!abort_) & (same ? near_ : (codir & (d1 + d2 <= a.wiggle)));
-        // the fp64 division of :136 only where the first test failed (rare for true overlaps)
-        if ((!abort_) & same & !near_) ok = (df * 100 / mx <= a.ratio_pct);
-      }
+      kd                = (m_plus >> k) & 1ull;
+      ld                = (m_plus >> l) & 1ull;
     }
-    const unsigned long long bits = __ballot(ok);
+    { // every lane evaluates a pair (lanes past P the dummy pair (0, 1)): no divergence, all masks are wave-uniform
+      typedef unsigned long long M;
+      const M         valid = __ballot(p < P && kd == ld); // pairs of one direction only
+      const ChainElem K = el[k], L = el[l];
+      double          d1, d2;
+      const NanoMasks f1 = nano_check(K.clo1, K.chi1, L.clo1, L.chi1, K.rlo1, K.rhi1, L.rlo1, L.rhi1, d1);
+      const NanoMasks f2 = nano_check(K.clo2, K.chi2, L.clo2, L.chi2, K.rlo2, K.rhi2, L.rlo2, L.rhi2, d2);
+      const M         KD = __ballot(kd);
+      const M p2 = (KD & f2.pos) | (~KD & f2.neg), n2 = (KD & f2.neg) | (~KD & f2.pos); // :131 flip by EdgeMatch(k).direction
+      const M codir   = (f1.pos & p2) | (f1.neg & n2); // :137 same sign
+      const M same    = codir & ~(f1.ovl ^ f2.ovl);    // :133 equal and non-zero
+      const M aborted = f1.abort_ | f2.abort_;
+      const double mx = fmax(d1, d2); // finite operands: the same values std::max / std::min return
+      const double df = mx - fmin(d1, d2);
+      const M near_ = __ballot(df <= a.wiggle), sum_ok = __ballot(d1 + d2 <= a.wiggle);
+      M       ok    = ~aborted & ((same & near_) | (~same & codir & sum_ok));
+      // the fp64 division of :136 only where the first test failed (rare for true overlaps)
+      const M need_div = ~aborted & same & ~near_ & valid;
+      if (need_div) {
+        bool pass = false;
+        if (__builtin_amdgcn_inverse_ballot_w64(need_div)) pass = df * 100 / mx <= a.ratio_pct;
+        ok |= __ballot(pass);
+      }
+      bits = ok & valid;
+    }
     // the pairs of row l are consecutive lanes; the first lane of each run stores the run's bits
     if (p < P && (k == 0 || lane == 0)) {
       const int          len = min(l - k, 64 - lane);
