@@ -74,7 +74,7 @@ struct msgpu_ctx {
 
   // results
   uint64_t n_edges = 0, n_ems = 0, n_orders = 0, n_ids = 0, n_visit = 0, total_bound = 0;
-  uint32_t n_list[3] = {0, 0, 0};
+  uint32_t n_list[4] = {0, 0, 0, 0};
 
   // arena
   DevBuf rows_in, cnt_read, first_key, read_off, cursor, bkt_key, bkt_idx, bkt_dead, by_read, read_cnt, alive_rank,
@@ -100,7 +100,7 @@ struct msgpu_ctx {
 namespace {
 
 // scalar slots in ctx->scalars (uint64 each)
-enum { SC_MAXIDS = 0 /*2 x u32*/, SC_ERR = 1, SC_TOTAL_A = 2, SC_TOTAL_B = 3, SC_TOTAL_C = 4, SC_NLISTS = 5 /*3 x u32, spans 5..6*/,
+enum { SC_MAXIDS = 0 /*2 x u32*/, SC_ERR = 1, SC_TOTAL_A = 2, SC_TOTAL_B = 3, SC_TOTAL_C = 4, SC_NLISTS = 5 /*4 x u32, spans 5..6*/,
        SC_NBIG = 7, SC_NALIVE = 8, SC_IXFLAGS = 9, SC_BIGSTATS = 10 /*2 x u64*/, SC_BIGCUR = 12 /*2 x u64*/,
        SC_COUNT = 16 };
 
@@ -388,14 +388,14 @@ int msgpu_calculate_edges(msgpu_ctx *c) {
 
   ENSURE(c, bound, (size_t(V) + 1) * 4);
   ENSURE(c, cand_off, (size_t(V) + 2) * 8);
-  ENSURE(c, lists, (size_t(V) + 1) * 4 * 3);
+  ENSURE(c, lists, (size_t(V) + 1) * 4 * 4);
   ENSURE(c, n_cand, (size_t(V) + 1) * 4);
   ENSURE(c, n_edge, (size_t(V) + 1) * 4);
   ENSURE(c, n_visit_arr, (size_t(V) + 1) * 4);
   ENSURE(c, em_base, (size_t(V) + 2) * 8);
   ENSURE(c, edge_base, (size_t(V) + 2) * 8);
   ENSURE(c, visit_base, (size_t(V) + 2) * 8);
-  uint32_t *l0 = c->lists.as<uint32_t>(), *l1 = l0 + V + 1, *l2 = l1 + V + 1;
+  uint32_t *l0 = c->lists.as<uint32_t>(), *l1 = l0 + V + 1, *l2 = l1 + V + 1, *l3 = l2 + V + 1;
 
   HIPCHK(c, hipMemsetAsync(scalar<uint32_t>(c, SC_NLISTS), 0, 16, st));
   HIPCHK(c, hipMemsetAsync(c->n_cand.p, 0, (size_t(V) + 1) * 4, st));
@@ -406,11 +406,11 @@ int msgpu_calculate_edges(msgpu_ctx *c) {
   exclusive_scan<uint64_t>(st, c->bound.as<uint32_t>(), V, c->cand_off.as<uint64_t>(), c->scan_tmp.as<uint64_t>(),
                            scalar<uint64_t>(c, SC_TOTAL_A));
   launch_classify_reads(st, c->read_cnt.as<uint32_t>(), c->bound.as<uint32_t>(), V, c->shard, c->nshards, l0, l1, l2,
-                        scalar<uint32_t>(c, SC_NLISTS));
+                        l3, scalar<uint32_t>(c, SC_NLISTS));
   HIPCHK(c, hipGetLastError());
   uint64_t total_bound = 0;
   HIPCHK(c, hipMemcpyAsync(&total_bound, scalar<uint64_t>(c, SC_TOTAL_A), 8, hipMemcpyDeviceToHost, st));
-  HIPCHK(c, hipMemcpyAsync(c->n_list, scalar<uint32_t>(c, SC_NLISTS), 12, hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipMemcpyAsync(c->n_list, scalar<uint32_t>(c, SC_NLISTS), 16, hipMemcpyDeviceToHost, st));
   HIPCHK(c, hipStreamSynchronize(st)); // sizes of the candidate scratch
   c->total_bound = total_bound;
 
@@ -439,12 +439,13 @@ int msgpu_calculate_edges(msgpu_ctx *c) {
   HIPCHK(c, hipMemsetAsync(a.big_stats, 0, 16, st));
   launch_candidates(st, a, 0, l0, c->n_list[0]);
   launch_candidates(st, a, 1, l1, c->n_list[1]);
-  if (c->n_list[2]) {
+  launch_candidates(st, a, 2, l2, c->n_list[2]);
+  if (c->n_list[3]) {
     ENSURE(c, big_key, tb * 8);
     ENSURE(c, big_t, tb * 4);
     ENSURE(c, big_r2s, tb * 4);
     ENSURE(c, big_pfx, (c->n_rows ? c->n_rows : 1) * 4);
-    launch_candidates_big(st, a, l2, c->n_list[2], c->big_key.as<uint64_t>(), c->big_t.as<uint32_t>(),
+    launch_candidates_big(st, a, l3, c->n_list[3], c->big_key.as<uint64_t>(), c->big_t.as<uint32_t>(),
                           c->big_r2s.as<uint32_t>(), c->big_pfx.as<uint32_t>());
   }
   exclusive_scan<uint64_t>(st, c->n_cand.as<uint32_t>(), V, c->em_base.as<uint64_t>(), c->scan_tmp.as<uint64_t>(),

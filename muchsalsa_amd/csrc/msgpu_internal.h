@@ -109,7 +109,7 @@ void launch_rank_anchor(hipStream_t st, const uint32_t *anchor_off, uint64_t n_r
 void launch_bound(hipStream_t st, const uint32_t *read_off, const uint32_t *read_cnt, const IRow *by_read,
                   const uint32_t *anchor_off, uint32_t V, uint32_t shard, uint32_t nshards, uint32_t *bound);
 void launch_classify_reads(hipStream_t st, const uint32_t *read_cnt, const uint32_t *bound, uint32_t V, uint32_t shard,
-                           uint32_t nshards, uint32_t *l0, uint32_t *l1, uint32_t *l2, uint32_t *n_lists);
+                           uint32_t nshards, uint32_t *l0, uint32_t *l1, uint32_t *l2, uint32_t *l3, uint32_t *n_lists);
 void launch_candidates(hipStream_t st, const CandArgs &a, int cls, const uint32_t *list, uint32_t n_list);
 void launch_candidates_big(hipStream_t st, const CandArgs &a, const uint32_t *list, uint32_t n_list, uint64_t *big_key,
                            uint32_t *big_t, uint32_t *big_r2s, uint32_t *big_pfx);

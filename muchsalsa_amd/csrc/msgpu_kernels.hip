@@ -464,8 +464,8 @@ __global__ __launch_bounds__(256) void k_bound(const uint32_t *read_off, const u
 template <int R1MAX, int CMAX>
 __global__ __launch_bounds__(256) void k_candidates(CandArgs a, const uint32_t *read_list, uint32_t n_list) {
   constexpr int      HSZ   = CMAX; // hash slots >= candidates: insertion always terminates
-  constexpr int      HBITS = CMAX == 1024 ? 10 : CMAX == 2048 ? 11 : CMAX == 4096 ? 12 : 13;
-  static_assert((1 << HBITS) == HSZ, "CMAX must be 1024, 2048, 4096 or 8192");
+  constexpr int      HBITS = CMAX == 512 ? 9 : CMAX == 1024 ? 10 : CMAX == 2048 ? 11 : CMAX == 4096 ? 12 : 13;
+  static_assert((1 << HBITS) == HSZ, "CMAX must be 512, 1024, 2048, 4096 or 8192");
   constexpr uint32_t EMPTY = 0xffffffffu;
   __shared__ int      s_ilo[R1MAX], s_ihi[R1MAX];
   __shared__ uint32_t s_aoff[R1MAX], s_pfx[R1MAX + 1];
@@ -676,24 +676,29 @@ __global__ __launch_bounds__(256) void k_candidates(CandArgs a, const uint32_t *
   }
 }
 
+template __global__ void k_candidates<256, 512>(CandArgs, const uint32_t *, uint32_t);
 template __global__ void k_candidates<256, 1024>(CandArgs, const uint32_t *, uint32_t);
 template __global__ void k_candidates<1024, 4096>(CandArgs, const uint32_t *, uint32_t);
 
 // classify reads of this shard by the LDS footprint their candidate scan needs
+// classes by LDS footprint: 0 = <256 rows, 512 candidates> (half the LDS of class 1, so twice as many reads per CU),
+// 1 = <256, 1024>, 2 = <1024, 4096>, 3 = global-scratch kernel
 __global__ __launch_bounds__(256) void k_classify_reads(const uint32_t *read_cnt, const uint32_t *bound, uint32_t V,
                                                         uint32_t shard, uint32_t nshards, uint32_t *list0,
-                                                        uint32_t *list1, uint32_t *list2, uint32_t *n_lists /*[3]*/) {
+                                                        uint32_t *list1, uint32_t *list2, uint32_t *list3,
+                                                        uint32_t *n_lists /*[4]*/) {
   uint32_t r   = blockIdx.x * 256 + threadIdx.x;
   int      cls = -1;
   if (r < V && r % nshards == shard) {
     uint32_t n1 = read_cnt[r], bd = bound[r];
-    if (n1 != 0 && bd != 0) cls = (n1 <= 256 && bd <= 1024) ? 0 : (n1 <= 1024 && bd <= 4096) ? 1 : 2;
+    if (n1 != 0 && bd != 0)
+      cls = (n1 <= 256 && bd <= 512) ? 0 : (n1 <= 256 && bd <= 1024) ? 1 : (n1 <= 1024 && bd <= 4096) ? 2 : 3;
   }
   // one atomic per wave and class
   const int lane = threadIdx.x & 63;
-  uint32_t *lists[3] = {list0, list1, list2};
+  uint32_t *lists[4] = {list0, list1, list2, list3};
 #pragma unroll
-  for (int k = 0; k < 3; ++k) {
+  for (int k = 0; k < 4; ++k) {
     unsigned long long m = __ballot(cls == k);
     if (!m) continue;
     uint32_t base = 0;
@@ -1882,14 +1887,16 @@ void launch_bound(hipStream_t st, const uint32_t *read_off, const uint32_t *read
                        nshards, bound);
 }
 void launch_classify_reads(hipStream_t st, const uint32_t *read_cnt, const uint32_t *bound, uint32_t V, uint32_t shard,
-                           uint32_t nshards, uint32_t *l0, uint32_t *l1, uint32_t *l2, uint32_t *n_lists) {
+                           uint32_t nshards, uint32_t *l0, uint32_t *l1, uint32_t *l2, uint32_t *l3, uint32_t *n_lists) {
   if (V)
     hipLaunchKernelGGL(k_classify_reads, grid1(V, 256), dim3(256), 0, st, read_cnt, bound, V, shard, nshards, l0, l1, l2,
-                       n_lists);
+                       l3, n_lists);
 }
 void launch_candidates(hipStream_t st, const CandArgs &a, int cls, const uint32_t *list, uint32_t n_list) {
   if (!n_list) return;
   if (cls == 0)
+    hipLaunchKernelGGL((k_candidates<256, 512>), dim3(n_list), dim3(256), 0, st, a, list, n_list);
+  else if (cls == 1)
     hipLaunchKernelGGL((k_candidates<256, 1024>), dim3(n_list), dim3(256), 0, st, a, list, n_list);
   else
     hipLaunchKernelGGL((k_candidates<1024, 4096>), dim3(n_list), dim3(256), 0, st, a, list, n_list);
