@@ -1,8 +1,8 @@
 /*
- * msgpu.h -- C-ABI of the MI355X-native overlap core for MuCHSALSA (libmsgpu.so).
+ * msgpu.h -- C-ABI of the MI355X-native overlap-and-consensus core for MuCHSALSA (libmsgpu.so).
  *
- * Drop-in boundary for the reference's overlap path.  Plain C, opaque context, caller-owned input buffers,
- * int status codes (0 = ok) + msgpu_last_error(); no exception crosses it.  Each entry point names the
+ * Drop-in boundary for the reference's hot path.  Plain C, opaque contexts, caller-owned input buffers,
+ * int status codes (0 = ok) + msgpu_*_last_error(); no exception crosses it.  Each entry point names the
  * reference interface it replaces (paths relative to the reference tree).
  *
  *   reference call site (src/main.cpp)                   replaced by
@@ -10,7 +10,12 @@
  *   ThreadPool(threadCount)                      :143    msgpu_create          (HIP stream dispatcher)
  *   BlastFileAccessor + BlastFileReader::read()  :153-156 msgpu_parse_paf + msgpu_load_rows
  *   MatchMap::calculateEdges()                   :157    msgpu_calculate_edges
+ *   SequenceAccessor + buildIndex()              :161-163 msgpu_seq_parse + msgpu_seq_upload (+ msgpu_seq_pack)
  *   for edge: Job(chainingAndOverlaps)           :170-178 msgpu_chaining_and_overlaps
+ *   for edge: Job(findContractionEdges)          :183-190 msgpu_find_contraction_edges
+ *   contraction ... decycle                      :194-288 msgpu_graph_create + msgpu_graph_clean_up
+ *   getConnectedComponents + assemblePaths       :300-310, 620-661  msgpu_graph_linearize + msgpu_graph_path_input
+ *   assemblePath per path + OutputWriter         :663-677 msgpu_assembly_add_paths + msgpu_assembly_finish / _text
  *   graph.getEdges()/Edge::getEdgeOrders()/...           msgpu_get_counts + msgpu_copy_tables
  *
  * Semantics are the single-thread reference's, bit for bit: int32 coordinates, IEEE fp64 scores/offsets
