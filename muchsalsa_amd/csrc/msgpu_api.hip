@@ -202,8 +202,8 @@ int build_index_once(msgpu_ctx *c, bool force_generic, uint32_t *ix_flags_out) {
                       c->bkt_idx.as<uint32_t>());
   launch_sort_read(st, c->read_off.as<uint32_t>(), c->cnt_read.as<uint32_t>(), V, c->bkt_key.as<IRow>(),
                    c->bkt_idx.as<uint32_t>(), c->by_read.as<IRow>(), c->read_cnt.as<uint32_t>(),
-                   c->alive_rank.as<uint32_t>(), c->anchor_cnt.as<uint32_t>(), c->bkt_dead.as<uint8_t>(), d_flags);
-  launch_fill_by_anchor(st, c->d_rows, n, c->alive_rank.as<uint32_t>(), c->by_anchor.as<IRow>(), d_flags);
+                   c->alive_rank.as<uint32_t>(), c->anchor_cnt.as<uint32_t>(), c->bkt_dead.as<uint8_t>(), d_flags,
+                   c->by_anchor.as<IRow>()); // fast mode: the sort writes the scaffold rows too
   // generic by_anchor path (no-ops in fast mode)
   exclusive_scan<uint32_t>(st, c->anchor_cnt.as<uint32_t>(), A, c->anchor_off_gen.as<uint32_t>(),
                            c->scan_tmp.as<uint32_t>(), scalar<uint32_t>(c, SC_NALIVE));

@@ -95,9 +95,7 @@ void launch_scatter_read(hipStream_t st, const msgpu_row *rows, uint64_t n, cons
                          IRow *bkt_row, uint32_t *bkt_idx);
 void launch_sort_read(hipStream_t st, const uint32_t *read_off, const uint32_t *cnt_read, uint32_t V, const IRow *bkt_row,
                       const uint32_t *bkt_idx, IRow *by_read, uint32_t *read_cnt, uint32_t *alive_rank,
-                      uint32_t *anchor_cnt, uint8_t *bkt_dead, uint32_t *flags);
-void launch_fill_by_anchor(hipStream_t st, const msgpu_row *rows, uint64_t n, const uint32_t *alive_rank, IRow *by_anchor,
-                           const uint32_t *flags);
+                      uint32_t *anchor_cnt, uint8_t *bkt_dead, uint32_t *flags, IRow *by_anchor);
 void launch_select_anchor_off(hipStream_t st, const uint32_t *flags, const uint32_t *fast_off, const uint32_t *gen_off,
                               uint32_t A, uint32_t *anchor_off, uint32_t *d_n_alive, uint32_t n_rows);
 void launch_scatter_anchor(hipStream_t st, const msgpu_row *rows, uint64_t n, const uint32_t *alive_rank,

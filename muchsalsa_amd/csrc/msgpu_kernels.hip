@@ -291,7 +291,7 @@ __device__ __forceinline__ bool key_less(int alo, int ahi, uint32_t aan, int blo
 __global__ __launch_bounds__(256) void k_sort_read(const uint32_t *read_off, const uint32_t *cnt_read, uint32_t V,
                                                    const IRow *bkt_row, const uint32_t *bkt_idx, IRow *by_read,
                                                    uint32_t *read_cnt, uint32_t *alive_rank, uint32_t *anchor_cnt,
-                                                   uint8_t *bkt_dead, uint32_t *flags) {
+                                                   uint8_t *bkt_dead, uint32_t *flags, IRow *by_anchor) {
   const int      lane = threadIdx.x & 63;
   const uint32_t r    = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
   if (r >= V) return;
@@ -334,8 +334,17 @@ __global__ __launch_bounds__(256) void k_sort_read(const uint32_t *read_off, con
     if (alive) {
       row.pf = (row.pf & ~PF_POS_MASK) | less;
       store_irow(&by_read[b + less], row);
-      alive_rank[idx] = less;
-      if (!fast) atomicAdd(&anchor_cnt[row.other], 1u);
+      if (fast) {
+        // input already grouped by anchor with ascending lines: the scaffold table is the input order, so this row's
+        // by_anchor entry (same 32 bytes, `other` = the read, rank in the read attached) goes straight to slot idx.
+        // A duplicate (read, anchor) pair found anywhere voids the fast table: the host rebuilds generically.
+        IRow w  = row;
+        w.other = r;
+        store_irow(&by_anchor[idx], w);
+      } else {
+        alive_rank[idx] = less;
+        atomicAdd(&anchor_cnt[row.other], 1u);
+      }
     } else if (have) {
       alive_rank[idx] = 0xffffffffu;
     }
@@ -373,24 +382,20 @@ __global__ __launch_bounds__(256) void k_sort_read(const uint32_t *read_off, con
       }
       k.pf = (k.pf & ~PF_POS_MASK) | less;
       store_irow(&by_read[b + less], k);
-      alive_rank[bkt_idx[b + e]] = less;
-      if (!fast) atomicAdd(&anchor_cnt[k.other], 1u);
+      if (fast) {
+        IRow w  = k;
+        w.other = r;
+        store_irow(&by_anchor[bkt_idx[b + e]], w);
+      } else {
+        alive_rank[bkt_idx[b + e]] = less;
+        atomicAdd(&anchor_cnt[k.other], 1u);
+      }
     }
     n_alive += static_cast<uint32_t>(__popcll(__ballot(alive)));
   }
   if (lane == 0) read_cnt[r] = n_alive;
 }
 
-// fast mode: the input order is the scaffold order, so by_anchor is a streaming rewrite of the rows
-// (other = read id, pf = flags | rank of the row inside its read)
-__global__ __launch_bounds__(256) void k_fill_by_anchor(const msgpu_row *rows, uint64_t n, const uint32_t *alive_rank,
-                                                        IRow *by_anchor, const uint32_t *flags) {
-  if ((*flags & ~IXF_DUPS) != 0) return; // generic mode: k_scatter_anchor + k_rank_anchor build it
-  uint64_t i = static_cast<uint64_t>(blockIdx.x) * 256 + threadIdx.x;
-  if (i >= n) return;
-  const msgpu_row row = rows[i];
-  store_irow(&by_anchor[i], make_irow(row, row.read_id, alive_rank[i]));
-}
 
 // scaffold offsets: the speculative ones of pass 1 (fast) or the scan of the alive counts (generic)
 __global__ __launch_bounds__(256) void k_select_anchor_off(const uint32_t *flags, const uint32_t *fast_off,
@@ -1852,14 +1857,10 @@ void launch_scatter_read(hipStream_t st, const msgpu_row *rows, uint64_t n, cons
 }
 void launch_sort_read(hipStream_t st, const uint32_t *read_off, const uint32_t *cnt_read, uint32_t V, const IRow *bkt_row,
                       const uint32_t *bkt_idx, IRow *by_read, uint32_t *read_cnt, uint32_t *alive_rank,
-                      uint32_t *anchor_cnt, uint8_t *bkt_dead, uint32_t *flags) {
+                      uint32_t *anchor_cnt, uint8_t *bkt_dead, uint32_t *flags, IRow *by_anchor) {
   if (V)
     hipLaunchKernelGGL(k_sort_read, grid1(V, 4), dim3(256), 0, st, read_off, cnt_read, V, bkt_row, bkt_idx, by_read,
-                       read_cnt, alive_rank, anchor_cnt, bkt_dead, flags);
-}
-void launch_fill_by_anchor(hipStream_t st, const msgpu_row *rows, uint64_t n, const uint32_t *alive_rank, IRow *by_anchor,
-                           const uint32_t *flags) {
-  if (n) hipLaunchKernelGGL(k_fill_by_anchor, grid1(n, 256), dim3(256), 0, st, rows, n, alive_rank, by_anchor, flags);
+                       read_cnt, alive_rank, anchor_cnt, bkt_dead, flags, by_anchor);
 }
 void launch_select_anchor_off(hipStream_t st, const uint32_t *flags, const uint32_t *fast_off, const uint32_t *gen_off,
                               uint32_t A, uint32_t *anchor_off, uint32_t *d_n_alive, uint32_t n_rows) {
