@@ -1767,22 +1767,48 @@ __global__ __launch_bounds__(256) void k_compact(CompactArgs a) {
     a.edges[e].order_off = oo;
     a.edges[e].order_cnt = static_cast<uint16_t>(no);
   }
-  for (unsigned long long rem = __ballot(no != 0); rem; rem &= rem - 1) {
-    const int      t    = __builtin_ctzll(rem);
-    const uint32_t t_no = rl_u32(no, t);
-    const uint64_t t_oo = rl_u64(oo, t), t_em = rl_u64(em_off, t);
-    uint64_t       t_io = rl_u64(io, t);
-    for (uint32_t i = 0; i < t_no; ++i) {
-      const uint32_t *src = reinterpret_cast<const uint32_t *>(&a.order_scr[t_em + i]);
-      uint32_t       *dst = reinterpret_cast<uint32_t *>(&a.orders[t_oo + i]);
+  // Four edges per step, a quarter wavefront (16 lanes) each: the copy of an order is 16 dwords anyway, and the chain
+  // "order record -> id count -> ids" of four edges is in flight at once instead of one after the other.
+  const int          grp = lane >> 4, sub = lane & 15;
+  unsigned long long rem = __ballot(no != 0);
+  while (rem) {
+    int t = 64; // the grp-th edge of this step (64 = none)
+    {
+      unsigned long long r2 = rem;
+      for (int g = 0; g < 4 && r2; ++g) {
+        const int tg = __builtin_ctzll(r2);
+        r2 &= r2 - 1;
+        if (g == grp) t = tg;
+      }
+      rem = r2;
+    }
+    // every lane takes part in every shuffle (a lane that sits out cannot be read from): select afterwards
+    const int      src_lane = t < 64 ? t : 0;
+    const uint32_t s_no     = static_cast<uint32_t>(__shfl(static_cast<int>(no), src_lane));
+    const uint32_t t_no     = t < 64 ? s_no : 0u;
+    const uint64_t t_oo = (static_cast<uint64_t>(static_cast<uint32_t>(__shfl(static_cast<int>(oo >> 32), src_lane))) << 32) |
+                          static_cast<uint32_t>(__shfl(static_cast<int>(oo), src_lane));
+    const uint64_t t_em = (static_cast<uint64_t>(static_cast<uint32_t>(__shfl(static_cast<int>(em_off >> 32), src_lane))) << 32) |
+                          static_cast<uint32_t>(__shfl(static_cast<int>(em_off), src_lane));
+    uint64_t       t_io = (static_cast<uint64_t>(static_cast<uint32_t>(__shfl(static_cast<int>(io >> 32), src_lane))) << 32) |
+                    static_cast<uint32_t>(__shfl(static_cast<int>(io), src_lane));
+    uint32_t max_no = t_no;
+    for (int d = 32; d >= 16; d >>= 1) max_no = max(max_no, static_cast<uint32_t>(__shfl_xor(static_cast<int>(max_no), d)));
+    for (uint32_t i = 0; i < max_no; ++i) { // every lane runs the same number of rounds (shuffles inside)
+      const bool      on  = i < t_no;
+      const uint32_t *src = reinterpret_cast<const uint32_t *>(&a.order_scr[t_em + (on ? i : 0)]);
+      uint32_t       *dst = reinterpret_cast<uint32_t *>(&a.orders[t_oo + (on ? i : 0)]);
       // msgpu_order as 16 dwords: [8,9] = ids_off (edge-relative in the scratch), [10] = ids_cnt
-      uint32_t w = lane < 16 ? src[lane] : 0;
-      const uint32_t rel = rl_u32(w, 8), cnt = rl_u32(w, 10);
-      if (lane == 8) w = static_cast<uint32_t>(t_io);
-      if (lane == 9) w = static_cast<uint32_t>(t_io >> 32);
-      if (lane < 16) dst[lane] = w;
-      for (uint32_t q = lane; q < cnt; q += 64) a.ids[t_io + q] = a.ids_scr[t_em + rel + q];
-      t_io += cnt;
+      uint32_t w = on ? src[sub] : 0;
+      const uint32_t rel = static_cast<uint32_t>(__shfl(static_cast<int>(w), (grp << 4) + 8));
+      const uint32_t cnt = static_cast<uint32_t>(__shfl(static_cast<int>(w), (grp << 4) + 10));
+      if (sub == 8) w = static_cast<uint32_t>(t_io);
+      if (sub == 9) w = static_cast<uint32_t>(t_io >> 32);
+      if (on) {
+        dst[sub] = w;
+        for (uint32_t q = sub; q < cnt; q += 16) a.ids[t_io + q] = a.ids_scr[t_em + rel + q];
+        t_io += cnt;
+      }
     }
   }
 }
