@@ -1154,13 +1154,15 @@ __global__ __launch_bounds__(256) void k_chain(ChainArgs a) {
   // ---- checkCompatibility (mpp.cpp:38-142) for every pair k < l of one direction, all 64 lanes busy ---------------
   // pair p = l(l-1)/2 + k, row-major over l; a lane handles p = it*64 + lane
   const int P = clean ? 0 : static_cast<int>(n * (n - 1) / 2);
+  uint32_t kl_next = lane < P ? a.pair_tab[lane] : 0u; // (k, l) of pair p: precomputed, the same for every edge
   for (int p0 = 0; p0 < P; p0 += 64) {
     const int          p = p0 + lane;
     int                k = 0, l = 1;
     unsigned long long bits = 0; // checkCompatibility(k, l) of the 64 pairs of this step
     bool               kd = false, ld = true;
+    const uint32_t     kl = kl_next;
+    if (p + 64 < P) kl_next = a.pair_tab[p + 64]; // the next step's pairs are on their way while this step computes
     if (p < P) {
-      const uint32_t kl = a.pair_tab[p]; // (k, l) of pair p: precomputed, the same for every edge
       k                 = static_cast<int>(kl & 0xffu);
       l                 = static_cast<int>(kl >> 8);
       kd                = (m_plus >> k) & 1ull;
