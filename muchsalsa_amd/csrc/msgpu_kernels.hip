@@ -1015,9 +1015,12 @@ __device__ __forceinline__ int paths_of_direction(unsigned long long act, bool d
 }
 
 __global__ __launch_bounds__(256) void k_chain(ChainArgs a) {
-  __shared__ ChainElem s_el[4][64];
-  __shared__ uint64_t  s_cm[4][64];
-  __shared__ PathRec   s_paths[4][2][64];
+  // per wave: the 64 ChainElem of the sweep, later (the elements are dead once the compatibility masks exist) the
+  // path lists of both directions in the same bytes -- 14 KB per workgroup instead of 26 KB, so LDS no longer caps
+  // the occupancy
+  static_assert(sizeof(ChainElem) * 64 == sizeof(PathRec) * 2 * 64, "the path lists overlay the element table");
+  __shared__ __attribute__((aligned(16))) unsigned char s_wavebuf[4][sizeof(ChainElem) * 64];
+  __shared__ uint64_t                                  s_cm[4][64];
   const int      wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const uint64_t e = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(blockIdx.x * 4 + wave));
   if (e >= a.n_edges) return;
@@ -1029,7 +1032,7 @@ __global__ __launch_bounds__(256) void k_chain(ChainArgs a) {
   const uint32_t v1 = ed.v1, v2 = ed.v2;
   const uint32_t n1 = a.read_cnt[v1], n2 = a.read_cnt[v2];
   const int      len1 = a.read_len[v1], len2 = a.read_len[v2];
-  ChainElem     *el = s_el[wave];
+  ChainElem     *el = reinterpret_cast<ChainElem *>(s_wavebuf[wave]);
   uint64_t      *cm = s_cm[wave];
 
   // ---- per-lane element: VertexMatch on v1 (row j of v1), VertexMatch on v2 (scaffold row t), EdgeMatch ----------
@@ -1244,7 +1247,7 @@ __global__ __launch_bounds__(256) void k_chain(ChainArgs a) {
   }
 
   // src/main.cpp:341-353: split by EdgeMatch direction, minus then plus
-  PathRec  *pmn = s_paths[wave][0], *ppl = s_paths[wave][1];
+  PathRec  *pmn = reinterpret_cast<PathRec *>(s_wavebuf[wave]), *ppl = pmn + 64; // el[] is dead from here on
   const int n_m = paths_of_direction(m_minus, false, lane, pop, pm, em_prim, j1, q2, n1, n2, a.alt_frac, pmn);
   const int n_p = paths_of_direction(m_plus, true, lane, pop, pm, em_prim, j1, q2, n1, n2, a.alt_frac, ppl);
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
