@@ -472,13 +472,26 @@ __global__ __launch_bounds__(256) void k_candidates(CandArgs a, const uint32_t *
   constexpr int      HBITS = CMAX == 512 ? 9 : CMAX == 1024 ? 10 : CMAX == 2048 ? 11 : CMAX == 4096 ? 12 : 13;
   static_assert((1 << HBITS) == HSZ, "CMAX must be 512, 1024, 2048, 4096 or 8192");
   constexpr uint32_t EMPTY = 0xffffffffu;
-  __shared__ int      s_ilo[R1MAX], s_ihi[R1MAX];
-  __shared__ uint32_t s_aoff[R1MAX], s_pfx[R1MAX + 1];
-  __shared__ uint32_t s_v2[CMAX];               // v2 of candidate c
+  // LDS, with the tables of the later phases laid over those of the earlier ones (lifetimes separated by the
+  // __syncthreads between the phases): fewer bytes per workgroup = more reads in flight per CU (the kernel waits on
+  // memory for most of its cycles).
+  //   region A: s_ilo, s_ihi, s_aoff, s_pfx (phases a-b)      later g_list, g_rank   (phase c2 on)
+  //   region B: s_v2 (phases b-c1)                            later g_slot, g_off    (phase c2 on)
+  static_assert(4 * R1MAX * 4 + 16 >= 2 * CMAX + 2 * HSZ, "region A must hold g_list + g_rank");
+  __shared__ __attribute__((aligned(16))) unsigned char s_regA[4 * R1MAX * 4 + 16];
+  __shared__ __attribute__((aligned(16))) unsigned char s_regB[4 * CMAX + 16];
+  int *const      s_ilo  = reinterpret_cast<int *>(s_regA);
+  int *const      s_ihi  = s_ilo + R1MAX;
+  uint32_t *const s_aoff = reinterpret_cast<uint32_t *>(s_ihi + R1MAX);
+  uint32_t *const s_pfx  = s_aoff + R1MAX; // R1MAX + 1 entries
+  uint16_t *const g_list = reinterpret_cast<uint16_t *>(s_regA);
+  uint16_t *const g_rank = g_list + CMAX; // HSZ entries
+  uint32_t *const s_v2   = reinterpret_cast<uint32_t *>(s_regB); // v2 of candidate c
+  uint16_t *const g_slot = reinterpret_cast<uint16_t *>(s_regB);
+  uint16_t *const g_off  = g_slot + CMAX; // CMAX + 1 entries
   __shared__ uint32_t s_t[CMAX];                // by_anchor row of candidate c, later of staging position pos
   __shared__ uint16_t s_j[CMAX], s_g[CMAX];     // j of candidate c / of staging position pos; group of pos
   __shared__ uint32_t h_key[HSZ], h_cnt[HSZ];   // open-addressing table v2 -> group; members per group
-  __shared__ uint16_t g_list[CMAX], g_rank[HSZ], g_slot[CMAX], g_off[CMAX + 1];
   __shared__ uint32_t s_wave[4], s_nc;
 
   if (blockIdx.x >= n_list) return;
