@@ -932,7 +932,11 @@ namespace msgpu {
 constexpr int      ED_DPL   = 4;                 // diagonals per lane
 constexpr int      ED_NDIAG = 64 * ED_DPL;       // 256 diagonals: k in [-128, 127]
 constexpr uint32_t ED_MAXW  = 127;
-constexpr uint32_t ED_LDS   = 24 * 1024;         // bytes of LDS per sequence; longer sequences stay in global memory
+#ifndef MSGPU_ED_LDS
+#define MSGPU_ED_LDS (12 * 1024)
+#endif
+constexpr uint32_t ED_LDS   = MSGPU_ED_LDS; // bytes of LDS per sequence (12 KiB: 3 workgroups per CU; 24 KiB left one and
+                                            // ran 2.5x slower on 7 kb queries); longer sequences stay in global memory
 constexpr uint32_t ED_INF   = 0x3fffffffu;
 
 template <bool IN_LDS>
