@@ -283,8 +283,67 @@ __device__ __forceinline__ bool key_less(int alo, int ahi, uint32_t aan, int blo
   return alo < blo || (alo == blo && (ahi < bhi || (ahi == bhi && aan < ban)));
 }
 
+// Reads with 65..64*K rows: every lane keeps K rows in registers and every row is broadcast once (readlane), so a row
+// costs 3 scalar reads + K compares per lane instead of a pass over the bucket in global memory.  Returns false (and
+// writes nothing) when a (read, anchor) pair occurs twice: the caller then takes the generic path.
+template <int K>
+__device__ __forceinline__ bool sort_read_in_registers(uint32_t r, uint32_t b, uint32_t n, int lane, bool fast,
+                                                       const IRow *bkt_row, const uint32_t *bkt_idx, IRow *by_read,
+                                                       uint32_t *read_cnt, uint32_t *alive_rank, uint32_t *anchor_cnt,
+                                                       IRow *by_anchor) {
+  IRow     row[K];
+  uint32_t idx[K], man[K], less[K];
+  int      mlo[K], mhi[K];
+  bool     dup = false;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const uint32_t e = static_cast<uint32_t>(k) * 64 + lane;
+    row[k]           = IRow{};
+    idx[k]           = 0xffffffffu;
+    if (e < n) {
+      row[k] = load_irow(&bkt_row[b + e]);
+      idx[k] = bkt_idx[b + e];
+    }
+    mlo[k]  = e < n ? row[k].n_lo : 0x7fffffff;
+    mhi[k]  = e < n ? row[k].n_hi : 0x7fffffff;
+    man[k]  = e < n ? row[k].other : 0xffffffffu;
+    less[k] = 0;
+  }
+#pragma unroll
+  for (int s = 0; s < K; ++s) {
+    const int cnt = min(64, static_cast<int>(n) - 64 * s); // wave-uniform
+    for (int t = 0; t < cnt; ++t) {
+      const int      olo = rl_i32(mlo[s], t), ohi = rl_i32(mhi[s], t);
+      const uint32_t oan = rl_u32(man[s], t);
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        less[k] += key_less(olo, ohi, oan, mlo[k], mhi[k], man[k]) ? 1u : 0u;
+        dup |= ((s != k) | (t != lane)) & (oan == man[k]);
+      }
+    }
+  }
+  if (__ballot(dup)) return false; // sentinel rows (anchor 0xffffffff) are never broadcast, so they cannot match
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    if (static_cast<uint32_t>(k) * 64 + lane < n) {
+      row[k].pf = (row[k].pf & ~PF_POS_MASK) | less[k];
+      store_irow(&by_read[b + less[k]], row[k]);
+      if (fast) {
+        IRow w  = row[k];
+        w.other = r;
+        store_irow(&by_anchor[idx[k]], w);
+      } else {
+        alive_rank[idx[k]] = less[k];
+        atomicAdd(&anchor_cnt[row[k].other], 1u);
+      }
+    }
+  }
+  if (lane == 0) read_cnt[r] = n;
+  return true;
+}
+
 // One wavefront per read: MatchMap::addVertexMatch's lowest-line rule (MatchMap.cpp:64-80) + the rank of every alive
-// row by (nanoporeRange, anchor id) = the order of mpp.cpp:164-172 / :259-267.  Reads with <= 64 rows sort in
+// row by (nanoporeRange, anchor id) = the order of mpp.cpp:164-172 / :259-267.  Reads with <= 256 rows sort in
 // registers (readlane broadcast); longer ones loop over the bucket in global memory.
 // Output: by_read rows (rank order), read_cnt, alive_rank[source row] (rank, or 0xffffffff for a dead row) and, in
 // generic mode, the per-anchor alive counts.
@@ -352,7 +411,16 @@ __global__ __launch_bounds__(256) void k_sort_read(const uint32_t *read_off, con
     if (lane == 0) read_cnt[r] = static_cast<uint32_t>(__popcll(alive_mask));
     return;
   }
-  // long read: bucket stays in global memory
+  if (n <= 128) {
+    if (sort_read_in_registers<2>(r, b, n, lane, fast, bkt_row, bkt_idx, by_read, read_cnt, alive_rank, anchor_cnt,
+                                  by_anchor))
+      return;
+  } else if (n <= 256) {
+    if (sort_read_in_registers<4>(r, b, n, lane, fast, bkt_row, bkt_idx, by_read, read_cnt, alive_rank, anchor_cnt,
+                                  by_anchor))
+      return;
+  }
+  // very long read, or one with a duplicated (read, anchor) pair: the bucket stays in global memory
   uint32_t n_alive = 0;
   for (uint32_t e0 = 0; e0 < n; e0 += 64) {
     const uint32_t e = e0 + lane;

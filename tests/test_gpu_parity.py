@@ -34,6 +34,26 @@ def test_dense_inputs_take_the_big_paths(oracle, shape, coverage, what):
     assert_tables_equal(got, want, what)
 
 
+@pytest.mark.parametrize("n_anchors,lo,hi", [(1200, 65, 128), (2400, 129, 256), (4800, 257, 2000)])
+def test_every_sort_path_of_the_index(oracle, n_anchors, lo, hi):
+    """k_sort_read ranks a read's rows in registers up to 256 rows (1, 2 or 4 rows per lane) and in global memory
+    beyond; a duplicated (read, anchor) pair sends a register-sized read down the global path too.  Each size class,
+    as grouped input (scaffold table = input order) and shuffled with duplicates (generic index build)."""
+    from muchsalsa_amd import synth
+    rows, _, _ = synth.accepted_rows(synth.paf_table(120, 20000, n_anchors, 5, coverage=10))
+    per_read = np.bincount(rows["read_id"])
+    assert ((per_read >= lo) & (per_read <= hi)).sum() > 20, per_read
+    want = oracle.overlap(rows)
+    assert_tables_equal(_gpu_tables(rows), want, "grouped input")
+    rng = np.random.default_rng(n_anchors)
+    dup = rows[rng.choice(len(rows), 60, replace=False)].copy()
+    dup["line"] = rows["line"].max() + 1 + np.arange(len(dup))
+    dup["n_hi"] += 3
+    allrows = np.concatenate([rows, dup])
+    rng.shuffle(allrows)
+    assert_tables_equal(_gpu_tables(allrows), want, "shuffled with duplicates")
+
+
 def test_shortcut_and_full_sweep_agree(oracle, monkeypatch):
     """k_chain's all-pairs-compatible shortcut must change nothing: same tables with it disabled, and equal to the
     oracle's; and it must actually be taken on clean synthetic overlaps."""
