@@ -295,6 +295,7 @@ def main():
     ctx.set_stream(work.cuda_stream)
     if world > 1:
         ctx.set_shard(rank, world)
+    ctx.set_id_space(len(read_names), len(anchor_names))  # Registry sizes, known to whoever parsed the PAF
     merged_keep = {}
 
     def step():

@@ -162,6 +162,12 @@ int msgpu_set_stream(msgpu_ctx *ctx, void *hip_stream);
  * 1-GPU result.  Must be called before msgpu_calculate_edges. */
 int msgpu_set_shard(msgpu_ctx *ctx, uint32_t shard, uint32_t n_shards);
 
+/* Optional: declare the id spaces of the rows that will be loaded (n_reads = highest read id + 1, n_anchors likewise;
+ * msgpu_paf_read_count / msgpu_paf_anchor_count of the loader, i.e. Registry::m_ui32Size, Registry.cpp:36-45).  The
+ * index build then skips its own pass over the table and one read-back.  Stays in force for later loads; (0, 0)
+ * returns to discovery.  A row with an id outside the declared space makes the load fail with MSGPU_E_IDS. */
+int msgpu_set_id_space(msgpu_ctx *ctx, uint32_t n_reads, uint32_t n_anchors);
+
 /* ---- A1: PAF loader (host) ------------------------------------------------------------------------------------- */
 
 /* Replaces BlastFileAccessor::_buildIndex (BlastFileAccessor.cpp:77-91) + BlastFileReader::read/parseLine

@@ -69,10 +69,14 @@ public:
     check(msgpu_parse_paf(pafPath.c_str(), &m_params, &m_paf), nullptr);
     std::size_t      n    = 0;
     msgpu_row const *rows = msgpu_paf_rows(m_paf, &n);
+    check(msgpu_set_id_space(m_ctx, msgpu_paf_read_count(m_paf), msgpu_paf_anchor_count(m_paf)), m_ctx);
     check(msgpu_load_rows(m_ctx, rows, n), m_ctx);
   }
   // Same from rows the caller already holds (Registry ids in first-line order).
-  void addRows(msgpu_row const *rows, std::size_t n) { check(msgpu_load_rows(m_ctx, rows, n), m_ctx); }
+  void addRows(msgpu_row const *rows, std::size_t n) {
+    check(msgpu_set_id_space(m_ctx, 0, 0), m_ctx);
+    check(msgpu_load_rows(m_ctx, rows, n), m_ctx);
+  }
 
   // MatchMap::calculateEdges() (src/main.cpp:157)
   void calculateEdges() { check(msgpu_calculate_edges(m_ctx), m_ctx); }

@@ -89,6 +89,7 @@ SYMBOLS = [
     ("msgpu_last_error", C.c_char_p, [C.c_void_p]),
     ("msgpu_set_stream", C.c_int, [C.c_void_p, C.c_void_p]),
     ("msgpu_set_shard", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32]),
+    ("msgpu_set_id_space", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32]),
     ("msgpu_parse_paf", C.c_int, [C.c_char_p, C.POINTER(Params), C.POINTER(C.c_void_p)]),
     ("msgpu_paf_free", None, [C.c_void_p]),
     ("msgpu_paf_rows", C.c_void_p, [C.c_void_p, C.POINTER(C.c_size_t)]),

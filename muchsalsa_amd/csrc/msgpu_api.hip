@@ -66,6 +66,7 @@ struct msgpu_ctx {
   char         err[512]   = {0};
   State        state      = ST_CREATED;
   uint32_t     shard = 0, nshards = 1;
+  uint32_t     decl_V = 0, decl_A = 0; // msgpu_set_id_space: id counts declared by the caller (0 = find them)
 
   // loaded rows
   uint64_t n_rows = 0, n_alive = 0;
@@ -143,13 +144,18 @@ int build_index_once(msgpu_ctx *c, bool force_generic, uint32_t *ix_flags_out) {
   ENSURE(c, scalars, SC_COUNT * sizeof(uint64_t));
   HIPCHK(c, hipMemsetAsync(c->scalars.p, 0, SC_COUNT * sizeof(uint64_t), st));
 
-  // id spaces
-  launch_max_ids(st, c->d_rows, n, scalar<uint32_t>(c, SC_MAXIDS));
-  uint32_t maxids[2] = {0, 0};
-  HIPCHK(c, hipMemcpyAsync(maxids, scalar<uint32_t>(c, SC_MAXIDS), sizeof(maxids), hipMemcpyDeviceToHost, st));
-  HIPCHK(c, hipStreamSynchronize(st));
-  c->V = maxids[0];
-  c->A = maxids[1];
+  // id spaces: declared by the caller (the parser knows them), else one pass over the rows and a read-back
+  if (c->decl_V && c->decl_A) {
+    c->V = c->decl_V;
+    c->A = c->decl_A;
+  } else {
+    launch_max_ids(st, c->d_rows, n, scalar<uint32_t>(c, SC_MAXIDS));
+    uint32_t maxids[2] = {0, 0};
+    HIPCHK(c, hipMemcpyAsync(maxids, scalar<uint32_t>(c, SC_MAXIDS), sizeof(maxids), hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    c->V = maxids[0];
+    c->A = maxids[1];
+  }
   const uint32_t V = c->V, A = c->A;
 
   const size_t nz = n ? n : 1;
@@ -180,12 +186,14 @@ int build_index_once(msgpu_ctx *c, bool force_generic, uint32_t *ix_flags_out) {
     ENSURE(c, scan_tmp, (size_t(scan_blocks(m)) + 1) * 8);
   }
 
-  HIPCHK(c, hipMemsetAsync(c->cnt_read.p, 0, (size_t(V) + 1) * 4, st));
-  HIPCHK(c, hipMemsetAsync(c->first_key.p, 0xff, (size_t(V) + 1) * 8, st));
-  HIPCHK(c, hipMemsetAsync(c->cursor.p, 0, mva * 4, st));
-  HIPCHK(c, hipMemsetAsync(c->read_cnt.p, 0, (size_t(V) + 1) * 4, st));
-  HIPCHK(c, hipMemsetAsync(c->anchor_cnt.p, 0, (size_t(A) + 1) * 4, st));
-  HIPCHK(c, hipMemsetAsync(c->anchor_first.p, 0xff, (size_t(A) + 2) * 4, st));
+  {
+    uint32_t *const zero[4]   = {c->cnt_read.as<uint32_t>(), c->cursor.as<uint32_t>(), c->read_cnt.as<uint32_t>(),
+                                 c->anchor_cnt.as<uint32_t>()};
+    const uint32_t  n_zero[4] = {V + 1, static_cast<uint32_t>(mva), V + 1, A + 1};
+    uint32_t *const ones[2]   = {c->first_key.as<uint32_t>(), c->anchor_first.as<uint32_t>()};
+    const uint32_t  n_ones[2] = {2 * (V + 1), A + 2};
+    launch_index_init(st, zero, n_zero, ones, n_ones);
+  }
   uint32_t *d_flags = scalar<uint32_t>(c, SC_IXFLAGS);
   if (force_generic) {
     const uint32_t f = IXF_FORCE;
@@ -193,7 +201,7 @@ int build_index_once(msgpu_ctx *c, bool force_generic, uint32_t *ix_flags_out) {
   }
 
   launch_index_pass1(st, c->d_rows, n, c->cnt_read.as<uint32_t>(), c->first_key.as<uint64_t>(),
-                     c->anchor_first.as<uint32_t>(), A, d_flags);
+                     c->anchor_first.as<uint32_t>(), V, A, d_flags, scalar<uint32_t>(c, SC_ERR));
   launch_read_facts(st, c->d_rows, c->first_key.as<uint64_t>(), V, c->read_len.as<int32_t>(),
                     c->read_first.as<uint32_t>(), scalar<uint32_t>(c, SC_ERR));
   exclusive_scan<uint32_t>(st, c->cnt_read.as<uint32_t>(), V, c->read_off.as<uint32_t>(), c->scan_tmp.as<uint32_t>(),
@@ -204,25 +212,38 @@ int build_index_once(msgpu_ctx *c, bool force_generic, uint32_t *ix_flags_out) {
                    c->bkt_idx.as<uint32_t>(), c->by_read.as<IRow>(), c->read_cnt.as<uint32_t>(),
                    c->alive_rank.as<uint32_t>(), c->anchor_cnt.as<uint32_t>(), c->bkt_dead.as<uint8_t>(), d_flags,
                    c->by_anchor.as<IRow>()); // fast mode: the sort writes the scaffold rows too
-  // generic by_anchor path (no-ops in fast mode)
-  exclusive_scan<uint32_t>(st, c->anchor_cnt.as<uint32_t>(), A, c->anchor_off_gen.as<uint32_t>(),
-                           c->scan_tmp.as<uint32_t>(), scalar<uint32_t>(c, SC_NALIVE));
+  // Fast mode (input grouped by anchor, ascending lines: what the PAF loader hands over) is finished here but for the
+  // scaffold offsets, which are the speculative ones of pass 1; the flags come back with the read-back below and
+  // only an input that is not in that form pays for the generic scaffold build (a second read-back).
   launch_select_anchor_off(st, d_flags, c->anchor_first.as<uint32_t>(), c->anchor_off_gen.as<uint32_t>(), A,
                            c->anchor_off.as<uint32_t>(), scalar<uint32_t>(c, SC_NALIVE), static_cast<uint32_t>(n));
-  HIPCHK(c, hipMemsetAsync(c->cursor.p, 0, mva * 4, st));
-  launch_scatter_anchor(st, c->d_rows, n, c->alive_rank.as<uint32_t>(), c->anchor_off.as<uint32_t>(),
-                        c->cursor.as<uint32_t>(), c->bkt2_idx.as<uint32_t>(), c->bkt2_line.as<uint32_t>(), d_flags);
-  launch_rank_anchor(st, c->anchor_off.as<uint32_t>(), n, scalar<uint32_t>(c, SC_NALIVE), c->bkt2_idx.as<uint32_t>(),
-                     c->bkt2_line.as<uint32_t>(), c->d_rows, c->alive_rank.as<uint32_t>(), c->by_anchor.as<IRow>(),
-                     d_flags);
   HIPCHK(c, hipGetLastError());
-  HIPCHK(c, hipEventRecord(c->ev[1], st));
 
   uint32_t err = 0, n_alive = 0, ixf = 0;
   HIPCHK(c, hipMemcpyAsync(&err, scalar<uint32_t>(c, SC_ERR), 4, hipMemcpyDeviceToHost, st));
   HIPCHK(c, hipMemcpyAsync(&n_alive, scalar<uint32_t>(c, SC_NALIVE), 4, hipMemcpyDeviceToHost, st));
   HIPCHK(c, hipMemcpyAsync(&ixf, d_flags, 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipEventRecord(c->ev[1], st));
   HIPCHK(c, hipStreamSynchronize(st));
+  if (err & 2u)
+    return fail(c, MSGPU_E_IDS, "a row has an id outside the declared id space (%u reads, %u anchors)", V, A);
+  if ((ixf & ~IXF_DUPS) != 0 && !(err & 1u)) {
+    // generic scaffold build: count, scan, bucket by anchor, rank by line (MatchMap.cpp:178-183)
+    exclusive_scan<uint32_t>(st, c->anchor_cnt.as<uint32_t>(), A, c->anchor_off_gen.as<uint32_t>(),
+                             c->scan_tmp.as<uint32_t>(), scalar<uint32_t>(c, SC_NALIVE));
+    launch_select_anchor_off(st, d_flags, c->anchor_first.as<uint32_t>(), c->anchor_off_gen.as<uint32_t>(), A,
+                             c->anchor_off.as<uint32_t>(), scalar<uint32_t>(c, SC_NALIVE), static_cast<uint32_t>(n));
+    HIPCHK(c, hipMemsetAsync(c->cursor.p, 0, mva * 4, st));
+    launch_scatter_anchor(st, c->d_rows, n, c->alive_rank.as<uint32_t>(), c->anchor_off.as<uint32_t>(),
+                          c->cursor.as<uint32_t>(), c->bkt2_idx.as<uint32_t>(), c->bkt2_line.as<uint32_t>(), d_flags);
+    launch_rank_anchor(st, c->anchor_off.as<uint32_t>(), n, scalar<uint32_t>(c, SC_NALIVE), c->bkt2_idx.as<uint32_t>(),
+                       c->bkt2_line.as<uint32_t>(), c->d_rows, c->alive_rank.as<uint32_t>(), c->by_anchor.as<IRow>(),
+                       d_flags);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(&n_alive, scalar<uint32_t>(c, SC_NALIVE), 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipEventRecord(c->ev[1], st));
+    HIPCHK(c, hipStreamSynchronize(st));
+  }
   c->n_alive    = n_alive;
   *ix_flags_out = ixf;
   if (err & 1u)
@@ -349,6 +370,14 @@ int msgpu_set_shard(msgpu_ctx *c, uint32_t shard, uint32_t n_shards) {
   c->shard   = shard;
   c->nshards = n_shards;
   if (c->state > ST_LOADED) c->state = ST_LOADED;
+  return MSGPU_OK;
+}
+
+int msgpu_set_id_space(msgpu_ctx *c, uint32_t n_reads, uint32_t n_anchors) {
+  if (!c) return MSGPU_E_ARG;
+  if ((n_reads == 0) != (n_anchors == 0)) return fail(c, MSGPU_E_ARG, "declare both id counts, or 0 and 0 to find them");
+  c->decl_V = n_reads;
+  c->decl_A = n_anchors;
   return MSGPU_OK;
 }
 

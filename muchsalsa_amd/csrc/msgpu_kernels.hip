@@ -218,14 +218,35 @@ __global__ __launch_bounds__(256) void k_max_ids(const msgpu_row *rows, uint64_t
   }
 }
 
+// one launch instead of six memsets: zero / all-ones fill of the per-read and per-anchor tables of the index build
+struct IndexInitArgs {
+  uint32_t *zero[4];
+  uint32_t  n_zero[4];
+  uint32_t *ones[2];
+  uint32_t  n_ones[2];
+};
+__global__ __launch_bounds__(256) void k_index_init(IndexInitArgs a) {
+  const uint32_t stride = gridDim.x * 256, t0 = blockIdx.x * 256 + threadIdx.x;
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    for (uint32_t i = t0; i < a.n_zero[k]; i += stride) a.zero[k][i] = 0;
+#pragma unroll
+  for (int k = 0; k < 2; ++k)
+    for (uint32_t i = t0; i < a.n_ones[k]; i += stride) a.ones[k][i] = 0xffffffffu;
+}
+
 // pass 1 over the rows: per-read row counts, first line per read, and -- speculatively -- the scaffold offsets that
 // hold when the table is already grouped by anchor with ascending lines (what a PAF from minimap2 looks like).
 __global__ __launch_bounds__(256) void k_index_pass1(const msgpu_row *rows, uint64_t n, uint32_t *cnt_read,
                                                      unsigned long long *first_key, uint32_t *anchor_first,
-                                                     uint32_t *flags) {
+                                                     uint32_t *flags, uint32_t V, uint32_t A, uint32_t *err) {
   uint64_t i = static_cast<uint64_t>(blockIdx.x) * 256 + threadIdx.x;
   if (i >= n) return;
   const uint32_t rd = rows[i].read_id, an = rows[i].anchor_id, ln = rows[i].line;
+  if (rd >= V || an >= A) { // only possible when the host declared the id space (msgpu_set_id_space)
+    atomicOr(err, 2u);
+    return;
+  }
   atomicAdd(&cnt_read[rd], 1u);
   atomicMin(&first_key[rd], (static_cast<unsigned long long>(ln) << 32) | static_cast<uint32_t>(i));
   if (i == 0) {
@@ -1948,11 +1969,28 @@ void launch_max_ids(hipStream_t st, const msgpu_row *rows, uint64_t n, uint32_t 
     hipLaunchKernelGGL(k_max_ids, dim3(static_cast<uint32_t>(nb < 2048 ? nb : 2048)), dim3(256), 0, st, rows, n, max_ids);
   }
 }
+void launch_index_init(hipStream_t st, uint32_t *const zero[4], const uint32_t n_zero[4], uint32_t *const ones[2],
+                       const uint32_t n_ones[2]) {
+  IndexInitArgs a;
+  uint32_t      most = 1;
+  for (int k = 0; k < 4; ++k) {
+    a.zero[k]   = zero[k];
+    a.n_zero[k] = n_zero[k];
+    most        = n_zero[k] > most ? n_zero[k] : most;
+  }
+  for (int k = 0; k < 2; ++k) {
+    a.ones[k]   = ones[k];
+    a.n_ones[k] = n_ones[k];
+    most        = n_ones[k] > most ? n_ones[k] : most;
+  }
+  uint32_t nb = (most + 255) / 256;
+  hipLaunchKernelGGL(k_index_init, dim3(nb < 1024 ? nb : 1024), dim3(256), 0, st, a);
+}
 void launch_index_pass1(hipStream_t st, const msgpu_row *rows, uint64_t n, uint32_t *cnt_read, uint64_t *first_key,
-                        uint32_t *anchor_first, uint32_t A, uint32_t *flags) {
+                        uint32_t *anchor_first, uint32_t V, uint32_t A, uint32_t *flags, uint32_t *err) {
   if (n)
     hipLaunchKernelGGL(k_index_pass1, grid1(n, 256), dim3(256), 0, st, rows, n, cnt_read,
-                       reinterpret_cast<unsigned long long *>(first_key), anchor_first, flags);
+                       reinterpret_cast<unsigned long long *>(first_key), anchor_first, flags, V, A, err);
   hipLaunchKernelGGL(k_check_anchor_first, grid1(static_cast<uint64_t>(A) + 1, 256), dim3(256), 0, st, anchor_first, A,
                      static_cast<uint32_t>(n), flags);
 }

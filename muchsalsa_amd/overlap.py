@@ -96,6 +96,10 @@ class OverlapContext:
     def set_shard(self, shard, n_shards):
         self._check(self._L.msgpu_set_shard(self._h, shard, n_shards))
 
+    def set_id_space(self, n_reads, n_anchors):
+        """Declare the id counts the loader already knows (Registry sizes); (0, 0) = let the index build find them."""
+        self._check(self._L.msgpu_set_id_space(self._h, int(n_reads), int(n_anchors)))
+
     def load_rows(self, rows):
         rows = np.ascontiguousarray(rows, dtype=ROW_DTYPE)
         self._check(self._L.msgpu_load_rows(self._h, rows.ctypes.data, len(rows)))

@@ -63,6 +63,7 @@ def run(contigs_paf, unitigs_path, nanopore_path, out_dir, threads=None, wiggle_
 
     t0 = time.perf_counter()
     ctx = overlap.OverlapContext(device=device, params=params)
+    ctx.set_id_space(len(paf.read_names), len(paf.anchor_names))
     ctx.load_rows(paf.rows)
     ctx.calculate_edges()
     ctx.chaining_and_overlaps()

@@ -199,6 +199,37 @@ def test_api_state_and_id_checks():
             assert a[k].tobytes() == b[k].tobytes()
 
 
+def test_declared_id_space(oracle):
+    """msgpu_set_id_space: the loader's Registry sizes replace the index build's own pass over the table; wrong
+    declarations are refused, a too-large anchor space (anchors without rows) is legal."""
+    from muchsalsa_amd import _lib, overlap, synth
+    rows = synth.synth_rows(300, 3000, 900, 1)
+    want = oracle.overlap(rows)
+    V, A = int(rows["read_id"].max()) + 1, int(rows["anchor_id"].max()) + 1
+
+    def run(ctx):
+        ctx.load_rows(rows)
+        ctx.calculate_edges()
+        ctx.chaining_and_overlaps()
+        return ctx.tables()
+
+    with overlap.OverlapContext(0) as ctx:
+        ctx.set_id_space(V, A)
+        assert_tables_equal(run(ctx), want, "declared")
+        ctx.set_id_space(V, A + 5)
+        assert_tables_equal(run(ctx), want, "anchor ids without rows")
+        for v, a in ((V - 1, A), (V, A - 1), (V + 1, A)):
+            ctx.set_id_space(v, a)
+            with pytest.raises(overlap.MsgpuError) as e:
+                ctx.load_rows(rows)
+            assert e.value.code == _lib.E_IDS, (v, a)
+        with pytest.raises(overlap.MsgpuError) as e:
+            ctx.set_id_space(V, 0)
+        assert e.value.code == _lib.E_ARG
+        ctx.set_id_space(0, 0)
+        assert_tables_equal(run(ctx), want, "discovery again")
+
+
 def test_property_checks_at_full_size():
     """cfg2-size run checked through size-independent properties (no oracle): table cross references are dense and
     consistent, every order's ids are a subset of its edge's EdgeMatch anchors in vStart order, shards partition."""
