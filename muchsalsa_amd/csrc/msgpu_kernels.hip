@@ -531,17 +531,19 @@ __global__ __launch_bounds__(256) void k_rank_anchor(const uint32_t *anchor_off,
 __global__ __launch_bounds__(256) void k_bound(const uint32_t *read_off, const uint32_t *read_cnt, const IRow *by_read,
                                                const uint32_t *anchor_off, uint32_t V, uint32_t shard, uint32_t nshards,
                                                uint32_t *bound) {
-  uint32_t r = blockIdx.x * 256 + threadIdx.x;
-  if (r >= V) return;
-  uint32_t s = 0;
-  if (r % nshards == shard) {
-    uint32_t b = read_off[r], n = read_cnt[r];
-    for (uint32_t j = 0; j < n; ++j) {
-      uint32_t a = by_read[b + j].other;
+  // 16 lanes per read: neighbouring lanes read neighbouring rows
+  const uint32_t r   = blockIdx.x * 16 + (threadIdx.x >> 4);
+  const uint32_t sub = threadIdx.x & 15;
+  uint32_t       s   = 0;
+  if (r < V && r % nshards == shard) {
+    const uint32_t b = read_off[r], n = read_cnt[r];
+    for (uint32_t j = sub; j < n; j += 16) {
+      const uint32_t a = by_read[b + j].other;
       s += anchor_off[a + 1] - anchor_off[a];
     }
   }
-  bound[r] = s;
+  for (int d = 8; d > 0; d >>= 1) s += __shfl_xor(s, d); // every lane takes part
+  if (r < V && sub == 0) bound[r] = s;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -790,28 +792,39 @@ template __global__ void k_candidates<1024, 4096>(CandArgs, const uint32_t *, ui
 // classify reads of this shard by the LDS footprint their candidate scan needs
 // classes by LDS footprint: 0 = <256 rows, 512 candidates> (half the LDS of class 1, so twice as many reads per CU),
 // 1 = <256, 1024>, 2 = <1024, 4096>, 3 = global-scratch kernel
-__global__ __launch_bounds__(256) void k_classify_reads(const uint32_t *read_cnt, const uint32_t *bound, uint32_t V,
-                                                        uint32_t shard, uint32_t nshards, uint32_t *list0,
-                                                        uint32_t *list1, uint32_t *list2, uint32_t *list3,
-                                                        uint32_t *n_lists /*[4]*/) {
-  uint32_t r   = blockIdx.x * 256 + threadIdx.x;
+__global__ __launch_bounds__(1024) void k_classify_reads(const uint32_t *read_cnt, const uint32_t *bound, uint32_t V,
+                                                         uint32_t shard, uint32_t nshards, uint32_t *list0,
+                                                         uint32_t *list1, uint32_t *list2, uint32_t *list3,
+                                                         uint32_t *n_lists /*[4]*/) {
+  // the four list cursors are single words (~88 atomics/us each): count inside the workgroup in LDS first, then one
+  // global atomic per workgroup and class
+  __shared__ uint32_t s_cnt[4], s_base[4];
+  if (threadIdx.x < 4) s_cnt[threadIdx.x] = 0;
+  __syncthreads();
+  uint32_t r   = blockIdx.x * 1024 + threadIdx.x;
   int      cls = -1;
   if (r < V && r % nshards == shard) {
     uint32_t n1 = read_cnt[r], bd = bound[r];
     if (n1 != 0 && bd != 0)
       cls = (n1 <= 256 && bd <= 512) ? 0 : (n1 <= 256 && bd <= 1024) ? 1 : (n1 <= 1024 && bd <= 4096) ? 2 : 3;
   }
-  // one atomic per wave and class
-  const int lane = threadIdx.x & 63;
-  uint32_t *lists[4] = {list0, list1, list2, list3};
+  const int lane  = threadIdx.x & 63;
+  uint32_t  local = 0;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     unsigned long long m = __ballot(cls == k);
-    if (!m) continue;
+    if (!m) continue; // wave-uniform
     uint32_t base = 0;
-    if (lane == __builtin_ctzll(m)) base = atomicAdd(&n_lists[k], static_cast<uint32_t>(__popcll(m)));
-    base = __shfl(base, __builtin_ctzll(m));
-    if (cls == k) lists[k][base + static_cast<uint32_t>(__popcll(m & ((1ull << lane) - 1)))] = r;
+    if (lane == __builtin_ctzll(m)) base = atomicAdd(&s_cnt[k], static_cast<uint32_t>(__popcll(m)));
+    base = rl_u32(base, __builtin_ctzll(m));
+    if (cls == k) local = base + static_cast<uint32_t>(__popcll(m & ((1ull << lane) - 1)));
+  }
+  __syncthreads();
+  if (threadIdx.x < 4 && s_cnt[threadIdx.x]) s_base[threadIdx.x] = atomicAdd(&n_lists[threadIdx.x], s_cnt[threadIdx.x]);
+  __syncthreads();
+  if (cls >= 0) {
+    uint32_t *list = cls == 0 ? list0 : cls == 1 ? list1 : cls == 2 ? list2 : list3;
+    list[s_base[cls] + local] = r;
   }
 }
 
@@ -940,15 +953,15 @@ __global__ __launch_bounds__(256) void k_emit_edges(const uint32_t *n_edge, cons
                                                     const uint64_t *cand_off, const uint32_t *edge_scr_v2,
                                                     const uint32_t *edge_scr_start, uint32_t V, msgpu_edge *edges,
                                                     uint64_t *edge_cand) {
-  // one wave per read
-  uint32_t r    = blockIdx.x * 4 + (threadIdx.x >> 6);
-  int      lane = threadIdx.x & 63;
+  // 16 lanes per read (a read has ~10 edges)
+  uint32_t r    = blockIdx.x * 16 + (threadIdx.x >> 4);
+  int      lane = threadIdx.x & 15;
   if (r >= V) return;
   uint32_t ne = n_edge[r];
   if (ne == 0) return;
   uint32_t nc = n_cand[r];
   uint64_t eb = edge_base[r], mb = em_base[r], co = cand_off[r];
-  for (uint32_t e = lane; e < ne; e += 64) {
+  for (uint32_t e = lane; e < ne; e += 16) {
     uint32_t   st  = edge_scr_start[co + e];
     uint32_t   en  = (e + 1 < ne) ? edge_scr_start[co + e + 1] : nc;
     msgpu_edge ed;
@@ -2034,13 +2047,13 @@ void launch_rank_anchor(hipStream_t st, const uint32_t *anchor_off, uint64_t n_r
 void launch_bound(hipStream_t st, const uint32_t *read_off, const uint32_t *read_cnt, const IRow *by_read,
                   const uint32_t *anchor_off, uint32_t V, uint32_t shard, uint32_t nshards, uint32_t *bound) {
   if (V)
-    hipLaunchKernelGGL(k_bound, grid1(V, 256), dim3(256), 0, st, read_off, read_cnt, by_read, anchor_off, V, shard,
+    hipLaunchKernelGGL(k_bound, grid1(V, 16), dim3(256), 0, st, read_off, read_cnt, by_read, anchor_off, V, shard,
                        nshards, bound);
 }
 void launch_classify_reads(hipStream_t st, const uint32_t *read_cnt, const uint32_t *bound, uint32_t V, uint32_t shard,
                            uint32_t nshards, uint32_t *l0, uint32_t *l1, uint32_t *l2, uint32_t *l3, uint32_t *n_lists) {
   if (V)
-    hipLaunchKernelGGL(k_classify_reads, grid1(V, 256), dim3(256), 0, st, read_cnt, bound, V, shard, nshards, l0, l1, l2,
+    hipLaunchKernelGGL(k_classify_reads, grid1(V, 1024), dim3(1024), 0, st, read_cnt, bound, V, shard, nshards, l0, l1, l2,
                        l3, n_lists);
 }
 void launch_candidates(hipStream_t st, const CandArgs &a, int cls, const uint32_t *list, uint32_t n_list) {
@@ -2062,7 +2075,7 @@ void launch_emit_edges(hipStream_t st, const uint32_t *n_edge, const uint32_t *n
                        const uint64_t *em_base, const uint64_t *cand_off, const uint32_t *scr_v2,
                        const uint32_t *scr_start, uint32_t V, msgpu_edge *edges, uint64_t *edge_cand) {
   if (V)
-    hipLaunchKernelGGL(k_emit_edges, grid1(V, 4), dim3(256), 0, st, n_edge, n_cand, edge_base, em_base, cand_off, scr_v2,
+    hipLaunchKernelGGL(k_emit_edges, grid1(V, 16), dim3(256), 0, st, n_edge, n_cand, edge_base, em_base, cand_off, scr_v2,
                        scr_start, V, edges, edge_cand);
 }
 void launch_fill_pair_tab(hipStream_t st, uint16_t *tab) {
