@@ -426,10 +426,14 @@ int msgpu_calculate_edges(msgpu_ctx *c) {
   ENSURE(c, visit_base, (size_t(V) + 2) * 8);
   uint32_t *l0 = c->lists.as<uint32_t>(), *l1 = l0 + V + 1, *l2 = l1 + V + 1, *l3 = l2 + V + 1;
 
-  HIPCHK(c, hipMemsetAsync(scalar<uint32_t>(c, SC_NLISTS), 0, 16, st));
-  HIPCHK(c, hipMemsetAsync(c->n_cand.p, 0, (size_t(V) + 1) * 4, st));
-  HIPCHK(c, hipMemsetAsync(c->n_edge.p, 0, (size_t(V) + 1) * 4, st));
-  HIPCHK(c, hipMemsetAsync(c->n_visit_arr.p, 0, (size_t(V) + 1) * 4, st));
+  {
+    uint32_t *const zero[4]   = {scalar<uint32_t>(c, SC_NLISTS), c->n_cand.as<uint32_t>(), c->n_edge.as<uint32_t>(),
+                                 c->n_visit_arr.as<uint32_t>()};
+    const uint32_t  n_zero[4] = {4, V + 1, V + 1, V + 1};
+    uint32_t *const ones[2]   = {nullptr, nullptr};
+    const uint32_t  n_ones[2] = {0, 0};
+    launch_index_init(st, zero, n_zero, ones, n_ones); // one launch instead of four memsets
+  }
   launch_bound(st, c->read_off.as<uint32_t>(), c->read_cnt.as<uint32_t>(), c->by_read.as<IRow>(),
                c->anchor_off.as<uint32_t>(), V, c->shard, c->nshards, c->bound.as<uint32_t>());
   exclusive_scan<uint64_t>(st, c->bound.as<uint32_t>(), V, c->cand_off.as<uint64_t>(), c->scan_tmp.as<uint64_t>(),
@@ -527,8 +531,6 @@ int msgpu_chaining_and_overlaps(msgpu_ctx *c) {
   ENSURE(c, big_list, (E + 1) * 4);
   ENSURE(c, visit_base, (E + 2) * 8); // re-used as the scan output of the per-edge shortcut flags
   ENSURE(c, scan_tmp, (size_t(scan_blocks(E > c->V ? E : c->V)) + 1) * 8);
-  HIPCHK(c, hipMemsetAsync(c->edge_norders.p, 0, (E + 1) * 4, st));
-  HIPCHK(c, hipMemsetAsync(c->edge_nids.p, 0, (E + 1) * 4, st));
 
   ChainArgs a;
   a.edges        = c->edges.as<msgpu_edge>();
@@ -553,7 +555,14 @@ int msgpu_chaining_and_overlaps(msgpu_ctx *c) {
   }
   a.pair_tab     = c->pair_tab.as<uint16_t>();
   ENSURE(c, edge_fast, (E + 1) * 4);
-  HIPCHK(c, hipMemsetAsync(c->edge_fast.p, 0, (E + 1) * 4, st));
+  {
+    uint32_t *const zero[4]   = {c->edge_norders.as<uint32_t>(), c->edge_nids.as<uint32_t>(), c->edge_fast.as<uint32_t>(),
+                                 nullptr};
+    const uint32_t  n_zero[4] = {static_cast<uint32_t>(E + 1), static_cast<uint32_t>(E + 1), static_cast<uint32_t>(E + 1), 0};
+    uint32_t *const ones[2]   = {nullptr, nullptr};
+    const uint32_t  n_ones[2] = {0, 0};
+    launch_index_init(st, zero, n_zero, ones, n_ones);
+  }
   a.edge_fast    = c->edge_fast.as<uint32_t>();
   a.fast_path    = c->fast_path ? 1 : 0;
   a.wiggle       = static_cast<double>(c->p.wiggle_room);

@@ -98,7 +98,7 @@ __device__ __forceinline__ uint32_t block_excl_scan_256(uint32_t v, uint32_t *s_
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// generic exclusive scan (u32 in, T out), three launches; total written to *d_total
+// generic exclusive scan (u32 in, T out), two launches; total written to *d_total
 // ---------------------------------------------------------------------------------------------------------------------
 
 constexpr int SCAN_ITEMS = 8; // per thread -> 2048 per block
@@ -117,42 +117,24 @@ template <class T> __global__ __launch_bounds__(256) void k_scan_reduce(const ui
   if (threadIdx.x == 0) block_sums[blockIdx.x] = s[0] + s[1] + s[2] + s[3];
 }
 
-template <class T> __global__ __launch_bounds__(256) void k_scan_blocksums(T *block_sums, uint32_t nb, T *d_total) {
-  // single workgroup; sequential chunks of 256 with a running carry
-  __shared__ T s_w[4];
-  __shared__ T s_carry;
-  if (threadIdx.x == 0) s_carry = 0;
-  __syncthreads();
-  for (uint32_t c = 0; c < nb; c += 256) {
-    uint32_t  i    = c + threadIdx.x;
-    T         v    = i < nb ? block_sums[i] : 0;
-    T         inc  = v;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int d = 1; d < 64; d <<= 1) {
-      T t = __shfl_up(inc, d);
-      if (lane >= d) inc += t;
-    }
-    if (lane == 63) s_w[wave] = inc;
-    __syncthreads();
-    T base = s_carry;
-    for (int w = 0; w < wave; ++w) base += s_w[w];
-    if (i < nb) block_sums[i] = base + inc - v;
-    __syncthreads();
-    if (threadIdx.x == 255) s_carry = base + inc;
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) *d_total = s_carry;
-}
-
 template <class T>
-__global__ __launch_bounds__(256) void k_scan_apply(const uint32_t *in, uint64_t n, const T *block_sums, T *out) {
-  // out has n+1 entries; out[n] = total is written by the last block
+__global__ __launch_bounds__(256) void k_scan_apply(const uint32_t *in, uint64_t n, const T *block_sums, T *out,
+                                                    T *d_total) {
+  // out has n+1 entries; out[n] = *d_total = total is written by the last block.  The carry of a block is the sum of
+  // the (raw) sums of the blocks before it: a few thousand words at most, cheaper than a launch of its own.
   __shared__ T s_w[4];
   __shared__ T s_carry;
   uint64_t     base = static_cast<uint64_t>(blockIdx.x) * 256 * SCAN_ITEMS;
-  if (threadIdx.x == 0) s_carry = block_sums[blockIdx.x];
-  __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int    lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  {
+    T c = 0;
+    for (uint32_t i = threadIdx.x; i < blockIdx.x; i += 256) c += block_sums[i];
+    for (int d = 32; d > 0; d >>= 1) c += __shfl_down(c, d);
+    if (lane == 0) s_w[wave] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) s_carry = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+    __syncthreads();
+  }
   for (int it = 0; it < SCAN_ITEMS; ++it) {
     uint64_t idx = base + static_cast<uint64_t>(it) * 256 + threadIdx.x;
     T        v   = idx < n ? in[idx] : 0;
@@ -166,7 +148,10 @@ __global__ __launch_bounds__(256) void k_scan_apply(const uint32_t *in, uint64_t
     T b = s_carry;
     for (int w = 0; w < wave; ++w) b += s_w[w];
     if (idx < n) out[idx] = b + inc - v;
-    if (idx == n - 1) out[n] = b + inc;
+    if (idx == n - 1) {
+      out[n]   = b + inc;
+      *d_total = b + inc;
+    }
     __syncthreads();
     if (threadIdx.x == 255) s_carry = b + inc;
     __syncthreads();
@@ -181,8 +166,7 @@ template <class T> void exclusive_scan(hipStream_t st, const uint32_t *in, uint6
   }
   uint32_t nb = static_cast<uint32_t>((n + 256 * SCAN_ITEMS - 1) / (256 * SCAN_ITEMS));
   hipLaunchKernelGGL(k_scan_reduce<T>, dim3(nb), dim3(256), 0, st, in, n, block_sums);
-  hipLaunchKernelGGL(k_scan_blocksums<T>, dim3(1), dim3(256), 0, st, block_sums, nb, d_total);
-  hipLaunchKernelGGL(k_scan_apply<T>, dim3(nb), dim3(256), 0, st, in, n, block_sums, out);
+  hipLaunchKernelGGL(k_scan_apply<T>, dim3(nb), dim3(256), 0, st, in, n, block_sums, out, d_total);
 }
 template void exclusive_scan<uint32_t>(hipStream_t, const uint32_t *, uint64_t, uint32_t *, uint32_t *, uint32_t *);
 template void exclusive_scan<uint64_t>(hipStream_t, const uint32_t *, uint64_t, uint64_t *, uint64_t *, uint64_t *);
