@@ -78,7 +78,7 @@ struct msgpu_ctx {
   uint32_t n_list[4] = {0, 0, 0, 0};
 
   // arena
-  DevBuf rows_in, cnt_read, first_key, read_off, cursor, bkt_key, bkt_idx, bkt_dead, by_read, read_cnt, alive_rank,
+  DevBuf rows_in, cnt_read, first_key, read_off, cursor, bkt_key, bkt_dead, by_read, read_cnt, alive_rank,
       anchor_cnt, anchor_off, anchor_first, anchor_off_gen, bkt2_idx, bkt2_line, by_anchor, read_len, read_first, scalars,
       scan_tmp;
   DevBuf bound, cand_off, cand_j, cand_t, scr_v2, scr_start, n_cand, n_edge, n_visit_arr, lists, em_base, edge_base,
@@ -126,7 +126,7 @@ int fail(msgpu_ctx *c, int code, const char *fmt, ...) {
 template <class T> T *scalar(msgpu_ctx *c, int slot) { return reinterpret_cast<T *>(c->scalars.as<uint64_t>() + slot); }
 
 void release_all(msgpu_ctx *c) {
-  DevBuf *all[] = {&c->g_deg, &c->g_off, &c->g_adj, &c->g_cand, &c->g_sane, &c->g_out, &c->rows_in, &c->cnt_read, &c->first_key, &c->read_off, &c->cursor, &c->bkt_key, &c->bkt_idx,
+  DevBuf *all[] = {&c->g_deg, &c->g_off, &c->g_adj, &c->g_cand, &c->g_sane, &c->g_out, &c->rows_in, &c->cnt_read, &c->first_key, &c->read_off, &c->cursor, &c->bkt_key,
                    &c->bkt_dead, &c->by_read, &c->read_cnt, &c->alive_rank, &c->anchor_cnt, &c->anchor_off,
                    &c->anchor_first, &c->anchor_off_gen,
                    &c->bkt2_idx, &c->bkt2_line, &c->by_anchor, &c->read_len, &c->read_first, &c->scalars, &c->scan_tmp,
@@ -165,7 +165,6 @@ int build_index_once(msgpu_ctx *c, bool force_generic, uint32_t *ix_flags_out) {
   ENSURE(c, read_off, (size_t(V) + 2) * 4);
   ENSURE(c, cursor, mva * 4);
   ENSURE(c, bkt_key, nz * sizeof(IRow));
-  ENSURE(c, bkt_idx, nz * 4);
   ENSURE(c, bkt_dead, nz);
   ENSURE(c, by_read, nz * sizeof(IRow));
   ENSURE(c, read_cnt, (size_t(V) + 1) * 4);
@@ -206,10 +205,9 @@ int build_index_once(msgpu_ctx *c, bool force_generic, uint32_t *ix_flags_out) {
                     c->read_first.as<uint32_t>(), scalar<uint32_t>(c, SC_ERR));
   exclusive_scan<uint32_t>(st, c->cnt_read.as<uint32_t>(), V, c->read_off.as<uint32_t>(), c->scan_tmp.as<uint32_t>(),
                            scalar<uint32_t>(c, SC_TOTAL_A));
-  launch_scatter_read(st, c->d_rows, n, c->read_off.as<uint32_t>(), c->cursor.as<uint32_t>(), c->bkt_key.as<IRow>(),
-                      c->bkt_idx.as<uint32_t>());
+  launch_scatter_read(st, c->d_rows, n, c->read_off.as<uint32_t>(), c->cursor.as<uint32_t>(), c->bkt_key.as<IRow>());
   launch_sort_read(st, c->read_off.as<uint32_t>(), c->cnt_read.as<uint32_t>(), V, c->bkt_key.as<IRow>(),
-                   c->bkt_idx.as<uint32_t>(), c->by_read.as<IRow>(), c->read_cnt.as<uint32_t>(),
+                   c->by_read.as<IRow>(), c->read_cnt.as<uint32_t>(),
                    c->alive_rank.as<uint32_t>(), c->anchor_cnt.as<uint32_t>(), c->bkt_dead.as<uint8_t>(), d_flags,
                    c->by_anchor.as<IRow>()); // fast mode: the sort writes the scaffold rows too
   // Fast mode (input grouped by anchor, ascending lines: what the PAF loader hands over) is finished here but for the
@@ -384,7 +382,7 @@ int msgpu_set_id_space(msgpu_ctx *c, uint32_t n_reads, uint32_t n_anchors) {
 int msgpu_load_rows(msgpu_ctx *c, const msgpu_row *rows, size_t n_rows) {
   if (!c) return MSGPU_E_ARG;
   if (n_rows && !rows) return fail(c, MSGPU_E_ARG, "Unexpected nullptr.");
-  if (n_rows >= 0xfffffff0ull) return fail(c, MSGPU_E_ARG, "row table too large (%zu rows)", n_rows);
+  if (n_rows > (1ull << 30)) return fail(c, MSGPU_E_ARG, "row table too large (%zu rows, at most 2^30)", n_rows);
   HIPCHK(c, hipSetDevice(c->device));
   c->state = ST_CREATED;
   ENSURE(c, rows_in, (n_rows ? n_rows : 1) * sizeof(msgpu_row));
@@ -398,7 +396,7 @@ int msgpu_load_rows(msgpu_ctx *c, const msgpu_row *rows, size_t n_rows) {
 int msgpu_load_rows_device(msgpu_ctx *c, const void *d_rows, size_t n_rows) {
   if (!c) return MSGPU_E_ARG;
   if (n_rows && !d_rows) return fail(c, MSGPU_E_ARG, "Unexpected nullptr.");
-  if (n_rows >= 0xfffffff0ull) return fail(c, MSGPU_E_ARG, "row table too large (%zu rows)", n_rows);
+  if (n_rows > (1ull << 30)) return fail(c, MSGPU_E_ARG, "row table too large (%zu rows, at most 2^30)", n_rows);
   HIPCHK(c, hipSetDevice(c->device));
   c->state  = ST_CREATED;
   c->d_rows = static_cast<const msgpu_row *>(d_rows);

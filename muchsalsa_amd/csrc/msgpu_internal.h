@@ -94,9 +94,9 @@ void launch_index_pass1(hipStream_t st, const msgpu_row *rows, uint64_t n, uint3
 void launch_read_facts(hipStream_t st, const msgpu_row *rows, const uint64_t *first_key, uint32_t V, int32_t *read_len,
                        uint32_t *read_first, uint32_t *err);
 void launch_scatter_read(hipStream_t st, const msgpu_row *rows, uint64_t n, const uint32_t *read_off, uint32_t *cursor,
-                         IRow *bkt_row, uint32_t *bkt_idx);
+                         IRow *bkt_row);
 void launch_sort_read(hipStream_t st, const uint32_t *read_off, const uint32_t *cnt_read, uint32_t V, const IRow *bkt_row,
-                      const uint32_t *bkt_idx, IRow *by_read, uint32_t *read_cnt, uint32_t *alive_rank,
+                      IRow *by_read, uint32_t *read_cnt, uint32_t *alive_rank,
                       uint32_t *anchor_cnt, uint8_t *bkt_dead, uint32_t *flags, IRow *by_anchor);
 void launch_select_anchor_off(hipStream_t st, const uint32_t *flags, const uint32_t *fast_off, const uint32_t *gen_off,
                               uint32_t A, uint32_t *anchor_off, uint32_t *d_n_alive, uint32_t n_rows);

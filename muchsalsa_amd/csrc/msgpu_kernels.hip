@@ -272,16 +272,17 @@ __global__ __launch_bounds__(256) void k_read_facts(const msgpu_row *rows, const
   }
 }
 
-// bucket rows by read: the whole row goes into the bucket (a fire-and-forget 32 B + 4 B scatter), so the sort
-// kernel reads its bucket with contiguous loads instead of gathering 40 B rows.  IRow.other = anchor, IRow.pf = flags.
+// bucket rows by read: the whole row goes into the bucket (a fire-and-forget 32 B scatter), so the sort kernel reads
+// its bucket with contiguous loads instead of gathering 40 B rows.  IRow.other = anchor, IRow.pf = flags | index of
+// the source row (the 30 position bits are free until the sort writes the rank there; the loaders cap the table at
+// 2^30 rows).
 __global__ __launch_bounds__(256) void k_scatter_read(const msgpu_row *rows, uint64_t n, const uint32_t *read_off,
-                                                      uint32_t *cursor, IRow *bkt_row, uint32_t *bkt_idx) {
+                                                      uint32_t *cursor, IRow *bkt_row) {
   uint64_t i = static_cast<uint64_t>(blockIdx.x) * 256 + threadIdx.x;
   if (i >= n) return;
   const msgpu_row row = rows[i];
   const uint32_t  pos = read_off[row.read_id] + atomicAdd(&cursor[row.read_id], 1u);
-  store_irow(&bkt_row[pos], make_irow(row, row.anchor_id, 0));
-  bkt_idx[pos] = static_cast<uint32_t>(i);
+  store_irow(&bkt_row[pos], make_irow(row, row.anchor_id, static_cast<uint32_t>(i)));
 }
 
 __device__ __forceinline__ bool key_less(int alo, int ahi, uint32_t aan, int blo, int bhi, uint32_t ban) {
@@ -293,7 +294,7 @@ __device__ __forceinline__ bool key_less(int alo, int ahi, uint32_t aan, int blo
 // writes nothing) when a (read, anchor) pair occurs twice: the caller then takes the generic path.
 template <int K>
 __device__ __forceinline__ bool sort_read_in_registers(uint32_t r, uint32_t b, uint32_t n, int lane, bool fast,
-                                                       const IRow *bkt_row, const uint32_t *bkt_idx, IRow *by_read,
+                                                       const IRow *bkt_row, IRow *by_read,
                                                        uint32_t *read_cnt, uint32_t *alive_rank, uint32_t *anchor_cnt,
                                                        IRow *by_anchor) {
   IRow     row[K];
@@ -307,7 +308,7 @@ __device__ __forceinline__ bool sort_read_in_registers(uint32_t r, uint32_t b, u
     idx[k]           = 0xffffffffu;
     if (e < n) {
       row[k] = load_irow(&bkt_row[b + e]);
-      idx[k] = bkt_idx[b + e];
+      idx[k] = row[k].pf & PF_POS_MASK;
     }
     mlo[k]  = e < n ? row[k].n_lo : 0x7fffffff;
     mhi[k]  = e < n ? row[k].n_hi : 0x7fffffff;
@@ -353,7 +354,7 @@ __device__ __forceinline__ bool sort_read_in_registers(uint32_t r, uint32_t b, u
 // Output: by_read rows (rank order), read_cnt, alive_rank[source row] (rank, or 0xffffffff for a dead row) and, in
 // generic mode, the per-anchor alive counts.
 __global__ __launch_bounds__(256) void k_sort_read(const uint32_t *read_off, const uint32_t *cnt_read, uint32_t V,
-                                                   const IRow *bkt_row, const uint32_t *bkt_idx, IRow *by_read,
+                                                   const IRow *bkt_row, IRow *by_read,
                                                    uint32_t *read_cnt, uint32_t *alive_rank, uint32_t *anchor_cnt,
                                                    uint8_t *bkt_dead, uint32_t *flags, IRow *by_anchor) {
   const int      lane = threadIdx.x & 63;
@@ -368,7 +369,7 @@ __global__ __launch_bounds__(256) void k_sort_read(const uint32_t *read_off, con
     uint32_t   idx = 0xffffffffu;
     if (have) {
       row = load_irow(&bkt_row[b + lane]);
-      idx = bkt_idx[b + lane];
+      idx = row.pf & PF_POS_MASK;
     }
     const int      mlo = have ? row.n_lo : 0x7fffffff, mhi = have ? row.n_hi : 0x7fffffff;
     const uint32_t man = have ? row.other : 0xffffffffu;
@@ -417,11 +418,11 @@ __global__ __launch_bounds__(256) void k_sort_read(const uint32_t *read_off, con
     return;
   }
   if (n <= 128) {
-    if (sort_read_in_registers<2>(r, b, n, lane, fast, bkt_row, bkt_idx, by_read, read_cnt, alive_rank, anchor_cnt,
+    if (sort_read_in_registers<2>(r, b, n, lane, fast, bkt_row, by_read, read_cnt, alive_rank, anchor_cnt,
                                   by_anchor))
       return;
   } else if (n <= 256) {
-    if (sort_read_in_registers<4>(r, b, n, lane, fast, bkt_row, bkt_idx, by_read, read_cnt, alive_rank, anchor_cnt,
+    if (sort_read_in_registers<4>(r, b, n, lane, fast, bkt_row, by_read, read_cnt, alive_rank, anchor_cnt,
                                   by_anchor))
       return;
   }
@@ -432,10 +433,10 @@ __global__ __launch_bounds__(256) void k_sort_read(const uint32_t *read_off, con
     bool           dead = false;
     if (e < n) {
       const IRow     k   = load_irow(&bkt_row[b + e]);
-      const uint32_t kix = bkt_idx[b + e];
+      const uint32_t kix = k.pf & PF_POS_MASK;
       for (uint32_t q = 0; q < n; ++q) {
         const IRow o = load_irow(&bkt_row[b + q]);
-        if (q != e && o.other == k.other) dead |= o.line < k.line || (o.line == k.line && bkt_idx[b + q] < kix);
+        if (q != e && o.other == k.other) dead |= o.line < k.line || (o.line == k.line && (o.pf & PF_POS_MASK) < kix);
       }
       bkt_dead[b + e] = dead ? 1 : 0;
       if (dead) alive_rank[kix] = 0xffffffffu;
@@ -447,8 +448,9 @@ __global__ __launch_bounds__(256) void k_sort_read(const uint32_t *read_off, con
     const uint32_t e     = e0 + lane;
     const bool     alive = e < n && !bkt_dead[b + e];
     if (alive) {
-      IRow     k    = load_irow(&bkt_row[b + e]);
-      uint32_t less = 0;
+      IRow           k    = load_irow(&bkt_row[b + e]);
+      const uint32_t kix  = k.pf & PF_POS_MASK;
+      uint32_t       less = 0;
       for (uint32_t q = 0; q < n; ++q) {
         const IRow o = load_irow(&bkt_row[b + q]);
         if (!bkt_dead[b + q]) less += key_less(o.n_lo, o.n_hi, o.other, k.n_lo, k.n_hi, k.other) ? 1u : 0u;
@@ -458,9 +460,9 @@ __global__ __launch_bounds__(256) void k_sort_read(const uint32_t *read_off, con
       if (fast) {
         IRow w  = k;
         w.other = r;
-        store_irow(&by_anchor[bkt_idx[b + e]], w);
+        store_irow(&by_anchor[kix], w);
       } else {
-        alive_rank[bkt_idx[b + e]] = less;
+        alive_rank[kix] = less;
         atomicAdd(&anchor_cnt[k.other], 1u);
       }
     }
@@ -1998,15 +2000,15 @@ void launch_read_facts(hipStream_t st, const msgpu_row *rows, const uint64_t *fi
                        reinterpret_cast<const unsigned long long *>(first_key), V, read_len, read_first, err);
 }
 void launch_scatter_read(hipStream_t st, const msgpu_row *rows, uint64_t n, const uint32_t *read_off, uint32_t *cursor,
-                         IRow *bkt_row, uint32_t *bkt_idx) {
+                         IRow *bkt_row) {
   if (n)
-    hipLaunchKernelGGL(k_scatter_read, grid1(n, 256), dim3(256), 0, st, rows, n, read_off, cursor, bkt_row, bkt_idx);
+    hipLaunchKernelGGL(k_scatter_read, grid1(n, 256), dim3(256), 0, st, rows, n, read_off, cursor, bkt_row);
 }
 void launch_sort_read(hipStream_t st, const uint32_t *read_off, const uint32_t *cnt_read, uint32_t V, const IRow *bkt_row,
-                      const uint32_t *bkt_idx, IRow *by_read, uint32_t *read_cnt, uint32_t *alive_rank,
+                      IRow *by_read, uint32_t *read_cnt, uint32_t *alive_rank,
                       uint32_t *anchor_cnt, uint8_t *bkt_dead, uint32_t *flags, IRow *by_anchor) {
   if (V)
-    hipLaunchKernelGGL(k_sort_read, grid1(V, 4), dim3(256), 0, st, read_off, cnt_read, V, bkt_row, bkt_idx, by_read,
+    hipLaunchKernelGGL(k_sort_read, grid1(V, 4), dim3(256), 0, st, read_off, cnt_read, V, bkt_row, by_read,
                        read_cnt, alive_rank, anchor_cnt, bkt_dead, flags, by_anchor);
 }
 void launch_select_anchor_off(hipStream_t st, const uint32_t *flags, const uint32_t *fast_off, const uint32_t *gen_off,
