@@ -66,6 +66,7 @@ struct msgpu_ctx {
   char         err[512]   = {0};
   State        state      = ST_CREATED;
   uint32_t     shard = 0, nshards = 1;
+  uint64_t    *h_scalars = nullptr; // pinned mirror of `scalars`: every read-back is ONE copy of the whole block
   uint32_t     decl_V = 0, decl_A = 0; // msgpu_set_id_space: id counts declared by the caller (0 = find them)
 
   // loaded rows
@@ -124,6 +125,16 @@ int fail(msgpu_ctx *c, int code, const char *fmt, ...) {
 #define ENSURE(c, buf, bytes) HIPCHK(c, (c)->buf.ensure(bytes))
 
 template <class T> T *scalar(msgpu_ctx *c, int slot) { return reinterpret_cast<T *>(c->scalars.as<uint64_t>() + slot); }
+// host value of a scalar slot after read_scalars()
+template <class T> const T *host_scalar(const msgpu_ctx *c, int slot) { return reinterpret_cast<const T *>(c->h_scalars + slot); }
+// One copy of the whole scalar block into pinned memory + a stream synchronisation.  (Separate 4-byte copies into
+// pageable host variables cost ~20 us each on this stack; there were up to three per read-back.)
+int read_scalars(msgpu_ctx *c, hipEvent_t mark = nullptr) {
+  HIPCHK(c, hipMemcpyAsync(c->h_scalars, c->scalars.p, SC_COUNT * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+  if (mark) HIPCHK(c, hipEventRecord(mark, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return MSGPU_OK;
+}
 
 void release_all(msgpu_ctx *c) {
   DevBuf *all[] = {&c->g_deg, &c->g_off, &c->g_adj, &c->g_cand, &c->g_sane, &c->g_out, &c->rows_in, &c->cnt_read, &c->first_key, &c->read_off, &c->cursor, &c->bkt_key,
@@ -150,11 +161,9 @@ int build_index_once(msgpu_ctx *c, bool force_generic, uint32_t *ix_flags_out) {
     c->A = c->decl_A;
   } else {
     launch_max_ids(st, c->d_rows, n, scalar<uint32_t>(c, SC_MAXIDS));
-    uint32_t maxids[2] = {0, 0};
-    HIPCHK(c, hipMemcpyAsync(maxids, scalar<uint32_t>(c, SC_MAXIDS), sizeof(maxids), hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipStreamSynchronize(st));
-    c->V = maxids[0];
-    c->A = maxids[1];
+    if (int rc = read_scalars(c)) return rc;
+    c->V = host_scalar<uint32_t>(c, SC_MAXIDS)[0];
+    c->A = host_scalar<uint32_t>(c, SC_MAXIDS)[1];
   }
   const uint32_t V = c->V, A = c->A;
 
@@ -217,12 +226,9 @@ int build_index_once(msgpu_ctx *c, bool force_generic, uint32_t *ix_flags_out) {
                            c->anchor_off.as<uint32_t>(), scalar<uint32_t>(c, SC_NALIVE), static_cast<uint32_t>(n));
   HIPCHK(c, hipGetLastError());
 
-  uint32_t err = 0, n_alive = 0, ixf = 0;
-  HIPCHK(c, hipMemcpyAsync(&err, scalar<uint32_t>(c, SC_ERR), 4, hipMemcpyDeviceToHost, st));
-  HIPCHK(c, hipMemcpyAsync(&n_alive, scalar<uint32_t>(c, SC_NALIVE), 4, hipMemcpyDeviceToHost, st));
-  HIPCHK(c, hipMemcpyAsync(&ixf, d_flags, 4, hipMemcpyDeviceToHost, st));
-  HIPCHK(c, hipEventRecord(c->ev[1], st));
-  HIPCHK(c, hipStreamSynchronize(st));
+  if (int rc = read_scalars(c, c->ev[1])) return rc;
+  const uint32_t err = *host_scalar<uint32_t>(c, SC_ERR), ixf = *host_scalar<uint32_t>(c, SC_IXFLAGS);
+  uint32_t       n_alive = *host_scalar<uint32_t>(c, SC_NALIVE);
   if (err & 2u)
     return fail(c, MSGPU_E_IDS, "a row has an id outside the declared id space (%u reads, %u anchors)", V, A);
   if ((ixf & ~IXF_DUPS) != 0 && !(err & 1u)) {
@@ -238,9 +244,8 @@ int build_index_once(msgpu_ctx *c, bool force_generic, uint32_t *ix_flags_out) {
                        c->bkt2_line.as<uint32_t>(), c->d_rows, c->alive_rank.as<uint32_t>(), c->by_anchor.as<IRow>(),
                        d_flags);
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipMemcpyAsync(&n_alive, scalar<uint32_t>(c, SC_NALIVE), 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipEventRecord(c->ev[1], st));
-    HIPCHK(c, hipStreamSynchronize(st));
+    if (int rc = read_scalars(c, c->ev[1])) return rc;
+    n_alive = *host_scalar<uint32_t>(c, SC_NALIVE);
   }
   c->n_alive    = n_alive;
   *ix_flags_out = ixf;
@@ -317,6 +322,11 @@ int msgpu_create(int device, const msgpu_params *params, msgpu_ctx **out) {
     return MSGPU_E_HIP;
   }
   c->stream = c->own_stream;
+  if (hipHostMalloc(reinterpret_cast<void **>(&c->h_scalars), SC_COUNT * sizeof(uint64_t), hipHostMallocDefault) != hipSuccess) {
+    c->h_scalars = nullptr;
+    msgpu_destroy(c);
+    return MSGPU_E_NOMEM;
+  }
   {
     const char *nf = getenv("MSGPU_NO_FASTPATH"); // test hook: force the full pair sweep on every edge
     c->fast_path   = !(nf && nf[0] == '1');
@@ -350,6 +360,7 @@ void msgpu_destroy(msgpu_ctx *c) {
     (void)hipStreamDestroy(c->side_stream);
   }
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+  if (c->h_scalars) (void)hipHostFree(c->h_scalars);
   delete c;
 }
 
@@ -439,10 +450,9 @@ int msgpu_calculate_edges(msgpu_ctx *c) {
   launch_classify_reads(st, c->read_cnt.as<uint32_t>(), c->bound.as<uint32_t>(), V, c->shard, c->nshards, l0, l1, l2,
                         l3, scalar<uint32_t>(c, SC_NLISTS));
   HIPCHK(c, hipGetLastError());
-  uint64_t total_bound = 0;
-  HIPCHK(c, hipMemcpyAsync(&total_bound, scalar<uint64_t>(c, SC_TOTAL_A), 8, hipMemcpyDeviceToHost, st));
-  HIPCHK(c, hipMemcpyAsync(c->n_list, scalar<uint32_t>(c, SC_NLISTS), 16, hipMemcpyDeviceToHost, st));
-  HIPCHK(c, hipStreamSynchronize(st)); // sizes of the candidate scratch
+  if (int rc = read_scalars(c)) return rc; // sizes of the candidate scratch
+  const uint64_t total_bound = *host_scalar<uint64_t>(c, SC_TOTAL_A);
+  for (int k = 0; k < 4; ++k) c->n_list[k] = host_scalar<uint32_t>(c, SC_NLISTS)[k];
   c->total_bound = total_bound;
 
   const size_t tb = total_bound ? total_bound : 1;
@@ -486,10 +496,8 @@ int msgpu_calculate_edges(msgpu_ctx *c) {
   exclusive_scan<uint64_t>(st, c->n_visit_arr.as<uint32_t>(), V, c->visit_base.as<uint64_t>(),
                            c->scan_tmp.as<uint64_t>(), scalar<uint64_t>(c, SC_TOTAL_C));
   HIPCHK(c, hipGetLastError());
-  uint64_t tot[3] = {0, 0, 0}, big[2] = {0, 0};
-  HIPCHK(c, hipMemcpyAsync(tot, scalar<uint64_t>(c, SC_TOTAL_A), 24, hipMemcpyDeviceToHost, st));
-  HIPCHK(c, hipMemcpyAsync(big, scalar<uint64_t>(c, SC_BIGSTATS), 16, hipMemcpyDeviceToHost, st));
-  HIPCHK(c, hipStreamSynchronize(st)); // sizes of the edge / EdgeMatch tables
+  if (int rc = read_scalars(c)) return rc; // sizes of the edge / EdgeMatch tables
+  const uint64_t *tot = host_scalar<uint64_t>(c, SC_TOTAL_A), *big = host_scalar<uint64_t>(c, SC_BIGSTATS);
   c->n_big_edges = big[0];
   c->n_big_ems   = big[1];
   c->n_ems   = tot[0];
@@ -589,7 +597,6 @@ int msgpu_chaining_and_overlaps(msgpu_ctx *c) {
   HIPCHK(c, hipGetLastError());
   if (n_big) HIPCHK(c, hipStreamWaitEvent(st, c->ev_side[1], 0));
 
-  uint64_t tot[2] = {0, 0};
   exclusive_scan<uint64_t>(st, c->edge_norders.as<uint32_t>(), E, c->order_base.as<uint64_t>(),
                            c->scan_tmp.as<uint64_t>(), scalar<uint64_t>(c, SC_TOTAL_A));
   exclusive_scan<uint64_t>(st, c->edge_nids.as<uint32_t>(), E, c->ids_base.as<uint64_t>(), c->scan_tmp.as<uint64_t>(),
@@ -597,9 +604,9 @@ int msgpu_chaining_and_overlaps(msgpu_ctx *c) {
   exclusive_scan<uint64_t>(st, c->edge_fast.as<uint32_t>(), E, c->visit_base.as<uint64_t>(),
                            c->scan_tmp.as<uint64_t>(), scalar<uint64_t>(c, SC_TOTAL_C));
   HIPCHK(c, hipEventRecord(c->ev[7], st));
-  HIPCHK(c, hipMemcpyAsync(&c->n_edges_fast, scalar<uint64_t>(c, SC_TOTAL_C), 8, hipMemcpyDeviceToHost, st));
-  HIPCHK(c, hipMemcpyAsync(tot, scalar<uint64_t>(c, SC_TOTAL_A), 16, hipMemcpyDeviceToHost, st));
-  HIPCHK(c, hipStreamSynchronize(st)); // sizes of the order / id tables
+  if (int rc = read_scalars(c)) return rc; // sizes of the order / id tables
+  c->n_edges_fast     = *host_scalar<uint64_t>(c, SC_TOTAL_C);
+  const uint64_t *tot = host_scalar<uint64_t>(c, SC_TOTAL_A);
   c->n_orders = tot[0];
   c->n_ids    = tot[1];
   ENSURE(c, orders, (c->n_orders ? c->n_orders : 1) * sizeof(msgpu_order));
