@@ -10,6 +10,7 @@ struct msgpu_assembly {
   msgpu_seqctx                 *ctx = nullptr;
   std::vector<msgpu_row>        rows;      // msgpu_assembly_set_rows: the MatchMap's VertexMatches, sorted by
   std::vector<uint64_t>         row_keys;  //   (read id << 32 | anchor id, line); row_keys[i] belongs to rows[i]
+  std::vector<uint64_t>         row_start; //   rows of read r are rows[row_start[r] .. row_start[r + 1])
   std::vector<msgpu_copy>       pieces; // dst_off = position in the raw buffer (records start 16-B aligned)
   uint64_t                      raw_bytes = 0;
   std::vector<msgpu_path_info>  paths;

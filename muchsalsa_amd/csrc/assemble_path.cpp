@@ -170,9 +170,11 @@ struct PathLayout {
     const uint64_t key = (static_cast<uint64_t>(read) << 32) | anchor;
     auto           it  = vm.find(key);
     if (it != vm.end()) return it->second;
-    if (shared) {
-      auto lo = std::lower_bound(shared->row_keys.begin(), shared->row_keys.end(), key);
-      if (lo != shared->row_keys.end() && *lo == key) return &shared->rows[static_cast<size_t>(lo - shared->row_keys.begin())];
+    if (shared && static_cast<size_t>(read) + 1 < shared->row_start.size()) { // the read's own ~50 rows only
+      const auto b  = shared->row_keys.begin() + static_cast<long>(shared->row_start[read]);
+      const auto e  = shared->row_keys.begin() + static_cast<long>(shared->row_start[read + 1]);
+      const auto lo = std::lower_bound(b, e, key);
+      if (lo != e && *lo == key) return &shared->rows[static_cast<size_t>(lo - shared->row_keys.begin())];
     }
     throw LayoutError("no VertexMatch for read " + std::to_string(read) + " on anchor " + std::to_string(anchor));
   }
@@ -759,18 +761,41 @@ int msgpu_assembly_set_rows(msgpu_assembly *a, const msgpu_row *rows, size_t n_r
       for (size_t i = 0; i < n_rows; ++i) order[cur[rows[i].read_id]++] = static_cast<uint32_t>(i);
     }
     auto key = [&](uint32_t i) { return (static_cast<uint64_t>(rows[i].read_id) << 32) | rows[i].anchor_id; };
-    for (size_t r = 0; r + 1 < start.size(); ++r)
-      std::sort(order.begin() + static_cast<long>(start[r]), order.begin() + static_cast<long>(start[r + 1]),
-                [&](uint32_t x, uint32_t y) { // lowest line first: MatchMap.cpp:64-80
-                  return rows[x].anchor_id != rows[y].anchor_id ? rows[x].anchor_id < rows[y].anchor_id
-                                                                : rows[x].line < rows[y].line;
-                });
     a->rows.resize(n_rows);
     a->row_keys.resize(n_rows);
-    for (size_t i = 0; i < n_rows; ++i) {
-      a->rows[i]     = rows[order[i]];
-      a->row_keys[i] = key(order[i]);
+    // per read: order its rows, then gather them -- independent per read, so split the reads over host threads
+    const size_t n_reads = start.size() - 1;
+    auto         work    = [&](size_t r0, size_t r1) {
+      for (size_t r = r0; r < r1; ++r)
+        std::sort(order.begin() + static_cast<long>(start[r]), order.begin() + static_cast<long>(start[r + 1]),
+                  [&](uint32_t x, uint32_t y) { // lowest line first: MatchMap.cpp:64-80
+                    return rows[x].anchor_id != rows[y].anchor_id ? rows[x].anchor_id < rows[y].anchor_id
+                                                                  : rows[x].line < rows[y].line;
+                  });
+      for (size_t i = start[r0]; i < start[r1]; ++i) {
+        a->rows[i]     = rows[order[i]];
+        a->row_keys[i] = key(order[i]);
+      }
+    };
+    unsigned nt = std::thread::hardware_concurrency();
+    nt          = nt == 0 ? 1 : (nt > 16 ? 16 : nt);
+    if (n_rows < (1u << 16) || nt == 1) {
+      work(0, n_reads);
+    } else {
+      std::vector<std::thread> pool;
+      size_t                   r0 = 0;
+      for (unsigned t = 0; t < nt; ++t) { // equal shares of ROWS, cut at read boundaries
+        const uint64_t want = n_rows * (t + 1) / nt;
+        size_t         r1   = t + 1 == nt ? n_reads
+                                          : static_cast<size_t>(std::upper_bound(start.begin(), start.end(), want) - start.begin()) - 1;
+        if (r1 < r0) r1 = r0;
+        if (r1 > n_reads) r1 = n_reads;
+        pool.emplace_back(work, r0, r1);
+        r0 = r1;
+      }
+      for (auto &th : pool) th.join();
     }
+    a->row_start = std::move(start);
   } catch (std::bad_alloc const &) { return MSGPU_E_NOMEM; }
   return MSGPU_OK;
 }

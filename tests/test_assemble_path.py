@@ -116,7 +116,19 @@ def test_chains_match_oracle_and_paf_text(world):
     w = world
     order = np.argsort(w.read_start)
     asm, want = Assembly(w.store), []
-    asm.set_rows(w.rows[::-1])  # any order: the table is indexed by (read, anchor, line)
+    # any order: the table is indexed by (read, anchor, line).  Padded past 2^16 rows so that the multi-threaded
+    # install runs, with rows of foreign reads and with higher-line duplicates of real pairs (which must lose).
+    rng = np.random.default_rng(3)
+    pad = np.zeros(70_000, dtype=w.rows.dtype)
+    pad["read_id"] = int(w.rows["read_id"].max()) + 1 + rng.integers(0, 500, len(pad))
+    pad["anchor_id"] = rng.integers(0, int(w.rows["anchor_id"].max()) + 1, len(pad))
+    pad["line"] = 10**6 + np.arange(len(pad))
+    dup = w.rows[rng.choice(len(w.rows), 50, replace=False)].copy()
+    dup["line"] += 2 * 10**6
+    dup["n_lo"] += 11
+    table = np.concatenate([w.rows[::-1], pad, dup])
+    rng.shuffle(table)
+    asm.set_rows(table)
     for k, s in enumerate(order[:60:4]):
         for flip in (False, True):
             path, steps = w.chain(int(s), max_len=8, flip_all=flip)
