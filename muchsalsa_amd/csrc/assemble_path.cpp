@@ -12,9 +12,15 @@
 // creation order, successors / predecessors ascending id, tap entries ascending id, std::sort ties stable.
 #include <algorithm>
 #include <atomic>
+#include <chrono>
+#include <pthread.h>
+#include <condition_variable>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <map>
+#include <mutex>
 #include <new>
 #include <set>
 #include <stdexcept>
@@ -143,6 +149,18 @@ struct Adg { // the anchor DiGraph of one path; vertices are registry ids 0..n-1
   }
 };
 
+// The same recursion on bit masks for clusters of up to 64 path edges (node i = i-th edge of the cluster, ascending):
+// vs keeps its ascending order through the recursion exactly as the vectors below do, and only the MEMBERS of the
+// returned clique are used by the caller, so a mask carries everything.
+uint64_t ramsey_mask(const uint64_t *adj, uint64_t vs) {
+  if (!vs) return 0;
+  const int      first = __builtin_ctzll(vs);
+  const uint64_t rest  = vs & (vs - 1);
+  const uint64_t cn    = ramsey_mask(adj, rest & adj[first]) | (1ull << first);
+  const uint64_t cnn   = ramsey_mask(adj, rest & ~adj[first]);
+  return __builtin_popcountll(cn) >= __builtin_popcountll(cnn) ? cn : cnn;
+}
+
 // ramseyR2 / getAnchorCliques, ap.cpp:91-138, on the small interval-intersection graph of one anchor
 std::vector<uint32_t> ramsey(const std::map<uint32_t, std::set<uint32_t>> &adj, const std::vector<uint32_t> &vs) {
   if (vs.empty()) return {};
@@ -216,7 +234,7 @@ struct PathLayout {
 };
 
 struct Candidate { // ap.cpp:621-629 (edges[i] is always path edge i)
-  std::set<uint32_t>                 open, visited;
+  std::vector<uint32_t>              open, visited; // the reference's id sets, kept as sorted unique vectors
   uint64_t                           score = 0, kinks = 0;
   std::vector<uint32_t>              orders; // index into in.orders
   std::vector<std::vector<uint32_t>> modifiers;
@@ -299,9 +317,30 @@ struct PathResult {
   std::vector<Record> queries;
   msgpu_path_info     info{};
   int                 left_most = 0;
+  std::string         paf; // the path's temp_1.align.paf lines, formatted by the layout thread
+};
+
+// MSGPU_ASM_DEBUG=1: nanoseconds per layout section, summed over all paths and threads, printed by msgpu_assembly_free
+std::atomic<uint64_t> g_sec_ns[10]; // 0..7 layout sections, 8 = wall time of the layout fan-out, 9 = commits
+const bool            g_sec_on = [] {
+  const char *e = getenv("MSGPU_ASM_DEBUG");
+  return e && e[0] == '1';
+}();
+struct SecTimer {
+  std::chrono::steady_clock::time_point t;
+  SecTimer() {
+    if (g_sec_on) t = std::chrono::steady_clock::now();
+  }
+  void mark(int i) {
+    if (!g_sec_on) return;
+    const auto n = std::chrono::steady_clock::now();
+    g_sec_ns[i] += static_cast<uint64_t>(std::chrono::duration_cast<std::chrono::nanoseconds>(n - t).count());
+    t = n;
+  }
 };
 
 PathResult layout_path(const msgpu_assembly *a, const msgpu_path_input &in) {
+  SecTimer sec;
   msgpu_seqctx *ctx = a->ctx;
   PathLayout    L(ctx, in);
   L.shared = a;
@@ -331,6 +370,7 @@ PathResult layout_path(const msgpu_assembly *a, const msgpu_path_input &in) {
     return it->second;
   };
 
+  sec.mark(0);
   // ---- which EdgeOrder per path edge, ap.cpp:631-706 -----------------------------------------------------------------
   std::vector<Candidate> candidates(1);
   for (uint32_t i = 0; i < n_edges; ++i) {
@@ -342,10 +382,14 @@ PathResult layout_path(const msgpu_assembly *a, const msgpu_path_input &in) {
         Candidate n;
         std::vector<uint32_t> mods;
         for (uint32_t id : ids)
-          if (!c.open.count(id) && c.visited.count(id)) mods.push_back(id);
-        n.open.insert(ids.begin(), ids.end());
-        n.visited = c.visited;
-        n.visited.insert(ids.begin(), ids.end());
+          if (!std::binary_search(c.open.begin(), c.open.end(), id) && std::binary_search(c.visited.begin(), c.visited.end(), id))
+            mods.push_back(id);
+        n.open = ids;
+        std::sort(n.open.begin(), n.open.end());
+        n.open.erase(std::unique(n.open.begin(), n.open.end()), n.open.end());
+        n.visited.resize(c.visited.size() + n.open.size());
+        n.visited.erase(std::set_union(c.visited.begin(), c.visited.end(), n.open.begin(), n.open.end(), n.visited.begin()),
+                        n.visited.end());
         n.score = c.score + in.orders[oi].score;
         n.kinks = c.kinks + mods.size();
         n.orders = c.orders;
@@ -369,6 +413,7 @@ PathResult layout_path(const msgpu_assembly *a, const msgpu_path_input &in) {
   const Candidate &best =
       *std::find_if(candidates.begin(), candidates.end(), [&](const Candidate &c) { return c.kinks == mk && c.score == ms; });
 
+  sec.mark(1);
   // ---- anchor clusters -> cliques -> common overlaps, :708-719 + getClusterAnchors :140-189 ----------------------------
   std::map<uint32_t, std::vector<uint32_t>> clusters;
   for (uint32_t idx = 0; idx < n_edges; ++idx) {
@@ -379,6 +424,44 @@ PathResult layout_path(const msgpu_assembly *a, const msgpu_path_input &in) {
   std::vector<std::unordered_map<uint32_t, uint32_t>> cluster_modifier(n_edges);
   for (const auto &cl : clusters) {
     const uint32_t                         anchor = cl.first;
+    if (cl.second.size() == 1) { // one path edge: one clique, its overlap (what the general code below yields)
+      cluster_modifier[cl.second[0]][anchor] = 0;
+      id2ov[Key(anchor, 0)]                  = em_of(cl.second[0], anchor);
+      continue;
+    }
+    const size_t m = cl.second.size();
+    if (m <= 64 && std::adjacent_find(cl.second.begin(), cl.second.end(), std::greater_equal<uint32_t>()) == cl.second.end()) {
+      // strictly ascending edge list (no anchor listed twice by one order): the same cliques on bit masks
+      Ov       ovs[64];
+      uint64_t madj[64];
+      for (size_t i = 0; i < m; ++i) {
+        ovs[i]  = em_of(cl.second[i], anchor);
+        madj[i] = 0;
+      }
+      for (size_t i = 0; i < m; ++i)
+        for (size_t j = 0; j < i; ++j)
+          if (std::max(ovs[i].first, ovs[j].first) <= std::min(ovs[i].second, ovs[j].second)) {
+            madj[i] |= 1ull << j;
+            madj[j] |= 1ull << i;
+          }
+      uint64_t left = m == 64 ? ~0ull : ((1ull << m) - 1);
+      uint32_t idx  = 0;
+      while (left) {
+        const uint64_t clique = ramsey_mask(madj, left); // never empty while nodes are left
+        left &= ~clique;
+        Ov   common;
+        bool have = false;
+        for (uint64_t c = clique; c; c &= c - 1) {
+          const int i = __builtin_ctzll(c);
+          cluster_modifier[cl.second[static_cast<size_t>(i)]][anchor] = idx;
+          common = have ? Ov(std::max(common.first, ovs[i].first), std::min(common.second, ovs[i].second)) : ovs[i];
+          have   = true;
+        }
+        id2ov[Key(anchor, idx)] = common;
+        ++idx;
+      }
+      continue;
+    }
     std::map<uint32_t, std::set<uint32_t>> adj;
     for (uint32_t e1 : cl.second) {
       adj[e1];
@@ -415,6 +498,7 @@ PathResult layout_path(const msgpu_assembly *a, const msgpu_path_input &in) {
     }
   }
 
+  sec.mark(2);
   // ---- anchors per read in read order, :721-752 --------------------------------------------------------------------------
   std::vector<std::vector<Info>>          vertex_info(n_edges + 1);
   std::unordered_map<uint32_t, uint32_t> match_modifiers;
@@ -430,6 +514,7 @@ PathResult layout_path(const msgpu_assembly *a, const msgpu_path_input &in) {
     }
   }
 
+  sec.mark(3);
   // ---- anchor DAG, anchor sequences, flanks, :754-853 ----------------------------------------------------------------------
   std::map<std::tuple<uint32_t, uint32_t, uint32_t>, uint32_t> registry; // tupleTuple2Id -> Registry id
   Adg                                                          adg;
@@ -498,6 +583,7 @@ PathResult layout_path(const msgpu_assembly *a, const msgpu_path_input &in) {
   }
   const uint32_t n_anchors = static_cast<uint32_t>(adg.succ.size());
 
+  sec.mark(4);
   // ---- sequences between neighbouring anchors, :855-863 + alignAnchorRegion :581-611 ---------------------------------------
   std::vector<int>              distances(adg.edges.size());
   std::vector<std::vector<Seg>> sequences(adg.edges.size());
@@ -526,6 +612,7 @@ PathResult layout_path(const msgpu_assembly *a, const msgpu_path_input &in) {
     }
   }
 
+  sec.mark(5);
   // ---- placement, :865-1010 -----------------------------------------------------------------------------------------------------
   const std::vector<uint32_t> order = adg.sort_topologically();
   if (order.empty() || order.size() != n_anchors) throw LayoutError("the anchor graph of the path has a cycle");
@@ -625,6 +712,7 @@ PathResult layout_path(const msgpu_assembly *a, const msgpu_path_input &in) {
     }
   }
 
+  sec.mark(6);
   // ---- output records, :1034-1361 ----------------------------------------------------------------------------------------------
   PathResult res;
   res.target    = glob.seg();
@@ -714,6 +802,7 @@ PathResult layout_path(const msgpu_assembly *a, const msgpu_path_input &in) {
   res.info.border_lo      = glob.lo();
   res.info.border_hi      = glob.hi();
   res.info.asm_idx        = in.asm_idx;
+  sec.mark(7);
   return res;
 }
 
@@ -741,6 +830,13 @@ int msgpu_assembly_create(msgpu_seqctx *ctx, msgpu_assembly **out) {
 }
 
 void msgpu_assembly_free(msgpu_assembly *a) {
+  if (a && g_sec_on) {
+    static const char *const names[10] = {"inputs", "edge orders", "cliques", "anchors per read", "anchor DAG + flanks",
+                                          "between anchors", "placement", "records", "add_paths: layout (wall)",
+                                          "add_paths: commit (wall)"};
+    for (int i = 0; i < 10; ++i)
+      fprintf(stderr, "[msgpu asm] %-22s %10.3f ms\n", names[i], static_cast<double>(g_sec_ns[i].exchange(0)) * 1e-6);
+  }
   if (a && a->release) a->release(a);
   delete a;
 }
@@ -838,12 +934,26 @@ int try_layout(const msgpu_assembly *a, const msgpu_path_input *in, PathResult &
 }
 
 // append a laid-out path to the assembly: raw layout, records, PAF text (OutputWriter order = path order)
+// the path's lines of temp_1.align.paf (ap.cpp:1041-1056 and the four other record sites): one line per query
+void format_paf(PathResult &r, int32_t asm_idx) {
+  const std::string tname = "muchsalsa_" + std::to_string(asm_idx);
+  uint32_t          qi    = 0;
+  for (const Record &q : r.queries) {
+    std::string name = msgpu::query_header(q.kind, asm_idx, qi++);
+    name             = name.substr(1, name.size() - 2); // without '>' and '\n'
+    char line[512];
+    const long long len = static_cast<long long>(q.seg.len), span = static_cast<long long>(q.rb - q.lb + 1);
+    snprintf(line, sizeof(line), "%s\t%lld\t0\t%lld\t+\t%s\t%llu\t%lld\t%lld\t%lld\t%lld\t255\n", name.c_str(), len, len,
+             tname.c_str(), static_cast<unsigned long long>(r.target.len), static_cast<long long>(q.lb),
+             static_cast<long long>(q.rb), span, span);
+    r.paf += line;
+  }
+}
+
 int commit(msgpu_assembly *a, PathResult &r, int32_t asm_idx) {
   try {
     r.info.target_raw_off = place(a, r.target);
     r.info.query_begin    = static_cast<uint32_t>(a->queries.size());
-    const std::string tname = "muchsalsa_" + std::to_string(asm_idx);
-    uint32_t          qi    = 0;
     for (const Record &q : r.queries) {
       msgpu_query_info info{};
       info.len     = q.seg.len;
@@ -853,19 +963,93 @@ int commit(msgpu_assembly *a, PathResult &r, int32_t asm_idx) {
       info.kind    = q.kind;
       info.path    = static_cast<uint32_t>(a->paths.size());
       a->queries.push_back(info);
-      std::string name = msgpu::query_header(q.kind, asm_idx, qi++);
-      name             = name.substr(1, name.size() - 2); // without '>' and '\n'
-      char line[512];
-      const long long len = static_cast<long long>(q.seg.len), span = static_cast<long long>(q.rb - q.lb + 1);
-      snprintf(line, sizeof(line), "%s\t%lld\t0\t%lld\t+\t%s\t%llu\t%lld\t%lld\t%lld\t%lld\t255\n", name.c_str(), len, len,
-               tname.c_str(), static_cast<unsigned long long>(r.target.len), static_cast<long long>(q.lb),
-               static_cast<long long>(q.rb), span, span);
-      a->paf += line;
     }
+    if (r.paf.empty() && !r.queries.empty()) format_paf(r, asm_idx);
+    a->paf += r.paf;
     r.info.query_end = static_cast<uint32_t>(a->queries.size());
     a->paths.push_back(r.info);
   } catch (std::bad_alloc const &) { return MSGPU_E_NOMEM; }
   return MSGPU_OK;
+}
+
+// Host threads of msgpu_assembly_add_paths.  Starting 15 std::threads costs about as much as laying out a hundred
+// paths, so they are started once per process and parked on a condition variable between calls (one fan-out at a
+// time; the pool is leaked at exit on purpose -- parked threads need no clean-up -- and forgotten in a forked child).
+class LayoutPool {
+ public:
+  ~LayoutPool() {
+    {
+      std::lock_guard<std::mutex> g(m_);
+      stop_ = true;
+    }
+    cv_work_.notify_all();
+    for (auto &t : th_) t.join();
+  }
+  // runs job() on `helpers` pool threads and on the caller; returns when all of them are done
+  void run(uint32_t helpers, const std::function<void()> &job) {
+    while (th_.size() < helpers) th_.emplace_back([this, idx = static_cast<uint32_t>(th_.size())] { loop(idx); });
+    {
+      std::lock_guard<std::mutex> g(m_);
+      job_     = &job;
+      helpers_ = helpers;
+      pending_ = helpers;
+      ++gen_;
+    }
+    cv_work_.notify_all();
+    job();
+    std::unique_lock<std::mutex> g(m_);
+    cv_done_.wait(g, [this] { return pending_ == 0; });
+    job_ = nullptr;
+  }
+
+ private:
+  void loop(uint32_t idx) {
+    uint64_t seen = 0;
+    for (;;) {
+      const std::function<void()> *job = nullptr;
+      {
+        std::unique_lock<std::mutex> g(m_);
+        cv_work_.wait(g, [&] { return stop_ || gen_ != seen; });
+        if (stop_) return;
+        seen = gen_;
+        if (idx >= helpers_) continue; // this call asked for fewer threads
+        job = job_;
+      }
+      (*job)();
+      {
+        std::lock_guard<std::mutex> g(m_);
+        --pending_;
+      }
+      cv_done_.notify_one();
+    }
+  }
+
+ public:
+  std::mutex run_lock; // one fan-out at a time
+
+ private:
+  std::vector<std::thread>     th_;
+  std::mutex                   m_;
+  std::condition_variable      cv_work_, cv_done_;
+  const std::function<void()> *job_     = nullptr;
+  uint32_t                     helpers_ = 0, pending_ = 0;
+  uint64_t                     gen_     = 0;
+  bool                         stop_    = false;
+};
+
+std::atomic<LayoutPool *> g_pool{nullptr};
+std::once_flag            g_pool_atfork;
+LayoutPool               *layout_pool() {
+  std::call_once(g_pool_atfork, [] { pthread_atfork(nullptr, nullptr, [] { g_pool.store(nullptr); }); });
+  LayoutPool *p = g_pool.load();
+  if (!p) {
+    LayoutPool *fresh = new LayoutPool();
+    if (g_pool.compare_exchange_strong(p, fresh))
+      p = fresh;
+    else
+      delete fresh; // another thread was first (it has no workers yet, so this is cheap)
+  }
+  return p;
 }
 
 } // namespace
@@ -894,20 +1078,33 @@ int msgpu_assembly_add_paths(msgpu_assembly *a, const msgpu_path_input *in, size
   std::vector<PathResult>  res;
   std::vector<std::string> msg;
   std::vector<int>         rc(n, MSGPU_OK);
+  SecTimer                 wall;
+  const auto               t_enter = std::chrono::steady_clock::now();
   try {
     res.resize(n);
     msg.resize(n);
-    std::atomic<size_t> next{0};
-    auto                work = [&]() {
-      for (size_t i = next.fetch_add(1); i < n; i = next.fetch_add(1)) rc[i] = try_layout(a, &in[i], res[i], msg[i]);
+    std::atomic<size_t>         next{0};
+    const std::function<void()> work = [&]() {
+      for (size_t i = next.fetch_add(1); i < n; i = next.fetch_add(1)) {
+        rc[i] = try_layout(a, &in[i], res[i], msg[i]);
+        if (rc[i] == MSGPU_OK) {
+          try {
+            format_paf(res[i], in[i].asm_idx);
+          } catch (std::bad_alloc const &) { rc[i] = MSGPU_E_NOMEM; }
+        }
+      }
     };
-    std::vector<std::thread> pool;
-    for (uint32_t t = 1; t < n_threads; ++t) pool.emplace_back(work);
-    work();
-    for (auto &t : pool) t.join();
+    if (n_threads > 1) {
+      LayoutPool                 &pool = *layout_pool();
+      std::lock_guard<std::mutex> one(pool.run_lock);
+      pool.run(n_threads - 1, work);
+    } else {
+      work();
+    }
   } catch (std::bad_alloc const &) { return MSGPU_E_NOMEM; } catch (std::system_error const &) {
     return MSGPU_E_NOMEM;
   }
+  wall.mark(8);
   int first_bad = MSGPU_OK;
   for (size_t i = 0; i < n; ++i) {
     if (rc[i] == MSGPU_OK) rc[i] = commit(a, res[i], in[i].asm_idx);
@@ -915,6 +1112,10 @@ int msgpu_assembly_add_paths(msgpu_assembly *a, const msgpu_path_input *in, size
     if (rc[i] != MSGPU_OK && a->err[0] == 0) snprintf(a->err, sizeof(a->err), "path %zu: %s", i, msg[i].c_str());
     if (rc[i] != MSGPU_OK && rc[i] != MSGPU_E_LAYOUT && first_bad == MSGPU_OK) first_bad = rc[i];
   }
+  wall.mark(9);
+  if (g_sec_on)
+    fprintf(stderr, "[msgpu asm] add_paths(%zu paths, %u threads) returned after %.3f ms\n", n, n_threads,
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_enter).count());
   return first_bad;
 }
 
