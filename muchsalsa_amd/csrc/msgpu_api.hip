@@ -89,8 +89,10 @@ struct msgpu_ctx {
   hipEvent_t  ev_side[2]  = {nullptr, nullptr};
   uint64_t    n_big_edges = 0, n_big_ems = 0;
   bool   fast_path = true;
+  bool   sub_wave  = true; // short edges share a wavefront (k_chain_sub); MSGPU_NO_SUBWAVE=1 sends them all to k_chain
+  uint32_t n_cls[3] = {0, 0, 0};
   uint64_t n_edges_fast = 0;
-  DevBuf ems, order_scr, ids_scr, edge_norders, edge_nids, order_base, ids_base, orders, ids, big_list, big_elems,
+  DevBuf ems, order_scr, ids_scr, edge_norders, edge_nids, order_base, ids_base, orders, ids, big_list, cls_list, big_elems,
       big_paths;
   DevBuf g_deg, g_off, g_adj, g_cand, g_sane, g_out; // findContractionEdges
 
@@ -104,7 +106,7 @@ namespace {
 // scalar slots in ctx->scalars (uint64 each)
 enum { SC_MAXIDS = 0 /*2 x u32*/, SC_ERR = 1, SC_TOTAL_A = 2, SC_TOTAL_B = 3, SC_TOTAL_C = 4, SC_NLISTS = 5 /*4 x u32, spans 5..6*/,
        SC_NBIG = 7, SC_NALIVE = 8, SC_IXFLAGS = 9, SC_BIGSTATS = 10 /*2 x u64*/, SC_BIGCUR = 12 /*2 x u64*/,
-       SC_COUNT = 16 };
+       SC_CLS = 14 /*3 x u32: edges per width class, spans 14..15*/, SC_COUNT = 16 };
 
 int fail(msgpu_ctx *c, int code, const char *fmt, ...) {
   va_list ap;
@@ -144,7 +146,7 @@ void release_all(msgpu_ctx *c) {
                    &c->bound, &c->cand_off, &c->cand_j, &c->cand_t, &c->scr_v2, &c->scr_start, &c->n_cand, &c->n_edge,
                    &c->n_visit_arr, &c->lists, &c->em_base, &c->edge_base, &c->visit_base, &c->edges, &c->edge_cand,
                    &c->big_key, &c->big_t, &c->big_r2s, &c->big_pfx, &c->pair_tab, &c->edge_fast, &c->big_off, &c->ems, &c->order_scr, &c->ids_scr,
-                   &c->edge_norders, &c->edge_nids, &c->order_base, &c->ids_base, &c->orders, &c->ids, &c->big_list,
+                   &c->edge_norders, &c->edge_nids, &c->order_base, &c->ids_base, &c->orders, &c->ids, &c->big_list, &c->cls_list,
                    &c->big_elems, &c->big_paths};
   for (DevBuf *b : all) b->release();
 }
@@ -330,6 +332,8 @@ int msgpu_create(int device, const msgpu_params *params, msgpu_ctx **out) {
   {
     const char *nf = getenv("MSGPU_NO_FASTPATH"); // test hook: force the full pair sweep on every edge
     c->fast_path   = !(nf && nf[0] == '1');
+    const char *ns = getenv("MSGPU_NO_SUBWAVE"); // test hook: one edge per wavefront whatever its size
+    c->sub_wave    = !(ns && ns[0] == '1');
   }
   for (auto &ev : c->ev)
     if (hipEventCreate(&ev) != hipSuccess) {
@@ -563,8 +567,8 @@ int msgpu_chaining_and_overlaps(msgpu_ctx *c) {
   ENSURE(c, edge_fast, (E + 1) * 4);
   {
     uint32_t *const zero[4]   = {c->edge_norders.as<uint32_t>(), c->edge_nids.as<uint32_t>(), c->edge_fast.as<uint32_t>(),
-                                 nullptr};
-    const uint32_t  n_zero[4] = {static_cast<uint32_t>(E + 1), static_cast<uint32_t>(E + 1), static_cast<uint32_t>(E + 1), 0};
+                                 scalar<uint32_t>(c, SC_CLS)};
+    const uint32_t  n_zero[4] = {static_cast<uint32_t>(E + 1), static_cast<uint32_t>(E + 1), static_cast<uint32_t>(E + 1), 4};
     uint32_t *const ones[2]   = {nullptr, nullptr};
     const uint32_t  n_ones[2] = {0, 0};
     launch_index_init(st, zero, n_zero, ones, n_ones);
@@ -591,8 +595,22 @@ int msgpu_chaining_and_overlaps(msgpu_ctx *c) {
                      c->big_elems.p, c->big_paths.p);
     HIPCHK(c, hipEventRecord(c->ev_side[1], c->side_stream));
   }
-  HIPCHK(c, hipEventRecord(c->ev[5], st));
-  launch_chain(st, a);
+  if (c->sub_wave && E) {
+    // width classes: <= 16 and 17..32 EdgeMatches share a wavefront four / two at a time, 33..64 take one each.  The
+    // class sizes have to come back before the launches (the big edges are already running on the side stream).
+    ENSURE(c, cls_list, 3 * (E + 1) * 4);
+    uint32_t *l16 = c->cls_list.as<uint32_t>(), *l32 = l16 + E + 1, *l64 = l32 + E + 1;
+    launch_list_edges_by_size(st, a.edges, E, l16, l32, l64, scalar<uint32_t>(c, SC_CLS));
+    if (int rc = read_scalars(c)) return rc;
+    for (int k = 0; k < 3; ++k) c->n_cls[k] = host_scalar<uint32_t>(c, SC_CLS)[k];
+    HIPCHK(c, hipEventRecord(c->ev[5], st));
+    launch_chain(st, a, l64, c->n_cls[2]); // the long ones first: the short classes fill the tail
+    launch_chain_sub(st, a, 32, l32, c->n_cls[1]);
+    launch_chain_sub(st, a, 16, l16, c->n_cls[0]);
+  } else {
+    HIPCHK(c, hipEventRecord(c->ev[5], st));
+    launch_chain(st, a, nullptr, 0);
+  }
   HIPCHK(c, hipEventRecord(c->ev[6], st));
   HIPCHK(c, hipGetLastError());
   if (n_big) HIPCHK(c, hipStreamWaitEvent(st, c->ev_side[1], 0));

@@ -1115,7 +1115,7 @@ __device__ __forceinline__ int paths_of_direction(unsigned long long act, bool d
   return np;
 }
 
-__global__ __launch_bounds__(256) void k_chain(ChainArgs a) {
+__global__ __launch_bounds__(256) void k_chain(ChainArgs a, const uint32_t *list, uint32_t n_list) {
   // per wave: the 64 ChainElem of the sweep, later (the elements are dead once the compatibility masks exist) the
   // path lists of both directions in the same bytes -- 14 KB per workgroup instead of 26 KB, so LDS no longer caps
   // the occupancy
@@ -1123,8 +1123,10 @@ __global__ __launch_bounds__(256) void k_chain(ChainArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned char s_wavebuf[4][sizeof(ChainElem) * 64];
   __shared__ uint64_t                                  s_cm[4][64];
   const int      wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const uint64_t e = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(blockIdx.x * 4 + wave));
-  if (e >= a.n_edges) return;
+  // list == nullptr: wave i takes edge i; else the edges of the list (the 33..64 class of k_list_edges_by_size)
+  const uint32_t slot = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(blockIdx.x * 4 + wave));
+  if (list ? slot >= n_list : slot >= a.n_edges) return;
+  const uint64_t e = list ? __builtin_amdgcn_readfirstlane(list[slot]) : slot;
   const msgpu_edge ed = a.edges[e];
   const uint32_t   n  = ed.em_cnt;
   if (n > 64) return; // handled by k_chain_big
@@ -1460,6 +1462,461 @@ __global__ __launch_bounds__(256) void k_chain(ChainArgs a) {
     a.edge_norders[e] = n_orders;
     a.edge_nids[e]    = n_ids;
     a.edges[e].shadow = shadow ? 1 : 0;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// chain, short edges: G = 64 / W edges share a wavefront, W = 16 or 32 lanes each (k_chain_sub<W>).
+//
+// k_chain spends a fixed ~550 vector instructions per edge outside the pair sweep and the DP (the element phase with
+// its six fp64 divisions, the path lists, the filters, getOverlap) whatever the edge's size, on 64 lanes of which an
+// edge with n EdgeMatches uses n.  Here every quantity that is wave-uniform in k_chain (the edge, its masks, counters,
+// the path being emitted) is uniform per GROUP of W lanes and lives in vector registers; wavefront masks (__ballot) are
+// cut to the group's W bits, broadcasts are ds_bpermute shuffles inside the group, and loops whose trip count depends
+// on the edge run to the largest count among the groups with the finished groups predicated off.  Same arithmetic in
+// the same order as k_chain, so the same bits.  Edges are assigned through a list built by k_list_edges_by_size.
+// ---------------------------------------------------------------------------------------------------------------------
+
+struct __attribute__((aligned(16))) SubPath { // a path of one direction; mask bit i = the group's i-th EdgeMatch
+  uint32_t mask, primary;
+  uint64_t score;
+};
+
+__device__ __forceinline__ double shfl_f64(double v, int src) {
+  const long long b  = __double_as_longlong(v);
+  const uint32_t  lo = __shfl(static_cast<uint32_t>(b), src), hi = __shfl(static_cast<uint32_t>(b >> 32), src);
+  return __longlong_as_double(static_cast<long long>((static_cast<unsigned long long>(hi) << 32) | lo));
+}
+
+// the W bits of a wavefront mask that belong to this lane's group
+template <int W> __device__ __forceinline__ uint32_t group_bits(unsigned long long m, int gbase) {
+  return static_cast<uint32_t>(m >> gbase) & (W == 32 ? 0xffffffffu : ((1u << W) - 1u));
+}
+
+// paths_of_direction for a group of W lanes; returns the group's path count (group-uniform, 0 for an empty direction)
+template <int W>
+__device__ __forceinline__ uint32_t paths_of_direction_sub(uint32_t act, bool direction, int sl, int gbase, double pop,
+                                                           uint32_t pm, bool em_prim, uint32_t j1, uint32_t q2,
+                                                           uint32_t n1, uint32_t n2, double alt_frac, SubPath *paths) {
+  const bool live = act != 0; // :150-152
+  const bool mine = (act >> sl) & 1u;
+  double     best = mine ? pop : -1.0; // argmax, :201-210
+  int        bi   = mine ? sl : 64;
+#pragma unroll
+  for (int d = W / 2; d > 0; d >>= 1) {
+    const double ob = __shfl_xor(best, d);
+    const int    oi = __shfl_xor(bi, d);
+    if (ob > best || (ob == best && oi < bi)) {
+      best = ob;
+      bi   = oi;
+    }
+  }
+  double maxv = 0.0;
+  int    maxi = live ? __builtin_ctz(act) : 0;
+  if (best > 0.0) {
+    maxv = best;
+    maxi = bi;
+  }
+  const uint32_t prim_lanes = group_bits<W>(__ballot(mine && em_prim), gbase);
+  const uint32_t m          = __shfl(pm, gbase + maxi);
+  const bool     hp         = ((m & prim_lanes) != 0) | (__popc(m) > 2); // :217-220
+  if (live && sl == 0) paths[0] = SubPath{m, hp ? 1u : 0u, static_cast<uint64_t>(maxv)};
+  uint32_t np = live ? 1u : 0u;
+  // alternatives, :223-249
+  const double thr  = maxv * alt_frac;
+  uint32_t     used = m;
+  uint32_t     cand = group_bits<W>(__ballot(mine && pop > thr), gbase);
+  while (true) {
+    cand &= group_bits<W>(__ballot((pm & used) == 0), gbase);
+    if (__ballot(cand != 0) == 0) break; // no group has a candidate left
+    const bool     has = cand != 0;
+    const int      p   = has ? __builtin_ctz(cand) : 0;
+    const uint32_t mp  = __shfl(pm, gbase + p);
+    const double   sp  = shfl_f64(pop, gbase + p);
+    if (has && sl == 0) paths[np] = SubPath{mp, (mp & prim_lanes) != 0 ? 1u : 0u, static_cast<uint64_t>(sp)};
+    if (has) {
+      ++np;
+      used |= mp;
+      cand &= ~(1u << p);
+    }
+  }
+  // single primary result, :251-302 (evaluated by every group, applied where it holds)
+  const bool     single = live && np == 1 && hp;
+  const uint32_t ms     = m ? m : 1u;
+  const int      first = __builtin_ctz(ms), last = 31 - __builtin_clz(ms);
+  const uint32_t qe = direction ? q2 : (n2 - 1 - q2);
+  const uint32_t jf = __shfl(j1, gbase + first), jl = __shfl(j1, gbase + last);
+  const uint32_t qf = __shfl(qe, gbase + first), ql = __shfl(qe, gbase + last);
+  const bool     ends   = (jf != 0 && qf != 0) || (jl != n1 - 1 && ql != n2 - 1); // :272-274
+  const bool     on     = (m >> sl) & 1u;
+  const uint32_t below  = m & ((1u << sl) - 1u);
+  const int      prev   = below ? 31 - __builtin_clz(below) : sl;
+  const uint32_t pj = __shfl(j1, gbase + prev), pq = __shfl(qe, gbase + prev);
+  const bool     firstt = below == 0;
+  const uint32_t i_t = firstt ? 0u : pj + 1u, jj_t = firstt ? 0u : pq + 1u;
+  const bool     viol  = on && qe < jj_t;
+  const uint32_t vmask = group_bits<W>(__ballot(viol), gbase);
+  const int      fv    = vmask ? __builtin_ctz(vmask) : 64;
+  const bool     i1    = j1 > i_t;
+  const bool     i2    = sl < fv ? (qe > jj_t) : (sl == fv ? (n2 > jj_t) : false);
+  const bool     inter = group_bits<W>(__ballot(on && i1 && i2), gbase) != 0;
+  if (single && (ends || inter) && sl == 0) paths[0].primary = 0;
+  return np;
+}
+
+template <int W>
+__global__ __launch_bounds__(256) void k_chain_sub(ChainArgs a, const uint32_t *list, uint32_t n_list) {
+  constexpr int G = 64 / W;
+  static_assert(W == 16 || W == 32, "group width");
+  static_assert(sizeof(ChainElem) * 64 >= sizeof(SubPath) * 2 * 64, "the path lists overlay the element table");
+  __shared__ __attribute__((aligned(16))) unsigned char s_wavebuf[4][sizeof(ChainElem) * 64];
+  __shared__ uint32_t                                  s_cm[4][64];
+  const int      wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int      g = lane / W, sl = lane % W, gbase = g * W;
+  const uint32_t slot    = (blockIdx.x * 4 + wave) * G + g;
+  const bool     valid_g = slot < n_list;
+  if (__ballot(valid_g) == 0) return;
+  const uint32_t   e  = valid_g ? list[slot] : list[0];
+  const msgpu_edge ed = a.edges[e];
+  const uint32_t   n  = (valid_g && ed.em_cnt <= static_cast<uint32_t>(W)) ? ed.em_cnt : 0u;
+  const uint64_t   cp = a.edge_cand[e];
+  const bool       act = sl < static_cast<int>(n);
+  const uint32_t   v1 = ed.v1, v2 = ed.v2;
+  const uint32_t   n1 = a.read_cnt[v1], n2 = a.read_cnt[v2];
+  const int        len1 = a.read_len[v1], len2 = a.read_len[v2];
+  ChainElem       *el = reinterpret_cast<ChainElem *>(s_wavebuf[wave]);
+  uint32_t        *cm = s_cm[wave];
+
+  // ---- per-lane element (as in k_chain) ------------------------------------------------------------------------------
+  uint32_t  j1 = 0, q2 = 0, anchor = 0;
+  double    clo1 = 0, clo2 = 0, ovr1 = 0, ovr2 = 0, em_score = 0;
+  bool      em_dir = false, em_prim = false;
+  ChainElem x{};
+  cm[lane] = 0;
+  if (act) {
+    j1               = a.cand_j[cp + sl];
+    const uint32_t t = a.cand_t[cp + sl];
+    const IRow m1 = load_irow(&a.by_read[a.read_off[v1] + j1]);
+    const IRow m2 = load_irow(&a.by_anchor[t]);
+    anchor        = m1.other;
+    q2            = m2.pf & PF_POS_MASK;
+    const int  ov_lo = max(m1.i_lo, m2.i_lo), ov_hi = min(m1.i_hi, m2.i_hi);
+    const bool d1 = (m1.pf & PF_DIR) != 0, d2 = (m2.pf & PF_DIR) != 0;
+    em_dir           = d1 == d2;
+    em_prim          = (m1.pf & PF_PRIM) && (m2.pf & PF_PRIM);
+    const bool   o1  = m1.line > m2.line;
+    const IRow  &om = o1 ? m1 : m2, &im = o1 ? m2 : m1;
+    const double ol  = static_cast<double>(om.i_hi - om.i_lo + 1);
+    const double il  = static_cast<double>(im.i_hi - im.i_lo + 1);
+    const double cl  = static_cast<double>(ov_hi - ov_lo + 1);
+    const double os  = static_cast<double>(om.score) * cl / ol;
+    const double is_ = static_cast<double>(im.score) * cl / il;
+    em_score         = os + is_;
+    {
+      uint4 *q = reinterpret_cast<uint4 *>(&a.ems[ed.em_off + sl]);
+      q[0]     = make_uint4(static_cast<uint32_t>(ov_lo), static_cast<uint32_t>(ov_hi),
+                            static_cast<uint32_t>(__double_as_longlong(em_score)),
+                            static_cast<uint32_t>(__double_as_longlong(em_score) >> 32));
+      q[1]     = make_uint4(anchor, om.line, (em_dir ? 1u : 0u) | (em_prim ? 2u : 0u), e);
+    }
+    {
+      const double rr1 = static_cast<double>(m1.i_hi - m1.i_lo + 1) / static_cast<double>(m1.n_hi - m1.n_lo + 1);
+      const double rr2 = static_cast<double>(m2.i_hi - m2.i_lo + 1) / static_cast<double>(m2.n_hi - m2.n_lo + 1);
+      const bool   l1  = m1.i_lo < m2.i_lo, l2 = m2.i_lo < m1.i_lo;
+      const bool   h1  = m1.i_hi > m2.i_hi, h2 = m2.i_hi > m1.i_hi;
+      const double qL  = static_cast<double>(l1 ? m2.i_lo - m1.i_lo : m1.i_lo - m2.i_lo) / (l1 ? rr1 : rr2);
+      const double qR  = static_cast<double>(h1 ? m1.i_hi - m2.i_hi : m2.i_hi - m1.i_hi) / (h1 ? rr1 : rr2);
+      double ncl1 = l1 ? qL : 0.0, ncr1 = h1 ? qR : 0.0, ncl2 = l2 ? qL : 0.0, ncr2 = h2 ? qR : 0.0;
+      if (!d1) {
+        const double tmp = ncl1;
+        ncl1             = ncr1;
+        ncr1             = tmp;
+      }
+      if (!d2) {
+        const double tmp = ncl2;
+        ncl2             = ncr2;
+        ncr2             = tmp;
+      }
+      x.rlo1 = m1.n_lo;
+      x.rhi1 = m1.n_hi;
+      x.clo1 = static_cast<double>(m1.n_lo) + ncl1;
+      x.chi1 = static_cast<double>(m1.n_hi) - ncr1;
+      ovr1   = static_cast<double>(len1 - m1.n_hi) + ncr1;
+      x.rlo2 = m2.n_lo;
+      x.rhi2 = m2.n_hi;
+      x.clo2 = static_cast<double>(m2.n_lo) + ncl2;
+      x.chi2 = static_cast<double>(m2.n_hi) - ncr2;
+      ovr2   = static_cast<double>(len2 - m2.n_hi) + ncr2;
+    }
+    clo1     = x.clo1;
+    clo2     = x.clo2;
+    el[lane] = x;
+  }
+  const uint32_t m_plus  = group_bits<W>(__ballot(act && em_dir), gbase);
+  const uint32_t m_minus = group_bits<W>(__ballot(act && !em_dir), gbase);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+
+  // ---- all-pairs-compatible shortcut (see k_chain) -------------------------------------------------------------------
+  bool clean = false;
+  {
+    const bool      try_clean = (m_plus == 0 || m_minus == 0) && n >= 2 && a.fast_path;
+    const bool      plus      = m_minus == 0;
+    const ChainElem Pv        = el[sl > 0 ? lane - 1 : lane];
+    bool            good      = true;
+    if (act && sl > 0) {
+      good = (Pv.clo1 < x.clo1) & (Pv.chi1 < x.chi1) & (Pv.rlo1 < x.rlo1) & (Pv.rhi1 < x.rhi1);
+      good &= plus ? ((Pv.clo2 < x.clo2) & (Pv.chi2 < x.chi2) & (Pv.rlo2 < x.rlo2) & (Pv.rhi2 < x.rhi2))
+                   : ((Pv.clo2 > x.clo2) & (Pv.chi2 > x.chi2) & (Pv.rlo2 > x.rlo2) & (Pv.rhi2 > x.rhi2));
+    }
+    const double av = plus ? x.clo1 - x.clo2 : x.clo1 + x.chi2;
+    const double bv = plus ? x.chi1 - x.chi2 : x.chi1 + x.clo2;
+    good &= (av > -1.0e9) & (av < 1.0e9) & (bv > -1.0e9) & (bv < 1.0e9) & (em_score > 1.0e-6);
+    const bool maybe = try_clean && group_bits<W>(__ballot(act && !good), gbase) == 0;
+    if (__ballot(maybe)) { // wave-uniform: some group passed the monotonicity test
+      int a_hi = act ? static_cast<int>(ceil(av)) : -2147483647 - 1;
+      int a_lo = act ? static_cast<int>(floor(av)) : 2147483647;
+      int b_hi = act ? static_cast<int>(ceil(bv)) : -2147483647 - 1;
+      int b_lo = act ? static_cast<int>(floor(bv)) : 2147483647;
+#pragma unroll
+      for (int d = W / 2; d > 0; d >>= 1) {
+        a_hi = max(a_hi, __shfl_xor(a_hi, d));
+        a_lo = min(a_lo, __shfl_xor(a_lo, d));
+        b_hi = max(b_hi, __shfl_xor(b_hi, d));
+        b_lo = min(b_lo, __shfl_xor(b_lo, d));
+      }
+      const long long Wg = static_cast<long long>(a.wiggle) - 3;
+      clean = maybe && static_cast<long long>(a_hi) - b_lo <= Wg && static_cast<long long>(b_hi) - a_lo <= Wg;
+    }
+  }
+  if (a.edge_fast && n && sl == 0) a.edge_fast[e] = clean ? 1u : 0u;
+
+  // ---- checkCompatibility for every pair k < l: a lane takes pair p0 + sl of ITS edge, W pairs per edge and step ------
+  const int P = clean ? 0 : static_cast<int>(n * (n - 1) / 2);
+  int       Pmax = P;
+#pragma unroll
+  for (int d = 32; d >= W; d >>= 1) Pmax = max(Pmax, __shfl_xor(Pmax, d));
+  Pmax = __builtin_amdgcn_readfirstlane(Pmax);
+  uint32_t kl_next = sl < P ? a.pair_tab[sl] : 0u;
+  for (int p0 = 0; p0 < Pmax; p0 += W) {
+    const int      p = p0 + sl;
+    int            k = 0, l = 1;
+    bool           kd = false, ld = true;
+    const uint32_t kl = kl_next;
+    if (p + W < P) kl_next = a.pair_tab[p + W];
+    if (p < P) {
+      k  = static_cast<int>(kl & 0xffu);
+      l  = static_cast<int>(kl >> 8);
+      kd = (m_plus >> k) & 1u;
+      ld = (m_plus >> l) & 1u;
+    }
+    unsigned long long bits;
+    {
+      typedef unsigned long long M;
+      const M         valid = __ballot(p < P && kd == ld);
+      const ChainElem K = el[gbase + k], L = el[gbase + l];
+      double          d1, d2;
+      const NanoMasks f1 = nano_check(K.clo1, K.chi1, L.clo1, L.chi1, K.rlo1, K.rhi1, L.rlo1, L.rhi1, d1);
+      const NanoMasks f2 = nano_check(K.clo2, K.chi2, L.clo2, L.chi2, K.rlo2, K.rhi2, L.rlo2, L.rhi2, d2);
+      const M         KD = __ballot(kd);
+      const M p2 = (KD & f2.pos) | (~KD & f2.neg), n2m = (KD & f2.neg) | (~KD & f2.pos);
+      const M codir   = (f1.pos & p2) | (f1.neg & n2m);
+      const M same    = codir & ~(f1.ovl ^ f2.ovl);
+      const M aborted = f1.abort_ | f2.abort_;
+      const double mx = fmax(d1, d2);
+      const double df = mx - fmin(d1, d2);
+      const M near_ = __ballot(df <= a.wiggle), sum_ok = __ballot(d1 + d2 <= a.wiggle);
+      M       ok    = ~aborted & ((same & near_) | (~same & codir & sum_ok));
+      const M need_div = ~aborted & same & ~near_ & valid;
+      if (need_div) {
+        bool pass = false;
+        if (__builtin_amdgcn_inverse_ballot_w64(need_div)) pass = df * 100 / mx <= a.ratio_pct;
+        ok |= __ballot(pass);
+      }
+      bits = ok & valid;
+    }
+    // the pairs of row l are consecutive lanes of the group; the first lane of each run stores the run's bits
+    const uint32_t gb = group_bits<W>(bits, gbase);
+    if (p < P && (k == 0 || sl == 0)) {
+      const int len = min(l - k, W - sl);
+      uint32_t  seg = gb >> sl;
+      if (len < 32) seg &= (1u << len) - 1u;
+      cm[gbase + l] |= seg << k;
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  // bit k: checkCompatibility(k, sl) for k < sl; a clean edge has them all (and then the DP below adds the scores up
+  // left to right, exactly the sum k_chain's shortcut forms)
+  const uint32_t mycm = clean ? (act ? (1u << sl) - 1u : 0u) : cm[lane];
+
+  // ---- chaining DP (mpp.cpp:181-199) ---------------------------------------------------------------------------------
+  int nmax = static_cast<int>(n);
+#pragma unroll
+  for (int d = 32; d >= W; d >>= 1) nmax = max(nmax, __shfl_xor(nmax, d));
+  nmax = __builtin_amdgcn_readfirstlane(nmax);
+  double   pop = em_score;
+  uint32_t pm  = 1u << sl;
+  {
+    uint32_t pred = static_cast<uint32_t>(sl);
+    uint32_t rev  = __builtin_bitreverse32(mycm); // bit k of mycm -> bit 31 - k
+    for (int k = 0; k + 1 < nmax; ++k) {
+      const double k_pop = shfl_f64(pop, gbase + k);
+      const double cand  = k_pop + em_score; // :189
+      const bool   comp  = static_cast<int32_t>(rev) < 0;
+      rev <<= 1;
+      if (comp && cand > pop) { // :190-197
+        pop  = cand;
+        pred = static_cast<uint32_t>(k);
+      }
+    }
+    uint32_t ptr = pred;
+    for (int span = 1; span < nmax; span <<= 1) {
+      const uint32_t o  = __shfl(pm, gbase + static_cast<int>(ptr));
+      const uint32_t p2 = __shfl(ptr, gbase + static_cast<int>(ptr));
+      pm |= o;
+      ptr = p2;
+    }
+  }
+
+  // src/main.cpp:341-353: split by EdgeMatch direction, minus then plus
+  SubPath *pmn = reinterpret_cast<SubPath *>(s_wavebuf[wave]) + gbase, *ppl = pmn + 64; // el[] is dead from here on
+  const uint32_t n_m = paths_of_direction_sub<W>(m_minus, false, sl, gbase, pop, pm, em_prim, j1, q2, n1, n2, a.alt_frac, pmn);
+  const uint32_t n_p = paths_of_direction_sub<W>(m_plus, true, sl, gbase, pop, pm, em_prim, j1, q2, n1, n2, a.alt_frac, ppl);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+
+  // filters of src/main.cpp:355-387
+  bool     k_m = false, k_p = false;
+  uint32_t prim_m = 0, prim_p = 0, len_m = 0, len_p = 0;
+  if (sl < static_cast<int>(n_m)) {
+    prim_m = pmn[sl].primary;
+    len_m  = static_cast<uint32_t>(__popc(pmn[sl].mask));
+    k_m    = true;
+  }
+  if (sl < static_cast<int>(n_p)) {
+    prim_p = ppl[sl].primary;
+    len_p  = static_cast<uint32_t>(__popc(ppl[sl].mask));
+    k_p    = true;
+  }
+  const bool has_primary = group_bits<W>(__ballot((k_m && prim_m) || (k_p && prim_p)), gbase) != 0;
+  if (has_primary) {
+    k_m = k_m && prim_m;
+    k_p = k_p && prim_p;
+  }
+  const bool has_multi = group_bits<W>(__ballot((k_m && len_m > 1) || (k_p && len_p > 1)), gbase) != 0;
+  if (has_multi) {
+    k_m = k_m && len_m > 1;
+    k_p = k_p && len_p > 1;
+  }
+  const uint32_t keep_m = group_bits<W>(__ballot(k_m), gbase), keep_p = group_bits<W>(__ballot(k_p), gbase);
+  const int      combined = __popc(keep_m) + __popc(keep_p);
+  bool           shadow   = true; // :389-391
+  if (combined == 1) shadow = !(keep_m ? pmn[__builtin_ctz(keep_m)].primary : ppl[__builtin_ctz(keep_p)].primary);
+
+  // getOverlap (ol.cpp:53-101) per kept path, minus first
+  uint32_t n_orders = 0, n_ids = 0;
+  for (int pass = 0; pass < 2; ++pass) {
+    uint32_t       keep = pass == 0 ? keep_m : keep_p;
+    const SubPath *pv   = pass == 0 ? pmn : ppl;
+    const bool     dir  = pass == 1;
+    while (__ballot(keep != 0)) {
+      const bool has = keep != 0;
+      const int  pi  = has ? __builtin_ctz(keep) : 0;
+      keep &= keep - 1u;
+      const SubPath  rec  = pv[pi];
+      const uint32_t mask = (has && rec.mask) ? rec.mask : 1u;
+      const int      f = __builtin_ctz(mask), l = 31 - __builtin_clz(mask);
+      const double   L1 = shfl_f64(clo1, gbase + f), R1 = shfl_f64(ovr1, gbase + l);
+      const double   L2 = shfl_f64(dir ? clo2 : ovr2, gbase + f), R2 = shfl_f64(dir ? ovr2 : clo2, gbase + l); // :73-76
+      bool     have = false;
+      uint32_t fl   = 0;
+      double   lo = 0, ro = 0;
+      if (L1 <= L2 && R1 <= R2) {
+        have = true;
+        fl   = MSGPU_ORD_START_V1 | MSGPU_ORD_CONTAINED;
+        lo   = L2 - L1;
+        ro   = R2 - R1;
+      } else if (L1 >= L2 && R1 >= R2) {
+        have = true;
+        fl   = MSGPU_ORD_CONTAINED;
+        lo   = L1 - L2;
+        ro   = R1 - R2;
+      } else if (L1 > L2 && R1 < R2) {
+        have = true;
+        fl   = MSGPU_ORD_START_V1;
+        lo   = L1 - L2;
+        ro   = R2 - R1;
+      } else if (L1 < L2 && R1 > R2) {
+        have = true;
+        fl   = 0;
+        lo   = L2 - L1;
+        ro   = R1 - R2;
+      }
+      const bool emit = has && have;
+      if (emit) {
+        const uint32_t cnt = static_cast<uint32_t>(__popc(mask));
+        if ((mask >> sl) & 1u) a.ids_scr[ed.em_off + n_ids + static_cast<uint32_t>(__popc(mask & ((1u << sl) - 1u)))] = anchor;
+        if (sl == 0) {
+          msgpu_order o;
+          o.edge_idx     = e;
+          o.flags        = fl | (dir ? MSGPU_ORD_DIR : 0u) | (rec.primary ? MSGPU_ORD_PRIMARY : 0u);
+          o.left_offset  = lo;
+          o.right_offset = ro;
+          o.score        = rec.score;
+          o.ids_off      = n_ids;
+          o.ids_cnt      = cnt;
+          o.start        = (fl & MSGPU_ORD_START_V1) ? v1 : v2;
+          o.end          = (fl & MSGPU_ORD_START_V1) ? v2 : v1;
+          o.base         = v1;
+          o.pad[0]       = 0;
+          o.pad[1]       = 0;
+          a.order_scr[ed.em_off + n_orders] = o;
+        }
+        ++n_orders;
+        n_ids += cnt;
+      }
+    }
+  }
+  if (n && sl == 0) {
+    a.edge_norders[e] = n_orders;
+    a.edge_nids[e]    = n_ids;
+    a.edges[e].shadow = shadow ? 1 : 0;
+  }
+}
+
+template __global__ void k_chain_sub<16>(ChainArgs, const uint32_t *, uint32_t);
+template __global__ void k_chain_sub<32>(ChainArgs, const uint32_t *, uint32_t);
+
+// edges by size class: <= 16, 17..32, 33..64 EdgeMatches (larger ones are listed by k_list_big_edges)
+__global__ __launch_bounds__(1024) void k_list_edges_by_size(const msgpu_edge *edges, uint64_t n_edges, uint32_t *list16,
+                                                             uint32_t *list32, uint32_t *list64, uint32_t *counts /*[3]*/) {
+  __shared__ uint32_t s_cnt[3], s_base[3];
+  if (threadIdx.x < 3) s_cnt[threadIdx.x] = 0;
+  __syncthreads();
+  const uint64_t e   = static_cast<uint64_t>(blockIdx.x) * 1024 + threadIdx.x;
+  int            cls = -1;
+  if (e < n_edges) {
+    const uint32_t n = edges[e].em_cnt;
+    cls              = n <= 16 ? 0 : n <= 32 ? 1 : n <= 64 ? 2 : -1;
+  }
+  const int lane  = threadIdx.x & 63;
+  uint32_t  local = 0;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    unsigned long long m = __ballot(cls == k);
+    if (!m) continue;
+    uint32_t base = 0;
+    if (lane == __builtin_ctzll(m)) base = atomicAdd(&s_cnt[k], static_cast<uint32_t>(__popcll(m)));
+    base = rl_u32(base, __builtin_ctzll(m));
+    if (cls == k) local = base + static_cast<uint32_t>(__popcll(m & ((1ull << lane) - 1)));
+  }
+  __syncthreads();
+  if (threadIdx.x < 3 && s_cnt[threadIdx.x]) s_base[threadIdx.x] = atomicAdd(&counts[threadIdx.x], s_cnt[threadIdx.x]);
+  __syncthreads();
+  if (cls >= 0) {
+    uint32_t *list = cls == 0 ? list16 : cls == 1 ? list32 : list64;
+    list[s_base[cls] + local] = static_cast<uint32_t>(e);
   }
 }
 
@@ -2067,8 +2524,21 @@ void launch_emit_edges(hipStream_t st, const uint32_t *n_edge, const uint32_t *n
 void launch_fill_pair_tab(hipStream_t st, uint16_t *tab) {
   hipLaunchKernelGGL(k_fill_pair_tab, dim3(8), dim3(256), 0, st, tab);
 }
-void launch_chain(hipStream_t st, const ChainArgs &a) {
-  if (a.n_edges) hipLaunchKernelGGL(k_chain, grid1(a.n_edges, 4), dim3(256), 0, st, a);
+void launch_chain(hipStream_t st, const ChainArgs &a, const uint32_t *list, uint32_t n_list) {
+  const uint64_t n = list ? n_list : a.n_edges;
+  if (n) hipLaunchKernelGGL(k_chain, grid1(n, 4), dim3(256), 0, st, a, list, n_list);
+}
+void launch_chain_sub(hipStream_t st, const ChainArgs &a, int width, const uint32_t *list, uint32_t n_list) {
+  if (!n_list) return;
+  if (width == 16)
+    hipLaunchKernelGGL(k_chain_sub<16>, grid1(n_list, 16), dim3(256), 0, st, a, list, n_list);
+  else
+    hipLaunchKernelGGL(k_chain_sub<32>, grid1(n_list, 8), dim3(256), 0, st, a, list, n_list);
+}
+void launch_list_edges_by_size(hipStream_t st, const msgpu_edge *edges, uint64_t n_edges, uint32_t *l16, uint32_t *l32,
+                               uint32_t *l64, uint32_t *counts) {
+  if (n_edges)
+    hipLaunchKernelGGL(k_list_edges_by_size, grid1(n_edges, 1024), dim3(1024), 0, st, edges, n_edges, l16, l32, l64, counts);
 }
 void launch_list_big_edges(hipStream_t st, const msgpu_edge *edges, uint64_t n_edges, uint32_t *big_list,
                            uint64_t *big_off, uint64_t *cursor) {
