@@ -1003,8 +1003,10 @@ __device__ __forceinline__ NanoMasks nano_check(double k_clo, double k_chi, doub
   const M    gt_lo = __ballot(k_clo > l_clo), gt_hi = __ballot(k_chi > l_chi);
   NanoMasks  f;
   f.ovl = __ballot(k_clo <= l_chi) & __ballot(l_clo <= k_chi);
-  f.pos = (f.ovl & lt_lo & lt_hi) | (~f.ovl & lt_lo);  // fwd2 | fwd1
-  f.neg = (f.ovl & gt_lo & gt_hi) | (~f.ovl & ~lt_lo); // bwd2 | bwd1
+  // fwd2 | fwd1 = (ovl & lt_lo & lt_hi) | (~ovl & lt_lo),  bwd2 | bwd1 = (ovl & gt_lo & gt_hi) | (~ovl & ~lt_lo), written
+  // with the fewest scalar instructions: the scalar unit, not the vector unit, is what this loop saturates
+  f.pos = lt_lo & (lt_hi | ~f.ovl);
+  f.neg = (f.ovl & gt_lo & gt_hi) | ~(f.ovl | lt_lo);
   // diff (:70-91): fwd -> k_chi - l_clo, bwd -> l_chi - k_clo, negated when the ranges do not overlap, + 1; 0 when
   // the ranges overlap without a strict order.  lt_lo selects the right difference in every case that has an order.
   const double x = k_chi - l_clo;
@@ -1260,44 +1262,54 @@ __global__ __launch_bounds__(256) void k_chain(ChainArgs a, const uint32_t *list
   // ---- checkCompatibility (mpp.cpp:38-142) for every pair k < l of one direction, all 64 lanes busy ---------------
   // pair p = l(l-1)/2 + k, row-major over l; a lane handles p = it*64 + lane
   const int P = clean ? 0 : static_cast<int>(n * (n - 1) / 2);
-  uint32_t kl_next = lane < P ? a.pair_tab[lane] : 0u; // (k, l) of pair p: precomputed, the same for every edge
+  // One-direction edges (the rule for true overlaps) need no per-pair direction test: every pair is "valid" and the
+  // flip of mpp.cpp:131 is the same for all of them.
+  const bool one_dir = m_plus == 0 || m_minus == 0; // wave-uniform
+  // (k, l) of pair p: precomputed, the same for every edge.  Lanes past P read the edge's last pair (a valid pair, masked
+  // out below), so the load needs no branch.
+  const int Pm1     = max(P - 1, 0);
+  uint32_t  kl_next = a.pair_tab[min(lane, Pm1)];
   for (int p0 = 0; p0 < P; p0 += 64) {
     const int          p = p0 + lane;
-    int                k = 0, l = 1;
     unsigned long long bits = 0; // checkCompatibility(k, l) of the 64 pairs of this step
-    bool               kd = false, ld = true;
     const uint32_t     kl = kl_next;
-    if (p + 64 < P) kl_next = a.pair_tab[p + 64]; // the next step's pairs are on their way while this step computes
-    if (p < P) {
-      k                 = static_cast<int>(kl & 0xffu);
-      l                 = static_cast<int>(kl >> 8);
-      kd                = (m_plus >> k) & 1ull;
-      ld                = (m_plus >> l) & 1ull;
-    }
-    { // every lane evaluates a pair (lanes past P the dummy pair (0, 1)): no divergence, all masks are wave-uniform
+    kl_next               = a.pair_tab[min(p + 64, Pm1)]; // the next step's pairs are on their way while this one computes
+    const int k = static_cast<int>(kl & 0xffu), l = static_cast<int>(kl >> 8);
+    { // every lane evaluates a pair: no divergence, all masks are wave-uniform
       typedef unsigned long long M;
-      const M         valid = __ballot(p < P && kd == ld); // pairs of one direction only
+      M valid = __ballot(p < P), KD = 0;
+      if (!one_dir) { // pairs of one direction only
+        const bool kd = (m_plus >> k) & 1ull, ld = (m_plus >> l) & 1ull;
+        valid &= __ballot(kd == ld);
+        KD = __ballot(kd);
+      }
       const ChainElem K = el[k], L = el[l];
       double          d1, d2;
       const NanoMasks f1 = nano_check(K.clo1, K.chi1, L.clo1, L.chi1, K.rlo1, K.rhi1, L.rlo1, L.rhi1, d1);
       const NanoMasks f2 = nano_check(K.clo2, K.chi2, L.clo2, L.chi2, K.rlo2, K.rhi2, L.rlo2, L.rhi2, d2);
-      const M         KD = __ballot(kd);
-      const M p2 = (KD & f2.pos) | (~KD & f2.neg), n2 = (KD & f2.neg) | (~KD & f2.pos); // :131 flip by EdgeMatch(k).direction
+      M p2, n2; // :131 flip by EdgeMatch(k).direction
+      if (one_dir) {
+        p2 = m_minus == 0 ? f2.pos : f2.neg;
+        n2 = m_minus == 0 ? f2.neg : f2.pos;
+      } else {
+        p2 = (KD & f2.pos) | (~KD & f2.neg);
+        n2 = (KD & f2.neg) | (~KD & f2.pos);
+      }
       const M codir   = (f1.pos & p2) | (f1.neg & n2); // :137 same sign
       const M same    = codir & ~(f1.ovl ^ f2.ovl);    // :133 equal and non-zero
-      const M aborted = f1.abort_ | f2.abort_;
+      const M live    = valid & ~(f1.abort_ | f2.abort_);
       const double mx = fmax(d1, d2); // finite operands: the same values std::max / std::min return
       const double df = mx - fmin(d1, d2);
       const M near_ = __ballot(df <= a.wiggle), sum_ok = __ballot(d1 + d2 <= a.wiggle);
-      M       ok    = ~aborted & ((same & near_) | (~same & codir & sum_ok));
+      M       ok    = ((same & near_) | (codir & ~same & sum_ok)) & live;
       // the fp64 division of :136 only where the first test failed (rare for true overlaps)
-      const M need_div = ~aborted & same & ~near_ & valid;
+      const M need_div = same & ~near_ & live;
       if (need_div) {
         bool pass = false;
         if (__builtin_amdgcn_inverse_ballot_w64(need_div)) pass = df * 100 / mx <= a.ratio_pct;
         ok |= __ballot(pass);
       }
-      bits = ok & valid;
+      bits = ok;
     }
     // the pairs of row l are consecutive lanes; the first lane of each run stores the run's bits
     if (p < P && (k == 0 || lane == 0)) {
@@ -1697,43 +1709,43 @@ __global__ __launch_bounds__(256) void k_chain_sub(ChainArgs a, const uint32_t *
 #pragma unroll
   for (int d = 32; d >= W; d >>= 1) Pmax = max(Pmax, __shfl_xor(Pmax, d));
   Pmax = __builtin_amdgcn_readfirstlane(Pmax);
-  uint32_t kl_next = sl < P ? a.pair_tab[sl] : 0u;
+  const bool               one_dir = __ballot(m_plus != 0 && m_minus != 0) == 0; // every edge of the wave has one direction
+  const unsigned long long KD_one  = __ballot(m_minus == 0);
+  const int                Pm1     = max(P - 1, 0); // lanes past P read their edge's last pair (or pair 0 = (0, 1))
+  uint32_t                 kl_next = a.pair_tab[min(sl, Pm1)];
   for (int p0 = 0; p0 < Pmax; p0 += W) {
-    const int      p = p0 + sl;
-    int            k = 0, l = 1;
-    bool           kd = false, ld = true;
+    const int      p  = p0 + sl;
     const uint32_t kl = kl_next;
-    if (p + W < P) kl_next = a.pair_tab[p + W];
-    if (p < P) {
-      k  = static_cast<int>(kl & 0xffu);
-      l  = static_cast<int>(kl >> 8);
-      kd = (m_plus >> k) & 1u;
-      ld = (m_plus >> l) & 1u;
-    }
+    kl_next           = a.pair_tab[min(p + W, Pm1)];
+    const int k = static_cast<int>(kl & 0xffu), l = static_cast<int>(kl >> 8);
     unsigned long long bits;
     {
       typedef unsigned long long M;
-      const M         valid = __ballot(p < P && kd == ld);
+      M valid = __ballot(p < P), KD = KD_one;
+      if (!one_dir) {
+        const bool kd = (m_plus >> k) & 1u, ld = (m_plus >> l) & 1u;
+        valid &= __ballot(kd == ld);
+        KD = __ballot(kd);
+      }
       const ChainElem K = el[gbase + k], L = el[gbase + l];
       double          d1, d2;
       const NanoMasks f1 = nano_check(K.clo1, K.chi1, L.clo1, L.chi1, K.rlo1, K.rhi1, L.rlo1, L.rhi1, d1);
       const NanoMasks f2 = nano_check(K.clo2, K.chi2, L.clo2, L.chi2, K.rlo2, K.rhi2, L.rlo2, L.rhi2, d2);
-      const M         KD = __ballot(kd);
       const M p2 = (KD & f2.pos) | (~KD & f2.neg), n2m = (KD & f2.neg) | (~KD & f2.pos);
       const M codir   = (f1.pos & p2) | (f1.neg & n2m);
       const M same    = codir & ~(f1.ovl ^ f2.ovl);
-      const M aborted = f1.abort_ | f2.abort_;
+      const M live    = valid & ~(f1.abort_ | f2.abort_);
       const double mx = fmax(d1, d2);
       const double df = mx - fmin(d1, d2);
       const M near_ = __ballot(df <= a.wiggle), sum_ok = __ballot(d1 + d2 <= a.wiggle);
-      M       ok    = ~aborted & ((same & near_) | (~same & codir & sum_ok));
-      const M need_div = ~aborted & same & ~near_ & valid;
+      M       ok    = ((same & near_) | (codir & ~same & sum_ok)) & live;
+      const M need_div = same & ~near_ & live;
       if (need_div) {
         bool pass = false;
         if (__builtin_amdgcn_inverse_ballot_w64(need_div)) pass = df * 100 / mx <= a.ratio_pct;
         ok |= __ballot(pass);
       }
-      bits = ok & valid;
+      bits = ok;
     }
     // the pairs of row l are consecutive lanes of the group; the first lane of each run stores the run's bits
     const uint32_t gb = group_bits<W>(bits, gbase);

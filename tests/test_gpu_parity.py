@@ -54,6 +54,30 @@ def test_every_sort_path_of_the_index(oracle, n_anchors, lo, hi):
     assert_tables_equal(_gpu_tables(allrows), want, "shuffled with duplicates")
 
 
+@pytest.mark.parametrize("dense", [False, True])
+def test_mixed_direction_edges(oracle, dense):
+    """Rows of one read with both strands give edges whose EdgeMatches differ in direction: the pair sweep then skips
+    pairs of unlike direction, both path lists fill, and the filters of main.cpp:355-387 work on their union.  (The
+    generators give every read one strand, so no other test has such an edge.)"""
+    from muchsalsa_amd import synth
+    ROW_DIR, ROW_PRIMARY = 1, 2  # MSGPU_ROW_DIR, MSGPU_ROW_PRIMARY (include/msgpu.h)
+    if dense:
+        rows, _, _ = synth.accepted_rows(synth.paf_table(120, 20000, 1200, 5, coverage=10))
+    else:
+        rows = synth.synth_rows(600, 4000, 1500, 13)
+    rows = rows.copy()
+    rng = np.random.default_rng(17 + dense)
+    flip = rng.random(len(rows)) < 0.3
+    rows["flags"] = np.where(flip, rows["flags"] ^ ROW_DIR, rows["flags"])
+    rows["flags"] = np.where(rng.random(len(rows)) < 0.2, rows["flags"] ^ ROW_PRIMARY, rows["flags"])
+    want = oracle.overlap(rows)
+    e, em = want["edges"], want["ems"]
+    plus = np.bincount(np.repeat(np.arange(len(e)), e["em_cnt"]), weights=em["flags"] & 1, minlength=len(e))
+    n_mixed = int(((plus > 0) & (plus < e["em_cnt"])).sum())
+    assert n_mixed > 200, n_mixed
+    assert_tables_equal(_gpu_tables(rows), want, "mixed directions (%d edges)" % n_mixed)
+
+
 def test_shortcut_and_full_sweep_agree(oracle, monkeypatch):
     """k_chain's all-pairs-compatible shortcut must change nothing: same tables with it disabled, and equal to the
     oracle's; and it must actually be taken on clean synthetic overlaps."""
