@@ -598,11 +598,12 @@ int msgpu_chaining_and_overlaps(msgpu_ctx *c) {
   if (c->sub_wave && E) {
     // width classes: <= 16 and 17..32 EdgeMatches share a wavefront four / two at a time, 33..64 take one each.  The
     // class sizes have to come back before the launches (the big edges are already running on the side stream).
-    ENSURE(c, cls_list, 3 * (E + 1) * 4);
-    uint32_t *l16 = c->cls_list.as<uint32_t>(), *l32 = l16 + E + 1, *l64 = l32 + E + 1;
-    launch_list_edges_by_size(st, a.edges, E, l16, l32, l64, scalar<uint32_t>(c, SC_CLS));
+    ENSURE(c, cls_list, (E + 1) * 4 + size_sort_part_bytes());
+    uint32_t *list = c->cls_list.as<uint32_t>(), *part = list + E + 1;
+    launch_sort_edges_by_size(st, a.edges, E, part, list, scalar<uint32_t>(c, SC_CLS));
     if (int rc = read_scalars(c)) return rc;
     for (int k = 0; k < 3; ++k) c->n_cls[k] = host_scalar<uint32_t>(c, SC_CLS)[k];
+    const uint32_t *l64 = list, *l32 = l64 + c->n_cls[2], *l16 = l32 + c->n_cls[1]; // sizes descending
     HIPCHK(c, hipEventRecord(c->ev[5], st));
     launch_chain(st, a, l64, c->n_cls[2]); // the long ones first: the short classes fill the tail
     launch_chain_sub(st, a, 32, l32, c->n_cls[1]);

@@ -119,8 +119,9 @@ void launch_emit_edges(hipStream_t st, const uint32_t *n_edge, const uint32_t *n
 void launch_fill_pair_tab(hipStream_t st, uint16_t *tab);
 void launch_chain(hipStream_t st, const ChainArgs &a, const uint32_t *list, uint32_t n_list);
 void launch_chain_sub(hipStream_t st, const ChainArgs &a, int width, const uint32_t *list, uint32_t n_list);
-void launch_list_edges_by_size(hipStream_t st, const msgpu_edge *edges, uint64_t n_edges, uint32_t *l16, uint32_t *l32,
-                               uint32_t *l64, uint32_t *counts);
+void launch_sort_edges_by_size(hipStream_t st, const msgpu_edge *edges, uint64_t n_edges, uint32_t *part, uint32_t *list,
+                               uint32_t *counts);
+size_t size_sort_part_bytes();
 void launch_list_big_edges(hipStream_t st, const msgpu_edge *edges, uint64_t n_edges, uint32_t *big_list,
                            uint64_t *big_off, uint64_t *cursor);
 size_t big_elem_bytes();

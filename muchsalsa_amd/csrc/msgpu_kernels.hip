@@ -1900,35 +1900,82 @@ __global__ __launch_bounds__(256) void k_chain_sub(ChainArgs a, const uint32_t *
 template __global__ void k_chain_sub<16>(ChainArgs, const uint32_t *, uint32_t);
 template __global__ void k_chain_sub<32>(ChainArgs, const uint32_t *, uint32_t);
 
-// edges by size class: <= 16, 17..32, 33..64 EdgeMatches (larger ones are listed by k_list_big_edges)
-__global__ __launch_bounds__(1024) void k_list_edges_by_size(const msgpu_edge *edges, uint64_t n_edges, uint32_t *list16,
-                                                             uint32_t *list32, uint32_t *list64, uint32_t *counts /*[3]*/) {
-  __shared__ uint32_t s_cnt[3], s_base[3];
-  if (threadIdx.x < 3) s_cnt[threadIdx.x] = 0;
+// Edges with <= 64 EdgeMatches ordered by size, largest first (a counting sort in three small launches: per-block
+// histograms, their scan, scatter).  The three width classes are then contiguous stretches of one list
+// [64..33 | 32..17 | 16..1], the edges that share a wavefront in k_chain_sub have (nearly) the same size, so no group
+// waits long for its neighbour, and the longest edges of a launch start first.
+constexpr int SIZE_SORT_BLOCKS = 128;
+
+__global__ __launch_bounds__(1024) void k_size_hist(const msgpu_edge *edges, uint32_t n_edges, uint32_t chunk,
+                                                    uint32_t *part /*[blocks][64]*/) {
+  __shared__ uint32_t s_h[64];
+  if (threadIdx.x < 64) s_h[threadIdx.x] = 0;
   __syncthreads();
-  const uint64_t e   = static_cast<uint64_t>(blockIdx.x) * 1024 + threadIdx.x;
-  int            cls = -1;
-  if (e < n_edges) {
+  const uint32_t b0 = blockIdx.x * chunk, b1 = min(b0 + chunk, n_edges);
+  for (uint32_t e = b0 + threadIdx.x; e < b1; e += 1024) {
     const uint32_t n = edges[e].em_cnt;
-    cls              = n <= 16 ? 0 : n <= 32 ? 1 : n <= 64 ? 2 : -1;
+    if (n >= 1 && n <= 64) atomicAdd(&s_h[n - 1], 1u);
   }
-  const int lane  = threadIdx.x & 63;
-  uint32_t  local = 0;
+  __syncthreads();
+  if (threadIdx.x < 64) part[blockIdx.x * 64 + threadIdx.x] = s_h[threadIdx.x];
+}
+
+// part[b][bin] -> first list position of block b's edges of that size; counts[0..2] = edges of <= 16, 17..32, 33..64.
+// One workgroup: thread (bin, seg) owns 8 consecutive blocks of one bin, so no thread walks the table serially.
+__global__ __launch_bounds__(1024) void k_size_scan(uint32_t *part, uint32_t *counts) {
+  static_assert(SIZE_SORT_BLOCKS == 128, "16 segments of 8 blocks");
+  __shared__ uint32_t s_seg[16][64], s_base[64];
+  const int bin = threadIdx.x & 63, seg = threadIdx.x >> 6;
+  uint32_t  c[8], sum = 0;
 #pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    unsigned long long m = __ballot(cls == k);
-    if (!m) continue;
-    uint32_t base = 0;
-    if (lane == __builtin_ctzll(m)) base = atomicAdd(&s_cnt[k], static_cast<uint32_t>(__popcll(m)));
-    base = rl_u32(base, __builtin_ctzll(m));
-    if (cls == k) local = base + static_cast<uint32_t>(__popcll(m & ((1ull << lane) - 1)));
+  for (int i = 0; i < 8; ++i) c[i] = part[(seg * 8 + i) * 64 + bin];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) sum += c[i];
+  s_seg[seg][bin] = sum;
+  __syncthreads();
+  if (seg == 0) { // one wavefront: totals per bin, then the exclusive prefix over the bins in DESCENDING size order
+    uint32_t run = 0;
+    for (int k = 0; k < 16; ++k) {
+      const uint32_t t = s_seg[k][bin];
+      s_seg[k][bin]    = run;
+      run += t;
+    }
+    uint32_t inc = run;
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t t = __shfl_down(inc, d);
+      if (bin + d < 64) inc += t;
+    }
+    s_base[bin] = inc - run;
+    uint32_t c16 = bin < 16 ? run : 0, c32 = (bin >= 16 && bin < 32) ? run : 0, c64 = bin >= 32 ? run : 0;
+    for (int d = 32; d > 0; d >>= 1) {
+      c16 += __shfl_xor(c16, d);
+      c32 += __shfl_xor(c32, d);
+      c64 += __shfl_xor(c64, d);
+    }
+    if (bin == 0) {
+      counts[0] = c16;
+      counts[1] = c32;
+      counts[2] = c64;
+    }
   }
   __syncthreads();
-  if (threadIdx.x < 3 && s_cnt[threadIdx.x]) s_base[threadIdx.x] = atomicAdd(&counts[threadIdx.x], s_cnt[threadIdx.x]);
+  uint32_t off = s_base[bin] + s_seg[seg][bin];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    part[(seg * 8 + i) * 64 + bin] = off;
+    off += c[i];
+  }
+}
+
+__global__ __launch_bounds__(1024) void k_size_scatter(const msgpu_edge *edges, uint32_t n_edges, uint32_t chunk,
+                                                       const uint32_t *part, uint32_t *list) {
+  __shared__ uint32_t s_pos[64];
+  if (threadIdx.x < 64) s_pos[threadIdx.x] = part[blockIdx.x * 64 + threadIdx.x];
   __syncthreads();
-  if (cls >= 0) {
-    uint32_t *list = cls == 0 ? list16 : cls == 1 ? list32 : list64;
-    list[s_base[cls] + local] = static_cast<uint32_t>(e);
+  const uint32_t b0 = blockIdx.x * chunk, b1 = min(b0 + chunk, n_edges);
+  for (uint32_t e = b0 + threadIdx.x; e < b1; e += 1024) {
+    const uint32_t n = edges[e].em_cnt;
+    if (n >= 1 && n <= 64) list[atomicAdd(&s_pos[n - 1], 1u)] = e;
   }
 }
 
@@ -2547,11 +2594,15 @@ void launch_chain_sub(hipStream_t st, const ChainArgs &a, int width, const uint3
   else
     hipLaunchKernelGGL(k_chain_sub<32>, grid1(n_list, 8), dim3(256), 0, st, a, list, n_list);
 }
-void launch_list_edges_by_size(hipStream_t st, const msgpu_edge *edges, uint64_t n_edges, uint32_t *l16, uint32_t *l32,
-                               uint32_t *l64, uint32_t *counts) {
-  if (n_edges)
-    hipLaunchKernelGGL(k_list_edges_by_size, grid1(n_edges, 1024), dim3(1024), 0, st, edges, n_edges, l16, l32, l64, counts);
+void launch_sort_edges_by_size(hipStream_t st, const msgpu_edge *edges, uint64_t n_edges, uint32_t *part, uint32_t *list,
+                               uint32_t *counts) {
+  if (!n_edges) return;
+  const uint32_t E = static_cast<uint32_t>(n_edges), chunk = (E + SIZE_SORT_BLOCKS - 1) / SIZE_SORT_BLOCKS;
+  hipLaunchKernelGGL(k_size_hist, dim3(SIZE_SORT_BLOCKS), dim3(1024), 0, st, edges, E, chunk, part);
+  hipLaunchKernelGGL(k_size_scan, dim3(1), dim3(1024), 0, st, part, counts);
+  hipLaunchKernelGGL(k_size_scatter, dim3(SIZE_SORT_BLOCKS), dim3(1024), 0, st, edges, E, chunk, part, list);
 }
+size_t size_sort_part_bytes() { return static_cast<size_t>(SIZE_SORT_BLOCKS) * 64 * 4; }
 void launch_list_big_edges(hipStream_t st, const msgpu_edge *edges, uint64_t n_edges, uint32_t *big_list,
                            uint64_t *big_off, uint64_t *cursor) {
   if (n_edges)
