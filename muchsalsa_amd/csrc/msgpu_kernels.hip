@@ -1117,7 +1117,7 @@ __device__ __forceinline__ int paths_of_direction(unsigned long long act, bool d
   return np;
 }
 
-__global__ __launch_bounds__(256) void k_chain(ChainArgs a, const uint32_t *list, uint32_t n_list) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_chain(ChainArgs a, const uint32_t *list, uint32_t n_list) {
   // per wave: the 64 ChainElem of the sweep, later (the elements are dead once the compatibility masks exist) the
   // path lists of both directions in the same bytes -- 14 KB per workgroup instead of 26 KB, so LDS no longer caps
   // the occupancy
