@@ -1911,8 +1911,10 @@ __global__ __launch_bounds__(1024) void k_size_hist(const msgpu_edge *edges, uin
   __shared__ uint32_t s_h[64];
   if (threadIdx.x < 64) s_h[threadIdx.x] = 0;
   __syncthreads();
-  const uint32_t b0 = blockIdx.x * chunk, b1 = min(b0 + chunk, n_edges);
-  for (uint32_t e = b0 + threadIdx.x; e < b1; e += 1024) {
+  const uint64_t b0_64 = static_cast<uint64_t>(blockIdx.x) * chunk;
+  const uint32_t b0 = static_cast<uint32_t>(min(b0_64, static_cast<uint64_t>(n_edges)));
+  const uint32_t b1 = static_cast<uint32_t>(min(b0_64 + chunk, static_cast<uint64_t>(n_edges)));
+  for (uint64_t e = static_cast<uint64_t>(b0) + threadIdx.x; e < b1; e += 1024) {
     const uint32_t n = edges[e].em_cnt;
     if (n >= 1 && n <= 64) atomicAdd(&s_h[n - 1], 1u);
   }
@@ -1972,10 +1974,12 @@ __global__ __launch_bounds__(1024) void k_size_scatter(const msgpu_edge *edges, 
   __shared__ uint32_t s_pos[64];
   if (threadIdx.x < 64) s_pos[threadIdx.x] = part[blockIdx.x * 64 + threadIdx.x];
   __syncthreads();
-  const uint32_t b0 = blockIdx.x * chunk, b1 = min(b0 + chunk, n_edges);
-  for (uint32_t e = b0 + threadIdx.x; e < b1; e += 1024) {
+  const uint64_t b0_64 = static_cast<uint64_t>(blockIdx.x) * chunk;
+  const uint32_t b0 = static_cast<uint32_t>(min(b0_64, static_cast<uint64_t>(n_edges)));
+  const uint32_t b1 = static_cast<uint32_t>(min(b0_64 + chunk, static_cast<uint64_t>(n_edges)));
+  for (uint64_t e = static_cast<uint64_t>(b0) + threadIdx.x; e < b1; e += 1024) {
     const uint32_t n = edges[e].em_cnt;
-    if (n >= 1 && n <= 64) list[atomicAdd(&s_pos[n - 1], 1u)] = e;
+    if (n >= 1 && n <= 64) list[atomicAdd(&s_pos[n - 1], 1u)] = static_cast<uint32_t>(e);
   }
 }
 
@@ -2597,7 +2601,8 @@ void launch_chain_sub(hipStream_t st, const ChainArgs &a, int width, const uint3
 void launch_sort_edges_by_size(hipStream_t st, const msgpu_edge *edges, uint64_t n_edges, uint32_t *part, uint32_t *list,
                                uint32_t *counts) {
   if (!n_edges) return;
-  const uint32_t E = static_cast<uint32_t>(n_edges), chunk = (E + SIZE_SORT_BLOCKS - 1) / SIZE_SORT_BLOCKS;
+  const uint32_t E = static_cast<uint32_t>(n_edges); // < 2^32 - 16 (checked by the caller)
+  const uint32_t chunk = static_cast<uint32_t>((n_edges + SIZE_SORT_BLOCKS - 1) / SIZE_SORT_BLOCKS);
   hipLaunchKernelGGL(k_size_hist, dim3(SIZE_SORT_BLOCKS), dim3(1024), 0, st, edges, E, chunk, part);
   hipLaunchKernelGGL(k_size_scan, dim3(1), dim3(1024), 0, st, part, counts);
   hipLaunchKernelGGL(k_size_scatter, dim3(SIZE_SORT_BLOCKS), dim3(1024), 0, st, edges, E, chunk, part, list);
