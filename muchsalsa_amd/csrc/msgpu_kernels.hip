@@ -610,53 +610,54 @@ __global__ __launch_bounds__(256) void k_candidates(CandArgs a, const uint32_t *
   if (tid == 0) s_pfx[n1] = T;
   __syncthreads();
 
-  // (b) visit every scaffold row of every anchor of v1.  Four rows per lane are fetched before any is tested, so
-  // the gathers of a whole read overlap instead of costing one memory round trip per 256 rows.
-  constexpr int XU = 4;
-  for (uint32_t x0 = 0; x0 < T; x0 += 256 * XU) {
-    IRow     o[XU];
-    uint32_t jj[XU], vmm[XU];
-    bool     in[XU];
+  // (b) visit every scaffold row of every anchor of v1: sixteen lanes per row of v1, lane i of the group takes scaffold
+  // rows i, i + 16, ... of that row's anchor (a scaffold has ~10 rows), so a visit costs no search for "which row of
+  // v1 am I in" -- the binary search over the prefix sums used to be a quarter of this kernel's vector instructions.
+  // Each lane keeps four rows of v1 in flight: all their gathers are issued before any is tested.
+  {
+    constexpr int RU  = 4;
+    const int     sub = tid & 15, grp = tid >> 4;
+    for (uint32_t j0 = 0; j0 < n1; j0 += 16 * RU) {
+      uint32_t jj[RU], cntj[RU], aoj[RU];
 #pragma unroll
-    for (int u = 0; u < XU; ++u) {
-      const uint32_t x = x0 + u * 256 + tid;
-      in[u]            = x < T;
-      jj[u] = vmm[u] = 0;
-      if (in[u]) {
-        uint32_t lo = 0, hi = n1; // largest j with s_pfx[j] <= x
-        while (hi - lo > 1) {
-          uint32_t mid = (lo + hi) >> 1;
-          if (s_pfx[mid] <= x)
-            lo = mid;
-          else
-            hi = mid;
+      for (int u = 0; u < RU; ++u) {
+        const uint32_t j = j0 + u * 16 + grp;
+        jj[u]            = j < n1 ? j : 0;
+        cntj[u]          = j < n1 ? s_pfx[j + 1] - s_pfx[j] : 0;
+        aoj[u]           = j < n1 ? s_aoff[j] : 0;
+      }
+      for (uint32_t i = sub;; i += 16) {
+        IRow o[RU];
+        bool in[RU], any = false;
+#pragma unroll
+        for (int u = 0; u < RU; ++u) {
+          in[u] = i < cntj[u];
+          any |= in[u];
+          if (in[u]) o[u] = load_irow(&a.by_anchor[aoj[u] + i]);
         }
-        jj[u]  = lo;
-        vmm[u] = s_aoff[lo] + (x - s_pfx[lo]);
-        o[u]   = load_irow(&a.by_anchor[vmm[u]]);
-      }
-    }
+        if (!__ballot(any)) break; // wave-uniform: every lane of the wavefront leaves together
 #pragma unroll
-    for (int u = 0; u < XU; ++u) {
-      if (x0 + u * 256 >= T) break; // uniform
-      bool           pass = false;
-      const uint32_t j = jj[u], r2 = in[u] ? o[u].other : 0;
-      if (in[u]) {
-        const int ovlo = max(o[u].i_lo, s_ilo[j]), ovhi = min(o[u].i_hi, s_ihi[j]);
-        // owner rule (v2 > v1 <=> v1 has the lower first line, MatchMap.cpp:204-213) + overlap test (:192)
-        pass = r2 > r && ovlo <= ovhi && (ovhi - ovlo) > static_cast<int>(a.th_overlap);
-      }
-      unsigned long long m = __ballot(pass);
-      if (m) {
-        uint32_t base = 0;
-        int      lane = tid & 63;
-        if (lane == 0) base = atomicAdd(&s_nc, static_cast<uint32_t>(__popcll(m)));
-        base = __shfl(base, 0);
-        if (pass) {
-          uint32_t c = base + static_cast<uint32_t>(__popcll(m & ((1ull << lane) - 1)));
-          s_v2[c]    = r2;
-          s_j[c]     = static_cast<uint16_t>(j);
-          s_t[c]     = vmm[u];
+        for (int u = 0; u < RU; ++u) {
+          bool           pass = false;
+          const uint32_t j = jj[u], r2 = in[u] ? o[u].other : 0;
+          if (in[u]) {
+            const int ovlo = max(o[u].i_lo, s_ilo[j]), ovhi = min(o[u].i_hi, s_ihi[j]);
+            // owner rule (v2 > v1 <=> v1 has the lower first line, MatchMap.cpp:204-213) + overlap test (:192)
+            pass = r2 > r && ovlo <= ovhi && (ovhi - ovlo) > static_cast<int>(a.th_overlap);
+          }
+          unsigned long long m = __ballot(pass);
+          if (m) {
+            uint32_t base = 0;
+            int      lane = tid & 63;
+            if (lane == 0) base = atomicAdd(&s_nc, static_cast<uint32_t>(__popcll(m)));
+            base = __shfl(base, 0);
+            if (pass) {
+              uint32_t c = base + static_cast<uint32_t>(__popcll(m & ((1ull << lane) - 1)));
+              s_v2[c]    = r2;
+              s_j[c]     = static_cast<uint16_t>(j);
+              s_t[c]     = aoj[u] + i;
+            }
+          }
         }
       }
     }
