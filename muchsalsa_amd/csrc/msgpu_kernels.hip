@@ -732,28 +732,60 @@ __global__ __launch_bounds__(256) void k_candidates(CandArgs a, const uint32_t *
   if (tid == 0) g_off[ng] = static_cast<uint16_t>(nc);
   __syncthreads();
 
-  // (c4) move every candidate to its group's staging segment (own values were read into registers before the sync)
+  // (c4/c5) inside a group the candidates go in the order of j = the vStart order of mpp.cpp:164-172 (j is unique
+  // inside a group).  One bitmap of R1MAX bits per group (in the bytes of h_cnt, dead since (c3)): every candidate sets
+  // bit j of its group, then its position is the number of set bits below j -- a popcount or two per candidate
+  // instead of a walk over the group's members (that walk was a quarter of this kernel's time).
+  constexpr uint32_t WPG = R1MAX / 32; // bitmap words per group
+  if (ng <= static_cast<uint32_t>(HSZ) / WPG) {
+    uint32_t *const bm = h_cnt;
+    for (uint32_t w = tid; w < ng * WPG; w += 256) bm[w] = 0;
+    __syncthreads();
+    uint32_t c_rk[CPT];
 #pragma unroll
-  for (int q = 0; q < CPT; ++q) {
-    const uint32_t c = tid + 256 * q;
-    if (c < nc) {
-      const uint32_t rk  = g_rank[c_slot[q]];
-      const uint32_t pos = g_off[rk] + c_li[q];
-      s_j[pos]           = c_j[q];
-      s_t[pos]           = c_t[q];
-      s_g[pos]           = static_cast<uint16_t>(rk);
+    for (int q = 0; q < CPT; ++q) {
+      const uint32_t c = tid + 256 * q;
+      c_rk[q]          = 0;
+      if (c < nc) {
+        c_rk[q] = g_rank[c_slot[q]];
+        atomicOr(&bm[c_rk[q] * WPG + (c_j[q] >> 5)], 1u << (c_j[q] & 31));
+      }
     }
-  }
-  __syncthreads();
-
-  // (c5) inside a group order by j = the vStart order of mpp.cpp:164-172 (j is unique inside a group)
-  for (uint32_t pos = tid; pos < nc; pos += 256) {
-    const uint32_t rk = s_g[pos], gs = g_off[rk], ge = g_off[rk + 1];
-    const uint16_t mj = s_j[pos];
-    uint32_t       rr = 0;
-    for (uint32_t q = gs; q < ge; ++q) rr += (s_j[q] < mj) ? 1u : 0u;
-    a.cand_j[co + gs + rr] = mj;
-    a.cand_t[co + gs + rr] = s_t[pos];
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < CPT; ++q) {
+      const uint32_t c = tid + 256 * q;
+      if (c < nc) {
+        const uint32_t *g  = bm + c_rk[q] * WPG;
+        const uint32_t  jw = c_j[q] >> 5;
+        uint32_t        rr = static_cast<uint32_t>(__popc(g[jw] & ((1u << (c_j[q] & 31)) - 1u)));
+        for (uint32_t w = 0; w < jw; ++w) rr += static_cast<uint32_t>(__popc(g[w]));
+        const uint64_t dst = co + g_off[c_rk[q]] + rr;
+        a.cand_j[dst]      = c_j[q];
+        a.cand_t[dst]      = c_t[q];
+      }
+    }
+  } else { // more groups than bitmaps fit: stage by group, rank by comparison
+#pragma unroll
+    for (int q = 0; q < CPT; ++q) {
+      const uint32_t c = tid + 256 * q;
+      if (c < nc) {
+        const uint32_t rk  = g_rank[c_slot[q]];
+        const uint32_t pos = g_off[rk] + c_li[q];
+        s_j[pos]           = c_j[q];
+        s_t[pos]           = c_t[q];
+        s_g[pos]           = static_cast<uint16_t>(rk);
+      }
+    }
+    __syncthreads();
+    for (uint32_t pos = tid; pos < nc; pos += 256) {
+      const uint32_t rk = s_g[pos], gs = g_off[rk], ge = g_off[rk + 1];
+      const uint16_t mj = s_j[pos];
+      uint32_t       rr = 0;
+      for (uint32_t q = gs; q < ge; ++q) rr += (s_j[q] < mj) ? 1u : 0u;
+      a.cand_j[co + gs + rr] = mj;
+      a.cand_t[co + gs + rr] = s_t[pos];
+    }
   }
   // (d) one edge per group (edges with more than 64 EdgeMatches are counted: they take k_chain_big)
   for (uint32_t g = tid; g < ng; g += 256) {

@@ -78,6 +78,22 @@ def test_mixed_direction_edges(oracle, dense):
     assert_tables_equal(_gpu_tables(rows), want, "mixed directions (%d edges)" % n_mixed)
 
 
+@pytest.mark.parametrize("n_anchors,coverage", [(100, 40), (200, 60)])
+def test_reads_with_many_partners(oracle, n_anchors, coverage):
+    """k_candidates orders a group's candidates by popcounts in one bitmap per group (64 / 128 groups fit in LDS,
+    depending on the class); a read with more partner reads than that takes the staged comparison ranking instead.
+    High coverage with few anchors per read gives such reads inside the LDS classes."""
+    from muchsalsa_amd import synth
+    rows, _, _ = synth.accepted_rows(synth.paf_table(600, 3000, n_anchors, 31, coverage=coverage))
+    want = oracle.overlap(rows)
+    partners = np.bincount(want["edges"]["v1"], minlength=int(rows["read_id"].max()) + 1)
+    visits = np.bincount(rows["read_id"], weights=np.bincount(rows["anchor_id"])[rows["anchor_id"]])
+    small = ((partners > 64) & (visits <= 512)).sum()
+    mid = ((partners > 128) & (visits > 512) & (visits <= 1024)).sum()
+    assert small + mid > 0, (int(partners.max()), int(visits.max()))
+    assert_tables_equal(_gpu_tables(rows), want, "many partners")
+
+
 def test_shortcut_and_full_sweep_agree(oracle, monkeypatch):
     """k_chain's all-pairs-compatible shortcut must change nothing: same tables with it disabled, and equal to the
     oracle's; and it must actually be taken on clean synthetic overlaps."""
