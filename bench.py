@@ -23,9 +23,10 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 # HBM bytes per launch from the PMC counters (FETCH_SIZE x 2 per the gfx950 note of MI355X_MICROARCH.md + WRITE_SIZE),
-# collected with rocprofv3 in separate --pmc passes of this same command: profiles/r1_03_final/pmc_summary.csv.
+# collected with rocprofv3 in separate --pmc passes of this same command (tools/pmc_passes.sh):
+# profiles/r1_08_final/pmc_summary.csv for the three chain kernels together, profiles/r1_05_gather for the gather.
 # They cannot be read from inside this process, so they are quoted for the one configuration they were measured on.
-PMC_TRAFFIC_BYTES = {("cfg3", 1): {"k_chain": 3.77e9, "k_gather_packed": 1.48e9}}  # profiles/r1_05_gather
+PMC_TRAFFIC_BYTES = {("cfg3", 1): {"k_chain": 3.77e9, "k_gather_packed": 1.48e9}}
 
 WORKLOADS = {
     # BASELINE.json configs[2]: the configuration the metric is quoted on
