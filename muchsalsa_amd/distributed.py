@@ -49,7 +49,7 @@ def gather_slabs(counts, fill_slab, device, group=None):
     dist.all_gather_into_tensor(allc, mine, group=group)
     all_counts = allc.cpu().numpy().reshape(world, 3)
     offs, slab_bytes = slab_layout(all_counts.max(axis=0))
-    slab = torch.zeros(slab_bytes, dtype=torch.uint8, device=device)
+    slab = torch.empty(slab_bytes, dtype=torch.uint8, device=device)  # padding between the tables is never read
     fill_slab(slab, offs)
     gathered = torch.empty(world * slab_bytes, dtype=torch.uint8, device=device)
     dist.all_gather_into_tensor(gathered, slab, group=group)  # the one collective of the path
