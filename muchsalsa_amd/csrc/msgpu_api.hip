@@ -560,10 +560,10 @@ int msgpu_chaining_and_overlaps(msgpu_ctx *c) {
   a.edge_nids    = c->edge_nids.as<uint32_t>();
   a.err          = scalar<uint32_t>(c, SC_ERR);
   if (!c->pair_tab.p) {
-    ENSURE(c, pair_tab, 2016 * sizeof(uint16_t));
-    launch_fill_pair_tab(st, c->pair_tab.as<uint16_t>());
+    ENSURE(c, pair_tab, 3 * PAIR_TAB_STRIDE * sizeof(uint32_t));
+    launch_fill_pair_tab(st, c->pair_tab.as<uint32_t>());
   }
-  a.pair_tab     = c->pair_tab.as<uint16_t>();
+  a.pair_tab     = c->pair_tab.as<uint32_t>();
   ENSURE(c, edge_fast, (E + 1) * 4);
   {
     uint32_t *const zero[4]   = {c->edge_norders.as<uint32_t>(), c->edge_nids.as<uint32_t>(), c->edge_fast.as<uint32_t>(),

@@ -47,7 +47,7 @@ struct ChainArgs {
   uint32_t        *ids_scr;   // slots em_off .. em_off + em_cnt of an edge
   uint32_t        *edge_norders, *edge_nids;
   uint32_t        *err;
-  const uint16_t  *pair_tab; // (l << 8 | k) for the 2016 pairs k < l < 64
+  const uint32_t  *pair_tab; // three tables (sweep width 64, 32, 16) of PAIR_TAB_STRIDE entries: k | l << 8 | run << 16
   uint32_t        *edge_fast; // per edge: 1 if the all-pairs-compatible shortcut was taken (may be null)
   int              fast_path; // 0 disables the shortcut (every edge takes the full pair sweep)
   double           wiggle, ratio_pct, alt_frac;
@@ -116,7 +116,8 @@ void launch_candidates_big(hipStream_t st, const CandArgs &a, const uint32_t *li
 void launch_emit_edges(hipStream_t st, const uint32_t *n_edge, const uint32_t *n_cand, const uint64_t *edge_base,
                        const uint64_t *em_base, const uint64_t *cand_off, const uint32_t *scr_v2,
                        const uint32_t *scr_start, uint32_t V, msgpu_edge *edges, uint64_t *edge_cand);
-void launch_fill_pair_tab(hipStream_t st, uint16_t *tab);
+constexpr uint32_t PAIR_TAB_STRIDE = 2016 + 128; // pairs k < l < 64 + padding read by lanes past the last pair
+void launch_fill_pair_tab(hipStream_t st, uint32_t *tab);
 void launch_chain(hipStream_t st, const ChainArgs &a, const uint32_t *list, uint32_t n_list);
 void launch_chain_sub(hipStream_t st, const ChainArgs &a, int width, const uint32_t *list, uint32_t n_list);
 void launch_sort_edges_by_size(hipStream_t st, const msgpu_edge *edges, uint64_t n_edges, uint32_t *part, uint32_t *list,

@@ -1298,19 +1298,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
   // One-direction edges (the rule for true overlaps) need no per-pair direction test: every pair is "valid" and the
   // flip of mpp.cpp:131 is the same for all of them.
   const bool one_dir = m_plus == 0 || m_minus == 0; // wave-uniform
-  // (k, l) of pair p: precomputed, the same for every edge.  Lanes past P read the edge's last pair (a valid pair, masked
-  // out below), so the load needs no branch.
-  const int Pm1     = max(P - 1, 0);
-  uint32_t  kl_next = a.pair_tab[min(lane, Pm1)];
+  // Pair p: k | l << 8 | run << 16 from a table that is the same for every edge (run = length of the stretch of row l
+  // that starts at this lane of a 64-wide step, 0 if none starts here).  The table is padded with (0, 1, 0) beyond the
+  // last pair and every (k, l) in it is < 64, so lanes past P read without a clamp or a branch and are masked out.
+  const uint32_t *tab     = a.pair_tab; // + p0 below: a scalar base, the lane's offset never changes
+  uint32_t        kl_next = tab[lane];
+  // The scalar registers of this loop are all taken by pair masks; a loop-invariant scalar operand would be spilled and
+  // re-read (v_readlane) in every step.  The one constant the common path compares with lives in a vector register.
+  double wiggle = a.wiggle;
+  asm volatile("" : "+v"(wiggle));
   for (int p0 = 0; p0 < P; p0 += 64) {
-    const int          p = p0 + lane;
     unsigned long long bits = 0; // checkCompatibility(k, l) of the 64 pairs of this step
     const uint32_t     kl = kl_next;
-    kl_next               = a.pair_tab[min(p + 64, Pm1)]; // the next step's pairs are on their way while this one computes
-    const int k = static_cast<int>(kl & 0xffu), l = static_cast<int>(kl >> 8);
+    kl_next               = (tab + p0 + 64)[lane]; // the next step's pairs are on their way while this one computes
+    const int k = static_cast<int>(kl & 0xffu), l = static_cast<int>((kl >> 8) & 0xffu), run = static_cast<int>(kl >> 16);
     { // every lane evaluates a pair: no divergence, all masks are wave-uniform
       typedef unsigned long long M;
-      M valid = __ballot(p < P), KD = 0;
+      M valid = __ballot(lane < P - p0), KD = 0;
       if (!one_dir) { // pairs of one direction only
         const bool kd = (m_plus >> k) & 1ull, ld = (m_plus >> l) & 1ull;
         valid &= __ballot(kd == ld);
@@ -1333,7 +1337,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
       const M live    = valid & ~(f1.abort_ | f2.abort_);
       const double mx = fmax(d1, d2); // finite operands: the same values std::max / std::min return
       const double df = mx - fmin(d1, d2);
-      const M near_ = __ballot(df <= a.wiggle), sum_ok = __ballot(d1 + d2 <= a.wiggle);
+      const M near_ = __ballot(df <= wiggle), sum_ok = __ballot(d1 + d2 <= wiggle);
       M       ok    = ((same & near_) | (codir & ~same & sum_ok)) & live;
       // the fp64 division of :136 only where the first test failed (rare for true overlaps)
       const M need_div = same & ~near_ & live;
@@ -1344,11 +1348,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
       }
       bits = ok;
     }
-    // the pairs of row l are consecutive lanes; the first lane of each run stores the run's bits
-    if (p < P && (k == 0 || lane == 0)) {
-      const int          len = min(l - k, 64 - lane);
+    // the pairs of row l are consecutive lanes; the first lane of each stretch stores the stretch's bits (lanes past P
+    // hold zeros in `bits`)
+    if (run) {
       unsigned long long seg = bits >> lane;
-      if (len < 64) seg &= (1ull << len) - 1;
+      if (run < 64) seg &= (1ull << run) - 1;
       cm[l] |= seg << k;
     }
   }
@@ -1744,13 +1748,18 @@ __global__ __launch_bounds__(256) void k_chain_sub(ChainArgs a, const uint32_t *
   Pmax = __builtin_amdgcn_readfirstlane(Pmax);
   const bool               one_dir = __ballot(m_plus != 0 && m_minus != 0) == 0; // every edge of the wave has one direction
   const unsigned long long KD_one  = __ballot(m_minus == 0);
-  const int                Pm1     = max(P - 1, 0); // lanes past P read their edge's last pair (or pair 0 = (0, 1))
-  uint32_t                 kl_next = a.pair_tab[min(sl, Pm1)];
+  // the table of this width (k | l << 8 | run << 16, run for W-wide steps); lanes past P read their edge's last pair (or
+  // pair 0 = (0, 1)), which keeps (k, l) inside the group
+  const uint32_t *tab     = a.pair_tab + (W == 32 ? PAIR_TAB_STRIDE : 2 * PAIR_TAB_STRIDE);
+  const int       Pm1     = max(P - 1, 0);
+  uint32_t        kl_next = tab[min(sl, Pm1)];
+  double          wiggle  = a.wiggle; // in a vector register: see k_chain
+  asm volatile("" : "+v"(wiggle));
   for (int p0 = 0; p0 < Pmax; p0 += W) {
     const int      p  = p0 + sl;
     const uint32_t kl = kl_next;
-    kl_next           = a.pair_tab[min(p + W, Pm1)];
-    const int k = static_cast<int>(kl & 0xffu), l = static_cast<int>(kl >> 8);
+    kl_next           = tab[min(p + W, Pm1)];
+    const int k = static_cast<int>(kl & 0xffu), l = static_cast<int>((kl >> 8) & 0xffu), run = static_cast<int>(kl >> 16);
     unsigned long long bits;
     {
       typedef unsigned long long M;
@@ -1770,7 +1779,7 @@ __global__ __launch_bounds__(256) void k_chain_sub(ChainArgs a, const uint32_t *
       const M live    = valid & ~(f1.abort_ | f2.abort_);
       const double mx = fmax(d1, d2);
       const double df = mx - fmin(d1, d2);
-      const M near_ = __ballot(df <= a.wiggle), sum_ok = __ballot(d1 + d2 <= a.wiggle);
+      const M near_ = __ballot(df <= wiggle), sum_ok = __ballot(d1 + d2 <= wiggle);
       M       ok    = ((same & near_) | (codir & ~same & sum_ok)) & live;
       const M need_div = same & ~near_ & live;
       if (need_div) {
@@ -1782,10 +1791,9 @@ __global__ __launch_bounds__(256) void k_chain_sub(ChainArgs a, const uint32_t *
     }
     // the pairs of row l are consecutive lanes of the group; the first lane of each run stores the run's bits
     const uint32_t gb = group_bits<W>(bits, gbase);
-    if (p < P && (k == 0 || sl == 0)) {
-      const int len = min(l - k, W - sl);
-      uint32_t  seg = gb >> sl;
-      if (len < 32) seg &= (1u << len) - 1u;
+    if (run && p < P) {
+      uint32_t seg = gb >> sl;
+      if (run < 32) seg &= (1u << run) - 1u;
       cm[gbase + l] |= seg << k;
     }
   }
@@ -2397,14 +2405,23 @@ __global__ __launch_bounds__(256) void k_list_big_edges(const msgpu_edge *edges,
   }
 }
 
-// (k, l) of the flattened pair index p = l(l-1)/2 + k, k < l < 64
-__global__ __launch_bounds__(256) void k_fill_pair_tab(uint16_t *tab) {
-  const int p = blockIdx.x * 256 + threadIdx.x;
-  if (p >= 2016) return;
+// Pair tables: entry p = k | l << 8 | run << 16 for the flattened pair index p = l(l-1)/2 + k, k < l < 64, where run
+// is the length of the stretch of row l that starts at lane p % W of a W-wide sweep step (0 if no stretch starts
+// there).  Three tables (W = 64, 32, 16) of PAIR_TAB_STRIDE entries, each padded with (0, 1, 0).
+__global__ __launch_bounds__(256) void k_fill_pair_tab(uint32_t *tab) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= 3 * static_cast<int>(PAIR_TAB_STRIDE)) return;
+  const int t = i / static_cast<int>(PAIR_TAB_STRIDE), p = i % static_cast<int>(PAIR_TAB_STRIDE), W = 64 >> t;
+  if (p >= 2016) {
+    tab[i] = 1u << 8;
+    return;
+  }
   int l = static_cast<int>((1.0f + __fsqrt_rn(1.0f + 8.0f * static_cast<float>(p))) * 0.5f);
   if (l * (l - 1) / 2 > p) --l;
   if ((l + 1) * l / 2 <= p) ++l;
-  tab[p] = static_cast<uint16_t>((l << 8) | (p - l * (l - 1) / 2));
+  const int k = p - l * (l - 1) / 2, lane = p % W;
+  const int run = (k == 0 || lane == 0) ? min(l - k, W - lane) : 0;
+  tab[i] = static_cast<uint32_t>(k | (l << 8) | (run << 16));
 }
 
 // dense, canonical order + id tables.  One wavefront per 64 edges: every lane fetches its edge's bookkeeping, then
@@ -2617,8 +2634,8 @@ void launch_emit_edges(hipStream_t st, const uint32_t *n_edge, const uint32_t *n
     hipLaunchKernelGGL(k_emit_edges, grid1(V, 16), dim3(256), 0, st, n_edge, n_cand, edge_base, em_base, cand_off, scr_v2,
                        scr_start, V, edges, edge_cand);
 }
-void launch_fill_pair_tab(hipStream_t st, uint16_t *tab) {
-  hipLaunchKernelGGL(k_fill_pair_tab, dim3(8), dim3(256), 0, st, tab);
+void launch_fill_pair_tab(hipStream_t st, uint32_t *tab) {
+  hipLaunchKernelGGL(k_fill_pair_tab, dim3((3 * PAIR_TAB_STRIDE + 255) / 256), dim3(256), 0, st, tab);
 }
 void launch_chain(hipStream_t st, const ChainArgs &a, const uint32_t *list, uint32_t n_list) {
   const uint64_t n = list ? n_list : a.n_edges;
