@@ -1298,9 +1298,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
   // One-direction edges (the rule for true overlaps) need no per-pair direction test: every pair is "valid" and the
   // flip of mpp.cpp:131 is the same for all of them.
   const bool one_dir = m_plus == 0 || m_minus == 0; // wave-uniform
-  // Pair p: k | l << 8 | run << 16 from a table that is the same for every edge (run = length of the stretch of row l
-  // that starts at this lane of a 64-wide step, 0 if none starts here).  The table is padded with (0, 1, 0) beyond the
-  // last pair and every (k, l) in it is < 64, so lanes past P read without a clamp or a branch and are masked out.
+  // Pair p: k | l << 8 | run << 16 | (64 - run - k) << 24 from a table that is the same for every edge (run = length of
+  // the stretch of row l that starts at this lane of a 64-wide step, 0 if none starts here).  The table is padded with
+  // (0, 1, 0) beyond the last pair and every (k, l) in it is < 64, so lanes past P read without a clamp or a branch and
+  // are masked out.
   const uint32_t *tab     = a.pair_tab; // + p0 below: a scalar base, the lane's offset never changes
   uint32_t        kl_next = tab[lane];
   // The scalar registers of this loop are all taken by pair masks; a loop-invariant scalar operand would be spilled and
@@ -1311,7 +1312,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     unsigned long long bits = 0; // checkCompatibility(k, l) of the 64 pairs of this step
     const uint32_t     kl = kl_next;
     kl_next               = (tab + p0 + 64)[lane]; // the next step's pairs are on their way while this one computes
-    const int k = static_cast<int>(kl & 0xffu), l = static_cast<int>((kl >> 8) & 0xffu), run = static_cast<int>(kl >> 16);
+    const int k = static_cast<int>(kl & 0xffu), l = static_cast<int>((kl >> 8) & 0xffu), run = static_cast<int>((kl >> 16) & 0xffu);
     { // every lane evaluates a pair: no divergence, all masks are wave-uniform
       typedef unsigned long long M;
       M valid = __ballot(lane < P - p0), KD = 0;
@@ -1350,10 +1351,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     }
     // the pairs of row l are consecutive lanes; the first lane of each stretch stores the stretch's bits (lanes past P
     // hold zeros in `bits`)
-    if (run) {
-      unsigned long long seg = bits >> lane;
-      if (run < 64) seg &= (1ull << run) - 1;
-      cm[l] |= seg << k;
+    if (run) { // keep `run` bits from bit `lane` on and put them at bit k: three shifts, the counts come from the table
+      const int up = 64 - run, down = static_cast<int>(kl >> 24); // down = up - k >= 1
+      cm[l] |= ((bits >> lane) << up) >> down;
     }
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1759,7 +1759,7 @@ __global__ __launch_bounds__(256) void k_chain_sub(ChainArgs a, const uint32_t *
     const int      p  = p0 + sl;
     const uint32_t kl = kl_next;
     kl_next           = tab[min(p + W, Pm1)];
-    const int k = static_cast<int>(kl & 0xffu), l = static_cast<int>((kl >> 8) & 0xffu), run = static_cast<int>(kl >> 16);
+    const int k = static_cast<int>(kl & 0xffu), l = static_cast<int>((kl >> 8) & 0xffu), run = static_cast<int>((kl >> 16) & 0xffu);
     unsigned long long bits;
     {
       typedef unsigned long long M;
@@ -1791,11 +1791,7 @@ __global__ __launch_bounds__(256) void k_chain_sub(ChainArgs a, const uint32_t *
     }
     // the pairs of row l are consecutive lanes of the group; the first lane of each run stores the run's bits
     const uint32_t gb = group_bits<W>(bits, gbase);
-    if (run && p < P) {
-      uint32_t seg = gb >> sl;
-      if (run < 32) seg &= (1u << run) - 1u;
-      cm[gbase + l] |= seg << k;
-    }
+    if (run && p < P) cm[gbase + l] |= __builtin_amdgcn_ubfe(gb, static_cast<uint32_t>(sl), static_cast<uint32_t>(run)) << k; // run <= 31
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -2405,7 +2401,7 @@ __global__ __launch_bounds__(256) void k_list_big_edges(const msgpu_edge *edges,
   }
 }
 
-// Pair tables: entry p = k | l << 8 | run << 16 for the flattened pair index p = l(l-1)/2 + k, k < l < 64, where run
+// Pair tables: entry p = k | l << 8 | run << 16 | (64 - run - k) << 24 for the flattened pair index p = l(l-1)/2 + k, k < l < 64, where run
 // is the length of the stretch of row l that starts at lane p % W of a W-wide sweep step (0 if no stretch starts
 // there).  Three tables (W = 64, 32, 16) of PAIR_TAB_STRIDE entries, each padded with (0, 1, 0).
 __global__ __launch_bounds__(256) void k_fill_pair_tab(uint32_t *tab) {
@@ -2421,7 +2417,7 @@ __global__ __launch_bounds__(256) void k_fill_pair_tab(uint32_t *tab) {
   if ((l + 1) * l / 2 <= p) ++l;
   const int k = p - l * (l - 1) / 2, lane = p % W;
   const int run = (k == 0 || lane == 0) ? min(l - k, W - lane) : 0;
-  tab[i] = static_cast<uint32_t>(k | (l << 8) | (run << 16));
+  tab[i] = static_cast<uint32_t>(k | (l << 8) | (run << 16)) | (static_cast<uint32_t>(64 - run - k) << 24);
 }
 
 // dense, canonical order + id tables.  One wavefront per 64 edges: every lane fetches its edge's bookkeeping, then
