@@ -1338,15 +1338,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
       const M codir   = (f1.pos & p2) | (f1.neg & n2); // :137 same sign
       const M same    = codir & ~(f1.ovl ^ f2.ovl);    // :133 equal and non-zero
       const M live    = valid & ~(f1.abort_ | f2.abort_);
-      const double mx = fmax(d1, d2); // finite operands: the same values std::max / std::min return
-      const double df = mx - fmin(d1, d2);
+      // std::max(d1, d2) - std::min(d1, d2) = |d1 - d2| bit for bit (a - b and b - a round to the same magnitude); the
+      // maximum itself is only needed by the division
+      const double df = fabs(d1 - d2);
       const M near_ = __ballot(df <= wiggle), sum_ok = __ballot(d1 + d2 <= wiggle);
       M       ok    = ((same & near_) | (codir & ~same & sum_ok)) & live;
       // the fp64 division of :136 only where the first test failed (rare for true overlaps)
       const M need_div = same & ~near_ & live;
       if (need_div) {
         bool pass = false;
-        if (__builtin_amdgcn_inverse_ballot_w64(need_div)) pass = df * 100 / mx <= a.ratio_pct;
+        if (__builtin_amdgcn_inverse_ballot_w64(need_div)) pass = df * 100 / fmax(d1, d2) <= a.ratio_pct;
         ok |= __ballot(pass);
       }
       bits = ok;
@@ -1779,14 +1780,13 @@ __global__ __launch_bounds__(256) void k_chain_sub(ChainArgs a, const uint32_t *
       const M codir   = (f1.pos & p2) | (f1.neg & n2m);
       const M same    = codir & ~(f1.ovl ^ f2.ovl);
       const M live    = valid & ~(f1.abort_ | f2.abort_);
-      const double mx = fmax(d1, d2);
-      const double df = mx - fmin(d1, d2);
+      const double df = fabs(d1 - d2); // = std::max - std::min, see k_chain
       const M near_ = __ballot(df <= wiggle), sum_ok = __ballot(d1 + d2 <= wiggle);
       M       ok    = ((same & near_) | (codir & ~same & sum_ok)) & live;
       const M need_div = same & ~near_ & live;
       if (need_div) {
         bool pass = false;
-        if (__builtin_amdgcn_inverse_ballot_w64(need_div)) pass = df * 100 / mx <= a.ratio_pct;
+        if (__builtin_amdgcn_inverse_ballot_w64(need_div)) pass = df * 100 / fmax(d1, d2) <= a.ratio_pct;
         ok |= __ballot(pass);
       }
       bits = ok;
