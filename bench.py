@@ -26,7 +26,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # collected with rocprofv3 in separate --pmc passes of this same command (tools/pmc_passes.sh):
 # profiles/r1_08_final/pmc_summary.csv for the three chain kernels together, profiles/r1_05_gather for the gather.
 # They cannot be read from inside this process, so they are quoted for the one configuration they were measured on.
-PMC_TRAFFIC_BYTES = {("cfg3", 1): {"k_chain": 3.77e9, "k_gather_packed": 1.48e9}}
+PMC_TRAFFIC_BYTES = {("cfg3", 1): {"k_chain": 5.35e9, "k_gather_packed": 1.48e9}}
 
 WORKLOADS = {
     # BASELINE.json configs[2]: the configuration the metric is quoted on
@@ -472,7 +472,9 @@ def main():
                          "traffic": PMC_TRAFFIC_BYTES.get((args.workload, world), {}).get("k_chain"),
                          "algorithmic_bytes_per_launch": int(alg_bytes), "kernel_ms": k_ms,
                          "note": "kernel_ms = the three launches together (HIP events around them on the launch stream); "
-                                 "vector-ALU bound: 80-85 % of the issue cycles, profiles/r1_08_final/README.md"},
+                                 "vector-ALU bound: 0.75-0.92 of the issue cycles; traffic is twice the algorithmic bytes because the "
+                                 "edges run in size order, not table order (rows of a read are re-fetched): "
+                                 "profiles/r1_08_final/README.md"},
         }
         if cons is not None:
             # algorithmic bytes on the 2-bit store: 0.25 B read + 1 B written per base (SURVEY 8(d) counted 1 B + 1 B for a
