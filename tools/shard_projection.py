@@ -17,11 +17,12 @@ from muchsalsa_amd import overlap, synth  # noqa: E402
 
 def main():
     w = WORKLOADS[sys.argv[1] if len(sys.argv) > 1 else "cfg3"]
-    rows = synth.synth_rows(w["n_reads"], w["read_len"], w["n_anchors"], w["seed"])
+    rows, read_names, anchor_names = synth.accepted_rows(synth.paf_table(w["n_reads"], w["read_len"], w["n_anchors"], w["seed"]))
     d_rows = torch.from_numpy(rows.view(np.uint8).copy()).cuda()
     out = {}
     for n in (1, 2, 4, 8):
         ctx = overlap.OverlapContext(device=0)
+        ctx.set_id_space(len(read_names), len(anchor_names))
         if n > 1:
             ctx.set_shard(0, n)
         best = None
