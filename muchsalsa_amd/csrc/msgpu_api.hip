@@ -151,7 +151,7 @@ void release_all(msgpu_ctx *c) {
   for (DevBuf *b : all) b->release();
 }
 
-int build_index_once(msgpu_ctx *c, bool force_generic, uint32_t *ix_flags_out) {
+int build_index_once(msgpu_ctx *c, bool force_generic, bool two_pass, uint32_t *ix_flags_out) {
   hipStream_t st = c->stream;
   const uint64_t n = c->n_rows;
   ENSURE(c, scalars, SC_COUNT * sizeof(uint64_t));
@@ -171,11 +171,16 @@ int build_index_once(msgpu_ctx *c, bool force_generic, uint32_t *ix_flags_out) {
 
   const size_t nz = n ? n : 1;
   const size_t mva = size_t(V > A ? V : A) + 2;
+  // One-pass bucketing: every read owns BUCKET_CAP slots, so the rows can be dropped into their read's bucket by the
+  // same pass that counts them (no offsets needed yet).  Used while that fits (reads x 128 x 32 B <= 4 GiB); a read
+  // with more rows raises IXF_OVERFLOW and build_index() comes back here with two_pass = true.
+  constexpr uint32_t BUCKET_CAP = 128;
+  const uint32_t     cap = (!two_pass && V && size_t(V) * BUCKET_CAP * sizeof(IRow) <= (size_t(4) << 30)) ? BUCKET_CAP : 0;
   ENSURE(c, cnt_read, (size_t(V) + 1) * 4);
   ENSURE(c, first_key, (size_t(V) + 1) * 8);
   ENSURE(c, read_off, (size_t(V) + 2) * 4);
   ENSURE(c, cursor, mva * 4);
-  ENSURE(c, bkt_key, nz * sizeof(IRow));
+  ENSURE(c, bkt_key, (cap ? size_t(V) * cap : nz) * sizeof(IRow));
   ENSURE(c, bkt_dead, nz);
   ENSURE(c, by_read, nz * sizeof(IRow));
   ENSURE(c, read_cnt, (size_t(V) + 1) * 4);
@@ -211,16 +216,16 @@ int build_index_once(msgpu_ctx *c, bool force_generic, uint32_t *ix_flags_out) {
   }
 
   launch_index_pass1(st, c->d_rows, n, c->cnt_read.as<uint32_t>(), c->first_key.as<uint64_t>(),
-                     c->anchor_first.as<uint32_t>(), V, A, d_flags, scalar<uint32_t>(c, SC_ERR));
+                     c->anchor_first.as<uint32_t>(), V, A, d_flags, scalar<uint32_t>(c, SC_ERR), c->bkt_key.as<IRow>(), cap);
   launch_read_facts(st, c->d_rows, c->first_key.as<uint64_t>(), V, c->read_len.as<int32_t>(),
                     c->read_first.as<uint32_t>(), scalar<uint32_t>(c, SC_ERR));
   exclusive_scan<uint32_t>(st, c->cnt_read.as<uint32_t>(), V, c->read_off.as<uint32_t>(), c->scan_tmp.as<uint32_t>(),
                            scalar<uint32_t>(c, SC_TOTAL_A));
-  launch_scatter_read(st, c->d_rows, n, c->read_off.as<uint32_t>(), c->cursor.as<uint32_t>(), c->bkt_key.as<IRow>());
+  if (!cap) launch_scatter_read(st, c->d_rows, n, c->read_off.as<uint32_t>(), c->cursor.as<uint32_t>(), c->bkt_key.as<IRow>());
   launch_sort_read(st, c->read_off.as<uint32_t>(), c->cnt_read.as<uint32_t>(), V, c->bkt_key.as<IRow>(),
                    c->by_read.as<IRow>(), c->read_cnt.as<uint32_t>(),
                    c->alive_rank.as<uint32_t>(), c->anchor_cnt.as<uint32_t>(), c->bkt_dead.as<uint8_t>(), d_flags,
-                   c->by_anchor.as<IRow>()); // fast mode: the sort writes the scaffold rows too
+                   c->by_anchor.as<IRow>(), cap); // fast mode: the sort writes the scaffold rows too
   // Fast mode (input grouped by anchor, ascending lines: what the PAF loader hands over) is finished here but for the
   // scaffold offsets, which are the speculative ones of pass 1; the flags come back with the read-back below and
   // only an input that is not in that form pays for the generic scaffold build (a second read-back).
@@ -233,6 +238,10 @@ int build_index_once(msgpu_ctx *c, bool force_generic, uint32_t *ix_flags_out) {
   uint32_t       n_alive = *host_scalar<uint32_t>(c, SC_NALIVE);
   if (err & 2u)
     return fail(c, MSGPU_E_IDS, "a row has an id outside the declared id space (%u reads, %u anchors)", V, A);
+  if (ixf & IXF_OVERFLOW) { // a read did not fit its bucket: nothing of this build is kept
+    *ix_flags_out = ixf;
+    return MSGPU_OK;
+  }
   if ((ixf & ~IXF_DUPS) != 0 && !(err & 1u)) {
     // generic scaffold build: count, scan, bucket by anchor, rank by line (MatchMap.cpp:178-183)
     exclusive_scan<uint32_t>(st, c->anchor_cnt.as<uint32_t>(), A, c->anchor_off_gen.as<uint32_t>(),
@@ -260,11 +269,17 @@ int build_index_once(msgpu_ctx *c, bool force_generic, uint32_t *ix_flags_out) {
 int build_index(msgpu_ctx *c) {
   HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
   uint32_t ixf = 0;
-  int      rc  = build_index_once(c, false, &ixf);
+  bool     two_pass = false;
+  int      rc  = build_index_once(c, false, two_pass, &ixf);
   if (rc != MSGPU_OK) return rc;
+  if (ixf & IXF_OVERFLOW) { // a read with more rows than a one-pass bucket holds: count, scan, scatter instead
+    two_pass = true;
+    rc       = build_index_once(c, false, two_pass, &ixf);
+    if (rc != MSGPU_OK) return rc;
+  }
   // the fast by_anchor path assumed no duplicate (read, anchor) pair; if one turned up, rebuild generically
   if ((ixf & IXF_DUPS) && (ixf & ~IXF_DUPS) == 0) {
-    rc = build_index_once(c, true, &ixf);
+    rc = build_index_once(c, true, two_pass, &ixf);
     if (rc != MSGPU_OK) return rc;
   }
   c->index_fast   = (ixf & ~IXF_DUPS) == 0;

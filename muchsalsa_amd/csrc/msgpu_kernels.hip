@@ -221,17 +221,30 @@ __global__ __launch_bounds__(256) void k_index_init(IndexInitArgs a) {
 
 // pass 1 over the rows: per-read row counts, first line per read, and -- speculatively -- the scaffold offsets that
 // hold when the table is already grouped by anchor with ascending lines (what a PAF from minimap2 looks like).
+// With cap != 0 the same pass also buckets the rows by read: every read owns `cap` slots (bkt_row[rd * cap ..]), a row
+// takes the slot its count atomic returns -- no offsets are needed, so the scan and the second pass over the table
+// (k_scatter_read) fall away.  A read with more than cap rows raises IXF_OVERFLOW and the host rebuilds in two passes.
 __global__ __launch_bounds__(256) void k_index_pass1(const msgpu_row *rows, uint64_t n, uint32_t *cnt_read,
                                                      unsigned long long *first_key, uint32_t *anchor_first,
-                                                     uint32_t *flags, uint32_t V, uint32_t A, uint32_t *err) {
+                                                     uint32_t *flags, uint32_t V, uint32_t A, uint32_t *err,
+                                                     IRow *bkt_row, uint32_t cap) {
   uint64_t i = static_cast<uint64_t>(blockIdx.x) * 256 + threadIdx.x;
   if (i >= n) return;
-  const uint32_t rd = rows[i].read_id, an = rows[i].anchor_id, ln = rows[i].line;
+  const msgpu_row row = rows[i];
+  const uint32_t  rd = row.read_id, an = row.anchor_id, ln = row.line;
   if (rd >= V || an >= A) { // only possible when the host declared the id space (msgpu_set_id_space)
     atomicOr(err, 2u);
     return;
   }
-  atomicAdd(&cnt_read[rd], 1u);
+  if (cap) {
+    const uint32_t pos = atomicAdd(&cnt_read[rd], 1u);
+    if (pos < cap)
+      store_irow(&bkt_row[static_cast<uint64_t>(rd) * cap + pos], make_irow(row, an, static_cast<uint32_t>(i)));
+    else
+      atomicOr(flags, IXF_OVERFLOW);
+  } else {
+    atomicAdd(&cnt_read[rd], 1u);
+  }
   atomicMin(&first_key[rd], (static_cast<unsigned long long>(ln) << 32) | static_cast<uint32_t>(i));
   if (i == 0) {
     anchor_first[an] = 0;
@@ -293,7 +306,7 @@ __device__ __forceinline__ bool key_less(int alo, int ahi, uint32_t aan, int blo
 // costs 3 scalar reads + K compares per lane instead of a pass over the bucket in global memory.  Returns false (and
 // writes nothing) when a (read, anchor) pair occurs twice: the caller then takes the generic path.
 template <int K>
-__device__ __forceinline__ bool sort_read_in_registers(uint32_t r, uint32_t b, uint32_t n, int lane, bool fast,
+__device__ __forceinline__ bool sort_read_in_registers(uint32_t r, uint64_t bs, uint32_t b, uint32_t n, int lane, bool fast,
                                                        const IRow *bkt_row, IRow *by_read,
                                                        uint32_t *read_cnt, uint32_t *alive_rank, uint32_t *anchor_cnt,
                                                        IRow *by_anchor) {
@@ -307,7 +320,7 @@ __device__ __forceinline__ bool sort_read_in_registers(uint32_t r, uint32_t b, u
     row[k]           = IRow{};
     idx[k]           = 0xffffffffu;
     if (e < n) {
-      row[k] = load_irow(&bkt_row[b + e]);
+      row[k] = load_irow(&bkt_row[bs + e]);
       idx[k] = row[k].pf & PF_POS_MASK;
     }
     mlo[k]  = e < n ? row[k].n_lo : 0x7fffffff;
@@ -356,11 +369,15 @@ __device__ __forceinline__ bool sort_read_in_registers(uint32_t r, uint32_t b, u
 __global__ __launch_bounds__(256) void k_sort_read(const uint32_t *read_off, const uint32_t *cnt_read, uint32_t V,
                                                    const IRow *bkt_row, IRow *by_read,
                                                    uint32_t *read_cnt, uint32_t *alive_rank, uint32_t *anchor_cnt,
-                                                   uint8_t *bkt_dead, uint32_t *flags, IRow *by_anchor) {
+                                                   uint8_t *bkt_dead, uint32_t *flags, IRow *by_anchor, uint32_t cap) {
   const int      lane = threadIdx.x & 63;
   const uint32_t r    = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
   if (r >= V) return;
-  const uint32_t b = read_off[r], n = cnt_read[r];
+  // bucket of read r: dense at read_off[r] (two-pass build) or slot r of `cap` rows (one-pass build; a read with more
+  // rows has raised IXF_OVERFLOW and everything written here is thrown away -- only stay inside the bucket)
+  const uint32_t b  = read_off[r];
+  const uint64_t bs = cap ? static_cast<uint64_t>(r) * cap : b;
+  const uint32_t n  = cap ? min(cnt_read[r], cap) : cnt_read[r];
   if (n == 0) return;
   const bool fast = (*flags & ~IXF_DUPS) == 0; // decided by pass 1; a duplicate found later is reported to the host
   if (n <= 64) {
@@ -368,7 +385,7 @@ __global__ __launch_bounds__(256) void k_sort_read(const uint32_t *read_off, con
     IRow       row{};
     uint32_t   idx = 0xffffffffu;
     if (have) {
-      row = load_irow(&bkt_row[b + lane]);
+      row = load_irow(&bkt_row[bs + lane]);
       idx = row.pf & PF_POS_MASK;
     }
     const int      mlo = have ? row.n_lo : 0x7fffffff, mhi = have ? row.n_hi : 0x7fffffff;
@@ -418,11 +435,11 @@ __global__ __launch_bounds__(256) void k_sort_read(const uint32_t *read_off, con
     return;
   }
   if (n <= 128) {
-    if (sort_read_in_registers<2>(r, b, n, lane, fast, bkt_row, by_read, read_cnt, alive_rank, anchor_cnt,
+    if (sort_read_in_registers<2>(r, bs, b, n, lane, fast, bkt_row, by_read, read_cnt, alive_rank, anchor_cnt,
                                   by_anchor))
       return;
   } else if (n <= 256) {
-    if (sort_read_in_registers<4>(r, b, n, lane, fast, bkt_row, by_read, read_cnt, alive_rank, anchor_cnt,
+    if (sort_read_in_registers<4>(r, bs, b, n, lane, fast, bkt_row, by_read, read_cnt, alive_rank, anchor_cnt,
                                   by_anchor))
       return;
   }
@@ -432,10 +449,10 @@ __global__ __launch_bounds__(256) void k_sort_read(const uint32_t *read_off, con
     const uint32_t e = e0 + lane;
     bool           dead = false;
     if (e < n) {
-      const IRow     k   = load_irow(&bkt_row[b + e]);
+      const IRow     k   = load_irow(&bkt_row[bs + e]);
       const uint32_t kix = k.pf & PF_POS_MASK;
       for (uint32_t q = 0; q < n; ++q) {
-        const IRow o = load_irow(&bkt_row[b + q]);
+        const IRow o = load_irow(&bkt_row[bs + q]);
         if (q != e && o.other == k.other) dead |= o.line < k.line || (o.line == k.line && (o.pf & PF_POS_MASK) < kix);
       }
       bkt_dead[b + e] = dead ? 1 : 0;
@@ -448,11 +465,11 @@ __global__ __launch_bounds__(256) void k_sort_read(const uint32_t *read_off, con
     const uint32_t e     = e0 + lane;
     const bool     alive = e < n && !bkt_dead[b + e];
     if (alive) {
-      IRow           k    = load_irow(&bkt_row[b + e]);
+      IRow           k    = load_irow(&bkt_row[bs + e]);
       const uint32_t kix  = k.pf & PF_POS_MASK;
       uint32_t       less = 0;
       for (uint32_t q = 0; q < n; ++q) {
-        const IRow o = load_irow(&bkt_row[b + q]);
+        const IRow o = load_irow(&bkt_row[bs + q]);
         if (!bkt_dead[b + q]) less += key_less(o.n_lo, o.n_hi, o.other, k.n_lo, k.n_hi, k.other) ? 1u : 0u;
       }
       k.pf = (k.pf & ~PF_POS_MASK) | less;
@@ -2554,10 +2571,11 @@ void launch_index_init(hipStream_t st, uint32_t *const zero[4], const uint32_t n
   hipLaunchKernelGGL(k_index_init, dim3(nb < 1024 ? nb : 1024), dim3(256), 0, st, a);
 }
 void launch_index_pass1(hipStream_t st, const msgpu_row *rows, uint64_t n, uint32_t *cnt_read, uint64_t *first_key,
-                        uint32_t *anchor_first, uint32_t V, uint32_t A, uint32_t *flags, uint32_t *err) {
+                        uint32_t *anchor_first, uint32_t V, uint32_t A, uint32_t *flags, uint32_t *err, IRow *bkt_row,
+                        uint32_t cap) {
   if (n)
     hipLaunchKernelGGL(k_index_pass1, grid1(n, 256), dim3(256), 0, st, rows, n, cnt_read,
-                       reinterpret_cast<unsigned long long *>(first_key), anchor_first, flags, V, A, err);
+                       reinterpret_cast<unsigned long long *>(first_key), anchor_first, flags, V, A, err, bkt_row, cap);
   hipLaunchKernelGGL(k_check_anchor_first, grid1(static_cast<uint64_t>(A) + 1, 256), dim3(256), 0, st, anchor_first, A,
                      static_cast<uint32_t>(n), flags);
 }
@@ -2574,10 +2592,10 @@ void launch_scatter_read(hipStream_t st, const msgpu_row *rows, uint64_t n, cons
 }
 void launch_sort_read(hipStream_t st, const uint32_t *read_off, const uint32_t *cnt_read, uint32_t V, const IRow *bkt_row,
                       IRow *by_read, uint32_t *read_cnt, uint32_t *alive_rank,
-                      uint32_t *anchor_cnt, uint8_t *bkt_dead, uint32_t *flags, IRow *by_anchor) {
+                      uint32_t *anchor_cnt, uint8_t *bkt_dead, uint32_t *flags, IRow *by_anchor, uint32_t cap) {
   if (V)
     hipLaunchKernelGGL(k_sort_read, grid1(V, 4), dim3(256), 0, st, read_off, cnt_read, V, bkt_row, by_read,
-                       read_cnt, alive_rank, anchor_cnt, bkt_dead, flags, by_anchor);
+                       read_cnt, alive_rank, anchor_cnt, bkt_dead, flags, by_anchor, cap);
 }
 void launch_select_anchor_off(hipStream_t st, const uint32_t *flags, const uint32_t *fast_off, const uint32_t *gen_off,
                               uint32_t A, uint32_t *anchor_off, uint32_t *d_n_alive, uint32_t n_rows) {
