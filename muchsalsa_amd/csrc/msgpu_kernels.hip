@@ -2439,14 +2439,13 @@ __global__ __launch_bounds__(256) void k_fill_pair_tab(uint32_t *tab) {
   tab[i] = static_cast<uint32_t>(k | (l << 8) | (run << 16)) | (static_cast<uint32_t>(64 - run - k) << 24);
 }
 
-// dense, canonical order + id tables.  One wavefront per 64 edges: every lane fetches its edge's bookkeeping, then
-// the wave walks the 64 edges together and copies each order (16 dwords) and its ids (<= 64 per order in one step)
-// with all lanes -- no serial per-thread copy loops.
+// dense, canonical order + id tables
 __global__ __launch_bounds__(256) void k_compact(CompactArgs a) {
-  const int      lane = threadIdx.x & 63;
-  const uint64_t e0   = (static_cast<uint64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6)) * 64;
-  if (e0 >= a.n_edges) return;
-  const uint64_t e    = e0 + lane;
+  // Four lanes per edge, sixteen edges per wavefront, all in flight together: a lane moves one 16-byte quarter of an
+  // order record and every fourth id.  (Most edges have one order; the dependent chain "order record -> id count ->
+  // ids" is then as long as a single edge's, not sixteen of them in a row.)
+  const int      lane = threadIdx.x & 63, sub = lane & 3;
+  const uint64_t e    = (static_cast<uint64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6)) * 16 + (lane >> 2);
   const bool     have = e < a.n_edges;
   uint32_t       no = 0;
   uint64_t       oo = 0, io = 0, em_off = 0;
@@ -2455,51 +2454,29 @@ __global__ __launch_bounds__(256) void k_compact(CompactArgs a) {
     oo     = a.order_base[e];
     io     = a.ids_base[e];
     em_off = a.edges[e].em_off;
-    a.edges[e].order_off = oo;
-    a.edges[e].order_cnt = static_cast<uint16_t>(no);
-  }
-  // Four edges per step, a quarter wavefront (16 lanes) each: the copy of an order is 16 dwords anyway, and the chain
-  // "order record -> id count -> ids" of four edges is in flight at once instead of one after the other.
-  const int          grp = lane >> 4, sub = lane & 15;
-  unsigned long long rem = __ballot(no != 0);
-  while (rem) {
-    int t = 64; // the grp-th edge of this step (64 = none)
-    {
-      unsigned long long r2 = rem;
-      for (int g = 0; g < 4 && r2; ++g) {
-        const int tg = __builtin_ctzll(r2);
-        r2 &= r2 - 1;
-        if (g == grp) t = tg;
-      }
-      rem = r2;
+    if (sub == 0) {
+      a.edges[e].order_off = oo;
+      a.edges[e].order_cnt = static_cast<uint16_t>(no);
     }
-    // every lane takes part in every shuffle (a lane that sits out cannot be read from): select afterwards
-    const int      src_lane = t < 64 ? t : 0;
-    const uint32_t s_no     = static_cast<uint32_t>(__shfl(static_cast<int>(no), src_lane));
-    const uint32_t t_no     = t < 64 ? s_no : 0u;
-    const uint64_t t_oo = (static_cast<uint64_t>(static_cast<uint32_t>(__shfl(static_cast<int>(oo >> 32), src_lane))) << 32) |
-                          static_cast<uint32_t>(__shfl(static_cast<int>(oo), src_lane));
-    const uint64_t t_em = (static_cast<uint64_t>(static_cast<uint32_t>(__shfl(static_cast<int>(em_off >> 32), src_lane))) << 32) |
-                          static_cast<uint32_t>(__shfl(static_cast<int>(em_off), src_lane));
-    uint64_t       t_io = (static_cast<uint64_t>(static_cast<uint32_t>(__shfl(static_cast<int>(io >> 32), src_lane))) << 32) |
-                    static_cast<uint32_t>(__shfl(static_cast<int>(io), src_lane));
-    uint32_t max_no = t_no;
-    for (int d = 32; d >= 16; d >>= 1) max_no = max(max_no, static_cast<uint32_t>(__shfl_xor(static_cast<int>(max_no), d)));
-    for (uint32_t i = 0; i < max_no; ++i) { // every lane runs the same number of rounds (shuffles inside)
-      const bool      on  = i < t_no;
-      const uint32_t *src = reinterpret_cast<const uint32_t *>(&a.order_scr[t_em + (on ? i : 0)]);
-      uint32_t       *dst = reinterpret_cast<uint32_t *>(&a.orders[t_oo + (on ? i : 0)]);
-      // msgpu_order as 16 dwords: [8,9] = ids_off (edge-relative in the scratch), [10] = ids_cnt
-      uint32_t w = on ? src[sub] : 0;
-      const uint32_t rel = static_cast<uint32_t>(__shfl(static_cast<int>(w), (grp << 4) + 8));
-      const uint32_t cnt = static_cast<uint32_t>(__shfl(static_cast<int>(w), (grp << 4) + 10));
-      if (sub == 8) w = static_cast<uint32_t>(t_io);
-      if (sub == 9) w = static_cast<uint32_t>(t_io >> 32);
-      if (on) {
-        dst[sub] = w;
-        for (uint32_t q = sub; q < cnt; q += 16) a.ids[t_io + q] = a.ids_scr[t_em + rel + q];
-        t_io += cnt;
-      }
+  }
+  uint32_t max_no = no; // every lane runs the same number of rounds (shuffles inside)
+  for (int d = 32; d >= 4; d >>= 1) max_no = max(max_no, static_cast<uint32_t>(__shfl_xor(static_cast<int>(max_no), d)));
+  for (uint32_t i = 0; i < max_no; ++i) {
+    const bool on = i < no;
+    uint4      w  = make_uint4(0, 0, 0, 0);
+    if (on) w = reinterpret_cast<const uint4 *>(&a.order_scr[em_off + i])[sub];
+    // msgpu_order as 16 dwords: [8,9] = ids_off (edge-relative in the scratch), [10] = ids_cnt -- the third quarter
+    const int      q2  = (lane & ~3) + 2;
+    const uint32_t rel = static_cast<uint32_t>(__shfl(static_cast<int>(w.x), q2));
+    const uint32_t cnt = static_cast<uint32_t>(__shfl(static_cast<int>(w.z), q2));
+    if (sub == 2) {
+      w.x = static_cast<uint32_t>(io);
+      w.y = static_cast<uint32_t>(io >> 32);
+    }
+    if (on) {
+      reinterpret_cast<uint4 *>(&a.orders[oo + i])[sub] = w;
+      for (uint32_t q = sub; q < cnt; q += 4) a.ids[io + q] = a.ids_scr[em_off + rel + q];
+      io += cnt;
     }
   }
 }
@@ -2695,7 +2672,7 @@ void launch_merge_gathered(hipStream_t st, const MergeArgs &a) {
   if (n) hipLaunchKernelGGL(k_merge_gathered, grid1(n, 256), dim3(256), 0, st, a);
 }
 void launch_compact(hipStream_t st, const CompactArgs &a) {
-  if (a.n_edges) hipLaunchKernelGGL(k_compact, grid1(a.n_edges, 256), dim3(256), 0, st, a);  // 4 waves x 64 edges
+  if (a.n_edges) hipLaunchKernelGGL(k_compact, grid1(a.n_edges, 64), dim3(256), 0, st, a); // 4 waves x 16 edges
 }
 
 } // namespace msgpu
