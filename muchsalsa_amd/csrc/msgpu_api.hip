@@ -90,7 +90,7 @@ struct msgpu_ctx {
   uint64_t    n_big_edges = 0, n_big_ems = 0;
   bool   fast_path = true;
   bool   sub_wave  = true; // short edges share a wavefront (k_chain_sub); MSGPU_NO_SUBWAVE=1 sends them all to k_chain
-  uint32_t n_cls[3] = {0, 0, 0};
+  uint32_t n_cls[4] = {0, 0, 0, 0}; // edges of 9..16, 17..32, 33..64 and <= 8 EdgeMatches
   uint64_t n_edges_fast = 0;
   DevBuf ems, order_scr, ids_scr, edge_norders, edge_nids, order_base, ids_base, orders, ids, big_list, cls_list, big_elems,
       big_paths;
@@ -106,7 +106,7 @@ namespace {
 // scalar slots in ctx->scalars (uint64 each)
 enum { SC_MAXIDS = 0 /*2 x u32*/, SC_ERR = 1, SC_TOTAL_A = 2, SC_TOTAL_B = 3, SC_TOTAL_C = 4, SC_NLISTS = 5 /*4 x u32, spans 5..6*/,
        SC_NBIG = 7, SC_NALIVE = 8, SC_IXFLAGS = 9, SC_BIGSTATS = 10 /*2 x u64*/, SC_BIGCUR = 12 /*2 x u64*/,
-       SC_CLS = 14 /*3 x u32: edges per width class, spans 14..15*/, SC_COUNT = 16 };
+       SC_CLS = 14 /*4 x u32: edges per width class, spans 14..15*/, SC_COUNT = 16 };
 
 int fail(msgpu_ctx *c, int code, const char *fmt, ...) {
   va_list ap;
@@ -575,7 +575,7 @@ int msgpu_chaining_and_overlaps(msgpu_ctx *c) {
   a.edge_nids    = c->edge_nids.as<uint32_t>();
   a.err          = scalar<uint32_t>(c, SC_ERR);
   if (!c->pair_tab.p) {
-    ENSURE(c, pair_tab, 3 * PAIR_TAB_STRIDE * sizeof(uint32_t));
+    ENSURE(c, pair_tab, 4 * PAIR_TAB_STRIDE * sizeof(uint32_t));
     launch_fill_pair_tab(st, c->pair_tab.as<uint32_t>());
   }
   a.pair_tab     = c->pair_tab.as<uint32_t>();
@@ -617,12 +617,13 @@ int msgpu_chaining_and_overlaps(msgpu_ctx *c) {
     uint32_t *list = c->cls_list.as<uint32_t>(), *part = list + E + 1;
     launch_sort_edges_by_size(st, a.edges, E, part, list, scalar<uint32_t>(c, SC_CLS));
     if (int rc = read_scalars(c)) return rc;
-    for (int k = 0; k < 3; ++k) c->n_cls[k] = host_scalar<uint32_t>(c, SC_CLS)[k];
-    const uint32_t *l64 = list, *l32 = l64 + c->n_cls[2], *l16 = l32 + c->n_cls[1]; // sizes descending
+    for (int k = 0; k < 4; ++k) c->n_cls[k] = host_scalar<uint32_t>(c, SC_CLS)[k];
+    const uint32_t *l64 = list, *l32 = l64 + c->n_cls[2], *l16 = l32 + c->n_cls[1], *l8 = l16 + c->n_cls[0]; // sizes descending
     HIPCHK(c, hipEventRecord(c->ev[5], st));
     launch_chain(st, a, l64, c->n_cls[2]); // the long ones first: the short classes fill the tail
     launch_chain_sub(st, a, 32, l32, c->n_cls[1]);
     launch_chain_sub(st, a, 16, l16, c->n_cls[0]);
+    launch_chain_sub(st, a, 8, l8, c->n_cls[3]);
   } else {
     HIPCHK(c, hipEventRecord(c->ev[5], st));
     launch_chain(st, a, nullptr, 0);

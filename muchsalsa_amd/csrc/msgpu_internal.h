@@ -47,7 +47,7 @@ struct ChainArgs {
   uint32_t        *ids_scr;   // slots em_off .. em_off + em_cnt of an edge
   uint32_t        *edge_norders, *edge_nids;
   uint32_t        *err;
-  const uint32_t  *pair_tab; // three tables (sweep width 64, 32, 16) of PAIR_TAB_STRIDE entries: k | l << 8 | run << 16
+  const uint32_t  *pair_tab; // four tables (sweep width 64, 32, 16, 8) of PAIR_TAB_STRIDE entries: k | l << 8 | run << 16
   uint32_t        *edge_fast; // per edge: 1 if the all-pairs-compatible shortcut was taken (may be null)
   int              fast_path; // 0 disables the shortcut (every edge takes the full pair sweep)
   double           wiggle, ratio_pct, alt_frac;

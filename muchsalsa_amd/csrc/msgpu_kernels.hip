@@ -1636,7 +1636,7 @@ __device__ __forceinline__ uint32_t paths_of_direction_sub(uint32_t act, bool di
 template <int W>
 __global__ __launch_bounds__(256) void k_chain_sub(ChainArgs a, const uint32_t *list, uint32_t n_list) {
   constexpr int G = 64 / W;
-  static_assert(W == 16 || W == 32, "group width");
+  static_assert(W == 8 || W == 16 || W == 32, "group width");
   static_assert(sizeof(ChainElem) * 64 >= sizeof(SubPath) * 2 * 64, "the path lists overlay the element table");
   __shared__ __attribute__((aligned(16))) unsigned char s_wavebuf[4][sizeof(ChainElem) * 64];
   __shared__ uint32_t                                  s_cm[4][64];
@@ -1770,7 +1770,7 @@ __global__ __launch_bounds__(256) void k_chain_sub(ChainArgs a, const uint32_t *
   const unsigned long long KD_one  = __ballot(m_minus == 0);
   // the table of this width (k | l << 8 | run << 16, run for W-wide steps); lanes past P read their edge's last pair (or
   // pair 0 = (0, 1)), which keeps (k, l) inside the group
-  const uint32_t *tab     = a.pair_tab + (W == 32 ? PAIR_TAB_STRIDE : 2 * PAIR_TAB_STRIDE);
+  const uint32_t *tab     = a.pair_tab + (W == 32 ? 1 : W == 16 ? 2 : 3) * PAIR_TAB_STRIDE;
   const int       Pm1     = max(P - 1, 0);
   uint32_t        kl_next = tab[min(sl, Pm1)];
   double          wiggle  = a.wiggle; // in a vector register: see k_chain
@@ -1953,6 +1953,7 @@ __global__ __launch_bounds__(256) void k_chain_sub(ChainArgs a, const uint32_t *
   }
 }
 
+template __global__ void k_chain_sub<8>(ChainArgs, const uint32_t *, uint32_t);
 template __global__ void k_chain_sub<16>(ChainArgs, const uint32_t *, uint32_t);
 template __global__ void k_chain_sub<32>(ChainArgs, const uint32_t *, uint32_t);
 
@@ -2004,8 +2005,10 @@ __global__ __launch_bounds__(1024) void k_size_scan(uint32_t *part, uint32_t *co
       if (bin + d < 64) inc += t;
     }
     s_base[bin] = inc - run;
-    uint32_t c16 = bin < 16 ? run : 0, c32 = (bin >= 16 && bin < 32) ? run : 0, c64 = bin >= 32 ? run : 0;
+    uint32_t c8 = bin < 8 ? run : 0, c16 = (bin >= 8 && bin < 16) ? run : 0, c32 = (bin >= 16 && bin < 32) ? run : 0,
+             c64 = bin >= 32 ? run : 0;
     for (int d = 32; d > 0; d >>= 1) {
+      c8 += __shfl_xor(c8, d);
       c16 += __shfl_xor(c16, d);
       c32 += __shfl_xor(c32, d);
       c64 += __shfl_xor(c64, d);
@@ -2014,6 +2017,7 @@ __global__ __launch_bounds__(1024) void k_size_scan(uint32_t *part, uint32_t *co
       counts[0] = c16;
       counts[1] = c32;
       counts[2] = c64;
+      counts[3] = c8;
     }
   }
   __syncthreads();
@@ -2422,10 +2426,10 @@ __global__ __launch_bounds__(256) void k_list_big_edges(const msgpu_edge *edges,
 
 // Pair tables: entry p = k | l << 8 | run << 16 | (64 - run - k) << 24 for the flattened pair index p = l(l-1)/2 + k, k < l < 64, where run
 // is the length of the stretch of row l that starts at lane p % W of a W-wide sweep step (0 if no stretch starts
-// there).  Three tables (W = 64, 32, 16) of PAIR_TAB_STRIDE entries, each padded with (0, 1, 0).
+// there).  Four tables (W = 64, 32, 16, 8) of PAIR_TAB_STRIDE entries, each padded with (0, 1, 0).
 __global__ __launch_bounds__(256) void k_fill_pair_tab(uint32_t *tab) {
   const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= 3 * static_cast<int>(PAIR_TAB_STRIDE)) return;
+  if (i >= 4 * static_cast<int>(PAIR_TAB_STRIDE)) return;
   const int t = i / static_cast<int>(PAIR_TAB_STRIDE), p = i % static_cast<int>(PAIR_TAB_STRIDE), W = 64 >> t;
   if (p >= 2016) {
     tab[i] = 1u << 8;
@@ -2628,7 +2632,7 @@ void launch_emit_edges(hipStream_t st, const uint32_t *n_edge, const uint32_t *n
                        scr_start, V, edges, edge_cand);
 }
 void launch_fill_pair_tab(hipStream_t st, uint32_t *tab) {
-  hipLaunchKernelGGL(k_fill_pair_tab, dim3((3 * PAIR_TAB_STRIDE + 255) / 256), dim3(256), 0, st, tab);
+  hipLaunchKernelGGL(k_fill_pair_tab, dim3((4 * PAIR_TAB_STRIDE + 255) / 256), dim3(256), 0, st, tab);
 }
 void launch_chain(hipStream_t st, const ChainArgs &a, const uint32_t *list, uint32_t n_list) {
   const uint64_t n = list ? n_list : a.n_edges;
@@ -2636,7 +2640,9 @@ void launch_chain(hipStream_t st, const ChainArgs &a, const uint32_t *list, uint
 }
 void launch_chain_sub(hipStream_t st, const ChainArgs &a, int width, const uint32_t *list, uint32_t n_list) {
   if (!n_list) return;
-  if (width == 16)
+  if (width == 8)
+    hipLaunchKernelGGL(k_chain_sub<8>, grid1(n_list, 32), dim3(256), 0, st, a, list, n_list);
+  else if (width == 16)
     hipLaunchKernelGGL(k_chain_sub<16>, grid1(n_list, 16), dim3(256), 0, st, a, list, n_list);
   else
     hipLaunchKernelGGL(k_chain_sub<32>, grid1(n_list, 8), dim3(256), 0, st, a, list, n_list);
