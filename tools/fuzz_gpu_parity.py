@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""One-off differential run on the GPU box: random small workloads (random strands / primary flags, duplicates, shuffled
+rows, several coverages) through libmsgpu and through the C oracle; every table must match bit for bit.
+    python tools/fuzz_gpu_parity.py [n_cases] [first_seed]"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import numpy as np  # noqa: E402
+
+import ms_oracle_ctypes as oracle  # noqa: E402
+from helpers import assert_tables_equal  # noqa: E402
+from muchsalsa_amd import overlap, synth  # noqa: E402
+
+
+def main():
+    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+    seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+    oracle.build()
+    for case in range(n_cases):
+        rng = np.random.default_rng(seed0 + case)
+        n_reads = int(rng.integers(50, 700))
+        read_len = int(rng.integers(2000, 12000))
+        cov = int(rng.choice([4, 8, 10, 20, 40]))
+        n_anchors = int(rng.integers(max(20, n_reads // 4), n_reads * 6))
+        rows, _, _ = synth.accepted_rows(synth.paf_table(n_reads, read_len, n_anchors, seed0 + case, coverage=cov))
+        rows = rows.copy()
+        mode = case % 4
+        if mode >= 1:  # random strands / primary flags
+            rows["flags"] = np.where(rng.random(len(rows)) < 0.25, rows["flags"] ^ 1, rows["flags"])
+            rows["flags"] = np.where(rng.random(len(rows)) < 0.2, rows["flags"] ^ 2, rows["flags"])
+        want = oracle.overlap(rows)
+        feed = rows
+        if mode >= 2 and len(rows) > 10:  # duplicates with higher line numbers + shuffled rows
+            dup = rows[rng.choice(len(rows), min(50, len(rows) // 5), replace=False)].copy()
+            dup["line"] = rows["line"].max() + 1 + np.arange(len(dup))
+            dup["n_lo"] += 5
+            feed = np.concatenate([rows, dup])
+            rng.shuffle(feed)
+        got = overlap.build_overlaps(feed)
+        assert_tables_equal(got, want, "case %d (reads %d, len %d, anchors %d, cov %d, mode %d)" % (
+            case, n_reads, read_len, n_anchors, cov, mode))
+        n = want["edges"]["em_cnt"]
+        print("case %3d ok: %6d rows %6d edges, EdgeMatches per edge max %3d, orders %6d" % (
+            case, len(rows), len(n), int(n.max()) if len(n) else 0, len(want["orders"])), flush=True)
+
+
+if __name__ == "__main__":
+    main()
