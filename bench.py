@@ -77,8 +77,12 @@ def cpu_baseline(workload, budget_reads, cores):
         # worker processes are SPAWNED (this process has initialised the GPU; its children must not inherit that)
         jobs = [(n_reads, w["read_len"], n_anchors, w["seed"] + 1000 + k) for k in range(cores)]
         t0 = time.perf_counter()
-        with ProcessPoolExecutor(max_workers=cores, mp_context=mp.get_context("spawn")) as pool:
-            res = list(pool.map(_cpu_sample, jobs))
+        try:
+            with ProcessPoolExecutor(max_workers=cores, mp_context=mp.get_context("spawn")) as pool:
+                res = list(pool.map(_cpu_sample, jobs))
+        except Exception as exc:  # a box that refuses worker processes must not cost the whole bench line
+            out["sample"] += "; the %d-core leg failed (%s: %s), one core reported" % (cores, type(exc).__name__, exc)
+            return out
         wall = time.perf_counter() - t0
         busy = max(r[3] for r in res)
         out.update({
