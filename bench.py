@@ -406,7 +406,8 @@ def main():
         n_edges_total = int(c.n_edges)
 
     asm_leg = graph_leg = None
-    if world == 1 and rank == 0 and args.assemble_window_mb > 0 and not args.no_consensus:
+    def aux_legs():
+        nonlocal asm_leg, graph_leg
         # what follows the chaining fan-out in main(): findContractionEdges on the GPU (tables still resident), then the
         # host graph stage (src/main.cpp:183-310).  Reported beside the metric, never inside `value`.
         torch.cuda.synchronize()
@@ -439,10 +440,28 @@ def main():
         ctx.close()
         asm_leg = assemble_leg(torch, dev, w, rows, read_names, anchor_names, tables, args.assemble_window_mb)
         del tables
+
+    # the legs reported BESIDE the metric must never cost the metric line itself
+    if world == 1 and rank == 0 and args.assemble_window_mb > 0 and not args.no_consensus:
+        try:
+            aux_legs()
+        except Exception as exc:  # noqa: BLE001
+            asm_leg = {"error": "%s: %s" % (type(exc).__name__, exc)}
     cons = None
     if not args.no_consensus:
         ctx.close()  # give the arena back before the ~3 GB of sequence buffers
-        cons = consensus_leg(torch, dev, world, rank, w, args.steps, args.warmup)
+        try:
+            cons = consensus_leg(torch, dev, world, rank, w, args.steps, args.warmup)
+        except Exception as exc:  # noqa: BLE001
+            if multi:
+                raise  # the other ranks are waiting in the all-reduce below
+            cons = None
+            consensus_error = "%s: %s" % (type(exc).__name__, exc)
+        else:
+            consensus_error = None
+    else:
+        consensus_error = None
+    if cons is not None:
         if multi:
             tt = torch.tensor([cons["ms"]], dtype=torch.float64, device=dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -502,7 +521,11 @@ def main():
             }
         if graph_leg is not None:
             out["graph_stage"] = graph_leg
-        if asm_leg is not None:
+        if consensus_error is not None:
+            out["consensus"] = {"error": consensus_error}
+        if asm_leg is not None and "error" in asm_leg:
+            out["assemble_path"] = asm_leg
+        elif asm_leg is not None:
             tot_ms = asm_leg["layout_ms"] + asm_leg["device_ms"]
             asm_leg["consensus_mbases_per_s"] = asm_leg["target_bases"] / (tot_ms * 1e-3) / 1e6
             asm_leg["stage"] = ("assemblePath on a bounded sample: host layout of every path + one gather + FASTA "
@@ -510,7 +533,10 @@ def main():
             out["assemble_path"] = asm_leg
         if world == 1 and args.cpu_sample_reads > 0:
             cores = args.cpu_cores if args.cpu_cores > 0 else max(1, min(16, os.cpu_count() or 1))
-            out["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_sample_reads, cores)
+            try:
+                out["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_sample_reads, cores)
+            except Exception as exc:  # noqa: BLE001
+                out["cpu_baseline"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     ctx.close()
     if multi:
