@@ -79,7 +79,7 @@ struct msgpu_ctx {
   uint32_t n_list[4] = {0, 0, 0, 0};
 
   // arena
-  DevBuf rows_in, cnt_read, first_key, read_off, cursor, bkt_key, bkt_dead, by_read, read_cnt, alive_rank,
+  DevBuf rows_in, cnt_read, read_off, cursor, bkt_key, bkt_dead, by_read, read_cnt, alive_rank,
       anchor_cnt, anchor_off, anchor_first, anchor_off_gen, bkt2_idx, bkt2_line, by_anchor, read_len, read_first, scalars,
       scan_tmp;
   DevBuf bound, cand_off, cand_j, cand_t, scr_v2, scr_start, n_cand, n_edge, n_visit_arr, lists, em_base, edge_base,
@@ -139,7 +139,7 @@ int read_scalars(msgpu_ctx *c, hipEvent_t mark = nullptr) {
 }
 
 void release_all(msgpu_ctx *c) {
-  DevBuf *all[] = {&c->g_deg, &c->g_off, &c->g_adj, &c->g_cand, &c->g_sane, &c->g_out, &c->rows_in, &c->cnt_read, &c->first_key, &c->read_off, &c->cursor, &c->bkt_key,
+  DevBuf *all[] = {&c->g_deg, &c->g_off, &c->g_adj, &c->g_cand, &c->g_sane, &c->g_out, &c->rows_in, &c->cnt_read, &c->read_off, &c->cursor, &c->bkt_key,
                    &c->bkt_dead, &c->by_read, &c->read_cnt, &c->alive_rank, &c->anchor_cnt, &c->anchor_off,
                    &c->anchor_first, &c->anchor_off_gen,
                    &c->bkt2_idx, &c->bkt2_line, &c->by_anchor, &c->read_len, &c->read_first, &c->scalars, &c->scan_tmp,
@@ -177,7 +177,6 @@ int build_index_once(msgpu_ctx *c, bool force_generic, bool two_pass, uint32_t *
   constexpr uint32_t BUCKET_CAP = 128;
   const uint32_t     cap = (!two_pass && V && size_t(V) * BUCKET_CAP * sizeof(IRow) <= (size_t(4) << 30)) ? BUCKET_CAP : 0;
   ENSURE(c, cnt_read, (size_t(V) + 1) * 4);
-  ENSURE(c, first_key, (size_t(V) + 1) * 8);
   ENSURE(c, read_off, (size_t(V) + 2) * 4);
   ENSURE(c, cursor, mva * 4);
   ENSURE(c, bkt_key, (cap ? size_t(V) * cap : nz) * sizeof(IRow));
@@ -205,8 +204,8 @@ int build_index_once(msgpu_ctx *c, bool force_generic, bool two_pass, uint32_t *
     uint32_t *const zero[4]   = {c->cnt_read.as<uint32_t>(), c->cursor.as<uint32_t>(), c->read_cnt.as<uint32_t>(),
                                  c->anchor_cnt.as<uint32_t>()};
     const uint32_t  n_zero[4] = {V + 1, static_cast<uint32_t>(mva), V + 1, A + 1};
-    uint32_t *const ones[2]   = {c->first_key.as<uint32_t>(), c->anchor_first.as<uint32_t>()};
-    const uint32_t  n_ones[2] = {2 * (V + 1), A + 2};
+    uint32_t *const ones[2]   = {c->anchor_first.as<uint32_t>(), nullptr};
+    const uint32_t  n_ones[2] = {A + 2, 0};
     launch_index_init(st, zero, n_zero, ones, n_ones);
   }
   uint32_t *d_flags = scalar<uint32_t>(c, SC_IXFLAGS);
@@ -215,17 +214,17 @@ int build_index_once(msgpu_ctx *c, bool force_generic, bool two_pass, uint32_t *
     HIPCHK(c, hipMemcpyAsync(d_flags, &f, 4, hipMemcpyHostToDevice, st));
   }
 
-  launch_index_pass1(st, c->d_rows, n, c->cnt_read.as<uint32_t>(), c->first_key.as<uint64_t>(),
-                     c->anchor_first.as<uint32_t>(), V, A, d_flags, scalar<uint32_t>(c, SC_ERR), c->bkt_key.as<IRow>(), cap);
-  launch_read_facts(st, c->d_rows, c->first_key.as<uint64_t>(), V, c->read_len.as<int32_t>(),
-                    c->read_first.as<uint32_t>(), scalar<uint32_t>(c, SC_ERR));
+  launch_index_pass1(st, c->d_rows, n, c->cnt_read.as<uint32_t>(), c->anchor_first.as<uint32_t>(), V, A, d_flags,
+                     scalar<uint32_t>(c, SC_ERR), c->bkt_key.as<IRow>(), cap);
   exclusive_scan<uint32_t>(st, c->cnt_read.as<uint32_t>(), V, c->read_off.as<uint32_t>(), c->scan_tmp.as<uint32_t>(),
                            scalar<uint32_t>(c, SC_TOTAL_A));
   if (!cap) launch_scatter_read(st, c->d_rows, n, c->read_off.as<uint32_t>(), c->cursor.as<uint32_t>(), c->bkt_key.as<IRow>());
   launch_sort_read(st, c->read_off.as<uint32_t>(), c->cnt_read.as<uint32_t>(), V, c->bkt_key.as<IRow>(),
                    c->by_read.as<IRow>(), c->read_cnt.as<uint32_t>(),
                    c->alive_rank.as<uint32_t>(), c->anchor_cnt.as<uint32_t>(), c->bkt_dead.as<uint8_t>(), d_flags,
-                   c->by_anchor.as<IRow>(), cap); // fast mode: the sort writes the scaffold rows too
+                   c->by_anchor.as<IRow>(), cap, c->d_rows, c->read_len.as<int32_t>(), c->read_first.as<uint32_t>(),
+                   scalar<uint32_t>(c, SC_ERR)); // fast mode: the sort writes the scaffold rows too; always: the Vertex facts
+  launch_check_read_order(st, c->read_first.as<uint32_t>(), V, scalar<uint32_t>(c, SC_ERR));
   // Fast mode (input grouped by anchor, ascending lines: what the PAF loader hands over) is finished here but for the
   // scaffold offsets, which are the speculative ones of pass 1; the flags come back with the read-back below and
   // only an input that is not in that form pays for the generic scaffold build (a second read-back).

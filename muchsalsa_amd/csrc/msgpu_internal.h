@@ -90,16 +90,15 @@ constexpr uint32_t IXF_FORCE    = 8u; // host asked for the generic path
 constexpr uint32_t IXF_OVERFLOW = 16u; // one-pass build: a read has more rows than a bucket holds (host rebuilds in two passes)
 void launch_index_init(hipStream_t st, uint32_t *const zero[4], const uint32_t n_zero[4], uint32_t *const ones[2],
                        const uint32_t n_ones[2]);
-void launch_index_pass1(hipStream_t st, const msgpu_row *rows, uint64_t n, uint32_t *cnt_read, uint64_t *first_key,
-                        uint32_t *anchor_first, uint32_t V, uint32_t A, uint32_t *flags, uint32_t *err, IRow *bkt_row,
-                        uint32_t cap);
-void launch_read_facts(hipStream_t st, const msgpu_row *rows, const uint64_t *first_key, uint32_t V, int32_t *read_len,
-                       uint32_t *read_first, uint32_t *err);
+void launch_index_pass1(hipStream_t st, const msgpu_row *rows, uint64_t n, uint32_t *cnt_read, uint32_t *anchor_first,
+                        uint32_t V, uint32_t A, uint32_t *flags, uint32_t *err, IRow *bkt_row, uint32_t cap);
+void launch_check_read_order(hipStream_t st, const uint32_t *read_first, uint32_t V, uint32_t *err);
 void launch_scatter_read(hipStream_t st, const msgpu_row *rows, uint64_t n, const uint32_t *read_off, uint32_t *cursor,
                          IRow *bkt_row);
 void launch_sort_read(hipStream_t st, const uint32_t *read_off, const uint32_t *cnt_read, uint32_t V, const IRow *bkt_row,
                       IRow *by_read, uint32_t *read_cnt, uint32_t *alive_rank,
-                      uint32_t *anchor_cnt, uint8_t *bkt_dead, uint32_t *flags, IRow *by_anchor, uint32_t cap);
+                      uint32_t *anchor_cnt, uint8_t *bkt_dead, uint32_t *flags, IRow *by_anchor, uint32_t cap,
+                      const msgpu_row *rows, int32_t *read_len, uint32_t *read_first, uint32_t *err);
 void launch_select_anchor_off(hipStream_t st, const uint32_t *flags, const uint32_t *fast_off, const uint32_t *gen_off,
                               uint32_t A, uint32_t *anchor_off, uint32_t *d_n_alive, uint32_t n_rows);
 void launch_scatter_anchor(hipStream_t st, const msgpu_row *rows, uint64_t n, const uint32_t *alive_rank,

@@ -225,9 +225,8 @@ __global__ __launch_bounds__(256) void k_index_init(IndexInitArgs a) {
 // takes the slot its count atomic returns -- no offsets are needed, so the scan and the second pass over the table
 // (k_scatter_read) fall away.  A read with more than cap rows raises IXF_OVERFLOW and the host rebuilds in two passes.
 __global__ __launch_bounds__(256) void k_index_pass1(const msgpu_row *rows, uint64_t n, uint32_t *cnt_read,
-                                                     unsigned long long *first_key, uint32_t *anchor_first,
-                                                     uint32_t *flags, uint32_t V, uint32_t A, uint32_t *err,
-                                                     IRow *bkt_row, uint32_t cap) {
+                                                     uint32_t *anchor_first, uint32_t *flags, uint32_t V, uint32_t A,
+                                                     uint32_t *err, IRow *bkt_row, uint32_t cap) {
   uint64_t i = static_cast<uint64_t>(blockIdx.x) * 256 + threadIdx.x;
   if (i >= n) return;
   const msgpu_row row = rows[i];
@@ -245,7 +244,6 @@ __global__ __launch_bounds__(256) void k_index_pass1(const msgpu_row *rows, uint
   } else {
     atomicAdd(&cnt_read[rd], 1u);
   }
-  atomicMin(&first_key[rd], (static_cast<unsigned long long>(ln) << 32) | static_cast<uint32_t>(i));
   if (i == 0) {
     anchor_first[an] = 0;
   } else {
@@ -265,23 +263,28 @@ __global__ __launch_bounds__(256) void k_check_anchor_first(uint32_t *anchor_fir
   if (anchor_first[a] == 0xffffffffu) atomicOr(flags, IXF_SPARSE);
 }
 
-// per read: Vertex(nanoporeLength, metaDatum(0) = first line) + Registry-order check
-__global__ __launch_bounds__(256) void k_read_facts(const msgpu_row *rows, const unsigned long long *first_key, uint32_t V,
-                                                    int32_t *read_len, uint32_t *read_first, uint32_t *err) {
-  uint32_t r = blockIdx.x * 256 + threadIdx.x;
-  if (r >= V) return;
-  unsigned long long k = first_key[r];
-  if (k == ~0ull) { // an id without any row: ids are not Registry-dense
-    atomicOr(err, 1u);
-    read_len[r]   = 0;
-    read_first[r] = 0xffffffffu;
-    return;
+// Registry-order check on the first lines the sort found: ids must follow first-line order (Registry.cpp:36-45); an id
+// without any row (marked 0xffffffff by the sort) means the ids are not dense
+__global__ __launch_bounds__(256) void k_check_read_order(const uint32_t *read_first, uint32_t V, uint32_t *err) {
+  const uint32_t r = blockIdx.x * 256 + threadIdx.x;
+  if (r + 1 >= V) return;
+  const uint32_t f0 = read_first[r], f1 = read_first[r + 1];
+  if (f0 != 0xffffffffu && f1 != 0xffffffffu && f1 <= f0) atomicOr(err, 1u);
+}
+
+// The Vertex of a read is made at its first line (Graph.cpp:148: nanoporeLength and metaDatum(0) of that line).  key =
+// line << 32 | source row index of a lane's row (all ones for a lane without one); every lane of the wavefront calls.
+__device__ __forceinline__ void note_first_row(int lane, unsigned long long key, uint32_t r, const msgpu_row *rows,
+                                               int32_t *read_len, uint32_t *read_first) {
+  for (int d = 32; d > 0; d >>= 1) {
+    const unsigned long long o =
+        (static_cast<unsigned long long>(static_cast<uint32_t>(__shfl_xor(static_cast<int>(key >> 32), d))) << 32) |
+        static_cast<uint32_t>(__shfl_xor(static_cast<int>(key), d));
+    key = o < key ? o : key;
   }
-  read_len[r]   = rows[static_cast<uint32_t>(k)].read_len;
-  read_first[r] = static_cast<uint32_t>(k >> 32);
-  if (r + 1 < V) {
-    unsigned long long k2 = first_key[r + 1];
-    if (k2 != ~0ull && (k2 >> 32) <= (k >> 32)) atomicOr(err, 1u); // ids must follow first-line order
+  if (lane == 0) {
+    read_first[r] = static_cast<uint32_t>(key >> 32);
+    read_len[r]   = rows[static_cast<uint32_t>(key)].read_len;
   }
 }
 
@@ -309,7 +312,8 @@ template <int K>
 __device__ __forceinline__ bool sort_read_in_registers(uint32_t r, uint64_t bs, uint32_t b, uint32_t n, int lane, bool fast,
                                                        const IRow *bkt_row, IRow *by_read,
                                                        uint32_t *read_cnt, uint32_t *alive_rank, uint32_t *anchor_cnt,
-                                                       IRow *by_anchor) {
+                                                       IRow *by_anchor, const msgpu_row *rows, int32_t *read_len,
+                                                       uint32_t *read_first) {
   IRow     row[K];
   uint32_t idx[K], man[K], less[K];
   int      mlo[K], mhi[K];
@@ -341,6 +345,13 @@ __device__ __forceinline__ bool sort_read_in_registers(uint32_t r, uint64_t bs, 
       }
     }
   }
+  {
+    unsigned long long fk = ~0ull;
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+      if (static_cast<uint32_t>(k) * 64 + lane < n) fk = min(fk, (static_cast<unsigned long long>(row[k].line) << 32) | idx[k]);
+    note_first_row(lane, fk, r, rows, read_len, read_first);
+  }
   if (__ballot(dup)) return false; // sentinel rows (anchor 0xffffffff) are never broadcast, so they cannot match
 #pragma unroll
   for (int k = 0; k < K; ++k) {
@@ -369,7 +380,9 @@ __device__ __forceinline__ bool sort_read_in_registers(uint32_t r, uint64_t bs, 
 __global__ __launch_bounds__(256) void k_sort_read(const uint32_t *read_off, const uint32_t *cnt_read, uint32_t V,
                                                    const IRow *bkt_row, IRow *by_read,
                                                    uint32_t *read_cnt, uint32_t *alive_rank, uint32_t *anchor_cnt,
-                                                   uint8_t *bkt_dead, uint32_t *flags, IRow *by_anchor, uint32_t cap) {
+                                                   uint8_t *bkt_dead, uint32_t *flags, IRow *by_anchor, uint32_t cap,
+                                                   const msgpu_row *rows, int32_t *read_len, uint32_t *read_first,
+                                                   uint32_t *err) {
   const int      lane = threadIdx.x & 63;
   const uint32_t r    = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
   if (r >= V) return;
@@ -378,7 +391,14 @@ __global__ __launch_bounds__(256) void k_sort_read(const uint32_t *read_off, con
   const uint32_t b  = read_off[r];
   const uint64_t bs = cap ? static_cast<uint64_t>(r) * cap : b;
   const uint32_t n  = cap ? min(cnt_read[r], cap) : cnt_read[r];
-  if (n == 0) return;
+  if (n == 0) { // an id without any row: ids are not Registry-dense
+    if (lane == 0) {
+      read_len[r]   = 0;
+      read_first[r] = 0xffffffffu;
+      atomicOr(err, 1u);
+    }
+    return;
+  }
   const bool fast = (*flags & ~IXF_DUPS) == 0; // decided by pass 1; a duplicate found later is reported to the host
   if (n <= 64) {
     const bool have = lane < static_cast<int>(n);
@@ -388,6 +408,7 @@ __global__ __launch_bounds__(256) void k_sort_read(const uint32_t *read_off, con
       row = load_irow(&bkt_row[bs + lane]);
       idx = row.pf & PF_POS_MASK;
     }
+    note_first_row(lane, have ? (static_cast<unsigned long long>(row.line) << 32) | idx : ~0ull, r, rows, read_len, read_first);
     const int      mlo = have ? row.n_lo : 0x7fffffff, mhi = have ? row.n_hi : 0x7fffffff;
     const uint32_t man = have ? row.other : 0xffffffffu;
     uint32_t       less = 0;
@@ -436,21 +457,23 @@ __global__ __launch_bounds__(256) void k_sort_read(const uint32_t *read_off, con
   }
   if (n <= 128) {
     if (sort_read_in_registers<2>(r, bs, b, n, lane, fast, bkt_row, by_read, read_cnt, alive_rank, anchor_cnt,
-                                  by_anchor))
+                                  by_anchor, rows, read_len, read_first))
       return;
   } else if (n <= 256) {
     if (sort_read_in_registers<4>(r, bs, b, n, lane, fast, bkt_row, by_read, read_cnt, alive_rank, anchor_cnt,
-                                  by_anchor))
+                                  by_anchor, rows, read_len, read_first))
       return;
   }
   // very long read, or one with a duplicated (read, anchor) pair: the bucket stays in global memory
-  uint32_t n_alive = 0;
+  uint32_t           n_alive = 0;
+  unsigned long long fk      = ~0ull;
   for (uint32_t e0 = 0; e0 < n; e0 += 64) {
     const uint32_t e = e0 + lane;
     bool           dead = false;
     if (e < n) {
       const IRow     k   = load_irow(&bkt_row[bs + e]);
       const uint32_t kix = k.pf & PF_POS_MASK;
+      fk                 = min(fk, (static_cast<unsigned long long>(k.line) << 32) | kix);
       for (uint32_t q = 0; q < n; ++q) {
         const IRow o = load_irow(&bkt_row[bs + q]);
         if (q != e && o.other == k.other) dead |= o.line < k.line || (o.line == k.line && (o.pf & PF_POS_MASK) < kix);
@@ -460,6 +483,7 @@ __global__ __launch_bounds__(256) void k_sort_read(const uint32_t *read_off, con
     }
     if (__ballot(e < n && dead) && lane == 0) atomicOr(flags, IXF_DUPS);
   }
+  note_first_row(lane, fk, r, rows, read_len, read_first);
   __threadfence(); // the dead flags are read back by other lanes of this wave
   for (uint32_t e0 = 0; e0 < n; e0 += 64) {
     const uint32_t e     = e0 + lane;
@@ -2551,20 +2575,16 @@ void launch_index_init(hipStream_t st, uint32_t *const zero[4], const uint32_t n
   uint32_t nb = (most + 255) / 256;
   hipLaunchKernelGGL(k_index_init, dim3(nb < 1024 ? nb : 1024), dim3(256), 0, st, a);
 }
-void launch_index_pass1(hipStream_t st, const msgpu_row *rows, uint64_t n, uint32_t *cnt_read, uint64_t *first_key,
-                        uint32_t *anchor_first, uint32_t V, uint32_t A, uint32_t *flags, uint32_t *err, IRow *bkt_row,
-                        uint32_t cap) {
+void launch_index_pass1(hipStream_t st, const msgpu_row *rows, uint64_t n, uint32_t *cnt_read, uint32_t *anchor_first,
+                        uint32_t V, uint32_t A, uint32_t *flags, uint32_t *err, IRow *bkt_row, uint32_t cap) {
   if (n)
-    hipLaunchKernelGGL(k_index_pass1, grid1(n, 256), dim3(256), 0, st, rows, n, cnt_read,
-                       reinterpret_cast<unsigned long long *>(first_key), anchor_first, flags, V, A, err, bkt_row, cap);
+    hipLaunchKernelGGL(k_index_pass1, grid1(n, 256), dim3(256), 0, st, rows, n, cnt_read, anchor_first, flags, V, A, err,
+                       bkt_row, cap);
   hipLaunchKernelGGL(k_check_anchor_first, grid1(static_cast<uint64_t>(A) + 1, 256), dim3(256), 0, st, anchor_first, A,
                      static_cast<uint32_t>(n), flags);
 }
-void launch_read_facts(hipStream_t st, const msgpu_row *rows, const uint64_t *first_key, uint32_t V, int32_t *read_len,
-                       uint32_t *read_first, uint32_t *err) {
-  if (V)
-    hipLaunchKernelGGL(k_read_facts, grid1(V, 256), dim3(256), 0, st, rows,
-                       reinterpret_cast<const unsigned long long *>(first_key), V, read_len, read_first, err);
+void launch_check_read_order(hipStream_t st, const uint32_t *read_first, uint32_t V, uint32_t *err) {
+  if (V > 1) hipLaunchKernelGGL(k_check_read_order, grid1(V, 256), dim3(256), 0, st, read_first, V, err);
 }
 void launch_scatter_read(hipStream_t st, const msgpu_row *rows, uint64_t n, const uint32_t *read_off, uint32_t *cursor,
                          IRow *bkt_row) {
@@ -2573,10 +2593,11 @@ void launch_scatter_read(hipStream_t st, const msgpu_row *rows, uint64_t n, cons
 }
 void launch_sort_read(hipStream_t st, const uint32_t *read_off, const uint32_t *cnt_read, uint32_t V, const IRow *bkt_row,
                       IRow *by_read, uint32_t *read_cnt, uint32_t *alive_rank,
-                      uint32_t *anchor_cnt, uint8_t *bkt_dead, uint32_t *flags, IRow *by_anchor, uint32_t cap) {
+                      uint32_t *anchor_cnt, uint8_t *bkt_dead, uint32_t *flags, IRow *by_anchor, uint32_t cap,
+                      const msgpu_row *rows, int32_t *read_len, uint32_t *read_first, uint32_t *err) {
   if (V)
     hipLaunchKernelGGL(k_sort_read, grid1(V, 4), dim3(256), 0, st, read_off, cnt_read, V, bkt_row, by_read,
-                       read_cnt, alive_rank, anchor_cnt, bkt_dead, flags, by_anchor, cap);
+                       read_cnt, alive_rank, anchor_cnt, bkt_dead, flags, by_anchor, cap, rows, read_len, read_first, err);
 }
 void launch_select_anchor_off(hipStream_t st, const uint32_t *flags, const uint32_t *fast_off, const uint32_t *gen_off,
                               uint32_t A, uint32_t *anchor_off, uint32_t *d_n_alive, uint32_t n_rows) {
