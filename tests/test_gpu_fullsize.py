@@ -1,0 +1,150 @@
+"""Full-size parity: the configurations BASELINE.json names (cfg2 = configs[1], cfg3 = configs[2], the one the
+metric is quoted on; cfg4 = cfg3 cut into 8 shards) through the C-ABI on the GPU, compared BIT FOR BIT with the CPU
+oracle on the same rows -- all four tables (edges, EdgeMatches, EdgeOrders, ids).  The C oracle needs ~3 s for cfg2 and
+~40 s for cfg3 on one host core.  The consensus half at the same sizes: assemblePath over chains that tile the whole
+genome, byte for byte against the Python restatement of ap.cpp."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import assert_tables_equal
+
+pytestmark = pytest.mark.gpu
+
+_CACHE = {}
+
+
+def _workload(cfg, oracle):
+    """rows + oracle tables of a named configuration (kept for the module: cfg3's oracle run is the slow part)."""
+    if cfg not in _CACHE:
+        from muchsalsa_amd import synth
+        tab = synth.paf_table(**synth.CONFIGS[cfg])
+        rows, read_names, anchor_names = synth.accepted_rows(tab)
+        _CACHE[cfg] = (rows, read_names, anchor_names, oracle.overlap(rows))
+    return _CACHE[cfg]
+
+
+def _shard_view(t, shard, world):
+    """Vectorised statement of what msgpu_set_shard(shard, world) must return: the edges with v1 % world == shard cut
+    out of the single-GPU tables, dense and re-based (muchsalsa_amd.distributed.shard_view_host without the loops)."""
+    e, em, o, ids = t["edges"], t["ems"], t["orders"], t["ids"]
+    keep = (e["v1"] % world) == shard
+    e2 = e[keep].copy()
+    em_keep = np.repeat(keep, e["em_cnt"])
+    o_keep = np.repeat(keep, e["order_cnt"])
+    em2, o2 = em[em_keep].copy(), o[o_keep].copy()
+    id_keep = np.repeat(o_keep, o["ids_cnt"])
+    ids2 = ids[id_keep].copy()
+    new_edge = np.cumsum(keep) - 1
+    em2["edge_idx"] = new_edge[em2["edge_idx"]]
+    o2["edge_idx"] = new_edge[o2["edge_idx"]]
+    e2["em_off"] = np.concatenate([[0], np.cumsum(e2["em_cnt"])[:-1]])
+    e2["order_off"] = np.concatenate([[0], np.cumsum(e2["order_cnt"])[:-1]])
+    o2["ids_off"] = np.concatenate([[0], np.cumsum(o2["ids_cnt"])[:-1]])
+    return {"edges": e2, "ems": em2, "orders": o2, "ids": ids2}
+
+
+@pytest.mark.parametrize("cfg", ["cfg2", "cfg3"])
+def test_named_config_bit_exact(oracle, cfg):
+    """BASELINE.json configs[1] / configs[2] at full size: every field of every record equals the oracle's."""
+    from muchsalsa_amd import overlap
+    rows, read_names, anchor_names, want = _workload(cfg, oracle)
+    with overlap.OverlapContext(0) as ctx:
+        ctx.set_id_space(len(read_names), len(anchor_names))  # what bench.py does
+        ctx.load_rows(rows)
+        ctx.calculate_edges()
+        ctx.chaining_and_overlaps()
+        got = ctx.tables()
+        c = ctx.counts()
+        rl, fl = ctx.reads()
+    assert_tables_equal(got, want, cfg)
+    assert c.n_edges == len(want["edges"]) and c.n_ems == len(want["ems"]) and c.n_orders == len(want["orders"])
+    assert np.array_equal(rl, want["read_len"]) and np.array_equal(fl, want["read_first_line"])
+    if cfg == "cfg2":  # the shape SURVEY.md section 8 measured with the reference (different PRNG, same densities)
+        assert 90_000 < c.n_edges < 105_000 and 2.4e6 < c.n_ems < 2.8e6
+    else:
+        assert 0.9e6 < c.n_edges < 1.05e6 and 24e6 < c.n_ems < 28e6
+
+
+def test_cfg4_shards_of_cfg3_bit_exact(oracle):
+    """BASELINE.json configs[3] (cfg3 sharded over 8 GPUs) as far as one GPU can show it: each of the 8 shards, run
+    here one after the other, equals its cut of the oracle's cfg3 tables bit for bit; the cuts partition the edge list.
+    (The all-gather + merge of the shards is covered at small size by test_gpu_parity / test_distributed_gloo.)"""
+    from muchsalsa_amd import overlap
+    rows, read_names, anchor_names, want = _workload("cfg3", oracle)
+    world, n_edges = 8, 0
+    with overlap.OverlapContext(0) as ctx:
+        ctx.set_id_space(len(read_names), len(anchor_names))
+        for r in range(world):
+            ctx.set_shard(r, world)
+            ctx.load_rows(rows)
+            ctx.calculate_edges()
+            ctx.chaining_and_overlaps()
+            got = ctx.tables()
+            assert_tables_equal(got, _shard_view(want, r, world), "cfg3 shard %d/8" % r)
+            n_edges += len(got["edges"])
+    assert n_edges == len(want["edges"])
+
+
+def _sequences(cfg, read_names, anchor_names):
+    """The synthetic genome's reads / unitigs keyed by Registry id, as the bytes the FASTA files hold."""
+    from muchsalsa_amd import synth
+    c = synth.CONFIGS[cfg]
+    n_reads, L, seed = c["n_reads"], c["read_len"], c["seed"]
+    G, r_start, r_fwd = synth.read_layout(n_reads, L, seed)
+    a_start, a_len = synth.anchor_layout(n_reads, L, c["n_anchors"], seed)
+    genome = synth.genome_bases(G, seed).tobytes()
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    ro = np.array([int(n[1:]) for n in read_names])
+    ao = np.array([int(n[1:]) for n in anchor_names])
+    nano = {i: (genome[r_start[o]:r_start[o] + L] if r_fwd[o] else genome[r_start[o]:r_start[o] + L].translate(comp)[::-1])
+            for i, o in enumerate(ro)}
+    illu = {i: genome[a_start[o]:a_start[o] + a_len[o]] for i, o in enumerate(ao)}
+    return G, L, r_start[ro], r_fwd[ro], nano, illu, genome
+
+
+@pytest.mark.parametrize("cfg,two_bit", [("cfg2", False), ("cfg2", True), ("cfg3", True)])
+def test_assemble_path_whole_genome(oracle, cfg, two_bit, tmp_path):
+    """The consensus half at full size: chains of reads tiling the WHOLE synthetic genome (window = G) over the overlap
+    tables the GPU just produced -> assemblePath (host layout on all host threads, one gather + FASTA wrapping on the
+    device) -> temp_1.{target.fa, query.fa, align.paf} byte-identical to oracle/ms_assemble_py.py on the same input.
+    A9 tolerance: edit distance 0 against the restatement."""
+    from oracle.ms_assemble_py import assemble_path
+    from muchsalsa_amd import overlap, synth
+    from muchsalsa_amd.assembly import Assembly
+    from muchsalsa_amd.sequences import ILLUMINA, NANOPORE, SeqFile, SeqStore
+    rows, read_names, anchor_names, want_tables = _workload(cfg, oracle)
+    tables = overlap.build_overlaps(rows)
+    assert tables["orders"].tobytes() == want_tables["orders"].tobytes()
+    G, L, rs, rf, nano, illu, genome = _sequences(cfg, read_names, anchor_names)
+    paths = synth.chain_paths(tables, rs, rf, L, G, max_reads=12)
+    assert sum(len(p) for p, _ in paths) > 0.1 * len(read_names)
+    for name, seqs in (("n.fa", nano), ("i.fa", illu)):
+        with open(tmp_path / name, "wb") as f:
+            for i in range(len(seqs)):
+                f.write(b">s%d\n" % i + seqs[i] + b"\n")
+    store = SeqStore(device=0)
+    store.upload(NANOPORE, SeqFile(str(tmp_path / "n.fa")))
+    store.upload(ILLUMINA, SeqFile(str(tmp_path / "i.fa")))
+    os.remove(tmp_path / "n.fa")
+    if two_bit:
+        store.pack()
+    asm = Assembly(store)
+    asm.set_rows(rows)
+    prepared = [Assembly.prepare(p, st, None, None, k) for k, (p, st) in enumerate(paths)]
+    status = asm.add_prepared_batch(prepared, min(16, os.cpu_count() or 1))
+    assert not status.any()
+    asm.finish()
+    # the restatement needs (read, anchor) -> row for the reads on paths only
+    on_path = np.zeros(len(read_names), dtype=bool)
+    for p, _ in paths:
+        on_path[[r["id"] for r in p]] = True
+    vm = {(int(r["read_id"]), int(r["anchor_id"])): r for r in rows[on_path[rows["read_id"]]]}
+    want = [assemble_path(p, st, vm, {}, nano, illu, k) for k, (p, st) in enumerate(paths)]
+    assert asm.text(2) == b"".join(r["paf"] for r in want)
+    assert asm.text(0) == b"".join(r["target_fa"] for r in want)
+    assert asm.text(1) == b"".join(r["query_fa"] for r in want)
+    T = int(asm.paths["target_len"].sum())
+    assert T == sum(len(r["target"]) for r in want) and T > 0.9 * G  # the chains tile the genome
+    store.close()
