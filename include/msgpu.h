@@ -470,6 +470,8 @@ typedef struct msgpu_graph_stats {
   uint64_t n_vertices, n_edges; /* after the clean-up */
   uint64_t n_components, n_paths, n_path_reads;
 } msgpu_graph_stats;
+/* The four tables are BORROWED, not copied (the EdgeMatch table alone is 0.8 GB on BASELINE.json configs[2]): they must
+ * stay valid and unchanged until msgpu_graph_free.  read_len / read_first_line are copied. */
 int  msgpu_graph_create(const msgpu_edge *edges, uint64_t n_edges, const msgpu_edgematch *ems, uint64_t n_ems,
                         const msgpu_order *orders, uint64_t n_orders, const uint32_t *ids, uint64_t n_ids,
                         const int32_t *read_len, const uint32_t *read_first_line, uint32_t n_reads, msgpu_graph **out);
@@ -491,6 +493,25 @@ int msgpu_graph_path_input(const msgpu_graph *g, uint32_t i, msgpu_path_input *o
  * order) alive flag, consensus direction (same coding) and weight */
 int msgpu_graph_state(const msgpu_graph *g, uint8_t *vertex_alive, uint8_t *vertex_direction, uint8_t *edge_alive,
                       uint8_t *edge_consensus, uint64_t *edge_weight);
+
+/* The graph primitives of the stage on caller-supplied graphs (vertices 0 .. n_vertices-1, edge i = (a[i], b[i])): the
+ * same code msgpu_graph_clean_up / msgpu_graph_linearize run, exposed so that the vectors the reference's own unit tests
+ * hold for them can be replayed through this boundary (tests/golden/ref_tests/).  consensus: 1 e_POS, 0 e_NEG, 2 e_NONE.
+ *   getMaxSpanTree          libms/src/kernel/mst.cpp:75-111   (libms/tests/MST_test.cpp:8-60)
+ *   getConnectedComponents  libms/src/kernel/cc.cpp:33-70     (libms/tests/CC_test.cpp:11-90)
+ *   GraphUtil::getShortestPath  include/ms/graph/Graph.h:927-978  (libms/tests/Graph_test.cpp:279-331); directed != 0:
+ *                           a DiGraph (edges a -> b, neighbours = successors)
+ *   DiGraph::sortTopologically  libms/src/graph/Graph.cpp:359-395 (libms/tests/Graph_test.cpp:393-423) */
+int msgpu_graph_max_span_tree(uint32_t n_vertices, const uint32_t *a, const uint32_t *b, const uint64_t *weight,
+                              const uint8_t *consensus, uint64_t n_edges, uint8_t *in_tree /* n_edges */);
+int msgpu_graph_connected_components(uint32_t n_vertices, const uint32_t *a, const uint32_t *b, const uint8_t *consensus,
+                                     uint64_t n_edges, uint32_t *component /* n_vertices */, uint32_t *n_components);
+/* *n_path: in = capacity of path, out = vertices on the path (0 = unreachable); MSGPU_E_ARG when it does not fit */
+int msgpu_graph_shortest_path(uint32_t n_vertices, const uint32_t *a, const uint32_t *b, uint64_t n_edges, int directed,
+                              uint32_t src, uint32_t dst, uint32_t *path, uint32_t *n_path);
+/* order: n_vertices entries of room; *n_order < n_vertices when the graph has a cycle (its vertices never appear) */
+int msgpu_graph_sort_topologically(uint32_t n_vertices, const uint32_t *a, const uint32_t *b, uint64_t n_edges,
+                                   uint32_t *order, uint32_t *n_order);
 
 /* ---- banded edit distance (no reference counterpart) ---------------------------------
  * The meter for north_star's "consensus sequences within a stated edit-distance tolerance": Levenshtein distance

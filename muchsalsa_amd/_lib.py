@@ -172,6 +172,14 @@ SYMBOLS = [
     ("msgpu_graph_path_count", C.c_uint32, [C.c_void_p]),
     ("msgpu_graph_path_input", C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(PathInput)]),
     ("msgpu_graph_state", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("msgpu_graph_max_span_tree", C.c_int, [C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64,
+                                            C.c_void_p]),
+    ("msgpu_graph_connected_components", C.c_int, [C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64,
+                                                   C.c_void_p, C.POINTER(C.c_uint32)]),
+    ("msgpu_graph_shortest_path", C.c_int, [C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_uint32,
+                                            C.c_uint32, C.c_void_p, C.POINTER(C.c_uint32)]),
+    ("msgpu_graph_sort_topologically", C.c_int, [C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p,
+                                                 C.POINTER(C.c_uint32)]),
     ("msgpu_gather_plan_create", C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     ("msgpu_gather_plan_free", None, [C.c_void_p]),
     ("msgpu_gather_plan_out_bytes", C.c_uint64, [C.c_void_p]),

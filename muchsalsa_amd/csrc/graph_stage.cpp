@@ -10,21 +10,34 @@
 //                                                         findConservationPathAlt, extractPaths, path joins
 //   assemblePaths          src/main.cpp:620-661           per component: directed graph -> paths -> msgpu_path_input
 //
-// The reference keeps shared_ptr vertices/edges in hash maps and fans jobs over a ThreadPool with one global mutex.
-// Here the undirected graph is a table of edges plus ordered adjacency maps, built once from the tables that
-// msgpu_copy_tables returns; findContractionEdges (the only part with per-edge independent arithmetic) runs on the
-// GPU (msgpu_find_contraction_edges) and is an input.  Serial, branchy, pointer-chasing work: host code by design.
+// The reference keeps shared_ptr vertices/edges in hash maps (Graph.h:404-407), copies whole adjacency maps per
+// neighbour query (Graph.cpp:260-287) and fans jobs over a ThreadPool with one global mutex.  Here every graph is FLAT:
+// vertices and edges are dense indices, adjacency is CSR (offsets + (neighbour, edge) pairs sorted by neighbour id),
+// deletion is a tombstone byte, a "copy" of a DiGraph is a second tombstone array over the same CSR, per-vertex state
+// lives in arrays indexed by id with round stamps instead of per-call hash maps.  findContractionEdges (the only part
+// with per-edge independent arithmetic) runs on the GPU (msgpu_find_contraction_edges) and is an input.
+//
+// Two restructurings keep the reference's results while dropping its quadratic loops:
+//  * decycle (main.cpp:575-618) asks for the tree path of ~every non-tree edge but only folds strand parities over it
+//    unless the parity is odd: the span forest is rooted once (parent, depth, parity-to-root), so the fold is two array
+//    reads and the path itself (climb to the common ancestor) is only walked for the conflicting edges.
+//  * extractPaths (lg.cpp:371-407) re-sorts the WHOLE remaining graph and re-runs findConservationPathAlt for every
+//    path it peels off.  Both are local to a weakly connected component: the stack-based topological order restricted
+//    to a component is the order that component has on its own, and components are visited in descending id of their
+//    zero-in-degree vertices.  So each component keeps its own best path, a heap picks the winner the global pass would
+//    pick (longest; ties: the sink that comes first in the global order), and only the component a path was taken from
+//    is re-solved.
 //
 // Iteration orders the reference leaves to hash containers (or to pointer VALUES: lg.cpp:419, main.cpp:211) are fixed
-// as in DESIGN.md section 9: vertices ascending id, edges in creation order ((v1, v2) table order for the undirected
-// graph), neighbours ascending id, std::sort ties stable, pointer-ordered containers ordered by vertex id.
+// as in DESIGN.md section 9: vertices ascending id, edges in creation order (table order for the undirected graph),
+// neighbours ascending id, std::sort ties stable, pointer-ordered containers ordered by vertex id.
 #include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <deque>
+#include <iterator>
 #include <map>
 #include <memory>
 #include <new>
@@ -33,21 +46,24 @@
 #include <stdexcept>
 #include <string>
 #include <thread>
-#include <unordered_map>
-#include <unordered_set>
 #include <vector>
 
 #include "msgpu.h"
 
 namespace {
 
-constexpr int    D_NONE = 0, D_POS = 1, D_NEG = -1;
+constexpr int8_t D_NONE = 0, D_POS = 1, D_NEG = -1;
 constexpr double BASE_WEIGHT_MULTIPLICATOR = 1.1; // src/main.cpp:96
 constexpr double MAX_WEIGHT_MULTIPLICATOR  = 0.8; // src/main.cpp:97
+constexpr uint32_t NIL = 0xffffffffu;
 
 struct GraphError : std::runtime_error {
   using std::runtime_error::runtime_error;
 };
+
+void require(bool ok, const char *what) {
+  if (!ok) throw GraphError(what);
+}
 
 struct Tick { // MSGPU_GRAPH_DEBUG=1: phase timings on stderr
   std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
@@ -60,180 +76,56 @@ struct Tick { // MSGPU_GRAPH_DEBUG=1: phase timings on stderr
   }
 };
 
-struct Vertex {
-  int32_t  length = 0;
-  uint32_t meta0  = 0;
-  int      direction = D_NONE;
-  bool     alive = false;
+// ---- flat adjacency ----------------------------------------------------------------------------------------------------
+
+struct Arc {
+  uint32_t to; // neighbour
+  uint32_t e;  // edge index
 };
 
-struct UEdge { // an Edge of the undirected Graph
-  uint32_t              a = 0, b = 0;
-  std::vector<uint32_t> orders; // indices into the order table
-  bool                  shadow = false, alive = true;
-  uint64_t              weight = 0;
-  int                   consensus = D_NONE;
+struct Csr { // segment of vertex v: arcs[off[v] .. off[v+1]), ascending `to`
+  std::vector<uint32_t> off;
+  std::vector<Arc>      arcs;
+  const Arc *begin(uint32_t v) const { return arcs.data() + off[v]; }
+  const Arc *end(uint32_t v) const { return arcs.data() + off[v + 1]; }
+  const Arc *find(uint32_t v, uint32_t to) const {
+    const Arc *lo = begin(v), *hi = end(v);
+    lo = std::lower_bound(lo, hi, to, [](const Arc &a, uint32_t t) { return a.to < t; });
+    return lo != hi && lo->to == to ? lo : nullptr;
+  }
 };
 
-struct DEdge { // an Edge of a DiGraph; shared between a DiGraph and its copies (Graph.h:773-774)
-  uint32_t              a, b;
-  std::vector<uint32_t> orders;
-  bool                  shadow = false;
-  uint64_t              weight = 0;
-  uint32_t              src = 0; // undirected edge whose EdgeMatches it carries (dg.cpp:97-99)
-  uint64_t              seq = 0; // creation order
-};
-using DEdgeP = std::shared_ptr<DEdge>;
-
-struct DiGraph {
-  std::set<uint32_t>                               vertices;
-  std::map<uint32_t, std::map<uint32_t, DEdgeP>>   succ, pred; // ascending ids
-  std::map<uint64_t, DEdgeP>                       edges;      // creation order
-  std::map<uint32_t, int64_t>                      indeg, outdeg;
-  uint64_t                                         next_seq = 0;
-
-  void add_vertex(uint32_t v) {
-    vertices.insert(v);
-    indeg.emplace(v, 0);
-    outdeg.emplace(v, 0);
+// CSR of n vertices from m (from[i] -> to[i]) pairs, edge index i; both_ways = undirected.  Segments end up ascending
+// in `to` (counting sort by source keeps input order; a segment that is not ascending already is sorted).
+Csr build_csr(uint32_t n, const uint32_t *from, const uint32_t *to, size_t m, bool both_ways) {
+  Csr c;
+  c.off.assign(static_cast<size_t>(n) + 1, 0);
+  for (size_t i = 0; i < m; ++i) {
+    ++c.off[from[i] + 1];
+    if (both_ways) ++c.off[to[i] + 1];
   }
-  bool   has_vertex(uint32_t v) const { return vertices.count(v) != 0; }
-  DEdgeP get_edge(uint32_t a, uint32_t b) const {
-    auto it = succ.find(a);
-    if (it == succ.end()) return nullptr;
-    auto jt = it->second.find(b);
-    return jt == it->second.end() ? nullptr : jt->second;
-  }
-  bool   has_edge(uint32_t a, uint32_t b) const { return get_edge(a, b) != nullptr; }
-  DEdgeP add_edge(uint32_t a, uint32_t b) { // GraphBase::_addEdge + DiGraph::_onEdgeAdded
-    if (!has_vertex(a) || !has_vertex(b)) return nullptr;
-    if (DEdgeP e = get_edge(a, b)) return e;
-    DEdgeP e = std::make_shared<DEdge>();
-    e->a   = a;
-    e->b   = b;
-    e->seq = next_seq++;
-    succ[a][b] = e;
-    pred[b][a] = e;
-    edges[e->seq] = e;
-    ++outdeg[a];
-    ++indeg[b];
-    return e;
-  }
-  void delete_edge(const DEdgeP &e) { // GraphBase::_deleteEdge(.., false)
-    auto it = succ.find(e->a);
-    if (it != succ.end() && it->second.erase(e->b)) {
-      pred[e->b].erase(e->a);
-      auto o = outdeg.find(e->a);
-      if (o != outdeg.end()) --o->second;
-      auto i = indeg.find(e->b);
-      if (i != indeg.end()) --i->second;
+  for (uint32_t v = 0; v < n; ++v) c.off[v + 1] += c.off[v];
+  c.arcs.resize(c.off[n]);
+  std::vector<uint32_t> cur(c.off.begin(), c.off.end() - 1);
+  if (both_ways) { // lower neighbours first: with a (v1, v2)-sorted table every segment comes out ascending
+    for (size_t i = 0; i < m; ++i) {
+      if (from[i] > to[i]) c.arcs[cur[from[i]]++] = Arc{to[i], static_cast<uint32_t>(i)};
+      else c.arcs[cur[to[i]]++] = Arc{from[i], static_cast<uint32_t>(i)};
     }
-    edges.erase(e->seq);
   }
-  void delete_vertex(uint32_t v) { // GraphBase::_deleteVertex(.., false) + DiGraph::deleteVertex
-    std::vector<DEdgeP> gone;
-    auto                s = succ.find(v);
-    if (s != succ.end())
-      for (auto &t : s->second) gone.push_back(t.second);
-    auto p = pred.find(v);
-    if (p != pred.end())
-      for (auto &t : p->second) gone.push_back(t.second);
-    for (auto &e : gone) delete_edge(e);
-    succ.erase(v);
-    pred.erase(v);
-    vertices.erase(v);
-    indeg.erase(v);
-    outdeg.erase(v);
+  for (size_t i = 0; i < m; ++i) {
+    if (!both_ways) c.arcs[cur[from[i]]++] = Arc{to[i], static_cast<uint32_t>(i)};
+    else if (from[i] > to[i]) c.arcs[cur[to[i]]++] = Arc{from[i], static_cast<uint32_t>(i)};
+    else c.arcs[cur[from[i]]++] = Arc{to[i], static_cast<uint32_t>(i)};
   }
-  std::vector<uint32_t> sort_topologically() const { // Graph.cpp:359-395
-    std::map<uint32_t, int64_t> nonnull;
-    std::vector<uint32_t>       ready, result;
-    for (auto &d : indeg) {
-      if (d.second > 0) nonnull[d.first] = d.second;
-      else ready.push_back(d.first);
-    }
-    while (!ready.empty()) {
-      const uint32_t v = ready.back();
-      ready.pop_back();
-      auto s = succ.find(v);
-      if (s != succ.end())
-        for (auto &t : s->second) {
-          int64_t &d = nonnull[t.first];
-          d -= 1;
-          if (d == 0) {
-            ready.push_back(t.first);
-            nonnull.erase(t.first);
-          }
-        }
-      result.push_back(v);
-    }
-    return result;
+  for (uint32_t v = 0; v < n; ++v) {
+    Arc *b = c.arcs.data() + c.off[v], *e = c.arcs.data() + c.off[v + 1];
+    bool sorted = true;
+    for (Arc *p = b; p + 1 < e && sorted; ++p) sorted = p->to <= (p + 1)->to;
+    if (!sorted) std::stable_sort(b, e, [](const Arc &x, const Arc &y) { return x.to < y.to; });
   }
-  const std::map<uint32_t, DEdgeP> &successors(uint32_t v) const {
-    static const std::map<uint32_t, DEdgeP> none;
-    auto                                    it = succ.find(v);
-    return it == succ.end() ? none : it->second;
-  }
-  const std::map<uint32_t, DEdgeP> &predecessors(uint32_t v) const {
-    static const std::map<uint32_t, DEdgeP> none;
-    auto                                    it = pred.find(v);
-    return it == pred.end() ? none : it->second;
-  }
-};
-
-} // namespace
-
-struct msgpu_graph {
-  // tables (copied)
-  std::vector<msgpu_edge>      t_edges;
-  std::vector<msgpu_edgematch> t_ems;
-  std::vector<msgpu_order>     t_orders;
-  std::vector<uint32_t>        t_ids;
-  // undirected graph
-  std::vector<Vertex>                         V;
-  std::vector<UEdge>                          E;   // creation order = table order
-  std::vector<std::map<uint32_t, uint32_t>>   adj; // neighbour -> edge index
-  struct Contain {
-    uint32_t nano, direction;
-    std::vector<uint32_t> anchors;
-  };
-  std::map<uint32_t, std::vector<Contain>> contain;
-  bool cleaned = false, linearized = false;
-  uint32_t n_threads = 1;
-  msgpu_graph_stats stats{};
-  // paths + storage the msgpu_path_input views point into
-  struct PathStore {
-    std::vector<msgpu_path_read>    reads;
-    std::vector<uint32_t>           order_off, em_off, contain_anchors;
-    std::vector<msgpu_path_order>   orders;
-    std::vector<msgpu_path_em>      ems;
-    std::vector<msgpu_path_contain> contains;
-  };
-  std::vector<PathStore> paths;
-  char err[256] = {0};
-
-  bool odir(uint32_t o) const { return (t_orders[o].flags & MSGPU_ORD_DIR) != 0; }
-  bool ocont(uint32_t o) const { return (t_orders[o].flags & MSGPU_ORD_CONTAINED) != 0; }
-
-  int64_t edge_between(uint32_t a, uint32_t b) const {
-    auto it = adj[a].find(b);
-    return it == adj[a].end() ? -1 : static_cast<int64_t>(it->second);
-  }
-  void delete_edge(uint32_t e) { // Graph::deleteEdge
-    if (!E[e].alive) return;
-    adj[E[e].a].erase(E[e].b);
-    adj[E[e].b].erase(E[e].a);
-    E[e].alive = false;
-  }
-  void delete_vertex(uint32_t v) { // Graph::deleteVertex
-    std::vector<uint32_t> gone;
-    for (auto &n : adj[v]) gone.push_back(n.second);
-    for (uint32_t e : gone) delete_edge(e);
-    V[v].alive = false;
-  }
-};
-
-namespace {
+  return c;
+}
 
 // mst.cpp:35-73, including unify()'s use of the weights of the vertices rather than of their roots
 struct UnionFind { // vertex ids are dense: vectors instead of the reference's two hash maps; weight 0 = "not seen yet"
@@ -264,391 +156,744 @@ struct UnionFind { // vertex ids are dense: vectors instead of the reference's t
   }
 };
 
-using TreeAdj = std::vector<std::map<uint32_t, uint32_t>>;
+// getMaxSpanTree (mst.cpp:75-111): Kruskal over the edges that have a consensus direction, heaviest first, ties in edge
+// order (std::sort on a vector built in edge order; canonical = stable).  `cand` = candidate edge indices in edge order;
+// ends(e) -> (a, b), weight(e).
+template <class Ends, class Weight>
+void max_span_tree(uint32_t nv, Ends ends, Weight weight, std::vector<uint32_t> cand, std::vector<uint8_t> &in_tree) {
+  std::vector<std::pair<uint64_t, uint32_t>> keyed(cand.size()); // (weight, position): one sort key, no gathers in the compare
+  for (size_t i = 0; i < cand.size(); ++i) keyed[i] = {weight(cand[i]), static_cast<uint32_t>(i)};
+  std::sort(keyed.begin(), keyed.end(), [](const std::pair<uint64_t, uint32_t> &x, const std::pair<uint64_t, uint32_t> &y) {
+    return x.first != y.first ? x.first > y.first : x.second < y.second;
+  });
+  UnionFind uf(nv);
+  for (auto &k : keyed) {
+    const uint32_t e = cand[k.second];
+    const auto     ab = ends(e);
+    if (uf.find(ab.first) != uf.find(ab.second)) {
+      in_tree[e] = 1;
+      uf.unify(ab.first, ab.second);
+    }
+  }
+}
 
-// GraphUtil::getShortestPath (Graph.h:927-978: Dijkstra with unit weights, ties by insertion order) on the span tree.
-// In a forest the path between two vertices is unique, and (distance, insertion counter) order is breadth-first order,
-// so this is a BFS with dense, stamp-reset scratch instead of three hash maps per call.
-struct TreeSearch {
-  std::vector<uint32_t> from, stamp, queue;
-  uint32_t              round = 0;
-  explicit TreeSearch(uint32_t n) : from(n), stamp(n, 0) {}
-  std::vector<uint32_t> path(const TreeAdj &tree, uint32_t src, uint32_t dst) {
-    ++round;
-    queue.assign(1, src);
-    stamp[src] = round;
-    bool found = src == dst;
-    for (size_t h = 0; h < queue.size() && !found; ++h) {
-      const uint32_t v = queue[h];
-      for (auto &n : tree[v]) {
-        if (stamp[n.first] == round) continue;
-        stamp[n.first] = round;
-        from[n.first]  = v;
-        if (n.first == dst) {
-          found = true;
-          break;
-        }
-        queue.push_back(n.first);
+// GraphUtil::getShortestPath (Graph.h:927-978): Dijkstra with unit weights whose queue is ordered by (distance,
+// insertion counter) -- i.e. breadth-first search, a vertex keeping the path of whoever reached it first; neighbours
+// ascending id (for a DiGraph: successors).  Empty result = unreachable.
+std::vector<uint32_t> shortest_path(const Csr &adj, const uint8_t *arc_ok_by_edge, uint32_t n, uint32_t src, uint32_t dst) {
+  std::vector<uint32_t> from(n, NIL), queue{src}, p;
+  std::vector<uint8_t>  seen(n, 0);
+  seen[src] = 1;
+  bool found = src == dst;
+  for (size_t h = 0; h < queue.size() && !found; ++h) {
+    const uint32_t v = queue[h];
+    for (const Arc *t = adj.begin(v); t != adj.end(v); ++t) {
+      if ((arc_ok_by_edge && !arc_ok_by_edge[t->e]) || seen[t->to]) continue;
+      seen[t->to] = 1;
+      from[t->to] = v;
+      if (t->to == dst) {
+        found = true;
+        break;
       }
+      queue.push_back(t->to);
     }
-    std::vector<uint32_t> p;
-    if (!found) return p;
-    for (uint32_t v = dst;; v = from[v]) {
-      p.push_back(v);
-      if (v == src) break;
+  }
+  if (!found) return p;
+  for (uint32_t v = dst;; v = from[v]) {
+    p.push_back(v);
+    if (v == src) break;
+  }
+  std::reverse(p.begin(), p.end());
+  return p;
+}
+
+// getConnectedComponents (cc.cpp:33-70): breadth-first over the edges that carry a consensus direction; vertices in
+// ascending id, neighbours ascending id.  v_ok(v): vertex in the graph; e_ok(e): edge in the graph and with a consensus
+// direction; set_comp(v, c) / get_comp(v): component number (NIL at the start).
+template <class VOk, class EOk, class GetComp, class SetComp>
+std::vector<std::vector<uint32_t>> connected_components(uint32_t nv, const Csr &adj, VOk v_ok, EOk e_ok, GetComp get_comp,
+                                                        SetComp set_comp) {
+  std::vector<std::vector<uint32_t>> comps;
+  for (uint32_t s = 0; s < nv; ++s) {
+    if (!v_ok(s) || get_comp(s) != NIL) continue;
+    const uint32_t        cid = static_cast<uint32_t>(comps.size());
+    std::vector<uint32_t> members{s};
+    set_comp(s, cid);
+    for (size_t h = 0; h < members.size(); ++h) {
+      const uint32_t cur = members[h];
+      for (const Arc *t = adj.begin(cur); t != adj.end(cur); ++t)
+        if (get_comp(t->to) == NIL && e_ok(t->e)) {
+          set_comp(t->to, cid);
+          members.push_back(t->to);
+        }
     }
-    std::reverse(p.begin(), p.end());
-    return p;
+    comps.push_back(std::move(members));
+  }
+  return comps;
+}
+
+// DiGraph::sortTopologically (Graph.cpp:359-395): vertices without predecessors are collected in ascending id and
+// taken from the BACK of that list; a vertex whose last predecessor has just been emitted goes on top.  Vertices on a
+// cycle never appear.  `alive` (per arc's edge index, optional) and `valive` (per vertex, optional) are tombstones.
+std::vector<uint32_t> sort_topologically(uint32_t n, const Csr &succ, const Csr &pred, const uint8_t *alive,
+                                         const uint8_t *valive) {
+  std::vector<int64_t>  deg(n, 0);
+  std::vector<uint32_t> ready, result;
+  for (uint32_t v = 0; v < n; ++v) {
+    if (valive && !valive[v]) continue;
+    for (const Arc *t = pred.begin(v); t != pred.end(v); ++t) deg[v] += !alive || alive[t->e];
+    if (deg[v] == 0) ready.push_back(v);
+  }
+  result.reserve(n);
+  while (!ready.empty()) {
+    const uint32_t v = ready.back();
+    ready.pop_back();
+    for (const Arc *t = succ.begin(v); t != succ.end(v); ++t)
+      if ((!alive || alive[t->e]) && --deg[t->to] == 0) ready.push_back(t->to);
+    result.push_back(v);
+  }
+  return result;
+}
+
+} // namespace
+
+struct msgpu_graph {
+  // tables (borrowed from the caller: valid until msgpu_graph_free)
+  const msgpu_edge      *t_edges = nullptr;
+  const msgpu_edgematch *t_ems   = nullptr;
+  const msgpu_order     *t_orders = nullptr;
+  const uint32_t        *t_ids   = nullptr;
+  uint64_t               n_edges = 0, n_ems = 0, n_orders = 0, n_ids = 0;
+  uint32_t               nv = 0;
+  // vertices and undirected edges (table order): one record each, so that a visit costs one cache line
+  struct Vertex {
+    int32_t  len   = 0;
+    uint32_t meta0 = 0;
+    uint32_t comp  = NIL; // connected component
+    uint32_t loc   = NIL; // local id inside its component's DiGraph
+    int8_t   dir   = D_NONE;
+    uint8_t  alive = 1, in_dg = 0;
+  };
+  struct Edge {
+    uint32_t a = 0, b = 0;
+    uint32_t ord_lo = 0;       // its orders: order table [ord_lo, ord_lo + ord_cnt), those with o_kept set
+    uint32_t first  = NIL;     // first kept order, NIL = none
+    uint32_t de_fwd = 0, de_bwd = 0; // its directed edges a -> b / b -> a in its component's DiGraph (+1; 0 = none)
+    uint64_t weight = 0;
+    uint16_t ord_cnt = 0;
+    int8_t   cons    = D_NONE;
+    uint8_t  alive = 1, shadow = 0;
+  };
+  std::vector<Vertex>  V;
+  std::vector<Edge>    E;
+  std::vector<uint8_t> o_kept;  // per order: still on its edge (findDeletableEdges drops the contained ones)
+  Csr                  adj;
+  struct Contain {
+    uint32_t nano, direction;
+    std::vector<uint32_t> anchors;
+  };
+  std::map<uint32_t, std::vector<Contain>> contain;
+  bool cleaned = false, linearized = false;
+  uint32_t n_threads = 1;
+  msgpu_graph_stats stats{};
+  // paths + storage the msgpu_path_input views point into
+  struct PathStore {
+    std::vector<msgpu_path_read>    reads;
+    std::vector<uint32_t>           order_off, em_off, contain_anchors;
+    std::vector<msgpu_path_order>   orders;
+    std::vector<msgpu_path_em>      ems;
+    std::vector<msgpu_path_contain> contains;
+  };
+  std::vector<PathStore> paths;
+  char err[256] = {0};
+
+  bool odir(uint32_t o) const { return (t_orders[o].flags & MSGPU_ORD_DIR) != 0; }
+  bool ocont(uint32_t o) const { return (t_orders[o].flags & MSGPU_ORD_CONTAINED) != 0; }
+  int64_t edge_between(uint32_t a, uint32_t b) const {
+    const Arc *t = adj.find(a, b);
+    return t && E[t->e].alive ? static_cast<int64_t>(t->e) : -1;
+  }
+  void delete_edge(uint32_t e) { E[e].alive = 0; }             // Graph::deleteEdge
+  void delete_vertex(uint32_t v) {                              // Graph::deleteVertex
+    for (const Arc *t = adj.begin(v); t != adj.end(v); ++t) E[t->e].alive = 0;
+    V[v].alive = 0;
   }
 };
 
+namespace {
+
+// ---- the DiGraph of one connected component (dg.cpp), flat ---------------------------------------------------------------
+
+struct DiG {
+  uint32_t              n = 0;
+  std::vector<uint32_t> ids;          // local -> global vertex id, ascending
+  std::vector<uint32_t> ea, eb, src;  // directed edges in creation order: local endpoints, undirected edge of origin
+  std::vector<uint8_t>  shadow;       // shared by the graph and its cycle-free copy (Graph.h:773-774: shallow copy)
+  std::vector<uint64_t> weight;
+  std::vector<uint32_t> ord_off, ord; // EdgeOrders per directed edge, in appendOrder order
+  Csr                   succ, pred;
+  size_t m() const { return ea.size(); }
+  int64_t get_edge(uint32_t a, uint32_t b) const {
+    const Arc *t = succ.find(a, b);
+    return t ? static_cast<int64_t>(t->e) : -1;
+  }
+};
+
+// getDirectedGraph, dg.cpp:35-121; the component = the vertices with comp_of == cid (its sub-graph keeps every alive
+// edge between those vertices, Graph.cpp:317-326)
+DiG get_directed_graph(msgpu_graph &g, uint32_t cid, const std::vector<uint32_t> &members, uint32_t start) {
+  DiG                                        dg;
+  std::vector<uint32_t>                      ea, eb;   // global endpoints while building
+  std::vector<std::pair<uint32_t, uint32_t>> pushes;   // (directed edge, order)
+  std::vector<std::pair<uint32_t, bool>>     stack{{start, true}};
+  auto add_vertex = [&](uint32_t v) { g.V[v].in_dg = 1; };
+  while (!stack.empty()) {
+    const uint32_t cur    = stack.back().first;
+    const bool     toggle = stack.back().second;
+    stack.pop_back();
+    if (!g.V[cur].in_dg) add_vertex(cur);
+    if (g.V[cur].dir == D_NONE) g.V[cur].dir = toggle ? D_POS : D_NEG;
+    // the walk is a chain of dependent cache misses (arc -> edge record -> its orders): ask for all of them up front
+    for (const Arc *n = g.adj.begin(cur); n != g.adj.end(cur); ++n) {
+      __builtin_prefetch(&g.E[n->e]);
+      __builtin_prefetch(&g.V[n->to]);
+    }
+    for (const Arc *n = g.adj.begin(cur); n != g.adj.end(cur); ++n)
+      if (g.E[n->e].alive && !g.E[n->e].de_fwd && !g.E[n->e].de_bwd) __builtin_prefetch(&g.t_orders[g.E[n->e].ord_lo]);
+    for (const Arc *n = g.adj.begin(cur); n != g.adj.end(cur); ++n) {
+      const uint32_t nb = n->to, ue = n->e;
+      if (!g.E[ue].alive || g.V[nb].comp != cid) continue;
+      bool other_exists = g.V[nb].in_dg != 0;
+      if (other_exists) other_exists = g.V[nb].dir != D_NONE;
+      if (!other_exists) add_vertex(nb);
+      if (g.E[ue].de_fwd || g.E[ue].de_bwd) continue; // hasEdge(a, b) || hasEdge(b, a)
+      const uint32_t lo = g.E[ue].ord_lo, hi = lo + g.E[ue].ord_cnt;
+      for (uint32_t oi = lo; oi < hi; ++oi) {
+        if (!g.o_kept[oi]) continue;
+        const msgpu_order &o    = g.t_orders[oi];
+        bool               flip = false;
+        if (!g.odir(oi) && o.base == nb) flip = !flip;
+        if (!toggle) flip = !flip;
+        const uint32_t s = flip ? o.end : o.start, t = flip ? o.start : o.end;
+        if (!((s == g.E[ue].a && t == g.E[ue].b) || (s == g.E[ue].b && t == g.E[ue].a)))
+          throw GraphError("getDirectedGraph: order between vertices outside the component");
+        uint32_t &slot = s == g.E[ue].a ? g.E[ue].de_fwd : g.E[ue].de_bwd;
+        if (!slot) {
+          ea.push_back(s);
+          eb.push_back(t);
+          dg.src.push_back(ue);
+          dg.shadow.push_back(g.E[ue].shadow);
+          dg.weight.push_back(g.E[ue].shadow ? 0 : g.E[ue].weight);
+          slot = static_cast<uint32_t>(ea.size());
+        }
+        pushes.emplace_back(slot - 1, oi);
+      }
+      if (g.E[ue].cons == D_NONE) continue;
+      const bool nxt = toggle == (g.E[ue].cons == D_POS);
+      if (!other_exists) stack.emplace_back(nb, nxt);
+    }
+  }
+  // local ids in ascending global id
+  for (uint32_t v : members)
+    if (g.V[v].in_dg) dg.ids.push_back(v);
+  std::sort(dg.ids.begin(), dg.ids.end());
+  dg.n = static_cast<uint32_t>(dg.ids.size());
+  for (uint32_t l = 0; l < dg.n; ++l) g.V[dg.ids[l]].loc = l;
+  const size_t m = ea.size();
+  dg.ea.resize(m);
+  dg.eb.resize(m);
+  for (size_t i = 0; i < m; ++i) {
+    dg.ea[i] = g.V[ea[i]].loc;
+    dg.eb[i] = g.V[eb[i]].loc;
+  }
+  dg.ord_off.assign(m + 1, 0);
+  for (auto &p : pushes) ++dg.ord_off[p.first + 1];
+  for (size_t i = 0; i < m; ++i) dg.ord_off[i + 1] += dg.ord_off[i];
+  dg.ord.resize(pushes.size());
+  std::vector<uint32_t> cur(dg.ord_off.begin(), dg.ord_off.end() - 1);
+  for (auto &p : pushes) dg.ord[cur[p.first]++] = p.second;
+  dg.succ = build_csr(dg.n, dg.ea.data(), dg.eb.data(), m, false);
+  dg.pred = build_csr(dg.n, dg.eb.data(), dg.ea.data(), m, false);
+  return dg;
+}
+
 // ---- linearizeGraph, lg.cpp ------------------------------------------------------------------------------------------
 
-void sort_reduction_by_weight(DiGraph &dg) { // lg.cpp:418-520
-  std::map<uint32_t, int64_t> nonnull;
-  std::deque<uint32_t>        null;
-  for (auto &d : dg.indeg) {
-    if (d.second > 0) nonnull[d.first] = d.second;
-    else null.push_back(d.first);
+// sortReductionByWeight (lg.cpp:418-520) on the cycle copy: `alive` = its edges; cut edges become shadow edges of BOTH
+// graphs (shared Edge objects) and leave the copy.
+void sort_reduction_by_weight(DiG &dg, std::vector<uint8_t> &alive) {
+  const uint32_t        n = dg.n;
+  std::vector<int64_t>  rem(n, 0);     // verticesWithNonNullInDegree[v]
+  std::vector<uint8_t>  innn(n, 0), resolved(n, 0);
+  std::vector<uint32_t> null;          // deque: consumed from `head`
+  size_t                head = 0, nn = 0;
+  for (uint32_t v = 0; v < n; ++v) {
+    for (const Arc *t = dg.pred.begin(v); t != dg.pred.end(v); ++t) rem[v] += alive[t->e];
+    if (rem[v] > 0) {
+      innn[v] = 1;
+      ++nn;
+    } else {
+      null.push_back(v);
+    }
   }
-  std::set<uint32_t> resolved, neighbors;
-  if (!nonnull.empty()) neighbors.insert(nonnull.begin()->first);
+  std::set<uint32_t> neighbors;
+  if (nn)
+    for (uint32_t v = 0; v < n; ++v)
+      if (innn[v]) {
+        neighbors.insert(v);
+        break;
+      }
   while (true) {
-    while (!null.empty()) {
-      const uint32_t v = null.front();
-      null.pop_front();
-      resolved.insert(v);
-      for (auto &s : dg.successors(v)) {
-        auto it = nonnull.find(s.first);
-        if (it == nonnull.end()) throw GraphError("sortReductionByWeight: in-degree map out of step");
-        if (--it->second == 0) {
-          null.push_back(s.first);
-          nonnull.erase(it);
-          neighbors.erase(s.first);
+    while (head < null.size()) {
+      const uint32_t v = null[head++];
+      resolved[v] = 1;
+      for (const Arc *s = dg.succ.begin(v); s != dg.succ.end(v); ++s) {
+        if (!alive[s->e]) continue;
+        if (!innn[s->to]) throw GraphError("sortReductionByWeight: in-degree map out of step");
+        if (--rem[s->to] == 0) {
+          null.push_back(s->to);
+          innn[s->to] = 0;
+          --nn;
+          neighbors.erase(s->to);
         } else {
-          neighbors.insert(s.first);
+          neighbors.insert(s->to);
         }
       }
     }
-    if (nonnull.empty()) break;
-    DEdgeP   min_edge;
+    if (!nn) break;
+    int64_t  min_edge = -1;
     uint32_t min_vertex = 0;
-    uint64_t min_score  = 0;
-    auto     scan       = [&](uint32_t cand) {
-      for (auto &p : dg.predecessors(cand))
-        if (!resolved.count(p.first) && (!min_edge || p.second->weight < min_score)) {
-          min_edge   = p.second;
+    uint64_t min_score = 0;
+    auto     scan = [&](uint32_t cand) {
+      for (const Arc *p = dg.pred.begin(cand); p != dg.pred.end(cand); ++p)
+        if (alive[p->e] && !resolved[p->to] && (min_edge < 0 || dg.weight[p->e] < min_score)) {
+          min_edge   = p->e;
           min_vertex = cand;
-          min_score  = p.second->weight;
+          min_score  = dg.weight[p->e];
         }
     };
-    if (neighbors.empty())
-      for (auto &kv : nonnull) scan(kv.first);
-    else
-      for (uint32_t n : neighbors) scan(n);
-    if (!min_edge) throw GraphError("sortReductionByWeight: no edge to cut");
-    min_edge->shadow = true;
-    dg.delete_edge(min_edge);
-    auto it = nonnull.find(min_vertex);
-    if (--it->second == 0) {
-      nonnull.erase(it);
+    if (neighbors.empty()) {
+      for (uint32_t v = 0; v < n; ++v)
+        if (innn[v]) scan(v);
+    } else {
+      for (uint32_t v : neighbors) scan(v);
+    }
+    if (min_edge < 0) throw GraphError("sortReductionByWeight: no edge to cut");
+    dg.shadow[min_edge] = 1;
+    alive[min_edge]     = 0;
+    if (--rem[min_vertex] == 0) {
+      innn[min_vertex] = 0;
+      --nn;
       null.push_back(min_vertex);
       neighbors.erase(min_vertex);
     }
   }
 }
 
-using ClusterWeights = std::unordered_map<const DEdge *, uint64_t>;
-
-bool subset(const std::set<size_t> &a, const std::set<size_t> &b) {
+bool subset(const std::vector<uint32_t> &a, const std::vector<uint32_t> &b) { // a within b, both ascending
   return std::includes(b.begin(), b.end(), a.begin(), a.end());
 }
 
-ClusterWeights find_cluster_weights(const DiGraph &dg) { // lg.cpp:144-264
-  const std::vector<uint32_t>          order = dg.sort_topologically();
-  std::unordered_map<uint32_t, size_t> idx;
-  for (size_t i = 0; i < order.size(); ++i) idx[order[i]] = i;
-  ClusterWeights result;
-  for (auto &e : dg.edges) result[e.second.get()] = 0;
-  std::unordered_map<uint32_t, std::set<size_t>> succ, pred;
-  for (uint32_t v : order) {
-    auto &s = succ[v];
-    for (auto &t : dg.successors(v)) s.insert(idx.at(t.first));
-    auto &p = pred[v];
-    for (auto &t : dg.predecessors(v)) p.insert(idx.at(t.first));
-  }
-  struct Cand {
-    std::set<size_t>    open;
-    std::vector<size_t> visited;
-  };
-  for (uint32_t v : order) {
-    std::vector<Cand> cands{Cand{succ.at(v), {idx.at(v)}}};
-    for (size_t i_out : succ.at(v)) {
-      const uint32_t active = order[i_out];
-      for (size_t i_in : pred.at(active))
-        for (size_t k = 0; k < cands.size(); ++k) // the bound grows with the emplace_back inside (:193)
-          if (cands[k].visited.back() == i_in && cands[k].open.count(i_out)) {
-            Cand n;
-            std::set_intersection(cands[k].open.begin(), cands[k].open.end(), succ.at(active).begin(),
-                                  succ.at(active).end(), std::inserter(n.open, n.open.end()));
-            n.visited = cands[k].visited;
-            n.visited.push_back(i_out);
-            cands.push_back(std::move(n));
+// successors / predecessors of every vertex as ascending topological indices (the std::set<size_t> of lg.cpp:160-176)
+struct TopoSets {
+  std::vector<uint32_t> order, idx, soff, sidx, poff, pidx;
+  TopoSets(const DiG &dg, const std::vector<uint8_t> &alive) {
+    order = sort_topologically(dg.n, dg.succ, dg.pred, alive.data(), nullptr);
+    idx.assign(dg.n, NIL);
+    for (uint32_t i = 0; i < order.size(); ++i) idx[order[i]] = i;
+    auto fill = [&](const Csr &c, std::vector<uint32_t> &off, std::vector<uint32_t> &out) {
+      off.assign(dg.n + 1, 0);
+      for (uint32_t v = 0; v < dg.n; ++v) {
+        off[v] = static_cast<uint32_t>(out.size());
+        for (const Arc *t = c.begin(v); t != c.end(v); ++t)
+          if (alive[t->e]) {
+            if (idx[t->to] == NIL) throw GraphError("findClusterWeights: vertex missing from the topological order");
+            out.push_back(idx[t->to]);
           }
-      std::vector<Cand> filtered;
+        std::sort(out.begin() + off[v], out.end());
+      }
+      off[dg.n] = static_cast<uint32_t>(out.size());
+    };
+    fill(dg.succ, soff, sidx);
+    fill(dg.pred, poff, pidx);
+  }
+};
+
+void add_path_weights(const DiG &dg, const std::vector<uint32_t> &order, const std::vector<uint32_t> &mv,
+                      std::vector<uint64_t> &result) {
+  size_t       c     = mv.size() - 1;
+  const size_t limit = std::max<size_t>(mv.size(), 1) - 1;
+  for (size_t i = 0; i < limit; ++i) {
+    const int64_t e = dg.get_edge(order[mv[i]], order[mv[i + 1]]);
+    require(e >= 0, "findClusterWeights: path edge missing");
+    result[e] += c;
+    c -= 1;
+  }
+}
+
+std::vector<uint64_t> find_cluster_weights(const DiG &dg, const std::vector<uint8_t> &alive) { // lg.cpp:144-264
+  const TopoSets        ts(dg, alive);
+  std::vector<uint64_t> result(dg.m(), 0);
+  struct Cand {
+    std::vector<uint32_t> open, visited; // both ascending (a visited index is always larger than the one before it)
+  };
+  std::vector<Cand> cands, filtered;
+  for (uint32_t v : ts.order) {
+    const uint32_t *sb = ts.sidx.data() + ts.soff[v], *se = ts.sidx.data() + ts.soff[v + 1];
+    if (sb == se) continue; // no successor: the only candidate is {v}, which adds nothing
+    cands.clear();
+    cands.push_back(Cand{std::vector<uint32_t>(sb, se), {ts.idx[v]}});
+    for (const uint32_t *po = sb; po != se; ++po) {
+      const uint32_t i_out = *po, active = ts.order[i_out];
+      const uint32_t *ab = ts.sidx.data() + ts.soff[active], *ae = ts.sidx.data() + ts.soff[active + 1];
+      for (uint32_t q = ts.poff[active]; q < ts.poff[active + 1]; ++q) {
+        const uint32_t i_in = ts.pidx[q];
+        for (size_t k = 0; k < cands.size(); ++k) // the bound grows with the emplace_back inside (:193)
+          if (cands[k].visited.back() == i_in && std::binary_search(cands[k].open.begin(), cands[k].open.end(), i_out)) {
+            Cand nc;
+            std::set_intersection(cands[k].open.begin(), cands[k].open.end(), ab, ae, std::back_inserter(nc.open));
+            nc.visited = cands[k].visited;
+            nc.visited.push_back(i_out);
+            cands.push_back(std::move(nc));
+          }
+      }
+      filtered.clear();
       for (size_t a = 0; a < cands.size(); ++a) {
-        bool                   dominated = false;
-        const std::set<size_t> va(cands[a].visited.begin(), cands[a].visited.end());
-        for (size_t b = 0; b < cands.size() && !dominated; ++b) {
-          if (a == b || !subset(cands[a].open, cands[b].open)) continue;
-          const std::set<size_t> vb(cands[b].visited.begin(), cands[b].visited.end());
-          dominated = subset(va, vb);
-        }
+        bool dominated = false;
+        for (size_t b = 0; b < cands.size() && !dominated; ++b)
+          dominated = a != b && subset(cands[a].open, cands[b].open) && subset(cands[a].visited, cands[b].visited);
         if (!dominated) filtered.push_back(cands[a]);
       }
-      cands = std::move(filtered);
+      cands.swap(filtered);
     }
-    std::vector<const std::vector<size_t> *> best;
-    size_t                                   best_len = 0;
-    for (auto &c : cands) {
-      if (c.visited.size() > best_len) {
-        best     = {&c.visited};
-        best_len = c.visited.size();
-      } else if (c.visited.size() == best_len) {
-        best.push_back(&c.visited);
-      }
-    }
-    for (auto *mv : best) {
-      size_t       c     = mv->size() - 1;
-      const size_t limit = std::max<size_t>(mv->size(), 1) - 1;
-      for (size_t i = 0; i < limit; ++i) {
-        result[dg.get_edge(order[(*mv)[i]], order[(*mv)[i + 1]]).get()] += c;
-        c -= 1;
-      }
-    }
-  }
-  return result;
-}
-
-ClusterWeights find_cluster_weights_heuristic(const DiGraph &dg) { // lg.cpp:72-141
-  const std::vector<uint32_t>          order = dg.sort_topologically();
-  std::unordered_map<uint32_t, size_t> idx;
-  for (size_t i = 0; i < order.size(); ++i) idx[order[i]] = i;
-  ClusterWeights result;
-  for (auto &e : dg.edges) result[e.second.get()] = 0;
-  for (uint32_t v : order) {
-    std::set<size_t> sorted_succ;
-    for (auto &t : dg.successors(v)) sorted_succ.insert(idx.at(t.first));
-    std::map<uint32_t, std::vector<size_t>> cands; // ascending id = the canonical iteration order of :122
-    cands[v] = {idx.at(v)};
-    for (size_t sid : sorted_succ) {
-      const uint32_t      w = order[sid];
-      std::vector<size_t> best;
-      for (auto &p : dg.predecessors(w)) {
-        auto c = cands.find(p.first);
-        if (c != cands.end() && c->second.size() > best.size()) best = c->second;
-      }
-      best.push_back(idx.at(w));
-      cands.emplace(w, std::move(best));
-    }
-    const std::vector<size_t> *best = nullptr;
+    size_t best_len = 0;
+    for (auto &c : cands) best_len = std::max(best_len, c.visited.size());
     for (auto &c : cands)
-      if (!best || c.second.size() > best->size()) best = &c.second;
-    size_t       c     = best->size() - 1;
-    const size_t limit = std::max<size_t>(best->size(), 1) - 1;
-    for (size_t i = 0; i < limit; ++i) {
-      result[dg.get_edge(order[(*best)[i]], order[(*best)[i + 1]]).get()] += c;
-      c -= 1;
-    }
+      if (c.visited.size() == best_len) add_path_weights(dg, ts.order, c.visited, result);
   }
   return result;
 }
 
-std::vector<std::vector<uint32_t>> extract_paths(DiGraph &dg) { // lg.cpp:347-414
-  Tick tick;
-  DiGraph cyc = dg;                                              // shallow: edges are shared
-  {
-    std::vector<DEdgeP> sh;
-    for (auto &e : cyc.edges)
-      if (e.second->shadow) sh.push_back(e.second);
-    for (auto &e : sh) cyc.delete_edge(e);
-  }
-  tick("copy + drop shadow edges");
-  sort_reduction_by_weight(cyc);
-  tick("sortReductionByWeight");
-  const ClusterWeights cw =
-      cyc.vertices.size() < 150000 ? find_cluster_weights(cyc) : find_cluster_weights_heuristic(cyc);
-  tick("findClusterWeights");
-  std::vector<std::vector<uint32_t>> paths;
-  std::unordered_set<uint32_t>       visited;
-  // The reference re-sorts the whole remaining graph topologically and re-runs findConservationPathAlt for every path
-  // it peels off (lg.cpp:371-407), O(paths x (V + E)) on hash maps.  Same loop here on a dense mirror of `cyc` that
-  // only holds vertices which still have an edge: vertices without edges keep their relative place in the stack-based
-  // topological order, can only ever offer a one-vertex path, and a path of >= 2 vertices exists while edges exist,
-  // so dropping them changes neither the path found nor the tie-breaks among the others.
-  struct Arc {
-    uint32_t     to;
-    const DEdge *e;
-  };
-  std::vector<uint32_t>                ids; // local -> global, ascending
-  std::unordered_map<uint32_t, uint32_t> loc;
-  for (uint32_t v : cyc.vertices)
-    if (!cyc.successors(v).empty() || !cyc.predecessors(v).empty()) {
-      loc.emplace(v, static_cast<uint32_t>(ids.size()));
-      ids.push_back(v);
-    }
-  const uint32_t                n = static_cast<uint32_t>(ids.size());
-  std::vector<std::vector<Arc>> succ(n), pred(n); // ascending neighbour (local ids keep the global order)
-  size_t                        n_arcs = 0;
-  for (uint32_t l = 0; l < n; ++l) {
-    for (auto &t : cyc.successors(ids[l])) succ[l].push_back(Arc{loc.at(t.first), t.second.get()});
-    for (auto &t : cyc.predecessors(ids[l])) pred[l].push_back(Arc{loc.at(t.first), t.second.get()});
-    n_arcs += succ[l].size();
-  }
-  std::vector<uint32_t> active(n);
-  for (uint32_t l = 0; l < n; ++l) active[l] = l;
-  std::vector<int64_t>  deg(n);
-  std::vector<uint32_t> order, ready, stamp(n, 0);
-  std::vector<std::pair<uint64_t, std::vector<uint32_t>>> open(n);
-  uint32_t round = 0;
-  while (n_arcs > 0) {
-    // DiGraph::sortTopologically (Graph.cpp:359-395) over the active vertices
-    order.clear();
-    ready.clear();
-    for (uint32_t v : active) {
-      deg[v] = static_cast<int64_t>(pred[v].size());
-      if (!deg[v]) ready.push_back(v);
-    }
-    while (!ready.empty()) {
-      const uint32_t v = ready.back();
-      ready.pop_back();
-      for (const Arc &t : succ[v])
-        if (--deg[t.to] == 0) ready.push_back(t.to);
-      order.push_back(v);
-    }
-    // findConservationPathAlt (lg.cpp:267-344); open[] entries are valid when stamp[] == round
+std::vector<uint64_t> find_cluster_weights_heuristic(const DiG &dg, const std::vector<uint8_t> &alive) { // lg.cpp:72-141
+  const TopoSets                     ts(dg, alive);
+  std::vector<uint64_t>              result(dg.m(), 0);
+  std::vector<uint32_t>              stamp(dg.n, 0), touched;
+  std::vector<std::vector<uint32_t>> cand(dg.n); // candidates[vertex], valid when stamp == round
+  uint32_t                           round = 0;
+  for (uint32_t v : ts.order) {
     ++round;
-    std::vector<uint32_t> final_path;
-    auto has_open = [&](uint32_t v) { return stamp[v] == round; };
-    auto touch    = [&](uint32_t v) -> std::pair<uint64_t, std::vector<uint32_t>> & { // operator[] of the reference
-      if (stamp[v] != round) {
-        stamp[v]      = round;
-        open[v].first = 0;
-        open[v].second.clear();
+    touched.assign(1, v);
+    stamp[v] = round;
+    cand[v].assign(1, ts.idx[v]);
+    for (uint32_t q = ts.soff[v]; q < ts.soff[v + 1]; ++q) {
+      const uint32_t               w = ts.order[ts.sidx[q]];
+      const std::vector<uint32_t> *best = nullptr;
+      for (const Arc *p = dg.pred.begin(w); p != dg.pred.end(w); ++p) // ascending id = the canonical order of :122
+        if (alive[p->e] && stamp[p->to] == round && cand[p->to].size() > (best ? best->size() : 0)) best = &cand[p->to];
+      if (stamp[w] == round) continue; // emplace: an existing entry stays
+      std::vector<uint32_t> np = best ? *best : std::vector<uint32_t>();
+      np.push_back(ts.idx[w]);
+      cand[w]  = std::move(np);
+      stamp[w] = round;
+      touched.push_back(w);
+    }
+    std::sort(touched.begin(), touched.end()); // std::max_element over the map: first longest, ascending id
+    const std::vector<uint32_t> *best = nullptr;
+    for (uint32_t t : touched)
+      if (!best || cand[t].size() > best->size()) best = &cand[t];
+    add_path_weights(dg, ts.order, *best, result);
+  }
+  return result;
+}
+
+// extractPaths (lg.cpp:347-414).  The repeated findConservationPathAlt (lg.cpp:267-344) runs per weakly connected
+// component of the remaining cycle-free graph; see the header of this file for why that gives the same sequence.
+struct PathPeeler {
+  const DiG                   &dg;
+  const std::vector<uint64_t> &cw;
+  std::vector<uint8_t>         alive, valive; // edges / vertices still in diGraphCycle
+  size_t                       n_arcs = 0;
+  // per-solve scratch (round-stamped)
+  std::vector<int64_t>  deg;
+  std::vector<uint32_t> ostamp, olen, seg, lab;
+  std::vector<int32_t>  ohead;
+  std::vector<uint64_t> oscore;
+  uint32_t              round = 0, lab_round = 0;
+  struct Node {
+    uint32_t v;
+    int32_t  parent;
+  };
+  std::vector<Node> nodes;
+  struct Comp {
+    std::vector<uint32_t> members, path; // members ascending
+    uint32_t              segroot = 0;
+  };
+  std::vector<Comp> comps;
+  struct Key {
+    uint32_t size, segroot, comp;
+    bool operator<(const Key &o) const { return size != o.size ? size < o.size : segroot < o.segroot; }
+  };
+  std::priority_queue<Key>      heap;
+  std::priority_queue<uint32_t> iso; // vertices without edges: each is a root and a sink of its own
+
+  PathPeeler(const DiG &d, const std::vector<uint8_t> &a, const std::vector<uint64_t> &w)
+      : dg(d), cw(w), alive(a), valive(d.n, 1), deg(d.n), ostamp(d.n, 0), olen(d.n), seg(d.n), lab(d.n, 0),
+        ohead(d.n), oscore(d.n) {
+    for (uint8_t x : alive) n_arcs += x;
+  }
+
+  bool has_arcs(uint32_t v) const {
+    for (const Arc *t = dg.succ.begin(v); t != dg.succ.end(v); ++t)
+      if (alive[t->e]) return true;
+    for (const Arc *t = dg.pred.begin(v); t != dg.pred.end(v); ++t)
+      if (alive[t->e]) return true;
+    return false;
+  }
+
+  // split `pool` (alive vertices, ascending) into weakly connected components; lone vertices go to `iso`
+  void split(const std::vector<uint32_t> &pool) {
+    ++lab_round;
+    std::vector<uint32_t> members;
+    for (uint32_t s : pool) {
+      if (!valive[s] || lab[s] == lab_round) continue;
+      members.assign(1, s);
+      lab[s] = lab_round;
+      for (size_t h = 0; h < members.size(); ++h) {
+        const uint32_t v = members[h];
+        for (const Csr *c : {&dg.succ, &dg.pred})
+          for (const Arc *t = c->begin(v); t != c->end(v); ++t)
+            if (alive[t->e] && lab[t->to] != lab_round) {
+              lab[t->to] = lab_round;
+              members.push_back(t->to);
+            }
       }
-      return open[v];
+      if (members.size() == 1) {
+        iso.push(s);
+        continue;
+      }
+      std::sort(members.begin(), members.end());
+      Comp c;
+      c.members = members;
+      solve(c);
+      heap.push(Key{static_cast<uint32_t>(c.path.size()), c.segroot, static_cast<uint32_t>(comps.size())});
+      comps.push_back(std::move(c));
+    }
+  }
+
+  int32_t node(uint32_t v, int32_t parent) {
+    nodes.push_back(Node{v, parent});
+    return static_cast<int32_t>(nodes.size() - 1);
+  }
+
+  // sortTopologically + findConservationPathAlt on one component
+  void solve(Comp &c) {
+    ++round;
+    nodes.clear();
+    std::vector<uint32_t> order, stack;
+    order.reserve(c.members.size());
+    for (uint32_t v : c.members) {
+      deg[v] = 0;
+      for (const Arc *t = dg.pred.begin(v); t != dg.pred.end(v); ++t) deg[v] += alive[t->e];
+    }
+    for (size_t i = c.members.size(); i-- > 0;) { // zero-in-degree vertices, highest id first
+      const uint32_t r = c.members[i];
+      bool           is_root = true;
+      for (const Arc *t = dg.pred.begin(r); t != dg.pred.end(r) && is_root; ++t) is_root = !alive[t->e];
+      if (!is_root) continue;
+      stack.assign(1, r);
+      while (!stack.empty()) {
+        const uint32_t v = stack.back();
+        stack.pop_back();
+        seg[v] = r;
+        order.push_back(v);
+        for (const Arc *t = dg.succ.begin(v); t != dg.succ.end(v); ++t)
+          if (alive[t->e] && --deg[t->to] == 0) stack.push_back(t->to);
+      }
+    }
+    auto has_open = [&](uint32_t v) { return ostamp[v] == round; };
+    auto touch    = [&](uint32_t v) { // operator[] of the reference: default-constructs (0, {})
+      if (ostamp[v] != round) {
+        ostamp[v] = round;
+        oscore[v] = 0;
+        olen[v]   = 0;
+        ohead[v]  = -1;
+      }
     };
-    std::vector<std::pair<uint32_t, uint32_t>> max_outs;
+    uint32_t final_len = 0, final_single = NIL, final_seg = 0;
+    int32_t  final_head = -1;
+    std::vector<uint32_t> max_outs;
     for (uint32_t v : order) {
-      if (succ[v].empty()) {
+      uint64_t max_out = 0;
+      max_outs.clear();
+      bool sink = true;
+      for (const Arc *t = dg.succ.begin(v); t != dg.succ.end(v); ++t) {
+        if (!alive[t->e]) continue;
+        sink = false;
+        const uint64_t w = cw[t->e];
+        if (w > max_out) {
+          max_out = w;
+          max_outs.assign(1, t->to);
+        } else if (w == max_out) {
+          max_outs.push_back(t->to);
+        }
+      }
+      if (sink) {
         if (!has_open(v)) {
-          if (final_path.empty()) final_path = {v};
+          if (final_len == 0) {
+            final_len    = 1;
+            final_single = v;
+            final_head   = -1;
+            final_seg    = seg[v];
+          }
         } else {
-          if (open[v].second.size() > final_path.size()) final_path = std::move(open[v].second);
-          open[v].second.clear();
+          if (olen[v] > final_len) {
+            final_len    = olen[v];
+            final_head   = ohead[v];
+            final_single = NIL;
+            final_seg    = seg[v];
+          }
+          olen[v]  = 0;
+          ohead[v] = -1;
         }
         continue;
       }
-      max_outs.clear();
-      uint64_t max_out = 0;
-      for (const Arc &t : succ[v]) {
-        const uint64_t w = cw.at(t.e);
-        if (w > max_out) {
-          max_out = w;
-          max_outs.clear();
-          max_outs.emplace_back(v, t.to);
-        } else if (w == max_out) {
-          max_outs.emplace_back(v, t.to);
-        }
-      }
-      for (auto &edge : max_outs) {
-        const uint32_t nxt = edge.second;
+      for (uint32_t nxt : max_outs) {
         if (has_open(nxt)) {
           bool take;
-          if (open[nxt].first < max_out) take = true;
-          else if (open[nxt].first == max_out) take = open[nxt].second.size() < touch(v).second.size() + 1;
-          else take = false;
+          if (oscore[nxt] < max_out) take = true;
+          else if (oscore[nxt] == max_out) {
+            touch(v);
+            take = olen[nxt] < olen[v] + 1;
+          } else take = false;
           if (take) {
-            std::vector<uint32_t> tmp = touch(v).second;
-            tmp.push_back(nxt);
-            open[nxt] = {max_out, std::move(tmp)};
+            touch(v);
+            ohead[nxt]  = node(nxt, ohead[v]);
+            olen[nxt]   = olen[v] + 1;
+            oscore[nxt] = max_out;
           }
         } else if (has_open(v)) {
-          std::vector<uint32_t> tmp = open[v].second;
-          tmp.push_back(nxt);
-          touch(nxt) = {max_out, std::move(tmp)};
+          touch(nxt);
+          ohead[nxt]  = node(nxt, ohead[v]);
+          olen[nxt]   = olen[v] + 1;
+          oscore[nxt] = max_out;
         } else {
-          touch(nxt) = {max_out, {edge.first, edge.second}};
+          touch(nxt);
+          ohead[nxt]  = node(nxt, node(v, -1));
+          olen[nxt]   = 2;
+          oscore[nxt] = max_out;
         }
       }
-      touch(v).second.clear();
+      touch(v);
+      olen[v]  = 0;
+      ohead[v] = -1;
     }
-    if (final_path.empty()) throw GraphError("extractPaths: empty path");
-    std::vector<uint32_t> longest;
-    for (uint32_t l : final_path) longest.push_back(ids[l]);
+    c.path.clear();
+    c.segroot = final_seg;
+    if (final_single != NIL) {
+      c.path.push_back(final_single);
+    } else {
+      for (int32_t p = final_head; p >= 0; p = nodes[p].parent) c.path.push_back(nodes[p].v);
+      std::reverse(c.path.begin(), c.path.end());
+    }
+    if (c.path.empty()) throw GraphError("extractPaths: empty path");
+  }
+
+  void delete_vertex(uint32_t v) {
+    for (const Csr *c : {&dg.succ, &dg.pred})
+      for (const Arc *t = c->begin(v); t != c->end(v); ++t)
+        if (alive[t->e]) {
+          alive[t->e] = 0;
+          --n_arcs;
+        }
+    valive[v] = 0;
+  }
+};
+
+std::vector<std::vector<uint32_t>> extract_paths(DiG &dg) { // local vertex ids
+  Tick                 tick;
+  std::vector<uint8_t> alive(dg.m());
+  for (size_t e = 0; e < dg.m(); ++e) alive[e] = !dg.shadow[e]; // the copy without its shadow edges (:351-356)
+  tick("copy + drop shadow edges");
+  sort_reduction_by_weight(dg, alive);
+  tick("sortReductionByWeight");
+  const std::vector<uint64_t> cw = dg.n < 150000 ? find_cluster_weights(dg, alive) : find_cluster_weights_heuristic(dg, alive);
+  tick("findClusterWeights");
+  std::vector<std::vector<uint32_t>> paths;
+  std::vector<uint8_t>               visited(dg.n, 0);
+  PathPeeler                         pp(dg, alive, cw);
+  {
+    std::vector<uint32_t> all(dg.n);
+    for (uint32_t v = 0; v < dg.n; ++v) all[v] = v;
+    pp.split(all);
+  }
+  std::vector<uint32_t> longest;
+  while (pp.n_arcs > 0) { // diGraphCycle.getSize() > 0
+    require(!pp.heap.empty(), "extractPaths: edges left but no component");
+    const PathPeeler::Key top = pp.heap.top();
+    bool                  lone = false;
+    if (top.size == 1) { // only then can a vertex without edges come first in the topological order and win
+      while (!pp.iso.empty() && !pp.valive[pp.iso.top()]) pp.iso.pop();
+      lone = !pp.iso.empty() && pp.iso.top() > top.segroot;
+    }
+    std::vector<uint32_t> pool;
+    if (lone) {
+      longest.assign(1, pp.iso.top());
+      pp.iso.pop();
+    } else {
+      pp.heap.pop();
+      longest = pp.comps[top.comp].path;
+      pool.swap(pp.comps[top.comp].members);
+      pp.comps[top.comp].path.clear();
+    }
     if (longest.size() < 10) {
       bool in_visit = false, out_visit = false;
-      for (auto &p : dg.predecessors(longest.front())) in_visit = in_visit || visited.count(p.first);
-      for (auto &q : dg.successors(longest.back())) out_visit = out_visit || visited.count(q.first);
+      for (const Arc *p = dg.pred.begin(longest.front()); p != dg.pred.end(longest.front()); ++p)
+        in_visit = in_visit || visited[p->to];
+      for (const Arc *q = dg.succ.begin(longest.back()); q != dg.succ.end(longest.back()); ++q)
+        out_visit = out_visit || visited[q->to];
       if ((!in_visit && !out_visit) || ((in_visit || out_visit) && longest.size() > 5)) paths.push_back(longest);
     } else {
       paths.push_back(longest);
     }
-    for (uint32_t l : final_path) { // diGraphCycle.deleteVertex
-      visited.insert(ids[l]);
-      for (const Arc &t : succ[l]) {
-        auto &pv = pred[t.to];
-        pv.erase(std::find_if(pv.begin(), pv.end(), [&](const Arc &a) { return a.to == l; }));
-      }
-      for (const Arc &t : pred[l]) {
-        auto &sv = succ[t.to];
-        sv.erase(std::find_if(sv.begin(), sv.end(), [&](const Arc &a) { return a.to == l; }));
-        --n_arcs;
-      }
-      n_arcs -= succ[l].size();
-      succ[l].clear();
-      pred[l].clear();
+    for (uint32_t v : longest) {
+      visited[v] = 1;
+      pp.delete_vertex(v);
     }
-    active.erase(std::remove_if(active.begin(), active.end(),
-                                [&](uint32_t v) { return succ[v].empty() && pred[v].empty(); }),
-                 active.end());
+    pp.split(pool);
   }
-  {
-    std::vector<uint32_t> left;
-    for (uint32_t v : cyc.vertices)
-      if (!visited.count(v)) left.push_back(v);
-    tick("conservation paths loop");
-    for (uint32_t v : left) paths.push_back({v});
-    return paths;
-  }
+  tick("conservation paths loop");
+  for (uint32_t v = 0; v < dg.n; ++v)
+    if (pp.valive[v]) paths.push_back({v});
+  return paths;
 }
 
-std::vector<std::vector<uint32_t>> linearize_graph(DiGraph &dg) { // lg.cpp:522-629
-  std::vector<std::vector<uint32_t>>   paths = extract_paths(dg);
-  std::vector<size_t>                  color_corr(paths.size()), color_len(paths.size());
-  std::unordered_map<uint32_t, size_t> v2idx, v2pos; // v2pos: what std::find returns on the still unjoined paths (:553-556)
+std::vector<std::vector<uint32_t>> linearize_graph(DiG &dg) { // lg.cpp:522-629
+  std::vector<std::vector<uint32_t>> paths = extract_paths(dg);
+  std::vector<size_t>                color_corr(paths.size()), color_len(paths.size());
+  std::vector<uint32_t> v2idx(dg.n, NIL), v2pos(dg.n, 0); // v2pos: what std::find returns on the still unjoined paths
   for (size_t i = 0; i < paths.size(); ++i) {
-    for (size_t k = 0; k < paths[i].size(); ++k) {
-      if (v2idx.emplace(paths[i][k], i).second) v2pos.emplace(paths[i][k], k);
-    }
+    for (size_t k = 0; k < paths[i].size(); ++k)
+      if (v2idx[paths[i][k]] == NIL) {
+        v2idx[paths[i][k]] = static_cast<uint32_t>(i);
+        v2pos[paths[i][k]] = static_cast<uint32_t>(k);
+      }
     color_corr[i] = i;
     color_len[i]  = paths[i].size();
   }
   auto index_in = [](const std::vector<uint32_t> &p, uint32_t v) {
     return static_cast<size_t>(std::find(p.begin(), p.end(), v) - p.begin());
   };
-  std::vector<std::pair<size_t, DEdgeP>> joins;
-  for (auto &kv : dg.edges) {
-    const DEdgeP &e = kv.second;
-    if (!e->shadow) continue;
-    auto i1 = v2idx.find(e->a), i2 = v2idx.find(e->b);
-    if (i1 == v2idx.end() || i2 == v2idx.end()) continue;
-    const size_t s1 = v2pos.at(e->a), s2 = v2pos.at(e->b);
-    const size_t l1_end = color_len[i1->second] - s1 - 1, l2_end = color_len[i2->second] - s2 - 1;
-    if (i1->second != i2->second && l1_end < s1 && s2 < l2_end) joins.emplace_back(l1_end + s2, e);
+  std::vector<std::pair<size_t, uint32_t>> joins;
+  for (size_t e = 0; e < dg.m(); ++e) {
+    if (!dg.shadow[e]) continue;
+    const uint32_t a = dg.ea[e], b = dg.eb[e];
+    if (v2idx[a] == NIL || v2idx[b] == NIL) continue;
+    const size_t i1 = v2idx[a], i2 = v2idx[b], s1 = v2pos[a], s2 = v2pos[b];
+    const size_t l1_end = color_len[i1] - s1 - 1, l2_end = color_len[i2] - s2 - 1;
+    if (i1 != i2 && l1_end < s1 && s2 < l2_end) joins.emplace_back(l1_end + s2, static_cast<uint32_t>(e));
   }
   std::stable_sort(joins.begin(), joins.end(),
-                   [](const std::pair<size_t, DEdgeP> &x, const std::pair<size_t, DEdgeP> &y) { return x.first < y.first; });
+                   [](const std::pair<size_t, uint32_t> &x, const std::pair<size_t, uint32_t> &y) { return x.first < y.first; });
   for (auto &j : joins) {
     const size_t dist = j.first;
     if (dist > 3) break;
@@ -656,9 +901,10 @@ std::vector<std::vector<uint32_t>> linearize_graph(DiGraph &dg) { // lg.cpp:522-
       while (color_corr[i] != i) i = color_corr[i];
       return i;
     };
-    const size_t c1 = color(v2idx.at(j.second->a)), c2 = color(v2idx.at(j.second->b));
+    const uint32_t a = dg.ea[j.second], b = dg.eb[j.second];
+    const size_t   c1 = color(v2idx[a]), c2 = color(v2idx[b]);
     if (c1 == c2) continue;
-    const size_t i1 = index_in(paths[c1], j.second->a), i2 = index_in(paths[c2], j.second->b);
+    const size_t i1 = index_in(paths[c1], a), i2 = index_in(paths[c2], b);
     if (i1 == paths[c1].size() || i2 == paths[c2].size()) continue;
     if (color_len[c1] - i1 - 1 + i2 != dist) continue;
     paths[c1].erase(paths[c1].begin() + static_cast<long>(i1 + 1), paths[c1].end());
@@ -673,255 +919,17 @@ std::vector<std::vector<uint32_t>> linearize_graph(DiGraph &dg) { // lg.cpp:522-
   return paths;
 }
 
-// getDirectedGraph, dg.cpp:35-121; `component` = vertex set of the connected component (its sub-graph keeps every
-// alive edge between those vertices, Graph.cpp:317-326)
-DiGraph get_directed_graph(msgpu_graph &g, const std::set<uint32_t> &component, uint32_t start) {
-  DiGraph                                 dg;
-  std::vector<std::pair<uint32_t, bool>> stack{{start, true}};
-  while (!stack.empty()) {
-    const uint32_t cur    = stack.back().first;
-    const bool     toggle = stack.back().second;
-    stack.pop_back();
-    if (!dg.has_vertex(cur)) dg.add_vertex(cur);
-    if (g.V[cur].direction == D_NONE) g.V[cur].direction = toggle ? D_POS : D_NEG;
-    for (auto &n : g.adj[cur]) {
-      const uint32_t nb = n.first;
-      if (!component.count(nb)) continue;
-      const UEdge &ne           = g.E[n.second];
-      bool         other_exists = dg.has_vertex(nb);
-      if (other_exists) other_exists = g.V[nb].direction != D_NONE;
-      if (!other_exists) dg.add_vertex(nb);
-      if (dg.has_edge(ne.a, ne.b) || dg.has_edge(ne.b, ne.a)) continue;
-      for (uint32_t oi : ne.orders) {
-        const msgpu_order &o    = g.t_orders[oi];
-        bool               flip = false;
-        if (!g.odir(oi) && o.base == nb) flip = !flip;
-        if (!toggle) flip = !flip;
-        const uint32_t s = flip ? o.end : o.start, t = flip ? o.start : o.end;
-        DEdgeP         de = dg.get_edge(s, t);
-        if (!de) {
-          de = dg.add_edge(s, t);
-          if (!de) throw GraphError("getDirectedGraph: order between vertices outside the component");
-          de->shadow = ne.shadow;
-          if (!ne.shadow) de->weight = ne.weight;
-          de->src = n.second;
-        }
-        de->orders.push_back(oi);
-      }
-      if (ne.consensus == D_NONE) continue;
-      const bool nxt = toggle == (ne.consensus == D_POS);
-      if (!other_exists) stack.emplace_back(nb, nxt);
-    }
-  }
-  return dg;
-}
-
-void require(bool ok, const char *what) {
-  if (!ok) throw GraphError(what);
-}
-
-} // namespace
-
-extern "C" {
-
-int msgpu_graph_create(const msgpu_edge *edges, uint64_t n_edges, const msgpu_edgematch *ems, uint64_t n_ems,
-                       const msgpu_order *orders, uint64_t n_orders, const uint32_t *ids, uint64_t n_ids,
-                       const int32_t *read_len, const uint32_t *read_first_line, uint32_t n_reads, msgpu_graph **out) {
-  if (!out || (n_edges && !edges) || (n_ems && !ems) || (n_orders && !orders) || (n_ids && !ids) ||
-      (n_reads && (!read_len || !read_first_line)) || n_edges >= 0xfffffff0ull || n_orders >= 0xfffffff0ull ||
-      n_ids >= 0xfffffff0ull)
-    return MSGPU_E_ARG;
-  *out = nullptr;
-  try {
-    std::unique_ptr<msgpu_graph> g(new msgpu_graph());
-    g->t_edges.assign(edges, edges + n_edges);
-    g->t_ems.assign(ems, ems + n_ems);
-    g->t_orders.assign(orders, orders + n_orders);
-    g->t_ids.assign(ids, ids + n_ids);
-    g->V.resize(n_reads);
-    g->adj.resize(n_reads);
-    for (uint32_t v = 0; v < n_reads; ++v) {
-      g->V[v].length = read_len[v];
-      g->V[v].meta0  = read_first_line[v];
-      g->V[v].alive  = true;
-    }
-    g->E.resize(n_edges);
-    for (uint64_t i = 0; i < n_edges; ++i) {
-      const msgpu_edge &e = edges[i];
-      if (e.v1 >= n_reads || e.v2 >= n_reads || e.v1 == e.v2 || e.order_off + e.order_cnt > n_orders ||
-          e.em_off + e.em_cnt > n_ems)
-        return MSGPU_E_ARG;
-      UEdge &u = g->E[i];
-      u.a      = e.v1;
-      u.b      = e.v2;
-      u.shadow = e.shadow != 0;
-      for (uint32_t k = 0; k < e.order_cnt; ++k) u.orders.push_back(static_cast<uint32_t>(e.order_off + k));
-      if (!g->adj[e.v1].emplace(e.v2, static_cast<uint32_t>(i)).second) return MSGPU_E_ARG; // duplicate edge
-      g->adj[e.v2].emplace(e.v1, static_cast<uint32_t>(i));
-    }
-    for (uint64_t k = 0; k < n_orders; ++k) {
-      const msgpu_order &o = orders[k];
-      if (o.start >= n_reads || o.end >= n_reads || o.base >= n_reads || o.ids_off + o.ids_cnt > n_ids) return MSGPU_E_ARG;
-    }
-    g->stats.n_vertices_in = n_reads;
-    g->stats.n_edges_in    = n_edges;
-    *out                   = g.release();
-  } catch (std::bad_alloc const &) { return MSGPU_E_NOMEM; }
-  return MSGPU_OK;
-}
-
-void        msgpu_graph_free(msgpu_graph *g) { delete g; }
-const char *msgpu_graph_last_error(const msgpu_graph *g) { return g ? g->err : "null graph"; }
-
-// src/main.cpp:194-288 after findContractionEdges
-int msgpu_graph_clean_up(msgpu_graph *g, const int64_t *contraction_order, const msgpu_row *rows, size_t n_rows) {
-  if (!g || (!g->E.empty() && !contraction_order) || (n_rows && !rows)) return MSGPU_E_ARG;
-  if (g->cleaned) return MSGPU_E_STATE;
-  g->err[0] = 0;
-  try {
-    Tick tick;
-    std::vector<uint64_t> has_vm(n_rows); // MatchMap::getVertexMatch(read, anchor) != nullptr: sorted (read, anchor) keys
-    for (size_t i = 0; i < n_rows; ++i) has_vm[i] = (static_cast<uint64_t>(rows[i].read_id) << 32) | rows[i].anchor_id;
-    std::sort(has_vm.begin(), has_vm.end());
-    std::vector<uint32_t> contraction; // order indices, in edge order
-    for (size_t e = 0; e < g->E.size(); ++e) {
-      const int64_t k = contraction_order[e];
-      if (k < 0) continue;
-      if (static_cast<uint64_t>(k) >= g->t_orders.size() || g->t_orders[k].edge_idx != e) return MSGPU_E_ARG;
-      contraction.push_back(static_cast<uint32_t>(k));
-    }
-    g->stats.n_contraction_edges = contraction.size();
-    const uint32_t        nv = static_cast<uint32_t>(g->V.size());
-    std::vector<uint32_t> targets(nv);
-    for (uint32_t v = 0; v < nv; ++v) targets[v] = v; // :194-197
-    for (uint32_t k : contraction) {                  // findContractionTargets, :465-482
-      const msgpu_order &o  = g->t_orders[k];
-      const uint32_t     to = targets[o.end];
-      if (targets[o.start] == o.start || g->V[targets[o.start]].meta0 > g->V[to].meta0) targets[o.start] = to;
-    }
-    std::set<uint32_t> deletable, roots;
-    for (uint32_t k : contraction) { // findDeletableVertices, :484-507
-      const msgpu_order &o = g->t_orders[k];
-      deletable.insert(o.start);
-      roots.insert(targets[o.start]);
-      roots.erase(o.start);
-    }
-    for (uint32_t k : contraction) { // contract, :509-531
-      const msgpu_order &o = g->t_orders[k];
-      if (!roots.count(o.end)) continue;
-      msgpu_graph::Contain c;
-      c.nano      = o.start;
-      c.direction = g->odir(k) ? 1u : 0u;
-      for (uint32_t i = 0; i < o.ids_cnt; ++i) {
-        const uint32_t a = g->t_ids[o.ids_off + i];
-        if (!rows || std::binary_search(has_vm.begin(), has_vm.end(), (static_cast<uint64_t>(o.start) << 32) | a))
-          c.anchors.push_back(a);
-      }
-      g->contain[o.end].push_back(std::move(c));
-      ++g->stats.n_contain_elements;
-    }
-    tick("contraction bookkeeping");
-    for (uint32_t v : deletable) g->delete_vertex(v); // :242-244
-    g->stats.n_deleted_vertices = deletable.size();
-    for (uint32_t e = 0; e < g->E.size(); ++e) { // findDeletableEdges, :534-549 (+ deletion :258-260)
-      UEdge &u = g->E[e];
-      if (!u.alive) continue;
-      std::vector<uint32_t> kept;
-      for (uint32_t oi : u.orders)
-        if (!g->ocont(oi)) kept.push_back(oi);
-      u.orders = std::move(kept);
-      if (u.orders.empty()) g->delete_edge(e);
-    }
-    std::vector<uint32_t> edges; // :264
-    for (uint32_t e = 0; e < g->E.size(); ++e)
-      if (g->E[e].alive) edges.push_back(e);
-    for (uint32_t e : edges) { // computeBitweight, :551-573
-      UEdge &u = g->E[e];
-      if (u.orders.empty()) continue;
-      const bool d0 = g->odir(u.orders[0]);
-      if (u.shadow) {
-        bool other = false;
-        for (uint32_t oi : u.orders) other = other || g->odir(oi) != d0;
-        if (!other) u.consensus = d0 ? D_POS : D_NEG;
-      } else {
-        u.weight    = g->t_orders[u.orders[0]].score;
-        u.consensus = d0 ? D_POS : D_NEG;
-      }
-    }
-    tick("deletions + bitweight");
-    // getMaxSpanTree, mst.cpp:75-111
-    std::vector<uint32_t> cand;
-    for (uint32_t e : edges)
-      if (g->E[e].consensus != D_NONE) cand.push_back(e);
-    std::stable_sort(cand.begin(), cand.end(), [&](uint32_t x, uint32_t y) { return g->E[x].weight > g->E[y].weight; });
-    UnionFind uf(nv);
-    TreeAdj   tree(nv);
-    for (uint32_t e : cand) {
-      const UEdge &u = g->E[e];
-      if (uf.find(u.a) != uf.find(u.b)) {
-        tree[u.a][u.b] = e;
-        tree[u.b][u.a] = e;
-        uf.unify(u.a, u.b);
-      }
-    }
-    tick("span tree");
-    std::set<uint32_t> dele;
-    TreeSearch         search(nv);
-    for (uint32_t e : edges) { // decycle, :575-618
-      const UEdge &u = g->E[e];
-      if (u.consensus == D_NONE || tree[u.a].count(u.b)) continue;
-      const std::vector<uint32_t> path = search.path(tree, u.a, u.b);
-      require(!path.empty(), "decycle: the span tree does not connect the ends of an edge");
-      bool                direction = u.consensus == D_POS;
-      std::vector<double> weights;
-      for (size_t i = 0; i + 1 < path.size(); ++i) {
-        const int64_t pe = g->edge_between(path[i], path[i + 1]);
-        require(pe >= 0, "decycle: tree edge missing from the graph");
-        direction = direction == (g->E[pe].consensus == D_POS);
-        weights.push_back(static_cast<double>(g->E[pe].weight));
-      }
-      if (!direction && !weights.empty()) {
-        const auto   lo = std::min_element(weights.begin(), weights.end());
-        const auto   hi = std::max_element(weights.begin(), weights.end());
-        const double base = static_cast<double>(u.weight);
-        if (*lo < base || (base * BASE_WEIGHT_MULTIPLICATOR >= *lo && *lo < *hi * MAX_WEIGHT_MULTIPLICATOR)) {
-          const size_t i = static_cast<size_t>(lo - weights.begin());
-          dele.insert(static_cast<uint32_t>(g->edge_between(path[i], path[i + 1])));
-        }
-        dele.insert(e);
-      }
-    }
-    tick("decycle");
-    for (uint32_t e : dele) g->delete_edge(e); // :285-287
-    g->stats.n_decycled_edges = dele.size();
-    uint64_t nv_alive = 0, ne_alive = 0;
-    for (auto &v : g->V) nv_alive += v.alive;
-    for (auto &e : g->E) ne_alive += e.alive;
-    g->stats.n_vertices = nv_alive;
-    g->stats.n_edges    = ne_alive;
-    g->cleaned          = true;
-  } catch (std::bad_alloc const &) {
-    return MSGPU_E_NOMEM;
-  } catch (std::exception const &e) { // GraphError and anything a container throws
-    snprintf(g->err, sizeof(g->err), "%s", e.what());
-    return MSGPU_E_LAYOUT;
-  }
-  return MSGPU_OK;
-}
-
-// getConnectedComponents (cc.cpp:33-70) + per component getDirectedGraph + linearizeGraph (src/main.cpp:300-310, 620-661)
-} // extern "C"
-
-namespace {
-
 // one connected component: getDirectedGraph + linearizeGraph + the assemblePath inputs of its paths (main.cpp:620-661)
-std::vector<msgpu_graph::PathStore> component_paths(msgpu_graph *g, const std::vector<uint32_t> &comp) {
-  const std::set<uint32_t> cset(comp.begin(), comp.end());
-  uint32_t                 start = *cset.begin();
-  for (uint32_t v : cset) // std::max_element: the first of the longest, vertices ascending
-    if (g->V[v].length > g->V[start].length) start = v;
-  Tick    tk;
-  DiGraph dg = get_directed_graph(*g, cset, start);
+std::vector<msgpu_graph::PathStore> component_paths(msgpu_graph *g, uint32_t cid, const std::vector<uint32_t> &comp) {
+  uint32_t start = NIL;
+  {
+    std::vector<uint32_t> sorted(comp);
+    std::sort(sorted.begin(), sorted.end());
+    for (uint32_t v : sorted) // std::max_element: the first of the longest, vertices ascending
+      if (start == NIL || g->V[v].len > g->V[start].len) start = v;
+  }
+  Tick tk;
+  DiG  dg = get_directed_graph(*g, cid, comp, start);
   tk("getDirectedGraph");
   const std::vector<std::vector<uint32_t>> lin = linearize_graph(dg);
   tk("linearizeGraph");
@@ -930,18 +938,19 @@ std::vector<msgpu_graph::PathStore> component_paths(msgpu_graph *g, const std::v
     msgpu_graph::PathStore ps;
     ps.order_off.push_back(0);
     ps.em_off.push_back(0);
-    for (uint32_t v : p) {
+    for (uint32_t l : p) {
+      const uint32_t  v = dg.ids[l];
       msgpu_path_read r{};
       r.read_id         = v;
-      r.direction       = g->V[v].direction == D_POS ? 1u : g->V[v].direction == D_NEG ? 0u : 2u;
-      r.nanopore_length = static_cast<uint64_t>(g->V[v].length);
+      r.direction       = g->V[v].dir == D_POS ? 1u : g->V[v].dir == D_NEG ? 0u : 2u;
+      r.nanopore_length = static_cast<uint64_t>(g->V[v].len);
       ps.reads.push_back(r);
     }
     for (size_t i = 0; i + 1 < p.size(); ++i) {
-      const DEdgeP de = dg.get_edge(p[i], p[i + 1]);
-      require(de != nullptr, "path edge missing in the directed graph");
-      for (uint32_t oi : de->orders) {
-        const msgpu_order &o = g->t_orders[oi];
+      const int64_t de = dg.get_edge(p[i], p[i + 1]);
+      require(de >= 0, "path edge missing in the directed graph");
+      for (uint32_t q = dg.ord_off[de]; q < dg.ord_off[de + 1]; ++q) {
+        const msgpu_order &o = g->t_orders[dg.ord[q]];
         msgpu_path_order   po{};
         po.score     = o.score;
         po.base_read = o.base;
@@ -949,7 +958,7 @@ std::vector<msgpu_graph::PathStore> component_paths(msgpu_graph *g, const std::v
         po.ids_cnt   = o.ids_cnt;
         ps.orders.push_back(po);
       }
-      const msgpu_edge &te = g->t_edges[de->src];
+      const msgpu_edge &te = g->t_edges[dg.src[de]];
       for (uint32_t k = 0; k < te.em_cnt; ++k) {
         const msgpu_edgematch &m = g->t_ems[te.em_off + k];
         ps.ems.push_back(msgpu_path_em{m.anchor_id, m.ov_lo, m.ov_hi});
@@ -957,8 +966,9 @@ std::vector<msgpu_graph::PathStore> component_paths(msgpu_graph *g, const std::v
       ps.order_off.push_back(static_cast<uint32_t>(ps.orders.size()));
       ps.em_off.push_back(static_cast<uint32_t>(ps.ems.size()));
     }
-    for (uint32_t v : p) {
-      auto c = g->contain.find(v);
+    for (uint32_t l : p) {
+      const uint32_t v = dg.ids[l];
+      auto           c = g->contain.find(v);
       if (c == g->contain.end()) continue;
       for (const msgpu_graph::Contain &ce : c->second) {
         msgpu_path_contain pc{};
@@ -980,6 +990,250 @@ std::vector<msgpu_graph::PathStore> component_paths(msgpu_graph *g, const std::v
 
 extern "C" {
 
+int msgpu_graph_create(const msgpu_edge *edges, uint64_t n_edges, const msgpu_edgematch *ems, uint64_t n_ems,
+                       const msgpu_order *orders, uint64_t n_orders, const uint32_t *ids, uint64_t n_ids,
+                       const int32_t *read_len, const uint32_t *read_first_line, uint32_t n_reads, msgpu_graph **out) {
+  if (!out || (n_edges && !edges) || (n_ems && !ems) || (n_orders && !orders) || (n_ids && !ids) ||
+      (n_reads && (!read_len || !read_first_line)) || n_edges >= 0x7ffffff0ull || n_orders >= 0xfffffff0ull ||
+      n_ids >= 0xfffffff0ull)
+    return MSGPU_E_ARG;
+  *out = nullptr;
+  try {
+    Tick                         tick;
+    std::unique_ptr<msgpu_graph> g(new msgpu_graph());
+    g->t_edges  = edges;
+    g->t_ems    = ems;
+    g->t_orders = orders;
+    g->t_ids    = ids;
+    g->n_edges  = n_edges;
+    g->n_ems    = n_ems;
+    g->n_orders = n_orders;
+    g->n_ids    = n_ids;
+    g->nv       = n_reads;
+    g->V.resize(n_reads);
+    for (uint32_t v = 0; v < n_reads; ++v) {
+      g->V[v].len   = read_len[v];
+      g->V[v].meta0 = read_first_line[v];
+    }
+    g->E.resize(n_edges);
+    g->o_kept.assign(n_orders, 0);
+    for (uint64_t i = 0; i < n_edges; ++i) {
+      const msgpu_edge &e = edges[i];
+      if (e.v1 >= n_reads || e.v2 >= n_reads || e.v1 == e.v2 || e.order_off + e.order_cnt > n_orders ||
+          e.em_off + e.em_cnt > n_ems)
+        return MSGPU_E_ARG;
+      msgpu_graph::Edge &u = g->E[i];
+      u.a       = e.v1;
+      u.b       = e.v2;
+      u.shadow  = e.shadow != 0;
+      u.ord_lo  = static_cast<uint32_t>(e.order_off);
+      u.ord_cnt = e.order_cnt;
+      for (uint32_t k = 0; k < e.order_cnt; ++k) {
+        if (g->o_kept[e.order_off + k]) return MSGPU_E_ARG; // an order on two edges
+        g->o_kept[e.order_off + k] = 1;
+      }
+      if (e.order_cnt) u.first = u.ord_lo;
+    }
+    for (uint64_t k = 0; k < n_orders; ++k) {
+      const msgpu_order &o = orders[k];
+      if (o.start >= n_reads || o.end >= n_reads || o.base >= n_reads || o.ids_off + o.ids_cnt > n_ids) return MSGPU_E_ARG;
+    }
+    {
+      std::vector<uint32_t> ea(n_edges), eb(n_edges);
+      for (uint64_t i = 0; i < n_edges; ++i) {
+        ea[i] = edges[i].v1;
+        eb[i] = edges[i].v2;
+      }
+      g->adj = build_csr(n_reads, ea.data(), eb.data(), n_edges, true);
+    }
+    for (uint32_t v = 0; v < n_reads; ++v) // duplicate edge
+      for (const Arc *t = g->adj.begin(v); t + 1 < g->adj.end(v); ++t)
+        if (t->to == (t + 1)->to) return MSGPU_E_ARG;
+    g->stats.n_vertices_in = n_reads;
+    g->stats.n_edges_in    = n_edges;
+    tick("graph create");
+    *out = g.release();
+  } catch (std::bad_alloc const &) { return MSGPU_E_NOMEM; }
+  return MSGPU_OK;
+}
+
+void        msgpu_graph_free(msgpu_graph *g) { delete g; }
+const char *msgpu_graph_last_error(const msgpu_graph *g) { return g ? g->err : "null graph"; }
+
+// src/main.cpp:194-288 after findContractionEdges
+int msgpu_graph_clean_up(msgpu_graph *g, const int64_t *contraction_order, const msgpu_row *rows, size_t n_rows) {
+  if (!g || (g->n_edges && !contraction_order) || (n_rows && !rows)) return MSGPU_E_ARG;
+  if (g->cleaned) return MSGPU_E_STATE;
+  g->err[0] = 0;
+  try {
+    Tick                  tick;
+    const uint32_t        nv = g->nv;
+    const size_t          ne = g->n_edges;
+    std::vector<uint32_t> contraction; // order indices, in edge order
+    for (size_t e = 0; e < ne; ++e) {
+      const int64_t k = contraction_order[e];
+      if (k < 0) continue;
+      if (static_cast<uint64_t>(k) >= g->n_orders || g->t_orders[k].edge_idx != e) return MSGPU_E_ARG;
+      contraction.push_back(static_cast<uint32_t>(k));
+    }
+    g->stats.n_contraction_edges = contraction.size();
+    std::vector<uint64_t> has_vm; // MatchMap::getVertexMatch(read, anchor) != nullptr: sorted (read, anchor) keys
+    if (!contraction.empty() && rows) {
+      has_vm.resize(n_rows);
+      for (size_t i = 0; i < n_rows; ++i) has_vm[i] = (static_cast<uint64_t>(rows[i].read_id) << 32) | rows[i].anchor_id;
+      std::sort(has_vm.begin(), has_vm.end());
+    }
+    std::vector<uint32_t> targets(nv);
+    for (uint32_t v = 0; v < nv; ++v) targets[v] = v; // :194-197
+    for (uint32_t k : contraction) {                  // findContractionTargets, :465-482
+      const msgpu_order &o  = g->t_orders[k];
+      const uint32_t     to = targets[o.end];
+      if (targets[o.start] == o.start || g->V[targets[o.start]].meta0 > g->V[to].meta0) targets[o.start] = to;
+    }
+    std::vector<uint8_t> deletable(nv, 0), roots(nv, 0);
+    for (uint32_t k : contraction) { // findDeletableVertices, :484-507
+      const msgpu_order &o = g->t_orders[k];
+      deletable[o.start]      = 1;
+      roots[targets[o.start]] = 1;
+      roots[o.start]          = 0;
+    }
+    for (uint32_t k : contraction) { // contract, :509-531
+      const msgpu_order &o = g->t_orders[k];
+      if (!roots[o.end]) continue;
+      msgpu_graph::Contain c;
+      c.nano      = o.start;
+      c.direction = g->odir(k) ? 1u : 0u;
+      for (uint32_t i = 0; i < o.ids_cnt; ++i) {
+        const uint32_t a = g->t_ids[o.ids_off + i];
+        if (!rows || std::binary_search(has_vm.begin(), has_vm.end(), (static_cast<uint64_t>(o.start) << 32) | a))
+          c.anchors.push_back(a);
+      }
+      g->contain[o.end].push_back(std::move(c));
+      ++g->stats.n_contain_elements;
+    }
+    tick("contraction bookkeeping");
+    for (uint32_t v = 0; v < nv; ++v) // :242-244
+      if (deletable[v]) {
+        g->delete_vertex(v);
+        ++g->stats.n_deleted_vertices;
+      }
+    for (size_t e = 0; e < ne; ++e) { // findDeletableEdges, :534-549 (+ deletion :258-260)
+      if (!g->E[e].alive) continue;
+      const uint32_t lo = g->E[e].ord_lo, hi = lo + g->E[e].ord_cnt;
+      uint32_t       first = NIL;
+      for (uint32_t oi = lo; oi < hi; ++oi) {
+        if (g->ocont(oi)) g->o_kept[oi] = 0;
+        else if (first == NIL) first = oi;
+      }
+      g->E[e].first = first;
+      if (first == NIL) g->delete_edge(static_cast<uint32_t>(e));
+    }
+    std::vector<uint32_t> cand; // alive edges with a consensus direction, in edge order (:264, mst.cpp:79-86)
+    for (size_t e = 0; e < ne; ++e) { // computeBitweight, :551-573
+      if (!g->E[e].alive || g->E[e].first == NIL) continue;
+      const uint32_t lo = g->E[e].first, hi = g->E[e].ord_lo + g->E[e].ord_cnt;
+      const bool     d0 = g->odir(lo);
+      if (g->E[e].shadow) {
+        bool other = false;
+        for (uint32_t oi = lo; oi < hi; ++oi) other = other || (g->o_kept[oi] && g->odir(oi) != d0);
+        if (!other) g->E[e].cons = d0 ? D_POS : D_NEG;
+      } else {
+        g->E[e].weight = g->t_orders[lo].score;
+        g->E[e].cons   = d0 ? D_POS : D_NEG;
+      }
+      if (g->E[e].cons != D_NONE) cand.push_back(static_cast<uint32_t>(e));
+    }
+    tick("deletions + bitweight");
+    std::vector<uint8_t> in_tree(ne, 0); // getMaxSpanTree, mst.cpp:75-111
+    max_span_tree(
+        nv, [&](uint32_t e) { return std::make_pair(g->E[e].a, g->E[e].b); }, [&](uint32_t e) { return g->E[e].weight; }, cand,
+        in_tree);
+    tick("span tree");
+    // the span forest, rooted: parent / edge to parent / depth / number of e_NEG edges to the root (mod 2)
+    std::vector<uint32_t> parent(nv, NIL), pedge(nv, NIL), depth(nv, 0);
+    std::vector<uint8_t>  negpar(nv, 0);
+    {
+      std::vector<uint32_t> queue;
+      for (uint32_t r = 0; r < nv; ++r) {
+        if (parent[r] != NIL) continue;
+        parent[r] = r;
+        queue.assign(1, r);
+        for (size_t h = 0; h < queue.size(); ++h) {
+          const uint32_t v = queue[h];
+          for (const Arc *t = g->adj.begin(v); t != g->adj.end(v); ++t)
+            if (in_tree[t->e] && parent[t->to] == NIL) {
+              parent[t->to] = v;
+              pedge[t->to]  = t->e;
+              depth[t->to]  = depth[v] + 1;
+              negpar[t->to] = negpar[v] ^ (g->E[t->e].cons == D_NEG);
+              queue.push_back(t->to);
+            }
+        }
+      }
+    }
+    std::vector<uint8_t>  dele(ne, 0);
+    std::vector<uint32_t> left, right;
+    for (uint32_t e : cand) { // decycle, :575-618
+      if (in_tree[e]) continue;
+      const uint32_t a = g->E[e].a, b = g->E[e].b;
+      // direction folded over the tree path a..b (:590-603): XNOR chain = parity of the e_NEG edges on it
+      const bool direction = !((g->E[e].cons == D_NEG) ^ negpar[a] ^ negpar[b]);
+      if (direction) continue;
+      left.clear();
+      right.clear();
+      uint32_t ua = a, ub = b;
+      while (depth[ua] > depth[ub]) {
+        left.push_back(pedge[ua]);
+        ua = parent[ua];
+      }
+      while (depth[ub] > depth[ua]) {
+        right.push_back(pedge[ub]);
+        ub = parent[ub];
+      }
+      while (ua != ub) {
+        require(parent[ua] != ua && parent[ub] != ub, "decycle: the span tree does not connect the ends of an edge");
+        left.push_back(pedge[ua]);
+        ua = parent[ua];
+        right.push_back(pedge[ub]);
+        ub = parent[ub];
+      }
+      left.insert(left.end(), right.rbegin(), right.rend()); // tree edges in path order a -> b
+      if (left.empty()) continue;
+      size_t lo = 0;
+      double wlo = static_cast<double>(g->E[left[0]].weight), whi = wlo;
+      for (size_t i = 1; i < left.size(); ++i) {
+        const double w = static_cast<double>(g->E[left[i]].weight);
+        if (w < wlo) { // std::min_element: the first minimum
+          wlo = w;
+          lo  = i;
+        }
+        if (w > whi) whi = w;
+      }
+      const double base = static_cast<double>(g->E[e].weight);
+      if (wlo < base || (base * BASE_WEIGHT_MULTIPLICATOR >= wlo && wlo < whi * MAX_WEIGHT_MULTIPLICATOR)) dele[left[lo]] = 1;
+      dele[e] = 1;
+    }
+    tick("decycle");
+    for (size_t e = 0; e < ne; ++e) // :285-287
+      if (dele[e]) {
+        g->delete_edge(static_cast<uint32_t>(e));
+        ++g->stats.n_decycled_edges;
+      }
+    uint64_t nv_alive = 0, ne_alive = 0;
+    for (auto &x : g->V) nv_alive += x.alive;
+    for (auto &x : g->E) ne_alive += x.alive;
+    g->stats.n_vertices = nv_alive;
+    g->stats.n_edges    = ne_alive;
+    g->cleaned          = true;
+  } catch (std::bad_alloc const &) {
+    return MSGPU_E_NOMEM;
+  } catch (std::exception const &e) { // GraphError and anything a container throws
+    snprintf(g->err, sizeof(g->err), "%s", e.what());
+    return MSGPU_E_LAYOUT;
+  }
+  return MSGPU_OK;
+}
+
 // host threads for the per-component work of msgpu_graph_linearize (default 1; the reference runs one assemblePaths job
 // per component on its ThreadPool, src/main.cpp:300-310)
 int msgpu_graph_set_threads(msgpu_graph *g, uint32_t n_threads) {
@@ -988,35 +1242,21 @@ int msgpu_graph_set_threads(msgpu_graph *g, uint32_t n_threads) {
   return MSGPU_OK;
 }
 
+// getConnectedComponents (cc.cpp:33-70) + per component getDirectedGraph + linearizeGraph (src/main.cpp:300-310, 620-661)
 int msgpu_graph_linearize(msgpu_graph *g) {
   if (!g) return MSGPU_E_ARG;
   if (!g->cleaned || g->linearized) return MSGPU_E_STATE;
   g->err[0] = 0;
   try {
-    // getConnectedComponents, cc.cpp:33-70
-    const uint32_t                     nv = static_cast<uint32_t>(g->V.size());
-    std::vector<bool>                  visited(nv, false);
-    std::vector<std::vector<uint32_t>> comps;
-    for (uint32_t s = 0; s < nv; ++s) {
-      if (!g->V[s].alive || visited[s]) continue;
-      std::vector<uint32_t> comp{s};
-      std::deque<uint32_t>  queue{s};
-      visited[s] = true;
-      while (!queue.empty()) {
-        const uint32_t cur = queue.front();
-        queue.pop_front();
-        for (auto &n : g->adj[cur])
-          if (!visited[n.first] && g->E[n.second].consensus != D_NONE) {
-            comp.push_back(n.first);
-            queue.push_back(n.first);
-            visited[n.first] = true;
-          }
-      }
-      comps.push_back(std::move(comp));
-    }
+    Tick tick;
+    const std::vector<std::vector<uint32_t>> comps = connected_components(
+        g->nv, g->adj, [&](uint32_t v) { return g->V[v].alive != 0; },
+        [&](uint32_t e) { return g->E[e].alive && g->E[e].cons != D_NONE; }, [&](uint32_t v) { return g->V[v].comp; },
+        [&](uint32_t v, uint32_t c) { g->V[v].comp = c; });
     g->stats.n_components = comps.size();
-    // Components are independent (a component only orients and reads its own vertices): largest first on the worker
-    // threads, results appended in component order -- the order a single-threaded reference run assembles them in.
+    tick("components");
+    // Components are independent (a component only orients and reads its own vertices and edges): largest first on the
+    // worker threads, results appended in component order -- the order a single-threaded reference run assembles them in.
     std::vector<std::vector<msgpu_graph::PathStore>> per(comps.size());
     std::vector<std::string>                         errs(comps.size());
     std::vector<int>                                 rcs(comps.size(), MSGPU_OK);
@@ -1028,7 +1268,7 @@ int msgpu_graph_linearize(msgpu_graph *g) {
       for (size_t k = next.fetch_add(1); k < by_size.size(); k = next.fetch_add(1)) {
         const size_t i = by_size[k];
         try {
-          per[i] = component_paths(g, comps[i]);
+          per[i] = component_paths(g, static_cast<uint32_t>(i), comps[i]);
         } catch (std::bad_alloc const &) { rcs[i] = MSGPU_E_NOMEM; } catch (std::exception const &e) {
           rcs[i]  = MSGPU_E_LAYOUT;
           errs[i] = e.what();
@@ -1081,7 +1321,7 @@ int msgpu_graph_path_input(const msgpu_graph *g, uint32_t i, msgpu_path_input *o
   out->asm_idx         = static_cast<int32_t>(i);
   out->order_off       = p.order_off.data();
   out->orders          = p.orders.data();
-  out->ids             = g->t_ids.data();
+  out->ids             = g->t_ids;
   out->em_off          = p.em_off.data();
   out->ems             = p.ems.data();
   out->contains        = p.contains.data();
@@ -1095,15 +1335,87 @@ int msgpu_graph_path_input(const msgpu_graph *g, uint32_t i, msgpu_path_input *o
 int msgpu_graph_state(const msgpu_graph *g, uint8_t *vertex_alive, uint8_t *vertex_direction, uint8_t *edge_alive,
                       uint8_t *edge_consensus, uint64_t *edge_weight) {
   if (!g) return MSGPU_E_ARG;
-  for (size_t v = 0; v < g->V.size(); ++v) {
+  for (size_t v = 0; v < g->nv; ++v) {
     if (vertex_alive) vertex_alive[v] = g->V[v].alive;
-    if (vertex_direction) vertex_direction[v] = g->V[v].direction == D_POS ? 1 : g->V[v].direction == D_NEG ? 0 : 2;
+    if (vertex_direction) vertex_direction[v] = g->V[v].dir == D_POS ? 1 : g->V[v].dir == D_NEG ? 0 : 2;
   }
-  for (size_t e = 0; e < g->E.size(); ++e) {
+  for (size_t e = 0; e < g->n_edges; ++e) {
     if (edge_alive) edge_alive[e] = g->E[e].alive;
-    if (edge_consensus) edge_consensus[e] = g->E[e].consensus == D_POS ? 1 : g->E[e].consensus == D_NEG ? 0 : 2;
+    if (edge_consensus) edge_consensus[e] = g->E[e].cons == D_POS ? 1 : g->E[e].cons == D_NEG ? 0 : 2;
     if (edge_weight) edge_weight[e] = g->E[e].weight;
   }
+  return MSGPU_OK;
+}
+
+// ---- the graph primitives of the stage on caller-supplied graphs ---------------------------------------------------------
+// Same code as above (max_span_tree, connected_components, shortest_path, sort_topologically); exposed so that the vectors
+// the reference's own unit tests hold for them (libms/tests/MST_test.cpp, CC_test.cpp, Graph_test.cpp) can be replayed
+// through the C-ABI.  consensus: 1 e_POS, 0 e_NEG, 2 e_NONE.
+
+static bool edges_ok(uint32_t n, const uint32_t *a, const uint32_t *b, uint64_t m) {
+  if (m && (!a || !b)) return false;
+  if (m >= 0x7ffffff0ull) return false;
+  for (uint64_t i = 0; i < m; ++i)
+    if (a[i] >= n || b[i] >= n) return false;
+  return true;
+}
+
+int msgpu_graph_max_span_tree(uint32_t n_vertices, const uint32_t *a, const uint32_t *b, const uint64_t *weight,
+                              const uint8_t *consensus, uint64_t n_edges, uint8_t *in_tree) {
+  if (!edges_ok(n_vertices, a, b, n_edges) || (n_edges && (!weight || !consensus || !in_tree))) return MSGPU_E_ARG;
+  try {
+    std::vector<uint32_t> cand;
+    for (uint64_t e = 0; e < n_edges; ++e)
+      if (consensus[e] != 2) cand.push_back(static_cast<uint32_t>(e));
+    std::vector<uint8_t> t(n_edges, 0);
+    max_span_tree(
+        n_vertices, [&](uint32_t e) { return std::make_pair(a[e], b[e]); }, [&](uint32_t e) { return weight[e]; }, cand, t);
+    std::copy(t.begin(), t.end(), in_tree);
+  } catch (std::bad_alloc const &) { return MSGPU_E_NOMEM; }
+  return MSGPU_OK;
+}
+
+int msgpu_graph_connected_components(uint32_t n_vertices, const uint32_t *a, const uint32_t *b, const uint8_t *consensus,
+                                     uint64_t n_edges, uint32_t *component, uint32_t *n_components) {
+  if (!edges_ok(n_vertices, a, b, n_edges) || (n_edges && !consensus) || (n_vertices && !component) || !n_components)
+    return MSGPU_E_ARG;
+  try {
+    const Csr           adj = build_csr(n_vertices, a, b, n_edges, true);
+    std::vector<uint32_t> comp(n_vertices, NIL);
+    const auto            comps = connected_components(
+        n_vertices, adj, [](uint32_t) { return true; }, [&](uint32_t e) { return consensus[e] != 2; },
+        [&](uint32_t v) { return comp[v]; }, [&](uint32_t v, uint32_t c) { comp[v] = c; });
+    std::copy(comp.begin(), comp.end(), component);
+    *n_components = static_cast<uint32_t>(comps.size());
+  } catch (std::bad_alloc const &) { return MSGPU_E_NOMEM; }
+  return MSGPU_OK;
+}
+
+int msgpu_graph_shortest_path(uint32_t n_vertices, const uint32_t *a, const uint32_t *b, uint64_t n_edges, int directed,
+                              uint32_t src, uint32_t dst, uint32_t *path, uint32_t *n_path) {
+  if (!edges_ok(n_vertices, a, b, n_edges) || src >= n_vertices || dst >= n_vertices || !n_path || (*n_path && !path))
+    return MSGPU_E_ARG;
+  try {
+    const Csr                   adj = build_csr(n_vertices, a, b, n_edges, !directed);
+    const std::vector<uint32_t> p   = shortest_path(adj, nullptr, n_vertices, src, dst);
+    const uint32_t              cap = *n_path;
+    *n_path                         = static_cast<uint32_t>(p.size());
+    if (p.size() > cap) return MSGPU_E_ARG;
+    std::copy(p.begin(), p.end(), path);
+  } catch (std::bad_alloc const &) { return MSGPU_E_NOMEM; }
+  return MSGPU_OK;
+}
+
+int msgpu_graph_sort_topologically(uint32_t n_vertices, const uint32_t *a, const uint32_t *b, uint64_t n_edges,
+                                   uint32_t *order, uint32_t *n_order) {
+  if (!edges_ok(n_vertices, a, b, n_edges) || (n_vertices && !order) || !n_order) return MSGPU_E_ARG;
+  try {
+    const Csr                   succ = build_csr(n_vertices, a, b, n_edges, false);
+    const Csr                   pred = build_csr(n_vertices, b, a, n_edges, false);
+    const std::vector<uint32_t> o    = sort_topologically(n_vertices, succ, pred, nullptr, nullptr);
+    std::copy(o.begin(), o.end(), order);
+    *n_order = static_cast<uint32_t>(o.size());
+  } catch (std::bad_alloc const &) { return MSGPU_E_NOMEM; }
   return MSGPU_OK;
 }
 

@@ -26,6 +26,7 @@ class GraphStage:
         rl = np.ascontiguousarray(read_len, dtype="<i4")
         fl = np.ascontiguousarray(read_first_line, dtype="<u4")
         self.n_edges, self.n_reads = len(e), len(rl)
+        self._tables = (e, m, o, i)  # msgpu_graph_create borrows the tables: they live as long as this object
 
         def ptr(a):
             return a.ctypes.data if len(a) else None
