@@ -182,6 +182,22 @@ uint32_t    msgpu_paf_anchor_count(const msgpu_paf *paf);
 const char *msgpu_paf_read_name(const msgpu_paf *paf, uint32_t read_id);     /* Registry reverse lookup */
 const char *msgpu_paf_anchor_name(const msgpu_paf *paf, uint32_t anchor_id);
 
+/* Host utilities of libms that the loader is made of, on their own (the reference's unit tests hold vectors for them:
+ * libms/tests/IO_test.cpp:12-35, Registry_test.cpp:5-14, Toggle_test.cpp:5-25; replayed from tests/golden/ref_tests/).
+ * msgpu_index_lines: the line index of BlastFileAccessor::_buildIndex (BlastFileAccessor.cpp:77-91) over readline
+ * (IO.cpp:54-97): every '\n' ends a line and belongs to it, a non-empty tail without '\n' is a line.  offsets (capacity
+ * entries, may be NULL with capacity 0 to count) receives the start of every line and, if it fits, the file size after
+ * the last one.  msgpu_registry_*: Registry (Registry.cpp:36-52), dense ids in first-seen order; clear() restarts at 0.
+ * msgpu_toggle_mul: Toggle::operator* (Toggle.h:127-153) = XNOR. */
+int msgpu_index_lines(const char *path, uint64_t *offsets, size_t capacity, size_t *n_lines);
+typedef struct msgpu_registry msgpu_registry;
+msgpu_registry *msgpu_registry_new(void);
+void     msgpu_registry_free(msgpu_registry *r);
+uint32_t msgpu_registry_id(msgpu_registry *r, const char *name); /* operator[]; 0xffffffff on error */
+uint32_t msgpu_registry_size(const msgpu_registry *r);
+void     msgpu_registry_clear(msgpu_registry *r);
+int      msgpu_toggle_mul(int a, int b);
+
 /* ---- A1 tail: fill the device-resident MatchMap/Graph-vertex equivalent ---------------------------------------- */
 
 /* Replaces the effect of BlastFileReader::read() on Graph (addVertex: first line wins, Graph.cpp:148) and

@@ -180,6 +180,13 @@ SYMBOLS = [
                                             C.c_uint32, C.c_void_p, C.POINTER(C.c_uint32)]),
     ("msgpu_graph_sort_topologically", C.c_int, [C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p,
                                                  C.POINTER(C.c_uint32)]),
+    ("msgpu_index_lines", C.c_int, [C.c_char_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
+    ("msgpu_registry_new", C.c_void_p, []),
+    ("msgpu_registry_free", None, [C.c_void_p]),
+    ("msgpu_registry_id", C.c_uint32, [C.c_void_p, C.c_char_p]),
+    ("msgpu_registry_size", C.c_uint32, [C.c_void_p]),
+    ("msgpu_registry_clear", None, [C.c_void_p]),
+    ("msgpu_toggle_mul", C.c_int, [C.c_int, C.c_int]),
     ("msgpu_gather_plan_create", C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     ("msgpu_gather_plan_free", None, [C.c_void_p]),
     ("msgpu_gather_plan_out_bytes", C.c_uint64, [C.c_void_p]),

@@ -27,6 +27,8 @@ struct msgpu_assembly {
 };
 
 namespace msgpu {
+// Toggle::operator* (include/ms/types/Toggle.h:127-153): the product of two toggles is their XNOR
+inline bool toggle_mul(bool a, bool b) { return a == b; }
 // header lines of the FASTA records, reference spelling (ap.cpp:1035-1040, 1059-1066, 1118-1125, 1175-1182, 1309-1318)
 std::string target_header(int32_t asm_idx);
 std::string query_header(uint32_t kind, int32_t asm_idx, uint32_t query_idx);

@@ -757,7 +757,7 @@ PathResult layout_path(const msgpu_assembly *a, const msgpu_path_input &in) {
       }
       if (cinfo.empty()) continue;
       std::sort(cinfo.begin(), cinfo.end());
-      const bool direction = (ce.direction != 0) == pos; // Toggle * bool = XNOR
+      const bool direction = msgpu::toggle_mul(ce.direction != 0, pos);
       if (!direction) std::reverse(cinfo.begin(), cinfo.end());
       std::vector<std::pair<int, int>> ranges;
       for (const auto &ci2 : cinfo) {

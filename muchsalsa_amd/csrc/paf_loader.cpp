@@ -27,6 +27,7 @@
 #include <thread>
 #include <vector>
 
+#include "asm_internal.h"
 #include "msgpu.h"
 
 namespace {
@@ -62,6 +63,10 @@ public:
   }
   uint32_t operator[](std::string_view name) { return get(name.data(), name.size(), name_hash(name.data(), name.size())); }
   uint32_t    size() const { return static_cast<uint32_t>(m_names.size()); }
+  void        clear() { // Registry::clear (Registry.cpp:47-52): numbering starts again at 0
+    m_names.clear();
+    m_slots.assign(1024, Slot{});
+  }
   const char *name(uint32_t id) const { return id < m_names.size() ? m_names[id]->c_str() : nullptr; }
 
 private:
@@ -196,9 +201,13 @@ void parse_chunk(Chunk &ch, size_t last_line, const msgpu_params &p) {
   }
 }
 
-size_t count_lines(const char *b, const char *e) {
+// The line structure of a text (BlastFileAccessor::_buildIndex over readline, BlastFileAccessor.cpp:77-91, IO.cpp:54-97):
+// every '\n' ends a line and stays part of it; a non-empty tail without '\n' is a line too.  starts (optional) receives
+// the offset of every line relative to `base`.
+size_t count_lines(const char *b, const char *e, const char *base = nullptr, uint64_t *starts = nullptr, size_t cap = 0) {
   size_t n = 0;
   for (const char *q = b; q < e;) {
+    if (starts && n < cap) starts[n] = static_cast<uint64_t>(q - base);
     ++n;
     const void *nl = memchr(q, '\n', static_cast<size_t>(e - q));
     q              = nl ? static_cast<const char *>(nl) + 1 : e;
@@ -345,5 +354,62 @@ uint32_t    msgpu_paf_read_count(const msgpu_paf *paf) { return paf ? paf->reads
 uint32_t    msgpu_paf_anchor_count(const msgpu_paf *paf) { return paf ? paf->anchors.size() : 0; }
 const char *msgpu_paf_read_name(const msgpu_paf *paf, uint32_t id) { return paf ? paf->reads.name(id) : nullptr; }
 const char *msgpu_paf_anchor_name(const msgpu_paf *paf, uint32_t id) { return paf ? paf->anchors.name(id) : nullptr; }
+
+
+/* ---- host utilities of libms the path relies on, at the boundary (vectors of the reference's unit tests) ------------ */
+
+/* BlastFileAccessor::_buildIndex (BlastFileAccessor.cpp:77-91) over readline (IO.cpp:54-97): the line starts of a file,
+ * by the same routine msgpu_parse_paf counts its lines with. */
+int msgpu_index_lines(const char *path, uint64_t *offsets, size_t capacity, size_t *n_lines) {
+  if (!path || !n_lines || (capacity && !offsets)) return MSGPU_E_ARG;
+  int fd = open(path, O_RDONLY | O_CLOEXEC);
+  if (fd < 0) return MSGPU_E_IO;
+  struct stat st;
+  if (fstat(fd, &st) != 0) {
+    close(fd);
+    return MSGPU_E_IO;
+  }
+  const size_t len  = static_cast<size_t>(st.st_size);
+  const char  *data = nullptr;
+  if (len) {
+    void *m = mmap(nullptr, len, PROT_READ, MAP_PRIVATE, fd, 0);
+    if (m == MAP_FAILED) {
+      close(fd);
+      return MSGPU_E_IO;
+    }
+    data = static_cast<const char *>(m);
+  }
+  close(fd);
+  const size_t n = count_lines(data, data + len, data, offsets, capacity);
+  if (offsets && n < capacity) offsets[n] = len; // end of the last line
+  *n_lines = n;
+  if (data) munmap(const_cast<char *>(data), len);
+  return MSGPU_OK;
+}
+
+struct msgpu_registry {
+  NameRegistry r;
+};
+
+msgpu_registry *msgpu_registry_new(void) {
+  try {
+    return new msgpu_registry();
+  } catch (std::bad_alloc const &) { return nullptr; }
+}
+void msgpu_registry_free(msgpu_registry *r) { delete r; }
+/* Registry::operator[] (Registry.cpp:36-45): the id of `name`, the next free id when it is new; 0xffffffff on error */
+uint32_t msgpu_registry_id(msgpu_registry *r, const char *name) {
+  if (!r || !name) return 0xffffffffu;
+  try {
+    return r->r[std::string_view(name)];
+  } catch (std::bad_alloc const &) { return 0xffffffffu; }
+}
+uint32_t msgpu_registry_size(const msgpu_registry *r) { return r ? r->r.size() : 0; }
+void     msgpu_registry_clear(msgpu_registry *r) {
+  if (r) r->r.clear();
+}
+
+/* Toggle::operator* / operator*= (include/ms/types/Toggle.h:127-153): XNOR */
+int msgpu_toggle_mul(int a, int b) { return msgpu::toggle_mul(a != 0, b != 0) ? 1 : 0; }
 
 } // extern "C"

@@ -8,6 +8,7 @@
 // rc(s1 s2 s3) = rc(s3) rc(s2) rc(s1) is expressed by reversing the piece order and toggling MSGPU_COPY_REVCOMP.
 #include <cmath>
 
+#include "asm_internal.h"
 #include "msgpu.h"
 
 namespace {
@@ -71,7 +72,7 @@ int msgpu_seg_anchor(msgpu_seqctx *ctx, const msgpu_row *m, int32_t ov_lo, int32
                      msgpu_copy *out, uint32_t *n_out, uint64_t *len) {
   if (!ctx || !m || !out || !n_out) return MSGPU_E_ARG;
   Composer c{ctx, out};
-  c.add(ILLU, m->anchor_id, ov_lo, ov_hi, mdir(m) == (direction != 0)); // Toggle * Toggle = XNOR
+  c.add(ILLU, m->anchor_id, ov_lo, ov_hi, msgpu::toggle_mul(mdir(m), direction != 0));
   const uint64_t l = c.finish(false);
   *n_out           = c.n;
   if (len) *len = l;

@@ -360,7 +360,8 @@ def shortest_path(g, src, dst):  # GraphUtil::getShortestPath, Graph.h:927-978 (
         dist[v] = d
         if v == dst:
             break
-        for nb, _e in g.neighbors(v):
+        # _getReachableVertices: Graph -> getNeighbors, DiGraph -> getSuccessors (Graph.h:982-992)
+        for nb, _e in (g.neighbors(v) if isinstance(g, Graph) else g.successors(v)):
             nd = dist[v] + 1
             if nb not in dist and (nb not in seen or nd < seen[nb]):
                 seen[nb] = nd
