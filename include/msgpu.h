@@ -242,6 +242,37 @@ int msgpu_merge_gathered(msgpu_ctx *ctx, const void *d_gathered, uint32_t world,
                          uint64_t slab_bytes, uint64_t off_edges, uint64_t off_orders, uint64_t off_ids, void *d_edges,
                          void *d_orders, void *d_ids);
 
+/* ---- the ThreadPool replacement: the whole overlap path, host memory to host memory, as batches on two HIP streams ----
+ * Replaces the phases of src/main.cpp:153-178 that the reference fans over its ThreadPool (one Job per PAF line, per
+ * anchor, per edge; libms/src/threading/ThreadPool.cpp:38-129) and closes with WaitGroup::wait() (WaitGroup.cpp:62-72):
+ *   rows -> HBM and index build once (msgpu_load_rows), then n_batches windows of owner reads, each one
+ *   msgpu_calculate_edges + msgpu_chaining_and_overlaps on the compute stream, while the previous window's edge /
+ *   EdgeMatch / order / id tables are copied to pinned host memory on a second stream (two table sets in HBM).
+ * The call returns when every batch is done (the phase barrier).  The host tables are the single-pass tables of
+ * msgpu_copy_tables bit for bit -- canonical order, cross references (em_off, order_off, edge_idx, ids_off) into the
+ * whole tables -- owned by the context and valid until its next msgpu_overlap_batched / msgpu_destroy.  HBM holds one
+ * window's tables at a time instead of the job's.  With msgpu_set_shard the windows cut this shard's reads.
+ * n_batches 0 = 8.  `rows` should be pinned (msgpu_pinned_alloc) for the copy to run at link speed. */
+typedef struct msgpu_host_tables {
+  const msgpu_edge      *edges;
+  const msgpu_edgematch *ems;
+  const msgpu_order     *orders;
+  const uint32_t        *ids;
+  const int32_t         *read_len;        /* Vertex::getNanoporeLength(), n_reads entries */
+  const uint32_t        *read_first_line; /* Vertex::metaDatum(0) */
+  uint64_t n_edges, n_ems, n_orders, n_ids;
+  uint32_t n_reads, n_anchors, n_batches, pad;
+  float wall_ms;         /* host clock: call entry -> all tables in host memory */
+  float load_ms;         /*   of which rows -> HBM + index build */
+  float first_batch_ms;  /*   first window computed (its copy starts here) */
+  float compute_done_ms; /*   last window computed (what remains is copy) */
+} msgpu_host_tables;
+int msgpu_overlap_batched(msgpu_ctx *ctx, const msgpu_row *rows, size_t n_rows, uint32_t n_batches,
+                          msgpu_host_tables *out);
+/* page-locked host memory for rows handed to msgpu_load_rows / msgpu_overlap_batched (NULL when out of memory) */
+void *msgpu_pinned_alloc(size_t bytes);
+void  msgpu_pinned_free(void *p);
+
 /* Block the host until everything queued on the context's stream has finished. */
 /* findContractionEdges (src/main.cpp:183-190, 416-463) with sanityCheck (libms/src/kernel/sc.cpp:29-90) -- the step
  * that follows the chaining fan-out -- on an edge/order table resident in HBM.  contraction_order (host, n_edges

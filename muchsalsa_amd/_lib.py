@@ -55,6 +55,14 @@ class Params(C.Structure):
                 ("alt_frac", C.c_double)]
 
 
+class HostTables(C.Structure):  # msgpu_host_tables
+    _fields_ = [("edges", C.c_void_p), ("ems", C.c_void_p), ("orders", C.c_void_p), ("ids", C.c_void_p),
+                ("read_len", C.c_void_p), ("read_first_line", C.c_void_p), ("n_edges", C.c_uint64),
+                ("n_ems", C.c_uint64), ("n_orders", C.c_uint64), ("n_ids", C.c_uint64), ("n_reads", C.c_uint32),
+                ("n_anchors", C.c_uint32), ("n_batches", C.c_uint32), ("pad", C.c_uint32), ("wall_ms", C.c_float),
+                ("load_ms", C.c_float), ("first_batch_ms", C.c_float), ("compute_done_ms", C.c_float)]
+
+
 class PathInput(C.Structure):
     _fields_ = [("reads", C.c_void_p), ("n_reads", C.c_uint32), ("asm_idx", C.c_int32), ("order_off", C.c_void_p),
                 ("orders", C.c_void_p), ("ids", C.c_void_p), ("em_off", C.c_void_p), ("ems", C.c_void_p),
@@ -180,6 +188,9 @@ SYMBOLS = [
                                             C.c_uint32, C.c_void_p, C.POINTER(C.c_uint32)]),
     ("msgpu_graph_sort_topologically", C.c_int, [C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p,
                                                  C.POINTER(C.c_uint32)]),
+    ("msgpu_overlap_batched", C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.POINTER(HostTables)]),
+    ("msgpu_pinned_alloc", C.c_void_p, [C.c_size_t]),
+    ("msgpu_pinned_free", None, [C.c_void_p]),
     ("msgpu_index_lines", C.c_int, [C.c_char_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     ("msgpu_registry_new", C.c_void_p, []),
     ("msgpu_registry_free", None, [C.c_void_p]),

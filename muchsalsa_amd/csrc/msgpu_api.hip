@@ -5,6 +5,8 @@
 // stream; the phase barrier is stream order.  The host blocks only where a table size is needed to allocate.
 #include <hip/hip_runtime.h>
 
+#include <chrono>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -66,6 +68,8 @@ struct msgpu_ctx {
   char         err[512]   = {0};
   State        state      = ST_CREATED;
   uint32_t     shard = 0, nshards = 1;
+  uint32_t     win_lo = 0, win_hi = 0xffffffffu; // owner-read window of the current batch (msgpu_overlap_batched)
+  uint64_t     base_edges = 0, base_ems = 0, base_orders = 0, base_ids = 0; // what precedes it in the job's tables
   uint64_t    *h_scalars = nullptr; // pinned mirror of `scalars`: every read-back is ONE copy of the whole block
   uint32_t     decl_V = 0, decl_A = 0; // msgpu_set_id_space: id counts declared by the caller (0 = find them)
 
@@ -95,6 +99,15 @@ struct msgpu_ctx {
   DevBuf ems, order_scr, ids_scr, edge_norders, edge_nids, order_base, ids_base, orders, ids, big_list, cls_list, big_elems,
       big_paths;
   DevBuf g_deg, g_off, g_adj, g_cand, g_sane, g_out; // findContractionEdges
+
+  // batched execution (msgpu_overlap_batched): second set of output tables, copy stream, pinned result arena
+  DevBuf      alt_edges, alt_ems, alt_orders, alt_ids;
+  hipStream_t copy_stream = nullptr;
+  hipEvent_t  ev_done[2] = {nullptr, nullptr}, ev_copied[2] = {nullptr, nullptr}, ev_wall[2] = {nullptr, nullptr};
+  struct HostBuf {
+    void  *p   = nullptr;
+    size_t cap = 0;
+  } h_edges, h_ems, h_orders, h_ids, h_read_len, h_read_first;
 
   // timing
   hipEvent_t ev[10] = {nullptr};
@@ -147,7 +160,7 @@ void release_all(msgpu_ctx *c) {
                    &c->n_visit_arr, &c->lists, &c->em_base, &c->edge_base, &c->visit_base, &c->edges, &c->edge_cand,
                    &c->big_key, &c->big_t, &c->big_r2s, &c->big_pfx, &c->pair_tab, &c->edge_fast, &c->big_off, &c->ems, &c->order_scr, &c->ids_scr,
                    &c->edge_norders, &c->edge_nids, &c->order_base, &c->ids_base, &c->orders, &c->ids, &c->big_list, &c->cls_list,
-                   &c->big_elems, &c->big_paths};
+                   &c->big_elems, &c->big_paths, &c->alt_edges, &c->alt_ems, &c->alt_orders, &c->alt_ids};
   for (DevBuf *b : all) b->release();
 }
 
@@ -360,6 +373,16 @@ int msgpu_create(int device, const msgpu_params *params, msgpu_ctx **out) {
     msgpu_destroy(c);
     return MSGPU_E_HIP;
   }
+  if (hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess) {
+    msgpu_destroy(c);
+    return MSGPU_E_HIP;
+  }
+  for (int k = 0; k < 2; ++k)
+    if (hipEventCreateWithFlags(&c->ev_done[k], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_copied[k], hipEventDisableTiming) != hipSuccess) {
+      msgpu_destroy(c);
+      return MSGPU_E_HIP;
+    }
   *out = c;
   return MSGPU_OK;
 }
@@ -377,6 +400,16 @@ void msgpu_destroy(msgpu_ctx *c) {
     (void)hipStreamSynchronize(c->side_stream);
     (void)hipStreamDestroy(c->side_stream);
   }
+  if (c->copy_stream) {
+    (void)hipStreamSynchronize(c->copy_stream);
+    (void)hipStreamDestroy(c->copy_stream);
+  }
+  for (int k = 0; k < 2; ++k) {
+    if (c->ev_done[k]) (void)hipEventDestroy(c->ev_done[k]);
+    if (c->ev_copied[k]) (void)hipEventDestroy(c->ev_copied[k]);
+  }
+  for (msgpu_ctx::HostBuf *h : {&c->h_edges, &c->h_ems, &c->h_orders, &c->h_ids, &c->h_read_len, &c->h_read_first})
+    if (h->p) (void)hipHostFree(h->p);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   if (c->h_scalars) (void)hipHostFree(c->h_scalars);
   delete c;
@@ -462,11 +495,11 @@ int msgpu_calculate_edges(msgpu_ctx *c) {
     launch_index_init(st, zero, n_zero, ones, n_ones); // one launch instead of four memsets
   }
   launch_bound(st, c->read_off.as<uint32_t>(), c->read_cnt.as<uint32_t>(), c->by_read.as<IRow>(),
-               c->anchor_off.as<uint32_t>(), V, c->shard, c->nshards, c->bound.as<uint32_t>());
+               c->anchor_off.as<uint32_t>(), V, c->shard, c->nshards, c->win_lo, c->win_hi, c->bound.as<uint32_t>());
   exclusive_scan<uint64_t>(st, c->bound.as<uint32_t>(), V, c->cand_off.as<uint64_t>(), c->scan_tmp.as<uint64_t>(),
                            scalar<uint64_t>(c, SC_TOTAL_A));
-  launch_classify_reads(st, c->read_cnt.as<uint32_t>(), c->bound.as<uint32_t>(), V, c->shard, c->nshards, l0, l1, l2,
-                        l3, scalar<uint32_t>(c, SC_NLISTS));
+  launch_classify_reads(st, c->read_cnt.as<uint32_t>(), c->bound.as<uint32_t>(), V, c->shard, c->nshards, c->win_lo,
+                        c->win_hi, l0, l1, l2, l3, scalar<uint32_t>(c, SC_NLISTS));
   HIPCHK(c, hipGetLastError());
   if (int rc = read_scalars(c)) return rc; // sizes of the candidate scratch
   const uint64_t total_bound = *host_scalar<uint64_t>(c, SC_TOTAL_A);
@@ -592,6 +625,7 @@ int msgpu_chaining_and_overlaps(msgpu_ctx *c) {
   a.wiggle       = static_cast<double>(c->p.wiggle_room);
   a.ratio_pct    = c->p.ratio_pct;
   a.alt_frac     = c->p.alt_frac;
+  a.out_edge_base = static_cast<uint32_t>(c->base_edges);
 
   // Edges with more than 64 EdgeMatches (counted by the candidate kernels, so the host already knows how many there
   // are and how much scratch they need) run in k_chain_big on the side stream, concurrently with k_chain.
@@ -656,6 +690,10 @@ int msgpu_chaining_and_overlaps(msgpu_ctx *c) {
   k.ids_scr      = c->ids_scr.as<uint32_t>();
   k.orders       = c->orders.as<msgpu_order>();
   k.ids          = c->ids.as<uint32_t>();
+  k.out_em_base    = c->base_ems;
+  k.out_order_base = c->base_orders; // known only now: the caller of a batched run adds the earlier batches' counts
+  k.out_ids_base   = c->base_ids;
+  k.out_edge_base  = static_cast<uint32_t>(c->base_edges);
   launch_compact(st, k);
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipEventRecord(c->ev[8], st));
@@ -804,6 +842,166 @@ int msgpu_merge_gathered(msgpu_ctx *c, const void *d_gathered, uint32_t world, c
   launch_merge_gathered(c->stream, a);
   HIPCHK(c, hipGetLastError());
   return MSGPU_OK;
+}
+
+// ---- the ThreadPool replacement: the whole overlap path as owner-read batches on two HIP streams -------------------------
+//
+// The reference fans one Job per PAF line / anchor / edge over ThreadPool workers and blocks in WaitGroup::wait() at the
+// end of each phase (libms/src/threading/ThreadPool.cpp:38-129, WaitGroup.cpp:36-72, src/main.cpp:143-178).  Here the
+// unit of dispatch is a BATCH of owner reads (the edges whose first vertex lies in a window of read ids): its candidate
+// scan, chaining and compaction are a few dozen kernel launches on the compute stream, and while batch k+1 computes,
+// batch k's four tables travel to pinned host memory on the copy stream (two sets of output tables in HBM, guarded by
+// events).  The phase barrier -- all batches done -- is the final wait on the copy stream.
+
+namespace {
+
+// pinned host block of at least `need` bytes that keeps its first `valid` bytes (the copy stream must be idle when it
+// moves); `hint` = expected final size
+int ensure_host(msgpu_ctx *c, msgpu_ctx::HostBuf &h, size_t need, size_t valid, size_t hint) {
+  if (need <= h.cap) return MSGPU_OK;
+  size_t want = need + need / 4 + 4096;
+  if (hint > want) want = hint;
+  void *np = nullptr;
+  HIPCHK(c, hipHostMalloc(&np, want, hipHostMallocDefault));
+  if (h.p) {
+    if (valid) {
+      hipError_t e = hipStreamSynchronize(c->copy_stream);
+      if (e != hipSuccess) {
+        (void)hipHostFree(np);
+        HIPCHK(c, e);
+      }
+      memcpy(np, h.p, valid);
+    }
+    HIPCHK(c, hipHostFree(h.p));
+  }
+  h.p   = np;
+  h.cap = want;
+  return MSGPU_OK;
+}
+
+} // namespace
+
+int msgpu_overlap_batched(msgpu_ctx *c, const msgpu_row *rows, size_t n_rows, uint32_t n_batches, msgpu_host_tables *out) {
+  if (!c || !out) return MSGPU_E_ARG;
+  memset(out, 0, sizeof(*out));
+  const auto t_start = std::chrono::steady_clock::now();
+  auto       ms_since = [&](std::chrono::steady_clock::time_point t0) {
+    return std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  };
+  c->win_lo = 0;
+  c->win_hi = 0xffffffffu;
+  c->base_edges = c->base_ems = c->base_orders = c->base_ids = 0;
+  if (int rc = msgpu_load_rows(c, rows, n_rows)) return rc; // rows host -> HBM once, index build once
+  out->load_ms = ms_since(t_start);
+  const uint32_t V = c->V;
+  uint32_t       B = n_batches ? n_batches : 8;
+  if (B > 256) B = 256;
+  if (B > V) B = V ? V : 1;
+  hipStream_t st = c->stream, cs = c->copy_stream;
+
+  // Vertex facts (Vertex::getNanoporeLength, metaDatum(0)) go first on the copy stream
+  if (int rc = ensure_host(c, c->h_read_len, (size_t(V) + 1) * 4, 0, 0)) return rc;
+  if (int rc = ensure_host(c, c->h_read_first, (size_t(V) + 1) * 4, 0, 0)) return rc;
+  HIPCHK(c, hipEventRecord(c->ev_done[0], st));
+  HIPCHK(c, hipStreamWaitEvent(cs, c->ev_done[0], 0));
+  if (V) {
+    HIPCHK(c, hipMemcpyAsync(c->h_read_len.p, c->read_len.p, size_t(V) * 4, hipMemcpyDeviceToHost, cs));
+    HIPCHK(c, hipMemcpyAsync(c->h_read_first.p, c->read_first.p, size_t(V) * 4, hipMemcpyDeviceToHost, cs));
+  }
+
+  // Windows of owner reads.  An edge belongs to its lower read id, so with ids that are unrelated to genome position
+  // read r owns about (V - r) / V of its pairs: windows that end at V (1 - sqrt(1 - k/B)) hold equal shares.  Balance
+  // is not needed for correctness, and hardly for speed: a batch computes several times faster than it copies.
+  auto cut = [&](uint32_t k) -> uint32_t {
+    if (k >= B) return V;
+    const double x = 1.0 - std::sqrt(1.0 - double(k) / double(B));
+    uint64_t     v = static_cast<uint64_t>(x * double(V));
+    return v > V ? V : static_cast<uint32_t>(v);
+  };
+  uint64_t tot_e = 0, tot_m = 0, tot_o = 0, tot_i = 0;
+  int      rc = MSGPU_OK;
+  for (uint32_t k = 0; k < B && rc == MSGPU_OK; ++k) {
+    const int set = static_cast<int>(k & 1);
+    c->win_lo      = cut(k);
+    c->win_hi      = cut(k + 1);
+    c->base_edges  = tot_e;
+    c->base_ems    = tot_m;
+    c->base_orders = tot_o;
+    c->base_ids    = tot_i;
+    // this set of output tables was last read by the copy of batch k - 2
+    if (k >= 2) rc = hipStreamWaitEvent(st, c->ev_copied[set], 0) == hipSuccess ? MSGPU_OK : fail(c, MSGPU_E_HIP, "hipStreamWaitEvent failed");
+    if (rc == MSGPU_OK) rc = msgpu_calculate_edges(c);
+    if (rc == MSGPU_OK) rc = msgpu_chaining_and_overlaps(c);
+    if (rc != MSGPU_OK) break;
+    if (tot_e + c->n_edges >= 0xfffffff0ull) {
+      rc = fail(c, MSGPU_E_ARG, "edge table too large");
+      break;
+    }
+    if (k == 0) out->first_batch_ms = ms_since(t_start);
+    auto guarded = [&](hipError_t e, const char *what) {
+      if (e != hipSuccess && rc == MSGPU_OK) rc = fail(c, MSGPU_E_HIP, "%s failed: %s", what, hipGetErrorString(e));
+    };
+    guarded(hipEventRecord(c->ev_done[set], st), "hipEventRecord");
+    // room in the pinned result tables; the expected job size is extrapolated from what the windows so far produced
+    const double share = double(c->win_hi) >= double(V) ? 1.0 : 1.0 - (1.0 - double(c->win_hi) / V) * (1.0 - double(c->win_hi) / V);
+    auto         hint  = [&](uint64_t have, size_t rec) {
+      return static_cast<size_t>(double(have) / (share > 0.02 ? share : 0.02) * 1.15) * rec;
+    };
+    if (rc == MSGPU_OK) rc = ensure_host(c, c->h_edges, (tot_e + c->n_edges + 1) * sizeof(msgpu_edge), tot_e * sizeof(msgpu_edge), hint(tot_e + c->n_edges, sizeof(msgpu_edge)));
+    if (rc == MSGPU_OK) rc = ensure_host(c, c->h_ems, (tot_m + c->n_ems + 1) * sizeof(msgpu_edgematch), tot_m * sizeof(msgpu_edgematch), hint(tot_m + c->n_ems, sizeof(msgpu_edgematch)));
+    if (rc == MSGPU_OK) rc = ensure_host(c, c->h_orders, (tot_o + c->n_orders + 1) * sizeof(msgpu_order), tot_o * sizeof(msgpu_order), hint(tot_o + c->n_orders, sizeof(msgpu_order)));
+    if (rc == MSGPU_OK) rc = ensure_host(c, c->h_ids, (tot_i + c->n_ids + 1) * 4, tot_i * 4, hint(tot_i + c->n_ids, 4));
+    if (rc != MSGPU_OK) break;
+    guarded(hipStreamWaitEvent(cs, c->ev_done[set], 0), "hipStreamWaitEvent");
+    if (c->n_edges) guarded(hipMemcpyAsync(static_cast<msgpu_edge *>(c->h_edges.p) + tot_e, c->edges.p, c->n_edges * sizeof(msgpu_edge), hipMemcpyDeviceToHost, cs), "copy of the edge table");
+    if (c->n_ems) guarded(hipMemcpyAsync(static_cast<msgpu_edgematch *>(c->h_ems.p) + tot_m, c->ems.p, c->n_ems * sizeof(msgpu_edgematch), hipMemcpyDeviceToHost, cs), "copy of the EdgeMatch table");
+    if (c->n_orders) guarded(hipMemcpyAsync(static_cast<msgpu_order *>(c->h_orders.p) + tot_o, c->orders.p, c->n_orders * sizeof(msgpu_order), hipMemcpyDeviceToHost, cs), "copy of the order table");
+    if (c->n_ids) guarded(hipMemcpyAsync(static_cast<uint32_t *>(c->h_ids.p) + tot_i, c->ids.p, c->n_ids * 4, hipMemcpyDeviceToHost, cs), "copy of the id table");
+    guarded(hipEventRecord(c->ev_copied[set], cs), "hipEventRecord");
+    tot_e += c->n_edges;
+    tot_m += c->n_ems;
+    tot_o += c->n_orders;
+    tot_i += c->n_ids;
+    // the next batch writes the other set
+    std::swap(c->edges, c->alt_edges);
+    std::swap(c->ems, c->alt_ems);
+    std::swap(c->orders, c->alt_orders);
+    std::swap(c->ids, c->alt_ids);
+  }
+  out->compute_done_ms = ms_since(t_start);
+  // WaitGroup::wait(): every batch's tables are in host memory
+  hipError_t e1 = hipStreamSynchronize(cs), e2 = hipStreamSynchronize(st);
+  c->win_lo = 0;
+  c->win_hi = 0xffffffffu;
+  c->base_edges = c->base_ems = c->base_orders = c->base_ids = 0;
+  c->state = ST_LOADED; // the context's own tables hold one batch only: results are the host tables
+  if (rc != MSGPU_OK) return rc;
+  HIPCHK(c, e1);
+  HIPCHK(c, e2);
+  out->edges           = static_cast<const msgpu_edge *>(c->h_edges.p);
+  out->ems             = static_cast<const msgpu_edgematch *>(c->h_ems.p);
+  out->orders          = static_cast<const msgpu_order *>(c->h_orders.p);
+  out->ids             = static_cast<const uint32_t *>(c->h_ids.p);
+  out->read_len        = static_cast<const int32_t *>(c->h_read_len.p);
+  out->read_first_line = static_cast<const uint32_t *>(c->h_read_first.p);
+  out->n_edges         = tot_e;
+  out->n_ems           = tot_m;
+  out->n_orders        = tot_o;
+  out->n_ids           = tot_i;
+  out->n_reads         = V;
+  out->n_anchors       = c->A;
+  out->n_batches       = B;
+  out->wall_ms         = ms_since(t_start);
+  return MSGPU_OK;
+}
+
+void *msgpu_pinned_alloc(size_t bytes) {
+  void *p = nullptr;
+  if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return nullptr;
+  return p;
+}
+void msgpu_pinned_free(void *p) {
+  if (p) (void)hipHostFree(p);
 }
 
 int msgpu_synchronize(msgpu_ctx *c) {

@@ -51,6 +51,7 @@ struct ChainArgs {
   uint32_t        *edge_fast; // per edge: 1 if the all-pairs-compatible shortcut was taken (may be null)
   int              fast_path; // 0 disables the shortcut (every edge takes the full pair sweep)
   double           wiggle, ratio_pct, alt_frac;
+  uint32_t         out_edge_base; // added to EdgeMatch::edge_idx: position of this batch's first edge in the job's table
 };
 
 struct CompactArgs {
@@ -62,6 +63,9 @@ struct CompactArgs {
   const uint32_t    *ids_scr;
   msgpu_order       *orders;
   uint32_t          *ids;
+  // a batch of a larger job: what precedes this batch in the job's tables (0 for a whole-job run)
+  uint64_t           out_em_base, out_order_base, out_ids_base;
+  uint32_t           out_edge_base;
 };
 
 constexpr uint32_t MAX_WORLD = 64;
@@ -108,9 +112,11 @@ void launch_rank_anchor(hipStream_t st, const uint32_t *anchor_off, uint64_t n_r
                         const uint32_t *bkt_idx, const uint32_t *bkt_line, const msgpu_row *rows,
                         const uint32_t *alive_rank, IRow *by_anchor, const uint32_t *flags);
 void launch_bound(hipStream_t st, const uint32_t *read_off, const uint32_t *read_cnt, const IRow *by_read,
-                  const uint32_t *anchor_off, uint32_t V, uint32_t shard, uint32_t nshards, uint32_t *bound);
+                  const uint32_t *anchor_off, uint32_t V, uint32_t shard, uint32_t nshards, uint32_t lo, uint32_t hi,
+                  uint32_t *bound);
 void launch_classify_reads(hipStream_t st, const uint32_t *read_cnt, const uint32_t *bound, uint32_t V, uint32_t shard,
-                           uint32_t nshards, uint32_t *l0, uint32_t *l1, uint32_t *l2, uint32_t *l3, uint32_t *n_lists);
+                           uint32_t nshards, uint32_t lo, uint32_t hi, uint32_t *l0, uint32_t *l1, uint32_t *l2,
+                           uint32_t *l3, uint32_t *n_lists);
 void launch_candidates(hipStream_t st, const CandArgs &a, int cls, const uint32_t *list, uint32_t n_list);
 void launch_candidates_big(hipStream_t st, const CandArgs &a, const uint32_t *list, uint32_t n_list, uint64_t *big_key,
                            uint32_t *big_t, uint32_t *big_r2s, uint32_t *big_pfx);

@@ -557,12 +557,12 @@ __global__ __launch_bounds__(256) void k_rank_anchor(const uint32_t *anchor_off,
 // upper bound of the scaffold rows a read has to visit = sum over its anchors of the scaffold size
 __global__ __launch_bounds__(256) void k_bound(const uint32_t *read_off, const uint32_t *read_cnt, const IRow *by_read,
                                                const uint32_t *anchor_off, uint32_t V, uint32_t shard, uint32_t nshards,
-                                               uint32_t *bound) {
+                                               uint32_t lo, uint32_t hi, uint32_t *bound) {
   // 16 lanes per read: neighbouring lanes read neighbouring rows
   const uint32_t r   = blockIdx.x * 16 + (threadIdx.x >> 4);
   const uint32_t sub = threadIdx.x & 15;
   uint32_t       s   = 0;
-  if (r < V && r % nshards == shard) {
+  if (r < V && r >= lo && r < hi && r % nshards == shard) { // owner reads of this shard / batch
     const uint32_t b = read_off[r], n = read_cnt[r];
     for (uint32_t j = sub; j < n; j += 16) {
       const uint32_t a = by_read[b + j].other;
@@ -853,7 +853,8 @@ template __global__ void k_candidates<1024, 4096>(CandArgs, const uint32_t *, ui
 // classes by LDS footprint: 0 = <256 rows, 512 candidates> (half the LDS of class 1, so twice as many reads per CU),
 // 1 = <256, 1024>, 2 = <1024, 4096>, 3 = global-scratch kernel
 __global__ __launch_bounds__(1024) void k_classify_reads(const uint32_t *read_cnt, const uint32_t *bound, uint32_t V,
-                                                         uint32_t shard, uint32_t nshards, uint32_t *list0,
+                                                         uint32_t shard, uint32_t nshards, uint32_t lo, uint32_t hi,
+                                                         uint32_t *list0,
                                                          uint32_t *list1, uint32_t *list2, uint32_t *list3,
                                                          uint32_t *n_lists /*[4]*/) {
   // the four list cursors are single words (~88 atomics/us each): count inside the workgroup in LDS first, then one
@@ -863,7 +864,7 @@ __global__ __launch_bounds__(1024) void k_classify_reads(const uint32_t *read_cn
   __syncthreads();
   uint32_t r   = blockIdx.x * 1024 + threadIdx.x;
   int      cls = -1;
-  if (r < V && r % nshards == shard) {
+  if (r < V && r >= lo && r < hi && r % nshards == shard) {
     uint32_t n1 = read_cnt[r], bd = bound[r];
     if (n1 != 0 && bd != 0)
       cls = (n1 <= 256 && bd <= 512) ? 0 : (n1 <= 256 && bd <= 1024) ? 1 : (n1 <= 1024 && bd <= 4096) ? 2 : 3;
@@ -1247,7 +1248,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
       q[0]     = make_uint4(static_cast<uint32_t>(ov_lo), static_cast<uint32_t>(ov_hi),
                             static_cast<uint32_t>(__double_as_longlong(em_score)),
                             static_cast<uint32_t>(__double_as_longlong(em_score) >> 32));
-      q[1]     = make_uint4(anchor, om.line, (em_dir ? 1u : 0u) | (em_prim ? 2u : 0u), static_cast<uint32_t>(e));
+      q[1]     = make_uint4(anchor, om.line, (em_dir ? 1u : 0u) | (em_prim ? 2u : 0u), static_cast<uint32_t>(e) + a.out_edge_base);
     }
     // corrected nanopore ranges (mpp.cpp:48-65) and overhangs (ol.cpp:37-47) on both vertices.  ov = [max lo, min hi]:
     // on each side at most ONE of the two rows has a non-zero correction numerator (the other one is 0 / rRatio = +0),
@@ -1710,7 +1711,7 @@ __global__ __launch_bounds__(256) void k_chain_sub(ChainArgs a, const uint32_t *
       q[0]     = make_uint4(static_cast<uint32_t>(ov_lo), static_cast<uint32_t>(ov_hi),
                             static_cast<uint32_t>(__double_as_longlong(em_score)),
                             static_cast<uint32_t>(__double_as_longlong(em_score) >> 32));
-      q[1]     = make_uint4(anchor, om.line, (em_dir ? 1u : 0u) | (em_prim ? 2u : 0u), e);
+      q[1]     = make_uint4(anchor, om.line, (em_dir ? 1u : 0u) | (em_prim ? 2u : 0u), e + a.out_edge_base);
     }
     {
       const double rr1 = static_cast<double>(m1.i_hi - m1.i_lo + 1) / static_cast<double>(m1.n_hi - m1.n_lo + 1);
@@ -2192,7 +2193,7 @@ __global__ __launch_bounds__(64) void k_chain_big(ChainArgs a, const uint32_t *b
     em.anchor_id = x.anchor;
     em.line      = om.line;
     em.flags     = x.flags;
-    em.edge_idx  = static_cast<uint32_t>(e);
+    em.edge_idx  = static_cast<uint32_t>(e) + a.out_edge_base;
     a.ems[ed.em_off + i] = em;
     {
       const double rr  = static_cast<double>(m1.i_hi - m1.i_lo + 1) / static_cast<double>(m1.n_hi - m1.n_lo + 1);
@@ -2482,9 +2483,10 @@ __global__ __launch_bounds__(256) void k_compact(CompactArgs a) {
     oo     = a.order_base[e];
     io     = a.ids_base[e];
     em_off = a.edges[e].em_off;
-    if (sub == 0) {
-      a.edges[e].order_off = oo;
+    if (sub == 0) { // cross references leave as positions in the whole job's tables (a batch / shard adds its bases)
+      a.edges[e].order_off = oo + a.out_order_base;
       a.edges[e].order_cnt = static_cast<uint16_t>(no);
+      a.edges[e].em_off    = em_off + a.out_em_base;
     }
   }
   uint32_t max_no = no; // every lane runs the same number of rounds (shuffles inside)
@@ -2498,9 +2500,11 @@ __global__ __launch_bounds__(256) void k_compact(CompactArgs a) {
     const uint32_t rel = static_cast<uint32_t>(__shfl(static_cast<int>(w.x), q2));
     const uint32_t cnt = static_cast<uint32_t>(__shfl(static_cast<int>(w.z), q2));
     if (sub == 2) {
-      w.x = static_cast<uint32_t>(io);
-      w.y = static_cast<uint32_t>(io >> 32);
+      const uint64_t gio = io + a.out_ids_base;
+      w.x = static_cast<uint32_t>(gio);
+      w.y = static_cast<uint32_t>(gio >> 32);
     }
+    if (sub == 0) w.x += a.out_edge_base; // dword 0 = edge_idx
     if (on) {
       reinterpret_cast<uint4 *>(&a.orders[oo + i])[sub] = w;
       for (uint32_t q = sub; q < cnt; q += 4) a.ids[io + q] = a.ids_scr[em_off + rel + q];
@@ -2619,15 +2623,17 @@ void launch_rank_anchor(hipStream_t st, const uint32_t *anchor_off, uint64_t n_r
                        rows, alive_rank, by_anchor, flags);
 }
 void launch_bound(hipStream_t st, const uint32_t *read_off, const uint32_t *read_cnt, const IRow *by_read,
-                  const uint32_t *anchor_off, uint32_t V, uint32_t shard, uint32_t nshards, uint32_t *bound) {
+                  const uint32_t *anchor_off, uint32_t V, uint32_t shard, uint32_t nshards, uint32_t lo, uint32_t hi,
+                  uint32_t *bound) {
   if (V)
     hipLaunchKernelGGL(k_bound, grid1(V, 16), dim3(256), 0, st, read_off, read_cnt, by_read, anchor_off, V, shard,
-                       nshards, bound);
+                       nshards, lo, hi, bound);
 }
 void launch_classify_reads(hipStream_t st, const uint32_t *read_cnt, const uint32_t *bound, uint32_t V, uint32_t shard,
-                           uint32_t nshards, uint32_t *l0, uint32_t *l1, uint32_t *l2, uint32_t *l3, uint32_t *n_lists) {
+                           uint32_t nshards, uint32_t lo, uint32_t hi, uint32_t *l0, uint32_t *l1, uint32_t *l2,
+                           uint32_t *l3, uint32_t *n_lists) {
   if (V)
-    hipLaunchKernelGGL(k_classify_reads, grid1(V, 1024), dim3(1024), 0, st, read_cnt, bound, V, shard, nshards, l0, l1, l2,
+    hipLaunchKernelGGL(k_classify_reads, grid1(V, 1024), dim3(1024), 0, st, read_cnt, bound, V, shard, nshards, lo, hi, l0, l1, l2,
                        l3, n_lists);
 }
 void launch_candidates(hipStream_t st, const CandArgs &a, int cls, const uint32_t *list, uint32_t n_list) {

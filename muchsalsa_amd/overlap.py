@@ -15,7 +15,7 @@ import os
 import numpy as np
 
 from . import _lib
-from ._lib import EDGE_DTYPE, EM_DTYPE, ORDER_DTYPE, ROW_DTYPE, Counts, Params, Timings
+from ._lib import EDGE_DTYPE, EM_DTYPE, ORDER_DTYPE, ROW_DTYPE, Counts, HostTables, Params, Timings
 
 
 class MsgpuError(RuntimeError):
@@ -60,6 +60,29 @@ def parse_paf(path, params=None):
         return Paf(rows, L.msgpu_paf_line_count(h), rn, an)
     finally:
         L.msgpu_paf_free(h)
+
+
+class PinnedRows:
+    """A msgpu_row table in page-locked host memory (msgpu_pinned_alloc): what msgpu_overlap_batched wants to be handed
+    so that the rows travel to HBM at link speed.  `.array` is a numpy view of it."""
+
+    def __init__(self, rows):
+        rows = np.ascontiguousarray(rows, dtype=ROW_DTYPE)
+        self._L = _lib.lib()
+        self._p = self._L.msgpu_pinned_alloc(max(rows.nbytes, 1))
+        if not self._p:
+            raise MemoryError("msgpu_pinned_alloc(%d)" % rows.nbytes)
+        buf = (C.c_char * max(rows.nbytes, 1)).from_address(self._p)
+        self.array = np.frombuffer(buf, dtype=ROW_DTYPE, count=len(rows))
+        self.array[:] = rows
+
+    def close(self):
+        if getattr(self, "_p", None):
+            self.array = None
+            self._L.msgpu_pinned_free(self._p)
+            self._p = None
+
+    __del__ = close
 
 
 class OverlapContext:
@@ -137,6 +160,30 @@ class OverlapContext:
         self._check(self._L.msgpu_copy_tables(self._h, edges.ctypes.data, ems.ctypes.data, orders.ctypes.data,
                                               ids.ctypes.data))
         return {"edges": edges, "ems": ems, "orders": orders, "ids": ids}
+
+    def overlap_batched(self, rows, n_batches=0, copy=True):
+        """msgpu_overlap_batched: rows (numpy table or PinnedRows) -> (tables, info).  The whole overlap path, host
+        memory to host memory, as `n_batches` windows of owner reads with the copy of window k behind the compute of
+        window k + 1.  tables = the dict of tables(), plus read_len / read_first_line; copy=False returns views of the
+        context's pinned result memory (valid until the next call)."""
+        arr = rows.array if isinstance(rows, PinnedRows) else np.ascontiguousarray(rows, dtype=ROW_DTYPE)
+        h = HostTables()
+        self._check(self._L.msgpu_overlap_batched(self._h, arr.ctypes.data if len(arr) else None, len(arr),
+                                                  int(n_batches), C.byref(h)))
+
+        def view(ptr, n, dt):
+            dt = np.dtype(dt)
+            if not n:
+                return np.zeros(0, dtype=dt)
+            a = np.frombuffer((C.c_char * (n * dt.itemsize)).from_address(ptr), dtype=dt, count=n)
+            return a.copy() if copy else a
+        t = {"edges": view(h.edges, h.n_edges, EDGE_DTYPE), "ems": view(h.ems, h.n_ems, EM_DTYPE),
+             "orders": view(h.orders, h.n_orders, ORDER_DTYPE), "ids": view(h.ids, h.n_ids, "<u4"),
+             "read_len": view(h.read_len, h.n_reads, "<i4"), "read_first_line": view(h.read_first_line, h.n_reads, "<u4")}
+        info = {"n_batches": h.n_batches, "wall_ms": h.wall_ms, "load_ms": h.load_ms,
+                "first_batch_ms": h.first_batch_ms, "compute_done_ms": h.compute_done_ms, "n_reads": h.n_reads,
+                "n_anchors": h.n_anchors}
+        return t, info
 
     def copy_tables_device(self, d_edges=None, d_ems=None, d_orders=None, d_ids=None):
         self._check(self._L.msgpu_copy_tables_device(self._h, C.c_void_p(d_edges), C.c_void_p(d_ems),

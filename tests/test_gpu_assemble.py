@@ -124,3 +124,36 @@ def test_fasta_format_line_boundaries():
     # capacity is checked before anything is launched
     assert L.msgpu_fasta_format(store._h, C.c_void_p(d_raw.data_ptr()), recs.ctypes.data, len(recs), headers,
                                 len(headers), C.c_void_p(d_text.data_ptr()), toff - 1, None) == _lib.E_ARG
+
+
+def test_seqctx_may_be_destroyed_before_its_assembly(gpu_world):
+    """Contract of include/msgpu.h (msgpu_assembly_create): the assembly uses its msgpu_seqctx until finish / validate
+    have returned, and msgpu_assembly_free never touches the context -- so the context may go first.  (Round 1 had a
+    use-after-free exactly there: the assembly's free path gave buffers back through the dead context.)  Raw C-ABI
+    calls, no Python wrapper bookkeeping; afterwards the GPU must still do unrelated work correctly."""
+    import ctypes as C
+
+    from muchsalsa_amd import _lib
+    from muchsalsa_amd.assembly import Assembly
+    from muchsalsa_amd.overlap import build_overlaps
+    from muchsalsa_amd.sequences import ILLUMINA, NANOPORE
+    w = gpu_world
+    L = _lib.lib()
+    for finish_first in (True, False):
+        ctx = C.c_void_p()
+        assert L.msgpu_seq_create(0, C.byref(ctx)) == 0
+        for kind, f in ((NANOPORE, w.files[0]), (ILLUMINA, w.files[1])):
+            assert L.msgpu_seq_upload(ctx, kind, f._h, None, len(f)) == 0
+        asm = C.c_void_p()
+        assert L.msgpu_assembly_create(ctx, C.byref(asm)) == 0
+        path, steps = w.chain(int(np.argsort(w.read_start)[0]), max_len=8)
+        prepared = Assembly.prepare(path, steps, w.rows, None, 0)
+        assert L.msgpu_assembly_add_path(asm, C.byref(prepared[0])) == 0
+        if finish_first:
+            assert L.msgpu_assembly_finish(asm, None) == 0
+            n = C.c_uint64()
+            assert L.msgpu_assembly_text(asm, 0, C.byref(n)) and n.value > 0
+        L.msgpu_seq_destroy(ctx)         # the context goes first ...
+        L.msgpu_assembly_free(asm)       # ... and the assembly's free path must not reach into it
+        t = build_overlaps(w.rows)       # the device is still healthy
+        assert t["orders"].tobytes() == w.tables["orders"].tobytes()

@@ -1,0 +1,90 @@
+"""msgpu_overlap_batched (the ThreadPool replacement: owner-read batches on two HIP streams, copy of batch k behind the
+compute of batch k+1): whatever the batch count, the host tables are the single-pass tables bit for bit."""
+import numpy as np
+import pytest
+
+from helpers import assert_tables_equal
+
+pytestmark = pytest.mark.gpu
+
+
+def _single(ctx, rows):
+    ctx.load_rows(rows)
+    ctx.calculate_edges()
+    ctx.chaining_and_overlaps()
+    t = ctx.tables()
+    t["read_len"], t["read_first_line"] = ctx.reads()
+    return t
+
+
+@pytest.mark.parametrize("shape", [(2000, 5000, 10000, 7), (400, 8000, 3200, 23)])
+def test_any_batch_count_gives_the_single_pass_tables(oracle, shape):
+    from muchsalsa_amd import overlap, synth
+    rows = synth.synth_rows(*shape)
+    want = oracle.overlap(rows)
+    with overlap.OverlapContext(0) as ctx:
+        single = _single(ctx, rows)
+        assert_tables_equal(single, want, "single pass")
+        pinned = overlap.PinnedRows(rows)
+        for b in (1, 2, 3, 8, 37, 0):
+            got, info = ctx.overlap_batched(pinned if b != 3 else rows, b)
+            assert info["n_batches"] == (b if b else 8)
+            assert_tables_equal(got, want, "%d batches" % b)
+            assert np.array_equal(got["read_len"], want["read_len"])
+            assert np.array_equal(got["read_first_line"], want["read_first_line"])
+            assert info["wall_ms"] >= info["compute_done_ms"] >= info["first_batch_ms"] >= info["load_ms"] > 0
+        # the context stays usable the ordinary way, and again batched (result memory is reused)
+        assert_tables_equal(_single(ctx, rows), want, "single pass after batched runs")
+        got, _ = ctx.overlap_batched(pinned, 5, copy=False)
+        assert_tables_equal(got, want, "views of the pinned result")
+        pinned.close()
+
+
+def test_batched_edge_cases(oracle):
+    """empty input, fewer reads than batches, big edges (> 64 EdgeMatches: side stream), duplicates + shuffled rows
+    (generic index build), and a shard's windows."""
+    from muchsalsa_amd import distributed as D, overlap, synth
+    with overlap.OverlapContext(0) as ctx:
+        empty = np.zeros(0, dtype=synth.ROW_DTYPE)
+        got, info = ctx.overlap_batched(empty, 4)
+        assert all(len(got[k]) == 0 for k in ("edges", "ems", "orders", "ids"))
+        tiny = synth.synth_rows(300, 3000, 900, 1)[:5].copy()
+        _, tiny["read_id"] = np.unique(tiny["read_id"], return_inverse=True)
+        _, tiny["anchor_id"] = np.unique(tiny["anchor_id"], return_inverse=True)
+        got, info = ctx.overlap_batched(tiny, 64)
+        assert_tables_equal(got, oracle.overlap(tiny), "tiny")
+        dense, _, _ = synth.accepted_rows(synth.paf_table(400, 4000, 120, 6, coverage=200))
+        want = oracle.overlap(dense)
+        assert want["edges"]["em_cnt"].max() > 64
+        got, _ = ctx.overlap_batched(dense, 6)
+        assert_tables_equal(got, want, "big edges")
+        rows = synth.synth_rows(300, 4000, 1000, 9)
+        rng = np.random.default_rng(5)
+        dup = rows[rng.choice(len(rows), 200, replace=False)].copy()
+        dup["line"] = rows["line"].max() + 1 + np.arange(len(dup))
+        dup["n_lo"] += 7
+        allrows = np.concatenate([rows, dup])
+        rng.shuffle(allrows)
+        got, _ = ctx.overlap_batched(allrows, 4)
+        assert_tables_equal(got, oracle.overlap(rows), "duplicates, shuffled")
+        rows = synth.synth_rows(1000, 5000, 4000, 13)
+        full = oracle.overlap(rows)
+        ctx.set_shard(1, 3)
+        got, _ = ctx.overlap_batched(rows, 4)
+        assert_tables_equal(got, D.shard_view_host(full, 1, 3), "windows of shard 1/3")
+        ctx.set_shard(0, 1)
+
+
+def test_batched_cfg2_full_size(oracle):
+    from muchsalsa_amd import overlap, synth
+    rows = synth.synth_rows(**synth.CONFIGS["cfg2"])
+    want = oracle.overlap(rows)
+    with overlap.OverlapContext(0) as ctx:
+        pinned = overlap.PinnedRows(rows)
+        got, info = ctx.overlap_batched(pinned, 8)
+        assert_tables_equal(got, want, "cfg2, 8 batches")
+        got, info2 = ctx.overlap_batched(pinned, 8)  # warm: no allocation left
+        assert_tables_equal(got, want, "cfg2, 8 batches, warm")
+        print("cfg2 batched: cold %.2f ms, warm %.2f ms (load %.2f, first batch at %.2f, compute done at %.2f)" % (
+            info["wall_ms"], info2["wall_ms"], info2["load_ms"], info2["first_batch_ms"], info2["compute_done_ms"]))
+        pinned.close()
