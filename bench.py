@@ -7,11 +7,24 @@ A step = one pass of the hot path over the synthetic batch, starting with the ac
   msgpu_chaining_and_overlaps (the chainingAndOverlaps fan-out)
   N > 1: one RCCL all-gather of the per-rank edge + order + id tables (each rank owns the edges with v1 % N == rank)
 
-Contract: python bench.py --gpus N --steps K --warmup W ; rank 0 prints ONE JSON line.
+Contract: python bench.py --gpus N --steps K --warmup W ; rank 0 prints ONE JSON line.  With --gpus N > 1 and no
+WORLD_SIZE in the environment the script starts the N ranks itself (torch.distributed.run, before any GPU call) and
+relays rank 0's line.
+
+Beside `value` (device-resident in / out, as the contract asks) the line carries:
+  roofline       the chain kernels against the HBM peak (algorithmic bytes / HIP-event time; traffic from profiles/)
+  host_to_host   SURVEY section 8(d)'s own region: rows in pinned host memory -> all four tables in pinned host memory
+                 (msgpu_overlap_batched: batches on two streams, the copy of batch k behind the compute of batch k+1)
+  consensus      the gather kernel at full size; assemble_path: assemblePath over chains tiling the WHOLE genome
+  graph_stage    findContractionEdges (GPU) + clean-up + linearizeGraph (host, flat CSR) on the job's tables, and
+                 assemblePath over the paths it yields
+  cpu_baseline   the C oracle (single-thread restatement of the reference) on the box's host cores
 """
 import argparse
+import glob
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -21,12 +34,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-
-# HBM bytes per launch from the PMC counters (FETCH_SIZE x 2 per the gfx950 note of MI355X_MICROARCH.md + WRITE_SIZE),
-# collected with rocprofv3 in separate --pmc passes of this same command (tools/pmc_passes.sh):
-# profiles/r1_08_final/pmc_summary.csv for the three chain kernels together, profiles/r1_05_gather for the gather.
-# They cannot be read from inside this process, so they are quoted for the one configuration they were measured on.
-PMC_TRAFFIC_BYTES = {("cfg3", 1): {"k_chain": 5.35e9, "k_gather_packed": 1.48e9}}
+CHAIN_KERNELS = ("msgpu::k_chain", "void msgpu::k_chain_sub<32>", "void msgpu::k_chain_sub<16>", "void msgpu::k_chain_sub<8>")
 
 WORKLOADS = {
     # BASELINE.json configs[2]: the configuration the metric is quoted on
@@ -38,6 +46,38 @@ WORKLOADS = {
     "tiny": dict(n_reads=2_000, read_len=5_000, n_anchors=10_000, seed=7, name="2k x5 kb, 10k anchors (smoke)"),
 }
 
+
+# ---- HBM traffic of the dominant kernels from the committed counter captures ---------------------------------------------
+
+def pmc_traffic(workload, world, kernels):
+    """HBM bytes per launch of `kernels` together, from the newest profiles/*/pmc_summary.csv whose pmc_meta.json names
+    this (workload, world): FETCH_SIZE x 2 (the gfx950 correction of MI355X_MICROARCH.md) + WRITE_SIZE, both KiB per
+    dispatch.  -> (bytes or None, source / reason, {kernel: VALU issue numbers} or None)"""
+    import csv
+    best = None
+    for meta in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_meta.json"))):
+        try:
+            m = json.load(open(meta))
+        except (OSError, ValueError):
+            continue
+        f = os.path.join(os.path.dirname(meta), "pmc_summary.csv")
+        if m.get("workload") == workload and int(m.get("world", 0)) == world and os.path.exists(f):
+            best = f  # sorted(): the last match is the newest round
+    if best is None:
+        return None, "no counter capture under profiles/ for (%s, %d GPU): run tools/pmc_passes.sh" % (workload, world), None
+    rows = {r["kernel"]: r for r in csv.DictReader(open(best))}
+    total, valu = 0.0, {}
+    for k in kernels:
+        r = rows.get(k)
+        if r is None or not r.get("FETCH_SIZE") or not r.get("WRITE_SIZE"):
+            return None, "%s lacks FETCH_SIZE/WRITE_SIZE for %s" % (os.path.relpath(best, ROOT), k), None
+        total += (2.0 * float(r["FETCH_SIZE"]) + float(r["WRITE_SIZE"])) * 1024.0
+        if r.get("SQ_INSTS_VALU"):
+            valu[k] = float(r["SQ_INSTS_VALU"])
+    return total, os.path.relpath(best, ROOT), valu
+
+
+# ---- CPU baseline ----------------------------------------------------------------------------------------------------------
 
 def _cpu_sample(job):
     """One sample of the workload shape through the C oracle on one core (runs in a worker process: no torch, no GPU)."""
@@ -52,11 +92,21 @@ def _cpu_sample(job):
     return len(t["edges"]), len(t["ems"]), int(t["compat_checks"]), dt
 
 
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(workload, budget_reads, cores):
     """The CPU side of the comparison: the C oracle (a single-thread restatement of the reference's algorithm) on a
     bounded sample of the same workload shape -- once on one core, and once as `cores` independent samples (different
     seeds), one per core, at the same time.  The second figure is what a perfectly scaling multi-threaded CPU build
-    could reach on this host; the reference's own ThreadPool fan-out scales worse than that."""
+    could reach on those cores; the reference's own ThreadPool fan-out gets SLOWER with threads."""
     import multiprocessing as mp
     from concurrent.futures import ProcessPoolExecutor
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -67,8 +117,11 @@ def cpu_baseline(workload, budget_reads, cores):
     n_reads = max(1, int(w["n_reads"] * scale))
     n_anchors = max(1, int(w["n_anchors"] * scale))
     e1, m1, c1, dt1 = _cpu_sample((n_reads, w["read_len"], n_anchors, w["seed"]))
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     out = {
-        "value": e1 / dt1, "unit": "overlap-pairs/s", "cores": 1, "kind": "port",
+        "value": e1 / dt1, "unit": "overlap-pairs/s", "cores": 1, "kind": "port", "cpu_model": _cpu_model(),
+        "cores_available": avail,
+        "core_policy": "min(16, cores this process may run on): 16 = the GPU box's CPU share per GPU",
         "sample": "%d reads x %d bp, %d anchors (same generator/seed/density as the GPU workload, %.0f%% scale): "
                   "%d edges, %d EdgeMatches, %d compat checks in %.2f s" % (
                       n_reads, w["read_len"], n_anchors, 100 * scale, e1, m1, c1, dt1),
@@ -94,15 +147,53 @@ def cpu_baseline(workload, budget_reads, cores):
     return out
 
 
+# ---- the legs reported beside the metric ---------------------------------------------------------------------------------
+
+def host_to_host_leg(ctx, rows, n_batches, reps=6):
+    """SURVEY section 8(d) / BASELINE.md 3.4: wall time from [row table in pinned host memory] to [edge, EdgeMatch, order
+    and id tables in pinned host memory], through msgpu_overlap_batched (the ThreadPool replacement)."""
+    from muchsalsa_amd import overlap
+    pinned = overlap.PinnedRows(rows)
+    try:
+        ctx.overlap_batched(pinned, n_batches, copy=False)  # warm-up: pinned result arena, second table set
+        walls, infos = [], []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            t, info = ctx.overlap_batched(pinned, n_batches, copy=False)
+            walls.append(1e3 * (time.perf_counter() - t0))
+            infos.append(info)
+        k = int(np.argsort(walls)[len(walls) // 2])
+        n_edges, nbytes = int(len(t["edges"])), int(sum(t[x].nbytes for x in ("edges", "ems", "orders", "ids")))
+        ok = bool(np.array_equal(t["edges"]["em_off"], np.concatenate([[0], np.cumsum(t["edges"]["em_cnt"])[:-1]]))
+                  and np.array_equal(t["ems"]["edge_idx"][:: max(1, len(t["ems"]) // 1000)],
+                                     np.repeat(np.arange(n_edges, dtype=np.uint32), t["edges"]["em_cnt"])[
+                                         :: max(1, len(t["ems"]) // 1000)]))
+        wall = walls[k]
+        h2d = rows.nbytes
+        return {"ms": wall, "overlap_pairs_per_s": n_edges / (wall * 1e-3), "batches": int(infos[k]["n_batches"]),
+                "rows_bytes_h2d": int(h2d), "table_bytes_d2h": nbytes,
+                "load_ms": infos[k]["load_ms"], "first_batch_ms": infos[k]["first_batch_ms"],
+                "compute_done_ms": infos[k]["compute_done_ms"], "ms_samples": [round(x, 3) for x in walls],
+                "link_gbs_over_whole_call": (h2d + nbytes) / (wall * 1e-3) / 1e9,
+                "tables_consistent": ok,
+                "floor": "the link: %.0f MB up + %.0f MB down at the ~55 GB/s PCIe Gen5 x16 delivers here = %.1f ms; the "
+                         "index build and the first batch (~1 ms) cannot hide behind a copy" % (
+                             h2d / 1e6, nbytes / 1e6, (h2d + nbytes) / 55e9 * 1e3),
+                "stage": "rows in pinned host memory -> msgpu_overlap_batched (H2D once, index once, %d windows of owner "
+                         "reads; window k's tables copied out while window k+1 computes) -> four tables in pinned host "
+                         "memory; median of %d calls" % (int(infos[k]["n_batches"]), reps)}
+    finally:
+        pinned.close()
+
+
 def consensus_leg(torch, dev, world, rank, w, steps, warmup):
     """Device half of the consensus stage (A9) on the same synthetic reads: slice / reverse-complement / stitch.
 
     Sequences: a random genome; read i = genome[start_i : start_i + L], reverse-complemented for '-' reads (built on the
-    device with the gather kernel itself and installed as the nanopore store).  Layout (host, numpy, NOT timed -- the
-    reference's layout logic, assemblePath's anchor DAG, is not built yet): reads in genome order stitched by the
-    updateConsensusBase append rule (ap.cpp:205-229: a read contributes the part that extends the contig) -> target
-    contigs; every read, oriented to the genome strand, is a query.  Timed: the gather kernel producing target+queries.
-    Checked at full size: the stitched target equals the genome intervals it covers, byte for byte.
+    device with the gather kernel itself and installed as the nanopore store).  Layout (host, numpy, not timed): reads in
+    genome order stitched by the updateConsensusBase append rule (ap.cpp:205-229: a read contributes the part that
+    extends the contig) -> target contigs; every read, oriented to the genome strand, is a query.  Timed: the gather
+    kernel producing target+queries.  Checked at full size: the stitched target equals the genome, byte for byte.
     """
     from muchsalsa_amd import sequences as S, synth
     from muchsalsa_amd._lib import COPY_DTYPE, COPY_ILLUMINA, COPY_REVCOMP
@@ -118,7 +209,6 @@ def consensus_leg(torch, dev, world, rank, w, steps, warmup):
     stream = tstream.cuda_stream
     store.upload_device(S.ILLUMINA, genome.data_ptr(), G, [0], [G])  # the genome as "unitig 0"
 
-    # reads on the device: one piece per read out of the genome
     mk = np.zeros(n_reads, dtype=COPY_DTYPE)
     mk["src_off"], mk["dst_off"], mk["len"] = r_start, np.arange(n_reads, dtype=np.uint64) * L, L
     mk["flags"] = COPY_ILLUMINA | np.where(r_fwd, 0, COPY_REVCOMP).astype(np.uint32)
@@ -130,7 +220,6 @@ def consensus_leg(torch, dev, world, rank, w, steps, warmup):
     del d_reads
     store.pack()  # 2 bits per base in HBM (+ exception list, empty here): the form the timed gather reads
 
-    # layout: append rule over reads in genome order
     order = np.argsort(r_start, kind="stable")
     st, en = r_start[order], r_start[order] + L
     cur = np.maximum.accumulate(np.concatenate([[0], en[:-1]]))  # contig end before each read
@@ -141,7 +230,6 @@ def consensus_leg(torch, dev, world, rank, w, steps, warmup):
     t_off = np.concatenate([[0], np.cumsum(t_len)[:-1]]).astype(np.uint64)
     T = int(t_len.sum())
     tgt = np.zeros(len(rid), dtype=COPY_DTYPE)
-    # genome interval [lo, hi) of read r: read coordinates lo-start.. (forward) / start+L-hi.. (reverse strand)
     left = np.where(fwd, lo - r_start[rid], r_start[rid] + L - hi)
     tgt["src_off"], tgt["dst_off"], tgt["len"] = rid.astype(np.uint64) * L + left.astype(np.uint64), t_off, t_len
     tgt["flags"] = np.where(fwd, 0, COPY_REVCOMP).astype(np.uint32)
@@ -169,7 +257,6 @@ def consensus_leg(torch, dev, world, rank, w, steps, warmup):
     ms = ev0.elapsed_time(ev1) / steps
     assert ms > 0.5 * wall_ms - 0.05, "event timing (%.4f ms) disagrees with the wall clock (%.4f ms)" % (ms, wall_ms)
 
-    # full-size check: the stitched target equals the genome it covers; queries equal the genome under each read
     exp = np.zeros(len(rid), dtype=COPY_DTYPE)
     exp["src_off"], exp["dst_off"], exp["len"], exp["flags"] = lo.astype(np.uint64), t_off, t_len, COPY_ILLUMINA
     want = torch.empty(max(T, 1), dtype=torch.uint8, device=dev)
@@ -188,17 +275,11 @@ def consensus_leg(torch, dev, world, rank, w, steps, warmup):
             "bases_this_rank": bases_mine, "verified": ok}
 
 
-def assemble_leg(torch, dev, w, rows, read_names, anchor_names, tables, window_mb):
-    """assemblePath (A9) end to end on a bounded sample: every read starting in the first `window_mb` Mb of the synthetic
-    genome is chained into paths (muchsalsa_amd.synth.chain_paths, the stand-in for linearizeGraph) over the overlap
-    tables the timed steps just produced; then, timed: host layout of every path (msgpu_assembly_add_path) and ONE
-    gather + FASTA-wrapping pass on the device with the texts copied back (msgpu_assembly_finish).  Self-check with the
-    product's own meter: the banded edit distance of every query record against the stretch of its contig that its PAF
-    line names (msgpu_assembly_validate).  Byte parity with the restatement of ap.cpp is the tests' job
-    (tests/test_gpu_assemble.py); nothing under oracle/ is touched here."""
+def build_stores(torch, dev, w, read_names, anchor_names):
+    """The two sequence stores of the workload, keyed by Registry id, cut out of the synthetic genome on the device and
+    packed to 2 bits per base.  -> (store, read starts, read strands) by Registry id"""
     from muchsalsa_amd import sequences as S, synth
     from muchsalsa_amd._lib import COPY_DTYPE, COPY_ILLUMINA, COPY_REVCOMP
-    from muchsalsa_amd.assembly import Assembly
     n_reads, L, seed = w["n_reads"], w["read_len"], w["seed"]
     G, r_start, r_fwd = synth.read_layout(n_reads, L, seed)
     a_start, a_len = synth.anchor_layout(n_reads, L, w["n_anchors"], seed)
@@ -210,7 +291,6 @@ def assemble_leg(torch, dev, w, rows, read_names, anchor_names, tables, window_m
         torch.randint(0, 4, (G,), device=dev, generator=gen)]
     store = S.SeqStore(device=dev.index)
     store.upload_device(S.ILLUMINA, genome.data_ptr(), G, [0], [G])
-    # the two stores, keyed by Registry id, cut out of the genome on the device
     rs, rf = r_start[read_orig], r_fwd[read_orig]
     mk = np.zeros(len(read_orig), dtype=COPY_DTYPE)
     mk["src_off"], mk["dst_off"], mk["len"] = rs, np.arange(len(rs), dtype=np.uint64) * L, L
@@ -229,21 +309,22 @@ def assemble_leg(torch, dev, w, rows, read_names, anchor_names, tables, window_m
     store.upload_device(S.ILLUMINA, d_anch.data_ptr(), d_anch.numel(), aoff, al)
     del d_reads, d_anch
     store.pack()
+    return store, rs, rf, G
 
-    t0 = time.perf_counter()
-    paths = synth.chain_paths(tables, rs, rf, L, int(window_mb * 1e6), max_reads=12)
-    t_paths = time.perf_counter() - t0
-    prepared = [Assembly.prepare(p, st, None, None, i) for i, (p, st) in enumerate(paths)]
-    threads = max(1, min(16, os.cpu_count() or 1))
-    warm = Assembly(store)  # warm-up pass (untimed), like the W warm-up steps of the overlap half: first-touch
-    warm.set_rows(rows)     # allocations, page pinning, code-object load
+
+def assemble_paths(store, rows, prepared, threads, band=64, reps=3):
+    """assemblePath over prepared path inputs, timed: install the VertexMatch table (msgpu_assembly_set_rows, once per
+    job) + host layout of every path (msgpu_assembly_add_paths) + ONE gather + FASTA wrapping with the texts copied back
+    (msgpu_assembly_finish).  Medians of `reps` fresh assemblies.  Self-check: msgpu_assembly_validate (banded edit
+    distance of every query against the stretch of its contig its PAF line names)."""
+    from muchsalsa_amd.assembly import Assembly
+    warm = Assembly(store)  # warm-up (untimed), like the W warm-up steps of the overlap half
+    warm.set_rows(rows)
     warm.add_prepared_batch(prepared, threads)
     warm.finish()
     warm.close()
-    # Host-side times on a shared box are noisy (a scheduler hiccup once turned 1 ms of layout into 8): the leg is run
-    # on REPS fresh assemblies and the medians are reported, with every sample listed beside them.
-    REPS, samples, asm = 5, [], None
-    for _ in range(REPS):
+    samples, asm = [], None
+    for _ in range(reps):
         if asm is not None:
             asm.close()
         asm = Assembly(store)
@@ -253,7 +334,6 @@ def assemble_leg(torch, dev, w, rows, read_names, anchor_names, tables, window_m
         t0 = time.perf_counter()
         status = asm.add_prepared_batch(prepared, threads)
         t_l = time.perf_counter() - t0
-        assert not status.any(), "a synthetic chain was rejected: %r" % status
         t0 = time.perf_counter()
         asm.finish()
         t_d = time.perf_counter() - t0
@@ -261,27 +341,112 @@ def assemble_leg(torch, dev, w, rows, read_names, anchor_names, tables, window_m
     t_layout, t_device, t_index = (float(np.median([x[k] for x in samples])) for k in range(3))
     info, qinfo = asm.paths, asm.queries
     T, Q = int(info["target_len"].sum()), int(qinfo["len"].sum())
-    # A10: the banded anti-diagonal DP kernel as the assembly's self-check (every query against its PAF window)
-    band = 64
     asm.validate(band)  # warm-up
     t0 = time.perf_counter()
     dist, cells = asm.validate(band)
     t_val = time.perf_counter() - t0
-
-    res = {"paths": len(paths), "reads_on_paths": int(sum(len(p) for p, _ in paths)), "target_bases": T,
-            "query_bases": Q, "queries": int(len(qinfo)), "pieces": int(len(asm.pieces)),
-            "layout_ms": 1e3 * t_layout, "layout_threads": threads, "device_ms": 1e3 * t_device, "row_index_ms": 1e3 * t_index,
-            "timing": "medians of %d fresh assemblies" % REPS,
-            "layout_ms_samples": [round(1e3 * x[0], 3) for x in samples],
-            "device_ms_samples": [round(1e3 * x[1], 3) for x in samples],
-            "path_builder_ms_untimed": 1e3 * t_paths,
-            "text_bytes": len(asm.text(0)) + len(asm.text(1)) + len(asm.text(2)), "window_mb": window_mb,
-            "validate": {"kernel": "k_edit_distance", "band": band, "pairs": int(len(dist)), "ms_incl_copies": 1e3 * t_val,
-                         "dp_cells": cells, "dp_gcells_per_s": cells / t_val / 1e9,
-                         "queries_within_band": int((dist <= band).sum()),
-                         "median_distance": float(np.median(dist)) if len(dist) else None}}
-    store.close()  # closes the assembly laid out over it as well
+    tot_ms = 1e3 * (t_index + t_layout + t_device)
+    res = {"paths": int(len(info)), "paths_rejected": int((status != 0).sum()), "target_bases": T, "query_bases": Q,
+           "queries": int(len(qinfo)), "pieces": int(len(asm.pieces)),
+           "row_index_ms": 1e3 * t_index, "layout_ms": 1e3 * t_layout, "layout_threads": threads,
+           "device_ms": 1e3 * t_device, "total_ms": tot_ms,
+           "consensus_mbases_per_s": T / (tot_ms * 1e-3) / 1e6 if tot_ms > 0 else 0.0,
+           "consensus_mbases_per_s_without_row_index": T / (1e3 * (t_layout + t_device) * 1e-3) / 1e6 if T else 0.0,
+           "timing": "medians of %d fresh assemblies; total = row_index + layout + device" % reps,
+           "text_bytes": len(asm.text(0)) + len(asm.text(1)) + len(asm.text(2)),
+           "validate": {"kernel": "k_edit_distance", "band": band, "pairs": int(len(dist)), "ms_incl_copies": 1e3 * t_val,
+                        "dp_cells": cells, "dp_gcells_per_s": cells / t_val / 1e9 if t_val > 0 else 0.0,
+                        "queries_within_band": int((dist <= band).sum()),
+                        "median_distance": float(np.median(dist)) if len(dist) else None}}
+    asm.close()
     return res
+
+
+def aux_legs(torch, dev, args, w, ctx, rows, read_names, anchor_names):
+    """What follows the chaining fan-out in main() on the job's own tables, never inside `value`:
+    findContractionEdges on the GPU (tables still resident), the host graph stage (src/main.cpp:183-310), and
+    assemblePath (a) over the paths linearizeGraph yields and (b) over chains that tile the whole synthetic genome."""
+    from muchsalsa_amd import synth
+    from muchsalsa_amd.assembly import Assembly
+    from muchsalsa_amd.graph import GraphStage
+    torch.cuda.synchronize()
+    ctx.find_contraction_edges()  # warm-up: arena allocation
+    t0 = time.perf_counter()
+    contraction = ctx.find_contraction_edges()
+    t_contr = time.perf_counter() - t0
+    tables = ctx.tables()
+    read_len, read_first = ctx.reads()
+    threads = max(1, min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)))
+    graph_leg = {"find_contraction_edges_ms_incl_copy_back": 1e3 * t_contr,
+                 "contraction_edges": int((contraction >= 0).sum()), "shadow_edges": int(tables["edges"]["shadow"].sum())}
+    best = None
+    for _ in range(3):  # host times on a shared box are noisy: best of three fresh graphs
+        t0 = time.perf_counter()
+        gs = GraphStage(tables, read_len, read_first)
+        t_build = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        gs.clean_up(contraction, None)
+        t_clean = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        gs.linearize(threads)
+        t_lin = time.perf_counter() - t0
+        if best is None or t_build + t_clean + t_lin < sum(best[:3]):
+            if best is not None:
+                best[3].close()
+            best = [t_build, t_clean, t_lin, gs]
+        else:
+            gs.close()
+    t_build, t_clean, t_lin, gs = best
+    st = gs.stats
+    graph_leg.update({"graph_build_ms": 1e3 * t_build, "clean_up_ms": 1e3 * t_clean, "linearize_ms": 1e3 * t_lin,
+                      "host_total_ms": 1e3 * (t_build + t_clean + t_lin), "linearize_threads": threads,
+                      "vertices_after": int(st.n_vertices), "edges_after": int(st.n_edges),
+                      "decycled_edges": int(st.n_decycled_edges), "components": int(st.n_components),
+                      "paths": int(st.n_paths), "path_reads": int(st.n_path_reads),
+                      "stage": "flat-CSR host graph stage (csrc/graph_stage.cpp) on the job's 1 M-edge graph; best of 3"})
+    ctx.close()  # give the arena back before the sequence buffers
+    store, rs, rf, G = build_stores(torch, dev, w, read_names, anchor_names)
+    # (a) the reference's own flow: the paths linearizeGraph found
+    prepared = [(gs.path_input(i), gs) for i in range(gs.path_count)]
+    if prepared:
+        graph_leg["assemble_path_over_these_paths"] = assemble_paths(store, rows, prepared, threads)
+    gs.close()
+    # (b) chains tiling the genome (a window of it with --assemble-window-mb): the consensus stage at the size of the job
+    window = int(args.assemble_window_mb * 1e6) if args.assemble_window_mb > 0 else G
+    t0 = time.perf_counter()
+    paths = synth.chain_paths(tables, rs, rf, w["read_len"], min(window, G), max_reads=12)
+    t_paths = time.perf_counter() - t0
+    prepared = [Assembly.prepare(p, stp, None, None, i) for i, (p, stp) in enumerate(paths)]
+    asm_leg = assemble_paths(store, rows, prepared, threads)
+    asm_leg.update({"reads_on_paths": int(sum(len(p) for p, _ in paths)), "window_mb": min(window, G) / 1e6,
+                    "genome_mb": G / 1e6, "path_builder_ms_untimed": 1e3 * t_paths,
+                    "stage": "assemblePath over chains of <= 12 reads tiling the synthetic genome (synth.chain_paths over "
+                             "the tables the timed steps produced): VertexMatch table install + host layout of every "
+                             "path + one gather + FASTA wrapping + copy-back of target.fa / query.fa"})
+    store.close()
+    return asm_leg, graph_leg
+
+
+# ---- N > 1: start the ranks -------------------------------------------------------------------------------------------------
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` without a launcher: start N ranks (one per GPU) with torch.distributed.run BEFORE this
+    process touches the GPU, relay rank 0's JSON line, exit with the children's status."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE)
+    line = None
+    for ln in proc.stdout.decode(errors="replace").splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+    if line is not None:
+        print(line, flush=True)
+    return proc.returncode if proc.returncode != 0 or line is not None else 1
 
 
 def main():
@@ -293,16 +458,24 @@ def main():
     ap.add_argument("--cpu-sample-reads", type=int, default=25_000,
                     help="reads in the CPU-baseline sample (0 disables the baseline leg)")
     ap.add_argument("--cpu-cores", type=int, default=0,
-                    help="host cores of the CPU-baseline leg (0 = min(16, cpu count): the box's CPU share per GPU)")
+                    help="host cores of the CPU-baseline leg (0 = min(16, cores this process may run on))")
     ap.add_argument("--no-consensus", action="store_true", help="skip the consensus (sequence gather) leg")
-    ap.add_argument("--assemble-window-mb", type=float, default=10.0,
-                    help="assemblePath leg: chain the reads starting in the first this-many Mb of the genome (0 = skip)")
-    ap.add_argument("--graph-stage", action="store_true",
-                    help="also time findContractionEdges (GPU) and the host graph stage on the job's tables (slow on "
-                         "this workload: one 100k-vertex component, see DESIGN.md section 10)")
+    ap.add_argument("--kernels-only", action="store_true",
+                    help="only the timed steps (profiling runs): no host-to-host, consensus, graph or CPU leg")
+    ap.add_argument("--assemble-window-mb", type=float, default=0.0,
+                    help="assemblePath leg: chain the reads starting in the first this-many Mb of the genome "
+                         "(0 = the whole genome, the default; negative = skip the assemblePath / graph legs)")
+    ap.add_argument("--batches", type=int, default=8, help="windows of the host-to-host leg (msgpu_overlap_batched)")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the N>1 exchange path (all-gather + merge) even at world size 1 (used by the GPU tests)")
+    ap.add_argument("--self-launch", action="store_true",
+                    help="start the rank processes through torch.distributed.run even for --gpus 1 (tests the relay)")
     args = ap.parse_args()
+    if args.kernels_only:
+        args.no_consensus, args.cpu_sample_reads, args.assemble_window_mb = True, 0, -1.0
+
+    if (args.gpus > 1 or args.self_launch) and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args, [a for a in sys.argv[1:] if a != "--self-launch"]))
 
     # stdout must carry exactly one JSON line: libraries (RCCL prints a version banner on stdout) write to fd 1 while
     # we run, so fd 1 is pointed at stderr for the duration and the JSON line goes to the saved descriptor.
@@ -319,14 +492,17 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    multi = world > 1 or args.force_dist
+    # started by a launcher (torchrun sets TORCHELASTIC_RUN_ID) = the distributed path, even with one rank
+    multi = world > 1 or args.force_dist or "TORCHELASTIC_RUN_ID" in os.environ
+    rccl_ranks = None
     if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+        rccl_ranks = dist.get_world_size()  # what RCCL saw, not what the command line asked for
 
     w = WORKLOADS[args.workload]
     rows, read_names, anchor_names = synth.accepted_rows(
@@ -343,6 +519,7 @@ def main():
         ctx.set_shard(rank, world)
     ctx.set_id_space(len(read_names), len(anchor_names))  # Registry sizes, known to whoever parsed the PAF
     merged_keep = {}
+    exchange = D.SlabExchange(dev) if multi else None
 
     def step():
         ctx.load_rows_device(d_rows.data_ptr(), len(rows), keep_alive=d_rows)
@@ -350,12 +527,12 @@ def main():
         ctx.chaining_and_overlaps()
         c = ctx.counts()
         if multi:
-            # merge the edge list: ONE all-gather of the per-rank (edges | orders | ids) slab over xGMI, then the
-            # HIP compaction/re-base kernel (msgpu_merge_gathered)
+            # merge the edge list: ONE all-gather of the per-rank (header | edges | orders | ids) slab over xGMI, then the
+            # HIP compaction / re-base kernel (msgpu_merge_gathered)
             def fill(slab, offs):
                 ctx.copy_tables_device(d_edges=slab.data_ptr() + offs[0], d_orders=slab.data_ptr() + offs[1],
                                        d_ids=slab.data_ptr() + offs[2])
-            gathered, allc, offs, slab_bytes = D.gather_slabs((c.n_edges, c.n_orders, c.n_ids), fill, dev)
+            gathered, allc, offs, slab_bytes = exchange.gather((c.n_edges, c.n_orders, c.n_ids), fill)
             tot = allc.sum(axis=0)
             m_e = torch.empty(max(int(tot[0]), 1) * EDGE_DTYPE.itemsize, dtype=torch.uint8, device=dev)
             m_o = torch.empty(max(int(tot[1]), 1) * ORDER_DTYPE.itemsize, dtype=torch.uint8, device=dev)
@@ -397,56 +574,33 @@ def main():
             own = ctx.tables()
             merge_ok = merge_ok and me.tobytes() == own["edges"].tobytes() and mo.tobytes() == own["orders"].tobytes() \
                 and mi.tobytes() == own["ids"].tobytes()
+    rank_ms = None
     if multi:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+        mine = torch.tensor([dt], dtype=torch.float64, device=dev)
+        allt = torch.empty(world, dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(allt, mine)
+        per_rank = [1e3 * float(x) / args.steps for x in allt.cpu()]
+        rank_ms = {"min": min(per_rank), "max": max(per_rank), "per_rank": [round(x, 4) for x in per_rank]}
+        dt = max(float(x) for x in allt.cpu())  # MAX over ranks
         n_edges_total = int(allc[:, 0].sum())
     else:
         n_edges_total = int(c.n_edges)
 
-    asm_leg = graph_leg = None
-    def aux_legs():
-        nonlocal asm_leg, graph_leg
-        # what follows the chaining fan-out in main(): findContractionEdges on the GPU (tables still resident), then the
-        # host graph stage (src/main.cpp:183-310).  Reported beside the metric, never inside `value`.
-        torch.cuda.synchronize()
-        ctx.find_contraction_edges()  # warm-up: arena allocation
-        t0 = time.perf_counter()
-        contraction = ctx.find_contraction_edges()
-        t_contr = time.perf_counter() - t0
-        tables = ctx.tables()
-        graph_leg = {"find_contraction_edges_ms_incl_copy_back": 1e3 * t_contr,
-                     "contraction_edges": int((contraction >= 0).sum()),
-                     "shadow_edges": int(tables["edges"]["shadow"].sum())}
-        if args.graph_stage:
-            from muchsalsa_amd.graph import GraphStage
-            read_len, read_first = ctx.reads()
-            t0 = time.perf_counter()
-            gs = GraphStage(tables, read_len, read_first)
-            t_build = time.perf_counter() - t0
-            t0 = time.perf_counter()
-            gs.clean_up(contraction, None)
-            t_clean = time.perf_counter() - t0
-            t0 = time.perf_counter()
-            gs.linearize()
-            t_lin = time.perf_counter() - t0
-            st = gs.stats
-            graph_leg.update({"graph_build_ms": 1e3 * t_build, "clean_up_ms": 1e3 * t_clean, "linearize_ms": 1e3 * t_lin,
-                              "vertices_after": int(st.n_vertices), "edges_after": int(st.n_edges),
-                              "decycled_edges": int(st.n_decycled_edges), "components": int(st.n_components),
-                              "paths": int(st.n_paths), "path_reads": int(st.n_path_reads)})
-            gs.close()
-        ctx.close()
-        asm_leg = assemble_leg(torch, dev, w, rows, read_names, anchor_names, tables, args.assemble_window_mb)
-        del tables
-
-    # the legs reported BESIDE the metric must never cost the metric line itself
-    if world == 1 and rank == 0 and args.assemble_window_mb > 0 and not args.no_consensus:
+    h2h = asm_leg = graph_leg = None
+    errors = {}
+    if world == 1 and rank == 0 and not args.kernels_only:
         try:
-            aux_legs()
-        except Exception as exc:  # noqa: BLE001
-            asm_leg = {"error": "%s: %s" % (type(exc).__name__, exc)}
+            h2h = host_to_host_leg(ctx, rows, args.batches)
+        except Exception as exc:  # noqa: BLE001 -- the legs reported BESIDE the metric must never cost the metric line
+            errors["host_to_host"] = "%s: %s" % (type(exc).__name__, exc)
+        if args.assemble_window_mb >= 0 and not args.no_consensus:
+            try:
+                ctx.load_rows_device(d_rows.data_ptr(), len(rows), keep_alive=d_rows)  # the job's tables again
+                ctx.calculate_edges()
+                ctx.chaining_and_overlaps()
+                asm_leg, graph_leg = aux_legs(torch, dev, args, w, ctx, rows, read_names, anchor_names)
+            except Exception as exc:  # noqa: BLE001
+                errors["assemble_path"] = "%s: %s" % (type(exc).__name__, exc)
     cons = None
     if not args.no_consensus:
         ctx.close()  # give the arena back before the ~3 GB of sequence buffers
@@ -455,25 +609,32 @@ def main():
         except Exception as exc:  # noqa: BLE001
             if multi:
                 raise  # the other ranks are waiting in the all-reduce below
-            cons = None
-            consensus_error = "%s: %s" % (type(exc).__name__, exc)
-        else:
-            consensus_error = None
-    else:
-        consensus_error = None
-    if cons is not None:
-        if multi:
-            tt = torch.tensor([cons["ms"]], dtype=torch.float64, device=dev)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            cons["ms"] = float(tt.item())
+            errors["consensus"] = "%s: %s" % (type(exc).__name__, exc)
+    if cons is not None and multi:
+        tt = torch.tensor([cons["ms"]], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        cons["ms"] = float(tt.item())
 
     if rank == 0:
         ms_per_step = 1e3 * dt / args.steps
-        # algorithmic bytes of the dominant kernel (k_chain), SURVEY.md section 8(d):
-        #   96 B per EdgeMatch (32 B EdgeMatch written + two 32 B VertexMatch rows read) + 64 B per order + 4 B per id
+        # algorithmic bytes of the dominant kernels: 96 B per EdgeMatch (32 B EdgeMatch written +
+        # two 32 B VertexMatch rows read) + 64 B per order + 4 B per id; one launch set processes all edges of the rank
         alg_bytes = 96 * c.n_ems + 64 * c.n_orders + 4 * c.n_ids
         k_ms = float(np.mean(chain_ms))
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        traffic, traffic_src, valu = pmc_traffic(args.workload, world, CHAIN_KERNELS)
+        roof = {"bound": "hbm", "kernel": "k_chain + k_chain_sub<32> + k_chain_sub<16> + k_chain_sub<8> (one pass over "
+                                          "the edges, four launches by edge size)",
+                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": traffic, "traffic_source": traffic_src,
+                "algorithmic_bytes_per_launch": int(alg_bytes), "kernel_ms": k_ms,
+                "note": "kernel_ms = the four launches together (HIP events around them on the launch stream); these "
+                        "kernels are bound by vector-ALU issue, not by HBM (valu_issue_frac)"}
+        if valu and k_ms > 0:
+            # SQ_INSTS_VALU counts wave-instructions; one costs 4 cycles of its SIMD's issue (MI355X_MICROARCH.md); 1024 SIMDs
+            insts = sum(valu.values())
+            roof["valu_issue_frac"] = insts * 4.0 / (k_ms * 1e-3 * 2.4e9 * 1024)
+            roof["valu_note"] = "SQ_INSTS_VALU of the four kernels (%s) x 4 cycles / (kernel_ms x 2.4 GHz x 1024 SIMDs)" % traffic_src
         out = {
             "metric": "overlap-pairs/s", "value": n_edges_total / (dt / args.steps), "unit": "overlap-pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
@@ -483,27 +644,27 @@ def main():
                        "anchors": int(c.n_anchors), "edges": n_edges_total, "edgematches_rank0": int(c.n_ems),
                        "orders_rank0": int(c.n_orders), "parallelism": "edges sharded by v1 %% %d" % world,
                        "edges_proven_clean_rank0": int(c.n_edges_fastpath), "merged_edge_list_consistent": merge_ok,
-                       "note": "value = overlap half of the metric; the consensus half is reported under 'consensus' "
-                               "(the gather kernel alone at full size) and 'assemble_path' (assemblePath end to end: "
-                               "host layout + gather + FASTA wrapping, on a bounded sample of paths)"},
+                       "note": "value = the overlap half of the metric with the row table resident in HBM; host_to_host = "
+                               "the same job from and to pinned host memory; the consensus half is under 'consensus' "
+                               "(gather kernel at full size), 'assemble_path' (assemblePath over the whole genome) and "
+                               "'graph_stage' (the paths the real graph stage yields)"},
             "stage_ms": {"index": tm.index_ms, "candidates": tm.candidates_ms, "chain_total": tm.chain_ms,
                          "chain_kernel": k_ms, "compact": tm.compact_ms},
-            "roofline": {"bound": "hbm", "kernel": "k_chain + k_chain_sub<32> + k_chain_sub<16> + k_chain_sub<8> (one pass "
-                                                   "over the edges, four launches by edge size)",
-                         "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": PMC_TRAFFIC_BYTES.get((args.workload, world), {}).get("k_chain"),
-                         "algorithmic_bytes_per_launch": int(alg_bytes), "kernel_ms": k_ms,
-                         "note": "kernel_ms = the four launches together (HIP events around them on the launch stream); "
-                                 "vector-ALU bound: 0.75-0.92 of the issue cycles; traffic is twice the algorithmic bytes because the "
-                                 "edges run in size order, not table order (rows of a read are re-fetched): "
-                                 "profiles/r1_08_final/README.md"},
+            "roofline": roof,
         }
+        if multi:
+            out["rccl_ranks"] = rccl_ranks
+            out["rank_ms_per_step"] = rank_ms
+            out["exchange"] = {"collectives_per_step": exchange.collectives / max(1, exchange.calls),
+                               "slab_bytes": int(exchange.slab_bytes), "regrows": exchange.regrows}
+        if h2h is not None:
+            out["host_to_host"] = h2h
         if cons is not None:
             # algorithmic bytes on the 2-bit store: 0.25 B read + 1 B written per base (SURVEY 8(d) counted 1 B + 1 B for a
             # byte-per-base source; that figure is kept as "bytes_if_byte_store" for comparison)
             gb = 1.25 * (cons["target_bases"] + cons["query_bases"]) / 1e9
             g_gbs = gb / (cons["ms"] * 1e-3)
+            g_traffic, g_src, _ = pmc_traffic(args.workload, world, ("msgpu::k_gather_packed",))
             out["consensus"] = {
                 "stage": "slice / reverse-complement / stitch kernel k_gather_packed on the 2-bit sequence store "
                          "(layout precomputed on the host, not timed)",
@@ -512,27 +673,22 @@ def main():
                 "target_bases": cons["target_bases"], "query_bases": cons["query_bases"], "pieces": cons["pieces"],
                 "ms": cons["ms"], "verified_against_genome": cons["verified"],
                 "roofline": {"bound": "hbm", "kernel": "k_gather_packed", "achieved": g_gbs, "peak": HBM_PEAK_GBS,
-                             "unit": "GB/s", "frac": g_gbs / HBM_PEAK_GBS,
-                             "traffic": PMC_TRAFFIC_BYTES.get((args.workload, world), {}).get("k_gather_packed"),
-                             "algorithmic_bytes_per_launch": int(gb * 1e9),
+                             "unit": "GB/s", "frac": g_gbs / HBM_PEAK_GBS, "traffic": g_traffic,
+                             "traffic_source": g_src, "algorithmic_bytes_per_launch": int(gb * 1e9),
                              "bytes_if_byte_store": int(2 * (cons["target_bases"] + cons["query_bases"])),
                              "note": "2 bits in + 1 byte out per base; the same launch on a byte-per-base source would "
                                      "move 2 B per base"},
             }
         if graph_leg is not None:
             out["graph_stage"] = graph_leg
-        if consensus_error is not None:
-            out["consensus"] = {"error": consensus_error}
-        if asm_leg is not None and "error" in asm_leg:
+        if asm_leg is not None:
             out["assemble_path"] = asm_leg
-        elif asm_leg is not None:
-            tot_ms = asm_leg["layout_ms"] + asm_leg["device_ms"]
-            asm_leg["consensus_mbases_per_s"] = asm_leg["target_bases"] / (tot_ms * 1e-3) / 1e6
-            asm_leg["stage"] = ("assemblePath on a bounded sample: host layout of every path + one gather + FASTA "
-                                "wrapping + copy-back of target.fa/query.fa (layout_ms + device_ms)")
-            out["assemble_path"] = asm_leg
+        for k, v in errors.items():
+            out.setdefault(k, {})
+            out[k] = {"error": v}
         if world == 1 and args.cpu_sample_reads > 0:
-            cores = args.cpu_cores if args.cpu_cores > 0 else max(1, min(16, os.cpu_count() or 1))
+            avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+            cores = args.cpu_cores if args.cpu_cores > 0 else max(1, min(16, avail))
             try:
                 out["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_sample_reads, cores)
             except Exception as exc:  # noqa: BLE001

@@ -56,6 +56,68 @@ def gather_slabs(counts, fill_slab, device, group=None):
     return gathered, all_counts, offs, slab_bytes
 
 
+HEADER = 256  # bytes in front of a slab: int64 {n_edges, n_orders, n_ids} of the sending rank
+
+
+class SlabExchange:
+    """The exchange step as ONE collective per call (north_star: "a single RCCL all-gather over xGMI to merge the edge
+    list").  gather_slabs() needs two -- the ranks first tell each other their table sizes so that everyone can size the
+    slab.  Here every slab starts with a header carrying its sender's counts, and the slab capacity is remembered from
+    call to call: the first call agrees on it with one small all-gather, later calls go straight to the slab
+    all-gather.  A rank whose tables outgrew the capacity sends its header alone; every rank reads the same headers, so
+    all of them enlarge the capacity and repeat the collective together (counted in `regrows`).  Identical decisions on
+    every rank by construction: nothing but gathered data enters them."""
+
+    def __init__(self, device, group=None, slack=1.125):
+        self.device, self.group, self.slack = device, group, slack
+        self.cap = None
+        self.calls = self.collectives = self.regrows = 0
+        self.slab_bytes = 0
+
+    def _layout(self):
+        offs, size = slab_layout(self.cap)
+        return tuple(HEADER + o for o in offs), HEADER + size
+
+    def _agree(self, counts):
+        import torch
+        import torch.distributed as dist
+        world = dist.get_world_size(self.group)
+        mine = torch.tensor([int(c) for c in counts], dtype=torch.int64, device=self.device)
+        allc = torch.empty(world * 3, dtype=torch.int64, device=self.device)
+        dist.all_gather_into_tensor(allc, mine, group=self.group)
+        self.collectives += 1
+        self._grow(allc.cpu().numpy().reshape(world, 3))
+
+    def _grow(self, all_counts):
+        need = all_counts.max(axis=0)
+        self.cap = tuple(int(n * self.slack) + 64 for n in need)
+
+    def gather(self, counts, fill_slab):
+        """counts = (n_edges, n_orders, n_ids) of this rank; fill_slab(slab, offs) writes the three tables at the byte
+        offsets offs.  -> (gathered, all_counts [world, 3], offs, slab_bytes): the arguments msgpu_merge_gathered takes."""
+        import torch
+        import torch.distributed as dist
+        world = dist.get_world_size(self.group)
+        self.calls += 1
+        if self.cap is None:
+            self._agree(counts)
+        while True:
+            offs, slab_bytes = self._layout()
+            self.slab_bytes = slab_bytes
+            slab = torch.empty(slab_bytes, dtype=torch.uint8, device=self.device)  # padding is never read
+            slab[:24].view(torch.int64).copy_(torch.tensor([int(c) for c in counts], dtype=torch.int64))
+            if all(int(c) <= k for c, k in zip(counts, self.cap)):
+                fill_slab(slab, offs)
+            gathered = torch.empty(world * slab_bytes, dtype=torch.uint8, device=self.device)
+            dist.all_gather_into_tensor(gathered, slab, group=self.group)  # the one collective of the path
+            self.collectives += 1
+            heads = gathered.view(world, slab_bytes)[:, :24].contiguous().view(torch.int64).cpu().numpy().reshape(world, 3)
+            if (heads <= np.asarray(self.cap, dtype=np.int64)[None, :]).all():
+                return gathered, heads.astype(np.int64), offs, slab_bytes
+            self._grow(heads)
+            self.regrows += 1
+
+
 def split_gathered_host(gathered, all_counts, offs, slab_bytes):
     """Host view of a gathered buffer: list of per-rank {edges, orders, ids} numpy tables."""
     buf = np.asarray(gathered, dtype=np.uint8)

@@ -53,6 +53,28 @@ def _worker(rank, world, port, rows_bytes, out_dir):
         got["edges"]["em_off"] = 0
         got["ems"] = want["ems"] = np.zeros(0, dtype=full["ems"].dtype)
         assert_tables_equal(got, want, "rank %d" % rank)
+        # the one-collective form (header inside the slab, capacity remembered): first call agrees on a capacity, the
+        # second goes straight to the slab all-gather, a rank that outgrows the capacity makes every rank repeat
+        ex = D.SlabExchange(torch.device("cpu"))
+        for call in range(3):
+            if call == 2:  # rank 0's tables outgrow the remembered capacity (its own tables repeated)
+                grown = {k: np.concatenate([mine[k]] * 3) for k in ("edges", "orders", "ids")} if rank == 0 else mine
+            else:
+                grown = mine
+
+            def fill2(slab, offs, t=grown):
+                for name, off in zip(("edges", "orders", "ids"), offs):
+                    b = torch.from_numpy(t[name].view(np.uint8).copy())
+                    slab[off: off + b.numel()] = b
+            cnt = (len(grown["edges"]), len(grown["orders"]), len(grown["ids"]))
+            g2, c2, offs2, sb2 = ex.gather(cnt, fill2)
+            assert np.array_equal(c2[rank], cnt)
+            parts = D.split_gathered_host(g2.numpy(), c2, offs2, sb2)
+            assert parts[rank]["orders"].tobytes() == grown["orders"].tobytes()
+            if call < 2:
+                m2 = D.canonicalize(D.merge_tables_host(parts))
+                assert m2["orders"].tobytes() == merged["orders"].tobytes() and m2["ids"].tobytes() == merged["ids"].tobytes()
+        assert ex.calls == 3 and ex.collectives == 1 + 1 + 1 + 2 and ex.regrows == 1, (ex.calls, ex.collectives, ex.regrows)
         open(os.path.join(out_dir, "ok%d" % rank), "w").write("ok")
     finally:
         dist.destroy_process_group()

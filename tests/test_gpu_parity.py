@@ -336,6 +336,29 @@ def test_bench_distributed_path_smoke():
     assert 0 < line["roofline"]["frac"] < 1
     assert line["config"]["merged_edge_list_consistent"] is True   # all-gather + merge reproduced our own tables
     assert line["consensus"]["verified_against_genome"] is True
+    assert line["rccl_ranks"] == 1 and line["rank_ms_per_step"]["min"] > 0
+    assert line["exchange"]["collectives_per_step"] < 1.5  # the slab all-gather alone once the capacity is agreed
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus N` without a launcher must start the rank processes itself (before touching the GPU) and
+    relay rank 0's line: exercised with one rank (--self-launch), which is all a one-GPU box can run."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--self-launch", "--workload",
+                          "tiny", "--steps", "2", "--warmup", "1", "--kernels-only"], env=env, capture_output=True,
+                         text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 1 and line["rccl_ranks"] == 1 and line["value"] > 0
+    assert line["config"]["merged_edge_list_consistent"] is True
 
 
 def test_find_contraction_edges_matches_oracle(oracle):
