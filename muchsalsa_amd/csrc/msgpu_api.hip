@@ -85,7 +85,7 @@ struct msgpu_ctx {
   // arena
   DevBuf rows_in, cnt_read, read_off, cursor, bkt_key, bkt_dead, by_read, read_cnt, alive_rank,
       anchor_cnt, anchor_off, anchor_first, anchor_off_gen, bkt2_idx, bkt2_line, by_anchor, read_len, read_first, scalars,
-      scan_tmp;
+      scan_tmp, vis16, spos2;
   DevBuf bound, cand_off, cand_j, cand_t, scr_v2, scr_start, n_cand, n_edge, n_visit_arr, lists, em_base, edge_base,
       visit_base, edges, edge_cand;
   DevBuf big_key, big_t, big_r2s, big_pfx, pair_tab, edge_fast, big_off;
@@ -160,7 +160,8 @@ void release_all(msgpu_ctx *c) {
                    &c->n_visit_arr, &c->lists, &c->em_base, &c->edge_base, &c->visit_base, &c->edges, &c->edge_cand,
                    &c->big_key, &c->big_t, &c->big_r2s, &c->big_pfx, &c->pair_tab, &c->edge_fast, &c->big_off, &c->ems, &c->order_scr, &c->ids_scr,
                    &c->edge_norders, &c->edge_nids, &c->order_base, &c->ids_base, &c->orders, &c->ids, &c->big_list, &c->cls_list,
-                   &c->big_elems, &c->big_paths, &c->alt_edges, &c->alt_ems, &c->alt_orders, &c->alt_ids};
+                   &c->big_elems, &c->big_paths, &c->alt_edges, &c->alt_ems, &c->alt_orders, &c->alt_ids, &c->vis16,
+                   &c->spos2};
   for (DevBuf *b : all) b->release();
 }
 
@@ -204,6 +205,8 @@ int build_index_once(msgpu_ctx *c, bool force_generic, bool two_pass, uint32_t *
   ENSURE(c, bkt2_idx, nz * 4);
   ENSURE(c, bkt2_line, nz * 4);
   ENSURE(c, by_anchor, nz * sizeof(IRow));
+  ENSURE(c, vis16, nz * 16);
+  ENSURE(c, spos2, nz * 8);
   ENSURE(c, read_len, (size_t(V) + 1) * 4);
   ENSURE(c, read_first, (size_t(V) + 1) * 4);
   {
@@ -228,7 +231,7 @@ int build_index_once(msgpu_ctx *c, bool force_generic, bool two_pass, uint32_t *
   }
 
   launch_index_pass1(st, c->d_rows, n, c->cnt_read.as<uint32_t>(), c->anchor_first.as<uint32_t>(), V, A, d_flags,
-                     scalar<uint32_t>(c, SC_ERR), c->bkt_key.as<IRow>(), cap);
+                     scalar<uint32_t>(c, SC_ERR), c->bkt_key.as<IRow>(), cap, c->spos2.as<uint2>());
   exclusive_scan<uint32_t>(st, c->cnt_read.as<uint32_t>(), V, c->read_off.as<uint32_t>(), c->scan_tmp.as<uint32_t>(),
                            scalar<uint32_t>(c, SC_TOTAL_A));
   if (!cap) launch_scatter_read(st, c->d_rows, n, c->read_off.as<uint32_t>(), c->cursor.as<uint32_t>(), c->bkt_key.as<IRow>());
@@ -236,7 +239,8 @@ int build_index_once(msgpu_ctx *c, bool force_generic, bool two_pass, uint32_t *
                    c->by_read.as<IRow>(), c->read_cnt.as<uint32_t>(),
                    c->alive_rank.as<uint32_t>(), c->anchor_cnt.as<uint32_t>(), c->bkt_dead.as<uint8_t>(), d_flags,
                    c->by_anchor.as<IRow>(), cap, c->d_rows, c->read_len.as<int32_t>(), c->read_first.as<uint32_t>(),
-                   scalar<uint32_t>(c, SC_ERR)); // fast mode: the sort writes the scaffold rows too; always: the Vertex facts
+                   scalar<uint32_t>(c, SC_ERR), c->spos2.as<uint2>(), c->vis16.as<uint4>()); // fast mode: the sort writes the scaffold rows too (at
+                                                                              // the places pass 1 left in spos2); always: the Vertex facts
   launch_check_read_order(st, c->read_first.as<uint32_t>(), V, scalar<uint32_t>(c, SC_ERR));
   // Fast mode (input grouped by anchor, ascending lines: what the PAF loader hands over) is finished here but for the
   // scaffold offsets, which are the speculative ones of pass 1; the flags come back with the read-back below and
@@ -265,7 +269,7 @@ int build_index_once(msgpu_ctx *c, bool force_generic, bool two_pass, uint32_t *
                           c->cursor.as<uint32_t>(), c->bkt2_idx.as<uint32_t>(), c->bkt2_line.as<uint32_t>(), d_flags);
     launch_rank_anchor(st, c->anchor_off.as<uint32_t>(), n, scalar<uint32_t>(c, SC_NALIVE), c->bkt2_idx.as<uint32_t>(),
                        c->bkt2_line.as<uint32_t>(), c->d_rows, c->alive_rank.as<uint32_t>(), c->by_anchor.as<IRow>(),
-                       d_flags);
+                       d_flags, c->read_off.as<uint32_t>(), c->by_read.as<IRow>(), c->vis16.as<uint4>());
     HIPCHK(c, hipGetLastError());
     if (int rc = read_scalars(c, c->ev[1])) return rc;
     n_alive = *host_scalar<uint32_t>(c, SC_NALIVE);
@@ -494,8 +498,8 @@ int msgpu_calculate_edges(msgpu_ctx *c) {
     const uint32_t  n_ones[2] = {0, 0};
     launch_index_init(st, zero, n_zero, ones, n_ones); // one launch instead of four memsets
   }
-  launch_bound(st, c->read_off.as<uint32_t>(), c->read_cnt.as<uint32_t>(), c->by_read.as<IRow>(),
-               c->anchor_off.as<uint32_t>(), V, c->shard, c->nshards, c->win_lo, c->win_hi, c->bound.as<uint32_t>());
+  launch_bound(st, c->read_off.as<uint32_t>(), c->read_cnt.as<uint32_t>(), c->vis16.as<uint4>(), V, c->shard, c->nshards,
+               c->win_lo, c->win_hi, c->bound.as<uint32_t>());
   exclusive_scan<uint64_t>(st, c->bound.as<uint32_t>(), V, c->cand_off.as<uint64_t>(), c->scan_tmp.as<uint64_t>(),
                            scalar<uint64_t>(c, SC_TOTAL_A));
   launch_classify_reads(st, c->read_cnt.as<uint32_t>(), c->bound.as<uint32_t>(), V, c->shard, c->nshards, c->win_lo,
@@ -518,6 +522,7 @@ int msgpu_calculate_edges(msgpu_ctx *c) {
   a.anchor_off     = c->anchor_off.as<uint32_t>();
   a.by_read        = c->by_read.as<IRow>();
   a.by_anchor      = c->by_anchor.as<IRow>();
+  a.vis            = c->vis16.as<uint4>();
   a.cand_off       = c->cand_off.as<uint64_t>();
   a.cand_j         = c->cand_j.as<uint32_t>();
   a.cand_t         = c->cand_t.as<uint32_t>();
@@ -529,9 +534,20 @@ int msgpu_calculate_edges(msgpu_ctx *c) {
   a.th_overlap     = c->p.th_overlap;
   a.big_stats      = scalar<unsigned long long>(c, SC_BIGSTATS);
   HIPCHK(c, hipMemsetAsync(a.big_stats, 0, 16, st));
+  // the LDS classes run side by side: the heavier, smaller classes on the side stream, so their tails overlap
+  const bool fork = (c->n_list[1] || c->n_list[2]) && c->n_list[0];
+  if (fork) {
+    HIPCHK(c, hipEventRecord(c->ev_side[0], st));
+    HIPCHK(c, hipStreamWaitEvent(c->side_stream, c->ev_side[0], 0));
+  }
+  hipStream_t st2 = fork ? c->side_stream : st;
+  launch_candidates(st2, a, 2, l2, c->n_list[2]);
+  launch_candidates(st2, a, 1, l1, c->n_list[1]);
   launch_candidates(st, a, 0, l0, c->n_list[0]);
-  launch_candidates(st, a, 1, l1, c->n_list[1]);
-  launch_candidates(st, a, 2, l2, c->n_list[2]);
+  if (fork) {
+    HIPCHK(c, hipEventRecord(c->ev_side[1], c->side_stream));
+    HIPCHK(c, hipStreamWaitEvent(st, c->ev_side[1], 0));
+  }
   if (c->n_list[3]) {
     ENSURE(c, big_key, tb * 8);
     ENSURE(c, big_t, tb * 4);
@@ -544,8 +560,6 @@ int msgpu_calculate_edges(msgpu_ctx *c) {
                            scalar<uint64_t>(c, SC_TOTAL_A));
   exclusive_scan<uint64_t>(st, c->n_edge.as<uint32_t>(), V, c->edge_base.as<uint64_t>(), c->scan_tmp.as<uint64_t>(),
                            scalar<uint64_t>(c, SC_TOTAL_B));
-  exclusive_scan<uint64_t>(st, c->n_visit_arr.as<uint32_t>(), V, c->visit_base.as<uint64_t>(),
-                           c->scan_tmp.as<uint64_t>(), scalar<uint64_t>(c, SC_TOTAL_C));
   HIPCHK(c, hipGetLastError());
   if (int rc = read_scalars(c)) return rc; // sizes of the edge / EdgeMatch tables
   const uint64_t *tot = host_scalar<uint64_t>(c, SC_TOTAL_A), *big = host_scalar<uint64_t>(c, SC_BIGSTATS);
@@ -553,7 +567,7 @@ int msgpu_calculate_edges(msgpu_ctx *c) {
   c->n_big_ems   = big[1];
   c->n_ems   = tot[0];
   c->n_edges = tot[1];
-  c->n_visit = tot[2];
+  c->n_visit = c->total_bound; // the scaffold rows visited = the bound (scaffolds in read-id order: only owned partners)
   if (c->n_edges >= 0xfffffff0ull) return fail(c, MSGPU_E_ARG, "edge table too large (%llu)", (unsigned long long)c->n_edges);
 
   ENSURE(c, edges, (c->n_edges ? c->n_edges : 1) * sizeof(msgpu_edge));

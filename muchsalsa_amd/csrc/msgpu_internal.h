@@ -10,8 +10,8 @@
 namespace msgpu {
 
 // 32-byte row of the two device tables (two 16-byte vector loads per row).
-//   by_read  : rows of one read sorted by (n_lo, n_hi, anchor) -- `other` = anchor id, pf = flags | own rank
-//   by_anchor: rows of one anchor (scaffold) sorted by line    -- `other` = read id,   pf = flags | rank in its read
+//   by_read  : rows of one read sorted by (n_lo, n_hi, anchor) -- `other` = anchor id, pf = flags | its place in by_anchor
+//   by_anchor: rows of one anchor (scaffold) sorted by read id -- `other` = read id,   pf = flags | rank in its read
 struct IRow {
   int32_t  n_lo, n_hi, i_lo, i_hi;
   uint32_t score, line, other, pf;
@@ -24,6 +24,7 @@ constexpr uint32_t PF_PRIM     = 1u << 31;
 struct CandArgs {
   const uint32_t *read_off, *read_cnt, *anchor_off;
   const IRow     *by_read, *by_anchor;
+  const uint4    *vis;  // per by_read row:   {i_lo, i_hi, first scaffold row behind it, rows behind it}
   const uint64_t *cand_off;     // per read: first slot of its candidate / edge scratch (exclusive scan of bound)
   uint32_t       *cand_j;       // sorted candidates: rank of the anchor in v1's row list
   uint32_t       *cand_t;       // sorted candidates: row of v2 in by_anchor
@@ -92,17 +93,19 @@ constexpr uint32_t IXF_SPARSE   = 2u; // an anchor id has no row
 constexpr uint32_t IXF_DUPS     = 4u; // a (read, anchor) pair occurs more than once
 constexpr uint32_t IXF_FORCE    = 8u; // host asked for the generic path
 constexpr uint32_t IXF_OVERFLOW = 16u; // one-pass build: a read has more rows than a bucket holds (host rebuilds in two passes)
+constexpr uint32_t IXF_BIGSCAF  = 32u; // a scaffold longer than the context pass 1 sorts it in
 void launch_index_init(hipStream_t st, uint32_t *const zero[4], const uint32_t n_zero[4], uint32_t *const ones[2],
                        const uint32_t n_ones[2]);
 void launch_index_pass1(hipStream_t st, const msgpu_row *rows, uint64_t n, uint32_t *cnt_read, uint32_t *anchor_first,
-                        uint32_t V, uint32_t A, uint32_t *flags, uint32_t *err, IRow *bkt_row, uint32_t cap);
+                        uint32_t V, uint32_t A, uint32_t *flags, uint32_t *err, IRow *bkt_row, uint32_t cap, uint2 *spos);
 void launch_check_read_order(hipStream_t st, const uint32_t *read_first, uint32_t V, uint32_t *err);
 void launch_scatter_read(hipStream_t st, const msgpu_row *rows, uint64_t n, const uint32_t *read_off, uint32_t *cursor,
                          IRow *bkt_row);
 void launch_sort_read(hipStream_t st, const uint32_t *read_off, const uint32_t *cnt_read, uint32_t V, const IRow *bkt_row,
                       IRow *by_read, uint32_t *read_cnt, uint32_t *alive_rank,
                       uint32_t *anchor_cnt, uint8_t *bkt_dead, uint32_t *flags, IRow *by_anchor, uint32_t cap,
-                      const msgpu_row *rows, int32_t *read_len, uint32_t *read_first, uint32_t *err);
+                      const msgpu_row *rows, int32_t *read_len, uint32_t *read_first, uint32_t *err,
+                      const uint2 *spos, uint4 *vis);
 void launch_select_anchor_off(hipStream_t st, const uint32_t *flags, const uint32_t *fast_off, const uint32_t *gen_off,
                               uint32_t A, uint32_t *anchor_off, uint32_t *d_n_alive, uint32_t n_rows);
 void launch_scatter_anchor(hipStream_t st, const msgpu_row *rows, uint64_t n, const uint32_t *alive_rank,
@@ -110,10 +113,10 @@ void launch_scatter_anchor(hipStream_t st, const msgpu_row *rows, uint64_t n, co
                            const uint32_t *flags);
 void launch_rank_anchor(hipStream_t st, const uint32_t *anchor_off, uint64_t n_rows, const uint32_t *d_n_alive,
                         const uint32_t *bkt_idx, const uint32_t *bkt_line, const msgpu_row *rows,
-                        const uint32_t *alive_rank, IRow *by_anchor, const uint32_t *flags);
-void launch_bound(hipStream_t st, const uint32_t *read_off, const uint32_t *read_cnt, const IRow *by_read,
-                  const uint32_t *anchor_off, uint32_t V, uint32_t shard, uint32_t nshards, uint32_t lo, uint32_t hi,
-                  uint32_t *bound);
+                        const uint32_t *alive_rank, IRow *by_anchor, const uint32_t *flags, const uint32_t *read_off,
+                        IRow *by_read, uint4 *vis);
+void launch_bound(hipStream_t st, const uint32_t *read_off, const uint32_t *read_cnt, const uint4 *vis, uint32_t V,
+                  uint32_t shard, uint32_t nshards, uint32_t lo, uint32_t hi, uint32_t *bound);
 void launch_classify_reads(hipStream_t st, const uint32_t *read_cnt, const uint32_t *bound, uint32_t V, uint32_t shard,
                            uint32_t nshards, uint32_t lo, uint32_t hi, uint32_t *l0, uint32_t *l1, uint32_t *l2,
                            uint32_t *l3, uint32_t *n_lists);

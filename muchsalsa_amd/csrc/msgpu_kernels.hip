@@ -17,6 +17,7 @@
 // with -ffp-contract=off: the reference's fp64 expressions are evaluated in its operation order, bit for bit.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "msgpu.h"
 #include "msgpu_internal.h"
@@ -79,7 +80,28 @@ __device__ __forceinline__ double rl_f64(double v, int lane) {
 __device__ __forceinline__ double std_max(double a, double b) { return (a < b) ? b : a; }
 __device__ __forceinline__ double std_min(double a, double b) { return (b < a) ? b : a; }
 
-// block-wide exclusive scan of one value per thread, 256 threads; returns exclusive prefix, total through *total
+// block-wide exclusive scan of one value per thread, NT threads; returns exclusive prefix, total through *total
+template <int NT> __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *s_wave /*[NT / 64]*/, uint32_t *total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t  inc  = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    uint32_t t = __shfl_up(inc, d);
+    if (lane >= d) inc += t;
+  }
+  if (lane == 63) s_wave[wave] = inc;
+  __syncthreads();
+  uint32_t base = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < NT / 64; ++w) {
+    const uint32_t x = s_wave[w];
+    base += w < wave ? x : 0u;
+    tot += x;
+  }
+  *total = tot;
+  __syncthreads();
+  return base + inc - v;
+}
 __device__ __forceinline__ uint32_t block_excl_scan_256(uint32_t v, uint32_t *s_wave /*[4]*/, uint32_t *total) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   uint32_t  inc  = v;
@@ -224,16 +246,53 @@ __global__ __launch_bounds__(256) void k_index_init(IndexInitArgs a) {
 // With cap != 0 the same pass also buckets the rows by read: every read owns `cap` slots (bkt_row[rd * cap ..]), a row
 // takes the slot its count atomic returns -- no offsets are needed, so the scan and the second pass over the table
 // (k_scatter_read) fall away.  A read with more than cap rows raises IXF_OVERFLOW and the host rebuilds in two passes.
+// Scaffolds are kept sorted by READ ID: read r then finds the partners it owns (read id > r, MatchMap.cpp:204-213) as the
+// stretch behind its own row, and never looks at the others.  With the input grouped by anchor (fast mode) the rows of a
+// scaffold sit next to each other: the scaffold starts `before` rows in front of row i, and row i belongs at the start
+// plus the number of the scaffold's rows with a lower read id.  Both are counted in an LDS tile with SCAF_HALO rows of
+// context on either side; a scaffold that does not fit the context raises IXF_BIGSCAF and the generic scaffold build
+// runs instead.
+constexpr int SCAF_HALO = 128;
 __global__ __launch_bounds__(256) void k_index_pass1(const msgpu_row *rows, uint64_t n, uint32_t *cnt_read,
                                                      uint32_t *anchor_first, uint32_t *flags, uint32_t V, uint32_t A,
-                                                     uint32_t *err, IRow *bkt_row, uint32_t cap) {
-  uint64_t i = static_cast<uint64_t>(blockIdx.x) * 256 + threadIdx.x;
+                                                     uint32_t *err, IRow *bkt_row, uint32_t cap, uint2 *spos) {
+  __shared__ uint32_t s_an[256 + 2 * SCAF_HALO], s_rd[256 + 2 * SCAF_HALO];
+  const uint64_t      i0 = static_cast<uint64_t>(blockIdx.x) * 256;
+  for (int t = threadIdx.x; t < 256 + 2 * SCAF_HALO; t += 256) {
+    const long long g  = static_cast<long long>(i0) - SCAF_HALO + t;
+    const bool      in = g >= 0 && static_cast<uint64_t>(g) < n;
+    uint2           ar = make_uint2(0xffffffffu, 0u); // no valid anchor id (ids are < A <= 2^32 - 1)
+    if (in) ar = *reinterpret_cast<const uint2 *>(&rows[g]); // anchor_id, read_id: the first eight bytes of a row
+    s_an[t] = ar.x;
+    s_rd[t] = ar.y;
+  }
+  __syncthreads();
+  uint64_t i = i0 + threadIdx.x;
   if (i >= n) return;
   const msgpu_row row = rows[i];
   const uint32_t  rd = row.read_id, an = row.anchor_id, ln = row.line;
   if (rd >= V || an >= A) { // only possible when the host declared the id space (msgpu_set_id_space)
     atomicOr(err, 2u);
     return;
+  }
+  {
+    const int c = static_cast<int>(threadIdx.x) + SCAF_HALO;
+    uint32_t  before = 0, lower = 0;
+    int       d;
+    for (d = 1; d <= SCAF_HALO && s_an[c - d] == an; ++d) {
+      ++before;
+      lower += s_rd[c - d] < rd ? 1u : 0u;
+    }
+    bool     big = d > SCAF_HALO;
+    uint32_t after = 0;
+    for (d = 1; d <= SCAF_HALO && s_an[c + d] == an; ++d) {
+      ++after;
+      lower += s_rd[c + d] < rd ? 1u : 0u;
+    }
+    big |= d > SCAF_HALO;
+    if (big) atomicOr(flags, IXF_BIGSCAF);
+    // place in the scaffold, and the number of scaffold rows behind it (= partners with a higher read id)
+    spos[i] = make_uint2(static_cast<uint32_t>(i) - before + lower, before + after - lower);
   }
   if (cap) {
     const uint32_t pos = atomicAdd(&cnt_read[rd], 1u);
@@ -247,7 +306,7 @@ __global__ __launch_bounds__(256) void k_index_pass1(const msgpu_row *rows, uint
   if (i == 0) {
     anchor_first[an] = 0;
   } else {
-    const uint32_t pa = rows[i - 1].anchor_id, pl = rows[i - 1].line;
+    const uint32_t pa = s_an[threadIdx.x + SCAF_HALO - 1], pl = rows[i - 1].line;
     if (pa > an || (pa == an && pl >= ln)) atomicOr(flags, IXF_UNSORTED);
     if (pa != an) anchor_first[an] = static_cast<uint32_t>(i);
   }
@@ -313,7 +372,7 @@ __device__ __forceinline__ bool sort_read_in_registers(uint32_t r, uint64_t bs, 
                                                        const IRow *bkt_row, IRow *by_read,
                                                        uint32_t *read_cnt, uint32_t *alive_rank, uint32_t *anchor_cnt,
                                                        IRow *by_anchor, const msgpu_row *rows, int32_t *read_len,
-                                                       uint32_t *read_first) {
+                                                       uint32_t *read_first, const uint2 *spos, uint4 *vis) {
   IRow     row[K];
   uint32_t idx[K], man[K], less[K];
   int      mlo[K], mhi[K];
@@ -357,12 +416,17 @@ __device__ __forceinline__ bool sort_read_in_registers(uint32_t r, uint64_t bs, 
   for (int k = 0; k < K; ++k) {
     if (static_cast<uint32_t>(k) * 64 + lane < n) {
       row[k].pf = (row[k].pf & ~PF_POS_MASK) | less[k];
-      store_irow(&by_read[b + less[k]], row[k]);
       if (fast) {
-        IRow w  = row[k];
-        w.other = r;
-        store_irow(&by_anchor[idx[k]], w);
-      } else {
+        IRow           w  = row[k];
+        const uint2    sc = spos[idx[k]];
+        const uint32_t sp = sc.x;
+        w.other           = r;
+        store_irow(&by_anchor[sp], w);
+        row[k].pf = (row[k].pf & ~PF_POS_MASK) | sp; // by_read rows carry their place in the scaffold
+        vis[b + less[k]] = make_uint4(static_cast<uint32_t>(row[k].i_lo), static_cast<uint32_t>(row[k].i_hi), sp + 1, sc.y);
+      }
+      store_irow(&by_read[b + less[k]], row[k]);
+      if (!fast) {
         alive_rank[idx[k]] = less[k];
         atomicAdd(&anchor_cnt[row[k].other], 1u);
       }
@@ -382,7 +446,7 @@ __global__ __launch_bounds__(256) void k_sort_read(const uint32_t *read_off, con
                                                    uint32_t *read_cnt, uint32_t *alive_rank, uint32_t *anchor_cnt,
                                                    uint8_t *bkt_dead, uint32_t *flags, IRow *by_anchor, uint32_t cap,
                                                    const msgpu_row *rows, int32_t *read_len, uint32_t *read_first,
-                                                   uint32_t *err) {
+                                                   uint32_t *err, const uint2 *spos, uint4 *vis) {
   const int      lane = threadIdx.x & 63;
   const uint32_t r    = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
   if (r >= V) return;
@@ -436,15 +500,23 @@ __global__ __launch_bounds__(256) void k_sort_read(const uint32_t *read_off, con
     }
     if (alive) {
       row.pf = (row.pf & ~PF_POS_MASK) | less;
-      store_irow(&by_read[b + less], row);
       if (fast) {
-        // input already grouped by anchor with ascending lines: the scaffold table is the input order, so this row's
-        // by_anchor entry (same 32 bytes, `other` = the read, rank in the read attached) goes straight to slot idx.
-        // A duplicate (read, anchor) pair found anywhere voids the fast table: the host rebuilds generically.
-        IRow w  = row;
-        w.other = r;
-        store_irow(&by_anchor[idx], w);
-      } else {
+        // input already grouped by anchor with ascending lines: the scaffold's rows are the input's, so this row's
+        // by_anchor entry (same 32 bytes, `other` = the read, rank in the read attached) goes straight to the place
+        // pass 1 worked out for it (scaffolds in read-id order).  A duplicate (read, anchor) pair found anywhere voids
+        // the fast table: the host rebuilds generically.
+        IRow           w  = row;
+        const uint2    sc = spos[idx];
+        const uint32_t sp = sc.x;
+        w.other           = r;
+        store_irow(&by_anchor[sp], w);
+        row.pf = (row.pf & ~PF_POS_MASK) | sp; // by_read rows carry their place in the scaffold
+        // what the candidate scan reads of this row: anchor interval + the stretch of the scaffold behind it (the
+        // partners with a higher read id)
+        vis[b + less] = make_uint4(static_cast<uint32_t>(row.i_lo), static_cast<uint32_t>(row.i_hi), sp + 1, sc.y);
+      }
+      store_irow(&by_read[b + less], row);
+      if (!fast) {
         alive_rank[idx] = less;
         atomicAdd(&anchor_cnt[row.other], 1u);
       }
@@ -457,11 +529,11 @@ __global__ __launch_bounds__(256) void k_sort_read(const uint32_t *read_off, con
   }
   if (n <= 128) {
     if (sort_read_in_registers<2>(r, bs, b, n, lane, fast, bkt_row, by_read, read_cnt, alive_rank, anchor_cnt,
-                                  by_anchor, rows, read_len, read_first))
+                                  by_anchor, rows, read_len, read_first, spos, vis))
       return;
   } else if (n <= 256) {
     if (sort_read_in_registers<4>(r, bs, b, n, lane, fast, bkt_row, by_read, read_cnt, alive_rank, anchor_cnt,
-                                  by_anchor, rows, read_len, read_first))
+                                  by_anchor, rows, read_len, read_first, spos, vis))
       return;
   }
   // very long read, or one with a duplicated (read, anchor) pair: the bucket stays in global memory
@@ -497,12 +569,17 @@ __global__ __launch_bounds__(256) void k_sort_read(const uint32_t *read_off, con
         if (!bkt_dead[b + q]) less += key_less(o.n_lo, o.n_hi, o.other, k.n_lo, k.n_hi, k.other) ? 1u : 0u;
       }
       k.pf = (k.pf & ~PF_POS_MASK) | less;
-      store_irow(&by_read[b + less], k);
       if (fast) {
-        IRow w  = k;
-        w.other = r;
-        store_irow(&by_anchor[kix], w);
-      } else {
+        IRow           w  = k;
+        const uint2    sc = spos[kix];
+        const uint32_t sp = sc.x;
+        w.other           = r;
+        store_irow(&by_anchor[sp], w);
+        k.pf = (k.pf & ~PF_POS_MASK) | sp;
+        vis[b + less] = make_uint4(static_cast<uint32_t>(k.i_lo), static_cast<uint32_t>(k.i_hi), sp + 1, sc.y);
+      }
+      store_irow(&by_read[b + less], k);
+      if (!fast) {
         alive_rank[kix] = less;
         atomicAdd(&anchor_cnt[k.other], 1u);
       }
@@ -533,13 +610,16 @@ __global__ __launch_bounds__(256) void k_scatter_anchor(const msgpu_row *rows, u
   uint32_t a    = rows[i].anchor_id;
   uint32_t pos  = anchor_off[a] + atomicAdd(&cursor[a], 1u);
   bkt_idx[pos]  = static_cast<uint32_t>(i);
-  bkt_line[pos] = rows[i].line;
+  bkt_line[pos] = rows[i].read_id; // the scaffold's sort key
 }
 
-// scaffold of each anchor sorted by line number (MatchMap.cpp:178-183)
+// scaffold of each anchor sorted by read id (alive rows: a read occurs once per scaffold).  The reference sorts by line
+// (MatchMap.cpp:178-183) only to name the outer match of a pair, which k_chain takes from the two rows' lines.  The
+// by_read copy of the row learns its place in the scaffold.
 __global__ __launch_bounds__(256) void k_rank_anchor(const uint32_t *anchor_off, const uint32_t *d_n_alive, const uint32_t *bkt_idx,
-                                                     const uint32_t *bkt_line, const msgpu_row *rows,
-                                                     const uint32_t *alive_rank, IRow *by_anchor, const uint32_t *flags) {
+                                                     const uint32_t *bkt_key, const msgpu_row *rows,
+                                                     const uint32_t *alive_rank, IRow *by_anchor, const uint32_t *flags,
+                                                     const uint32_t *read_off, IRow *by_read, uint4 *vis) {
   if ((*flags & ~IXF_DUPS) == 0) return;
   uint64_t p = static_cast<uint64_t>(blockIdx.x) * 256 + threadIdx.x;
   if (p >= *d_n_alive) return;
@@ -547,27 +627,26 @@ __global__ __launch_bounds__(256) void k_rank_anchor(const uint32_t *anchor_off,
   msgpu_row row = rows[idx];
   uint32_t  b = anchor_off[row.anchor_id], e = anchor_off[row.anchor_id + 1];
   uint32_t  rank = 0;
-  for (uint32_t q = b; q < e; ++q) {
-    uint32_t l = bkt_line[q];
-    rank += (l < row.line || (l == row.line && bkt_idx[q] < idx)) ? 1u : 0u;
-  }
-  store_irow(&by_anchor[b + rank], make_irow(row, row.read_id, alive_rank[idx]));
+  for (uint32_t q = b; q < e; ++q) rank += bkt_key[q] < row.read_id ? 1u : 0u;
+  const uint32_t ar = alive_rank[idx], sp = b + rank;
+  store_irow(&by_anchor[sp], make_irow(row, row.read_id, ar));
+  const uint32_t at = read_off[row.read_id] + ar;
+  uint32_t      *pf = &by_read[at].pf;
+  *pf               = (*pf & ~PF_POS_MASK) | sp;
+  vis[at] = make_uint4(static_cast<uint32_t>(row.i_lo), static_cast<uint32_t>(row.i_hi), sp + 1, e - (sp + 1));
 }
 
-// upper bound of the scaffold rows a read has to visit = sum over its anchors of the scaffold size
-__global__ __launch_bounds__(256) void k_bound(const uint32_t *read_off, const uint32_t *read_cnt, const IRow *by_read,
-                                               const uint32_t *anchor_off, uint32_t V, uint32_t shard, uint32_t nshards,
-                                               uint32_t lo, uint32_t hi, uint32_t *bound) {
+// the scaffold rows a read has to visit = sum over its anchors of the rows behind its own (scaffolds are in read-id order)
+__global__ __launch_bounds__(256) void k_bound(const uint32_t *read_off, const uint32_t *read_cnt, const uint4 *vis,
+                                               uint32_t V, uint32_t shard, uint32_t nshards, uint32_t lo, uint32_t hi,
+                                               uint32_t *bound) {
   // 16 lanes per read: neighbouring lanes read neighbouring rows
   const uint32_t r   = blockIdx.x * 16 + (threadIdx.x >> 4);
   const uint32_t sub = threadIdx.x & 15;
   uint32_t       s   = 0;
   if (r < V && r >= lo && r < hi && r % nshards == shard) { // owner reads of this shard / batch
     const uint32_t b = read_off[r], n = read_cnt[r];
-    for (uint32_t j = sub; j < n; j += 16) {
-      const uint32_t a = by_read[b + j].other;
-      s += anchor_off[a + 1] - anchor_off[a];
-    }
+    for (uint32_t j = sub; j < n; j += 16) s += vis[b + j].w; // the rows behind this read's own row in each scaffold
   }
   for (int d = 8; d > 0; d >>= 1) s += __shfl_xor(s, d); // every lane takes part
   if (r < V && sub == 0) bound[r] = s;
@@ -584,8 +663,10 @@ __global__ __launch_bounds__(256) void k_bound(const uint32_t *read_off, const u
 // born in one workgroup and can be grouped in LDS.  The list is sorted by (v2, j) where j is the rank of the anchor
 // in v1's (nanoporeRange, anchor) order, i.e. each edge comes out in the vStart order of mpp.cpp:164-172.
 
-template <int R1MAX, int CMAX>
-__global__ __launch_bounds__(256) void k_candidates(CandArgs a, const uint32_t *read_list, uint32_t n_list) {
+// NT threads per workgroup (= per owner read): 128 for the reads with few scaffold rows to visit -- twice as many reads in
+// flight per CU, and the kernel waits on memory for most of its cycles -- 256 otherwise.
+template <int R1MAX, int CMAX, int NT>
+__global__ __launch_bounds__(NT) void k_candidates(CandArgs a, const uint32_t *read_list, uint32_t n_list) {
   constexpr int      HSZ   = CMAX; // hash slots >= candidates: insertion always terminates
   constexpr int      HBITS = CMAX == 512 ? 9 : CMAX == 1024 ? 10 : CMAX == 2048 ? 11 : CMAX == 4096 ? 12 : 13;
   static_assert((1 << HBITS) == HSZ, "CMAX must be 512, 1024, 2048, 4096 or 8192");
@@ -610,112 +691,81 @@ __global__ __launch_bounds__(256) void k_candidates(CandArgs a, const uint32_t *
   __shared__ uint32_t s_t[CMAX];                // by_anchor row of candidate c, later of staging position pos
   __shared__ uint16_t s_j[CMAX], s_g[CMAX];     // j of candidate c / of staging position pos; group of pos
   __shared__ uint32_t h_key[HSZ], h_cnt[HSZ];   // open-addressing table v2 -> group; members per group
-  __shared__ uint32_t s_wave[4], s_nc;
+  __shared__ uint32_t s_wave[NT / 64];
 
   if (blockIdx.x >= n_list) return;
   const uint32_t r  = read_list[blockIdx.x];
   const uint32_t rb = a.read_off[r], n1 = a.read_cnt[r];
   const uint64_t co = a.cand_off[r];
   const int      tid = threadIdx.x;
-  if (tid == 0) s_nc = 0;
-  for (int h = tid; h < HSZ; h += 256) {
+  for (int h = tid; h < HSZ; h += NT) {
     h_key[h] = EMPTY;
     h_cnt[h] = 0;
   }
 
-  // (a) v1's rows (already in vStart order) and the scaffold extents of their anchors
-  constexpr int JPT = R1MAX / 256; // rows per thread, consecutive
+  // (a) v1's rows (already in vStart order) and, per row, the stretch of its anchor's scaffold behind v1's own row
+  constexpr int JPT = R1MAX / NT; // rows per thread, consecutive
   uint32_t      cnt[JPT], tsum = 0;
 #pragma unroll
   for (int q = 0; q < JPT; ++q) {
     uint32_t j = tid * JPT + q;
     cnt[q]     = 0;
-    if (j < n1) {
-      IRow row  = load_irow(&a.by_read[rb + j]);
-      s_ilo[j]  = row.i_lo;
-      s_ihi[j]  = row.i_hi;
-      uint32_t ao = a.anchor_off[row.other];
-      s_aoff[j] = ao;
-      cnt[q]    = a.anchor_off[row.other + 1] - ao;
+    if (j < n1) { // anchor interval, first scaffold row behind v1's own (= first partner with a higher id), their number
+      const uint4 vr = a.vis[rb + j];
+      s_ilo[j]       = static_cast<int>(vr.x);
+      s_ihi[j]       = static_cast<int>(vr.y);
+      s_aoff[j]      = vr.z;
+      cnt[q]         = vr.w;
     }
     tsum += cnt[q];
   }
   uint32_t T;
-  uint32_t ex = block_excl_scan_256(tsum, s_wave, &T);
+  uint32_t ex = block_excl_scan<NT>(tsum, s_wave, &T);
+  // every visit x in [0, T) is one candidate slot: s_j[x] = the row of v1 it belongs to (filled here, stretch by
+  // stretch), so the scan below is one scaffold row per lane with no search, no per-row lane groups and no compaction
+  // (nearly every visit passes the overlap test now that only the owned partners are visited; the few that fail keep
+  // an EMPTY slot that the later phases skip)
 #pragma unroll
   for (int q = 0; q < JPT; ++q) {
     uint32_t j = tid * JPT + q;
-    if (j < n1) s_pfx[j] = ex;
+    if (j < n1) {
+      s_pfx[j] = ex;
+      for (uint32_t k = 0; k < cnt[q]; ++k) s_j[ex + k] = static_cast<uint16_t>(j);
+    }
     ex += cnt[q];
   }
-  if (tid == 0) s_pfx[n1] = T;
   __syncthreads();
 
-  // (b) visit every scaffold row of every anchor of v1: sixteen lanes per row of v1, lane i of the group takes scaffold
-  // rows i, i + 16, ... of that row's anchor (a scaffold has ~10 rows), so a visit costs no search for "which row of
-  // v1 am I in" -- the binary search over the prefix sums used to be a quarter of this kernel's vector instructions.
-  // Each lane keeps four rows of v1 in flight: all their gathers are issued before any is tested.
-  {
-    constexpr int RU  = 4;
-    const int     sub = tid & 15, grp = tid >> 4;
-    for (uint32_t j0 = 0; j0 < n1; j0 += 16 * RU) {
-      uint32_t jj[RU], cntj[RU], aoj[RU];
-#pragma unroll
-      for (int u = 0; u < RU; ++u) {
-        const uint32_t j = j0 + u * 16 + grp;
-        jj[u]            = j < n1 ? j : 0;
-        cntj[u]          = j < n1 ? s_pfx[j + 1] - s_pfx[j] : 0;
-        aoj[u]           = j < n1 ? s_aoff[j] : 0;
-      }
-      for (uint32_t i = sub;; i += 16) {
-        IRow o[RU];
-        bool in[RU], any = false;
-#pragma unroll
-        for (int u = 0; u < RU; ++u) {
-          in[u] = i < cntj[u];
-          any |= in[u];
-          if (in[u]) o[u] = load_irow(&a.by_anchor[aoj[u] + i]);
-        }
-        if (!__ballot(any)) break; // wave-uniform: every lane of the wavefront leaves together
-#pragma unroll
-        for (int u = 0; u < RU; ++u) {
-          bool           pass = false;
-          const uint32_t j = jj[u], r2 = in[u] ? o[u].other : 0;
-          if (in[u]) {
-            const int ovlo = max(o[u].i_lo, s_ilo[j]), ovhi = min(o[u].i_hi, s_ihi[j]);
-            // owner rule (v2 > v1 <=> v1 has the lower first line, MatchMap.cpp:204-213) + overlap test (:192)
-            pass = r2 > r && ovlo <= ovhi && (ovhi - ovlo) > static_cast<int>(a.th_overlap);
-          }
-          unsigned long long m = __ballot(pass);
-          if (m) {
-            uint32_t base = 0;
-            int      lane = tid & 63;
-            if (lane == 0) base = atomicAdd(&s_nc, static_cast<uint32_t>(__popcll(m)));
-            base = __shfl(base, 0);
-            if (pass) {
-              uint32_t c = base + static_cast<uint32_t>(__popcll(m & ((1ull << lane) - 1)));
-              s_v2[c]    = r2;
-              s_j[c]     = static_cast<uint16_t>(j);
-              s_t[c]     = aoj[u] + i;
-            }
-          }
-        }
-      }
+  // (b) one scaffold row per lane: consecutive lanes read consecutive rows of a scaffold
+  for (uint32_t x0 = 0; x0 < T; x0 += NT) {
+    const uint32_t x = x0 + tid;
+    if (x < T) {
+      const uint32_t j  = s_j[x];
+      const uint32_t vm = s_aoff[j] + (x - s_pfx[j]);
+      const IRow     o  = load_irow(&a.by_anchor[vm]);
+      const int      ovlo = max(o.i_lo, s_ilo[j]), ovhi = min(o.i_hi, s_ihi[j]);
+      // overlap test (MatchMap.cpp:192); the owner rule (v2 > v1 <=> v1 has the lower first line, :204-213) is the
+      // choice of the rows visited: scaffolds are in read-id order and the walk starts behind v1's own row
+      const bool pass = ovlo <= ovhi && (ovhi - ovlo) > static_cast<int>(a.th_overlap);
+      s_v2[x] = pass ? o.other : EMPTY;
+      s_t[x]  = vm;
     }
   }
   __syncthreads();
-  const uint32_t nc = s_nc;
+  const uint32_t nc = T; // candidate slots (EMPTY ones included)
 
   // (c1) group by v2: open-addressing insert; li = arrival number inside the group (any order)
-  constexpr int CPT = CMAX / 256;
+  constexpr int CPT = CMAX / NT;
   uint16_t      c_slot[CPT], c_li[CPT], c_j[CPT];
   uint32_t      c_t[CPT];
+  bool          c_ok[CPT]; // slot c holds a candidate (a visit that passed the overlap test)
 #pragma unroll
   for (int q = 0; q < CPT; ++q) {
-    const uint32_t c = tid + 256 * q;
+    const uint32_t c = tid + NT * q;
     c_slot[q] = c_li[q] = c_j[q] = 0;
     c_t[q]                       = 0;
-    if (c < nc) {
+    c_ok[q]                      = c < nc && s_v2[c] != EMPTY;
+    if (c_ok[q]) {
       const uint32_t v2 = s_v2[c];
       uint32_t       h  = (v2 * 2654435761u) >> (32 - HBITS);
       while (true) {
@@ -740,12 +790,12 @@ __global__ __launch_bounds__(256) void k_candidates(CandArgs a, const uint32_t *
     osum += occ[q];
   }
   uint32_t ng;
-  uint32_t gex = block_excl_scan_256(osum, s_wave, &ng);
+  uint32_t gex = block_excl_scan<NT>(osum, s_wave, &ng);
 #pragma unroll
   for (int q = 0; q < CPT; ++q)
     if (occ[q]) g_list[gex++] = static_cast<uint16_t>(tid * CPT + q);
   __syncthreads();
-  for (uint32_t g = tid; g < ng; g += 256) {
+  for (uint32_t g = tid; g < ng; g += NT) {
     const uint32_t slot = g_list[g], key = h_key[slot];
     uint32_t       rank = 0;
     for (uint32_t q = 0; q < ng; ++q) rank += (h_key[g_list[q]] < key) ? 1u : 0u;
@@ -763,14 +813,14 @@ __global__ __launch_bounds__(256) void k_candidates(CandArgs a, const uint32_t *
     gsum += gc[q];
   }
   uint32_t tot;
-  uint32_t oex = block_excl_scan_256(gsum, s_wave, &tot);
+  uint32_t oex = block_excl_scan<NT>(gsum, s_wave, &tot);
 #pragma unroll
   for (int q = 0; q < CPT; ++q) {
     const uint32_t rk = tid * CPT + q;
     if (rk < ng) g_off[rk] = static_cast<uint16_t>(oex);
     oex += gc[q];
   }
-  if (tid == 0) g_off[ng] = static_cast<uint16_t>(nc);
+  if (tid == 0) g_off[ng] = static_cast<uint16_t>(tot); // candidates of this read
   __syncthreads();
 
   // (c4/c5) inside a group the candidates go in the order of j = the vStart order of mpp.cpp:164-172 (j is unique
@@ -780,14 +830,13 @@ __global__ __launch_bounds__(256) void k_candidates(CandArgs a, const uint32_t *
   constexpr uint32_t WPG = R1MAX / 32; // bitmap words per group
   if (ng <= static_cast<uint32_t>(HSZ) / WPG) {
     uint32_t *const bm = h_cnt;
-    for (uint32_t w = tid; w < ng * WPG; w += 256) bm[w] = 0;
+    for (uint32_t w = tid; w < ng * WPG; w += NT) bm[w] = 0;
     __syncthreads();
     uint32_t c_rk[CPT];
 #pragma unroll
     for (int q = 0; q < CPT; ++q) {
-      const uint32_t c = tid + 256 * q;
-      c_rk[q]          = 0;
-      if (c < nc) {
+      c_rk[q] = 0;
+      if (c_ok[q]) {
         c_rk[q] = g_rank[c_slot[q]];
         atomicOr(&bm[c_rk[q] * WPG + (c_j[q] >> 5)], 1u << (c_j[q] & 31));
       }
@@ -795,8 +844,7 @@ __global__ __launch_bounds__(256) void k_candidates(CandArgs a, const uint32_t *
     __syncthreads();
 #pragma unroll
     for (int q = 0; q < CPT; ++q) {
-      const uint32_t c = tid + 256 * q;
-      if (c < nc) {
+      if (c_ok[q]) {
         const uint32_t *g  = bm + c_rk[q] * WPG;
         const uint32_t  jw = c_j[q] >> 5;
         uint32_t        rr = static_cast<uint32_t>(__popc(g[jw] & ((1u << (c_j[q] & 31)) - 1u)));
@@ -809,8 +857,7 @@ __global__ __launch_bounds__(256) void k_candidates(CandArgs a, const uint32_t *
   } else { // more groups than bitmaps fit: stage by group, rank by comparison
 #pragma unroll
     for (int q = 0; q < CPT; ++q) {
-      const uint32_t c = tid + 256 * q;
-      if (c < nc) {
+      if (c_ok[q]) {
         const uint32_t rk  = g_rank[c_slot[q]];
         const uint32_t pos = g_off[rk] + c_li[q];
         s_j[pos]           = c_j[q];
@@ -819,7 +866,7 @@ __global__ __launch_bounds__(256) void k_candidates(CandArgs a, const uint32_t *
       }
     }
     __syncthreads();
-    for (uint32_t pos = tid; pos < nc; pos += 256) {
+    for (uint32_t pos = tid; pos < tot; pos += NT) {
       const uint32_t rk = s_g[pos], gs = g_off[rk], ge = g_off[rk + 1];
       const uint16_t mj = s_j[pos];
       uint32_t       rr = 0;
@@ -829,7 +876,7 @@ __global__ __launch_bounds__(256) void k_candidates(CandArgs a, const uint32_t *
     }
   }
   // (d) one edge per group (edges with more than 64 EdgeMatches are counted: they take k_chain_big)
-  for (uint32_t g = tid; g < ng; g += 256) {
+  for (uint32_t g = tid; g < ng; g += NT) {
     a.edge_scr_v2[co + g]    = h_key[g_slot[g]];
     a.edge_scr_start[co + g] = g_off[g];
     const uint32_t cnt = static_cast<uint32_t>(g_off[g + 1]) - g_off[g];
@@ -839,15 +886,16 @@ __global__ __launch_bounds__(256) void k_candidates(CandArgs a, const uint32_t *
     }
   }
   if (tid == 0) {
-    a.n_cand[r]  = nc;
+    a.n_cand[r]  = tot;
     a.n_edge[r]  = ng;
     a.n_visit[r] = T;
   }
 }
 
-template __global__ void k_candidates<256, 512>(CandArgs, const uint32_t *, uint32_t);
-template __global__ void k_candidates<256, 1024>(CandArgs, const uint32_t *, uint32_t);
-template __global__ void k_candidates<1024, 4096>(CandArgs, const uint32_t *, uint32_t);
+template __global__ void k_candidates<256, 512, 128>(CandArgs, const uint32_t *, uint32_t);
+template __global__ void k_candidates<256, 512, 256>(CandArgs, const uint32_t *, uint32_t);
+template __global__ void k_candidates<256, 1024, 256>(CandArgs, const uint32_t *, uint32_t);
+template __global__ void k_candidates<1024, 4096, 256>(CandArgs, const uint32_t *, uint32_t);
 
 // classify reads of this shard by the LDS footprint their candidate scan needs
 // classes by LDS footprint: 0 = <256 rows, 512 candidates> (half the LDS of class 1, so twice as many reads per CU),
@@ -910,8 +958,8 @@ __global__ __launch_bounds__(256) void k_candidates_big(CandArgs a, const uint32
   for (uint32_t j0 = 0; j0 < n1; j0 += 256) {
     uint32_t j = j0 + tid, c = 0;
     if (j < n1) {
-      uint32_t an = a.by_read[rb + j].other;
-      c           = a.anchor_off[an + 1] - a.anchor_off[an];
+      const uint32_t an = a.by_read[rb + j].other, sp = a.by_read[rb + j].pf & PF_POS_MASK;
+      c                 = a.anchor_off[an + 1] - (sp + 1);
     }
     uint32_t tot;
     uint32_t ex = block_excl_scan_256(c, s_wave, &tot);
@@ -939,11 +987,11 @@ __global__ __launch_bounds__(256) void k_candidates_big(CandArgs a, const uint32
       }
       j        = lo;
       IRow me  = load_irow(&a.by_read[rb + j]);
-      vm       = a.anchor_off[me.other] + (x - pfx[j]);
+      vm       = (me.pf & PF_POS_MASK) + 1 + (x - pfx[j]);
       IRow o   = load_irow(&a.by_anchor[vm]);
       r2       = o.other;
       int ovlo = max(o.i_lo, me.i_lo), ovhi = min(o.i_hi, me.i_hi);
-      pass     = r2 > r && ovlo <= ovhi && (ovhi - ovlo) > static_cast<int>(a.th_overlap);
+      pass     = ovlo <= ovhi && (ovhi - ovlo) > static_cast<int>(a.th_overlap);
     }
     unsigned long long m = __ballot(pass);
     if (m) {
@@ -2580,10 +2628,11 @@ void launch_index_init(hipStream_t st, uint32_t *const zero[4], const uint32_t n
   hipLaunchKernelGGL(k_index_init, dim3(nb < 1024 ? nb : 1024), dim3(256), 0, st, a);
 }
 void launch_index_pass1(hipStream_t st, const msgpu_row *rows, uint64_t n, uint32_t *cnt_read, uint32_t *anchor_first,
-                        uint32_t V, uint32_t A, uint32_t *flags, uint32_t *err, IRow *bkt_row, uint32_t cap) {
+                        uint32_t V, uint32_t A, uint32_t *flags, uint32_t *err, IRow *bkt_row, uint32_t cap,
+                        uint2 *spos) {
   if (n)
     hipLaunchKernelGGL(k_index_pass1, grid1(n, 256), dim3(256), 0, st, rows, n, cnt_read, anchor_first, flags, V, A, err,
-                       bkt_row, cap);
+                       bkt_row, cap, spos);
   hipLaunchKernelGGL(k_check_anchor_first, grid1(static_cast<uint64_t>(A) + 1, 256), dim3(256), 0, st, anchor_first, A,
                      static_cast<uint32_t>(n), flags);
 }
@@ -2598,10 +2647,12 @@ void launch_scatter_read(hipStream_t st, const msgpu_row *rows, uint64_t n, cons
 void launch_sort_read(hipStream_t st, const uint32_t *read_off, const uint32_t *cnt_read, uint32_t V, const IRow *bkt_row,
                       IRow *by_read, uint32_t *read_cnt, uint32_t *alive_rank,
                       uint32_t *anchor_cnt, uint8_t *bkt_dead, uint32_t *flags, IRow *by_anchor, uint32_t cap,
-                      const msgpu_row *rows, int32_t *read_len, uint32_t *read_first, uint32_t *err) {
+                      const msgpu_row *rows, int32_t *read_len, uint32_t *read_first, uint32_t *err,
+                      const uint2 *spos, uint4 *vis) {
   if (V)
     hipLaunchKernelGGL(k_sort_read, grid1(V, 4), dim3(256), 0, st, read_off, cnt_read, V, bkt_row, by_read,
-                       read_cnt, alive_rank, anchor_cnt, bkt_dead, flags, by_anchor, cap, rows, read_len, read_first, err);
+                       read_cnt, alive_rank, anchor_cnt, bkt_dead, flags, by_anchor, cap, rows, read_len, read_first, err,
+                       spos, vis);
 }
 void launch_select_anchor_off(hipStream_t st, const uint32_t *flags, const uint32_t *fast_off, const uint32_t *gen_off,
                               uint32_t A, uint32_t *anchor_off, uint32_t *d_n_alive, uint32_t n_rows) {
@@ -2617,17 +2668,17 @@ void launch_scatter_anchor(hipStream_t st, const msgpu_row *rows, uint64_t n, co
 }
 void launch_rank_anchor(hipStream_t st, const uint32_t *anchor_off, uint64_t n_rows, const uint32_t *d_n_alive,
                         const uint32_t *bkt_idx, const uint32_t *bkt_line, const msgpu_row *rows,
-                        const uint32_t *alive_rank, IRow *by_anchor, const uint32_t *flags) {
+                        const uint32_t *alive_rank, IRow *by_anchor, const uint32_t *flags, const uint32_t *read_off,
+                        IRow *by_read, uint4 *vis) {
   if (n_rows)
     hipLaunchKernelGGL(k_rank_anchor, grid1(n_rows, 256), dim3(256), 0, st, anchor_off, d_n_alive, bkt_idx, bkt_line,
-                       rows, alive_rank, by_anchor, flags);
+                       rows, alive_rank, by_anchor, flags, read_off, by_read, vis);
 }
-void launch_bound(hipStream_t st, const uint32_t *read_off, const uint32_t *read_cnt, const IRow *by_read,
-                  const uint32_t *anchor_off, uint32_t V, uint32_t shard, uint32_t nshards, uint32_t lo, uint32_t hi,
-                  uint32_t *bound) {
+void launch_bound(hipStream_t st, const uint32_t *read_off, const uint32_t *read_cnt, const uint4 *vis, uint32_t V,
+                  uint32_t shard, uint32_t nshards, uint32_t lo, uint32_t hi, uint32_t *bound) {
   if (V)
-    hipLaunchKernelGGL(k_bound, grid1(V, 16), dim3(256), 0, st, read_off, read_cnt, by_read, anchor_off, V, shard,
-                       nshards, lo, hi, bound);
+    hipLaunchKernelGGL(k_bound, grid1(V, 16), dim3(256), 0, st, read_off, read_cnt, vis, V, shard, nshards, lo, hi,
+                       bound);
 }
 void launch_classify_reads(hipStream_t st, const uint32_t *read_cnt, const uint32_t *bound, uint32_t V, uint32_t shard,
                            uint32_t nshards, uint32_t lo, uint32_t hi, uint32_t *l0, uint32_t *l1, uint32_t *l2,
@@ -2638,12 +2689,15 @@ void launch_classify_reads(hipStream_t st, const uint32_t *read_cnt, const uint3
 }
 void launch_candidates(hipStream_t st, const CandArgs &a, int cls, const uint32_t *list, uint32_t n_list) {
   if (!n_list) return;
-  if (cls == 0)
-    hipLaunchKernelGGL((k_candidates<256, 512>), dim3(n_list), dim3(256), 0, st, a, list, n_list);
+  static const bool nt128 = getenv("MSGPU_CAND_NT128") != nullptr; // experiment switch
+  if (cls == 0 && nt128)
+    hipLaunchKernelGGL((k_candidates<256, 512, 128>), dim3(n_list), dim3(128), 0, st, a, list, n_list);
+  else if (cls == 0)
+    hipLaunchKernelGGL((k_candidates<256, 512, 256>), dim3(n_list), dim3(256), 0, st, a, list, n_list);
   else if (cls == 1)
-    hipLaunchKernelGGL((k_candidates<256, 1024>), dim3(n_list), dim3(256), 0, st, a, list, n_list);
+    hipLaunchKernelGGL((k_candidates<256, 1024, 256>), dim3(n_list), dim3(256), 0, st, a, list, n_list);
   else
-    hipLaunchKernelGGL((k_candidates<1024, 4096>), dim3(n_list), dim3(256), 0, st, a, list, n_list);
+    hipLaunchKernelGGL((k_candidates<1024, 4096, 256>), dim3(n_list), dim3(256), 0, st, a, list, n_list);
 }
 void launch_candidates_big(hipStream_t st, const CandArgs &a, const uint32_t *list, uint32_t n_list, uint64_t *big_key,
                            uint32_t *big_t, uint32_t *big_r2s, uint32_t *big_pfx) {
