@@ -19,6 +19,8 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "msgpu.h"
 #include "msgpu_internal.h"
 
@@ -252,29 +254,39 @@ __global__ __launch_bounds__(256) void k_index_init(IndexInitArgs a) {
 // plus the number of the scaffold's rows with a lower read id.  Both are counted in an LDS tile with SCAF_HALO rows of
 // context on either side; a scaffold that does not fit the context raises IXF_BIGSCAF and the generic scaffold build
 // runs instead.
-constexpr int SCAF_HALO = 128;
+#ifndef MSGPU_SCAF_HALO
+#define MSGPU_SCAF_HALO 128
+#endif
+constexpr int SCAF_HALO = MSGPU_SCAF_HALO;
 __global__ __launch_bounds__(256) void k_index_pass1(const msgpu_row *rows, uint64_t n, uint32_t *cnt_read,
                                                      uint32_t *anchor_first, uint32_t *flags, uint32_t V, uint32_t A,
                                                      uint32_t *err, IRow *bkt_row, uint32_t cap, uint2 *spos) {
   __shared__ uint32_t s_an[256 + 2 * SCAF_HALO], s_rd[256 + 2 * SCAF_HALO];
   const uint64_t      i0 = static_cast<uint64_t>(blockIdx.x) * 256;
-  for (int t = threadIdx.x; t < 256 + 2 * SCAF_HALO; t += 256) {
-    const long long g  = static_cast<long long>(i0) - SCAF_HALO + t;
-    const bool      in = g >= 0 && static_cast<uint64_t>(g) < n;
-    uint2           ar = make_uint2(0xffffffffu, 0u); // no valid anchor id (ids are < A <= 2^32 - 1)
-    if (in) ar = *reinterpret_cast<const uint2 *>(&rows[g]); // anchor_id, read_id: the first eight bytes of a row
-    s_an[t] = ar.x;
-    s_rd[t] = ar.y;
+  const uint64_t      i  = i0 + threadIdx.x;
+  msgpu_row           row{};
+  if (i < n) row = rows[i];
+  // tile = (anchor, read) of this workgroup's rows plus SCAF_HALO rows of context on either side
+  s_an[SCAF_HALO + threadIdx.x] = i < n ? row.anchor_id : 0xffffffffu; // no valid anchor id (ids are < A <= 2^32 - 1)
+  s_rd[SCAF_HALO + threadIdx.x] = row.read_id;
+  for (int t = threadIdx.x; t < 2 * SCAF_HALO; t += 256) {
+    const int       slot = t < SCAF_HALO ? t : 256 + t;
+    const long long g    = static_cast<long long>(i0) - SCAF_HALO + slot;
+    uint2           ar   = make_uint2(0xffffffffu, 0u);
+    if (g >= 0 && static_cast<uint64_t>(g) < n) ar = *reinterpret_cast<const uint2 *>(&rows[g]); // anchor_id, read_id
+    s_an[slot] = ar.x;
+    s_rd[slot] = ar.y;
   }
   __syncthreads();
-  uint64_t i = i0 + threadIdx.x;
   if (i >= n) return;
-  const msgpu_row row = rows[i];
-  const uint32_t  rd = row.read_id, an = row.anchor_id, ln = row.line;
+  const uint32_t rd = row.read_id, an = row.anchor_id, ln = row.line;
   if (rd >= V || an >= A) { // only possible when the host declared the id space (msgpu_set_id_space)
     atomicOr(err, 2u);
     return;
   }
+#ifdef MSGPU_X_NOSPOS
+  spos[i] = make_uint2(static_cast<uint32_t>(i), 0);
+#else
   {
     const int c = static_cast<int>(threadIdx.x) + SCAF_HALO;
     uint32_t  before = 0, lower = 0;
@@ -294,6 +306,7 @@ __global__ __launch_bounds__(256) void k_index_pass1(const msgpu_row *rows, uint
     // place in the scaffold, and the number of scaffold rows behind it (= partners with a higher read id)
     spos[i] = make_uint2(static_cast<uint32_t>(i) - before + lower, before + after - lower);
   }
+#endif
   if (cap) {
     const uint32_t pos = atomicAdd(&cnt_read[rd], 1u);
     if (pos < cap)
@@ -1118,6 +1131,14 @@ struct __attribute__((aligned(16))) ChainElem {
 struct NanoMasks {
   unsigned long long pos, neg, ovl, abort_;
 };
+// WF ("well formed", checked once per edge, practically always true): no NaN and lo <= hi in every corrected range of
+// the edge.  Then the overlap predicate is the sign of the one difference the diff needs anyway
+//   k_clo < l_clo: k_clo < l_clo <= l_chi, so ovl = (l_clo <= k_chi) = (x >= 0);   else l_clo <= k_clo <= k_chi, ovl = (y >= 0)
+// and the diff is |difference| + 1 (ovl keeps a non-negative difference, no-ovl negates a negative one): one compare
+// and two selects less per vertex, bit for bit the same masks and the same diff.
+// SORTED (vertex 1 only): the pairs run k < l in v1's (n_lo, n_hi, anchor) order, so k_rlo <= l_rlo <= l_rhi: the first
+// half of the raw overlap test is true and "k behind l" (um2) is false -- three raw compares instead of six.
+template <bool WF, bool SORTED>
 __device__ __forceinline__ NanoMasks nano_check(double k_clo, double k_chi, double l_clo, double l_chi, int k_rlo,
                                                 int k_rhi, int l_rlo, int l_rhi, double &d) {
   typedef unsigned long long M;
@@ -1125,25 +1146,36 @@ __device__ __forceinline__ NanoMasks nano_check(double k_clo, double k_chi, doub
   const M    lt_lo = __ballot(lt_lo_b), lt_hi = __ballot(k_chi < l_chi);
   const M    gt_lo = __ballot(k_clo > l_clo), gt_hi = __ballot(k_chi > l_chi);
   NanoMasks  f;
-  f.ovl = __ballot(k_clo <= l_chi) & __ballot(l_clo <= k_chi);
-  // fwd2 | fwd1 = (ovl & lt_lo & lt_hi) | (~ovl & lt_lo),  bwd2 | bwd1 = (ovl & gt_lo & gt_hi) | (~ovl & ~lt_lo), written
-  // with few scalar instructions (the loop keeps the scalar unit about half busy, the vector unit at 80-85 %)
-  f.pos = lt_lo & (lt_hi | ~f.ovl);
-  f.neg = (f.ovl & gt_lo & gt_hi) | ~(f.ovl | lt_lo);
   // diff (:70-91): fwd -> k_chi - l_clo, bwd -> l_chi - k_clo, negated when the ranges do not overlap, + 1.  lt_lo
   // selects the right difference in every case that has an order.
   const double x = k_chi - l_clo;
   const double y = l_chi - k_clo;
   double       t = lt_lo_b ? x : y;
-  t              = __builtin_amdgcn_inverse_ballot_w64(f.ovl) ? t : -t;
-  // (the reference leaves diff = 0 when the ranges overlap without a strict order, orientation 0; checkCompatibility
-  // reads the differences only when BOTH orientations are non-zero, :133-138, so that case needs no select here)
-  d = t + 1;
-  const M rovl = __ballot(k_rlo <= l_rhi) & __ballot(l_rlo <= k_rhi);
-  const M u2   = __ballot(k_rlo < l_rlo) & __ballot(k_rhi < l_rhi);
-  const M um2  = __ballot(k_rlo > l_rlo) & __ballot(k_rhi > l_rhi);
+  if (WF) {
+    f.ovl = __ballot(t >= 0.0);
+    d     = fabs(t) + 1;
+  } else {
+    f.ovl = __ballot(k_clo <= l_chi) & __ballot(l_clo <= k_chi);
+    t     = __builtin_amdgcn_inverse_ballot_w64(f.ovl) ? t : -t;
+    // (the reference leaves diff = 0 when the ranges overlap without a strict order, orientation 0; checkCompatibility
+    // reads the differences only when BOTH orientations are non-zero, :133-138, so that case needs no select here)
+    d = t + 1;
+  }
+  // fwd2 | fwd1 = (ovl & lt_lo & lt_hi) | (~ovl & lt_lo),  bwd2 | bwd1 = (ovl & gt_lo & gt_hi) | (~ovl & ~lt_lo), written
+  // with few scalar instructions (the loop keeps the scalar unit about half busy, the vector unit at 80-85 %)
+  f.pos = lt_lo & (lt_hi | ~f.ovl);
+  f.neg = (f.ovl & gt_lo & gt_hi) | ~(f.ovl | lt_lo);
   // abort when the raw ranges overlap and their order contradicts the corrected orientation (:93-109)
-  f.abort_ = rovl & ((f.neg & ~um2) | (f.pos & ~u2));
+  if (SORTED) {
+    const M rovl = __ballot(l_rlo <= k_rhi);
+    const M u2   = __ballot(k_rlo < l_rlo) & __ballot(k_rhi < l_rhi);
+    f.abort_     = rovl & (f.neg | (f.pos & ~u2));
+  } else {
+    const M rovl = __ballot(k_rlo <= l_rhi) & __ballot(l_rlo <= k_rhi);
+    const M u2   = __ballot(k_rlo < l_rlo) & __ballot(k_rhi < l_rhi);
+    const M um2  = __ballot(k_rlo > l_rlo) & __ballot(k_rhi > l_rhi);
+    f.abort_     = rovl & ((f.neg & ~um2) | (f.pos & ~u2));
+  }
   return f;
 }
 
@@ -1400,7 +1432,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
   // re-read (v_readlane) in every step.  The one constant the common path compares with lives in a vector register.
   double wiggle = a.wiggle;
   asm volatile("" : "+v"(wiggle));
-  for (int p0 = 0; p0 < P; p0 += 64) {
+  // every element well formed (see nano_check) and v1's raw ranges in list order: the lean pair test; else the general one
+  bool wf_lane = true;
+  if (act) {
+    const int prev_rlo1 = el[lane > 0 ? lane - 1 : 0].rlo1;
+    wf_lane = (x.clo1 <= x.chi1) & (x.clo2 <= x.chi2) & (x.rlo1 <= x.rhi1) & (lane == 0 || prev_rlo1 <= x.rlo1);
+  }
+  const bool wf = __ballot(!wf_lane) == 0;
+  auto sweep_step = [&](int p0, auto wft) __attribute__((always_inline)) {
+    typedef decltype(wft) WFT;
     unsigned long long bits = 0; // checkCompatibility(k, l) of the 64 pairs of this step
     const uint32_t     kl = kl_next;
     kl_next               = (tab + p0 + 64)[lane]; // the next step's pairs are on their way while this one computes
@@ -1415,8 +1455,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
       }
       const ChainElem K = el[k], L = el[l];
       double          d1, d2;
-      const NanoMasks f1 = nano_check(K.clo1, K.chi1, L.clo1, L.chi1, K.rlo1, K.rhi1, L.rlo1, L.rhi1, d1);
-      const NanoMasks f2 = nano_check(K.clo2, K.chi2, L.clo2, L.chi2, K.rlo2, K.rhi2, L.rlo2, L.rhi2, d2);
+      const NanoMasks f1 = nano_check<WFT::value, WFT::value>(K.clo1, K.chi1, L.clo1, L.chi1, K.rlo1, K.rhi1, L.rlo1, L.rhi1, d1);
+      const NanoMasks f2 = nano_check<WFT::value, false>(K.clo2, K.chi2, L.clo2, L.chi2, K.rlo2, K.rhi2, L.rlo2, L.rhi2, d2);
       M p2, n2; // :131 flip by EdgeMatch(k).direction
       if (one_dir) {
         p2 = m_minus == 0 ? f2.pos : f2.neg;
@@ -1448,7 +1488,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
       const int up = 64 - run, down = static_cast<int>(kl >> 24); // down = up - k >= 1
       cm[l] |= ((bits >> lane) << up) >> down;
     }
-  }
+  };
+  if (wf)
+    for (int p0 = 0; p0 < P; p0 += 64) sweep_step(p0, std::true_type{});
+  else
+    for (int p0 = 0; p0 < P; p0 += 64) sweep_step(p0, std::false_type{});
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   const uint64_t mycm = cm[lane]; // bit k: checkCompatibility(k, lane) for k < lane of the same direction
@@ -1848,7 +1892,15 @@ __global__ __launch_bounds__(256) void k_chain_sub(ChainArgs a, const uint32_t *
   uint32_t        kl_next = tab[min(sl, Pm1)];
   double          wiggle  = a.wiggle; // in a vector register: see k_chain
   asm volatile("" : "+v"(wiggle));
-  for (int p0 = 0; p0 < Pmax; p0 += W) {
+  // every element of every group well formed (see nano_check) and v1's raw ranges in list order: the lean pair test
+  bool wf_lane = true;
+  if (act) {
+    const int prev_rlo1 = el[sl > 0 ? lane - 1 : lane].rlo1;
+    wf_lane = (x.clo1 <= x.chi1) & (x.clo2 <= x.chi2) & (x.rlo1 <= x.rhi1) & (sl == 0 || prev_rlo1 <= x.rlo1);
+  }
+  const bool wf = __ballot(!wf_lane) == 0;
+  auto sweep_step = [&](int p0, auto wft) __attribute__((always_inline)) {
+    typedef decltype(wft) WFT;
     const int      p  = p0 + sl;
     const uint32_t kl = kl_next;
     kl_next           = tab[min(p + W, Pm1)];
@@ -1864,8 +1916,8 @@ __global__ __launch_bounds__(256) void k_chain_sub(ChainArgs a, const uint32_t *
       }
       const ChainElem K = el[gbase + k], L = el[gbase + l];
       double          d1, d2;
-      const NanoMasks f1 = nano_check(K.clo1, K.chi1, L.clo1, L.chi1, K.rlo1, K.rhi1, L.rlo1, L.rhi1, d1);
-      const NanoMasks f2 = nano_check(K.clo2, K.chi2, L.clo2, L.chi2, K.rlo2, K.rhi2, L.rlo2, L.rhi2, d2);
+      const NanoMasks f1 = nano_check<WFT::value, WFT::value>(K.clo1, K.chi1, L.clo1, L.chi1, K.rlo1, K.rhi1, L.rlo1, L.rhi1, d1);
+      const NanoMasks f2 = nano_check<WFT::value, false>(K.clo2, K.chi2, L.clo2, L.chi2, K.rlo2, K.rhi2, L.rlo2, L.rhi2, d2);
       const M p2 = (KD & f2.pos) | (~KD & f2.neg), n2m = (KD & f2.neg) | (~KD & f2.pos);
       const M codir   = (f1.pos & p2) | (f1.neg & n2m);
       const M same    = codir & ~(f1.ovl ^ f2.ovl);
@@ -1884,7 +1936,11 @@ __global__ __launch_bounds__(256) void k_chain_sub(ChainArgs a, const uint32_t *
     // the pairs of row l are consecutive lanes of the group; the first lane of each run stores the run's bits
     const uint32_t gb = group_bits<W>(bits, gbase);
     if (run && p < P) cm[gbase + l] |= __builtin_amdgcn_ubfe(gb, static_cast<uint32_t>(sl), static_cast<uint32_t>(run)) << k; // run <= 31
-  }
+  };
+  if (wf)
+    for (int p0 = 0; p0 < Pmax; p0 += W) sweep_step(p0, std::true_type{});
+  else
+    for (int p0 = 0; p0 < Pmax; p0 += W) sweep_step(p0, std::false_type{});
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   // bit k: checkCompatibility(k, sl) for k < sl; a clean edge has them all (and then the DP below adds the scores up
