@@ -8,9 +8,16 @@
 
 struct msgpu_assembly {
   msgpu_seqctx                 *ctx = nullptr;
-  std::vector<msgpu_row>        rows;      // msgpu_assembly_set_rows: the MatchMap's VertexMatches, sorted by
-  std::vector<uint64_t>         row_keys;  //   (read id << 32 | anchor id, line); row_keys[i] belongs to rows[i]
-  std::vector<uint64_t>         row_start; //   rows of read r are rows[row_start[r] .. row_start[r + 1])
+  // msgpu_assembly_set_rows: the MatchMap's VertexMatches.  rows = a copy in input order; row_recs = one record per row
+  // grouped by read and, inside a read, ordered by (anchor id, line); the records of read r are
+  // row_recs[row_start[r] .. row_start[r + 1])
+  struct RowRec {
+    uint64_t key; // read id << 32 | anchor id
+    uint32_t line, idx; // idx = position in rows
+  };
+  std::vector<msgpu_row>        rows;
+  std::vector<RowRec>           row_recs;
+  std::vector<uint64_t>         row_start;
   std::vector<msgpu_copy>       pieces; // dst_off = position in the raw buffer (records start 16-B aligned)
   uint64_t                      raw_bytes = 0;
   std::vector<msgpu_path_info>  paths;

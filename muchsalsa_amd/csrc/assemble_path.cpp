@@ -189,10 +189,10 @@ struct PathLayout {
     auto           it  = vm.find(key);
     if (it != vm.end()) return it->second;
     if (shared && static_cast<size_t>(read) + 1 < shared->row_start.size()) { // the read's own ~50 rows only
-      const auto b  = shared->row_keys.begin() + static_cast<long>(shared->row_start[read]);
-      const auto e  = shared->row_keys.begin() + static_cast<long>(shared->row_start[read + 1]);
-      const auto lo = std::lower_bound(b, e, key);
-      if (lo != e && *lo == key) return &shared->rows[static_cast<size_t>(lo - shared->row_keys.begin())];
+      const auto b  = shared->row_recs.begin() + static_cast<long>(shared->row_start[read]);
+      const auto e  = shared->row_recs.begin() + static_cast<long>(shared->row_start[read + 1]);
+      const auto lo = std::lower_bound(b, e, key, [](const msgpu_assembly::RowRec &r, uint64_t k) { return r.key < k; });
+      if (lo != e && lo->key == key) return &shared->rows[lo->idx]; // the first of equal keys = the lowest line
     }
     throw LayoutError("no VertexMatch for read " + std::to_string(read) + " on anchor " + std::to_string(anchor));
   }
@@ -842,60 +842,6 @@ void msgpu_assembly_free(msgpu_assembly *a) {
 }
 const char *msgpu_assembly_last_error(const msgpu_assembly *a) { return a ? a->err : "null assembly"; }
 
-int msgpu_assembly_set_rows(msgpu_assembly *a, const msgpu_row *rows, size_t n_rows) {
-  if (!a || (n_rows && !rows)) return MSGPU_E_ARG;
-  try {
-    // bucket by read id (dense Registry ids: a counting sort), then order each read's few rows by (anchor, line)
-    uint32_t max_read = 0;
-    for (size_t i = 0; i < n_rows; ++i) max_read = std::max(max_read, rows[i].read_id);
-    std::vector<uint64_t> start(static_cast<size_t>(max_read) + 2, 0);
-    for (size_t i = 0; i < n_rows; ++i) ++start[rows[i].read_id + 1];
-    for (size_t r = 0; r + 1 < start.size(); ++r) start[r + 1] += start[r];
-    std::vector<uint32_t> order(n_rows);
-    {
-      std::vector<uint64_t> cur(start.begin(), start.end() - 1);
-      for (size_t i = 0; i < n_rows; ++i) order[cur[rows[i].read_id]++] = static_cast<uint32_t>(i);
-    }
-    auto key = [&](uint32_t i) { return (static_cast<uint64_t>(rows[i].read_id) << 32) | rows[i].anchor_id; };
-    a->rows.resize(n_rows);
-    a->row_keys.resize(n_rows);
-    // per read: order its rows, then gather them -- independent per read, so split the reads over host threads
-    const size_t n_reads = start.size() - 1;
-    auto         work    = [&](size_t r0, size_t r1) {
-      for (size_t r = r0; r < r1; ++r)
-        std::sort(order.begin() + static_cast<long>(start[r]), order.begin() + static_cast<long>(start[r + 1]),
-                  [&](uint32_t x, uint32_t y) { // lowest line first: MatchMap.cpp:64-80
-                    return rows[x].anchor_id != rows[y].anchor_id ? rows[x].anchor_id < rows[y].anchor_id
-                                                                  : rows[x].line < rows[y].line;
-                  });
-      for (size_t i = start[r0]; i < start[r1]; ++i) {
-        a->rows[i]     = rows[order[i]];
-        a->row_keys[i] = key(order[i]);
-      }
-    };
-    unsigned nt = std::thread::hardware_concurrency();
-    nt          = nt == 0 ? 1 : (nt > 16 ? 16 : nt);
-    if (n_rows < (1u << 16) || nt == 1) {
-      work(0, n_reads);
-    } else {
-      std::vector<std::thread> pool;
-      size_t                   r0 = 0;
-      for (unsigned t = 0; t < nt; ++t) { // equal shares of ROWS, cut at read boundaries
-        const uint64_t want = n_rows * (t + 1) / nt;
-        size_t         r1   = t + 1 == nt ? n_reads
-                                          : static_cast<size_t>(std::upper_bound(start.begin(), start.end(), want) - start.begin()) - 1;
-        if (r1 < r0) r1 = r0;
-        if (r1 > n_reads) r1 = n_reads;
-        pool.emplace_back(work, r0, r1);
-        r0 = r1;
-      }
-      for (auto &th : pool) th.join();
-    }
-    a->row_start = std::move(start);
-  } catch (std::bad_alloc const &) { return MSGPU_E_NOMEM; }
-  return MSGPU_OK;
-}
-
 namespace {
 
 int check_input(const msgpu_path_input *in) {
@@ -1053,6 +999,99 @@ LayoutPool               *layout_pool() {
 }
 
 } // namespace
+
+// MatchMap::getVertexMatch for every later path: the rows grouped by read (dense Registry ids: a counting sort), each
+// read's few rows ordered by (anchor, line) -- lowest line first, MatchMap.cpp:64-80.  5 M rows are a job of their own,
+// so every pass runs on the layout threads: chunks of the input count their reads (one histogram per chunk), a prefix
+// over (read, chunk) hands every chunk its slots, the chunks scatter their row numbers without atomics (input order
+// inside a read is kept), and the reads are finished in parallel (a PAF grouped by query is already in order there).
+int msgpu_assembly_set_rows(msgpu_assembly *a, const msgpu_row *rows, size_t n_rows) {
+  if (!a || (n_rows && !rows)) return MSGPU_E_ARG;
+  if (n_rows >= 0xffffffffull) return MSGPU_E_ARG;
+  try {
+    unsigned nt = std::thread::hardware_concurrency();
+    nt          = nt == 0 ? 1 : (nt > 16 ? 16 : nt);
+    if (n_rows < (1u << 16)) nt = 1;
+    LayoutPool                  *pool = layout_pool();
+    std::lock_guard<std::mutex> one(pool->run_lock);
+    auto chunk = [&](unsigned t) { return std::make_pair(n_rows * t / nt, n_rows * (t + 1) / nt); };
+    std::atomic<unsigned> next{0};
+    auto                  fan = [&](const std::function<void(unsigned)> &body) { // body(t) for t = 0 .. nt-1 on the pool
+      next.store(0);
+      const std::function<void()> job = [&] {
+        for (unsigned t = next.fetch_add(1); t < nt; t = next.fetch_add(1)) body(t);
+      };
+      if (nt == 1) job();
+      else pool->run(nt - 1, job);
+    };
+    std::vector<uint32_t> cmax(nt, 0);
+    fan([&](unsigned t) {
+      uint32_t m = 0;
+      for (size_t i = chunk(t).first; i < chunk(t).second; ++i) m = std::max(m, rows[i].read_id);
+      cmax[t] = m;
+    });
+    const size_t n_reads = n_rows ? static_cast<size_t>(*std::max_element(cmax.begin(), cmax.end())) + 1 : 0;
+    std::vector<uint32_t> hist(static_cast<size_t>(nt) * n_reads, 0); // hist[t * n_reads + read]
+    fan([&](unsigned t) {
+      uint32_t *h = hist.data() + static_cast<size_t>(t) * n_reads;
+      for (size_t i = chunk(t).first; i < chunk(t).second; ++i) ++h[rows[i].read_id];
+    });
+    std::vector<uint64_t> start(n_reads + 1, 0);
+    {
+      // rows per read (parallel over read ranges), then the running sum over reads (serial, n_reads adds), then every
+      // (read, chunk) cell becomes the first slot of that chunk's rows of that read
+      fan([&](unsigned t) {
+        for (size_t r = n_reads * t / nt; r < n_reads * (t + 1) / nt; ++r) {
+          uint64_t c = 0;
+          for (unsigned k = 0; k < nt; ++k) c += hist[static_cast<size_t>(k) * n_reads + r];
+          start[r + 1] = c;
+        }
+      });
+      for (size_t r = 0; r < n_reads; ++r) start[r + 1] += start[r];
+      fan([&](unsigned t) {
+        for (size_t r = n_reads * t / nt; r < n_reads * (t + 1) / nt; ++r) {
+          uint32_t run = static_cast<uint32_t>(start[r]);
+          for (unsigned k = 0; k < nt; ++k) {
+            uint32_t &cell = hist[static_cast<size_t>(k) * n_reads + r];
+            const uint32_t c = cell;
+            cell             = run;
+            run += c;
+          }
+        }
+      });
+    }
+    // the scatter carries the sort key along, so nothing below reads the input out of order
+    a->row_recs.resize(n_rows);
+    a->rows.resize(n_rows);
+    msgpu_assembly::RowRec *recs = a->row_recs.data();
+    fan([&](unsigned t) {
+      uint32_t *h = hist.data() + static_cast<size_t>(t) * n_reads;
+      for (size_t i = chunk(t).first; i < chunk(t).second; ++i) {
+        const msgpu_row &row = rows[i];
+        a->rows[i]           = row;
+        recs[h[row.read_id]++] =
+            msgpu_assembly::RowRec{(static_cast<uint64_t>(row.read_id) << 32) | row.anchor_id, row.line, static_cast<uint32_t>(i)};
+      }
+    });
+    auto less = [](const msgpu_assembly::RowRec &x, const msgpu_assembly::RowRec &y) { // lowest line first: MatchMap.cpp:64-80
+      return x.key != y.key ? x.key < y.key : x.line < y.line;
+    };
+    fan([&](unsigned t) { // equal shares of ROWS, cut at read boundaries
+      auto cut = [&](uint64_t want) {
+        return static_cast<size_t>(std::upper_bound(start.begin(), start.end(), want) - start.begin()) - 1;
+      };
+      const size_t r0 = t == 0 ? 0 : cut(n_rows * t / nt), r1 = t + 1 == nt ? n_reads : cut(n_rows * (t + 1) / nt);
+      for (size_t r = r0; r < r1; ++r) {
+        msgpu_assembly::RowRec *b = recs + start[r], *e = recs + start[r + 1];
+        if (!std::is_sorted(b, e, less)) std::sort(b, e, less);
+      }
+    });
+    a->row_start = std::move(start);
+  } catch (std::bad_alloc const &) { return MSGPU_E_NOMEM; } catch (std::system_error const &) {
+    return MSGPU_E_NOMEM; // could not start a thread
+  }
+  return MSGPU_OK;
+}
 
 int msgpu_assembly_add_path(msgpu_assembly *a, const msgpu_path_input *in) {
   if (!a) return MSGPU_E_ARG;
