@@ -154,6 +154,7 @@ def host_to_host_leg(ctx, rows, n_batches, reps=6):
     and id tables in pinned host memory], through msgpu_overlap_batched (the ThreadPool replacement)."""
     from muchsalsa_amd import overlap
     pinned = overlap.PinnedRows(rows)
+    ctx.set_stream(None)  # the context's own compute stream next to its copy stream (the timed steps ran on torch's)
     try:
         ctx.overlap_batched(pinned, n_batches, copy=False)  # warm-up: pinned result arena, second table set
         walls, infos = [], []
@@ -590,7 +591,8 @@ def main():
     errors = {}
     if world == 1 and rank == 0 and not args.kernels_only:
         try:
-            h2h = host_to_host_leg(ctx, rows, args.batches)
+            if args.batches >= 0 and not (args.batches == 0 and args.assemble_window_mb < 0):  # counter passes skip it
+                h2h = host_to_host_leg(ctx, rows, args.batches)
         except Exception as exc:  # noqa: BLE001 -- the legs reported BESIDE the metric must never cost the metric line
             errors["host_to_host"] = "%s: %s" % (type(exc).__name__, exc)
         if args.assemble_window_mb >= 0 and not args.no_consensus:

@@ -114,7 +114,8 @@ class OverlapContext:
             raise MsgpuError(rc, self._L.msgpu_last_error(self._h).decode())
 
     def set_stream(self, hip_stream_ptr):
-        self._check(self._L.msgpu_set_stream(self._h, C.c_void_p(hip_stream_ptr)))
+        """run on an existing HIP stream (raw hipStream_t value); None / 0 = the context's own stream again"""
+        self._check(self._L.msgpu_set_stream(self._h, C.c_void_p(hip_stream_ptr or None)))
 
     def set_shard(self, shard, n_shards):
         self._check(self._L.msgpu_set_shard(self._h, shard, n_shards))

@@ -22,3 +22,12 @@ def assert_tables_equal(got, want, what=""):
         else:
             bad = np.nonzero(g != w)[0]
             assert len(bad) == 0, "%s %s differs at %d entries, first %d" % (what, name, len(bad), bad[0])
+
+
+# north_star: "consensus sequences within a stated edit-distance tolerance" (DESIGN.md section 9).
+#  * against the restatement of ap.cpp (oracle/ms_assemble_py.py) on the same input: edit distance 0 -- the three output
+#    texts are compared byte for byte;
+#  * against the genome the reads were cut from, with exact PAF coordinates: at most this many edits per placed anchor
+#    (the reference's inclusive slices duplicate a few bases at every anchor joint, SequenceUtils.cpp:27-38).
+A9_TOLERANCE_VS_RESTATEMENT = 0
+A9_TOLERANCE_EDITS_PER_ANCHOR_VS_GENOME = 8

@@ -8,7 +8,7 @@ import os
 import numpy as np
 import pytest
 
-from helpers import assert_tables_equal
+from helpers import A9_TOLERANCE_VS_RESTATEMENT, assert_tables_equal
 
 pytestmark = pytest.mark.gpu
 
@@ -142,6 +142,7 @@ def test_assemble_path_whole_genome(oracle, cfg, two_bit, tmp_path):
         on_path[[r["id"] for r in p]] = True
     vm = {(int(r["read_id"]), int(r["anchor_id"])): r for r in rows[on_path[rows["read_id"]]]}
     want = [assemble_path(p, st, vm, {}, nano, illu, k) for k, (p, st) in enumerate(paths)]
+    assert A9_TOLERANCE_VS_RESTATEMENT == 0  # the stated tolerance: identical texts
     assert asm.text(2) == b"".join(r["paf"] for r in want)
     assert asm.text(0) == b"".join(r["target_fa"] for r in want)
     assert asm.text(1) == b"".join(r["query_fa"] for r in want)

@@ -10,6 +10,7 @@ import numpy as np
 import pytest
 
 from graphcases import make_dataset
+from helpers import A9_TOLERANCE_EDITS_PER_ANCHOR_VS_GENOME
 
 pytestmark = pytest.mark.gpu
 _COMP = bytes.maketrans(b"ACGT", b"TGCA")
@@ -54,7 +55,7 @@ def test_files_in_files_out(oracle, tmp_path, seed, jitter, fastq):
     assert len(longest["target"]) > 0.95 * len(genome)
     if jitter == 0:
         lo, hi = int(lay["r_start"].min()), int((lay["r_start"] + lay["r_len"]).max())
-        bound = 8 * longest["n_anchors"]
+        bound = A9_TOLERANCE_EDITS_PER_ANCHOR_VS_GENOME * longest["n_anchors"]
         d = oracle.edit_distance_banded(longest["target"], genome[lo:hi], bound)
         if d > bound:  # the contig may be the other strand
             d = oracle.edit_distance_banded(longest["target"].translate(_COMP)[::-1], genome[lo:hi], bound)

@@ -37,6 +37,8 @@ def main():
             if c not in counters:
                 counters.append(c)
         for (k, c), (tot, disp) in per_run.items():
+            if c in acc.get(k, {}) and "gather" in os.path.basename(f) and "k_gather" not in k:
+                continue  # the gather passes are there for the gather kernels; the other kernels keep their own passes
             acc.setdefault(k, {})[c] = (tot / max(len(disp), 1), len(disp))
     with open(os.path.join(out, "pmc_summary.csv"), "w") as f:
         f.write("kernel,dispatches," + ",".join(counters) + "\n")
