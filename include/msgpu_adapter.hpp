@@ -84,6 +84,25 @@ public:
   // the whole "for edge: Job(chainingAndOverlaps); wg.wait()" phase (src/main.cpp:170-178)
   void chainingAndOverlaps() { check(msgpu_chaining_and_overlaps(m_ctx), m_ctx); }
 
+  // read() must have run.  MatchMap::calculateEdges() + the chainingAndOverlaps fan-out as ONE msgpu_overlap_batched
+  // call (the ThreadPool / WaitGroup phases of src/main.cpp:153-178 as windows of owner reads on two HIP streams): the
+  // tables arrive in host memory while later windows still compute.  Same tables as calculateEdges() +
+  // chainingAndOverlaps() + tables(), bit for bit.
+  OverlapTables overlapBatched(unsigned nBatches = 0) {
+    std::size_t      n    = 0;
+    msgpu_row const *rows = msgpu_paf_rows(m_paf, &n);
+    msgpu_host_tables h;
+    check(msgpu_overlap_batched(m_ctx, rows, n, nBatches, &h), m_ctx);
+    OverlapTables t;
+    t.edges.assign(h.edges, h.edges + h.n_edges);
+    t.ems.assign(h.ems, h.ems + h.n_ems);
+    t.orders.assign(h.orders, h.orders + h.n_orders);
+    t.ids.assign(h.ids, h.ids + h.n_ids);
+    t.readLength.assign(h.read_len, h.read_len + h.n_reads);
+    t.readFirstLine.assign(h.read_first_line, h.read_first_line + h.n_reads);
+    return t;
+  }
+
   // Graph::getOrder() / Graph::getSize() as TRACEd at src/main.cpp:159
   msgpu_counts counts() const {
     msgpu_counts c;
