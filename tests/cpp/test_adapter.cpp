@@ -128,6 +128,19 @@ int main(int argc, char **argv) {
   core.calculateEdges();
   core.chainingAndOverlaps();
   auto const t = core.tables();
+  { // the same phases as one batched call (msgpu_overlap_batched) must hand back the same tables
+    auto const b = core.overlapBatched(3);
+    auto same = [](auto const &x, auto const &y) {
+      return x.size() == y.size() && (x.empty() || std::memcmp(x.data(), y.data(), x.size() * sizeof(x[0])) == 0);
+    };
+    if (!same(b.edges, t.edges) || !same(b.ems, t.ems) || !same(b.orders, t.orders) || !same(b.ids, t.ids) ||
+        !same(b.readLength, t.readLength) || !same(b.readFirstLine, t.readFirstLine)) {
+      std::puts("FAIL: overlapBatched tables differ from the single-pass tables");
+      return 1;
+    }
+    core.calculateEdges(); // the context is left loaded: rebuild its own tables for what follows
+    core.chainingAndOverlaps();
+  }
   mock::Graph    graph;
   mock::MatchMap matchMap;
   mock::Registry rn, ri;

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Per-rank stage times of one cfg3 job when the edges are cut into N shards (run on ONE GPU as shard 0 of N):
-what each rank of an N-GPU run spends before the all-gather.  python tools/shard_projection.py [workload]"""
+"""Per-rank stage times of one cfg3 job when the edges are cut into N shards (run on ONE GPU as shard 0 and as the last
+shard of N): what each rank of an N-GPU run spends before the all-gather, index build included, and the bytes it would
+put into the all-gather.  A projection, not a scaling measurement.  python tools/shard_projection.py [workload]"""
 import json
 import os
 import sys
@@ -23,9 +24,10 @@ def main():
     for n in (1, 2, 4, 8):
         ctx = overlap.OverlapContext(device=0)
         ctx.set_id_space(len(read_names), len(anchor_names))
-        if n > 1:
-            ctx.set_shard(0, n)
         best = None
+        shard = 0 if len(sys.argv) < 3 else min(int(sys.argv[2]), n - 1)
+        if n > 1:
+            ctx.set_shard(shard, n)
         for it in range(6):
             torch.cuda.synchronize()
             t0 = time.perf_counter()
@@ -38,10 +40,12 @@ def main():
                 tm = ctx.timings()
                 best = (dt, tm.index_ms, tm.candidates_ms, tm.chain_ms, tm.compact_ms)
         c = ctx.counts()
-        out[n] = dict(ms=best[0], index=best[1], candidates=best[2], chain=best[3], compact=best[4],
-                      edges=int(c.n_edges), orders=int(c.n_orders))
+        out[n] = dict(ms=round(best[0], 4), index=round(best[1], 4), candidates=round(best[2], 4), chain=round(best[3], 4),
+                      compact=round(best[4], 4), edges=int(c.n_edges), orders=int(c.n_orders),
+                      slab_mb=round((32 * c.n_edges + 64 * c.n_orders + 4 * c.n_ids) / 1e6, 2),
+                      gathered_mb=round(n * (32 * c.n_edges + 64 * c.n_orders + 4 * c.n_ids) / 1e6, 1))
         ctx.close()
-    print(json.dumps(out, indent=1))
+    print(json.dumps(out))
 
 
 if __name__ == "__main__":
