@@ -1,6 +1,7 @@
 // asm_internal.h -- the assembly object shared by assemble_path.cpp (host layout) and msgpu_seq.hip (device finish).
 #pragma once
 #include <cstdint>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -15,8 +16,22 @@ struct msgpu_assembly {
     uint64_t key; // read id << 32 | anchor id
     uint32_t line, idx; // idx = position in rows
   };
-  std::vector<msgpu_row>        rows;
-  std::vector<RowRec>           row_recs;
+  template <class T> struct RawBuf { // storage that is NOT zero-filled on allocation (hundreds of MB here)
+    std::unique_ptr<T[]> p;
+    size_t               n = 0;
+    void   resize(size_t k) {
+      p.reset(k ? new T[k] : nullptr); // default-initialisation: no fill for these plain records
+      n = k;
+    }
+    T       *data() { return p.get(); }
+    const T *data() const { return p.get(); }
+    const T *begin() const { return p.get(); }
+    size_t   size() const { return n; }
+    T       &operator[](size_t i) { return p[i]; }
+    const T &operator[](size_t i) const { return p[i]; }
+  };
+  RawBuf<msgpu_row>             rows;
+  RawBuf<RowRec>                row_recs;
   std::vector<uint64_t>         row_start;
   std::vector<msgpu_copy>       pieces; // dst_off = position in the raw buffer (records start 16-B aligned)
   uint64_t                      raw_bytes = 0;

@@ -1000,93 +1000,95 @@ LayoutPool               *layout_pool() {
 
 } // namespace
 
-// MatchMap::getVertexMatch for every later path: the rows grouped by read (dense Registry ids: a counting sort), each
-// read's few rows ordered by (anchor, line) -- lowest line first, MatchMap.cpp:64-80.  5 M rows are a job of their own,
-// so every pass runs on the layout threads: chunks of the input count their reads (one histogram per chunk), a prefix
-// over (read, chunk) hands every chunk its slots, the chunks scatter their row numbers without atomics (input order
-// inside a read is kept), and the reads are finished in parallel (a PAF grouped by query is already in order there).
+// MatchMap::getVertexMatch for every later path: one record per row, grouped by read (dense Registry ids) and, inside a
+// read, ordered by (anchor, line) -- lowest line first, MatchMap.cpp:64-80.  5 M rows are a job of their own, and a plain
+// counting sort by read scatters every record to a random place (one cache miss per row).  So it runs in two levels on
+// the layout threads, every pass either sequential or inside a cache-sized block:
+//   1. the chunks of the input count their rows per PARTITION (a few hundred consecutive read ids);
+//   2. a prefix over (partition, chunk) hands every chunk its slots; the chunks copy their rows (input order) and append
+//      a record {read << 32 | anchor, line, row number} to each partition -- a few hundred sequential write streams;
+//   3. every partition (tens of thousands of records, cache resident) is counting-sorted by read into its final place
+//      and its reads are put in (anchor, line) order (a PAF grouped by query is already in order there).
 int msgpu_assembly_set_rows(msgpu_assembly *a, const msgpu_row *rows, size_t n_rows) {
   if (!a || (n_rows && !rows)) return MSGPU_E_ARG;
   if (n_rows >= 0xffffffffull) return MSGPU_E_ARG;
   try {
+    typedef msgpu_assembly::RowRec Rec;
     unsigned nt = std::thread::hardware_concurrency();
     nt          = nt == 0 ? 1 : (nt > 16 ? 16 : nt);
     if (n_rows < (1u << 16)) nt = 1;
     LayoutPool                  *pool = layout_pool();
     std::lock_guard<std::mutex> one(pool->run_lock);
     auto chunk = [&](unsigned t) { return std::make_pair(n_rows * t / nt, n_rows * (t + 1) / nt); };
-    std::atomic<unsigned> next{0};
-    auto                  fan = [&](const std::function<void(unsigned)> &body) { // body(t) for t = 0 .. nt-1 on the pool
+    std::atomic<size_t> next{0};
+    auto                fan = [&](size_t n_items, const std::function<void(size_t)> &body) { // body(i), i < n_items, on the pool
       next.store(0);
       const std::function<void()> job = [&] {
-        for (unsigned t = next.fetch_add(1); t < nt; t = next.fetch_add(1)) body(t);
+        for (size_t i = next.fetch_add(1); i < n_items; i = next.fetch_add(1)) body(i);
       };
       if (nt == 1) job();
       else pool->run(nt - 1, job);
     };
     std::vector<uint32_t> cmax(nt, 0);
-    fan([&](unsigned t) {
+    fan(nt, [&](size_t t) {
       uint32_t m = 0;
       for (size_t i = chunk(t).first; i < chunk(t).second; ++i) m = std::max(m, rows[i].read_id);
       cmax[t] = m;
     });
     const size_t n_reads = n_rows ? static_cast<size_t>(*std::max_element(cmax.begin(), cmax.end())) + 1 : 0;
-    std::vector<uint32_t> hist(static_cast<size_t>(nt) * n_reads, 0); // hist[t * n_reads + read]
-    fan([&](unsigned t) {
-      uint32_t *h = hist.data() + static_cast<size_t>(t) * n_reads;
-      for (size_t i = chunk(t).first; i < chunk(t).second; ++i) ++h[rows[i].read_id];
+    // partitions of 2^shift consecutive read ids, at most 1024 of them
+    unsigned shift = 8;
+    while ((n_reads >> shift) >= 1024) ++shift;
+    const size_t          n_part = (n_reads >> shift) + 1;
+    std::vector<uint64_t> cell(static_cast<size_t>(nt) * n_part, 0); // rows of chunk t in partition p, then their first slot
+    fan(nt, [&](size_t t) {
+      uint64_t *h = cell.data() + t * n_part;
+      for (size_t i = chunk(t).first; i < chunk(t).second; ++i) ++h[rows[i].read_id >> shift];
     });
-    std::vector<uint64_t> start(n_reads + 1, 0);
-    {
-      // rows per read (parallel over read ranges), then the running sum over reads (serial, n_reads adds), then every
-      // (read, chunk) cell becomes the first slot of that chunk's rows of that read
-      fan([&](unsigned t) {
-        for (size_t r = n_reads * t / nt; r < n_reads * (t + 1) / nt; ++r) {
-          uint64_t c = 0;
-          for (unsigned k = 0; k < nt; ++k) c += hist[static_cast<size_t>(k) * n_reads + r];
-          start[r + 1] = c;
-        }
-      });
-      for (size_t r = 0; r < n_reads; ++r) start[r + 1] += start[r];
-      fan([&](unsigned t) {
-        for (size_t r = n_reads * t / nt; r < n_reads * (t + 1) / nt; ++r) {
-          uint32_t run = static_cast<uint32_t>(start[r]);
-          for (unsigned k = 0; k < nt; ++k) {
-            uint32_t &cell = hist[static_cast<size_t>(k) * n_reads + r];
-            const uint32_t c = cell;
-            cell             = run;
-            run += c;
-          }
-        }
-      });
+    std::vector<uint64_t> part_start(n_part + 1, 0);
+    for (size_t p = 0; p < n_part; ++p) {
+      uint64_t run = part_start[p];
+      for (unsigned t = 0; t < nt; ++t) {
+        uint64_t &c = cell[static_cast<size_t>(t) * n_part + p];
+        const uint64_t k = c;
+        c                = run;
+        run += k;
+      }
+      part_start[p + 1] = run;
     }
-    // the scatter carries the sort key along, so nothing below reads the input out of order
-    a->row_recs.resize(n_rows);
     a->rows.resize(n_rows);
-    msgpu_assembly::RowRec *recs = a->row_recs.data();
-    fan([&](unsigned t) {
-      uint32_t *h = hist.data() + static_cast<size_t>(t) * n_reads;
+    a->row_recs.resize(n_rows);
+    msgpu_assembly::RawBuf<Rec> staged;
+    staged.resize(n_rows);
+    fan(nt, [&](size_t t) {
+      uint64_t *h = cell.data() + t * n_part;
       for (size_t i = chunk(t).first; i < chunk(t).second; ++i) {
         const msgpu_row &row = rows[i];
         a->rows[i]           = row;
-        recs[h[row.read_id]++] =
-            msgpu_assembly::RowRec{(static_cast<uint64_t>(row.read_id) << 32) | row.anchor_id, row.line, static_cast<uint32_t>(i)};
+        staged[h[row.read_id >> shift]++] =
+            Rec{(static_cast<uint64_t>(row.read_id) << 32) | row.anchor_id, row.line, static_cast<uint32_t>(i)};
       }
     });
-    auto less = [](const msgpu_assembly::RowRec &x, const msgpu_assembly::RowRec &y) { // lowest line first: MatchMap.cpp:64-80
-      return x.key != y.key ? x.key < y.key : x.line < y.line;
-    };
-    fan([&](unsigned t) { // equal shares of ROWS, cut at read boundaries
-      auto cut = [&](uint64_t want) {
-        return static_cast<size_t>(std::upper_bound(start.begin(), start.end(), want) - start.begin()) - 1;
-      };
-      const size_t r0 = t == 0 ? 0 : cut(n_rows * t / nt), r1 = t + 1 == nt ? n_reads : cut(n_rows * (t + 1) / nt);
+    std::vector<uint64_t> start(n_reads + 1, 0);
+    Rec                  *recs = a->row_recs.data();
+    auto less = [](const Rec &x, const Rec &y) { return x.key != y.key ? x.key < y.key : x.line < y.line; };
+    fan(n_part, [&](size_t p) {
+      const size_t r0 = p << shift, r1 = std::min(n_reads, (p + 1) << shift);
+      if (r0 >= r1) return;
+      const Rec *b = staged.data() + part_start[p], *e = staged.data() + part_start[p + 1];
+      std::vector<uint64_t> cur(r1 - r0 + 1, 0);
+      for (const Rec *q = b; q != e; ++q) ++cur[(q->key >> 32) - r0 + 1];
+      cur[0] = part_start[p];
+      for (size_t r = 0; r + 1 < cur.size(); ++r) cur[r + 1] += cur[r];
+      for (size_t r = r0; r < r1; ++r) start[r] = cur[r - r0]; // partitions are consecutive in read order
+      for (const Rec *q = b; q != e; ++q) recs[cur[(q->key >> 32) - r0]++] = *q; // input order inside a read is kept
       for (size_t r = r0; r < r1; ++r) {
-        msgpu_assembly::RowRec *b = recs + start[r], *e = recs + start[r + 1];
-        if (!std::is_sorted(b, e, less)) std::sort(b, e, less);
+        Rec *rb = recs + start[r], *re = recs + cur[r - r0];
+        if (!std::is_sorted(rb, re, less)) std::sort(rb, re, less);
       }
     });
-    a->row_start = std::move(start);
+    start[n_reads] = n_rows;
+    a->row_start   = std::move(start);
   } catch (std::bad_alloc const &) { return MSGPU_E_NOMEM; } catch (std::system_error const &) {
     return MSGPU_E_NOMEM; // could not start a thread
   }
