@@ -1512,13 +1512,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     // The loop carries only the score and the predecessor (9 vector instructions per step instead of 15 with the
     // 64-bit path mask): "k compatible with me" is the sign bit of the bit-reversed mask, shifted left once per step.
     uint32_t pred = static_cast<uint32_t>(lane);
-    uint64_t rev  = __builtin_bitreverse64(mycm); // bit k of mycm -> bit 63 - k
-    for (int k = 0; k + 1 < static_cast<int>(n); ++k) {
+    // bit k of mycm -> the sign bit after k shifts, in two 32-bit halves (k < 32, k >= 32): 32-bit compare and shift
+    uint32_t rev = __builtin_bitreverse32(static_cast<uint32_t>(mycm));
+    const int n1 = static_cast<int>(n) - 1, nlo = n1 < 32 ? n1 : 32;
+    for (int k = 0; k < nlo; ++k) {
       const double k_pop = rl_f64(pop, k);
       const double cand  = k_pop + em_score; // :189
-      const bool   comp  = static_cast<int64_t>(rev) < 0;
+      const bool   comp  = static_cast<int32_t>(rev) < 0;
       rev <<= 1;
       if (comp && cand > pop) { // :190-197
+        pop  = cand;
+        pred = static_cast<uint32_t>(k);
+      }
+    }
+    rev = __builtin_bitreverse32(static_cast<uint32_t>(mycm >> 32));
+    for (int k = 32; k < n1; ++k) {
+      const double k_pop = rl_f64(pop, k);
+      const double cand  = k_pop + em_score;
+      const bool   comp  = static_cast<int32_t>(rev) < 0;
+      rev <<= 1;
+      if (comp && cand > pop) {
         pop  = cand;
         pred = static_cast<uint32_t>(k);
       }
