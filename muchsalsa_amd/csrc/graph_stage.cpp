@@ -119,6 +119,7 @@ Csr build_csr(uint32_t n, const uint32_t *from, const uint32_t *to, size_t m, bo
     else c.arcs[cur[from[i]]++] = Arc{to[i], static_cast<uint32_t>(i)};
   }
   for (uint32_t v = 0; v < n; ++v) {
+    if (c.off[v + 1] - c.off[v] < 2) continue;
     Arc *b = c.arcs.data() + c.off[v], *e = c.arcs.data() + c.off[v + 1];
     bool sorted = true;
     for (Arc *p = b; p + 1 < e && sorted; ++p) sorted = p->to <= (p + 1)->to;
@@ -1047,8 +1048,8 @@ int msgpu_graph_create(const msgpu_edge *edges, uint64_t n_edges, const msgpu_ed
       g->adj = build_csr(n_reads, ea.data(), eb.data(), n_edges, true);
     }
     for (uint32_t v = 0; v < n_reads; ++v) // duplicate edge
-      for (const Arc *t = g->adj.begin(v); t + 1 < g->adj.end(v); ++t)
-        if (t->to == (t + 1)->to) return MSGPU_E_ARG;
+      for (uint32_t q = g->adj.off[v]; q + 1 < g->adj.off[v + 1]; ++q)
+        if (g->adj.arcs[q].to == g->adj.arcs[q + 1].to) return MSGPU_E_ARG;
     g->stats.n_vertices_in = n_reads;
     g->stats.n_edges_in    = n_edges;
     tick("graph create");

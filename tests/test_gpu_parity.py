@@ -54,6 +54,23 @@ def test_every_sort_path_of_the_index(oracle, n_anchors, lo, hi):
     assert_tables_equal(_gpu_tables(allrows), want, "shuffled with duplicates")
 
 
+@pytest.mark.parametrize("coverage,n_anchors", [(40, 400), (85, 60), (95, 60), (300, 40)])
+def test_scaffold_lengths_around_the_pass1_context(oracle, coverage, n_anchors):
+    """Scaffolds are kept in read-id order.  With the input grouped by anchor, k_index_pass1 places every row inside its
+    scaffold from an LDS tile holding 128 rows of context on either side; a scaffold that does not fit raises IXF_BIGSCAF
+    and the generic scaffold build (rank by read id) runs.  Scaffolds of tens of rows (the tile path, straddling
+    workgroup boundaries), just under and around the limit, and of 500 rows (generic), grouped and shuffled."""
+    from muchsalsa_amd import synth
+    rows, _, _ = synth.accepted_rows(synth.paf_table(500, 4000, n_anchors, 77, coverage=coverage))
+    longest = int(np.bincount(rows["anchor_id"]).max())
+    assert longest > (30 if coverage == 40 else 100), longest
+    want = oracle.overlap(rows)
+    assert_tables_equal(_gpu_tables(rows), want, "grouped, longest scaffold %d" % longest)
+    sh = rows.copy()
+    np.random.default_rng(coverage).shuffle(sh)
+    assert_tables_equal(_gpu_tables(sh), want, "shuffled, longest scaffold %d" % longest)
+
+
 @pytest.mark.parametrize("dense", [False, True])
 def test_mixed_direction_edges(oracle, dense):
     """Rows of one read with both strands give edges whose EdgeMatches differ in direction: the pair sweep then skips

@@ -26,6 +26,8 @@ def main():
         read_len = int(rng.integers(2000, 12000))
         cov = int(rng.choice([4, 8, 10, 20, 40]))
         n_anchors = int(rng.integers(max(20, n_reads // 4), n_reads * 6))
+        if case % 5 == 4:  # scaffolds far longer than the context pass 1 sorts them in (generic scaffold build)
+            cov, n_anchors = int(rng.choice([150, 300])), int(rng.integers(10, 60))
         rows, _, _ = synth.accepted_rows(synth.paf_table(n_reads, read_len, n_anchors, seed0 + case, coverage=cov))
         rows = rows.copy()
         mode = case % 4
@@ -40,12 +42,17 @@ def main():
             dup["n_lo"] += 5
             feed = np.concatenate([rows, dup])
             rng.shuffle(feed)
+        what = "case %d (reads %d, len %d, anchors %d, cov %d, mode %d)" % (case, n_reads, read_len, n_anchors, cov, mode)
         got = overlap.build_overlaps(feed)
-        assert_tables_equal(got, want, "case %d (reads %d, len %d, anchors %d, cov %d, mode %d)" % (
-            case, n_reads, read_len, n_anchors, cov, mode))
+        assert_tables_equal(got, want, what)
+        with overlap.OverlapContext(0) as ctx:  # and the same job as windows of owner reads
+            nb = int(rng.integers(1, 12))
+            got, _ = ctx.overlap_batched(feed, nb)
+            assert_tables_equal(got, want, what + ", %d windows" % nb)
+        scaf = np.bincount(rows["anchor_id"]).max() if len(rows) else 0
         n = want["edges"]["em_cnt"]
-        print("case %3d ok: %6d rows %6d edges, EdgeMatches per edge max %3d, orders %6d" % (
-            case, len(rows), len(n), int(n.max()) if len(n) else 0, len(want["orders"])), flush=True)
+        print("case %3d ok: %6d rows %6d edges, EdgeMatches per edge max %3d, orders %6d, longest scaffold %d" % (
+            case, len(rows), len(n), int(n.max()) if len(n) else 0, len(want["orders"]), int(scaf)), flush=True)
 
 
 if __name__ == "__main__":
