@@ -268,3 +268,47 @@ def test_limit_length_and_headers():
     L = _lib.lib()
     for n in (0, 1, 59, 60, 61, 120, 121, 6001):
         assert L.msgpu_fasta_text_bytes(5, n) == 5 + len(limit_length(b"A" * n)) + 1
+
+
+def test_row_table_install_at_scale(oracle, tmp_path):
+    """msgpu_assembly_set_rows on a table large enough for its threaded two-level counting sort (cfg2: 512 k rows),
+    grouped by anchor and shuffled with duplicate (read, anchor) rows of higher line numbers: every layout that looks
+    its VertexMatches up in the installed table equals the layout that was handed exactly its own rows."""
+    from muchsalsa_amd import synth
+    cfg = synth.CONFIGS["cfg2"]
+    rows, read_names, anchor_names = synth.accepted_rows(synth.paf_table(**cfg))
+    tables = oracle.overlap(rows)
+    G, r_start, r_fwd = synth.read_layout(cfg["n_reads"], cfg["read_len"], cfg["seed"])
+    ro = np.array([int(n[1:]) for n in read_names])
+    paths = synth.chain_paths(tables, r_start[ro], r_fwd[ro], cfg["read_len"], G // 4, max_reads=10, max_paths=12)
+    assert len(paths) >= 8
+    # layout only: no base is read, but every slice is clipped to its sequence's length
+    _, a_len = synth.anchor_layout(cfg["n_reads"], cfg["read_len"], cfg["n_anchors"], cfg["seed"])
+    ao = np.array([int(n[1:]) for n in anchor_names])
+    with open(tmp_path / "n.fa", "wb") as f:
+        f.write(b"".join(b">r%d\n" % i + b"A" * cfg["read_len"] + b"\n" for i in range(len(read_names))))
+    with open(tmp_path / "i.fa", "wb") as f:
+        f.write(b"".join(b">u%d\n" % i + b"C" * int(a_len[o]) + b"\n" for i, o in enumerate(ao)))
+    store = SeqStore(device=-1)
+    store.upload(NANOPORE, SeqFile(str(tmp_path / "n.fa")))
+    store.upload(ILLUMINA, SeqFile(str(tmp_path / "i.fa")))
+    ref = Assembly(store)
+    for k, (p, st) in enumerate(paths):  # every path with exactly the rows of its own reads
+        mine = rows[np.isin(rows["read_id"], [r["id"] for r in p])]
+        ref.add_path(p, st, mine, None, k)
+    rng = np.random.default_rng(3)
+    dup = rows[rng.choice(len(rows), 5000, replace=False)].copy()
+    dup["line"] = rows["line"].max() + 1 + np.arange(len(dup))  # the lowest line must win (MatchMap.cpp:64-80)
+    dup["n_lo"] += 11
+    shuffled = np.concatenate([rows, dup])
+    rng.shuffle(shuffled)
+    for name, table in (("grouped by anchor", rows), ("shuffled + duplicates", shuffled)):
+        got = Assembly(store)
+        got.set_rows(table)
+        status = got.add_prepared_batch([Assembly.prepare(p, st, None, None, k) for k, (p, st) in enumerate(paths)], 4)
+        assert not status.any(), name
+        assert got.text(2) == ref.text(2), name
+        assert got.pieces.tobytes() == ref.pieces.tobytes(), name
+        got.close()
+    ref.close()
+    store.close()
