@@ -188,7 +188,14 @@ struct PathLayout {
     const uint64_t key = (static_cast<uint64_t>(read) << 32) | anchor;
     auto           it  = vm.find(key);
     if (it != vm.end()) return it->second;
-    if (shared && static_cast<size_t>(read) + 1 < shared->row_start.size()) { // the read's own ~50 rows only
+    if (shared && static_cast<size_t>(anchor) + 1 < shared->anchor_start.size()) { // the anchor's own scaffold only
+      const msgpu_row *best = nullptr;
+      for (uint64_t i = shared->anchor_start[anchor], e = shared->anchor_start[static_cast<size_t>(anchor) + 1]; i < e; ++i) {
+        const msgpu_row &m = shared->rows[i];
+        if (m.read_id == read && (!best || m.line < best->line)) best = &m; // of equal keys the lowest line
+      }
+      if (best) return best;
+    } else if (shared && static_cast<size_t>(read) + 1 < shared->row_start.size()) { // the read's own ~50 rows only
       const auto b  = shared->row_recs.begin() + static_cast<long>(shared->row_start[read]);
       const auto e  = shared->row_recs.begin() + static_cast<long>(shared->row_start[read + 1]);
       const auto lo = std::lower_bound(b, e, key, [](const msgpu_assembly::RowRec &r, uint64_t k) { return r.key < k; });
@@ -1030,12 +1037,42 @@ int msgpu_assembly_set_rows(msgpu_assembly *a, const msgpu_row *rows, size_t n_r
       else pool->run(nt - 1, job);
     };
     std::vector<uint32_t> cmax(nt, 0);
+    std::vector<char>     asc(nt, 1); // chunk t's anchor ids never decrease (its first row compared with the row before it)
+    a->rows.resize(n_rows);
+    a->row_recs.resize(0);
+    a->row_start.clear();
+    a->anchor_start.clear();
     fan(nt, [&](size_t t) {
       uint32_t m = 0;
-      for (size_t i = chunk(t).first; i < chunk(t).second; ++i) m = std::max(m, rows[i].read_id);
+      bool     up = true;
+      const size_t b = chunk(t).first, e = chunk(t).second;
+      uint32_t     prev = b ? rows[b - 1].anchor_id : 0;
+      for (size_t i = b; i < e; ++i) {
+        m = std::max(m, rows[i].read_id);
+        up &= prev <= rows[i].anchor_id;
+        prev = rows[i].anchor_id;
+      }
+      if (e > b) memcpy(a->rows.data() + b, rows + b, (e - b) * sizeof(msgpu_row));
       cmax[t] = m;
+      asc[t]  = up;
     });
     const size_t n_reads = n_rows ? static_cast<size_t>(*std::max_element(cmax.begin(), cmax.end())) + 1 : 0;
+    if (n_rows && std::find(asc.begin(), asc.end(), 0) == asc.end()) {
+      // Grouped by ascending anchor id -- what a PAF is (grouped by query, ids handed out in first-seen order): the
+      // table needs no sort, only where each anchor's rows start.  Every chunk fills the starts of the anchors that
+      // begin inside it (and of the absent ids before them): disjoint stretches of anchor_start.
+      const size_t n_anchors = static_cast<size_t>(rows[n_rows - 1].anchor_id) + 1;
+      a->anchor_start.resize(n_anchors + 1);
+      uint64_t *st = a->anchor_start.data();
+      fan(nt, [&](size_t t) {
+        for (size_t i = chunk(t).first; i < chunk(t).second; ++i) {
+          const size_t from = i == 0 ? 0 : static_cast<size_t>(rows[i - 1].anchor_id) + 1;
+          for (size_t id = from; id <= rows[i].anchor_id; ++id) st[id] = i;
+        }
+      });
+      st[n_anchors] = n_rows;
+      return MSGPU_OK;
+    }
     // partitions of 2^shift consecutive read ids, at most 1024 of them
     unsigned shift = 8;
     while ((n_reads >> shift) >= 1024) ++shift;
@@ -1056,7 +1093,6 @@ int msgpu_assembly_set_rows(msgpu_assembly *a, const msgpu_row *rows, size_t n_r
       }
       part_start[p + 1] = run;
     }
-    a->rows.resize(n_rows);
     a->row_recs.resize(n_rows);
     msgpu_assembly::RawBuf<Rec> staged;
     staged.resize(n_rows);
@@ -1064,7 +1100,6 @@ int msgpu_assembly_set_rows(msgpu_assembly *a, const msgpu_row *rows, size_t n_r
       uint64_t *h = cell.data() + t * n_part;
       for (size_t i = chunk(t).first; i < chunk(t).second; ++i) {
         const msgpu_row &row = rows[i];
-        a->rows[i]           = row;
         staged[h[row.read_id >> shift]++] =
             Rec{(static_cast<uint64_t>(row.read_id) << 32) | row.anchor_id, row.line, static_cast<uint32_t>(i)};
       }

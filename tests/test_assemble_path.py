@@ -145,6 +145,40 @@ def test_chains_match_oracle_and_paf_text(world):
     assert e.value.code == _lib.E_NODEVICE
 
 
+@pytest.mark.parametrize("n_pad", [40, 70_000])
+def test_row_table_in_anchor_order(world, n_pad):
+    """Rows in ascending anchor-id order (what a PAF grouped by query yields): msgpu_assembly_set_rows records where
+    each anchor starts instead of sorting.  With anchor ids the table never mentions (between and after the ones it
+    has), higher-line duplicates ahead of the rows they repeat, one thread (40 extra rows) and many (70 k)."""
+    from oracle.ms_assemble_py import assemble_path
+    w = world
+    rng = np.random.default_rng(11)
+    top = int(w.rows["anchor_id"].max())
+    pad = np.zeros(n_pad, dtype=w.rows.dtype)
+    pad["read_id"] = int(w.rows["read_id"].max()) + 1 + rng.integers(0, 500, n_pad)
+    pad["anchor_id"] = top + 3 + 4 * rng.integers(0, 2000, n_pad)  # gaps of unused ids
+    pad["line"] = 10**6 + np.arange(n_pad)
+    dup = w.rows[rng.choice(len(w.rows), 50, replace=False)].copy()
+    dup["line"] += 2 * 10**6
+    dup["n_lo"] += 11
+    table = np.concatenate([w.rows, pad, dup])
+    table = table[np.lexsort((-table["line"].astype(np.int64), table["anchor_id"]))]
+    asm = Assembly(w.store)
+    asm.set_rows(table)
+    want = []
+    order = np.argsort(w.read_start)
+    for k, s in enumerate(order[:40:4]):
+        path, steps = w.chain(int(s), max_len=8)
+        if len(path) < 2:
+            continue
+        want.append(assemble_path(path, steps, w.vm, {}, w.nano, w.illu, k))
+        asm.add_path(path, steps, None, None, k)
+    assert len(want) >= 5
+    for i, r in enumerate(want):
+        compare(w, asm, r, i)
+    asm.close()
+
+
 def test_fuzzed_paths_match_oracle_every_branch(world):
     from oracle.ms_assemble_py import AssemblyError, assemble_path
     w = world
@@ -302,7 +336,14 @@ def test_row_table_install_at_scale(oracle, tmp_path):
     dup["n_lo"] += 11
     shuffled = np.concatenate([rows, dup])
     rng.shuffle(shuffled)
-    for name, table in (("grouped by anchor", rows), ("shuffled + duplicates", shuffled)):
+    # ascending anchor ids with the duplicates INSIDE their scaffolds and ahead of the rows they repeat (the table that
+    # needs no sort: msgpu_assembly_set_rows only records where every anchor starts)
+    both = np.concatenate([rows, dup])
+    by_anchor = both[np.lexsort((-both["line"].astype(np.int64), both["anchor_id"]))]
+    by_read = both[np.argsort(both["read_id"], kind="stable")]
+    assert np.all(np.diff(rows["anchor_id"].astype(np.int64)) >= 0)
+    for name, table in (("grouped by anchor", rows), ("shuffled + duplicates", shuffled),
+                        ("ascending anchors + duplicates", by_anchor), ("grouped by read + duplicates", by_read)):
         got = Assembly(store)
         got.set_rows(table)
         status = got.add_prepared_batch([Assembly.prepare(p, st, None, None, k) for k, (p, st) in enumerate(paths)], 4)
