@@ -481,14 +481,15 @@ int msgpu_calculate_edges(msgpu_ctx *c) {
 
   ENSURE(c, bound, (size_t(V) + 1) * 4);
   ENSURE(c, cand_off, (size_t(V) + 2) * 8);
-  ENSURE(c, lists, (size_t(V) + 1) * 4 * 4);
+  ENSURE(c, lists, (size_t(V) + 1) * (3 * sizeof(CandDesc) + 4));
   ENSURE(c, n_cand, (size_t(V) + 1) * 4);
   ENSURE(c, n_edge, (size_t(V) + 1) * 4);
   ENSURE(c, n_visit_arr, (size_t(V) + 1) * 4);
   ENSURE(c, em_base, (size_t(V) + 2) * 8);
   ENSURE(c, edge_base, (size_t(V) + 2) * 8);
   ENSURE(c, visit_base, (size_t(V) + 2) * 8);
-  uint32_t *l0 = c->lists.as<uint32_t>(), *l1 = l0 + V + 1, *l2 = l1 + V + 1, *l3 = l2 + V + 1;
+  CandDesc *l0 = c->lists.as<CandDesc>(), *l1 = l0 + V + 1, *l2 = l1 + V + 1;
+  uint32_t *l3 = reinterpret_cast<uint32_t *>(l2 + V + 1);
 
   {
     uint32_t *const zero[4]   = {scalar<uint32_t>(c, SC_NLISTS), c->n_cand.as<uint32_t>(), c->n_edge.as<uint32_t>(),
@@ -502,8 +503,9 @@ int msgpu_calculate_edges(msgpu_ctx *c) {
                c->win_lo, c->win_hi, c->bound.as<uint32_t>());
   exclusive_scan<uint64_t>(st, c->bound.as<uint32_t>(), V, c->cand_off.as<uint64_t>(), c->scan_tmp.as<uint64_t>(),
                            scalar<uint64_t>(c, SC_TOTAL_A));
-  launch_classify_reads(st, c->read_cnt.as<uint32_t>(), c->bound.as<uint32_t>(), V, c->shard, c->nshards, c->win_lo,
-                        c->win_hi, l0, l1, l2, l3, scalar<uint32_t>(c, SC_NLISTS));
+  launch_classify_reads(st, c->read_off.as<uint32_t>(), c->read_cnt.as<uint32_t>(), c->bound.as<uint32_t>(),
+                        c->cand_off.as<uint64_t>(), V, c->shard, c->nshards, c->win_lo, c->win_hi, l0, l1, l2, l3,
+                        scalar<uint32_t>(c, SC_NLISTS));
   HIPCHK(c, hipGetLastError());
   if (int rc = read_scalars(c)) return rc; // sizes of the candidate scratch
   const uint64_t total_bound = *host_scalar<uint64_t>(c, SC_TOTAL_A);

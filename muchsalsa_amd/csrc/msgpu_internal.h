@@ -21,6 +21,13 @@ constexpr uint32_t PF_POS_MASK = 0x3fffffffu;
 constexpr uint32_t PF_DIR      = 1u << 30;
 constexpr uint32_t PF_PRIM     = 1u << 31;
 
+// one owner read of an LDS class, as its candidate workgroup needs it (written by k_classify_reads)
+struct CandDesc {
+  uint32_t r, rb, n1, bound; // read id, first row in by_read, rows, scaffold rows to visit
+  uint64_t co, pad;          // first slot of its candidate / edge scratch
+};
+static_assert(sizeof(CandDesc) == 32, "CandDesc must be 32 bytes");
+
 struct CandArgs {
   const uint32_t *read_off, *read_cnt, *anchor_off;
   const IRow     *by_read, *by_anchor;
@@ -117,10 +124,10 @@ void launch_rank_anchor(hipStream_t st, const uint32_t *anchor_off, uint64_t n_r
                         IRow *by_read, uint4 *vis);
 void launch_bound(hipStream_t st, const uint32_t *read_off, const uint32_t *read_cnt, const uint4 *vis, uint32_t V,
                   uint32_t shard, uint32_t nshards, uint32_t lo, uint32_t hi, uint32_t *bound);
-void launch_classify_reads(hipStream_t st, const uint32_t *read_cnt, const uint32_t *bound, uint32_t V, uint32_t shard,
-                           uint32_t nshards, uint32_t lo, uint32_t hi, uint32_t *l0, uint32_t *l1, uint32_t *l2,
-                           uint32_t *l3, uint32_t *n_lists);
-void launch_candidates(hipStream_t st, const CandArgs &a, int cls, const uint32_t *list, uint32_t n_list);
+void launch_classify_reads(hipStream_t st, const uint32_t *read_off, const uint32_t *read_cnt, const uint32_t *bound,
+                           const uint64_t *cand_off, uint32_t V, uint32_t shard, uint32_t nshards, uint32_t lo,
+                           uint32_t hi, CandDesc *l0, CandDesc *l1, CandDesc *l2, uint32_t *l3, uint32_t *n_lists);
+void launch_candidates(hipStream_t st, const CandArgs &a, int cls, const CandDesc *list, uint32_t n_list);
 void launch_candidates_big(hipStream_t st, const CandArgs &a, const uint32_t *list, uint32_t n_list, uint64_t *big_key,
                            uint32_t *big_t, uint32_t *big_r2s, uint32_t *big_pfx);
 void launch_emit_edges(hipStream_t st, const uint32_t *n_edge, const uint32_t *n_cand, const uint64_t *edge_base,

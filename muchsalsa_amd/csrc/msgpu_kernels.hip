@@ -679,7 +679,7 @@ __global__ __launch_bounds__(256) void k_bound(const uint32_t *read_off, const u
 // NT threads per workgroup (= per owner read): 128 for the reads with few scaffold rows to visit -- twice as many reads in
 // flight per CU, and the kernel waits on memory for most of its cycles -- 256 otherwise.
 template <int R1MAX, int CMAX, int NT>
-__global__ __launch_bounds__(NT) void k_candidates(CandArgs a, const uint32_t *read_list, uint32_t n_list) {
+__global__ __launch_bounds__(NT) void k_candidates(CandArgs a, const CandDesc *desc, uint32_t n_list) {
   constexpr int      HSZ   = CMAX; // hash slots >= candidates: insertion always terminates
   constexpr int      HBITS = CMAX == 512 ? 9 : CMAX == 1024 ? 10 : CMAX == 2048 ? 11 : CMAX == 4096 ? 12 : 13;
   static_assert((1 << HBITS) == HSZ, "CMAX must be 512, 1024, 2048, 4096 or 8192");
@@ -687,29 +687,29 @@ __global__ __launch_bounds__(NT) void k_candidates(CandArgs a, const uint32_t *r
   // LDS, with the tables of the later phases laid over those of the earlier ones (lifetimes separated by the
   // __syncthreads between the phases): fewer bytes per workgroup = more reads in flight per CU (the kernel waits on
   // memory for most of its cycles).
-  //   region A: s_ilo, s_ihi, s_aoff, s_pfx (phases a-b)      later g_list, g_rank   (phase c2 on)
-  //   region B: s_v2 (phases b-c1)                            later g_slot, g_off    (phase c2 on)
+  //   region A: s_row (phases a-b)                            later g_list, g_rank   (phase c2 on)
+  //   region B: g_slot, g_off (phase c2 on)
   static_assert(4 * R1MAX * 4 + 16 >= 2 * CMAX + 2 * HSZ, "region A must hold g_list + g_rank");
   __shared__ __attribute__((aligned(16))) unsigned char s_regA[4 * R1MAX * 4 + 16];
   __shared__ __attribute__((aligned(16))) unsigned char s_regB[4 * CMAX + 16];
-  int *const      s_ilo  = reinterpret_cast<int *>(s_regA);
-  int *const      s_ihi  = s_ilo + R1MAX;
-  uint32_t *const s_aoff = reinterpret_cast<uint32_t *>(s_ihi + R1MAX);
-  uint32_t *const s_pfx  = s_aoff + R1MAX; // R1MAX + 1 entries
+  // per row j of v1: {i_lo, i_hi, first scaffold row behind v1's own MINUS the row's first candidate slot, -}: one
+  // 16-byte LDS read per visit gives the anchor interval and, added to the slot number, the scaffold row to load
+  uint4 *const    s_row  = reinterpret_cast<uint4 *>(s_regA);
   uint16_t *const g_list = reinterpret_cast<uint16_t *>(s_regA);
   uint16_t *const g_rank = g_list + CMAX; // HSZ entries
-  uint32_t *const s_v2   = reinterpret_cast<uint32_t *>(s_regB); // v2 of candidate c
   uint16_t *const g_slot = reinterpret_cast<uint16_t *>(s_regB);
   uint16_t *const g_off  = g_slot + CMAX; // CMAX + 1 entries
-  __shared__ uint32_t s_t[CMAX];                // by_anchor row of candidate c, later of staging position pos
-  __shared__ uint16_t s_j[CMAX], s_g[CMAX];     // j of candidate c / of staging position pos; group of pos
+  __shared__ uint32_t s_t[CMAX];                // (fallback staging only) by_anchor row of staging position pos
+  __shared__ uint16_t s_j[CMAX], s_g[CMAX];     // row j of candidate slot c, later of staging position pos; group of pos
   __shared__ uint32_t h_key[HSZ], h_cnt[HSZ];   // open-addressing table v2 -> group; members per group
   __shared__ uint32_t s_wave[NT / 64];
 
   if (blockIdx.x >= n_list) return;
-  const uint32_t r  = read_list[blockIdx.x];
-  const uint32_t rb = a.read_off[r], n1 = a.read_cnt[r];
-  const uint64_t co = a.cand_off[r];
+  // everything the workgroup needs to know about its read in one 32-byte scalar load (k_classify_reads wrote it): the
+  // read's row range and scratch offset used to be a second level of dependent loads behind the list entry
+  const CandDesc dsc = desc[blockIdx.x];
+  const uint32_t r = dsc.r, rb = dsc.rb, n1 = dsc.n1;
+  const uint64_t co = dsc.co;
   const int      tid = threadIdx.x;
   for (int h = tid; h < HSZ; h += NT) {
     h_key[h] = EMPTY;
@@ -718,68 +718,65 @@ __global__ __launch_bounds__(NT) void k_candidates(CandArgs a, const uint32_t *r
 
   // (a) v1's rows (already in vStart order) and, per row, the stretch of its anchor's scaffold behind v1's own row
   constexpr int JPT = R1MAX / NT; // rows per thread, consecutive
-  uint32_t      cnt[JPT], tsum = 0;
+  uint4         vr[JPT];
+  uint32_t      tsum = 0;
 #pragma unroll
   for (int q = 0; q < JPT; ++q) {
-    uint32_t j = tid * JPT + q;
-    cnt[q]     = 0;
-    if (j < n1) { // anchor interval, first scaffold row behind v1's own (= first partner with a higher id), their number
-      const uint4 vr = a.vis[rb + j];
-      s_ilo[j]       = static_cast<int>(vr.x);
-      s_ihi[j]       = static_cast<int>(vr.y);
-      s_aoff[j]      = vr.z;
-      cnt[q]         = vr.w;
-    }
-    tsum += cnt[q];
+    const uint32_t j = tid * JPT + q;
+    // anchor interval, first scaffold row behind v1's own (= first partner with a higher id), their number
+    vr[q] = j < n1 ? a.vis[rb + j] : make_uint4(0, 0, 0, 0);
+    tsum += vr[q].w;
   }
   uint32_t T;
   uint32_t ex = block_excl_scan<NT>(tsum, s_wave, &T);
   // every visit x in [0, T) is one candidate slot: s_j[x] = the row of v1 it belongs to (filled here, stretch by
   // stretch), so the scan below is one scaffold row per lane with no search, no per-row lane groups and no compaction
   // (nearly every visit passes the overlap test now that only the owned partners are visited; the few that fail keep
-  // an EMPTY slot that the later phases skip)
+  // an empty slot that the later phases skip)
 #pragma unroll
   for (int q = 0; q < JPT; ++q) {
-    uint32_t j = tid * JPT + q;
+    const uint32_t j = tid * JPT + q;
     if (j < n1) {
-      s_pfx[j] = ex;
-      for (uint32_t k = 0; k < cnt[q]; ++k) s_j[ex + k] = static_cast<uint16_t>(j);
+      s_row[j] = make_uint4(vr[q].x, vr[q].y, vr[q].z - ex, 0u);
+      for (uint32_t k = 0; k < vr[q].w; ++k) s_j[ex + k] = static_cast<uint16_t>(j);
     }
-    ex += cnt[q];
+    ex += vr[q].w;
   }
   __syncthreads();
+  const uint32_t nc = T; // candidate slots (empty ones included)
 
-  // (b) one scaffold row per lane: consecutive lanes read consecutive rows of a scaffold
-  for (uint32_t x0 = 0; x0 < T; x0 += NT) {
-    const uint32_t x = x0 + tid;
-    if (x < T) {
-      const uint32_t j  = s_j[x];
-      const uint32_t vm = s_aoff[j] + (x - s_pfx[j]);
-      const IRow     o  = load_irow(&a.by_anchor[vm]);
-      const int      ovlo = max(o.i_lo, s_ilo[j]), ovhi = min(o.i_hi, s_ihi[j]);
-      // overlap test (MatchMap.cpp:192); the owner rule (v2 > v1 <=> v1 has the lower first line, :204-213) is the
-      // choice of the rows visited: scaffolds are in read-id order and the walk starts behind v1's own row
-      const bool pass = ovlo <= ovhi && (ovhi - ovlo) > static_cast<int>(a.th_overlap);
-      s_v2[x] = pass ? o.other : EMPTY;
-      s_t[x]  = vm;
-    }
-  }
-  __syncthreads();
-  const uint32_t nc = T; // candidate slots (EMPTY ones included)
-
-  // (c1) group by v2: open-addressing insert; li = arrival number inside the group (any order)
+  // (b) one scaffold row per lane: consecutive lanes read consecutive rows of a scaffold.  Slot c = tid + NT * q stays
+  // with its thread through phase (c): v2, the scaffold row and j never leave the registers.
   constexpr int CPT = CMAX / NT;
   uint16_t      c_slot[CPT], c_li[CPT], c_j[CPT];
-  uint32_t      c_t[CPT];
+  uint32_t      c_t[CPT], c_v2[CPT];
   bool          c_ok[CPT]; // slot c holds a candidate (a visit that passed the overlap test)
 #pragma unroll
   for (int q = 0; q < CPT; ++q) {
     const uint32_t c = tid + NT * q;
     c_slot[q] = c_li[q] = c_j[q] = 0;
-    c_t[q]                       = 0;
-    c_ok[q]                      = c < nc && s_v2[c] != EMPTY;
+    c_t[q] = c_v2[q] = 0;
+    c_ok[q]          = false;
+    if (c < nc) {
+      const uint32_t j  = s_j[c];
+      const uint4    rw = s_row[j];
+      const uint32_t vm = rw.z + c;
+      const IRow     o  = load_irow(&a.by_anchor[vm]);
+      const int      ovlo = max(o.i_lo, static_cast<int>(rw.x)), ovhi = min(o.i_hi, static_cast<int>(rw.y));
+      // overlap test (MatchMap.cpp:192); the owner rule (v2 > v1 <=> v1 has the lower first line, :204-213) is the
+      // choice of the rows visited: scaffolds are in read-id order and the walk starts behind v1's own row
+      c_ok[q] = ovlo <= ovhi && (ovhi - ovlo) > static_cast<int>(a.th_overlap);
+      c_v2[q] = o.other;
+      c_t[q]  = vm;
+      c_j[q]  = static_cast<uint16_t>(j);
+    }
+  }
+
+  // (c1) group by v2: open-addressing insert; li = arrival number inside the group (any order)
+#pragma unroll
+  for (int q = 0; q < CPT; ++q) {
     if (c_ok[q]) {
-      const uint32_t v2 = s_v2[c];
+      const uint32_t v2 = c_v2[q];
       uint32_t       h  = (v2 * 2654435761u) >> (32 - HBITS);
       while (true) {
         const uint32_t old = atomicCAS(&h_key[h], EMPTY, v2);
@@ -788,8 +785,6 @@ __global__ __launch_bounds__(NT) void k_candidates(CandArgs a, const uint32_t *r
       }
       c_slot[q] = static_cast<uint16_t>(h);
       c_li[q]   = static_cast<uint16_t>(atomicAdd(&h_cnt[h], 1u));
-      c_j[q]    = s_j[c];
-      c_t[q]    = s_t[c];
     }
   }
   __syncthreads();
@@ -905,19 +900,18 @@ __global__ __launch_bounds__(NT) void k_candidates(CandArgs a, const uint32_t *r
   }
 }
 
-template __global__ void k_candidates<256, 512, 128>(CandArgs, const uint32_t *, uint32_t);
-template __global__ void k_candidates<256, 512, 256>(CandArgs, const uint32_t *, uint32_t);
-template __global__ void k_candidates<256, 1024, 256>(CandArgs, const uint32_t *, uint32_t);
-template __global__ void k_candidates<1024, 4096, 256>(CandArgs, const uint32_t *, uint32_t);
+template __global__ void k_candidates<256, 512, 256>(CandArgs, const CandDesc *, uint32_t);
+template __global__ void k_candidates<256, 1024, 256>(CandArgs, const CandDesc *, uint32_t);
+template __global__ void k_candidates<1024, 4096, 256>(CandArgs, const CandDesc *, uint32_t);
 
 // classify reads of this shard by the LDS footprint their candidate scan needs
 // classes by LDS footprint: 0 = <256 rows, 512 candidates> (half the LDS of class 1, so twice as many reads per CU),
 // 1 = <256, 1024>, 2 = <1024, 4096>, 3 = global-scratch kernel
-__global__ __launch_bounds__(1024) void k_classify_reads(const uint32_t *read_cnt, const uint32_t *bound, uint32_t V,
+__global__ __launch_bounds__(1024) void k_classify_reads(const uint32_t *read_off, const uint32_t *read_cnt,
+                                                         const uint32_t *bound, const uint64_t *cand_off, uint32_t V,
                                                          uint32_t shard, uint32_t nshards, uint32_t lo, uint32_t hi,
-                                                         uint32_t *list0,
-                                                         uint32_t *list1, uint32_t *list2, uint32_t *list3,
-                                                         uint32_t *n_lists /*[4]*/) {
+                                                         CandDesc *list0, CandDesc *list1, CandDesc *list2,
+                                                         uint32_t *list3, uint32_t *n_lists /*[4]*/) {
   // the four list cursors are single words (~88 atomics/us each): count inside the workgroup in LDS first, then one
   // global atomic per workgroup and class
   __shared__ uint32_t s_cnt[4], s_base[4];
@@ -925,8 +919,10 @@ __global__ __launch_bounds__(1024) void k_classify_reads(const uint32_t *read_cn
   __syncthreads();
   uint32_t r   = blockIdx.x * 1024 + threadIdx.x;
   int      cls = -1;
+  uint32_t n1 = 0, bd = 0;
   if (r < V && r >= lo && r < hi && r % nshards == shard) {
-    uint32_t n1 = read_cnt[r], bd = bound[r];
+    n1 = read_cnt[r];
+    bd = bound[r];
     if (n1 != 0 && bd != 0)
       cls = (n1 <= 256 && bd <= 512) ? 0 : (n1 <= 256 && bd <= 1024) ? 1 : (n1 <= 1024 && bd <= 4096) ? 2 : 3;
   }
@@ -944,9 +940,17 @@ __global__ __launch_bounds__(1024) void k_classify_reads(const uint32_t *read_cn
   __syncthreads();
   if (threadIdx.x < 4 && s_cnt[threadIdx.x]) s_base[threadIdx.x] = atomicAdd(&n_lists[threadIdx.x], s_cnt[threadIdx.x]);
   __syncthreads();
-  if (cls >= 0) {
-    uint32_t *list = cls == 0 ? list0 : cls == 1 ? list1 : cls == 2 ? list2 : list3;
-    list[s_base[cls] + local] = r;
+  if (cls == 3) {
+    list3[s_base[3] + local] = r;
+  } else if (cls >= 0) {
+    CandDesc d;
+    d.r     = r;
+    d.rb    = read_off[r];
+    d.n1    = n1;
+    d.bound = bd;
+    d.co    = cand_off[r];
+    d.pad   = 0;
+    (cls == 0 ? list0 : cls == 1 ? list1 : list2)[s_base[cls] + local] = d;
   }
 }
 
@@ -2749,19 +2753,16 @@ void launch_bound(hipStream_t st, const uint32_t *read_off, const uint32_t *read
     hipLaunchKernelGGL(k_bound, grid1(V, 16), dim3(256), 0, st, read_off, read_cnt, vis, V, shard, nshards, lo, hi,
                        bound);
 }
-void launch_classify_reads(hipStream_t st, const uint32_t *read_cnt, const uint32_t *bound, uint32_t V, uint32_t shard,
-                           uint32_t nshards, uint32_t lo, uint32_t hi, uint32_t *l0, uint32_t *l1, uint32_t *l2,
-                           uint32_t *l3, uint32_t *n_lists) {
+void launch_classify_reads(hipStream_t st, const uint32_t *read_off, const uint32_t *read_cnt, const uint32_t *bound,
+                           const uint64_t *cand_off, uint32_t V, uint32_t shard, uint32_t nshards, uint32_t lo,
+                           uint32_t hi, CandDesc *l0, CandDesc *l1, CandDesc *l2, uint32_t *l3, uint32_t *n_lists) {
   if (V)
-    hipLaunchKernelGGL(k_classify_reads, grid1(V, 1024), dim3(1024), 0, st, read_cnt, bound, V, shard, nshards, lo, hi, l0, l1, l2,
-                       l3, n_lists);
+    hipLaunchKernelGGL(k_classify_reads, grid1(V, 1024), dim3(1024), 0, st, read_off, read_cnt, bound, cand_off, V, shard,
+                       nshards, lo, hi, l0, l1, l2, l3, n_lists);
 }
-void launch_candidates(hipStream_t st, const CandArgs &a, int cls, const uint32_t *list, uint32_t n_list) {
+void launch_candidates(hipStream_t st, const CandArgs &a, int cls, const CandDesc *list, uint32_t n_list) {
   if (!n_list) return;
-  static const bool nt128 = getenv("MSGPU_CAND_NT128") != nullptr; // experiment switch
-  if (cls == 0 && nt128)
-    hipLaunchKernelGGL((k_candidates<256, 512, 128>), dim3(n_list), dim3(128), 0, st, a, list, n_list);
-  else if (cls == 0)
+  if (cls == 0)
     hipLaunchKernelGGL((k_candidates<256, 512, 256>), dim3(n_list), dim3(256), 0, st, a, list, n_list);
   else if (cls == 1)
     hipLaunchKernelGGL((k_candidates<256, 1024, 256>), dim3(n_list), dim3(256), 0, st, a, list, n_list);
