@@ -83,14 +83,22 @@ __device__ __forceinline__ double std_max(double a, double b) { return (a < b) ?
 __device__ __forceinline__ double std_min(double a, double b) { return (b < a) ? b : a; }
 
 // block-wide exclusive scan of one value per thread, NT threads; returns exclusive prefix, total through *total
+// inclusive scan over the wavefront with data-parallel-primitive moves (vector-ALU latency; __shfl_up is a ds_bpermute, one
+// LDS round trip per step): Hillis-Steele inside the rows of 16 lanes (lanes without a source add 0), then lane 15 of
+// rows 0 / 2 into rows 1 / 3 (row_bcast:15, row mask 0xa) and lane 31 into rows 2 and 3 (row_bcast:31, row mask 0xc)
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
+  v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x111, 0xf, 0xf, false)); // row_shr:1
+  v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x112, 0xf, 0xf, false)); // row_shr:2
+  v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x114, 0xf, 0xf, false)); // row_shr:4
+  v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x118, 0xf, 0xf, false)); // row_shr:8
+  v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x142, 0xa, 0xf, false)); // row_bcast:15
+  v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x143, 0xc, 0xf, false)); // row_bcast:31
+  return v;
+}
+
 template <int NT> __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *s_wave /*[NT / 64]*/, uint32_t *total) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  uint32_t  inc  = v;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    uint32_t t = __shfl_up(inc, d);
-    if (lane >= d) inc += t;
-  }
+  const int      lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t inc  = wave_incl_scan(v);
   if (lane == 63) s_wave[wave] = inc;
   __syncthreads();
   uint32_t base = 0, tot = 0;
@@ -687,22 +695,23 @@ __global__ __launch_bounds__(NT) void k_candidates(CandArgs a, const CandDesc *d
   // LDS, with the tables of the later phases laid over those of the earlier ones (lifetimes separated by the
   // __syncthreads between the phases): fewer bytes per workgroup = more reads in flight per CU (the kernel waits on
   // memory for most of its cycles).
-  //   region A: s_row (phases a-b)                            later g_list, g_rank   (phase c2 on)
+  //   region A: s_row (phases a-b)                            later g_rank   (phase c2 on)
   //   region B: g_slot, g_off (phase c2 on)
-  static_assert(4 * R1MAX * 4 + 16 >= 2 * CMAX + 2 * HSZ, "region A must hold g_list + g_rank");
+  static_assert(4 * R1MAX * 4 + 16 >= 2 * HSZ, "region A must hold g_rank");
   __shared__ __attribute__((aligned(16))) unsigned char s_regA[4 * R1MAX * 4 + 16];
   __shared__ __attribute__((aligned(16))) unsigned char s_regB[4 * CMAX + 16];
   // per row j of v1: {i_lo, i_hi, first scaffold row behind v1's own MINUS the row's first candidate slot, -}: one
   // 16-byte LDS read per visit gives the anchor interval and, added to the slot number, the scaffold row to load
   uint4 *const    s_row  = reinterpret_cast<uint4 *>(s_regA);
-  uint16_t *const g_list = reinterpret_cast<uint16_t *>(s_regA);
-  uint16_t *const g_rank = g_list + CMAX; // HSZ entries
+  uint16_t *const g_rank = reinterpret_cast<uint16_t *>(s_regA); // HSZ entries
   uint16_t *const g_slot = reinterpret_cast<uint16_t *>(s_regB);
   uint16_t *const g_off  = g_slot + CMAX; // CMAX + 1 entries
   __shared__ uint32_t s_t[CMAX];                // (fallback staging only) by_anchor row of staging position pos
   __shared__ uint16_t s_j[CMAX], s_g[CMAX];     // row j of candidate slot c, later of staging position pos; group of pos
   __shared__ uint32_t h_key[HSZ], h_cnt[HSZ];   // open-addressing table v2 -> group; members per group
-  __shared__ uint32_t s_wave[NT / 64];
+  __shared__ uint32_t s_bm[HSZ];                // per group (in v2 order): bitmap of the rows j it holds, R1MAX bits
+  __shared__ uint32_t s_wave[NT / 64], s_ng;    // s_ng: groups created so far
+  uint16_t *const     g_list = s_g;             // slots of the groups in creation order (s_g is idle until the staging path)
 
   if (blockIdx.x >= n_list) return;
   // everything the workgroup needs to know about its read in one 32-byte scalar load (k_classify_reads wrote it): the
@@ -714,7 +723,9 @@ __global__ __launch_bounds__(NT) void k_candidates(CandArgs a, const CandDesc *d
   for (int h = tid; h < HSZ; h += NT) {
     h_key[h] = EMPTY;
     h_cnt[h] = 0;
+    s_bm[h]  = 0;
   }
+  if (tid == 0) s_ng = 0;
 
   // (a) v1's rows (already in vStart order) and, per row, the stretch of its anchor's scaffold behind v1's own row
   constexpr int JPT = R1MAX / NT; // rows per thread, consecutive
@@ -772,7 +783,8 @@ __global__ __launch_bounds__(NT) void k_candidates(CandArgs a, const CandDesc *d
     }
   }
 
-  // (c1) group by v2: open-addressing insert; li = arrival number inside the group (any order)
+  // (c1) group by v2: open-addressing insert; the thread that creates a group numbers it (creation order, any);
+  // li = arrival number inside the group (any order)
 #pragma unroll
   for (int q = 0; q < CPT; ++q) {
     if (c_ok[q]) {
@@ -780,6 +792,7 @@ __global__ __launch_bounds__(NT) void k_candidates(CandArgs a, const CandDesc *d
       uint32_t       h  = (v2 * 2654435761u) >> (32 - HBITS);
       while (true) {
         const uint32_t old = atomicCAS(&h_key[h], EMPTY, v2);
+        if (old == EMPTY) g_list[atomicAdd(&s_ng, 1u)] = static_cast<uint16_t>(h);
         if (old == EMPTY || old == v2) break;
         h = (h + 1) & (HSZ - 1);
       }
@@ -789,58 +802,58 @@ __global__ __launch_bounds__(NT) void k_candidates(CandArgs a, const CandDesc *d
   }
   __syncthreads();
 
-  // (c2) the groups (= edges), ranked by v2
-  uint32_t occ[CPT], osum = 0;
-#pragma unroll
-  for (int q = 0; q < CPT; ++q) {
-    const int h = tid * CPT + q;
-    occ[q]      = h_key[h] != EMPTY ? 1u : 0u;
-    osum += occ[q];
+  // (c2/c3) the groups (= edges) ranked by v2, and the first staging position of every group in that order.  A read
+  // has a handful of partners: up to 64 groups are ranked by ONE wavefront with the keys and counts in registers
+  // (v_readlane in a loop over the groups; rank and offset come out of the same loop), no scan and no LDS round trips
+  // in the loop -- this phase used to be two workgroup scans and a loop of dependent LDS reads.
+  const uint32_t ng = s_ng;
+  if (ng <= 64) {
+    if (tid < 64) { // wave 0
+      const bool     have = static_cast<uint32_t>(tid) < ng;
+      const uint32_t slot = have ? g_list[tid] : 0u;
+      const uint32_t key = have ? h_key[slot] : EMPTY, cnt = have ? h_cnt[slot] : 0u;
+      uint32_t       rank = 0, off = 0;
+      for (uint32_t q = 0; q < ng; ++q) { // wave-uniform
+        const uint32_t kq = rl_u32(key, static_cast<int>(q)), cq = rl_u32(cnt, static_cast<int>(q));
+        const bool     lower = kq < key;
+        rank += lower ? 1u : 0u;
+        off += lower ? cq : 0u;
+      }
+      if (have) {
+        g_rank[slot] = static_cast<uint16_t>(rank);
+        g_slot[rank] = static_cast<uint16_t>(slot);
+        g_off[rank]  = static_cast<uint16_t>(off);
+        if (rank + 1 == ng) g_off[ng] = static_cast<uint16_t>(off + cnt); // candidates of this read
+      }
+    }
+  } else { // many partners: the same ranking with the keys read from LDS
+    for (uint32_t g = tid; g < ng; g += NT) {
+      const uint32_t slot = g_list[g], key = h_key[slot];
+      uint32_t       rank = 0, off = 0;
+      for (uint32_t q = 0; q < ng; ++q) {
+        const uint32_t sq = g_list[q];
+        const bool     lower = h_key[sq] < key;
+        rank += lower ? 1u : 0u;
+        off += lower ? h_cnt[sq] : 0u;
+      }
+      g_rank[slot] = static_cast<uint16_t>(rank);
+      g_slot[rank] = static_cast<uint16_t>(slot);
+      g_off[rank]  = static_cast<uint16_t>(off);
+      if (rank + 1 == ng) g_off[ng] = static_cast<uint16_t>(off + h_cnt[slot]);
+    }
   }
-  uint32_t ng;
-  uint32_t gex = block_excl_scan<NT>(osum, s_wave, &ng);
-#pragma unroll
-  for (int q = 0; q < CPT; ++q)
-    if (occ[q]) g_list[gex++] = static_cast<uint16_t>(tid * CPT + q);
+  if (ng == 0 && tid == 0) g_off[0] = 0;
   __syncthreads();
-  for (uint32_t g = tid; g < ng; g += NT) {
-    const uint32_t slot = g_list[g], key = h_key[slot];
-    uint32_t       rank = 0;
-    for (uint32_t q = 0; q < ng; ++q) rank += (h_key[g_list[q]] < key) ? 1u : 0u;
-    g_rank[slot] = static_cast<uint16_t>(rank);
-    g_slot[rank] = static_cast<uint16_t>(slot);
-  }
-  __syncthreads();
-
-  // (c3) first staging position of every group, in v2 order
-  uint32_t gc[CPT], gsum = 0;
-#pragma unroll
-  for (int q = 0; q < CPT; ++q) {
-    const uint32_t rk = tid * CPT + q;
-    gc[q]             = rk < ng ? h_cnt[g_slot[rk]] : 0u;
-    gsum += gc[q];
-  }
-  uint32_t tot;
-  uint32_t oex = block_excl_scan<NT>(gsum, s_wave, &tot);
-#pragma unroll
-  for (int q = 0; q < CPT; ++q) {
-    const uint32_t rk = tid * CPT + q;
-    if (rk < ng) g_off[rk] = static_cast<uint16_t>(oex);
-    oex += gc[q];
-  }
-  if (tid == 0) g_off[ng] = static_cast<uint16_t>(tot); // candidates of this read
-  __syncthreads();
+  const uint32_t tot = g_off[ng];
 
   // (c4/c5) inside a group the candidates go in the order of j = the vStart order of mpp.cpp:164-172 (j is unique
-  // inside a group).  One bitmap of R1MAX bits per group (in the bytes of h_cnt, dead since (c3)): every candidate sets
+  // inside a group).  One bitmap of R1MAX bits per group: every candidate sets
   // bit j of its group, then its position is the number of set bits below j -- a popcount or two per candidate
   // instead of a walk over the group's members (that walk was a quarter of this kernel's time).
   constexpr uint32_t WPG = R1MAX / 32; // bitmap words per group
   if (ng <= static_cast<uint32_t>(HSZ) / WPG) {
-    uint32_t *const bm = h_cnt;
-    for (uint32_t w = tid; w < ng * WPG; w += NT) bm[w] = 0;
-    __syncthreads();
-    uint32_t c_rk[CPT];
+    uint32_t *const bm = s_bm; // zeroed with the hash table
+    uint32_t        c_rk[CPT];
 #pragma unroll
     for (int q = 0; q < CPT; ++q) {
       c_rk[q] = 0;
