@@ -85,7 +85,7 @@ struct msgpu_ctx {
   // arena
   DevBuf rows_in, cnt_read, read_off, cursor, bkt_key, bkt_dead, by_read, read_cnt, alive_rank,
       anchor_cnt, anchor_off, anchor_first, anchor_off_gen, bkt2_idx, bkt2_line, by_anchor, read_len, read_first, scalars,
-      scan_tmp, vis16, spos2;
+      scan_tmp, vis16, spos2, visits;
   DevBuf bound, cand_off, cand_j, cand_t, scr_v2, scr_start, n_cand, n_edge, n_visit_arr, lists, em_base, edge_base,
       visit_base, edges, edge_cand;
   DevBuf big_key, big_t, big_r2s, big_pfx, pair_tab, edge_fast, big_off;
@@ -160,7 +160,7 @@ void release_all(msgpu_ctx *c) {
                    &c->n_visit_arr, &c->lists, &c->em_base, &c->edge_base, &c->visit_base, &c->edges, &c->edge_cand,
                    &c->big_key, &c->big_t, &c->big_r2s, &c->big_pfx, &c->pair_tab, &c->edge_fast, &c->big_off, &c->ems, &c->order_scr, &c->ids_scr,
                    &c->edge_norders, &c->edge_nids, &c->order_base, &c->ids_base, &c->orders, &c->ids, &c->big_list, &c->cls_list,
-                   &c->big_elems, &c->big_paths, &c->alt_edges, &c->alt_ems, &c->alt_orders, &c->alt_ids, &c->vis16,
+                   &c->big_elems, &c->big_paths, &c->alt_edges, &c->alt_ems, &c->alt_orders, &c->alt_ids, &c->vis16, &c->visits,
                    &c->spos2};
   for (DevBuf *b : all) b->release();
 }
@@ -207,13 +207,14 @@ int build_index_once(msgpu_ctx *c, bool force_generic, bool two_pass, uint32_t *
   ENSURE(c, by_anchor, nz * sizeof(IRow));
   ENSURE(c, vis16, nz * 16);
   ENSURE(c, spos2, nz * 8);
+  ENSURE(c, visits, (size_t(V) + 1) * 4);
   ENSURE(c, read_len, (size_t(V) + 1) * 4);
   ENSURE(c, read_first, (size_t(V) + 1) * 4);
   {
     uint64_t m = n;
     if (V > m) m = V;
     if (A > m) m = A;
-    ENSURE(c, scan_tmp, (size_t(scan_blocks(m)) + 1) * 8);
+    ENSURE(c, scan_tmp, 3 * (size_t(scan_blocks(m)) + 1) * 8);
   }
 
   {
@@ -239,7 +240,7 @@ int build_index_once(msgpu_ctx *c, bool force_generic, bool two_pass, uint32_t *
                    c->by_read.as<IRow>(), c->read_cnt.as<uint32_t>(),
                    c->alive_rank.as<uint32_t>(), c->anchor_cnt.as<uint32_t>(), c->bkt_dead.as<uint8_t>(), d_flags,
                    c->by_anchor.as<IRow>(), cap, c->d_rows, c->read_len.as<int32_t>(), c->read_first.as<uint32_t>(),
-                   scalar<uint32_t>(c, SC_ERR), c->spos2.as<uint2>(), c->vis16.as<uint4>()); // fast mode: the sort writes the scaffold rows too (at
+                   scalar<uint32_t>(c, SC_ERR), c->spos2.as<uint2>(), c->vis16.as<uint4>(), c->visits.as<uint32_t>()); // fast mode: the sort writes the scaffold rows too (at
                                                                               // the places pass 1 left in spos2); always: the Vertex facts
   launch_check_read_order(st, c->read_first.as<uint32_t>(), V, scalar<uint32_t>(c, SC_ERR));
   // Fast mode (input grouped by anchor, ascending lines: what the PAF loader hands over) is finished here but for the
@@ -499,11 +500,16 @@ int msgpu_calculate_edges(msgpu_ctx *c) {
     const uint32_t  n_ones[2] = {0, 0};
     launch_index_init(st, zero, n_zero, ones, n_ones); // one launch instead of four memsets
   }
-  launch_bound(st, c->read_off.as<uint32_t>(), c->read_cnt.as<uint32_t>(), c->vis16.as<uint4>(), V, c->shard, c->nshards,
-               c->win_lo, c->win_hi, c->bound.as<uint32_t>());
-  exclusive_scan<uint64_t>(st, c->bound.as<uint32_t>(), V, c->cand_off.as<uint64_t>(), c->scan_tmp.as<uint64_t>(),
+  // the scaffold rows each owner read visits: the index build's sort left the sum per read (fast index); a shard or a
+  // window of owner reads, or a generically built index (scan view patched after the sort), counts them here
+  const bool      all_reads = c->index_fast && c->nshards == 1 && c->win_lo == 0 && c->win_hi >= V;
+  const uint32_t *bound     = all_reads ? c->visits.as<uint32_t>() : c->bound.as<uint32_t>();
+  if (!all_reads)
+    launch_bound(st, c->read_off.as<uint32_t>(), c->read_cnt.as<uint32_t>(), c->vis16.as<uint4>(), V, c->shard,
+                 c->nshards, c->win_lo, c->win_hi, c->bound.as<uint32_t>());
+  exclusive_scan<uint64_t>(st, bound, V, c->cand_off.as<uint64_t>(), c->scan_tmp.as<uint64_t>(),
                            scalar<uint64_t>(c, SC_TOTAL_A));
-  launch_classify_reads(st, c->read_off.as<uint32_t>(), c->read_cnt.as<uint32_t>(), c->bound.as<uint32_t>(),
+  launch_classify_reads(st, c->read_off.as<uint32_t>(), c->read_cnt.as<uint32_t>(), bound,
                         c->cand_off.as<uint64_t>(), V, c->shard, c->nshards, c->win_lo, c->win_hi, l0, l1, l2, l3,
                         scalar<uint32_t>(c, SC_NLISTS));
   HIPCHK(c, hipGetLastError());
@@ -537,7 +543,8 @@ int msgpu_calculate_edges(msgpu_ctx *c) {
   a.big_stats      = scalar<unsigned long long>(c, SC_BIGSTATS);
   HIPCHK(c, hipMemsetAsync(a.big_stats, 0, 16, st));
   // the LDS classes run side by side: the heavier, smaller classes on the side stream, so their tails overlap
-  const bool fork = (c->n_list[1] || c->n_list[2]) && c->n_list[0];
+  static const bool no_fork = getenv("MSGPU_NO_FORK") != nullptr; // measurement switch: the classes one after the other
+  const bool fork = (c->n_list[1] || c->n_list[2]) && c->n_list[0] && !no_fork;
   if (fork) {
     HIPCHK(c, hipEventRecord(c->ev_side[0], st));
     HIPCHK(c, hipStreamWaitEvent(c->side_stream, c->ev_side[0], 0));
@@ -558,10 +565,12 @@ int msgpu_calculate_edges(msgpu_ctx *c) {
     launch_candidates_big(st, a, l3, c->n_list[3], c->big_key.as<uint64_t>(), c->big_t.as<uint32_t>(),
                           c->big_r2s.as<uint32_t>(), c->big_pfx.as<uint32_t>());
   }
-  exclusive_scan<uint64_t>(st, c->n_cand.as<uint32_t>(), V, c->em_base.as<uint64_t>(), c->scan_tmp.as<uint64_t>(),
-                           scalar<uint64_t>(c, SC_TOTAL_A));
-  exclusive_scan<uint64_t>(st, c->n_edge.as<uint32_t>(), V, c->edge_base.as<uint64_t>(), c->scan_tmp.as<uint64_t>(),
-                           scalar<uint64_t>(c, SC_TOTAL_B));
+  {
+    const uint32_t *const in[2]  = {c->n_cand.as<uint32_t>(), c->n_edge.as<uint32_t>()};
+    uint64_t *const       out[2] = {c->em_base.as<uint64_t>(), c->edge_base.as<uint64_t>()};
+    uint64_t *const       tot[2] = {scalar<uint64_t>(c, SC_TOTAL_A), scalar<uint64_t>(c, SC_TOTAL_B)};
+    exclusive_scan_set(st, 2, in, V, out, c->scan_tmp.as<uint64_t>(), tot);
+  }
   HIPCHK(c, hipGetLastError());
   if (int rc = read_scalars(c)) return rc; // sizes of the edge / EdgeMatch tables
   const uint64_t *tot = host_scalar<uint64_t>(c, SC_TOTAL_A), *big = host_scalar<uint64_t>(c, SC_BIGSTATS);
@@ -603,7 +612,7 @@ int msgpu_chaining_and_overlaps(msgpu_ctx *c) {
   ENSURE(c, ids_base, (E + 2) * 8);
   ENSURE(c, big_list, (E + 1) * 4);
   ENSURE(c, visit_base, (E + 2) * 8); // re-used as the scan output of the per-edge shortcut flags
-  ENSURE(c, scan_tmp, (size_t(scan_blocks(E > c->V ? E : c->V)) + 1) * 8);
+  ENSURE(c, scan_tmp, 3 * (size_t(scan_blocks(E > c->V ? E : c->V)) + 1) * 8);
 
   ChainArgs a;
   a.edges        = c->edges.as<msgpu_edge>();
@@ -681,12 +690,12 @@ int msgpu_chaining_and_overlaps(msgpu_ctx *c) {
   HIPCHK(c, hipGetLastError());
   if (n_big) HIPCHK(c, hipStreamWaitEvent(st, c->ev_side[1], 0));
 
-  exclusive_scan<uint64_t>(st, c->edge_norders.as<uint32_t>(), E, c->order_base.as<uint64_t>(),
-                           c->scan_tmp.as<uint64_t>(), scalar<uint64_t>(c, SC_TOTAL_A));
-  exclusive_scan<uint64_t>(st, c->edge_nids.as<uint32_t>(), E, c->ids_base.as<uint64_t>(), c->scan_tmp.as<uint64_t>(),
-                           scalar<uint64_t>(c, SC_TOTAL_B));
-  exclusive_scan<uint64_t>(st, c->edge_fast.as<uint32_t>(), E, c->visit_base.as<uint64_t>(),
-                           c->scan_tmp.as<uint64_t>(), scalar<uint64_t>(c, SC_TOTAL_C));
+  {
+    const uint32_t *const in[3]  = {c->edge_norders.as<uint32_t>(), c->edge_nids.as<uint32_t>(), c->edge_fast.as<uint32_t>()};
+    uint64_t *const       out[3] = {c->order_base.as<uint64_t>(), c->ids_base.as<uint64_t>(), c->visit_base.as<uint64_t>()};
+    uint64_t *const       tot[3] = {scalar<uint64_t>(c, SC_TOTAL_A), scalar<uint64_t>(c, SC_TOTAL_B), scalar<uint64_t>(c, SC_TOTAL_C)};
+    exclusive_scan_set(st, 3, in, E, out, c->scan_tmp.as<uint64_t>(), tot);
+  }
   HIPCHK(c, hipEventRecord(c->ev[7], st));
   if (int rc = read_scalars(c)) return rc; // sizes of the order / id tables
   c->n_edges_fast     = *host_scalar<uint64_t>(c, SC_TOTAL_C);

@@ -91,6 +91,9 @@ struct MergeArgs {
 };
 
 template <class T> void exclusive_scan(hipStream_t st, const uint32_t *in, uint64_t n, T *out, T *block_sums, T *d_total);
+// k <= 3 scans of the same length n in one pair of launches; block_sums holds k * (scan_blocks(n) + 1) words
+void exclusive_scan_set(hipStream_t st, int k, const uint32_t *const *in, uint64_t n, uint64_t *const *out, uint64_t *block_sums,
+                        uint64_t *const *d_total);
 uint32_t scan_blocks(uint64_t n);
 
 void launch_max_ids(hipStream_t st, const msgpu_row *rows, uint64_t n, uint32_t *max_ids);
@@ -112,7 +115,7 @@ void launch_sort_read(hipStream_t st, const uint32_t *read_off, const uint32_t *
                       IRow *by_read, uint32_t *read_cnt, uint32_t *alive_rank,
                       uint32_t *anchor_cnt, uint8_t *bkt_dead, uint32_t *flags, IRow *by_anchor, uint32_t cap,
                       const msgpu_row *rows, int32_t *read_len, uint32_t *read_first, uint32_t *err,
-                      const uint2 *spos, uint4 *vis);
+                      const uint2 *spos, uint4 *vis, uint32_t *visits);
 void launch_select_anchor_off(hipStream_t st, const uint32_t *flags, const uint32_t *fast_off, const uint32_t *gen_off,
                               uint32_t A, uint32_t *anchor_off, uint32_t *d_n_alive, uint32_t n_rows);
 void launch_scatter_anchor(hipStream_t st, const msgpu_row *rows, uint64_t n, const uint32_t *alive_rank,

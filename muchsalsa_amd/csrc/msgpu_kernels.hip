@@ -96,6 +96,22 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
   return v;
 }
 
+// the same scan of 32-bit items with a 64-bit result
+__device__ __forceinline__ uint64_t wave_incl_scan64(uint32_t v) {
+  uint64_t inc = v;
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint64_t t = __shfl_up(inc, d);
+    if (lane >= d) inc += t;
+  }
+  return inc;
+}
+// sum over the wavefront, the same value in every lane
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+  return static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(wave_incl_scan(v)), 63));
+}
+
 template <int NT> __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *s_wave /*[NT / 64]*/, uint32_t *total) {
   const int      lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t inc  = wave_incl_scan(v);
@@ -134,6 +150,7 @@ __device__ __forceinline__ uint32_t block_excl_scan_256(uint32_t v, uint32_t *s_
 // ---------------------------------------------------------------------------------------------------------------------
 
 constexpr int SCAN_ITEMS = 8; // per thread -> 2048 per block
+uint32_t      scan_blocks(uint64_t n);
 
 template <class T> __global__ __launch_bounds__(256) void k_scan_reduce(const uint32_t *in, uint64_t n, T *block_sums) {
   __shared__ T s[4];
@@ -202,6 +219,82 @@ template <class T> void exclusive_scan(hipStream_t st, const uint32_t *in, uint6
 }
 template void exclusive_scan<uint32_t>(hipStream_t, const uint32_t *, uint64_t, uint32_t *, uint32_t *, uint32_t *);
 template void exclusive_scan<uint64_t>(hipStream_t, const uint32_t *, uint64_t, uint64_t *, uint64_t *, uint64_t *);
+
+// up to three scans of the same length in one pair of launches (blockIdx.y picks the array): the per-read / per-edge
+// size arrays of one stage are scanned together -- each scan is two launches of a few microseconds, mostly launch cost
+struct ScanSet {
+  const uint32_t *in[3];
+  uint64_t       *out[3], *sums[3], *total[3];
+};
+__global__ __launch_bounds__(256) void k_scan_reduce_set(ScanSet s, uint64_t n) {
+  __shared__ uint64_t sh[4];
+  const uint32_t     *in   = s.in[blockIdx.y];
+  uint64_t            base = static_cast<uint64_t>(blockIdx.x) * 256 * SCAN_ITEMS;
+  uint64_t            sum  = 0;
+  for (int i = 0; i < SCAN_ITEMS; ++i) {
+    uint64_t idx = base + static_cast<uint64_t>(i) * 256 + threadIdx.x;
+    if (idx < n) sum += in[idx];
+  }
+  for (int d = 32; d > 0; d >>= 1) sum += __shfl_down(sum, d);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = sum;
+  __syncthreads();
+  if (threadIdx.x == 0) s.sums[blockIdx.y][blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+__global__ __launch_bounds__(256) void k_scan_apply_set(ScanSet s, uint64_t n) {
+  __shared__ uint64_t s_w[4];
+  __shared__ uint64_t s_carry;
+  const uint32_t     *in         = s.in[blockIdx.y];
+  const uint64_t     *block_sums = s.sums[blockIdx.y];
+  uint64_t           *out        = s.out[blockIdx.y];
+  uint64_t            base       = static_cast<uint64_t>(blockIdx.x) * 256 * SCAN_ITEMS;
+  const int           lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  {
+    uint64_t c = 0;
+    for (uint32_t i = threadIdx.x; i < blockIdx.x; i += 256) c += block_sums[i];
+    for (int d = 32; d > 0; d >>= 1) c += __shfl_down(c, d);
+    if (lane == 0) s_w[wave] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) s_carry = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+    __syncthreads();
+  }
+  for (int it = 0; it < SCAN_ITEMS; ++it) {
+    uint64_t       idx = base + static_cast<uint64_t>(it) * 256 + threadIdx.x;
+    const uint32_t v   = idx < n ? in[idx] : 0u;
+    const uint64_t inc = wave_incl_scan64(v);
+    if (lane == 63) s_w[wave] = inc;
+    __syncthreads();
+    uint64_t b = s_carry;
+    for (int w = 0; w < wave; ++w) b += s_w[w];
+    if (idx < n) out[idx] = b + inc - v;
+    if (idx == n - 1) {
+      out[n]              = b + inc;
+      *s.total[blockIdx.y] = b + inc;
+    }
+    __syncthreads();
+    if (threadIdx.x == 255) s_carry = b + inc;
+    __syncthreads();
+  }
+}
+void exclusive_scan_set(hipStream_t st, int k, const uint32_t *const *in, uint64_t n, uint64_t *const *out, uint64_t *block_sums,
+                        uint64_t *const *d_total) {
+  const uint32_t nb = scan_blocks(n ? n : 1);
+  ScanSet        s{};
+  for (int i = 0; i < k; ++i) {
+    s.in[i]    = in[i];
+    s.out[i]   = out[i];
+    s.sums[i]  = block_sums + static_cast<size_t>(i) * (nb + 1);
+    s.total[i] = d_total[i];
+  }
+  if (n == 0) {
+    for (int i = 0; i < k; ++i) {
+      (void)hipMemsetAsync(out[i], 0, 8, st);
+      (void)hipMemsetAsync(d_total[i], 0, 8, st);
+    }
+    return;
+  }
+  hipLaunchKernelGGL(k_scan_reduce_set, dim3(nb, k), dim3(256), 0, st, s, n);
+  hipLaunchKernelGGL(k_scan_apply_set, dim3(nb, k), dim3(256), 0, st, s, n);
+}
 
 uint32_t scan_blocks(uint64_t n) { return static_cast<uint32_t>((n + 256 * SCAN_ITEMS - 1) / (256 * SCAN_ITEMS)); }
 
@@ -393,7 +486,8 @@ __device__ __forceinline__ bool sort_read_in_registers(uint32_t r, uint64_t bs, 
                                                        const IRow *bkt_row, IRow *by_read,
                                                        uint32_t *read_cnt, uint32_t *alive_rank, uint32_t *anchor_cnt,
                                                        IRow *by_anchor, const msgpu_row *rows, int32_t *read_len,
-                                                       uint32_t *read_first, const uint2 *spos, uint4 *vis) {
+                                                       uint32_t *read_first, const uint2 *spos, uint4 *vis,
+                                                       uint32_t *visits) {
   IRow     row[K];
   uint32_t idx[K], man[K], less[K];
   int      mlo[K], mhi[K];
@@ -433,6 +527,7 @@ __device__ __forceinline__ bool sort_read_in_registers(uint32_t r, uint64_t bs, 
     note_first_row(lane, fk, r, rows, read_len, read_first);
   }
   if (__ballot(dup)) return false; // sentinel rows (anchor 0xffffffff) are never broadcast, so they cannot match
+  uint32_t behind = 0; // scaffold rows behind this read's own rows = the visits of its candidate scan
 #pragma unroll
   for (int k = 0; k < K; ++k) {
     if (static_cast<uint32_t>(k) * 64 + lane < n) {
@@ -445,6 +540,7 @@ __device__ __forceinline__ bool sort_read_in_registers(uint32_t r, uint64_t bs, 
         store_irow(&by_anchor[sp], w);
         row[k].pf = (row[k].pf & ~PF_POS_MASK) | sp; // by_read rows carry their place in the scaffold
         vis[b + less[k]] = make_uint4(static_cast<uint32_t>(row[k].i_lo), static_cast<uint32_t>(row[k].i_hi), sp + 1, sc.y);
+        behind += sc.y;
       }
       store_irow(&by_read[b + less[k]], row[k]);
       if (!fast) {
@@ -453,7 +549,11 @@ __device__ __forceinline__ bool sort_read_in_registers(uint32_t r, uint64_t bs, 
       }
     }
   }
-  if (lane == 0) read_cnt[r] = n;
+  behind = wave_sum(behind);
+  if (lane == 0) {
+    read_cnt[r] = n;
+    visits[r]   = behind;
+  }
   return true;
 }
 
@@ -467,7 +567,7 @@ __global__ __launch_bounds__(256) void k_sort_read(const uint32_t *read_off, con
                                                    uint32_t *read_cnt, uint32_t *alive_rank, uint32_t *anchor_cnt,
                                                    uint8_t *bkt_dead, uint32_t *flags, IRow *by_anchor, uint32_t cap,
                                                    const msgpu_row *rows, int32_t *read_len, uint32_t *read_first,
-                                                   uint32_t *err, const uint2 *spos, uint4 *vis) {
+                                                   uint32_t *err, const uint2 *spos, uint4 *vis, uint32_t *visits) {
   const int      lane = threadIdx.x & 63;
   const uint32_t r    = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
   if (r >= V) return;
@@ -480,6 +580,7 @@ __global__ __launch_bounds__(256) void k_sort_read(const uint32_t *read_off, con
     if (lane == 0) {
       read_len[r]   = 0;
       read_first[r] = 0xffffffffu;
+      visits[r]     = 0;
       atomicOr(err, 1u);
     }
     return;
@@ -504,7 +605,8 @@ __global__ __launch_bounds__(256) void k_sort_read(const uint32_t *read_off, con
       less += key_less(olo, ohi, oan, mlo, mhi, man) ? 1u : 0u;
       dup |= (t != lane) & (oan == man);
     }
-    bool alive = have;
+    bool     alive  = have;
+    uint32_t behind = 0; // scaffold rows behind this row = its visits in the candidate scan (fast mode)
     if (__ballot(dup && have)) { // rare: a (read, anchor) pair occurs more than once -- lowest line wins
       bool dead = false;
       for (int t = 0; t < static_cast<int>(n); ++t) {
@@ -535,6 +637,7 @@ __global__ __launch_bounds__(256) void k_sort_read(const uint32_t *read_off, con
         // what the candidate scan reads of this row: anchor interval + the stretch of the scaffold behind it (the
         // partners with a higher read id)
         vis[b + less] = make_uint4(static_cast<uint32_t>(row.i_lo), static_cast<uint32_t>(row.i_hi), sp + 1, sc.y);
+        behind = sc.y;
       }
       store_irow(&by_read[b + less], row);
       if (!fast) {
@@ -545,20 +648,24 @@ __global__ __launch_bounds__(256) void k_sort_read(const uint32_t *read_off, con
       alive_rank[idx] = 0xffffffffu;
     }
     const unsigned long long alive_mask = __ballot(alive); // all lanes vote (not inside the lane-0 branch)
-    if (lane == 0) read_cnt[r] = static_cast<uint32_t>(__popcll(alive_mask));
+    behind = wave_sum(behind);
+    if (lane == 0) {
+      read_cnt[r] = static_cast<uint32_t>(__popcll(alive_mask));
+      visits[r]   = behind;
+    }
     return;
   }
   if (n <= 128) {
     if (sort_read_in_registers<2>(r, bs, b, n, lane, fast, bkt_row, by_read, read_cnt, alive_rank, anchor_cnt,
-                                  by_anchor, rows, read_len, read_first, spos, vis))
+                                  by_anchor, rows, read_len, read_first, spos, vis, visits))
       return;
   } else if (n <= 256) {
     if (sort_read_in_registers<4>(r, bs, b, n, lane, fast, bkt_row, by_read, read_cnt, alive_rank, anchor_cnt,
-                                  by_anchor, rows, read_len, read_first, spos, vis))
+                                  by_anchor, rows, read_len, read_first, spos, vis, visits))
       return;
   }
   // very long read, or one with a duplicated (read, anchor) pair: the bucket stays in global memory
-  uint32_t           n_alive = 0;
+  uint32_t           n_alive = 0, n_behind = 0;
   unsigned long long fk      = ~0ull;
   for (uint32_t e0 = 0; e0 < n; e0 += 64) {
     const uint32_t e = e0 + lane;
@@ -598,6 +705,7 @@ __global__ __launch_bounds__(256) void k_sort_read(const uint32_t *read_off, con
         store_irow(&by_anchor[sp], w);
         k.pf = (k.pf & ~PF_POS_MASK) | sp;
         vis[b + less] = make_uint4(static_cast<uint32_t>(k.i_lo), static_cast<uint32_t>(k.i_hi), sp + 1, sc.y);
+        n_behind += sc.y;
       }
       store_irow(&by_read[b + less], k);
       if (!fast) {
@@ -607,7 +715,11 @@ __global__ __launch_bounds__(256) void k_sort_read(const uint32_t *read_off, con
     }
     n_alive += static_cast<uint32_t>(__popcll(__ballot(alive)));
   }
-  if (lane == 0) read_cnt[r] = n_alive;
+  n_behind = wave_sum(n_behind);
+  if (lane == 0) {
+    read_cnt[r] = n_alive;
+    visits[r]   = n_behind;
+  }
 }
 
 
@@ -700,13 +812,12 @@ __global__ __launch_bounds__(NT) void k_candidates(CandArgs a, const CandDesc *d
   static_assert(4 * R1MAX * 4 + 16 >= 2 * HSZ, "region A must hold g_rank");
   __shared__ __attribute__((aligned(16))) unsigned char s_regA[4 * R1MAX * 4 + 16];
   __shared__ __attribute__((aligned(16))) unsigned char s_regB[4 * CMAX + 16];
-  // per row j of v1: {i_lo, i_hi, first scaffold row behind v1's own MINUS the row's first candidate slot, -}: one
-  // 16-byte LDS read per visit gives the anchor interval and, added to the slot number, the scaffold row to load
+  // per row j of v1: {i_lo, i_hi, -, -}, the anchor interval on v1's side
   uint4 *const    s_row  = reinterpret_cast<uint4 *>(s_regA);
   uint16_t *const g_rank = reinterpret_cast<uint16_t *>(s_regA); // HSZ entries
   uint16_t *const g_slot = reinterpret_cast<uint16_t *>(s_regB);
   uint16_t *const g_off  = g_slot + CMAX; // CMAX + 1 entries
-  __shared__ uint32_t s_t[CMAX];                // (fallback staging only) by_anchor row of staging position pos
+  __shared__ uint32_t s_t[CMAX];                // by_anchor row of candidate slot c, later (staging) of position pos
   __shared__ uint16_t s_j[CMAX], s_g[CMAX];     // row j of candidate slot c, later of staging position pos; group of pos
   __shared__ uint32_t h_key[HSZ], h_cnt[HSZ];   // open-addressing table v2 -> group; members per group
   __shared__ uint32_t s_bm[HSZ];                // per group (in v2 order): bitmap of the rows j it holds, R1MAX bits
@@ -738,22 +849,36 @@ __global__ __launch_bounds__(NT) void k_candidates(CandArgs a, const CandDesc *d
     vr[q] = j < n1 ? a.vis[rb + j] : make_uint4(0, 0, 0, 0);
     tsum += vr[q].w;
   }
-  uint32_t T;
-  uint32_t ex = block_excl_scan<NT>(tsum, s_wave, &T);
-  // every visit x in [0, T) is one candidate slot: s_j[x] = the row of v1 it belongs to (filled here, stretch by
-  // stretch), so the scan below is one scaffold row per lane with no search, no per-row lane groups and no compaction
-  // (nearly every visit passes the overlap test now that only the owned partners are visited; the few that fail keep
-  // an empty slot that the later phases skip)
+  // every visit x in [0, T) is one candidate slot: s_j[x] = the row of v1 it belongs to and s_t[x] = the scaffold row
+  // to load (filled here, stretch by stretch), so the scan below is one scaffold row per lane with no search, no
+  // per-row lane groups and no compaction (nearly every visit passes the overlap test now that only the owned partners
+  // are visited; the few that fail keep an empty slot that the later phases skip).  A read of up to 64 rows (the rule)
+  // is scanned by its first wavefront alone: no workgroup scan, no barrier before the one that publishes the slots.
+  const bool one_wave = JPT == 1 && n1 <= 64; // workgroup-uniform
+  uint32_t   T = 0, ex = 0;
+  if (one_wave) {
+    if (tid < 64) {
+      const uint32_t inc = wave_incl_scan(tsum);
+      ex                 = inc - tsum;
+      if (tid == 63) s_wave[0] = inc;
+    }
+  } else {
+    ex = block_excl_scan<NT>(tsum, s_wave, &T);
+  }
 #pragma unroll
   for (int q = 0; q < JPT; ++q) {
     const uint32_t j = tid * JPT + q;
     if (j < n1) {
-      s_row[j] = make_uint4(vr[q].x, vr[q].y, vr[q].z - ex, 0u);
-      for (uint32_t k = 0; k < vr[q].w; ++k) s_j[ex + k] = static_cast<uint16_t>(j);
+      s_row[j] = make_uint4(vr[q].x, vr[q].y, 0u, 0u);
+      for (uint32_t k = 0; k < vr[q].w; ++k) {
+        s_j[ex + k] = static_cast<uint16_t>(j);
+        s_t[ex + k] = vr[q].z + k;
+      }
     }
     ex += vr[q].w;
   }
   __syncthreads();
+  if (one_wave) T = s_wave[0];
   const uint32_t nc = T; // candidate slots (empty ones included)
 
   // (b) one scaffold row per lane: consecutive lanes read consecutive rows of a scaffold.  Slot c = tid + NT * q stays
@@ -770,9 +895,9 @@ __global__ __launch_bounds__(NT) void k_candidates(CandArgs a, const CandDesc *d
     c_ok[q]          = false;
     if (c < nc) {
       const uint32_t j  = s_j[c];
-      const uint4    rw = s_row[j];
-      const uint32_t vm = rw.z + c;
+      const uint32_t vm = s_t[c];
       const IRow     o  = load_irow(&a.by_anchor[vm]);
+      const uint4    rw = s_row[j]; // the anchor interval on v1's side: needed only once the scaffold row is here
       const int      ovlo = max(o.i_lo, static_cast<int>(rw.x)), ovhi = min(o.i_hi, static_cast<int>(rw.y));
       // overlap test (MatchMap.cpp:192); the owner rule (v2 > v1 <=> v1 has the lower first line, :204-213) is the
       // choice of the rows visited: scaffolds are in read-id order and the walk starts behind v1's own row
@@ -2734,11 +2859,11 @@ void launch_sort_read(hipStream_t st, const uint32_t *read_off, const uint32_t *
                       IRow *by_read, uint32_t *read_cnt, uint32_t *alive_rank,
                       uint32_t *anchor_cnt, uint8_t *bkt_dead, uint32_t *flags, IRow *by_anchor, uint32_t cap,
                       const msgpu_row *rows, int32_t *read_len, uint32_t *read_first, uint32_t *err,
-                      const uint2 *spos, uint4 *vis) {
+                      const uint2 *spos, uint4 *vis, uint32_t *visits) {
   if (V)
     hipLaunchKernelGGL(k_sort_read, grid1(V, 4), dim3(256), 0, st, read_off, cnt_read, V, bkt_row, by_read,
                        read_cnt, alive_rank, anchor_cnt, bkt_dead, flags, by_anchor, cap, rows, read_len, read_first, err,
-                       spos, vis);
+                       spos, vis, visits);
 }
 void launch_select_anchor_off(hipStream_t st, const uint32_t *flags, const uint32_t *fast_off, const uint32_t *gen_off,
                               uint32_t A, uint32_t *anchor_off, uint32_t *d_n_alive, uint32_t n_rows) {
