@@ -583,9 +583,14 @@ int msgpu_calculate_edges(msgpu_ctx *c) {
 
   ENSURE(c, edges, (c->n_edges ? c->n_edges : 1) * sizeof(msgpu_edge));
   ENSURE(c, edge_cand, (c->n_edges ? c->n_edges : 1) * 8);
+  // the edges with more than 64 EdgeMatches (counted by the candidate kernels) are listed as they are emitted
+  ENSURE(c, big_list, (c->n_big_edges + 1) * 4);
+  ENSURE(c, big_off, (c->n_big_edges + 1) * 8);
+  HIPCHK(c, hipMemsetAsync(scalar<uint64_t>(c, SC_BIGCUR), 0, 16, st));
   launch_emit_edges(st, c->n_edge.as<uint32_t>(), c->n_cand.as<uint32_t>(), c->edge_base.as<uint64_t>(),
                     c->em_base.as<uint64_t>(), c->cand_off.as<uint64_t>(), c->scr_v2.as<uint32_t>(),
-                    c->scr_start.as<uint32_t>(), V, c->edges.as<msgpu_edge>(), c->edge_cand.as<uint64_t>());
+                    c->scr_start.as<uint32_t>(), V, c->edges.as<msgpu_edge>(), c->edge_cand.as<uint64_t>(),
+                    c->big_list.as<uint32_t>(), c->big_off.as<uint64_t>(), scalar<unsigned long long>(c, SC_BIGCUR));
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipEventRecord(c->ev[3], st));
   c->have_cand_t = true;
@@ -610,7 +615,6 @@ int msgpu_chaining_and_overlaps(msgpu_ctx *c) {
   ENSURE(c, edge_nids, (E + 1) * 4);
   ENSURE(c, order_base, (E + 2) * 8);
   ENSURE(c, ids_base, (E + 2) * 8);
-  ENSURE(c, big_list, (E + 1) * 4);
   ENSURE(c, visit_base, (E + 2) * 8); // re-used as the scan output of the per-edge shortcut flags
   ENSURE(c, scan_tmp, 3 * (size_t(scan_blocks(E > c->V ? E : c->V)) + 1) * 8);
 
@@ -656,13 +660,9 @@ int msgpu_chaining_and_overlaps(msgpu_ctx *c) {
   // are and how much scratch they need) run in k_chain_big on the side stream, concurrently with k_chain.
   const uint32_t n_big = static_cast<uint32_t>(c->n_big_edges);
   if (n_big) {
-    ENSURE(c, big_off, (size_t(n_big) + 1) * 8);
     ENSURE(c, big_elems, (c->n_big_ems ? c->n_big_ems : 1) * big_elem_bytes());
     ENSURE(c, big_paths, (c->n_big_ems ? c->n_big_ems : 1) * 2 * big_path_bytes());
-    HIPCHK(c, hipMemsetAsync(scalar<uint64_t>(c, SC_BIGCUR), 0, 16, st));
-    launch_list_big_edges(st, a.edges, E, c->big_list.as<uint32_t>(), c->big_off.as<uint64_t>(),
-                          scalar<uint64_t>(c, SC_BIGCUR));
-    HIPCHK(c, hipEventRecord(c->ev_side[0], st));
+    HIPCHK(c, hipEventRecord(c->ev_side[0], st)); // (the list and the scratch offsets: k_emit_edges)
     HIPCHK(c, hipStreamWaitEvent(c->side_stream, c->ev_side[0], 0));
     launch_chain_big(c->side_stream, a, c->big_list.as<uint32_t>(), c->big_off.as<uint64_t>(), n_big,
                      c->big_elems.p, c->big_paths.p);

@@ -135,7 +135,8 @@ void launch_candidates_big(hipStream_t st, const CandArgs &a, const uint32_t *li
                            uint32_t *big_t, uint32_t *big_r2s, uint32_t *big_pfx);
 void launch_emit_edges(hipStream_t st, const uint32_t *n_edge, const uint32_t *n_cand, const uint64_t *edge_base,
                        const uint64_t *em_base, const uint64_t *cand_off, const uint32_t *scr_v2,
-                       const uint32_t *scr_start, uint32_t V, msgpu_edge *edges, uint64_t *edge_cand);
+                       const uint32_t *scr_start, uint32_t V, msgpu_edge *edges, uint64_t *edge_cand,
+                       uint32_t *big_list, uint64_t *big_off, unsigned long long *big_cursor);
 constexpr uint32_t PAIR_TAB_STRIDE = 2016 + 128; // pairs k < l < 64 + padding read by lanes past the last pair
 void launch_fill_pair_tab(hipStream_t st, uint32_t *tab);
 void launch_chain(hipStream_t st, const ChainArgs &a, const uint32_t *list, uint32_t n_list);
@@ -143,8 +144,6 @@ void launch_chain_sub(hipStream_t st, const ChainArgs &a, int width, const uint3
 void launch_sort_edges_by_size(hipStream_t st, const msgpu_edge *edges, uint64_t n_edges, uint32_t *part, uint32_t *list,
                                uint32_t *counts);
 size_t size_sort_part_bytes();
-void launch_list_big_edges(hipStream_t st, const msgpu_edge *edges, uint64_t n_edges, uint32_t *big_list,
-                           uint64_t *big_off, uint64_t *cursor);
 size_t big_elem_bytes();
 size_t big_path_bytes();
 void launch_chain_big(hipStream_t st, const ChainArgs &a, const uint32_t *big_list, const uint64_t *big_off,

@@ -1216,7 +1216,8 @@ __global__ __launch_bounds__(256) void k_emit_edges(const uint32_t *n_edge, cons
                                                     const uint64_t *edge_base, const uint64_t *em_base,
                                                     const uint64_t *cand_off, const uint32_t *edge_scr_v2,
                                                     const uint32_t *edge_scr_start, uint32_t V, msgpu_edge *edges,
-                                                    uint64_t *edge_cand) {
+                                                    uint64_t *edge_cand, uint32_t *big_list, uint64_t *big_off,
+                                                    unsigned long long *big_cursor /*[2]*/) {
   // 16 lanes per read (a read has ~10 edges)
   uint32_t r    = blockIdx.x * 16 + (threadIdx.x >> 4);
   int      lane = threadIdx.x & 15;
@@ -1239,6 +1240,11 @@ __global__ __launch_bounds__(256) void k_emit_edges(const uint32_t *n_edge, cons
     ed.pad       = 0;
     edges[eb + e]     = ed;
     edge_cand[eb + e] = co + st;
+    if (ed.em_cnt > 64) { // the few edges k_chain_big takes: listed here, with the first scratch element of each
+      const unsigned long long i = atomicAdd(&big_cursor[0], 1ull);
+      big_list[i] = static_cast<uint32_t>(eb + e);
+      big_off[i]  = atomicAdd(&big_cursor[1], static_cast<unsigned long long>(ed.em_cnt));
+    }
   }
 }
 
@@ -2696,18 +2702,6 @@ __global__ __launch_bounds__(64) void k_chain_big(ChainArgs a, const uint32_t *b
   }
 }
 
-__global__ __launch_bounds__(256) void k_list_big_edges(const msgpu_edge *edges, uint64_t n_edges, uint32_t *big_list,
-                                                        uint64_t *big_off, unsigned long long *cursor /*[2]*/) {
-  uint64_t e = static_cast<uint64_t>(blockIdx.x) * 256 + threadIdx.x;
-  if (e >= n_edges) return;
-  const uint32_t n = edges[e].em_cnt;
-  if (n > 64) {
-    const unsigned long long i = atomicAdd(&cursor[0], 1ull);
-    big_list[i] = static_cast<uint32_t>(e);
-    big_off[i]  = atomicAdd(&cursor[1], static_cast<unsigned long long>(n)); // first scratch element of this edge
-  }
-}
-
 // Pair tables: entry p = k | l << 8 | run << 16 | (64 - run - k) << 24 for the flattened pair index p = l(l-1)/2 + k, k < l < 64, where run
 // is the length of the stretch of row l that starts at lane p % W of a W-wide sweep step (0 if no stretch starts
 // there).  Four tables (W = 64, 32, 16, 8) of PAIR_TAB_STRIDE entries, each padded with (0, 1, 0).
@@ -2915,10 +2909,11 @@ void launch_candidates_big(hipStream_t st, const CandArgs &a, const uint32_t *li
 }
 void launch_emit_edges(hipStream_t st, const uint32_t *n_edge, const uint32_t *n_cand, const uint64_t *edge_base,
                        const uint64_t *em_base, const uint64_t *cand_off, const uint32_t *scr_v2,
-                       const uint32_t *scr_start, uint32_t V, msgpu_edge *edges, uint64_t *edge_cand) {
+                       const uint32_t *scr_start, uint32_t V, msgpu_edge *edges, uint64_t *edge_cand,
+                       uint32_t *big_list, uint64_t *big_off, unsigned long long *big_cursor) {
   if (V)
     hipLaunchKernelGGL(k_emit_edges, grid1(V, 16), dim3(256), 0, st, n_edge, n_cand, edge_base, em_base, cand_off, scr_v2,
-                       scr_start, V, edges, edge_cand);
+                       scr_start, V, edges, edge_cand, big_list, big_off, big_cursor);
 }
 void launch_fill_pair_tab(hipStream_t st, uint32_t *tab) {
   hipLaunchKernelGGL(k_fill_pair_tab, dim3((4 * PAIR_TAB_STRIDE + 255) / 256), dim3(256), 0, st, tab);
@@ -2946,12 +2941,6 @@ void launch_sort_edges_by_size(hipStream_t st, const msgpu_edge *edges, uint64_t
   hipLaunchKernelGGL(k_size_scatter, dim3(SIZE_SORT_BLOCKS), dim3(1024), 0, st, edges, E, chunk, part, list);
 }
 size_t size_sort_part_bytes() { return static_cast<size_t>(SIZE_SORT_BLOCKS) * 64 * 4; }
-void launch_list_big_edges(hipStream_t st, const msgpu_edge *edges, uint64_t n_edges, uint32_t *big_list,
-                           uint64_t *big_off, uint64_t *cursor) {
-  if (n_edges)
-    hipLaunchKernelGGL(k_list_big_edges, grid1(n_edges, 256), dim3(256), 0, st, edges, n_edges, big_list, big_off,
-                       reinterpret_cast<unsigned long long *>(cursor));
-}
 size_t big_elem_bytes() { return sizeof(BigElem); }
 size_t big_path_bytes() { return sizeof(BigPath); }
 void launch_chain_big(hipStream_t st, const ChainArgs &a, const uint32_t *big_list, const uint64_t *big_off,
