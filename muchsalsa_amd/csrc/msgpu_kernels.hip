@@ -1566,16 +1566,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 
   // ---- checkCompatibility (mpp.cpp:38-142) for every pair k < l of one direction, all 64 lanes busy ---------------
   // pair p = l(l-1)/2 + k, row-major over l; a lane handles p = it*64 + lane
-  const int P = clean ? 0 : static_cast<int>(n * (n - 1) / 2);
-  // One-direction edges (the rule for true overlaps) need no per-pair direction test: every pair is "valid" and the
-  // flip of mpp.cpp:131 is the same for all of them.
-  const bool one_dir = m_plus == 0 || m_minus == 0; // wave-uniform
+  const int P = __builtin_amdgcn_readfirstlane(clean ? 0 : static_cast<int>(n * (n - 1) / 2)); // scalar loop control
   // Pair p: k | l << 8 | run << 16 | (64 - run - k) << 24 from a table that is the same for every edge (run = length of
   // the stretch of row l that starts at this lane of a 64-wide step, 0 if none starts here).  The table is padded with
   // (0, 1, 0) beyond the last pair and every (k, l) in it is < 64, so lanes past P read without a clamp or a branch and
   // are masked out.
-  const uint32_t *tab     = a.pair_tab; // + p0 below: a scalar base, the lane's offset never changes
-  uint32_t        kl_next = tab[lane];
+  static_assert(sizeof(ChainElem) == 48, "the pair table holds byte offsets of 48-byte elements");
+  const uint2 *tab     = a.pair_tab64; // + p0 below: a scalar base, the lane's offset never changes
+  uint2        kl_next = tab[lane];
   // The scalar registers of this loop are all taken by pair masks; a loop-invariant scalar operand would be spilled and
   // re-read (v_readlane) in every step.  The one constant the common path compares with lives in a vector register.
   double wiggle = a.wiggle;
@@ -1587,42 +1585,55 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     wf_lane = (x.clo1 <= x.chi1) & (x.clo2 <= x.chi2) & (x.rlo1 <= x.rhi1) & (lane == 0 || prev_rlo1 <= x.rlo1);
   }
   const bool wf = __ballot(!wf_lane) == 0;
-  auto sweep_step = [&](int p0, auto wft) __attribute__((always_inline)) {
-    typedef decltype(wft) WFT;
-    unsigned long long bits = 0; // checkCompatibility(k, l) of the 64 pairs of this step
-    const uint32_t     kl = kl_next;
-    kl_next               = (tab + p0 + 64)[lane]; // the next step's pairs are on their way while this one computes
-    const int k = static_cast<int>(kl & 0xffu), l = static_cast<int>((kl >> 8) & 0xffu), run = static_cast<int>((kl >> 16) & 0xffu);
+  // DIR: 0 = every EdgeMatch forward, 1 = every EdgeMatch reverse (the flip of mpp.cpp:131 is then the same for all
+  // pairs and costs nothing), 2 = both directions present (pairs of one direction only, flip per pair).  The loop is
+  // bound by SCALAR issue (the mask algebra), so everything wave-uniform is decided outside it: six instances.
+  auto sweep_step = [&](int p0, auto wft, auto dirt) __attribute__((always_inline)) {
+    typedef decltype(wft)  WFT;
+    typedef decltype(dirt) DIRT;
+    constexpr int          DIR = DIRT::value;
+    unsigned long long     bits = 0; // checkCompatibility(k, l) of the 64 pairs of this step
+    const uint2 kl = kl_next;
+    kl_next        = (tab + p0 + 64)[lane]; // the next step's pairs are on their way while this one computes
     { // every lane evaluates a pair: no divergence, all masks are wave-uniform
       typedef unsigned long long M;
-      M valid = __ballot(lane < P - p0), KD = 0;
-      if (!one_dir) { // pairs of one direction only
+      // lanes past the last pair evaluate the padding pair (0, 1) and have run = 0: their bits are never stored, so
+      // one-direction edges need no "valid" mask at all
+      M valid = ~0ull, KD = 0;
+      if (DIR == 2) { // pairs of one direction only
+        const int  k = static_cast<int>((kl.x & 0xffffu) / 48u), l = static_cast<int>((kl.x >> 16) / 48u);
         const bool kd = (m_plus >> k) & 1ull, ld = (m_plus >> l) & 1ull;
-        valid &= __ballot(kd == ld);
-        KD = __ballot(kd);
+        valid = __ballot(kd == ld);
+        KD    = __ballot(kd);
       }
-      const ChainElem K = el[k], L = el[l];
+      const unsigned char *elb = reinterpret_cast<const unsigned char *>(el);
+      const ChainElem      K = *reinterpret_cast<const ChainElem *>(elb + (kl.x & 0xffffu));
+      const ChainElem      L = *reinterpret_cast<const ChainElem *>(elb + (kl.x >> 16));
       double          d1, d2;
       const NanoMasks f1 = nano_check<WFT::value, WFT::value>(K.clo1, K.chi1, L.clo1, L.chi1, K.rlo1, K.rhi1, L.rlo1, L.rhi1, d1);
       const NanoMasks f2 = nano_check<WFT::value, false>(K.clo2, K.chi2, L.clo2, L.chi2, K.rlo2, K.rhi2, L.rlo2, L.rhi2, d2);
       M p2, n2; // :131 flip by EdgeMatch(k).direction
-      if (one_dir) {
-        p2 = m_minus == 0 ? f2.pos : f2.neg;
-        n2 = m_minus == 0 ? f2.neg : f2.pos;
+      if (DIR == 0) {
+        p2 = f2.pos;
+        n2 = f2.neg;
+      } else if (DIR == 1) {
+        p2 = f2.neg;
+        n2 = f2.pos;
       } else {
         p2 = (KD & f2.pos) | (~KD & f2.neg);
         n2 = (KD & f2.neg) | (~KD & f2.pos);
       }
-      const M codir   = (f1.pos & p2) | (f1.neg & n2); // :137 same sign
-      const M same    = codir & ~(f1.ovl ^ f2.ovl);    // :133 equal and non-zero
-      const M live    = valid & ~(f1.abort_ | f2.abort_);
+      const M codir = (f1.pos & p2) | (f1.neg & n2); // :137 same sign
+      const M mixed = f1.ovl ^ f2.ovl;               // :133 "equal and non-zero" fails: one overlaps, one does not
+      M       cl    = codir & ~(f1.abort_ | f2.abort_);
+      if (DIR == 2) cl &= valid;
       // std::max(d1, d2) - std::min(d1, d2) = |d1 - d2| bit for bit (a - b and b - a round to the same magnitude); the
       // maximum itself is only needed by the division
       const double df = fabs(d1 - d2);
       const M near_ = __ballot(df <= wiggle), sum_ok = __ballot(d1 + d2 <= wiggle);
-      M       ok    = ((same & near_) | (codir & ~same & sum_ok)) & live;
+      M       ok    = cl & ((near_ & ~mixed) | (sum_ok & mixed));
       // the fp64 division of :136 only where the first test failed (rare for true overlaps)
-      const M need_div = same & ~near_ & live;
+      const M need_div = cl & ~(mixed | near_);
       if (need_div) {
         bool pass = false;
         if (__builtin_amdgcn_inverse_ballot_w64(need_div)) pass = df * 100 / fmax(d1, d2) <= a.ratio_pct;
@@ -1630,17 +1641,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
       }
       bits = ok;
     }
-    // the pairs of row l are consecutive lanes; the first lane of each stretch stores the stretch's bits (lanes past P
-    // hold zeros in `bits`)
-    if (run) { // keep `run` bits from bit `lane` on and put them at bit k: three shifts, the counts come from the table
-      const int up = 64 - run, down = static_cast<int>(kl >> 24); // down = up - k >= 1
-      cm[l] |= ((bits >> lane) << up) >> down;
+    // the pairs of row l are consecutive lanes; the first lane of each stretch stores the stretch's bits
+    if (static_cast<int>(kl.y) < 0) { // run != 0: keep `run` bits from bit `lane` on and put them at bit k -- three shifts,
+                                      // the counts (64 - run, 64 - run - k) come from the table
+      uint64_t *row = reinterpret_cast<uint64_t *>(reinterpret_cast<unsigned char *>(cm) - 0x8000 + (kl.y >> 16));
+      *row |= ((bits >> lane) << (kl.y & 63u)) >> ((kl.y >> 8) & 63u);
     }
   };
-  if (wf)
-    for (int p0 = 0; p0 < P; p0 += 64) sweep_step(p0, std::true_type{});
-  else
-    for (int p0 = 0; p0 < P; p0 += 64) sweep_step(p0, std::false_type{});
+  auto sweep = [&](auto wft, auto dirt) __attribute__((always_inline)) {
+    for (int p0 = 0; p0 < P; p0 += 64) sweep_step(p0, wft, dirt);
+  };
+  auto sweep_dir = [&](auto wft) __attribute__((always_inline)) {
+    if (m_minus == 0) sweep(wft, std::integral_constant<int, 0>{});
+    else if (m_plus == 0) sweep(wft, std::integral_constant<int, 1>{});
+    else sweep(wft, std::integral_constant<int, 2>{});
+  };
+  if (wf) sweep_dir(std::true_type{});
+  else sweep_dir(std::false_type{});
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   const uint64_t mycm = cm[lane]; // bit k: checkCompatibility(k, lane) for k < lane of the same direction
@@ -2705,12 +2722,25 @@ __global__ __launch_bounds__(64) void k_chain_big(ChainArgs a, const uint32_t *b
 // Pair tables: entry p = k | l << 8 | run << 16 | (64 - run - k) << 24 for the flattened pair index p = l(l-1)/2 + k, k < l < 64, where run
 // is the length of the stretch of row l that starts at lane p % W of a W-wide sweep step (0 if no stretch starts
 // there).  Four tables (W = 64, 32, 16, 8) of PAIR_TAB_STRIDE entries, each padded with (0, 1, 0).
+// The width-64 table once more, 8 bytes per pair, with the fields in the form k_chain's sweep consumes them (byte offsets
+// that an SDWA add takes as they are, the first shift count in the low six bits of its word):
+//   x = byte offset of element k in the wavefront's element array | byte offset of element l << 16
+//   y = (64 - run) & 63 | (64 - run - k) << 8 | (byte offset of row l in the compatibility rows + 0x8000 if run != 0) << 16
+//       (run != 0 is the sign of y; the 0x8000 it adds to the row offset is taken off the base the offset is added to)
+// (k and l themselves, which only mixed-direction edges need, are the offsets / 48)
+__device__ __forceinline__ void tab64_entry(uint32_t *tab, int p, int k, int l, int run) {
+  uint2 *t64 = reinterpret_cast<uint2 *>(tab + 4 * PAIR_TAB_STRIDE);
+  t64[p]     = make_uint2(static_cast<uint32_t>(k * 48) | (static_cast<uint32_t>(l * 48) << 16),
+                          (static_cast<uint32_t>(64 - run) & 63u) | (static_cast<uint32_t>((64 - run - k) & 63) << 8) |
+                              (static_cast<uint32_t>(l * 8 + (run ? 0x8000 : 0)) << 16));
+}
 __global__ __launch_bounds__(256) void k_fill_pair_tab(uint32_t *tab) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= 4 * static_cast<int>(PAIR_TAB_STRIDE)) return;
   const int t = i / static_cast<int>(PAIR_TAB_STRIDE), p = i % static_cast<int>(PAIR_TAB_STRIDE), W = 64 >> t;
   if (p >= 2016) {
     tab[i] = 1u << 8;
+    if (t == 0) tab64_entry(tab, p, 0, 1, 0);
     return;
   }
   int l = static_cast<int>((1.0f + __fsqrt_rn(1.0f + 8.0f * static_cast<float>(p))) * 0.5f);
@@ -2719,6 +2749,7 @@ __global__ __launch_bounds__(256) void k_fill_pair_tab(uint32_t *tab) {
   const int k = p - l * (l - 1) / 2, lane = p % W;
   const int run = (k == 0 || lane == 0) ? min(l - k, W - lane) : 0;
   tab[i] = static_cast<uint32_t>(k | (l << 8) | (run << 16)) | (static_cast<uint32_t>(64 - run - k) << 24);
+  if (t == 0) tab64_entry(tab, p, k, l, run);
 }
 
 // dense, canonical order + id tables
