@@ -1312,7 +1312,10 @@ __device__ __forceinline__ NanoMasks nano_check(double k_clo, double k_chi, doub
   // fwd2 | fwd1 = (ovl & lt_lo & lt_hi) | (~ovl & lt_lo),  bwd2 | bwd1 = (ovl & gt_lo & gt_hi) | (~ovl & ~lt_lo), written
   // with few scalar instructions (the loop keeps the scalar unit about half busy, the vector unit at 80-85 %)
   f.pos = lt_lo & (lt_hi | ~f.ovl);
-  f.neg = (f.ovl & gt_lo & gt_hi) | ~(f.ovl | lt_lo);
+  if (WF) // without an overlap exactly one of lt_lo / gt_lo holds (lo <= hi on both sides), so ~(ovl | lt_lo) = ~ovl & gt_lo
+    f.neg = gt_lo & (gt_hi | ~f.ovl);
+  else
+    f.neg = (f.ovl & gt_lo & gt_hi) | ~(f.ovl | lt_lo);
   // abort when the raw ranges overlap and their order contradicts the corrected orientation (:93-109)
   if (SORTED) {
     const M rovl = __ballot(l_rlo <= k_rhi);
@@ -2077,8 +2080,13 @@ __global__ __launch_bounds__(256) void k_chain_sub(ChainArgs a, const uint32_t *
     wf_lane = (x.clo1 <= x.chi1) & (x.clo2 <= x.chi2) & (x.rlo1 <= x.rhi1) & (sl == 0 || prev_rlo1 <= x.rlo1);
   }
   const bool wf = __ballot(!wf_lane) == 0;
-  auto sweep_step = [&](int p0, auto wft) __attribute__((always_inline)) {
-    typedef decltype(wft) WFT;
+  // DIR (see k_chain: the loop is bound by scalar issue): 0 = every EdgeMatch of every edge of the wavefront forward,
+  // 1 = all reverse, 3 = one direction per edge (the flip mask is a constant of the wavefront), 2 = an edge with both
+  // directions (pairs of one direction only, flip per pair)
+  auto sweep_step = [&](int p0, auto wft, auto dirt) __attribute__((always_inline)) {
+    typedef decltype(wft)  WFT;
+    typedef decltype(dirt) DIRT;
+    constexpr int          DIR = DIRT::value;
     const int      p  = p0 + sl;
     const uint32_t kl = kl_next;
     kl_next           = tab[min(p + W, Pm1)];
@@ -2086,24 +2094,37 @@ __global__ __launch_bounds__(256) void k_chain_sub(ChainArgs a, const uint32_t *
     unsigned long long bits;
     {
       typedef unsigned long long M;
-      M valid = __ballot(p < P), KD = KD_one;
-      if (!one_dir) {
+      // lanes past their edge's last pair evaluate that pair again and store nothing (the store tests p < P)
+      M valid = ~0ull, KD = KD_one;
+      if (DIR == 2) {
         const bool kd = (m_plus >> k) & 1u, ld = (m_plus >> l) & 1u;
-        valid &= __ballot(kd == ld);
-        KD = __ballot(kd);
+        valid = __ballot(kd == ld);
+        KD    = __ballot(kd);
       }
       const ChainElem K = el[gbase + k], L = el[gbase + l];
       double          d1, d2;
       const NanoMasks f1 = nano_check<WFT::value, WFT::value>(K.clo1, K.chi1, L.clo1, L.chi1, K.rlo1, K.rhi1, L.rlo1, L.rhi1, d1);
       const NanoMasks f2 = nano_check<WFT::value, false>(K.clo2, K.chi2, L.clo2, L.chi2, K.rlo2, K.rhi2, L.rlo2, L.rhi2, d2);
-      const M p2 = (KD & f2.pos) | (~KD & f2.neg), n2m = (KD & f2.neg) | (~KD & f2.pos);
-      const M codir   = (f1.pos & p2) | (f1.neg & n2m);
-      const M same    = codir & ~(f1.ovl ^ f2.ovl);
-      const M live    = valid & ~(f1.abort_ | f2.abort_);
+      M p2, n2m; // :131 flip by EdgeMatch(k).direction
+      if (DIR == 0) {
+        p2  = f2.pos;
+        n2m = f2.neg;
+      } else if (DIR == 1) {
+        p2  = f2.neg;
+        n2m = f2.pos;
+      } else {
+        const M fl = KD & (f2.pos ^ f2.neg); // where the direction is forward, the two swap
+        p2         = f2.neg ^ fl;
+        n2m        = f2.pos ^ fl;
+      }
+      const M codir = (f1.pos & p2) | (f1.neg & n2m);
+      const M mixed = f1.ovl ^ f2.ovl;
+      M       cl    = codir & ~(f1.abort_ | f2.abort_);
+      if (DIR == 2) cl &= valid;
       const double df = fabs(d1 - d2); // = std::max - std::min, see k_chain
       const M near_ = __ballot(df <= wiggle), sum_ok = __ballot(d1 + d2 <= wiggle);
-      M       ok    = ((same & near_) | (codir & ~same & sum_ok)) & live;
-      const M need_div = same & ~near_ & live;
+      M       ok    = cl & ((near_ & ~mixed) | (sum_ok & mixed));
+      const M need_div = cl & ~(mixed | near_);
       if (need_div) {
         bool pass = false;
         if (__builtin_amdgcn_inverse_ballot_w64(need_div)) pass = df * 100 / fmax(d1, d2) <= a.ratio_pct;
@@ -2115,10 +2136,17 @@ __global__ __launch_bounds__(256) void k_chain_sub(ChainArgs a, const uint32_t *
     const uint32_t gb = group_bits<W>(bits, gbase);
     if (run && p < P) cm[gbase + l] |= __builtin_amdgcn_ubfe(gb, static_cast<uint32_t>(sl), static_cast<uint32_t>(run)) << k; // run <= 31
   };
-  if (wf)
-    for (int p0 = 0; p0 < Pmax; p0 += W) sweep_step(p0, std::true_type{});
-  else
-    for (int p0 = 0; p0 < Pmax; p0 += W) sweep_step(p0, std::false_type{});
+  auto sweep = [&](auto wft, auto dirt) __attribute__((always_inline)) {
+    for (int p0 = 0; p0 < Pmax; p0 += W) sweep_step(p0, wft, dirt);
+  };
+  auto sweep_dir = [&](auto wft) __attribute__((always_inline)) {
+    if (!one_dir) sweep(wft, std::integral_constant<int, 2>{});
+    else if (KD_one == ~0ull) sweep(wft, std::integral_constant<int, 0>{});
+    else if (KD_one == 0) sweep(wft, std::integral_constant<int, 1>{});
+    else sweep(wft, std::integral_constant<int, 3>{});
+  };
+  if (wf) sweep_dir(std::true_type{});
+  else sweep_dir(std::false_type{});
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   // bit k: checkCompatibility(k, sl) for k < sl; a clean edge has them all (and then the DP below adds the scores up
