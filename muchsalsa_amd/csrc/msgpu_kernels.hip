@@ -1575,8 +1575,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
   // (0, 1, 0) beyond the last pair and every (k, l) in it is < 64, so lanes past P read without a clamp or a branch and
   // are masked out.
   static_assert(sizeof(ChainElem) == 48, "the pair table holds byte offsets of 48-byte elements");
-  const uint2 *tab     = a.pair_tab64; // + p0 below: a scalar base, the lane's offset never changes
-  uint2        kl_next = tab[lane];
+  // the pair table through a buffer descriptor: scalar offset (the step) + constant lane offset, no vector address
+  // arithmetic in the loop
+  const __amdgpu_buffer_rsrc_t tab_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<uint2 *>(a.pair_tab64), 0, PAIR_TAB_STRIDE * 8, 0x00020000);
+  const uint32_t tab_lane = static_cast<uint32_t>(lane) * 8u;
+  auto           load_pairs = [&](int p0) __attribute__((always_inline)) -> uint2 {
+    typedef int v2i __attribute__((ext_vector_type(2)));
+    const v2i   v = __builtin_amdgcn_raw_buffer_load_b64(tab_rsrc, tab_lane, p0 * 8, 0);
+    return make_uint2(static_cast<uint32_t>(v.x), static_cast<uint32_t>(v.y));
+  };
   // The scalar registers of this loop are all taken by pair masks; a loop-invariant scalar operand would be spilled and
   // re-read (v_readlane) in every step.  The one constant the common path compares with lives in a vector register.
   double wiggle = a.wiggle;
@@ -1591,13 +1599,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
   // DIR: 0 = every EdgeMatch forward, 1 = every EdgeMatch reverse (the flip of mpp.cpp:131 is then the same for all
   // pairs and costs nothing), 2 = both directions present (pairs of one direction only, flip per pair).  The loop is
   // bound by SCALAR issue (the mask algebra), so everything wave-uniform is decided outside it: six instances.
-  auto sweep_step = [&](int p0, auto wft, auto dirt) __attribute__((always_inline)) {
+  auto sweep_step = [&](const uint2 kl, auto wft, auto dirt) __attribute__((always_inline)) {
     typedef decltype(wft)  WFT;
     typedef decltype(dirt) DIRT;
     constexpr int          DIR = DIRT::value;
     unsigned long long     bits = 0; // checkCompatibility(k, l) of the 64 pairs of this step
-    const uint2 kl = kl_next;
-    kl_next        = (tab + p0 + 64)[lane]; // the next step's pairs are on their way while this one computes
     { // every lane evaluates a pair: no divergence, all masks are wave-uniform
       typedef unsigned long long M;
       // lanes past the last pair evaluate the padding pair (0, 1) and have run = 0: their bits are never stored, so
@@ -1652,7 +1658,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     }
   };
   auto sweep = [&](auto wft, auto dirt) __attribute__((always_inline)) {
-    for (int p0 = 0; p0 < P; p0 += 64) sweep_step(p0, wft, dirt);
+    // two steps per trip, each with its own registers for the table entries: the next step's pairs are on their way
+    // while this one computes, and nothing is copied from "next" to "current"
+    uint2 ka = load_pairs(0);
+    for (int p0 = 0; p0 < P; p0 += 128) {
+      const uint2 kb = load_pairs(p0 + 64);
+      sweep_step(ka, wft, dirt);
+      if (p0 + 64 >= P) break;
+      ka = load_pairs(p0 + 128);
+      sweep_step(kb, wft, dirt);
+    }
   };
   auto sweep_dir = [&](auto wft) __attribute__((always_inline)) {
     if (m_minus == 0) sweep(wft, std::integral_constant<int, 0>{});
