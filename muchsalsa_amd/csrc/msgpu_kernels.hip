@@ -597,14 +597,23 @@ __global__ __launch_bounds__(256) void k_sort_read(const uint32_t *read_off, con
     note_first_row(lane, have ? (static_cast<unsigned long long>(row.line) << 32) | idx : ~0ull, r, rows, read_len, read_first);
     const int      mlo = have ? row.n_lo : 0x7fffffff, mhi = have ? row.n_hi : 0x7fffffff;
     const uint32_t man = have ? row.other : 0xffffffffu;
-    uint32_t       less = 0;
-    bool           dup  = false;
+    // rank = rows with a smaller (n_lo, n_hi, anchor).  Branch-free, every predicate a wavefront mask: (n_lo, n_hi) as
+    // one order-preserving 64-bit key (one compare for "less", one for "equal"), the anchor decides ties, the count goes
+    // up through the carry; "same anchor on another row" collects in a scalar mask.
+    const uint32_t klo = static_cast<uint32_t>(mhi) ^ 0x80000000u, khi = static_cast<uint32_t>(mlo) ^ 0x80000000u;
+    const uint64_t mkey = (static_cast<uint64_t>(khi) << 32) | klo;
+    uint32_t           less = 0;
+    unsigned long long dupm = 0;
     for (int t = 0; t < static_cast<int>(n); ++t) {
-      const int      olo = rl_i32(mlo, t), ohi = rl_i32(mhi, t);
-      const uint32_t oan = rl_u32(man, t);
-      less += key_less(olo, ohi, oan, mlo, mhi, man) ? 1u : 0u;
-      dup |= (t != lane) & (oan == man);
+      const uint64_t okey = (static_cast<uint64_t>(rl_u32(khi, t)) << 32) | rl_u32(klo, t);
+      const uint32_t oan  = rl_u32(man, t);
+      const unsigned long long lt = __ballot(okey < mkey), eq = __ballot(okey == mkey);
+      const unsigned long long al = __ballot(oan < man), ae = __ballot(oan == man);
+      // less += 1 in the lanes of the mask: the mask goes in as the carry of an add-with-carry (one instruction)
+      asm("v_addc_co_u32 %0, vcc, 0, %0, %1" : "+v"(less) : "s"(lt | (eq & al)) : "vcc");
+      dupm |= ae & ~(1ull << t);
     }
+    const bool dup = (dupm >> lane) & 1ull;
     bool     alive  = have;
     uint32_t behind = 0; // scaffold rows behind this row = its visits in the candidate scan (fast mode)
     if (__ballot(dup && have)) { // rare: a (read, anchor) pair occurs more than once -- lowest line wins
