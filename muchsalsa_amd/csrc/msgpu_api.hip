@@ -636,11 +636,12 @@ int msgpu_chaining_and_overlaps(msgpu_ctx *c) {
   a.edge_nids    = c->edge_nids.as<uint32_t>();
   a.err          = scalar<uint32_t>(c, SC_ERR);
   if (!c->pair_tab.p) {
-    ENSURE(c, pair_tab, 4 * PAIR_TAB_STRIDE * sizeof(uint32_t) + PAIR_TAB_STRIDE * sizeof(uint2));
+    ENSURE(c, pair_tab, 4 * PAIR_TAB_STRIDE * sizeof(uint32_t) + PAIR_TAB_STRIDE * sizeof(uint2) + 3 * PAIR_TAB_STRIDE * 8);
     launch_fill_pair_tab(st, c->pair_tab.as<uint32_t>());
   }
   a.pair_tab     = c->pair_tab.as<uint32_t>();
   a.pair_tab64   = reinterpret_cast<const uint2 *>(c->pair_tab.as<uint32_t>() + 4 * PAIR_TAB_STRIDE);
+  a.pair_tab_sub = c->pair_tab.as<uint32_t>() + 4 * PAIR_TAB_STRIDE + 2 * PAIR_TAB_STRIDE;
   ENSURE(c, edge_fast, (E + 1) * 4);
   {
     uint32_t *const zero[4]   = {c->edge_norders.as<uint32_t>(), c->edge_nids.as<uint32_t>(), c->edge_fast.as<uint32_t>(),

@@ -2090,11 +2090,21 @@ __global__ __launch_bounds__(256) void k_chain_sub(ChainArgs a, const uint32_t *
   Pmax = __builtin_amdgcn_readfirstlane(Pmax);
   const bool               one_dir = __ballot(m_plus != 0 && m_minus != 0) == 0; // every edge of the wave has one direction
   const unsigned long long KD_one  = __ballot(m_minus == 0);
-  // the table of this width (k | l << 8 | run << 16, run for W-wide steps); lanes past P read their edge's last pair (or
-  // pair 0 = (0, 1)), which keeps (k, l) inside the group
-  const uint32_t *tab     = a.pair_tab + (W == 32 ? 1 : W == 16 ? 2 : 3) * PAIR_TAB_STRIDE;
-  const int       Pm1     = max(P - 1, 0);
-  uint32_t        kl_next = tab[min(sl, Pm1)];
+  // the table of this width through a buffer descriptor (scalar step offset + constant lane offset).  Lanes past their
+  // edge's last pair read on into pairs the edge does not have: k < l < W keeps them inside the group's elements, and
+  // they store nothing (the store tests the pair number)
+  static_assert(sizeof(ChainElem) == 48, "the pair table holds byte offsets of 48-byte elements");
+  const __amdgpu_buffer_rsrc_t tab_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<uint32_t *>(a.pair_tab_sub) + (W == 32 ? 0 : W == 16 ? 1 : 2) * PAIR_TAB_STRIDE * 2, 0, PAIR_TAB_STRIDE * 8, 0x00020000);
+  const uint32_t tab_lane = static_cast<uint32_t>(sl) * 8u;
+  auto           load_pairs = [&](int p0) __attribute__((always_inline)) -> uint2 {
+    typedef int v2i __attribute__((ext_vector_type(2)));
+    const v2i   v = __builtin_amdgcn_raw_buffer_load_b64(tab_rsrc, tab_lane, p0 * 8, 0);
+    return make_uint2(static_cast<uint32_t>(v.x), static_cast<uint32_t>(v.y));
+  };
+  const int            Pl  = P - sl; // pair p0 + sl exists iff p0 < Pl
+  const unsigned char *elg = reinterpret_cast<const unsigned char *>(el + gbase);
+  unsigned char       *cmg = reinterpret_cast<unsigned char *>(cm + gbase);
   double          wiggle  = a.wiggle; // in a vector register: see k_chain
   asm volatile("" : "+v"(wiggle));
   // every element of every group well formed (see nano_check) and v1's raw ranges in list order: the lean pair test
@@ -2107,25 +2117,25 @@ __global__ __launch_bounds__(256) void k_chain_sub(ChainArgs a, const uint32_t *
   // DIR (see k_chain: the loop is bound by scalar issue): 0 = every EdgeMatch of every edge of the wavefront forward,
   // 1 = all reverse, 3 = one direction per edge (the flip mask is a constant of the wavefront), 2 = an edge with both
   // directions (pairs of one direction only, flip per pair)
-  auto sweep_step = [&](int p0, auto wft, auto dirt) __attribute__((always_inline)) {
+  auto sweep_step = [&](int p0, const uint2 kl, auto wft, auto dirt) __attribute__((always_inline)) {
     typedef decltype(wft)  WFT;
     typedef decltype(dirt) DIRT;
     constexpr int          DIR = DIRT::value;
-    const int      p  = p0 + sl;
-    const uint32_t kl = kl_next;
-    kl_next           = tab[min(p + W, Pm1)];
-    const int k = static_cast<int>(kl & 0xffu), l = static_cast<int>((kl >> 8) & 0xffu), run = static_cast<int>((kl >> 16) & 0xffu);
-    unsigned long long bits;
+    unsigned long long     bits;
+    const bool             in_range = p0 < Pl; // this lane's pair exists
     {
       typedef unsigned long long M;
-      // lanes past their edge's last pair evaluate that pair again and store nothing (the store tests p < P)
-      M valid = ~0ull, KD = KD_one;
+      // lanes past their edge's last pair evaluate pairs the edge does not have (elements nobody wrote): they store
+      // nothing, and they are masked out so that they never send the wavefront into the division
+      M valid = __ballot(in_range), KD = KD_one;
       if (DIR == 2) {
+        const int  k = static_cast<int>(kl.y & 0xffu), l = static_cast<int>(kl.y >> 18);
         const bool kd = (m_plus >> k) & 1u, ld = (m_plus >> l) & 1u;
-        valid = __ballot(kd == ld);
+        valid &= __ballot(kd == ld);
         KD    = __ballot(kd);
       }
-      const ChainElem K = el[gbase + k], L = el[gbase + l];
+      const ChainElem K = *reinterpret_cast<const ChainElem *>(elg + (kl.x & 0xffffu));
+      const ChainElem L = *reinterpret_cast<const ChainElem *>(elg + (kl.x >> 16));
       double          d1, d2;
       const NanoMasks f1 = nano_check<WFT::value, WFT::value>(K.clo1, K.chi1, L.clo1, L.chi1, K.rlo1, K.rhi1, L.rlo1, L.rhi1, d1);
       const NanoMasks f2 = nano_check<WFT::value, false>(K.clo2, K.chi2, L.clo2, L.chi2, K.rlo2, K.rhi2, L.rlo2, L.rhi2, d2);
@@ -2144,7 +2154,7 @@ __global__ __launch_bounds__(256) void k_chain_sub(ChainArgs a, const uint32_t *
       const M codir = (f1.pos & p2) | (f1.neg & n2m);
       const M mixed = f1.ovl ^ f2.ovl;
       M       cl    = codir & ~(f1.abort_ | f2.abort_);
-      if (DIR == 2) cl &= valid;
+      cl &= valid;
       const double df = fabs(d1 - d2); // = std::max - std::min, see k_chain
       const M near_ = __ballot(df <= wiggle), sum_ok = __ballot(d1 + d2 <= wiggle);
       M       ok    = cl & ((near_ & ~mixed) | (sum_ok & mixed));
@@ -2156,12 +2166,24 @@ __global__ __launch_bounds__(256) void k_chain_sub(ChainArgs a, const uint32_t *
       }
       bits = ok;
     }
-    // the pairs of row l are consecutive lanes of the group; the first lane of each run stores the run's bits
-    const uint32_t gb = group_bits<W>(bits, gbase);
-    if (run && p < P) cm[gbase + l] |= __builtin_amdgcn_ubfe(gb, static_cast<uint32_t>(sl), static_cast<uint32_t>(run)) << k; // run <= 31
+    // the pairs of row l are consecutive lanes of the group; the first lane of each run stores the run's bits: `run`
+    // bits from bit `lane` on, put at bit k (run <= 31; the shift count k is the low five bits of its table word)
+    const uint32_t run = (kl.y >> 8) & 0xffu;
+    if (run != 0 && in_range) {
+      uint32_t *row = reinterpret_cast<uint32_t *>(cmg + (kl.y >> 16));
+      *row |= __builtin_amdgcn_ubfe(static_cast<uint32_t>(bits >> lane), 0u, run) << (kl.y & 31u);
+    }
   };
   auto sweep = [&](auto wft, auto dirt) __attribute__((always_inline)) {
-    for (int p0 = 0; p0 < Pmax; p0 += W) sweep_step(p0, wft, dirt);
+    // two steps per trip, each with its own registers for the table entries (see k_chain)
+    uint2 ka = load_pairs(0);
+    for (int p0 = 0; p0 < Pmax; p0 += 2 * W) {
+      const uint2 kb = load_pairs(p0 + W);
+      sweep_step(p0, ka, wft, dirt);
+      if (p0 + W >= Pmax) break;
+      ka = load_pairs(p0 + 2 * W);
+      sweep_step(p0 + W, kb, wft, dirt);
+    }
   };
   auto sweep_dir = [&](auto wft) __attribute__((always_inline)) {
     if (!one_dir) sweep(wft, std::integral_constant<int, 2>{});
@@ -2786,6 +2808,15 @@ __device__ __forceinline__ void tab64_entry(uint32_t *tab, int p, int k, int l, 
                           (static_cast<uint32_t>(64 - run) & 63u) | (static_cast<uint32_t>((64 - run - k) & 63) << 8) |
                               (static_cast<uint32_t>(l * 8 + (run ? 0x8000 : 0)) << 16));
 }
+// The tables of the sub-wavefront kernels (W = 32, 16, 8) once more, 8 bytes per pair, in the form their sweep consumes:
+//   x = byte offset of element k in the group's elements | byte offset of element l << 16
+//   y = k | run << 8 | byte offset of row l in the group's compatibility rows << 16   (k: low five bits = shift count;
+//       run = 0: this lane stores nothing)
+__device__ __forceinline__ void tabsub_entry(uint32_t *tab, int t, int p, int k, int l, int run) {
+  uint32_t *e = tab + 4 * PAIR_TAB_STRIDE + 2 * PAIR_TAB_STRIDE + (static_cast<size_t>(t - 1) * PAIR_TAB_STRIDE + p) * 2;
+  e[0]        = static_cast<uint32_t>(k * 48) | (static_cast<uint32_t>(l * 48) << 16);
+  e[1]        = static_cast<uint32_t>(k) | (static_cast<uint32_t>(run) << 8) | (static_cast<uint32_t>(l * 4) << 16);
+}
 __global__ __launch_bounds__(256) void k_fill_pair_tab(uint32_t *tab) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= 4 * static_cast<int>(PAIR_TAB_STRIDE)) return;
@@ -2793,6 +2824,7 @@ __global__ __launch_bounds__(256) void k_fill_pair_tab(uint32_t *tab) {
   if (p >= 2016) {
     tab[i] = 1u << 8;
     if (t == 0) tab64_entry(tab, p, 0, 1, 0);
+    else tabsub_entry(tab, t, p, 0, 1, 0);
     return;
   }
   int l = static_cast<int>((1.0f + __fsqrt_rn(1.0f + 8.0f * static_cast<float>(p))) * 0.5f);
@@ -2802,6 +2834,7 @@ __global__ __launch_bounds__(256) void k_fill_pair_tab(uint32_t *tab) {
   const int run = (k == 0 || lane == 0) ? min(l - k, W - lane) : 0;
   tab[i] = static_cast<uint32_t>(k | (l << 8) | (run << 16)) | (static_cast<uint32_t>(64 - run - k) << 24);
   if (t == 0) tab64_entry(tab, p, k, l, run);
+  else tabsub_entry(tab, t, p, k, l, run);
 }
 
 // dense, canonical order + id tables
