@@ -1956,7 +1956,7 @@ __device__ __forceinline__ uint32_t paths_of_direction_sub(uint32_t act, bool di
 }
 
 template <int W>
-__global__ __launch_bounds__(256) void k_chain_sub(ChainArgs a, const uint32_t *list, uint32_t n_list) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W == 32 ? 7 : 6, W == 32 ? 7 : 6))) void k_chain_sub(ChainArgs a, const uint32_t *list, uint32_t n_list) {
   constexpr int G = 64 / W;
   static_assert(W == 8 || W == 16 || W == 32, "group width");
   static_assert(sizeof(ChainElem) * 64 >= sizeof(SubPath) * 2 * 64, "the path lists overlay the element table");
