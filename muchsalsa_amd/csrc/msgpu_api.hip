@@ -206,7 +206,7 @@ int build_index_once(msgpu_ctx *c, bool force_generic, bool two_pass, uint32_t *
   ENSURE(c, bkt2_line, nz * 4);
   ENSURE(c, by_anchor, nz * sizeof(IRow));
   ENSURE(c, vis16, nz * 16);
-  ENSURE(c, spos2, nz * 8);
+  ENSURE(c, spos2, (cap ? size_t(V) * cap : nz) * 8); // one-pass build: by bucket slot, else by source row
   ENSURE(c, visits, (size_t(V) + 1) * 4);
   ENSURE(c, read_len, (size_t(V) + 1) * 4);
   ENSURE(c, read_first, (size_t(V) + 1) * 4);

@@ -385,9 +385,7 @@ __global__ __launch_bounds__(256) void k_index_pass1(const msgpu_row *rows, uint
     atomicOr(err, 2u);
     return;
   }
-#ifdef MSGPU_X_NOSPOS
-  spos[i] = make_uint2(static_cast<uint32_t>(i), 0);
-#else
+  uint2 sp; // place in the scaffold, scaffold rows behind it
   {
     const int c = static_cast<int>(threadIdx.x) + SCAF_HALO;
     uint32_t  before = 0, lower = 0;
@@ -405,16 +403,21 @@ __global__ __launch_bounds__(256) void k_index_pass1(const msgpu_row *rows, uint
     big |= d > SCAF_HALO;
     if (big) atomicOr(flags, IXF_BIGSCAF);
     // place in the scaffold, and the number of scaffold rows behind it (= partners with a higher read id)
-    spos[i] = make_uint2(static_cast<uint32_t>(i) - before + lower, before + after - lower);
+    sp = make_uint2(static_cast<uint32_t>(i) - before + lower, before + after - lower);
   }
-#endif
   if (cap) {
+    // one-pass build: the pair travels with the row, at the row's bucket slot -- the sort reads it next to the row
+    // (a contiguous read per bucket) instead of gathering 8 bytes per row by source index
     const uint32_t pos = atomicAdd(&cnt_read[rd], 1u);
-    if (pos < cap)
-      store_irow(&bkt_row[static_cast<uint64_t>(rd) * cap + pos], make_irow(row, an, static_cast<uint32_t>(i)));
-    else
+    if (pos < cap) {
+      const uint64_t slot = static_cast<uint64_t>(rd) * cap + pos;
+      store_irow(&bkt_row[slot], make_irow(row, an, static_cast<uint32_t>(i)));
+      spos[slot] = sp;
+    } else {
       atomicOr(flags, IXF_OVERFLOW);
+    }
   } else {
+    spos[i] = sp; // two-pass build: by source row
     atomicAdd(&cnt_read[rd], 1u);
   }
   if (i == 0) {
@@ -487,7 +490,7 @@ __device__ __forceinline__ bool sort_read_in_registers(uint32_t r, uint64_t bs, 
                                                        uint32_t *read_cnt, uint32_t *alive_rank, uint32_t *anchor_cnt,
                                                        IRow *by_anchor, const msgpu_row *rows, int32_t *read_len,
                                                        uint32_t *read_first, const uint2 *spos, uint4 *vis,
-                                                       uint32_t *visits) {
+                                                       uint32_t *visits, bool by_slot) {
   IRow     row[K];
   uint32_t idx[K], man[K], less[K];
   int      mlo[K], mhi[K];
@@ -534,7 +537,7 @@ __device__ __forceinline__ bool sort_read_in_registers(uint32_t r, uint64_t bs, 
       row[k].pf = (row[k].pf & ~PF_POS_MASK) | less[k];
       if (fast) {
         IRow           w  = row[k];
-        const uint2    sc = spos[idx[k]];
+        const uint2    sc = spos[by_slot ? bs + static_cast<uint32_t>(k) * 64 + lane : idx[k]];
         const uint32_t sp = sc.x;
         w.other           = r;
         store_irow(&by_anchor[sp], w);
@@ -638,7 +641,7 @@ __global__ __launch_bounds__(256) void k_sort_read(const uint32_t *read_off, con
         // pass 1 worked out for it (scaffolds in read-id order).  A duplicate (read, anchor) pair found anywhere voids
         // the fast table: the host rebuilds generically.
         IRow           w  = row;
-        const uint2    sc = spos[idx];
+        const uint2    sc = spos[cap ? bs + lane : idx];
         const uint32_t sp = sc.x;
         w.other           = r;
         store_irow(&by_anchor[sp], w);
@@ -666,11 +669,11 @@ __global__ __launch_bounds__(256) void k_sort_read(const uint32_t *read_off, con
   }
   if (n <= 128) {
     if (sort_read_in_registers<2>(r, bs, b, n, lane, fast, bkt_row, by_read, read_cnt, alive_rank, anchor_cnt,
-                                  by_anchor, rows, read_len, read_first, spos, vis, visits))
+                                  by_anchor, rows, read_len, read_first, spos, vis, visits, cap != 0))
       return;
   } else if (n <= 256) {
     if (sort_read_in_registers<4>(r, bs, b, n, lane, fast, bkt_row, by_read, read_cnt, alive_rank, anchor_cnt,
-                                  by_anchor, rows, read_len, read_first, spos, vis, visits))
+                                  by_anchor, rows, read_len, read_first, spos, vis, visits, cap != 0))
       return;
   }
   // very long read, or one with a duplicated (read, anchor) pair: the bucket stays in global memory
@@ -708,7 +711,7 @@ __global__ __launch_bounds__(256) void k_sort_read(const uint32_t *read_off, con
       k.pf = (k.pf & ~PF_POS_MASK) | less;
       if (fast) {
         IRow           w  = k;
-        const uint2    sc = spos[kix];
+        const uint2    sc = spos[cap ? bs + e : kix];
         const uint32_t sp = sc.x;
         w.other           = r;
         store_irow(&by_anchor[sp], w);
