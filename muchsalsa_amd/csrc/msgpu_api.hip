@@ -70,7 +70,9 @@ struct msgpu_ctx {
   uint32_t     shard = 0, nshards = 1;
   uint32_t     win_lo = 0, win_hi = 0xffffffffu; // owner-read window of the current batch (msgpu_overlap_batched)
   uint64_t     base_edges = 0, base_ems = 0, base_orders = 0, base_ids = 0; // what precedes it in the job's tables
-  uint64_t    *h_scalars = nullptr; // pinned mirror of `scalars`: every read-back is ONE copy of the whole block
+  uint64_t    *h_scalars = nullptr; // pinned, device-mapped mirror of `scalars` (+ one word: the read-back sequence number)
+  uint64_t    *h_scalars_dev = nullptr; // the same memory as the device sees it
+  uint64_t     readback_seq = 0;
   uint32_t     decl_V = 0, decl_A = 0; // msgpu_set_id_space: id counts declared by the caller (0 = find them)
 
   // loaded rows
@@ -144,9 +146,32 @@ template <class T> T *scalar(msgpu_ctx *c, int slot) { return reinterpret_cast<T
 template <class T> const T *host_scalar(const msgpu_ctx *c, int slot) { return reinterpret_cast<const T *>(c->h_scalars + slot); }
 // One copy of the whole scalar block into pinned memory + a stream synchronisation.  (Separate 4-byte copies into
 // pageable host variables cost ~20 us each on this stack; there were up to three per read-back.)
+// Default: no copy and no stream synchronisation -- a one-wavefront kernel writes the block into the (mapped) pinned
+// mirror and publishes a sequence number; the host polls for it (about half the latency of copy + synchronise, and
+// the host is back on the stream sooner).  A stream that stops making progress (a failed launch) is noticed by
+// hipStreamQuery and handled by the synchronising path, which is also what MSGPU_SYNC_READBACK=1 selects.
 int read_scalars(msgpu_ctx *c, hipEvent_t mark = nullptr) {
+  static const bool sync_path = getenv("MSGPU_SYNC_READBACK") != nullptr;
+  if (!sync_path && c->h_scalars_dev) {
+    const uint64_t seq = ++c->readback_seq;
+    launch_publish_scalars(c->stream, c->scalars.as<uint64_t>(), c->h_scalars_dev, SC_COUNT, seq);
+    if (mark) HIPCHK(c, hipEventRecord(mark, c->stream));
+    volatile uint64_t *flag = c->h_scalars + SC_COUNT;
+    for (uint64_t spins = 1;; ++spins) {
+      if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) return MSGPU_OK;
+      __builtin_ia32_pause();
+      if ((spins & 0xffff) == 0) { // every ~1 ms: is the stream still alive?
+        const hipError_t q = hipStreamQuery(c->stream);
+        if (q == hipSuccess) { // everything ran: the flag is there, or something is badly wrong
+          if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) return MSGPU_OK;
+          break;
+        }
+        if (q != hipErrorNotReady) break;
+      }
+    }
+  }
   HIPCHK(c, hipMemcpyAsync(c->h_scalars, c->scalars.p, SC_COUNT * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
-  if (mark) HIPCHK(c, hipEventRecord(mark, c->stream));
+  if (mark && (sync_path || !c->h_scalars_dev)) HIPCHK(c, hipEventRecord(mark, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return MSGPU_OK;
 }
@@ -356,11 +381,14 @@ int msgpu_create(int device, const msgpu_params *params, msgpu_ctx **out) {
     return MSGPU_E_HIP;
   }
   c->stream = c->own_stream;
-  if (hipHostMalloc(reinterpret_cast<void **>(&c->h_scalars), SC_COUNT * sizeof(uint64_t), hipHostMallocDefault) != hipSuccess) {
+  if (hipHostMalloc(reinterpret_cast<void **>(&c->h_scalars), (SC_COUNT + 1) * sizeof(uint64_t),
+                    hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {
     c->h_scalars = nullptr;
     msgpu_destroy(c);
     return MSGPU_E_NOMEM;
   }
+  memset(c->h_scalars, 0, (SC_COUNT + 1) * sizeof(uint64_t));
+  if (hipHostGetDevicePointer(reinterpret_cast<void **>(&c->h_scalars_dev), c->h_scalars, 0) != hipSuccess) c->h_scalars_dev = nullptr;
   {
     const char *nf = getenv("MSGPU_NO_FASTPATH"); // test hook: force the full pair sweep on every edge
     c->fast_path   = !(nf && nf[0] == '1');

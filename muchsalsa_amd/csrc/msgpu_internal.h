@@ -106,6 +106,7 @@ constexpr uint32_t IXF_DUPS     = 4u; // a (read, anchor) pair occurs more than 
 constexpr uint32_t IXF_FORCE    = 8u; // host asked for the generic path
 constexpr uint32_t IXF_OVERFLOW = 16u; // one-pass build: a read has more rows than a bucket holds (host rebuilds in two passes)
 constexpr uint32_t IXF_BIGSCAF  = 32u; // a scaffold longer than the context pass 1 sorts it in
+void launch_publish_scalars(hipStream_t st, const uint64_t *src, uint64_t *dst_host, uint32_t n, uint64_t seq);
 void launch_index_init(hipStream_t st, uint32_t *const zero[4], const uint32_t n_zero[4], uint32_t *const ones[2],
                        const uint32_t n_ones[2]);
 void launch_index_pass1(hipStream_t st, const msgpu_row *rows, uint64_t n, uint32_t *cnt_read, uint32_t *anchor_first,

@@ -296,6 +296,20 @@ void exclusive_scan_set(hipStream_t st, int k, const uint32_t *const *in, uint64
   hipLaunchKernelGGL(k_scan_apply_set, dim3(nb, k), dim3(256), 0, st, s, n);
 }
 
+// read-back without a copy engine and without a stream synchronisation: one wavefront writes the scalar block into
+// mapped host memory, makes it visible system-wide and then publishes a sequence number the host is polling for
+__global__ __launch_bounds__(64) void k_publish_scalars(const uint64_t *src, uint64_t *dst_host, uint32_t n, uint64_t seq) {
+  if (threadIdx.x < n) dst_host[threadIdx.x] = src[threadIdx.x];
+  __threadfence_system();
+  __builtin_amdgcn_s_barrier();
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(&dst_host[n], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+void launch_publish_scalars(hipStream_t st, const uint64_t *src, uint64_t *dst_host, uint32_t n, uint64_t seq) {
+  hipLaunchKernelGGL(k_publish_scalars, dim3(1), dim3(64), 0, st, src, dst_host, n, seq);
+}
+
 uint32_t scan_blocks(uint64_t n) { return static_cast<uint32_t>((n + 256 * SCAN_ITEMS - 1) / (256 * SCAN_ITEMS)); }
 
 // ---------------------------------------------------------------------------------------------------------------------
