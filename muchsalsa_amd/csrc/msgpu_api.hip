@@ -569,7 +569,9 @@ int msgpu_calculate_edges(msgpu_ctx *c) {
   a.n_visit        = c->n_visit_arr.as<uint32_t>();
   a.th_overlap     = c->p.th_overlap;
   a.big_stats      = scalar<unsigned long long>(c, SC_BIGSTATS);
-  HIPCHK(c, hipMemsetAsync(a.big_stats, 0, 16, st));
+  // big-edge statistics, the big-edge list cursor and the width-class counts: slots SC_BIGSTATS .. SC_CLS, one memset
+  static_assert(SC_BIGCUR == SC_BIGSTATS + 2 && SC_CLS == SC_BIGCUR + 2 && SC_COUNT == SC_CLS + 2, "adjacent scalar slots");
+  HIPCHK(c, hipMemsetAsync(a.big_stats, 0, 48, st));
   // the LDS classes run side by side: the heavier, smaller classes on the side stream, so their tails overlap
   static const bool no_fork = getenv("MSGPU_NO_FORK") != nullptr; // measurement switch: the classes one after the other
   const bool fork = (c->n_list[1] || c->n_list[2]) && c->n_list[0] && !no_fork;
@@ -593,6 +595,9 @@ int msgpu_calculate_edges(msgpu_ctx *c) {
     launch_candidates_big(st, a, l3, c->n_list[3], c->big_key.as<uint64_t>(), c->big_t.as<uint32_t>(),
                           c->big_r2s.as<uint32_t>(), c->big_pfx.as<uint32_t>());
   }
+  // edges per width class of the chain kernels: they come back with the table sizes below
+  launch_count_classes(st, c->n_edge.as<uint32_t>(), c->n_cand.as<uint32_t>(), c->cand_off.as<uint64_t>(),
+                       c->scr_start.as<uint32_t>(), V, scalar<uint32_t>(c, SC_CLS));
   {
     const uint32_t *const in[2]  = {c->n_cand.as<uint32_t>(), c->n_edge.as<uint32_t>()};
     uint64_t *const       out[2] = {c->em_base.as<uint64_t>(), c->edge_base.as<uint64_t>()};
@@ -604,6 +609,7 @@ int msgpu_calculate_edges(msgpu_ctx *c) {
   const uint64_t *tot = host_scalar<uint64_t>(c, SC_TOTAL_A), *big = host_scalar<uint64_t>(c, SC_BIGSTATS);
   c->n_big_edges = big[0];
   c->n_big_ems   = big[1];
+  for (int k = 0; k < 4; ++k) c->n_cls[k] = host_scalar<uint32_t>(c, SC_CLS)[k];
   c->n_ems   = tot[0];
   c->n_edges = tot[1];
   c->n_visit = c->total_bound; // the scaffold rows visited = the bound (scaffolds in read-id order: only owned partners)
@@ -614,7 +620,6 @@ int msgpu_calculate_edges(msgpu_ctx *c) {
   // the edges with more than 64 EdgeMatches (counted by the candidate kernels) are listed as they are emitted
   ENSURE(c, big_list, (c->n_big_edges + 1) * 4);
   ENSURE(c, big_off, (c->n_big_edges + 1) * 8);
-  HIPCHK(c, hipMemsetAsync(scalar<uint64_t>(c, SC_BIGCUR), 0, 16, st));
   launch_emit_edges(st, c->n_edge.as<uint32_t>(), c->n_cand.as<uint32_t>(), c->edge_base.as<uint64_t>(),
                     c->em_base.as<uint64_t>(), c->cand_off.as<uint64_t>(), c->scr_v2.as<uint32_t>(),
                     c->scr_start.as<uint32_t>(), V, c->edges.as<msgpu_edge>(), c->edge_cand.as<uint64_t>(),
@@ -700,12 +705,10 @@ int msgpu_chaining_and_overlaps(msgpu_ctx *c) {
   }
   if (c->sub_wave && E) {
     // width classes: <= 16 and 17..32 EdgeMatches share a wavefront four / two at a time, 33..64 take one each.  The
-    // class sizes have to come back before the launches (the big edges are already running on the side stream).
+    // class sizes are known since msgpu_calculate_edges (k_count_classes): no read-back between the sort and the launches.
     ENSURE(c, cls_list, (E + 1) * 4 + size_sort_part_bytes());
     uint32_t *list = c->cls_list.as<uint32_t>(), *part = list + E + 1;
     launch_sort_edges_by_size(st, a.edges, E, part, list, scalar<uint32_t>(c, SC_CLS));
-    if (int rc = read_scalars(c)) return rc;
-    for (int k = 0; k < 4; ++k) c->n_cls[k] = host_scalar<uint32_t>(c, SC_CLS)[k];
     const uint32_t *l64 = list, *l32 = l64 + c->n_cls[2], *l16 = l32 + c->n_cls[1], *l8 = l16 + c->n_cls[0]; // sizes descending
     HIPCHK(c, hipEventRecord(c->ev[5], st));
     launch_chain(st, a, l64, c->n_cls[2]); // the long ones first: the short classes fill the tail

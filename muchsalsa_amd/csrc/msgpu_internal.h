@@ -136,6 +136,8 @@ void launch_classify_reads(hipStream_t st, const uint32_t *read_off, const uint3
 void launch_candidates(hipStream_t st, const CandArgs &a, int cls, const CandDesc *list, uint32_t n_list);
 void launch_candidates_big(hipStream_t st, const CandArgs &a, const uint32_t *list, uint32_t n_list, uint64_t *big_key,
                            uint32_t *big_t, uint32_t *big_r2s, uint32_t *big_pfx);
+void launch_count_classes(hipStream_t st, const uint32_t *n_edge, const uint32_t *n_cand, const uint64_t *cand_off,
+                          const uint32_t *scr_start, uint32_t V, uint32_t *counts);
 void launch_emit_edges(hipStream_t st, const uint32_t *n_edge, const uint32_t *n_cand, const uint64_t *edge_base,
                        const uint64_t *em_base, const uint64_t *cand_off, const uint32_t *scr_v2,
                        const uint32_t *scr_start, uint32_t V, msgpu_edge *edges, uint64_t *edge_cand,

@@ -1274,6 +1274,47 @@ __global__ __launch_bounds__(256) void k_emit_edges(const uint32_t *n_edge, cons
   }
 }
 
+// Edges per width class of the chain kernels (<= 8, 9..16, 17..32, 33..64 EdgeMatches), counted from the candidate
+// scratch before the edges exist, so that the numbers come back with the table sizes and the chain stage needs no
+// read-back of its own.  counts[0..3] = 9..16, 17..32, 33..64, <= 8 (the order k_size_scan uses).
+__global__ __launch_bounds__(1024) void k_count_classes(const uint32_t *n_edge, const uint32_t *n_cand, const uint64_t *cand_off,
+                                                        const uint32_t *edge_scr_start, uint32_t V, uint32_t *counts) {
+  __shared__ uint32_t s_c[4];
+  if (threadIdx.x < 4) s_c[threadIdx.x] = 0;
+  __syncthreads();
+  uint32_t  c8 = 0, c16 = 0, c32 = 0, c64 = 0;
+  const int sub = threadIdx.x & 15; // 16 lanes per read, as in k_emit_edges
+  for (uint32_t r = (blockIdx.x * 1024 + threadIdx.x) >> 4; r < V; r += gridDim.x * 64) {
+    const uint32_t ne = n_edge[r];
+    if (ne == 0) continue;
+    const uint32_t nc = n_cand[r];
+    const uint64_t co = cand_off[r];
+    for (uint32_t e = sub; e < ne; e += 16) {
+      const uint32_t st = edge_scr_start[co + e], en = (e + 1 < ne) ? edge_scr_start[co + e + 1] : nc, cnt = en - st;
+      c8 += (cnt >= 1 && cnt <= 8) ? 1u : 0u;
+      c16 += (cnt > 8 && cnt <= 16) ? 1u : 0u;
+      c32 += (cnt > 16 && cnt <= 32) ? 1u : 0u;
+      c64 += (cnt > 32 && cnt <= 64) ? 1u : 0u;
+    }
+  }
+  c8  = wave_sum(c8);
+  c16 = wave_sum(c16);
+  c32 = wave_sum(c32);
+  c64 = wave_sum(c64);
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(&s_c[0], c16);
+    atomicAdd(&s_c[1], c32);
+    atomicAdd(&s_c[2], c64);
+    atomicAdd(&s_c[3], c8);
+  }
+  __syncthreads();
+  if (threadIdx.x < 4 && s_c[threadIdx.x]) atomicAdd(&counts[threadIdx.x], s_c[threadIdx.x]);
+}
+void launch_count_classes(hipStream_t st, const uint32_t *n_edge, const uint32_t *n_cand, const uint64_t *cand_off,
+                          const uint32_t *scr_start, uint32_t V, uint32_t *counts) {
+  if (V) hipLaunchKernelGGL(k_count_classes, dim3(256), dim3(1024), 0, st, n_edge, n_cand, cand_off, scr_start, V, counts);
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // chain: EdgeMatch + getMaxPairwisePaths + chainingAndOverlaps filters + getOverlap, one wavefront per edge
 // ---------------------------------------------------------------------------------------------------------------------
