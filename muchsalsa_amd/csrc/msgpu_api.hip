@@ -73,6 +73,8 @@ struct msgpu_ctx {
   uint64_t    *h_scalars = nullptr; // pinned, device-mapped mirror of `scalars` (+ one word: the read-back sequence number)
   uint64_t    *h_scalars_dev = nullptr; // the same memory as the device sees it
   uint64_t     readback_seq = 0;
+  bool         readback_polled = false;
+  hipEvent_t   ev_readback = nullptr; // the synchronising read-back path waits for the copy only
   uint32_t     decl_V = 0, decl_A = 0; // msgpu_set_id_space: id counts declared by the caller (0 = find them)
 
   // loaded rows
@@ -98,7 +100,7 @@ struct msgpu_ctx {
   bool   sub_wave  = true; // short edges share a wavefront (k_chain_sub); MSGPU_NO_SUBWAVE=1 sends them all to k_chain
   uint32_t n_cls[4] = {0, 0, 0, 0}; // edges of 9..16, 17..32, 33..64 and <= 8 EdgeMatches
   uint64_t n_edges_fast = 0;
-  DevBuf ems, order_scr, ids_scr, edge_norders, edge_nids, order_base, ids_base, orders, ids, big_list, cls_list, big_elems,
+  DevBuf ems, order_scr, ids_scr, edge_norders, edge_nids, order_base, ids_base, orders, ids, big_list, cls_list, cls_part, big_elems,
       big_paths;
   DevBuf g_deg, g_off, g_adj, g_cand, g_sane, g_out; // findContractionEdges
 
@@ -150,12 +152,23 @@ template <class T> const T *host_scalar(const msgpu_ctx *c, int slot) { return r
 // mirror and publishes a sequence number; the host polls for it (about half the latency of copy + synchronise, and
 // the host is back on the stream sooner).  A stream that stops making progress (a failed launch) is noticed by
 // hipStreamQuery and handled by the synchronising path, which is also what MSGPU_SYNC_READBACK=1 selects.
-int read_scalars(msgpu_ctx *c, hipEvent_t mark = nullptr) {
+// publish_scalars() enqueues the publication, wait_scalars() polls for it: work that does not depend on the values can
+// be enqueued in between and keeps the GPU busy while the host turns around.
+int publish_scalars(msgpu_ctx *c, hipEvent_t mark = nullptr) {
   static const bool sync_path = getenv("MSGPU_SYNC_READBACK") != nullptr;
-  if (!sync_path && c->h_scalars_dev) {
-    const uint64_t seq = ++c->readback_seq;
-    launch_publish_scalars(c->stream, c->scalars.as<uint64_t>(), c->h_scalars_dev, SC_COUNT, seq);
-    if (mark) HIPCHK(c, hipEventRecord(mark, c->stream));
+  c->readback_polled = !sync_path && c->h_scalars_dev;
+  if (c->readback_polled) {
+    launch_publish_scalars(c->stream, c->scalars.as<uint64_t>(), c->h_scalars_dev, SC_COUNT, ++c->readback_seq);
+  } else {
+    HIPCHK(c, hipMemcpyAsync(c->h_scalars, c->scalars.p, SC_COUNT * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipEventRecord(c->ev_readback, c->stream));
+  }
+  if (mark) HIPCHK(c, hipEventRecord(mark, c->stream));
+  return MSGPU_OK;
+}
+int wait_scalars(msgpu_ctx *c) {
+  if (c->readback_polled) {
+    const uint64_t     seq  = c->readback_seq;
     volatile uint64_t *flag = c->h_scalars + SC_COUNT;
     for (uint64_t spins = 1;; ++spins) {
       if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) return MSGPU_OK;
@@ -169,11 +182,17 @@ int read_scalars(msgpu_ctx *c, hipEvent_t mark = nullptr) {
         if (q != hipErrorNotReady) break;
       }
     }
+    // the stream stopped making progress: take the values the slow way (and surface the error)
+    HIPCHK(c, hipMemcpyAsync(c->h_scalars, c->scalars.p, SC_COUNT * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return MSGPU_OK;
   }
-  HIPCHK(c, hipMemcpyAsync(c->h_scalars, c->scalars.p, SC_COUNT * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
-  if (mark && (sync_path || !c->h_scalars_dev)) HIPCHK(c, hipEventRecord(mark, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipEventSynchronize(c->ev_readback)); // the copy, not whatever was enqueued behind it
   return MSGPU_OK;
+}
+int read_scalars(msgpu_ctx *c, hipEvent_t mark = nullptr) {
+  if (int rc = publish_scalars(c, mark)) return rc;
+  return wait_scalars(c);
 }
 
 void release_all(msgpu_ctx *c) {
@@ -184,7 +203,7 @@ void release_all(msgpu_ctx *c) {
                    &c->bound, &c->cand_off, &c->cand_j, &c->cand_t, &c->scr_v2, &c->scr_start, &c->n_cand, &c->n_edge,
                    &c->n_visit_arr, &c->lists, &c->em_base, &c->edge_base, &c->visit_base, &c->edges, &c->edge_cand,
                    &c->big_key, &c->big_t, &c->big_r2s, &c->big_pfx, &c->pair_tab, &c->edge_fast, &c->big_off, &c->ems, &c->order_scr, &c->ids_scr,
-                   &c->edge_norders, &c->edge_nids, &c->order_base, &c->ids_base, &c->orders, &c->ids, &c->big_list, &c->cls_list,
+                   &c->edge_norders, &c->edge_nids, &c->order_base, &c->ids_base, &c->orders, &c->ids, &c->big_list, &c->cls_list, &c->cls_part,
                    &c->big_elems, &c->big_paths, &c->alt_edges, &c->alt_ems, &c->alt_orders, &c->alt_ids, &c->vis16, &c->visits,
                    &c->spos2};
   for (DevBuf *b : all) b->release();
@@ -402,7 +421,8 @@ int msgpu_create(int device, const msgpu_params *params, msgpu_ctx **out) {
     }
   if (hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_side[0], hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&c->ev_side[1], hipEventDisableTiming) != hipSuccess) {
+      hipEventCreateWithFlags(&c->ev_side[1], hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_readback, hipEventDisableTiming) != hipSuccess) {
     msgpu_destroy(c);
     return MSGPU_E_HIP;
   }
@@ -429,6 +449,7 @@ void msgpu_destroy(msgpu_ctx *c) {
     if (ev) (void)hipEventDestroy(ev);
   for (auto &ev : c->ev_side)
     if (ev) (void)hipEventDestroy(ev);
+  if (c->ev_readback) (void)hipEventDestroy(c->ev_readback);
   if (c->side_stream) {
     (void)hipStreamSynchronize(c->side_stream);
     (void)hipStreamDestroy(c->side_stream);
@@ -605,7 +626,39 @@ int msgpu_calculate_edges(msgpu_ctx *c) {
     exclusive_scan_set(st, 2, in, V, out, c->scan_tmp.as<uint64_t>(), tot);
   }
   HIPCHK(c, hipGetLastError());
-  if (int rc = read_scalars(c)) return rc; // sizes of the edge / EdgeMatch tables
+  if (int rc = publish_scalars(c)) return rc; // sizes of the edge / EdgeMatch tables, big-edge and width-class counts
+  // While the host waits for those numbers and turns around, the GPU writes the edges and sorts them by size -- into
+  // whatever the tables hold from earlier calls.  Kernels and host compare the same counts with the same capacities:
+  // if something does not fit, the kernels write nothing and the host allocates and launches again (the first call of
+  // a context always does).
+  ENSURE(c, cls_part, size_sort_part_bytes());
+  auto emit_and_sort = [&](uint64_t cap_edges, uint64_t cap_big) {
+    launch_emit_edges(st, c->n_edge.as<uint32_t>(), c->n_cand.as<uint32_t>(), c->edge_base.as<uint64_t>(),
+                      c->em_base.as<uint64_t>(), c->cand_off.as<uint64_t>(), c->scr_v2.as<uint32_t>(),
+                      c->scr_start.as<uint32_t>(), V, c->edges.as<msgpu_edge>(), c->edge_cand.as<uint64_t>(),
+                      c->big_list.as<uint32_t>(), c->big_off.as<uint64_t>(), scalar<unsigned long long>(c, SC_BIGCUR),
+                      cap_edges, cap_big, scalar<unsigned long long>(c, SC_BIGSTATS));
+    // width classes of the chain kernels: <= 16 and 17..32 EdgeMatches share a wavefront four / two at a time, 33..64
+    // take one each; the edges are listed by size, largest first
+    if (c->sub_wave)
+      launch_sort_edges_by_size(st, c->edges.as<msgpu_edge>(), c->edge_base.as<uint64_t>() + V, cap_edges,
+                                c->cls_part.as<uint32_t>(), c->cls_list.as<uint32_t>(), scalar<uint32_t>(c, SC_CLS));
+  };
+  auto capacities = [&](uint64_t *cap_edges, uint64_t *cap_big) {
+    uint64_t ce = c->edges.cap / sizeof(msgpu_edge);
+    if (c->edge_cand.cap / 8 < ce) ce = c->edge_cand.cap / 8;
+    if (c->sub_wave && c->cls_list.cap / 4 < ce) ce = c->cls_list.cap / 4;
+    uint64_t cb = c->big_list.cap / 4;
+    if (c->big_off.cap / 8 < cb) cb = c->big_off.cap / 8;
+    *cap_edges = ce;
+    *cap_big   = cb;
+  };
+  uint64_t cap_edges = 0, cap_big = 0;
+  capacities(&cap_edges, &cap_big);
+  const bool speculated = cap_edges != 0 && cap_big != 0;
+  if (speculated) emit_and_sort(cap_edges, cap_big);
+  HIPCHK(c, hipGetLastError());
+  if (int rc = wait_scalars(c)) return rc;
   const uint64_t *tot = host_scalar<uint64_t>(c, SC_TOTAL_A), *big = host_scalar<uint64_t>(c, SC_BIGSTATS);
   c->n_big_edges = big[0];
   c->n_big_ems   = big[1];
@@ -614,16 +667,16 @@ int msgpu_calculate_edges(msgpu_ctx *c) {
   c->n_edges = tot[1];
   c->n_visit = c->total_bound; // the scaffold rows visited = the bound (scaffolds in read-id order: only owned partners)
   if (c->n_edges >= 0xfffffff0ull) return fail(c, MSGPU_E_ARG, "edge table too large (%llu)", (unsigned long long)c->n_edges);
-
-  ENSURE(c, edges, (c->n_edges ? c->n_edges : 1) * sizeof(msgpu_edge));
-  ENSURE(c, edge_cand, (c->n_edges ? c->n_edges : 1) * 8);
-  // the edges with more than 64 EdgeMatches (counted by the candidate kernels) are listed as they are emitted
-  ENSURE(c, big_list, (c->n_big_edges + 1) * 4);
-  ENSURE(c, big_off, (c->n_big_edges + 1) * 8);
-  launch_emit_edges(st, c->n_edge.as<uint32_t>(), c->n_cand.as<uint32_t>(), c->edge_base.as<uint64_t>(),
-                    c->em_base.as<uint64_t>(), c->cand_off.as<uint64_t>(), c->scr_v2.as<uint32_t>(),
-                    c->scr_start.as<uint32_t>(), V, c->edges.as<msgpu_edge>(), c->edge_cand.as<uint64_t>(),
-                    c->big_list.as<uint32_t>(), c->big_off.as<uint64_t>(), scalar<unsigned long long>(c, SC_BIGCUR));
+  if (!speculated || c->n_edges > cap_edges || c->n_big_edges >= cap_big) { // (the kernels' own test, see k_emit_edges)
+    ENSURE(c, edges, (c->n_edges ? c->n_edges : 1) * sizeof(msgpu_edge));
+    ENSURE(c, edge_cand, (c->n_edges ? c->n_edges : 1) * 8);
+    ENSURE(c, cls_list, (c->n_edges + 1) * 4);
+    // the edges with more than 64 EdgeMatches (counted by the candidate kernels) are listed as they are emitted
+    ENSURE(c, big_list, (c->n_big_edges + 1) * 4);
+    ENSURE(c, big_off, (c->n_big_edges + 1) * 8);
+    capacities(&cap_edges, &cap_big);
+    emit_and_sort(cap_edges, cap_big);
+  }
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipEventRecord(c->ev[3], st));
   c->have_cand_t = true;
@@ -704,11 +757,8 @@ int msgpu_chaining_and_overlaps(msgpu_ctx *c) {
     HIPCHK(c, hipEventRecord(c->ev_side[1], c->side_stream));
   }
   if (c->sub_wave && E) {
-    // width classes: <= 16 and 17..32 EdgeMatches share a wavefront four / two at a time, 33..64 take one each.  The
-    // class sizes are known since msgpu_calculate_edges (k_count_classes): no read-back between the sort and the launches.
-    ENSURE(c, cls_list, (E + 1) * 4 + size_sort_part_bytes());
-    uint32_t *list = c->cls_list.as<uint32_t>(), *part = list + E + 1;
-    launch_sort_edges_by_size(st, a.edges, E, part, list, scalar<uint32_t>(c, SC_CLS));
+    // the size-sorted edge list and the class sizes are there since msgpu_calculate_edges
+    const uint32_t *list = c->cls_list.as<uint32_t>();
     const uint32_t *l64 = list, *l32 = l64 + c->n_cls[2], *l16 = l32 + c->n_cls[1], *l8 = l16 + c->n_cls[0]; // sizes descending
     HIPCHK(c, hipEventRecord(c->ev[5], st));
     launch_chain(st, a, l64, c->n_cls[2]); // the long ones first: the short classes fill the tail
@@ -730,29 +780,42 @@ int msgpu_chaining_and_overlaps(msgpu_ctx *c) {
     exclusive_scan_set(st, 3, in, E, out, c->scan_tmp.as<uint64_t>(), tot);
   }
   HIPCHK(c, hipEventRecord(c->ev[7], st));
-  if (int rc = read_scalars(c)) return rc; // sizes of the order / id tables
+  if (int rc = publish_scalars(c)) return rc; // sizes of the order / id tables
+  // the compaction is enqueued behind the publication, into what the two tables hold from earlier calls (see
+  // msgpu_calculate_edges): the GPU is busy while the host turns around
+  auto compact = [&]() {
+    CompactArgs k;
+    k.edges        = c->edges.as<msgpu_edge>();
+    k.n_edges      = E;
+    k.edge_norders = c->edge_norders.as<uint32_t>();
+    k.order_base   = c->order_base.as<uint64_t>();
+    k.ids_base     = c->ids_base.as<uint64_t>();
+    k.order_scr    = c->order_scr.as<msgpu_order>();
+    k.ids_scr      = c->ids_scr.as<uint32_t>();
+    k.orders       = c->orders.as<msgpu_order>();
+    k.ids          = c->ids.as<uint32_t>();
+    k.out_em_base    = c->base_ems;
+    k.out_order_base = c->base_orders; // (a batched run: the earlier batches' counts, known to the caller)
+    k.out_ids_base   = c->base_ids;
+    k.out_edge_base  = static_cast<uint32_t>(c->base_edges);
+    k.cap_orders     = c->orders.cap / sizeof(msgpu_order);
+    k.cap_ids        = c->ids.cap / 4;
+    launch_compact(st, k);
+  };
+  const uint64_t cap_orders = c->orders.cap / sizeof(msgpu_order), cap_ids = c->ids.cap / 4;
+  const bool     speculated = cap_orders != 0 && cap_ids != 0;
+  if (speculated) compact();
+  HIPCHK(c, hipGetLastError());
+  if (int rc = wait_scalars(c)) return rc;
   c->n_edges_fast     = *host_scalar<uint64_t>(c, SC_TOTAL_C);
   const uint64_t *tot = host_scalar<uint64_t>(c, SC_TOTAL_A);
   c->n_orders = tot[0];
   c->n_ids    = tot[1];
-  ENSURE(c, orders, (c->n_orders ? c->n_orders : 1) * sizeof(msgpu_order));
-  ENSURE(c, ids, (c->n_ids ? c->n_ids : 1) * 4);
-
-  CompactArgs k;
-  k.edges        = c->edges.as<msgpu_edge>();
-  k.n_edges      = E;
-  k.edge_norders = c->edge_norders.as<uint32_t>();
-  k.order_base   = c->order_base.as<uint64_t>();
-  k.ids_base     = c->ids_base.as<uint64_t>();
-  k.order_scr    = c->order_scr.as<msgpu_order>();
-  k.ids_scr      = c->ids_scr.as<uint32_t>();
-  k.orders       = c->orders.as<msgpu_order>();
-  k.ids          = c->ids.as<uint32_t>();
-  k.out_em_base    = c->base_ems;
-  k.out_order_base = c->base_orders; // known only now: the caller of a batched run adds the earlier batches' counts
-  k.out_ids_base   = c->base_ids;
-  k.out_edge_base  = static_cast<uint32_t>(c->base_edges);
-  launch_compact(st, k);
+  if (!speculated || c->n_orders > cap_orders || c->n_ids > cap_ids) { // (the kernel's own test)
+    ENSURE(c, orders, (c->n_orders ? c->n_orders : 1) * sizeof(msgpu_order));
+    ENSURE(c, ids, (c->n_ids ? c->n_ids : 1) * 4);
+    compact();
+  }
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipEventRecord(c->ev[8], st));
   c->have_chain_t = true;

@@ -76,6 +76,7 @@ struct CompactArgs {
   // a batch of a larger job: what precedes this batch in the job's tables (0 for a whole-job run)
   uint64_t           out_em_base, out_order_base, out_ids_base;
   uint32_t           out_edge_base;
+  uint64_t           cap_orders, cap_ids; // records `orders` / `ids` can hold (the launch may precede the size read-back)
 };
 
 constexpr uint32_t MAX_WORLD = 64;
@@ -141,13 +142,14 @@ void launch_count_classes(hipStream_t st, const uint32_t *n_edge, const uint32_t
 void launch_emit_edges(hipStream_t st, const uint32_t *n_edge, const uint32_t *n_cand, const uint64_t *edge_base,
                        const uint64_t *em_base, const uint64_t *cand_off, const uint32_t *scr_v2,
                        const uint32_t *scr_start, uint32_t V, msgpu_edge *edges, uint64_t *edge_cand,
-                       uint32_t *big_list, uint64_t *big_off, unsigned long long *big_cursor);
+                       uint32_t *big_list, uint64_t *big_off, unsigned long long *big_cursor, uint64_t cap_edges,
+                       uint64_t cap_big, const unsigned long long *big_stats);
 constexpr uint32_t PAIR_TAB_STRIDE = 2016 + 128; // pairs k < l < 64 + padding read by lanes past the last pair
 void launch_fill_pair_tab(hipStream_t st, uint32_t *tab);
 void launch_chain(hipStream_t st, const ChainArgs &a, const uint32_t *list, uint32_t n_list);
 void launch_chain_sub(hipStream_t st, const ChainArgs &a, int width, const uint32_t *list, uint32_t n_list);
-void launch_sort_edges_by_size(hipStream_t st, const msgpu_edge *edges, uint64_t n_edges, uint32_t *part, uint32_t *list,
-                               uint32_t *counts);
+void launch_sort_edges_by_size(hipStream_t st, const msgpu_edge *edges, const uint64_t *d_n_edges, uint64_t cap_edges,
+                               uint32_t *part, uint32_t *list, uint32_t *counts);
 size_t size_sort_part_bytes();
 size_t big_elem_bytes();
 size_t big_path_bytes();

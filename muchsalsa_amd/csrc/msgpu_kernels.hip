@@ -1243,7 +1243,12 @@ __global__ __launch_bounds__(256) void k_emit_edges(const uint32_t *n_edge, cons
                                                     const uint64_t *cand_off, const uint32_t *edge_scr_v2,
                                                     const uint32_t *edge_scr_start, uint32_t V, msgpu_edge *edges,
                                                     uint64_t *edge_cand, uint32_t *big_list, uint64_t *big_off,
-                                                    unsigned long long *big_cursor /*[2]*/) {
+                                                    unsigned long long *big_cursor /*[2]*/, uint64_t cap_edges,
+                                                    uint64_t cap_big, const unsigned long long *big_stats) {
+  // The launch may be speculative (enqueued before the host knows the table sizes, into whatever the tables hold from
+  // earlier calls): if the edges or the list of big edges do not fit, nothing is written; the host, which compares the
+  // same numbers, allocates and launches again.
+  if (edge_base[V] > cap_edges || big_stats[0] >= cap_big) return;
   // 16 lanes per read (a read has ~10 edges)
   uint32_t r    = blockIdx.x * 16 + (threadIdx.x >> 4);
   int      lane = threadIdx.x & 15;
@@ -2402,9 +2407,13 @@ template __global__ void k_chain_sub<32>(ChainArgs, const uint32_t *, uint32_t);
 // waits long for its neighbour, and the longest edges of a launch start first.
 constexpr int SIZE_SORT_BLOCKS = 128;
 
-__global__ __launch_bounds__(1024) void k_size_hist(const msgpu_edge *edges, uint32_t n_edges, uint32_t chunk,
+// (the edge count is read from device memory and a capacity is checked, for the same reason as in k_emit_edges)
+__global__ __launch_bounds__(1024) void k_size_hist(const msgpu_edge *edges, const uint64_t *d_n_edges, uint64_t cap_edges,
                                                     uint32_t *part /*[blocks][64]*/) {
   __shared__ uint32_t s_h[64];
+  const uint64_t      ne64 = *d_n_edges;
+  if (ne64 > cap_edges) return;
+  const uint32_t n_edges = static_cast<uint32_t>(ne64), chunk = (n_edges + SIZE_SORT_BLOCKS - 1) / SIZE_SORT_BLOCKS;
   if (threadIdx.x < 64) s_h[threadIdx.x] = 0;
   __syncthreads();
   const uint64_t b0_64 = static_cast<uint64_t>(blockIdx.x) * chunk;
@@ -2468,9 +2477,12 @@ __global__ __launch_bounds__(1024) void k_size_scan(uint32_t *part, uint32_t *co
   }
 }
 
-__global__ __launch_bounds__(1024) void k_size_scatter(const msgpu_edge *edges, uint32_t n_edges, uint32_t chunk,
+__global__ __launch_bounds__(1024) void k_size_scatter(const msgpu_edge *edges, const uint64_t *d_n_edges, uint64_t cap_edges,
                                                        const uint32_t *part, uint32_t *list) {
   __shared__ uint32_t s_pos[64];
+  const uint64_t      ne64 = *d_n_edges;
+  if (ne64 > cap_edges) return;
+  const uint32_t n_edges = static_cast<uint32_t>(ne64), chunk = (n_edges + SIZE_SORT_BLOCKS - 1) / SIZE_SORT_BLOCKS;
   if (threadIdx.x < 64) s_pos[threadIdx.x] = part[blockIdx.x * 64 + threadIdx.x];
   __syncthreads();
   const uint64_t b0_64 = static_cast<uint64_t>(blockIdx.x) * chunk;
@@ -2900,6 +2912,8 @@ __global__ __launch_bounds__(256) void k_compact(CompactArgs a) {
   // Four lanes per edge, sixteen edges per wavefront, all in flight together: a lane moves one 16-byte quarter of an
   // order record and every fourth id.  (Most edges have one order; the dependent chain "order record -> id count ->
   // ids" is then as long as a single edge's, not sixteen of them in a row.)
+  // (may be launched before the host knows the table sizes: see k_emit_edges)
+  if (a.order_base[a.n_edges] > a.cap_orders || a.ids_base[a.n_edges] > a.cap_ids) return;
   const int      lane = threadIdx.x & 63, sub = lane & 3;
   const uint64_t e    = (static_cast<uint64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6)) * 16 + (lane >> 2);
   const bool     have = e < a.n_edges;
@@ -3084,10 +3098,11 @@ void launch_candidates_big(hipStream_t st, const CandArgs &a, const uint32_t *li
 void launch_emit_edges(hipStream_t st, const uint32_t *n_edge, const uint32_t *n_cand, const uint64_t *edge_base,
                        const uint64_t *em_base, const uint64_t *cand_off, const uint32_t *scr_v2,
                        const uint32_t *scr_start, uint32_t V, msgpu_edge *edges, uint64_t *edge_cand,
-                       uint32_t *big_list, uint64_t *big_off, unsigned long long *big_cursor) {
+                       uint32_t *big_list, uint64_t *big_off, unsigned long long *big_cursor, uint64_t cap_edges,
+                       uint64_t cap_big, const unsigned long long *big_stats) {
   if (V)
     hipLaunchKernelGGL(k_emit_edges, grid1(V, 16), dim3(256), 0, st, n_edge, n_cand, edge_base, em_base, cand_off, scr_v2,
-                       scr_start, V, edges, edge_cand, big_list, big_off, big_cursor);
+                       scr_start, V, edges, edge_cand, big_list, big_off, big_cursor, cap_edges, cap_big, big_stats);
 }
 void launch_fill_pair_tab(hipStream_t st, uint32_t *tab) {
   hipLaunchKernelGGL(k_fill_pair_tab, dim3((4 * PAIR_TAB_STRIDE + 255) / 256), dim3(256), 0, st, tab);
@@ -3105,14 +3120,11 @@ void launch_chain_sub(hipStream_t st, const ChainArgs &a, int width, const uint3
   else
     hipLaunchKernelGGL(k_chain_sub<32>, grid1(n_list, 8), dim3(256), 0, st, a, list, n_list);
 }
-void launch_sort_edges_by_size(hipStream_t st, const msgpu_edge *edges, uint64_t n_edges, uint32_t *part, uint32_t *list,
-                               uint32_t *counts) {
-  if (!n_edges) return;
-  const uint32_t E = static_cast<uint32_t>(n_edges); // < 2^32 - 16 (checked by the caller)
-  const uint32_t chunk = static_cast<uint32_t>((n_edges + SIZE_SORT_BLOCKS - 1) / SIZE_SORT_BLOCKS);
-  hipLaunchKernelGGL(k_size_hist, dim3(SIZE_SORT_BLOCKS), dim3(1024), 0, st, edges, E, chunk, part);
+void launch_sort_edges_by_size(hipStream_t st, const msgpu_edge *edges, const uint64_t *d_n_edges, uint64_t cap_edges,
+                               uint32_t *part, uint32_t *list, uint32_t *counts) {
+  hipLaunchKernelGGL(k_size_hist, dim3(SIZE_SORT_BLOCKS), dim3(1024), 0, st, edges, d_n_edges, cap_edges, part);
   hipLaunchKernelGGL(k_size_scan, dim3(1), dim3(1024), 0, st, part, counts);
-  hipLaunchKernelGGL(k_size_scatter, dim3(SIZE_SORT_BLOCKS), dim3(1024), 0, st, edges, E, chunk, part, list);
+  hipLaunchKernelGGL(k_size_scatter, dim3(SIZE_SORT_BLOCKS), dim3(1024), 0, st, edges, d_n_edges, cap_edges, part, list);
 }
 size_t size_sort_part_bytes() { return static_cast<size_t>(SIZE_SORT_BLOCKS) * 64 * 4; }
 size_t big_elem_bytes() { return sizeof(BigElem); }
