@@ -72,6 +72,10 @@ struct msgpu_ctx {
   uint64_t     base_edges = 0, base_ems = 0, base_orders = 0, base_ids = 0; // what precedes it in the job's tables
   uint64_t    *h_scalars = nullptr; // pinned, device-mapped mirror of `scalars` (+ one word: the read-back sequence number)
   uint64_t    *h_scalars_dev = nullptr; // the same memory as the device sees it
+  bool         no_prologue = false; // msgpu_overlap_batched with several windows: every window has its own opening
+  bool         prologue_ok = false; // the candidate stage's opening ran with the index build (whole table, fast index)
+  uint64_t     prologue_bound = 0;
+  uint32_t     prologue_lists[4] = {0, 0, 0, 0};
   uint64_t     readback_seq = 0;
   bool         readback_polled = false;
   hipEvent_t   ev_readback = nullptr; // the synchronising read-back path waits for the copy only
@@ -293,9 +297,32 @@ int build_index_once(msgpu_ctx *c, bool force_generic, bool two_pass, uint32_t *
   launch_select_anchor_off(st, d_flags, c->anchor_first.as<uint32_t>(), c->anchor_off_gen.as<uint32_t>(), A,
                            c->anchor_off.as<uint32_t>(), scalar<uint32_t>(c, SC_NALIVE), static_cast<uint32_t>(n));
   HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipEventRecord(c->ev[1], st));
+  // The opening of msgpu_calculate_edges for the whole table (scratch offsets from the visit counts the sort left, owner
+  // reads classified by LDS footprint) runs here, so that its two numbers come back with the index flags instead of
+  // costing a read-back of their own.  Valid for a fast index of an unsharded context; anything else redoes it there.
+  c->prologue_ok           = false;
+  static const bool env_no_prologue = getenv("MSGPU_NO_PROLOGUE") != nullptr; // measurement switch
+  const bool want_prologue = !env_no_prologue && !force_generic && !c->no_prologue && V != 0 && c->nshards == 1 && c->win_lo == 0 && c->win_hi >= V;
+  if (want_prologue) {
+    ENSURE(c, cand_off, (size_t(V) + 2) * 8);
+    ENSURE(c, lists, (size_t(V) + 1) * (3 * sizeof(CandDesc) + 4));
+    CandDesc *l0 = c->lists.as<CandDesc>(), *l1 = l0 + V + 1, *l2 = l1 + V + 1;
+    exclusive_scan<uint64_t>(st, c->visits.as<uint32_t>(), V, c->cand_off.as<uint64_t>(), c->scan_tmp.as<uint64_t>(),
+                             scalar<uint64_t>(c, SC_TOTAL_A));
+    launch_classify_reads(st, c->read_off.as<uint32_t>(), c->read_cnt.as<uint32_t>(), c->visits.as<uint32_t>(),
+                          c->cand_off.as<uint64_t>(), V, 0, 1, 0, 0xffffffffu, l0, l1, l2,
+                          reinterpret_cast<uint32_t *>(l2 + V + 1), scalar<uint32_t>(c, SC_NLISTS));
+    HIPCHK(c, hipGetLastError());
+  }
 
-  if (int rc = read_scalars(c, c->ev[1])) return rc;
+  if (int rc = read_scalars(c)) return rc;
   const uint32_t err = *host_scalar<uint32_t>(c, SC_ERR), ixf = *host_scalar<uint32_t>(c, SC_IXFLAGS);
+  if (want_prologue && ixf == 0 && err == 0) {
+    c->prologue_ok    = true;
+    c->prologue_bound = *host_scalar<uint64_t>(c, SC_TOTAL_A);
+    for (int k = 0; k < 4; ++k) c->prologue_lists[k] = host_scalar<uint32_t>(c, SC_NLISTS)[k];
+  }
   uint32_t       n_alive = *host_scalar<uint32_t>(c, SC_NALIVE);
   if (err & 2u)
     return fail(c, MSGPU_E_IDS, "a row has an id outside the declared id space (%u reads, %u anchors)", V, A);
@@ -553,18 +580,24 @@ int msgpu_calculate_edges(msgpu_ctx *c) {
   // window of owner reads, or a generically built index (scan view patched after the sort), counts them here
   const bool      all_reads = c->index_fast && c->nshards == 1 && c->win_lo == 0 && c->win_hi >= V;
   const uint32_t *bound     = all_reads ? c->visits.as<uint32_t>() : c->bound.as<uint32_t>();
-  if (!all_reads)
-    launch_bound(st, c->read_off.as<uint32_t>(), c->read_cnt.as<uint32_t>(), c->vis16.as<uint4>(), V, c->shard,
-                 c->nshards, c->win_lo, c->win_hi, c->bound.as<uint32_t>());
-  exclusive_scan<uint64_t>(st, bound, V, c->cand_off.as<uint64_t>(), c->scan_tmp.as<uint64_t>(),
-                           scalar<uint64_t>(c, SC_TOTAL_A));
-  launch_classify_reads(st, c->read_off.as<uint32_t>(), c->read_cnt.as<uint32_t>(), bound,
-                        c->cand_off.as<uint64_t>(), V, c->shard, c->nshards, c->win_lo, c->win_hi, l0, l1, l2, l3,
-                        scalar<uint32_t>(c, SC_NLISTS));
-  HIPCHK(c, hipGetLastError());
-  if (int rc = read_scalars(c)) return rc; // sizes of the candidate scratch
-  const uint64_t total_bound = *host_scalar<uint64_t>(c, SC_TOTAL_A);
-  for (int k = 0; k < 4; ++k) c->n_list[k] = host_scalar<uint32_t>(c, SC_NLISTS)[k];
+  uint64_t total_bound;
+  if (all_reads && c->prologue_ok) { // done with the index build; the numbers came back with its flags
+    total_bound = c->prologue_bound;
+    for (int k = 0; k < 4; ++k) c->n_list[k] = c->prologue_lists[k];
+  } else {
+    if (!all_reads)
+      launch_bound(st, c->read_off.as<uint32_t>(), c->read_cnt.as<uint32_t>(), c->vis16.as<uint4>(), V, c->shard,
+                   c->nshards, c->win_lo, c->win_hi, c->bound.as<uint32_t>());
+    exclusive_scan<uint64_t>(st, bound, V, c->cand_off.as<uint64_t>(), c->scan_tmp.as<uint64_t>(),
+                             scalar<uint64_t>(c, SC_TOTAL_A));
+    launch_classify_reads(st, c->read_off.as<uint32_t>(), c->read_cnt.as<uint32_t>(), bound,
+                          c->cand_off.as<uint64_t>(), V, c->shard, c->nshards, c->win_lo, c->win_hi, l0, l1, l2, l3,
+                          scalar<uint32_t>(c, SC_NLISTS));
+    HIPCHK(c, hipGetLastError());
+    if (int rc = read_scalars(c)) return rc; // sizes of the candidate scratch
+    total_bound = *host_scalar<uint64_t>(c, SC_TOTAL_A);
+    for (int k = 0; k < 4; ++k) c->n_list[k] = host_scalar<uint32_t>(c, SC_NLISTS)[k];
+  }
   c->total_bound = total_bound;
 
   const size_t tb = total_bound ? total_bound : 1;
@@ -1012,7 +1045,10 @@ int msgpu_overlap_batched(msgpu_ctx *c, const msgpu_row *rows, size_t n_rows, ui
   c->win_lo = 0;
   c->win_hi = 0xffffffffu;
   c->base_edges = c->base_ems = c->base_orders = c->base_ids = 0;
-  if (int rc = msgpu_load_rows(c, rows, n_rows)) return rc; // rows host -> HBM once, index build once
+  c->no_prologue = (n_batches ? n_batches : 8) > 1; // several windows: each has its own scratch offsets and read lists
+  const int rc_load = msgpu_load_rows(c, rows, n_rows); // rows host -> HBM once, index build once
+  c->no_prologue    = false;
+  if (rc_load) return rc_load;
   out->load_ms = ms_since(t_start);
   const uint32_t V = c->V;
   uint32_t       B = n_batches ? n_batches : 8;
