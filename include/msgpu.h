@@ -224,6 +224,10 @@ int msgpu_chaining_and_overlaps(msgpu_ctx *ctx);
 
 int msgpu_get_counts(msgpu_ctx *ctx, msgpu_counts *out);
 int msgpu_get_timings(msgpu_ctx *ctx, msgpu_timings *out);
+/* The stage boundaries (index / candidates / chain / compact) are marked with HIP events on the context's stream; every
+ * marker costs a few microseconds of command-processor time.  on = 0 drops them: msgpu_get_timings then reports only
+ * chain_kernel_ms (the two events around the chain kernels stay) and zeros for the stages.  Default: on. */
+int msgpu_set_stage_events(msgpu_ctx *ctx, int on);
 
 /* Copy result tables to HOST buffers sized from msgpu_get_counts (any pointer may be NULL to skip). */
 int msgpu_copy_tables(msgpu_ctx *ctx, msgpu_edge *edges, msgpu_edgematch *ems, msgpu_order *orders, uint32_t *ids);

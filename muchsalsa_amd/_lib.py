@@ -112,6 +112,7 @@ SYMBOLS = [
     ("msgpu_chaining_and_overlaps", C.c_int, [C.c_void_p]),
     ("msgpu_get_counts", C.c_int, [C.c_void_p, C.POINTER(Counts)]),
     ("msgpu_get_timings", C.c_int, [C.c_void_p, C.POINTER(Timings)]),
+    ("msgpu_set_stage_events", C.c_int, [C.c_void_p, C.c_int]),
     ("msgpu_copy_tables", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("msgpu_copy_tables_device", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("msgpu_copy_reads", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -72,6 +72,7 @@ struct msgpu_ctx {
   uint64_t     base_edges = 0, base_ems = 0, base_orders = 0, base_ids = 0; // what precedes it in the job's tables
   uint64_t    *h_scalars = nullptr; // pinned, device-mapped mirror of `scalars` (+ one word: the read-back sequence number)
   uint64_t    *h_scalars_dev = nullptr; // the same memory as the device sees it
+  bool         stage_events = true; // the stage boundaries are marked with events (msgpu_set_stage_events)
   bool         no_prologue = false; // msgpu_overlap_batched with several windows: every window has its own opening
   bool         prologue_ok = false; // the candidate stage's opening ran with the index build (whole table, fast index)
   uint64_t     prologue_bound = 0;
@@ -120,6 +121,7 @@ struct msgpu_ctx {
   // timing
   hipEvent_t ev[10] = {nullptr};
   bool       have_index_t = false, have_cand_t = false, have_chain_t = false, index_fast = false;
+  bool   have_stage_t = false;
 };
 
 namespace {
@@ -297,7 +299,7 @@ int build_index_once(msgpu_ctx *c, bool force_generic, bool two_pass, uint32_t *
   launch_select_anchor_off(st, d_flags, c->anchor_first.as<uint32_t>(), c->anchor_off_gen.as<uint32_t>(), A,
                            c->anchor_off.as<uint32_t>(), scalar<uint32_t>(c, SC_NALIVE), static_cast<uint32_t>(n));
   HIPCHK(c, hipGetLastError());
-  HIPCHK(c, hipEventRecord(c->ev[1], st));
+  if (c->stage_events) HIPCHK(c, hipEventRecord(c->ev[1], st));
   // The opening of msgpu_calculate_edges for the whole table (scratch offsets from the visit counts the sort left, owner
   // reads classified by LDS footprint) runs here, so that its two numbers come back with the index flags instead of
   // costing a read-back of their own.  Valid for a fast index of an unsharded context; anything else redoes it there.
@@ -355,7 +357,7 @@ int build_index_once(msgpu_ctx *c, bool force_generic, bool two_pass, uint32_t *
 }
 
 int build_index(msgpu_ctx *c) {
-  HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+  if (c->stage_events) HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
   uint32_t ixf = 0;
   bool     two_pass = false;
   int      rc  = build_index_once(c, false, two_pass, &ixf);
@@ -371,7 +373,7 @@ int build_index(msgpu_ctx *c) {
     if (rc != MSGPU_OK) return rc;
   }
   c->index_fast   = (ixf & ~IXF_DUPS) == 0;
-  c->have_index_t = true;
+  c->have_index_t = c->stage_events;
   c->state        = ST_LOADED;
   return MSGPU_OK;
 }
@@ -446,7 +448,11 @@ int msgpu_create(int device, const msgpu_params *params, msgpu_ctx **out) {
       msgpu_destroy(c);
       return MSGPU_E_HIP;
     }
-  if (hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking) != hipSuccess ||
+  // the side stream carries the few heavy workgroups that run beside a stage's main kernel (large LDS classes, edges with
+  // more than 64 EdgeMatches): highest priority, so that they finish first and the join never waits for them
+  int prio_least = 0, prio_greatest = 0;
+  if (hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest) != hipSuccess) prio_least = prio_greatest = 0;
+  if (hipStreamCreateWithPriority(&c->side_stream, hipStreamNonBlocking, prio_greatest) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_side[0], hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_side[1], hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_readback, hipEventDisableTiming) != hipSuccess) {
@@ -554,7 +560,7 @@ int msgpu_calculate_edges(msgpu_ctx *c) {
   hipStream_t    st = c->stream;
   const uint32_t V  = c->V;
   c->state          = ST_LOADED;
-  HIPCHK(c, hipEventRecord(c->ev[2], st));
+  if (c->stage_events) HIPCHK(c, hipEventRecord(c->ev[2], st));
 
   ENSURE(c, bound, (size_t(V) + 1) * 4);
   ENSURE(c, cand_off, (size_t(V) + 2) * 8);
@@ -711,8 +717,8 @@ int msgpu_calculate_edges(msgpu_ctx *c) {
     emit_and_sort(cap_edges, cap_big);
   }
   HIPCHK(c, hipGetLastError());
-  HIPCHK(c, hipEventRecord(c->ev[3], st));
-  c->have_cand_t = true;
+  if (c->stage_events) HIPCHK(c, hipEventRecord(c->ev[3], st));
+  c->have_cand_t = c->stage_events;
   c->n_orders    = 0;
   c->n_ids       = 0;
   c->state       = ST_EDGES;
@@ -725,7 +731,7 @@ int msgpu_chaining_and_overlaps(msgpu_ctx *c) {
   HIPCHK(c, hipSetDevice(c->device));
   hipStream_t    st = c->stream;
   const uint64_t E = c->n_edges, M = c->n_ems;
-  HIPCHK(c, hipEventRecord(c->ev[4], st));
+  if (c->stage_events) HIPCHK(c, hipEventRecord(c->ev[4], st));
 
   ENSURE(c, ems, (M ? M : 1) * sizeof(msgpu_edgematch));
   ENSURE(c, order_scr, (M ? M : 1) * sizeof(msgpu_order));
@@ -812,7 +818,7 @@ int msgpu_chaining_and_overlaps(msgpu_ctx *c) {
     uint64_t *const       tot[3] = {scalar<uint64_t>(c, SC_TOTAL_A), scalar<uint64_t>(c, SC_TOTAL_B), scalar<uint64_t>(c, SC_TOTAL_C)};
     exclusive_scan_set(st, 3, in, E, out, c->scan_tmp.as<uint64_t>(), tot);
   }
-  HIPCHK(c, hipEventRecord(c->ev[7], st));
+  if (c->stage_events) HIPCHK(c, hipEventRecord(c->ev[7], st));
   if (int rc = publish_scalars(c)) return rc; // sizes of the order / id tables
   // the compaction is enqueued behind the publication, into what the two tables hold from earlier calls (see
   // msgpu_calculate_edges): the GPU is busy while the host turns around
@@ -850,9 +856,16 @@ int msgpu_chaining_and_overlaps(msgpu_ctx *c) {
     compact();
   }
   HIPCHK(c, hipGetLastError());
-  HIPCHK(c, hipEventRecord(c->ev[8], st));
+  if (c->stage_events) HIPCHK(c, hipEventRecord(c->ev[8], st));
   c->have_chain_t = true;
+  c->have_stage_t = c->stage_events;
   c->state        = ST_CHAINED;
+  return MSGPU_OK;
+}
+
+int msgpu_set_stage_events(msgpu_ctx *c, int on) {
+  if (!c) return MSGPU_E_ARG;
+  c->stage_events = on != 0;
   return MSGPU_OK;
 }
 
@@ -879,8 +892,10 @@ int msgpu_get_timings(msgpu_ctx *c, msgpu_timings *out) {
   if (c->have_index_t) HIPCHK(c, hipEventElapsedTime(&out->index_ms, c->ev[0], c->ev[1]));
   if (c->have_cand_t) HIPCHK(c, hipEventElapsedTime(&out->candidates_ms, c->ev[2], c->ev[3]));
   if (c->have_chain_t) {
-    HIPCHK(c, hipEventElapsedTime(&out->chain_ms, c->ev[4], c->ev[7]));
-    HIPCHK(c, hipEventElapsedTime(&out->compact_ms, c->ev[7], c->ev[8]));
+    if (c->have_stage_t) {
+      HIPCHK(c, hipEventElapsedTime(&out->chain_ms, c->ev[4], c->ev[7]));
+      HIPCHK(c, hipEventElapsedTime(&out->compact_ms, c->ev[7], c->ev[8]));
+    }
     HIPCHK(c, hipEventElapsedTime(&out->chain_kernel_ms, c->ev[5], c->ev[6]));
     out->chain_kernel_launches = c->n_edges ? 1 : 0;
   }

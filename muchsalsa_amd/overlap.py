@@ -146,6 +146,10 @@ class OverlapContext:
         self._check(self._L.msgpu_get_counts(self._h, C.byref(c)))
         return c
 
+    def set_stage_events(self, on):
+        """mark the stage boundaries with events (timings() per stage) or not (a few microseconds less per marker)"""
+        self._check(self._L.msgpu_set_stage_events(self._h, 1 if on else 0))
+
     def timings(self):
         t = Timings()
         self._check(self._L.msgpu_get_timings(self._h, C.byref(t)))
