@@ -134,8 +134,8 @@ typedef struct msgpu_timings {
   float candidates_ms; /* msgpu_calculate_edges: pair scan + group by edge                                    */
   float chain_ms;      /* msgpu_chaining_and_overlaps: EdgeMatch + chaining DP + overlap kernel (dominant)    */
   float compact_ms;    /* msgpu_chaining_and_overlaps: order/id compaction                                    */
-  float chain_kernel_ms; /* the chaining kernel alone (HIP events directly around its launch)                 */
-  uint32_t chain_kernel_launches;
+  float chain_kernel_ms; /* the chain kernels alone (HIP events directly around their launches): mean over the   */
+  uint32_t chain_kernel_launches; /* ... msgpu_chaining_and_overlaps calls since the last msgpu_get_timings (<= 256)    */
   uint32_t pad;
 } msgpu_timings;
 

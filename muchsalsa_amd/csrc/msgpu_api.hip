@@ -120,6 +120,11 @@ struct msgpu_ctx {
 
   // timing
   hipEvent_t ev[10] = {nullptr};
+  // the two events around the chain kernels, one pair per msgpu_chaining_and_overlaps call in a ring: msgpu_get_timings
+  // averages over the calls since the last msgpu_get_timings without having synchronised after each of them
+  static constexpr int CK_RING = 256;
+  hipEvent_t ck_ev[CK_RING][2] = {};
+  uint32_t   ck_head = 0, ck_count = 0; // next slot; pairs recorded since the last msgpu_get_timings
   bool       have_index_t = false, have_cand_t = false, have_chain_t = false, index_fast = false;
   bool   have_stage_t = false;
 };
@@ -483,6 +488,9 @@ void msgpu_destroy(msgpu_ctx *c) {
   for (auto &ev : c->ev_side)
     if (ev) (void)hipEventDestroy(ev);
   if (c->ev_readback) (void)hipEventDestroy(c->ev_readback);
+  for (auto &pair : c->ck_ev)
+    for (auto &ev : pair)
+      if (ev) (void)hipEventDestroy(ev);
   if (c->side_stream) {
     (void)hipStreamSynchronize(c->side_stream);
     (void)hipStreamDestroy(c->side_stream);
@@ -731,6 +739,9 @@ int msgpu_chaining_and_overlaps(msgpu_ctx *c) {
   HIPCHK(c, hipSetDevice(c->device));
   hipStream_t    st = c->stream;
   const uint64_t E = c->n_edges, M = c->n_ems;
+  for (int k = 0; k < 2; ++k)
+    if (!c->ck_ev[c->ck_head][k]) HIPCHK(c, hipEventCreate(&c->ck_ev[c->ck_head][k]));
+  const hipEvent_t ck_begin = c->ck_ev[c->ck_head][0], ck_end = c->ck_ev[c->ck_head][1];
   if (c->stage_events) HIPCHK(c, hipEventRecord(c->ev[4], st));
 
   ENSURE(c, ems, (M ? M : 1) * sizeof(msgpu_edgematch));
@@ -799,16 +810,18 @@ int msgpu_chaining_and_overlaps(msgpu_ctx *c) {
     // the size-sorted edge list and the class sizes are there since msgpu_calculate_edges
     const uint32_t *list = c->cls_list.as<uint32_t>();
     const uint32_t *l64 = list, *l32 = l64 + c->n_cls[2], *l16 = l32 + c->n_cls[1], *l8 = l16 + c->n_cls[0]; // sizes descending
-    HIPCHK(c, hipEventRecord(c->ev[5], st));
+    HIPCHK(c, hipEventRecord(ck_begin, st));
     launch_chain(st, a, l64, c->n_cls[2]); // the long ones first: the short classes fill the tail
     launch_chain_sub(st, a, 32, l32, c->n_cls[1]);
     launch_chain_sub(st, a, 16, l16, c->n_cls[0]);
     launch_chain_sub(st, a, 8, l8, c->n_cls[3]);
   } else {
-    HIPCHK(c, hipEventRecord(c->ev[5], st));
+    HIPCHK(c, hipEventRecord(ck_begin, st));
     launch_chain(st, a, nullptr, 0);
   }
-  HIPCHK(c, hipEventRecord(c->ev[6], st));
+  HIPCHK(c, hipEventRecord(ck_end, st));
+  c->ck_head = (c->ck_head + 1) % msgpu_ctx::CK_RING;
+  if (c->ck_count < msgpu_ctx::CK_RING) ++c->ck_count;
   HIPCHK(c, hipGetLastError());
   if (n_big) HIPCHK(c, hipStreamWaitEvent(st, c->ev_side[1], 0));
 
@@ -896,8 +909,19 @@ int msgpu_get_timings(msgpu_ctx *c, msgpu_timings *out) {
       HIPCHK(c, hipEventElapsedTime(&out->chain_ms, c->ev[4], c->ev[7]));
       HIPCHK(c, hipEventElapsedTime(&out->compact_ms, c->ev[7], c->ev[8]));
     }
-    HIPCHK(c, hipEventElapsedTime(&out->chain_kernel_ms, c->ev[5], c->ev[6]));
-    out->chain_kernel_launches = c->n_edges ? 1 : 0;
+    // mean over the msgpu_chaining_and_overlaps calls since the last msgpu_get_timings (at most CK_RING of them)
+    double   sum = 0;
+    uint32_t n   = 0;
+    for (uint32_t i = 0; i < c->ck_count; ++i) {
+      const uint32_t slot = (c->ck_head + msgpu_ctx::CK_RING - 1 - i) % msgpu_ctx::CK_RING;
+      float          ms   = 0;
+      HIPCHK(c, hipEventElapsedTime(&ms, c->ck_ev[slot][0], c->ck_ev[slot][1]));
+      sum += ms;
+      ++n;
+    }
+    out->chain_kernel_ms       = n ? static_cast<float>(sum / n) : 0.f;
+    out->chain_kernel_launches = n;
+    c->ck_count                = 0;
   }
   return MSGPU_OK;
 }
