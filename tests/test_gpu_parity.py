@@ -150,6 +150,30 @@ def test_sub_wavefront_and_whole_wavefront_chaining_agree(oracle, monkeypatch):
     assert_tables_equal(_gpu_tables(rows), want, "one edge per wavefront")
 
 
+def test_one_context_many_jobs_of_changing_size(oracle):
+    """A context keeps its tables between calls and launches edge emission, size sort and compaction into them before it
+    knows the new sizes (the kernels and the host compare the same counts with the same capacities).  Jobs that grow, shrink
+    and grow again on ONE context -- every launch-again and every first-try path -- each equal the oracle; with the stage
+    markers off the tables are the same and only the chain-kernel time is reported."""
+    from muchsalsa_amd import overlap, synth
+    shapes = [(300, 3000, 900, 1), (2000, 5000, 10000, 7), (300, 3000, 900, 2), (1500, 10000, 8000, 11), (2000, 5000, 10000, 8),
+              (40, 3000, 200, 3), (120, 20000, 2400, 5)]
+    with overlap.OverlapContext(0) as ctx:
+        for k, shape in enumerate(shapes):
+            rows = synth.synth_rows(*shape) if k != len(shapes) - 1 else synth.accepted_rows(synth.paf_table(*shape, coverage=10))[0]
+            want = oracle.overlap(rows)
+            ctx.set_stage_events(k % 2 == 0)
+            for rep in range(2):  # the second pass over the same job finds every table large enough
+                ctx.load_rows(rows)
+                ctx.calculate_edges()
+                ctx.chaining_and_overlaps()
+                assert_tables_equal(ctx.tables(), want, "job %d %r pass %d" % (k, shape, rep))
+            tm = ctx.timings()
+            assert tm.chain_kernel_launches == 2 and tm.chain_kernel_ms > 0
+            assert (tm.index_ms > 0 and tm.candidates_ms > 0 and tm.chain_ms > 0) == (k % 2 == 0)
+            assert ctx.timings().chain_kernel_launches == 0  # the window of chain-kernel events starts afresh
+
+
 def test_empty_and_tiny(oracle):
     from muchsalsa_amd import synth
     rows = synth.synth_rows(300, 3000, 900, 1)
