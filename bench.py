@@ -314,13 +314,13 @@ def build_stores(torch, dev, w, read_names, anchor_names):
 
 
 def assemble_paths(store, rows, prepared, threads, band=64, reps=3):
-    """assemblePath over prepared path inputs, timed: install the VertexMatch table (msgpu_assembly_set_rows, once per
+    """assemblePath over prepared path inputs, timed: install the VertexMatch table (msgpu_assembly_borrow_rows, once per
     job) + host layout of every path (msgpu_assembly_add_paths) + ONE gather + FASTA wrapping with the texts copied back
     (msgpu_assembly_finish).  Medians of `reps` fresh assemblies.  Self-check: msgpu_assembly_validate (banded edit
     distance of every query against the stretch of its contig its PAF line names)."""
     from muchsalsa_amd.assembly import Assembly
     warm = Assembly(store)  # warm-up (untimed), like the W warm-up steps of the overlap half
-    warm.set_rows(rows)
+    warm.set_rows(rows, copy=False)
     warm.add_prepared_batch(prepared, threads)
     warm.finish()
     warm.close()
@@ -330,7 +330,7 @@ def assemble_paths(store, rows, prepared, threads, band=64, reps=3):
             asm.close()
         asm = Assembly(store)
         t0 = time.perf_counter()
-        asm.set_rows(rows)
+        asm.set_rows(rows, copy=False)  # msgpu_assembly_borrow_rows: the PAF loader's table stays where it is
         t_i = time.perf_counter() - t0
         t0 = time.perf_counter()
         status = asm.add_prepared_batch(prepared, threads)

@@ -470,6 +470,9 @@ const char *msgpu_assembly_last_error(const msgpu_assembly *a);
 /* Install the VertexMatch table once (MatchMap::getVertexMatch for every later path; copied, n_rows < 2^32).  A path's
  * own msgpu_path_input.rows, when given, are looked up first. */
 int msgpu_assembly_set_rows(msgpu_assembly *a, const msgpu_row *rows, size_t n_rows);
+/* The same without the copy: `rows` (e.g. msgpu_paf_rows of a live msgpu_paf) stays the caller's and must outlive the
+ * assembly's last msgpu_assembly_add_path(s).  The reference's MatchMap hands out pointers into its own table the same way. */
+int msgpu_assembly_borrow_rows(msgpu_assembly *a, const msgpu_row *rows, size_t n_rows);
 /* MSGPU_E_LAYOUT leaves the assembly unchanged (the path is skipped). */
 int      msgpu_assembly_add_path(msgpu_assembly *a, const msgpu_path_input *in);
 /* The assemblePaths fan-out (src/main.cpp:620-677): n paths laid out by n_threads host threads, appended in input

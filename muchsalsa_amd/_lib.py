@@ -156,6 +156,7 @@ SYMBOLS = [
     ("msgpu_assembly_free", None, [C.c_void_p]),
     ("msgpu_assembly_last_error", C.c_char_p, [C.c_void_p]),
     ("msgpu_assembly_set_rows", C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    ("msgpu_assembly_borrow_rows", C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     ("msgpu_assembly_add_path", C.c_int, [C.c_void_p, C.POINTER(PathInput)]),
     ("msgpu_assembly_add_paths", C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p]),
     ("msgpu_assembly_path_count", C.c_uint32, [C.c_void_p]),

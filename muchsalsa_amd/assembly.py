@@ -44,10 +44,13 @@ class Assembly:
         if rc != 0:
             raise MsgpuError(rc, (self._L.msgpu_assembly_last_error(self._h) or b"").decode())
 
-    def set_rows(self, rows):
-        """install the VertexMatch table once; later paths may pass rows=None"""
+    def set_rows(self, rows, copy=True):
+        """install the VertexMatch table once; later paths may pass rows=None.  copy=False: the library keeps reading the
+        caller's array (kept alive here) instead of copying it"""
         rows = np.ascontiguousarray(rows, dtype=ROW_DTYPE)
-        self._check(self._L.msgpu_assembly_set_rows(self._h, rows.ctypes.data if len(rows) else None, len(rows)))
+        fn = self._L.msgpu_assembly_set_rows if copy else self._L.msgpu_assembly_borrow_rows
+        self._check(fn(self._h, rows.ctypes.data if len(rows) else None, len(rows)))
+        self._rows_keep = None if copy else rows
 
     def add_path(self, path, steps, rows, contains=None, asm_idx=1):
         self.add_prepared(self.prepare(path, steps, rows, contains, asm_idx))

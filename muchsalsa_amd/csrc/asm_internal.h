@@ -30,7 +30,8 @@ struct msgpu_assembly {
     T       &operator[](size_t i) { return p[i]; }
     const T &operator[](size_t i) const { return p[i]; }
   };
-  RawBuf<msgpu_row>             rows;
+  RawBuf<msgpu_row>             rows;      // msgpu_assembly_set_rows: the copy
+  const msgpu_row              *rows_view = nullptr; // the installed table: `rows`, or the caller's (msgpu_assembly_borrow_rows)
   RawBuf<RowRec>                row_recs;
   std::vector<uint64_t>         row_start;
   // rows that arrive in ascending anchor-id order (a PAF is grouped by its query) need no per-read table:

@@ -191,7 +191,7 @@ struct PathLayout {
     if (shared && static_cast<size_t>(anchor) + 1 < shared->anchor_start.size()) { // the anchor's own scaffold only
       const msgpu_row *best = nullptr;
       for (uint64_t i = shared->anchor_start[anchor], e = shared->anchor_start[static_cast<size_t>(anchor) + 1]; i < e; ++i) {
-        const msgpu_row &m = shared->rows[i];
+        const msgpu_row &m = shared->rows_view[i];
         if (m.read_id == read && (!best || m.line < best->line)) best = &m; // of equal keys the lowest line
       }
       if (best) return best;
@@ -199,7 +199,7 @@ struct PathLayout {
       const auto b  = shared->row_recs.begin() + static_cast<long>(shared->row_start[read]);
       const auto e  = shared->row_recs.begin() + static_cast<long>(shared->row_start[read + 1]);
       const auto lo = std::lower_bound(b, e, key, [](const msgpu_assembly::RowRec &r, uint64_t k) { return r.key < k; });
-      if (lo != e && lo->key == key) return &shared->rows[lo->idx]; // the first of equal keys = the lowest line
+      if (lo != e && lo->key == key) return &shared->rows_view[lo->idx]; // the first of equal keys = the lowest line
     }
     throw LayoutError("no VertexMatch for read " + std::to_string(read) + " on anchor " + std::to_string(anchor));
   }
@@ -1016,7 +1016,7 @@ LayoutPool               *layout_pool() {
 //      a record {read << 32 | anchor, line, row number} to each partition -- a few hundred sequential write streams;
 //   3. every partition (tens of thousands of records, cache resident) is counting-sorted by read into its final place
 //      and its reads are put in (anchor, line) order (a PAF grouped by query is already in order there).
-int msgpu_assembly_set_rows(msgpu_assembly *a, const msgpu_row *rows, size_t n_rows) {
+static int install_rows(msgpu_assembly *a, const msgpu_row *rows, size_t n_rows, bool copy) {
   if (!a || (n_rows && !rows)) return MSGPU_E_ARG;
   if (n_rows >= 0xffffffffull) return MSGPU_E_ARG;
   try {
@@ -1038,7 +1038,8 @@ int msgpu_assembly_set_rows(msgpu_assembly *a, const msgpu_row *rows, size_t n_r
     };
     std::vector<uint32_t> cmax(nt, 0);
     std::vector<char>     asc(nt, 1); // chunk t's anchor ids never decrease (its first row compared with the row before it)
-    a->rows.resize(n_rows);
+    a->rows.resize(copy ? n_rows : 0);
+    a->rows_view = copy ? a->rows.data() : rows;
     a->row_recs.resize(0);
     a->row_start.clear();
     a->anchor_start.clear();
@@ -1052,7 +1053,7 @@ int msgpu_assembly_set_rows(msgpu_assembly *a, const msgpu_row *rows, size_t n_r
         up &= prev <= rows[i].anchor_id;
         prev = rows[i].anchor_id;
       }
-      if (e > b) memcpy(a->rows.data() + b, rows + b, (e - b) * sizeof(msgpu_row));
+      if (copy && e > b) memcpy(a->rows.data() + b, rows + b, (e - b) * sizeof(msgpu_row));
       cmax[t] = m;
       asc[t]  = up;
     });
@@ -1129,6 +1130,9 @@ int msgpu_assembly_set_rows(msgpu_assembly *a, const msgpu_row *rows, size_t n_r
   }
   return MSGPU_OK;
 }
+
+int msgpu_assembly_set_rows(msgpu_assembly *a, const msgpu_row *rows, size_t n_rows) { return install_rows(a, rows, n_rows, true); }
+int msgpu_assembly_borrow_rows(msgpu_assembly *a, const msgpu_row *rows, size_t n_rows) { return install_rows(a, rows, n_rows, false); }
 
 int msgpu_assembly_add_path(msgpu_assembly *a, const msgpu_path_input *in) {
   if (!a) return MSGPU_E_ARG;

@@ -344,12 +344,13 @@ def test_row_table_install_at_scale(oracle, tmp_path):
     assert np.all(np.diff(rows["anchor_id"].astype(np.int64)) >= 0)
     for name, table in (("grouped by anchor", rows), ("shuffled + duplicates", shuffled),
                         ("ascending anchors + duplicates", by_anchor), ("grouped by read + duplicates", by_read)):
-        got = Assembly(store)
-        got.set_rows(table)
-        status = got.add_prepared_batch([Assembly.prepare(p, st, None, None, k) for k, (p, st) in enumerate(paths)], 4)
-        assert not status.any(), name
-        assert got.text(2) == ref.text(2), name
-        assert got.pieces.tobytes() == ref.pieces.tobytes(), name
-        got.close()
+        for copy in (True, False):  # copied, or read where the caller keeps it (msgpu_assembly_borrow_rows)
+            got = Assembly(store)
+            got.set_rows(table, copy=copy)
+            status = got.add_prepared_batch([Assembly.prepare(p, st, None, None, k) for k, (p, st) in enumerate(paths)], 4)
+            assert not status.any(), name
+            assert got.text(2) == ref.text(2), name
+            assert got.pieces.tobytes() == ref.pieces.tobytes(), name
+            got.close()
     ref.close()
     store.close()
