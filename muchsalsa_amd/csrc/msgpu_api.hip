@@ -105,7 +105,7 @@ struct msgpu_ctx {
   bool   sub_wave  = true; // short edges share a wavefront (k_chain_sub); MSGPU_NO_SUBWAVE=1 sends them all to k_chain
   uint32_t n_cls[4] = {0, 0, 0, 0}; // edges of 9..16, 17..32, 33..64 and <= 8 EdgeMatches
   uint64_t n_edges_fast = 0;
-  DevBuf ems, order_scr, ids_scr, edge_norders, edge_nids, order_base, ids_base, orders, ids, big_list, cls_list, cls_part, big_elems,
+  DevBuf ems, order_scr, ids_scr, edge_norders, edge_nids, order_base, ids_base, orders, ids, big_list, cls_list, cls_part, cls_partials, big_elems,
       big_paths;
   DevBuf g_deg, g_off, g_adj, g_cand, g_sane, g_out; // findContractionEdges
 
@@ -214,7 +214,7 @@ void release_all(msgpu_ctx *c) {
                    &c->bound, &c->cand_off, &c->cand_j, &c->cand_t, &c->scr_v2, &c->scr_start, &c->n_cand, &c->n_edge,
                    &c->n_visit_arr, &c->lists, &c->em_base, &c->edge_base, &c->visit_base, &c->edges, &c->edge_cand,
                    &c->big_key, &c->big_t, &c->big_r2s, &c->big_pfx, &c->pair_tab, &c->edge_fast, &c->big_off, &c->ems, &c->order_scr, &c->ids_scr,
-                   &c->edge_norders, &c->edge_nids, &c->order_base, &c->ids_base, &c->orders, &c->ids, &c->big_list, &c->cls_list, &c->cls_part,
+                   &c->edge_norders, &c->edge_nids, &c->order_base, &c->ids_base, &c->orders, &c->ids, &c->big_list, &c->cls_list, &c->cls_part, &c->cls_partials,
                    &c->big_elems, &c->big_paths, &c->alt_edges, &c->alt_ems, &c->alt_orders, &c->alt_ids, &c->vis16, &c->visits,
                    &c->spos2};
   for (DevBuf *b : all) b->release();
@@ -664,13 +664,15 @@ int msgpu_calculate_edges(msgpu_ctx *c) {
                           c->big_r2s.as<uint32_t>(), c->big_pfx.as<uint32_t>());
   }
   // edges per width class of the chain kernels: they come back with the table sizes below
+  ENSURE(c, cls_partials, (size_t(count_classes_blocks(V)) + 1) * 16);
   launch_count_classes(st, c->n_edge.as<uint32_t>(), c->n_cand.as<uint32_t>(), c->cand_off.as<uint64_t>(),
-                       c->scr_start.as<uint32_t>(), V, scalar<uint32_t>(c, SC_CLS));
+                       c->scr_start.as<uint32_t>(), V, c->cls_partials.as<uint32_t>());
   {
     const uint32_t *const in[2]  = {c->n_cand.as<uint32_t>(), c->n_edge.as<uint32_t>()};
     uint64_t *const       out[2] = {c->em_base.as<uint64_t>(), c->edge_base.as<uint64_t>()};
     uint64_t *const       tot[2] = {scalar<uint64_t>(c, SC_TOTAL_A), scalar<uint64_t>(c, SC_TOTAL_B)};
-    exclusive_scan_set(st, 2, in, V, out, c->scan_tmp.as<uint64_t>(), tot);
+    exclusive_scan_set(st, 2, in, V, out, c->scan_tmp.as<uint64_t>(), tot, c->cls_partials.as<uint32_t>(),
+                       count_classes_blocks(V), scalar<uint32_t>(c, SC_CLS));
   }
   HIPCHK(c, hipGetLastError());
   if (int rc = publish_scalars(c)) return rc; // sizes of the edge / EdgeMatch tables, big-edge and width-class counts

@@ -95,8 +95,11 @@ struct MergeArgs {
 
 template <class T> void exclusive_scan(hipStream_t st, const uint32_t *in, uint64_t n, T *out, T *block_sums, T *d_total);
 // k <= 3 scans of the same length n in one pair of launches; block_sums holds k * (scan_blocks(n) + 1) words
+// optional rider: the four column sums of a [n_partials][4] table (16-byte aligned) go to partial_totals[0..3]
 void exclusive_scan_set(hipStream_t st, int k, const uint32_t *const *in, uint64_t n, uint64_t *const *out, uint64_t *block_sums,
-                        uint64_t *const *d_total);
+                        uint64_t *const *d_total, const uint32_t *partials = nullptr, uint32_t n_partials = 0,
+                        uint32_t *partial_totals = nullptr);
+uint32_t count_classes_blocks(uint32_t V);
 uint32_t scan_blocks(uint64_t n);
 
 void launch_max_ids(hipStream_t st, const msgpu_row *rows, uint64_t n, uint32_t *max_ids);
@@ -138,7 +141,7 @@ void launch_candidates(hipStream_t st, const CandArgs &a, int cls, const CandDes
 void launch_candidates_big(hipStream_t st, const CandArgs &a, const uint32_t *list, uint32_t n_list, uint64_t *big_key,
                            uint32_t *big_t, uint32_t *big_r2s, uint32_t *big_pfx);
 void launch_count_classes(hipStream_t st, const uint32_t *n_edge, const uint32_t *n_cand, const uint64_t *cand_off,
-                          const uint32_t *scr_start, uint32_t V, uint32_t *counts);
+                          const uint32_t *scr_start, uint32_t V, uint32_t *partials);
 void launch_emit_edges(hipStream_t st, const uint32_t *n_edge, const uint32_t *n_cand, const uint64_t *edge_base,
                        const uint64_t *em_base, const uint64_t *cand_off, const uint32_t *scr_v2,
                        const uint32_t *scr_start, uint32_t V, msgpu_edge *edges, uint64_t *edge_cand,

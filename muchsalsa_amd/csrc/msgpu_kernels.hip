@@ -225,9 +225,34 @@ template void exclusive_scan<uint64_t>(hipStream_t, const uint32_t *, uint64_t, 
 struct ScanSet {
   const uint32_t *in[3];
   uint64_t       *out[3], *sums[3], *total[3];
+  // a rider on the reduce launch (blockIdx.y = n_scans): column sums of a [n_partials][4] table of per-workgroup counts
+  // (k_count_classes), so that 1,500 workgroups need no atomics on four words
+  const uint32_t *partials;
+  uint32_t        n_partials, n_scans;
+  uint32_t       *partial_totals;
 };
 __global__ __launch_bounds__(256) void k_scan_reduce_set(ScanSet s, uint64_t n) {
   __shared__ uint64_t sh[4];
+  if (blockIdx.y == s.n_scans) { // the rider: four column sums
+    if (blockIdx.x != 0) return;
+    __shared__ uint32_t s_col[4][4];
+    uint32_t            c[4] = {0, 0, 0, 0};
+    for (uint32_t i = threadIdx.x; i < s.n_partials; i += 256) {
+      const uint4 p = reinterpret_cast<const uint4 *>(s.partials)[i];
+      c[0] += p.x;
+      c[1] += p.y;
+      c[2] += p.z;
+      c[3] += p.w;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      c[k] = wave_sum(c[k]);
+      if ((threadIdx.x & 63) == 0) s_col[k][threadIdx.x >> 6] = c[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) s.partial_totals[threadIdx.x] = s_col[threadIdx.x][0] + s_col[threadIdx.x][1] + s_col[threadIdx.x][2] + s_col[threadIdx.x][3];
+    return;
+  }
   const uint32_t     *in   = s.in[blockIdx.y];
   uint64_t            base = static_cast<uint64_t>(blockIdx.x) * 256 * SCAN_ITEMS;
   uint64_t            sum  = 0;
@@ -276,9 +301,13 @@ __global__ __launch_bounds__(256) void k_scan_apply_set(ScanSet s, uint64_t n) {
   }
 }
 void exclusive_scan_set(hipStream_t st, int k, const uint32_t *const *in, uint64_t n, uint64_t *const *out, uint64_t *block_sums,
-                        uint64_t *const *d_total) {
+                        uint64_t *const *d_total, const uint32_t *partials, uint32_t n_partials, uint32_t *partial_totals) {
   const uint32_t nb = scan_blocks(n ? n : 1);
   ScanSet        s{};
+  s.n_scans        = static_cast<uint32_t>(k);
+  s.partials       = partials;
+  s.n_partials     = n_partials;
+  s.partial_totals = partial_totals;
   for (int i = 0; i < k; ++i) {
     s.in[i]    = in[i];
     s.out[i]   = out[i];
@@ -290,9 +319,10 @@ void exclusive_scan_set(hipStream_t st, int k, const uint32_t *const *in, uint64
       (void)hipMemsetAsync(out[i], 0, 8, st);
       (void)hipMemsetAsync(d_total[i], 0, 8, st);
     }
+    if (partials) (void)hipMemsetAsync(partial_totals, 0, 16, st);
     return;
   }
-  hipLaunchKernelGGL(k_scan_reduce_set, dim3(nb, k), dim3(256), 0, st, s, n);
+  hipLaunchKernelGGL(k_scan_reduce_set, dim3(nb, k + (partials ? 1 : 0)), dim3(256), 0, st, s, n);
   hipLaunchKernelGGL(k_scan_apply_set, dim3(nb, k), dim3(256), 0, st, s, n);
 }
 
@@ -1283,23 +1313,23 @@ __global__ __launch_bounds__(256) void k_emit_edges(const uint32_t *n_edge, cons
 // scratch before the edges exist, so that the numbers come back with the table sizes and the chain stage needs no
 // read-back of its own.  counts[0..3] = 9..16, 17..32, 33..64, <= 8 (the order k_size_scan uses).
 __global__ __launch_bounds__(1024) void k_count_classes(const uint32_t *n_edge, const uint32_t *n_cand, const uint64_t *cand_off,
-                                                        const uint32_t *edge_scr_start, uint32_t V, uint32_t *counts) {
-  __shared__ uint32_t s_c[4];
-  if (threadIdx.x < 4) s_c[threadIdx.x] = 0;
-  __syncthreads();
+                                                        const uint32_t *edge_scr_start, uint32_t V, uint32_t *partials /*[blocks][4]*/) {
+  __shared__ uint32_t s_c[16][4];
   uint32_t  c8 = 0, c16 = 0, c32 = 0, c64 = 0;
-  const int sub = threadIdx.x & 15; // 16 lanes per read, as in k_emit_edges
-  for (uint32_t r = (blockIdx.x * 1024 + threadIdx.x) >> 4; r < V; r += gridDim.x * 64) {
+  const int sub = threadIdx.x & 15; // 16 lanes per read (as in k_emit_edges), 64 reads per workgroup, every read once
+  const uint32_t r = (blockIdx.x * 1024 + threadIdx.x) >> 4;
+  if (r < V) {
     const uint32_t ne = n_edge[r];
-    if (ne == 0) continue;
-    const uint32_t nc = n_cand[r];
-    const uint64_t co = cand_off[r];
-    for (uint32_t e = sub; e < ne; e += 16) {
-      const uint32_t st = edge_scr_start[co + e], en = (e + 1 < ne) ? edge_scr_start[co + e + 1] : nc, cnt = en - st;
-      c8 += (cnt >= 1 && cnt <= 8) ? 1u : 0u;
-      c16 += (cnt > 8 && cnt <= 16) ? 1u : 0u;
-      c32 += (cnt > 16 && cnt <= 32) ? 1u : 0u;
-      c64 += (cnt > 32 && cnt <= 64) ? 1u : 0u;
+    if (ne != 0) {
+      const uint32_t nc = n_cand[r];
+      const uint64_t co = cand_off[r];
+      for (uint32_t e = sub; e < ne; e += 16) {
+        const uint32_t st = edge_scr_start[co + e], en = (e + 1 < ne) ? edge_scr_start[co + e + 1] : nc, cnt = en - st;
+        c8 += (cnt >= 1 && cnt <= 8) ? 1u : 0u;
+        c16 += (cnt > 8 && cnt <= 16) ? 1u : 0u;
+        c32 += (cnt > 16 && cnt <= 32) ? 1u : 0u;
+        c64 += (cnt > 32 && cnt <= 64) ? 1u : 0u;
+      }
     }
   }
   c8  = wave_sum(c8);
@@ -1307,17 +1337,25 @@ __global__ __launch_bounds__(1024) void k_count_classes(const uint32_t *n_edge, 
   c32 = wave_sum(c32);
   c64 = wave_sum(c64);
   if ((threadIdx.x & 63) == 0) {
-    atomicAdd(&s_c[0], c16);
-    atomicAdd(&s_c[1], c32);
-    atomicAdd(&s_c[2], c64);
-    atomicAdd(&s_c[3], c8);
+    uint32_t *w = s_c[threadIdx.x >> 6];
+    w[0] = c16;
+    w[1] = c32;
+    w[2] = c64;
+    w[3] = c8;
   }
   __syncthreads();
-  if (threadIdx.x < 4 && s_c[threadIdx.x]) atomicAdd(&counts[threadIdx.x], s_c[threadIdx.x]);
+  if (threadIdx.x < 4) { // no atomics: the column sums are taken by the scan launch that follows (exclusive_scan_set)
+    uint32_t t = 0;
+    for (int w = 0; w < 16; ++w) t += s_c[w][threadIdx.x];
+    partials[blockIdx.x * 4 + threadIdx.x] = t;
+  }
 }
+uint32_t count_classes_blocks(uint32_t V) { return (V + 63) / 64; }
 void launch_count_classes(hipStream_t st, const uint32_t *n_edge, const uint32_t *n_cand, const uint64_t *cand_off,
-                          const uint32_t *scr_start, uint32_t V, uint32_t *counts) {
-  if (V) hipLaunchKernelGGL(k_count_classes, dim3(256), dim3(1024), 0, st, n_edge, n_cand, cand_off, scr_start, V, counts);
+                          const uint32_t *scr_start, uint32_t V, uint32_t *partials) {
+  if (V)
+    hipLaunchKernelGGL(k_count_classes, dim3(count_classes_blocks(V)), dim3(1024), 0, st, n_edge, n_cand, cand_off, scr_start, V,
+                       partials);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
