@@ -778,7 +778,7 @@ int msgpu_chaining_and_overlaps(msgpu_ctx *c) {
     launch_fill_pair_tab(st, c->pair_tab.as<uint32_t>());
   }
   a.pair_tab     = c->pair_tab.as<uint32_t>();
-  a.pair_tab64   = reinterpret_cast<const uint2 *>(c->pair_tab.as<uint32_t>() + 4 * PAIR_TAB_STRIDE);
+  a.pair_tab64   = c->pair_tab.as<uint32_t>() + 4 * PAIR_TAB_STRIDE;
   a.pair_tab_sub = c->pair_tab.as<uint32_t>() + 4 * PAIR_TAB_STRIDE + 2 * PAIR_TAB_STRIDE;
   ENSURE(c, edge_fast, (E + 1) * 4);
   {

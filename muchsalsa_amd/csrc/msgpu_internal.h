@@ -56,7 +56,7 @@ struct ChainArgs {
   uint32_t        *edge_norders, *edge_nids;
   uint32_t        *err;
   const uint32_t  *pair_tab; // four tables (sweep width 64, 32, 16, 8) of PAIR_TAB_STRIDE entries: k | l << 8 | run << 16
-  const uint2     *pair_tab64; // the width-64 table with every field k_chain's sweep needs ready to use (k_fill_pair_tab)
+  const uint32_t  *pair_tab64; // the width-64 table with every field k_chain's sweep needs ready to use (k_fill_pair_tab)
   const uint32_t  *pair_tab_sub; // the width-32 / 16 / 8 tables, 8 bytes per pair, in the form k_chain_sub's sweep consumes
   uint32_t        *edge_fast; // per edge: 1 if the all-pairs-compatible shortcut was taken (may be null)
   int              fast_path; // 0 disables the shortcut (every edge takes the full pair sweep)

@@ -1541,7 +1541,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
   // the occupancy
   static_assert(sizeof(ChainElem) * 64 == sizeof(PathRec) * 2 * 64, "the path lists overlay the element table");
   __shared__ __attribute__((aligned(16))) unsigned char s_wavebuf[4][sizeof(ChainElem) * 64];
-  __shared__ uint64_t                                  s_cm[4][64];
+  // the verdicts of the pair sweep, one 64-bit wavefront mask per step (pairs p0 .. p0 + 63): at most 32 steps (+ 2 words
+  // that the row extraction may touch past the last one)
+  __shared__ uint64_t                                  s_cm[4][34];
   const int      wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   // list == nullptr: wave i takes edge i; else the edges of the list (the 33..64 class of k_list_edges_by_size)
   const uint32_t slot = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(blockIdx.x * 4 + wave));
@@ -1563,7 +1565,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
   double   clo1 = 0, clo2 = 0, ovr1 = 0, ovr2 = 0, em_score = 0;
   bool     em_dir = false, em_prim = false;
   ChainElem x{};
-  cm[lane]        = 0;
   if (act) {
     j1               = a.cand_j[cp + lane];
     const uint32_t t = a.cand_t[cp + lane];
@@ -1688,12 +1689,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
   // the pair table through a buffer descriptor: scalar offset (the step) + constant lane offset, no vector address
   // arithmetic in the loop
   const __amdgpu_buffer_rsrc_t tab_rsrc =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<uint2 *>(a.pair_tab64), 0, PAIR_TAB_STRIDE * 8, 0x00020000);
-  const uint32_t tab_lane = static_cast<uint32_t>(lane) * 8u;
-  auto           load_pairs = [&](int p0) __attribute__((always_inline)) -> uint2 {
-    typedef int v2i __attribute__((ext_vector_type(2)));
-    const v2i   v = __builtin_amdgcn_raw_buffer_load_b64(tab_rsrc, tab_lane, p0 * 8, 0);
-    return make_uint2(static_cast<uint32_t>(v.x), static_cast<uint32_t>(v.y));
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(a.pair_tab64), 0, PAIR_TAB_STRIDE * 4, 0x00020000);
+  const uint32_t tab_lane = static_cast<uint32_t>(lane) * 4u;
+  auto           load_pairs = [&](int p0) __attribute__((always_inline)) -> uint32_t {
+    return static_cast<uint32_t>(__builtin_amdgcn_raw_buffer_load_b32(tab_rsrc, tab_lane, p0 * 4, 0));
   };
   // The scalar registers of this loop are all taken by pair masks; a loop-invariant scalar operand would be spilled and
   // re-read (v_readlane) in every step.  The one constant the common path compares with lives in a vector register.
@@ -1709,7 +1708,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
   // DIR: 0 = every EdgeMatch forward, 1 = every EdgeMatch reverse (the flip of mpp.cpp:131 is then the same for all
   // pairs and costs nothing), 2 = both directions present (pairs of one direction only, flip per pair).  The loop is
   // bound by SCALAR issue (the mask algebra), so everything wave-uniform is decided outside it: six instances.
-  auto sweep_step = [&](const uint2 kl, auto wft, auto dirt) __attribute__((always_inline)) {
+  auto sweep_step = [&](const int step, const uint32_t kl, auto wft, auto dirt) __attribute__((always_inline)) {
     typedef decltype(wft)  WFT;
     typedef decltype(dirt) DIRT;
     constexpr int          DIR = DIRT::value;
@@ -1720,14 +1719,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
       // one-direction edges need no "valid" mask at all
       M valid = ~0ull, KD = 0;
       if (DIR == 2) { // pairs of one direction only
-        const int  k = static_cast<int>((kl.x & 0xffffu) / 48u), l = static_cast<int>((kl.x >> 16) / 48u);
+        const int  k = static_cast<int>((kl & 0xffffu) / 48u), l = static_cast<int>((kl >> 16) / 48u);
         const bool kd = (m_plus >> k) & 1ull, ld = (m_plus >> l) & 1ull;
         valid = __ballot(kd == ld);
         KD    = __ballot(kd);
       }
       const unsigned char *elb = reinterpret_cast<const unsigned char *>(el);
-      const ChainElem      K = *reinterpret_cast<const ChainElem *>(elb + (kl.x & 0xffffu));
-      const ChainElem      L = *reinterpret_cast<const ChainElem *>(elb + (kl.x >> 16));
+      const ChainElem      K = *reinterpret_cast<const ChainElem *>(elb + (kl & 0xffffu));
+      const ChainElem      L = *reinterpret_cast<const ChainElem *>(elb + (kl >> 16));
       double          d1, d2;
       const NanoMasks f1 = nano_check<WFT::value, WFT::value>(K.clo1, K.chi1, L.clo1, L.chi1, K.rlo1, K.rhi1, L.rlo1, L.rhi1, d1);
       const NanoMasks f2 = nano_check<WFT::value, false>(K.clo2, K.chi2, L.clo2, L.chi2, K.rlo2, K.rhi2, L.rlo2, L.rhi2, d2);
@@ -1760,23 +1759,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
       }
       bits = ok;
     }
-    // the pairs of row l are consecutive lanes; the first lane of each stretch stores the stretch's bits
-    if (static_cast<int>(kl.y) < 0) { // run != 0: keep `run` bits from bit `lane` on and put them at bit k -- three shifts,
-                                      // the counts (64 - run, 64 - run - k) come from the table
-      uint64_t *row = reinterpret_cast<uint64_t *>(reinterpret_cast<unsigned char *>(cm) - 0x8000 + (kl.y >> 16));
-      *row |= ((bits >> lane) << (kl.y & 63u)) >> ((kl.y >> 8) & 63u);
-    }
+    // One lane parks the step's 64 verdicts; every lane cuts its own row out of the parked words after the sweep.  (The
+    // stretch of every row used to be shifted into place and OR-ed into the row's word by its first lane in every step:
+    // eight vector instructions per step instead of three.  The same change makes the sub-wavefront kernels slower --
+    // their registers are the tighter resource -- so they keep the per-step store.)  Lanes past the last pair evaluate
+    // the padding pair: their bits lie beyond every row.
+    if (lane == 0) cm[step] = bits;
   };
   auto sweep = [&](auto wft, auto dirt) __attribute__((always_inline)) {
     // two steps per trip, each with its own registers for the table entries: the next step's pairs are on their way
     // while this one computes, and nothing is copied from "next" to "current"
-    uint2 ka = load_pairs(0);
+    uint32_t ka = load_pairs(0);
     for (int p0 = 0; p0 < P; p0 += 128) {
-      const uint2 kb = load_pairs(p0 + 64);
-      sweep_step(ka, wft, dirt);
+      const uint32_t kb = load_pairs(p0 + 64);
+      sweep_step(p0 >> 6, ka, wft, dirt);
       if (p0 + 64 >= P) break;
       ka = load_pairs(p0 + 128);
-      sweep_step(kb, wft, dirt);
+      sweep_step((p0 >> 6) + 1, kb, wft, dirt);
     }
   };
   auto sweep_dir = [&](auto wft) __attribute__((always_inline)) {
@@ -1788,7 +1787,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
   else sweep_dir(std::false_type{});
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
-  const uint64_t mycm = cm[lane]; // bit k: checkCompatibility(k, lane) for k < lane of the same direction
+  // bit k of mycm: checkCompatibility(k, lane) for k < lane of the same direction = pair lane (lane - 1) / 2 + k: the row
+  // starts at bit b of word w and may run on into word w + 1 (bits past the row, and words past the last step, are
+  // masked off: they may hold anything)
+  uint64_t mycm = 0;
+  if (act && lane > 0 && P != 0) {
+    const int      pr = lane * (lane - 1) / 2, w = pr >> 6, b = pr & 63;
+    const uint64_t lo = cm[w] >> b, hi = (cm[w + 1] << 1) << (63 - b);
+    mycm              = (lo | hi) & ((1ull << lane) - 1ull);
+  }
 
   // ---- chaining DP (mpp.cpp:181-199), both directions at once: they never share a compatible pair -----------------
   double   pop = em_score;      // population[l].score
@@ -2904,17 +2911,12 @@ __global__ __launch_bounds__(64) void k_chain_big(ChainArgs a, const uint32_t *b
 // Pair tables: entry p = k | l << 8 | run << 16 | (64 - run - k) << 24 for the flattened pair index p = l(l-1)/2 + k, k < l < 64, where run
 // is the length of the stretch of row l that starts at lane p % W of a W-wide sweep step (0 if no stretch starts
 // there).  Four tables (W = 64, 32, 16, 8) of PAIR_TAB_STRIDE entries, each padded with (0, 1, 0).
-// The width-64 table once more, 8 bytes per pair, with the fields in the form k_chain's sweep consumes them (byte offsets
-// that an SDWA add takes as they are, the first shift count in the low six bits of its word):
-//   x = byte offset of element k in the wavefront's element array | byte offset of element l << 16
-//   y = (64 - run) & 63 | (64 - run - k) << 8 | (byte offset of row l in the compatibility rows + 0x8000 if run != 0) << 16
-//       (run != 0 is the sign of y; the 0x8000 it adds to the row offset is taken off the base the offset is added to)
+// The width-64 table once more, 4 bytes per pair, in the form k_chain's sweep consumes it (byte offsets that an SDWA add
+// takes as they are): byte offset of element k in the wavefront's element array | byte offset of element l << 16
 // (k and l themselves, which only mixed-direction edges need, are the offsets / 48)
 __device__ __forceinline__ void tab64_entry(uint32_t *tab, int p, int k, int l, int run) {
-  uint2 *t64 = reinterpret_cast<uint2 *>(tab + 4 * PAIR_TAB_STRIDE);
-  t64[p]     = make_uint2(static_cast<uint32_t>(k * 48) | (static_cast<uint32_t>(l * 48) << 16),
-                          (static_cast<uint32_t>(64 - run) & 63u) | (static_cast<uint32_t>((64 - run - k) & 63) << 8) |
-                              (static_cast<uint32_t>(l * 8 + (run ? 0x8000 : 0)) << 16));
+  (void)run;
+  tab[4 * PAIR_TAB_STRIDE + p] = static_cast<uint32_t>(k * 48) | (static_cast<uint32_t>(l * 48) << 16);
 }
 // The tables of the sub-wavefront kernels (W = 32, 16, 8) once more, 8 bytes per pair, in the form their sweep consumes:
 //   x = byte offset of element k in the group's elements | byte offset of element l << 16
