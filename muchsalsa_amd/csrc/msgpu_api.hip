@@ -643,14 +643,15 @@ int msgpu_calculate_edges(msgpu_ctx *c) {
   // the LDS classes run side by side: the heavier, smaller classes on the side stream, so their tails overlap
   static const bool no_fork = getenv("MSGPU_NO_FORK") != nullptr; // measurement switch: the classes one after the other
   const bool fork = (c->n_list[1] || c->n_list[2]) && c->n_list[0] && !no_fork;
-  if (fork) {
-    HIPCHK(c, hipEventRecord(c->ev_side[0], st));
-    HIPCHK(c, hipStreamWaitEvent(c->side_stream, c->ev_side[0], 0));
-  }
+  // (the main stream's kernel is launched first: the four host calls of the fork would otherwise stand in front of it;
+  // the side stream's workgroups have the higher priority and still finish first)
+  if (fork) HIPCHK(c, hipEventRecord(c->ev_side[0], st));
   hipStream_t st2 = fork ? c->side_stream : st;
+  if (fork) launch_candidates(st, a, 0, l0, c->n_list[0]);
+  if (fork) HIPCHK(c, hipStreamWaitEvent(c->side_stream, c->ev_side[0], 0));
   launch_candidates(st2, a, 2, l2, c->n_list[2]);
   launch_candidates(st2, a, 1, l1, c->n_list[1]);
-  launch_candidates(st, a, 0, l0, c->n_list[0]);
+  if (!fork) launch_candidates(st, a, 0, l0, c->n_list[0]);
   if (fork) {
     HIPCHK(c, hipEventRecord(c->ev_side[1], c->side_stream));
     HIPCHK(c, hipStreamWaitEvent(st, c->ev_side[1], 0));
@@ -803,11 +804,15 @@ int msgpu_chaining_and_overlaps(msgpu_ctx *c) {
     ENSURE(c, big_elems, (c->n_big_ems ? c->n_big_ems : 1) * big_elem_bytes());
     ENSURE(c, big_paths, (c->n_big_ems ? c->n_big_ems : 1) * 2 * big_path_bytes());
     HIPCHK(c, hipEventRecord(c->ev_side[0], st)); // (the list and the scratch offsets: k_emit_edges)
+  }
+  auto launch_big = [&]() -> int { // after the main stream's chain kernels are on their way (see msgpu_calculate_edges)
+    if (!n_big) return MSGPU_OK;
     HIPCHK(c, hipStreamWaitEvent(c->side_stream, c->ev_side[0], 0));
     launch_chain_big(c->side_stream, a, c->big_list.as<uint32_t>(), c->big_off.as<uint64_t>(), n_big,
                      c->big_elems.p, c->big_paths.p);
     HIPCHK(c, hipEventRecord(c->ev_side[1], c->side_stream));
-  }
+    return MSGPU_OK;
+  };
   if (c->sub_wave && E) {
     // the size-sorted edge list and the class sizes are there since msgpu_calculate_edges
     const uint32_t *list = c->cls_list.as<uint32_t>();
@@ -822,6 +827,7 @@ int msgpu_chaining_and_overlaps(msgpu_ctx *c) {
     launch_chain(st, a, nullptr, 0);
   }
   HIPCHK(c, hipEventRecord(ck_end, st));
+  if (int rc = launch_big()) return rc;
   c->ck_head = (c->ck_head + 1) % msgpu_ctx::CK_RING;
   if (c->ck_count < msgpu_ctx::CK_RING) ++c->ck_count;
   HIPCHK(c, hipGetLastError());
