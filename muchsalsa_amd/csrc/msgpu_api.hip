@@ -73,6 +73,7 @@ struct msgpu_ctx {
   uint64_t    *h_scalars = nullptr; // pinned, device-mapped mirror of `scalars` (+ one word: the read-back sequence number)
   uint64_t    *h_scalars_dev = nullptr; // the same memory as the device sees it
   bool         stage_events = true; // the stage boundaries are marked with events (msgpu_set_stage_events)
+  bool         chain_zeroed = false; // msgpu_calculate_edges zeroed the chain stage's per-edge counters
   bool         no_prologue = false; // msgpu_overlap_batched with several windows: every window has its own opening
   bool         prologue_ok = false; // the candidate stage's opening ran with the index build (whole table, fast index)
   uint64_t     prologue_bound = 0;
@@ -561,6 +562,20 @@ int msgpu_load_rows_device(msgpu_ctx *c, const void *d_rows, size_t n_rows) {
   return build_index(c);
 }
 
+// the per-edge counters of the chain stage (orders, ids, shortcut flag per edge), zeroed in one launch
+static int zero_chain_counters(msgpu_ctx *c, uint64_t E) {
+  ENSURE(c, edge_norders, (E + 1) * 4);
+  ENSURE(c, edge_nids, (E + 1) * 4);
+  ENSURE(c, edge_fast, (E + 1) * 4);
+  uint32_t *const zero[4]   = {c->edge_norders.as<uint32_t>(), c->edge_nids.as<uint32_t>(), c->edge_fast.as<uint32_t>(), nullptr};
+  const uint32_t  n_zero[4] = {static_cast<uint32_t>(E + 1), static_cast<uint32_t>(E + 1), static_cast<uint32_t>(E + 1), 0};
+  uint32_t *const ones[2]   = {nullptr, nullptr};
+  const uint32_t  n_ones[2] = {0, 0};
+  launch_index_init(c->stream, zero, n_zero, ones, n_ones);
+  HIPCHK(c, hipGetLastError());
+  return MSGPU_OK;
+}
+
 int msgpu_calculate_edges(msgpu_ctx *c) {
   if (!c) return MSGPU_E_ARG;
   if (c->state < ST_LOADED) return fail(c, MSGPU_E_STATE, "msgpu_calculate_edges before msgpu_load_rows");
@@ -727,6 +742,10 @@ int msgpu_calculate_edges(msgpu_ctx *c) {
     capacities(&cap_edges, &cap_big);
     emit_and_sort(cap_edges, cap_big);
   }
+  // the chain stage's per-edge counters are zeroed here, behind the size sort: msgpu_chaining_and_overlaps then starts
+  // with its kernels
+  if (int rc = zero_chain_counters(c, c->n_edges)) return rc;
+  c->chain_zeroed = true;
   HIPCHK(c, hipGetLastError());
   if (c->stage_events) HIPCHK(c, hipEventRecord(c->ev[3], st));
   c->have_cand_t = c->stage_events;
@@ -782,14 +801,9 @@ int msgpu_chaining_and_overlaps(msgpu_ctx *c) {
   a.pair_tab64   = c->pair_tab.as<uint32_t>() + 4 * PAIR_TAB_STRIDE;
   a.pair_tab_sub = c->pair_tab.as<uint32_t>() + 4 * PAIR_TAB_STRIDE + 2 * PAIR_TAB_STRIDE;
   ENSURE(c, edge_fast, (E + 1) * 4);
-  {
-    uint32_t *const zero[4]   = {c->edge_norders.as<uint32_t>(), c->edge_nids.as<uint32_t>(), c->edge_fast.as<uint32_t>(),
-                                 scalar<uint32_t>(c, SC_CLS)};
-    const uint32_t  n_zero[4] = {static_cast<uint32_t>(E + 1), static_cast<uint32_t>(E + 1), static_cast<uint32_t>(E + 1), 4};
-    uint32_t *const ones[2]   = {nullptr, nullptr};
-    const uint32_t  n_ones[2] = {0, 0};
-    launch_index_init(st, zero, n_zero, ones, n_ones);
-  }
+  if (!c->chain_zeroed) // (msgpu_calculate_edges left the per-edge counters zeroed; a second chaining pass zeroes them here)
+    if (int rc = zero_chain_counters(c, E)) return rc;
+  c->chain_zeroed = false;
   a.edge_fast    = c->edge_fast.as<uint32_t>();
   a.fast_path    = c->fast_path ? 1 : 0;
   a.wiggle       = static_cast<double>(c->p.wiggle_room);
