@@ -273,6 +273,27 @@ typedef struct msgpu_host_tables {
 } msgpu_host_tables;
 int msgpu_overlap_batched(msgpu_ctx *ctx, const msgpu_row *rows, size_t n_rows, uint32_t n_batches,
                           msgpu_host_tables *out);
+/* The same with options (flags = 0: msgpu_overlap_batched).
+ *   MSGPU_BATCH_RESIDENT        the job's four tables stay WHOLE in HBM (window k writes behind window k-1; 288 GB of HBM
+ *                               hold the 1 GB of BASELINE.json configs[2] many times over): no second table set, the
+ *                               compute stream never waits for a copy, and afterwards the context is in the state
+ *                               msgpu_chaining_and_overlaps leaves -- msgpu_find_contraction_edges, msgpu_copy_tables
+ *                               [_device], msgpu_get_edgematches and msgpu_get_counts work on the job's tables.
+ *   MSGPU_BATCH_NO_EDGEMATCHES  (implies RESIDENT) the EdgeMatch table is NOT copied to the host: out->ems = NULL,
+ *                               out->n_ems is still its size.  Downstream only assemblePath reads EdgeMatches, and only
+ *                               those of path edges (dg.cpp:99-101 -> ap.cpp:631-706): fetch them with
+ *                               msgpu_get_edgematches.  Moves 154 MB instead of 971 MB on configs[2]. */
+#define MSGPU_BATCH_RESIDENT 1u
+#define MSGPU_BATCH_NO_EDGEMATCHES 2u
+int msgpu_overlap_batched_ex(msgpu_ctx *ctx, const msgpu_row *rows, size_t n_rows, uint32_t n_batches, uint32_t flags,
+                             msgpu_host_tables *out);
+/* MatchMap::getEdgeMatches(edge) (libms/src/matching/MatchMap.cpp:136-159) for a LIST of edges, from the EdgeMatch table
+ * resident in HBM (after msgpu_chaining_and_overlaps or a resident msgpu_overlap_batched_ex): one gather kernel + one
+ * copy.  edge_idx[i] = index in the edge table.  *em_off (n + 1 entries) / *ems: the EdgeMatches of edge_idx[i] are
+ * (*ems)[(*em_off)[i] .. (*em_off)[i+1]), in table order (edge_idx of each record is unchanged).  Both arrays are pinned
+ * host memory owned by the context, valid until its next msgpu_get_edgematches / msgpu_destroy. */
+int msgpu_get_edgematches(msgpu_ctx *ctx, const uint32_t *edge_idx, size_t n, const uint64_t **em_off,
+                          const msgpu_edgematch **ems);
 /* page-locked host memory for rows handed to msgpu_load_rows / msgpu_overlap_batched (NULL when out of memory) */
 void *msgpu_pinned_alloc(size_t bytes);
 void  msgpu_pinned_free(void *p);
@@ -524,11 +545,19 @@ typedef struct msgpu_graph_stats {
   uint64_t n_vertices, n_edges; /* after the clean-up */
   uint64_t n_components, n_paths, n_path_reads;
 } msgpu_graph_stats;
-/* The four tables are BORROWED, not copied (the EdgeMatch table alone is 0.8 GB on BASELINE.json configs[2]): they must
- * stay valid and unchanged until msgpu_graph_free.  read_len / read_first_line are copied. */
+/* The four tables are COPIED (read_len / read_first_line always are).  ems = NULL (n_ems ignored): no EdgeMatch table on
+ * the host -- the graph stage itself never reads one; the EdgeMatches of the path edges, which assemblePath needs
+ * (dg.cpp:99-101), are supplied after msgpu_graph_linearize through msgpu_graph_path_edges + msgpu_get_edgematches +
+ * msgpu_graph_set_path_edgematches. */
 int  msgpu_graph_create(const msgpu_edge *edges, uint64_t n_edges, const msgpu_edgematch *ems, uint64_t n_ems,
                         const msgpu_order *orders, uint64_t n_orders, const uint32_t *ids, uint64_t n_ids,
                         const int32_t *read_len, const uint32_t *read_first_line, uint32_t n_reads, msgpu_graph **out);
+/* The same WITHOUT the copy: the four tables are borrowed (e.g. the pinned result of msgpu_overlap_batched; the EdgeMatch
+ * table alone is 0.8 GB on BASELINE.json configs[2]) and must stay valid and unchanged until msgpu_graph_free. */
+int  msgpu_graph_create_borrowed(const msgpu_edge *edges, uint64_t n_edges, const msgpu_edgematch *ems, uint64_t n_ems,
+                                 const msgpu_order *orders, uint64_t n_orders, const uint32_t *ids, uint64_t n_ids,
+                                 const int32_t *read_len, const uint32_t *read_first_line, uint32_t n_reads,
+                                 msgpu_graph **out);
 void msgpu_graph_free(msgpu_graph *g);
 const char *msgpu_graph_last_error(const msgpu_graph *g);
 /* rows (optional): the VertexMatch table, for contract()'s "getVertexMatch(start, id) != nullptr" (main.cpp:514-519);
@@ -540,6 +569,12 @@ int msgpu_graph_set_threads(msgpu_graph *g, uint32_t n_threads);
 int msgpu_graph_linearize(msgpu_graph *g);
 int msgpu_graph_get_stats(const msgpu_graph *g, msgpu_graph_stats *out);
 uint32_t msgpu_graph_path_count(const msgpu_graph *g);
+/* After msgpu_graph_linearize: the edge-table index of the edge under every path step, paths concatenated in path order
+ * (path i contributes n_reads_i - 1 entries); owned by the graph.  With a graph created without an EdgeMatch table, hand
+ * this list to msgpu_get_edgematches and its result to msgpu_graph_set_path_edgematches (copied) before
+ * msgpu_graph_path_input, which fails with MSGPU_E_STATE until then. */
+int msgpu_graph_path_edges(const msgpu_graph *g, const uint32_t **edge_idx, size_t *n);
+int msgpu_graph_set_path_edgematches(msgpu_graph *g, const uint64_t *em_off, const msgpu_edgematch *ems);
 /* path i (asm_idx = i) as assemblePath input; pointers are owned by the graph and valid until msgpu_graph_free;
  * rows / n_rows are left empty (use msgpu_assembly_set_rows). */
 int msgpu_graph_path_input(const msgpu_graph *g, uint32_t i, msgpu_path_input *out);

@@ -62,15 +62,20 @@ public:
   // BlastFileAccessor(path) + BlastFileReader::read() (src/main.cpp:153-156): parse, filter, register ids, then fill the
   // device-resident vertex / VertexMatch store.
   void read(std::string const &pafPath) {
+    parse(pafPath);
+    std::size_t      n    = 0;
+    msgpu_row const *rows = msgpu_paf_rows(m_paf, &n);
+    check(msgpu_load_rows(m_ctx, rows, n), m_ctx);
+  }
+  // The host half of read() alone (parse, filter, Registry ids): for callers that go on with overlapBatched() /
+  // overlapResident(), which carry the rows to HBM themselves.
+  void parse(std::string const &pafPath) {
     if (m_paf) {
       msgpu_paf_free(m_paf);
       m_paf = nullptr;
     }
     check(msgpu_parse_paf(pafPath.c_str(), &m_params, &m_paf), nullptr);
-    std::size_t      n    = 0;
-    msgpu_row const *rows = msgpu_paf_rows(m_paf, &n);
     check(msgpu_set_id_space(m_ctx, msgpu_paf_read_count(m_paf), msgpu_paf_anchor_count(m_paf)), m_ctx);
-    check(msgpu_load_rows(m_ctx, rows, n), m_ctx);
   }
   // Same from rows the caller already holds (Registry ids in first-line order).
   void addRows(msgpu_row const *rows, std::size_t n) {
@@ -101,6 +106,23 @@ public:
     t.readLength.assign(h.read_len, h.read_len + h.n_reads);
     t.readFirstLine.assign(h.read_first_line, h.read_first_line + h.n_reads);
     return t;
+  }
+
+  // The same with the job's tables kept whole in HBM and the EdgeMatch table left there (msgpu_overlap_batched_ex,
+  // MSGPU_BATCH_NO_EDGEMATCHES): edges / orders / ids / Vertex facts arrive as VIEWS of the context's pinned result memory
+  // (valid until the next overlap call on this object); findContractionEdges() and edgeMatchesOf() then work on the
+  // resident tables.  h.ems is null.
+  msgpu_host_tables overlapResident(unsigned nBatches = 0) {
+    std::size_t      n    = 0;
+    msgpu_row const *rows = msgpu_paf_rows(m_paf, &n);
+    msgpu_host_tables h;
+    check(msgpu_overlap_batched_ex(m_ctx, rows, n, nBatches, MSGPU_BATCH_NO_EDGEMATCHES, &h), m_ctx);
+    return h;
+  }
+  // MatchMap::getEdgeMatches(edge) for a list of edge-table indices, from the EdgeMatch table in HBM (views, valid until the
+  // next call): the EdgeMatches of edgeIdx[i] are ems[off[i] .. off[i + 1])
+  void edgeMatchesOf(std::uint32_t const *edgeIdx, std::size_t n, std::uint64_t const **off, msgpu_edgematch const **ems) {
+    check(msgpu_get_edgematches(m_ctx, edgeIdx, n, off, ems), m_ctx);
   }
 
   // Graph::getOrder() / Graph::getSize() as TRACEd at src/main.cpp:159
@@ -245,7 +267,7 @@ inline AssemblyCounts assemble(std::string const &contigsPaf, std::string const 
                                std::size_t wiggleRoom = 300, int device = 0) {
   AssemblyCounts n;
   OverlapCore    core(device, wiggleRoom);
-  core.read(contigsPaf); // :153-156
+  core.parse(contigsPaf); // :153-156 (the rows travel to HBM inside overlapResident below)
 
   struct Seq { // :161-163 -- needs only the Registry: the files are parsed (pure host work) on a second thread while the
                // GPU and the graph stage work; every HIP call stays on the calling thread (upload after the join)
@@ -282,27 +304,37 @@ inline AssemblyCounts assemble(std::string const &contigsPaf, std::string const 
     }
   } joiner{loader};
 
-  core.calculateEdges();                       // :157
-  core.chainingAndOverlaps();                  // :170-178
-  auto const contraction = core.findContractionEdges(); // :183-190
-  auto const t           = core.tables();
+  // :157 + :170-178 -- calculateEdges and the chainingAndOverlaps fan-out as windows of owner reads on two HIP streams (the
+  // ThreadPool replacement); the tables arrive in pinned host memory while later windows compute, the EdgeMatch table
+  // stays in HBM
+  msgpu_host_tables const t = core.overlapResident();
+  auto const contraction    = core.findContractionEdges(); // :183-190, on the resident tables
   std::size_t      nRows = 0;
   msgpu_row const *rows  = core.rows(&nRows);
-  n.rows = nRows, n.reads = t.readLength.size(), n.edges = t.edges.size(), n.orders = t.orders.size();
+  n.rows = nRows, n.reads = t.n_reads, n.edges = t.n_edges, n.orders = t.n_orders;
   for (auto c : contraction) n.contractionEdges += c >= 0;
 
   struct Graph { // :194-310
     msgpu_graph *g = nullptr;
     ~Graph() { msgpu_graph_free(g); }
   } graph;
-  detail::require(msgpu_graph_create(t.edges.data(), t.edges.size(), t.ems.data(), t.ems.size(), t.orders.data(),
-                                     t.orders.size(), t.ids.data(), t.ids.size(), t.readLength.data(),
-                                     t.readFirstLine.data(), static_cast<std::uint32_t>(t.readLength.size()), &graph.g),
-                  "msgpu_graph_create");
+  detail::require(msgpu_graph_create_borrowed(t.edges, t.n_edges, nullptr, 0, t.orders, t.n_orders, t.ids, t.n_ids,
+                                              t.read_len, t.read_first_line, t.n_reads, &graph.g),
+                  "msgpu_graph_create_borrowed"); // (views of core's pinned memory: core outlives graph)
   detail::require(msgpu_graph_clean_up(graph.g, contraction.data(), rows, nRows), "msgpu_graph_clean_up",
                   msgpu_graph_last_error(graph.g));
   msgpu_graph_set_threads(graph.g, threads ? threads : 1);
   detail::require(msgpu_graph_linearize(graph.g), "msgpu_graph_linearize", msgpu_graph_last_error(graph.g));
+  { // MatchMap::getEdgeMatches of the path edges (dg.cpp:99-101): the only EdgeMatches anything downstream reads
+    std::uint32_t const *pathEdges = nullptr;
+    std::size_t          nPathEdges = 0;
+    detail::require(msgpu_graph_path_edges(graph.g, &pathEdges, &nPathEdges), "msgpu_graph_path_edges");
+    std::uint64_t const   *emOff = nullptr;
+    msgpu_edgematch const *ems   = nullptr;
+    core.edgeMatchesOf(pathEdges, nPathEdges, &emOff, &ems);
+    detail::require(msgpu_graph_set_path_edgematches(graph.g, emOff, ems), "msgpu_graph_set_path_edgematches",
+                    msgpu_graph_last_error(graph.g));
+  }
 
   loader.join();
   if (loadError) std::rethrow_exception(loadError);

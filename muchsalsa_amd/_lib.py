@@ -47,6 +47,7 @@ E_IO, E_FORMAT, E_NUMBER, E_NOMEM, E_ARG, E_HIP, E_STATE, E_IDS, E_NODEVICE = -1
 E_LAYOUT = -10
 
 ORD_START_V1, ORD_CONTAINED, ORD_DIR, ORD_PRIMARY = 1, 2, 4, 8
+BATCH_RESIDENT, BATCH_NO_EDGEMATCHES = 1, 2
 
 
 class Params(C.Structure):
@@ -173,6 +174,11 @@ SYMBOLS = [
                                      C.c_void_p, C.c_uint64, C.c_void_p]),
     ("msgpu_graph_create", C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p,
                                      C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]),
+    ("msgpu_graph_create_borrowed", C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64,
+                                              C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint32,
+                                              C.POINTER(C.c_void_p)]),
+    ("msgpu_graph_path_edges", C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
+    ("msgpu_graph_set_path_edgematches", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     ("msgpu_graph_free", None, [C.c_void_p]),
     ("msgpu_graph_last_error", C.c_char_p, [C.c_void_p]),
     ("msgpu_graph_clean_up", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
@@ -191,6 +197,9 @@ SYMBOLS = [
     ("msgpu_graph_sort_topologically", C.c_int, [C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p,
                                                  C.POINTER(C.c_uint32)]),
     ("msgpu_overlap_batched", C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.POINTER(HostTables)]),
+    ("msgpu_overlap_batched_ex", C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32,
+                                           C.POINTER(HostTables)]),
+    ("msgpu_get_edgematches", C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     ("msgpu_pinned_alloc", C.c_void_p, [C.c_size_t]),
     ("msgpu_pinned_free", None, [C.c_void_p]),
     ("msgpu_index_lines", C.c_int, [C.c_char_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),

@@ -53,6 +53,19 @@ struct msgpu_assembly {
 };
 
 namespace msgpu {
+// Host memory for tables that travel to HBM (msgpu_api.hip): page-locked when a HIP device is present, so that the copy
+// runs at link speed; plain memory otherwise (parsing without a GPU).  Never null: throws std::bad_alloc.
+void *host_table_alloc(size_t bytes);
+void  host_table_free(void *p) noexcept;
+template <class T> struct HostTableAlloc { // std::allocator for such tables
+  using value_type = T;
+  HostTableAlloc() = default;
+  template <class U> HostTableAlloc(const HostTableAlloc<U> &) noexcept {}
+  T   *allocate(size_t n) { return static_cast<T *>(host_table_alloc(n * sizeof(T))); }
+  void deallocate(T *p, size_t) noexcept { host_table_free(p); }
+  template <class U> bool operator==(const HostTableAlloc<U> &) const noexcept { return true; }
+  template <class U> bool operator!=(const HostTableAlloc<U> &) const noexcept { return false; }
+};
 // Toggle::operator* (include/ms/types/Toggle.h:127-153): the product of two toggles is their XNOR
 inline bool toggle_mul(bool a, bool b) { return a == b; }
 // header lines of the FASTA records, reference spelling (ap.cpp:1035-1040, 1059-1066, 1118-1125, 1175-1182, 1309-1318)

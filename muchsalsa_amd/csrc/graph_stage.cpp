@@ -259,7 +259,14 @@ std::vector<uint32_t> sort_topologically(uint32_t n, const Csr &succ, const Csr 
 } // namespace
 
 struct msgpu_graph {
-  // tables (borrowed from the caller: valid until msgpu_graph_free)
+  // tables: the caller's (msgpu_graph_create_borrowed: valid until msgpu_graph_free) or copies held in own_* (msgpu_graph_create)
+  std::vector<msgpu_edge>      own_edges;
+  std::vector<msgpu_edgematch> own_ems;
+  std::vector<msgpu_order>     own_orders;
+  std::vector<uint32_t>        own_ids;
+  bool                         ems_on_demand = false; // no EdgeMatch table: msgpu_graph_set_path_edgematches supplies the path edges'
+  bool                         have_path_ems = false;
+  std::vector<uint32_t>        path_edges;            // table index of the edge under every path step, paths concatenated
   const msgpu_edge      *t_edges = nullptr;
   const msgpu_edgematch *t_ems   = nullptr;
   const msgpu_order     *t_orders = nullptr;
@@ -300,7 +307,7 @@ struct msgpu_graph {
   // paths + storage the msgpu_path_input views point into
   struct PathStore {
     std::vector<msgpu_path_read>    reads;
-    std::vector<uint32_t>           order_off, em_off, contain_anchors;
+    std::vector<uint32_t>           order_off, em_off, contain_anchors, step_edge; // step_edge: edge-table index per step
     std::vector<msgpu_path_order>   orders;
     std::vector<msgpu_path_em>      ems;
     std::vector<msgpu_path_contain> contains;
@@ -960,10 +967,12 @@ std::vector<msgpu_graph::PathStore> component_paths(msgpu_graph *g, uint32_t cid
         ps.orders.push_back(po);
       }
       const msgpu_edge &te = g->t_edges[dg.src[de]];
-      for (uint32_t k = 0; k < te.em_cnt; ++k) {
-        const msgpu_edgematch &m = g->t_ems[te.em_off + k];
-        ps.ems.push_back(msgpu_path_em{m.anchor_id, m.ov_lo, m.ov_hi});
-      }
+      ps.step_edge.push_back(dg.src[de]);
+      if (!g->ems_on_demand)
+        for (uint32_t k = 0; k < te.em_cnt; ++k) {
+          const msgpu_edgematch &m = g->t_ems[te.em_off + k];
+          ps.ems.push_back(msgpu_path_em{m.anchor_id, m.ov_lo, m.ov_hi});
+        }
       ps.order_off.push_back(static_cast<uint32_t>(ps.orders.size()));
       ps.em_off.push_back(static_cast<uint32_t>(ps.ems.size()));
     }
@@ -991,10 +1000,14 @@ std::vector<msgpu_graph::PathStore> component_paths(msgpu_graph *g, uint32_t cid
 
 extern "C" {
 
-int msgpu_graph_create(const msgpu_edge *edges, uint64_t n_edges, const msgpu_edgematch *ems, uint64_t n_ems,
-                       const msgpu_order *orders, uint64_t n_orders, const uint32_t *ids, uint64_t n_ids,
-                       const int32_t *read_len, const uint32_t *read_first_line, uint32_t n_reads, msgpu_graph **out) {
-  if (!out || (n_edges && !edges) || (n_ems && !ems) || (n_orders && !orders) || (n_ids && !ids) ||
+static int graph_create(const msgpu_edge *edges, uint64_t n_edges, const msgpu_edgematch *ems, uint64_t n_ems,
+                        const msgpu_order *orders, uint64_t n_orders, const uint32_t *ids, uint64_t n_ids,
+                        const int32_t *read_len, const uint32_t *read_first_line, uint32_t n_reads, bool copy,
+                        msgpu_graph **out) {
+  // ems == NULL (with edges that carry em_off / em_cnt): the EdgeMatch table stays where it is (HBM); the EdgeMatches of
+  // the path edges arrive later through msgpu_graph_set_path_edgematches
+  const bool on_demand = ems == nullptr;
+  if (!out || (n_edges && !edges) || (n_orders && !orders) || (n_ids && !ids) ||
       (n_reads && (!read_len || !read_first_line)) || n_edges >= 0x7ffffff0ull || n_orders >= 0xfffffff0ull ||
       n_ids >= 0xfffffff0ull)
     return MSGPU_E_ARG;
@@ -1002,6 +1015,17 @@ int msgpu_graph_create(const msgpu_edge *edges, uint64_t n_edges, const msgpu_ed
   try {
     Tick                         tick;
     std::unique_ptr<msgpu_graph> g(new msgpu_graph());
+    if (copy) {
+      g->own_edges.assign(edges, edges + n_edges);
+      g->own_orders.assign(orders, orders + n_orders);
+      g->own_ids.assign(ids, ids + n_ids);
+      if (!on_demand) g->own_ems.assign(ems, ems + n_ems);
+      edges  = g->own_edges.data();
+      orders = g->own_orders.data();
+      ids    = g->own_ids.data();
+      ems    = on_demand ? nullptr : g->own_ems.data();
+    }
+    g->ems_on_demand = on_demand;
     g->t_edges  = edges;
     g->t_ems    = ems;
     g->t_orders = orders;
@@ -1021,7 +1045,7 @@ int msgpu_graph_create(const msgpu_edge *edges, uint64_t n_edges, const msgpu_ed
     for (uint64_t i = 0; i < n_edges; ++i) {
       const msgpu_edge &e = edges[i];
       if (e.v1 >= n_reads || e.v2 >= n_reads || e.v1 == e.v2 || e.order_off + e.order_cnt > n_orders ||
-          e.em_off + e.em_cnt > n_ems)
+          (!on_demand && e.em_off + e.em_cnt > n_ems))
         return MSGPU_E_ARG;
       msgpu_graph::Edge &u = g->E[i];
       u.a       = e.v1;
@@ -1056,6 +1080,18 @@ int msgpu_graph_create(const msgpu_edge *edges, uint64_t n_edges, const msgpu_ed
     *out = g.release();
   } catch (std::bad_alloc const &) { return MSGPU_E_NOMEM; }
   return MSGPU_OK;
+}
+
+int msgpu_graph_create(const msgpu_edge *edges, uint64_t n_edges, const msgpu_edgematch *ems, uint64_t n_ems,
+                       const msgpu_order *orders, uint64_t n_orders, const uint32_t *ids, uint64_t n_ids,
+                       const int32_t *read_len, const uint32_t *read_first_line, uint32_t n_reads, msgpu_graph **out) {
+  return graph_create(edges, n_edges, ems, n_ems, orders, n_orders, ids, n_ids, read_len, read_first_line, n_reads, true, out);
+}
+int msgpu_graph_create_borrowed(const msgpu_edge *edges, uint64_t n_edges, const msgpu_edgematch *ems, uint64_t n_ems,
+                                const msgpu_order *orders, uint64_t n_orders, const uint32_t *ids, uint64_t n_ids,
+                                const int32_t *read_len, const uint32_t *read_first_line, uint32_t n_reads,
+                                msgpu_graph **out) {
+  return graph_create(edges, n_edges, ems, n_ems, orders, n_orders, ids, n_ids, read_len, read_first_line, n_reads, false, out);
 }
 
 void        msgpu_graph_free(msgpu_graph *g) { delete g; }
@@ -1293,6 +1329,8 @@ int msgpu_graph_linearize(msgpu_graph *g) {
         g->paths.push_back(std::move(ps));
       }
     g->stats.n_paths = g->paths.size();
+    g->path_edges.clear();
+    for (const auto &ps : g->paths) g->path_edges.insert(g->path_edges.end(), ps.step_edge.begin(), ps.step_edge.end());
     g->linearized    = true;
   } catch (std::bad_alloc const &) {
     return MSGPU_E_NOMEM;
@@ -1313,8 +1351,43 @@ uint32_t msgpu_graph_path_count(const msgpu_graph *g) { return g ? static_cast<u
 
 // path i as the input of msgpu_assembly_add_path(s); the pointers stay valid until msgpu_graph_free.  asm_idx = i
 // (the reference numbers assemblies 0, 1, ... in the order assemblePathsSub runs, src/main.cpp:300,673)
+int msgpu_graph_path_edges(const msgpu_graph *g, const uint32_t **edge_idx, size_t *n) {
+  if (!g || !edge_idx || !n) return MSGPU_E_ARG;
+  if (!g->linearized) return MSGPU_E_STATE;
+  *edge_idx = g->path_edges.data();
+  *n        = g->path_edges.size();
+  return MSGPU_OK;
+}
+
+// the EdgeMatches of msgpu_graph_path_edges' list (what msgpu_get_edgematches returns for it), copied into the path inputs
+int msgpu_graph_set_path_edgematches(msgpu_graph *g, const uint64_t *em_off, const msgpu_edgematch *ems) {
+  if (!g || (!g->path_edges.empty() && !em_off)) return MSGPU_E_ARG;
+  if (!g->linearized) return MSGPU_E_STATE;
+  try {
+    size_t step = 0;
+    for (auto &ps : g->paths) {
+      ps.ems.clear();
+      ps.em_off.assign(1, 0);
+      for (size_t k = 0; k < ps.step_edge.size(); ++k, ++step) {
+        const msgpu_edge &te = g->t_edges[ps.step_edge[k]];
+        if (em_off[step + 1] - em_off[step] != te.em_cnt || (te.em_cnt && !ems)) {
+          snprintf(g->err, sizeof(g->err), "EdgeMatch list of path step %zu has %llu entries, its edge %u", step,
+                   (unsigned long long)(em_off[step + 1] - em_off[step]), te.em_cnt);
+          return MSGPU_E_ARG;
+        }
+        for (uint64_t q = em_off[step]; q < em_off[step + 1]; ++q)
+          ps.ems.push_back(msgpu_path_em{ems[q].anchor_id, ems[q].ov_lo, ems[q].ov_hi});
+        ps.em_off.push_back(static_cast<uint32_t>(ps.ems.size()));
+      }
+    }
+  } catch (std::bad_alloc const &) { return MSGPU_E_NOMEM; }
+  g->have_path_ems = true;
+  return MSGPU_OK;
+}
+
 int msgpu_graph_path_input(const msgpu_graph *g, uint32_t i, msgpu_path_input *out) {
   if (!g || !out || i >= g->paths.size()) return MSGPU_E_ARG;
+  if (g->ems_on_demand && !g->have_path_ems) return MSGPU_E_STATE; // msgpu_graph_set_path_edgematches first
   const msgpu_graph::PathStore &p = g->paths[i];
   std::memset(out, 0, sizeof(*out));
   out->reads           = p.reads.data();

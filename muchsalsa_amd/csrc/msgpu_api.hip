@@ -13,50 +13,103 @@
 #include <cstring>
 #include <new>
 
+#include "asm_internal.h"
 #include "msgpu.h"
 #include "msgpu_internal.h"
 
 using namespace msgpu;
 
+// ---- host tables that travel to HBM (the PAF loader's row table): page-locked when there is a device ---------------------
+namespace msgpu {
+namespace {
+constexpr size_t   HT_HEADER = 64; // keeps the 64-byte alignment of the block; its first word says who allocated it
+constexpr uint64_t HT_PINNED = 0x6d7367707550494eull, HT_PLAIN = 0x6d736770754d414cull;
+} // namespace
+void *host_table_alloc(size_t bytes) {
+  static const bool have_device = [] {
+    int n = 0;
+    return hipGetDeviceCount(&n) == hipSuccess && n > 0;
+  }();
+  void *p = nullptr;
+  if (have_device && hipHostMalloc(&p, bytes + HT_HEADER, hipHostMallocPortable) == hipSuccess && p) {
+    *static_cast<uint64_t *>(p) = HT_PINNED;
+    return static_cast<char *>(p) + HT_HEADER;
+  }
+  if (posix_memalign(&p, 64, bytes + HT_HEADER) != 0 || !p) throw std::bad_alloc();
+  *static_cast<uint64_t *>(p) = HT_PLAIN;
+  return static_cast<char *>(p) + HT_HEADER;
+}
+void host_table_free(void *q) noexcept {
+  if (!q) return;
+  void *p = static_cast<char *>(q) - HT_HEADER;
+  if (*static_cast<uint64_t *>(p) == HT_PINNED) (void)hipHostFree(p);
+  else free(p);
+}
+} // namespace msgpu
+
 namespace {
 
 struct DevBuf {
-  void  *p   = nullptr;
-  size_t cap = 0;
-  hipError_t ensure(size_t bytes) {
-    if (bytes <= cap) return hipSuccess;
-    if (p) {
-      hipError_t e = hipFree(p);
+  void  *p   = nullptr; // the allocation
+  size_t cap = 0;       // its size in bytes
+  // A buffer can be used as a VIEW that starts `off` bytes into the allocation: the job-wide result tables of a
+  // resident batched run (msgpu_overlap_batched_ex) -- window k writes behind what the windows before it left, and a
+  // reallocation keeps those first `off` bytes.  off = 0 everywhere else.
+  size_t off  = 0;
+  size_t hint = 0; // expected final size of the allocation (bytes): a reallocation asks for at least this much
+  hipError_t ensure(size_t bytes) { // room for `bytes` behind `off`
+    if (off + bytes <= cap) return hipSuccess;
+    const size_t need = off + bytes;
+    size_t       want = need + need / 8 + 256; // slack so slowly growing inputs do not reallocate each run
+    if (hint > want) want = hint;
+    void      *np = nullptr;
+    hipError_t e;
+    if (p && !off) { // nothing to keep: give the old block back first
+      e   = hipFree(p);
       p   = nullptr;
       cap = 0;
       if (e != hipSuccess) return e;
     }
-    size_t want = bytes + bytes / 8 + 256; // slack so slowly growing inputs do not reallocate each run
-    hipError_t e = hipMalloc(&p, want);
-    if (e != hipSuccess) {
-      p = nullptr;
-      return e;
-    }
-    cap = want;
+    e = hipMalloc(&np, want);
+    if (e != hipSuccess) return e;
     // MSGPU_POISON=1 (debugging): fresh device memory is filled with 0xA5 so that a kernel which relies on zeroed scratch
     // fails every time instead of only when the allocator hands back recycled pages
     static const bool poison = std::getenv("MSGPU_POISON") != nullptr;
     if (poison) {
-      e = hipMemset(p, 0xA5, want); // null stream, may return before it ran: wait, the context's stream does not
+      e = hipMemset(np, 0xA5, want); // null stream, may return before it ran: wait, the context's stream does not
       if (e == hipSuccess) e = hipDeviceSynchronize();
-      if (e != hipSuccess) return e;
+      if (e != hipSuccess) {
+        (void)hipFree(np);
+        return e;
+      }
     }
+    if (p) { // a view that outgrew its allocation: everything in flight on the old block first, then its kept part moves
+      e = hipDeviceSynchronize();
+      if (e == hipSuccess) e = hipMemcpy(np, p, off, hipMemcpyDeviceToDevice);
+      if (e == hipSuccess) e = hipDeviceSynchronize();
+      if (e != hipSuccess) {
+        (void)hipFree(np);
+        return e;
+      }
+      (void)hipFree(p);
+    }
+    p   = np;
+    cap = want;
     return hipSuccess;
   }
   void release() {
     if (p) (void)hipFree(p);
     p   = nullptr;
     cap = 0;
+    off = hint = 0;
   }
-  template <class T> T *as() const { return static_cast<T *>(p); }
+  template <class T> T *as() const { return reinterpret_cast<T *>(static_cast<char *>(p) + off); }
+  void  *at() const { return static_cast<char *>(p) + off; }
+  size_t room() const { return cap > off ? cap - off : 0; } // bytes behind `off`
 };
 
-enum State { ST_CREATED = 0, ST_LOADED = 1, ST_EDGES = 2, ST_CHAINED = 3 };
+enum State { ST_CREATED = 0, ST_LOADED = 1, ST_EDGES = 2, ST_CHAINED = 3,
+             ST_RESULT = 4 /* the whole job's tables, built window by window (msgpu_overlap_batched_ex, resident): no per-edge scratch */ };
 
 } // namespace
 
@@ -109,6 +162,7 @@ struct msgpu_ctx {
   DevBuf ems, order_scr, ids_scr, edge_norders, edge_nids, order_base, ids_base, orders, ids, big_list, cls_list, cls_part, cls_partials, big_elems,
       big_paths;
   DevBuf g_deg, g_off, g_adj, g_cand, g_sane, g_out; // findContractionEdges
+  DevBuf sel_idx, sel_cnt, sel_off, sel_ems;          // msgpu_get_edgematches
 
   // batched execution (msgpu_overlap_batched): second set of output tables, copy stream, pinned result arena
   DevBuf      alt_edges, alt_ems, alt_orders, alt_ids;
@@ -117,7 +171,7 @@ struct msgpu_ctx {
   struct HostBuf {
     void  *p   = nullptr;
     size_t cap = 0;
-  } h_edges, h_ems, h_orders, h_ids, h_read_len, h_read_first;
+  } h_edges, h_ems, h_orders, h_ids, h_read_len, h_read_first, h_sel_off, h_sel_ems;
 
   // timing
   hipEvent_t ev[10] = {nullptr};
@@ -208,7 +262,7 @@ int read_scalars(msgpu_ctx *c, hipEvent_t mark = nullptr) {
 }
 
 void release_all(msgpu_ctx *c) {
-  DevBuf *all[] = {&c->g_deg, &c->g_off, &c->g_adj, &c->g_cand, &c->g_sane, &c->g_out, &c->rows_in, &c->cnt_read, &c->read_off, &c->cursor, &c->bkt_key,
+  DevBuf *all[] = {&c->sel_idx, &c->sel_cnt, &c->sel_off, &c->sel_ems, &c->g_deg, &c->g_off, &c->g_adj, &c->g_cand, &c->g_sane, &c->g_out, &c->rows_in, &c->cnt_read, &c->read_off, &c->cursor, &c->bkt_key,
                    &c->bkt_dead, &c->by_read, &c->read_cnt, &c->alive_rank, &c->anchor_cnt, &c->anchor_off,
                    &c->anchor_first, &c->anchor_off_gen,
                    &c->bkt2_idx, &c->bkt2_line, &c->by_anchor, &c->read_len, &c->read_first, &c->scalars, &c->scan_tmp,
@@ -504,7 +558,8 @@ void msgpu_destroy(msgpu_ctx *c) {
     if (c->ev_done[k]) (void)hipEventDestroy(c->ev_done[k]);
     if (c->ev_copied[k]) (void)hipEventDestroy(c->ev_copied[k]);
   }
-  for (msgpu_ctx::HostBuf *h : {&c->h_edges, &c->h_ems, &c->h_orders, &c->h_ids, &c->h_read_len, &c->h_read_first})
+  for (msgpu_ctx::HostBuf *h : {&c->h_edges, &c->h_ems, &c->h_orders, &c->h_ids, &c->h_read_len, &c->h_read_first, &c->h_sel_off,
+                               &c->h_sel_ems})
     if (h->p) (void)hipHostFree(h->p);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   if (c->h_scalars) (void)hipHostFree(c->h_scalars);
@@ -710,7 +765,7 @@ int msgpu_calculate_edges(msgpu_ctx *c) {
                                 c->cls_part.as<uint32_t>(), c->cls_list.as<uint32_t>(), scalar<uint32_t>(c, SC_CLS));
   };
   auto capacities = [&](uint64_t *cap_edges, uint64_t *cap_big) {
-    uint64_t ce = c->edges.cap / sizeof(msgpu_edge);
+    uint64_t ce = c->edges.room() / sizeof(msgpu_edge);
     if (c->edge_cand.cap / 8 < ce) ce = c->edge_cand.cap / 8;
     if (c->sub_wave && c->cls_list.cap / 4 < ce) ce = c->cls_list.cap / 4;
     uint64_t cb = c->big_list.cap / 4;
@@ -757,7 +812,8 @@ int msgpu_calculate_edges(msgpu_ctx *c) {
 
 int msgpu_chaining_and_overlaps(msgpu_ctx *c) {
   if (!c) return MSGPU_E_ARG;
-  if (c->state < ST_EDGES) return fail(c, MSGPU_E_STATE, "msgpu_chaining_and_overlaps before msgpu_calculate_edges");
+  if (c->state < ST_EDGES || c->state == ST_RESULT)
+    return fail(c, MSGPU_E_STATE, "msgpu_chaining_and_overlaps before msgpu_calculate_edges");
   HIPCHK(c, hipSetDevice(c->device));
   hipStream_t    st = c->stream;
   const uint64_t E = c->n_edges, M = c->n_ems;
@@ -872,11 +928,11 @@ int msgpu_chaining_and_overlaps(msgpu_ctx *c) {
     k.out_order_base = c->base_orders; // (a batched run: the earlier batches' counts, known to the caller)
     k.out_ids_base   = c->base_ids;
     k.out_edge_base  = static_cast<uint32_t>(c->base_edges);
-    k.cap_orders     = c->orders.cap / sizeof(msgpu_order);
-    k.cap_ids        = c->ids.cap / 4;
+    k.cap_orders     = c->orders.room() / sizeof(msgpu_order);
+    k.cap_ids        = c->ids.room() / 4;
     launch_compact(st, k);
   };
-  const uint64_t cap_orders = c->orders.cap / sizeof(msgpu_order), cap_ids = c->ids.cap / 4;
+  const uint64_t cap_orders = c->orders.room() / sizeof(msgpu_order), cap_ids = c->ids.room() / 4;
   const bool     speculated = cap_orders != 0 && cap_ids != 0;
   if (speculated) compact();
   HIPCHK(c, hipGetLastError());
@@ -955,10 +1011,10 @@ static int copy_tables(msgpu_ctx *c, void *edges, void *ems, void *orders, void 
     return fail(c, MSGPU_E_STATE, "EdgeMatch/order tables exist only after msgpu_chaining_and_overlaps");
   HIPCHK(c, hipSetDevice(c->device));
   hipStream_t st = c->stream;
-  if (edges && c->n_edges) HIPCHK(c, hipMemcpyAsync(edges, c->edges.p, c->n_edges * sizeof(msgpu_edge), kind, st));
-  if (ems && c->n_ems) HIPCHK(c, hipMemcpyAsync(ems, c->ems.p, c->n_ems * sizeof(msgpu_edgematch), kind, st));
-  if (orders && c->n_orders) HIPCHK(c, hipMemcpyAsync(orders, c->orders.p, c->n_orders * sizeof(msgpu_order), kind, st));
-  if (ids && c->n_ids) HIPCHK(c, hipMemcpyAsync(ids, c->ids.p, c->n_ids * 4, kind, st));
+  if (edges && c->n_edges) HIPCHK(c, hipMemcpyAsync(edges, c->edges.at(), c->n_edges * sizeof(msgpu_edge), kind, st));
+  if (ems && c->n_ems) HIPCHK(c, hipMemcpyAsync(ems, c->ems.at(), c->n_ems * sizeof(msgpu_edgematch), kind, st));
+  if (orders && c->n_orders) HIPCHK(c, hipMemcpyAsync(orders, c->orders.at(), c->n_orders * sizeof(msgpu_order), kind, st));
+  if (ids && c->n_ids) HIPCHK(c, hipMemcpyAsync(ids, c->ids.at(), c->n_ids * 4, kind, st));
   if (kind == hipMemcpyDeviceToHost) HIPCHK(c, hipStreamSynchronize(st));
   return MSGPU_OK;
 }
@@ -991,8 +1047,8 @@ int msgpu_find_contraction_edges(msgpu_ctx *c, const void *d_edges, uint64_t n_e
     if (c->state < ST_CHAINED) return fail(c, MSGPU_E_STATE, "msgpu_find_contraction_edges before msgpu_chaining_and_overlaps");
     if (c->nshards > 1)
       return fail(c, MSGPU_E_STATE, "a shard holds only its own edges: pass the merged tables (msgpu_merge_gathered)");
-    d_edges  = c->edges.p;
-    d_orders = c->orders.p;
+    d_edges  = c->edges.at();
+    d_orders = c->orders.at();
     n_edges  = c->n_edges;
     n_orders = c->n_orders;
     n_reads  = c->V;
@@ -1097,15 +1153,28 @@ int ensure_host(msgpu_ctx *c, msgpu_ctx::HostBuf &h, size_t need, size_t valid, 
 } // namespace
 
 int msgpu_overlap_batched(msgpu_ctx *c, const msgpu_row *rows, size_t n_rows, uint32_t n_batches, msgpu_host_tables *out) {
+  return msgpu_overlap_batched_ex(c, rows, n_rows, n_batches, 0, out);
+}
+
+int msgpu_overlap_batched_ex(msgpu_ctx *c, const msgpu_row *rows, size_t n_rows, uint32_t n_batches, uint32_t flags,
+                             msgpu_host_tables *out) {
   if (!c || !out) return MSGPU_E_ARG;
   memset(out, 0, sizeof(*out));
+  if (flags & ~(MSGPU_BATCH_RESIDENT | MSGPU_BATCH_NO_EDGEMATCHES)) return fail(c, MSGPU_E_ARG, "unknown flags %#x", flags);
+  if (flags & MSGPU_BATCH_NO_EDGEMATCHES) flags |= MSGPU_BATCH_RESIDENT; // (an EdgeMatch that is not copied must stay)
+  const bool resident = (flags & MSGPU_BATCH_RESIDENT) != 0, copy_ems = !(flags & MSGPU_BATCH_NO_EDGEMATCHES);
   const auto t_start = std::chrono::steady_clock::now();
   auto       ms_since = [&](std::chrono::steady_clock::time_point t0) {
     return std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
   };
+  DevBuf *const tabs[4] = {&c->edges, &c->ems, &c->orders, &c->ids};
+  auto reset_views = [&]() {
+    for (DevBuf *b : tabs) b->off = b->hint = 0;
+  };
   c->win_lo = 0;
   c->win_hi = 0xffffffffu;
   c->base_edges = c->base_ems = c->base_orders = c->base_ids = 0;
+  reset_views();
   c->no_prologue = (n_batches ? n_batches : 8) > 1; // several windows: each has its own scratch offsets and read lists
   const int rc_load = msgpu_load_rows(c, rows, n_rows); // rows host -> HBM once, index build once
   c->no_prologue    = false;
@@ -1136,7 +1205,7 @@ int msgpu_overlap_batched(msgpu_ctx *c, const msgpu_row *rows, size_t n_rows, ui
     uint64_t     v = static_cast<uint64_t>(x * double(V));
     return v > V ? V : static_cast<uint32_t>(v);
   };
-  uint64_t tot_e = 0, tot_m = 0, tot_o = 0, tot_i = 0;
+  uint64_t tot_e = 0, tot_m = 0, tot_o = 0, tot_i = 0, tot_fast = 0;
   int      rc = MSGPU_OK;
   for (uint32_t k = 0; k < B && rc == MSGPU_OK; ++k) {
     const int set = static_cast<int>(k & 1);
@@ -1146,8 +1215,27 @@ int msgpu_overlap_batched(msgpu_ctx *c, const msgpu_row *rows, size_t n_rows, ui
     c->base_ems    = tot_m;
     c->base_orders = tot_o;
     c->base_ids    = tot_i;
-    // this set of output tables was last read by the copy of batch k - 2
-    if (k >= 2) rc = hipStreamWaitEvent(st, c->ev_copied[set], 0) == hipSuccess ? MSGPU_OK : fail(c, MSGPU_E_HIP, "hipStreamWaitEvent failed");
+    // the share of the job's records the windows up to and including this one hold (used to extrapolate sizes)
+    const double share = double(c->win_hi) >= double(V) ? 1.0 : 1.0 - (1.0 - double(c->win_hi) / V) * (1.0 - double(c->win_hi) / V);
+    auto         hint  = [&](uint64_t have, size_t rec) {
+      return static_cast<size_t>(double(have) / (share > 0.02 ? share : 0.02) * 1.15) * rec;
+    };
+    if (resident) {
+      // the job's tables stay whole in HBM: this window writes behind the earlier ones
+      c->edges.off  = tot_e * sizeof(msgpu_edge);
+      c->ems.off    = tot_m * sizeof(msgpu_edgematch);
+      c->orders.off = tot_o * sizeof(msgpu_order);
+      c->ids.off    = tot_i * 4;
+      if (k) { // (what the windows so far produced, extrapolated to the job)
+        c->edges.hint  = hint(tot_e, sizeof(msgpu_edge));
+        c->ems.hint    = hint(tot_m, sizeof(msgpu_edgematch));
+        c->orders.hint = hint(tot_o, sizeof(msgpu_order));
+        c->ids.hint    = hint(tot_i, 4);
+      }
+    } else if (k >= 2) {
+      // this set of output tables was last read by the copy of batch k - 2
+      rc = hipStreamWaitEvent(st, c->ev_copied[set], 0) == hipSuccess ? MSGPU_OK : fail(c, MSGPU_E_HIP, "hipStreamWaitEvent failed");
+    }
     if (rc == MSGPU_OK) rc = msgpu_calculate_edges(c);
     if (rc == MSGPU_OK) rc = msgpu_chaining_and_overlaps(c);
     if (rc != MSGPU_OK) break;
@@ -1161,30 +1249,28 @@ int msgpu_overlap_batched(msgpu_ctx *c, const msgpu_row *rows, size_t n_rows, ui
     };
     guarded(hipEventRecord(c->ev_done[set], st), "hipEventRecord");
     // room in the pinned result tables; the expected job size is extrapolated from what the windows so far produced
-    const double share = double(c->win_hi) >= double(V) ? 1.0 : 1.0 - (1.0 - double(c->win_hi) / V) * (1.0 - double(c->win_hi) / V);
-    auto         hint  = [&](uint64_t have, size_t rec) {
-      return static_cast<size_t>(double(have) / (share > 0.02 ? share : 0.02) * 1.15) * rec;
-    };
     if (rc == MSGPU_OK) rc = ensure_host(c, c->h_edges, (tot_e + c->n_edges + 1) * sizeof(msgpu_edge), tot_e * sizeof(msgpu_edge), hint(tot_e + c->n_edges, sizeof(msgpu_edge)));
-    if (rc == MSGPU_OK) rc = ensure_host(c, c->h_ems, (tot_m + c->n_ems + 1) * sizeof(msgpu_edgematch), tot_m * sizeof(msgpu_edgematch), hint(tot_m + c->n_ems, sizeof(msgpu_edgematch)));
+    if (rc == MSGPU_OK && copy_ems) rc = ensure_host(c, c->h_ems, (tot_m + c->n_ems + 1) * sizeof(msgpu_edgematch), tot_m * sizeof(msgpu_edgematch), hint(tot_m + c->n_ems, sizeof(msgpu_edgematch)));
     if (rc == MSGPU_OK) rc = ensure_host(c, c->h_orders, (tot_o + c->n_orders + 1) * sizeof(msgpu_order), tot_o * sizeof(msgpu_order), hint(tot_o + c->n_orders, sizeof(msgpu_order)));
     if (rc == MSGPU_OK) rc = ensure_host(c, c->h_ids, (tot_i + c->n_ids + 1) * 4, tot_i * 4, hint(tot_i + c->n_ids, 4));
     if (rc != MSGPU_OK) break;
     guarded(hipStreamWaitEvent(cs, c->ev_done[set], 0), "hipStreamWaitEvent");
-    if (c->n_edges) guarded(hipMemcpyAsync(static_cast<msgpu_edge *>(c->h_edges.p) + tot_e, c->edges.p, c->n_edges * sizeof(msgpu_edge), hipMemcpyDeviceToHost, cs), "copy of the edge table");
-    if (c->n_ems) guarded(hipMemcpyAsync(static_cast<msgpu_edgematch *>(c->h_ems.p) + tot_m, c->ems.p, c->n_ems * sizeof(msgpu_edgematch), hipMemcpyDeviceToHost, cs), "copy of the EdgeMatch table");
-    if (c->n_orders) guarded(hipMemcpyAsync(static_cast<msgpu_order *>(c->h_orders.p) + tot_o, c->orders.p, c->n_orders * sizeof(msgpu_order), hipMemcpyDeviceToHost, cs), "copy of the order table");
-    if (c->n_ids) guarded(hipMemcpyAsync(static_cast<uint32_t *>(c->h_ids.p) + tot_i, c->ids.p, c->n_ids * 4, hipMemcpyDeviceToHost, cs), "copy of the id table");
+    if (c->n_edges) guarded(hipMemcpyAsync(static_cast<msgpu_edge *>(c->h_edges.p) + tot_e, c->edges.at(), c->n_edges * sizeof(msgpu_edge), hipMemcpyDeviceToHost, cs), "copy of the edge table");
+    if (c->n_ems && copy_ems) guarded(hipMemcpyAsync(static_cast<msgpu_edgematch *>(c->h_ems.p) + tot_m, c->ems.at(), c->n_ems * sizeof(msgpu_edgematch), hipMemcpyDeviceToHost, cs), "copy of the EdgeMatch table");
+    if (c->n_orders) guarded(hipMemcpyAsync(static_cast<msgpu_order *>(c->h_orders.p) + tot_o, c->orders.at(), c->n_orders * sizeof(msgpu_order), hipMemcpyDeviceToHost, cs), "copy of the order table");
+    if (c->n_ids) guarded(hipMemcpyAsync(static_cast<uint32_t *>(c->h_ids.p) + tot_i, c->ids.at(), c->n_ids * 4, hipMemcpyDeviceToHost, cs), "copy of the id table");
     guarded(hipEventRecord(c->ev_copied[set], cs), "hipEventRecord");
     tot_e += c->n_edges;
     tot_m += c->n_ems;
     tot_o += c->n_orders;
     tot_i += c->n_ids;
-    // the next batch writes the other set
-    std::swap(c->edges, c->alt_edges);
-    std::swap(c->ems, c->alt_ems);
-    std::swap(c->orders, c->alt_orders);
-    std::swap(c->ids, c->alt_ids);
+    tot_fast += c->n_edges_fast;
+    if (!resident) { // the next batch writes the other set
+      std::swap(c->edges, c->alt_edges);
+      std::swap(c->ems, c->alt_ems);
+      std::swap(c->orders, c->alt_orders);
+      std::swap(c->ids, c->alt_ids);
+    }
   }
   out->compute_done_ms = ms_since(t_start);
   // WaitGroup::wait(): every batch's tables are in host memory
@@ -1192,12 +1278,21 @@ int msgpu_overlap_batched(msgpu_ctx *c, const msgpu_row *rows, size_t n_rows, ui
   c->win_lo = 0;
   c->win_hi = 0xffffffffu;
   c->base_edges = c->base_ems = c->base_orders = c->base_ids = 0;
+  reset_views();
   c->state = ST_LOADED; // the context's own tables hold one batch only: results are the host tables
   if (rc != MSGPU_OK) return rc;
   HIPCHK(c, e1);
   HIPCHK(c, e2);
+  if (resident) { // ... or the whole job: the state msgpu_chaining_and_overlaps leaves, minus the per-edge scratch
+    c->n_edges      = tot_e;
+    c->n_ems        = tot_m;
+    c->n_orders     = tot_o;
+    c->n_ids        = tot_i;
+    c->n_edges_fast = tot_fast;
+    c->state        = ST_RESULT;
+  }
   out->edges           = static_cast<const msgpu_edge *>(c->h_edges.p);
-  out->ems             = static_cast<const msgpu_edgematch *>(c->h_ems.p);
+  out->ems             = copy_ems ? static_cast<const msgpu_edgematch *>(c->h_ems.p) : nullptr;
   out->orders          = static_cast<const msgpu_order *>(c->h_orders.p);
   out->ids             = static_cast<const uint32_t *>(c->h_ids.p);
   out->read_len        = static_cast<const int32_t *>(c->h_read_len.p);
@@ -1210,6 +1305,50 @@ int msgpu_overlap_batched(msgpu_ctx *c, const msgpu_row *rows, size_t n_rows, ui
   out->n_anchors       = c->A;
   out->n_batches       = B;
   out->wall_ms         = ms_since(t_start);
+  return MSGPU_OK;
+}
+
+// MatchMap::getEdgeMatches(edge) (libms/src/matching/MatchMap.cpp:136-159) for a list of edges, out of the EdgeMatch table
+// resident in HBM: what assemblePath reads of it (ap.cpp:631-706 via dg.cpp:99-101) is the EdgeMatches of the path edges.
+int msgpu_get_edgematches(msgpu_ctx *c, const uint32_t *edge_idx, size_t n, const uint64_t **em_off,
+                          const msgpu_edgematch **ems) {
+  if (!c || !em_off || !ems || (n && !edge_idx)) return MSGPU_E_ARG;
+  *em_off = nullptr;
+  *ems    = nullptr;
+  if (c->state < ST_CHAINED) return fail(c, MSGPU_E_STATE, "no EdgeMatch table resident (run the chaining stage first)");
+  if (n >= 0xfffffff0ull) return fail(c, MSGPU_E_ARG, "edge list too long");
+  for (size_t i = 0; i < n; ++i)
+    if (edge_idx[i] >= c->n_edges) return fail(c, MSGPU_E_ARG, "edge index %u out of range (%llu edges)", edge_idx[i], (unsigned long long)c->n_edges);
+  HIPCHK(c, hipSetDevice(c->device));
+  hipStream_t st = c->stream;
+  if (int rc = ensure_host(c, c->h_sel_off, (n + 1) * 8, 0, 0)) return rc;
+  uint64_t *h_off = static_cast<uint64_t *>(c->h_sel_off.p);
+  h_off[0]        = 0;
+  if (n) {
+    ENSURE(c, sel_idx, n * 4);
+    ENSURE(c, sel_cnt, (n + 1) * 4);
+    ENSURE(c, sel_off, (n + 2) * 8);
+    ENSURE(c, scan_tmp, 3 * (size_t(scan_blocks(n)) + 1) * 8);
+    HIPCHK(c, hipMemcpyAsync(c->sel_idx.p, edge_idx, n * 4, hipMemcpyHostToDevice, st));
+    launch_em_counts(st, c->edges.as<msgpu_edge>(), c->sel_idx.as<uint32_t>(), n, c->sel_cnt.as<uint32_t>());
+    exclusive_scan<uint64_t>(st, c->sel_cnt.as<uint32_t>(), n, c->sel_off.as<uint64_t>(), c->scan_tmp.as<uint64_t>(),
+                             c->sel_off.as<uint64_t>() + n + 1); // (out[n] = the total closes the offset list)
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(h_off, c->sel_off.p, (n + 1) * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+  }
+  const uint64_t total = h_off[n];
+  if (int rc = ensure_host(c, c->h_sel_ems, (total + 1) * sizeof(msgpu_edgematch), 0, 0)) return rc;
+  if (total) {
+    ENSURE(c, sel_ems, total * sizeof(msgpu_edgematch));
+    launch_em_gather(st, c->edges.as<msgpu_edge>(), c->ems.as<msgpu_edgematch>(), c->sel_idx.as<uint32_t>(), n,
+                     c->sel_off.as<uint64_t>(), c->sel_ems.as<msgpu_edgematch>());
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(c->h_sel_ems.p, c->sel_ems.p, total * sizeof(msgpu_edgematch), hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+  }
+  *em_off = h_off;
+  *ems    = static_cast<const msgpu_edgematch *>(c->h_sel_ems.p);
   return MSGPU_OK;
 }
 

@@ -166,6 +166,31 @@ __global__ __launch_bounds__(256) void k_pick_contraction(const msgpu_edge *edge
   out[e] = r;
 }
 
+// ---- MatchMap::getEdgeMatches for a list of edges (msgpu_get_edgematches) -------------------------------------------------
+__global__ __launch_bounds__(256) void k_em_counts(const msgpu_edge *edges, const uint32_t *sel, uint64_t n, uint32_t *cnt) {
+  const uint64_t i = blockIdx.x * 256ull + threadIdx.x;
+  if (i < n) cnt[i] = edges[sel[i]].em_cnt;
+}
+// one wavefront per listed edge: its EdgeMatches (32 B each, two 16-byte halves per lane) move to out[off[i] ...)
+__global__ __launch_bounds__(256) void k_em_gather(const msgpu_edge *edges, const msgpu_edgematch *ems, const uint32_t *sel,
+                                                   uint64_t n, const uint64_t *off, msgpu_edgematch *out) {
+  const uint64_t i = blockIdx.x * 4ull + (threadIdx.x >> 6);
+  if (i >= n) return;
+  const int        lane = threadIdx.x & 63;
+  const msgpu_edge e    = edges[sel[i]];
+  const uint4     *src  = reinterpret_cast<const uint4 *>(ems + e.em_off);
+  uint4           *dst  = reinterpret_cast<uint4 *>(out + off[i]);
+  for (uint32_t k = lane; k < 2 * e.em_cnt; k += 64) dst[k] = src[k];
+}
+
+void launch_em_counts(hipStream_t st, const msgpu_edge *edges, const uint32_t *sel, uint64_t n, uint32_t *cnt) {
+  if (n) hipLaunchKernelGGL(k_em_counts, dim3((n + 255) / 256), dim3(256), 0, st, edges, sel, n, cnt);
+}
+void launch_em_gather(hipStream_t st, const msgpu_edge *edges, const msgpu_edgematch *ems, const uint32_t *sel, uint64_t n,
+                      const uint64_t *off, msgpu_edgematch *out) {
+  if (n) hipLaunchKernelGGL(k_em_gather, dim3((n + 3) / 4), dim3(256), 0, st, edges, ems, sel, n, off, out);
+}
+
 void launch_degree(hipStream_t st, const msgpu_edge *edges, uint64_t n_edges, uint32_t *deg) {
   if (n_edges) hipLaunchKernelGGL(k_degree, dim3((n_edges + 255) / 256), dim3(256), 0, st, edges, n_edges, deg);
 }

@@ -171,6 +171,10 @@ void launch_check_contraction(hipStream_t st, const msgpu_edge *edges, uint64_t 
 void launch_pick_contraction(hipStream_t st, const msgpu_edge *edges, uint64_t n_edges, const uint8_t *sane,
                              int64_t *out);
 void launch_compact(hipStream_t st, const CompactArgs &a);
+// msgpu_get_edgematches: the EdgeMatches of a list of edges out of the resident table
+void launch_em_counts(hipStream_t st, const msgpu_edge *edges, const uint32_t *sel, uint64_t n, uint32_t *cnt);
+void launch_em_gather(hipStream_t st, const msgpu_edge *edges, const msgpu_edgematch *ems, const uint32_t *sel, uint64_t n,
+                      const uint64_t *off, msgpu_edgematch *out);
 
 } // namespace msgpu
 

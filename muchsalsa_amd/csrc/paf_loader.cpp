@@ -108,7 +108,7 @@ bool parse_int(const char *s, const char *e, int &out) {
 } // namespace
 
 struct msgpu_paf {
-  std::vector<msgpu_row> rows;
+  std::vector<msgpu_row, msgpu::HostTableAlloc<msgpu_row>> rows; // page-locked when a GPU is present: msgpu_load_rows / msgpu_overlap_batched copy it at link speed
   size_t                 n_lines = 0;
   NameRegistry           reads, anchors;
 };

@@ -4,6 +4,7 @@ getDirectedGraph and linearizeGraph -- everything between the overlap tables and
     g = GraphStage(tables, read_len, read_first_line)     # tables of OverlapContext.tables(), reads of .reads()
     g.clean_up(contraction_order, rows)                   # contraction_order from OverlapContext.find_contraction_edges
     g.linearize()
+    g.set_path_edgematches(*ctx.get_edgematches(g.path_edges()))   # only when tables["ems"] is None (EdgeMatches in HBM)
     for i in range(g.path_count): asm.add_prepared((g.path_input(i), g))
 """
 import ctypes as C
@@ -20,18 +21,22 @@ class GraphStage:
         self._L = _lib.lib()
         self._h = C.c_void_p()
         e = np.ascontiguousarray(tables["edges"], dtype=EDGE_DTYPE)
-        m = np.ascontiguousarray(tables["ems"], dtype=EM_DTYPE)
+        # ems None: the EdgeMatch table stayed in HBM; the path edges' EdgeMatches follow through set_path_edgematches
+        m = None if tables.get("ems") is None else np.ascontiguousarray(tables["ems"], dtype=EM_DTYPE)
         o = np.ascontiguousarray(tables["orders"], dtype=ORDER_DTYPE)
         i = np.ascontiguousarray(tables["ids"], dtype="<u4")
         rl = np.ascontiguousarray(read_len, dtype="<i4")
         fl = np.ascontiguousarray(read_first_line, dtype="<u4")
         self.n_edges, self.n_reads = len(e), len(rl)
-        self._tables = (e, m, o, i)  # msgpu_graph_create borrows the tables: they live as long as this object
+        self._tables = (e, m, o, i)  # msgpu_graph_create_borrowed: the tables live as long as this object
 
         def ptr(a):
-            return a.ctypes.data if len(a) else None
-        rc = self._L.msgpu_graph_create(ptr(e), len(e), ptr(m), len(m), ptr(o), len(o), ptr(i), len(i), ptr(rl), ptr(fl),
-                                        len(rl), C.byref(self._h))
+            return a.ctypes.data if a is not None and len(a) else None
+        if m is not None and len(m) == 0 and len(e):  # (a NULL EdgeMatch table means "on demand": keep an empty one apart)
+            m = np.zeros(1, dtype=EM_DTYPE)
+            self._tables = (e, m, o, i)
+        rc = self._L.msgpu_graph_create_borrowed(ptr(e), len(e), ptr(m), 0 if m is None else len(m), ptr(o), len(o),
+                                                 ptr(i), len(i), ptr(rl), ptr(fl), len(rl), C.byref(self._h))
         if rc != 0:
             self._h = C.c_void_p()
             raise MsgpuError(rc)
@@ -68,6 +73,19 @@ class GraphStage:
     @property
     def path_count(self):
         return int(self._L.msgpu_graph_path_count(self._h))
+
+    def path_edges(self):
+        """edge-table index of the edge under every path step, paths concatenated (msgpu_graph_path_edges)"""
+        p, n = C.c_void_p(), C.c_size_t()
+        self._check(self._L.msgpu_graph_path_edges(self._h, C.byref(p), C.byref(n)))
+        if not n.value:
+            return np.zeros(0, dtype="<u4")
+        return np.frombuffer(C.string_at(p.value, n.value * 4), dtype="<u4").copy()
+
+    def set_path_edgematches(self, em_off, ems):
+        off = np.ascontiguousarray(em_off, dtype="<u8")
+        m = np.ascontiguousarray(ems, dtype=EM_DTYPE)
+        self._check(self._L.msgpu_graph_set_path_edgematches(self._h, off.ctypes.data, m.ctypes.data if len(m) else None))
 
     def path_input(self, i):
         p = PathInput()

@@ -32,7 +32,9 @@ def default_params():
 
 
 class Paf:
-    """Result of msgpu_parse_paf: accepted rows + the two registries."""
+    """Result of msgpu_parse_paf: accepted rows + the two registries.  `rows` is a view of the loader's own table (no
+    copy): page-locked when a GPU is present, so msgpu_load_rows / msgpu_overlap_batched take it at link speed.  The
+    view (and every slice of it) keeps the loader's memory alive."""
 
     def __init__(self, rows, n_lines, read_names, anchor_names):
         self.rows = rows
@@ -41,25 +43,34 @@ class Paf:
         self.anchor_names = anchor_names
 
 
+class _PafHandle:
+    def __init__(self, L, h):
+        self._L, self._h = L, h
+
+    def __del__(self):
+        if self._h:
+            self._L.msgpu_paf_free(self._h)
+            self._h = None
+
+
 def parse_paf(path, params=None):
     L = _lib.lib()
     h = C.c_void_p()
     rc = L.msgpu_parse_paf(os.fsencode(path), C.byref(params) if params is not None else None, C.byref(h))
     if rc != 0:
         raise MsgpuError(rc, str(path))
-    try:
-        n = C.c_size_t()
-        ptr = L.msgpu_paf_rows(h, C.byref(n))
-        if n.value:
-            buf = (C.c_char * (n.value * ROW_DTYPE.itemsize)).from_address(ptr)
-            rows = np.frombuffer(buf, dtype=ROW_DTYPE, count=n.value).copy()
-        else:
-            rows = np.zeros(0, dtype=ROW_DTYPE)
-        rn = [L.msgpu_paf_read_name(h, i).decode() for i in range(L.msgpu_paf_read_count(h))]
-        an = [L.msgpu_paf_anchor_name(h, i).decode() for i in range(L.msgpu_paf_anchor_count(h))]
-        return Paf(rows, L.msgpu_paf_line_count(h), rn, an)
-    finally:
-        L.msgpu_paf_free(h)
+    owner = _PafHandle(L, h)
+    n = C.c_size_t()
+    ptr = L.msgpu_paf_rows(h, C.byref(n))
+    if n.value:
+        buf = (C.c_char * (n.value * ROW_DTYPE.itemsize)).from_address(ptr)
+        buf._owner = owner  # numpy keeps `buf` as the base of the view, and with it the loader's table
+        rows = np.frombuffer(buf, dtype=ROW_DTYPE, count=n.value)
+    else:
+        rows = np.zeros(0, dtype=ROW_DTYPE)
+    rn = [L.msgpu_paf_read_name(h, i).decode() for i in range(L.msgpu_paf_read_count(h))]
+    an = [L.msgpu_paf_anchor_name(h, i).decode() for i in range(L.msgpu_paf_anchor_count(h))]
+    return Paf(rows, L.msgpu_paf_line_count(h), rn, an)
 
 
 class PinnedRows:
@@ -166,15 +177,18 @@ class OverlapContext:
                                               ids.ctypes.data))
         return {"edges": edges, "ems": ems, "orders": orders, "ids": ids}
 
-    def overlap_batched(self, rows, n_batches=0, copy=True):
-        """msgpu_overlap_batched: rows (numpy table or PinnedRows) -> (tables, info).  The whole overlap path, host
+    def overlap_batched(self, rows, n_batches=0, copy=True, resident=False, edgematches=True):
+        """msgpu_overlap_batched[_ex]: rows (numpy table or PinnedRows) -> (tables, info).  The whole overlap path, host
         memory to host memory, as `n_batches` windows of owner reads with the copy of window k behind the compute of
         window k + 1.  tables = the dict of tables(), plus read_len / read_first_line; copy=False returns views of the
-        context's pinned result memory (valid until the next call)."""
+        context's pinned result memory (valid until the next call).  resident=True keeps the job's tables whole in HBM
+        (find_contraction_edges / get_edgematches / tables() then work on them); edgematches=False (implies resident)
+        leaves the EdgeMatch table there: tables["ems"] is None."""
         arr = rows.array if isinstance(rows, PinnedRows) else np.ascontiguousarray(rows, dtype=ROW_DTYPE)
         h = HostTables()
-        self._check(self._L.msgpu_overlap_batched(self._h, arr.ctypes.data if len(arr) else None, len(arr),
-                                                  int(n_batches), C.byref(h)))
+        flags = (_lib.BATCH_RESIDENT if resident else 0) | (0 if edgematches else _lib.BATCH_NO_EDGEMATCHES)
+        self._check(self._L.msgpu_overlap_batched_ex(self._h, arr.ctypes.data if len(arr) else None, len(arr),
+                                                     int(n_batches), flags, C.byref(h)))
 
         def view(ptr, n, dt):
             dt = np.dtype(dt)
@@ -182,13 +196,27 @@ class OverlapContext:
                 return np.zeros(0, dtype=dt)
             a = np.frombuffer((C.c_char * (n * dt.itemsize)).from_address(ptr), dtype=dt, count=n)
             return a.copy() if copy else a
-        t = {"edges": view(h.edges, h.n_edges, EDGE_DTYPE), "ems": view(h.ems, h.n_ems, EM_DTYPE),
+        t = {"edges": view(h.edges, h.n_edges, EDGE_DTYPE),
+             "ems": view(h.ems, h.n_ems, EM_DTYPE) if edgematches else None,
              "orders": view(h.orders, h.n_orders, ORDER_DTYPE), "ids": view(h.ids, h.n_ids, "<u4"),
              "read_len": view(h.read_len, h.n_reads, "<i4"), "read_first_line": view(h.read_first_line, h.n_reads, "<u4")}
         info = {"n_batches": h.n_batches, "wall_ms": h.wall_ms, "load_ms": h.load_ms,
                 "first_batch_ms": h.first_batch_ms, "compute_done_ms": h.compute_done_ms, "n_reads": h.n_reads,
-                "n_anchors": h.n_anchors}
+                "n_anchors": h.n_anchors, "n_ems": h.n_ems}
         return t, info
+
+    def get_edgematches(self, edge_idx, copy=True):
+        """msgpu_get_edgematches: MatchMap::getEdgeMatches for a list of edge-table indices, out of the EdgeMatch table
+        resident in HBM -> (em_off [n + 1], ems)"""
+        idx = np.ascontiguousarray(edge_idx, dtype="<u4")
+        p_off, p_ems = C.c_void_p(), C.c_void_p()
+        self._check(self._L.msgpu_get_edgematches(self._h, idx.ctypes.data if len(idx) else None, len(idx),
+                                                  C.byref(p_off), C.byref(p_ems)))
+        off = np.frombuffer((C.c_char * ((len(idx) + 1) * 8)).from_address(p_off.value), dtype="<u8", count=len(idx) + 1)
+        n = int(off[-1])
+        ems = (np.frombuffer((C.c_char * (n * EM_DTYPE.itemsize)).from_address(p_ems.value), dtype=EM_DTYPE, count=n)
+               if n else np.zeros(0, dtype=EM_DTYPE))
+        return (off.copy(), ems.copy()) if copy else (off, ems)
 
     def copy_tables_device(self, d_edges=None, d_ems=None, d_orders=None, d_ids=None):
         self._check(self._L.msgpu_copy_tables_device(self._h, C.c_void_p(d_edges), C.c_void_p(d_ems),

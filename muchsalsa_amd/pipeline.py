@@ -2,9 +2,9 @@
 temp_1.target.fa / temp_1.query.fa / temp_1.align.paf.
 
     stage (reference, src/main.cpp)                     here
-    :153-157 BlastFileReader::read + calculateEdges      parse_paf (host) + OverlapContext (HIP)
+    :153-157 BlastFileReader::read + calculateEdges      parse_paf (host) + OverlapContext.overlap_batched (HIP: the
+    :170-178 chainingAndOverlaps fan-out                   ThreadPool replacement, EdgeMatch table left in HBM)
     :161-163 SequenceAccessor::buildIndex                SeqFile (host parse) + SeqStore.upload (HBM)
-    :170-178 chainingAndOverlaps fan-out                 OverlapContext.chaining_and_overlaps (HIP)
     :183-190 findContractionEdges                        OverlapContext.find_contraction_edges (HIP)
     :194-288 contraction, deletions, bitweight, MST, decycle   GraphStage.clean_up (host)
     :300-310 components -> getDirectedGraph -> linearizeGraph   GraphStage.linearize (host)
@@ -33,7 +33,8 @@ def _registry_ids(seqfile, names):
     return ids, len(reg)
 
 
-def run(contigs_paf, unitigs_path, nanopore_path, out_dir, threads=None, wiggle_room=300, device=0, timings=None):
+def run(contigs_paf, unitigs_path, nanopore_path, out_dir, threads=None, wiggle_room=300, device=0, timings=None,
+        batches=8):
     """-> dict of counts; writes the three output files into out_dir (created by the caller, Application.cpp:65-82)."""
     t = {}
     n_threads = int(threads) if threads else max(1, min(16, os.cpu_count() or 1))
@@ -64,21 +65,24 @@ def run(contigs_paf, unitigs_path, nanopore_path, out_dir, threads=None, wiggle_
     t0 = time.perf_counter()
     ctx = overlap.OverlapContext(device=device, params=params)
     ctx.set_id_space(len(paf.read_names), len(paf.anchor_names))
-    ctx.load_rows(paf.rows)
-    ctx.calculate_edges()
-    ctx.chaining_and_overlaps()
-    contraction = ctx.find_contraction_edges()
-    tables = ctx.tables()
-    read_len, read_first = ctx.reads()
+    # the ThreadPool replacement (msgpu_overlap_batched_ex): rows -> HBM once, windows of owner reads on two streams, the
+    # edge / order / id tables arrive in pinned host memory while later windows compute.  The EdgeMatch table (5/6 of the
+    # bytes) stays in HBM: the graph stage never reads it, assemblePath only the path edges' (fetched below).
+    tables, _ = ctx.overlap_batched(paf.rows, batches, copy=False, resident=True, edgematches=False)
     counts = ctx.counts()
-    ctx.close()
     t["overlap_gpu"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    contraction = ctx.find_contraction_edges()
+    t["contraction_gpu"] = time.perf_counter() - t0
 
     t0 = time.perf_counter()
-    g = GraphStage(tables, read_len, read_first)
+    g = GraphStage(tables, tables["read_len"], tables["read_first_line"])
     g.clean_up(contraction, paf.rows)
     g.linearize(n_threads)
     t["graph_host"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    g.set_path_edgematches(*ctx.get_edgematches(g.path_edges(), copy=False))  # MatchMap::getEdgeMatches of the path edges
+    t["path_edgematches"] = time.perf_counter() - t0
 
     t0 = time.perf_counter()
     loader.join()
@@ -97,6 +101,9 @@ def run(contigs_paf, unitigs_path, nanopore_path, out_dir, threads=None, wiggle_
     asm.set_rows(paf.rows)
     status = asm.add_prepared_batch([(g.path_input(i), g) for i in range(g.path_count)], n_threads) \
         if g.path_count else np.zeros(0, dtype=np.int32)
+    st = g.stats
+    g.close()
+    ctx.close()  # (the graph had borrowed the context's pinned result tables: the context outlives it)
     asm.finish()
     t["assemble"] = time.perf_counter() - t0
 
@@ -105,7 +112,6 @@ def run(contigs_paf, unitigs_path, nanopore_path, out_dir, threads=None, wiggle_
         with open(os.path.join(out_dir, name), "wb") as f:
             f.write(asm.text(which))
     t["write"] = time.perf_counter() - t0
-    st = g.stats
     info = asm.paths
     out = {"rows": len(paf.rows), "reads": int(counts.n_reads), "anchors": int(counts.n_anchors),
            "edges": int(counts.n_edges), "orders": int(counts.n_orders),

@@ -88,3 +88,90 @@ def test_batched_cfg2_full_size(oracle):
         print("cfg2 batched: cold %.2f ms, warm %.2f ms (load %.2f, first batch at %.2f, compute done at %.2f)" % (
             info["wall_ms"], info2["wall_ms"], info2["load_ms"], info2["first_batch_ms"], info2["compute_done_ms"]))
         pinned.close()
+
+
+def _host_edgematches_of(t, idx):
+    e = t["edges"][idx]
+    off = np.concatenate([[0], np.cumsum(e["em_cnt"].astype(np.uint64))]).astype("<u8")
+    parts = [t["ems"][int(o): int(o) + int(c)] for o, c in zip(e["em_off"], e["em_cnt"])]
+    return off, (np.concatenate(parts) if parts else np.zeros(0, dtype=t["ems"].dtype))
+
+
+def test_resident_run_leaves_the_job_tables_in_hbm(oracle):
+    """msgpu_overlap_batched_ex(MSGPU_BATCH_RESIDENT): same host tables, and afterwards the context holds the WHOLE job's
+    tables like a single pass does -- copy_tables, find_contraction_edges and get_edgematches work on them.
+    MSGPU_BATCH_NO_EDGEMATCHES: the EdgeMatch table is not copied; any edge's EdgeMatches come on demand."""
+    from muchsalsa_amd import _lib, overlap, synth
+    rows = synth.synth_rows(2000, 5000, 10000, 7)
+    want = oracle.overlap(rows)
+    want_co = oracle.find_contraction_edges(want, len(want["read_len"]))
+    rng = np.random.default_rng(3)
+    with overlap.OverlapContext(0) as ctx:
+        for b in (1, 3, 8, 37):
+            got, info = ctx.overlap_batched(rows, b, resident=True)
+            assert_tables_equal(got, want, "resident, %d windows: host tables" % b)
+            assert_tables_equal(ctx.tables(), want, "resident, %d windows: the context's own tables" % b)
+            c = ctx.counts()
+            assert (c.n_edges, c.n_ems, c.n_orders, c.n_ids) == tuple(len(want[k]) for k in ("edges", "ems", "orders", "ids"))
+            assert np.array_equal(ctx.find_contraction_edges(), want_co)
+            with pytest.raises(overlap.MsgpuError) as e:  # no per-edge scratch of the whole job: chaining needs its stage
+                ctx.chaining_and_overlaps()
+            assert e.value.code == _lib.E_STATE
+        got, info = ctx.overlap_batched(overlap.PinnedRows(rows), 5, resident=True, edgematches=False, copy=False)
+        assert got["ems"] is None and info["n_ems"] == len(want["ems"])
+        for k in ("edges", "orders", "ids"):
+            assert got[k].tobytes() == want[k].tobytes(), k
+        idx = np.concatenate([[0, len(want["edges"]) - 1], rng.integers(0, len(want["edges"]), 700)]).astype("<u4")
+        off, ems = ctx.get_edgematches(idx)
+        w_off, w_ems = _host_edgematches_of(want, idx)
+        assert np.array_equal(off, w_off) and ems.tobytes() == w_ems.tobytes()
+        off, ems = ctx.get_edgematches(np.zeros(0, dtype="<u4"))
+        assert list(off) == [0] and len(ems) == 0
+        with pytest.raises(overlap.MsgpuError) as e:
+            ctx.get_edgematches([len(want["edges"])])
+        assert e.value.code == _lib.E_ARG
+        assert np.array_equal(ctx.find_contraction_edges(), want_co)
+        # the ordinary call sequence afterwards, and the on-demand fetch from ITS resident table
+        ctx.load_rows(rows)
+        with pytest.raises(overlap.MsgpuError) as e:
+            ctx.get_edgematches([0])
+        assert e.value.code == _lib.E_STATE
+        ctx.calculate_edges()
+        ctx.chaining_and_overlaps()
+        assert_tables_equal(ctx.tables(), want, "single pass after resident runs")
+        off, ems = ctx.get_edgematches(idx[:50])
+        w_off, w_ems = _host_edgematches_of(want, idx[:50])
+        assert np.array_equal(off, w_off) and ems.tobytes() == w_ems.tobytes()
+        # windows of a shard, resident; big edges (side stream) resident
+        full = oracle.overlap(synth.synth_rows(1000, 5000, 4000, 13))
+        ctx.set_shard(2, 3)
+        got, _ = ctx.overlap_batched(synth.synth_rows(1000, 5000, 4000, 13), 4, resident=True)
+        from muchsalsa_amd import distributed as D
+        assert_tables_equal(got, D.shard_view_host(full, 2, 3), "resident windows of shard 2/3")
+        assert_tables_equal(ctx.tables(), D.shard_view_host(full, 2, 3), "... and the context's tables")
+        ctx.set_shard(0, 1)
+        dense, _, _ = synth.accepted_rows(synth.paf_table(400, 4000, 120, 6, coverage=200))
+        wd = oracle.overlap(dense)
+        got, _ = ctx.overlap_batched(dense, 6, resident=True, edgematches=False)
+        assert_tables_equal(dict(got, ems=ctx.tables()["ems"]), wd, "big edges, resident")
+        big = np.nonzero(wd["edges"]["em_cnt"] > 64)[0].astype("<u4")
+        off, ems = ctx.get_edgematches(big)
+        w_off, w_ems = _host_edgematches_of(wd, big)
+        assert len(big) and np.array_equal(off, w_off) and ems.tobytes() == w_ems.tobytes()
+
+
+def test_resident_cfg2_full_size_and_first_call_growth(oracle):
+    """cfg2 at full size on a FRESH context: the job tables grow window by window (the kept part of a view moves on
+    reallocation) and still come out bit-exact; a warm second call allocates nothing."""
+    from muchsalsa_amd import overlap, synth
+    rows = synth.synth_rows(**synth.CONFIGS["cfg2"])
+    want = oracle.overlap(rows)
+    with overlap.OverlapContext(0) as ctx:
+        pinned = overlap.PinnedRows(rows)
+        got, cold = ctx.overlap_batched(pinned, 8, resident=True, edgematches=False)
+        assert_tables_equal(dict(got, ems=ctx.tables()["ems"]), want, "cfg2 resident, cold")
+        got, warm = ctx.overlap_batched(pinned, 8, resident=True, edgematches=False, copy=False)
+        assert_tables_equal(dict(got, ems=ctx.tables()["ems"]), want, "cfg2 resident, warm")
+        print("cfg2 resident without EdgeMatches: cold %.2f ms, warm %.2f ms (load %.2f, compute done at %.2f)" % (
+            cold["wall_ms"], warm["wall_ms"], warm["load_ms"], warm["compute_done_ms"]))
+        pinned.close()

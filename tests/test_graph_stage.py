@@ -202,3 +202,81 @@ def test_graph_stage_on_random_graphs(oracle):
     for k in ("cycle_cut", "decycle", "decycle_weak_tree_edge", "short_path_dropped", "two_way_edge"):
         assert G.COVER.get(k, 0) > 0, "branch never reached: " + k
     assert n_ok > 200 and n_paths > 300, (n_ok, n_rejected, n_paths)
+
+
+def _host_edgematches_of(t, idx):
+    """what msgpu_get_edgematches returns for a list of edge-table indices, stated on the host tables"""
+    e = t["edges"][idx]
+    off = np.concatenate([[0], np.cumsum(e["em_cnt"].astype(np.uint64))]).astype("<u8")
+    parts = [t["ems"][int(o): int(o) + int(c)] for o, c in zip(e["em_off"], e["em_cnt"])]
+    return off, (np.concatenate(parts) if parts else np.zeros(0, dtype=_lib.EM_DTYPE))
+
+
+def test_edgematches_on_demand_give_the_same_path_inputs(oracle):
+    """A graph created WITHOUT the EdgeMatch table (it stays in HBM in the product flow) + the path edges' EdgeMatches
+    supplied after linearize == the graph created with the whole table (MatchMap::getEdgeMatches is only ever asked for
+    path edges: dg.cpp:99-101 -> ap.cpp:631-706)."""
+    rows = varlen_rows(400, 2500, 250_000, 2, tiled=True)
+    t = oracle.overlap(rows)
+    co = oracle.find_contraction_edges(t, len(t["read_len"]))
+    full = GraphStage(t, t["read_len"], t["read_first_line"])
+    lean = GraphStage(dict(t, ems=None), t["read_len"], t["read_first_line"])
+    for g in (full, lean):
+        with pytest.raises(MsgpuError) as e:
+            g.path_edges()
+        assert e.value.code == _lib.E_STATE
+        g.clean_up(co, rows)
+        g.linearize(3)
+    assert full.path_count == lean.path_count > 0
+    with pytest.raises(MsgpuError) as e:
+        lean.path_input(0)
+    assert e.value.code == _lib.E_STATE
+    idx = lean.path_edges()
+    assert np.array_equal(idx, full.path_edges())
+    assert len(idx) == sum(full.path_input(i).n_reads - 1 for i in range(full.path_count))
+    off, ems = _host_edgematches_of(t, idx)
+    with pytest.raises(MsgpuError) as e:  # a list that does not match the edges' EdgeMatch counts is refused
+        bad = off.copy()
+        bad[1:] += 1
+        lean.set_path_edgematches(bad, np.concatenate([ems, ems[:1]]))
+    assert e.value.code == _lib.E_ARG
+    lean.set_path_edgematches(off, ems)
+    for i in range(full.path_count):
+        assert lean.path(i) == full.path(i), i
+
+
+def test_graph_create_copies_and_create_borrowed_borrows(oracle):
+    """msgpu_graph_create owns copies of the tables (the caller may free or reuse its buffers right away);
+    msgpu_graph_create_borrowed is the variant that reads the caller's memory until msgpu_graph_free."""
+    import ctypes as C
+    L = _lib.lib()
+    rows = varlen_rows(200, 1500, 120_000, 6, tiled=True)
+    t = oracle.overlap(rows)
+    co = oracle.find_contraction_edges(t, len(t["read_len"]))
+    ref = GraphStage(t, t["read_len"], t["read_first_line"])
+    ref.clean_up(co, rows)
+    ref.linearize()
+    want = [ref.path(i) for i in range(ref.path_count)]
+    assert want
+    e, m, o, i = (t[k].copy() for k in ("edges", "ems", "orders", "ids"))
+    rl, fl = t["read_len"].astype("<i4"), t["read_first_line"].astype("<u4")
+    h = C.c_void_p()
+    assert L.msgpu_graph_create(e.ctypes.data, len(e), m.ctypes.data, len(m), o.ctypes.data, len(o), i.ctypes.data, len(i),
+                                rl.ctypes.data, fl.ctypes.data, len(rl), C.byref(h)) == 0
+    for a in (e, m, o, i):  # scramble the caller's buffers: the graph must not notice
+        a.view(np.uint8)[:] = 0xEE
+    cov = np.ascontiguousarray(co, dtype="<i8")
+    assert L.msgpu_graph_clean_up(h, cov.ctypes.data, None, 0) == 0
+    assert L.msgpu_graph_linearize(h) == 0
+    assert L.msgpu_graph_path_count(h) == len(want)
+    for k, (wp, _, _) in enumerate(want):
+        p = _lib.PathInput()
+        assert L.msgpu_graph_path_input(h, k, C.byref(p)) == 0
+        reads = np.frombuffer(C.string_at(p.reads, p.n_reads * 16), dtype=_lib.PATH_READ_DTYPE)
+        assert [int(r["read_id"]) for r in reads] == [r["id"] for r in wp]
+        n_ids = max((int(x["ids_off"]) + int(x["ids_cnt"]) for x in np.frombuffer(
+            C.string_at(p.orders, int(np.frombuffer(C.string_at(p.order_off, 4 * p.n_reads), "<u4")[-1]) * 24),
+            dtype=_lib.PATH_ORDER_DTYPE)), default=0)
+        if n_ids:  # the id pool the path input points into is the graph's own copy, not the scrambled buffer
+            assert np.array_equal(np.frombuffer(C.string_at(p.ids, 4 * n_ids), "<u4"), t["ids"][:n_ids])
+    L.msgpu_graph_free(h)
