@@ -218,6 +218,76 @@ def host_to_host_leg(ctx, rows, n_batches, reps=6):
         pinned.close()
 
 
+def sharded_host_to_host_leg(torch, dist, D, dev, ctx, rows, world, rank, n_batches, reps=5):
+    """SURVEY 8(d)'s region -- rows in host memory -> tables in host memory -- over the node's N PCIe links instead of one:
+      rows      every rank holds the job's row table in its own pinned host memory, uploads 1/N of it over ITS link, and
+                ONE all-gather over xGMI completes the table in every HBM (a second, input-side collective: xGMI moves the
+                202 MB of configs[2] in well under the 3.7 ms one PCIe link needs for them);
+      compute   msgpu_overlap_batched_ex on the rank's shard (edges with v1 % N == rank), windows on two streams, tables
+                resident; the shard's four tables travel to the rank's pinned host memory over its own link;
+      merge     edges | orders | ids through the one-collective SlabExchange + msgpu_merge_gathered: the merged edge list
+                in every HBM (what msgpu_find_contraction_edges takes); EdgeMatch tables stay rank-local.
+    Wall = max over ranks; the result tables are distributed over the ranks' host memories."""
+    from muchsalsa_amd import overlap
+    from muchsalsa_amd._lib import EDGE_DTYPE, ORDER_DTYPE
+    n = len(rows)
+    per = (n + world - 1) // world
+    lo, hi = min(rank * per, n), min((rank + 1) * per, n)
+    pin = torch.empty(per * rows.itemsize, dtype=torch.uint8).pin_memory()
+    pin[: (hi - lo) * rows.itemsize] = torch.from_numpy(rows[lo:hi].view(np.uint8).copy())
+    d_slice = torch.empty(per * rows.itemsize, dtype=torch.uint8, device=dev)
+    d_rows = torch.empty(world * per * rows.itemsize, dtype=torch.uint8, device=dev)
+    exchange = D.SlabExchange(dev)
+    stream = torch.cuda.Stream(device=dev)
+    ctx.set_stream(stream.cuda_stream)
+    if world > 1:
+        ctx.set_shard(rank, world)
+    keep = {}
+
+    def once():
+        with torch.cuda.stream(stream):
+            d_slice.copy_(pin, non_blocking=True)                   # 1/N of the rows over this rank's link
+            dist.all_gather_into_tensor(d_rows, d_slice)            # ... the rest over xGMI
+            t, info = ctx.overlap_batched(None, n_batches, copy=False, resident=True, device_rows=(d_rows.data_ptr(), n))
+            c = ctx.counts()
+
+            def fill(slab, offs):
+                ctx.copy_tables_device(d_edges=slab.data_ptr() + offs[0], d_orders=slab.data_ptr() + offs[1],
+                                       d_ids=slab.data_ptr() + offs[2])
+            gathered, allc, offs, slab_bytes = exchange.gather((c.n_edges, c.n_orders, c.n_ids), fill)
+            tot = allc.sum(axis=0)
+            m_e = torch.empty(max(int(tot[0]), 1) * EDGE_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+            m_o = torch.empty(max(int(tot[1]), 1) * ORDER_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+            m_i = torch.empty(max(int(tot[2]), 1) * 4, dtype=torch.uint8, device=dev)
+            ctx.merge_gathered(gathered.data_ptr(), allc, slab_bytes, offs, m_e.data_ptr(), m_o.data_ptr(), m_i.data_ptr())
+            stream.synchronize()
+            keep.update(t=t, info=info, allc=allc, c=c)
+
+    once()  # warm-up: arenas, capacity agreement
+    once()
+    walls = []
+    for _ in range(reps):
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        once()
+        dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+        walls.append(1e3 * float(dt.item()))
+    ctx.set_stream(None)
+    k = int(np.argsort(walls)[len(walls) // 2])
+    t, allc = keep["t"], keep["allc"]
+    n_edges = int(allc[:, 0].sum())
+    mine = int(sum(t[x].nbytes for x in ("edges", "ems", "orders", "ids")))
+    return {"ms": walls[k], "overlap_pairs_per_s": n_edges / (walls[k] * 1e-3), "ms_samples": [round(x, 3) for x in walls],
+            "edges": n_edges, "rows_bytes_h2d_this_rank": int(per * rows.itemsize), "table_bytes_d2h_this_rank": mine,
+            "collectives_per_call": 2, "windows": int(keep["info"]["n_batches"]),
+            "scaling": "strong",
+            "stage": "rows in every rank's pinned host memory -> 1/N H2D per rank + one xGMI all-gather of the row table -> "
+                     "msgpu_overlap_batched_ex on the rank's shard, its four tables to the rank's pinned host memory -> one "
+                     "all-gather + merge of edges | orders | ids; wall = max over ranks, median of %d calls" % reps}
+
+
 def consensus_leg(torch, dev, world, rank, w, steps, warmup):
     """Device half of the consensus stage (A9) on the same synthetic reads: slice / reverse-complement / stitch.
 
@@ -498,6 +568,12 @@ def main():
                     help="assemblePath leg: chain the reads starting in the first this-many Mb of the genome "
                          "(0 = the whole genome, the default; negative = skip the assemblePath / graph legs)")
     ap.add_argument("--batches", type=int, default=8, help="windows of the host-to-host leg (msgpu_overlap_batched)")
+    ap.add_argument("--scaling", default="auto", choices=("auto", "weak", "strong"),
+                    help="N > 1: weak = every rank runs one partition of an N-partition job (each of the workload's shape; "
+                         "disjoint read / anchor id ranges), the merged edge list all-gathered on a communication stream "
+                         "beside the next step's compute; strong = the ONE job of the workload sharded over the ranks by "
+                         "v1 %% N (BASELINE.json configs[3]).  auto = weak, with the strong figure and the rank-sharded "
+                         "host-to-host figure reported beside it")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the N>1 exchange path (all-gather + merge) even at world size 1 (used by the GPU tests)")
     ap.add_argument("--self-launch", action="store_true",
@@ -537,93 +613,202 @@ def main():
         rccl_ranks = dist.get_world_size()  # what RCCL saw, not what the command line asked for
 
     w = WORKLOADS[args.workload]
-    rows, read_names, anchor_names = synth.accepted_rows(
-        synth.paf_table(w["n_reads"], w["read_len"], w["n_anchors"], w["seed"]))
+    weak = multi and args.scaling in ("auto", "weak")
+    # weak scaling: rank r holds partition r of an N-partition job -- the workload's shape, its own seed (rank 0: the
+    # workload itself), its own reads and anchors (ids from 0; the merge adds the partition's id bases).  Reads of
+    # different partitions share no anchor, so no edge crosses a partition: what sharding a genome by chromosome gives.
+    seed = w["seed"] + (rank if weak else 0)
+    rows, read_names, anchor_names = synth.accepted_rows(synth.paf_table(w["n_reads"], w["read_len"], w["n_anchors"], seed))
     d_rows = torch.from_numpy(rows.view(np.uint8).copy()).to(dev)  # the accepted-row table, resident in HBM
     torch.cuda.synchronize()
 
     ctx = overlap.OverlapContext(device=local_rank)
-    # One real (non-null) stream carries everything: libmsgpu's kernels, torch's allocations and the RCCL collective
-    # are ordered by it, so the all-gather cannot overtake the table copies nor the merge kernel the all-gather.
+    # One real (non-null) stream carries the compute: libmsgpu's kernels and torch's copies are ordered by it.
     work = torch.cuda.Stream(device=dev)
     ctx.set_stream(work.cuda_stream)
-    if world > 1:
-        ctx.set_shard(rank, world)
     ctx.set_id_space(len(read_names), len(anchor_names))  # Registry sizes, known to whoever parsed the PAF
     merged_keep = {}
-    exchange = D.SlabExchange(dev) if multi else None
 
-    def step():
+    def compute():
         ctx.load_rows_device(d_rows.data_ptr(), len(rows), keep_alive=d_rows)
         ctx.calculate_edges()
         ctx.chaining_and_overlaps()
-        c = ctx.counts()
-        if multi:
+        return ctx.counts()
+
+    def fill(slab, offs):
+        ctx.copy_tables_device(d_edges=slab.data_ptr() + offs[0], d_orders=slab.data_ptr() + offs[1],
+                               d_ids=slab.data_ptr() + offs[2])
+
+    def timed_region(step, finish=None):
+        """W warm-up steps, then K timed steps between barrier + synchronize on both sides; chain-kernel events of the
+        timed steps; three more steps with stage markers.  -> (seconds, last step's result, chain kernel ms, stage ms)"""
+        with torch.cuda.stream(work):
+            ctx.set_stage_events(False)
+            for _ in range(args.warmup):
+                step()
+            if finish:
+                finish()
+            if multi:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            ctx.timings()  # (starts a fresh window of chain-kernel event pairs)
+            for _ in range(args.steps):
+                res = step()  # no synchronisation between steps: the next index build queues up behind the compaction
+            if finish:
+                res = finish() or res
+            torch.cuda.synchronize()
+            if multi:
+                dist.barrier()
+            dt = time.perf_counter() - t0
+            k_ms = ctx.timings().chain_kernel_ms  # HIP events around the chain kernels of every timed step, averaged
+            ctx.set_stage_events(True)
+            for _ in range(3):
+                step()
+            if finish:
+                finish()
+            tm = ctx.timings()
+        return dt, res, k_ms, tm
+
+    def over_ranks(dt):
+        """-> (max over ranks, {min, max, per_rank} ms per step)"""
+        mine = torch.tensor([dt], dtype=torch.float64, device=dev)
+        allt = torch.empty(world, dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(allt, mine)
+        per_rank = [1e3 * float(x) / args.steps for x in allt.cpu()]
+        return max(float(x) for x in allt.cpu()), {"min": min(per_rank), "max": max(per_rank),
+                                                   "per_rank": [round(x, 4) for x in per_rank]}
+
+    def merged_tables(keep, k):
+        tot = keep["tot"][k]
+        me = keep["e"][k].cpu().numpy()[: int(tot[0]) * EDGE_DTYPE.itemsize].view(EDGE_DTYPE)
+        mo = keep["o"][k].cpu().numpy()[: int(tot[1]) * ORDER_DTYPE.itemsize].view(ORDER_DTYPE)
+        mi = keep["i"][k].cpu().numpy()[: int(tot[2]) * 4].view("<u4")
+        return me, mo, mi
+
+    def merged_consistent(me, mo, mi):
+        return bool(
+            np.array_equal(me["order_off"], np.concatenate([[0], np.cumsum(me["order_cnt"])[:-1]]).astype(np.uint64))
+            and np.array_equal(mo["edge_idx"], np.repeat(np.arange(len(me), dtype=np.uint32), me["order_cnt"]))
+            and np.array_equal(mo["ids_off"], np.concatenate([[0], np.cumsum(mo["ids_cnt"])[:-1]]).astype(np.uint64))
+            and int(mo["ids_cnt"].sum()) == len(mi) and bool(np.all(mo["base"] == me["v1"][mo["edge_idx"]])))
+
+    exchange_info = strong_leg = sharded_h2h = None
+    merge_ok = rank_ms = None
+    scaling = "weak"
+    if not multi:
+        dt, c, k_ms, tm = timed_region(compute)
+        n_edges_total = int(c.n_edges)
+    elif weak:
+        # ---- weak scaling: N partitions, the merge of batch k over xGMI beside the compute of batch k + 1 ----------------
+        sizes = torch.tensor([len(read_names), len(anchor_names)], dtype=torch.int64, device=dev)
+        alls = torch.empty(world * 2, dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(alls, sizes)  # set-up, untimed: the partitions' id-space sizes
+        alls = alls.cpu().numpy().reshape(world, 2)
+        id_base = np.concatenate([np.zeros((1, 2), dtype=np.int64), np.cumsum(alls, axis=0)[:-1]]).astype("<u4")
+        merged_keep.update(e=[None, None], o=[None, None], i=[None, None], tot=[None, None])
+
+        def merge(gathered, allc, offs, slab_bytes, k, stream):
+            tot = allc.sum(axis=0)
+            for key, n in (("e", int(tot[0]) * EDGE_DTYPE.itemsize), ("o", int(tot[1]) * ORDER_DTYPE.itemsize), ("i", int(tot[2]) * 4)):
+                if merged_keep[key][k] is None or merged_keep[key][k].numel() < n:  # (first batches only)
+                    merged_keep[key][k] = torch.empty(int(n * 1.125) + 256, dtype=torch.uint8, device=dev)
+            ctx.merge_gathered(gathered.data_ptr(), allc, slab_bytes, offs, merged_keep["e"][k].data_ptr(),
+                               merged_keep["o"][k].data_ptr(), merged_keep["i"][k].data_ptr(), id_base=id_base,
+                               stream=stream.cuda_stream)
+            merged_keep["tot"][k] = tot
+            merged_keep["last"], merged_keep["allc"] = k, allc
+
+        pe = D.PipelinedExchange(dev, merge)
+
+        def step():
+            c = compute()
+            pe.submit((c.n_edges, c.n_orders, c.n_ids), fill)  # slab filled on the compute stream; all-gather on its own
+            pe.collect()                                        # the batch before: headers, merge behind its all-gather
+            return c
+
+        def finish():
+            pe.drain()
+
+        dt, c, k_ms, tm = timed_region(step, finish)
+        allc = merged_keep["allc"]
+        n_edges_total = int(allc[:, 0].sum())
+        dt, rank_ms = over_ranks(dt)
+        exchange_info = {"collectives_per_step": pe.collectives / max(1, pe.calls), "slab_bytes": int(pe.slab_bytes),
+                         "regrows": pe.regrows, "overlapped": "all-gather + merge of step k on a communication stream "
+                                                              "beside the compute of step k + 1"}
+        if rank == 0:  # not timed: the merged edge list is a consistent table whose first partition is our own
+            me, mo, mi = merged_tables(merged_keep, merged_keep["last"])
+            own = ctx.tables()
+            ne, no, ni = (len(own[x]) for x in ("edges", "orders", "ids"))
+            merge_ok = merged_consistent(me, mo, mi) and me[:ne].tobytes() == own["edges"].tobytes() \
+                and mo[:no].tobytes() == own["orders"].tobytes() and mi[:ni].tobytes() == own["ids"].tobytes() \
+                and bool(np.all(np.diff(me["v1"].astype(np.int64)) >= 0))  # id bases ascend: (v1, v2)-sorted
+            if world > 1:
+                merge_ok = merge_ok and int(me["v1"][ne]) >= int(id_base[1][0]) and int(mi[ni:].min()) >= int(id_base[1][1])
+    if multi and (not weak or args.scaling == "auto"):
+        # ---- strong scaling (BASELINE.json configs[3]): the ONE job of the workload, edges owned by v1 % N ---------------
+        if weak:  # every rank needs the job's table now (rank 0 holds it already)
+            rows_s, rn_s, an_s = synth.accepted_rows(synth.paf_table(w["n_reads"], w["read_len"], w["n_anchors"], w["seed"])) \
+                if rank else (rows, read_names, anchor_names)
+            d_rows_s = torch.from_numpy(rows_s.view(np.uint8).copy()).to(dev) if rank else d_rows
+        else:
+            rows_s, rn_s, an_s, d_rows_s = rows, read_names, anchor_names, d_rows
+        ctx.set_id_space(len(rn_s), len(an_s))
+        if world > 1:
+            ctx.set_shard(rank, world)
+        exchange = D.SlabExchange(dev)
+        s_keep = {}
+
+        def strong_step():
+            ctx.load_rows_device(d_rows_s.data_ptr(), len(rows_s), keep_alive=d_rows_s)
+            ctx.calculate_edges()
+            ctx.chaining_and_overlaps()
+            c = ctx.counts()
             # merge the edge list: ONE all-gather of the per-rank (header | edges | orders | ids) slab over xGMI, then the
-            # HIP compaction / re-base kernel (msgpu_merge_gathered)
-            def fill(slab, offs):
-                ctx.copy_tables_device(d_edges=slab.data_ptr() + offs[0], d_orders=slab.data_ptr() + offs[1],
-                                       d_ids=slab.data_ptr() + offs[2])
+            # HIP compaction / re-base kernel (msgpu_merge_gathered); everything on the compute stream
             gathered, allc, offs, slab_bytes = exchange.gather((c.n_edges, c.n_orders, c.n_ids), fill)
             tot = allc.sum(axis=0)
             m_e = torch.empty(max(int(tot[0]), 1) * EDGE_DTYPE.itemsize, dtype=torch.uint8, device=dev)
             m_o = torch.empty(max(int(tot[1]), 1) * ORDER_DTYPE.itemsize, dtype=torch.uint8, device=dev)
             m_i = torch.empty(max(int(tot[2]), 1) * 4, dtype=torch.uint8, device=dev)
-            ctx.merge_gathered(gathered.data_ptr(), allc, slab_bytes, offs, m_e.data_ptr(), m_o.data_ptr(),
-                               m_i.data_ptr())
-            merged_keep.update(e=m_e, o=m_o, i=m_i, tot=tot)
-            return c, allc
-        return c, None
+            ctx.merge_gathered(gathered.data_ptr(), allc, slab_bytes, offs, m_e.data_ptr(), m_o.data_ptr(), m_i.data_ptr())
+            s_keep.update(e=[m_e], o=[m_o], i=[m_i], tot=[tot], allc=allc)
+            return c
 
-    with torch.cuda.stream(work):
-        # the timed steps carry only the two events around the chain kernels (the roofline's measurement); the stage
-        # boundaries are marked in a few extra steps afterwards -- every marker costs microseconds of command-processor time
-        ctx.set_stage_events(False)
-        for _ in range(args.warmup):
-            step()
-        if multi:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        ctx.timings()  # (starts a fresh window of chain-kernel event pairs)
-        for _ in range(args.steps):
-            c, allc = step()  # no synchronisation between steps: the next index build queues up behind the compaction
-        torch.cuda.synchronize()
-        if multi:
-            dist.barrier()
-        dt = time.perf_counter() - t0
-        # HIP events around the chain kernels of every timed step (a ring inside the library), averaged here
-        chain_ms = [ctx.timings().chain_kernel_ms]
-        ctx.set_stage_events(True)
-        for _ in range(3):
-            step()
-        tm = ctx.timings()
-    merge_ok = None
-    if multi and rank == 0:  # not timed: the merged edge list must be a consistent table (and, alone, equal our own)
-        tot = merged_keep["tot"]
-        me = merged_keep["e"].cpu().numpy()[: int(tot[0]) * EDGE_DTYPE.itemsize].view(EDGE_DTYPE)
-        mo = merged_keep["o"].cpu().numpy()[: int(tot[1]) * ORDER_DTYPE.itemsize].view(ORDER_DTYPE)
-        mi = merged_keep["i"].cpu().numpy()[: int(tot[2]) * 4].view("<u4")
-        merge_ok = bool(
-            np.array_equal(me["order_off"], np.concatenate([[0], np.cumsum(me["order_cnt"])[:-1]]).astype(np.uint64))
-            and np.array_equal(mo["edge_idx"], np.repeat(np.arange(len(me), dtype=np.uint32), me["order_cnt"]))
-            and np.array_equal(mo["ids_off"], np.concatenate([[0], np.cumsum(mo["ids_cnt"])[:-1]]).astype(np.uint64))
-            and int(mo["ids_cnt"].sum()) == len(mi) and bool(np.all(mo["base"] == me["v1"][mo["edge_idx"]])))
-        if world == 1:
-            own = ctx.tables()
-            merge_ok = merge_ok and me.tobytes() == own["edges"].tobytes() and mo.tobytes() == own["orders"].tobytes() \
-                and mi.tobytes() == own["ids"].tobytes()
-    rank_ms = None
-    if multi:
-        mine = torch.tensor([dt], dtype=torch.float64, device=dev)
-        allt = torch.empty(world, dtype=torch.float64, device=dev)
-        dist.all_gather_into_tensor(allt, mine)
-        per_rank = [1e3 * float(x) / args.steps for x in allt.cpu()]
-        rank_ms = {"min": min(per_rank), "max": max(per_rank), "per_rank": [round(x, 4) for x in per_rank]}
-        dt = max(float(x) for x in allt.cpu())  # MAX over ranks
-        n_edges_total = int(allc[:, 0].sum())
-    else:
-        n_edges_total = int(c.n_edges)
+        s_dt, s_c, s_k_ms, s_tm = timed_region(strong_step)
+        s_dt, s_rank_ms = over_ranks(s_dt)
+        s_edges = int(s_keep["allc"][:, 0].sum())
+        s_ok = None
+        if rank == 0:
+            me, mo, mi = merged_tables(s_keep, 0)
+            s_ok = merged_consistent(me, mo, mi)
+            if world == 1:
+                own = ctx.tables()
+                s_ok = s_ok and me.tobytes() == own["edges"].tobytes() and mo.tobytes() == own["orders"].tobytes() \
+                    and mi.tobytes() == own["ids"].tobytes()
+        strong_leg = {"scaling": "strong", "value": s_edges / (s_dt / args.steps), "unit": "overlap-pairs/s",
+                      "ms_per_step": 1e3 * s_dt / args.steps, "edges": s_edges, "rank_ms_per_step": s_rank_ms,
+                      "merged_edge_list_consistent": s_ok,
+                      "exchange": {"collectives_per_step": exchange.collectives / max(1, exchange.calls),
+                                   "slab_bytes": int(exchange.slab_bytes), "regrows": exchange.regrows},
+                      "stage_ms": {"index": s_tm.index_ms, "candidates": s_tm.candidates_ms, "chain_total": s_tm.chain_ms,
+                                   "chain_kernel": s_k_ms, "compact": s_tm.compact_ms},
+                      "workload": "%s as ONE job: every rank indexes the whole row table (replicated), owns the edges with "
+                                  "v1 %% %d == rank, one all-gather + merge per step on the compute stream "
+                                  "(BASELINE.json configs[3] at N = 8)" % (w["name"], world)}
+        if not weak:
+            scaling = "strong"
+            dt, c, k_ms, tm, rank_ms, n_edges_total, merge_ok = s_dt, s_c, s_k_ms, s_tm, s_rank_ms, s_edges, s_ok
+            exchange_info, strong_leg = strong_leg["exchange"], None
+        try:
+            sharded_h2h = sharded_host_to_host_leg(torch, dist, D, dev, ctx, rows_s, world, rank, args.batches)
+        except Exception as exc:  # noqa: BLE001 -- (raised on every rank alike: same code, same sizes)
+            sharded_h2h = {"error": "%s: %s" % (type(exc).__name__, exc)}
+        ctx.set_shard(0, 1)
+        ctx.set_id_space(len(read_names), len(anchor_names))
+        if weak:
+            del d_rows_s
 
     h2h = asm_leg = graph_leg = None
     errors = {}
@@ -660,7 +845,7 @@ def main():
         # algorithmic bytes of the dominant kernels: 96 B per EdgeMatch (32 B EdgeMatch written +
         # two 32 B VertexMatch rows read) + 64 B per order + 4 B per id; one launch set processes all edges of the rank
         alg_bytes = 96 * c.n_ems + 64 * c.n_orders + 4 * c.n_ids
-        k_ms = float(np.mean(chain_ms))
+        k_ms = float(k_ms)
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         traffic, traffic_src, valu = pmc_traffic(args.workload, world, CHAIN_KERNELS)
         roof = {"bound": "hbm", "kernel": "k_chain + k_chain_sub<32> + k_chain_sub<16> + k_chain_sub<8> (one pass over "
@@ -678,11 +863,17 @@ def main():
         out = {
             "metric": "overlap-pairs/s", "value": n_edges_total / (dt / args.steps), "unit": "overlap-pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "int32+f64",
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "int32+f64",
             "data": "synthetic",
-            "config": {"workload": w["name"], "rows": int(len(rows)), "reads": int(c.n_reads),
+            "config": {"workload": (w["name"] if not (weak and world > 1) else
+                                    "%d partitions, each: %s (seeds %d..%d; disjoint read / anchor id ranges, so no edge "
+                                    "crosses a partition), one partition per GPU" % (world, w["name"], w["seed"], w["seed"] + world - 1)),
+                       "rows": int(len(rows)), "reads": int(c.n_reads),
                        "anchors": int(c.n_anchors), "edges": n_edges_total, "edgematches_rank0": int(c.n_ems),
-                       "orders_rank0": int(c.n_orders), "parallelism": "edges sharded by v1 %% %d" % world,
+                       "orders_rank0": int(c.n_orders),
+                       "parallelism": ("one job on one GPU" if not multi else
+                                       "dp%d: one partition per rank, one RCCL all-gather + merge of the edge list per step on "
+                                       "a communication stream" % world if weak else "edges sharded by v1 %% %d" % world),
                        "edges_proven_clean_rank0": int(c.n_edges_fastpath), "merged_edge_list_consistent": merge_ok,
                        "note": "value = the overlap half of the metric with the row table resident in HBM; host_to_host = "
                                "the same job from and to pinned host memory; the consensus half is under 'consensus' "
@@ -697,8 +888,11 @@ def main():
         if multi:
             out["rccl_ranks"] = rccl_ranks
             out["rank_ms_per_step"] = rank_ms
-            out["exchange"] = {"collectives_per_step": exchange.collectives / max(1, exchange.calls),
-                               "slab_bytes": int(exchange.slab_bytes), "regrows": exchange.regrows}
+            out["exchange"] = exchange_info
+            if strong_leg is not None:
+                out["strong"] = strong_leg
+            if sharded_h2h is not None:
+                out["host_to_host_sharded"] = sharded_h2h
         if h2h is not None:
             out["host_to_host"] = h2h
         if cons is not None:

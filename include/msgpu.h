@@ -246,6 +246,15 @@ int msgpu_merge_gathered(msgpu_ctx *ctx, const void *d_gathered, uint32_t world,
                          uint64_t slab_bytes, uint64_t off_edges, uint64_t off_orders, uint64_t off_ids, void *d_edges,
                          void *d_orders, void *d_ids);
 
+/* The same with (a) id bases: id_base = world x {read id base, anchor id base} (NULL = zeros) is added to the read ids
+ * (v1, v2, start, end, base) and to the anchor ids of rank r's records -- the ranks hold PARTITIONS of a larger job
+ * (disjoint sets of reads and anchors, e.g. chromosomes: no edge crosses a partition), each with ids from 0, and the merged
+ * list is the larger job's, (v1, v2)-sorted when the bases ascend; (b) the stream the merge kernel runs on (NULL = the
+ * context's), so that an exchange can run on its own stream beside the next batch's compute. */
+int msgpu_merge_gathered_ex(msgpu_ctx *ctx, const void *d_gathered, uint32_t world, const uint64_t *counts,
+                            uint64_t slab_bytes, uint64_t off_edges, uint64_t off_orders, uint64_t off_ids,
+                            const uint32_t *id_base, void *d_edges, void *d_orders, void *d_ids, void *hip_stream);
+
 /* ---- the ThreadPool replacement: the whole overlap path, host memory to host memory, as batches on two HIP streams ----
  * Replaces the phases of src/main.cpp:153-178 that the reference fans over its ThreadPool (one Job per PAF line, per
  * anchor, per edge; libms/src/threading/ThreadPool.cpp:38-129) and closes with WaitGroup::wait() (WaitGroup.cpp:62-72):
@@ -282,9 +291,13 @@ int msgpu_overlap_batched(msgpu_ctx *ctx, const msgpu_row *rows, size_t n_rows, 
  *   MSGPU_BATCH_NO_EDGEMATCHES  (implies RESIDENT) the EdgeMatch table is NOT copied to the host: out->ems = NULL,
  *                               out->n_ems is still its size.  Downstream only assemblePath reads EdgeMatches, and only
  *                               those of path edges (dg.cpp:99-101 -> ap.cpp:631-706): fetch them with
- *                               msgpu_get_edgematches.  Moves 154 MB instead of 971 MB on configs[2]. */
+ *                               msgpu_get_edgematches.  Moves 154 MB instead of 971 MB on configs[2].
+ *   MSGPU_BATCH_ROWS_ON_DEVICE  `rows` is a DEVICE pointer (msgpu_load_rows_device): the table is in HBM already, e.g.
+ *                               all-gathered over xGMI from the 1/N slices the ranks of a node uploaded over their own links.
+ */
 #define MSGPU_BATCH_RESIDENT 1u
 #define MSGPU_BATCH_NO_EDGEMATCHES 2u
+#define MSGPU_BATCH_ROWS_ON_DEVICE 4u
 int msgpu_overlap_batched_ex(msgpu_ctx *ctx, const msgpu_row *rows, size_t n_rows, uint32_t n_batches, uint32_t flags,
                              msgpu_host_tables *out);
 /* MatchMap::getEdgeMatches(edge) (libms/src/matching/MatchMap.cpp:136-159) for a LIST of edges, from the EdgeMatch table

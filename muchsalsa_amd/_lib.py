@@ -47,7 +47,7 @@ E_IO, E_FORMAT, E_NUMBER, E_NOMEM, E_ARG, E_HIP, E_STATE, E_IDS, E_NODEVICE = -1
 E_LAYOUT = -10
 
 ORD_START_V1, ORD_CONTAINED, ORD_DIR, ORD_PRIMARY = 1, 2, 4, 8
-BATCH_RESIDENT, BATCH_NO_EDGEMATCHES = 1, 2
+BATCH_RESIDENT, BATCH_NO_EDGEMATCHES, BATCH_ROWS_ON_DEVICE = 1, 2, 4
 
 
 class Params(C.Structure):
@@ -119,6 +119,9 @@ SYMBOLS = [
     ("msgpu_copy_reads", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     ("msgpu_merge_gathered", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_uint64,
                                        C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("msgpu_merge_gathered_ex", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_uint64,
+                                          C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.c_void_p]),
     ("msgpu_find_contraction_edges", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint32,
                                                C.c_void_p]),
     ("msgpu_synchronize", C.c_int, [C.c_void_p]),

@@ -1090,6 +1090,13 @@ int msgpu_find_contraction_edges(msgpu_ctx *c, const void *d_edges, uint64_t n_e
 int msgpu_merge_gathered(msgpu_ctx *c, const void *d_gathered, uint32_t world, const uint64_t *counts,
                          uint64_t slab_bytes, uint64_t off_edges, uint64_t off_orders, uint64_t off_ids, void *d_edges,
                          void *d_orders, void *d_ids) {
+  return msgpu_merge_gathered_ex(c, d_gathered, world, counts, slab_bytes, off_edges, off_orders, off_ids, nullptr, d_edges,
+                                 d_orders, d_ids, nullptr);
+}
+
+int msgpu_merge_gathered_ex(msgpu_ctx *c, const void *d_gathered, uint32_t world, const uint64_t *counts,
+                            uint64_t slab_bytes, uint64_t off_edges, uint64_t off_orders, uint64_t off_ids,
+                            const uint32_t *id_base, void *d_edges, void *d_orders, void *d_ids, void *hip_stream) {
   if (!c) return MSGPU_E_ARG;
   if (!d_gathered || !counts || world == 0 || world > MAX_WORLD) return fail(c, MSGPU_E_ARG, "bad merge arguments");
   HIPCHK(c, hipSetDevice(c->device));
@@ -1100,17 +1107,20 @@ int msgpu_merge_gathered(msgpu_ctx *c, const void *d_gathered, uint32_t world, c
   a.off_orders = off_orders;
   a.off_ids    = off_ids;
   a.world      = world;
-  a.base[0]    = MergeBase{0, 0, 0};
+  a.base[0]    = MergeBase{0, 0, 0, 0, 0};
   for (uint32_t r = 0; r < world; ++r) {
     a.base[r + 1].edges  = a.base[r].edges + counts[3 * r + 0];
     a.base[r + 1].orders = a.base[r].orders + counts[3 * r + 1];
     a.base[r + 1].ids    = a.base[r].ids + counts[3 * r + 2];
+    a.base[r].read_id    = id_base ? id_base[2 * r + 0] : 0;
+    a.base[r].anchor_id  = id_base ? id_base[2 * r + 1] : 0;
   }
+  a.base[world].read_id = a.base[world].anchor_id = 0;
   if (a.base[world].edges >= 0xfffffff0ull) return fail(c, MSGPU_E_ARG, "merged edge table too large");
   a.edges  = static_cast<msgpu_edge *>(d_edges);
   a.orders = static_cast<msgpu_order *>(d_orders);
   a.ids    = static_cast<uint32_t *>(d_ids);
-  launch_merge_gathered(c->stream, a);
+  launch_merge_gathered(hip_stream ? static_cast<hipStream_t>(hip_stream) : c->stream, a);
   HIPCHK(c, hipGetLastError());
   return MSGPU_OK;
 }
@@ -1160,7 +1170,8 @@ int msgpu_overlap_batched_ex(msgpu_ctx *c, const msgpu_row *rows, size_t n_rows,
                              msgpu_host_tables *out) {
   if (!c || !out) return MSGPU_E_ARG;
   memset(out, 0, sizeof(*out));
-  if (flags & ~(MSGPU_BATCH_RESIDENT | MSGPU_BATCH_NO_EDGEMATCHES)) return fail(c, MSGPU_E_ARG, "unknown flags %#x", flags);
+  if (flags & ~(MSGPU_BATCH_RESIDENT | MSGPU_BATCH_NO_EDGEMATCHES | MSGPU_BATCH_ROWS_ON_DEVICE))
+    return fail(c, MSGPU_E_ARG, "unknown flags %#x", flags);
   if (flags & MSGPU_BATCH_NO_EDGEMATCHES) flags |= MSGPU_BATCH_RESIDENT; // (an EdgeMatch that is not copied must stay)
   const bool resident = (flags & MSGPU_BATCH_RESIDENT) != 0, copy_ems = !(flags & MSGPU_BATCH_NO_EDGEMATCHES);
   const auto t_start = std::chrono::steady_clock::now();
@@ -1176,7 +1187,8 @@ int msgpu_overlap_batched_ex(msgpu_ctx *c, const msgpu_row *rows, size_t n_rows,
   c->base_edges = c->base_ems = c->base_orders = c->base_ids = 0;
   reset_views();
   c->no_prologue = (n_batches ? n_batches : 8) > 1; // several windows: each has its own scratch offsets and read lists
-  const int rc_load = msgpu_load_rows(c, rows, n_rows); // rows host -> HBM once, index build once
+  // rows host -> HBM once (unless they are there already), index build once
+  const int rc_load = (flags & MSGPU_BATCH_ROWS_ON_DEVICE) ? msgpu_load_rows_device(c, rows, n_rows) : msgpu_load_rows(c, rows, n_rows);
   c->no_prologue    = false;
   if (rc_load) return rc_load;
   out->load_ms = ms_since(t_start);

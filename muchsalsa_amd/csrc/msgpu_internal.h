@@ -82,6 +82,7 @@ struct CompactArgs {
 constexpr uint32_t MAX_WORLD = 64;
 struct MergeBase {
   uint64_t edges, orders, ids;
+  uint32_t read_id, anchor_id; // added to the read ids (v1, v2, start, end, base) / anchor ids (id pool) of this rank's records
 };
 struct MergeArgs {
   const uint8_t *gathered;

@@ -3010,6 +3010,8 @@ __global__ __launch_bounds__(256) void k_merge_gathered(MergeArgs a) {
     const msgpu_edge *src = reinterpret_cast<const msgpu_edge *>(a.gathered + r * a.slab_bytes + a.off_edges);
     msgpu_edge        e  = src[k];
     e.order_off += a.base[r].orders;
+    e.v1 += a.base[r].read_id; // (partitions of a larger job: the rank's read ids start at its base)
+    e.v2 += a.base[r].read_id;
     a.edges[i] = e;
   }
   if (i < nO) {
@@ -3020,6 +3022,9 @@ __global__ __launch_bounds__(256) void k_merge_gathered(MergeArgs a) {
     msgpu_order        o   = src[k];
     o.edge_idx += static_cast<uint32_t>(a.base[r].edges);
     o.ids_off += a.base[r].ids;
+    o.start += a.base[r].read_id;
+    o.end += a.base[r].read_id;
+    o.base += a.base[r].read_id;
     a.orders[i] = o;
   }
   if (i < nI) {
@@ -3027,7 +3032,7 @@ __global__ __launch_bounds__(256) void k_merge_gathered(MergeArgs a) {
     while (i >= a.base[r + 1].ids) ++r;
     const uint64_t  k   = i - a.base[r].ids;
     const uint32_t *src = reinterpret_cast<const uint32_t *>(a.gathered + r * a.slab_bytes + a.off_ids);
-    a.ids[i]            = src[k];
+    a.ids[i]            = src[k] + a.base[r].anchor_id;
   }
 }
 

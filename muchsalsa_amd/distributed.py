@@ -203,3 +203,173 @@ def shard_view_host(tables, shard, world):
         ob += no
     cat = lambda xs, dt: np.concatenate(xs) if xs else np.zeros(0, dtype=dt)  # noqa: E731
     return {"edges": e2, "ems": cat(em_parts, em.dtype), "orders": cat(o_parts, ORDER_DTYPE), "ids": cat(id_parts, "<u4")}
+
+
+class PipelinedExchange:
+    """The one-collective exchange of SlabExchange, taken OFF the compute stream: a batch's slab is filled on the caller's
+    stream, the all-gather and the merge run on a communication stream of their own, and the host looks at a batch's
+    headers one batch later -- so batch k's merge over xGMI overlaps batch k + 1's candidate scan and chaining (the
+    reference's ThreadPool keeps its workers busy the same way while a finished phase's results are consumed,
+    libms/src/threading/ThreadPool.cpp:38-129).
+
+        pe = PipelinedExchange(device, merge)       # merge(gathered, all_counts, offs, slab_bytes, slot, stream)
+        for every batch:
+            ... compute ...
+            pe.submit(counts, fill_slab)            # slab k % 2; all-gather enqueued on the communication stream
+            pe.collect()                            # the batch BEFORE: headers checked, merge enqueued behind its all-gather
+        pe.drain()                                  # the last batch
+
+    Capacity protocol = SlabExchange's (header in the slab, capacity remembered, identical decisions on every rank because
+    only gathered data enters them).  A rank that outgrows the capacity sends its header alone and keeps its tables in a
+    private stash; when the headers are read (one batch later) every rank enlarges the capacity, re-lays its own slab of
+    THAT batch (still intact: a slot is reused two batches later; or the stash) and repeats the collective, synchronously.
+    On CPU tensors (gloo, the tests) there are no streams: every call completes before it returns."""
+
+    def __init__(self, device, merge, group=None, slack=1.125):
+        import torch
+        self.device, self.group, self.slack, self.merge = device, group, slack, merge
+        self.cuda = device.type == "cuda"
+        self.comm = torch.cuda.Stream(device=device) if self.cuda else None
+        self.cap = None
+        self.calls = self.collectives = self.regrows = 0
+        self.slab_bytes = 0
+        self.slots = [dict(pending=False) for _ in range(2)]
+        self.results = [None, None]  # per slot: (all_counts, offs, slab_bytes) of the last merged batch
+
+    # ---- layout --------------------------------------------------------------------------------------------------
+    def _layout(self):
+        offs, size = slab_layout(self.cap)
+        return tuple(HEADER + o for o in offs), HEADER + size
+
+    def _agree(self, counts):
+        import torch
+        import torch.distributed as dist
+        world = dist.get_world_size(self.group)
+        mine = torch.tensor([int(c) for c in counts], dtype=torch.int64, device=self.device)
+        allc = torch.empty(world * 3, dtype=torch.int64, device=self.device)
+        dist.all_gather_into_tensor(allc, mine, group=self.group)
+        self.collectives += 1
+        self.cap = tuple(int(n * self.slack) + 64 for n in allc.cpu().numpy().reshape(world, 3).max(axis=0))
+
+    def _buffers(self, slot, world):
+        """the slot's slab / gathered / header tensors for the current capacity (persistent: no allocation per batch)"""
+        import torch
+        offs, slab_bytes = self._layout()
+        if slot.get("slab_bytes") != slab_bytes or slot.get("world") != world:
+            slot["slab"] = torch.empty(slab_bytes, dtype=torch.uint8, device=self.device)
+            slot["gathered"] = torch.empty(world * slab_bytes, dtype=torch.uint8, device=self.device)
+            slot["heads_dev"] = torch.empty(world * 3, dtype=torch.int64, device=self.device)
+            slot["heads"] = torch.empty(world * 3, dtype=torch.int64, pin_memory=self.cuda)
+            slot["hdr"] = torch.empty(3, dtype=torch.int64, pin_memory=self.cuda)  # (pinned: the header copy never blocks)
+            slot["slab_bytes"], slot["world"] = slab_bytes, world
+        self.slab_bytes = slab_bytes
+        return offs, slab_bytes
+
+    def _gather(self, slot, world):
+        """all-gather of the slot's slab + its headers to pinned host memory, on the communication stream"""
+        import torch
+        import torch.distributed as dist
+
+        def run():
+            dist.all_gather_into_tensor(slot["gathered"], slot["slab"], group=self.group)  # the one collective
+            slot["heads_dev"].copy_(slot["gathered"].view(world, slot["slab_bytes"])[:, :24].contiguous().view(torch.int64).view(-1))
+            slot["heads"].copy_(slot["heads_dev"], non_blocking=True)
+        if self.cuda:
+            filled = torch.cuda.Event()
+            filled.record(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(self.comm):
+                self.comm.wait_event(filled)
+                run()
+                slot["done"] = torch.cuda.Event()
+                slot["done"].record(self.comm)
+        else:
+            run()
+        self.collectives += 1
+
+    # ---- the three calls -----------------------------------------------------------------------------------------
+    def submit(self, counts, fill_slab):
+        """counts = (n_edges, n_orders, n_ids) of this rank's batch; fill_slab(slab, offs) copies its three tables to the
+        byte offsets offs (enqueued on the caller's current stream)."""
+        import torch
+        import torch.distributed as dist
+        world = dist.get_world_size(self.group)
+        if self.cap is None:
+            self._agree(counts)
+        slot = self.slots[self.calls % 2]
+        self.calls += 1
+        if slot["pending"]:
+            self._collect(slot)  # (collect() after every submit() keeps this from happening)
+        offs, slab_bytes = self._buffers(slot, world)
+        if self.cuda and slot.get("merged") is not None:
+            torch.cuda.current_stream(self.device).wait_event(slot["merged"])  # the slab's last reader: two batches ago
+        counts = tuple(int(c) for c in counts)
+        slot["hdr"].copy_(torch.tensor(counts, dtype=torch.int64))
+        slot["slab"][:24].view(torch.int64).copy_(slot["hdr"], non_blocking=True)
+        slot["counts"], slot["offs"], slot["stash"], slot["cap"] = counts, offs, None, self.cap
+        if all(c <= k for c, k in zip(counts, self.cap)):
+            fill_slab(slot["slab"], offs)
+        else:  # outgrown: header only; the tables wait in a private block laid out for their own size
+            s_offs, s_size = slab_layout(counts)
+            stash = torch.empty(HEADER + s_size, dtype=torch.uint8, device=self.device)
+            s_offs = tuple(HEADER + o for o in s_offs)
+            fill_slab(stash, s_offs)
+            slot["stash"] = (stash, s_offs)
+        self._gather(slot, world)
+        slot["pending"] = True
+
+    def _relayout(self, slot, world):
+        """the capacity grew: this batch's own tables move into a slab of the new layout"""
+        import torch
+        src, s_offs = slot["stash"] if slot["stash"] is not None else (slot["slab"], slot["offs"])
+        counts = slot["counts"]
+        slot.pop("slab_bytes", None)
+        offs, _ = self._buffers(slot, world)
+        slot["hdr"].copy_(torch.tensor(counts, dtype=torch.int64))
+        slot["slab"][:24].view(torch.int64).copy_(slot["hdr"], non_blocking=True)
+        for n, rec, so, do in zip(counts, (EDGE_DTYPE.itemsize, ORDER_DTYPE.itemsize, 4), s_offs, offs):
+            slot["slab"][do: do + n * rec].copy_(src[so: so + n * rec])
+        slot["offs"], slot["stash"], slot["cap"] = offs, None, self.cap
+
+    def _collect(self, slot):
+        import torch
+        import torch.distributed as dist
+        world = dist.get_world_size(self.group)
+        while True:
+            if self.cuda:
+                slot["done"].synchronize()
+            heads = slot["heads"].numpy().reshape(world, 3).astype(np.int64)
+            # against the capacity THIS batch was sent with: the batch after it may have gone out before the capacity grew
+            if (heads <= np.asarray(slot["cap"], dtype=np.int64)[None, :]).all():
+                break
+            self.cap = tuple(max(c, int(n * self.slack) + 64) for c, n in zip(self.cap, heads.max(axis=0)))  # same on every rank
+            self.regrows += 1
+            if self.cuda:
+                torch.cuda.current_stream(self.device).wait_stream(self.comm)
+            self._relayout(slot, world)
+            self._gather(slot, world)
+        k = 0 if slot is self.slots[0] else 1
+        if self.cuda:
+            with torch.cuda.stream(self.comm):
+                self.merge(slot["gathered"], heads, slot["offs"], slot["slab_bytes"], k, self.comm)
+                slot["merged"] = torch.cuda.Event()
+                slot["merged"].record(self.comm)
+        else:
+            self.merge(slot["gathered"], heads, slot["offs"], slot["slab_bytes"], k, None)
+        self.results[k] = (heads, slot["offs"], slot["slab_bytes"])
+        slot["pending"] = False
+        return heads
+
+    def collect(self):
+        """finish the batch BEFORE the one just submitted (no-op when there is none) -> its all_counts or None"""
+        slot = self.slots[self.calls % 2]  # the slot the NEXT submit would take = the older of the two
+        return self._collect(slot) if slot["pending"] else None
+
+    def drain(self):
+        """finish everything submitted; returns the all_counts of the last batch"""
+        last = None
+        for k in (self.calls % 2, (self.calls + 1) % 2):  # older first
+            if self.slots[k]["pending"]:
+                last = self._collect(self.slots[k])
+        if self.cuda:
+            self.comm.synchronize()
+        return last

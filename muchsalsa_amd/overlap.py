@@ -177,18 +177,23 @@ class OverlapContext:
                                               ids.ctypes.data))
         return {"edges": edges, "ems": ems, "orders": orders, "ids": ids}
 
-    def overlap_batched(self, rows, n_batches=0, copy=True, resident=False, edgematches=True):
+    def overlap_batched(self, rows, n_batches=0, copy=True, resident=False, edgematches=True, device_rows=None):
         """msgpu_overlap_batched[_ex]: rows (numpy table or PinnedRows) -> (tables, info).  The whole overlap path, host
         memory to host memory, as `n_batches` windows of owner reads with the copy of window k behind the compute of
         window k + 1.  tables = the dict of tables(), plus read_len / read_first_line; copy=False returns views of the
         context's pinned result memory (valid until the next call).  resident=True keeps the job's tables whole in HBM
         (find_contraction_edges / get_edgematches / tables() then work on them); edgematches=False (implies resident)
-        leaves the EdgeMatch table there: tables["ems"] is None."""
-        arr = rows.array if isinstance(rows, PinnedRows) else np.ascontiguousarray(rows, dtype=ROW_DTYPE)
+        leaves the EdgeMatch table there: tables["ems"] is None.  device_rows=(device pointer, n_rows): the row table is
+        in HBM already (MSGPU_BATCH_ROWS_ON_DEVICE; `rows` is ignored)."""
         h = HostTables()
         flags = (_lib.BATCH_RESIDENT if resident else 0) | (0 if edgematches else _lib.BATCH_NO_EDGEMATCHES)
-        self._check(self._L.msgpu_overlap_batched_ex(self._h, arr.ctypes.data if len(arr) else None, len(arr),
-                                                     int(n_batches), flags, C.byref(h)))
+        if device_rows is not None:
+            ptr, n = C.c_void_p(int(device_rows[0]) or None), int(device_rows[1])
+            flags |= _lib.BATCH_ROWS_ON_DEVICE
+        else:
+            arr = rows.array if isinstance(rows, PinnedRows) else np.ascontiguousarray(rows, dtype=ROW_DTYPE)
+            ptr, n = (arr.ctypes.data if len(arr) else None), len(arr)
+        self._check(self._L.msgpu_overlap_batched_ex(self._h, ptr, n, int(n_batches), flags, C.byref(h)))
 
         def view(ptr, n, dt):
             dt = np.dtype(dt)
@@ -222,12 +227,17 @@ class OverlapContext:
         self._check(self._L.msgpu_copy_tables_device(self._h, C.c_void_p(d_edges), C.c_void_p(d_ems),
                                                      C.c_void_p(d_orders), C.c_void_p(d_ids)))
 
-    def merge_gathered(self, d_gathered, counts, slab_bytes, offs, d_edges, d_orders, d_ids):
-        """counts: world x 3 (n_edges, n_orders, n_ids); offs: byte offsets (edges, orders, ids) inside a slab."""
+    def merge_gathered(self, d_gathered, counts, slab_bytes, offs, d_edges, d_orders, d_ids, id_base=None, stream=None):
+        """counts: world x 3 (n_edges, n_orders, n_ids); offs: byte offsets (edges, orders, ids) inside a slab; id_base:
+        world x 2 (read id base, anchor id base) added to rank r's ids, None = zeros; stream: raw hipStream_t the merge
+        kernel runs on, None = the context's (msgpu_merge_gathered_ex)."""
         cnt = np.ascontiguousarray(counts, dtype="<u8")
-        self._check(self._L.msgpu_merge_gathered(self._h, C.c_void_p(d_gathered), cnt.shape[0], cnt.ctypes.data,
-                                                 slab_bytes, offs[0], offs[1], offs[2], C.c_void_p(d_edges),
-                                                 C.c_void_p(d_orders), C.c_void_p(d_ids)))
+        base = None if id_base is None else np.ascontiguousarray(id_base, dtype="<u4")
+        assert base is None or base.shape == (cnt.shape[0], 2)
+        self._check(self._L.msgpu_merge_gathered_ex(self._h, C.c_void_p(d_gathered), cnt.shape[0], cnt.ctypes.data,
+                                                    slab_bytes, offs[0], offs[1], offs[2],
+                                                    base.ctypes.data if base is not None else None, C.c_void_p(d_edges),
+                                                    C.c_void_p(d_orders), C.c_void_p(d_ids), C.c_void_p(stream or None)))
 
     def find_contraction_edges(self, d_edges=None, n_edges=0, d_orders=None, n_orders=0, n_reads=0):
         """findContractionEdges + sanityCheck (src/main.cpp:416-463, sc.cpp:29-90) on the context's own tables, or on

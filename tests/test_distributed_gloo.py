@@ -80,6 +80,66 @@ def _worker(rank, world, port, rows_bytes, out_dir):
         dist.destroy_process_group()
 
 
+def _pipelined_worker(rank, world, port, rows_bytes, out_dir):
+    """PipelinedExchange under gloo: batches submitted one ahead of their collection, a rank that outgrows the capacity in
+    two consecutive batches (the second one goes out before the first one's headers were read), id bases in the merge."""
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path[:0] = [os.path.dirname(here), os.path.join(os.path.dirname(here), "oracle"), here]
+    import ms_oracle_ctypes as oracle
+    from muchsalsa_amd import distributed as D
+    from muchsalsa_amd._lib import ROW_DTYPE
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rows = np.frombuffer(rows_bytes, dtype=ROW_DTYPE)
+        full = oracle.overlap(rows)
+        shards = [D.shard_view_host(full, r, world) for r in range(world)]
+        big0 = {k: np.concatenate([shards[0][k]] * 3) for k in ("edges", "orders", "ids")}
+        # what every rank holds in batch b: the shards; in batches 2 and 3 rank 0's tables are three times as long
+        held = lambda b, r: big0 if (r == 0 and b in (2, 3)) else shards[r]  # noqa: E731
+        merged = []
+
+        def merge(gathered, allc, offs, slab_bytes, k, stream):
+            assert stream is None
+            merged.append((D.split_gathered_host(gathered.numpy(), allc, offs, slab_bytes), allc.copy()))
+
+        pe = D.PipelinedExchange(torch.device("cpu"), merge)
+        for b in range(6):
+            t = held(b, rank)
+
+            def fill(slab, offs, t=t):
+                for name, off in zip(("edges", "orders", "ids"), offs):
+                    buf = torch.from_numpy(t[name].view(np.uint8).copy())
+                    slab[off: off + buf.numel()] = buf
+            pe.submit((len(t["edges"]), len(t["orders"]), len(t["ids"])), fill)
+            got = pe.collect()
+            assert (got is None) == (b == 0)  # the batch before, from the second submit on
+        last = pe.drain()
+        assert last is not None and len(merged) == 6
+        for b, (parts, allc) in enumerate(merged):  # merged in submission order, every rank's tables intact
+            for r in range(world):
+                want = held(b, r)
+                assert tuple(allc[r]) == (len(want["edges"]), len(want["orders"]), len(want["ids"])), (b, r)
+                for k in ("edges", "orders", "ids"):
+                    assert parts[r][k].tobytes() == want[k].tobytes(), (b, r, k)
+        # one agreement + one collective per batch + one repeat each for the two outgrown batches
+        assert pe.calls == 6 and pe.regrows == 2 and pe.collectives == 1 + 6 + 2, (pe.calls, pe.regrows, pe.collectives)
+        open(os.path.join(out_dir, "pipe%d" % rank), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_pipelined_exchange_one_batch_behind(tmp_path, world):
+    from muchsalsa_amd import synth
+    rows = synth.synth_rows(300, 4000, 1100, 8)
+    port = _free_port()
+    mp.spawn(_pipelined_worker, args=(world, port, rows.tobytes(), str(tmp_path)), nprocs=world, join=True)
+    assert all(os.path.exists(tmp_path / ("pipe%d" % r)) for r in range(world))
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_gather_and_merge_equals_single_process(tmp_path, world):
     from muchsalsa_amd import synth

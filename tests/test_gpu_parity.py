@@ -379,6 +379,18 @@ def test_bench_distributed_path_smoke():
     assert line["consensus"]["verified_against_genome"] is True
     assert line["rccl_ranks"] == 1 and line["rank_ms_per_step"]["min"] > 0
     assert line["exchange"]["collectives_per_step"] < 1.5  # the slab all-gather alone once the capacity is agreed
+    # the default N > 1 line: weak scaling (the exchange one step behind the compute, on its own stream), with the strong
+    # (one job sharded by v1 % N) and the rank-sharded host-to-host figures beside it
+    assert line["scaling"] == "weak" and line["exchange"]["regrows"] == 0
+    assert line["strong"]["merged_edge_list_consistent"] is True and line["strong"]["value"] > 0
+    assert line["strong"]["edges"] == line["config"]["edges"]
+    assert line["host_to_host_sharded"]["edges"] == line["config"]["edges"] and line["host_to_host_sharded"]["ms"] > 0
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "tiny", "--steps", "2",
+                          "--warmup", "1", "--kernels-only", "--force-dist", "--scaling", "strong"], env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["scaling"] == "strong" and line["config"]["merged_edge_list_consistent"] is True and "strong" not in line
 
 
 def test_bench_starts_its_own_ranks():
