@@ -731,12 +731,13 @@ def main():
             pe.drain()
 
         dt, c, k_ms, tm = timed_region(step, finish)
+        pe.close()
         allc = merged_keep["allc"]
         n_edges_total = int(allc[:, 0].sum())
         dt, rank_ms = over_ranks(dt)
         exchange_info = {"collectives_per_step": pe.collectives / max(1, pe.calls), "slab_bytes": int(pe.slab_bytes),
-                         "regrows": pe.regrows, "overlapped": "all-gather + merge of step k on a communication stream "
-                                                              "beside the compute of step k + 1"}
+                         "regrows": pe.regrows, "overlapped": "all-gather + merge of step k on a communication stream, issued "
+                                                              "by a communication thread, beside the compute of step k + 1"}
         if rank == 0:  # not timed: the merged edge list is a consistent table whose first partition is our own
             me, mo, mi = merged_tables(merged_keep, merged_keep["last"])
             own = ctx.tables()

@@ -206,35 +206,47 @@ def shard_view_host(tables, shard, world):
 
 
 class PipelinedExchange:
-    """The one-collective exchange of SlabExchange, taken OFF the compute stream: a batch's slab is filled on the caller's
-    stream, the all-gather and the merge run on a communication stream of their own, and the host looks at a batch's
-    headers one batch later -- so batch k's merge over xGMI overlaps batch k + 1's candidate scan and chaining (the
-    reference's ThreadPool keeps its workers busy the same way while a finished phase's results are consumed,
+    """The one-collective exchange of SlabExchange, taken OFF the compute stream and off the compute thread: a batch's slab
+    is filled on the caller's stream, and its all-gather, header check and merge run on a communication stream of their
+    own, issued by a communication thread -- so batch k's merge over xGMI overlaps batch k + 1's candidate scan and
+    chaining on the GPU, and the host calls of the exchange overlap the host's waits inside libmsgpu (the reference's
+    ThreadPool keeps its workers busy the same way while a finished phase's results are consumed,
     libms/src/threading/ThreadPool.cpp:38-129).
 
         pe = PipelinedExchange(device, merge)       # merge(gathered, all_counts, offs, slab_bytes, slot, stream)
         for every batch:
             ... compute ...
-            pe.submit(counts, fill_slab)            # slab k % 2; all-gather enqueued on the communication stream
-            pe.collect()                            # the batch BEFORE: headers checked, merge enqueued behind its all-gather
-        pe.drain()                                  # the last batch
+            pe.submit(counts, fill_slab)            # slab k % 2 filled on the caller's stream; the rest happens behind
+            pe.collect()                            # (without a communication thread: finishes the batch BEFORE)
+        pe.drain()                                  # everything submitted is merged
 
     Capacity protocol = SlabExchange's (header in the slab, capacity remembered, identical decisions on every rank because
     only gathered data enters them).  A rank that outgrows the capacity sends its header alone and keeps its tables in a
-    private stash; when the headers are read (one batch later) every rank enlarges the capacity, re-lays its own slab of
-    THAT batch (still intact: a slot is reused two batches later; or the stash) and repeats the collective, synchronously.
-    On CPU tensors (gloo, the tests) there are no streams: every call completes before it returns."""
+    private stash; when the headers are read every rank enlarges the capacity, re-lays its own slab of THAT batch (still
+    intact: a slot is reused two batches later; or the stash) and repeats the collective.  Collectives are issued in
+    submission order by one thread, so every rank issues the same sequence.
+    On CPU tensors (gloo, the tests) there are no streams and no thread: the all-gather completes inside submit() and
+    collect() finishes the batch before the one just submitted, which keeps the one-batch-behind bookkeeping honest."""
 
-    def __init__(self, device, merge, group=None, slack=1.125):
+    def __init__(self, device, merge, group=None, slack=1.125, threaded=None):
         import torch
         self.device, self.group, self.slack, self.merge = device, group, slack, merge
         self.cuda = device.type == "cuda"
         self.comm = torch.cuda.Stream(device=device) if self.cuda else None
+        self.threaded = self.cuda if threaded is None else (threaded and self.cuda)
         self.cap = None
         self.calls = self.collectives = self.regrows = 0
         self.slab_bytes = 0
         self.slots = [dict(pending=False) for _ in range(2)]
         self.results = [None, None]  # per slot: (all_counts, offs, slab_bytes) of the last merged batch
+        self._error = None
+        self._thread = None
+        if self.threaded:
+            import queue
+            import threading
+            self._queue = queue.Queue()
+            self._thread = threading.Thread(target=self._comm_loop, name="msgpu-exchange", daemon=True)
+            self._thread.start()
 
     # ---- layout --------------------------------------------------------------------------------------------------
     def _layout(self):
@@ -266,7 +278,8 @@ class PipelinedExchange:
         return offs, slab_bytes
 
     def _gather(self, slot, world):
-        """all-gather of the slot's slab + its headers to pinned host memory, on the communication stream"""
+        """all-gather of the slot's slab + its headers to pinned host memory, on the communication stream (behind the
+        event that says the slab is filled)"""
         import torch
         import torch.distributed as dist
 
@@ -275,16 +288,20 @@ class PipelinedExchange:
             slot["heads_dev"].copy_(slot["gathered"].view(world, slot["slab_bytes"])[:, :24].contiguous().view(torch.int64).view(-1))
             slot["heads"].copy_(slot["heads_dev"], non_blocking=True)
         if self.cuda:
-            filled = torch.cuda.Event()
-            filled.record(torch.cuda.current_stream(self.device))
             with torch.cuda.stream(self.comm):
-                self.comm.wait_event(filled)
+                self.comm.wait_event(slot["filled"])
                 run()
                 slot["done"] = torch.cuda.Event()
                 slot["done"].record(self.comm)
         else:
             run()
         self.collectives += 1
+
+    def _mark_filled(self, slot):
+        import torch
+        if self.cuda:
+            slot["filled"] = torch.cuda.Event()
+            slot["filled"].record(torch.cuda.current_stream(self.device))
 
     # ---- the three calls -----------------------------------------------------------------------------------------
     def submit(self, counts, fill_slab):
@@ -293,12 +310,13 @@ class PipelinedExchange:
         import torch
         import torch.distributed as dist
         world = dist.get_world_size(self.group)
+        self._raise()
         if self.cap is None:
             self._agree(counts)
         slot = self.slots[self.calls % 2]
         self.calls += 1
         if slot["pending"]:
-            self._collect(slot)  # (collect() after every submit() keeps this from happening)
+            self._finish(slot)  # the batch two submissions ago (collect() after every submit() has done it already)
         offs, slab_bytes = self._buffers(slot, world)
         if self.cuda and slot.get("merged") is not None:
             torch.cuda.current_stream(self.device).wait_event(slot["merged"])  # the slab's last reader: two batches ago
@@ -314,8 +332,45 @@ class PipelinedExchange:
             s_offs = tuple(HEADER + o for o in s_offs)
             fill_slab(stash, s_offs)
             slot["stash"] = (stash, s_offs)
-        self._gather(slot, world)
+        self._mark_filled(slot)
         slot["pending"] = True
+        if self.threaded:
+            import threading
+            slot["finished"] = threading.Event()
+            self._queue.put(slot)
+        else:
+            self._gather(slot, world)
+
+    def _comm_loop(self):
+        """the communication thread: all-gather, header check (+ repeat) and merge of every submitted batch, in order"""
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(self.device)
+        while True:
+            slot = self._queue.get()
+            if slot is None:
+                return
+            try:
+                if self._error is None:
+                    self._gather(slot, dist.get_world_size(self.group))
+                    self._collect(slot)
+            except BaseException as exc:  # noqa: BLE001 -- handed to the submitting thread
+                self._error = exc
+            finally:
+                slot["pending"] = False
+                slot["finished"].set()
+
+    def _raise(self):
+        if self._error is not None:
+            exc, self._error = self._error, None
+            raise exc
+
+    def _finish(self, slot):
+        if self.threaded:
+            slot["finished"].wait()
+            self._raise()
+            return self.results[0 if slot is self.slots[0] else 1][0]
+        return self._collect(slot)
 
     def _relayout(self, slot, world):
         """the capacity grew: this batch's own tables move into a slab of the new layout"""
@@ -343,9 +398,12 @@ class PipelinedExchange:
                 break
             self.cap = tuple(max(c, int(n * self.slack) + 64) for c, n in zip(self.cap, heads.max(axis=0)))  # same on every rank
             self.regrows += 1
-            if self.cuda:
-                torch.cuda.current_stream(self.device).wait_stream(self.comm)
-            self._relayout(slot, world)
+            if self.cuda:  # the re-laid slab is written on the communication stream, behind the failed all-gather
+                with torch.cuda.stream(self.comm):
+                    self._relayout(slot, world)
+                    self._mark_filled(slot)
+            else:
+                self._relayout(slot, world)
             self._gather(slot, world)
         k = 0 if slot is self.slots[0] else 1
         if self.cuda:
@@ -360,7 +418,11 @@ class PipelinedExchange:
         return heads
 
     def collect(self):
-        """finish the batch BEFORE the one just submitted (no-op when there is none) -> its all_counts or None"""
+        """without a communication thread: finish the batch BEFORE the one just submitted (no-op when there is none) -> its
+        all_counts or None.  With one: nothing to do here (returns None)."""
+        if self.threaded:
+            self._raise()
+            return None
         slot = self.slots[self.calls % 2]  # the slot the NEXT submit would take = the older of the two
         return self._collect(slot) if slot["pending"] else None
 
@@ -368,8 +430,15 @@ class PipelinedExchange:
         """finish everything submitted; returns the all_counts of the last batch"""
         last = None
         for k in (self.calls % 2, (self.calls + 1) % 2):  # older first
-            if self.slots[k]["pending"]:
-                last = self._collect(self.slots[k])
+            if self.slots[k]["pending"] or (self.threaded and "finished" in self.slots[k]):
+                r = self._finish(self.slots[k])
+                last = r if r is not None else last
         if self.cuda:
             self.comm.synchronize()
         return last
+
+    def close(self):
+        if self._thread is not None:
+            self._queue.put(None)
+            self._thread.join()
+            self._thread = None
