@@ -46,17 +46,34 @@ def _uniform(seed, stream, n, lo, hi):
     return lo + (hi - lo) * u
 
 
-def read_layout(n_reads, read_len, seed, coverage=10):
+def read_lengths(n_reads, read_len, seed, read_len_min=None):
+    """per-read lengths: exactly read_len (the BASELINE shape), or ~U{read_len_min..read_len} (reads of mixed length, so
+    that short reads lie inside long ones: contained EdgeOrders, the input of findContractionEdges)"""
+    if read_len_min is None or read_len_min >= read_len:
+        return np.full(n_reads, read_len, dtype=np.int64)
+    return _randint(seed, 9, n_reads, read_len_min, read_len)
+
+
+def read_layout(n_reads, read_len, seed, coverage=10, read_len_min=None):
     """(genome length, read starts, read strands) -- the same draws paf_table() makes."""
     G = max(int(n_reads) * int(read_len) // int(coverage), read_len + 1500)
-    r_start = _randint(seed, 3, n_reads, 0, G - read_len)
+    r_start = _randint(seed, 3, n_reads, 0, G - read_lengths(n_reads, read_len, seed, read_len_min))
     r_fwd = (splitmix64(seed, 4, n_reads) & np.uint64(1)).astype(bool)
     return G, r_start, r_fwd
 
 
-def anchor_layout(n_reads, read_len, n_anchors, seed, coverage=10):
-    """(anchor starts, anchor lengths) on the genome -- the same draws paf_table() makes."""
+def anchor_layout(n_reads, read_len, n_anchors, seed, coverage=10, tiled=False):
+    """(anchor starts, anchor lengths) on the genome -- the same draws paf_table() makes.  tiled: the anchors are
+    consecutive, NON-overlapping stretches of length ~U{500..1500} separated by gaps ~U{0..300} that cover the genome end to
+    end -- what the unitigs of one genome are (n_anchors is ignored; about G / 1150 of them)."""
     G = max(int(n_reads) * int(read_len) // int(coverage), read_len + 1500)
+    if tiled:
+        n_max = G // 500 + 2
+        a_len = _randint(seed, 1, n_max, 500, 1500)
+        gap = _randint(seed, 10, n_max, 0, 300)
+        a_start = np.cumsum(a_len + gap) - a_len - gap + _randint(seed, 11, 1, 0, 199)[0]
+        keep = a_start + a_len <= G
+        return a_start[keep], a_len[keep]
     a_len = _randint(seed, 1, n_anchors, 500, 1500)
     a_start = _randint(seed, 2, n_anchors, 0, G - a_len)
     return a_start, a_len
@@ -70,13 +87,14 @@ def genome_bases(G, seed):
     return np.frombuffer(b"ACGT", dtype=np.uint8)[codes]
 
 
-def paf_table(n_reads, read_len, n_anchors, seed, coverage=10, min_intersection=420, jitter=15):
-    """PAF-level columns of the synthetic alignment set (before the reference's filter)."""
-    G = max(int(n_reads) * int(read_len) // int(coverage), read_len + 1500)
-    a_len = _randint(seed, 1, n_anchors, 500, 1500)
-    a_start = _randint(seed, 2, n_anchors, 0, G - a_len)
-    r_start = _randint(seed, 3, n_reads, 0, G - read_len)
-    r_fwd = (splitmix64(seed, 4, n_reads) & np.uint64(1)).astype(bool)
+def paf_table(n_reads, read_len, n_anchors, seed, coverage=10, min_intersection=420, jitter=15, tiled=False,
+              read_len_min=None):
+    """PAF-level columns of the synthetic alignment set (before the reference's filter).  tiled / read_len_min: see
+    anchor_layout / read_lengths (defaults = the BASELINE shape: independent random anchors, reads of exactly read_len)."""
+    G, r_start, r_fwd = read_layout(n_reads, read_len, seed, coverage, read_len_min)
+    a_start, a_len = anchor_layout(n_reads, read_len, n_anchors, seed, coverage, tiled)
+    n_anchors = len(a_start)
+    read_len = read_lengths(n_reads, read_len, seed, read_len_min)  # per read from here on
 
     order = np.argsort(a_start, kind="stable")
     starts = a_start[order]
@@ -89,7 +107,7 @@ def paf_table(n_reads, read_len, n_anchors, seed, coverage=10, min_intersection=
     k = np.arange(tot, dtype=np.int64) - first + np.repeat(lo, cnt)
     aid = order[k]
     g_lo = np.maximum(a_start[aid], r_start[rid])
-    g_hi = np.minimum(a_start[aid] + a_len[aid], r_start[rid] + read_len)
+    g_hi = np.minimum(a_start[aid] + a_len[aid], r_start[rid] + read_len[rid])
     keep = (g_hi - g_lo) >= min_intersection
     aid, rid, g_lo, g_hi = aid[keep], rid[keep], g_lo[keep], g_hi[keep]
     # rows grouped by anchor id, then read id
@@ -99,13 +117,13 @@ def paf_table(n_reads, read_len, n_anchors, seed, coverage=10, min_intersection=
     q_lo = g_lo - a_start[aid]
     q_hi = g_hi - a_start[aid]
     fwd = r_fwd[rid]
-    t_lo = np.where(fwd, g_lo - r_start[rid], r_start[rid] + read_len - g_hi)
-    t_hi = np.where(fwd, g_hi - r_start[rid], r_start[rid] + read_len - g_lo)
+    t_lo = np.where(fwd, g_lo - r_start[rid], r_start[rid] + read_len[rid] - g_hi)
+    t_hi = np.where(fwd, g_hi - r_start[rid], r_start[rid] + read_len[rid] - g_lo)
     t_lo = np.maximum(0, t_lo + _randint(seed, 5, n, -jitter, jitter))
-    t_hi = np.minimum(read_len, t_hi + _randint(seed, 6, n, -jitter, jitter))
+    t_hi = np.minimum(read_len[rid], t_hi + _randint(seed, 6, n, -jitter, jitter))
     nmatch = np.floor((q_hi - q_lo) * _uniform(seed, 7, n, 0.86, 0.97)).astype(np.int64)
     return {"qname_id": aid, "qlen": a_len[aid], "qstart": q_lo, "qend": q_hi, "strand": fwd, "tname_id": rid,
-            "tlen": np.full(n, read_len, dtype=np.int64), "tstart": t_lo, "tend": t_hi, "nmatch": nmatch,
+            "tlen": read_len[rid], "tstart": t_lo, "tend": t_hi, "nmatch": nmatch,
             "genome": G}
 
 
@@ -150,9 +168,9 @@ def paf_lines(tab):
     return out
 
 
-def synth_rows(n_reads, read_len, n_anchors, seed, coverage=10):
+def synth_rows(n_reads, read_len, n_anchors, seed, coverage=10, **shape):
     """Convenience: accepted msgpu_row table of a synthetic workload."""
-    rows, _, _ = accepted_rows(paf_table(n_reads, read_len, n_anchors, seed, coverage))
+    rows, _, _ = accepted_rows(paf_table(n_reads, read_len, n_anchors, seed, coverage, **shape))
     return rows
 
 
@@ -222,4 +240,10 @@ def chain_paths(tables, read_start, read_fwd, read_len, window_end, max_reads=12
 CONFIGS = {
     "cfg2": dict(n_reads=10_000, read_len=5_000, n_anchors=50_000, seed=42),
     "cfg3": dict(n_reads=100_000, read_len=10_000, n_anchors=500_000, seed=43),
+}
+# the same sizes on the shape the graph stage and assemblePath exist for: unitigs that TILE the genome (no two anchors
+# overlap) and reads of mixed length (short ones contained in long ones).  Not BASELINE configurations.
+TILED = {
+    "cfg2": dict(n_reads=10_000, read_len=5_000, n_anchors=0, seed=42, tiled=True, read_len_min=1_250),
+    "cfg3": dict(n_reads=100_000, read_len=10_000, n_anchors=0, seed=43, tiled=True, read_len_min=2_500),
 }

@@ -94,3 +94,22 @@ def make_dataset(d, seed, jitter, fastq, n_reads=400, genome_len=250_000):
             else:
                 f.write(b">r%d\n" % i + nano[i] + b"\n")
     return rows, lay, genome, nano, illu, name
+
+
+def synth_sequences(shape, read_names, anchor_names):
+    """The reads / unitigs of a muchsalsa_amd.synth workload (CONFIGS or TILED entry) keyed by Registry id, as the bytes
+    the FASTA files hold -> (genome length, read starts, read strands, read lengths, nano {id: bytes}, illu {id: bytes})"""
+    from muchsalsa_amd import synth
+    n_reads, L, seed = shape["n_reads"], shape["read_len"], shape["seed"]
+    G, r_start, r_fwd = synth.read_layout(n_reads, L, seed, read_len_min=shape.get("read_len_min"))
+    r_len = synth.read_lengths(n_reads, L, seed, shape.get("read_len_min"))
+    a_start, a_len = synth.anchor_layout(n_reads, L, shape["n_anchors"], seed, tiled=shape.get("tiled", False))
+    genome = synth.genome_bases(G, seed).tobytes()
+    ro = np.array([int(n[1:]) for n in read_names])
+    ao = np.array([int(n[1:]) for n in anchor_names])
+    nano = {}
+    for i, o in enumerate(ro):
+        s = genome[r_start[o]: r_start[o] + r_len[o]]
+        nano[i] = s if r_fwd[o] else s.translate(_COMP)[::-1]
+    illu = {i: genome[a_start[o]: a_start[o] + a_len[o]] for i, o in enumerate(ao)}
+    return G, r_start[ro], r_fwd[ro], r_len[ro], nano, illu

@@ -149,3 +149,124 @@ def test_assemble_path_whole_genome(oracle, cfg, two_bit, tmp_path):
     T = int(asm.paths["target_len"].sum())
     assert T == sum(len(r["target"]) for r in want) and T > 0.9 * G  # the chains tile the genome
     store.close()
+
+
+# ---- the rows SURVEY.md section 8(f) marks "next", at full size: findContractionEdges (GPU), graph stage, real-path A9 ----
+
+def _tiled(cfg, oracle):
+    """synth.TILED[cfg]: unitigs that tile the genome, reads of mixed length -> rows, names, oracle tables"""
+    key = "tiled-" + cfg
+    if key not in _CACHE:
+        from muchsalsa_amd import synth
+        rows, read_names, anchor_names = synth.accepted_rows(synth.paf_table(**synth.TILED[cfg]))
+        _CACHE[key] = (rows, read_names, anchor_names, oracle.overlap(rows))
+    return _CACHE[key]
+
+
+def _promote_contained(t):
+    """every contained EdgeOrder made primary: more candidates for findContractionEdges, all four containment cases of
+    sanityCheck (sc.cpp:41-82) at scale"""
+    o = t["orders"].copy()
+    o["flags"] |= np.where(o["flags"] & 2, 8, 0).astype(np.uint32)
+    return dict(t, orders=o)
+
+
+@pytest.mark.parametrize("shape,cfg", [("baseline", "cfg2"), ("baseline", "cfg3"), ("tiled", "cfg2"), ("tiled", "cfg3")])
+def test_find_contraction_edges_full_size(oracle, shape, cfg):
+    """findContractionEdges + sanityCheck (src/main.cpp:416-463, sc.cpp:29-90) as k_check_contraction at the size of
+    BASELINE.json configs[1] / configs[2]: on the tables the GPU just produced (bit-exact themselves), plain and with
+    every contained order promoted to primary, == the C oracle's list.  The BASELINE shape has no contraction edge until
+    promoted (reads of one length are never contained); the tiled shape has tens of thousands."""
+    import torch
+    from muchsalsa_amd import overlap
+    rows, read_names, anchor_names, want = (_workload if shape == "baseline" else _tiled)(cfg, oracle)
+    n = len(want["read_len"])
+    with overlap.OverlapContext(0) as ctx:
+        ctx.set_id_space(len(read_names), len(anchor_names))
+        ctx.load_rows(rows)
+        ctx.calculate_edges()
+        ctx.chaining_and_overlaps()
+        assert_tables_equal(ctx.tables(), want, "%s %s" % (shape, cfg))
+        got = ctx.find_contraction_edges()
+        want_co = oracle.find_contraction_edges(want, n)
+        assert np.array_equal(got, want_co)
+        hits = int((want_co >= 0).sum())
+        assert hits > (0 if shape == "baseline" else len(want["edges"]) // 10), hits
+        promoted = _promote_contained(want)
+        d_e = torch.from_numpy(promoted["edges"].view(np.uint8).copy()).cuda()
+        d_o = torch.from_numpy(promoted["orders"].view(np.uint8).copy()).cuda()
+        got = ctx.find_contraction_edges(d_e.data_ptr(), len(promoted["edges"]), d_o.data_ptr(), len(promoted["orders"]), n)
+        want_co = oracle.find_contraction_edges(promoted, n)
+        assert np.array_equal(got, want_co)
+        n_contained = int(((want["orders"]["flags"] & 2) != 0).sum())
+        if n_contained:
+            assert int((want_co >= 0).sum()) >= hits and int((want_co >= 0).sum()) > 0
+        print("%s %s: %d edges, %d contained orders, %d contraction edges, %d when promoted" % (
+            shape, cfg, len(want["edges"]), n_contained, hits, int((want_co >= 0).sum())))
+
+
+@pytest.mark.parametrize("shape,cfg", [("baseline", "cfg2"), ("tiled", "cfg3")])
+def test_graph_stage_full_size_on_gpu_tables(oracle, shape, cfg):
+    """The flat-CSR host graph stage (rooted span forest for decycle, per-component heap for extractPaths) on the tables
+    and the contraction list the GPU produced, == oracle/ms_graph_py.py: BASELINE.json configs[1] (98 k edges, one giant
+    component of shadow edges) and the tiled shape at the size of configs[2] (100 k reads, 578 k edges, 94 k contraction
+    edges, hundreds of components); each also with a tenth of the order directions flipped (decycle conflicts)."""
+    from test_graph_fullsize import compare_stage, flip_strands
+    from muchsalsa_amd import overlap
+    rows, read_names, anchor_names, want = (_workload if shape == "baseline" else _tiled)(cfg, oracle)
+    n = len(want["read_len"])
+    with overlap.OverlapContext(0) as ctx:
+        ctx.set_id_space(len(read_names), len(anchor_names))
+        t, _ = ctx.overlap_batched(rows, 4, resident=True)
+        assert_tables_equal(t, want, "%s %s" % (shape, cfg))
+        co = ctx.find_contraction_edges()
+        c = compare_stage(oracle, rows, t, co, threads=8)
+        print(shape, cfg, c)
+        assert c is not None and c["n_paths"] > 0
+        if shape == "tiled":
+            assert c["n_contraction_edges"] > 50_000 and c["n_components"] > 100 and c["longest_path"] > 200
+        t2 = flip_strands(t, 11, every=10 if shape == "tiled" else 40)
+        d_e = __import__("torch").from_numpy(t2["edges"].view(np.uint8).copy()).cuda()
+        d_o = __import__("torch").from_numpy(t2["orders"].view(np.uint8).copy()).cuda()
+        co2 = ctx.find_contraction_edges(d_e.data_ptr(), len(t2["edges"]), d_o.data_ptr(), len(t2["orders"]), n)
+        assert np.array_equal(co2, oracle.find_contraction_edges(t2, n))
+    c2 = compare_stage(oracle, rows, t2, co2, threads=8)
+    print(shape, cfg, "flipped:", c2)
+    assert c2 is None or c2["n_decycled_edges"] > 0
+
+
+@pytest.mark.parametrize("cfg", ["cfg2", "cfg3"])
+def test_whole_flow_tiled_full_size(oracle, cfg, tmp_path):
+    """PAF text + FASTA in -> temp_1.{target.fa, query.fa, align.paf} out of muchsalsa_amd.pipeline.run (the dispatcher
+    with the EdgeMatch table left in HBM, the GPU contraction test, the host graph stage, the path edges' EdgeMatches on
+    demand, assemblePath over the paths linearizeGraph yields) at the size of configs[1] / configs[2] on the tiled shape,
+    byte-identical to the flow made of oracles only (C overlap oracle, C findContractionEdges, Python graph stage, Python
+    assemblePath): A9 on the REAL paths, tolerance 0 against the restatement -- and the contigs cover the genome."""
+    from graphcases import synth_sequences
+    from test_gpu_pipeline import oracle_flow
+    from muchsalsa_amd import pipeline, synth
+    shape = synth.TILED[cfg]
+    tab = synth.paf_table(**shape)
+    rows, read_names, anchor_names, _ = _tiled(cfg, oracle)
+    G, rs, rf, rl, nano, illu = synth_sequences(shape, read_names, anchor_names)
+    (tmp_path / "contigs.paf").write_text("\n".join(synth.paf_lines(tab)) + "\n")
+    with open(tmp_path / "unitigs.fa", "wb") as f:
+        for j, name in enumerate(anchor_names):
+            f.write(b">%s\n" % name.encode() + illu[j] + b"\n")
+    with open(tmp_path / "nanopore.fa", "wb") as f:
+        for i, name in enumerate(read_names):
+            f.write(b">%s\n" % name.encode() + nano[i] + b"\n")
+    out = tmp_path / "out"
+    out.mkdir()
+    timings = {}
+    res = pipeline.run(str(tmp_path / "contigs.paf"), str(tmp_path / "unitigs.fa"), str(tmp_path / "nanopore.fa"), str(out),
+                       threads=min(16, os.cpu_count() or 1), timings=timings)
+    print(cfg, res, {k: round(v, 4) for k, v in timings.items()})
+    assert res["rows"] == len(rows) and res["paths_skipped"] == 0 and res["contraction_edges"] > res["edges"] // 10
+    want = oracle_flow(oracle, rows, nano, illu)
+    assert res["contigs"] == len(want) > 0
+    assert A9_TOLERANCE_VS_RESTATEMENT == 0
+    assert (out / "temp_1.align.paf").read_bytes() == b"".join(r["paf"] for r in want)
+    assert (out / "temp_1.target.fa").read_bytes() == b"".join(r["target_fa"] for r in want)
+    assert (out / "temp_1.query.fa").read_bytes() == b"".join(r["query_fa"] for r in want)
+    assert 0.97 * G < res["target_bases"] < 1.03 * G  # (contigs tile the genome; joints duplicate a few bases each)
