@@ -129,6 +129,7 @@ struct msgpu_ctx {
   bool         chain_zeroed = false; // msgpu_calculate_edges zeroed the chain stage's per-edge counters
   bool         no_prologue = false; // msgpu_overlap_batched with several windows: every window has its own opening
   bool         prologue_ok = false; // the candidate stage's opening ran with the index build (whole table, fast index)
+  bool         cand_zeroed = false; // ... including the zeroing of the candidate kernels' counters (used up by the next msgpu_calculate_edges)
   uint64_t     prologue_bound = 0;
   uint32_t     prologue_lists[4] = {0, 0, 0, 0};
   uint64_t     readback_seq = 0;
@@ -152,8 +153,8 @@ struct msgpu_ctx {
   DevBuf bound, cand_off, cand_j, cand_t, scr_v2, scr_start, n_cand, n_edge, n_visit_arr, lists, em_base, edge_base,
       visit_base, edges, edge_cand;
   DevBuf big_key, big_t, big_r2s, big_pfx, pair_tab, edge_fast, big_off;
-  hipStream_t side_stream = nullptr;
-  hipEvent_t  ev_side[2]  = {nullptr, nullptr};
+  hipStream_t side_stream = nullptr, side_stream2 = nullptr;
+  hipEvent_t  ev_side[2]  = {nullptr, nullptr}, ev_side2 = nullptr;
   uint64_t    n_big_edges = 0, n_big_ems = 0;
   bool   fast_path = true;
   bool   sub_wave  = true; // short edges share a wavefront (k_chain_sub); MSGPU_NO_SUBWAVE=1 sends them all to k_chain
@@ -375,13 +376,27 @@ int build_index_once(msgpu_ctx *c, bool force_generic, bool two_pass, uint32_t *
     launch_classify_reads(st, c->read_off.as<uint32_t>(), c->read_cnt.as<uint32_t>(), c->visits.as<uint32_t>(),
                           c->cand_off.as<uint64_t>(), V, 0, 1, 0, 0xffffffffu, l0, l1, l2,
                           reinterpret_cast<uint32_t *>(l2 + V + 1), scalar<uint32_t>(c, SC_NLISTS));
+    // ... and so does the zeroing the candidate kernels need (per-read counters, big-edge statistics / cursor / width
+    // classes): on an idle queue every launch costs ~12 us of host latency, here it hides behind the index kernels
+    ENSURE(c, n_cand, (size_t(V) + 1) * 4);
+    ENSURE(c, n_edge, (size_t(V) + 1) * 4);
+    ENSURE(c, n_visit_arr, (size_t(V) + 1) * 4);
+    static_assert(SC_BIGCUR == SC_BIGSTATS + 2 && SC_CLS == SC_BIGCUR + 2 && SC_COUNT == SC_CLS + 2, "adjacent scalar slots");
+    uint32_t *const zero[4]   = {scalar<uint32_t>(c, SC_BIGSTATS), c->n_cand.as<uint32_t>(), c->n_edge.as<uint32_t>(),
+                                 c->n_visit_arr.as<uint32_t>()};
+    const uint32_t  n_zero[4] = {12, V + 1, V + 1, V + 1};
+    uint32_t *const ones[2]   = {nullptr, nullptr};
+    const uint32_t  n_ones[2] = {0, 0};
+    launch_index_init(st, zero, n_zero, ones, n_ones);
     HIPCHK(c, hipGetLastError());
   }
 
   if (int rc = read_scalars(c)) return rc;
   const uint32_t err = *host_scalar<uint32_t>(c, SC_ERR), ixf = *host_scalar<uint32_t>(c, SC_IXFLAGS);
+  c->cand_zeroed = false;
   if (want_prologue && ixf == 0 && err == 0) {
     c->prologue_ok    = true;
+    c->cand_zeroed    = true;
     c->prologue_bound = *host_scalar<uint64_t>(c, SC_TOTAL_A);
     for (int k = 0; k < 4; ++k) c->prologue_lists[k] = host_scalar<uint32_t>(c, SC_NLISTS)[k];
   }
@@ -513,6 +528,8 @@ int msgpu_create(int device, const msgpu_params *params, msgpu_ctx **out) {
   int prio_least = 0, prio_greatest = 0;
   if (hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest) != hipSuccess) prio_least = prio_greatest = 0;
   if (hipStreamCreateWithPriority(&c->side_stream, hipStreamNonBlocking, prio_greatest) != hipSuccess ||
+      hipStreamCreateWithPriority(&c->side_stream2, hipStreamNonBlocking, prio_greatest) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_side2, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_side[0], hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_side[1], hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_readback, hipEventDisableTiming) != hipSuccess) {
@@ -543,6 +560,11 @@ void msgpu_destroy(msgpu_ctx *c) {
   for (auto &ev : c->ev_side)
     if (ev) (void)hipEventDestroy(ev);
   if (c->ev_readback) (void)hipEventDestroy(c->ev_readback);
+  if (c->ev_side2) (void)hipEventDestroy(c->ev_side2);
+  if (c->side_stream2) {
+    (void)hipStreamSynchronize(c->side_stream2);
+    (void)hipStreamDestroy(c->side_stream2);
+  }
   for (auto &pair : c->ck_ev)
     for (auto &ev : pair)
       if (ev) (void)hipEventDestroy(ev);
@@ -652,7 +674,10 @@ int msgpu_calculate_edges(msgpu_ctx *c) {
   CandDesc *l0 = c->lists.as<CandDesc>(), *l1 = l0 + V + 1, *l2 = l1 + V + 1;
   uint32_t *l3 = reinterpret_cast<uint32_t *>(l2 + V + 1);
 
-  {
+  const bool all_reads = c->index_fast && c->nshards == 1 && c->win_lo == 0 && c->win_hi >= V;
+  const bool zeroed    = all_reads && c->prologue_ok && c->cand_zeroed; // the index build's prologue did it already
+  c->cand_zeroed       = false;
+  if (!zeroed) {
     uint32_t *const zero[4]   = {scalar<uint32_t>(c, SC_NLISTS), c->n_cand.as<uint32_t>(), c->n_edge.as<uint32_t>(),
                                  c->n_visit_arr.as<uint32_t>()};
     const uint32_t  n_zero[4] = {4, V + 1, V + 1, V + 1};
@@ -662,7 +687,6 @@ int msgpu_calculate_edges(msgpu_ctx *c) {
   }
   // the scaffold rows each owner read visits: the index build's sort left the sum per read (fast index); a shard or a
   // window of owner reads, or a generically built index (scan view patched after the sort), counts them here
-  const bool      all_reads = c->index_fast && c->nshards == 1 && c->win_lo == 0 && c->win_hi >= V;
   const uint32_t *bound     = all_reads ? c->visits.as<uint32_t>() : c->bound.as<uint32_t>();
   uint64_t total_bound;
   if (all_reads && c->prologue_ok) { // done with the index build; the numbers came back with its flags
@@ -709,22 +733,34 @@ int msgpu_calculate_edges(msgpu_ctx *c) {
   a.big_stats      = scalar<unsigned long long>(c, SC_BIGSTATS);
   // big-edge statistics, the big-edge list cursor and the width-class counts: slots SC_BIGSTATS .. SC_CLS, one memset
   static_assert(SC_BIGCUR == SC_BIGSTATS + 2 && SC_CLS == SC_BIGCUR + 2 && SC_COUNT == SC_CLS + 2, "adjacent scalar slots");
-  HIPCHK(c, hipMemsetAsync(a.big_stats, 0, 48, st));
-  // the LDS classes run side by side: the heavier, smaller classes on the side stream, so their tails overlap
+  if (!zeroed) HIPCHK(c, hipMemsetAsync(a.big_stats, 0, 48, st));
+  // The LDS classes run side by side, each on a stream of its own, and the two heavy ones are launched FIRST: a
+  // workgroup of class 2 needs 112 KB of LDS and one of class 1 28 KB, a CU that is full of class-0 workgroups (8 x 16 KB)
+  // never has that much free while class 0's grid keeps refilling it -- launched behind class 0 the nine class-2
+  // workgroups of BASELINE.json configs[2] waited for the END of class 0 (240 us for a few microseconds of work,
+  // profiles/r2_08/timeline_one_step.txt) and class 1 queued behind them.  Launched first they take their CUs while
+  // those are empty and class 0 fills the rest.
   static const bool no_fork = getenv("MSGPU_NO_FORK") != nullptr; // measurement switch: the classes one after the other
   const bool fork = (c->n_list[1] || c->n_list[2]) && c->n_list[0] && !no_fork;
-  // (the main stream's kernel is launched first: the four host calls of the fork would otherwise stand in front of it;
-  // the side stream's workgroups have the higher priority and still finish first)
-  if (fork) HIPCHK(c, hipEventRecord(c->ev_side[0], st));
-  hipStream_t st2 = fork ? c->side_stream : st;
-  if (fork) launch_candidates(st, a, 0, l0, c->n_list[0]);
-  if (fork) HIPCHK(c, hipStreamWaitEvent(c->side_stream, c->ev_side[0], 0));
-  launch_candidates(st2, a, 2, l2, c->n_list[2]);
-  launch_candidates(st2, a, 1, l1, c->n_list[1]);
-  if (!fork) launch_candidates(st, a, 0, l0, c->n_list[0]);
   if (fork) {
-    HIPCHK(c, hipEventRecord(c->ev_side[1], c->side_stream));
-    HIPCHK(c, hipStreamWaitEvent(st, c->ev_side[1], 0));
+    HIPCHK(c, hipEventRecord(c->ev_side[0], st));
+    if (c->n_list[2]) {
+      HIPCHK(c, hipStreamWaitEvent(c->side_stream, c->ev_side[0], 0));
+      launch_candidates(c->side_stream, a, 2, l2, c->n_list[2]);
+      HIPCHK(c, hipEventRecord(c->ev_side[1], c->side_stream));
+    }
+    if (c->n_list[1]) {
+      HIPCHK(c, hipStreamWaitEvent(c->side_stream2, c->ev_side[0], 0));
+      launch_candidates(c->side_stream2, a, 1, l1, c->n_list[1]);
+      HIPCHK(c, hipEventRecord(c->ev_side2, c->side_stream2));
+    }
+    launch_candidates(st, a, 0, l0, c->n_list[0]);
+    if (c->n_list[2]) HIPCHK(c, hipStreamWaitEvent(st, c->ev_side[1], 0));
+    if (c->n_list[1]) HIPCHK(c, hipStreamWaitEvent(st, c->ev_side2, 0));
+  } else {
+    launch_candidates(st, a, 2, l2, c->n_list[2]);
+    launch_candidates(st, a, 1, l1, c->n_list[1]);
+    launch_candidates(st, a, 0, l0, c->n_list[0]);
   }
   if (c->n_list[3]) {
     ENSURE(c, big_key, tb * 8);
