@@ -76,6 +76,45 @@ struct Tick { // MSGPU_GRAPH_DEBUG=1: phase timings on stderr
   }
 };
 
+// host threads for the loops over all edges / orders of the stage (results never depend on the count): the cores this
+// process may use, at most 16; MSGPU_GRAPH_THREADS overrides
+unsigned stage_threads() {
+  static const unsigned n = [] {
+    if (const char *e = std::getenv("MSGPU_GRAPH_THREADS")) {
+      const int v = std::atoi(e);
+      if (v > 0) return static_cast<unsigned>(v);
+    }
+    unsigned hw = std::thread::hardware_concurrency();
+    return hw == 0 ? 1u : hw > 16 ? 16u : hw;
+  }();
+  return n;
+}
+// f(chunk, begin, end) over [0, n) cut into contiguous chunks, one per thread; chunk indices ascend with the range, so
+// per-chunk results concatenated in chunk order are in index order.  The first exception of a chunk is rethrown here.
+template <class F> unsigned parallel_chunks(size_t n, F f) {
+  unsigned nt = stage_threads();
+  if (n < (size_t(1) << 16)) nt = 1;
+  if (nt <= 1) {
+    f(0u, size_t(0), n);
+    return 1;
+  }
+  const size_t                    per = (n + nt - 1) / nt;
+  std::vector<std::exception_ptr> err(nt);
+  std::vector<std::thread>        pool;
+  auto run = [&](unsigned c) {
+    const size_t b = std::min(n, per * c), e = std::min(n, per * (c + 1));
+    try {
+      f(c, b, e);
+    } catch (...) { err[c] = std::current_exception(); }
+  };
+  for (unsigned c = 1; c < nt; ++c) pool.emplace_back(run, c);
+  run(0);
+  for (auto &t : pool) t.join();
+  for (auto &e : err)
+    if (e) std::rethrow_exception(e);
+  return nt;
+}
+
 // ---- flat adjacency ----------------------------------------------------------------------------------------------------
 
 struct Arc {
@@ -162,20 +201,30 @@ struct UnionFind { // vertex ids are dense: vectors instead of the reference's t
 // ends(e) -> (a, b), weight(e).
 template <class Ends, class Weight>
 void max_span_tree(uint32_t nv, Ends ends, Weight weight, std::vector<uint32_t> cand, std::vector<uint8_t> &in_tree) {
-  std::vector<std::pair<uint64_t, uint32_t>> keyed(cand.size()); // (weight, position): one sort key, no gathers in the compare
-  for (size_t i = 0; i < cand.size(); ++i) keyed[i] = {weight(cand[i]), static_cast<uint32_t>(i)};
+  // (weight, position): one sort key, no gathers in the compare.  Edges of weight 0 (every shadow edge: 97 % of the edges
+  // of BASELINE.json configs[2]) come last whatever their number and keep their edge order among themselves: they are
+  // not sorted at all.
+  std::vector<std::pair<uint64_t, uint32_t>> keyed;
+  std::vector<uint32_t>                      zeros;
+  for (size_t i = 0; i < cand.size(); ++i) {
+    const uint64_t w = weight(cand[i]);
+    if (w) keyed.emplace_back(w, static_cast<uint32_t>(i));
+    else zeros.push_back(static_cast<uint32_t>(i));
+  }
   std::sort(keyed.begin(), keyed.end(), [](const std::pair<uint64_t, uint32_t> &x, const std::pair<uint64_t, uint32_t> &y) {
     return x.first != y.first ? x.first > y.first : x.second < y.second;
   });
   UnionFind uf(nv);
-  for (auto &k : keyed) {
-    const uint32_t e = cand[k.second];
+  auto      take = [&](uint32_t pos) {
+    const uint32_t e  = cand[pos];
     const auto     ab = ends(e);
     if (uf.find(ab.first) != uf.find(ab.second)) {
       in_tree[e] = 1;
       uf.unify(ab.first, ab.second);
     }
-  }
+  };
+  for (auto &k : keyed) take(k.second);
+  for (uint32_t pos : zeros) take(pos);
 }
 
 // GraphUtil::getShortestPath (Graph.h:927-978): Dijkstra with unit weights whose queue is ordered by (distance,
@@ -295,6 +344,10 @@ struct msgpu_graph {
   std::vector<Vertex>  V;
   std::vector<Edge>    E;
   std::vector<uint8_t> o_kept;  // per order: still on its edge (findDeletableEdges drops the contained ones)
+  struct OLite { // what the walks over the graph read of an EdgeOrder (16 of its 64 bytes: the random accesses of
+    uint32_t start, end, base, flags; // getDirectedGraph stay inside a quarter of the cache footprint)
+  };
+  std::vector<OLite> ol;
   Csr                  adj;
   struct Contain {
     uint32_t nano, direction;
@@ -315,8 +368,8 @@ struct msgpu_graph {
   std::vector<PathStore> paths;
   char err[256] = {0};
 
-  bool odir(uint32_t o) const { return (t_orders[o].flags & MSGPU_ORD_DIR) != 0; }
-  bool ocont(uint32_t o) const { return (t_orders[o].flags & MSGPU_ORD_CONTAINED) != 0; }
+  bool odir(uint32_t o) const { return (ol[o].flags & MSGPU_ORD_DIR) != 0; }
+  bool ocont(uint32_t o) const { return (ol[o].flags & MSGPU_ORD_CONTAINED) != 0; }
   int64_t edge_between(uint32_t a, uint32_t b) const {
     const Arc *t = adj.find(a, b);
     return t && E[t->e].alive ? static_cast<int64_t>(t->e) : -1;
@@ -367,7 +420,7 @@ DiG get_directed_graph(msgpu_graph &g, uint32_t cid, const std::vector<uint32_t>
       __builtin_prefetch(&g.V[n->to]);
     }
     for (const Arc *n = g.adj.begin(cur); n != g.adj.end(cur); ++n)
-      if (g.E[n->e].alive && !g.E[n->e].de_fwd && !g.E[n->e].de_bwd) __builtin_prefetch(&g.t_orders[g.E[n->e].ord_lo]);
+      if (g.E[n->e].alive && !g.E[n->e].de_fwd && !g.E[n->e].de_bwd) __builtin_prefetch(&g.ol[g.E[n->e].ord_lo]);
     for (const Arc *n = g.adj.begin(cur); n != g.adj.end(cur); ++n) {
       const uint32_t nb = n->to, ue = n->e;
       if (!g.E[ue].alive || g.V[nb].comp != cid) continue;
@@ -378,8 +431,8 @@ DiG get_directed_graph(msgpu_graph &g, uint32_t cid, const std::vector<uint32_t>
       const uint32_t lo = g.E[ue].ord_lo, hi = lo + g.E[ue].ord_cnt;
       for (uint32_t oi = lo; oi < hi; ++oi) {
         if (!g.o_kept[oi]) continue;
-        const msgpu_order &o    = g.t_orders[oi];
-        bool               flip = false;
+        const msgpu_graph::OLite &o = g.ol[oi];
+        bool                      flip = false;
         if (!g.odir(oi) && o.base == nb) flip = !flip;
         if (!toggle) flip = !flip;
         const uint32_t s = flip ? o.end : o.start, t = flip ? o.start : o.end;
@@ -401,6 +454,8 @@ DiG get_directed_graph(msgpu_graph &g, uint32_t cid, const std::vector<uint32_t>
       if (!other_exists) stack.emplace_back(nb, nxt);
     }
   }
+  Tick tk;
+  tk("  dg: (walk, reported by caller)");
   // local ids in ascending global id
   for (uint32_t v : members)
     if (g.V[v].in_dg) dg.ids.push_back(v);
@@ -420,8 +475,27 @@ DiG get_directed_graph(msgpu_graph &g, uint32_t cid, const std::vector<uint32_t>
   dg.ord.resize(pushes.size());
   std::vector<uint32_t> cur(dg.ord_off.begin(), dg.ord_off.end() - 1);
   for (auto &p : pushes) dg.ord[cur[p.first]++] = p.second;
-  dg.succ = build_csr(dg.n, dg.ea.data(), dg.eb.data(), m, false);
-  dg.pred = build_csr(dg.n, dg.eb.data(), dg.ea.data(), m, false);
+  tk("  dg: ids + order lists");
+  if (m > (size_t(1) << 16) && stage_threads() > 1) { // the two adjacencies of a large component side by side
+    std::exception_ptr err;
+    std::thread        t([&] {
+      try {
+        dg.pred = build_csr(dg.n, dg.eb.data(), dg.ea.data(), m, false);
+      } catch (...) { err = std::current_exception(); }
+    });
+    try {
+      dg.succ = build_csr(dg.n, dg.ea.data(), dg.eb.data(), m, false);
+    } catch (...) {
+      t.join();
+      throw;
+    }
+    t.join();
+    if (err) std::rethrow_exception(err);
+  } else {
+    dg.succ = build_csr(dg.n, dg.ea.data(), dg.eb.data(), m, false);
+    dg.pred = build_csr(dg.n, dg.eb.data(), dg.ea.data(), m, false);
+  }
+  tk("  dg: succ / pred CSR");
   return dg;
 }
 
@@ -1042,26 +1116,53 @@ static int graph_create(const msgpu_edge *edges, uint64_t n_edges, const msgpu_e
     }
     g->E.resize(n_edges);
     g->o_kept.assign(n_orders, 0);
-    for (uint64_t i = 0; i < n_edges; ++i) {
-      const msgpu_edge &e = edges[i];
-      if (e.v1 >= n_reads || e.v2 >= n_reads || e.v1 == e.v2 || e.order_off + e.order_cnt > n_orders ||
-          (!on_demand && e.em_off + e.em_cnt > n_ems))
-        return MSGPU_E_ARG;
-      msgpu_graph::Edge &u = g->E[i];
-      u.a       = e.v1;
-      u.b       = e.v2;
-      u.shadow  = e.shadow != 0;
-      u.ord_lo  = static_cast<uint32_t>(e.order_off);
-      u.ord_cnt = e.order_cnt;
-      for (uint32_t k = 0; k < e.order_cnt; ++k) {
-        if (g->o_kept[e.order_off + k]) return MSGPU_E_ARG; // an order on two edges
-        g->o_kept[e.order_off + k] = 1;
+    g->ol.resize(n_orders);
+    std::atomic<int> bad{0};
+    parallel_chunks(n_edges, [&](unsigned, size_t b, size_t e_end) {
+      for (size_t i = b; i < e_end; ++i) {
+        const msgpu_edge &e = edges[i];
+        if (e.v1 >= n_reads || e.v2 >= n_reads || e.v1 == e.v2 || e.order_off + e.order_cnt > n_orders ||
+            (!on_demand && e.em_off + e.em_cnt > n_ems)) {
+          bad = 1;
+          return;
+        }
+        msgpu_graph::Edge &u = g->E[i];
+        u.a       = e.v1;
+        u.b       = e.v2;
+        u.shadow  = e.shadow != 0;
+        u.ord_lo  = static_cast<uint32_t>(e.order_off);
+        u.ord_cnt = e.order_cnt;
+        for (uint32_t k = 0; k < e.order_cnt; ++k) g->o_kept[e.order_off + k] = 1;
+        if (e.order_cnt) u.first = u.ord_lo;
       }
-      if (e.order_cnt) u.first = u.ord_lo;
-    }
-    for (uint64_t k = 0; k < n_orders; ++k) {
-      const msgpu_order &o = orders[k];
-      if (o.start >= n_reads || o.end >= n_reads || o.base >= n_reads || o.ids_off + o.ids_cnt > n_ids) return MSGPU_E_ARG;
+    });
+    if (bad) return MSGPU_E_ARG;
+    {
+      // an order on two edges: the edges' order ranges would cover fewer orders than their lengths add up to
+      std::vector<uint64_t> sums(stage_threads() + 1, 0), kept(stage_threads() + 1, 0);
+      parallel_chunks(n_edges, [&](unsigned c, size_t b, size_t e_end) {
+        uint64_t s = 0;
+        for (size_t i = b; i < e_end; ++i) s += edges[i].order_cnt;
+        sums[c] = s;
+      });
+      parallel_chunks(n_orders, [&](unsigned c, size_t b, size_t e_end) {
+        uint64_t s = 0;
+        for (size_t k = b; k < e_end; ++k) {
+          const msgpu_order &o = orders[k];
+          if (o.start >= n_reads || o.end >= n_reads || o.base >= n_reads || o.ids_off + o.ids_cnt > n_ids) {
+            bad = 1;
+            return;
+          }
+          g->ol[k] = msgpu_graph::OLite{o.start, o.end, o.base, o.flags};
+          s += g->o_kept[k];
+        }
+        kept[c] = s;
+      });
+      if (bad) return MSGPU_E_ARG;
+      uint64_t a = 0, b = 0;
+      for (uint64_t x : sums) a += x;
+      for (uint64_t x : kept) b += x;
+      if (a != b) return MSGPU_E_ARG;
     }
     {
       std::vector<uint32_t> ea(n_edges), eb(n_edges);
@@ -1154,32 +1255,38 @@ int msgpu_graph_clean_up(msgpu_graph *g, const int64_t *contraction_order, const
         g->delete_vertex(v);
         ++g->stats.n_deleted_vertices;
       }
-    for (size_t e = 0; e < ne; ++e) { // findDeletableEdges, :534-549 (+ deletion :258-260)
-      if (!g->E[e].alive) continue;
-      const uint32_t lo = g->E[e].ord_lo, hi = lo + g->E[e].ord_cnt;
-      uint32_t       first = NIL;
-      for (uint32_t oi = lo; oi < hi; ++oi) {
-        if (g->ocont(oi)) g->o_kept[oi] = 0;
-        else if (first == NIL) first = oi;
+    // findDeletableEdges (:534-549, + deletion :258-260) and computeBitweight (:551-573): per-edge independent, on all host
+    // threads; the candidate list of the span tree is the per-chunk lists in chunk order = edge order (:264, mst.cpp:79-86)
+    std::vector<std::vector<uint32_t>> cand_of(stage_threads() + 1);
+    parallel_chunks(ne, [&](unsigned chunk, size_t e_begin, size_t e_end) {
+      std::vector<uint32_t> &mine = cand_of[chunk];
+      for (size_t e = e_begin; e < e_end; ++e) {
+        if (!g->E[e].alive) continue;
+        const uint32_t lo = g->E[e].ord_lo, hi = lo + g->E[e].ord_cnt;
+        uint32_t       first = NIL;
+        for (uint32_t oi = lo; oi < hi; ++oi) {
+          if (g->ocont(oi)) g->o_kept[oi] = 0;
+          else if (first == NIL) first = oi;
+        }
+        g->E[e].first = first;
+        if (first == NIL) {
+          g->delete_edge(static_cast<uint32_t>(e));
+          continue;
+        }
+        const bool d0 = g->odir(first);
+        if (g->E[e].shadow) {
+          bool other = false;
+          for (uint32_t oi = first; oi < hi; ++oi) other = other || (g->o_kept[oi] && g->odir(oi) != d0);
+          if (!other) g->E[e].cons = d0 ? D_POS : D_NEG;
+        } else {
+          g->E[e].weight = g->t_orders[first].score;
+          g->E[e].cons   = d0 ? D_POS : D_NEG;
+        }
+        if (g->E[e].cons != D_NONE) mine.push_back(static_cast<uint32_t>(e));
       }
-      g->E[e].first = first;
-      if (first == NIL) g->delete_edge(static_cast<uint32_t>(e));
-    }
-    std::vector<uint32_t> cand; // alive edges with a consensus direction, in edge order (:264, mst.cpp:79-86)
-    for (size_t e = 0; e < ne; ++e) { // computeBitweight, :551-573
-      if (!g->E[e].alive || g->E[e].first == NIL) continue;
-      const uint32_t lo = g->E[e].first, hi = g->E[e].ord_lo + g->E[e].ord_cnt;
-      const bool     d0 = g->odir(lo);
-      if (g->E[e].shadow) {
-        bool other = false;
-        for (uint32_t oi = lo; oi < hi; ++oi) other = other || (g->o_kept[oi] && g->odir(oi) != d0);
-        if (!other) g->E[e].cons = d0 ? D_POS : D_NEG;
-      } else {
-        g->E[e].weight = g->t_orders[lo].score;
-        g->E[e].cons   = d0 ? D_POS : D_NEG;
-      }
-      if (g->E[e].cons != D_NONE) cand.push_back(static_cast<uint32_t>(e));
-    }
+    });
+    std::vector<uint32_t> cand; // alive edges with a consensus direction, in edge order
+    for (auto &v : cand_of) cand.insert(cand.end(), v.begin(), v.end());
     tick("deletions + bitweight");
     std::vector<uint8_t> in_tree(ne, 0); // getMaxSpanTree, mst.cpp:75-111
     max_span_tree(
