@@ -613,6 +613,8 @@ def tiled_leg(torch, dev, args, workload, threads):
     asm.set_rows(rows, copy=False)
     asm.add_prepared_batch([(gs.path_input(i), gs) for i in range(gs.path_count)], threads)
     contig_len = asm.paths["target_len"].astype(np.int64)
+    n_shadow = int(tables["edges"]["shadow"].sum())  # (`tables` are views of the context's pinned memory: read before close)
+    del tables
     asm.close()
     gs.close()
     store.close()
@@ -628,7 +630,7 @@ def tiled_leg(torch, dev, args, workload, threads):
             "edges_proven_clean": int(c.n_edges_fastpath),
             "host_to_host_without_edgematches_ms": float(np.median(walls)),
             "find_contraction_edges_ms_incl_copy_back": t_contr, "contraction_edges": int((contraction >= 0).sum()),
-            "shadow_edges": int(tables["edges"]["shadow"].sum()),
+            "shadow_edges": n_shadow,
             "graph_stage_ms": t_graph, "path_edgematches_ms": t_ems, "vertices_after": int(st.n_vertices),
             "edges_after": int(st.n_edges), "components": int(st.n_components), "paths": int(st.n_paths),
             "path_reads": int(st.n_path_reads), "assemble_path": ap,

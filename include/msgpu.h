@@ -126,6 +126,8 @@ typedef struct msgpu_counts {
   uint64_t n_ids;        /* sum of |EdgeOrder::ids| (this shard)                                              */
   uint64_t n_pairs_scanned; /* scaffold rows visited while looking for pairs (both directions of each pair)   */
   uint64_t n_edges_fastpath; /* edges whose pairs were all proven compatible without the O(n^2) sweep (this shard) */
+  uint64_t n_lost_publications; /* size read-backs of this context whose publication into mapped host memory never arrived
+                                   although the stream finished (the values were re-read by copy): 0 on a healthy system */
 } msgpu_counts;
 
 /* Device time of the last run of each stage, milliseconds, measured with HIP events on the context's stream. */
@@ -181,6 +183,14 @@ uint32_t    msgpu_paf_read_count(const msgpu_paf *paf);
 uint32_t    msgpu_paf_anchor_count(const msgpu_paf *paf);
 const char *msgpu_paf_read_name(const msgpu_paf *paf, uint32_t read_id);     /* Registry reverse lookup */
 const char *msgpu_paf_anchor_name(const msgpu_paf *paf, uint32_t anchor_id);
+
+/* Registry::operator[] for every record of a parsed sequence file, on the registries of `paf` (the reference's
+ * SequenceAccessor calls the very Registry objects BlastFileReader filled: SequenceAccessor.cpp:171,215, src/main.cpp:
+ * 149-163): a name the PAF registered keeps its id, an unknown name takes the next free id in file order (the registry
+ * grows).  kind 0 = reads (nanopore registry), 1 = unitigs (illumina registry).  ids: msgpu_seq_count(f) entries, what
+ * msgpu_seq_upload takes; *id_space (optional) = the registry's size afterwards. */
+struct msgpu_seqfile;
+int msgpu_paf_register_sequences(msgpu_paf *paf, int kind, const struct msgpu_seqfile *f, uint32_t *ids, uint32_t *id_space);
 
 /* Host utilities of libms that the loader is made of, on their own (the reference's unit tests hold vectors for them:
  * libms/tests/IO_test.cpp:12-35, Registry_test.cpp:5-14, Toggle_test.cpp:5-25; replayed from tests/golden/ref_tests/).

@@ -153,6 +153,14 @@ public:
     check(msgpu_find_contraction_edges(m_ctx, nullptr, 0, nullptr, 0, 0, out.data()), m_ctx);
     return out;
   }
+  // SequenceAccessor::_build*Idx (SequenceAccessor.cpp:143-231): Registry::operator[] per record of a parsed sequence file,
+  // on the registries read() / parse() filled -- names the PAF registered keep their id, unknown names take the next free
+  // ids in file order.  kind 0 = reads, 1 = unitigs.
+  std::vector<std::uint32_t> registerSequences(int kind, msgpu_seqfile const *f, std::uint32_t *idSpace) {
+    std::vector<std::uint32_t> ids(msgpu_seq_count(f));
+    check(msgpu_paf_register_sequences(m_paf, kind, f, ids.data(), idSpace), nullptr);
+    return ids;
+  }
   std::uint32_t readCount() const { return msgpu_paf_read_count(m_paf); }
   std::uint32_t anchorCount() const { return msgpu_paf_anchor_count(m_paf); }
   char const *readName(std::uint32_t id) const { return msgpu_paf_read_name(m_paf, id); }
@@ -247,18 +255,6 @@ inline void require(int rc, char const *what, char const *detail = nullptr) {
   if (detail && *detail) msg += std::string(" (") + detail + ")";
   throw std::runtime_error(msg);
 }
-// SequenceAccessor::_build*Idx (SequenceAccessor.cpp:143-231): Registry::operator[] per record -- names the PAF
-// registered keep their id, unknown names take the next free ids in file order
-inline std::vector<std::uint32_t> registryIds(msgpu_seqfile const *f, std::uint32_t known, char const *(*name)(void const *, std::uint32_t),
-                                              void const *ctx, std::uint32_t *space) {
-  std::unordered_map<std::string, std::uint32_t> reg;
-  for (std::uint32_t i = 0; i < known; ++i) reg.emplace(name(ctx, i), i);
-  std::vector<std::uint32_t> ids(msgpu_seq_count(f));
-  for (std::uint32_t i = 0; i < ids.size(); ++i)
-    ids[i] = reg.emplace(msgpu_seq_name(f, i), static_cast<std::uint32_t>(reg.size())).first->second;
-  *space = static_cast<std::uint32_t>(reg.size());
-  return ids;
-}
 } // namespace detail
 
 // main() of the reference (src/main.cpp:130-322): contigs PAF, unitig FASTA, long-read FASTA/FASTQ -> outDir/temp_1.*
@@ -267,10 +263,10 @@ inline AssemblyCounts assemble(std::string const &contigsPaf, std::string const 
                                std::size_t wiggleRoom = 300, int device = 0) {
   AssemblyCounts n;
   OverlapCore    core(device, wiggleRoom);
-  core.parse(contigsPaf); // :153-156 (the rows travel to HBM inside overlapResident below)
 
-  struct Seq { // :161-163 -- needs only the Registry: the files are parsed (pure host work) on a second thread while the
-               // GPU and the graph stage work; every HIP call stays on the calling thread (upload after the join)
+  struct Seq { // :161-163 -- parsing the two sequence files needs nothing from the PAF: one thread per file, started before
+               // the PAF is read, beside the parser, the GPU and the graph stage; every HIP call stays on the calling
+               // thread (upload after the join)
     msgpu_seqctx   *ctx = nullptr;
     msgpu_seqfile  *fn = nullptr, *fi = nullptr;
     msgpu_assembly *as = nullptr;
@@ -281,28 +277,26 @@ inline AssemblyCounts assemble(std::string const &contigsPaf, std::string const 
       msgpu_seq_destroy(ctx);
     }
   } s;
-  std::exception_ptr         loadError;
-  std::vector<std::uint32_t> readIds, anchorIds;
-  std::uint32_t              readSpace = 0, anchorSpace = 0;
-  std::thread                loader([&]() {
-    try {
-      detail::require(msgpu_seq_parse(nanoporePath.c_str(), -1, &s.fn), "nanopore file");
-      detail::require(msgpu_seq_parse(unitigsPath.c_str(), 0, &s.fi), "unitig file");
-      readIds = detail::registryIds(
-          s.fn, core.readCount(),
-          [](void const *c, std::uint32_t i) { return static_cast<OverlapCore const *>(c)->readName(i); }, &core, &readSpace);
-      anchorIds = detail::registryIds(
-          s.fi, core.anchorCount(),
-          [](void const *c, std::uint32_t i) { return static_cast<OverlapCore const *>(c)->anchorName(i); }, &core,
-          &anchorSpace);
-    } catch (...) { loadError = std::current_exception(); }
-  });
+  std::exception_ptr loadError[2];
+  std::thread        loaders[2] = {std::thread([&]() {
+                                try {
+                                  detail::require(msgpu_seq_parse(nanoporePath.c_str(), -1, &s.fn), "nanopore file");
+                                } catch (...) { loadError[0] = std::current_exception(); }
+                              }),
+                              std::thread([&]() {
+                                try {
+                                  detail::require(msgpu_seq_parse(unitigsPath.c_str(), 0, &s.fi), "unitig file");
+                                } catch (...) { loadError[1] = std::current_exception(); }
+                              })};
   struct Joiner {
-    std::thread &t;
+    std::thread (&t)[2];
     ~Joiner() {
-      if (t.joinable()) t.join();
+      for (auto &x : t)
+        if (x.joinable()) x.join();
     }
-  } joiner{loader};
+  } joiner{loaders};
+
+  core.parse(contigsPaf); // :153-156 (the rows travel to HBM inside overlapResident below)
 
   // :157 + :170-178 -- calculateEdges and the chainingAndOverlaps fan-out as windows of owner reads on two HIP streams (the
   // ThreadPool replacement); the tables arrive in pinned host memory while later windows compute, the EdgeMatch table
@@ -336,8 +330,11 @@ inline AssemblyCounts assemble(std::string const &contigsPaf, std::string const 
                     msgpu_graph_last_error(graph.g));
   }
 
-  loader.join();
-  if (loadError) std::rethrow_exception(loadError);
+  for (auto &t : loaders) t.join();
+  for (auto &e : loadError)
+    if (e) std::rethrow_exception(e);
+  std::uint32_t                    readSpace = 0, anchorSpace = 0;
+  std::vector<std::uint32_t> const readIds = core.registerSequences(0, s.fn, &readSpace), anchorIds = core.registerSequences(1, s.fi, &anchorSpace);
   detail::require(msgpu_seq_create(device, &s.ctx), "msgpu_seq_create");
   detail::require(msgpu_seq_upload(s.ctx, 0, s.fn, readIds.data(), readSpace), "upload reads", msgpu_seq_last_error(s.ctx));
   detail::require(msgpu_seq_upload(s.ctx, 1, s.fi, anchorIds.data(), anchorSpace), "upload unitigs",
@@ -345,7 +342,7 @@ inline AssemblyCounts assemble(std::string const &contigsPaf, std::string const 
   detail::require(msgpu_seq_pack(s.ctx), "msgpu_seq_pack", msgpu_seq_last_error(s.ctx)); // 2 bits per base in HBM
 
   detail::require(msgpu_assembly_create(s.ctx, &s.as), "msgpu_assembly_create"); // :300-310, 620-677
-  detail::require(msgpu_assembly_set_rows(s.as, rows, nRows), "msgpu_assembly_set_rows");
+  detail::require(msgpu_assembly_borrow_rows(s.as, rows, nRows), "msgpu_assembly_borrow_rows"); // (the loader's table: core outlives s.as)
   std::vector<msgpu_path_input> in(msgpu_graph_path_count(graph.g));
   for (std::uint32_t i = 0; i < in.size(); ++i) detail::require(msgpu_graph_path_input(graph.g, i, &in[i]), "path input");
   std::vector<int> status(in.size(), 0);

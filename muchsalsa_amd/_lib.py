@@ -80,7 +80,8 @@ class GraphStats(C.Structure):
 class Counts(C.Structure):
     _fields_ = [("n_rows_in", C.c_uint64), ("n_rows_alive", C.c_uint64), ("n_reads", C.c_uint32),
                 ("n_anchors", C.c_uint32), ("n_edges", C.c_uint64), ("n_ems", C.c_uint64), ("n_orders", C.c_uint64),
-                ("n_ids", C.c_uint64), ("n_pairs_scanned", C.c_uint64), ("n_edges_fastpath", C.c_uint64)]
+                ("n_ids", C.c_uint64), ("n_pairs_scanned", C.c_uint64), ("n_edges_fastpath", C.c_uint64),
+                ("n_lost_publications", C.c_uint64)]
 
 
 class Timings(C.Structure):
@@ -107,6 +108,7 @@ SYMBOLS = [
     ("msgpu_paf_anchor_count", C.c_uint32, [C.c_void_p]),
     ("msgpu_paf_read_name", C.c_char_p, [C.c_void_p, C.c_uint32]),
     ("msgpu_paf_anchor_name", C.c_char_p, [C.c_void_p, C.c_uint32]),
+    ("msgpu_paf_register_sequences", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32)]),
     ("msgpu_load_rows", C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     ("msgpu_load_rows_device", C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     ("msgpu_calculate_edges", C.c_int, [C.c_void_p]),

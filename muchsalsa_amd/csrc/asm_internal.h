@@ -37,6 +37,7 @@ struct msgpu_assembly {
   // rows that arrive in ascending anchor-id order (a PAF is grouped by its query) need no per-read table:
   // rows[anchor_start[a] .. anchor_start[a + 1]) are anchor a's, and row_recs / row_start stay empty
   std::vector<uint64_t>         anchor_start;
+  bool                          anchor_sorted_by_read = false; // ... and inside every anchor the read ids never decrease: look-ups are binary searches
   std::vector<msgpu_copy>       pieces; // dst_off = position in the raw buffer (records start 16-B aligned)
   uint64_t                      raw_bytes = 0;
   std::vector<msgpu_path_info>  paths;

@@ -18,6 +18,7 @@
 #include <cstdlib>
 #include <cstdio>
 #include <cstring>
+#include <exception>
 #include <functional>
 #include <map>
 #include <mutex>
@@ -189,10 +190,16 @@ struct PathLayout {
     auto           it  = vm.find(key);
     if (it != vm.end()) return it->second;
     if (shared && static_cast<size_t>(anchor) + 1 < shared->anchor_start.size()) { // the anchor's own scaffold only
+      const msgpu_row *b = shared->rows_view + shared->anchor_start[anchor];
+      const msgpu_row *e = shared->rows_view + shared->anchor_start[static_cast<size_t>(anchor) + 1];
+      // scaffolds in read-id order (what msgpu_parse_paf's output grouped by query and target is): O(log n) whatever the
+      // coverage; otherwise the table was only accepted with short scaffolds (install_rows) and a scan is as good
+      if (shared->anchor_sorted_by_read)
+        b = std::lower_bound(b, e, read, [](const msgpu_row &m, uint32_t r) { return m.read_id < r; });
       const msgpu_row *best = nullptr;
-      for (uint64_t i = shared->anchor_start[anchor], e = shared->anchor_start[static_cast<size_t>(anchor) + 1]; i < e; ++i) {
-        const msgpu_row &m = shared->rows_view[i];
-        if (m.read_id == read && (!best || m.line < best->line)) best = &m; // of equal keys the lowest line
+      for (const msgpu_row *m = b; m < e; ++m) {
+        if (shared->anchor_sorted_by_read && m->read_id != read) break;
+        if (m->read_id == read && (!best || m->line < best->line)) best = m; // of equal keys the lowest line
       }
       if (best) return best;
     } else if (shared && static_cast<size_t>(read) + 1 < shared->row_start.size()) { // the read's own ~50 rows only
@@ -938,7 +945,9 @@ class LayoutPool {
     cv_work_.notify_all();
     for (auto &t : th_) t.join();
   }
-  // runs job() on `helpers` pool threads and on the caller; returns when all of them are done
+  // runs job() on `helpers` pool threads and on the caller; returns when ALL of them are done -- also when one of them
+  // threw (bad_alloc in a body): the helpers work on the caller's stack frame, so nobody leaves before the last one has
+  // finished, and the first exception is rethrown on the caller afterwards
   void run(uint32_t helpers, const std::function<void()> &job) {
     while (th_.size() < helpers) th_.emplace_back([this, idx = static_cast<uint32_t>(th_.size())] { loop(idx); });
     {
@@ -949,10 +958,17 @@ class LayoutPool {
       ++gen_;
     }
     cv_work_.notify_all();
-    job();
+    std::exception_ptr mine;
+    try {
+      job();
+    } catch (...) { mine = std::current_exception(); }
     std::unique_lock<std::mutex> g(m_);
     cv_done_.wait(g, [this] { return pending_ == 0; });
     job_ = nullptr;
+    std::exception_ptr err = mine ? mine : err_;
+    err_                   = nullptr;
+    g.unlock();
+    if (err) std::rethrow_exception(err);
   }
 
  private:
@@ -968,9 +984,13 @@ class LayoutPool {
         if (idx >= helpers_) continue; // this call asked for fewer threads
         job = job_;
       }
-      (*job)();
+      std::exception_ptr err;
+      try {
+        (*job)();
+      } catch (...) { err = std::current_exception(); } // (an exception leaving a thread function is std::terminate)
       {
         std::lock_guard<std::mutex> g(m_);
+        if (err && !err_) err_ = err;
         --pending_;
       }
       cv_done_.notify_one();
@@ -988,6 +1008,7 @@ class LayoutPool {
   uint32_t                     helpers_ = 0, pending_ = 0;
   uint64_t                     gen_     = 0;
   bool                         stop_    = false;
+  std::exception_ptr           err_;    // first exception of a helper in the current fan-out
 };
 
 std::atomic<LayoutPool *> g_pool{nullptr};
@@ -1038,6 +1059,7 @@ static int install_rows(msgpu_assembly *a, const msgpu_row *rows, size_t n_rows,
     };
     std::vector<uint32_t> cmax(nt, 0);
     std::vector<char>     asc(nt, 1); // chunk t's anchor ids never decrease (its first row compared with the row before it)
+    std::vector<char>     rasc(nt, 1); // ... and inside an anchor its read ids never decrease
     a->rows.resize(copy ? n_rows : 0);
     a->rows_view = copy ? a->rows.data() : rows;
     a->row_recs.resize(0);
@@ -1045,18 +1067,22 @@ static int install_rows(msgpu_assembly *a, const msgpu_row *rows, size_t n_rows,
     a->anchor_start.clear();
     fan(nt, [&](size_t t) {
       uint32_t m = 0;
-      bool     up = true;
+      bool     up = true, rup = true;
       const size_t b = chunk(t).first, e = chunk(t).second;
-      uint32_t     prev = b ? rows[b - 1].anchor_id : 0;
+      uint32_t     prev = b ? rows[b - 1].anchor_id : 0, prev_read = b ? rows[b - 1].read_id : 0;
       for (size_t i = b; i < e; ++i) {
         m = std::max(m, rows[i].read_id);
         up &= prev <= rows[i].anchor_id;
-        prev = rows[i].anchor_id;
+        rup &= prev != rows[i].anchor_id || prev_read <= rows[i].read_id || i == 0;
+        prev      = rows[i].anchor_id;
+        prev_read = rows[i].read_id;
       }
       if (copy && e > b) memcpy(a->rows.data() + b, rows + b, (e - b) * sizeof(msgpu_row));
       cmax[t] = m;
       asc[t]  = up;
+      rasc[t] = rup;
     });
+    a->anchor_sorted_by_read = false;
     const size_t n_reads = n_rows ? static_cast<size_t>(*std::max_element(cmax.begin(), cmax.end())) + 1 : 0;
     if (n_rows && std::find(asc.begin(), asc.end(), 0) == asc.end()) {
       // Grouped by ascending anchor id -- what a PAF is (grouped by query, ids handed out in first-seen order): the
@@ -1072,7 +1098,15 @@ static int install_rows(msgpu_assembly *a, const msgpu_row *rows, size_t n_rows,
         }
       });
       st[n_anchors] = n_rows;
-      return MSGPU_OK;
+      a->anchor_sorted_by_read = std::find(rasc.begin(), rasc.end(), 0) == rasc.end();
+      // Look-ups search an anchor's rows by read id (binary when they are in read order).  A table whose scaffolds are in
+      // no order is kept in this form only while every scaffold is short (a scan of <= 64 rows); a deep one (repeat
+      // anchors, high coverage: thousands of rows) takes the per-read table below, as any other order does.
+      uint64_t longest = 0;
+      if (!a->anchor_sorted_by_read)
+        for (size_t id = 0; id < n_anchors; ++id) longest = std::max(longest, st[id + 1] - st[id]);
+      if (longest <= 64) return MSGPU_OK;
+      a->anchor_start.clear();
     }
     // partitions of 2^shift consecutive read ids, at most 1024 of them
     unsigned shift = 8;

@@ -133,6 +133,7 @@ struct msgpu_ctx {
   uint64_t     prologue_bound = 0;
   uint32_t     prologue_lists[4] = {0, 0, 0, 0};
   uint64_t     readback_seq = 0;
+  uint64_t     lost_publications = 0; // read-backs whose publication never arrived (wait_scalars fell back to a copy)
   bool         readback_polled = false;
   hipEvent_t   ev_readback = nullptr; // the synchronising read-back path waits for the copy only
   uint32_t     decl_V = 0, decl_A = 0; // msgpu_set_id_space: id counts declared by the caller (0 = find them)
@@ -249,7 +250,13 @@ int wait_scalars(msgpu_ctx *c) {
         if (q != hipErrorNotReady) break;
       }
     }
-    // the stream stopped making progress: take the values the slow way (and surface the error)
+    // The stream stopped making progress, or finished without the publication arriving in mapped memory.  Take the values
+    // the slow way, surface a stream error if there is one, and leave a trace either way: a lost publication is counted
+    // (msgpu_counts.n_lost_publications) and named in msgpu_last_error even when the call goes on to succeed.
+    ++c->lost_publications;
+    snprintf(c->err, sizeof(c->err), "read-back %llu: the stream finished without publishing its sizes to mapped host memory; "
+             "values re-read by copy (%llu such read-backs on this context)", (unsigned long long)seq,
+             (unsigned long long)c->lost_publications);
     HIPCHK(c, hipMemcpyAsync(c->h_scalars, c->scalars.p, SC_COUNT * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return MSGPU_OK;
@@ -1009,6 +1016,7 @@ int msgpu_get_counts(msgpu_ctx *c, msgpu_counts *out) {
   out->n_ids           = c->state >= ST_CHAINED ? c->n_ids : 0;
   out->n_pairs_scanned = c->state >= ST_EDGES ? c->n_visit : 0;
   out->n_edges_fastpath = c->state >= ST_CHAINED ? c->n_edges_fast : 0;
+  out->n_lost_publications = c->lost_publications;
   return MSGPU_OK;
 }
 

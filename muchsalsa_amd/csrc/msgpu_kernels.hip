@@ -2474,8 +2474,12 @@ __global__ __launch_bounds__(1024) void k_size_hist(const msgpu_edge *edges, con
 
 // part[b][bin] -> first list position of block b's edges of that size; counts[0..2] = edges of <= 16, 17..32, 33..64.
 // One workgroup: thread (bin, seg) owns 8 consecutive blocks of one bin, so no thread walks the table serially.
-__global__ __launch_bounds__(1024) void k_size_scan(uint32_t *part, uint32_t *counts) {
+__global__ __launch_bounds__(1024) void k_size_scan(uint32_t *part, uint32_t *counts, const uint64_t *d_n_edges,
+                                                    uint64_t cap_edges) {
   static_assert(SIZE_SORT_BLOCKS == 128, "16 segments of 8 blocks");
+  // a speculative launch into tables that turn out too small: k_size_hist wrote nothing, `part` is stale -- keep the class
+  // counts k_count_classes published (the host re-launches the three kernels after it has allocated)
+  if (*d_n_edges > cap_edges) return;
   __shared__ uint32_t s_seg[16][64], s_base[64];
   const int bin = threadIdx.x & 63, seg = threadIdx.x >> 6;
   uint32_t  c[8], sum = 0;
@@ -3168,7 +3172,7 @@ void launch_chain_sub(hipStream_t st, const ChainArgs &a, int width, const uint3
 void launch_sort_edges_by_size(hipStream_t st, const msgpu_edge *edges, const uint64_t *d_n_edges, uint64_t cap_edges,
                                uint32_t *part, uint32_t *list, uint32_t *counts) {
   hipLaunchKernelGGL(k_size_hist, dim3(SIZE_SORT_BLOCKS), dim3(1024), 0, st, edges, d_n_edges, cap_edges, part);
-  hipLaunchKernelGGL(k_size_scan, dim3(1), dim3(1024), 0, st, part, counts);
+  hipLaunchKernelGGL(k_size_scan, dim3(1), dim3(1024), 0, st, part, counts, d_n_edges, cap_edges);
   hipLaunchKernelGGL(k_size_scatter, dim3(SIZE_SORT_BLOCKS), dim3(1024), 0, st, edges, d_n_edges, cap_edges, part, list);
 }
 size_t size_sort_part_bytes() { return static_cast<size_t>(SIZE_SORT_BLOCKS) * 64 * 4; }

@@ -345,6 +345,20 @@ int msgpu_parse_paf(const char *path, const msgpu_params *params, msgpu_paf **ou
 
 void msgpu_paf_free(msgpu_paf *paf) { delete paf; }
 
+// Registry::operator[] for every record of a sequence file, on the PAF's own registries (SequenceAccessor.cpp:171,215
+// call the Registry objects BlastFileReader filled, src/main.cpp:149-163)
+int msgpu_paf_register_sequences(msgpu_paf *paf, int kind, const msgpu_seqfile *f, uint32_t *ids, uint32_t *id_space) {
+  if (!paf || !f || (kind != 0 && kind != 1)) return MSGPU_E_ARG;
+  const uint32_t n = msgpu_seq_count(f);
+  if (n && !ids) return MSGPU_E_ARG;
+  try {
+    NameRegistry &reg = kind == 0 ? paf->reads : paf->anchors;
+    for (uint32_t i = 0; i < n; ++i) ids[i] = reg[std::string_view(msgpu_seq_name(f, i))];
+    if (id_space) *id_space = reg.size();
+  } catch (std::bad_alloc const &) { return MSGPU_E_NOMEM; }
+  return MSGPU_OK;
+}
+
 const msgpu_row *msgpu_paf_rows(const msgpu_paf *paf, size_t *n_rows) {
   if (n_rows) *n_rows = paf ? paf->rows.size() : 0;
   return paf && !paf->rows.empty() ? paf->rows.data() : nullptr;

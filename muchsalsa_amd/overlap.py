@@ -36,11 +36,23 @@ class Paf:
     copy): page-locked when a GPU is present, so msgpu_load_rows / msgpu_overlap_batched take it at link speed.  The
     view (and every slice of it) keeps the loader's memory alive."""
 
-    def __init__(self, rows, n_lines, read_names, anchor_names):
+    def __init__(self, rows, n_lines, read_names, anchor_names, handle=None):
         self.rows = rows
         self.n_lines = n_lines
         self.read_names = read_names
         self.anchor_names = anchor_names
+        self._handle = handle
+
+    def register_sequences(self, kind, seqfile):
+        """msgpu_paf_register_sequences: Registry::operator[] for every record of a SeqFile on this PAF's registries
+        (kind 0 reads, 1 unitigs) -> (ids per record, id space): what SeqStore.upload takes"""
+        ids = np.zeros(len(seqfile), dtype="<u4")
+        space = C.c_uint32()
+        rc = _lib.lib().msgpu_paf_register_sequences(self._handle._h, int(kind), seqfile._h,
+                                                     ids.ctypes.data if len(ids) else None, C.byref(space))
+        if rc != 0:
+            raise MsgpuError(rc)
+        return ids, int(space.value)
 
 
 class _PafHandle:
@@ -70,7 +82,7 @@ def parse_paf(path, params=None):
         rows = np.zeros(0, dtype=ROW_DTYPE)
     rn = [L.msgpu_paf_read_name(h, i).decode() for i in range(L.msgpu_paf_read_count(h))]
     an = [L.msgpu_paf_anchor_name(h, i).decode() for i in range(L.msgpu_paf_anchor_count(h))]
-    return Paf(rows, L.msgpu_paf_line_count(h), rn, an)
+    return Paf(rows, L.msgpu_paf_line_count(h), rn, an, owner)
 
 
 class PinnedRows:

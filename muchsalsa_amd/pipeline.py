@@ -23,44 +23,36 @@ from .graph import GraphStage
 from .sequences import ILLUMINA, NANOPORE, SeqFile, SeqStore
 
 
-def _registry_ids(seqfile, names):
-    """Registry::operator[] for every record of a sequence file (SequenceAccessor.cpp:171,215): names the PAF
-    registered keep their id, unknown names get the next free ids in file order."""
-    reg = {n: i for i, n in enumerate(names)}
-    ids = np.zeros(len(seqfile), dtype="<u4")
-    for i, n in enumerate(seqfile.names):
-        ids[i] = reg.setdefault(n, len(reg))
-    return ids, len(reg)
-
-
 def run(contigs_paf, unitigs_path, nanopore_path, out_dir, threads=None, wiggle_room=300, device=0, timings=None,
         batches=8):
     """-> dict of counts; writes the three output files into out_dir (created by the caller, Application.cpp:65-82)."""
     t = {}
     n_threads = int(threads) if threads else max(1, min(16, os.cpu_count() or 1))
-    t0 = time.perf_counter()
     params = overlap.default_params()
     params.wiggle_room = int(wiggle_room)
-    paf = overlap.parse_paf(contigs_paf, params)
-    t["parse_paf"] = time.perf_counter() - t0
 
-    # SequenceAccessor::buildIndex needs only the Registry: the sequence files are parsed (pure host work) on a second
-    # thread while the GPU builds the overlap graph and the host runs the graph stage (ctypes calls release the GIL).
-    # Every HIP call stays on this thread: the upload happens after the join.
+    # SequenceAccessor::buildIndex: parsing the two sequence files is pure host work that needs nothing from the PAF -- one
+    # thread per file, started before the PAF is read, beside the parser, the GPU and the graph stage (ctypes calls release
+    # the GIL).  Registry::operator[] for their records (SequenceAccessor.cpp:171,215) follows once the PAF's registries
+    # exist.  Every HIP call stays on this thread: the upload happens after the join.
     seq = {}
 
-    def load_sequences():
+    def parse_file(key, path):
         t1 = time.perf_counter()
         try:
-            fn, fi = SeqFile(nanopore_path), SeqFile(unitigs_path)
-            seq["files"] = (fn, fi)
-            seq["ids"] = (_registry_ids(fn, paf.read_names), _registry_ids(fi, paf.anchor_names))
+            seq[key] = SeqFile(path)
         except BaseException as e:  # re-raised on the main thread
             seq["error"] = e
-        t["sequences_parse"] = time.perf_counter() - t1
+        t["sequences_parse_" + key] = time.perf_counter() - t1
 
-    loader = threading.Thread(target=load_sequences, name="msgpu-sequences")
-    loader.start()
+    loaders = [threading.Thread(target=parse_file, args=("nanopore", nanopore_path), name="msgpu-nanopore"),
+               threading.Thread(target=parse_file, args=("unitigs", unitigs_path), name="msgpu-unitigs")]
+    for th in loaders:
+        th.start()
+
+    t0 = time.perf_counter()
+    paf = overlap.parse_paf(contigs_paf, params)
+    t["parse_paf"] = time.perf_counter() - t0
 
     t0 = time.perf_counter()
     ctx = overlap.OverlapContext(device=device, params=params)
@@ -85,20 +77,25 @@ def run(contigs_paf, unitigs_path, nanopore_path, out_dir, threads=None, wiggle_
     t["path_edgematches"] = time.perf_counter() - t0
 
     t0 = time.perf_counter()
-    loader.join()
+    for th in loaders:
+        th.join()
     t["sequences_wait"] = time.perf_counter() - t0
     if "error" in seq:
         raise seq["error"]
     t0 = time.perf_counter()
+    fn, fi = seq["nanopore"], seq["unitigs"]
+    ids = (paf.register_sequences(NANOPORE, fn), paf.register_sequences(ILLUMINA, fi))
+    t["sequences_registry"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
     store = SeqStore(device=device)
-    for kind, f, (ids, n) in zip((NANOPORE, ILLUMINA), seq["files"], seq["ids"]):
-        store.upload(kind, f, ids, n)
+    for kind, f, (ids_k, n) in zip((NANOPORE, ILLUMINA), (fn, fi), ids):
+        store.upload(kind, f, ids_k, n)
     store.pack()  # 2 bits per base + exception list: a quarter of the footprint, less gather traffic, same bytes out
     t["sequences_upload"] = time.perf_counter() - t0
 
     t0 = time.perf_counter()
     asm = Assembly(store)
-    asm.set_rows(paf.rows)
+    asm.set_rows(paf.rows, copy=False)  # (msgpu_assembly_borrow_rows: the loader's table outlives the layout)
     status = asm.add_prepared_batch([(g.path_input(i), g) for i in range(g.path_count)], n_threads) \
         if g.path_count else np.zeros(0, dtype=np.int32)
     st = g.stats
