@@ -174,11 +174,11 @@ def host_to_host_leg(ctx, rows, n_batches, reps=6):
         # SURVEY 8(d) literally: "row table in host memory -> order/edge tables in host memory".  The EdgeMatch table (5/6 of
         # the bytes) stays in HBM (MSGPU_BATCH_NO_EDGEMATCHES); downstream only assemblePath reads EdgeMatches, and only the
         # path edges' (msgpu_get_edgematches).  This is what muchsalsa_amd.pipeline.run / msgpu::assemble call.
-        ctx.overlap_batched(pinned, n_batches, copy=False, resident=True, edgematches=False)  # warm-up: job tables in HBM
+        ctx.overlap_batched(pinned, 0, copy=False, resident=True, edgematches=False)  # warm-up: job tables in HBM
         lw, li = [], []
         for _ in range(reps):
             t0 = time.perf_counter()
-            t2, info2 = ctx.overlap_batched(pinned, n_batches, copy=False, resident=True, edgematches=False)
+            t2, info2 = ctx.overlap_batched(pinned, 0, copy=False, resident=True, edgematches=False)  # 0 = the library's choice
             lw.append(1e3 * (time.perf_counter() - t0))
             li.append(info2)
         k2 = int(np.argsort(lw)[len(lw) // 2])
@@ -194,7 +194,7 @@ def host_to_host_leg(ctx, rows, n_batches, reps=6):
                 sel[int(off[i]): int(off[i + 1])].tobytes() == t["ems"][int(t["edges"]["em_off"][e]): int(t["edges"]["em_off"][e]) + int(t["edges"]["em_cnt"][e])].tobytes()
                 for i, e in enumerate(probe))
         lean = {"ms": lw[k2], "overlap_pairs_per_s": n_edges / (lw[k2] * 1e-3), "table_bytes_d2h": lean_bytes,
-                "load_ms": li[k2]["load_ms"], "compute_done_ms": li[k2]["compute_done_ms"],
+                "load_ms": li[k2]["load_ms"], "compute_done_ms": li[k2]["compute_done_ms"], "batches": int(li[k2]["n_batches"]),
                 "ms_samples": [round(x, 3) for x in lw], "tables_equal_full_run": lean_ok,
                 "edgematches_left_in_hbm": int(li[k2]["n_ems"]),
                 "get_edgematches_of_10k_edges_ms": t_sel, "edgematches_fetched": int(off[-1]) if len(off) else 0,
@@ -579,11 +579,11 @@ def tiled_leg(torch, dev, args, workload, threads):
     c = ctx.counts()
     ctx.set_stream(None)
     pinned = overlap.PinnedRows(rows)
-    ctx.overlap_batched(pinned, args.batches, copy=False, resident=True, edgematches=False)
+    ctx.overlap_batched(pinned, 0, copy=False, resident=True, edgematches=False)
     walls = []
     for _ in range(5):
         t0 = time.perf_counter()
-        tables, _ = ctx.overlap_batched(pinned, args.batches, copy=False, resident=True, edgematches=False)
+        tables, _ = ctx.overlap_batched(pinned, 0, copy=False, resident=True, edgematches=False)
         walls.append(1e3 * (time.perf_counter() - t0))
     ctx.find_contraction_edges()
     t0 = time.perf_counter()
@@ -680,7 +680,7 @@ def e2e_leg(args, w, tab, read_names_all, threads):
         timings = {}
         t0 = time.perf_counter()
         res = pipeline.run(os.path.join(d, "contigs.paf"), os.path.join(d, "unitigs.fa"), os.path.join(d, "nanopore.fa"), out,
-                           threads=threads, timings=timings, batches=args.batches)
+                           threads=threads, timings=timings)
         wall = time.perf_counter() - t0
         out_bytes = {k: os.path.getsize(os.path.join(out, k)) for k in ("temp_1.target.fa", "temp_1.query.fa", "temp_1.align.paf")}
     finally:

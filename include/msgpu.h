@@ -275,7 +275,7 @@ int msgpu_merge_gathered_ex(msgpu_ctx *ctx, const void *d_gathered, uint32_t wor
  * msgpu_copy_tables bit for bit -- canonical order, cross references (em_off, order_off, edge_idx, ids_off) into the
  * whole tables -- owned by the context and valid until its next msgpu_overlap_batched / msgpu_destroy.  HBM holds one
  * window's tables at a time instead of the job's.  With msgpu_set_shard the windows cut this shard's reads.
- * n_batches 0 = 8.  `rows` should be pinned (msgpu_pinned_alloc) for the copy to run at link speed. */
+ * n_batches 0 = 8 (3 with MSGPU_BATCH_NO_EDGEMATCHES).  `rows` should be pinned (msgpu_pinned_alloc) for the copy to run at link speed. */
 typedef struct msgpu_host_tables {
   const msgpu_edge      *edges;
   const msgpu_edgematch *ems;

@@ -1230,14 +1230,17 @@ int msgpu_overlap_batched_ex(msgpu_ctx *c, const msgpu_row *rows, size_t n_rows,
   c->win_hi = 0xffffffffu;
   c->base_edges = c->base_ems = c->base_orders = c->base_ids = 0;
   reset_views();
-  c->no_prologue = (n_batches ? n_batches : 8) > 1; // several windows: each has its own scratch offsets and read lists
+  // windows: the caller's choice, else 8 when all four tables travel (the link is the bound: many windows hide the first
+  // one's compute) and 3 when the EdgeMatch table stays (compute and copies weigh about the same: few, large windows)
+  if (!n_batches) n_batches = copy_ems ? 8 : 3;
+  c->no_prologue = n_batches > 1; // several windows: each has its own scratch offsets and read lists
   // rows host -> HBM once (unless they are there already), index build once
   const int rc_load = (flags & MSGPU_BATCH_ROWS_ON_DEVICE) ? msgpu_load_rows_device(c, rows, n_rows) : msgpu_load_rows(c, rows, n_rows);
   c->no_prologue    = false;
   if (rc_load) return rc_load;
   out->load_ms = ms_since(t_start);
   const uint32_t V = c->V;
-  uint32_t       B = n_batches ? n_batches : 8;
+  uint32_t       B = n_batches;
   if (B > 256) B = 256;
   if (B > V) B = V ? V : 1;
   hipStream_t st = c->stream, cs = c->copy_stream;
@@ -1311,6 +1314,11 @@ int msgpu_overlap_batched_ex(msgpu_ctx *c, const msgpu_row *rows, size_t n_rows,
     if (rc == MSGPU_OK) rc = ensure_host(c, c->h_ids, (tot_i + c->n_ids + 1) * 4, tot_i * 4, hint(tot_i + c->n_ids, 4));
     if (rc != MSGPU_OK) break;
     guarded(hipStreamWaitEvent(cs, c->ev_done[set], 0), "hipStreamWaitEvent");
+    // (Device-to-host copies are shader blits on this stack -- __amd_rocclr_copyBuffer in a kernel trace, not SDMA -- and a
+    // compute kernel that overlaps one completes only when that copy kernel does, so a window's chain of small dependent
+    // kernels barely advances while its predecessor's tables travel: few, large windows overlap best.  Cutting the
+    // copies into 1 MB pieces was tried and lost more link efficiency than it gained: 30.6 instead of 22.0 ms for the
+    // full tables.)
     if (c->n_edges) guarded(hipMemcpyAsync(static_cast<msgpu_edge *>(c->h_edges.p) + tot_e, c->edges.at(), c->n_edges * sizeof(msgpu_edge), hipMemcpyDeviceToHost, cs), "copy of the edge table");
     if (c->n_ems && copy_ems) guarded(hipMemcpyAsync(static_cast<msgpu_edgematch *>(c->h_ems.p) + tot_m, c->ems.at(), c->n_ems * sizeof(msgpu_edgematch), hipMemcpyDeviceToHost, cs), "copy of the EdgeMatch table");
     if (c->n_orders) guarded(hipMemcpyAsync(static_cast<msgpu_order *>(c->h_orders.p) + tot_o, c->orders.at(), c->n_orders * sizeof(msgpu_order), hipMemcpyDeviceToHost, cs), "copy of the order table");

@@ -24,7 +24,7 @@ from .sequences import ILLUMINA, NANOPORE, SeqFile, SeqStore
 
 
 def run(contigs_paf, unitigs_path, nanopore_path, out_dir, threads=None, wiggle_room=300, device=0, timings=None,
-        batches=8):
+        batches=0):
     """-> dict of counts; writes the three output files into out_dir (created by the caller, Application.cpp:65-82)."""
     t = {}
     n_threads = int(threads) if threads else max(1, min(16, os.cpu_count() or 1))

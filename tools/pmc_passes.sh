@@ -17,7 +17,7 @@ run write WRITE_SIZE
 run l2 TCC_HIT_sum TCC_MISS_sum
 # the gather kernel of the consensus leg (not part of --kernels-only): its two traffic counters
 rung() { # name, counter
-  timeout -k 10 300 rocprofv3 --pmc "$2" --output-format csv -d "$OUT" -o "pmc_$1" -- python3 bench.py --steps 3 --warmup 1 --cpu-sample-reads 0 --assemble-window-mb -1 --batches 0 --workload "$WL" > "$OUT/pmc_$1.json" 2> "$OUT/pmc_$1.err" || echo "pass $1 failed"
+  timeout -k 10 300 rocprofv3 --pmc "$2" --output-format csv -d "$OUT" -o "pmc_$1" -- python3 bench.py --steps 3 --warmup 1 --cpu-sample-reads 0 --assemble-window-mb -1 --batches 0 --no-tiled --no-e2e --workload "$WL" > "$OUT/pmc_$1.json" 2> "$OUT/pmc_$1.err" || echo "pass $1 failed"
 }
 rung zfetch_gather FETCH_SIZE
 rung zwrite_gather WRITE_SIZE
