@@ -61,3 +61,44 @@ def test_str_slice_matches_oracle(oracle):
         size = int(rng.integers(0, 40))
         i, j = (int(x) for x in rng.integers(-60, 60, 2))
         assert sequences.str_slice(size, i, j) == oracle.str_slice(size, i, j), (size, i, j)
+
+
+def _records(f):
+    return f.names, [f.sequence(i) for i in range(len(f))]
+
+
+@pytest.mark.parametrize("threads", [2, 3, 7, 16])
+def test_chunked_parse_equals_sequential(oracle, tmp_path, monkeypatch, threads):
+    """Large files are parsed in chunks on several threads, each chunk by the same sequential state machine, the cuts
+    verified afterwards (MSGPU_SEQ_THREADS forces the chunked path at any size).  Same records as one pass -- and as the
+    oracle -- for multi-line FASTA, duplicates across chunks (first wins), FASTQ, and a FASTQ whose quality lines begin
+    with '@' (which '@' lines are descriptions depends on everything before them: the cuts do not verify and the file
+    takes the sequential pass)."""
+    rng = np.random.default_rng(threads)
+    bases = np.frombuffer(b"ACGTN", dtype=np.uint8)
+
+    def seq(n):
+        return bases[rng.integers(0, 5, n)].tobytes()
+    fa = b"leading junk\n"
+    for i in range(400):
+        s = seq(int(rng.integers(0, 900)))
+        name = b"r%d" % (i if i % 37 else i // 2)  # every 37th record repeats an earlier id
+        fa += b">" + name + b" some description\n" + b"\n".join(s[k:k + 70] for k in range(0, len(s), 70)) + b"\n"
+    fq = b""
+    for i in range(300):
+        s = seq(int(rng.integers(1, 300)))
+        fq += b"@q%d x\n" % i + s + b"\n+\n" + b"I" * len(s) + b"\n"
+    evil = b""
+    for i in range(300):  # quality lines that start with '@', sequence lengths that vary: cuts land on them
+        s = seq(int(rng.integers(1, 200)))
+        evil += b"@e%d\n" % i + s + b"\n+\n" + b"@" + b"F" * (len(s) - 1) + b"\n"
+    for name, text in (("m.fa", fa), ("s.fq", fq), ("evil.fq", evil), ("one.fa", b">x\nACGT\n"), ("none.fa", b"")):
+        path = _write(tmp_path, name, text)
+        monkeypatch.setenv("MSGPU_SEQ_THREADS", "1")
+        want = _records(sequences.SeqFile(path))
+        monkeypatch.setenv("MSGPU_SEQ_THREADS", str(threads))
+        got = _records(sequences.SeqFile(path))
+        assert got == want, (name, threads)
+        o_names, o_seqs = oracle.seq_load(path)
+        assert got == (o_names, o_seqs), (name, "oracle")
+    assert len(_records(sequences.SeqFile(_write(tmp_path, "m2.fa", fa)))[0]) == len({b"r%d" % (i if i % 37 else i // 2) for i in range(400)})
