@@ -79,21 +79,26 @@ struct Tick { // MSGPU_GRAPH_DEBUG=1: phase timings on stderr
 // host threads for the loops over all edges / orders of the stage (results never depend on the count): the cores this
 // process may use, at most 16; MSGPU_GRAPH_THREADS overrides
 unsigned stage_threads() {
-  static const unsigned n = [] {
-    if (const char *e = std::getenv("MSGPU_GRAPH_THREADS")) {
-      const int v = std::atoi(e);
-      if (v > 0) return static_cast<unsigned>(v);
-    }
-    unsigned hw = std::thread::hardware_concurrency();
-    return hw == 0 ? 1u : hw > 16 ? 16u : hw;
-  }();
-  return n;
+  if (const char *e = std::getenv("MSGPU_GRAPH_THREADS")) {
+    const int v = std::atoi(e);
+    if (v > 0) return static_cast<unsigned>(v > 64 ? 64 : v);
+  }
+  static const unsigned hw = std::thread::hardware_concurrency();
+  return hw == 0 ? 1u : hw > 16 ? 16u : hw;
+}
+// below this many items a loop stays on the calling thread (MSGPU_GRAPH_PAR_MIN overrides: tests run the threaded code on small graphs)
+size_t par_min() {
+  if (const char *e = std::getenv("MSGPU_GRAPH_PAR_MIN")) {
+    const long v = std::atol(e);
+    if (v > 0) return static_cast<size_t>(v);
+  }
+  return size_t(1) << 16;
 }
 // f(chunk, begin, end) over [0, n) cut into contiguous chunks, one per thread; chunk indices ascend with the range, so
 // per-chunk results concatenated in chunk order are in index order.  The first exception of a chunk is rethrown here.
 template <class F> unsigned parallel_chunks(size_t n, F f) {
   unsigned nt = stage_threads();
-  if (n < (size_t(1) << 16)) nt = 1;
+  if (n < par_min()) nt = 1;
   if (nt <= 1) {
     f(0u, size_t(0), n);
     return 1;
@@ -113,6 +118,29 @@ template <class F> unsigned parallel_chunks(size_t n, F f) {
   for (auto &e : err)
     if (e) std::rethrow_exception(e);
   return nt;
+}
+
+// f(begin, end) over [0, n) in pieces of `grain` handed out by a counter: for loops whose cost per index is uneven
+template <class F> void parallel_dynamic(size_t n, size_t grain, F f) {
+  unsigned nt = stage_threads();
+  if (n < 4 * grain || n < par_min()) nt = 1;
+  if (nt <= 1) {
+    f(size_t(0), n);
+    return;
+  }
+  std::atomic<size_t>             next{0};
+  std::vector<std::exception_ptr> err(nt);
+  std::vector<std::thread>        pool;
+  auto run = [&](unsigned c) {
+    try {
+      for (size_t b = next.fetch_add(grain); b < n; b = next.fetch_add(grain)) f(b, std::min(n, b + grain));
+    } catch (...) { err[c] = std::current_exception(); }
+  };
+  for (unsigned c = 1; c < nt; ++c) pool.emplace_back(run, c);
+  run(0);
+  for (auto &t : pool) t.join();
+  for (auto &e : err)
+    if (e) std::rethrow_exception(e);
 }
 
 // ---- flat adjacency ----------------------------------------------------------------------------------------------------
@@ -136,8 +164,85 @@ struct Csr { // segment of vertex v: arcs[off[v] .. off[v+1]), ascending `to`
 
 // CSR of n vertices from m (from[i] -> to[i]) pairs, edge index i; both_ways = undirected.  Segments end up ascending
 // in `to` (counting sort by source keeps input order; a segment that is not ascending already is sorted).
+// The undirected adjacency of a large graph on all host threads, arc for arc what the serial builder below produces: every
+// thread owns a contiguous stretch of the edge table and counts, per vertex, the edges of its stretch that have the vertex
+// as their HIGHER end and as their LOWER end; a prefix over (vertex, thread) turns the counts into the first slot of every
+// thread inside the vertex's "lower neighbours" and "higher neighbours" runs (both in edge order); the threads then drop
+// their arcs without meeting each other.
+bool build_csr_undirected_parallel(uint32_t n, const uint32_t *from, const uint32_t *to, size_t m, Csr &c) {
+  const unsigned nt = stage_threads();
+  if (nt < 2 || m < par_min() || static_cast<size_t>(nt) * 2 * (static_cast<size_t>(n) + 1) > (size_t(1) << 26)) return false;
+  const size_t          stride = static_cast<size_t>(n) + 1;
+  std::vector<uint32_t> hist(static_cast<size_t>(nt) * 2 * stride); // [thread][hi | lo][vertex]
+  auto chunk = [&](unsigned t) { return std::make_pair(m * t / nt, m * (t + 1) / nt); };
+  auto on_threads = [&](auto &&body) { // body(t) for t < nt
+    std::vector<std::exception_ptr> err(nt);
+    std::vector<std::thread>        pool;
+    auto run = [&](unsigned t) {
+      try {
+        body(t);
+      } catch (...) { err[t] = std::current_exception(); }
+    };
+    for (unsigned t = 1; t < nt; ++t) pool.emplace_back(run, t);
+    run(0);
+    for (auto &th : pool) th.join();
+    for (auto &e : err)
+      if (e) std::rethrow_exception(e);
+  };
+  on_threads([&](unsigned t) {
+    uint32_t *hi = hist.data() + static_cast<size_t>(t) * 2 * stride, *lo = hi + stride;
+    std::fill(hi, hi + 2 * stride, 0u);
+    for (size_t i = chunk(t).first; i < chunk(t).second; ++i) {
+      const uint32_t a = from[i], b = to[i];
+      ++hi[a > b ? a : b];
+      ++lo[a > b ? b : a];
+    }
+  });
+  c.off.assign(stride, 0);
+  on_threads([&](unsigned t) { // vertices [v0, v1): counts -> first slot of every thread inside the vertex's two runs
+    const size_t v0 = stride * t / nt, v1 = stride * (t + 1) / nt;
+    for (size_t v = v0; v < v1; ++v) {
+      uint32_t run = 0;
+      for (unsigned k = 0; k < nt; ++k) {
+        uint32_t &h = hist[static_cast<size_t>(k) * 2 * stride + v];
+        const uint32_t cnt = h;
+        h                  = run;
+        run += cnt;
+      }
+      for (unsigned k = 0; k < nt; ++k) {
+        uint32_t &l = hist[static_cast<size_t>(k) * 2 * stride + stride + v];
+        const uint32_t cnt = l;
+        l                  = run;
+        run += cnt;
+      }
+      if (v < n) c.off[v + 1] = run; // (slot n of the histograms is never counted into: vertex ids are < n)
+    }
+  });
+  for (uint32_t v = 0; v < n; ++v) c.off[v + 1] += c.off[v];
+  c.arcs.resize(c.off[n]);
+  on_threads([&](unsigned t) {
+    uint32_t *hi = hist.data() + static_cast<size_t>(t) * 2 * stride, *lo = hi + stride;
+    for (size_t i = chunk(t).first; i < chunk(t).second; ++i) {
+      const uint32_t a = from[i], b = to[i], h = a > b ? a : b, l = a > b ? b : a;
+      c.arcs[c.off[h] + hi[h]++] = Arc{l, static_cast<uint32_t>(i)};
+      c.arcs[c.off[l] + lo[l]++] = Arc{h, static_cast<uint32_t>(i)};
+    }
+  });
+  on_threads([&](unsigned t) {
+    for (size_t v = static_cast<size_t>(n) * t / nt; v < static_cast<size_t>(n) * (t + 1) / nt; ++v) {
+      if (c.off[v + 1] - c.off[v] < 2) continue;
+      Arc *b = c.arcs.data() + c.off[v], *e = c.arcs.data() + c.off[v + 1];
+      bool sorted = true;
+      for (Arc *p = b; p + 1 < e && sorted; ++p) sorted = p->to <= (p + 1)->to;
+      if (!sorted) std::stable_sort(b, e, [](const Arc &x, const Arc &y) { return x.to < y.to; });
+    }
+  });
+  return true;
+}
+
 Csr build_csr(uint32_t n, const uint32_t *from, const uint32_t *to, size_t m, bool both_ways) {
   Csr c;
+  if (both_ways && build_csr_undirected_parallel(n, from, to, m, c)) return c;
   c.off.assign(static_cast<size_t>(n) + 1, 0);
   for (size_t i = 0; i < m; ++i) {
     ++c.off[from[i] + 1];
@@ -171,25 +276,25 @@ Csr build_csr(uint32_t n, const uint32_t *from, const uint32_t *to, size_t m, bo
 struct UnionFind { // vertex ids are dense: vectors instead of the reference's two hash maps; weight 0 = "not seen yet"
   std::vector<uint32_t> parent;
   std::vector<uint64_t> weight;
-  std::vector<uint32_t> path;
   explicit UnionFind(uint32_t n) : parent(n), weight(n, 0) {}
-  uint32_t find(uint32_t v) {
+  uint32_t find(uint32_t v) { // mst.cpp:40-60: walk to the vertex that is its own parent, then hang the whole path on it
     if (!weight[v]) {
       parent[v] = v;
       weight[v] = 1;
       return v;
     }
-    path.assign(1, v);
-    uint32_t root = parent[v];
-    while (root != path.back()) {
-      path.push_back(root);
-      root = parent[root];
+    uint32_t root = v;
+    while (parent[root] != root) root = parent[root];
+    for (uint32_t a = v; a != root;) {
+      const uint32_t next = parent[a];
+      parent[a]           = root;
+      a                   = next;
     }
-    for (uint32_t a : path) parent[a] = root;
     return root;
   }
-  void unify(uint32_t v1, uint32_t v2) {
-    uint32_t first = find(v1), second = find(v2);
+  // unify (mst.cpp:62-73) with the two roots its own find() calls return (the caller has just found them: a second
+  // find() of a compressed path changes nothing)
+  void unify(uint32_t v1, uint32_t v2, uint32_t first, uint32_t second) {
     if (weight[v2] > weight[v1]) std::swap(first, second);
     weight[first] += weight[second];
     parent[second] = first;
@@ -218,9 +323,10 @@ void max_span_tree(uint32_t nv, Ends ends, Weight weight, std::vector<uint32_t> 
   auto      take = [&](uint32_t pos) {
     const uint32_t e  = cand[pos];
     const auto     ab = ends(e);
-    if (uf.find(ab.first) != uf.find(ab.second)) {
+    const uint32_t ra = uf.find(ab.first), rb = uf.find(ab.second);
+    if (ra != rb) {
       in_tree[e] = 1;
-      uf.unify(ab.first, ab.second);
+      uf.unify(ab.first, ab.second, ra, rb);
     }
   };
   for (auto &k : keyed) take(k.second);
@@ -328,6 +434,7 @@ struct msgpu_graph {
     uint32_t meta0 = 0;
     uint32_t comp  = NIL; // connected component
     uint32_t loc   = NIL; // local id inside its component's DiGraph
+    uint32_t seq   = NIL; // number of its first pop in getDirectedGraph's walk (NIL: never popped)
     int8_t   dir   = D_NONE;
     uint8_t  alive = 1, in_dg = 0;
   };
@@ -355,6 +462,7 @@ struct msgpu_graph {
   };
   std::map<uint32_t, std::vector<Contain>> contain;
   bool cleaned = false, linearized = false;
+  bool every_alive_edge_kept = false; // set with the arc flags in msgpu_graph_linearize
   uint32_t n_threads = 1;
   msgpu_graph_stats stats{};
   // paths + storage the msgpu_path_input views point into
@@ -401,82 +509,169 @@ struct DiG {
 };
 
 // getDirectedGraph, dg.cpp:35-121; the component = the vertices with comp_of == cid (its sub-graph keeps every alive
-// edge between those vertices, Graph.cpp:317-326)
-DiG get_directed_graph(msgpu_graph &g, uint32_t cid, const std::vector<uint32_t> &members, uint32_t start) {
-  DiG                                        dg;
-  std::vector<uint32_t>                      ea, eb;   // global endpoints while building
-  std::vector<std::pair<uint32_t, uint32_t>> pushes;   // (directed edge, order)
-  std::vector<std::pair<uint32_t, bool>>     stack{{start, true}};
-  auto add_vertex = [&](uint32_t v) { g.V[v].in_dg = 1; };
+// edge between those vertices, Graph.cpp:317-326).
+//
+// The reference walks the component with a stack and, for every edge it meets for the first time, turns the edge's
+// EdgeOrders into directed edges.  Which endpoint meets an edge first, and with which toggle, is the only thing that
+// depends on the walk: an edge with at least one kept order gets its directed edges when the first of its endpoints is
+// popped for the first time (all of that vertex's edges are handled in that one pop; hasEdge() then makes every later
+// visit skip it, including the visit's push), and the toggle of a first pop is the direction the vertex receives there.
+// So the walk below only settles pop order, directions and reachability -- per arc it reads two flag bytes and the
+// neighbour's 24-byte record, no edge record and no order -- and the directed edges are produced afterwards, on all host
+// threads, in exactly the creation order of the reference: by pop number of the processing vertex, its arcs in
+// ascending neighbour id, an edge's orders in table order, a direction's edge on its first order.
+DiG get_directed_graph(msgpu_graph &g, uint32_t cid, const std::vector<uint32_t> &members, uint32_t start,
+                       const std::vector<uint8_t> &arc_flags) {
+  constexpr uint8_t AF_ALIVE = 1, AF_KEPT = 2, AF_CONS = 4, AF_POS = 8; // per arc: edge alive / has a kept order / consensus set / e_POS
+  DiG                                    dg;
+  Tick                                   tk;
+  std::vector<uint32_t>                  pop_order;                 // vertices in the order of their FIRST pop
+  std::vector<std::pair<uint32_t, bool>> stack{{start, true}};
+  const Arc *const                       arcs0 = g.adj.arcs.data();
   while (!stack.empty()) {
     const uint32_t cur    = stack.back().first;
     const bool     toggle = stack.back().second;
     stack.pop_back();
-    if (!g.V[cur].in_dg) add_vertex(cur);
-    if (g.V[cur].dir == D_NONE) g.V[cur].dir = toggle ? D_POS : D_NEG;
-    // the walk is a chain of dependent cache misses (arc -> edge record -> its orders): ask for all of them up front
-    for (const Arc *n = g.adj.begin(cur); n != g.adj.end(cur); ++n) {
-      __builtin_prefetch(&g.E[n->e]);
-      __builtin_prefetch(&g.V[n->to]);
+    msgpu_graph::Vertex &vc    = g.V[cur];
+    const bool           first = vc.seq == NIL;
+    if (first) {
+      vc.seq = static_cast<uint32_t>(pop_order.size());
+      pop_order.push_back(cur);
     }
-    for (const Arc *n = g.adj.begin(cur); n != g.adj.end(cur); ++n)
-      if (g.E[n->e].alive && !g.E[n->e].de_fwd && !g.E[n->e].de_bwd) __builtin_prefetch(&g.ol[g.E[n->e].ord_lo]);
+    vc.in_dg = 1;
+    if (vc.dir == D_NONE) vc.dir = toggle ? D_POS : D_NEG;
+    // A vertex is pushed once by every neighbour that sees it before its first pop, and every later pop walks its arcs
+    // again -- to no effect when each alive edge has a kept order (always, after the clean-up): hasEdge() skips them all,
+    // and the neighbours it would mark are marked since the first pop.  (About ten pops per vertex on configs[2].)
+    if (!first && g.every_alive_edge_kept) continue;
+    for (const Arc *n = g.adj.begin(cur); n != g.adj.end(cur); ++n) __builtin_prefetch(&g.V[n->to]);
     for (const Arc *n = g.adj.begin(cur); n != g.adj.end(cur); ++n) {
-      const uint32_t nb = n->to, ue = n->e;
-      if (!g.E[ue].alive || g.V[nb].comp != cid) continue;
-      bool other_exists = g.V[nb].in_dg != 0;
-      if (other_exists) other_exists = g.V[nb].dir != D_NONE;
-      if (!other_exists) add_vertex(nb);
-      if (g.E[ue].de_fwd || g.E[ue].de_bwd) continue; // hasEdge(a, b) || hasEdge(b, a)
-      const uint32_t lo = g.E[ue].ord_lo, hi = lo + g.E[ue].ord_cnt;
-      for (uint32_t oi = lo; oi < hi; ++oi) {
-        if (!g.o_kept[oi]) continue;
-        const msgpu_graph::OLite &o = g.ol[oi];
-        bool                      flip = false;
-        if (!g.odir(oi) && o.base == nb) flip = !flip;
-        if (!toggle) flip = !flip;
-        const uint32_t s = flip ? o.end : o.start, t = flip ? o.start : o.end;
-        if (!((s == g.E[ue].a && t == g.E[ue].b) || (s == g.E[ue].b && t == g.E[ue].a)))
-          throw GraphError("getDirectedGraph: order between vertices outside the component");
-        uint32_t &slot = s == g.E[ue].a ? g.E[ue].de_fwd : g.E[ue].de_bwd;
-        if (!slot) {
-          ea.push_back(s);
-          eb.push_back(t);
-          dg.src.push_back(ue);
-          dg.shadow.push_back(g.E[ue].shadow);
-          dg.weight.push_back(g.E[ue].shadow ? 0 : g.E[ue].weight);
-          slot = static_cast<uint32_t>(ea.size());
-        }
-        pushes.emplace_back(slot - 1, oi);
-      }
-      if (g.E[ue].cons == D_NONE) continue;
-      const bool nxt = toggle == (g.E[ue].cons == D_POS);
-      if (!other_exists) stack.emplace_back(nb, nxt);
+      const uint8_t af = arc_flags[n - arcs0];
+      if (!(af & AF_ALIVE)) continue;
+      msgpu_graph::Vertex &vn = g.V[n->to];
+      if (vn.comp != cid) continue;
+      const bool other_exists = vn.in_dg != 0 && vn.dir != D_NONE;
+      if (!other_exists) vn.in_dg = 1;
+      // hasEdge(a, b) || hasEdge(b, a): the edge got its directed edges at an earlier first pop of either end
+      if ((af & AF_KEPT) && (!first || vn.seq != NIL)) continue;
+      if (!(af & AF_CONS)) continue;
+      const bool nxt = toggle == ((af & AF_POS) != 0);
+      if (!other_exists) stack.emplace_back(n->to, nxt);
     }
   }
-  Tick tk;
-  tk("  dg: (walk, reported by caller)");
+  tk("  dg: walk");
+  // the directed edges: vertex i of the pop order handles its edges to the vertices popped after it (or never)
+  const size_t          np = pop_order.size();
+  std::vector<uint64_t> slot_base(np + 1, 0), ord_base(np + 1, 0);
+  auto for_edges_of = [&](size_t i, auto &&body) { // body(undirected edge, neighbour, toggle of the processing vertex)
+    const uint32_t v      = pop_order[i];
+    const bool     toggle = g.V[v].dir == D_POS;
+    for (const Arc *n = g.adj.begin(v); n != g.adj.end(v); ++n) {
+      const uint8_t af = arc_flags[n - arcs0];
+      if ((af & (AF_ALIVE | AF_KEPT)) != (AF_ALIVE | AF_KEPT)) continue;
+      const msgpu_graph::Vertex &vn = g.V[n->to];
+      if (vn.comp != cid || (vn.seq != NIL && vn.seq < i)) continue;
+      body(n->e, n->to, toggle);
+    }
+  };
+  auto direction_of = [&](uint32_t ue, uint32_t oi, uint32_t nb, bool toggle) -> bool { // true: the order runs E.a -> E.b
+    const msgpu_graph::OLite &o = g.ol[oi];
+    bool                      flip = false;
+    if (!g.odir(oi) && o.base == nb) flip = !flip;
+    if (!toggle) flip = !flip;
+    const uint32_t s = flip ? o.end : o.start, t = flip ? o.start : o.end;
+    if (!((s == g.E[ue].a && t == g.E[ue].b) || (s == g.E[ue].b && t == g.E[ue].a)))
+      throw GraphError("getDirectedGraph: order between vertices outside the component");
+    return s == g.E[ue].a;
+  };
+  // (a vertex popped early meets most of its neighbours unpopped, a late one hardly any: pieces by counter, not by range)
+  parallel_dynamic(np, 2048, [&](size_t b, size_t e) { // pass 1: directed edges and orders per processing vertex
+    for (size_t i = b; i < e; ++i) {
+      uint64_t ns = 0, no = 0;
+      for_edges_of(i, [&](uint32_t ue, uint32_t nb, bool toggle) {
+        bool           fwd = false, bwd = false;
+        const uint32_t lo = g.E[ue].ord_lo, hi = lo + g.E[ue].ord_cnt;
+        for (uint32_t oi = lo; oi < hi; ++oi) {
+          if (!g.o_kept[oi]) continue;
+          (direction_of(ue, oi, nb, toggle) ? fwd : bwd) = true;
+          ++no;
+        }
+        ns += (fwd ? 1 : 0) + (bwd ? 1 : 0);
+      });
+      slot_base[i + 1] = ns;
+      ord_base[i + 1]  = no;
+    }
+  });
+  for (size_t i = 0; i < np; ++i) {
+    slot_base[i + 1] += slot_base[i];
+    ord_base[i + 1] += ord_base[i];
+  }
+  const size_t          m = slot_base[np];
+  std::vector<uint32_t> ea(m), eb(m); // global endpoints
+  dg.src.resize(m);
+  dg.shadow.resize(m);
+  dg.weight.resize(m);
+  dg.ord_off.assign(m + 1, 0);
+  dg.ord.resize(ord_base[np]);
+  parallel_dynamic(np, 2048, [&](size_t b, size_t e) { // pass 2: fill, every vertex into its own stretch
+    for (size_t i = b; i < e; ++i) {
+      uint64_t slot = slot_base[i], op = ord_base[i];
+      for_edges_of(i, [&](uint32_t ue, uint32_t nb, bool toggle) {
+        msgpu_graph::Edge &E = g.E[ue];
+        const uint32_t     lo = E.ord_lo, hi = lo + E.ord_cnt;
+        int64_t            s_fwd = -1, s_bwd = -1; // the two possible directed edges, numbered in order of first use
+        uint32_t           n_fwd = 0, n_bwd = 0;
+        for (uint32_t oi = lo; oi < hi; ++oi) {
+          if (!g.o_kept[oi]) continue;
+          if (direction_of(ue, oi, nb, toggle)) {
+            if (s_fwd < 0) s_fwd = static_cast<int64_t>(slot++);
+            ++n_fwd;
+          } else {
+            if (s_bwd < 0) s_bwd = static_cast<int64_t>(slot++);
+            ++n_bwd;
+          }
+        }
+        auto make = [&](int64_t sl, bool fwd, uint32_t cnt, uint64_t first_ord) {
+          ea[sl]            = fwd ? E.a : E.b;
+          eb[sl]            = fwd ? E.b : E.a;
+          dg.src[sl]        = ue;
+          dg.shadow[sl]     = E.shadow;
+          dg.weight[sl]     = E.shadow ? 0 : E.weight;
+          dg.ord_off[sl]    = static_cast<uint32_t>(first_ord); // (ord_off[m] is set below)
+          (fwd ? E.de_fwd : E.de_bwd) = static_cast<uint32_t>(sl + 1);
+          (void)cnt;
+        };
+        // a directed edge's orders are contiguous in dg.ord, the edges in slot order
+        const bool     fwd_first = s_fwd >= 0 && (s_bwd < 0 || s_fwd < s_bwd);
+        const uint64_t o_first = op, o_second = op + (fwd_first ? n_fwd : n_bwd);
+        if (s_fwd >= 0) make(s_fwd, true, n_fwd, fwd_first ? o_first : o_second);
+        if (s_bwd >= 0) make(s_bwd, false, n_bwd, fwd_first ? o_second : o_first);
+        uint64_t pf = fwd_first ? o_first : o_second, pb = fwd_first ? o_second : o_first;
+        for (uint32_t oi = lo; oi < hi; ++oi) {
+          if (!g.o_kept[oi]) continue;
+          if (direction_of(ue, oi, nb, toggle)) dg.ord[pf++] = oi;
+          else dg.ord[pb++] = oi;
+        }
+        op += n_fwd + n_bwd;
+      });
+    }
+  });
+  dg.ord_off[m] = static_cast<uint32_t>(ord_base[np]);
+  tk("  dg: directed edges");
   // local ids in ascending global id
   for (uint32_t v : members)
     if (g.V[v].in_dg) dg.ids.push_back(v);
   std::sort(dg.ids.begin(), dg.ids.end());
   dg.n = static_cast<uint32_t>(dg.ids.size());
   for (uint32_t l = 0; l < dg.n; ++l) g.V[dg.ids[l]].loc = l;
-  const size_t m = ea.size();
   dg.ea.resize(m);
   dg.eb.resize(m);
   for (size_t i = 0; i < m; ++i) {
     dg.ea[i] = g.V[ea[i]].loc;
     dg.eb[i] = g.V[eb[i]].loc;
   }
-  dg.ord_off.assign(m + 1, 0);
-  for (auto &p : pushes) ++dg.ord_off[p.first + 1];
-  for (size_t i = 0; i < m; ++i) dg.ord_off[i + 1] += dg.ord_off[i];
-  dg.ord.resize(pushes.size());
-  std::vector<uint32_t> cur(dg.ord_off.begin(), dg.ord_off.end() - 1);
-  for (auto &p : pushes) dg.ord[cur[p.first]++] = p.second;
   tk("  dg: ids + order lists");
-  if (m > (size_t(1) << 16) && stage_threads() > 1) { // the two adjacencies of a large component side by side
+  if (m > par_min() && stage_threads() > 1) { // the two adjacencies of a large component side by side
     std::exception_ptr err;
     std::thread        t([&] {
       try {
@@ -1002,7 +1197,8 @@ std::vector<std::vector<uint32_t>> linearize_graph(DiG &dg) { // lg.cpp:522-629
 }
 
 // one connected component: getDirectedGraph + linearizeGraph + the assemblePath inputs of its paths (main.cpp:620-661)
-std::vector<msgpu_graph::PathStore> component_paths(msgpu_graph *g, uint32_t cid, const std::vector<uint32_t> &comp) {
+std::vector<msgpu_graph::PathStore> component_paths(msgpu_graph *g, uint32_t cid, const std::vector<uint32_t> &comp,
+                                                    const std::vector<uint8_t> &arc_flags) {
   uint32_t start = NIL;
   {
     std::vector<uint32_t> sorted(comp);
@@ -1011,7 +1207,7 @@ std::vector<msgpu_graph::PathStore> component_paths(msgpu_graph *g, uint32_t cid
       if (start == NIL || g->V[v].len > g->V[start].len) start = v;
   }
   Tick tk;
-  DiG  dg = get_directed_graph(*g, cid, comp, start);
+  DiG  dg = get_directed_graph(*g, cid, comp, start, arc_flags);
   tk("getDirectedGraph");
   const std::vector<std::vector<uint32_t>> lin = linearize_graph(dg);
   tk("linearizeGraph");
@@ -1315,48 +1511,54 @@ int msgpu_graph_clean_up(msgpu_graph *g, const int64_t *contraction_order, const
         }
       }
     }
-    std::vector<uint8_t>  dele(ne, 0);
-    std::vector<uint32_t> left, right;
-    for (uint32_t e : cand) { // decycle, :575-618
-      if (in_tree[e]) continue;
-      const uint32_t a = g->E[e].a, b = g->E[e].b;
-      // direction folded over the tree path a..b (:590-603): XNOR chain = parity of the e_NEG edges on it
-      const bool direction = !((g->E[e].cons == D_NEG) ^ negpar[a] ^ negpar[b]);
-      if (direction) continue;
-      left.clear();
-      right.clear();
-      uint32_t ua = a, ub = b;
-      while (depth[ua] > depth[ub]) {
-        left.push_back(pedge[ua]);
-        ua = parent[ua];
-      }
-      while (depth[ub] > depth[ua]) {
-        right.push_back(pedge[ub]);
-        ub = parent[ub];
-      }
-      while (ua != ub) {
-        require(parent[ua] != ua && parent[ub] != ub, "decycle: the span tree does not connect the ends of an edge");
-        left.push_back(pedge[ua]);
-        ua = parent[ua];
-        right.push_back(pedge[ub]);
-        ub = parent[ub];
-      }
-      left.insert(left.end(), right.rbegin(), right.rend()); // tree edges in path order a -> b
-      if (left.empty()) continue;
-      size_t lo = 0;
-      double wlo = static_cast<double>(g->E[left[0]].weight), whi = wlo;
-      for (size_t i = 1; i < left.size(); ++i) {
-        const double w = static_cast<double>(g->E[left[i]].weight);
-        if (w < wlo) { // std::min_element: the first minimum
-          wlo = w;
-          lo  = i;
+    std::vector<uint8_t> dele(ne, 0);
+    // decycle, :575-618: every non-tree edge is judged against the finished span forest on its own (dele is only ever set
+    // to 1), so the candidates are cut over the host threads
+    parallel_chunks(cand.size(), [&](unsigned, size_t c_begin, size_t c_end) {
+      std::vector<uint32_t> left, right;
+      for (size_t ci = c_begin; ci < c_end; ++ci) {
+        const uint32_t e = cand[ci];
+        if (in_tree[e]) continue;
+        const uint32_t a = g->E[e].a, b = g->E[e].b;
+        // direction folded over the tree path a..b (:590-603): XNOR chain = parity of the e_NEG edges on it
+        const bool direction = !((g->E[e].cons == D_NEG) ^ negpar[a] ^ negpar[b]);
+        if (direction) continue;
+        left.clear();
+        right.clear();
+        uint32_t ua = a, ub = b;
+        while (depth[ua] > depth[ub]) {
+          left.push_back(pedge[ua]);
+          ua = parent[ua];
         }
-        if (w > whi) whi = w;
+        while (depth[ub] > depth[ua]) {
+          right.push_back(pedge[ub]);
+          ub = parent[ub];
+        }
+        while (ua != ub) {
+          require(parent[ua] != ua && parent[ub] != ub, "decycle: the span tree does not connect the ends of an edge");
+          left.push_back(pedge[ua]);
+          ua = parent[ua];
+          right.push_back(pedge[ub]);
+          ub = parent[ub];
+        }
+        left.insert(left.end(), right.rbegin(), right.rend()); // tree edges in path order a -> b
+        if (left.empty()) continue;
+        size_t lo = 0;
+        double wlo = static_cast<double>(g->E[left[0]].weight), whi = wlo;
+        for (size_t i = 1; i < left.size(); ++i) {
+          const double w = static_cast<double>(g->E[left[i]].weight);
+          if (w < wlo) { // std::min_element: the first minimum
+            wlo = w;
+            lo  = i;
+          }
+          if (w > whi) whi = w;
+        }
+        const double base = static_cast<double>(g->E[e].weight);
+        if (wlo < base || (base * BASE_WEIGHT_MULTIPLICATOR >= wlo && wlo < whi * MAX_WEIGHT_MULTIPLICATOR))
+          __atomic_store_n(&dele[left[lo]], uint8_t(1), __ATOMIC_RELAXED); // (several edges may name the same tree edge)
+        __atomic_store_n(&dele[e], uint8_t(1), __ATOMIC_RELAXED);
       }
-      const double base = static_cast<double>(g->E[e].weight);
-      if (wlo < base || (base * BASE_WEIGHT_MULTIPLICATOR >= wlo && wlo < whi * MAX_WEIGHT_MULTIPLICATOR)) dele[left[lo]] = 1;
-      dele[e] = 1;
-    }
+    });
     tick("decycle");
     for (size_t e = 0; e < ne; ++e) // :285-287
       if (dele[e]) {
@@ -1393,12 +1595,30 @@ int msgpu_graph_linearize(msgpu_graph *g) {
   g->err[0] = 0;
   try {
     Tick tick;
+    std::vector<uint8_t> edge_ok(g->n_edges); // one byte per edge (cache resident) instead of its 40-byte record in the BFS
+    parallel_chunks(g->n_edges, [&](unsigned, size_t b, size_t e_end) {
+      for (size_t e = b; e < e_end; ++e) edge_ok[e] = g->E[e].alive && g->E[e].cons != D_NONE;
+    });
     const std::vector<std::vector<uint32_t>> comps = connected_components(
-        g->nv, g->adj, [&](uint32_t v) { return g->V[v].alive != 0; },
-        [&](uint32_t e) { return g->E[e].alive && g->E[e].cons != D_NONE; }, [&](uint32_t v) { return g->V[v].comp; },
-        [&](uint32_t v, uint32_t c) { g->V[v].comp = c; });
+        g->nv, g->adj, [&](uint32_t v) { return g->V[v].alive != 0; }, [&](uint32_t e) { return edge_ok[e] != 0; },
+        [&](uint32_t v) { return g->V[v].comp; }, [&](uint32_t v, uint32_t c) { g->V[v].comp = c; });
     g->stats.n_components = comps.size();
     tick("components");
+    // what getDirectedGraph's walk reads of an edge, next to the arc (two bytes of flags instead of a 40-byte record)
+    std::vector<uint8_t> arc_flags(g->adj.arcs.size());
+    std::atomic<int>     unkept{0};
+    parallel_chunks(arc_flags.size(), [&](unsigned, size_t b, size_t e_end) {
+      bool any = false;
+      for (size_t q = b; q < e_end; ++q) {
+        const msgpu_graph::Edge &E = g->E[g->adj.arcs[q].e];
+        arc_flags[q] = static_cast<uint8_t>((E.alive ? 1 : 0) | (E.first != NIL ? 2 : 0) | (E.cons != D_NONE ? 4 : 0) |
+                                            (E.cons == D_POS ? 8 : 0));
+        any = any || (E.alive && E.first == NIL);
+      }
+      if (any) unkept = 1;
+    });
+    g->every_alive_edge_kept = unkept == 0;
+    tick("arc flags");
     // Components are independent (a component only orients and reads its own vertices and edges): largest first on the
     // worker threads, results appended in component order -- the order a single-threaded reference run assembles them in.
     std::vector<std::vector<msgpu_graph::PathStore>> per(comps.size());
@@ -1412,7 +1632,7 @@ int msgpu_graph_linearize(msgpu_graph *g) {
       for (size_t k = next.fetch_add(1); k < by_size.size(); k = next.fetch_add(1)) {
         const size_t i = by_size[k];
         try {
-          per[i] = component_paths(g, static_cast<uint32_t>(i), comps[i]);
+          per[i] = component_paths(g, static_cast<uint32_t>(i), comps[i], arc_flags);
         } catch (std::bad_alloc const &) { rcs[i] = MSGPU_E_NOMEM; } catch (std::exception const &e) {
           rcs[i]  = MSGPU_E_LAYOUT;
           errs[i] = e.what();

@@ -69,7 +69,13 @@ def flip_strands(t, seed, every=10):
     return t2
 
 
-def test_tiled_cfg2_graph_stage_matches_restatement(oracle):
+@pytest.mark.parametrize("par_min", [None, "512"])
+def test_tiled_cfg2_graph_stage_matches_restatement(oracle, monkeypatch, par_min):
+    """par_min = 512: the loops that go to all host threads on graphs of 65 k items and more (adjacency build, per-edge
+    clean-up loops, decycle, the directed edges of getDirectedGraph) do so here too, with grains that cut this graph."""
+    if par_min:
+        monkeypatch.setenv("MSGPU_GRAPH_PAR_MIN", par_min)
+        monkeypatch.setenv("MSGPU_GRAPH_THREADS", "5")
     rows = synth.synth_rows(**synth.TILED["cfg2"])
     t = oracle.overlap(rows)
     n = len(t["read_len"])
