@@ -78,13 +78,20 @@ struct Tick { // MSGPU_GRAPH_DEBUG=1: phase timings on stderr
 
 // host threads for the loops over all edges / orders of the stage (results never depend on the count): the cores this
 // process may use, at most 16; MSGPU_GRAPH_THREADS overrides
-unsigned stage_threads() {
+// a worker that runs beside other workers (one component each in msgpu_graph_linearize) limits the loops it starts to its
+// share of the threads, so that the stage never runs more threads than it was given (a CPU quota punishes that twice)
+thread_local unsigned tl_thread_share = 0; // 0 = no limit
+unsigned stage_threads_total() {
   if (const char *e = std::getenv("MSGPU_GRAPH_THREADS")) {
     const int v = std::atoi(e);
     if (v > 0) return static_cast<unsigned>(v > 64 ? 64 : v);
   }
   static const unsigned hw = std::thread::hardware_concurrency();
   return hw == 0 ? 1u : hw > 16 ? 16u : hw;
+}
+unsigned stage_threads() {
+  const unsigned n = stage_threads_total();
+  return tl_thread_share && tl_thread_share < n ? tl_thread_share : n;
 }
 // below this many items a loop stays on the calling thread (MSGPU_GRAPH_PAR_MIN overrides: tests run the threaded code on small graphs)
 size_t par_min() {
@@ -122,8 +129,12 @@ template <class F> unsigned parallel_chunks(size_t n, F f) {
 
 // f(begin, end) over [0, n) in pieces of `grain` handed out by a counter: for loops whose cost per index is uneven
 template <class F> void parallel_dynamic(size_t n, size_t grain, F f) {
+  if (std::getenv("MSGPU_GRAPH_STATIC")) { // measurement switch: contiguous ranges instead
+    parallel_chunks(n, [&](unsigned, size_t b, size_t e) { f(b, e); });
+    return;
+  }
   unsigned nt = stage_threads();
-  if (n < 4 * grain || n < par_min()) nt = 1;
+  if (n < 4 * grain) nt = 1;
   if (nt <= 1) {
     f(size_t(0), n);
     return;
@@ -171,6 +182,7 @@ struct Csr { // segment of vertex v: arcs[off[v] .. off[v+1]), ascending `to`
 // their arcs without meeting each other.
 bool build_csr_undirected_parallel(uint32_t n, const uint32_t *from, const uint32_t *to, size_t m, Csr &c) {
   const unsigned nt = stage_threads();
+  if (std::getenv("MSGPU_GRAPH_SERIAL_CSR")) return false; // measurement switch
   if (nt < 2 || m < par_min() || static_cast<size_t>(nt) * 2 * (static_cast<size_t>(n) + 1) > (size_t(1) << 26)) return false;
   const size_t          stride = static_cast<size_t>(n) + 1;
   std::vector<uint32_t> hist(static_cast<size_t>(nt) * 2 * stride); // [thread][hi | lo][vertex]
@@ -585,7 +597,9 @@ DiG get_directed_graph(msgpu_graph &g, uint32_t cid, const std::vector<uint32_t>
     return s == g.E[ue].a;
   };
   // (a vertex popped early meets most of its neighbours unpopped, a late one hardly any: pieces by counter, not by range)
-  parallel_dynamic(np, 2048, [&](size_t b, size_t e) { // pass 1: directed edges and orders per processing vertex
+  // (vertices, each with tens of arcs: pieces of 2048; the tests' small graphs get pieces that still cut them)
+  const size_t grain = par_min() >= (size_t(1) << 16) ? 2048 : std::max<size_t>(16, par_min() / 32);
+  parallel_dynamic(np, grain, [&](size_t b, size_t e) { // pass 1: directed edges and orders per processing vertex
     for (size_t i = b; i < e; ++i) {
       uint64_t ns = 0, no = 0;
       for_edges_of(i, [&](uint32_t ue, uint32_t nb, bool toggle) {
@@ -613,7 +627,7 @@ DiG get_directed_graph(msgpu_graph &g, uint32_t cid, const std::vector<uint32_t>
   dg.weight.resize(m);
   dg.ord_off.assign(m + 1, 0);
   dg.ord.resize(ord_base[np]);
-  parallel_dynamic(np, 2048, [&](size_t b, size_t e) { // pass 2: fill, every vertex into its own stretch
+  parallel_dynamic(np, grain, [&](size_t b, size_t e) { // pass 2: fill, every vertex into its own stretch
     for (size_t i = b; i < e; ++i) {
       uint64_t slot = slot_base[i], op = ord_base[i];
       for_edges_of(i, [&](uint32_t ue, uint32_t nb, bool toggle) {
@@ -1627,16 +1641,23 @@ int msgpu_graph_linearize(msgpu_graph *g) {
     std::vector<size_t>                              by_size(comps.size());
     for (size_t i = 0; i < by_size.size(); ++i) by_size[i] = i;
     std::stable_sort(by_size.begin(), by_size.end(), [&](size_t x, size_t y) { return comps[x].size() > comps[y].size(); });
+    // the workers' own loops (directed edges, adjacency builds) share the stage's threads: a large component gets
+    // threads / (large components running beside it), a small one runs on its worker alone
+    size_t n_large = 0;
+    for (const auto &c : comps) n_large += c.size() >= par_min() / 8;
     std::atomic<size_t> next{0};
     auto                work = [&]() {
       for (size_t k = next.fetch_add(1); k < by_size.size(); k = next.fetch_add(1)) {
         const size_t i = by_size[k];
+        const size_t beside = std::min<size_t>(std::max<size_t>(n_large, 1), std::max<uint32_t>(g->n_threads, 1));
+        tl_thread_share = comps[i].size() >= par_min() / 8 ? std::max<unsigned>(1, static_cast<unsigned>(stage_threads_total() / beside)) : 1;
         try {
           per[i] = component_paths(g, static_cast<uint32_t>(i), comps[i], arc_flags);
         } catch (std::bad_alloc const &) { rcs[i] = MSGPU_E_NOMEM; } catch (std::exception const &e) {
           rcs[i]  = MSGPU_E_LAYOUT;
           errs[i] = e.what();
         }
+        tl_thread_share = 0;
       }
     };
     uint32_t nt = g->n_threads;
