@@ -10,6 +10,8 @@
 // HBM-bound byte work: 16 B per lane, aligned 16-B stores, unaligned source handled with v_alignbyte.
 #include <hip/hip_runtime.h>
 
+#include <thread>
+
 #include <algorithm>
 #include <chrono>
 #include <cstdlib>
@@ -798,15 +800,58 @@ int msgpu_assembly_finish(msgpu_assembly *a, void *hip_stream) {
       t_bytes += msgpu_fasta_text_bytes(static_cast<uint32_t>(h.size()), p.target_len);
     }
     q_off = (t_bytes + 15) & ~15ull;
-    for (const msgpu_path_info &p : a->paths)
-      for (uint32_t q = p.query_begin; q < p.query_end; ++q) {
-        const msgpu_query_info &qi = a->queries[q];
-        const std::string       qh = msgpu::query_header(qi.kind, p.asm_idx, q - p.query_begin);
-        recs.push_back(msgpu_fasta_record{qi.raw_off, q_off + q_bytes, static_cast<uint32_t>(qi.len),
-                                          static_cast<uint32_t>(hdr.size()), static_cast<uint32_t>(qh.size()), 0});
-        hdr += qh;
-        q_bytes += msgpu_fasta_text_bytes(static_cast<uint32_t>(qh.size()), qi.len);
+    // the query records (path order = ascending record number): header texts and text offsets of a deep assembly -- 643 k
+    // records on the tiled workload -- are built in stretches on host threads, then shifted by what precedes each stretch
+    const size_t nq = a->queries.size();
+    unsigned     nt = std::thread::hardware_concurrency();
+    nt              = nt == 0 ? 1 : (nt > 16 ? 16 : nt);
+    if (nq < 50000) nt = 1;
+    struct Part {
+      std::string                     hdr;
+      std::vector<msgpu_fasta_record> recs;
+      uint64_t                        text = 0;
+      bool                            oom  = false;
+    };
+    std::vector<Part> parts(nt);
+    auto              build = [&](unsigned t) {
+      Part &pt = parts[t];
+      try {
+        const size_t b = nq * t / nt, e = nq * (t + 1) / nt;
+        pt.recs.reserve(e - b);
+        for (size_t q = b; q < e; ++q) {
+          const msgpu_query_info &qi = a->queries[q];
+          const msgpu_path_info  &p  = a->paths[qi.path];
+          const std::string       qh = msgpu::query_header(qi.kind, p.asm_idx, static_cast<uint32_t>(q) - p.query_begin);
+          pt.recs.push_back(msgpu_fasta_record{qi.raw_off, pt.text, static_cast<uint32_t>(qi.len),
+                                               static_cast<uint32_t>(pt.hdr.size()), static_cast<uint32_t>(qh.size()), 0});
+          pt.hdr += qh;
+          pt.text += msgpu_fasta_text_bytes(static_cast<uint32_t>(qh.size()), qi.len);
+        }
+      } catch (std::bad_alloc const &) { pt.oom = true; }
+    };
+    {
+      std::vector<std::thread> pool;
+      for (unsigned t = 1; t < nt; ++t) pool.emplace_back(build, t);
+      build(0);
+      for (auto &t : pool) t.join();
+    }
+    for (const Part &pt : parts)
+      if (pt.oom) return MSGPU_E_NOMEM;
+    size_t hdr_total = hdr.size();
+    for (const Part &pt : parts) hdr_total += pt.hdr.size();
+    if (hdr_total > 0xffffffffull) return MSGPU_E_ARG;
+    recs.reserve(recs.size() + nq);
+    hdr.reserve(hdr_total);
+    for (Part &pt : parts) {
+      const uint32_t hbase = static_cast<uint32_t>(hdr.size());
+      for (msgpu_fasta_record r : pt.recs) {
+        r.text_off += q_off + q_bytes;
+        r.header_off += hbase;
+        recs.push_back(r);
       }
+      hdr += pt.hdr;
+      q_bytes += pt.text;
+    }
   } catch (std::bad_alloc const &) { return MSGPU_E_NOMEM; }
   const uint64_t     text_bytes = q_off + q_bytes;
   const bool         dbg        = std::getenv("MSGPU_SEQ_DEBUG") != nullptr;
