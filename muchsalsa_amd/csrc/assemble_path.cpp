@@ -1307,6 +1307,11 @@ int msgpu_assembly_add_paths(msgpu_assembly *a, const msgpu_path_input *in, size
       if (!r.paf.empty()) memcpy(&a->paf[sp.paf], r.paf.data(), r.paf.size());
       r.info.query_end  = static_cast<uint32_t>(qi);
       a->paths[sp.path] = r.info;
+      // give the path's layout back here, on this thread: hundreds of thousands of small vectors freed one after the other
+      // at the end of the call took as long as laying the paths out
+      std::vector<Record>().swap(r.queries);
+      Seg().p.swap(r.target.p);
+      std::string().swap(r.paf);
     });
     a->raw_bytes = raw;
   } catch (std::bad_alloc const &) { return MSGPU_E_NOMEM; } catch (std::system_error const &) {
