@@ -741,6 +741,11 @@ def main():
                          "beside the next step's compute; strong = the ONE job of the workload sharded over the ranks by "
                          "v1 %% N (BASELINE.json configs[3]).  auto = weak, with the strong figure and the rank-sharded "
                          "host-to-host figure reported beside it")
+    ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
+                    help="torch.distributed backend of the N > 1 path: nccl = RCCL over xGMI (what is measured); gloo = a "
+                         "REHEARSAL of the N > 1 control flow on hardware that cannot run N RCCL ranks")
+    ap.add_argument("--single-device", action="store_true",
+                    help="rehearsal: every rank uses GPU 0 (RCCL refuses two ranks on one device: use with --backend gloo)")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the N>1 exchange path (all-gather + merge) even at world size 1 (used by the GPU tests)")
     ap.add_argument("--self-launch", action="store_true",
@@ -769,6 +774,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if args.single_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     # started by a launcher (torchrun sets TORCHELASTIC_RUN_ID) = the distributed path, even with one rank
@@ -777,7 +784,10 @@ def main():
     if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
-        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
         rccl_ranks = dist.get_world_size()  # what RCCL saw, not what the command line asked for
 
     w = WORKLOADS[args.workload]
@@ -1071,7 +1081,10 @@ def main():
             "roofline": roof,
         }
         if multi:
-            out["rccl_ranks"] = rccl_ranks
+            out["rccl_ranks"] = rccl_ranks if args.backend == "nccl" else None
+            if args.backend != "nccl":
+                out["rehearsal"] = "backend %s%s: control flow of the N > 1 path only, NOT a measurement" % (
+                    args.backend, ", every rank on GPU 0" if args.single_device else "")
             out["rank_ms_per_step"] = rank_ms
             out["exchange"] = exchange_info
             if strong_leg is not None:

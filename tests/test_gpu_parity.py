@@ -393,6 +393,34 @@ def test_bench_distributed_path_smoke():
     assert line["scaling"] == "strong" and line["config"]["merged_edge_list_consistent"] is True and "strong" not in line
 
 
+def test_bench_two_and_three_ranks_rehearsal():
+    """The N > 1 control flow of bench.py with REAL ranks: RCCL refuses two ranks on one device, so this runs them over gloo
+    with every rank on GPU 0 (a rehearsal, labelled so in the line; nothing of it is a measurement) -- weak scaling with the
+    communication thread (partitions, id bases in the merge), the strong leg (shards by v1 % N) and the rank-sharded
+    host-to-host leg (1/N of the rows per rank + all-gather of the row table) all complete and agree on the edge counts."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    single = None
+    for n in (2, 3):
+        out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n), "--backend", "gloo",
+                              "--single-device", "--workload", "tiny", "--steps", "2", "--warmup", "1", "--kernels-only"],
+                             env=env, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+        assert line["n_gpus"] == n and line["scaling"] == "weak" and "rehearsal" in line and line["rccl_ranks"] is None
+        assert line["config"]["merged_edge_list_consistent"] is True and line["exchange"]["regrows"] == 0
+        assert len(line["rank_ms_per_step"]["per_rank"]) == n
+        s, h = line["strong"], line["host_to_host_sharded"]
+        assert s["merged_edge_list_consistent"] is True and s["edges"] == h["edges"] > 0
+        single = single or s["edges"]
+        assert s["edges"] == single                      # the ONE job has the same edges however many ranks share it
+        assert line["config"]["edges"] > (n - 1) * single  # n partitions of that shape
+
+
 def test_bench_starts_its_own_ranks():
     """`python bench.py --gpus N` without a launcher must start the rank processes itself (before touching the GPU) and
     relay rank 0's line: exercised with one rank (--self-launch), which is all a one-GPU box can run."""
