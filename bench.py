@@ -147,6 +147,57 @@ def cpu_baseline(workload, budget_reads, cores):
     return out
 
 
+def cpu_consensus_baseline():
+    """The consensus half on the CPU: everything behind the overlap tables -- contraction test, graph clean-up,
+    getDirectedGraph, linearizeGraph, assemblePath incl. the string stitching -- through the oracles (C for the contraction
+    test, the Python restatements oracle/ms_graph_py.py and ms_assemble_py.py for the rest: they are the only CPU statement
+    of those stages that exists here), one core, on the tiled shape at the size of BASELINE.json configs[1]."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import ms_oracle_ctypes as oracle
+    from oracle import ms_graph_py as G
+    from oracle.ms_assemble_py import assemble_path
+    from muchsalsa_amd import synth
+    shape = synth.TILED["cfg2"]
+    rows, read_names, anchor_names = synth.accepted_rows(synth.paf_table(**shape))
+    n_reads, L, seed = shape["n_reads"], shape["read_len"], shape["seed"]
+    Gn, r_start, r_fwd = synth.read_layout(n_reads, L, seed, read_len_min=shape["read_len_min"])
+    r_len = synth.read_lengths(n_reads, L, seed, shape["read_len_min"])
+    a_start, a_len = synth.anchor_layout(n_reads, L, 0, seed, tiled=True)
+    genome = synth.genome_bases(Gn, seed).tobytes()
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    nano, illu = {}, {}
+    for i, nm in enumerate(read_names):
+        o = int(nm[1:])
+        sq = genome[r_start[o]: r_start[o] + r_len[o]]
+        nano[i] = sq if r_fwd[o] else sq.translate(comp)[::-1]
+    for j, nm in enumerate(anchor_names):
+        o = int(nm[1:])
+        illu[j] = genome[a_start[o]: a_start[o] + a_len[o]]
+    t = oracle.overlap(rows)
+    t0 = time.perf_counter()
+    co = oracle.find_contraction_edges(t, len(t["read_len"]))
+    vm = {(int(r["read_id"]), int(r["anchor_id"])): r for r in rows}
+    g, el, oo = G.build_graph(t, t["read_len"], t["read_first_line"])
+    contain = G.clean_up(g, el, oo, co, lambda r, a: (r, a) in vm)
+    edges, ems = t["edges"], t["ems"]
+    eidx = {(int(e["v1"]), int(e["v2"])): i for i, e in enumerate(edges)}
+
+    def em_of(a, b):
+        e = edges[eidx[(a, b)]]
+        return {int(m["anchor_id"]): (int(m["ov_lo"]), int(m["ov_hi"]))
+                for m in ems[int(e["em_off"]): int(e["em_off"]) + int(e["em_cnt"])]}
+    oc = {v: [dict(nano=c["nano"], dir=c["direction"], matches={a: vm[(c["nano"], a)] for a in c["anchors"]})
+              for c in lst] for v, lst in contain.items()}
+    res = [assemble_path(p, st, vm, oc, nano, illu, k) for k, (p, st) in enumerate(G.assemble_all(g, em_of))]
+    dt = time.perf_counter() - t0
+    T = sum(len(r["target"]) for r in res)
+    return {"value": T / dt / 1e6, "unit": "consensus-Mbases/s", "cores": 1,
+            "kind": "port (Python restatements of src/main.cpp:194-310, dg.cpp, lg.cpp, ap.cpp; C for findContractionEdges)",
+            "sample": "tiled shape at configs[1] size (%d reads, %d unitigs, %d edges): %d contigs, %d bases in %.2f s; "
+                      "the reference itself, measured by the survey on a 1 Mb genome: 0.23 consensus-Mbases/s (SURVEY.md "
+                      "section 6)" % (n_reads, len(anchor_names), len(edges), len(res), T, dt)}
+
+
 # ---- the legs reported beside the metric ---------------------------------------------------------------------------------
 
 def host_to_host_leg(ctx, rows, n_batches, reps=6):
@@ -1133,6 +1184,10 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_sample_reads, cores)
             except Exception as exc:  # noqa: BLE001
                 out["cpu_baseline"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+            try:
+                out["cpu_baseline"]["consensus"] = cpu_consensus_baseline()
+            except Exception as exc:  # noqa: BLE001
+                out["cpu_baseline"]["consensus"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     ctx.close()
     if multi:

@@ -1375,16 +1375,21 @@ static int graph_create(const msgpu_edge *edges, uint64_t n_edges, const msgpu_e
       if (a != b) return MSGPU_E_ARG;
     }
     {
-      std::vector<uint32_t> ea(n_edges), eb(n_edges);
-      for (uint64_t i = 0; i < n_edges; ++i) {
-        ea[i] = edges[i].v1;
-        eb[i] = edges[i].v2;
-      }
-      g->adj = build_csr(n_reads, ea.data(), eb.data(), n_edges, true);
+      std::unique_ptr<uint32_t[]> ea(new uint32_t[n_edges ? n_edges : 1]), eb(new uint32_t[n_edges ? n_edges : 1]); // (not zero-filled)
+      parallel_chunks(n_edges, [&](unsigned, size_t b, size_t e_end) {
+        for (size_t i = b; i < e_end; ++i) {
+          ea[i] = edges[i].v1;
+          eb[i] = edges[i].v2;
+        }
+      });
+      g->adj = build_csr(n_reads, ea.get(), eb.get(), n_edges, true);
     }
-    for (uint32_t v = 0; v < n_reads; ++v) // duplicate edge
-      for (uint32_t q = g->adj.off[v]; q + 1 < g->adj.off[v + 1]; ++q)
-        if (g->adj.arcs[q].to == g->adj.arcs[q + 1].to) return MSGPU_E_ARG;
+    parallel_chunks(n_reads, [&](unsigned, size_t b, size_t e_end) { // duplicate edge
+      for (size_t v = b; v < e_end; ++v)
+        for (uint32_t q = g->adj.off[v]; q + 1 < g->adj.off[v + 1]; ++q)
+          if (g->adj.arcs[q].to == g->adj.arcs[q + 1].to) bad = 1;
+    });
+    if (bad) return MSGPU_E_ARG;
     g->stats.n_vertices_in = n_reads;
     g->stats.n_edges_in    = n_edges;
     tick("graph create");
