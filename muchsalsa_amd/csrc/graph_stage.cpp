@@ -46,6 +46,7 @@
 #include <stdexcept>
 #include <string>
 #include <thread>
+#include <type_traits>
 #include <vector>
 
 #include "msgpu.h"
@@ -183,7 +184,7 @@ struct Csr { // segment of vertex v: arcs[off[v] .. off[v+1]), ascending `to`
 bool build_csr_undirected_parallel(uint32_t n, const uint32_t *from, const uint32_t *to, size_t m, Csr &c) {
   const unsigned nt = stage_threads();
   if (std::getenv("MSGPU_GRAPH_SERIAL_CSR")) return false; // measurement switch
-  if (nt < 2 || m < par_min() || static_cast<size_t>(nt) * 2 * (static_cast<size_t>(n) + 1) > (size_t(1) << 26)) return false;
+  if (nt < 2 || m < par_min() || m < 2 * static_cast<size_t>(n) || static_cast<size_t>(nt) * 2 * (static_cast<size_t>(n) + 1) > (size_t(1) << 26)) return false;
   const size_t          stride = static_cast<size_t>(n) + 1;
   std::vector<uint32_t> hist(static_cast<size_t>(nt) * 2 * stride); // [thread][hi | lo][vertex]
   auto chunk = [&](unsigned t) { return std::make_pair(m * t / nt, m * (t + 1) / nt); };
@@ -377,7 +378,7 @@ std::vector<uint32_t> shortest_path(const Csr &adj, const uint8_t *arc_ok_by_edg
 
 // getConnectedComponents (cc.cpp:33-70): breadth-first over the edges that carry a consensus direction; vertices in
 // ascending id, neighbours ascending id.  v_ok(v): vertex in the graph; e_ok(e): edge in the graph and with a consensus
-// direction; set_comp(v, c) / get_comp(v): component number (NIL at the start).
+// direction, asked per arc (const Arc *); set_comp(v, c) / get_comp(v): component number (NIL at the start).
 template <class VOk, class EOk, class GetComp, class SetComp>
 std::vector<std::vector<uint32_t>> connected_components(uint32_t nv, const Csr &adj, VOk v_ok, EOk e_ok, GetComp get_comp,
                                                         SetComp set_comp) {
@@ -390,7 +391,7 @@ std::vector<std::vector<uint32_t>> connected_components(uint32_t nv, const Csr &
     for (size_t h = 0; h < members.size(); ++h) {
       const uint32_t cur = members[h];
       for (const Arc *t = adj.begin(cur); t != adj.end(cur); ++t)
-        if (get_comp(t->to) == NIL && e_ok(t->e)) {
+        if (get_comp(t->to) == NIL && e_ok(t)) {
           set_comp(t->to, cid);
           members.push_back(t->to);
         }
@@ -424,6 +425,29 @@ std::vector<uint32_t> sort_topologically(uint32_t n, const Csr &succ, const Csr 
 }
 
 } // namespace
+
+// An array whose elements are constructed by whoever fills it (on the threads that fill it): a std::vector would
+// construct -- and page in -- tens of megabytes on the calling thread first.
+template <class T> struct RawArray {
+  T     *p = nullptr;
+  size_t n = 0;
+  RawArray() = default;
+  RawArray(const RawArray &) = delete;
+  RawArray &operator=(const RawArray &) = delete;
+  ~RawArray() { std::free(p); } // (T is trivially destructible)
+  void allocate(size_t k) {
+    static_assert(std::is_trivially_destructible<T>::value, "RawArray elements are never destroyed");
+    std::free(p);
+    p = static_cast<T *>(std::malloc((k ? k : 1) * sizeof(T)));
+    if (!p) throw std::bad_alloc();
+    n = k;
+  }
+  T       &operator[](size_t i) { return p[i]; }
+  const T &operator[](size_t i) const { return p[i]; }
+  size_t   size() const { return n; }
+  T       *begin() { return p; }
+  T       *end() { return p + n; }
+};
 
 struct msgpu_graph {
   // tables: the caller's (msgpu_graph_create_borrowed: valid until msgpu_graph_free) or copies held in own_* (msgpu_graph_create)
@@ -461,12 +485,12 @@ struct msgpu_graph {
     uint8_t  alive = 1, shadow = 0;
   };
   std::vector<Vertex>  V;
-  std::vector<Edge>    E;
+  RawArray<Edge>       E; // (constructed in graph_create's parallel fill)
   std::vector<uint8_t> o_kept;  // per order: still on its edge (findDeletableEdges drops the contained ones)
   struct OLite { // what the walks over the graph read of an EdgeOrder (16 of its 64 bytes: the random accesses of
     uint32_t start, end, base, flags; // getDirectedGraph stay inside a quarter of the cache footprint)
   };
-  std::vector<OLite> ol;
+  RawArray<OLite> ol;
   Csr                  adj;
   struct Contain {
     uint32_t nano, direction;
@@ -1324,9 +1348,11 @@ static int graph_create(const msgpu_edge *edges, uint64_t n_edges, const msgpu_e
       g->V[v].len   = read_len[v];
       g->V[v].meta0 = read_first_line[v];
     }
-    g->E.resize(n_edges);
+    tick("  create: copies + vertices");
+    g->E.allocate(n_edges);
     g->o_kept.assign(n_orders, 0);
-    g->ol.resize(n_orders);
+    g->ol.allocate(n_orders);
+    tick("  create: table allocation");
     std::atomic<int> bad{0};
     parallel_chunks(n_edges, [&](unsigned, size_t b, size_t e_end) {
       for (size_t i = b; i < e_end; ++i) {
@@ -1336,7 +1362,7 @@ static int graph_create(const msgpu_edge *edges, uint64_t n_edges, const msgpu_e
           bad = 1;
           return;
         }
-        msgpu_graph::Edge &u = g->E[i];
+        msgpu_graph::Edge &u = *new (&g->E[i]) msgpu_graph::Edge();
         u.a       = e.v1;
         u.b       = e.v2;
         u.shadow  = e.shadow != 0;
@@ -1374,6 +1400,7 @@ static int graph_create(const msgpu_edge *edges, uint64_t n_edges, const msgpu_e
       for (uint64_t x : kept) b += x;
       if (a != b) return MSGPU_E_ARG;
     }
+    tick("  create: edge + order records");
     {
       std::unique_ptr<uint32_t[]> ea(new uint32_t[n_edges ? n_edges : 1]), eb(new uint32_t[n_edges ? n_edges : 1]); // (not zero-filled)
       parallel_chunks(n_edges, [&](unsigned, size_t b, size_t e_end) {
@@ -1384,6 +1411,7 @@ static int graph_create(const msgpu_edge *edges, uint64_t n_edges, const msgpu_e
       });
       g->adj = build_csr(n_reads, ea.get(), eb.get(), n_edges, true);
     }
+    tick("  create: adjacency");
     parallel_chunks(n_reads, [&](unsigned, size_t b, size_t e_end) { // duplicate edge
       for (size_t v = b; v < e_end; ++v)
         for (uint32_t q = g->adj.off[v]; q + 1 < g->adj.off[v + 1]; ++q)
@@ -1512,6 +1540,16 @@ int msgpu_graph_clean_up(msgpu_graph *g, const int64_t *contraction_order, const
     std::vector<uint32_t> parent(nv, NIL), pedge(nv, NIL), depth(nv, 0);
     std::vector<uint8_t>  negpar(nv, 0);
     {
+      // (over an adjacency of the tree edges alone -- one edge in ten here --, not over every arc of the graph; how the
+      // forest is rooted does not matter to decycle: the tree path between two vertices is the same under any root)
+      std::vector<uint32_t> te, ta, tb;
+      for (uint32_t e : cand)
+        if (in_tree[e]) {
+          te.push_back(e);
+          ta.push_back(g->E[e].a);
+          tb.push_back(g->E[e].b);
+        }
+      const Csr             tree = build_csr(nv, ta.data(), tb.data(), te.size(), true);
       std::vector<uint32_t> queue;
       for (uint32_t r = 0; r < nv; ++r) {
         if (parent[r] != NIL) continue;
@@ -1519,17 +1557,19 @@ int msgpu_graph_clean_up(msgpu_graph *g, const int64_t *contraction_order, const
         queue.assign(1, r);
         for (size_t h = 0; h < queue.size(); ++h) {
           const uint32_t v = queue[h];
-          for (const Arc *t = g->adj.begin(v); t != g->adj.end(v); ++t)
-            if (in_tree[t->e] && parent[t->to] == NIL) {
-              parent[t->to] = v;
-              pedge[t->to]  = t->e;
-              depth[t->to]  = depth[v] + 1;
-              negpar[t->to] = negpar[v] ^ (g->E[t->e].cons == D_NEG);
+          for (const Arc *t = tree.begin(v); t != tree.end(v); ++t)
+            if (parent[t->to] == NIL) {
+              const uint32_t e = te[t->e];
+              parent[t->to]    = v;
+              pedge[t->to]     = e;
+              depth[t->to]     = depth[v] + 1;
+              negpar[t->to]    = negpar[v] ^ (g->E[e].cons == D_NEG);
               queue.push_back(t->to);
             }
         }
       }
     }
+    tick("span forest rooted");
     std::vector<uint8_t> dele(ne, 0);
     // decycle, :575-618: every non-tree edge is judged against the finished span forest on its own (dele is only ever set
     // to 1), so the candidates are cut over the host threads
@@ -1614,16 +1654,7 @@ int msgpu_graph_linearize(msgpu_graph *g) {
   g->err[0] = 0;
   try {
     Tick tick;
-    std::vector<uint8_t> edge_ok(g->n_edges); // one byte per edge (cache resident) instead of its 40-byte record in the BFS
-    parallel_chunks(g->n_edges, [&](unsigned, size_t b, size_t e_end) {
-      for (size_t e = b; e < e_end; ++e) edge_ok[e] = g->E[e].alive && g->E[e].cons != D_NONE;
-    });
-    const std::vector<std::vector<uint32_t>> comps = connected_components(
-        g->nv, g->adj, [&](uint32_t v) { return g->V[v].alive != 0; }, [&](uint32_t e) { return edge_ok[e] != 0; },
-        [&](uint32_t v) { return g->V[v].comp; }, [&](uint32_t v, uint32_t c) { g->V[v].comp = c; });
-    g->stats.n_components = comps.size();
-    tick("components");
-    // what getDirectedGraph's walk reads of an edge, next to the arc (two bytes of flags instead of a 40-byte record)
+    // what the walks read of an edge, next to the arc (a byte of flags instead of a 40-byte record, and no random access)
     std::vector<uint8_t> arc_flags(g->adj.arcs.size());
     std::atomic<int>     unkept{0};
     parallel_chunks(arc_flags.size(), [&](unsigned, size_t b, size_t e_end) {
@@ -1638,6 +1669,13 @@ int msgpu_graph_linearize(msgpu_graph *g) {
     });
     g->every_alive_edge_kept = unkept == 0;
     tick("arc flags");
+    const Arc *const arcs0 = g->adj.arcs.data();
+    const std::vector<std::vector<uint32_t>> comps = connected_components(
+        g->nv, g->adj, [&](uint32_t v) { return g->V[v].alive != 0; },
+        [&](const Arc *t) { return (arc_flags[t - arcs0] & 5) == 5; }, // alive and with a consensus direction
+        [&](uint32_t v) { return g->V[v].comp; }, [&](uint32_t v, uint32_t c) { g->V[v].comp = c; });
+    g->stats.n_components = comps.size();
+    tick("components");
     // Components are independent (a component only orients and reads its own vertices and edges): largest first on the
     // worker threads, results appended in component order -- the order a single-threaded reference run assembles them in.
     std::vector<std::vector<msgpu_graph::PathStore>> per(comps.size());
@@ -1648,14 +1686,17 @@ int msgpu_graph_linearize(msgpu_graph *g) {
     std::stable_sort(by_size.begin(), by_size.end(), [&](size_t x, size_t y) { return comps[x].size() > comps[y].size(); });
     // the workers' own loops (directed edges, adjacency builds) share the stage's threads: a large component gets
     // threads / (large components running beside it), a small one runs on its worker alone
-    size_t n_large = 0;
-    for (const auto &c : comps) n_large += c.size() >= par_min() / 8;
+    size_t large_vertices = 0;
+    for (const auto &c : comps)
+      if (c.size() >= par_min() / 8) large_vertices += c.size();
     std::atomic<size_t> next{0};
     auto                work = [&]() {
       for (size_t k = next.fetch_add(1); k < by_size.size(); k = next.fetch_add(1)) {
         const size_t i = by_size[k];
-        const size_t beside = std::min<size_t>(std::max<size_t>(n_large, 1), std::max<uint32_t>(g->n_threads, 1));
-        tl_thread_share = comps[i].size() >= par_min() / 8 ? std::max<unsigned>(1, static_cast<unsigned>(stage_threads_total() / beside)) : 1;
+        // (its share of the vertices of the large components, at least one thread)
+        tl_thread_share = comps[i].size() >= par_min() / 8 && large_vertices
+                              ? std::max<unsigned>(1, static_cast<unsigned>(stage_threads_total() * comps[i].size() / large_vertices))
+                              : 1;
         try {
           per[i] = component_paths(g, static_cast<uint32_t>(i), comps[i], arc_flags);
         } catch (std::bad_alloc const &) { rcs[i] = MSGPU_E_NOMEM; } catch (std::exception const &e) {
@@ -1810,7 +1851,7 @@ int msgpu_graph_connected_components(uint32_t n_vertices, const uint32_t *a, con
     const Csr           adj = build_csr(n_vertices, a, b, n_edges, true);
     std::vector<uint32_t> comp(n_vertices, NIL);
     const auto            comps = connected_components(
-        n_vertices, adj, [](uint32_t) { return true; }, [&](uint32_t e) { return consensus[e] != 2; },
+        n_vertices, adj, [](uint32_t) { return true; }, [&](const Arc *t) { return consensus[t->e] != 2; },
         [&](uint32_t v) { return comp[v]; }, [&](uint32_t v, uint32_t c) { comp[v] = c; });
     std::copy(comp.begin(), comp.end(), component);
     *n_components = static_cast<uint32_t>(comps.size());
