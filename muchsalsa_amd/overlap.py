@@ -36,12 +36,29 @@ class Paf:
     copy): page-locked when a GPU is present, so msgpu_load_rows / msgpu_overlap_batched take it at link speed.  The
     view (and every slice of it) keeps the loader's memory alive."""
 
-    def __init__(self, rows, n_lines, read_names, anchor_names, handle=None):
+    def __init__(self, rows, n_lines, read_names, anchor_names, handle=None, n_reads=None, n_anchors=None):
         self.rows = rows
         self.n_lines = n_lines
-        self.read_names = read_names
-        self.anchor_names = anchor_names
+        self._read_names, self._anchor_names = read_names, anchor_names
         self._handle = handle
+        self.n_reads = len(read_names) if n_reads is None else n_reads        # Registry sizes
+        self.n_anchors = len(anchor_names) if n_anchors is None else n_anchors
+
+    # the Registry's reverse look-ups as Python lists: built on first use (600 k ctypes calls on BASELINE configs[2] --
+    # a quarter second the pipeline never needs: it maps sequence names to ids natively, msgpu_paf_register_sequences)
+    @property
+    def read_names(self):
+        if self._read_names is None:
+            L, h = _lib.lib(), self._handle._h
+            self._read_names = [L.msgpu_paf_read_name(h, i).decode() for i in range(self.n_reads)]
+        return self._read_names
+
+    @property
+    def anchor_names(self):
+        if self._anchor_names is None:
+            L, h = _lib.lib(), self._handle._h
+            self._anchor_names = [L.msgpu_paf_anchor_name(h, i).decode() for i in range(self.n_anchors)]
+        return self._anchor_names
 
     def register_sequences(self, kind, seqfile):
         """msgpu_paf_register_sequences: Registry::operator[] for every record of a SeqFile on this PAF's registries
@@ -80,9 +97,7 @@ def parse_paf(path, params=None):
         rows = np.frombuffer(buf, dtype=ROW_DTYPE, count=n.value)
     else:
         rows = np.zeros(0, dtype=ROW_DTYPE)
-    rn = [L.msgpu_paf_read_name(h, i).decode() for i in range(L.msgpu_paf_read_count(h))]
-    an = [L.msgpu_paf_anchor_name(h, i).decode() for i in range(L.msgpu_paf_anchor_count(h))]
-    return Paf(rows, L.msgpu_paf_line_count(h), rn, an, owner)
+    return Paf(rows, L.msgpu_paf_line_count(h), None, None, owner, L.msgpu_paf_read_count(h), L.msgpu_paf_anchor_count(h))
 
 
 class PinnedRows:

@@ -56,7 +56,7 @@ def run(contigs_paf, unitigs_path, nanopore_path, out_dir, threads=None, wiggle_
 
     t0 = time.perf_counter()
     ctx = overlap.OverlapContext(device=device, params=params)
-    ctx.set_id_space(len(paf.read_names), len(paf.anchor_names))
+    ctx.set_id_space(paf.n_reads, paf.n_anchors)
     # the ThreadPool replacement (msgpu_overlap_batched_ex): rows -> HBM once, windows of owner reads on two streams, the
     # edge / order / id tables arrive in pinned host memory while later windows compute.  The EdgeMatch table (5/6 of the
     # bytes) stays in HBM: the graph stage never reads it, assemblePath only the path edges' (fetched below).
