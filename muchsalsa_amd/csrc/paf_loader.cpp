@@ -256,7 +256,7 @@ int msgpu_parse_paf(const char *path, const msgpu_params *params, msgpu_paf **ou
     // line order -- the ids are those of the single-thread reference.
     unsigned nthr = std::thread::hardware_concurrency();
     if (nthr == 0) nthr = 1;
-    if (nthr > 32) nthr = 32;
+    if (nthr > 16) nthr = 16;
     if (const char *e = getenv("MSGPU_PARSE_THREADS")) nthr = static_cast<unsigned>(std::max(1, atoi(e)));
     while (nthr > 1 && len / nthr < (1u << 20)) --nthr; // at least 1 MiB per thread
     std::vector<Chunk> chunks(nthr);

@@ -178,7 +178,7 @@ int msgpu_seq_parse(const char *path, int is_fastq, msgpu_seqfile **out) {
     // line may begin with '@', and which '@' lines are descriptions depends on everything before them): checked for
     // every chunk, and any mismatch sends the whole file through one sequential pass.
     unsigned nt = std::thread::hardware_concurrency();
-    nt          = nt == 0 ? 1 : (nt > 16 ? 16 : nt);
+    nt          = nt == 0 ? 1 : (nt > 8 ? 8 : nt); // (two files are parsed side by side, beside the PAF parser)
     if (const char *e = std::getenv("MSGPU_SEQ_THREADS")) nt = static_cast<unsigned>(std::max(1, std::atoi(e))); // (tests: any size)
     else if (len < (size_t(32) << 20)) nt = 1;
     std::vector<size_t> starts{0};
