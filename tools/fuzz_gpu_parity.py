@@ -28,7 +28,10 @@ def main():
         n_anchors = int(rng.integers(max(20, n_reads // 4), n_reads * 6))
         if case % 5 == 4:  # scaffolds far longer than the context pass 1 sorts them in (generic scaffold build)
             cov, n_anchors = int(rng.choice([150, 300])), int(rng.integers(10, 60))
-        rows, _, _ = synth.accepted_rows(synth.paf_table(n_reads, read_len, n_anchors, seed0 + case, coverage=cov))
+        shape = {}
+        if case % 3 == 2:  # the tiled / mixed-length shape: contained orders, contraction edges, the all-compatible shortcut
+            shape = dict(tiled=bool(rng.integers(0, 2)), read_len_min=int(read_len // rng.integers(2, 6)))
+        rows, _, _ = synth.accepted_rows(synth.paf_table(n_reads, read_len, n_anchors, seed0 + case, coverage=cov, **shape))
         rows = rows.copy()
         mode = case % 4
         if mode >= 1:  # random strands / primary flags
@@ -49,6 +52,20 @@ def main():
             nb = int(rng.integers(1, 12))
             got, _ = ctx.overlap_batched(feed, nb)
             assert_tables_equal(got, want, what + ", %d windows" % nb)
+            # ... with the job's tables resident and the EdgeMatch table left in HBM (what pipeline.run calls): host tables,
+            # the context's own tables, findContractionEdges on them, EdgeMatches of random edges on demand
+            nb2 = int(rng.integers(0, 9))
+            lean, info = ctx.overlap_batched(feed, nb2, resident=True, edgematches=False)
+            assert lean["ems"] is None and info["n_ems"] == len(want["ems"])
+            assert_tables_equal(dict(lean, ems=ctx.tables()["ems"]), want, what + ", resident, %d windows" % nb2)
+            n_r = len(want["read_len"])
+            assert np.array_equal(ctx.find_contraction_edges(), oracle.find_contraction_edges(want, n_r)), what
+            if len(want["edges"]):
+                idx = rng.integers(0, len(want["edges"]), 40).astype("<u4")
+                off, ems = ctx.get_edgematches(idx)
+                e = want["edges"][idx]
+                exp = np.concatenate([want["ems"][int(o): int(o) + int(c)] for o, c in zip(e["em_off"], e["em_cnt"])])
+                assert ems.tobytes() == exp.tobytes() and int(off[-1]) == len(exp), what
         scaf = np.bincount(rows["anchor_id"]).max() if len(rows) else 0
         n = want["edges"]["em_cnt"]
         print("case %3d ok: %6d rows %6d edges, EdgeMatches per edge max %3d, orders %6d, longest scaffold %d" % (
