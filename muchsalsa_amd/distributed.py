@@ -241,6 +241,7 @@ class PipelinedExchange:
         self.results = [None, None]  # per slot: (all_counts, offs, slab_bytes) of the last merged batch
         self._error = None
         self._thread = None
+        self._world = None
         if self.threaded:
             import queue
             import threading
@@ -266,6 +267,8 @@ class PipelinedExchange:
     def _buffers(self, slot, world):
         """the slot's slab / gathered / header tensors for the current capacity (persistent: no allocation per batch)"""
         import torch
+        if slot.get("layout_cap") == self.cap and slot.get("world") == world and "slab_bytes" in slot:
+            return slot["layout"]  # (the per-batch path: nothing to compute, nothing to allocate)
         offs, slab_bytes = self._layout()
         if slot.get("slab_bytes") != slab_bytes or slot.get("world") != world:
             slot["slab"] = torch.empty(slab_bytes, dtype=torch.uint8, device=self.device)
@@ -275,6 +278,7 @@ class PipelinedExchange:
             slot["hdr"] = torch.empty(3, dtype=torch.int64, pin_memory=self.cuda)  # (pinned: the header copy never blocks)
             slot["slab_bytes"], slot["world"] = slab_bytes, world
         self.slab_bytes = slab_bytes
+        slot["layout_cap"], slot["layout"] = self.cap, (offs, slab_bytes)
         return offs, slab_bytes
 
     def _gather(self, slot, world):
@@ -284,6 +288,8 @@ class PipelinedExchange:
         import torch.distributed as dist
 
         def run():
+            slot["hdr"].copy_(torch.tensor(slot["counts"], dtype=torch.int64))
+            slot["slab"][:24].view(torch.int64).copy_(slot["hdr"], non_blocking=True)
             dist.all_gather_into_tensor(slot["gathered"], slot["slab"], group=self.group)  # the one collective
             slot["heads_dev"].copy_(slot["gathered"].view(world, slot["slab_bytes"])[:, :24].contiguous().view(torch.int64).view(-1))
             slot["heads"].copy_(slot["heads_dev"], non_blocking=True)
@@ -291,7 +297,8 @@ class PipelinedExchange:
             with torch.cuda.stream(self.comm):
                 self.comm.wait_event(slot["filled"])
                 run()
-                slot["done"] = torch.cuda.Event()
+                if "done" not in slot:
+                    slot["done"] = torch.cuda.Event()
                 slot["done"].record(self.comm)
         else:
             run()
@@ -300,7 +307,8 @@ class PipelinedExchange:
     def _mark_filled(self, slot):
         import torch
         if self.cuda:
-            slot["filled"] = torch.cuda.Event()
+            if "filled" not in slot:
+                slot["filled"] = torch.cuda.Event()
             slot["filled"].record(torch.cuda.current_stream(self.device))
 
     # ---- the three calls -----------------------------------------------------------------------------------------
@@ -309,7 +317,9 @@ class PipelinedExchange:
         byte offsets offs (enqueued on the caller's current stream)."""
         import torch
         import torch.distributed as dist
-        world = dist.get_world_size(self.group)
+        if self._world is None:
+            self._world = dist.get_world_size(self.group)
+        world = self._world
         self._raise()
         if self.cap is None:
             self._agree(counts)
@@ -321,8 +331,8 @@ class PipelinedExchange:
         if self.cuda and slot.get("merged") is not None:
             torch.cuda.current_stream(self.device).wait_event(slot["merged"])  # the slab's last reader: two batches ago
         counts = tuple(int(c) for c in counts)
-        slot["hdr"].copy_(torch.tensor(counts, dtype=torch.int64))
-        slot["slab"][:24].view(torch.int64).copy_(slot["hdr"], non_blocking=True)
+        # (the header is written behind the fill, on the communication stream, by whoever issues the all-gather: the thread
+        # that drives the compute stream does nothing here but enqueue the fill and one event)
         slot["counts"], slot["offs"], slot["stash"], slot["cap"] = counts, offs, None, self.cap
         if all(c <= k for c, k in zip(counts, self.cap)):
             fill_slab(slot["slab"], offs)
@@ -379,8 +389,6 @@ class PipelinedExchange:
         counts = slot["counts"]
         slot.pop("slab_bytes", None)
         offs, _ = self._buffers(slot, world)
-        slot["hdr"].copy_(torch.tensor(counts, dtype=torch.int64))
-        slot["slab"][:24].view(torch.int64).copy_(slot["hdr"], non_blocking=True)
         for n, rec, so, do in zip(counts, (EDGE_DTYPE.itemsize, ORDER_DTYPE.itemsize, 4), s_offs, offs):
             slot["slab"][do: do + n * rec].copy_(src[so: so + n * rec])
         slot["offs"], slot["stash"], slot["cap"] = offs, None, self.cap
@@ -409,7 +417,8 @@ class PipelinedExchange:
         if self.cuda:
             with torch.cuda.stream(self.comm):
                 self.merge(slot["gathered"], heads, slot["offs"], slot["slab_bytes"], k, self.comm)
-                slot["merged"] = torch.cuda.Event()
+                if slot.get("merged") is None:
+                    slot["merged"] = torch.cuda.Event()
                 slot["merged"].record(self.comm)
         else:
             self.merge(slot["gathered"], heads, slot["offs"], slot["slab_bytes"], k, None)
