@@ -595,14 +595,15 @@ def n50(lengths):
     return int(ls[np.searchsorted(np.cumsum(ls), ls.sum() / 2.0)])
 
 
-def tiled_leg(torch, dev, args, workload, threads):
+def tiled_leg(torch, dev, args, workload, threads, seed_offset=0):
     """NOT a BASELINE configuration: the same number of reads on the shape the graph stage and assemblePath exist for --
     unitigs that TILE the genome (no two anchors overlap, synth.TILED) and reads of mixed length (short ones contained in
     long ones).  Every stage of the flow produces a number on it: the overlap step (with the all-pairs-compatible
     shortcut), findContractionEdges hits, the graph stage, the paths, assemblePath, contig N50 against the genome."""
     from muchsalsa_amd import overlap, synth
     from muchsalsa_amd.graph import GraphStage
-    shape = synth.TILED[workload]
+    shape = dict(synth.TILED[workload])
+    shape["seed"] += seed_offset  # (N > 1: rank r runs partition r)
     rows, read_names, anchor_names = synth.accepted_rows(synth.paf_table(**shape))
     d_rows = torch.from_numpy(rows.view(np.uint8).copy()).to(dev)
     ctx = overlap.OverlapContext(device=dev.index)
@@ -1076,6 +1077,31 @@ def main():
         tt = torch.tensor([cons["ms"]], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         cons["ms"] = float(tt.item())
+    cons_weak = None
+    if multi and not args.kernels_only and args.workload in synth.TILED:
+        # the consensus half at N GPUs: partitions are independent (no collective on the path) -- every rank runs the flow
+        # behind the overlap tables (contraction test, graph stage, path EdgeMatches, assemblePath) on its own partition of
+        # the tiled shape; bases of all ranks / the slowest rank's time
+        try:
+            ctx.close()
+            host_threads = max(1, min(16, (len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)) // max(1, world)))
+            tl = tiled_leg(torch, dev, args, args.workload, host_threads, seed_offset=rank)
+            mine = torch.tensor([tl["system_ms"], float(tl["assemble_path"]["target_bases"]), tl["overlap_ms_per_step"],
+                                 float(tl["edges"])], dtype=torch.float64, device=dev)
+        except Exception as exc:  # noqa: BLE001
+            errors["consensus_weak"] = "%s: %s" % (type(exc).__name__, exc)
+            mine = torch.tensor([float("nan")] * 4, dtype=torch.float64, device=dev)
+        allm = torch.empty(world * 4, dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(allm, mine)
+        allm = allm.cpu().numpy().reshape(world, 4)
+        if not np.isnan(allm).any():
+            cons_weak = {"scaling": "weak", "system_consensus_mbases_per_s": float(allm[:, 1].sum() / (allm[:, 0].max() * 1e-3) / 1e6),
+                         "system_ms_per_rank": [round(float(x), 2) for x in allm[:, 0]], "contig_bases": int(allm[:, 1].sum()),
+                         "overlap_pairs_per_s": float(allm[:, 3].sum() / (allm[:, 2].max() * 1e-3)),
+                         "host_threads_per_rank": host_threads,
+                         "stage": "every rank: findContractionEdges + host graph stage + path EdgeMatches + assemblePath on its own "
+                                  "partition of the tiled shape (synth.TILED, seed + rank; NOT a BASELINE configuration); no "
+                                  "collective on the path; contig bases of all ranks / the slowest rank's time"}
     tiled = e2e = None
     if world == 1 and rank == 0 and not args.kernels_only:
         host_threads = max(1, min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)))
@@ -1150,6 +1176,8 @@ def main():
                 out["strong"] = strong_leg
             if sharded_h2h is not None:
                 out["host_to_host_sharded"] = sharded_h2h
+            if cons_weak is not None:
+                out["consensus_system"] = cons_weak
         if h2h is not None:
             out["host_to_host"] = h2h
         if cons is not None:
