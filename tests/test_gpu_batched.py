@@ -113,6 +113,7 @@ def test_resident_run_leaves_the_job_tables_in_hbm(oracle):
             assert_tables_equal(ctx.tables(), want, "resident, %d windows: the context's own tables" % b)
             c = ctx.counts()
             assert (c.n_edges, c.n_ems, c.n_orders, c.n_ids) == tuple(len(want[k]) for k in ("edges", "ems", "orders", "ids"))
+            assert c.n_lost_publications == 0  # every size read-back arrived through the mapped-memory publication
             assert np.array_equal(ctx.find_contraction_edges(), want_co)
             with pytest.raises(overlap.MsgpuError) as e:  # no per-edge scratch of the whole job: chaining needs its stage
                 ctx.chaining_and_overlaps()

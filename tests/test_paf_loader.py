@@ -93,3 +93,28 @@ def test_crlf_and_leading_space_numbers(tmp_path):
     # std::stoi skips leading whitespace and stops at the first non-digit ('\r' stays in the last column)
     p = overlap.parse_paf(_write(tmp_path, [_line(qs=" 7", nm="550\r", extra=""), SENTINEL]))
     assert len(p.rows) == 1 and int(p.rows[0]["i_lo"]) == 7 and int(p.rows[0]["score"]) == 550
+
+
+def test_register_sequences_follows_the_registry(tmp_path):
+    """msgpu_paf_register_sequences = Registry::operator[] per record of a sequence file on the PAF's own registries
+    (SequenceAccessor.cpp:171,215): names the PAF registered keep their id, unknown names take the next free ids in file
+    order, a name that occurs twice in the file has one id; reads and unitigs are separate registries."""
+    from muchsalsa_amd import overlap, sequences
+    paf = tmp_path / "x.paf"
+    lines = ["u1\t900\t0\t900\t+\tr7\t5000\t10\t910\t800\t900\t60", "u0\t900\t0\t900\t-\tr3\t5000\t10\t910\t800\t900\t60",
+             "u1\t900\t0\t900\t+\tr3\t5000\t2000\t2900\t800\t900\t60", "last\t1\t0\t1\t+\tnever\t1\t0\t1\t0\t1\t0"]
+    paf.write_text("\n".join(lines) + "\n")
+    p = overlap.parse_paf(str(paf))
+    assert p.read_names == ["r7", "r3"] and p.anchor_names == ["u1", "u0"] and (p.n_reads, p.n_anchors) == (2, 2)
+    fa = tmp_path / "n.fa"
+    fa.write_bytes(b">r3 d\nACGT\n>new1\nAC\n>r7\nGG\n>new2\nTT\n")
+    f = sequences.SeqFile(str(fa))
+    ids, space = p.register_sequences(0, f)
+    assert list(ids) == [1, 2, 0, 3] and space == 4
+    ids2, space2 = p.register_sequences(0, f)  # registering again changes nothing
+    assert list(ids2) == [1, 2, 0, 3] and space2 == 4
+    fu = tmp_path / "u.fa"
+    fu.write_bytes(b">u0\nAC\n>u9\nGT\n>u1\nTT\n")
+    idu, spu = p.register_sequences(1, sequences.SeqFile(str(fu)))
+    assert list(idu) == [1, 2, 0] and spu == 3
+    assert p.read_names == ["r7", "r3"]  # the view's name lists are the PAF's own registrations
