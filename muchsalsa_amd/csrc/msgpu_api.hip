@@ -750,20 +750,20 @@ int msgpu_calculate_edges(msgpu_ctx *c) {
   static const bool no_fork = getenv("MSGPU_NO_FORK") != nullptr; // measurement switch: the classes one after the other
   const bool fork = (c->n_list[1] || c->n_list[2]) && c->n_list[0] && !no_fork;
   if (fork) {
-    HIPCHK(c, hipEventRecord(c->ev_side[0], st));
-    if (c->n_list[2]) {
-      HIPCHK(c, hipStreamWaitEvent(c->side_stream, c->ev_side[0], 0));
-      launch_candidates(c->side_stream, a, 2, l2, c->n_list[2]);
-      HIPCHK(c, hipEventRecord(c->ev_side[1], c->side_stream));
-    }
+    // class 1 beside class 0 on a stream of its own; the handful of class-2 workgroups IN FRONT of class 0 on the main
+    // stream (17 us alone on an empty GPU): a launch on another stream costs ~15-20 us of host latency each, and class 0 --
+    // the stage's critical kernel -- used to start 36 us late behind two of them
     if (c->n_list[1]) {
+      HIPCHK(c, hipEventRecord(c->ev_side[0], st));
       HIPCHK(c, hipStreamWaitEvent(c->side_stream2, c->ev_side[0], 0));
+    }
+    launch_candidates(st, a, 2, l2, c->n_list[2]);
+    launch_candidates(st, a, 0, l0, c->n_list[0]);
+    if (c->n_list[1]) {
       launch_candidates(c->side_stream2, a, 1, l1, c->n_list[1]);
       HIPCHK(c, hipEventRecord(c->ev_side2, c->side_stream2));
+      HIPCHK(c, hipStreamWaitEvent(st, c->ev_side2, 0));
     }
-    launch_candidates(st, a, 0, l0, c->n_list[0]);
-    if (c->n_list[2]) HIPCHK(c, hipStreamWaitEvent(st, c->ev_side[1], 0));
-    if (c->n_list[1]) HIPCHK(c, hipStreamWaitEvent(st, c->ev_side2, 0));
   } else {
     launch_candidates(st, a, 2, l2, c->n_list[2]);
     launch_candidates(st, a, 1, l1, c->n_list[1]);
