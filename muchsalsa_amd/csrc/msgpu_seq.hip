@@ -10,6 +10,8 @@
 // HBM-bound byte work: 16 B per lane, aligned 16-B stores, unaligned source handled with v_alignbyte.
 #include <hip/hip_runtime.h>
 
+#include <memory>
+#include <system_error>
 #include <thread>
 
 #include <algorithm>
@@ -505,30 +507,78 @@ int msgpu_gather_plan_create(msgpu_seqctx *c, const msgpu_copy *pieces, size_t n
   *out = nullptr;
   if (c->device < 0) return MSGPU_E_NODEVICE;
   SHIP(c, hipSetDevice(c->device));
-  std::vector<uint32_t> cmap, smap; // 2 words per chunk
-  uint64_t              chunks = 0, supers = 0, out_bytes = 0, bases = 0;
-  for (size_t i = 0; i < n; ++i) {
-    const msgpu_copy &p = pieces[i];
-    const SeqStore   &s = c->st[(p.flags & MSGPU_COPY_ILLUMINA) ? 1 : 0];
-    if (p.src_off + p.len > s.n_bases || p.len >= 0x7fffffffu) return MSGPU_E_ARG; // never read outside the store
-    if (p.len) {
-      const uint64_t k = ((p.dst_off + p.len) - (p.dst_off & ~15ull) + GCHUNK - 1) / GCHUNK;
-      if (chunks + k >= 0x1fffffffcull) return MSGPU_E_ARG; // grid.x = chunks / 4 must fit 31 bits
-      try {
-        for (uint64_t q = 0; q < k; ++q) {
-          cmap.push_back(static_cast<uint32_t>(i));
-          cmap.push_back(static_cast<uint32_t>(q));
+  // the work partition: every piece is cut into 1-KiB chunks (cmap) and 4-KiB super-chunks (smap) of its output, 2 words
+  // each.  A deep assembly has millions of pieces: counted and filled in stretches on host threads (a stretch's first
+  // chunk number is the prefix over the stretches before it).
+  std::unique_ptr<uint32_t[]> cmap, smap;
+  uint64_t                    chunks = 0, supers = 0, out_bytes = 0, bases = 0;
+  {
+    unsigned nt = std::thread::hardware_concurrency();
+    nt          = nt == 0 ? 1 : (nt > 16 ? 16 : nt);
+    if (n < 200000) nt = 1;
+    struct Part {
+      uint64_t chunks = 0, supers = 0, out_bytes = 0, bases = 0;
+      int      rc = MSGPU_OK;
+    };
+    std::vector<Part> part(nt);
+    auto chunks_of = [](const msgpu_copy &p) { return ((p.dst_off + p.len) - (p.dst_off & ~15ull) + GCHUNK - 1) / GCHUNK; };
+    auto on_threads = [&](auto &&body) {
+      std::vector<std::thread> pool;
+      for (unsigned t = 1; t < nt; ++t) pool.emplace_back(body, t);
+      body(0u);
+      for (auto &th : pool) th.join();
+    };
+    try {
+      on_threads([&](unsigned t) {
+        Part &pt = part[t];
+        for (size_t i = n * t / nt; i < n * (t + 1) / nt; ++i) {
+          const msgpu_copy &p = pieces[i];
+          const SeqStore   &s = c->st[(p.flags & MSGPU_COPY_ILLUMINA) ? 1 : 0];
+          if (p.src_off + p.len > s.n_bases || p.len >= 0x7fffffffu) { // never read outside the store
+            pt.rc = MSGPU_E_ARG;
+            return;
+          }
+          if (p.len) {
+            const uint64_t k = chunks_of(p);
+            pt.chunks += k;
+            pt.supers += (k + SSUB - 1) / SSUB;
+          }
+          if (p.dst_off + p.len > pt.out_bytes) pt.out_bytes = p.dst_off + p.len;
+          pt.bases += p.len;
         }
-        for (uint64_t q = 0; q < (k + SSUB - 1) / SSUB; ++q) {
-          smap.push_back(static_cast<uint32_t>(i));
-          smap.push_back(static_cast<uint32_t>(q));
+      });
+      std::vector<uint64_t> cbase(nt + 1, 0), sbase(nt + 1, 0);
+      for (unsigned t = 0; t < nt; ++t) {
+        if (part[t].rc != MSGPU_OK) return part[t].rc;
+        cbase[t + 1] = cbase[t] + part[t].chunks;
+        sbase[t + 1] = sbase[t] + part[t].supers;
+        if (part[t].out_bytes > out_bytes) out_bytes = part[t].out_bytes;
+        bases += part[t].bases;
+      }
+      chunks = cbase[nt];
+      supers = sbase[nt];
+      if (chunks >= 0x1fffffffcull) return MSGPU_E_ARG; // grid.x = chunks / 4 must fit 31 bits
+      cmap.reset(new uint32_t[2 * (chunks ? chunks : 1)]);
+      smap.reset(new uint32_t[2 * (supers ? supers : 1)]);
+      on_threads([&](unsigned t) {
+        uint64_t cq = 2 * cbase[t], sq = 2 * sbase[t];
+        for (size_t i = n * t / nt; i < n * (t + 1) / nt; ++i) {
+          const msgpu_copy &p = pieces[i];
+          if (!p.len) continue;
+          const uint64_t k = chunks_of(p);
+          for (uint64_t q = 0; q < k; ++q) {
+            cmap[cq++] = static_cast<uint32_t>(i);
+            cmap[cq++] = static_cast<uint32_t>(q);
+          }
+          for (uint64_t q = 0; q < (k + SSUB - 1) / SSUB; ++q) {
+            smap[sq++] = static_cast<uint32_t>(i);
+            smap[sq++] = static_cast<uint32_t>(q);
+          }
         }
-      } catch (std::bad_alloc const &) { return MSGPU_E_NOMEM; }
-      chunks += k;
-      supers += (k + SSUB - 1) / SSUB;
+      });
+    } catch (std::bad_alloc const &) { return MSGPU_E_NOMEM; } catch (std::system_error const &) {
+      return MSGPU_E_NOMEM;
     }
-    if (p.dst_off + p.len > out_bytes) out_bytes = p.dst_off + p.len;
-    bases += p.len;
   }
   auto *pl = new (std::nothrow) msgpu_gather_plan();
   if (!pl) return MSGPU_E_NOMEM;
@@ -543,9 +593,9 @@ int msgpu_gather_plan_create(msgpu_seqctx *c, const msgpu_copy *pieces, size_t n
   if (e == hipSuccess && n)
     e = hipMemcpyAsync(pl->d_pieces, pieces, n * sizeof(msgpu_copy), hipMemcpyHostToDevice, c->stream);
   if (e == hipSuccess && chunks)
-    e = hipMemcpyAsync(pl->d_chunk_map, cmap.data(), chunks * 8, hipMemcpyHostToDevice, c->stream);
+    e = hipMemcpyAsync(pl->d_chunk_map, cmap.get(), chunks * 8, hipMemcpyHostToDevice, c->stream);
   if (e == hipSuccess && supers)
-    e = hipMemcpyAsync(pl->d_super_map, smap.data(), supers * 8, hipMemcpyHostToDevice, c->stream);
+    e = hipMemcpyAsync(pl->d_super_map, smap.get(), supers * 8, hipMemcpyHostToDevice, c->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
   if (e != hipSuccess) {
     if (pl->d_pieces) (void)hipFree(pl->d_pieces);
