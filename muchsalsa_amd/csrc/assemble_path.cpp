@@ -1197,9 +1197,14 @@ int msgpu_assembly_add_paths(msgpu_assembly *a, const msgpu_path_input *in, size
   try {
     res.resize(n);
     msg.resize(n);
+    // longest paths first: a path of hundreds of reads laid out last would leave the other threads idle behind it
+    std::vector<uint32_t> by_size(n);
+    for (size_t i = 0; i < n; ++i) by_size[i] = static_cast<uint32_t>(i);
+    std::stable_sort(by_size.begin(), by_size.end(), [&](uint32_t x, uint32_t y) { return in[x].n_reads > in[y].n_reads; });
     std::atomic<size_t>         next{0};
     const std::function<void()> work = [&]() {
-      for (size_t i = next.fetch_add(1); i < n; i = next.fetch_add(1)) {
+      for (size_t k = next.fetch_add(1); k < n; k = next.fetch_add(1)) {
+        const size_t i = by_size[k];
         rc[i] = try_layout(a, &in[i], res[i], msg[i]);
         if (rc[i] == MSGPU_OK) {
           try {
