@@ -355,6 +355,9 @@ uint32_t    msgpu_seq_count(const msgpu_seqfile *f);
 const char *msgpu_seq_name(const msgpu_seqfile *f, uint32_t record);   /* cleaned id (cut at the first whitespace) */
 uint64_t    msgpu_seq_length(const msgpu_seqfile *f, uint32_t record);
 const char *msgpu_seq_bases(const msgpu_seqfile *f, uint32_t record);  /* not NUL-terminated                       */
+/* the one buffer every record's bytes lie in (msgpu_seq_bases points into it; records need not touch each other) and
+ * its used size: what msgpu_seq_upload copies to HBM */
+const char *msgpu_seq_buffer(const msgpu_seqfile *f, uint64_t *bytes);
 
 /* strSlice (SequenceUtils.cpp:27-38) as (returned offset, *len): Python-like indices, INCLUSIVE clipped end. */
 uint64_t msgpu_str_slice(uint64_t size, int32_t start, int32_t end, uint64_t *len);
@@ -367,6 +370,12 @@ const char *msgpu_seq_last_error(const msgpu_seqctx *ctx);
 /* kind 0 = nanopore reads, 1 = illumina unitigs.  ids[record] = Registry id of that record (0xffffffff = skip);
  * NULL = record order.  n_ids = size of the id space. */
 int msgpu_seq_upload(msgpu_seqctx *ctx, int kind, const msgpu_seqfile *f, const uint32_t *ids, uint32_t n_ids);
+/* The same in two steps, for a caller that parses the sequence files beside the PAF (SequenceAccessor::buildIndex needs
+ * the Registry only for the ids, SequenceAccessor.cpp:171,215): the bytes as soon as a file is parsed -- the two kinds may
+ * be sent (and converted, msgpu_seq_pack_store) from two host threads at the same time --, the ids of the SAME file once
+ * the registries exist (MSGPU_E_STATE when the store holds another file's bytes). */
+int msgpu_seq_upload_bases(msgpu_seqctx *ctx, int kind, const msgpu_seqfile *f);
+int msgpu_seq_set_ids(msgpu_seqctx *ctx, int kind, const msgpu_seqfile *f, const uint32_t *ids, uint32_t n_ids);
 
 /* Same from a device buffer that already holds the whitespace-free bases (copied device-to-device into the store):
  * off[id] / len[id] = position of sequence `id` inside it (off = ~0 for an id without sequence). */
@@ -378,6 +387,7 @@ int msgpu_seq_upload_device(msgpu_seqctx *ctx, int kind, const void *d_bases, ui
  * 1.25 instead of 2 bytes of traffic per gathered base.  Results of every later gather are unchanged.  A new upload
  * returns the store to the byte form. */
 int msgpu_seq_pack(msgpu_seqctx *ctx);
+int msgpu_seq_pack_store(msgpu_seqctx *ctx, int kind); /* one store only */
 
 /* One piece of output: `len` bases starting at `src_off` of a store, as they are or reverse-complemented, written
  * at dst_off.  24 bytes. */

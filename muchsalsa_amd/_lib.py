@@ -133,6 +133,7 @@ SYMBOLS = [
     ("msgpu_seq_name", C.c_char_p, [C.c_void_p, C.c_uint32]),
     ("msgpu_seq_length", C.c_uint64, [C.c_void_p, C.c_uint32]),
     ("msgpu_seq_bases", C.c_void_p, [C.c_void_p, C.c_uint32]),
+    ("msgpu_seq_buffer", C.c_void_p, [C.c_void_p, C.POINTER(C.c_uint64)]),
     ("msgpu_str_slice", C.c_uint64, [C.c_uint64, C.c_int32, C.c_int32, C.POINTER(C.c_uint64)]),
     ("msgpu_seq_create", C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
     ("msgpu_seq_destroy", None, [C.c_void_p]),
@@ -141,6 +142,9 @@ SYMBOLS = [
     ("msgpu_seq_upload_device", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,
                                           C.c_uint32]),
     ("msgpu_seq_pack", C.c_int, [C.c_void_p]),
+    ("msgpu_seq_pack_store", C.c_int, [C.c_void_p, C.c_int]),
+    ("msgpu_seq_upload_bases", C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    ("msgpu_seq_set_ids", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_uint32]),
     ("msgpu_seq_resolve", C.c_int, [C.c_void_p, C.c_int, C.c_uint32, C.c_int32, C.c_int32, C.c_int, C.c_void_p]),
     ("msgpu_seg_anchor", C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int, C.c_void_p,
                                    C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]),

@@ -144,3 +144,11 @@ class Assembly:
         if not p and which < 2:
             raise MsgpuError(_lib.E_STATE, "finish() first")
         return C.string_at(p, n.value) if n.value else b""
+
+    def text_view(self, which):
+        """the same bytes without a copy (valid until the next batch / close): what the pipeline hands to write()"""
+        n = C.c_uint64()
+        p = self._L.msgpu_assembly_text(self._h, int(which), C.byref(n))
+        if not p and which < 2:
+            raise MsgpuError(_lib.E_STATE, "finish() first")
+        return memoryview((C.c_char * n.value).from_address(p)).cast("B") if n.value else memoryview(b"")

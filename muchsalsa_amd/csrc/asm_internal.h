@@ -1,5 +1,8 @@
 // asm_internal.h -- the assembly object shared by assemble_path.cpp (host layout) and msgpu_seq.hip (device finish).
 #pragma once
+#include <type_traits>
+#include <utility>
+#include <new>
 #include <cstdint>
 #include <memory>
 #include <string>
@@ -64,6 +67,9 @@ template <class T> struct HostTableAlloc { // std::allocator for such tables
   template <class U> HostTableAlloc(const HostTableAlloc<U> &) noexcept {}
   T   *allocate(size_t n) { return static_cast<T *>(host_table_alloc(n * sizeof(T))); }
   void deallocate(T *p, size_t) noexcept { host_table_free(p); }
+  // resize() leaves new rows of a plain type as they are (the loader's threads fill them): no pass of zeroes over the table
+  template <class U> void construct(U *p) noexcept(std::is_nothrow_default_constructible<U>::value) { ::new (static_cast<void *>(p)) U; }
+  template <class U, class... A> void construct(U *p, A &&...a) { ::new (static_cast<void *>(p)) U(std::forward<A>(a)...); }
   template <class U> bool operator==(const HostTableAlloc<U> &) const noexcept { return true; }
   template <class U> bool operator!=(const HostTableAlloc<U> &) const noexcept { return false; }
 };

@@ -322,6 +322,7 @@ constexpr size_t PACK_PAD = 16; // words of zero padding in front of and behind 
 struct SeqStore {
   void                 *d_buf = nullptr; // SEQ_PAD + bases + SEQ_PAD (freed by msgpu_seq_pack)
   uint64_t              n_bases = 0;
+  hipStream_t           stream = nullptr; // uploads and the 2-bit conversion of THIS store (the two stores may be filled from two host threads)
   // 2-bit form (msgpu_seq_pack): 16 words of zero padding, (n_bases + 15) / 16 words, 16 words of padding
   void    *d_words = nullptr, *d_exc_pos = nullptr, *d_exc_byte = nullptr;
   uint64_t n_exc = 0;
@@ -399,7 +400,12 @@ int msgpu_seq_create(int device, msgpu_seqctx **out) {
   auto *c = new (std::nothrow) msgpu_seqctx();
   if (!c) return MSGPU_E_NOMEM;
   c->device = device;
-  if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+  if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithFlags(&c->st[0].stream, hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithFlags(&c->st[1].stream, hipStreamNonBlocking) != hipSuccess) {
+    for (auto &st : c->st)
+      if (st.stream) (void)hipStreamDestroy(st.stream);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return MSGPU_E_HIP;
   }
@@ -416,6 +422,10 @@ void msgpu_seq_destroy(msgpu_seqctx *c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   for (auto &s : c->st) {
+    if (s.stream) {
+      (void)hipStreamSynchronize(s.stream);
+      (void)hipStreamDestroy(s.stream);
+    }
     if (s.d_buf) (void)hipFree(s.d_buf);
     s.drop_packed();
   }
@@ -427,40 +437,68 @@ void msgpu_seq_destroy(msgpu_seqctx *c) {
 
 const char *msgpu_seq_last_error(const msgpu_seqctx *c) { return c ? c->err : "null context"; }
 
-int msgpu_seq_upload(msgpu_seqctx *c, int kind, const msgpu_seqfile *f, const uint32_t *ids, uint32_t n_ids) {
+// The two halves of msgpu_seq_upload.  The bytes need nothing but the parsed file, the id table needs the Registry ids of
+// its records (which exist once the PAF is read): a caller that parses the sequence files beside the PAF sends the bytes
+// as soon as a file is parsed (from the parsing thread: the two stores have their own streams) and sets the ids later.
+int msgpu_seq_upload_bases(msgpu_seqctx *c, int kind, const msgpu_seqfile *f) {
   if (!c || !f || kind < 0 || kind > 1) return MSGPU_E_ARG;
-  if (c->device >= 0) SHIP(c, hipSetDevice(c->device));
-  SeqStore      &s = c->st[kind];
-  const uint32_t n = msgpu_seq_count(f);
-  uint32_t       space = ids ? n_ids : n;
-  for (uint32_t i = 0; ids && i < n; ++i)
-    if (ids[i] != 0xffffffffu && ids[i] >= space) return MSGPU_E_ARG;
-  s.off.assign(space, ~0ull);
-  s.len.assign(space, 0);
-  const char *first = n ? msgpu_seq_bases(f, 0) : nullptr;
-  uint64_t    total = 0;
-  for (uint32_t i = 0; i < n; ++i) {
-    const uint32_t id = ids ? ids[i] : i;
-    const uint64_t l  = msgpu_seq_length(f, i);
-    if (id != 0xffffffffu && s.off[id] == ~0ull) { // emplace: the first record of an id wins
-      s.off[id] = static_cast<uint64_t>(msgpu_seq_bases(f, i) - first);
-      s.len[id] = l;
-    }
-    total += l;
-  }
+  SeqStore &s = c->st[kind];
+  uint64_t  total = 0; // the records' bytes go up as they lie in the loader's buffer (with what lies between them)
+  const char *first = msgpu_seq_buffer(f, &total);
+  s.off.clear();
+  s.len.clear();
   s.n_bases = total;
   if (c->device < 0) return MSGPU_OK; // layout-only context: offsets and lengths are all it needs
+  SHIP(c, hipSetDevice(c->device));
   s.drop_packed();
   if (s.d_buf) {
     SHIP(c, hipFree(s.d_buf));
     s.d_buf = nullptr;
   }
   SHIP(c, hipMalloc(&s.d_buf, total + 2 * SEQ_PAD));
-  SHIP(c, hipMemsetAsync(s.d_buf, 0, total + 2 * SEQ_PAD, c->stream));
+  SHIP(c, hipMemsetAsync(s.d_buf, 0, SEQ_PAD, s.stream));
+  SHIP(c, hipMemsetAsync(static_cast<uint8_t *>(s.d_buf) + SEQ_PAD + total, 0, SEQ_PAD, s.stream));
   if (total)
-    SHIP(c, hipMemcpyAsync(static_cast<uint8_t *>(s.d_buf) + SEQ_PAD, first, total, hipMemcpyHostToDevice, c->stream));
-  SHIP(c, hipStreamSynchronize(c->stream));
+    SHIP(c, hipMemcpyAsync(static_cast<uint8_t *>(s.d_buf) + SEQ_PAD, first, total, hipMemcpyHostToDevice, s.stream));
+  SHIP(c, hipStreamSynchronize(s.stream));
   return MSGPU_OK;
+}
+
+int msgpu_seq_set_ids(msgpu_seqctx *c, int kind, const msgpu_seqfile *f, const uint32_t *ids, uint32_t n_ids) {
+  if (!c || !f || kind < 0 || kind > 1) return MSGPU_E_ARG;
+  SeqStore      &s = c->st[kind];
+  const uint32_t n = msgpu_seq_count(f);
+  uint32_t       space = ids ? n_ids : n;
+  uint64_t       total = 0;
+  const char    *first = msgpu_seq_buffer(f, &total);
+  if (total != s.n_bases) { // not the file msgpu_seq_upload_bases sent
+    snprintf(c->err, sizeof(c->err), "msgpu_seq_set_ids: the store holds %llu bytes, the file %llu",
+             static_cast<unsigned long long>(s.n_bases), static_cast<unsigned long long>(total));
+    return MSGPU_E_STATE;
+  }
+  for (uint32_t i = 0; ids && i < n; ++i)
+    if (ids[i] != 0xffffffffu && ids[i] >= space) return MSGPU_E_ARG;
+  try {
+    s.off.assign(space, ~0ull);
+    s.len.assign(space, 0);
+  } catch (std::bad_alloc const &) { return MSGPU_E_NOMEM; }
+  for (uint32_t i = 0; i < n; ++i) {
+    const uint32_t id = ids ? ids[i] : i;
+    if (id != 0xffffffffu && s.off[id] == ~0ull) { // emplace: the first record of an id wins
+      s.off[id] = static_cast<uint64_t>(msgpu_seq_bases(f, i) - first);
+      s.len[id] = msgpu_seq_length(f, i);
+    }
+  }
+  return MSGPU_OK;
+}
+
+int msgpu_seq_upload(msgpu_seqctx *c, int kind, const msgpu_seqfile *f, const uint32_t *ids, uint32_t n_ids) {
+  if (!c || !f || kind < 0 || kind > 1) return MSGPU_E_ARG;
+  const uint32_t n = msgpu_seq_count(f);
+  for (uint32_t i = 0; ids && i < n; ++i) // (before anything is touched)
+    if (ids[i] != 0xffffffffu && ids[i] >= n_ids) return MSGPU_E_ARG;
+  const int rc = msgpu_seq_upload_bases(c, kind, f);
+  return rc != MSGPU_OK ? rc : msgpu_seq_set_ids(c, kind, f, ids, n_ids);
 }
 
 int msgpu_seq_upload_device(msgpu_seqctx *c, int kind, const void *d_bases, uint64_t n_bases, const uint64_t *off,
@@ -654,44 +692,47 @@ int msgpu_gather_run(msgpu_seqctx *c, const msgpu_gather_plan *pl, void *d_out, 
   return MSGPU_OK;
 }
 
-// Convert both resident stores to the 2-bit form (+ exception lists) and free the byte-per-base buffers.
-int msgpu_seq_pack(msgpu_seqctx *c) {
-  if (!c) return MSGPU_E_ARG;
+// Convert one resident store to the 2-bit form (+ exception list) and free its byte-per-base buffer (on the store's own
+// stream: the two stores may be converted from two host threads).
+int msgpu_seq_pack_store(msgpu_seqctx *c, int kind) {
+  if (!c || kind < 0 || kind > 1) return MSGPU_E_ARG;
   if (c->device < 0) return MSGPU_E_NODEVICE;
   SHIP(c, hipSetDevice(c->device));
-  for (SeqStore &s : c->st) {
-    if (s.packed || !s.d_buf) continue;
+  {
+    SeqStore &s = c->st[kind];
+    if (s.packed || !s.d_buf) return MSGPU_OK;
+    hipStream_t st = s.stream;
     const uint64_t n_words = (s.n_bases + 15) / 16;
     const uint8_t *bases   = static_cast<const uint8_t *>(s.d_buf) + SEQ_PAD;
     void          *d_cnt   = nullptr;
     SHIP(c, hipMalloc(&s.d_words, (n_words + 2 * PACK_PAD) * 4));
     hipError_t e = hipMalloc(&d_cnt, 8);
-    if (e == hipSuccess) e = hipMemsetAsync(s.d_words, 0, (n_words + 2 * PACK_PAD) * 4, c->stream);
-    if (e == hipSuccess) e = hipMemsetAsync(d_cnt, 0, 8, c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(s.d_words, 0, (n_words + 2 * PACK_PAD) * 4, st);
+    if (e == hipSuccess) e = hipMemsetAsync(d_cnt, 0, 8, st);
     unsigned long long n_exc = 0;
     if (e == hipSuccess && n_words) {
-      hipLaunchKernelGGL(k_pack_bases, dim3(static_cast<uint32_t>((n_words + 255) / 256)), dim3(256), 0, c->stream, bases,
+      hipLaunchKernelGGL(k_pack_bases, dim3(static_cast<uint32_t>((n_words + 255) / 256)), dim3(256), 0, st, bases,
                          s.n_bases, static_cast<uint32_t *>(s.d_words) + PACK_PAD, static_cast<unsigned long long *>(d_cnt),
                          static_cast<uint64_t *>(nullptr), static_cast<uint8_t *>(nullptr), 0);
       e = hipGetLastError();
     }
-    if (e == hipSuccess) e = hipMemcpyAsync(&n_exc, d_cnt, 8, hipMemcpyDeviceToHost, c->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(&n_exc, d_cnt, 8, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e == hipSuccess && n_exc) { // second pass records them; sorted by position on the host (they are few)
       e = hipMalloc(&s.d_exc_pos, n_exc * 8);
       if (e == hipSuccess) e = hipMalloc(&s.d_exc_byte, n_exc);
-      if (e == hipSuccess) e = hipMemsetAsync(d_cnt, 0, 8, c->stream);
+      if (e == hipSuccess) e = hipMemsetAsync(d_cnt, 0, 8, st);
       if (e == hipSuccess) {
-        hipLaunchKernelGGL(k_pack_bases, dim3(static_cast<uint32_t>((n_words + 255) / 256)), dim3(256), 0, c->stream, bases,
+        hipLaunchKernelGGL(k_pack_bases, dim3(static_cast<uint32_t>((n_words + 255) / 256)), dim3(256), 0, st, bases,
                            s.n_bases, static_cast<uint32_t *>(nullptr), static_cast<unsigned long long *>(d_cnt),
                            static_cast<uint64_t *>(s.d_exc_pos), static_cast<uint8_t *>(s.d_exc_byte), 1);
         e = hipGetLastError();
       }
       std::vector<uint64_t> pos(n_exc);
       std::vector<uint8_t>  byt(n_exc);
-      if (e == hipSuccess) e = hipMemcpyAsync(pos.data(), s.d_exc_pos, n_exc * 8, hipMemcpyDeviceToHost, c->stream);
-      if (e == hipSuccess) e = hipMemcpyAsync(byt.data(), s.d_exc_byte, n_exc, hipMemcpyDeviceToHost, c->stream);
-      if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+      if (e == hipSuccess) e = hipMemcpyAsync(pos.data(), s.d_exc_pos, n_exc * 8, hipMemcpyDeviceToHost, st);
+      if (e == hipSuccess) e = hipMemcpyAsync(byt.data(), s.d_exc_byte, n_exc, hipMemcpyDeviceToHost, st);
+      if (e == hipSuccess) e = hipStreamSynchronize(st);
       if (e == hipSuccess) {
         std::vector<uint64_t> idx(n_exc);
         for (uint64_t i = 0; i < n_exc; ++i) idx[i] = i;
@@ -702,9 +743,9 @@ int msgpu_seq_pack(msgpu_seqctx *c) {
           spos[i] = pos[idx[i]];
           sbyt[i] = byt[idx[i]];
         }
-        e = hipMemcpyAsync(s.d_exc_pos, spos.data(), n_exc * 8, hipMemcpyHostToDevice, c->stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(s.d_exc_byte, sbyt.data(), n_exc, hipMemcpyHostToDevice, c->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        e = hipMemcpyAsync(s.d_exc_pos, spos.data(), n_exc * 8, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(s.d_exc_byte, sbyt.data(), n_exc, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
       }
     }
     if (d_cnt) (void)hipFree(d_cnt);
@@ -716,6 +757,16 @@ int msgpu_seq_pack(msgpu_seqctx *c) {
     s.packed = true;
     (void)hipFree(s.d_buf); // the byte-per-base copy is no longer needed
     s.d_buf = nullptr;
+  }
+  return MSGPU_OK;
+}
+
+// Convert both resident stores.
+int msgpu_seq_pack(msgpu_seqctx *c) {
+  if (!c) return MSGPU_E_ARG;
+  for (int kind = 0; kind < 2; ++kind) {
+    const int rc = msgpu_seq_pack_store(c, kind);
+    if (rc != MSGPU_OK) return rc;
   }
   return MSGPU_OK;
 }

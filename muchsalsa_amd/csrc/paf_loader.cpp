@@ -47,6 +47,7 @@ class NameRegistry {
 public:
   NameRegistry() : m_slots(1024) {}
   uint32_t get(const char *s, size_t n, uint64_t h) {
+    if (m_stale) index_names();
     if ((m_names.size() + 1) * 2 > m_slots.size()) grow();
     size_t i = h & (m_slots.size() - 1);
     while (m_slots[i].id_plus_1) {
@@ -66,26 +67,47 @@ public:
   void        clear() { // Registry::clear (Registry.cpp:47-52): numbering starts again at 0
     m_names.clear();
     m_slots.assign(1024, Slot{});
+    m_stale = false;
   }
   const char *name(uint32_t id) const { return id < m_names.size() ? m_names[id]->c_str() : nullptr; }
+
+  // The loader's way in: it knows the id of every name already (first-seen order over the whole file, worked out on its
+  // threads).  The table is sized here, the names are put in place by the loader's threads (set_name: any order, distinct
+  // ids), and the hash index follows when the first look-up asks for it.
+  void bulk_begin(uint32_t n) {
+    m_names.clear();
+    m_names.resize(n);
+    m_stale = true;
+  }
+  void set_name(uint32_t id, const char *s, size_t n) { m_names[id] = std::make_unique<std::string>(s, n); }
 
 private:
   struct Slot {
     uint64_t hash      = 0;
     uint32_t id_plus_1 = 0;
   };
+  void place(std::vector<Slot> &into, const Slot &sl) {
+    size_t i = sl.hash & (into.size() - 1);
+    while (into[i].id_plus_1) i = (i + 1) & (into.size() - 1);
+    into[i] = sl;
+  }
   void grow() {
     std::vector<Slot> ns(m_slots.size() * 2);
     for (const Slot &sl : m_slots)
-      if (sl.id_plus_1) {
-        size_t i = sl.hash & (ns.size() - 1);
-        while (ns[i].id_plus_1) i = (i + 1) & (ns.size() - 1);
-        ns[i] = sl;
-      }
+      if (sl.id_plus_1) place(ns, sl);
     m_slots.swap(ns);
+  }
+  void index_names() {
+    size_t cap = 1024;
+    while (cap < 2 * (m_names.size() + 1)) cap <<= 1;
+    m_slots.assign(cap, Slot{});
+    for (size_t id = 0; id < m_names.size(); ++id)
+      place(m_slots, Slot{name_hash(m_names[id]->data(), m_names[id]->size()), static_cast<uint32_t>(id + 1)});
+    m_stale = false;
   }
   std::vector<std::unique_ptr<std::string>> m_names;
   std::vector<Slot>                         m_slots;
+  bool                                      m_stale = false; // m_names was bulk-loaded: m_slots is rebuilt by the next get()
 };
 
 // std::stoi: optional whitespace, optional sign, at least one digit, value must fit int.
@@ -115,21 +137,52 @@ struct msgpu_paf {
 
 namespace {
 
-// one accepted line before Registry ids exist: names are views into the mmap'ed file
-struct RawRow {
-  const char *qname, *tname;
-  uint64_t    qhash, thash;    // name hashes (computed in parallel, consumed by the sequential Registry pass)
-  uint32_t    qlen, tlen_name; // name lengths
-  int32_t     read_len, i_lo, i_hi, n_lo, n_hi;
-  uint32_t    score, line, flags;
+// The names of one chunk of the file (one list per registry), in the order the chunk meets them: what the Registry would
+// hold had the file begun with this chunk.  The ids of the whole file follow from these lists (assign_ids below).
+struct NameEntry {
+  const char      *s; // view into the mmap'ed file
+  uint32_t         n;
+  uint32_t         id;    // Registry id (set by assign_ids)
+  uint64_t         hash;
+  const NameEntry *first; // the entry of an earlier chunk with the same name (nullptr: this is the name's first appearance)
+};
+class ChunkNames {
+public:
+  uint32_t get(const char *s, uint32_t n, uint64_t h) { // position of the name in the chunk's list
+    if ((list.size() + 1) * 2 > m_slots.size()) grow();
+    size_t i = h & (m_slots.size() - 1);
+    for (; m_slots[i]; i = (i + 1) & (m_slots.size() - 1)) {
+      const NameEntry &e = list[m_slots[i] - 1];
+      if (e.hash == h && e.n == n && memcmp(e.s, s, n) == 0) return m_slots[i] - 1;
+    }
+    list.push_back(NameEntry{s, n, 0, h, nullptr});
+    m_slots[i] = static_cast<uint32_t>(list.size());
+    return static_cast<uint32_t>(list.size() - 1);
+  }
+  void drop_index() { std::vector<uint32_t>().swap(m_slots); }
+  std::vector<NameEntry> list;
+
+private:
+  void grow() {
+    std::vector<uint32_t> ns(m_slots.empty() ? 4096 : m_slots.size() * 2, 0);
+    for (uint32_t v : m_slots)
+      if (v) {
+        size_t i = list[v - 1].hash & (ns.size() - 1);
+        while (ns[i]) i = (i + 1) & (ns.size() - 1);
+        ns[i] = v;
+      }
+    m_slots.swap(ns);
+  }
+  std::vector<uint32_t> m_slots; // position + 1
 };
 
 struct Chunk {
-  const char         *begin = nullptr, *end = nullptr;
-  size_t              n_lines = 0, first_line = 0;
-  std::vector<RawRow> rows;
-  int                 err = MSGPU_OK;
-  size_t              err_line = 0;
+  const char            *begin = nullptr, *end = nullptr;
+  size_t                 n_lines = 0, first_line = 0;
+  std::vector<msgpu_row> rows; // accepted lines; read_id / anchor_id = positions in the chunk's own name lists
+  ChunkNames             reads, anchors;
+  int                    err = MSGPU_OK;
+  size_t                 err_line = 0;
 };
 
 // parse the lines of one chunk (BlastFileReader::parseLine, BlastFileReader.cpp:86-130), except the file's last line
@@ -182,13 +235,10 @@ void parse_chunk(Chunk &ch, size_t last_line, const msgpu_params &p) {
     }
     const bool dir  = (te[4] - tb[4] == 1) && *tb[4] == '+';
     const bool prim = span >= static_cast<int>(p.th_length) && static_cast<uint32_t>(nom) >= p.th_matches;
-    RawRow     r;
-    r.qname     = tb[0];
-    r.qlen      = static_cast<uint32_t>(te[0] - tb[0]);
-    r.tname     = tb[5];
-    r.tlen_name = static_cast<uint32_t>(te[5] - tb[5]);
-    r.qhash     = name_hash(r.qname, r.qlen);
-    r.thash     = name_hash(r.tname, r.tlen_name);
+    msgpu_row  r;
+    // Registry::operator[] (BlastFileReader.cpp:110-111), chunk-local for now
+    r.read_id   = ch.reads.get(tb[5], static_cast<uint32_t>(te[5] - tb[5]), name_hash(tb[5], static_cast<size_t>(te[5] - tb[5])));
+    r.anchor_id = ch.anchors.get(tb[0], static_cast<uint32_t>(te[0] - tb[0]), name_hash(tb[0], static_cast<size_t>(te[0] - tb[0])));
     r.read_len  = nle;
     r.i_lo      = irs;
     r.i_hi      = ire - 1;
@@ -257,8 +307,10 @@ int msgpu_parse_paf(const char *path, const msgpu_params *params, msgpu_paf **ou
     unsigned nthr = std::thread::hardware_concurrency();
     if (nthr == 0) nthr = 1;
     if (nthr > 16) nthr = 16;
-    if (const char *e = getenv("MSGPU_PARSE_THREADS")) nthr = static_cast<unsigned>(std::max(1, atoi(e)));
-    while (nthr > 1 && len / nthr < (1u << 20)) --nthr; // at least 1 MiB per thread
+    if (const char *e = getenv("MSGPU_PARSE_THREADS")) // (tests: any number of chunks at any size)
+      nthr = static_cast<unsigned>(std::min<size_t>(std::max(1, atoi(e)), std::max<size_t>(1, len)));
+    else
+      while (nthr > 1 && len / nthr < (1u << 20)) --nthr; // at least 1 MiB per thread
     std::vector<Chunk> chunks(nthr);
     const char        *end = data + len, *cur = data;
     for (unsigned t = 0; t < nthr; ++t) {
@@ -311,25 +363,95 @@ int msgpu_parse_paf(const char *path, const msgpu_params *params, msgpu_paf **ou
         break;
       }
     if (rc == MSGPU_OK) {
-      size_t total = 0;
-      for (auto &c : chunks) total += c.rows.size();
-      paf->rows.reserve(total);
-      for (auto &c : chunks)
-        for (const RawRow &r : c.rows) { // Registry in line order: nanopore id first (:110), then illumina (:111)
-          msgpu_row o;
-          o.read_id   = paf->reads.get(r.tname, r.tlen_name, r.thash);
-          o.anchor_id = paf->anchors.get(r.qname, r.qlen, r.qhash);
-          o.read_len  = r.read_len;
-          o.i_lo      = r.i_lo;
-          o.i_hi      = r.i_hi;
-          o.n_lo      = r.n_lo;
-          o.n_hi      = r.n_hi;
-          o.score     = r.score;
-          o.line      = r.line;
-          o.flags     = r.flags;
-          paf->rows.push_back(o);
+      // Registry ids = first-seen order over the whole file, line by line (:110-111), from the chunks' own lists: a name's
+      // id is its rank among the names' first appearances, and the first appearances of the file are, chunk after chunk,
+      // the names of that chunk's list no earlier chunk holds.
+      std::vector<int> bad(nthr, 0);
+      auto             guarded = [&](auto &&fn) {
+        run([&](unsigned t) {
+          try {
+            fn(t);
+          } catch (std::bad_alloc const &) { bad[t] = 1; }
+        });
+        for (int o : bad)
+          if (o) throw std::bad_alloc();
+      };
+      for (int which = 0; which < 2; ++which) {
+        auto          names_of = [&](Chunk &c) -> ChunkNames          &{ return which == 0 ? c.reads : c.anchors; };
+        NameRegistry &reg = which == 0 ? paf->reads : paf->anchors;
+        size_t        n_entries = 0;
+        for (auto &c : chunks) n_entries += names_of(c).list.size();
+        // (1) which entries are first appearances: thread t owns the names whose hash falls into its share and walks the
+        // lists in file order with an open-addressing table of its own
+        guarded([&](unsigned t) {
+          size_t cap = 1024;
+          while (cap < 4 * (n_entries / nthr + 1)) cap <<= 1;
+          std::vector<NameEntry *> slot(cap, nullptr);
+          size_t                   used = 0;
+          for (unsigned k = 0; k < nthr; ++k)
+            for (NameEntry &e : names_of(chunks[k]).list) {
+              if (nthr > 1 && static_cast<unsigned>((e.hash >> 40) % nthr) != t) continue;
+              if ((used + 1) * 2 > cap) { // (only a very uneven hash gets here)
+                std::vector<NameEntry *> ns(cap * 2, nullptr);
+                for (NameEntry *x : slot)
+                  if (x) {
+                    size_t i = x->hash & (cap * 2 - 1);
+                    while (ns[i]) i = (i + 1) & (cap * 2 - 1);
+                    ns[i] = x;
+                  }
+                slot.swap(ns);
+                cap *= 2;
+              }
+              size_t i = e.hash & (cap - 1);
+              for (; slot[i]; i = (i + 1) & (cap - 1)) {
+                const NameEntry *x = slot[i];
+                if (x->hash == e.hash && x->n == e.n && memcmp(x->s, e.s, e.n) == 0) break;
+              }
+              if (slot[i]) {
+                e.first = slot[i];
+              } else {
+                slot[i] = &e;
+                ++used;
+              }
+            }
+        });
+        // (2) ids of the first appearances, chunk after chunk; (3) every other entry takes the id of its first appearance
+        std::vector<uint32_t> base(nthr + 1, 0);
+        for (unsigned k = 0; k < nthr; ++k) {
+          uint32_t firsts = 0;
+          for (const NameEntry &e : names_of(chunks[k]).list) firsts += e.first == nullptr;
+          base[k + 1] = base[k] + firsts;
         }
+        reg.bulk_begin(base[nthr]);
+        guarded([&](unsigned k) {
+          uint32_t id = base[k];
+          for (NameEntry &e : names_of(chunks[k]).list)
+            if (!e.first) {
+              e.id = id++;
+              reg.set_name(e.id, e.s, e.n);
+            }
+        });
+        guarded([&](unsigned k) {
+          for (NameEntry &e : names_of(chunks[k]).list)
+            if (e.first) e.id = e.first->id;
+        });
+      }
       lap("registry");
+      // the rows of the file, chunk after chunk, with the file's ids
+      std::vector<size_t> row_base(nthr + 1, 0);
+      for (unsigned k = 0; k < nthr; ++k) row_base[k + 1] = row_base[k] + chunks[k].rows.size();
+      paf->rows.resize(row_base[nthr]);
+      guarded([&](unsigned k) {
+        const NameEntry *rd = chunks[k].reads.list.data(), *an = chunks[k].anchors.list.data();
+        msgpu_row       *o  = paf->rows.data() + row_base[k];
+        for (const msgpu_row &r : chunks[k].rows) {
+          *o           = r;
+          o->read_id   = rd[r.read_id].id;
+          o->anchor_id = an[r.anchor_id].id;
+          ++o;
+        }
+      });
+      lap("rows");
     }
   } catch (std::bad_alloc const &) { rc = MSGPU_E_NOMEM; } catch (std::system_error const &) {
     rc = MSGPU_E_NOMEM; // could not start a thread

@@ -18,6 +18,8 @@
 
 #include <algorithm>
 #include <cctype>
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
@@ -25,15 +27,39 @@
 #include <string_view>
 #include <system_error>
 #include <thread>
-#include <unordered_map>
 #include <vector>
 
 #include "msgpu.h"
 
+// The records' bytes live in ONE anonymous mapping as large as the file: a stretch of the file is stripped into the same
+// stretch of the mapping (stripping only removes bytes), so the parser threads write their records where they stay -- no
+// per-thread buffers, no merge copy, and the pages are first touched by the thread that fills them.  Between the records
+// lie the bytes the description lines, line ends and dropped duplicates took in the file.
+struct BaseBuffer {
+  char  *p   = nullptr;
+  size_t cap = 0;
+  BaseBuffer() = default;
+  BaseBuffer(const BaseBuffer &) = delete;
+  BaseBuffer &operator=(const BaseBuffer &) = delete;
+  ~BaseBuffer() {
+    if (p) munmap(p, cap);
+  }
+  void allocate(size_t bytes) {
+    if (!bytes) return;
+    void *m = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+    if (m == MAP_FAILED) throw std::bad_alloc();
+    madvise(m, bytes, MADV_HUGEPAGE); // 1.5 GB of first touches: 2 MiB pages where the kernel grants them
+    p   = static_cast<char *>(m);
+    cap = bytes;
+  }
+};
+
 struct msgpu_seqfile {
   std::vector<std::string> names; // cleaned ids, first-occurrence order
-  std::vector<uint64_t>    off;   // names.size() + 1 offsets into bases
-  std::string              bases;
+  std::vector<uint64_t>    off;   // per record: offset of its bytes in the buffer
+  std::vector<uint64_t>    len;   // per record: its length
+  BaseBuffer               bases;
+  uint64_t                 extent = 0; // end of the last record in the buffer
 };
 
 namespace {
@@ -79,42 +105,68 @@ inline bool has_byte_below_0x21(const char *p, size_t n) {
   return false;
 }
 
-struct ChunkRecords { // the records of one stretch of the file: off has names.size() + 1 entries into bases
-  std::vector<std::string> names;
-  std::vector<uint64_t>    off{0};
-  std::string              bases;
+struct Record { // one record of a stretch of the file; the name is a view into the file image
+  const char *name;
+  uint32_t    name_len;
+  uint32_t    duplicate; // set by the first-wins pass: an earlier record has this id
+  uint64_t    hash;      // FNV-1a of the name
+  uint64_t    off, len;  // the record's bytes in the file-sized buffer
 };
+struct ChunkRecords { // the records of one stretch of the file, in the order of the file
+  std::vector<Record> recs;
+  size_t              end = 0; // behind the last byte written (the records of a stretch lie back to back from its start)
+};
+
+inline uint64_t name_hash(const char *s, size_t n) {
+  uint64_t h = 1469598103934665603ull;
+  for (size_t i = 0; i < n; ++i) {
+    h ^= static_cast<unsigned char>(s[i]);
+    h *= 1099511628211ull;
+  }
+  return h;
+}
+
+constexpr size_t CUT_CROSSED = ~size_t(0); // parse_range: a record ran over the stretch's limit (the cut was not a record boundary)
 
 // The record loop of SequenceAccessor::_build*Idx + getSequenceFromFile (SequenceAccessor.cpp:54-69, 143-231) over
 // [begin, len): description lines at or behind `limit` are not taken.  -> the position of the description line it
-// stopped at (len at the end of the file).  Records with an id this stretch has seen already are dropped (first wins).
-size_t parse_range(const char *data, size_t len, size_t begin, size_t limit, char desc, char split, ChunkRecords &out) {
-  out.bases.reserve((limit > begin ? limit - begin : 0) + 16);
-  std::unordered_map<std::string, uint32_t> ids;
+// stopped at (len at the end of the file), CUT_CROSSED when a record's lines reach over `limit` (nothing is written behind
+// `limit`).  The records' bytes go to dst back to back from `begin` on: never ahead of the bytes they are read from.
+// Which of two records with one id stays (the first, unordered_map::emplace, :171) is decided afterwards, over the whole
+// file: a later duplicate's bytes lie unused between its neighbours.
+size_t parse_range(const char *data, size_t len, size_t begin, size_t limit, char desc, char split, char *dst,
+                   ChunkRecords &out) {
   LineReader rl{data, len};
   rl.pos   = begin;
   long ret = rl.next();
   while (ret != -1 && rl.line[0] != desc) ret = rl.next(); // :149-158
+  size_t w = begin;                                         // write cursor: <= the read position at any time
+  out.end  = begin;
   while (ret != -1 && rl.line[0] == desc) {                 // :160 (a last line starting with the description character would loop forever in the reference; EOF ends it here)
     const size_t at = static_cast<size_t>(rl.line - data);
     if (at >= limit) return at;
     size_t idl = 0;
     while (1 + idl < rl.line_len && !std::isspace(static_cast<unsigned char>(rl.line[1 + idl]))) ++idl;
-    std::string id(rl.line + 1, idl);
-    const bool  is_new = ids.emplace(id, static_cast<uint32_t>(out.names.size())).second;
-    if (is_new) out.names.push_back(std::move(id));
-    bool cut = false; // an embedded NUL ends the record (std::string(buffer.data()), :65-67)
-    while (true) {    // :167-179
+    Record r;
+    r.name      = rl.line + 1;
+    r.name_len  = static_cast<uint32_t>(idl);
+    r.duplicate = 0;
+    r.hash      = name_hash(r.name, idl);
+    r.off       = w;
+    bool cut    = false; // an embedded NUL ends the record (std::string(buffer.data()), :65-67)
+    while (true) {       // :167-179
       ret = rl.next();
       if (ret == -1 || rl.line[0] == split) break;
-      if (!is_new || cut) continue;
+      if (static_cast<size_t>(rl.line - data) >= limit) return CUT_CROSSED;
+      if (cut) continue;
       // strip std::isspace characters: the usual line is bases + '\n' (or "\r\n"), so trim the tail and copy the
       // rest with one memcpy when no other blank or NUL is inside; fall back to the byte loop otherwise
       const char *p = rl.line;
       size_t      n = rl.line_len;
       while (n && BLANK[static_cast<unsigned char>(p[n - 1])] == 1) --n;
       if (!has_byte_below_0x21(p, n)) { // no blank, no NUL, no control byte inside
-        out.bases.append(p, n);
+        memcpy(dst + w, p, n);
+        w += n;
       } else {
         for (size_t q = 0; q < n; ++q) {
           const unsigned char ch = static_cast<unsigned char>(p[q]);
@@ -122,14 +174,73 @@ size_t parse_range(const char *data, size_t len, size_t begin, size_t limit, cha
             cut = true;
             break;
           }
-          if (BLANK[ch] != 1) out.bases.push_back(static_cast<char>(ch));
+          if (BLANK[ch] != 1) dst[w++] = static_cast<char>(ch);
         }
       }
     }
-    if (is_new) out.off.push_back(out.bases.size());
+    r.len = w - r.off;
+    out.recs.push_back(r);
+    out.end = w;
     while (ret != -1 && rl.line[0] != desc) ret = rl.next(); // :181-184
   }
   return len;
+}
+
+// "of two records with the same id the first one wins" over all stretches, on nt threads: thread t owns the ids whose hash
+// falls into its share, walks every stretch in file order and keeps its ids in an open-addressing table of its own.
+void mark_duplicates(std::vector<ChunkRecords> &parts, unsigned nt) {
+  size_t n_all = 0;
+  for (auto &c : parts) n_all += c.recs.size();
+  if (nt > 1 && n_all < 4096) nt = 1;
+  auto share = [&](unsigned t) {
+    size_t cap = 1024;
+    while (cap < 4 * (n_all / nt + 1)) cap <<= 1;
+    std::vector<Record *> slot(cap, nullptr);
+    size_t                used = 0;
+    for (auto &c : parts)
+      for (Record &r : c.recs) {
+        if (nt > 1 && static_cast<unsigned>((r.hash >> 40) % nt) != t) continue;
+        if ((used + 1) * 2 > cap) { // (only a very uneven hash gets here)
+          std::vector<Record *> ns(cap * 2, nullptr);
+          for (Record *x : slot)
+            if (x) {
+              size_t i = x->hash & (cap * 2 - 1);
+              while (ns[i]) i = (i + 1) & (cap * 2 - 1);
+              ns[i] = x;
+            }
+          slot.swap(ns);
+          cap *= 2;
+        }
+        size_t i = r.hash & (cap - 1);
+        for (; slot[i]; i = (i + 1) & (cap - 1)) {
+          const Record *x = slot[i];
+          if (x->hash == r.hash && x->name_len == r.name_len && memcmp(x->name, r.name, r.name_len) == 0) break;
+        }
+        if (slot[i]) {
+          r.duplicate = 1;
+        } else {
+          slot[i] = &r;
+          ++used;
+        }
+      }
+  };
+  if (nt <= 1) {
+    nt = 1;
+    share(0);
+    return;
+  }
+  std::vector<std::thread> pool;
+  std::vector<int>         oom(nt, 0);
+  auto                     guarded = [&](unsigned t) {
+    try {
+      share(t);
+    } catch (std::bad_alloc const &) { oom[t] = 1; }
+  };
+  for (unsigned t = 1; t < nt; ++t) pool.emplace_back(guarded, t);
+  guarded(0);
+  for (auto &t : pool) t.join();
+  for (int o : oom)
+    if (o) throw std::bad_alloc();
 }
 
 bool is_fastq_name(const char *path) {
@@ -169,6 +280,14 @@ int msgpu_seq_parse(const char *path, int is_fastq, msgpu_seqfile **out) {
   if (is_fastq < 0) is_fastq = is_fastq_name(path) ? 1 : 0;
   const char desc = is_fastq ? '@' : '>', split = is_fastq ? '+' : '>';
 
+  const bool dbg = std::getenv("MSGPU_PARSE_DEBUG") != nullptr;
+  auto       t0  = std::chrono::steady_clock::now();
+  auto       lap = [&](const char *what) {
+    if (!dbg) return;
+    auto t1 = std::chrono::steady_clock::now();
+    fprintf(stderr, "msgpu_seq_parse %s: %-8s %.1f ms\n", path, what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+    t0 = t1;
+  };
   std::unique_ptr<msgpu_seqfile> f;
   try {
     f = std::make_unique<msgpu_seqfile>();
@@ -199,9 +318,11 @@ int msgpu_seq_parse(const char *path, int is_fastq, msgpu_seqfile **out) {
     std::vector<ChunkRecords> parts(nc);
     std::vector<size_t>       stops(nc, 0);
     std::vector<int>          oom(nc, 0);
-    auto                      work = [&](unsigned k) {
+    f->bases.allocate(len);
+    char *dst  = f->bases.p;
+    auto  work = [&](unsigned k) {
       try {
-        stops[k] = parse_range(data, len, starts[k], k + 1 < nc ? starts[k + 1] : len, desc, split, parts[k]);
+        stops[k] = parse_range(data, len, starts[k], k + 1 < nc ? starts[k + 1] : len, desc, split, dst, parts[k]);
       } catch (std::bad_alloc const &) { oom[k] = 1; }
     };
     {
@@ -212,45 +333,54 @@ int msgpu_seq_parse(const char *path, int is_fastq, msgpu_seqfile **out) {
     }
     for (int o : oom)
       if (o) throw std::bad_alloc();
+    lap("records");
     bool consistent = true;
     for (unsigned k = 0; k + 1 < nc; ++k) consistent = consistent && stops[k] == starts[k + 1];
     if (!consistent) { // (only a FASTQ whose quality lines start with '@' in unlucky places gets here)
       parts.assign(1, ChunkRecords());
-      parse_range(data, len, 0, len, desc, split, parts[0]);
+      parse_range(data, len, 0, len, desc, split, dst, parts[0]);
     }
-    // merge in file order: of two records with the same id the first one wins (unordered_map::emplace, :171)
-    std::unordered_map<std::string_view, uint32_t> ids;
-    std::vector<std::pair<uint32_t, uint32_t>>     kept; // (chunk, record) of every record that stays
-    uint64_t                                       total = 0;
-    f->off.push_back(0);
-    for (uint32_t c = 0; c < parts.size(); ++c)
-      for (uint32_t r = 0; r < parts[c].names.size(); ++r) {
-        if (parts.size() > 1 && !ids.emplace(std::string_view(parts[c].names[r]), 0u).second) continue;
-        kept.emplace_back(c, r);
-        total += parts[c].off[r + 1] - parts[c].off[r];
-        f->off.push_back(total);
+    // the records in file order, first occurrence of an id only (unordered_map::emplace, :171)
+    mark_duplicates(parts, nt);
+    lap("first-wins");
+    std::vector<size_t> base(parts.size() + 1, 0);
+    for (size_t k = 0; k < parts.size(); ++k) {
+      size_t kept = 0;
+      for (const Record &r : parts[k].recs) kept += !r.duplicate;
+      base[k + 1] = base[k] + kept;
+    }
+    f->names.resize(base.back());
+    f->off.resize(base.back());
+    f->len.resize(base.back());
+    auto fill = [&](size_t k) {
+      size_t i = base[k];
+      for (const Record &r : parts[k].recs) {
+        if (r.duplicate) continue;
+        f->names[i].assign(r.name, r.name_len);
+        f->off[i] = r.off;
+        f->len[i] = r.len;
+        ++i;
       }
-    if (parts.size() == 1) {
-      f->names = std::move(parts[0].names);
-      f->bases = std::move(parts[0].bases);
-    } else {
-      f->bases.resize(total);
-      f->names.resize(kept.size());
-      const size_t             nk = kept.size();
+    };
+    {
       std::vector<std::thread> pool;
-      auto                     copy = [&](size_t b, size_t e) {
-        for (size_t i = b; i < e; ++i) {
-          ChunkRecords &p = parts[kept[i].first];
-          const uint32_t r = kept[i].second;
-          f->names[i]      = std::move(p.names[r]);
-          memcpy(&f->bases[f->off[i]], p.bases.data() + p.off[r], p.off[r + 1] - p.off[r]);
-        }
+      std::vector<int>         bad(parts.size(), 0);
+      auto                     guarded = [&](size_t k) {
+        try {
+          fill(k);
+        } catch (std::bad_alloc const &) { bad[k] = 1; }
       };
-      ids.clear(); // (its keys view the names that are about to move)
-      for (unsigned t = 1; t < nt; ++t) pool.emplace_back(copy, nk * t / nt, nk * (t + 1) / nt);
-      copy(0, nk / nt);
+      for (size_t k = 1; k < parts.size(); ++k) pool.emplace_back(guarded, k);
+      guarded(0);
       for (auto &t : pool) t.join();
+      for (int o : bad)
+        if (o) throw std::bad_alloc();
     }
+    // what the description lines and line ends of a stretch took lies unused between its last record and the next
+    // stretch: filled with a base, so that the 2-bit form of the store (msgpu_seq_pack) sees no exceptional bytes there
+    for (size_t k = 0; k + 1 < parts.size(); ++k) memset(dst + parts[k].end, 'A', starts[k + 1] - parts[k].end);
+    f->extent = parts.empty() ? 0 : parts.back().end;
+    lap("merge");
   } catch (std::bad_alloc const &) {
     if (data) munmap(const_cast<char *>(data), len);
     return MSGPU_E_NOMEM;
@@ -268,11 +398,13 @@ uint32_t msgpu_seq_count(const msgpu_seqfile *f) { return f ? static_cast<uint32
 const char *msgpu_seq_name(const msgpu_seqfile *f, uint32_t i) {
   return f && i < f->names.size() ? f->names[i].c_str() : nullptr;
 }
-uint64_t msgpu_seq_length(const msgpu_seqfile *f, uint32_t i) {
-  return f && i < f->names.size() ? f->off[i + 1] - f->off[i] : 0;
-}
+uint64_t msgpu_seq_length(const msgpu_seqfile *f, uint32_t i) { return f && i < f->names.size() ? f->len[i] : 0; }
 const char *msgpu_seq_bases(const msgpu_seqfile *f, uint32_t i) {
-  return f && i < f->names.size() ? f->bases.data() + f->off[i] : nullptr;
+  return f && i < f->names.size() ? f->bases.p + f->off[i] : nullptr;
+}
+const char *msgpu_seq_buffer(const msgpu_seqfile *f, uint64_t *bytes) {
+  if (bytes) *bytes = f ? f->extent : 0;
+  return f ? f->bases.p : nullptr;
 }
 
 // strSlice (libms/src/SequenceUtils.cpp:27-38) as (offset, length): Python-like indices, INCLUSIVE clipped end.

@@ -33,30 +33,71 @@ def run(contigs_paf, unitigs_path, nanopore_path, out_dir, threads=None, wiggle_
 
     # SequenceAccessor::buildIndex: parsing the two sequence files is pure host work that needs nothing from the PAF -- one
     # thread per file, started before the PAF is read, beside the parser, the GPU and the graph stage (ctypes calls release
-    # the GIL).  Registry::operator[] for their records (SequenceAccessor.cpp:171,215) follows once the PAF's registries
-    # exist.  Every HIP call stays on this thread: the upload happens after the join.
+    # the GIL).  Each thread sends its file's bytes to HBM and converts them to the 2-bit form as soon as the file is parsed
+    # (the store has one stream per kind).  Registry::operator[] for the records (SequenceAccessor.cpp:171,215) follows on a
+    # third thread once the PAF's registries exist, beside the overlap and graph stages.
     seq = {}
+    store_ready = threading.Event()
 
-    def parse_file(key, path):
+    def parse_file(key, kind, path):
         t1 = time.perf_counter()
         try:
             seq[key] = SeqFile(path)
+            t["sequences_parse_" + key] = time.perf_counter() - t1
+            store_ready.wait()
+            t1 = time.perf_counter()
+            if "store" in seq:
+                seq["store"].upload_bases(kind, seq[key])
+                seq["store"].pack_store(kind)  # 2 bits per base + exception list: a quarter of the footprint, same bytes out
+            t["sequences_upload_" + key] = time.perf_counter() - t1
         except BaseException as e:  # re-raised on the main thread
             seq["error"] = e
-        t["sequences_parse_" + key] = time.perf_counter() - t1
 
-    loaders = [threading.Thread(target=parse_file, args=("nanopore", nanopore_path), name="msgpu-nanopore"),
-               threading.Thread(target=parse_file, args=("unitigs", unitigs_path), name="msgpu-unitigs")]
+    loaders = [threading.Thread(target=parse_file, args=("nanopore", NANOPORE, nanopore_path), name="msgpu-nanopore"),
+               threading.Thread(target=parse_file, args=("unitigs", ILLUMINA, unitigs_path), name="msgpu-unitigs")]
     for th in loaders:
         th.start()
+    t0 = time.perf_counter()
+    try:
+        seq["store"] = store = SeqStore(device=device)  # (the HIP runtime starts beside the parsers)
+    finally:
+        store_ready.set()
+    t["device_init"] = time.perf_counter() - t0
 
     t0 = time.perf_counter()
     paf = overlap.parse_paf(contigs_paf, params)
     t["parse_paf"] = time.perf_counter() - t0
 
+    n_reads, n_anchors = paf.n_reads, paf.n_anchors  # (the sequence files' records may add ids to the registries)
+
+    def register():
+        try:
+            for th in loaders:
+                th.join()
+            if "error" in seq:
+                return
+            t1 = time.perf_counter()
+
+            def one(kind, key):  # (two registries, two stores: the kinds do not meet)
+                try:
+                    store.set_ids(kind, seq[key], *paf.register_sequences(kind, seq[key]))
+                except BaseException as e:
+                    seq["error"] = e
+
+            other = threading.Thread(target=one, args=(ILLUMINA, "unitigs"), name="msgpu-registry-unitigs")
+            other.start()
+            one(NANOPORE, "nanopore")
+            other.join()
+            t["sequences_registry"] = time.perf_counter() - t1
+        except BaseException as e:
+            seq["error"] = e
+
+    registrar = threading.Thread(target=register, name="msgpu-registry")
+    registrar.start()
+
     t0 = time.perf_counter()
     ctx = overlap.OverlapContext(device=device, params=params)
-    ctx.set_id_space(paf.n_reads, paf.n_anchors)
+    ctx.set_id_space(n_reads, n_anchors)
     # the ThreadPool replacement (msgpu_overlap_batched_ex): rows -> HBM once, windows of owner reads on two streams, the
     # edge / order / id tables arrive in pinned host memory while later windows compute.  The EdgeMatch table (5/6 of the
     # bytes) stays in HBM: the graph stage never reads it, assemblePath only the path edges' (fetched below).
@@ -77,21 +118,10 @@ def run(contigs_paf, unitigs_path, nanopore_path, out_dir, threads=None, wiggle_
     t["path_edgematches"] = time.perf_counter() - t0
 
     t0 = time.perf_counter()
-    for th in loaders:
-        th.join()
+    registrar.join()
     t["sequences_wait"] = time.perf_counter() - t0
     if "error" in seq:
         raise seq["error"]
-    t0 = time.perf_counter()
-    fn, fi = seq["nanopore"], seq["unitigs"]
-    ids = (paf.register_sequences(NANOPORE, fn), paf.register_sequences(ILLUMINA, fi))
-    t["sequences_registry"] = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    store = SeqStore(device=device)
-    for kind, f, (ids_k, n) in zip((NANOPORE, ILLUMINA), (fn, fi), ids):
-        store.upload(kind, f, ids_k, n)
-    store.pack()  # 2 bits per base + exception list: a quarter of the footprint, less gather traffic, same bytes out
-    t["sequences_upload"] = time.perf_counter() - t0
 
     t0 = time.perf_counter()
     asm = Assembly(store)
@@ -105,9 +135,23 @@ def run(contigs_paf, unitigs_path, nanopore_path, out_dir, threads=None, wiggle_
     t["assemble"] = time.perf_counter() - t0
 
     t0 = time.perf_counter()
-    for which, name in ((0, "temp_1.target.fa"), (1, "temp_1.query.fa"), (2, "temp_1.align.paf")):
-        with open(os.path.join(out_dir, name), "wb") as f:
-            f.write(asm.text(which))
+    failed = []
+
+    def write_file(which, name):  # (write() releases the GIL: the three files go out side by side, straight from the library's buffers)
+        try:
+            with open(os.path.join(out_dir, name), "wb") as f:
+                f.write(asm.text_view(which))
+        except BaseException as e:
+            failed.append(e)
+
+    writers = [threading.Thread(target=write_file, args=a) for a in ((0, "temp_1.target.fa"), (1, "temp_1.query.fa"))]
+    for th in writers:
+        th.start()
+    write_file(2, "temp_1.align.paf")
+    for th in writers:
+        th.join()
+    if failed:
+        raise failed[0]
     t["write"] = time.perf_counter() - t0
     info = asm.paths
     out = {"rows": len(paf.rows), "reads": int(counts.n_reads), "anchors": int(counts.n_anchors),

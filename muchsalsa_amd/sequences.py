@@ -51,6 +51,12 @@ class SeqFile:
     def length(self, i):
         return int(self._L.msgpu_seq_length(self._h, i))
 
+    def buffer(self):
+        """the bytes msgpu_seq_upload sends to HBM: every record's bases plus what lies between them (msgpu_seq_buffer)"""
+        n = C.c_uint64()
+        p = self._L.msgpu_seq_buffer(self._h, C.byref(n))
+        return C.string_at(p, n.value) if n.value else b""
+
 
 def str_slice(size, start, end):
     n = C.c_uint64()
@@ -132,6 +138,21 @@ class SeqStore:
             self._check(self._L.msgpu_seq_upload(self._h, kind, seqfile._h, ids.ctypes.data, int(n_ids)))
         else:
             self._check(self._L.msgpu_seq_upload(self._h, kind, seqfile._h, None, 0))
+
+    def upload_bases(self, kind, seqfile):
+        """first half of upload: the file's bytes (callable from the thread that parsed the file, one kind per thread)"""
+        self._check(self._L.msgpu_seq_upload_bases(self._h, kind, seqfile._h))
+
+    def set_ids(self, kind, seqfile, ids=None, n_ids=0):
+        """second half of upload: ids[record] = Registry id of every record of the same file"""
+        if ids is not None:
+            ids = np.ascontiguousarray(ids, dtype="<u4")
+            self._check(self._L.msgpu_seq_set_ids(self._h, kind, seqfile._h, ids.ctypes.data, int(n_ids)))
+        else:
+            self._check(self._L.msgpu_seq_set_ids(self._h, kind, seqfile._h, None, 0))
+
+    def pack_store(self, kind):
+        self._check(self._L.msgpu_seq_pack_store(self._h, kind))
 
     def upload_device(self, kind, d_bases_ptr, n_bases, off, length):
         off = np.ascontiguousarray(off, dtype="<u8")

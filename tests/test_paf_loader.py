@@ -118,3 +118,30 @@ def test_register_sequences_follows_the_registry(tmp_path):
     idu, spu = p.register_sequences(1, sequences.SeqFile(str(fu)))
     assert list(idu) == [1, 2, 0] and spu == 3
     assert p.read_names == ["r7", "r3"]  # the view's name lists are the PAF's own registrations
+
+
+@pytest.mark.parametrize("threads", [2, 3, 7, 16, 64])
+def test_chunked_parse_keeps_the_registry_order(oracle, tmp_path, monkeypatch, threads):
+    """The file is parsed in chunks on several threads, each with its own name lists; the Registry ids of the whole file
+    (first-seen order, line by line, BlastFileReader.cpp:110-111) are worked out from those lists.  Same rows, ids and name
+    tables as the one-thread parse and the oracle for any number of chunks -- with names that return in later chunks,
+    rejected lines (their names register nothing), and look-ups of further names afterwards (the registry's hash index is
+    built at the first look-up)."""
+    from muchsalsa_amd import sequences
+    rng = np.random.default_rng(threads)
+    lines = []
+    for i in range(3000):
+        q, t = "u%d" % rng.integers(0, 400), "read_%d" % rng.integers(0, 150)
+        nm = int(rng.choice([550, 20]))  # (20 < MINIMUM_MATCHES: the line is dropped before the Registry sees it)
+        lines.append(_line(q=q, t=t, ts=int(rng.integers(0, 3000)), te=int(rng.integers(3000, 5000)), nm=nm))
+    path = _write(tmp_path, lines + [SENTINEL])
+    want = oracle.parse_paf(path)
+    monkeypatch.setenv("MSGPU_PARSE_THREADS", str(threads))
+    got = overlap.parse_paf(path)
+    assert got.rows.tobytes() == want["rows"].tobytes() and got.n_lines == want["n_lines"]
+    assert got.read_names == want["read_names"] and got.anchor_names == want["anchor_names"]
+    fa = tmp_path / "n.fa"
+    fa.write_bytes(b">read_3\nAC\n>brand_new\nGG\n>" + want["read_names"][-1].encode() + b"\nTT\n")
+    ids, space = got.register_sequences(0, sequences.SeqFile(str(fa)))
+    n = len(want["read_names"])
+    assert list(ids) == [want["read_names"].index("read_3"), n, n - 1] and space == n + 1

@@ -97,8 +97,13 @@ def test_chunked_parse_equals_sequential(oracle, tmp_path, monkeypatch, threads)
         monkeypatch.setenv("MSGPU_SEQ_THREADS", "1")
         want = _records(sequences.SeqFile(path))
         monkeypatch.setenv("MSGPU_SEQ_THREADS", str(threads))
-        got = _records(sequences.SeqFile(path))
+        f = sequences.SeqFile(path)
+        got = _records(f)
         assert got == want, (name, threads)
+        # what goes to HBM: the records where they lie in ONE buffer, nothing but bases between them (the 2-bit form of the
+        # store keeps a list of every other byte)
+        buf = f.buffer()
+        assert len(buf) <= len(text) and (name == "evil.fq" or set(buf) <= set(b"ACGTN")), (name, threads)
         o_names, o_seqs = oracle.seq_load(path)
         assert got == (o_names, o_seqs), (name, "oracle")
     assert len(_records(sequences.SeqFile(_write(tmp_path, "m2.fa", fa)))[0]) == len({b"r%d" % (i if i % 37 else i // 2) for i in range(400)})
