@@ -358,6 +358,7 @@ const char *msgpu_seq_bases(const msgpu_seqfile *f, uint32_t record);  /* not NU
 /* the one buffer every record's bytes lie in (msgpu_seq_bases points into it; records need not touch each other) and
  * its used size: what msgpu_seq_upload copies to HBM */
 const char *msgpu_seq_buffer(const msgpu_seqfile *f, uint64_t *bytes);
+uint64_t    msgpu_seq_offset(const msgpu_seqfile *f, uint32_t record);  /* of the record's bytes inside that buffer */
 
 /* strSlice (SequenceUtils.cpp:27-38) as (returned offset, *len): Python-like indices, INCLUSIVE clipped end. */
 uint64_t msgpu_str_slice(uint64_t size, int32_t start, int32_t end, uint64_t *len);
@@ -375,6 +376,11 @@ int msgpu_seq_upload(msgpu_seqctx *ctx, int kind, const msgpu_seqfile *f, const 
  * be sent (and converted, msgpu_seq_pack_store) from two host threads at the same time --, the ids of the SAME file once
  * the registries exist (MSGPU_E_STATE when the store holds another file's bytes). */
 int msgpu_seq_upload_bases(msgpu_seqctx *ctx, int kind, const msgpu_seqfile *f);
+/* msgpu_seq_parse + msgpu_seq_upload_bases in one pass over the file: the parser's threads strip the records into a ring
+ * of page-locked slots that travel to the store while the file is still being read; the host never holds the bases.  The
+ * msgpu_seqfile that comes back has names, lengths and offsets (msgpu_seq_set_ids and msgpu_paf_register_sequences take
+ * it) but no bytes: msgpu_seq_bases and msgpu_seq_buffer return NULL for it. */
+int msgpu_seq_parse_upload(msgpu_seqctx *ctx, int kind, const char *path, int is_fastq, msgpu_seqfile **out);
 int msgpu_seq_set_ids(msgpu_seqctx *ctx, int kind, const msgpu_seqfile *f, const uint32_t *ids, uint32_t n_ids);
 
 /* Same from a device buffer that already holds the whitespace-free bases (copied device-to-device into the store):

@@ -144,6 +144,8 @@ SYMBOLS = [
     ("msgpu_seq_pack", C.c_int, [C.c_void_p]),
     ("msgpu_seq_pack_store", C.c_int, [C.c_void_p, C.c_int]),
     ("msgpu_seq_upload_bases", C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    ("msgpu_seq_parse_upload", C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]),
+    ("msgpu_seq_offset", C.c_uint64, [C.c_void_p, C.c_uint32]),
     ("msgpu_seq_set_ids", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_uint32]),
     ("msgpu_seq_resolve", C.c_int, [C.c_void_p, C.c_int, C.c_uint32, C.c_int32, C.c_int32, C.c_int, C.c_void_p]),
     ("msgpu_seg_anchor", C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int, C.c_void_p,

@@ -73,6 +73,25 @@ template <class T> struct HostTableAlloc { // std::allocator for such tables
   template <class U> bool operator==(const HostTableAlloc<U> &) const noexcept { return true; }
   template <class U> bool operator!=(const HostTableAlloc<U> &) const noexcept { return false; }
 };
+// Where the whitespace-free bytes of a sequence file go while it is parsed (seq_loader.cpp): the loader's own host buffer
+// (msgpu_seq_parse) or, through a ring of page-locked slots, straight to a store in HBM (msgpu_seq_parse_upload).  The
+// file is parsed in stretches on several threads; stretch k writes ascending positions of [start of the stretch in the
+// file, start of the next one).
+struct ByteSink {
+  virtual void put(uint64_t at, const char *p, size_t n) = 0;
+  virtual void done() {} // the stretch is over: nothing more comes
+  virtual ~ByteSink() = default;
+};
+struct SeqDestination {
+  virtual void      prepare(uint64_t file_bytes, unsigned n_stretches) = 0; // before the first byte (may throw std::bad_alloc)
+  virtual ByteSink *stretch(unsigned k) = 0;            // owned by the destination; used by one thread at a time
+  virtual void      restart() = 0;                      // the cuts did not verify: what came so far is void, stretch(0) takes the whole file
+  virtual void      fill(uint64_t from, uint64_t to) = 0; // bytes no record uses, between two stretches: they must read as bases
+  virtual int       finish(uint64_t extent) = 0;        // everything is in (extent = end of the last record) -> MSGPU_OK or the error met on the way
+  virtual ~SeqDestination() = default;
+};
+// msgpu_seq_parse with the bytes going to dst (nullptr: a host buffer inside the msgpu_seqfile)
+int seq_parse_into(const char *path, int is_fastq, SeqDestination *dst, msgpu_seqfile **out);
 // Toggle::operator* (include/ms/types/Toggle.h:127-153): the product of two toggles is their XNOR
 inline bool toggle_mul(bool a, bool b) { return a == b; }
 // header lines of the FASTA records, reference spelling (ap.cpp:1035-1040, 1059-1066, 1118-1125, 1175-1182, 1309-1318)

@@ -8,6 +8,7 @@
 // which here become one kernel over a list of copy pieces {source range, orientation, destination}.  Sequences stay
 // resident in HBM one byte per base (exact: N, lower case and IUPAC codes survive; only A,C,G,T are complemented).
 // HBM-bound byte work: 16 B per lane, aligned 16-B stores, unaligned source handled with v_alignbyte.
+#include <atomic>
 #include <hip/hip_runtime.h>
 
 #include <memory>
@@ -323,6 +324,8 @@ struct SeqStore {
   void                 *d_buf = nullptr; // SEQ_PAD + bases + SEQ_PAD (freed by msgpu_seq_pack)
   uint64_t              n_bases = 0;
   hipStream_t           stream = nullptr; // uploads and the 2-bit conversion of THIS store (the two stores may be filled from two host threads)
+  void                 *ring = nullptr;   // page-locked slots of msgpu_seq_parse_upload (kept for the next file)
+  size_t                ring_bytes = 0;
   // 2-bit form (msgpu_seq_pack): 16 words of zero padding, (n_bases + 15) / 16 words, 16 words of padding
   void    *d_words = nullptr, *d_exc_pos = nullptr, *d_exc_byte = nullptr;
   uint64_t n_exc = 0;
@@ -427,6 +430,7 @@ void msgpu_seq_destroy(msgpu_seqctx *c) {
       (void)hipStreamDestroy(s.stream);
     }
     if (s.d_buf) (void)hipFree(s.d_buf);
+    if (s.ring) (void)hipHostFree(s.ring);
     s.drop_packed();
   }
   for (msgpu_seqctx::Scratch *x : {&c->scr_text, &c->scr_recs, &c->scr_map, &c->scr_hdr})
@@ -445,6 +449,7 @@ int msgpu_seq_upload_bases(msgpu_seqctx *c, int kind, const msgpu_seqfile *f) {
   SeqStore &s = c->st[kind];
   uint64_t  total = 0; // the records' bytes go up as they lie in the loader's buffer (with what lies between them)
   const char *first = msgpu_seq_buffer(f, &total);
+  if (total && !first && c->device >= 0) return MSGPU_E_ARG; // (a file of msgpu_seq_parse_upload: its bytes are in a store already)
   s.off.clear();
   s.len.clear();
   s.n_bases = total;
@@ -464,14 +469,142 @@ int msgpu_seq_upload_bases(msgpu_seqctx *c, int kind, const msgpu_seqfile *f) {
   return MSGPU_OK;
 }
 
+namespace {
+// msgpu_seq_parse_upload: every parser thread strips its stretch of the file into page-locked slots of a few MiB, and a
+// full slot goes to its place in HBM (the position its bytes have in the file-sized layout of seq_loader.cpp) while the
+// thread fills the next one.  The host never holds the file's bases: no gigabyte of first-touch page faults, nothing to
+// give back afterwards, and the copy engine works while the file is still being read.
+constexpr size_t RING_SLOT  = size_t(4) << 20;
+constexpr int    RING_SLOTS = 2; // per stretch
+struct DeviceDestination final : msgpu::SeqDestination {
+  struct Sink final : msgpu::ByteSink {
+    DeviceDestination *d = nullptr;
+    char              *slot[RING_SLOTS] = {nullptr};
+    hipEvent_t         ev[RING_SLOTS]   = {nullptr};
+    bool               busy[RING_SLOTS] = {false};
+    int                cur = 0;
+    size_t             fill = 0;
+    uint64_t           at0 = 0; // position of slot[cur][0]
+    void flush() {
+      if (!fill) return;
+      hipError_t e = hipMemcpyAsync(d->d_bases + at0, slot[cur], fill, hipMemcpyHostToDevice, d->stream);
+      if (e == hipSuccess) e = hipEventRecord(ev[cur], d->stream);
+      if (e != hipSuccess) d->fail(e);
+      busy[cur] = true;
+      at0 += fill;
+      fill = 0;
+      cur  = (cur + 1) % RING_SLOTS;
+      if (busy[cur]) { // the slot we are about to fill again must have left
+        e = hipEventSynchronize(ev[cur]);
+        if (e != hipSuccess) d->fail(e);
+        busy[cur] = false;
+      }
+    }
+    void put(uint64_t at, const char *p, size_t n) override {
+      if (at != at0 + fill) { // (a stretch writes back to back; a jump can only be the start of the stretch)
+        flush();
+        at0 = at;
+      }
+      while (n) {
+        const size_t k = std::min(n, RING_SLOT - fill);
+        memcpy(slot[cur] + fill, p, k);
+        fill += k;
+        p += k;
+        n -= k;
+        if (fill == RING_SLOT) flush();
+      }
+    }
+    void done() override { flush(); }
+  };
+  msgpu_seqctx     *c;
+  SeqStore         &s;
+  hipStream_t       stream;
+  uint8_t          *d_bases = nullptr;
+  std::vector<Sink> sinks;
+  std::atomic<int>  err{hipSuccess};
+  DeviceDestination(msgpu_seqctx *ctx, SeqStore &st) : c(ctx), s(st), stream(st.stream) {}
+  ~DeviceDestination() override {
+    for (Sink &k : sinks)
+      for (hipEvent_t e : k.ev)
+        if (e) (void)hipEventDestroy(e);
+  }
+  void fail(hipError_t e) {
+    int none = hipSuccess;
+    err.compare_exchange_strong(none, static_cast<int>(e));
+  }
+  void prepare(uint64_t file_bytes, unsigned n) override {
+    if (hipSetDevice(c->device) != hipSuccess) throw std::bad_alloc();
+    s.off.clear();
+    s.len.clear();
+    s.n_bases = 0;
+    s.drop_packed();
+    if (s.d_buf) {
+      (void)hipFree(s.d_buf);
+      s.d_buf = nullptr;
+    }
+    if (hipMalloc(&s.d_buf, file_bytes + 2 * SEQ_PAD) != hipSuccess) throw std::bad_alloc();
+    d_bases = static_cast<uint8_t *>(s.d_buf) + SEQ_PAD;
+    // what no record uses (description lines, line ends) must read as bases: the 2-bit form lists every other byte
+    hipError_t e = hipMemsetAsync(s.d_buf, 0, SEQ_PAD, stream);
+    if (e == hipSuccess && file_bytes) e = hipMemsetAsync(d_bases, 'A', file_bytes, stream);
+    if (e != hipSuccess) fail(e);
+    const size_t want = size_t(n) * RING_SLOTS * RING_SLOT;
+    if (s.ring_bytes < want) {
+      if (s.ring) (void)hipHostFree(s.ring);
+      s.ring       = nullptr;
+      s.ring_bytes = 0;
+      if (hipHostMalloc(&s.ring, want, hipHostMallocDefault) != hipSuccess) throw std::bad_alloc();
+      s.ring_bytes = want;
+    }
+    sinks.resize(n);
+    for (unsigned k = 0; k < n; ++k) {
+      sinks[k].d = this;
+      for (int q = 0; q < RING_SLOTS; ++q) {
+        sinks[k].slot[q] = static_cast<char *>(s.ring) + (size_t(k) * RING_SLOTS + q) * RING_SLOT;
+        if (hipEventCreateWithFlags(&sinks[k].ev[q], hipEventDisableTiming) != hipSuccess) throw std::bad_alloc();
+      }
+    }
+  }
+  msgpu::ByteSink *stretch(unsigned k) override {
+    (void)hipSetDevice(c->device); // (called on the thread that is about to fill the stretch)
+    return &sinks[k];
+  }
+  void restart() override {
+    for (Sink &k : sinks) { // (every stretch has called done(): nothing is half filled)
+      k.at0  = 0;
+      k.fill = 0;
+    }
+    // what the stretches sent is overwritten by the one pass that follows, in stream order
+  }
+  void fill(uint64_t, uint64_t) override {} // (the whole buffer was filled with a base before the first byte arrived)
+  int  finish(uint64_t extent) override {
+    hipError_t e = hipMemsetAsync(d_bases + extent, 0, SEQ_PAD, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    if (e != hipSuccess) fail(e);
+    if (err.load() != hipSuccess) return sfail(c, MSGPU_E_HIP, "msgpu_seq_parse_upload", static_cast<hipError_t>(err.load()));
+    s.n_bases = extent;
+    return MSGPU_OK;
+  }
+};
+} // namespace
+
+int msgpu_seq_parse_upload(msgpu_seqctx *c, int kind, const char *path, int is_fastq, msgpu_seqfile **out) {
+  if (!c || !path || !out || kind < 0 || kind > 1) return MSGPU_E_ARG;
+  if (c->device < 0) return MSGPU_E_NODEVICE;
+  try {
+    DeviceDestination dst(c, c->st[kind]);
+    return msgpu::seq_parse_into(path, is_fastq, &dst, out);
+  } catch (std::bad_alloc const &) { return MSGPU_E_NOMEM; }
+}
+
 int msgpu_seq_set_ids(msgpu_seqctx *c, int kind, const msgpu_seqfile *f, const uint32_t *ids, uint32_t n_ids) {
   if (!c || !f || kind < 0 || kind > 1) return MSGPU_E_ARG;
   SeqStore      &s = c->st[kind];
   const uint32_t n = msgpu_seq_count(f);
   uint32_t       space = ids ? n_ids : n;
   uint64_t       total = 0;
-  const char    *first = msgpu_seq_buffer(f, &total);
-  if (total != s.n_bases) { // not the file msgpu_seq_upload_bases sent
+  (void)msgpu_seq_buffer(f, &total);
+  if (total != s.n_bases) { // not the file msgpu_seq_upload_bases / msgpu_seq_parse_upload sent
     snprintf(c->err, sizeof(c->err), "msgpu_seq_set_ids: the store holds %llu bytes, the file %llu",
              static_cast<unsigned long long>(s.n_bases), static_cast<unsigned long long>(total));
     return MSGPU_E_STATE;
@@ -485,7 +618,7 @@ int msgpu_seq_set_ids(msgpu_seqctx *c, int kind, const msgpu_seqfile *f, const u
   for (uint32_t i = 0; i < n; ++i) {
     const uint32_t id = ids ? ids[i] : i;
     if (id != 0xffffffffu && s.off[id] == ~0ull) { // emplace: the first record of an id wins
-      s.off[id] = static_cast<uint64_t>(msgpu_seq_bases(f, i) - first);
+      s.off[id] = msgpu_seq_offset(f, i);
       s.len[id] = msgpu_seq_length(f, i);
     }
   }

@@ -29,6 +29,7 @@
 #include <thread>
 #include <vector>
 
+#include "asm_internal.h"
 #include "msgpu.h"
 
 // The records' bytes live in ONE anonymous mapping as large as the file: a stretch of the file is stripped into the same
@@ -36,22 +37,33 @@
 // per-thread buffers, no merge copy, and the pages are first touched by the thread that fills them.  Between the records
 // lie the bytes the description lines, line ends and dropped duplicates took in the file.
 struct BaseBuffer {
-  char  *p   = nullptr;
+  char  *p   = nullptr; // 2 MiB aligned
   size_t cap = 0;
   BaseBuffer() = default;
   BaseBuffer(const BaseBuffer &) = delete;
   BaseBuffer &operator=(const BaseBuffer &) = delete;
   ~BaseBuffer() {
-    if (p) munmap(p, cap);
+    // in slices: giving back a gigabyte of small pages takes the address-space lock for tens of milliseconds, and every
+    // other thread that maps or pins memory meanwhile (the HIP runtime does) would wait for all of it
+    constexpr size_t SLICE = size_t(8) << 20;
+    for (size_t o = 0; o < m_len; o += SLICE) munmap(m_raw + o, std::min(SLICE, m_len - o));
   }
   void allocate(size_t bytes) {
     if (!bytes) return;
-    void *m = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+    constexpr size_t HUGE = size_t(2) << 20;
+    const size_t     want = ((bytes + HUGE - 1) & ~(HUGE - 1)) + HUGE;
+    void            *m    = mmap(nullptr, want, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
     if (m == MAP_FAILED) throw std::bad_alloc();
-    madvise(m, bytes, MADV_HUGEPAGE); // 1.5 GB of first touches: 2 MiB pages where the kernel grants them
-    p   = static_cast<char *>(m);
-    cap = bytes;
+    m_raw = static_cast<char *>(m);
+    m_len = want;
+    p     = reinterpret_cast<char *>((reinterpret_cast<uintptr_t>(m_raw) + HUGE - 1) & ~(uintptr_t(HUGE) - 1));
+    cap   = bytes;
+    madvise(p, want - HUGE, MADV_HUGEPAGE); // 1.5 GB of first touches: 2 MiB pages where the kernel grants them
   }
+
+private:
+  char  *m_raw = nullptr;
+  size_t m_len = 0;
 };
 
 struct msgpu_seqfile {
@@ -105,7 +117,7 @@ inline bool has_byte_below_0x21(const char *p, size_t n) {
   return false;
 }
 
-struct Record { // one record of a stretch of the file; the name is a view into the file image
+struct Record { // one record of a stretch of the file; the name lies in the stretch's own name block
   const char *name;
   uint32_t    name_len;
   uint32_t    duplicate; // set by the first-wins pass: an earlier record has this id
@@ -114,7 +126,11 @@ struct Record { // one record of a stretch of the file; the name is a view into 
 };
 struct ChunkRecords { // the records of one stretch of the file, in the order of the file
   std::vector<Record> recs;
+  std::string         names; // the ids one after the other (the file image is given back as soon as a stretch is parsed)
   size_t              end = 0; // behind the last byte written (the records of a stretch lie back to back from its start)
+  void                bind_names() { // once nothing is appended any more: Record::name = offset -> pointer
+    for (Record &r : recs) r.name = names.data() + reinterpret_cast<uintptr_t>(r.name);
+  }
 };
 
 inline uint64_t name_hash(const char *s, size_t n) {
@@ -131,10 +147,10 @@ constexpr size_t CUT_CROSSED = ~size_t(0); // parse_range: a record ran over the
 // The record loop of SequenceAccessor::_build*Idx + getSequenceFromFile (SequenceAccessor.cpp:54-69, 143-231) over
 // [begin, len): description lines at or behind `limit` are not taken.  -> the position of the description line it
 // stopped at (len at the end of the file), CUT_CROSSED when a record's lines reach over `limit` (nothing is written behind
-// `limit`).  The records' bytes go to dst back to back from `begin` on: never ahead of the bytes they are read from.
+// `limit`).  The records' bytes go to dst at positions back to back from `begin` on: never ahead of the bytes they are read from.
 // Which of two records with one id stays (the first, unordered_map::emplace, :171) is decided afterwards, over the whole
 // file: a later duplicate's bytes lie unused between its neighbours.
-size_t parse_range(const char *data, size_t len, size_t begin, size_t limit, char desc, char split, char *dst,
+size_t parse_range(const char *data, size_t len, size_t begin, size_t limit, char desc, char split, msgpu::ByteSink &dst,
                    ChunkRecords &out) {
   LineReader rl{data, len};
   rl.pos   = begin;
@@ -148,10 +164,11 @@ size_t parse_range(const char *data, size_t len, size_t begin, size_t limit, cha
     size_t idl = 0;
     while (1 + idl < rl.line_len && !std::isspace(static_cast<unsigned char>(rl.line[1 + idl]))) ++idl;
     Record r;
-    r.name      = rl.line + 1;
+    r.name      = reinterpret_cast<const char *>(static_cast<uintptr_t>(out.names.size())); // (offset until bind_names)
     r.name_len  = static_cast<uint32_t>(idl);
     r.duplicate = 0;
-    r.hash      = name_hash(r.name, idl);
+    r.hash      = name_hash(rl.line + 1, idl);
+    out.names.append(rl.line + 1, idl);
     r.off       = w;
     bool cut    = false; // an embedded NUL ends the record (std::string(buffer.data()), :65-67)
     while (true) {       // :167-179
@@ -165,7 +182,7 @@ size_t parse_range(const char *data, size_t len, size_t begin, size_t limit, cha
       size_t      n = rl.line_len;
       while (n && BLANK[static_cast<unsigned char>(p[n - 1])] == 1) --n;
       if (!has_byte_below_0x21(p, n)) { // no blank, no NUL, no control byte inside
-        memcpy(dst + w, p, n);
+        dst.put(w, p, n);
         w += n;
       } else {
         for (size_t q = 0; q < n; ++q) {
@@ -174,7 +191,10 @@ size_t parse_range(const char *data, size_t len, size_t begin, size_t limit, cha
             cut = true;
             break;
           }
-          if (BLANK[ch] != 1) dst[w++] = static_cast<char>(ch);
+          if (BLANK[ch] != 1) {
+            const char one = static_cast<char>(ch);
+            dst.put(w++, &one, 1);
+          }
         }
       }
     }
@@ -243,6 +263,23 @@ void mark_duplicates(std::vector<ChunkRecords> &parts, unsigned nt) {
     if (o) throw std::bad_alloc();
 }
 
+struct HostDestination final : msgpu::SeqDestination { // the loader's own buffer, as large as the file
+  struct Sink final : msgpu::ByteSink {
+    char *base = nullptr;
+    void  put(uint64_t at, const char *p, size_t n) override { memcpy(base + at, p, n); }
+  } sink;
+  BaseBuffer &buf;
+  explicit HostDestination(BaseBuffer &b) : buf(b) {}
+  void prepare(uint64_t file_bytes, unsigned) override {
+    buf.allocate(file_bytes);
+    sink.base = buf.p;
+  }
+  msgpu::ByteSink *stretch(unsigned) override { return &sink; } // (positions of different stretches do not meet)
+  void             restart() override {}
+  void             fill(uint64_t from, uint64_t to) override { memset(buf.p + from, 'A', to - from); }
+  int              finish(uint64_t) override { return MSGPU_OK; }
+};
+
 bool is_fastq_name(const char *path) {
   std::string_view p(path);
   size_t           dot = p.find_last_of('.');
@@ -253,9 +290,7 @@ bool is_fastq_name(const char *path) {
 
 } // namespace
 
-extern "C" {
-
-int msgpu_seq_parse(const char *path, int is_fastq, msgpu_seqfile **out) {
+int msgpu::seq_parse_into(const char *path, int is_fastq, msgpu::SeqDestination *dest, msgpu_seqfile **out) {
   if (!path || !out) return MSGPU_E_ARG;
   *out   = nullptr;
   int fd = open(path, O_RDONLY | O_CLOEXEC);
@@ -318,11 +353,23 @@ int msgpu_seq_parse(const char *path, int is_fastq, msgpu_seqfile **out) {
     std::vector<ChunkRecords> parts(nc);
     std::vector<size_t>       stops(nc, 0);
     std::vector<int>          oom(nc, 0);
-    f->bases.allocate(len);
-    char *dst  = f->bases.p;
-    auto  work = [&](unsigned k) {
+    HostDestination host(f->bases);
+    if (!dest) dest = &host;
+    lap("cuts");
+    dest->prepare(len, nc);
+    lap("prepare");
+    auto work = [&](unsigned k) {
       try {
-        stops[k] = parse_range(data, len, starts[k], k + 1 < nc ? starts[k + 1] : len, desc, split, dst, parts[k]);
+        msgpu::ByteSink &sink = *dest->stretch(k);
+        const size_t     lim  = k + 1 < nc ? starts[k + 1] : len;
+        stops[k] = parse_range(data, len, starts[k], lim, desc, split, sink, parts[k]);
+        sink.done();
+        parts[k].bind_names();
+        // the pages of this stretch leave the mapping here, on this thread: taking a gigabyte of page-cache pages out of
+        // the address space is tens of milliseconds of work, done on one thread if it is left to the final munmap
+        const size_t page = static_cast<size_t>(sysconf(_SC_PAGESIZE));
+        const size_t lo = (starts[k] + page - 1) / page * page, hi = lim / page * page;
+        if (hi > lo) madvise(const_cast<char *>(data) + lo, hi - lo, MADV_DONTNEED);
       } catch (std::bad_alloc const &) { oom[k] = 1; }
     };
     {
@@ -338,7 +385,11 @@ int msgpu_seq_parse(const char *path, int is_fastq, msgpu_seqfile **out) {
     for (unsigned k = 0; k + 1 < nc; ++k) consistent = consistent && stops[k] == starts[k + 1];
     if (!consistent) { // (only a FASTQ whose quality lines start with '@' in unlucky places gets here)
       parts.assign(1, ChunkRecords());
-      parse_range(data, len, 0, len, desc, split, dst, parts[0]);
+      dest->restart();
+      msgpu::ByteSink &sink = *dest->stretch(0);
+      parse_range(data, len, 0, len, desc, split, sink, parts[0]);
+      sink.done();
+      parts[0].bind_names();
     }
     // the records in file order, first occurrence of an id only (unordered_map::emplace, :171)
     mark_duplicates(parts, nt);
@@ -378,9 +429,24 @@ int msgpu_seq_parse(const char *path, int is_fastq, msgpu_seqfile **out) {
     }
     // what the description lines and line ends of a stretch took lies unused between its last record and the next
     // stretch: filled with a base, so that the 2-bit form of the store (msgpu_seq_pack) sees no exceptional bytes there
-    for (size_t k = 0; k + 1 < parts.size(); ++k) memset(dst + parts[k].end, 'A', starts[k + 1] - parts[k].end);
+    for (size_t k = 0; k + 1 < parts.size(); ++k)
+      if (starts[k + 1] > parts[k].end) dest->fill(parts[k].end, starts[k + 1]);
     f->extent = parts.empty() ? 0 : parts.back().end;
+    const int drc = dest->finish(f->extent);
+    lap("finish");
+    if (drc != MSGPU_OK) {
+      if (data) munmap(const_cast<char *>(data), len);
+      return drc;
+    }
     lap("merge");
+    if (dbg) { // how much of the process' anonymous memory sits in 2 MiB pages right now
+      if (FILE *fp = fopen("/proc/self/smaps_rollup", "r")) {
+        char line[256];
+        while (fgets(line, sizeof line, fp))
+          if (!strncmp(line, "AnonHugePages:", 14) || !strncmp(line, "Anonymous:", 10)) fprintf(stderr, "  %s", line);
+        fclose(fp);
+      }
+    }
   } catch (std::bad_alloc const &) {
     if (data) munmap(const_cast<char *>(data), len);
     return MSGPU_E_NOMEM;
@@ -393,6 +459,10 @@ int msgpu_seq_parse(const char *path, int is_fastq, msgpu_seqfile **out) {
   return MSGPU_OK;
 }
 
+extern "C" {
+
+int msgpu_seq_parse(const char *path, int is_fastq, msgpu_seqfile **out) { return msgpu::seq_parse_into(path, is_fastq, nullptr, out); }
+
 void msgpu_seq_free(msgpu_seqfile *f) { delete f; }
 uint32_t msgpu_seq_count(const msgpu_seqfile *f) { return f ? static_cast<uint32_t>(f->names.size()) : 0; }
 const char *msgpu_seq_name(const msgpu_seqfile *f, uint32_t i) {
@@ -400,8 +470,9 @@ const char *msgpu_seq_name(const msgpu_seqfile *f, uint32_t i) {
 }
 uint64_t msgpu_seq_length(const msgpu_seqfile *f, uint32_t i) { return f && i < f->names.size() ? f->len[i] : 0; }
 const char *msgpu_seq_bases(const msgpu_seqfile *f, uint32_t i) {
-  return f && i < f->names.size() ? f->bases.p + f->off[i] : nullptr;
+  return f && i < f->names.size() && f->bases.p ? f->bases.p + f->off[i] : nullptr;
 }
+uint64_t msgpu_seq_offset(const msgpu_seqfile *f, uint32_t i) { return f && i < f->names.size() ? f->off[i] : 0; }
 const char *msgpu_seq_buffer(const msgpu_seqfile *f, uint64_t *bytes) {
   if (bytes) *bytes = f ? f->extent : 0;
   return f ? f->bases.p : nullptr;

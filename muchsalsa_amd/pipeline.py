@@ -33,36 +33,40 @@ def run(contigs_paf, unitigs_path, nanopore_path, out_dir, threads=None, wiggle_
 
     # SequenceAccessor::buildIndex: parsing the two sequence files is pure host work that needs nothing from the PAF -- one
     # thread per file, started before the PAF is read, beside the parser, the GPU and the graph stage (ctypes calls release
-    # the GIL).  Each thread sends its file's bytes to HBM and converts them to the 2-bit form as soon as the file is parsed
-    # (the store has one stream per kind).  Registry::operator[] for the records (SequenceAccessor.cpp:171,215) follows on a
+    # the GIL).  A file's bytes travel to HBM while it is parsed (msgpu_seq_parse_upload: the host never holds them) and are
+    # converted to the 2-bit form there (the store has one stream per kind).  Registry::operator[] for the records (SequenceAccessor.cpp:171,215) follows on a
     # third thread once the PAF's registries exist, beside the overlap and graph stages.
     seq = {}
     store_ready = threading.Event()
 
     def parse_file(key, kind, path):
-        t1 = time.perf_counter()
         try:
-            seq[key] = SeqFile(path)
-            t["sequences_parse_" + key] = time.perf_counter() - t1
             store_ready.wait()
+            if "store" not in seq:
+                return
             t1 = time.perf_counter()
-            if "store" in seq:
-                seq["store"].upload_bases(kind, seq[key])
-                seq["store"].pack_store(kind)  # 2 bits per base + exception list: a quarter of the footprint, same bytes out
-            t["sequences_upload_" + key] = time.perf_counter() - t1
+            seq[key] = seq["store"].parse_upload(kind, path)  # records -> page-locked ring -> HBM while the file is read
+            t["sequences_parse_" + key] = time.perf_counter() - t1
+            t1 = time.perf_counter()
+            seq["store"].pack_store(kind)  # 2 bits per base + exception list: a quarter of the footprint, same bytes out
+            t["sequences_pack_" + key] = time.perf_counter() - t1
         except BaseException as e:  # re-raised on the main thread
             seq["error"] = e
 
     loaders = [threading.Thread(target=parse_file, args=("nanopore", NANOPORE, nanopore_path), name="msgpu-nanopore"),
                threading.Thread(target=parse_file, args=("unitigs", ILLUMINA, unitigs_path), name="msgpu-unitigs")]
-    for th in loaders:
+    def make_store():  # (the HIP runtime starts here, beside the PAF parser)
+        t1 = time.perf_counter()
+        try:
+            seq["store"] = SeqStore(device=device)
+        except BaseException as e:
+            seq["error"] = e
+        finally:
+            store_ready.set()
+        t["device_init"] = time.perf_counter() - t1
+
+    for th in [threading.Thread(target=make_store, name="msgpu-device")] + loaders:
         th.start()
-    t0 = time.perf_counter()
-    try:
-        seq["store"] = store = SeqStore(device=device)  # (the HIP runtime starts beside the parsers)
-    finally:
-        store_ready.set()
-    t["device_init"] = time.perf_counter() - t0
 
     t0 = time.perf_counter()
     paf = overlap.parse_paf(contigs_paf, params)
@@ -77,6 +81,7 @@ def run(contigs_paf, unitigs_path, nanopore_path, out_dir, threads=None, wiggle_
             if "error" in seq:
                 return
             t1 = time.perf_counter()
+            store = seq["store"]
 
             def one(kind, key):  # (two registries, two stores: the kinds do not meet)
                 try:
@@ -122,6 +127,7 @@ def run(contigs_paf, unitigs_path, nanopore_path, out_dir, threads=None, wiggle_
     t["sequences_wait"] = time.perf_counter() - t0
     if "error" in seq:
         raise seq["error"]
+    store = seq["store"]
 
     t0 = time.perf_counter()
     asm = Assembly(store)
@@ -153,6 +159,7 @@ def run(contigs_paf, unitigs_path, nanopore_path, out_dir, threads=None, wiggle_
     if failed:
         raise failed[0]
     t["write"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
     info = asm.paths
     out = {"rows": len(paf.rows), "reads": int(counts.n_reads), "anchors": int(counts.n_anchors),
            "edges": int(counts.n_edges), "orders": int(counts.n_orders),
@@ -160,7 +167,17 @@ def run(contigs_paf, unitigs_path, nanopore_path, out_dir, threads=None, wiggle_
            "edges_after_cleanup": int(st.n_edges), "components": int(st.n_components), "paths": int(st.n_paths),
            "paths_skipped": int((status != 0).sum()), "contigs": int(len(info)),
            "target_bases": int(info["target_len"].sum()) if len(info) else 0, "queries": int(len(asm.queries))}
+    t["collect"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    asm.close()
+    asm._rows_keep = None
+    t["teardown_asm"] = time.perf_counter() - t0
+    store.close()
+    for key in ("nanopore", "unitigs"):
+        seq[key].close()
+    t["teardown_store"] = time.perf_counter() - t0
+    del paf, tables  # (the loader's table goes with its last view)
+    t["teardown"] = time.perf_counter() - t0
     if timings is not None:
         timings.update(t)
-    store.close()
     return out

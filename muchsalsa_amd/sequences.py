@@ -22,9 +22,12 @@ NANOPORE, ILLUMINA = 0, 1
 
 
 class SeqFile:
-    def __init__(self, path, is_fastq=-1):
+    def __init__(self, path, is_fastq=-1, _handle=None):
         self._L = _lib.lib()
         self._h = C.c_void_p()
+        if _handle is not None:  # (SeqStore.parse_upload: names, lengths and offsets only -- the bytes went to HBM)
+            self._h = _handle
+            return
         rc = self._L.msgpu_seq_parse(os.fsencode(path), is_fastq, C.byref(self._h))
         if rc != 0:
             self._h = C.c_void_p()
@@ -55,7 +58,7 @@ class SeqFile:
         """the bytes msgpu_seq_upload sends to HBM: every record's bases plus what lies between them (msgpu_seq_buffer)"""
         n = C.c_uint64()
         p = self._L.msgpu_seq_buffer(self._h, C.byref(n))
-        return C.string_at(p, n.value) if n.value else b""
+        return C.string_at(p, n.value) if n.value and p else b""  # (no bytes on the host after SeqStore.parse_upload)
 
 
 def str_slice(size, start, end):
@@ -138,6 +141,13 @@ class SeqStore:
             self._check(self._L.msgpu_seq_upload(self._h, kind, seqfile._h, ids.ctypes.data, int(n_ids)))
         else:
             self._check(self._L.msgpu_seq_upload(self._h, kind, seqfile._h, None, 0))
+
+    def parse_upload(self, kind, path, is_fastq=-1):
+        """msgpu_seq_parse_upload: parse the file and send its bytes to this store in one pass (page-locked ring, no host
+        copy of the bases) -> SeqFile without bytes, for Paf.register_sequences + set_ids"""
+        h = C.c_void_p()
+        self._check(self._L.msgpu_seq_parse_upload(self._h, kind, os.fsencode(path), is_fastq, C.byref(h)))
+        return SeqFile(path, _handle=h)
 
     def upload_bases(self, kind, seqfile):
         """first half of upload: the file's bytes (callable from the thread that parsed the file, one kind per thread)"""

@@ -218,3 +218,46 @@ def test_segment_builders_through_the_gather_kernel(oracle, tmp_path):
                 emit(ps, oseq)
         got = _run(store, np.concatenate(pieces))
         assert got == b"".join(want)
+
+
+@pytest.mark.parametrize("threads", [1, 3, 8])
+def test_parse_upload_equals_parse_then_upload(tmp_path, monkeypatch, threads):
+    """msgpu_seq_parse_upload strips the records into a ring of page-locked slots that travel to HBM while the file is
+    read (any number of parser threads; records far longer than a slot; duplicates; a FASTQ whose cuts do not verify and
+    is parsed a second time in one pass): same names and lengths as msgpu_seq_parse, and every record read back from the
+    store -- byte-per-base or 2-bit -- is the host parser's record."""
+    from muchsalsa_amd import sequences as S
+    rng = np.random.default_rng(threads)
+    alphabet = np.frombuffer(b"ACGTACGTACGTNacgt", dtype=np.uint8)
+
+    def seq(n):
+        return alphabet[rng.integers(0, len(alphabet), int(n))].tobytes()
+    fa = b"junk\n"
+    for i in range(60):
+        s = seq(rng.choice([0, 7, 900, 70_000, 1_300_000]) if i % 9 else 5_000_000)  # 5 MB > one 4 MiB slot
+        name = b"r%d" % (i if i % 13 else i // 2)  # some ids come twice: the first record wins
+        fa += b">" + name + b" x\n" + (b"\n".join(s[k:k + 20_011] for k in range(0, len(s), 20_011)) if i % 2 else s) + b"\n"
+    evil = b""
+    for i in range(400):  # quality lines that start with '@': the cuts land on them and the file takes the one-pass route
+        s = seq(rng.integers(1, 3000))
+        evil += b"@e%d\n" % i + s + b"\n+\n@" + b"F" * (len(s) - 1) + b"\n"
+    monkeypatch.setenv("MSGPU_SEQ_THREADS", str(threads))
+    for name, text in (("big.fa", fa), ("evil.fq", evil), ("none.fa", b"")):
+        path = tmp_path / name
+        path.write_bytes(text)
+        host = S.SeqFile(str(path))
+        with S.SeqStore(0) as store:
+            dev = store.parse_upload(S.NANOPORE, str(path))
+            assert dev.names == host.names and [dev.length(i) for i in range(len(dev))] == [host.length(i) for i in range(len(host))]
+            assert dev.buffer() == b""  # (no bytes on the host)
+            store.set_ids(S.NANOPORE, dev)
+            if not len(host):
+                continue
+            pieces, off = [], 0
+            for i in range(len(host)):
+                n = host.length(i)
+                if n:
+                    pieces.append(store.resolve(S.NANOPORE, i, 0, n, True, dst_off=off))
+                    off += n
+            got = _run(store, np.array(pieces))
+            assert got == b"".join(host.sequence(i) for i in range(len(host))), (name, threads)
