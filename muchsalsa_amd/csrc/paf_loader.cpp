@@ -140,7 +140,7 @@ namespace {
 // The names of one chunk of the file (one list per registry), in the order the chunk meets them: what the Registry would
 // hold had the file begun with this chunk.  The ids of the whole file follow from these lists (assign_ids below).
 struct NameEntry {
-  const char      *s; // view into the mmap'ed file
+  const char      *s; // in the chunk's own name block (an offset into it until ChunkNames::bind)
   uint32_t         n;
   uint32_t         id;    // Registry id (set by assign_ids)
   uint64_t         hash;
@@ -148,19 +148,27 @@ struct NameEntry {
 };
 class ChunkNames {
 public:
+  void set_shares(unsigned n) { share.assign(n, {}); }
   uint32_t get(const char *s, uint32_t n, uint64_t h) { // position of the name in the chunk's list
     if ((list.size() + 1) * 2 > m_slots.size()) grow();
     size_t i = h & (m_slots.size() - 1);
     for (; m_slots[i]; i = (i + 1) & (m_slots.size() - 1)) {
       const NameEntry &e = list[m_slots[i] - 1];
-      if (e.hash == h && e.n == n && memcmp(e.s, s, n) == 0) return m_slots[i] - 1;
+      if (e.hash == h && e.n == n && memcmp(m_block.data() + reinterpret_cast<uintptr_t>(e.s), s, n) == 0) return m_slots[i] - 1;
     }
-    list.push_back(NameEntry{s, n, 0, h, nullptr});
+    list.push_back(NameEntry{reinterpret_cast<const char *>(static_cast<uintptr_t>(m_block.size())), n, 0, h, nullptr});
+    m_block.append(s, n); // (the file image is given back as soon as the chunk is parsed)
     m_slots[i] = static_cast<uint32_t>(list.size());
+    share[share_of(h, static_cast<unsigned>(share.size()))].push_back(static_cast<uint32_t>(list.size() - 1));
     return static_cast<uint32_t>(list.size() - 1);
   }
-  void drop_index() { std::vector<uint32_t>().swap(m_slots); }
-  std::vector<NameEntry> list;
+  void bind() { // the chunk is parsed: offsets -> pointers, the look-up table goes
+    for (NameEntry &e : list) e.s = m_block.data() + reinterpret_cast<uintptr_t>(e.s);
+    std::vector<uint32_t>().swap(m_slots);
+  }
+  static unsigned share_of(uint64_t h, unsigned n) { return static_cast<unsigned>((h >> 40) % n); }
+  std::vector<NameEntry>             list;
+  std::vector<std::vector<uint32_t>> share; // share[t]: the positions of the names thread t looks after (by hash), ascending
 
 private:
   void grow() {
@@ -174,6 +182,7 @@ private:
     m_slots.swap(ns);
   }
   std::vector<uint32_t> m_slots; // position + 1
+  std::string           m_block;
 };
 
 struct Chunk {
@@ -348,12 +357,37 @@ int msgpu_parse_paf(const char *path, const msgpu_params *params, msgpu_paf **ou
     paf->n_lines          = n_lines;
     const size_t last     = n_lines ? n_lines - 1 : 0;
     std::vector<int> oom(nthr, 0);
+    // (the row table is page-locked memory when a GPU is present, and locking 200 MB takes as long as a fifth of the
+    // parse: room for every line is made on a thread of its own meanwhile)
+    int         reserve_failed = 0;
+    std::thread reserve([&] {
+      try {
+        paf->rows.reserve(n_lines);
+      } catch (std::bad_alloc const &) { reserve_failed = 1; }
+    });
+    struct Joiner { // (run() may throw before the join below)
+      std::thread &t;
+      ~Joiner() {
+        if (t.joinable()) t.join();
+      }
+    } join_reserve{reserve};
+    const size_t page = static_cast<size_t>(sysconf(_SC_PAGESIZE));
     run([&](unsigned t) {
       try {
-        if (n_lines) parse_chunk(chunks[t], last, p);
+        Chunk &c = chunks[t];
+        c.reads.set_shares(nthr);
+        c.anchors.set_shares(nthr);
+        if (n_lines) parse_chunk(c, last, p);
+        c.reads.bind();
+        c.anchors.bind();
+        // this chunk's pages leave the mapping here, on this thread (the final munmap would do all of them on one)
+        const size_t lo = (static_cast<size_t>(c.begin - data) + page - 1) / page * page, hi = static_cast<size_t>(c.end - data) / page * page;
+        if (hi > lo) madvise(const_cast<char *>(data) + lo, hi - lo, MADV_DONTNEED);
       } catch (std::bad_alloc const &) { oom[t] = 1; }
     });
+    reserve.join();
     lap("tokenise");
+    if (reserve_failed) throw std::bad_alloc();
     for (unsigned t = 0; t < nthr; ++t)
       if (oom[t]) throw std::bad_alloc();
     // the reference stops at the first bad line in line order
@@ -389,8 +423,8 @@ int msgpu_parse_paf(const char *path, const msgpu_params *params, msgpu_paf **ou
           std::vector<NameEntry *> slot(cap, nullptr);
           size_t                   used = 0;
           for (unsigned k = 0; k < nthr; ++k)
-            for (NameEntry &e : names_of(chunks[k]).list) {
-              if (nthr > 1 && static_cast<unsigned>((e.hash >> 40) % nthr) != t) continue;
+            for (uint32_t at : names_of(chunks[k]).share[t]) {
+              NameEntry &e = names_of(chunks[k]).list[at];
               if ((used + 1) * 2 > cap) { // (only a very uneven hash gets here)
                 std::vector<NameEntry *> ns(cap * 2, nullptr);
                 for (NameEntry *x : slot)

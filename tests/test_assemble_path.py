@@ -29,7 +29,10 @@ def world(oracle, tmp_path_factory):
     w.store = SeqStore(device=-1)  # layout-only: offsets and lengths, nothing can be gathered
     w.store.upload(NANOPORE, w.files[0])
     w.store.upload(ILLUMINA, w.files[1])
-    w.flat = (b"".join(w.nano[i] for i in range(len(w.nano))), b"".join(w.illu[i] for i in range(len(w.illu))))
+    # what a device store would hold: the loader's buffer as it is (a file parsed in several stretches leaves unused
+    # bytes between them, so this is not the concatenation of the records)
+    w.flat = (w.files[0].buffer(), w.files[1].buffer())
+    assert all(w.files[0].sequence(i) == w.nano[i] for i in range(len(w.nano)))
     return w
 
 

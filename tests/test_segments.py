@@ -16,9 +16,11 @@ def _store(tmp_path, reads, unis):
     write(tmp_path / "r.fa", reads, "r")
     write(tmp_path / "u.fa", unis, "u")
     st = S.SeqStore(device=-1)  # layout-only: no device needed
-    st.upload(S.NANOPORE, S.SeqFile(str(tmp_path / "r.fa")))
-    st.upload(S.ILLUMINA, S.SeqFile(str(tmp_path / "u.fa")))
-    return st, (b"".join(reads), b"".join(unis))
+    fr, fu = S.SeqFile(str(tmp_path / "r.fa")), S.SeqFile(str(tmp_path / "u.fa"))
+    st.upload(S.NANOPORE, fr)
+    st.upload(S.ILLUMINA, fu)
+    # (what a device store would hold: the loader's buffer as it is -- a file parsed in stretches has unused bytes between them)
+    return st, (fr.buffer(), fu.buffer())
 
 
 @pytest.mark.parametrize("seed", [1, 2, 3])
