@@ -742,8 +742,9 @@ def e2e_leg(args, w, tab, read_names_all, threads):
             "counts": res, "input_bytes": in_bytes, "output_bytes": out_bytes, "threads": threads,
             "input_generation_s_untimed": t_gen, "tmpdir": "tmpfs" if base else "disk",
             "stage": "muchsalsa_amd.pipeline.run: PAF text + unitig FASTA + read FASTA in -> temp_1.{target.fa, query.fa, "
-                     "align.paf} out; both rates are over the WHOLE run (parse, overlap, graph, sequences, assemblePath, write); "
-                     "sequences_parse runs on a second thread beside overlap + graph"}
+                     "align.paf} out; both rates are over the WHOLE run (parse, overlap, graph, sequences, assemblePath, write, teardown); "
+                     "sequences_parse_* (file -> page-locked ring -> HBM) and sequences_pack_* run on one thread per file beside "
+                     "parse_paf, sequences_registry on another beside overlap + graph: they overlap the other stages"}
 
 
 # ---- N > 1: start the ranks -------------------------------------------------------------------------------------------------

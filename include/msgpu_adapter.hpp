@@ -264,9 +264,10 @@ inline AssemblyCounts assemble(std::string const &contigsPaf, std::string const 
   AssemblyCounts n;
   OverlapCore    core(device, wiggleRoom);
 
-  struct Seq { // :161-163 -- parsing the two sequence files needs nothing from the PAF: one thread per file, started before
-               // the PAF is read, beside the parser, the GPU and the graph stage; every HIP call stays on the calling
-               // thread (upload after the join)
+  struct Seq { // :161-163 -- the two sequence files need nothing from the PAF: one thread per file, started before the PAF
+               // is read, beside the parser, the GPU and the graph stage.  A file's bytes travel to HBM while it is parsed
+               // (msgpu_seq_parse_upload: page-locked ring, the host never holds the bases; one stream per kind) and are
+               // converted to the 2-bit form there; the Registry ids of the records follow once the PAF is read.
     msgpu_seqctx   *ctx = nullptr;
     msgpu_seqfile  *fn = nullptr, *fi = nullptr;
     msgpu_assembly *as = nullptr;
@@ -277,17 +278,16 @@ inline AssemblyCounts assemble(std::string const &contigsPaf, std::string const 
       msgpu_seq_destroy(ctx);
     }
   } s;
+  detail::require(msgpu_seq_create(device, &s.ctx), "msgpu_seq_create");
   std::exception_ptr loadError[2];
-  std::thread        loaders[2] = {std::thread([&]() {
-                                try {
-                                  detail::require(msgpu_seq_parse(nanoporePath.c_str(), -1, &s.fn), "nanopore file");
-                                } catch (...) { loadError[0] = std::current_exception(); }
-                              }),
-                              std::thread([&]() {
-                                try {
-                                  detail::require(msgpu_seq_parse(unitigsPath.c_str(), 0, &s.fi), "unitig file");
-                                } catch (...) { loadError[1] = std::current_exception(); }
-                              })};
+  auto               load = [&](int kind, std::string const &path, int isFastq, msgpu_seqfile **f, char const *what) {
+    try {
+      detail::require(msgpu_seq_parse_upload(s.ctx, kind, path.c_str(), isFastq, f), what, msgpu_seq_last_error(s.ctx));
+      detail::require(msgpu_seq_pack_store(s.ctx, kind), "msgpu_seq_pack_store", msgpu_seq_last_error(s.ctx)); // 2 bits per base in HBM
+    } catch (...) { loadError[kind] = std::current_exception(); }
+  };
+  std::thread loaders[2] = {std::thread([&]() { load(0, nanoporePath, -1, &s.fn, "nanopore file"); }),
+                            std::thread([&]() { load(1, unitigsPath, 0, &s.fi, "unitig file"); })};
   struct Joiner {
     std::thread (&t)[2];
     ~Joiner() {
@@ -335,11 +335,9 @@ inline AssemblyCounts assemble(std::string const &contigsPaf, std::string const 
     if (e) std::rethrow_exception(e);
   std::uint32_t                    readSpace = 0, anchorSpace = 0;
   std::vector<std::uint32_t> const readIds = core.registerSequences(0, s.fn, &readSpace), anchorIds = core.registerSequences(1, s.fi, &anchorSpace);
-  detail::require(msgpu_seq_create(device, &s.ctx), "msgpu_seq_create");
-  detail::require(msgpu_seq_upload(s.ctx, 0, s.fn, readIds.data(), readSpace), "upload reads", msgpu_seq_last_error(s.ctx));
-  detail::require(msgpu_seq_upload(s.ctx, 1, s.fi, anchorIds.data(), anchorSpace), "upload unitigs",
+  detail::require(msgpu_seq_set_ids(s.ctx, 0, s.fn, readIds.data(), readSpace), "ids of the reads", msgpu_seq_last_error(s.ctx));
+  detail::require(msgpu_seq_set_ids(s.ctx, 1, s.fi, anchorIds.data(), anchorSpace), "ids of the unitigs",
                   msgpu_seq_last_error(s.ctx));
-  detail::require(msgpu_seq_pack(s.ctx), "msgpu_seq_pack", msgpu_seq_last_error(s.ctx)); // 2 bits per base in HBM
 
   detail::require(msgpu_assembly_create(s.ctx, &s.as), "msgpu_assembly_create"); // :300-310, 620-677
   detail::require(msgpu_assembly_borrow_rows(s.as, rows, nRows), "msgpu_assembly_borrow_rows"); // (the loader's table: core outlives s.as)

@@ -116,6 +116,10 @@ class Assembly:
         return out
 
     @property
+    def query_count(self):
+        return int(self._L.msgpu_assembly_query_count(self._h))
+
+    @property
     def pieces(self):
         n = self._L.msgpu_assembly_pieces(self._h, None, 0)
         out = np.zeros(n, dtype=COPY_DTYPE)

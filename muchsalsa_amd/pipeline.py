@@ -135,8 +135,20 @@ def run(contigs_paf, unitigs_path, nanopore_path, out_dir, threads=None, wiggle_
     status = asm.add_prepared_batch([(g.path_input(i), g) for i in range(g.path_count)], n_threads) \
         if g.path_count else np.zeros(0, dtype=np.int32)
     st = g.stats
-    g.close()
-    ctx.close()  # (the graph had borrowed the context's pinned result tables: the context outlives it)
+    n_rows = len(paf.rows)
+    held = [g, ctx, paf, tables]
+    del paf, tables
+    asm._rows_keep = None  # (the layout is done: nothing reads the borrowed row table any more)
+
+    def release():
+        # the graph, the overlap context (device tables, page-locked result tables: the graph had borrowed them, so it goes
+        # first) and the loader's page-locked row table are done with: they go back beside the gather and the writes
+        held[0].close()
+        held[1].close()
+        del held[:]
+
+    releaser = threading.Thread(target=release, name="msgpu-release")
+    releaser.start()
     asm.finish()
     t["assemble"] = time.perf_counter() - t0
 
@@ -161,22 +173,19 @@ def run(contigs_paf, unitigs_path, nanopore_path, out_dir, threads=None, wiggle_
     t["write"] = time.perf_counter() - t0
     t0 = time.perf_counter()
     info = asm.paths
-    out = {"rows": len(paf.rows), "reads": int(counts.n_reads), "anchors": int(counts.n_anchors),
+    out = {"rows": n_rows, "reads": int(counts.n_reads), "anchors": int(counts.n_anchors),
            "edges": int(counts.n_edges), "orders": int(counts.n_orders),
            "contraction_edges": int((contraction >= 0).sum()), "vertices_after_cleanup": int(st.n_vertices),
            "edges_after_cleanup": int(st.n_edges), "components": int(st.n_components), "paths": int(st.n_paths),
            "paths_skipped": int((status != 0).sum()), "contigs": int(len(info)),
-           "target_bases": int(info["target_len"].sum()) if len(info) else 0, "queries": int(len(asm.queries))}
+           "target_bases": int(info["target_len"].sum()) if len(info) else 0, "queries": asm.query_count}
     t["collect"] = time.perf_counter() - t0
     t0 = time.perf_counter()
     asm.close()
-    asm._rows_keep = None
-    t["teardown_asm"] = time.perf_counter() - t0
     store.close()
     for key in ("nanopore", "unitigs"):
         seq[key].close()
-    t["teardown_store"] = time.perf_counter() - t0
-    del paf, tables  # (the loader's table goes with its last view)
+    releaser.join()
     t["teardown"] = time.perf_counter() - t0
     if timings is not None:
         timings.update(t)
