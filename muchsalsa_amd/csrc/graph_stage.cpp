@@ -401,6 +401,57 @@ std::vector<std::vector<uint32_t>> connected_components(uint32_t nv, const Csr &
   return comps;
 }
 
+// The same components for a large graph, on the stage's threads: lock-free union-find over the arcs e_ok accepts (the
+// larger root goes under the smaller, so a tree's root is its lowest vertex), then the components are numbered in the order
+// the scan above meets them -- by their first vertex v_ok accepts -- and every vertex whose tree has a number joins it,
+// vertices ascending (the scan's members come in search order; nothing downstream reads that order).
+template <class VOk, class EOk, class SetComp>
+std::vector<std::vector<uint32_t>> connected_components_parallel(uint32_t nv, const Csr &adj, VOk v_ok, EOk e_ok, SetComp set_comp) {
+  std::unique_ptr<std::atomic<uint32_t>[]> parent(new std::atomic<uint32_t>[nv]);
+  parallel_chunks(nv, [&](unsigned, size_t b, size_t e) {
+    for (size_t v = b; v < e; ++v) parent[v].store(static_cast<uint32_t>(v), std::memory_order_relaxed);
+  });
+  auto find = [&](uint32_t x) {
+    for (;;) {
+      uint32_t p = parent[x].load(std::memory_order_relaxed);
+      if (p == x) return x;
+      const uint32_t gp = parent[p].load(std::memory_order_relaxed);
+      if (gp != p) parent[x].compare_exchange_weak(p, gp, std::memory_order_relaxed); // path halving (a lost race changes nothing)
+      x = gp;
+    }
+  };
+  parallel_dynamic(nv, 1024, [&](size_t b, size_t e) {
+    for (size_t v = b; v < e; ++v)
+      for (const Arc *t = adj.begin(static_cast<uint32_t>(v)); t != adj.end(static_cast<uint32_t>(v)); ++t) {
+        if (t->to <= v || !e_ok(t)) continue; // (every undirected edge has an arc at both ends)
+        uint32_t x = static_cast<uint32_t>(v), y = t->to;
+        for (;;) {
+          x = find(x);
+          y = find(y);
+          if (x == y) break;
+          if (x < y) std::swap(x, y); // x: the larger root
+          uint32_t expect = x;
+          if (parent[x].compare_exchange_strong(expect, y, std::memory_order_relaxed)) break;
+        }
+      }
+  });
+  std::vector<uint32_t> cid(nv, NIL);
+  uint32_t              n_comp = 0;
+  for (uint32_t s = 0; s < nv; ++s) {
+    if (!v_ok(s)) continue;
+    const uint32_t r = find(s);
+    if (cid[r] == NIL) cid[r] = n_comp++;
+  }
+  std::vector<std::vector<uint32_t>> comps(n_comp);
+  for (uint32_t v = 0; v < nv; ++v) {
+    const uint32_t c = cid[find(v)];
+    if (c == NIL) continue;
+    set_comp(v, c);
+    comps[c].push_back(v);
+  }
+  return comps;
+}
+
 // DiGraph::sortTopologically (Graph.cpp:359-395): vertices without predecessors are collected in ascending id and
 // taken from the BACK of that list; a vertex whose last predecessor has just been emitted goes on top.  Vertices on a
 // cycle never appear.  `alive` (per arc's edge index, optional) and `valive` (per vertex, optional) are tombstones.
@@ -1670,10 +1721,13 @@ int msgpu_graph_linearize(msgpu_graph *g) {
     g->every_alive_edge_kept = unkept == 0;
     tick("arc flags");
     const Arc *const arcs0 = g->adj.arcs.data();
-    const std::vector<std::vector<uint32_t>> comps = connected_components(
-        g->nv, g->adj, [&](uint32_t v) { return g->V[v].alive != 0; },
-        [&](const Arc *t) { return (arc_flags[t - arcs0] & 5) == 5; }, // alive and with a consensus direction
-        [&](uint32_t v) { return g->V[v].comp; }, [&](uint32_t v, uint32_t c) { g->V[v].comp = c; });
+    auto v_ok = [&](uint32_t v) { return g->V[v].alive != 0; };
+    auto e_ok = [&](const Arc *t) { return (arc_flags[t - arcs0] & 5) == 5; }; // alive and with a consensus direction
+    auto set_comp = [&](uint32_t v, uint32_t c) { g->V[v].comp = c; };
+    const std::vector<std::vector<uint32_t>> comps =
+        g->nv >= par_min() && stage_threads() > 1
+            ? connected_components_parallel(g->nv, g->adj, v_ok, e_ok, set_comp)
+            : connected_components(g->nv, g->adj, v_ok, e_ok, [&](uint32_t v) { return g->V[v].comp; }, set_comp);
     g->stats.n_components = comps.size();
     tick("components");
     // Components are independent (a component only orients and reads its own vertices and edges): largest first on the
