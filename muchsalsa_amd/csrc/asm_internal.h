@@ -61,6 +61,14 @@ namespace msgpu {
 // runs at link speed; plain memory otherwise (parsing without a GPU).  Never null: throws std::bad_alloc.
 void *host_table_alloc(size_t bytes);
 void  host_table_free(void *p) noexcept;
+// ... page-locked once it is filled: the loader's threads touch the block's pages when they write the rows (first touches
+// spread over the threads), and locking pages that are there already takes a fraction of a millisecond per 100 MB
+void host_table_pin(void *p) noexcept;
+// Page-locked host memory for everything else (result tables, text, rings): an anonymous mapping on 2 MiB pages where the
+// kernel grants them, first touched on several threads, then registered with the HIP runtime -- a few milliseconds per
+// 200 MB where hipHostMalloc takes 30 (it touches every 4 KiB page on the calling thread).  nullptr when out of memory.
+void *pinned_block_alloc(size_t bytes) noexcept;
+void  pinned_block_free(void *p) noexcept;
 template <class T> struct HostTableAlloc { // std::allocator for such tables
   using value_type = T;
   HostTableAlloc() = default;

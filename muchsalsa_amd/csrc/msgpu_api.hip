@@ -12,6 +12,11 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <thread>
+#include <vector>
+#include <algorithm>
+#include <sys/mman.h>
+#include <unistd.h>
 
 #include "asm_internal.h"
 #include "msgpu.h"
@@ -19,33 +24,119 @@
 
 using namespace msgpu;
 
-// ---- host tables that travel to HBM (the PAF loader's row table): page-locked when there is a device ---------------------
+// ---- page-locked host memory ---------------------------------------------------------------------------------------------
+// hipHostMalloc spends its time touching the block's pages one by one on the calling thread (30 ms per 200 MB, and 17 ms
+// to give them back): tables that are written once and read once never earn that back.  Here a block is an anonymous
+// mapping on 2 MiB pages where the kernel grants them, its pages are touched by several threads (or by the threads that
+// fill it), and hipHostRegister locks what is there (0.6 ms per 200 MB on 2 MiB pages, 5 ms on 4 KiB pages); copies run at
+// the same 54 GB/s (tools/experiments/pin_timing.cpp).
 namespace msgpu {
 namespace {
-constexpr size_t   HT_HEADER = 64; // keeps the 64-byte alignment of the block; its first word says who allocated it
-constexpr uint64_t HT_PINNED = 0x6d7367707550494eull, HT_PLAIN = 0x6d736770754d414cull;
-} // namespace
-void *host_table_alloc(size_t bytes) {
-  static const bool have_device = [] {
+constexpr size_t   PB_HEADER = 64;                // keeps the 64-byte alignment of the payload
+constexpr size_t   PB_HUGE   = size_t(2) << 20;
+constexpr uint64_t PB_MAGIC  = 0x6d7367707550494eull;
+struct BlockHeader {
+  uint64_t magic;
+  void    *raw;        // what mmap returned
+  size_t   raw_len;
+  size_t   span;       // header + payload, rounded up to pages: what is (to be) registered
+  uint32_t registered; // hipHostRegister succeeded
+  uint32_t hip_alloc;  // fallback: the block came from hipHostMalloc
+};
+static_assert(sizeof(BlockHeader) <= PB_HEADER, "header");
+bool have_device() {
+  static const bool yes = [] {
     int n = 0;
     return hipGetDeviceCount(&n) == hipSuccess && n > 0;
   }();
-  void *p = nullptr;
-  if (have_device && hipHostMalloc(&p, bytes + HT_HEADER, hipHostMallocPortable) == hipSuccess && p) {
-    *static_cast<uint64_t *>(p) = HT_PINNED;
-    return static_cast<char *>(p) + HT_HEADER;
+  return yes;
+}
+BlockHeader *header_of(void *payload) { return reinterpret_cast<BlockHeader *>(static_cast<char *>(payload) - PB_HEADER); }
+void *block_map(size_t bytes) noexcept { // -> payload, untouched and unregistered; nullptr when the mapping fails
+  const size_t page = static_cast<size_t>(sysconf(_SC_PAGESIZE));
+  const size_t span = (PB_HEADER + bytes + page - 1) / page * page;
+  const size_t len  = span + PB_HUGE;
+  void        *raw  = mmap(nullptr, len, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+  if (raw == MAP_FAILED) return nullptr;
+  char *base = reinterpret_cast<char *>((reinterpret_cast<uintptr_t>(raw) + PB_HUGE - 1) & ~(uintptr_t(PB_HUGE) - 1));
+  madvise(base, span, MADV_HUGEPAGE);
+  auto *h = reinterpret_cast<BlockHeader *>(base);
+  *h      = BlockHeader{PB_MAGIC, raw, len, span, 0, 0};
+  return base + PB_HEADER;
+}
+void block_touch(void *payload) noexcept { // first touch of every page, on a few threads when the block is large
+  BlockHeader *h    = header_of(payload);
+  char        *base = reinterpret_cast<char *>(h);
+  const size_t page = static_cast<size_t>(sysconf(_SC_PAGESIZE));
+  auto         touch = [&](size_t b, size_t e) {
+    for (size_t o = b; o < e; o += page) static_cast<volatile char *>(base)[o < PB_HEADER ? PB_HEADER : o] = 0;
+  };
+  unsigned nt = std::thread::hardware_concurrency();
+  nt          = nt > 16 ? 16 : (nt ? nt : 1);
+  if (h->span < (size_t(8) << 20)) nt = 1;
+  const size_t per = ((h->span + nt - 1) / nt + PB_HUGE - 1) / PB_HUGE * PB_HUGE;
+  std::vector<std::thread> pool;
+  try {
+    for (unsigned t = 1; t < nt; ++t)
+      if (per * t < h->span) pool.emplace_back(touch, per * t, std::min(h->span, per * (t + 1)));
+  } catch (...) { // (no thread to be had: the caller touches the rest)
+    const size_t done = pool.size() + 1;
+    touch(per * done, h->span);
   }
-  if (posix_memalign(&p, 64, bytes + HT_HEADER) != 0 || !p) throw std::bad_alloc();
-  *static_cast<uint64_t *>(p) = HT_PLAIN;
-  return static_cast<char *>(p) + HT_HEADER;
+  touch(0, std::min(h->span, per));
+  for (auto &t : pool) t.join();
+}
+void block_register(void *payload) noexcept {
+  BlockHeader *h = header_of(payload);
+  if (h->registered || !have_device()) return;
+  if (hipHostRegister(h, h->span, hipHostRegisterDefault) == hipSuccess) h->registered = 1;
+  else (void)hipGetLastError(); // (the block stays pageable: copies still work, through the runtime's staging)
+}
+void block_unmap(void *payload) noexcept {
+  BlockHeader *h = header_of(payload);
+  if (h->hip_alloc) {
+    (void)hipHostFree(h);
+    return;
+  }
+  if (h->registered) (void)hipHostUnregister(h);
+  munmap(h->raw, h->raw_len);
+}
+} // namespace
+
+void *pinned_block_alloc(size_t bytes) noexcept {
+  void *p = block_map(bytes ? bytes : 1);
+  if (p) {
+    block_touch(p);
+    block_register(p);
+    if (header_of(p)->registered || !have_device()) return p;
+    block_unmap(p); // (registration refused, e.g. a locked-memory limit: let the runtime allocate)
+  }
+  void *q = nullptr;
+  if (hipHostMalloc(&q, PB_HEADER + (bytes ? bytes : 1), hipHostMallocDefault) != hipSuccess || !q) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  *static_cast<BlockHeader *>(q) = BlockHeader{PB_MAGIC, q, 0, 0, 0, 1};
+  return static_cast<char *>(q) + PB_HEADER;
+}
+void pinned_block_free(void *p) noexcept {
+  if (p) block_unmap(p);
+}
+
+// the PAF loader's row table: mapped here, touched by the loader's threads as they write the rows, locked by host_table_pin
+void *host_table_alloc(size_t bytes) {
+  void *p = block_map(bytes ? bytes : 1);
+  if (!p) throw std::bad_alloc();
+  return p;
 }
 void host_table_free(void *q) noexcept {
-  if (!q) return;
-  void *p = static_cast<char *>(q) - HT_HEADER;
-  if (*static_cast<uint64_t *>(p) == HT_PINNED) (void)hipHostFree(p);
-  else free(p);
+  if (q) block_unmap(q);
+}
+void host_table_pin(void *q) noexcept {
+  if (q) block_register(q);
 }
 } // namespace msgpu
+
 
 namespace {
 
@@ -589,7 +680,7 @@ void msgpu_destroy(msgpu_ctx *c) {
   }
   for (msgpu_ctx::HostBuf *h : {&c->h_edges, &c->h_ems, &c->h_orders, &c->h_ids, &c->h_read_len, &c->h_read_first, &c->h_sel_off,
                                &c->h_sel_ems})
-    if (h->p) (void)hipHostFree(h->p);
+    if (h->p) pinned_block_free(h->p);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   if (c->h_scalars) (void)hipHostFree(c->h_scalars);
   delete c;
@@ -1186,18 +1277,18 @@ int ensure_host(msgpu_ctx *c, msgpu_ctx::HostBuf &h, size_t need, size_t valid, 
   if (need <= h.cap) return MSGPU_OK;
   size_t want = need + need / 4 + 4096;
   if (hint > want) want = hint;
-  void *np = nullptr;
-  HIPCHK(c, hipHostMalloc(&np, want, hipHostMallocDefault));
+  void *np = pinned_block_alloc(want);
+  if (!np) return fail(c, MSGPU_E_NOMEM, "page-locked host table of %zu bytes", want);
   if (h.p) {
     if (valid) {
       hipError_t e = hipStreamSynchronize(c->copy_stream);
       if (e != hipSuccess) {
-        (void)hipHostFree(np);
+        pinned_block_free(np);
         HIPCHK(c, e);
       }
       memcpy(np, h.p, valid);
     }
-    HIPCHK(c, hipHostFree(h.p));
+    pinned_block_free(h.p);
   }
   h.p   = np;
   h.cap = want;
@@ -1416,14 +1507,8 @@ int msgpu_get_edgematches(msgpu_ctx *c, const uint32_t *edge_idx, size_t n, cons
   return MSGPU_OK;
 }
 
-void *msgpu_pinned_alloc(size_t bytes) {
-  void *p = nullptr;
-  if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return nullptr;
-  return p;
-}
-void msgpu_pinned_free(void *p) {
-  if (p) (void)hipHostFree(p);
-}
+void *msgpu_pinned_alloc(size_t bytes) { return pinned_block_alloc(bytes); }
+void  msgpu_pinned_free(void *p) { pinned_block_free(p); }
 
 int msgpu_synchronize(msgpu_ctx *c) {
   if (!c) return MSGPU_E_ARG;

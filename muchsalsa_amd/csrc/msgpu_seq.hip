@@ -430,7 +430,7 @@ void msgpu_seq_destroy(msgpu_seqctx *c) {
       (void)hipStreamDestroy(s.stream);
     }
     if (s.d_buf) (void)hipFree(s.d_buf);
-    if (s.ring) (void)hipHostFree(s.ring);
+    if (s.ring) msgpu::pinned_block_free(s.ring);
     s.drop_packed();
   }
   for (msgpu_seqctx::Scratch *x : {&c->scr_text, &c->scr_recs, &c->scr_map, &c->scr_hdr})
@@ -550,10 +550,10 @@ struct DeviceDestination final : msgpu::SeqDestination {
     if (e != hipSuccess) fail(e);
     const size_t want = size_t(n) * RING_SLOTS * RING_SLOT;
     if (s.ring_bytes < want) {
-      if (s.ring) (void)hipHostFree(s.ring);
-      s.ring       = nullptr;
+      if (s.ring) msgpu::pinned_block_free(s.ring);
       s.ring_bytes = 0;
-      if (hipHostMalloc(&s.ring, want, hipHostMallocDefault) != hipSuccess) throw std::bad_alloc();
+      s.ring       = msgpu::pinned_block_alloc(want);
+      if (!s.ring) throw std::bad_alloc();
       s.ring_bytes = want;
     }
     sinks.resize(n);
@@ -987,7 +987,7 @@ struct ParkedBuffers {
     for (const Buf &b : free_list) same += b.device == device;
     if (same >= 2) { // keep the pool small: release instead
       g.unlock();
-      if (device < 0) (void)hipHostFree(p);
+      if (device < 0) msgpu::pinned_block_free(p);
       else (void)hipFree(p);
       return;
     }
@@ -1109,7 +1109,8 @@ int msgpu_assembly_finish(msgpu_assembly *a, void *hip_stream) {
   }
   if (e == hipSuccess) e = c->scr_text.ensure(text_bytes + 16);
   if (e == hipSuccess && !h_text) {
-    e = hipHostMalloc(reinterpret_cast<void **>(&h_text), text_bytes + 16, hipHostMallocDefault);
+    h_text = static_cast<char *>(msgpu::pinned_block_alloc(text_bytes + 16));
+    if (!h_text) e = hipErrorOutOfMemory;
     if (e == hipSuccess) parked().lend(h_text, text_bytes + 16);
   }
   if (e == hipSuccess && std::getenv("MSGPU_POISON")) { // see DevBuf::ensure in msgpu_api.hip

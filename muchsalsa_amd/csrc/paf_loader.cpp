@@ -357,20 +357,6 @@ int msgpu_parse_paf(const char *path, const msgpu_params *params, msgpu_paf **ou
     paf->n_lines          = n_lines;
     const size_t last     = n_lines ? n_lines - 1 : 0;
     std::vector<int> oom(nthr, 0);
-    // (the row table is page-locked memory when a GPU is present, and locking 200 MB takes as long as a fifth of the
-    // parse: room for every line is made on a thread of its own meanwhile)
-    int         reserve_failed = 0;
-    std::thread reserve([&] {
-      try {
-        paf->rows.reserve(n_lines);
-      } catch (std::bad_alloc const &) { reserve_failed = 1; }
-    });
-    struct Joiner { // (run() may throw before the join below)
-      std::thread &t;
-      ~Joiner() {
-        if (t.joinable()) t.join();
-      }
-    } join_reserve{reserve};
     const size_t page = static_cast<size_t>(sysconf(_SC_PAGESIZE));
     run([&](unsigned t) {
       try {
@@ -385,9 +371,7 @@ int msgpu_parse_paf(const char *path, const msgpu_params *params, msgpu_paf **ou
         if (hi > lo) madvise(const_cast<char *>(data) + lo, hi - lo, MADV_DONTNEED);
       } catch (std::bad_alloc const &) { oom[t] = 1; }
     });
-    reserve.join();
     lap("tokenise");
-    if (reserve_failed) throw std::bad_alloc();
     for (unsigned t = 0; t < nthr; ++t)
       if (oom[t]) throw std::bad_alloc();
     // the reference stops at the first bad line in line order
@@ -485,6 +469,9 @@ int msgpu_parse_paf(const char *path, const msgpu_params *params, msgpu_paf **ou
           ++o;
         }
       });
+      // (the table's pages were first touched by the threads above, each its own stretch: locking them for the copy to
+      // HBM -- a GPU present -- is a fraction of a millisecond now)
+      if (!paf->rows.empty()) msgpu::host_table_pin(paf->rows.data());
       lap("rows");
     }
   } catch (std::bad_alloc const &) { rc = MSGPU_E_NOMEM; } catch (std::system_error const &) {
