@@ -68,7 +68,7 @@ class SlabExchange:
     all of them enlarge the capacity and repeat the collective together (counted in `regrows`).  Identical decisions on
     every rank by construction: nothing but gathered data enters them."""
 
-    def __init__(self, device, group=None, slack=1.125):
+    def __init__(self, device, group=None, slack=1.03125):
         self.device, self.group, self.slack = device, group, slack
         self.cap = None
         self.calls = self.collectives = self.regrows = 0
@@ -221,14 +221,15 @@ class PipelinedExchange:
         pe.drain()                                  # everything submitted is merged
 
     Capacity protocol = SlabExchange's (header in the slab, capacity remembered, identical decisions on every rank because
-    only gathered data enters them).  A rank that outgrows the capacity sends its header alone and keeps its tables in a
+    only gathered data enters them).  The capacity is the largest rank's tables + 1/32: every rank's slab is padded to it
+    and the padding travels, so slack is xGMI time in every step, while outgrowing it costs one repeated collective once.  A rank that outgrows the capacity sends its header alone and keeps its tables in a
     private stash; when the headers are read every rank enlarges the capacity, re-lays its own slab of THAT batch (still
     intact: a slot is reused two batches later; or the stash) and repeats the collective.  Collectives are issued in
     submission order by one thread, so every rank issues the same sequence.
     On CPU tensors (gloo, the tests) there are no streams and no thread: the all-gather completes inside submit() and
     collect() finishes the batch before the one just submitted, which keeps the one-batch-behind bookkeeping honest."""
 
-    def __init__(self, device, merge, group=None, slack=1.125, threaded=None):
+    def __init__(self, device, merge, group=None, slack=1.03125, threaded=None):
         import torch
         self.device, self.group, self.slack, self.merge = device, group, slack, merge
         self.cuda = device.type == "cuda"
