@@ -32,13 +32,22 @@
 
 namespace {
 
-inline uint64_t name_hash(const char *s, size_t n) { // FNV-1a, computed by the parallel tokenisers
-  uint64_t h = 1469598103934665603ull;
-  for (size_t i = 0; i < n; ++i) {
-    h ^= static_cast<unsigned char>(s[i]);
-    h *= 1099511628211ull;
+inline uint64_t name_hash(const char *s, size_t n) { // eight bytes per step (internal: only equal names need equal values)
+  uint64_t h = 0x9e3779b97f4a7c15ull ^ (static_cast<uint64_t>(n) * 0xff51afd7ed558ccdull);
+  for (; n >= 8; s += 8, n -= 8) {
+    uint64_t x;
+    memcpy(&x, s, 8);
+    h = (h ^ x) * 0x9fb21c651e98df25ull;
+    h ^= h >> 29;
   }
-  return h;
+  if (n) {
+    uint64_t x = 0;
+    for (size_t i = 0; i < n; ++i) x |= static_cast<uint64_t>(static_cast<unsigned char>(s[i])) << (8 * i);
+    h = (h ^ x) * 0x9fb21c651e98df25ull;
+  }
+  h ^= h >> 32;
+  h *= 0xd6e8feb86659fd93ull;
+  return h ^ (h >> 29);
 }
 
 // Registry (libms/src/Registry.cpp:36-45): name -> dense id in first-seen order, plus the reverse table.
@@ -149,40 +158,48 @@ struct NameEntry {
 class ChunkNames {
 public:
   void set_shares(unsigned n) { share.assign(n, {}); }
-  uint32_t get(const char *s, uint32_t n, uint64_t h) { // position of the name in the chunk's list
+  // position of the name in the chunk's list.  A look-up touches one slot (hash, length, place of the characters) and the
+  // characters: two cache lines, wherever the tables have grown to.
+  uint32_t get(const char *s, uint32_t n, uint64_t h) {
     if ((list.size() + 1) * 2 > m_slots.size()) grow();
     size_t i = h & (m_slots.size() - 1);
-    for (; m_slots[i]; i = (i + 1) & (m_slots.size() - 1)) {
-      const NameEntry &e = list[m_slots[i] - 1];
-      if (e.hash == h && e.n == n && memcmp(m_block.data() + reinterpret_cast<uintptr_t>(e.s), s, n) == 0) return m_slots[i] - 1;
+    for (; m_slots[i].at_plus_1; i = (i + 1) & (m_slots.size() - 1)) {
+      const Slot &sl = m_slots[i];
+      if (sl.hash == h && sl.n == n && memcmp(m_block.data() + sl.off, s, n) == 0) return sl.at_plus_1 - 1;
     }
-    list.push_back(NameEntry{reinterpret_cast<const char *>(static_cast<uintptr_t>(m_block.size())), n, 0, h, nullptr});
+    if (m_block.size() + n > 0xffffffffull) throw std::bad_alloc(); // (4 GB of distinct names in one chunk)
+    const uint32_t off = static_cast<uint32_t>(m_block.size());
+    list.push_back(NameEntry{reinterpret_cast<const char *>(static_cast<uintptr_t>(off)), n, 0, h, nullptr});
     m_block.append(s, n); // (the file image is given back as soon as the chunk is parsed)
-    m_slots[i] = static_cast<uint32_t>(list.size());
+    m_slots[i] = Slot{h, static_cast<uint32_t>(list.size()), off, n};
     share[share_of(h, static_cast<unsigned>(share.size()))].push_back(static_cast<uint32_t>(list.size() - 1));
     return static_cast<uint32_t>(list.size() - 1);
   }
   void bind() { // the chunk is parsed: offsets -> pointers, the look-up table goes
     for (NameEntry &e : list) e.s = m_block.data() + reinterpret_cast<uintptr_t>(e.s);
-    std::vector<uint32_t>().swap(m_slots);
+    std::vector<Slot>().swap(m_slots);
   }
   static unsigned share_of(uint64_t h, unsigned n) { return static_cast<unsigned>((h >> 40) % n); }
   std::vector<NameEntry>             list;
   std::vector<std::vector<uint32_t>> share; // share[t]: the positions of the names thread t looks after (by hash), ascending
 
 private:
+  struct Slot {
+    uint64_t hash;
+    uint32_t at_plus_1, off, n;
+  };
   void grow() {
-    std::vector<uint32_t> ns(m_slots.empty() ? 4096 : m_slots.size() * 2, 0);
-    for (uint32_t v : m_slots)
-      if (v) {
-        size_t i = list[v - 1].hash & (ns.size() - 1);
-        while (ns[i]) i = (i + 1) & (ns.size() - 1);
+    std::vector<Slot> ns(m_slots.empty() ? 4096 : m_slots.size() * 2, Slot{0, 0, 0, 0});
+    for (const Slot &v : m_slots)
+      if (v.at_plus_1) {
+        size_t i = v.hash & (ns.size() - 1);
+        while (ns[i].at_plus_1) i = (i + 1) & (ns.size() - 1);
         ns[i] = v;
       }
     m_slots.swap(ns);
   }
-  std::vector<uint32_t> m_slots; // position + 1
-  std::string           m_block;
+  std::vector<Slot> m_slots;
+  std::string       m_block;
 };
 
 struct Chunk {
@@ -198,6 +215,8 @@ struct Chunk {
 void parse_chunk(Chunk &ch, size_t last_line, const msgpu_params &p) {
   const char *q = ch.begin;
   size_t      li = ch.first_line;
+  const char *last_q = nullptr; // the query name of the last accepted line and its place in the chunk's list
+  uint32_t    last_qn = 0, last_id = 0;
   ch.rows.reserve(ch.n_lines);
   for (; q < ch.end; ++li) {
     const void *nlp = memchr(q, '\n', static_cast<size_t>(ch.end - q));
@@ -212,11 +231,9 @@ void parse_chunk(Chunk &ch, size_t last_line, const msgpu_params &p) {
     for (const char *c = ls;; ++c) {
       if (c == le || *c == '\t') {
         if (c == le && s == le) break;
-        if (nt < 10) {
-          tb[nt] = s;
-          te[nt] = c;
-        }
-        ++nt;
+        tb[nt] = s;
+        te[nt] = c;
+        if (++nt == 10) break; // (the columns behind the tenth are not read)
         s = c + 1;
         if (c == le) break;
       }
@@ -246,8 +263,14 @@ void parse_chunk(Chunk &ch, size_t last_line, const msgpu_params &p) {
     const bool prim = span >= static_cast<int>(p.th_length) && static_cast<uint32_t>(nom) >= p.th_matches;
     msgpu_row  r;
     // Registry::operator[] (BlastFileReader.cpp:110-111), chunk-local for now
-    r.read_id   = ch.reads.get(tb[5], static_cast<uint32_t>(te[5] - tb[5]), name_hash(tb[5], static_cast<size_t>(te[5] - tb[5])));
-    r.anchor_id = ch.anchors.get(tb[0], static_cast<uint32_t>(te[0] - tb[0]), name_hash(tb[0], static_cast<size_t>(te[0] - tb[0])));
+    r.read_id = ch.reads.get(tb[5], static_cast<uint32_t>(te[5] - tb[5]), name_hash(tb[5], static_cast<size_t>(te[5] - tb[5])));
+    const uint32_t qn = static_cast<uint32_t>(te[0] - tb[0]);
+    if (!(last_q && qn == last_qn && memcmp(last_q, tb[0], qn) == 0)) { // (a PAF is grouped by its query: mostly the line before's)
+      last_id = ch.anchors.get(tb[0], qn, name_hash(tb[0], qn));
+      last_q  = tb[0];
+      last_qn = qn;
+    }
+    r.anchor_id = last_id;
     r.read_len  = nle;
     r.i_lo      = irs;
     r.i_hi      = ire - 1;
