@@ -892,7 +892,7 @@ void add_path_weights(const DiG &dg, const std::vector<uint32_t> &order, const s
   for (size_t i = 0; i < limit; ++i) {
     const int64_t e = dg.get_edge(order[mv[i]], order[mv[i + 1]]);
     require(e >= 0, "findClusterWeights: path edge missing");
-    result[e] += c;
+    __atomic_fetch_add(&result[e], static_cast<uint64_t>(c), __ATOMIC_RELAXED); // (sums: the vertices of findClusterWeights run on several threads)
     c -= 1;
   }
 }
@@ -903,40 +903,46 @@ std::vector<uint64_t> find_cluster_weights(const DiG &dg, const std::vector<uint
   struct Cand {
     std::vector<uint32_t> open, visited; // both ascending (a visited index is always larger than the one before it)
   };
-  std::vector<Cand> cands, filtered;
-  for (uint32_t v : ts.order) {
-    const uint32_t *sb = ts.sidx.data() + ts.soff[v], *se = ts.sidx.data() + ts.soff[v + 1];
-    if (sb == se) continue; // no successor: the only candidate is {v}, which adds nothing
-    cands.clear();
-    cands.push_back(Cand{std::vector<uint32_t>(sb, se), {ts.idx[v]}});
-    for (const uint32_t *po = sb; po != se; ++po) {
-      const uint32_t i_out = *po, active = ts.order[i_out];
-      const uint32_t *ab = ts.sidx.data() + ts.soff[active], *ae = ts.sidx.data() + ts.soff[active + 1];
-      for (uint32_t q = ts.poff[active]; q < ts.poff[active + 1]; ++q) {
-        const uint32_t i_in = ts.pidx[q];
-        for (size_t k = 0; k < cands.size(); ++k) // the bound grows with the emplace_back inside (:193)
-          if (cands[k].visited.back() == i_in && std::binary_search(cands[k].open.begin(), cands[k].open.end(), i_out)) {
-            Cand nc;
-            std::set_intersection(cands[k].open.begin(), cands[k].open.end(), ab, ae, std::back_inserter(nc.open));
-            nc.visited = cands[k].visited;
-            nc.visited.push_back(i_out);
-            cands.push_back(std::move(nc));
-          }
+  // every vertex of the order adds the weights of its own best paths to the edges: sums, so the vertices are handed to
+  // the stage's threads in pieces (the result does not depend on who adds what when)
+  const size_t grain = par_min() >= (size_t(1) << 16) ? 256 : std::max<size_t>(8, par_min() / 64);
+  parallel_dynamic(ts.order.size(), grain, [&](size_t ob, size_t oe) {
+    std::vector<Cand> cands, filtered;
+    for (size_t oi = ob; oi < oe; ++oi) {
+      const uint32_t  v  = ts.order[oi];
+      const uint32_t *sb = ts.sidx.data() + ts.soff[v], *se = ts.sidx.data() + ts.soff[v + 1];
+      if (sb == se) continue; // no successor: the only candidate is {v}, which adds nothing
+      cands.clear();
+      cands.push_back(Cand{std::vector<uint32_t>(sb, se), {ts.idx[v]}});
+      for (const uint32_t *po = sb; po != se; ++po) {
+        const uint32_t i_out = *po, active = ts.order[i_out];
+        const uint32_t *ab = ts.sidx.data() + ts.soff[active], *ae = ts.sidx.data() + ts.soff[active + 1];
+        for (uint32_t q = ts.poff[active]; q < ts.poff[active + 1]; ++q) {
+          const uint32_t i_in = ts.pidx[q];
+          for (size_t k = 0; k < cands.size(); ++k) // the bound grows with the emplace_back inside (:193)
+            if (cands[k].visited.back() == i_in && std::binary_search(cands[k].open.begin(), cands[k].open.end(), i_out)) {
+              Cand nc;
+              std::set_intersection(cands[k].open.begin(), cands[k].open.end(), ab, ae, std::back_inserter(nc.open));
+              nc.visited = cands[k].visited;
+              nc.visited.push_back(i_out);
+              cands.push_back(std::move(nc));
+            }
+        }
+        filtered.clear();
+        for (size_t a = 0; a < cands.size(); ++a) {
+          bool dominated = false;
+          for (size_t b = 0; b < cands.size() && !dominated; ++b)
+            dominated = a != b && subset(cands[a].open, cands[b].open) && subset(cands[a].visited, cands[b].visited);
+          if (!dominated) filtered.push_back(cands[a]);
+        }
+        cands.swap(filtered);
       }
-      filtered.clear();
-      for (size_t a = 0; a < cands.size(); ++a) {
-        bool dominated = false;
-        for (size_t b = 0; b < cands.size() && !dominated; ++b)
-          dominated = a != b && subset(cands[a].open, cands[b].open) && subset(cands[a].visited, cands[b].visited);
-        if (!dominated) filtered.push_back(cands[a]);
-      }
-      cands.swap(filtered);
+      size_t best_len = 0;
+      for (auto &c : cands) best_len = std::max(best_len, c.visited.size());
+      for (auto &c : cands)
+        if (c.visited.size() == best_len) add_path_weights(dg, ts.order, c.visited, result);
     }
-    size_t best_len = 0;
-    for (auto &c : cands) best_len = std::max(best_len, c.visited.size());
-    for (auto &c : cands)
-      if (c.visited.size() == best_len) add_path_weights(dg, ts.order, c.visited, result);
-  }
+  });
   return result;
 }
 
@@ -1192,6 +1198,7 @@ std::vector<std::vector<uint32_t>> extract_paths(DiG &dg) { // local vertex ids
     for (uint32_t v = 0; v < dg.n; ++v) all[v] = v;
     pp.split(all);
   }
+  tick("conservation paths: first split");
   std::vector<uint32_t> longest;
   while (pp.n_arcs > 0) { // diGraphCycle.getSize() > 0
     require(!pp.heap.empty(), "extractPaths: edges left but no component");
@@ -1738,19 +1745,22 @@ int msgpu_graph_linearize(msgpu_graph *g) {
     std::vector<size_t>                              by_size(comps.size());
     for (size_t i = 0; i < by_size.size(); ++i) by_size[i] = i;
     std::stable_sort(by_size.begin(), by_size.end(), [&](size_t x, size_t y) { return comps[x].size() > comps[y].size(); });
-    // the workers' own loops (directed edges, adjacency builds) share the stage's threads: a large component gets
-    // threads / (large components running beside it), a small one runs on its worker alone
-    size_t large_vertices = 0;
+    // the workers' own loops (directed edges, adjacency builds, cluster weights) share the stage's threads: a large
+    // component gets its share of them, a small one runs on its worker alone
+    // (by the SQUARE of its size: the largest component is the stage's critical path -- its walk and its linearizeGraph
+    // are serial -- and the smaller ones have the time its serial parts take to finish their own parallel loops on fewer threads)
+    double large_weight = 0;
     for (const auto &c : comps)
-      if (c.size() >= par_min() / 8) large_vertices += c.size();
+      if (c.size() >= par_min() / 8) large_weight += static_cast<double>(c.size()) * static_cast<double>(c.size());
     std::atomic<size_t> next{0};
     auto                work = [&]() {
       for (size_t k = next.fetch_add(1); k < by_size.size(); k = next.fetch_add(1)) {
         const size_t i = by_size[k];
         // (its share of the vertices of the large components, at least one thread)
-        tl_thread_share = comps[i].size() >= par_min() / 8 && large_vertices
-                              ? std::max<unsigned>(1, static_cast<unsigned>(stage_threads_total() * comps[i].size() / large_vertices))
-                              : 1;
+        const double mine = static_cast<double>(comps[i].size()) * static_cast<double>(comps[i].size());
+        tl_thread_share   = comps[i].size() >= par_min() / 8 && large_weight > 0
+                                ? std::max<unsigned>(1, static_cast<unsigned>(stage_threads_total() * mine / large_weight + 0.5))
+                                : 1;
         try {
           per[i] = component_paths(g, static_cast<uint32_t>(i), comps[i], arc_flags);
         } catch (std::bad_alloc const &) { rcs[i] = MSGPU_E_NOMEM; } catch (std::exception const &e) {
