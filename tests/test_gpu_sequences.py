@@ -242,7 +242,11 @@ def test_parse_upload_equals_parse_then_upload(tmp_path, monkeypatch, threads):
         s = seq(rng.integers(1, 3000))
         evil += b"@e%d\n" % i + s + b"\n+\n@" + b"F" * (len(s) - 1) + b"\n"
     monkeypatch.setenv("MSGPU_SEQ_THREADS", str(threads))
-    for name, text in (("big.fa", fa), ("evil.fq", evil), ("none.fa", b"")):
+    small = [("a.fa", b">r1 desc\nACGT\nNN\n>r2\n\nTT TT\r\n>r1\nGGGG\n>r3"),  # dup id, blank / CRLF / space, empty record
+             ("b.fasta", b"junk before\n>x\tdesc\nAC\nGT"),                     # no trailing newline, tab in the header
+             ("c.fq", b"@q1 a\nACGT\nAC\n+\nFFFF\nFF\n@q2\nTTTT\n+q2\nIIII\n"),  # multi-line FASTQ record
+             ("f.fa", b"no records here\n")]
+    for name, text in [("big.fa", fa), ("evil.fq", evil), ("none.fa", b"")] + small:
         path = tmp_path / name
         path.write_bytes(text)
         host = S.SeqFile(str(path))
