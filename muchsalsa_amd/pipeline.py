@@ -136,19 +136,24 @@ def run(contigs_paf, unitigs_path, nanopore_path, out_dir, threads=None, wiggle_
         if g.path_count else np.zeros(0, dtype=np.int32)
     st = g.stats
     n_rows = len(paf.rows)
-    held = [g, ctx, paf, tables]
+    held, held_rows = [g, ctx], [paf, tables]
     del paf, tables
     asm._rows_keep = None  # (the layout is done: nothing reads the borrowed row table any more)
 
     def release():
-        # the graph, the overlap context (device tables, page-locked result tables: the graph had borrowed them, so it goes
-        # first) and the loader's page-locked row table are done with: they go back beside the gather and the writes
+        # the graph and the overlap context (device tables, page-locked result tables: the graph had borrowed them, so it
+        # goes first) are done with: they go back beside the gather and the writes ...
         held[0].close()
         held[1].close()
         del held[:]
 
-    releaser = threading.Thread(target=release, name="msgpu-release")
-    releaser.start()
+    def release_rows():  # ... and so does the loader's page-locked row table (its last views die here)
+        del held_rows[:]
+
+    releasers = [threading.Thread(target=release, name="msgpu-release"),
+                 threading.Thread(target=release_rows, name="msgpu-release-rows")]
+    for th in releasers:
+        th.start()
     asm.finish()
     t["assemble"] = time.perf_counter() - t0
 
@@ -185,7 +190,8 @@ def run(contigs_paf, unitigs_path, nanopore_path, out_dir, threads=None, wiggle_
     store.close()
     for key in ("nanopore", "unitigs"):
         seq[key].close()
-    releaser.join()
+    for th in releasers:
+        th.join()
     t["teardown"] = time.perf_counter() - t0
     if timings is not None:
         timings.update(t)
