@@ -102,6 +102,13 @@ size_t par_min() {
   }
   return size_t(1) << 16;
 }
+struct JoinAll { // a thread that could not be started must not leave the started ones unjoined behind the exception
+  std::vector<std::thread> &t;
+  ~JoinAll() {
+    for (auto &x : t)
+      if (x.joinable()) x.join();
+  }
+};
 // f(chunk, begin, end) over [0, n) cut into contiguous chunks, one per thread; chunk indices ascend with the range, so
 // per-chunk results concatenated in chunk order are in index order.  The first exception of a chunk is rethrown here.
 template <class F> unsigned parallel_chunks(size_t n, F f) {
@@ -114,6 +121,7 @@ template <class F> unsigned parallel_chunks(size_t n, F f) {
   const size_t                    per = (n + nt - 1) / nt;
   std::vector<std::exception_ptr> err(nt);
   std::vector<std::thread>        pool;
+  JoinAll                  join_all{pool};
   auto run = [&](unsigned c) {
     const size_t b = std::min(n, per * c), e = std::min(n, per * (c + 1));
     try {
@@ -143,6 +151,7 @@ template <class F> void parallel_dynamic(size_t n, size_t grain, F f) {
   std::atomic<size_t>             next{0};
   std::vector<std::exception_ptr> err(nt);
   std::vector<std::thread>        pool;
+  JoinAll                  join_all{pool};
   auto run = [&](unsigned c) {
     try {
       for (size_t b = next.fetch_add(grain); b < n; b = next.fetch_add(grain)) f(b, std::min(n, b + grain));
@@ -191,6 +200,7 @@ bool build_csr_undirected_parallel(uint32_t n, const uint32_t *from, const uint3
   auto on_threads = [&](auto &&body) { // body(t) for t < nt
     std::vector<std::exception_ptr> err(nt);
     std::vector<std::thread>        pool;
+    JoinAll                  join_all{pool};
     auto run = [&](unsigned t) {
       try {
         body(t);
@@ -1773,6 +1783,7 @@ int msgpu_graph_linearize(msgpu_graph *g) {
     uint32_t nt = g->n_threads;
     if (nt > comps.size()) nt = static_cast<uint32_t>(comps.size() ? comps.size() : 1);
     std::vector<std::thread> pool;
+    JoinAll                  join_all{pool};
     for (uint32_t t = 1; t < nt; ++t) pool.emplace_back(work);
     work();
     for (auto &t : pool) t.join();

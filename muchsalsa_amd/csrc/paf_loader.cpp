@@ -358,6 +358,13 @@ int msgpu_parse_paf(const char *path, const msgpu_params *params, msgpu_paf **ou
     }
     auto run = [&](auto &&fn) {
       std::vector<std::thread> th;
+      struct JoinAll { // (a thread that could not be started must not leave the started ones unjoined behind the exception)
+        std::vector<std::thread> &t;
+        ~JoinAll() {
+          for (auto &x : t)
+            if (x.joinable()) x.join();
+        }
+      } join_all{th};
       for (unsigned t = 1; t < nthr; ++t) th.emplace_back(fn, t);
       fn(0u);
       for (auto &x : th) x.join();

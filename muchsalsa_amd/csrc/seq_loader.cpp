@@ -76,6 +76,14 @@ struct msgpu_seqfile {
 
 namespace {
 
+struct JoinAll { // a thread that could not be started must not leave the started ones unjoined behind an exception
+  std::vector<std::thread> &t;
+  ~JoinAll() {
+    for (auto &x : t)
+      if (x.joinable()) x.join();
+  }
+};
+
 struct LineReader { // readline (libms/src/IO.cpp:54-97) over a memory image
   const char *buf;
   size_t      len, pos = 0;
@@ -250,6 +258,7 @@ void mark_duplicates(std::vector<ChunkRecords> &parts, unsigned nt) {
     return;
   }
   std::vector<std::thread> pool;
+  JoinAll                  join_all{pool};
   std::vector<int>         oom(nt, 0);
   auto                     guarded = [&](unsigned t) {
     try {
@@ -374,6 +383,7 @@ int msgpu::seq_parse_into(const char *path, int is_fastq, msgpu::SeqDestination 
     };
     {
       std::vector<std::thread> pool;
+      JoinAll                  join_all{pool};
       for (unsigned k = 1; k < nc; ++k) pool.emplace_back(work, k);
       work(0);
       for (auto &t : pool) t.join();
@@ -415,6 +425,7 @@ int msgpu::seq_parse_into(const char *path, int is_fastq, msgpu::SeqDestination 
     };
     {
       std::vector<std::thread> pool;
+      JoinAll                  join_all{pool};
       std::vector<int>         bad(parts.size(), 0);
       auto                     guarded = [&](size_t k) {
         try {
