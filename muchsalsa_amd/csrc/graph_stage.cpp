@@ -34,12 +34,16 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
+#include <functional>
 #include <iterator>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <new>
 #include <queue>
 #include <set>
@@ -109,8 +113,105 @@ struct JoinAll { // a thread that could not be started must not leave the starte
       if (x.joinable()) x.join();
   }
 };
-// f(chunk, begin, end) over [0, n) cut into contiguous chunks, one per thread; chunk indices ascend with the range, so
-// per-chunk results concatenated in chunk order are in index order.  The first exception of a chunk is rethrown here.
+// The stage's loops run on a pool of parked threads: a loop that started its own threads paid 0.3-0.5 ms for them, and the
+// stage has some thirty such loops on its critical path.  A loop invites helpers and takes part itself: items are handed out
+// by a counter, whoever is free takes the next one, and the caller leaves when the counter has run out and every helper
+// that joined has left (a helper that arrives later finds nothing to do and never touches the caller's frame).  Loops of
+// several callers (the component workers of msgpu_graph_linearize) share the pool.
+class StagePool {
+public:
+  static StagePool &get() {
+    static StagePool p;
+    return p;
+  }
+  // body(i) for every i < n_items, on up to `want` threads including this one; the first exception is rethrown here
+  template <class Body> void run(unsigned want, size_t n_items, Body &&body) {
+    if (want <= 1 || n_items <= 1) {
+      for (size_t i = 0; i < n_items; ++i) body(i);
+      return;
+    }
+    auto r   = std::make_shared<Region>();
+    r->n     = n_items;
+    r->body  = [&body](size_t i) { body(i); };
+    const unsigned helpers = static_cast<unsigned>(std::min<size_t>(want - 1, n_items - 1));
+    invite(r, helpers);
+    work(*r);
+    std::unique_lock<std::mutex> lk(r->m);
+    r->cv.wait(lk, [&] { return r->active == 0; });
+    if (r->err) std::rethrow_exception(r->err);
+  }
+
+private:
+  struct Region {
+    std::atomic<size_t>          next{0};
+    size_t                       n = 0;
+    std::function<void(size_t)>  body;
+    std::mutex                   m;
+    std::condition_variable      cv;
+    int                          active = 0; // helpers inside work()
+    std::exception_ptr           err;
+  };
+  static void work(Region &r) {
+    for (size_t i = r.next.fetch_add(1); i < r.n; i = r.next.fetch_add(1)) {
+      try {
+        r.body(i);
+      } catch (...) {
+        r.next.store(r.n); // nothing more is handed out
+        std::lock_guard<std::mutex> g(r.m);
+        if (!r.err) r.err = std::current_exception();
+      }
+    }
+  }
+  void invite(const std::shared_ptr<Region> &r, unsigned helpers) {
+    std::lock_guard<std::mutex> g(m_);
+    try {
+      while (workers_.size() < helpers && workers_.size() < 63) workers_.emplace_back([this] { loop(); });
+    } catch (std::system_error const &) {} // (no thread to be had: the loop runs on those there are)
+    for (unsigned k = 0; k < helpers; ++k) q_.push_back(r);
+    if (helpers == 1) cv_.notify_one();
+    else cv_.notify_all();
+  }
+  void loop() {
+    for (;;) {
+      std::shared_ptr<Region> r;
+      {
+        std::unique_lock<std::mutex> lk(m_);
+        cv_.wait(lk, [&] { return stop_ || !q_.empty(); });
+        if (q_.empty()) return; // stop_
+        r = std::move(q_.front());
+        q_.pop_front();
+      }
+      if (r->next.load() >= r->n) continue; // the loop is over already
+      {
+        std::lock_guard<std::mutex> g(r->m);
+        ++r->active;
+      }
+      work(*r);
+      {
+        std::lock_guard<std::mutex> g(r->m);
+        if (--r->active == 0) r->cv.notify_all();
+      }
+    }
+  }
+  StagePool() = default;
+  ~StagePool() {
+    {
+      std::lock_guard<std::mutex> g(m_);
+      stop_ = true;
+      q_.clear();
+    }
+    cv_.notify_all();
+    for (auto &t : workers_) t.join();
+  }
+  std::mutex                          m_;
+  std::condition_variable             cv_;
+  std::deque<std::shared_ptr<Region>> q_;
+  std::vector<std::thread>            workers_;
+  bool                                stop_ = false;
+};
+
+// f(chunk, begin, end) over [0, n) cut into contiguous chunks, one per thread of the stage; chunk indices ascend with the
+// range, so per-chunk results concatenated in chunk order are in index order.  The first exception of a chunk is rethrown here.
 template <class F> unsigned parallel_chunks(size_t n, F f) {
   unsigned nt = stage_threads();
   if (n < par_min()) nt = 1;
@@ -118,21 +219,8 @@ template <class F> unsigned parallel_chunks(size_t n, F f) {
     f(0u, size_t(0), n);
     return 1;
   }
-  const size_t                    per = (n + nt - 1) / nt;
-  std::vector<std::exception_ptr> err(nt);
-  std::vector<std::thread>        pool;
-  JoinAll                  join_all{pool};
-  auto run = [&](unsigned c) {
-    const size_t b = std::min(n, per * c), e = std::min(n, per * (c + 1));
-    try {
-      f(c, b, e);
-    } catch (...) { err[c] = std::current_exception(); }
-  };
-  for (unsigned c = 1; c < nt; ++c) pool.emplace_back(run, c);
-  run(0);
-  for (auto &t : pool) t.join();
-  for (auto &e : err)
-    if (e) std::rethrow_exception(e);
+  const size_t per = (n + nt - 1) / nt;
+  StagePool::get().run(nt, nt, [&](size_t c) { f(static_cast<unsigned>(c), std::min(n, per * c), std::min(n, per * (c + 1))); });
   return nt;
 }
 
@@ -148,20 +236,7 @@ template <class F> void parallel_dynamic(size_t n, size_t grain, F f) {
     f(size_t(0), n);
     return;
   }
-  std::atomic<size_t>             next{0};
-  std::vector<std::exception_ptr> err(nt);
-  std::vector<std::thread>        pool;
-  JoinAll                  join_all{pool};
-  auto run = [&](unsigned c) {
-    try {
-      for (size_t b = next.fetch_add(grain); b < n; b = next.fetch_add(grain)) f(b, std::min(n, b + grain));
-    } catch (...) { err[c] = std::current_exception(); }
-  };
-  for (unsigned c = 1; c < nt; ++c) pool.emplace_back(run, c);
-  run(0);
-  for (auto &t : pool) t.join();
-  for (auto &e : err)
-    if (e) std::rethrow_exception(e);
+  StagePool::get().run(nt, (n + grain - 1) / grain, [&](size_t k) { f(k * grain, std::min(n, (k + 1) * grain)); });
 }
 
 // ---- flat adjacency ----------------------------------------------------------------------------------------------------
@@ -198,19 +273,7 @@ bool build_csr_undirected_parallel(uint32_t n, const uint32_t *from, const uint3
   std::vector<uint32_t> hist(static_cast<size_t>(nt) * 2 * stride); // [thread][hi | lo][vertex]
   auto chunk = [&](unsigned t) { return std::make_pair(m * t / nt, m * (t + 1) / nt); };
   auto on_threads = [&](auto &&body) { // body(t) for t < nt
-    std::vector<std::exception_ptr> err(nt);
-    std::vector<std::thread>        pool;
-    JoinAll                  join_all{pool};
-    auto run = [&](unsigned t) {
-      try {
-        body(t);
-      } catch (...) { err[t] = std::current_exception(); }
-    };
-    for (unsigned t = 1; t < nt; ++t) pool.emplace_back(run, t);
-    run(0);
-    for (auto &th : pool) th.join();
-    for (auto &e : err)
-      if (e) std::rethrow_exception(e);
+    StagePool::get().run(nt, nt, [&](size_t t) { body(static_cast<unsigned>(t)); });
   };
   on_threads([&](unsigned t) {
     uint32_t *hi = hist.data() + static_cast<size_t>(t) * 2 * stride, *lo = hi + stride;
