@@ -19,6 +19,7 @@
 #include <unistd.h>
 
 #include "asm_internal.h"
+#include "host_pool.h"
 #include "msgpu.h"
 #include "msgpu_internal.h"
 
@@ -75,16 +76,12 @@ void block_touch(void *payload) noexcept { // first touch of every page, on a fe
   nt          = nt > 16 ? 16 : (nt ? nt : 1);
   if (h->span < (size_t(8) << 20)) nt = 1;
   const size_t per = ((h->span + nt - 1) / nt + PB_HUGE - 1) / PB_HUGE * PB_HUGE;
-  std::vector<std::thread> pool;
+  const size_t n_pieces = (h->span + per - 1) / per;
   try {
-    for (unsigned t = 1; t < nt; ++t)
-      if (per * t < h->span) pool.emplace_back(touch, per * t, std::min(h->span, per * (t + 1)));
-  } catch (...) { // (no thread to be had: the caller touches the rest)
-    const size_t done = pool.size() + 1;
-    touch(per * done, h->span);
+    msgpu::HostPool::get().run(nt, n_pieces, [&](size_t k) { touch(per * k, std::min(h->span, per * (k + 1))); });
+  } catch (...) { // (cannot happen: touching memory does not throw)
+    touch(0, h->span);
   }
-  touch(0, std::min(h->span, per));
-  for (auto &t : pool) t.join();
 }
 void block_register(void *payload) noexcept {
   BlockHeader *h = header_of(payload);
