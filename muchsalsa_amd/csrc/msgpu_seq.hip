@@ -25,6 +25,7 @@
 #include <vector>
 
 #include "asm_internal.h"
+#include "host_pool.h"
 #include "msgpu.h"
 #include "msgpu_internal.h"
 
@@ -693,11 +694,8 @@ int msgpu_gather_plan_create(msgpu_seqctx *c, const msgpu_copy *pieces, size_t n
     };
     std::vector<Part> part(nt);
     auto chunks_of = [](const msgpu_copy &p) { return ((p.dst_off + p.len) - (p.dst_off & ~15ull) + GCHUNK - 1) / GCHUNK; };
-    auto on_threads = [&](auto &&body) {
-      std::vector<std::thread> pool;
-      for (unsigned t = 1; t < nt; ++t) pool.emplace_back(body, t);
-      body(0u);
-      for (auto &th : pool) th.join();
+    auto on_threads = [&](auto &&body) { // body(t) for t < nt on the library's parked threads
+      msgpu::HostPool::get().run(nt, nt, [&](size_t t) { body(static_cast<unsigned>(t)); });
     };
     try {
       on_threads([&](unsigned t) {
@@ -1063,12 +1061,7 @@ int msgpu_assembly_finish(msgpu_assembly *a, void *hip_stream) {
         }
       } catch (std::bad_alloc const &) { pt.oom = true; }
     };
-    {
-      std::vector<std::thread> pool;
-      for (unsigned t = 1; t < nt; ++t) pool.emplace_back(build, t);
-      build(0);
-      for (auto &t : pool) t.join();
-    }
+    msgpu::HostPool::get().run(nt, nt, [&](size_t t) { build(static_cast<unsigned>(t)); });
     for (const Part &pt : parts)
       if (pt.oom) return MSGPU_E_NOMEM;
     size_t hdr_total = hdr.size();
