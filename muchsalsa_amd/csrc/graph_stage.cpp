@@ -153,7 +153,23 @@ template <class F> void parallel_dynamic(size_t n, size_t grain, F f) {
 struct Arc {
   uint32_t to; // neighbour
   uint32_t e;  // edge index
+  Arc() {}     // (left as it is: a vector of arcs is sized first and filled by the stage's threads, which also touch its pages first)
+  Arc(uint32_t to_, uint32_t e_) : to(to_), e(e_) {}
 };
+// std::vector whose resize() leaves new elements of a plain type as they are (no pass of zeroes on the calling thread
+// over tables the stage's threads are about to fill)
+template <class T> struct LeaveAlone {
+  using value_type = T;
+  LeaveAlone() = default;
+  template <class U> LeaveAlone(const LeaveAlone<U> &) noexcept {}
+  T   *allocate(size_t n) { return std::allocator<T>().allocate(n); }
+  void deallocate(T *p, size_t n) noexcept { std::allocator<T>().deallocate(p, n); }
+  template <class U> void construct(U *p) noexcept { ::new (static_cast<void *>(p)) U; }
+  template <class U, class... A> void construct(U *p, A &&...a) { ::new (static_cast<void *>(p)) U(std::forward<A>(a)...); }
+  template <class U> bool operator==(const LeaveAlone<U> &) const noexcept { return true; }
+  template <class U> bool operator!=(const LeaveAlone<U> &) const noexcept { return false; }
+};
+template <class T> using RawVec = std::vector<T, LeaveAlone<T>>;
 
 struct Csr { // segment of vertex v: arcs[off[v] .. off[v+1]), ascending `to`
   std::vector<uint32_t> off;
@@ -179,13 +195,13 @@ bool build_csr_undirected_parallel(uint32_t n, const uint32_t *from, const uint3
   if (std::getenv("MSGPU_GRAPH_SERIAL_CSR")) return false; // measurement switch
   if (nt < 2 || m < par_min() || m < 2 * static_cast<size_t>(n) || static_cast<size_t>(nt) * 2 * (static_cast<size_t>(n) + 1) > (size_t(1) << 26)) return false;
   const size_t          stride = static_cast<size_t>(n) + 1;
-  std::vector<uint32_t> hist(static_cast<size_t>(nt) * 2 * stride); // [thread][hi | lo][vertex]
+  std::unique_ptr<uint32_t[]> hist(new uint32_t[static_cast<size_t>(nt) * 2 * stride]); // [thread][hi | lo][vertex]; zeroed by its threads
   auto chunk = [&](unsigned t) { return std::make_pair(m * t / nt, m * (t + 1) / nt); };
   auto on_threads = [&](auto &&body) { // body(t) for t < nt
     StagePool::get().run(nt, nt, [&](size_t t) { body(static_cast<unsigned>(t)); });
   };
   on_threads([&](unsigned t) {
-    uint32_t *hi = hist.data() + static_cast<size_t>(t) * 2 * stride, *lo = hi + stride;
+    uint32_t *hi = hist.get() + static_cast<size_t>(t) * 2 * stride, *lo = hi + stride;
     std::fill(hi, hi + 2 * stride, 0u);
     for (size_t i = chunk(t).first; i < chunk(t).second; ++i) {
       const uint32_t a = from[i], b = to[i];
@@ -216,7 +232,7 @@ bool build_csr_undirected_parallel(uint32_t n, const uint32_t *from, const uint3
   for (uint32_t v = 0; v < n; ++v) c.off[v + 1] += c.off[v];
   c.arcs.resize(c.off[n]);
   on_threads([&](unsigned t) {
-    uint32_t *hi = hist.data() + static_cast<size_t>(t) * 2 * stride, *lo = hi + stride;
+    uint32_t *hi = hist.get() + static_cast<size_t>(t) * 2 * stride, *lo = hi + stride;
     for (size_t i = chunk(t).first; i < chunk(t).second; ++i) {
       const uint32_t a = from[i], b = to[i], h = a > b ? a : b, l = a > b ? b : a;
       c.arcs[c.off[h] + hi[h]++] = Arc{l, static_cast<uint32_t>(i)};
@@ -565,10 +581,11 @@ namespace {
 struct DiG {
   uint32_t              n = 0;
   std::vector<uint32_t> ids;          // local -> global vertex id, ascending
-  std::vector<uint32_t> ea, eb, src;  // directed edges in creation order: local endpoints, undirected edge of origin
-  std::vector<uint8_t>  shadow;       // shared by the graph and its cycle-free copy (Graph.h:773-774: shallow copy)
-  std::vector<uint64_t> weight;
-  std::vector<uint32_t> ord_off, ord; // EdgeOrders per directed edge, in appendOrder order
+  RawVec<uint32_t>      ea, eb, src;  // directed edges in creation order: local endpoints, undirected edge of origin
+  RawVec<uint8_t>       shadow;       // shared by the graph and its cycle-free copy (Graph.h:773-774: shallow copy)
+  RawVec<uint64_t>      weight;
+  std::vector<uint32_t> ord_off;      // EdgeOrders per directed edge, in appendOrder order
+  RawVec<uint32_t>      ord;
   Csr                   succ, pred;
   size_t m() const { return ea.size(); }
   int64_t get_edge(uint32_t a, uint32_t b) const {
@@ -590,7 +607,7 @@ struct DiG {
 // threads, in exactly the creation order of the reference: by pop number of the processing vertex, its arcs in
 // ascending neighbour id, an edge's orders in table order, a direction's edge on its first order.
 DiG get_directed_graph(msgpu_graph &g, uint32_t cid, const std::vector<uint32_t> &members, uint32_t start,
-                       const std::vector<uint8_t> &arc_flags) {
+                       const RawVec<uint8_t> &arc_flags) {
   constexpr uint8_t AF_ALIVE = 1, AF_KEPT = 2, AF_CONS = 4, AF_POS = 8; // per arc: edge alive / has a kept order / consensus set / e_POS
   DiG                                    dg;
   Tick                                   tk;
@@ -678,7 +695,7 @@ DiG get_directed_graph(msgpu_graph &g, uint32_t cid, const std::vector<uint32_t>
     ord_base[i + 1] += ord_base[i];
   }
   const size_t          m = slot_base[np];
-  std::vector<uint32_t> ea(m), eb(m); // global endpoints
+  RawVec<uint32_t> ea(m), eb(m); // global endpoints
   dg.src.resize(m);
   dg.shadow.resize(m);
   dg.weight.resize(m);
@@ -1276,7 +1293,7 @@ std::vector<std::vector<uint32_t>> linearize_graph(DiG &dg) { // lg.cpp:522-629
 
 // one connected component: getDirectedGraph + linearizeGraph + the assemblePath inputs of its paths (main.cpp:620-661)
 std::vector<msgpu_graph::PathStore> component_paths(msgpu_graph *g, uint32_t cid, const std::vector<uint32_t> &comp,
-                                                    const std::vector<uint8_t> &arc_flags) {
+                                                    const RawVec<uint8_t> &arc_flags) {
   uint32_t start = NIL;
   {
     std::vector<uint32_t> sorted(comp);
@@ -1695,7 +1712,7 @@ int msgpu_graph_linearize(msgpu_graph *g) {
   try {
     Tick tick;
     // what the walks read of an edge, next to the arc (a byte of flags instead of a 40-byte record, and no random access)
-    std::vector<uint8_t> arc_flags(g->adj.arcs.size());
+    RawVec<uint8_t> arc_flags(g->adj.arcs.size());
     std::atomic<int>     unkept{0};
     parallel_chunks(arc_flags.size(), [&](unsigned, size_t b, size_t e_end) {
       bool any = false;
