@@ -1021,10 +1021,15 @@ struct PathPeeler {
     return false;
   }
 
-  // split `pool` (alive vertices, ascending) into weakly connected components; lone vertices go to `iso`
+  // split `pool` (alive vertices, ascending) into weakly connected components; lone vertices go to `iso`.  The components
+  // are independent (a solve reads and writes the scratch of its own vertices only): those of a large pool -- the first
+  // split of a large component, thousands of them -- are solved on the stage's threads and enter the heap in the order a
+  // single thread would have found them.
   void split(const std::vector<uint32_t> &pool) {
     ++lab_round;
     std::vector<uint32_t> members;
+    std::vector<Comp>     found;
+    const bool            fan_out = pool.size() >= par_min() / 4 && stage_threads() > 1;
     for (uint32_t s : pool) {
       if (!valive[s] || lab[s] == lab_round) continue;
       members.assign(1, s);
@@ -1042,23 +1047,39 @@ struct PathPeeler {
         iso.push(s);
         continue;
       }
-      std::sort(members.begin(), members.end());
       Comp c;
       c.members = members;
-      solve(c);
+      if (fan_out) {
+        found.push_back(std::move(c));
+        continue;
+      }
+      std::sort(c.members.begin(), c.members.end());
+      solve(c, ++round, nodes);
+      heap.push(Key{static_cast<uint32_t>(c.path.size()), c.segroot, static_cast<uint32_t>(comps.size())});
+      comps.push_back(std::move(c));
+    }
+    if (found.empty()) return;
+    const uint32_t first_round = round + 1; // every solve has a round of its own
+    round += static_cast<uint32_t>(found.size());
+    parallel_dynamic(found.size(), 16, [&](size_t b, size_t e) {
+      std::vector<Node> my_nodes;
+      for (size_t k = b; k < e; ++k) {
+        std::sort(found[k].members.begin(), found[k].members.end());
+        solve(found[k], first_round + static_cast<uint32_t>(k), my_nodes);
+      }
+    });
+    for (Comp &c : found) {
       heap.push(Key{static_cast<uint32_t>(c.path.size()), c.segroot, static_cast<uint32_t>(comps.size())});
       comps.push_back(std::move(c));
     }
   }
 
-  int32_t node(uint32_t v, int32_t parent) {
-    nodes.push_back(Node{v, parent});
-    return static_cast<int32_t>(nodes.size() - 1);
-  }
-
   // sortTopologically + findConservationPathAlt on one component
-  void solve(Comp &c) {
-    ++round;
+  void solve(Comp &c, const uint32_t round, std::vector<Node> &nodes) { // (round, nodes: this solve's own -- solves may run side by side)
+    auto node = [&](uint32_t v, int32_t parent) {
+      nodes.push_back(Node{v, parent});
+      return static_cast<int32_t>(nodes.size() - 1);
+    };
     nodes.clear();
     std::vector<uint32_t> order, stack;
     order.reserve(c.members.size());
