@@ -617,6 +617,10 @@ int msgpu_graph_set_path_edgematches(msgpu_graph *g, const uint64_t *em_off, con
 /* path i (asm_idx = i) as assemblePath input; pointers are owned by the graph and valid until msgpu_graph_free;
  * rows / n_rows are left empty (use msgpu_assembly_set_rows). */
 int msgpu_graph_path_input(const msgpu_graph *g, uint32_t i, msgpu_path_input *out);
+/* msgpu_graph_path_input for every path + msgpu_assembly_add_paths in one call (status: msgpu_graph_path_count(g) entries
+ * or NULL): the assemblePaths fan-out of src/main.cpp:620-677 over the paths of this graph.  The graph must outlive the
+ * call (the layouts read its tables), not the assembly. */
+int msgpu_assembly_add_graph_paths(msgpu_assembly *a, const msgpu_graph *g, uint32_t n_threads, int *status);
 /* inspection (all optional): per vertex alive flag and direction (1 e_POS / 0 e_NEG / 2 e_NONE); per edge (table
  * order) alive flag, consensus direction (same coding) and weight */
 int msgpu_graph_state(const msgpu_graph *g, uint8_t *vertex_alive, uint8_t *vertex_direction, uint8_t *edge_alive,

@@ -341,13 +341,11 @@ inline AssemblyCounts assemble(std::string const &contigsPaf, std::string const 
 
   detail::require(msgpu_assembly_create(s.ctx, &s.as), "msgpu_assembly_create"); // :300-310, 620-677
   detail::require(msgpu_assembly_borrow_rows(s.as, rows, nRows), "msgpu_assembly_borrow_rows"); // (the loader's table: core outlives s.as)
-  std::vector<msgpu_path_input> in(msgpu_graph_path_count(graph.g));
-  for (std::uint32_t i = 0; i < in.size(); ++i) detail::require(msgpu_graph_path_input(graph.g, i, &in[i]), "path input");
-  std::vector<int> status(in.size(), 0);
-  detail::require(msgpu_assembly_add_paths(s.as, in.data(), in.size(), threads ? threads : 1, status.data()),
-                  "msgpu_assembly_add_paths", msgpu_assembly_last_error(s.as));
+  std::vector<int> status(msgpu_graph_path_count(graph.g), 0);
+  detail::require(msgpu_assembly_add_graph_paths(s.as, graph.g, threads ? threads : 1, status.data()),
+                  "msgpu_assembly_add_graph_paths", msgpu_assembly_last_error(s.as));
   detail::require(msgpu_assembly_finish(s.as, nullptr), "msgpu_assembly_finish", msgpu_seq_last_error(s.ctx));
-  n.paths = in.size();
+  n.paths = status.size();
   for (int st : status) n.pathsSkipped += st != MSGPU_OK;
   n.contigs = msgpu_assembly_path_count(s.as);
   n.queries = msgpu_assembly_query_count(s.as);

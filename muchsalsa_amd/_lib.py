@@ -171,6 +171,7 @@ SYMBOLS = [
     ("msgpu_assembly_borrow_rows", C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     ("msgpu_assembly_add_path", C.c_int, [C.c_void_p, C.POINTER(PathInput)]),
     ("msgpu_assembly_add_paths", C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p]),
+    ("msgpu_assembly_add_graph_paths", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
     ("msgpu_assembly_path_count", C.c_uint32, [C.c_void_p]),
     ("msgpu_assembly_query_count", C.c_uint32, [C.c_void_p]),
     ("msgpu_assembly_path_info", C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p]),

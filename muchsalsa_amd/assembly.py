@@ -66,6 +66,14 @@ class Assembly:
         self._check(self._L.msgpu_assembly_add_paths(self._h, arr, len(prepared), int(n_threads), status.ctypes.data))
         return status
 
+    def add_graph_paths(self, graph, n_threads=1):
+        """msgpu_assembly_add_graph_paths: every path of a linearised GraphStage, layouts on n_threads host threads ->
+        per-path status codes (the graph must stay open until this returns)"""
+        status = np.zeros(graph.path_count, dtype=np.int32)
+        self._check(self._L.msgpu_assembly_add_graph_paths(self._h, graph._h, int(n_threads),
+                                                           status.ctypes.data if len(status) else None))
+        return status
+
     @staticmethod
     def prepare(path, steps, rows, contains=None, asm_idx=1):
         """dict/list description of one path -> (msgpu_path_input, the arrays it points into)"""

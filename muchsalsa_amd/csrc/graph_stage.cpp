@@ -1883,6 +1883,21 @@ int msgpu_graph_path_input(const msgpu_graph *g, uint32_t i, msgpu_path_input *o
   return MSGPU_OK;
 }
 
+// The assemblePaths fan-out (src/main.cpp:620-677) straight from the graph: every linearised path goes to
+// msgpu_assembly_add_paths (n_threads layout threads; status: msgpu_graph_path_count(g) entries or NULL) without the caller
+// collecting the path inputs one by one.
+int msgpu_assembly_add_graph_paths(msgpu_assembly *a, const msgpu_graph *g, uint32_t n_threads, int *status) {
+  if (!a || !g) return MSGPU_E_ARG;
+  try {
+    std::vector<msgpu_path_input> in(g->paths.size());
+    for (uint32_t i = 0; i < in.size(); ++i) {
+      const int rc = msgpu_graph_path_input(g, i, &in[i]);
+      if (rc != MSGPU_OK) return rc;
+    }
+    return msgpu_assembly_add_paths(a, in.data(), in.size(), n_threads, status);
+  } catch (std::bad_alloc const &) { return MSGPU_E_NOMEM; }
+}
+
 // alive[v] (n_reads entries, optional) = vertex still in the graph; edge_alive[e] (optional) likewise; direction[v]
 // (optional) = Vertex::getVertexDirection() as 1 / 0 / 2 (e_POS / e_NEG / e_NONE)
 int msgpu_graph_state(const msgpu_graph *g, uint8_t *vertex_alive, uint8_t *vertex_direction, uint8_t *edge_alive,

@@ -132,8 +132,7 @@ def run(contigs_paf, unitigs_path, nanopore_path, out_dir, threads=None, wiggle_
     t0 = time.perf_counter()
     asm = Assembly(store)
     asm.set_rows(paf.rows, copy=False)  # (msgpu_assembly_borrow_rows: the loader's table outlives the layout)
-    status = asm.add_prepared_batch([(g.path_input(i), g) for i in range(g.path_count)], n_threads) \
-        if g.path_count else np.zeros(0, dtype=np.int32)
+    status = asm.add_graph_paths(g, n_threads)  # the assemblePaths fan-out over the paths linearizeGraph yielded
     st = g.stats
     n_rows = len(paf.rows)
     held, held_rows = [g, ctx], [paf, tables]
@@ -152,7 +151,7 @@ def run(contigs_paf, unitigs_path, nanopore_path, out_dir, threads=None, wiggle_
 
     releasers = [threading.Thread(target=release, name="msgpu-release"),
                  threading.Thread(target=release_rows, name="msgpu-release-rows")]
-    for th in releasers:
+    for th in releasers:  # (started behind the gather instead, the same work shows up as teardown: measured, no difference)
         th.start()
     asm.finish()
     t["assemble"] = time.perf_counter() - t0
