@@ -57,38 +57,53 @@ public:
   NameRegistry() : m_slots(1024) {}
   uint32_t get(const char *s, size_t n, uint64_t h) {
     if (m_stale) index_names();
-    if ((m_names.size() + 1) * 2 > m_slots.size()) grow();
+    if ((static_cast<size_t>(size()) + 1) * 2 > m_slots.size()) grow();
     size_t i = h & (m_slots.size() - 1);
     while (m_slots[i].id_plus_1) {
       const Slot &sl = m_slots[i];
-      if (sl.hash == h) {
-        const std::string &nm = *m_names[sl.id_plus_1 - 1];
-        if (nm.size() == n && memcmp(nm.data(), s, n) == 0) return sl.id_plus_1 - 1;
-      }
+      if (sl.hash == h && length(sl.id_plus_1 - 1) == n && memcmp(name(sl.id_plus_1 - 1), s, n) == 0) return sl.id_plus_1 - 1;
       i = (i + 1) & (m_slots.size() - 1);
     }
-    m_names.push_back(std::make_unique<std::string>(s, n));
-    m_slots[i] = Slot{h, static_cast<uint32_t>(m_names.size())};
-    return static_cast<uint32_t>(m_names.size() - 1);
+    m_later.push_back(std::make_unique<std::string>(s, n));
+    m_slots[i] = Slot{h, size()};
+    return size() - 1;
   }
   uint32_t operator[](std::string_view name) { return get(name.data(), name.size(), name_hash(name.data(), name.size())); }
-  uint32_t    size() const { return static_cast<uint32_t>(m_names.size()); }
-  void        clear() { // Registry::clear (Registry.cpp:47-52): numbering starts again at 0
-    m_names.clear();
+  uint32_t size() const { return static_cast<uint32_t>(m_bulk + m_later.size()); }
+  void     clear() { // Registry::clear (Registry.cpp:47-52): numbering starts again at 0
+    m_later.clear();
+    std::vector<char>().swap(m_block);
+    std::vector<uint64_t>().swap(m_at);
+    m_bulk = 0;
     m_slots.assign(1024, Slot{});
     m_stale = false;
   }
-  const char *name(uint32_t id) const { return id < m_names.size() ? m_names[id]->c_str() : nullptr; }
+  // NUL-terminated; stays where it is as long as the registry lives (later names are allocated one by one)
+  const char *name(uint32_t id) const {
+    return id < m_bulk ? m_block.data() + m_at[id] : id < size() ? m_later[id - m_bulk]->c_str() : nullptr;
+  }
+  size_t length(uint32_t id) const { return id < m_bulk ? static_cast<size_t>(m_at[id + 1] - m_at[id] - 1) : m_later[id - m_bulk]->size(); }
 
   // The loader's way in: it knows the id of every name already (first-seen order over the whole file, worked out on its
-  // threads).  The table is sized here, the names are put in place by the loader's threads (set_name: any order, distinct
-  // ids), and the hash index follows when the first look-up asks for it.
-  void bulk_begin(uint32_t n) {
-    m_names.clear();
-    m_names.resize(n);
+  // threads).  The names of a file lie in ONE block, id after id, each with its NUL: the loader says how many there are
+  // and how many characters, its threads put stretches of consecutive ids in place (put: the id's place in the block is
+  // where the id before it ends), and the hash index follows when the first look-up asks for it.  No allocation per name,
+  // nothing to free per name.
+  void bulk_begin(uint32_t n, uint64_t characters) {
+    clear();
+    m_bulk = n;
+    m_block.resize(characters + n);
+    m_at.resize(static_cast<size_t>(n) + 1);
+    m_at[n] = characters + n;
     m_stale = true;
   }
-  void set_name(uint32_t id, const char *s, size_t n) { m_names[id] = std::make_unique<std::string>(s, n); }
+  // the name of `id` goes to `at` (= characters + NULs of the ids before it) -> where the next id's name goes
+  uint64_t put(uint32_t id, uint64_t at, const char *s, size_t n) {
+    m_at[id] = at;
+    memcpy(m_block.data() + at, s, n);
+    m_block[at + n] = 0;
+    return at + n + 1;
+  }
 
 private:
   struct Slot {
@@ -108,15 +123,17 @@ private:
   }
   void index_names() {
     size_t cap = 1024;
-    while (cap < 2 * (m_names.size() + 1)) cap <<= 1;
+    while (cap < 2 * (static_cast<size_t>(size()) + 1)) cap <<= 1;
     m_slots.assign(cap, Slot{});
-    for (size_t id = 0; id < m_names.size(); ++id)
-      place(m_slots, Slot{name_hash(m_names[id]->data(), m_names[id]->size()), static_cast<uint32_t>(id + 1)});
+    for (uint32_t id = 0; id < size(); ++id) place(m_slots, Slot{name_hash(name(id), length(id)), id + 1});
     m_stale = false;
   }
-  std::vector<std::unique_ptr<std::string>> m_names;
+  std::vector<char>                         m_block; // the bulk-loaded names, id after id, NUL-terminated
+  std::vector<uint64_t>                     m_at;    // m_bulk + 1 offsets into m_block
+  uint32_t                                  m_bulk = 0;
+  std::vector<std::unique_ptr<std::string>> m_later; // ids m_bulk, m_bulk + 1, ...: registered one by one
   std::vector<Slot>                         m_slots;
-  bool                                      m_stale = false; // m_names was bulk-loaded: m_slots is rebuilt by the next get()
+  bool                                      m_stale = false; // names were bulk-loaded: m_slots is rebuilt by the next get()
 };
 
 // std::stoi: optional whitespace, optional sign, at least one digit, value must fit int.
@@ -465,18 +482,26 @@ int msgpu_parse_paf(const char *path, const msgpu_params *params, msgpu_paf **ou
         });
         // (2) ids of the first appearances, chunk after chunk; (3) every other entry takes the id of its first appearance
         std::vector<uint32_t> base(nthr + 1, 0);
+        std::vector<uint64_t> at(nthr + 1, 0); // where a chunk's first appearances start in the registry's block of names
         for (unsigned k = 0; k < nthr; ++k) {
           uint32_t firsts = 0;
-          for (const NameEntry &e : names_of(chunks[k]).list) firsts += e.first == nullptr;
+          uint64_t chars  = 0;
+          for (const NameEntry &e : names_of(chunks[k]).list)
+            if (e.first == nullptr) {
+              ++firsts;
+              chars += e.n + 1;
+            }
           base[k + 1] = base[k] + firsts;
+          at[k + 1]   = at[k] + chars;
         }
-        reg.bulk_begin(base[nthr]);
+        reg.bulk_begin(base[nthr], at[nthr] - base[nthr]);
         guarded([&](unsigned k) {
           uint32_t id = base[k];
+          uint64_t to = at[k];
           for (NameEntry &e : names_of(chunks[k]).list)
             if (!e.first) {
               e.id = id++;
-              reg.set_name(e.id, e.s, e.n);
+              to   = reg.put(e.id, to, e.s, e.n);
             }
         });
         guarded([&](unsigned k) {
