@@ -145,3 +145,30 @@ def test_chunked_parse_keeps_the_registry_order(oracle, tmp_path, monkeypatch, t
     ids, space = got.register_sequences(0, sequences.SeqFile(str(fa)))
     n = len(want["read_names"])
     assert list(ids) == [want["read_names"].index("read_3"), n, n - 1] and space == n + 1
+
+
+def test_column_counts_and_trailing_tabs(oracle, tmp_path):
+    """std::getline drops an empty token behind the final delimiter and keeps empty tokens in the middle; the tokeniser
+    looks at the first ten columns only.  Lines of every length around the 16-byte steps of the line scanner, with and
+    without columns behind the tenth, against the oracle's parser; a line with nine columns and a trailing tab is short."""
+    from muchsalsa_amd import _lib
+    ten = _line(extra="")                     # exactly ten columns
+    assert len(overlap.parse_paf(_write(tmp_path, [ten, SENTINEL])).rows) == 1
+    assert len(overlap.parse_paf(_write(tmp_path, [ten + "\t", SENTINEL])).rows) == 1          # an empty eleventh token
+    assert len(overlap.parse_paf(_write(tmp_path, [ten + "\t\t\tx\t", SENTINEL])).rows) == 1   # empty tokens in the middle
+    nine = "\t".join(ten.split("\t")[:9])
+    for bad in (nine, nine + "\t"):
+        with pytest.raises(overlap.MsgpuError) as e:
+            overlap.parse_paf(_write(tmp_path, [bad, SENTINEL]))
+        assert e.value.code == _lib.E_FORMAT
+    lines = []
+    for pad in range(0, 40):                   # names of every length: tabs and line ends at every offset of a 16-byte step
+        lines.append(_line(q="u" + "x" * pad, t="r" + "y" * (pad % 7), extra="600\t60" if pad % 3 else ""))
+        lines.append(_line(q="u%d" % pad, t="r" * (pad + 1), extra="z" * pad))
+    path = _write(tmp_path, lines + [SENTINEL])
+    got, want = overlap.parse_paf(path), oracle.parse_paf(path)
+    assert got.rows.tobytes() == want["rows"].tobytes() and len(got.rows) == len(lines)
+    assert got.read_names == want["read_names"] and got.anchor_names == want["anchor_names"]
+    # the same without a trailing newline behind the (never parsed) last line, and with the file ending inside a 16-byte step
+    path = _write(tmp_path, lines + ["x"], trailing_newline=False)
+    assert overlap.parse_paf(path).rows.tobytes() == want["rows"].tobytes()
