@@ -394,6 +394,7 @@ int msgpu::seq_parse_into(const char *path, int is_fastq, msgpu::SeqDestination 
     bool consistent = true;
     for (unsigned k = 0; k + 1 < nc; ++k) consistent = consistent && stops[k] == starts[k + 1];
     if (!consistent) { // (only a FASTQ whose quality lines start with '@' in unlucky places gets here)
+      if (dbg) fprintf(stderr, "msgpu_seq_parse %s: the cuts did not verify, one pass over the file\n", path);
       parts.assign(1, ChunkRecords());
       dest->restart();
       msgpu::ByteSink &sink = *dest->stretch(0);

@@ -241,12 +241,18 @@ def test_parse_upload_equals_parse_then_upload(tmp_path, monkeypatch, threads):
     for i in range(400):  # quality lines that start with '@': the cuts land on them and the file takes the one-pass route
         s = seq(rng.integers(1, 3000))
         evil += b"@e%d\n" % i + s + b"\n+\n@" + b"F" * (len(s) - 1) + b"\n"
+    evil3 = b""
+    for i in range(400):  # ... and three-line records whose first quality line begins with '@' and whose third begins with '+'
+        s = seq(rng.integers(3, 3000))
+        a, b = len(s) // 3, 2 * len(s) // 3
+        q = b"@" + b"F" * (a - 1), b"F" * (b - a), b"+" + b"F" * (len(s) - b - 1)
+        evil3 += b"@t%d\n" % i + s[:a] + b"\n" + s[a:b] + b"\n" + s[b:] + b"\n+\n" + b"\n".join(q) + b"\n"
     monkeypatch.setenv("MSGPU_SEQ_THREADS", str(threads))
     small = [("a.fa", b">r1 desc\nACGT\nNN\n>r2\n\nTT TT\r\n>r1\nGGGG\n>r3"),  # dup id, blank / CRLF / space, empty record
              ("b.fasta", b"junk before\n>x\tdesc\nAC\nGT"),                     # no trailing newline, tab in the header
              ("c.fq", b"@q1 a\nACGT\nAC\n+\nFFFF\nFF\n@q2\nTTTT\n+q2\nIIII\n"),  # multi-line FASTQ record
              ("f.fa", b"no records here\n")]
-    for name, text in [("big.fa", fa), ("evil.fq", evil), ("none.fa", b"")] + small:
+    for name, text in [("big.fa", fa), ("evil.fq", evil), ("evil3.fq", evil3), ("none.fa", b"")] + small:
         path = tmp_path / name
         path.write_bytes(text)
         host = S.SeqFile(str(path))

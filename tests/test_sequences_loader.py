@@ -92,7 +92,13 @@ def test_chunked_parse_equals_sequential(oracle, tmp_path, monkeypatch, threads)
     for i in range(300):  # quality lines that start with '@', sequence lengths that vary: cuts land on them
         s = seq(int(rng.integers(1, 200)))
         evil += b"@e%d\n" % i + s + b"\n+\n" + b"@" + b"F" * (len(s) - 1) + b"\n"
-    for name, text in (("m.fa", fa), ("s.fq", fq), ("evil.fq", evil), ("one.fa", b">x\nACGT\n"), ("none.fa", b"")):
+    evil3 = b""
+    for i in range(300):  # three-line records whose first quality line begins with '@' and whose third begins with '+'
+        s = seq(int(rng.integers(3, 200)))
+        a, b = len(s) // 3, 2 * len(s) // 3
+        q = b"@" + b"F" * (a - 1), b"F" * (b - a), b"+" + b"F" * (len(s) - b - 1)
+        evil3 += b"@t%d\n" % i + s[:a] + b"\n" + s[a:b] + b"\n" + s[b:] + b"\n+\n" + b"\n".join(q) + b"\n"
+    for name, text in (("m.fa", fa), ("s.fq", fq), ("evil.fq", evil), ("evil3.fq", evil3), ("one.fa", b">x\nACGT\n"), ("none.fa", b"")):
         path = _write(tmp_path, name, text)
         monkeypatch.setenv("MSGPU_SEQ_THREADS", "1")
         want = _records(sequences.SeqFile(path))
@@ -103,7 +109,7 @@ def test_chunked_parse_equals_sequential(oracle, tmp_path, monkeypatch, threads)
         # what goes to HBM: the records where they lie in ONE buffer, nothing but bases between them (the 2-bit form of the
         # store keeps a list of every other byte)
         buf = f.buffer()
-        assert len(buf) <= len(text) and (name == "evil.fq" or set(buf) <= set(b"ACGTN")), (name, threads)
+        assert len(buf) <= len(text) and (name.startswith("evil") or set(buf) <= set(b"ACGTN")), (name, threads)
         o_names, o_seqs = oracle.seq_load(path)
         assert got == (o_names, o_seqs), (name, "oracle")
     assert len(_records(sequences.SeqFile(_write(tmp_path, "m2.fa", fa)))[0]) == len({b"r%d" % (i if i % 37 else i // 2) for i in range(400)})
