@@ -692,39 +692,46 @@ def tiled_leg(torch, dev, args, workload, threads, seed_offset=0):
             "system_note": "contig bases / (findContractionEdges + graph stage + path EdgeMatches + assemblePath), tables resident"}
 
 
+def write_e2e_inputs(d, w, tab):
+    """BASELINE-shaped inputs of the whole executable as files in directory d: contigs.paf (the table as PAF text + the
+    line the reference never parses), nanopore.fa, unitigs.fa.  Names are the generator's indices (the Registry does not
+    care what a name looks like)."""
+    import pandas as pd
+    from muchsalsa_amd import synth
+    n = len(tab["qname_id"])
+    pd.DataFrame({"q": tab["qname_id"], "ql": tab["qlen"], "qs": tab["qstart"], "qe": tab["qend"],
+                  "s": np.where(tab["strand"], "+", "-"), "t": tab["tname_id"], "tl": tab["tlen"], "ts": tab["tstart"],
+                  "te": tab["tend"], "nm": tab["nmatch"], "bl": tab["qend"] - tab["qstart"],
+                  "mq": np.full(n, 60)}).to_csv(os.path.join(d, "contigs.paf"), sep="\t", header=False, index=False)
+    with open(os.path.join(d, "contigs.paf"), "a") as f:
+        f.write("0\t1\t0\t1\t+\t0\t1\t0\t1\t0\t1\t0\n")  # the line the reference never parses (BlastFileReader.cpp:76)
+    n_reads, L, seed = w["n_reads"], w["read_len"], w["seed"]
+    G, r_start, r_fwd = synth.read_layout(n_reads, L, seed)
+    a_start, a_len = synth.anchor_layout(n_reads, L, w["n_anchors"], seed)
+    genome = synth.genome_bases(G, seed).tobytes()
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    with open(os.path.join(d, "nanopore.fa"), "wb") as f:
+        for i in range(n_reads):
+            sq = genome[r_start[i]: r_start[i] + L]
+            f.write(b">%d\n" % i + (sq if r_fwd[i] else sq.translate(comp)[::-1]) + b"\n")
+    with open(os.path.join(d, "unitigs.fa"), "wb") as f:
+        for j in range(len(a_start)):
+            f.write(b">%d\n" % j + genome[a_start[j]: a_start[j] + a_len[j]] + b"\n")
+
+
 def e2e_leg(args, w, tab, read_names_all, threads):
     """The whole executable, files in -> files out, at the size of the workload: the PAF text and the two FASTA files of
     the BASELINE workload are written to a temporary directory (untimed) and muchsalsa_amd.pipeline.run (= main() of the
     reference, src/main.cpp:130-322) turns them into temp_1.{target.fa, query.fa, align.paf}.  Stage seconds as the
-    driver measures them.  Names are the generator's indices (the Registry does not care what a name looks like)."""
+    driver measures them."""
     import shutil
     import tempfile
-    import pandas as pd
-    from muchsalsa_amd import pipeline, synth
+    from muchsalsa_amd import pipeline
     t_gen = time.perf_counter()
     base = "/dev/shm" if os.path.isdir("/dev/shm") and shutil.disk_usage("/dev/shm").free > 8e9 else None
     d = tempfile.mkdtemp(prefix="msgpu_e2e_", dir=base)
     try:
-        n = len(tab["qname_id"])
-        pd.DataFrame({"q": tab["qname_id"], "ql": tab["qlen"], "qs": tab["qstart"], "qe": tab["qend"],
-                      "s": np.where(tab["strand"], "+", "-"), "t": tab["tname_id"], "tl": tab["tlen"], "ts": tab["tstart"],
-                      "te": tab["tend"], "nm": tab["nmatch"], "bl": tab["qend"] - tab["qstart"],
-                      "mq": np.full(n, 60)}).to_csv(os.path.join(d, "contigs.paf"), sep="\t", header=False, index=False)
-        with open(os.path.join(d, "contigs.paf"), "a") as f:
-            f.write("0\t1\t0\t1\t+\t0\t1\t0\t1\t0\t1\t0\n")  # the line the reference never parses (BlastFileReader.cpp:76)
-        n_reads, L, seed = w["n_reads"], w["read_len"], w["seed"]
-        G, r_start, r_fwd = synth.read_layout(n_reads, L, seed)
-        a_start, a_len = synth.anchor_layout(n_reads, L, w["n_anchors"], seed)
-        genome = synth.genome_bases(G, seed).tobytes()
-        comp = bytes.maketrans(b"ACGT", b"TGCA")
-        with open(os.path.join(d, "nanopore.fa"), "wb") as f:
-            for i in range(n_reads):
-                sq = genome[r_start[i]: r_start[i] + L]
-                f.write(b">%d\n" % i + (sq if r_fwd[i] else sq.translate(comp)[::-1]) + b"\n")
-        with open(os.path.join(d, "unitigs.fa"), "wb") as f:
-            for j in range(len(a_start)):
-                f.write(b">%d\n" % j + genome[a_start[j]: a_start[j] + a_len[j]] + b"\n")
-        del genome
+        write_e2e_inputs(d, w, tab)
         in_bytes = {k: os.path.getsize(os.path.join(d, k)) for k in ("contigs.paf", "nanopore.fa", "unitigs.fa")}
         t_gen = time.perf_counter() - t_gen
         out = os.path.join(d, "out")
