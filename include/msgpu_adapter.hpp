@@ -26,6 +26,7 @@
 #include <exception>
 #include <stdexcept>
 #include <string>
+#include <future>
 #include <thread>
 #include <utility>
 #include <vector>
@@ -286,17 +287,42 @@ inline AssemblyCounts assemble(std::string const &contigsPaf, std::string const 
       detail::require(msgpu_seq_pack_store(s.ctx, kind), "msgpu_seq_pack_store", msgpu_seq_last_error(s.ctx)); // 2 bits per base in HBM
     } catch (...) { loadError[kind] = std::current_exception(); }
   };
-  std::thread loaders[2] = {std::thread([&]() { load(0, nanoporePath, -1, &s.fn, "nanopore file"); }),
-                            std::thread([&]() { load(1, unitigsPath, 0, &s.fi, "unitig file"); })};
-  struct Joiner {
-    std::thread (&t)[2];
-    ~Joiner() {
-      for (auto &x : t)
-        if (x.joinable()) x.join();
+  // Registry::operator[] for the records of both files (SequenceAccessor.cpp:171,215) needs the PAF's registries: a third
+  // thread waits for the two loaders and for the PAF, then registers the records and hands the ids to the stores -- beside
+  // the overlap and graph stages, which read neither.
+  std::promise<bool> pafParsed;
+  std::exception_ptr regError;
+  std::thread        loaders[2] = {std::thread([&]() { load(0, nanoporePath, -1, &s.fn, "nanopore file"); }),
+                                   std::thread([&]() { load(1, unitigsPath, 0, &s.fi, "unitig file"); })};
+  std::thread        registrar([&, parsed = pafParsed.get_future()]() mutable {
+    for (auto &t : loaders) t.join();
+    try {
+      if (!parsed.get()) return; // (the PAF could not be read: nothing to register)
+      for (auto &e : loadError)
+        if (e) std::rethrow_exception(e);
+      std::uint32_t                    readSpace = 0, anchorSpace = 0;
+      std::vector<std::uint32_t> const readIds = core.registerSequences(0, s.fn, &readSpace), anchorIds = core.registerSequences(1, s.fi, &anchorSpace);
+      detail::require(msgpu_seq_set_ids(s.ctx, 0, s.fn, readIds.data(), readSpace), "ids of the reads", msgpu_seq_last_error(s.ctx));
+      detail::require(msgpu_seq_set_ids(s.ctx, 1, s.fi, anchorIds.data(), anchorSpace), "ids of the unitigs",
+                      msgpu_seq_last_error(s.ctx));
+    } catch (...) { regError = std::current_exception(); }
+  });
+  struct Joiner { // (whatever happens below, the three threads are over before their captures go)
+    std::promise<bool> &parsed;
+    std::thread        &t;
+    bool                told = false;
+    void tell(bool ok) {
+      if (!told) parsed.set_value(ok);
+      told = true;
     }
-  } joiner{loaders};
+    ~Joiner() {
+      tell(false);
+      if (t.joinable()) t.join();
+    }
+  } joiner{pafParsed, registrar};
 
   core.parse(contigsPaf); // :153-156 (the rows travel to HBM inside overlapResident below)
+  joiner.tell(true);
 
   // :157 + :170-178 -- calculateEdges and the chainingAndOverlaps fan-out as windows of owner reads on two HIP streams (the
   // ThreadPool replacement); the tables arrive in pinned host memory while later windows compute, the EdgeMatch table
@@ -330,14 +356,8 @@ inline AssemblyCounts assemble(std::string const &contigsPaf, std::string const 
                     msgpu_graph_last_error(graph.g));
   }
 
-  for (auto &t : loaders) t.join();
-  for (auto &e : loadError)
-    if (e) std::rethrow_exception(e);
-  std::uint32_t                    readSpace = 0, anchorSpace = 0;
-  std::vector<std::uint32_t> const readIds = core.registerSequences(0, s.fn, &readSpace), anchorIds = core.registerSequences(1, s.fi, &anchorSpace);
-  detail::require(msgpu_seq_set_ids(s.ctx, 0, s.fn, readIds.data(), readSpace), "ids of the reads", msgpu_seq_last_error(s.ctx));
-  detail::require(msgpu_seq_set_ids(s.ctx, 1, s.fi, anchorIds.data(), anchorSpace), "ids of the unitigs",
-                  msgpu_seq_last_error(s.ctx));
+  registrar.join();
+  if (regError) std::rethrow_exception(regError);
 
   detail::require(msgpu_assembly_create(s.ctx, &s.as), "msgpu_assembly_create"); // :300-310, 620-677
   detail::require(msgpu_assembly_borrow_rows(s.as, rows, nRows), "msgpu_assembly_borrow_rows"); // (the loader's table: core outlives s.as)
@@ -355,14 +375,22 @@ inline AssemblyCounts assemble(std::string const &contigsPaf, std::string const 
     n.targetBases += pi.target_len;
   }
   char const *const names[3] = {"/temp_1.target.fa", "/temp_1.query.fa", "/temp_1.align.paf"}; // :294-296
-  for (int w = 0; w < 3; ++w) {
+  std::string       writeError[3];
+  auto              write = [&](int w) { // (straight from the library's buffers, the three files side by side)
     std::uint64_t len  = 0;
     char const   *text = msgpu_assembly_text(s.as, w, &len);
     std::FILE    *f    = std::fopen((outDir + names[w]).c_str(), "wb");
-    if (!f) throw std::runtime_error("cannot write " + outDir + names[w]);
-    if (len) std::fwrite(text, 1, len, f);
-    std::fclose(f);
+    if (!f || (len && std::fwrite(text, 1, len, f) != len)) writeError[w] = "cannot write " + outDir + names[w];
+    if (f && std::fclose(f) != 0) writeError[w] = "cannot write " + outDir + names[w];
+  };
+  {
+    std::thread a([&] { write(0); }), b([&] { write(1); });
+    write(2);
+    a.join();
+    b.join();
   }
+  for (auto const &e : writeError)
+    if (!e.empty()) throw std::runtime_error(e);
   return n;
 }
 

@@ -62,3 +62,36 @@ def test_cpp_whole_flow_writes_the_same_files_as_the_python_driver(adapter_bin, 
     assert got["contigs"] >= 1 and got["target_bases"] > 200_000
     for name in ("temp_1.target.fa", "temp_1.query.fa", "temp_1.align.paf"):
         assert (tmp_path / "cpp" / name).read_bytes() == (tmp_path / "py" / name).read_bytes(), name
+
+
+@pytest.mark.gpu
+def test_executable_takes_the_reference_argument_list(tmp_path):
+    """muchsalsa_amd/muchsalsa_gpu (csrc/muchsalsa_main.cpp, built by the library's Makefile): the reference's executable on
+    libmsgpu with no Python in the process -- same argument list (src/Application.cpp:34-39), same three files as the Python
+    driver writes for the same inputs, "Finished assembly" at the end; too few arguments -> usage and -1."""
+    import __graft_entry__ as g
+    from graphcases import make_dataset
+    from muchsalsa_amd import pipeline
+    g.build()
+    exe = os.path.join(ROOT, "muchsalsa_amd", "muchsalsa_gpu")
+    assert os.path.exists(exe)
+    r = subprocess.run([exe, "only", "three", "args"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 255 and "usage" in r.stderr
+    make_dataset(tmp_path, 12, 5, False)
+    (tmp_path / "cpp").mkdir()
+    (tmp_path / "py").mkdir()
+    r = subprocess.run([exe, str(tmp_path / "contigs.paf"), str(tmp_path / "unitigs.fa"), str(tmp_path / "nanopore.fa"),
+                        str(tmp_path / "cpp"), "3", "300"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = r.stdout.strip().splitlines()
+    assert lines[-1] == "Finished assembly"
+    got = json.loads(lines[-2])
+    want = pipeline.run(str(tmp_path / "contigs.paf"), str(tmp_path / "unitigs.fa"), str(tmp_path / "nanopore.fa"),
+                        str(tmp_path / "py"), threads=3)
+    for k in ("rows", "edges", "contraction_edges", "paths", "paths_skipped", "contigs", "target_bases", "queries"):
+        assert got[k] == want[k], k
+    for name in ("temp_1.target.fa", "temp_1.query.fa", "temp_1.align.paf"):
+        assert (tmp_path / "cpp" / name).read_bytes() == (tmp_path / "py" / name).read_bytes(), name
+    r = subprocess.run([exe, str(tmp_path / "missing.paf"), str(tmp_path / "unitigs.fa"), str(tmp_path / "nanopore.fa"),
+                        str(tmp_path / "cpp")], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 1 and "muchsalsa_gpu:" in r.stderr

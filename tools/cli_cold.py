@@ -41,6 +41,18 @@ def main():
                 wall, inside, sec.get("device_init", 0.0), res["contigs"]), flush=True)
             if rep == reps - 1:
                 print(json.dumps(sec))
+        exe = os.path.join(ROOT, "muchsalsa_amd", "muchsalsa_gpu")  # the same without Python in the process
+        for rep in range(reps if os.path.exists(exe) else 0):
+            out = os.path.join(d, "cpp%d" % rep)
+            os.mkdir(out)
+            t0 = time.perf_counter()
+            r = subprocess.run([exe, os.path.join(d, "contigs.paf"), os.path.join(d, "unitigs.fa"), os.path.join(d, "nanopore.fa"), out],
+                               capture_output=True, text=True)
+            wall = time.perf_counter() - t0
+            if r.returncode != 0:
+                print(r.stderr[-2000:])
+                raise SystemExit(r.returncode)
+            print("muchsalsa_gpu (C++): process wall %.3f s; %s" % (wall, r.stdout.strip().splitlines()[-2]), flush=True)
     finally:
         shutil.rmtree(d, ignore_errors=True)
 
