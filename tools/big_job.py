@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""A job several times BASELINE configs[2] through the single pass and the resident dispatcher, every table against the C
+oracle bit for bit (the oracle takes a minute or two on the box's cores), and the time of a step.
+    python tools/big_job.py [factor = 4] [check = 1]"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")):
+    sys.path.insert(0, p)
+import numpy as np  # noqa: E402
+
+from muchsalsa_amd import overlap, synth  # noqa: E402
+
+
+def main():
+    factor = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+    check = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    t0 = time.perf_counter()
+    rows, rn, an = synth.accepted_rows(synth.paf_table(100_000 * factor, 10_000, 500_000 * factor, 43))
+    print("%d rows, %d reads, %d anchors (generated in %.1f s)" % (len(rows), len(rn), len(an), time.perf_counter() - t0), flush=True)
+    pinned = overlap.PinnedRows(rows)
+    with overlap.OverlapContext(0) as ctx:
+        ctx.set_id_space(len(rn), len(an))
+        ctx.load_rows(pinned.array)
+        ctx.calculate_edges()
+        ctx.chaining_and_overlaps()
+        ctx.synchronize()
+        ts = []
+        for _ in range(5):
+            t1 = time.perf_counter()
+            ctx.load_rows(pinned.array)
+            ctx.calculate_edges()
+            ctx.chaining_and_overlaps()
+            ctx.synchronize()
+            ts.append(time.perf_counter() - t1)
+        c = ctx.counts()
+        print("single pass incl. H2D of the rows: %.2f ms; edges %d, EdgeMatches %d, orders %d, ids %d -> %.0f M overlap-pairs/s" % (
+            1e3 * min(ts), c.n_edges, c.n_ems, c.n_orders, c.n_ids, c.n_edges / min(ts) / 1e6), flush=True)
+        got = ctx.tables() if check else None
+        lean, info = ctx.overlap_batched(pinned.array, 0, copy=False, resident=True, edgematches=False)
+        t1 = time.perf_counter()
+        lean, info = ctx.overlap_batched(pinned.array, 0, copy=False, resident=True, edgematches=False)
+        print("resident dispatcher, EdgeMatch table left in HBM, host to host: %.2f ms" % (1e3 * (time.perf_counter() - t1)), flush=True)
+        if check:
+            import ms_oracle_ctypes as oracle
+            from helpers import assert_tables_equal
+            oracle.build()
+            t1 = time.perf_counter()
+            import threading
+            done = threading.Event()
+
+            def heartbeat():  # (a long silent run looks hung to whoever watches it)
+                while not done.wait(60):
+                    print("  ... oracle at work, %.0f s" % (time.perf_counter() - t1), flush=True)
+            threading.Thread(target=heartbeat, daemon=True).start()
+            want = oracle.overlap(rows)
+            done.set()
+            print("oracle: %.1f s" % (time.perf_counter() - t1), flush=True)
+            assert_tables_equal(got, want, "single pass, factor %d" % factor)
+            assert_tables_equal(dict(lean, ems=ctx.tables()["ems"]), want, "resident dispatcher, factor %d" % factor)
+            print("every table bit for bit", flush=True)
+
+
+if __name__ == "__main__":
+    main()
