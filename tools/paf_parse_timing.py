@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """msgpu_parse_paf alone on the machine: BASELINE configs[2] as PAF text (270 MB) in tmpfs, parsed several times
-(MSGPU_PARSE_DEBUG=1 prints the loader's phases).   python tools/paf_parse_timing.py [reps]"""
+(MSGPU_PARSE_DEBUG=1 prints the loader's phases).   python tools/paf_parse_timing.py [reps] [factor]"""
 import os
 import shutil
 import sys
@@ -17,7 +17,9 @@ from muchsalsa_amd import overlap, synth  # noqa: E402
 
 def main():
     reps = int(sys.argv[1]) if len(sys.argv) > 1 else 6
-    w = bench.WORKLOADS["cfg3"]
+    w = dict(bench.WORKLOADS["cfg3"])
+    factor = int(sys.argv[2]) if len(sys.argv) > 2 else 1  # (a file `factor` times as large, same generator)
+    w["n_reads"], w["n_anchors"] = w["n_reads"] * factor, w["n_anchors"] * factor
     tab = synth.paf_table(w["n_reads"], w["read_len"], w["n_anchors"], w["seed"])
     d = tempfile.mkdtemp(prefix="msgpu_paf_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
     try:
