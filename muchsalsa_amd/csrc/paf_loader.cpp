@@ -192,6 +192,16 @@ public:
     share[share_of(h, static_cast<unsigned>(share.size()))].push_back(static_cast<uint32_t>(list.size() - 1));
     return static_cast<uint32_t>(list.size() - 1);
   }
+  // A look-up costs two cache lines (slot, characters), and with hundreds of thousands of names per chunk neither is in
+  // a cache: the tokeniser works in blocks of lines and asks for the lines of a whole block ahead of resolving them.
+  void want_slot(uint64_t h) const {
+    if (!m_slots.empty()) __builtin_prefetch(&m_slots[h & (m_slots.size() - 1)]);
+  }
+  void want_chars(uint64_t h) const {
+    if (m_slots.empty()) return;
+    const Slot &sl = m_slots[h & (m_slots.size() - 1)];
+    if (sl.at_plus_1 && sl.hash == h) __builtin_prefetch(m_block.data() + sl.off);
+  }
   void bind() { // the chunk is parsed: offsets -> pointers, the look-up table goes
     for (NameEntry &e : list) e.s = m_block.data() + reinterpret_cast<uintptr_t>(e.s);
     std::vector<Slot>().swap(m_slots);
@@ -235,6 +245,36 @@ void parse_chunk(Chunk &ch, size_t last_line, const msgpu_params &p) {
   const char *last_q = nullptr; // the query name of the last accepted line and its place in the chunk's list
   uint32_t    last_qn = 0, last_id = 0;
   ch.rows.reserve(ch.n_lines);
+  // Accepted lines wait in a block until their names are resolved: first the block's lines are tokenised and the slots of
+  // their names asked for, then the characters behind the slots, then the look-ups run -- on warm lines -- in line order.
+  struct Pending {
+    msgpu_row   r;
+    const char *tname, *qname;
+    uint32_t    tn, qn;
+    uint64_t    th, qh; // qh = 0: the same query name as the pending line before (no look-up of its own)
+  };
+  constexpr int BLOCK = 16;
+  Pending       pend[BLOCK];
+  int           n_pend = 0;
+  auto          resolve = [&] {
+    for (int k = 0; k < n_pend; ++k) {
+      ch.reads.want_chars(pend[k].th);
+      if (pend[k].qh) ch.anchors.want_chars(pend[k].qh);
+    }
+    for (int k = 0; k < n_pend; ++k) {
+      Pending &x = pend[k];
+      // Registry::operator[] (BlastFileReader.cpp:110-111), chunk-local for now
+      x.r.read_id = ch.reads.get(x.tname, x.tn, x.th);
+      if (!(last_q && x.qn == last_qn && memcmp(last_q, x.qname, x.qn) == 0)) { // (a PAF is grouped by its query: mostly the line before's)
+        last_id = ch.anchors.get(x.qname, x.qn, x.qh ? x.qh : name_hash(x.qname, x.qn));
+        last_q  = x.qname;
+        last_qn = x.qn;
+      }
+      x.r.anchor_id = last_id;
+      ch.rows.push_back(x.r);
+    }
+    n_pend = 0;
+  };
   for (; q < ch.end; ++li) {
     const void *nlp = memchr(q, '\n', static_cast<size_t>(ch.end - q));
     const char *le  = nlp ? static_cast<const char *>(nlp) : ch.end;
@@ -278,26 +318,28 @@ void parse_chunk(Chunk &ch, size_t last_line, const msgpu_params &p) {
     }
     const bool dir  = (te[4] - tb[4] == 1) && *tb[4] == '+';
     const bool prim = span >= static_cast<int>(p.th_length) && static_cast<uint32_t>(nom) >= p.th_matches;
-    msgpu_row  r;
-    // Registry::operator[] (BlastFileReader.cpp:110-111), chunk-local for now
-    r.read_id = ch.reads.get(tb[5], static_cast<uint32_t>(te[5] - tb[5]), name_hash(tb[5], static_cast<size_t>(te[5] - tb[5])));
-    const uint32_t qn = static_cast<uint32_t>(te[0] - tb[0]);
-    if (!(last_q && qn == last_qn && memcmp(last_q, tb[0], qn) == 0)) { // (a PAF is grouped by its query: mostly the line before's)
-      last_id = ch.anchors.get(tb[0], qn, name_hash(tb[0], qn));
-      last_q  = tb[0];
-      last_qn = qn;
-    }
-    r.anchor_id = last_id;
-    r.read_len  = nle;
-    r.i_lo      = irs;
-    r.i_hi      = ire - 1;
-    r.n_lo      = nrs;
-    r.n_hi      = nre - 1;
-    r.score     = static_cast<uint32_t>(nom);
-    r.line      = static_cast<uint32_t>(li);
-    r.flags     = (dir ? MSGPU_ROW_DIR : 0u) | (prim ? MSGPU_ROW_PRIMARY : 0u);
-    ch.rows.push_back(r);
+    Pending   &x    = pend[n_pend];
+    x.tname         = tb[5];
+    x.tn            = static_cast<uint32_t>(te[5] - tb[5]);
+    x.th            = name_hash(x.tname, x.tn);
+    x.qname         = tb[0];
+    x.qn            = static_cast<uint32_t>(te[0] - tb[0]);
+    const char *before   = n_pend ? pend[n_pend - 1].qname : last_q;
+    const uint32_t before_n = n_pend ? pend[n_pend - 1].qn : last_qn;
+    x.qh            = before && before_n == x.qn && memcmp(before, x.qname, x.qn) == 0 ? 0 : name_hash(x.qname, x.qn);
+    ch.reads.want_slot(x.th);
+    if (x.qh) ch.anchors.want_slot(x.qh);
+    x.r.read_len = nle;
+    x.r.i_lo     = irs;
+    x.r.i_hi     = ire - 1;
+    x.r.n_lo     = nrs;
+    x.r.n_hi     = nre - 1;
+    x.r.score    = static_cast<uint32_t>(nom);
+    x.r.line     = static_cast<uint32_t>(li);
+    x.r.flags    = (dir ? MSGPU_ROW_DIR : 0u) | (prim ? MSGPU_ROW_PRIMARY : 0u);
+    if (++n_pend == BLOCK) resolve();
   }
+  resolve();
 }
 
 // The line structure of a text (BlastFileAccessor::_buildIndex over readline, BlastFileAccessor.cpp:77-91, IO.cpp:54-97):
