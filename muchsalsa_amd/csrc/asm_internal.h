@@ -1,5 +1,6 @@
 // asm_internal.h -- the assembly object shared by assemble_path.cpp (host layout) and msgpu_seq.hip (device finish).
 #pragma once
+#include <cstdlib>
 #include <type_traits>
 #include <utility>
 #include <new>
@@ -100,6 +101,31 @@ struct SeqDestination {
 };
 // msgpu_seq_parse with the bytes going to dst (nullptr: a host buffer inside the msgpu_seqfile)
 int seq_parse_into(const char *path, int is_fastq, SeqDestination *dst, msgpu_seqfile **out);
+// std::allocator for host tables that may grow to gigabytes (the loaders' per-chunk tables): large blocks come from
+// mappings on 2 MiB pages (first touches and, above all, giving the pages back cost a fraction of what 4 KiB pages do),
+// smaller ones from malloc (a small table on a 2 MiB page pays for zeroing the whole page, and malloc hands a block of
+// up to 32 MiB that was freed straight to the next caller).  New elements of a plain type
+// are left as they are.
+template <class T> struct BigTableAlloc {
+  using value_type = T;
+  static constexpr size_t BIG = size_t(40) << 20; // (above the 32 MiB up to which malloc keeps freed blocks for the next one)
+  BigTableAlloc() = default;
+  template <class U> BigTableAlloc(const BigTableAlloc<U> &) noexcept {}
+  T *allocate(size_t n) {
+    if (n * sizeof(T) >= BIG) return static_cast<T *>(host_table_alloc(n * sizeof(T)));
+    void *p = std::malloc(n * sizeof(T) ? n * sizeof(T) : 1);
+    if (!p) throw std::bad_alloc();
+    return static_cast<T *>(p);
+  }
+  void deallocate(T *p, size_t n) noexcept {
+    if (n * sizeof(T) >= BIG) host_table_free(p);
+    else std::free(p);
+  }
+  template <class U> void construct(U *p) noexcept(std::is_nothrow_default_constructible<U>::value) { ::new (static_cast<void *>(p)) U; }
+  template <class U, class... A> void construct(U *p, A &&...a) { ::new (static_cast<void *>(p)) U(std::forward<A>(a)...); }
+  template <class U> bool operator==(const BigTableAlloc<U> &) const noexcept { return true; }
+  template <class U> bool operator!=(const BigTableAlloc<U> &) const noexcept { return false; }
+};
 // Toggle::operator* (include/ms/types/Toggle.h:127-153): the product of two toggles is their XNOR
 inline bool toggle_mul(bool a, bool b) { return a == b; }
 // header lines of the FASTA records, reference spelling (ap.cpp:1035-1040, 1059-1066, 1118-1125, 1175-1182, 1309-1318)

@@ -219,11 +219,11 @@ public:
   }
   void bind() { // the chunk is parsed: offsets -> pointers, the look-up table goes
     for (NameEntry &e : list) e.s = m_block.data() + reinterpret_cast<uintptr_t>(e.s);
-    std::vector<Slot>().swap(m_slots);
+    SlotTable().swap(m_slots);
   }
   static unsigned share_of(uint64_t h, unsigned n) { return static_cast<unsigned>((h >> 40) % n); }
-  std::vector<NameEntry>             list;
-  std::vector<std::vector<uint32_t>> share; // share[t]: the positions of the names thread t looks after (by hash), ascending
+  std::vector<NameEntry, msgpu::BigTableAlloc<NameEntry>>  list;
+  std::vector<std::vector<uint32_t>>                        share; // share[t]: the positions of the names thread t looks after (by hash), ascending
 
 private:
   struct Slot {
@@ -231,7 +231,7 @@ private:
     uint32_t at_plus_1, off, n;
   };
   void grow() {
-    std::vector<Slot> ns(m_slots.empty() ? 4096 : m_slots.size() * 2, Slot{0, 0, 0, 0});
+    SlotTable ns(m_slots.empty() ? 4096 : m_slots.size() * 2, Slot{0, 0, 0, 0});
     for (const Slot &v : m_slots)
       if (v.at_plus_1) {
         size_t i = v.hash & (ns.size() - 1);
@@ -240,14 +240,18 @@ private:
       }
     m_slots.swap(ns);
   }
-  std::vector<Slot> m_slots;
-  std::string       m_block;
+  using SlotTable = std::vector<Slot, msgpu::BigTableAlloc<Slot>>;
+  SlotTable   m_slots;
+  std::string m_block;
 };
 
 struct Chunk {
   const char            *begin = nullptr, *end = nullptr;
   size_t                 n_lines = 0, first_line = 0;
-  std::vector<msgpu_row> rows; // accepted lines; read_id / anchor_id = positions in the chunk's own name lists
+  // accepted lines; read_id / anchor_id = positions in the chunk's own name lists.  (Tables of a chunk live in mappings on
+  // 2 MiB pages where the kernel grants them: at sizes of gigabytes, first touches and -- above all -- giving 4 KiB pages
+  // back one by one cost as much as the tokeniser itself.)
+  std::vector<msgpu_row, msgpu::BigTableAlloc<msgpu_row>> rows;
   ChunkNames             reads, anchors;
   int                    err = MSGPU_OK;
   size_t                 err_line = 0;
@@ -585,6 +589,15 @@ int msgpu_parse_paf(const char *path, const msgpu_params *params, msgpu_paf **ou
       // HBM -- a GPU present -- is a fraction of a millisecond now)
       if (!paf->rows.empty()) msgpu::host_table_pin(paf->rows.data());
       lap("rows");
+      // (what the chunks held goes back on the threads too: at sizes of gigabytes, handing their row and name tables back one
+      // after the other at the end of this function took longer than counting the file's lines)
+      run([&](unsigned t) {
+        Chunk &c = chunks[t];
+        std::vector<msgpu_row, msgpu::BigTableAlloc<msgpu_row>>().swap(c.rows);
+        c.reads   = ChunkNames();
+        c.anchors = ChunkNames();
+      });
+      lap("release");
     }
   } catch (std::bad_alloc const &) { rc = MSGPU_E_NOMEM; } catch (std::system_error const &) {
     rc = MSGPU_E_NOMEM; // could not start a thread
