@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """A job several times BASELINE configs[2] through the single pass and the resident dispatcher, every table against the C
 oracle bit for bit (the oracle takes a minute or two on the box's cores), and the time of a step.
-    python tools/big_job.py [factor = 4] [check = 1]"""
+    python tools/big_job.py [factor = 4] [check = 1] [tiled]"""
 import os
 import sys
 import time
@@ -17,8 +17,14 @@ from muchsalsa_amd import overlap, synth  # noqa: E402
 def main():
     factor = int(sys.argv[1]) if len(sys.argv) > 1 else 4
     check = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    tiled = len(sys.argv) > 3 and sys.argv[3] == "tiled"  # (unitigs that tile the genome, reads of mixed lengths: synth.TILED)
     t0 = time.perf_counter()
-    rows, rn, an = synth.accepted_rows(synth.paf_table(100_000 * factor, 10_000, 500_000 * factor, 43))
+    if tiled:
+        shape = dict(synth.TILED["cfg3"])
+        shape["n_reads"] *= factor
+        rows, rn, an = synth.accepted_rows(synth.paf_table(**shape))
+    else:
+        rows, rn, an = synth.accepted_rows(synth.paf_table(100_000 * factor, 10_000, 500_000 * factor, 43))
     print("%d rows, %d reads, %d anchors (generated in %.1f s)" % (len(rows), len(rn), len(an), time.perf_counter() - t0), flush=True)
     pinned = overlap.PinnedRows(rows)
     with overlap.OverlapContext(0) as ctx:
@@ -61,6 +67,9 @@ def main():
             assert_tables_equal(got, want, "single pass, factor %d" % factor)
             assert_tables_equal(dict(lean, ems=ctx.tables()["ems"]), want, "resident dispatcher, factor %d" % factor)
             print("every table bit for bit", flush=True)
+            co = ctx.find_contraction_edges()  # (on the resident tables)
+            assert np.array_equal(co, oracle.find_contraction_edges(want, len(want["read_len"])))
+            print("findContractionEdges: %d contraction edges, equal to the oracle's" % int((co >= 0).sum()), flush=True)
 
 
 if __name__ == "__main__":
