@@ -541,11 +541,16 @@ struct msgpu_graph {
   };
   RawArray<OLite> ol;
   Csr                  adj;
+  // ContainElements (src/main.cpp:509-531) by host read: those of read v are contain[contain_first[v] .. contain_first[v + 1]),
+  // in contraction order; their anchors lie in contain_anchor (one flat table instead of a map of vectors of vectors)
   struct Contain {
     uint32_t nano, direction;
-    std::vector<uint32_t> anchors;
+    uint64_t anchors_off;
+    uint32_t anchors_cnt;
   };
-  std::map<uint32_t, std::vector<Contain>> contain;
+  std::vector<uint64_t> contain_first; // nv + 1 entries (empty before the clean-up)
+  RawArray<Contain>     contain;
+  std::vector<uint32_t> contain_anchor;
   bool cleaned = false, linearized = false;
   bool every_alive_edge_kept = false; // set with the arc flags in msgpu_graph_linearize
   uint32_t n_threads = 1;
@@ -1364,16 +1369,17 @@ std::vector<msgpu_graph::PathStore> component_paths(msgpu_graph *g, uint32_t cid
     }
     for (uint32_t l : p) {
       const uint32_t v = dg.ids[l];
-      auto           c = g->contain.find(v);
-      if (c == g->contain.end()) continue;
-      for (const msgpu_graph::Contain &ce : c->second) {
-        msgpu_path_contain pc{};
+      if (g->contain_first.empty()) continue;
+      for (uint64_t q = g->contain_first[v]; q < g->contain_first[v + 1]; ++q) {
+        const msgpu_graph::Contain &ce = g->contain[q];
+        msgpu_path_contain          pc{};
         pc.host_read   = v;
         pc.nano        = ce.nano;
         pc.direction   = ce.direction;
         pc.anchors_off = static_cast<uint32_t>(ps.contain_anchors.size());
-        pc.anchors_cnt = static_cast<uint32_t>(ce.anchors.size());
-        ps.contain_anchors.insert(ps.contain_anchors.end(), ce.anchors.begin(), ce.anchors.end());
+        pc.anchors_cnt = ce.anchors_cnt;
+        ps.contain_anchors.insert(ps.contain_anchors.end(), g->contain_anchor.begin() + static_cast<long>(ce.anchors_off),
+                                  g->contain_anchor.begin() + static_cast<long>(ce.anchors_off + ce.anchors_cnt));
         ps.contains.push_back(pc);
       }
     }
@@ -1536,12 +1542,53 @@ int msgpu_graph_clean_up(msgpu_graph *g, const int64_t *contraction_order, const
       contraction.push_back(static_cast<uint32_t>(k));
     }
     g->stats.n_contraction_edges = contraction.size();
-    std::vector<uint64_t> has_vm; // MatchMap::getVertexMatch(read, anchor) != nullptr: sorted (read, anchor) keys
+    tick("  contraction: its orders");
+    // MatchMap::getVertexMatch(read, anchor) != nullptr for the anchors of the contraction orders.  A PAF is grouped by
+    // its query and the Registry numbers the anchors as they come, so the rows of anchor a are rows[first[a] .. first[a + 1])
+    // as they stand (checked): a look-up walks the handful of rows of one anchor.  Rows in any other order are keyed and
+    // sorted instead (the tests' shuffled tables).
+    std::vector<uint64_t> has_vm;    // sorted (read, anchor) keys -- only when the rows are not grouped by ascending anchor
+    std::vector<uint64_t> first_row; // first_row[a] .. first_row[a + 1]: the rows of anchor a -- when they are
     if (!contraction.empty() && rows) {
-      has_vm.resize(n_rows);
-      for (size_t i = 0; i < n_rows; ++i) has_vm[i] = (static_cast<uint64_t>(rows[i].read_id) << 32) | rows[i].anchor_id;
-      std::sort(has_vm.begin(), has_vm.end());
+      std::atomic<int> unordered{0};
+      parallel_chunks(n_rows, [&](unsigned, size_t b, size_t e) {
+        for (size_t i = std::max<size_t>(b, 1); i < e; ++i)
+          if (rows[i].anchor_id < rows[i - 1].anchor_id) {
+            unordered = 1;
+            return;
+          }
+      });
+      if (!unordered && n_rows) {
+        const uint32_t n_anchors = rows[n_rows - 1].anchor_id + 1;
+        first_row.assign(static_cast<size_t>(n_anchors) + 1, 0);
+        parallel_chunks(n_rows, [&](unsigned, size_t b, size_t e) { // first_row[a] for every anchor a that BEGINS in [b, e), and for the empty ones in front of it
+          for (size_t i = b; i < e; ++i) {
+            const uint32_t a = rows[i].anchor_id, before = i ? rows[i - 1].anchor_id : 0;
+            if (i == 0) {
+              for (uint32_t x = 0; x <= a; ++x) first_row[x] = 0;
+            } else if (a != before) {
+              for (uint32_t x = before + 1; x <= a; ++x) first_row[x] = i;
+            }
+          }
+        });
+        first_row[n_anchors] = n_rows;
+      } else {
+        has_vm.resize(n_rows);
+        for (size_t i = 0; i < n_rows; ++i) has_vm[i] = (static_cast<uint64_t>(rows[i].read_id) << 32) | rows[i].anchor_id;
+        std::sort(has_vm.begin(), has_vm.end());
+      }
     }
+    tick("  contraction: rows by anchor");
+    auto has_vertex_match = [&](uint32_t read, uint32_t anchor) {
+      if (!rows) return true;
+      if (!first_row.empty()) {
+        if (static_cast<size_t>(anchor) + 1 >= first_row.size()) return false;
+        for (uint64_t i = first_row[anchor]; i < first_row[anchor + 1]; ++i)
+          if (rows[i].read_id == read) return true;
+        return false;
+      }
+      return std::binary_search(has_vm.begin(), has_vm.end(), (static_cast<uint64_t>(read) << 32) | anchor);
+    };
     std::vector<uint32_t> targets(nv);
     for (uint32_t v = 0; v < nv; ++v) targets[v] = v; // :194-197
     for (uint32_t k : contraction) {                  // findContractionTargets, :465-482
@@ -1556,19 +1603,51 @@ int msgpu_graph_clean_up(msgpu_graph *g, const int64_t *contraction_order, const
       roots[targets[o.start]] = 1;
       roots[o.start]          = 0;
     }
-    for (uint32_t k : contraction) { // contract, :509-531
-      const msgpu_order &o = g->t_orders[k];
-      if (!roots[o.end]) continue;
-      msgpu_graph::Contain c;
-      c.nano      = o.start;
-      c.direction = g->odir(k) ? 1u : 0u;
-      for (uint32_t i = 0; i < o.ids_cnt; ++i) {
-        const uint32_t a = g->t_ids[o.ids_off + i];
-        if (!rows || std::binary_search(has_vm.begin(), has_vm.end(), (static_cast<uint64_t>(o.start) << 32) | a))
-          c.anchors.push_back(a);
+    tick("  contraction: targets + roots");
+    // contract, :509-531.  Which anchors of a contraction order have a VertexMatch on the contained read is looked up on
+    // the stage's threads (two passes: count, fill); the ContainElements enter the map in contraction order.
+    std::vector<uint64_t> keep_off(contraction.size() + 1, 0);
+    parallel_chunks(contraction.size(), [&](unsigned, size_t b, size_t e) {
+      for (size_t j = b; j < e; ++j) {
+        const msgpu_order &o = g->t_orders[contraction[j]];
+        uint64_t           n = 0;
+        if (roots[o.end])
+          for (uint32_t i = 0; i < o.ids_cnt; ++i) n += has_vertex_match(o.start, g->t_ids[o.ids_off + i]);
+        keep_off[j + 1] = n;
       }
-      g->contain[o.end].push_back(std::move(c));
-      ++g->stats.n_contain_elements;
+    });
+    for (size_t j = 0; j < contraction.size(); ++j) keep_off[j + 1] += keep_off[j];
+    g->contain_anchor.resize(keep_off[contraction.size()]);
+    uint32_t *const kept_anchor = g->contain_anchor.data();
+    parallel_chunks(contraction.size(), [&](unsigned, size_t b, size_t e) {
+      for (size_t j = b; j < e; ++j) {
+        const msgpu_order &o = g->t_orders[contraction[j]];
+        if (!roots[o.end]) continue;
+        uint64_t at = keep_off[j];
+        for (uint32_t i = 0; i < o.ids_cnt; ++i) {
+          const uint32_t a = g->t_ids[o.ids_off + i];
+          if (has_vertex_match(o.start, a)) kept_anchor[at++] = a;
+        }
+      }
+    });
+    tick("  contraction: anchors with a VertexMatch");
+    // the ContainElements by host read, those of one read in contraction order (a counting sort by host)
+    g->contain_first.assign(static_cast<size_t>(nv) + 1, 0);
+    for (uint32_t k : contraction) {
+      const msgpu_order &o = g->t_orders[k];
+      if (roots[o.end]) ++g->contain_first[o.end + 1];
+    }
+    for (uint32_t v = 0; v < nv; ++v) g->contain_first[v + 1] += g->contain_first[v];
+    g->contain.allocate(g->contain_first[nv]);
+    {
+      std::vector<uint64_t> cur(g->contain_first.begin(), g->contain_first.end() - 1);
+      for (size_t j = 0; j < contraction.size(); ++j) {
+        const uint32_t     k = contraction[j];
+        const msgpu_order &o = g->t_orders[k];
+        if (!roots[o.end]) continue;
+        g->contain[cur[o.end]++] = msgpu_graph::Contain{o.start, g->odir(k) ? 1u : 0u, keep_off[j], static_cast<uint32_t>(keep_off[j + 1] - keep_off[j])};
+        ++g->stats.n_contain_elements;
+      }
     }
     tick("contraction bookkeeping");
     for (uint32_t v = 0; v < nv; ++v) // :242-244
