@@ -148,6 +148,27 @@ template <class F> void parallel_dynamic(size_t n, size_t grain, F f) {
   StagePool::get().run(nt, (n + grain - 1) / grain, [&](size_t k) { f(k * grain, std::min(n, (k + 1) * grain)); });
 }
 
+// std::sort on the stage's threads: stretches sorted side by side, then merged pairwise (log2 rounds; the keys sorted here
+// are unique, so the result is the one std::sort gives)
+template <class It, class Cmp> void parallel_sort(It first, It last, Cmp cmp) {
+  const size_t n  = static_cast<size_t>(last - first);
+  unsigned     nt = stage_threads();
+  if (n < par_min() || nt <= 1) {
+    std::sort(first, last, cmp);
+    return;
+  }
+  std::vector<size_t> cut(nt + 1);
+  for (unsigned k = 0; k <= nt; ++k) cut[k] = n * k / nt;
+  StagePool::get().run(nt, nt, [&](size_t k) { std::sort(first + static_cast<long>(cut[k]), first + static_cast<long>(cut[k + 1]), cmp); });
+  for (unsigned width = 1; width < nt; width *= 2) {
+    const unsigned pairs = (nt + 2 * width - 1) / (2 * width);
+    StagePool::get().run(pairs, pairs, [&](size_t p) {
+      const unsigned lo = static_cast<unsigned>(p) * 2 * width, mid = std::min(nt, lo + width), hi = std::min(nt, lo + 2 * width);
+      if (mid < hi) std::inplace_merge(first + static_cast<long>(cut[lo]), first + static_cast<long>(cut[mid]), first + static_cast<long>(cut[hi]), cmp);
+    });
+  }
+}
+
 // ---- flat adjacency ----------------------------------------------------------------------------------------------------
 
 struct Arc {
@@ -327,7 +348,7 @@ void max_span_tree(uint32_t nv, Ends ends, Weight weight, std::vector<uint32_t> 
     if (w) keyed.emplace_back(w, static_cast<uint32_t>(i));
     else zeros.push_back(static_cast<uint32_t>(i));
   }
-  std::sort(keyed.begin(), keyed.end(), [](const std::pair<uint64_t, uint32_t> &x, const std::pair<uint64_t, uint32_t> &y) {
+  parallel_sort(keyed.begin(), keyed.end(), [](const std::pair<uint64_t, uint32_t> &x, const std::pair<uint64_t, uint32_t> &y) {
     return x.first != y.first ? x.first > y.first : x.second < y.second;
   });
   UnionFind uf(nv);
