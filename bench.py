@@ -801,6 +801,9 @@ def main():
                          "beside the next step's compute; strong = the ONE job of the workload sharded over the ranks by "
                          "v1 %% N (BASELINE.json configs[3]).  auto = weak, with the strong figure and the rank-sharded "
                          "host-to-host figure reported beside it")
+    ap.add_argument("--exchange-format", default="wire", choices=("wire", "whole"),
+                    help="what the N > 1 exchange sends: the wire form of include/msgpu.h (17-byte edges, 33-byte orders; "
+                         "msgpu_pack_wire / msgpu_merge_wire) or whole records (msgpu_copy_tables_device / msgpu_merge_gathered)")
     ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
                     help="torch.distributed backend of the N > 1 path: nccl = RCCL over xGMI (what is measured); gloo = a "
                          "REHEARSAL of the N > 1 control flow on hardware that cannot run N RCCL ranks")
@@ -874,9 +877,17 @@ def main():
         ctx.chaining_and_overlaps()
         return ctx.counts()
 
+    wire = args.exchange_format == "wire"
+
     def fill(slab, offs):
-        ctx.copy_tables_device(d_edges=slab.data_ptr() + offs[0], d_orders=slab.data_ptr() + offs[1],
-                               d_ids=slab.data_ptr() + offs[2])
+        if wire:  # one pack kernel + the id copy behind the compaction, on the compute stream
+            ctx.pack_wire(slab.data_ptr() + offs[0], slab.data_ptr() + offs[1], slab.data_ptr() + offs[2])
+        else:
+            ctx.copy_tables_device(d_edges=slab.data_ptr() + offs[0], d_orders=slab.data_ptr() + offs[1],
+                                   d_ids=slab.data_ptr() + offs[2])
+
+    def merge_slabs(*a, **kw):
+        return (ctx.merge_wire if wire else ctx.merge_gathered)(*a, **kw)
 
     def timed_region(step, finish=None):
         """W warm-up steps, then K timed steps between barrier + synchronize on both sides; chain-kernel events of the
@@ -955,13 +966,13 @@ def main():
                 for key, n in (("e", int(tot[0]) * EDGE_DTYPE.itemsize), ("o", int(tot[1]) * ORDER_DTYPE.itemsize), ("i", int(tot[2]) * 4)):
                     if merged_keep[key][k] is None or merged_keep[key][k].numel() < n:  # (first batches only)
                         merged_keep[key][k] = torch.empty(int(n * 1.125) + 256, dtype=torch.uint8, device=dev)
-                ctx.merge_gathered(gathered.data_ptr(), allc, slab_bytes, offs, merged_keep["e"][k].data_ptr(),
-                                   merged_keep["o"][k].data_ptr(), merged_keep["i"][k].data_ptr(), id_base=id_base,
-                                   stream=stream.cuda_stream)
+                merge_slabs(gathered.data_ptr(), allc, slab_bytes, offs, merged_keep["e"][k].data_ptr(),
+                            merged_keep["o"][k].data_ptr(), merged_keep["i"][k].data_ptr(), id_base=id_base,
+                            stream=stream.cuda_stream)
                 merged_keep["tot"][k] = tot
                 merged_keep["last"], merged_keep["allc"] = k, allc
 
-            pe = D.PipelinedExchange(dev, merge)
+            pe = D.PipelinedExchange(dev, merge, wire=wire)
 
             def step():
                 c = compute()
@@ -978,6 +989,8 @@ def main():
             n_edges_total = int(allc[:, 0].sum())
             dt, rank_ms = over_ranks(dt)
             exchange_info = {"collectives_per_step": pe.collectives / max(1, pe.calls), "slab_bytes": int(pe.slab_bytes),
+                             "format": "wire form (17-byte edges, 33-byte orders, ids)" if wire else "whole records",
+                             "whole_record_slab_bytes": int(D.HEADER + D.slab_layout(pe.cap)[1]),
                              "regrows": pe.regrows, "overlapped": "all-gather + merge of step k on a communication stream, issued "
                                                                   "by a communication thread, beside the compute of step k + 1"}
             if rank == 0:  # not timed: the merged edge list is a consistent table whose first partition is our own
@@ -1003,7 +1016,7 @@ def main():
         ctx.set_id_space(len(rn_s), len(an_s))
         if world > 1:
             ctx.set_shard(rank, world)
-        exchange = D.SlabExchange(dev)
+        exchange = D.SlabExchange(dev, wire=wire)
         s_keep = {}
 
         def strong_step():
@@ -1018,7 +1031,7 @@ def main():
             m_e = torch.empty(max(int(tot[0]), 1) * EDGE_DTYPE.itemsize, dtype=torch.uint8, device=dev)
             m_o = torch.empty(max(int(tot[1]), 1) * ORDER_DTYPE.itemsize, dtype=torch.uint8, device=dev)
             m_i = torch.empty(max(int(tot[2]), 1) * 4, dtype=torch.uint8, device=dev)
-            ctx.merge_gathered(gathered.data_ptr(), allc, slab_bytes, offs, m_e.data_ptr(), m_o.data_ptr(), m_i.data_ptr())
+            merge_slabs(gathered.data_ptr(), allc, slab_bytes, offs, m_e.data_ptr(), m_o.data_ptr(), m_i.data_ptr())
             s_keep.update(e=[m_e], o=[m_o], i=[m_i], tot=[tot], allc=allc)
             return c
 

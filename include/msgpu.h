@@ -265,6 +265,26 @@ int msgpu_merge_gathered_ex(msgpu_ctx *ctx, const void *d_gathered, uint32_t wor
                             uint64_t slab_bytes, uint64_t off_edges, uint64_t off_orders, uint64_t off_ids,
                             const uint32_t *id_base, void *d_edges, void *d_orders, void *d_ids, void *hip_stream);
 
+/* The exchange's WIRE FORM: the same merge with about 30 % fewer bytes over xGMI.  What a receiver can derive is not sent:
+ * a rank's tables are dense (every record's slice of the next table starts where the one before ends), so the 64-bit
+ * offsets travel as 32-bit CSR columns of n + 1 entries and the counts are their differences; an EdgeOrder's start / end /
+ * base vertices follow from its flags and its edge (src/main.cpp:397-411: base = the edge's first vertex); padding is not
+ * sent.  Columns, in this order, every block densely packed for the rank's OWN record count n:
+ *   edge block  (msgpu_wire_edges_bytes(n)  = 17 n + 8): em_off[n+1] u32 | order_off[n+1] u32 | v1[n] | v2[n] | shadow[n] u8
+ *   order block (msgpu_wire_orders_bytes(n) = 33 n + 4): left[n] f64 | right[n] f64 | score[n] u64 | ids_off[n+1] u32 |
+ *                                                        edge_idx[n] u32 | flags[n] u8
+ *   id block    (4 n): as in the tables.
+ * msgpu_pack_wire writes the context's tables (after msgpu_chaining_and_overlaps) in that form into three DEVICE blocks
+ * (edge and id blocks 4-byte, order block 8-byte aligned) on the context's stream; MSGPU_E_ARG when a table has more than
+ * 2^32 - 1 EdgeMatches, orders or ids (exchange such tables whole).  msgpu_merge_wire = msgpu_merge_gathered_ex over
+ * slabs whose three blocks are in wire form: the merged tables are the same, byte for byte. */
+uint64_t msgpu_wire_edges_bytes(uint64_t n_edges);
+uint64_t msgpu_wire_orders_bytes(uint64_t n_orders);
+int msgpu_pack_wire(msgpu_ctx *ctx, void *d_wire_edges, void *d_wire_orders, void *d_ids);
+int msgpu_merge_wire(msgpu_ctx *ctx, const void *d_gathered, uint32_t world, const uint64_t *counts, uint64_t slab_bytes,
+                     uint64_t off_edges, uint64_t off_orders, uint64_t off_ids, const uint32_t *id_base, void *d_edges,
+                     void *d_orders, void *d_ids, void *hip_stream);
+
 /* ---- the ThreadPool replacement: the whole overlap path, host memory to host memory, as batches on two HIP streams ----
  * Replaces the phases of src/main.cpp:153-178 that the reference fans over its ThreadPool (one Job per PAF line, per
  * anchor, per edge; libms/src/threading/ThreadPool.cpp:38-129) and closes with WaitGroup::wait() (WaitGroup.cpp:62-72):

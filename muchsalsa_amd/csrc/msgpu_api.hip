@@ -1257,6 +1257,69 @@ int msgpu_merge_gathered_ex(msgpu_ctx *c, const void *d_gathered, uint32_t world
   return MSGPU_OK;
 }
 
+// ---- the exchange's wire form -------------------------------------------------------------------------------------------
+
+uint64_t msgpu_wire_edges_bytes(uint64_t n_edges) { return wire_edges_bytes(n_edges); }
+uint64_t msgpu_wire_orders_bytes(uint64_t n_orders) { return wire_orders_bytes(n_orders); }
+
+int msgpu_pack_wire(msgpu_ctx *c, void *d_wire_edges, void *d_wire_orders, void *d_ids) {
+  if (!c) return MSGPU_E_ARG;
+  if (c->state < ST_CHAINED) return fail(c, MSGPU_E_STATE, "msgpu_pack_wire before msgpu_chaining_and_overlaps");
+  if (!d_wire_edges || !d_wire_orders || !d_ids) return fail(c, MSGPU_E_ARG, "msgpu_pack_wire: a null block");
+  if (c->n_ems > 0xffffffffull || c->n_orders > 0xffffffffull || c->n_ids > 0xffffffffull)
+    return fail(c, MSGPU_E_ARG, "tables beyond the wire form's 32-bit offsets: exchange them whole "
+                                "(msgpu_copy_tables_device + msgpu_merge_gathered)");
+  if ((reinterpret_cast<uintptr_t>(d_wire_edges) & 3) || (reinterpret_cast<uintptr_t>(d_wire_orders) & 7))
+    return fail(c, MSGPU_E_ARG, "msgpu_pack_wire: the edge block needs 4-byte, the order block 8-byte alignment");
+  HIPCHK(c, hipSetDevice(c->device));
+  PackWireArgs a;
+  a.edges    = static_cast<const msgpu_edge *>(c->edges.at());
+  a.orders   = static_cast<const msgpu_order *>(c->orders.at());
+  a.n_edges  = c->n_edges;
+  a.n_orders = c->n_orders;
+  a.w_edges  = static_cast<uint8_t *>(d_wire_edges);
+  a.w_orders = static_cast<uint8_t *>(d_wire_orders);
+  launch_pack_wire(c->stream, a);
+  HIPCHK(c, hipGetLastError());
+  if (c->n_ids) HIPCHK(c, hipMemcpyAsync(d_ids, c->ids.at(), c->n_ids * 4, hipMemcpyDeviceToDevice, c->stream));
+  return MSGPU_OK;
+}
+
+int msgpu_merge_wire(msgpu_ctx *c, const void *d_gathered, uint32_t world, const uint64_t *counts, uint64_t slab_bytes,
+                     uint64_t off_edges, uint64_t off_orders, uint64_t off_ids, const uint32_t *id_base, void *d_edges,
+                     void *d_orders, void *d_ids, void *hip_stream) {
+  if (!c) return MSGPU_E_ARG;
+  if (!d_gathered || !counts || world == 0 || world > MAX_WORLD) return fail(c, MSGPU_E_ARG, "bad merge arguments");
+  if ((reinterpret_cast<uintptr_t>(d_gathered) & 7) || (slab_bytes & 7) || (off_edges & 3) || (off_orders & 7) || (off_ids & 3))
+    return fail(c, MSGPU_E_ARG, "msgpu_merge_wire: slabs and order blocks need 8-byte, edge and id blocks 4-byte alignment");
+  HIPCHK(c, hipSetDevice(c->device));
+  MergeArgs a;
+  a.gathered   = static_cast<const uint8_t *>(d_gathered);
+  a.slab_bytes = slab_bytes;
+  a.off_edges  = off_edges;
+  a.off_orders = off_orders;
+  a.off_ids    = off_ids;
+  a.world      = world;
+  a.base[0]    = MergeBase{0, 0, 0, 0, 0};
+  for (uint32_t r = 0; r < world; ++r) {
+    if (counts[3 * r + 1] > 0xffffffffull || counts[3 * r + 2] > 0xffffffffull)
+      return fail(c, MSGPU_E_ARG, "a rank's tables are beyond the wire form's 32-bit offsets");
+    a.base[r + 1].edges  = a.base[r].edges + counts[3 * r + 0];
+    a.base[r + 1].orders = a.base[r].orders + counts[3 * r + 1];
+    a.base[r + 1].ids    = a.base[r].ids + counts[3 * r + 2];
+    a.base[r].read_id    = id_base ? id_base[2 * r + 0] : 0;
+    a.base[r].anchor_id  = id_base ? id_base[2 * r + 1] : 0;
+  }
+  a.base[world].read_id = a.base[world].anchor_id = 0;
+  if (a.base[world].edges >= 0xfffffff0ull) return fail(c, MSGPU_E_ARG, "merged edge table too large");
+  a.edges  = static_cast<msgpu_edge *>(d_edges);
+  a.orders = static_cast<msgpu_order *>(d_orders);
+  a.ids    = static_cast<uint32_t *>(d_ids);
+  launch_merge_wire(hip_stream ? static_cast<hipStream_t>(hip_stream) : c->stream, a);
+  HIPCHK(c, hipGetLastError());
+  return MSGPU_OK;
+}
+
 // ---- the ThreadPool replacement: the whole overlap path as owner-read batches on two HIP streams -------------------------
 //
 // The reference fans one Job per PAF line / anchor / edge over ThreadPool workers and blocks in WaitGroup::wait() at the

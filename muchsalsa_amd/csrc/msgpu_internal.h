@@ -94,6 +94,18 @@ struct MergeArgs {
   uint32_t      *ids;
 };
 
+// the exchange's wire form (include/msgpu.h, "wire form"): columns, 32-bit CSR offsets, nothing the receiver can derive
+struct PackWireArgs {
+  const msgpu_edge  *edges;
+  const msgpu_order *orders;
+  uint64_t           n_edges, n_orders;
+  uint8_t           *w_edges, *w_orders;
+};
+inline uint64_t wire_edges_bytes(uint64_t n) { return 17 * n + 8; }
+inline uint64_t wire_orders_bytes(uint64_t n) { return 33 * n + 4; }
+void launch_pack_wire(hipStream_t st, const PackWireArgs &a);
+void launch_merge_wire(hipStream_t st, const MergeArgs &a);
+
 template <class T> void exclusive_scan(hipStream_t st, const uint32_t *in, uint64_t n, T *out, T *block_sums, T *d_total);
 // k <= 3 scans of the same length n in one pair of launches; block_sums holds k * (scan_blocks(n) + 1) words
 // optional rider: the four column sums of a [n_partials][4] table (16-byte aligned) go to partial_totals[0..3]

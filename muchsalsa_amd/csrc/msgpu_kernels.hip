@@ -3041,6 +3041,121 @@ __global__ __launch_bounds__(256) void k_merge_gathered(MergeArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// the exchange's wire form: what travels over xGMI is what the receiver cannot derive.  Per rank
+//   edges  part (17 n + 8 bytes): em_off[n + 1] u32 | order_off[n + 1] u32 | v1[n] | v2[n] | shadow[n] u8
+//   orders part (33 n + 4 bytes): left[n] f64 | right[n] f64 | score[n] u64 | ids_off[n + 1] u32 | edge_idx[n] u32 | flags[n] u8
+// The counts are differences of the CSR offsets (a rank's tables are dense: every record's slice starts where the one
+// before ends), start / end / base follow from the flags and the edge's vertices (k_chain's emission: base = v1).
+// ---------------------------------------------------------------------------------------------------------------------
+
+struct WireEdges {
+  const uint32_t *em_off, *order_off, *v1, *v2;
+  const uint8_t  *shadow;
+  __device__ WireEdges(const uint8_t *p, uint64_t n) {
+    em_off    = reinterpret_cast<const uint32_t *>(p);
+    order_off = em_off + (n + 1);
+    v1        = order_off + (n + 1);
+    v2        = v1 + n;
+    shadow    = reinterpret_cast<const uint8_t *>(v2 + n);
+  }
+};
+struct WireOrders {
+  const double   *left, *right;
+  const uint64_t *score;
+  const uint32_t *ids_off, *edge_idx;
+  const uint8_t  *flags;
+  __device__ WireOrders(const uint8_t *p, uint64_t n) {
+    left     = reinterpret_cast<const double *>(p);
+    right    = left + n;
+    score    = reinterpret_cast<const uint64_t *>(right + n);
+    ids_off  = reinterpret_cast<const uint32_t *>(score + n);
+    edge_idx = ids_off + (n + 1);
+    flags    = reinterpret_cast<const uint8_t *>(edge_idx + n);
+  }
+};
+
+__global__ __launch_bounds__(256) void k_pack_wire(PackWireArgs a) {
+  const uint64_t i = static_cast<uint64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (i < a.n_edges) {
+    const WireEdges  w(a.w_edges, a.n_edges);
+    const msgpu_edge e = a.edges[i];
+    const_cast<uint32_t *>(w.em_off)[i]    = static_cast<uint32_t>(e.em_off);
+    const_cast<uint32_t *>(w.order_off)[i] = static_cast<uint32_t>(e.order_off);
+    const_cast<uint32_t *>(w.v1)[i]        = e.v1;
+    const_cast<uint32_t *>(w.v2)[i]        = e.v2;
+    const_cast<uint8_t *>(w.shadow)[i]     = e.shadow;
+    if (i + 1 == a.n_edges) {
+      const_cast<uint32_t *>(w.em_off)[i + 1]    = static_cast<uint32_t>(e.em_off + e.em_cnt);
+      const_cast<uint32_t *>(w.order_off)[i + 1] = static_cast<uint32_t>(e.order_off + e.order_cnt);
+    }
+  }
+  if (i < a.n_orders) {
+    const WireOrders  w(a.w_orders, a.n_orders);
+    const msgpu_order o = a.orders[i];
+    const_cast<double *>(w.left)[i]       = o.left_offset;
+    const_cast<double *>(w.right)[i]      = o.right_offset;
+    const_cast<uint64_t *>(w.score)[i]    = o.score;
+    const_cast<uint32_t *>(w.ids_off)[i]  = static_cast<uint32_t>(o.ids_off);
+    const_cast<uint32_t *>(w.edge_idx)[i] = o.edge_idx;
+    const_cast<uint8_t *>(w.flags)[i]     = static_cast<uint8_t>(o.flags);
+    if (i + 1 == a.n_orders) const_cast<uint32_t *>(w.ids_off)[i + 1] = static_cast<uint32_t>(o.ids_off + o.ids_cnt);
+  }
+}
+
+// the merge of k_merge_gathered over slabs in wire form: the same dense rank-major tables, byte for byte
+__global__ __launch_bounds__(256) void k_merge_wire(MergeArgs a) {
+  const uint64_t i = static_cast<uint64_t>(blockIdx.x) * 256 + threadIdx.x;
+  const uint64_t nE = a.base[a.world].edges, nO = a.base[a.world].orders, nI = a.base[a.world].ids;
+  if (i < nE) {
+    uint32_t r = 0;
+    while (i >= a.base[r + 1].edges) ++r;
+    const uint64_t  k = i - a.base[r].edges;
+    const WireEdges w(a.gathered + r * a.slab_bytes + a.off_edges, a.base[r + 1].edges - a.base[r].edges);
+    const uint32_t  m0 = w.em_off[k], q0 = w.order_off[k];
+    msgpu_edge      e;
+    e.v1        = w.v1[k] + a.base[r].read_id;
+    e.v2        = w.v2[k] + a.base[r].read_id;
+    e.em_off    = m0;
+    e.order_off = q0 + a.base[r].orders;
+    e.em_cnt    = w.em_off[k + 1] - m0;
+    e.order_cnt = static_cast<uint16_t>(w.order_off[k + 1] - q0);
+    e.shadow    = w.shadow[k];
+    e.pad       = 0;
+    a.edges[i]  = e;
+  }
+  if (i < nO) {
+    uint32_t r = 0;
+    while (i >= a.base[r + 1].orders) ++r;
+    const uint64_t   k = i - a.base[r].orders;
+    const WireOrders w(a.gathered + r * a.slab_bytes + a.off_orders, a.base[r + 1].orders - a.base[r].orders);
+    const WireEdges  we(a.gathered + r * a.slab_bytes + a.off_edges, a.base[r + 1].edges - a.base[r].edges);
+    const uint32_t   ei = w.edge_idx[k], fl = w.flags[k], j0 = w.ids_off[k];
+    const uint32_t   v1 = we.v1[ei] + a.base[r].read_id, v2 = we.v2[ei] + a.base[r].read_id;
+    msgpu_order      o;
+    o.edge_idx     = ei + static_cast<uint32_t>(a.base[r].edges);
+    o.flags        = fl;
+    o.left_offset  = w.left[k];
+    o.right_offset = w.right[k];
+    o.score        = w.score[k];
+    o.ids_off      = j0 + a.base[r].ids;
+    o.ids_cnt      = w.ids_off[k + 1] - j0;
+    o.start        = (fl & MSGPU_ORD_START_V1) ? v1 : v2;
+    o.end          = (fl & MSGPU_ORD_START_V1) ? v2 : v1;
+    o.base         = v1;
+    o.pad[0]       = 0;
+    o.pad[1]       = 0;
+    a.orders[i]    = o;
+  }
+  if (i < nI) {
+    uint32_t r = 0;
+    while (i >= a.base[r + 1].ids) ++r;
+    const uint64_t  k   = i - a.base[r].ids;
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(a.gathered + r * a.slab_bytes + a.off_ids);
+    a.ids[i]            = src[k] + a.base[r].anchor_id;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // host-callable launchers
 // ---------------------------------------------------------------------------------------------------------------------
 
@@ -3189,6 +3304,16 @@ void launch_merge_gathered(hipStream_t st, const MergeArgs &a) {
   if (a.base[a.world].orders > n) n = a.base[a.world].orders;
   if (a.base[a.world].ids > n) n = a.base[a.world].ids;
   if (n) hipLaunchKernelGGL(k_merge_gathered, grid1(n, 256), dim3(256), 0, st, a);
+}
+void launch_merge_wire(hipStream_t st, const MergeArgs &a) {
+  uint64_t n = a.base[a.world].edges;
+  if (a.base[a.world].orders > n) n = a.base[a.world].orders;
+  if (a.base[a.world].ids > n) n = a.base[a.world].ids;
+  if (n) hipLaunchKernelGGL(k_merge_wire, grid1(n, 256), dim3(256), 0, st, a);
+}
+void launch_pack_wire(hipStream_t st, const PackWireArgs &a) {
+  const uint64_t n = a.n_edges > a.n_orders ? a.n_edges : a.n_orders;
+  if (n) hipLaunchKernelGGL(k_pack_wire, grid1(n, 256), dim3(256), 0, st, a);
 }
 void launch_compact(hipStream_t st, const CompactArgs &a) {
   if (a.n_edges) hipLaunchKernelGGL(k_compact, grid1(a.n_edges, 64), dim3(256), 0, st, a); // 4 waves x 16 edges

@@ -24,14 +24,73 @@ def _round_up(n, a=ALIGN):
     return (n + a - 1) // a * a
 
 
-def slab_layout(max_counts):
+def block_bytes(counts, wire=False):
+    """Bytes of a rank's (edge, order, id) blocks: whole records, or the wire form of include/msgpu.h (17 n + 8, 33 n + 4)."""
+    ne, no, ni = (int(x) for x in counts)
+    if wire:
+        return 17 * ne + 8, 33 * no + 4, 4 * ni
+    return ne * EDGE_DTYPE.itemsize, no * ORDER_DTYPE.itemsize, ni * 4
+
+
+def slab_layout(max_counts, wire=False):
     """Byte offsets of (edges, orders, ids) inside a slab sized for the largest rank, and the slab size."""
-    ne, no, ni = (int(x) for x in max_counts)
+    be, bo, bi = block_bytes(max_counts, wire)
     off_e = 0
-    off_o = _round_up(off_e + ne * EDGE_DTYPE.itemsize)
-    off_i = _round_up(off_o + no * ORDER_DTYPE.itemsize)
-    size = _round_up(off_i + ni * 4)
+    off_o = _round_up(off_e + be)
+    off_i = _round_up(off_o + bo)
+    size = _round_up(off_i + bi)
     return (off_e, off_o, off_i), max(size, ALIGN)
+
+
+def pack_wire_host(t):
+    """Host statement of msgpu_pack_wire: a rank's {edges, orders, ids} -> (edge block, order block, id block) as uint8
+    arrays.  Asserts what the wire form relies on: dense tables, start / end / base given by flags and edge, zero padding."""
+    e, o, ids = t["edges"], t["orders"], np.ascontiguousarray(t["ids"], dtype="<u4")
+    ne, no = len(e), len(o)
+
+    def csr(off, cnt, total=None):
+        off, cnt = off.astype(np.uint64), cnt.astype(np.uint64)
+        dense = np.concatenate([[0], np.cumsum(cnt)]).astype(np.uint64)
+        first = off[0] if len(off) else np.uint64(0)  # (a block of a larger table may start anywhere; it must be dense)
+        assert np.array_equal(off, dense[:-1] + first), "the wire form needs dense tables"
+        assert int(first + dense[-1]) < 2 ** 32
+        assert total is None or not len(off) or int(first) == 0 and int(dense[-1]) == total
+        return (dense + first).astype("<u4")
+    v1, v2 = e["v1"][o["edge_idx"]], e["v2"][o["edge_idx"]]
+    sv1 = (o["flags"] & 1).astype(bool)
+    assert np.array_equal(o["start"], np.where(sv1, v1, v2)) and np.array_equal(o["end"], np.where(sv1, v2, v1))
+    assert np.array_equal(o["base"], v1) and not o["pad"].any() and not e["pad"].any() and int(o["flags"].max(initial=0)) < 256
+    eb = np.concatenate([csr(e["em_off"], e["em_cnt"]).view(np.uint8), csr(e["order_off"], e["order_cnt"], no).view(np.uint8),
+                         e["v1"].astype("<u4").view(np.uint8), e["v2"].astype("<u4").view(np.uint8), e["shadow"].astype(np.uint8)])
+    ob = np.concatenate([o["left_offset"].astype("<f8").view(np.uint8), o["right_offset"].astype("<f8").view(np.uint8),
+                         o["score"].astype("<u8").view(np.uint8), csr(o["ids_off"], o["ids_cnt"], len(ids)).view(np.uint8),
+                         o["edge_idx"].astype("<u4").view(np.uint8), o["flags"].astype(np.uint8)])
+    assert len(eb) == 17 * ne + 8 and len(ob) == 33 * no + 4
+    return eb, ob, ids.view(np.uint8)
+
+
+def unpack_wire_host(eb, ob, ib, counts):
+    """Host statement of what msgpu_merge_wire reconstructs for ONE rank (no re-basing): blocks -> {edges, orders, ids}."""
+    ne, no, ni = (int(x) for x in counts)
+    eb, ob = np.ascontiguousarray(eb[: 17 * ne + 8]), np.ascontiguousarray(ob[: 33 * no + 4])
+    u4 = lambda b, lo, n: b[lo: lo + 4 * n].view("<u4")  # noqa: E731
+    em_off, order_off = u4(eb, 0, ne + 1), u4(eb, 4 * (ne + 1), ne + 1)
+    e = np.zeros(ne, dtype=EDGE_DTYPE)
+    e["v1"], e["v2"] = u4(eb, 8 * (ne + 1), ne), u4(eb, 8 * (ne + 1) + 4 * ne, ne)
+    e["em_off"], e["em_cnt"] = em_off[:-1], np.diff(em_off.astype(np.int64))
+    e["order_off"], e["order_cnt"] = order_off[:-1], np.diff(order_off.astype(np.int64))
+    e["shadow"] = eb[8 * (ne + 1) + 8 * ne: 8 * (ne + 1) + 9 * ne]
+    o = np.zeros(no, dtype=ORDER_DTYPE)
+    o["left_offset"], o["right_offset"] = ob[: 8 * no].view("<f8"), ob[8 * no: 16 * no].view("<f8")
+    o["score"] = ob[16 * no: 24 * no].view("<u8")
+    ids_off = u4(ob, 24 * no, no + 1)
+    o["ids_off"], o["ids_cnt"] = ids_off[:-1], np.diff(ids_off.astype(np.int64))
+    o["edge_idx"] = u4(ob, 24 * no + 4 * (no + 1), no)
+    o["flags"] = ob[24 * no + 4 * (no + 1) + 4 * no: 24 * no + 4 * (no + 1) + 5 * no]
+    v1, v2 = e["v1"][o["edge_idx"]], e["v2"][o["edge_idx"]]
+    sv1 = (o["flags"] & 1).astype(bool)
+    o["start"], o["end"], o["base"] = np.where(sv1, v1, v2), np.where(sv1, v2, v1), v1
+    return {"edges": e, "orders": o, "ids": np.ascontiguousarray(ib[: 4 * ni]).view("<u4").copy()}
 
 
 def gather_slabs(counts, fill_slab, device, group=None):
@@ -68,14 +127,14 @@ class SlabExchange:
     all of them enlarge the capacity and repeat the collective together (counted in `regrows`).  Identical decisions on
     every rank by construction: nothing but gathered data enters them."""
 
-    def __init__(self, device, group=None, slack=1.03125):
-        self.device, self.group, self.slack = device, group, slack
+    def __init__(self, device, group=None, slack=1.03125, wire=False):
+        self.device, self.group, self.slack, self.wire = device, group, slack, wire
         self.cap = None
         self.calls = self.collectives = self.regrows = 0
         self.slab_bytes = 0
 
     def _layout(self):
-        offs, size = slab_layout(self.cap)
+        offs, size = slab_layout(self.cap, self.wire)
         return tuple(HEADER + o for o in offs), HEADER + size
 
     def _agree(self, counts):
@@ -118,12 +177,15 @@ class SlabExchange:
             self.regrows += 1
 
 
-def split_gathered_host(gathered, all_counts, offs, slab_bytes):
+def split_gathered_host(gathered, all_counts, offs, slab_bytes, wire=False):
     """Host view of a gathered buffer: list of per-rank {edges, orders, ids} numpy tables."""
     buf = np.asarray(gathered, dtype=np.uint8)
     out = []
     for r, (ne, no, ni) in enumerate(np.asarray(all_counts, dtype=np.int64)):
         base = r * slab_bytes
+        if wire:
+            out.append(unpack_wire_host(buf[base + offs[0]:], buf[base + offs[1]:], buf[base + offs[2]:], (ne, no, ni)))
+            continue
         out.append({
             "edges": buf[base + offs[0]: base + offs[0] + ne * EDGE_DTYPE.itemsize].view(EDGE_DTYPE).copy(),
             "orders": buf[base + offs[1]: base + offs[1] + no * ORDER_DTYPE.itemsize].view(ORDER_DTYPE).copy(),
@@ -229,9 +291,9 @@ class PipelinedExchange:
     On CPU tensors (gloo, the tests) there are no streams and no thread: the all-gather completes inside submit() and
     collect() finishes the batch before the one just submitted, which keeps the one-batch-behind bookkeeping honest."""
 
-    def __init__(self, device, merge, group=None, slack=1.03125, threaded=None):
+    def __init__(self, device, merge, group=None, slack=1.03125, threaded=None, wire=False):
         import torch
-        self.device, self.group, self.slack, self.merge = device, group, slack, merge
+        self.device, self.group, self.slack, self.merge, self.wire = device, group, slack, merge, wire
         self.cuda = device.type == "cuda"
         self.comm = torch.cuda.Stream(device=device) if self.cuda else None
         self.threaded = self.cuda if threaded is None else (threaded and self.cuda)
@@ -252,7 +314,7 @@ class PipelinedExchange:
 
     # ---- layout --------------------------------------------------------------------------------------------------
     def _layout(self):
-        offs, size = slab_layout(self.cap)
+        offs, size = slab_layout(self.cap, self.wire)
         return tuple(HEADER + o for o in offs), HEADER + size
 
     def _agree(self, counts):
@@ -338,7 +400,7 @@ class PipelinedExchange:
         if all(c <= k for c, k in zip(counts, self.cap)):
             fill_slab(slot["slab"], offs)
         else:  # outgrown: header only; the tables wait in a private block laid out for their own size
-            s_offs, s_size = slab_layout(counts)
+            s_offs, s_size = slab_layout(counts, self.wire)
             stash = torch.empty(HEADER + s_size, dtype=torch.uint8, device=self.device)
             s_offs = tuple(HEADER + o for o in s_offs)
             fill_slab(stash, s_offs)
@@ -390,8 +452,8 @@ class PipelinedExchange:
         counts = slot["counts"]
         slot.pop("slab_bytes", None)
         offs, _ = self._buffers(slot, world)
-        for n, rec, so, do in zip(counts, (EDGE_DTYPE.itemsize, ORDER_DTYPE.itemsize, 4), s_offs, offs):
-            slot["slab"][do: do + n * rec].copy_(src[so: so + n * rec])
+        for nb, so, do in zip(block_bytes(counts, self.wire), s_offs, offs):  # (a block is packed for the rank's own counts)
+            slot["slab"][do: do + nb].copy_(src[so: so + nb])
         slot["offs"], slot["stash"], slot["cap"] = offs, None, self.cap
 
     def _collect(self, slot):

@@ -266,6 +266,21 @@ class OverlapContext:
                                                     base.ctypes.data if base is not None else None, C.c_void_p(d_edges),
                                                     C.c_void_p(d_orders), C.c_void_p(d_ids), C.c_void_p(stream or None)))
 
+    def pack_wire(self, d_wire_edges, d_wire_orders, d_ids):
+        """The context's edge / order / id tables in the exchange's wire form (include/msgpu.h) into three device blocks,
+        on the context's stream."""
+        self._check(self._L.msgpu_pack_wire(self._h, C.c_void_p(d_wire_edges), C.c_void_p(d_wire_orders), C.c_void_p(d_ids)))
+
+    def merge_wire(self, d_gathered, counts, slab_bytes, offs, d_edges, d_orders, d_ids, id_base=None, stream=None):
+        """merge_gathered over slabs whose blocks are in wire form (msgpu_merge_wire): the same merged tables."""
+        cnt = np.ascontiguousarray(counts, dtype="<u8")
+        base = None if id_base is None else np.ascontiguousarray(id_base, dtype="<u4")
+        assert base is None or base.shape == (cnt.shape[0], 2)
+        self._check(self._L.msgpu_merge_wire(self._h, C.c_void_p(d_gathered), cnt.shape[0], cnt.ctypes.data, slab_bytes,
+                                             offs[0], offs[1], offs[2], base.ctypes.data if base is not None else None,
+                                             C.c_void_p(d_edges), C.c_void_p(d_orders), C.c_void_p(d_ids),
+                                             C.c_void_p(stream or None)))
+
     def find_contraction_edges(self, d_edges=None, n_edges=0, d_orders=None, n_orders=0, n_reads=0):
         """findContractionEdges + sanityCheck (src/main.cpp:416-463, sc.cpp:29-90) on the context's own tables, or on
         device tables given by pointer -> int64 per edge: index of its contraction order, -1 = none."""

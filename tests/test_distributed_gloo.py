@@ -21,7 +21,25 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, rows_bytes, out_dir):
+def _three_times(D, t):
+    """a rank's tables three times over as ONE dense table set (what a three times larger shard would hold)"""
+    m = D.merge_tables_host([t, t, t])
+    m["edges"]["em_off"] = np.concatenate([[0], np.cumsum(m["edges"]["em_cnt"].astype(np.uint64))[:-1]])
+    return m
+
+
+def _filler(D, t, wire):
+    """fill_slab of the exchange classes for host tables: whole records, or the wire form's three blocks"""
+    blocks = D.pack_wire_host(t) if wire else [t[name].view(np.uint8) for name in ("edges", "orders", "ids")]
+
+    def fill(slab, offs):
+        for b, off in zip(blocks, offs):
+            b = torch.from_numpy(np.ascontiguousarray(b).copy())
+            slab[off: off + b.numel()] = b
+    return fill
+
+
+def _worker(rank, world, port, rows_bytes, out_dir, wire=False):
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
     sys.path[:0] = [os.path.dirname(here), os.path.join(os.path.dirname(here), "oracle"), here]
@@ -44,6 +62,8 @@ def _worker(rank, world, port, rows_bytes, out_dir):
         counts = (len(mine["edges"]), len(mine["orders"]), len(mine["ids"]))
         gathered, all_counts, offs, slab_bytes = D.gather_slabs(counts, fill, torch.device("cpu"))
         per_rank = D.split_gathered_host(gathered.numpy(), all_counts, offs, slab_bytes)
+        for name, blk in zip(("edges", "orders", "ids"), D.unpack_wire_host(*D.pack_wire_host(mine), counts).items()):
+            assert blk[1].tobytes() == mine[name].tobytes(), name  # the wire form loses nothing of a shard's tables
         merged = D.canonicalize(D.merge_tables_host(per_rank))
         assert int(all_counts[:, 0].sum()) == len(full["edges"])
         # em_off is rank-local by contract; everything else must equal the single-process tables
@@ -55,21 +75,16 @@ def _worker(rank, world, port, rows_bytes, out_dir):
         assert_tables_equal(got, want, "rank %d" % rank)
         # the one-collective form (header inside the slab, capacity remembered): first call agrees on a capacity, the
         # second goes straight to the slab all-gather, a rank that outgrows the capacity makes every rank repeat
-        ex = D.SlabExchange(torch.device("cpu"))
+        ex = D.SlabExchange(torch.device("cpu"), wire=wire)
         for call in range(3):
-            if call == 2:  # rank 0's tables outgrow the remembered capacity (its own tables repeated)
-                grown = {k: np.concatenate([mine[k]] * 3) for k in ("edges", "orders", "ids")} if rank == 0 else mine
+            if call == 2:  # rank 0's tables outgrow the remembered capacity (its own tables three times over)
+                grown = _three_times(D, mine) if rank == 0 else mine
             else:
                 grown = mine
-
-            def fill2(slab, offs, t=grown):
-                for name, off in zip(("edges", "orders", "ids"), offs):
-                    b = torch.from_numpy(t[name].view(np.uint8).copy())
-                    slab[off: off + b.numel()] = b
             cnt = (len(grown["edges"]), len(grown["orders"]), len(grown["ids"]))
-            g2, c2, offs2, sb2 = ex.gather(cnt, fill2)
+            g2, c2, offs2, sb2 = ex.gather(cnt, _filler(D, grown, wire))
             assert np.array_equal(c2[rank], cnt)
-            parts = D.split_gathered_host(g2.numpy(), c2, offs2, sb2)
+            parts = D.split_gathered_host(g2.numpy(), c2, offs2, sb2, wire=wire)
             assert parts[rank]["orders"].tobytes() == grown["orders"].tobytes()
             if call < 2:
                 m2 = D.canonicalize(D.merge_tables_host(parts))
@@ -80,7 +95,7 @@ def _worker(rank, world, port, rows_bytes, out_dir):
         dist.destroy_process_group()
 
 
-def _pipelined_worker(rank, world, port, rows_bytes, out_dir):
+def _pipelined_worker(rank, world, port, rows_bytes, out_dir, wire=False):
     """PipelinedExchange under gloo: batches submitted one ahead of their collection, a rank that outgrows the capacity in
     two consecutive batches (the second one goes out before the first one's headers were read), id bases in the merge."""
     import sys
@@ -96,24 +111,19 @@ def _pipelined_worker(rank, world, port, rows_bytes, out_dir):
         rows = np.frombuffer(rows_bytes, dtype=ROW_DTYPE)
         full = oracle.overlap(rows)
         shards = [D.shard_view_host(full, r, world) for r in range(world)]
-        big0 = {k: np.concatenate([shards[0][k]] * 3) for k in ("edges", "orders", "ids")}
+        big0 = _three_times(D, shards[0])
         # what every rank holds in batch b: the shards; in batches 2 and 3 rank 0's tables are three times as long
         held = lambda b, r: big0 if (r == 0 and b in (2, 3)) else shards[r]  # noqa: E731
         merged = []
 
         def merge(gathered, allc, offs, slab_bytes, k, stream):
             assert stream is None
-            merged.append((D.split_gathered_host(gathered.numpy(), allc, offs, slab_bytes), allc.copy()))
+            merged.append((D.split_gathered_host(gathered.numpy(), allc, offs, slab_bytes, wire=wire), allc.copy()))
 
-        pe = D.PipelinedExchange(torch.device("cpu"), merge)
+        pe = D.PipelinedExchange(torch.device("cpu"), merge, wire=wire)
         for b in range(6):
             t = held(b, rank)
-
-            def fill(slab, offs, t=t):
-                for name, off in zip(("edges", "orders", "ids"), offs):
-                    buf = torch.from_numpy(t[name].view(np.uint8).copy())
-                    slab[off: off + buf.numel()] = buf
-            pe.submit((len(t["edges"]), len(t["orders"]), len(t["ids"])), fill)
+            pe.submit((len(t["edges"]), len(t["orders"]), len(t["ids"])), _filler(D, t, wire))
             got = pe.collect()
             assert (got is None) == (b == 0)  # the batch before, from the second submit on
         last = pe.drain()
@@ -131,21 +141,21 @@ def _pipelined_worker(rank, world, port, rows_bytes, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_pipelined_exchange_one_batch_behind(tmp_path, world):
+@pytest.mark.parametrize("world,wire", [(2, False), (3, False), (2, True), (3, True)])
+def test_pipelined_exchange_one_batch_behind(tmp_path, world, wire):
     from muchsalsa_amd import synth
     rows = synth.synth_rows(300, 4000, 1100, 8)
     port = _free_port()
-    mp.spawn(_pipelined_worker, args=(world, port, rows.tobytes(), str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_pipelined_worker, args=(world, port, rows.tobytes(), str(tmp_path), wire), nprocs=world, join=True)
     assert all(os.path.exists(tmp_path / ("pipe%d" % r)) for r in range(world))
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_gather_and_merge_equals_single_process(tmp_path, world):
+@pytest.mark.parametrize("world,wire", [(2, False), (3, False), (2, True), (3, True)])
+def test_gather_and_merge_equals_single_process(tmp_path, world, wire):
     from muchsalsa_amd import synth
     rows = synth.synth_rows(400, 4000, 1500, 5)
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, rows.tobytes(), str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, rows.tobytes(), str(tmp_path), wire), nprocs=world, join=True)
     assert all(os.path.exists(tmp_path / ("ok%d" % r)) for r in range(world))
 
 

@@ -265,6 +265,69 @@ def test_shards_union_equals_single_gpu(oracle, world):
     assert_tables_equal(canon, want, "merged world=%d" % world)
 
 
+@pytest.mark.parametrize("world", [1, 3, 8])
+def test_wire_form_merge_equals_whole_record_merge(oracle, world):
+    """The exchange's wire form (msgpu_pack_wire / msgpu_merge_wire): every shard's tables packed on the GPU equal the host
+    statement of the form byte for byte, and the merge of the wire slabs -- with id bases -- is the merge of the whole-record
+    slabs, byte for byte (so everything proven for msgpu_merge_gathered holds for it)."""
+    import torch
+    from muchsalsa_amd import distributed as D, overlap, synth
+    from muchsalsa_amd._lib import EDGE_DTYPE, ORDER_DTYPE
+    dev = torch.device("cuda", 0)
+    shapes = [(1000, 5000, 4000, 13), (120, 20000, 2400, 5)] if world == 1 else [(1000, 5000, 4000, 13)]
+    for shape in shapes:
+        rows = synth.synth_rows(*shape) if shape[0] == 1000 else synth.accepted_rows(synth.paf_table(*shape, coverage=10))[0]
+        full = oracle.overlap(rows)
+        shards, blocks = [], []
+        for r in range(world):
+            with overlap.OverlapContext(0) as ctx:
+                ctx.set_shard(r, world)
+                ctx.load_rows(rows)
+                ctx.calculate_edges()
+                ctx.chaining_and_overlaps()
+                t = ctx.tables()
+                assert_tables_equal(t, D.shard_view_host(full, r, world), "shard %d/%d" % (r, world))
+                cnt = (len(t["edges"]), len(t["orders"]), len(t["ids"]))
+                nb = D.block_bytes(cnt, wire=True)
+                assert nb[0] == ctx._L.msgpu_wire_edges_bytes(cnt[0]) and nb[1] == ctx._L.msgpu_wire_orders_bytes(cnt[1])
+                d = [torch.full((n + 8,), 0xAB, dtype=torch.uint8, device=dev) for n in nb]
+                ctx.pack_wire(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr())
+                ctx.synchronize()
+                got = [x.cpu().numpy() for x in d]
+            want = D.pack_wire_host(t)
+            for name, g, w_, n in zip(("edges", "orders", "ids"), got, want, nb):
+                assert g[:n].tobytes() == w_.tobytes(), (name, r)
+                assert (g[n:] == 0xAB).all(), (name, r)  # nothing written behind a block
+            back = D.unpack_wire_host(*want, cnt)
+            for k in ("edges", "orders", "ids"):
+                assert back[k].tobytes() == t[k].tobytes(), (k, r)
+            shards.append(t)
+            blocks.append(want)
+        counts = np.array([[len(t["edges"]), len(t["orders"]), len(t["ids"])] for t in shards], dtype=np.int64)
+        id_base = np.array([[r * 1000, r * 70000] for r in range(world)], dtype="<u4")
+        tot = counts.sum(axis=0)
+        results = []
+        with overlap.OverlapContext(0) as ctx:
+            for wire in (False, True):
+                offs, slab_bytes = D.slab_layout(counts.max(axis=0), wire=wire)
+                gathered = np.full(world * slab_bytes, 0xCD, dtype=np.uint8)
+                for r, t in enumerate(shards):
+                    parts = blocks[r] if wire else [t[name].view(np.uint8) for name in ("edges", "orders", "ids")]
+                    for b, off in zip(parts, offs):
+                        gathered[r * slab_bytes + off: r * slab_bytes + off + len(b)] = b
+                d_g = torch.from_numpy(gathered).to(dev)
+                d_e = torch.zeros(max(int(tot[0]), 1) * EDGE_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+                d_o = torch.zeros(max(int(tot[1]), 1) * ORDER_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+                d_i = torch.zeros(max(int(tot[2]), 1) * 4, dtype=torch.uint8, device=dev)
+                (ctx.merge_wire if wire else ctx.merge_gathered)(d_g.data_ptr(), counts, slab_bytes, offs, d_e.data_ptr(),
+                                                                 d_o.data_ptr(), d_i.data_ptr(), id_base=id_base)
+                ctx.synchronize()
+                results.append([x.cpu().numpy().tobytes() for x in (d_e, d_o, d_i)])
+        assert int(tot[0]) > 0 and int(tot[1]) > 0
+        for name, a, b in zip(("edges", "orders", "ids"), *results):
+            assert a == b, (name, world)
+
+
 def test_api_state_and_id_checks():
     from muchsalsa_amd import _lib, overlap, synth
     rows = synth.synth_rows(100, 3000, 300, 2)
@@ -361,7 +424,8 @@ def test_property_checks_at_full_size():
 
 
 def test_bench_distributed_path_smoke():
-    """bench.py's N>1 step (copy_tables_device -> all-gather over RCCL -> msgpu_merge_gathered) at world size 1."""
+    """bench.py's N>1 step (msgpu_pack_wire -> all-gather over RCCL -> msgpu_merge_wire; with --exchange-format whole:
+    copy_tables_device -> all-gather -> msgpu_merge_gathered) at world size 1."""
     import json
     import os
     import subprocess
@@ -382,12 +446,13 @@ def test_bench_distributed_path_smoke():
     # the default N > 1 line: weak scaling (the exchange one step behind the compute, on its own stream), with the strong
     # (one job sharded by v1 % N) and the rank-sharded host-to-host figures beside it
     assert line["scaling"] == "weak" and line["exchange"]["regrows"] == 0
+    assert line["exchange"]["format"].startswith("wire") and line["exchange"]["slab_bytes"] < line["exchange"]["whole_record_slab_bytes"]
     assert line["strong"]["merged_edge_list_consistent"] is True and line["strong"]["value"] > 0
     assert line["strong"]["edges"] == line["config"]["edges"]
     assert line["host_to_host_sharded"]["edges"] == line["config"]["edges"] and line["host_to_host_sharded"]["ms"] > 0
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "tiny", "--steps", "2",
-                          "--warmup", "1", "--kernels-only", "--force-dist", "--scaling", "strong"], env=env,
-                         capture_output=True, text=True, timeout=300)
+                          "--warmup", "1", "--kernels-only", "--force-dist", "--scaling", "strong", "--exchange-format", "whole"],
+                         env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads(out.stdout.strip().splitlines()[-1])
     assert line["scaling"] == "strong" and line["config"]["merged_edge_list_consistent"] is True and "strong" not in line
