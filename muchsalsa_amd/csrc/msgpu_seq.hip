@@ -1271,7 +1271,7 @@ __device__ __forceinline__ uint32_t edit_distance_wave(const uint8_t *a, uint32_
   return v > W ? W + 1 : v;
 }
 
-__global__ __launch_bounds__(128) void k_edit_distance(const uint8_t *base_a, const uint8_t *base_b,
+__global__ __launch_bounds__(128) void k_edit_distance_dp(const uint8_t *base_a, const uint8_t *base_b,
                                                        const msgpu_align_pair *pairs, uint32_t n_pairs, uint32_t W,
                                                        uint32_t *out) {
   __shared__ uint8_t s_a[2][ED_LDS], s_b[2][ED_LDS];
@@ -1293,6 +1293,125 @@ __global__ __launch_bounds__(128) void k_edit_distance(const uint8_t *base_a, co
   if (lane == 0) out[p] = d;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same distance by furthest-reaching points (Ukkonen 1985, Myers 1986): the DP over (edits e, diagonal k) instead of
+// over (i, j).  F_e[k] = the largest i such that a[0, i) and b[0, i + k) are within e edits:
+//     F_e[k] = slide(max(F_{e-1}[k] + 1, F_{e-1}[k-1], F_{e-1}[k+1] + 1)),   slide(i) = i + |common prefix of a[i..), b[i+k..)|
+// and the distance is the first e with F_e[m - n] = n.  What k_edit_distance_dp spends on (n + m) anti-diagonal steps of
+// 2W + 1 cells each, this form spends on at most W + 1 steps of 2e + 1 diagonals plus the slides -- for the pairs the
+// meter exists for (a query against its window of the contig: a handful of edits in 7 kb) one slide over the sequence.
+// The result is the same number for every input: the banded DP gives min(d, W + 1) because a path of d <= W edits never
+// leaves the band, and so does this (tests: both kernels against the full-DP oracle and against each other).
+//
+// One wavefront per pair.  Lane l owns the diagonals k = l + 64 c - 128, c = 0..3 (neighbouring diagonals in neighbouring
+// lanes: one shuffle per side and step).  A slide starts lane-local, 8 bytes per comparison; a lane that is still
+// matching after 16 bytes hands its diagonal to the whole wavefront, which compares 512 bytes per round (8 per lane,
+// first mismatch by ballot) -- the long slides of near-identical pairs run at the wavefront's width, not one lane's.
+// No LDS: every base is read about once, straight from HBM/L2 (staging would be a second pass); 8 waves per SIMD.
+// ---------------------------------------------------------------------------------------------------------------------
+
+constexpr int FR_NONE = -(1 << 30);
+
+// length of the common prefix of pa[0, valid) and pb[0, valid), valid <= 8 (nothing behind `valid` is read)
+__device__ __forceinline__ int match_run8(const uint8_t *pa, const uint8_t *pb, int valid) {
+  if (valid >= 8) {
+    uint64_t x, y;
+    __builtin_memcpy(&x, pa, 8);
+    __builtin_memcpy(&y, pb, 8);
+    const uint64_t d = x ^ y;
+    return d ? (__builtin_ctzll(d) >> 3) : 8;
+  }
+  int r = 0;
+  while (r < valid && pa[r] == pb[r]) ++r;
+  return r;
+}
+
+__device__ __forceinline__ uint32_t edit_distance_fr_wave(const uint8_t *a, int n, const uint8_t *b, int m, int W) {
+  const int lane = threadIdx.x & 63;
+  const int ks   = m - n;
+  if ((ks < 0 ? -ks : ks) > W) return static_cast<uint32_t>(W + 1);
+  int fr[4] = {FR_NONE, FR_NONE, FR_NONE, FR_NONE};
+  for (int e = 0; e <= W; ++e) {
+    int nf[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int k = lane + 64 * c - 128;
+      int       x;
+      if (e == 0) {
+        x = k == 0 ? 0 : FR_NONE;
+      } else {
+        int lo = __shfl_up(fr[c], 1), hi = __shfl_down(fr[c], 1); // diagonals k - 1, k + 1
+        const int lo_edge = c > 0 ? __shfl(fr[c > 0 ? c - 1 : 0], 63) : FR_NONE;
+        const int hi_edge = c < 3 ? __shfl(fr[c < 3 ? c + 1 : 3], 0) : FR_NONE;
+        if (lane == 0) lo = lo_edge;
+        if (lane == 63) hi = hi_edge;
+        x = max(max(fr[c] + 1, lo), hi + 1);
+        const int ak = k < 0 ? -k : k;
+        if (ak > W || ak > e) x = FR_NONE;
+        x = min(x, min(n, m - k));
+        if (x < 0 || x + k < 0) x = FR_NONE;
+      }
+      nf[c] = x;
+    }
+    const int R = e < W ? e : W; // diagonals |k| <= R can hold a point
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      if (!(64 * c - 128 <= R && 64 * c - 65 >= -R)) continue; // (uniform: none of this c's diagonals is in reach)
+      const int k = lane + 64 * c - 128;
+      int       x = nf[c];
+      bool      more = false;
+      if (x >= 0) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          const int valid = min(8, min(n - x, m - (x + k)));
+          const int run   = match_run8(a + x, b + (x + k), valid);
+          x += run;
+          more = run == 8;
+          if (!more) break;
+        }
+      }
+      unsigned long long mask = __ballot(more);
+      while (mask) { // the diagonals that keep matching, one after the other at the wavefront's width
+        const int L = __builtin_ctzll(mask);
+        mask &= mask - 1;
+        int       xs = __shfl(x, L);
+        const int kk = L + 64 * c - 128;
+        for (;;) {
+          const int px    = xs + 8 * lane;
+          const int valid = min(8, min(n - px, m - (px + kk)));
+          const int run   = valid > 0 ? match_run8(a + px, b + (px + kk), valid) : 0;
+          const unsigned long long stop = __ballot(run < 8);
+          if (stop) {
+            const int F = __builtin_ctzll(stop);
+            xs += 8 * F + __shfl(run, F);
+            break;
+          }
+          xs += 512;
+        }
+        if (lane == L) x = xs;
+      }
+      nf[c] = x;
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) fr[c] = nf[c];
+    const int slot = ks + 128, cs = slot >> 6;
+    const int v    = __shfl(cs == 0 ? fr[0] : cs == 1 ? fr[1] : cs == 2 ? fr[2] : fr[3], slot & 63);
+    if (v >= n) return static_cast<uint32_t>(e);
+  }
+  return static_cast<uint32_t>(W + 1);
+}
+
+__global__ __launch_bounds__(256) void k_edit_distance(const uint8_t *base_a, const uint8_t *base_b,
+                                                       const msgpu_align_pair *pairs, uint32_t n_pairs, uint32_t W,
+                                                       uint32_t *out) {
+  const uint32_t p = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (p >= n_pairs) return; // (whole wavefronts leave)
+  const msgpu_align_pair pr = pairs[p];
+  const uint32_t d = edit_distance_fr_wave(base_a + pr.a_off, static_cast<int>(pr.a_len), base_b + pr.b_off,
+                                           static_cast<int>(pr.b_len), static_cast<int>(W));
+  if ((threadIdx.x & 63) == 0) out[p] = d;
+}
+
 } // namespace msgpu
 
 extern "C" {
@@ -1302,16 +1421,27 @@ int msgpu_edit_distance(msgpu_seqctx *c, const void *d_a, const void *d_b, const
   if (!c || (n && (!pairs || !out || !d_a || !d_b)) || band > ED_MAXW || n >= 0x7fffffffull) return MSGPU_E_ARG;
   if (c->device < 0) return MSGPU_E_NODEVICE;
   if (!n) return MSGPU_OK;
+  for (size_t i = 0; i < n; ++i)
+    if (pairs[i].a_len >= (1u << 30) || pairs[i].b_len >= (1u << 30)) return MSGPU_E_ARG; // (positions are ints on the device)
   SHIP(c, hipSetDevice(c->device));
   void *d_pairs = nullptr, *d_out = nullptr;
   SHIP(c, hipMalloc(&d_pairs, n * sizeof(msgpu_align_pair)));
   hipError_t e = hipMalloc(&d_out, n * sizeof(uint32_t));
   if (e == hipSuccess) e = hipMemcpyAsync(d_pairs, pairs, n * sizeof(msgpu_align_pair), hipMemcpyHostToDevice, c->stream);
   if (e == hipSuccess) {
-    hipLaunchKernelGGL(k_edit_distance, dim3(static_cast<uint32_t>((n + 1) / 2)), dim3(128), 0, c->stream,
-                       static_cast<const uint8_t *>(d_a), static_cast<const uint8_t *>(d_b),
-                       static_cast<const msgpu_align_pair *>(d_pairs), static_cast<uint32_t>(n), band,
-                       static_cast<uint32_t *>(d_out));
+    // MSGPU_ED_DP=1: the anti-diagonal banded DP instead of the furthest-reaching form (same numbers; A/B and cross-check)
+    const char *ed_dp  = std::getenv("MSGPU_ED_DP");
+    const bool  use_dp = ed_dp && ed_dp[0] == '1';
+    if (use_dp)
+      hipLaunchKernelGGL(k_edit_distance_dp, dim3(static_cast<uint32_t>((n + 1) / 2)), dim3(128), 0, c->stream,
+                         static_cast<const uint8_t *>(d_a), static_cast<const uint8_t *>(d_b),
+                         static_cast<const msgpu_align_pair *>(d_pairs), static_cast<uint32_t>(n), band,
+                         static_cast<uint32_t *>(d_out));
+    else
+      hipLaunchKernelGGL(k_edit_distance, dim3(static_cast<uint32_t>((n + 3) / 4)), dim3(256), 0, c->stream,
+                         static_cast<const uint8_t *>(d_a), static_cast<const uint8_t *>(d_b),
+                         static_cast<const msgpu_align_pair *>(d_pairs), static_cast<uint32_t>(n), band,
+                         static_cast<uint32_t *>(d_out));
     e = hipGetLastError();
   }
   if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, n * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream);
