@@ -668,7 +668,10 @@ int msgpu_graph_sort_topologically(uint32_t n_vertices, const uint32_t *a, const
 /* ---- banded edit distance (no reference counterpart) ---------------------------------
  * The meter for north_star's "consensus sequences within a stated edit-distance tolerance": Levenshtein distance
  * (unit costs, global) of n pairs a[a_off .. a_off+a_len) vs b[b_off .. b_off+b_len) taken from two DEVICE buffers,
- * inside the band |j - i| <= band (band <= 127).  out[p] (host) = the distance when it is <= band, else band + 1. */
+ * inside the band |j - i| <= band (band <= 127).  out[p] (host) = the distance when it is <= band, else band + 1
+ * (= min(distance, band + 1): a path of d <= band edits never leaves the band).  Sequences shorter than 2^30 bytes.
+ * Computed by furthest-reaching points per (edits, diagonal); MSGPU_ED_DP=1 in the environment selects the banded
+ * anti-diagonal DP kernel instead (same numbers, for cross-checks). */
 typedef struct msgpu_align_pair {
   uint64_t a_off, b_off;
   uint32_t a_len, b_len;
