@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """One-off differential run on the GPU box: random small workloads (random strands / primary flags, duplicates, shuffled
-rows, several coverages) through libmsgpu and through the C oracle; every table must match bit for bit.
+rows, several coverages) through libmsgpu and through the C oracle; every table must match bit for bit.  Every case also
+sends its tables through the exchange's wire form (pack kernel == host statement, wire merge == whole-record merge) and
+measures random sequence pairs with msgpu_edit_distance against the full-DP oracle.
     python tools/fuzz_gpu_parity.py [n_cases] [first_seed]"""
 import os
 import sys
@@ -14,6 +16,76 @@ import numpy as np  # noqa: E402
 import ms_oracle_ctypes as oracle  # noqa: E402
 from helpers import assert_tables_equal  # noqa: E402
 from muchsalsa_amd import overlap, synth  # noqa: E402
+
+
+def wire_roundtrip(ctx, want, rng, what):
+    """the exchange's wire form of the context's (resident) tables == the host statement of the form, and the merge of two
+    such slabs with id bases == the merge of the whole-record slabs"""
+    import torch
+    from muchsalsa_amd import distributed as D
+    from muchsalsa_amd._lib import EDGE_DTYPE, ORDER_DTYPE
+    dev = torch.device("cuda", 0)
+    cnt = (len(want["edges"]), len(want["orders"]), len(want["ids"]))
+    nb = D.block_bytes(cnt, wire=True)
+    d = [torch.full((n + 8,), 0xAB, dtype=torch.uint8, device=dev) for n in nb]
+    ctx.pack_wire(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr())
+    ctx.synchronize()
+    blocks = D.pack_wire_host(want)
+    for g, w_, n in zip(d, blocks, nb):
+        g = g.cpu().numpy()
+        assert g[:n].tobytes() == w_.tobytes() and (g[n:] == 0xAB).all(), what + ": wire block"
+    counts = np.array([cnt, cnt], dtype=np.int64)
+    id_base = np.array([[0, 0], [int(rng.integers(1, 1 << 20)), int(rng.integers(1, 1 << 20))]], dtype="<u4")
+    res = []
+    for wire in (False, True):
+        offs, slab_bytes = D.slab_layout(cnt, wire=wire)
+        slab = np.full(slab_bytes, 0xCD, dtype=np.uint8)
+        for b, off in zip(blocks if wire else [want[k].view(np.uint8) for k in ("edges", "orders", "ids")], offs):
+            slab[off: off + len(b)] = b
+        d_g = torch.from_numpy(np.concatenate([slab, slab])).to(dev)
+        out = [torch.zeros(max(2 * n, 1) * sz, dtype=torch.uint8, device=dev)
+               for n, sz in zip(cnt, (EDGE_DTYPE.itemsize, ORDER_DTYPE.itemsize, 4))]
+        (ctx.merge_wire if wire else ctx.merge_gathered)(d_g.data_ptr(), counts, slab_bytes, offs, out[0].data_ptr(),
+                                                         out[1].data_ptr(), out[2].data_ptr(), id_base=id_base)
+        ctx.synchronize()
+        res.append([x.cpu().numpy().tobytes() for x in out])
+    assert res[0] == res[1], what + ": wire merge"
+
+
+def edit_distances(rng, what):
+    """msgpu_edit_distance (furthest-reaching kernel) on random pairs against the full-DP oracle, random bound"""
+    import torch
+    from muchsalsa_amd import sequences as S
+    from muchsalsa_amd._lib import ALIGN_PAIR_DTYPE
+    alpha = np.frombuffer(b"ACGTN", dtype=np.uint8)
+    band = int(rng.choice([0, 1, 5, 31, 64, 100, 127]))
+    pairs = []
+    for _ in range(24):
+        a = bytearray(rng.choice(alpha[: int(rng.integers(1, 6))], int(rng.integers(0, 1500))).tobytes())
+        b = bytearray(a)
+        for _ in range(int(rng.integers(0, band + 8))):
+            op, pos = int(rng.integers(0, 3)), int(rng.integers(0, len(b) + 1))
+            if op == 0 and b:
+                b[min(pos, len(b) - 1)] = int(rng.choice(alpha))
+            elif op == 1:
+                b.insert(pos, int(rng.choice(alpha)))
+            elif b:
+                del b[min(pos, len(b) - 1)]
+        if rng.random() < 0.15:  # a low-complexity tail: many diagonals slide together
+            a += b"A" * int(rng.integers(0, 600))
+            b += b"A" * int(rng.integers(0, 600))
+        pairs.append((bytes(a), bytes(b)))
+    desc = np.zeros(len(pairs), dtype=ALIGN_PAIR_DTYPE)
+    ao = bo = 0
+    for i, (x, y) in enumerate(pairs):
+        desc[i] = (ao, bo, len(x), len(y))
+        ao, bo = ao + len(x), bo + len(y)
+    da = torch.frombuffer(bytearray(b"".join(p[0] for p in pairs) + b"\0"), dtype=torch.uint8).cuda()
+    db = torch.frombuffer(bytearray(b"".join(p[1] for p in pairs) + b"\0"), dtype=torch.uint8).cuda()
+    torch.cuda.synchronize()
+    with S.SeqStore(0) as st:
+        got = st.edit_distance(da.data_ptr(), db.data_ptr(), desc, band)
+    assert list(got) == [oracle.edit_distance(x, y, band) for x, y in pairs], what + ": edit distances, bound %d" % band
 
 
 def main():
@@ -66,6 +138,8 @@ def main():
                 e = want["edges"][idx]
                 exp = np.concatenate([want["ems"][int(o): int(o) + int(c)] for o, c in zip(e["em_off"], e["em_cnt"])])
                 assert ems.tobytes() == exp.tobytes() and int(off[-1]) == len(exp), what
+            wire_roundtrip(ctx, want, rng, what)
+        edit_distances(rng, what)
         scaf = np.bincount(rows["anchor_id"]).max() if len(rows) else 0
         n = want["edges"]["em_cnt"]
         print("case %3d ok: %6d rows %6d edges, EdgeMatches per edge max %3d, orders %6d, longest scaffold %d" % (
