@@ -862,7 +862,19 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+            # RCCL's own stream at high priority: the all-gather's few workgroups must not queue behind a grid-filling
+            # compute kernel of the next step, or "beside the compute" turns into "after it" (MSGPU_EXCHANGE_PRIORITY=0:
+            # default priority; at world 1, where nothing crosses a link, the two measure the same)
+            kw = {}
+            try:
+                if os.environ.get("MSGPU_EXCHANGE_PRIORITY", "2") != "0":
+                    kw["pg_options"] = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
+            except Exception:  # noqa: BLE001 -- (a build without the option: default priority)
+                kw = {}
+            try:
+                dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world, **kw)
+            except TypeError:  # (signature without pg_options: raised before anything was set up)
+                dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         rccl_ranks = dist.get_world_size()  # what RCCL saw, not what the command line asked for
@@ -891,17 +903,25 @@ def main():
         ctx.chaining_and_overlaps()
         return ctx.counts()
 
-    wire = args.exchange_format == "wire"
+    # what the exchange sends: 0 = whole records, 4 / 3 = the wire form with 4- / 3-byte anchor ids (3 while every rank's
+    # anchor id space fits 24 bits -- decided per leg from numbers every rank holds, so every rank decides alike)
+    form = {"wire": 0 if args.exchange_format == "whole" else 4}
 
     def fill(slab, offs):
-        if wire:  # one pack kernel + the id copy behind the compaction, on the compute stream
-            ctx.pack_wire(slab.data_ptr() + offs[0], slab.data_ptr() + offs[1], slab.data_ptr() + offs[2])
+        if form["wire"]:  # one pack kernel (+ the id copy with 4-byte ids) behind the compaction, on the compute stream
+            ctx.pack_wire(slab.data_ptr() + offs[0], slab.data_ptr() + offs[1], slab.data_ptr() + offs[2],
+                          id_bytes=form["wire"])
         else:
             ctx.copy_tables_device(d_edges=slab.data_ptr() + offs[0], d_orders=slab.data_ptr() + offs[1],
                                    d_ids=slab.data_ptr() + offs[2])
 
     def merge_slabs(*a, **kw):
-        return (ctx.merge_wire if wire else ctx.merge_gathered)(*a, **kw)
+        if form["wire"]:
+            return ctx.merge_wire(*a, id_bytes=form["wire"], **kw)
+        return ctx.merge_gathered(*a, **kw)
+
+    def form_name():
+        return "wire form (17-byte edges, 33-byte orders, %d-byte ids)" % form["wire"] if form["wire"] else "whole records"
 
     def timed_region(step, finish=None):
         """W warm-up steps, then K timed steps between barrier + synchronize on both sides; chain-kernel events of the
@@ -986,7 +1006,9 @@ def main():
                 merged_keep["tot"][k] = tot
                 merged_keep["last"], merged_keep["allc"] = k, allc
 
-            pe = D.PipelinedExchange(dev, merge, wire=wire)
+            if form["wire"]:
+                form["wire"] = 3 if int(alls[:, 1].max()) <= 1 << 24 else 4
+            pe = D.PipelinedExchange(dev, merge, wire=form["wire"])
 
             def step():
                 c = compute()
@@ -1003,7 +1025,7 @@ def main():
             n_edges_total = int(allc[:, 0].sum())
             dt, rank_ms = over_ranks(dt)
             exchange_info = {"collectives_per_step": pe.collectives / max(1, pe.calls), "slab_bytes": int(pe.slab_bytes),
-                             "format": "wire form (17-byte edges, 33-byte orders, ids)" if wire else "whole records",
+                             "format": form_name(),
                              "whole_record_slab_bytes": int(D.HEADER + D.slab_layout(pe.cap)[1]),
                              "regrows": pe.regrows, "overlapped": "all-gather + merge of step k on a communication stream, issued "
                                                                   "by a communication thread, beside the compute of step k + 1"}
@@ -1030,7 +1052,9 @@ def main():
         ctx.set_id_space(len(rn_s), len(an_s))
         if world > 1:
             ctx.set_shard(rank, world)
-        exchange = D.SlabExchange(dev, wire=wire)
+        if form["wire"]:
+            form["wire"] = 3 if len(an_s) <= 1 << 24 else 4
+        exchange = D.SlabExchange(dev, wire=form["wire"])
         s_keep = {}
 
         def strong_step():
@@ -1064,7 +1088,8 @@ def main():
                       "ms_per_step": 1e3 * s_dt / args.steps, "edges": s_edges, "rank_ms_per_step": s_rank_ms,
                       "merged_edge_list_consistent": s_ok,
                       "exchange": {"collectives_per_step": exchange.collectives / max(1, exchange.calls),
-                                   "slab_bytes": int(exchange.slab_bytes), "regrows": exchange.regrows},
+                                   "slab_bytes": int(exchange.slab_bytes), "regrows": exchange.regrows,
+                                   "format": form_name()},
                       "stage_ms": {"index": s_tm.index_ms, "candidates": s_tm.candidates_ms, "chain_total": s_tm.chain_ms,
                                    "chain_kernel": s_k_ms, "compact": s_tm.compact_ms},
                       "workload": "%s as ONE job: every rank indexes the whole row table (replicated), owns the edges with "

@@ -273,17 +273,20 @@ int msgpu_merge_gathered_ex(msgpu_ctx *ctx, const void *d_gathered, uint32_t wor
  *   edge block  (msgpu_wire_edges_bytes(n)  = 17 n + 8): em_off[n+1] u32 | order_off[n+1] u32 | v1[n] | v2[n] | shadow[n] u8
  *   order block (msgpu_wire_orders_bytes(n) = 33 n + 4): left[n] f64 | right[n] f64 | score[n] u64 | ids_off[n+1] u32 |
  *                                                        edge_idx[n] u32 | flags[n] u8
- *   id block    (4 n): as in the tables.
+ *   id block    (msgpu_wire_ids_bytes(n, id_bytes)): id_bytes = 4: as in the tables (4 n); id_bytes = 3, while the job's
+ *               anchor ids fit 24 bits: four ids in three words (3 n, rounded up to a word) -- the ids are half of the
+ *               wire slab, so this takes another 13 % off it.  Every rank of an exchange must use the same id_bytes.
  * msgpu_pack_wire writes the context's tables (after msgpu_chaining_and_overlaps) in that form into three DEVICE blocks
  * (edge and id blocks 4-byte, order block 8-byte aligned) on the context's stream; MSGPU_E_ARG when a table has more than
- * 2^32 - 1 EdgeMatches, orders or ids (exchange such tables whole).  msgpu_merge_wire = msgpu_merge_gathered_ex over
+ * 2^32 - 1 EdgeMatches, orders or ids (exchange such tables whole) or, with id_bytes = 3, an anchor id space beyond 2^24.  msgpu_merge_wire = msgpu_merge_gathered_ex over
  * slabs whose three blocks are in wire form: the merged tables are the same, byte for byte. */
 uint64_t msgpu_wire_edges_bytes(uint64_t n_edges);
 uint64_t msgpu_wire_orders_bytes(uint64_t n_orders);
-int msgpu_pack_wire(msgpu_ctx *ctx, void *d_wire_edges, void *d_wire_orders, void *d_ids);
+uint64_t msgpu_wire_ids_bytes(uint64_t n_ids, uint32_t id_bytes);
+int msgpu_pack_wire(msgpu_ctx *ctx, void *d_wire_edges, void *d_wire_orders, void *d_ids, uint32_t id_bytes);
 int msgpu_merge_wire(msgpu_ctx *ctx, const void *d_gathered, uint32_t world, const uint64_t *counts, uint64_t slab_bytes,
-                     uint64_t off_edges, uint64_t off_orders, uint64_t off_ids, const uint32_t *id_base, void *d_edges,
-                     void *d_orders, void *d_ids, void *hip_stream);
+                     uint64_t off_edges, uint64_t off_orders, uint64_t off_ids, uint32_t id_bytes, const uint32_t *id_base,
+                     void *d_edges, void *d_orders, void *d_ids, void *hip_stream);
 
 /* ---- the ThreadPool replacement: the whole overlap path, host memory to host memory, as batches on two HIP streams ----
  * Replaces the phases of src/main.cpp:153-178 that the reference fans over its ThreadPool (one Job per PAF line, per

@@ -126,9 +126,10 @@ SYMBOLS = [
                                           C.c_void_p]),
     ("msgpu_wire_edges_bytes", C.c_uint64, [C.c_uint64]),
     ("msgpu_wire_orders_bytes", C.c_uint64, [C.c_uint64]),
-    ("msgpu_pack_wire", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("msgpu_wire_ids_bytes", C.c_uint64, [C.c_uint64, C.c_uint32]),
+    ("msgpu_pack_wire", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]),
     ("msgpu_merge_wire", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64,
-                                   C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+                                   C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("msgpu_find_contraction_edges", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint32,
                                                C.c_void_p]),
     ("msgpu_synchronize", C.c_int, [C.c_void_p]),

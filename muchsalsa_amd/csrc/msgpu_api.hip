@@ -1261,16 +1261,21 @@ int msgpu_merge_gathered_ex(msgpu_ctx *c, const void *d_gathered, uint32_t world
 
 uint64_t msgpu_wire_edges_bytes(uint64_t n_edges) { return wire_edges_bytes(n_edges); }
 uint64_t msgpu_wire_orders_bytes(uint64_t n_orders) { return wire_orders_bytes(n_orders); }
+uint64_t msgpu_wire_ids_bytes(uint64_t n_ids, uint32_t id_bytes) { return wire_ids_bytes(n_ids, id_bytes); }
 
-int msgpu_pack_wire(msgpu_ctx *c, void *d_wire_edges, void *d_wire_orders, void *d_ids) {
+int msgpu_pack_wire(msgpu_ctx *c, void *d_wire_edges, void *d_wire_orders, void *d_ids, uint32_t id_bytes) {
   if (!c) return MSGPU_E_ARG;
+  if (id_bytes != 3 && id_bytes != 4) return fail(c, MSGPU_E_ARG, "msgpu_pack_wire: id_bytes is 3 or 4");
+  if (id_bytes == 3 && c->A > (1u << 24))
+    return fail(c, MSGPU_E_ARG, "msgpu_pack_wire: anchor ids beyond 24 bits need id_bytes = 4");
   if (c->state < ST_CHAINED) return fail(c, MSGPU_E_STATE, "msgpu_pack_wire before msgpu_chaining_and_overlaps");
   if (!d_wire_edges || !d_wire_orders || !d_ids) return fail(c, MSGPU_E_ARG, "msgpu_pack_wire: a null block");
   if (c->n_ems > 0xffffffffull || c->n_orders > 0xffffffffull || c->n_ids > 0xffffffffull)
     return fail(c, MSGPU_E_ARG, "tables beyond the wire form's 32-bit offsets: exchange them whole "
                                 "(msgpu_copy_tables_device + msgpu_merge_gathered)");
-  if ((reinterpret_cast<uintptr_t>(d_wire_edges) & 3) || (reinterpret_cast<uintptr_t>(d_wire_orders) & 7))
-    return fail(c, MSGPU_E_ARG, "msgpu_pack_wire: the edge block needs 4-byte, the order block 8-byte alignment");
+  if ((reinterpret_cast<uintptr_t>(d_wire_edges) & 3) || (reinterpret_cast<uintptr_t>(d_wire_orders) & 7) ||
+      (reinterpret_cast<uintptr_t>(d_ids) & 3))
+    return fail(c, MSGPU_E_ARG, "msgpu_pack_wire: the edge and id blocks need 4-byte, the order block 8-byte alignment");
   HIPCHK(c, hipSetDevice(c->device));
   PackWireArgs a;
   a.edges    = static_cast<const msgpu_edge *>(c->edges.at());
@@ -1279,16 +1284,21 @@ int msgpu_pack_wire(msgpu_ctx *c, void *d_wire_edges, void *d_wire_orders, void 
   a.n_orders = c->n_orders;
   a.w_edges  = static_cast<uint8_t *>(d_wire_edges);
   a.w_orders = static_cast<uint8_t *>(d_wire_orders);
+  a.ids      = id_bytes == 3 ? static_cast<const uint32_t *>(c->ids.at()) : nullptr;
+  a.n_ids    = c->n_ids;
+  a.w_ids    = static_cast<uint32_t *>(d_ids);
   launch_pack_wire(c->stream, a);
   HIPCHK(c, hipGetLastError());
-  if (c->n_ids) HIPCHK(c, hipMemcpyAsync(d_ids, c->ids.at(), c->n_ids * 4, hipMemcpyDeviceToDevice, c->stream));
+  if (id_bytes == 4 && c->n_ids)
+    HIPCHK(c, hipMemcpyAsync(d_ids, c->ids.at(), c->n_ids * 4, hipMemcpyDeviceToDevice, c->stream));
   return MSGPU_OK;
 }
 
 int msgpu_merge_wire(msgpu_ctx *c, const void *d_gathered, uint32_t world, const uint64_t *counts, uint64_t slab_bytes,
-                     uint64_t off_edges, uint64_t off_orders, uint64_t off_ids, const uint32_t *id_base, void *d_edges,
-                     void *d_orders, void *d_ids, void *hip_stream) {
+                     uint64_t off_edges, uint64_t off_orders, uint64_t off_ids, uint32_t id_bytes, const uint32_t *id_base,
+                     void *d_edges, void *d_orders, void *d_ids, void *hip_stream) {
   if (!c) return MSGPU_E_ARG;
+  if (id_bytes != 3 && id_bytes != 4) return fail(c, MSGPU_E_ARG, "msgpu_merge_wire: id_bytes is 3 or 4");
   if (!d_gathered || !counts || world == 0 || world > MAX_WORLD) return fail(c, MSGPU_E_ARG, "bad merge arguments");
   if ((reinterpret_cast<uintptr_t>(d_gathered) & 7) || (slab_bytes & 7) || (off_edges & 3) || (off_orders & 7) || (off_ids & 3))
     return fail(c, MSGPU_E_ARG, "msgpu_merge_wire: slabs and order blocks need 8-byte, edge and id blocks 4-byte alignment");
@@ -1315,7 +1325,7 @@ int msgpu_merge_wire(msgpu_ctx *c, const void *d_gathered, uint32_t world, const
   a.edges  = static_cast<msgpu_edge *>(d_edges);
   a.orders = static_cast<msgpu_order *>(d_orders);
   a.ids    = static_cast<uint32_t *>(d_ids);
-  launch_merge_wire(hip_stream ? static_cast<hipStream_t>(hip_stream) : c->stream, a);
+  launch_merge_wire(hip_stream ? static_cast<hipStream_t>(hip_stream) : c->stream, a, id_bytes == 3);
   HIPCHK(c, hipGetLastError());
   return MSGPU_OK;
 }

@@ -98,13 +98,16 @@ struct MergeArgs {
 struct PackWireArgs {
   const msgpu_edge  *edges;
   const msgpu_order *orders;
-  uint64_t           n_edges, n_orders;
+  const uint32_t    *ids;      // non-null: the id block as 3-byte ids (four ids = three words), n_ids of them
+  uint64_t           n_edges, n_orders, n_ids;
   uint8_t           *w_edges, *w_orders;
+  uint32_t          *w_ids;
 };
 inline uint64_t wire_edges_bytes(uint64_t n) { return 17 * n + 8; }
 inline uint64_t wire_orders_bytes(uint64_t n) { return 33 * n + 4; }
+inline uint64_t wire_ids_bytes(uint64_t n, uint32_t id_bytes) { return id_bytes == 3 ? (3 * n + 3) / 4 * 4 : 4 * n; }
 void launch_pack_wire(hipStream_t st, const PackWireArgs &a);
-void launch_merge_wire(hipStream_t st, const MergeArgs &a);
+void launch_merge_wire(hipStream_t st, const MergeArgs &a, bool ids3);
 
 template <class T> void exclusive_scan(hipStream_t st, const uint32_t *in, uint64_t n, T *out, T *block_sums, T *d_total);
 // k <= 3 scans of the same length n in one pair of launches; block_sums holds k * (scan_blocks(n) + 1) words

@@ -3044,6 +3044,7 @@ __global__ __launch_bounds__(256) void k_merge_gathered(MergeArgs a) {
 // the exchange's wire form: what travels over xGMI is what the receiver cannot derive.  Per rank
 //   edges  part (17 n + 8 bytes): em_off[n + 1] u32 | order_off[n + 1] u32 | v1[n] | v2[n] | shadow[n] u8
 //   orders part (33 n + 4 bytes): left[n] f64 | right[n] f64 | score[n] u64 | ids_off[n + 1] u32 | edge_idx[n] u32 | flags[n] u8
+//   ids    part: 4 n bytes, or -- while every anchor id fits 24 bits -- 3 n bytes (four ids in three words)
 // The counts are differences of the CSR offsets (a rank's tables are dense: every record's slice starts where the one
 // before ends), start / end / base follow from the flags and the edge's vertices (k_chain's emission: base = v1).
 // ---------------------------------------------------------------------------------------------------------------------
@@ -3100,10 +3101,19 @@ __global__ __launch_bounds__(256) void k_pack_wire(PackWireArgs a) {
     const_cast<uint8_t *>(w.flags)[i]     = static_cast<uint8_t>(o.flags);
     if (i + 1 == a.n_orders) const_cast<uint32_t *>(w.ids_off)[i + 1] = static_cast<uint32_t>(o.ids_off + o.ids_cnt);
   }
+  if (a.ids && 4 * i < a.n_ids) { // 3-byte ids: four ids -> three words (the last group writes the words its ids reach into)
+    const uint64_t rem = a.n_ids - 4 * i;
+    const uint32_t i0 = a.ids[4 * i], i1 = rem > 1 ? a.ids[4 * i + 1] : 0, i2 = rem > 2 ? a.ids[4 * i + 2] : 0,
+                   i3 = rem > 3 ? a.ids[4 * i + 3] : 0;
+    uint32_t *w = a.w_ids + 3 * i;
+    w[0] = i0 | (i1 << 24);
+    if (rem > 1) w[1] = (i1 >> 8) | (i2 << 16);
+    if (rem > 2) w[2] = (i2 >> 16) | (i3 << 8);
+  }
 }
 
 // the merge of k_merge_gathered over slabs in wire form: the same dense rank-major tables, byte for byte
-__global__ __launch_bounds__(256) void k_merge_wire(MergeArgs a) {
+template <bool IDS3> __global__ __launch_bounds__(256) void k_merge_wire(MergeArgs a) {
   const uint64_t i = static_cast<uint64_t>(blockIdx.x) * 256 + threadIdx.x;
   const uint64_t nE = a.base[a.world].edges, nO = a.base[a.world].orders, nI = a.base[a.world].ids;
   if (i < nE) {
@@ -3151,7 +3161,16 @@ __global__ __launch_bounds__(256) void k_merge_wire(MergeArgs a) {
     while (i >= a.base[r + 1].ids) ++r;
     const uint64_t  k   = i - a.base[r].ids;
     const uint32_t *src = reinterpret_cast<const uint32_t *>(a.gathered + r * a.slab_bytes + a.off_ids);
-    a.ids[i]            = src[k] + a.base[r].anchor_id;
+    uint32_t        id;
+    if (IDS3) {
+      const uint32_t *w = src + 3 * (k >> 2);
+      const uint32_t  j = static_cast<uint32_t>(k & 3);
+      id = j == 0 ? (w[0] & 0xffffffu) : j == 1 ? ((w[0] >> 24) | ((w[1] & 0xffffu) << 8))
+           : j == 2 ? ((w[1] >> 16) | ((w[2] & 0xffu) << 16)) : (w[2] >> 8);
+    } else {
+      id = src[k];
+    }
+    a.ids[i] = id + a.base[r].anchor_id;
   }
 }
 
@@ -3305,14 +3324,19 @@ void launch_merge_gathered(hipStream_t st, const MergeArgs &a) {
   if (a.base[a.world].ids > n) n = a.base[a.world].ids;
   if (n) hipLaunchKernelGGL(k_merge_gathered, grid1(n, 256), dim3(256), 0, st, a);
 }
-void launch_merge_wire(hipStream_t st, const MergeArgs &a) {
+void launch_merge_wire(hipStream_t st, const MergeArgs &a, bool ids3) {
   uint64_t n = a.base[a.world].edges;
   if (a.base[a.world].orders > n) n = a.base[a.world].orders;
   if (a.base[a.world].ids > n) n = a.base[a.world].ids;
-  if (n) hipLaunchKernelGGL(k_merge_wire, grid1(n, 256), dim3(256), 0, st, a);
+  if (!n) return;
+  if (ids3)
+    hipLaunchKernelGGL(k_merge_wire<true>, grid1(n, 256), dim3(256), 0, st, a);
+  else
+    hipLaunchKernelGGL(k_merge_wire<false>, grid1(n, 256), dim3(256), 0, st, a);
 }
 void launch_pack_wire(hipStream_t st, const PackWireArgs &a) {
-  const uint64_t n = a.n_edges > a.n_orders ? a.n_edges : a.n_orders;
+  uint64_t n = a.n_edges > a.n_orders ? a.n_edges : a.n_orders;
+  if (a.ids && (a.n_ids + 3) / 4 > n) n = (a.n_ids + 3) / 4;
   if (n) hipLaunchKernelGGL(k_pack_wire, grid1(n, 256), dim3(256), 0, st, a);
 }
 void launch_compact(hipStream_t st, const CompactArgs &a) {

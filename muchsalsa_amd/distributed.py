@@ -24,11 +24,18 @@ def _round_up(n, a=ALIGN):
     return (n + a - 1) // a * a
 
 
+def wire_id_bytes(wire):
+    """wire: False / 0 = whole records; True / 4 = wire form with 4-byte ids; 3 = wire form with 3-byte ids -> 0, 4 or 3"""
+    return 0 if not wire else (3 if int(wire) == 3 else 4)
+
+
 def block_bytes(counts, wire=False):
-    """Bytes of a rank's (edge, order, id) blocks: whole records, or the wire form of include/msgpu.h (17 n + 8, 33 n + 4)."""
+    """Bytes of a rank's (edge, order, id) blocks: whole records, or the wire form of include/msgpu.h (17 n + 8, 33 n + 4,
+    4 n or -- wire = 3 -- 3 n rounded up to a word)."""
     ne, no, ni = (int(x) for x in counts)
-    if wire:
-        return 17 * ne + 8, 33 * no + 4, 4 * ni
+    ib = wire_id_bytes(wire)
+    if ib:
+        return 17 * ne + 8, 33 * no + 4, (4 * ni if ib == 4 else (3 * ni + 3) // 4 * 4)
     return ne * EDGE_DTYPE.itemsize, no * ORDER_DTYPE.itemsize, ni * 4
 
 
@@ -42,7 +49,7 @@ def slab_layout(max_counts, wire=False):
     return (off_e, off_o, off_i), max(size, ALIGN)
 
 
-def pack_wire_host(t):
+def pack_wire_host(t, id_bytes=4):
     """Host statement of msgpu_pack_wire: a rank's {edges, orders, ids} -> (edge block, order block, id block) as uint8
     arrays.  Asserts what the wire form relies on: dense tables, start / end / base given by flags and edge, zero padding."""
     e, o, ids = t["edges"], t["orders"], np.ascontiguousarray(t["ids"], dtype="<u4")
@@ -66,10 +73,15 @@ def pack_wire_host(t):
                          o["score"].astype("<u8").view(np.uint8), csr(o["ids_off"], o["ids_cnt"], len(ids)).view(np.uint8),
                          o["edge_idx"].astype("<u4").view(np.uint8), o["flags"].astype(np.uint8)])
     assert len(eb) == 17 * ne + 8 and len(ob) == 33 * no + 4
+    if wire_id_bytes(id_bytes) == 3:  # the low three bytes of every id, rounded up to a word with zeros
+        assert int(ids.max(initial=0)) < 1 << 24
+        ib = np.zeros((3 * len(ids) + 3) // 4 * 4, dtype=np.uint8)
+        ib[: 3 * len(ids)] = ids.view(np.uint8).reshape(-1, 4)[:, :3].reshape(-1)
+        return eb, ob, ib
     return eb, ob, ids.view(np.uint8)
 
 
-def unpack_wire_host(eb, ob, ib, counts):
+def unpack_wire_host(eb, ob, ib, counts, id_bytes=4):
     """Host statement of what msgpu_merge_wire reconstructs for ONE rank (no re-basing): blocks -> {edges, orders, ids}."""
     ne, no, ni = (int(x) for x in counts)
     eb, ob = np.ascontiguousarray(eb[: 17 * ne + 8]), np.ascontiguousarray(ob[: 33 * no + 4])
@@ -90,6 +102,10 @@ def unpack_wire_host(eb, ob, ib, counts):
     v1, v2 = e["v1"][o["edge_idx"]], e["v2"][o["edge_idx"]]
     sv1 = (o["flags"] & 1).astype(bool)
     o["start"], o["end"], o["base"] = np.where(sv1, v1, v2), np.where(sv1, v2, v1), v1
+    if wire_id_bytes(id_bytes) == 3:
+        ids = np.zeros((ni, 4), dtype=np.uint8)
+        ids[:, :3] = np.ascontiguousarray(ib[: 3 * ni]).reshape(ni, 3)
+        return {"edges": e, "orders": o, "ids": ids.reshape(-1).view("<u4").copy()}
     return {"edges": e, "orders": o, "ids": np.ascontiguousarray(ib[: 4 * ni]).view("<u4").copy()}
 
 
@@ -184,7 +200,7 @@ def split_gathered_host(gathered, all_counts, offs, slab_bytes, wire=False):
     for r, (ne, no, ni) in enumerate(np.asarray(all_counts, dtype=np.int64)):
         base = r * slab_bytes
         if wire:
-            out.append(unpack_wire_host(buf[base + offs[0]:], buf[base + offs[1]:], buf[base + offs[2]:], (ne, no, ni)))
+            out.append(unpack_wire_host(buf[base + offs[0]:], buf[base + offs[1]:], buf[base + offs[2]:], (ne, no, ni), wire))
             continue
         out.append({
             "edges": buf[base + offs[0]: base + offs[0] + ne * EDGE_DTYPE.itemsize].view(EDGE_DTYPE).copy(),
@@ -295,7 +311,13 @@ class PipelinedExchange:
         import torch
         self.device, self.group, self.slack, self.merge, self.wire = device, group, slack, merge, wire
         self.cuda = device.type == "cuda"
-        self.comm = torch.cuda.Stream(device=device) if self.cuda else None
+        # default priority: MSGPU_EXCHANGE_PRIORITY=1 puts this stream (the exchange's small copies and its merge) ahead of
+        # the next batch's kernels -- measured at world 1 that costs the step 0.045 ms (the merge then takes bandwidth from
+        # the compute instead of filling its gaps; profiles/r3_04/priority_ab.txt); RCCL's own stream is high-priority
+        # by default (bench.py, mode 2; 0 = neither)
+        import os
+        prio = -1 if os.environ.get("MSGPU_EXCHANGE_PRIORITY", "2") == "1" else 0
+        self.comm = torch.cuda.Stream(device=device, priority=prio) if self.cuda else None
         self.threaded = self.cuda if threaded is None else (threaded and self.cuda)
         self.cap = None
         self.calls = self.collectives = self.regrows = 0

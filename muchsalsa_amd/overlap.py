@@ -266,18 +266,20 @@ class OverlapContext:
                                                     base.ctypes.data if base is not None else None, C.c_void_p(d_edges),
                                                     C.c_void_p(d_orders), C.c_void_p(d_ids), C.c_void_p(stream or None)))
 
-    def pack_wire(self, d_wire_edges, d_wire_orders, d_ids):
+    def pack_wire(self, d_wire_edges, d_wire_orders, d_ids, id_bytes=4):
         """The context's edge / order / id tables in the exchange's wire form (include/msgpu.h) into three device blocks,
-        on the context's stream."""
-        self._check(self._L.msgpu_pack_wire(self._h, C.c_void_p(d_wire_edges), C.c_void_p(d_wire_orders), C.c_void_p(d_ids)))
+        on the context's stream; id_bytes = 3: anchor ids as 24-bit numbers."""
+        self._check(self._L.msgpu_pack_wire(self._h, C.c_void_p(d_wire_edges), C.c_void_p(d_wire_orders), C.c_void_p(d_ids),
+                                            int(id_bytes)))
 
-    def merge_wire(self, d_gathered, counts, slab_bytes, offs, d_edges, d_orders, d_ids, id_base=None, stream=None):
+    def merge_wire(self, d_gathered, counts, slab_bytes, offs, d_edges, d_orders, d_ids, id_base=None, stream=None, id_bytes=4):
         """merge_gathered over slabs whose blocks are in wire form (msgpu_merge_wire): the same merged tables."""
         cnt = np.ascontiguousarray(counts, dtype="<u8")
         base = None if id_base is None else np.ascontiguousarray(id_base, dtype="<u4")
         assert base is None or base.shape == (cnt.shape[0], 2)
         self._check(self._L.msgpu_merge_wire(self._h, C.c_void_p(d_gathered), cnt.shape[0], cnt.ctypes.data, slab_bytes,
-                                             offs[0], offs[1], offs[2], base.ctypes.data if base is not None else None,
+                                             offs[0], offs[1], offs[2], int(id_bytes),
+                                             base.ctypes.data if base is not None else None,
                                              C.c_void_p(d_edges), C.c_void_p(d_orders), C.c_void_p(d_ids),
                                              C.c_void_p(stream or None)))
 

@@ -30,7 +30,7 @@ def _three_times(D, t):
 
 def _filler(D, t, wire):
     """fill_slab of the exchange classes for host tables: whole records, or the wire form's three blocks"""
-    blocks = D.pack_wire_host(t) if wire else [t[name].view(np.uint8) for name in ("edges", "orders", "ids")]
+    blocks = D.pack_wire_host(t, wire) if wire else [t[name].view(np.uint8) for name in ("edges", "orders", "ids")]
 
     def fill(slab, offs):
         for b, off in zip(blocks, offs):
@@ -62,8 +62,9 @@ def _worker(rank, world, port, rows_bytes, out_dir, wire=False):
         counts = (len(mine["edges"]), len(mine["orders"]), len(mine["ids"]))
         gathered, all_counts, offs, slab_bytes = D.gather_slabs(counts, fill, torch.device("cpu"))
         per_rank = D.split_gathered_host(gathered.numpy(), all_counts, offs, slab_bytes)
-        for name, blk in zip(("edges", "orders", "ids"), D.unpack_wire_host(*D.pack_wire_host(mine), counts).items()):
-            assert blk[1].tobytes() == mine[name].tobytes(), name  # the wire form loses nothing of a shard's tables
+        for ib in (4, 3):  # the wire form loses nothing of a shard's tables, with 4-byte and with 3-byte ids
+            for name, blk in zip(("edges", "orders", "ids"), D.unpack_wire_host(*D.pack_wire_host(mine, ib), counts, ib).items()):
+                assert blk[1].tobytes() == mine[name].tobytes(), (name, ib)
         merged = D.canonicalize(D.merge_tables_host(per_rank))
         assert int(all_counts[:, 0].sum()) == len(full["edges"])
         # em_off is rank-local by contract; everything else must equal the single-process tables
@@ -141,7 +142,7 @@ def _pipelined_worker(rank, world, port, rows_bytes, out_dir, wire=False):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,wire", [(2, False), (3, False), (2, True), (3, True)])
+@pytest.mark.parametrize("world,wire", [(2, False), (3, False), (2, True), (3, 3)])
 def test_pipelined_exchange_one_batch_behind(tmp_path, world, wire):
     from muchsalsa_amd import synth
     rows = synth.synth_rows(300, 4000, 1100, 8)
@@ -150,7 +151,7 @@ def test_pipelined_exchange_one_batch_behind(tmp_path, world, wire):
     assert all(os.path.exists(tmp_path / ("pipe%d" % r)) for r in range(world))
 
 
-@pytest.mark.parametrize("world,wire", [(2, False), (3, False), (2, True), (3, True)])
+@pytest.mark.parametrize("world,wire", [(2, False), (3, False), (2, 3), (3, True)])
 def test_gather_and_merge_equals_single_process(tmp_path, world, wire):
     from muchsalsa_amd import synth
     rows = synth.synth_rows(400, 4000, 1500, 5)

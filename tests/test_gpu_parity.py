@@ -288,44 +288,54 @@ def test_wire_form_merge_equals_whole_record_merge(oracle, world):
                 t = ctx.tables()
                 assert_tables_equal(t, D.shard_view_host(full, r, world), "shard %d/%d" % (r, world))
                 cnt = (len(t["edges"]), len(t["orders"]), len(t["ids"]))
-                nb = D.block_bytes(cnt, wire=True)
-                assert nb[0] == ctx._L.msgpu_wire_edges_bytes(cnt[0]) and nb[1] == ctx._L.msgpu_wire_orders_bytes(cnt[1])
-                d = [torch.full((n + 8,), 0xAB, dtype=torch.uint8, device=dev) for n in nb]
-                ctx.pack_wire(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr())
-                ctx.synchronize()
-                got = [x.cpu().numpy() for x in d]
-            want = D.pack_wire_host(t)
-            for name, g, w_, n in zip(("edges", "orders", "ids"), got, want, nb):
-                assert g[:n].tobytes() == w_.tobytes(), (name, r)
-                assert (g[n:] == 0xAB).all(), (name, r)  # nothing written behind a block
-            back = D.unpack_wire_host(*want, cnt)
-            for k in ("edges", "orders", "ids"):
-                assert back[k].tobytes() == t[k].tobytes(), (k, r)
+                per_form = {}
+                for ib in (4, 3):  # 4-byte and 3-byte anchor ids
+                    nb = D.block_bytes(cnt, wire=ib)
+                    assert nb[0] == ctx._L.msgpu_wire_edges_bytes(cnt[0]) and nb[1] == ctx._L.msgpu_wire_orders_bytes(cnt[1])
+                    assert nb[2] == ctx._L.msgpu_wire_ids_bytes(cnt[2], ib)
+                    d = [torch.full((n + 8,), 0xAB, dtype=torch.uint8, device=dev) for n in nb]
+                    ctx.pack_wire(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), id_bytes=ib)
+                    ctx.synchronize()
+                    got = [x.cpu().numpy() for x in d]
+                    want = D.pack_wire_host(t, ib)
+                    for name, g, w_, n in zip(("edges", "orders", "ids"), got, want, nb):
+                        # (the last word of a 3-byte id block may end in padding the kernel writes as zeros, like the host)
+                        assert g[:n].tobytes() == w_.tobytes(), (name, r, ib)
+                        assert (g[n:] == 0xAB).all(), (name, r, ib)  # nothing written behind a block
+                    back = D.unpack_wire_host(*want, cnt, ib)
+                    for k in ("edges", "orders", "ids"):
+                        assert back[k].tobytes() == t[k].tobytes(), (k, r, ib)
+                    per_form[ib] = want
             shards.append(t)
-            blocks.append(want)
+            blocks.append(per_form)
         counts = np.array([[len(t["edges"]), len(t["orders"]), len(t["ids"])] for t in shards], dtype=np.int64)
         id_base = np.array([[r * 1000, r * 70000] for r in range(world)], dtype="<u4")
         tot = counts.sum(axis=0)
         results = []
         with overlap.OverlapContext(0) as ctx:
-            for wire in (False, True):
+            for wire in (False, 4, 3):
                 offs, slab_bytes = D.slab_layout(counts.max(axis=0), wire=wire)
                 gathered = np.full(world * slab_bytes, 0xCD, dtype=np.uint8)
                 for r, t in enumerate(shards):
-                    parts = blocks[r] if wire else [t[name].view(np.uint8) for name in ("edges", "orders", "ids")]
+                    parts = blocks[r][wire] if wire else [t[name].view(np.uint8) for name in ("edges", "orders", "ids")]
                     for b, off in zip(parts, offs):
                         gathered[r * slab_bytes + off: r * slab_bytes + off + len(b)] = b
                 d_g = torch.from_numpy(gathered).to(dev)
                 d_e = torch.zeros(max(int(tot[0]), 1) * EDGE_DTYPE.itemsize, dtype=torch.uint8, device=dev)
                 d_o = torch.zeros(max(int(tot[1]), 1) * ORDER_DTYPE.itemsize, dtype=torch.uint8, device=dev)
                 d_i = torch.zeros(max(int(tot[2]), 1) * 4, dtype=torch.uint8, device=dev)
-                (ctx.merge_wire if wire else ctx.merge_gathered)(d_g.data_ptr(), counts, slab_bytes, offs, d_e.data_ptr(),
-                                                                 d_o.data_ptr(), d_i.data_ptr(), id_base=id_base)
+                if wire:
+                    ctx.merge_wire(d_g.data_ptr(), counts, slab_bytes, offs, d_e.data_ptr(), d_o.data_ptr(), d_i.data_ptr(),
+                                   id_base=id_base, id_bytes=wire)
+                else:
+                    ctx.merge_gathered(d_g.data_ptr(), counts, slab_bytes, offs, d_e.data_ptr(), d_o.data_ptr(),
+                                       d_i.data_ptr(), id_base=id_base)
                 ctx.synchronize()
                 results.append([x.cpu().numpy().tobytes() for x in (d_e, d_o, d_i)])
         assert int(tot[0]) > 0 and int(tot[1]) > 0
-        for name, a, b in zip(("edges", "orders", "ids"), *results):
-            assert a == b, (name, world)
+        for form in (1, 2):
+            for name, a, b in zip(("edges", "orders", "ids"), results[0], results[form]):
+                assert a == b, (name, world, form)
 
 
 def test_api_state_and_id_checks():
@@ -446,7 +456,7 @@ def test_bench_distributed_path_smoke():
     # the default N > 1 line: weak scaling (the exchange one step behind the compute, on its own stream), with the strong
     # (one job sharded by v1 % N) and the rank-sharded host-to-host figures beside it
     assert line["scaling"] == "weak" and line["exchange"]["regrows"] == 0
-    assert line["exchange"]["format"].startswith("wire") and line["exchange"]["slab_bytes"] < line["exchange"]["whole_record_slab_bytes"]
+    assert line["exchange"]["format"].startswith("wire") and line["exchange"]["slab_bytes"] < 0.7 * line["exchange"]["whole_record_slab_bytes"]
     assert line["strong"]["merged_edge_list_consistent"] is True and line["strong"]["value"] > 0
     assert line["strong"]["edges"] == line["config"]["edges"]
     assert line["host_to_host_sharded"]["edges"] == line["config"]["edges"] and line["host_to_host_sharded"]["ms"] > 0

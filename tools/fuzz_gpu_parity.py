@@ -26,18 +26,19 @@ def wire_roundtrip(ctx, want, rng, what):
     from muchsalsa_amd._lib import EDGE_DTYPE, ORDER_DTYPE
     dev = torch.device("cuda", 0)
     cnt = (len(want["edges"]), len(want["orders"]), len(want["ids"]))
-    nb = D.block_bytes(cnt, wire=True)
+    ib = int(rng.choice([3, 4]))  # 3-byte or 4-byte anchor ids
+    nb = D.block_bytes(cnt, wire=ib)
     d = [torch.full((n + 8,), 0xAB, dtype=torch.uint8, device=dev) for n in nb]
-    ctx.pack_wire(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr())
+    ctx.pack_wire(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), id_bytes=ib)
     ctx.synchronize()
-    blocks = D.pack_wire_host(want)
+    blocks = D.pack_wire_host(want, ib)
     for g, w_, n in zip(d, blocks, nb):
         g = g.cpu().numpy()
         assert g[:n].tobytes() == w_.tobytes() and (g[n:] == 0xAB).all(), what + ": wire block"
     counts = np.array([cnt, cnt], dtype=np.int64)
     id_base = np.array([[0, 0], [int(rng.integers(1, 1 << 20)), int(rng.integers(1, 1 << 20))]], dtype="<u4")
     res = []
-    for wire in (False, True):
+    for wire in (False, ib):
         offs, slab_bytes = D.slab_layout(cnt, wire=wire)
         slab = np.full(slab_bytes, 0xCD, dtype=np.uint8)
         for b, off in zip(blocks if wire else [want[k].view(np.uint8) for k in ("edges", "orders", "ids")], offs):
@@ -45,8 +46,9 @@ def wire_roundtrip(ctx, want, rng, what):
         d_g = torch.from_numpy(np.concatenate([slab, slab])).to(dev)
         out = [torch.zeros(max(2 * n, 1) * sz, dtype=torch.uint8, device=dev)
                for n, sz in zip(cnt, (EDGE_DTYPE.itemsize, ORDER_DTYPE.itemsize, 4))]
+        kw = dict(id_bytes=ib) if wire else {}
         (ctx.merge_wire if wire else ctx.merge_gathered)(d_g.data_ptr(), counts, slab_bytes, offs, out[0].data_ptr(),
-                                                         out[1].data_ptr(), out[2].data_ptr(), id_base=id_base)
+                                                         out[1].data_ptr(), out[2].data_ptr(), id_base=id_base, **kw)
         ctx.synchronize()
         res.append([x.cpu().numpy().tobytes() for x in out])
     assert res[0] == res[1], what + ": wire merge"
