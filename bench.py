@@ -276,7 +276,7 @@ def sharded_host_to_host_leg(torch, dist, D, dev, ctx, rows, world, rank, n_batc
                 202 MB of configs[2] in well under the 3.7 ms one PCIe link needs for them);
       compute   msgpu_overlap_batched_ex on the rank's shard (edges with v1 % N == rank), windows on two streams, tables
                 resident; the shard's four tables travel to the rank's pinned host memory over its own link;
-      merge     edges | orders | ids through the one-collective SlabExchange + msgpu_merge_gathered: the merged edge list
+      merge     edges | orders | ids in wire form through the one-collective SlabExchange + msgpu_merge_wire: the merged edge list
                 in every HBM (what msgpu_find_contraction_edges takes); EdgeMatch tables stay rank-local.
     Wall = max over ranks; the result tables are distributed over the ranks' host memories."""
     from muchsalsa_amd import overlap
@@ -288,7 +288,8 @@ def sharded_host_to_host_leg(torch, dist, D, dev, ctx, rows, world, rank, n_batc
     pin[: (hi - lo) * rows.itemsize] = torch.from_numpy(rows[lo:hi].view(np.uint8).copy())
     d_slice = torch.empty(per * rows.itemsize, dtype=torch.uint8, device=dev)
     d_rows = torch.empty(world * per * rows.itemsize, dtype=torch.uint8, device=dev)
-    exchange = D.SlabExchange(dev)
+    id_bytes = 3 if int(rows["anchor_id"].max(initial=0)) < 1 << 24 else 4  # (every rank holds the job's rows: same decision)
+    exchange = D.SlabExchange(dev, wire=id_bytes)  # the wire form of include/msgpu.h
     stream = torch.cuda.Stream(device=dev)
     ctx.set_stream(stream.cuda_stream)
     if world > 1:
@@ -303,14 +304,14 @@ def sharded_host_to_host_leg(torch, dist, D, dev, ctx, rows, world, rank, n_batc
             c = ctx.counts()
 
             def fill(slab, offs):
-                ctx.copy_tables_device(d_edges=slab.data_ptr() + offs[0], d_orders=slab.data_ptr() + offs[1],
-                                       d_ids=slab.data_ptr() + offs[2])
+                ctx.pack_wire(slab.data_ptr() + offs[0], slab.data_ptr() + offs[1], slab.data_ptr() + offs[2], id_bytes=id_bytes)
             gathered, allc, offs, slab_bytes = exchange.gather((c.n_edges, c.n_orders, c.n_ids), fill)
             tot = allc.sum(axis=0)
             m_e = torch.empty(max(int(tot[0]), 1) * EDGE_DTYPE.itemsize, dtype=torch.uint8, device=dev)
             m_o = torch.empty(max(int(tot[1]), 1) * ORDER_DTYPE.itemsize, dtype=torch.uint8, device=dev)
             m_i = torch.empty(max(int(tot[2]), 1) * 4, dtype=torch.uint8, device=dev)
-            ctx.merge_gathered(gathered.data_ptr(), allc, slab_bytes, offs, m_e.data_ptr(), m_o.data_ptr(), m_i.data_ptr())
+            ctx.merge_wire(gathered.data_ptr(), allc, slab_bytes, offs, m_e.data_ptr(), m_o.data_ptr(), m_i.data_ptr(),
+                           id_bytes=id_bytes)
             stream.synchronize()
             keep.update(t=t, info=info, allc=allc, c=c)
 

@@ -364,7 +364,7 @@ struct msgpu_seqctx {
       if (e == hipSuccess) cap = want;
       return e;
     }
-  } scr_text, scr_recs, scr_map, scr_hdr;
+  } scr_text, scr_recs, scr_map, scr_hdr, scr_pairs, scr_dist; // (the last two: msgpu_edit_distance's pair table and result)
 };
 
 struct msgpu_gather_plan {
@@ -434,7 +434,7 @@ void msgpu_seq_destroy(msgpu_seqctx *c) {
     if (s.ring) msgpu::pinned_block_free(s.ring);
     s.drop_packed();
   }
-  for (msgpu_seqctx::Scratch *x : {&c->scr_text, &c->scr_recs, &c->scr_map, &c->scr_hdr})
+  for (msgpu_seqctx::Scratch *x : {&c->scr_text, &c->scr_recs, &c->scr_map, &c->scr_hdr, &c->scr_pairs, &c->scr_dist})
     if (x->p) (void)hipFree(x->p);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -1424,10 +1424,10 @@ int msgpu_edit_distance(msgpu_seqctx *c, const void *d_a, const void *d_b, const
   for (size_t i = 0; i < n; ++i)
     if (pairs[i].a_len >= (1u << 30) || pairs[i].b_len >= (1u << 30)) return MSGPU_E_ARG; // (positions are ints on the device)
   SHIP(c, hipSetDevice(c->device));
-  void *d_pairs = nullptr, *d_out = nullptr;
-  SHIP(c, hipMalloc(&d_pairs, n * sizeof(msgpu_align_pair)));
-  hipError_t e = hipMalloc(&d_out, n * sizeof(uint32_t));
-  if (e == hipSuccess) e = hipMemcpyAsync(d_pairs, pairs, n * sizeof(msgpu_align_pair), hipMemcpyHostToDevice, c->stream);
+  SHIP(c, c->scr_pairs.ensure(n * sizeof(msgpu_align_pair)));
+  SHIP(c, c->scr_dist.ensure(n * sizeof(uint32_t)));
+  void *d_pairs = c->scr_pairs.p, *d_out = c->scr_dist.p;
+  hipError_t e = hipMemcpyAsync(d_pairs, pairs, n * sizeof(msgpu_align_pair), hipMemcpyHostToDevice, c->stream);
   if (e == hipSuccess) {
     // MSGPU_ED_DP=1: the anti-diagonal banded DP instead of the furthest-reaching form (same numbers; A/B and cross-check)
     const char *ed_dp  = std::getenv("MSGPU_ED_DP");
@@ -1446,8 +1446,6 @@ int msgpu_edit_distance(msgpu_seqctx *c, const void *d_a, const void *d_b, const
   }
   if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, n * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-  (void)hipFree(d_pairs);
-  if (d_out) (void)hipFree(d_out);
   if (e != hipSuccess) return sfail(c, MSGPU_E_HIP, "msgpu_edit_distance", e);
   return MSGPU_OK;
 }
