@@ -145,10 +145,15 @@ struct DevBuf {
   // reallocation keeps those first `off` bytes.  off = 0 everywhere else.
   size_t off  = 0;
   size_t hint = 0; // expected final size of the allocation (bytes): a reallocation asks for at least this much
+  // While a batched job runs its first windows, every (re)allocation on this thread asks for the size the job's LARGEST
+  // window will need, not the current one's (msgpu_overlap_batched_ex sets this: windows grow, and a scratch table that
+  // grows with them is freed and allocated again -- a device-wide synchronisation -- in every window of a first call)
+  static inline thread_local double grow_by = 1.0;
   hipError_t ensure(size_t bytes) { // room for `bytes` behind `off`
     if (off + bytes <= cap) return hipSuccess;
     const size_t need = off + bytes;
     size_t       want = need + need / 8 + 256; // slack so slowly growing inputs do not reallocate each run
+    if (grow_by > 1.0) want = off + static_cast<size_t>(double(want - off) * grow_by);
     if (hint > want) want = hint;
     void      *np = nullptr;
     hipError_t e;
@@ -1356,7 +1361,16 @@ int ensure_host(msgpu_ctx *c, msgpu_ctx::HostBuf &h, size_t need, size_t valid, 
         pinned_block_free(np);
         HIPCHK(c, e);
       }
-      memcpy(np, h.p, valid);
+      // (on the host threads: one thread moves 100 MB in 10 ms, and the GPU waits for the result tables meanwhile)
+      const size_t piece = size_t(4) << 20, n_pieces = (valid + piece - 1) / piece;
+      char        *dst = static_cast<char *>(np);
+      const char  *src = static_cast<const char *>(h.p);
+      auto         move = [&](size_t k) { memcpy(dst + k * piece, src + k * piece, std::min(piece, valid - k * piece)); };
+      try {
+        msgpu::HostPool::get().run(n_pieces > 1 ? 16 : 1, n_pieces, move);
+      } catch (...) { // (no thread to be had: copying does not throw)
+        memcpy(np, h.p, valid);
+      }
     }
     pinned_block_free(h.p);
   }
@@ -1427,30 +1441,48 @@ int msgpu_overlap_batched_ex(msgpu_ctx *c, const msgpu_row *rows, size_t n_rows,
   };
   uint64_t tot_e = 0, tot_m = 0, tot_o = 0, tot_i = 0, tot_fast = 0;
   int      rc = MSGPU_OK;
+  const bool dbg = std::getenv("MSGPU_BATCH_DEBUG") != nullptr;
+  if (dbg) fprintf(stderr, "[batched] rows loaded + index at %.2f ms\n", ms_since(t_start));
+  struct GrowGuard { // (back to 1 however the loop is left)
+    ~GrowGuard() { DevBuf::grow_by = 1.0; }
+  } grow_guard;
   for (uint32_t k = 0; k < B && rc == MSGPU_OK; ++k) {
     const int set = static_cast<int>(k & 1);
     c->win_lo      = cut(k);
     c->win_hi      = cut(k + 1);
+    { // the largest window still to come, in reads, against this one (records per read are about even)
+      uint32_t most = 0;
+      for (uint32_t j = k + 1; j < B; ++j) most = std::max(most, cut(j + 1) - cut(j));
+      const uint32_t mine = c->win_hi - c->win_lo;
+      DevBuf::grow_by     = mine && most > mine ? std::min(6.0, double(most) / double(mine)) : 1.0;
+    }
     c->base_edges  = tot_e;
     c->base_ems    = tot_m;
     c->base_orders = tot_o;
     c->base_ids    = tot_i;
-    // the share of the job's records the windows up to and including this one hold (used to extrapolate sizes)
-    const double share = double(c->win_hi) >= double(V) ? 1.0 : 1.0 - (1.0 - double(c->win_hi) / V) * (1.0 - double(c->win_hi) / V);
-    auto         hint  = [&](uint64_t have, size_t rec) {
-      return static_cast<size_t>(double(have) / (share > 0.02 ? share : 0.02) * 1.15) * rec;
+    // the share of the job's records the windows up to and including this one hold, at least (used to extrapolate sizes).
+    // With read ids unrelated to genome position a read owns its pairs with every later read and the windows hold
+    // 1 - (1 - hi/V)^2 of the records; with ids that follow the genome (a PAF whose anchors come in assembly order) every
+    // read owns about half of its pairs and the share is hi/V.  Real inputs lie between (BASELINE configs[2]: 26 / 29 /
+    // 45 % in three windows cut for equal shares of the first kind), so sizes are extrapolated with the smaller share:
+    // too large a table costs address space, too small a one an allocation and a move in the middle of the job.
+    const double share = double(c->win_hi) >= double(V) ? 1.0 : double(c->win_hi) / V;
+    const double share_before = double(c->win_lo) / (V ? V : 1); // ... the windows before this one hold
+    auto         hint_of = [&](uint64_t have, size_t rec, double sh) {
+      return static_cast<size_t>(double(have) / (sh > 0.02 ? sh : 0.02) * 1.15) * rec;
     };
+    auto hint = [&](uint64_t have, size_t rec) { return hint_of(have, rec, share); };
     if (resident) {
       // the job's tables stay whole in HBM: this window writes behind the earlier ones
       c->edges.off  = tot_e * sizeof(msgpu_edge);
       c->ems.off    = tot_m * sizeof(msgpu_edgematch);
       c->orders.off = tot_o * sizeof(msgpu_order);
       c->ids.off    = tot_i * 4;
-      if (k) { // (what the windows so far produced, extrapolated to the job)
-        c->edges.hint  = hint(tot_e, sizeof(msgpu_edge));
-        c->ems.hint    = hint(tot_m, sizeof(msgpu_edgematch));
-        c->orders.hint = hint(tot_o, sizeof(msgpu_order));
-        c->ids.hint    = hint(tot_i, 4);
+      if (k) { // (what the windows so far produced, extrapolated to the job by THEIR share of it)
+        c->edges.hint  = hint_of(tot_e, sizeof(msgpu_edge), share_before);
+        c->ems.hint    = hint_of(tot_m, sizeof(msgpu_edgematch), share_before);
+        c->orders.hint = hint_of(tot_o, sizeof(msgpu_order), share_before);
+        c->ids.hint    = hint_of(tot_i, 4, share_before);
       }
     } else if (k >= 2) {
       // this set of output tables was last read by the copy of batch k - 2
@@ -1468,12 +1500,16 @@ int msgpu_overlap_batched_ex(msgpu_ctx *c, const msgpu_row *rows, size_t n_rows,
       if (e != hipSuccess && rc == MSGPU_OK) rc = fail(c, MSGPU_E_HIP, "%s failed: %s", what, hipGetErrorString(e));
     };
     guarded(hipEventRecord(c->ev_done[set], st), "hipEventRecord");
+    if (dbg) fprintf(stderr, "[batched] window %u: launched at %.2f ms (edges %llu, orders %llu, ids %llu)\n", k, ms_since(t_start),
+                     (unsigned long long)c->n_edges, (unsigned long long)c->n_orders, (unsigned long long)c->n_ids);
     // room in the pinned result tables; the expected job size is extrapolated from what the windows so far produced
     if (rc == MSGPU_OK) rc = ensure_host(c, c->h_edges, (tot_e + c->n_edges + 1) * sizeof(msgpu_edge), tot_e * sizeof(msgpu_edge), hint(tot_e + c->n_edges, sizeof(msgpu_edge)));
     if (rc == MSGPU_OK && copy_ems) rc = ensure_host(c, c->h_ems, (tot_m + c->n_ems + 1) * sizeof(msgpu_edgematch), tot_m * sizeof(msgpu_edgematch), hint(tot_m + c->n_ems, sizeof(msgpu_edgematch)));
     if (rc == MSGPU_OK) rc = ensure_host(c, c->h_orders, (tot_o + c->n_orders + 1) * sizeof(msgpu_order), tot_o * sizeof(msgpu_order), hint(tot_o + c->n_orders, sizeof(msgpu_order)));
     if (rc == MSGPU_OK) rc = ensure_host(c, c->h_ids, (tot_i + c->n_ids + 1) * 4, tot_i * 4, hint(tot_i + c->n_ids, 4));
     if (rc != MSGPU_OK) break;
+    if (dbg) fprintf(stderr, "[batched] window %u: host tables ready at %.2f ms (caps %zu %zu %zu)\n", k, ms_since(t_start),
+                     c->h_edges.cap, c->h_orders.cap, c->h_ids.cap);
     guarded(hipStreamWaitEvent(cs, c->ev_done[set], 0), "hipStreamWaitEvent");
     // (Device-to-host copies are shader blits on this stack -- __amd_rocclr_copyBuffer in a kernel trace, not SDMA -- and a
     // compute kernel that overlaps one completes only when that copy kernel does, so a window's chain of small dependent
@@ -1500,6 +1536,7 @@ int msgpu_overlap_batched_ex(msgpu_ctx *c, const msgpu_row *rows, size_t n_rows,
   out->compute_done_ms = ms_since(t_start);
   // WaitGroup::wait(): every batch's tables are in host memory
   hipError_t e1 = hipStreamSynchronize(cs), e2 = hipStreamSynchronize(st);
+  if (dbg) fprintf(stderr, "[batched] loop left at %.2f ms, streams idle at %.2f ms\n", out->compute_done_ms, ms_since(t_start));
   c->win_lo = 0;
   c->win_hi = 0xffffffffu;
   c->base_edges = c->base_ems = c->base_orders = c->base_ids = 0;
