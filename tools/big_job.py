@@ -14,6 +14,33 @@ import numpy as np  # noqa: E402
 from muchsalsa_amd import overlap, synth  # noqa: E402
 
 
+def wire_round_trip(ctx, host, n_anchors):
+    """the resident tables -> the exchange's wire form (msgpu_pack_wire) -> msgpu_merge_wire at world 1 must give the tables
+    back byte for byte: at these sizes the blocks and tables pass 2 GiB (the orders of the 32x job: 2.1 GB)"""
+    import torch
+    from muchsalsa_amd import distributed as D
+    from muchsalsa_amd._lib import EDGE_DTYPE, ORDER_DTYPE
+    dev = torch.device("cuda", 0)
+    cnt = (len(host["edges"]), len(host["orders"]), len(host["ids"]))
+    for ib in ((3, 4) if n_anchors <= 1 << 24 else (4,)):
+        offs, slab_bytes = D.slab_layout(cnt, wire=ib)
+        slab = torch.empty(slab_bytes, dtype=torch.uint8, device=dev)
+        t1 = time.perf_counter()
+        ctx.pack_wire(slab.data_ptr() + offs[0], slab.data_ptr() + offs[1], slab.data_ptr() + offs[2], id_bytes=ib)
+        out = [torch.empty(max(n, 1) * sz, dtype=torch.uint8, device=dev) for n, sz in zip(cnt, (EDGE_DTYPE.itemsize, ORDER_DTYPE.itemsize, 4))]
+        ctx.merge_wire(slab.data_ptr(), np.array([cnt], dtype=np.int64), slab_bytes, offs, out[0].data_ptr(), out[1].data_ptr(),
+                       out[2].data_ptr(), id_bytes=ib)
+        ctx.synchronize()
+        dt = time.perf_counter() - t1
+        for name, o, n, sz in zip(("edges", "orders", "ids"), out, cnt, (EDGE_DTYPE.itemsize, ORDER_DTYPE.itemsize, 4)):
+            want = torch.from_numpy(host[name].view(np.uint8).reshape(-1))
+            assert torch.equal(o[: n * sz].cpu(), want), (name, ib)
+        whole = sum(n * sz for n, sz in zip(cnt, (EDGE_DTYPE.itemsize, ORDER_DTYPE.itemsize, 4)))
+        print("wire form, %d-byte ids: slab %.3f GB against %.3f GB of whole records; pack + merge %.2f ms; the merge gives the "
+              "tables back byte for byte" % (ib, slab_bytes / 1e9, whole / 1e9, 1e3 * dt), flush=True)
+        del slab, out
+
+
 def main():
     factor = int(sys.argv[1]) if len(sys.argv) > 1 else 4
     check = int(sys.argv[2]) if len(sys.argv) > 2 else 1
@@ -49,6 +76,7 @@ def main():
         t1 = time.perf_counter()
         lean, info = ctx.overlap_batched(pinned.array, 0, copy=False, resident=True, edgematches=False)
         print("resident dispatcher, EdgeMatch table left in HBM, host to host: %.2f ms" % (1e3 * (time.perf_counter() - t1)), flush=True)
+        wire_round_trip(ctx, lean, len(an))
         if check:
             import ms_oracle_ctypes as oracle
             from helpers import assert_tables_equal
