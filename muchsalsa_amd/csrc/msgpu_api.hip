@@ -149,12 +149,16 @@ struct DevBuf {
   // window will need, not the current one's (msgpu_overlap_batched_ex sets this: windows grow, and a scratch table that
   // grows with them is freed and allocated again -- a device-wide synchronisation -- in every window of a first call)
   static inline thread_local double grow_by = 1.0;
+  double own_grow_by = 0.0; // the same for this buffer alone (a job-wide result table while the job's FIRST window fills it)
   hipError_t ensure(size_t bytes) { // room for `bytes` behind `off`
     if (off + bytes <= cap) return hipSuccess;
     const size_t need = off + bytes;
     size_t       want = need + need / 8 + 256; // slack so slowly growing inputs do not reallocate each run
-    if (grow_by > 1.0) want = off + static_cast<size_t>(double(want - off) * grow_by);
+    const double by = own_grow_by > grow_by ? own_grow_by : grow_by;
+    if (by > 1.0) want = off + static_cast<size_t>(double(want - off) * by);
     if (hint > want) want = hint;
+    static const bool dbg_alloc = std::getenv("MSGPU_ALLOC_DEBUG") != nullptr;
+    if (dbg_alloc) fprintf(stderr, "[alloc] %zu -> %zu bytes (need %zu, kept %zu, hint %zu, grow_by %.2f)\n", cap, want, need, off, hint, grow_by);
     void      *np = nullptr;
     hipError_t e;
     if (p && !off) { // nothing to keep: give the old block back first
@@ -1399,7 +1403,10 @@ int msgpu_overlap_batched_ex(msgpu_ctx *c, const msgpu_row *rows, size_t n_rows,
   };
   DevBuf *const tabs[4] = {&c->edges, &c->ems, &c->orders, &c->ids};
   auto reset_views = [&]() {
-    for (DevBuf *b : tabs) b->off = b->hint = 0;
+    for (DevBuf *b : tabs) {
+      b->off = b->hint = 0;
+      b->own_grow_by   = 0.0;
+    }
   };
   c->win_lo = 0;
   c->win_hi = 0xffffffffu;
@@ -1478,6 +1485,8 @@ int msgpu_overlap_batched_ex(msgpu_ctx *c, const msgpu_row *rows, size_t n_rows,
       c->ems.off    = tot_m * sizeof(msgpu_edgematch);
       c->orders.off = tot_o * sizeof(msgpu_order);
       c->ids.off    = tot_i * 4;
+      // the first window cannot be extrapolated from: its tables are asked to hold the job at this window's share of it
+      for (DevBuf *b : tabs) b->own_grow_by = k == 0 && share > 0 ? std::min(8.0, 1.15 / share) : 0.0;
       if (k) { // (what the windows so far produced, extrapolated to the job by THEIR share of it)
         c->edges.hint  = hint_of(tot_e, sizeof(msgpu_edge), share_before);
         c->ems.hint    = hint_of(tot_m, sizeof(msgpu_edgematch), share_before);
