@@ -155,9 +155,45 @@ int  msgpu_create(int device, const msgpu_params *params, msgpu_ctx **out);
 void msgpu_destroy(msgpu_ctx *ctx);
 const char *msgpu_last_error(const msgpu_ctx *ctx);
 
+/* ---- STREAM AND THREAD CONTRACT -- who orders what at this boundary ---------------------------------------------------
+ * (The reference states its notification contract where it has one: MatchMap observes the Graph's deletions,
+ * include/ms/matching/MatchMap.h:200-207.  This boundary's equivalent is stream order.)
+ *
+ * 1. A context queues all its work on ONE stream: its own (created hipStreamNonBlocking: it does NOT synchronise with the
+ *    legacy default stream, nor with any other stream, e.g. the one a tensor library fills buffers on) or the one given to
+ *    msgpu_set_stream.  Entry points that take a `hip_stream` argument queue on that stream instead (NULL = the context's).
+ * 2. HOST buffers (msgpu_load_rows, msgpu_copy_tables, msgpu_copy_reads, msgpu_find_contraction_edges' result,
+ *    msgpu_overlap_batched[_ex], msgpu_get_edgematches): the call returns when the bytes are there / have been consumed.
+ *    Nothing to order.
+ * 3. DEVICE buffers of the caller -- read: msgpu_load_rows_device (d_rows, until the next load or msgpu_destroy),
+ *    msgpu_overlap_batched_ex with MSGPU_BATCH_ROWS_ON_DEVICE, msgpu_merge_gathered[_ex] / msgpu_merge_wire (d_gathered),
+ *    msgpu_find_contraction_edges (d_edges, d_orders); written: msgpu_copy_tables_device, msgpu_pack_wire,
+ *    msgpu_merge_gathered[_ex] / msgpu_merge_wire (d_edges, d_orders, d_ids) -- are touched ASYNCHRONOUSLY, in the order of
+ *    the stream of rule 1 and in no order with anything else.  The CALLER must therefore
+ *      (a) have finished -- in stream order -- whatever it queued on those buffers before the call (a fill, a memset, the
+ *          all-gather that produced d_gathered): otherwise the library's kernel and the caller's run concurrently and the
+ *          buffer ends up a mixture of both;
+ *      (b) not read, overwrite or free them before the library's work has finished -- in stream order.
+ *    Three ways to meet (a) and (b), cheapest first:
+ *      - msgpu_set_stream(ctx, the stream the caller works on): everything is one stream's order;
+ *      - msgpu_stream_wait(ctx, s) before the call -- the context's stream waits for what is queued on s so far -- and
+ *        msgpu_stream_release(ctx, s) after it -- s waits for what the context has queued so far (two event operations,
+ *        no host wait);
+ *      - a host wait: the caller synchronises its stream before the call and calls msgpu_synchronize(ctx) after it.
+ * 4. msgpu_last_error is meaningful only after a call returned a non-zero code.
+ * 5. A context is NOT thread-safe: one host thread at a time.  One exception, what an exchange thread needs:
+ *    msgpu_merge_gathered_ex / msgpu_merge_wire with a hip_stream of the caller's may run on a second thread beside any
+ *    other call (they touch no state of the context except, on failure, the error text). */
+
 /* Run all work of this context on an existing HIP stream (hipStream_t), e.g. the caller's current stream.
- * NULL restores the context's own stream. */
+ * NULL restores the context's own stream.  Waits for the stream used so far. */
 int msgpu_set_stream(msgpu_ctx *ctx, void *hip_stream);
+/* The hipStream_t the context queues on at the moment (its own unless msgpu_set_stream changed it). */
+void *msgpu_get_stream(const msgpu_ctx *ctx);
+/* Rule 3: the context's stream waits for everything queued so far on `hip_stream` (NULL = the legacy default stream);
+ * `hip_stream` waits for everything the context has queued so far.  Neither blocks the host. */
+int msgpu_stream_wait(msgpu_ctx *ctx, void *hip_stream);
+int msgpu_stream_release(msgpu_ctx *ctx, void *hip_stream);
 
 /* Multi-GPU: this context owns the edges whose v1 satisfies v1 % n_shards == shard (default 0 of 1).
  * Every shard loads the full row table; edges/orders of different shards are disjoint and their union is the
@@ -215,7 +251,8 @@ int      msgpu_toggle_mul(int a, int b);
  * `rows` may be in any order and may contain (read, anchor) duplicates.  Read ids must follow first-line
  * order (what msgpu_parse_paf produces), else MSGPU_E_IDS.  Host buffer; copied to HBM. */
 int msgpu_load_rows(msgpu_ctx *ctx, const msgpu_row *rows, size_t n_rows);
-/* Same, rows already resident in HBM (device pointer, n_rows * 40 bytes).  The buffer is only read. */
+/* Same, rows already resident in HBM (device pointer, n_rows * 40 bytes).  The buffer is only read -- by this call and by
+ * every later stage until the next load (STREAM CONTRACT rule 3: the rows must be complete in the context's stream order). */
 int msgpu_load_rows_device(msgpu_ctx *ctx, const void *d_rows, size_t n_rows);
 
 /* ---- A2/A3: MatchMap::calculateEdges (MatchMap.cpp:161-224) ----------------------------------------------------- */
@@ -241,7 +278,8 @@ int msgpu_set_stage_events(msgpu_ctx *ctx, int on);
 
 /* Copy result tables to HOST buffers sized from msgpu_get_counts (any pointer may be NULL to skip). */
 int msgpu_copy_tables(msgpu_ctx *ctx, msgpu_edge *edges, msgpu_edgematch *ems, msgpu_order *orders, uint32_t *ids);
-/* Same into DEVICE buffers (device-to-device on the context's stream; used in front of the RCCL all-gather). */
+/* Same into DEVICE buffers (device-to-device on the context's stream; used in front of the RCCL all-gather).
+ * Asynchronous: STREAM CONTRACT rule 3 applies to the destination buffers. */
 int msgpu_copy_tables_device(msgpu_ctx *ctx, void *d_edges, void *d_ems, void *d_orders, void *d_ids);
 /* Per-read Vertex facts: Vertex::getNanoporeLength() and metaDatum(0) (first line), n_reads entries each (host). */
 int msgpu_copy_reads(msgpu_ctx *ctx, int32_t *read_len, uint32_t *read_first_line);
@@ -251,7 +289,8 @@ int msgpu_copy_reads(msgpu_ctx *ctx, int32_t *read_len, uint32_t *read_first_lin
  * holding that rank's edge / order / id tables at off_edges / off_orders / off_ids (padding after each is ignored).
  * counts = world x {n_edges, n_orders, n_ids} (host).  Output (device): dense rank-major tables with order_off,
  * edge_idx and ids_off re-based to the merged tables; em_off stays rank-local (EdgeMatch tables are not gathered).
- * The reference has no counterpart (single process); consumed like graph.getEdges() + Edge::getEdgeOrders(). */
+ * The reference has no counterpart (single process); consumed like graph.getEdges() + Edge::getEdgeOrders().
+ * Asynchronous: STREAM CONTRACT rule 3 applies to d_gathered (read) and to d_edges / d_orders / d_ids (written). */
 int msgpu_merge_gathered(msgpu_ctx *ctx, const void *d_gathered, uint32_t world, const uint64_t *counts,
                          uint64_t slab_bytes, uint64_t off_edges, uint64_t off_orders, uint64_t off_ids, void *d_edges,
                          void *d_orders, void *d_ids);
@@ -279,7 +318,10 @@ int msgpu_merge_gathered_ex(msgpu_ctx *ctx, const void *d_gathered, uint32_t wor
  * msgpu_pack_wire writes the context's tables (after msgpu_chaining_and_overlaps) in that form into three DEVICE blocks
  * (edge and id blocks 4-byte, order block 8-byte aligned) on the context's stream; MSGPU_E_ARG when a table has more than
  * 2^32 - 1 EdgeMatches, orders or ids (exchange such tables whole) or, with id_bytes = 3, an anchor id space beyond 2^24.  msgpu_merge_wire = msgpu_merge_gathered_ex over
- * slabs whose three blocks are in wire form: the merged tables are the same, byte for byte. */
+ * slabs whose three blocks are in wire form: the merged tables are the same, byte for byte.
+ * Both are asynchronous: STREAM CONTRACT rule 3 applies to the three blocks msgpu_pack_wire writes (a fill of those
+ * buffers queued on another stream races with the pack kernel) and to msgpu_merge_wire's input and output buffers.
+ * A table without records still sends its closing CSR entries (zeros): 8 bytes of the edge block, 4 of the order block. */
 uint64_t msgpu_wire_edges_bytes(uint64_t n_edges);
 uint64_t msgpu_wire_orders_bytes(uint64_t n_orders);
 uint64_t msgpu_wire_ids_bytes(uint64_t n_ids, uint32_t id_bytes);
@@ -344,17 +386,18 @@ int msgpu_get_edgematches(msgpu_ctx *ctx, const uint32_t *edge_idx, size_t n, co
 void *msgpu_pinned_alloc(size_t bytes);
 void  msgpu_pinned_free(void *p);
 
-/* Block the host until everything queued on the context's stream has finished. */
 /* findContractionEdges (src/main.cpp:183-190, 416-463) with sanityCheck (libms/src/kernel/sc.cpp:29-90) -- the step
  * that follows the chaining fan-out -- on an edge/order table resident in HBM.  contraction_order (host, n_edges
  * entries): for every edge the index in the order table of its first contained & primary EdgeOrder that is sane against
  * every non-shadow neighbour of the order's start vertex (what the reference inserts into `contractionEdges`), or -1.
  * d_edges = d_orders = NULL: the context's own tables (single GPU, after msgpu_chaining_and_overlaps); otherwise any
  * (v1, v2)-sorted edge table + its order table, e.g. the merged list of msgpu_merge_gathered; n_reads = max id + 1.
- * Uses msgpu_params.wiggle_room.  Synchronous. */
+ * Uses msgpu_params.wiggle_room.  Synchronous for the host; caller tables are read in the context's stream order
+ * (STREAM CONTRACT rule 3 (a): they must be complete there). */
 int msgpu_find_contraction_edges(msgpu_ctx *ctx, const void *d_edges, uint64_t n_edges, const void *d_orders,
                                  uint64_t n_orders, uint32_t n_reads, int64_t *contraction_order);
 
+/* Block the host until everything queued on the context's stream has finished. */
 int msgpu_synchronize(msgpu_ctx *ctx);
 
 /* ==== sequence store + slice / reverse-complement / stitch kernel: device half of the "consensus" stage (A9) ========

@@ -98,6 +98,9 @@ SYMBOLS = [
     ("msgpu_destroy", None, [C.c_void_p]),
     ("msgpu_last_error", C.c_char_p, [C.c_void_p]),
     ("msgpu_set_stream", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("msgpu_get_stream", C.c_void_p, [C.c_void_p]),
+    ("msgpu_stream_wait", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("msgpu_stream_release", C.c_int, [C.c_void_p, C.c_void_p]),
     ("msgpu_set_shard", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32]),
     ("msgpu_set_id_space", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32]),
     ("msgpu_parse_paf", C.c_int, [C.c_char_p, C.POINTER(Params), C.POINTER(C.c_void_p)]),

@@ -233,6 +233,7 @@ struct msgpu_ctx {
   uint64_t     lost_publications = 0; // read-backs whose publication never arrived (wait_scalars fell back to a copy)
   bool         readback_polled = false;
   hipEvent_t   ev_readback = nullptr; // the synchronising read-back path waits for the copy only
+  hipEvent_t   ev_order = nullptr;    // msgpu_stream_wait / msgpu_stream_release
   uint32_t     decl_V = 0, decl_A = 0; // msgpu_set_id_space: id counts declared by the caller (0 = find them)
 
   // loaded rows
@@ -349,11 +350,9 @@ int wait_scalars(msgpu_ctx *c) {
     }
     // The stream stopped making progress, or finished without the publication arriving in mapped memory.  Take the values
     // the slow way, surface a stream error if there is one, and leave a trace either way: a lost publication is counted
-    // (msgpu_counts.n_lost_publications) and named in msgpu_last_error even when the call goes on to succeed.
+    // (msgpu_counts.n_lost_publications).  The error text is NOT touched on a call that goes on to succeed (msgpu.h,
+    // STREAM AND THREAD CONTRACT rule 4: the text belongs to a non-zero return code).
     ++c->lost_publications;
-    snprintf(c->err, sizeof(c->err), "read-back %llu: the stream finished without publishing its sizes to mapped host memory; "
-             "values re-read by copy (%llu such read-backs on this context)", (unsigned long long)seq,
-             (unsigned long long)c->lost_publications);
     HIPCHK(c, hipMemcpyAsync(c->h_scalars, c->scalars.p, SC_COUNT * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return MSGPU_OK;
@@ -636,7 +635,8 @@ int msgpu_create(int device, const msgpu_params *params, msgpu_ctx **out) {
       hipEventCreateWithFlags(&c->ev_side2, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_side[0], hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_side[1], hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&c->ev_readback, hipEventDisableTiming) != hipSuccess) {
+      hipEventCreateWithFlags(&c->ev_readback, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_order, hipEventDisableTiming) != hipSuccess) {
     msgpu_destroy(c);
     return MSGPU_E_HIP;
   }
@@ -664,6 +664,7 @@ void msgpu_destroy(msgpu_ctx *c) {
   for (auto &ev : c->ev_side)
     if (ev) (void)hipEventDestroy(ev);
   if (c->ev_readback) (void)hipEventDestroy(c->ev_readback);
+  if (c->ev_order) (void)hipEventDestroy(c->ev_order);
   if (c->ev_side2) (void)hipEventDestroy(c->ev_side2);
   if (c->side_stream2) {
     (void)hipStreamSynchronize(c->side_stream2);
@@ -698,6 +699,28 @@ int msgpu_set_stream(msgpu_ctx *c, void *hip_stream) {
   if (!c) return MSGPU_E_ARG;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->own_stream;
+  return MSGPU_OK;
+}
+
+void *msgpu_get_stream(const msgpu_ctx *c) { return c ? static_cast<void *>(c->stream) : nullptr; }
+
+// STREAM CONTRACT rule 3 (include/msgpu.h): order the context's stream behind / in front of a stream of the caller's
+int msgpu_stream_wait(msgpu_ctx *c, void *hip_stream) {
+  if (!c) return MSGPU_E_ARG;
+  hipStream_t other = static_cast<hipStream_t>(hip_stream);
+  if (other == c->stream) return MSGPU_OK;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipEventRecord(c->ev_order, other));
+  HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_order, 0));
+  return MSGPU_OK;
+}
+int msgpu_stream_release(msgpu_ctx *c, void *hip_stream) {
+  if (!c) return MSGPU_E_ARG;
+  hipStream_t other = static_cast<hipStream_t>(hip_stream);
+  if (other == c->stream) return MSGPU_OK;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipEventRecord(c->ev_order, c->stream));
+  HIPCHK(c, hipStreamWaitEvent(other, c->ev_order, 0));
   return MSGPU_OK;
 }
 

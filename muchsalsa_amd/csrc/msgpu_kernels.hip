@@ -3101,6 +3101,14 @@ __global__ __launch_bounds__(256) void k_pack_wire(PackWireArgs a) {
     const_cast<uint8_t *>(w.flags)[i]     = static_cast<uint8_t>(o.flags);
     if (i + 1 == a.n_orders) const_cast<uint32_t *>(w.ids_off)[i + 1] = static_cast<uint32_t>(o.ids_off + o.ids_cnt);
   }
+  if (i == 0) { // an empty table still has its closing CSR entries on the wire (the host statement writes zeros there)
+    if (a.n_edges == 0) {
+      const WireEdges w(a.w_edges, 0);
+      const_cast<uint32_t *>(w.em_off)[0]    = 0;
+      const_cast<uint32_t *>(w.order_off)[0] = 0;
+    }
+    if (a.n_orders == 0) const_cast<uint32_t *>(WireOrders(a.w_orders, 0).ids_off)[0] = 0;
+  }
   if (a.ids && 4 * i < a.n_ids) { // 3-byte ids: four ids -> three words (the last group writes the words its ids reach into)
     const uint64_t rem = a.n_ids - 4 * i;
     const uint32_t i0 = a.ids[4 * i], i1 = rem > 1 ? a.ids[4 * i + 1] : 0, i2 = rem > 2 ? a.ids[4 * i + 2] : 0,
@@ -3337,7 +3345,8 @@ void launch_merge_wire(hipStream_t st, const MergeArgs &a, bool ids3) {
 void launch_pack_wire(hipStream_t st, const PackWireArgs &a) {
   uint64_t n = a.n_edges > a.n_orders ? a.n_edges : a.n_orders;
   if (a.ids && (a.n_ids + 3) / 4 > n) n = (a.n_ids + 3) / 4;
-  if (n) hipLaunchKernelGGL(k_pack_wire, grid1(n, 256), dim3(256), 0, st, a);
+  if (!n) n = 1; // empty tables: thread 0 writes the closing CSR entries
+  hipLaunchKernelGGL(k_pack_wire, grid1(n, 256), dim3(256), 0, st, a);
 }
 void launch_compact(hipStream_t st, const CompactArgs &a) {
   if (a.n_edges) hipLaunchKernelGGL(k_compact, grid1(a.n_edges, 64), dim3(256), 0, st, a); // 4 waves x 16 edges

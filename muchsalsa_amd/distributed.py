@@ -299,7 +299,11 @@ class PipelinedExchange:
         pe.drain()                                  # everything submitted is merged
 
     Capacity protocol = SlabExchange's (header in the slab, capacity remembered, identical decisions on every rank because
-    only gathered data enters them).  The capacity is the largest rank's tables + 1/32: every rank's slab is padded to it
+    only gathered data enters them -- and because a grown capacity is ADOPTED AT A FIXED POINT: the communication side keeps
+    its own capacity (`_comm_cap`, grown while it checks headers, in batch order) and publishes it into the finished slot;
+    submit() of batch k + 2 adopts what batch k published, after it has waited for batch k -- never what batch k + 1 may or
+    may not have published by then.  So batch k + 1 always goes out with the capacity batch k was sent with, with or without
+    the communication thread, on every rank).  The capacity is the largest rank's tables + 1/32: every rank's slab is padded to it
     and the padding travels, so slack is xGMI time in every step, while outgrowing it costs one repeated collective once.  A rank that outgrows the capacity sends its header alone and keeps its tables in a
     private stash; when the headers are read every rank enlarges the capacity, re-lays its own slab of THAT batch (still
     intact: a slot is reused two batches later; or the stash) and repeats the collective.  Collectives are issued in
@@ -318,8 +322,11 @@ class PipelinedExchange:
         import os
         prio = -1 if os.environ.get("MSGPU_EXCHANGE_PRIORITY", "2") == "1" else 0
         self.comm = torch.cuda.Stream(device=device, priority=prio) if self.cuda else None
-        self.threaded = self.cuda if threaded is None else (threaded and self.cuda)
-        self.cap = None
+        # the communication thread: default on a GPU; on CPU tensors (gloo) only on request -- the tests' rehearsal of the
+        # threaded capacity protocol, where there are no streams but the same two threads
+        self.threaded = self.cuda if threaded is None else bool(threaded)
+        self.cap = None        # the submitting side's capacity: written by submit() only
+        self._comm_cap = None  # the communication side's: written by _collect() only (the thread, when there is one)
         self.calls = self.collectives = self.regrows = 0
         self.slab_bytes = 0
         self.slots = [dict(pending=False) for _ in range(2)]
@@ -335,8 +342,8 @@ class PipelinedExchange:
             self._thread.start()
 
     # ---- layout --------------------------------------------------------------------------------------------------
-    def _layout(self):
-        offs, size = slab_layout(self.cap, self.wire)
+    def _layout(self, cap):
+        offs, size = slab_layout(cap, self.wire)
         return tuple(HEADER + o for o in offs), HEADER + size
 
     def _agree(self, counts):
@@ -347,14 +354,15 @@ class PipelinedExchange:
         allc = torch.empty(world * 3, dtype=torch.int64, device=self.device)
         dist.all_gather_into_tensor(allc, mine, group=self.group)
         self.collectives += 1
-        self.cap = tuple(int(n * self.slack) + 64 for n in allc.cpu().numpy().reshape(world, 3).max(axis=0))
+        self.cap = self._comm_cap = tuple(int(n * self.slack) + 64 for n in allc.cpu().numpy().reshape(world, 3).max(axis=0))
 
-    def _buffers(self, slot, world):
-        """the slot's slab / gathered / header tensors for the current capacity (persistent: no allocation per batch)"""
+    def _buffers(self, slot, world, cap):
+        """the slot's slab / gathered / header tensors for capacity `cap` (persistent: no allocation per batch).  Called by
+        the side that owns the slot at the moment: submit() until the slot is queued, the communication side afterwards."""
         import torch
-        if slot.get("layout_cap") == self.cap and slot.get("world") == world and "slab_bytes" in slot:
+        if slot.get("layout_cap") == cap and slot.get("world") == world and "slab_bytes" in slot:
             return slot["layout"]  # (the per-batch path: nothing to compute, nothing to allocate)
-        offs, slab_bytes = self._layout()
+        offs, slab_bytes = self._layout(cap)
         if slot.get("slab_bytes") != slab_bytes or slot.get("world") != world:
             slot["slab"] = torch.empty(slab_bytes, dtype=torch.uint8, device=self.device)
             slot["gathered"] = torch.empty(world * slab_bytes, dtype=torch.uint8, device=self.device)
@@ -362,8 +370,8 @@ class PipelinedExchange:
             slot["heads"] = torch.empty(world * 3, dtype=torch.int64, pin_memory=self.cuda)
             slot["hdr"] = torch.empty(3, dtype=torch.int64, pin_memory=self.cuda)  # (pinned: the header copy never blocks)
             slot["slab_bytes"], slot["world"] = slab_bytes, world
-        self.slab_bytes = slab_bytes
-        slot["layout_cap"], slot["layout"] = self.cap, (offs, slab_bytes)
+        self.slab_bytes = slab_bytes  # (informational: the last layout made)
+        slot["layout_cap"], slot["layout"] = cap, (offs, slab_bytes)
         return offs, slab_bytes
 
     def _gather(self, slot, world):
@@ -412,14 +420,18 @@ class PipelinedExchange:
         self.calls += 1
         if slot["pending"]:
             self._finish(slot)  # the batch two submissions ago (collect() after every submit() has done it already)
-        offs, slab_bytes = self._buffers(slot, world)
+        if slot.get("new_cap") is not None:  # the fixed point: what the batch two submissions ago published, nothing later
+            self.cap = tuple(max(a, b) for a, b in zip(self.cap, slot["new_cap"]))
+            slot["new_cap"] = None
+        cap = self.cap  # read once: layout, the slot's record and the fit test below see the same capacity
+        offs, slab_bytes = self._buffers(slot, world, cap)
         if self.cuda and slot.get("merged") is not None:
             torch.cuda.current_stream(self.device).wait_event(slot["merged"])  # the slab's last reader: two batches ago
         counts = tuple(int(c) for c in counts)
         # (the header is written behind the fill, on the communication stream, by whoever issues the all-gather: the thread
         # that drives the compute stream does nothing here but enqueue the fill and one event)
-        slot["counts"], slot["offs"], slot["stash"], slot["cap"] = counts, offs, None, self.cap
-        if all(c <= k for c, k in zip(counts, self.cap)):
+        slot["counts"], slot["offs"], slot["stash"], slot["cap"] = counts, offs, None, cap
+        if all(c <= k for c, k in zip(counts, cap)):
             fill_slab(slot["slab"], offs)
         else:  # outgrown: header only; the tables wait in a private block laid out for their own size
             s_offs, s_size = slab_layout(counts, self.wire)
@@ -440,7 +452,8 @@ class PipelinedExchange:
         """the communication thread: all-gather, header check (+ repeat) and merge of every submitted batch, in order"""
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(self.device)
+        if self.cuda:
+            torch.cuda.set_device(self.device)
         while True:
             slot = self._queue.get()
             if slot is None:
@@ -473,10 +486,14 @@ class PipelinedExchange:
         src, s_offs = slot["stash"] if slot["stash"] is not None else (slot["slab"], slot["offs"])
         counts = slot["counts"]
         slot.pop("slab_bytes", None)
-        offs, _ = self._buffers(slot, world)
+        offs, _ = self._buffers(slot, world, self._comm_cap)
         for nb, so, do in zip(block_bytes(counts, self.wire), s_offs, offs):  # (a block is packed for the rank's own counts)
             slot["slab"][do: do + nb].copy_(src[so: so + nb])
-        slot["offs"], slot["stash"], slot["cap"] = offs, None, self.cap
+        if self.cuda:
+            # `src` (the stash, or the slot's old slab) was allocated on the caller's compute stream and is dropped here while
+            # the copies above are still queued on the communication stream: tell the caching allocator about that reader
+            src.record_stream(torch.cuda.current_stream(self.device))
+        slot["offs"], slot["stash"], slot["cap"] = offs, None, self._comm_cap
 
     def _collect(self, slot):
         import torch
@@ -489,7 +506,8 @@ class PipelinedExchange:
             # against the capacity THIS batch was sent with: the batch after it may have gone out before the capacity grew
             if (heads <= np.asarray(slot["cap"], dtype=np.int64)[None, :]).all():
                 break
-            self.cap = tuple(max(c, int(n * self.slack) + 64) for c, n in zip(self.cap, heads.max(axis=0)))  # same on every rank
+            # same on every rank: a function of gathered headers, in batch order
+            self._comm_cap = tuple(max(c, int(n * self.slack) + 64) for c, n in zip(self._comm_cap, heads.max(axis=0)))
             self.regrows += 1
             if self.cuda:  # the re-laid slab is written on the communication stream, behind the failed all-gather
                 with torch.cuda.stream(self.comm):
@@ -508,6 +526,7 @@ class PipelinedExchange:
         else:
             self.merge(slot["gathered"], heads, slot["offs"], slot["slab_bytes"], k, None)
         self.results[k] = (heads, slot["offs"], slot["slab_bytes"])
+        slot["new_cap"] = self._comm_cap  # adopted by the submit() that takes this slot next
         slot["pending"] = False
         return heads
 

@@ -155,6 +155,20 @@ class OverlapContext:
         """run on an existing HIP stream (raw hipStream_t value); None / 0 = the context's own stream again"""
         self._check(self._L.msgpu_set_stream(self._h, C.c_void_p(hip_stream_ptr or None)))
 
+    def stream(self):
+        """the raw hipStream_t the context queues on (msgpu_get_stream)"""
+        return self._L.msgpu_get_stream(self._h) or 0
+
+    def stream_wait(self, hip_stream_ptr):
+        """msgpu_stream_wait: the context's stream waits for what is queued on `hip_stream_ptr` so far -- call it before a
+        library call that touches device buffers the other stream filled (include/msgpu.h, STREAM CONTRACT rule 3)"""
+        self._check(self._L.msgpu_stream_wait(self._h, C.c_void_p(hip_stream_ptr or None)))
+
+    def stream_release(self, hip_stream_ptr):
+        """msgpu_stream_release: `hip_stream_ptr` waits for what the context has queued so far -- call it after a library
+        call whose device output the other stream is going to read"""
+        self._check(self._L.msgpu_stream_release(self._h, C.c_void_p(hip_stream_ptr or None)))
+
     def set_shard(self, shard, n_shards):
         self._check(self._L.msgpu_set_shard(self._h, shard, n_shards))
 

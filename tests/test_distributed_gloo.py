@@ -119,7 +119,7 @@ def _pipelined_worker(rank, world, port, rows_bytes, out_dir, wire=False):
 
         def merge(gathered, allc, offs, slab_bytes, k, stream):
             assert stream is None
-            merged.append((D.split_gathered_host(gathered.numpy(), allc, offs, slab_bytes, wire=wire), allc.copy()))
+            merged.append((D.split_gathered_host(gathered.numpy(), allc, offs, slab_bytes, wire=wire), allc.copy(), slab_bytes))
 
         pe = D.PipelinedExchange(torch.device("cpu"), merge, wire=wire)
         for b in range(6):
@@ -129,7 +129,34 @@ def _pipelined_worker(rank, world, port, rows_bytes, out_dir, wire=False):
             assert (got is None) == (b == 0)  # the batch before, from the second submit on
         last = pe.drain()
         assert last is not None and len(merged) == 6
-        for b, (parts, allc) in enumerate(merged):  # merged in submission order, every rank's tables intact
+        # The same six batches with the COMMUNICATION THREAD (what a GPU run uses): a grown capacity is adopted at a fixed
+        # point -- submit() of batch k + 2 takes what batch k published -- so every batch goes out with the slab size it had
+        # without the thread, on every rank, however the two threads interleave (a capacity picked up early on one rank only
+        # would be an all-gather of unequal slabs).
+        plain, plain_sizes = merged, [m[2] for m in merged]
+        for attempt in range(3):
+            merged = []
+            pt = D.PipelinedExchange(torch.device("cpu"), merge, wire=wire, threaded=True)
+            try:
+                for b in range(6):
+                    t = held(b, rank)
+                    pt.submit((len(t["edges"]), len(t["orders"]), len(t["ids"])), _filler(D, t, wire))
+                    assert pt.collect() is None
+                    if attempt == 1 and b % 2:
+                        import time
+                        time.sleep(0.05)  # (another interleaving: the thread gets ahead of the submitter)
+                assert pt.drain() is not None and len(merged) == 6
+            finally:
+                pt.close()
+            assert [m[2] for m in merged] == plain_sizes, (attempt, [m[2] for m in merged], plain_sizes)
+            assert pt.calls == 6 and pt.regrows == 2 and pt.collectives == 1 + 6 + 2, (pt.calls, pt.regrows, pt.collectives)
+            for (parts, allc, _), (parts0, allc0, _) in zip(merged, plain):
+                assert np.array_equal(allc, allc0)
+                for r in range(world):
+                    for k in ("edges", "orders", "ids"):
+                        assert parts[r][k].tobytes() == parts0[r][k].tobytes()
+        merged = plain
+        for b, (parts, allc, _) in enumerate(merged):  # merged in submission order, every rank's tables intact
             for r in range(world):
                 want = held(b, r)
                 assert tuple(allc[r]) == (len(want["edges"]), len(want["orders"]), len(want["ids"])), (b, r)

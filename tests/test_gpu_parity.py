@@ -294,8 +294,13 @@ def test_wire_form_merge_equals_whole_record_merge(oracle, world):
                     assert nb[0] == ctx._L.msgpu_wire_edges_bytes(cnt[0]) and nb[1] == ctx._L.msgpu_wire_orders_bytes(cnt[1])
                     assert nb[2] == ctx._L.msgpu_wire_ids_bytes(cnt[2], ib)
                     d = [torch.full((n + 8,), 0xAB, dtype=torch.uint8, device=dev) for n in nb]
+                    # The fills run on torch's stream, the pack kernel on the context's own (non-blocking) stream: without
+                    # an order between them the two write the blocks concurrently (round 3's red run: the head of a block
+                    # still 0xAB, its tail packed).  include/msgpu.h, STREAM CONTRACT rule 3 -- here: the event way.
+                    ts = torch.cuda.current_stream().cuda_stream
+                    ctx.stream_wait(ts)
                     ctx.pack_wire(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), id_bytes=ib)
-                    ctx.synchronize()
+                    ctx.stream_release(ts)
                     got = [x.cpu().numpy() for x in d]
                     want = D.pack_wire_host(t, ib)
                     for name, g, w_, n in zip(("edges", "orders", "ids"), got, want, nb):
@@ -324,6 +329,7 @@ def test_wire_form_merge_equals_whole_record_merge(oracle, world):
                 d_e = torch.zeros(max(int(tot[0]), 1) * EDGE_DTYPE.itemsize, dtype=torch.uint8, device=dev)
                 d_o = torch.zeros(max(int(tot[1]), 1) * ORDER_DTYPE.itemsize, dtype=torch.uint8, device=dev)
                 d_i = torch.zeros(max(int(tot[2]), 1) * 4, dtype=torch.uint8, device=dev)
+                torch.cuda.synchronize()  # STREAM CONTRACT rule 3, the host-wait way: the zero fills are done before the merge is queued
                 if wire:
                     ctx.merge_wire(d_g.data_ptr(), counts, slab_bytes, offs, d_e.data_ptr(), d_o.data_ptr(), d_i.data_ptr(),
                                    id_base=id_base, id_bytes=wire)
@@ -336,6 +342,78 @@ def test_wire_form_merge_equals_whole_record_merge(oracle, world):
         for form in (1, 2):
             for name, a, b in zip(("edges", "orders", "ids"), results[0], results[form]):
                 assert a == b, (name, world, form)
+
+
+@pytest.mark.parametrize("way", ["set_stream", "events", "host_wait"])
+def test_stream_contract_caller_buffers(oracle, way):
+    """include/msgpu.h, STREAM CONTRACT rule 3: device buffers of the caller are touched in the order of the context's
+    stream only.  The caller fills its blocks on ITS stream (torch's), behind 256 MB of other work so that the fill is still
+    queued when the library call is made -- the situation in which round 3's wire-form test turned red -- and orders the
+    library against it in each of the three documented ways; afterwards it reads the blocks on its own stream again.  Also
+    the empty table: its closing CSR entries are on the wire (zeros), nothing else is written."""
+    import torch
+    from muchsalsa_amd import distributed as D, overlap, synth
+    from muchsalsa_amd._lib import EDGE_DTYPE, ORDER_DTYPE
+    dev = torch.device("cuda", 0)
+    rows = synth.synth_rows(1000, 5000, 4000, 13)
+    full = oracle.overlap(rows)
+    cnt = (len(full["edges"]), len(full["orders"]), len(full["ids"]))
+    want = D.pack_wire_host(full, 3)
+    nb = D.block_bytes(cnt, wire=3)
+    offs, slab_bytes = D.slab_layout(cnt, wire=3)
+    ballast = torch.empty(256 << 20, dtype=torch.uint8, device=dev)
+    ts = torch.cuda.current_stream().cuda_stream
+    with overlap.OverlapContext(0) as ctx:
+        ctx.load_rows(rows)
+        ctx.calculate_edges()
+        ctx.chaining_and_overlaps()
+        own = ctx.stream()
+        assert own and own != ts
+        if way == "set_stream":
+            ctx.set_stream(ts)
+            assert ctx.stream() == ts
+        for it in range(8):
+            slab = torch.empty(slab_bytes + 8, dtype=torch.uint8, device=dev)
+            out = [torch.empty(max(n, 1) * sz + 8, dtype=torch.uint8, device=dev)
+                   for n, sz in zip(cnt, (EDGE_DTYPE.itemsize, ORDER_DTYPE.itemsize, 4))]
+            for k in range(4):
+                ballast.fill_(k)          # work in front of the fills on the caller's stream
+            slab.fill_(0xAB)
+            for o in out:
+                o.fill_(0xCD)
+            if way == "events":
+                ctx.stream_wait(ts)
+            elif way == "host_wait":
+                torch.cuda.synchronize()
+            ctx.pack_wire(slab.data_ptr() + offs[0], slab.data_ptr() + offs[1], slab.data_ptr() + offs[2], id_bytes=3)
+            ctx.merge_wire(slab.data_ptr(), np.array([cnt], dtype=np.int64), slab_bytes, offs, out[0].data_ptr(),
+                           out[1].data_ptr(), out[2].data_ptr(), id_bytes=3)
+            if way == "events":
+                ctx.stream_release(ts)
+            elif way == "host_wait":
+                ctx.synchronize()
+            got = slab.cpu().numpy()      # on the caller's stream again
+            for name, off, w_, n in zip(("edges", "orders", "ids"), offs, want, nb):
+                assert got[off: off + n].tobytes() == w_.tobytes(), (way, it, name)
+            for name, o, n, sz in zip(("edges", "orders", "ids"), out, cnt, (EDGE_DTYPE.itemsize, ORDER_DTYPE.itemsize, 4)):
+                g = o.cpu().numpy()
+                assert g[: n * sz].tobytes() == full[name].tobytes(), (way, it, name)
+                assert (g[n * sz:] == 0xCD).all(), (way, it, name)
+        if way == "set_stream":
+            ctx.set_stream(None)
+            assert ctx.stream() == own
+        # an empty job: 8 + 4 bytes of closing CSR entries, as the host statement has them
+        ctx.load_rows(rows[:0])
+        ctx.calculate_edges()
+        ctx.chaining_and_overlaps()
+        empty = {k: full[k][:0] for k in ("edges", "orders", "ids")}
+        d = [torch.full((16,), 0xAB, dtype=torch.uint8, device=dev) for _ in range(3)]
+        torch.cuda.synchronize()
+        ctx.pack_wire(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), id_bytes=3)
+        ctx.synchronize()
+        for g, w_ in zip(d, D.pack_wire_host(empty, 3)):
+            g = g.cpu().numpy()
+            assert g[: len(w_)].tobytes() == w_.tobytes() and (g[len(w_):] == 0xAB).all()
 
 
 def test_api_state_and_id_checks():
@@ -515,6 +593,24 @@ def test_bench_starts_its_own_ranks():
     line = json.loads(lines[0])
     assert line["n_gpus"] == 1 and line["rccl_ranks"] == 1 and line["value"] > 0
     assert line["config"]["merged_edge_list_consistent"] is True
+
+
+def test_pipelined_exchange_threaded_regrow_world1():
+    """The exchange as a GPU run drives it (RCCL at world 1, communication thread + stream): a rank outgrows the slab
+    capacity in two consecutive batches; merged tables == own tables in every batch, and every batch goes out with the slab
+    size the unthreaded protocol gives (capacity adopted at a fixed point: tests/scripts/exchange_world1.py)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
+    for wire in ("3", "4"):
+        out = subprocess.run([sys.executable, os.path.join(here, "scripts", "exchange_world1.py"), wire], capture_output=True,
+                             text=True, timeout=600, env=env)
+        assert out.returncode == 0, out.stderr[-3000:]
+        line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+        assert line["ok"] and line["regrows"] == 2
 
 
 def test_find_contraction_edges_matches_oracle(oracle):

@@ -29,6 +29,7 @@ def wire_roundtrip(ctx, want, rng, what):
     ib = int(rng.choice([3, 4]))  # 3-byte or 4-byte anchor ids
     nb = D.block_bytes(cnt, wire=ib)
     d = [torch.full((n + 8,), 0xAB, dtype=torch.uint8, device=dev) for n in nb]
+    torch.cuda.synchronize()  # include/msgpu.h STREAM CONTRACT rule 3: torch's fills are done before the pack kernel is queued on the context's stream
     ctx.pack_wire(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), id_bytes=ib)
     ctx.synchronize()
     blocks = D.pack_wire_host(want, ib)
@@ -47,6 +48,7 @@ def wire_roundtrip(ctx, want, rng, what):
         out = [torch.zeros(max(2 * n, 1) * sz, dtype=torch.uint8, device=dev)
                for n, sz in zip(cnt, (EDGE_DTYPE.itemsize, ORDER_DTYPE.itemsize, 4))]
         kw = dict(id_bytes=ib) if wire else {}
+        torch.cuda.synchronize()  # (rule 3 again: the zero fills before the merge)
         (ctx.merge_wire if wire else ctx.merge_gathered)(d_g.data_ptr(), counts, slab_bytes, offs, out[0].data_ptr(),
                                                          out[1].data_ptr(), out[2].data_ptr(), id_base=id_base, **kw)
         ctx.synchronize()
