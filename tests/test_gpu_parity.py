@@ -344,7 +344,7 @@ def test_wire_form_merge_equals_whole_record_merge(oracle, world):
                 assert a == b, (name, world, form)
 
 
-@pytest.mark.parametrize("way", ["set_stream", "events", "host_wait"])
+@pytest.mark.parametrize("way", ["set_stream", "events", "events_default_stream", "host_wait"])
 def test_stream_contract_caller_buffers(oracle, way):
     """include/msgpu.h, STREAM CONTRACT rule 3: device buffers of the caller are touched in the order of the context's
     stream only.  The caller fills its blocks on ITS stream (torch's), behind 256 MB of other work so that the fill is still
@@ -362,13 +362,19 @@ def test_stream_contract_caller_buffers(oracle, way):
     nb = D.block_bytes(cnt, wire=3)
     offs, slab_bytes = D.slab_layout(cnt, wire=3)
     ballast = torch.empty(256 << 20, dtype=torch.uint8, device=dev)
-    ts = torch.cuda.current_stream().cuda_stream
-    with overlap.OverlapContext(0) as ctx:
+    # the caller's stream: a stream of its own, or (events_default_stream) the legacy default stream, which a non-blocking
+    # stream does not synchronise with either (its handle is NULL: msgpu_set_stream cannot name it, the event calls can)
+    caller = torch.cuda.Stream(device=dev) if way != "events_default_stream" else torch.cuda.default_stream(dev)
+    if way == "events_default_stream":
+        way = "events"
+    torch.cuda.synchronize()
+    with overlap.OverlapContext(0) as ctx, torch.cuda.stream(caller):
+        ts = torch.cuda.current_stream().cuda_stream
         ctx.load_rows(rows)
         ctx.calculate_edges()
         ctx.chaining_and_overlaps()
         own = ctx.stream()
-        assert own and own != ts
+        assert own and own != ts and (ts != 0) == (caller != torch.cuda.default_stream(dev))
         if way == "set_stream":
             ctx.set_stream(ts)
             assert ctx.stream() == ts
