@@ -128,7 +128,13 @@ typedef struct msgpu_counts {
   uint64_t n_edges_fastpath; /* edges whose pairs were all proven compatible without the O(n^2) sweep (this shard) */
   uint64_t n_lost_publications; /* size read-backs of this context whose publication into mapped host memory never arrived
                                    although the stream finished (the values were re-read by copy): 0 on a healthy system */
+  uint64_t index_path;   /* how the last msgpu_load_rows built its index: MSGPU_INDEX_* (same tables whichever way)    */
 } msgpu_counts;
+#define MSGPU_INDEX_BIN 0u      /* rows binned by coarse read-id bucket, no global atomic per row: rows grouped by anchor with
+                                   ascending lines and no duplicate (read, anchor) pair -- what msgpu_parse_paf produces      */
+#define MSGPU_INDEX_ATOMIC 1u   /* one counter atomic per row, fixed-size bucket per read (rounds 1-3; MSGPU_NO_BIN=1 forces it) */
+#define MSGPU_INDEX_TWO_PASS 2u /* count, scan, scatter: a read with more rows than a fixed bucket holds                      */
+#define MSGPU_INDEX_GENERIC 4u  /* OR-ed in: scaffolds built by the generic per-anchor pass (any row order, duplicates)        */
 
 /* Device time of the last run of each stage, milliseconds, measured with HIP events on the context's stream. */
 typedef struct msgpu_timings {

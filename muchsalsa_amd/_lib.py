@@ -81,7 +81,10 @@ class Counts(C.Structure):
     _fields_ = [("n_rows_in", C.c_uint64), ("n_rows_alive", C.c_uint64), ("n_reads", C.c_uint32),
                 ("n_anchors", C.c_uint32), ("n_edges", C.c_uint64), ("n_ems", C.c_uint64), ("n_orders", C.c_uint64),
                 ("n_ids", C.c_uint64), ("n_pairs_scanned", C.c_uint64), ("n_edges_fastpath", C.c_uint64),
-                ("n_lost_publications", C.c_uint64)]
+                ("n_lost_publications", C.c_uint64), ("index_path", C.c_uint64)]
+
+
+INDEX_BIN, INDEX_ATOMIC, INDEX_TWO_PASS, INDEX_GENERIC = 0, 1, 2, 4
 
 
 class Timings(C.Structure):

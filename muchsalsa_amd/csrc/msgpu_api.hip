@@ -248,7 +248,7 @@ struct msgpu_ctx {
   // arena
   DevBuf rows_in, cnt_read, read_off, cursor, bkt_key, bkt_dead, by_read, read_cnt, alive_rank,
       anchor_cnt, anchor_off, anchor_first, anchor_off_gen, bkt2_idx, bkt2_line, by_anchor, read_len, read_first, scalars,
-      scan_tmp, vis16, spos2, visits;
+      scan_tmp, vis16, spos2, visits, bin_cursor, bin_start;
   DevBuf bound, cand_off, cand_j, cand_t, scr_v2, scr_start, n_cand, n_edge, n_visit_arr, lists, em_base, edge_base,
       visit_base, edges, edge_cand;
   DevBuf big_key, big_t, big_r2s, big_pfx, pair_tab, edge_fast, big_off;
@@ -282,6 +282,9 @@ struct msgpu_ctx {
   uint32_t   ck_head = 0, ck_count = 0; // next slot; pairs recorded since the last msgpu_get_timings
   bool       have_index_t = false, have_cand_t = false, have_chain_t = false, index_fast = false;
   bool   have_stage_t = false;
+  uint32_t index_path = 0;  // MSGPU_INDEX_* of the last index build
+  bool     index_binned = false; // the last build_index_once ran the bin path's kernels
+  bool     use_bin = true;  // try the bin path first (MSGPU_NO_BIN=1: never)
 };
 
 namespace {
@@ -375,11 +378,11 @@ void release_all(msgpu_ctx *c) {
                    &c->big_key, &c->big_t, &c->big_r2s, &c->big_pfx, &c->pair_tab, &c->edge_fast, &c->big_off, &c->ems, &c->order_scr, &c->ids_scr,
                    &c->edge_norders, &c->edge_nids, &c->order_base, &c->ids_base, &c->orders, &c->ids, &c->big_list, &c->cls_list, &c->cls_part, &c->cls_partials,
                    &c->big_elems, &c->big_paths, &c->alt_edges, &c->alt_ems, &c->alt_orders, &c->alt_ids, &c->vis16, &c->visits,
-                   &c->spos2};
+                   &c->spos2, &c->bin_cursor, &c->bin_start};
   for (DevBuf *b : all) b->release();
 }
 
-int build_index_once(msgpu_ctx *c, bool force_generic, bool two_pass, uint32_t *ix_flags_out) {
+int build_index_once(msgpu_ctx *c, bool force_generic, bool two_pass, bool bin, uint32_t *ix_flags_out) {
   hipStream_t st = c->stream;
   const uint64_t n = c->n_rows;
   ENSURE(c, scalars, SC_COUNT * sizeof(uint64_t));
@@ -403,11 +406,23 @@ int build_index_once(msgpu_ctx *c, bool force_generic, bool two_pass, uint32_t *
   // same pass that counts them (no offsets needed yet).  Used while that fits (reads x 128 x 32 B <= 4 GiB); a read
   // with more rows raises IXF_OVERFLOW and build_index() comes back here with two_pass = true.
   constexpr uint32_t BUCKET_CAP = 128;
-  const uint32_t     cap = (!two_pass && V && size_t(V) * BUCKET_CAP * sizeof(IRow) <= (size_t(4) << 30)) ? BUCKET_CAP : 0;
+  // The bin path (msgpu_index.hip): no global atomic per row.  Rows go to coarse buckets of 16 / 32 / 64 consecutive read ids
+  // (k_index_bin), a workgroup per bucket groups and ranks them (k_index_sort_bin).  Covers what msgpu_parse_paf hands
+  // over; anything else raises a flag and build_index() comes back with bin = false.
+  const uint32_t reads_per_pass = BIN_NB_MAX << BIN_RPB_SHIFT;
+  const uint32_t bpasses = (bin && !force_generic && !two_pass && n && V) ? static_cast<uint32_t>((size_t(V) + reads_per_pass - 1) / reads_per_pass) : 0;
+  const uint32_t bcap    = (bpasses && bpasses <= BIN_PASSES_MAX) ? bin_capacity(n, V) : 0;
+  const uint32_t bshift  = bcap ? BIN_RPB_SHIFT : 0; // != 0: this build takes the bin path
+  const uint32_t nb      = bshift ? static_cast<uint32_t>((size_t(std::min(V, reads_per_pass)) + (1u << bshift) - 1) >> bshift) : 0; // buckets of a (full) pass
+  const uint32_t     cap = (!bshift && !two_pass && V && size_t(V) * BUCKET_CAP * sizeof(IRow) <= (size_t(4) << 30)) ? BUCKET_CAP : 0;
   ENSURE(c, cnt_read, (size_t(V) + 1) * 4);
   ENSURE(c, read_off, (size_t(V) + 2) * 4);
   ENSURE(c, cursor, mva * 4);
-  ENSURE(c, bkt_key, (cap ? size_t(V) * cap : nz) * sizeof(IRow));
+  if (bshift) {
+    ENSURE(c, bin_cursor, (size_t(bpasses) * (nb + 1) + 1) * 4); // per pass: the bucket cursors; last word: by_read rows of the passes so far
+    ENSURE(c, bin_start, (size_t(nb) + 2) * 4);
+  }
+  ENSURE(c, bkt_key, (bshift ? size_t(nb) * bcap * 2 : cap ? size_t(V) * cap : nz) * sizeof(IRow)); // (bin path: 64-byte records)
   ENSURE(c, bkt_dead, nz);
   ENSURE(c, by_read, nz * sizeof(IRow));
   ENSURE(c, read_cnt, (size_t(V) + 1) * 4);
@@ -420,7 +435,7 @@ int build_index_once(msgpu_ctx *c, bool force_generic, bool two_pass, uint32_t *
   ENSURE(c, bkt2_line, nz * 4);
   ENSURE(c, by_anchor, nz * sizeof(IRow));
   ENSURE(c, vis16, nz * 16);
-  ENSURE(c, spos2, (cap ? size_t(V) * cap : nz) * 8); // one-pass build: by bucket slot, else by source row
+  ENSURE(c, spos2, (bshift ? 1 : cap ? size_t(V) * cap : nz) * 8); // one-pass build: by bucket slot, else by source row (bin path: inside the record)
   ENSURE(c, visits, (size_t(V) + 1) * 4);
   ENSURE(c, read_len, (size_t(V) + 1) * 4);
   ENSURE(c, read_first, (size_t(V) + 1) * 4);
@@ -432,9 +447,10 @@ int build_index_once(msgpu_ctx *c, bool force_generic, bool two_pass, uint32_t *
   }
 
   {
-    uint32_t *const zero[4]   = {c->cnt_read.as<uint32_t>(), c->cursor.as<uint32_t>(), c->read_cnt.as<uint32_t>(),
-                                 c->anchor_cnt.as<uint32_t>()};
-    const uint32_t  n_zero[4] = {V + 1, static_cast<uint32_t>(mva), V + 1, A + 1};
+    // (the bin path counts per bucket, not per read: its cursors take the per-read counters' place in the zero list)
+    uint32_t *const zero[4]   = {bshift ? c->bin_cursor.as<uint32_t>() : c->cnt_read.as<uint32_t>(), c->cursor.as<uint32_t>(),
+                                 c->read_cnt.as<uint32_t>(), c->anchor_cnt.as<uint32_t>()};
+    const uint32_t  n_zero[4] = {bshift ? bpasses * (nb + 1) + 1 : V + 1, static_cast<uint32_t>(mva), V + 1, A + 1};
     uint32_t *const ones[2]   = {c->anchor_first.as<uint32_t>(), nullptr};
     const uint32_t  n_ones[2] = {A + 2, 0};
     launch_index_init(st, zero, n_zero, ones, n_ones);
@@ -445,6 +461,22 @@ int build_index_once(msgpu_ctx *c, bool force_generic, bool two_pass, uint32_t *
     HIPCHK(c, hipMemcpyAsync(d_flags, &f, 4, hipMemcpyHostToDevice, st));
   }
 
+  if (bshift) {
+    uint32_t *row_base = c->bin_cursor.as<uint32_t>() + size_t(bpasses) * (nb + 1);
+    for (uint32_t p = 0; p < bpasses; ++p) { // one pass per 131,072 reads (BASELINE.json configs[2]: one)
+      const uint32_t rd_lo = p * reads_per_pass;
+      const uint32_t nb_p  = static_cast<uint32_t>((size_t(std::min(V - rd_lo, reads_per_pass)) + (1u << bshift) - 1) >> bshift);
+      uint32_t      *cur   = c->bin_cursor.as<uint32_t>() + size_t(p) * (nb + 1);
+      launch_index_bin(st, c->d_rows, n, V, A, d_flags, scalar<uint32_t>(c, SC_ERR), c->anchor_first.as<uint32_t>(), cur,
+                       c->bkt_key.as<uint4>(), rd_lo, nb_p, bcap, c->bin_start.as<uint32_t>(), row_base,
+                       p + 1 == bpasses ? c->read_off.as<uint32_t>() + V : nullptr);
+      if (p == 0) launch_check_anchor_first(st, c->anchor_first.as<uint32_t>(), A, n, d_flags);
+      launch_index_sort_bin(st, cur, c->bin_start.as<uint32_t>(), V, rd_lo, nb_p, bcap, c->bkt_key.as<uint4>(),
+                            c->by_read.as<IRow>(), c->by_anchor.as<IRow>(), c->vis16.as<uint4>(), c->read_off.as<uint32_t>(),
+                            c->read_cnt.as<uint32_t>(), c->read_len.as<int32_t>(), c->read_first.as<uint32_t>(),
+                            c->visits.as<uint32_t>(), c->d_rows, d_flags, scalar<uint32_t>(c, SC_ERR));
+    }
+  } else {
   launch_index_pass1(st, c->d_rows, n, c->cnt_read.as<uint32_t>(), c->anchor_first.as<uint32_t>(), V, A, d_flags,
                      scalar<uint32_t>(c, SC_ERR), c->bkt_key.as<IRow>(), cap, c->spos2.as<uint2>());
   exclusive_scan<uint32_t>(st, c->cnt_read.as<uint32_t>(), V, c->read_off.as<uint32_t>(), c->scan_tmp.as<uint32_t>(),
@@ -456,6 +488,7 @@ int build_index_once(msgpu_ctx *c, bool force_generic, bool two_pass, uint32_t *
                    c->by_anchor.as<IRow>(), cap, c->d_rows, c->read_len.as<int32_t>(), c->read_first.as<uint32_t>(),
                    scalar<uint32_t>(c, SC_ERR), c->spos2.as<uint2>(), c->vis16.as<uint4>(), c->visits.as<uint32_t>()); // fast mode: the sort writes the scaffold rows too (at
                                                                               // the places pass 1 left in spos2); always: the Vertex facts
+  }
   launch_check_read_order(st, c->read_first.as<uint32_t>(), V, scalar<uint32_t>(c, SC_ERR));
   // Fast mode (input grouped by anchor, ascending lines: what the PAF loader hands over) is finished here but for the
   // scaffold offsets, which are the speculative ones of pass 1; the flags come back with the read-back below and
@@ -506,6 +539,12 @@ int build_index_once(msgpu_ctx *c, bool force_generic, bool two_pass, uint32_t *
   uint32_t       n_alive = *host_scalar<uint32_t>(c, SC_NALIVE);
   if (err & 2u)
     return fail(c, MSGPU_E_IDS, "a row has an id outside the declared id space (%u reads, %u anchors)", V, A);
+  c->index_binned = bshift != 0;
+  if (bshift && ixf != 0) { // the bin path covers the loader's form only: nothing of this build is kept, the atomic path decides
+    c->prologue_ok = c->cand_zeroed = false;
+    *ix_flags_out  = ixf | IXF_BINFAIL;
+    return MSGPU_OK;
+  }
   if (ixf & IXF_OVERFLOW) { // a read did not fit its bucket: nothing of this build is kept
     *ix_flags_out = ixf;
     return MSGPU_OK;
@@ -538,19 +577,26 @@ int build_index(msgpu_ctx *c) {
   if (c->stage_events) HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
   uint32_t ixf = 0;
   bool     two_pass = false;
-  int      rc  = build_index_once(c, false, two_pass, &ixf);
+  int      rc  = build_index_once(c, false, two_pass, c->use_bin, &ixf);
   if (rc != MSGPU_OK) return rc;
+  const bool binned = c->use_bin && !(ixf & IXF_BINFAIL) && c->index_binned;
+  if (ixf & IXF_BINFAIL) { // not the loader's form (or beyond the bin path's capacities): the atomic path covers every input
+    ixf = 0;
+    rc  = build_index_once(c, false, two_pass, false, &ixf);
+    if (rc != MSGPU_OK) return rc;
+  }
   if (ixf & IXF_OVERFLOW) { // a read with more rows than a one-pass bucket holds: count, scan, scatter instead
     two_pass = true;
-    rc       = build_index_once(c, false, two_pass, &ixf);
+    rc       = build_index_once(c, false, two_pass, false, &ixf);
     if (rc != MSGPU_OK) return rc;
   }
   // the fast by_anchor path assumed no duplicate (read, anchor) pair; if one turned up, rebuild generically
   if ((ixf & IXF_DUPS) && (ixf & ~IXF_DUPS) == 0) {
-    rc = build_index_once(c, true, two_pass, &ixf);
+    rc = build_index_once(c, true, two_pass, false, &ixf);
     if (rc != MSGPU_OK) return rc;
   }
   c->index_fast   = (ixf & ~IXF_DUPS) == 0;
+  c->index_path   = (binned ? MSGPU_INDEX_BIN : two_pass ? MSGPU_INDEX_TWO_PASS : MSGPU_INDEX_ATOMIC) | (c->index_fast ? 0u : MSGPU_INDEX_GENERIC);
   c->have_index_t = c->stage_events;
   c->state        = ST_LOADED;
   return MSGPU_OK;
@@ -620,6 +666,8 @@ int msgpu_create(int device, const msgpu_params *params, msgpu_ctx **out) {
     c->fast_path   = !(nf && nf[0] == '1');
     const char *ns = getenv("MSGPU_NO_SUBWAVE"); // test hook: one edge per wavefront whatever its size
     c->sub_wave    = !(ns && ns[0] == '1');
+    const char *nbin = getenv("MSGPU_NO_BIN"); // A/B switch: the index build's atomic path (rounds 1-3) for every input
+    c->use_bin       = !(nbin && nbin[0] == '1');
   }
   for (auto &ev : c->ev)
     if (hipEventCreate(&ev) != hipSuccess) {
@@ -1137,6 +1185,7 @@ int msgpu_get_counts(msgpu_ctx *c, msgpu_counts *out) {
   out->n_pairs_scanned = c->state >= ST_EDGES ? c->n_visit : 0;
   out->n_edges_fastpath = c->state >= ST_CHAINED ? c->n_edges_fast : 0;
   out->n_lost_publications = c->lost_publications;
+  out->index_path          = c->index_path;
   return MSGPU_OK;
 }
 

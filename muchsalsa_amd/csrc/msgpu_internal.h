@@ -126,6 +126,20 @@ constexpr uint32_t IXF_DUPS     = 4u; // a (read, anchor) pair occurs more than 
 constexpr uint32_t IXF_FORCE    = 8u; // host asked for the generic path
 constexpr uint32_t IXF_OVERFLOW = 16u; // one-pass build: a read has more rows than a bucket holds (host rebuilds in two passes)
 constexpr uint32_t IXF_BIGSCAF  = 32u; // a scaffold longer than the context pass 1 sorts it in
+constexpr uint32_t IXF_BINFAIL  = 64u; // bin path (msgpu_index.hip): a bucket beyond its capacity, a duplicate pair or a read of > 256 rows
+// the bin path: rows binned by coarse bucket (consecutive read ids) without a global atomic per row, then a workgroup per bucket
+constexpr uint32_t BIN_NB_MAX    = 8192; // coarse buckets per pass (k_index_bin's LDS histogram)
+constexpr uint32_t BIN_RPB_SHIFT = 4;    // 16 read ids per coarse bucket
+constexpr uint32_t BIN_PASSES_MAX = 8;   // passes over the row table (BIN_NB_MAX * 16 = 131,072 reads each); more reads: the atomic path
+uint32_t bin_capacity(uint64_t n, uint32_t V); // rows a coarse bucket can hold; 0 = the bin path does not apply
+void launch_index_bin(hipStream_t st, const msgpu_row *rows, uint64_t n, uint32_t V, uint32_t A, uint32_t *flags, uint32_t *err,
+                      uint32_t *anchor_first, uint32_t *cursor, uint4 *bin_rec, uint32_t rd_lo, uint32_t nb, uint32_t cap,
+                      uint32_t *bin_start, uint32_t *row_base, uint32_t *read_off_end);
+void launch_index_sort_bin(hipStream_t st, const uint32_t *cursor, const uint32_t *bin_start, uint32_t V, uint32_t rd_lo, uint32_t nb,
+                           uint32_t cap, const uint4 *bin_rec, IRow *by_read, IRow *by_anchor, uint4 *vis, uint32_t *read_off,
+                           uint32_t *read_cnt, int32_t *read_len, uint32_t *read_first, uint32_t *visits, const msgpu_row *rows,
+                           uint32_t *flags, uint32_t *err);
+void launch_check_anchor_first(hipStream_t st, uint32_t *anchor_first, uint32_t A, uint64_t n, uint32_t *flags);
 void launch_publish_scalars(hipStream_t st, const uint64_t *src, uint64_t *dst_host, uint32_t n, uint64_t seq);
 void launch_index_init(hipStream_t st, uint32_t *const zero[4], const uint32_t n_zero[4], uint32_t *const ones[2],
                        const uint32_t n_ones[2]);

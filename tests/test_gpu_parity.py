@@ -135,6 +135,59 @@ def test_shortcut_and_full_sweep_agree(oracle, monkeypatch):
     assert_tables_equal(slow, want, "full sweep")
 
 
+def test_index_bin_path_and_atomic_path_agree(oracle, monkeypatch):
+    """The index build has two ways to the same tables: the bin path (rows binned by coarse read-id bucket, no global atomic per
+    row: what a table from msgpu_parse_paf takes) and the atomic path of rounds 1-3 (every input).  A loader-shaped table takes
+    the bin path; MSGPU_NO_BIN=1 forces the atomic one; shuffled rows, a duplicate (read, anchor) pair, a read of more than 256
+    rows and a scaffold longer than pass 1's context fall back by themselves.  All equal the oracle -- and each other, down to
+    the per-read Vertex facts."""
+    from muchsalsa_amd import _lib, overlap, synth
+
+    def run(rows):
+        with overlap.OverlapContext(0) as ctx:
+            ctx.load_rows(rows)
+            ctx.calculate_edges()
+            ctx.chaining_and_overlaps()
+            return ctx.tables(), ctx.reads(), int(ctx.counts().index_path)
+
+    shapes = [(1000, 5000, 4000, 13), (37, 3000, 150, 4), (3000, 2500, 9000, 5), (400, 30000, 3000, 6)]
+    for shape in shapes:
+        rows = synth.synth_rows(*shape)
+        want = oracle.overlap(rows)
+        t_bin, reads_bin, path = run(rows)
+        assert path == _lib.INDEX_BIN, (shape, path)
+        assert_tables_equal(t_bin, want, "bin path %r" % (shape,))
+        monkeypatch.setenv("MSGPU_NO_BIN", "1")
+        t_at, reads_at, path = run(rows)
+        monkeypatch.delenv("MSGPU_NO_BIN")
+        assert path == _lib.INDEX_ATOMIC, (shape, path)
+        assert_tables_equal(t_at, want, "atomic path %r" % (shape,))
+        assert all(np.array_equal(a, b) for a, b in zip(reads_bin, reads_at))
+    rows = synth.synth_rows(1000, 5000, 4000, 13)
+    want = oracle.overlap(rows)
+    rng = np.random.default_rng(3)
+    shuffled = rows.copy()
+    rng.shuffle(shuffled)
+    t, _, path = run(shuffled)                       # not grouped by anchor: generic scaffolds on the atomic path
+    assert path == (_lib.INDEX_ATOMIC | _lib.INDEX_GENERIC), path
+    assert_tables_equal(t, want, "shuffled")
+    dup = rows[100:101].copy()                       # a second row of one (read, anchor) pair, on a later line: it loses
+    dup["line"] = rows["line"].max() + 5
+    dup["n_lo"] += 3
+    k = int(np.searchsorted(rows["anchor_id"], dup["anchor_id"][0], side="right"))
+    with_dup = np.concatenate([rows[:k], dup, rows[k:]])
+    with_dup["line"][k + 1:] += 0                    # (lines stay ascending inside every anchor: the duplicate has the largest)
+    t, _, path = run(with_dup)
+    assert path & _lib.INDEX_GENERIC and (path & 3) == _lib.INDEX_ATOMIC, path
+    assert_tables_equal(t, want, "duplicate pair")
+    # a read of more than 256 rows (long read, dense anchors): beyond what a wavefront ranks in registers
+    long_rows = synth.accepted_rows(synth.paf_table(60, 60000, 9000, 5, coverage=10))[0]
+    assert np.bincount(long_rows["read_id"]).max() > 256
+    t, _, path = run(long_rows)
+    assert (path & 3) != _lib.INDEX_BIN, path
+    assert_tables_equal(t, oracle.overlap(long_rows), "long reads")
+
+
 def test_sub_wavefront_and_whole_wavefront_chaining_agree(oracle, monkeypatch):
     """Edges of <= 32 EdgeMatches share a wavefront (k_chain_sub<8|16|32>), longer ones take one each (k_chain):
     MSGPU_NO_SUBWAVE=1 sends every edge through k_chain.  Both must give the oracle's tables; the workload has edges
