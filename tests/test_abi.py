@@ -39,7 +39,7 @@ def test_record_layouts_match_oracle_header(lib):
     for a, b in ((lib.ROW_DTYPE, O.ROW_DTYPE), (lib.EDGE_DTYPE, O.EDGE_DTYPE), (lib.EM_DTYPE, O.EM_DTYPE),
                  (lib.ORDER_DTYPE, O.ORDER_DTYPE)):
         assert a == b
-    assert C.sizeof(lib.Params) == 40 and C.sizeof(lib.Counts) == 80 and C.sizeof(lib.Timings) == 28
+    assert C.sizeof(lib.Params) == 40 and C.sizeof(lib.Counts) == 88 and C.sizeof(lib.Timings) == 28
 
 
 def test_default_params_are_the_reference_constants(lib):
