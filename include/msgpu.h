@@ -336,6 +336,48 @@ int msgpu_merge_wire(msgpu_ctx *ctx, const void *d_gathered, uint32_t world, con
                      uint64_t off_edges, uint64_t off_orders, uint64_t off_ids, uint32_t id_bytes, const uint32_t *id_base,
                      void *d_edges, void *d_orders, void *d_ids, void *hip_stream);
 
+/* ---- one process, the node's GPUs: a GROUP of contexts behind the same call site -------------------------------------------
+ * The reference is ONE process that fans jobs over its workers and closes each phase with a barrier (src/main.cpp:143-178,
+ * libms/src/threading/ThreadPool.cpp:38-129, WaitGroup.cpp:62-72).  Its multi-GPU equivalent: one process, one context per
+ * device, one host thread per device for the duration of a call, and ONE collective on the path.  msgpu_group_overlap =
+ *   rows (host) -> every device's HBM over that device's own link -> index build on every device (replicated: a member needs
+ *   the rank of every row inside its read) -> device i computes the edges with v1 % n == i (msgpu_set_shard) -> its edge /
+ *   order / id tables in WIRE FORM into its slab (msgpu_pack_wire) -> ONE grouped RCCL all-gather over xGMI
+ *   (ncclGroupStart / n x ncclAllGather / ncclGroupEnd, each on its member's stream) -> msgpu_merge_wire on every device:
+ *   the merged edge list of the job in every HBM, and (from device 0) in host memory; WaitGroup::wait() = the join of the
+ *   member threads.
+ * The merged tables are the ones msgpu_merge_wire defines: rank-major (member 0's edges in (v1, v2) order, then member 1's ...),
+ * order_off / edge_idx / ids_off re-based to the merged tables, em_off local to the owning member (EdgeMatch tables are not
+ * gathered: msgpu_get_edgematches on msgpu_group_ctx(g, v1 % n)).  With n = 1 they are the single-context tables bit for bit.
+ * RCCL is loaded on first use (dlopen of librccl.so.1: the process's own copy where a framework already brought one); a
+ * process that never creates a group never maps it.  MSGPU_E_NODEVICE when a device is missing, MSGPU_E_HIP with the RCCL
+ * error text when a collective fails.  A group is driven by one host thread at a time (STREAM AND THREAD CONTRACT rule 5);
+ * the members' contexts must not be used by the caller while a group call runs. */
+typedef struct msgpu_group msgpu_group;
+typedef struct msgpu_group_tables {
+  const msgpu_edge  *edges;   /* host (pinned, owned by the group, valid until its next call): the merged edge list     */
+  const msgpu_order *orders;
+  const uint32_t    *ids;
+  const int32_t     *read_len;        /* Vertex::getNanoporeLength(), n_reads entries                                  */
+  const uint32_t    *read_first_line; /* Vertex::metaDatum(0)                                                          */
+  uint64_t n_edges, n_orders, n_ids, n_ems; /* n_ems: EdgeMatches over all members (the tables stay in their HBMs)     */
+  uint32_t n_reads, n_anchors, n_members, id_bytes; /* id_bytes: 3 or 4, how anchor ids travelled                      */
+  uint64_t slab_bytes;        /* bytes every member sent (the largest member's wire blocks)                            */
+  float wall_ms;              /* host clock: call entry -> merged tables in host memory                                */
+  float compute_ms;           /*   slowest member: rows in HBM + index + its shard                                     */
+  float exchange_ms;          /*   slowest member: pack + all-gather + merge (device time, HIP events)                 */
+  float pad;
+} msgpu_group_tables;
+int  msgpu_group_create(const int *devices, int n, const msgpu_params *params, msgpu_group **out);
+void msgpu_group_destroy(msgpu_group *g);
+const char *msgpu_group_last_error(const msgpu_group *g);
+int  msgpu_group_size(const msgpu_group *g);
+msgpu_ctx *msgpu_group_ctx(msgpu_group *g, int member); /* member i's context: its counts, its EdgeMatch table, its merged device tables */
+int  msgpu_group_overlap(msgpu_group *g, const msgpu_row *rows, size_t n_rows, msgpu_group_tables *out);
+/* The merged tables as member `member` holds them in ITS HBM (device pointers, valid until the group's next call): what
+ * msgpu_find_contraction_edges(msgpu_group_ctx(g, member), d_edges, n_edges, d_orders, n_orders, n_reads, ...) takes. */
+int  msgpu_group_device_tables(msgpu_group *g, int member, const void **d_edges, const void **d_orders, const void **d_ids);
+
 /* ---- the ThreadPool replacement: the whole overlap path, host memory to host memory, as batches on two HIP streams ----
  * Replaces the phases of src/main.cpp:153-178 that the reference fans over its ThreadPool (one Job per PAF line, per
  * anchor, per edge; libms/src/threading/ThreadPool.cpp:38-129) and closes with WaitGroup::wait() (WaitGroup.cpp:62-72):

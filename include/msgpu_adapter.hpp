@@ -55,6 +55,7 @@ public:
   }
   ~OverlapCore() {
     if (m_paf) msgpu_paf_free(m_paf);
+    if (m_group) msgpu_group_destroy(m_group);
     if (m_ctx) msgpu_destroy(m_ctx);
   }
   OverlapCore(OverlapCore const &)            = delete;
@@ -170,6 +171,27 @@ public:
 
   msgpu_ctx *handle() const { return m_ctx; }
 
+  // The node's GPUs behind the same call site (src/main.cpp:143-178: one process, the phase closed by WaitGroup::wait()):
+  // parse() must have run.  Every device in `devices` takes the row table, builds the index and computes the edges with
+  // v1 % n == its position; ONE grouped RCCL all-gather over xGMI + the merge on every device give the job's merged edge
+  // list (msgpu_group_overlap).  Views of the group's pinned result memory, valid until the next call; the EdgeMatches of an
+  // edge stay with its owner: msgpu_get_edgematches(msgpu_group_ctx(group(), v1 % n), ...).
+  msgpu_group_tables overlapOnDevices(std::vector<int> const &devices) {
+    if (!m_group || m_groupDevices != devices) {
+      if (m_group) msgpu_group_destroy(m_group);
+      m_group = nullptr;
+      check(msgpu_group_create(devices.data(), static_cast<int>(devices.size()), &m_params, &m_group), nullptr);
+      m_groupDevices = devices;
+    }
+    std::size_t        n    = 0;
+    msgpu_row const   *rows = msgpu_paf_rows(m_paf, &n);
+    msgpu_group_tables t;
+    int const          rc = msgpu_group_overlap(m_group, rows, n, &t);
+    if (rc != MSGPU_OK) throw std::runtime_error(std::string(msgpu_strerror(rc)) + ": " + msgpu_group_last_error(m_group));
+    return t;
+  }
+  msgpu_group *group() const { return m_group; }
+
 private:
   static void check(int rc, msgpu_ctx const *ctx) {
     if (rc == MSGPU_OK) return;
@@ -189,6 +211,8 @@ private:
   msgpu_params m_params{};
   msgpu_ctx   *m_ctx = nullptr;
   msgpu_paf   *m_paf = nullptr;
+  msgpu_group *m_group = nullptr;
+  std::vector<int> m_groupDevices;
 };
 
 // Replay rows + result tables into the reference's containers.  Template parameters are the reference types

@@ -84,6 +84,14 @@ class Counts(C.Structure):
                 ("n_lost_publications", C.c_uint64), ("index_path", C.c_uint64)]
 
 
+class GroupTables(C.Structure):
+    _fields_ = [("edges", C.c_void_p), ("orders", C.c_void_p), ("ids", C.c_void_p), ("read_len", C.c_void_p),
+                ("read_first_line", C.c_void_p), ("n_edges", C.c_uint64), ("n_orders", C.c_uint64), ("n_ids", C.c_uint64),
+                ("n_ems", C.c_uint64), ("n_reads", C.c_uint32), ("n_anchors", C.c_uint32), ("n_members", C.c_uint32),
+                ("id_bytes", C.c_uint32), ("slab_bytes", C.c_uint64), ("wall_ms", C.c_float), ("compute_ms", C.c_float),
+                ("exchange_ms", C.c_float), ("pad", C.c_float)]
+
+
 INDEX_BIN, INDEX_ATOMIC, INDEX_TWO_PASS, INDEX_GENERIC = 0, 1, 2, 4
 
 
@@ -220,6 +228,14 @@ SYMBOLS = [
                                             C.c_uint32, C.c_void_p, C.POINTER(C.c_uint32)]),
     ("msgpu_graph_sort_topologically", C.c_int, [C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p,
                                                  C.POINTER(C.c_uint32)]),
+    ("msgpu_group_create", C.c_int, [C.POINTER(C.c_int), C.c_int, C.POINTER(Params), C.POINTER(C.c_void_p)]),
+    ("msgpu_group_destroy", None, [C.c_void_p]),
+    ("msgpu_group_last_error", C.c_char_p, [C.c_void_p]),
+    ("msgpu_group_size", C.c_int, [C.c_void_p]),
+    ("msgpu_group_ctx", C.c_void_p, [C.c_void_p, C.c_int]),
+    ("msgpu_group_overlap", C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(GroupTables)]),
+    ("msgpu_group_device_tables", C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                            C.POINTER(C.c_void_p)]),
     ("msgpu_overlap_batched", C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.POINTER(HostTables)]),
     ("msgpu_overlap_batched_ex", C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32,
                                            C.POINTER(HostTables)]),

@@ -1,0 +1,355 @@
+// msgpu_group.cpp -- one process, the node's GPUs: a group of contexts behind the reference's call site.
+//
+// The reference is one process whose phases fan jobs over ThreadPool workers and end in WaitGroup::wait()
+// (src/main.cpp:143-178, libms/src/threading/ThreadPool.cpp:38-129, WaitGroup.cpp:62-72).  Here the workers are devices: one
+// msgpu_ctx per GPU, one host thread per GPU while a call runs (a context's calls wait for table sizes, so n devices need
+// n callers), device i owns the edges with v1 % n == i, and the phase ends with ONE grouped RCCL all-gather over xGMI of the
+// members' wire-form slabs + msgpu_merge_wire on every device.  Everything goes through the public C-ABI of include/msgpu.h;
+// this file adds no kernel.  RCCL is resolved at run time (dlopen): a process that never makes a group never maps it.
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <chrono>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+#include "msgpu.h"
+
+namespace {
+
+struct Rccl {
+  void *handle = nullptr;
+  decltype(&ncclCommInitAll)    CommInitAll    = nullptr;
+  decltype(&ncclCommDestroy)    CommDestroy    = nullptr;
+  decltype(&ncclAllGather)      AllGather      = nullptr;
+  decltype(&ncclGroupStart)     GroupStart     = nullptr;
+  decltype(&ncclGroupEnd)       GroupEnd       = nullptr;
+  decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  char why[256] = {0};
+};
+
+// the process's RCCL: the copy already loaded under its soname if there is one (a framework's), else the ROCm installation's
+Rccl *rccl() {
+  static Rccl       r;
+  static std::mutex m;
+  std::lock_guard<std::mutex> lock(m);
+  if (r.handle || r.why[0]) return &r;
+  for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+    r.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+    if (r.handle) break;
+  }
+  if (!r.handle) {
+    snprintf(r.why, sizeof(r.why), "librccl.so.1 not found: %s", dlerror());
+    return &r;
+  }
+#define RESOLVE(field, symbol)                                                                                          \
+  r.field = reinterpret_cast<decltype(r.field)>(dlsym(r.handle, symbol));                                               \
+  if (!r.field) snprintf(r.why, sizeof(r.why), "librccl lacks %s", symbol)
+  RESOLVE(CommInitAll, "ncclCommInitAll");
+  RESOLVE(CommDestroy, "ncclCommDestroy");
+  RESOLVE(AllGather, "ncclAllGather");
+  RESOLVE(GroupStart, "ncclGroupStart");
+  RESOLVE(GroupEnd, "ncclGroupEnd");
+  RESOLVE(GetErrorString, "ncclGetErrorString");
+#undef RESOLVE
+  return &r;
+}
+
+struct DevBlock { // a device buffer that only grows
+  void  *p   = nullptr;
+  size_t cap = 0;
+  hipError_t ensure(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    if (p) (void)hipFree(p);
+    p   = nullptr;
+    cap = 0;
+    const size_t want = bytes + bytes / 8 + 4096;
+    hipError_t   e    = hipMalloc(&p, want);
+    if (e == hipSuccess) cap = want;
+    return e;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p   = nullptr;
+    cap = 0;
+  }
+};
+struct HostBlock { // pinned, grows only
+  void  *p   = nullptr;
+  size_t cap = 0;
+  bool ensure(size_t bytes) {
+    if (bytes <= cap) return true;
+    if (p) msgpu_pinned_free(p);
+    cap = 0;
+    p   = msgpu_pinned_alloc(bytes + bytes / 8 + 4096);
+    if (p) cap = bytes + bytes / 8 + 4096;
+    return p != nullptr;
+  }
+  void release() {
+    if (p) msgpu_pinned_free(p);
+    p   = nullptr;
+    cap = 0;
+  }
+};
+
+struct Member {
+  int          device = 0;
+  msgpu_ctx   *ctx    = nullptr;
+  ncclComm_t   comm   = nullptr;
+  DevBlock     slab, gathered, m_edges, m_orders, m_ids;
+  hipEvent_t   ev0 = nullptr, ev1 = nullptr;
+  msgpu_counts counts{};
+  int          rc = MSGPU_OK;
+  char         err[512] = {0};
+  double       compute_ms = 0;
+};
+
+constexpr uint64_t ALIGN = 256; // blocks inside a slab (muchsalsa_amd/distributed.py uses the same layout)
+uint64_t round_up(uint64_t n) { return (n + ALIGN - 1) / ALIGN * ALIGN; }
+
+} // namespace
+
+struct msgpu_group {
+  std::vector<Member> m;
+  msgpu_params        p;
+  char                err[640] = {0};
+  HostBlock           h_edges, h_orders, h_ids, h_read_len, h_read_first;
+  bool                comms_ok = false;
+};
+
+namespace {
+
+int gfail(msgpu_group *g, int code, const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g->err, sizeof(g->err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+#define GHIP(g, expr)                                                                                                  \
+  do {                                                                                                                 \
+    hipError_t _e = (expr);                                                                                            \
+    if (_e != hipSuccess)                                                                                              \
+      return gfail((g), _e == hipErrorOutOfMemory ? MSGPU_E_NOMEM : MSGPU_E_HIP, "%s failed: %s (%s:%d)", #expr,       \
+                   hipGetErrorString(_e), __FILE__, __LINE__);                                                         \
+  } while (0)
+#define GNCCL(g, expr)                                                                                                 \
+  do {                                                                                                                 \
+    ncclResult_t _r = (expr);                                                                                          \
+    if (_r != ncclSuccess)                                                                                             \
+      return gfail((g), MSGPU_E_HIP, "%s failed: %s (%s:%d)", #expr, rccl()->GetErrorString(_r), __FILE__, __LINE__);  \
+  } while (0)
+
+} // namespace
+
+extern "C" {
+
+int msgpu_group_create(const int *devices, int n, const msgpu_params *params, msgpu_group **out) {
+  if (!out) return MSGPU_E_ARG;
+  *out = nullptr;
+  if (!devices || n <= 0 || n > 64) return MSGPU_E_ARG;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return MSGPU_E_NODEVICE;
+  for (int i = 0; i < n; ++i) {
+    if (devices[i] < 0 || devices[i] >= ndev) return MSGPU_E_NODEVICE;
+    for (int j = 0; j < i; ++j)
+      if (devices[j] == devices[i]) return MSGPU_E_ARG; // one member per device
+  }
+  msgpu_group *g = new (std::nothrow) msgpu_group();
+  if (!g) return MSGPU_E_NOMEM;
+  if (params)
+    g->p = *params;
+  else
+    msgpu_default_params(&g->p);
+  g->m.resize(static_cast<size_t>(n));
+  for (int i = 0; i < n; ++i) {
+    Member &mb = g->m[static_cast<size_t>(i)];
+    mb.device  = devices[i];
+    int rc     = msgpu_create(devices[i], &g->p, &mb.ctx);
+    if (rc == MSGPU_OK) rc = msgpu_set_shard(mb.ctx, static_cast<uint32_t>(i), static_cast<uint32_t>(n));
+    if (rc == MSGPU_OK && (hipSetDevice(devices[i]) != hipSuccess || hipEventCreate(&mb.ev0) != hipSuccess ||
+                           hipEventCreate(&mb.ev1) != hipSuccess))
+      rc = MSGPU_E_HIP;
+    if (rc != MSGPU_OK) {
+      msgpu_group_destroy(g);
+      return rc;
+    }
+  }
+  *out = g; // (the communicators are made by the first msgpu_group_overlap: creating a group costs no RCCL start-up)
+  return MSGPU_OK;
+}
+
+void msgpu_group_destroy(msgpu_group *g) {
+  if (!g) return;
+  for (Member &mb : g->m) {
+    (void)hipSetDevice(mb.device);
+    if (mb.ctx) (void)msgpu_synchronize(mb.ctx);
+    if (mb.comm && rccl()->CommDestroy) (void)rccl()->CommDestroy(mb.comm);
+    for (DevBlock *b : {&mb.slab, &mb.gathered, &mb.m_edges, &mb.m_orders, &mb.m_ids}) b->release();
+    if (mb.ev0) (void)hipEventDestroy(mb.ev0);
+    if (mb.ev1) (void)hipEventDestroy(mb.ev1);
+    if (mb.ctx) msgpu_destroy(mb.ctx);
+  }
+  for (HostBlock *h : {&g->h_edges, &g->h_orders, &g->h_ids, &g->h_read_len, &g->h_read_first}) h->release();
+  delete g;
+}
+
+const char *msgpu_group_last_error(const msgpu_group *g) { return g ? g->err : "null group"; }
+int         msgpu_group_size(const msgpu_group *g) { return g ? static_cast<int>(g->m.size()) : 0; }
+msgpu_ctx  *msgpu_group_ctx(msgpu_group *g, int member) {
+  return (g && member >= 0 && static_cast<size_t>(member) < g->m.size()) ? g->m[static_cast<size_t>(member)].ctx : nullptr;
+}
+
+int msgpu_group_device_tables(msgpu_group *g, int member, const void **d_edges, const void **d_orders, const void **d_ids) {
+  if (!g || member < 0 || static_cast<size_t>(member) >= g->m.size()) return MSGPU_E_ARG;
+  const Member &mb = g->m[static_cast<size_t>(member)];
+  if (d_edges) *d_edges = mb.m_edges.p;
+  if (d_orders) *d_orders = mb.m_orders.p;
+  if (d_ids) *d_ids = mb.m_ids.p;
+  return MSGPU_OK;
+}
+
+int msgpu_group_overlap(msgpu_group *g, const msgpu_row *rows, size_t n_rows, msgpu_group_tables *out) {
+  if (!g || !out) return MSGPU_E_ARG;
+  if (n_rows && !rows) return gfail(g, MSGPU_E_ARG, "Unexpected nullptr.");
+  const auto   t_start = std::chrono::steady_clock::now();
+  const size_t n       = g->m.size();
+  memset(out, 0, sizeof(*out));
+  Rccl *nc = rccl();
+  if (nc->why[0]) return gfail(g, MSGPU_E_HIP, "RCCL is not available: %s", nc->why);
+  if (!g->comms_ok) { // one communicator per member, all in this process
+    std::vector<ncclComm_t> comms(n);
+    std::vector<int>        devs(n);
+    for (size_t i = 0; i < n; ++i) devs[i] = g->m[i].device;
+    GNCCL(g, nc->CommInitAll(comms.data(), static_cast<int>(n), devs.data()));
+    for (size_t i = 0; i < n; ++i) g->m[i].comm = comms[i];
+    g->comms_ok = true;
+  }
+
+  // ---- the fan-out: every member takes the rows over its own link, builds the index, computes its shard ----------------
+  auto work = [&](size_t i) {
+    Member    &mb = g->m[i];
+    const auto t0 = std::chrono::steady_clock::now();
+    mb.rc         = hipSetDevice(mb.device) == hipSuccess ? MSGPU_OK : MSGPU_E_HIP;
+    if (mb.rc == MSGPU_OK) mb.rc = msgpu_load_rows(mb.ctx, rows, n_rows);
+    if (mb.rc == MSGPU_OK) mb.rc = msgpu_calculate_edges(mb.ctx);
+    if (mb.rc == MSGPU_OK) mb.rc = msgpu_chaining_and_overlaps(mb.ctx);
+    if (mb.rc == MSGPU_OK) mb.rc = msgpu_get_counts(mb.ctx, &mb.counts);
+    if (mb.rc == MSGPU_OK) mb.rc = msgpu_synchronize(mb.ctx);
+    if (mb.rc != MSGPU_OK) snprintf(mb.err, sizeof(mb.err), "member %zu (device %d): %s", i, mb.device, msgpu_last_error(mb.ctx));
+    mb.compute_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  };
+  {
+    std::vector<std::thread> th;
+    try {
+      for (size_t i = 1; i < n; ++i) th.emplace_back(work, i);
+    } catch (...) { // no thread to be had: the members that have none run here, one after the other
+      for (size_t i = th.size() + 1; i < n; ++i) work(i);
+    }
+    work(0);
+    for (std::thread &t : th) t.join(); // WaitGroup::wait()
+  }
+  for (size_t i = 0; i < n; ++i)
+    if (g->m[i].rc != MSGPU_OK) return gfail(g, g->m[i].rc, "%s", g->m[i].err);
+
+  // ---- the one exchange: wire-form slabs, one grouped all-gather, the merge on every device ---------------------------
+  std::vector<uint64_t> counts(3 * n);
+  uint64_t              mx[3] = {0, 0, 0}, tot[3] = {0, 0, 0}, n_ems = 0;
+  for (size_t i = 0; i < n; ++i) {
+    const msgpu_counts &c = g->m[i].counts;
+    const uint64_t      v[3] = {c.n_edges, c.n_orders, c.n_ids};
+    for (int k = 0; k < 3; ++k) {
+      counts[3 * i + k] = v[k];
+      mx[k]             = std::max(mx[k], v[k]);
+      tot[k] += v[k];
+    }
+    n_ems += c.n_ems;
+  }
+  const uint32_t id_bytes = g->m[0].counts.n_anchors <= (1u << 24) ? 3u : 4u; // every member holds the same rows: same id space
+  const uint64_t off_e = 0, off_o = round_up(off_e + msgpu_wire_edges_bytes(mx[0])),
+                 off_i = round_up(off_o + msgpu_wire_orders_bytes(mx[1])),
+                 slab_bytes = std::max<uint64_t>(round_up(off_i + msgpu_wire_ids_bytes(mx[2], id_bytes)), ALIGN);
+  for (size_t i = 0; i < n; ++i) {
+    Member &mb = g->m[i];
+    GHIP(g, hipSetDevice(mb.device));
+    GHIP(g, mb.slab.ensure(slab_bytes));
+    GHIP(g, mb.gathered.ensure(n * slab_bytes));
+    GHIP(g, mb.m_edges.ensure(std::max<uint64_t>(tot[0], 1) * sizeof(msgpu_edge)));
+    GHIP(g, mb.m_orders.ensure(std::max<uint64_t>(tot[1], 1) * sizeof(msgpu_order)));
+    GHIP(g, mb.m_ids.ensure(std::max<uint64_t>(tot[2], 1) * 4));
+    hipStream_t st = static_cast<hipStream_t>(msgpu_get_stream(mb.ctx));
+    GHIP(g, hipEventRecord(mb.ev0, st));
+    char *slab = static_cast<char *>(mb.slab.p);
+    if (int rc = msgpu_pack_wire(mb.ctx, slab + off_e, slab + off_o, slab + off_i, id_bytes))
+      return gfail(g, rc, "member %zu: %s", i, msgpu_last_error(mb.ctx));
+  }
+  GNCCL(g, nc->GroupStart()); // one thread drives n communicators: the n calls are one collective
+  for (size_t i = 0; i < n; ++i) {
+    Member &mb = g->m[i];
+    GNCCL(g, nc->AllGather(mb.slab.p, mb.gathered.p, slab_bytes, ncclChar, mb.comm, static_cast<hipStream_t>(msgpu_get_stream(mb.ctx))));
+  }
+  GNCCL(g, nc->GroupEnd());
+  for (size_t i = 0; i < n; ++i) {
+    Member &mb = g->m[i];
+    GHIP(g, hipSetDevice(mb.device));
+    if (int rc = msgpu_merge_wire(mb.ctx, mb.gathered.p, static_cast<uint32_t>(n), counts.data(), slab_bytes, off_e, off_o, off_i,
+                                  id_bytes, nullptr, mb.m_edges.p, mb.m_orders.p, mb.m_ids.p, nullptr))
+      return gfail(g, rc, "member %zu: %s", i, msgpu_last_error(mb.ctx));
+    GHIP(g, hipEventRecord(mb.ev1, static_cast<hipStream_t>(msgpu_get_stream(mb.ctx))));
+  }
+  // ---- the merged list in host memory (from member 0), the Vertex facts -------------------------------------------------
+  const uint32_t V = g->m[0].counts.n_reads;
+  if (!g->h_edges.ensure(std::max<uint64_t>(tot[0], 1) * sizeof(msgpu_edge)) ||
+      !g->h_orders.ensure(std::max<uint64_t>(tot[1], 1) * sizeof(msgpu_order)) || !g->h_ids.ensure(std::max<uint64_t>(tot[2], 1) * 4) ||
+      !g->h_read_len.ensure((size_t(V) + 1) * 4) || !g->h_read_first.ensure((size_t(V) + 1) * 4))
+    return gfail(g, MSGPU_E_NOMEM, "page-locked host tables of the merged edge list");
+  {
+    Member     &mb = g->m[0];
+    hipStream_t st = static_cast<hipStream_t>(msgpu_get_stream(mb.ctx));
+    GHIP(g, hipSetDevice(mb.device));
+    if (tot[0]) GHIP(g, hipMemcpyAsync(g->h_edges.p, mb.m_edges.p, tot[0] * sizeof(msgpu_edge), hipMemcpyDeviceToHost, st));
+    if (tot[1]) GHIP(g, hipMemcpyAsync(g->h_orders.p, mb.m_orders.p, tot[1] * sizeof(msgpu_order), hipMemcpyDeviceToHost, st));
+    if (tot[2]) GHIP(g, hipMemcpyAsync(g->h_ids.p, mb.m_ids.p, tot[2] * 4, hipMemcpyDeviceToHost, st));
+    if (V)
+      if (int rc = msgpu_copy_reads(mb.ctx, static_cast<int32_t *>(g->h_read_len.p), static_cast<uint32_t *>(g->h_read_first.p)))
+        return gfail(g, rc, "member 0: %s", msgpu_last_error(mb.ctx));
+  }
+  float exchange_ms = 0;
+  for (size_t i = 0; i < n; ++i) { // the phase barrier: every member's stream has drained
+    Member &mb = g->m[i];
+    GHIP(g, hipSetDevice(mb.device));
+    GHIP(g, hipStreamSynchronize(static_cast<hipStream_t>(msgpu_get_stream(mb.ctx))));
+    float ms = 0;
+    GHIP(g, hipEventElapsedTime(&ms, mb.ev0, mb.ev1));
+    exchange_ms = std::max(exchange_ms, ms);
+  }
+  out->edges           = static_cast<const msgpu_edge *>(g->h_edges.p);
+  out->orders          = static_cast<const msgpu_order *>(g->h_orders.p);
+  out->ids             = static_cast<const uint32_t *>(g->h_ids.p);
+  out->read_len        = static_cast<const int32_t *>(g->h_read_len.p);
+  out->read_first_line = static_cast<const uint32_t *>(g->h_read_first.p);
+  out->n_edges         = tot[0];
+  out->n_orders        = tot[1];
+  out->n_ids           = tot[2];
+  out->n_ems           = n_ems;
+  out->n_reads         = V;
+  out->n_anchors       = g->m[0].counts.n_anchors;
+  out->n_members       = static_cast<uint32_t>(n);
+  out->id_bytes        = id_bytes;
+  out->slab_bytes      = slab_bytes;
+  double cm = 0;
+  for (const Member &mb : g->m) cm = std::max(cm, mb.compute_ms);
+  out->compute_ms  = static_cast<float>(cm);
+  out->exchange_ms = exchange_ms;
+  out->wall_ms     = static_cast<float>(std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count());
+  g->err[0]        = 0;
+  return MSGPU_OK;
+}
+
+} // extern "C"

@@ -316,6 +316,84 @@ class OverlapContext:
         return rl, fl
 
 
+class OverlapGroup:
+    """msgpu_group: one process, several GPUs behind one call (include/msgpu.h, "a GROUP of contexts").  overlap(rows) ->
+    (merged tables, info): every device loads the rows over its own link, builds the index, computes the edges with
+    v1 % n == its position; one grouped RCCL all-gather + msgpu_merge_wire merge the edge list on every device."""
+
+    def __init__(self, devices=(0,), params=None):
+        self._L = _lib.lib()
+        self._h = C.c_void_p()
+        self.params = params if params is not None else default_params()
+        devs = (C.c_int * len(devices))(*[int(d) for d in devices])
+        rc = self._L.msgpu_group_create(devs, len(devices), C.byref(self.params), C.byref(self._h))
+        if rc != 0:
+            self._h = C.c_void_p()
+            raise MsgpuError(rc)
+        self.n = len(devices)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._L.msgpu_group_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def overlap(self, rows, copy=True):
+        arr = rows.array if isinstance(rows, PinnedRows) else np.ascontiguousarray(rows, dtype=ROW_DTYPE)
+        t = _lib.GroupTables()
+        rc = self._L.msgpu_group_overlap(self._h, arr.ctypes.data if len(arr) else None, len(arr), C.byref(t))
+        if rc != 0:
+            raise MsgpuError(rc, self._L.msgpu_group_last_error(self._h).decode())
+
+        def view(ptr, n, dt):
+            dt = np.dtype(dt)
+            if not n:
+                return np.zeros(0, dtype=dt)
+            a = np.frombuffer((C.c_char * (n * dt.itemsize)).from_address(ptr), dtype=dt, count=n)
+            return a.copy() if copy else a
+        tables = {"edges": view(t.edges, t.n_edges, EDGE_DTYPE), "orders": view(t.orders, t.n_orders, ORDER_DTYPE),
+                  "ids": view(t.ids, t.n_ids, "<u4"), "read_len": view(t.read_len, t.n_reads, "<i4"),
+                  "read_first_line": view(t.read_first_line, t.n_reads, "<u4")}
+        info = {k: getattr(t, k) for k in ("n_ems", "n_reads", "n_anchors", "n_members", "id_bytes", "slab_bytes", "wall_ms",
+                                           "compute_ms", "exchange_ms")}
+        return tables, info
+
+    def member_edgematches(self, member, edge_idx_local):
+        """MatchMap::getEdgeMatches for edges of member `member`, by their index in THAT member's edge table"""
+        ctx = OverlapContext.__new__(OverlapContext)
+        ctx._L, ctx._h, ctx._keep = self._L, C.c_void_p(self._L.msgpu_group_ctx(self._h, int(member))), None
+        try:
+            return ctx.get_edgematches(edge_idx_local)
+        finally:
+            ctx._h = C.c_void_p()  # (the group owns the context)
+
+    def device_tables(self, member=0):
+        """device pointers of the merged tables in member `member`'s HBM: (d_edges, d_orders, d_ids)"""
+        p = [C.c_void_p(), C.c_void_p(), C.c_void_p()]
+        rc = self._L.msgpu_group_device_tables(self._h, int(member), C.byref(p[0]), C.byref(p[1]), C.byref(p[2]))
+        if rc != 0:
+            raise MsgpuError(rc)
+        return tuple(x.value or 0 for x in p)
+
+    def find_contraction_edges(self, n_edges, n_orders, n_reads, member=0):
+        """findContractionEdges + sanityCheck on the merged list in member `member`'s HBM"""
+        d_e, d_o, _ = self.device_tables(member)
+        out = np.full(int(n_edges), -1, dtype="<i8")
+        ctxp = C.c_void_p(self._L.msgpu_group_ctx(self._h, int(member)))
+        rc = self._L.msgpu_find_contraction_edges(ctxp, C.c_void_p(d_e), int(n_edges), C.c_void_p(d_o), int(n_orders),
+                                                  int(n_reads), out.ctypes.data if len(out) else None)
+        if rc != 0:
+            raise MsgpuError(rc, self._L.msgpu_last_error(ctxp).decode())
+        return out
+
+
 def build_overlaps(rows, device=0, params=None, shard=0, n_shards=1):
     """rows -> result tables in one call."""
     with OverlapContext(device, params) as ctx:

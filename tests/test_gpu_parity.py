@@ -654,6 +654,38 @@ def test_bench_starts_its_own_ranks():
     assert line["config"]["merged_edge_list_consistent"] is True
 
 
+def test_group_of_one_over_rccl_equals_single_context(oracle):
+    """msgpu_group (one process, the node's GPUs, ONE grouped RCCL all-gather): with one member the whole path -- shard 0 of 1,
+    wire-form pack, ncclAllGather through librccl, msgpu_merge_wire, copy-out -- must give the single-context tables bit for bit,
+    EdgeMatches on demand from the member's context, and findContractionEdges on the merged list in HBM == the oracle's.  (The
+    protocol at world 2 / 3 runs under gloo on the CPU: tests/test_distributed_gloo.py; two members on real GPUs need a
+    multi-GPU box.)  A second job on the same group re-uses its communicator and its buffers."""
+    from muchsalsa_amd import overlap, synth
+    from graphcases import varlen_rows
+    with overlap.OverlapGroup([0]) as grp:
+        for k, rows in enumerate((synth.synth_rows(1000, 5000, 4000, 13), varlen_rows(400, 2500, 250_000, 2),
+                                  synth.synth_rows(300, 3000, 900, 1))):
+            want = oracle.overlap(rows)
+            t, info = grp.overlap(rows)
+            assert info["n_members"] == 1 and info["id_bytes"] == 3 and info["n_ems"] == len(want["ems"])
+            got = dict(t, ems=want["ems"])  # (EdgeMatch tables are not gathered: checked through the member below)
+            assert_tables_equal(got, want, "group of one, job %d" % k)
+            rl, fl = want["read_len"], want["read_first_line"]
+            assert np.array_equal(t["read_len"], rl) and np.array_equal(t["read_first_line"], fl)
+            pick = np.array([0, len(want["edges"]) // 2, len(want["edges"]) - 1], dtype="<u4")
+            off, ems = grp.member_edgematches(0, pick)
+            e = want["edges"]
+            assert ems.tobytes() == b"".join(want["ems"][int(e["em_off"][i]): int(e["em_off"][i]) + int(e["em_cnt"][i])].tobytes()
+                                             for i in pick)
+            co = grp.find_contraction_edges(len(t["edges"]), len(t["orders"]), len(rl))
+            assert np.array_equal(co, oracle.find_contraction_edges(want, len(rl)))
+            assert info["exchange_ms"] > 0 and info["wall_ms"] >= info["compute_ms"] > 0
+    with pytest.raises(overlap.MsgpuError):
+        overlap.OverlapGroup([0, 0])  # one member per device
+    with pytest.raises(overlap.MsgpuError):
+        overlap.OverlapGroup([99])
+
+
 def test_pipelined_exchange_threaded_regrow_world1():
     """The exchange as a GPU run drives it (RCCL at world 1, communication thread + stream): a rank outgrows the slab
     capacity in two consecutive batches; merged tables == own tables in every batch, and every batch goes out with the slab
