@@ -77,6 +77,43 @@ def pmc_traffic(workload, world, kernels):
     return total, os.path.relpath(best, ROOT), valu
 
 
+def pmc_stage(workload, world, prefixes):
+    """Counter traffic of every kernel whose name starts with one of `prefixes` (a stage's kernels), from the same capture as
+    pmc_traffic: -> (bytes per step or None, source, [kernels counted])"""
+    import csv
+    best = None
+    for meta in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_meta.json"))):
+        try:
+            m = json.load(open(meta))
+        except (OSError, ValueError):
+            continue
+        f = os.path.join(os.path.dirname(meta), "pmc_summary.csv")
+        if m.get("workload") == workload and int(m.get("world", 0)) == world and os.path.exists(f):
+            best = f
+    if best is None:
+        return None, "no counter capture under profiles/ for (%s, %d GPU)" % (workload, world), []
+    total, used = 0.0, []
+    table = list(csv.DictReader(open(best)))
+    # steps in the capture = dispatches of a kernel that runs once per step
+    steps = max([float(r["dispatches"]) for r in table if r["kernel"].replace("void ", "") == "msgpu::k_compact"] or [1.0])
+    for r in table:
+        name = r["kernel"].replace("void ", "")
+        if any(name.startswith(p) for p in prefixes) and r.get("FETCH_SIZE") and r.get("WRITE_SIZE"):
+            # per-dispatch averages x dispatches per step (a kernel launched twice per step counts twice)
+            total += (2.0 * float(r["FETCH_SIZE"]) + float(r["WRITE_SIZE"])) * 1024.0 * float(r["dispatches"]) / steps
+            used.append(name)
+    return (total if used else None), os.path.relpath(best, ROOT), used
+
+
+STAGE_KERNELS = {  # the kernels of each stage, by name prefix (profiles/*/kernel_stats.csv)
+    "index": ("msgpu::k_index_", "msgpu::k_bin_scan", "msgpu::k_sort_read", "msgpu::k_check_", "msgpu::k_select_anchor_off",
+              "msgpu::k_scatter_", "msgpu::k_rank_anchor", "msgpu::k_max_ids"),
+    "candidates": ("msgpu::k_candidates", "msgpu::k_emit_edges", "msgpu::k_classify_reads", "msgpu::k_count_classes", "msgpu::k_bound",
+                   "msgpu::k_size_"),
+    "compact": ("msgpu::k_compact",),
+}
+
+
 # ---- CPU baseline ----------------------------------------------------------------------------------------------------------
 
 def _cpu_sample(job):
@@ -139,12 +176,23 @@ def cpu_baseline(workload, budget_reads, cores):
         wall = time.perf_counter() - t0
         busy = max(r[3] for r in res)
         out.update({
-            "one_core_value": out["value"], "value": sum(r[0] for r in res) / busy, "cores": cores,
+            "one_core_quarter_sample_value": out["value"], "value": sum(r[0] for r in res) / busy, "cores": cores,
             "sample": "%d independent samples of that shape (seeds differ), one per core, run together: %d edges in "
                       "%.2f s (slowest worker; %.2f s with process start-up); one core alone: %s" % (
                           cores, sum(r[0] for r in res), busy, wall, out["sample"]),
         })
     return out
+
+
+def cpu_one_core_full(workload):
+    """The C oracle ONCE on the line's own workload (every row of it), one core, in a worker process of its own."""
+    import multiprocessing as mp
+    from concurrent.futures import ProcessPoolExecutor
+    w = WORKLOADS[workload]
+    with ProcessPoolExecutor(max_workers=1, mp_context=mp.get_context("spawn")) as pool:
+        e, m, c, dt = pool.submit(_cpu_sample, (w["n_reads"], w["read_len"], w["n_anchors"], w["seed"])).result()
+    return {"value": e / dt, "unit": "overlap-pairs/s", "cores": 1, "kind": "port",
+            "sample": "the workload of this line, whole: %d edges, %d EdgeMatches, %d compat checks in %.2f s on one core" % (e, m, c, dt)}
 
 
 def cpu_consensus_baseline():
@@ -265,6 +313,30 @@ def host_to_host_leg(ctx, rows, n_batches, reps=6):
                 "stage": "rows in pinned host memory -> msgpu_overlap_batched (H2D once, index once, %d windows of owner "
                          "reads; window k's tables copied out while window k+1 computes) -> four tables in pinned host "
                          "memory; median of %d calls" % (int(infos[k]["n_batches"]), reps)}
+    finally:
+        pinned.close()
+
+
+def group_leg(rows, reps=4):
+    """msgpu_group_overlap with the devices this process may use as members (here: one): rows in pinned host memory -> every
+    member's HBM -> index + shard -> wire-form slab -> ONE grouped RCCL all-gather -> merge -> merged list in host memory."""
+    from muchsalsa_amd import overlap
+    pinned = overlap.PinnedRows(rows)
+    try:
+        with overlap.OverlapGroup([0]) as grp:
+            grp.overlap(pinned, copy=False)  # warm-up: communicator, buffers
+            best = None
+            for _ in range(reps):
+                t, info = grp.overlap(pinned, copy=False)
+                if best is None or info["wall_ms"] < best["wall_ms"]:
+                    best = dict(info, n_edges=int(len(t["edges"])))
+        return {"members": int(best["n_members"]), "wall_ms": best["wall_ms"], "compute_ms": best["compute_ms"],
+                "exchange_ms": best["exchange_ms"], "overlap_pairs_per_s": best["n_edges"] / (best["wall_ms"] * 1e-3),
+                "slab_bytes": int(best["slab_bytes"]), "id_bytes": int(best["id_bytes"]),
+                "stage": "msgpu_group_overlap (C++, one process): rows in pinned host memory -> HBM of every member over its own link "
+                         "-> index + shard v1 %% n -> msgpu_pack_wire -> ncclGroupStart / ncclAllGather per member / ncclGroupEnd -> "
+                         "msgpu_merge_wire -> merged edge, order and id tables in host memory; %d member(s) here: a rehearsal of the "
+                         "path, not a scaling measurement" % int(best["n_members"])}
     finally:
         pinned.close()
 
@@ -1109,7 +1181,7 @@ def main():
         if partition_rows:
             del d_rows_s
 
-    h2h = asm_leg = graph_leg = None
+    h2h = asm_leg = graph_leg = grp_leg = None
     errors = {}
     if world == 1 and rank == 0 and not args.kernels_only:
         try:
@@ -1117,6 +1189,11 @@ def main():
                 h2h = host_to_host_leg(ctx, rows, args.batches)
         except Exception as exc:  # noqa: BLE001 -- the legs reported BESIDE the metric must never cost the metric line
             errors["host_to_host"] = "%s: %s" % (type(exc).__name__, exc)
+        if h2h is not None:
+            try:  # the in-process group (msgpu_group: what a C++ caller uses on a node) with one member: every step of its path
+                grp_leg = group_leg(rows)
+            except Exception as exc:  # noqa: BLE001
+                errors["group"] = "%s: %s" % (type(exc).__name__, exc)
         if args.assemble_window_mb >= 0 and not args.no_consensus:
             try:
                 ctx.load_rows_device(d_rows.data_ptr(), len(rows), keep_alive=d_rows)  # the job's tables again
@@ -1194,11 +1271,29 @@ def main():
                 "algorithmic_bytes_per_launch": int(alg_bytes), "kernel_ms": k_ms,
                 "note": "kernel_ms = the four launches together (HIP events around them on the launch stream); these "
                         "kernels are bound by vector-ALU issue, not by HBM (valu_issue_frac)"}
+        roof["time_share_of_value"] = k_ms / ms_per_step if ms_per_step > 0 else None
         if valu and k_ms > 0:
             # SQ_INSTS_VALU counts wave-instructions; one costs 4 cycles of its SIMD's issue (MI355X_MICROARCH.md); 1024 SIMDs
             insts = sum(valu.values())
             roof["valu_issue_frac"] = insts * 4.0 / (k_ms * 1e-3 * 2.4e9 * 1024)
             roof["valu_note"] = "SQ_INSTS_VALU of the four kernels (%s) x 4 cycles / (kernel_ms x 2.4 GHz x 1024 SIMDs)" % traffic_src
+        # every stage against the HBM roofline: algorithmic bytes (DESIGN.md section 4's formulas) / HIP-event time of the stage
+        # (stage markers of an extra step), counter traffic of the stage's kernels from the newest capture under profiles/
+        R_rows, P_emit = int(len(rows)), int(c.n_ems)
+        stage_alg = {"index": 40 * R_rows + 80 * R_rows,                       # rows in; by_read + by_anchor + scan view out
+                     "candidates": 16 * R_rows + 32 * P_emit + 8 * P_emit,     # scan view + scaffold rows read, (j, t) written
+                     "compact": 2 * (64 * int(c.n_orders) + 4 * int(c.n_ids))}  # order slots + ids read, dense tables written
+        stage_t = {"index": tm.index_ms, "candidates": tm.candidates_ms, "compact": tm.compact_ms}
+        roof_stages = {}
+        for name, nbytes in stage_alg.items():
+            t_ms = float(stage_t[name])
+            tr, src, used = pmc_stage(args.workload, world, STAGE_KERNELS[name])
+            ach = nbytes / (t_ms * 1e-3) / 1e9 if t_ms > 0 else 0.0
+            roof_stages[name] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                                 "algorithmic_bytes": int(nbytes), "stage_ms": t_ms, "traffic": tr, "traffic_source": src,
+                                 "traffic_kernels": used, "time_share_of_value": t_ms / ms_per_step if ms_per_step > 0 else None}
+        roof_stages["index"]["path"] = {0: "bin (no global atomic per row)", 1: "atomic", 2: "two-pass"}.get(int(c.index_path) & 3, "?") + (
+            " + generic scaffolds" if int(c.index_path) & 4 else "")
         out = {
             "metric": "overlap-pairs/s", "value": n_edges_total / (dt / args.steps), "unit": "overlap-pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
@@ -1214,8 +1309,9 @@ def main():
                                        "dp%d: one partition per rank, one RCCL all-gather + merge of the edge list per step on "
                                        "a communication stream" % world if weak else "edges sharded by v1 %% %d" % world),
                        "edges_proven_clean_rank0": int(c.n_edges_fastpath), "merged_edge_list_consistent": merge_ok,
-                       "note": "value = the overlap half of the metric with the row table resident in HBM; host_to_host = "
-                               "the same job from and to pinned host memory; the consensus half is under 'consensus' "
+                       "note": "value = the overlap half of the metric with the row table resident in HBM when the timed region "
+                               "starts (the bench contract); survey_8d_region = SURVEY 8(d)'s own region, host memory to host "
+                               "memory; host_to_host = that region's details; the consensus half is under 'consensus' "
                                "(gather kernel at full size), 'assemble_path' (assemblePath over the whole genome) and "
                                "'graph_stage' (the paths the real graph stage yields)"},
             "stage_ms": {"index": tm.index_ms, "candidates": tm.candidates_ms, "chain_total": tm.chain_ms,
@@ -1223,6 +1319,7 @@ def main():
                          "note": "index / candidates / chain_total / compact: stage markers (HIP events) of an extra step "
                                  "after the timed ones; chain_kernel: mean over the timed steps"},
             "roofline": roof,
+            "roofline_stages": roof_stages,
         }
         if multi:
             out["rccl_ranks"] = rccl_ranks if args.backend == "nccl" else None
@@ -1241,6 +1338,19 @@ def main():
                 out["consensus_system"] = cons_weak
         if h2h is not None:
             out["host_to_host"] = h2h
+            lean = h2h.get("without_edgematches") or {}
+            # SURVEY.md section 8(d) / BASELINE.md 3.4 define overlap-pairs/s over [row table in host memory -> order / edge
+            # tables in host memory].  The bench contract fixes `value` on inputs resident in HBM (the PCIe-inclusive rate "is
+            # never value"), so that region's figures stand here, at the top level, beside it.
+            out["survey_8d_region"] = {
+                "overlap_pairs_per_s": lean.get("overlap_pairs_per_s"), "ms": lean.get("ms"),
+                "region": "rows in pinned host memory -> edge, order and id tables in pinned host memory "
+                          "(msgpu_overlap_batched_ex, MSGPU_BATCH_NO_EDGEMATCHES: the EdgeMatch table stays in HBM, fetched per "
+                          "edge list by msgpu_get_edgematches); what pipeline.run / msgpu::assemble call",
+                "all_four_tables_overlap_pairs_per_s": h2h.get("overlap_pairs_per_s"), "all_four_tables_ms": h2h.get("ms"),
+                "note": "PCIe-inclusive: bounded by the host link (floor in host_to_host.floor), not by the kernels"}
+        if grp_leg is not None:
+            out["group"] = grp_leg
         if cons is not None:
             # algorithmic bytes on the 2-bit store: 0.25 B read + 1 B written per base (SURVEY 8(d) counted 1 B + 1 B for a
             # byte-per-base source; that figure is kept as "bytes_if_byte_store" for comparison)
@@ -1281,6 +1391,16 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_sample_reads, cores)
             except Exception as exc:  # noqa: BLE001
                 out["cpu_baseline"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+            try:  # one core on the workload of the line itself, beside the scaled samples
+                full = cpu_one_core_full(args.workload)
+                out["cpu_baseline"]["one_core_value"] = full["value"]
+                out["cpu_baseline"]["one_core_sample"] = full["sample"]
+                out["cpu_baseline"]["which_is_which"] = (
+                    "value: %d scaled samples run together, one per core (what a perfectly scaling multi-threaded port would reach); "
+                    "one_core_value: the C oracle on the WHOLE workload of this line, one core; one_core_quarter_sample_value: one "
+                    "scaled sample alone.  kind 'port': the oracle is ~9x faster than the reference it restates (DESIGN.md)" % cores)
+            except Exception as exc:  # noqa: BLE001
+                out["cpu_baseline"]["one_core_error"] = "%s: %s" % (type(exc).__name__, exc)
             try:
                 out["cpu_baseline"]["consensus"] = cpu_consensus_baseline()
             except Exception as exc:  # noqa: BLE001
