@@ -12,7 +12,7 @@ import csv,sys,re
 rows=list(csv.DictReader(open(sys.argv[1])))
 tot=0
 # steps in the trace = launches of the index pass (warm-up + timed + the stage-marker steps bench.py adds)
-steps=max([int(r["Calls"]) for r in rows if "k_index_pass1" in r["Name"]] or [1])
+steps=max([int(r["Calls"]) for r in rows if "k_compact" in r["Name"]] or [1])
 for r in rows:
     n=re.sub(r"\(.*","",r["Name"]).replace("void ","").replace("msgpu::","")
     if "rocclr" in n or "at::" in n: continue

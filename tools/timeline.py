@@ -6,7 +6,7 @@ import sys
 
 rows = list(csv.DictReader(open(sys.argv[1])))
 ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0].replace("void ", "").replace("msgpu::", "")[:44], r.get("Queue_Id")) for r in rows)
-starts = [i for i, e in enumerate(ev) if e[2].endswith("k_index_pass1")]
+starts = [i for i, e in enumerate(ev) if e[2].endswith(("k_index_pass1", "k_index_bin"))]
 k = int(sys.argv[2]) if len(sys.argv) > 2 else len(starts) // 2
 step = ev[starts[k] - 1:starts[k + 1] - 1]
 t0, prev_end, idle = step[0][0], step[0][0], 0
