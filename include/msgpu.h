@@ -750,6 +750,39 @@ int msgpu_graph_state(const msgpu_graph *g, uint8_t *vertex_alive, uint8_t *vert
  *   DiGraph::sortTopologically  libms/src/graph/Graph.cpp:359-395 (libms/tests/Graph_test.cpp:393-423) */
 int msgpu_graph_max_span_tree(uint32_t n_vertices, const uint32_t *a, const uint32_t *b, const uint64_t *weight,
                               const uint8_t *consensus, uint64_t n_edges, uint8_t *in_tree /* n_edges */);
+/* Graph / DiGraph bookkeeping on its own -- what the clean-up's deletions (src/main.cpp:243,259,286) and the component split
+ * (src/main.cpp:625 getSubgraph) rest on; the reference's tests hold vectors for it (libms/tests/Graph_test.cpp:81-277,
+ * 333-391: EdgeDeletion, VertexDeletion, Neighboor, Subgraph, Degree).  A flat graph of n_vertices and the pairs (a[i], b[i])
+ * -- undirected, or a -> b when directed != 0; a pair given twice is ONE edge, as Graph::addEdge has it (Graph.cpp:212-230) --
+ * is built by the stage's CSR builder; `ops` is run over it in order, with tombstones as the stage keeps them; every query
+ * appends to `out`:
+ *   MSGPU_GOP_DELETE_EDGE x y    Graph::deleteEdge (Graph.cpp:187-210); nothing when there is no such edge
+ *   MSGPU_GOP_DELETE_VERTEX x    Graph::deleteVertex (:158-185): the vertex and every edge at it
+ *   MSGPU_GOP_ORDER / _SIZE      getOrder() / getSize()                                   -> 1 word
+ *   MSGPU_GOP_HAS_EDGE x y       hasEdge (undirected: either way round)                   -> 0 | 1
+ *   MSGPU_GOP_NEIGHBORS x        getNeighbors (undirected) / getSuccessors (directed)     -> count, then the ids ascending
+ *   MSGPU_GOP_PREDECESSORS x     getPredecessors (directed only)                          -> count, ids
+ *   MSGPU_GOP_IN_DEGREE x / _OUT_DEGREE x   getInDegrees().at(x) / getOutDegrees().at(x)  -> 1 word (0xffffffff: x was deleted)
+ *   MSGPU_GOP_SUBGRAPH x y       getSubgraph of the y vertices listed in ops[x .. x + y) (entries MSGPU_GOP_ARG, .x = vertex)
+ *                                                                                         -> order, size, then (a, b) per edge
+ * *n_out = words the script produces; MSGPU_E_ARG when they do not fit out_capacity (call again with room) or an operand is
+ * out of range. */
+typedef struct msgpu_graph_op {
+  uint32_t op, x, y;
+} msgpu_graph_op;
+#define MSGPU_GOP_DELETE_EDGE 1u
+#define MSGPU_GOP_DELETE_VERTEX 2u
+#define MSGPU_GOP_ORDER 3u
+#define MSGPU_GOP_SIZE 4u
+#define MSGPU_GOP_HAS_EDGE 5u
+#define MSGPU_GOP_NEIGHBORS 6u
+#define MSGPU_GOP_PREDECESSORS 7u
+#define MSGPU_GOP_IN_DEGREE 8u
+#define MSGPU_GOP_OUT_DEGREE 9u
+#define MSGPU_GOP_SUBGRAPH 10u
+#define MSGPU_GOP_ARG 11u
+int msgpu_graph_bookkeeping(uint32_t n_vertices, const uint32_t *a, const uint32_t *b, uint64_t n_edges, int directed,
+                            const msgpu_graph_op *ops, size_t n_ops, uint32_t *out, size_t out_capacity, size_t *n_out);
 int msgpu_graph_connected_components(uint32_t n_vertices, const uint32_t *a, const uint32_t *b, const uint8_t *consensus,
                                      uint64_t n_edges, uint32_t *component /* n_vertices */, uint32_t *n_components);
 /* *n_path: in = capacity of path, out = vertices on the path (0 = unreachable); MSGPU_E_ARG when it does not fit */

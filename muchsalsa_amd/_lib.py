@@ -222,6 +222,8 @@ SYMBOLS = [
     ("msgpu_graph_state", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("msgpu_graph_max_span_tree", C.c_int, [C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64,
                                             C.c_void_p]),
+    ("msgpu_graph_bookkeeping", C.c_int, [C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_size_t,
+                                          C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     ("msgpu_graph_connected_components", C.c_int, [C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64,
                                                    C.c_void_p, C.POINTER(C.c_uint32)]),
     ("msgpu_graph_shortest_path", C.c_int, [C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_uint32,

@@ -204,6 +204,21 @@ struct Csr { // segment of vertex v: arcs[off[v] .. off[v+1]), ascending `to`
   }
 };
 
+// Graph::deleteVertex (Graph.cpp:158-185): the vertex goes, and with it every edge at it -- here: a tombstone per incident
+// edge (`bury`), over the out-arcs and, for a DiGraph, the in-arcs.  Shared by msgpu_graph::delete_vertex (the clean-up's
+// deletions, src/main.cpp:243,259,286) and msgpu_graph_bookkeeping (the reference's own test vectors for it).
+template <class Bury> inline void bury_vertex(const Csr &out, const Csr *in, uint32_t v, Bury &&bury) {
+  for (const Arc *t = out.begin(v); t != out.end(v); ++t) bury(t->e);
+  if (in)
+    for (const Arc *t = in->begin(v); t != in->end(v); ++t) bury(t->e);
+}
+// Graph::getNeighbors / DiGraph::getSuccessors / getPredecessors (Graph.cpp:232-287): the other ends of the vertex's living
+// edges, ascending (the reference hands out a hash map: no order)
+template <class Alive, class Emit> inline void living_neighbours(const Csr &c, uint32_t v, Alive &&alive, Emit &&emit) {
+  for (const Arc *t = c.begin(v); t != c.end(v); ++t)
+    if (alive(t->e)) emit(t->to);
+}
+
 // CSR of n vertices from m (from[i] -> to[i]) pairs, edge index i; both_ways = undirected.  Segments end up ascending
 // in `to` (counting sort by source keeps input order; a segment that is not ascending already is sorted).
 // The undirected adjacency of a large graph on all host threads, arc for arc what the serial builder below produces: every
@@ -595,7 +610,7 @@ struct msgpu_graph {
   }
   void delete_edge(uint32_t e) { E[e].alive = 0; }             // Graph::deleteEdge
   void delete_vertex(uint32_t v) {                              // Graph::deleteVertex
-    for (const Arc *t = adj.begin(v); t != adj.end(v); ++t) E[t->e].alive = 0;
+    bury_vertex(adj, nullptr, v, [&](uint32_t e) { E[e].alive = 0; });
     V[v].alive = 0;
   }
 };
@@ -2070,6 +2085,119 @@ int msgpu_graph_shortest_path(uint32_t n_vertices, const uint32_t *a, const uint
     *n_path                         = static_cast<uint32_t>(p.size());
     if (p.size() > cap) return MSGPU_E_ARG;
     std::copy(p.begin(), p.end(), path);
+  } catch (std::bad_alloc const &) { return MSGPU_E_NOMEM; }
+  return MSGPU_OK;
+}
+
+// Graph / DiGraph bookkeeping on its own (include/msgpu.h): a script of deletions and queries over a flat graph built by the
+// stage's CSR builder, tombstones as the stage keeps them.
+int msgpu_graph_bookkeeping(uint32_t n_vertices, const uint32_t *a, const uint32_t *b, uint64_t n_edges, int directed,
+                            const msgpu_graph_op *ops, size_t n_ops, uint32_t *out, size_t out_capacity, size_t *n_out) {
+  if (!edges_ok(n_vertices, a, b, n_edges) || (n_ops && !ops) || !n_out || (out_capacity && !out)) return MSGPU_E_ARG;
+  try {
+    // Graph::addEdge keeps ONE edge per vertex pair (per direction in a DiGraph): Graph.cpp:212-230 (hasEdge first)
+    std::vector<uint32_t> ea, eb;
+    {
+      std::vector<std::pair<uint32_t, uint32_t>> seen;
+      for (uint64_t i = 0; i < n_edges; ++i) {
+        std::pair<uint32_t, uint32_t> key(a[i], b[i]);
+        if (!directed && key.first > key.second) std::swap(key.first, key.second);
+        if (std::find(seen.begin(), seen.end(), key) != seen.end()) continue;
+        seen.push_back(key);
+        ea.push_back(a[i]);
+        eb.push_back(b[i]);
+      }
+    }
+    const size_t         m    = ea.size();
+    const Csr            outc = build_csr(n_vertices, ea.data(), eb.data(), m, !directed);
+    const Csr            inc  = directed ? build_csr(n_vertices, eb.data(), ea.data(), m, false) : Csr();
+    std::vector<uint8_t> ealive(m, 1), valive(n_vertices, 1);
+    size_t               w = 0;
+    auto push = [&](uint32_t x) {
+      if (w < out_capacity) out[w] = x;
+      ++w;
+    };
+    auto edge_of = [&](uint32_t x, uint32_t y) -> int64_t { // Graph::getEdge: undirected either way round, directed x -> y
+      const Arc *t = outc.find(x, y);
+      return t && ealive[t->e] ? static_cast<int64_t>(t->e) : -1;
+    };
+    auto alive_e = [&](uint32_t e) { return ealive[e] != 0; };
+    for (size_t k = 0; k < n_ops; ++k) {
+      const msgpu_graph_op &op = ops[k];
+      if (op.op != MSGPU_GOP_ORDER && op.op != MSGPU_GOP_SIZE && op.op != MSGPU_GOP_SUBGRAPH &&
+          (op.x >= n_vertices || ((op.op == MSGPU_GOP_DELETE_EDGE || op.op == MSGPU_GOP_HAS_EDGE) && op.y >= n_vertices)))
+        return MSGPU_E_ARG;
+      switch (op.op) {
+      case MSGPU_GOP_DELETE_EDGE: { // Graph::deleteEdge (Graph.cpp:187-210)
+        const int64_t e = edge_of(op.x, op.y);
+        if (e >= 0) ealive[static_cast<size_t>(e)] = 0;
+        break;
+      }
+      case MSGPU_GOP_DELETE_VERTEX: // Graph::deleteVertex
+        if (valive[op.x]) {
+          bury_vertex(outc, directed ? &inc : nullptr, op.x, [&](uint32_t e) { ealive[e] = 0; });
+          valive[op.x] = 0;
+        }
+        break;
+      case MSGPU_GOP_ORDER: push(static_cast<uint32_t>(std::count(valive.begin(), valive.end(), uint8_t(1)))); break;
+      case MSGPU_GOP_SIZE: push(static_cast<uint32_t>(std::count(ealive.begin(), ealive.end(), uint8_t(1)))); break;
+      case MSGPU_GOP_HAS_EDGE: push(edge_of(op.x, op.y) >= 0 ? 1u : 0u); break;
+      case MSGPU_GOP_NEIGHBORS: // getNeighbors (undirected) / getSuccessors (directed)
+      case MSGPU_GOP_PREDECESSORS: {
+        if (op.op == MSGPU_GOP_PREDECESSORS && !directed) return MSGPU_E_ARG;
+        const size_t at = w;
+        push(0);
+        uint32_t cnt = 0;
+        living_neighbours(op.op == MSGPU_GOP_PREDECESSORS ? inc : outc, op.x, alive_e, [&](uint32_t v) {
+          push(v);
+          ++cnt;
+        });
+        if (at < out_capacity) out[at] = cnt;
+        break;
+      }
+      case MSGPU_GOP_IN_DEGREE:
+      case MSGPU_GOP_OUT_DEGREE: { // DiGraph::getInDegrees / getOutDegrees of one living vertex
+        if (!directed) return MSGPU_E_ARG;
+        uint32_t cnt = 0;
+        living_neighbours(op.op == MSGPU_GOP_IN_DEGREE ? inc : outc, op.x, alive_e, [&](uint32_t) { ++cnt; });
+        push(valive[op.x] ? cnt : 0xffffffffu); // (a deleted vertex has no entry in the reference's degree maps)
+        break;
+      }
+      case MSGPU_GOP_SUBGRAPH: {
+        // Graph::getSubgraph (Graph.cpp:317-326): the listed vertices and every living edge between two of them -- the rule
+        // by which a connected component becomes its own graph (getDirectedGraph's walk keeps to comp_of == cid).  x = first
+        // entry of the vertex list inside `ops` (entries with op MSGPU_GOP_ARG, x = vertex), y = their number.  Emits the
+        // order, the size, then the edges as (a, b) pairs in table order.
+        if (static_cast<size_t>(op.x) + op.y > n_ops) return MSGPU_E_ARG;
+        std::vector<uint8_t> member(n_vertices, 0);
+        uint32_t             order = 0;
+        for (uint32_t q = 0; q < op.y; ++q) {
+          const msgpu_graph_op &arg = ops[op.x + q];
+          if (arg.op != MSGPU_GOP_ARG || arg.x >= n_vertices) return MSGPU_E_ARG;
+          if (valive[arg.x] && !member[arg.x]) {
+            member[arg.x] = 1;
+            ++order;
+          }
+        }
+        push(order);
+        const size_t at = w;
+        push(0);
+        uint32_t cnt = 0;
+        for (size_t e = 0; e < m; ++e)
+          if (ealive[e] && member[ea[e]] && member[eb[e]]) {
+            push(ea[e]);
+            push(eb[e]);
+            ++cnt;
+          }
+        if (at < out_capacity) out[at] = cnt;
+        break;
+      }
+      case MSGPU_GOP_ARG: break; // (data of a MSGPU_GOP_SUBGRAPH entry)
+      default: return MSGPU_E_ARG;
+      }
+    }
+    *n_out = w;
+    if (w > out_capacity) return MSGPU_E_ARG;
   } catch (std::bad_alloc const &) { return MSGPU_E_NOMEM; }
   return MSGPU_OK;
 }

