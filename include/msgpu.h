@@ -186,6 +186,10 @@ const char *msgpu_last_error(const msgpu_ctx *ctx);
  *        msgpu_stream_release(ctx, s) after it -- s waits for what the context has queued so far (two event operations,
  *        no host wait);
  *      - a host wait: the caller synchronises its stream before the call and calls msgpu_synchronize(ctx) after it.
+ *    A sequence store (msgpu_seqctx, below) is a context of its own with a stream of its own, and the same rule holds for
+ *    the caller's device buffers it touches: msgpu_seq_upload_device (d_bases, read), msgpu_gather_run (d_out, written),
+ *    msgpu_fasta_format (d_raw read, d_text written), msgpu_edit_distance (d_a, d_b read); its entry points take the stream to
+ *    queue on as `hip_stream` (NULL = the store's own), msgpu_seq_synchronize is its host wait.
  * 4. msgpu_last_error is meaningful only after a call returned a non-zero code.
  * 5. A context is NOT thread-safe: one host thread at a time.  One exception, what an exchange thread needs:
  *    msgpu_merge_gathered_ex / msgpu_merge_wire with a hip_stream of the caller's may run on a second thread beside any

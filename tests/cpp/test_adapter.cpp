@@ -62,15 +62,19 @@ struct EdgeMatch {
 };
 struct MatchMap {
   std::size_t nVertexMatches = 0, nEdgeMatches = 0;
-  std::map<std::pair<unsigned, unsigned>, std::size_t> vm;
+  std::map<std::pair<unsigned, unsigned>, std::shared_ptr<VertexMatch>> vm;
+  std::map<Edge const *, std::vector<std::pair<unsigned, std::shared_ptr<EdgeMatch>>>> em; // per edge, in insertion order
   void addVertexMatch(unsigned n, unsigned i, std::shared_ptr<VertexMatch> const &m) {
     auto it = vm.find({n, i});
-    if (it == vm.end() || it->second > m->lineNumber) { // lowest line wins (MatchMap.cpp:64-80)
+    if (it == vm.end() || it->second->lineNumber > m->lineNumber) { // lowest line wins (MatchMap.cpp:64-80)
       if (it == vm.end()) ++nVertexMatches;
-      vm[{n, i}] = m->lineNumber;
+      vm[{n, i}] = m;
     }
   }
-  void addEdgeMatch(Edge const *, unsigned, std::shared_ptr<EdgeMatch> const &) { ++nEdgeMatches; }
+  void addEdgeMatch(Edge const *e, unsigned anchor, std::shared_ptr<EdgeMatch> const &m) {
+    ++nEdgeMatches;
+    em[e].emplace_back(anchor, m);
+  }
 };
 struct Registry {
   std::unordered_map<std::string, unsigned> ids;
@@ -146,6 +150,49 @@ int main(int argc, char **argv) {
   mock::Registry rn, ri;
   msgpu::fillReferenceObjects<mock::Vertex, mock::VertexMatch, mock::EdgeMatch, mock::EdgeOrder>(core, t, graph, matchMap,
                                                                                                 rn, ri);
+  if (argc >= 3) { // every object the adapter filled, one line each, for the comparison with the oracle's tables
+    auto bits = [](double d) {
+      unsigned long long u;
+      std::memcpy(&u, &d, 8);
+      return u;
+    };
+    std::FILE *f = std::fopen(argv[2], "w");
+    if (!f) return 3;
+    for (auto const &kv : graph.vertices) std::fprintf(f, "V %u %zu %zu\n", kv.second->id, kv.second->len, kv.second->line);
+    for (auto const &kv : matchMap.vm) {
+      auto const &m = *kv.second;
+      std::fprintf(f, "VM %u %u %d %d %d %d %016llx %d %zu %d %zu\n", kv.first.first, kv.first.second, m.nanoporeRange.first,
+                   m.nanoporeRange.second, m.illuminaRange.first, m.illuminaRange.second, bits(m.rRatio), int(m.direction), m.score,
+                   int(m.isPrimary), m.lineNumber);
+    }
+    for (auto const &kv : graph.edges) {
+      std::fprintf(f, "E %u %u %d %zu\n", kv.first.first, kv.first.second, int(kv.second->shadow), kv.second->orders.size());
+      auto const it = matchMap.em.find(kv.second.get());
+      if (it != matchMap.em.end())
+        for (auto const &am : it->second)
+          std::fprintf(f, "EM %u %u %u %d %d %d %016llx %d %zu\n", kv.first.first, kv.first.second, am.first, am.second->overlap.first,
+                       am.second->overlap.second, int(am.second->direction), bits(am.second->score), int(am.second->isPrimary),
+                       am.second->lineNumber);
+      std::size_t k = 0;
+      for (auto const &o : kv.second->orders) {
+        std::fprintf(f, "O %u %u %zu %u %u %u %016llx %016llx %d %zu %d %d", kv.first.first, kv.first.second, k++, o.startVertex->id,
+                     o.endVertex->id, o.baseVertex->id, bits(o.leftOffset), bits(o.rightOffset), int(o.isContained), o.score,
+                     int(o.direction), int(o.isPrimary));
+        for (unsigned id : o.ids) std::fprintf(f, " %u", id);
+        std::fputc('\n', f);
+      }
+    }
+    std::fclose(f);
+    // the same job on a group of one device (msgpu_group_overlap through RCCL): the merged tables are these tables
+    msgpu_group_tables const gt = core.overlapOnDevices({0});
+    if (gt.n_edges != t.edges.size() || gt.n_orders != t.orders.size() || gt.n_ids != t.ids.size() ||
+        std::memcmp(gt.edges, t.edges.data(), t.edges.size() * sizeof(msgpu_edge)) != 0 ||
+        std::memcmp(gt.orders, t.orders.data(), t.orders.size() * sizeof(msgpu_order)) != 0 ||
+        std::memcmp(gt.ids, t.ids.data(), t.ids.size() * 4) != 0) {
+      std::puts("FAIL: overlapOnDevices({0}) differs from the single-context tables");
+      return 1;
+    }
+  }
   std::size_t orders = 0, shadows = 0, ids = 0;
   for (auto const &kv : graph.edges) {
     orders += kv.second->orders.size();

@@ -60,3 +60,54 @@ def test_cfg1_plumbing(oracle, tmp_path):
     # the FASTQ index path of the same config
     fq = S.SeqFile(os.path.join(GOLD, "fastq.fq"))
     assert [fq.sequence(i).decode() for i in range(len(fq))] == sa["FastQTest"]["nanopore"]
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_cfg1_on_the_gpu(oracle, tmp_path):
+    """The GPU-visible half of BASELINE.json configs[0]: the same four PAF lines through the loader, the HBM index build, the
+    candidate scan and the chain kernels (msgpu_load_rows .. msgpu_chaining_and_overlaps, then the resident dispatcher and a
+    group of one) == the oracle's tables in every field; and the reference's test_data/fasta.fa through the HBM sequence
+    store and the gather kernel (both store forms): the anchor segments of the job's one EdgeMatch, byte for byte."""
+    import torch
+    from helpers import assert_tables_equal
+    path = tmp_path / "cfg1.paf"
+    path.write_text(PAF)
+    paf = overlap.parse_paf(str(path))
+    want = oracle.overlap(paf.rows)
+    with overlap.OverlapContext(0) as ctx:
+        ctx.load_rows(paf.rows)
+        ctx.calculate_edges()
+        ctx.chaining_and_overlaps()
+        assert_tables_equal(ctx.tables(), want, "cfg1")
+        rl, fl = ctx.reads()
+        assert list(rl) == [1231, 1020] and list(fl) == [0, 1]
+        lean, _ = ctx.overlap_batched(paf.rows, 2, resident=True, edgematches=False)
+        assert_tables_equal(dict(lean, ems=ctx.tables()["ems"]), want, "cfg1, resident dispatcher")
+    with overlap.OverlapGroup([0]) as grp:
+        t, info = grp.overlap(paf.rows)
+        assert_tables_equal(dict(t, ems=want["ems"]), want, "cfg1, group of one")
+    em = want["ems"][0]
+    sa = json.load(open(os.path.join(GOLD, "sa_test_expected.json")))
+    unitig = sa["FastaTest"]["sequences"][0].encode()
+    f = S.SeqFile(os.path.join(GOLD, "fasta.fa"))
+    rid = np.array([paf.read_names.index(n) if n in paf.read_names else 0xffffffff for n in f.names], dtype=np.uint32)
+    aid = np.array([paf.anchor_names.index(n) if n in paf.anchor_names else 0xffffffff for n in f.names], dtype=np.uint32)
+    for packed in (False, True):
+        st = S.SeqStore(device=0)
+        st.upload(S.NANOPORE, f, rid, len(paf.read_names))
+        st.upload(S.ILLUMINA, f, aid, len(paf.anchor_names))
+        if packed:
+            st.pack()
+        for row, direction in ((paf.rows[0], True), (paf.rows[1], True), (paf.rows[1], False)):
+            pieces, n = st.seg_anchor(row, (int(em["ov_lo"]), int(em["ov_hi"])), direction)
+            plan = st.plan(pieces)
+            out = torch.full((n + 64,), 0x2e, dtype=torch.uint8, device="cuda:0")
+            torch.cuda.synchronize()  # (the store's stream is its own: include/msgpu.h, STREAM CONTRACT rule 3)
+            st.run(plan, out.data_ptr(), n)
+            st.synchronize()
+            host = out.cpu().numpy()
+            assert host[:n].tobytes() == oracle.anchor_sequence(row, unitig, (200, 909), direction) and (host[n:] == 0x2e).all()
+        st.close()

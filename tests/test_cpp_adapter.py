@@ -32,7 +32,8 @@ def test_adapter_end_to_end_fills_reference_shaped_objects(adapter_bin, oracle, 
     tab = synth.paf_table(300, 4000, 1000, 31)
     path = tmp_path / "in.paf"
     path.write_text("\n".join(synth.paf_lines(tab)) + "\n")
-    r = subprocess.run([adapter_bin, str(path)], capture_output=True, text=True, timeout=300)
+    dump = tmp_path / "objects.txt"
+    r = subprocess.run([adapter_bin, str(path), str(dump)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     got = json.loads(r.stdout.strip().splitlines()[-1])
     rows = oracle.parse_paf(str(path))["rows"]
@@ -40,6 +41,41 @@ def test_adapter_end_to_end_fills_reference_shaped_objects(adapter_bin, oracle, 
     assert got == {"vertices": int(rows["read_id"].max()) + 1, "edges": len(t["edges"]),
                    "vertexmatches": t["rows_alive"], "edgematches": len(t["ems"]), "orders": len(t["orders"]),
                    "shadows": t["shadow_edges"], "ids": len(t["ids"])}
+    # ... and the OBJECTS themselves: every Vertex, VertexMatch, Edge (shadow flag), EdgeMatch and EdgeOrder (vertices, offsets
+    # bit for bit, score, flags, ids) that fillReferenceObjects put into the reference-shaped containers, against the oracle's
+    # tables.  (The test's PAF names reads and anchors in id order, so the mock registries number them as the loader did.)
+    import struct
+    bits = lambda d: "%016x" % struct.unpack("<Q", struct.pack("<d", float(d)))[0]  # noqa: E731
+    want = []
+    for v in range(len(t["read_len"])):
+        want.append("V %d %d %d" % (v, t["read_len"][v], t["read_first_line"][v]))
+    best = {}
+    for r_ in rows:  # lowest line per (read, anchor): MatchMap.cpp:64-80
+        k = (int(r_["read_id"]), int(r_["anchor_id"]))
+        if k not in best or int(best[k]["line"]) > int(r_["line"]):
+            best[k] = r_
+    for (rd, an), r_ in sorted(best.items()):
+        rr = float(int(r_["i_hi"]) - int(r_["i_lo"]) + 1) / float(int(r_["n_hi"]) - int(r_["n_lo"]) + 1)
+        want.append("VM %d %d %d %d %d %d %s %d %d %d %d" % (rd, an, r_["n_lo"], r_["n_hi"], r_["i_lo"], r_["i_hi"], bits(rr),
+                                                            int(r_["flags"]) & 1, r_["score"], (int(r_["flags"]) >> 1) & 1, r_["line"]))
+    e, em, o, ids = t["edges"], t["ems"], t["orders"], t["ids"]
+    for i in range(len(e)):
+        v1, v2 = int(e["v1"][i]), int(e["v2"][i])
+        want.append("E %d %d %d %d" % (v1, v2, e["shadow"][i], e["order_cnt"][i]))
+        for m in em[int(e["em_off"][i]): int(e["em_off"][i]) + int(e["em_cnt"][i])]:
+            want.append("EM %d %d %d %d %d %d %s %d %d" % (v1, v2, m["anchor_id"], m["ov_lo"], m["ov_hi"], int(m["flags"]) & 1,
+                                                          bits(m["score"]), (int(m["flags"]) >> 1) & 1, m["line"]))
+        for k, q in enumerate(o[int(e["order_off"][i]): int(e["order_off"][i]) + int(e["order_cnt"][i])]):
+            fl = int(q["flags"])
+            want.append(("O %d %d %d %d %d %d %s %s %d %d %d %d" % (v1, v2, k, q["start"], q["end"], q["base"], bits(q["left_offset"]),
+                                                                   bits(q["right_offset"]), (fl >> 1) & 1, q["score"], (fl >> 2) & 1,
+                                                                   (fl >> 3) & 1)) +
+                        "".join(" %d" % x for x in ids[int(q["ids_off"]): int(q["ids_off"]) + int(q["ids_cnt"])]))
+    have = dump.read_text().splitlines()
+    assert len(have) == len(want) and sorted(have) == sorted(want)
+    # EdgeMatches and EdgeOrders keep their order inside an edge (vStart order; minus paths first): compare those in sequence
+    seq = lambda lines, tag: [ln for ln in lines if ln.startswith(tag)]  # noqa: E731
+    assert seq(have, "EM ") == seq(want, "EM ") and seq(have, "O ") == seq(want, "O ")
 
 
 @pytest.mark.gpu
