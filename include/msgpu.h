@@ -577,7 +577,7 @@ int msgpu_seq_synchronize(msgpu_seqctx *ctx);
  * the texts are what OutputWriter::writeTarget / writeQuery / writePaf (OutputWriter.cpp:49-62) receive, in path order.
  *
  * Hash-order note: where ap.cpp iterates std::unordered_map / unordered_set (graph vertices, edges, successors, tap
- * entries) the reference's order is unspecified; this library uses ascending ids / creation order. */
+ * entries) the reference's order is unspecified; this library uses ascending ids / creation order ("canonical order"). */
 typedef struct msgpu_path_read {
   uint32_t read_id;          /* Vertex::getId()                                         */
   uint32_t direction;        /* Vertex::getVertexDirection(): 1 = e_POS, 0 = e_NEG, 2 = e_NONE */
@@ -694,7 +694,7 @@ int msgpu_fasta_format(msgpu_seqctx *ctx, const void *d_raw, const msgpu_fasta_r
  * getDirectedGraph (dg.cpp:35-121) + linearizeGraph (lg.cpp:41-629) as the assemblePaths job does (main.cpp:620-661).
  * Input: the tables of msgpu_copy_tables / msgpu_copy_reads (copied) and the result of msgpu_find_contraction_edges.
  * Output: one msgpu_path_input per linearised path, ready for msgpu_assembly_add_paths.  Iteration orders the
- * reference leaves to hash containers follow DESIGN.md section 9.  MSGPU_E_LAYOUT = the reference would terminate. */
+ * reference leaves to hash containers follow DESIGN.md section 2, "canonical order".  MSGPU_E_LAYOUT = the reference would terminate. */
 typedef struct msgpu_graph msgpu_graph;
 typedef struct msgpu_graph_stats {
   uint64_t n_vertices_in, n_edges_in;

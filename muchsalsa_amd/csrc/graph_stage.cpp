@@ -29,7 +29,7 @@
 //    is re-solved.
 //
 // Iteration orders the reference leaves to hash containers (or to pointer VALUES: lg.cpp:419, main.cpp:211) are fixed
-// as in DESIGN.md section 9: vertices ascending id, edges in creation order (table order for the undirected graph),
+// as in DESIGN.md section 2, "canonical order": vertices ascending id, edges in creation order (table order for the undirected graph),
 // neighbours ascending id, std::sort ties stable, pointer-ordered containers ordered by vertex id.
 #include <algorithm>
 #include <atomic>

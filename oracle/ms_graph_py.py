@@ -15,7 +15,7 @@ inputs only.  PARITY UNPINNED: no reference test covers these functions and the 
 
 Hash-order: the reference iterates unordered containers keyed by pointers (and one std::map / std::set ordered by
 pointer VALUE, lg.cpp:419, main.cpp:211) in places where the order changes the result, so it differs between runs.
-This restatement fixes one admissible order, the same the product uses: vertices ascending id,
+This restatement fixes one admissible order, the same the product uses ("canonical order"): vertices ascending id,
 edges in creation order (the undirected graph's edges in (v1, v2) table order), neighbours ascending id, std::sort
 ties stable, pointer-ordered containers ordered by vertex id.
 """

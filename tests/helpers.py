@@ -24,7 +24,7 @@ def assert_tables_equal(got, want, what=""):
             assert len(bad) == 0, "%s %s differs at %d entries, first %d" % (what, name, len(bad), bad[0])
 
 
-# north_star: "consensus sequences within a stated edit-distance tolerance" (DESIGN.md section 9).
+# north_star: "consensus sequences within a stated edit-distance tolerance" ("canonical order").
 #  * against the restatement of ap.cpp (oracle/ms_assemble_py.py) on the same input: edit distance 0 -- the three output
 #    texts are compared byte for byte;
 #  * against the genome the reads were cut from, with exact PAF coordinates: at most this many edits per placed anchor

@@ -109,7 +109,7 @@ def test_assemble_path_whole_genome(oracle, cfg, two_bit, tmp_path):
     """The consensus half at full size: chains of reads tiling the WHOLE synthetic genome (window = G) over the overlap
     tables the GPU just produced -> assemblePath (host layout on all host threads, one gather + FASTA wrapping on the
     device) -> temp_1.{target.fa, query.fa, align.paf} byte-identical to oracle/ms_assemble_py.py on the same input.
-    A9 tolerance: edit distance 0 against the restatement."""
+    A9 tolerance ("canonical order"): edit distance 0 against the restatement."""
     from oracle.ms_assemble_py import assemble_path
     from muchsalsa_amd import overlap, synth
     from muchsalsa_amd.assembly import Assembly

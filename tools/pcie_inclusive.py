@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""PCIe-inclusive rate of the overlap path (host row table -> host result tables), for DESIGN.md section 5.
+"""PCIe-inclusive rate of the overlap path (host row table -> host result tables), for DESIGN.md section 5 (survey_8d_region).
 Never bench.py's `value` (that one starts with the rows resident in HBM)."""
 import sys
 import time
