@@ -188,6 +188,23 @@ def test_index_bin_path_and_atomic_path_agree(oracle, monkeypatch):
     assert_tables_equal(t, oracle.overlap(long_rows), "long reads")
 
 
+def test_index_bin_path_takes_several_passes_beyond_131072_reads(oracle):
+    """k_index_bin bins 8192 buckets of 16 read ids per pass: 139,978 reads take two passes over the row table (the second one's
+    buckets start behind the first one's rows in by_read).  Every table equal to the oracle's; the Vertex facts too."""
+    from muchsalsa_amd import _lib, overlap, synth
+    rows = synth.synth_rows(140000, 1500, 120000, 17)
+    assert int(rows["read_id"].max()) + 1 > 131072
+    want = oracle.overlap(rows)
+    with overlap.OverlapContext(0) as ctx:
+        ctx.load_rows(rows)
+        ctx.calculate_edges()
+        ctx.chaining_and_overlaps()
+        assert int(ctx.counts().index_path) == _lib.INDEX_BIN
+        assert_tables_equal(ctx.tables(), want, "two passes")
+        rl, fl = ctx.reads()
+        assert np.array_equal(rl, want["read_len"]) and np.array_equal(fl, want["read_first_line"])
+
+
 def test_sub_wavefront_and_whole_wavefront_chaining_agree(oracle, monkeypatch):
     """Edges of <= 32 EdgeMatches share a wavefront (k_chain_sub<8|16|32>), longer ones take one each (k_chain):
     MSGPU_NO_SUBWAVE=1 sends every edge through k_chain.  Both must give the oracle's tables; the workload has edges

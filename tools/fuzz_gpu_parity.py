@@ -96,6 +96,8 @@ def main():
     n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
     oracle.build()
+    group = overlap.OverlapGroup([0])  # msgpu_group_overlap with one member: the C++ multi-GPU path, through RCCL
+    paths = {}
     for case in range(n_cases):
         rng = np.random.default_rng(seed0 + case)
         n_reads = int(rng.integers(50, 700))
@@ -122,8 +124,23 @@ def main():
             feed = np.concatenate([rows, dup])
             rng.shuffle(feed)
         what = "case %d (reads %d, len %d, anchors %d, cov %d, mode %d)" % (case, n_reads, read_len, n_anchors, cov, mode)
-        got = overlap.build_overlaps(feed)
+        with overlap.OverlapContext(0) as ctx0:
+            ctx0.load_rows(feed)
+            ctx0.calculate_edges()
+            ctx0.chaining_and_overlaps()
+            got, ipath = ctx0.tables(), int(ctx0.counts().index_path)
         assert_tables_equal(got, want, what)
+        paths[ipath] = paths.get(ipath, 0) + 1
+        if ipath == 0:  # the bin path took it: the atomic path must give the same tables (and the per-read Vertex facts)
+            os.environ["MSGPU_NO_BIN"] = "1"
+            try:
+                assert_tables_equal(overlap.build_overlaps(feed), want, what + ", atomic index path")
+            finally:
+                del os.environ["MSGPU_NO_BIN"]
+        if case % 4 == 0:
+            gt, ginfo = group.overlap(feed)
+            assert_tables_equal(dict(gt, ems=want["ems"]), want, what + ", group of one")
+            assert np.array_equal(gt["read_len"], want["read_len"]) and np.array_equal(gt["read_first_line"], want["read_first_line"])
         with overlap.OverlapContext(0) as ctx:  # and the same job as windows of owner reads
             nb = int(rng.integers(1, 12))
             got, _ = ctx.overlap_batched(feed, nb)
@@ -146,8 +163,10 @@ def main():
         edit_distances(rng, what)
         scaf = np.bincount(rows["anchor_id"]).max() if len(rows) else 0
         n = want["edges"]["em_cnt"]
-        print("case %3d ok: %6d rows %6d edges, EdgeMatches per edge max %3d, orders %6d, longest scaffold %d" % (
-            case, len(rows), len(n), int(n.max()) if len(n) else 0, len(want["orders"]), int(scaf)), flush=True)
+        print("case %3d ok: %6d rows %6d edges, EdgeMatches per edge max %3d, orders %6d, longest scaffold %d, index path %d" % (
+            case, len(rows), len(n), int(n.max()) if len(n) else 0, len(want["orders"]), int(scaf), ipath), flush=True)
+    group.close()
+    print("index paths taken (0 bin, 1 atomic, 2 two-pass, +4 generic scaffolds):", dict(sorted(paths.items())), flush=True)
 
 
 if __name__ == "__main__":
