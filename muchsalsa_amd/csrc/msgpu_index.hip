@@ -248,6 +248,64 @@ struct BinLds { // views into the dynamic LDS block, [cap] each
   uint16_t *idx;           // arrival positions grouped by read
 };
 
+// value of lane ^ J: quad permutes for 1 and 2, ds_swizzle (bit mode: and 0x1f, xor J; no LDS memory touched) for 4, 8, 16,
+// a shuffle for 32
+template <int J> __device__ __forceinline__ uint32_t lane_xor(uint32_t v) {
+  if (J == 1) return static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0xB1, 0xf, 0xf, false)); // quad_perm:[1,0,3,2]
+  if (J == 2) return static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x4E, 0xf, 0xf, false)); // quad_perm:[2,3,0,1]
+  if (J == 4) return static_cast<uint32_t>(__builtin_amdgcn_ds_swizzle(static_cast<int>(v), 0x101f));
+  if (J == 8) return static_cast<uint32_t>(__builtin_amdgcn_ds_swizzle(static_cast<int>(v), 0x201f));
+  if (J == 16) return static_cast<uint32_t>(__builtin_amdgcn_ds_swizzle(static_cast<int>(v), 0x401f));
+  return static_cast<uint32_t>(__shfl_xor(static_cast<int>(v), 32));
+}
+// lanes that keep the SMALLER key of their pair in the stage (block size KB, distance J): the lower lane of a pair inside an
+// ascending block (bit KB of the lane clear; the last merge, KB = 64, is ascending throughout), the upper lane inside a
+// descending one
+constexpr unsigned long long bitonic_min_mask(int KB, int J) {
+  unsigned long long m = 0;
+  for (int l = 0; l < 64; ++l) {
+    const bool asc = KB == 64 || (l & KB) == 0, lower = (l & J) == 0;
+    if (lower == asc) m |= 1ull << l;
+  }
+  return m;
+}
+template <int KB, int J>
+__device__ __forceinline__ void bitonic_stage(uint32_t &khi, uint32_t &klo, uint32_t &org) {
+  constexpr unsigned long long MIN = bitonic_min_mask(KB, J);
+  const uint32_t ph = lane_xor<J>(khi), pl = lane_xor<J>(klo), po = lane_xor<J>(org);
+  const uint64_t mine = (static_cast<uint64_t>(khi) << 32) | klo, other = (static_cast<uint64_t>(ph) << 32) | pl;
+  // both lanes of a pair reach the same verdict: the one that keeps the minimum takes a smaller partner, the other one a larger
+  // partner; equal keys stay where they are (and are found afterwards)
+  const unsigned long long take = (__ballot(other < mine) & MIN) | (__ballot(mine < other) & ~MIN);
+  const bool               t    = __builtin_amdgcn_inverse_ballot_w64(take);
+  khi = t ? ph : khi;
+  klo = t ? pl : klo;
+  org = t ? po : org;
+}
+__device__ __forceinline__ void bitonic_sort64(uint32_t &khi, uint32_t &klo, uint32_t &org, int) {
+  bitonic_stage<2, 1>(khi, klo, org);
+  bitonic_stage<4, 2>(khi, klo, org);
+  bitonic_stage<4, 1>(khi, klo, org);
+  bitonic_stage<8, 4>(khi, klo, org);
+  bitonic_stage<8, 2>(khi, klo, org);
+  bitonic_stage<8, 1>(khi, klo, org);
+  bitonic_stage<16, 8>(khi, klo, org);
+  bitonic_stage<16, 4>(khi, klo, org);
+  bitonic_stage<16, 2>(khi, klo, org);
+  bitonic_stage<16, 1>(khi, klo, org);
+  bitonic_stage<32, 16>(khi, klo, org);
+  bitonic_stage<32, 8>(khi, klo, org);
+  bitonic_stage<32, 4>(khi, klo, org);
+  bitonic_stage<32, 2>(khi, klo, org);
+  bitonic_stage<32, 1>(khi, klo, org);
+  bitonic_stage<64, 32>(khi, klo, org);
+  bitonic_stage<64, 16>(khi, klo, org);
+  bitonic_stage<64, 8>(khi, klo, org);
+  bitonic_stage<64, 4>(khi, klo, org);
+  bitonic_stage<64, 2>(khi, klo, org);
+  bitonic_stage<64, 1>(khi, klo, org);
+}
+
 template <int K>
 __device__ __forceinline__ bool sort_bin_read(uint32_t r, uint32_t n, uint32_t b /*first by_read row*/, uint32_t off /*first LDS row*/,
                                               int lane, const BinLds &s, IRow *by_read, IRow *by_anchor, uint4 *vis,
@@ -281,19 +339,21 @@ __device__ __forceinline__ bool sort_bin_read(uint32_t r, uint32_t n, uint32_t b
   }
   bool ranked = false;
   if (K == 1) {
-    // One row per lane: rank by the nanopore range alone, as one order-preserving 64-bit key -- two readlanes, one compare,
-    // one add-with-carry per row -- and note whether two rows share a range (then the anchor decides, below).  Duplicate
-    // (read, anchor) pairs are pass 1's to find.
-    const uint32_t     klo = static_cast<uint32_t>(mhi[0]) ^ 0x80000000u, khi = static_cast<uint32_t>(mlo[0]) ^ 0x80000000u;
-    const uint64_t     mkey = (static_cast<uint64_t>(khi) << 32) | klo;
-    unsigned long long tie  = 0;
-    for (int t = 0; t < static_cast<int>(n); ++t) {
-      const uint64_t okey = (static_cast<uint64_t>(rl_u32(khi, t)) << 32) | rl_u32(klo, t);
-      less[0] += okey < mkey ? 1u : 0u;
-      tie |= __ballot(okey == mkey) & ~(1ull << t);
-    }
-    ranked = tie == 0;
-    if (!ranked) less[0] = 0;
+    // One row per lane: SORT (nanopore range as one order-preserving 64-bit key, original lane as payload) with a bitonic
+    // network over the wavefront -- 21 compare-exchange stages of two compares and three selects, partners through DPP /
+    // ds_swizzle -- instead of broadcasting every row to every lane (n x (2 readlanes + 2 compares + add)): the broadcast
+    // loop was what bounded this kernel (about 1,000 instructions per read).  Lanes without a row hold the largest key and
+    // sort to the end.  Two rows with the same range (the anchor decides then) show up as equal neighbours afterwards: the
+    // broadcast loop below ranks such a read.  Duplicate (read, anchor) pairs are pass 1's to find.
+    uint32_t khi = static_cast<uint32_t>(mlo[0]) ^ 0x80000000u, klo = static_cast<uint32_t>(mhi[0]) ^ 0x80000000u;
+    if (static_cast<uint32_t>(lane) >= n) khi = klo = 0xffffffffu;
+    uint32_t org = static_cast<uint32_t>(lane);
+    bitonic_sort64(khi, klo, org, lane);
+    const uint32_t nhi = static_cast<uint32_t>(__shfl_down(static_cast<int>(khi), 1)), nlo = static_cast<uint32_t>(__shfl_down(static_cast<int>(klo), 1));
+    const bool     tie = lane < 63 && static_cast<uint32_t>(lane) < n && nhi == khi && nlo == klo; // (lane n - 1 against a lane without a row: a row with the largest key)
+    ranked = __ballot(tie) == 0;
+    // lane p holds the row that came from lane org: that row's rank is p
+    if (ranked) less[0] = static_cast<uint32_t>(__builtin_amdgcn_ds_permute(static_cast<int>(org << 2), lane));
   }
   if (!ranked)
 #pragma unroll

@@ -1284,11 +1284,16 @@ __device__ __forceinline__ NanoMasks nano_check(double k_clo, double k_chi, doub
   }
   // fwd2 | fwd1 = (ovl & lt_lo & lt_hi) | (~ovl & lt_lo),  bwd2 | bwd1 = (ovl & gt_lo & gt_hi) | (~ovl & ~lt_lo), written
   // with few scalar instructions (the loop keeps the scalar unit about half busy, the vector unit at 80-85 %)
-  f.pos = lt_lo & (lt_hi | ~f.ovl);
-  if (WF) // without an overlap exactly one of lt_lo / gt_lo holds (lo <= hi on both sides), so ~(ovl | lt_lo) = ~ovl & gt_lo
-    f.neg = gt_lo & (gt_hi | ~f.ovl);
-  else
+  if (WF) {
+    // lo <= hi on both sides: ranges that do not overlap and k starts first means k ends before l starts (k_chi < l_clo <=
+    // l_chi), so lt_hi holds without asking for the overlap -- and the same for gt: pos = lt_lo & lt_hi, neg = gt_lo & gt_hi
+    // cover orientation +-1 and +-2 alike (the scalar unit is as busy as the vector unit in this loop: four instructions less)
+    f.pos = lt_lo & lt_hi;
+    f.neg = gt_lo & gt_hi;
+  } else {
+    f.pos = lt_lo & (lt_hi | ~f.ovl);
     f.neg = (f.ovl & gt_lo & gt_hi) | ~(f.ovl | lt_lo);
+  }
   // abort when the raw ranges overlap and their order contradicts the corrected orientation (:93-109)
   if (SORTED) {
     const M rovl = __ballot(l_rlo <= k_rhi);
