@@ -69,6 +69,7 @@ def main():
             ctx.synchronize()
             ts.append(time.perf_counter() - t1)
         c = ctx.counts()
+        print("index path: %d (0 = bin path; it takes one pass per 131,072 reads: %d here)" % (int(c.index_path), (len(rn) + 131071) // 131072), flush=True)
         print("single pass incl. H2D of the rows: %.2f ms; edges %d, EdgeMatches %d, orders %d, ids %d -> %.0f M overlap-pairs/s" % (
             1e3 * min(ts), c.n_edges, c.n_ems, c.n_orders, c.n_ids, c.n_edges / min(ts) / 1e6), flush=True)
         got = ctx.tables() if check else None
