@@ -539,12 +539,12 @@ void launch_index_sort_bin(hipStream_t st, const uint32_t *cursor, const uint32_
                            uint32_t *read_cnt, int32_t *read_len, uint32_t *read_first, uint32_t *visits, const msgpu_row *rows,
                            uint32_t *flags, uint32_t *err) {
   if (!nb) return;
-  static bool attr_set = false; // more than 64 KB of dynamic LDS needs the attribute (once per process)
-  if (!attr_set) {
+  const size_t lds = static_cast<size_t>(cap) * BIN_LDS_PER_ROW;
+  // more than 64 KB of dynamic LDS needs the attribute -- on the device the launch goes to (a group drives several devices
+  // from one process), so it is set with the launch that needs it rather than once
+  if (lds > (64u << 10))
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_index_sort_bin), hipFuncAttributeMaxDynamicSharedMemorySize, 96 << 10);
-    attr_set = true;
-  }
-  hipLaunchKernelGGL(k_index_sort_bin, dim3(nb), dim3(BIN_SORT_NT), static_cast<size_t>(cap) * BIN_LDS_PER_ROW, st, cursor, bin_start, V,
+  hipLaunchKernelGGL(k_index_sort_bin, dim3(nb), dim3(BIN_SORT_NT), lds, st, cursor, bin_start, V,
                      rd_lo, cap, bin_rec, by_read, by_anchor, vis, read_off, read_cnt, read_len, read_first, visits, rows, flags, err);
 }
 

@@ -150,7 +150,9 @@ def test_index_bin_path_and_atomic_path_agree(oracle, monkeypatch):
             ctx.chaining_and_overlaps()
             return ctx.tables(), ctx.reads(), int(ctx.counts().index_path)
 
-    shapes = [(1000, 5000, 4000, 13), (37, 3000, 150, 4), (3000, 2500, 9000, 5), (400, 30000, 3000, 6)]
+    # (the last two: reads of 65..128 and 129..256 rows -- two and four rows per lane in the ranking; the very last one's buckets
+    # need more than 64 KB of LDS in k_index_sort_bin)
+    shapes = [(1000, 5000, 4000, 13), (37, 3000, 150, 4), (3000, 2500, 9000, 5), (400, 30000, 3000, 6), (400, 30000, 4400, 6)]
     for shape in shapes:
         rows = synth.synth_rows(*shape)
         want = oracle.overlap(rows)
