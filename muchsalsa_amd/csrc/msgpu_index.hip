@@ -30,6 +30,23 @@
 
 namespace msgpu {
 
+// Diagnostic build only (tools/micro/index_stamps.hip compiles this file with -DMSGPU_STAMPS): s_memtime at the phase
+// boundaries of the two kernels, one row of stamps per workgroup, into a buffer nothing else reads.  The product build has
+// no stamp in it.
+#ifdef MSGPU_STAMPS
+__device__ unsigned long long *g_stamps = nullptr; // [workgroups][8]
+#define STAMP(k)                                                                                                       \
+  do {                                                                                                                 \
+    if (threadIdx.x == 0 && g_stamps) {                                                                                \
+      unsigned long long t_;                                                                                           \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                                       \
+      g_stamps[static_cast<size_t>(blockIdx.x) * 8 + (k)] = t_;                                                        \
+    }                                                                                                                  \
+  } while (0)
+#else
+#define STAMP(k) do { } while (0)
+#endif
+
 constexpr int      BIN_PT    = 4;                  // rows per thread of k_index_bin
 constexpr int      BIN_NT    = 512;
 constexpr int      BIN_TILE  = BIN_PT * BIN_NT;    // 2048 rows per workgroup
@@ -58,6 +75,7 @@ void k_index_bin(const msgpu_row *rows, uint64_t n, uint32_t V, uint32_t A, uint
   const uint32_t rd_hi = min(V, rd_lo + (nb << BIN_RPB_SHIFT));
   const int      lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (uint32_t b = threadIdx.x; b < nb; b += BIN_NT) s_cnt[b] = 0;
+  STAMP(0);
   // the tile's rows: every load is in flight before the first one is used (a row is read once)
   msgpu_row row[BIN_PT];
 #pragma unroll
@@ -84,6 +102,7 @@ void k_index_bin(const msgpu_row *rows, uint64_t n, uint32_t V, uint32_t A, uint
     s_rd[slot] = halo.y;
   }
   __syncthreads();
+  STAMP(1);
   // where scaffolds begin, as bit masks (a wavefront covers 64 consecutive positions: one ballot per word).  Position 0 counts
   // as a beginning: a scaffold that reaches it is longer than the context and is reported as such below.
   static_assert((BIN_TILE + 2 * BIN_HALO) % 64 == 0 && BIN_HALO % 64 == 0, "whole words");
@@ -108,6 +127,7 @@ void k_index_bin(const msgpu_row *rows, uint64_t n, uint32_t V, uint32_t A, uint
     lr[k] = atomicAdd(&s_cnt[bk[k]], 1u); // LDS: rank inside (tile, bucket)
   }
   __syncthreads();
+  STAMP(2);
   // one global atomic per (tile, non-empty bucket); a wave instruction covers 64 adjacent counters (merged requests)
   // (all of a thread's atomics are in flight together: a returning atomic takes microseconds at the memory side)
   {
@@ -128,6 +148,7 @@ void k_index_bin(const msgpu_row *rows, uint64_t n, uint32_t V, uint32_t A, uint
       if (cc[q]) s_cnt[q * BIN_NT + threadIdx.x] = base[q];
   }
   __syncthreads();
+  STAMP(3);
 #pragma unroll
   for (int k = 0; k < BIN_PT; ++k) {
     const uint64_t i = i0 + static_cast<uint64_t>(k) * BIN_NT + threadIdx.x; // (every lane runs the iteration: the stores below are the wavefront's)
@@ -202,6 +223,11 @@ void k_index_bin(const msgpu_row *rows, uint64_t n, uint32_t V, uint32_t A, uint
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); // the tile's reads are done before the next iteration's writes
     __builtin_amdgcn_wave_barrier();
   }
+#ifdef MSGPU_STAMPS
+  __syncthreads();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  STAMP(4);
+#endif
 }
 
 // ---- bucket counts -> first by_read row of every bucket (one workgroup; nb <= BIN_NB_MAX) ------------------------------
@@ -425,6 +451,7 @@ __global__ __launch_bounds__(BIN_SORT_NT) void k_index_sort_bin(const uint32_t *
   if (threadIdx.x < RPB) s_rcnt[threadIdx.x] = 0;
   __syncthreads();
   if (s_stop) return;
+  STAMP(0);
   BinLds s;
   s.row_a = reinterpret_cast<uint4 *>(s_dyn);
   s.row_b = s.row_a + cap;
@@ -463,6 +490,7 @@ __global__ __launch_bounds__(BIN_SORT_NT) void k_index_sort_bin(const uint32_t *
     }
   }
   __syncthreads();
+  STAMP(1);
   if (threadIdx.x < 64) { // RPB <= 64 reads: one wavefront scans the counts
     const uint32_t c   = lane < static_cast<int>(nr) ? s_rcnt[lane] : 0u;
     const uint32_t inc = wave_incl_scan(c);
@@ -475,6 +503,7 @@ __global__ __launch_bounds__(BIN_SORT_NT) void k_index_sort_bin(const uint32_t *
   __syncthreads();
   for (uint32_t e = threadIdx.x; e < n_b; e += BIN_SORT_NT) s.idx[atomicAdd(&s_fill[s.aux[e] >> 18], 1u)] = static_cast<uint16_t>(e);
   __syncthreads();
+  STAMP(2);
   const uint32_t start = bin_start[b];
   for (uint32_t q = wave; q < nr; q += BIN_SORT_NT / 64) { // a wavefront per read
     const uint32_t r = r0 + q, n = s_rcnt[q], off = s_roff[q];
@@ -503,11 +532,17 @@ __global__ __launch_bounds__(BIN_SORT_NT) void k_index_sort_bin(const uint32_t *
     }
   }
   __syncthreads();
+  STAMP(3);
   if (threadIdx.x < nr) { // the Vertex facts of the bucket's reads: first line, and the read length that line states
     const unsigned long long fk = s_first[threadIdx.x];
     read_first[r0 + threadIdx.x] = static_cast<uint32_t>(fk >> 32);
     read_len[r0 + threadIdx.x]   = fk == ~0ull ? 0 : rows[static_cast<uint32_t>(fk)].read_len;
   }
+#ifdef MSGPU_STAMPS
+  __syncthreads();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  STAMP(4);
+#endif
 }
 
 // ---- launchers -----------------------------------------------------------------------------------------------------------
