@@ -356,7 +356,10 @@ int msgpu_merge_wire(msgpu_ctx *ctx, const void *d_gathered, uint32_t world, con
  * RCCL is loaded on first use (dlopen of librccl.so.1: the process's own copy where a framework already brought one); a
  * process that never creates a group never maps it.  MSGPU_E_NODEVICE when a device is missing, MSGPU_E_HIP with the RCCL
  * error text when a collective fails.  A group is driven by one host thread at a time (STREAM AND THREAD CONTRACT rule 5);
- * the members' contexts must not be used by the caller while a group call runs. */
+ * the members' contexts must not be used by the caller while a group call runs.
+ * Rehearsal on a box with fewer GPUs than members: with MSGPU_GROUP_TRANSPORT=copy in the environment when the group is
+ * created, the all-gather is carried by device-to-device copies of this process instead of RCCL and members may share a device;
+ * shards, threads, slab layout, pack and merge are the same code.  For tests; never the default. */
 typedef struct msgpu_group msgpu_group;
 typedef struct msgpu_group_tables {
   const msgpu_edge  *edges;   /* host (pinned, owned by the group, valid until its next call): the merged edge list     */

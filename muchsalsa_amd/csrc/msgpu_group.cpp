@@ -11,6 +11,7 @@
 #include <rccl/rccl.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -121,6 +122,10 @@ struct msgpu_group {
   char                err[640] = {0};
   HostBlock           h_edges, h_orders, h_ids, h_read_len, h_read_first;
   bool                comms_ok = false;
+  // Rehearsal transport (MSGPU_GROUP_TRANSPORT=copy, read at creation): the all-gather as device-to-device copies issued by
+  // this process instead of RCCL, so that a group of SEVERAL members can run on a box with fewer GPUs (members may then share
+  // a device).  Everything else -- shards, threads, slab layout, pack, merge -- is the path RCCL carries.  Never the default.
+  bool                copy_transport = false;
 };
 
 namespace {
@@ -156,13 +161,16 @@ int msgpu_group_create(const int *devices, int n, const msgpu_params *params, ms
   if (!devices || n <= 0 || n > 64) return MSGPU_E_ARG;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return MSGPU_E_NODEVICE;
+  const char *tr   = getenv("MSGPU_GROUP_TRANSPORT");
+  const bool  copy = tr && strcmp(tr, "copy") == 0;
   for (int i = 0; i < n; ++i) {
     if (devices[i] < 0 || devices[i] >= ndev) return MSGPU_E_NODEVICE;
     for (int j = 0; j < i; ++j)
-      if (devices[j] == devices[i]) return MSGPU_E_ARG; // one member per device
+      if (devices[j] == devices[i] && !copy) return MSGPU_E_ARG; // one member per device (RCCL: one rank per GPU)
   }
   msgpu_group *g = new (std::nothrow) msgpu_group();
   if (!g) return MSGPU_E_NOMEM;
+  g->copy_transport = copy;
   if (params)
     g->p = *params;
   else
@@ -221,9 +229,9 @@ int msgpu_group_overlap(msgpu_group *g, const msgpu_row *rows, size_t n_rows, ms
   const auto   t_start = std::chrono::steady_clock::now();
   const size_t n       = g->m.size();
   memset(out, 0, sizeof(*out));
-  Rccl *nc = rccl();
-  if (nc->why[0]) return gfail(g, MSGPU_E_HIP, "RCCL is not available: %s", nc->why);
-  if (!g->comms_ok) { // one communicator per member, all in this process
+  Rccl *nc = g->copy_transport ? nullptr : rccl();
+  if (nc && nc->why[0]) return gfail(g, MSGPU_E_HIP, "RCCL is not available: %s", nc->why);
+  if (nc && !g->comms_ok) { // one communicator per member, all in this process
     std::vector<ncclComm_t> comms(n);
     std::vector<int>        devs(n);
     for (size_t i = 0; i < n; ++i) devs[i] = g->m[i].device;
@@ -289,12 +297,26 @@ int msgpu_group_overlap(msgpu_group *g, const msgpu_row *rows, size_t n_rows, ms
     if (int rc = msgpu_pack_wire(mb.ctx, slab + off_e, slab + off_o, slab + off_i, id_bytes))
       return gfail(g, rc, "member %zu: %s", i, msgpu_last_error(mb.ctx));
   }
-  GNCCL(g, nc->GroupStart()); // one thread drives n communicators: the n calls are one collective
-  for (size_t i = 0; i < n; ++i) {
-    Member &mb = g->m[i];
-    GNCCL(g, nc->AllGather(mb.slab.p, mb.gathered.p, slab_bytes, ncclChar, mb.comm, static_cast<hipStream_t>(msgpu_get_stream(mb.ctx))));
+  if (nc) {
+    GNCCL(g, nc->GroupStart()); // one thread drives n communicators: the n calls are one collective
+    for (size_t i = 0; i < n; ++i) {
+      Member &mb = g->m[i];
+      GNCCL(g, nc->AllGather(mb.slab.p, mb.gathered.p, slab_bytes, ncclChar, mb.comm, static_cast<hipStream_t>(msgpu_get_stream(mb.ctx))));
+    }
+    GNCCL(g, nc->GroupEnd());
+  } else { // rehearsal transport: every slab is complete (its stream drained), then member i copies all n slabs
+    for (size_t i = 0; i < n; ++i) {
+      GHIP(g, hipSetDevice(g->m[i].device));
+      GHIP(g, hipStreamSynchronize(static_cast<hipStream_t>(msgpu_get_stream(g->m[i].ctx))));
+    }
+    for (size_t i = 0; i < n; ++i) {
+      Member &mb = g->m[i];
+      GHIP(g, hipSetDevice(mb.device));
+      for (size_t r = 0; r < n; ++r)
+        GHIP(g, hipMemcpyPeerAsync(static_cast<char *>(mb.gathered.p) + r * slab_bytes, mb.device, g->m[r].slab.p, g->m[r].device, slab_bytes,
+                                   static_cast<hipStream_t>(msgpu_get_stream(mb.ctx))));
+    }
   }
-  GNCCL(g, nc->GroupEnd());
   for (size_t i = 0; i < n; ++i) {
     Member &mb = g->m[i];
     GHIP(g, hipSetDevice(mb.device));
