@@ -446,14 +446,31 @@ int build_index_once(msgpu_ctx *c, bool force_generic, bool two_pass, bool bin, 
     ENSURE(c, scan_tmp, 3 * (size_t(scan_blocks(m)) + 1) * 8);
   }
 
+  // The opening of msgpu_calculate_edges for the whole table (scratch offsets from the visit counts the sort leaves, owner
+  // reads classified by LDS footprint, counters zeroed) runs inside the index build, so that its two numbers come back with
+  // the index flags instead of costing a read-back of their own.  Valid for a fast index of an unsharded context; anything
+  // else redoes it there.
+  c->prologue_ok           = false;
+  static const bool env_no_prologue = getenv("MSGPU_NO_PROLOGUE") != nullptr; // measurement switch
+  const bool want_prologue = !env_no_prologue && !force_generic && !c->no_prologue && V != 0 && c->nshards == 1 && c->win_lo == 0 && c->win_hi >= V;
+  if (want_prologue) {
+    ENSURE(c, n_cand, (size_t(V) + 1) * 4);
+    ENSURE(c, n_edge, (size_t(V) + 1) * 4);
+    ENSURE(c, n_visit_arr, (size_t(V) + 1) * 4);
+  }
   {
-    // (the bin path counts per bucket, not per read: its cursors take the per-read counters' place in the zero list)
-    uint32_t *const zero[4]   = {bshift ? c->bin_cursor.as<uint32_t>() : c->cnt_read.as<uint32_t>(), c->cursor.as<uint32_t>(),
-                                 c->read_cnt.as<uint32_t>(), c->anchor_cnt.as<uint32_t>()};
-    const uint32_t  n_zero[4] = {bshift ? bpasses * (nb + 1) + 1 : V + 1, static_cast<uint32_t>(mva), V + 1, A + 1};
+    // (the bin path counts per bucket, not per read: its cursors take the per-read counters' place in the zero list; the
+    // last four are what the candidate kernels need zeroed -- per-read counters, big-edge statistics / cursor / width
+    // classes -- in the same launch: nothing touches them before those kernels run)
+    static_assert(SC_BIGCUR == SC_BIGSTATS + 2 && SC_CLS == SC_BIGCUR + 2 && SC_COUNT == SC_CLS + 2, "adjacent scalar slots");
+    uint32_t *const zero[8]   = {bshift ? c->bin_cursor.as<uint32_t>() : c->cnt_read.as<uint32_t>(), c->cursor.as<uint32_t>(),
+                                 c->read_cnt.as<uint32_t>(), c->anchor_cnt.as<uint32_t>(),
+                                 want_prologue ? scalar<uint32_t>(c, SC_BIGSTATS) : nullptr, want_prologue ? c->n_cand.as<uint32_t>() : nullptr,
+                                 want_prologue ? c->n_edge.as<uint32_t>() : nullptr, want_prologue ? c->n_visit_arr.as<uint32_t>() : nullptr};
+    const uint32_t  n_zero[8] = {bshift ? bpasses * (nb + 1) + 1 : V + 1, static_cast<uint32_t>(mva), V + 1, A + 1, 12, V + 1, V + 1, V + 1};
     uint32_t *const ones[2]   = {c->anchor_first.as<uint32_t>(), nullptr};
     const uint32_t  n_ones[2] = {A + 2, 0};
-    launch_index_init(st, zero, n_zero, ones, n_ones);
+    launch_index_init8(st, zero, n_zero, ones, n_ones);
   }
   uint32_t *d_flags = scalar<uint32_t>(c, SC_IXFLAGS);
   if (force_generic) {
@@ -469,8 +486,7 @@ int build_index_once(msgpu_ctx *c, bool force_generic, bool two_pass, bool bin, 
       uint32_t      *cur   = c->bin_cursor.as<uint32_t>() + size_t(p) * (nb + 1);
       launch_index_bin(st, c->d_rows, n, V, A, d_flags, scalar<uint32_t>(c, SC_ERR), c->anchor_first.as<uint32_t>(), cur,
                        c->bkt_key.as<uint4>(), rd_lo, nb_p, bcap, c->bin_start.as<uint32_t>(), row_base,
-                       p + 1 == bpasses ? c->read_off.as<uint32_t>() + V : nullptr);
-      if (p == 0) launch_check_anchor_first(st, c->anchor_first.as<uint32_t>(), A, n, d_flags);
+                       p + 1 == bpasses ? c->read_off.as<uint32_t>() + V : nullptr, p == 0);
       launch_index_sort_bin(st, cur, c->bin_start.as<uint32_t>(), V, rd_lo, nb_p, bcap, c->bkt_key.as<uint4>(),
                             c->by_read.as<IRow>(), c->by_anchor.as<IRow>(), c->vis16.as<uint4>(), c->read_off.as<uint32_t>(),
                             c->read_cnt.as<uint32_t>(), c->read_len.as<int32_t>(), c->read_first.as<uint32_t>(),
@@ -489,21 +505,16 @@ int build_index_once(msgpu_ctx *c, bool force_generic, bool two_pass, bool bin, 
                    scalar<uint32_t>(c, SC_ERR), c->spos2.as<uint2>(), c->vis16.as<uint4>(), c->visits.as<uint32_t>()); // fast mode: the sort writes the scaffold rows too (at
                                                                               // the places pass 1 left in spos2); always: the Vertex facts
   }
-  launch_check_read_order(st, c->read_first.as<uint32_t>(), V, scalar<uint32_t>(c, SC_ERR));
-  // Fast mode (input grouped by anchor, ascending lines: what the PAF loader hands over) is finished here but for the
-  // scaffold offsets, which are the speculative ones of pass 1; the flags come back with the read-back below and
-  // only an input that is not in that form pays for the generic scaffold build (a second read-back).
-  launch_select_anchor_off(st, d_flags, c->anchor_first.as<uint32_t>(), c->anchor_off_gen.as<uint32_t>(), A,
-                           c->anchor_off.as<uint32_t>(), scalar<uint32_t>(c, SC_NALIVE), static_cast<uint32_t>(n));
+  // the Registry-order check on the first lines the sort found and, in the same launch, the scaffold offsets: fast mode
+  // (input grouped by anchor, ascending lines: what the PAF loader hands over) is finished here but for them, and they are
+  // the speculative ones of pass 1; the flags come back with the read-back below and only an input that is not in that
+  // form pays for the generic scaffold build (a second read-back).
+  launch_index_finish(st, c->read_first.as<uint32_t>(), V, scalar<uint32_t>(c, SC_ERR), d_flags, c->anchor_first.as<uint32_t>(),
+                      c->anchor_off_gen.as<uint32_t>(), A, c->anchor_off.as<uint32_t>(), scalar<uint32_t>(c, SC_NALIVE),
+                      static_cast<uint32_t>(n));
   HIPCHK(c, hipGetLastError());
   if (c->stage_events) HIPCHK(c, hipEventRecord(c->ev[1], st));
-  // The opening of msgpu_calculate_edges for the whole table (scratch offsets from the visit counts the sort left, owner
-  // reads classified by LDS footprint) runs here, so that its two numbers come back with the index flags instead of
-  // costing a read-back of their own.  Valid for a fast index of an unsharded context; anything else redoes it there.
-  c->prologue_ok           = false;
-  static const bool env_no_prologue = getenv("MSGPU_NO_PROLOGUE") != nullptr; // measurement switch
-  const bool want_prologue = !env_no_prologue && !force_generic && !c->no_prologue && V != 0 && c->nshards == 1 && c->win_lo == 0 && c->win_hi >= V;
-  if (want_prologue) {
+  if (want_prologue) { // (see the top of this function)
     ENSURE(c, cand_off, (size_t(V) + 2) * 8);
     ENSURE(c, lists, (size_t(V) + 1) * (3 * sizeof(CandDesc) + 4));
     CandDesc *l0 = c->lists.as<CandDesc>(), *l1 = l0 + V + 1, *l2 = l1 + V + 1;
@@ -512,18 +523,6 @@ int build_index_once(msgpu_ctx *c, bool force_generic, bool two_pass, bool bin, 
     launch_classify_reads(st, c->read_off.as<uint32_t>(), c->read_cnt.as<uint32_t>(), c->visits.as<uint32_t>(),
                           c->cand_off.as<uint64_t>(), V, 0, 1, 0, 0xffffffffu, l0, l1, l2,
                           reinterpret_cast<uint32_t *>(l2 + V + 1), scalar<uint32_t>(c, SC_NLISTS));
-    // ... and so does the zeroing the candidate kernels need (per-read counters, big-edge statistics / cursor / width
-    // classes): on an idle queue every launch costs ~12 us of host latency, here it hides behind the index kernels
-    ENSURE(c, n_cand, (size_t(V) + 1) * 4);
-    ENSURE(c, n_edge, (size_t(V) + 1) * 4);
-    ENSURE(c, n_visit_arr, (size_t(V) + 1) * 4);
-    static_assert(SC_BIGCUR == SC_BIGSTATS + 2 && SC_CLS == SC_BIGCUR + 2 && SC_COUNT == SC_CLS + 2, "adjacent scalar slots");
-    uint32_t *const zero[4]   = {scalar<uint32_t>(c, SC_BIGSTATS), c->n_cand.as<uint32_t>(), c->n_edge.as<uint32_t>(),
-                                 c->n_visit_arr.as<uint32_t>()};
-    const uint32_t  n_zero[4] = {12, V + 1, V + 1, V + 1};
-    uint32_t *const ones[2]   = {nullptr, nullptr};
-    const uint32_t  n_ones[2] = {0, 0};
-    launch_index_init(st, zero, n_zero, ones, n_ones);
     HIPCHK(c, hipGetLastError());
   }
 

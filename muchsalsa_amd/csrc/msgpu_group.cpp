@@ -299,11 +299,14 @@ int msgpu_group_overlap(msgpu_group *g, const msgpu_row *rows, size_t n_rows, ms
   }
   if (nc) {
     GNCCL(g, nc->GroupStart()); // one thread drives n communicators: the n calls are one collective
-    for (size_t i = 0; i < n; ++i) {
+    ncclResult_t first_bad = ncclSuccess;
+    for (size_t i = 0; i < n && first_bad == ncclSuccess; ++i) {
       Member &mb = g->m[i];
-      GNCCL(g, nc->AllGather(mb.slab.p, mb.gathered.p, slab_bytes, ncclChar, mb.comm, static_cast<hipStream_t>(msgpu_get_stream(mb.ctx))));
+      first_bad  = nc->AllGather(mb.slab.p, mb.gathered.p, slab_bytes, ncclChar, mb.comm, static_cast<hipStream_t>(msgpu_get_stream(mb.ctx)));
     }
-    GNCCL(g, nc->GroupEnd());
+    const ncclResult_t closed = nc->GroupEnd(); // (closed whatever happened inside: an open group would swallow the next call)
+    GNCCL(g, first_bad);
+    GNCCL(g, closed);
   } else { // rehearsal transport: every slab is complete (its stream drained), then member i copies all n slabs
     for (size_t i = 0; i < n; ++i) {
       GHIP(g, hipSetDevice(g->m[i].device));

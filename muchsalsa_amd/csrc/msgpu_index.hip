@@ -230,11 +230,21 @@ void k_index_bin(const msgpu_row *rows, uint64_t n, uint32_t V, uint32_t A, uint
 #endif
 }
 
-// ---- bucket counts -> first by_read row of every bucket (one workgroup; nb <= BIN_NB_MAX) ------------------------------
-// row_base: by_read rows of the passes before this one (device word, updated for the next pass)
+// ---- bucket counts -> first by_read row of every bucket (workgroup 0; nb <= BIN_NB_MAX) --------------------------------
+// row_base: by_read rows of the passes before this one (device word, updated for the next pass).  The workgroups behind the
+// first (the job's first pass launches them) are k_check_anchor_first over the anchors: the closing entry of the scaffold
+// starts k_index_bin left, IXF_SPARSE for an anchor id without a row -- independent of the scan, so in its launch.
 __global__ __launch_bounds__(1024) void k_bin_scan(const uint32_t *cursor, uint32_t nb, uint32_t cap, uint32_t *bin_start /*[nb + 1]*/,
                                                    uint32_t *row_base, uint32_t *read_off_end /*&read_off[V] or null*/,
-                                                   uint32_t *flags) {
+                                                   uint32_t *flags, uint32_t *anchor_first, uint32_t A, uint32_t n_rows) {
+  if (blockIdx.x != 0) {
+    const uint32_t a = (blockIdx.x - 1) * 1024 + threadIdx.x;
+    if (a == A)
+      anchor_first[A] = n_rows;
+    else if (a < A && anchor_first[a] == 0xffffffffu)
+      atomicOr(flags, IXF_SPARSE);
+    return;
+  }
   __shared__ uint32_t s_wave[16];
   constexpr int PT = BIN_NB_MAX / 1024;
   uint32_t      c[PT], sum = 0;
@@ -563,11 +573,13 @@ uint32_t bin_capacity(uint64_t n, uint32_t V) {
 }
 void launch_index_bin(hipStream_t st, const msgpu_row *rows, uint64_t n, uint32_t V, uint32_t A, uint32_t *flags, uint32_t *err,
                       uint32_t *anchor_first, uint32_t *cursor, uint4 *bin_rec, uint32_t rd_lo, uint32_t nb, uint32_t cap,
-                      uint32_t *bin_start, uint32_t *row_base, uint32_t *read_off_end) {
+                      uint32_t *bin_start, uint32_t *row_base, uint32_t *read_off_end, bool check_anchors) {
   if (n)
     hipLaunchKernelGGL(k_index_bin, dim3(static_cast<uint32_t>((n + BIN_TILE - 1) / BIN_TILE)), dim3(BIN_NT), 0, st, rows, n, V, A,
                        flags, err, anchor_first, cursor, bin_rec, rd_lo, nb, cap);
-  hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, st, cursor, nb, cap, bin_start, row_base, read_off_end, flags);
+  const uint32_t check_blocks = check_anchors ? static_cast<uint32_t>((static_cast<uint64_t>(A) + 1 + 1023) / 1024) : 0;
+  hipLaunchKernelGGL(k_bin_scan, dim3(1 + check_blocks), dim3(1024), 0, st, cursor, nb, cap, bin_start, row_base, read_off_end, flags,
+                     anchor_first, A, static_cast<uint32_t>(n));
 }
 void launch_index_sort_bin(hipStream_t st, const uint32_t *cursor, const uint32_t *bin_start, uint32_t V, uint32_t rd_lo, uint32_t nb,
                            uint32_t cap, const uint4 *bin_rec, IRow *by_read, IRow *by_anchor, uint4 *vis, uint32_t *read_off,

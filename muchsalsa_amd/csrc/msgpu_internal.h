@@ -134,18 +134,18 @@ constexpr uint32_t BIN_PASSES_MAX = 8;   // passes over the row table (BIN_NB_MA
 uint32_t bin_capacity(uint64_t n, uint32_t V); // rows a coarse bucket can hold; 0 = the bin path does not apply
 void launch_index_bin(hipStream_t st, const msgpu_row *rows, uint64_t n, uint32_t V, uint32_t A, uint32_t *flags, uint32_t *err,
                       uint32_t *anchor_first, uint32_t *cursor, uint4 *bin_rec, uint32_t rd_lo, uint32_t nb, uint32_t cap,
-                      uint32_t *bin_start, uint32_t *row_base, uint32_t *read_off_end);
+                      uint32_t *bin_start, uint32_t *row_base, uint32_t *read_off_end, bool check_anchors);
 void launch_index_sort_bin(hipStream_t st, const uint32_t *cursor, const uint32_t *bin_start, uint32_t V, uint32_t rd_lo, uint32_t nb,
                            uint32_t cap, const uint4 *bin_rec, IRow *by_read, IRow *by_anchor, uint4 *vis, uint32_t *read_off,
                            uint32_t *read_cnt, int32_t *read_len, uint32_t *read_first, uint32_t *visits, const msgpu_row *rows,
                            uint32_t *flags, uint32_t *err);
-void launch_check_anchor_first(hipStream_t st, uint32_t *anchor_first, uint32_t A, uint64_t n, uint32_t *flags);
 void launch_publish_scalars(hipStream_t st, const uint64_t *src, uint64_t *dst_host, uint32_t n, uint64_t seq);
 void launch_index_init(hipStream_t st, uint32_t *const zero[4], const uint32_t n_zero[4], uint32_t *const ones[2],
                        const uint32_t n_ones[2]);
+void launch_index_init8(hipStream_t st, uint32_t *const zero[8], const uint32_t n_zero[8], uint32_t *const ones[2],
+                        const uint32_t n_ones[2]);
 void launch_index_pass1(hipStream_t st, const msgpu_row *rows, uint64_t n, uint32_t *cnt_read, uint32_t *anchor_first,
                         uint32_t V, uint32_t A, uint32_t *flags, uint32_t *err, IRow *bkt_row, uint32_t cap, uint2 *spos);
-void launch_check_read_order(hipStream_t st, const uint32_t *read_first, uint32_t V, uint32_t *err);
 void launch_scatter_read(hipStream_t st, const msgpu_row *rows, uint64_t n, const uint32_t *read_off, uint32_t *cursor,
                          IRow *bkt_row);
 void launch_sort_read(hipStream_t st, const uint32_t *read_off, const uint32_t *cnt_read, uint32_t V, const IRow *bkt_row,
@@ -153,6 +153,9 @@ void launch_sort_read(hipStream_t st, const uint32_t *read_off, const uint32_t *
                       uint32_t *anchor_cnt, uint8_t *bkt_dead, uint32_t *flags, IRow *by_anchor, uint32_t cap,
                       const msgpu_row *rows, int32_t *read_len, uint32_t *read_first, uint32_t *err,
                       const uint2 *spos, uint4 *vis, uint32_t *visits);
+void launch_index_finish(hipStream_t st, const uint32_t *read_first, uint32_t V, uint32_t *err, const uint32_t *flags,
+                         const uint32_t *fast_off, const uint32_t *gen_off, uint32_t A, uint32_t *anchor_off, uint32_t *d_n_alive,
+                         uint32_t n_rows);
 void launch_select_anchor_off(hipStream_t st, const uint32_t *flags, const uint32_t *fast_off, const uint32_t *gen_off,
                               uint32_t A, uint32_t *anchor_off, uint32_t *d_n_alive, uint32_t n_rows);
 void launch_scatter_anchor(hipStream_t st, const msgpu_row *rows, uint64_t n, const uint32_t *alive_rank,

@@ -255,15 +255,15 @@ __global__ __launch_bounds__(256) void k_max_ids(const msgpu_row *rows, uint64_t
 
 // one launch instead of six memsets: zero / all-ones fill of the per-read and per-anchor tables of the index build
 struct IndexInitArgs {
-  uint32_t *zero[4];
-  uint32_t  n_zero[4];
+  uint32_t *zero[8];
+  uint32_t  n_zero[8];
   uint32_t *ones[2];
   uint32_t  n_ones[2];
 };
 __global__ __launch_bounds__(256) void k_index_init(IndexInitArgs a) {
   const uint32_t stride = gridDim.x * 256, t0 = blockIdx.x * 256 + threadIdx.x;
 #pragma unroll
-  for (int k = 0; k < 4; ++k)
+  for (int k = 0; k < 8; ++k)
     for (uint32_t i = t0; i < a.n_zero[k]; i += stride) a.zero[k][i] = 0;
 #pragma unroll
   for (int k = 0; k < 2; ++k)
@@ -363,15 +363,6 @@ __global__ __launch_bounds__(256) void k_check_anchor_first(uint32_t *anchor_fir
     return;
   }
   if (anchor_first[a] == 0xffffffffu) atomicOr(flags, IXF_SPARSE);
-}
-
-// Registry-order check on the first lines the sort found: ids must follow first-line order (Registry.cpp:36-45); an id
-// without any row (marked 0xffffffff by the sort) means the ids are not dense
-__global__ __launch_bounds__(256) void k_check_read_order(const uint32_t *read_first, uint32_t V, uint32_t *err) {
-  const uint32_t r = blockIdx.x * 256 + threadIdx.x;
-  if (r + 1 >= V) return;
-  const uint32_t f0 = read_first[r], f1 = read_first[r + 1];
-  if (f0 != 0xffffffffu && f1 != 0xffffffffu && f1 <= f0) atomicOr(err, 1u);
 }
 
 // bucket rows by read: the whole row goes into the bucket (a fire-and-forget 32 B scatter), so the sort kernel reads
@@ -650,6 +641,22 @@ __global__ __launch_bounds__(256) void k_select_anchor_off(const uint32_t *flags
   const bool fast = (*flags & ~IXF_DUPS) == 0;
   if (a <= A) anchor_off[a] = fast ? fast_off[a] : gen_off[a];
   if (a == 0 && fast) *d_n_alive = n_rows;
+}
+
+// the two element-wise closings of an index build in one launch.  Over the reads: the Registry-order check on the first lines
+// the sort found -- ids must follow first-line order (Registry.cpp:36-45); an id without any row (marked 0xffffffff by the
+// sort) means the ids are not dense.  Over the anchors: k_select_anchor_off.
+__global__ __launch_bounds__(256) void k_index_finish(const uint32_t *read_first, uint32_t V, uint32_t *err, const uint32_t *flags,
+                                                      const uint32_t *fast_off, const uint32_t *gen_off, uint32_t A,
+                                                      uint32_t *anchor_off, uint32_t *d_n_alive, uint32_t n_rows) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i + 1 < V) {
+    const uint32_t f0 = read_first[i], f1 = read_first[i + 1];
+    if (f0 != 0xffffffffu && f1 != 0xffffffffu && f1 <= f0) atomicOr(err, 1u);
+  }
+  const bool fast = (*flags & ~IXF_DUPS) == 0;
+  if (i <= A) anchor_off[i] = fast ? fast_off[i] : gen_off[i];
+  if (i == 0 && fast) *d_n_alive = n_rows;
 }
 
 __global__ __launch_bounds__(256) void k_scatter_anchor(const msgpu_row *rows, uint64_t n, const uint32_t *alive_rank,
@@ -1174,7 +1181,7 @@ __global__ __launch_bounds__(256) void k_emit_edges(const uint32_t *n_edge, cons
 
 // Edges per width class of the chain kernels (<= 8, 9..16, 17..32, 33..64 EdgeMatches), counted from the candidate
 // scratch before the edges exist, so that the numbers come back with the table sizes and the chain stage needs no
-// read-back of its own.  counts[0..3] = 9..16, 17..32, 33..64, <= 8 (the order k_size_scan uses).
+// read-back of its own.  counts[0..3] = 9..16, 17..32, 33..64, <= 8 (the order k_size_scatter uses).
 __global__ __launch_bounds__(1024) void k_count_classes(const uint32_t *n_edge, const uint32_t *n_cand, const uint64_t *cand_off,
                                                         const uint32_t *edge_scr_start, uint32_t V, uint32_t *partials /*[blocks][4]*/) {
   __shared__ uint32_t s_c[16][4];
@@ -2314,8 +2321,8 @@ template __global__ void k_chain_sub<8>(ChainArgs, const uint32_t *, uint32_t);
 template __global__ void k_chain_sub<16>(ChainArgs, const uint32_t *, uint32_t);
 template __global__ void k_chain_sub<32>(ChainArgs, const uint32_t *, uint32_t);
 
-// Edges with <= 64 EdgeMatches ordered by size, largest first (a counting sort in three small launches: per-block
-// histograms, their scan, scatter).  The three width classes are then contiguous stretches of one list
+// Edges with <= 64 EdgeMatches ordered by size, largest first (a counting sort in two small launches: per-block
+// histograms, then their scan and the scatter together).  The three width classes are then contiguous stretches of one list
 // [64..33 | 32..17 | 16..1], the edges that share a wavefront in k_chain_sub have (nearly) the same size, so no group
 // waits long for its neighbour, and the longest edges of a launch start first.
 constexpr int SIZE_SORT_BLOCKS = 128;
@@ -2340,15 +2347,19 @@ __global__ __launch_bounds__(1024) void k_size_hist(const msgpu_edge *edges, con
   if (threadIdx.x < 64) part[blockIdx.x * 64 + threadIdx.x] = s_h[threadIdx.x];
 }
 
-// part[b][bin] -> first list position of block b's edges of that size; counts[0..2] = edges of <= 16, 17..32, 33..64.
-// One workgroup: thread (bin, seg) owns 8 consecutive blocks of one bin, so no thread walks the table serially.
-__global__ __launch_bounds__(1024) void k_size_scan(uint32_t *part, uint32_t *counts, const uint64_t *d_n_edges,
-                                                    uint64_t cap_edges) {
+// part[b][bin] (k_size_hist) -> first list position of block b's edges of that size, then the scatter.  Every workgroup takes
+// the prefix over the whole 128 x 64 table itself (32 KB out of L2, thread (bin, seg) owns 8 consecutive blocks of one bin) and
+// keeps its own row: a scan launch between the histogram and the scatter would cost more than 128 redundant scans.
+// counts[0..3] = edges of 9..16, 17..32, 33..64, <= 8 EdgeMatches (workgroup 0 writes them; k_count_classes published the
+// same numbers earlier, from the candidate scratch).
+__global__ __launch_bounds__(1024) void k_size_scatter(const msgpu_edge *edges, const uint64_t *d_n_edges, uint64_t cap_edges,
+                                                       const uint32_t *part, uint32_t *list, uint32_t *counts) {
   static_assert(SIZE_SORT_BLOCKS == 128, "16 segments of 8 blocks");
-  // a speculative launch into tables that turn out too small: k_size_hist wrote nothing, `part` is stale -- keep the class
-  // counts k_count_classes published (the host re-launches the three kernels after it has allocated)
-  if (*d_n_edges > cap_edges) return;
-  __shared__ uint32_t s_seg[16][64], s_base[64];
+  __shared__ uint32_t s_seg[16][64], s_base[64], s_pos[64];
+  const uint64_t      ne64 = *d_n_edges;
+  // a speculative launch into tables that turn out too small: k_size_hist wrote nothing, `part` is stale (the host
+  // re-launches the kernels after it has allocated)
+  if (ne64 > cap_edges) return;
   const int bin = threadIdx.x & 63, seg = threadIdx.x >> 6;
   uint32_t  c[8], sum = 0;
 #pragma unroll
@@ -2370,38 +2381,31 @@ __global__ __launch_bounds__(1024) void k_size_scan(uint32_t *part, uint32_t *co
       if (bin + d < 64) inc += t;
     }
     s_base[bin] = inc - run;
-    uint32_t c8 = bin < 8 ? run : 0, c16 = (bin >= 8 && bin < 16) ? run : 0, c32 = (bin >= 16 && bin < 32) ? run : 0,
-             c64 = bin >= 32 ? run : 0;
-    for (int d = 32; d > 0; d >>= 1) {
-      c8 += __shfl_xor(c8, d);
-      c16 += __shfl_xor(c16, d);
-      c32 += __shfl_xor(c32, d);
-      c64 += __shfl_xor(c64, d);
-    }
-    if (bin == 0) {
-      counts[0] = c16;
-      counts[1] = c32;
-      counts[2] = c64;
-      counts[3] = c8;
+    if (blockIdx.x == 0) {
+      uint32_t c8 = bin < 8 ? run : 0, c16 = (bin >= 8 && bin < 16) ? run : 0, c32 = (bin >= 16 && bin < 32) ? run : 0,
+               c64 = bin >= 32 ? run : 0;
+      for (int d = 32; d > 0; d >>= 1) {
+        c8 += __shfl_xor(c8, d);
+        c16 += __shfl_xor(c16, d);
+        c32 += __shfl_xor(c32, d);
+        c64 += __shfl_xor(c64, d);
+      }
+      if (bin == 0) {
+        counts[0] = c16;
+        counts[1] = c32;
+        counts[2] = c64;
+        counts[3] = c8;
+      }
     }
   }
   __syncthreads();
-  uint32_t off = s_base[bin] + s_seg[seg][bin];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    part[(seg * 8 + i) * 64 + bin] = off;
-    off += c[i];
+  if (seg == static_cast<int>(blockIdx.x >> 3)) { // the wavefront whose 8 blocks hold this workgroup's row
+    uint32_t off = s_base[bin] + s_seg[seg][bin];
+    for (uint32_t i = 0; i < (blockIdx.x & 7u); ++i) off += c[i];
+    s_pos[bin] = off;
   }
-}
-
-__global__ __launch_bounds__(1024) void k_size_scatter(const msgpu_edge *edges, const uint64_t *d_n_edges, uint64_t cap_edges,
-                                                       const uint32_t *part, uint32_t *list) {
-  __shared__ uint32_t s_pos[64];
-  const uint64_t      ne64 = *d_n_edges;
-  if (ne64 > cap_edges) return;
+  __syncthreads();
   const uint32_t n_edges = static_cast<uint32_t>(ne64), chunk = (n_edges + SIZE_SORT_BLOCKS - 1) / SIZE_SORT_BLOCKS;
-  if (threadIdx.x < 64) s_pos[threadIdx.x] = part[blockIdx.x * 64 + threadIdx.x];
-  __syncthreads();
   const uint64_t b0_64 = static_cast<uint64_t>(blockIdx.x) * chunk;
   const uint32_t b0 = static_cast<uint32_t>(min(b0_64, static_cast<uint64_t>(n_edges)));
   const uint32_t b1 = static_cast<uint32_t>(min(b0_64 + chunk, static_cast<uint64_t>(n_edges)));
@@ -3064,12 +3068,18 @@ void launch_max_ids(hipStream_t st, const msgpu_row *rows, uint64_t n, uint32_t 
 }
 void launch_index_init(hipStream_t st, uint32_t *const zero[4], const uint32_t n_zero[4], uint32_t *const ones[2],
                        const uint32_t n_ones[2]) {
+  uint32_t *const z8[8] = {zero[0], zero[1], zero[2], zero[3], nullptr, nullptr, nullptr, nullptr};
+  const uint32_t  n8[8] = {n_zero[0], n_zero[1], n_zero[2], n_zero[3], 0, 0, 0, 0};
+  launch_index_init8(st, z8, n8, ones, n_ones);
+}
+void launch_index_init8(hipStream_t st, uint32_t *const zero[8], const uint32_t n_zero[8], uint32_t *const ones[2],
+                        const uint32_t n_ones[2]) {
   IndexInitArgs a;
   uint32_t      most = 1;
-  for (int k = 0; k < 4; ++k) {
+  for (int k = 0; k < 8; ++k) {
     a.zero[k]   = zero[k];
-    a.n_zero[k] = n_zero[k];
-    most        = n_zero[k] > most ? n_zero[k] : most;
+    a.n_zero[k] = zero[k] ? n_zero[k] : 0;
+    most        = a.n_zero[k] > most ? a.n_zero[k] : most;
   }
   for (int k = 0; k < 2; ++k) {
     a.ones[k]   = ones[k];
@@ -3088,13 +3098,6 @@ void launch_index_pass1(hipStream_t st, const msgpu_row *rows, uint64_t n, uint3
   hipLaunchKernelGGL(k_check_anchor_first, grid1(static_cast<uint64_t>(A) + 1, 256), dim3(256), 0, st, anchor_first, A,
                      static_cast<uint32_t>(n), flags);
 }
-void launch_check_anchor_first(hipStream_t st, uint32_t *anchor_first, uint32_t A, uint64_t n, uint32_t *flags) {
-  hipLaunchKernelGGL(k_check_anchor_first, grid1(static_cast<uint64_t>(A) + 1, 256), dim3(256), 0, st, anchor_first, A,
-                     static_cast<uint32_t>(n), flags);
-}
-void launch_check_read_order(hipStream_t st, const uint32_t *read_first, uint32_t V, uint32_t *err) {
-  if (V > 1) hipLaunchKernelGGL(k_check_read_order, grid1(V, 256), dim3(256), 0, st, read_first, V, err);
-}
 void launch_scatter_read(hipStream_t st, const msgpu_row *rows, uint64_t n, const uint32_t *read_off, uint32_t *cursor,
                          IRow *bkt_row) {
   if (n)
@@ -3109,6 +3112,13 @@ void launch_sort_read(hipStream_t st, const uint32_t *read_off, const uint32_t *
     hipLaunchKernelGGL(k_sort_read, grid1(V, 4), dim3(256), 0, st, read_off, cnt_read, V, bkt_row, by_read,
                        read_cnt, alive_rank, anchor_cnt, bkt_dead, flags, by_anchor, cap, rows, read_len, read_first, err,
                        spos, vis, visits);
+}
+void launch_index_finish(hipStream_t st, const uint32_t *read_first, uint32_t V, uint32_t *err, const uint32_t *flags,
+                         const uint32_t *fast_off, const uint32_t *gen_off, uint32_t A, uint32_t *anchor_off, uint32_t *d_n_alive,
+                         uint32_t n_rows) {
+  const uint64_t most = V > static_cast<uint64_t>(A) + 1 ? V : static_cast<uint64_t>(A) + 1;
+  hipLaunchKernelGGL(k_index_finish, grid1(most, 256), dim3(256), 0, st, read_first, V, err, flags, fast_off, gen_off, A, anchor_off,
+                     d_n_alive, n_rows);
 }
 void launch_select_anchor_off(hipStream_t st, const uint32_t *flags, const uint32_t *fast_off, const uint32_t *gen_off,
                               uint32_t A, uint32_t *anchor_off, uint32_t *d_n_alive, uint32_t n_rows) {
@@ -3186,8 +3196,7 @@ void launch_chain_sub(hipStream_t st, const ChainArgs &a, int width, const uint3
 void launch_sort_edges_by_size(hipStream_t st, const msgpu_edge *edges, const uint64_t *d_n_edges, uint64_t cap_edges,
                                uint32_t *part, uint32_t *list, uint32_t *counts) {
   hipLaunchKernelGGL(k_size_hist, dim3(SIZE_SORT_BLOCKS), dim3(1024), 0, st, edges, d_n_edges, cap_edges, part);
-  hipLaunchKernelGGL(k_size_scan, dim3(1), dim3(1024), 0, st, part, counts, d_n_edges, cap_edges);
-  hipLaunchKernelGGL(k_size_scatter, dim3(SIZE_SORT_BLOCKS), dim3(1024), 0, st, edges, d_n_edges, cap_edges, part, list);
+  hipLaunchKernelGGL(k_size_scatter, dim3(SIZE_SORT_BLOCKS), dim3(1024), 0, st, edges, d_n_edges, cap_edges, part, list, counts);
 }
 size_t size_sort_part_bytes() { return static_cast<size_t>(SIZE_SORT_BLOCKS) * 64 * 4; }
 size_t big_elem_bytes() { return sizeof(BigElem); }

@@ -64,7 +64,7 @@ int main() {
     CK(hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &d_st, sizeof(d_st)));
     hipEvent_t e0, e1, e2; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1)); CK(hipEventCreate(&e2));
     CK(hipEventRecord(e0, 0));
-    launch_index_bin(0, d_rows, R, V, A, d_flags, d_err, d_first, d_cursor, d_rec, 0, nb, cap, d_start, d_base, d_off + V);
+    launch_index_bin(0, d_rows, R, V, A, d_flags, d_err, d_first, d_cursor, d_rec, 0, nb, cap, d_start, d_base, d_off + V, true);
     CK(hipEventRecord(e1, 0));
     CK(hipDeviceSynchronize());
     CK(hipMemcpy(st.data(), d_st, wg1 * 64, hipMemcpyDeviceToHost));
