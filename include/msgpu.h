@@ -344,12 +344,14 @@ int msgpu_merge_wire(msgpu_ctx *ctx, const void *d_gathered, uint32_t world, con
  * The reference is ONE process that fans jobs over its workers and closes each phase with a barrier (src/main.cpp:143-178,
  * libms/src/threading/ThreadPool.cpp:38-129, WaitGroup.cpp:62-72).  Its multi-GPU equivalent: one process, one context per
  * device, one host thread per device for the duration of a call, and ONE collective on the path.  msgpu_group_overlap =
- *   rows (host) -> every device's HBM over that device's own link -> index build on every device (replicated: a member needs
+ *   rows (host) -> a 1/n-th over each device's own link, completed in every HBM by a grouped in-place all-gather over xGMI
+ *   (MSGPU_GROUP_ROWS=replicate at creation, a group of one, or fewer than 1024 rows: the whole table over every link) ->
+ *   index build on every device (replicated: a member needs
  *   the rank of every row inside its read) -> device i computes the edges with v1 % n == i (msgpu_set_shard) -> its edge /
  *   order / id tables in WIRE FORM into its slab (msgpu_pack_wire) -> ONE grouped RCCL all-gather over xGMI
  *   (ncclGroupStart / n x ncclAllGather / ncclGroupEnd, each on its member's stream) -> msgpu_merge_wire on every device:
- *   the merged edge list of the job in every HBM, and (from device 0) in host memory; WaitGroup::wait() = the join of the
- *   member threads.
+ *   the merged edge list of the job in every HBM, and in host memory (member i sends the i-th slice of every table over its
+ *   own link: every member holds the same bytes); WaitGroup::wait() = the join of the member threads.
  * The merged tables are the ones msgpu_merge_wire defines: rank-major (member 0's edges in (v1, v2) order, then member 1's ...),
  * order_off / edge_idx / ids_off re-based to the merged tables, em_off local to the owning member (EdgeMatch tables are not
  * gathered: msgpu_get_edgematches on msgpu_group_ctx(g, v1 % n)).  With n = 1 they are the single-context tables bit for bit.
@@ -373,7 +375,7 @@ typedef struct msgpu_group_tables {
   float wall_ms;              /* host clock: call entry -> merged tables in host memory                                */
   float compute_ms;           /*   slowest member: rows in HBM + index + its shard                                     */
   float exchange_ms;          /*   slowest member: pack + all-gather + merge (device time, HIP events)                 */
-  float pad;
+  uint32_t rows_sliced;       /* 1: every member took a 1/n-th of the rows over its link, an all-gather did the rest   */
 } msgpu_group_tables;
 int  msgpu_group_create(const int *devices, int n, const msgpu_params *params, msgpu_group **out);
 void msgpu_group_destroy(msgpu_group *g);

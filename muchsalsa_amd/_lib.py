@@ -89,7 +89,7 @@ class GroupTables(C.Structure):
                 ("read_first_line", C.c_void_p), ("n_edges", C.c_uint64), ("n_orders", C.c_uint64), ("n_ids", C.c_uint64),
                 ("n_ems", C.c_uint64), ("n_reads", C.c_uint32), ("n_anchors", C.c_uint32), ("n_members", C.c_uint32),
                 ("id_bytes", C.c_uint32), ("slab_bytes", C.c_uint64), ("wall_ms", C.c_float), ("compute_ms", C.c_float),
-                ("exchange_ms", C.c_float), ("pad", C.c_float)]
+                ("exchange_ms", C.c_float), ("rows_sliced", C.c_uint32)]
 
 
 INDEX_BIN, INDEX_ATOMIC, INDEX_TWO_PASS, INDEX_GENERIC = 0, 1, 2, 4

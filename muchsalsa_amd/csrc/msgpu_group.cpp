@@ -103,7 +103,7 @@ struct Member {
   int          device = 0;
   msgpu_ctx   *ctx    = nullptr;
   ncclComm_t   comm   = nullptr;
-  DevBlock     slab, gathered, m_edges, m_orders, m_ids;
+  DevBlock     slab, gathered, m_edges, m_orders, m_ids, rows;
   hipEvent_t   ev0 = nullptr, ev1 = nullptr;
   msgpu_counts counts{};
   int          rc = MSGPU_OK;
@@ -126,6 +126,9 @@ struct msgpu_group {
   // this process instead of RCCL, so that a group of SEVERAL members can run on a box with fewer GPUs (members may then share
   // a device).  Everything else -- shards, threads, slab layout, pack, merge -- is the path RCCL carries.  Never the default.
   bool                copy_transport = false;
+  // MSGPU_GROUP_ROWS=replicate (read at creation): every member takes the whole row table over its own link, as a group of
+  // one does.  Default with several members: a 1/n-th each, all-gathered over xGMI (see msgpu_group_overlap).
+  bool                replicate_rows = false;
 };
 
 namespace {
@@ -171,6 +174,8 @@ int msgpu_group_create(const int *devices, int n, const msgpu_params *params, ms
   msgpu_group *g = new (std::nothrow) msgpu_group();
   if (!g) return MSGPU_E_NOMEM;
   g->copy_transport = copy;
+  const char *rw    = getenv("MSGPU_GROUP_ROWS");
+  g->replicate_rows = rw && strcmp(rw, "replicate") == 0;
   if (params)
     g->p = *params;
   else
@@ -199,7 +204,7 @@ void msgpu_group_destroy(msgpu_group *g) {
     (void)hipSetDevice(mb.device);
     if (mb.ctx) (void)msgpu_synchronize(mb.ctx);
     if (mb.comm && rccl()->CommDestroy) (void)rccl()->CommDestroy(mb.comm);
-    for (DevBlock *b : {&mb.slab, &mb.gathered, &mb.m_edges, &mb.m_orders, &mb.m_ids}) b->release();
+    for (DevBlock *b : {&mb.slab, &mb.gathered, &mb.m_edges, &mb.m_orders, &mb.m_ids, &mb.rows}) b->release();
     if (mb.ev0) (void)hipEventDestroy(mb.ev0);
     if (mb.ev1) (void)hipEventDestroy(mb.ev1);
     if (mb.ctx) msgpu_destroy(mb.ctx);
@@ -240,12 +245,58 @@ int msgpu_group_overlap(msgpu_group *g, const msgpu_row *rows, size_t n_rows, ms
     g->comms_ok = true;
   }
 
-  // ---- the fan-out: every member takes the rows over its own link, builds the index, computes its shard ----------------
+  // ---- the rows: n links carry a 1/n-th each, xGMI carries the rest ------------------------------------------------------
+  // Every member needs the whole row table (the index is replicated).  n copies of it over n PCIe links would all come out of
+  // the same host memory; instead member i takes rows [i per, (i + 1) per) over its link and ONE grouped in-place all-gather
+  // on the members' streams completes every copy -- the links move the table once, the fabric (7 x the bandwidth of a link
+  // per device) the other n - 1 times.  The index build of a member is stream-ordered behind its all-gather.
+  const bool   sliced = n > 1 && !g->replicate_rows && n_rows >= 1024;
+  const size_t per    = sliced ? (n_rows + n - 1) / n : 0;
+  if (sliced) {
+    for (size_t i = 0; i < n; ++i) {
+      Member &mb = g->m[i];
+      GHIP(g, hipSetDevice(mb.device));
+      GHIP(g, mb.rows.ensure(n * per * sizeof(msgpu_row)));
+      const size_t lo = std::min(i * per, n_rows), hi = std::min(lo + per, n_rows);
+      if (hi > lo)
+        GHIP(g, hipMemcpyAsync(static_cast<msgpu_row *>(mb.rows.p) + lo, rows + lo, (hi - lo) * sizeof(msgpu_row), hipMemcpyHostToDevice,
+                               static_cast<hipStream_t>(msgpu_get_stream(mb.ctx))));
+    }
+    if (nc) {
+      GNCCL(g, nc->GroupStart());
+      ncclResult_t first_bad = ncclSuccess;
+      for (size_t i = 0; i < n && first_bad == ncclSuccess; ++i) {
+        Member &mb = g->m[i];
+        first_bad  = nc->AllGather(static_cast<msgpu_row *>(mb.rows.p) + i * per, mb.rows.p, per * sizeof(msgpu_row), ncclChar, mb.comm,
+                                   static_cast<hipStream_t>(msgpu_get_stream(mb.ctx)));
+      }
+      const ncclResult_t closed = nc->GroupEnd();
+      GNCCL(g, first_bad);
+      GNCCL(g, closed);
+    } else { // rehearsal transport: every slice has landed, then member i fetches the other n - 1
+      for (size_t i = 0; i < n; ++i) {
+        GHIP(g, hipSetDevice(g->m[i].device));
+        GHIP(g, hipStreamSynchronize(static_cast<hipStream_t>(msgpu_get_stream(g->m[i].ctx))));
+      }
+      for (size_t i = 0; i < n; ++i) {
+        Member &mb = g->m[i];
+        GHIP(g, hipSetDevice(mb.device));
+        for (size_t r = 0; r < n; ++r) {
+          const size_t lo = std::min(r * per, n_rows), hi = std::min(lo + per, n_rows);
+          if (r != i && hi > lo)
+            GHIP(g, hipMemcpyPeerAsync(static_cast<msgpu_row *>(mb.rows.p) + lo, mb.device, static_cast<msgpu_row *>(g->m[r].rows.p) + lo,
+                                       g->m[r].device, (hi - lo) * sizeof(msgpu_row), static_cast<hipStream_t>(msgpu_get_stream(mb.ctx))));
+        }
+      }
+    }
+  }
+
+  // ---- the fan-out: every member builds the index and computes its shard ------------------------------------------------
   auto work = [&](size_t i) {
     Member    &mb = g->m[i];
     const auto t0 = std::chrono::steady_clock::now();
     mb.rc         = hipSetDevice(mb.device) == hipSuccess ? MSGPU_OK : MSGPU_E_HIP;
-    if (mb.rc == MSGPU_OK) mb.rc = msgpu_load_rows(mb.ctx, rows, n_rows);
+    if (mb.rc == MSGPU_OK) mb.rc = sliced ? msgpu_load_rows_device(mb.ctx, mb.rows.p, n_rows) : msgpu_load_rows(mb.ctx, rows, n_rows);
     if (mb.rc == MSGPU_OK) mb.rc = msgpu_calculate_edges(mb.ctx);
     if (mb.rc == MSGPU_OK) mb.rc = msgpu_chaining_and_overlaps(mb.ctx);
     if (mb.rc == MSGPU_OK) mb.rc = msgpu_get_counts(mb.ctx, &mb.counts);
@@ -328,19 +379,35 @@ int msgpu_group_overlap(msgpu_group *g, const msgpu_row *rows, size_t n_rows, ms
       return gfail(g, rc, "member %zu: %s", i, msgpu_last_error(mb.ctx));
     GHIP(g, hipEventRecord(mb.ev1, static_cast<hipStream_t>(msgpu_get_stream(mb.ctx))));
   }
-  // ---- the merged list in host memory (from member 0), the Vertex facts -------------------------------------------------
+  // ---- the merged list in host memory, the Vertex facts ------------------------------------------------------------------
   const uint32_t V = g->m[0].counts.n_reads;
   if (!g->h_edges.ensure(std::max<uint64_t>(tot[0], 1) * sizeof(msgpu_edge)) ||
       !g->h_orders.ensure(std::max<uint64_t>(tot[1], 1) * sizeof(msgpu_order)) || !g->h_ids.ensure(std::max<uint64_t>(tot[2], 1) * 4) ||
       !g->h_read_len.ensure((size_t(V) + 1) * 4) || !g->h_read_first.ensure((size_t(V) + 1) * 4))
     return gfail(g, MSGPU_E_NOMEM, "page-locked host tables of the merged edge list");
+  // Every member holds the same merged tables: member i sends the i-th slice of each over ITS link, so the copy-out of a group
+  // of n takes a 1/n-th of one link's time (a table below 64 KB goes whole from member 0: a copy costs more than it moves).
   {
-    Member     &mb = g->m[0];
-    hipStream_t st = static_cast<hipStream_t>(msgpu_get_stream(mb.ctx));
+    const struct {
+      HostBlock *dst;
+      DevBlock Member::*src;
+      uint64_t  count, rec;
+    } tabs[3] = {{&g->h_edges, &Member::m_edges, tot[0], sizeof(msgpu_edge)},
+                 {&g->h_orders, &Member::m_orders, tot[1], sizeof(msgpu_order)},
+                 {&g->h_ids, &Member::m_ids, tot[2], 4}};
+    for (const auto &t : tabs) {
+      const uint64_t parts = t.count * t.rec < (1u << 16) ? 1 : n, per = (t.count + parts - 1) / parts;
+      for (uint64_t i = 0; i < parts; ++i) {
+        const uint64_t lo = std::min(i * per, t.count), hi = std::min(lo + per, t.count);
+        if (hi == lo) continue;
+        Member &mb = g->m[i];
+        GHIP(g, hipSetDevice(mb.device));
+        GHIP(g, hipMemcpyAsync(static_cast<char *>(t.dst->p) + lo * t.rec, static_cast<const char *>((mb.*(t.src)).p) + lo * t.rec,
+                               (hi - lo) * t.rec, hipMemcpyDeviceToHost, static_cast<hipStream_t>(msgpu_get_stream(mb.ctx))));
+      }
+    }
+    Member &mb = g->m[0];
     GHIP(g, hipSetDevice(mb.device));
-    if (tot[0]) GHIP(g, hipMemcpyAsync(g->h_edges.p, mb.m_edges.p, tot[0] * sizeof(msgpu_edge), hipMemcpyDeviceToHost, st));
-    if (tot[1]) GHIP(g, hipMemcpyAsync(g->h_orders.p, mb.m_orders.p, tot[1] * sizeof(msgpu_order), hipMemcpyDeviceToHost, st));
-    if (tot[2]) GHIP(g, hipMemcpyAsync(g->h_ids.p, mb.m_ids.p, tot[2] * 4, hipMemcpyDeviceToHost, st));
     if (V)
       if (int rc = msgpu_copy_reads(mb.ctx, static_cast<int32_t *>(g->h_read_len.p), static_cast<uint32_t *>(g->h_read_first.p)))
         return gfail(g, rc, "member 0: %s", msgpu_last_error(mb.ctx));
@@ -368,6 +435,7 @@ int msgpu_group_overlap(msgpu_group *g, const msgpu_row *rows, size_t n_rows, ms
   out->n_members       = static_cast<uint32_t>(n);
   out->id_bytes        = id_bytes;
   out->slab_bytes      = slab_bytes;
+  out->rows_sliced     = sliced ? 1u : 0u;
   double cm = 0;
   for (const Member &mb : g->m) cm = std::max(cm, mb.compute_ms);
   out->compute_ms  = static_cast<float>(cm);

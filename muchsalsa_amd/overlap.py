@@ -362,7 +362,7 @@ class OverlapGroup:
                   "ids": view(t.ids, t.n_ids, "<u4"), "read_len": view(t.read_len, t.n_reads, "<i4"),
                   "read_first_line": view(t.read_first_line, t.n_reads, "<u4")}
         info = {k: getattr(t, k) for k in ("n_ems", "n_reads", "n_anchors", "n_members", "id_bytes", "slab_bytes", "wall_ms",
-                                           "compute_ms", "exchange_ms")}
+                                           "compute_ms", "exchange_ms", "rows_sliced")}
         return tables, info
 
     def member_edgematches(self, member, edge_idx_local):

@@ -687,7 +687,7 @@ def test_group_of_one_over_rccl_equals_single_context(oracle):
                                   synth.synth_rows(300, 3000, 900, 1))):
             want = oracle.overlap(rows)
             t, info = grp.overlap(rows)
-            assert info["n_members"] == 1 and info["id_bytes"] == 3 and info["n_ems"] == len(want["ems"])
+            assert info["n_members"] == 1 and info["id_bytes"] == 3 and info["n_ems"] == len(want["ems"]) and not info["rows_sliced"]
             got = dict(t, ems=want["ems"])  # (EdgeMatch tables are not gathered: checked through the member below)
             assert_tables_equal(got, want, "group of one, job %d" % k)
             rl, fl = want["read_len"], want["read_first_line"]
@@ -706,15 +706,19 @@ def test_group_of_one_over_rccl_equals_single_context(oracle):
         overlap.OverlapGroup([99])
 
 
-@pytest.mark.parametrize("members", [2, 3, 8])
-def test_group_of_several_members_rehearsed_on_one_gpu(oracle, monkeypatch, members):
+@pytest.mark.parametrize("members,row_mode", [(2, "sliced"), (3, "sliced"), (8, "sliced"), (3, "replicate")])
+def test_group_of_several_members_rehearsed_on_one_gpu(oracle, monkeypatch, members, row_mode):
     """msgpu_group with n > 1 on a box with ONE GPU: MSGPU_GROUP_TRANSPORT=copy carries the all-gather by device-to-device copies
     instead of RCCL and lets the members share the device -- a member thread per shard, v1 % n sharding, the slab layout sized
     by the largest member, msgpu_pack_wire, msgpu_merge_wire with the counts of all members: everything of the n > 1 path but the
     ncclAllGather call itself.  The merged list == the host statement of the merge over the oracle's shard cuts, and, sorted back
-    into (v1, v2) order, the single-GPU tables; EdgeMatches from the owning member."""
+    into (v1, v2) order, the single-GPU tables; EdgeMatches from the owning member.  The rows reach the members as a 1/n-th each
+    over the link + an all-gather among them (the default with n > 1; 41,322 rows: a ragged last slice with 8 members) or whole to every
+    member (MSGPU_GROUP_ROWS=replicate); the merged tables leave as n slices, one per member."""
     from muchsalsa_amd import distributed as D, overlap, synth
     monkeypatch.setenv("MSGPU_GROUP_TRANSPORT", "copy")
+    if row_mode == "replicate":
+        monkeypatch.setenv("MSGPU_GROUP_ROWS", "replicate")
     rows = synth.synth_rows(1000, 5000, 4000, 13)
     full = oracle.overlap(rows)
     shards = [D.shard_view_host(full, r, members) for r in range(members)]
@@ -723,6 +727,7 @@ def test_group_of_several_members_rehearsed_on_one_gpu(oracle, monkeypatch, memb
         for rep in range(2):  # (the second call re-uses every buffer)
             t, info = grp.overlap(rows)
             assert info["n_members"] == members and info["n_ems"] == len(full["ems"])
+            assert info["rows_sliced"] == (row_mode == "sliced")
             for k in ("edges", "orders", "ids"):
                 got = t[k].copy()
                 want = host[k].copy()
