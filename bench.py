@@ -341,6 +341,26 @@ def group_leg(rows, reps=4):
         pinned.close()
 
 
+def group_on_node(world, workload, timeout_s=420):
+    """msgpu_group_overlap over the node's `world` GPUs -- the in-process C++ driver of the N > 1 path (a libms caller's view:
+    include/msgpu.h msgpu_group_*, RCCL resolved by the library) -- run as a CHILD process of rank 0 after the ranks' own process
+    group is gone: a failure or a hang of a collective that has never run on hardware cannot take the line with it."""
+    cmd = [sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "group_rehearsal.py"), "--devices",
+           ",".join(str(d) for d in range(world)), "--workload", workload, "--json"]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MSGPU_GROUP_TRANSPORT")}
+    try:
+        time.sleep(1.0)  # (the other ranks' processes let go of their devices)
+        run = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout_s)
+        lines = [ln for ln in run.stdout.splitlines() if ln.startswith("{")]
+        if run.returncode != 0 or not lines:
+            return {"error": "exit code %d: %s" % (run.returncode, run.stderr[-600:])}
+        return json.loads(lines[-1])
+    except subprocess.TimeoutExpired:
+        return {"error": "no result within %d s (the child process was killed)" % timeout_s}
+    except Exception as exc:  # noqa: BLE001
+        return {"error": "%s: %s" % (type(exc).__name__, exc)}
+
+
 def sharded_host_to_host_leg(torch, dist, D, dev, ctx, rows, world, rank, n_batches, reps=5):
     """SURVEY 8(d)'s region -- rows in host memory -> tables in host memory -- over the node's N PCIe links instead of one:
       rows      every rank holds the job's row table in its own pinned host memory, uploads 1/N of it over ITS link, and
@@ -1405,10 +1425,14 @@ def main():
                 out["cpu_baseline"]["consensus"] = cpu_consensus_baseline()
             except Exception as exc:  # noqa: BLE001
                 out["cpu_baseline"]["consensus"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
-        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     ctx.close()
     if multi:
         dist.destroy_process_group()
+    if rank == 0:
+        if multi and args.backend == "nccl" and not args.single_device and not args.kernels_only:
+            # every rank has left its process group (the others exit now): the node's GPUs go to ONE process, the C++ group
+            out["group_on_node"] = group_on_node(world, args.workload)
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
 
 
 if __name__ == "__main__":

@@ -653,6 +653,22 @@ def test_bench_two_and_three_ranks_rehearsal():
         assert line["config"]["edges"] > (n - 1) * single  # n partitions of that shape
 
 
+def test_bench_group_on_node_child_process():
+    """What `bench.py --gpus N` attaches to its line as "group_on_node": msgpu_group_overlap over the node's devices in a child
+    process of rank 0 (tools/group_rehearsal.py --devices ... --json), verified against the host merge of the shard tables on
+    every repetition.  One device here; a failure comes back as {"error": ...}, never as an exception."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    got = bench.group_on_node(1, "tiny")
+    assert "error" not in got, got
+    assert got["members"] == 1 and got["transport"] == "rccl" and got["edges"] > 0 and got["wall_ms"] >= got["compute_ms"] > 0
+    assert got["verified"].startswith("merged edge / order / id tables ==")
+    bad = bench.group_on_node(1, "no such workload", timeout_s=120)
+    assert "error" in bad
+
+
 def test_bench_starts_its_own_ranks():
     """`python bench.py --gpus N` without a launcher must start the rank processes itself (before touching the GPU) and
     relay rank 0's line: exercised with one rank (--self-launch), which is all a one-GPU box can run."""
