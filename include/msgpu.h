@@ -339,6 +339,14 @@ int msgpu_pack_wire(msgpu_ctx *ctx, void *d_wire_edges, void *d_wire_orders, voi
 int msgpu_merge_wire(msgpu_ctx *ctx, const void *d_gathered, uint32_t world, const uint64_t *counts, uint64_t slab_bytes,
                      uint64_t off_edges, uint64_t off_orders, uint64_t off_ids, uint32_t id_bytes, const uint32_t *id_base,
                      void *d_edges, void *d_orders, void *d_ids, void *hip_stream);
+/* The receiving end on the HOST: one set of wire blocks (host memory) back into records, on up to `threads` host threads (0 = 16).
+ * base[4] = what precedes the set in the tables its records point into {edges, EdgeMatches, orders, ids}: added to edge_idx,
+ * em_off, order_off, ids_off (NULL = zeros: the records of msgpu_copy_tables for the same context).  msgpu_overlap_batched_ex
+ * uses it for its windows when the EdgeMatch table stays in HBM (the tables travel over the host link in wire form).  No GPU,
+ * no context: plain host code. */
+int msgpu_unpack_wire_host(const void *wire_edges, const void *wire_orders, const void *wire_ids, uint32_t id_bytes,
+                           uint64_t n_edges, uint64_t n_orders, uint64_t n_ids, const uint64_t *base, msgpu_edge *edges,
+                           msgpu_order *orders, uint32_t *ids, uint32_t threads);
 
 /* ---- one process, the node's GPUs: a GROUP of contexts behind the same call site -------------------------------------------
  * The reference is ONE process that fans jobs over its workers and closes each phase with a barrier (src/main.cpp:143-178,
@@ -397,6 +405,8 @@ int  msgpu_group_device_tables(msgpu_group *g, int member, const void **d_edges,
  * msgpu_copy_tables bit for bit -- canonical order, cross references (em_off, order_off, edge_idx, ids_off) into the
  * whole tables -- owned by the context and valid until its next msgpu_overlap_batched / msgpu_destroy.  HBM holds one
  * window's tables at a time instead of the job's.  With msgpu_set_shard the windows cut this shard's reads.
+ * The windows are cut by measured work (the index build counts, per read, the scaffold rows it visits as an owner), so they
+ * hold the shares wanted whatever the read ids have to do with genome position.
  * n_batches 0 = 8 (3 with MSGPU_BATCH_NO_EDGEMATCHES).  `rows` should be pinned (msgpu_pinned_alloc) for the copy to run at link speed. */
 typedef struct msgpu_host_tables {
   const msgpu_edge      *edges;
@@ -423,7 +433,12 @@ int msgpu_overlap_batched(msgpu_ctx *ctx, const msgpu_row *rows, size_t n_rows, 
  *   MSGPU_BATCH_NO_EDGEMATCHES  (implies RESIDENT) the EdgeMatch table is NOT copied to the host: out->ems = NULL,
  *                               out->n_ems is still its size.  Downstream only assemblePath reads EdgeMatches, and only
  *                               those of path edges (dg.cpp:99-101 -> ap.cpp:631-706): fetch them with
- *                               msgpu_get_edgematches.  Moves 154 MB instead of 971 MB on configs[2].
+ *                               msgpu_get_edgematches.  The other three tables cross the host link in the exchange's
+ *                               wire form (msgpu_pack_wire per window; 93 MB instead of 154 MB -- or 971 MB with the
+ *                               EdgeMatches -- on configs[2]) and a host thread of the call turns every window back
+ *                               into records (msgpu_unpack_wire_host) while the next one computes: the tables handed
+ *                               out are the same records.  MSGPU_NO_WIRE_COPY=1 in the environment of msgpu_create:
+ *                               whole records over the link (A/B switch).
  *   MSGPU_BATCH_ROWS_ON_DEVICE  `rows` is a DEVICE pointer (msgpu_load_rows_device): the table is in HBM already, e.g.
  *                               all-gathered over xGMI from the 1/N slices the ranks of a node uploaded over their own links.
  */

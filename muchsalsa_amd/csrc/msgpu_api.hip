@@ -11,6 +11,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
 #include <new>
 #include <thread>
 #include <vector>
@@ -271,7 +274,11 @@ struct msgpu_ctx {
   struct HostBuf {
     void  *p   = nullptr;
     size_t cap = 0;
-  } h_edges, h_ems, h_orders, h_ids, h_read_len, h_read_first, h_sel_off, h_sel_ems;
+  } h_edges, h_ems, h_orders, h_ids, h_read_len, h_read_first, h_sel_off, h_sel_ems, h_wire[2];
+  hipEvent_t ev_part[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}}; // a window's wire blocks, copied one by one
+  DevBuf win_cuts;        // the dispatcher's window cuts by measured work (k_window_cuts)
+  DevBuf wire_dev[2];     // a window's edge / order / id tables in wire form, on their way to the host (two sets: see the dispatcher)
+  bool   wire_copy = true; // MSGPU_NO_WIRE_COPY=1: windows always leave as whole records (A/B switch)
 
   // timing
   hipEvent_t ev[10] = {nullptr};
@@ -378,7 +385,7 @@ void release_all(msgpu_ctx *c) {
                    &c->big_key, &c->big_t, &c->big_r2s, &c->big_pfx, &c->pair_tab, &c->edge_fast, &c->big_off, &c->ems, &c->order_scr, &c->ids_scr,
                    &c->edge_norders, &c->edge_nids, &c->order_base, &c->ids_base, &c->orders, &c->ids, &c->big_list, &c->cls_list, &c->cls_part, &c->cls_partials,
                    &c->big_elems, &c->big_paths, &c->alt_edges, &c->alt_ems, &c->alt_orders, &c->alt_ids, &c->vis16, &c->visits,
-                   &c->spos2, &c->bin_cursor, &c->bin_start};
+                   &c->spos2, &c->bin_cursor, &c->bin_start, &c->wire_dev[0], &c->wire_dev[1], &c->win_cuts};
   for (DevBuf *b : all) b->release();
 }
 
@@ -665,6 +672,8 @@ int msgpu_create(int device, const msgpu_params *params, msgpu_ctx **out) {
     c->fast_path   = !(nf && nf[0] == '1');
     const char *ns = getenv("MSGPU_NO_SUBWAVE"); // test hook: one edge per wavefront whatever its size
     c->sub_wave    = !(ns && ns[0] == '1');
+    const char *nw = getenv("MSGPU_NO_WIRE_COPY");
+    c->wire_copy   = !(nw && nw[0] == '1');
     const char *nbin = getenv("MSGPU_NO_BIN"); // A/B switch: the index build's atomic path (rounds 1-3) for every input
     c->use_bin       = !(nbin && nbin[0] == '1');
   }
@@ -680,6 +689,12 @@ int msgpu_create(int device, const msgpu_params *params, msgpu_ctx **out) {
   if (hipStreamCreateWithPriority(&c->side_stream, hipStreamNonBlocking, prio_greatest) != hipSuccess ||
       hipStreamCreateWithPriority(&c->side_stream2, hipStreamNonBlocking, prio_greatest) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_side2, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_part[0][0], hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_part[0][1], hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_part[0][2], hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_part[1][0], hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_part[1][1], hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_part[1][2], hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_side[0], hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_side[1], hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_readback, hipEventDisableTiming) != hipSuccess ||
@@ -713,6 +728,9 @@ void msgpu_destroy(msgpu_ctx *c) {
   if (c->ev_readback) (void)hipEventDestroy(c->ev_readback);
   if (c->ev_order) (void)hipEventDestroy(c->ev_order);
   if (c->ev_side2) (void)hipEventDestroy(c->ev_side2);
+  for (auto &per_set : c->ev_part)
+    for (hipEvent_t e : per_set)
+      if (e) (void)hipEventDestroy(e);
   if (c->side_stream2) {
     (void)hipStreamSynchronize(c->side_stream2);
     (void)hipStreamDestroy(c->side_stream2);
@@ -733,7 +751,7 @@ void msgpu_destroy(msgpu_ctx *c) {
     if (c->ev_copied[k]) (void)hipEventDestroy(c->ev_copied[k]);
   }
   for (msgpu_ctx::HostBuf *h : {&c->h_edges, &c->h_ems, &c->h_orders, &c->h_ids, &c->h_read_len, &c->h_read_first, &c->h_sel_off,
-                               &c->h_sel_ems})
+                               &c->h_sel_ems, &c->h_wire[0], &c->h_wire[1]})
     if (h->p) pinned_block_free(h->p);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   if (c->h_scalars) (void)hipHostFree(c->h_scalars);
@@ -1085,7 +1103,7 @@ int msgpu_chaining_and_overlaps(msgpu_ctx *c) {
     ENSURE(c, big_paths, (c->n_big_ems ? c->n_big_ems : 1) * 2 * big_path_bytes());
     HIPCHK(c, hipEventRecord(c->ev_side[0], st)); // (the list and the scratch offsets: k_emit_edges)
   }
-  auto launch_big = [&]() -> int { // after the main stream's chain kernels are on their way (see msgpu_calculate_edges)
+  auto launch_big = [&]() -> int {
     if (!n_big) return MSGPU_OK;
     HIPCHK(c, hipStreamWaitEvent(c->side_stream, c->ev_side[0], 0));
     launch_chain_big(c->side_stream, a, c->big_list.as<uint32_t>(), c->big_off.as<uint64_t>(), n_big,
@@ -1093,6 +1111,7 @@ int msgpu_chaining_and_overlaps(msgpu_ctx *c) {
     HIPCHK(c, hipEventRecord(c->ev_side[1], c->side_stream));
     return MSGPU_OK;
   };
+  if (int rc = launch_big()) return rc; // (first: its few long-lived wavefronts get their registers before k_chain fills the device)
   if (c->sub_wave && E) {
     // the size-sorted edge list and the class sizes are there since msgpu_calculate_edges
     const uint32_t *list = c->cls_list.as<uint32_t>();
@@ -1107,7 +1126,6 @@ int msgpu_chaining_and_overlaps(msgpu_ctx *c) {
     launch_chain(st, a, nullptr, 0);
   }
   HIPCHK(c, hipEventRecord(ck_end, st));
-  if (int rc = launch_big()) return rc;
   c->ck_head = (c->ck_head + 1) % msgpu_ctx::CK_RING;
   if (c->ck_count < msgpu_ctx::CK_RING) ++c->ck_count;
   HIPCHK(c, hipGetLastError());
@@ -1374,6 +1392,25 @@ int msgpu_pack_wire(msgpu_ctx *c, void *d_wire_edges, void *d_wire_orders, void 
   return MSGPU_OK;
 }
 
+int msgpu_unpack_wire_host(const void *wire_edges, const void *wire_orders, const void *wire_ids, uint32_t id_bytes, uint64_t n_edges,
+                           uint64_t n_orders, uint64_t n_ids, const uint64_t *base, msgpu_edge *edges, msgpu_order *orders,
+                           uint32_t *ids, uint32_t threads) {
+  if ((id_bytes != 3 && id_bytes != 4) || !wire_edges || !wire_orders || (n_ids && !wire_ids) || (n_edges && !edges) ||
+      (n_orders && !orders) || (n_ids && !ids))
+    return MSGPU_E_ARG;
+  if ((reinterpret_cast<uintptr_t>(wire_edges) & 3) || (reinterpret_cast<uintptr_t>(wire_orders) & 7) ||
+      (reinterpret_cast<uintptr_t>(wire_ids) & 3))
+    return MSGPU_E_ARG;
+  try {
+    unpack_wire_host(static_cast<const uint8_t *>(wire_edges), static_cast<const uint8_t *>(wire_orders),
+                     static_cast<const uint32_t *>(wire_ids), id_bytes, n_edges, n_orders, n_ids, base ? base[0] : 0, base ? base[1] : 0,
+                     base ? base[2] : 0, base ? base[3] : 0, edges, orders, ids, threads ? threads : 16);
+  } catch (...) {
+    return MSGPU_E_NOMEM;
+  }
+  return MSGPU_OK;
+}
+
 int msgpu_merge_wire(msgpu_ctx *c, const void *d_gathered, uint32_t world, const uint64_t *counts, uint64_t slab_bytes,
                      uint64_t off_edges, uint64_t off_orders, uint64_t off_ids, uint32_t id_bytes, const uint32_t *id_base,
                      void *d_edges, void *d_orders, void *d_ids, void *hip_stream) {
@@ -1454,6 +1491,95 @@ int ensure_host(msgpu_ctx *c, msgpu_ctx::HostBuf &h, size_t need, size_t valid, 
   return MSGPU_OK;
 }
 
+// The receiving end of a dispatcher window that left in wire form: a thread that waits for the window's copy and turns the
+// blocks into records (unpack_wire_host on the host pool) while the stream thread goes on with the next window.
+struct WindowUnpacker {
+  struct Job {
+    hipEvent_t      copied;
+    const uint8_t  *w_edges, *w_orders;
+    const uint32_t *w_ids; // null: the ids travelled as they are, straight into the table
+    uint64_t        n_edges, n_orders, n_ids, base_edges, base_ems, base_orders, base_ids;
+    msgpu_edge     *edges;
+    msgpu_order    *orders;
+    uint32_t       *ids;
+    unsigned        tables = 7; // 1 edges, 2 orders, 4 ids: which of them this job turns into records
+  };
+  int                     device = 0;
+  bool                    debug = false; // MSGPU_BATCH_DEBUG: when every window's copy was seen and when its records stood
+  std::chrono::steady_clock::time_point t0;
+  std::mutex              m;
+  std::condition_variable cv;
+  std::deque<Job>         q;
+  uint64_t                pushed = 0, done = 0;
+  bool                    stop = false;
+  hipError_t              err = hipSuccess;
+  std::thread             th;
+  bool start(int dev) {
+    device = dev;
+    try {
+      th = std::thread([this] { loop(); });
+    } catch (...) {
+      return false;
+    }
+    return true;
+  }
+  void loop() {
+    (void)hipSetDevice(device);
+    for (;;) {
+      Job j;
+      {
+        std::unique_lock<std::mutex> lk(m);
+        cv.wait(lk, [&] { return stop || !q.empty(); });
+        if (q.empty()) return;
+        j = q.front();
+        q.pop_front();
+      }
+      hipError_t e = hipEventSynchronize(j.copied);
+      const auto t_copied = std::chrono::steady_clock::now();
+      if (e == hipSuccess) {
+        try {
+          unpack_wire_host(j.w_edges, j.w_orders, j.w_ids, j.w_ids ? 3 : 4, j.n_edges, j.n_orders, j.w_ids ? j.n_ids : 0, j.base_edges,
+                           j.base_ems, j.base_orders, j.base_ids, j.edges, j.orders, j.ids, 16, j.tables);
+        } catch (...) {
+          e = hipErrorOutOfMemory;
+        }
+      }
+      if (debug)
+        fprintf(stderr, "[batched] unpacker: tables %u of the copy of %llu edges / %llu orders / %llu ids seen at %.2f ms, records at %.2f ms\n",
+                j.tables, (unsigned long long)j.n_edges, (unsigned long long)j.n_orders, (unsigned long long)j.n_ids,
+                std::chrono::duration<double, std::milli>(t_copied - t0).count(),
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+      std::lock_guard<std::mutex> g(m);
+      if (e != hipSuccess && err == hipSuccess) err = e;
+      ++done;
+      cv.notify_all();
+    }
+  }
+  void push(const Job &j) {
+    std::lock_guard<std::mutex> g(m);
+    q.push_back(j);
+    ++pushed;
+    cv.notify_all();
+  }
+  void wait_done(uint64_t upto) { // the first `upto` windows pushed are records in the host tables
+    std::unique_lock<std::mutex> lk(m);
+    cv.wait(lk, [&] { return done >= upto; });
+  }
+  void drain() { wait_done(pushed); }
+  hipError_t finish() {
+    if (th.joinable()) {
+      {
+        std::lock_guard<std::mutex> g(m);
+        stop = true;
+        cv.notify_all();
+      }
+      th.join(); // (the loop empties the queue before it looks at `stop`)
+    }
+    return err;
+  }
+  ~WindowUnpacker() { (void)finish(); }
+};
+
 } // namespace
 
 int msgpu_overlap_batched(msgpu_ctx *c, const msgpu_row *rows, size_t n_rows, uint32_t n_batches, msgpu_host_tables *out) {
@@ -1508,17 +1634,68 @@ int msgpu_overlap_batched_ex(msgpu_ctx *c, const msgpu_row *rows, size_t n_rows,
     HIPCHK(c, hipMemcpyAsync(c->h_read_first.p, c->read_first.p, size_t(V) * 4, hipMemcpyDeviceToHost, cs));
   }
 
-  // Windows of owner reads.  An edge belongs to its lower read id, so with ids that are unrelated to genome position
-  // read r owns about (V - r) / V of its pairs: windows that end at V (1 - sqrt(1 - k/B)) hold equal shares.  Balance
-  // is not needed for correctness, and hardly for speed: a batch computes several times faster than it copies.
-  auto cut = [&](uint32_t k) -> uint32_t {
-    if (k >= B) return V;
-    const double x = 1.0 - std::sqrt(1.0 - double(k) / double(B));
-    uint64_t     v = static_cast<uint64_t>(x * double(V));
-    return v > V ? V : static_cast<uint32_t>(v);
-  };
+  // Windows of owner reads, cut by measured work: the index build left, per read, the scaffold rows it visits as an owner
+  // (`visits`: what its candidate scan costs and, closely, what it yields); a prefix sum over them and one binary search per
+  // cut give windows that hold the wanted shares of the job whatever the read ids have to do with genome position.  Shares:
+  // equal -- unless the windows leave in wire form (below): then the job waits for the compute, and what is left when the last
+  // window is done is that window's copy and its unpacking, so the windows shrink towards the end (9 : 7 : 4 for three).
+  // Without visit counts (a generic index; nothing to visit) the cuts assume read ids unrelated to genome position: read r owns
+  // about (V - r) / V of its pairs, windows that end at V (1 - sqrt(1 - k/B)) hold equal shares.
+  const bool wire_wanted = !copy_ems && c->wire_copy && V != 0;
+  std::vector<uint32_t> cuts(size_t(B) + 1, V);
+  std::vector<double>   cum_share(size_t(B) + 1, 1.0); // share of the job's work in front of every cut (for the size hints)
+  cuts[0]      = 0;
+  cum_share[0] = 0.0;
+  bool measured = false;
+  if (B > 1 && c->index_fast) {
+    WindowCutArgs wa;
+    wa.n = B - 1;
+    double acc = 0, sum = 0;
+    auto   weight = [&](uint32_t k) { return wire_wanted ? 1.0 + 1.25 * double(B - 1 - k) / double(B - 1) : 1.0; };
+    for (uint32_t k = 0; k < B; ++k) sum += weight(k);
+    for (uint32_t k = 0; k + 1 < B; ++k) {
+      acc += weight(k) / sum;
+      wa.frac[k] = static_cast<float>(acc);
+    }
+    ENSURE(c, cand_off, (size_t(V) + 2) * 8);
+    ENSURE(c, win_cuts, (2 * size_t(B) + 1) * 8);
+    exclusive_scan<uint64_t>(st, c->visits.as<uint32_t>(), V, c->cand_off.as<uint64_t>(), c->scan_tmp.as<uint64_t>(),
+                             c->cand_off.as<uint64_t>() + V);
+    launch_window_cuts(st, c->cand_off.as<uint64_t>(), V, wa, c->win_cuts.as<uint64_t>());
+    HIPCHK(c, hipGetLastError());
+    std::vector<uint64_t> got(2 * size_t(B) - 1);
+    HIPCHK(c, hipMemcpyAsync(got.data(), c->win_cuts.p, got.size() * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    const uint64_t total = got[2 * size_t(B) - 2];
+    if (total) {
+      measured = true;
+      for (uint32_t k = 1; k < B; ++k) {
+        cuts[k]      = static_cast<uint32_t>(std::min<uint64_t>(got[k - 1], V));
+        cum_share[k] = double(got[B - 1 + k - 1]) / double(total);
+      }
+    }
+  }
+  if (!measured)
+    for (uint32_t k = 1; k < B; ++k) {
+      const double x = 1.0 - std::sqrt(1.0 - double(k) / double(B));
+      cuts[k]        = static_cast<uint32_t>(std::min<uint64_t>(static_cast<uint64_t>(x * double(V)), V));
+      // (the smaller of the two shares a cut can hold, see below: ids unrelated to position / ids that follow the genome)
+      cum_share[k] = double(cuts[k]) / double(V ? V : 1);
+    }
+  for (uint32_t k = 1; k < B; ++k) cuts[k] = std::max(cuts[k], cuts[k - 1] + 1);            // no empty window (B <= V)
+  for (uint32_t k = B - 1; k >= 1; --k) cuts[k] = std::min(cuts[k], V - (B - k));
+  auto cut = [&](uint32_t k) -> uint32_t { return k >= B ? V : cuts[k]; };
   uint64_t tot_e = 0, tot_m = 0, tot_o = 0, tot_i = 0, tot_fast = 0;
   int      rc = MSGPU_OK;
+  // The EdgeMatch table stays in HBM: from the first window on the job waits for the host link, so the other three tables
+  // cross it in the exchange's wire form (17 + 33 bytes per edge + order instead of 32 + 64, three bytes per anchor id while
+  // the ids fit 24 bits) and a host thread turns every window back into records while the next one computes.
+  WindowUnpacker unpacker;
+  unpacker.debug = std::getenv("MSGPU_BATCH_DEBUG") != nullptr;
+  unpacker.t0    = t_start;
+  bool           wire = !copy_ems && c->wire_copy && V != 0 && unpacker.start(c->device);
+  const bool     wire_ids3 = c->A <= (1u << 24);
+  uint64_t       job_of_set[2] = {0, 0}; // the unpacker's job count after the last window that used this set's host block
   const bool dbg = std::getenv("MSGPU_BATCH_DEBUG") != nullptr;
   if (dbg) fprintf(stderr, "[batched] rows loaded + index at %.2f ms\n", ms_since(t_start));
   struct GrowGuard { // (back to 1 however the loop is left)
@@ -1538,14 +1715,14 @@ int msgpu_overlap_batched_ex(msgpu_ctx *c, const msgpu_row *rows, size_t n_rows,
     c->base_ems    = tot_m;
     c->base_orders = tot_o;
     c->base_ids    = tot_i;
-    // the share of the job's records the windows up to and including this one hold, at least (used to extrapolate sizes).
-    // With read ids unrelated to genome position a read owns its pairs with every later read and the windows hold
-    // 1 - (1 - hi/V)^2 of the records; with ids that follow the genome (a PAF whose anchors come in assembly order) every
-    // read owns about half of its pairs and the share is hi/V.  Real inputs lie between (BASELINE configs[2]: 26 / 29 /
-    // 45 % in three windows cut for equal shares of the first kind), so sizes are extrapolated with the smaller share:
-    // too large a table costs address space, too small a one an allocation and a move in the middle of the job.
-    const double share = double(c->win_hi) >= double(V) ? 1.0 : double(c->win_hi) / V;
-    const double share_before = double(c->win_lo) / (V ? V : 1); // ... the windows before this one hold
+    // the share of the job's records the windows up to and including this one hold (used to extrapolate sizes): measured by
+    // the visit counts the cuts were made with, or -- without them -- at least: with read ids unrelated to genome position a
+    // read owns its pairs with every later read and the windows hold 1 - (1 - hi/V)^2 of the records; with ids that follow the
+    // genome (a PAF whose anchors come in assembly order) every read owns about half of its pairs and the share is hi/V.
+    // Real inputs lie between, so sizes are then extrapolated with the smaller share: too large a table costs address space,
+    // too small a one an allocation and a move in the middle of the job.
+    const double share        = cum_share[k + 1];
+    const double share_before = cum_share[k]; // ... the windows before this one hold
     auto         hint_of = [&](uint64_t have, size_t rec, double sh) {
       return static_cast<size_t>(double(have) / (sh > 0.02 ? sh : 0.02) * 1.15) * rec;
     };
@@ -1579,9 +1756,46 @@ int msgpu_overlap_batched_ex(msgpu_ctx *c, const msgpu_row *rows, size_t n_rows,
     auto guarded = [&](hipError_t e, const char *what) {
       if (e != hipSuccess && rc == MSGPU_OK) rc = fail(c, MSGPU_E_HIP, "%s failed: %s", what, hipGetErrorString(e));
     };
+    // this window in wire form?  (32-bit offsets inside a window; the staging block of this set was last read by the copy of
+    // window k - 2)
+    const bool     w_this = wire && c->n_ems <= 0xffffffffull && c->n_orders <= 0xffffffffull && c->n_ids <= 0xffffffffull;
+    const uint64_t w_off_o = (wire_edges_bytes(c->n_edges) + 255) & ~uint64_t(255),
+                   w_off_i = (w_off_o + wire_orders_bytes(c->n_orders) + 255) & ~uint64_t(255),
+                   w_total = wire_ids3 ? ((w_off_i + wire_ids_bytes(c->n_ids, 3) + 255) & ~uint64_t(255)) : w_off_i;
+    PackWireArgs pa;
+    auto         pack_into = [&](void *block, hipStream_t on) {
+      pa.edges       = static_cast<const msgpu_edge *>(c->edges.at());
+      pa.orders      = static_cast<const msgpu_order *>(c->orders.at());
+      pa.n_edges     = c->n_edges;
+      pa.n_orders    = c->n_orders;
+      pa.w_edges     = static_cast<uint8_t *>(block);
+      pa.w_orders    = pa.w_edges + w_off_o;
+      pa.ids         = wire_ids3 ? static_cast<const uint32_t *>(c->ids.at()) : nullptr;
+      pa.n_ids       = c->n_ids;
+      pa.w_ids       = reinterpret_cast<uint32_t *>(pa.w_edges + w_off_i);
+      pa.base_edges  = static_cast<uint32_t>(tot_e);
+      pa.base_ems    = tot_m;
+      pa.base_orders = tot_o;
+      pa.base_ids    = tot_i;
+      launch_pack_wire(on, pa);
+      guarded(hipGetLastError(), "the pack kernel");
+    };
+    if (w_this) {
+      guarded(c->wire_dev[set].ensure(w_total), "device block of the wire form");
+      if (rc == MSGPU_OK && k >= 2) guarded(hipStreamWaitEvent(st, c->ev_copied[set], 0), "hipStreamWaitEvent");
+      if (rc != MSGPU_OK) break;
+      pack_into(c->wire_dev[set].p, st);
+    }
     guarded(hipEventRecord(c->ev_done[set], st), "hipEventRecord");
-    if (dbg) fprintf(stderr, "[batched] window %u: launched at %.2f ms (edges %llu, orders %llu, ids %llu)\n", k, ms_since(t_start),
-                     (unsigned long long)c->n_edges, (unsigned long long)c->n_orders, (unsigned long long)c->n_ids);
+    if (dbg) fprintf(stderr, "[batched] window %u: launched at %.2f ms (edges %llu, orders %llu, ids %llu%s)\n", k, ms_since(t_start),
+                     (unsigned long long)c->n_edges, (unsigned long long)c->n_orders, (unsigned long long)c->n_ids, w_this ? ", wire form" : "");
+    if (wire) { // a host table that has to grow moves: every window before this one must be in it first
+      const bool grows = (tot_e + c->n_edges + 1) * sizeof(msgpu_edge) > c->h_edges.cap || (tot_o + c->n_orders + 1) * sizeof(msgpu_order) > c->h_orders.cap ||
+                         (tot_i + c->n_ids + 1) * 4 > c->h_ids.cap;
+      if (grows) unpacker.drain();
+      if (w_this) unpacker.wait_done(job_of_set[set]); // the host block of this set is free again
+      if (rc == MSGPU_OK && w_this) rc = ensure_host(c, c->h_wire[set], w_total, 0, 0);
+    }
     // room in the pinned result tables; the expected job size is extrapolated from what the windows so far produced
     if (rc == MSGPU_OK) rc = ensure_host(c, c->h_edges, (tot_e + c->n_edges + 1) * sizeof(msgpu_edge), tot_e * sizeof(msgpu_edge), hint(tot_e + c->n_edges, sizeof(msgpu_edge)));
     if (rc == MSGPU_OK && copy_ems) rc = ensure_host(c, c->h_ems, (tot_m + c->n_ems + 1) * sizeof(msgpu_edgematch), tot_m * sizeof(msgpu_edgematch), hint(tot_m + c->n_ems, sizeof(msgpu_edgematch)));
@@ -1591,16 +1805,55 @@ int msgpu_overlap_batched_ex(msgpu_ctx *c, const msgpu_row *rows, size_t n_rows,
     if (dbg) fprintf(stderr, "[batched] window %u: host tables ready at %.2f ms (caps %zu %zu %zu)\n", k, ms_since(t_start),
                      c->h_edges.cap, c->h_orders.cap, c->h_ids.cap);
     guarded(hipStreamWaitEvent(cs, c->ev_done[set], 0), "hipStreamWaitEvent");
-    // (Device-to-host copies are shader blits on this stack -- __amd_rocclr_copyBuffer in a kernel trace, not SDMA -- and a
-    // compute kernel that overlaps one completes only when that copy kernel does, so a window's chain of small dependent
-    // kernels barely advances while its predecessor's tables travel: few, large windows overlap best.  Cutting the
-    // copies into 1 MB pieces was tried and lost more link efficiency than it gained: 30.6 instead of 22.0 ms for the
-    // full tables.)
-    if (c->n_edges) guarded(hipMemcpyAsync(static_cast<msgpu_edge *>(c->h_edges.p) + tot_e, c->edges.at(), c->n_edges * sizeof(msgpu_edge), hipMemcpyDeviceToHost, cs), "copy of the edge table");
-    if (c->n_ems && copy_ems) guarded(hipMemcpyAsync(static_cast<msgpu_edgematch *>(c->h_ems.p) + tot_m, c->ems.at(), c->n_ems * sizeof(msgpu_edgematch), hipMemcpyDeviceToHost, cs), "copy of the EdgeMatch table");
-    if (c->n_orders) guarded(hipMemcpyAsync(static_cast<msgpu_order *>(c->h_orders.p) + tot_o, c->orders.at(), c->n_orders * sizeof(msgpu_order), hipMemcpyDeviceToHost, cs), "copy of the order table");
-    if (c->n_ids) guarded(hipMemcpyAsync(static_cast<uint32_t *>(c->h_ids.p) + tot_i, c->ids.at(), c->n_ids * 4, hipMemcpyDeviceToHost, cs), "copy of the id table");
-    guarded(hipEventRecord(c->ev_copied[set], cs), "hipEventRecord");
+    // (Device-to-host copies are shader blits on this stack -- __amd_rocclr_copyBuffer in a kernel trace -- and a compute
+    // kernel beside one makes next to no progress until the copy is over (profiles/r4_06/window_timeline_*.txt: the 16 us
+    // kernel that opens the next window takes as long as the copy beside it; k_chain beside a copy takes its own time plus
+    // the copy's).  So windows buy little overlap, the job is the sum of compute and link time, and fewer bytes are what
+    // helps: few, large windows, wire form.  Tried and dropped: copies in 1 MB pieces (30.6 instead of 22.0 ms for the full
+    // tables); a window's copy held back until the next window's long kernels start; a copy kernel of our own with 8..256
+    // workgroups writing mapped host memory (every size slower: 8.1-9.1 against 7.9 ms -- it is the host writes, not the
+    // occupied wave slots, that stall the others); the pack kernel writing host memory itself (8.9 ms); host tables from
+    // hipHostMalloc instead of registered blocks; the runtime's copy-engine switches.)
+    if (w_this) {
+      // three blocks, three copies, three unpacking jobs: the edge block first (the orders take their vertices from it), and what
+      // is left to do when the last copy lands is one table
+      const uint8_t *hw = static_cast<const uint8_t *>(c->h_wire[set].p);
+      WindowUnpacker::Job j;
+      j.w_edges     = hw;
+      j.w_orders    = hw + w_off_o;
+      j.w_ids       = wire_ids3 ? reinterpret_cast<const uint32_t *>(hw + w_off_i) : nullptr;
+      j.n_edges     = c->n_edges;
+      j.n_orders    = c->n_orders;
+      j.n_ids       = c->n_ids;
+      j.base_edges  = tot_e;
+      j.base_ems    = tot_m;
+      j.base_orders = tot_o;
+      j.base_ids    = tot_i;
+      j.edges       = static_cast<msgpu_edge *>(c->h_edges.p) + tot_e;
+      j.orders      = static_cast<msgpu_order *>(c->h_orders.p) + tot_o;
+      j.ids         = static_cast<uint32_t *>(c->h_ids.p) + tot_i;
+      const uint64_t lo[3] = {0, w_off_o, w_off_i}, hi[3] = {w_off_o, w_off_i, w_total};
+      for (int part = 0; part < 3 && rc == MSGPU_OK; ++part) {
+        if (hi[part] > lo[part])
+          guarded(hipMemcpyAsync(static_cast<char *>(c->h_wire[set].p) + lo[part], static_cast<const char *>(c->wire_dev[set].p) + lo[part],
+                                 hi[part] - lo[part], hipMemcpyDeviceToHost, cs), "copy of a wire block");
+        if (part == 2 && !wire_ids3 && c->n_ids) // 4-byte ids are not packed: they go straight into the id table
+          guarded(hipMemcpyAsync(static_cast<uint32_t *>(c->h_ids.p) + tot_i, c->ids.at(), c->n_ids * 4, hipMemcpyDeviceToHost, cs), "copy of the id table");
+        guarded(hipEventRecord(c->ev_part[set][part], cs), "hipEventRecord");
+        if (rc != MSGPU_OK) break;
+        j.copied = c->ev_part[set][part];
+        j.tables = 1u << part;
+        unpacker.push(j);
+      }
+      guarded(hipEventRecord(c->ev_copied[set], cs), "hipEventRecord");
+      job_of_set[set] = unpacker.pushed; // (only this thread pushes)
+    } else {
+      if (c->n_edges) guarded(hipMemcpyAsync(static_cast<msgpu_edge *>(c->h_edges.p) + tot_e, c->edges.at(), c->n_edges * sizeof(msgpu_edge), hipMemcpyDeviceToHost, cs), "copy of the edge table");
+      if (c->n_ems && copy_ems) guarded(hipMemcpyAsync(static_cast<msgpu_edgematch *>(c->h_ems.p) + tot_m, c->ems.at(), c->n_ems * sizeof(msgpu_edgematch), hipMemcpyDeviceToHost, cs), "copy of the EdgeMatch table");
+      if (c->n_orders) guarded(hipMemcpyAsync(static_cast<msgpu_order *>(c->h_orders.p) + tot_o, c->orders.at(), c->n_orders * sizeof(msgpu_order), hipMemcpyDeviceToHost, cs), "copy of the order table");
+      if (c->n_ids) guarded(hipMemcpyAsync(static_cast<uint32_t *>(c->h_ids.p) + tot_i, c->ids.at(), c->n_ids * 4, hipMemcpyDeviceToHost, cs), "copy of the id table");
+    }
+    if (!w_this) guarded(hipEventRecord(c->ev_copied[set], cs), "hipEventRecord");
     tot_e += c->n_edges;
     tot_m += c->n_ems;
     tot_o += c->n_orders;
@@ -1615,6 +1868,7 @@ int msgpu_overlap_batched_ex(msgpu_ctx *c, const msgpu_row *rows, size_t n_rows,
   }
   out->compute_done_ms = ms_since(t_start);
   // WaitGroup::wait(): every batch's tables are in host memory
+  const hipError_t e0 = unpacker.finish(); // (its windows are records now)
   hipError_t e1 = hipStreamSynchronize(cs), e2 = hipStreamSynchronize(st);
   if (dbg) fprintf(stderr, "[batched] loop left at %.2f ms, streams idle at %.2f ms\n", out->compute_done_ms, ms_since(t_start));
   c->win_lo = 0;
@@ -1623,6 +1877,7 @@ int msgpu_overlap_batched_ex(msgpu_ctx *c, const msgpu_row *rows, size_t n_rows,
   reset_views();
   c->state = ST_LOADED; // the context's own tables hold one batch only: results are the host tables
   if (rc != MSGPU_OK) return rc;
+  HIPCHK(c, e0);
   HIPCHK(c, e1);
   HIPCHK(c, e2);
   if (resident) { // ... or the whole job: the state msgpu_chaining_and_overlaps leaves, minus the per-edge scratch

@@ -102,11 +102,24 @@ struct PackWireArgs {
   uint64_t           n_edges, n_orders, n_ids;
   uint8_t           *w_edges, *w_orders;
   uint32_t          *w_ids;
+  // what the records' cross references carry beyond this table set (a window of the dispatcher: the job's records before it);
+  // the wire offsets are relative to the set, so they fit 32 bits whatever came before
+  uint64_t           base_ems = 0, base_orders = 0, base_ids = 0;
+  uint32_t           base_edges = 0;
 };
 inline uint64_t wire_edges_bytes(uint64_t n) { return 17 * n + 8; }
 inline uint64_t wire_orders_bytes(uint64_t n) { return 33 * n + 4; }
 inline uint64_t wire_ids_bytes(uint64_t n, uint32_t id_bytes) { return id_bytes == 3 ? (3 * n + 3) / 4 * 4 : 4 * n; }
+struct WindowCutArgs {
+  uint32_t n;         // cuts wanted (windows - 1, at most 255)
+  float    frac[255]; // cumulative share of the work in front of cut j
+};
+void launch_window_cuts(hipStream_t st, const uint64_t *cum, uint32_t V, const WindowCutArgs &a, uint64_t *out);
 void launch_pack_wire(hipStream_t st, const PackWireArgs &a);
+// the wire form back into records on the host (wire_host.cpp): what k_merge_wire does for one slab, with the bases added
+void unpack_wire_host(const uint8_t *w_edges, const uint8_t *w_orders, const uint32_t *w_ids, uint32_t id_bytes, uint64_t n_edges,
+                      uint64_t n_orders, uint64_t n_ids, uint64_t base_edges, uint64_t base_ems, uint64_t base_orders,
+                      uint64_t base_ids, msgpu_edge *edges, msgpu_order *orders, uint32_t *ids, unsigned threads, unsigned tables = 7);
 void launch_merge_wire(hipStream_t st, const MergeArgs &a, bool ids3);
 
 template <class T> void exclusive_scan(hipStream_t st, const uint32_t *in, uint64_t n, T *out, T *block_sums, T *d_total);

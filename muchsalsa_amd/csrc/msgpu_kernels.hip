@@ -222,6 +222,26 @@ void launch_publish_scalars(hipStream_t st, const uint64_t *src, uint64_t *dst_h
   hipLaunchKernelGGL(k_publish_scalars, dim3(1), dim3(64), 0, st, src, dst_host, n, seq);
 }
 
+// Window cuts of the dispatcher by measured work: cum[r] = scaffold rows the owner reads before r visit (exclusive prefix of
+// the index build's `visits`, cum[V] = all of them); thread j finds the first read whose prefix reaches target j.
+__global__ __launch_bounds__(256) void k_window_cuts(const uint64_t *cum, uint32_t V, WindowCutArgs a, uint64_t *out /*[2 n + 1]*/) {
+  const uint64_t total = cum[V];
+  if (threadIdx.x == 0) out[2 * a.n] = total;
+  if (threadIdx.x >= a.n) return;
+  const uint64_t t  = static_cast<uint64_t>(static_cast<double>(a.frac[threadIdx.x]) * static_cast<double>(total));
+  uint32_t       lo = 0, hi = V; // first index in [0, V] with cum[index] >= t
+  while (lo < hi) {
+    const uint32_t mid = lo + (hi - lo) / 2;
+    if (cum[mid] >= t) hi = mid;
+    else lo = mid + 1;
+  }
+  out[threadIdx.x]       = lo;
+  out[a.n + threadIdx.x] = cum[lo];
+}
+void launch_window_cuts(hipStream_t st, const uint64_t *cum, uint32_t V, const WindowCutArgs &a, uint64_t *out) {
+  hipLaunchKernelGGL(k_window_cuts, dim3(1), dim3(256), 0, st, cum, V, a, out);
+}
+
 uint32_t scan_blocks(uint64_t n) { return static_cast<uint32_t>((n + 256 * SCAN_ITEMS - 1) / (256 * SCAN_ITEMS)); }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -2433,8 +2453,13 @@ struct BigPath {
   uint64_t score;
 };
 
-__device__ __forceinline__ bool big_compat(const BigElem &K, const BigElem &L, bool direction, double wiggle,
-                                           double ratio_pct) {
+// the fields of a BigElem checkCompatibility looks at
+struct BigHot {
+  int    rlo1, rhi1, rlo2, rhi2;
+  double clo1, chi1, clo2, chi2;
+};
+template <class EK, class EL>
+__device__ __forceinline__ bool big_compat(const EK &K, const EL &L, bool direction, double wiggle, double ratio_pct) {
   int    o1 = 0, o2 = 0;
   double d1 = 0, d2 = 0;
   bool   abort_ = false;
@@ -2497,6 +2522,7 @@ __device__ __forceinline__ bool big_compat(const BigElem &K, const BigElem &L, b
   return false;
 }
 
+constexpr uint32_t BIG_REG_CAP = 256; // four elements per lane
 __global__ __launch_bounds__(64) void k_chain_big(ChainArgs a, const uint32_t *big_list, const uint64_t *big_off,
                                                   uint32_t n_big, BigElem *elems,
                                                   BigPath *paths /* 2 slots per EdgeMatch: minus then plus */) {
@@ -2511,6 +2537,19 @@ __global__ __launch_bounds__(64) void k_chain_big(ChainArgs a, const uint32_t *b
   const int        len1 = a.read_len[v1], len2 = a.read_len[v2];
   BigElem         *E  = elems + big_off[blockIdx.x];
   BigPath         *Pm = paths + 2 * big_off[blockIdx.x], *Pp = Pm + n;
+  // Up to BIG_REG_CAP EdgeMatches (nearly every edge that comes here) the chaining DP keeps its state in registers -- lane l
+  // holds elements l, l + 64, ... -- and element k reaches the others by readlane, as in k_chain; what the sequential tails
+  // chase afterwards (score, predecessor, "used", direction) lies in 5 KB of LDS.  With that state in the global scratch every
+  // one of an edge's ~2 n DP steps and every hop of a path walk was a dependent trip to memory: 0.3-0.4 ms for the slowest
+  // edge whatever the number of edges -- hidden beside k_chain on a whole job, but the longest thing in a dispatcher window or
+  // in the shard of a group member.  Larger edges take the old way.
+  __shared__ double   s_pop[BIG_REG_CAP];
+  __shared__ uint32_t s_pred[BIG_REG_CAP], s_used[BIG_REG_CAP], s_flags[BIG_REG_CAP];
+  const bool fast = n <= BIG_REG_CAP;
+  auto POP   = [&](uint32_t i) -> double & { return fast ? s_pop[i] : E[i].pop; };
+  auto PRED  = [&](uint32_t i) -> uint32_t & { return fast ? s_pred[i] : E[i].pred; };
+  auto USED  = [&](uint32_t i) -> uint32_t & { return fast ? s_used[i] : E[i].used; };
+  auto FLAGS = [&](uint32_t i) -> uint32_t { return fast ? s_flags[i] : E[i].flags; };
 
   // elements + EdgeMatch table
   for (uint32_t i = lane; i < n; i += 64) {
@@ -2580,13 +2619,84 @@ __global__ __launch_bounds__(64) void k_chain_big(ChainArgs a, const uint32_t *b
   __threadfence_block();
   __syncthreads();
 
+  if (fast) {
+    // both directions in one loop: a pair is only looked at when its two EdgeMatches have the same direction, and element k's
+    // score is final once the steps before k are done (mpp.cpp:185-199 per direction, src/main.cpp:341-353)
+    BigHot   Lh[4];
+    double   sc[4], pp[4];
+    uint32_t pr[4], fl[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const uint32_t l = static_cast<uint32_t>(lane) + 64u * r;
+      Lh[r] = BigHot{0, 0, 0, 0, 0.0, 0.0, 0.0, 0.0};
+      sc[r] = pp[r] = 0.0;
+      pr[r] = 0xffffffffu;
+      fl[r] = 0;
+      if (l < n) {
+        const BigElem x = E[l];
+        Lh[r] = BigHot{x.rlo1, x.rhi1, x.rlo2, x.rhi2, x.clo1, x.chi1, x.clo2, x.chi2};
+        sc[r] = pp[r] = x.score;
+        fl[r] = x.flags;
+      }
+    }
+    for (uint32_t k = 0; k + 1 < n; ++k) {
+      const int src = static_cast<int>(k & 63u);
+      BigHot    K;
+      double    k_pop;
+      uint32_t  k_fl;
+      auto take = [&](int r) { // element k from the lane that holds it (r is wave-uniform)
+        K.rlo1 = rl_i32(Lh[r].rlo1, src);
+        K.rhi1 = rl_i32(Lh[r].rhi1, src);
+        K.rlo2 = rl_i32(Lh[r].rlo2, src);
+        K.rhi2 = rl_i32(Lh[r].rhi2, src);
+        K.clo1 = rl_f64(Lh[r].clo1, src);
+        K.chi1 = rl_f64(Lh[r].chi1, src);
+        K.clo2 = rl_f64(Lh[r].clo2, src);
+        K.chi2 = rl_f64(Lh[r].chi2, src);
+        k_pop  = rl_f64(pp[r], src);
+        k_fl   = rl_u32(fl[r], src);
+      };
+      switch (k >> 6) {
+        case 0: take(0); break;
+        case 1: take(1); break;
+        case 2: take(2); break;
+        default: take(3); break;
+      }
+      const bool direction = (k_fl & 1u) != 0;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (64u * r + 63u <= k || 64u * r >= n) continue; // (wave-uniform: nothing of this slot lies behind k, or at all)
+        const uint32_t l = static_cast<uint32_t>(lane) + 64u * r;
+        if (l > k && l < n && ((fl[r] ^ k_fl) & 1u) == 0) {
+          const bool   ok   = big_compat(K, Lh[r], direction, a.wiggle, a.ratio_pct);
+          const double cand = k_pop + sc[r];
+          if (ok && cand > pp[r]) {
+            pp[r] = cand;
+            pr[r] = k;
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const uint32_t l = static_cast<uint32_t>(lane) + 64u * r;
+      if (l < n) {
+        s_pop[l]   = pp[r];
+        s_pred[l]  = pr[r];
+        s_used[l]  = 0;
+        s_flags[l] = fl[r];
+      }
+    }
+    __syncthreads();
+  }
+
   uint32_t np_dir[2] = {0, 0};
   for (int pass = 0; pass < 2; ++pass) {
     const bool     direction = pass == 1;
     const uint32_t want      = direction ? 1u : 0u;
     BigPath       *P         = direction ? Pp : Pm;
-    // DP
-    for (uint32_t k = 0; k + 1 < n; ++k) {
+    // DP (an edge beyond the register path: state in the global scratch)
+    for (uint32_t k = 0; !fast && k + 1 < n; ++k) {
       const BigElem K = E[k];
       if ((K.flags & 1u) != want) continue;
       for (uint32_t l = k + 1 + lane; l < n; l += 64) {
@@ -2608,10 +2718,10 @@ __global__ __launch_bounds__(64) void k_chain_big(ChainArgs a, const uint32_t *b
       double   maxv = 0.0;
       uint32_t maxi = 0xffffffffu, firsti = 0xffffffffu;
       for (uint32_t i = 0; i < n; ++i) {
-        if ((E[i].flags & 1u) != want) continue;
+        if ((FLAGS(i) & 1u) != want) continue;
         if (firsti == 0xffffffffu) firsti = i;
-        if (E[i].pop > maxv) {
-          maxv = E[i].pop;
+        if (POP(i) > maxv) {
+          maxv = POP(i);
           maxi = i;
         }
       }
@@ -2621,9 +2731,9 @@ __global__ __launch_bounds__(64) void k_chain_big(ChainArgs a, const uint32_t *b
         {
           uint32_t len = 0, first = maxi;
           bool     prim = false;
-          for (uint32_t c = maxi; c != 0xffffffffu; c = E[c].pred) {
-            E[c].used = 1;
-            prim |= (E[c].flags & 2u) != 0;
+          for (uint32_t c = maxi; c != 0xffffffffu; c = PRED(c)) {
+            USED(c) = 1;
+            prim |= (FLAGS(c) & 2u) != 0;
             first = c;
             ++len;
           }
@@ -2636,26 +2746,26 @@ __global__ __launch_bounds__(64) void k_chain_big(ChainArgs a, const uint32_t *b
         }
         const double thr = maxv * a.alt_frac;
         for (uint32_t p = 0; p < n; ++p) {
-          if ((E[p].flags & 1u) != want || !(E[p].pop > thr)) continue;
+          if ((FLAGS(p) & 1u) != want || !(POP(p) > thr)) continue;
           bool     disjoint = true;
           uint32_t len = 0, first = p;
           bool     prim = false;
-          for (uint32_t c = p; c != 0xffffffffu; c = E[c].pred) {
-            if (E[c].used) {
+          for (uint32_t c = p; c != 0xffffffffu; c = PRED(c)) {
+            if (USED(c)) {
               disjoint = false;
               break;
             }
-            prim |= (E[c].flags & 2u) != 0;
+            prim |= (FLAGS(c) & 2u) != 0;
             first = c;
             ++len;
           }
           if (!disjoint) continue;
-          for (uint32_t c = p; c != 0xffffffffu; c = E[c].pred) E[c].used = 1;
+          for (uint32_t c = p; c != 0xffffffffu; c = PRED(c)) USED(c) = 1;
           P[np].end     = p;
           P[np].first   = first;
           P[np].len     = len;
           P[np].primary = prim ? 1u : 0u;
-          P[np].score   = static_cast<uint64_t>(E[p].pop);
+          P[np].score   = static_cast<uint64_t>(POP(p));
           ++np;
         }
         if (np == 1 && P[0].primary) {
@@ -2668,7 +2778,7 @@ __global__ __launch_bounds__(64) void k_chain_big(ChainArgs a, const uint32_t *b
             // ascending walk: reverse the pred chain into the id scratch of this edge (free at this point)
             uint32_t *tmp = a.ids_scr + ed.em_off;
             uint32_t  len = P[0].len, w = len;
-            for (uint32_t c = l; c != 0xffffffffu; c = E[c].pred) tmp[--w] = c;
+            for (uint32_t c = l; c != 0xffffffffu; c = PRED(c)) tmp[--w] = c;
             long long i = 0, jj = 0;
             bool      is_shadow = false;
             for (uint32_t t = 0; t < len && !is_shadow; ++t) {
@@ -2759,7 +2869,7 @@ __global__ __launch_bounds__(64) void k_chain_big(ChainArgs a, const uint32_t *b
         if (!have) continue;
         const uint32_t cnt = pv[pi].len;
         uint32_t       w   = cnt;
-        for (uint32_t c = l; c != 0xffffffffu; c = E[c].pred) a.ids_scr[ed.em_off + n_ids + --w] = E[c].anchor;
+        for (uint32_t c = l; c != 0xffffffffu; c = PRED(c)) a.ids_scr[ed.em_off + n_ids + --w] = E[c].anchor;
         msgpu_order o;
         o.edge_idx     = static_cast<uint32_t>(e);
         o.flags        = fl | (dir ? MSGPU_ORD_DIR : 0u) | (pv[pi].primary ? MSGPU_ORD_PRIMARY : 0u);
@@ -2952,14 +3062,14 @@ __global__ __launch_bounds__(256) void k_pack_wire(PackWireArgs a) {
   if (i < a.n_edges) {
     const WireEdges  w(a.w_edges, a.n_edges);
     const msgpu_edge e = a.edges[i];
-    const_cast<uint32_t *>(w.em_off)[i]    = static_cast<uint32_t>(e.em_off);
-    const_cast<uint32_t *>(w.order_off)[i] = static_cast<uint32_t>(e.order_off);
+    const_cast<uint32_t *>(w.em_off)[i]    = static_cast<uint32_t>(e.em_off - a.base_ems);
+    const_cast<uint32_t *>(w.order_off)[i] = static_cast<uint32_t>(e.order_off - a.base_orders);
     const_cast<uint32_t *>(w.v1)[i]        = e.v1;
     const_cast<uint32_t *>(w.v2)[i]        = e.v2;
     const_cast<uint8_t *>(w.shadow)[i]     = e.shadow;
     if (i + 1 == a.n_edges) {
-      const_cast<uint32_t *>(w.em_off)[i + 1]    = static_cast<uint32_t>(e.em_off + e.em_cnt);
-      const_cast<uint32_t *>(w.order_off)[i + 1] = static_cast<uint32_t>(e.order_off + e.order_cnt);
+      const_cast<uint32_t *>(w.em_off)[i + 1]    = static_cast<uint32_t>(e.em_off - a.base_ems + e.em_cnt);
+      const_cast<uint32_t *>(w.order_off)[i + 1] = static_cast<uint32_t>(e.order_off - a.base_orders + e.order_cnt);
     }
   }
   if (i < a.n_orders) {
@@ -2968,10 +3078,10 @@ __global__ __launch_bounds__(256) void k_pack_wire(PackWireArgs a) {
     const_cast<double *>(w.left)[i]       = o.left_offset;
     const_cast<double *>(w.right)[i]      = o.right_offset;
     const_cast<uint64_t *>(w.score)[i]    = o.score;
-    const_cast<uint32_t *>(w.ids_off)[i]  = static_cast<uint32_t>(o.ids_off);
-    const_cast<uint32_t *>(w.edge_idx)[i] = o.edge_idx;
+    const_cast<uint32_t *>(w.ids_off)[i]  = static_cast<uint32_t>(o.ids_off - a.base_ids);
+    const_cast<uint32_t *>(w.edge_idx)[i] = o.edge_idx - a.base_edges;
     const_cast<uint8_t *>(w.flags)[i]     = static_cast<uint8_t>(o.flags);
-    if (i + 1 == a.n_orders) const_cast<uint32_t *>(w.ids_off)[i + 1] = static_cast<uint32_t>(o.ids_off + o.ids_cnt);
+    if (i + 1 == a.n_orders) const_cast<uint32_t *>(w.ids_off)[i + 1] = static_cast<uint32_t>(o.ids_off - a.base_ids + o.ids_cnt);
   }
   if (i == 0) { // an empty table still has its closing CSR entries on the wire (the host statement writes zeros there)
     if (a.n_edges == 0) {

@@ -161,6 +161,31 @@ def test_resident_run_leaves_the_job_tables_in_hbm(oracle):
         assert len(big) and np.array_equal(off, w_off) and ems.tobytes() == w_ems.tobytes()
 
 
+@pytest.mark.parametrize("mode", ["wire", "wire, 4-byte ids", "records"])
+def test_lean_windows_leave_in_wire_form_or_as_records(oracle, monkeypatch, mode):
+    """MSGPU_BATCH_NO_EDGEMATCHES: the windows' edge / order / id tables cross the host link in the exchange's wire form and a
+    host thread turns them back into records (msgpu_unpack_wire_host with the window's bases) -- 3-byte anchor ids while the id
+    space fits 24 bits, else the ids as they are; MSGPU_NO_WIRE_COPY=1 sends whole records.  Same host tables, bit for bit, for
+    any window count, on a fresh context (host tables grow and move while earlier windows are being unpacked) and a warm one.
+    Window cuts follow the visit counts of the index (a grouped input) or the id model (the declared-but-empty anchor ids of
+    the 4-byte case make the index generic)."""
+    from muchsalsa_amd import overlap, synth
+    if mode == "records":
+        monkeypatch.setenv("MSGPU_NO_WIRE_COPY", "1")
+    rows = synth.synth_rows(2000, 5000, 10000, 7)
+    want = oracle.overlap(rows)
+    for windows in (1, 2, 3, 7, 0):
+        with overlap.OverlapContext(0) as ctx:
+            if mode == "wire, 4-byte ids":
+                ctx.set_id_space(int(rows["read_id"].max()) + 1, (1 << 24) + 11)
+            for rep in ("cold", "warm"):
+                got, info = ctx.overlap_batched(overlap.PinnedRows(rows), windows, resident=True, edgematches=False)
+                assert got["ems"] is None and info["n_ems"] == len(want["ems"])
+                for k in ("edges", "orders", "ids", "read_len", "read_first_line"):
+                    assert got[k].tobytes() == want[k].tobytes(), (k, windows, rep)
+            assert_tables_equal(ctx.tables(), want, "%s, %d windows: the context's own tables" % (mode, windows))
+
+
 def test_resident_cfg2_full_size_and_first_call_growth(oracle):
     """cfg2 at full size on a FRESH context: the job tables grow window by window (the kept part of a view moves on
     reallocation) and still come out bit-exact; a warm second call allocates nothing."""

@@ -9,7 +9,7 @@ OUT=${TMPDIR:-/tmp}/libmsgpu_asan.so
 cd "$ROOT/muchsalsa_amd/csrc"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O1 -g -std=c++17 -fPIC -pthread -ffp-contract=off \
   -fsanitize=address,undefined -fno-gpu-sanitize -fno-omit-frame-pointer -I../../include -I. -shared -o "$OUT" \
-  msgpu_api.hip msgpu_kernels.hip msgpu_index.hip msgpu_graph.hip msgpu_seq.hip msgpu_group.cpp paf_loader.cpp seq_loader.cpp seg_compose.cpp \
+  msgpu_api.hip msgpu_kernels.hip msgpu_index.hip msgpu_graph.hip msgpu_seq.hip msgpu_group.cpp wire_host.cpp paf_loader.cpp seq_loader.cpp seg_compose.cpp \
   consensus_base.cpp assemble_path.cpp graph_stage.cpp
 cd "$ROOT"
 LD_PRELOAD="$($CLANG -print-file-name=libclang_rt.asan-x86_64.so)" \
