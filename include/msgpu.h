@@ -341,12 +341,14 @@ int msgpu_merge_wire(msgpu_ctx *ctx, const void *d_gathered, uint32_t world, con
                      void *d_edges, void *d_orders, void *d_ids, void *hip_stream);
 /* The receiving end on the HOST: one set of wire blocks (host memory) back into records, on up to `threads` host threads (0 = 16).
  * base[4] = what precedes the set in the tables its records point into {edges, EdgeMatches, orders, ids}: added to edge_idx,
- * em_off, order_off, ids_off (NULL = zeros: the records of msgpu_copy_tables for the same context).  msgpu_overlap_batched_ex
- * uses it for its windows when the EdgeMatch table stays in HBM (the tables travel over the host link in wire form).  No GPU,
- * no context: plain host code. */
+ * em_off, order_off, ids_off (NULL = zeros: the records of msgpu_copy_tables for the same context).  tables: which of them to
+ * write -- 1 edges, 2 orders, 4 ids, 0 = all; a caller whose blocks arrive one after the other unpacks each as it lands (the
+ * orders read the edge BLOCK for their vertices, not the edge records).  msgpu_overlap_batched_ex uses it for its windows
+ * when the EdgeMatch table stays in HBM, msgpu_group_overlap for every member's slab (the tables travel over the host link in
+ * wire form).  No GPU, no context: plain host code. */
 int msgpu_unpack_wire_host(const void *wire_edges, const void *wire_orders, const void *wire_ids, uint32_t id_bytes,
                            uint64_t n_edges, uint64_t n_orders, uint64_t n_ids, const uint64_t *base, msgpu_edge *edges,
-                           msgpu_order *orders, uint32_t *ids, uint32_t threads);
+                           msgpu_order *orders, uint32_t *ids, uint32_t threads, uint32_t tables);
 
 /* ---- one process, the node's GPUs: a GROUP of contexts behind the same call site -------------------------------------------
  * The reference is ONE process that fans jobs over its workers and closes each phase with a barrier (src/main.cpp:143-178,
@@ -358,8 +360,9 @@ int msgpu_unpack_wire_host(const void *wire_edges, const void *wire_orders, cons
  *   the rank of every row inside its read) -> device i computes the edges with v1 % n == i (msgpu_set_shard) -> its edge /
  *   order / id tables in WIRE FORM into its slab (msgpu_pack_wire) -> ONE grouped RCCL all-gather over xGMI
  *   (ncclGroupStart / n x ncclAllGather / ncclGroupEnd, each on its member's stream) -> msgpu_merge_wire on every device:
- *   the merged edge list of the job in every HBM, and in host memory (member i sends the i-th slice of every table over its
- *   own link: every member holds the same bytes); WaitGroup::wait() = the join of the member threads.
+ *   the merged edge list of the job in every HBM, and in host memory (every member sends its OWN slab, still in wire form,
+ *   over its own link beside the exchange; host threads turn the slabs into the merged records: msgpu_unpack_wire_host with
+ *   the member's bases); WaitGroup::wait() = the join of the member threads.
  * The merged tables are the ones msgpu_merge_wire defines: rank-major (member 0's edges in (v1, v2) order, then member 1's ...),
  * order_off / edge_idx / ids_off re-based to the merged tables, em_off local to the owning member (EdgeMatch tables are not
  * gathered: msgpu_get_edgematches on msgpu_group_ctx(g, v1 % n)).  With n = 1 they are the single-context tables bit for bit.

@@ -1394,9 +1394,10 @@ int msgpu_pack_wire(msgpu_ctx *c, void *d_wire_edges, void *d_wire_orders, void 
 
 int msgpu_unpack_wire_host(const void *wire_edges, const void *wire_orders, const void *wire_ids, uint32_t id_bytes, uint64_t n_edges,
                            uint64_t n_orders, uint64_t n_ids, const uint64_t *base, msgpu_edge *edges, msgpu_order *orders,
-                           uint32_t *ids, uint32_t threads) {
-  if ((id_bytes != 3 && id_bytes != 4) || !wire_edges || !wire_orders || (n_ids && !wire_ids) || (n_edges && !edges) ||
-      (n_orders && !orders) || (n_ids && !ids))
+                           uint32_t *ids, uint32_t threads, uint32_t tables) {
+  if (!tables) tables = 7;
+  if ((id_bytes != 3 && id_bytes != 4) || tables > 7 || !wire_edges || ((tables & 2u) && !wire_orders) || ((tables & 4u) && n_ids && !wire_ids) ||
+      ((tables & 1u) && n_edges && !edges) || ((tables & 2u) && n_orders && !orders) || ((tables & 4u) && n_ids && !ids))
     return MSGPU_E_ARG;
   if ((reinterpret_cast<uintptr_t>(wire_edges) & 3) || (reinterpret_cast<uintptr_t>(wire_orders) & 7) ||
       (reinterpret_cast<uintptr_t>(wire_ids) & 3))
@@ -1404,7 +1405,7 @@ int msgpu_unpack_wire_host(const void *wire_edges, const void *wire_orders, cons
   try {
     unpack_wire_host(static_cast<const uint8_t *>(wire_edges), static_cast<const uint8_t *>(wire_orders),
                      static_cast<const uint32_t *>(wire_ids), id_bytes, n_edges, n_orders, n_ids, base ? base[0] : 0, base ? base[1] : 0,
-                     base ? base[2] : 0, base ? base[3] : 0, edges, orders, ids, threads ? threads : 16);
+                     base ? base[2] : 0, base ? base[3] : 0, edges, orders, ids, threads ? threads : 16, tables);
   } catch (...) {
     return MSGPU_E_NOMEM;
   }

@@ -105,6 +105,10 @@ struct Member {
   ncclComm_t   comm   = nullptr;
   DevBlock     slab, gathered, m_edges, m_orders, m_ids, rows;
   hipEvent_t   ev0 = nullptr, ev1 = nullptr;
+  // the way out to the host: the member's OWN slab, block by block, on a stream of its own beside the exchange
+  hipStream_t  out_stream = nullptr;
+  hipEvent_t   ev_packed = nullptr, ev_out[3] = {nullptr, nullptr, nullptr};
+  HostBlock    h_slab;
   msgpu_counts counts{};
   int          rc = MSGPU_OK;
   char         err[512] = {0};
@@ -187,7 +191,11 @@ int msgpu_group_create(const int *devices, int n, const msgpu_params *params, ms
     int rc     = msgpu_create(devices[i], &g->p, &mb.ctx);
     if (rc == MSGPU_OK) rc = msgpu_set_shard(mb.ctx, static_cast<uint32_t>(i), static_cast<uint32_t>(n));
     if (rc == MSGPU_OK && (hipSetDevice(devices[i]) != hipSuccess || hipEventCreate(&mb.ev0) != hipSuccess ||
-                           hipEventCreate(&mb.ev1) != hipSuccess))
+                           hipEventCreate(&mb.ev1) != hipSuccess || hipStreamCreateWithFlags(&mb.out_stream, hipStreamNonBlocking) != hipSuccess ||
+                           hipEventCreateWithFlags(&mb.ev_packed, hipEventDisableTiming) != hipSuccess ||
+                           hipEventCreateWithFlags(&mb.ev_out[0], hipEventDisableTiming) != hipSuccess ||
+                           hipEventCreateWithFlags(&mb.ev_out[1], hipEventDisableTiming) != hipSuccess ||
+                           hipEventCreateWithFlags(&mb.ev_out[2], hipEventDisableTiming) != hipSuccess))
       rc = MSGPU_E_HIP;
     if (rc != MSGPU_OK) {
       msgpu_group_destroy(g);
@@ -207,6 +215,13 @@ void msgpu_group_destroy(msgpu_group *g) {
     for (DevBlock *b : {&mb.slab, &mb.gathered, &mb.m_edges, &mb.m_orders, &mb.m_ids, &mb.rows}) b->release();
     if (mb.ev0) (void)hipEventDestroy(mb.ev0);
     if (mb.ev1) (void)hipEventDestroy(mb.ev1);
+    if (mb.out_stream) {
+      (void)hipStreamSynchronize(mb.out_stream);
+      (void)hipStreamDestroy(mb.out_stream);
+    }
+    for (hipEvent_t e : {mb.ev_packed, mb.ev_out[0], mb.ev_out[1], mb.ev_out[2]})
+      if (e) (void)hipEventDestroy(e);
+    mb.h_slab.release();
     if (mb.ctx) msgpu_destroy(mb.ctx);
   }
   for (HostBlock *h : {&g->h_edges, &g->h_orders, &g->h_ids, &g->h_read_len, &g->h_read_first}) h->release();
@@ -334,9 +349,18 @@ int msgpu_group_overlap(msgpu_group *g, const msgpu_row *rows, size_t n_rows, ms
   const uint64_t off_e = 0, off_o = round_up(off_e + msgpu_wire_edges_bytes(mx[0])),
                  off_i = round_up(off_o + msgpu_wire_orders_bytes(mx[1])),
                  slab_bytes = std::max<uint64_t>(round_up(off_i + msgpu_wire_ids_bytes(mx[2], id_bytes)), ALIGN);
+  // the merged list in host memory is put together from the members' OWN slabs -- wire form over every member's link (a 1/n-th
+  // of the job each, 40 % fewer bytes than records), beside the exchange instead of behind it -- and unpacked by host threads
+  // with the member's bases (msgpu_unpack_wire_host): the records msgpu_merge_wire writes in HBM, byte for byte
+  const uint32_t V = g->m[0].counts.n_reads;
+  if (!g->h_edges.ensure(std::max<uint64_t>(tot[0], 1) * sizeof(msgpu_edge)) ||
+      !g->h_orders.ensure(std::max<uint64_t>(tot[1], 1) * sizeof(msgpu_order)) || !g->h_ids.ensure(std::max<uint64_t>(tot[2], 1) * 4) ||
+      !g->h_read_len.ensure((size_t(V) + 1) * 4) || !g->h_read_first.ensure((size_t(V) + 1) * 4))
+    return gfail(g, MSGPU_E_NOMEM, "page-locked host tables of the merged edge list");
   for (size_t i = 0; i < n; ++i) {
     Member &mb = g->m[i];
     GHIP(g, hipSetDevice(mb.device));
+    if (!mb.h_slab.ensure(slab_bytes)) return gfail(g, MSGPU_E_NOMEM, "page-locked slab of member %zu", i);
     GHIP(g, mb.slab.ensure(slab_bytes));
     GHIP(g, mb.gathered.ensure(n * slab_bytes));
     GHIP(g, mb.m_edges.ensure(std::max<uint64_t>(tot[0], 1) * sizeof(msgpu_edge)));
@@ -347,6 +371,16 @@ int msgpu_group_overlap(msgpu_group *g, const msgpu_row *rows, size_t n_rows, ms
     char *slab = static_cast<char *>(mb.slab.p);
     if (int rc = msgpu_pack_wire(mb.ctx, slab + off_e, slab + off_o, slab + off_i, id_bytes))
       return gfail(g, rc, "member %zu: %s", i, msgpu_last_error(mb.ctx));
+    GHIP(g, hipEventRecord(mb.ev_packed, st));
+    GHIP(g, hipStreamWaitEvent(mb.out_stream, mb.ev_packed, 0));
+    const uint64_t lo[3] = {off_e, off_o, off_i},
+                   len[3] = {msgpu_wire_edges_bytes(counts[3 * i]), msgpu_wire_orders_bytes(counts[3 * i + 1]),
+                             msgpu_wire_ids_bytes(counts[3 * i + 2], id_bytes)};
+    for (int part = 0; part < 3; ++part) { // edge block first: the orders take their vertices from it
+      if (len[part])
+        GHIP(g, hipMemcpyAsync(static_cast<char *>(mb.h_slab.p) + lo[part], slab + lo[part], len[part], hipMemcpyDeviceToHost, mb.out_stream));
+      GHIP(g, hipEventRecord(mb.ev_out[part], mb.out_stream));
+    }
   }
   if (nc) {
     GNCCL(g, nc->GroupStart()); // one thread drives n communicators: the n calls are one collective
@@ -379,38 +413,31 @@ int msgpu_group_overlap(msgpu_group *g, const msgpu_row *rows, size_t n_rows, ms
       return gfail(g, rc, "member %zu: %s", i, msgpu_last_error(mb.ctx));
     GHIP(g, hipEventRecord(mb.ev1, static_cast<hipStream_t>(msgpu_get_stream(mb.ctx))));
   }
-  // ---- the merged list in host memory, the Vertex facts ------------------------------------------------------------------
-  const uint32_t V = g->m[0].counts.n_reads;
-  if (!g->h_edges.ensure(std::max<uint64_t>(tot[0], 1) * sizeof(msgpu_edge)) ||
-      !g->h_orders.ensure(std::max<uint64_t>(tot[1], 1) * sizeof(msgpu_order)) || !g->h_ids.ensure(std::max<uint64_t>(tot[2], 1) * 4) ||
-      !g->h_read_len.ensure((size_t(V) + 1) * 4) || !g->h_read_first.ensure((size_t(V) + 1) * 4))
-    return gfail(g, MSGPU_E_NOMEM, "page-locked host tables of the merged edge list");
-  // Every member holds the same merged tables: member i sends the i-th slice of each over ITS link, so the copy-out of a group
-  // of n takes a 1/n-th of one link's time (a table below 64 KB goes whole from member 0: a copy costs more than it moves).
+  // ---- the Vertex facts; the members' slabs into records as their blocks land ---------------------------------------------
   {
-    const struct {
-      HostBlock *dst;
-      DevBlock Member::*src;
-      uint64_t  count, rec;
-    } tabs[3] = {{&g->h_edges, &Member::m_edges, tot[0], sizeof(msgpu_edge)},
-                 {&g->h_orders, &Member::m_orders, tot[1], sizeof(msgpu_order)},
-                 {&g->h_ids, &Member::m_ids, tot[2], 4}};
-    for (const auto &t : tabs) {
-      const uint64_t parts = t.count * t.rec < (1u << 16) ? 1 : n, per = (t.count + parts - 1) / parts;
-      for (uint64_t i = 0; i < parts; ++i) {
-        const uint64_t lo = std::min(i * per, t.count), hi = std::min(lo + per, t.count);
-        if (hi == lo) continue;
-        Member &mb = g->m[i];
-        GHIP(g, hipSetDevice(mb.device));
-        GHIP(g, hipMemcpyAsync(static_cast<char *>(t.dst->p) + lo * t.rec, static_cast<const char *>((mb.*(t.src)).p) + lo * t.rec,
-                               (hi - lo) * t.rec, hipMemcpyDeviceToHost, static_cast<hipStream_t>(msgpu_get_stream(mb.ctx))));
-      }
-    }
     Member &mb = g->m[0];
     GHIP(g, hipSetDevice(mb.device));
     if (V)
       if (int rc = msgpu_copy_reads(mb.ctx, static_cast<int32_t *>(g->h_read_len.p), static_cast<uint32_t *>(g->h_read_first.p)))
         return gfail(g, rc, "member 0: %s", msgpu_last_error(mb.ctx));
+  }
+  {
+    uint64_t base[4] = {0, 0, 0, 0}; // {edges, EdgeMatches (local to the owner: 0), orders, ids} in front of member i
+    for (size_t i = 0; i < n; ++i) {
+      Member     &mb = g->m[i];
+      const char *hs = static_cast<const char *>(mb.h_slab.p);
+      GHIP(g, hipSetDevice(mb.device));
+      for (int part = 0; part < 3; ++part) {
+        GHIP(g, hipEventSynchronize(mb.ev_out[part]));
+        if (int rc = msgpu_unpack_wire_host(hs + off_e, hs + off_o, hs + off_i, id_bytes, counts[3 * i], counts[3 * i + 1], counts[3 * i + 2], base,
+                                            static_cast<msgpu_edge *>(g->h_edges.p) + base[0], static_cast<msgpu_order *>(g->h_orders.p) + base[2],
+                                            static_cast<uint32_t *>(g->h_ids.p) + base[3], 16, 1u << part))
+          return gfail(g, rc, "unpacking the slab of member %zu", i);
+      }
+      base[0] += counts[3 * i];
+      base[2] += counts[3 * i + 1];
+      base[3] += counts[3 * i + 2];
+    }
   }
   float exchange_ms = 0;
   for (size_t i = 0; i < n; ++i) { // the phase barrier: every member's stream has drained

@@ -19,16 +19,18 @@ def _aligned(b, align=8):
     return raw[off: off + len(b)], raw
 
 
-def _unpack(L, blocks, counts, id_bytes, base=None, threads=0):
+def _unpack(L, blocks, counts, id_bytes, base=None, threads=0, tables=(0,)):
     ne, no, ni = counts
     (eb, keep0), (ob, keep1), (ib, keep2) = (_aligned(np.ascontiguousarray(b)) for b in blocks)
     e, o, ids = np.zeros(ne, dtype=EDGE_DTYPE), np.zeros(no, dtype=ORDER_DTYPE), np.zeros(ni, dtype="<u4")
     e.view(np.uint8)[:] = 0xAB  # every byte must be written, padding included
     o.view(np.uint8)[:] = 0xAB
     b = (C.c_uint64 * 4)(*base) if base is not None else None
-    rc = L.msgpu_unpack_wire_host(eb.ctypes.data, ob.ctypes.data, ib.ctypes.data if len(ib) else None, id_bytes, ne, no, ni, b,
-                                  e.ctypes.data if ne else None, o.ctypes.data if no else None, ids.ctypes.data if ni else None, threads)
-    assert rc == 0
+    for mask in tables:  # all at once (0), or table by table as a caller does whose blocks arrive one after the other
+        rc = L.msgpu_unpack_wire_host(eb.ctypes.data, ob.ctypes.data, ib.ctypes.data if len(ib) else None, id_bytes, ne, no, ni, b,
+                                      e.ctypes.data if ne else None, o.ctypes.data if no else None, ids.ctypes.data if ni else None,
+                                      threads, mask)
+        assert rc == 0
     return {"edges": e, "orders": o, "ids": ids}
 
 
@@ -43,11 +45,11 @@ def test_whole_tables_round_trip(tables, id_bytes):
     t = {k: tables[k] for k in ("edges", "orders", "ids")}
     blocks = D.pack_wire_host(t, id_bytes)
     counts = (len(t["edges"]), len(t["orders"]), len(t["ids"]))
-    for threads in (1, 0):
-        got = _unpack(L, blocks, counts, id_bytes, threads=threads)
+    for threads, tables in ((1, (0,)), (0, (0,)), (0, (1, 2, 4)), (3, (4, 1, 2))):
+        got = _unpack(L, blocks, counts, id_bytes, threads=threads, tables=tables)
         want = D.unpack_wire_host(*blocks, counts, id_bytes)
         for k in ("edges", "orders", "ids"):
-            assert got[k].tobytes() == want[k].tobytes() == t[k].tobytes(), (k, threads)
+            assert got[k].tobytes() == want[k].tobytes() == t[k].tobytes(), (k, threads, tables)
 
 
 @pytest.mark.parametrize("id_bytes", [3, 4])
@@ -88,6 +90,7 @@ def test_three_byte_ids_of_any_count(n_ids):
 def test_bad_arguments_are_refused():
     L = _lib.lib()
     z = np.zeros(16, dtype=np.uint8)
-    assert L.msgpu_unpack_wire_host(z.ctypes.data, z.ctypes.data, None, 5, 0, 0, 0, None, None, None, None, 0) != 0
-    assert L.msgpu_unpack_wire_host(None, z.ctypes.data, None, 3, 0, 0, 0, None, None, None, None, 0) != 0
-    assert L.msgpu_unpack_wire_host(z.ctypes.data, z.ctypes.data, None, 3, 1, 0, 0, None, None, None, None, 0) != 0
+    assert L.msgpu_unpack_wire_host(z.ctypes.data, z.ctypes.data, None, 5, 0, 0, 0, None, None, None, None, 0, 0) != 0
+    assert L.msgpu_unpack_wire_host(None, z.ctypes.data, None, 3, 0, 0, 0, None, None, None, None, 0, 0) != 0
+    assert L.msgpu_unpack_wire_host(z.ctypes.data, z.ctypes.data, None, 3, 1, 0, 0, None, None, None, None, 0, 0) != 0
+    assert L.msgpu_unpack_wire_host(z.ctypes.data, z.ctypes.data, None, 3, 0, 0, 0, None, None, None, None, 0, 8) != 0
