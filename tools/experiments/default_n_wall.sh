@@ -1,7 +1,7 @@
 #!/bin/bash
 # wall time of the default bench line at world 1 over RCCL (--force-dist) and with 2 / 4 real ranks over gloo on one GPU
 set -u
-OUT=gpurun_out/r3_04
+OUT=gpurun_out/r4_31
 mkdir -p "$OUT"
 SECONDS=0
 timeout -k 10 500 python3 bench.py --force-dist > "$OUT/default_force_dist.json" 2> "$OUT/default_force_dist.err" || { echo "force-dist failed"; tail -20 "$OUT/default_force_dist.err"; }
@@ -15,7 +15,7 @@ python3 - <<'PY'
 import json
 for f in ("default_force_dist","default_rehearsal_2","default_rehearsal_4"):
     try:
-        l=json.loads([x for x in open('gpurun_out/r3_04/%s.json'%f) if x.startswith('{')][-1])
+        l=json.loads([x for x in open('gpurun_out/r4_31/%s.json'%f) if x.startswith('{')][-1])
         print(f, l['n_gpus'], l['scaling'], round(l['ms_per_step'],3), l['config'].get('merged_edge_list_consistent'), l.get('errors'), sorted(k for k in l if isinstance(l[k],dict)))
     except Exception as e: print(f, 'ERR', e)
 PY
