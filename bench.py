@@ -985,7 +985,9 @@ def main():
 
     ctx = overlap.OverlapContext(device=local_rank)
     # One real (non-null) stream carries the compute: libmsgpu's kernels and torch's copies are ordered by it.
-    work = torch.cuda.Stream(device=dev)
+    # (high priority: the exchange's kernels on the communication stream fill what the compute leaves, not the other way round --
+    # 2.85 -> 2.77 ms per step at world 1; MSGPU_WORK_PRIORITY=0: default priority)
+    work = torch.cuda.Stream(device=dev, priority=0 if os.environ.get("MSGPU_WORK_PRIORITY") == "0" else -1)
     ctx.set_stream(work.cuda_stream)
     ctx.set_id_space(len(read_names), len(anchor_names))  # Registry sizes, known to whoever parsed the PAF
     merged_keep = {}
@@ -1102,6 +1104,9 @@ def main():
             if form["wire"]:
                 form["wire"] = 3 if int(alls[:, 1].max()) <= 1 << 24 else 4
             pe = D.PipelinedExchange(dev, merge, wire=form["wire"])
+            if os.environ.get("MSGPU_EXCHANGE_GATE", "1") != "0":  # the exchange of step k beside the chain stage of step k + 1
+                pe.gate_arm = lambda: ctx.chain_launches() + 1
+                pe.gate_wait = lambda count: ctx.wait_chain_launch(count, 1000)
 
             def step():
                 c = compute()

@@ -144,6 +144,8 @@ SYMBOLS = [
     ("msgpu_pack_wire", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]),
     ("msgpu_merge_wire", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64,
                                    C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("msgpu_chain_launches", C.c_uint64, [C.c_void_p]),
+    ("msgpu_wait_chain_launch", C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32]),
     ("msgpu_unpack_wire_host", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint64,
                                          C.POINTER(C.c_uint64), C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]),
     ("msgpu_find_contraction_edges", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint32,

@@ -276,6 +276,11 @@ struct msgpu_ctx {
     size_t cap = 0;
   } h_edges, h_ems, h_orders, h_ids, h_read_len, h_read_first, h_sel_off, h_sel_ems, h_wire[2];
   hipEvent_t ev_part[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}}; // a window's wire blocks, copied one by one
+  // how often the chain kernels have been launched: another thread can wait for the next launch (msgpu_wait_chain_launch) to
+  // put its own device work beside the chain stage instead of beside the memory-bound stages before it
+  std::mutex              gate_m;
+  std::condition_variable gate_cv;
+  uint64_t                chain_launches = 0;
   DevBuf win_cuts;        // the dispatcher's window cuts by measured work (k_window_cuts)
   DevBuf wire_dev[2];     // a window's edge / order / id tables in wire form, on their way to the host (two sets: see the dispatcher)
   bool   wire_copy = true; // MSGPU_NO_WIRE_COPY=1: windows always leave as whole records (A/B switch)
@@ -1111,6 +1116,11 @@ int msgpu_chaining_and_overlaps(msgpu_ctx *c) {
     HIPCHK(c, hipEventRecord(c->ev_side[1], c->side_stream));
     return MSGPU_OK;
   };
+  {
+    std::lock_guard<std::mutex> g(c->gate_m);
+    ++c->chain_launches;
+  }
+  c->gate_cv.notify_all();
   if (int rc = launch_big()) return rc; // (first: its few long-lived wavefronts get their registers before k_chain fills the device)
   if (c->sub_wave && E) {
     // the size-sorted edge list and the class sizes are there since msgpu_calculate_edges
@@ -1952,6 +1962,17 @@ int msgpu_get_edgematches(msgpu_ctx *c, const uint32_t *edge_idx, size_t n, cons
 
 void *msgpu_pinned_alloc(size_t bytes) { return pinned_block_alloc(bytes); }
 void  msgpu_pinned_free(void *p) { pinned_block_free(p); }
+
+uint64_t msgpu_chain_launches(msgpu_ctx *c) {
+  if (!c) return 0;
+  std::lock_guard<std::mutex> g(c->gate_m);
+  return c->chain_launches;
+}
+int msgpu_wait_chain_launch(msgpu_ctx *c, uint64_t count, uint32_t timeout_us) {
+  if (!c) return MSGPU_E_ARG;
+  std::unique_lock<std::mutex> lk(c->gate_m);
+  return c->gate_cv.wait_for(lk, std::chrono::microseconds(timeout_us), [&] { return c->chain_launches >= count; }) ? MSGPU_OK : 1;
+}
 
 int msgpu_synchronize(msgpu_ctx *c) {
   if (!c) return MSGPU_E_ARG;

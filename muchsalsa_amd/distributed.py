@@ -334,6 +334,13 @@ class PipelinedExchange:
         self._error = None
         self._thread = None
         self._world = None
+        # An optional gate in front of every all-gather (threaded mode): gate_arm() is called by submit() and returns a token,
+        # gate_wait(token) by the communication thread, repeatedly, until it returns True or drain() has opened the gates.
+        # bench.py arms it with "the next launch of the chain kernels" (OverlapContext.wait_chain_launch): the all-gather and the
+        # merge of step k then run beside the issue-bound chain stage of step k + 1 instead of beside its memory-bound index
+        # build and candidate scan.
+        self.gate_arm = self.gate_wait = None
+        self._gates_open = False
         if self.threaded:
             import queue
             import threading
@@ -440,6 +447,7 @@ class PipelinedExchange:
             fill_slab(stash, s_offs)
             slot["stash"] = (stash, s_offs)
         self._mark_filled(slot)
+        slot["gate"] = self.gate_arm() if (self.threaded and self.gate_arm is not None) else None
         slot["pending"] = True
         if self.threaded:
             import threading
@@ -460,6 +468,9 @@ class PipelinedExchange:
                 return
             try:
                 if self._error is None:
+                    if slot.get("gate") is not None and self.gate_wait is not None:
+                        while not self._gates_open and not self.gate_wait(slot["gate"]):
+                            pass  # (gate_wait times out every millisecond or so: drain() is noticed)
                     self._gather(slot, dist.get_world_size(self.group))
                     self._collect(slot)
             except BaseException as exc:  # noqa: BLE001 -- handed to the submitting thread
@@ -542,12 +553,14 @@ class PipelinedExchange:
     def drain(self):
         """finish everything submitted; returns the all_counts of the last batch"""
         last = None
+        self._gates_open = True  # nothing comes behind these batches: they go now
         for k in (self.calls % 2, (self.calls + 1) % 2):  # older first
             if self.slots[k]["pending"] or (self.threaded and "finished" in self.slots[k]):
                 r = self._finish(self.slots[k])
                 last = r if r is not None else last
         if self.cuda:
             self.comm.synchronize()
+        self._gates_open = False
         return last
 
     def close(self):

@@ -172,6 +172,14 @@ class OverlapContext:
     def set_shard(self, shard, n_shards):
         self._check(self._L.msgpu_set_shard(self._h, shard, n_shards))
 
+    def chain_launches(self):
+        """how often chaining_and_overlaps has launched its chain kernels (any thread)"""
+        return int(self._L.msgpu_chain_launches(self._h))
+
+    def wait_chain_launch(self, count, timeout_us=1000):
+        """block until chain_launches() >= count -> True, or the timeout has passed -> False (any thread; the GIL is released)"""
+        return self._L.msgpu_wait_chain_launch(self._h, int(count), int(timeout_us)) == 0
+
     def set_id_space(self, n_reads, n_anchors):
         """Declare the id counts the loader already knows (Registry sizes); (0, 0) = let the index build find them."""
         self._check(self._L.msgpu_set_id_space(self._h, int(n_reads), int(n_anchors)))

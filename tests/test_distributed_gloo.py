@@ -137,15 +137,26 @@ def _pipelined_worker(rank, world, port, rows_bytes, out_dir, wire=False):
         for attempt in range(3):
             merged = []
             pt = D.PipelinedExchange(torch.device("cpu"), merge, wire=wire, threaded=True)
+            launches, waits = [0], [0]
+            if attempt == 2:  # the gate bench.py arms: batch b's all-gather is held until "the chain launch of step b + 1"
+                import time
+
+                def gate_wait(token):
+                    waits[0] += 1
+                    time.sleep(0.001)
+                    return launches[0] >= token
+                pt.gate_arm, pt.gate_wait = (lambda: launches[0] + 1), gate_wait
             try:
                 for b in range(6):
+                    launches[0] += 1  # (step b's chain stage starts: the batch before may go)
                     t = held(b, rank)
                     pt.submit((len(t["edges"]), len(t["orders"]), len(t["ids"])), _filler(D, t, wire))
                     assert pt.collect() is None
                     if attempt == 1 and b % 2:
                         import time
                         time.sleep(0.05)  # (another interleaving: the thread gets ahead of the submitter)
-                assert pt.drain() is not None and len(merged) == 6
+                assert pt.drain() is not None and len(merged) == 6  # (drain opens the gate of the last batch)
+                assert attempt != 2 or waits[0] >= 1  # (batches still queued when drain() opened the gates skip theirs)
             finally:
                 pt.close()
             assert [m[2] for m in merged] == plain_sizes, (attempt, [m[2] for m in merged], plain_sizes)
