@@ -328,7 +328,8 @@ int msgpu_merge_gathered_ex(msgpu_ctx *ctx, const void *d_gathered, uint32_t wor
  * msgpu_pack_wire writes the context's tables (after msgpu_chaining_and_overlaps) in that form into three DEVICE blocks
  * (edge and id blocks 4-byte, order block 8-byte aligned) on the context's stream; MSGPU_E_ARG when a table has more than
  * 2^32 - 1 EdgeMatches, orders or ids (exchange such tables whole) or, with id_bytes = 3, an anchor id space beyond 2^24.  msgpu_merge_wire = msgpu_merge_gathered_ex over
- * slabs whose three blocks are in wire form: the merged tables are the same, byte for byte.
+ * slabs whose three blocks are in wire form: the merged tables are the same, byte for byte (d_edges and d_orders 16-byte
+ * aligned: the records leave as whole lines).
  * Both are asynchronous: STREAM CONTRACT rule 3 applies to the three blocks msgpu_pack_wire writes (a fill of those
  * buffers queued on another stream races with the pack kernel) and to msgpu_merge_wire's input and output buffers.
  * A table without records still sends its closing CSR entries (zeros): 8 bytes of the edge block, 4 of the order block. */

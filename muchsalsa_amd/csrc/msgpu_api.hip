@@ -1430,6 +1430,8 @@ int msgpu_merge_wire(msgpu_ctx *c, const void *d_gathered, uint32_t world, const
   if (!d_gathered || !counts || world == 0 || world > MAX_WORLD) return fail(c, MSGPU_E_ARG, "bad merge arguments");
   if ((reinterpret_cast<uintptr_t>(d_gathered) & 7) || (slab_bytes & 7) || (off_edges & 3) || (off_orders & 7) || (off_ids & 3))
     return fail(c, MSGPU_E_ARG, "msgpu_merge_wire: slabs and order blocks need 8-byte, edge and id blocks 4-byte alignment");
+  if ((reinterpret_cast<uintptr_t>(d_edges) & 15) || (reinterpret_cast<uintptr_t>(d_orders) & 15))
+    return fail(c, MSGPU_E_ARG, "msgpu_merge_wire: the merged edge and order tables need 16-byte alignment (whole-line stores)");
   HIPCHK(c, hipSetDevice(c->device));
   MergeArgs a;
   a.gathered   = static_cast<const uint8_t *>(d_gathered);
