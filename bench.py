@@ -1104,7 +1104,7 @@ def main():
             if form["wire"]:
                 form["wire"] = 3 if int(alls[:, 1].max()) <= 1 << 24 else 4
             pe = D.PipelinedExchange(dev, merge, wire=form["wire"])
-            if os.environ.get("MSGPU_EXCHANGE_GATE", "1") != "0":  # the exchange of step k beside the chain stage of step k + 1
+            if os.environ.get("MSGPU_EXCHANGE_GATE", "1") != "0":  # the merge of step k beside the chain stage of step k + 1
                 pe.gate_arm = lambda: ctx.chain_launches() + 1
                 pe.gate_wait = lambda count: ctx.wait_chain_launch(count, 1000)
 

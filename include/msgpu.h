@@ -479,8 +479,8 @@ int msgpu_synchronize(msgpu_ctx *ctx);
  * msgpu_chain_launches = how often msgpu_chaining_and_overlaps has launched its chain kernels so far; msgpu_wait_chain_launch
  * blocks the calling thread until that count reaches `count` (0) or `timeout_us` has passed (1).  The chain stage is bound by
  * instruction issue, the stages before it by memory: work enqueued on another stream when the wait returns runs beside the
- * stage that has bandwidth to spare (bench.py --gpus N: the all-gather and merge of step k beside the chain stage of step
- * k + 1).  The two calls may be made from any thread while another thread drives the context (the one exception to rule 5 of
+ * stage that has bandwidth to spare (bench.py --gpus N: the merge of step k's gathered slabs beside the chain stage of step
+ * k + 1; the all-gather itself, bound by the links, is not held).  The two calls may be made from any thread while another thread drives the context (the one exception to rule 5 of
  * the STREAM AND THREAD CONTRACT besides msgpu_merge_*_ex); they touch nothing but the counter. */
 uint64_t msgpu_chain_launches(msgpu_ctx *ctx);
 int msgpu_wait_chain_launch(msgpu_ctx *ctx, uint64_t count, uint32_t timeout_us);

@@ -334,11 +334,12 @@ class PipelinedExchange:
         self._error = None
         self._thread = None
         self._world = None
-        # An optional gate in front of every all-gather (threaded mode): gate_arm() is called by submit() and returns a token,
+        # An optional gate in front of every MERGE (threaded mode): gate_arm() is called by submit() and returns a token,
         # gate_wait(token) by the communication thread, repeatedly, until it returns True or drain() has opened the gates.
-        # bench.py arms it with "the next launch of the chain kernels" (OverlapContext.wait_chain_launch): the all-gather and the
-        # merge of step k then run beside the issue-bound chain stage of step k + 1 instead of beside its memory-bound index
-        # build and candidate scan.
+        # bench.py arms it with "the next launch of the chain kernels" (OverlapContext.wait_chain_launch): the merge of step k
+        # (bound by HBM) then runs beside the issue-bound chain stage of step k + 1 instead of beside its memory-bound index
+        # build and candidate scan.  The all-gather is not held: over xGMI it is bound by the links, takes most of a step at
+        # 8 ranks and hardly touches HBM.
         self.gate_arm = self.gate_wait = None
         self._gates_open = False
         if self.threaded:
@@ -468,9 +469,6 @@ class PipelinedExchange:
                 return
             try:
                 if self._error is None:
-                    if slot.get("gate") is not None and self.gate_wait is not None:
-                        while not self._gates_open and not self.gate_wait(slot["gate"]):
-                            pass  # (gate_wait times out every millisecond or so: drain() is noticed)
                     self._gather(slot, dist.get_world_size(self.group))
                     self._collect(slot)
             except BaseException as exc:  # noqa: BLE001 -- handed to the submitting thread
@@ -528,6 +526,10 @@ class PipelinedExchange:
                 self._relayout(slot, world)
             self._gather(slot, world)
         k = 0 if slot is self.slots[0] else 1
+        if self.threaded and slot.get("gate") is not None and self.gate_wait is not None:
+            # the all-gather (bound by the links: it hardly touches HBM) went out at once; the merge (bound by HBM) waits here
+            while not self._gates_open and not self.gate_wait(slot["gate"]):
+                pass  # (gate_wait times out every millisecond or so: drain() is noticed)
         if self.cuda:
             with torch.cuda.stream(self.comm):
                 self.merge(slot["gathered"], heads, slot["offs"], slot["slab_bytes"], k, self.comm)
