@@ -1599,9 +1599,21 @@ int msgpu_overlap_batched(msgpu_ctx *c, const msgpu_row *rows, size_t n_rows, ui
   return msgpu_overlap_batched_ex(c, rows, n_rows, n_batches, 0, out);
 }
 
+static int overlap_batched_impl(msgpu_ctx *c, const msgpu_row *rows, size_t n_rows, uint32_t n_batches, uint32_t flags,
+                                msgpu_host_tables *out);
 int msgpu_overlap_batched_ex(msgpu_ctx *c, const msgpu_row *rows, size_t n_rows, uint32_t n_batches, uint32_t flags,
                              msgpu_host_tables *out) {
   if (!c || !out) return MSGPU_E_ARG;
+  try { // (the dispatcher keeps a few small host containers and starts a thread: nothing C++ may leave through the C boundary)
+    return overlap_batched_impl(c, rows, n_rows, n_batches, flags, out);
+  } catch (const std::bad_alloc &) {
+    return fail(c, MSGPU_E_NOMEM, "host memory for the dispatcher's bookkeeping");
+  } catch (...) {
+    return fail(c, MSGPU_E_HIP, "unexpected C++ exception in the dispatcher");
+  }
+}
+static int overlap_batched_impl(msgpu_ctx *c, const msgpu_row *rows, size_t n_rows, uint32_t n_batches, uint32_t flags,
+                                msgpu_host_tables *out) {
   memset(out, 0, sizeof(*out));
   if (flags & ~(MSGPU_BATCH_RESIDENT | MSGPU_BATCH_NO_EDGEMATCHES | MSGPU_BATCH_ROWS_ON_DEVICE))
     return fail(c, MSGPU_E_ARG, "unknown flags %#x", flags);
