@@ -354,7 +354,8 @@ int msgpu_unpack_wire_host(const void *wire_edges, const void *wire_orders, cons
 /* ---- one process, the node's GPUs: a GROUP of contexts behind the same call site -------------------------------------------
  * The reference is ONE process that fans jobs over its workers and closes each phase with a barrier (src/main.cpp:143-178,
  * libms/src/threading/ThreadPool.cpp:38-129, WaitGroup.cpp:62-72).  Its multi-GPU equivalent: one process, one context per
- * device, one host thread per device for the duration of a call, and ONE collective on the path.  msgpu_group_overlap =
+ * device, one host thread per device for the duration of a call, and ONE collective on the results (with several members a
+ * second, input-side one completes the row table in every HBM).  msgpu_group_overlap =
  *   rows (host) -> a 1/n-th over each device's own link, completed in every HBM by a grouped in-place all-gather over xGMI
  *   (MSGPU_GROUP_ROWS=replicate at creation, a group of one, or fewer than 1024 rows: the whole table over every link) ->
  *   index build on every device (replicated: a member needs
