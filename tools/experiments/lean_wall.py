@@ -16,8 +16,11 @@ windows = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 all4 = len(sys.argv) > 3 and sys.argv[3] == "1"
 w = WORKLOADS["cfg3"]
 rows, rn, an = synth.accepted_rows(synth.paf_table(w["n_reads"], w["read_len"], w["n_anchors"], w["seed"]))
+DECLARE = os.environ.get("LEAN_DECLARE_IDS", "1") != "0"
 pinned = overlap.PinnedRows(rows)
 with overlap.OverlapContext(0) as ctx:
+    if DECLARE:
+        ctx.set_id_space(len(rn), len(an))  # (the parser knows the Registry sizes: what pipeline.run and bench.py do)
     kw = dict(copy=False) if all4 else dict(copy=False, resident=True, edgematches=False)
     ctx.overlap_batched(pinned, windows, **kw)
     walls, infos = [], []
