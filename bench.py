@@ -341,7 +341,7 @@ def group_leg(rows, reps=4):
         pinned.close()
 
 
-def group_on_node(world, workload, timeout_s=420):
+def group_on_node(world, workload, timeout_s=300):
     """msgpu_group_overlap over the node's `world` GPUs -- the in-process C++ driver of the N > 1 path (a libms caller's view:
     include/msgpu.h msgpu_group_*, RCCL resolved by the library) -- run as a CHILD process of rank 0 after the ranks' own process
     group is gone: a failure or a hang of a collective that has never run on hardware cannot take the line with it."""
