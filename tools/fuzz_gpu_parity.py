@@ -97,6 +97,14 @@ def main():
     seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
     oracle.build()
     group = overlap.OverlapGroup([0])  # msgpu_group_overlap with one member: the C++ multi-GPU path, through RCCL
+    # ... and with two and three members sharing this GPU through the rehearsal transport (the switch is read at creation):
+    # shards, member threads, sliced row upload + row all-gather, slab layout, pack, merge, slab-wise unpacking on the host
+    from muchsalsa_amd import distributed as D
+    os.environ["MSGPU_GROUP_TRANSPORT"] = "copy"
+    try:
+        rehearsal = {k: overlap.OverlapGroup([0] * k) for k in (2, 3)}
+    finally:
+        del os.environ["MSGPU_GROUP_TRANSPORT"]
     paths = {}
     for case in range(n_cases):
         rng = np.random.default_rng(seed0 + case)
@@ -140,6 +148,14 @@ def main():
         if case % 4 == 0:
             gt, ginfo = group.overlap(feed)
             assert_tables_equal(dict(gt, ems=want["ems"]), want, what + ", group of one")
+            assert np.array_equal(gt["read_len"], want["read_len"]) and np.array_equal(gt["read_first_line"], want["read_first_line"])
+        if case % 4 == 2:
+            k = 2 + (case // 4) % 2
+            host = D.merge_tables_host([D.shard_view_host(want, r, k) for r in range(k)])
+            gt, ginfo = rehearsal[k].overlap(feed)
+            assert ginfo["n_members"] == k and ginfo["n_ems"] == len(want["ems"])
+            for name in ("edges", "orders", "ids"):
+                assert gt[name].tobytes() == host[name].tobytes(), (what, "group of %d" % k, name)
             assert np.array_equal(gt["read_len"], want["read_len"]) and np.array_equal(gt["read_first_line"], want["read_first_line"])
         with overlap.OverlapContext(0) as ctx:  # and the same job as windows of owner reads
             nb = int(rng.integers(1, 12))
