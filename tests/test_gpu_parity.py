@@ -617,6 +617,8 @@ def test_bench_distributed_path_smoke():
     assert line["strong"]["merged_edge_list_consistent"] is True and line["strong"]["value"] > 0
     assert line["strong"]["edges"] == line["config"]["edges"]
     assert line["host_to_host_sharded"]["edges"] == line["config"]["edges"] and line["host_to_host_sharded"]["ms"] > 0
+    # ... and, once the ranks have left their process group, msgpu_group_overlap over the node's devices in a child process
+    assert "error" not in line["group_on_node"] and line["group_on_node"]["members"] == 1 and line["group_on_node"]["transport"] == "rccl"
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "tiny", "--steps", "2",
                           "--warmup", "1", "--kernels-only", "--force-dist", "--scaling", "strong", "--exchange-format", "whole"],
                          env=env, capture_output=True, text=True, timeout=300)
