@@ -65,7 +65,12 @@ def pmc_traffic(workload, world, kernels):
             best = f  # sorted(): the last match is the newest round
     if best is None:
         return None, "no counter capture under profiles/ for (%s, %d GPU): run tools/pmc_passes.sh" % (workload, world), None
-    rows = {r["kernel"]: r for r in csv.DictReader(open(best))}
+    table = list(csv.DictReader(open(best)))
+    gone = capture_is_stale(table)
+    if gone:
+        return None, "%s was taken with kernels this build no longer has (%s): traffic dropped" % (
+            os.path.relpath(best, ROOT), ", ".join(gone[:4])), None
+    rows = {r["kernel"]: r for r in table}
     total, valu = 0.0, {}
     for k in kernels:
         r = rows.get(k)
@@ -75,6 +80,30 @@ def pmc_traffic(workload, world, kernels):
         if r.get("SQ_INSTS_VALU"):
             valu[k] = float(r["SQ_INSTS_VALU"])
     return total, os.path.relpath(best, ROOT), valu
+
+
+def current_library_kernels():
+    """base names (k_chain, k_index_bin, ...) of the kernels in the built libmsgpu.so, read from its symbol strings"""
+    import re
+    try:
+        data = open(os.path.join(ROOT, "muchsalsa_amd", "libmsgpu.so"), "rb").read()
+    except OSError:
+        return set()
+    return {name[:int(n)].decode() for n, name in re.findall(rb"_ZN5msgpu(\d+)(k_[A-Za-z0-9_]+)", data)}
+
+
+def capture_is_stale(table):
+    """kernels of a counter capture that the current build no longer has (by base name) -> sorted list"""
+    import re
+    current = current_library_kernels()
+    if not current:
+        return []
+    gone = set()
+    for r in table:
+        m = re.search(r"msgpu::(k_[A-Za-z0-9_]+)", r["kernel"])
+        if m and m.group(1) not in current:
+            gone.add(m.group(1))
+    return sorted(gone)
 
 
 def pmc_stage(workload, world, prefixes):
@@ -95,7 +124,14 @@ def pmc_stage(workload, world, prefixes):
     total, used = 0.0, []
     table = list(csv.DictReader(open(best)))
     # steps in the capture = dispatches of a kernel that runs once per step
-    steps = max([float(r["dispatches"]) for r in table if r["kernel"].replace("void ", "") == "msgpu::k_compact"] or [1.0])
+    anchor = [float(r["dispatches"]) for r in table if r["kernel"].replace("void ", "") == "msgpu::k_compact"]
+    if not anchor:  # (without the once-per-step kernel the per-step share of a dispatch count is unknown)
+        return None, "%s has no msgpu::k_compact row to count its steps by" % os.path.relpath(best, ROOT), []
+    steps = max(anchor)
+    gone = capture_is_stale(table)  # the capture must be of THIS build's kernels
+    if gone:
+        return None, "%s was taken with kernels this build no longer has (%s): traffic dropped" % (
+            os.path.relpath(best, ROOT), ", ".join(gone[:4])), []
     for r in table:
         name = r["kernel"].replace("void ", "")
         if any(name.startswith(p) for p in prefixes) and r.get("FETCH_SIZE") and r.get("WRITE_SIZE"):
@@ -157,6 +193,8 @@ def cpu_baseline(workload, budget_reads, cores):
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     out = {
         "value": e1 / dt1, "unit": "overlap-pairs/s", "cores": 1, "kind": "port", "cpu_model": _cpu_model(),
+        "kind_detail": "port (oracle/ms_oracle.c, a single-thread C restatement; the reference itself does not build here: it "
+                       "needs microsoft/GSL, which is neither under /root/reference nor in the image)",
         "cores_available": avail,
         "core_policy": "min(16, cores this process may run on): 16 = the GPU box's CPU share per GPU",
         "sample": "%d reads x %d bp, %d anchors (same generator/seed/density as the GPU workload, %.0f%% scale): "
@@ -240,7 +278,9 @@ def cpu_consensus_baseline():
     dt = time.perf_counter() - t0
     T = sum(len(r["target"]) for r in res)
     return {"value": T / dt / 1e6, "unit": "consensus-Mbases/s", "cores": 1,
-            "kind": "port (Python restatements of src/main.cpp:194-310, dg.cpp, lg.cpp, ap.cpp; C for findContractionEdges)",
+            "kind": "port (PYTHON restatements of src/main.cpp:194-310, dg.cpp, lg.cpp, ap.cpp; C for findContractionEdges): an "
+                    "interpreter's speed, a weak bar -- the only figure for the reference's own code is the survey's 0.23 "
+                    "consensus-Mbases/s, measured on another machine (see sample)",
             "sample": "tiled shape at configs[1] size (%d reads, %d unitigs, %d edges): %d contigs, %d bases in %.2f s; "
                       "the reference itself, measured by the survey on a 1 Mb genome: 0.23 consensus-Mbases/s (SURVEY.md "
                       "section 6)" % (n_reads, len(anchor_names), len(edges), len(res), T, dt)}
@@ -906,8 +946,8 @@ def main():
                     help="N > 1: weak = every rank runs one partition of an N-partition job (each of the workload's shape; "
                          "disjoint read / anchor id ranges), the merged edge list all-gathered on a communication stream "
                          "beside the next step's compute; strong = the ONE job of the workload sharded over the ranks by "
-                         "v1 %% N (BASELINE.json configs[3]).  auto = weak, with the strong figure and the rank-sharded "
-                         "host-to-host figure reported beside it")
+                         "v1 %% N (BASELINE.json configs[3]).  auto = strong is `value` (the configuration BASELINE names), the "
+                         "weak figure and the rank-sharded host-to-host figure are reported beside it")
     ap.add_argument("--exchange-format", default="wire", choices=("wire", "whole"),
                     help="what the N > 1 exchange sends: the wire form of include/msgpu.h (17-byte edges, 33-byte orders; "
                          "msgpu_pack_wire / msgpu_merge_wire) or whole records (msgpu_copy_tables_device / msgpu_merge_gathered)")
@@ -1074,7 +1114,7 @@ def main():
 
     partition_rows = weak  # (rank > 0 holds a partition's rows, not the job's)
     weak_error = None
-    exchange_info = strong_leg = sharded_h2h = None
+    exchange_info = strong_leg = sharded_h2h = weak_leg = None
     merge_ok = rank_ms = None
     scaling = "weak"
     if not multi:
@@ -1136,9 +1176,13 @@ def main():
                     and bool(np.all(np.diff(me["v1"].astype(np.int64)) >= 0))  # id bases ascend: (v1, v2)-sorted
                 if world > 1:
                     merge_ok = merge_ok and int(me["v1"][ne]) >= int(id_base[1][0]) and int(mi[ni:].min()) >= int(id_base[1][1])
-        except Exception as exc:  # noqa: BLE001 -- (deterministic failures hit every rank alike: the strong leg becomes the line)
+        except Exception as exc:  # noqa: BLE001 -- (deterministic failures hit every rank alike: the strong leg is the line anyway)
             weak_error = "%s: %s" % (type(exc).__name__, exc)
             weak = False
+            try:
+                pe.close()  # (its communication thread must not go on polling the context beside the later legs)
+            except Exception:  # noqa: BLE001
+                pass
     if multi and (not weak or args.scaling == "auto"):
         # ---- strong scaling (BASELINE.json configs[3]): the ONE job of the workload, edges owned by v1 % N ---------------
         if partition_rows:  # every rank needs the job's table now (rank 0 holds it already)
@@ -1193,10 +1237,22 @@ def main():
                       "workload": "%s as ONE job: every rank indexes the whole row table (replicated), owns the edges with "
                                   "v1 %% %d == rank, one all-gather + merge per step on the compute stream "
                                   "(BASELINE.json configs[3] at N = 8)" % (w["name"], world)}
-        if not weak:
-            scaling = "strong"
-            dt, c, k_ms, tm, rank_ms, n_edges_total, merge_ok = s_dt, s_c, s_k_ms, s_tm, s_rank_ms, s_edges, s_ok
-            exchange_info, strong_leg = strong_leg["exchange"], None
+        # `value` at N > 1 is the STRONG figure -- BASELINE.json configs[3] is ONE 100k x 10 kb job sharded over the GPUs of a
+        # node -- and the weak figure (N partitions of that shape: not a configuration BASELINE names) stands beside it
+        if weak:
+            weak_leg = {"scaling": "weak", "value": n_edges_total / (dt / args.steps), "unit": "overlap-pairs/s",
+                        "ms_per_step": 1e3 * dt / args.steps, "edges": n_edges_total, "rank_ms_per_step": rank_ms,
+                        "merged_edge_list_consistent": merge_ok, "exchange": exchange_info,
+                        "stage_ms": {"index": tm.index_ms, "candidates": tm.candidates_ms, "chain_total": tm.chain_ms,
+                                     "chain_kernel": float(k_ms), "compact": tm.compact_ms},
+                        "workload": "%d partitions, each: %s (seeds %d..%d; disjoint read / anchor id ranges, so no edge crosses "
+                                    "a partition), one partition per GPU; the all-gather + merge of step k on a communication "
+                                    "stream beside the compute of step k + 1.  NOT a BASELINE configuration"
+                                    % (world, w["name"], w["seed"], w["seed"] + world - 1)}
+            weak = False
+        scaling = "strong"
+        dt, c, k_ms, tm, rank_ms, n_edges_total, merge_ok = s_dt, s_c, s_k_ms, s_tm, s_rank_ms, s_edges, s_ok
+        exchange_info, strong_leg = strong_leg["exchange"], None
         try:
             sharded_h2h = sharded_host_to_host_leg(torch, dist, D, dev, ctx, rows_s, world, rank, args.batches)
         except Exception as exc:  # noqa: BLE001 -- (raised on every rank alike: same code, same sizes)
@@ -1324,9 +1380,13 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "int32+f64",
             "data": "synthetic",
-            "config": {"workload": (w["name"] if not (weak and world > 1) else
+            "config": {"workload": (w["name"] if world == 1 else
                                     "%d partitions, each: %s (seeds %d..%d; disjoint read / anchor id ranges, so no edge "
-                                    "crosses a partition), one partition per GPU" % (world, w["name"], w["seed"], w["seed"] + world - 1)),
+                                    "crosses a partition), one partition per GPU" % (world, w["name"], w["seed"], w["seed"] + world - 1)
+                                    if weak else
+                                    "%s -- ONE job sharded across %d GPUs: every rank indexes the replicated row table and owns the "
+                                    "edges with v1 %% %d == rank, one RCCL all-gather + merge of the edge list per step "
+                                    "(BASELINE.json configs[3] is this at N = 8)" % (w["name"], world, world)),
                        "rows": int(len(rows)), "reads": int(c.n_reads),
                        "anchors": int(c.n_anchors), "edges": n_edges_total, "edgematches_rank0": int(c.n_ems),
                        "orders_rank0": int(c.n_orders),
@@ -1354,9 +1414,11 @@ def main():
             out["rank_ms_per_step"] = rank_ms
             out["exchange"] = exchange_info
             if weak_error is not None:
-                out["weak_scaling_error"] = weak_error + " -- `value` is the strong-scaling figure"
+                out["weak_scaling_error"] = weak_error + " -- the weak figure beside `value` is missing"
             if strong_leg is not None:
                 out["strong"] = strong_leg
+            if weak_leg is not None:
+                out["weak"] = weak_leg
             if sharded_h2h is not None:
                 out["host_to_host_sharded"] = sharded_h2h
             if cons_weak is not None:
@@ -1367,6 +1429,20 @@ def main():
             # SURVEY.md section 8(d) / BASELINE.md 3.4 define overlap-pairs/s over [row table in host memory -> order / edge
             # tables in host memory].  The bench contract fixes `value` on inputs resident in HBM (the PCIe-inclusive rate "is
             # never value"), so that region's figures stand here, at the top level, beside it.
+            # ... and as plain scalars inside `config` and `roofline`, the two objects the driver's record keeps whole
+            # (BENCH_r04.json retained `survey_8d_region` as a bare key name only)
+            link_floor_ms = (h2h.get("rows_bytes_h2d", 0) + (lean.get("table_bytes_d2h") or 0)) / 55e9 * 1e3
+            for holder in (out["config"], out["roofline"]):
+                holder["survey_8d_ms"] = lean.get("ms")
+                holder["survey_8d_overlap_pairs_per_s"] = lean.get("overlap_pairs_per_s")
+                holder["survey_8d_all_tables_ms"] = h2h.get("ms")
+                holder["survey_8d_all_tables_overlap_pairs_per_s"] = h2h.get("overlap_pairs_per_s")
+                holder["survey_8d_link_floor_ms"] = link_floor_ms
+                holder["survey_8d_rows_bytes_h2d"] = h2h.get("rows_bytes_h2d")
+            out["config"]["survey_8d_note"] = (
+                "SURVEY 8(d)'s own region: rows in pinned host memory -> edge / order / id tables in pinned host memory (EdgeMatch "
+                "table left in HBM); all_tables = with the EdgeMatch table copied out too; link_floor = bytes up + down of the lean "
+                "region at the ~55 GB/s this PCIe link delivers.  PCIe-inclusive, so never `value`")
             out["survey_8d_region"] = {
                 "overlap_pairs_per_s": lean.get("overlap_pairs_per_s"), "ms": lean.get("ms"),
                 "region": "rows in pinned host memory -> edge, order and id tables in pinned host memory "
@@ -1423,21 +1499,59 @@ def main():
                 out["cpu_baseline"]["which_is_which"] = (
                     "value: %d scaled samples run together, one per core (what a perfectly scaling multi-threaded port would reach); "
                     "one_core_value: the C oracle on the WHOLE workload of this line, one core; one_core_quarter_sample_value: one "
-                    "scaled sample alone.  kind 'port': the oracle is ~9x faster than the reference it restates (DESIGN.md)" % cores)
+                    "scaled sample alone.  kind 'port': the oracle is roughly 9x faster than the reference it restates -- a "
+                    "CROSS-MACHINE ratio (the reference: 3.26 k overlap-pairs/s on the survey's 2.1 GHz Xeon container, SURVEY.md "
+                    "section 6; the oracle: this box's host CPU), not a same-machine calibration" % cores)
             except Exception as exc:  # noqa: BLE001
                 out["cpu_baseline"]["one_core_error"] = "%s: %s" % (type(exc).__name__, exc)
             try:
                 out["cpu_baseline"]["consensus"] = cpu_consensus_baseline()
             except Exception as exc:  # noqa: BLE001
                 out["cpu_baseline"]["consensus"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
-    ctx.close()
-    if multi:
-        dist.destroy_process_group()
-    if rank == 0:
-        if multi and args.backend == "nccl" and not args.single_device and not args.kernels_only:
-            # every rank has left its process group (the others exit now): the node's GPUs go to ONE process, the C++ group
-            out["group_on_node"] = group_on_node(world, args.workload)
+    # The metric line must never be lost to what follows the measurement.  Ranks other than 0 tear down and leave.  Rank 0 arms
+    # a watchdog that writes the line as it stands (and ends the process) should anything below stall, runs the group child under
+    # its own, shorter limit, WRITES THE LINE, and only then tears down its context and process group: a hang or an abort in
+    # RCCL's teardown comes after the line.
+    if rank != 0:
+        ctx.close()
+        if multi:
+            dist.destroy_process_group()
+        return
+    import threading
+    written = threading.Lock()
+
+    def write_line(extra=None):
+        if not written.acquire(blocking=False):
+            return
+        if extra:
+            out.update(extra)
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
+
+    want_group = multi and args.backend == "nccl" and not args.single_device and not args.kernels_only
+    group_limit_s = float(os.environ.get("MSGPU_BENCH_GROUP_LIMIT_S", "150"))
+
+    def watchdog():
+        write_line({"group_on_node": {"error": "rank 0 stalled behind the measurement (teardown or the group child): "
+                                               "line written by the watchdog"}} if want_group else None)
+        os._exit(0)
+
+    guard = threading.Timer((group_limit_s if want_group else 0.0) + 60.0, watchdog)
+    guard.daemon = True
+    guard.start()
+    try:
+        ctx.close()  # our own arena: the group child gets GPU 0's memory
+        if want_group:
+            # the other ranks are leaving (or gone): the node's GPUs also go to ONE process, the C++ group, a child of this one
+            out["group_on_node"] = group_on_node(world, args.workload, timeout_s=group_limit_s)
+    except Exception as exc:  # noqa: BLE001
+        out.setdefault("group_on_node", {"error": "%s: %s" % (type(exc).__name__, exc)})
+    write_line()
+    guard.cancel()
+    if multi:
+        try:
+            dist.destroy_process_group()
+        except Exception as exc:  # noqa: BLE001 -- (after the line: nothing to lose)
+            print("destroy_process_group: %s" % exc, file=sys.stderr)
 
 
 if __name__ == "__main__":

@@ -46,6 +46,9 @@ extern "C" {
 #define MSGPU_E_NODEVICE (-9) /* no HIP device: the product has NO CPU fallback                                */
 #define MSGPU_E_LAYOUT (-10)  /* assemblePath input the reference itself cannot assemble (it would terminate, hang
                                  or read past a container): text in msgpu_assembly_last_error                     */
+#define MSGPU_E_TIMEOUT (-11) /* a deadline (msgpu_set_deadline, msgpu_group_set_timeout) passed with device work
+                                 still queued: the reference's one catch at src/main.cpp:313-315 sees an error
+                                 instead of a process that never returns                                          */
 
 /* ---- records (byte-identical to oracle/ms_oracle.h) ----------------------------------------------------------- */
 
@@ -396,6 +399,16 @@ const char *msgpu_group_last_error(const msgpu_group *g);
 int  msgpu_group_size(const msgpu_group *g);
 msgpu_ctx *msgpu_group_ctx(msgpu_group *g, int member); /* member i's context: its counts, its EdgeMatch table, its merged device tables */
 int  msgpu_group_overlap(msgpu_group *g, const msgpu_row *rows, size_t n_rows, msgpu_group_tables *out);
+/* A way out of a collective that never completes.  timeout_ms > 0: msgpu_group_overlap gives up that long after its entry --
+ * every host wait of the call (the members' table sizes, the slabs landing in host memory, the closing barrier) polls instead of
+ * blocking -- then aborts the members' communicators (ncclCommAbort: the collective's kernels leave the streams), waits at most
+ * the same time again for the streams to drain, and returns MSGPU_E_TIMEOUT with the text saying whether they did.  The next call
+ * builds fresh communicators.  0 = wait for ever (the default; MSGPU_GROUP_TIMEOUT_MS in the environment at creation sets
+ * another).  The one-catch error model of src/main.cpp:313-315: the caller sees a code, not a process that hangs.
+ * On ANY error return the group has synchronised what it queued where that was possible (nothing of the call reads `rows` or
+ * writes the group's host tables any more unless the text says the streams did not drain); the calling thread's current HIP
+ * device is restored on every return. */
+int  msgpu_group_set_timeout(msgpu_group *g, uint32_t timeout_ms);
 /* The merged tables as member `member` holds them in ITS HBM (device pointers, valid until the group's next call): what
  * msgpu_find_contraction_edges(msgpu_group_ctx(g, member), d_edges, n_edges, d_orders, n_orders, n_reads, ...) takes. */
 int  msgpu_group_device_tables(msgpu_group *g, int member, const void **d_edges, const void **d_orders, const void **d_ids);
@@ -476,6 +489,13 @@ int msgpu_find_contraction_edges(msgpu_ctx *ctx, const void *d_edges, uint64_t n
 
 /* Block the host until everything queued on the context's stream has finished. */
 int msgpu_synchronize(msgpu_ctx *ctx);
+/* A deadline for the host waits of this context: from now on, and until the next msgpu_set_deadline, every wait a call of this
+ * context makes for its stream (table sizes coming back in msgpu_load_rows* / msgpu_calculate_edges /
+ * msgpu_chaining_and_overlaps, msgpu_synchronize, msgpu_copy_reads) gives up `timeout_ms` after THIS call and returns
+ * MSGPU_E_TIMEOUT; 0 = no deadline (the default: the runtime's blocking waits).  Nothing is cancelled: the work stays queued,
+ * the caller removes what holds the stream up (e.g. aborts its collective) and synchronises, or destroys the context.  Exists
+ * for contexts whose stream also carries somebody else's collective (msgpu_group_overlap sets it from the group's timeout). */
+int msgpu_set_deadline(msgpu_ctx *ctx, uint32_t timeout_ms);
 /* A gate for a caller's OTHER thread that has device work of its own to place (an exchange of the previous job's tables, say):
  * msgpu_chain_launches = how often msgpu_chaining_and_overlaps has launched its chain kernels so far; msgpu_wait_chain_launch
  * blocks the calling thread until that count reaches `count` (0) or `timeout_us` has passed (1).  The chain stage is bound by

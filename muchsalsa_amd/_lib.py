@@ -45,6 +45,7 @@ assert ALIGN_PAIR_DTYPE.itemsize == 24
 OK = 0
 E_IO, E_FORMAT, E_NUMBER, E_NOMEM, E_ARG, E_HIP, E_STATE, E_IDS, E_NODEVICE = -1, -2, -3, -4, -5, -6, -7, -8, -9
 E_LAYOUT = -10
+E_TIMEOUT = -11
 
 ORD_START_V1, ORD_CONTAINED, ORD_DIR, ORD_PRIMARY = 1, 2, 4, 8
 BATCH_RESIDENT, BATCH_NO_EDGEMATCHES, BATCH_ROWS_ON_DEVICE = 1, 2, 4
@@ -151,6 +152,7 @@ SYMBOLS = [
     ("msgpu_find_contraction_edges", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint32,
                                                C.c_void_p]),
     ("msgpu_synchronize", C.c_int, [C.c_void_p]),
+    ("msgpu_set_deadline", C.c_int, [C.c_void_p, C.c_uint32]),
     ("msgpu_seq_parse", C.c_int, [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]),
     ("msgpu_seq_free", None, [C.c_void_p]),
     ("msgpu_seq_count", C.c_uint32, [C.c_void_p]),
@@ -240,6 +242,7 @@ SYMBOLS = [
     ("msgpu_group_size", C.c_int, [C.c_void_p]),
     ("msgpu_group_ctx", C.c_void_p, [C.c_void_p, C.c_int]),
     ("msgpu_group_overlap", C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(GroupTables)]),
+    ("msgpu_group_set_timeout", C.c_int, [C.c_void_p, C.c_uint32]),
     ("msgpu_group_device_tables", C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                             C.POINTER(C.c_void_p)]),
     ("msgpu_overlap_batched", C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.POINTER(HostTables)]),

@@ -238,6 +238,10 @@ struct msgpu_ctx {
   hipEvent_t   ev_readback = nullptr; // the synchronising read-back path waits for the copy only
   hipEvent_t   ev_order = nullptr;    // msgpu_stream_wait / msgpu_stream_release
   uint32_t     decl_V = 0, decl_A = 0; // msgpu_set_id_space: id counts declared by the caller (0 = find them)
+  // msgpu_set_deadline: the host waits of this context's calls give up at this point in time (a collective of the caller's
+  // that never completes in front of our work on the stream must not hold a libms caller for ever)
+  bool                                  has_deadline = false;
+  std::chrono::steady_clock::time_point deadline{};
 
   // loaded rows
   uint64_t n_rows = 0, n_alive = 0;
@@ -335,6 +339,26 @@ template <class T> const T *host_scalar(const msgpu_ctx *c, int slot) { return r
 // hipStreamQuery and handled by the synchronising path, which is also what MSGPU_SYNC_READBACK=1 selects.
 // publish_scalars() enqueues the publication, wait_scalars() polls for it: work that does not depend on the values can
 // be enqueued in between and keeps the GPU busy while the host turns around.
+bool past_deadline(const msgpu_ctx *c) { return c->has_deadline && std::chrono::steady_clock::now() >= c->deadline; }
+// A host wait for a stream (or an event) that honours the context's deadline: without one the runtime's blocking wait, with
+// one a poll that gives up with MSGPU_E_TIMEOUT and leaves the work queued (the caller aborts what blocks it, or destroys).
+int host_sync(msgpu_ctx *c, hipStream_t st, hipEvent_t ev = nullptr) {
+  if (!c->has_deadline) {
+    if (ev) HIPCHK(c, hipEventSynchronize(ev));
+    else HIPCHK(c, hipStreamSynchronize(st));
+    return MSGPU_OK;
+  }
+  for (uint32_t spins = 0;; ++spins) {
+    const hipError_t q = ev ? hipEventQuery(ev) : hipStreamQuery(st);
+    if (q == hipSuccess) return MSGPU_OK;
+    if (q != hipErrorNotReady) return fail(c, MSGPU_E_HIP, "%s failed: %s", ev ? "hipEventQuery" : "hipStreamQuery", hipGetErrorString(q));
+    if (past_deadline(c))
+      return fail(c, MSGPU_E_TIMEOUT, "the context's stream did not drain before the deadline (msgpu_set_deadline): work is still queued");
+    if (spins < 2000) __builtin_ia32_pause();
+    else std::this_thread::sleep_for(std::chrono::microseconds(50));
+  }
+}
+
 int publish_scalars(msgpu_ctx *c, hipEvent_t mark = nullptr) {
   static const bool sync_path = getenv("MSGPU_SYNC_READBACK") != nullptr;
   c->readback_polled = !sync_path && c->h_scalars_dev;
@@ -361,6 +385,9 @@ int wait_scalars(msgpu_ctx *c) {
           break;
         }
         if (q != hipErrorNotReady) break;
+        if (past_deadline(c))
+          return fail(c, MSGPU_E_TIMEOUT, "table sizes did not come back before the deadline (msgpu_set_deadline): the stream is "
+                                          "held up by work queued in front of ours");
       }
     }
     // The stream stopped making progress, or finished without the publication arriving in mapped memory.  Take the values
@@ -369,11 +396,9 @@ int wait_scalars(msgpu_ctx *c) {
     // STREAM AND THREAD CONTRACT rule 4: the text belongs to a non-zero return code).
     ++c->lost_publications;
     HIPCHK(c, hipMemcpyAsync(c->h_scalars, c->scalars.p, SC_COUNT * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    return MSGPU_OK;
+    return host_sync(c, c->stream);
   }
-  HIPCHK(c, hipEventSynchronize(c->ev_readback)); // the copy, not whatever was enqueued behind it
-  return MSGPU_OK;
+  return host_sync(c, nullptr, c->ev_readback); // the copy, not whatever was enqueued behind it
 }
 int read_scalars(msgpu_ctx *c, hipEvent_t mark = nullptr) {
   if (int rc = publish_scalars(c, mark)) return rc;
@@ -423,7 +448,8 @@ int build_index_once(msgpu_ctx *c, bool force_generic, bool two_pass, bool bin, 
   // over; anything else raises a flag and build_index() comes back with bin = false.
   const uint32_t reads_per_pass = BIN_NB_MAX << BIN_RPB_SHIFT;
   const uint32_t bpasses = (bin && !force_generic && !two_pass && n && V) ? static_cast<uint32_t>((size_t(V) + reads_per_pass - 1) / reads_per_pass) : 0;
-  const uint32_t bcap    = (bpasses && bpasses <= BIN_PASSES_MAX) ? bin_capacity(n, V) : 0;
+  uint32_t       bcap    = (bpasses && bpasses <= BIN_PASSES_MAX) ? bin_capacity(n, V) : 0;
+  if (bcap && !index_sort_bin_prepare(bcap)) bcap = 0; // (the device does not grant the bucket's LDS: the atomic path from the start)
   const uint32_t bshift  = bcap ? BIN_RPB_SHIFT : 0; // != 0: this build takes the bin path
   const uint32_t nb      = bshift ? static_cast<uint32_t>((size_t(std::min(V, reads_per_pass)) + (1u << bshift) - 1) >> bshift) : 0; // buckets of a (full) pass
   const uint32_t     cap = (!bshift && !two_pass && V && size_t(V) * BUCKET_CAP * sizeof(IRow) <= (size_t(4) << 30)) ? BUCKET_CAP : 0;
@@ -641,6 +667,7 @@ const char *msgpu_strerror(int code) {
   case MSGPU_E_IDS: return "read ids are not in Registry (first-line) order";
   case MSGPU_E_NODEVICE: return "no HIP device (libmsgpu has no CPU fallback)";
   case MSGPU_E_LAYOUT: return "path cannot be assembled (the reference would terminate or hang on it)";
+  case MSGPU_E_TIMEOUT: return "a deadline passed while device work was still queued";
   default: return "unknown error";
   }
 }
@@ -1274,8 +1301,7 @@ int msgpu_copy_reads(msgpu_ctx *c, int32_t *read_len, uint32_t *read_first_line)
     HIPCHK(c, hipMemcpyAsync(read_len, c->read_len.p, size_t(c->V) * 4, hipMemcpyDeviceToHost, c->stream));
   if (read_first_line && c->V)
     HIPCHK(c, hipMemcpyAsync(read_first_line, c->read_first.p, size_t(c->V) * 4, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  return MSGPU_OK;
+  return host_sync(c, c->stream);
 }
 
 // findContractionEdges (src/main.cpp:183-190, 416-463) + sanityCheck (sc.cpp:29-90) over a resident edge/order table
@@ -1990,7 +2016,13 @@ int msgpu_wait_chain_launch(msgpu_ctx *c, uint64_t count, uint32_t timeout_us) {
 
 int msgpu_synchronize(msgpu_ctx *c) {
   if (!c) return MSGPU_E_ARG;
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return host_sync(c, c->stream);
+}
+
+int msgpu_set_deadline(msgpu_ctx *c, uint32_t timeout_ms) {
+  if (!c) return MSGPU_E_ARG;
+  c->has_deadline = timeout_ms != 0;
+  if (timeout_ms) c->deadline = std::chrono::steady_clock::now() + std::chrono::milliseconds(timeout_ms);
   return MSGPU_OK;
 }
 

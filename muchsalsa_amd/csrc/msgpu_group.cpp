@@ -28,6 +28,7 @@ struct Rccl {
   void *handle = nullptr;
   decltype(&ncclCommInitAll)    CommInitAll    = nullptr;
   decltype(&ncclCommDestroy)    CommDestroy    = nullptr;
+  decltype(&ncclCommAbort)      CommAbort      = nullptr;
   decltype(&ncclAllGather)      AllGather      = nullptr;
   decltype(&ncclGroupStart)     GroupStart     = nullptr;
   decltype(&ncclGroupEnd)       GroupEnd       = nullptr;
@@ -54,6 +55,7 @@ Rccl *rccl() {
   if (!r.field) snprintf(r.why, sizeof(r.why), "librccl lacks %s", symbol)
   RESOLVE(CommInitAll, "ncclCommInitAll");
   RESOLVE(CommDestroy, "ncclCommDestroy");
+  RESOLVE(CommAbort, "ncclCommAbort");
   RESOLVE(AllGather, "ncclAllGather");
   RESOLVE(GroupStart, "ncclGroupStart");
   RESOLVE(GroupEnd, "ncclGroupEnd");
@@ -133,6 +135,9 @@ struct msgpu_group {
   // MSGPU_GROUP_ROWS=replicate (read at creation): every member takes the whole row table over its own link, as a group of
   // one does.  Default with several members: a 1/n-th each, all-gathered over xGMI (see msgpu_group_overlap).
   bool                replicate_rows = false;
+  // msgpu_group_set_timeout: 0 = the blocking waits of the runtime, else every host wait of a call polls against one deadline
+  uint32_t            timeout_ms = 0;
+  bool                dirty = false; // an earlier call gave up with work still queued on the members' streams
 };
 
 namespace {
@@ -151,6 +156,49 @@ int gfail(msgpu_group *g, int code, const char *fmt, ...) {
       return gfail((g), _e == hipErrorOutOfMemory ? MSGPU_E_NOMEM : MSGPU_E_HIP, "%s failed: %s (%s:%d)", #expr,       \
                    hipGetErrorString(_e), __FILE__, __LINE__);                                                         \
   } while (0)
+// the one deadline of a msgpu_group_overlap call
+struct Deadline {
+  bool                                  on = false;
+  std::chrono::steady_clock::time_point at{};
+  bool passed() const { return on && std::chrono::steady_clock::now() >= at; }
+};
+Deadline deadline_in(uint32_t ms) {
+  Deadline d;
+  d.on = ms != 0;
+  if (ms) d.at = std::chrono::steady_clock::now() + std::chrono::milliseconds(ms);
+  return d;
+}
+// hipStreamSynchronize / hipEventSynchronize that give up at the deadline (0 = done, 1 = deadline passed, else a HIP error)
+int wait_for(hipStream_t st, hipEvent_t ev, const Deadline &dl, hipError_t *err) {
+  *err = hipSuccess;
+  if (!dl.on) {
+    *err = ev ? hipEventSynchronize(ev) : hipStreamSynchronize(st);
+    return *err == hipSuccess ? 0 : 2;
+  }
+  for (uint32_t spins = 0;; ++spins) {
+    const hipError_t q = ev ? hipEventQuery(ev) : hipStreamQuery(st);
+    if (q == hipSuccess) return 0;
+    if (q != hipErrorNotReady) {
+      *err = q;
+      return 2;
+    }
+    if (dl.passed()) return 1;
+    if (spins < 2000) std::this_thread::yield();
+    else std::this_thread::sleep_for(std::chrono::microseconds(50));
+  }
+}
+#define GWAIT(g, st, ev, dl, what)                                                                                     \
+  do {                                                                                                                 \
+    hipError_t _e;                                                                                                     \
+    const int  _w = wait_for((st), (ev), (dl), &_e);                                                                   \
+    if (_w == 1) return gfail((g), MSGPU_E_TIMEOUT, "%s did not finish within %u ms (msgpu_group_set_timeout)", (what), (g)->timeout_ms); \
+    if (_w == 2) return gfail((g), MSGPU_E_HIP, "waiting for %s: %s (%s:%d)", (what), hipGetErrorString(_e), __FILE__, __LINE__);        \
+  } while (0)
+
+// test hook (MSGPU_GROUP_TEST_STALL_MS / _AT, read per call): a host function that sleeps on a member's stream -- what a
+// collective that does not complete looks like to everything queued behind it
+void stall_fn(void *ms) { std::this_thread::sleep_for(std::chrono::milliseconds(reinterpret_cast<uintptr_t>(ms))); }
+
 #define GNCCL(g, expr)                                                                                                 \
   do {                                                                                                                 \
     ncclResult_t _r = (expr);                                                                                          \
@@ -177,7 +225,16 @@ int msgpu_group_create(const int *devices, int n, const msgpu_params *params, ms
   }
   msgpu_group *g = new (std::nothrow) msgpu_group();
   if (!g) return MSGPU_E_NOMEM;
+  int caller_dev = -1;
+  if (hipGetDevice(&caller_dev) != hipSuccess) caller_dev = -1;
+  struct Restore { // the calling thread's current device is the caller's business
+    int d;
+    ~Restore() {
+      if (d >= 0) (void)hipSetDevice(d);
+    }
+  } restore{caller_dev};
   g->copy_transport = copy;
+  if (const char *to = getenv("MSGPU_GROUP_TIMEOUT_MS")) g->timeout_ms = static_cast<uint32_t>(strtoul(to, nullptr, 10));
   const char *rw    = getenv("MSGPU_GROUP_ROWS");
   g->replicate_rows = rw && strcmp(rw, "replicate") == 0;
   if (params)
@@ -243,12 +300,20 @@ int msgpu_group_device_tables(msgpu_group *g, int member, const void **d_edges, 
   return MSGPU_OK;
 }
 
-int msgpu_group_overlap(msgpu_group *g, const msgpu_row *rows, size_t n_rows, msgpu_group_tables *out) {
-  if (!g || !out) return MSGPU_E_ARG;
-  if (n_rows && !rows) return gfail(g, MSGPU_E_ARG, "Unexpected nullptr.");
+static int group_overlap_inner(msgpu_group *g, const msgpu_row *rows, size_t n_rows, msgpu_group_tables *out, const Deadline &dl) {
   const auto   t_start = std::chrono::steady_clock::now();
   const size_t n       = g->m.size();
-  memset(out, 0, sizeof(*out));
+  uint32_t     stall_ms = 0, stall_at = 0;
+  if (const char *sm = getenv("MSGPU_GROUP_TEST_STALL_MS")) stall_ms = static_cast<uint32_t>(strtoul(sm, nullptr, 10));
+  if (const char *sa = getenv("MSGPU_GROUP_TEST_STALL_AT")) stall_at = static_cast<uint32_t>(strtoul(sa, nullptr, 10));
+  auto stall = [&](uint32_t where) -> hipError_t { // on the LAST member's stream
+    if (!stall_ms || stall_at != where) return hipSuccess;
+    Member &mb = g->m[n - 1];
+    hipError_t e = hipSetDevice(mb.device);
+    if (e == hipSuccess)
+      e = hipLaunchHostFunc(static_cast<hipStream_t>(msgpu_get_stream(mb.ctx)), stall_fn, reinterpret_cast<void *>(static_cast<uintptr_t>(stall_ms)));
+    return e;
+  };
   Rccl *nc = g->copy_transport ? nullptr : rccl();
   if (nc && nc->why[0]) return gfail(g, MSGPU_E_HIP, "RCCL is not available: %s", nc->why);
   if (nc && !g->comms_ok) { // one communicator per member, all in this process
@@ -267,6 +332,7 @@ int msgpu_group_overlap(msgpu_group *g, const msgpu_row *rows, size_t n_rows, ms
   // per device) the other n - 1 times.  The index build of a member is stream-ordered behind its all-gather.
   const bool   sliced = n > 1 && !g->replicate_rows && n_rows >= 1024;
   const size_t per    = sliced ? (n_rows + n - 1) / n : 0;
+  GHIP(g, stall(0));
   if (sliced) {
     for (size_t i = 0; i < n; ++i) {
       Member &mb = g->m[i];
@@ -291,7 +357,7 @@ int msgpu_group_overlap(msgpu_group *g, const msgpu_row *rows, size_t n_rows, ms
     } else { // rehearsal transport: every slice has landed, then member i fetches the other n - 1
       for (size_t i = 0; i < n; ++i) {
         GHIP(g, hipSetDevice(g->m[i].device));
-        GHIP(g, hipStreamSynchronize(static_cast<hipStream_t>(msgpu_get_stream(g->m[i].ctx))));
+        GWAIT(g, static_cast<hipStream_t>(msgpu_get_stream(g->m[i].ctx)), nullptr, dl, "a member's slice of the rows");
       }
       for (size_t i = 0; i < n; ++i) {
         Member &mb = g->m[i];
@@ -332,6 +398,7 @@ int msgpu_group_overlap(msgpu_group *g, const msgpu_row *rows, size_t n_rows, ms
   for (size_t i = 0; i < n; ++i)
     if (g->m[i].rc != MSGPU_OK) return gfail(g, g->m[i].rc, "%s", g->m[i].err);
 
+  GHIP(g, stall(1));
   // ---- the one exchange: wire-form slabs, one grouped all-gather, the merge on every device ---------------------------
   std::vector<uint64_t> counts(3 * n);
   uint64_t              mx[3] = {0, 0, 0}, tot[3] = {0, 0, 0}, n_ems = 0;
@@ -395,7 +462,7 @@ int msgpu_group_overlap(msgpu_group *g, const msgpu_row *rows, size_t n_rows, ms
   } else { // rehearsal transport: every slab is complete (its stream drained), then member i copies all n slabs
     for (size_t i = 0; i < n; ++i) {
       GHIP(g, hipSetDevice(g->m[i].device));
-      GHIP(g, hipStreamSynchronize(static_cast<hipStream_t>(msgpu_get_stream(g->m[i].ctx))));
+      GWAIT(g, static_cast<hipStream_t>(msgpu_get_stream(g->m[i].ctx)), nullptr, dl, "a member's slab");
     }
     for (size_t i = 0; i < n; ++i) {
       Member &mb = g->m[i];
@@ -428,7 +495,7 @@ int msgpu_group_overlap(msgpu_group *g, const msgpu_row *rows, size_t n_rows, ms
       const char *hs = static_cast<const char *>(mb.h_slab.p);
       GHIP(g, hipSetDevice(mb.device));
       for (int part = 0; part < 3; ++part) {
-        GHIP(g, hipEventSynchronize(mb.ev_out[part]));
+        GWAIT(g, nullptr, mb.ev_out[part], dl, "a member's slab on its way to the host");
         if (int rc = msgpu_unpack_wire_host(hs + off_e, hs + off_o, hs + off_i, id_bytes, counts[3 * i], counts[3 * i + 1], counts[3 * i + 2], base,
                                             static_cast<msgpu_edge *>(g->h_edges.p) + base[0], static_cast<msgpu_order *>(g->h_orders.p) + base[2],
                                             static_cast<uint32_t *>(g->h_ids.p) + base[3], 16, 1u << part))
@@ -443,7 +510,7 @@ int msgpu_group_overlap(msgpu_group *g, const msgpu_row *rows, size_t n_rows, ms
   for (size_t i = 0; i < n; ++i) { // the phase barrier: every member's stream has drained
     Member &mb = g->m[i];
     GHIP(g, hipSetDevice(mb.device));
-    GHIP(g, hipStreamSynchronize(static_cast<hipStream_t>(msgpu_get_stream(mb.ctx))));
+    GWAIT(g, static_cast<hipStream_t>(msgpu_get_stream(mb.ctx)), nullptr, dl, "the exchange (all-gather + merge) on a member's stream");
     float ms = 0;
     GHIP(g, hipEventElapsedTime(&ms, mb.ev0, mb.ev1));
     exchange_ms = std::max(exchange_ms, ms);
@@ -470,6 +537,64 @@ int msgpu_group_overlap(msgpu_group *g, const msgpu_row *rows, size_t n_rows, ms
   out->wall_ms     = static_cast<float>(std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count());
   g->err[0]        = 0;
   return MSGPU_OK;
+}
+
+// every member's stream and copy-out stream has drained (true), or the deadline passed first / a wait failed (false)
+static bool drain_members(msgpu_group *g, const Deadline &dl) {
+  bool ok = true;
+  for (Member &mb : g->m) {
+    if (hipSetDevice(mb.device) != hipSuccess) {
+      ok = false;
+      continue;
+    }
+    hipError_t e;
+    if (mb.ctx && wait_for(static_cast<hipStream_t>(msgpu_get_stream(mb.ctx)), nullptr, dl, &e) != 0) ok = false;
+    if (mb.out_stream && wait_for(mb.out_stream, nullptr, dl, &e) != 0) ok = false;
+  }
+  (void)hipGetLastError();
+  return ok;
+}
+
+int msgpu_group_set_timeout(msgpu_group *g, uint32_t timeout_ms) {
+  if (!g) return MSGPU_E_ARG;
+  g->timeout_ms = timeout_ms;
+  return MSGPU_OK;
+}
+
+int msgpu_group_overlap(msgpu_group *g, const msgpu_row *rows, size_t n_rows, msgpu_group_tables *out) {
+  if (!g || !out) return MSGPU_E_ARG;
+  memset(out, 0, sizeof(*out));
+  if (n_rows && !rows) return gfail(g, MSGPU_E_ARG, "Unexpected nullptr.");
+  int caller_dev = -1;
+  if (hipGetDevice(&caller_dev) != hipSuccess) caller_dev = -1;
+  const Deadline dl = deadline_in(g->timeout_ms);
+  for (Member &mb : g->m) (void)msgpu_set_deadline(mb.ctx, g->timeout_ms); // the members' own waits (table sizes) share it
+  int rc = MSGPU_OK;
+  if (g->dirty) { // an earlier call gave up with work still queued: it has to be gone before buffers are written again
+    g->dirty = !drain_members(g, dl);
+    if (g->dirty) rc = gfail(g, MSGPU_E_TIMEOUT, "the members' streams still hold work of an earlier call that timed out");
+  }
+  if (rc == MSGPU_OK) rc = group_overlap_inner(g, rows, n_rows, out, dl);
+  if (rc != MSGPU_OK) {
+    // No early return leaves work behind that reads the caller's rows or writes the group's host tables: abort what can hang
+    // (a timed-out collective), then wait for everything the call queued -- for ever without a timeout, else once more as long.
+    memset(out, 0, sizeof(*out));
+    Rccl *nc = g->copy_transport ? nullptr : rccl();
+    if (rc == MSGPU_E_TIMEOUT && nc && g->comms_ok) {
+      for (Member &mb : g->m) {
+        if (mb.comm && nc->CommAbort) (void)nc->CommAbort(mb.comm);
+        mb.comm = nullptr;
+      }
+      g->comms_ok = false; // the next call builds fresh communicators
+    }
+    g->dirty = !drain_members(g, deadline_in(g->timeout_ms));
+    const size_t len = strlen(g->err);
+    snprintf(g->err + len, sizeof(g->err) - len, "%s", g->dirty ? "; the members' streams have NOT drained: keep `rows` alive until the next call or msgpu_group_destroy"
+                                                                : "; everything the call queued has finished");
+  }
+  for (Member &mb : g->m) (void)msgpu_set_deadline(mb.ctx, 0);
+  if (caller_dev >= 0) (void)hipSetDevice(caller_dev);
+  return rc;
 }
 
 } // extern "C"

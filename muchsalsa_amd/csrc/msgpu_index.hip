@@ -5,7 +5,7 @@
 // Why (tools/micro/index_limits.hip, MI355X, the 5.06 M rows of BASELINE.json configs[2]): a global atomic on a counter
 // chosen by the row's read id -- read ids are unrelated to the row's place in the file -- runs at 24 G atomics/s whether it
 // returns a value or not (every lane of a wave instruction is a memory-side request of its own): 206 us, which was
-// k_index_pass1's 220 us through round 3.  Here a 4096-row tile is binned by COARSE bucket (16 consecutive read ids) with
+// k_index_pass1's 220 us through round 3.  Here a 2048-row tile (BIN_TILE) is binned by COARSE bucket (16 consecutive read ids) with
 // LDS atomics, the tile's rows of a bucket are reserved with ONE global atomic per (tile, bucket) on adjacent counters (a
 // wave instruction covers 64 neighbouring counters: merged requests), and a workgroup per bucket stages its ~10^3 rows in
 // LDS -- read once, coalesced -- grouped by read, then ranks every read's rows in registers as k_sort_read does (rank by
@@ -571,6 +571,20 @@ uint32_t bin_capacity(uint64_t n, uint32_t V) {
   if (cap * BIN_LDS_PER_ROW > (96u << 10) || cap * std::min<uint64_t>(n_buckets, BIN_NB_MAX) >= 0xffffffffull) return 0;
   return static_cast<uint32_t>(cap);
 }
+// Can k_index_sort_bin be launched with buckets of `cap` rows on the CURRENT device?  More than 64 KB of dynamic LDS needs
+// the function attribute -- per device (a group drives several devices from one process), so it is asked for by every build
+// that needs it, BEFORE anything of the bin path is launched: a device (or a runtime) that refuses sends the build down the
+// atomic path, which covers every input, instead of into a launch that fails.
+bool index_sort_bin_prepare(uint32_t cap) {
+  const size_t lds = static_cast<size_t>(cap) * BIN_LDS_PER_ROW;
+  if (lds > (96u << 10)) return false;
+  if (lds <= (64u << 10)) return true;
+  if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_index_sort_bin), hipFuncAttributeMaxDynamicSharedMemorySize, 96 << 10) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  return true;
+}
 void launch_index_bin(hipStream_t st, const msgpu_row *rows, uint64_t n, uint32_t V, uint32_t A, uint32_t *flags, uint32_t *err,
                       uint32_t *anchor_first, uint32_t *cursor, uint4 *bin_rec, uint32_t rd_lo, uint32_t nb, uint32_t cap,
                       uint32_t *bin_start, uint32_t *row_base, uint32_t *read_off_end, bool check_anchors) {
@@ -586,11 +600,7 @@ void launch_index_sort_bin(hipStream_t st, const uint32_t *cursor, const uint32_
                            uint32_t *read_cnt, int32_t *read_len, uint32_t *read_first, uint32_t *visits, const msgpu_row *rows,
                            uint32_t *flags, uint32_t *err) {
   if (!nb) return;
-  const size_t lds = static_cast<size_t>(cap) * BIN_LDS_PER_ROW;
-  // more than 64 KB of dynamic LDS needs the attribute -- on the device the launch goes to (a group drives several devices
-  // from one process), so it is set with the launch that needs it rather than once
-  if (lds > (64u << 10))
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_index_sort_bin), hipFuncAttributeMaxDynamicSharedMemorySize, 96 << 10);
+  const size_t lds = static_cast<size_t>(cap) * BIN_LDS_PER_ROW; // (granted by index_sort_bin_prepare, which the host asks first)
   hipLaunchKernelGGL(k_index_sort_bin, dim3(nb), dim3(BIN_SORT_NT), lds, st, cursor, bin_start, V,
                      rd_lo, cap, bin_rec, by_read, by_anchor, vis, read_off, read_cnt, read_len, read_first, visits, rows, flags, err);
 }

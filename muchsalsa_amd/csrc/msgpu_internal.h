@@ -145,6 +145,7 @@ constexpr uint32_t BIN_NB_MAX    = 8192; // coarse buckets per pass (k_index_bin
 constexpr uint32_t BIN_RPB_SHIFT = 4;    // 16 read ids per coarse bucket
 constexpr uint32_t BIN_PASSES_MAX = 8;   // passes over the row table (BIN_NB_MAX * 16 = 131,072 reads each); more reads: the atomic path
 uint32_t bin_capacity(uint64_t n, uint32_t V); // rows a coarse bucket can hold; 0 = the bin path does not apply
+bool index_sort_bin_prepare(uint32_t cap);   // k_index_sort_bin can be launched with such buckets on the current device (asks for > 64 KB of LDS where needed)
 void launch_index_bin(hipStream_t st, const msgpu_row *rows, uint64_t n, uint32_t V, uint32_t A, uint32_t *flags, uint32_t *err,
                       uint32_t *anchor_first, uint32_t *cursor, uint4 *bin_rec, uint32_t rd_lo, uint32_t nb, uint32_t cap,
                       uint32_t *bin_start, uint32_t *row_base, uint32_t *read_off_end, bool check_anchors);

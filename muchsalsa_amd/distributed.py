@@ -567,6 +567,9 @@ class PipelinedExchange:
 
     def close(self):
         if self._thread is not None:
+            # a batch still held at its gate (close() without drain(): the caller's step raised) goes now -- the gate is a
+            # scheduling hint, and a communication thread looping in gate_wait would never reach the None behind its batch
+            self._gates_open = True
             self._queue.put(None)
             self._thread.join()
             self._thread = None

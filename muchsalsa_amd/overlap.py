@@ -178,7 +178,10 @@ class OverlapContext:
 
     def wait_chain_launch(self, count, timeout_us=1000):
         """block until chain_launches() >= count -> True, or the timeout has passed -> False (any thread; the GIL is released)"""
-        return self._L.msgpu_wait_chain_launch(self._h, int(count), int(timeout_us)) == 0
+        h = self._h
+        if not h:  # a closed context holds nothing back: the gate is open
+            return True
+        return self._L.msgpu_wait_chain_launch(h, int(count), int(timeout_us)) == 0
 
     def set_id_space(self, n_reads, n_anchors):
         """Declare the id counts the loader already knows (Registry sizes); (0, 0) = let the index build find them."""
@@ -352,6 +355,12 @@ class OverlapGroup:
 
     def __exit__(self, *exc):
         self.close()
+
+    def set_timeout(self, timeout_ms):
+        """msgpu_group_set_timeout: overlap() gives up (MsgpuError, code MSGPU_E_TIMEOUT) that long after its entry; 0 = never"""
+        rc = self._L.msgpu_group_set_timeout(self._h, int(timeout_ms))
+        if rc != 0:
+            raise MsgpuError(rc)
 
     def overlap(self, rows, copy=True):
         arr = rows.array if isinstance(rows, PinnedRows) else np.ascontiguousarray(rows, dtype=ROW_DTYPE)

@@ -54,6 +54,44 @@ def test_every_sort_path_of_the_index(oracle, n_anchors, lo, hi):
     assert_tables_equal(_gpu_tables(allrows), want, "shuffled with duplicates")
 
 
+def test_bin_path_ranks_reads_with_equal_nanopore_ranges(oracle):
+    """Regression shape for round 4's 02:15 abort (profiles/r5_01/README.md): dense reads of 50..130 rows ON THE BIN PATH -- the
+    wavefront-wide bitonic ranking of k_index_sort_bin (one row per lane) and the two-rows-per-lane broadcast ranking -- with
+    rows of one read that share their nanopore range, so that the anchor id decides (mpp.cpp:164-172) and the sort network's
+    equal-neighbour test must send the read to the broadcast loop.  The dense shape of test_dense_inputs_take_the_big_paths
+    itself (200x coverage) leaves the bin path at pass 1 (scaffolds of 400 rows): its index path is asserted here too."""
+    from muchsalsa_amd import _lib, overlap, synth
+
+    def run(rows):
+        with overlap.OverlapContext(0) as ctx:
+            ctx.load_rows(rows)
+            ctx.calculate_edges()
+            ctx.chaining_and_overlaps()
+            return ctx.tables(), int(ctx.counts().index_path)
+
+    rows = synth.accepted_rows(synth.paf_table(400, 4000, 400, 6, coverage=60))[0].copy()  # reads of 52..78 rows
+    per_read = np.bincount(rows["read_id"])
+    assert per_read.max() > 64 and (per_read <= 64).sum() > 50 and np.bincount(rows["anchor_id"]).max() < 128, (per_read.min(), per_read.max())
+    # ties: in every third read, the second row (in file order) takes the first row's nanopore range
+    order = np.argsort(rows["read_id"], kind="stable")
+    starts = np.concatenate([[0], np.cumsum(per_read)[:-1]])
+    n_ties = 0
+    for r in range(0, len(per_read), 3):
+        if per_read[r] >= 2:
+            a, b = order[starts[r]], order[starts[r] + 1]
+            rows["n_lo"][b], rows["n_hi"][b] = rows["n_lo"][a], rows["n_hi"][a]
+            n_ties += 1
+    assert n_ties > 100
+    want = oracle.overlap(rows)
+    got, path = run(rows)
+    assert path == _lib.INDEX_BIN, path
+    assert_tables_equal(got, want, "bin path, equal nanopore ranges inside a read")
+    dense = synth.accepted_rows(synth.paf_table(400, 4000, 120, 6, coverage=200))[0]
+    got, path = run(dense)
+    assert (path & 3) != _lib.INDEX_BIN, path  # scaffolds beyond pass 1's context: the atomic path
+    assert_tables_equal(got, oracle.overlap(dense), "dense shape of the round-4 abort")
+
+
 @pytest.mark.parametrize("coverage,n_anchors", [(40, 400), (85, 60), (95, 60), (300, 40)])
 def test_scaffold_lengths_around_the_pass1_context(oracle, coverage, n_anchors):
     """Scaffolds are kept in read-id order.  With the input grouped by anchor, k_index_pass1 places every row inside its
@@ -610,12 +648,15 @@ def test_bench_distributed_path_smoke():
     assert line["consensus"]["verified_against_genome"] is True
     assert line["rccl_ranks"] == 1 and line["rank_ms_per_step"]["min"] > 0
     assert line["exchange"]["collectives_per_step"] < 1.5  # the slab all-gather alone once the capacity is agreed
-    # the default N > 1 line: weak scaling (the exchange one step behind the compute, on its own stream), with the strong
-    # (one job sharded by v1 % N) and the rank-sharded host-to-host figures beside it
-    assert line["scaling"] == "weak" and line["exchange"]["regrows"] == 0
-    assert line["exchange"]["format"].startswith("wire") and line["exchange"]["slab_bytes"] < 0.7 * line["exchange"]["whole_record_slab_bytes"]
-    assert line["strong"]["merged_edge_list_consistent"] is True and line["strong"]["value"] > 0
-    assert line["strong"]["edges"] == line["config"]["edges"]
+    # the default N > 1 line: STRONG scaling (BASELINE.json configs[3]: the one job sharded by v1 % N) is `value`; the weak
+    # figure (N partitions, the exchange one step behind the compute on its own stream) and the rank-sharded host-to-host
+    # figure stand beside it
+    assert line["scaling"] == "strong" and line["exchange"]["regrows"] == 0 and "strong" not in line
+    wk = line["weak"]
+    assert wk["scaling"] == "weak" and wk["exchange"]["regrows"] == 0 and wk["exchange"]["collectives_per_step"] < 1.5
+    assert wk["exchange"]["format"].startswith("wire") and wk["exchange"]["slab_bytes"] < 0.7 * wk["exchange"]["whole_record_slab_bytes"]
+    assert wk["merged_edge_list_consistent"] is True and wk["value"] > 0
+    assert wk["edges"] == line["config"]["edges"]  # (world 1: one partition = the job)
     assert line["host_to_host_sharded"]["edges"] == line["config"]["edges"] and line["host_to_host_sharded"]["ms"] > 0
     # ... and, once the ranks have left their process group, msgpu_group_overlap over the node's devices in a child process
     assert "error" not in line["group_on_node"] and line["group_on_node"]["members"] == 1 and line["group_on_node"]["transport"] == "rccl"
@@ -645,14 +686,15 @@ def test_bench_two_and_three_ranks_rehearsal():
                              env=env, capture_output=True, text=True, timeout=300)
         assert out.returncode == 0, out.stderr[-2000:]
         line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
-        assert line["n_gpus"] == n and line["scaling"] == "weak" and "rehearsal" in line and line["rccl_ranks"] is None
+        assert line["n_gpus"] == n and line["scaling"] == "strong" and "rehearsal" in line and line["rccl_ranks"] is None
         assert line["config"]["merged_edge_list_consistent"] is True and line["exchange"]["regrows"] == 0
         assert len(line["rank_ms_per_step"]["per_rank"]) == n
-        s, h = line["strong"], line["host_to_host_sharded"]
-        assert s["merged_edge_list_consistent"] is True and s["edges"] == h["edges"] > 0
-        single = single or s["edges"]
-        assert s["edges"] == single                      # the ONE job has the same edges however many ranks share it
-        assert line["config"]["edges"] > (n - 1) * single  # n partitions of that shape
+        wk, h = line["weak"], line["host_to_host_sharded"]
+        assert wk["merged_edge_list_consistent"] is True and wk["exchange"]["regrows"] == 0
+        assert line["config"]["edges"] == h["edges"] > 0
+        single = single or line["config"]["edges"]
+        assert line["config"]["edges"] == single   # the ONE job has the same edges however many ranks share it
+        assert wk["edges"] > (n - 1) * single      # n partitions of that shape
 
 
 def test_bench_group_on_node_child_process():
@@ -769,6 +811,45 @@ def test_group_of_several_members_rehearsed_on_one_gpu(oracle, monkeypatch, memb
     monkeypatch.delenv("MSGPU_GROUP_TRANSPORT")
     with pytest.raises(overlap.MsgpuError):
         overlap.OverlapGroup([0, 0])  # without the rehearsal transport: one member per device
+
+
+@pytest.mark.parametrize("stall_at", [0, 1])
+def test_group_deadline_on_a_stalled_stream(oracle, monkeypatch, stall_at):
+    """msgpu_group_set_timeout: a member's stream that stops draining (the test hook queues a sleeping host function on the last
+    member's stream -- in front of the row exchange, stall_at 0, or in front of the slab exchange, stall_at 1: what a collective
+    that never completes looks like to everything behind it) must end the call with MSGPU_E_TIMEOUT instead of holding the
+    caller; the group is usable again once the stream has moved on, with the same tables as before.  Rehearsal transport, two
+    members on the one GPU.  The reference's error model: one catch at src/main.cpp:313-315."""
+    import time
+    from muchsalsa_amd import _lib, overlap, synth
+    monkeypatch.setenv("MSGPU_GROUP_TRANSPORT", "copy")
+    # page-locked rows, as msgpu_parse_paf hands them over: a copy out of pageable memory is staged by the calling thread
+    # and would itself wait behind the stalled stream
+    rows = overlap.PinnedRows(synth.synth_rows(1000, 5000, 4000, 13))
+    with overlap.OverlapGroup([0, 0]) as grp:
+        good, _ = grp.overlap(rows)  # (buffers, first-call allocations)
+        grp.set_timeout(250)
+        monkeypatch.setenv("MSGPU_GROUP_TEST_STALL_MS", "1500")
+        monkeypatch.setenv("MSGPU_GROUP_TEST_STALL_AT", str(stall_at))
+        t0 = time.perf_counter()
+        with pytest.raises(overlap.MsgpuError) as info:
+            grp.overlap(rows)
+        dt = time.perf_counter() - t0
+        assert info.value.code == _lib.E_TIMEOUT, str(info.value)
+        assert "NOT drained" in str(info.value)  # (the stall outlasts deadline + grace: the text says what is still queued)
+        assert dt < 1.2, dt                       # 250 ms + 250 ms of grace, not the 1.5 s of the stall
+        monkeypatch.delenv("MSGPU_GROUP_TEST_STALL_MS")
+        # while the stall lasts the next call gives up as well (its first act is to drain what the last one left) ...
+        with pytest.raises(overlap.MsgpuError) as info2:
+            grp.overlap(rows)
+        assert info2.value.code == _lib.E_TIMEOUT
+        # ... and once the stream has moved on the group works again, without a timeout in its way
+        time.sleep(1.6)
+        grp.set_timeout(0)
+        again, _ = grp.overlap(rows)
+        for k in ("edges", "orders", "ids"):
+            assert again[k].tobytes() == good[k].tobytes(), k
+    rows.close()
 
 
 def test_pipelined_exchange_threaded_regrow_world1():
