@@ -258,7 +258,7 @@ struct msgpu_ctx {
       scan_tmp, vis16, spos2, visits, bin_cursor, bin_start;
   DevBuf bound, cand_off, cand_j, cand_t, scr_v2, scr_start, n_cand, n_edge, n_visit_arr, lists, em_base, edge_base,
       visit_base, edges, edge_cand;
-  DevBuf big_key, big_t, big_r2s, big_pfx, pair_tab, edge_fast, big_off;
+  DevBuf big_key, big_t, big_r2s, big_pfx, pair_tab, chain_chunks, big_off;
   hipStream_t side_stream = nullptr, side_stream2 = nullptr;
   hipEvent_t  ev_side[2]  = {nullptr, nullptr}, ev_side2 = nullptr;
   uint64_t    n_big_edges = 0, n_big_ems = 0;
@@ -412,7 +412,7 @@ void release_all(msgpu_ctx *c) {
                    &c->bkt2_idx, &c->bkt2_line, &c->by_anchor, &c->read_len, &c->read_first, &c->scalars, &c->scan_tmp,
                    &c->bound, &c->cand_off, &c->cand_j, &c->cand_t, &c->scr_v2, &c->scr_start, &c->n_cand, &c->n_edge,
                    &c->n_visit_arr, &c->lists, &c->em_base, &c->edge_base, &c->visit_base, &c->edges, &c->edge_cand,
-                   &c->big_key, &c->big_t, &c->big_r2s, &c->big_pfx, &c->pair_tab, &c->edge_fast, &c->big_off, &c->ems, &c->order_scr, &c->ids_scr,
+                   &c->big_key, &c->big_t, &c->big_r2s, &c->big_pfx, &c->pair_tab, &c->chain_chunks, &c->big_off, &c->ems, &c->order_scr, &c->ids_scr,
                    &c->edge_norders, &c->edge_nids, &c->order_base, &c->ids_base, &c->orders, &c->ids, &c->big_list, &c->cls_list, &c->cls_part, &c->cls_partials,
                    &c->big_elems, &c->big_paths, &c->alt_edges, &c->alt_ems, &c->alt_orders, &c->alt_ids, &c->vis16, &c->visits,
                    &c->spos2, &c->bin_cursor, &c->bin_start, &c->wire_dev[0], &c->wire_dev[1], &c->win_cuts};
@@ -863,19 +863,8 @@ int msgpu_load_rows_device(msgpu_ctx *c, const void *d_rows, size_t n_rows) {
   return build_index(c);
 }
 
-// the per-edge counters of the chain stage (orders, ids, shortcut flag per edge), zeroed in one launch
-static int zero_chain_counters(msgpu_ctx *c, uint64_t E) {
-  ENSURE(c, edge_norders, (E + 1) * 4);
-  ENSURE(c, edge_nids, (E + 1) * 4);
-  ENSURE(c, edge_fast, (E + 1) * 4);
-  uint32_t *const zero[4]   = {c->edge_norders.as<uint32_t>(), c->edge_nids.as<uint32_t>(), c->edge_fast.as<uint32_t>(), nullptr};
-  const uint32_t  n_zero[4] = {static_cast<uint32_t>(E + 1), static_cast<uint32_t>(E + 1), static_cast<uint32_t>(E + 1), 0};
-  uint32_t *const ones[2]   = {nullptr, nullptr};
-  const uint32_t  n_ones[2] = {0, 0};
-  launch_index_init(c->stream, zero, n_zero, ones, n_ones);
-  HIPCHK(c, hipGetLastError());
-  return MSGPU_OK;
-}
+// words of the chain stage's chunk sums (two 64-bit words per chunk of COMPACT_CHUNK edges) for a table of up to n edges
+static size_t chunk_words(uint64_t n_edges) { return 2 * static_cast<size_t>(n_edges / COMPACT_CHUNK + 2); }
 
 int msgpu_calculate_edges(msgpu_ctx *c) {
   if (!c) return MSGPU_E_ARG;
@@ -1020,9 +1009,11 @@ int msgpu_calculate_edges(msgpu_ctx *c) {
                       cap_edges, cap_big, scalar<unsigned long long>(c, SC_BIGSTATS));
     // width classes of the chain kernels: <= 16 and 17..32 EdgeMatches share a wavefront four / two at a time, 33..64
     // take one each; the edges are listed by size, largest first
+    // (its second kernel also zeroes the chunk sums the chain kernels add to: no launch of its own for that)
     if (c->sub_wave)
       launch_sort_edges_by_size(st, c->edges.as<msgpu_edge>(), c->edge_base.as<uint64_t>() + V, cap_edges,
-                                c->cls_part.as<uint32_t>(), c->cls_list.as<uint32_t>(), scalar<uint32_t>(c, SC_CLS));
+                                c->cls_part.as<uint32_t>(), c->cls_list.as<uint32_t>(), scalar<uint32_t>(c, SC_CLS),
+                                c->chain_chunks.as<unsigned long long>(), static_cast<uint32_t>(chunk_words(cap_edges)));
   };
   auto capacities = [&](uint64_t *cap_edges, uint64_t *cap_big) {
     uint64_t ce = c->edges.room() / sizeof(msgpu_edge);
@@ -1030,6 +1021,7 @@ int msgpu_calculate_edges(msgpu_ctx *c) {
     if (c->sub_wave && c->cls_list.cap / 4 < ce) ce = c->cls_list.cap / 4;
     uint64_t cb = c->big_list.cap / 4;
     if (c->big_off.cap / 8 < cb) cb = c->big_off.cap / 8;
+    if (c->chain_chunks.cap / 8 < chunk_words(ce)) ce = 0; // (sized with the edge table below: never the limit once both exist)
     *cap_edges = ce;
     *cap_big   = cb;
   };
@@ -1054,13 +1046,12 @@ int msgpu_calculate_edges(msgpu_ctx *c) {
     // the edges with more than 64 EdgeMatches (counted by the candidate kernels) are listed as they are emitted
     ENSURE(c, big_list, (c->n_big_edges + 1) * 4);
     ENSURE(c, big_off, (c->n_big_edges + 1) * 8);
+    ENSURE(c, chain_chunks, chunk_words(c->edges.room() / sizeof(msgpu_edge)) * 8);
     capacities(&cap_edges, &cap_big);
     emit_and_sort(cap_edges, cap_big);
   }
-  // the chain stage's per-edge counters are zeroed here, behind the size sort: msgpu_chaining_and_overlaps then starts
-  // with its kernels
-  if (int rc = zero_chain_counters(c, c->n_edges)) return rc;
-  c->chain_zeroed = true;
+  // the chain stage's chunk sums were zeroed by the size sort: msgpu_chaining_and_overlaps starts with its kernels
+  c->chain_zeroed = c->sub_wave;
   HIPCHK(c, hipGetLastError());
   if (c->stage_events) HIPCHK(c, hipEventRecord(c->ev[3], st));
   c->have_cand_t = c->stage_events;
@@ -1085,12 +1076,9 @@ int msgpu_chaining_and_overlaps(msgpu_ctx *c) {
   ENSURE(c, ems, (M ? M : 1) * sizeof(msgpu_edgematch));
   ENSURE(c, order_scr, (M ? M : 1) * sizeof(msgpu_order));
   ENSURE(c, ids_scr, (M ? M : 1) * 4);
-  ENSURE(c, edge_norders, (E + 1) * 4);
-  ENSURE(c, edge_nids, (E + 1) * 4);
-  ENSURE(c, order_base, (E + 2) * 8);
-  ENSURE(c, ids_base, (E + 2) * 8);
-  ENSURE(c, visit_base, (E + 2) * 8); // re-used as the scan output of the per-edge shortcut flags
-  ENSURE(c, scan_tmp, 3 * (size_t(scan_blocks(E > c->V ? E : c->V)) + 1) * 8);
+  ENSURE(c, edge_norders, (E + 4) * 4);
+  ENSURE(c, edge_nids, (E + 4) * 4);
+  ENSURE(c, chain_chunks, chunk_words(E) * 8);
 
   ChainArgs a;
   a.edges        = c->edges.as<msgpu_edge>();
@@ -1116,11 +1104,10 @@ int msgpu_chaining_and_overlaps(msgpu_ctx *c) {
   a.pair_tab     = c->pair_tab.as<uint32_t>();
   a.pair_tab64   = c->pair_tab.as<uint32_t>() + 4 * PAIR_TAB_STRIDE;
   a.pair_tab_sub = c->pair_tab.as<uint32_t>() + 4 * PAIR_TAB_STRIDE + 2 * PAIR_TAB_STRIDE;
-  ENSURE(c, edge_fast, (E + 1) * 4);
-  if (!c->chain_zeroed) // (msgpu_calculate_edges left the per-edge counters zeroed; a second chaining pass zeroes them here)
-    if (int rc = zero_chain_counters(c, E)) return rc;
+  if (!c->chain_zeroed) // (msgpu_calculate_edges' size sort left the chunk sums zeroed; a second chaining pass, or a run without the sort, zeroes them here)
+    HIPCHK(c, hipMemsetAsync(c->chain_chunks.p, 0, chunk_words(E) * 8, st));
   c->chain_zeroed = false;
-  a.edge_fast    = c->edge_fast.as<uint32_t>();
+  a.chunk_sums   = c->chain_chunks.as<unsigned long long>();
   a.fast_path    = c->fast_path ? 1 : 0;
   a.wiggle       = static_cast<double>(c->p.wiggle_room);
   a.ratio_pct    = c->p.ratio_pct;
@@ -1168,23 +1155,28 @@ int msgpu_chaining_and_overlaps(msgpu_ctx *c) {
   HIPCHK(c, hipGetLastError());
   if (n_big) HIPCHK(c, hipStreamWaitEvent(st, c->ev_side[1], 0));
 
-  {
-    const uint32_t *const in[3]  = {c->edge_norders.as<uint32_t>(), c->edge_nids.as<uint32_t>(), c->edge_fast.as<uint32_t>()};
-    uint64_t *const       out[3] = {c->order_base.as<uint64_t>(), c->ids_base.as<uint64_t>(), c->visit_base.as<uint64_t>()};
-    uint64_t *const       tot[3] = {scalar<uint64_t>(c, SC_TOTAL_A), scalar<uint64_t>(c, SC_TOTAL_B), scalar<uint64_t>(c, SC_TOTAL_C)};
-    exclusive_scan_set(st, 3, in, E, out, c->scan_tmp.as<uint64_t>(), tot);
-  }
   if (c->stage_events) HIPCHK(c, hipEventRecord(c->ev[7], st));
-  if (int rc = publish_scalars(c)) return rc; // sizes of the order / id tables
-  // the compaction is enqueued behind the publication, into what the two tables hold from earlier calls (see
-  // msgpu_calculate_edges): the GPU is busy while the host turns around
-  auto compact = [&]() {
+  // ONE launch closes the stage: k_compact sums the chunk sums the chain kernels left (the scan), its first workgroup writes the
+  // table sizes into the scalar block and publishes it to the host, and the move into the dense tables follows in the same
+  // kernel -- into what the two tables hold from earlier calls (see msgpu_calculate_edges): the GPU is busy while the host
+  // turns around; if the tables turn out too small the kernel has written nothing and is launched again behind the allocation.
+  static const bool sync_path = getenv("MSGPU_SYNC_READBACK") != nullptr;
+  c->readback_polled = !sync_path && c->h_scalars_dev;
+  auto compact = [&](bool publish) {
     CompactArgs k;
     k.edges        = c->edges.as<msgpu_edge>();
     k.n_edges      = E;
     k.edge_norders = c->edge_norders.as<uint32_t>();
-    k.order_base   = c->order_base.as<uint64_t>();
-    k.ids_base     = c->ids_base.as<uint64_t>();
+    k.edge_nids    = c->edge_nids.as<uint32_t>();
+    k.chunk_sums   = c->chain_chunks.as<unsigned long long>();
+    k.n_chunks     = static_cast<uint32_t>((E + COMPACT_CHUNK - 1) / COMPACT_CHUNK);
+    k.scalars      = c->scalars.as<uint64_t>();
+    k.host_scalars = (publish && c->readback_polled) ? c->h_scalars_dev : nullptr;
+    k.slot_orders  = SC_TOTAL_A;
+    k.slot_ids     = SC_TOTAL_B;
+    k.slot_fast    = SC_TOTAL_C;
+    k.n_scalars    = SC_COUNT;
+    k.seq          = (publish && c->readback_polled) ? ++c->readback_seq : 0;
     k.order_scr    = c->order_scr.as<msgpu_order>();
     k.ids_scr      = c->ids_scr.as<uint32_t>();
     k.orders       = c->orders.as<msgpu_order>();
@@ -1198,18 +1190,21 @@ int msgpu_chaining_and_overlaps(msgpu_ctx *c) {
     launch_compact(st, k);
   };
   const uint64_t cap_orders = c->orders.room() / sizeof(msgpu_order), cap_ids = c->ids.room() / 4;
-  const bool     speculated = cap_orders != 0 && cap_ids != 0;
-  if (speculated) compact();
+  compact(true);
   HIPCHK(c, hipGetLastError());
+  if (!c->readback_polled) { // the synchronising read-back path (MSGPU_SYNC_READBACK=1, or no mapped mirror): a copy behind the kernel
+    HIPCHK(c, hipMemcpyAsync(c->h_scalars, c->scalars.p, SC_COUNT * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipEventRecord(c->ev_readback, st));
+  }
   if (int rc = wait_scalars(c)) return rc;
   c->n_edges_fast     = *host_scalar<uint64_t>(c, SC_TOTAL_C);
   const uint64_t *tot = host_scalar<uint64_t>(c, SC_TOTAL_A);
   c->n_orders = tot[0];
   c->n_ids    = tot[1];
-  if (!speculated || c->n_orders > cap_orders || c->n_ids > cap_ids) { // (the kernel's own test)
+  if (c->n_orders > cap_orders || c->n_ids > cap_ids) { // (the kernel's own test)
     ENSURE(c, orders, (c->n_orders ? c->n_orders : 1) * sizeof(msgpu_order));
     ENSURE(c, ids, (c->n_ids ? c->n_ids : 1) * 4);
-    compact();
+    compact(false);
   }
   HIPCHK(c, hipGetLastError());
   if (c->stage_events) HIPCHK(c, hipEventRecord(c->ev[8], st));

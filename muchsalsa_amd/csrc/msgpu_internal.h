@@ -58,17 +58,24 @@ struct ChainArgs {
   const uint32_t  *pair_tab; // four tables (sweep width 64, 32, 16, 8) of PAIR_TAB_STRIDE entries: k | l << 8 | run << 16
   const uint32_t  *pair_tab64; // the width-64 table with every field k_chain's sweep needs ready to use (k_fill_pair_tab)
   const uint32_t  *pair_tab_sub; // the width-32 / 16 / 8 tables, 8 bytes per pair, in the form k_chain_sub's sweep consumes
-  uint32_t        *edge_fast; // per edge: 1 if the all-pairs-compatible shortcut was taken (may be null)
+  unsigned long long *chunk_sums; // per chunk of COMPACT_CHUNK edges: {shortcut edges | orders << 32, ids} (see chunk_add)
   int              fast_path; // 0 disables the shortcut (every edge takes the full pair sweep)
   double           wiggle, ratio_pct, alt_frac;
   uint32_t         out_edge_base; // added to EdgeMatch::edge_idx: position of this batch's first edge in the job's table
 };
 
+constexpr uint32_t COMPACT_CHUNK = 1024; // edges per workgroup of k_compact = per pair of chunk sums of the chain kernels
 struct CompactArgs {
   msgpu_edge        *edges;
   uint64_t           n_edges;
-  const uint32_t    *edge_norders;
-  const uint64_t    *order_base, *ids_base;
+  const uint32_t    *edge_norders, *edge_nids;
+  const unsigned long long *chunk_sums; // [2 n_chunks], left by the chain kernels
+  uint32_t           n_chunks;          // ceil(n_edges / COMPACT_CHUNK)
+  // the read-back of the table sizes rides on workgroup 0: the scalar block (device), its mapped host mirror (null: no
+  // publication), the slots of the three sizes, the words to publish and the sequence number the host polls for (0: none)
+  uint64_t          *scalars, *host_scalars;
+  uint32_t           slot_orders, slot_ids, slot_fast, n_scalars;
+  uint64_t           seq;
   const msgpu_order *order_scr;
   const uint32_t    *ids_scr;
   msgpu_order       *orders;
@@ -199,7 +206,7 @@ void launch_fill_pair_tab(hipStream_t st, uint32_t *tab);
 void launch_chain(hipStream_t st, const ChainArgs &a, const uint32_t *list, uint32_t n_list);
 void launch_chain_sub(hipStream_t st, const ChainArgs &a, int width, const uint32_t *list, uint32_t n_list);
 void launch_sort_edges_by_size(hipStream_t st, const msgpu_edge *edges, const uint64_t *d_n_edges, uint64_t cap_edges,
-                               uint32_t *part, uint32_t *list, uint32_t *counts);
+                               uint32_t *part, uint32_t *list, uint32_t *counts, unsigned long long *chunk_sums, uint32_t n_chunk_words);
 size_t size_sort_part_bytes();
 size_t big_elem_bytes();
 size_t big_path_bytes();

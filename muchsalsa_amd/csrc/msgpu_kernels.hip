@@ -1252,6 +1252,17 @@ void launch_count_classes(hipStream_t st, const uint32_t *n_edge, const uint32_t
 // chain: EdgeMatch + getMaxPairwisePaths + chainingAndOverlaps filters + getOverlap, one wavefront per edge
 // ---------------------------------------------------------------------------------------------------------------------
 
+// The scan behind the chain kernels without a scan launch: every edge adds its order / id counts (and whether the shortcut
+// took it) to the sums of its CHUNK of COMPACT_CHUNK consecutive edges -- two fire-and-forget atomics per edge on ~10^3
+// counters (1 M edges: nothing beside the kernels' own work) -- and k_compact takes a workgroup per chunk: the chunk's base is
+// the sum of the chunks before it (a few hundred words, summed by every workgroup), the prefix inside the chunk a block scan.
+//   chunk_sums[2 c]     += shortcut | orders << 32        chunk_sums[2 c + 1] += ids
+__device__ __forceinline__ void chunk_add(unsigned long long *chunk_sums, uint64_t e, bool clean, uint32_t n_orders, uint32_t n_ids) {
+  unsigned long long *c = chunk_sums + 2 * (e / COMPACT_CHUNK);
+  __hip_atomic_fetch_add(c, (clean ? 1ull : 0ull) | (static_cast<unsigned long long>(n_orders) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_fetch_add(c + 1, static_cast<unsigned long long>(n_ids), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 struct PathRec {
   uint64_t mask;    // lanes (= EdgeMatches of the edge, vStart order) on the path
   uint64_t score;   // truncated like path_t's std::size_t
@@ -1571,7 +1582,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
       clean = static_cast<long long>(a_hi) - b_lo <= W && static_cast<long long>(b_hi) - a_lo <= W;
     }
   }
-  if (a.edge_fast && lane == 0) a.edge_fast[e] = clean ? 1u : 0u;
 
   // ---- checkCompatibility (mpp.cpp:38-142) for every pair k < l of one direction, all 64 lanes busy ---------------
   // pair p = l(l-1)/2 + k, row-major over l; a lane handles p = it*64 + lane
@@ -1856,6 +1866,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     a.edge_norders[e] = n_orders;
     a.edge_nids[e]    = n_ids;
     a.edges[e].shadow = shadow ? 1 : 0;
+    chunk_add(a.chunk_sums, e, clean, n_orders, n_ids);
   }
 }
 
@@ -2083,7 +2094,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W == 32 ? 7
       clean = maybe && static_cast<long long>(a_hi) - b_lo <= Wg && static_cast<long long>(b_hi) - a_lo <= Wg;
     }
   }
-  if (a.edge_fast && n && sl == 0) a.edge_fast[e] = clean ? 1u : 0u;
 
   // ---- checkCompatibility for every pair k < l: a lane takes pair p0 + sl of ITS edge, W pairs per edge and step ------
   const int P = clean ? 0 : static_cast<int>(n * (n - 1) / 2);
@@ -2334,6 +2344,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W == 32 ? 7
     a.edge_norders[e] = n_orders;
     a.edge_nids[e]    = n_ids;
     a.edges[e].shadow = shadow ? 1 : 0;
+    chunk_add(a.chunk_sums, e, clean, n_orders, n_ids);
   }
 }
 
@@ -2373,9 +2384,12 @@ __global__ __launch_bounds__(1024) void k_size_hist(const msgpu_edge *edges, con
 // counts[0..3] = edges of 9..16, 17..32, 33..64, <= 8 EdgeMatches (workgroup 0 writes them; k_count_classes published the
 // same numbers earlier, from the candidate scratch).
 __global__ __launch_bounds__(1024) void k_size_scatter(const msgpu_edge *edges, const uint64_t *d_n_edges, uint64_t cap_edges,
-                                                       const uint32_t *part, uint32_t *list, uint32_t *counts) {
+                                                       const uint32_t *part, uint32_t *list, uint32_t *counts,
+                                                       unsigned long long *chunk_sums, uint32_t n_chunk_words) {
   static_assert(SIZE_SORT_BLOCKS == 128, "16 segments of 8 blocks");
   __shared__ uint32_t s_seg[16][64], s_base[64], s_pos[64];
+  // the chain kernels' chunk sums start from zero (the last launch in front of them: no launch of its own for it)
+  for (uint32_t i = blockIdx.x * 1024 + threadIdx.x; i < n_chunk_words; i += SIZE_SORT_BLOCKS * 1024) chunk_sums[i] = 0;
   const uint64_t      ne64 = *d_n_edges;
   // a speculative launch into tables that turn out too small: k_size_hist wrote nothing, `part` is stale (the host
   // re-launches the kernels after it has allocated)
@@ -2891,6 +2905,7 @@ __global__ __launch_bounds__(64) void k_chain_big(ChainArgs a, const uint32_t *b
     a.edge_norders[e] = n_orders;
     a.edge_nids[e]    = n_ids;
     a.edges[e].shadow = shadow ? 1 : 0;
+    chunk_add(a.chunk_sums, e, false, n_orders, n_ids);
   }
 }
 
@@ -2933,49 +2948,141 @@ __global__ __launch_bounds__(256) void k_fill_pair_tab(uint32_t *tab) {
   else tabsub_entry(tab, t, p, k, l, run);
 }
 
-// dense, canonical order + id tables
+// dense, canonical order + id tables -- and the scan that places them, and the read-back of their sizes, in the same launch.
+// A workgroup per chunk of COMPACT_CHUNK edges.  Every workgroup sums the chunk sums the chain kernels left (chunk_add): the
+// ones before its own are its base, all of them the table sizes.  Workgroup 0 writes the sizes into the scalar block and
+// publishes the block to the host AT ONCE (k_publish_scalars' protocol): the host turns around while the tables are still being
+// written.  Then the prefix inside the chunk (a block scan over the per-edge counts), then the move.
 __global__ __launch_bounds__(256) void k_compact(CompactArgs a) {
+  __shared__ unsigned long long s_red[4][6];
+  __shared__ uint32_t           s_ob[COMPACT_CHUNK], s_ib[COMPACT_CHUNK], s_w[2][4];
+  const int      lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t chunk = blockIdx.x;
+  unsigned long long t[6] = {0, 0, 0, 0, 0, 0}; // orders, ids, shortcut edges: of the chunks before this one | of all chunks
+  for (uint32_t c = threadIdx.x; c < a.n_chunks; c += 256) {
+    const unsigned long long w0 = a.chunk_sums[2 * c], w1 = a.chunk_sums[2 * c + 1];
+    const unsigned long long no = w0 >> 32, nf = w0 & 0xffffffffull;
+    if (c < chunk) {
+      t[0] += no;
+      t[1] += w1;
+    }
+    t[3] += no;
+    t[4] += w1;
+    t[5] += nf;
+  }
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    if (k == 2) continue;
+    for (int d = 32; d > 0; d >>= 1) t[k] += __shfl_xor(t[k], d);
+    if (lane == 0) s_red[wave][k] = t[k];
+  }
+  __syncthreads();
+  const unsigned long long base_o = s_red[0][0] + s_red[1][0] + s_red[2][0] + s_red[3][0];
+  const unsigned long long base_i = s_red[0][1] + s_red[1][1] + s_red[2][1] + s_red[3][1];
+  const unsigned long long tot_o  = s_red[0][3] + s_red[1][3] + s_red[2][3] + s_red[3][3];
+  const unsigned long long tot_i  = s_red[0][4] + s_red[1][4] + s_red[2][4] + s_red[3][4];
+  const unsigned long long tot_f  = s_red[0][5] + s_red[1][5] + s_red[2][5] + s_red[3][5];
+  if (chunk == 0 && a.scalars) {
+    // (every launch writes the sizes; only the first launch of a call publishes -- a repeat after a reallocation has seq = 0)
+    if (threadIdx.x == 0) {
+      a.scalars[a.slot_orders] = tot_o;
+      a.scalars[a.slot_ids]    = tot_i;
+      a.scalars[a.slot_fast]   = tot_f;
+    }
+    if (a.host_scalars && a.seq) {
+      if (threadIdx.x < a.n_scalars) {
+        const uint32_t k = threadIdx.x;
+        a.host_scalars[k] = k == a.slot_orders ? tot_o : k == a.slot_ids ? tot_i : k == a.slot_fast ? tot_f : a.scalars[k];
+      }
+      __threadfence_system();
+      __syncthreads();
+      if (threadIdx.x == 0) __hip_atomic_store(&a.host_scalars[a.n_scalars], a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+  // (may be launched before the host knows the table sizes, into whatever the tables hold from earlier calls: if they do not
+  // fit nothing is written; the host, which compares the same numbers, allocates and launches again)
+  if (tot_o > a.cap_orders || tot_i > a.cap_ids) return;
+  const uint64_t e0 = static_cast<uint64_t>(chunk) * COMPACT_CHUNK;
+  if (e0 >= a.n_edges) return;
+  {
+    // prefix inside the chunk: a thread takes COMPACT_CHUNK / 256 = 4 consecutive edges
+    static_assert(COMPACT_CHUNK == 1024, "four edges per thread");
+    uint32_t no[4], ni[4];
+    const uint64_t ef = e0 + threadIdx.x * 4;
+    if (ef + 4 <= a.n_edges) {
+      const uint4 vo = *reinterpret_cast<const uint4 *>(&a.edge_norders[ef]), vi = *reinterpret_cast<const uint4 *>(&a.edge_nids[ef]);
+      no[0] = vo.x, no[1] = vo.y, no[2] = vo.z, no[3] = vo.w;
+      ni[0] = vi.x, ni[1] = vi.y, ni[2] = vi.z, ni[3] = vi.w;
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        no[k] = ef + k < a.n_edges ? a.edge_norders[ef + k] : 0u;
+        ni[k] = ef + k < a.n_edges ? a.edge_nids[ef + k] : 0u;
+      }
+    }
+    const uint32_t so = no[0] + no[1] + no[2] + no[3], si = ni[0] + ni[1] + ni[2] + ni[3];
+    const uint32_t io = wave_incl_scan(so), ii = wave_incl_scan(si);
+    if (lane == 63) {
+      s_w[0][wave] = io;
+      s_w[1][wave] = ii;
+    }
+    __syncthreads();
+    uint32_t bo = io - so, bi = ii - si;
+    for (int w = 0; w < wave; ++w) {
+      bo += s_w[0][w];
+      bi += s_w[1][w];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      s_ob[threadIdx.x * 4 + k] = bo;
+      s_ib[threadIdx.x * 4 + k] = bi;
+      bo += no[k];
+      bi += ni[k];
+    }
+  }
+  __syncthreads();
   // Four lanes per edge, sixteen edges per wavefront, all in flight together: a lane moves one 16-byte quarter of an
   // order record and every fourth id.  (Most edges have one order; the dependent chain "order record -> id count ->
   // ids" is then as long as a single edge's, not sixteen of them in a row.)
-  // (may be launched before the host knows the table sizes: see k_emit_edges)
-  if (a.order_base[a.n_edges] > a.cap_orders || a.ids_base[a.n_edges] > a.cap_ids) return;
-  const int      lane = threadIdx.x & 63, sub = lane & 3;
-  const uint64_t e    = (static_cast<uint64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6)) * 16 + (lane >> 2);
-  const bool     have = e < a.n_edges;
-  uint32_t       no = 0;
-  uint64_t       oo = 0, io = 0, em_off = 0;
-  if (have) {
-    no     = a.edge_norders[e];
-    oo     = a.order_base[e];
-    io     = a.ids_base[e];
-    em_off = a.edges[e].em_off;
-    if (sub == 0) { // cross references leave as positions in the whole job's tables (a batch / shard adds its bases)
-      a.edges[e].order_off = oo + a.out_order_base;
-      a.edges[e].order_cnt = static_cast<uint16_t>(no);
-      a.edges[e].em_off    = em_off + a.out_em_base;
+  const int sub = lane & 3;
+  for (uint32_t round = 0; round < COMPACT_CHUNK / 64; ++round) {
+    const uint32_t le   = round * 64 + wave * 16 + (lane >> 2);
+    const uint64_t e    = e0 + le;
+    const bool     have = e < a.n_edges;
+    uint32_t       no = 0;
+    uint64_t       oo = 0, io = 0, em_off = 0;
+    if (have) {
+      no     = a.edge_norders[e];
+      oo     = base_o + s_ob[le];
+      io     = base_i + s_ib[le];
+      em_off = a.edges[e].em_off;
+      if (sub == 0) { // cross references leave as positions in the whole job's tables (a batch / shard adds its bases)
+        a.edges[e].order_off = oo + a.out_order_base;
+        a.edges[e].order_cnt = static_cast<uint16_t>(no);
+        a.edges[e].em_off    = em_off + a.out_em_base;
+      }
     }
-  }
-  uint32_t max_no = no; // every lane runs the same number of rounds (shuffles inside)
-  for (int d = 32; d >= 4; d >>= 1) max_no = max(max_no, static_cast<uint32_t>(__shfl_xor(static_cast<int>(max_no), d)));
-  for (uint32_t i = 0; i < max_no; ++i) {
-    const bool on = i < no;
-    uint4      w  = make_uint4(0, 0, 0, 0);
-    if (on) w = reinterpret_cast<const uint4 *>(&a.order_scr[em_off + i])[sub];
-    // msgpu_order as 16 dwords: [8,9] = ids_off (edge-relative in the scratch), [10] = ids_cnt -- the third quarter
-    const int      q2  = (lane & ~3) + 2;
-    const uint32_t rel = static_cast<uint32_t>(__shfl(static_cast<int>(w.x), q2));
-    const uint32_t cnt = static_cast<uint32_t>(__shfl(static_cast<int>(w.z), q2));
-    if (sub == 2) {
-      const uint64_t gio = io + a.out_ids_base;
-      w.x = static_cast<uint32_t>(gio);
-      w.y = static_cast<uint32_t>(gio >> 32);
-    }
-    if (sub == 0) w.x += a.out_edge_base; // dword 0 = edge_idx
-    if (on) {
-      reinterpret_cast<uint4 *>(&a.orders[oo + i])[sub] = w;
-      for (uint32_t q = sub; q < cnt; q += 4) a.ids[io + q] = a.ids_scr[em_off + rel + q];
-      io += cnt;
+    uint32_t max_no = no; // every lane runs the same number of rounds (shuffles inside)
+    for (int d = 32; d >= 4; d >>= 1) max_no = max(max_no, static_cast<uint32_t>(__shfl_xor(static_cast<int>(max_no), d)));
+    for (uint32_t i = 0; i < max_no; ++i) {
+      const bool on = i < no;
+      uint4      w  = make_uint4(0, 0, 0, 0);
+      if (on) w = reinterpret_cast<const uint4 *>(&a.order_scr[em_off + i])[sub];
+      // msgpu_order as 16 dwords: [8,9] = ids_off (edge-relative in the scratch), [10] = ids_cnt -- the third quarter
+      const int      q2  = (lane & ~3) + 2;
+      const uint32_t rel = static_cast<uint32_t>(__shfl(static_cast<int>(w.x), q2));
+      const uint32_t cnt = static_cast<uint32_t>(__shfl(static_cast<int>(w.z), q2));
+      if (sub == 2) {
+        const uint64_t gio = io + a.out_ids_base;
+        w.x = static_cast<uint32_t>(gio);
+        w.y = static_cast<uint32_t>(gio >> 32);
+      }
+      if (sub == 0) w.x += a.out_edge_base; // dword 0 = edge_idx
+      if (on) {
+        reinterpret_cast<uint4 *>(&a.orders[oo + i])[sub] = w;
+        for (uint32_t q = sub; q < cnt; q += 4) a.ids[io + q] = a.ids_scr[em_off + rel + q];
+        io += cnt;
+      }
     }
   }
 }
@@ -3321,9 +3428,10 @@ void launch_chain_sub(hipStream_t st, const ChainArgs &a, int width, const uint3
     hipLaunchKernelGGL(k_chain_sub<32>, grid1(n_list, 8), dim3(256), 0, st, a, list, n_list);
 }
 void launch_sort_edges_by_size(hipStream_t st, const msgpu_edge *edges, const uint64_t *d_n_edges, uint64_t cap_edges,
-                               uint32_t *part, uint32_t *list, uint32_t *counts) {
+                               uint32_t *part, uint32_t *list, uint32_t *counts, unsigned long long *chunk_sums, uint32_t n_chunk_words) {
   hipLaunchKernelGGL(k_size_hist, dim3(SIZE_SORT_BLOCKS), dim3(1024), 0, st, edges, d_n_edges, cap_edges, part);
-  hipLaunchKernelGGL(k_size_scatter, dim3(SIZE_SORT_BLOCKS), dim3(1024), 0, st, edges, d_n_edges, cap_edges, part, list, counts);
+  hipLaunchKernelGGL(k_size_scatter, dim3(SIZE_SORT_BLOCKS), dim3(1024), 0, st, edges, d_n_edges, cap_edges, part, list, counts,
+                     chunk_sums, n_chunk_words);
 }
 size_t size_sort_part_bytes() { return static_cast<size_t>(SIZE_SORT_BLOCKS) * 64 * 4; }
 size_t big_elem_bytes() { return sizeof(BigElem); }
@@ -3356,8 +3464,8 @@ void launch_pack_wire(hipStream_t st, const PackWireArgs &a) {
   if (!n) n = 1; // empty tables: thread 0 writes the closing CSR entries
   hipLaunchKernelGGL(k_pack_wire, grid1(n, 256), dim3(256), 0, st, a);
 }
-void launch_compact(hipStream_t st, const CompactArgs &a) {
-  if (a.n_edges) hipLaunchKernelGGL(k_compact, grid1(a.n_edges, 64), dim3(256), 0, st, a); // 4 waves x 16 edges
+void launch_compact(hipStream_t st, const CompactArgs &a) { // a workgroup per chunk; one even without edges: it publishes the sizes
+  hipLaunchKernelGGL(k_compact, dim3(a.n_chunks ? a.n_chunks : 1), dim3(256), 0, st, a);
 }
 
 } // namespace msgpu
