@@ -229,6 +229,11 @@ struct msgpu_ctx {
   bool         chain_zeroed = false; // msgpu_calculate_edges zeroed the chain stage's per-edge counters
   bool         no_prologue = false; // msgpu_overlap_batched with several windows: every window has its own opening
   bool         prologue_ok = false; // the candidate stage's opening ran with the index build (whole table, fast index)
+  bool         scalars_clean = false; // the scalar block is zero where a build counts from nothing (k_index_epilogue's publisher left it so)
+  bool         bin_clean = false;     // the bin path's bucket cursors are zero (k_index_sort_bin leaves them so)
+  uint32_t     prologue_shard = 0, prologue_nshards = 1; // the shard the index build's classification was made for
+  uint64_t     prologue_own = 0;      // ... and the visits of its owner reads
+  bool         nlists_clean = false; // the four list cursors of k_classify_reads are zero (see msgpu_calculate_edges)
   bool         cand_zeroed = false; // ... including the zeroing of the candidate kernels' counters (used up by the next msgpu_calculate_edges)
   uint64_t     prologue_bound = 0;
   uint32_t     prologue_lists[4] = {0, 0, 0, 0};
@@ -258,7 +263,7 @@ struct msgpu_ctx {
       scan_tmp, vis16, spos2, visits, bin_cursor, bin_start;
   DevBuf bound, cand_off, cand_j, cand_t, scr_v2, scr_start, n_cand, n_edge, n_visit_arr, lists, em_base, edge_base,
       visit_base, edges, edge_cand;
-  DevBuf big_key, big_t, big_r2s, big_pfx, pair_tab, chain_chunks, big_off;
+  DevBuf big_key, big_t, big_r2s, big_pfx, pair_tab, chain_chunks, big_off, cand_sums, bucket_visits;
   hipStream_t side_stream = nullptr, side_stream2 = nullptr;
   hipEvent_t  ev_side[2]  = {nullptr, nullptr}, ev_side2 = nullptr;
   uint64_t    n_big_edges = 0, n_big_ems = 0;
@@ -308,7 +313,9 @@ namespace {
 // scalar slots in ctx->scalars (uint64 each)
 enum { SC_MAXIDS = 0 /*2 x u32*/, SC_ERR = 1, SC_TOTAL_A = 2, SC_TOTAL_B = 3, SC_TOTAL_C = 4, SC_NLISTS = 5 /*4 x u32, spans 5..6*/,
        SC_NBIG = 7, SC_NALIVE = 8, SC_IXFLAGS = 9, SC_BIGSTATS = 10 /*2 x u64*/, SC_BIGCUR = 12 /*2 x u64*/,
-       SC_CLS = 14 /*4 x u32: edges per width class, spans 14..15*/, SC_COUNT = 16 };
+       SC_CLS = 14 /*4 x u32: edges per width class, spans 14..15*/,
+       SC_HEADS = 16 /*k_index_bin: finished workgroups (low half) | scaffolds that begin (high half)*/, SC_DONE = 17 /*u32: finished workgroups of k_index_epilogue*/,
+       SC_OWN = 18 /*visits of the owner reads classified by k_index_epilogue*/, SC_COUNT = 19 };
 
 int fail(msgpu_ctx *c, int code, const char *fmt, ...) {
   va_list ap;
@@ -331,6 +338,23 @@ int fail(msgpu_ctx *c, int code, const char *fmt, ...) {
 template <class T> T *scalar(msgpu_ctx *c, int slot) { return reinterpret_cast<T *>(c->scalars.as<uint64_t>() + slot); }
 // host value of a scalar slot after read_scalars()
 template <class T> const T *host_scalar(const msgpu_ctx *c, int slot) { return reinterpret_cast<const T *>(c->h_scalars + slot); }
+// The candidate stage's per-chunk block (cand_sums): [chunks][2] 64-bit sums, then [chunks][64] 32-bit size histograms.
+static uint32_t cand_chunks(uint32_t V) { return (V + CAND_CHUNK - 1) / CAND_CHUNK; }
+static size_t   cand_sums_bytes(uint32_t V) { return static_cast<size_t>(cand_chunks(V) + 1) * (16 + 256); }
+static unsigned long long *cand_chunk_sums(msgpu_ctx *c) { return c->cand_sums.as<unsigned long long>(); }
+static uint32_t *cand_hist(msgpu_ctx *c, uint32_t V) { return reinterpret_cast<uint32_t *>(c->cand_sums.as<unsigned long long>() + 2 * static_cast<size_t>(cand_chunks(V) + 1)); }
+// what k_classify_reads zeroes in front of the candidate kernels (buffers must exist)
+static CandZero cand_zero(msgpu_ctx *c, uint32_t V) {
+  static_assert(SC_BIGCUR == SC_BIGSTATS + 2 && SC_CLS == SC_BIGCUR + 2 && SC_HEADS == SC_CLS + 2, "adjacent scalar slots");
+  static_assert(SC_COUNT <= SC_PUBLISH_MAX, "a fused read-back publishes the whole scalar block");
+  CandZero z;
+  z.n_cand         = c->n_cand.as<uint32_t>();
+  z.n_edge         = c->n_edge.as<uint32_t>();
+  z.scalar_words   = scalar<uint32_t>(c, SC_BIGSTATS);
+  z.n_scalar_words = 12; // big-edge statistics (2 x u64), big-edge cursors (2 x u64), class counts (4 x u32)
+  return z;
+}
+
 // One copy of the whole scalar block into pinned memory + a stream synchronisation.  (Separate 4-byte copies into
 // pageable host variables cost ~20 us each on this stack; there were up to three per read-back.)
 // Default: no copy and no stream synchronisation -- a one-wavefront kernel writes the block into the (mapped) pinned
@@ -412,7 +436,7 @@ void release_all(msgpu_ctx *c) {
                    &c->bkt2_idx, &c->bkt2_line, &c->by_anchor, &c->read_len, &c->read_first, &c->scalars, &c->scan_tmp,
                    &c->bound, &c->cand_off, &c->cand_j, &c->cand_t, &c->scr_v2, &c->scr_start, &c->n_cand, &c->n_edge,
                    &c->n_visit_arr, &c->lists, &c->em_base, &c->edge_base, &c->visit_base, &c->edges, &c->edge_cand,
-                   &c->big_key, &c->big_t, &c->big_r2s, &c->big_pfx, &c->pair_tab, &c->chain_chunks, &c->big_off, &c->ems, &c->order_scr, &c->ids_scr,
+                   &c->big_key, &c->big_t, &c->big_r2s, &c->big_pfx, &c->pair_tab, &c->chain_chunks, &c->big_off, &c->cand_sums, &c->bucket_visits, &c->ems, &c->order_scr, &c->ids_scr,
                    &c->edge_norders, &c->edge_nids, &c->order_base, &c->ids_base, &c->orders, &c->ids, &c->big_list, &c->cls_list, &c->cls_part, &c->cls_partials,
                    &c->big_elems, &c->big_paths, &c->alt_edges, &c->alt_ems, &c->alt_orders, &c->alt_ids, &c->vis16, &c->visits,
                    &c->spos2, &c->bin_cursor, &c->bin_start, &c->wire_dev[0], &c->wire_dev[1], &c->win_cuts};
@@ -422,14 +446,29 @@ void release_all(msgpu_ctx *c) {
 int build_index_once(msgpu_ctx *c, bool force_generic, bool two_pass, bool bin, uint32_t *ix_flags_out) {
   hipStream_t st = c->stream;
   const uint64_t n = c->n_rows;
-  ENSURE(c, scalars, SC_COUNT * sizeof(uint64_t));
-  HIPCHK(c, hipMemsetAsync(c->scalars.p, 0, SC_COUNT * sizeof(uint64_t), st));
+  {
+    const void *before = c->scalars.p;
+    ENSURE(c, scalars, SC_COUNT * sizeof(uint64_t));
+    if (c->scalars.p != before) c->scalars_clean = false;
+  }
+  // The scalar block is zero at rest where a build counts from nothing (k_index_epilogue's last workgroup leaves it so, behind
+  // its publication): a build that follows one of those needs no memset.  Anything else -- a first build, a build after an
+  // error, the synchronising read-back path, ids to be discovered -- zeroes the block here.
+  bool scalars_zeroed = false;
+  auto zero_scalars = [&]() -> int {
+    if (scalars_zeroed) return MSGPU_OK;
+    HIPCHK(c, hipMemsetAsync(c->scalars.p, 0, SC_COUNT * sizeof(uint64_t), st));
+    scalars_zeroed  = true;
+    c->nlists_clean = true;
+    return MSGPU_OK;
+  };
 
   // id spaces: declared by the caller (the parser knows them), else one pass over the rows and a read-back
   if (c->decl_V && c->decl_A) {
     c->V = c->decl_V;
     c->A = c->decl_A;
   } else {
+    if (int rc = zero_scalars()) return rc;
     launch_max_ids(st, c->d_rows, n, scalar<uint32_t>(c, SC_MAXIDS));
     if (int rc = read_scalars(c)) return rc;
     c->V = host_scalar<uint32_t>(c, SC_MAXIDS)[0];
@@ -457,9 +496,17 @@ int build_index_once(msgpu_ctx *c, bool force_generic, bool two_pass, bool bin, 
   ENSURE(c, read_off, (size_t(V) + 2) * 4);
   ENSURE(c, cursor, mva * 4);
   if (bshift) {
+    const void *before = c->bin_cursor.p;
     ENSURE(c, bin_cursor, (size_t(bpasses) * (nb + 1) + 1) * 4); // per pass: the bucket cursors; last word: by_read rows of the passes so far
+    if (c->bin_cursor.p != before) c->bin_clean = false;
     ENSURE(c, bin_start, (size_t(nb) + 2) * 4);
+    ENSURE(c, bucket_visits, ((size_t(V) >> BIN_RPB_SHIFT) + 2) * 4);
   }
+  static const bool sync_path = getenv("MSGPU_SYNC_READBACK") != nullptr;
+  const bool fused_readback = bshift != 0 && !sync_path && c->h_scalars_dev; // k_index_epilogue publishes (and zeroes behind it)
+  if (!(bshift && c->scalars_clean && fused_readback))
+    if (int rc = zero_scalars()) return rc;
+  c->scalars_clean = false; // (until this build's publisher has left it so again)
   ENSURE(c, bkt_key, (bshift ? size_t(nb) * bcap * 2 : cap ? size_t(V) * cap : nz) * sizeof(IRow)); // (bin path: 64-byte records)
   ENSURE(c, bkt_dead, nz);
   ENSURE(c, by_read, nz * sizeof(IRow));
@@ -490,25 +537,32 @@ int build_index_once(msgpu_ctx *c, bool force_generic, bool two_pass, bool bin, 
   // else redoes it there.
   c->prologue_ok           = false;
   static const bool env_no_prologue = getenv("MSGPU_NO_PROLOGUE") != nullptr; // measurement switch
-  const bool want_prologue = !env_no_prologue && !force_generic && !c->no_prologue && V != 0 && c->nshards == 1 && c->win_lo == 0 && c->win_hi >= V;
+  // (the bin path classifies for the context's shard; the atomic path's prologue is the unsharded one)
+  const bool want_prologue = !env_no_prologue && !force_generic && !c->no_prologue && V != 0 && (c->nshards == 1 || bshift) && c->win_lo == 0 && c->win_hi >= V;
   if (want_prologue) {
     ENSURE(c, n_cand, (size_t(V) + 1) * 4);
     ENSURE(c, n_edge, (size_t(V) + 1) * 4);
-    ENSURE(c, n_visit_arr, (size_t(V) + 1) * 4);
+    ENSURE(c, cand_sums, cand_sums_bytes(V));
   }
   {
-    // (the bin path counts per bucket, not per read: its cursors take the per-read counters' place in the zero list; the
-    // last four are what the candidate kernels need zeroed -- per-read counters, big-edge statistics / cursor / width
-    // classes -- in the same launch: nothing touches them before those kernels run)
-    static_assert(SC_BIGCUR == SC_BIGSTATS + 2 && SC_CLS == SC_BIGCUR + 2 && SC_COUNT == SC_CLS + 2, "adjacent scalar slots");
+    // (the bin path counts per bucket, not per read: its cursors take the per-read counters' place in the zero list.  What the
+    // candidate kernels add to is zeroed by k_classify_reads, the launch in front of them.)
     uint32_t *const zero[8]   = {bshift ? c->bin_cursor.as<uint32_t>() : c->cnt_read.as<uint32_t>(), c->cursor.as<uint32_t>(),
-                                 c->read_cnt.as<uint32_t>(), c->anchor_cnt.as<uint32_t>(),
-                                 want_prologue ? scalar<uint32_t>(c, SC_BIGSTATS) : nullptr, want_prologue ? c->n_cand.as<uint32_t>() : nullptr,
-                                 want_prologue ? c->n_edge.as<uint32_t>() : nullptr, want_prologue ? c->n_visit_arr.as<uint32_t>() : nullptr};
-    const uint32_t  n_zero[8] = {bshift ? bpasses * (nb + 1) + 1 : V + 1, static_cast<uint32_t>(mva), V + 1, A + 1, 12, V + 1, V + 1, V + 1};
+                                 c->read_cnt.as<uint32_t>(), c->anchor_cnt.as<uint32_t>(), nullptr, nullptr, nullptr, nullptr};
+    const uint32_t  n_zero[8] = {bshift ? bpasses * (nb + 1) + 1 : V + 1, static_cast<uint32_t>(mva), V + 1, A + 1, 0, 0, 0, 0};
     uint32_t *const ones[2]   = {c->anchor_first.as<uint32_t>(), nullptr};
     const uint32_t  n_ones[2] = {A + 2, 0};
-    launch_index_init8(st, zero, n_zero, ones, n_ones);
+    // the bin path needs its bucket cursors zero and nothing else of this list (the cursors are zero at rest: k_index_sort_bin
+    // leaves them so; sparse anchor ids are found by counting scaffolds, not by looking into a filled anchor_first)
+    if (!bshift) launch_index_init8(st, zero, n_zero, ones, n_ones);
+    else if (!c->bin_clean) {
+      uint32_t *const z4[4] = {zero[0], nullptr, nullptr, nullptr};
+      const uint32_t  n4[4] = {n_zero[0], 0, 0, 0};
+      uint32_t *const o2[2] = {nullptr, nullptr};
+      const uint32_t  no2[2] = {0, 0};
+      launch_index_init(st, z4, n4, o2, no2);
+    }
+    c->bin_clean = false;
   }
   uint32_t *d_flags = scalar<uint32_t>(c, SC_IXFLAGS);
   if (force_generic) {
@@ -522,13 +576,17 @@ int build_index_once(msgpu_ctx *c, bool force_generic, bool two_pass, bool bin, 
       const uint32_t rd_lo = p * reads_per_pass;
       const uint32_t nb_p  = static_cast<uint32_t>((size_t(std::min(V - rd_lo, reads_per_pass)) + (1u << bshift) - 1) >> bshift);
       uint32_t      *cur   = c->bin_cursor.as<uint32_t>() + size_t(p) * (nb + 1);
+      BinTail        tail;
+      tail.bin_start    = c->bin_start.as<uint32_t>();
+      tail.row_base     = row_base;
+      tail.read_off_end = p + 1 == bpasses ? c->read_off.as<uint32_t>() + V : nullptr;
+      tail.done_heads   = scalar<unsigned long long>(c, SC_HEADS);
       launch_index_bin(st, c->d_rows, n, V, A, d_flags, scalar<uint32_t>(c, SC_ERR), c->anchor_first.as<uint32_t>(), cur,
-                       c->bkt_key.as<uint4>(), rd_lo, nb_p, bcap, c->bin_start.as<uint32_t>(), row_base,
-                       p + 1 == bpasses ? c->read_off.as<uint32_t>() + V : nullptr, p == 0);
+                       c->bkt_key.as<uint4>(), rd_lo, nb_p, bcap, tail);
       launch_index_sort_bin(st, cur, c->bin_start.as<uint32_t>(), V, rd_lo, nb_p, bcap, c->bkt_key.as<uint4>(),
                             c->by_read.as<IRow>(), c->by_anchor.as<IRow>(), c->vis16.as<uint4>(), c->read_off.as<uint32_t>(),
                             c->read_cnt.as<uint32_t>(), c->read_len.as<int32_t>(), c->read_first.as<uint32_t>(),
-                            c->visits.as<uint32_t>(), c->d_rows, d_flags, scalar<uint32_t>(c, SC_ERR));
+                            c->visits.as<uint32_t>(), c->d_rows, d_flags, scalar<uint32_t>(c, SC_ERR), c->bucket_visits.as<uint32_t>());
     }
   } else {
   launch_index_pass1(st, c->d_rows, n, c->cnt_read.as<uint32_t>(), c->anchor_first.as<uint32_t>(), V, A, d_flags,
@@ -543,6 +601,67 @@ int build_index_once(msgpu_ctx *c, bool force_generic, bool two_pass, bool bin, 
                    scalar<uint32_t>(c, SC_ERR), c->spos2.as<uint2>(), c->vis16.as<uint4>(), c->visits.as<uint32_t>()); // fast mode: the sort writes the scaffold rows too (at
                                                                               // the places pass 1 left in spos2); always: the Vertex facts
   }
+  if (bshift) {
+    // ONE launch closes a bin-path build (k_index_epilogue): the Registry-order check, the scaffold offsets, the scan of the
+    // visit counts, the owner reads classified for the candidate kernels (for this context's shard; a window job classifies
+    // per window), and the read-back of flags and sizes by its last workgroup -- which also leaves the scalar block zero where
+    // the next build counts from nothing.
+    ENSURE(c, cand_off, (size_t(V) + 2) * 8);
+    ENSURE(c, lists, (size_t(V) + 1) * (3 * sizeof(CandDesc) + 4));
+    CandDesc *l0 = c->lists.as<CandDesc>(), *l1 = l0 + V + 1, *l2 = l1 + V + 1;
+    if (want_prologue && !c->nlists_clean) {
+      HIPCHK(c, hipMemsetAsync(scalar<uint32_t>(c, SC_NLISTS), 0, 16, st));
+      c->nlists_clean = true;
+    }
+    IndexEpilogueArgs k;
+    k.read_first     = c->read_first.as<uint32_t>();
+    k.V              = V;
+    k.A              = A;
+    k.n_rows         = static_cast<uint32_t>(n);
+    k.err            = scalar<uint32_t>(c, SC_ERR);
+    k.flags          = d_flags;
+    k.anchor_first   = c->anchor_first.as<uint32_t>();
+    k.anchor_off_gen = c->anchor_off_gen.as<uint32_t>();
+    k.anchor_off     = c->anchor_off.as<uint32_t>();
+    k.n_alive        = scalar<uint32_t>(c, SC_NALIVE);
+    k.heads          = scalar<uint32_t>(c, SC_HEADS) + 1; // (the high half)
+    k.row_base       = c->bin_cursor.as<uint32_t>() + size_t(bpasses) * (nb + 1);
+    k.visits         = c->visits.as<uint32_t>();
+    k.bucket_visits  = c->bucket_visits.as<uint32_t>();
+    k.n_buckets      = static_cast<uint32_t>((size_t(V) + (1u << BIN_RPB_SHIFT) - 1) >> BIN_RPB_SHIFT);
+    k.cand_off       = c->cand_off.as<uint64_t>();
+    k.total          = scalar<uint64_t>(c, SC_TOTAL_A);
+    k.classify       = want_prologue ? 1 : 0;
+    k.read_off       = c->read_off.as<uint32_t>();
+    k.read_cnt       = c->read_cnt.as<uint32_t>();
+    k.shard          = c->shard;
+    k.nshards        = c->nshards;
+    k.list0          = l0;
+    k.list1          = l1;
+    k.list2          = l2;
+    k.list3          = reinterpret_cast<uint32_t *>(l2 + V + 1);
+    k.n_lists        = scalar<uint32_t>(c, SC_NLISTS);
+    k.own_total      = scalar<unsigned long long>(c, SC_OWN);
+    k.z              = want_prologue ? cand_zero(c, V) : CandZero{};
+    k.done           = scalar<uint32_t>(c, SC_DONE);
+    k.scalars        = c->scalars.as<uint64_t>();
+    k.host_scalars   = fused_readback ? c->h_scalars_dev : nullptr;
+    k.n_scalars      = SC_COUNT;
+    c->readback_polled = fused_readback;
+    k.seq            = fused_readback ? ++c->readback_seq : 0;
+    // zeroed behind the publication: error bits, index flags, the scaffold count, the finished-workgroup counters, the owner
+    // reads' visits.  (Not with the synchronising read-back: its copy comes after the kernel.)
+    k.zero_mask      = fused_readback ? ((1ull << SC_ERR) | (1ull << SC_IXFLAGS) | (1ull << SC_HEADS) | (1ull << SC_DONE) | (1ull << SC_OWN)) : 0ull;
+    launch_index_epilogue(st, k);
+    if (want_prologue) c->nlists_clean = false;
+    HIPCHK(c, hipGetLastError());
+    if (c->stage_events) HIPCHK(c, hipEventRecord(c->ev[1], st));
+    if (!fused_readback) {
+      HIPCHK(c, hipMemcpyAsync(c->h_scalars, c->scalars.p, SC_COUNT * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+      HIPCHK(c, hipEventRecord(c->ev_readback, st));
+    }
+    if (int rc = wait_scalars(c)) return rc;
+  } else {
   // the Registry-order check on the first lines the sort found and, in the same launch, the scaffold offsets: fast mode
   // (input grouped by anchor, ascending lines: what the PAF loader hands over) is finished here but for them, and they are
   // the speculative ones of pass 1; the flags come back with the read-back below and only an input that is not in that
@@ -560,17 +679,23 @@ int build_index_once(msgpu_ctx *c, bool force_generic, bool two_pass, bool bin, 
                              scalar<uint64_t>(c, SC_TOTAL_A));
     launch_classify_reads(st, c->read_off.as<uint32_t>(), c->read_cnt.as<uint32_t>(), c->visits.as<uint32_t>(),
                           c->cand_off.as<uint64_t>(), V, 0, 1, 0, 0xffffffffu, l0, l1, l2,
-                          reinterpret_cast<uint32_t *>(l2 + V + 1), scalar<uint32_t>(c, SC_NLISTS));
+                          reinterpret_cast<uint32_t *>(l2 + V + 1), scalar<uint32_t>(c, SC_NLISTS), cand_zero(c, V));
+    c->nlists_clean = false;
     HIPCHK(c, hipGetLastError());
   }
 
   if (int rc = read_scalars(c)) return rc;
+  }
   const uint32_t err = *host_scalar<uint32_t>(c, SC_ERR), ixf = *host_scalar<uint32_t>(c, SC_IXFLAGS);
   c->cand_zeroed = false;
+  if (bshift && fused_readback && ixf == 0 && err == 0) c->scalars_clean = c->bin_clean = true; // (zero at rest, see above)
   if (want_prologue && ixf == 0 && err == 0) {
-    c->prologue_ok    = true;
-    c->cand_zeroed    = true;
-    c->prologue_bound = *host_scalar<uint64_t>(c, SC_TOTAL_A);
+    c->prologue_ok      = true;
+    c->cand_zeroed      = true;
+    c->prologue_bound   = *host_scalar<uint64_t>(c, SC_TOTAL_A);
+    c->prologue_shard   = bshift ? c->shard : 0;
+    c->prologue_nshards = bshift ? c->nshards : 1;
+    c->prologue_own     = (bshift && c->nshards > 1) ? *host_scalar<uint64_t>(c, SC_OWN) : c->prologue_bound;
     for (int k = 0; k < 4; ++k) c->prologue_lists[k] = host_scalar<uint32_t>(c, SC_NLISTS)[k];
   }
   uint32_t       n_alive = *host_scalar<uint32_t>(c, SC_NALIVE);
@@ -880,46 +1005,53 @@ int msgpu_calculate_edges(msgpu_ctx *c) {
   ENSURE(c, lists, (size_t(V) + 1) * (3 * sizeof(CandDesc) + 4));
   ENSURE(c, n_cand, (size_t(V) + 1) * 4);
   ENSURE(c, n_edge, (size_t(V) + 1) * 4);
-  ENSURE(c, n_visit_arr, (size_t(V) + 1) * 4);
-  ENSURE(c, em_base, (size_t(V) + 2) * 8);
-  ENSURE(c, edge_base, (size_t(V) + 2) * 8);
-  ENSURE(c, visit_base, (size_t(V) + 2) * 8);
+  ENSURE(c, cand_sums, cand_sums_bytes(V));
   CandDesc *l0 = c->lists.as<CandDesc>(), *l1 = l0 + V + 1, *l2 = l1 + V + 1;
   uint32_t *l3 = reinterpret_cast<uint32_t *>(l2 + V + 1);
 
   const bool all_reads = c->index_fast && c->nshards == 1 && c->win_lo == 0 && c->win_hi >= V;
-  const bool zeroed    = all_reads && c->prologue_ok && c->cand_zeroed; // the index build's prologue did it already
+  // the index build classified the owner reads already: for this shard, the whole table
+  const bool use_prologue = c->index_fast && c->win_lo == 0 && c->win_hi >= V && c->prologue_ok && c->prologue_shard == c->shard &&
+                            c->prologue_nshards == c->nshards;
+  // What the candidate kernels add to (per-read counts, chunk sums, size histograms, big-edge statistics) is zeroed by
+  // k_classify_reads, the launch in front of them: by the index build's prologue, or here.
+  const bool zeroed    = use_prologue && c->cand_zeroed; // the index build's prologue did it, and nothing has used it up
   c->cand_zeroed       = false;
-  if (!zeroed) {
-    uint32_t *const zero[4]   = {scalar<uint32_t>(c, SC_NLISTS), c->n_cand.as<uint32_t>(), c->n_edge.as<uint32_t>(),
-                                 c->n_visit_arr.as<uint32_t>()};
-    const uint32_t  n_zero[4] = {4, V + 1, V + 1, V + 1};
-    uint32_t *const ones[2]   = {nullptr, nullptr};
-    const uint32_t  n_ones[2] = {0, 0};
-    launch_index_init(st, zero, n_zero, ones, n_ones); // one launch instead of four memsets
-  }
   // the scaffold rows each owner read visits: the index build's sort left the sum per read (fast index); a shard or a
   // window of owner reads, or a generically built index (scan view patched after the sort), counts them here
   const uint32_t *bound     = all_reads ? c->visits.as<uint32_t>() : c->bound.as<uint32_t>();
-  uint64_t total_bound;
-  if (all_reads && c->prologue_ok) { // done with the index build; the numbers came back with its flags
-    total_bound = c->prologue_bound;
+  uint64_t total_bound, own_bound;
+  if (use_prologue) { // done with the index build; the numbers came back with its flags
+    total_bound = c->prologue_bound; // (the candidate scratch is laid out for ALL reads: the scan is the whole table's)
+    own_bound   = c->prologue_own;
     for (int k = 0; k < 4; ++k) c->n_list[k] = c->prologue_lists[k];
+    if (!zeroed) { // a second msgpu_calculate_edges on the same index: the lists stand, the sums start over (one launch, rare)
+      const CandZero  z         = cand_zero(c, V);
+      uint32_t *const zero[4]   = {z.n_cand, z.n_edge, z.scalar_words, nullptr};
+      const uint32_t  n_zero[4] = {V + 1, V + 1, z.n_scalar_words, 0};
+      uint32_t *const ones[2]   = {nullptr, nullptr};
+      const uint32_t  n_ones[2] = {0, 0};
+      launch_index_init(st, zero, n_zero, ones, n_ones);
+    }
   } else {
+    // the four list cursors are zero at rest (the scalar block's memset of the index build, k_emit_edges afterwards); a call
+    // that ended between k_classify_reads and k_emit_edges left them dirty
+    if (!c->nlists_clean) HIPCHK(c, hipMemsetAsync(scalar<uint32_t>(c, SC_NLISTS), 0, 16, st));
     if (!all_reads)
       launch_bound(st, c->read_off.as<uint32_t>(), c->read_cnt.as<uint32_t>(), c->vis16.as<uint4>(), V, c->shard,
                    c->nshards, c->win_lo, c->win_hi, c->bound.as<uint32_t>());
     exclusive_scan<uint64_t>(st, bound, V, c->cand_off.as<uint64_t>(), c->scan_tmp.as<uint64_t>(),
                              scalar<uint64_t>(c, SC_TOTAL_A));
+    c->nlists_clean = false;
     launch_classify_reads(st, c->read_off.as<uint32_t>(), c->read_cnt.as<uint32_t>(), bound,
                           c->cand_off.as<uint64_t>(), V, c->shard, c->nshards, c->win_lo, c->win_hi, l0, l1, l2, l3,
-                          scalar<uint32_t>(c, SC_NLISTS));
+                          scalar<uint32_t>(c, SC_NLISTS), cand_zero(c, V));
     HIPCHK(c, hipGetLastError());
     if (int rc = read_scalars(c)) return rc; // sizes of the candidate scratch
-    total_bound = *host_scalar<uint64_t>(c, SC_TOTAL_A);
+    total_bound = own_bound = *host_scalar<uint64_t>(c, SC_TOTAL_A);
     for (int k = 0; k < 4; ++k) c->n_list[k] = host_scalar<uint32_t>(c, SC_NLISTS)[k];
   }
-  c->total_bound = total_bound;
+  c->total_bound = own_bound; // the scaffold rows this context's owner reads visit
 
   const size_t tb = total_bound ? total_bound : 1;
   ENSURE(c, cand_j, tb * 4);
@@ -941,12 +1073,8 @@ int msgpu_calculate_edges(msgpu_ctx *c) {
   a.edge_scr_start = c->scr_start.as<uint32_t>();
   a.n_cand         = c->n_cand.as<uint32_t>();
   a.n_edge         = c->n_edge.as<uint32_t>();
-  a.n_visit        = c->n_visit_arr.as<uint32_t>();
   a.th_overlap     = c->p.th_overlap;
   a.big_stats      = scalar<unsigned long long>(c, SC_BIGSTATS);
-  // big-edge statistics, the big-edge list cursor and the width-class counts: slots SC_BIGSTATS .. SC_CLS, one memset
-  static_assert(SC_BIGCUR == SC_BIGSTATS + 2 && SC_CLS == SC_BIGCUR + 2 && SC_COUNT == SC_CLS + 2, "adjacent scalar slots");
-  if (!zeroed) HIPCHK(c, hipMemsetAsync(a.big_stats, 0, 48, st));
   // The LDS classes run side by side, each on a stream of its own, and the two heavy ones are launched FIRST: a
   // workgroup of class 2 needs 112 KB of LDS and one of class 1 28 KB, a CU that is full of class-0 workgroups (8 x 16 KB)
   // never has that much free while class 0's grid keeps refilling it -- launched behind class 0 the nine class-2
@@ -983,53 +1111,65 @@ int msgpu_calculate_edges(msgpu_ctx *c) {
     launch_candidates_big(st, a, l3, c->n_list[3], c->big_key.as<uint64_t>(), c->big_t.as<uint32_t>(),
                           c->big_r2s.as<uint32_t>(), c->big_pfx.as<uint32_t>());
   }
-  // edges per width class of the chain kernels: they come back with the table sizes below
-  ENSURE(c, cls_partials, (size_t(count_classes_blocks(V)) + 1) * 16);
-  launch_count_classes(st, c->n_edge.as<uint32_t>(), c->n_cand.as<uint32_t>(), c->cand_off.as<uint64_t>(),
-                       c->scr_start.as<uint32_t>(), V, c->cls_partials.as<uint32_t>());
-  {
-    const uint32_t *const in[2]  = {c->n_cand.as<uint32_t>(), c->n_edge.as<uint32_t>()};
-    uint64_t *const       out[2] = {c->em_base.as<uint64_t>(), c->edge_base.as<uint64_t>()};
-    uint64_t *const       tot[2] = {scalar<uint64_t>(c, SC_TOTAL_A), scalar<uint64_t>(c, SC_TOTAL_B)};
-    exclusive_scan_set(st, 2, in, V, out, c->scan_tmp.as<uint64_t>(), tot, c->cls_partials.as<uint32_t>(),
-                       count_classes_blocks(V), scalar<uint32_t>(c, SC_CLS));
-  }
   HIPCHK(c, hipGetLastError());
-  if (int rc = publish_scalars(c)) return rc; // sizes of the edge / EdgeMatch tables, big-edge and width-class counts
-  // While the host waits for those numbers and turns around, the GPU writes the edges and sorts them by size -- into
-  // whatever the tables hold from earlier calls.  Kernels and host compare the same counts with the same capacities:
-  // if something does not fit, the kernels write nothing and the host allocates and launches again (the first call of
-  // a context always does).
-  ENSURE(c, cls_part, size_sort_part_bytes());
-  auto emit_and_sort = [&](uint64_t cap_edges, uint64_t cap_big) {
-    launch_emit_edges(st, c->n_edge.as<uint32_t>(), c->n_cand.as<uint32_t>(), c->edge_base.as<uint64_t>(),
-                      c->em_base.as<uint64_t>(), c->cand_off.as<uint64_t>(), c->scr_v2.as<uint32_t>(),
-                      c->scr_start.as<uint32_t>(), V, c->edges.as<msgpu_edge>(), c->edge_cand.as<uint64_t>(),
-                      c->big_list.as<uint32_t>(), c->big_off.as<uint64_t>(), scalar<unsigned long long>(c, SC_BIGCUR),
-                      cap_edges, cap_big, scalar<unsigned long long>(c, SC_BIGSTATS));
-    // width classes of the chain kernels: <= 16 and 17..32 EdgeMatches share a wavefront four / two at a time, 33..64
-    // take one each; the edges are listed by size, largest first
-    // (its second kernel also zeroes the chunk sums the chain kernels add to: no launch of its own for that)
-    if (c->sub_wave)
-      launch_sort_edges_by_size(st, c->edges.as<msgpu_edge>(), c->edge_base.as<uint64_t>() + V, cap_edges,
-                                c->cls_part.as<uint32_t>(), c->cls_list.as<uint32_t>(), scalar<uint32_t>(c, SC_CLS),
-                                c->chain_chunks.as<unsigned long long>(), static_cast<uint32_t>(chunk_words(cap_edges)));
-  };
+  // ONE launch closes the stage (k_emit_edges): the scans of the per-read counts, the edge table, the list of big edges, the
+  // size-sorted edge list with its class sizes -- and the read-back: its first workgroup publishes the table sizes before the
+  // tables are written, so the GPU is busy while the host turns around.  The launch goes into whatever the tables hold from
+  // earlier calls; kernel and host compare the same counts with the same capacities: if something does not fit the kernel
+  // has written nothing and the host allocates and launches again (the first call of a context always does).
+  static const bool sync_path = getenv("MSGPU_SYNC_READBACK") != nullptr;
+  c->readback_polled = !sync_path && c->h_scalars_dev;
   auto capacities = [&](uint64_t *cap_edges, uint64_t *cap_big) {
     uint64_t ce = c->edges.room() / sizeof(msgpu_edge);
     if (c->edge_cand.cap / 8 < ce) ce = c->edge_cand.cap / 8;
-    if (c->sub_wave && c->cls_list.cap / 4 < ce) ce = c->cls_list.cap / 4;
+    if (c->cls_list.cap / 4 < ce) ce = c->cls_list.cap / 4;
     uint64_t cb = c->big_list.cap / 4;
     if (c->big_off.cap / 8 < cb) cb = c->big_off.cap / 8;
     if (c->chain_chunks.cap / 8 < chunk_words(ce)) ce = 0; // (sized with the edge table below: never the limit once both exist)
     *cap_edges = ce;
     *cap_big   = cb;
   };
+  auto emit = [&](uint64_t cap_edges, uint64_t cap_big, bool publish) {
+    EmitArgs k;
+    k.n_edge         = c->n_edge.as<uint32_t>();
+    k.n_cand         = c->n_cand.as<uint32_t>();
+    k.cand_off       = c->cand_off.as<uint64_t>();
+    k.edge_scr_v2    = c->scr_v2.as<uint32_t>();
+    k.edge_scr_start = c->scr_start.as<uint32_t>();
+    k.V              = V;
+    k.hist           = cand_hist(c, V);
+    k.chunk_sums     = cand_chunk_sums(c);
+    k.n_chunks       = cand_chunks(V);
+    k.edges          = c->edges.as<msgpu_edge>();
+    k.edge_cand      = c->edge_cand.as<uint64_t>();
+    k.list           = c->cls_list.as<uint32_t>();
+    k.big_list       = c->big_list.as<uint32_t>();
+    k.big_off        = c->big_off.as<uint64_t>();
+    k.big_cursor     = scalar<unsigned long long>(c, SC_BIGCUR);
+    k.big_stats      = scalar<unsigned long long>(c, SC_BIGSTATS);
+    k.cap_edges      = cap_edges;
+    k.cap_big        = cap_big;
+    k.chain_chunk_sums    = c->chain_chunks.as<unsigned long long>();
+    k.n_chain_chunk_words = cap_edges ? static_cast<uint32_t>(chunk_words(cap_edges)) : 0u;
+    k.scalars        = c->scalars.as<uint64_t>();
+    k.host_scalars   = (publish && c->readback_polled) ? c->h_scalars_dev : nullptr;
+    k.slot_ems       = SC_TOTAL_A;
+    k.slot_edges     = SC_TOTAL_B;
+    k.slot_cls       = SC_CLS;
+    k.n_scalars      = SC_COUNT;
+    k.seq            = (publish && c->readback_polled) ? ++c->readback_seq : 0;
+    k.nlists         = scalar<unsigned long long>(c, SC_NLISTS);
+    launch_emit_edges(st, k, publish); // (the first launch of a call: with k_cand_reduce in front)
+  };
   uint64_t cap_edges = 0, cap_big = 0;
   capacities(&cap_edges, &cap_big);
-  const bool speculated = cap_edges != 0 && cap_big != 0;
-  if (speculated) emit_and_sort(cap_edges, cap_big);
+  emit(cap_edges, cap_big, true);
+  c->nlists_clean = true; // (its first workgroup zeroes the list cursors behind the publication)
   HIPCHK(c, hipGetLastError());
+  if (!c->readback_polled) { // the synchronising read-back path: a copy behind the kernel
+    HIPCHK(c, hipMemcpyAsync(c->h_scalars, c->scalars.p, SC_COUNT * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipEventRecord(c->ev_readback, st));
+  }
   if (int rc = wait_scalars(c)) return rc;
   const uint64_t *tot = host_scalar<uint64_t>(c, SC_TOTAL_A), *big = host_scalar<uint64_t>(c, SC_BIGSTATS);
   c->n_big_edges = big[0];
@@ -1039,7 +1179,7 @@ int msgpu_calculate_edges(msgpu_ctx *c) {
   c->n_edges = tot[1];
   c->n_visit = c->total_bound; // the scaffold rows visited = the bound (scaffolds in read-id order: only owned partners)
   if (c->n_edges >= 0xfffffff0ull) return fail(c, MSGPU_E_ARG, "edge table too large (%llu)", (unsigned long long)c->n_edges);
-  if (!speculated || c->n_edges > cap_edges || c->n_big_edges >= cap_big) { // (the kernels' own test, see k_emit_edges)
+  if (c->n_edges > cap_edges || c->n_big_edges >= cap_big) { // (the kernel's own test, see k_emit_edges)
     ENSURE(c, edges, (c->n_edges ? c->n_edges : 1) * sizeof(msgpu_edge));
     ENSURE(c, edge_cand, (c->n_edges ? c->n_edges : 1) * 8);
     ENSURE(c, cls_list, (c->n_edges + 1) * 4);
@@ -1048,10 +1188,10 @@ int msgpu_calculate_edges(msgpu_ctx *c) {
     ENSURE(c, big_off, (c->n_big_edges + 1) * 8);
     ENSURE(c, chain_chunks, chunk_words(c->edges.room() / sizeof(msgpu_edge)) * 8);
     capacities(&cap_edges, &cap_big);
-    emit_and_sort(cap_edges, cap_big);
+    emit(cap_edges, cap_big, false);
   }
-  // the chain stage's chunk sums were zeroed by the size sort: msgpu_chaining_and_overlaps starts with its kernels
-  c->chain_zeroed = c->sub_wave;
+  // the chain stage's chunk sums were zeroed by k_emit_edges: msgpu_chaining_and_overlaps starts with its kernels
+  c->chain_zeroed = true;
   HIPCHK(c, hipGetLastError());
   if (c->stage_events) HIPCHK(c, hipEventRecord(c->ev[3], st));
   c->have_cand_t = c->stage_events;

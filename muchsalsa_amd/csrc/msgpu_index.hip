@@ -65,8 +65,9 @@ constexpr int      BIN_SORT_NT = 512;              // threads of k_index_sort_bi
 // rd_lo == 0 only.
 __global__ __launch_bounds__(BIN_NT) __attribute__((amdgpu_waves_per_eu(4, 8)))
 void k_index_bin(const msgpu_row *rows, uint64_t n, uint32_t V, uint32_t A, uint32_t *flags, uint32_t *err, uint32_t *anchor_first,
-                 uint32_t *cursor /*[nb]*/, uint4 *bin_rec, uint32_t rd_lo, uint32_t nb, uint32_t cap) {
+                 uint32_t *cursor /*[nb]*/, uint4 *bin_rec, uint32_t rd_lo, uint32_t nb, uint32_t cap, BinTail tail) {
   __shared__ uint32_t s_an[BIN_TILE + 2 * BIN_HALO], s_rd[BIN_TILE + 2 * BIN_HALO];
+  __shared__ uint32_t s_heads, s_last;
   __shared__ uint32_t s_cnt[BIN_NB_MAX];
   __shared__ unsigned long long s_head[(BIN_TILE + 2 * BIN_HALO) / 64]; // bit t: position t begins a scaffold (its anchor differs from t - 1's)
   __shared__ uint4    s_stage[BIN_NT / 64][64][3];
@@ -75,6 +76,7 @@ void k_index_bin(const msgpu_row *rows, uint64_t n, uint32_t V, uint32_t A, uint
   const uint32_t rd_hi = min(V, rd_lo + (nb << BIN_RPB_SHIFT));
   const int      lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (uint32_t b = threadIdx.x; b < nb; b += BIN_NT) s_cnt[b] = 0;
+  if (threadIdx.x == 0) s_heads = 0;
   STAMP(0);
   // the tile's rows: every load is in flight before the first one is used (a row is read once)
   msgpu_row row[BIN_PT];
@@ -106,10 +108,17 @@ void k_index_bin(const msgpu_row *rows, uint64_t n, uint32_t V, uint32_t A, uint
   // where scaffolds begin, as bit masks (a wavefront covers 64 consecutive positions: one ballot per word).  Position 0 counts
   // as a beginning: a scaffold that reaches it is longer than the context and is reported as such below.
   static_assert((BIN_TILE + 2 * BIN_HALO) % 64 == 0 && BIN_HALO % 64 == 0, "whole words");
+  uint32_t my_heads = 0; // scaffolds that begin among this tile's own rows (lane 0 of a wavefront counts its words)
   for (int t = threadIdx.x; t < BIN_TILE + 2 * BIN_HALO; t += BIN_NT) {
-    const unsigned long long m = __ballot(t == 0 || s_an[t] != s_an[t - 1]);
+    const bool               head = t == 0 || s_an[t] != s_an[t - 1];
+    const unsigned long long m    = __ballot(head);
     if (lane == 0) s_head[t >> 6] = m;
+    const bool own = t >= BIN_HALO && t < BIN_HALO + BIN_TILE && i0 + static_cast<uint64_t>(t - BIN_HALO) < n;
+    my_heads += static_cast<uint32_t>(__popcll(__ballot(head && own)));
   }
+  // IXF_SPARSE without a filled table to look into: the rows are grouped by anchor with ascending ids (else IXF_UNSORTED), so
+  // the scaffolds that begin are the distinct anchor ids -- all A of them have a row iff A scaffolds begin (k_index_epilogue)
+  if (lane == 0 && rd_lo == 0 && my_heads) atomicAdd(&s_heads, my_heads);
   uint32_t bk[BIN_PT], lr[BIN_PT];
 #pragma unroll
   for (int k = 0; k < BIN_PT; ++k) {
@@ -228,50 +237,49 @@ void k_index_bin(const msgpu_row *rows, uint64_t n, uint32_t V, uint32_t A, uint
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   STAMP(4);
 #endif
-}
-
-// ---- bucket counts -> first by_read row of every bucket (workgroup 0; nb <= BIN_NB_MAX) --------------------------------
-// row_base: by_read rows of the passes before this one (device word, updated for the next pass).  The workgroups behind the
-// first (the job's first pass launches them) are k_check_anchor_first over the anchors: the closing entry of the scaffold
-// starts k_index_bin left, IXF_SPARSE for an anchor id without a row -- independent of the scan, so in its launch.
-__global__ __launch_bounds__(1024) void k_bin_scan(const uint32_t *cursor, uint32_t nb, uint32_t cap, uint32_t *bin_start /*[nb + 1]*/,
-                                                   uint32_t *row_base, uint32_t *read_off_end /*&read_off[V] or null*/,
-                                                   uint32_t *flags, uint32_t *anchor_first, uint32_t A, uint32_t n_rows) {
-  if (blockIdx.x != 0) {
-    const uint32_t a = (blockIdx.x - 1) * 1024 + threadIdx.x;
-    if (a == A)
-      anchor_first[A] = n_rows;
-    else if (a < A && anchor_first[a] == 0xffffffffu)
-      atomicOr(flags, IXF_SPARSE);
-    return;
-  }
-  __shared__ uint32_t s_wave[16];
-  constexpr int PT = BIN_NB_MAX / 1024;
-  uint32_t      c[PT], sum = 0;
-  bool          over = false;
-#pragma unroll
-  for (int k = 0; k < PT; ++k) {
-    const uint32_t b = threadIdx.x * PT + k;
-    c[k]             = b < nb ? cursor[b] : 0u;
-    over |= c[k] > cap;
-    sum += c[k];
-  }
-  uint32_t total;
-  uint32_t base = block_excl_scan<1024>(sum, s_wave, &total) + *row_base;
+  // ---- the LAST workgroup to get here turns the bucket counts into the first by_read row of every bucket (what used to be
+  // k_bin_scan's launch): every workgroup's counter updates are out (they returned values) and ordered in front of its ticket
+  // (No fence: an agent-scope release writes the L2 back on this part -- it doubled the kernel's time, profiles/r5_04.  None
+  // is needed: the counters were updated with atomics whose values came back, so they are done; the ticket is one more atomic
+  // behind them in program order; the tail reads the counters with agent-scope loads.)
   __syncthreads();
-#pragma unroll
-  for (int k = 0; k < PT; ++k) {
-    const uint32_t b = threadIdx.x * PT + k;
-    if (b < nb) bin_start[b] = base;
-    base += c[k];
-  }
   if (threadIdx.x == 0) {
-    const uint32_t end = *row_base + total;
-    bin_start[nb]      = end;
-    *row_base          = end;
-    if (read_off_end) *read_off_end = end;
+    // one word: finished workgroups in the low half, scaffolds that began (first pass) in the high half
+    const unsigned long long t = atomicAdd(tail.done_heads, (static_cast<unsigned long long>(rd_lo == 0 ? s_heads : 0u) << 32) | 1ull);
+    s_last = static_cast<uint32_t>(t) == gridDim.x - 1 ? 1u : 0u;
   }
-  if (over) atomicOr(flags, IXF_BINFAIL);
+  __syncthreads();
+  if (!s_last) return;
+  {
+    uint32_t *s_wave = s_slot[0]; // (idle by now)
+    constexpr int PT = BIN_NB_MAX / BIN_NT;
+    uint32_t      c[PT], sum = 0;
+    bool          over = false;
+#pragma unroll
+    for (int k = 0; k < PT; ++k) {
+      const uint32_t b = threadIdx.x * PT + k;
+      c[k]             = b < nb ? __hip_atomic_load(&cursor[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+      over |= c[k] > cap;
+      sum += c[k];
+    }
+    uint32_t       total;
+    const uint32_t rb   = *tail.row_base;
+    uint32_t       base = block_excl_scan<BIN_NT>(sum, s_wave, &total) + rb;
+#pragma unroll
+    for (int k = 0; k < PT; ++k) {
+      const uint32_t b = threadIdx.x * PT + k;
+      if (b < nb) tail.bin_start[b] = base;
+      base += c[k];
+    }
+    if (threadIdx.x == 0) {
+      const uint32_t end = rb + total;
+      tail.bin_start[nb] = end;
+      *tail.row_base     = end;
+      if (tail.read_off_end) *tail.read_off_end = end;
+      *reinterpret_cast<uint32_t *>(tail.done_heads) = 0; // the low half: zero at rest, the next launch counts from nothing
+    }
+    if (over) atomicOr(flags, IXF_BINFAIL);
+  }
 }
 
 // ---- pass 2: one workgroup per coarse bucket -----------------------------------------------------------------------------
@@ -446,11 +454,12 @@ __device__ __forceinline__ bool sort_bin_read(uint32_t r, uint32_t n, uint32_t b
   return true;
 }
 
-__global__ __launch_bounds__(BIN_SORT_NT) void k_index_sort_bin(const uint32_t *cursor, const uint32_t *bin_start, uint32_t V,
+__global__ __launch_bounds__(BIN_SORT_NT) void k_index_sort_bin(uint32_t *cursor, const uint32_t *bin_start, uint32_t V,
                                                                 uint32_t rd_lo, uint32_t cap, const uint4 *bin_rec, IRow *by_read,
                                                                 IRow *by_anchor, uint4 *vis, uint32_t *read_off, uint32_t *read_cnt,
                                                                 int32_t *read_len, uint32_t *read_first, uint32_t *visits,
-                                                                const msgpu_row *rows, uint32_t *flags, uint32_t *err) {
+                                                                const msgpu_row *rows, uint32_t *flags, uint32_t *err,
+                                                                uint32_t *bucket_visits /*[all buckets of the job]*/) {
   constexpr uint32_t RPB = 1u << BIN_RPB_SHIFT;
   extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
   __shared__ uint32_t s_rcnt[RPB], s_roff[RPB + 1], s_fill[RPB], s_stop;
@@ -500,6 +509,7 @@ __global__ __launch_bounds__(BIN_SORT_NT) void k_index_sort_bin(const uint32_t *
     }
   }
   __syncthreads();
+  if (threadIdx.x == 0) cursor[b] = 0; // zero at rest: every thread has read the count; the next build bins from nothing
   STAMP(1);
   if (threadIdx.x < 64) { // RPB <= 64 reads: one wavefront scans the counts
     const uint32_t c   = lane < static_cast<int>(nr) ? s_rcnt[lane] : 0u;
@@ -548,6 +558,14 @@ __global__ __launch_bounds__(BIN_SORT_NT) void k_index_sort_bin(const uint32_t *
     read_first[r0 + threadIdx.x] = static_cast<uint32_t>(fk >> 32);
     read_len[r0 + threadIdx.x]   = fk == ~0ull ? 0 : rows[static_cast<uint32_t>(fk)].read_len;
   }
+  // the bucket's share of the candidate scan's visits: k_index_epilogue scans the per-read counts with these as its carries.
+  // (`visits` of this bucket's reads were written by this workgroup's wavefronts in front of the barrier above: an agent-scope
+  // load sees them whatever cache the stores went through.)
+  if (threadIdx.x < 64) {
+    uint32_t v = threadIdx.x < nr ? __hip_atomic_load(&visits[r0 + threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0u;
+    v          = wave_sum(v);
+    if (threadIdx.x == 0) bucket_visits[r0 >> BIN_RPB_SHIFT] = v;
+  }
 #ifdef MSGPU_STAMPS
   __syncthreads();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -587,22 +605,20 @@ bool index_sort_bin_prepare(uint32_t cap) {
 }
 void launch_index_bin(hipStream_t st, const msgpu_row *rows, uint64_t n, uint32_t V, uint32_t A, uint32_t *flags, uint32_t *err,
                       uint32_t *anchor_first, uint32_t *cursor, uint4 *bin_rec, uint32_t rd_lo, uint32_t nb, uint32_t cap,
-                      uint32_t *bin_start, uint32_t *row_base, uint32_t *read_off_end, bool check_anchors) {
-  if (n)
-    hipLaunchKernelGGL(k_index_bin, dim3(static_cast<uint32_t>((n + BIN_TILE - 1) / BIN_TILE)), dim3(BIN_NT), 0, st, rows, n, V, A,
-                       flags, err, anchor_first, cursor, bin_rec, rd_lo, nb, cap);
-  const uint32_t check_blocks = check_anchors ? static_cast<uint32_t>((static_cast<uint64_t>(A) + 1 + 1023) / 1024) : 0;
-  hipLaunchKernelGGL(k_bin_scan, dim3(1 + check_blocks), dim3(1024), 0, st, cursor, nb, cap, bin_start, row_base, read_off_end, flags,
-                     anchor_first, A, static_cast<uint32_t>(n));
+                      const BinTail &tail) {
+  // (n == 0: one workgroup without rows still runs the tail -- bin_start and the closing read_off entry are written)
+  hipLaunchKernelGGL(k_index_bin, dim3(n ? static_cast<uint32_t>((n + BIN_TILE - 1) / BIN_TILE) : 1), dim3(BIN_NT), 0, st, rows, n, V, A,
+                     flags, err, anchor_first, cursor, bin_rec, rd_lo, nb, cap, tail);
 }
-void launch_index_sort_bin(hipStream_t st, const uint32_t *cursor, const uint32_t *bin_start, uint32_t V, uint32_t rd_lo, uint32_t nb,
+void launch_index_sort_bin(hipStream_t st, uint32_t *cursor, const uint32_t *bin_start, uint32_t V, uint32_t rd_lo, uint32_t nb,
                            uint32_t cap, const uint4 *bin_rec, IRow *by_read, IRow *by_anchor, uint4 *vis, uint32_t *read_off,
                            uint32_t *read_cnt, int32_t *read_len, uint32_t *read_first, uint32_t *visits, const msgpu_row *rows,
-                           uint32_t *flags, uint32_t *err) {
+                           uint32_t *flags, uint32_t *err, uint32_t *bucket_visits) {
   if (!nb) return;
   const size_t lds = static_cast<size_t>(cap) * BIN_LDS_PER_ROW; // (granted by index_sort_bin_prepare, which the host asks first)
   hipLaunchKernelGGL(k_index_sort_bin, dim3(nb), dim3(BIN_SORT_NT), lds, st, cursor, bin_start, V,
-                     rd_lo, cap, bin_rec, by_read, by_anchor, vis, read_off, read_cnt, read_len, read_first, visits, rows, flags, err);
+                     rd_lo, cap, bin_rec, by_read, by_anchor, vis, read_off, read_cnt, read_len, read_first, visits, rows, flags, err,
+                     bucket_visits);
 }
 
 } // namespace msgpu

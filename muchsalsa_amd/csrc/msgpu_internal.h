@@ -37,9 +37,41 @@ struct CandArgs {
   uint32_t       *cand_t;       // sorted candidates: row of v2 in by_anchor
   uint32_t       *edge_scr_v2;  // per-read edge scratch: v2
   uint32_t       *edge_scr_start; // per-read edge scratch: first candidate of the edge
-  uint32_t       *n_cand, *n_edge, *n_visit; // per read
+  uint32_t       *n_cand, *n_edge; // per read
   unsigned long long *big_stats; // [0] edges with > 64 EdgeMatches, [1] their EdgeMatches (this launch set)
   uint32_t        th_overlap;
+};
+constexpr uint32_t CAND_CHUNK = 256;     // read ids per chunk of the candidate stage's sums = per workgroup of k_emit_edges
+constexpr uint32_t SC_PUBLISH_MAX = 64;  // scalar words a fused read-back can publish (one wavefront)
+// what k_classify_reads zeroes for the candidate kernels (they ADD to it)
+struct CandZero {
+  uint32_t *n_cand, *n_edge;   // per read, V + 1 entries
+  uint32_t *scalar_words;      // big-edge statistics / cursors / class counts in the scalar block
+  uint32_t  n_scalar_words;
+};
+// k_emit_edges: the candidate stage's closing launch (scans, edge table, size-sorted edge list, read-back)
+struct EmitArgs {
+  const uint32_t *n_edge, *n_cand;
+  const uint64_t *cand_off;
+  const uint32_t *edge_scr_v2, *edge_scr_start;
+  uint32_t        V;
+  const uint32_t *hist;
+  const unsigned long long *chunk_sums;
+  uint32_t        n_chunks;             // ceil(V / CAND_CHUNK)
+  msgpu_edge     *edges;
+  uint64_t       *edge_cand;
+  uint32_t       *list;                 // the edges of <= 64 EdgeMatches by size, largest first
+  uint32_t       *big_list;
+  uint64_t       *big_off;
+  unsigned long long *big_cursor;       // [2]
+  const unsigned long long *big_stats;  // [2]
+  uint64_t        cap_edges, cap_big;
+  unsigned long long *chain_chunk_sums; // zeroed here for the chain kernels
+  uint32_t        n_chain_chunk_words;
+  uint64_t       *scalars, *host_scalars; // the read-back (see CompactArgs)
+  uint32_t        slot_ems, slot_edges, slot_cls, n_scalars;
+  uint64_t        seq;
+  unsigned long long *nlists;           // the four list cursors of k_classify_reads (2 words): zero at rest, zeroed here
 };
 
 struct ChainArgs {
@@ -135,7 +167,6 @@ template <class T> void exclusive_scan(hipStream_t st, const uint32_t *in, uint6
 void exclusive_scan_set(hipStream_t st, int k, const uint32_t *const *in, uint64_t n, uint64_t *const *out, uint64_t *block_sums,
                         uint64_t *const *d_total, const uint32_t *partials = nullptr, uint32_t n_partials = 0,
                         uint32_t *partial_totals = nullptr);
-uint32_t count_classes_blocks(uint32_t V);
 uint32_t scan_blocks(uint64_t n);
 
 void launch_max_ids(hipStream_t st, const msgpu_row *rows, uint64_t n, uint32_t *max_ids);
@@ -151,15 +182,52 @@ constexpr uint32_t IXF_BINFAIL  = 64u; // bin path (msgpu_index.hip): a bucket b
 constexpr uint32_t BIN_NB_MAX    = 8192; // coarse buckets per pass (k_index_bin's LDS histogram)
 constexpr uint32_t BIN_RPB_SHIFT = 4;    // 16 read ids per coarse bucket
 constexpr uint32_t BIN_PASSES_MAX = 8;   // passes over the row table (BIN_NB_MAX * 16 = 131,072 reads each); more reads: the atomic path
+// what the last workgroup of k_index_bin needs to turn the bucket counts into bucket starts (the former k_bin_scan), and the
+// two zero-at-rest counters of the launch
+struct BinTail {
+  uint32_t *bin_start;     // [nb + 1]
+  uint32_t *row_base;      // by_read rows of the passes before this one (device word, updated for the next pass)
+  uint32_t *read_off_end;  // &read_off[V] in the last pass, else null
+  unsigned long long *done_heads; // low half: workgroups that have finished (the last one runs the tail and resets it); high
+                                  // half: scaffolds that begin (first pass) -- k_index_epilogue compares it with the anchor count
+};
+// k_index_epilogue: everything element-wise behind the sort of a bin-path build in ONE launch -- the Registry-order check over
+// the reads, the scaffold offsets over the anchors, the scan of the per-read visit counts (carries from the buckets' sums),
+// the classification of the owner reads for the candidate kernels, and the read-back of flags and sizes by the last workgroup
+struct IndexEpilogueArgs {
+  const uint32_t *read_first;
+  uint32_t        V, A, n_rows;
+  uint32_t       *err, *flags;
+  const uint32_t *anchor_first, *anchor_off_gen;
+  uint32_t       *anchor_off, *n_alive;
+  uint32_t       *heads, *row_base;       // consumed here (IXF_SPARSE), both zeroed for the next build
+  const uint32_t *visits, *bucket_visits;
+  uint32_t        n_buckets;
+  uint64_t       *cand_off;               // [V + 1] out
+  uint64_t       *total;                  // sum of all visits
+  int             classify;               // 0: offsets and checks only (a window job classifies per window)
+  const uint32_t *read_off, *read_cnt;
+  uint32_t        shard, nshards;
+  CandDesc       *list0, *list1, *list2;
+  uint32_t       *list3, *n_lists;
+  unsigned long long *own_total;          // visits of the reads classified (= total without shards)
+  CandZero        z;
+  uint32_t       *done;                   // zero at rest
+  uint64_t       *scalars, *host_scalars;
+  uint32_t        n_scalars;
+  uint64_t        seq;
+  uint64_t        zero_mask;              // scalar words zeroed behind the publication (bit = slot): error bits, flags, counters
+};
+void launch_index_epilogue(hipStream_t st, const IndexEpilogueArgs &a);
 uint32_t bin_capacity(uint64_t n, uint32_t V); // rows a coarse bucket can hold; 0 = the bin path does not apply
 bool index_sort_bin_prepare(uint32_t cap);   // k_index_sort_bin can be launched with such buckets on the current device (asks for > 64 KB of LDS where needed)
 void launch_index_bin(hipStream_t st, const msgpu_row *rows, uint64_t n, uint32_t V, uint32_t A, uint32_t *flags, uint32_t *err,
                       uint32_t *anchor_first, uint32_t *cursor, uint4 *bin_rec, uint32_t rd_lo, uint32_t nb, uint32_t cap,
-                      uint32_t *bin_start, uint32_t *row_base, uint32_t *read_off_end, bool check_anchors);
-void launch_index_sort_bin(hipStream_t st, const uint32_t *cursor, const uint32_t *bin_start, uint32_t V, uint32_t rd_lo, uint32_t nb,
+                      const BinTail &tail);
+void launch_index_sort_bin(hipStream_t st, uint32_t *cursor, const uint32_t *bin_start, uint32_t V, uint32_t rd_lo, uint32_t nb,
                            uint32_t cap, const uint4 *bin_rec, IRow *by_read, IRow *by_anchor, uint4 *vis, uint32_t *read_off,
                            uint32_t *read_cnt, int32_t *read_len, uint32_t *read_first, uint32_t *visits, const msgpu_row *rows,
-                           uint32_t *flags, uint32_t *err);
+                           uint32_t *flags, uint32_t *err, uint32_t *bucket_visits);
 void launch_publish_scalars(hipStream_t st, const uint64_t *src, uint64_t *dst_host, uint32_t n, uint64_t seq);
 void launch_index_init(hipStream_t st, uint32_t *const zero[4], const uint32_t n_zero[4], uint32_t *const ones[2],
                        const uint32_t n_ones[2]);
@@ -190,24 +258,15 @@ void launch_bound(hipStream_t st, const uint32_t *read_off, const uint32_t *read
                   uint32_t shard, uint32_t nshards, uint32_t lo, uint32_t hi, uint32_t *bound);
 void launch_classify_reads(hipStream_t st, const uint32_t *read_off, const uint32_t *read_cnt, const uint32_t *bound,
                            const uint64_t *cand_off, uint32_t V, uint32_t shard, uint32_t nshards, uint32_t lo,
-                           uint32_t hi, CandDesc *l0, CandDesc *l1, CandDesc *l2, uint32_t *l3, uint32_t *n_lists);
+                           uint32_t hi, CandDesc *l0, CandDesc *l1, CandDesc *l2, uint32_t *l3, uint32_t *n_lists, const CandZero &z);
 void launch_candidates(hipStream_t st, const CandArgs &a, int cls, const CandDesc *list, uint32_t n_list);
 void launch_candidates_big(hipStream_t st, const CandArgs &a, const uint32_t *list, uint32_t n_list, uint64_t *big_key,
                            uint32_t *big_t, uint32_t *big_r2s, uint32_t *big_pfx);
-void launch_count_classes(hipStream_t st, const uint32_t *n_edge, const uint32_t *n_cand, const uint64_t *cand_off,
-                          const uint32_t *scr_start, uint32_t V, uint32_t *partials);
-void launch_emit_edges(hipStream_t st, const uint32_t *n_edge, const uint32_t *n_cand, const uint64_t *edge_base,
-                       const uint64_t *em_base, const uint64_t *cand_off, const uint32_t *scr_v2,
-                       const uint32_t *scr_start, uint32_t V, msgpu_edge *edges, uint64_t *edge_cand,
-                       uint32_t *big_list, uint64_t *big_off, unsigned long long *big_cursor, uint64_t cap_edges,
-                       uint64_t cap_big, const unsigned long long *big_stats);
+void launch_emit_edges(hipStream_t st, const EmitArgs &a, bool reduce); // reduce: k_cand_reduce in front (a repeat after a reallocation needs none)
 constexpr uint32_t PAIR_TAB_STRIDE = 2016 + 128; // pairs k < l < 64 + padding read by lanes past the last pair
 void launch_fill_pair_tab(hipStream_t st, uint32_t *tab);
 void launch_chain(hipStream_t st, const ChainArgs &a, const uint32_t *list, uint32_t n_list);
 void launch_chain_sub(hipStream_t st, const ChainArgs &a, int width, const uint32_t *list, uint32_t n_list);
-void launch_sort_edges_by_size(hipStream_t st, const msgpu_edge *edges, const uint64_t *d_n_edges, uint64_t cap_edges,
-                               uint32_t *part, uint32_t *list, uint32_t *counts, unsigned long long *chunk_sums, uint32_t n_chunk_words);
-size_t size_sort_part_bytes();
 size_t big_elem_bytes();
 size_t big_path_bytes();
 void launch_chain_big(hipStream_t st, const ChainArgs &a, const uint32_t *big_list, const uint64_t *big_off,

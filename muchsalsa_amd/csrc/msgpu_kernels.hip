@@ -978,9 +978,8 @@ __global__ __launch_bounds__(NT) void k_candidates(CandArgs a, const CandDesc *d
     }
   }
   if (tid == 0) {
-    a.n_cand[r]  = tot;
-    a.n_edge[r]  = ng;
-    a.n_visit[r] = T;
+    a.n_cand[r] = tot;
+    a.n_edge[r] = ng;
   }
 }
 
@@ -995,13 +994,18 @@ __global__ __launch_bounds__(1024) void k_classify_reads(const uint32_t *read_of
                                                          const uint32_t *bound, const uint64_t *cand_off, uint32_t V,
                                                          uint32_t shard, uint32_t nshards, uint32_t lo, uint32_t hi,
                                                          CandDesc *list0, CandDesc *list1, CandDesc *list2,
-                                                         uint32_t *list3, uint32_t *n_lists /*[4]*/) {
+                                                         uint32_t *list3, uint32_t *n_lists /*[4]*/, CandZero z) {
   // the four list cursors are single words (~88 atomics/us each): count inside the workgroup in LDS first, then one
   // global atomic per workgroup and class
   __shared__ uint32_t s_cnt[4], s_base[4];
   if (threadIdx.x < 4) s_cnt[threadIdx.x] = 0;
   __syncthreads();
   uint32_t r   = blockIdx.x * 1024 + threadIdx.x;
+  // What the candidate kernels ADD to starts from zero here -- this launch is in front of them on every path: the per-read
+  // counts of the reads no workgroup will take (not owned, nothing to visit) and the block of big-edge statistics / cursors /
+  // class counts in the scalars.
+  if (r <= V) z.n_cand[r] = z.n_edge[r] = 0;
+  if (blockIdx.x == 0 && threadIdx.x < z.n_scalar_words) z.scalar_words[threadIdx.x] = 0;
   int      cls = -1;
   uint32_t n1 = 0, bd = 0;
   if (r < V && r >= lo && r < hi && r % nshards == shard) {
@@ -1036,6 +1040,142 @@ __global__ __launch_bounds__(1024) void k_classify_reads(const uint32_t *read_of
     d.pad   = 0;
     (cls == 0 ? list0 : cls == 1 ? list1 : list2)[s_base[cls] + local] = d;
   }
+}
+
+// The closing launch of a bin-path index build (see IndexEpilogueArgs).  Thread i takes read i and anchor i.
+//   reads:   ids must follow first-line order (Registry.cpp:36-45); an id without any row (0xffffffff from the sort) = not dense
+//   anchors: the scaffold offsets are the speculative ones of pass 1; IXF_SPARSE when fewer scaffolds began than there are ids
+//   scan:    cand_off = exclusive prefix of the visit counts -- the carry of a workgroup's 1024 reads is the sum of the buckets
+//            in front of them (k_index_sort_bin left one sum per bucket of 16 reads), the rest a block scan: no scan launches
+//   classes: k_classify_reads' body, with the offset straight out of the scan
+//   read-back: the LAST workgroup to finish publishes the scalar block (flags, error bits, sizes, list lengths) and zeroes
+//            what the next build counts from nothing
+__global__ __launch_bounds__(1024) void k_index_epilogue(IndexEpilogueArgs a) {
+  __shared__ uint32_t           s_cnt[4], s_base[4], s_wave[16], s_last;
+  __shared__ unsigned long long s_carry[16];
+  const uint32_t i    = blockIdx.x * 1024 + threadIdx.x;
+  const int      lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x < 4) s_cnt[threadIdx.x] = 0;
+  // What the LAST workgroup publishes must be done when a workgroup takes its ticket.  No fence for that (an agent-scope release
+  // writes the L2 back: 40 us of this kernel's 49 in profiles/r5_04): every scalar is written with an atomic whose old value
+  // comes BACK (so it has been performed where every CU sees it), collected in `dep`, which the ticket waits for.
+  uint32_t dep = 0;
+  // ---- reads: Registry order -------------------------------------------------------------------------------------------------
+  if (i + 1 < a.V) {
+    const uint32_t f0 = a.read_first[i], f1 = a.read_first[i + 1];
+    if (f0 != 0xffffffffu && f1 != 0xffffffffu && f1 <= f0) dep |= atomicOr(a.err, 1u);
+  }
+  // ---- anchors: scaffold offsets (speculative / generic), the closing entry, sparse ids ------------------------------------------
+  const uint32_t heads = *a.heads;
+  if (i == 0 && heads != a.A) dep |= atomicOr(a.flags, IXF_SPARSE);
+  const bool fast = (*a.flags & ~IXF_DUPS) == 0 && heads == a.A;
+  if (i <= a.A) a.anchor_off[i] = fast ? (i == a.A ? a.n_rows : a.anchor_first[i]) : a.anchor_off_gen[i];
+  if (i == 0 && fast) dep |= atomicExch(a.n_alive, a.n_rows);
+  // ---- scan of the visit counts ------------------------------------------------------------------------------------------------
+  unsigned long long carry = 0, all = 0;
+  {
+    constexpr uint32_t BPW = 1024u >> BIN_RPB_SHIFT; // buckets per workgroup
+    const uint32_t     before = min(a.n_buckets, blockIdx.x * BPW);
+    for (uint32_t b = threadIdx.x; b < a.n_buckets; b += 1024) {
+      const unsigned long long v = a.bucket_visits[b];
+      carry += b < before ? v : 0ull;
+      all += v;
+    }
+    for (int d = 32; d > 0; d >>= 1) {
+      carry += __shfl_xor(carry, d);
+      all += __shfl_xor(all, d);
+    }
+    if (lane == 0) s_carry[wave] = carry;
+    __syncthreads();
+    carry = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) carry += s_carry[w];
+    if (blockIdx.x == 0) { // (the total, for workgroup 0 only: one more round through LDS)
+      __syncthreads();
+      if (lane == 0) s_carry[wave] = all;
+      __syncthreads();
+      all = 0;
+#pragma unroll
+      for (int w = 0; w < 16; ++w) all += s_carry[w];
+      if (threadIdx.x == 0) dep |= static_cast<uint32_t>(atomicExch(reinterpret_cast<unsigned long long *>(a.total), all));
+    }
+  }
+  const uint32_t vis = i < a.V ? a.visits[i] : 0u;
+  uint32_t       blk_total;
+  const uint32_t ex = block_excl_scan<1024>(vis, s_wave, &blk_total);
+  const uint64_t co = carry + ex;
+  if (i <= a.V) a.cand_off[i] = co;
+  // ---- classification (k_classify_reads) --------------------------------------------------------------------------------------
+  if (a.classify) {
+    if (i <= a.V) a.z.n_cand[i] = a.z.n_edge[i] = 0;
+    if (blockIdx.x == 0 && threadIdx.x < a.z.n_scalar_words) a.z.scalar_words[threadIdx.x] = 0;
+    int      cls = -1;
+    uint32_t n1  = 0;
+    if (i < a.V && i % a.nshards == a.shard) {
+      n1 = a.read_cnt[i];
+      if (n1 != 0 && vis != 0) cls = (n1 <= 256 && vis <= 512) ? 0 : (n1 <= 256 && vis <= 1024) ? 1 : (n1 <= 1024 && vis <= 4096) ? 2 : 3;
+    }
+    uint32_t local = 0;
+    if (a.nshards > 1) { // the visits of THIS shard's owner reads (without shards: the total, the host knows that)
+      // one atomic per workgroup: a single word takes ~88 atomics/us, one per wavefront made this kernel five times as long
+      unsigned long long own = cls >= 0 ? vis : 0u;
+      for (int d = 32; d > 0; d >>= 1) own += __shfl_xor(own, d);
+      if (lane == 0) s_carry[wave] = own;
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        own = 0;
+        for (int w = 0; w < 16; ++w) own += s_carry[w];
+        if (own) dep |= static_cast<uint32_t>(atomicAdd(a.own_total, own));
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const unsigned long long m = __ballot(cls == k);
+      if (!m) continue; // wave-uniform
+      uint32_t base = 0;
+      if (lane == __builtin_ctzll(m)) base = atomicAdd(&s_cnt[k], static_cast<uint32_t>(__popcll(m)));
+      base = rl_u32(base, __builtin_ctzll(m));
+      if (cls == k) local = base + static_cast<uint32_t>(__popcll(m & ((1ull << lane) - 1)));
+    }
+    __syncthreads();
+    if (threadIdx.x < 4 && s_cnt[threadIdx.x]) s_base[threadIdx.x] = atomicAdd(&a.n_lists[threadIdx.x], s_cnt[threadIdx.x]);
+    __syncthreads();
+    if (cls == 3) {
+      a.list3[s_base[3] + local] = i;
+    } else if (cls >= 0) {
+      CandDesc d;
+      d.r     = i;
+      d.rb    = a.read_off[i];
+      d.n1    = n1;
+      d.bound = vis;
+      d.co    = co;
+      d.pad   = 0;
+      (cls == 0 ? a.list0 : cls == 1 ? a.list1 : a.list2)[s_base[cls] + local] = d;
+    }
+  }
+  // ---- the last workgroup publishes --------------------------------------------------------------------------------------------
+  asm volatile("" ::"v"(dep)); // (the atomics' old values have arrived: they are performed)
+  __syncthreads();
+  if (threadIdx.x == 0) s_last = atomicAdd(a.done, 1u) == gridDim.x - 1 ? 1u : 0u;
+  __syncthreads();
+  if (!s_last) return;
+  if (threadIdx.x < 64) {
+    uint64_t v = 0;
+    if (static_cast<uint32_t>(lane) < a.n_scalars) v = __hip_atomic_load(&a.scalars[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (a.host_scalars && a.seq) {
+      if (static_cast<uint32_t>(lane) < a.n_scalars) a.host_scalars[lane] = v;
+      __threadfence_system();
+      if (lane == 0) __hip_atomic_store(&a.host_scalars[a.n_scalars], a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    // zero at rest: the error bits, the index flags and the counters of this build (the host has them, or reads the block with a
+    // copy BEFORE this point never: the synchronising read-back path does not use this kernel's zeroing, see the host side)
+    if ((a.zero_mask >> lane) & 1ull) a.scalars[lane] = 0;
+    if (lane == 0) *a.row_base = 0;
+  }
+}
+void launch_index_epilogue(hipStream_t st, const IndexEpilogueArgs &a) {
+  const uint32_t m = (a.V > a.A ? a.V : a.A) + 1;
+  hipLaunchKernelGGL(k_index_epilogue, dim3((m + 1023) / 1024), dim3(1024), 0, st, a);
 }
 
 // big reads: same algorithm with every staging array in global memory (slow path, any size)
@@ -1151,101 +1291,237 @@ __global__ __launch_bounds__(256) void k_candidates_big(CandArgs a, const uint32
     }
   }
   if (tid == 0) {
-    a.n_cand[r]  = nc;
-    a.n_edge[r]  = s_carry;
-    a.n_visit[r] = T;
+    a.n_cand[r] = nc;
+    a.n_edge[r] = s_carry;
   }
 }
 
-// dense edge table (ascending (v1, v2)) from the per-read edge scratch
-__global__ __launch_bounds__(256) void k_emit_edges(const uint32_t *n_edge, const uint32_t *n_cand,
-                                                    const uint64_t *edge_base, const uint64_t *em_base,
-                                                    const uint64_t *cand_off, const uint32_t *edge_scr_v2,
-                                                    const uint32_t *edge_scr_start, uint32_t V, msgpu_edge *edges,
-                                                    uint64_t *edge_cand, uint32_t *big_list, uint64_t *big_off,
-                                                    unsigned long long *big_cursor /*[2]*/, uint64_t cap_edges,
-                                                    uint64_t cap_big, const unsigned long long *big_stats) {
-  // The launch may be speculative (enqueued before the host knows the table sizes, into whatever the tables hold from
-  // earlier calls): if the edges or the list of big edges do not fit, nothing is written; the host, which compares the
-  // same numbers, allocates and launches again.
-  if (edge_base[V] > cap_edges || big_stats[0] >= cap_big) return;
-  // 16 lanes per read (a read has ~10 edges)
-  uint32_t r    = blockIdx.x * 16 + (threadIdx.x >> 4);
-  int      lane = threadIdx.x & 15;
-  if (r >= V) return;
-  uint32_t ne = n_edge[r];
-  if (ne == 0) return;
-  uint32_t nc = n_cand[r];
-  uint64_t eb = edge_base[r], mb = em_base[r], co = cand_off[r];
-  for (uint32_t e = lane; e < ne; e += 16) {
-    uint32_t   st  = edge_scr_start[co + e];
-    uint32_t   en  = (e + 1 < ne) ? edge_scr_start[co + e + 1] : nc;
-    msgpu_edge ed;
-    ed.v1        = r;
-    ed.v2        = edge_scr_v2[co + e];
-    ed.em_off    = mb + st;
-    ed.order_off = 0;
-    ed.em_cnt    = en - st;
-    ed.order_cnt = 0;
-    ed.shadow    = 0;
-    ed.pad       = 0;
-    edges[eb + e]     = ed;
-    edge_cand[eb + e] = co + st;
-    if (ed.em_cnt > 64) { // the few edges k_chain_big takes: listed here, with the first scratch element of each
-      const unsigned long long i = atomicAdd(&big_cursor[0], 1ull);
-      big_list[i] = static_cast<uint32_t>(eb + e);
-      big_off[i]  = atomicAdd(&big_cursor[1], static_cast<unsigned long long>(ed.em_cnt));
+// Per chunk of CAND_CHUNK read ids: the sums of the reads' candidate and edge counts and a histogram of the chunk's edges by
+// size (1..64 EdgeMatches; larger ones take k_chain_big and are counted by the candidate kernels), written as plain rows -- what
+// k_emit_edges needs from ALL chunks before it can place anything.  (The candidate kernels adding to such rows with atomics, one
+// per edge, cost them 50 us on BASELINE.json configs[2]: 1.2 M memory-side operations beside a kernel that is bound by exactly
+// that pipe, profiles/r5_03.  This pass reads 4 bytes per edge out of L2 instead.)  16 lanes per read, as in k_emit_edges.
+__global__ __launch_bounds__(1024) void k_cand_reduce(const uint32_t *n_edge, const uint32_t *n_cand, const uint64_t *cand_off,
+                                                      const uint32_t *edge_scr_start, uint32_t V, unsigned long long *chunk_sums,
+                                                      uint32_t *hist) {
+  __shared__ uint32_t           s_h[64];
+  __shared__ unsigned long long s_sum[16][2];
+  const uint32_t chunk = blockIdx.x;
+  const int      lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = threadIdx.x & 15;
+  if (threadIdx.x < 64) s_h[threadIdx.x] = 0;
+  __syncthreads();
+  unsigned long long sc = 0, se = 0;
+#pragma unroll
+  for (uint32_t round = 0; round < CAND_CHUNK / 64; ++round) { // 64 reads per round, every load of a round in flight together
+    const uint32_t r = chunk * CAND_CHUNK + round * 64 + (threadIdx.x >> 4);
+    if (r >= V) continue;
+    const uint32_t ne = n_edge[r];
+    if (ne == 0) continue;
+    const uint32_t nc = n_cand[r];
+    const uint64_t co = cand_off[r];
+    if (sub == 0) {
+      sc += nc;
+      se += ne;
+    }
+    for (uint32_t e = sub; e < ne; e += 16) {
+      const uint32_t st = edge_scr_start[co + e], en = (e + 1 < ne) ? edge_scr_start[co + e + 1] : nc, cnt = en - st;
+      if (cnt >= 1 && cnt <= 64) atomicAdd(&s_h[cnt - 1], 1u);
     }
   }
+  for (int d = 32; d > 0; d >>= 1) {
+    sc += __shfl_xor(sc, d);
+    se += __shfl_xor(se, d);
+  }
+  if (lane == 0) {
+    s_sum[wave][0] = sc;
+    s_sum[wave][1] = se;
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) hist[static_cast<size_t>(chunk) * 64 + threadIdx.x] = s_h[threadIdx.x];
+  if (threadIdx.x == 0) {
+    unsigned long long tc = 0, te = 0;
+    for (int w = 0; w < 16; ++w) {
+      tc += s_sum[w][0];
+      te += s_sum[w][1];
+    }
+    chunk_sums[2 * chunk]     = tc;
+    chunk_sums[2 * chunk + 1] = te;
+  }
 }
 
-// Edges per width class of the chain kernels (<= 8, 9..16, 17..32, 33..64 EdgeMatches), counted from the candidate
-// scratch before the edges exist, so that the numbers come back with the table sizes and the chain stage needs no
-// read-back of its own.  counts[0..3] = 9..16, 17..32, 33..64, <= 8 (the order k_size_scatter uses).
-__global__ __launch_bounds__(1024) void k_count_classes(const uint32_t *n_edge, const uint32_t *n_cand, const uint64_t *cand_off,
-                                                        const uint32_t *edge_scr_start, uint32_t V, uint32_t *partials /*[blocks][4]*/) {
-  __shared__ uint32_t s_c[16][4];
-  uint32_t  c8 = 0, c16 = 0, c32 = 0, c64 = 0;
-  const int sub = threadIdx.x & 15; // 16 lanes per read (as in k_emit_edges), 64 reads per workgroup, every read once
-  const uint32_t r = (blockIdx.x * 1024 + threadIdx.x) >> 4;
-  if (r < V) {
-    const uint32_t ne = n_edge[r];
-    if (ne != 0) {
-      const uint32_t nc = n_cand[r];
-      const uint64_t co = cand_off[r];
-      for (uint32_t e = sub; e < ne; e += 16) {
-        const uint32_t st = edge_scr_start[co + e], en = (e + 1 < ne) ? edge_scr_start[co + e + 1] : nc, cnt = en - st;
-        c8 += (cnt >= 1 && cnt <= 8) ? 1u : 0u;
-        c16 += (cnt > 8 && cnt <= 16) ? 1u : 0u;
-        c32 += (cnt > 16 && cnt <= 32) ? 1u : 0u;
-        c64 += (cnt > 32 && cnt <= 64) ? 1u : 0u;
+// The candidate stage closes in ONE more launch: the scans of the per-read candidate / edge counts, the dense edge table (ascending
+// (v1, v2)), the list of big edges, the edges of <= 64 EdgeMatches listed by size (largest first: the width classes of the
+// chain kernels are contiguous stretches [64..33 | 32..17 | 16..9 | 8..1], the edges that share a wavefront in k_chain_sub have
+// (nearly) the same size, the longest edges of a launch start first), the class sizes, and the read-back of all the sizes.
+// A workgroup per chunk of CAND_CHUNK reads.  Every workgroup sums the rows k_cand_reduce left per chunk: the sums of the chunks before its own are its bases -- first edge, first EdgeMatch, and per size the first
+// list position of the chunk's edges of that size -- the sums over all chunks the table sizes; workgroup 0 writes those into the
+// scalar block and publishes it to the host at once (k_publish_scalars' protocol), the host turns around while the tables are
+// written.  The launch may be speculative (into whatever the tables hold from earlier calls): if the edges or the list of big
+// edges do not fit nothing is written; the host, which compares the same numbers, allocates and launches again.
+__global__ __launch_bounds__(1024) void k_emit_edges(EmitArgs a) {
+  __shared__ unsigned long long s_red[16][4];
+  __shared__ uint32_t           s_hb[16][64], s_ht[16][64], s_pos[64], s_w[2][4];
+  __shared__ uint32_t           s_ne[CAND_CHUNK], s_nc[CAND_CHUNK], s_eb[CAND_CHUNK], s_mb[CAND_CHUNK];
+  static_assert(CAND_CHUNK == 256, "the first four wavefronts hold a read per lane");
+  const int      lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t chunk = blockIdx.x;
+  // the chain stage's chunk sums start from zero (this is the last launch in front of the chain kernels)
+  for (uint32_t i = blockIdx.x * 1024 + threadIdx.x; i < a.n_chain_chunk_words; i += gridDim.x * 1024) a.chain_chunk_sums[i] = 0;
+  // ---- sums over the chunks: candidates and edges before this chunk / in all chunks ---------------------------------------
+  unsigned long long t[4] = {0, 0, 0, 0};
+  for (uint32_t c = threadIdx.x; c < a.n_chunks; c += 1024) {
+    const unsigned long long nc = a.chunk_sums[2 * c], ne = a.chunk_sums[2 * c + 1];
+    if (c < chunk) {
+      t[0] += nc;
+      t[1] += ne;
+    }
+    t[2] += nc;
+    t[3] += ne;
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    for (int d = 32; d > 0; d >>= 1) t[k] += __shfl_xor(t[k], d);
+    if (lane == 0) s_red[wave][k] = t[k];
+  }
+  // ---- the size histograms: per size, the edges of the chunks before this one / of all chunks (a wavefront takes every
+  // sixteenth chunk, a lane one size) -------------------------------------------------------------------------------------
+  {
+    uint32_t hb = 0, ht = 0;
+    for (uint32_t c0 = wave; c0 < a.n_chunks; c0 += 64) { // four rows in flight per trip
+      uint32_t v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const uint32_t c = c0 + 16 * u;
+        v[u]             = c < a.n_chunks ? a.hist[static_cast<size_t>(c) * 64 + lane] : 0u;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        hb += c0 + 16 * u < chunk ? v[u] : 0u;
+        ht += v[u];
+      }
+    }
+    s_hb[wave][lane] = hb;
+    s_ht[wave][lane] = ht;
+  }
+  __syncthreads();
+  unsigned long long base_m = 0, base_e = 0, tot_m = 0, tot_e = 0;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) {
+    base_m += s_red[w][0];
+    base_e += s_red[w][1];
+    tot_m += s_red[w][2];
+    tot_e += s_red[w][3];
+  }
+  uint32_t c8 = 0, c16 = 0, c32 = 0, c64 = 0;
+  if (wave == 0) { // lane = size - 1: first list position of this chunk's edges of the size, sizes DESCENDING
+    uint32_t before = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+      before += s_hb[w][lane];
+      total += s_ht[w][lane];
+    }
+    uint32_t inc = total;
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t o = __shfl_down(inc, d);
+      if (lane + d < 64) inc += o;
+    }
+    s_pos[lane] = inc - total + before;
+    c8 = lane < 8 ? total : 0, c16 = (lane >= 8 && lane < 16) ? total : 0, c32 = (lane >= 16 && lane < 32) ? total : 0, c64 = lane >= 32 ? total : 0;
+    for (int d = 32; d > 0; d >>= 1) {
+      c8 += __shfl_xor(c8, d);
+      c16 += __shfl_xor(c16, d);
+      c32 += __shfl_xor(c32, d);
+      c64 += __shfl_xor(c64, d);
+    }
+  }
+  if (chunk == 0 && threadIdx.x < 64) { // (wave 0: the class sizes are in its registers)
+    // counts[0..3] = edges of 9..16, 17..32, 33..64, <= 8 EdgeMatches
+    const unsigned long long cls_lo = static_cast<unsigned long long>(c16) | (static_cast<unsigned long long>(c32) << 32);
+    const unsigned long long cls_hi = static_cast<unsigned long long>(c64) | (static_cast<unsigned long long>(c8) << 32);
+    if (lane == 0) {
+      a.scalars[a.slot_ems]     = tot_m;
+      a.scalars[a.slot_edges]   = tot_e;
+      a.scalars[a.slot_cls]     = cls_lo;
+      a.scalars[a.slot_cls + 1] = cls_hi;
+    }
+    if (a.host_scalars && a.seq) {
+      if (static_cast<uint32_t>(lane) < a.n_scalars) {
+        const uint32_t k = lane;
+        a.host_scalars[k] = k == a.slot_ems ? tot_m : k == a.slot_edges ? tot_e : k == a.slot_cls ? cls_lo : k == a.slot_cls + 1 ? cls_hi : a.scalars[k];
+      }
+      __threadfence_system();
+      if (lane == 0) __hip_atomic_store(&a.host_scalars[a.n_scalars], a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    // the list cursors of k_classify_reads are used up (the host read them before it launched the candidate kernels): zero
+    // at rest for the next classification
+    if (lane == 0 && a.nlists) a.nlists[0] = a.nlists[1] = 0;
+  }
+  static_assert(SC_PUBLISH_MAX <= 64, "one wavefront publishes the scalar block");
+  if (tot_e > a.cap_edges || a.big_stats[0] >= a.cap_big) return;
+  // ---- prefix inside the chunk: a read per thread of the first four wavefronts ------------------------------------------------
+  uint32_t ne_r = 0, nc_r = 0, ie = 0, im = 0;
+  if (threadIdx.x < CAND_CHUNK) {
+    const uint32_t r = chunk * CAND_CHUNK + threadIdx.x;
+    ne_r             = r < a.V ? a.n_edge[r] : 0u;
+    nc_r             = r < a.V ? a.n_cand[r] : 0u;
+    ie               = wave_incl_scan(ne_r);
+    im               = wave_incl_scan(nc_r);
+    if (lane == 63) {
+      s_w[0][wave] = ie;
+      s_w[1][wave] = im;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < CAND_CHUNK) {
+    uint32_t be = ie - ne_r, bm = im - nc_r;
+    for (int w = 0; w < wave; ++w) {
+      be += s_w[0][w];
+      bm += s_w[1][w];
+    }
+    s_ne[threadIdx.x] = ne_r;
+    s_nc[threadIdx.x] = nc_r;
+    s_eb[threadIdx.x] = be;
+    s_mb[threadIdx.x] = bm;
+  }
+  __syncthreads();
+  // ---- the edges: 16 lanes per read (a read has ~10 edges), 64 reads per round ---------------------------------------------------
+  const int sub = threadIdx.x & 15;
+#pragma unroll
+  for (uint32_t round = 0; round < CAND_CHUNK / 64; ++round) {
+    const uint32_t lr = round * 64 + (threadIdx.x >> 4), r = chunk * CAND_CHUNK + lr;
+    const uint32_t ne = s_ne[lr];
+    if (ne == 0) continue;
+    const uint32_t nc = s_nc[lr];
+    const uint64_t eb = base_e + s_eb[lr], mb = base_m + s_mb[lr], co = a.cand_off[r];
+    for (uint32_t e = sub; e < ne; e += 16) {
+      const uint32_t st = a.edge_scr_start[co + e];
+      const uint32_t en = (e + 1 < ne) ? a.edge_scr_start[co + e + 1] : nc;
+      msgpu_edge     ed;
+      ed.v1        = r;
+      ed.v2        = a.edge_scr_v2[co + e];
+      ed.em_off    = mb + st;
+      ed.order_off = 0;
+      ed.em_cnt    = en - st;
+      ed.order_cnt = 0;
+      ed.shadow    = 0;
+      ed.pad       = 0;
+      a.edges[eb + e]     = ed;
+      a.edge_cand[eb + e] = co + st;
+      if (ed.em_cnt > 64) { // the few edges k_chain_big takes: listed here, with the first scratch element of each
+        const unsigned long long i = atomicAdd(&a.big_cursor[0], 1ull);
+        a.big_list[i] = static_cast<uint32_t>(eb + e);
+        a.big_off[i]  = atomicAdd(&a.big_cursor[1], static_cast<unsigned long long>(ed.em_cnt));
+      } else if (ed.em_cnt) {
+        a.list[atomicAdd(&s_pos[ed.em_cnt - 1], 1u)] = static_cast<uint32_t>(eb + e);
       }
     }
   }
-  c8  = wave_sum(c8);
-  c16 = wave_sum(c16);
-  c32 = wave_sum(c32);
-  c64 = wave_sum(c64);
-  if ((threadIdx.x & 63) == 0) {
-    uint32_t *w = s_c[threadIdx.x >> 6];
-    w[0] = c16;
-    w[1] = c32;
-    w[2] = c64;
-    w[3] = c8;
-  }
-  __syncthreads();
-  if (threadIdx.x < 4) { // no atomics: the column sums are taken by the scan launch that follows (exclusive_scan_set)
-    uint32_t t = 0;
-    for (int w = 0; w < 16; ++w) t += s_c[w][threadIdx.x];
-    partials[blockIdx.x * 4 + threadIdx.x] = t;
-  }
 }
-uint32_t count_classes_blocks(uint32_t V) { return (V + 63) / 64; }
-void launch_count_classes(hipStream_t st, const uint32_t *n_edge, const uint32_t *n_cand, const uint64_t *cand_off,
-                          const uint32_t *scr_start, uint32_t V, uint32_t *partials) {
-  if (V)
-    hipLaunchKernelGGL(k_count_classes, dim3(count_classes_blocks(V)), dim3(1024), 0, st, n_edge, n_cand, cand_off, scr_start, V,
-                       partials);
+void launch_emit_edges(hipStream_t st, const EmitArgs &a, bool reduce) {
+  if (reduce && a.n_chunks)
+    hipLaunchKernelGGL(k_cand_reduce, dim3(a.n_chunks), dim3(1024), 0, st, a.n_edge, a.n_cand, a.cand_off, a.edge_scr_start, a.V,
+                       const_cast<unsigned long long *>(a.chunk_sums), const_cast<uint32_t *>(a.hist));
+  hipLaunchKernelGGL(k_emit_edges, dim3(a.n_chunks ? a.n_chunks : 1), dim3(1024), 0, st, a);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -2352,103 +2628,6 @@ template __global__ void k_chain_sub<8>(ChainArgs, const uint32_t *, uint32_t);
 template __global__ void k_chain_sub<16>(ChainArgs, const uint32_t *, uint32_t);
 template __global__ void k_chain_sub<32>(ChainArgs, const uint32_t *, uint32_t);
 
-// Edges with <= 64 EdgeMatches ordered by size, largest first (a counting sort in two small launches: per-block
-// histograms, then their scan and the scatter together).  The three width classes are then contiguous stretches of one list
-// [64..33 | 32..17 | 16..1], the edges that share a wavefront in k_chain_sub have (nearly) the same size, so no group
-// waits long for its neighbour, and the longest edges of a launch start first.
-constexpr int SIZE_SORT_BLOCKS = 128;
-
-// (the edge count is read from device memory and a capacity is checked, for the same reason as in k_emit_edges)
-__global__ __launch_bounds__(1024) void k_size_hist(const msgpu_edge *edges, const uint64_t *d_n_edges, uint64_t cap_edges,
-                                                    uint32_t *part /*[blocks][64]*/) {
-  __shared__ uint32_t s_h[64];
-  const uint64_t      ne64 = *d_n_edges;
-  if (ne64 > cap_edges) return;
-  const uint32_t n_edges = static_cast<uint32_t>(ne64), chunk = (n_edges + SIZE_SORT_BLOCKS - 1) / SIZE_SORT_BLOCKS;
-  if (threadIdx.x < 64) s_h[threadIdx.x] = 0;
-  __syncthreads();
-  const uint64_t b0_64 = static_cast<uint64_t>(blockIdx.x) * chunk;
-  const uint32_t b0 = static_cast<uint32_t>(min(b0_64, static_cast<uint64_t>(n_edges)));
-  const uint32_t b1 = static_cast<uint32_t>(min(b0_64 + chunk, static_cast<uint64_t>(n_edges)));
-  for (uint64_t e = static_cast<uint64_t>(b0) + threadIdx.x; e < b1; e += 1024) {
-    const uint32_t n = edges[e].em_cnt;
-    if (n >= 1 && n <= 64) atomicAdd(&s_h[n - 1], 1u);
-  }
-  __syncthreads();
-  if (threadIdx.x < 64) part[blockIdx.x * 64 + threadIdx.x] = s_h[threadIdx.x];
-}
-
-// part[b][bin] (k_size_hist) -> first list position of block b's edges of that size, then the scatter.  Every workgroup takes
-// the prefix over the whole 128 x 64 table itself (32 KB out of L2, thread (bin, seg) owns 8 consecutive blocks of one bin) and
-// keeps its own row: a scan launch between the histogram and the scatter would cost more than 128 redundant scans.
-// counts[0..3] = edges of 9..16, 17..32, 33..64, <= 8 EdgeMatches (workgroup 0 writes them; k_count_classes published the
-// same numbers earlier, from the candidate scratch).
-__global__ __launch_bounds__(1024) void k_size_scatter(const msgpu_edge *edges, const uint64_t *d_n_edges, uint64_t cap_edges,
-                                                       const uint32_t *part, uint32_t *list, uint32_t *counts,
-                                                       unsigned long long *chunk_sums, uint32_t n_chunk_words) {
-  static_assert(SIZE_SORT_BLOCKS == 128, "16 segments of 8 blocks");
-  __shared__ uint32_t s_seg[16][64], s_base[64], s_pos[64];
-  // the chain kernels' chunk sums start from zero (the last launch in front of them: no launch of its own for it)
-  for (uint32_t i = blockIdx.x * 1024 + threadIdx.x; i < n_chunk_words; i += SIZE_SORT_BLOCKS * 1024) chunk_sums[i] = 0;
-  const uint64_t      ne64 = *d_n_edges;
-  // a speculative launch into tables that turn out too small: k_size_hist wrote nothing, `part` is stale (the host
-  // re-launches the kernels after it has allocated)
-  if (ne64 > cap_edges) return;
-  const int bin = threadIdx.x & 63, seg = threadIdx.x >> 6;
-  uint32_t  c[8], sum = 0;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) c[i] = part[(seg * 8 + i) * 64 + bin];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) sum += c[i];
-  s_seg[seg][bin] = sum;
-  __syncthreads();
-  if (seg == 0) { // one wavefront: totals per bin, then the exclusive prefix over the bins in DESCENDING size order
-    uint32_t run = 0;
-    for (int k = 0; k < 16; ++k) {
-      const uint32_t t = s_seg[k][bin];
-      s_seg[k][bin]    = run;
-      run += t;
-    }
-    uint32_t inc = run;
-    for (int d = 1; d < 64; d <<= 1) {
-      const uint32_t t = __shfl_down(inc, d);
-      if (bin + d < 64) inc += t;
-    }
-    s_base[bin] = inc - run;
-    if (blockIdx.x == 0) {
-      uint32_t c8 = bin < 8 ? run : 0, c16 = (bin >= 8 && bin < 16) ? run : 0, c32 = (bin >= 16 && bin < 32) ? run : 0,
-               c64 = bin >= 32 ? run : 0;
-      for (int d = 32; d > 0; d >>= 1) {
-        c8 += __shfl_xor(c8, d);
-        c16 += __shfl_xor(c16, d);
-        c32 += __shfl_xor(c32, d);
-        c64 += __shfl_xor(c64, d);
-      }
-      if (bin == 0) {
-        counts[0] = c16;
-        counts[1] = c32;
-        counts[2] = c64;
-        counts[3] = c8;
-      }
-    }
-  }
-  __syncthreads();
-  if (seg == static_cast<int>(blockIdx.x >> 3)) { // the wavefront whose 8 blocks hold this workgroup's row
-    uint32_t off = s_base[bin] + s_seg[seg][bin];
-    for (uint32_t i = 0; i < (blockIdx.x & 7u); ++i) off += c[i];
-    s_pos[bin] = off;
-  }
-  __syncthreads();
-  const uint32_t n_edges = static_cast<uint32_t>(ne64), chunk = (n_edges + SIZE_SORT_BLOCKS - 1) / SIZE_SORT_BLOCKS;
-  const uint64_t b0_64 = static_cast<uint64_t>(blockIdx.x) * chunk;
-  const uint32_t b0 = static_cast<uint32_t>(min(b0_64, static_cast<uint64_t>(n_edges)));
-  const uint32_t b1 = static_cast<uint32_t>(min(b0_64 + chunk, static_cast<uint64_t>(n_edges)));
-  for (uint64_t e = static_cast<uint64_t>(b0) + threadIdx.x; e < b1; e += 1024) {
-    const uint32_t n = edges[e].em_cnt;
-    if (n >= 1 && n <= 64) list[atomicAdd(&s_pos[n - 1], 1u)] = static_cast<uint32_t>(e);
-  }
-}
-
 // ---------------------------------------------------------------------------------------------------------------------
 // chain, big edges (> 64 EdgeMatches): same algorithm, one wavefront per edge, element state in global scratch.
 // The O(n^2) compatibility sweep is lane-parallel; the (short) sequential tails run on lane 0.  Slow path, any size.
@@ -2953,50 +3132,53 @@ __global__ __launch_bounds__(256) void k_fill_pair_tab(uint32_t *tab) {
 // ones before its own are its base, all of them the table sizes.  Workgroup 0 writes the sizes into the scalar block and
 // publishes the block to the host AT ONCE (k_publish_scalars' protocol): the host turns around while the tables are still being
 // written.  Then the prefix inside the chunk (a block scan over the per-edge counts), then the move.
-__global__ __launch_bounds__(256) void k_compact(CompactArgs a) {
-  __shared__ unsigned long long s_red[4][6];
-  __shared__ uint32_t           s_ob[COMPACT_CHUNK], s_ib[COMPACT_CHUNK], s_w[2][4];
+__global__ __launch_bounds__(1024) void k_compact(CompactArgs a) {
+  __shared__ unsigned long long s_red[16][5];
+  __shared__ uint32_t           s_ob[COMPACT_CHUNK], s_ib[COMPACT_CHUNK], s_w[2][16];
+  static_assert(COMPACT_CHUNK == 1024, "an edge per thread");
   const int      lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t chunk = blockIdx.x;
-  unsigned long long t[6] = {0, 0, 0, 0, 0, 0}; // orders, ids, shortcut edges: of the chunks before this one | of all chunks
-  for (uint32_t c = threadIdx.x; c < a.n_chunks; c += 256) {
+  unsigned long long t[5] = {0, 0, 0, 0, 0}; // orders, ids of the chunks before this one | orders, ids, shortcut edges of all chunks
+  for (uint32_t c = threadIdx.x; c < a.n_chunks; c += 1024) {
     const unsigned long long w0 = a.chunk_sums[2 * c], w1 = a.chunk_sums[2 * c + 1];
     const unsigned long long no = w0 >> 32, nf = w0 & 0xffffffffull;
     if (c < chunk) {
       t[0] += no;
       t[1] += w1;
     }
-    t[3] += no;
-    t[4] += w1;
-    t[5] += nf;
+    t[2] += no;
+    t[3] += w1;
+    t[4] += nf;
   }
 #pragma unroll
-  for (int k = 0; k < 6; ++k) {
-    if (k == 2) continue;
+  for (int k = 0; k < 5; ++k) {
     for (int d = 32; d > 0; d >>= 1) t[k] += __shfl_xor(t[k], d);
     if (lane == 0) s_red[wave][k] = t[k];
   }
   __syncthreads();
-  const unsigned long long base_o = s_red[0][0] + s_red[1][0] + s_red[2][0] + s_red[3][0];
-  const unsigned long long base_i = s_red[0][1] + s_red[1][1] + s_red[2][1] + s_red[3][1];
-  const unsigned long long tot_o  = s_red[0][3] + s_red[1][3] + s_red[2][3] + s_red[3][3];
-  const unsigned long long tot_i  = s_red[0][4] + s_red[1][4] + s_red[2][4] + s_red[3][4];
-  const unsigned long long tot_f  = s_red[0][5] + s_red[1][5] + s_red[2][5] + s_red[3][5];
-  if (chunk == 0 && a.scalars) {
+  unsigned long long base_o = 0, base_i = 0, tot_o = 0, tot_i = 0, tot_f = 0;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) {
+    base_o += s_red[w][0];
+    base_i += s_red[w][1];
+    tot_o += s_red[w][2];
+    tot_i += s_red[w][3];
+    tot_f += s_red[w][4];
+  }
+  if (chunk == 0 && a.scalars && threadIdx.x < 64) {
     // (every launch writes the sizes; only the first launch of a call publishes -- a repeat after a reallocation has seq = 0)
-    if (threadIdx.x == 0) {
+    if (lane == 0) {
       a.scalars[a.slot_orders] = tot_o;
       a.scalars[a.slot_ids]    = tot_i;
       a.scalars[a.slot_fast]   = tot_f;
     }
     if (a.host_scalars && a.seq) {
-      if (threadIdx.x < a.n_scalars) {
-        const uint32_t k = threadIdx.x;
+      if (static_cast<uint32_t>(lane) < a.n_scalars) {
+        const uint32_t k = lane;
         a.host_scalars[k] = k == a.slot_orders ? tot_o : k == a.slot_ids ? tot_i : k == a.slot_fast ? tot_f : a.scalars[k];
       }
       __threadfence_system();
-      __syncthreads();
-      if (threadIdx.x == 0) __hip_atomic_store(&a.host_scalars[a.n_scalars], a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      if (lane == 0) __hip_atomic_store(&a.host_scalars[a.n_scalars], a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
   // (may be launched before the host knows the table sizes, into whatever the tables hold from earlier calls: if they do not
@@ -3005,48 +3187,31 @@ __global__ __launch_bounds__(256) void k_compact(CompactArgs a) {
   const uint64_t e0 = static_cast<uint64_t>(chunk) * COMPACT_CHUNK;
   if (e0 >= a.n_edges) return;
   {
-    // prefix inside the chunk: a thread takes COMPACT_CHUNK / 256 = 4 consecutive edges
-    static_assert(COMPACT_CHUNK == 1024, "four edges per thread");
-    uint32_t no[4], ni[4];
-    const uint64_t ef = e0 + threadIdx.x * 4;
-    if (ef + 4 <= a.n_edges) {
-      const uint4 vo = *reinterpret_cast<const uint4 *>(&a.edge_norders[ef]), vi = *reinterpret_cast<const uint4 *>(&a.edge_nids[ef]);
-      no[0] = vo.x, no[1] = vo.y, no[2] = vo.z, no[3] = vo.w;
-      ni[0] = vi.x, ni[1] = vi.y, ni[2] = vi.z, ni[3] = vi.w;
-    } else {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        no[k] = ef + k < a.n_edges ? a.edge_norders[ef + k] : 0u;
-        ni[k] = ef + k < a.n_edges ? a.edge_nids[ef + k] : 0u;
-      }
-    }
-    const uint32_t so = no[0] + no[1] + no[2] + no[3], si = ni[0] + ni[1] + ni[2] + ni[3];
-    const uint32_t io = wave_incl_scan(so), ii = wave_incl_scan(si);
+    // prefix inside the chunk: an edge per thread
+    const uint64_t e  = e0 + threadIdx.x;
+    const uint32_t no = e < a.n_edges ? a.edge_norders[e] : 0u, ni = e < a.n_edges ? a.edge_nids[e] : 0u;
+    const uint32_t io = wave_incl_scan(no), ii = wave_incl_scan(ni);
     if (lane == 63) {
       s_w[0][wave] = io;
       s_w[1][wave] = ii;
     }
     __syncthreads();
-    uint32_t bo = io - so, bi = ii - si;
+    uint32_t bo = io - no, bi = ii - ni;
     for (int w = 0; w < wave; ++w) {
       bo += s_w[0][w];
       bi += s_w[1][w];
     }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      s_ob[threadIdx.x * 4 + k] = bo;
-      s_ib[threadIdx.x * 4 + k] = bi;
-      bo += no[k];
-      bi += ni[k];
-    }
+    s_ob[threadIdx.x] = bo;
+    s_ib[threadIdx.x] = bi;
   }
   __syncthreads();
   // Four lanes per edge, sixteen edges per wavefront, all in flight together: a lane moves one 16-byte quarter of an
   // order record and every fourth id.  (Most edges have one order; the dependent chain "order record -> id count ->
   // ids" is then as long as a single edge's, not sixteen of them in a row.)
   const int sub = lane & 3;
-  for (uint32_t round = 0; round < COMPACT_CHUNK / 64; ++round) {
-    const uint32_t le   = round * 64 + wave * 16 + (lane >> 2);
+#pragma unroll
+  for (uint32_t round = 0; round < COMPACT_CHUNK / 256; ++round) {
+    const uint32_t le   = round * 256 + wave * 16 + (lane >> 2);
     const uint64_t e    = e0 + le;
     const bool     have = e < a.n_edges;
     uint32_t       no = 0;
@@ -3382,10 +3547,10 @@ void launch_bound(hipStream_t st, const uint32_t *read_off, const uint32_t *read
 }
 void launch_classify_reads(hipStream_t st, const uint32_t *read_off, const uint32_t *read_cnt, const uint32_t *bound,
                            const uint64_t *cand_off, uint32_t V, uint32_t shard, uint32_t nshards, uint32_t lo,
-                           uint32_t hi, CandDesc *l0, CandDesc *l1, CandDesc *l2, uint32_t *l3, uint32_t *n_lists) {
+                           uint32_t hi, CandDesc *l0, CandDesc *l1, CandDesc *l2, uint32_t *l3, uint32_t *n_lists, const CandZero &z) {
   if (V)
     hipLaunchKernelGGL(k_classify_reads, grid1(V, 1024), dim3(1024), 0, st, read_off, read_cnt, bound, cand_off, V, shard,
-                       nshards, lo, hi, l0, l1, l2, l3, n_lists);
+                       nshards, lo, hi, l0, l1, l2, l3, n_lists, z);
 }
 void launch_candidates(hipStream_t st, const CandArgs &a, int cls, const CandDesc *list, uint32_t n_list) {
   if (!n_list) return;
@@ -3401,15 +3566,6 @@ void launch_candidates_big(hipStream_t st, const CandArgs &a, const uint32_t *li
   if (!n_list) return;
   hipLaunchKernelGGL(k_candidates_big, dim3(n_list), dim3(256), 0, st, a, list, n_list, big_key, big_t, big_r2s,
                      big_pfx);
-}
-void launch_emit_edges(hipStream_t st, const uint32_t *n_edge, const uint32_t *n_cand, const uint64_t *edge_base,
-                       const uint64_t *em_base, const uint64_t *cand_off, const uint32_t *scr_v2,
-                       const uint32_t *scr_start, uint32_t V, msgpu_edge *edges, uint64_t *edge_cand,
-                       uint32_t *big_list, uint64_t *big_off, unsigned long long *big_cursor, uint64_t cap_edges,
-                       uint64_t cap_big, const unsigned long long *big_stats) {
-  if (V)
-    hipLaunchKernelGGL(k_emit_edges, grid1(V, 16), dim3(256), 0, st, n_edge, n_cand, edge_base, em_base, cand_off, scr_v2,
-                       scr_start, V, edges, edge_cand, big_list, big_off, big_cursor, cap_edges, cap_big, big_stats);
 }
 void launch_fill_pair_tab(hipStream_t st, uint32_t *tab) {
   hipLaunchKernelGGL(k_fill_pair_tab, dim3((4 * PAIR_TAB_STRIDE + 255) / 256), dim3(256), 0, st, tab);
@@ -3427,13 +3583,6 @@ void launch_chain_sub(hipStream_t st, const ChainArgs &a, int width, const uint3
   else
     hipLaunchKernelGGL(k_chain_sub<32>, grid1(n_list, 8), dim3(256), 0, st, a, list, n_list);
 }
-void launch_sort_edges_by_size(hipStream_t st, const msgpu_edge *edges, const uint64_t *d_n_edges, uint64_t cap_edges,
-                               uint32_t *part, uint32_t *list, uint32_t *counts, unsigned long long *chunk_sums, uint32_t n_chunk_words) {
-  hipLaunchKernelGGL(k_size_hist, dim3(SIZE_SORT_BLOCKS), dim3(1024), 0, st, edges, d_n_edges, cap_edges, part);
-  hipLaunchKernelGGL(k_size_scatter, dim3(SIZE_SORT_BLOCKS), dim3(1024), 0, st, edges, d_n_edges, cap_edges, part, list, counts,
-                     chunk_sums, n_chunk_words);
-}
-size_t size_sort_part_bytes() { return static_cast<size_t>(SIZE_SORT_BLOCKS) * 64 * 4; }
 size_t big_elem_bytes() { return sizeof(BigElem); }
 size_t big_path_bytes() { return sizeof(BigPath); }
 void launch_chain_big(hipStream_t st, const ChainArgs &a, const uint32_t *big_list, const uint64_t *big_off,
@@ -3465,7 +3614,7 @@ void launch_pack_wire(hipStream_t st, const PackWireArgs &a) {
   hipLaunchKernelGGL(k_pack_wire, grid1(n, 256), dim3(256), 0, st, a);
 }
 void launch_compact(hipStream_t st, const CompactArgs &a) { // a workgroup per chunk; one even without edges: it publishes the sizes
-  hipLaunchKernelGGL(k_compact, dim3(a.n_chunks ? a.n_chunks : 1), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(k_compact, dim3(a.n_chunks ? a.n_chunks : 1), dim3(1024), 0, st, a);
 }
 
 } // namespace msgpu
