@@ -1573,7 +1573,7 @@ struct NanoMasks {
 // and two selects less per vertex, bit for bit the same masks and the same diff.
 // SORTED (vertex 1 only): the pairs run k < l in v1's (n_lo, n_hi, anchor) order, so k_rlo <= l_rlo <= l_rhi: the first
 // half of the raw overlap test is true and "k behind l" (um2) is false -- three raw compares instead of six.
-template <bool WF, bool SORTED>
+template <bool WF, int SORTED /*0: any order; 1: k_rlo <= l_rlo (and lo <= hi); 2: k_rlo >= l_rlo (and lo <= hi)*/>
 __device__ __forceinline__ NanoMasks nano_check(double k_clo, double k_chi, double l_clo, double l_chi, int k_rlo,
                                                 int k_rhi, int l_rlo, int l_rhi, double &d) {
   typedef unsigned long long M;
@@ -1609,10 +1609,16 @@ __device__ __forceinline__ NanoMasks nano_check(double k_clo, double k_chi, doub
     f.neg = (f.ovl & gt_lo & gt_hi) | ~(f.ovl | lt_lo);
   }
   // abort when the raw ranges overlap and their order contradicts the corrected orientation (:93-109)
-  if (SORTED) {
+  if (SORTED == 1) {
     const M rovl = __ballot(l_rlo <= k_rhi);
     const M u2   = __ballot(k_rlo < l_rlo) & __ballot(k_rhi < l_rhi);
     f.abort_     = rovl & (f.neg | (f.pos & ~u2));
+  } else if (SORTED == 2) {
+    // the mirror image (a reverse edge's second vertex): l_rlo <= k_rlo <= k_rhi, so the second half of the raw overlap test
+    // is true and "k in front of l" (u2) is false
+    const M rovl = __ballot(k_rlo <= l_rhi);
+    const M um2  = __ballot(k_rlo > l_rlo) & __ballot(k_rhi > l_rhi);
+    f.abort_     = rovl & (f.pos | (f.neg & ~um2));
   } else {
     const M rovl = __ballot(k_rlo <= l_rhi) & __ballot(l_rlo <= k_rhi);
     const M u2   = __ballot(k_rlo < l_rlo) & __ballot(k_rhi < l_rhi);
@@ -1717,18 +1723,37 @@ __device__ __forceinline__ int paths_of_direction(unsigned long long act, bool d
   return np;
 }
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_chain(ChainArgs a, const uint32_t *list, uint32_t n_list) {
-  // per wave: the 64 ChainElem of the sweep, later (the elements are dead once the compatibility masks exist) the
-  // path lists of both directions in the same bytes -- 14 KB per workgroup instead of 26 KB, so LDS no longer caps
-  // the occupancy
+// a ChainElem at an absolute LDS address (three 16-byte reads)
+__device__ __forceinline__ ChainElem lds_elem(uint32_t addr) {
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  typedef __attribute__((address_space(3))) const u32x4 lds_u4;
+  lds_u4     *q = reinterpret_cast<lds_u4 *>(static_cast<uintptr_t>(addr));
+  const u32x4 a = q[0], b = q[1], c = q[2];
+  ChainElem   e;
+  e.clo1 = __hiloint2double(static_cast<int>(a.y), static_cast<int>(a.x));
+  e.chi1 = __hiloint2double(static_cast<int>(a.w), static_cast<int>(a.z));
+  e.clo2 = __hiloint2double(static_cast<int>(b.y), static_cast<int>(b.x));
+  e.chi2 = __hiloint2double(static_cast<int>(b.w), static_cast<int>(b.z));
+  e.rlo1 = static_cast<int>(c.x);
+  e.rhi1 = static_cast<int>(c.y);
+  e.rlo2 = static_cast<int>(c.z);
+  e.rhi2 = static_cast<int>(c.w);
+  return e;
+}
+constexpr uint32_t CHAIN_LDS_EL = 0, CHAIN_LDS_CM = sizeof(ChainElem) * 64, CHAIN_LDS_BYTES = CHAIN_LDS_CM + 34 * 8;
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_chain(ChainArgs a, const uint32_t *list, uint32_t n_list) {
+  // ONE wavefront per workgroup, and no static LDS: the dynamic block starts at LDS address 0, so the element table's
+  // address is a compile-time constant and the pair table can hold the LDS offsets of a pair's two elements ready to use --
+  // the two address additions per sweep step (5 % of the loop's vector instructions) are gone.
+  //   [0, 3072)     the 64 ChainElem of the sweep, later (the elements are dead once the compatibility masks exist) the path
+  //                 lists of both directions in the same bytes
+  //   [3072, 3344)  the verdicts of the pair sweep, one 64-bit wavefront mask per step (pairs p0 .. p0 + 63): at most 32 steps
+  //                 (+ 2 words that the row extraction may touch past the last one)
   static_assert(sizeof(ChainElem) * 64 == sizeof(PathRec) * 2 * 64, "the path lists overlay the element table");
-  __shared__ __attribute__((aligned(16))) unsigned char s_wavebuf[4][sizeof(ChainElem) * 64];
-  // the verdicts of the pair sweep, one 64-bit wavefront mask per step (pairs p0 .. p0 + 63): at most 32 steps (+ 2 words
-  // that the row extraction may touch past the last one)
-  __shared__ uint64_t                                  s_cm[4][34];
-  const int      wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  // list == nullptr: wave i takes edge i; else the edges of the list (the 33..64 class of k_list_edges_by_size)
-  const uint32_t slot = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(blockIdx.x * 4 + wave));
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_chain_lds[];
+  const int      lane = threadIdx.x;
+  // list == nullptr: wave i takes edge i; else the edges of the list (the 33..64 class of the size-sorted list)
+  const uint32_t slot = blockIdx.x;
   if (list ? slot >= n_list : slot >= a.n_edges) return;
   const uint64_t e = list ? __builtin_amdgcn_readfirstlane(list[slot]) : slot;
   const msgpu_edge ed = a.edges[e];
@@ -1739,8 +1764,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
   const uint32_t v1 = ed.v1, v2 = ed.v2;
   const uint32_t n1 = a.read_cnt[v1], n2 = a.read_cnt[v2];
   const int      len1 = a.read_len[v1], len2 = a.read_len[v2];
-  ChainElem     *el = reinterpret_cast<ChainElem *>(s_wavebuf[wave]);
-  uint64_t      *cm = s_cm[wave];
+  ChainElem     *el = reinterpret_cast<ChainElem *>(s_chain_lds + CHAIN_LDS_EL);
+  uint64_t      *cm = reinterpret_cast<uint64_t *>(s_chain_lds + CHAIN_LDS_CM);
 
   // ---- per-lane element: VertexMatch on v1 (row j of v1), VertexMatch on v2 (scaffold row t), EdgeMatch ----------
   uint32_t j1 = 0, q2 = 0, anchor = 0;
@@ -1870,10 +1895,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
   // the pair table through a buffer descriptor: scalar offset (the step) + constant lane offset, no vector address
   // arithmetic in the loop
   const __amdgpu_buffer_rsrc_t tab_rsrc =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(a.pair_tab64), 0, PAIR_TAB_STRIDE * 4, 0x00020000);
-  const uint32_t tab_lane = static_cast<uint32_t>(lane) * 4u;
-  auto           load_pairs = [&](int p0) __attribute__((always_inline)) -> uint32_t {
-    return static_cast<uint32_t>(__builtin_amdgcn_raw_buffer_load_b32(tab_rsrc, tab_lane, p0 * 4, 0));
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(a.pair_tab64), 0, PAIR_TAB_STRIDE * 8, 0x00020000);
+  const uint32_t tab_lane = static_cast<uint32_t>(lane) * 8u;
+  typedef uint32_t pair_t __attribute__((ext_vector_type(2))); // {LDS offset of element k, of element l}
+  auto           load_pairs = [&](int p0) __attribute__((always_inline)) -> pair_t {
+    return __builtin_amdgcn_raw_buffer_load_b64(tab_rsrc, tab_lane, p0 * 8, 0);
   };
   // The scalar registers of this loop are all taken by pair masks; a loop-invariant scalar operand would be spilled and
   // re-read (v_readlane) in every step.  The one constant the common path compares with lives in a vector register.
@@ -1886,12 +1912,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     wf_lane = (x.clo1 <= x.chi1) & (x.clo2 <= x.chi2) & (x.rlo1 <= x.rhi1) & (lane == 0 || prev_rlo1 <= x.rlo1);
   }
   const bool wf = __ballot(!wf_lane) == 0;
+  // (The lean raw test for the SECOND vertex too -- its raw ranges in list order on forward edges, in reverse order on reverse
+  // ones, nano_check<.., 1 / 2> -- was built and measured in round 5: on BASELINE.json's reads the +-15 bp jitter of the
+  // alignment coordinates puts some neighbouring anchors of nearly every edge out of order on the second read, the instances
+  // fired on next to no edge, and four more copies of the loop are four more loops in the instruction cache.  Not kept.)
   // DIR: 0 = every EdgeMatch forward, 1 = every EdgeMatch reverse (the flip of mpp.cpp:131 is then the same for all
   // pairs and costs nothing), 2 = both directions present (pairs of one direction only, flip per pair).  The loop is
   // bound by SCALAR issue (the mask algebra), so everything wave-uniform is decided outside it: six instances.
-  auto sweep_step = [&](const int step, const uint32_t kl, auto wft, auto dirt) __attribute__((always_inline)) {
+  // LDS address of the verdict word of the current PAIR of steps, kept in a vector register (a scalar one would be copied into a
+  // vector register for every store)
+  uint32_t cm_addr = CHAIN_LDS_CM;
+  asm volatile("" : "+v"(cm_addr));
+  auto sweep_step = [&](const int step, const pair_t kl, auto wft, auto dirt, auto s2t) __attribute__((always_inline)) {
     typedef decltype(wft)  WFT;
     typedef decltype(dirt) DIRT;
+    typedef decltype(s2t)  S2T;
     constexpr int          DIR = DIRT::value;
     unsigned long long     bits = 0; // checkCompatibility(k, l) of the 64 pairs of this step
     { // every lane evaluates a pair: no divergence, all masks are wave-uniform
@@ -1900,17 +1935,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
       // one-direction edges need no "valid" mask at all
       M valid = ~0ull, KD = 0;
       if (DIR == 2) { // pairs of one direction only
-        const int  k = static_cast<int>((kl & 0xffffu) / 48u), l = static_cast<int>((kl >> 16) / 48u);
+        const int  k = static_cast<int>((kl.x - CHAIN_LDS_EL) / 48u), l = static_cast<int>((kl.y - CHAIN_LDS_EL) / 48u);
         const bool kd = (m_plus >> k) & 1ull, ld = (m_plus >> l) & 1ull;
         valid = __ballot(kd == ld);
         KD    = __ballot(kd);
       }
-      const unsigned char *elb = reinterpret_cast<const unsigned char *>(el);
-      const ChainElem      K = *reinterpret_cast<const ChainElem *>(elb + (kl & 0xffffu));
-      const ChainElem      L = *reinterpret_cast<const ChainElem *>(elb + (kl >> 16));
+      // (the table holds LDS ADDRESSES -- the block starts at LDS address 0 -- used as they are: through the array's symbol the
+      // compiler would add its link-time address, "+ 0", in every step)
+      const ChainElem K = lds_elem(kl.x), L = lds_elem(kl.y);
       double          d1, d2;
-      const NanoMasks f1 = nano_check<WFT::value, WFT::value>(K.clo1, K.chi1, L.clo1, L.chi1, K.rlo1, K.rhi1, L.rlo1, L.rhi1, d1);
-      const NanoMasks f2 = nano_check<WFT::value, false>(K.clo2, K.chi2, L.clo2, L.chi2, K.rlo2, K.rhi2, L.rlo2, L.rhi2, d2);
+      const NanoMasks f1 = nano_check<WFT::value, WFT::value ? 1 : 0>(K.clo1, K.chi1, L.clo1, L.chi1, K.rlo1, K.rhi1, L.rlo1, L.rhi1, d1);
+      const NanoMasks f2 = nano_check<WFT::value, S2T::value>(K.clo2, K.chi2, L.clo2, L.chi2, K.rlo2, K.rhi2, L.rlo2, L.rhi2, d2);
       M p2, n2; // :131 flip by EdgeMatch(k).direction
       if (DIR == 0) {
         p2 = f2.pos;
@@ -1926,46 +1961,70 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
       const M mixed = f1.ovl ^ f2.ovl;               // :133 "equal and non-zero" fails: one overlaps, one does not
       M       cl    = codir & ~(f1.abort_ | f2.abort_);
       if (DIR == 2) cl &= valid;
-      // std::max(d1, d2) - std::min(d1, d2) = |d1 - d2| bit for bit (a - b and b - a round to the same magnitude); the
-      // maximum itself is only needed by the division
-      const double df = fabs(d1 - d2);
-      const M near_ = __ballot(df <= wiggle), sum_ok = __ballot(d1 + d2 <= wiggle);
-      M       ok    = cl & ((near_ & ~mixed) | (sum_ok & mixed));
-      // the fp64 division of :136 only where the first test failed (rare for true overlaps)
-      const M need_div = cl & ~(mixed | near_);
+      // :133-138 in one comparison: a pair whose orientations are equal needs |d1 - d2| <= wiggle (or the 15 % rule), a
+      // mixed pair d1 + d2 <= wiggle -- so the second difference is negated where the pair is not mixed (exact: a - b is
+      // a + (-b) bit for bit) and ONE sum serves both: |d1 +- d2| <= wiggle (d1 + d2 >= 2 is its own magnitude).  Three
+      // scalar instructions and a compare less per step than testing both and choosing by mask: scalar and vector issue bound
+      // this loop about equally.
+      double val = d1 - d2;
+      {
+        M saved; // (the sum for the mixed pairs, written over the difference under their mask as EXEC: one vector instruction)
+        asm volatile("s_and_saveexec_b64 %[sv], %[m]\n\t"
+                     "v_add_f64 %[val], %[x], %[y]\n\t"
+                     "s_mov_b64 exec, %[sv]"
+                     : [val] "+v"(val), [sv] "=&s"(saved)
+                     : [m] "s"(mixed), [x] "v"(d1), [y] "v"(d2)
+                     : "scc");
+      }
+      const M pass = __ballot(fabs(val) <= wiggle);
+      M            ok   = cl & pass;
+      // the fp64 division of :136 only where the first test failed (rare for true overlaps): std::max(d1, d2) -
+      // std::min(d1, d2) = |d1 - d2| bit for bit (a - b and b - a round to the same magnitude); the maximum itself is only
+      // needed by the division
+      const M need_div = (cl & ~mixed) & ~pass;
       if (need_div) {
-        bool pass = false;
-        if (__builtin_amdgcn_inverse_ballot_w64(need_div)) pass = df * 100 / fmax(d1, d2) <= a.ratio_pct;
-        ok |= __ballot(pass);
+        bool passd = false;
+        if (__builtin_amdgcn_inverse_ballot_w64(need_div)) passd = fabs(val) * 100 / fmax(d1, d2) <= a.ratio_pct;
+        ok |= __ballot(passd);
       }
       bits = ok;
     }
-    // One lane parks the step's 64 verdicts; every lane cuts its own row out of the parked words after the sweep.  (The
-    // stretch of every row used to be shifted into place and OR-ed into the row's word by its first lane in every step:
-    // eight vector instructions per step instead of three.  The same change makes the sub-wavefront kernels slower --
-    // their registers are the tighter resource -- so they keep the per-step store.)  Lanes past the last pair evaluate
-    // the padding pair: their bits lie beyond every row.
-    if (lane == 0) cm[step] = bits;
-  };
-  auto sweep = [&](auto wft, auto dirt) __attribute__((always_inline)) {
-    // two steps per trip, each with its own registers for the table entries: the next step's pairs are on their way
-    // while this one computes, and nothing is copied from "next" to "current"
-    uint32_t ka = load_pairs(0);
-    for (int p0 = 0; p0 < P; p0 += 128) {
-      const uint32_t kb = load_pairs(p0 + 64);
-      sweep_step(p0 >> 6, ka, wft, dirt);
-      if (p0 + 64 >= P) break;
-      ka = load_pairs(p0 + 128);
-      sweep_step((p0 >> 6) + 1, kb, wft, dirt);
+    // Every lane parks the step's 64 verdicts in the same word (no EXEC round trip for "lane 0 only": two scalar instructions
+    // less); every lane cuts its own row out of the parked words after the sweep.  (The stretch of every row used to be shifted
+    // into place and OR-ed into the row's word by its first lane in every step: eight vector instructions per step instead of
+    // three.  The same change makes the sub-wavefront kernels slower -- their registers are the tighter resource -- so they keep
+    // the per-step store.)  Lanes past the last pair evaluate the padding pair: their bits lie beyond every row.
+    {
+      typedef __attribute__((address_space(3))) unsigned long long lds_u64;
+      *reinterpret_cast<lds_u64 *>(static_cast<uintptr_t>(cm_addr + (step & 1) * 8u)) = bits;
     }
   };
-  auto sweep_dir = [&](auto wft) __attribute__((always_inline)) {
-    if (m_minus == 0) sweep(wft, std::integral_constant<int, 0>{});
-    else if (m_plus == 0) sweep(wft, std::integral_constant<int, 1>{});
-    else sweep(wft, std::integral_constant<int, 2>{});
+  auto sweep = [&](auto wft, auto dirt, auto s2t) __attribute__((always_inline)) {
+    // two steps per trip, each with its own registers for the table entries: the next step's pairs are on their way
+    // while this one computes, and nothing is copied from "next" to "current"
+    pair_t ka = load_pairs(0);
+    for (int p0 = 0; p0 < P; p0 += 128) {
+      const pair_t kb = load_pairs(p0 + 64);
+      sweep_step(p0 >> 6, ka, wft, dirt, s2t);
+      if (p0 + 64 >= P) break;
+      ka = load_pairs(p0 + 128);
+      sweep_step((p0 >> 6) + 1, kb, wft, dirt, s2t);
+      cm_addr += 16;
+    }
   };
-  if (wf) sweep_dir(std::true_type{});
-  else sweep_dir(std::false_type{});
+  typedef std::integral_constant<int, 0> I0;
+  typedef std::integral_constant<int, 1> I1;
+  typedef std::integral_constant<int, 2> I2;
+  // six instances: {well formed, general} x {forward, reverse, both directions}
+  if (wf) {
+    if (m_minus == 0) sweep(std::true_type{}, I0{}, I0{});
+    else if (m_plus == 0) sweep(std::true_type{}, I1{}, I0{});
+    else sweep(std::true_type{}, I2{}, I0{});
+  } else {
+    if (m_minus == 0) sweep(std::false_type{}, I0{}, I0{});
+    else if (m_plus == 0) sweep(std::false_type{}, I1{}, I0{});
+    else sweep(std::false_type{}, I2{}, I0{});
+  }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   // bit k of mycm: checkCompatibility(k, lane) for k < lane of the same direction = pair lane (lane - 1) / 2 + k: the row
@@ -1996,27 +2055,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     // bit k of mycm -> the sign bit after k shifts, in two 32-bit halves (k < 32, k >= 32): 32-bit compare and shift
     uint32_t rev = __builtin_bitreverse32(static_cast<uint32_t>(mycm));
     const int n1 = static_cast<int>(n) - 1, nlo = n1 < 32 ? n1 : 32;
-    for (int k = 0; k < nlo; ++k) {
-      const double k_pop = rl_f64(pop, k);
-      const double cand  = k_pop + em_score; // :189
-      const bool   comp  = static_cast<int32_t>(rev) < 0;
-      rev <<= 1;
-      if (comp && cand > pop) { // :190-197
-        pop  = cand;
-        pred = static_cast<uint32_t>(k);
-      }
-    }
+    // Seven vector instructions per step (was ten): the compatibility bit and the shift are ONE add with carry-out (rev + rev:
+    // the carry is the old sign bit, as a wavefront mask), and the three conditional moves (score: two, predecessor: one, the
+    // step number copied into a vector register for it: one) are two plain moves under the condition as EXEC mask.
+    auto dp_step = [&](int k) __attribute__((always_inline)) {
+      const double       k_pop = rl_f64(pop, k);
+      const double       cand  = k_pop + em_score; // :189
+      unsigned long long comp, saved;
+      asm volatile("v_add_co_u32 %0, %1, %0, %0" : "+v"(rev), "=s"(comp));
+      const unsigned long long upd = comp & __ballot(cand > pop); // :190-197
+      asm volatile("s_and_saveexec_b64 %[sv], %[m]\n\t"
+                   "v_mov_b64 %[pop], %[cand]\n\t"
+                   "v_mov_b32 %[pred], %[k]\n\t"
+                   "s_mov_b64 exec, %[sv]"
+                   : [pop] "+v"(pop), [pred] "+v"(pred), [sv] "=&s"(saved)
+                   : [m] "s"(upd), [cand] "v"(cand), [k] "s"(k)
+                   : "scc"); // (s_and_saveexec writes SCC: without the clobber the loop's compare may sit in front of this block
+                             // and its branch behind it -- an endless loop, gpurun call 535)
+    };
+    for (int k = 0; k < nlo; ++k) dp_step(k);
     rev = __builtin_bitreverse32(static_cast<uint32_t>(mycm >> 32));
-    for (int k = 32; k < n1; ++k) {
-      const double k_pop = rl_f64(pop, k);
-      const double cand  = k_pop + em_score;
-      const bool   comp  = static_cast<int32_t>(rev) < 0;
-      rev <<= 1;
-      if (comp && cand > pop) {
-        pop  = cand;
-        pred = static_cast<uint32_t>(k);
-      }
-    }
+    for (int k = 32; k < n1; ++k) dp_step(k);
     // population[l].path = population[pred].path + {l} with pred's path already final when l took it (pred < l): the
     // path masks are the closure of the predecessor pointers, built by pointer doubling in ceil(log2 n) rounds.
     uint32_t ptr = pred;
@@ -2030,7 +2089,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
   }
 
   // src/main.cpp:341-353: split by EdgeMatch direction, minus then plus
-  PathRec  *pmn = reinterpret_cast<PathRec *>(s_wavebuf[wave]), *ppl = pmn + 64; // el[] is dead from here on
+  PathRec  *pmn = reinterpret_cast<PathRec *>(s_chain_lds + CHAIN_LDS_EL), *ppl = pmn + 64; // el[] is dead from here on
   const int n_m = paths_of_direction(m_minus, false, lane, pop, pm, em_prim, j1, q2, n1, n2, a.alt_frac, pmn);
   const int n_p = paths_of_direction(m_plus, true, lane, pop, pm, em_prim, j1, q2, n1, n2, a.alt_frac, ppl);
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -2498,15 +2557,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W == 32 ? 7
   {
     uint32_t pred = static_cast<uint32_t>(sl);
     uint32_t rev  = __builtin_bitreverse32(mycm); // bit k of mycm -> bit 31 - k
+    const uint32_t base4 = static_cast<uint32_t>(gbase) * 4u; // ds_bpermute takes a byte address: lane * 4
     for (int k = 0; k + 1 < nmax; ++k) {
-      const double k_pop = shfl_f64(pop, gbase + k);
-      const double cand  = k_pop + em_score; // :189
-      const bool   comp  = static_cast<int32_t>(rev) < 0;
-      rev <<= 1;
-      if (comp && cand > pop) { // :190-197
-        pop  = cand;
-        pred = static_cast<uint32_t>(k);
-      }
+      // population[k] of this lane's group: one address addition per step (__shfl adds, masks and shifts for every call)
+      const int       src = static_cast<int>(base4 + static_cast<uint32_t>(k) * 4u);
+      const long long pb  = __double_as_longlong(pop);
+      const uint32_t  plo = static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute(src, static_cast<int>(static_cast<uint32_t>(pb))));
+      const uint32_t  phi = static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute(src, static_cast<int>(static_cast<uint32_t>(pb >> 32))));
+      const double    k_pop = __longlong_as_double(static_cast<long long>((static_cast<unsigned long long>(phi) << 32) | plo));
+      const double    cand  = k_pop + em_score; // :189
+      // (as in k_chain: bit test and shift are one add with carry-out, the three conditional moves two moves under EXEC)
+      unsigned long long comp, saved;
+      asm volatile("v_add_co_u32 %0, %1, %0, %0" : "+v"(rev), "=s"(comp));
+      const unsigned long long upd = comp & __ballot(cand > pop); // :190-197
+      asm volatile("s_and_saveexec_b64 %[sv], %[m]\n\t"
+                   "v_mov_b64 %[pop], %[cand]\n\t"
+                   "v_mov_b32 %[pred], %[k]\n\t"
+                   "s_mov_b64 exec, %[sv]"
+                   : [pop] "+v"(pop), [pred] "+v"(pred), [sv] "=&s"(saved)
+                   : [m] "s"(upd), [cand] "v"(cand), [k] "s"(k)
+                   : "scc");
     }
     uint32_t ptr = pred;
     for (int span = 1; span < nmax; span <<= 1) {
@@ -3096,7 +3166,9 @@ __global__ __launch_bounds__(64) void k_chain_big(ChainArgs a, const uint32_t *b
 // (k and l themselves, which only mixed-direction edges need, are the offsets / 48)
 __device__ __forceinline__ void tab64_entry(uint32_t *tab, int p, int k, int l, int run) {
   (void)run;
-  tab[4 * PAIR_TAB_STRIDE + p] = static_cast<uint32_t>(k * 48) | (static_cast<uint32_t>(l * 48) << 16);
+  // k_chain: the LDS addresses of the pair's two elements (its element table starts at LDS address CHAIN_LDS_EL = 0)
+  tab[4 * PAIR_TAB_STRIDE + 2 * p]     = static_cast<uint32_t>(k * 48);
+  tab[4 * PAIR_TAB_STRIDE + 2 * p + 1] = static_cast<uint32_t>(l * 48);
 }
 // The tables of the sub-wavefront kernels (W = 32, 16, 8) once more, 8 bytes per pair, in the form their sweep consumes:
 //   x = byte offset of element k in the group's elements | byte offset of element l << 16
@@ -3572,7 +3644,7 @@ void launch_fill_pair_tab(hipStream_t st, uint32_t *tab) {
 }
 void launch_chain(hipStream_t st, const ChainArgs &a, const uint32_t *list, uint32_t n_list) {
   const uint64_t n = list ? n_list : a.n_edges;
-  if (n) hipLaunchKernelGGL(k_chain, grid1(n, 4), dim3(256), 0, st, a, list, n_list);
+  if (n) hipLaunchKernelGGL(k_chain, dim3(static_cast<uint32_t>(n)), dim3(64), CHAIN_LDS_BYTES, st, a, list, n_list); // a wavefront per workgroup
 }
 void launch_chain_sub(hipStream_t st, const ChainArgs &a, int width, const uint32_t *list, uint32_t n_list) {
   if (!n_list) return;

@@ -3,7 +3,11 @@
 # workload's kernels-only line, and a kernel trace of it.   tools/gpu_cycle.sh OUTDIR [quick]
 out=${1:-gpurun_out/cycle}; mkdir -p "$out"
 set -o pipefail
-MSGPU_POISON=1 timeout -k 10 600 python -m pytest tests/test_gpu_parity.py -x -q -k "not bench and not rehearsal and not exchange" > "$out/pytest_parity_poison.log" 2>&1 || { tail -30 "$out/pytest_parity_poison.log"; echo "PARITY FAILED"; exit 1; }
+# the library that travelled must be newer than every kernel source (a failed local build leaves the old one behind)
+for f in muchsalsa_amd/csrc/*.hip muchsalsa_amd/csrc/*.cpp muchsalsa_amd/csrc/*.h include/*.h; do
+  if [ "$f" -nt muchsalsa_amd/libmsgpu.so ]; then echo "STALE LIBRARY: $f is newer than libmsgpu.so"; exit 1; fi
+done
+MSGPU_POISON=1 timeout -k 10 200 python -m pytest --timeout 60 tests/test_gpu_parity.py -x -q -k "not bench and not rehearsal and not exchange" > "$out/pytest_parity_poison.log" 2>&1 || { tail -30 "$out/pytest_parity_poison.log"; echo "PARITY FAILED"; exit 1; }
 tail -2 "$out/pytest_parity_poison.log"
 if [ "$2" != "quick" ]; then
   timeout -k 10 600 python -m pytest tests/test_gpu_fullsize.py tests/test_gpu_batched.py tests/test_golden_fixtures.py -x -q -m gpu > "$out/pytest_full.log" 2>&1 || { tail -30 "$out/pytest_full.log"; echo "FULLSIZE FAILED"; exit 1; }
