@@ -321,6 +321,31 @@ def host_to_host_leg(ctx, rows, n_batches, reps=6):
             lw.append(1e3 * (time.perf_counter() - t0))
             li.append(info2)
         k2 = int(np.argsort(lw)[len(lw) // 2])
+        # ... and with the rows in the 28-byte link form (msgpu_pack_rows: read lengths once per read, lines as runs, flags in
+        # the score's top bits; expanded in HBM by one kernel): what a loader that writes this form hands over
+        packed_leg = None
+        try:
+            packed = overlap.PackedRows(rows, int(rows["read_id"].max()) + 1 if len(rows) else 0)
+            try:
+                ctx.overlap_batched(packed, 0, copy=False, resident=True, edgematches=False)
+                pw, pi = [], []
+                for _ in range(reps):
+                    t0 = time.perf_counter()
+                    t3, info3 = ctx.overlap_batched(packed, 0, copy=False, resident=True, edgematches=False)
+                    pw.append(1e3 * (time.perf_counter() - t0))
+                    pi.append(info3)
+                k3 = int(np.argsort(pw)[len(pw) // 2])
+                packed_leg = {"ms": pw[k3], "overlap_pairs_per_s": int(len(t3["edges"])) / (pw[k3] * 1e-3), "load_ms": pi[k3]["load_ms"],
+                              "rows_bytes_h2d": int(packed.link_bytes), "line_runs": int(packed.n_runs),
+                              "ms_samples": [round(x, 3) for x in pw],
+                              "tables_equal_unpacked_run": bool(all(t3[x].tobytes() == t2[x].tobytes() for x in ("edges", "orders", "ids"))),
+                              "stage": "the same region with the row table in its 28-byte link form (msgpu_row28: %d bytes up instead "
+                                       "of %d), msgpu_overlap_batched_ex(MSGPU_BATCH_ROWS_PACKED | MSGPU_BATCH_NO_EDGEMATCHES)" % (
+                                           int(packed.link_bytes), int(rows.nbytes))}
+            finally:
+                packed.close()
+        except Exception as exc:  # noqa: BLE001 -- (a table that does not pack: the 40-byte figures stand alone)
+            packed_leg = {"error": "%s: %s" % (type(exc).__name__, exc)}
         lean_bytes = int(sum(t2[x].nbytes for x in ("edges", "orders", "ids")))
         lean_ok = bool(t2["ems"] is None and all(t2[x].tobytes() == t[x].tobytes() for x in ("edges", "orders", "ids")))
         pick = np.random.default_rng(1).integers(0, max(n_edges, 1), 10_000).astype("<u4") if n_edges else np.zeros(0, "<u4")
@@ -340,7 +365,8 @@ def host_to_host_leg(ctx, rows, n_batches, reps=6):
                 "floor": "%.0f MB up + %.0f MB down at ~55 GB/s = %.1f ms, + index and first window" % (
                     h2d / 1e6, lean_bytes / 1e6, (h2d + lean_bytes) / 55e9 * 1e3),
                 "stage": "rows in pinned host memory -> msgpu_overlap_batched_ex(MSGPU_BATCH_NO_EDGEMATCHES) -> edge, order "
-                         "and id tables in pinned host memory, EdgeMatch table resident in HBM; what pipeline.run calls"}
+                         "and id tables in pinned host memory, EdgeMatch table resident in HBM; what pipeline.run calls",
+                "packed_rows": packed_leg}
         return {"ms": wall, "without_edgematches": lean, "overlap_pairs_per_s": n_edges / (wall * 1e-3), "batches": int(infos[k]["n_batches"]),
                 "rows_bytes_h2d": int(h2d), "table_bytes_d2h": nbytes,
                 "load_ms": infos[k]["load_ms"], "first_batch_ms": infos[k]["first_batch_ms"],
@@ -1431,20 +1457,26 @@ def main():
             # never value"), so that region's figures stand here, at the top level, beside it.
             # ... and as plain scalars inside `config` and `roofline`, the two objects the driver's record keeps whole
             # (BENCH_r04.json retained `survey_8d_region` as a bare key name only)
-            link_floor_ms = (h2h.get("rows_bytes_h2d", 0) + (lean.get("table_bytes_d2h") or 0)) / 55e9 * 1e3
+            pk0 = lean.get("packed_rows") or {}
+            link_floor_ms = ((pk0.get("rows_bytes_h2d") or h2h.get("rows_bytes_h2d", 0)) + (lean.get("table_bytes_d2h") or 0)) / 55e9 * 1e3
+            pk = lean.get("packed_rows") or {}
+            best = pk if pk.get("ms") and pk.get("tables_equal_unpacked_run") and pk["ms"] < (lean.get("ms") or 1e30) else lean
             for holder in (out["config"], out["roofline"]):
-                holder["survey_8d_ms"] = lean.get("ms")
-                holder["survey_8d_overlap_pairs_per_s"] = lean.get("overlap_pairs_per_s")
+                holder["survey_8d_ms"] = best.get("ms")
+                holder["survey_8d_overlap_pairs_per_s"] = best.get("overlap_pairs_per_s")
+                holder["survey_8d_rows_form"] = "28-byte link form (msgpu_row28)" if best is pk else "40-byte msgpu_row"
+                holder["survey_8d_40_byte_rows_ms"] = lean.get("ms")
                 holder["survey_8d_all_tables_ms"] = h2h.get("ms")
                 holder["survey_8d_all_tables_overlap_pairs_per_s"] = h2h.get("overlap_pairs_per_s")
                 holder["survey_8d_link_floor_ms"] = link_floor_ms
-                holder["survey_8d_rows_bytes_h2d"] = h2h.get("rows_bytes_h2d")
+                holder["survey_8d_rows_bytes_h2d"] = (best.get("rows_bytes_h2d") if best is pk else h2h.get("rows_bytes_h2d"))
             out["config"]["survey_8d_note"] = (
                 "SURVEY 8(d)'s own region: rows in pinned host memory -> edge / order / id tables in pinned host memory (EdgeMatch "
                 "table left in HBM); all_tables = with the EdgeMatch table copied out too; link_floor = bytes up + down of the lean "
                 "region at the ~55 GB/s this PCIe link delivers.  PCIe-inclusive, so never `value`")
             out["survey_8d_region"] = {
-                "overlap_pairs_per_s": lean.get("overlap_pairs_per_s"), "ms": lean.get("ms"),
+                "overlap_pairs_per_s": best.get("overlap_pairs_per_s"), "ms": best.get("ms"),
+                "rows_form": out["config"]["survey_8d_rows_form"], "ms_with_40_byte_rows": lean.get("ms"),
                 "region": "rows in pinned host memory -> edge, order and id tables in pinned host memory "
                           "(msgpu_overlap_batched_ex, MSGPU_BATCH_NO_EDGEMATCHES: the EdgeMatch table stays in HBM, fetched per "
                           "edge list by msgpu_get_edgematches); what pipeline.run / msgpu::assemble call",

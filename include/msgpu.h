@@ -67,6 +67,33 @@ typedef struct msgpu_row {
 #define MSGPU_ROW_DIR 1u
 #define MSGPU_ROW_PRIMARY 2u
 
+/* The same table as it crosses the host link: 28 bytes per row instead of 40.  What a loader-produced table carries that the
+ * link need not (BlastFileReader.cpp:101-126 is what a row must hold): `read_len` once per READ instead of once per row (the
+ * Vertex takes it from the read's first line, Graph.cpp:148); `line` as RUNS -- accepted lines are consecutive file lines
+ * except where a line was rejected, so line = row index + a delta that changes at few places; the two flag bits in the top
+ * bits of the score (a score of 2^30 or more does not pack: msgpu_pack_rows says so and the caller keeps the 40-byte form).
+ * msgpu_load_rows_packed expands it in HBM (one kernel, ~0.1 ms for 5 M rows) to exactly the rows msgpu_load_rows would have
+ * been given: every table downstream is the same, bit for bit. */
+typedef struct msgpu_row28 {
+  uint32_t anchor_id, read_id;
+  int32_t  i_lo, i_hi, n_lo, n_hi;
+  uint32_t score_flags; /* score | direction << 30 | isPrimary << 31 */
+} msgpu_row28;
+typedef struct msgpu_packed_rows {
+  const msgpu_row28 *rows;      /* n_rows of them, in the order of the msgpu_row table                                  */
+  uint64_t           n_rows;
+  const int32_t     *read_len;  /* n_reads entries: msgpu_row::read_len of the read's FIRST row                         */
+  uint32_t           n_reads, n_runs;
+  const uint32_t    *run_start; /* n_runs ascending row indices, run_start[0] = 0: rows [run_start[k], run_start[k+1])  */
+  const uint32_t    *run_delta; /* ... have line = row index + run_delta[k]                                             */
+  void              *owner;     /* msgpu_pack_rows: the one page-locked block everything above lives in                 */
+} msgpu_packed_rows;
+/* Host code (a few threads): the packed form of a row table whose read ids are < n_reads.  Page-locked memory, to be given
+ * back with msgpu_packed_rows_free.  MSGPU_E_ARG when the table does not pack (a score >= 2^30, a read id >= n_reads, a line
+ * below its row index -- lines ascend with the rows in a loader's table) -- the 40-byte form takes every input. */
+int  msgpu_pack_rows(const msgpu_row *rows, size_t n_rows, uint32_t n_reads, msgpu_packed_rows *out);
+void msgpu_packed_rows_free(msgpu_packed_rows *p);
+
 /* graph::Edge (Edge.h:212-218) as a table row.  32 bytes.  Table order: ascending (v1, v2). */
 typedef struct msgpu_edge {
   uint32_t v1, v2;    /* Edge::getVertices(): v1 = read with the lower first line (MatchMap.cpp:204-213)      */
@@ -264,6 +291,8 @@ int      msgpu_toggle_mul(int a, int b);
  * `rows` may be in any order and may contain (read, anchor) duplicates.  Read ids must follow first-line
  * order (what msgpu_parse_paf produces), else MSGPU_E_IDS.  Host buffer; copied to HBM. */
 int msgpu_load_rows(msgpu_ctx *ctx, const msgpu_row *rows, size_t n_rows);
+/* msgpu_load_rows for the 28-byte form: packed rows over the link (page-locked: msgpu_pack_rows), expanded in HBM. */
+int msgpu_load_rows_packed(msgpu_ctx *ctx, const msgpu_packed_rows *packed);
 /* Same, rows already resident in HBM (device pointer, n_rows * 40 bytes).  The buffer is only read -- by this call and by
  * every later stage until the next load (STREAM CONTRACT rule 3: the rows must be complete in the context's stream order). */
 int msgpu_load_rows_device(msgpu_ctx *ctx, const void *d_rows, size_t n_rows);
@@ -459,10 +488,13 @@ int msgpu_overlap_batched(msgpu_ctx *ctx, const msgpu_row *rows, size_t n_rows, 
  *                               whole records over the link (A/B switch).
  *   MSGPU_BATCH_ROWS_ON_DEVICE  `rows` is a DEVICE pointer (msgpu_load_rows_device): the table is in HBM already, e.g.
  *                               all-gathered over xGMI from the 1/N slices the ranks of a node uploaded over their own links.
+ *   MSGPU_BATCH_ROWS_PACKED     `rows` points to a msgpu_packed_rows (below) and n_rows is its n_rows: 28 bytes per row over
+ *                               the host link instead of 40 (msgpu_load_rows_packed).
  */
 #define MSGPU_BATCH_RESIDENT 1u
 #define MSGPU_BATCH_NO_EDGEMATCHES 2u
 #define MSGPU_BATCH_ROWS_ON_DEVICE 4u
+#define MSGPU_BATCH_ROWS_PACKED 8u
 int msgpu_overlap_batched_ex(msgpu_ctx *ctx, const msgpu_row *rows, size_t n_rows, uint32_t n_batches, uint32_t flags,
                              msgpu_host_tables *out);
 /* MatchMap::getEdgeMatches(edge) (libms/src/matching/MatchMap.cpp:136-159) for a LIST of edges, from the EdgeMatch table

@@ -48,13 +48,18 @@ E_LAYOUT = -10
 E_TIMEOUT = -11
 
 ORD_START_V1, ORD_CONTAINED, ORD_DIR, ORD_PRIMARY = 1, 2, 4, 8
-BATCH_RESIDENT, BATCH_NO_EDGEMATCHES, BATCH_ROWS_ON_DEVICE = 1, 2, 4
+BATCH_RESIDENT, BATCH_NO_EDGEMATCHES, BATCH_ROWS_ON_DEVICE, BATCH_ROWS_PACKED = 1, 2, 4, 8
 
 
 class Params(C.Structure):
     _fields_ = [("min_matches", C.c_uint32), ("th_length", C.c_uint32), ("th_matches", C.c_uint32),
                 ("th_overlap", C.c_uint32), ("wiggle_room", C.c_uint64), ("ratio_pct", C.c_double),
                 ("alt_frac", C.c_double)]
+
+
+class PackedRows(C.Structure):  # msgpu_packed_rows: the row table's 28-byte form for the host link
+    _fields_ = [("rows", C.c_void_p), ("n_rows", C.c_uint64), ("read_len", C.c_void_p), ("n_reads", C.c_uint32),
+                ("n_runs", C.c_uint32), ("run_start", C.c_void_p), ("run_delta", C.c_void_p), ("owner", C.c_void_p)]
 
 
 class HostTables(C.Structure):  # msgpu_host_tables
@@ -151,6 +156,9 @@ SYMBOLS = [
                                          C.POINTER(C.c_uint64), C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]),
     ("msgpu_find_contraction_edges", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint32,
                                                C.c_void_p]),
+    ("msgpu_pack_rows", C.c_int, [C.c_void_p, C.c_size_t, C.c_uint32, C.POINTER(PackedRows)]),
+    ("msgpu_packed_rows_free", None, [C.POINTER(PackedRows)]),
+    ("msgpu_load_rows_packed", C.c_int, [C.c_void_p, C.POINTER(PackedRows)]),
     ("msgpu_synchronize", C.c_int, [C.c_void_p]),
     ("msgpu_set_deadline", C.c_int, [C.c_void_p, C.c_uint32]),
     ("msgpu_seq_parse", C.c_int, [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]),

@@ -258,7 +258,7 @@ struct msgpu_ctx {
   uint32_t n_list[4] = {0, 0, 0, 0};
 
   // arena
-  DevBuf rows_in, cnt_read, read_off, cursor, bkt_key, bkt_dead, by_read, read_cnt, alive_rank,
+  DevBuf rows_in, rows_pk, cnt_read, read_off, cursor, bkt_key, bkt_dead, by_read, read_cnt, alive_rank,
       anchor_cnt, anchor_off, anchor_first, anchor_off_gen, bkt2_idx, bkt2_line, by_anchor, read_len, read_first, scalars,
       scan_tmp, vis16, spos2, visits, bin_cursor, bin_start;
   DevBuf bound, cand_off, cand_j, cand_t, scr_v2, scr_start, n_cand, n_edge, n_visit_arr, lists, em_base, edge_base,
@@ -430,7 +430,7 @@ int read_scalars(msgpu_ctx *c, hipEvent_t mark = nullptr) {
 }
 
 void release_all(msgpu_ctx *c) {
-  DevBuf *all[] = {&c->sel_idx, &c->sel_cnt, &c->sel_off, &c->sel_ems, &c->g_deg, &c->g_off, &c->g_adj, &c->g_cand, &c->g_sane, &c->g_out, &c->rows_in, &c->cnt_read, &c->read_off, &c->cursor, &c->bkt_key,
+  DevBuf *all[] = {&c->sel_idx, &c->sel_cnt, &c->sel_off, &c->sel_ems, &c->g_deg, &c->g_off, &c->g_adj, &c->g_cand, &c->g_sane, &c->g_out, &c->rows_in, &c->rows_pk, &c->cnt_read, &c->read_off, &c->cursor, &c->bkt_key,
                    &c->bkt_dead, &c->by_read, &c->read_cnt, &c->alive_rank, &c->anchor_cnt, &c->anchor_off,
                    &c->anchor_first, &c->anchor_off_gen,
                    &c->bkt2_idx, &c->bkt2_line, &c->by_anchor, &c->read_len, &c->read_first, &c->scalars, &c->scan_tmp,
@@ -974,6 +974,37 @@ int msgpu_load_rows(msgpu_ctx *c, const msgpu_row *rows, size_t n_rows) {
     HIPCHK(c, hipMemcpyAsync(c->rows_in.p, rows, n_rows * sizeof(msgpu_row), hipMemcpyHostToDevice, c->stream));
   c->d_rows = c->rows_in.as<msgpu_row>();
   c->n_rows = n_rows;
+  return build_index(c);
+}
+
+int msgpu_load_rows_packed(msgpu_ctx *c, const msgpu_packed_rows *p) {
+  if (!c) return MSGPU_E_ARG;
+  if (!p || (p->n_rows && (!p->rows || !p->run_start || !p->run_delta || !p->n_runs)) || (p->n_reads && !p->read_len))
+    return fail(c, MSGPU_E_ARG, "Unexpected nullptr.");
+  if (p->n_rows > (1ull << 30)) return fail(c, MSGPU_E_ARG, "row table too large (%llu rows, at most 2^30)", (unsigned long long)p->n_rows);
+  HIPCHK(c, hipSetDevice(c->device));
+  c->state = ST_CREATED;
+  const size_t n = static_cast<size_t>(p->n_rows);
+  // 28 bytes per row + the per-read lengths + the line runs cross the link; the 40-byte rows are made in HBM
+  const size_t off_len = (n * sizeof(msgpu_row28) + 255) / 256 * 256, off_rs = off_len + (size_t(p->n_reads) * 4 + 255) / 256 * 256,
+               off_rd = off_rs + (size_t(p->n_runs) * 4 + 255) / 256 * 256, total = off_rd + size_t(p->n_runs) * 4 + 256;
+  ENSURE(c, rows_pk, total);
+  ENSURE(c, rows_in, (n ? n : 1) * sizeof(msgpu_row));
+  char *d = c->rows_pk.as<char>();
+  if (n) {
+    HIPCHK(c, hipMemcpyAsync(d, p->rows, n * sizeof(msgpu_row28), hipMemcpyHostToDevice, c->stream));
+    if (p->n_reads) HIPCHK(c, hipMemcpyAsync(d + off_len, p->read_len, size_t(p->n_reads) * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d + off_rs, p->run_start, size_t(p->n_runs) * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d + off_rd, p->run_delta, size_t(p->n_runs) * 4, hipMemcpyHostToDevice, c->stream));
+    // (a read id beyond the per-read table -- msgpu_pack_rows makes no such table -- gets length 0 and a note in a scratch
+    // word; the index build reports ids outside its id space itself)
+    launch_expand_rows(c->stream, d, n, reinterpret_cast<const int32_t *>(d + off_len), p->n_reads, reinterpret_cast<const uint32_t *>(d + off_rs),
+                       reinterpret_cast<const uint32_t *>(d + off_rd), p->n_runs, c->rows_in.as<msgpu_row>(),
+                       reinterpret_cast<uint32_t *>(d + off_rd + size_t(p->n_runs) * 4));
+    HIPCHK(c, hipGetLastError());
+  }
+  c->d_rows = c->rows_in.as<msgpu_row>();
+  c->n_rows = n;
   return build_index(c);
 }
 
@@ -1776,8 +1807,10 @@ int msgpu_overlap_batched_ex(msgpu_ctx *c, const msgpu_row *rows, size_t n_rows,
 static int overlap_batched_impl(msgpu_ctx *c, const msgpu_row *rows, size_t n_rows, uint32_t n_batches, uint32_t flags,
                                 msgpu_host_tables *out) {
   memset(out, 0, sizeof(*out));
-  if (flags & ~(MSGPU_BATCH_RESIDENT | MSGPU_BATCH_NO_EDGEMATCHES | MSGPU_BATCH_ROWS_ON_DEVICE))
+  if (flags & ~(MSGPU_BATCH_RESIDENT | MSGPU_BATCH_NO_EDGEMATCHES | MSGPU_BATCH_ROWS_ON_DEVICE | MSGPU_BATCH_ROWS_PACKED))
     return fail(c, MSGPU_E_ARG, "unknown flags %#x", flags);
+  if ((flags & MSGPU_BATCH_ROWS_PACKED) && (flags & MSGPU_BATCH_ROWS_ON_DEVICE))
+    return fail(c, MSGPU_E_ARG, "MSGPU_BATCH_ROWS_PACKED is a host form: not with MSGPU_BATCH_ROWS_ON_DEVICE");
   if (flags & MSGPU_BATCH_NO_EDGEMATCHES) flags |= MSGPU_BATCH_RESIDENT; // (an EdgeMatch that is not copied must stay)
   const bool resident = (flags & MSGPU_BATCH_RESIDENT) != 0, copy_ems = !(flags & MSGPU_BATCH_NO_EDGEMATCHES);
   const auto t_start = std::chrono::steady_clock::now();
@@ -1800,7 +1833,9 @@ static int overlap_batched_impl(msgpu_ctx *c, const msgpu_row *rows, size_t n_ro
   if (!n_batches) n_batches = copy_ems ? 8 : 3;
   c->no_prologue = n_batches > 1; // several windows: each has its own scratch offsets and read lists
   // rows host -> HBM once (unless they are there already), index build once
-  const int rc_load = (flags & MSGPU_BATCH_ROWS_ON_DEVICE) ? msgpu_load_rows_device(c, rows, n_rows) : msgpu_load_rows(c, rows, n_rows);
+  const int rc_load = (flags & MSGPU_BATCH_ROWS_PACKED)      ? msgpu_load_rows_packed(c, reinterpret_cast<const msgpu_packed_rows *>(rows))
+                      : (flags & MSGPU_BATCH_ROWS_ON_DEVICE) ? msgpu_load_rows_device(c, rows, n_rows)
+                                                             : msgpu_load_rows(c, rows, n_rows);
   c->no_prologue    = false;
   if (rc_load) return rc_load;
   out->load_ms = ms_since(t_start);

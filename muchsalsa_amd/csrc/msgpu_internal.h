@@ -170,6 +170,8 @@ void exclusive_scan_set(hipStream_t st, int k, const uint32_t *const *in, uint64
 uint32_t scan_blocks(uint64_t n);
 
 void launch_max_ids(hipStream_t st, const msgpu_row *rows, uint64_t n, uint32_t *max_ids);
+void launch_expand_rows(hipStream_t st, const void *pk, uint64_t n, const int32_t *read_len, uint32_t n_reads, const uint32_t *run_start,
+                        const uint32_t *run_delta, uint32_t n_runs, msgpu_row *out, uint32_t *err);
 // index flags (device word): why the fast by_anchor path cannot be used
 constexpr uint32_t IXF_UNSORTED = 1u; // rows are not strictly ascending in (anchor id, line)
 constexpr uint32_t IXF_SPARSE   = 2u; // an anchor id has no row

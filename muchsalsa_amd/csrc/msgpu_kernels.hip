@@ -273,6 +273,69 @@ __global__ __launch_bounds__(256) void k_max_ids(const msgpu_row *rows, uint64_t
   }
 }
 
+// The row table's 28-byte link form (include/msgpu.h: msgpu_row28 / msgpu_packed_rows) back into the 40-byte rows the index
+// build reads: read_len from the per-read table, line = row index + the delta of the row's run, the two flag bits out of the
+// score's top bits.  256 rows per workgroup, both sides through LDS so that global loads and stores are whole dwords / 16-byte
+// pieces of consecutive addresses (a 28-byte record is not a vector the memory system knows).
+__global__ __launch_bounds__(256) void k_expand_rows(const uint32_t *pk, uint64_t n, const int32_t *read_len, uint32_t n_reads,
+                                                     const uint32_t *run_start, const uint32_t *run_delta, uint32_t n_runs,
+                                                     msgpu_row *out, uint32_t *err) {
+  __shared__ uint32_t s_in[256 * 7];
+  __shared__ __attribute__((aligned(16))) uint32_t s_out[256 * 10];
+  __shared__ uint32_t s_k0;
+  const uint64_t i0  = static_cast<uint64_t>(blockIdx.x) * 256;
+  const uint32_t cnt = static_cast<uint32_t>(min(static_cast<uint64_t>(256), n - i0));
+  for (uint32_t w = threadIdx.x; w < cnt * 7; w += 256) s_in[w] = pk[i0 * 7 + w];
+  if (threadIdx.x == 0) { // the run of the workgroup's first row: last k with run_start[k] <= i0 (run_start[0] = 0)
+    uint32_t lo = 0, hi = n_runs;
+    while (hi - lo > 1) {
+      const uint32_t mid = lo + (hi - lo) / 2;
+      if (run_start[mid] <= i0) lo = mid;
+      else hi = mid;
+    }
+    s_k0 = lo;
+  }
+  __syncthreads();
+  if (threadIdx.x < cnt) {
+    const uint64_t  i = i0 + threadIdx.x;
+    const uint32_t *r = s_in + threadIdx.x * 7;
+    uint32_t lo = s_k0, hi = min(n_runs, s_k0 + 257u); // at most 256 runs begin among the workgroup's other rows
+    while (hi - lo > 1) {
+      const uint32_t mid = lo + (hi - lo) / 2;
+      if (run_start[mid] <= i) lo = mid;
+      else hi = mid;
+    }
+    const uint32_t rd = r[1], sf = r[6];
+    int32_t        len = 0;
+    if (rd < n_reads) len = read_len[rd];
+    else atomicOr(err, 2u); // (the index build reports it: an id outside the declared space)
+    uint32_t *o = s_out + threadIdx.x * 10;
+    o[0] = r[0];
+    o[1] = rd;
+    o[2] = static_cast<uint32_t>(len);
+    o[3] = r[2];
+    o[4] = r[3];
+    o[5] = r[4];
+    o[6] = r[5];
+    o[7] = sf & 0x3fffffffu;
+    o[8] = static_cast<uint32_t>(i) + run_delta[lo];
+    o[9] = sf >> 30;
+  }
+  __syncthreads();
+  static_assert(sizeof(msgpu_row) == 40, "ten dwords per row");
+  uint4       *dst = reinterpret_cast<uint4 *>(out + i0); // (i0 is a multiple of 256: 16-byte aligned)
+  const uint4 *src = reinterpret_cast<const uint4 *>(s_out);
+  const uint32_t quads = cnt * 10 / 4, tail = cnt * 10 % 4;
+  for (uint32_t q = threadIdx.x; q < quads; q += 256) dst[q] = src[q];
+  if (threadIdx.x < tail) reinterpret_cast<uint32_t *>(out + i0)[quads * 4 + threadIdx.x] = s_out[quads * 4 + threadIdx.x];
+}
+void launch_expand_rows(hipStream_t st, const void *pk, uint64_t n, const int32_t *read_len, uint32_t n_reads, const uint32_t *run_start,
+                        const uint32_t *run_delta, uint32_t n_runs, msgpu_row *out, uint32_t *err) {
+  if (n)
+    hipLaunchKernelGGL(k_expand_rows, dim3(static_cast<uint32_t>((n + 255) / 256)), dim3(256), 0, st, static_cast<const uint32_t *>(pk), n,
+                       read_len, n_reads, run_start, run_delta, n_runs, out, err);
+}
+
 // one launch instead of six memsets: zero / all-ones fill of the per-read and per-anchor tables of the index build
 struct IndexInitArgs {
   uint32_t *zero[8];

@@ -9,7 +9,10 @@
 #include <string.h>
 
 #include <algorithm>
+#include <utility>
+#include <vector>
 
+#include "asm_internal.h"
 #include "host_pool.h"
 #include "msgpu_internal.h"
 
@@ -108,3 +111,80 @@ void unpack_wire_host(const uint8_t *w_edges, const uint8_t *w_orders, const uin
 }
 
 } // namespace msgpu
+
+// ---- the row table's 28-byte form for the host link (include/msgpu.h, msgpu_row28 / msgpu_packed_rows) ---------------------------
+// BlastFileReader.cpp:101-126 is what a row must hold; what the link need not carry is derived in HBM by k_expand_rows.
+extern "C" int msgpu_pack_rows(const msgpu_row *rows, size_t n_rows, uint32_t n_reads, msgpu_packed_rows *out) {
+  using namespace msgpu;
+  if (!out || (n_rows && !rows) || n_rows >= (1ull << 32)) return MSGPU_E_ARG;
+  memset(out, 0, sizeof(*out));
+  // pass 1 (threads): what does not pack; the places where line - row index changes; first row of every read
+  const unsigned nt = 16;
+  const size_t   per = (n_rows + nt - 1) / nt;
+  std::vector<std::vector<std::pair<uint32_t, uint32_t>>> runs(nt); // (row, delta) where the delta differs from the row before
+  std::vector<int>                                        bad(nt, 0);
+  HostPool::get().run(nt, nt, [&](size_t t) {
+    const size_t lo = std::min(n_rows, t * per), hi = std::min(n_rows, lo + per);
+    for (size_t i = lo; i < hi; ++i) {
+      const msgpu_row &r = rows[i];
+      if (r.score >= (1u << 30) || r.read_id >= n_reads || r.line < i || (r.flags & ~3u)) {
+        bad[t] = 1;
+        return;
+      }
+      const uint32_t d = r.line - static_cast<uint32_t>(i);
+      if (i == lo || d != rows[i - 1].line - static_cast<uint32_t>(i - 1)) runs[t].emplace_back(static_cast<uint32_t>(i), d);
+    }
+  });
+  for (int b : bad)
+    if (b) return MSGPU_E_ARG;
+  // (a piece's first row always opens a run: merge it into the piece before where the delta did not change)
+  std::vector<std::pair<uint32_t, uint32_t>> all;
+  for (unsigned t = 0; t < nt; ++t)
+    for (const auto &rn : runs[t])
+      if (all.empty() || all.back().second != rn.second) all.push_back(rn);
+  if (all.empty()) all.emplace_back(0u, 0u);
+  const size_t n_runs = all.size();
+  const size_t off_len = (n_rows * sizeof(msgpu_row28) + 63) / 64 * 64, off_rs = off_len + (size_t(n_reads) * 4 + 63) / 64 * 64,
+               off_rd = off_rs + (n_runs * 4 + 63) / 64 * 64, total = off_rd + n_runs * 4 + 64;
+  char *blk = static_cast<char *>(pinned_block_alloc(total));
+  if (!blk) return MSGPU_E_NOMEM;
+  msgpu_row28 *pr  = reinterpret_cast<msgpu_row28 *>(blk);
+  int32_t     *len = reinterpret_cast<int32_t *>(blk + off_len);
+  uint32_t    *rs = reinterpret_cast<uint32_t *>(blk + off_rs), *rd = reinterpret_cast<uint32_t *>(blk + off_rd);
+  for (size_t k = 0; k < n_runs; ++k) {
+    rs[k] = all[k].first;
+    rd[k] = all[k].second;
+  }
+  HostPool::get().run(nt, nt, [&](size_t t) {
+    const size_t lo = std::min(n_rows, t * per), hi = std::min(n_rows, lo + per);
+    for (size_t i = lo; i < hi; ++i) {
+      const msgpu_row &r = rows[i];
+      pr[i] = msgpu_row28{r.anchor_id, r.read_id, r.i_lo, r.i_hi, r.n_lo, r.n_hi, r.score | ((r.flags & 1u) << 30) | ((r.flags & 2u) << 30)};
+    }
+  });
+  // the Vertex' length is its FIRST line's (Graph.cpp:148): lowest line number among the read's rows
+  std::vector<uint32_t> first_line(n_reads, 0xffffffffu);
+  for (size_t i = 0; i < n_rows; ++i) {
+    const msgpu_row &r = rows[i];
+    if (r.line < first_line[r.read_id]) {
+      first_line[r.read_id] = r.line;
+      len[r.read_id]        = r.read_len;
+    }
+  }
+  for (uint32_t v = 0; v < n_reads; ++v)
+    if (first_line[v] == 0xffffffffu) len[v] = 0;
+  out->rows      = pr;
+  out->n_rows    = n_rows;
+  out->read_len  = len;
+  out->n_reads   = n_reads;
+  out->n_runs    = static_cast<uint32_t>(n_runs);
+  out->run_start = rs;
+  out->run_delta = rd;
+  out->owner     = blk;
+  return MSGPU_OK;
+}
+extern "C" void msgpu_packed_rows_free(msgpu_packed_rows *p) {
+  if (p && p->owner) msgpu::pinned_block_free(p->owner);
+  if (p) memset(p, 0, sizeof(*p));
+}
+

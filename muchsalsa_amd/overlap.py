@@ -123,6 +123,30 @@ class PinnedRows:
     __del__ = close
 
 
+class PackedRows:
+    """msgpu_pack_rows: a msgpu_row table in the 28-byte form that crosses the host link (page-locked memory; include/msgpu.h
+    msgpu_row28 / msgpu_packed_rows): read lengths once per read, lines as runs, flags in the score's top bits.  Raises
+    MsgpuError(MSGPU_E_ARG) for a table that does not pack (a score of 2^30 or more, ...)."""
+
+    def __init__(self, rows, n_reads):
+        rows = np.ascontiguousarray(rows, dtype=ROW_DTYPE)
+        self._L = _lib.lib()
+        self.c = _lib.PackedRows()
+        rc = self._L.msgpu_pack_rows(rows.ctypes.data if len(rows) else None, len(rows), int(n_reads), C.byref(self.c))
+        if rc != 0:
+            self.c = None
+            raise MsgpuError(rc)
+        self.n_rows, self.n_runs = int(self.c.n_rows), int(self.c.n_runs)
+        self.link_bytes = 28 * self.n_rows + 4 * int(n_reads) + 8 * self.n_runs
+
+    def close(self):
+        if getattr(self, "c", None) is not None:
+            self._L.msgpu_packed_rows_free(C.byref(self.c))
+            self.c = None
+
+    __del__ = close
+
+
 class OverlapContext:
     def __init__(self, device=0, params=None):
         self._L = _lib.lib()
@@ -191,6 +215,10 @@ class OverlapContext:
         rows = np.ascontiguousarray(rows, dtype=ROW_DTYPE)
         self._check(self._L.msgpu_load_rows(self._h, rows.ctypes.data, len(rows)))
 
+    def load_rows_packed(self, packed):
+        """msgpu_load_rows_packed: a PackedRows table (28 bytes per row over the link, expanded in HBM)"""
+        self._check(self._L.msgpu_load_rows_packed(self._h, C.byref(packed.c)))
+
     def load_rows_device(self, dev_ptr, n_rows, keep_alive=None):
         self._keep = keep_alive  # the caller's device buffer must outlive the context's use of it
         self._check(self._L.msgpu_load_rows_device(self._h, C.c_void_p(dev_ptr), n_rows))
@@ -242,6 +270,9 @@ class OverlapContext:
         if device_rows is not None:
             ptr, n = C.c_void_p(int(device_rows[0]) or None), int(device_rows[1])
             flags |= _lib.BATCH_ROWS_ON_DEVICE
+        elif isinstance(rows, PackedRows):  # MSGPU_BATCH_ROWS_PACKED: `rows` = the descriptor
+            ptr, n = C.cast(C.byref(rows.c), C.c_void_p), rows.n_rows
+            flags |= _lib.BATCH_ROWS_PACKED
         else:
             arr = rows.array if isinstance(rows, PinnedRows) else np.ascontiguousarray(rows, dtype=ROW_DTYPE)
             ptr, n = (arr.ctypes.data if len(arr) else None), len(arr)
