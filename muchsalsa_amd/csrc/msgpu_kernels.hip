@@ -1697,23 +1697,18 @@ __device__ __forceinline__ int paths_of_direction(unsigned long long act, bool d
                                                   uint32_t n2, double alt_frac, PathRec *paths) {
   if (act == 0) return 0; // :150-152
   const bool mine = (act >> lane) & 1ull;
-  // argmax, :201-210: strict > starting from 0.0, first maximum wins, iterator starts at begin()
+  // argmax, :201-210: strict > starting from 0.0, first maximum wins, iterator starts at begin().  The maximum alone is
+  // reduced over the wavefront (one v_max_f64 per butterfly step; the scores are finite, so the hardware maximum is the
+  // comparison's); the FIRST lane that holds it comes out of one ballot -- the index used to travel through the butterfly
+  // with two compares and three selects per step.
   double best = mine ? pop : -1.0;
-  int    bi   = mine ? lane : 64;
 #pragma unroll
-  for (int d = 32; d > 0; d >>= 1) {
-    double ob = __shfl_xor(best, d);
-    int    oi = __shfl_xor(bi, d);
-    if (ob > best || (ob == best && oi < bi)) {
-      best = ob;
-      bi   = oi;
-    }
-  }
+  for (int d = 32; d > 0; d >>= 1) best = __builtin_fmax(best, __shfl_xor(best, d));
   double maxv;
   int    maxi;
   if (best > 0.0) {
     maxv = best;
-    maxi = bi;
+    maxi = __builtin_ctzll(__ballot(mine && pop == best));
   } else {
     maxv = 0.0;
     maxi = __builtin_ctzll(act);
@@ -2303,22 +2298,15 @@ __device__ __forceinline__ uint32_t paths_of_direction_sub(uint32_t act, bool di
                                                            uint32_t n1, uint32_t n2, double alt_frac, SubPath *paths) {
   const bool live = act != 0; // :150-152
   const bool mine = (act >> sl) & 1u;
-  double     best = mine ? pop : -1.0; // argmax, :201-210
-  int        bi   = mine ? sl : 64;
+  double     best = mine ? pop : -1.0; // argmax, :201-210 (as in paths_of_direction: the maximum by v_max_f64, its first lane by a ballot)
 #pragma unroll
-  for (int d = W / 2; d > 0; d >>= 1) {
-    const double ob = __shfl_xor(best, d);
-    const int    oi = __shfl_xor(bi, d);
-    if (ob > best || (ob == best && oi < bi)) {
-      best = ob;
-      bi   = oi;
-    }
-  }
+  for (int d = W / 2; d > 0; d >>= 1) best = __builtin_fmax(best, __shfl_xor(best, d));
   double maxv = 0.0;
   int    maxi = live ? __builtin_ctz(act) : 0;
   if (best > 0.0) {
     maxv = best;
-    maxi = bi;
+    const uint32_t at = group_bits<W>(__ballot(mine && pop == best), gbase);
+    maxi = at ? __builtin_ctz(at) : 0;
   }
   const uint32_t prim_lanes = group_bits<W>(__ballot(mine && em_prim), gbase);
   const uint32_t m          = __shfl(pm, gbase + maxi);
