@@ -144,8 +144,7 @@ def pmc_stage(workload, world, prefixes):
 STAGE_KERNELS = {  # the kernels of each stage, by name prefix (profiles/*/kernel_stats.csv)
     "index": ("msgpu::k_index_", "msgpu::k_bin_scan", "msgpu::k_sort_read", "msgpu::k_check_", "msgpu::k_select_anchor_off",
               "msgpu::k_scatter_", "msgpu::k_rank_anchor", "msgpu::k_max_ids"),
-    "candidates": ("msgpu::k_candidates", "msgpu::k_emit_edges", "msgpu::k_classify_reads", "msgpu::k_count_classes", "msgpu::k_bound",
-                   "msgpu::k_size_"),
+    "candidates": ("msgpu::k_candidates", "msgpu::k_cand_reduce", "msgpu::k_emit_edges", "msgpu::k_classify_reads", "msgpu::k_bound"),
     "compact": ("msgpu::k_compact",),
 }
 

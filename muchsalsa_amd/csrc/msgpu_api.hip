@@ -1115,20 +1115,23 @@ int msgpu_calculate_edges(msgpu_ctx *c) {
   static const bool no_fork = getenv("MSGPU_NO_FORK") != nullptr; // measurement switch: the classes one after the other
   const bool fork = (c->n_list[1] || c->n_list[2]) && c->n_list[0] && !no_fork;
   if (fork) {
-    // class 1 beside class 0 on a stream of its own; the handful of class-2 workgroups IN FRONT of class 0 on the main
-    // stream (17 us alone on an empty GPU): a launch on another stream costs ~15-20 us of host latency each, and class 0 --
-    // the stage's critical kernel -- used to start 36 us late behind two of them
-    if (c->n_list[1]) {
-      HIPCHK(c, hipEventRecord(c->ev_side[0], st));
-      HIPCHK(c, hipStreamWaitEvent(c->side_stream2, c->ev_side[0], 0));
+    // class 1 beside class 0 on a stream of its own, and the handful of class-2 workgroups on the other side stream (idle until
+    // the chain stage), launched FIRST: alone in front of class 0 on the main stream they cost 17 us of every step (one or two
+    // workgroups at the latency of a whole kernel -- a fifth of a shard-of-eight's candidate stage, profiles/r5_05)
+    HIPCHK(c, hipEventRecord(c->ev_side[0], st));
+    if (c->n_list[2]) {
+      HIPCHK(c, hipStreamWaitEvent(c->side_stream, c->ev_side[0], 0));
+      launch_candidates(c->side_stream, a, 2, l2, c->n_list[2]);
+      HIPCHK(c, hipEventRecord(c->ev_side[1], c->side_stream));
     }
-    launch_candidates(st, a, 2, l2, c->n_list[2]);
+    if (c->n_list[1]) HIPCHK(c, hipStreamWaitEvent(c->side_stream2, c->ev_side[0], 0));
     launch_candidates(st, a, 0, l0, c->n_list[0]);
     if (c->n_list[1]) {
       launch_candidates(c->side_stream2, a, 1, l1, c->n_list[1]);
       HIPCHK(c, hipEventRecord(c->ev_side2, c->side_stream2));
       HIPCHK(c, hipStreamWaitEvent(st, c->ev_side2, 0));
     }
+    if (c->n_list[2]) HIPCHK(c, hipStreamWaitEvent(st, c->ev_side[1], 0));
   } else {
     launch_candidates(st, a, 2, l2, c->n_list[2]);
     launch_candidates(st, a, 1, l1, c->n_list[1]);
@@ -1312,10 +1315,24 @@ int msgpu_chaining_and_overlaps(msgpu_ctx *c) {
     const uint32_t *list = c->cls_list.as<uint32_t>();
     const uint32_t *l64 = list, *l32 = l64 + c->n_cls[2], *l16 = l32 + c->n_cls[1], *l8 = l16 + c->n_cls[0]; // sizes descending
     HIPCHK(c, hipEventRecord(ck_begin, st));
+    // The two short classes beside the two long ones, on the side stream the candidate stage used: a kernel of a few thousand
+    // wavefronts lasts as long as ONE of its wavefronts (45 us each for the 16- and 8-wide classes of a shard of eight, one
+    // after the other behind k_chain and k_chain_sub<32>: a third of that shard's chain stage, profiles/r5_05); side by side
+    // they fill what the long classes leave.  On the whole job the four kernels' work is the same either way.
+    static const bool serial = getenv("MSGPU_CHAIN_SERIAL") != nullptr; // A/B switch: the four classes one after the other
+    const bool beside = !serial && (c->n_cls[0] || c->n_cls[3]) && (c->n_cls[2] || c->n_cls[1]);
+    if (beside) {
+      HIPCHK(c, hipEventRecord(c->ev_side2, st));
+      HIPCHK(c, hipStreamWaitEvent(c->side_stream2, c->ev_side2, 0));
+    }
     launch_chain(st, a, l64, c->n_cls[2]); // the long ones first: the short classes fill the tail
     launch_chain_sub(st, a, 32, l32, c->n_cls[1]);
-    launch_chain_sub(st, a, 16, l16, c->n_cls[0]);
-    launch_chain_sub(st, a, 8, l8, c->n_cls[3]);
+    launch_chain_sub(beside ? c->side_stream2 : st, a, 16, l16, c->n_cls[0]);
+    launch_chain_sub(beside ? c->side_stream2 : st, a, 8, l8, c->n_cls[3]);
+    if (beside) {
+      HIPCHK(c, hipEventRecord(c->ev_side2, c->side_stream2));
+      HIPCHK(c, hipStreamWaitEvent(st, c->ev_side2, 0));
+    }
   } else {
     HIPCHK(c, hipEventRecord(ck_begin, st));
     launch_chain(st, a, nullptr, 0);
