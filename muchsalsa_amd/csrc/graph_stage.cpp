@@ -287,9 +287,59 @@ bool build_csr_undirected_parallel(uint32_t n, const uint32_t *from, const uint3
   return true;
 }
 
+// The same for a DIRECTED adjacency (the successor / predecessor lists of a component's DiGraph: on the critical path of the
+// largest component, where the serial builder took a quarter of getDirectedGraph): every thread counts the sources of its
+// stretch of the edge list, a prefix over (vertex, thread) gives every thread its first slot inside the vertex's segment (edge
+// order is kept: stretches ascend with the threads), the threads drop their arcs, segments that are not ascending are sorted.
+bool build_csr_directed_parallel(uint32_t n, const uint32_t *from, const uint32_t *to, size_t m, Csr &c) {
+  const unsigned nt = stage_threads();
+  if (std::getenv("MSGPU_GRAPH_SERIAL_CSR")) return false; // measurement switch
+  if (nt < 2 || m < par_min() || static_cast<size_t>(nt) * (static_cast<size_t>(n) + 1) > (size_t(1) << 26)) return false;
+  const size_t                stride = static_cast<size_t>(n) + 1;
+  std::unique_ptr<uint32_t[]> hist(new uint32_t[static_cast<size_t>(nt) * stride]); // [thread][vertex]; zeroed by its threads
+  auto chunk = [&](unsigned t) { return std::make_pair(m * t / nt, m * (t + 1) / nt); };
+  auto on_threads = [&](auto &&body) { StagePool::get().run(nt, nt, [&](size_t t) { body(static_cast<unsigned>(t)); }); };
+  on_threads([&](unsigned t) {
+    uint32_t *h = hist.get() + static_cast<size_t>(t) * stride;
+    std::fill(h, h + stride, 0u);
+    for (size_t i = chunk(t).first; i < chunk(t).second; ++i) ++h[from[i]];
+  });
+  c.off.assign(stride, 0);
+  on_threads([&](unsigned t) {
+    const size_t v0 = stride * t / nt, v1 = stride * (t + 1) / nt;
+    for (size_t v = v0; v < v1; ++v) {
+      uint32_t run = 0;
+      for (unsigned k = 0; k < nt; ++k) {
+        uint32_t      &h   = hist[static_cast<size_t>(k) * stride + v];
+        const uint32_t cnt = h;
+        h                  = run;
+        run += cnt;
+      }
+      if (v < n) c.off[v + 1] = run;
+    }
+  });
+  for (uint32_t v = 0; v < n; ++v) c.off[v + 1] += c.off[v];
+  c.arcs.resize(c.off[n]);
+  on_threads([&](unsigned t) {
+    uint32_t *h = hist.get() + static_cast<size_t>(t) * stride;
+    for (size_t i = chunk(t).first; i < chunk(t).second; ++i) c.arcs[c.off[from[i]] + h[from[i]]++] = Arc{to[i], static_cast<uint32_t>(i)};
+  });
+  on_threads([&](unsigned t) {
+    for (size_t v = static_cast<size_t>(n) * t / nt; v < static_cast<size_t>(n) * (t + 1) / nt; ++v) {
+      if (c.off[v + 1] - c.off[v] < 2) continue;
+      Arc *b = c.arcs.data() + c.off[v], *e = c.arcs.data() + c.off[v + 1];
+      bool sorted = true;
+      for (Arc *p = b; p + 1 < e && sorted; ++p) sorted = p->to <= (p + 1)->to;
+      if (!sorted) std::stable_sort(b, e, [](const Arc &x, const Arc &y) { return x.to < y.to; });
+    }
+  });
+  return true;
+}
+
 Csr build_csr(uint32_t n, const uint32_t *from, const uint32_t *to, size_t m, bool both_ways) {
   Csr c;
   if (both_ways && build_csr_undirected_parallel(n, from, to, m, c)) return c;
+  if (!both_ways && build_csr_directed_parallel(n, from, to, m, c)) return c;
   c.off.assign(static_cast<size_t>(n) + 1, 0);
   for (size_t i = 0; i < m; ++i) {
     ++c.off[from[i] + 1];
@@ -572,6 +622,7 @@ struct msgpu_graph {
   std::vector<Vertex>  V;
   RawArray<Edge>       E; // (constructed in graph_create's parallel fill)
   std::vector<uint8_t> o_kept;  // per order: still on its edge (findDeletableEdges drops the contained ones)
+  std::vector<uint8_t> o_fwd;   // per kept order: it runs E.a -> E.b in its component's DiGraph (getDirectedGraph, pass 1)
   struct OLite { // what the walks over the graph read of an EdgeOrder (16 of its 64 bytes: the random accesses of
     uint32_t start, end, base, flags; // getDirectedGraph stay inside a quarter of the cache footprint)
   };
@@ -714,6 +765,11 @@ DiG get_directed_graph(msgpu_graph &g, uint32_t cid, const std::vector<uint32_t>
   // (a vertex popped early meets most of its neighbours unpopped, a late one hardly any: pieces by counter, not by range)
   // (vertices, each with tens of arcs: pieces of 2048; the tests' small graphs get pieces that still cut them)
   const size_t grain = par_min() >= (size_t(1) << 16) ? 2048 : std::max<size_t>(16, par_min() / 32);
+  // the direction of every kept order, found once (pass 1) and read back by pass 2: an order belongs to one edge, an edge is
+  // handled by one vertex, so no two threads write the same byte (pass 2 used to find each direction twice more: two more
+  // random reads of the order and the edge record per order)
+  require(g.o_fwd.size() >= g.o_kept.size(), "getDirectedGraph: direction table not allocated");
+  uint8_t *const o_fwd = g.o_fwd.data();
   parallel_dynamic(np, grain, [&](size_t b, size_t e) { // pass 1: directed edges and orders per processing vertex
     for (size_t i = b; i < e; ++i) {
       uint64_t ns = 0, no = 0;
@@ -722,7 +778,9 @@ DiG get_directed_graph(msgpu_graph &g, uint32_t cid, const std::vector<uint32_t>
         const uint32_t lo = g.E[ue].ord_lo, hi = lo + g.E[ue].ord_cnt;
         for (uint32_t oi = lo; oi < hi; ++oi) {
           if (!g.o_kept[oi]) continue;
-          (direction_of(ue, oi, nb, toggle) ? fwd : bwd) = true;
+          const bool f = direction_of(ue, oi, nb, toggle);
+          o_fwd[oi]    = f ? 1 : 0;
+          (f ? fwd : bwd) = true;
           ++no;
         }
         ns += (fwd ? 1 : 0) + (bwd ? 1 : 0);
@@ -750,9 +808,11 @@ DiG get_directed_graph(msgpu_graph &g, uint32_t cid, const std::vector<uint32_t>
         const uint32_t     lo = E.ord_lo, hi = lo + E.ord_cnt;
         int64_t            s_fwd = -1, s_bwd = -1; // the two possible directed edges, numbered in order of first use
         uint32_t           n_fwd = 0, n_bwd = 0;
+        (void)nb;
+        (void)toggle;
         for (uint32_t oi = lo; oi < hi; ++oi) {
           if (!g.o_kept[oi]) continue;
-          if (direction_of(ue, oi, nb, toggle)) {
+          if (o_fwd[oi]) {
             if (s_fwd < 0) s_fwd = static_cast<int64_t>(slot++);
             ++n_fwd;
           } else {
@@ -778,7 +838,7 @@ DiG get_directed_graph(msgpu_graph &g, uint32_t cid, const std::vector<uint32_t>
         uint64_t pf = fwd_first ? o_first : o_second, pb = fwd_first ? o_second : o_first;
         for (uint32_t oi = lo; oi < hi; ++oi) {
           if (!g.o_kept[oi]) continue;
-          if (direction_of(ue, oi, nb, toggle)) dg.ord[pf++] = oi;
+          if (o_fwd[oi]) dg.ord[pf++] = oi;
           else dg.ord[pb++] = oi;
         }
         op += n_fwd + n_bwd;
@@ -792,33 +852,21 @@ DiG get_directed_graph(msgpu_graph &g, uint32_t cid, const std::vector<uint32_t>
     if (g.V[v].in_dg) dg.ids.push_back(v);
   std::sort(dg.ids.begin(), dg.ids.end());
   dg.n = static_cast<uint32_t>(dg.ids.size());
-  for (uint32_t l = 0; l < dg.n; ++l) g.V[dg.ids[l]].loc = l;
+  parallel_chunks(dg.n, [&](unsigned, size_t b, size_t e) {
+    for (size_t l = b; l < e; ++l) g.V[dg.ids[l]].loc = static_cast<uint32_t>(l);
+  });
   dg.ea.resize(m);
   dg.eb.resize(m);
-  for (size_t i = 0; i < m; ++i) {
-    dg.ea[i] = g.V[ea[i]].loc;
-    dg.eb[i] = g.V[eb[i]].loc;
-  }
-  tk("  dg: ids + order lists");
-  if (m > par_min() && stage_threads() > 1) { // the two adjacencies of a large component side by side
-    std::exception_ptr err;
-    std::thread        t([&] {
-      try {
-        dg.pred = build_csr(dg.n, dg.eb.data(), dg.ea.data(), m, false);
-      } catch (...) { err = std::current_exception(); }
-    });
-    try {
-      dg.succ = build_csr(dg.n, dg.ea.data(), dg.eb.data(), m, false);
-    } catch (...) {
-      t.join();
-      throw;
+  parallel_chunks(m, [&](unsigned, size_t b, size_t e) { // (a million random reads of the vertex table: on all threads)
+    for (size_t i = b; i < e; ++i) {
+      dg.ea[i] = g.V[ea[i]].loc;
+      dg.eb[i] = g.V[eb[i]].loc;
     }
-    t.join();
-    if (err) std::rethrow_exception(err);
-  } else {
-    dg.succ = build_csr(dg.n, dg.ea.data(), dg.eb.data(), m, false);
-    dg.pred = build_csr(dg.n, dg.eb.data(), dg.ea.data(), m, false);
-  }
+  });
+  tk("  dg: ids + order lists");
+  // the two adjacencies, each on all the stage's threads (round 5: they were two serial builds side by side)
+  dg.succ = build_csr(dg.n, dg.ea.data(), dg.eb.data(), m, false);
+  dg.pred = build_csr(dg.n, dg.eb.data(), dg.ea.data(), m, false);
   tk("  dg: succ / pred CSR");
   return dg;
 }
@@ -1471,6 +1519,7 @@ static int graph_create(const msgpu_edge *edges, uint64_t n_edges, const msgpu_e
     tick("  create: copies + vertices");
     g->E.allocate(n_edges);
     g->o_kept.assign(n_orders, 0);
+    g->o_fwd.assign(n_orders, 0); // (sized here: the component workers of msgpu_graph_linearize write it side by side)
     g->ol.allocate(n_orders);
     tick("  create: table allocation");
     std::atomic<int> bad{0};
