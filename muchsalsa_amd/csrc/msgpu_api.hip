@@ -231,6 +231,7 @@ struct msgpu_ctx {
   bool         prologue_ok = false; // the candidate stage's opening ran with the index build (whole table, fast index)
   bool         scalars_clean = false; // the scalar block is zero where a build counts from nothing (k_index_epilogue's publisher left it so)
   bool         bin_clean = false;     // the bin path's bucket cursors are zero (k_index_sort_bin leaves them so)
+  size_t       bin_zero_words = 0;    // ... as far as an init launch has ever zeroed them (a larger job needs words beyond that)
   uint32_t     prologue_shard = 0, prologue_nshards = 1; // the shard the index build's classification was made for
   uint64_t     prologue_own = 0;      // ... and the visits of its owner reads
   bool         nlists_clean = false; // the four list cursors of k_classify_reads are zero (see msgpu_calculate_edges)
@@ -498,7 +499,11 @@ int build_index_once(msgpu_ctx *c, bool force_generic, bool two_pass, bool bin, 
   if (bshift) {
     const void *before = c->bin_cursor.p;
     ENSURE(c, bin_cursor, (size_t(bpasses) * (nb + 1) + 1) * 4); // per pass: the bucket cursors; last word: by_read rows of the passes so far
-    if (c->bin_cursor.p != before) c->bin_clean = false;
+    if (c->bin_cursor.p != before) {
+      c->bin_clean      = false;
+      c->bin_zero_words = 0;
+    }
+    if (size_t(bpasses) * (nb + 1) + 1 > c->bin_zero_words) c->bin_clean = false; // (words no init launch has reached yet)
     ENSURE(c, bin_start, (size_t(nb) + 2) * 4);
     ENSURE(c, bucket_visits, ((size_t(V) >> BIN_RPB_SHIFT) + 2) * 4);
   }
@@ -544,6 +549,7 @@ int build_index_once(msgpu_ctx *c, bool force_generic, bool two_pass, bool bin, 
     ENSURE(c, n_edge, (size_t(V) + 1) * 4);
     ENSURE(c, cand_sums, cand_sums_bytes(V));
   }
+  size_t zero_words_known = 0;
   {
     // (the bin path counts per bucket, not per read: its cursors take the per-read counters' place in the zero list.  What the
     // candidate kernels add to is zeroed by k_classify_reads, the launch in front of them.)
@@ -556,6 +562,7 @@ int build_index_once(msgpu_ctx *c, bool force_generic, bool two_pass, bool bin, 
     // leaves them so; sparse anchor ids are found by counting scaffolds, not by looking into a filled anchor_first)
     if (!bshift) launch_index_init8(st, zero, n_zero, ones, n_ones);
     else if (!c->bin_clean) {
+      c->bin_zero_words     = std::max<size_t>(c->bin_zero_words, n_zero[0]);
       uint32_t *const z4[4] = {zero[0], nullptr, nullptr, nullptr};
       const uint32_t  n4[4] = {n_zero[0], 0, 0, 0};
       uint32_t *const o2[2] = {nullptr, nullptr};
@@ -563,6 +570,10 @@ int build_index_once(msgpu_ctx *c, bool force_generic, bool two_pass, bool bin, 
       launch_index_init(st, z4, n4, o2, no2);
     }
     c->bin_clean = false;
+    if (bshift) { // while a build is in flight nothing is known to be zero: it is again once the build has come back clean
+      zero_words_known  = c->bin_zero_words;
+      c->bin_zero_words = 0;
+    }
   }
   uint32_t *d_flags = scalar<uint32_t>(c, SC_IXFLAGS);
   if (force_generic) {
@@ -688,7 +699,10 @@ int build_index_once(msgpu_ctx *c, bool force_generic, bool two_pass, bool bin, 
   }
   const uint32_t err = *host_scalar<uint32_t>(c, SC_ERR), ixf = *host_scalar<uint32_t>(c, SC_IXFLAGS);
   c->cand_zeroed = false;
-  if (bshift && fused_readback && ixf == 0 && err == 0) c->scalars_clean = c->bin_clean = true; // (zero at rest, see above)
+  if (bshift && fused_readback && ixf == 0 && err == 0) { // (zero at rest, see above)
+    c->scalars_clean = c->bin_clean = true;
+    c->bin_zero_words = zero_words_known;
+  }
   if (want_prologue && ixf == 0 && err == 0) {
     c->prologue_ok      = true;
     c->cand_zeroed      = true;

@@ -229,6 +229,49 @@ def test_index_bin_path_and_atomic_path_agree(oracle, monkeypatch):
     assert_tables_equal(t, oracle.overlap(long_rows), "long reads")
 
 
+def test_a_context_reused_for_growing_and_failing_jobs_stays_on_the_bin_path(oracle):
+    """The bin path's bucket cursors and the scalar block are zero AT REST (no init launch, no memset per build: round 5): whoever
+    consumes a counter last leaves it zero.  The corner cases of that bookkeeping on ONE context: a job with more buckets than any
+    before it but inside the buffer's slack (words no init launch has reached: poisoned when the suite runs under MSGPU_POISON=1,
+    as tools/gpu_cycle.sh does), a job the bin path refuses (duplicates: flags raised, cursors left behind), the same sizes again
+    afterwards, and back-to-back loads without the later stages -- every loader-shaped job must take the bin path and give the
+    oracle's tables."""
+    from muchsalsa_amd import _lib, overlap, synth
+
+    def tables_of(ctx, rows):
+        ctx.load_rows(rows)
+        ctx.calculate_edges()
+        ctx.chaining_and_overlaps()
+        return ctx.tables(), int(ctx.counts().index_path)
+
+    small = synth.synth_rows(3000, 2500, 9000, 5)
+    larger = synth.synth_rows(3900, 2500, 11000, 6)  # 244 buckets instead of 188: inside the cursor buffer's slack
+    with overlap.OverlapContext(0) as ctx:
+        for name, rows in (("small", small), ("larger", larger), ("small again", small)):
+            got, path = tables_of(ctx, rows)
+            assert path == _lib.INDEX_BIN, (name, path)
+            assert_tables_equal(got, oracle.overlap(rows), name)
+        dup = larger[100:101].copy()  # a second row of one (read, anchor) pair on a later line: the bin path raises its flag and stops
+        dup["line"] = larger["line"].max() + 5
+        k = int(np.searchsorted(larger["anchor_id"], dup["anchor_id"][0], side="right"))
+        with_dup = np.concatenate([larger[:k], dup, larger[k:]])
+        got, path = tables_of(ctx, with_dup)
+        assert (path & 3) != _lib.INDEX_BIN, path
+        assert_tables_equal(got, oracle.overlap(larger), "duplicate pair")
+        for name, rows in (("larger after the refused job", larger), ("small after it", small)):
+            got, path = tables_of(ctx, rows)
+            assert path == _lib.INDEX_BIN, (name, path)
+            assert_tables_equal(got, oracle.overlap(rows), name)
+        ctx.load_rows(small)   # loads without the later stages: the list cursors of the first are still standing
+        ctx.load_rows(larger)
+        got, path = tables_of(ctx, small)
+        assert path == _lib.INDEX_BIN and ctx.counts().n_lost_publications == 0
+        assert_tables_equal(got, oracle.overlap(small), "after two bare loads")
+        ctx.calculate_edges()  # the candidate stage twice on one index: its sums start over
+        ctx.chaining_and_overlaps()
+        assert_tables_equal(ctx.tables(), oracle.overlap(small), "second candidate stage on the same index")
+
+
 def test_index_bin_path_takes_several_passes_beyond_131072_reads(oracle):
     """k_index_bin bins 8192 buckets of 16 read ids per pass: 139,978 reads take two passes over the row table (the second one's
     buckets start behind the first one's rows in by_read).  Every table equal to the oracle's; the Vertex facts too."""
