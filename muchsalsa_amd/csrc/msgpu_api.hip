@@ -262,8 +262,7 @@ struct msgpu_ctx {
   DevBuf rows_in, rows_pk, cnt_read, read_off, cursor, bkt_key, bkt_dead, by_read, read_cnt, alive_rank,
       anchor_cnt, anchor_off, anchor_first, anchor_off_gen, bkt2_idx, bkt2_line, by_anchor, read_len, read_first, scalars,
       scan_tmp, vis16, spos2, visits, bin_cursor, bin_start;
-  DevBuf bound, cand_off, cand_j, cand_t, scr_v2, scr_start, n_cand, n_edge, n_visit_arr, lists, em_base, edge_base,
-      visit_base, edges, edge_cand;
+  DevBuf bound, cand_off, cand_j, cand_t, scr_v2, scr_start, n_cand, n_edge, lists, edges, edge_cand;
   DevBuf big_key, big_t, big_r2s, big_pfx, pair_tab, chain_chunks, big_off, cand_sums, bucket_visits;
   hipStream_t side_stream = nullptr, side_stream2 = nullptr;
   hipEvent_t  ev_side[2]  = {nullptr, nullptr}, ev_side2 = nullptr;
@@ -272,7 +271,7 @@ struct msgpu_ctx {
   bool   sub_wave  = true; // short edges share a wavefront (k_chain_sub); MSGPU_NO_SUBWAVE=1 sends them all to k_chain
   uint32_t n_cls[4] = {0, 0, 0, 0}; // edges of 9..16, 17..32, 33..64 and <= 8 EdgeMatches
   uint64_t n_edges_fast = 0;
-  DevBuf ems, order_scr, ids_scr, edge_norders, edge_nids, order_base, ids_base, orders, ids, big_list, cls_list, cls_part, cls_partials, big_elems,
+  DevBuf ems, order_scr, ids_scr, edge_norders, edge_nids, orders, ids, big_list, cls_list, big_elems,
       big_paths;
   DevBuf g_deg, g_off, g_adj, g_cand, g_sane, g_out; // findContractionEdges
   DevBuf sel_idx, sel_cnt, sel_off, sel_ems;          // msgpu_get_edgematches
@@ -436,10 +435,9 @@ void release_all(msgpu_ctx *c) {
                    &c->anchor_first, &c->anchor_off_gen,
                    &c->bkt2_idx, &c->bkt2_line, &c->by_anchor, &c->read_len, &c->read_first, &c->scalars, &c->scan_tmp,
                    &c->bound, &c->cand_off, &c->cand_j, &c->cand_t, &c->scr_v2, &c->scr_start, &c->n_cand, &c->n_edge,
-                   &c->n_visit_arr, &c->lists, &c->em_base, &c->edge_base, &c->visit_base, &c->edges, &c->edge_cand,
+                   &c->lists, &c->edges, &c->edge_cand,
                    &c->big_key, &c->big_t, &c->big_r2s, &c->big_pfx, &c->pair_tab, &c->chain_chunks, &c->big_off, &c->cand_sums, &c->bucket_visits, &c->ems, &c->order_scr, &c->ids_scr,
-                   &c->edge_norders, &c->edge_nids, &c->order_base, &c->ids_base, &c->orders, &c->ids, &c->big_list, &c->cls_list, &c->cls_part, &c->cls_partials,
-                   &c->big_elems, &c->big_paths, &c->alt_edges, &c->alt_ems, &c->alt_orders, &c->alt_ids, &c->vis16, &c->visits,
+                   &c->edge_norders, &c->edge_nids, &c->orders, &c->ids, &c->big_list, &c->cls_list, &c->big_elems, &c->big_paths, &c->alt_edges, &c->alt_ems, &c->alt_orders, &c->alt_ids, &c->vis16, &c->visits,
                    &c->spos2, &c->bin_cursor, &c->bin_start, &c->wire_dev[0], &c->wire_dev[1], &c->win_cuts};
   for (DevBuf *b : all) b->release();
 }

@@ -162,11 +162,6 @@ void unpack_wire_host(const uint8_t *w_edges, const uint8_t *w_orders, const uin
 void launch_merge_wire(hipStream_t st, const MergeArgs &a, bool ids3);
 
 template <class T> void exclusive_scan(hipStream_t st, const uint32_t *in, uint64_t n, T *out, T *block_sums, T *d_total);
-// k <= 3 scans of the same length n in one pair of launches; block_sums holds k * (scan_blocks(n) + 1) words
-// optional rider: the four column sums of a [n_partials][4] table (16-byte aligned) go to partial_totals[0..3]
-void exclusive_scan_set(hipStream_t st, int k, const uint32_t *const *in, uint64_t n, uint64_t *const *out, uint64_t *block_sums,
-                        uint64_t *const *d_total, const uint32_t *partials = nullptr, uint32_t n_partials = 0,
-                        uint32_t *partial_totals = nullptr);
 uint32_t scan_blocks(uint64_t n);
 
 void launch_max_ids(hipStream_t st, const msgpu_row *rows, uint64_t n, uint32_t *max_ids);

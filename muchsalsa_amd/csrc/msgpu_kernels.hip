@@ -102,112 +102,6 @@ template <class T> void exclusive_scan(hipStream_t st, const uint32_t *in, uint6
 template void exclusive_scan<uint32_t>(hipStream_t, const uint32_t *, uint64_t, uint32_t *, uint32_t *, uint32_t *);
 template void exclusive_scan<uint64_t>(hipStream_t, const uint32_t *, uint64_t, uint64_t *, uint64_t *, uint64_t *);
 
-// up to three scans of the same length in one pair of launches (blockIdx.y picks the array): the per-read / per-edge
-// size arrays of one stage are scanned together -- each scan is two launches of a few microseconds, mostly launch cost
-struct ScanSet {
-  const uint32_t *in[3];
-  uint64_t       *out[3], *sums[3], *total[3];
-  // a rider on the reduce launch (blockIdx.y = n_scans): column sums of a [n_partials][4] table of per-workgroup counts
-  // (k_count_classes), so that 1,500 workgroups need no atomics on four words
-  const uint32_t *partials;
-  uint32_t        n_partials, n_scans;
-  uint32_t       *partial_totals;
-};
-__global__ __launch_bounds__(256) void k_scan_reduce_set(ScanSet s, uint64_t n) {
-  __shared__ uint64_t sh[4];
-  if (blockIdx.y == s.n_scans) { // the rider: four column sums
-    if (blockIdx.x != 0) return;
-    __shared__ uint32_t s_col[4][4];
-    uint32_t            c[4] = {0, 0, 0, 0};
-    for (uint32_t i = threadIdx.x; i < s.n_partials; i += 256) {
-      const uint4 p = reinterpret_cast<const uint4 *>(s.partials)[i];
-      c[0] += p.x;
-      c[1] += p.y;
-      c[2] += p.z;
-      c[3] += p.w;
-    }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      c[k] = wave_sum(c[k]);
-      if ((threadIdx.x & 63) == 0) s_col[k][threadIdx.x >> 6] = c[k];
-    }
-    __syncthreads();
-    if (threadIdx.x < 4) s.partial_totals[threadIdx.x] = s_col[threadIdx.x][0] + s_col[threadIdx.x][1] + s_col[threadIdx.x][2] + s_col[threadIdx.x][3];
-    return;
-  }
-  const uint32_t     *in   = s.in[blockIdx.y];
-  uint64_t            base = static_cast<uint64_t>(blockIdx.x) * 256 * SCAN_ITEMS;
-  uint64_t            sum  = 0;
-  for (int i = 0; i < SCAN_ITEMS; ++i) {
-    uint64_t idx = base + static_cast<uint64_t>(i) * 256 + threadIdx.x;
-    if (idx < n) sum += in[idx];
-  }
-  for (int d = 32; d > 0; d >>= 1) sum += __shfl_down(sum, d);
-  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = sum;
-  __syncthreads();
-  if (threadIdx.x == 0) s.sums[blockIdx.y][blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
-}
-__global__ __launch_bounds__(256) void k_scan_apply_set(ScanSet s, uint64_t n) {
-  __shared__ uint64_t s_w[4];
-  __shared__ uint64_t s_carry;
-  const uint32_t     *in         = s.in[blockIdx.y];
-  const uint64_t     *block_sums = s.sums[blockIdx.y];
-  uint64_t           *out        = s.out[blockIdx.y];
-  uint64_t            base       = static_cast<uint64_t>(blockIdx.x) * 256 * SCAN_ITEMS;
-  const int           lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  {
-    uint64_t c = 0;
-    for (uint32_t i = threadIdx.x; i < blockIdx.x; i += 256) c += block_sums[i];
-    for (int d = 32; d > 0; d >>= 1) c += __shfl_down(c, d);
-    if (lane == 0) s_w[wave] = c;
-    __syncthreads();
-    if (threadIdx.x == 0) s_carry = s_w[0] + s_w[1] + s_w[2] + s_w[3];
-    __syncthreads();
-  }
-  for (int it = 0; it < SCAN_ITEMS; ++it) {
-    uint64_t       idx = base + static_cast<uint64_t>(it) * 256 + threadIdx.x;
-    const uint32_t v   = idx < n ? in[idx] : 0u;
-    const uint64_t inc = wave_incl_scan64(v);
-    if (lane == 63) s_w[wave] = inc;
-    __syncthreads();
-    uint64_t b = s_carry;
-    for (int w = 0; w < wave; ++w) b += s_w[w];
-    if (idx < n) out[idx] = b + inc - v;
-    if (idx == n - 1) {
-      out[n]              = b + inc;
-      *s.total[blockIdx.y] = b + inc;
-    }
-    __syncthreads();
-    if (threadIdx.x == 255) s_carry = b + inc;
-    __syncthreads();
-  }
-}
-void exclusive_scan_set(hipStream_t st, int k, const uint32_t *const *in, uint64_t n, uint64_t *const *out, uint64_t *block_sums,
-                        uint64_t *const *d_total, const uint32_t *partials, uint32_t n_partials, uint32_t *partial_totals) {
-  const uint32_t nb = scan_blocks(n ? n : 1);
-  ScanSet        s{};
-  s.n_scans        = static_cast<uint32_t>(k);
-  s.partials       = partials;
-  s.n_partials     = n_partials;
-  s.partial_totals = partial_totals;
-  for (int i = 0; i < k; ++i) {
-    s.in[i]    = in[i];
-    s.out[i]   = out[i];
-    s.sums[i]  = block_sums + static_cast<size_t>(i) * (nb + 1);
-    s.total[i] = d_total[i];
-  }
-  if (n == 0) {
-    for (int i = 0; i < k; ++i) {
-      (void)hipMemsetAsync(out[i], 0, 8, st);
-      (void)hipMemsetAsync(d_total[i], 0, 8, st);
-    }
-    if (partials) (void)hipMemsetAsync(partial_totals, 0, 16, st);
-    return;
-  }
-  hipLaunchKernelGGL(k_scan_reduce_set, dim3(nb, k + (partials ? 1 : 0)), dim3(256), 0, st, s, n);
-  hipLaunchKernelGGL(k_scan_apply_set, dim3(nb, k), dim3(256), 0, st, s, n);
-}
-
 // read-back without a copy engine and without a stream synchronisation: one wavefront writes the scalar block into
 // mapped host memory, makes it visible system-wide and then publishes a sequence number the host is polling for
 __global__ __launch_bounds__(64) void k_publish_scalars(const uint64_t *src, uint64_t *dst_host, uint32_t n, uint64_t seq) {
