@@ -255,7 +255,8 @@ void launch_bound(hipStream_t st, const uint32_t *read_off, const uint32_t *read
                   uint32_t shard, uint32_t nshards, uint32_t lo, uint32_t hi, uint32_t *bound);
 void launch_classify_reads(hipStream_t st, const uint32_t *read_off, const uint32_t *read_cnt, const uint32_t *bound,
                            const uint64_t *cand_off, uint32_t V, uint32_t shard, uint32_t nshards, uint32_t lo,
-                           uint32_t hi, CandDesc *l0, CandDesc *l1, CandDesc *l2, uint32_t *l3, uint32_t *n_lists, const CandZero &z);
+                           uint32_t hi, CandDesc *l0, CandDesc *l1, CandDesc *l2, uint32_t *l3, uint32_t *n_lists, const CandZero &z,
+                           unsigned long long *own_total = nullptr);
 void launch_candidates(hipStream_t st, const CandArgs &a, int cls, const CandDesc *list, uint32_t n_list);
 void launch_candidates_big(hipStream_t st, const CandArgs &a, const uint32_t *list, uint32_t n_list, uint64_t *big_key,
                            uint32_t *big_t, uint32_t *big_r2s, uint32_t *big_pfx);

@@ -951,7 +951,8 @@ __global__ __launch_bounds__(1024) void k_classify_reads(const uint32_t *read_of
                                                          const uint32_t *bound, const uint64_t *cand_off, uint32_t V,
                                                          uint32_t shard, uint32_t nshards, uint32_t lo, uint32_t hi,
                                                          CandDesc *list0, CandDesc *list1, CandDesc *list2,
-                                                         uint32_t *list3, uint32_t *n_lists /*[4]*/, CandZero z) {
+                                                         uint32_t *list3, uint32_t *n_lists /*[4]*/, CandZero z,
+                                                         unsigned long long *own_total /*null, or: += visits of the reads classified*/) {
   // the four list cursors are single words (~88 atomics/us each): count inside the workgroup in LDS first, then one
   // global atomic per workgroup and class
   __shared__ uint32_t s_cnt[4], s_base[4];
@@ -973,6 +974,18 @@ __global__ __launch_bounds__(1024) void k_classify_reads(const uint32_t *read_of
   }
   const int lane  = threadIdx.x & 63;
   uint32_t  local = 0;
+  if (own_total) { // (one atomic per workgroup: a single word takes ~88 atomics/us)
+    __shared__ unsigned long long s_own[16];
+    unsigned long long            own = cls >= 0 ? bd : 0u;
+    for (int d = 32; d > 0; d >>= 1) own += __shfl_xor(own, d);
+    if (lane == 0) s_own[threadIdx.x >> 6] = own;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      own = 0;
+      for (int w = 0; w < 16; ++w) own += s_own[w];
+      if (own) atomicAdd(own_total, own);
+    }
+  }
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     unsigned long long m = __ballot(cls == k);
@@ -3564,10 +3577,11 @@ void launch_bound(hipStream_t st, const uint32_t *read_off, const uint32_t *read
 }
 void launch_classify_reads(hipStream_t st, const uint32_t *read_off, const uint32_t *read_cnt, const uint32_t *bound,
                            const uint64_t *cand_off, uint32_t V, uint32_t shard, uint32_t nshards, uint32_t lo,
-                           uint32_t hi, CandDesc *l0, CandDesc *l1, CandDesc *l2, uint32_t *l3, uint32_t *n_lists, const CandZero &z) {
+                           uint32_t hi, CandDesc *l0, CandDesc *l1, CandDesc *l2, uint32_t *l3, uint32_t *n_lists, const CandZero &z,
+                           unsigned long long *own_total) {
   if (V)
     hipLaunchKernelGGL(k_classify_reads, grid1(V, 1024), dim3(1024), 0, st, read_off, read_cnt, bound, cand_off, V, shard,
-                       nshards, lo, hi, l0, l1, l2, l3, n_lists, z);
+                       nshards, lo, hi, l0, l1, l2, l3, n_lists, z, own_total);
 }
 void launch_candidates(hipStream_t st, const CandArgs &a, int cls, const CandDesc *list, uint32_t n_list) {
   if (!n_list) return;
