@@ -464,9 +464,10 @@ def sharded_host_to_host_leg(torch, dist, D, dev, ctx, rows, world, rank, n_batc
                 ctx.pack_wire(slab.data_ptr() + offs[0], slab.data_ptr() + offs[1], slab.data_ptr() + offs[2], id_bytes=id_bytes)
             gathered, allc, offs, slab_bytes = exchange.gather((c.n_edges, c.n_orders, c.n_ids), fill)
             tot = allc.sum(axis=0)
-            m_e = torch.empty(max(int(tot[0]), 1) * EDGE_DTYPE.itemsize, dtype=torch.uint8, device=dev)
-            m_o = torch.empty(max(int(tot[1]), 1) * ORDER_DTYPE.itemsize, dtype=torch.uint8, device=dev)
-            m_i = torch.empty(max(int(tot[2]), 1) * 4, dtype=torch.uint8, device=dev)
+            need = (max(int(tot[0]), 1) * EDGE_DTYPE.itemsize, max(int(tot[1]), 1) * ORDER_DTYPE.itemsize, max(int(tot[2]), 1) * 4)
+            if "bufs" not in keep or any(b.numel() < k for b, k in zip(keep["bufs"], need)):  # (the merged tables: kept from run to run)
+                keep["bufs"] = tuple(torch.empty(int(k * 1.05) + 256, dtype=torch.uint8, device=dev) for k in need)
+            m_e, m_o, m_i = keep["bufs"]
             ctx.merge_wire(gathered.data_ptr(), allc, slab_bytes, offs, m_e.data_ptr(), m_o.data_ptr(), m_i.data_ptr(),
                            id_bytes=id_bytes)
             stream.synchronize()
@@ -1233,9 +1234,10 @@ def main():
             # HIP compaction / re-base kernel (msgpu_merge_gathered); everything on the compute stream
             gathered, allc, offs, slab_bytes = exchange.gather((c.n_edges, c.n_orders, c.n_ids), fill)
             tot = allc.sum(axis=0)
-            m_e = torch.empty(max(int(tot[0]), 1) * EDGE_DTYPE.itemsize, dtype=torch.uint8, device=dev)
-            m_o = torch.empty(max(int(tot[1]), 1) * ORDER_DTYPE.itemsize, dtype=torch.uint8, device=dev)
-            m_i = torch.empty(max(int(tot[2]), 1) * 4, dtype=torch.uint8, device=dev)
+            need = (max(int(tot[0]), 1) * EDGE_DTYPE.itemsize, max(int(tot[1]), 1) * ORDER_DTYPE.itemsize, max(int(tot[2]), 1) * 4)
+            if "bufs" not in s_keep or any(b.numel() < k for b, k in zip(s_keep["bufs"], need)):  # (the merged tables: kept from step to step)
+                s_keep["bufs"] = tuple(torch.empty(int(k * 1.05) + 256, dtype=torch.uint8, device=dev) for k in need)
+            m_e, m_o, m_i = s_keep["bufs"]
             merge_slabs(gathered.data_ptr(), allc, slab_bytes, offs, m_e.data_ptr(), m_o.data_ptr(), m_i.data_ptr())
             s_keep.update(e=[m_e], o=[m_o], i=[m_i], tot=[tot], allc=allc)
             return c
