@@ -161,9 +161,9 @@ class OverlapContext:
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
             self._L.msgpu_destroy(self._h)
-            self._h = C.c_void_p()
+            self._h = None
 
-    __del__ = close
+    __del__ = close  # (at interpreter shutdown the module globals may be gone already: nothing of them is used above)
 
     def __enter__(self):
         return self
