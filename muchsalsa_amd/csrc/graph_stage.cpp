@@ -50,6 +50,7 @@
 #include <stdexcept>
 #include <string>
 #include <thread>
+#include <sys/mman.h>
 #include <type_traits>
 #include <vector>
 
@@ -71,13 +72,20 @@ void require(bool ok, const char *what) {
   if (!ok) throw GraphError(what);
 }
 
-struct Tick { // MSGPU_GRAPH_DEBUG=1: phase timings on stderr
+// MSGPU_GRAPH_DEBUG=1: phase timings on stderr -- the phase's own time, the moment it ended (ms since the entry point began)
+// and the component the calling worker is on (the components of msgpu_graph_linearize run side by side)
+std::chrono::steady_clock::time_point g_tick_epoch = std::chrono::steady_clock::now();
+thread_local int                      tl_tick_tag  = -1;
+struct Tick {
   std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
   bool on = std::getenv("MSGPU_GRAPH_DEBUG") != nullptr;
   void operator()(const char *what) {
     if (!on) return;
     auto n = std::chrono::steady_clock::now();
-    fprintf(stderr, "[graph] %-28s %8.3f s\n", what, std::chrono::duration<double>(n - t).count());
+    char tag[16] = "";
+    if (tl_tick_tag >= 0) snprintf(tag, sizeof(tag), " c%d", tl_tick_tag);
+    fprintf(stderr, "[graph%s @%7.2f] %-28s %8.3f s\n", tag, 1e3 * std::chrono::duration<double>(n - g_tick_epoch).count(), what,
+            std::chrono::duration<double>(n - t).count());
     t = n;
   }
 };
@@ -183,8 +191,30 @@ template <class T> struct LeaveAlone {
   using value_type = T;
   LeaveAlone() = default;
   template <class U> LeaveAlone(const LeaveAlone<U> &) noexcept {}
-  T   *allocate(size_t n) { return std::allocator<T>().allocate(n); }
-  void deallocate(T *p, size_t n) noexcept { std::allocator<T>().deallocate(p, n); }
+  // a large table asks for transparent huge pages (where the kernel hands them out on request): the stage's threads touch
+  // tens of megabytes for the first time in every phase, one page fault per 4 KB otherwise (MSGPU_GRAPH_THP=0: measurement switch)
+  static bool huge(size_t n) {
+    static const bool on = [] {
+      const char *e = std::getenv("MSGPU_GRAPH_THP");
+      return !(e && e[0] == '0');
+    }();
+    return on && n * sizeof(T) >= (size_t(4) << 20);
+  }
+  T *allocate(size_t n) {
+    if (huge(n)) {
+      constexpr size_t HP = size_t(2) << 20;
+      const size_t     bytes = (n * sizeof(T) + HP - 1) & ~(HP - 1);
+      void            *p = nullptr;
+      if (posix_memalign(&p, HP, bytes) != 0) throw std::bad_alloc();
+      madvise(p, bytes, MADV_HUGEPAGE); // (advice: a refusal changes nothing)
+      return static_cast<T *>(p);
+    }
+    return std::allocator<T>().allocate(n);
+  }
+  void deallocate(T *p, size_t n) noexcept {
+    if (huge(n)) std::free(p);
+    else std::allocator<T>().deallocate(p, n);
+  }
   template <class U> void construct(U *p) noexcept { ::new (static_cast<void *>(p)) U; }
   template <class U, class... A> void construct(U *p, A &&...a) { ::new (static_cast<void *>(p)) U(std::forward<A>(a)...); }
   template <class U> bool operator==(const LeaveAlone<U> &) const noexcept { return true; }
@@ -194,7 +224,7 @@ template <class T> using RawVec = std::vector<T, LeaveAlone<T>>;
 
 struct Csr { // segment of vertex v: arcs[off[v] .. off[v+1]), ascending `to`
   std::vector<uint32_t> off;
-  std::vector<Arc>      arcs;
+  RawVec<Arc>           arcs;
   const Arc *begin(uint32_t v) const { return arcs.data() + off[v]; }
   const Arc *end(uint32_t v) const { return arcs.data() + off[v + 1]; }
   const Arc *find(uint32_t v, uint32_t to) const {
@@ -402,32 +432,125 @@ struct UnionFind { // vertex ids are dense: vectors instead of the reference's t
 // order (std::sort on a vector built in edge order; canonical = stable).  `cand` = candidate edge indices in edge order;
 // ends(e) -> (a, b), weight(e).
 template <class Ends, class Weight>
-void max_span_tree(uint32_t nv, Ends ends, Weight weight, std::vector<uint32_t> cand, std::vector<uint8_t> &in_tree) {
+void max_span_tree(uint32_t nv, Ends ends, Weight weight, const std::vector<uint32_t> &cand, std::vector<uint8_t> &in_tree) {
   // (weight, position): one sort key, no gathers in the compare.  Edges of weight 0 (every shadow edge: 97 % of the edges
   // of BASELINE.json configs[2]) come last whatever their number and keep their edge order among themselves: they are
   // not sorted at all.
+  Tick                                                    tick;
+  const size_t                                            nc = cand.size();
+  std::vector<std::vector<std::pair<uint64_t, uint32_t>>> keyed_of(stage_threads() + 1);
+  RawVec<uint8_t>                                         zero(nc);
+  parallel_chunks(nc, [&](unsigned chunk, size_t b, size_t e) {
+    for (size_t i = b; i < e; ++i) {
+      const uint64_t w = weight(cand[i]);
+      zero[i]          = w == 0;
+      if (w) keyed_of[chunk].emplace_back(w, static_cast<uint32_t>(i));
+    }
+  });
   std::vector<std::pair<uint64_t, uint32_t>> keyed;
-  std::vector<uint32_t>                      zeros;
-  for (size_t i = 0; i < cand.size(); ++i) {
-    const uint64_t w = weight(cand[i]);
-    if (w) keyed.emplace_back(w, static_cast<uint32_t>(i));
-    else zeros.push_back(static_cast<uint32_t>(i));
-  }
+  for (auto &k : keyed_of) keyed.insert(keyed.end(), k.begin(), k.end());
   parallel_sort(keyed.begin(), keyed.end(), [](const std::pair<uint64_t, uint32_t> &x, const std::pair<uint64_t, uint32_t> &y) {
     return x.first != y.first ? x.first > y.first : x.second < y.second;
   });
-  UnionFind uf(nv);
-  auto      take = [&](uint32_t pos) {
-    const uint32_t e  = cand[pos];
-    const auto     ab = ends(e);
-    const uint32_t ra = uf.find(ab.first), rb = uf.find(ab.second);
-    if (ra != rb) {
-      in_tree[e] = 1;
-      uf.unify(ab.first, ab.second, ra, rb);
+  tick("  mst: keys + sort");
+  // Whether an edge joins the tree depends on one thing only: are its ends connected by the edges taken before it (which root
+  // a set hangs on -- mst.cpp:62-73 goes by the weights of the two vertices, not of their roots -- decides nothing).
+  if (nc < par_min() || stage_threads() < 2) {
+    UnionFind uf(nv);
+    auto      take = [&](uint32_t pos) {
+      const uint32_t e  = cand[pos];
+      const auto     ab = ends(e);
+      const uint32_t ra = uf.find(ab.first), rb = uf.find(ab.second);
+      if (ra != rb) {
+        in_tree[e] = 1;
+        uf.unify(ab.first, ab.second, ra, rb);
+      }
+    };
+    for (auto &k : keyed) take(k.second);
+    for (size_t i = 0; i < nc; ++i)
+      if (zero[i]) take(static_cast<uint32_t>(i));
+    return;
+  }
+  // A large graph.  Kruskal's order is a total order here (weight, then position in `cand`), so the forest it builds is THE
+  // minimum spanning forest under that order, and any way of finding it finds the same edges.  The way that runs on all host
+  // threads (Boruvka's): every set of vertices connected so far takes the FIRST edge of the order that leaves it -- by the
+  // cut property an edge of the forest --, the sets are merged along those edges, and again, until no edge leaves a set:
+  // at most log2(vertices) rounds of one pass over the edges that still join two sets.  (Kruskal's loop took a million turns
+  // of two find() calls on one thread: two thirds of the clean-up's span-tree time on BASELINE configs[2].)
+  require(nc < (size_t(1) << 31), "getMaxSpanTree: too many edges");
+  const uint32_t   nk = static_cast<uint32_t>(keyed.size());
+  RawVec<uint32_t> rank(nc), ea(nc), eb(nc); // place in Kruskal's order; the ends
+  RawVec<uint8_t>  dead(nc);
+  parallel_chunks(nc, [&](unsigned, size_t b, size_t e) {
+    for (size_t i = b; i < e; ++i) {
+      const auto ab = ends(cand[i]);
+      ea[i]         = ab.first;
+      eb[i]         = ab.second;
+      dead[i]       = 0;
+      if (zero[i]) rank[i] = nk + static_cast<uint32_t>(i); // behind every weighted edge, in edge order
     }
-  };
-  for (auto &k : keyed) take(k.second);
-  for (uint32_t pos : zeros) take(pos);
+  });
+  parallel_chunks(nk, [&](unsigned, size_t b, size_t e) {
+    for (size_t j = b; j < e; ++j) rank[keyed[j].second] = static_cast<uint32_t>(j);
+  });
+  constexpr uint64_t NONE = ~uint64_t(0);
+  RawVec<uint32_t>   comp(nv), hook(nv);
+  RawVec<uint64_t>   best(nv); // per set (at its representative): rank << 32 | position of the first edge that leaves it
+  parallel_chunks(nv, [&](unsigned, size_t b, size_t e) {
+    for (size_t v = b; v < e; ++v) comp[v] = static_cast<uint32_t>(v);
+  });
+  for (;;) {
+    parallel_chunks(nv, [&](unsigned, size_t b, size_t e) {
+      for (size_t v = b; v < e; ++v) {
+        best[v] = NONE;
+        hook[v] = static_cast<uint32_t>(v);
+      }
+    });
+    std::atomic<int> any{0};
+    parallel_dynamic(nc, 8192, [&](size_t b, size_t e) {
+      bool mine = false;
+      for (size_t i = b; i < e; ++i) {
+        if (dead[i]) continue;
+        const uint32_t ca = comp[ea[i]], cb = comp[eb[i]];
+        if (ca == cb) { // inside a set from now on (also an edge from a vertex to itself)
+          dead[i] = 1;
+          continue;
+        }
+        mine                = true;
+        const uint64_t key = (static_cast<uint64_t>(rank[i]) << 32) | static_cast<uint64_t>(i);
+        for (const uint32_t c : {ca, cb}) {
+          uint64_t seen = __atomic_load_n(&best[c], __ATOMIC_RELAXED);
+          while (key < seen && !__atomic_compare_exchange_n(&best[c], &seen, key, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {
+          }
+        }
+      }
+      if (mine) any.store(1, std::memory_order_relaxed);
+    });
+    if (!any.load()) break;
+    // every set with an edge out takes it and hangs itself on the set at the other end; two sets that chose the same edge: the
+    // one with the higher representative hangs on the other (the chosen edges have no other cycle: ranks are unique)
+    parallel_chunks(nv, [&](unsigned, size_t b, size_t e) {
+      for (size_t c = b; c < e; ++c) {
+        if (best[c] == NONE) continue;
+        const uint32_t i = static_cast<uint32_t>(best[c]);
+        __atomic_store_n(&in_tree[cand[i]], uint8_t(1), __ATOMIC_RELAXED); // (both ends may choose the edge)
+        const uint32_t ca = comp[ea[i]], cb = comp[eb[i]], other = ca == c ? cb : ca;
+        if (static_cast<uint32_t>(best[other]) == i && best[other] != NONE && c < other) continue;
+        hook[c] = other;
+      }
+    });
+    parallel_chunks(nv, [&](unsigned, size_t b, size_t e) { // every vertex on the representative of its merged set
+      for (size_t v = b; v < e; ++v) {
+        uint32_t r = comp[v];
+        while (hook[r] != r) r = hook[r];
+        best[v] = r; // (best is idle until the next round clears it: comp is still being read by the other threads)
+      }
+    });
+    parallel_chunks(nv, [&](unsigned, size_t b, size_t e) {
+      for (size_t v = b; v < e; ++v) comp[v] = static_cast<uint32_t>(best[v]);
+    });
+  }
+  tick("  mst: Boruvka rounds");
 }
 
 // GraphUtil::getShortestPath (Graph.h:927-978): Dijkstra with unit weights whose queue is ordered by (distance,
@@ -679,6 +802,7 @@ struct DiG {
   std::vector<uint32_t> ord_off;      // EdgeOrders per directed edge, in appendOrder order
   RawVec<uint32_t>      ord;
   Csr                   succ, pred;
+  Csr                   lsucc, lpred; // the arcs of the cycle-free copy: the edges that were no shadow edges when extract_paths began
   size_t m() const { return ea.size(); }
   int64_t get_edge(uint32_t a, uint32_t b) const {
     const Arc *t = succ.find(a, b);
@@ -706,6 +830,53 @@ DiG get_directed_graph(msgpu_graph &g, uint32_t cid, const std::vector<uint32_t>
   std::vector<uint32_t>                  pop_order;                 // vertices in the order of their FIRST pop
   std::vector<std::pair<uint32_t, bool>> stack{{start, true}};
   const Arc *const                       arcs0 = g.adj.arcs.data();
+  if (g.every_alive_edge_kept) {
+    // The reference's loop (kept below for graphs with an alive edge without a kept order) pushes a vertex once for every
+    // neighbour that meets it before its first pop -- about ten entries per vertex on configs[2], nine of which are popped to no
+    // effect.  With every alive edge kept, a pop other than the first does nothing, and the first pop of a vertex is the entry
+    // pushed LAST for it: the one of the most recently popped neighbour -- its parent in a depth-first search that takes a
+    // vertex's arcs from the last to the first and descends into a neighbour that has not been popped yet when its turn comes
+    // (an entry pushed by an earlier neighbour lies deeper in the stack and finds the vertex popped).  So: that search, one
+    // frame per vertex, with the toggle the parent's entry would have carried.  Every arc of a popped vertex is still looked
+    // at once, so the in_dg marks end up the same.
+    struct Frame {
+      uint32_t v, next; // next: one past the arc to look at next (arcs are taken in descending order)
+      bool     toggle;
+    };
+    std::vector<Frame> frames;
+    auto               pop_first = [&](uint32_t v, bool toggle) {
+      msgpu_graph::Vertex &vc = g.V[v];
+      vc.seq                  = static_cast<uint32_t>(pop_order.size());
+      pop_order.push_back(v);
+      vc.in_dg = 1;
+      vc.dir   = toggle ? D_POS : D_NEG; // (D_NONE until here: nothing else sets a direction)
+      for (const Arc *n = g.adj.begin(v); n != g.adj.end(v); ++n) __builtin_prefetch(&g.V[n->to]);
+      frames.push_back(Frame{v, static_cast<uint32_t>(g.adj.end(v) - arcs0), toggle});
+    };
+    require(g.V[start].seq == NIL && g.V[start].dir == D_NONE, "getDirectedGraph: start vertex already directed");
+    pop_first(start, true);
+    while (!frames.empty()) {
+      const uint32_t v = frames.back().v, first_arc = static_cast<uint32_t>(g.adj.begin(v) - arcs0);
+      const bool     toggle = frames.back().toggle;
+      uint32_t       q = frames.back().next;
+      bool           descended = false;
+      while (q > first_arc) {
+        --q;
+        const uint8_t af = arc_flags[q];
+        if (!(af & AF_ALIVE)) continue;
+        msgpu_graph::Vertex &vn = g.V[arcs0[q].to];
+        if (vn.comp != cid) continue;
+        vn.in_dg = 1;
+        if (vn.seq != NIL || !(af & AF_CONS)) continue; // popped already / no consensus direction: not pushed
+        frames.back().next = q;
+        pop_first(arcs0[q].to, toggle == ((af & AF_POS) != 0)); // (frames may move: nothing of the old frame is used below)
+        descended = true;
+        break;
+      }
+      if (!descended) frames.pop_back();
+    }
+    stack.clear();
+  }
   while (!stack.empty()) {
     const uint32_t cur    = stack.back().first;
     const bool     toggle = stack.back().second;
@@ -882,7 +1053,7 @@ void sort_reduction_by_weight(DiG &dg, std::vector<uint8_t> &alive) {
   std::vector<uint32_t> null;          // deque: consumed from `head`
   size_t                head = 0, nn = 0;
   for (uint32_t v = 0; v < n; ++v) {
-    for (const Arc *t = dg.pred.begin(v); t != dg.pred.end(v); ++t) rem[v] += alive[t->e];
+    for (const Arc *t = dg.lpred.begin(v); t != dg.lpred.end(v); ++t) rem[v] += alive[t->e];
     if (rem[v] > 0) {
       innn[v] = 1;
       ++nn;
@@ -901,7 +1072,7 @@ void sort_reduction_by_weight(DiG &dg, std::vector<uint8_t> &alive) {
     while (head < null.size()) {
       const uint32_t v = null[head++];
       resolved[v] = 1;
-      for (const Arc *s = dg.succ.begin(v); s != dg.succ.end(v); ++s) {
+      for (const Arc *s = dg.lsucc.begin(v); s != dg.lsucc.end(v); ++s) {
         if (!alive[s->e]) continue;
         if (!innn[s->to]) throw GraphError("sortReductionByWeight: in-degree map out of step");
         if (--rem[s->to] == 0) {
@@ -919,7 +1090,7 @@ void sort_reduction_by_weight(DiG &dg, std::vector<uint8_t> &alive) {
     uint32_t min_vertex = 0;
     uint64_t min_score = 0;
     auto     scan = [&](uint32_t cand) {
-      for (const Arc *p = dg.pred.begin(cand); p != dg.pred.end(cand); ++p)
+      for (const Arc *p = dg.lpred.begin(cand); p != dg.lpred.end(cand); ++p)
         if (alive[p->e] && !resolved[p->to] && (min_edge < 0 || dg.weight[p->e] < min_score)) {
           min_edge   = p->e;
           min_vertex = cand;
@@ -952,7 +1123,7 @@ bool subset(const std::vector<uint32_t> &a, const std::vector<uint32_t> &b) { //
 struct TopoSets {
   std::vector<uint32_t> order, idx, soff, sidx, poff, pidx;
   TopoSets(const DiG &dg, const std::vector<uint8_t> &alive) {
-    order = sort_topologically(dg.n, dg.succ, dg.pred, alive.data(), nullptr);
+    order = sort_topologically(dg.n, dg.lsucc, dg.lpred, alive.data(), nullptr);
     idx.assign(dg.n, NIL);
     for (uint32_t i = 0; i < order.size(); ++i) idx[order[i]] = i;
     auto fill = [&](const Csr &c, std::vector<uint32_t> &off, std::vector<uint32_t> &out) {
@@ -968,8 +1139,8 @@ struct TopoSets {
       }
       off[dg.n] = static_cast<uint32_t>(out.size());
     };
-    fill(dg.succ, soff, sidx);
-    fill(dg.pred, poff, pidx);
+    fill(dg.lsucc, soff, sidx);
+    fill(dg.lpred, poff, pidx);
   }
 };
 
@@ -1048,7 +1219,7 @@ std::vector<uint64_t> find_cluster_weights_heuristic(const DiG &dg, const std::v
     for (uint32_t q = ts.soff[v]; q < ts.soff[v + 1]; ++q) {
       const uint32_t               w = ts.order[ts.sidx[q]];
       const std::vector<uint32_t> *best = nullptr;
-      for (const Arc *p = dg.pred.begin(w); p != dg.pred.end(w); ++p) // ascending id = the canonical order of :122
+      for (const Arc *p = dg.lpred.begin(w); p != dg.lpred.end(w); ++p) // ascending id = the canonical order of :122
         if (alive[p->e] && stamp[p->to] == round && cand[p->to].size() > (best ? best->size() : 0)) best = &cand[p->to];
       if (stamp[w] == round) continue; // emplace: an existing entry stays
       std::vector<uint32_t> np = best ? *best : std::vector<uint32_t>();
@@ -1103,9 +1274,9 @@ struct PathPeeler {
   }
 
   bool has_arcs(uint32_t v) const {
-    for (const Arc *t = dg.succ.begin(v); t != dg.succ.end(v); ++t)
+    for (const Arc *t = dg.lsucc.begin(v); t != dg.lsucc.end(v); ++t)
       if (alive[t->e]) return true;
-    for (const Arc *t = dg.pred.begin(v); t != dg.pred.end(v); ++t)
+    for (const Arc *t = dg.lpred.begin(v); t != dg.lpred.end(v); ++t)
       if (alive[t->e]) return true;
     return false;
   }
@@ -1125,7 +1296,7 @@ struct PathPeeler {
       lab[s] = lab_round;
       for (size_t h = 0; h < members.size(); ++h) {
         const uint32_t v = members[h];
-        for (const Csr *c : {&dg.succ, &dg.pred})
+        for (const Csr *c : {&dg.lsucc, &dg.lpred})
           for (const Arc *t = c->begin(v); t != c->end(v); ++t)
             if (alive[t->e] && lab[t->to] != lab_round) {
               lab[t->to] = lab_round;
@@ -1174,12 +1345,12 @@ struct PathPeeler {
     order.reserve(c.members.size());
     for (uint32_t v : c.members) {
       deg[v] = 0;
-      for (const Arc *t = dg.pred.begin(v); t != dg.pred.end(v); ++t) deg[v] += alive[t->e];
+      for (const Arc *t = dg.lpred.begin(v); t != dg.lpred.end(v); ++t) deg[v] += alive[t->e];
     }
     for (size_t i = c.members.size(); i-- > 0;) { // zero-in-degree vertices, highest id first
       const uint32_t r = c.members[i];
       bool           is_root = true;
-      for (const Arc *t = dg.pred.begin(r); t != dg.pred.end(r) && is_root; ++t) is_root = !alive[t->e];
+      for (const Arc *t = dg.lpred.begin(r); t != dg.lpred.end(r) && is_root; ++t) is_root = !alive[t->e];
       if (!is_root) continue;
       stack.assign(1, r);
       while (!stack.empty()) {
@@ -1187,7 +1358,7 @@ struct PathPeeler {
         stack.pop_back();
         seg[v] = r;
         order.push_back(v);
-        for (const Arc *t = dg.succ.begin(v); t != dg.succ.end(v); ++t)
+        for (const Arc *t = dg.lsucc.begin(v); t != dg.lsucc.end(v); ++t)
           if (alive[t->e] && --deg[t->to] == 0) stack.push_back(t->to);
       }
     }
@@ -1207,7 +1378,7 @@ struct PathPeeler {
       uint64_t max_out = 0;
       max_outs.clear();
       bool sink = true;
-      for (const Arc *t = dg.succ.begin(v); t != dg.succ.end(v); ++t) {
+      for (const Arc *t = dg.lsucc.begin(v); t != dg.lsucc.end(v); ++t) {
         if (!alive[t->e]) continue;
         sink = false;
         const uint64_t w = cw[t->e];
@@ -1280,7 +1451,7 @@ struct PathPeeler {
   }
 
   void delete_vertex(uint32_t v) {
-    for (const Csr *c : {&dg.succ, &dg.pred})
+    for (const Csr *c : {&dg.lsucc, &dg.lpred})
       for (const Arc *t = c->begin(v); t != c->end(v); ++t)
         if (alive[t->e]) {
           alive[t->e] = 0;
@@ -1294,6 +1465,20 @@ std::vector<std::vector<uint32_t>> extract_paths(DiG &dg) { // local vertex ids
   Tick                 tick;
   std::vector<uint8_t> alive(dg.m());
   for (size_t e = 0; e < dg.m(); ++e) alive[e] = !dg.shadow[e]; // the copy without its shadow edges (:351-356)
+  // (the copy's own adjacency: 3 % of the arcs on BASELINE configs[2]; every pass below still asks `alive`, which only loses edges)
+  {
+    std::vector<uint32_t> le, la, lb;
+    for (size_t e = 0; e < dg.m(); ++e)
+      if (alive[e]) {
+        le.push_back(static_cast<uint32_t>(e));
+        la.push_back(dg.ea[e]);
+        lb.push_back(dg.eb[e]);
+      }
+    dg.lsucc = build_csr(dg.n, la.data(), lb.data(), le.size(), false);
+    dg.lpred = build_csr(dg.n, lb.data(), la.data(), le.size(), false);
+    for (Csr *c : {&dg.lsucc, &dg.lpred})
+      for (Arc &t : c->arcs) t.e = le[t.e]; // (build_csr numbers the edges it is given)
+  }
   tick("copy + drop shadow edges");
   sort_reduction_by_weight(dg, alive);
   tick("sortReductionByWeight");
@@ -1344,8 +1529,10 @@ std::vector<std::vector<uint32_t>> extract_paths(DiG &dg) { // local vertex ids
     pp.split(pool);
   }
   tick("conservation paths loop");
-  for (uint32_t v = 0; v < dg.n; ++v)
-    if (pp.valive[v]) paths.push_back({v});
+  // lg.cpp:409-411 appends a path of one vertex for every vertex left over.  linearizeGraph (the only caller) joins no such
+  // path to anything -- it has nothing in front of its vertex and nothing behind it (the test of lg.cpp:560) -- and drops every
+  // path of one vertex at its end (lg.cpp:626); no vertex left over is on another path.  So they are not made: tens of thousands
+  // of one-element vectors on a large component.
   return paths;
 }
 
@@ -1416,8 +1603,11 @@ std::vector<msgpu_graph::PathStore> component_paths(msgpu_graph *g, uint32_t cid
   tk("getDirectedGraph");
   const std::vector<std::vector<uint32_t>> lin = linearize_graph(dg);
   tk("linearizeGraph");
-  std::vector<msgpu_graph::PathStore> out;
-  for (const std::vector<uint32_t> &p : lin) {
+  // (a path's store is made of its own vertices and edges alone: the paths of a large component on the stage's threads)
+  std::vector<msgpu_graph::PathStore> out(lin.size());
+  parallel_dynamic(lin.size(), lin.size() >= 256 ? 16 : std::max<size_t>(1, lin.size()), [&](size_t p_begin, size_t p_end) {
+  for (size_t pi = p_begin; pi < p_end; ++pi) {
+    const std::vector<uint32_t> &p = lin[pi];
     msgpu_graph::PathStore ps;
     ps.order_off.push_back(0);
     ps.em_off.push_back(0);
@@ -1467,8 +1657,10 @@ std::vector<msgpu_graph::PathStore> component_paths(msgpu_graph *g, uint32_t cid
         ps.contains.push_back(pc);
       }
     }
-    out.push_back(std::move(ps));
+    out[pi] = std::move(ps);
   }
+  });
+  tk("path stores");
   return out;
 }
 
@@ -1616,6 +1808,7 @@ int msgpu_graph_clean_up(msgpu_graph *g, const int64_t *contraction_order, const
   if (g->cleaned) return MSGPU_E_STATE;
   g->err[0] = 0;
   try {
+    g_tick_epoch = std::chrono::steady_clock::now();
     Tick                  tick;
     const uint32_t        nv = g->nv;
     const size_t          ne = g->n_edges;
@@ -1784,13 +1977,17 @@ int msgpu_graph_clean_up(msgpu_graph *g, const int64_t *contraction_order, const
     {
       // (over an adjacency of the tree edges alone -- one edge in ten here --, not over every arc of the graph; how the
       // forest is rooted does not matter to decycle: the tree path between two vertices is the same under any root)
-      std::vector<uint32_t> te, ta, tb;
-      for (uint32_t e : cand)
-        if (in_tree[e]) {
-          te.push_back(e);
-          ta.push_back(g->E[e].a);
-          tb.push_back(g->E[e].b);
-        }
+      std::vector<uint32_t>              te, ta, tb;
+      std::vector<std::vector<uint32_t>> te_of(stage_threads() + 1);
+      parallel_chunks(cand.size(), [&](unsigned chunk, size_t b, size_t e_end) {
+        for (size_t i = b; i < e_end; ++i)
+          if (in_tree[cand[i]]) te_of[chunk].push_back(cand[i]);
+      });
+      for (auto &v : te_of) te.insert(te.end(), v.begin(), v.end()); // (chunk order = edge order)
+      for (uint32_t e : te) {
+        ta.push_back(g->E[e].a);
+        tb.push_back(g->E[e].b);
+      }
       const Csr             tree = build_csr(nv, ta.data(), tb.data(), te.size(), true);
       std::vector<uint32_t> queue;
       for (uint32_t r = 0; r < nv; ++r) {
@@ -1861,16 +2058,24 @@ int msgpu_graph_clean_up(msgpu_graph *g, const int64_t *contraction_order, const
       }
     });
     tick("decycle");
-    for (size_t e = 0; e < ne; ++e) // :285-287
-      if (dele[e]) {
-        g->delete_edge(static_cast<uint32_t>(e));
-        ++g->stats.n_decycled_edges;
+    std::atomic<uint64_t> n_dele{0}, n_alive{0}; // :285-287, and the edges that are left (one pass over the records, on all threads)
+    parallel_chunks(ne, [&](unsigned, size_t e_begin, size_t e_end) {
+      uint64_t d = 0, a = 0;
+      for (size_t e = e_begin; e < e_end; ++e) {
+        if (dele[e]) {
+          g->delete_edge(static_cast<uint32_t>(e));
+          ++d;
+        }
+        a += g->E[e].alive;
       }
-    uint64_t nv_alive = 0, ne_alive = 0;
+      n_dele += d;
+      n_alive += a;
+    });
+    g->stats.n_decycled_edges += n_dele;
+    uint64_t nv_alive = 0;
     for (auto &x : g->V) nv_alive += x.alive;
-    for (auto &x : g->E) ne_alive += x.alive;
     g->stats.n_vertices = nv_alive;
-    g->stats.n_edges    = ne_alive;
+    g->stats.n_edges    = n_alive;
     g->cleaned          = true;
   } catch (std::bad_alloc const &) {
     return MSGPU_E_NOMEM;
@@ -1895,6 +2100,7 @@ int msgpu_graph_linearize(msgpu_graph *g) {
   if (!g->cleaned || g->linearized) return MSGPU_E_STATE;
   g->err[0] = 0;
   try {
+    g_tick_epoch = std::chrono::steady_clock::now();
     Tick tick;
     // what the walks read of an edge, next to the arc (a byte of flags instead of a 40-byte record, and no random access)
     RawVec<uint8_t> arc_flags(g->adj.arcs.size());
@@ -1945,6 +2151,8 @@ int msgpu_graph_linearize(msgpu_graph *g) {
         tl_thread_share   = comps[i].size() >= par_min() / 8 && large_weight > 0
                                 ? std::max<unsigned>(1, static_cast<unsigned>(stage_threads_total() * mine / large_weight + 0.5))
                                 : 1;
+        tl_tick_tag = static_cast<int>(i);
+        if (std::getenv("MSGPU_GRAPH_DEBUG")) fprintf(stderr, "[graph c%zu] %zu vertices, %u threads\n", i, comps[i].size(), tl_thread_share);
         try {
           per[i] = component_paths(g, static_cast<uint32_t>(i), comps[i], arc_flags);
         } catch (std::bad_alloc const &) { rcs[i] = MSGPU_E_NOMEM; } catch (std::exception const &e) {
@@ -1952,6 +2160,7 @@ int msgpu_graph_linearize(msgpu_graph *g) {
           errs[i] = e.what();
         }
         tl_thread_share = 0;
+        tl_tick_tag     = -1;
       }
     };
     uint32_t nt = g->n_threads;

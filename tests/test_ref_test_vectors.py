@@ -76,6 +76,31 @@ def test_max_span_tree_MST_test(L, oracle):
     assert not any(mst.has_edge(*p) for p in fx["expect"]["has_no_edge"])
 
 
+def test_max_span_tree_on_all_threads_is_kruskals_tree(L, monkeypatch):
+    """getMaxSpanTree on a large graph finds the forest with Boruvka's rounds on all host threads (csrc/graph_stage.cpp):
+    the same edges as the one-thread loop of mst.cpp:75-111 -- heaviest first, equal weights in edge order -- on random
+    multigraphs with many equal and zero weights, loops, edges without a consensus direction and isolated vertices."""
+    rng = np.random.default_rng(11)
+    for case in range(40):
+        n = int(rng.integers(2, 400))
+        m = int(rng.integers(1, 6 * n))
+        a, b = u32(rng.integers(0, n, m)), u32(rng.integers(0, n, m))
+        if case % 3 == 0:  # long chains: many rounds, long hooks
+            k = min(m, n - 1)
+            a[:k], b[:k] = np.arange(k), np.arange(1, k + 1)
+        w = np.ascontiguousarray(rng.integers(0, 4, m) * (rng.integers(0, 3, m) > 0), dtype="<u8")
+        cons = np.ascontiguousarray(rng.integers(0, 3, m), dtype=np.uint8)  # 2 = e_NONE: not a candidate
+        want, got = np.zeros(m, np.uint8), np.zeros(m, np.uint8)
+        monkeypatch.delenv("MSGPU_GRAPH_PAR_MIN", raising=False)
+        monkeypatch.setenv("MSGPU_GRAPH_THREADS", "1")
+        assert L.msgpu_graph_max_span_tree(n, a.ctypes.data, b.ctypes.data, w.ctypes.data, cons.ctypes.data, m, want.ctypes.data) == 0
+        monkeypatch.setenv("MSGPU_GRAPH_PAR_MIN", "1")
+        monkeypatch.setenv("MSGPU_GRAPH_THREADS", "4")
+        assert L.msgpu_graph_max_span_tree(n, a.ctypes.data, b.ctypes.data, w.ctypes.data, cons.ctypes.data, m, got.ctypes.data) == 0
+        assert np.array_equal(got, want), case
+        assert not got[cons == 2].any() and not got[a == b].any()
+
+
 def test_connected_components_CC_test(L, oracle):
     fx = fixture("cc")
     p1, p2 = fx["phase1"], fx["phase2"]
