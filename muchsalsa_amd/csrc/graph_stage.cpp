@@ -850,7 +850,13 @@ DiG get_directed_graph(msgpu_graph &g, uint32_t cid, const std::vector<uint32_t>
       pop_order.push_back(v);
       vc.in_dg = 1;
       vc.dir   = toggle ? D_POS : D_NEG; // (D_NONE until here: nothing else sets a direction)
-      for (const Arc *n = g.adj.begin(v); n != g.adj.end(v); ++n) __builtin_prefetch(&g.V[n->to]);
+      for (const Arc *n = g.adj.begin(v); n != g.adj.end(v); ++n) {
+        __builtin_prefetch(&g.V[n->to]);
+        // (and where the neighbour's own arcs begin: most neighbours are popped soon after, and a pop starts on those lines)
+        const uint32_t o = g.adj.off[n->to];
+        __builtin_prefetch(arcs0 + o);
+        __builtin_prefetch(arc_flags.data() + o);
+      }
       frames.push_back(Frame{v, static_cast<uint32_t>(g.adj.end(v) - arcs0), toggle});
     };
     require(g.V[start].seq == NIL && g.V[start].dir == D_NONE, "getDirectedGraph: start vertex already directed");
@@ -915,6 +921,13 @@ DiG get_directed_graph(msgpu_graph &g, uint32_t cid, const std::vector<uint32_t>
   auto for_edges_of = [&](size_t i, auto &&body) { // body(undirected edge, neighbour, toggle of the processing vertex)
     const uint32_t v      = pop_order[i];
     const bool     toggle = g.V[v].dir == D_POS;
+    // (the edge records and the neighbours' records are the random reads of both passes: asked for ahead of the loop that
+    // waits for them -- a vertex has tens of arcs)
+    for (const Arc *n = g.adj.begin(v); n != g.adj.end(v); ++n) {
+      __builtin_prefetch(&g.E[n->e]);
+      __builtin_prefetch(&g.V[n->to]);
+    }
+    for (const Arc *n = g.adj.begin(v); n != g.adj.end(v); ++n) __builtin_prefetch(&g.ol[g.E[n->e].ord_lo]); // (its first order: edges have one or two)
     for (const Arc *n = g.adj.begin(v); n != g.adj.end(v); ++n) {
       const uint8_t af = arc_flags[n - arcs0];
       if ((af & (AF_ALIVE | AF_KEPT)) != (AF_ALIVE | AF_KEPT)) continue;
@@ -1984,10 +1997,17 @@ int msgpu_graph_clean_up(msgpu_graph *g, const int64_t *contraction_order, const
           if (in_tree[cand[i]]) te_of[chunk].push_back(cand[i]);
       });
       for (auto &v : te_of) te.insert(te.end(), v.begin(), v.end()); // (chunk order = edge order)
-      for (uint32_t e : te) {
-        ta.push_back(g->E[e].a);
-        tb.push_back(g->E[e].b);
-      }
+      ta.resize(te.size());
+      tb.resize(te.size());
+      std::vector<uint8_t> tneg(te.size()); // the tree edge's consensus direction is e_NEG (read here, not record by record in the walk below)
+      parallel_chunks(te.size(), [&](unsigned, size_t b, size_t e_end) {
+        for (size_t k = b; k < e_end; ++k) {
+          const msgpu_graph::Edge &E = g->E[te[k]];
+          ta[k]   = E.a;
+          tb[k]   = E.b;
+          tneg[k] = E.cons == D_NEG;
+        }
+      });
       const Csr             tree = build_csr(nv, ta.data(), tb.data(), te.size(), true);
       std::vector<uint32_t> queue;
       for (uint32_t r = 0; r < nv; ++r) {
@@ -1998,11 +2018,10 @@ int msgpu_graph_clean_up(msgpu_graph *g, const int64_t *contraction_order, const
           const uint32_t v = queue[h];
           for (const Arc *t = tree.begin(v); t != tree.end(v); ++t)
             if (parent[t->to] == NIL) {
-              const uint32_t e = te[t->e];
-              parent[t->to]    = v;
-              pedge[t->to]     = e;
-              depth[t->to]     = depth[v] + 1;
-              negpar[t->to]    = negpar[v] ^ (g->E[e].cons == D_NEG);
+              parent[t->to] = v;
+              pedge[t->to]  = te[t->e];
+              depth[t->to]  = depth[v] + 1;
+              negpar[t->to] = negpar[v] ^ tneg[t->e];
               queue.push_back(t->to);
             }
         }
@@ -2108,6 +2127,7 @@ int msgpu_graph_linearize(msgpu_graph *g) {
     parallel_chunks(arc_flags.size(), [&](unsigned, size_t b, size_t e_end) {
       bool any = false;
       for (size_t q = b; q < e_end; ++q) {
+        if (q + 24 < e_end) __builtin_prefetch(&g->E[g->adj.arcs[q + 24].e]); // (a random record per arc)
         const msgpu_graph::Edge &E = g->E[g->adj.arcs[q].e];
         arc_flags[q] = static_cast<uint8_t>((E.alive ? 1 : 0) | (E.first != NIL ? 2 : 0) | (E.cons != D_NONE ? 4 : 0) |
                                             (E.cons == D_POS ? 8 : 0));
