@@ -1065,16 +1065,27 @@ static int install_rows(msgpu_assembly *a, const msgpu_row *rows, size_t n_rows,
     a->row_recs.resize(0);
     a->row_start.clear();
     a->anchor_start.clear();
+    // (the same pass notes where every anchor's rows start, as if the table were grouped by ascending anchor id -- it is, when
+    // it comes from a PAF --: a chunk fills the starts of the anchors that begin inside it and of the absent ids before them,
+    // for as long as its ids ascend; the result is used only if every chunk's did.  One pass over the 200 MB of configs[2]'s
+    // table instead of two.)
+    const size_t n_anchors_guess = n_rows ? static_cast<size_t>(rows[n_rows - 1].anchor_id) + 1 : 0;
+    const bool   ahead = n_anchors_guess <= 2 * n_rows + 1024; // (a table in another order may end on any id: no table sized by it then)
+    if (ahead) a->anchor_start.resize(n_anchors_guess + 1);
+    uint64_t *st = a->anchor_start.data();
     fan(nt, [&](size_t t) {
       uint32_t m = 0;
       bool     up = true, rup = true;
       const size_t b = chunk(t).first, e = chunk(t).second;
       uint32_t     prev = b ? rows[b - 1].anchor_id : 0, prev_read = b ? rows[b - 1].read_id : 0;
       for (size_t i = b; i < e; ++i) {
+        const uint32_t an = rows[i].anchor_id;
         m = std::max(m, rows[i].read_id);
-        up &= prev <= rows[i].anchor_id;
-        rup &= prev != rows[i].anchor_id || prev_read <= rows[i].read_id || i == 0;
-        prev      = rows[i].anchor_id;
+        up &= prev <= an;
+        rup &= prev != an || prev_read <= rows[i].read_id || i == 0;
+        if (ahead && up && an < n_anchors_guess && (i == 0 || prev != an))
+          for (size_t id = i == 0 ? 0 : static_cast<size_t>(prev) + 1; id <= an; ++id) st[id] = i;
+        prev      = an;
         prev_read = rows[i].read_id;
       }
       if (copy && e > b) memcpy(a->rows.data() + b, rows + b, (e - b) * sizeof(msgpu_row));
@@ -1088,15 +1099,17 @@ static int install_rows(msgpu_assembly *a, const msgpu_row *rows, size_t n_rows,
       // Grouped by ascending anchor id -- what a PAF is (grouped by query, ids handed out in first-seen order): the
       // table needs no sort, only where each anchor's rows start.  Every chunk fills the starts of the anchors that
       // begin inside it (and of the absent ids before them): disjoint stretches of anchor_start.
-      const size_t n_anchors = static_cast<size_t>(rows[n_rows - 1].anchor_id) + 1;
-      a->anchor_start.resize(n_anchors + 1);
-      uint64_t *st = a->anchor_start.data();
-      fan(nt, [&](size_t t) {
-        for (size_t i = chunk(t).first; i < chunk(t).second; ++i) {
-          const size_t from = i == 0 ? 0 : static_cast<size_t>(rows[i - 1].anchor_id) + 1;
-          for (size_t id = from; id <= rows[i].anchor_id; ++id) st[id] = i;
-        }
-      });
+      const size_t n_anchors = n_anchors_guess; // (ascending: the last row holds the highest id)
+      if (!ahead) { // sparse ids: the starts in a pass of their own
+        a->anchor_start.resize(n_anchors + 1);
+        st = a->anchor_start.data();
+        fan(nt, [&](size_t t) {
+          for (size_t i = chunk(t).first; i < chunk(t).second; ++i) {
+            const size_t from = i == 0 ? 0 : static_cast<size_t>(rows[i - 1].anchor_id) + 1;
+            for (size_t id = from; id <= rows[i].anchor_id; ++id) st[id] = i;
+          }
+        });
+      }
       st[n_anchors] = n_rows;
       a->anchor_sorted_by_read = std::find(rasc.begin(), rasc.end(), 0) == rasc.end();
       // Look-ups search an anchor's rows by read id (binary when they are in read order).  A table whose scaffolds are in
@@ -1106,8 +1119,8 @@ static int install_rows(msgpu_assembly *a, const msgpu_row *rows, size_t n_rows,
       if (!a->anchor_sorted_by_read)
         for (size_t id = 0; id < n_anchors; ++id) longest = std::max(longest, st[id + 1] - st[id]);
       if (longest <= 64) return MSGPU_OK;
-      a->anchor_start.clear();
     }
+    a->anchor_start.clear();
     // partitions of 2^shift consecutive read ids, at most 1024 of them
     unsigned shift = 8;
     while ((n_reads >> shift) >= 1024) ++shift;
