@@ -432,7 +432,8 @@ struct UnionFind { // vertex ids are dense: vectors instead of the reference's t
 // order (std::sort on a vector built in edge order; canonical = stable).  `cand` = candidate edge indices in edge order;
 // ends(e) -> (a, b), weight(e).
 template <class Ends, class Weight>
-void max_span_tree(uint32_t nv, Ends ends, Weight weight, const std::vector<uint32_t> &cand, std::vector<uint8_t> &in_tree) {
+void max_span_tree(uint32_t nv, Ends ends, Weight weight, const std::vector<uint32_t> &cand, std::vector<uint8_t> &in_tree,
+                   std::vector<uint32_t> *set_of = nullptr /*large graphs: per vertex, a vertex of its connected set*/) {
   // (weight, position): one sort key, no gathers in the compare.  Edges of weight 0 (every shadow edge: 97 % of the edges
   // of BASELINE.json configs[2]) come last whatever their number and keep their edge order among themselves: they are
   // not sorted at all.
@@ -550,6 +551,7 @@ void max_span_tree(uint32_t nv, Ends ends, Weight weight, const std::vector<uint
       for (size_t v = b; v < e; ++v) comp[v] = static_cast<uint32_t>(best[v]);
     });
   }
+  if (set_of) set_of->assign(comp.begin(), comp.end());
   tick("  mst: Boruvka rounds");
 }
 
@@ -745,6 +747,9 @@ struct msgpu_graph {
   std::vector<Vertex>  V;
   RawArray<Edge>       E; // (constructed in graph_create's parallel fill)
   std::vector<uint8_t> o_kept;  // per order: still on its edge (findDeletableEdges drops the contained ones)
+  std::vector<uint32_t> walk_seq; // per vertex: its pop number in getDirectedGraph's walk (compact copy of Vertex::seq for the walk itself)
+  std::vector<uint32_t> span_set; // per vertex, a vertex of its set in the span forest (large graphs; empty: not known) -- the
+                                  // connected components of msgpu_graph_linearize when decycle() removed no edge
   std::vector<uint8_t> o_fwd;   // per kept order: it runs E.a -> E.b in its component's DiGraph (getDirectedGraph, pass 1)
   struct OLite { // what the walks over the graph read of an EdgeOrder (16 of its 64 bytes: the random accesses of
     uint32_t start, end, base, flags; // getDirectedGraph stay inside a quarter of the cache footprint)
@@ -839,48 +844,64 @@ DiG get_directed_graph(msgpu_graph &g, uint32_t cid, const std::vector<uint32_t>
     // (an entry pushed by an earlier neighbour lies deeper in the stack and finds the vertex popped).  So: that search, one
     // frame per vertex, with the toggle the parent's entry would have carried.  Every arc of a popped vertex is still looked
     // at once, so the in_dg marks end up the same.
+    // What the search reads per arc: the flag byte beside the arc and ONE word of a table of pop numbers (400 KB for the
+    // 100 k reads of configs[2]: it stays in the core's cache; the vertex records, 24 bytes each, do not).  A neighbour over an
+    // alive edge with a consensus direction is a vertex of this component by the component's definition, so no record has
+    // to say so.  Directions, pop numbers and marks go into the records afterwards, on all threads.
     struct Frame {
       uint32_t v, next; // next: one past the arc to look at next (arcs are taken in descending order)
       bool     toggle;
     };
-    std::vector<Frame> frames;
-    auto               pop_first = [&](uint32_t v, bool toggle) {
-      msgpu_graph::Vertex &vc = g.V[v];
-      vc.seq                  = static_cast<uint32_t>(pop_order.size());
+    std::vector<Frame>   frames;
+    std::vector<uint8_t> pop_toggle;
+    uint32_t *const      seq = g.walk_seq.data(); // NIL for every vertex when msgpu_graph_linearize hands out the components
+    const uint32_t *const off = g.adj.off.data();
+    auto                 pop_first = [&](uint32_t v, bool toggle) {
+      seq[v] = static_cast<uint32_t>(pop_order.size());
       pop_order.push_back(v);
-      vc.in_dg = 1;
-      vc.dir   = toggle ? D_POS : D_NEG; // (D_NONE until here: nothing else sets a direction)
-      for (const Arc *n = g.adj.begin(v); n != g.adj.end(v); ++n) {
-        __builtin_prefetch(&g.V[n->to]);
-        // (and where the neighbour's own arcs begin: most neighbours are popped soon after, and a pop starts on those lines)
-        const uint32_t o = g.adj.off[n->to];
-        __builtin_prefetch(arcs0 + o);
-        __builtin_prefetch(arc_flags.data() + o);
-      }
-      frames.push_back(Frame{v, static_cast<uint32_t>(g.adj.end(v) - arcs0), toggle});
+      pop_toggle.push_back(toggle ? 1 : 0);
+      frames.push_back(Frame{v, off[v + 1], toggle}); // (asking for the neighbours' arc rows ahead changed nothing: tools/experiments/graph_walk_ab.sh)
     };
-    require(g.V[start].seq == NIL && g.V[start].dir == D_NONE, "getDirectedGraph: start vertex already directed");
+    require(g.walk_seq.size() == g.V.size(), "getDirectedGraph: pop-number table not allocated");
+    require(g.V[start].seq == NIL && g.V[start].dir == D_NONE && seq[start] == NIL, "getDirectedGraph: start vertex already directed");
+    pop_order.reserve(members.size());
+    pop_toggle.reserve(members.size());
     pop_first(start, true);
     while (!frames.empty()) {
-      const uint32_t v = frames.back().v, first_arc = static_cast<uint32_t>(g.adj.begin(v) - arcs0);
+      const uint32_t v = frames.back().v, first_arc = off[v];
       const bool     toggle = frames.back().toggle;
       uint32_t       q = frames.back().next;
       bool           descended = false;
       while (q > first_arc) {
         --q;
         const uint8_t af = arc_flags[q];
-        if (!(af & AF_ALIVE)) continue;
-        msgpu_graph::Vertex &vn = g.V[arcs0[q].to];
-        if (vn.comp != cid) continue;
-        vn.in_dg = 1;
-        if (vn.seq != NIL || !(af & AF_CONS)) continue; // popped already / no consensus direction: not pushed
+        if ((af & (AF_ALIVE | AF_CONS)) != (AF_ALIVE | AF_CONS)) continue; // (no consensus direction: not pushed)
+        const uint32_t to = arcs0[q].to;
+        if (seq[to] != NIL) continue; // popped already
         frames.back().next = q;
-        pop_first(arcs0[q].to, toggle == ((af & AF_POS) != 0)); // (frames may move: nothing of the old frame is used below)
+        pop_first(to, toggle == ((af & AF_POS) != 0)); // (frames may move: nothing of the old frame is used below)
         descended = true;
         break;
       }
       if (!descended) frames.pop_back();
     }
+    const size_t n_popped = pop_order.size();
+    parallel_chunks(n_popped, [&](unsigned, size_t b, size_t e) {
+      for (size_t i = b; i < e; ++i) {
+        msgpu_graph::Vertex &vc = g.V[pop_order[i]];
+        if (vc.comp != cid) throw GraphError("getDirectedGraph: the walk left its component");
+        vc.seq   = static_cast<uint32_t>(i);
+        vc.dir   = pop_toggle[i] ? D_POS : D_NEG; // (D_NONE until here: nothing else sets a direction)
+        vc.in_dg = 1;
+      }
+    });
+    // the reference marks every neighbour a popped vertex has over an alive edge inside the component; the component is
+    // connected over such edges (cc.cpp:33-70 built it from them), so those are its vertices, all popped above.  Should a
+    // vertex of it be left (it cannot), the marks are made the long way.
+    if (n_popped != members.size())
+      for (uint32_t v : pop_order)
+        for (uint32_t q = off[v]; q < off[v + 1]; ++q)
+          if ((arc_flags[q] & AF_ALIVE) && g.V[arcs0[q].to].comp == cid) g.V[arcs0[q].to].in_dg = 1;
     stack.clear();
   }
   while (!stack.empty()) {
@@ -1476,17 +1497,22 @@ struct PathPeeler {
 
 std::vector<std::vector<uint32_t>> extract_paths(DiG &dg) { // local vertex ids
   Tick                 tick;
-  std::vector<uint8_t> alive(dg.m());
-  for (size_t e = 0; e < dg.m(); ++e) alive[e] = !dg.shadow[e]; // the copy without its shadow edges (:351-356)
+  std::vector<uint8_t>               alive(dg.m());
+  std::vector<std::vector<uint32_t>> le_of(stage_threads() + 1);
+  parallel_chunks(dg.m(), [&](unsigned chunk, size_t b, size_t e_end) { // the copy without its shadow edges (:351-356)
+    for (size_t e = b; e < e_end; ++e) {
+      alive[e] = !dg.shadow[e];
+      if (alive[e]) le_of[chunk].push_back(static_cast<uint32_t>(e));
+    }
+  });
   // (the copy's own adjacency: 3 % of the arcs on BASELINE configs[2]; every pass below still asks `alive`, which only loses edges)
   {
     std::vector<uint32_t> le, la, lb;
-    for (size_t e = 0; e < dg.m(); ++e)
-      if (alive[e]) {
-        le.push_back(static_cast<uint32_t>(e));
-        la.push_back(dg.ea[e]);
-        lb.push_back(dg.eb[e]);
-      }
+    for (auto &v : le_of) le.insert(le.end(), v.begin(), v.end()); // (chunk order = edge order)
+    for (uint32_t e : le) {
+      la.push_back(dg.ea[e]);
+      lb.push_back(dg.eb[e]);
+    }
     dg.lsucc = build_csr(dg.n, la.data(), lb.data(), le.size(), false);
     dg.lpred = build_csr(dg.n, lb.data(), la.data(), le.size(), false);
     for (Csr *c : {&dg.lsucc, &dg.lpred})
@@ -1980,9 +2006,10 @@ int msgpu_graph_clean_up(msgpu_graph *g, const int64_t *contraction_order, const
     for (auto &v : cand_of) cand.insert(cand.end(), v.begin(), v.end());
     tick("deletions + bitweight");
     std::vector<uint8_t> in_tree(ne, 0); // getMaxSpanTree, mst.cpp:75-111
+    g->span_set.clear();
     max_span_tree(
         nv, [&](uint32_t e) { return std::make_pair(g->E[e].a, g->E[e].b); }, [&](uint32_t e) { return g->E[e].weight; }, cand,
-        in_tree);
+        in_tree, &g->span_set);
     tick("span tree");
     // the span forest, rooted: parent / edge to parent / depth / number of e_NEG edges to the root (mod 2)
     std::vector<uint32_t> parent(nv, NIL), pedge(nv, NIL), depth(nv, 0);
@@ -2091,6 +2118,7 @@ int msgpu_graph_clean_up(msgpu_graph *g, const int64_t *contraction_order, const
       n_alive += a;
     });
     g->stats.n_decycled_edges += n_dele;
+    if (n_dele != 0) g->span_set.clear(); // (the sets of the span forest are the components only while decycle took no edge away)
     uint64_t nv_alive = 0;
     for (auto &x : g->V) nv_alive += x.alive;
     g->stats.n_vertices = nv_alive;
@@ -2141,11 +2169,28 @@ int msgpu_graph_linearize(msgpu_graph *g) {
     auto v_ok = [&](uint32_t v) { return g->V[v].alive != 0; };
     auto e_ok = [&](const Arc *t) { return (arc_flags[t - arcs0] & 5) == 5; }; // alive and with a consensus direction
     auto set_comp = [&](uint32_t v, uint32_t c) { g->V[v].comp = c; };
-    const std::vector<std::vector<uint32_t>> comps =
-        g->nv >= par_min() && stage_threads() > 1
-            ? connected_components_parallel(g->nv, g->adj, v_ok, e_ok, set_comp)
-            : connected_components(g->nv, g->adj, v_ok, e_ok, [&](uint32_t v) { return g->V[v].comp; }, set_comp);
+    std::vector<std::vector<uint32_t>> comps;
+    if (g->span_set.size() == g->nv && g->nv) {
+      // the span forest was grown over exactly these edges (alive, with a consensus direction; decycle() removed none): its
+      // sets are the components.  Numbered as the scans below number them: by their first vertex in the graph, members ascending.
+      std::vector<uint32_t> cid(g->nv, NIL);
+      uint32_t              n_comp = 0;
+      for (uint32_t s = 0; s < g->nv; ++s)
+        if (v_ok(s) && cid[g->span_set[s]] == NIL) cid[g->span_set[s]] = n_comp++;
+      comps.resize(n_comp);
+      for (uint32_t v = 0; v < g->nv; ++v) {
+        const uint32_t c = cid[g->span_set[v]];
+        if (c == NIL) continue;
+        set_comp(v, c);
+        comps[c].push_back(v);
+      }
+    } else {
+      comps = g->nv >= par_min() && stage_threads() > 1
+                  ? connected_components_parallel(g->nv, g->adj, v_ok, e_ok, set_comp)
+                  : connected_components(g->nv, g->adj, v_ok, e_ok, [&](uint32_t v) { return g->V[v].comp; }, set_comp);
+    }
     g->stats.n_components = comps.size();
+    g->walk_seq.assign(g->nv, NIL);
     tick("components");
     // Components are independent (a component only orients and reads its own vertices and edges): largest first on the
     // worker threads, results appended in component order -- the order a single-threaded reference run assembles them in.
