@@ -1279,16 +1279,23 @@ struct PathPeeler {
   std::vector<uint8_t>         alive, valive; // edges / vertices still in diGraphCycle
   size_t                       n_arcs = 0;
   // per-solve scratch (round-stamped)
-  std::vector<int64_t>  deg;
-  std::vector<uint32_t> ostamp, olen, seg, lab;
-  std::vector<int32_t>  ohead;
-  std::vector<uint64_t> oscore;
+  struct VState { // one record per vertex (a solve touches all of these for every vertex it meets: one cache line, not seven)
+    uint64_t oscore;
+    int32_t  deg, ohead;
+    uint32_t ostamp, olen, seg, lab;
+  };
+  std::vector<VState> vs;
   uint32_t              round = 0, lab_round = 0;
   struct Node {
     uint32_t v;
     int32_t  parent;
   };
-  std::vector<Node> nodes;
+  struct Scratch { // a solve's own work space, kept from solve to solve (a peeling takes thousands of rounds of a few vertices each)
+    std::vector<Node>     nodes;
+    std::vector<uint32_t> order, stack, max_outs;
+  };
+  Scratch               scratch;     // of the calling thread's solves
+  std::vector<uint32_t> members_tmp; // split()'s search
   struct Comp {
     std::vector<uint32_t> members, path; // members ascending
     uint32_t              segroot = 0;
@@ -1302,8 +1309,7 @@ struct PathPeeler {
   std::priority_queue<uint32_t> iso; // vertices without edges: each is a root and a sink of its own
 
   PathPeeler(const DiG &d, const std::vector<uint8_t> &a, const std::vector<uint64_t> &w)
-      : dg(d), cw(w), alive(a), valive(d.n, 1), deg(d.n), ostamp(d.n, 0), olen(d.n), seg(d.n), lab(d.n, 0),
-        ohead(d.n), oscore(d.n) {
+      : dg(d), cw(w), alive(a), valive(d.n, 1), vs(d.n, VState{0, 0, 0, 0, 0, 0, 0}) {
     for (uint8_t x : alive) n_arcs += x;
   }
 
@@ -1321,19 +1327,19 @@ struct PathPeeler {
   // single thread would have found them.
   void split(const std::vector<uint32_t> &pool) {
     ++lab_round;
-    std::vector<uint32_t> members;
-    std::vector<Comp>     found;
+    std::vector<uint32_t> &members = members_tmp;
+    std::vector<Comp>      found;
     const bool            fan_out = pool.size() >= par_min() / 4 && stage_threads() > 1;
     for (uint32_t s : pool) {
-      if (!valive[s] || lab[s] == lab_round) continue;
+      if (!valive[s] || vs[s].lab == lab_round) continue;
       members.assign(1, s);
-      lab[s] = lab_round;
+      vs[s].lab = lab_round;
       for (size_t h = 0; h < members.size(); ++h) {
         const uint32_t v = members[h];
         for (const Csr *c : {&dg.lsucc, &dg.lpred})
           for (const Arc *t = c->begin(v); t != c->end(v); ++t)
-            if (alive[t->e] && lab[t->to] != lab_round) {
-              lab[t->to] = lab_round;
+            if (alive[t->e] && vs[t->to].lab != lab_round) {
+              vs[t->to].lab = lab_round;
               members.push_back(t->to);
             }
       }
@@ -1348,7 +1354,7 @@ struct PathPeeler {
         continue;
       }
       std::sort(c.members.begin(), c.members.end());
-      solve(c, ++round, nodes);
+      solve(c, ++round, scratch);
       heap.push(Key{static_cast<uint32_t>(c.path.size()), c.segroot, static_cast<uint32_t>(comps.size())});
       comps.push_back(std::move(c));
     }
@@ -1356,10 +1362,10 @@ struct PathPeeler {
     const uint32_t first_round = round + 1; // every solve has a round of its own
     round += static_cast<uint32_t>(found.size());
     parallel_dynamic(found.size(), 16, [&](size_t b, size_t e) {
-      std::vector<Node> my_nodes;
+      Scratch mine;
       for (size_t k = b; k < e; ++k) {
         std::sort(found[k].members.begin(), found[k].members.end());
-        solve(found[k], first_round + static_cast<uint32_t>(k), my_nodes);
+        solve(found[k], first_round + static_cast<uint32_t>(k), mine);
       }
     });
     for (Comp &c : found) {
@@ -1369,17 +1375,19 @@ struct PathPeeler {
   }
 
   // sortTopologically + findConservationPathAlt on one component
-  void solve(Comp &c, const uint32_t round, std::vector<Node> &nodes) { // (round, nodes: this solve's own -- solves may run side by side)
+  void solve(Comp &c, const uint32_t round, Scratch &sc) { // (round, sc: this solve's own -- solves may run side by side)
+    std::vector<Node>     &nodes = sc.nodes;
+    std::vector<uint32_t> &order = sc.order, &stack = sc.stack, &max_outs = sc.max_outs;
     auto node = [&](uint32_t v, int32_t parent) {
       nodes.push_back(Node{v, parent});
       return static_cast<int32_t>(nodes.size() - 1);
     };
     nodes.clear();
-    std::vector<uint32_t> order, stack;
+    order.clear();
     order.reserve(c.members.size());
     for (uint32_t v : c.members) {
-      deg[v] = 0;
-      for (const Arc *t = dg.lpred.begin(v); t != dg.lpred.end(v); ++t) deg[v] += alive[t->e];
+      vs[v].deg = 0;
+      for (const Arc *t = dg.lpred.begin(v); t != dg.lpred.end(v); ++t) vs[v].deg += alive[t->e];
     }
     for (size_t i = c.members.size(); i-- > 0;) { // zero-in-degree vertices, highest id first
       const uint32_t r = c.members[i];
@@ -1390,24 +1398,23 @@ struct PathPeeler {
       while (!stack.empty()) {
         const uint32_t v = stack.back();
         stack.pop_back();
-        seg[v] = r;
+        vs[v].seg = r;
         order.push_back(v);
         for (const Arc *t = dg.lsucc.begin(v); t != dg.lsucc.end(v); ++t)
-          if (alive[t->e] && --deg[t->to] == 0) stack.push_back(t->to);
+          if (alive[t->e] && --vs[t->to].deg == 0) stack.push_back(t->to);
       }
     }
-    auto has_open = [&](uint32_t v) { return ostamp[v] == round; };
+    auto has_open = [&](uint32_t v) { return vs[v].ostamp == round; };
     auto touch    = [&](uint32_t v) { // operator[] of the reference: default-constructs (0, {})
-      if (ostamp[v] != round) {
-        ostamp[v] = round;
-        oscore[v] = 0;
-        olen[v]   = 0;
-        ohead[v]  = -1;
+      if (vs[v].ostamp != round) {
+        vs[v].ostamp = round;
+        vs[v].oscore = 0;
+        vs[v].olen   = 0;
+        vs[v].ohead  = -1;
       }
     };
     uint32_t final_len = 0, final_single = NIL, final_seg = 0;
     int32_t  final_head = -1;
-    std::vector<uint32_t> max_outs;
     for (uint32_t v : order) {
       uint64_t max_out = 0;
       max_outs.clear();
@@ -1429,49 +1436,49 @@ struct PathPeeler {
             final_len    = 1;
             final_single = v;
             final_head   = -1;
-            final_seg    = seg[v];
+            final_seg    = vs[v].seg;
           }
         } else {
-          if (olen[v] > final_len) {
-            final_len    = olen[v];
-            final_head   = ohead[v];
+          if (vs[v].olen > final_len) {
+            final_len    = vs[v].olen;
+            final_head   = vs[v].ohead;
             final_single = NIL;
-            final_seg    = seg[v];
+            final_seg    = vs[v].seg;
           }
-          olen[v]  = 0;
-          ohead[v] = -1;
+          vs[v].olen  = 0;
+          vs[v].ohead = -1;
         }
         continue;
       }
       for (uint32_t nxt : max_outs) {
         if (has_open(nxt)) {
           bool take;
-          if (oscore[nxt] < max_out) take = true;
-          else if (oscore[nxt] == max_out) {
+          if (vs[nxt].oscore < max_out) take = true;
+          else if (vs[nxt].oscore == max_out) {
             touch(v);
-            take = olen[nxt] < olen[v] + 1;
+            take = vs[nxt].olen < vs[v].olen + 1;
           } else take = false;
           if (take) {
             touch(v);
-            ohead[nxt]  = node(nxt, ohead[v]);
-            olen[nxt]   = olen[v] + 1;
-            oscore[nxt] = max_out;
+            vs[nxt].ohead  = node(nxt, vs[v].ohead);
+            vs[nxt].olen   = vs[v].olen + 1;
+            vs[nxt].oscore = max_out;
           }
         } else if (has_open(v)) {
           touch(nxt);
-          ohead[nxt]  = node(nxt, ohead[v]);
-          olen[nxt]   = olen[v] + 1;
-          oscore[nxt] = max_out;
+          vs[nxt].ohead  = node(nxt, vs[v].ohead);
+          vs[nxt].olen   = vs[v].olen + 1;
+          vs[nxt].oscore = max_out;
         } else {
           touch(nxt);
-          ohead[nxt]  = node(nxt, node(v, -1));
-          olen[nxt]   = 2;
-          oscore[nxt] = max_out;
+          vs[nxt].ohead  = node(nxt, node(v, -1));
+          vs[nxt].olen   = 2;
+          vs[nxt].oscore = max_out;
         }
       }
       touch(v);
-      olen[v]  = 0;
-      ohead[v] = -1;
+      vs[v].olen  = 0;
+      vs[v].ohead = -1;
     }
     c.path.clear();
     c.segroot = final_seg;
@@ -1533,7 +1540,9 @@ std::vector<std::vector<uint32_t>> extract_paths(DiG &dg) { // local vertex ids
   }
   tick("conservation paths: first split");
   std::vector<uint32_t> longest;
+  size_t                n_rounds = 0;
   while (pp.n_arcs > 0) { // diGraphCycle.getSize() > 0
+    ++n_rounds;
     require(!pp.heap.empty(), "extractPaths: edges left but no component");
     const PathPeeler::Key top = pp.heap.top();
     bool                  lone = false;
@@ -1547,7 +1556,7 @@ std::vector<std::vector<uint32_t>> extract_paths(DiG &dg) { // local vertex ids
       pp.iso.pop();
     } else {
       pp.heap.pop();
-      longest = pp.comps[top.comp].path;
+      longest.swap(pp.comps[top.comp].path); // (its component is done with it)
       pool.swap(pp.comps[top.comp].members);
       pp.comps[top.comp].path.clear();
     }
@@ -1567,6 +1576,7 @@ std::vector<std::vector<uint32_t>> extract_paths(DiG &dg) { // local vertex ids
     }
     pp.split(pool);
   }
+  if (std::getenv("MSGPU_GRAPH_DEBUG")) fprintf(stderr, "[graph] %zu peeling rounds, %zu paths kept, %zu solves\n", n_rounds, paths.size(), static_cast<size_t>(pp.round));
   tick("conservation paths loop");
   // lg.cpp:409-411 appends a path of one vertex for every vertex left over.  linearizeGraph (the only caller) joins no such
   // path to anything -- it has nothing in front of its vertex and nothing behind it (the test of lg.cpp:560) -- and drops every
