@@ -3162,9 +3162,9 @@ __global__ __launch_bounds__(256) void k_fill_pair_tab(uint32_t *tab) {
 // ones before its own are its base, all of them the table sizes.  Workgroup 0 writes the sizes into the scalar block and
 // publishes the block to the host AT ONCE (k_publish_scalars' protocol): the host turns around while the tables are still being
 // written.  Then the prefix inside the chunk (a block scan over the per-edge counts), then the move.
-__global__ __launch_bounds__(1024) void k_compact(CompactArgs a) {
-  __shared__ unsigned long long s_red[16][5];
-  __shared__ uint32_t           s_ob[COMPACT_CHUNK], s_ib[COMPACT_CHUNK], s_w[2][16];
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_compact(CompactArgs a) {
+  __shared__ unsigned long long s_red[16][5], s_tot[5], s_em[COMPACT_CHUNK];
+  __shared__ uint32_t           s_ob[COMPACT_CHUNK], s_ib[COMPACT_CHUNK], s_no[COMPACT_CHUNK], s_w[2][16];
   static_assert(COMPACT_CHUNK == 1024, "an edge per thread");
   const int      lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t chunk = blockIdx.x;
@@ -3186,15 +3186,18 @@ __global__ __launch_bounds__(1024) void k_compact(CompactArgs a) {
     if (lane == 0) s_red[wave][k] = t[k];
   }
   __syncthreads();
-  unsigned long long base_o = 0, base_i = 0, tot_o = 0, tot_i = 0, tot_f = 0;
+  // (the sixteen partial sums are added by the first wavefront and handed to everybody as five words: every thread adding all
+  // eighty of them held them in registers at once, and the kernel must stay within 64 to have two workgroups on a CU)
+  if (wave == 0) {
 #pragma unroll
-  for (int w = 0; w < 16; ++w) {
-    base_o += s_red[w][0];
-    base_i += s_red[w][1];
-    tot_o += s_red[w][2];
-    tot_i += s_red[w][3];
-    tot_f += s_red[w][4];
+    for (int k = 0; k < 5; ++k) {
+      unsigned long long v = lane < 16 ? s_red[lane][k] : 0ull;
+      for (int d = 8; d > 0; d >>= 1) v += __shfl_xor(v, d);
+      if (lane == 0) s_tot[k] = v;
+    }
   }
+  __syncthreads();
+  const unsigned long long base_o = s_tot[0], base_i = s_tot[1], tot_o = s_tot[2], tot_i = s_tot[3], tot_f = s_tot[4];
   if (chunk == 0 && a.scalars && threadIdx.x < 64) {
     // (every launch writes the sizes; only the first launch of a call publishes -- a repeat after a reallocation has seq = 0)
     if (lane == 0) {
@@ -3217,9 +3220,12 @@ __global__ __launch_bounds__(1024) void k_compact(CompactArgs a) {
   const uint64_t e0 = static_cast<uint64_t>(chunk) * COMPACT_CHUNK;
   if (e0 >= a.n_edges) return;
   {
-    // prefix inside the chunk: an edge per thread
+    // prefix inside the chunk: an edge per thread.  What the move below needs of the edge -- its order count and where its
+    // scratch begins -- is read here too, beside the counts, and handed over through LDS: the move's chain of dependent reads
+    // (edge -> order record -> ids) is one read shorter, and the four rounds of it start together.
     const uint64_t e  = e0 + threadIdx.x;
     const uint32_t no = e < a.n_edges ? a.edge_norders[e] : 0u, ni = e < a.n_edges ? a.edge_nids[e] : 0u;
+    const uint64_t em = e < a.n_edges ? a.edges[e].em_off : 0ull;
     const uint32_t io = wave_incl_scan(no), ii = wave_incl_scan(ni);
     if (lane == 63) {
       s_w[0][wave] = io;
@@ -3233,24 +3239,28 @@ __global__ __launch_bounds__(1024) void k_compact(CompactArgs a) {
     }
     s_ob[threadIdx.x] = bo;
     s_ib[threadIdx.x] = bi;
+    s_no[threadIdx.x] = no;
+    s_em[threadIdx.x] = em;
   }
   __syncthreads();
-  // Four lanes per edge, sixteen edges per wavefront, all in flight together: a lane moves one 16-byte quarter of an
+  // Four lanes per edge, sixteen edges per wavefront, four rounds per workgroup: a lane moves one 16-byte quarter of an
   // order record and every fourth id.  (Most edges have one order; the dependent chain "order record -> id count ->
-  // ids" is then as long as a single edge's, not sixteen of them in a row.)
-  const int sub = lane & 3;
-#pragma unroll
-  for (uint32_t round = 0; round < COMPACT_CHUNK / 256; ++round) {
+  // ids" is then as long as a single edge's, not sixteen of them in a row.)  The kernel waits on memory: what counts is how
+  // many such chains a CU has in flight -- two workgroups (64 registers a lane: the rounds are NOT unrolled into each other,
+  // which took 96 and left room for one).
+  constexpr int ROUNDS = COMPACT_CHUNK / 256;
+  const int     sub = lane & 3;
+#pragma unroll 1
+  for (int round = 0; round < ROUNDS; ++round) {
     const uint32_t le   = round * 256 + wave * 16 + (lane >> 2);
     const uint64_t e    = e0 + le;
     const bool     have = e < a.n_edges;
-    uint32_t       no = 0;
-    uint64_t       oo = 0, io = 0, em_off = 0;
+    const uint32_t no   = have ? s_no[le] : 0u;
+    const uint64_t em_off = s_em[le];
+    uint64_t       oo = 0, io = 0;
     if (have) {
-      no     = a.edge_norders[e];
-      oo     = base_o + s_ob[le];
-      io     = base_i + s_ib[le];
-      em_off = a.edges[e].em_off;
+      oo = base_o + s_ob[le];
+      io = base_i + s_ib[le];
       if (sub == 0) { // cross references leave as positions in the whole job's tables (a batch / shard adds its bases)
         a.edges[e].order_off = oo + a.out_order_base;
         a.edges[e].order_cnt = static_cast<uint16_t>(no);
