@@ -500,6 +500,7 @@ void max_span_tree(uint32_t nv, Ends ends, Weight weight, const std::vector<uint
   parallel_chunks(nv, [&](unsigned, size_t b, size_t e) {
     for (size_t v = b; v < e; ++v) comp[v] = static_cast<uint32_t>(v);
   });
+  unsigned n_rounds = 0;
   for (;;) {
     parallel_chunks(nv, [&](unsigned, size_t b, size_t e) {
       for (size_t v = b; v < e; ++v) {
@@ -528,6 +529,7 @@ void max_span_tree(uint32_t nv, Ends ends, Weight weight, const std::vector<uint
       if (mine) any.store(1, std::memory_order_relaxed);
     });
     if (!any.load()) break;
+    ++n_rounds;
     // every set with an edge out takes it and hangs itself on the set at the other end; two sets that chose the same edge: the
     // one with the higher representative hangs on the other (the chosen edges have no other cycle: ranks are unique)
     parallel_chunks(nv, [&](unsigned, size_t b, size_t e) {
@@ -552,6 +554,7 @@ void max_span_tree(uint32_t nv, Ends ends, Weight weight, const std::vector<uint
     });
   }
   if (set_of) set_of->assign(comp.begin(), comp.end());
+  if (std::getenv("MSGPU_GRAPH_DEBUG")) fprintf(stderr, "[graph]   mst: %u rounds (configs[2]: 10; a million edges leave the sets in the first four)\n", n_rounds);
   tick("  mst: Boruvka rounds");
 }
 
