@@ -1084,7 +1084,8 @@ static int install_rows(msgpu_assembly *a, const msgpu_row *rows, size_t n_rows,
         up &= prev <= an;
         rup &= prev != an || prev_read <= rows[i].read_id || i == 0;
         if (ahead && up && an < n_anchors_guess && (i == 0 || prev != an))
-          for (size_t id = i == 0 ? 0 : static_cast<size_t>(prev) + 1; id <= an; ++id) st[id] = i;
+          for (size_t id = i == 0 ? 0 : static_cast<size_t>(prev) + 1; id <= an; ++id)
+            __atomic_store_n(&st[id], static_cast<uint64_t>(i), __ATOMIC_RELAXED); // (chunks of a table in another order may meet on an id: the table is dropped then)
         prev      = an;
         prev_read = rows[i].read_id;
       }
