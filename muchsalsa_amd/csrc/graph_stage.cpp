@@ -158,10 +158,10 @@ template <class F> void parallel_dynamic(size_t n, size_t grain, F f) {
 
 // std::sort on the stage's threads: stretches sorted side by side, then merged pairwise (log2 rounds; the keys sorted here
 // are unique, so the result is the one std::sort gives)
-template <class It, class Cmp> void parallel_sort(It first, It last, Cmp cmp) {
+template <class It, class Cmp> void parallel_sort(It first, It last, Cmp cmp, size_t min_n = 0 /*0: par_min()*/) {
   const size_t n  = static_cast<size_t>(last - first);
   unsigned     nt = stage_threads();
-  if (n < par_min() || nt <= 1) {
+  if (n < (min_n ? min_n : par_min()) || nt <= 1) {
     std::sort(first, last, cmp);
     return;
   }
@@ -450,9 +450,10 @@ void max_span_tree(uint32_t nv, Ends ends, Weight weight, const std::vector<uint
   });
   std::vector<std::pair<uint64_t, uint32_t>> keyed;
   for (auto &k : keyed_of) keyed.insert(keyed.end(), k.begin(), k.end());
+  // (the weighted edges of configs[2] are 33 k: two milliseconds on one thread, and this function is on the stage's critical path)
   parallel_sort(keyed.begin(), keyed.end(), [](const std::pair<uint64_t, uint32_t> &x, const std::pair<uint64_t, uint32_t> &y) {
     return x.first != y.first ? x.first > y.first : x.second < y.second;
-  });
+  }, nc >= par_min() ? size_t(4096) : size_t(0));
   tick("  mst: keys + sort");
   // Whether an edge joins the tree depends on one thing only: are its ends connected by the edges taken before it (which root
   // a set hangs on -- mst.cpp:62-73 goes by the weights of the two vertices, not of their roots -- decides nothing).
@@ -500,20 +501,22 @@ void max_span_tree(uint32_t nv, Ends ends, Weight weight, const std::vector<uint
   parallel_chunks(nv, [&](unsigned, size_t b, size_t e) {
     for (size_t v = b; v < e; ++v) comp[v] = static_cast<uint32_t>(v);
   });
-  unsigned n_rounds = 0;
+  parallel_chunks(nv, [&](unsigned, size_t b, size_t e) {
+    for (size_t v = b; v < e; ++v) {
+      best[v] = NONE;
+      hook[v] = static_cast<uint32_t>(v);
+    }
+  });
+  RawVec<uint32_t> next_comp(nv);
+  unsigned         n_rounds = 0;
   for (;;) {
-    parallel_chunks(nv, [&](unsigned, size_t b, size_t e) {
-      for (size_t v = b; v < e; ++v) {
-        best[v] = NONE;
-        hook[v] = static_cast<uint32_t>(v);
-      }
-    });
     std::atomic<int> any{0};
+    const bool       first_round = n_rounds == 0; // every vertex is its own set: nothing to look up
     parallel_dynamic(nc, 8192, [&](size_t b, size_t e) {
       bool mine = false;
       for (size_t i = b; i < e; ++i) {
         if (dead[i]) continue;
-        const uint32_t ca = comp[ea[i]], cb = comp[eb[i]];
+        const uint32_t ca = first_round ? ea[i] : comp[ea[i]], cb = first_round ? eb[i] : comp[eb[i]];
         if (ca == cb) { // inside a set from now on (also an edge from a vertex to itself)
           dead[i] = 1;
           continue;
@@ -546,11 +549,15 @@ void max_span_tree(uint32_t nv, Ends ends, Weight weight, const std::vector<uint
       for (size_t v = b; v < e; ++v) {
         uint32_t r = comp[v];
         while (hook[r] != r) r = hook[r];
-        best[v] = r; // (best is idle until the next round clears it: comp is still being read by the other threads)
+        next_comp[v] = r; // (comp and hook are still being read by the other threads)
       }
     });
-    parallel_chunks(nv, [&](unsigned, size_t b, size_t e) {
-      for (size_t v = b; v < e; ++v) comp[v] = static_cast<uint32_t>(best[v]);
+    parallel_chunks(nv, [&](unsigned, size_t b, size_t e) { // ... and the next round's clean slate
+      for (size_t v = b; v < e; ++v) {
+        comp[v] = next_comp[v];
+        best[v] = NONE;
+        hook[v] = static_cast<uint32_t>(v);
+      }
     });
   }
   if (set_of) set_of->assign(comp.begin(), comp.end());

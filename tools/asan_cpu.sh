@@ -16,4 +16,4 @@ LD_PRELOAD="$($CLANG -print-file-name=libclang_rt.asan-x86_64.so)" \
 ASAN_OPTIONS=detect_leaks=0:halt_on_error=1 UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1 MSGPU_LIB="$OUT" \
 MSGPU_GRAPH_PAR_MIN=64 MSGPU_GRAPH_THREADS=6 MSGPU_SEQ_THREADS=5 \
   python -m pytest tests/test_assemble_path.py tests/test_graph_stage.py tests/test_graph_fullsize.py tests/test_segments.py \
-  tests/test_sequences_loader.py tests/test_paf_loader.py tests/test_cfg1_plumbing.py tests/test_ref_test_vectors.py tests/test_wire_host.py -x -q "$@"
+  tests/test_sequences_loader.py tests/test_paf_loader.py tests/test_cfg1_plumbing.py tests/test_ref_test_vectors.py tests/test_wire_host.py -x -q -m "not gpu" "$@"

@@ -15,4 +15,4 @@ cd "$ROOT"
 LD_PRELOAD="$($CLANG -print-file-name=libclang_rt.tsan-x86_64.so)" TSAN_OPTIONS=halt_on_error=1:report_signal_unsafe=0 \
   MSGPU_LIB="$OUT" MSGPU_GRAPH_PAR_MIN=64 MSGPU_GRAPH_THREADS=6 MSGPU_SEQ_THREADS=5 \
   python -m pytest tests/test_assemble_path.py tests/test_graph_stage.py tests/test_graph_fullsize.py tests/test_paf_loader.py \
-  tests/test_sequences_loader.py tests/test_wire_host.py -x -q "$@"
+  tests/test_sequences_loader.py tests/test_wire_host.py tests/test_ref_test_vectors.py -x -q -m "not gpu" "$@"
