@@ -17,7 +17,7 @@
 // lives in arrays indexed by id with round stamps instead of per-call hash maps.  findContractionEdges (the only part
 // with per-edge independent arithmetic) runs on the GPU (msgpu_find_contraction_edges) and is an input.
 //
-// Two restructurings keep the reference's results while dropping its quadratic loops:
+// Restructurings that keep the reference's results while dropping its quadratic loops and its one-thread passes:
 //  * decycle (main.cpp:575-618) asks for the tree path of ~every non-tree edge but only folds strand parities over it
 //    unless the parity is odd: the span forest is rooted once (parent, depth, parity-to-root), so the fold is two array
 //    reads and the path itself (climb to the common ancestor) is only walked for the conflicting edges.
@@ -27,6 +27,16 @@
 //    zero-in-degree vertices.  So each component keeps its own best path, a heap picks the winner the global pass would
 //    pick (longest; ties: the sink that comes first in the global order), and only the component a path was taken from
 //    is re-solved.
+//
+//  * getDirectedGraph's walk (dg.cpp:44-118) pushes a vertex once per neighbour that meets it before its first pop; with
+//    every alive edge holding a kept order (always, after the clean-up) that is a depth-first search with the arcs taken
+//    last to first, one frame per vertex; the directed edges are made afterwards, on all threads, in the reference's order.
+//  * getMaxSpanTree (mst.cpp:75-111) is Kruskal's loop over a TOTAL order (weight, then edge order), so its forest is the
+//    one minimum spanning forest of that order: large graphs find it with Boruvka's rounds on all threads, and its sets
+//    double as getConnectedComponents' result when decycle removed no edge.
+//  * the cycle-free copy of a component's DiGraph (lg.cpp:351-356: everything but the shadow edges, a few per cent of the
+//    edges) has an adjacency of its own instead of a tombstone array over the full one.
+// Where the stage's time goes and what each of these bought: profiles/r5_08/README.md.
 //
 // Iteration orders the reference leaves to hash containers (or to pointer VALUES: lg.cpp:419, main.cpp:211) are fixed
 // as in DESIGN.md section 2, "canonical order": vertices ascending id, edges in creation order (table order for the undirected graph),
