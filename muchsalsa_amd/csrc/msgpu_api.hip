@@ -1349,20 +1349,26 @@ int msgpu_chaining_and_overlaps(msgpu_ctx *c) {
     const uint32_t *list = c->cls_list.as<uint32_t>();
     const uint32_t *l64 = list, *l32 = l64 + c->n_cls[2], *l16 = l32 + c->n_cls[1], *l8 = l16 + c->n_cls[0]; // sizes descending
     HIPCHK(c, hipEventRecord(ck_begin, st));
-    // The two short classes beside the two long ones, on the side stream the candidate stage used: a kernel of a few thousand
-    // wavefronts lasts as long as ONE of its wavefronts (45 us each for the 16- and 8-wide classes of a shard of eight, one
-    // after the other behind k_chain and k_chain_sub<32>: a third of that shard's chain stage, profiles/r5_05); side by side
-    // they fill what the long classes leave.  On the whole job the four kernels' work is the same either way.
-    static const bool serial = getenv("MSGPU_CHAIN_SERIAL") != nullptr; // A/B switch: the four classes one after the other
-    const bool beside = !serial && (c->n_cls[0] || c->n_cls[3]) && (c->n_cls[2] || c->n_cls[1]);
+    // The three sub-wavefront classes go out as ONE launch (k_chain_sub_all: its workgroups take the 32-, 16- and 8-wide class
+    // in turn) on the side stream the candidate stage used, beside k_chain: a kernel of a few thousand wavefronts lasts as long
+    // as ONE of its wavefronts (45 us each for the 16- and 8-wide classes of a shard of eight, one after the other behind
+    // k_chain and k_chain_sub<32>: a third of that shard's chain stage, profiles/r5_05); side by side they fill what the long
+    // class leaves.  On the whole job the kernels' work is the same either way.
+    static const bool serial = getenv("MSGPU_CHAIN_SERIAL") != nullptr; // A/B switch: the four classes one after the other, a launch each
+    const bool any_sub = c->n_cls[0] || c->n_cls[1] || c->n_cls[3];
+    const bool beside  = !serial && any_sub && c->n_cls[2];
     if (beside) {
       HIPCHK(c, hipEventRecord(c->ev_side2, st));
       HIPCHK(c, hipStreamWaitEvent(c->side_stream2, c->ev_side2, 0));
     }
     launch_chain(st, a, l64, c->n_cls[2]); // the long ones first: the short classes fill the tail
-    launch_chain_sub(st, a, 32, l32, c->n_cls[1]);
-    launch_chain_sub(beside ? c->side_stream2 : st, a, 16, l16, c->n_cls[0]);
-    launch_chain_sub(beside ? c->side_stream2 : st, a, 8, l8, c->n_cls[3]);
+    if (serial) {
+      launch_chain_sub(st, a, 32, l32, c->n_cls[1]);
+      launch_chain_sub(st, a, 16, l16, c->n_cls[0]);
+      launch_chain_sub(st, a, 8, l8, c->n_cls[3]);
+    } else if (any_sub) {
+      launch_chain_sub_all(beside ? c->side_stream2 : st, a, l32, c->n_cls[1], l16, c->n_cls[0], l8, c->n_cls[3]);
+    }
     if (beside) {
       HIPCHK(c, hipEventRecord(c->ev_side2, c->side_stream2));
       HIPCHK(c, hipStreamWaitEvent(st, c->ev_side2, 0));

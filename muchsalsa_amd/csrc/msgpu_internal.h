@@ -265,6 +265,12 @@ constexpr uint32_t PAIR_TAB_STRIDE = 2016 + 128; // pairs k < l < 64 + padding r
 void launch_fill_pair_tab(hipStream_t st, uint32_t *tab);
 void launch_chain(hipStream_t st, const ChainArgs &a, const uint32_t *list, uint32_t n_list);
 void launch_chain_sub(hipStream_t st, const ChainArgs &a, int width, const uint32_t *list, uint32_t n_list);
+struct ChainSubLists { // the three sub-wavefront classes of k_chain_sub_all: edge lists, their lengths, workgroups of the first two
+  const uint32_t *list32, *list16, *list8;
+  uint32_t        n32, n16, n8, nb32, nb16;
+};
+void launch_chain_sub_all(hipStream_t st, const ChainArgs &a, const uint32_t *l32, uint32_t n32, const uint32_t *l16, uint32_t n16,
+                          const uint32_t *l8, uint32_t n8);
 size_t big_elem_bytes();
 size_t big_path_bytes();
 void launch_chain_big(hipStream_t st, const ChainArgs &a, const uint32_t *big_list, const uint64_t *big_off,

@@ -2262,16 +2262,17 @@ __device__ __forceinline__ uint32_t paths_of_direction_sub(uint32_t act, bool di
   return np;
 }
 
+// The body of k_chain_sub<W> for workgroup `block` of its class (the kernels below supply the LDS: the same two arrays for
+// every width).
 template <int W>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W == 32 ? 7 : 6, W == 32 ? 7 : 6))) void k_chain_sub(ChainArgs a, const uint32_t *list, uint32_t n_list) {
+__device__ __forceinline__ void chain_sub_body(const ChainArgs &a, const uint32_t *list, uint32_t n_list, uint32_t block,
+                                               unsigned char (*s_wavebuf)[sizeof(ChainElem) * 64], uint32_t (*s_cm)[64]) {
   constexpr int G = 64 / W;
   static_assert(W == 8 || W == 16 || W == 32, "group width");
   static_assert(sizeof(ChainElem) * 64 >= sizeof(SubPath) * 2 * 64, "the path lists overlay the element table");
-  __shared__ __attribute__((aligned(16))) unsigned char s_wavebuf[4][sizeof(ChainElem) * 64];
-  __shared__ uint32_t                                  s_cm[4][64];
   const int      wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int      g = lane / W, sl = lane % W, gbase = g * W;
-  const uint32_t slot    = (blockIdx.x * 4 + wave) * G + g;
+  const uint32_t slot    = (block * 4 + wave) * G + g;
   const bool     valid_g = slot < n_list;
   if (__ballot(valid_g) == 0) return;
   const uint32_t   e  = valid_g ? list[slot] : list[0];
@@ -2652,6 +2653,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W == 32 ? 7
   }
 }
 
+template <int W>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W == 32 ? 7 : 6, W == 32 ? 7 : 6))) void k_chain_sub(ChainArgs a, const uint32_t *list, uint32_t n_list) {
+  __shared__ __attribute__((aligned(16))) unsigned char s_wavebuf[4][sizeof(ChainElem) * 64];
+  __shared__ uint32_t                                  s_cm[4][64];
+  chain_sub_body<W>(a, list, n_list, blockIdx.x, s_wavebuf, s_cm);
+}
+// The three sub-wavefront classes in ONE launch (the step's launches: 14 -> 12): workgroups [0, nb32) take the 32-wide class,
+// the next nb16 the 16-wide one, the rest the 8-wide one -- the longest-lived first.  (One kernel = one register budget: 80,
+// what the two narrow classes need; the 32-wide class alone was built at 72 with four spilled.)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_chain_sub_all(ChainArgs a, ChainSubLists l) {
+  __shared__ __attribute__((aligned(16))) unsigned char s_wavebuf[4][sizeof(ChainElem) * 64];
+  __shared__ uint32_t                                  s_cm[4][64];
+  uint32_t b = blockIdx.x; // (workgroup-uniform branches)
+  if (b < l.nb32) {
+    chain_sub_body<32>(a, l.list32, l.n32, b, s_wavebuf, s_cm);
+  } else if ((b -= l.nb32) < l.nb16) {
+    chain_sub_body<16>(a, l.list16, l.n16, b, s_wavebuf, s_cm);
+  } else {
+    chain_sub_body<8>(a, l.list8, l.n8, b - l.nb16, s_wavebuf, s_cm);
+  }
+}
 template __global__ void k_chain_sub<8>(ChainArgs, const uint32_t *, uint32_t);
 template __global__ void k_chain_sub<16>(ChainArgs, const uint32_t *, uint32_t);
 template __global__ void k_chain_sub<32>(ChainArgs, const uint32_t *, uint32_t);
@@ -3623,6 +3645,15 @@ void launch_chain_sub(hipStream_t st, const ChainArgs &a, int width, const uint3
     hipLaunchKernelGGL(k_chain_sub<16>, grid1(n_list, 16), dim3(256), 0, st, a, list, n_list);
   else
     hipLaunchKernelGGL(k_chain_sub<32>, grid1(n_list, 8), dim3(256), 0, st, a, list, n_list);
+}
+void launch_chain_sub_all(hipStream_t st, const ChainArgs &a, const uint32_t *l32, uint32_t n32, const uint32_t *l16, uint32_t n16,
+                          const uint32_t *l8, uint32_t n8) {
+  ChainSubLists l;
+  l.list32 = l32, l.list16 = l16, l.list8 = l8;
+  l.n32 = n32, l.n16 = n16, l.n8 = n8;
+  l.nb32 = n32 ? grid1(n32, 8).x : 0u, l.nb16 = n16 ? grid1(n16, 16).x : 0u;
+  const uint32_t nb8 = n8 ? grid1(n8, 32).x : 0u, nb = l.nb32 + l.nb16 + nb8;
+  if (nb) hipLaunchKernelGGL(k_chain_sub_all, dim3(nb), dim3(256), 0, st, a, l);
 }
 size_t big_elem_bytes() { return sizeof(BigElem); }
 size_t big_path_bytes() { return sizeof(BigPath); }
