@@ -1354,7 +1354,7 @@ int msgpu_chaining_and_overlaps(msgpu_ctx *c) {
     // as ONE of its wavefronts (45 us each for the 16- and 8-wide classes of a shard of eight, one after the other behind
     // k_chain and k_chain_sub<32>: a third of that shard's chain stage, profiles/r5_05); side by side they fill what the long
     // class leaves.  On the whole job the kernels' work is the same either way.
-    static const bool serial = getenv("MSGPU_CHAIN_SERIAL") != nullptr; // A/B switch: the four classes one after the other, a launch each
+    const bool serial = getenv("MSGPU_CHAIN_SERIAL") != nullptr; // A/B switch (read per call: a test flips it): the four classes one after the other, a launch each
     const bool any_sub = c->n_cls[0] || c->n_cls[1] || c->n_cls[3];
     const bool beside  = !serial && any_sub && c->n_cls[2];
     if (beside) {

@@ -290,9 +290,10 @@ def test_index_bin_path_takes_several_passes_beyond_131072_reads(oracle):
 
 
 def test_sub_wavefront_and_whole_wavefront_chaining_agree(oracle, monkeypatch):
-    """Edges of <= 32 EdgeMatches share a wavefront (k_chain_sub<8|16|32>), longer ones take one each (k_chain):
-    MSGPU_NO_SUBWAVE=1 sends every edge through k_chain.  Both must give the oracle's tables; the workload has edges
-    in all four width classes."""
+    """Edges of <= 32 EdgeMatches share a wavefront (the 8-, 16- and 32-wide bodies of k_chain_sub_all: one launch), longer
+    ones take one each (k_chain): MSGPU_CHAIN_SERIAL=1 gives every width a launch of its own (k_chain_sub<8|16|32>, one
+    after the other), MSGPU_NO_SUBWAVE=1 sends every edge through k_chain.  All three must give the oracle's tables; the
+    workload has edges in all four width classes."""
     from muchsalsa_amd import overlap, synth
     rows, _, _ = synth.accepted_rows(synth.paf_table(400, 8000, 3200, 23, coverage=8))
     want = oracle.overlap(rows)
@@ -300,6 +301,9 @@ def test_sub_wavefront_and_whole_wavefront_chaining_agree(oracle, monkeypatch):
     assert (n <= 8).sum() > 100 and ((n > 8) & (n <= 16)).sum() > 100 and ((n > 16) & (n <= 32)).sum() > 100 \
         and ((n > 32) & (n <= 64)).sum() > 100, np.bincount(np.minimum(n, 65) // 9)
     assert_tables_equal(_gpu_tables(rows), want, "width classes")
+    monkeypatch.setenv("MSGPU_CHAIN_SERIAL", "1")
+    assert_tables_equal(_gpu_tables(rows), want, "a launch per width")
+    monkeypatch.delenv("MSGPU_CHAIN_SERIAL")
     monkeypatch.setenv("MSGPU_NO_SUBWAVE", "1")
     assert_tables_equal(_gpu_tables(rows), want, "one edge per wavefront")
 
