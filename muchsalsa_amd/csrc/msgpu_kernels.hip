@@ -1022,7 +1022,7 @@ __global__ __launch_bounds__(1024) void k_classify_reads(const uint32_t *read_of
 //            what the next build counts from nothing
 __global__ __launch_bounds__(1024) void k_index_epilogue(IndexEpilogueArgs a) {
   __shared__ uint32_t           s_cnt[4], s_base[4], s_wave[16], s_last;
-  __shared__ unsigned long long s_carry[16];
+  __shared__ unsigned long long s_carry[33];
   const uint32_t i    = blockIdx.x * 1024 + threadIdx.x;
   const int      lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (threadIdx.x < 4) s_cnt[threadIdx.x] = 0;
@@ -1055,20 +1055,21 @@ __global__ __launch_bounds__(1024) void k_index_epilogue(IndexEpilogueArgs a) {
       carry += __shfl_xor(carry, d);
       all += __shfl_xor(all, d);
     }
-    if (lane == 0) s_carry[wave] = carry;
-    __syncthreads();
-    carry = 0;
-#pragma unroll
-    for (int w = 0; w < 16; ++w) carry += s_carry[w];
-    if (blockIdx.x == 0) { // (the total, for workgroup 0 only: one more round through LDS)
-      __syncthreads();
-      if (lane == 0) s_carry[wave] = all;
-      __syncthreads();
-      all = 0;
-#pragma unroll
-      for (int w = 0; w < 16; ++w) all += s_carry[w];
-      if (threadIdx.x == 0) dep |= static_cast<uint32_t>(atomicExch(reinterpret_cast<unsigned long long *>(a.total), all));
+    if (lane == 0) {
+      s_carry[wave]      = carry;
+      s_carry[16 + wave] = all;
     }
+    __syncthreads();
+    // (the sixteen partial sums are added by the first wavefront and handed on as one word: sixteen 64-bit words live in
+    // every thread kept the kernel above 64 registers, one workgroup to a CU)
+    if (wave == 0) {
+      unsigned long long v = lane < 32 ? s_carry[lane] : 0ull; // lanes 0..15: carries, 16..31: totals
+      for (int d = 8; d > 0; d >>= 1) v += __shfl_xor(v, d);
+      if (lane == 0) s_carry[32] = v;
+      if (lane == 16 && blockIdx.x == 0) dep |= static_cast<uint32_t>(atomicExch(reinterpret_cast<unsigned long long *>(a.total), v));
+    }
+    __syncthreads();
+    carry = s_carry[32];
   }
   const uint32_t vis = i < a.V ? a.visits[i] : 0u;
   uint32_t       blk_total;
@@ -1329,7 +1330,7 @@ __global__ __launch_bounds__(1024) void k_cand_reduce(const uint32_t *n_edge, co
 // written.  The launch may be speculative (into whatever the tables hold from earlier calls): if the edges or the list of big
 // edges do not fit nothing is written; the host, which compares the same numbers, allocates and launches again.
 __global__ __launch_bounds__(1024) void k_emit_edges(EmitArgs a) {
-  __shared__ unsigned long long s_red[16][4];
+  __shared__ unsigned long long s_red[16][4], s_tot[4];
   __shared__ uint32_t           s_hb[16][64], s_ht[16][64], s_pos[64], s_w[2][4];
   __shared__ uint32_t           s_ne[CAND_CHUNK], s_nc[CAND_CHUNK], s_eb[CAND_CHUNK], s_mb[CAND_CHUNK];
   static_assert(CAND_CHUNK == 256, "the first four wavefronts hold a read per lane");
@@ -1374,13 +1375,15 @@ __global__ __launch_bounds__(1024) void k_emit_edges(EmitArgs a) {
     s_ht[wave][lane] = ht;
   }
   __syncthreads();
-  unsigned long long base_m = 0, base_e = 0, tot_m = 0, tot_e = 0;
+  // (the sixteen partial sums are added by the second wavefront -- the first one has the histogram below -- and handed to
+  // everybody as four words: every thread adding all sixty-four of them itself cost the kernel 128 registers and spills)
+  if (wave == 1) {
 #pragma unroll
-  for (int w = 0; w < 16; ++w) {
-    base_m += s_red[w][0];
-    base_e += s_red[w][1];
-    tot_m += s_red[w][2];
-    tot_e += s_red[w][3];
+    for (int k = 0; k < 4; ++k) {
+      unsigned long long v = lane < 16 ? s_red[lane][k] : 0ull;
+      for (int d = 8; d > 0; d >>= 1) v += __shfl_xor(v, d);
+      if (lane == 0) s_tot[k] = v;
+    }
   }
   uint32_t c8 = 0, c16 = 0, c32 = 0, c64 = 0;
   if (wave == 0) { // lane = size - 1: first list position of this chunk's edges of the size, sizes DESCENDING
@@ -1404,6 +1407,8 @@ __global__ __launch_bounds__(1024) void k_emit_edges(EmitArgs a) {
       c64 += __shfl_xor(c64, d);
     }
   }
+  __syncthreads();
+  const unsigned long long base_m = s_tot[0], base_e = s_tot[1], tot_m = s_tot[2], tot_e = s_tot[3];
   if (chunk == 0 && threadIdx.x < 64) { // (wave 0: the class sizes are in its registers)
     // counts[0..3] = edges of 9..16, 17..32, 33..64, <= 8 EdgeMatches
     const unsigned long long cls_lo = static_cast<unsigned long long>(c16) | (static_cast<unsigned long long>(c32) << 32);
@@ -1454,21 +1459,45 @@ __global__ __launch_bounds__(1024) void k_emit_edges(EmitArgs a) {
     s_mb[threadIdx.x] = bm;
   }
   __syncthreads();
-  // ---- the edges: 16 lanes per read (a read has ~10 edges), 64 reads per round ---------------------------------------------------
-  const int sub = threadIdx.x & 15;
+  // ---- the edges: 16 lanes per read (a read has ~24 edges), 64 reads per round, four rounds ---------------------------------------
+  // The kernel waits on memory -- read's scratch offset -> its edges' (start, v2) -> the stores -- and a workgroup that took its
+  // four rounds one after the other waited four times as long: every level of that chain is asked for in all four rounds
+  // before the next level is touched (the first sixteen edges of a read; the few reads with more finish in the loop behind).
+  constexpr int ROUNDS = CAND_CHUNK / 64;
+  const int     sub = threadIdx.x & 15;
+  uint32_t      ne_r4[ROUNDS], nc_r4[ROUNDS], st_r[ROUNDS], en_r[ROUNDS], v2_r[ROUNDS];
+  uint64_t      co_r[ROUNDS];
 #pragma unroll
-  for (uint32_t round = 0; round < CAND_CHUNK / 64; ++round) {
+  for (int round = 0; round < ROUNDS; ++round) {
     const uint32_t lr = round * 64 + (threadIdx.x >> 4), r = chunk * CAND_CHUNK + lr;
-    const uint32_t ne = s_ne[lr];
+    ne_r4[round] = s_ne[lr];
+    nc_r4[round] = s_nc[lr];
+    co_r[round]  = ne_r4[round] ? a.cand_off[r] : 0ull;
+  }
+#pragma unroll
+  for (int round = 0; round < ROUNDS; ++round) {
+    const uint32_t e = sub;
+    st_r[round] = en_r[round] = v2_r[round] = 0;
+    if (e < ne_r4[round]) {
+      st_r[round] = a.edge_scr_start[co_r[round] + e];
+      en_r[round] = (e + 1 < ne_r4[round]) ? a.edge_scr_start[co_r[round] + e + 1] : nc_r4[round];
+      v2_r[round] = a.edge_scr_v2[co_r[round] + e];
+    }
+  }
+#pragma unroll
+  for (int round = 0; round < ROUNDS; ++round) {
+    const uint32_t lr = round * 64 + (threadIdx.x >> 4), r = chunk * CAND_CHUNK + lr;
+    const uint32_t ne = ne_r4[round];
     if (ne == 0) continue;
-    const uint32_t nc = s_nc[lr];
-    const uint64_t eb = base_e + s_eb[lr], mb = base_m + s_mb[lr], co = a.cand_off[r];
+    const uint32_t nc = nc_r4[round];
+    const uint64_t eb = base_e + s_eb[lr], mb = base_m + s_mb[lr], co = co_r[round];
     for (uint32_t e = sub; e < ne; e += 16) {
-      const uint32_t st = a.edge_scr_start[co + e];
-      const uint32_t en = (e + 1 < ne) ? a.edge_scr_start[co + e + 1] : nc;
+      const bool     first = e == static_cast<uint32_t>(sub);
+      const uint32_t st = first ? st_r[round] : a.edge_scr_start[co + e];
+      const uint32_t en = first ? en_r[round] : ((e + 1 < ne) ? a.edge_scr_start[co + e + 1] : nc);
       msgpu_edge     ed;
       ed.v1        = r;
-      ed.v2        = a.edge_scr_v2[co + e];
+      ed.v2        = first ? v2_r[round] : a.edge_scr_v2[co + e];
       ed.em_off    = mb + st;
       ed.order_off = 0;
       ed.em_cnt    = en - st;
