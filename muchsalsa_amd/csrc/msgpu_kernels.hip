@@ -1336,6 +1336,13 @@ __global__ __launch_bounds__(1024) void k_emit_edges(EmitArgs a) {
   static_assert(CAND_CHUNK == 256, "the first four wavefronts hold a read per lane");
   const int      lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t chunk = blockIdx.x;
+  // (this thread's read, for the prefix inside the chunk: asked for now, used behind the sums below)
+  uint32_t ne_r = 0, nc_r = 0;
+  if (threadIdx.x < CAND_CHUNK) {
+    const uint32_t r = chunk * CAND_CHUNK + threadIdx.x;
+    ne_r             = r < a.V ? a.n_edge[r] : 0u;
+    nc_r             = r < a.V ? a.n_cand[r] : 0u;
+  }
   // the chain stage's chunk sums start from zero (this is the last launch in front of the chain kernels)
   for (uint32_t i = blockIdx.x * 1024 + threadIdx.x; i < a.n_chain_chunk_words; i += gridDim.x * 1024) a.chain_chunk_sums[i] = 0;
   // ---- sums over the chunks: candidates and edges before this chunk / in all chunks ---------------------------------------
@@ -1434,11 +1441,8 @@ __global__ __launch_bounds__(1024) void k_emit_edges(EmitArgs a) {
   static_assert(SC_PUBLISH_MAX <= 64, "one wavefront publishes the scalar block");
   if (tot_e > a.cap_edges || a.big_stats[0] >= a.cap_big) return;
   // ---- prefix inside the chunk: a read per thread of the first four wavefronts ------------------------------------------------
-  uint32_t ne_r = 0, nc_r = 0, ie = 0, im = 0;
+  uint32_t ie = 0, im = 0;
   if (threadIdx.x < CAND_CHUNK) {
-    const uint32_t r = chunk * CAND_CHUNK + threadIdx.x;
-    ne_r             = r < a.V ? a.n_edge[r] : 0u;
-    nc_r             = r < a.V ? a.n_cand[r] : 0u;
     ie               = wave_incl_scan(ne_r);
     im               = wave_incl_scan(nc_r);
     if (lane == 63) {
@@ -3219,6 +3223,10 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
   static_assert(COMPACT_CHUNK == 1024, "an edge per thread");
   const int      lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t chunk = blockIdx.x;
+  // (this thread's edge: asked for now, used behind the sums below -- one wait instead of two in a row)
+  const uint64_t my_e  = static_cast<uint64_t>(chunk) * COMPACT_CHUNK + threadIdx.x;
+  const uint32_t my_no = my_e < a.n_edges ? a.edge_norders[my_e] : 0u, my_ni = my_e < a.n_edges ? a.edge_nids[my_e] : 0u;
+  const uint64_t my_em = my_e < a.n_edges ? a.edges[my_e].em_off : 0ull;
   unsigned long long t[5] = {0, 0, 0, 0, 0}; // orders, ids of the chunks before this one | orders, ids, shortcut edges of all chunks
   for (uint32_t c = threadIdx.x; c < a.n_chunks; c += 1024) {
     const unsigned long long w0 = a.chunk_sums[2 * c], w1 = a.chunk_sums[2 * c + 1];
@@ -3274,9 +3282,8 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
     // prefix inside the chunk: an edge per thread.  What the move below needs of the edge -- its order count and where its
     // scratch begins -- is read here too, beside the counts, and handed over through LDS: the move's chain of dependent reads
     // (edge -> order record -> ids) is one read shorter, and the four rounds of it start together.
-    const uint64_t e  = e0 + threadIdx.x;
-    const uint32_t no = e < a.n_edges ? a.edge_norders[e] : 0u, ni = e < a.n_edges ? a.edge_nids[e] : 0u;
-    const uint64_t em = e < a.n_edges ? a.edges[e].em_off : 0ull;
+    const uint32_t no = my_no, ni = my_ni;
+    const uint64_t em = my_em;
     const uint32_t io = wave_incl_scan(no), ii = wave_incl_scan(ni);
     if (lane == 63) {
       s_w[0][wave] = io;
