@@ -1328,11 +1328,13 @@ int msgpu_chaining_and_overlaps(msgpu_ctx *c) {
   if (n_big) {
     ENSURE(c, big_elems, (c->n_big_ems ? c->n_big_ems : 1) * big_elem_bytes());
     ENSURE(c, big_paths, (c->n_big_ems ? c->n_big_ems : 1) * 2 * big_path_bytes());
-    HIPCHK(c, hipEventRecord(c->ev_side[0], st)); // (the list and the scratch offsets: k_emit_edges)
   }
+  // ONE event marks "the candidate stage is done" on the main stream: the chain kernels' timing window begins there, and both side
+  // streams wait for it (an event of its own for each cost the main stream two more packets in front of k_chain)
+  HIPCHK(c, hipEventRecord(ck_begin, st));
   auto launch_big = [&]() -> int {
     if (!n_big) return MSGPU_OK;
-    HIPCHK(c, hipStreamWaitEvent(c->side_stream, c->ev_side[0], 0));
+    HIPCHK(c, hipStreamWaitEvent(c->side_stream, ck_begin, 0)); // (the list and the scratch offsets: k_emit_edges)
     launch_chain_big(c->side_stream, a, c->big_list.as<uint32_t>(), c->big_off.as<uint64_t>(), n_big,
                      c->big_elems.p, c->big_paths.p);
     HIPCHK(c, hipEventRecord(c->ev_side[1], c->side_stream));
@@ -1348,7 +1350,6 @@ int msgpu_chaining_and_overlaps(msgpu_ctx *c) {
     // the size-sorted edge list and the class sizes are there since msgpu_calculate_edges
     const uint32_t *list = c->cls_list.as<uint32_t>();
     const uint32_t *l64 = list, *l32 = l64 + c->n_cls[2], *l16 = l32 + c->n_cls[1], *l8 = l16 + c->n_cls[0]; // sizes descending
-    HIPCHK(c, hipEventRecord(ck_begin, st));
     // The three sub-wavefront classes go out as ONE launch (k_chain_sub_all: its workgroups take the 32-, 16- and 8-wide class
     // in turn) on the side stream the candidate stage used, beside k_chain: a kernel of a few thousand wavefronts lasts as long
     // as ONE of its wavefronts (45 us each for the 16- and 8-wide classes of a shard of eight, one after the other behind
@@ -1357,10 +1358,7 @@ int msgpu_chaining_and_overlaps(msgpu_ctx *c) {
     const bool serial = getenv("MSGPU_CHAIN_SERIAL") != nullptr; // A/B switch (read per call: a test flips it): the four classes one after the other, a launch each
     const bool any_sub = c->n_cls[0] || c->n_cls[1] || c->n_cls[3];
     const bool beside  = !serial && any_sub && c->n_cls[2];
-    if (beside) {
-      HIPCHK(c, hipEventRecord(c->ev_side2, st));
-      HIPCHK(c, hipStreamWaitEvent(c->side_stream2, c->ev_side2, 0));
-    }
+    if (beside) HIPCHK(c, hipStreamWaitEvent(c->side_stream2, ck_begin, 0));
     launch_chain(st, a, l64, c->n_cls[2]); // the long ones first: the short classes fill the tail
     if (serial) {
       launch_chain_sub(st, a, 32, l32, c->n_cls[1]);
@@ -1374,7 +1372,6 @@ int msgpu_chaining_and_overlaps(msgpu_ctx *c) {
       HIPCHK(c, hipStreamWaitEvent(st, c->ev_side2, 0));
     }
   } else {
-    HIPCHK(c, hipEventRecord(ck_begin, st));
     launch_chain(st, a, nullptr, 0);
   }
   HIPCHK(c, hipEventRecord(ck_end, st));
