@@ -1152,20 +1152,23 @@ int msgpu_calculate_edges(msgpu_ctx *c) {
     // class 1 beside class 0 on a stream of its own, and the handful of class-2 workgroups on the other side stream (idle until
     // the chain stage), launched FIRST: alone in front of class 0 on the main stream they cost 17 us of every step (one or two
     // workgroups at the latency of a whole kernel -- a fifth of a shard-of-eight's candidate stage, profiles/r5_05)
+    // (in front of class 0's launch only what must be there: every runtime call is a few microseconds of the host's turn-around)
     HIPCHK(c, hipEventRecord(c->ev_side[0], st));
     if (c->n_list[2]) {
       HIPCHK(c, hipStreamWaitEvent(c->side_stream, c->ev_side[0], 0));
       launch_candidates(c->side_stream, a, 2, l2, c->n_list[2]);
-      HIPCHK(c, hipEventRecord(c->ev_side[1], c->side_stream));
     }
-    if (c->n_list[1]) HIPCHK(c, hipStreamWaitEvent(c->side_stream2, c->ev_side[0], 0));
     launch_candidates(st, a, 0, l0, c->n_list[0]);
     if (c->n_list[1]) {
+      HIPCHK(c, hipStreamWaitEvent(c->side_stream2, c->ev_side[0], 0));
       launch_candidates(c->side_stream2, a, 1, l1, c->n_list[1]);
       HIPCHK(c, hipEventRecord(c->ev_side2, c->side_stream2));
       HIPCHK(c, hipStreamWaitEvent(st, c->ev_side2, 0));
     }
-    if (c->n_list[2]) HIPCHK(c, hipStreamWaitEvent(st, c->ev_side[1], 0));
+    if (c->n_list[2]) {
+      HIPCHK(c, hipEventRecord(c->ev_side[1], c->side_stream));
+      HIPCHK(c, hipStreamWaitEvent(st, c->ev_side[1], 0));
+    }
   } else {
     launch_candidates(st, a, 2, l2, c->n_list[2]);
     launch_candidates(st, a, 1, l1, c->n_list[1]);
