@@ -1332,12 +1332,15 @@ int msgpu_chaining_and_overlaps(msgpu_ctx *c) {
     ENSURE(c, big_elems, (c->n_big_ems ? c->n_big_ems : 1) * big_elem_bytes());
     ENSURE(c, big_paths, (c->n_big_ems ? c->n_big_ems : 1) * 2 * big_path_bytes());
   }
-  // ONE event marks "the candidate stage is done" on the main stream: the chain kernels' timing window begins there, and both side
-  // streams wait for it (an event of its own for each cost the main stream two more packets in front of k_chain)
-  HIPCHK(c, hipEventRecord(ck_begin, st));
+  // Two events mark "the candidate stage is done" on the main stream: the first releases k_chain_big on its side stream, the
+  // second opens the chain kernels' timing window and releases the sub-wavefront classes on theirs (a third one for those cost the
+  // main stream one more packet in front of k_chain).  k_chain_big keeps an event of its own, recorded FIRST: released by the
+  // same event as the others it started behind k_chain, its thousand long-lived wavefronts then sat beside the others for the whole
+  // stage instead of its first fifth, and the stage took 30 us longer (gpurun_out/r5_45 against r5_38).
+  if (n_big) HIPCHK(c, hipEventRecord(c->ev_side[0], st)); // (the list and the scratch offsets: k_emit_edges)
   auto launch_big = [&]() -> int {
     if (!n_big) return MSGPU_OK;
-    HIPCHK(c, hipStreamWaitEvent(c->side_stream, ck_begin, 0)); // (the list and the scratch offsets: k_emit_edges)
+    HIPCHK(c, hipStreamWaitEvent(c->side_stream, c->ev_side[0], 0));
     launch_chain_big(c->side_stream, a, c->big_list.as<uint32_t>(), c->big_off.as<uint64_t>(), n_big,
                      c->big_elems.p, c->big_paths.p);
     HIPCHK(c, hipEventRecord(c->ev_side[1], c->side_stream));
@@ -1349,6 +1352,7 @@ int msgpu_chaining_and_overlaps(msgpu_ctx *c) {
   }
   c->gate_cv.notify_all();
   if (int rc = launch_big()) return rc; // (first: its few long-lived wavefronts get their registers before k_chain fills the device)
+  HIPCHK(c, hipEventRecord(ck_begin, st));
   if (c->sub_wave && E) {
     // the size-sorted edge list and the class sizes are there since msgpu_calculate_edges
     const uint32_t *list = c->cls_list.as<uint32_t>();
