@@ -2695,7 +2695,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W == 32 ? 7
 // The three sub-wavefront classes in ONE launch (the step's launches: 14 -> 12): workgroups [0, nb32) take the 32-wide class,
 // the next nb16 the 16-wide one, the rest the 8-wide one -- the longest-lived first.  (One kernel = one register budget: 80,
 // what the two narrow classes need; the 32-wide class alone was built at 72 with four spilled.)
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_chain_sub_all(ChainArgs a, ChainSubLists l) {
+#ifndef MSGPU_SUB_WAVES
+#define MSGPU_SUB_WAVES 6 // (experiment builds: 7 and 8 spill 18 and 52 registers a lane -- profiles/r5_08/README.md)
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MSGPU_SUB_WAVES, MSGPU_SUB_WAVES))) void k_chain_sub_all(ChainArgs a, ChainSubLists l) {
   __shared__ __attribute__((aligned(16))) unsigned char s_wavebuf[4][sizeof(ChainElem) * 64];
   __shared__ uint32_t                                  s_cm[4][64];
   uint32_t b = blockIdx.x; // (workgroup-uniform branches)
