@@ -2299,7 +2299,8 @@ __device__ __forceinline__ uint32_t paths_of_direction_sub(uint32_t act, bool di
 // every width).
 template <int W>
 __device__ __forceinline__ void chain_sub_body(const ChainArgs &a, const uint32_t *list, uint32_t n_list, uint32_t block,
-                                               unsigned char (*s_wavebuf)[sizeof(ChainElem) * 64], uint32_t (*s_cm)[64]) {
+                                               unsigned char (*s_wavebuf)[sizeof(ChainElem) * 64], uint32_t (*s_cm)[64],
+                                               double (*s_keep)[64][4], uint32_t (*s_anchor)[64]) {
   constexpr int G = 64 / W;
   static_assert(W == 8 || W == 16 || W == 32, "group width");
   static_assert(sizeof(ChainElem) * 64 >= sizeof(SubPath) * 2 * 64, "the path lists overlay the element table");
@@ -2383,6 +2384,13 @@ __device__ __forceinline__ void chain_sub_body(const ChainArgs &a, const uint32_
     clo1     = x.clo1;
     clo2     = x.clo2;
     el[lane] = x;
+  }
+  // the four numbers the overhangs at the very end are made of wait in LDS, not in eight registers across the sweep and the DP
+  // (the element table itself is overwritten by the path lists before then)
+  {
+    double *kp = s_keep[wave][lane];
+    kp[0] = clo1, kp[1] = clo2, kp[2] = ovr1, kp[3] = ovr2;
+    s_anchor[wave][lane] = anchor; // (the ids at the very end)
   }
   const uint32_t m_plus  = group_bits<W>(__ballot(act && em_dir), gbase);
   const uint32_t m_minus = group_bits<W>(__ballot(act && !em_dir), gbase);
@@ -2627,8 +2635,9 @@ __device__ __forceinline__ void chain_sub_body(const ChainArgs &a, const uint32_
       const SubPath  rec  = pv[pi];
       const uint32_t mask = (has && rec.mask) ? rec.mask : 1u;
       const int      f = __builtin_ctz(mask), l = 31 - __builtin_clz(mask);
-      const double   L1 = shfl_f64(clo1, gbase + f), R1 = shfl_f64(ovr1, gbase + l);
-      const double   L2 = shfl_f64(dir ? clo2 : ovr2, gbase + f), R2 = shfl_f64(dir ? ovr2 : clo2, gbase + l); // :73-76
+      const double  *kf = s_keep[wave][gbase + f], *kl = s_keep[wave][gbase + l];
+      const double   L1 = kf[0], R1 = kl[2];
+      const double   L2 = dir ? kf[1] : kf[3], R2 = dir ? kl[3] : kl[1]; // :73-76
       bool     have = false;
       uint32_t fl   = 0;
       double   lo = 0, ro = 0;
@@ -2656,7 +2665,7 @@ __device__ __forceinline__ void chain_sub_body(const ChainArgs &a, const uint32_
       const bool emit = has && have;
       if (emit) {
         const uint32_t cnt = static_cast<uint32_t>(__popc(mask));
-        if ((mask >> sl) & 1u) a.ids_scr[ed.em_off + n_ids + static_cast<uint32_t>(__popc(mask & ((1u << sl) - 1u)))] = anchor;
+        if ((mask >> sl) & 1u) a.ids_scr[ed.em_off + n_ids + static_cast<uint32_t>(__popc(mask & ((1u << sl) - 1u)))] = s_anchor[wave][lane];
         if (sl == 0) {
           msgpu_order o;
           o.edge_idx     = e;
@@ -2690,24 +2699,31 @@ template <int W>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W == 32 ? 7 : 6, W == 32 ? 7 : 6))) void k_chain_sub(ChainArgs a, const uint32_t *list, uint32_t n_list) {
   __shared__ __attribute__((aligned(16))) unsigned char s_wavebuf[4][sizeof(ChainElem) * 64];
   __shared__ uint32_t                                  s_cm[4][64];
-  chain_sub_body<W>(a, list, n_list, blockIdx.x, s_wavebuf, s_cm);
+  __shared__ __attribute__((aligned(16))) double       s_keep[4][64][4];
+  __shared__ uint32_t                                  s_anchor[4][64];
+  chain_sub_body<W>(a, list, n_list, blockIdx.x, s_wavebuf, s_cm, s_keep, s_anchor);
 }
 // The three sub-wavefront classes in ONE launch (the step's launches: 14 -> 12): workgroups [0, nb32) take the 32-wide class,
-// the next nb16 the 16-wide one, the rest the 8-wide one -- the longest-lived first.  (One kernel = one register budget: 80,
-// what the two narrow classes need; the 32-wide class alone was built at 72 with four spilled.)
+// the next nb16 the 16-wide one, the rest the 8-wide one -- the longest-lived first.  (One kernel = one register budget for the three bodies.)
+// Wavefronts per SIMD: 7 since the sub-wavefront body parks what only its last lines need -- the four numbers of the overhangs,
+// the anchor id -- in LDS (9 KB a workgroup: seven workgroups still fit a CU) instead of nine registers across the sweep and the
+// DP: 71 registers, six spilled outside every loop.  Six wavefronts (73 registers, none spilled) are 20 us slower, eight spill
+// inside the loops (profiles/r5_08/README.md).
 #ifndef MSGPU_SUB_WAVES
-#define MSGPU_SUB_WAVES 6 // (experiment builds: 7 and 8 spill 18 and 52 registers a lane -- profiles/r5_08/README.md)
+#define MSGPU_SUB_WAVES 7
 #endif
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MSGPU_SUB_WAVES, MSGPU_SUB_WAVES))) void k_chain_sub_all(ChainArgs a, ChainSubLists l) {
   __shared__ __attribute__((aligned(16))) unsigned char s_wavebuf[4][sizeof(ChainElem) * 64];
   __shared__ uint32_t                                  s_cm[4][64];
+  __shared__ __attribute__((aligned(16))) double       s_keep[4][64][4];
+  __shared__ uint32_t                                  s_anchor[4][64];
   uint32_t b = blockIdx.x; // (workgroup-uniform branches)
   if (b < l.nb32) {
-    chain_sub_body<32>(a, l.list32, l.n32, b, s_wavebuf, s_cm);
+    chain_sub_body<32>(a, l.list32, l.n32, b, s_wavebuf, s_cm, s_keep, s_anchor);
   } else if ((b -= l.nb32) < l.nb16) {
-    chain_sub_body<16>(a, l.list16, l.n16, b, s_wavebuf, s_cm);
+    chain_sub_body<16>(a, l.list16, l.n16, b, s_wavebuf, s_cm, s_keep, s_anchor);
   } else {
-    chain_sub_body<8>(a, l.list8, l.n8, b - l.nb16, s_wavebuf, s_cm);
+    chain_sub_body<8>(a, l.list8, l.n8, b - l.nb16, s_wavebuf, s_cm, s_keep, s_anchor);
   }
 }
 template __global__ void k_chain_sub<8>(ChainArgs, const uint32_t *, uint32_t);
